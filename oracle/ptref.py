@@ -1,0 +1,182 @@
+"""ORACLE binding (test infrastructure only): ctypes wrapper around oracle/_ref/libptref.so and librefpin.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module. It is the checker,
+never the thing measured or shipped.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_ref", "libptref.so")
+_PIN = os.path.join(_HERE, "_ref", "librefpin.so")
+
+
+def build(quiet=True):
+    """Compile the oracle (and, when /root/reference exists, the reference pin) into oracle/_ref/."""
+    r = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    if not quiet:
+        print(r.stdout)
+
+
+def _load(path):
+    if not os.path.exists(path):
+        build()
+    return ctypes.CDLL(path)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = _load(_LIB)
+        L.ptref_create.restype = ctypes.c_void_p
+        L.ptref_radiance.restype = ctypes.POINTER(ctypes.c_float)
+        for n in ("ptref_hash32", "ptref_hash32_combine", "ptref_sobol", "ptref_owen_scramble", "ptref_f32tof16", "ptref_num_tris"):
+            getattr(L, n).restype = ctypes.c_uint32
+        L.ptref_hash32_to_float.restype = ctypes.c_float
+        L.ptref_f16tof32.restype = ctypes.c_float
+        L.ptref_f32tof16.argtypes = [ctypes.c_float]
+        _lib = L
+    return _lib
+
+
+def refpin():
+    """The reference's own compiled sources (None when unavailable, e.g. on the GPU box without a prebuilt .so)."""
+    if not os.path.exists(_PIN):
+        if os.path.isdir("/root/reference/Rtxpt/Shaders"):
+            build()
+        if not os.path.exists(_PIN):
+            return None
+    L = ctypes.CDLL(_PIN)
+    for n in ("refpin_hash32", "refpin_hash32_combine", "refpin_sobol"):
+        getattr(L, n).restype = ctypes.c_uint32
+    L.refpin_hash32_to_float.restype = ctypes.c_float
+    L.refpin_eval_mis.restype = ctypes.c_float
+    L.refpin_eval_mis.argtypes = [ctypes.c_int] + [ctypes.c_float] * 4
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Oracle:
+    """Mirrors the call order of Sample::Render: set scene -> set camera/settings -> render(sample range) -> radiance."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = ctypes.c_void_p(self.L.ptref_create())
+        self.w = self.h_ = 0
+
+    def close(self):
+        if self.h:
+            self.L.ptref_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, sc):
+        L, h = self.L, self.h
+        self._keep = sc
+        L.ptref_clear_textures(h)
+        for (w, hh, fmt, px) in sc["textures"]:
+            L.ptref_add_texture(h, w, hh, fmt, _p(px))
+        L.ptref_set_materials(h, _p(sc["materials"]), len(sc["materials"]))
+        L.ptref_set_geometry(h, _p(sc["indices"]), sc["indices"].size, _p(sc["positions"]), _p(sc["uvs"]), _p(sc["normals"]), _p(sc["tangents"]),
+                             sc["positions"].shape[0], _p(sc["geometries"]), len(sc["geometries"]), _p(sc["meshes"]), len(sc["meshes"]))
+        L.ptref_set_instances(h, _p(sc["instances"]), len(sc["instances"]))
+        if sc.get("env") is not None:
+            rgb, tw, cm = sc["env"]
+            L.ptref_set_environment(h, _p(rgb), rgb.shape[1], rgb.shape[0], _p(tw), _p(cm))
+        else:
+            L.ptref_set_environment(h, None, 0, 0, None, None)
+        if sc.get("lights") is not None:
+            base, ex = sc["lights"]
+            L.ptref_set_lights(h, _p(base), _p(ex), len(base))
+
+    def set_instances(self, inst):
+        self._inst = inst
+        self.L.ptref_set_instances(self.h, _p(inst), len(inst))
+
+    def set_camera(self, cam):
+        self._cam = np.ascontiguousarray(cam)
+        self.L.ptref_set_camera(self.h, _p(self._cam))
+
+    def set_settings(self, s):
+        self._set = np.ascontiguousarray(s)
+        self.L.ptref_set_settings(self.h, _p(self._set))
+
+    def resize(self, w, h):
+        self.w, self.h_ = w, h
+        self.L.ptref_resize(self.h, w, h)
+
+    def reset_accumulation(self):
+        self.L.ptref_reset_accumulation(self.h)
+
+    def render(self, first, n, rect=None):
+        if rect is None:
+            self.L.ptref_render(self.h, first, n)
+        else:
+            self.L.ptref_render_rect(self.h, first, n, *rect)
+
+    def radiance(self):
+        p = self.L.ptref_radiance(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.h_, self.w, 4)).copy()
+
+    def counters(self):
+        c = (ctypes.c_uint64 * 7)()
+        self.L.ptref_get_counters(self.h, c)
+        k = ("extendRays", "shadowRays", "hits", "nodeVisitsExt", "triTestsExt", "nodeVisitsSh", "triTestsSh")
+        return dict(zip(k, [int(x) for x in c]))
+
+    def num_tris(self):
+        return int(self.L.ptref_num_tris(self.h))
+
+    def trace_closest(self, rays, brute=False):
+        rays = np.ascontiguousarray(rays, np.float32)
+        out = np.zeros((rays.shape[0], 4), np.float32)
+        self.L.ptref_trace_closest(self.h, _p(rays), rays.shape[0], _p(out), 1 if brute else 0)
+        return out
+
+    def trace_visibility(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32)
+        out = np.zeros(rays.shape[0], np.uint32)
+        self.L.ptref_trace_visibility(self.h, _p(rays), rays.shape[0], _p(out))
+        return out
+
+    def lights(self):
+        n, np_, dim = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self.L.ptref_get_lights(self.h, ctypes.byref(n), ctypes.byref(np_), None, None, None, None, None, ctypes.byref(dim))
+        lights = np.zeros((n.value, 8), np.uint32)
+        ex = np.zeros((n.value, 4), np.uint32)
+        pc = np.zeros(n.value, np.uint32)
+        pi = np.zeros(np_.value, np.uint32)
+        el = np.zeros(dim.value * dim.value, np.uint32)
+        self.L.ptref_get_lights(self.h, None, None, _p(lights), _p(ex), _p(pc), _p(pi), _p(el), None)
+        return dict(lights=lights, lightsEx=ex, proxyCounters=pc, proxyIndices=pi, envLookup=el, envLookupDim=dim.value)
+
+    def subinstances(self):
+        n = ctypes.c_uint32()
+        self.L.ptref_get_subinstances(self.h, ctypes.byref(n), None)
+        out = np.zeros((n.value, 8), np.uint32)
+        self.L.ptref_get_subinstances(self.h, None, _p(out))
+        return out
+
+    def camera_ray(self, px, py, sample_index):
+        o = (ctypes.c_float * 6)()
+        self.L.ptref_camera_ray(self.h, px, py, sample_index, o)
+        return np.array(o, np.float32)
+
+
+def num_threads():
+    return int(lib().ptref_num_threads())

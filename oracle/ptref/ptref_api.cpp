@@ -1,0 +1,509 @@
+// ORACLE (test infrastructure only) — C entry points for ctypes (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+// Scene finalisation (sub-instances, world-space triangles, BVH), light baking and the frame loop.
+// Reference anchors:
+//   Rtxpt/Materials/MaterialsBaker.cpp:960-1017         SubInstanceData fill (alpha cutoff quantised to 8 bit at :990)
+//   Rtxpt/Lighting/LightsBaker.cpp:663-827               light order: env quads, analytic lights, emissive triangles per sub-instance
+//   Rtxpt/Lighting/LightsBaker.hlsl:167-198,262-467      env quad-tree (base 4x4, 24 subdivisions, 20 boost subdivisions per node)
+//   Rtxpt/Lighting/LightsBaker.hlsl:544-716              BakeEmissiveTriangles
+//   Rtxpt/Lighting/LightsBaker.hlsl:738-751,880-948      ComputeWeight (flux^0.8) and ComputeProxyCounts
+//   Rtxpt/Lighting/Distant/EnvMapImportanceSamplingBaker.hlsl:57-90   importance/radiance map (1024^2, 16 taps per texel)
+//   Rtxpt/ProcessingPasses/AccumulationPass.hlsl:36-66 + Rtxpt/Sample.cpp:2770-2778   accumulation lerp, weight 1/(n+1)
+#include "pathtracer.h"
+#include <cstdio>
+#include <cstdlib>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace ptref;
+
+namespace ptref {
+
+static const uint RTXPT_LIGHTING_MAX_LIGHTS = 512 * 1024, RTXPT_LIGHTING_SAMPLING_PROXY_RATIO = 12;
+static const uint RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT = 256 * 1024;
+static const float RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD = 1e-8f;
+static const uint QT_BASE_RES = 4, QT_SUBDIV = 24, QT_UNBOOSTED = QT_BASE_RES * QT_BASE_RES + 3 * QT_SUBDIV, QT_BOOST_DPT = 3, QT_BOOST_SUBDIV = 20,
+                  QT_BOOST_MULT = QT_BOOST_SUBDIV * 3 + 1, QT_TOTAL = QT_UNBOOSTED * QT_BOOST_MULT;
+static const uint EMISB_IMPORTANCE_MAP_DIM = 1024, EMISB_SAMPLES = 16;
+
+void finalize_geometry(Scene& sc) {
+    sc.instFirstSubInstance.clear(); sc.subInstToInstGeom.clear(); sc.subInstances.clear(); sc.tris.clear();
+    uint running = 0;
+    for (size_t i = 0; i < sc.instances.size(); i++) {
+        const MeshDesc& m = sc.meshes[sc.instances[i].meshIndex];
+        sc.instFirstSubInstance.push_back(running);
+        for (uint g = 0; g < m.numGeometries; g++) {
+            uint gi = m.firstGeometry + g;
+            const GeometryDesc& gd = sc.geometries[gi];
+            const PTMaterialData& mat = sc.materials[gd.materialIndex];
+            SubInstanceData si; memset(&si, 0, sizeof(si));
+            bool alphaTested = (gd.geomFlags & GEOMF_ALPHA_TESTED) && (mat.Flags & PTMaterialFlags_UseBaseOrDiffuseTexture) && (gd.flags & GEOM_HAS_UV);
+            if (alphaTested) {
+                si.FlagsAndAlphaInfo |= SubInstanceData::Flags_AlphaTested;
+                uint cutoff = (uint)(saturate(mat.AlphaCutoff) * 255.0f);                    // MaterialsBaker.cpp:990
+                si.FlagsAndAlphaInfo |= (cutoff & 0xFFu) << SubInstanceData::Flags_AlphaOffsetOffset;
+                si.FlagsAndAlphaInfo |= (mat.BaseOrDiffuseTextureIndex & 0xFFFFu);
+            }
+            if (gd.geomFlags & GEOMF_EXCLUDE_FROM_NEE) si.FlagsAndAlphaInfo |= SubInstanceData::Flags_ExcludeFromNEE;
+            si.GlobalGeometryIndex_PTMaterialDataIndex = (gi << 16) | (gd.materialIndex & 0xFFFFu);
+            si.EmissiveLightMappingOffset = 0xFFFFFFFFu; si.AnalyticProxyLightIndex = 0xFFFFFFFFu;
+            si.IndexOffset = gd.indexOffset; si.TexCoord1Offset = gd.vertexOffset;
+            uint2 ig = {(uint)i, gi};
+            sc.subInstToInstGeom.push_back(ig);
+            sc.subInstances.push_back(si);
+            uint subInst = running + g;
+            const float3x4& M = sc.instances[i].transform;
+            // non-opaque if alpha tested or excluded from NEE (AccelerationStructureUtil.h:60-70)
+            uint triFlags = (alphaTested ? 1u : 0u) | ((gd.geomFlags & GEOMF_EXCLUDE_FROM_NEE) ? 3u : 0u);
+            for (uint t = 0; t < gd.numIndices / 3; t++) {
+                const uint* idx = &sc.indices[gd.indexOffset + 3 * t];
+                float3 p0 = xform_point(M, sc.positions[gd.vertexOffset + idx[0]]);
+                float3 p1 = xform_point(M, sc.positions[gd.vertexOffset + idx[1]]);
+                float3 p2 = xform_point(M, sc.positions[gd.vertexOffset + idx[2]]);
+                Triangle tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.subInstance = subInst; tr.triIndex = t; tr.flags = triFlags;
+                sc.tris.push_back(tr);
+            }
+        }
+        running += m.numGeometries;
+    }
+}
+
+// ---- binned SAH BVH2
+struct BuildPrim { float3 bmin, bmax, c; };
+static void tri_bounds(const Triangle& t, float3& mn, float3& mx) {
+    float3 p1 = t.v0 + t.e1, p2 = t.v0 + t.e2;
+    mn = min3v(t.v0, min3v(p1, p2)); mx = max3v(t.v0, max3v(p1, p2));
+}
+static float half_area(float3 mn, float3 mx) { float3 e = mx - mn; return e.x * e.y + e.y * e.z + e.z * e.x; }
+static void subdivide(Scene& sc, std::vector<BuildPrim>& prims, uint nodeIdx, uint first, uint count) {
+    float3 mn = make_float3(1e30f), mx = make_float3(-1e30f), cmn = mn, cmx = mx;
+    for (uint i = first; i < first + count; i++) {
+        const BuildPrim& p = prims[sc.triOrder[i]];
+        mn = min3v(mn, p.bmin); mx = max3v(mx, p.bmax); cmn = min3v(cmn, p.c); cmx = max3v(cmx, p.c);
+    }
+    // pad boxes a little (relative + absolute) so conservative culling never loses an acceptable hit
+    float3 ext = mx - mn; float pad = 1e-5f * fmaxf_(ext.x, fmaxf_(ext.y, ext.z)) + 1e-7f;
+    sc.nodes[nodeIdx].bmin = mn - make_float3(pad); sc.nodes[nodeIdx].bmax = mx + make_float3(pad);
+    if (count <= 4) { sc.nodes[nodeIdx].leftFirst = first; sc.nodes[nodeIdx].count = count; return; }
+    const int NB = 16; int bestAxis = -1, bestSplit = 0; float bestCost = 1e30f;
+    for (int a = 0; a < 3; a++) {
+        float lo = (&cmn.x)[a], hi = (&cmx.x)[a];
+        if (!(hi > lo)) continue;
+        float3 bmn[NB], bmx[NB]; uint bc[NB];
+        for (int b = 0; b < NB; b++) { bmn[b] = make_float3(1e30f); bmx[b] = make_float3(-1e30f); bc[b] = 0; }
+        float scale = (float)NB / (hi - lo);
+        for (uint i = first; i < first + count; i++) {
+            const BuildPrim& p = prims[sc.triOrder[i]];
+            int b = (int)(((&p.c.x)[a] - lo) * scale); if (b > NB - 1) b = NB - 1; if (b < 0) b = 0;
+            bmn[b] = min3v(bmn[b], p.bmin); bmx[b] = max3v(bmx[b], p.bmax); bc[b]++;
+        }
+        float la[NB], ra[NB]; uint lc[NB], rc[NB];
+        float3 amn = make_float3(1e30f), amx = make_float3(-1e30f); uint cnt = 0;
+        for (int b = 0; b < NB - 1; b++) { amn = min3v(amn, bmn[b]); amx = max3v(amx, bmx[b]); cnt += bc[b]; la[b] = cnt ? half_area(amn, amx) : 0; lc[b] = cnt; }
+        amn = make_float3(1e30f); amx = make_float3(-1e30f); cnt = 0;
+        for (int b = NB - 1; b > 0; b--) { amn = min3v(amn, bmn[b]); amx = max3v(amx, bmx[b]); cnt += bc[b]; ra[b - 1] = cnt ? half_area(amn, amx) : 0; rc[b - 1] = cnt; }
+        for (int b = 0; b < NB - 1; b++) {
+            if (!lc[b] || !rc[b]) continue;
+            float cost = la[b] * (float)lc[b] + ra[b] * (float)rc[b];
+            if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = b; }
+        }
+    }
+    uint mid;
+    if (bestAxis < 0) mid = first + count / 2;
+    else {
+        float lo = (&cmn.x)[bestAxis], hi = (&cmx.x)[bestAxis]; float scale = (float)NB / (hi - lo);
+        uint* b = &sc.triOrder[first]; uint* e = b + count;
+        uint* m = std::partition(b, e, [&](uint pi) {
+            int bin = (int)(((&prims[pi].c.x)[bestAxis] - lo) * scale); if (bin > NB - 1) bin = NB - 1; if (bin < 0) bin = 0;
+            return bin <= bestSplit; });
+        mid = first + (uint)(m - b);
+        if (mid == first || mid == first + count) mid = first + count / 2;
+    }
+    uint left = (uint)sc.nodes.size();
+    sc.nodes.push_back(Scene::Node()); sc.nodes.push_back(Scene::Node());
+    sc.nodes[nodeIdx].leftFirst = left; sc.nodes[nodeIdx].count = 0;
+    subdivide(sc, prims, left, first, mid - first);
+    subdivide(sc, prims, left + 1, mid, first + count - mid);
+}
+void build_bvh(Scene& sc) {
+    sc.nodes.clear(); sc.triOrder.clear();
+    uint n = (uint)sc.tris.size();
+    if (!n) return;
+    std::vector<BuildPrim> prims(n);
+    sc.triOrder.resize(n);
+    for (uint i = 0; i < n; i++) { tri_bounds(sc.tris[i], prims[i].bmin, prims[i].bmax); prims[i].c = (prims[i].bmin + prims[i].bmax) * 0.5f; sc.triOrder[i] = i; }
+    sc.nodes.reserve(2 * n);
+    sc.nodes.push_back(Scene::Node());
+    subdivide(sc, prims, 0, 0, n);
+}
+
+// ---- environment importance map + quad tree (host restatement of the baker compute passes)
+struct EnvImportance { uint dim, mipCount; std::vector<std::vector<float4> > mips; };   // rgb = mean radiance, w = mean (lum+avg)/2
+static void build_env_importance(const Scene& sc, EnvImportance& im) {
+    im.dim = EMISB_IMPORTANCE_MAP_DIM; im.mipCount = 11; im.mips.resize(im.mipCount);
+    const uint sx = 4, sy = EMISB_SAMPLES / 4; const uint dimS = im.dim * sx;
+    im.mips[0].resize((size_t)im.dim * im.dim);
+    const float invSamples = 1.f / (float)(sx * sy);
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int y = 0; y < (int)im.dim; y++) for (uint x = 0; x < im.dim; x++) {
+        float L = 0.f; float3 R = make_float3(0.f);
+        for (uint j = 0; j < sy; j++) for (uint i = 0; i < sx; i++) {
+            float2 p = make_float2(((float)(x * sx + i) + 0.5f) / (float)dimS, ((float)((uint)y * sy + j) + 0.5f) / (float)(im.dim * sy));
+            float3 dir = oct_to_ndir_equal_area_unorm(p);
+            float3 radiance = xyz(sample_trilinear(sc.env.tex, [&]{ float2 uv = EnvMap::dir_to_latlong(dir); float mh = (float)sc.env.tex.h; uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh); return uv; }(), 0.f));
+            L += (Luminance(radiance) + Average(radiance)) * 0.5f;
+            R += radiance;
+        }
+        im.mips[0][(size_t)y * im.dim + x] = make_float4(R.x * invSamples, R.y * invSamples, R.z * invSamples, L * invSamples);
+    }
+    for (uint l = 1; l < im.mipCount; l++) {
+        uint pd = im.dim >> (l - 1), d = im.dim >> l;
+        im.mips[l].resize((size_t)d * d);
+        for (uint y = 0; y < d; y++) for (uint x = 0; x < d; x++) {
+            const std::vector<float4>& p = im.mips[l - 1];
+            float4 s = (p[(size_t)(2 * y) * pd + 2 * x] + p[(size_t)(2 * y) * pd + 2 * x + 1]) + (p[(size_t)(2 * y + 1) * pd + 2 * x] + p[(size_t)(2 * y + 1) * pd + 2 * x + 1]);
+            im.mips[l][(size_t)y * d + x] = s * 0.25f;
+        }
+    }
+}
+static uint firstbithigh(uint v) { uint r = 0; while (v >>= 1) r++; return r; }
+static uint qt_weight(const EnvImportance& im, uint dim, uint x, uint y, uint lightIndex, uint depthLimit) {   // EnvironmentComputeWeightForQTBuild
+    uint mipLevel = im.mipCount - firstbithigh(dim) - 1;
+    float areaMul = (float)(1u << (mipLevel * 2));
+    float radiance = im.mips[mipLevel][(size_t)y * dim + x].w;
+    float ret = areaMul * radiance;
+    ret = fmaxf_(sq(1.0f / 100.0f) * (float)mipLevel, ret);
+    ret *= (mipLevel > depthLimit) ? 1.0f : 0.0f;
+    uint v = (uint)(FastSqrt(ret) * 100 + 0.5f); if (v > 0x000FFFFFu) v = 0x000FFFFFu;
+    return (v << 12) | lightIndex;
+}
+struct QTNode { uint dim, x, y; };
+static void qt_subdivide(const EnvImportance& im, std::vector<QTNode>& nodes, std::vector<uint>& packed, uint subdivisions, uint depthLimit) {
+    for (uint si = 0; si < subdivisions; si++) {
+        uint best = 0; for (size_t i = 0; i < packed.size(); i++) best = std::max(best, packed[i]);
+        uint gi = best & 0xFFFu;
+        QTNode n = nodes[gi];
+        for (uint k = 0; k < 4; k++) {
+            QTNode c; c.dim = n.dim * 2; c.x = n.x * 2 + (k % 2); c.y = n.y * 2 + (k / 2);
+            uint ni = (k == 0) ? gi : (uint)nodes.size();
+            if (k == 0) { nodes[gi] = c; packed[gi] = qt_weight(im, c.dim, c.x, c.y, ni, depthLimit); }
+            else { nodes.push_back(c); packed.push_back(qt_weight(im, c.dim, c.x, c.y, ni, depthLimit)); }
+        }
+    }
+}
+static void bake_env_quads(Scene& sc) {
+    EnvImportance im; build_env_importance(sc, im);
+    std::vector<QTNode> base; std::vector<uint> packed;
+    for (uint li = 0; li < QT_BASE_RES * QT_BASE_RES; li++) {
+        QTNode n; n.dim = QT_BASE_RES; n.x = li / QT_BASE_RES; n.y = li % QT_BASE_RES;
+        base.push_back(n); packed.push_back(qt_weight(im, n.dim, n.x, n.y, li, QT_BOOST_DPT));
+    }
+    qt_subdivide(im, base, packed, QT_SUBDIV, QT_BOOST_DPT);
+    sc.envLookupDim = im.dim; sc.envLookup.assign((size_t)im.dim * im.dim, 0);
+    const float distantVsLocal = 1.0f * 0.0002f;                                  // LightsBaker.cpp:1029-1030
+    for (uint g = 0; g < QT_UNBOOSTED; g++) {
+        std::vector<QTNode> nodes(1, base[g]); std::vector<uint> pk(1, qt_weight(im, base[g].dim, base[g].x, base[g].y, 0, 0));
+        qt_subdivide(im, nodes, pk, QT_BOOST_SUBDIV, 0);
+        for (uint li = 0; li < QT_BOOST_MULT; li++) {
+            EnvironmentQuadLight e; e.NodeDim = nodes[li].dim; e.NodeX = nodes[li].x; e.NodeY = nodes[li].y;
+            uint mipLevel = im.mipCount - firstbithigh(e.NodeDim) - 1;          // EnvironmentComputeRadianceAndWeight
+            float areaMul = (float)(1u << (mipLevel * 2));
+            float4 value = im.mips[mipLevel][(size_t)e.NodeY * e.NodeDim + e.NodeX];
+            e.Weight = areaMul * fmaxf_(0.f, value.w * Average(sc.env.colorMultiplier) * distantVsLocal);
+            e.Radiance = xyz(value) * sc.env.colorMultiplier;
+            uint uniqueID = 0;
+            PolymorphicLightInfoFull lf = e.Store(uniqueID);
+            float2 sub = make_float2(((float)e.NodeX + 0.5f) / (float)e.NodeDim, ((float)e.NodeY + 0.5f) / (float)e.NodeDim);
+            lf.Base.Center = mul_vec_mat3(oct_to_ndir_equal_area_unorm(sub), sc.env.toWorld) * DISTANT_LIGHT_DISTANCE;
+            uint out = g * QT_BOOST_MULT + li;
+            sc.lights[out] = lf.Base; sc.lightsEx[out] = lf.Extended;
+            uint dimScale = im.dim / e.NodeDim;                                    // EnvLightsFillLookupMap
+            for (uint yy = 0; yy < dimScale; yy++) for (uint xx = 0; xx < dimScale; xx++)
+                sc.envLookup[(size_t)(e.NodeY * dimScale + yy) * im.dim + (e.NodeX * dimScale + xx)] = out;
+        }
+    }
+}
+
+void bake_lights(Scene& sc, bool neeEnabled) {
+    sc.lights.clear(); sc.lightsEx.clear(); sc.proxyCounters.clear(); sc.proxyIndices.clear(); sc.envLookup.clear(); sc.envLookupDim = 0;
+    for (size_t i = 0; i < sc.subInstances.size(); i++) sc.subInstances[i].EmissiveLightMappingOffset = 0xFFFFFFFFu;
+    if (neeEnabled) {
+        if (sc.env.enabled) { sc.lights.resize(QT_TOTAL); sc.lightsEx.resize(QT_TOTAL); bake_env_quads(sc); }
+        for (size_t i = 0; i < sc.analyticLights.size(); i++) { sc.lights.push_back(sc.analyticLights[i].Base); sc.lightsEx.push_back(sc.analyticLights[i].Extended); }
+        // emissive triangles, in sub-instance order (LightsBaker.cpp:663-827 + LightsBaker.hlsl:544-716)
+        for (size_t s = 0; s < sc.subInstances.size(); s++) {
+            SubInstanceData& si = sc.subInstances[s];
+            const GeometryDesc& g = sc.geometries[si.GlobalGeometryIndex_PTMaterialDataIndex >> 16];
+            const PTMaterialData& mat = sc.materials[g.materialIndex];
+            bool isEmissive = any_gt0(mat.EmissiveColor);                          // PTMaterial::IsEmissive (MaterialsBaker.cpp:511-514)
+            uint ntri = g.numIndices / 3;
+            if (!isEmissive || sc.lights.size() + ntri >= RTXPT_LIGHTING_MAX_LIGHTS) continue;
+            si.EmissiveLightMappingOffset = (uint)sc.lights.size();
+            const InstanceDesc& inst = sc.instances[sc.subInstToInstGeom[s].x];
+            bool isFlipped = det3(inst.transform) < 0.f;
+            for (uint t = 0; t < ntri; t++) {
+                const uint* idx = &sc.indices[g.indexOffset + 3 * t];
+                float3 p0 = xform_point(inst.transform, sc.positions[g.vertexOffset + idx[0]]);
+                float3 p1 = xform_point(inst.transform, sc.positions[g.vertexOffset + idx[1]]);
+                float3 p2 = xform_point(inst.transform, sc.positions[g.vertexOffset + idx[2]]);
+                float3 radiance = mat.EmissiveColor;
+                if ((mat.Flags & PTMaterialFlags_UseEmissiveTexture) && (g.flags & GEOM_HAS_UV)) {
+                    // reference: anisotropic SampleGrad at the centroid (LightsBaker.hlsl:591-650); restated as a trilinear tap whose LOD
+                    // comes from the longer of the two gradient axes
+                    float2 uv0 = sc.uvs[g.vertexOffset + idx[0]], uv1 = sc.uvs[g.vertexOffset + idx[1]], uv2 = sc.uvs[g.vertexOffset + idx[2]];
+                    float2 e0 = uv1 - uv0, e1 = uv2 - uv1, e2 = uv0 - uv2;
+                    float l0 = length(e0), l1 = length(e1), l2 = length(e2);
+                    float2 shortE, longE1, longE2;
+                    if (l0 < l1 && l0 < l2) { shortE = e0; longE1 = e1; longE2 = e2; } else if (l1 < l2) { shortE = e1; longE1 = e2; longE2 = e0; } else { shortE = e2; longE1 = e0; longE2 = e1; }
+                    float2 sg = shortE * (2.0f / 3.0f); float2 lg = (longE1 + longE2) * (1.0f / 3.0f);
+                    const Texture& tex = sc.textures[mat.EmissiveTextureIndex & 0xFFFFu];
+                    float fw = fmaxf_(length(make_float2(sg.x * (float)tex.w, sg.y * (float)tex.h)), length(make_float2(lg.x * (float)tex.w, lg.y * (float)tex.h)));
+                    float lod = RayCone::SafeLog2(fw);
+                    float2 c = (uv0 + uv1 + uv2) * (1.0f / 3.0f);
+                    radiance = radiance * xyz(sample_trilinear(tex, c, lod));
+                }
+                radiance = max3v(radiance, make_float3(0.f));
+                TriangleLight tl; tl.base = p0;
+                if (!isFlipped) { tl.edge1 = p1 - p0; tl.edge2 = p2 - p0; } else { tl.edge1 = p2 - p0; tl.edge2 = p1 - p0; }
+                if (fmaxf_(radiance.x, fmaxf_(radiance.y, radiance.z)) < 1e-7f) radiance = make_float3(0.f);
+                tl.radiance = radiance; tl.normal = make_float3(0.f); tl.surfaceArea = 0;
+                PolymorphicLightInfoFull lf = tl.Store(0);
+                sc.lights.push_back(lf.Base); sc.lightsEx.push_back(lf.Extended);
+            }
+        }
+        // weights + proxies (LightsBaker.hlsl:738-751, 836-948); NEEType 1: no frustum/intensity boosts, no feedback
+        uint N = (uint)sc.lights.size();
+        std::vector<float> w(N); float weightSum = 0.f;
+        for (uint i = 0; i < N; i++) {
+            PolymorphicLightInfoFull lf; lf.Base = sc.lights[i]; lf.Extended = sc.lightsEx[i];
+            float flux = PolymorphicLight_GetPower(lf);
+            float wt = dm_pow(flux, 0.8f);
+            if (!(wt >= RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD)) wt = 0;
+            w[i] = wt; weightSum += wt;
+        }
+        uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
+        sc.proxyCounters.assign(N, 0);
+        for (uint i = 0; i < N; i++) {
+            uint c = 0;
+            if (w[i] > 0) c = (uint)ceilf(((float)(budget - N) * w[i]) / weightSum);
+            c = std::min(c, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1);
+            sc.proxyCounters[i] = c;
+            for (uint k = 0; k < c; k++) sc.proxyIndices.push_back(i);
+        }
+    }
+    LightTable& T = sc.lightTable;
+    T.Lights = sc.lights.data(); T.LightsEx = sc.lightsEx.data(); T.ProxyCounters = sc.proxyCounters.data(); T.ProxyIndices = sc.proxyIndices.data();
+    T.TotalLightCount = (uint)sc.lights.size(); T.SamplingProxyCount = (uint)sc.proxyIndices.size();
+    T.EnvLookupMap = sc.envLookup.data(); T.EnvLookupDim = sc.envLookupDim; T.EnvToWorld = sc.env.toWorld; T.WorldToEnv = sc.env.toLocal;
+}
+
+struct Context {
+    Scene sc; PtSettings S; PathTracerCameraData cam; uint w, h; std::vector<float4> accum; uint accumCount; RayCounters ctr;
+    bool geomDirty, lightsDirty;
+};
+
+} // namespace ptref
+
+extern "C" {
+
+void* ptref_create() {
+    Context* c = new Context();
+    memset(&c->S, 0, sizeof(c->S)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->ctr, 0, sizeof(c->ctr));
+    c->w = c->h = 0; c->accumCount = 0; c->geomDirty = c->lightsDirty = true;
+    c->sc.env.enabled = false; c->sc.envLookupDim = 0;
+    float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->sc.env.toWorld.m, I, 48); memcpy(c->sc.env.toLocal.m, I, 48);
+    c->sc.env.colorMultiplier = make_float3(1.f);
+    return c;
+}
+void ptref_destroy(void* h) { delete (Context*)h; }
+
+void ptref_set_geometry(void* h, const uint32_t* indices, uint32_t nIdx, const float* positions, const float* uvs, const uint32_t* normals, const uint32_t* tangents,
+                        uint32_t nVerts, const GeometryDesc* geoms, uint32_t nGeoms, const MeshDesc* meshes, uint32_t nMeshes) {
+    Context* c = (Context*)h; Scene& sc = c->sc;
+    sc.indices.assign(indices, indices + nIdx);
+    sc.positions.resize(nVerts); memcpy(sc.positions.data(), positions, (size_t)nVerts * 12);
+    sc.uvs.resize(nVerts); if (uvs) memcpy(sc.uvs.data(), uvs, (size_t)nVerts * 8); else memset(sc.uvs.data(), 0, (size_t)nVerts * 8);
+    sc.normals.resize(nVerts); if (normals) memcpy(sc.normals.data(), normals, (size_t)nVerts * 4); else memset(sc.normals.data(), 0, (size_t)nVerts * 4);
+    sc.tangents.resize(nVerts); if (tangents) memcpy(sc.tangents.data(), tangents, (size_t)nVerts * 4); else memset(sc.tangents.data(), 0, (size_t)nVerts * 4);
+    sc.geometries.assign(geoms, geoms + nGeoms); sc.meshes.assign(meshes, meshes + nMeshes);
+    c->geomDirty = true;
+}
+void ptref_set_instances(void* h, const InstanceDesc* inst, uint32_t n) { Context* c = (Context*)h; c->sc.instances.assign(inst, inst + n); c->geomDirty = true; }
+void ptref_set_materials(void* h, const PTMaterialData* m, uint32_t n) { Context* c = (Context*)h; c->sc.materials.assign(m, m + n); c->geomDirty = true; }
+// format: 0 = RGBA8 UNORM, 1 = RGBA8 sRGB (rgb decoded to linear at load, like an _SRGB view), 2 = RGBA32F
+void ptref_add_texture(void* h, uint32_t w, uint32_t hgt, uint32_t format, const void* pixels) {
+    Context* c = (Context*)h; Texture t; t.w = w; t.h = hgt; t.mips.resize(1); t.mips[0].resize((size_t)w * hgt);
+    for (size_t i = 0; i < (size_t)w * hgt; i++) {
+        float4 v;
+        if (format == 2) { const float* p = (const float*)pixels + 4 * i; v = make_float4(p[0], p[1], p[2], p[3]); }
+        else {
+            const uint8_t* p = (const uint8_t*)pixels + 4 * i;
+            v = make_float4((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f);
+            if (format == 1) { v.x = srgb_to_linear(v.x); v.y = srgb_to_linear(v.y); v.z = srgb_to_linear(v.z); }
+        }
+        t.mips[0][i] = v;
+    }
+    build_mips(t);
+    c->sc.textures.push_back(t); c->geomDirty = true;
+}
+void ptref_clear_textures(void* h) { ((Context*)h)->sc.textures.clear(); }
+// lat-long float RGB, row 0 at +Y; transform: 12 floats local->world (row major 3x4), colorMultiplier rgb; w==0 disables
+void ptref_set_environment(void* h, const float* rgb, uint32_t w, uint32_t hgt, const float* toWorld, const float* colorMul) {
+    Context* c = (Context*)h; EnvMap& e = c->sc.env;
+    e.enabled = (w != 0);
+    if (w) {
+        e.tex.w = w; e.tex.h = hgt; e.tex.mips.clear(); e.tex.mips.resize(1); e.tex.mips[0].resize((size_t)w * hgt);
+        for (size_t i = 0; i < (size_t)w * hgt; i++) e.tex.mips[0][i] = make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.f);
+        build_mips(e.tex);
+    }
+    if (toWorld) {
+        memcpy(e.toWorld.m, toWorld, 48);
+        // inverse of a rotation = transpose (EnvMapSceneParams.InvTransform)
+        float3x4 inv; memset(&inv, 0, sizeof(inv));
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) inv.m[r * 4 + k] = e.toWorld.m[k * 4 + r];
+        e.toLocal = inv;
+    }
+    if (colorMul) e.colorMultiplier = make_float3(colorMul[0], colorMul[1], colorMul[2]);
+    c->lightsDirty = true;
+}
+void ptref_set_lights(void* h, const PolymorphicLightInfo* base, const PolymorphicLightInfoEx* ex, uint32_t n) {
+    Context* c = (Context*)h; c->sc.analyticLights.clear();
+    for (uint32_t i = 0; i < n; i++) { PolymorphicLightInfoFull f; f.Base = base[i]; if (ex) f.Extended = ex[i]; else memset(&f.Extended, 0, 16); c->sc.analyticLights.push_back(f); }
+    c->lightsDirty = true;
+}
+void ptref_set_camera(void* h, const PathTracerCameraData* cam) { ((Context*)h)->cam = *cam; }
+void ptref_set_settings(void* h, const PtSettings* s) { Context* c = (Context*)h; if (c->S.NEEEnabled != s->NEEEnabled) c->lightsDirty = true; c->S = *s; }
+void ptref_resize(void* h, uint32_t w, uint32_t hgt) { Context* c = (Context*)h; c->w = w; c->h = hgt; c->accum.assign((size_t)w * hgt, make_float4(0, 0, 0, 0)); c->accumCount = 0; }
+void ptref_reset_accumulation(void* h) { Context* c = (Context*)h; std::fill(c->accum.begin(), c->accum.end(), make_float4(0, 0, 0, 0)); c->accumCount = 0; memset(&c->ctr, 0, sizeof(c->ctr)); }
+
+static void prepare(Context* c) {
+    if (c->geomDirty) { finalize_geometry(c->sc); build_bvh(c->sc); c->geomDirty = false; c->lightsDirty = true; }
+    if (c->lightsDirty) { bake_lights(c->sc, c->S.NEEEnabled != 0); c->lightsDirty = false; }
+}
+void ptref_prepare(void* h) { prepare((Context*)h); }
+
+// Sample::Render for n accumulated frames starting at sample index `first` (Sample.cpp:1416-1450, 2770-2778).
+// Restricting to a pixel rectangle is an oracle-only convenience for bounded-time checks.
+void ptref_render_rect(void* h, uint32_t first, uint32_t n, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    Context* c = (Context*)h; prepare(c);
+    for (uint32_t s = 0; s < n; s++) {
+        uint32_t sampleIndex = first + s;
+        float blend = 1.0f / (float)(c->accumCount + 1);
+        RayCounters total; memset(&total, 0, sizeof(total));
+#pragma omp parallel
+        {
+            RayCounters local; memset(&local, 0, sizeof(local));
+            PathTracer pt(c->sc, c->S, c->cam, sampleIndex, &local);
+#pragma omp for schedule(dynamic, 1) nowait
+            for (int y = (int)y0; y < (int)y1; y++) for (uint32_t x = x0; x < x1; x++) {
+                float4 col = pt.tracePixel(x, (uint32_t)y);
+                float4& a = c->accum[(size_t)y * c->w + x];
+                a = (blend < 1.f) ? lerp4(a, col, blend) : col;
+            }
+#pragma omp critical
+            { total.extendRays += local.extendRays; total.shadowRays += local.shadowRays; total.hits += local.hits; total.nodeVisitsExt += local.nodeVisitsExt;
+              total.triTestsExt += local.triTestsExt; total.nodeVisitsSh += local.nodeVisitsSh; total.triTestsSh += local.triTestsSh; }
+        }
+        c->ctr.extendRays += total.extendRays; c->ctr.shadowRays += total.shadowRays; c->ctr.hits += total.hits; c->ctr.nodeVisitsExt += total.nodeVisitsExt;
+        c->ctr.triTestsExt += total.triTestsExt; c->ctr.nodeVisitsSh += total.nodeVisitsSh; c->ctr.triTestsSh += total.triTestsSh;
+        c->accumCount++;
+    }
+}
+void ptref_render(void* h, uint32_t first, uint32_t n) { Context* c = (Context*)h; ptref_render_rect(h, first, n, 0, 0, c->w, c->h); }
+const float* ptref_radiance(void* h) { return (const float*)((Context*)h)->accum.data(); }
+void ptref_get_counters(void* h, uint64_t* out7) { memcpy(out7, &((Context*)h)->ctr, sizeof(RayCounters)); }
+int ptref_num_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+// ---- probes used by parity / known-answer tests
+uint32_t ptref_num_tris(void* h) { Context* c = (Context*)h; prepare(c); return (uint32_t)c->sc.tris.size(); }
+// rays: n x 8 floats (o.xyz, tmin, d.xyz, tmax); out: n x 4 (t, prim as uint bits, u, v). mode 0 = BVH, 1 = brute force
+void ptref_trace_closest(void* h, const float* rays, uint32_t n, float* out, int mode) {
+    Context* c = (Context*)h; prepare(c);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < (int)n; i++) {
+        const float* r = rays + 8 * (size_t)i;
+        float3 o = make_float3(r[0], r[1], r[2]), d = make_float3(r[4], r[5], r[6]);
+        HitInfo hi = mode ? trace_closest_bruteforce(c->sc, o, d, r[3], r[7]) : trace_closest(c->sc, o, d, r[3], r[7]);
+        float* q = out + 4 * (size_t)i; q[0] = hi.t; q[1] = asfloat(hi.prim); q[2] = hi.u; q[3] = hi.v;
+    }
+}
+void ptref_trace_visibility(void* h, const float* rays, uint32_t n, uint32_t* outVisible) {
+    Context* c = (Context*)h; prepare(c);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < (int)n; i++) {
+        const float* r = rays + 8 * (size_t)i;
+        outVisible[i] = trace_visibility(c->sc, make_float3(r[0], r[1], r[2]), make_float3(r[4], r[5], r[6]), r[3], r[7]) ? 1u : 0u;
+    }
+}
+// light table read-back: returns counts; copies when pointers are non-null
+void ptref_get_lights(void* h, uint32_t* nLights, uint32_t* nProxies, void* lights32, void* lightsEx16, uint32_t* proxyCounters, uint32_t* proxyIndices, uint32_t* envLookup, uint32_t* envLookupDim) {
+    Context* c = (Context*)h; prepare(c); Scene& sc = c->sc;
+    if (nLights) *nLights = (uint32_t)sc.lights.size(); if (nProxies) *nProxies = (uint32_t)sc.proxyIndices.size(); if (envLookupDim) *envLookupDim = sc.envLookupDim;
+    if (lights32) memcpy(lights32, sc.lights.data(), sc.lights.size() * 32); if (lightsEx16) memcpy(lightsEx16, sc.lightsEx.data(), sc.lightsEx.size() * 16);
+    if (proxyCounters) memcpy(proxyCounters, sc.proxyCounters.data(), sc.proxyCounters.size() * 4);
+    if (proxyIndices) memcpy(proxyIndices, sc.proxyIndices.data(), sc.proxyIndices.size() * 4);
+    if (envLookup) memcpy(envLookup, sc.envLookup.data(), sc.envLookup.size() * 4);
+}
+void ptref_get_subinstances(void* h, uint32_t* n, void* out32) {
+    Context* c = (Context*)h; prepare(c);
+    if (n) *n = (uint32_t)c->sc.subInstances.size(); if (out32) memcpy(out32, c->sc.subInstances.data(), c->sc.subInstances.size() * 32);
+}
+
+// ---- scalar known-answer probes
+uint32_t ptref_hash32(uint32_t x) { return Hash32(x); }
+uint32_t ptref_hash32_combine(uint32_t s, uint32_t v) { return Hash32Combine(s, v); }
+uint32_t ptref_sobol(uint32_t index, uint32_t dim) { return bhos_sobol(index, dim); }
+uint32_t ptref_owen_scramble(uint32_t x, uint32_t seed) { return bhos_owen_scramble(x, seed); }
+float ptref_hash32_to_float(uint32_t x) { return Hash32ToFloat(x); }
+uint32_t ptref_f32tof16(float f) { return f32tof16(f); }
+float ptref_f16tof32(uint32_t h) { return f16tof32(h); }
+// sample streams: kind 0 = SampleSequenceGenerator::Generate (LD), 1 = UniformSampleSequenceGenerator::Generate,
+// 2 = UniformSampleSequenceGenerator::make + n x Next (floats), 3 = SampleSequenceGenerator::make(lowDiscrepancy=false) + Next
+void ptref_sample_stream(uint32_t packedPixel, uint32_t vertexIndex, uint32_t sampleIndex, uint32_t effectSeed, int kind, uint32_t n, float* out) {
+    SampleGeneratorVertexBase vb = SampleGeneratorVertexBase::make(packedPixel, vertexIndex, sampleIndex);
+    if (kind == 0) { float4 v = SampleSequenceGenerator::Generate(n, vb, effectSeed); memcpy(out, &v, 4 * (n > 4 ? 4 : n)); }
+    else if (kind == 1) { float4 v = UniformSampleSequenceGenerator::Generate(n, vb, effectSeed); memcpy(out, &v, 4 * (n > 4 ? 4 : n)); }
+    else if (kind == 2) { UniformSampleSequenceGenerator g = UniformSampleSequenceGenerator::make(vb, effectSeed); for (uint32_t i = 0; i < n; i++) out[i] = sampleNext1D(g); }
+    else { SampleSequenceGenerator g = SampleSequenceGenerator::make(vb, effectSeed, kind == 4); for (uint32_t i = 0; i < n; i++) out[i] = sampleNext1D(g); }
+}
+void ptref_dmath(int fn, const float* x, const float* y, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; i++) {
+        switch (fn) {
+        case 0: out[i] = dm_sin(x[i]); break; case 1: out[i] = dm_cos(x[i]); break; case 2: out[i] = dm_exp2(x[i]); break; case 3: out[i] = dm_log2(x[i]); break;
+        case 4: out[i] = dm_atan2(y[i], x[i]); break; case 5: out[i] = dm_pow(x[i], y[i]); break; case 6: out[i] = FastACos(x[i]); break; default: out[i] = FastSqrt(x[i]); break;
+        }
+    }
+}
+// BSDF probe: material parameters -> eval / pdf / sample in the local frame N=(0,0,1), T=(1,0,0), B=(0,1,0).
+// in: params[14] = diffuse rgb, specular rgb, roughness, metallic, transmission rgb, diffTrans, specTrans, eta ; thin, diffuseModel
+// mode 0: eval(wi, wo) -> out[0..3], pdf -> out[4]; mode 1: sample(u.xyz) -> out[0..2]=wo, [3]=pdf, [4..6]=weight, [7]=lobe, [8]=lobeP, [9]=valid
+void ptref_bsdf_probe(const float* params, int thin, int diffuseModel, const float* wi, const float* wo_or_u, int mode, float* out) {
+    ShadingData sd; memset(&sd, 0, sizeof(sd));
+    sd.N = make_float3(0, 0, 1); sd.T = make_float3(1, 0, 0); sd.B = make_float3(0, 1, 0); sd.V = make_float3(wi[0], wi[1], wi[2]);
+    sd.faceNCorrected = sd.N; sd.vertexN = sd.N; sd.frontFacing = true; sd.mtl = MaterialHeader::make(); sd.mtl.setActiveLobes(Lobe_All); sd.mtl.setThinSurface(thin != 0);
+    StandardBSDF b; b.diffuseModel = diffuseModel;
+    b.data.diffuse = make_float3(params[0], params[1], params[2]); b.data.specular = make_float3(params[3], params[4], params[5]);
+    b.data.roughness = params[6]; b.data.metallic = params[7]; b.data.transmission = make_float3(params[8], params[9], params[10]);
+    b.data.diffuseTransmission = params[11]; b.data.specularTransmission = params[12]; b.data.eta = params[13];
+    if (mode == 0) {
+        float3 wo = make_float3(wo_or_u[0], wo_or_u[1], wo_or_u[2]);
+        float4 e = b.eval(sd, wo); out[0] = e.x; out[1] = e.y; out[2] = e.z; out[3] = e.w; out[4] = b.evalPdf(sd, wo); out[5] = (float)b.getLobes();
+    } else {
+        BSDFSample s; memset(&s, 0, sizeof(s));
+        bool v = b.sample(sd, make_float4(wo_or_u[0], wo_or_u[1], wo_or_u[2], 0), s);
+        out[0] = s.wo.x; out[1] = s.wo.y; out[2] = s.wo.z; out[3] = s.pdf; out[4] = s.weight.x; out[5] = s.weight.y; out[6] = s.weight.z; out[7] = (float)s.lobe; out[8] = s.lobeP; out[9] = v ? 1.f : 0.f;
+    }
+}
+// camera probe
+void ptref_camera_ray(void* h, uint32_t px, uint32_t py, uint32_t sampleIndex, float* out6) {
+    Context* c = (Context*)h; PathTracer pt(c->sc, c->S, c->cam, sampleIndex, 0); float3 o, d; pt.computeCameraRay(px, py, o, d);
+    out6[0] = o.x; out6[1] = o.y; out6[2] = o.z; out6[3] = d.x; out6[4] = d.y; out6[5] = d.z;
+}
+
+} // extern "C"

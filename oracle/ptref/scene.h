@@ -1,0 +1,275 @@
+// ORACLE (test infrastructure only) — scene data contract, textures, environment map, BVH + intersection.
+//
+// Data contract (mirrors the buffers the reference binds at Rtxpt/Sample.cpp:2319-2384):
+//   * PTMaterialData 128 B        Rtxpt/Shaders/PathTracer/Materials/MaterialPT.h:45-77 (flags :24-42)
+//   * SubInstanceData 32 B        Rtxpt/Shaders/SubInstanceData.h:23-46
+//   * GeometryData / InstanceData Donut structs (absent): index u32, position float3, uv float2,
+//                                 normal/tangent SNORM8x4 — fetched as in PathTracerBridgeDonut.hlsli:152-256
+// What the DXR driver does (BLAS/TLAS build + traversal, Sample.cpp:1061-1079,1200-1240; BridgeDonut:993-1055) is replaced
+// by an explicit binned-SAH BVH2 over world-space triangles with a Moeller-Trumbore test. Any exact BVH returns the same
+// closest hit; ties on t are broken towards the lower global primitive index so that the result is traversal-order free.
+// Texture filtering (fixed-function in the reference) is restated as explicit wrap-mode bilinear/trilinear on a box-filtered
+// mip chain; the environment is sampled from the source lat-long image (the EnvMapBaker cube conversion is out of scope).
+#pragma once
+#include "lights.h"
+#include <vector>
+#include <algorithm>
+
+namespace ptref {
+
+// ---- MaterialPT.h:24-42
+enum : uint {
+    PTMaterialFlags_UseSpecularGlossModel = 0x1, PTMaterialFlags_UseMetalRoughOrSpecularTexture = 0x4,
+    PTMaterialFlags_UseBaseOrDiffuseTexture = 0x8, PTMaterialFlags_UseEmissiveTexture = 0x10, PTMaterialFlags_UseNormalTexture = 0x20,
+    PTMaterialFlags_UseTransmissionTexture = 0x80, PTMaterialFlags_MetalnessInRedChannel = 0x100, PTMaterialFlags_ThinSurface = 0x200,
+    PTMaterialFlags_PSDExclude = 0x400, PTMaterialFlags_EnableAsAnalyticLightProxy = 0x800, PTMaterialFlags_IgnoreMeshTangentSpace = 1u << 12,
+    PTMaterialFlags_NestedPriorityMask = 0xF0000000u, PTMaterialFlags_NestedPriorityShift = 28,
+};
+// ---- MaterialPT.h:45-77 (128 bytes)
+struct PTMaterialData {
+    float3 BaseOrDiffuseColor; uint Flags;
+    float3 SpecularColor; int _padding0;
+    float3 EmissiveColor; float ShadowNoLFadeout;
+    float Opacity, Roughness, Metalness, NormalTextureScale;
+    float _padding1, AlphaCutoff, TransmissionFactor; uint BaseOrDiffuseTextureIndex;
+    uint MetalRoughOrSpecularTextureIndex, EmissiveTextureIndex, NormalTextureIndex, OcclusionTextureIndex;
+    uint TransmissionTextureIndex; float IoR, ThicknessFactor, DiffuseTransmissionFactor;
+    float3 AttenuationColor; float AttenuationDistance;
+};
+static_assert(sizeof(PTMaterialData) == 128, "PTMaterialData must be 128 bytes");
+
+// ---- SubInstanceData.h:23-46
+struct SubInstanceData {
+    enum : uint { Flags_AlphaTested = 1u << 16, Flags_ExcludeFromNEE = 1u << 17, Flags_AlphaOffsetOffset = 24 };
+    uint FlagsAndAlphaInfo, GlobalGeometryIndex_PTMaterialDataIndex, EmissiveLightMappingOffset, AnalyticProxyLightIndex;
+    // SUBINSTANCEDATA_EXTENDED words (SubInstanceData.h:37-42): here element (not byte) offsets into the shared streams
+    uint IndexBufferIndex_VertexBufferIndex, IndexOffset, TexCoord1Offset, padding0;
+    float AlphaCutoff() const { return (float)(FlagsAndAlphaInfo >> Flags_AlphaOffsetOffset) / 255.0f; }
+    uint AlphaTextureIndex() const { return FlagsAndAlphaInfo & 0xFFFFu; }
+};
+
+// geometry = one glTF primitive; vertex streams share one vertex base
+struct GeometryDesc {
+    uint indexOffset, numIndices;      // into the u32 index array
+    uint vertexOffset, numVertices;    // into the vertex streams
+    uint flags;                        // bit0 has uv, bit1 has normals, bit2 has tangents
+    uint materialIndex;
+    uint geomFlags;                    // bit0 alpha-tested, bit1 exclude-from-NEE (AccelerationStructureUtil.h:35-104)
+    uint _pad;
+};
+enum : uint { GEOM_HAS_UV = 1, GEOM_HAS_NORMAL = 2, GEOM_HAS_TANGENT = 4, GEOMF_ALPHA_TESTED = 1, GEOMF_EXCLUDE_FROM_NEE = 2 };
+struct MeshDesc { uint firstGeometry, numGeometries; };
+struct InstanceDesc { float3x4 transform; uint meshIndex; uint _pad[3]; };
+
+// ---- textures: RGBA float texels, full mip chain (box filter), wrap addressing
+struct Texture {
+    uint w, h, mipLevels;
+    std::vector<std::vector<float4> > mips;
+    const float4& texel(uint mip, int x, int y) const {
+        uint mw = std::max(1u, w >> mip), mh = std::max(1u, h >> mip);
+        int xi = x % (int)mw; if (xi < 0) xi += mw;
+        int yi = y % (int)mh; if (yi < 0) yi += mh;
+        return mips[mip][(size_t)yi * mw + xi];
+    }
+};
+static inline float srgb_to_linear(float c) { return (c <= 0.04045f) ? c / 12.92f : dm_pow((c + 0.055f) / 1.055f, 2.4f); }
+static inline void build_mips(Texture& t) {
+    uint lv = 1; { uint m = std::max(t.w, t.h); while (m > 1) { m >>= 1; lv++; } }
+    t.mipLevels = lv; t.mips.resize(lv);
+    for (uint l = 1; l < lv; l++) {
+        uint pw = std::max(1u, t.w >> (l - 1)), ph = std::max(1u, t.h >> (l - 1));
+        uint mw = std::max(1u, t.w >> l), mh = std::max(1u, t.h >> l);
+        t.mips[l].resize((size_t)mw * mh);
+        for (uint y = 0; y < mh; y++) for (uint x = 0; x < mw; x++) {
+            uint x0 = std::min(2 * x, pw - 1), x1 = std::min(2 * x + 1, pw - 1), y0 = std::min(2 * y, ph - 1), y1 = std::min(2 * y + 1, ph - 1);
+            const std::vector<float4>& p = t.mips[l - 1];
+            float4 s = (p[(size_t)y0 * pw + x0] + p[(size_t)y0 * pw + x1]) + (p[(size_t)y1 * pw + x0] + p[(size_t)y1 * pw + x1]);
+            t.mips[l][(size_t)y * mw + x] = s * 0.25f;
+        }
+    }
+}
+// bilinear at an integer mip, wrap addressing, texel centres at (i+0.5)/dim
+static inline float4 sample_bilinear(const Texture& t, uint mip, float2 uv) {
+    uint mw = std::max(1u, t.w >> mip), mh = std::max(1u, t.h >> mip);
+    float fx = uv.x * (float)mw - 0.5f, fy = uv.y * (float)mh - 0.5f;
+    float flx = floorf(fx), fly = floorf(fy);
+    float ax = fx - flx, ay = fy - fly;
+    // keep the integer conversion in range for huge |uv|
+    flx = flx - floorf(flx / (float)mw) * (float)mw; fly = fly - floorf(fly / (float)mh) * (float)mh;
+    int x0 = (int)flx, y0 = (int)fly;
+    float4 a = lerp4(t.texel(mip, x0, y0), t.texel(mip, x0 + 1, y0), ax);
+    float4 b = lerp4(t.texel(mip, x0, y0 + 1), t.texel(mip, x0 + 1, y0 + 1), ax);
+    return lerp4(a, b, ay);
+}
+// Texture2D.SampleLevel(sampler, uv, lambda) with trilinear filtering
+static inline float4 sample_trilinear(const Texture& t, float2 uv, float lambda) {
+    float maxl = (float)(t.mipLevels - 1);
+    float l = clampf(lambda, 0.0f, maxl);
+    float l0 = floorf(l);
+    uint m0 = (uint)l0, m1 = std::min(m0 + 1, t.mipLevels - 1);
+    float f = l - l0;
+    float4 a = sample_bilinear(t, m0, uv);
+    if (f == 0.0f || m1 == m0) return a;
+    float4 b = sample_bilinear(t, m1, uv);
+    return lerp4(a, b, f);
+}
+
+// ---- environment: lat-long RGB image (row 0 = +Y pole), bilinear + mips; EnvMap.hlsli:54-93 semantics for transform/multiplier
+struct EnvMap {
+    bool enabled; Texture tex; float3x4 toWorld, toLocal; float3 colorMultiplier;
+    float3 ToLocal(float3 dir) const { return mul_vec_mat3(dir, toLocal); }
+    float3 ToWorld(float3 dir) const { return mul_vec_mat3(dir, toWorld); }
+    // direction -> lat-long uv (MathHelpers.hlsli:92-104 world_to_latlong_map convention: +Y up, u from atan2(x,-z))
+    static float2 dir_to_latlong(float3 d) {
+        float phi = dm_atan2(d.x, -d.z);                          // [-pi, pi]
+        float u = phi * (0.5f * K_1_PI) + 0.5f;
+        float yc = clampf(d.y, -1.0f, 1.0f);
+        // acos(y)/pi through atan2 to stay within the deterministic function set
+        float theta = dm_atan2(sqrtf_(fmaxf_(0.0f, 1.0f - yc * yc)), yc);
+        return make_float2(u, theta * K_1_PI);
+    }
+    float3 EvalLocal(float3 localDir, float lod) const {
+        float2 uv = dir_to_latlong(localDir);
+        // clamp v so that bilinear taps do not wrap over the poles
+        uint mip = (uint)clampf(lod, 0.0f, (float)(tex.mipLevels - 1));
+        float mh = (float)std::max(1u, tex.h >> mip);
+        uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh);
+        float4 c = sample_trilinear(tex, uv, lod);
+        return xyz(c) * colorMultiplier;
+    }
+};
+
+// ---- the scene
+struct Triangle { float3 v0, e1, e2; uint subInstance, triIndex, flags; };   // world space; flags bit0 = non-opaque (alpha tested), bit1 = exclude from NEE
+struct Scene {
+    std::vector<uint> indices; std::vector<float3> positions; std::vector<float2> uvs; std::vector<uint> normals, tangents;
+    std::vector<GeometryDesc> geometries; std::vector<MeshDesc> meshes; std::vector<InstanceDesc> instances;
+    std::vector<PTMaterialData> materials; std::vector<Texture> textures;
+    EnvMap env;
+    // derived
+    std::vector<uint> instFirstSubInstance;                 // InstanceData.firstGeometryInstanceIndex
+    std::vector<uint2> subInstToInstGeom;                   // subInstance -> (instanceIndex, global geometry index)
+    std::vector<SubInstanceData> subInstances;
+    std::vector<Triangle> tris;
+    // lights
+    std::vector<PolymorphicLightInfo> lights; std::vector<PolymorphicLightInfoEx> lightsEx;
+    std::vector<uint> proxyCounters, proxyIndices, envLookup; uint envLookupDim;
+    std::vector<PolymorphicLightInfoFull> analyticLights;   // supplied by the host (pt_set_lights)
+    LightTable lightTable;
+    // BVH2
+    struct Node { float3 bmin; uint leftFirst; float3 bmax; uint count; };   // count==0: inner (children leftFirst, leftFirst+1)
+    std::vector<Node> nodes; std::vector<uint> triOrder;
+};
+
+static_assert(sizeof(SubInstanceData) == 32, "SubInstanceData must be 32 bytes");
+struct HitInfo { float t; uint prim; float u, v; };      // prim = global triangle index, 0xFFFFFFFF = miss
+
+// Moeller-Trumbore; both sides; accepts tmin < t < tmax. (u,v) are the DXR barycentrics of vertices 1 and 2.
+static inline bool intersect_tri(const Triangle& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
+    float3 pvec = cross(d, tr.e2);
+    float det = dot(tr.e1, pvec);
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    float3 tvec = o - tr.v0;
+    u = dot(tvec, pvec) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    float3 qvec = cross(tvec, tr.e1);
+    v = dot(d, qvec) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot(tr.e2, qvec) * inv;
+    return (t > tmin) && (t < tmax);
+}
+
+// BridgeDonut:929-971 AlphaTestImpl — base-colour texture alpha at mip 0 vs the 8-bit quantised cutoff
+static inline bool AlphaTest(const Scene& sc, const Triangle& tr, float u, float v) {
+    const SubInstanceData& si = sc.subInstances[tr.subInstance];
+    if ((si.FlagsAndAlphaInfo & SubInstanceData::Flags_AlphaTested) == 0) return true;
+    const GeometryDesc& g = sc.geometries[si.GlobalGeometryIndex_PTMaterialDataIndex >> 16];
+    const uint* idx = &sc.indices[g.indexOffset + tr.triIndex * 3];
+    float2 t0 = sc.uvs[g.vertexOffset + idx[0]], t1 = sc.uvs[g.vertexOffset + idx[1]], t2 = sc.uvs[g.vertexOffset + idx[2]];
+    float b0 = 1.0f - (u + v);
+    float2 tc = (t0 * b0 + t1 * u) + t2 * v;
+    const Texture& tex = sc.textures[si.AlphaTextureIndex()];
+    float opacity = sample_bilinear(tex, 0, tc).w;
+    return opacity >= si.AlphaCutoff();
+}
+
+static inline bool slab(const Scene::Node& n, float3 o, float3 id, float tmax) {
+    float tx1 = (n.bmin.x - o.x) * id.x, tx2 = (n.bmax.x - o.x) * id.x;
+    float tmn = fminf_(tx1, tx2), tmx = fmaxf_(tx1, tx2);
+    float ty1 = (n.bmin.y - o.y) * id.y, ty2 = (n.bmax.y - o.y) * id.y;
+    tmn = fmaxf_(tmn, fminf_(ty1, ty2)); tmx = fminf_(tmx, fmaxf_(ty1, ty2));
+    float tz1 = (n.bmin.z - o.z) * id.z, tz2 = (n.bmax.z - o.z) * id.z;
+    tmn = fmaxf_(tmn, fminf_(tz1, tz2)); tmx = fminf_(tmx, fmaxf_(tz1, tz2));
+    // generous conservative margins: the oracle must never cull a triangle the exact test would accept
+    return (tmx * 1.00001f + 1e-6f >= tmn * 0.99999f - 1e-6f) && (tmn * 0.99999f - 1e-6f < tmax) && (tmx * 1.00001f + 1e-6f > 0.0f);
+}
+
+// closest hit (BridgeDonut:1029-1055 traceScatterRay): RAY_FLAG_NONE, alpha test on non-opaque candidates
+static inline HitInfo trace_closest(const Scene& sc, float3 o, float3 d, float tmin, float tmax, uint64_t* nodeVisits = 0, uint64_t* triTests = 0) {
+    HitInfo h; h.t = tmax; h.prim = 0xFFFFFFFFu; h.u = h.v = 0;
+    if (sc.nodes.empty()) return h;
+    float3 id = make_float3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const Scene::Node& n = sc.nodes[stack[--sp]];
+        if (nodeVisits) (*nodeVisits)++;
+        if (!slab(n, o, id, h.t)) continue;
+        if (n.count) {
+            for (uint i = 0; i < n.count; i++) {
+                uint p = sc.triOrder[n.leftFirst + i];
+                const Triangle& tr = sc.tris[p];
+                float t, u, v;
+                if (triTests) (*triTests)++;
+                if (!intersect_tri(tr, o, d, tmin, tmax, t, u, v)) continue;
+                if (!(t < h.t || (t == h.t && p < h.prim))) continue;
+                if ((tr.flags & 1u) && !AlphaTest(sc, tr, u, v)) continue;
+                h.t = t; h.prim = p; h.u = u; h.v = v;
+            }
+        } else { stack[sp++] = n.leftFirst; stack[sp++] = n.leftFirst + 1; }
+    }
+    return h;
+}
+// any hit (BridgeDonut:993-1027 traceVisibilityRay): returns true when VISIBLE (nothing committed)
+static inline bool trace_visibility(const Scene& sc, float3 o, float3 d, float tmin, float tmax, uint64_t* nodeVisits = 0, uint64_t* triTests = 0) {
+    if (sc.nodes.empty()) return true;
+    float3 id = make_float3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const Scene::Node& n = sc.nodes[stack[--sp]];
+        if (nodeVisits) (*nodeVisits)++;
+        if (!slab(n, o, id, tmax)) continue;
+        if (n.count) {
+            for (uint i = 0; i < n.count; i++) {
+                const Triangle& tr = sc.tris[sc.triOrder[n.leftFirst + i]];
+                float t, u, v;
+                if (triTests) (*triTests)++;
+                if (!intersect_tri(tr, o, d, tmin, tmax, t, u, v)) continue;
+                if (tr.flags & 1u) {                       // non-opaque candidate: AlphaTestVisibilityRay (BridgeDonut:981-989)
+                    if (tr.flags & 2u) continue;          // ExcludeFromNEE
+                    if (!AlphaTest(sc, tr, u, v)) continue;
+                }
+                return false;
+            }
+        } else { stack[sp++] = n.leftFirst; stack[sp++] = n.leftFirst + 1; }
+    }
+    return true;
+}
+static inline HitInfo trace_closest_bruteforce(const Scene& sc, float3 o, float3 d, float tmin, float tmax) {
+    HitInfo h; h.t = tmax; h.prim = 0xFFFFFFFFu; h.u = h.v = 0;
+    for (uint p = 0; p < sc.tris.size(); p++) {
+        float t, u, v;
+        if (!intersect_tri(sc.tris[p], o, d, tmin, tmax, t, u, v)) continue;
+        if (!(t < h.t || (t == h.t && p < h.prim))) continue;
+        if ((sc.tris[p].flags & 1u) && !AlphaTest(sc, sc.tris[p], u, v)) continue;
+        h.t = t; h.prim = p; h.u = u; h.v = v;
+    }
+    return h;
+}
+
+// ---- scene finalisation: sub-instances, world-space triangles, BVH
+void finalize_geometry(Scene& sc);        // scene.cpp part of ptref_api.cpp
+void build_bvh(Scene& sc);
+void bake_lights(Scene& sc, bool neeEnabled);
+
+} // namespace ptref
