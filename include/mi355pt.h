@@ -1,0 +1,195 @@
+/* mi355pt — C-ABI of the MI355X-native wavefront path tracer (libmi355pt.so).
+ *
+ * Drop-in boundary for ONE hot path of NVIDIA-RTX/RTXPT v1.8.1: the reference-mode ray-tracing mega-pass
+ * (Rtxpt/Shaders/PathTracerSample.hlsl and the Rtxpt/Shaders/PathTracer/ directory) together with the driver-side BVH build/refit it
+ * depends on. The entry points mirror the seam `Sample` exposes to Donut's render loop:
+ * every function returns an int32 status (PT_OK == 0), never throws; the last error text is available through
+ * pt_get_last_error(). A pt_context is single-thread-affine, like Donut's render thread (Rtxpt/SampleCommon/SampleBaseApp.cpp:93,183).
+ *
+ * Plain C, plain pointers and sizes; no torch / HIP types in any signature. All pointers are HOST pointers unless a
+ * parameter is explicitly called "device pointer".
+ */
+#ifndef MI355PT_H
+#define MI355PT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_context pt_context;
+
+enum {
+    PT_OK = 0,
+    PT_ERROR_INVALID_ARGUMENT = 1,
+    PT_ERROR_NO_DEVICE = 2,          /* no HIP device / HIP runtime failure: the library has NO CPU fallback */
+    PT_ERROR_HIP = 3,
+    PT_ERROR_IO = 4,                 /* glTF / file problems (Sample::LoadScene returning false) */
+    PT_ERROR_UNSUPPORTED = 5,        /* a setting outside the supported parity-knob set */
+    PT_ERROR_NOT_READY = 6,
+};
+
+/* --- data contract ------------------------------------------------------------------------------------------------ */
+
+/* Rtxpt/Shaders/PathTracer/Materials/MaterialPT.h:45-77 (128 bytes, identical field order); flag bits :24-42.
+ * Texture words: baseLOD<<24 | mipLevels<<16 | textureIndex (Rtxpt/Materials/MaterialsBaker.cpp:497-508), 0xFFFFFFFF = none. */
+typedef struct PTMaterialData {
+    float    BaseOrDiffuseColor[3]; uint32_t Flags;
+    float    SpecularColor[3];      int32_t  _padding0;
+    float    EmissiveColor[3];      float    ShadowNoLFadeout;
+    float    Opacity, Roughness, Metalness, NormalTextureScale;
+    float    _padding1, AlphaCutoff, TransmissionFactor; uint32_t BaseOrDiffuseTextureIndex;
+    uint32_t MetalRoughOrSpecularTextureIndex, EmissiveTextureIndex, NormalTextureIndex, OcclusionTextureIndex;
+    uint32_t TransmissionTextureIndex; float IoR, ThicknessFactor, DiffuseTransmissionFactor;
+    float    AttenuationColor[3];   float    AttenuationDistance;          /* VolumePTConstants */
+} PTMaterialData;
+
+/* Rtxpt/Shaders/PathTracer/PathTracerShared.h:24-42 (112 bytes, identical field order) */
+typedef struct PathTracerCameraData {
+    float PosW[3];       float NearZ;
+    float DirectionW[3]; float PixelConeSpreadAngle;
+    float CameraU[3];    float FarZ;
+    float CameraV[3];    float FocalDistance;
+    float CameraW[3];    float AspectRatio;
+    uint32_t ViewportSize[2]; float ApertureRadius; float _padding0;
+    float Jitter[2];     float _padding1, _padding2;
+} PathTracerCameraData;
+
+/* Rtxpt/Shaders/PathTracer/Lighting/PolymorphicLight.h:47-72 */
+typedef struct PolymorphicLightInfo { float Center[3]; uint32_t ColorTypeAndFlags; uint32_t Direction1, Direction2, Scalars, LogRadiance; } PolymorphicLightInfo;
+typedef struct PolymorphicLightInfoEx { uint32_t IesProfileIndex, PrimaryAxis, CosConeAngleAndSoftness, UniqueID; } PolymorphicLightInfoEx;
+
+/* One glTF primitive ("geometry" in Donut). The vertex streams of all geometries live in shared arrays; offsets are in elements.
+ * Stream formats follow Donut's GeometryData use at PathTracerBridgeDonut.hlsli:166-243: indices u32, positions float3,
+ * uv float2, normal / tangent RGBA8_SNORM (Packing.hlsli:127-167). */
+typedef struct PtGeometryDesc {
+    uint32_t indexOffset, numIndices;
+    uint32_t vertexOffset, numVertices;
+    uint32_t flags;            /* PT_GEOM_HAS_* */
+    uint32_t materialIndex;
+    uint32_t geomFlags;        /* PT_GEOMF_* (Rtxpt/SampleCommon/AccelerationStructureUtil.h:35-104: opaque unless alpha tested / excluded from NEE) */
+    uint32_t _pad;
+} PtGeometryDesc;
+enum { PT_GEOM_HAS_UV = 1, PT_GEOM_HAS_NORMAL = 2, PT_GEOM_HAS_TANGENT = 4 };
+enum { PT_GEOMF_ALPHA_TESTED = 1, PT_GEOMF_EXCLUDE_FROM_NEE = 2 };
+typedef struct PtMeshDesc { uint32_t firstGeometry, numGeometries; } PtMeshDesc;            /* one BLAS in the reference */
+typedef struct PtInstanceDesc { float transform[12]; uint32_t meshIndex; uint32_t _pad[3]; } PtInstanceDesc;   /* row-major 3x4, InstanceData.transform */
+
+typedef struct PtGeometryBuffers {
+    const uint32_t* indices;   uint32_t numIndices;
+    const float*    positions;                      /* numVertices x 3 */
+    const float*    uvs;                            /* numVertices x 2 or NULL */
+    const uint32_t* normals;                        /* numVertices or NULL */
+    const uint32_t* tangents;                       /* numVertices or NULL */
+    uint32_t        numVertices;
+} PtGeometryBuffers;
+
+enum { PT_TEX_RGBA8_UNORM = 0, PT_TEX_RGBA8_SRGB = 1, PT_TEX_RGBA32F = 2 };
+typedef struct PtTextureDesc { uint32_t width, height, format; const void* pixels; } PtTextureDesc;
+
+/* EnvMapSceneParams (Rtxpt/Shaders/PathTracer/Lighting/EnvMap.hlsli:22-30): local->world rotation and colour multiplier. */
+typedef struct PtEnvMapSceneParams { float Transform[12]; float ColorMultiplier[3]; float Enabled; } PtEnvMapSceneParams;
+
+/* Subset of PathTracerConstants (PathTracerShared.h:45-103) plus the shader macros Sample::FillPTPipelineGlobalMacros pushes
+ * (Rtxpt/Sample.cpp:988-1042) that affect the reference-mode estimator. Defaults: pt_default_settings(). */
+typedef struct PtSettings {
+    uint32_t bounceCount, diffuseBounceCount;
+    float    perPixelJitterAAScale;
+    float    texLODBias;
+    float    fireflyFilterThreshold;        /* 0 = disabled */
+    float    envMapDiffuseSampleMIPLevel;
+    uint32_t NEEEnabled, NEEType, NEECandidateSamples, NEEFullSamples;
+    uint32_t enableRussianRoulette;
+    uint32_t nestedDielectricsQuality;      /* RTXPT_NESTED_DIELECTRICS_QUALITY 0/1/2 */
+    uint32_t enableLDSamplerForBSDF;
+    uint32_t diffuseBrdf;                   /* 0 Lambert, 2 Frostbite */
+    uint32_t _pad[2];
+} PtSettings;
+
+typedef struct PtDeviceDesc {
+    int32_t  deviceOrdinal;                 /* HIP device of this context (one context per GPU / process) */
+    uint32_t shardRank, shardCount;         /* pixel-tile shard of this context: tile t belongs to rank morton(t) % shardCount */
+    uint32_t flags;
+} PtDeviceDesc;
+
+typedef struct PtFrameStats {
+    uint64_t extendRays, shadowRays, hits;                  /* "rays" of the Mrays/s metric = extendRays + shadowRays */
+    uint64_t nodeVisitsExtend, triTestsExtend, nodeVisitsShadow, triTestsShadow;   /* in-kernel BVH counters (when enabled) */
+    double   gpuMilliseconds;                               /* whole pt_render call, HIP events */
+    double   extendKernelMs, shadeKernelMs, shadowKernelMs; /* summed per-kernel HIP-event time */
+    uint32_t extendLaunches, iterations;
+    uint32_t pathsTraced, _pad;
+} PtFrameStats;
+
+/* --- entry points (reference seam each one replaces) -------------------------------------------------------------- */
+
+/* DeviceManager creation + Sample::Init (Rtxpt/SampleCommon/SampleBaseApp.cpp:63-140, Rtxpt/Sample.cpp:136) */
+int32_t pt_create(const PtDeviceDesc* desc, pt_context** out);
+/* SceneUnloading + destructor (Rtxpt/Sample.cpp:523-560) */
+int32_t pt_destroy(pt_context* ctx);
+const char* pt_get_last_error(pt_context* ctx);
+
+/* Sample::LoadScene + SceneLoaded + MaterialsBaker::ImportFromDonut (Rtxpt/Sample.cpp:447-560, Rtxpt/Materials/MaterialsBaker.cpp:660-705) */
+int32_t pt_load_scene_gltf(pt_context* ctx, const char* path);
+/* raw-buffer path: the same data the bakers upload (GeometryData/InstanceData/PTMaterialData/SubInstanceData, Rtxpt/Sample.cpp:2319-2384) */
+int32_t pt_set_geometry(pt_context* ctx, const PtGeometryBuffers* buffers, const PtGeometryDesc* geometries, uint32_t numGeometries,
+                        const PtMeshDesc* meshes, uint32_t numMeshes);
+int32_t pt_set_instances(pt_context* ctx, const PtInstanceDesc* instances, uint32_t numInstances);
+int32_t pt_set_materials(pt_context* ctx, const PTMaterialData* materials, uint32_t numMaterials, const PtTextureDesc* textures, uint32_t numTextures);
+/* EnvMapBaker source + EnvMapSceneParams (Rtxpt/Sample.cpp:1364-1388,1939): lat-long float RGB image, row 0 at +Y. width==0 disables. */
+int32_t pt_set_environment(pt_context* ctx, const float* rgbLatLong, uint32_t width, uint32_t height, const PtEnvMapSceneParams* params);
+/* analytic lights already converted by the host (LightsBaker.cpp:456-556 ConvertLight); emissive triangles are baked automatically */
+int32_t pt_set_lights(pt_context* ctx, const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint32_t numLights);
+
+/* BridgeCamera (PathTracerShared.h:109-141) */
+int32_t pt_bridge_camera(uint32_t viewportWidth, uint32_t viewportHeight, const float camPos[3], const float camDir[3], const float camUp[3], float fovY,
+                         float nearZ, float farZ, float focalDistance, float apertureRadius, const float jitter[2], PathTracerCameraData* out);
+int32_t pt_set_camera(pt_context* ctx, const PathTracerCameraData* camera);                 /* Sample.cpp:2052 */
+int32_t pt_default_settings(PtSettings* out);                                               /* SampleUI.h:152-183 with the §8a parity knobs pinned */
+int32_t pt_set_settings(pt_context* ctx, const PtSettings* settings);                       /* UpdatePathTracerConstants, Sample.cpp:1464-1556 */
+
+/* Animate + Scene::Refresh + UpdateSkinnedBLASs/BuildTLAS (Rtxpt/Sample.cpp:785-811,1170-1240): new instance transforms and/or
+ * new vertex positions (same topology) -> LBVH refit (or rebuild when rebuild != 0) + emissive light re-bake. Either pointer may be NULL. */
+int32_t pt_animate(pt_context* ctx, const PtInstanceDesc* instances, uint32_t numInstances, const float* positions, uint32_t numVertices, int32_t rebuild);
+/* BackBufferResizing / RenderTargets::Init (Rtxpt/SampleCommon/RenderTargets.cpp:35-240) */
+int32_t pt_resize(pt_context* ctx, uint32_t width, uint32_t height);
+/* Render -> SampleRenderCode -> PathTrace -> AccumulationPass for samples [first, first+count) (Rtxpt/Sample.cpp:1891-2313, 2438-2559, 2770-2778).
+ * All `count` samples are traced as one wavefront pool and folded into the accumulation buffer in sample order. */
+int32_t pt_render(pt_context* ctx, uint32_t sampleIndexFirst, uint32_t sampleCount, PtFrameStats* stats);
+int32_t pt_reset_accumulation(pt_context* ctx);                                             /* m_ui.ResetAccumulation */
+/* AccumulatedRadiance read-back (SaveTextureToFile seam): full-frame RGBA32F on the host; pixels of other shards are zero. */
+int32_t pt_map_radiance(pt_context* ctx, const float** rgba32f, size_t* rowPitchBytes);
+int32_t pt_unmap_radiance(pt_context* ctx);
+
+/* --- multi-GPU tile sharding (new; no reference analogue) ------------------------------------------- */
+/* number of pixels this shard owns and the packed RGBA32F byte size */
+int32_t pt_shard_info(pt_context* ctx, uint32_t* numOwnedPixels, size_t* packedBytes);
+/* pack this shard's pixels contiguously into a DEVICE buffer (e.g. a torch tensor) — the send buffer of the RCCL gather */
+int32_t pt_pack_shard(pt_context* ctx, void* devicePtrDst, size_t bytes);
+/* rank 0: scatter the packed pixels of shard `rank` (DEVICE pointer, as received from the gather) into the full frame */
+int32_t pt_unpack_shard(pt_context* ctx, const void* devicePtrSrc, size_t bytes, uint32_t rank);
+/* the accumulation buffer as a device pointer (RGBA32F, width*height) for zero-copy consumers */
+int32_t pt_device_radiance(pt_context* ctx, void** devicePtr);
+
+/* --- probes used by the parity tests and bench.py (not part of the reference seam) --------------------------------- */
+/* closest-hit / any-hit queries through the same BVH + kernels the renderer uses. rays: n x 8 floats (o.xyz,tmin,d.xyz,tmax);
+ * closest out: n x 4 (t, prim bits, u, v) with prim 0xFFFFFFFF on miss; visibility out: n x u32 (1 = visible) */
+int32_t pt_trace_closest(pt_context* ctx, const float* rays, uint32_t n, float* out, double* kernelMs);
+int32_t pt_trace_visibility(pt_context* ctx, const float* rays, uint32_t n, uint32_t* out, double* kernelMs);
+/* light table / sub-instance read-back; pass NULL pointers to query sizes */
+int32_t pt_get_lights(pt_context* ctx, uint32_t* numLights, uint32_t* numProxies, void* lights32B, void* lightsEx16B, uint32_t* proxyCounters,
+                      uint32_t* proxyIndices, uint32_t* envLookup, uint32_t* envLookupDim);
+int32_t pt_get_subinstances(pt_context* ctx, uint32_t* count, void* out32B);
+int32_t pt_get_scene_info(pt_context* ctx, uint32_t* numTriangles, uint32_t* numBvhNodes, uint32_t* numInstances, uint32_t* numMaterials);
+/* device-side evaluation of leaf functions for known-answer tests (kind: see pt_probe.h values in rtxpt_amd/csrc/pt_api.hip) */
+int32_t pt_probe(pt_context* ctx, int32_t kind, const void* in, size_t inBytes, void* out, size_t outBytes, uint32_t n);
+/* BVH build/refit timing of the last geometry update, milliseconds */
+int32_t pt_get_build_stats(pt_context* ctx, double* buildMs, double* refitMs, double* lightBakeMs);
+/* enable in-kernel BVH node/triangle counters (slower); default off */
+int32_t pt_set_counters(pt_context* ctx, int32_t enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355PT_H */

@@ -1,0 +1,264 @@
+"""rtxpt_amd — host-side mirror of the reference's render-pass seam over the C-ABI of libmi355pt.so.
+
+The product is the shared library (hand-written HIP for gfx950, built in-tree by `rtxpt_amd/csrc/Makefile`); this
+package is the thin Python host binding used by the tests and bench.py: same call order as `Sample::Render`
+(/root/reference/Rtxpt/Sample.cpp:1891-2313): load/set scene -> set camera/settings -> render(sample range) -> map radiance.
+
+There is no CPU fallback: importing works anywhere, but creating a `PathTracer` without the built library or without
+a HIP device raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from . import scenes  # noqa: F401  (scene generators + data-contract dtypes)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355pt.so")
+
+PT_OK = 0
+STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3: "PT_ERROR_HIP", 4: "PT_ERROR_IO", 5: "PT_ERROR_UNSUPPORTED", 6: "PT_ERROR_NOT_READY"}
+
+# every symbol include/mi355pt.h declares
+EXPORTS = [
+    "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
+    "pt_set_environment", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
+    "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_subinstances",
+    "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
+]
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s (%d): %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class PtGeometryBuffers(ctypes.Structure):
+    _fields_ = [("indices", ctypes.c_void_p), ("numIndices", ctypes.c_uint32), ("positions", ctypes.c_void_p), ("uvs", ctypes.c_void_p),
+                ("normals", ctypes.c_void_p), ("tangents", ctypes.c_void_p), ("numVertices", ctypes.c_uint32)]
+
+
+class PtTextureDesc(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("format", ctypes.c_uint32), ("pixels", ctypes.c_void_p)]
+
+
+class PtEnvMapSceneParams(ctypes.Structure):
+    _fields_ = [("Transform", ctypes.c_float * 12), ("ColorMultiplier", ctypes.c_float * 3), ("Enabled", ctypes.c_float)]
+
+
+class PtDeviceDesc(ctypes.Structure):
+    _fields_ = [("deviceOrdinal", ctypes.c_int32), ("shardRank", ctypes.c_uint32), ("shardCount", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+
+
+class PtFrameStats(ctypes.Structure):
+    _fields_ = [("extendRays", ctypes.c_uint64), ("shadowRays", ctypes.c_uint64), ("hits", ctypes.c_uint64),
+                ("nodeVisitsExtend", ctypes.c_uint64), ("triTestsExtend", ctypes.c_uint64), ("nodeVisitsShadow", ctypes.c_uint64), ("triTestsShadow", ctypes.c_uint64),
+                ("gpuMilliseconds", ctypes.c_double), ("extendKernelMs", ctypes.c_double), ("shadeKernelMs", ctypes.c_double), ("shadowKernelMs", ctypes.c_double),
+                ("extendLaunches", ctypes.c_uint32), ("iterations", ctypes.c_uint32), ("pathsTraced", ctypes.c_uint32), ("_pad", ctypes.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "_pad"}
+
+
+def build_library(verbose=False):
+    """Compile libmi355pt.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("libmi355pt.so build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmi355pt.so. Raises if it has not been built: the product path never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmi355pt.so is missing (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C rtxpt_amd/csrc`." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.pt_get_last_error.restype = ctypes.c_char_p
+        L.pt_get_last_error.argtypes = [ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def bridge_camera(width, height, pos, direction, up, fov_y, near_z=0.01, far_z=1e5, focal_distance=10.0, aperture_radius=0.0, jitter=(0.0, 0.0)):
+    """pt_bridge_camera: the library's BridgeCamera (PathTracerShared.h:109-141). Does not need a device."""
+    L = load_library()
+    cam = np.zeros((), dtype=scenes.CAMERA_DTYPE)
+    f3 = lambda v: (ctypes.c_float * 3)(*[float(x) for x in v])
+    j = (ctypes.c_float * 2)(float(jitter[0]), float(jitter[1]))
+    r = L.pt_bridge_camera(ctypes.c_uint32(width), ctypes.c_uint32(height), f3(pos), f3(direction), f3(up), ctypes.c_float(fov_y), ctypes.c_float(near_z),
+                           ctypes.c_float(far_z), ctypes.c_float(focal_distance), ctypes.c_float(aperture_radius), j, _p(cam))
+    if r != PT_OK:
+        raise PtError(r, "pt_bridge_camera")
+    return cam
+
+
+class PathTracer:
+    """One pt_context (one GPU). Method names follow the C-ABI; the call order follows Sample::Render."""
+
+    def __init__(self, device=0, shard_rank=0, shard_count=1):
+        self.L = load_library()
+        self.h = ctypes.c_void_p()
+        desc = PtDeviceDesc(device, shard_rank, shard_count, 0)
+        r = self.L.pt_create(ctypes.byref(desc), ctypes.byref(self.h))
+        if r != PT_OK:
+            raise PtError(r, "pt_create failed (no HIP device? this library has no CPU path)")
+        self.width = self.height = 0
+        self.shard_rank, self.shard_count = shard_rank, shard_count
+        self._keep = []
+
+    def _chk(self, r, what):
+        if r != PT_OK:
+            raise PtError(r, what + ": " + (self.L.pt_get_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.L.pt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scene
+    def load_scene_gltf(self, path):
+        self._chk(self.L.pt_load_scene_gltf(self.h, path.encode()), "pt_load_scene_gltf")
+
+    def set_scene(self, sc):
+        """sc: dict from rtxpt_amd.scenes (same arrays the oracle receives)."""
+        self._keep = [sc]
+        tex = (PtTextureDesc * max(1, len(sc["textures"])))()
+        for i, (w, h, fmt, px) in enumerate(sc["textures"]):
+            tex[i] = PtTextureDesc(w, h, fmt, px.ctypes.data)
+        self._chk(self.L.pt_set_materials(self.h, _p(sc["materials"]), len(sc["materials"]), tex, len(sc["textures"])), "pt_set_materials")
+        gb = PtGeometryBuffers(sc["indices"].ctypes.data, sc["indices"].size, sc["positions"].ctypes.data, sc["uvs"].ctypes.data,
+                               sc["normals"].ctypes.data, sc["tangents"].ctypes.data, sc["positions"].shape[0])
+        self._chk(self.L.pt_set_geometry(self.h, ctypes.byref(gb), _p(sc["geometries"]), len(sc["geometries"]), _p(sc["meshes"]), len(sc["meshes"])), "pt_set_geometry")
+        self._chk(self.L.pt_set_instances(self.h, _p(sc["instances"]), len(sc["instances"])), "pt_set_instances")
+        if sc.get("env") is not None:
+            rgb, tw, cm = sc["env"]
+            p = PtEnvMapSceneParams((ctypes.c_float * 12)(*tw.tolist()), (ctypes.c_float * 3)(*cm.tolist()), 1.0)
+            self._chk(self.L.pt_set_environment(self.h, _p(rgb), rgb.shape[1], rgb.shape[0], ctypes.byref(p)), "pt_set_environment")
+        else:
+            self._chk(self.L.pt_set_environment(self.h, None, 0, 0, None), "pt_set_environment")
+        if sc.get("lights") is not None:
+            base, ex = sc["lights"]
+            self._chk(self.L.pt_set_lights(self.h, _p(base), _p(ex), len(base)), "pt_set_lights")
+
+    def animate(self, instances=None, positions=None, rebuild=False):
+        self._chk(self.L.pt_animate(self.h, _p(instances), 0 if instances is None else len(instances), _p(positions), 0 if positions is None else positions.shape[0],
+                                    1 if rebuild else 0), "pt_animate")
+
+    # ---- per-frame state
+    def set_camera(self, cam):
+        cam = np.ascontiguousarray(cam)
+        self._chk(self.L.pt_set_camera(self.h, _p(cam)), "pt_set_camera")
+
+    def default_settings(self):
+        s = np.zeros((), dtype=scenes.SETTINGS_DTYPE)
+        self._chk(self.L.pt_default_settings(_p(s)), "pt_default_settings")
+        return s
+
+    def set_settings(self, s):
+        s = np.ascontiguousarray(s)
+        self._chk(self.L.pt_set_settings(self.h, _p(s)), "pt_set_settings")
+
+    def resize(self, w, h):
+        self.width, self.height = w, h
+        self._chk(self.L.pt_resize(self.h, w, h), "pt_resize")
+
+    def reset_accumulation(self):
+        self._chk(self.L.pt_reset_accumulation(self.h), "pt_reset_accumulation")
+
+    def set_counters(self, enable):
+        self._chk(self.L.pt_set_counters(self.h, 1 if enable else 0), "pt_set_counters")
+
+    def render(self, first, count):
+        st = PtFrameStats()
+        self._chk(self.L.pt_render(self.h, first, count, ctypes.byref(st)), "pt_render")
+        return st.as_dict()
+
+    def radiance(self):
+        ptr = ctypes.POINTER(ctypes.c_float)()
+        pitch = ctypes.c_size_t()
+        self._chk(self.L.pt_map_radiance(self.h, ctypes.byref(ptr), ctypes.byref(pitch)), "pt_map_radiance")
+        img = np.ctypeslib.as_array(ptr, shape=(self.height, self.width, 4)).copy()
+        self.L.pt_unmap_radiance(self.h)
+        return img
+
+    # ---- multi-GPU shard plumbing (device pointers come from torch tensors)
+    def shard_info(self):
+        n, b = ctypes.c_uint32(), ctypes.c_size_t()
+        self._chk(self.L.pt_shard_info(self.h, ctypes.byref(n), ctypes.byref(b)), "pt_shard_info")
+        return n.value, b.value
+
+    def pack_shard(self, device_ptr, nbytes):
+        self._chk(self.L.pt_pack_shard(self.h, ctypes.c_void_p(device_ptr), ctypes.c_size_t(nbytes)), "pt_pack_shard")
+
+    def unpack_shard(self, device_ptr, nbytes, rank):
+        self._chk(self.L.pt_unpack_shard(self.h, ctypes.c_void_p(device_ptr), ctypes.c_size_t(nbytes), rank), "pt_unpack_shard")
+
+    # ---- probes
+    def trace_closest(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32)
+        out = np.zeros((rays.shape[0], 4), np.float32)
+        ms = ctypes.c_double()
+        self._chk(self.L.pt_trace_closest(self.h, _p(rays), rays.shape[0], _p(out), ctypes.byref(ms)), "pt_trace_closest")
+        return out, ms.value
+
+    def trace_visibility(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32)
+        out = np.zeros(rays.shape[0], np.uint32)
+        ms = ctypes.c_double()
+        self._chk(self.L.pt_trace_visibility(self.h, _p(rays), rays.shape[0], _p(out), ctypes.byref(ms)), "pt_trace_visibility")
+        return out, ms.value
+
+    def lights(self):
+        n, npx, dim = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._chk(self.L.pt_get_lights(self.h, ctypes.byref(n), ctypes.byref(npx), None, None, None, None, None, ctypes.byref(dim)), "pt_get_lights")
+        lights = np.zeros((n.value, 8), np.uint32)
+        ex = np.zeros((n.value, 4), np.uint32)
+        pc = np.zeros(n.value, np.uint32)
+        pi = np.zeros(npx.value, np.uint32)
+        el = np.zeros(dim.value * dim.value, np.uint32)
+        self._chk(self.L.pt_get_lights(self.h, None, None, _p(lights), _p(ex), _p(pc), _p(pi), _p(el), None), "pt_get_lights")
+        return dict(lights=lights, lightsEx=ex, proxyCounters=pc, proxyIndices=pi, envLookup=el, envLookupDim=dim.value)
+
+    def subinstances(self):
+        n = ctypes.c_uint32()
+        self._chk(self.L.pt_get_subinstances(self.h, ctypes.byref(n), None), "pt_get_subinstances")
+        out = np.zeros((n.value, 8), np.uint32)
+        self._chk(self.L.pt_get_subinstances(self.h, None, _p(out)), "pt_get_subinstances")
+        return out
+
+    def scene_info(self):
+        a, b, c, d = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._chk(self.L.pt_get_scene_info(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)), "pt_get_scene_info")
+        return dict(triangles=a.value, bvhNodes=b.value, instances=c.value, materials=d.value)
+
+    def build_stats(self):
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._chk(self.L.pt_get_build_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "pt_get_build_stats")
+        return dict(buildMs=a.value, refitMs=b.value, lightBakeMs=c.value)
+
+    def probe(self, kind, inp, out_shape, out_dtype=np.float32):
+        inp = np.ascontiguousarray(inp)
+        out = np.zeros(out_shape, out_dtype)
+        self._chk(self.L.pt_probe(self.h, kind, _p(inp), inp.nbytes, _p(out), out.nbytes, out_shape[0]), "pt_probe")
+        return out

@@ -1,0 +1,738 @@
+// mi355pt — C-ABI implementation (include/mi355pt.h): context, scene upload, BVH build/refit orchestration, light baking,
+// the wavefront frame loop and read-back. Host side of the seam `Sample` implements in the reference
+// (Rtxpt/Sample.cpp:1891-2313 Render, :2438-2559 PathTrace, :1464-1556 UpdatePathTracerConstants, :2770-2778 accumulation).
+// There is NO CPU fallback: every entry point that needs the device fails with PT_ERROR_NO_DEVICE / PT_ERROR_HIP.
+#include "../../include/mi355pt.h"
+#include "pt_wavefront.h"
+#include "pt_build.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ptk;
+
+static_assert(sizeof(::PTMaterialData) == sizeof(ptk::PTMaterialData), "material ABI");
+static_assert(sizeof(::PathTracerCameraData) == sizeof(ptk::PathTracerCameraData), "camera ABI");
+static_assert(sizeof(::PtSettings) == sizeof(ptk::PtSettings), "settings ABI");
+static_assert(sizeof(::PtGeometryDesc) == sizeof(ptk::GeometryDesc), "geometry ABI");
+static_assert(sizeof(::PtInstanceDesc) == sizeof(ptk::InstanceDesc), "instance ABI");
+static_assert(sizeof(::PolymorphicLightInfo) == sizeof(ptk::PolymorphicLightInfo), "light ABI");
+
+namespace {
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    hipError_t resize(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc(&p, sizeof(T) * (count ? count : 1));
+        if (e == hipSuccess) n = count ? count : 1;
+        return e;
+    }
+    hipError_t upload(const T* src, size_t count, hipStream_t st) {
+        hipError_t e = resize(count); if (e != hipSuccess) return e;
+        if (!count) return hipSuccess;
+        return hipMemcpyAsync(p, src, sizeof(T) * count, hipMemcpyHostToDevice, st);
+    }
+    hipError_t upload(const std::vector<T>& v, hipStream_t st) { return upload(v.data(), v.size(), st); }
+    void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct HostTexture { uint w, h, mipLevels; std::vector<std::vector<ptk::float4>> mips; };
+
+static const uint TILE = 32;
+
+} // namespace
+
+struct pt_context {
+    int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
+    std::string lastError;
+    // host copies of the scene (kept for re-bake / animation)
+    std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
+    std::vector<GeometryDesc> geometries; std::vector<MeshDesc> meshes; std::vector<InstanceDesc> instances;
+    std::vector<ptk::PTMaterialData> materials; std::vector<HostTexture> textures; HostTexture envTex; bool envEnabled = false;
+    float3x4 envToWorld, envToLocal; ptk::float3 envColorMul;
+    std::vector<PolymorphicLightInfoFull> analyticLights;
+    std::vector<SubInstanceData> subInstances; std::vector<ptk::uint2> subInstToInstGeom; std::vector<ptk::uint2> primInfo;
+    std::vector<ptk::PolymorphicLightInfo> lights; std::vector<ptk::PolymorphicLightInfoEx> lightsEx; std::vector<uint> proxyCounters, proxyIndices, envLookup; uint envLookupDim = 0;
+    // device
+    DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
+    DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
+    DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
+    DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
+    DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters;
+    std::vector<TexInfo> texInfos; TexInfo envTexInfo;
+    BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0;
+    DeviceScene dsc;
+    // frame state
+    ptk::PtSettings S; ptk::PathTracerCameraData cam; uint width = 0, height = 0, accumCount = 0; std::vector<uint> owned; std::vector<std::vector<uint>> shardPixels;
+    std::vector<float> hostRadiance; bool countersEnabled = false;
+    bool geomDirty = true, lightsDirty = true, texDirty = true;
+    double buildMs = 0, refitMs = 0, lightBakeMs = 0;
+    uint poolCapacity = 0;
+};
+
+namespace {
+
+int fail(pt_context* c, int code, const std::string& msg) { if (c) c->lastError = msg; return code; }
+#define PT_CHECK_HIP(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(c, PT_ERROR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+void build_mips(HostTexture& t) {
+    uint lv = 1; { uint m = std::max(t.w, t.h); while (m > 1) { m >>= 1; lv++; } }
+    t.mipLevels = lv; t.mips.resize(lv);
+    for (uint l = 1; l < lv; l++) {
+        uint pw = std::max(1u, t.w >> (l - 1)), ph = std::max(1u, t.h >> (l - 1));
+        uint mw = std::max(1u, t.w >> l), mh = std::max(1u, t.h >> l);
+        t.mips[l].resize((size_t)mw * mh);
+        const std::vector<ptk::float4>& p = t.mips[l - 1];
+        for (uint y = 0; y < mh; y++) for (uint x = 0; x < mw; x++) {
+            uint x0 = std::min(2 * x, pw - 1), x1 = std::min(2 * x + 1, pw - 1), y0 = std::min(2 * y, ph - 1), y1 = std::min(2 * y + 1, ph - 1);
+            ptk::float4 s = (p[(size_t)y0 * pw + x0] + p[(size_t)y0 * pw + x1]) + (p[(size_t)y1 * pw + x0] + p[(size_t)y1 * pw + x1]);
+            t.mips[l][(size_t)y * mw + x] = s * 0.25f;
+        }
+    }
+}
+float srgb_to_linear(float c) { return (c <= 0.04045f) ? c / 12.92f : dm_pow((c + 0.055f) / 1.055f, 2.4f); }
+
+uint morton2(uint x, uint y) {
+    auto part = [](uint v) { v &= 0xFFFF; v = (v | (v << 8)) & 0x00FF00FF; v = (v | (v << 4)) & 0x0F0F0F0F; v = (v | (v << 2)) & 0x33333333; v = (v | (v << 1)) & 0x55555555; return v; };
+    return part(x) | (part(y) << 1);
+}
+// pixel ownership: 32x32 tiles, tile t -> rank morton(t) % shardCount; inside a tile pixels are listed in 8x8 blocks so that the
+// 64 lanes of a wave start as an 8x8 screen block (coherent primary rays)
+void build_shards(pt_context* c) {
+    c->shardPixels.assign(c->shardCount, std::vector<uint>());
+    uint tx = (c->width + TILE - 1) / TILE, ty = (c->height + TILE - 1) / TILE;
+    std::vector<std::pair<uint, uint>> tiles;
+    for (uint y = 0; y < ty; y++) for (uint x = 0; x < tx; x++) tiles.push_back({morton2(x, y), y * tx + x});
+    std::sort(tiles.begin(), tiles.end());
+    uint order = 0;
+    for (auto& t : tiles) {
+        uint tX = t.second % tx, tY = t.second / tx;
+        std::vector<uint>& dst = c->shardPixels[order % c->shardCount];
+        order++;
+        for (uint by = 0; by < TILE; by += 8) for (uint bx = 0; bx < TILE; bx += 8)
+            for (uint y = 0; y < 8; y++) for (uint x = 0; x < 8; x++) {
+                uint px = tX * TILE + bx + x, py = tY * TILE + by + y;
+                if (px < c->width && py < c->height) dst.push_back((px << 16) | py);
+            }
+    }
+    c->owned = c->shardPixels[c->shardRank];
+}
+
+int upload_textures(pt_context* c) {
+    std::vector<ptk::float4> pool; c->texInfos.clear();
+    auto add = [&](const HostTexture& t) {
+        TexInfo ti; memset(&ti, 0, sizeof(ti)); ti.w = t.w; ti.h = t.h; ti.mipLevels = t.mipLevels; ti.base = pool.size();
+        size_t off = 0;
+        for (uint l = 0; l < t.mipLevels && l < 16; l++) { ti.mipOffset[l] = (uint)off; off += t.mips[l].size(); pool.insert(pool.end(), t.mips[l].begin(), t.mips[l].end()); }
+        return ti;
+    };
+    for (auto& t : c->textures) c->texInfos.push_back(add(t));
+    memset(&c->envTexInfo, 0, sizeof(TexInfo));
+    if (c->envEnabled) c->envTexInfo = add(c->envTex);
+    PT_CHECK_HIP(c, c->dTexels.upload(pool, c->stream));
+    PT_CHECK_HIP(c, c->dTexInfos.upload(c->texInfos, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    c->texDirty = false;
+    return PT_OK;
+}
+
+void refresh_scene_view(pt_context* c) {
+    DeviceScene& d = c->dsc;
+    d.indices = c->dIndices.p; d.positions = c->dPositions.p; d.uvs = c->dUvs.p; d.normals = c->dNormals.p; d.tangents = c->dTangents.p;
+    d.geometries = c->dGeometries.p; d.instances = c->dInstances.p; d.subInstances = c->dSubInstances.p; d.subInstToInstGeom = c->dSubInstToInstGeom.p;
+    d.materials = c->dMaterials.p; d.materialCount = (uint)c->materials.size(); d.textures = c->dTexInfos.p; d.texels = c->dTexels.p;
+    d.envTex = c->envTexInfo; d.envEnabled = c->envEnabled ? 1u : 0u; d.envToWorld = c->envToWorld; d.envToLocal = c->envToLocal; d.envColorMultiplier = c->envColorMul;
+    d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
+    d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = (uint)c->proxyIndices.size();
+    d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
+    d.nodes = c->bvh.nodes; d.tris = c->bvh.triSorted; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
+}
+
+// SubInstanceData fill (Rtxpt/Materials/MaterialsBaker.cpp:960-1017) + primitive table; then GPU LBVH build
+int finalize_geometry(pt_context* c) {
+    c->subInstances.clear(); c->subInstToInstGeom.clear(); c->primInfo.clear();
+    for (size_t i = 0; i < c->instances.size(); i++) {
+        if (c->instances[i].meshIndex >= c->meshes.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "instance references a missing mesh");
+        const MeshDesc& m = c->meshes[c->instances[i].meshIndex];
+        for (uint g = 0; g < m.numGeometries; g++) {
+            uint gi = m.firstGeometry + g;
+            if (gi >= c->geometries.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "mesh references a missing geometry");
+            const GeometryDesc& gd = c->geometries[gi];
+            if (gd.materialIndex >= c->materials.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "geometry references a missing material");
+            const ptk::PTMaterialData& mat = c->materials[gd.materialIndex];
+            SubInstanceData si; memset(&si, 0, sizeof(si));
+            bool alphaTested = (gd.geomFlags & GEOMF_ALPHA_TESTED) && (mat.Flags & PTMaterialFlags_UseBaseOrDiffuseTexture) && (gd.flags & GEOM_HAS_UV);
+            if (alphaTested) {
+                si.FlagsAndAlphaInfo |= SubInstanceData::Flags_AlphaTested;
+                uint cutoff = (uint)(saturate(mat.AlphaCutoff) * 255.0f);
+                si.FlagsAndAlphaInfo |= (cutoff & 0xFFu) << SubInstanceData::Flags_AlphaOffsetOffset;
+                si.FlagsAndAlphaInfo |= (mat.BaseOrDiffuseTextureIndex & 0xFFFFu);
+            }
+            if (gd.geomFlags & GEOMF_EXCLUDE_FROM_NEE) si.FlagsAndAlphaInfo |= SubInstanceData::Flags_ExcludeFromNEE;
+            si.GlobalGeometryIndex_PTMaterialDataIndex = (gi << 16) | (gd.materialIndex & 0xFFFFu);
+            si.EmissiveLightMappingOffset = 0xFFFFFFFFu; si.AnalyticProxyLightIndex = 0xFFFFFFFFu;
+            si.IndexOffset = gd.indexOffset; si.TexCoord1Offset = gd.vertexOffset;
+            uint subInst = (uint)c->subInstances.size();
+            c->subInstToInstGeom.push_back(ptk::make_uint2((uint)i, gi));
+            c->subInstances.push_back(si);
+            for (uint t = 0; t < gd.numIndices / 3; t++) c->primInfo.push_back(ptk::make_uint2(subInst, t));
+        }
+    }
+    c->numTris = (uint)c->primInfo.size();
+    hipStream_t st = c->stream;
+    PT_CHECK_HIP(c, c->dIndices.upload(c->indices, st)); PT_CHECK_HIP(c, c->dPositions.upload(c->positions, st)); PT_CHECK_HIP(c, c->dUvs.upload(c->uvs, st));
+    PT_CHECK_HIP(c, c->dNormals.upload(c->normals, st)); PT_CHECK_HIP(c, c->dTangents.upload(c->tangents, st));
+    PT_CHECK_HIP(c, c->dGeometries.upload(c->geometries, st)); PT_CHECK_HIP(c, c->dInstances.upload(c->instances, st));
+    PT_CHECK_HIP(c, c->dSubInstances.upload(c->subInstances, st)); PT_CHECK_HIP(c, c->dSubInstToInstGeom.upload(c->subInstToInstGeom, st));
+    PT_CHECK_HIP(c, c->dPrimInfo.upload(c->primInfo, st)); PT_CHECK_HIP(c, c->dMaterials.upload(c->materials, st));
+    if (c->bvhAllocated && c->bvh.capacity < c->numTris) { bvh_free(c->bvh); c->bvhAllocated = false; }
+    if (!c->bvhAllocated) { PT_CHECK_HIP(c, bvh_alloc(c->bvh, c->numTris)); c->bvhAllocated = true; }
+    refresh_scene_view(c);
+    hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
+    PT_CHECK_HIP(c, hipEventRecord(e0, st));
+    PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, st));
+    PT_CHECK_HIP(c, hipEventRecord(e1, st));
+    PT_CHECK_HIP(c, hipStreamSynchronize(st));
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); c->buildMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    c->geomDirty = false; c->lightsDirty = true;
+    return PT_OK;
+}
+
+// ---- light baking. Order (Rtxpt/Lighting/LightsBaker.cpp:663-827): env quads, analytic lights, emissive triangles per sub-instance.
+const uint RTXPT_LIGHTING_MAX_LIGHTS = 512 * 1024, RTXPT_LIGHTING_SAMPLING_PROXY_RATIO = 12, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT = 256 * 1024;
+const float RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD = 1e-8f;
+const uint QT_BASE_RES = 4, QT_SUBDIV = 24, QT_UNBOOSTED = QT_BASE_RES * QT_BASE_RES + 3 * QT_SUBDIV, QT_BOOST_DPT = 3, QT_BOOST_SUBDIV = 20,
+           QT_BOOST_MULT = QT_BOOST_SUBDIV * 3 + 1, QT_TOTAL = QT_UNBOOSTED * QT_BOOST_MULT, EMISB_DIM = 1024;
+struct EnvImportance { uint dim, mipCount; std::vector<std::vector<ptk::float4>> mips; };
+uint firstbithigh(uint v) { uint r = 0; while (v >>= 1) r++; return r; }
+// EnvironmentComputeWeightForQTBuild (LightsBaker.hlsl:181-198)
+uint qt_weight(const EnvImportance& im, uint dim, uint x, uint y, uint lightIndex, uint depthLimit) {
+    uint mipLevel = im.mipCount - firstbithigh(dim) - 1;
+    float areaMul = (float)(1u << (mipLevel * 2));
+    float radiance = im.mips[mipLevel][(size_t)y * dim + x].w;
+    float ret = areaMul * radiance;
+    ret = fmaxf_(sq(1.0f / 100.0f) * (float)mipLevel, ret);
+    ret *= (mipLevel > depthLimit) ? 1.0f : 0.0f;
+    uint v = (uint)(FastSqrt(ret) * 100 + 0.5f); if (v > 0x000FFFFFu) v = 0x000FFFFFu;
+    return (v << 12) | lightIndex;
+}
+struct QTNode { uint dim, x, y; };
+// EnvLightsSubdivideBase / EnvLightsSubdivideBoost (LightsBaker.hlsl:262-467): greedy split of the heaviest node
+void qt_subdivide(const EnvImportance& im, std::vector<QTNode>& nodes, std::vector<uint>& packed, uint subdivisions, uint depthLimit) {
+    for (uint si = 0; si < subdivisions; si++) {
+        uint best = 0; for (size_t i = 0; i < packed.size(); i++) best = std::max(best, packed[i]);
+        uint gi = best & 0xFFFu;
+        QTNode n = nodes[gi];
+        for (uint k = 0; k < 4; k++) {
+            QTNode ch; ch.dim = n.dim * 2; ch.x = n.x * 2 + (k % 2); ch.y = n.y * 2 + (k / 2);
+            uint ni = (k == 0) ? gi : (uint)nodes.size();
+            if (k == 0) { nodes[gi] = ch; packed[gi] = qt_weight(im, ch.dim, ch.x, ch.y, ni, depthLimit); }
+            else { nodes.push_back(ch); packed.push_back(qt_weight(im, ch.dim, ch.x, ch.y, ni, depthLimit)); }
+        }
+    }
+}
+int bake_env_quads(pt_context* c) {
+    EnvImportance im; im.dim = EMISB_DIM; im.mipCount = 11; im.mips.resize(im.mipCount);
+    PT_CHECK_HIP(c, c->dScratch4.resize((size_t)im.dim * im.dim));
+    launch_env_importance(c->dsc, im.dim, 4, 4, c->dScratch4.p, c->stream);
+    im.mips[0].resize((size_t)im.dim * im.dim);
+    PT_CHECK_HIP(c, hipMemcpyAsync(im.mips[0].data(), c->dScratch4.p, sizeof(ptk::float4) * im.mips[0].size(), hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint l = 1; l < im.mipCount; l++) {
+        uint pd = im.dim >> (l - 1), d = im.dim >> l;
+        im.mips[l].resize((size_t)d * d);
+        const std::vector<ptk::float4>& p = im.mips[l - 1];
+        for (uint y = 0; y < d; y++) for (uint x = 0; x < d; x++) {
+            ptk::float4 s = (p[(size_t)(2 * y) * pd + 2 * x] + p[(size_t)(2 * y) * pd + 2 * x + 1]) + (p[(size_t)(2 * y + 1) * pd + 2 * x] + p[(size_t)(2 * y + 1) * pd + 2 * x + 1]);
+            im.mips[l][(size_t)y * d + x] = s * 0.25f;
+        }
+    }
+    std::vector<QTNode> base; std::vector<uint> packed;
+    for (uint li = 0; li < QT_BASE_RES * QT_BASE_RES; li++) {
+        QTNode n; n.dim = QT_BASE_RES; n.x = li / QT_BASE_RES; n.y = li % QT_BASE_RES;
+        base.push_back(n); packed.push_back(qt_weight(im, n.dim, n.x, n.y, li, QT_BOOST_DPT));
+    }
+    qt_subdivide(im, base, packed, QT_SUBDIV, QT_BOOST_DPT);
+    c->envLookupDim = im.dim; c->envLookup.assign((size_t)im.dim * im.dim, 0);
+    const float distantVsLocal = 1.0f * 0.0002f;                                       // LightsBaker.cpp:1029-1030
+    for (uint g = 0; g < QT_UNBOOSTED; g++) {
+        std::vector<QTNode> nodes(1, base[g]); std::vector<uint> pk(1, qt_weight(im, base[g].dim, base[g].x, base[g].y, 0, 0));
+        qt_subdivide(im, nodes, pk, QT_BOOST_SUBDIV, 0);
+        for (uint li = 0; li < QT_BOOST_MULT; li++) {
+            EnvironmentQuadLight e; e.NodeDim = nodes[li].dim; e.NodeX = nodes[li].x; e.NodeY = nodes[li].y;
+            uint mipLevel = im.mipCount - firstbithigh(e.NodeDim) - 1;               // EnvironmentComputeRadianceAndWeight (LightsBaker.hlsl:167-175)
+            float areaMul = (float)(1u << (mipLevel * 2));
+            ptk::float4 value = im.mips[mipLevel][(size_t)e.NodeY * e.NodeDim + e.NodeX];
+            e.Weight = areaMul * fmaxf_(0.f, value.w * Average(c->envColorMul) * distantVsLocal);
+            e.Radiance = xyz(value) * c->envColorMul;
+            PolymorphicLightInfoFull lf = e.Store(0);
+            ptk::float2 sub = ptk::make_float2(((float)e.NodeX + 0.5f) / (float)e.NodeDim, ((float)e.NodeY + 0.5f) / (float)e.NodeDim);
+            lf.Base.Center = mul_vec_mat3(oct_to_ndir_equal_area_unorm(sub), c->envToWorld) * DISTANT_LIGHT_DISTANCE;
+            uint out = g * QT_BOOST_MULT + li;
+            c->lights[out] = lf.Base; c->lightsEx[out] = lf.Extended;
+            uint dimScale = im.dim / e.NodeDim;                                        // EnvLightsFillLookupMap (LightsBaker.hlsl:472-492)
+            for (uint yy = 0; yy < dimScale; yy++) for (uint xx = 0; xx < dimScale; xx++)
+                c->envLookup[(size_t)(e.NodeY * dimScale + yy) * im.dim + (e.NodeX * dimScale + xx)] = out;
+        }
+    }
+    return PT_OK;
+}
+int bake_lights(pt_context* c) {
+    hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
+    PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
+    c->lights.clear(); c->lightsEx.clear(); c->proxyCounters.clear(); c->proxyIndices.clear(); c->envLookup.clear(); c->envLookupDim = 0;
+    for (auto& si : c->subInstances) si.EmissiveLightMappingOffset = 0xFFFFFFFFu;
+    if (c->S.NEEEnabled) {
+        if (c->envEnabled) { c->lights.resize(QT_TOTAL); c->lightsEx.resize(QT_TOTAL); int r = bake_env_quads(c); if (r != PT_OK) return r; }
+        for (auto& a : c->analyticLights) { c->lights.push_back(a.Base); c->lightsEx.push_back(a.Extended); }
+        // emissive triangles: host decides the layout (LightsBaker.cpp:663-827), the GPU bakes the records (LightsBaker.hlsl:544-716)
+        std::vector<uint> list, offsets; uint total = 0; uint lightBase = (uint)c->lights.size();
+        for (size_t s = 0; s < c->subInstances.size(); s++) {
+            const GeometryDesc& g = c->geometries[c->subInstances[s].GlobalGeometryIndex_PTMaterialDataIndex >> 16];
+            const ptk::PTMaterialData& mat = c->materials[g.materialIndex];
+            bool isEmissive = any_gt0(mat.EmissiveColor);                            // PTMaterial::IsEmissive (MaterialsBaker.cpp:511-514)
+            uint ntri = g.numIndices / 3;
+            if (!isEmissive || (size_t)lightBase + total + ntri >= RTXPT_LIGHTING_MAX_LIGHTS) continue;
+            c->subInstances[s].EmissiveLightMappingOffset = lightBase + total;
+            list.push_back((uint)s); offsets.push_back(total); total += ntri;
+        }
+        c->lights.resize((size_t)lightBase + total); c->lightsEx.resize((size_t)lightBase + total);
+        PT_CHECK_HIP(c, c->dLights.resize(c->lights.size())); PT_CHECK_HIP(c, c->dLightsEx.resize(c->lightsEx.size()));
+        if (total) {
+            PT_CHECK_HIP(c, c->dEmissiveList.upload(list, c->stream)); PT_CHECK_HIP(c, c->dEmissiveOffsets.upload(offsets, c->stream));
+            launch_bake_emissive(c->dsc, c->dEmissiveList.p, c->dEmissiveOffsets.p, (uint)list.size(), total, lightBase, c->dLights.p, c->dLightsEx.p, c->stream);
+            PT_CHECK_HIP(c, hipMemcpyAsync(c->lights.data() + lightBase, c->dLights.p + lightBase, sizeof(ptk::PolymorphicLightInfo) * total, hipMemcpyDeviceToHost, c->stream));
+            PT_CHECK_HIP(c, hipMemcpyAsync(c->lightsEx.data() + lightBase, c->dLightsEx.p + lightBase, sizeof(ptk::PolymorphicLightInfoEx) * total, hipMemcpyDeviceToHost, c->stream));
+            PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        // ComputeWeights + ComputeProxyCounts (LightsBaker.hlsl:738-751, 836-948); NEEType 0 = uniform (1 proxy per light)
+        uint N = (uint)c->lights.size();
+        std::vector<float> w(N); float weightSum = 0.f;
+        for (uint i = 0; i < N; i++) {
+            PolymorphicLightInfoFull lf; lf.Base = c->lights[i]; lf.Extended = c->lightsEx[i];
+            float wt = dm_pow(PolymorphicLight_GetPower(lf), 0.8f);
+            if (!(wt >= RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD)) wt = 0;
+            w[i] = wt; weightSum += wt;
+        }
+        uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
+        c->proxyCounters.assign(N, 0);
+        for (uint i = 0; i < N; i++) {
+            uint cnt = 0;
+            if (w[i] > 0) cnt = (c->S.NEEType == 0) ? 1u : (uint)ceilf(((float)(budget - N) * w[i]) / weightSum);
+            cnt = std::min(cnt, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1);
+            c->proxyCounters[i] = cnt;
+            for (uint k = 0; k < cnt; k++) c->proxyIndices.push_back(i);
+        }
+    }
+    PT_CHECK_HIP(c, c->dLights.upload(c->lights, c->stream)); PT_CHECK_HIP(c, c->dLightsEx.upload(c->lightsEx, c->stream));
+    PT_CHECK_HIP(c, c->dProxyCounters.upload(c->proxyCounters, c->stream)); PT_CHECK_HIP(c, c->dProxyIndices.upload(c->proxyIndices, c->stream));
+    PT_CHECK_HIP(c, c->dEnvLookup.upload(c->envLookup, c->stream)); PT_CHECK_HIP(c, c->dSubInstances.upload(c->subInstances, c->stream));
+    PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); c->lightBakeMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    refresh_scene_view(c);
+    c->lightsDirty = false;
+    return PT_OK;
+}
+int prepare(pt_context* c) {
+    if (c->texDirty) { int r = upload_textures(c); if (r != PT_OK) return r; refresh_scene_view(c); c->lightsDirty = true; }
+    if (c->geomDirty) { int r = finalize_geometry(c); if (r != PT_OK) return r; }
+    if (c->lightsDirty) { int r = bake_lights(c); if (r != PT_OK) return r; }
+    return PT_OK;
+}
+int ensure_pool(pt_context* c, uint n) {
+    if (n <= c->poolCapacity) return PT_OK;
+    PT_CHECK_HIP(c, c->dS0.resize(n)); PT_CHECK_HIP(c, c->dS1.resize(n)); PT_CHECK_HIP(c, c->dS2.resize(n)); PT_CHECK_HIP(c, c->dS3.resize(n)); PT_CHECK_HIP(c, c->dS4.resize(n));
+    PT_CHECK_HIP(c, c->dHit.resize(n)); PT_CHECK_HIP(c, c->dQueue[0].resize(n)); PT_CHECK_HIP(c, c->dQueue[1].resize(n));
+    PT_CHECK_HIP(c, c->dSq0.resize(n)); PT_CHECK_HIP(c, c->dSq1.resize(n)); PT_CHECK_HIP(c, c->dSq2.resize(n));
+    c->poolCapacity = n;
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
+    if (!out) return PT_ERROR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PT_ERROR_NO_DEVICE;
+    int dev = desc ? desc->deviceOrdinal : 0;
+    if (dev < 0 || dev >= ndev) return PT_ERROR_INVALID_ARGUMENT;
+    if (hipSetDevice(dev) != hipSuccess) return PT_ERROR_HIP;
+    pt_context* c = new pt_context();
+    c->device = dev; c->shardRank = desc ? desc->shardRank : 0; c->shardCount = (desc && desc->shardCount) ? desc->shardCount : 1;
+    if (c->shardRank >= c->shardCount) { delete c; return PT_ERROR_INVALID_ARGUMENT; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
+    memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
+    pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
+    const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.f);
+    if (c->dCounters.resize(1) != hipSuccess) { delete c; return PT_ERROR_HIP; }
+    *out = c;
+    return PT_OK;
+}
+int32_t pt_destroy(pt_context* c) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream);
+    if (c->bvhAllocated) bvh_free(c->bvh);
+    c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
+    c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
+    c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
+    c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PT_OK;
+}
+const char* pt_get_last_error(pt_context* c) { return c ? c->lastError.c_str() : "null context"; }
+
+int32_t pt_set_geometry(pt_context* c, const PtGeometryBuffers* b, const PtGeometryDesc* geoms, uint32_t nGeoms, const PtMeshDesc* meshes, uint32_t nMeshes) {
+    if (!c || !b || !geoms || !meshes) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
+    if (!b->indices || !b->positions) return fail(c, PT_ERROR_INVALID_ARGUMENT, "indices and positions are required");
+    for (uint32_t g = 0; g < nGeoms; g++) {
+        if ((size_t)geoms[g].indexOffset + geoms[g].numIndices > b->numIndices || (size_t)geoms[g].vertexOffset + geoms[g].numVertices > b->numVertices || geoms[g].numIndices % 3)
+            return fail(c, PT_ERROR_INVALID_ARGUMENT, "geometry range outside the supplied streams");
+        if ((geoms[g].flags & PT_GEOM_HAS_UV) && !b->uvs) return fail(c, PT_ERROR_INVALID_ARGUMENT, "geometry has uv flag but no uv stream");
+        if ((geoms[g].flags & PT_GEOM_HAS_NORMAL) && !b->normals) return fail(c, PT_ERROR_INVALID_ARGUMENT, "geometry has normal flag but no normal stream");
+        if ((geoms[g].flags & PT_GEOM_HAS_TANGENT) && !b->tangents) return fail(c, PT_ERROR_INVALID_ARGUMENT, "geometry has tangent flag but no tangent stream");
+    }
+    uint nv = b->numVertices;
+    c->indices.assign(b->indices, b->indices + b->numIndices);
+    c->positions.assign(b->positions, b->positions + 3 * (size_t)nv);
+    c->uvs.assign(nv, ptk::make_float2(0, 0)); if (b->uvs) memcpy(c->uvs.data(), b->uvs, 8 * (size_t)nv);
+    c->normals.assign(nv, 0); if (b->normals) memcpy(c->normals.data(), b->normals, 4 * (size_t)nv);
+    c->tangents.assign(nv, 0); if (b->tangents) memcpy(c->tangents.data(), b->tangents, 4 * (size_t)nv);
+    c->geometries.resize(nGeoms); memcpy(c->geometries.data(), geoms, sizeof(GeometryDesc) * nGeoms);
+    c->meshes.resize(nMeshes); memcpy(c->meshes.data(), meshes, sizeof(MeshDesc) * nMeshes);
+    c->geomDirty = true;
+    return PT_OK;
+}
+int32_t pt_set_instances(pt_context* c, const PtInstanceDesc* inst, uint32_t n) {
+    if (!c || (!inst && n)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
+    c->instances.resize(n); if (n) memcpy(c->instances.data(), inst, sizeof(InstanceDesc) * n);
+    c->geomDirty = true;
+    return PT_OK;
+}
+int32_t pt_set_materials(pt_context* c, const ::PTMaterialData* mats, uint32_t nMats, const PtTextureDesc* tex, uint32_t nTex) {
+    if (!c || (!mats && nMats) || (!tex && nTex)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
+    c->materials.resize(nMats); if (nMats) memcpy(c->materials.data(), mats, 128 * (size_t)nMats);
+    c->textures.clear();
+    for (uint32_t i = 0; i < nTex; i++) {
+        const PtTextureDesc& d = tex[i];
+        if (!d.pixels || !d.width || !d.height || d.format > 2) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad texture descriptor");
+        HostTexture t; t.w = d.width; t.h = d.height; t.mips.resize(1); t.mips[0].resize((size_t)d.width * d.height);
+        for (size_t k = 0; k < (size_t)d.width * d.height; k++) {
+            ptk::float4 v;
+            if (d.format == PT_TEX_RGBA32F) { const float* p = (const float*)d.pixels + 4 * k; v = ptk::make_float4(p[0], p[1], p[2], p[3]); }
+            else {
+                const uint8_t* p = (const uint8_t*)d.pixels + 4 * k;
+                v = ptk::make_float4((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f);
+                if (d.format == PT_TEX_RGBA8_SRGB) { v.x = srgb_to_linear(v.x); v.y = srgb_to_linear(v.y); v.z = srgb_to_linear(v.z); }
+            }
+            t.mips[0][k] = v;
+        }
+        build_mips(t);
+        c->textures.push_back(std::move(t));
+    }
+    for (uint32_t m = 0; m < nMats; m++) {
+        const ptk::PTMaterialData& mm = c->materials[m];
+        auto chk = [&](uint flag, uint word) { return !(mm.Flags & flag) || (word & 0xFFFFu) < nTex; };
+        if (!chk(PTMaterialFlags_UseBaseOrDiffuseTexture, mm.BaseOrDiffuseTextureIndex) || !chk(PTMaterialFlags_UseEmissiveTexture, mm.EmissiveTextureIndex) ||
+            !chk(PTMaterialFlags_UseNormalTexture, mm.NormalTextureIndex) || !chk(PTMaterialFlags_UseMetalRoughOrSpecularTexture, mm.MetalRoughOrSpecularTextureIndex) ||
+            !chk(PTMaterialFlags_UseTransmissionTexture, mm.TransmissionTextureIndex))
+            return fail(c, PT_ERROR_INVALID_ARGUMENT, "material references a missing texture");
+        if (mm.Flags & PTMaterialFlags_UseSpecularGlossModel) return fail(c, PT_ERROR_UNSUPPORTED, "specular-gloss materials are not supported");
+    }
+    c->texDirty = true; c->geomDirty = true;
+    return PT_OK;
+}
+int32_t pt_set_environment(pt_context* c, const float* rgb, uint32_t w, uint32_t h, const PtEnvMapSceneParams* params) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    c->envEnabled = (w != 0 && h != 0 && rgb && (!params || params->Enabled != 0.f));
+    if (c->envEnabled) {
+        HostTexture& t = c->envTex; t.w = w; t.h = h; t.mips.clear(); t.mips.resize(1); t.mips[0].resize((size_t)w * h);
+        for (size_t i = 0; i < (size_t)w * h; i++) t.mips[0][i] = ptk::make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.f);
+        build_mips(t);
+    }
+    if (params) {
+        memcpy(c->envToWorld.m, params->Transform, 48);
+        memset(&c->envToLocal, 0, sizeof(float3x4));
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) c->envToLocal.m[r * 4 + k] = c->envToWorld.m[k * 4 + r];   // rotation inverse = transpose
+        c->envColorMul = ptk::make_float3(params->ColorMultiplier[0], params->ColorMultiplier[1], params->ColorMultiplier[2]);
+    }
+    c->texDirty = true; c->lightsDirty = true;
+    return PT_OK;
+}
+int32_t pt_set_lights(pt_context* c, const ::PolymorphicLightInfo* lights, const ::PolymorphicLightInfoEx* ex, uint32_t n) {
+    if (!c || (!lights && n)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
+    c->analyticLights.clear();
+    for (uint32_t i = 0; i < n; i++) {
+        PolymorphicLightInfoFull f; memcpy(&f.Base, &lights[i], 32);
+        if (ex) memcpy(&f.Extended, &ex[i], 16); else memset(&f.Extended, 0, 16);
+        uint type = DecodeLightType(f.Base);
+        if (type != kSphere) return fail(c, PT_ERROR_UNSUPPORTED, "only sphere analytic lights are enabled (PolymorphicLightPTConfig.h:17-22)");
+        c->analyticLights.push_back(f);
+    }
+    c->lightsDirty = true;
+    return PT_OK;
+}
+
+int32_t pt_bridge_camera(uint32_t w, uint32_t h, const float pos[3], const float dir[3], const float up[3], float fovY, float nearZ, float farZ, float focalDistance,
+                         float apertureRadius, const float jitter[2], ::PathTracerCameraData* out) {
+    if (!out || !pos || !dir || !up || !w || !h) return PT_ERROR_INVALID_ARGUMENT;
+    // PathTracerShared.h:109-141 (donut::math normalize = v / length(v))
+    auto nrm = [](ptk::float3 v) { float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); return ptk::make_float3(v.x / l, v.y / l, v.z / l); };
+    ptk::PathTracerCameraData d; memset(&d, 0, sizeof(d));
+    float aspect = (float)w / (float)h;
+    d.FocalDistance = focalDistance; d.PosW = ptk::make_float3(pos[0], pos[1], pos[2]); d.NearZ = nearZ; d.FarZ = farZ; d.AspectRatio = aspect;
+    d.ViewportSize = ptk::make_uint2(w, h);
+    ptk::float3 camDir = ptk::make_float3(dir[0], dir[1], dir[2]), camUp = ptk::make_float3(up[0], up[1], up[2]);
+    d.DirectionW = nrm(camDir);
+    d.CameraW = nrm(camDir) * d.FocalDistance;
+    d.CameraU = nrm(cross(d.CameraW, camUp));
+    d.CameraV = nrm(cross(d.CameraU, d.CameraW));
+    const float ulen = d.FocalDistance * std::tan(fovY * 0.5f) * d.AspectRatio;
+    d.CameraU = d.CameraU * ulen;
+    const float vlen = d.FocalDistance * std::tan(fovY * 0.5f);
+    d.CameraV = d.CameraV * vlen;
+    d.ApertureRadius = apertureRadius;
+    d.PixelConeSpreadAngle = std::atan(2.0f * std::tan(fovY * 0.5f) / (float)h);
+    d.Jitter = ptk::make_float2(jitter ? jitter[0] : 0.f, jitter ? -jitter[1] : 0.f);
+    memcpy(out, &d, sizeof(d));
+    return PT_OK;
+}
+int32_t pt_set_camera(pt_context* c, const ::PathTracerCameraData* cam) {
+    if (!c || !cam) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
+    memcpy(&c->cam, cam, sizeof(c->cam));
+    return PT_OK;
+}
+int32_t pt_default_settings(::PtSettings* s) {
+    if (!s) return PT_ERROR_INVALID_ARGUMENT;
+    memset(s, 0, sizeof(*s));
+    s->bounceCount = 8; s->diffuseBounceCount = 8; s->perPixelJitterAAScale = 1.0f; s->texLODBias = -1.0f; s->fireflyFilterThreshold = 0.f; s->envMapDiffuseSampleMIPLevel = 0.f;
+    s->NEEEnabled = 1; s->NEEType = 1; s->NEECandidateSamples = 5; s->NEEFullSamples = 1; s->enableRussianRoulette = 1; s->nestedDielectricsQuality = 1;
+    s->enableLDSamplerForBSDF = 1; s->diffuseBrdf = 2;
+    return PT_OK;
+}
+int32_t pt_set_settings(pt_context* c, const ::PtSettings* s) {
+    if (!c || !s) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
+    if (s->NEEEnabled && s->NEEFullSamples != 1) return fail(c, PT_ERROR_UNSUPPORTED, "NEEFullSamples must be 1 (one shadow-queue entry per path vertex)");
+    if (s->NEEType > 1) return fail(c, PT_ERROR_UNSUPPORTED, "NEEType 2 (NEE-AT temporal feedback) is out of scope; use 0 (uniform) or 1 (power)");
+    if (s->NEECandidateSamples == 0 || s->NEECandidateSamples > 63) return fail(c, PT_ERROR_INVALID_ARGUMENT, "NEECandidateSamples must be in [1,63]");
+    if (s->nestedDielectricsQuality > 2 || (s->diffuseBrdf != 0 && s->diffuseBrdf != 2) || s->bounceCount > 96) return fail(c, PT_ERROR_INVALID_ARGUMENT, "setting out of range");
+    if (c->S.NEEEnabled != s->NEEEnabled || c->S.NEEType != s->NEEType) c->lightsDirty = true;
+    memcpy(&c->S, s, sizeof(c->S));
+    return PT_OK;
+}
+int32_t pt_resize(pt_context* c, uint32_t w, uint32_t h) {
+    if (!c || !w || !h || w > 65535 || h > 65535) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad size");
+    (void)hipSetDevice(c->device);
+    c->width = w; c->height = h; c->accumCount = 0;
+    build_shards(c);
+    PT_CHECK_HIP(c, c->dAccum.resize((size_t)w * h));
+    PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)w * h, c->stream));
+    PT_CHECK_HIP(c, c->dOwned.upload(c->owned, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+int32_t pt_reset_accumulation(pt_context* c) {
+    if (!c || !c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    (void)hipSetDevice(c->device);
+    c->accumCount = 0;
+    PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)c->width * c->height, c->stream));
+    return PT_OK;
+}
+int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts, int32_t rebuild) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (c->geomDirty || c->texDirty) { int r = prepare(c); if (r != PT_OK) return r; }
+    if (inst) {
+        if (nInst != c->instances.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: instance count must not change");
+        for (uint32_t i = 0; i < nInst; i++) if (inst[i].meshIndex != c->instances[i].meshIndex) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: topology must not change");
+        memcpy(c->instances.data(), inst, sizeof(InstanceDesc) * nInst);
+        PT_CHECK_HIP(c, c->dInstances.upload(c->instances, c->stream));
+    }
+    if (positions) {
+        if ((size_t)nVerts * 3 != c->positions.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: vertex count must not change");
+        memcpy(c->positions.data(), positions, 12 * (size_t)nVerts);
+        PT_CHECK_HIP(c, c->dPositions.upload(c->positions, c->stream));
+    }
+    refresh_scene_view(c);
+    hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
+    PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
+    if (rebuild) PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, c->stream)); else PT_CHECK_HIP(c, bvh_refit(c->bvh, c->dsc, c->numTris, c->stream));
+    PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); if (rebuild) c->buildMs = ms; else c->refitMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    c->lightsDirty = true;                    // emissive triangle lights move with the geometry (Sample.cpp:1170-1198)
+    c->accumCount = 0;                        // any scene change resets accumulation in reference mode
+    PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)c->width * c->height, c->stream));
+    return bake_lights(c);
+}
+
+int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* stats) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    if (!count) return PT_OK;
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    uint numOwned = (uint)c->owned.size();
+    if ((unsigned long long)numOwned * count > 0xF0000000ull) return fail(c, PT_ERROR_INVALID_ARGUMENT, "too many paths in one pt_render call");
+    uint total = numOwned * count;
+    hipStream_t st = c->stream;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (total == 0) { c->accumCount += count; return PT_OK; }
+    r = ensure_pool(c, total); if (r != PT_OK) return r;
+    PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
+    PathPool pool = {c->dS0.p, c->dS1.p, c->dS2.p, c->dS3.p, c->dS4.p, c->dHit.p};
+    ShadowQueue sq = {c->dSq0.p, c->dSq1.p, c->dSq2.p};
+    WaveCounters* wc = c->dCounters.p;
+    WaveCounters hwc; memset(&hwc, 0, sizeof(hwc)); hwc.extendCount[0] = total;
+    std::vector<hipEvent_t> ev; auto mark = [&]() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; };
+    struct Span { size_t a, b; int kind; }; std::vector<Span> spans;
+    size_t t0 = mark();
+    PT_CHECK_HIP(c, hipMemcpyAsync(wc, &hwc, sizeof(hwc), hipMemcpyHostToDevice, st));
+    launch_generate(k, pool, c->dOwned.p, numOwned, first, count, c->dQueue[0].p, st);
+    uint cur = 0, active = total, iterations = 0; unsigned long long extendRays = 0, shadowRays = 0;
+    // upper bound on extend passes: bounceCount+1 vertices plus rejected (nested dielectric) re-traces
+    uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u));
+    while (active && iterations < maxIter) {
+        uint nxt = cur ^ 1u;
+        uint zero2[2] = {0u, 0u};
+        PT_CHECK_HIP(c, hipMemcpyAsync(&wc->extendCount[nxt], &zero2[0], 4, hipMemcpyHostToDevice, st));
+        PT_CHECK_HIP(c, hipMemcpyAsync(&wc->shadowCount, &zero2[1], 4, hipMemcpyHostToDevice, st));
+        size_t a = mark(); launch_extend(c->dsc, pool, c->dQueue[cur].p, &wc->extendCount[cur], active, wc, c->countersEnabled, st); size_t b = mark(); spans.push_back({a, b, 0});
+        launch_shade(k, pool, c->dQueue[cur].p, &wc->extendCount[cur], active, c->dQueue[nxt].p, &wc->extendCount[nxt], sq, wc, st); size_t d = mark(); spans.push_back({b, d, 1});
+        extendRays += active;
+        PT_CHECK_HIP(c, hipMemcpyAsync(&hwc, wc, 16, hipMemcpyDeviceToHost, st));
+        PT_CHECK_HIP(c, hipStreamSynchronize(st));
+        uint nShadow = hwc.shadowCount;
+        if (nShadow) { size_t e = mark(); launch_shadow(c->dsc, pool, sq, &wc->shadowCount, nShadow, wc, c->countersEnabled, st); size_t f = mark(); spans.push_back({e, f, 2}); shadowRays += nShadow; }
+        active = hwc.extendCount[nxt]; cur = nxt; iterations++;
+    }
+    launch_accumulate(pool, c->dOwned.p, numOwned, count, c->dAccum.p, c->accumCount, c->width, st);
+    size_t t1 = mark();
+    PT_CHECK_HIP(c, hipMemcpyAsync(&hwc, wc, sizeof(hwc), hipMemcpyDeviceToHost, st));
+    PT_CHECK_HIP(c, hipStreamSynchronize(st));
+    PT_CHECK_HIP(c, hipGetLastError());
+    c->accumCount += count;
+    if (stats) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, ev[t0], ev[t1]); stats->gpuMilliseconds = ms;
+        for (auto& s : spans) { float m = 0; (void)hipEventElapsedTime(&m, ev[s.a], ev[s.b]); if (s.kind == 0) { stats->extendKernelMs += m; stats->extendLaunches++; } else if (s.kind == 1) stats->shadeKernelMs += m; else stats->shadowKernelMs += m; }
+        stats->extendRays = extendRays; stats->shadowRays = shadowRays; stats->hits = hwc.hits; stats->nodeVisitsExtend = hwc.nodeVisitsExt; stats->triTestsExtend = hwc.triTestsExt;
+        stats->nodeVisitsShadow = hwc.nodeVisitsSh; stats->triTestsShadow = hwc.triTestsSh; stats->iterations = iterations; stats->pathsTraced = total;
+    }
+    for (auto e : ev) (void)hipEventDestroy(e);
+    return PT_OK;
+}
+
+int32_t pt_map_radiance(pt_context* c, const float** rgba, size_t* pitch) {
+    if (!c || !rgba) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    (void)hipSetDevice(c->device);
+    c->hostRadiance.resize((size_t)c->width * c->height * 4);
+    PT_CHECK_HIP(c, hipMemcpyAsync(c->hostRadiance.data(), c->dAccum.p, sizeof(float) * c->hostRadiance.size(), hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    *rgba = c->hostRadiance.data(); if (pitch) *pitch = (size_t)c->width * 16;
+    return PT_OK;
+}
+int32_t pt_unmap_radiance(pt_context* c) { return c ? PT_OK : PT_ERROR_INVALID_ARGUMENT; }
+
+int32_t pt_shard_info(pt_context* c, uint32_t* numOwned, size_t* bytes) {
+    if (!c || !c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    if (numOwned) *numOwned = (uint32_t)c->owned.size(); if (bytes) *bytes = c->owned.size() * 16;
+    return PT_OK;
+}
+int32_t pt_pack_shard(pt_context* c, void* dst, size_t bytes) {
+    if (!c || !dst || !c->width) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad argument");
+    if (bytes < c->owned.size() * 16) return fail(c, PT_ERROR_INVALID_ARGUMENT, "destination too small");
+    (void)hipSetDevice(c->device);
+    launch_pack(c->dAccum.p, c->dOwned.p, (uint)c->owned.size(), c->width, (ptk::float4*)dst, c->stream);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+int32_t pt_unpack_shard(pt_context* c, const void* src, size_t bytes, uint32_t rank) {
+    if (!c || !src || !c->width || rank >= c->shardCount) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad argument");
+    const std::vector<uint>& px = c->shardPixels[rank];
+    if (bytes < px.size() * 16) return fail(c, PT_ERROR_INVALID_ARGUMENT, "source too small");
+    (void)hipSetDevice(c->device);
+    DevBuf<uint> tmp; PT_CHECK_HIP(c, tmp.upload(px, c->stream));
+    launch_unpack(c->dAccum.p, tmp.p, (uint)px.size(), c->width, (const ptk::float4*)src, c->stream);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    tmp.free();
+    return PT_OK;
+}
+int32_t pt_device_radiance(pt_context* c, void** p) { if (!c || !p || !c->width) return PT_ERROR_INVALID_ARGUMENT; *p = c->dAccum.p; return PT_OK; }
+
+static int trace_probe(pt_context* c, const float* rays, uint32_t n, float* outClosest, uint32_t* outVisible, double* kernelMs) {
+    if (!c || !rays || !n) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad argument");
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    DevBuf<ptk::float4> dr, dc; DevBuf<uint> dv;
+    PT_CHECK_HIP(c, dr.upload((const ptk::float4*)rays, 2 * (size_t)n, c->stream));
+    if (outClosest) PT_CHECK_HIP(c, dc.resize(n)); else PT_CHECK_HIP(c, dv.resize(n));
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, c->stream);
+    launch_trace_probe(c->dsc, dr.p, n, outClosest ? dc.p : nullptr, outClosest ? nullptr : dv.p, c->stream);
+    (void)hipEventRecord(e1, c->stream);
+    if (outClosest) PT_CHECK_HIP(c, hipMemcpyAsync(outClosest, dc.p, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    else PT_CHECK_HIP(c, hipMemcpyAsync(outVisible, dv.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); if (kernelMs) *kernelMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    dr.free(); dc.free(); dv.free();
+    return PT_OK;
+}
+int32_t pt_trace_closest(pt_context* c, const float* rays, uint32_t n, float* out, double* ms) { if (!out) return PT_ERROR_INVALID_ARGUMENT; return trace_probe(c, rays, n, out, nullptr, ms); }
+int32_t pt_trace_visibility(pt_context* c, const float* rays, uint32_t n, uint32_t* out, double* ms) { if (!out) return PT_ERROR_INVALID_ARGUMENT; return trace_probe(c, rays, n, nullptr, out, ms); }
+
+int32_t pt_get_lights(pt_context* c, uint32_t* nLights, uint32_t* nProxies, void* lights, void* lightsEx, uint32_t* pc, uint32_t* pi, uint32_t* envLookup, uint32_t* envDim) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    if (nLights) *nLights = (uint32_t)c->lights.size(); if (nProxies) *nProxies = (uint32_t)c->proxyIndices.size(); if (envDim) *envDim = c->envLookupDim;
+    // read back from the DEVICE copies: this is what the kernels sample from
+    if (lights && c->lights.size()) PT_CHECK_HIP(c, hipMemcpy(lights, c->dLights.p, 32 * c->lights.size(), hipMemcpyDeviceToHost));
+    if (lightsEx && c->lights.size()) PT_CHECK_HIP(c, hipMemcpy(lightsEx, c->dLightsEx.p, 16 * c->lights.size(), hipMemcpyDeviceToHost));
+    if (pc && c->lights.size()) PT_CHECK_HIP(c, hipMemcpy(pc, c->dProxyCounters.p, 4 * c->lights.size(), hipMemcpyDeviceToHost));
+    if (pi && c->proxyIndices.size()) PT_CHECK_HIP(c, hipMemcpy(pi, c->dProxyIndices.p, 4 * c->proxyIndices.size(), hipMemcpyDeviceToHost));
+    if (envLookup && c->envLookup.size()) PT_CHECK_HIP(c, hipMemcpy(envLookup, c->dEnvLookup.p, 4 * c->envLookup.size(), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+int32_t pt_get_subinstances(pt_context* c, uint32_t* count, void* out) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    if (count) *count = (uint32_t)c->subInstances.size();
+    if (out && c->subInstances.size()) PT_CHECK_HIP(c, hipMemcpy(out, c->dSubInstances.p, 32 * c->subInstances.size(), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+int32_t pt_get_scene_info(pt_context* c, uint32_t* nTris, uint32_t* nNodes, uint32_t* nInst, uint32_t* nMat) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    if (nTris) *nTris = c->numTris; if (nNodes) *nNodes = c->numTris ? c->numTris - 1 : 0; if (nInst) *nInst = (uint32_t)c->instances.size(); if (nMat) *nMat = (uint32_t)c->materials.size();
+    return PT_OK;
+}
+int32_t pt_probe(pt_context* c, int32_t kind, const void* in, size_t inBytes, void* out, size_t outBytes, uint32_t n) {
+    if (!c || !in || !out || !n) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad argument");
+    (void)hipSetDevice(c->device);
+    DevBuf<unsigned char> di, dout;
+    PT_CHECK_HIP(c, di.upload((const unsigned char*)in, inBytes, c->stream)); PT_CHECK_HIP(c, dout.resize(outBytes));
+    PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
+    launch_probe(k, kind, di.p, dout.p, n, c->stream);
+    PT_CHECK_HIP(c, hipMemcpyAsync(out, dout.p, outBytes, hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    PT_CHECK_HIP(c, hipGetLastError());
+    di.free(); dout.free();
+    return PT_OK;
+}
+int32_t pt_get_build_stats(pt_context* c, double* b, double* r, double* l) { if (!c) return PT_ERROR_INVALID_ARGUMENT; if (b) *b = c->buildMs; if (r) *r = c->refitMs; if (l) *l = c->lightBakeMs; return PT_OK; }
+int32_t pt_set_counters(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->countersEnabled = enable != 0; return PT_OK; }
+
+} // extern "C"

@@ -1,0 +1,37 @@
+// mi355pt — GPU LBVH build / refit (replaces the driver's BLAS/TLAS build: Rtxpt/Sample.cpp:1061-1079, 1170-1240).
+//
+//   k_tri_setup     one thread per triangle: instance transform -> world-space TriRecord + scene bounds (wave-reduced atomics)
+//   k_morton        63-bit Morton code of the centroid (21 bits / axis)
+//   rocprim sort    (code, primitive) pairs — library radix sort, build step only
+//   k_karras        Karras 2012 hierarchy over the sorted codes (duplicate codes split on the index bits)
+//   k_bounds        bottom-up AABB propagation, one atomic ticket per inner node (agent-scope fences: inner nodes are
+//                   finished by whichever workgroup arrives second, possibly on another XCD)
+//   k_emit          collapse sub-trees of <= 4 triangles into leaves and write the traversal nodes (both child boxes per node)
+// Refit (animated instances / deformed vertices, same topology) re-runs k_tri_setup, k_bounds, k_emit only.
+#pragma once
+#include "pt_scene.h"
+#include <hip/hip_runtime.h>
+
+namespace ptk {
+
+struct BvhBuildBuffers {
+    TriRecord* triWorld;        // by global primitive id
+    TriRecord* triSorted;       // leaf order
+    unsigned long long* keys; unsigned long long* keysSorted;
+    uint* prims; uint* primsSorted;
+    uint* childL; uint* childR; uint* parent; uint* leafParent; uint* rangeFirst; uint* rangeLast;
+    uint* tickets;
+    float4* boxLmin; float4* boxLmax; float4* boxRmin; float4* boxRmax;
+    uint* sceneBounds;          // 6 ordered-uint encoded floats (min xyz, max xyz)
+    BvhNode* nodes;
+    void* sortTemp; size_t sortTempBytes;
+    uint capacity;
+};
+
+hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris);
+void bvh_free(BvhBuildBuffers& b);
+// full build: fills b.triSorted / b.nodes; scene must already reference primInfo/instances/geometries/streams
+hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint numTris, hipStream_t stream);
+hipError_t bvh_refit(BvhBuildBuffers& b, const DeviceScene& sc, uint numTris, hipStream_t stream);
+
+} // namespace ptk

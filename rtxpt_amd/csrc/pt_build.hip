@@ -1,0 +1,227 @@
+// mi355pt — GPU LBVH build / refit kernels. See pt_build.h for the pipeline.
+#include "pt_build.h"
+#include <rocprim/rocprim.hpp>
+
+namespace ptk {
+
+#define PT_HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+__device__ __forceinline__ uint enc_float(float f) { uint b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float dec_float(uint u) { uint b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; return __uint_as_float(b); }
+
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+
+__global__ void __launch_bounds__(256) k_tri_setup(DeviceScene sc, uint numTris, TriRecord* __restrict__ triWorld, uint* __restrict__ sceneBounds) {
+    uint p = blockIdx.x * 256u + threadIdx.x;
+    float3 mn = make_float3(3.0e38f), mx = make_float3(-3.0e38f);
+    if (p < numTris) {
+        uint2 pi = sc.primInfo[p];
+        uint2 ig = sc.subInstToInstGeom[pi.x];
+        const InstanceDesc& inst = sc.instances[ig.x];
+        const GeometryDesc& g = sc.geometries[ig.y];
+        const SubInstanceData& si = sc.subInstances[pi.x];
+        const uint* idx = sc.indices + g.indexOffset + 3u * pi.y;
+        const float* P = sc.positions;
+        uint i0 = g.vertexOffset + idx[0], i1 = g.vertexOffset + idx[1], i2 = g.vertexOffset + idx[2];
+        float3 p0 = xform_point(inst.transform, make_float3(P[3 * i0], P[3 * i0 + 1], P[3 * i0 + 2]));
+        float3 p1 = xform_point(inst.transform, make_float3(P[3 * i1], P[3 * i1 + 1], P[3 * i1 + 2]));
+        float3 p2 = xform_point(inst.transform, make_float3(P[3 * i2], P[3 * i2 + 1], P[3 * i2 + 2]));
+        bool alphaTested = (si.FlagsAndAlphaInfo & SubInstanceData::Flags_AlphaTested) != 0;
+        bool excl = (si.FlagsAndAlphaInfo & SubInstanceData::Flags_ExcludeFromNEE) != 0;
+        TriRecord tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.prim = p; tr.flags = (alphaTested ? 1u : 0u) | (excl ? 3u : 0u); tr._pad = 0;
+        triWorld[p] = tr;
+        // bounds from the SAME vertices traversal reconstructs (v0, v0+e1, v0+e2)
+        float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
+        mn = min3v(p0, min3v(q1, q2)); mx = max3v(p0, max3v(q1, q2));
+    }
+    float a = wave_min(mn.x), b = wave_min(mn.y), c = wave_min(mn.z), d = wave_max(mx.x), e = wave_max(mx.y), f = wave_max(mx.z);
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicMin(&sceneBounds[0], enc_float(a)); atomicMin(&sceneBounds[1], enc_float(b)); atomicMin(&sceneBounds[2], enc_float(c));
+        atomicMax(&sceneBounds[3], enc_float(d)); atomicMax(&sceneBounds[4], enc_float(e)); atomicMax(&sceneBounds[5], enc_float(f));
+    }
+}
+
+__device__ __forceinline__ unsigned long long expand21(uint v) {
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void __launch_bounds__(256) k_morton(const TriRecord* __restrict__ triWorld, uint numTris, const uint* __restrict__ sceneBounds,
+                                                unsigned long long* __restrict__ keys, uint* __restrict__ prims) {
+    uint p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= numTris) return;
+    float3 mn = make_float3(dec_float(sceneBounds[0]), dec_float(sceneBounds[1]), dec_float(sceneBounds[2]));
+    float3 mx = make_float3(dec_float(sceneBounds[3]), dec_float(sceneBounds[4]), dec_float(sceneBounds[5]));
+    float3 ext = mx - mn;
+    TriRecord tr = triWorld[p];
+    float3 c = tr.v0 + (tr.e1 + tr.e2) * (1.0f / 3.0f);
+    float sx = ext.x > 0.f ? (c.x - mn.x) / ext.x : 0.f, sy = ext.y > 0.f ? (c.y - mn.y) / ext.y : 0.f, sz = ext.z > 0.f ? (c.z - mn.z) / ext.z : 0.f;
+    uint qx = (uint)fminf(fmaxf(sx * 2097152.0f, 0.0f), 2097151.0f), qy = (uint)fminf(fmaxf(sy * 2097152.0f, 0.0f), 2097151.0f), qz = (uint)fminf(fmaxf(sz * 2097152.0f, 0.0f), 2097151.0f);
+    keys[p] = (expand21(qx) << 2) | (expand21(qy) << 1) | expand21(qz);
+    prims[p] = p;
+}
+
+__device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    unsigned long long ki = keys[i], kj = keys[j];
+    if (ki == kj) return 64 + __clz((uint)i ^ (uint)j);
+    return __clzll((long long)(ki ^ kj));
+}
+// Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012
+__global__ void __launch_bounds__(256) k_karras(const unsigned long long* __restrict__ keys, int n, uint* __restrict__ childL, uint* __restrict__ childR,
+                                                uint* __restrict__ parent, uint* __restrict__ leafParent, uint* __restrict__ rangeFirst, uint* __restrict__ rangeLast) {
+    int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= n - 1) return;
+    int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int deltaMin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > deltaMin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2) if (delta(keys, n, i, i + (l + t) * d) > deltaMin) l += t;
+    int j = i + l * d;
+    int deltaNode = delta(keys, n, i, j);
+    int s = 0;
+    int div = 2; int t = (l + div - 1) / div;
+    while (true) {
+        if (delta(keys, n, i, i + (s + t) * d) > deltaNode) s += t;
+        if (t == 1) break;
+        div *= 2; t = (l + div - 1) / div;
+    }
+    int gamma = i + s * d + (d < 0 ? d : 0);
+    int lo = i < j ? i : j, hi = i < j ? j : i;
+    uint left = (lo == gamma) ? ((uint)gamma | BVH_LEAF_BIT) : (uint)gamma;
+    uint right = (hi == gamma + 1) ? ((uint)(gamma + 1) | BVH_LEAF_BIT) : (uint)(gamma + 1);
+    childL[i] = left; childR[i] = right; rangeFirst[i] = (uint)lo; rangeLast[i] = (uint)hi;
+    if (left & BVH_LEAF_BIT) leafParent[gamma] = (uint)i; else parent[gamma] = (uint)i;
+    if (right & BVH_LEAF_BIT) leafParent[gamma + 1] = (uint)i; else parent[gamma + 1] = (uint)i;
+    if (i == 0) parent[0] = 0xFFFFFFFFu;
+}
+
+__global__ void __launch_bounds__(256) k_bounds(const TriRecord* __restrict__ triWorld, const uint* __restrict__ primsSorted, uint n, TriRecord* __restrict__ triSorted,
+                                                const uint* __restrict__ childL, const uint* __restrict__ parent, const uint* __restrict__ leafParent, uint* __restrict__ tickets,
+                                                float4* boxLmin, float4* boxLmax, float4* boxRmin, float4* boxRmax) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    TriRecord tr = triWorld[primsSorted[i]];
+    triSorted[i] = tr;
+    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
+    float3 mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+    if (n == 1) { boxLmin[0] = make_float4(mn.x, mn.y, mn.z, 0.f); boxLmax[0] = make_float4(mx.x, mx.y, mx.z, 0.f); return; }
+    uint childRef = i | BVH_LEAF_BIT;
+    uint node = leafParent[i];
+    while (true) {
+        bool isLeft = (childL[node] == childRef);
+        if (isLeft) { boxLmin[node] = make_float4(mn.x, mn.y, mn.z, 0.f); boxLmax[node] = make_float4(mx.x, mx.y, mx.z, 0.f); }
+        else        { boxRmin[node] = make_float4(mn.x, mn.y, mn.z, 0.f); boxRmax[node] = make_float4(mx.x, mx.y, mx.z, 0.f); }
+        __threadfence();                                   // release my box before taking the ticket
+        uint old = atomicAdd(&tickets[node], 1u);
+        if (old == 0u) return;                             // first arrival: the sibling finishes this node
+        __threadfence();                                   // acquire the sibling's box
+        float4 omn = isLeft ? boxRmin[node] : boxLmin[node];
+        float4 omx = isLeft ? boxRmax[node] : boxLmax[node];
+        mn = min3v(mn, make_float3(omn.x, omn.y, omn.z)); mx = max3v(mx, make_float3(omx.x, omx.y, omx.z));
+        if (node == 0u) return;
+        childRef = node;
+        node = parent[node];
+    }
+}
+
+__device__ __forceinline__ void pad_box(float3& mn, float3& mx, float scenePad) {
+    float3 e = mx - mn;
+    float pad = 2e-5f * fmaxf(e.x, fmaxf(e.y, e.z)) + scenePad;
+    mn = mn - make_float3(pad); mx = mx + make_float3(pad);
+}
+__global__ void __launch_bounds__(256) k_emit(uint n, const uint* __restrict__ childL, const uint* __restrict__ childR, const uint* __restrict__ rangeFirst,
+                                              const uint* __restrict__ rangeLast, const float4* __restrict__ boxLmin, const float4* __restrict__ boxLmax,
+                                              const float4* __restrict__ boxRmin, const float4* __restrict__ boxRmax, const uint* __restrict__ sceneBounds, BvhNode* __restrict__ nodes) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    float3 smn = make_float3(dec_float(sceneBounds[0]), dec_float(sceneBounds[1]), dec_float(sceneBounds[2]));
+    float3 smx = make_float3(dec_float(sceneBounds[3]), dec_float(sceneBounds[4]), dec_float(sceneBounds[5]));
+    float scenePad = 1e-7f * length(smx - smn);
+    if (n == 1) {
+        if (i == 0) {
+            BvhNode nd; float4 a = boxLmin[0], b = boxLmax[0];
+            nd.lmin = make_float3(a.x, a.y, a.z); nd.lmax = make_float3(b.x, b.y, b.z); pad_box(nd.lmin, nd.lmax, scenePad);
+            nd.rmin = nd.lmin; nd.rmax = nd.lmax; nd.left = BVH_LEAF_BIT | 0u; nd.right = BVH_EMPTY; nd._pad0 = nd._pad1 = 0;
+            nodes[0] = nd;
+        }
+        return;
+    }
+    if (i >= n - 1) return;
+    uint cnt = rangeLast[i] - rangeFirst[i] + 1u;
+    if (i != 0u && cnt <= BVH_MAX_LEAF) return;            // collapsed into its parent's leaf reference
+    uint refs[2] = {childL[i], childR[i]};
+    uint outRef[2];
+    for (int k = 0; k < 2; k++) {
+        uint r = refs[k];
+        if (r & BVH_LEAF_BIT) outRef[k] = BVH_LEAF_BIT | ((r & 0x7FFFFFFFu) << 3) | 0u;
+        else {
+            uint c = rangeLast[r] - rangeFirst[r] + 1u;
+            outRef[k] = (c <= BVH_MAX_LEAF) ? (BVH_LEAF_BIT | (rangeFirst[r] << 3) | (c - 1u)) : r;
+        }
+    }
+    BvhNode nd; float4 a = boxLmin[i], b = boxLmax[i], c = boxRmin[i], d = boxRmax[i];
+    nd.lmin = make_float3(a.x, a.y, a.z); nd.lmax = make_float3(b.x, b.y, b.z); nd.rmin = make_float3(c.x, c.y, c.z); nd.rmax = make_float3(d.x, d.y, d.z);
+    pad_box(nd.lmin, nd.lmax, scenePad); pad_box(nd.rmin, nd.rmax, scenePad);
+    nd.left = outRef[0]; nd.right = outRef[1]; nd._pad0 = nd._pad1 = 0;
+    nodes[i] = nd;
+}
+__global__ void k_init_bounds(uint* sceneBounds) {
+    if (threadIdx.x < 3) sceneBounds[threadIdx.x] = 0xFFFFFFFFu; else if (threadIdx.x < 6) sceneBounds[threadIdx.x] = 0u;
+}
+
+hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
+    __builtin_memset(&b, 0, sizeof(b));
+    uint n = numTris < 2 ? 2 : numTris;
+    b.capacity = n;
+    PT_HIP_TRY(hipMalloc(&b.triWorld, sizeof(TriRecord) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.triSorted, sizeof(TriRecord) * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.keys, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.keysSorted, 8 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.prims, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.primsSorted, 4 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.childL, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.childR, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.parent, 4 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.leafParent, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.rangeFirst, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.rangeLast, 4 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.tickets, 4 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.boxLmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxLmax, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmax, 16 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.sceneBounds, 32)); PT_HIP_TRY(hipMalloc(&b.nodes, sizeof(BvhNode) * (size_t)n));
+    size_t tmp = 0;
+    PT_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64));
+    b.sortTempBytes = tmp; PT_HIP_TRY(hipMalloc(&b.sortTemp, tmp ? tmp : 16));
+    return hipSuccess;
+}
+void bvh_free(BvhBuildBuffers& b) {
+    void* ps[] = {b.triWorld, b.triSorted, b.keys, b.keysSorted, b.prims, b.primsSorted, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast, b.tickets,
+                  b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    __builtin_memset(&b, 0, sizeof(b));
+}
+static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, uint n, hipStream_t st) {
+    uint g = (n + 255u) / 256u;
+    PT_HIP_TRY(hipMemsetAsync(b.tickets, 0, 4 * (size_t)(n < 2 ? 2 : n), st));
+    hipLaunchKernelGGL(k_bounds, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.childL, b.parent, b.leafParent, b.tickets, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax);
+    hipLaunchKernelGGL(k_emit, dim3(g), dim3(256), 0, st, n, b.childL, b.childR, b.rangeFirst, b.rangeLast, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes);
+    return hipGetLastError();
+}
+hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint g = (n + 255u) / 256u;
+    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, st, b.sceneBounds);
+    hipLaunchKernelGGL(k_tri_setup, dim3(g), dim3(256), 0, st, sc, n, b.triWorld, b.sceneBounds);
+    hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, st, b.triWorld, n, b.sceneBounds, b.keys, b.prims);
+    size_t tmp = b.sortTempBytes;
+    PT_HIP_TRY(rocprim::radix_sort_pairs(b.sortTemp, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64, st));
+    if (n > 1) hipLaunchKernelGGL(k_karras, dim3(g), dim3(256), 0, st, b.keysSorted, (int)n, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast);
+    return bvh_bounds_and_emit(b, n, st);
+}
+hipError_t bvh_refit(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    uint g = (n + 255u) / 256u;
+    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, st, b.sceneBounds);
+    hipLaunchKernelGGL(k_tri_setup, dim3(g), dim3(256), 0, st, sc, n, b.triWorld, b.sceneBounds);
+    return bvh_bounds_and_emit(b, n, st);
+}
+
+} // namespace ptk

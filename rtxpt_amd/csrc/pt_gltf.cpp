@@ -1,0 +1,327 @@
+// mi355pt — glTF 2.0 scene import behind pt_load_scene_gltf (Sample::LoadScene + SceneLoaded, Rtxpt/Sample.cpp:447-560;
+// material import mirrors MaterialsBaker::ImportFromDonut + PTMaterial::FillData, Rtxpt/Materials/MaterialsBaker.cpp:516-591, 660-705).
+// The reference delegates glTF parsing to Donut/cgltf (absent); this is a self-contained reader: JSON, external/base64
+// buffers, accessors (float / normalised integer), node hierarchy (matrix or TRS), PNG textures (8-bit, non-interlaced) via zlib.
+// Output goes through the same raw-buffer entry points the bakers use (pt_set_materials / pt_set_geometry / pt_set_instances).
+#include "../../include/mi355pt.h"
+#include <zlib.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------- minimal JSON
+struct JValue {
+    enum Type { Null, Bool, Num, Str, Arr, Obj } type = Null;
+    double num = 0; bool b = false; std::string str; std::vector<JValue> arr; std::vector<std::pair<std::string, JValue>> obj;
+    const JValue* get(const char* k) const { if (type != Obj) return nullptr; for (auto& kv : obj) if (kv.first == k) return &kv.second; return nullptr; }
+    double numOr(const char* k, double d) const { const JValue* v = get(k); return (v && v->type == Num) ? v->num : d; }
+    int intOr(const char* k, int d) const { const JValue* v = get(k); return (v && v->type == Num) ? (int)v->num : d; }
+    std::string strOr(const char* k, const char* d) const { const JValue* v = get(k); return (v && v->type == Str) ? v->str : std::string(d); }
+    size_t size() const { return type == Arr ? arr.size() : 0; }
+};
+struct JParser {
+    const char* p; const char* e; bool ok = true;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++; }
+    JValue parse() {
+        ws(); JValue v;
+        if (p >= e) { ok = false; return v; }
+        if (*p == '{') { p++; v.type = JValue::Obj; ws(); if (p < e && *p == '}') { p++; return v; }
+            while (ok) { ws(); JValue k = parse(); if (k.type != JValue::Str) { ok = false; break; } ws(); if (p >= e || *p != ':') { ok = false; break; } p++;
+                JValue val = parse(); v.obj.emplace_back(k.str, std::move(val)); ws(); if (p < e && *p == ',') { p++; continue; } if (p < e && *p == '}') { p++; break; } ok = false; }
+            return v; }
+        if (*p == '[') { p++; v.type = JValue::Arr; ws(); if (p < e && *p == ']') { p++; return v; }
+            while (ok) { v.arr.push_back(parse()); ws(); if (p < e && *p == ',') { p++; continue; } if (p < e && *p == ']') { p++; break; } ok = false; }
+            return v; }
+        if (*p == '"') { p++; v.type = JValue::Str;
+            while (p < e && *p != '"') { if (*p == '\\' && p + 1 < e) { p++; char c = *p; if (c == 'n') v.str += '\n'; else if (c == 't') v.str += '\t'; else if (c == 'u') { p += 4; v.str += '?'; } else v.str += c; p++; } else v.str += *p++; }
+            if (p < e) p++; else ok = false; return v; }
+        if (!strncmp(p, "true", 4)) { p += 4; v.type = JValue::Bool; v.b = true; return v; }
+        if (!strncmp(p, "false", 5)) { p += 5; v.type = JValue::Bool; v.b = false; return v; }
+        if (!strncmp(p, "null", 4)) { p += 4; return v; }
+        char* end = nullptr; v.num = strtod(p, &end); if (end == p) { ok = false; return v; } p = end; v.type = JValue::Num; return v;
+    }
+};
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0); size_t r = n > 0 ? fread(out.data(), 1, (size_t)n, f) : 0; fclose(f);
+    return r == out.size();
+}
+bool base64_decode(const std::string& s, size_t start, std::vector<uint8_t>& out) {
+    auto val = [](char c) -> int { if (c >= 'A' && c <= 'Z') return c - 'A'; if (c >= 'a' && c <= 'z') return c - 'a' + 26; if (c >= '0' && c <= '9') return c - '0' + 52; if (c == '+') return 62; if (c == '/') return 63; return -1; };
+    uint32_t acc = 0; int bits = 0;
+    for (size_t i = start; i < s.size(); i++) { int v = val(s[i]); if (v < 0) continue; acc = (acc << 6) | (uint32_t)v; bits += 6; if (bits >= 8) { bits -= 8; out.push_back((uint8_t)((acc >> bits) & 0xFF)); } }
+    return true;
+}
+bool load_uri(const std::string& baseDir, const std::string& uri, std::vector<uint8_t>& out) {
+    if (uri.compare(0, 5, "data:") == 0) { size_t c = uri.find(','); if (c == std::string::npos) return false; return base64_decode(uri, c + 1, out); }
+    return read_file(baseDir + uri, out);
+}
+
+// ---------------------------------------------------------------- PNG (8-bit, non-interlaced; gray / gray+alpha / RGB / RGBA / palette)
+bool decode_png(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba) {
+    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    if (d.size() < 8 || memcmp(d.data(), sig, 8)) return false;
+    size_t p = 8; std::vector<uint8_t> idat, plte, trns; int depth = 0, ctype = 0, interlace = 0; w = h = 0;
+    auto be32 = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
+    while (p + 8 <= d.size()) {
+        uint32_t len = be32(p); std::string type((const char*)&d[p + 4], 4); p += 8;
+        if (p + len + 4 > d.size()) return false;
+        if (type == "IHDR") { w = be32(p); h = be32(p + 4); depth = d[p + 8]; ctype = d[p + 9]; interlace = d[p + 12]; }
+        else if (type == "PLTE") plte.assign(d.begin() + p, d.begin() + p + len);
+        else if (type == "tRNS") trns.assign(d.begin() + p, d.begin() + p + len);
+        else if (type == "IDAT") idat.insert(idat.end(), d.begin() + p, d.begin() + p + len);
+        else if (type == "IEND") break;
+        p += len + 4;
+    }
+    if (!w || !h || depth != 8 || interlace) return false;
+    int ch = (ctype == 0) ? 1 : (ctype == 2) ? 3 : (ctype == 3) ? 1 : (ctype == 4) ? 2 : (ctype == 6) ? 4 : 0;
+    if (!ch) return false;
+    size_t stride = (size_t)w * ch; std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf outLen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &outLen, idat.data(), (uLong)idat.size()) != Z_OK || outLen != raw.size()) return false;
+    std::vector<uint8_t> img(stride * h);
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t* in = &raw[(stride + 1) * y]; uint8_t ft = in[0]; in++;
+        uint8_t* out = &img[stride * y]; const uint8_t* prev = y ? &img[stride * (y - 1)] : nullptr;
+        for (size_t x = 0; x < stride; x++) {
+            int a = x >= (size_t)ch ? out[x - ch] : 0, b = prev ? prev[x] : 0, c = (prev && x >= (size_t)ch) ? prev[x - ch] : 0, v = in[x];
+            switch (ft) { case 0: break; case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
+                case 4: { int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); } break; default: return false; }
+            out[x] = (uint8_t)v;
+        }
+    }
+    rgba.resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        uint8_t r, g, b, a = 255; const uint8_t* s = &img[i * ch];
+        if (ctype == 0) { r = g = b = s[0]; } else if (ctype == 2) { r = s[0]; g = s[1]; b = s[2]; } else if (ctype == 4) { r = g = b = s[0]; a = s[1]; }
+        else if (ctype == 6) { r = s[0]; g = s[1]; b = s[2]; a = s[3]; }
+        else { size_t k = s[0]; if (k * 3 + 2 >= plte.size()) return false; r = plte[k * 3]; g = plte[k * 3 + 1]; b = plte[k * 3 + 2]; if (k < trns.size()) a = trns[k]; }
+        rgba[i * 4] = r; rgba[i * 4 + 1] = g; rgba[i * 4 + 2] = b; rgba[i * 4 + 3] = a;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- matrices (column-major 4x4 like glTF)
+struct M4 { double m[16]; };
+M4 m4_identity() { M4 r; memset(&r, 0, sizeof(r)); r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1; return r; }
+M4 m4_mul(const M4& a, const M4& b) { M4 r; for (int c = 0; c < 4; c++) for (int rr = 0; rr < 4; rr++) { double s = 0; for (int k = 0; k < 4; k++) s += a.m[k * 4 + rr] * b.m[c * 4 + k]; r.m[c * 4 + rr] = s; } return r; }
+M4 m4_trs(const double t[3], const double q[4], const double s[3]) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    M4 r = m4_identity();
+    r.m[0] = (1 - 2 * (y * y + z * z)) * s[0]; r.m[1] = (2 * (x * y + z * w)) * s[0]; r.m[2] = (2 * (x * z - y * w)) * s[0];
+    r.m[4] = (2 * (x * y - z * w)) * s[1]; r.m[5] = (1 - 2 * (x * x + z * z)) * s[1]; r.m[6] = (2 * (y * z + x * w)) * s[1];
+    r.m[8] = (2 * (x * z + y * w)) * s[2]; r.m[9] = (2 * (y * z - x * w)) * s[2]; r.m[10] = (1 - 2 * (x * x + y * y)) * s[2];
+    r.m[12] = t[0]; r.m[13] = t[1]; r.m[14] = t[2];
+    return r;
+}
+
+uint32_t pack_snorm8(const float* v, int n) {   // Packing.hlsli:127-140
+    uint32_t out = 0;
+    for (int i = 0; i < n; i++) { float c = v[i] < -1.f ? -1.f : (v[i] > 1.f ? 1.f : v[i]); out |= ((uint32_t)((int)(c * 127.0f)) & 0xFFu) << (8 * i); }
+    return out;
+}
+uint32_t pack_texture_word(uint32_t index, uint32_t w, uint32_t h) {   // MaterialsBaker.cpp:497-508
+    uint32_t mips = 1; { uint32_t m = w > h ? w : h; while (m > 1) { m >>= 1; mips++; } }
+    uint32_t baseLOD = (uint32_t)lround(log2((double)w * (double)h));
+    return (baseLOD << 24) | (mips << 16) | (index & 0xFFFF);
+}
+
+struct Loader {
+    pt_context* ctx; std::string baseDir; JValue root; std::vector<std::vector<uint8_t>> buffers; std::string err;
+    std::vector<uint32_t> indices; std::vector<float> positions, uvs; std::vector<uint32_t> normals, tangents;
+    std::vector<PtGeometryDesc> geoms; std::vector<PtMeshDesc> meshes; std::vector<PtInstanceDesc> instances; std::vector<PTMaterialData> materials;
+    std::vector<std::vector<uint8_t>> texPixels; std::vector<PtTextureDesc> texDescs; std::map<std::pair<int, int>, uint32_t> texCache;   // (image, srgb) -> texture word
+    std::vector<int> meshMap;
+
+    bool accessor(int idx, std::vector<double>& out, int& comps) {
+        const JValue* accs = root.get("accessors"); if (!accs || idx < 0 || (size_t)idx >= accs->size()) { err = "bad accessor index"; return false; }
+        const JValue& a = accs->arr[idx];
+        int ct = a.intOr("componentType", 0), count = a.intOr("count", 0); std::string type = a.strOr("type", "");
+        comps = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 0;
+        bool normalized = a.get("normalized") && a.get("normalized")->b;
+        if (!comps || a.get("sparse")) { err = "unsupported accessor"; return false; }
+        int bv = a.intOr("bufferView", -1); const JValue* bvs = root.get("bufferViews");
+        if (!bvs || bv < 0 || (size_t)bv >= bvs->size()) { err = "accessor without bufferView"; return false; }
+        const JValue& v = bvs->arr[bv];
+        int buf = v.intOr("buffer", 0); size_t off = (size_t)v.numOr("byteOffset", 0) + (size_t)a.numOr("byteOffset", 0);
+        int csz = (ct == 5120 || ct == 5121) ? 1 : (ct == 5122 || ct == 5123) ? 2 : (ct == 5125 || ct == 5126) ? 4 : 0;
+        if (!csz || buf < 0 || (size_t)buf >= buffers.size()) { err = "unsupported component type"; return false; }
+        size_t stride = (size_t)v.numOr("byteStride", 0); if (!stride) stride = (size_t)csz * comps;
+        const std::vector<uint8_t>& b = buffers[buf];
+        if (count && off + stride * (size_t)(count - 1) + (size_t)csz * comps > b.size()) { err = "accessor out of range"; return false; }
+        out.resize((size_t)count * comps);
+        for (int i = 0; i < count; i++) for (int k = 0; k < comps; k++) {
+            const uint8_t* p = &b[off + stride * i + (size_t)csz * k]; double val;
+            switch (ct) { case 5120: val = *(const int8_t*)p; if (normalized) val = val / 127.0 < -1 ? -1 : val / 127.0; break; case 5121: val = *p; if (normalized) val /= 255.0; break;
+                case 5122: { int16_t s; memcpy(&s, p, 2); val = s; if (normalized) val = val / 32767.0 < -1 ? -1 : val / 32767.0; } break;
+                case 5123: { uint16_t s; memcpy(&s, p, 2); val = s; if (normalized) val /= 65535.0; } break;
+                case 5125: { uint32_t s; memcpy(&s, p, 4); val = s; } break; default: { float f; memcpy(&f, p, 4); val = f; } break; }
+            out[(size_t)i * comps + k] = val;
+        }
+        return true;
+    }
+    uint32_t texture(const JValue* texRef, bool srgb) {          // returns packed texture word or 0xFFFFFFFF
+        if (!texRef) return 0xFFFFFFFFu;
+        int ti = texRef->intOr("index", -1); const JValue* texs = root.get("textures"); const JValue* imgs = root.get("images");
+        if (!texs || !imgs || ti < 0 || (size_t)ti >= texs->size()) return 0xFFFFFFFFu;
+        int img = texs->arr[ti].intOr("source", -1); if (img < 0 || (size_t)img >= imgs->size()) return 0xFFFFFFFFu;
+        auto key = std::make_pair(img, srgb ? 1 : 0); auto it = texCache.find(key); if (it != texCache.end()) return it->second;
+        const JValue& im = imgs->arr[img]; std::vector<uint8_t> file;
+        if (im.get("uri")) { if (!load_uri(baseDir, im.strOr("uri", ""), file)) return 0xFFFFFFFFu; }
+        else {
+            int bv = im.intOr("bufferView", -1); const JValue* bvs = root.get("bufferViews"); if (!bvs || bv < 0 || (size_t)bv >= bvs->size()) return 0xFFFFFFFFu;
+            const JValue& v = bvs->arr[bv]; int buf = v.intOr("buffer", 0); size_t off = (size_t)v.numOr("byteOffset", 0), len = (size_t)v.numOr("byteLength", 0);
+            if ((size_t)buf >= buffers.size() || off + len > buffers[buf].size()) return 0xFFFFFFFFu;
+            file.assign(buffers[buf].begin() + off, buffers[buf].begin() + off + len);
+        }
+        uint32_t w, h; std::vector<uint8_t> rgba;
+        if (!decode_png(file, w, h, rgba)) return 0xFFFFFFFFu;          // unsupported image formats are treated as "texture not loaded"
+        uint32_t index = (uint32_t)texDescs.size();
+        texPixels.push_back(std::move(rgba));
+        PtTextureDesc d; d.width = w; d.height = h; d.format = srgb ? PT_TEX_RGBA8_SRGB : PT_TEX_RGBA8_UNORM; d.pixels = nullptr; texDescs.push_back(d);
+        uint32_t word = pack_texture_word(index, w, h); texCache[key] = word; return word;
+    }
+    void importMaterials() {
+        const JValue* mats = root.get("materials"); size_t n = mats ? mats->size() : 0;
+        for (size_t i = 0; i <= n; i++) {            // one extra default material for primitives without one
+            PTMaterialData m; memset(&m, 0, sizeof(m));
+            m.BaseOrDiffuseColor[0] = m.BaseOrDiffuseColor[1] = m.BaseOrDiffuseColor[2] = 1.f; m.Opacity = 1.f; m.Roughness = 1.f; m.Metalness = 1.f; m.NormalTextureScale = 1.f;
+            m.AlphaCutoff = 0.5f; m.IoR = 1.5f; m.AttenuationColor[0] = m.AttenuationColor[1] = m.AttenuationColor[2] = 1.f; m.AttenuationDistance = 3.402823466e+38f;
+            m.BaseOrDiffuseTextureIndex = m.MetalRoughOrSpecularTextureIndex = m.EmissiveTextureIndex = m.NormalTextureIndex = m.OcclusionTextureIndex = m.TransmissionTextureIndex = 0xFFFFFFFFu;
+            m._padding0 = 42; m._padding1 = 42.f;
+            uint32_t flags = 0; bool enableTransmission = false; float emissiveStrength = 1.f;
+            if (i == n) { m.Metalness = 0.f; }
+            else {
+                const JValue& j = mats->arr[i];
+                if (const JValue* pbr = j.get("pbrMetallicRoughness")) {
+                    if (const JValue* c = pbr->get("baseColorFactor")) if (c->size() >= 3) { for (int k = 0; k < 3; k++) m.BaseOrDiffuseColor[k] = (float)c->arr[k].num; if (c->size() > 3) m.Opacity = (float)c->arr[3].num; }
+                    m.Metalness = (float)pbr->numOr("metallicFactor", 1.0); m.Roughness = (float)pbr->numOr("roughnessFactor", 1.0);
+                    uint32_t t = texture(pbr->get("baseColorTexture"), true); if (t != 0xFFFFFFFFu) { m.BaseOrDiffuseTextureIndex = t; flags |= 0x8; }
+                    t = texture(pbr->get("metallicRoughnessTexture"), false); if (t != 0xFFFFFFFFu) { m.MetalRoughOrSpecularTextureIndex = t; flags |= 0x4; }
+                }
+                if (const JValue* e = j.get("emissiveFactor")) if (e->size() >= 3) for (int k = 0; k < 3; k++) m.EmissiveColor[k] = (float)e->arr[k].num;
+                { uint32_t t = texture(j.get("emissiveTexture"), true); if (t != 0xFFFFFFFFu) { m.EmissiveTextureIndex = t; flags |= 0x10; } }
+                if (const JValue* nt = j.get("normalTexture")) { uint32_t t = texture(nt, false); if (t != 0xFFFFFFFFu) { m.NormalTextureIndex = t; flags |= 0x20; m.NormalTextureScale = (float)nt->numOr("scale", 1.0); } }
+                m.AlphaCutoff = (float)j.numOr("alphaCutoff", 0.5);
+                if (const JValue* ext = j.get("extensions")) {
+                    if (const JValue* es = ext->get("KHR_materials_emissive_strength")) emissiveStrength = (float)es->numOr("emissiveStrength", 1.0);
+                    if (const JValue* tr = ext->get("KHR_materials_transmission")) {
+                        m.TransmissionFactor = (float)tr->numOr("transmissionFactor", 0.0); enableTransmission = m.TransmissionFactor > 0.f;
+                        uint32_t t = texture(tr->get("transmissionTexture"), false); if (t != 0xFFFFFFFFu) { m.TransmissionTextureIndex = t; flags |= 0x80; enableTransmission = true; }
+                    }
+                    if (const JValue* ior = ext->get("KHR_materials_ior")) m.IoR = (float)ior->numOr("ior", 1.5);
+                    if (const JValue* vol = ext->get("KHR_materials_volume")) {
+                        m.ThicknessFactor = (float)vol->numOr("thicknessFactor", 0.0); m.AttenuationDistance = (float)vol->numOr("attenuationDistance", 3.402823466e+38);
+                        if (const JValue* ac = vol->get("attenuationColor")) if (ac->size() >= 3) for (int k = 0; k < 3; k++) m.AttenuationColor[k] = (float)ac->arr[k].num;
+                    }
+                }
+            }
+            for (int k = 0; k < 3; k++) m.EmissiveColor[k] *= emissiveStrength;              // EmissiveColor * EmissiveIntensity (FillData)
+            if (!enableTransmission) { m.TransmissionFactor = 0.f; m.DiffuseTransmissionFactor = 0.f; flags &= ~0x80u; }
+            bool thickVolume = enableTransmission && m.ThicknessFactor > 0.f;                 // ThinSurface unless a volume is declared; forced when transmission is off (:543-544)
+            if (!thickVolume) flags |= 0x200;
+            m.Flags = flags;
+            materials.push_back(m);
+        }
+    }
+    bool importMeshes() {
+        const JValue* ms = root.get("meshes"); size_t n = ms ? ms->size() : 0; const JValue* mats = root.get("materials"); size_t nMat = mats ? mats->size() : 0;
+        meshMap.assign(n, -1);
+        for (size_t mi = 0; mi < n; mi++) {
+            const JValue* prims = ms->arr[mi].get("primitives"); if (!prims) continue;
+            uint32_t firstGeom = (uint32_t)geoms.size();
+            for (auto& pr : prims->arr) {
+                if (pr.intOr("mode", 4) != 4) continue;
+                const JValue* at = pr.get("attributes"); if (!at || !at->get("POSITION")) continue;
+                std::vector<double> P, N, T, UV, I; int c;
+                if (!accessor(at->intOr("POSITION", -1), P, c) || c != 3) { if (err.empty()) err = "POSITION must be VEC3"; return false; }
+                uint32_t nv = (uint32_t)(P.size() / 3), flags = 0;
+                if (at->get("NORMAL")) { if (!accessor(at->intOr("NORMAL", -1), N, c) || c != 3 || N.size() / 3 != nv) return false; flags |= PT_GEOM_HAS_NORMAL; }
+                if (at->get("TANGENT")) { if (!accessor(at->intOr("TANGENT", -1), T, c) || c != 4 || T.size() / 4 != nv) return false; flags |= PT_GEOM_HAS_TANGENT; }
+                if (at->get("TEXCOORD_0")) { if (!accessor(at->intOr("TEXCOORD_0", -1), UV, c) || c != 2 || UV.size() / 2 != nv) return false; flags |= PT_GEOM_HAS_UV; }
+                if (pr.get("indices")) { if (!accessor(pr.intOr("indices", -1), I, c) || c != 1) return false; } else { I.resize(nv); for (uint32_t k = 0; k < nv; k++) I[k] = k; }
+                uint32_t ni = (uint32_t)(I.size() / 3) * 3;
+                PtGeometryDesc g; memset(&g, 0, sizeof(g));
+                g.indexOffset = (uint32_t)indices.size(); g.numIndices = ni; g.vertexOffset = (uint32_t)(positions.size() / 3); g.numVertices = nv; g.flags = flags;
+                int mat = pr.intOr("material", -1); g.materialIndex = (mat >= 0 && (size_t)mat < nMat) ? (uint32_t)mat : (uint32_t)nMat;
+                if (mat >= 0 && (size_t)mat < nMat && mats->arr[mat].strOr("alphaMode", "OPAQUE") == "MASK") g.geomFlags |= PT_GEOMF_ALPHA_TESTED;   // MaterialDomain::AlphaTested
+                for (uint32_t k = 0; k < ni; k++) { uint32_t v = (uint32_t)I[k]; if (v >= nv) { err = "index out of range"; return false; } indices.push_back(v); }
+                for (uint32_t k = 0; k < nv; k++) {
+                    positions.push_back((float)P[3 * k]); positions.push_back((float)P[3 * k + 1]); positions.push_back((float)P[3 * k + 2]);
+                    float uv[2] = {0, 0}; if (flags & PT_GEOM_HAS_UV) { uv[0] = (float)UV[2 * k]; uv[1] = (float)UV[2 * k + 1]; } uvs.push_back(uv[0]); uvs.push_back(uv[1]);
+                    float nn[3] = {0, 0, 0}; if (flags & PT_GEOM_HAS_NORMAL) { nn[0] = (float)N[3 * k]; nn[1] = (float)N[3 * k + 1]; nn[2] = (float)N[3 * k + 2]; } normals.push_back(pack_snorm8(nn, 3));
+                    float tt[4] = {0, 0, 0, 0}; if (flags & PT_GEOM_HAS_TANGENT) { for (int q = 0; q < 4; q++) tt[q] = (float)T[4 * k + q]; } tangents.push_back(pack_snorm8(tt, 4));
+                }
+                geoms.push_back(g);
+            }
+            if (geoms.size() > firstGeom) { PtMeshDesc md; md.firstGeometry = firstGeom; md.numGeometries = (uint32_t)geoms.size() - firstGeom; meshMap[mi] = (int)meshes.size(); meshes.push_back(md); }
+        }
+        return true;
+    }
+    void visit(int node, const M4& parent, int depth) {
+        const JValue* nodes = root.get("nodes"); if (!nodes || node < 0 || (size_t)node >= nodes->size() || depth > 256) return;
+        const JValue& n = nodes->arr[node]; M4 local = m4_identity();
+        if (const JValue* mx = n.get("matrix")) { if (mx->size() == 16) for (int i = 0; i < 16; i++) local.m[i] = mx->arr[i].num; }
+        else {
+            double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
+            if (const JValue* v = n.get("translation")) if (v->size() == 3) for (int i = 0; i < 3; i++) t[i] = v->arr[i].num;
+            if (const JValue* v = n.get("rotation")) if (v->size() == 4) for (int i = 0; i < 4; i++) q[i] = v->arr[i].num;
+            if (const JValue* v = n.get("scale")) if (v->size() == 3) for (int i = 0; i < 3; i++) s[i] = v->arr[i].num;
+            local = m4_trs(t, q, s);
+        }
+        M4 world = m4_mul(parent, local);
+        int mesh = n.intOr("mesh", -1);
+        if (mesh >= 0 && (size_t)mesh < meshMap.size() && meshMap[mesh] >= 0) {
+            PtInstanceDesc inst; memset(&inst, 0, sizeof(inst)); inst.meshIndex = (uint32_t)meshMap[mesh];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) inst.transform[r * 4 + c] = (float)world.m[c * 4 + r];   // column-major 4x4 -> row-major 3x4
+            instances.push_back(inst);
+        }
+        if (const JValue* ch = n.get("children")) for (auto& c : ch->arr) visit((int)c.num, world, depth + 1);
+    }
+};
+
+} // namespace
+
+extern "C" int32_t pt_load_scene_gltf(pt_context* ctx, const char* path) {
+    if (!ctx || !path) return PT_ERROR_INVALID_ARGUMENT;
+    std::vector<uint8_t> file;
+    if (!read_file(path, file)) return PT_ERROR_IO;
+    Loader L; L.ctx = ctx;
+    std::string sp(path); size_t slash = sp.find_last_of('/'); L.baseDir = slash == std::string::npos ? "" : sp.substr(0, slash + 1);
+    const char* jb = (const char*)file.data(); size_t jn = file.size(); std::vector<uint8_t> glbBin;
+    if (file.size() >= 20 && !memcmp(file.data(), "glTF", 4)) {                       // GLB container
+        uint32_t jlen; memcpy(&jlen, &file[12], 4); if (20 + (size_t)jlen > file.size()) return PT_ERROR_IO;
+        jb = (const char*)&file[20]; jn = jlen; size_t p = 20 + jlen;
+        if (p + 8 <= file.size()) { uint32_t blen; memcpy(&blen, &file[p], 4); if (p + 8 + blen <= file.size()) glbBin.assign(file.begin() + p + 8, file.begin() + p + 8 + blen); }
+    }
+    JParser jp; jp.p = jb; jp.e = jb + jn; L.root = jp.parse();
+    if (!jp.ok || L.root.type != JValue::Obj) return PT_ERROR_IO;
+    if (const JValue* bufs = L.root.get("buffers")) for (auto& b : bufs->arr) {
+        std::vector<uint8_t> data;
+        if (b.get("uri")) { if (!load_uri(L.baseDir, b.strOr("uri", ""), data)) return PT_ERROR_IO; } else data = glbBin;
+        L.buffers.push_back(std::move(data));
+    }
+    L.importMaterials();
+    if (!L.importMeshes()) return PT_ERROR_IO;
+    int sceneIdx = L.root.intOr("scene", 0); const JValue* scenes = L.root.get("scenes");
+    if (scenes && (size_t)sceneIdx < scenes->size()) { if (const JValue* ns = scenes->arr[sceneIdx].get("nodes")) for (auto& n : ns->arr) L.visit((int)n.num, m4_identity(), 0); }
+    else if (const JValue* nodes = L.root.get("nodes")) for (size_t i = 0; i < nodes->size(); i++) L.visit((int)i, m4_identity(), 0);
+    if (L.instances.empty() || L.geoms.empty()) return PT_ERROR_IO;
+    for (size_t i = 0; i < L.texDescs.size(); i++) L.texDescs[i].pixels = L.texPixels[i].data();
+    int32_t r = pt_set_materials(ctx, L.materials.data(), (uint32_t)L.materials.size(), L.texDescs.data(), (uint32_t)L.texDescs.size());
+    if (r != PT_OK) return r;
+    PtGeometryBuffers gb; gb.indices = L.indices.data(); gb.numIndices = (uint32_t)L.indices.size(); gb.positions = L.positions.data(); gb.uvs = L.uvs.data();
+    gb.normals = L.normals.data(); gb.tangents = L.tangents.data(); gb.numVertices = (uint32_t)(L.positions.size() / 3);
+    r = pt_set_geometry(ctx, &gb, L.geoms.data(), (uint32_t)L.geoms.size(), L.meshes.data(), (uint32_t)L.meshes.size());
+    if (r != PT_OK) return r;
+    return pt_set_instances(ctx, L.instances.data(), (uint32_t)L.instances.size());
+}

@@ -1,0 +1,335 @@
+// mi355pt device/host leaf library — polymorphic lights and the global light sampler
+// Part of the PRODUCT path (libmi355pt.so). Written to the arithmetic contract stated in pt_vec.h so that the HIP kernels
+// reproduce the reference estimator bit-for-bit against the independent CPU oracle used by the tests.
+// Reference anchors are cited per function (paths relative to /root/reference/Rtxpt/Shaders/PathTracer/ unless noted).
+// Follows:
+//   Lighting/PolymorphicLight.h:18-79                         packed 32 B + 16 B light records, type codes
+//   Lighting/PolymorphicLight.hlsli:93-259 (SphereLight), :399-503 (TriangleLight), :562-640 (EnvironmentQuadLight),
+//     :642-676 (CalcSample dispatch + shaping), :752-792 (UnpackRadiance / UnpackColor / PackColor)
+//   Lighting/LightShaping.hlsli:16-42,76-99                    spot shaping
+//   Utils/Utils.hlsli:115-152                                  Encode/Decode_Oct, NDirToOctUnorm32/OctToNDirUnorm32
+//   Lighting/LightSampler.hlsli:100-146,318-345,400-432        SampleGlobal(+PDF), LoadLight, BSDF-side MIS
+// (paths relative to /root/reference/Rtxpt/Shaders/PathTracer/)
+#pragma once
+#include "pt_sampling.h"
+
+namespace ptk {
+#pragma clang force_cuda_host_device begin
+
+static const uint kPolymorphicLightTypeShift = 24, kPolymorphicLightTypeMask = 0xf;
+static const uint kPolymorphicLightShapingEnableBit = 1u << 28;
+static const uint kPolymorphicLightShapingUseMinFalloff = 1u << 30;
+static const float kPolymorphicLightMinLog2Radiance = -8.f, kPolymorphicLightMaxLog2Radiance = 40.f;
+static const float kMinSpotlightFalloff = 0.0001f;
+static const float DISTANT_LIGHT_DISTANCE = 100000.0f;
+static const float FLT_EPSILON_MINI = 2e-9f, MAX_SOLID_ANGLE_PDF = 1e10f;
+static const uint RTXPT_INVALID_LIGHT_INDEX = 0xFFFFFFFFu;
+enum PolymorphicLightType : uint { kSphere = 0, kTriangle, kDirectional, kEnvironment, kPoint, kEnvironmentQuad };
+
+struct PolymorphicLightInfo {   // 32 B
+    float3 Center; uint ColorTypeAndFlags;
+    uint Direction1, Direction2, Scalars, LogRadiance;
+    bool HasLightShaping() const { return (ColorTypeAndFlags & kPolymorphicLightShapingEnableBit) != 0; }
+};
+struct PolymorphicLightInfoEx { // 16 B
+    uint IesProfileIndex, PrimaryAxis, CosConeAngleAndSoftness, UniqueID;
+};
+struct PolymorphicLightInfoFull { PolymorphicLightInfo Base; PolymorphicLightInfoEx Extended; };
+
+struct PolymorphicLightSample {
+    float3 Position, Normal, Radiance; float SolidAnglePdf; bool LightSampleableByBSDF;
+};
+
+// Utils.hlsli:127-152
+static inline float3 Decode_Oct(float2 f) {
+    f = make_float2(f.x * 2.0f - 1.0f, f.y * 2.0f - 1.0f);
+    float3 n = make_float3(f.x, f.y, 1.0f - fabsf(f.x) - fabsf(f.y));
+    float t = saturate(-n.z);
+    n.x += (n.x >= 0.0f) ? -t : t;
+    n.y += (n.y >= 0.0f) ? -t : t;
+    return normalize(n);
+}
+static inline float2 Encode_Oct(float3 n) {
+    float s = fabsf(n.x) + fabsf(n.y) + fabsf(n.z);
+    n = n / s;
+    float2 xy = make_float2(n.x, n.y);
+    if (!(n.z >= 0.0f)) xy = make_float2((1.0f - fabsf(n.y)) * ((n.x >= 0.0f) ? 1.0f : -1.0f), (1.0f - fabsf(n.x)) * ((n.y >= 0.0f) ? 1.0f : -1.0f));
+    return make_float2(xy.x * 0.5f + 0.5f, xy.y * 0.5f + 0.5f);
+}
+static inline uint NDirToOctUnorm32(float3 n) {
+    float2 p = Encode_Oct(n);
+    p = make_float2(saturate(p.x * 0.5f + 0.5f), saturate(p.y * 0.5f + 0.5f));
+    return (uint)(p.x * 65534.0f) | ((uint)(p.y * 65534.0f) << 16);
+}
+static inline float3 OctToNDirUnorm32(uint pUnorm) {
+    float2 p;
+    p.x = saturate((float)(pUnorm & 0xffffu) / 65534.0f);
+    p.y = saturate((float)(pUnorm >> 16) / 65534.0f);
+    p = make_float2(p.x * 2.0f - 1.0f, p.y * 2.0f - 1.0f);
+    return Decode_Oct(p);
+}
+
+// PolymorphicLight.hlsli:752-792
+static inline float UnpackLightRadiance(uint logRadiance) {
+    return (logRadiance == 0) ? 0.f
+        : dm_exp2(((float)(logRadiance - 1) / 65534.0f) * (kPolymorphicLightMaxLog2Radiance - kPolymorphicLightMinLog2Radiance) + kPolymorphicLightMinLog2Radiance);
+}
+static inline float3 UnpackLightColor(const PolymorphicLightInfo& b) {
+    float3 color = Unpack_R8G8B8_UFLOAT(b.ColorTypeAndFlags);
+    float radiance = UnpackLightRadiance(b.LogRadiance & 0xffffu);
+    return color * radiance;
+}
+static inline void PackLightColor(float3 radiance, PolymorphicLightInfo& b) {
+    float intensity = fmaxf_(radiance.x, fmaxf_(radiance.y, radiance.z));
+    if (intensity > 0.0f) {
+        float logRadiance = saturate((dm_log2(intensity) - kPolymorphicLightMinLog2Radiance) / (kPolymorphicLightMaxLog2Radiance - kPolymorphicLightMinLog2Radiance));
+        uint packedRadiance = (uint)ceilf(logRadiance * 65534.0f) + 1u;
+        if (packedRadiance > 0xffffu) packedRadiance = 0xffffu;
+        float unpackedRadiance = UnpackLightRadiance(packedRadiance);
+        float3 normalizedRadiance = saturate3(radiance / make_float3(unpackedRadiance));
+        b.LogRadiance |= packedRadiance;
+        b.ColorTypeAndFlags |= Pack_R8G8B8_UFLOAT(normalizedRadiance);
+    }
+}
+
+// LightShaping.hlsli:16-42, 76-99
+struct LightShaping { float cosConeAngle; float3 primaryAxis; float cosConeSoftness; uint isSpot; float minFalloff; };
+static inline LightShaping unpackLightShaping(const PolymorphicLightInfoFull& li) {
+    LightShaping s; s.cosConeAngle = 0; s.primaryAxis = make_float3(0.f); s.cosConeSoftness = 0; s.isSpot = 0; s.minFalloff = 0;
+    if (li.Base.HasLightShaping()) {
+        s.isSpot = 1;
+        s.primaryAxis = OctToNDirUnorm32(li.Extended.PrimaryAxis);
+        s.cosConeAngle = f16tof32(li.Extended.CosConeAngleAndSoftness);
+        s.cosConeSoftness = f16tof32(li.Extended.CosConeAngleAndSoftness >> 16);
+        s.minFalloff = (li.Base.ColorTypeAndFlags & kPolymorphicLightShapingUseMinFalloff) ? kMinSpotlightFalloff : 0.0f;
+    }
+    return s;
+}
+static inline float smoothstep_(float a, float b, float x) { float t = saturate((x - a) / (b - a)); return t * t * (3.0f - 2.0f * t); }
+static inline float evaluateLightShaping(const LightShaping& s, float3 surfacePosition, float3 lightSamplePosition) {
+    if (!s.isSpot) return 1.0f;
+    float3 lightToSurface = normalize(surfacePosition - lightSamplePosition);
+    float cosTheta = dot(s.primaryAxis, lightToSurface);
+    float smoothFalloff = smoothstep_(s.cosConeAngle, s.cosConeAngle + s.cosConeSoftness, cosTheta);
+    float softSpotlight = fmaxf_(s.minFalloff, smoothFalloff);
+    if (softSpotlight <= 0) return 0.0f;
+    return softSpotlight;    // IES disabled in the reference (LightShaping.hlsli:44-74)
+}
+
+// PolymorphicLight.hlsli:399-503
+struct TriangleLight {
+    float3 base, edge1, edge2, radiance, normal; float surfaceArea;
+    static TriangleLight Create(const PolymorphicLightInfoFull& li) {
+        TriangleLight t;
+        t.edge1 = make_float3(f16tof32(li.Base.Direction1 & 0xffffu), f16tof32(li.Base.Direction2 & 0xffffu), f16tof32(li.Base.Scalars & 0xffffu));
+        t.edge2 = make_float3(f16tof32(li.Base.Direction1 >> 16), f16tof32(li.Base.Direction2 >> 16), f16tof32(li.Base.Scalars >> 16));
+        t.base = li.Base.Center - ((t.edge1 + t.edge2) / 3.0f);
+        t.radiance = UnpackLightColor(li.Base);
+        float3 lightNormal = cross(t.edge1, t.edge2);
+        float lightNormalLength = length(lightNormal);
+        if (lightNormalLength > 0.0f) { t.surfaceArea = 0.5f * lightNormalLength; t.normal = lightNormal / lightNormalLength; }
+        else { t.surfaceArea = 0.0f; t.normal = make_float3(0.f); }
+        return t;
+    }
+    PolymorphicLightInfoFull Store(uint uniqueID) const {
+        PolymorphicLightInfoFull li; __builtin_memset(&li, 0, sizeof(li));
+        PackLightColor(radiance, li.Base);
+        li.Base.Center = base + ((edge1 + edge2) / 3.0f);
+        li.Base.Direction1 = (f32tof16(edge1.x) & 0xffffu) | (f32tof16(edge2.x) << 16);
+        li.Base.Direction2 = (f32tof16(edge1.y) & 0xffffu) | (f32tof16(edge2.y) << 16);
+        li.Base.Scalars    = (f32tof16(edge1.z) & 0xffffu) | (f32tof16(edge2.z) << 16);
+        li.Base.ColorTypeAndFlags |= (uint)kTriangle << kPolymorphicLightTypeShift;
+        li.Extended.UniqueID = uniqueID;
+        return li;
+    }
+    PolymorphicLightSample CalcSample(float2 random, float3 viewerPosition) const {
+        PolymorphicLightSample r; __builtin_memset(&r, 0, sizeof(r));
+        float3 bary = SampleTriangleUniform(random);
+        r.Position = (base + edge1 * bary.y) + edge2 * bary.z;
+        r.Position = ComputeRayOrigin(r.Position, normal);
+        r.Normal = normal;
+        float3 toLight = r.Position - viewerPosition;
+        float distSqr = fmaxf_(FLT_EPSILON_MINI, dot(toLight, toLight));
+        float distance = sqrtf_(distSqr);
+        float3 dir = toLight / distance;
+        float cosTheta = dot(normal, -dir);
+        r.SolidAnglePdf = 0.f; r.Radiance = make_float3(0.f);
+        if (cosTheta <= 0.f) return r;
+        float areaPdf = fmaxf_(FLT_EPSILON_MINI, 1.0f / surfaceArea);
+        r.SolidAnglePdf = fminf_(MAX_SOLID_ANGLE_PDF, pdfAtoW(areaPdf, distance, cosTheta));
+        r.Radiance = radiance;
+        r.LightSampleableByBSDF = true;
+        return r;
+    }
+    float CalcSolidAnglePdfForMIS(float3 viewerPosition, float3 lightSamplePosition) const {
+        float3 toLight = lightSamplePosition - viewerPosition;
+        float distSqr = fmaxf_(FLT_EPSILON_MINI, dot(toLight, toLight));
+        float distance = sqrtf_(distSqr);
+        float3 dir = toLight / distance;
+        float cosTheta = dot(normal, -dir);
+        float areaPdf = fmaxf_(FLT_EPSILON_MINI, 1.0f / surfaceArea);
+        return fminf_(MAX_SOLID_ANGLE_PDF, pdfAtoW(areaPdf, distance, cosTheta));
+    }
+    float GetPower() const { return surfaceArea * K_PI * Luminance(radiance); }
+};
+
+// PolymorphicLight.hlsli:93-259 (sampling + MIS pdf only; proxy-mesh Eval is N3)
+struct SphereLight {
+    float3 position; float radius; float3 radiance; LightShaping shaping;
+    static SphereLight Create(const PolymorphicLightInfoFull& li) {
+        SphereLight s; s.position = li.Base.Center; s.radius = f16tof32(li.Base.Scalars);
+        s.radiance = UnpackLightColor(li.Base); s.shaping = unpackLightShaping(li); return s;
+    }
+    PolymorphicLightSample CalcSample(float2 random, float3 viewerPosition) const {
+        PolymorphicLightSample ls; __builtin_memset(&ls, 0, sizeof(ls));
+        float3 lightVector = position - viewerPosition;
+        float lightDistance2 = dot(lightVector, lightVector);
+        float radius2 = sq(radius);
+        if (lightDistance2 < radius2) {
+            ls.Position = position; ls.Normal = make_float3(0.f); ls.Radiance = make_float3(0.f); ls.SolidAnglePdf = 1.0f; ls.LightSampleableByBSDF = false;
+            return ls;
+        }
+        float lightDistance = sqrtf_(lightDistance2);
+        float2 u = random;
+        float sinThetaMax2 = radius2 / lightDistance2;
+        float cosThetaMax = sqrtf_(fmaxf_(0.0f, 1.0f - sinThetaMax2));
+        float phi = 2.0f * K_PI * u.x;
+        float cosTheta = lerpf(cosThetaMax, 1.0f, u.y);
+        float sinTheta = sqrtf_(fmaxf_(0.0f, 1.0f - sq(cosTheta)));
+        float sinTheta2 = sinTheta * sinTheta;
+        const float cLIGHT_SAMPING_EPSILON = 1e-10f;
+        float dc = lightDistance, dc2 = lightDistance2;
+        float ds = dc * cosTheta - sqrtf_(fmaxf_(cLIGHT_SAMPING_EPSILON, radius2 - dc2 * sinTheta2));
+        float cosAlpha = (dc2 + radius2 - sq(ds)) / (2.0f * dc * radius);
+        float sinAlpha = sqrtf_(fmaxf_(0.0f, 1.0f - sq(cosAlpha)));
+        float3 n = normalize(lightVector), tg, bt;
+        BranchlessONB(n, tg, bt);
+        float sinPhi, cosPhi; dm_sincos(phi, sinPhi, cosPhi);
+        float3 x = -tg, y = -bt, z = -n;
+        float3 radiusVector = (sinAlpha * cosPhi * x + sinAlpha * sinPhi * y) + cosAlpha * z;
+        ls.Position = position + radius * radiusVector;
+        ls.Normal = normalize(radiusVector);
+        ls.Radiance = radiance;
+        ls.SolidAnglePdf = 1.0f / (2.0f * K_PI * (1.0f - cosThetaMax));
+        ls.LightSampleableByBSDF = false;
+        return ls;
+    }
+    float GetPower() const { return 4 * K_PI * sq(radius) * K_PI * Luminance(radiance); }  // shaping flux factor = 1 for unshaped
+};
+
+// PolymorphicLight.hlsli:562-640. ToWorld uses the env map transform (PathTracerNEE.hlsli:16-33).
+struct EnvironmentQuadLight {
+    uint NodeX, NodeY, NodeDim; float Weight; float3 Radiance;
+    static EnvironmentQuadLight Create(const PolymorphicLightInfoFull& li) {
+        EnvironmentQuadLight e;
+        e.NodeX = li.Base.Direction1 >> 16; e.NodeY = li.Base.Direction1 & 0xFFFFu; e.NodeDim = li.Base.Direction2 >> 16;
+        e.Weight = asfloat(li.Base.Scalars); e.Radiance = UnpackLightColor(li.Base);
+        return e;
+    }
+    PolymorphicLightInfoFull Store(uint uniqueID) const {
+        PolymorphicLightInfoFull li; __builtin_memset(&li, 0, sizeof(li));
+        PackLightColor(Radiance, li.Base);
+        li.Base.Direction1 = (NodeX << 16) | NodeY;
+        li.Base.Direction2 = (NodeDim << 16);
+        li.Base.Scalars = asuint(Weight);
+        li.Base.ColorTypeAndFlags |= (uint)kEnvironmentQuad << kPolymorphicLightTypeShift;
+        li.Extended.UniqueID = uniqueID;
+        return li;
+    }
+    PolymorphicLightSample CalcSample(float2 random, float3 viewerPosition, const float3x4& envToWorld) const {
+        PolymorphicLightSample pls;
+        float2 subTexelPos = make_float2(((float)NodeX + random.x) / (float)NodeDim, ((float)NodeY + random.y) / (float)NodeDim);
+        float3 localDir = oct_to_ndir_equal_area_unorm(subTexelPos);
+        float3 worldDir = mul_vec_mat3(localDir, envToWorld);
+        pls.Position = viewerPosition + worldDir * DISTANT_LIGHT_DISTANCE;
+        pls.Normal = -worldDir;
+        pls.Radiance = Radiance;                                      // NEE_AT_SAMPLE_BAKED_ENVIRONMENT == 1
+        pls.SolidAnglePdf = (float)(NodeDim * NodeDim) / (4.0f * K_PI);
+        pls.LightSampleableByBSDF = true;
+        return pls;
+    }
+    float CalcSolidAnglePdfForMIS() const { return (float)(NodeDim * NodeDim) / (4.0f * K_PI); }
+};
+
+static inline uint DecodeLightType(const PolymorphicLightInfo& b) { return (b.ColorTypeAndFlags >> kPolymorphicLightTypeShift) & kPolymorphicLightTypeMask; }
+
+// PolymorphicLight.hlsli:642-676
+static inline PolymorphicLightSample PolymorphicLight_CalcSample(const PolymorphicLightInfoFull& li, float2 random, float3 viewerPosition, const float3x4& envToWorld) {
+    PolymorphicLightSample s; __builtin_memset(&s, 0, sizeof(s));
+    switch (DecodeLightType(li.Base)) {
+    case kSphere: s = SphereLight::Create(li).CalcSample(random, viewerPosition); break;
+    case kTriangle: s = TriangleLight::Create(li).CalcSample(random, viewerPosition); break;
+    case kEnvironmentQuad: s = EnvironmentQuadLight::Create(li).CalcSample(random, viewerPosition, envToWorld); break;
+    default: break;
+    }
+    if (s.SolidAnglePdf > 0) s.Radiance = s.Radiance * evaluateLightShaping(unpackLightShaping(li), viewerPosition, s.Position);
+    return s;
+}
+// PolymorphicLight.hlsli:700-724
+static inline float PolymorphicLight_GetPower(const PolymorphicLightInfoFull& li) {
+    switch (DecodeLightType(li.Base)) {
+    case kSphere: return SphereLight::Create(li).GetPower();
+    case kTriangle: return TriangleLight::Create(li).GetPower();
+    case kEnvironmentQuad: return EnvironmentQuadLight::Create(li).Weight;
+    default: return 0;
+    }
+}
+
+// The runtime light table (LightingTypes.hlsli:78-123 LightingControlData subset + the buffers LightSampler binds).
+struct LightTable {
+    const PolymorphicLightInfo* Lights; const PolymorphicLightInfoEx* LightsEx;
+    const uint* ProxyCounters; const uint* ProxyIndices;
+    uint TotalLightCount, SamplingProxyCount;
+    const uint* EnvLookupMap; uint EnvLookupDim;       // equal-area-octahedral texel -> env quad light index
+    float3x4 EnvToWorld, WorldToEnv;
+};
+// LightSampler.hlsli:100-146, 400-432 (NEEType==1 "power": global sampler only, local count == 0)
+struct LightSampler {
+    const LightTable* T;
+    bool IsEmpty() const { return T->SamplingProxyCount == 0; }
+    uint SampleGlobal(float rnd, float& pdf) const {
+        uint total = T->SamplingProxyCount;
+        uint idx = (uint)(rnd * (float)total);
+        if (idx > total - 1) idx = total - 1;
+        uint lightIndex = T->ProxyIndices[idx];
+        pdf = (float)T->ProxyCounters[lightIndex] / (float)total;
+        return lightIndex;
+    }
+    float SampleGlobalPDF(uint lightIndex) const { return (float)T->ProxyCounters[lightIndex] / (float)T->SamplingProxyCount; }
+    PolymorphicLightInfoFull LoadLight(uint index) const {
+        PolymorphicLightInfoFull f; f.Base = T->Lights[index]; __builtin_memset(&f.Extended, 0, sizeof(f.Extended));
+        if (f.Base.HasLightShaping()) f.Extended = T->LightsEx[index];
+        return f;
+    }
+    // :318-332 (localCount == 0 => localPdf == 0)
+    float ComputeLightVsBSDF_MIS_ForBSDF(uint lightIndex, float bsdfPdf, float solidAnglePdf, uint fullSampleCount) const {
+        float globalPdf = SampleGlobalPDF(lightIndex);
+        float lightAvgPdf = (0.0f + globalPdf) * (float)fullSampleCount;
+        return EvalMIS_Balance(1, bsdfPdf, 1, lightAvgPdf * solidAnglePdf);
+    }
+    // :334-345
+    float ComputeBSDFMISForEmissiveTriangle(uint lightIndex, float bsdfPdf, float3 viewerPosition, float3 lightSamplePosition, uint fullSamples) const {
+        if (bsdfPdf == 0 || lightIndex == RTXPT_INVALID_LIGHT_INDEX) return 1;
+        TriangleLight tl = TriangleLight::Create(LoadLight(lightIndex));
+        float solidAnglePdf = tl.CalcSolidAnglePdfForMIS(viewerPosition, lightSamplePosition);
+        return ComputeLightVsBSDF_MIS_ForBSDF(lightIndex, bsdfPdf, solidAnglePdf, fullSamples);
+    }
+    // :347-362
+    float ComputeBSDFMISForEnvironmentQuad(uint lightIndex, float bsdfPdf, uint fullSamples) const {
+        if (bsdfPdf == 0 || lightIndex == RTXPT_INVALID_LIGHT_INDEX) return 1;
+        EnvironmentQuadLight eq = EnvironmentQuadLight::Create(LoadLight(lightIndex));
+        return ComputeLightVsBSDF_MIS_ForBSDF(lightIndex, bsdfPdf, eq.CalcSolidAnglePdfForMIS(), fullSamples);
+    }
+    // :423-432
+    uint LookupEnvLightByDirection(float3 localDir) const {
+        if (T->EnvLookupDim == 0) return RTXPT_INVALID_LIGHT_INDEX;
+        float2 uv = ndir_to_oct_equal_area_unorm(localDir);
+        uint x = (uint)(uv.x * (float)T->EnvLookupDim), y = (uint)(uv.y * (float)T->EnvLookupDim);
+        if (x > T->EnvLookupDim - 1) x = T->EnvLookupDim - 1;     // Texture.Load out of range returns 0; uv==1 is clamped here instead
+        if (y > T->EnvLookupDim - 1) y = T->EnvLookupDim - 1;
+        return T->EnvLookupMap[y * T->EnvLookupDim + x];
+    }
+};
+
+#pragma clang force_cuda_host_device end
+} // namespace ptk

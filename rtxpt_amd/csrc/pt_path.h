@@ -1,0 +1,565 @@
+// mi355pt — per-vertex path logic of the reference-mode estimator, shared by the wavefront kernels.
+// One PathState is 80 bytes exactly like the reference's PathPayload (PathPayload.hlsli:19-21, PathState.hlsli:83-267);
+// in HBM it lives as five uint4 SoA streams (see pt_wavefront.hip) so that a wave reads/writes 1 KiB per stream instruction.
+// Function-by-function anchors (paths relative to /root/reference/Rtxpt/Shaders/):
+//   PathTracer/PathTracer.hlsli:40-45,47-91,182-208,217-380,382-404,407-503,505-762
+//   PathTracer/PathTracerNEE.hlsli:41-161,166-275,277-346          NEE: WRS candidates -> one shadow ray
+//   PathTracer/PathTracerNestedDielectrics.hlsli:24-128, PathTracer/Rendering/Materials/InteriorList.hlsli:28-248
+//   PathTracer/PathTracerHelpers.hlsli:126-219, PathTracer/Rendering/Materials/TexLODHelpers.hlsli:57-143
+//   PathTracerBridgeDonut.hlsli:152-256,280-428,543-564,612-887    Bridge::loadSurface & friends
+// Wavefront split of HandleHit: everything up to and including the NEE light sample happens in k_shade; the visibility
+// ray + "L += radiance" half of ProcessLightSample (PathTracerNEE.hlsli:199-265) is deferred to the shadow queue. The
+// deferred radiance is computed with the same operations, in the same order, as the reference computes it after the ray.
+#pragma once
+#include "pt_bsdf.h"
+#include "pt_rng.h"
+#include "pt_scene.h"
+
+namespace ptk {
+#pragma clang force_cuda_host_device begin
+
+static const float kMaxRayTravel = 1e15f;
+static const float kSpecularRoughnessThreshold = 0.25f;
+
+struct PathTracerCameraData {
+    float3 PosW; float NearZ; float3 DirectionW; float PixelConeSpreadAngle; float3 CameraU; float FarZ;
+    float3 CameraV; float FocalDistance; float3 CameraW; float AspectRatio; uint2 ViewportSize; float ApertureRadius; float _padding0;
+    float2 Jitter; float _padding1, _padding2;
+};
+static_assert(sizeof(PathTracerCameraData) == 112, "PathTracerCameraData layout");
+struct PtSettings {
+    uint bounceCount, diffuseBounceCount; float perPixelJitterAAScale, texLODBias, fireflyFilterThreshold, envMapDiffuseSampleMIPLevel;
+    uint NEEEnabled, NEEType, NEECandidateSamples, NEEFullSamples, enableRussianRoulette, nestedDielectricsQuality, enableLDSamplerForBSDF, diffuseBrdf, _pad[2];
+};
+static_assert(sizeof(PtSettings) == 64, "PtSettings layout");
+
+// TexLODHelpers.hlsli:57-123
+struct RayCone {
+    uint widthSpreadAngleFP16;
+    float getWidth() const { return f16tof32(widthSpreadAngleFP16 >> 16); }
+    float getSpreadAngle() const { return f16tof32(widthSpreadAngleFP16 & 0xffffu); }
+    static RayCone make(float width, float angle) { RayCone r; r.widthSpreadAngleFP16 = (f32tof16(width) << 16) | f32tof16(angle); return r; }
+    RayCone propagateDistance(float hitT) const { float angle = getSpreadAngle(), width = getWidth(); return make(angle * hitT + width, angle); }
+    static float SafeLog2(float x) { return dm_log2(clampf(x, FLT_MIN_, FLT_MAX_)); }
+    float computeLOD(float triLODConstant, float3 rayDir, float3 normal, bool moreDetailOnSlopes) const {
+        float lambda = triLODConstant;
+        float distTerm = fabsf(getWidth());
+        float normalTerm = fabsf(dot(rayDir, normal));
+        if (moreDetailOnSlopes) normalTerm = sqrtf_(normalTerm);
+        lambda += SafeLog2(distTerm / normalTerm);
+        return lambda;
+    }
+};
+// InteriorList.hlsli:28-248
+struct InteriorList {
+    static const uint kNoMaterial = 0xffffffffu, kMaterialMask = (1u << 28) - 1u, kNestedPriorityOffset = 28, kMaxNestedPriority = 15;
+    uint slots[2];
+    bool isEmpty() const { return slots[0] == 0; }
+    uint getTopNestedPriority() const { return slots[0] >> kNestedPriorityOffset; }
+    uint getTopMaterialID() const { return slots[0] != 0 ? (slots[0] & kMaterialMask) : kNoMaterial; }
+    uint getNextMaterialID() const { return slots[1] != 0 ? (slots[1] & kMaterialMask) : kNoMaterial; }
+    bool isTrueIntersection(uint nestedPriority) const { return nestedPriority == 0 || nestedPriority >= getTopNestedPriority(); }
+    void handleIntersection(uint materialID, uint nestedPriority, bool entering) {
+        if (nestedPriority == 0) nestedPriority = kMaxNestedPriority;
+        uint slot = (nestedPriority << kNestedPriorityOffset) | (materialID & kMaterialMask);
+        if (entering && slots[0] == 0) slots[0] = slot;
+        else if (!entering && slots[0] != 0 && (slots[0] & kMaterialMask) == materialID) slots[0] = 0;
+        else if (entering && slots[1] == 0) slots[1] = slot;
+        else if (!entering && slots[1] != 0 && (slots[1] & kMaterialMask) == materialID) slots[1] = 0;
+        if (slots[0] < slots[1]) { uint t = slots[0]; slots[0] = slots[1]; slots[1] = t; }
+    }
+};
+enum : uint {
+    PF_active = 1 << 0, PF_hit = 1 << 1, PF_transmission = 1 << 2, PF_specular = 1 << 3, PF_delta = 1 << 4,
+    PF_insideDielectricVolume = 1 << 5, PF_terminateAtNextBounce = 1 << 6, PF_enableThreadReorder = 1 << 9, PF_deltaOnlyPath = 1 << 12,
+};
+enum { PC_DiffuseBounces = 0, PC_RejectedHits = 1 };
+static const uint kVertexIndexBitCount = 10, kVertexIndexBitMask = (1u << 10) - 1u;
+
+// PathState.hlsli:83-267; the stableBranchID word (unused in reference mode) carries the sample index of the path
+struct PathState {
+    float3 origin; uint id; float3 dir; float sceneLength;
+    uint pack23[2]; uint pack45[2];
+    InteriorList interiorList; uint packedCounters; RayCone rayCone;
+    uint pack0, pack1, flagsAndVertexIndex, sampleIndex;
+
+    void SetFireflyFilterK_BsdfScatterPdf(float k, float pdf) { pack0 = (f32tof16(clampf(k, 0, HLF_MAX)) << 16) | f32tof16(clampf(pdf, 0, HLF_MAX)); }
+    float GetFireflyFilterK() const { return f16tof32(pack0 >> 16); }
+    float GetBsdfScatterPdf() const { return f16tof32(pack0 & 0xFFFFu); }
+    void SetPackedMISInfo_ThpRuRuCorrection(uint mis, float c) { pack1 = (mis << 16) | f32tof16(clampf(c, 0, HLF_MAX)); }
+    uint GetPackedMISInfo() const { return pack1 >> 16; }
+    float GetThpRuRuCorrection() const { return f16tof32(pack1 & 0xFFFFu); }
+    void SetThp(float3 thp) { thp = clamp3(thp, 0.f, HLF_MAX); pack23[0] = Fp32ToFp16NoClamp(make_float2(thp.x, thp.y)); pack23[1] = Fp32ToFp16NoClamp(make_float2(thp.z, 0.f)); }
+    float3 GetThp() const { float2 a = Fp16ToFp32(pack23[0]), b = Fp16ToFp32(pack23[1]); return make_float3(a.x, a.y, b.x); }
+    void SetL(float4 l) { pack45[0] = Fp32ToFp16NoClamp(make_float2(clampf(l.x, 0, HLF_MAX), clampf(l.y, 0, HLF_MAX))); pack45[1] = Fp32ToFp16NoClamp(make_float2(clampf(l.z, 0, HLF_MAX), clampf(l.w, 0, HLF_MAX))); }
+    float4 GetL() const { float2 a = Fp16ToFp32(pack45[0]), b = Fp16ToFp32(pack45[1]); return make_float4(a.x, a.y, b.x, b.y); }
+    bool hasFlag(uint f) const { return (flagsAndVertexIndex & (f << kVertexIndexBitCount)) != 0; }
+    void setFlag(uint f, bool v = true) { uint bit = f << kVertexIndexBitCount; if (v) flagsAndVertexIndex |= bit; else flagsAndVertexIndex &= ~bit; }
+    bool isActive() const { return hasFlag(PF_active); }
+    void terminate() { setFlag(PF_active, false); }
+    bool isTerminatingAtNextBounce() const { return hasFlag(PF_terminateAtNextBounce); }
+    void clearScatterEventFlags() { flagsAndVertexIndex &= ~((PF_transmission | PF_specular | PF_delta) << kVertexIndexBitCount); }
+    uint getCounter(uint type) const { return (packedCounters >> (type << 3)) & 0xff; }
+    void incrementCounter(uint type) { packedCounters += (1u << (type << 3)); }
+    uint getVertexIndex() const { return flagsAndVertexIndex & kVertexIndexBitMask; }
+    void incrementVertexIndex() { flagsAndVertexIndex += 1; }
+    void decrementVertexIndex() { flagsAndVertexIndex -= 1; }
+};
+// PathTracerTypes.hlsli:89-160
+struct NEEBSDFMISInfo {
+    bool LightSamplingEnabled, LightSamplingIsSSC; uint CandidateSamples, FullSamples;
+    static NEEBSDFMISInfo empty() { NEEBSDFMISInfo r; r.LightSamplingEnabled = false; r.LightSamplingIsSSC = false; r.CandidateSamples = 0; r.FullSamples = 0; return r; }
+    static NEEBSDFMISInfo Unpack16bit(uint p) { NEEBSDFMISInfo r; r.LightSamplingEnabled = (p & (1u << 15)) != 0; r.LightSamplingIsSSC = (p & (1u << 13)) != 0; r.CandidateSamples = (p >> 6) & 0x3F; r.FullSamples = p & 0x3F; return r; }
+    uint Pack16bit() const { return ((LightSamplingEnabled ? 1u : 0u) << 15) | ((LightSamplingIsSSC ? 1u : 0u) << 13) | ((CandidateSamples & 0x3F) << 6) | (FullSamples & 0x3F); }
+};
+struct LightSample {
+    float3 Li; float Distance; float3 Direction; uint LightIndex; float SelectionPdf, SolidAnglePdf; bool LightSampleableByBSDF;
+    bool Valid() const { return any_gt0(Li); }
+};
+struct SurfaceData { ShadingData shadingData; StandardBSDF bsdf; float interiorIoR; uint neeTriangleLightIndex; };
+// what k_shade hands to the shadow queue (the deferred half of ProcessLightSample)
+struct ShadowRequest { bool valid; float3 origin, dir; float tmax; float3 radiance; };
+
+// PathTracerHelpers.hlsli:164-219
+static inline float ComputeRayConeSpreadAngleExpansionByScatterPDF(float bsdfScatterPdf, float growthFactor) {
+    return growthFactor * 2.0f * FastACos(fmaxf_(-1.0f, 1.0f - (1.0f / bsdfScatterPdf) / (2.0f * K_PI)));
+}
+static inline float ComputeNewScatterFireflyFilterK(float currentK, float bouncePDF, float lobeP) {
+    const float minK = 0.00001f;
+    float angle = (bouncePDF == 0) ? 0.f : ComputeRayConeSpreadAngleExpansionByScatterPDF(bouncePDF, 1.0f);
+    const float k = 32;
+    float p = k / (k + angle * angle);
+    p *= FastSqrt(lobeP);
+    return fmaxf_(minK, currentK * p);
+}
+static inline float3 FireflyFilter(float3 signalIn, float threshold, float fireflyFilterK) {
+    float t = threshold * fireflyFilterK;
+    float maxR = Average(signalIn);
+    if (maxR > t) signalIn = signalIn / maxR * t;
+    return signalIn;
+}
+static inline float FireflyFilterShort(float signalAverage, float threshold, float fireflyFilterK) {
+    float t = threshold * fireflyFilterK;
+    return (signalAverage > t) ? (1.0f / signalAverage * t) : 1.0f;
+}
+// TexLODHelpers.hlsli:129-143
+static inline float computeRayConeTriangleLODValue(const float3 v[3], const float2 t[3], const float3x4& M) {
+    float2 tx10 = t[1] - t[0], tx20 = t[2] - t[0];
+    float Ta = fabsf(tx10.x * tx20.y - tx20.x * tx10.y);
+    float3 edge01 = xform_vector(M, v[1] - v[0]);
+    float3 edge02 = xform_vector(M, v[2] - v[0]);
+    float Pa = length(cross(edge01, edge02));
+    return 0.5f * RayCone::SafeLog2(Ta / Pa);
+}
+
+struct PathKernelContext {
+    DeviceScene sc; PtSettings S; PathTracerCameraData cam;
+
+    bool HasFinishedSurfaceBounces(uint vertexIndex, uint diffuseBounces) const {      // PathTracer.hlsli:40-45
+        if (S.bounceCount < vertexIndex) return true;
+        return diffuseBounces > S.diffuseBounceCount;
+    }
+    // EmptyPathInitialize + SetupPathPrimaryRay + Bridge::computeCameraRay (PathTracer.hlsli:47-119, BridgeDonut:543-564, PathTracerHelpers.hlsli:126-153)
+    PathState generate(uint px, uint py, uint sampleIndex) const {
+        PathState p; __builtin_memset(&p, 0, sizeof(p));
+        p.id = (px << 16) | py; p.sampleIndex = sampleIndex;
+        p.SetThp(make_float3(1.f));
+        p.setFlag(PF_active); p.setFlag(PF_deltaOnlyPath, true);
+        p.rayCone = RayCone::make(0, cam.PixelConeSpreadAngle);
+        p.SetL(make_float4(0, 0, 0, 0));
+        p.SetFireflyFilterK_BsdfScatterPdf(1.0f, 0.0f);
+        p.SetPackedMISInfo_ThpRuRuCorrection(NEEBSDFMISInfo::empty().Pack16bit(), 1.0f);
+        if (HasFinishedSurfaceBounces(p.getVertexIndex() + 1, p.getCounter(PC_DiffuseBounces))) p.setFlag(PF_terminateAtNextBounce);
+        SampleGeneratorVertexBase vb = SampleGeneratorVertexBase::make((px << 16) | py, 0, sampleIndex);
+        SampleSequenceGenerator sg = SampleSequenceGenerator::make(vb);
+        float2 r0 = sampleNext2D(sg);
+        float2 subPixelOffset = make_float2(cam.Jitter.x + (r0.x - 0.5f) * S.perPixelJitterAAScale, cam.Jitter.y + (r0.y - 0.5f) * S.perPixelJitterAAScale);
+        float2 dof = sampleNext2D(sg);
+        float2 pp = make_float2(((float)px + 0.5f + -subPixelOffset.x) / (float)cam.ViewportSize.x, ((float)py + 0.5f + subPixelOffset.y) / (float)cam.ViewportSize.y);
+        float2 ndc = make_float2(2.f * pp.x + -1.f, -2.f * pp.y + 1.f);
+        float3 org = cam.PosW;
+        float3 dir = (ndc.x * cam.CameraU + ndc.y * cam.CameraV) + cam.CameraW;
+        float2 ap = sample_disk(dof);
+        float3 rayTarget = org + dir;
+        org = org + cam.ApertureRadius * (ap.x * normalize(cam.CameraU) + ap.y * normalize(cam.CameraV));
+        dir = normalize(rayTarget - org);
+        float invCos = 1.f / dot(normalize(cam.CameraW), dir);
+        float tMin = cam.NearZ * invCos;
+        p.origin = org + dir * tMin; p.dir = dir;
+        return p;
+    }
+
+    float4 sampleTexture(uint textureIndexAndInfo, float lambdaNoDims, float2 uv) const {       // BridgeDonut:270-278, TextureSampler.hlsli:126-134
+        uint textureIndex = textureIndexAndInfo & 0xFFFFu, baseLOD = textureIndexAndInfo >> 24, mipLevels = (textureIndexAndInfo >> 16) & 0xFFu;
+        float lambda = 0.5f * (float)baseLOD + lambdaNoDims;
+        lambda = fminf_(lambda, fmaxf_((float)mipLevels - 5.0f, 0.0f));
+        return sample_trilinear(sc, sc.textures[textureIndex], uv, lambda);
+    }
+    static void computeTangentSpace(ShadingData& sd, float4 tangentW, bool ignoreTangent) {     // ShadingUtils.hlsli:110-139
+        float3 t3 = xyz(tangentW);
+        float NdotT = dot(t3, sd.N);
+        bool nonParallel = fabsf(NdotT) < 0.9999f;
+        bool nonZero = dot(t3, t3) > 0.f;
+        bool valid = tangentW.w != 0.f && nonZero && nonParallel;
+        if (!ignoreTangent && valid) { sd.T = normalize(t3 - sd.N * NdotT); sd.B = cross(sd.N, sd.T) * tangentW.w; }
+        else { sd.T = perp_stark(sd.N); sd.B = cross(sd.N, sd.T); }
+    }
+    static void adjustShadingNormal(ShadingData& sd, float4 tangentW, bool recompute, bool ignoreTangent) {   // ShadingUtils.hlsli:146-165
+        float3 Ng = sd.faceNCorrected;
+        float signN = dot(sd.N, Ng) >= 0.f ? 1.f : -1.f;
+        float3 Ns = signN * sd.N;
+        const float kCosThetaThreshold = 0.1f;
+        float cosTheta = dot(sd.V, Ns);
+        if (cosTheta <= kCosThetaThreshold) {
+            float t = saturate(cosTheta * (1.f / kCosThetaThreshold));
+            sd.N = signN * normalize(lerp3(Ng, Ns, t));
+        }
+        if (cosTheta <= kCosThetaThreshold || recompute) computeTangentSpace(sd, tangentW, ignoreTangent);
+    }
+    // Bridge::loadSurface (BridgeDonut:612-853): the divergent gather of the pipeline
+    SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone) const {
+        uint2 pinfo = sc.primInfo[prim];
+        uint subInst = pinfo.x, triangleIndex = pinfo.y;
+        uint2 ig = sc.subInstToInstGeom[subInst];
+        const InstanceDesc& inst = sc.instances[ig.x];
+        const SubInstanceData& si = sc.subInstances[subInst];
+        const GeometryDesc& g = sc.geometries[ig.y];
+        const float3x4& M = inst.transform;
+        float3 bary = make_float3(1.0f - (bu + bv), bu, bv);
+        const uint* idx = sc.indices + g.indexOffset + triangleIndex * 3;
+        uint vi[3] = {g.vertexOffset + idx[0], g.vertexOffset + idx[1], g.vertexOffset + idx[2]};
+        float3 vp[3]; float2 vt[3] = {make_float2(0, 0), make_float2(0, 0), make_float2(0, 0)};
+        for (int k = 0; k < 3; k++) vp[k] = make_float3(sc.positions[3 * vi[k]], sc.positions[3 * vi[k] + 1], sc.positions[3 * vi[k] + 2]);
+        float3 objPos = (vp[0] * bary.x + vp[1] * bary.y) + vp[2] * bary.z;
+        float2 texcoord = make_float2(0, 0);
+        if (g.flags & GEOM_HAS_UV) {
+            for (int k = 0; k < 3; k++) vt[k] = sc.uvs[vi[k]];
+            texcoord = (vt[0] * bary.x + vt[1] * bary.y) + vt[2] * bary.z;
+        }
+        float3 objFlatN = SafeNormalize(cross(vp[1] - vp[0], vp[2] - vp[0]));
+        float3 geometryNormal = make_float3(0.f);
+        if (g.flags & GEOM_HAS_NORMAL) {
+            float3 n[3];
+            for (int k = 0; k < 3; k++) {
+                n[k] = normalize(Unpack_RGB8_SNORM(sc.normals[vi[k]]));
+                if (dot(n[k], objFlatN) < 0.f) n[k] = -n[k];
+            }
+            geometryNormal = (n[0] * bary.x + n[1] * bary.y) + n[2] * bary.z;
+            geometryNormal = SafeNormalize(xform_vector(M, geometryNormal));
+        }
+        float4 tangent = make_float4(0, 0, 0, 0);
+        if (g.flags & GEOM_HAS_TANGENT) {
+            float4 tg[3];
+            for (int k = 0; k < 3; k++) tg[k] = Unpack_RGBA8_SNORM(sc.tangents[vi[k]]);
+            float3 t3 = (xyz(tg[0]) * bary.x + xyz(tg[1]) * bary.y) + xyz(tg[2]) * bary.z;
+            t3 = SafeNormalize(xform_vector(M, t3));
+            tangent = make_float4(t3, tg[0].w);
+        }
+        float3 flatNormal = SafeNormalize(xform_vector(M, objFlatN));
+        bool frontFacing = dot(-rayDir, flatNormal) >= 0.0f;
+        if (!(g.flags & GEOM_HAS_NORMAL)) geometryNormal = flatNormal;
+        float3 posW = xform_point(M, objPos);
+        float coneTexLODValue = computeRayConeTriangleLODValue(vp, vt, M);
+        float lambda = rayCone.computeLOD(coneTexLODValue, rayDir, flatNormal, true) + S.texLODBias;
+
+        ShadingData sd; __builtin_memset(&sd, 0, sizeof(sd));
+        sd.posW = posW; sd.V = -rayDir; sd.N = geometryNormal;
+        uint materialIndex = si.GlobalGeometryIndex_PTMaterialDataIndex & 0xFFFFu;
+        const PTMaterialData& material = sc.materials[materialIndex];
+        const uint mflags = material.Flags;
+        float4 texBase = make_float4(1, 1, 1, 1), texEmissive = make_float4(1, 1, 1, 1), texNormal = make_float4(0.5f, 0.5f, 1.0f, 0.f),
+               texMR = make_float4(1, 1, 1, 1), texTrans = make_float4(1, 1, 1, 1);
+        bool hasUV = (g.flags & GEOM_HAS_UV) != 0;
+        if (hasUV && (mflags & PTMaterialFlags_UseBaseOrDiffuseTexture)) texBase = sampleTexture(material.BaseOrDiffuseTextureIndex, lambda, texcoord);
+        if (hasUV && (mflags & PTMaterialFlags_UseEmissiveTexture)) texEmissive = sampleTexture(material.EmissiveTextureIndex, lambda, texcoord);
+        if (hasUV && (mflags & PTMaterialFlags_UseNormalTexture)) texNormal = sampleTexture(material.NormalTextureIndex, lambda, texcoord);
+        if (hasUV && (mflags & PTMaterialFlags_UseMetalRoughOrSpecularTexture)) texMR = sampleTexture(material.MetalRoughOrSpecularTextureIndex, lambda, texcoord);
+        if (hasUV && (mflags & PTMaterialFlags_UseTransmissionTexture)) texTrans = sampleTexture(material.TransmissionTextureIndex, lambda, texcoord);
+
+        float3 mGeometryNormal = normalize(geometryNormal), mShadingNormal = mGeometryNormal;
+        float3 baseColor = material.BaseOrDiffuseColor * xyz(texBase);
+        float roughness = material.Roughness * texMR.y;
+        float metalness = (mflags & PTMaterialFlags_MetalnessInRedChannel) ? material.Metalness * texMR.x : material.Metalness * texMR.z;
+        float transmission = material.TransmissionFactor, diffuseTransmission = material.DiffuseTransmissionFactor;
+        if (mflags & PTMaterialFlags_UseTransmissionTexture) { transmission *= texTrans.x; diffuseTransmission *= texTrans.x; }
+        float3 emissiveColor = material.EmissiveColor;
+        if (mflags & PTMaterialFlags_UseEmissiveTexture) emissiveColor = emissiveColor * xyz(texEmissive);
+        float matIoR = material.IoR;
+        if (hasUV && (mflags & PTMaterialFlags_UseNormalTexture)) {                                   // ApplyNormalMapRTXPT
+            float sqT = dot(xyz(tangent), xyz(tangent));
+            if (sqT != 0 && tangent.w != 0) {
+                float nx = (texNormal.x * 2.0f - 1.0f) * material.NormalTextureScale, ny = (texNormal.y * 2.0f - 1.0f) * material.NormalTextureScale, nz;
+                if (texNormal.z <= 0) nz = sqrtf_(saturate(1.0f - nx * nx - ny * ny)); else nz = fabsf(texNormal.z * 2.0f - 1.0f);
+                float sqN = (nx * nx + ny * ny) + nz * nz;
+                if (sqN != 0) {
+                    float nl = sqrtf_(sqN);
+                    float3 localNormal = make_float3(nx / nl, ny / nl, nz / nl);
+                    float3 tn = xyz(tangent) * (1.0f / sqrtf_(sqT));
+                    float3 bitangent = cross(mGeometryNormal, tn) * tangent.w;
+                    mShadingNormal = normalize((tn * localNormal.x + bitangent * localNormal.y) + mGeometryNormal * localNormal.z);
+                }
+            }
+        }
+        bool ignoreTangent = (mflags & PTMaterialFlags_IgnoreMeshTangentSpace) != 0;
+        computeTangentSpace(sd, tangent, ignoreTangent);
+        sd.faceNCorrected = frontFacing ? flatNormal : -flatNormal;
+        sd.vertexN = frontFacing ? geometryNormal : -geometryNormal;
+        sd.frontFacing = frontFacing;
+        sd.N = frontFacing ? mShadingNormal : -mShadingNormal;
+        bool thin = (mflags & PTMaterialFlags_ThinSurface) != 0;
+        sd.materialID = materialIndex;
+        sd.mtl = MaterialHeader::make();
+        { uint pr = 1 + (mflags >> PTMaterialFlags_NestedPriorityShift); sd.mtl.setNestedPriority(pr < InteriorList::kMaxNestedPriority ? pr : InteriorList::kMaxNestedPriority); }
+        sd.mtl.setThinSurface(thin);
+        adjustShadingNormal(sd, tangent, true, ignoreTangent);
+        sd.shadowNoLFadeout = material.ShadowNoLFadeout;
+        float bsdfSpecTrans = transmission * (1 - metalness), bsdfDiffTrans = diffuseTransmission * (1 - metalness);
+        sd.mtl.setActiveLobes(Lobe_All);
+        float f = (matIoR - 1.f) / (matIoR + 1.f);
+        float F0 = f * f;
+        StandardBSDFData bd;
+        bd.diffuse = lerp3(baseColor, make_float3(0.f), metalness);
+        bd.specular = lerp3(make_float3(F0), baseColor, metalness);
+        bd.roughness = roughness; bd.metallic = metalness;
+        bd.transmission = baseColor; bd.diffuseTransmission = bsdfDiffTrans; bd.specularTransmission = bsdfSpecTrans;
+        sd.IoR = 1.f;
+        bd.eta = sd.IoR / matIoR;
+        if (!sd.mtl.isThinSurface() && !sd.frontFacing) bd.eta = matIoR / sd.IoR;
+        SurfaceData ret;
+        ret.neeTriangleLightIndex = RTXPT_INVALID_LIGHT_INDEX;
+        if (sd.frontFacing && any_gt0(emissiveColor)) {
+            sd.emission = emissiveColor;
+            uint baseIndex = si.EmissiveLightMappingOffset;
+            if (baseIndex != 0xFFFFFFFFu) ret.neeTriangleLightIndex = baseIndex + triangleIndex;
+        }
+        ret.shadingData = sd; ret.bsdf.data = bd; ret.bsdf.diffuseModel = (int)S.diffuseBrdf; ret.interiorIoR = matIoR;
+        return ret;
+    }
+    float loadIoR(uint materialID) const { return (materialID >= sc.materialCount) ? 1.0f : sc.materials[materialID].IoR; }
+    float3 volumeTransmittance(uint materialID, float t) const {                                        // BridgeDonut:871-887
+        if (materialID >= sc.materialCount) return make_float3(1.f);
+        const PTMaterialData& m = sc.materials[materialID];
+        float3 c = clamp3(m.AttenuationColor, 1e-7f, 1.f);
+        float d = fmaxf_(1e-30f, m.AttenuationDistance);
+        float3 sigmaA = make_float3(-dm_log(c.x) / d, -dm_log(c.y) / d, -dm_log(c.z) / d);
+        return make_float3(dm_exp(-t * sigmaA.x), dm_exp(-t * sigmaA.y), dm_exp(-t * sigmaA.z));
+    }
+    void UpdatePathTravelled(PathState& path, float rayT) const {                                      // PathTracer.hlsli:382-404
+        path.incrementVertexIndex();
+        path.rayCone = path.rayCone.propagateDistance(rayT);
+        path.sceneLength = fminf_(path.sceneLength + rayT, kMaxRayTravel);
+    }
+    static void AccumulatePathRadiance(PathState& path, float3 radiance) { float4 L = path.GetL(); path.SetL(make_float4(L.x + radiance.x, L.y + radiance.y, L.z + radiance.z, L.w + 0.f)); }
+
+    // PathTracer.hlsli:407-503
+    void HandleMiss(PathState& path, float3 rayDir, float rayT) const {
+        UpdatePathTravelled(path, rayT);
+        float3 environmentEmission = make_float3(0.f);
+        NEEBSDFMISInfo misInfo = NEEBSDFMISInfo::Unpack16bit(path.GetPackedMISInfo());
+        LightSampler lightSampler; lightSampler.T = &sc.lights;
+        if (sc.envEnabled) {
+            float mipLevel = (path.getCounter(PC_DiffuseBounces) > 1) ? S.envMapDiffuseSampleMIPLevel : 0.f;
+            float3 localDir = mul_vec_mat3(rayDir, sc.envToLocal);
+            float3 Le = env_eval_local(sc, localDir, mipLevel);
+            float misWeight = 1.0f;
+            float bsdfScatterPdf = path.GetBsdfScatterPdf();
+            if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0) {
+                uint envIdx = lightSampler.LookupEnvLightByDirection(localDir);
+                misWeight = lightSampler.ComputeBSDFMISForEnvironmentQuad(envIdx, bsdfScatterPdf, misInfo.FullSamples);
+            }
+            environmentEmission = misWeight * Le;
+        }
+        if (S.fireflyFilterThreshold != 0) environmentEmission = FireflyFilter(environmentEmission, S.fireflyFilterThreshold, path.GetFireflyFilterK());
+        if (any_gt0(environmentEmission)) AccumulatePathRadiance(path, path.GetThp() * environmentEmission);
+        path.setFlag(PF_hit, false);
+        path.terminate();
+    }
+    float ComputeOutsideIoR(const InteriorList& il, uint materialID, bool entering) const {             // PathTracerNestedDielectrics.hlsli:24-44
+        uint outside = il.getTopMaterialID();
+        if (!entering) { if (outside == materialID) outside = il.getNextMaterialID(); }
+        if (outside == InteriorList::kNoMaterial) return 1.f;
+        return loadIoR(outside);
+    }
+    bool HandleNestedDielectrics(SurfaceData& sfd, PathState& path) const {                             // :49-113
+        if (S.nestedDielectricsQuality == 0) return true;
+        const uint kMaxRejected = (S.nestedDielectricsQuality == 1) ? 4u : 16u;
+        const bool avoidTermination = (S.nestedDielectricsQuality == 1);
+        if (sfd.shadingData.mtl.isThinSurface()) return true;
+        uint nestedPriority = sfd.shadingData.mtl.getNestedPriority();
+        if ((!avoidTermination || path.getCounter(PC_RejectedHits) < kMaxRejected) && !path.interiorList.isTrueIntersection(nestedPriority)) {
+            if (avoidTermination || path.getCounter(PC_RejectedHits) < kMaxRejected) {
+                path.incrementCounter(PC_RejectedHits);
+                path.interiorList.handleIntersection(sfd.shadingData.materialID, nestedPriority, sfd.shadingData.frontFacing);
+                path.origin = ComputeRayOrigin(sfd.shadingData.posW, -sfd.shadingData.faceNCorrected);
+                path.decrementVertexIndex();
+            } else path.terminate();
+            return false;
+        }
+        float outsideIoR = ComputeOutsideIoR(path.interiorList, sfd.shadingData.materialID, sfd.shadingData.frontFacing);
+        sfd.shadingData.IoR = outsideIoR;
+        sfd.bsdf.data.eta = sfd.shadingData.frontFacing ? (sfd.shadingData.IoR / sfd.interiorIoR) : (sfd.interiorIoR / sfd.shadingData.IoR);
+        return true;
+    }
+    // PathTracer.hlsli:217-380
+    bool GenerateScatterRay(const ShadingData& sd, const StandardBSDF& bsdf, PathState& path, const SampleGeneratorVertexBase& sgBase) const {
+        float4 u;
+        if (S.enableLDSamplerForBSDF && path.getCounter(PC_DiffuseBounces) < kDisableLowDiscrepancySamplingAfterDiffuseBounceCount)
+            u = SampleSequenceGenerator::Generate(3, sgBase, SGES_ScatterBSDF);
+        else
+            u = UniformSampleSequenceGenerator::Generate(3, sgBase, SGES_ScatterBSDF);
+        BSDFSample bs;
+        bool valid = bsdf.sample(sd, u, bs);
+        if (!valid) return false;
+        path.dir = bs.wo;
+        path.SetThp(path.GetThp() * bs.weight);
+        path.clearScatterEventFlags();
+        path.origin = sd.computeNewRayOrigin(bs.isLobe(Lobe_Reflection));
+        float roughness = bsdf.data.roughness;
+        bool isDiffuse = bs.isLobe(Lobe_DiffuseReflection) || bs.isLobe(Lobe_DiffuseTransmission) || roughness > kSpecularRoughnessThreshold;
+        if (isDiffuse) {
+            if (!(bs.isLobe(Lobe_DiffuseTransmission) && ((path.getVertexIndex() % 2) == 1))) path.incrementCounter(PC_DiffuseBounces);
+        } else path.setFlag(PF_specular);
+        if (bs.isLobe(Lobe_Transmission)) {
+            path.setFlag(PF_transmission);
+            if (S.nestedDielectricsQuality > 0 && !sd.mtl.isThinSurface()) {
+                path.interiorList.handleIntersection(sd.materialID, sd.mtl.getNestedPriority(), sd.frontFacing);
+                path.setFlag(PF_insideDielectricVolume, !path.interiorList.isEmpty());
+            }
+        }
+        if (bs.isLobe(Lobe_Delta)) path.setFlag(PF_delta);
+        else {
+            path.setFlag(PF_deltaOnlyPath, false);
+            path.rayCone = RayCone::make(path.rayCone.getWidth(), fminf_(path.rayCone.getSpreadAngle() + ComputeRayConeSpreadAngleExpansionByScatterPDF(bs.pdf, 0.3f), 2.0f * K_PI));
+        }
+        float fireflyFilterK = ComputeNewScatterFireflyFilterK(path.GetFireflyFilterK(), bs.pdf, bs.lobeP);
+        path.SetFireflyFilterK_BsdfScatterPdf(fireflyFilterK, bs.pdf);
+        path.setFlag(PF_enableThreadReorder, true);
+        return true;
+    }
+    // PathTracerNEE.hlsli:88-161
+    LightSample GenerateLightSample(const LightSampler& lightSampler, const ShadingData& sd, const StandardBSDF& bsdf, uint candidateSampleCount, UniformSampleSequenceGenerator& sg) const {
+        LightSample cand; __builtin_memset(&cand, 0, sizeof(cand));
+        float weightSum = 0, candWeight = 0;
+        for (uint i = 0; i < candidateSampleCount; i++) {
+            float selectionPdf = 0;
+            float rnd = sampleNext1D(sg);
+            uint lightIndex = lightSampler.SampleGlobal(rnd, selectionPdf);
+            PolymorphicLightInfoFull li = lightSampler.LoadLight(lightIndex);
+            float2 interior = sampleNext2D(sg);
+            PolymorphicLightSample ls = PolymorphicLight_CalcSample(li, interior, sd.posW, sc.envToWorld);
+            LightSample c;
+            float pdf = ls.SolidAnglePdf * selectionPdf;
+            c.Li = pdf > 0.f ? (ls.Radiance / pdf) : make_float3(0.f);
+            c.SolidAnglePdf = ls.SolidAnglePdf;
+            float3 surfToLight = ls.Position - sd.posW;
+            c.Distance = length(surfToLight);
+            c.Direction = surfToLight / fmaxf_(c.Distance, 1e-7f);
+            c.LightIndex = lightIndex; c.SelectionPdf = selectionPdf; c.LightSampleableByBSDF = ls.LightSampleableByBSDF;
+            float wrsWeight = max3(c.Li) * bsdf.evalPdf(sd, c.Direction);
+            float r = sampleNext1D(sg);
+            weightSum += wrsWeight;
+            float thr = saturate(wrsWeight / weightSum);
+            if (r < thr) { cand = c; candWeight = wrsWeight; }
+        }
+        cand.Li = cand.Li * (1.0f / (candWeight / weightSum));
+        return cand;
+    }
+    // HandleNEE (PathTracerNEE.hlsli:303-346) with ProcessLightSample (:185-275) split at the visibility ray. NEEFullSamples == 1.
+    uint HandleNEE(const PathState& pre, const ShadingData& sd, const StandardBSDF& bsdf, UniformSampleSequenceGenerator& sg, ShadowRequest& req) const {
+        req.valid = false;
+        LightSampler lightSampler; lightSampler.T = &sc.lights;
+        const uint fullSamples = 1;
+        bool hasNonDeltaLobes = (bsdf.getLobes() & Lobe_NonDelta) != 0;
+        bool applyNEE = hasNonDeltaLobes && !lightSampler.IsEmpty();
+        if (!applyNEE) return NEEBSDFMISInfo::empty().Pack16bit();
+        uint candidateSampleCount = S.NEECandidateSamples;
+        NEEBSDFMISInfo info; info.LightSamplingEnabled = true; info.LightSamplingIsSSC = false; info.CandidateSamples = candidateSampleCount; info.FullSamples = fullSamples;
+        LightSample ls = GenerateLightSample(lightSampler, sd, bsdf, candidateSampleCount, sg);
+        if (ls.Valid()) {
+            float faceSide = dot(sd.N, ls.Direction) >= 0 ? 1.f : -1.f;
+            float3 o = ComputeRayOrigin(sd.posW, sd.faceNCorrected * faceSide);
+            float fadeOut = (sd.shadowNoLFadeout > 0) ? saturate((dot(ls.Direction, sd.vertexN) - sd.shadowNoLFadeout) / (2.0f * sd.shadowNoLFadeout)) : 1.0f;
+            float globalCount = (float)candidateSampleCount;
+            float thisPdf = ls.SelectionPdf, otherPdf = 0.f, thisCount = globalCount;
+            float wrsMIS = EvalMIS_Balance(1, thisPdf, 1, otherPdf);
+            wrsMIS = wrsMIS / thisCount;
+            float scatterPdfForDir = bsdf.evalPdf(sd, ls.Direction);
+            float lightAvgPdf = (thisPdf + otherPdf) * (float)fullSamples;
+            float pathMIS = EvalMIS_Balance(1, lightAvgPdf * ls.SolidAnglePdf, 1, ls.LightSampleableByBSDF ? scatterPdfForDir : 0.f);
+            float3 Li = ls.Li * (fadeOut * wrsMIS * pathMIS / (float)fullSamples);
+            float4 bsdfThp = bsdf.eval(sd, ls.Direction);
+            float3 radiance = xyz(bsdfThp) * Li;
+            float radianceAvg = Average(radiance);
+            if (S.fireflyFilterThreshold != 0) {
+                float pdf = ls.SelectionPdf * ls.SolidAnglePdf;
+                float k = ComputeNewScatterFireflyFilterK(pre.GetFireflyFilterK(), pdf, 1.0f);
+                radiance = radiance * FireflyFilterShort(radianceAvg, S.fireflyFilterThreshold, k);
+            }
+            radiance = radiance * pre.GetThp();
+            req.valid = true; req.origin = o; req.dir = ls.Direction; req.tmax = ls.Distance * 0.9985f; req.radiance = radiance;
+        }
+        return info.Pack16bit();
+    }
+    bool HandleRussianRoulette(PathState& path, UniformSampleSequenceGenerator& sg) const {             // PathTracer.hlsli:182-208
+        if (!S.enableRussianRoulette) return false;
+        float rrVal = sqrtf_(Luminance(path.GetThp()));
+        float prob = saturate(0.85f - rrVal); prob = prob * prob;
+        prob = saturate(prob + fmaxf_(0.f, ((float)path.getVertexIndex() / (float)S.bounceCount - 0.4f)));
+        if (sampleNext1D(sg) < prob) return true;
+        path.SetPackedMISInfo_ThpRuRuCorrection(path.GetPackedMISInfo(), 1.0f / (1.0f - prob));
+        return false;
+    }
+    // PathTracer.hlsli:505-762 (reference mode), shadow test deferred through `req`
+    void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req) const {
+        req.valid = false;
+        const float3 rayOrigin = path.origin, rayDir = path.dir;
+        UpdatePathTravelled(path, hit.t);
+        SurfaceData sfd = loadSurface(hit.prim, hit.u, hit.v, rayDir, path.rayCone);
+        if (S.nestedDielectricsQuality > 0 && !path.interiorList.isEmpty()) {
+            float3 tr = volumeTransmittance(path.interiorList.getTopMaterialID(), hit.t);
+            path.SetThp(path.GetThp() * tr);
+        }
+        if (!HandleNestedDielectrics(sfd, path)) return;
+        const ShadingData& sd = sfd.shadingData; const StandardBSDF& bsdf = sfd.bsdf;
+        float3 surfaceEmission = make_float3(0.f);
+        NEEBSDFMISInfo misInfo = NEEBSDFMISInfo::Unpack16bit(path.GetPackedMISInfo());
+        if (any_gt0(sd.emission)) {
+            float misWeight = 1.0f;
+            float bsdfScatterPdf = path.GetBsdfScatterPdf();
+            if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0) {
+                LightSampler lightSampler; lightSampler.T = &sc.lights;
+                misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(sfd.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.FullSamples);
+            }
+            surfaceEmission = sd.emission * misWeight;
+        }
+        if (any_gt0(surfaceEmission)) {
+            if (S.fireflyFilterThreshold != 0) surfaceEmission = FireflyFilter(surfaceEmission, S.fireflyFilterThreshold, path.GetFireflyFilterK());
+            if (any_gt0(surfaceEmission)) AccumulatePathRadiance(path, path.GetThp() * surfaceEmission);
+        }
+        if (path.isTerminatingAtNextBounce()) { path.terminate(); return; }
+        float rr = path.GetThpRuRuCorrection();
+        path.SetThp(path.GetThp() * make_float3(rr));
+        SampleGeneratorVertexBase vb = SampleGeneratorVertexBase::make(path.id, path.getVertexIndex(), path.sampleIndex);
+        UniformSampleSequenceGenerator uniformSG = UniformSampleSequenceGenerator::make(vb, SGES_Base);
+        const PathState preScatterPath = path;
+        bool scatterValid = GenerateScatterRay(sd, bsdf, path, vb);
+        uint misPacked = S.NEEEnabled ? HandleNEE(preScatterPath, sd, bsdf, uniformSG, req) : NEEBSDFMISInfo::empty().Pack16bit();
+        path.SetPackedMISInfo_ThpRuRuCorrection(misPacked, path.GetThpRuRuCorrection());
+        if (!scatterValid) path.terminate();
+        bool shouldTerminate = HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces));
+        shouldTerminate |= HandleRussianRoulette(path, uniformSG);
+        if (shouldTerminate) path.setFlag(PF_terminateAtNextBounce);
+    }
+    // the deferred half: NEEResult::AccumulateRadiance (fp16, PathTracerTypes.hlsli:170-207) then AccumulatePathRadiance (PathTracer.hlsli:722-746)
+    static void ResolveShadow(uint pack45[2], float3 radiance) {
+        uint r0 = Fp32ToFp16(make_float2(0.f + radiance.x, 0.f + radiance.y)), r1 = Fp32ToFp16(make_float2(0.f + radiance.z, 0.f));
+        float2 a = Fp16ToFp32(r0), b = Fp16ToFp32(r1);
+        if (!(a.x > 0 || a.y > 0 || b.x > 0)) return;
+        float2 l0 = Fp16ToFp32(pack45[0]), l1 = Fp16ToFp32(pack45[1]);
+        pack45[0] = Fp32ToFp16NoClamp(make_float2(clampf(l0.x + a.x, 0, HLF_MAX), clampf(l0.y + a.y, 0, HLF_MAX)));
+        pack45[1] = Fp32ToFp16NoClamp(make_float2(clampf(l1.x + b.x, 0, HLF_MAX), clampf(l1.y + 0.f, 0, HLF_MAX)));
+    }
+};
+
+#pragma clang force_cuda_host_device end
+} // namespace ptk

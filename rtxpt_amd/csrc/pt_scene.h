@@ -1,0 +1,150 @@
+// mi355pt — device-side scene view: HBM data layout, texture / environment sampling, BVH traversal.
+//
+// HBM layout (all resident for the life of the scene; sized for 288 GB, nothing is streamed):
+//   vertex streams   indices u32 | positions float3 | uvs float2 | normals,tangents RGBA8_SNORM      (object space, as uploaded)
+//   GeometryDesc 32 B, InstanceDesc 64 B, SubInstanceData 32 B (Rtxpt/Shaders/SubInstanceData.h:23-46), PTMaterialData 128 B
+//   TriRecord 48 B   world-space v0/e1/e2 + global primitive id + flags, stored in BVH leaf order (one contiguous run per leaf)
+//   BvhNode 64 B     BVH2 node holding BOTH child boxes (one 64 B fetch decides both children) + two child references
+//   primInfo 8 B     global primitive id -> (subInstance, triangle index)
+//   texel pool       RGBA32F texels of every mip of every texture (mips built on the host in float so that device == oracle)
+//   light table      PolymorphicLightInfo 32 B (+Ex 16 B), proxy counters, proxy index array, env lookup map
+// The reference gets traversal from the DXR driver (Rtxpt/Shaders/PathTracerBridgeDonut.hlsli:993-1055); here it is explicit.
+#pragma once
+#include "pt_lights.h"
+
+namespace ptk {
+#pragma clang force_cuda_host_device begin
+
+// ---- MaterialPT.h:24-42
+enum : uint {
+    PTMaterialFlags_UseSpecularGlossModel = 0x1, PTMaterialFlags_UseMetalRoughOrSpecularTexture = 0x4,
+    PTMaterialFlags_UseBaseOrDiffuseTexture = 0x8, PTMaterialFlags_UseEmissiveTexture = 0x10, PTMaterialFlags_UseNormalTexture = 0x20,
+    PTMaterialFlags_UseTransmissionTexture = 0x80, PTMaterialFlags_MetalnessInRedChannel = 0x100, PTMaterialFlags_ThinSurface = 0x200,
+    PTMaterialFlags_IgnoreMeshTangentSpace = 1u << 12, PTMaterialFlags_NestedPriorityShift = 28,
+};
+// MaterialPT.h:45-77
+struct PTMaterialData {
+    float3 BaseOrDiffuseColor; uint Flags;
+    float3 SpecularColor; int _padding0;
+    float3 EmissiveColor; float ShadowNoLFadeout;
+    float Opacity, Roughness, Metalness, NormalTextureScale;
+    float _padding1, AlphaCutoff, TransmissionFactor; uint BaseOrDiffuseTextureIndex;
+    uint MetalRoughOrSpecularTextureIndex, EmissiveTextureIndex, NormalTextureIndex, OcclusionTextureIndex;
+    uint TransmissionTextureIndex; float IoR, ThicknessFactor, DiffuseTransmissionFactor;
+    float3 AttenuationColor; float AttenuationDistance;
+};
+static_assert(sizeof(PTMaterialData) == 128, "PTMaterialData must be 128 bytes");
+// SubInstanceData.h:23-46 (extended words hold element offsets into the shared streams)
+struct SubInstanceData {
+    enum : uint { Flags_AlphaTested = 1u << 16, Flags_ExcludeFromNEE = 1u << 17, Flags_AlphaOffsetOffset = 24 };
+    uint FlagsAndAlphaInfo, GlobalGeometryIndex_PTMaterialDataIndex, EmissiveLightMappingOffset, AnalyticProxyLightIndex;
+    uint IndexBufferIndex_VertexBufferIndex, IndexOffset, TexCoord1Offset, padding0;
+    float AlphaCutoff() const { return (float)(FlagsAndAlphaInfo >> Flags_AlphaOffsetOffset) / 255.0f; }
+    uint AlphaTextureIndex() const { return FlagsAndAlphaInfo & 0xFFFFu; }
+};
+static_assert(sizeof(SubInstanceData) == 32, "SubInstanceData must be 32 bytes");
+struct GeometryDesc { uint indexOffset, numIndices, vertexOffset, numVertices, flags, materialIndex, geomFlags, _pad; };
+enum : uint { GEOM_HAS_UV = 1, GEOM_HAS_NORMAL = 2, GEOM_HAS_TANGENT = 4, GEOMF_ALPHA_TESTED = 1, GEOMF_EXCLUDE_FROM_NEE = 2 };
+struct MeshDesc { uint firstGeometry, numGeometries; };
+struct InstanceDesc { float3x4 transform; uint meshIndex; uint _pad[3]; };
+static_assert(sizeof(InstanceDesc) == 64, "InstanceDesc must be 64 bytes");
+
+struct TriRecord { float3 v0; uint prim; float3 e1; uint flags; float3 e2; uint _pad; };    // flags bit0 non-opaque, bit1 exclude from NEE
+static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
+struct BvhNode { float3 lmin, lmax, rmin, rmax; uint left, right, _pad0, _pad1; };           // child ref: bit31 = leaf (first<<3 | count-1)
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_LEAF = 4, BVH_STACK = 64;
+
+struct TexInfo { uint w, h, mipLevels, _pad; unsigned long long base; uint mipOffset[16]; };   // offsets in texels relative to base
+
+struct DeviceScene {
+    const uint* indices; const float* positions; const float2* uvs; const uint* normals; const uint* tangents;
+    const GeometryDesc* geometries; const InstanceDesc* instances; const SubInstanceData* subInstances; const uint2* subInstToInstGeom;
+    const PTMaterialData* materials; uint materialCount;
+    const TexInfo* textures; const float4* texels;
+    TexInfo envTex; uint envEnabled; float3x4 envToWorld, envToLocal; float3 envColorMultiplier;
+    LightTable lights;
+    const BvhNode* nodes; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
+};
+
+struct HitInfo { float t; uint prim; float u, v; };
+
+// ---- texture sampling: wrap addressing, texel centres at (i+0.5)/dim, bilinear per mip, linear between mips
+static inline const float4& tex_texel(const DeviceScene& sc, const TexInfo& t, uint mip, int x, int y) {
+    uint mw = t.w >> mip; if (mw < 1u) mw = 1u;
+    uint mh = t.h >> mip; if (mh < 1u) mh = 1u;
+    int xi = x % (int)mw; if (xi < 0) xi += (int)mw;
+    int yi = y % (int)mh; if (yi < 0) yi += (int)mh;
+    return sc.texels[t.base + t.mipOffset[mip] + (unsigned long long)yi * mw + (uint)xi];
+}
+static inline float4 sample_bilinear(const DeviceScene& sc, const TexInfo& t, uint mip, float2 uv) {
+    uint mw = t.w >> mip; if (mw < 1u) mw = 1u;
+    uint mh = t.h >> mip; if (mh < 1u) mh = 1u;
+    float fx = uv.x * (float)mw - 0.5f, fy = uv.y * (float)mh - 0.5f;
+    float flx = floorf(fx), fly = floorf(fy);
+    float ax = fx - flx, ay = fy - fly;
+    flx = flx - floorf(flx / (float)mw) * (float)mw; fly = fly - floorf(fly / (float)mh) * (float)mh;
+    int x0 = (int)flx, y0 = (int)fly;
+    float4 a = lerp4(tex_texel(sc, t, mip, x0, y0), tex_texel(sc, t, mip, x0 + 1, y0), ax);
+    float4 b = lerp4(tex_texel(sc, t, mip, x0, y0 + 1), tex_texel(sc, t, mip, x0 + 1, y0 + 1), ax);
+    return lerp4(a, b, ay);
+}
+static inline float4 sample_trilinear(const DeviceScene& sc, const TexInfo& t, float2 uv, float lambda) {
+    float maxl = (float)(t.mipLevels - 1);
+    float l = clampf(lambda, 0.0f, maxl);
+    float l0 = floorf(l);
+    uint m0 = (uint)l0, m1 = m0 + 1; if (m1 > t.mipLevels - 1) m1 = t.mipLevels - 1;
+    float f = l - l0;
+    float4 a = sample_bilinear(sc, t, m0, uv);
+    if (f == 0.0f || m1 == m0) return a;
+    float4 b = sample_bilinear(sc, t, m1, uv);
+    return lerp4(a, b, f);
+}
+// EnvMap.hlsli:54-93 on the source lat-long image (world_to_latlong_map, MathHelpers.hlsli:92-104)
+static inline float2 dir_to_latlong(float3 d) {
+    float phi = dm_atan2(d.x, -d.z);
+    float u = phi * (0.5f * K_1_PI) + 0.5f;
+    float yc = clampf(d.y, -1.0f, 1.0f);
+    float theta = dm_atan2(sqrtf_(fmaxf_(0.0f, 1.0f - yc * yc)), yc);
+    return make_float2(u, theta * K_1_PI);
+}
+static inline float3 env_eval_local(const DeviceScene& sc, float3 localDir, float lod) {
+    float2 uv = dir_to_latlong(localDir);
+    uint mip = (uint)clampf(lod, 0.0f, (float)(sc.envTex.mipLevels - 1));
+    uint mhu = sc.envTex.h >> mip; if (mhu < 1u) mhu = 1u;
+    float mh = (float)mhu;
+    uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh);
+    float4 c = sample_trilinear(sc, sc.envTex, uv, lod);
+    return xyz(c) * sc.envColorMultiplier;
+}
+
+// ---- ray / triangle (Moeller-Trumbore, both sides, tmin < t < tmax); (u,v) = DXR barycentrics of vertices 1,2
+static inline bool intersect_tri(const TriRecord& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
+    float3 pvec = cross(d, tr.e2);
+    float det = dot(tr.e1, pvec);
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    float3 tvec = o - tr.v0;
+    u = dot(tvec, pvec) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    float3 qvec = cross(tvec, tr.e1);
+    v = dot(d, qvec) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot(tr.e2, qvec) * inv;
+    return (t > tmin) && (t < tmax);
+}
+// AlphaTestImpl (BridgeDonut:929-971)
+static inline bool alpha_test(const DeviceScene& sc, uint prim, float u, float v) {
+    uint2 pi = sc.primInfo[prim];
+    const SubInstanceData& si = sc.subInstances[pi.x];
+    if ((si.FlagsAndAlphaInfo & SubInstanceData::Flags_AlphaTested) == 0) return true;
+    const uint* idx = sc.indices + si.IndexOffset + pi.y * 3;
+    float2 t0 = sc.uvs[si.TexCoord1Offset + idx[0]], t1 = sc.uvs[si.TexCoord1Offset + idx[1]], t2 = sc.uvs[si.TexCoord1Offset + idx[2]];
+    float b0 = 1.0f - (u + v);
+    float2 tc = (t0 * b0 + t1 * u) + t2 * v;
+    float opacity = sample_bilinear(sc, sc.textures[si.AlphaTextureIndex()], 0, tc).w;
+    return opacity >= si.AlphaCutoff();
+}
+
+#pragma clang force_cuda_host_device end
+} // namespace ptk

@@ -1,0 +1,40 @@
+// mi355pt — wavefront kernels (declarations + HBM stream layout of the path pool and queues).
+//
+// Path pool (N = owned pixels x samples in flight; ALL samples of a pt_render call are resident at once — HBM is 288 GB):
+//   s0[N] uint4  origin.xyz | pixel id (x<<16|y)          s1[N] uint4  dir.xyz | sceneLength
+//   s2[N] uint4  thp fp16x4 (2 words) | L fp16x4 (2 words) s3[N] uint4  interiorList[2] | packedCounters | rayCone(fp16x2)
+//   s4[N] uint4  {fireflyK,bsdfPdf} | {MISinfo,RRcorr} | flags+vertexIndex | sampleIndex
+//   = 80 B per path, the reference's PathPayload size (Rtxpt/Shaders/PathTracer/PathTracerShared.h:21).
+//   hit[N] uint4 t | global primitive | bary u | bary v   (written by k_extend, read by k_shade)
+// Queues: extend queue = compacted u32 path indices (ping-pong); shadow queue = 3 x float4 per entry
+//   q0 origin.xyz|tmax, q1 dir.xyz|path index, q2 radiance.rgb (already multiplied by throughput, MIS, BSDF).
+// Queue appends use one atomic per wave64: ballot -> popcount prefix -> lane-0 atomicAdd -> broadcast.
+#pragma once
+#include "pt_path.h"
+#include "pt_traverse.h"
+#include <hip/hip_runtime.h>
+
+namespace ptk {
+
+struct PathPool { uint4* s0; uint4* s1; uint4* s2; uint4* s3; uint4* s4; uint4* hit; };
+struct ShadowQueue { float4* q0; float4* q1; float4* q2; };
+struct WaveCounters {           // device-resident counters / stats (one 256 B block)
+    uint extendCount[2]; uint shadowCount; uint _pad0;
+    unsigned long long hits, nodeVisitsExt, triTestsExt, nodeVisitsSh, triTestsSh;
+};
+
+void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st);
+void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st);
+void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr,
+                  ShadowQueue sq, WaveCounters* wc, hipStream_t st);
+void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st);
+void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st);
+void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, hipStream_t st);
+void launch_pack(const float4* accum, const uint* ownedPixels, uint numOwned, uint width, float4* dst, hipStream_t st);
+void launch_unpack(float4* accum, const uint* pixels, uint num, uint width, const float4* src, hipStream_t st);
+void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, float4* out, hipStream_t st);
+void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const uint* subInstTriOffset, uint numEmissiveSubInst, uint totalTris, uint lightBase,
+                          PolymorphicLightInfo* lights, PolymorphicLightInfoEx* lightsEx, hipStream_t st);
+void launch_probe(const PathKernelContext& k, int kind, const void* dIn, void* dOut, uint n, hipStream_t st);
+
+} // namespace ptk

@@ -1,0 +1,297 @@
+// mi355pt — wavefront kernels: generate / extend / shade / shadow / accumulate (+ bake and probe kernels).
+// The reference runs all of this as ONE DXR dispatch, one thread per pixel looping over bounces
+// (Rtxpt/Shaders/PathTracerSample.hlsl:200-250) and relies on SER to re-sort threads (:136-148). Here each stage is its own
+// kernel over a compacted queue, so every wave starts full regardless of how many paths died in the previous bounce.
+#include "pt_wavefront.h"
+
+namespace ptk {
+
+static const uint EXTEND_BLOCK = 128;     // 2 waves; LDS stack 64 entries x 128 threads x 4 B = 32 KiB per block
+
+__device__ __forceinline__ uint lane_id() { return __lane_id(); }
+// one atomic per wave: returns this lane's slot if `pred`, garbage otherwise
+__device__ __forceinline__ uint wave_append(bool pred, uint* counter) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    uint lane = lane_id();
+    uint leader = (uint)__ffsll((long long)mask) - 1u;
+    uint base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    return base + (uint)__popcll(mask & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ void wave_add64(unsigned long long v, unsigned long long* counter) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane_id() == 0 && v) atomicAdd(counter, v);
+}
+
+__device__ __forceinline__ void store_path(const PathPool& pool, uint i, const PathState& p) {
+    pool.s0[i] = make_uint4(asuint(p.origin.x), asuint(p.origin.y), asuint(p.origin.z), p.id);
+    pool.s1[i] = make_uint4(asuint(p.dir.x), asuint(p.dir.y), asuint(p.dir.z), asuint(p.sceneLength));
+    pool.s2[i] = make_uint4(p.pack23[0], p.pack23[1], p.pack45[0], p.pack45[1]);
+    pool.s3[i] = make_uint4(p.interiorList.slots[0], p.interiorList.slots[1], p.packedCounters, p.rayCone.widthSpreadAngleFP16);
+    pool.s4[i] = make_uint4(p.pack0, p.pack1, p.flagsAndVertexIndex, p.sampleIndex);
+}
+__device__ __forceinline__ PathState load_path(const PathPool& pool, uint i) {
+    PathState p;
+    uint4 a = pool.s0[i], b = pool.s1[i], c = pool.s2[i], d = pool.s3[i], e = pool.s4[i];
+    p.origin = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)); p.id = a.w;
+    p.dir = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z)); p.sceneLength = asfloat(b.w);
+    p.pack23[0] = c.x; p.pack23[1] = c.y; p.pack45[0] = c.z; p.pack45[1] = c.w;
+    p.interiorList.slots[0] = d.x; p.interiorList.slots[1] = d.y; p.packedCounters = d.z; p.rayCone.widthSpreadAngleFP16 = d.w;
+    p.pack0 = e.x; p.pack1 = e.y; p.flagsAndVertexIndex = e.z; p.sampleIndex = e.w;
+    return p;
+}
+
+__global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* __restrict__ queue) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    uint total = numOwned * spp;
+    if (i >= total) return;
+    uint s = i / numOwned, px = ownedPixels[i - s * numOwned];
+    PathState p = k.generate(px >> 16, px & 0xFFFFu, sampleFirst + s);
+    store_path(pool, i, p);
+    queue[i] = i;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(EXTEND_BLOCK) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc) {
+    __shared__ uint stack[BVH_STACK * EXTEND_BLOCK];
+    const uint count = *countPtr;
+    TraverseCounters ctr; ctr.nodeVisits = 0; ctr.triTests = 0;
+    for (uint i = blockIdx.x * EXTEND_BLOCK + threadIdx.x; i < count; i += gridDim.x * EXTEND_BLOCK) {
+        uint p = queue[i];
+        uint4 a = pool.s0[p], b = pool.s1[p];
+        float3 o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)), d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
+        HitInfo h = traverse<false, COUNT>(sc, o, d, 0.0f, kMaxRayTravel, stack + threadIdx.x, EXTEND_BLOCK, ctr);
+        pool.hit[p] = make_uint4(asuint(h.t), h.prim, asuint(h.u), asuint(h.v));
+    }
+    if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); }
+}
+
+__global__ void __launch_bounds__(256) k_shade(PathKernelContext k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
+                                               uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc) {
+    const uint count = *countInPtr;
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    bool inRange = i < count;
+    bool alive = false; bool isHit = false; uint p = 0;
+    ShadowRequest req; req.valid = false;
+    if (inRange) {
+        p = queueIn[i];
+        PathState path = load_path(pool, p);
+        uint4 hr = pool.hit[p];
+        HitInfo h; h.t = asfloat(hr.x); h.prim = hr.y; h.u = asfloat(hr.z); h.v = asfloat(hr.w);
+        if (h.prim == 0xFFFFFFFFu) k.HandleMiss(path, path.dir, kMaxRayTravel);
+        else { isHit = true; k.HandleHit(path, h, req); }
+        store_path(pool, p, path);
+        alive = path.isActive();
+    }
+    uint slot = wave_append(alive, countOutPtr);
+    if (alive) queueOut[slot] = p;
+    uint sslot = wave_append(req.valid, &wc->shadowCount);
+    if (req.valid) {
+        sq.q0[sslot] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
+        sq.q1[sslot] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
+        sq.q2[sslot] = make_float4(req.radiance.x, req.radiance.y, req.radiance.z, 0.f);
+    }
+    wave_add64(isHit ? 1ull : 0ull, &wc->hits);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(EXTEND_BLOCK) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc) {
+    __shared__ uint stack[BVH_STACK * EXTEND_BLOCK];
+    const uint count = *countPtr;
+    TraverseCounters ctr; ctr.nodeVisits = 0; ctr.triTests = 0;
+    for (uint i = blockIdx.x * EXTEND_BLOCK + threadIdx.x; i < count; i += gridDim.x * EXTEND_BLOCK) {
+        float4 a = sq.q0[i], b = sq.q1[i];
+        HitInfo h = traverse<true, COUNT>(sc, make_float3(a.x, a.y, a.z), make_float3(b.x, b.y, b.z), 0.0f, a.w, stack + threadIdx.x, EXTEND_BLOCK, ctr);
+        if (h.prim == 0xFFFFFFFFu) {                       // visible: nothing committed (BridgeDonut:1026)
+            float4 r = sq.q2[i];
+            uint p = asuint(b.w);
+            uint4 c = pool.s2[p];
+            uint pack45[2] = {c.z, c.w};
+            PathKernelContext::ResolveShadow(pack45, make_float3(r.x, r.y, r.z));
+            c.z = pack45[0]; c.w = pack45[1];
+            pool.s2[p] = c;
+        }
+    }
+    if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsSh); wave_add64(ctr.triTests, &wc->triTestsSh); }
+}
+
+// CommitPixel + AccumulationPass (PathTracer.hlsli:165-169, AccumulationPass.hlsl:36-66): samples folded in order with weight 1/(n+1)
+__global__ void __launch_bounds__(256) k_accumulate(PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint spp, float4* __restrict__ accum, uint accumCountBase, uint width) {
+    uint kpx = blockIdx.x * 256u + threadIdx.x;
+    if (kpx >= numOwned) return;
+    uint px = ownedPixels[kpx];
+    uint addr = (px & 0xFFFFu) * width + (px >> 16);
+    float4 acc = accum[addr];
+    for (uint s = 0; s < spp; s++) {
+        uint4 c = pool.s2[s * numOwned + kpx];
+        float2 l0 = Fp16ToFp32(c.z), l1 = Fp16ToFp32(c.w);
+        float4 col = make_float4(l0.x, l0.y, l1.x, 1.0f);
+        float blend = 1.0f / (float)(accumCountBase + s + 1u);
+        acc = (blend < 1.f) ? lerp4(acc, col, blend) : col;
+    }
+    accum[addr] = acc;
+}
+
+__global__ void __launch_bounds__(EXTEND_BLOCK) k_trace_probe(DeviceScene sc, const float4* __restrict__ rays, uint n, float4* __restrict__ outClosest, uint* __restrict__ outVisible) {
+    __shared__ uint stack[BVH_STACK * EXTEND_BLOCK];
+    TraverseCounters ctr; ctr.nodeVisits = 0; ctr.triTests = 0;
+    for (uint i = blockIdx.x * EXTEND_BLOCK + threadIdx.x; i < n; i += gridDim.x * EXTEND_BLOCK) {
+        float4 a = rays[2 * i], b = rays[2 * i + 1];
+        float3 o = make_float3(a.x, a.y, a.z), d = make_float3(b.x, b.y, b.z);
+        if (outClosest) {
+            HitInfo h = traverse<false, false>(sc, o, d, a.w, b.w, stack + threadIdx.x, EXTEND_BLOCK, ctr);
+            outClosest[i] = make_float4(h.t, asfloat(h.prim), h.u, h.v);
+        } else {
+            HitInfo h = traverse<true, false>(sc, o, d, a.w, b.w, stack + threadIdx.x, EXTEND_BLOCK, ctr);
+            outVisible[i] = (h.prim == 0xFFFFFFFFu) ? 1u : 0u;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pack(const float4* __restrict__ accum, const uint* __restrict__ pixels, uint num, uint width, float4* __restrict__ dst) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= num) return;
+    uint px = pixels[i]; dst[i] = accum[(px & 0xFFFFu) * width + (px >> 16)];
+}
+__global__ void __launch_bounds__(256) k_unpack(float4* __restrict__ accum, const uint* __restrict__ pixels, uint num, uint width, const float4* __restrict__ src) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= num) return;
+    uint px = pixels[i]; accum[(px & 0xFFFFu) * width + (px >> 16)] = src[i];
+}
+
+// BuildMIPDescentImportanceMapCS (Rtxpt/Lighting/Distant/EnvMapImportanceSamplingBaker.hlsl:57-90) on the lat-long source
+__global__ void __launch_bounds__(256) k_env_importance(DeviceScene sc, uint dim, uint sx, uint sy, float4* __restrict__ out) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= dim * dim) return;
+    uint x = i % dim, y = i / dim;
+    float L = 0.f; float3 R = make_float3(0.f);
+    const float invSamples = 1.f / (float)(sx * sy);
+    for (uint j = 0; j < sy; j++) for (uint ii = 0; ii < sx; ii++) {
+        float2 p = make_float2(((float)(x * sx + ii) + 0.5f) / (float)(dim * sx), ((float)(y * sy + j) + 0.5f) / (float)(dim * sy));
+        float3 dir = oct_to_ndir_equal_area_unorm(p);
+        float2 uv = dir_to_latlong(dir); float mh = (float)sc.envTex.h; uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh);
+        float3 radiance = xyz(sample_trilinear(sc, sc.envTex, uv, 0.f));
+        L += (Luminance(radiance) + Average(radiance)) * 0.5f;
+        R += radiance;
+    }
+    out[i] = make_float4(R.x * invSamples, R.y * invSamples, R.z * invSamples, L * invSamples);
+}
+
+// BakeEmissiveTriangles (Rtxpt/Lighting/LightsBaker.hlsl:544-716): one thread per emissive triangle, output in sub-instance order
+__global__ void __launch_bounds__(256) k_bake_emissive(DeviceScene sc, const uint* __restrict__ subInstList, const uint* __restrict__ subInstTriOffset, uint numEmissiveSubInst,
+                                                       uint totalTris, uint lightBase, PolymorphicLightInfo* __restrict__ lights, PolymorphicLightInfoEx* __restrict__ lightsEx) {
+    uint t = blockIdx.x * 256u + threadIdx.x; if (t >= totalTris) return;
+    uint lo = 0, hi = numEmissiveSubInst;                 // last k with offset[k] <= t
+    while (hi - lo > 1) { uint mid = (lo + hi) >> 1; if (subInstTriOffset[mid] <= t) lo = mid; else hi = mid; }
+    uint s = subInstList[lo], tri = t - subInstTriOffset[lo];
+    uint2 ig = sc.subInstToInstGeom[s];
+    const InstanceDesc& inst = sc.instances[ig.x];
+    const GeometryDesc& g = sc.geometries[ig.y];
+    const PTMaterialData& mat = sc.materials[g.materialIndex];
+    const uint* idx = sc.indices + g.indexOffset + 3u * tri;
+    uint i0 = g.vertexOffset + idx[0], i1 = g.vertexOffset + idx[1], i2 = g.vertexOffset + idx[2];
+    const float* P = sc.positions;
+    float3 p0 = xform_point(inst.transform, make_float3(P[3 * i0], P[3 * i0 + 1], P[3 * i0 + 2]));
+    float3 p1 = xform_point(inst.transform, make_float3(P[3 * i1], P[3 * i1 + 1], P[3 * i1 + 2]));
+    float3 p2 = xform_point(inst.transform, make_float3(P[3 * i2], P[3 * i2 + 1], P[3 * i2 + 2]));
+    float3 radiance = mat.EmissiveColor;
+    if ((mat.Flags & PTMaterialFlags_UseEmissiveTexture) && (g.flags & GEOM_HAS_UV)) {
+        float2 uv0 = sc.uvs[i0], uv1 = sc.uvs[i1], uv2 = sc.uvs[i2];
+        float2 e0 = uv1 - uv0, e1 = uv2 - uv1, e2 = uv0 - uv2;
+        float l0 = length(e0), l1 = length(e1), l2 = length(e2);
+        float2 shortE, longE1, longE2;
+        if (l0 < l1 && l0 < l2) { shortE = e0; longE1 = e1; longE2 = e2; } else if (l1 < l2) { shortE = e1; longE1 = e2; longE2 = e0; } else { shortE = e2; longE1 = e0; longE2 = e1; }
+        float2 sg = shortE * (2.0f / 3.0f); float2 lg = (longE1 + longE2) * (1.0f / 3.0f);
+        const TexInfo& tex = sc.textures[mat.EmissiveTextureIndex & 0xFFFFu];
+        float fw = fmaxf_(length(make_float2(sg.x * (float)tex.w, sg.y * (float)tex.h)), length(make_float2(lg.x * (float)tex.w, lg.y * (float)tex.h)));
+        float lod = RayCone::SafeLog2(fw);
+        float2 c = (uv0 + uv1 + uv2) * (1.0f / 3.0f);
+        radiance = radiance * xyz(sample_trilinear(sc, tex, c, lod));
+    }
+    radiance = max3v(radiance, make_float3(0.f));
+    bool isFlipped = det3(inst.transform) < 0.f;
+    TriangleLight tl; tl.base = p0;
+    if (!isFlipped) { tl.edge1 = p1 - p0; tl.edge2 = p2 - p0; } else { tl.edge1 = p2 - p0; tl.edge2 = p1 - p0; }
+    if (fmaxf_(radiance.x, fmaxf_(radiance.y, radiance.z)) < 1e-7f) radiance = make_float3(0.f);
+    tl.radiance = radiance; tl.normal = make_float3(0.f); tl.surfaceArea = 0;
+    PolymorphicLightInfoFull lf = tl.Store(0);
+    lights[lightBase + t] = lf.Base; lightsEx[lightBase + t] = lf.Extended;
+}
+
+// known-answer probes for the tests: the device evaluates leaf functions so they can be compared bit-for-bit with the oracle
+__global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, const float* __restrict__ in, float* __restrict__ out, uint n) {
+    uint i = blockIdx.x * 64u + threadIdx.x; if (i >= n) return;
+    switch (kind) {
+    case 0: { const float* p = in + 3 * i; int fn = (int)p[0]; float x = p[1], y = p[2]; float r;      // dmath: (fn, x, y)
+        switch (fn) { case 0: r = dm_sin(x); break; case 1: r = dm_cos(x); break; case 2: r = dm_exp2(x); break; case 3: r = dm_log2(x); break;
+                      case 4: r = dm_atan2(y, x); break; case 5: r = dm_pow(x, y); break; case 6: r = FastACos(x); break; default: r = FastSqrt(x); break; }
+        out[i] = r; } break;
+    case 1: { float x = in[i]; uint hbits = f32tof16(x); out[2 * i] = asfloat(hbits); out[2 * i + 1] = f16tof32(hbits); } break;          // fp16 round trip
+    case 2: { const uint* p = reinterpret_cast<const uint*>(in) + 6 * i;                                   // sample stream: pixel, vertex, sample, seed, kind, count(<=8)
+        SampleGeneratorVertexBase vb = SampleGeneratorVertexBase::make(p[0], p[1], p[2]);
+        uint cnt = p[5] > 8 ? 8 : p[5];
+        if (p[4] == 0) { float4 v = SampleSequenceGenerator::Generate(cnt, vb, p[3]); out[8 * i] = v.x; out[8 * i + 1] = v.y; out[8 * i + 2] = v.z; out[8 * i + 3] = v.w; }
+        else if (p[4] == 1) { float4 v = UniformSampleSequenceGenerator::Generate(cnt, vb, p[3]); out[8 * i] = v.x; out[8 * i + 1] = v.y; out[8 * i + 2] = v.z; out[8 * i + 3] = v.w; }
+        else if (p[4] == 2) { UniformSampleSequenceGenerator g = UniformSampleSequenceGenerator::make(vb, p[3]); for (uint j = 0; j < cnt; j++) out[8 * i + j] = sampleNext1D(g); }
+        else { SampleSequenceGenerator g = SampleSequenceGenerator::make(vb, p[3], p[4] == 4); for (uint j = 0; j < cnt; j++) out[8 * i + j] = sampleNext1D(g); } } break;
+    case 3: { const float* p = in + 24 * i;                                                              // bsdf probe: params[14], thin, model, wi[3], w[3], mode
+        ShadingData sd; __builtin_memset(&sd, 0, sizeof(sd));
+        sd.N = make_float3(0, 0, 1); sd.T = make_float3(1, 0, 0); sd.B = make_float3(0, 1, 0); sd.V = make_float3(p[16], p[17], p[18]);
+        sd.faceNCorrected = sd.N; sd.vertexN = sd.N; sd.frontFacing = true; sd.mtl = MaterialHeader::make(); sd.mtl.setActiveLobes(Lobe_All); sd.mtl.setThinSurface(p[14] != 0.f);
+        StandardBSDF b; b.diffuseModel = (int)p[15];
+        b.data.diffuse = make_float3(p[0], p[1], p[2]); b.data.specular = make_float3(p[3], p[4], p[5]); b.data.roughness = p[6]; b.data.metallic = p[7];
+        b.data.transmission = make_float3(p[8], p[9], p[10]); b.data.diffuseTransmission = p[11]; b.data.specularTransmission = p[12]; b.data.eta = p[13];
+        float* o = out + 10 * i;
+        if (p[22] == 0.f) { float3 wo = make_float3(p[19], p[20], p[21]); float4 e = b.eval(sd, wo); o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = e.w; o[4] = b.evalPdf(sd, wo); o[5] = (float)b.getLobes(); o[6] = o[7] = o[8] = o[9] = 0.f; }
+        else { BSDFSample s; __builtin_memset(&s, 0, sizeof(s)); bool v = b.sample(sd, make_float4(p[19], p[20], p[21], 0), s);
+               o[0] = s.wo.x; o[1] = s.wo.y; o[2] = s.wo.z; o[3] = s.pdf; o[4] = s.weight.x; o[5] = s.weight.y; o[6] = s.weight.z; o[7] = (float)s.lobe; o[8] = s.lobeP; o[9] = v ? 1.f : 0.f; } } break;
+    case 4: { const uint* p = reinterpret_cast<const uint*>(in) + 3 * i;                                   // camera ray: px, py, sampleIndex
+        PathState ps = k.generate(p[0], p[1], p[2]);
+        out[6 * i] = ps.origin.x; out[6 * i + 1] = ps.origin.y; out[6 * i + 2] = ps.origin.z; out[6 * i + 3] = ps.dir.x; out[6 * i + 4] = ps.dir.y; out[6 * i + 5] = ps.dir.z; } break;
+    default: break;
+    }
+}
+
+static inline uint grid_for(uint count, uint block, uint maxBlocks) { uint g = (count + block - 1) / block; if (g < 1) g = 1; if (g > maxBlocks) g = maxBlocks; return g; }
+
+void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st) {
+    uint total = numOwned * spp;
+    hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, st, k, pool, ownedPixels, numOwned, sampleFirst, spp, queue);
+}
+void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st) {
+    uint g = grid_for(count, EXTEND_BLOCK, 256 * 5 * 8);
+    if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(EXTEND_BLOCK), 0, st, sc, pool, queue, countPtr, wc);
+    else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(EXTEND_BLOCK), 0, st, sc, pool, queue, countPtr, wc);
+}
+void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, hipStream_t st) {
+    hipLaunchKernelGGL(k_shade, dim3((countIn + 255) / 256), dim3(256), 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+}
+void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st) {
+    uint g = grid_for(count, EXTEND_BLOCK, 256 * 5 * 8);
+    if (counters) hipLaunchKernelGGL((k_shadow<true>), dim3(g), dim3(EXTEND_BLOCK), 0, st, sc, pool, sq, countPtr, wc);
+    else hipLaunchKernelGGL((k_shadow<false>), dim3(g), dim3(EXTEND_BLOCK), 0, st, sc, pool, sq, countPtr, wc);
+}
+void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
+    hipLaunchKernelGGL(k_accumulate, dim3((numOwned + 255) / 256), dim3(256), 0, st, pool, ownedPixels, numOwned, spp, accum, accumCountBase, width);
+}
+void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, hipStream_t st) {
+    hipLaunchKernelGGL(k_trace_probe, dim3(grid_for(n, EXTEND_BLOCK, 256 * 5 * 8)), dim3(EXTEND_BLOCK), 0, st, sc, rays, n, outClosest, outVisible);
+}
+void launch_pack(const float4* accum, const uint* pixels, uint num, uint width, float4* dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack, dim3((num + 255) / 256), dim3(256), 0, st, accum, pixels, num, width, dst);
+}
+void launch_unpack(float4* accum, const uint* pixels, uint num, uint width, const float4* src, hipStream_t st) {
+    hipLaunchKernelGGL(k_unpack, dim3((num + 255) / 256), dim3(256), 0, st, accum, pixels, num, width, src);
+}
+void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, float4* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_env_importance, dim3((dim * dim + 255) / 256), dim3(256), 0, st, sc, dim, sx, sy, out);
+}
+void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const uint* subInstTriOffset, uint numEmissiveSubInst, uint totalTris, uint lightBase,
+                          PolymorphicLightInfo* lights, PolymorphicLightInfoEx* lightsEx, hipStream_t st) {
+    if (!totalTris) return;
+    hipLaunchKernelGGL(k_bake_emissive, dim3((totalTris + 255) / 256), dim3(256), 0, st, sc, subInstList, subInstTriOffset, numEmissiveSubInst, totalTris, lightBase, lights, lightsEx);
+}
+void launch_probe(const PathKernelContext& k, int kind, const void* dIn, void* dOut, uint n, hipStream_t st) {
+    hipLaunchKernelGGL(k_probe, dim3((n + 63) / 64), dim3(64), 0, st, k, kind, (const float*)dIn, (float*)dOut, n);
+}
+
+} // namespace ptk
