@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric: Mrays/s + ms/frame at 4K, 4 spp, 8 bounces, Bistro).
+
+A "step" is one pt_render() of the whole frame: generate -> {extend, shade, shadow}* -> accumulate for 4 accumulated
+samples of the 3840x2160 bistro-like scene (the real Bistro asset is unobtainable offline), plus, for
+N > 1, the single gather of the packed radiance tiles to rank 0 (RCCL over xGMI). Scene, BVH, textures and light tables are
+resident in HBM before the timed region; nothing is uploaded inside it.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line. `value` = (extend + shadow rays of all ranks) / wall time of the K timed steps (max over ranks).
+The frame is fixed as N grows (pixel-tile sharding) => "scaling": "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+# algorithmic bytes: extend ray 52 B fixed + BVH: 64 B per node visit + 48 B per triangle test
+B_EXTEND_FIXED, B_NODE, B_TRI, B_SHADE, B_SHADOW_FIXED = 52.0, 64.0, 48.0, 656.0, 80.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--scale", type=float, default=1.0, help="triangle-count scale of the bistro-like generator (1.0 = 2.8 M triangles)")
+    ap.add_argument("--tex", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes, parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the library has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    sc, cam = scenes.bistro_like(scale=args.scale, tex_size=args.tex)
+    S = scenes.default_settings()                 # 8 bounces, NEE (emissive triangles + env quads), Russian roulette
+    W, H, SPP = args.width, args.height, args.spp
+    camd = scenes.bridge_camera(W, H, **cam)
+    g = pt.PathTracer(device=local_rank, shard_rank=rank, shard_count=world)
+    g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(W, H)
+    n_owned, packed_bytes = g.shard_info()
+    counts = [parallel.shard_pixels(W, H, r, world).size for r in range(world)] if world > 1 else [n_owned]
+    send = torch.empty((n_owned, 4), dtype=torch.float32, device="cuda")
+
+    def step():
+        g.reset_accumulation()
+        st = g.render(0, SPP)
+        if world > 1:
+            g.pack_shard(send.data_ptr(), packed_bytes)
+            got = parallel.gather_packed(send, rank, world, dist, counts)
+            if rank == 0:
+                for r in range(1, world):
+                    buf = got[r].contiguous()
+                    g.unpack_shard(buf.data_ptr(), buf.numel() * 4, r)
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+    rays_local = float(sum(s["extendRays"] + s["shadowRays"] for s in stats))
+    tl = torch.tensor([elapsed, rays_local], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tl[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rsum = tl[1:2].clone(); dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+        elapsed, rays_total = float(tmax.item()), float(rsum.item())
+    else:
+        rays_total = rays_local
+
+    # roofline of the dominant kernel (k_extend): one extra, untimed step with the in-kernel BVH counters enabled gives the mean
+    # node visits / triangle tests per ray; the kernel time comes from the HIP events recorded on the library's stream in the TIMED steps
+    g.set_counters(True); g.reset_accumulation(); cst = g.render(0, SPP); g.set_counters(False)
+    nodes_per_ext = cst["nodeVisitsExtend"] / max(1, cst["extendRays"]); tris_per_ext = cst["triTestsExtend"] / max(1, cst["extendRays"])
+    nodes_per_sh = cst["nodeVisitsShadow"] / max(1, cst["shadowRays"]); tris_per_sh = cst["triTestsShadow"] / max(1, cst["shadowRays"])
+    ext_ms = sum(s["extendKernelMs"] for s in stats); ext_launches = sum(s["extendLaunches"] for s in stats); ext_rays = sum(s["extendRays"] for s in stats)
+    bytes_per_ext = B_EXTEND_FIXED + nodes_per_ext * B_NODE + tris_per_ext * B_TRI
+    ext_gbs = ext_rays * bytes_per_ext / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+    sh_ms = sum(s["shadowKernelMs"] for s in stats); shade_ms = sum(s["shadeKernelMs"] for s in stats)
+
+    if rank == 0:
+        info = g.scene_info()
+        out = {
+            "metric": "Mrays/s at 4K 4spp 8-bounce bistro-like (extend + shadow rays / wall time of pt_render)",
+            "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3 bistro-like street canyon, %d triangles, 64 materials, 32 textures %d^2, %d emissive-triangle + env-quad lights, %dx%d, %d spp, 8 bounces, NEE 5 candidates + RR"
+                                   % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP),
+                       "parallelism": "pixel-tile shard x%d + 1 gather" % world, "rays_per_step": rays_total / args.steps,
+                       "extend_rays_per_step": ext_rays / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
+            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_ray": bytes_per_ext, "node_visits_per_ray": nodes_per_ext, "tri_tests_per_ray": tris_per_ext,
+                         "avg_launch_ms": ext_ms / max(1, ext_launches), "launches": ext_launches,
+                         "kernel_ms_per_step": {"k_extend": ext_ms / args.steps, "k_shade": shade_ms / args.steps, "k_shadow": sh_ms / args.steps},
+                         "shadow_node_visits_per_ray": nodes_per_sh, "shadow_tri_tests_per_ray": tris_per_sh},
+            "build": g.build_stats(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, cam, S, W, H)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, cam, S, W, H):
+    """The CPU oracle (a port: RTXPT has no CPU path) on a bounded sample of the SAME workload: a 480x270 block of
+    the 4K frame, 1 accumulated sample, all host cores (OpenMP). Reported per ray so that it is resolution independent."""
+    from oracle import ptref
+    from rtxpt_amd import scenes
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(scenes.bridge_camera(W, H, **cam)); o.set_settings(S); o.resize(W, H)
+    t0 = time.perf_counter(); o.L.ptref_prepare(o.h); prep = time.perf_counter() - t0
+    x0, y0 = W // 2 - 240, H // 2 - 135
+    t0 = time.perf_counter(); o.render(0, 1, rect=(x0, y0, x0 + 480, y0 + 270)); dt = time.perf_counter() - t0
+    c = o.counters()
+    rays = c["extendRays"] + c["shadowRays"]
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": ptref.num_threads(), "kind": "port",
+            "sample": "480x270 centre block of the 4K frame, 1 spp, %d rays in %.2f s (SAH BVH build + light bake %.1f s not included)" % (rays, dt, prep)}
+
+
+if __name__ == "__main__":
+    main()

@@ -350,3 +350,238 @@ def config_settings(name):
     if name == "C1":
         return default_settings(bounceCount=2, diffuseBounceCount=2, enableRussianRoulette=0, diffuseBrdf=0)
     return default_settings()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "bistro-like" street canyon. The real Bistro asset is not obtainable offline.
+# ---------------------------------------------------------------------------------------------------------------------
+def _value_noise(rng, size, octaves=(4, 8, 16, 32, 64, 128), persistence=0.6):
+    img = np.zeros((size, size), np.float32)
+    amp, total = 1.0, 0.0
+    for o in octaves:
+        g = rng.random((o, o), dtype=np.float32)
+        # bilinear upsample with wrap
+        x = (np.arange(size, dtype=np.float32) + 0.5) * (o / size) - 0.5
+        x0 = np.floor(x).astype(np.int64)
+        fx = (x - x0).astype(np.float32)
+        x0m, x1m = x0 % o, (x0 + 1) % o
+        rows = g[:, x0m] * (1 - fx)[None, :] + g[:, x1m] * fx[None, :]
+        up = rows[x0m, :] * (1 - fx)[:, None] + rows[x1m, :] * fx[:, None]
+        img += amp * up
+        total += amp
+        amp *= persistence
+    return img / total
+
+
+def _make_textures(rng, b, tex_size):
+    """24 base-colour (sRGB) + 4 leaf RGBA (alpha) + 4 normal maps = 32 textures. Returns lists of packed texture words."""
+    base_words, leaf_words, normal_words = [], [], []
+    for i in range(24):
+        n = _value_noise(rng, tex_size)
+        n2 = _value_noise(rng, tex_size, octaves=(16, 64, 256) if tex_size >= 256 else (4, 8, 16))
+        tint = 0.35 + 0.6 * rng.random(3)
+        # brick / plank like banding
+        yy = (np.arange(tex_size) // max(1, tex_size // (8 + 4 * (i % 4)))) % 2
+        band = (0.85 + 0.15 * yy)[:, None]
+        rgb = np.clip((0.45 + 0.55 * n)[..., None] * tint[None, None, :] * band[..., None] * (0.8 + 0.2 * n2)[..., None], 0, 1)
+        px = np.concatenate([(rgb * 255).astype(np.uint8), np.full((tex_size, tex_size, 1), 255, np.uint8)], -1)
+        base_words.append(b.add_texture(px, TEX_RGBA8_SRGB))
+    for i in range(4):
+        n = _value_noise(rng, tex_size, octaves=(8, 16, 32, 64))
+        alpha = (n > 0.52 - 0.02 * i).astype(np.uint8) * 255
+        g = np.clip(0.25 + 0.5 * _value_noise(rng, tex_size), 0, 1)
+        rgb = np.stack([0.25 * g, 0.75 * g, 0.15 * g], -1)
+        px = np.concatenate([(rgb * 255).astype(np.uint8), alpha[..., None]], -1)
+        leaf_words.append(b.add_texture(px, TEX_RGBA8_SRGB))
+    for i in range(4):
+        hgt = _value_noise(rng, tex_size, octaves=(16, 32, 64))
+        dx = np.roll(hgt, -1, 1) - np.roll(hgt, 1, 1)
+        dy = np.roll(hgt, -1, 0) - np.roll(hgt, 1, 0)
+        nrm = np.stack([-dx * 6.0, -dy * 6.0, np.ones_like(hgt)], -1)
+        nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+        px = np.concatenate([((nrm * 0.5 + 0.5) * 255).astype(np.uint8), np.full((tex_size, tex_size, 1), 255, np.uint8)], -1)
+        normal_words.append(b.add_texture(px, TEX_RGBA8_UNORM))
+    return base_words, leaf_words, normal_words
+
+
+def _quads(c, a, bb, uv_scale=None):
+    """c, a, bb: (n,3) centre and half axes -> unshared quads. Returns pos (4n,3), idx (6n), uv (4n,2), normal (4n,3), tangent (4n,4)."""
+    c, a, bb = (np.asarray(v, np.float32) for v in (c, a, bb))
+    n = c.shape[0]
+    pos = np.stack([c - a - bb, c + a - bb, c + a + bb, c - a + bb], 1).reshape(-1, 3)
+    base = (np.arange(n, dtype=np.uint32) * 4)[:, None]
+    idx = (base + np.array([0, 1, 2, 0, 2, 3], np.uint32)[None, :]).reshape(-1)
+    nrm = np.cross(a, bb)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+    tan = a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-20)
+    if uv_scale is None:
+        uv_scale = np.ones((n, 2), np.float32)
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)[None, :, :] * np.asarray(uv_scale, np.float32)[:, None, :]
+    return (pos, idx, uv.reshape(-1, 2), np.repeat(nrm, 4, 0), np.concatenate([np.repeat(tan, 4, 0), np.ones((4 * n, 1), np.float32)], 1))
+
+
+def _boxes(c, h, yaw):
+    """axis boxes (n) with centre c, half sizes h, yaw about y -> 6n quads."""
+    n = c.shape[0]
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    ex = np.stack([cy, np.zeros(n), -sy], 1).astype(np.float32)
+    ez = np.stack([sy, np.zeros(n), cy], 1).astype(np.float32)
+    eyv = np.tile(np.array([[0, 1, 0]], np.float32), (n, 1))
+    hx, hy, hz = h[:, 0:1], h[:, 1:2], h[:, 2:3]
+    C, A, B = [], [], []
+    for (nv, hn, av, ha, bv, hb) in ((ex, hx, eyv, hy, ez, hz), (-ex, hx, ez, hz, eyv, hy), (eyv, hy, ez, hz, ex, hx), (-eyv, hy, ex, hx, ez, hz), (ez, hz, ex, hx, eyv, hy), (-ez, hz, eyv, hy, ex, hx)):
+        C.append(c + nv * hn); A.append(av * ha); B.append(bv * hb)
+    C, A, B = np.concatenate(C), np.concatenate(A), np.concatenate(B)
+    # make winding outward: normal = cross(a,b) must point along nv
+    nvs = np.concatenate([ex, -ex, eyv, -eyv, ez, -ez])
+    flip = (np.cross(A, B) * nvs).sum(1) < 0
+    A2 = np.where(flip[:, None], B, A); B2 = np.where(flip[:, None], A, B)
+    return C, A2, B2
+
+
+def bistro_like(scale=1.0, seed=SEED_BASE + 3, tex_size=1024, animated=False):
+    """Street canyon 120 x 40 x 25 m: ~2.8 M triangles at scale=1 (60 % long thin facade quads, 25 % alpha-tested foliage cards,
+    15 % clutter boxes), 2000 emissive triangles, 64 materials, 32 textures, sky environment. `scale` shrinks the triangle counts
+    (tests use small scales; the structure is identical). Returns (scene dict, camera kwargs)."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    base_w, leaf_w, normal_w = _make_textures(rng, b, tex_size)
+    mats = []
+    for i in range(24):       # textured facade materials, 8 of them normal mapped, a few metallic
+        mats.append(b.add_material(make_material(base=(1, 1, 1), roughness=float(0.35 + 0.55 * rng.random()), metalness=1.0 if i % 11 == 5 else 0.0, ior=1.5,
+                                                 base_tex=base_w[i], normal_tex=normal_w[i % 4] if i < 8 else None)))
+    for i in range(8):        # painted
+        mats.append(b.add_material(make_material(base=tuple(0.2 + 0.7 * rng.random(3)), roughness=float(0.3 + 0.6 * rng.random()), ior=1.5)))
+    leaf_mats = [b.add_material(make_material(base=(1, 1, 1), roughness=0.7, ior=1.4, base_tex=leaf_w[i], alpha_cutoff=0.5, diff_transmission=0.0)) for i in range(4)]
+    clutter_mats = [b.add_material(make_material(base=tuple(0.15 + 0.75 * rng.random(3)), roughness=float(0.15 + 0.5 * rng.random()), metalness=1.0 if i % 3 == 0 else 0.0, ior=1.5)) for i in range(8)]
+    glass_mats = [b.add_material(make_material(base=(0.9, 0.95, 0.97), roughness=0.0, ior=1.5, transmission=0.9, thin=True)) for i in range(4)]
+    le = 10.0 ** rng.uniform(1.0, 4.0, 16)
+    em_mats = [b.add_material(make_material(base=(0.8, 0.8, 0.8), emissive=tuple(float(le[i]) * np.array([1.0, 0.82 + 0.15 * rng.random(), 0.5 + 0.4 * rng.random()])), roughness=1.0, ior=1.5)) for i in range(16)]
+    assert len(b.materials) == 64
+
+    L, Wd, Hh = 120.0, 40.0, 25.0
+    z0, z1 = 8.0, 32.0                      # facade planes; street between them
+    n_facade = max(64, int(840000 * scale)); n_cards = max(64, int(350000 * scale)); n_boxes = max(16, int(35000 * scale)); n_em = max(8, int(1000 * scale))
+
+    # --- static shell: ground, two big walls, end caps (one mesh)
+    b.begin_mesh()
+    p, i, uv, n, t = quad((0, 0, 0), (0, 0, Wd), (L, 0, Wd), (L, 0, 0), uv_scale=30.0); b.add_geometry(p, i, mats[0], uv=uv, normal=n, tangent=t)
+    p, i, uv, n, t = quad((0, 0, z0), (0, Hh, z0), (L, Hh, z0), (L, 0, z0), uv_scale=20.0); b.add_geometry(p, i, mats[1], uv=uv, normal=n, tangent=t)       # normal +z
+    p, i, uv, n, t = quad((0, 0, z1), (L, 0, z1), (L, Hh, z1), (0, Hh, z1), uv_scale=20.0); b.add_geometry(p, i, mats[2], uv=uv, normal=n, tangent=t)       # normal -z
+    p, i, uv, n, t = quad((L, 0, z0), (L, Hh, z0), (L, Hh, z1), (L, 0, z1), uv_scale=8.0); b.add_geometry(p, i, mats[3], uv=uv, normal=n, tangent=t)        # far cap, normal -x
+    shell = b.end_mesh(); b.add_instance(shell)
+
+    # --- facade detail: long thin quads hugging both walls, split over 24 "building" meshes x material groups
+    side = rng.integers(0, 2, n_facade)
+    horiz = rng.random(n_facade) < 0.6
+    length = rng.uniform(0.4, 4.0, n_facade).astype(np.float32); width = rng.uniform(0.02, 0.15, n_facade).astype(np.float32)
+    cx = rng.uniform(0.5, L - 0.5, n_facade); cyv = rng.uniform(0.3, Hh - 0.3, n_facade); depth = rng.uniform(0.01, 0.35, n_facade)
+    cz = np.where(side == 0, z0 + depth, z1 - depth)
+    tilt = rng.normal(0, 0.15, n_facade)      # slats tilted out of the wall plane a little (louvre-like)
+    ax = np.where(horiz, 1.0, 0.0); ay = np.where(horiz, 0.0, 1.0)
+    a = np.stack([ax * length * 0.5, ay * length * 0.5, np.zeros(n_facade)], 1)
+    bx = np.where(horiz, 0.0, 1.0); by = np.where(horiz, 1.0, 0.0)
+    bvec = np.stack([bx * np.cos(tilt), by * np.cos(tilt), np.sin(tilt)], 1) * (width * 0.5)[:, None]
+    # face the street: normal = cross(a,b) should have +z on side 0 and -z on side 1
+    nz = np.cross(a, bvec)[:, 2]
+    want = np.where(side == 0, 1.0, -1.0)
+    flip = (nz * want) < 0
+    bvec = np.where(flip[:, None], -bvec, bvec)
+    c = np.stack([cx, cyv, cz], 1)
+    building = np.minimum((cx / (L / 24)).astype(np.int64), 23)
+    matsel = rng.integers(0, 32, n_facade)
+    uvs_scale = np.stack([length / 1.0, width / 1.0], 1)
+    for bi in range(24):
+        sel_b = building == bi
+        if not sel_b.any():
+            continue
+        b.begin_mesh()
+        for m in np.unique(matsel[sel_b]):
+            s = sel_b & (matsel == m)
+            p, i, uv, n, t = _quads(c[s], a[s], bvec[s], uvs_scale[s])
+            b.add_geometry(p, i, mats[int(m)], uv=uv, normal=n, tangent=t)
+        # windows: a few thin glass panes per building
+        ng = max(2, int(40 * scale))
+        gx = rng.uniform(bi * L / 24 + 0.5, (bi + 1) * L / 24 - 0.5, ng); gy = rng.uniform(2, Hh - 2, ng); gs = rng.integers(0, 2, ng)
+        gc = np.stack([gx, gy, np.where(gs == 0, z0 + 0.4, z1 - 0.4)], 1)
+        ga = np.stack([np.full(ng, 0.6), np.zeros(ng), np.zeros(ng)], 1); gb = np.stack([np.zeros(ng), np.full(ng, 0.9), np.zeros(ng)], 1)
+        gb = np.where((gs == 1)[:, None], -gb, gb)
+        p, i, uv, n, t = _quads(gc, ga, gb)
+        b.add_geometry(p, i, glass_mats[bi % 4], uv=uv, normal=n, tangent=t)
+        b.add_instance(b.end_mesh())
+
+    # --- foliage: 8 tree meshes of alpha-tested cards, instanced along the pavements
+    n_tree_meshes, n_tree_inst = 8, 25
+    cards_per_tree = max(8, n_cards // (n_tree_meshes * n_tree_inst))
+    tree_meshes = []
+    for tm in range(n_tree_meshes):
+        r = rng.random(cards_per_tree) ** (1 / 3) * 1.6
+        dirv = rng.normal(size=(cards_per_tree, 3)); dirv /= np.linalg.norm(dirv, axis=1, keepdims=True)
+        cc = dirv * r[:, None] * np.array([1.0, 0.8, 1.0]) + np.array([0, 4.0, 0])
+        ua = rng.normal(size=(cards_per_tree, 3)); ua /= np.linalg.norm(ua, axis=1, keepdims=True)
+        ub = np.cross(ua, rng.normal(size=(cards_per_tree, 3))); ub /= np.maximum(np.linalg.norm(ub, axis=1, keepdims=True), 1e-9)
+        sz = rng.uniform(0.12, 0.3, cards_per_tree)[:, None]
+        p, i, uv, n, t = _quads(cc, ua * sz, ub * sz)
+        b.begin_mesh()
+        b.add_geometry(p, i, leaf_mats[tm % 4], uv=uv, normal=n, tangent=t, geom_flags=GEOMF_ALPHA_TESTED)
+        # trunk: one thin box
+        tc, ta, tb = _boxes(np.array([[0, 2.0, 0]], np.float32), np.array([[0.12, 2.0, 0.12]], np.float32), np.zeros(1))
+        p, i, uv, n, t = _quads(tc, ta, tb)
+        b.add_geometry(p, i, mats[24 + tm % 8], uv=uv, normal=n, tangent=t)
+        tree_meshes.append(b.end_mesh())
+    tree_instances = []
+    for k in range(n_tree_meshes * n_tree_inst):
+        x = 2.0 + (L - 4.0) * ((k * 0.61803398875) % 1.0); z = (z0 + 2.2) if (k % 2 == 0) else (z1 - 2.2)
+        s = float(0.8 + 0.5 * rng.random())
+        tree_instances.append(len(b.instances))
+        b.add_instance(tree_meshes[k % n_tree_meshes], trs((x, 0.0, z), rot_y=float(rng.uniform(0, 6.283)), scale=(s, s, s)))
+
+    # --- clutter: boxes (crates, cars, kiosks) on the street, 40 rigid groups (animated in C5)
+    n_groups = 40
+    per_group = max(1, n_boxes // n_groups)
+    clutter_instances = []
+    for gidx in range(n_groups):
+        bc = np.stack([rng.uniform(-1.5, 1.5, per_group), np.zeros(per_group), rng.uniform(-1.5, 1.5, per_group)], 1).astype(np.float32)
+        bh = np.stack([rng.uniform(0.05, 0.45, per_group), rng.uniform(0.05, 0.6, per_group), rng.uniform(0.05, 0.45, per_group)], 1).astype(np.float32)
+        bc[:, 1] = bh[:, 1] + rng.uniform(0, 1.2, per_group) * (rng.random(per_group) < 0.3)
+        C, A, B = _boxes(bc, bh, rng.uniform(0, 6.283, per_group))
+        msel = rng.integers(0, 8, C.shape[0] // 6); msel6 = np.tile(msel, 6)
+        b.begin_mesh()
+        for m in np.unique(msel6):
+            s = msel6 == m
+            p, i, uv, n, t = _quads(C[s], A[s], B[s])
+            b.add_geometry(p, i, clutter_mats[int(m)], uv=uv, normal=n, tangent=t)
+        mesh = b.end_mesh()
+        clutter_instances.append(len(b.instances))
+        b.add_instance(mesh, trs((float(rng.uniform(3, L - 3)), 0.0, float(rng.uniform(z0 + 3.5, z1 - 3.5))), rot_y=float(rng.uniform(0, 6.283))))
+
+    # --- emissive: lamps and string lights (2 triangles each), 16 emissive materials with log-uniform radiance
+    ex = rng.uniform(1, L - 1, n_em); ey = rng.uniform(2.5, 7.0, n_em); ez = rng.uniform(z0 + 0.6, z1 - 0.6, n_em)
+    es = rng.uniform(0.03, 0.12, n_em)
+    ec = np.stack([ex, ey, ez], 1)
+    ea = np.stack([es, np.zeros(n_em), np.zeros(n_em)], 1); eb = np.stack([np.zeros(n_em), np.zeros(n_em), -es], 1)    # cross(a,b) = +? (es,0,0)x(0,0,-es) = (0*(-es)-0*0, 0*0-es*(-es), 0) = (0, es^2, 0) -> flip to face down
+    eb = -eb; ea, eb = eb, ea
+    emsel = rng.integers(0, 16, n_em)
+    b.begin_mesh()
+    for m in np.unique(emsel):
+        s = emsel == m
+        p, i, uv, n, t = _quads(ec[s], ea[s], eb[s])
+        b.add_geometry(p, i, em_mats[int(m)], uv=uv, normal=n, tangent=t)
+    b.add_instance(b.end_mesh())
+
+    b.set_environment(sky_equirect(sun_dir=(0.25, 0.75, -0.35), sun_radiance=2e4), color_multiplier=(1, 1, 1))
+    sc = b.finish()
+    sc["anim"] = dict(clutter_instances=clutter_instances, tree_instances=tree_instances)
+    cam = dict(pos=(4.0, 1.7, 20.0), direction=(1.0, 0.12, 0.05), up=(0, 1, 0), fov_y=math.radians(60.0), near_z=0.05, far_z=1000.0, focal_distance=10.0)
+    return sc, cam
+
+
+def animate_instances(sc, t):
+    """Rigid keyframed motion of the clutter groups (game props = TLAS instance transforms only)."""
+    inst = sc["instances"].copy()
+    for k, idx in enumerate(sc["anim"]["clutter_instances"]):
+        tr = inst["transform"][idx].copy()
+        tr[3] += 0.8 * math.sin(0.7 * t + k)
+        tr[11] += 0.5 * math.cos(0.5 * t + 1.3 * k)
+        inst["transform"][idx] = tr
+    return inst

@@ -1,0 +1,80 @@
+"""Test helper: writes a scene dict (rtxpt_amd.scenes) as glTF 2.0 (.gltf + .bin) so that pt_load_scene_gltf can be exercised."""
+import json
+import os
+import struct
+
+import numpy as np
+
+
+def _unpack_snorm8(v, n):
+    out = np.zeros((v.size, n), np.float32)
+    for k in range(n):
+        b = ((v >> (8 * k)) & 0xFF).astype(np.int32)
+        b = np.where(b > 127, b - 256, b)
+        out[:, k] = np.clip(b / 127.0, -1, 1)
+    return out
+
+
+def write_gltf(sc, path):
+    bin_path = os.path.splitext(path)[0] + ".bin"
+    blob = bytearray()
+    views, accessors = [], []
+
+    def add(arr, ctype, typ, target=None):
+        nonlocal blob
+        while len(blob) % 4:
+            blob += b"\0"
+        off = len(blob)
+        data = np.ascontiguousarray(arr).tobytes()
+        blob += data
+        v = {"buffer": 0, "byteOffset": off, "byteLength": len(data)}
+        if target:
+            v["target"] = target
+        views.append(v)
+        acc = {"bufferView": len(views) - 1, "componentType": ctype, "count": int(arr.shape[0]), "type": typ}
+        if typ == "VEC3" and ctype == 5126:
+            acc["min"] = [float(x) for x in arr.min(0)]; acc["max"] = [float(x) for x in arr.max(0)]
+        accessors.append(acc)
+        return len(accessors) - 1
+
+    materials = []
+    for m in sc["materials"]:
+        flags = int(m["Flags"])
+        j = {"pbrMetallicRoughness": {"baseColorFactor": [float(x) for x in m["BaseOrDiffuseColor"]] + [1.0], "metallicFactor": float(m["Metalness"]), "roughnessFactor": float(m["Roughness"])},
+             "emissiveFactor": [1.0, 1.0, 1.0] if any(m["EmissiveColor"] > 0) else [0.0, 0.0, 0.0], "extensions": {"KHR_materials_ior": {"ior": float(m["IoR"])}}}
+        if any(m["EmissiveColor"] > 0):
+            mx = float(max(m["EmissiveColor"]))
+            j["emissiveFactor"] = [float(x) / mx for x in m["EmissiveColor"]]
+            j["extensions"]["KHR_materials_emissive_strength"] = {"emissiveStrength": mx}
+        if m["TransmissionFactor"] > 0:
+            j["extensions"]["KHR_materials_transmission"] = {"transmissionFactor": float(m["TransmissionFactor"])}
+            if not (flags & 0x200):
+                j["extensions"]["KHR_materials_volume"] = {"thicknessFactor": 1.0, "attenuationDistance": float(m["AttenuationDistance"]), "attenuationColor": [float(x) for x in m["AttenuationColor"]]}
+        materials.append(j)
+    meshes = []
+    for (fg, ng) in sc["meshes"]:
+        prims = []
+        for g in sc["geometries"][fg:fg + ng]:
+            vo, nv = int(g["vertexOffset"]), int(g["numVertices"])
+            at = {"POSITION": add(sc["positions"][vo:vo + nv], 5126, "VEC3", 34962)}
+            if g["flags"] & 1:
+                at["TEXCOORD_0"] = add(sc["uvs"][vo:vo + nv], 5126, "VEC2", 34962)
+            if g["flags"] & 2:
+                at["NORMAL"] = add(_unpack_snorm8(sc["normals"][vo:vo + nv], 3), 5126, "VEC3", 34962)
+            if g["flags"] & 4:
+                at["TANGENT"] = add(_unpack_snorm8(sc["tangents"][vo:vo + nv], 4), 5126, "VEC4", 34962)
+            idx = add(sc["indices"][int(g["indexOffset"]):int(g["indexOffset"]) + int(g["numIndices"])].astype(np.uint32), 5125, "SCALAR", 34963)
+            prims.append({"attributes": at, "indices": idx, "material": int(g["materialIndex"]), "mode": 4})
+        meshes.append({"primitives": prims})
+    nodes = []
+    for inst in sc["instances"]:
+        t = inst["transform"].reshape(3, 4)
+        m4 = np.eye(4, dtype=np.float64); m4[:3, :] = t
+        nodes.append({"mesh": int(inst["meshIndex"]), "matrix": [float(x) for x in m4.T.reshape(-1)]})
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": list(range(len(nodes)))}], "nodes": nodes, "meshes": meshes, "materials": materials,
+           "accessors": accessors, "bufferViews": views, "buffers": [{"uri": os.path.basename(bin_path), "byteLength": len(blob)}],
+           "extensionsUsed": ["KHR_materials_ior", "KHR_materials_emissive_strength", "KHR_materials_transmission", "KHR_materials_volume"]}
+    with open(bin_path, "wb") as f:
+        f.write(bytes(blob))
+    with open(path, "w") as f:
+        json.dump(doc, f)

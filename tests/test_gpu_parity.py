@@ -1,0 +1,284 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs. Integer work (RNG, hit records, light tables) must be bit-exact. Radiance is floating point: the stated
+tolerance is relative L2 <= 1e-6 over the linear RGBA32F accumulation buffer (north_star allows 1e-3); because both sides are
+written to one arithmetic contract (single IEEE ops in fixed order, shared deterministic elementary functions) the observed
+difference is exactly 0 and the tests additionally report the number of non-identical pixels."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REL_L2_TOL = 1e-6
+
+
+def _imports():
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes, parallel
+    from oracle import ptref
+    return pt, scenes, parallel, ptref
+
+
+def rel_l2(a, b):
+    a = a[..., :3].astype(np.float64); b = b[..., :3].astype(np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def render_both(sc, cam, S, w, h, first, count):
+    pt, scenes, parallel, ptref = _imports()
+    camd = scenes.bridge_camera(w, h, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(w, h)
+    stats = g.render(first, count)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.render(first, count)
+    return g, o, stats
+
+
+def check_images(g, o):
+    a, b = g.radiance(), o.radiance()
+    assert not np.isnan(a).any()
+    d = rel_l2(a, b)
+    nonident = int((np.abs(a[..., :3] - b[..., :3]).max(-1) > 0).sum())
+    print("relL2 %.3e non-identical pixels %d / %d" % (d, nonident, a.shape[0] * a.shape[1]))
+    assert d <= REL_L2_TOL
+    return nonident
+
+
+def test_library_is_the_hip_build():
+    pt, *_ = _imports()
+    L = pt.load_library()
+    assert os.path.samefile(L._name, pt.LIB_PATH)
+    import torch
+    assert torch.cuda.is_available()
+
+
+def test_c1_cornell_lambertian_256():
+    """BASELINE configs[0]: Cornell 256x256, 1 spp, 2 bounces."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.cornell_box("C1")
+    g, o, st = render_both(sc, cam, scenes.config_settings("C1"), 256, 256, 0, 1)
+    assert check_images(g, o) == 0
+    c = o.counters()
+    assert st["extendRays"] == c["extendRays"] and st["shadowRays"] == c["shadowRays"] and st["hits"] == c["hits"]
+
+
+def test_c2_cornell_standard_bsdf_env_nee():
+    """BASELINE configs[1] at reduced resolution (the oracle finishes in seconds): full StandardBSDF, nested dielectric glass box,
+    metal box, sky environment with quad-tree NEE, Russian roulette, 8 bounces, 4 accumulated samples."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.cornell_box("C2")
+    g, o, st = render_both(sc, cam, scenes.config_settings("C2"), 480, 270, 0, 4)
+    assert check_images(g, o) == 0
+    c = o.counters()
+    assert st["extendRays"] == c["extendRays"] and st["shadowRays"] == c["shadowRays"]
+
+
+def test_bistro_like_small_textures_alpha_normalmaps():
+    """C3 structure at 1/100 scale: textured + normal-mapped facades, alpha-tested foliage, 2000->20 emissive triangles, instances."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.bistro_like(scale=0.01, tex_size=128)
+    g, o, st = render_both(sc, cam, scenes.default_settings(), 320, 180, 0, 2)
+    assert check_images(g, o) == 0
+    lg, lo = g.lights(), o.lights()
+    for k in ("lights", "lightsEx", "proxyCounters", "proxyIndices", "envLookup"):
+        assert np.array_equal(lg[k], lo[k]), k
+    assert np.array_equal(g.subinstances(), o.subinstances())
+
+
+def test_firefly_filter_and_sample_offsets():
+    """fireflyFilterThreshold != 0 path + non-zero first sample index + accumulation over two pt_render calls."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.cornell_box("C2")
+    S = scenes.default_settings(fireflyFilterThreshold=2.5, envMapDiffuseSampleMIPLevel=2.0, nestedDielectricsQuality=2)
+    w, h = 200, 120
+    camd = scenes.bridge_camera(w, h, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(w, h)
+    g.render(7, 2); g.render(9, 1)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.render(7, 3)
+    assert check_images(g, o) == 0
+
+
+def test_hit_records_bit_exact_random_rays():
+    """k_extend / k_shadow through the probe entry points vs the oracle's BVH on 200k random rays (SURVEY.md §7 gate 4)."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.bistro_like(scale=0.02, tex_size=64)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(scenes.default_settings())
+    o = ptref.Oracle(); o.set_scene(sc); o.set_settings(scenes.default_settings())
+    rng = np.random.default_rng(0x5EED0003)
+    n = 200000
+    org = rng.uniform((0.5, 0.05, 8.2), (119.5, 24.0, 31.8), (n, 3))
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = np.where(rng.random(n) < 0.5, 1e15, rng.uniform(0.5, 30.0, n))
+    rays = np.concatenate([org, np.zeros((n, 1)), d, tmax[:, None]], 1).astype(np.float32)
+    hg, ms = g.trace_closest(rays)
+    ho = o.trace_closest(rays)
+    same = (hg.view(np.uint32) == ho.view(np.uint32)).all(1)
+    print("closest-hit records identical: %d / %d (%.3f ms on GPU)" % (same.sum(), n, ms))
+    assert same.all()
+    vg, _ = g.trace_visibility(rays)
+    vo = o.trace_visibility(rays)
+    assert np.array_equal(vg, vo)
+    assert 0.05 < vg.mean() < 0.95
+
+
+def test_leaf_functions_bit_exact():
+    """Device vs oracle: deterministic math, fp16 packing, sample streams, BSDF eval/sample, camera rays."""
+    pt, scenes, parallel, ptref = _imports()
+    L = ptref.lib()
+    g = pt.PathTracer()
+    rng = np.random.default_rng(3)
+    n = 20000
+    for fn, lo, hi in ((0, -30, 30), (1, -30, 30), (2, -140, 130), (3, 1e-30, 1e30), (4, -5, 5), (5, 1e-3, 50), (6, -1, 1), (7, 0, 4)):
+        x = (10.0 ** rng.uniform(-30, 30, n) if fn == 3 else rng.uniform(lo, hi, n)).astype(np.float32)
+        y = rng.uniform(-3, 3, n).astype(np.float32)
+        inp = np.stack([np.full(n, fn, np.float32), x, y], 1)
+        dev = g.probe(0, inp, (n,))
+        ref = np.zeros(n, np.float32)
+        L.ptref_dmath(fn, x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), n, ref.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32)), "dmath fn %d" % fn
+    xs = np.concatenate([rng.uniform(-70000, 70000, n), 10.0 ** rng.uniform(-9, 5, n), [0.0, 65504.0, 65519.9, 65520.0, 5.9604645e-8, 2.9802322e-8]]).astype(np.float32)
+    dev = g.probe(1, xs, (xs.size, 2))
+    with np.errstate(over="ignore"):
+        exp = xs.astype(np.float16)
+    assert np.array_equal(dev[:, 0].view(np.uint32), exp.view(np.uint16).astype(np.uint32))
+    assert np.array_equal(dev[:, 1], exp.astype(np.float32))
+    m = 4000
+    q = np.stack([rng.integers(0, 2**32, m), rng.integers(0, 12, m), rng.integers(0, 4096, m), rng.integers(0, 7, m), rng.integers(0, 5, m), np.full(m, 8)], 1).astype(np.uint32)
+    q[q[:, 4] < 2, 5] = 4
+    dev = g.probe(2, q, (m, 8))
+    ref = np.zeros(8, np.float32)
+    for i in range(m):
+        ref[:] = 0
+        L.ptref_sample_stream(int(q[i, 0]), int(q[i, 1]), int(q[i, 2]), int(q[i, 3]), int(q[i, 4]), int(q[i, 5]), ref.ctypes.data_as(ctypes.c_void_p))
+        k = int(q[i, 5])
+        assert np.array_equal(dev[i, :k].view(np.uint32), ref[:k].view(np.uint32)), q[i]
+    # BSDF eval + sample
+    m = 3000
+    P = np.zeros((m, 24), np.float32)
+    P[:, 0:3] = rng.random((m, 3)); P[:, 3:6] = rng.random((m, 1)) * 0.2; P[:, 6] = rng.random(m); P[:, 7] = (rng.random(m) < 0.3) * rng.random(m)
+    P[:, 8:11] = rng.random((m, 3)); P[:, 11] = (rng.random(m) < 0.3) * rng.random(m); P[:, 12] = (rng.random(m) < 0.4) * rng.random(m); P[:, 13] = np.where(rng.random(m) < 0.5, 1 / 1.5, 1.5)
+    P[:, 14] = rng.random(m) < 0.5; P[:, 15] = np.where(rng.random(m) < 0.3, 0, 2)
+    wi = rng.normal(size=(m, 3)); wi[:, 2] = np.abs(wi[:, 2]) + 0.05; wi /= np.linalg.norm(wi, axis=1, keepdims=True); P[:, 16:19] = wi
+    mode = (rng.random(m) < 0.5)
+    wo = rng.normal(size=(m, 3)); wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    P[:, 19:22] = np.where(mode[:, None], rng.random((m, 3)), wo); P[:, 22] = mode
+    dev = g.probe(3, P, (m, 10))
+    ref = np.zeros(10, np.float32)
+    for i in range(m):
+        ref[:] = 0
+        L.ptref_bsdf_probe(P[i, :14].ctypes.data_as(ctypes.c_void_p), int(P[i, 14]), int(P[i, 15]), P[i, 16:19].copy().ctypes.data_as(ctypes.c_void_p),
+                           P[i, 19:22].copy().ctypes.data_as(ctypes.c_void_p), int(P[i, 22]), ref.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(dev[i].view(np.uint32), ref.view(np.uint32)), (i, dev[i], ref)
+    # camera rays (thin lens with aperture)
+    cam = scenes.bridge_camera(640, 360, (1, 2, 3), (0.3, -0.2, 1), (0, 1, 0), 0.9, aperture_radius=0.05, focal_distance=4.0)
+    g.set_camera(cam); g.set_settings(scenes.default_settings())
+    o = ptref.Oracle(); o.set_camera(cam); o.set_settings(scenes.default_settings())
+    q = np.stack([rng.integers(0, 640, 500), rng.integers(0, 360, 500), rng.integers(0, 64, 500)], 1).astype(np.uint32)
+    dev = g.probe(4, q, (500, 6))
+    for i in range(500):
+        assert np.array_equal(dev[i].view(np.uint32), o.camera_ray(int(q[i, 0]), int(q[i, 1]), int(q[i, 2])).view(np.uint32))
+
+
+def test_gltf_import_equals_raw_buffers(tmp_path):
+    """pt_load_scene_gltf (Sample::LoadScene seam) produces the same frame as the raw-buffer path for the same scene."""
+    pt, scenes, parallel, ptref = _imports()
+    from tests.gltf_writer import write_gltf
+    sc, cam = scenes.cornell_box("C2")
+    path = str(tmp_path / "cornell.gltf")
+    write_gltf(sc, path)
+    S = scenes.config_settings("C2"); w, h = 160, 96
+    camd = scenes.bridge_camera(w, h, **cam)
+    a = pt.PathTracer(); a.set_scene(sc); a.set_camera(camd); a.set_settings(S); a.resize(w, h); a.render(0, 2)
+    b = pt.PathTracer(); b.load_scene_gltf(path)
+    rgb, tw, cm = sc["env"]
+    p = pt.PtEnvMapSceneParams((ctypes.c_float * 12)(*tw.tolist()), (ctypes.c_float * 3)(*cm.tolist()), 1.0)
+    assert b.L.pt_set_environment(b.h, rgb.ctypes.data_as(ctypes.c_void_p), rgb.shape[1], rgb.shape[0], ctypes.byref(p)) == 0
+    b.set_camera(camd); b.set_settings(S); b.resize(w, h); b.render(0, 2)
+    assert b.scene_info()["triangles"] == a.scene_info()["triangles"]
+    d = rel_l2(b.radiance(), a.radiance())
+    print("gltf vs raw relL2 %.3e" % d)
+    assert d <= 2e-2      # SNORM8 normals/tangents are re-quantised from the glTF floats and instance matrices go through TRS text: not bit-identical
+    with pytest.raises(pt.PtError):
+        pt.PathTracer().load_scene_gltf(str(tmp_path / "missing.gltf"))
+
+
+def test_refit_equals_rebuild_and_oracle():
+    """pt_animate: instance motion -> LBVH refit; refit, full rebuild and the oracle (fresh SAH build) agree bit-for-bit."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.bistro_like(scale=0.01, tex_size=64)
+    S = scenes.default_settings(); w, h = 256, 144
+    camd = scenes.bridge_camera(w, h, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(w, h); g.render(0, 1)
+    inst = scenes.animate_instances(sc, 1.7)
+    g.animate(instances=inst, rebuild=False); g.render(0, 2); a = g.radiance()
+    assert g.build_stats()["refitMs"] > 0
+    g.animate(instances=inst, rebuild=True); g.render(0, 2); b = g.radiance()
+    assert np.array_equal(a, b)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_instances(inst); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.render(0, 2)
+    assert rel_l2(a, o.radiance()) <= REL_L2_TOL
+    assert np.array_equal(a[..., :3], o.radiance()[..., :3])
+    # deformation: move vertices of one geometry (skinned-mesh style), refit
+    pos = sc["positions"].copy(); pos[: pos.shape[0] // 50, 1] += 0.05
+    g.animate(positions=pos, rebuild=False); g.render(0, 1); c = g.radiance()
+    sc2 = dict(sc); sc2["positions"] = pos
+    o2 = ptref.Oracle(); o2.set_scene(sc2); o2.set_instances(inst); o2.set_camera(camd); o2.set_settings(S); o2.resize(w, h); o2.render(0, 1)
+    assert np.array_equal(c[..., :3], o2.radiance()[..., :3])
+
+
+def test_tile_shards_reassemble_bit_exact():
+    """2-way pixel-tile sharding on one GPU: each shard traces only its tiles; pack -> (gather) -> unpack reproduces the
+    single-context frame bit-for-bit (RNG keyed on absolute pixel + sample index)."""
+    pt, scenes, parallel, ptref = _imports()
+    import torch
+    sc, cam = scenes.cornell_box("C2")
+    S = scenes.config_settings("C2"); w, h = 200, 136
+    camd = scenes.bridge_camera(w, h, **cam)
+    full = pt.PathTracer(); full.set_scene(sc); full.set_camera(camd); full.set_settings(S); full.resize(w, h); full.render(0, 2)
+    ref = full.radiance()
+    ctxs = []
+    for r in range(2):
+        c = pt.PathTracer(shard_rank=r, shard_count=2); c.set_scene(sc); c.set_camera(camd); c.set_settings(S); c.resize(w, h); c.render(0, 2); ctxs.append(c)
+    bufs = []
+    for r, c in enumerate(ctxs):
+        n, nbytes = c.shard_info()
+        assert n == parallel.shard_pixels(w, h, r, 2).size
+        t = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        c.pack_shard(t.data_ptr(), nbytes); torch.cuda.synchronize()
+        bufs.append(t)
+        own = parallel.shard_pixels(w, h, r, 2)
+        assert np.array_equal(t.cpu().numpy(), ref[(own & 0xFFFF).astype(np.int64), (own >> 16).astype(np.int64)])
+    ctxs[0].unpack_shard(bufs[1].data_ptr(), bufs[1].numel() * 4, 1)
+    assert np.array_equal(ctxs[0].radiance(), ref)
+
+
+def test_golden_fixture_c1_32():
+    """Committed fixture (tests/golden/c1_32_radiance.npy, written by the oracle in the build container): no oracle call here."""
+    pt, scenes, parallel, ptref = _imports()
+    path = os.path.join(ROOT, "tests", "golden", "c1_32_radiance.npy")
+    sc, cam = scenes.cornell_box("C1")
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(scenes.bridge_camera(32, 32, **cam)); g.set_settings(scenes.config_settings("C1")); g.resize(32, 32); g.render(0, 4)
+    assert np.array_equal(g.radiance(), np.load(path))
+
+
+def test_full_size_properties_1080p():
+    """BASELINE configs[1] at its full size (1920x1080, 4 spp, 8 bounces) through size-independent properties: accumulation is
+    associative over pt_render calls (bit-exact), finite/non-negative radiance, ray budget <= 17 per path, and the frame
+    and 8 complete pixel rows are bit-identical to the oracle."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.cornell_box("C2")
+    S = scenes.config_settings("C2"); w, h = 1920, 1080
+    camd = scenes.bridge_camera(w, h, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(w, h)
+    st = g.render(0, 4); a = g.radiance()
+    g.reset_accumulation(); g.render(0, 1); g.render(1, 2); g.render(3, 1); b = g.radiance()
+    assert np.array_equal(a, b)
+    assert np.isfinite(a).all() and (a >= 0).all() and np.all(a[..., 3] == 1.0)
+    assert st["extendRays"] + st["shadowRays"] <= 17 * st["pathsTraced"] + 4 * st["pathsTraced"]
+    # 8 full rows of the 1080p frame, bit-exact against the oracle (one oracle context per row keeps the accumulation weights aligned)
+    for y0 in range(4, h - 8, 135):
+        orow = ptref.Oracle(); orow.set_scene(sc); orow.set_camera(camd); orow.set_settings(S); orow.resize(w, h)
+        orow.render(0, 4, rect=(0, y0, w, y0 + 1))
+        assert np.array_equal(a[y0, :, :3], orow.radiance()[y0, :, :3]), y0

@@ -1,0 +1,86 @@
+"""Analytic-scene checks of the oracle (SURVEY.md §7 gate 1c/1d) and BVH == brute force."""
+import numpy as np
+import pytest
+
+from oracle import ptref
+from rtxpt_amd import scenes
+
+
+def make_oracle(sc, cam, settings, w, h):
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(settings); o.resize(w, h)
+    return o
+
+
+def test_direct_lighting_closed_form():
+    """Quad light over a diffuse plane, one bounce: L = rho/pi * Le * integral(cos cos' / r^2 dA). With F0 = 0 and view/light
+    directions near the normal the Schlick grazing term of the specular lobe is < 1e-4 of the diffuse term."""
+    rho, le, hgt, half = 0.6, 10.0, 1.0, 0.25
+    b = scenes.SceneBuilder()
+    m_plane = b.add_material(scenes.make_material(base=(rho,) * 3, roughness=1.0, ior=1.0))
+    m_light = b.add_material(scenes.make_material(base=(0.0,) * 3, emissive=(le,) * 3, roughness=1.0, ior=1.0))
+    b.begin_mesh()
+    p, i, uv, n, t = scenes.quad((-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5)); b.add_geometry(p, i, m_plane, uv=uv, normal=n, tangent=t)          # normal +y
+    p, i, uv, n, t = scenes.quad((-half, hgt, -half), (half, hgt, -half), (half, hgt, half), (-half, hgt, half)); b.add_geometry(p, i, m_light, uv=uv, normal=n, tangent=t)   # normal -y
+    b.add_instance(b.end_mesh())
+    sc = b.finish()
+    cam = dict(pos=(0.0, 0.5, 0.0), direction=(0, -1, 0), up=(0, 0, 1), fov_y=0.02, near_z=0.001, far_z=10, focal_distance=1.0)
+    xs = (np.arange(400) + 0.5) / 400 * 2 * half - half
+    X, Z = np.meshgrid(xs, xs)
+    r2 = X ** 2 + Z ** 2 + hgt ** 2
+    E = le * ((hgt * hgt) / (r2 * r2)).sum() * (2 * half / 400) ** 2
+    expect = rho / np.pi * E
+    for nee in (1, 0):
+        S = scenes.default_settings(bounceCount=1, diffuseBounceCount=8, NEEEnabled=nee, enableRussianRoulette=0, diffuseBrdf=0)
+        o = make_oracle(sc, cam, S, 16, 16); o.render(0, 64 if nee else 256)
+        got = o.radiance()[..., :3].mean()
+        assert abs(got - expect) / expect < (0.01 if nee else 0.04), (nee, got, expect)
+
+
+def test_nee_on_off_same_mean():
+    """MIS correctness: NEE on / off estimate the same image (SURVEY.md gate 1d)."""
+    sc, cam = scenes.cornell_box("C1")
+    w = h = 48
+    means = []
+    for nee in (0, 1):
+        S = scenes.default_settings(bounceCount=3, diffuseBounceCount=3, NEEEnabled=nee, enableRussianRoulette=0, diffuseBrdf=0)
+        o = make_oracle(sc, cam, S, w, h); o.render(0, 256 if nee == 0 else 64)
+        means.append(o.radiance()[..., :3].mean((0, 1)))
+    assert np.allclose(means[0], means[1], rtol=0.05), means
+
+
+def test_russian_roulette_unbiased():
+    sc, cam = scenes.cornell_box("C1")
+    w = h = 40
+    means = []
+    for rr in (0, 1):
+        S = scenes.default_settings(bounceCount=8, diffuseBounceCount=8, enableRussianRoulette=rr, diffuseBrdf=0)
+        o = make_oracle(sc, cam, S, w, h); o.render(0, 96)
+        means.append(o.radiance()[..., :3].mean((0, 1)))
+    assert np.allclose(means[0], means[1], rtol=0.05), means
+
+
+@pytest.mark.parametrize("scene", ["cornell", "bistro"])
+def test_bvh_equals_bruteforce(scene):
+    if scene == "cornell":
+        sc, cam = scenes.cornell_box("C2")
+    else:
+        sc, cam = scenes.bistro_like(scale=0.002, tex_size=32)
+    o = ptref.Oracle(); o.set_scene(sc)
+    rng = np.random.default_rng(11)
+    n = 20000 if scene == "cornell" else 3000
+    org = rng.uniform((0.01, 0.01, 0.01), (0.54, 0.54, 0.55), (n, 3)) if scene == "cornell" else rng.uniform((0, 0, 8), (120, 25, 32), (n, 3))
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, np.zeros((n, 1)), d, np.full((n, 1), 1e15)], 1).astype(np.float32)
+    a, b = o.trace_closest(rays), o.trace_closest(rays, brute=True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert (a[:, 1].view(np.uint32) != 0xFFFFFFFF).mean() > 0.5
+
+
+def test_alpha_tested_geometry_lets_rays_through():
+    sc, cam = scenes.bistro_like(scale=0.002, tex_size=32)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_settings(scenes.default_settings())
+    sub = o.subinstances()
+    assert ((sub[:, 0] >> 16) & 1).sum() >= 8          # the 8 tree meshes x instances are alpha tested
+    lights = o.lights()
+    assert lights["lights"].shape[0] > 5368 and lights["envLookupDim"] == 1024
+    assert lights["proxyIndices"].size > 600000
