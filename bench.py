@@ -140,18 +140,18 @@ def main():
 
 
 def cpu_baseline(sc, cam, S, W, H):
-    """The CPU oracle (a port: RTXPT has no CPU path) on a bounded sample of the SAME workload: a 480x270 block of
-    the 4K frame, 1 accumulated sample, all host cores (OpenMP). Reported per ray so that it is resolution independent."""
+    """The CPU oracle (a port: RTXPT has no CPU path) on a bounded sample of the SAME workload: a 960x540 block of
+    the 4K frame, 4 accumulated samples, all host cores (OpenMP). Reported per ray so that it is resolution independent."""
     from oracle import ptref
     from rtxpt_amd import scenes
     o = ptref.Oracle(); o.set_scene(sc); o.set_camera(scenes.bridge_camera(W, H, **cam)); o.set_settings(S); o.resize(W, H)
     t0 = time.perf_counter(); o.L.ptref_prepare(o.h); prep = time.perf_counter() - t0
-    x0, y0 = W // 2 - 240, H // 2 - 135
-    t0 = time.perf_counter(); o.render(0, 1, rect=(x0, y0, x0 + 480, y0 + 270)); dt = time.perf_counter() - t0
+    x0, y0 = W // 2 - 480, H // 2 - 270
+    t0 = time.perf_counter(); o.render(0, 4, rect=(x0, y0, x0 + 960, y0 + 540)); dt = time.perf_counter() - t0
     c = o.counters()
     rays = c["extendRays"] + c["shadowRays"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": ptref.num_threads(), "kind": "port",
-            "sample": "480x270 centre block of the 4K frame, 1 spp, %d rays in %.2f s (SAH BVH build + light bake %.1f s not included)" % (rays, dt, prep)}
+            "sample": "960x540 centre block of the 4K frame, 4 spp, %d rays in %.2f s (SAH BVH build + light bake %.1f s not included)" % (rays, dt, prep)}
 
 
 if __name__ == "__main__":

@@ -471,56 +471,102 @@ def bistro_like(scale=1.0, seed=SEED_BASE + 3, tex_size=1024, animated=False):
     p, i, uv, n, t = quad((L, 0, z0), (L, Hh, z0), (L, Hh, z1), (L, 0, z1), uv_scale=8.0); b.add_geometry(p, i, mats[3], uv=uv, normal=n, tangent=t)        # far cap, normal -x
     shell = b.end_mesh(); b.add_instance(shell)
 
-    # --- facade detail: long thin quads hugging both walls, split over 24 "building" meshes x material groups
-    side = rng.integers(0, 2, n_facade)
-    horiz = rng.random(n_facade) < 0.6
-    length = rng.uniform(0.4, 4.0, n_facade).astype(np.float32); width = rng.uniform(0.02, 0.15, n_facade).astype(np.float32)
-    cx = rng.uniform(0.5, L - 0.5, n_facade); cyv = rng.uniform(0.3, Hh - 0.3, n_facade); depth = rng.uniform(0.01, 0.35, n_facade)
-    cz = np.where(side == 0, z0 + depth, z1 - depth)
-    tilt = rng.normal(0, 0.15, n_facade)      # slats tilted out of the wall plane a little (louvre-like)
-    ax = np.where(horiz, 1.0, 0.0); ay = np.where(horiz, 0.0, 1.0)
-    a = np.stack([ax * length * 0.5, ay * length * 0.5, np.zeros(n_facade)], 1)
-    bx = np.where(horiz, 0.0, 1.0); by = np.where(horiz, 1.0, 0.0)
-    bvec = np.stack([bx * np.cos(tilt), by * np.cos(tilt), np.sin(tilt)], 1) * (width * 0.5)[:, None]
-    # face the street: normal = cross(a,b) should have +z on side 0 and -z on side 1
-    nz = np.cross(a, bvec)[:, 2]
-    want = np.where(side == 0, 1.0, -1.0)
-    flip = (nz * want) < 0
-    bvec = np.where(flip[:, None], -bvec, bvec)
-    c = np.stack([cx, cyv, cz], 1)
-    building = np.minimum((cx / (L / 24)).astype(np.int64), 23)
-    matsel = rng.integers(0, 32, n_facade)
-    uvs_scale = np.stack([length / 1.0, width / 1.0], 1)
-    for bi in range(24):
-        sel_b = building == bi
-        if not sel_b.any():
-            continue
+    # --- facade detail (60 % of the triangles): 8 "window bay" meshes of long thin quads — louvre shutters, balcony railings, window
+    # frames, brick courses — instanced over every wall of the canyon and of the side alleys, plus roof tile strips.
+    bay_w, bay_h = 3.0, 3.5
+    walls = [((0.0, 0.0, z0), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0), L), ((L, 0.0, z1), (-1.0, 0.0, 0.0), (0.0, 0.0, -1.0), L)]   # origin, along, normal, length
+    for k in range(10):                       # side alleys: two facing walls each, 7 m deep behind the main facades
+        xa = 6.0 + k * 12.0
+        walls.append(((xa, 0.0, z0), (0.0, 0.0, -1.0), (1.0, 0.0, 0.0), 7.0)); walls.append(((xa + 3.0, 0.0, z0 - 7.0), (0.0, 0.0, 1.0), (-1.0, 0.0, 0.0), 7.0))
+        walls.append(((xa + 3.0, 0.0, z1), (0.0, 0.0, 1.0), (-1.0, 0.0, 0.0), 7.0)); walls.append(((xa, 0.0, z1 + 7.0), (0.0, 0.0, -1.0), (1.0, 0.0, 0.0), 7.0))
+    n_rows = int(Hh // bay_h)
+    n_bays = sum(int(wl[3] // bay_w) for wl in walls) * n_rows
+    n_roof = max(8, int(60000 * scale))
+    per_bay = max(12, (n_facade - n_roof) // max(1, n_bays))
+    n_slats = max(2, int(per_bay * 0.20))      # per shutter leaf, 4 leaves per bay
+    n_bars = max(2, int(per_bay * 0.12))
+    n_courses = max(2, per_bay - 4 * n_slats - n_bars - 10)
+    bay_meshes = []
+    for v in range(8):
+        C, A, B, M = [], [], [], []
+        def add(cq, aq, bq, m):
+            C.append(np.atleast_2d(cq)); A.append(np.atleast_2d(aq)); B.append(np.atleast_2d(bq)); M.append(np.full(np.atleast_2d(cq).shape[0], m))
+        # local frame: x along the wall, y up, z out of the wall (towards the street). Quads face +z.
+        for wx in (0.75, 2.25):                # two windows per bay, each with two shutter leaves
+            for leaf in (-1, 1):
+                sx = wx + leaf * 0.48
+                ys = 0.9 + (np.arange(n_slats) + 0.5) * (1.6 / n_slats)
+                tilt = 0.5 + 0.1 * v
+                hw = 0.45 * (1.6 / n_slats)
+                cq = np.stack([np.full(n_slats, sx), ys, np.full(n_slats, 0.06)], 1)
+                aq = np.tile(np.array([[0.2, 0, 0]]), (n_slats, 1))
+                bq = np.tile(np.array([[0, hw * math.cos(tilt), hw * math.sin(tilt)]]), (n_slats, 1))
+                add(cq, aq, bq, (3 * v + 1) % 32)
+            # window frame (4 thin quads) + glass handled below
+            add([[wx, 0.9, 0.03], [wx, 2.5, 0.03]], [[0.3, 0, 0]] * 2, [[0, 0.03, 0]] * 2, 24 + v % 8)
+            add([[wx - 0.3, 1.7, 0.03], [wx + 0.3, 1.7, 0.03]], [[0.03, 0, 0]] * 2, [[0, 0.8, 0]] * 2, 24 + v % 8)
+        xs = 0.15 + (np.arange(n_bars) + 0.5) * (2.7 / n_bars)          # balcony railing bars + rail
+        add(np.stack([xs, np.full(n_bars, 0.45), np.full(n_bars, 0.45)], 1), np.tile([[0.4 * 2.7 / n_bars, 0, 0]], (n_bars, 1)), np.tile([[0, 0.45, 0]], (n_bars, 1)), (5 * v + 2) % 32)
+        add([[1.5, 0.92, 0.45], [1.5, 0.0, 0.25]], [[1.4, 0, 0], [1.4, 0, 0]], [[0, 0.03, 0], [0, 0, -0.25]], 24 + (v + 3) % 8)
+        ys = (np.arange(n_courses) + 0.5) * (bay_h / n_courses)           # brick courses / ledges: full-width thin strips
+        add(np.stack([np.full(n_courses, 1.5), ys, np.full(n_courses, 0.012 + 0.004 * (v % 3))], 1), np.tile([[1.5, 0, 0]], (n_courses, 1)),
+            np.tile([[0, 0.3 * bay_h / n_courses, 0]], (n_courses, 1)), (7 * v + 3) % 32)
+        C, A, B, M = np.concatenate(C).astype(np.float32), np.concatenate(A).astype(np.float32), np.concatenate(B).astype(np.float32), np.concatenate(M)
         b.begin_mesh()
-        for m in np.unique(matsel[sel_b]):
-            s = sel_b & (matsel == m)
-            p, i, uv, n, t = _quads(c[s], a[s], bvec[s], uvs_scale[s])
+        for m in np.unique(M):
+            sel = M == m
+            sz = np.stack([np.linalg.norm(A[sel], axis=1) * 2, np.linalg.norm(B[sel], axis=1) * 2], 1)
+            p, i, uv, n, t = _quads(C[sel], A[sel], B[sel], sz)
             b.add_geometry(p, i, mats[int(m)], uv=uv, normal=n, tangent=t)
-        # windows: a few thin glass panes per building
-        ng = max(2, int(40 * scale))
-        gx = rng.uniform(bi * L / 24 + 0.5, (bi + 1) * L / 24 - 0.5, ng); gy = rng.uniform(2, Hh - 2, ng); gs = rng.integers(0, 2, ng)
-        gc = np.stack([gx, gy, np.where(gs == 0, z0 + 0.4, z1 - 0.4)], 1)
-        ga = np.stack([np.full(ng, 0.6), np.zeros(ng), np.zeros(ng)], 1); gb = np.stack([np.zeros(ng), np.full(ng, 0.9), np.zeros(ng)], 1)
-        gb = np.where((gs == 1)[:, None], -gb, gb)
-        p, i, uv, n, t = _quads(gc, ga, gb)
-        b.add_geometry(p, i, glass_mats[bi % 4], uv=uv, normal=n, tangent=t)
-        b.add_instance(b.end_mesh())
+        gq = _quads(np.array([[0.75, 1.7, 0.02], [2.25, 1.7, 0.02]], np.float32), np.array([[0.27, 0, 0]] * 2, np.float32), np.array([[0, 0.77, 0]] * 2, np.float32))
+        b.add_geometry(gq[0], gq[1], glass_mats[v % 4], uv=gq[2], normal=gq[3], tangent=gq[4])
+        bay_meshes.append(b.end_mesh())
+    bay_idx = 0
+    for (org, along, nrm, length) in walls:
+        along = np.array(along, np.float32); nrm = np.array(nrm, np.float32); org = np.array(org, np.float32)
+        for col in range(int(length // bay_w)):
+            for row in range(n_rows):
+                o = org + along * (col * bay_w) + np.array([0, row * bay_h, 0], np.float32)
+                # local (x, y, z) -> world: x*along + y*up + z*normal  (row-major 3x4)
+                tr = np.array([along[0], 0, nrm[0], o[0], along[1], 1, nrm[1], o[1], along[2], 0, nrm[2], o[2]], np.float32)
+                b.add_instance(bay_meshes[(bay_idx * 5 + row) % 8], tr)
+                bay_idx += 1
+    # alley back walls + side walls (large quads behind the detail)
+    b.begin_mesh()
+    for (org, along, nrm, length) in walls[2:]:
+        org = np.array(org, np.float32); along = np.array(along, np.float32)
+        p0 = org; p1 = org + along * length
+        # winding such that cross(p1-p0, up) == normal direction
+        q = quad(tuple(p0), tuple(p1), tuple(p1 + np.array([0, Hh, 0], np.float32)), tuple(p0 + np.array([0, Hh, 0], np.float32)), uv_scale=6.0)
+        if np.dot(q[3][0], np.array(nrm, np.float32)) < 0:
+            q = quad(tuple(p1), tuple(p0), tuple(p0 + np.array([0, Hh, 0], np.float32)), tuple(p1 + np.array([0, Hh, 0], np.float32)), uv_scale=6.0)
+        b.add_geometry(q[0], q[1], mats[4 + (int(org[0]) % 4)], uv=q[2], normal=q[3], tangent=q[4])
+    b.add_instance(b.end_mesh())
+    # roofs: sloped tile strips above both facade rows
+    for sidez, sgn in ((z0, -1.0), (z1, 1.0)):
+        rows_n = n_roof // 2
+        tq = (np.arange(rows_n) + 0.5) / rows_n
+        slope = 0.45
+        cq = np.stack([np.full(rows_n, L / 2), Hh + tq * 8.0 * slope, sidez + sgn * tq * 8.0], 1)
+        aq = np.tile([[L / 2, 0, 0]], (rows_n, 1)).astype(np.float32)
+        hw = 0.6 * 8.0 / rows_n
+        bq = np.tile([[0, hw * slope, sgn * hw]], (rows_n, 1)).astype(np.float32)
+        if sgn > 0:
+            aq = -aq                              # keep the normal pointing up/outwards
+        p, i, uv, n, t = _quads(cq, aq, bq, np.tile([[40.0, 0.2]], (rows_n, 1)))
+        b.begin_mesh(); b.add_geometry(p, i, mats[10 + (0 if sgn < 0 else 1)], uv=uv, normal=n, tangent=t); b.add_instance(b.end_mesh())
 
     # --- foliage: 8 tree meshes of alpha-tested cards, instanced along the pavements
     n_tree_meshes, n_tree_inst = 8, 25
     cards_per_tree = max(8, n_cards // (n_tree_meshes * n_tree_inst))
     tree_meshes = []
     for tm in range(n_tree_meshes):
-        r = rng.random(cards_per_tree) ** (1 / 3) * 1.6
+        r = rng.random(cards_per_tree) ** (1 / 3) * 2.2
         dirv = rng.normal(size=(cards_per_tree, 3)); dirv /= np.linalg.norm(dirv, axis=1, keepdims=True)
-        cc = dirv * r[:, None] * np.array([1.0, 0.8, 1.0]) + np.array([0, 4.0, 0])
+        cc = dirv * r[:, None] * np.array([1.0, 0.8, 1.0]) + np.array([0, 4.6, 0])
         ua = rng.normal(size=(cards_per_tree, 3)); ua /= np.linalg.norm(ua, axis=1, keepdims=True)
         ub = np.cross(ua, rng.normal(size=(cards_per_tree, 3))); ub /= np.maximum(np.linalg.norm(ub, axis=1, keepdims=True), 1e-9)
-        sz = rng.uniform(0.12, 0.3, cards_per_tree)[:, None]
+        sz = rng.uniform(0.05, 0.12, cards_per_tree)[:, None]
         p, i, uv, n, t = _quads(cc, ua * sz, ub * sz)
         b.begin_mesh()
         b.add_geometry(p, i, leaf_mats[tm % 4], uv=uv, normal=n, tangent=t, geom_flags=GEOMF_ALPHA_TESTED)
@@ -541,8 +587,8 @@ def bistro_like(scale=1.0, seed=SEED_BASE + 3, tex_size=1024, animated=False):
     per_group = max(1, n_boxes // n_groups)
     clutter_instances = []
     for gidx in range(n_groups):
-        bc = np.stack([rng.uniform(-1.5, 1.5, per_group), np.zeros(per_group), rng.uniform(-1.5, 1.5, per_group)], 1).astype(np.float32)
-        bh = np.stack([rng.uniform(0.05, 0.45, per_group), rng.uniform(0.05, 0.6, per_group), rng.uniform(0.05, 0.45, per_group)], 1).astype(np.float32)
+        bc = np.stack([rng.uniform(-4.0, 4.0, per_group), np.zeros(per_group), rng.uniform(-4.0, 4.0, per_group)], 1).astype(np.float32)
+        bh = np.stack([rng.uniform(0.03, 0.25, per_group), rng.uniform(0.03, 0.4, per_group), rng.uniform(0.03, 0.25, per_group)], 1).astype(np.float32)
         bc[:, 1] = bh[:, 1] + rng.uniform(0, 1.2, per_group) * (rng.random(per_group) < 0.3)
         C, A, B = _boxes(bc, bh, rng.uniform(0, 6.283, per_group))
         msel = rng.integers(0, 8, C.shape[0] // 6); msel6 = np.tile(msel, 6)
@@ -553,7 +599,7 @@ def bistro_like(scale=1.0, seed=SEED_BASE + 3, tex_size=1024, animated=False):
             b.add_geometry(p, i, clutter_mats[int(m)], uv=uv, normal=n, tangent=t)
         mesh = b.end_mesh()
         clutter_instances.append(len(b.instances))
-        b.add_instance(mesh, trs((float(rng.uniform(3, L - 3)), 0.0, float(rng.uniform(z0 + 3.5, z1 - 3.5))), rot_y=float(rng.uniform(0, 6.283))))
+        b.add_instance(mesh, trs((float(rng.uniform(6, L - 6)), 0.0, float(rng.uniform(z0 + 6.0, z1 - 6.0))), rot_y=float(rng.uniform(0, 6.283))))
 
     # --- emissive: lamps and string lights (2 triangles each), 16 emissive materials with log-uniform radiance
     ex = rng.uniform(1, L - 1, n_em); ey = rng.uniform(2.5, 7.0, n_em); ez = rng.uniform(z0 + 0.6, z1 - 0.6, n_em)
