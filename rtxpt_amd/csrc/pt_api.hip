@@ -151,7 +151,7 @@ void refresh_scene_view(pt_context* c) {
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = (uint)c->proxyIndices.size();
     d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
-    d.nodes = c->bvh.nodes; d.tris = c->bvh.triSorted; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
+    d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
 }
 
 // SubInstanceData fill (Rtxpt/Materials/MaterialsBaker.cpp:960-1017) + primitive table; then GPU LBVH build
@@ -621,6 +621,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     PT_CHECK_HIP(c, hipMemcpyAsync(&hwc, wc, sizeof(hwc), hipMemcpyDeviceToHost, st));
     PT_CHECK_HIP(c, hipStreamSynchronize(st));
     PT_CHECK_HIP(c, hipGetLastError());
+    if (hwc.overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal stack overflow (raise BVH8_STACK)");
     c->accumCount += count;
     if (stats) {
         float ms = 0; (void)hipEventElapsedTime(&ms, ev[t0], ev[t1]); stats->gpuMilliseconds = ms;
@@ -679,7 +680,7 @@ static int trace_probe(pt_context* c, const float* rays, uint32_t n, float* outC
     if (outClosest) PT_CHECK_HIP(c, dc.resize(n)); else PT_CHECK_HIP(c, dv.resize(n));
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, c->stream);
-    launch_trace_probe(c->dsc, dr.p, n, outClosest ? dc.p : nullptr, outClosest ? nullptr : dv.p, c->stream);
+    launch_trace_probe(c->dsc, dr.p, n, outClosest ? dc.p : nullptr, outClosest ? nullptr : dv.p, &c->dCounters.p->overflow, c->stream);
     (void)hipEventRecord(e1, c->stream);
     if (outClosest) PT_CHECK_HIP(c, hipMemcpyAsync(outClosest, dc.p, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     else PT_CHECK_HIP(c, hipMemcpyAsync(outVisible, dv.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));

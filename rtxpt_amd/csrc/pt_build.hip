@@ -175,6 +175,72 @@ __global__ void k_init_bounds(uint* sceneBounds) {
     if (threadIdx.x < 3) sceneBounds[threadIdx.x] = 0xFFFFFFFFu; else if (threadIdx.x < 6) sceneBounds[threadIdx.x] = 0u;
 }
 
+// ---- BVH2 -> BVH8 collapse (one thread per wide node of the current level; host loops over levels)
+__device__ __forceinline__ float box_area(float3 mn, float3 mx) { float3 e = mx - mn; return e.x * e.y + e.y * e.z + e.z * e.x; }
+__device__ __forceinline__ uint pow2_exp_ge(float s) {          // biased exponent eb with 2^(eb-127) >= s, eb in [1, 254]
+    uint b = __float_as_uint(s);
+    uint eb = (b >> 23) & 0xFFu;
+    if (b & 0x7FFFFFu) eb++;
+    if (eb < 1u) eb = 1u;
+    if (eb > 254u) eb = 254u;
+    return eb;
+}
+__device__ __forceinline__ float q_decode(float o, uint q, float s) { return o + (float)q * s; }   // identical expression in traversal
+__global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ nodes2, const uint* __restrict__ levelIn, uint nIn, uint* __restrict__ levelOut,
+                                                   uint* __restrict__ counter, Bvh8Node* __restrict__ nodes8) {
+    uint i = blockIdx.x * 128u + threadIdx.x;
+    if (i >= nIn) return;
+    uint wide = levelIn[2 * i], r = levelIn[2 * i + 1];
+    float3 cmn[8], cmx[8]; uint cref[8]; uint n = 0;
+    { BvhNode nd = nodes2[r];
+      if (nd.left != BVH_EMPTY) { cmn[n] = nd.lmin; cmx[n] = nd.lmax; cref[n] = nd.left; n++; }
+      if (nd.right != BVH_EMPTY) { cmn[n] = nd.rmin; cmx[n] = nd.rmax; cref[n] = nd.right; n++; } }
+    while (n < 8u) {
+        int best = -1; float bestA = -1.f;
+        for (uint k = 0; k < n; k++) if (!(cref[k] & BVH_LEAF_BIT)) { float a = box_area(cmn[k], cmx[k]); if (a > bestA) { bestA = a; best = (int)k; } }
+        if (best < 0) break;
+        BvhNode nd = nodes2[cref[best]];
+        cmn[best] = nd.lmin; cmx[best] = nd.lmax; cref[best] = nd.left;
+        cmn[n] = nd.rmin; cmx[n] = nd.rmax; cref[n] = nd.right; n++;
+    }
+    float3 mn = cmn[0], mx = cmx[0];
+    for (uint k = 1; k < n; k++) { mn = min3v(mn, cmn[k]); mx = max3v(mx, cmx[k]); }
+    uint ex = pow2_exp_ge((mx.x - mn.x) / 255.0f), ey = pow2_exp_ge((mx.y - mn.y) / 255.0f), ez = pow2_exp_ge((mx.z - mn.z) / 255.0f);
+    // make sure code 255 reaches the node maximum under the decode arithmetic
+    while (q_decode(mn.x, 255u, __uint_as_float(ex << 23)) < mx.x && ex < 254u) ex++;
+    while (q_decode(mn.y, 255u, __uint_as_float(ey << 23)) < mx.y && ey < 254u) ey++;
+    while (q_decode(mn.z, 255u, __uint_as_float(ez << 23)) < mx.z && ez < 254u) ez++;
+    float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23), sz = __uint_as_float(ez << 23);
+    uint nInner = 0;
+    for (uint k = 0; k < n; k++) if (!(cref[k] & BVH_LEAF_BIT)) nInner++;
+    uint wbase = 0, obase = 0;
+    if (nInner) { wbase = atomicAdd(&counter[0], nInner); obase = atomicAdd(&counter[1], nInner); }
+    Bvh8Node out;
+    out.ox = mn.x; out.oy = mn.y; out.oz = mn.z; out.exps = ex | (ey << 8) | (ez << 16) | (n << 24);
+    out._pad[0] = out._pad[1] = out._pad[2] = out._pad[3] = 0;
+    uint inner = 0;
+    for (uint k = 0; k < 8u; k++) {
+        Bvh8Child c;
+        if (k >= n) { c.ref = BVH_EMPTY; c.qloqhi0 = 0x00FFFFFFu; c.qhi1 = 0u; out.c[k] = c; continue; }     // inverted box
+        float lo[3] = {cmn[k].x, cmn[k].y, cmn[k].z}, hi[3] = {cmx[k].x, cmx[k].y, cmx[k].z}, o[3] = {mn.x, mn.y, mn.z}, sc3[3] = {sx, sy, sz};
+        uint ql[3], qh[3];
+        for (int a = 0; a < 3; a++) {
+            float fl = floorf((lo[a] - o[a]) / sc3[a]); fl = fminf(fmaxf(fl, 0.f), 255.f); uint q = (uint)fl;
+            while (q > 0u && q_decode(o[a], q, sc3[a]) > lo[a]) q--;
+            ql[a] = q;
+            float fh = ceilf((hi[a] - o[a]) / sc3[a]); fh = fminf(fmaxf(fh, 0.f), 255.f); q = (uint)fh;
+            while (q < 255u && q_decode(o[a], q, sc3[a]) < hi[a]) q++;
+            qh[a] = q;
+        }
+        c.qloqhi0 = ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24);
+        c.qhi1 = qh[1] | (qh[2] << 8);
+        if (cref[k] & BVH_LEAF_BIT) c.ref = cref[k];
+        else { c.ref = wbase + inner; levelOut[2 * (obase + inner)] = wbase + inner; levelOut[2 * (obase + inner) + 1] = cref[k]; inner++; }
+        out.c[k] = c;
+    }
+    nodes8[wide] = out;
+}
+
 hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
     __builtin_memset(&b, 0, sizeof(b));
     uint n = numTris < 2 ? 2 : numTris;
@@ -187,6 +253,7 @@ hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
     PT_HIP_TRY(hipMalloc(&b.tickets, 4 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.boxLmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxLmax, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmax, 16 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.sceneBounds, 32)); PT_HIP_TRY(hipMalloc(&b.nodes, sizeof(BvhNode) * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.nodes8, sizeof(Bvh8Node) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelA, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelB, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.wideCounter, 16));
     size_t tmp = 0;
     PT_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64));
     b.sortTempBytes = tmp; PT_HIP_TRY(hipMalloc(&b.sortTemp, tmp ? tmp : 16));
@@ -194,7 +261,7 @@ hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
 }
 void bvh_free(BvhBuildBuffers& b) {
     void* ps[] = {b.triWorld, b.triSorted, b.keys, b.keysSorted, b.prims, b.primsSorted, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast, b.tickets,
-                  b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp};
+                  b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter};
     for (void* p : ps) if (p) (void)hipFree(p);
     __builtin_memset(&b, 0, sizeof(b));
 }
@@ -203,6 +270,22 @@ static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, uint n, hipStream_t st
     PT_HIP_TRY(hipMemsetAsync(b.tickets, 0, 4 * (size_t)(n < 2 ? 2 : n), st));
     hipLaunchKernelGGL(k_bounds, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.childL, b.parent, b.leafParent, b.tickets, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax);
     hipLaunchKernelGGL(k_emit, dim3(g), dim3(256), 0, st, n, b.childL, b.childR, b.rangeFirst, b.rangeLast, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes);
+    // BVH8 collapse, level by level (the per-level node count comes back to the host: a build step, not the hot path)
+    uint init[4] = {0u, 0u, 1u, 0u};                       // levelA[0] = (wide 0, bvh2 root 0); counter = {next wide index = 1, out count = 0}
+    PT_HIP_TRY(hipMemcpyAsync(b.levelA, init, 8, hipMemcpyHostToDevice, st));
+    PT_HIP_TRY(hipMemcpyAsync(b.wideCounter, init + 2, 8, hipMemcpyHostToDevice, st));
+    uint nIn = 1, levels = 0; uint* in = b.levelA; uint* out = b.levelB;
+    while (nIn) {
+        hipLaunchKernelGGL(k_collapse8, dim3((nIn + 127u) / 128u), dim3(128), 0, st, b.nodes, in, nIn, out, b.wideCounter, b.nodes8);
+        uint host[2];
+        PT_HIP_TRY(hipMemcpyAsync(host, b.wideCounter, 8, hipMemcpyDeviceToHost, st));
+        PT_HIP_TRY(hipStreamSynchronize(st));
+        b.numNodes8 = host[0]; nIn = host[1];
+        uint zero = 0; PT_HIP_TRY(hipMemcpyAsync(b.wideCounter + 1, &zero, 4, hipMemcpyHostToDevice, st));
+        uint* t = in; in = out; out = t;
+        if (++levels > 4096u) return hipErrorUnknown;
+    }
+    b.collapseLevels = levels;
     return hipGetLastError();
 }
 hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {

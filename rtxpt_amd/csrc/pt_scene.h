@@ -54,6 +54,13 @@ static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
 struct BvhNode { float3 lmin, lmax, rmin, rmax; uint left, right, _pad0, _pad1; };           // child ref: bit31 = leaf (first<<3 | count-1)
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_LEAF = 4, BVH_STACK = 64;
+// BVH8 node, 128 B = one cache line: the 8 lanes of a ray's lane group each fetch one 12 B child slot plus the shared 16 B header, so a
+// whole node costs one line lookup per group instead of four 16 B gathers per lane. Child boxes are 8-bit quantised relative to the node
+// origin with power-of-two scales (conservative: decoded lo <= true lo, decoded hi >= true hi, verified with the decode arithmetic itself).
+struct Bvh8Child { uint ref; uint qloqhi0; uint qhi1; };     // ref | qlo.xyz,qhi.x | qhi.y,qhi.z (low 16 bits)
+struct Bvh8Node { float ox, oy, oz; uint exps; Bvh8Child c[8]; uint _pad[4]; };
+static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
+static const uint BVH8_STACK = 96, BVH8_STACK_STRIDE = 97;
 
 struct TexInfo { uint w, h, mipLevels, _pad; unsigned long long base; uint mipOffset[16]; };   // offsets in texels relative to base
 
@@ -64,7 +71,7 @@ struct DeviceScene {
     const TexInfo* textures; const float4* texels;
     TexInfo envTex; uint envEnabled; float3x4 envToWorld, envToLocal; float3 envColorMultiplier;
     LightTable lights;
-    const BvhNode* nodes; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
+    const BvhNode* nodes; const Bvh8Node* nodes8; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
 };
 
 struct HitInfo { float t; uint prim; float u, v; };

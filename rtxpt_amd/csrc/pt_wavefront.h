@@ -11,7 +11,6 @@
 // Queue appends use one atomic per wave64: ballot -> popcount prefix -> lane-0 atomicAdd -> broadcast.
 #pragma once
 #include "pt_path.h"
-#include "pt_traverse.h"
 #include <hip/hip_runtime.h>
 
 namespace ptk {
@@ -19,7 +18,7 @@ namespace ptk {
 struct PathPool { uint4* s0; uint4* s1; uint4* s2; uint4* s3; uint4* s4; uint4* hit; };
 struct ShadowQueue { float4* q0; float4* q1; float4* q2; };
 struct WaveCounters {           // device-resident counters / stats (one 256 B block)
-    uint extendCount[2]; uint shadowCount; uint _pad0;
+    uint extendCount[2]; uint shadowCount; uint overflow;
     unsigned long long hits, nodeVisitsExt, triTestsExt, nodeVisitsSh, triTestsSh;
 };
 
@@ -29,7 +28,7 @@ void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn
                   ShadowQueue sq, WaveCounters* wc, hipStream_t st);
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st);
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st);
-void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, hipStream_t st);
+void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st);
 void launch_pack(const float4* accum, const uint* ownedPixels, uint numOwned, uint width, float4* dst, hipStream_t st);
 void launch_unpack(float4* accum, const uint* pixels, uint num, uint width, const float4* src, hipStream_t st);
 void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, float4* out, hipStream_t st);

@@ -3,10 +3,10 @@
 // (Rtxpt/Shaders/PathTracerSample.hlsl:200-250) and relies on SER to re-sort threads (:136-148). Here each stage is its own
 // kernel over a compacted queue, so every wave starts full regardless of how many paths died in the previous bounce.
 #include "pt_wavefront.h"
+#include "pt_traverse8.h"
 
 namespace ptk {
 
-static const uint EXTEND_BLOCK = 128;     // 2 waves; LDS stack 64 entries x 128 threads x 4 B = 32 KiB per block
 
 __device__ __forceinline__ uint lane_id() { return __lane_id(); }
 // one atomic per wave: returns this lane's slot if `pred`, garbage otherwise
@@ -54,17 +54,19 @@ __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool 
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(EXTEND_BLOCK) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc) {
-    __shared__ uint stack[BVH_STACK * EXTEND_BLOCK];
+__global__ void __launch_bounds__(T8_BLOCK) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     const uint count = *countPtr;
-    TraverseCounters ctr; ctr.nodeVisits = 0; ctr.triTests = 0;
-    for (uint i = blockIdx.x * EXTEND_BLOCK + threadIdx.x; i < count; i += gridDim.x * EXTEND_BLOCK) {
+    Traverse8Counters ctr; ctr.nodeVisits = 0; ctr.triTests = 0;
+    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax) -> uint {
         uint p = queue[i];
         uint4 a = pool.s0[p], b = pool.s1[p];
-        float3 o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)), d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
-        HitInfo h = traverse<false, COUNT>(sc, o, d, 0.0f, kMaxRayTravel, stack + threadIdx.x, EXTEND_BLOCK, ctr);
-        pool.hit[p] = make_uint4(asuint(h.t), h.prim, asuint(h.u), asuint(h.v));
-    }
+        o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)); d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
+        tmin = 0.0f; tmax = kMaxRayTravel;
+        return p;
+    };
+    auto commit = [&](uint p, const HitInfo& h) { pool.hit[p] = make_uint4(asuint(h.t), h.prim, asuint(h.u), asuint(h.v)); };
+    traverse8_persistent<false, COUNT>(sc, count, stack, fetch, commit, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); }
 }
 
@@ -97,23 +99,26 @@ __global__ void __launch_bounds__(256) k_shade(PathKernelContext k, PathPool poo
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(EXTEND_BLOCK) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc) {
-    __shared__ uint stack[BVH_STACK * EXTEND_BLOCK];
+__global__ void __launch_bounds__(T8_BLOCK) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     const uint count = *countPtr;
-    TraverseCounters ctr; ctr.nodeVisits = 0; ctr.triTests = 0;
-    for (uint i = blockIdx.x * EXTEND_BLOCK + threadIdx.x; i < count; i += gridDim.x * EXTEND_BLOCK) {
+    Traverse8Counters ctr; ctr.nodeVisits = 0; ctr.triTests = 0;
+    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax) -> uint {
         float4 a = sq.q0[i], b = sq.q1[i];
-        HitInfo h = traverse<true, COUNT>(sc, make_float3(a.x, a.y, a.z), make_float3(b.x, b.y, b.z), 0.0f, a.w, stack + threadIdx.x, EXTEND_BLOCK, ctr);
-        if (h.prim == 0xFFFFFFFFu) {                       // visible: nothing committed (BridgeDonut:1026)
-            float4 r = sq.q2[i];
-            uint p = asuint(b.w);
-            uint4 c = pool.s2[p];
-            uint pack45[2] = {c.z, c.w};
-            PathKernelContext::ResolveShadow(pack45, make_float3(r.x, r.y, r.z));
-            c.z = pack45[0]; c.w = pack45[1];
-            pool.s2[p] = c;
-        }
-    }
+        o = make_float3(a.x, a.y, a.z); d = make_float3(b.x, b.y, b.z); tmin = 0.0f; tmax = a.w;
+        return i;
+    };
+    auto commit = [&](uint i, const HitInfo& h) {
+        if (h.prim != 0xFFFFFFFFu) return;                 // occluded; visible == nothing committed (BridgeDonut:1026)
+        float4 r = sq.q2[i];
+        uint p = asuint(sq.q1[i].w);
+        uint4 c = pool.s2[p];
+        uint pack45[2] = {c.z, c.w};
+        PathKernelContext::ResolveShadow(pack45, make_float3(r.x, r.y, r.z));
+        c.z = pack45[0]; c.w = pack45[1];
+        pool.s2[p] = c;
+    };
+    traverse8_persistent<true, COUNT>(sc, count, stack, fetch, commit, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsSh); wave_add64(ctr.triTests, &wc->triTestsSh); }
 }
 
@@ -134,19 +139,20 @@ __global__ void __launch_bounds__(256) k_accumulate(PathPool pool, const uint* _
     accum[addr] = acc;
 }
 
-__global__ void __launch_bounds__(EXTEND_BLOCK) k_trace_probe(DeviceScene sc, const float4* __restrict__ rays, uint n, float4* __restrict__ outClosest, uint* __restrict__ outVisible) {
-    __shared__ uint stack[BVH_STACK * EXTEND_BLOCK];
-    TraverseCounters ctr; ctr.nodeVisits = 0; ctr.triTests = 0;
-    for (uint i = blockIdx.x * EXTEND_BLOCK + threadIdx.x; i < n; i += gridDim.x * EXTEND_BLOCK) {
+__global__ void __launch_bounds__(T8_BLOCK) k_trace_probe(DeviceScene sc, const float4* __restrict__ rays, uint n, float4* __restrict__ outClosest, uint* __restrict__ outVisible, uint* overflow) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
+    Traverse8Counters ctr; ctr.nodeVisits = 0; ctr.triTests = 0;
+    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax) -> uint {
         float4 a = rays[2 * i], b = rays[2 * i + 1];
-        float3 o = make_float3(a.x, a.y, a.z), d = make_float3(b.x, b.y, b.z);
-        if (outClosest) {
-            HitInfo h = traverse<false, false>(sc, o, d, a.w, b.w, stack + threadIdx.x, EXTEND_BLOCK, ctr);
-            outClosest[i] = make_float4(h.t, asfloat(h.prim), h.u, h.v);
-        } else {
-            HitInfo h = traverse<true, false>(sc, o, d, a.w, b.w, stack + threadIdx.x, EXTEND_BLOCK, ctr);
-            outVisible[i] = (h.prim == 0xFFFFFFFFu) ? 1u : 0u;
-        }
+        o = make_float3(a.x, a.y, a.z); d = make_float3(b.x, b.y, b.z); tmin = a.w; tmax = b.w;
+        return i;
+    };
+    if (outClosest) {
+        auto commit = [&](uint i, const HitInfo& h) { outClosest[i] = make_float4(h.t, asfloat(h.prim), h.u, h.v); };
+        traverse8_persistent<false, false>(sc, n, stack, fetch, commit, ctr, overflow);
+    } else {
+        auto commit = [&](uint i, const HitInfo& h) { outVisible[i] = (h.prim == 0xFFFFFFFFu) ? 1u : 0u; };
+        traverse8_persistent<true, false>(sc, n, stack, fetch, commit, ctr, overflow);
     }
 }
 
@@ -251,6 +257,7 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
     }
 }
 
+static const uint T8_MAX_BLOCKS = 256 * 6 * 4;     // persistent waves stride over 64-ray chunks
 static inline uint grid_for(uint count, uint block, uint maxBlocks) { uint g = (count + block - 1) / block; if (g < 1) g = 1; if (g > maxBlocks) g = maxBlocks; return g; }
 
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st) {
@@ -258,23 +265,23 @@ void launch_generate(const PathKernelContext& k, PathPool pool, const uint* owne
     hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, st, k, pool, ownedPixels, numOwned, sampleFirst, spp, queue);
 }
 void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st) {
-    uint g = grid_for(count, EXTEND_BLOCK, 256 * 5 * 8);
-    if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(EXTEND_BLOCK), 0, st, sc, pool, queue, countPtr, wc);
-    else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(EXTEND_BLOCK), 0, st, sc, pool, queue, countPtr, wc);
+    uint g = grid_for(count, T8_BLOCK, T8_MAX_BLOCKS);
+    if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc);
+    else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc);
 }
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, hipStream_t st) {
     hipLaunchKernelGGL(k_shade, dim3((countIn + 255) / 256), dim3(256), 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
 }
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st) {
-    uint g = grid_for(count, EXTEND_BLOCK, 256 * 5 * 8);
-    if (counters) hipLaunchKernelGGL((k_shadow<true>), dim3(g), dim3(EXTEND_BLOCK), 0, st, sc, pool, sq, countPtr, wc);
-    else hipLaunchKernelGGL((k_shadow<false>), dim3(g), dim3(EXTEND_BLOCK), 0, st, sc, pool, sq, countPtr, wc);
+    uint g = grid_for(count, T8_BLOCK, T8_MAX_BLOCKS);
+    if (counters) hipLaunchKernelGGL((k_shadow<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc);
+    else hipLaunchKernelGGL((k_shadow<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc);
 }
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3((numOwned + 255) / 256), dim3(256), 0, st, pool, ownedPixels, numOwned, spp, accum, accumCountBase, width);
 }
-void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, hipStream_t st) {
-    hipLaunchKernelGGL(k_trace_probe, dim3(grid_for(n, EXTEND_BLOCK, 256 * 5 * 8)), dim3(EXTEND_BLOCK), 0, st, sc, rays, n, outClosest, outVisible);
+void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st) {
+    hipLaunchKernelGGL(k_trace_probe, dim3(grid_for(n, T8_BLOCK, T8_MAX_BLOCKS)), dim3(T8_BLOCK), 0, st, sc, rays, n, outClosest, outVisible, overflow);
 }
 void launch_pack(const float4* accum, const uint* pixels, uint num, uint width, float4* dst, hipStream_t st) {
     hipLaunchKernelGGL(k_pack, dim3((num + 255) / 256), dim3(256), 0, st, accum, pixels, num, width, dst);
