@@ -16,7 +16,7 @@ import numpy as np
 from . import scenes  # noqa: F401  (scene generators + data-contract dtypes)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355pt.so")
+LIB_PATH = os.environ.get("MI355PT_LIB", os.path.join(_HERE, "libmi355pt.so"))   # MI355PT_LIB: developer A/B builds only
 
 PT_OK = 0
 STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3: "PT_ERROR_HIP", 4: "PT_ERROR_IO", 5: "PT_ERROR_UNSUPPORTED", 6: "PT_ERROR_NOT_READY"}

@@ -220,8 +220,7 @@ __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ n
     out._pad[0] = out._pad[1] = out._pad[2] = out._pad[3] = 0;
     uint inner = 0;
     for (uint k = 0; k < 8u; k++) {
-        Bvh8Child c;
-        if (k >= n) { c.ref = BVH_EMPTY; c.qloqhi0 = 0x00FFFFFFu; c.qhi1 = 0u; out.c[k] = c; continue; }     // inverted box
+        if (k >= n) { out.ref[k] = BVH_EMPTY; out.q[k] = make_uint2(0x00FFFFFFu, 0u); continue; }     // inverted box
         float lo[3] = {cmn[k].x, cmn[k].y, cmn[k].z}, hi[3] = {cmx[k].x, cmx[k].y, cmx[k].z}, o[3] = {mn.x, mn.y, mn.z}, sc3[3] = {sx, sy, sz};
         uint ql[3], qh[3];
         for (int a = 0; a < 3; a++) {
@@ -232,11 +231,9 @@ __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ n
             while (q < 255u && q_decode(o[a], q, sc3[a]) < hi[a]) q++;
             qh[a] = q;
         }
-        c.qloqhi0 = ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24);
-        c.qhi1 = qh[1] | (qh[2] << 8);
-        if (cref[k] & BVH_LEAF_BIT) c.ref = cref[k];
-        else { c.ref = wbase + inner; levelOut[2 * (obase + inner)] = wbase + inner; levelOut[2 * (obase + inner) + 1] = cref[k]; inner++; }
-        out.c[k] = c;
+        out.q[k] = make_uint2(ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24), qh[1] | (qh[2] << 8));
+        if (cref[k] & BVH_LEAF_BIT) out.ref[k] = cref[k];
+        else { out.ref[k] = wbase + inner; levelOut[2 * (obase + inner)] = wbase + inner; levelOut[2 * (obase + inner) + 1] = cref[k]; inner++; }
     }
     nodes8[wide] = out;
 }

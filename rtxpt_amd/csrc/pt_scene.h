@@ -53,14 +53,22 @@ struct TriRecord { float3 v0; uint prim; float3 e1; uint flags; float3 e2; uint 
 static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
 struct BvhNode { float3 lmin, lmax, rmin, rmax; uint left, right, _pad0, _pad1; };           // child ref: bit31 = leaf (first<<3 | count-1)
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
-static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_LEAF = 4, BVH_STACK = 64;
+#ifndef PT_BVH_MAX_LEAF
+#define PT_BVH_MAX_LEAF 8
+#endif
+static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_LEAF = PT_BVH_MAX_LEAF, BVH_STACK = 64;
 // BVH8 node, 128 B = one cache line: the 8 lanes of a ray's lane group each fetch one 12 B child slot plus the shared 16 B header, so a
 // whole node costs one line lookup per group instead of four 16 B gathers per lane. Child boxes are 8-bit quantised relative to the node
 // origin with power-of-two scales (conservative: decoded lo <= true lo, decoded hi >= true hi, verified with the decode arithmetic itself).
-struct Bvh8Child { uint ref; uint qloqhi0; uint qhi1; };     // ref | qlo.xyz,qhi.x | qhi.y,qhi.z (low 16 bits)
-struct Bvh8Node { float ox, oy, oz; uint exps; Bvh8Child c[8]; uint _pad[4]; };
+struct Bvh8Node { float ox, oy, oz; uint exps; uint ref[8]; uint2 q[8]; uint _pad[4]; };   // q[k] = qlo.xyz,qhi.x | qhi.y,qhi.z (low 16 bits)
+typedef uint u32x4 __attribute__((ext_vector_type(4)));      // 16-byte aligned vector loads (global_load_dwordx4)
+typedef uint u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
-static const uint BVH8_STACK = 96, BVH8_STACK_STRIDE = 97;
+#ifndef PT_BVH8_STACK
+#define PT_BVH8_STACK 96
+#endif
+static const uint BVH8_STACK = PT_BVH8_STACK, BVH8_STACK_STRIDE = PT_BVH8_STACK + 1;   // odd stride: groups land on different LDS banks
 
 struct TexInfo { uint w, h, mipLevels, _pad; unsigned long long base; uint mipOffset[16]; };   // offsets in texels relative to base
 

@@ -23,6 +23,22 @@ __device__ __forceinline__ float t8_rcp_dir(float d) {
     return 1.0f / ((d < 0.0f) ? -s : s);
 }
 __device__ __forceinline__ uint group_bits(unsigned long long m, uint gl) { return (uint)(m >> gl) & 0xFFu; }
+// In-group (8 lanes) data exchange with DPP modifiers only — no LDS crossbar (ds_bpermute) latency on the critical path.
+// xor-1/2/3 are quad permutes; row_half_mirror maps lane i -> 7-i (= i^7), so i^m for m = 4..7 is half_mirror followed by the quad permute of 7^m.
+#define DPP_QP_XOR1 0xB1
+#define DPP_QP_XOR2 0x4E
+#define DPP_QP_XOR3 0x1B
+#define DPP_HALF_MIRROR 0x141
+template <int CTRL> __device__ __forceinline__ uint dpp_u(uint v) { return (uint)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __uint_as_float(dpp_u<CTRL>(__float_as_uint(v))); }
+
+// compile-time knobs (A/B tested on the GPU, see profiles/)
+#ifndef T8_ORDERED_PUSH
+#define T8_ORDERED_PUSH 1        // 1: far-to-near ordered pushes (7 in-group shuffles); 0: nearest followed, rest pushed in lane order
+#endif
+#ifndef T8_INNER_REPEAT
+#define T8_INNER_REPEAT 1        // inner-node steps per outer iteration before leaves are serviced ("while-while" when > 1)
+#endif
 
 // Src: uint fetch(uint i, float3& o, float3& d, float& tmin, float& tmax) -> user tag (e.g. path index); called by all 8 lanes of a group
 // Dst: void commit(uint tag, const HitInfo& h) ; called by the group leader only (closest: best hit or prim == ~0; any-hit: prim != ~0 when occluded)
@@ -34,7 +50,8 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     const uint wavesPerBlock = T8_BLOCK / 64u;
     const uint waveId = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), numWaves = gridDim.x * wavesPerBlock;
     const char* nodes = reinterpret_cast<const char*>(sc.nodes8);
-    const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
+    const char* tris = reinterpret_cast<const char*>(sc.tris);
+    const float INF = __uint_as_float(0x7F800000u);
 
     uint chunk = waveId;
     uint chunkPos = chunk * T8_CHUNK, chunkEnd = (chunkPos + T8_CHUNK < count) ? chunkPos + T8_CHUNK : count;
@@ -47,6 +64,16 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     float tmin = 0.f, tmax = 0.f;
     HitInfo best; best.t = 0.f; best.prim = 0xFFFFFFFFu; best.u = best.v = 0.f;
     uint cur = 0, sp = 0, tag = 0;
+
+    // pop the next node whose entry distance can still matter; finishes the ray when the stack is empty
+    auto pop = [&]() {
+        while (true) {
+            if (sp == 0u) { if (j == 0u) { if (ANYHIT) { best.prim = 0xFFFFFFFFu; } commit(tag, best); } active = false; break; }
+            sp--;
+            uint2 e = stack[sp];
+            if (ANYHIT || __uint_as_float(e.y) <= best.t) { cur = e.x; break; }
+        }
+    };
 
     while (true) {
         // ---- refill idle groups from the wave's current chunk
@@ -72,53 +99,77 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
             }
         }
         if (__ballot(active) == 0ull) { if (__ballot(!exhausted) == 0ull) break; else continue; }
-        if (!active) continue;
 
-        bool doPop = false;
-        if (!(cur & BVH_LEAF_BIT)) {
-            // ---- inner node: lane j tests child j
-            const uint4 hdr = *reinterpret_cast<const uint4*>(nodes + (size_t)cur * 128u);
-            const uint* cp = reinterpret_cast<const uint*>(nodes + (size_t)cur * 128u + 16u + 12u * j);
-            const uint cref = cp[0], q0 = cp[1], q1 = cp[2];
-            if (COUNT && j == 0u) ctr.nodeVisits++;
-            const float sx = __uint_as_float((hdr.w & 0xFFu) << 23), sy = __uint_as_float(((hdr.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((hdr.w >> 16) & 0xFFu) << 23);
-            const float ox = __uint_as_float(hdr.x), oy = __uint_as_float(hdr.y), oz = __uint_as_float(hdr.z);
-            const float lox = ox + (float)(q0 & 0xFFu) * sx, loy = oy + (float)((q0 >> 8) & 0xFFu) * sy, loz = oz + (float)((q0 >> 16) & 0xFFu) * sz;
-            const float hix = ox + (float)(q0 >> 24) * sx, hiy = oy + (float)(q1 & 0xFFu) * sy, hiz = oz + (float)((q1 >> 8) & 0xFFu) * sz;
-            float tx1 = (lox - o.x) * id.x, tx2 = (hix - o.x) * id.x;
-            float ty1 = (loy - o.y) * id.y, ty2 = (hiy - o.y) * id.y;
-            float tz1 = (loz - o.z) * id.z, tz2 = (hiz - o.z) * id.z;
-            float tn = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fmaxf(fminf(tz1, tz2), tmin));
-            float tf = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fminf(fmaxf(tz1, tz2), best.t));
-            bool hit = (cref != BVH_EMPTY) && (tn <= tf * 1.0000005f);
-            float key = hit ? tn : __uint_as_float(0x7F800000u);
-            uint hitBits = group_bits(__ballot(hit), gl);
-            uint nhit = (uint)__popc(hitBits);
-            if (nhit == 0u) doPop = true;
-            else {
-                uint rank = 0;
-#pragma unroll
-                for (uint k = 1; k < 8u; k++) {
-                    uint oj = (j + k) & 7u;
-                    float ok = __shfl(key, (int)(gl + oj));
-                    rank += ((ok < key) || (ok == key && oj < j)) ? 1u : 0u;
+        // ---- inner nodes: lane j tests child j
+#pragma unroll 1
+        for (int rep = 0; rep < T8_INNER_REPEAT; rep++) {
+            bool inner = active && !(cur & BVH_LEAF_BIT);
+            if (T8_INNER_REPEAT > 1 && __ballot(inner) == 0ull) break;
+            if (inner) {
+                const char* np = nodes + (size_t)cur * 128u;
+                const u32x4 hdr = *reinterpret_cast<const u32x4*>(np);
+                const uint cref = *reinterpret_cast<const uint*>(np + 16u + 4u * j);
+                const u32x2 q = *reinterpret_cast<const u32x2*>(np + 48u + 8u * j);
+                if (COUNT && j == 0u) ctr.nodeVisits++;
+                const float sx = __uint_as_float((hdr.w & 0xFFu) << 23), sy = __uint_as_float(((hdr.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((hdr.w >> 16) & 0xFFu) << 23);
+                const float ox = __uint_as_float(hdr.x), oy = __uint_as_float(hdr.y), oz = __uint_as_float(hdr.z);
+                const float lox = ox + (float)(q.x & 0xFFu) * sx, loy = oy + (float)((q.x >> 8) & 0xFFu) * sy, loz = oz + (float)((q.x >> 16) & 0xFFu) * sz;
+                const float hix = ox + (float)(q.x >> 24) * sx, hiy = oy + (float)(q.y & 0xFFu) * sy, hiz = oz + (float)((q.y >> 8) & 0xFFu) * sz;
+                float tx1 = (lox - o.x) * id.x, tx2 = (hix - o.x) * id.x;
+                float ty1 = (loy - o.y) * id.y, ty2 = (hiy - o.y) * id.y;
+                float tz1 = (loz - o.z) * id.z, tz2 = (hiz - o.z) * id.z;
+                float tn = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fmaxf(fminf(tz1, tz2), tmin));
+                float tf = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fminf(fmaxf(tz1, tz2), best.t));
+                bool hit = (cref != BVH_EMPTY) && (tn <= tf * 1.0000005f);
+                float key = hit ? tn : INF;
+                uint hitBits = group_bits(__ballot(hit), gl);
+                uint nhit = (uint)__popc(hitBits);
+                if (nhit == 0u) pop();
+                else if (T8_ORDERED_PUSH) {
+                    // rank of my child among the hit children (ties to the lower lane): compare against lanes j^1 .. j^7
+                    const float hm = dpp_f<DPP_HALF_MIRROR>(key);
+                    const float k1 = dpp_f<DPP_QP_XOR1>(key), k2 = dpp_f<DPP_QP_XOR2>(key), k3 = dpp_f<DPP_QP_XOR3>(key);
+                    const float k4 = dpp_f<DPP_QP_XOR3>(hm), k5 = dpp_f<DPP_QP_XOR2>(hm), k6 = dpp_f<DPP_QP_XOR1>(hm), k7 = hm;
+                    uint rank = 0;
+                    rank += ((k1 < key) || (k1 == key && (j ^ 1u) < j)) ? 1u : 0u;
+                    rank += ((k2 < key) || (k2 == key && (j ^ 2u) < j)) ? 1u : 0u;
+                    rank += ((k3 < key) || (k3 == key && (j ^ 3u) < j)) ? 1u : 0u;
+                    rank += ((k4 < key) || (k4 == key && (j ^ 4u) < j)) ? 1u : 0u;
+                    rank += ((k5 < key) || (k5 == key && (j ^ 5u) < j)) ? 1u : 0u;
+                    rank += ((k6 < key) || (k6 == key && (j ^ 6u) < j)) ? 1u : 0u;
+                    rank += ((k7 < key) || (k7 == key && (j ^ 7u) < j)) ? 1u : 0u;
+                    // the nearest child's reference reaches every lane through a 3-step butterfly (rank 0 holds it)
+                    uint next = (hit && rank == 0u) ? cref : 0u;
+                    next |= dpp_u<DPP_QP_XOR1>(next); next |= dpp_u<DPP_QP_XOR2>(next); next |= dpp_u<DPP_QP_XOR3>(dpp_u<DPP_HALF_MIRROR>(next));
+                    if (nhit > 1u) {
+                        if (sp + nhit - 1u > BVH8_STACK) { if (j == 0u) atomicOr(overflowFlag, 1u); }
+                        else { if (hit && rank > 0u) stack[sp + (nhit - 1u - rank)] = make_uint2(cref, __float_as_uint(tn)); sp += nhit - 1u; }
+                    }
+                    cur = next;
+                } else {
+                    float mk = fminf(key, dpp_f<DPP_QP_XOR1>(key)); mk = fminf(mk, dpp_f<DPP_QP_XOR2>(mk)); mk = fminf(mk, dpp_f<DPP_QP_XOR3>(dpp_f<DPP_HALF_MIRROR>(mk)));
+                    uint nearBits = group_bits(__ballot(hit && key == mk), gl);
+                    uint nearLane = (uint)__ffs((int)nearBits) - 1u;
+                    uint next = (j == nearLane) ? cref : 0u;
+                    next |= dpp_u<DPP_QP_XOR1>(next); next |= dpp_u<DPP_QP_XOR2>(next); next |= dpp_u<DPP_QP_XOR3>(dpp_u<DPP_HALF_MIRROR>(next));
+                    uint pushBits = hitBits & ~(1u << nearLane);
+                    uint npush = nhit - 1u;
+                    if (npush) {
+                        if (sp + npush > BVH8_STACK) { if (j == 0u) atomicOr(overflowFlag, 1u); }
+                        else { if ((pushBits >> j) & 1u) stack[sp + (uint)__popc(pushBits & ((1u << j) - 1u))] = make_uint2(cref, __float_as_uint(tn)); sp += npush; }
+                    }
+                    cur = next;
                 }
-                uint nearBits = group_bits(__ballot(hit && rank == 0u), gl);
-                uint nearLane = (uint)__ffs((int)nearBits) - 1u;
-                uint next = (uint)__shfl((int)cref, (int)(gl + nearLane));
-                if (nhit > 1u) {
-                    if (sp + nhit - 1u > BVH8_STACK) { if (j == 0u) atomicOr(overflowFlag, 1u); }
-                    else if (hit && rank > 0u) stack[sp + (nhit - 1u - rank)] = make_uint2(cref, __float_as_uint(tn));
-                    if (sp + nhit - 1u <= BVH8_STACK) sp += nhit - 1u;
-                }
-                cur = next;
             }
-        } else {
-            // ---- leaf: lane j tests triangle j
+        }
+
+        // ---- leaves: lane j tests triangle j
+        if (active && (cur & BVH_LEAF_BIT)) {
             const uint first = (cur & 0x7FFFFFFFu) >> 3, cnt = (cur & 7u) + 1u;
             bool cand = false; float t = 0.f, u = 0.f, v = 0.f; uint prim = 0xFFFFFFFFu;
             if (j < cnt) {
-                const float4 a = tris4[(first + j) * 3u + 0u], b = tris4[(first + j) * 3u + 1u], c = tris4[(first + j) * 3u + 2u];
+                const char* tp = tris + (size_t)(first + j) * 48u;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(tp), b = *reinterpret_cast<const f32x4*>(tp + 16), c = *reinterpret_cast<const f32x4*>(tp + 32);
                 TriRecord tr; tr.v0 = make_float3(a.x, a.y, a.z); tr.prim = __float_as_uint(a.w);
                 tr.e1 = make_float3(b.x, b.y, b.z); tr.flags = __float_as_uint(b.w); tr.e2 = make_float3(c.x, c.y, c.z);
                 if (COUNT) ctr.triTests++;
@@ -134,33 +185,31 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 }
             }
             uint candBits = group_bits(__ballot(cand), gl);
+            bool finished = false;
             if (candBits) {
                 if (ANYHIT) {
                     uint wl = (uint)__ffs((int)candBits) - 1u;
-                    best.t = __shfl(t, (int)(gl + wl)); best.prim = (uint)__shfl((int)prim, (int)(gl + wl));
+                    float wt = (j == wl) ? t : 0.f; uint wp = (j == wl) ? prim : 0u;      // butterfly-OR broadcast from the first candidate lane
+                    uint wtb = __float_as_uint(wt);
+                    wtb |= dpp_u<DPP_QP_XOR1>(wtb); wtb |= dpp_u<DPP_QP_XOR2>(wtb); wtb |= dpp_u<DPP_QP_XOR3>(dpp_u<DPP_HALF_MIRROR>(wtb));
+                    wp |= dpp_u<DPP_QP_XOR1>(wp); wp |= dpp_u<DPP_QP_XOR2>(wp); wp |= dpp_u<DPP_QP_XOR3>(dpp_u<DPP_HALF_MIRROR>(wp));
+                    best.t = __uint_as_float(wtb); best.prim = wp;
                     if (j == 0u) commit(tag, best);
-                    active = false;
+                    active = false; finished = true;
                 } else {
-                    float tk = cand ? t : __uint_as_float(0x7F800000u); uint pk = cand ? prim : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int m = 1; m < 8; m <<= 1) {
-                        float ot = __shfl_xor(tk, m); uint op = (uint)__shfl_xor((int)pk, m);
-                        if (ot < tk || (ot == tk && op < pk)) { tk = ot; pk = op; }
-                    }
-                    uint winBits = group_bits(__ballot(cand && prim == pk), gl);
-                    uint wl = (uint)__ffs((int)winBits) - 1u;
-                    best.t = tk; best.prim = pk; best.u = __shfl(u, (int)(gl + wl)); best.v = __shfl(v, (int)(gl + wl));
+                    // lexicographic min of (t, prim) over the group, carrying (u, v): 3 butterfly steps, branch-free
+                    float tk = cand ? t : INF; uint pk = cand ? prim : 0xFFFFFFFFu; float uk = u, vk = v;
+                    {   float ot = dpp_f<DPP_QP_XOR1>(tk); uint op = dpp_u<DPP_QP_XOR1>(pk); float ou = dpp_f<DPP_QP_XOR1>(uk), ov = dpp_f<DPP_QP_XOR1>(vk);
+                        bool take = (ot < tk) || (ot == tk && op < pk); tk = take ? ot : tk; pk = take ? op : pk; uk = take ? ou : uk; vk = take ? ov : vk; }
+                    {   float ot = dpp_f<DPP_QP_XOR2>(tk); uint op = dpp_u<DPP_QP_XOR2>(pk); float ou = dpp_f<DPP_QP_XOR2>(uk), ov = dpp_f<DPP_QP_XOR2>(vk);
+                        bool take = (ot < tk) || (ot == tk && op < pk); tk = take ? ot : tk; pk = take ? op : pk; uk = take ? ou : uk; vk = take ? ov : vk; }
+                    {   float ot = dpp_f<DPP_QP_XOR3>(dpp_f<DPP_HALF_MIRROR>(tk)); uint op = dpp_u<DPP_QP_XOR3>(dpp_u<DPP_HALF_MIRROR>(pk));
+                        float ou = dpp_f<DPP_QP_XOR3>(dpp_f<DPP_HALF_MIRROR>(uk)), ov = dpp_f<DPP_QP_XOR3>(dpp_f<DPP_HALF_MIRROR>(vk));
+                        bool take = (ot < tk) || (ot == tk && op < pk); tk = take ? ot : tk; pk = take ? op : pk; uk = take ? ou : uk; vk = take ? ov : vk; }
+                    best.t = tk; best.prim = pk; best.u = uk; best.v = vk;
                 }
             }
-            doPop = active;
-        }
-        if (doPop) {
-            while (true) {
-                if (sp == 0u) { if (j == 0u) { if (ANYHIT) { best.prim = 0xFFFFFFFFu; } commit(tag, best); } active = false; break; }
-                sp--;
-                uint2 e = stack[sp];
-                if (ANYHIT || __uint_as_float(e.y) <= best.t) { cur = e.x; break; }
-            }
+            if (!finished) pop();
         }
     }
 }

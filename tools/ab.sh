@@ -1,0 +1,9 @@
+#!/bin/bash
+# developer A/B: runs bench.py against every variant library under gpurun_ab/ (usage: tools/ab.sh [steps])
+STEPS=${1:-2}
+for lib in gpurun_ab/lib_*.so; do
+  MI355PT_LIB=$PWD/$lib python bench.py --steps $STEPS --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.load(sys.stdin); r=d['roofline']; k=r['kernel_ms_per_step']
+print('%-28s %7.1f Mrays/s %7.1f ms  ext %6.1f shade %5.1f shadow %5.1f | nodes %.1f tris %.1f sh_nodes %.1f sh_tris %.1f' % ('$lib'.split('/')[-1], d['value'], d['ms_per_step'], k['k_extend'], k['k_shade'], k['k_shadow'], r['node_visits_per_ray'], r['tri_tests_per_ray'], r['shadow_node_visits_per_ray'], r['shadow_tri_tests_per_ray']))"
+done
