@@ -128,7 +128,15 @@ def main():
                          "bytes_per_ray": bytes_per_ext, "node_visits_per_ray": nodes_per_ext, "tri_tests_per_ray": tris_per_ext,
                          "avg_launch_ms": ext_ms / max(1, ext_launches), "launches": ext_launches,
                          "kernel_ms_per_step": {"k_extend": ext_ms / args.steps, "k_shade": shade_ms / args.steps, "k_shadow": sh_ms / args.steps},
-                         "shadow_node_visits_per_ray": nodes_per_sh, "shadow_tri_tests_per_ray": tris_per_sh},
+                         "shadow_node_visits_per_ray": nodes_per_sh, "shadow_tri_tests_per_ray": tris_per_sh,
+                         "leaf_visits_per_ray": cst["leafVisitsExtend"] / max(1, cst["extendRays"]),
+                         "wave_iterations_per_ray": cst["waveItersExtend"] / max(1, cst["extendRays"]),
+                         "phase_cycle_share": [c / max(1, sum(cst["extendPhaseCycles"])) for c in cst["extendPhaseCycles"]],
+                         "cycles_per_wave_iteration": sum(cst["extendPhaseCycles"]) / max(1, cst["waveItersExtend"]),
+                         "leaf_block_share": cst["leafBlocksExtend"] / max(1, cst["waveItersExtend"]),
+                         "block_runs_per_wave_iteration": dict(zip(["refill", "chunk_load", "inner", "leaf", "alpha_test", "hit_reduce", "pop", "pop_trips"],
+                                                                  [e / max(1, cst["waveItersExtend"]) for e in cst["extendEvents"]])),
+                         "lane_group_utilisation": (cst["nodeVisitsExtend"] + cst["leafVisitsExtend"]) / max(1, 8 * cst["waveItersExtend"])},
             "build": g.build_stats(),
         }
         if world == 1 and not args.no_cpu_baseline:

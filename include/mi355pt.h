@@ -116,6 +116,10 @@ typedef struct PtDeviceDesc {
 typedef struct PtFrameStats {
     uint64_t extendRays, shadowRays, hits;                  /* "rays" of the Mrays/s metric = extendRays + shadowRays */
     uint64_t nodeVisitsExtend, triTestsExtend, nodeVisitsShadow, triTestsShadow;   /* in-kernel BVH counters (when enabled) */
+    uint64_t leafVisitsExtend, waveItersExtend, leafVisitsShadow, waveItersShadow; /* leaf steps; traversal-loop iterations summed over waves */
+    uint64_t extendPhaseCycles[4];          /* s_memtime cycles summed over waves: refill, inner block, leaf block, slot bookkeeping */
+    uint64_t leafBlocksExtend;              /* iterations in which the wave executed the leaf block */
+    uint64_t extendEvents[8];               /* wave-level block executions: refill, chunk load, inner, leaf, alpha test, hit reduction, pop loop, pop trips */
     double   gpuMilliseconds;                               /* whole pt_render call, HIP events */
     double   extendKernelMs, shadeKernelMs, shadowKernelMs; /* summed per-kernel HIP-event time */
     uint32_t extendLaunches, iterations;

@@ -57,11 +57,13 @@ class PtDeviceDesc(ctypes.Structure):
 class PtFrameStats(ctypes.Structure):
     _fields_ = [("extendRays", ctypes.c_uint64), ("shadowRays", ctypes.c_uint64), ("hits", ctypes.c_uint64),
                 ("nodeVisitsExtend", ctypes.c_uint64), ("triTestsExtend", ctypes.c_uint64), ("nodeVisitsShadow", ctypes.c_uint64), ("triTestsShadow", ctypes.c_uint64),
+                ("leafVisitsExtend", ctypes.c_uint64), ("waveItersExtend", ctypes.c_uint64), ("leafVisitsShadow", ctypes.c_uint64), ("waveItersShadow", ctypes.c_uint64),
+                ("extendPhaseCycles", ctypes.c_uint64 * 4), ("leafBlocksExtend", ctypes.c_uint64), ("extendEvents", ctypes.c_uint64 * 8),
                 ("gpuMilliseconds", ctypes.c_double), ("extendKernelMs", ctypes.c_double), ("shadeKernelMs", ctypes.c_double), ("shadowKernelMs", ctypes.c_double),
                 ("extendLaunches", ctypes.c_uint32), ("iterations", ctypes.c_uint32), ("pathsTraced", ctypes.c_uint32), ("_pad", ctypes.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "_pad"}
+        return {n: (list(getattr(self, n)) if isinstance(getattr(self, n), ctypes.Array) else getattr(self, n)) for n, _ in self._fields_ if n != "_pad"}
 
 
 def build_library(verbose=False):

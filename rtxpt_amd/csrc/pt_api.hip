@@ -627,7 +627,11 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         float ms = 0; (void)hipEventElapsedTime(&ms, ev[t0], ev[t1]); stats->gpuMilliseconds = ms;
         for (auto& s : spans) { float m = 0; (void)hipEventElapsedTime(&m, ev[s.a], ev[s.b]); if (s.kind == 0) { stats->extendKernelMs += m; stats->extendLaunches++; } else if (s.kind == 1) stats->shadeKernelMs += m; else stats->shadowKernelMs += m; }
         stats->extendRays = extendRays; stats->shadowRays = shadowRays; stats->hits = hwc.hits; stats->nodeVisitsExtend = hwc.nodeVisitsExt; stats->triTestsExtend = hwc.triTestsExt;
-        stats->nodeVisitsShadow = hwc.nodeVisitsSh; stats->triTestsShadow = hwc.triTestsSh; stats->iterations = iterations; stats->pathsTraced = total;
+        stats->nodeVisitsShadow = hwc.nodeVisitsSh; stats->triTestsShadow = hwc.triTestsSh;
+        stats->leafVisitsExtend = hwc.leafVisitsExt; stats->waveItersExtend = hwc.itersExt; stats->leafVisitsShadow = hwc.leafVisitsSh; stats->waveItersShadow = hwc.itersSh;
+        for (int q = 0; q < 4; q++) stats->extendPhaseCycles[q] = hwc.phaseCycExt[q];
+        stats->leafBlocksExtend = hwc.leafBlocksExt;
+        for (int q = 0; q < 8; q++) stats->extendEvents[q] = hwc.eventsExt[q]; stats->iterations = iterations; stats->pathsTraced = total;
     }
     for (auto e : ev) (void)hipEventDestroy(e);
     return PT_OK;

@@ -185,7 +185,7 @@ __device__ __forceinline__ uint pow2_exp_ge(float s) {          // biased expone
     if (eb > 254u) eb = 254u;
     return eb;
 }
-__device__ __forceinline__ float q_decode(float o, uint q, float s) { return o + (float)q * s; }   // identical expression in traversal
+__device__ __forceinline__ float q_decode(float o, uint q, float s) { return fmaf((float)q, s, o); }   // identical expression in traversal (v_pk_fma_f32)
 __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ nodes2, const uint* __restrict__ levelIn, uint nIn, uint* __restrict__ levelOut,
                                                    uint* __restrict__ counter, Bvh8Node* __restrict__ nodes8) {
     uint i = blockIdx.x * 128u + threadIdx.x;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ n
     out._pad[0] = out._pad[1] = out._pad[2] = out._pad[3] = 0;
     uint inner = 0;
     for (uint k = 0; k < 8u; k++) {
-        if (k >= n) { out.ref[k] = BVH_EMPTY; out.q[k] = make_uint2(0x00FFFFFFu, 0u); continue; }     // inverted box
+        if (k >= n) { out.c[k].ref = BVH_EMPTY; out.c[k].q0 = 0x00FFFFFFu; out.c[k].q1 = 0u; continue; }     // inverted box
         float lo[3] = {cmn[k].x, cmn[k].y, cmn[k].z}, hi[3] = {cmx[k].x, cmx[k].y, cmx[k].z}, o[3] = {mn.x, mn.y, mn.z}, sc3[3] = {sx, sy, sz};
         uint ql[3], qh[3];
         for (int a = 0; a < 3; a++) {
@@ -231,9 +231,9 @@ __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ n
             while (q < 255u && q_decode(o[a], q, sc3[a]) < hi[a]) q++;
             qh[a] = q;
         }
-        out.q[k] = make_uint2(ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24), qh[1] | (qh[2] << 8));
-        if (cref[k] & BVH_LEAF_BIT) out.ref[k] = cref[k];
-        else { out.ref[k] = wbase + inner; levelOut[2 * (obase + inner)] = wbase + inner; levelOut[2 * (obase + inner) + 1] = cref[k]; inner++; }
+        out.c[k].q0 = ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24); out.c[k].q1 = qh[1] | (qh[2] << 8);
+        if (cref[k] & BVH_LEAF_BIT) out.c[k].ref = cref[k];
+        else { out.c[k].ref = wbase + inner; levelOut[2 * (obase + inner)] = wbase + inner; levelOut[2 * (obase + inner) + 1] = cref[k]; inner++; }
     }
     nodes8[wide] = out;
 }

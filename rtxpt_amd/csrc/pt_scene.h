@@ -60,13 +60,16 @@ static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_L
 // BVH8 node, 128 B = one cache line: the 8 lanes of a ray's lane group each fetch one 12 B child slot plus the shared 16 B header, so a
 // whole node costs one line lookup per group instead of four 16 B gathers per lane. Child boxes are 8-bit quantised relative to the node
 // origin with power-of-two scales (conservative: decoded lo <= true lo, decoded hi >= true hi, verified with the decode arithmetic itself).
-struct Bvh8Node { float ox, oy, oz; uint exps; uint ref[8]; uint2 q[8]; uint _pad[4]; };   // q[k] = qlo.xyz,qhi.x | qhi.y,qhi.z (low 16 bits)
+struct Bvh8Child { uint ref, q0, q1; };                       // q0 = qlo.x | qlo.y<<8 | qlo.z<<16 | qhi.x<<24, q1 = qhi.y | qhi.z<<8
+struct Bvh8Node { float ox, oy, oz; uint exps; Bvh8Child c[8]; uint _pad[4]; };   // exps = ex | ey<<8 | ez<<16 | childCount<<24 (scale = 2^(e-127))
 typedef uint u32x4 __attribute__((ext_vector_type(4)));      // 16-byte aligned vector loads (global_load_dwordx4)
 typedef uint u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // v_pk_*_f32 operands
+struct __attribute__((packed, aligned(4))) u32x3p { uint x, y, z; };   // 12-byte child slot load (global_load_dwordx3)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
 #ifndef PT_BVH8_STACK
-#define PT_BVH8_STACK 96
+#define PT_BVH8_STACK 64
 #endif
 static const uint BVH8_STACK = PT_BVH8_STACK, BVH8_STACK_STRIDE = PT_BVH8_STACK + 1;   // odd stride: groups land on different LDS banks
 

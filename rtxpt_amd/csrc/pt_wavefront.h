@@ -19,7 +19,7 @@ struct PathPool { uint4* s0; uint4* s1; uint4* s2; uint4* s3; uint4* s4; uint4* 
 struct ShadowQueue { float4* q0; float4* q1; float4* q2; };
 struct WaveCounters {           // device-resident counters / stats (one 256 B block)
     uint extendCount[2]; uint shadowCount; uint overflow;
-    unsigned long long hits, nodeVisitsExt, triTestsExt, nodeVisitsSh, triTestsSh;
+    unsigned long long hits, nodeVisitsExt, triTestsExt, nodeVisitsSh, triTestsSh, leafVisitsExt, itersExt, leafVisitsSh, itersSh, phaseCycExt[4], leafBlocksExt, eventsExt[8];
 };
 
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st);
