@@ -114,6 +114,13 @@ def main():
     ext_gbs = ext_rays * bytes_per_ext / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
     sh_ms = sum(s["shadowKernelMs"] for s in stats); shade_ms = sum(s["shadeKernelMs"] for s in stats)
 
+    # HBM traffic of one k_extend launch from the PMC passes (tools/pmc_traffic.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): the counters
+    # cannot be read from inside this process, so the committed summary of the same workload is quoted (null when the workload differs)
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tp) and (W, H, SPP, args.scale, args.tex, world) == (3840, 2160, 4, 1.0, 1024, 1):
+        tj = json.load(open(tp)); traffic = tj["k_extend"]["hbm_bytes_per_launch"]; traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+
     if rank == 0:
         info = g.scene_info()
         out = {
@@ -124,7 +131,7 @@ def main():
                                    % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP),
                        "parallelism": "pixel-tile shard x%d + 1 gather" % world, "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": ext_rays / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_ray": bytes_per_ext, "node_visits_per_ray": nodes_per_ext, "tri_tests_per_ray": tris_per_ext,
                          "avg_launch_ms": ext_ms / max(1, ext_launches), "launches": ext_launches,
                          "kernel_ms_per_step": {"k_extend": ext_ms / args.steps, "k_shade": shade_ms / args.steps, "k_shadow": sh_ms / args.steps},
@@ -136,7 +143,7 @@ def main():
                          "leaf_block_share": cst["leafBlocksExtend"] / max(1, cst["waveItersExtend"]),
                          "block_runs_per_wave_iteration": dict(zip(["refill", "chunk_load", "inner", "leaf", "alpha_test", "hit_reduce", "pop", "pop_trips"],
                                                                   [e / max(1, cst["waveItersExtend"]) for e in cst["extendEvents"]])),
-                         "lane_group_utilisation": (cst["nodeVisitsExtend"] + cst["leafVisitsExtend"]) / max(1, 8 * cst["waveItersExtend"])},
+                         "work_slots_per_quad_iteration": (cst["nodeVisitsExtend"] + cst["leafVisitsExtend"]) / max(1, 16 * cst["waveItersExtend"])},
             "build": g.build_stats(),
         }
         if world == 1 and not args.no_cpu_baseline:

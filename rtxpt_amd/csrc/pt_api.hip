@@ -64,7 +64,7 @@ struct pt_context {
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
-    DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters;
+    DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
     BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0;
     DeviceScene dsc;
@@ -144,6 +144,8 @@ int upload_textures(pt_context* c) {
 
 void refresh_scene_view(pt_context* c) {
     DeviceScene& d = c->dsc;
+    if (!c->dTravSpill.p) (void)c->dTravSpill.resize((size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH);   // traversal stack tails (302 MB of 288 GB)
+    d.travSpill = c->dTravSpill.p;
     d.indices = c->dIndices.p; d.positions = c->dPositions.p; d.uvs = c->dUvs.p; d.normals = c->dNormals.p; d.tangents = c->dTangents.p;
     d.geometries = c->dGeometries.p; d.instances = c->dInstances.p; d.subInstances = c->dSubInstances.p; d.subInstToInstGeom = c->dSubInstToInstGeom.p;
     d.materials = c->dMaterials.p; d.materialCount = (uint)c->materials.size(); d.textures = c->dTexInfos.p; d.texels = c->dTexels.p;
@@ -385,7 +387,7 @@ int32_t pt_destroy(pt_context* c) {
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
     c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
-    c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free();
+    c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free();
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;
@@ -621,7 +623,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     PT_CHECK_HIP(c, hipMemcpyAsync(&hwc, wc, sizeof(hwc), hipMemcpyDeviceToHost, st));
     PT_CHECK_HIP(c, hipStreamSynchronize(st));
     PT_CHECK_HIP(c, hipGetLastError());
-    if (hwc.overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal stack overflow (raise BVH8_STACK)");
+    if (hwc.overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal stack overflow (raise T8_SPILL_DEPTH)");
     c->accumCount += count;
     if (stats) {
         float ms = 0; (void)hipEventElapsedTime(&ms, ev[t0], ev[t1]); stats->gpuMilliseconds = ms;

@@ -69,9 +69,13 @@ struct __attribute__((packed, aligned(4))) u32x3p { uint x, y, z; };   // 12-byt
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
 #ifndef PT_BVH8_STACK
-#define PT_BVH8_STACK 64
+#define PT_BVH8_STACK 32
 #endif
-static const uint BVH8_STACK = PT_BVH8_STACK, BVH8_STACK_STRIDE = PT_BVH8_STACK + 1;   // odd stride: groups land on different LDS banks
+// traversal launch geometry (pt_traverse8.h): 256-thread blocks, 4 lanes per ray -> 64 rays in flight per block, each with an LDS stack of
+// BVH8_STACK entries (odd stride: quads land on different banks) and a T8_SPILL_DEPTH-entry tail in global memory (DeviceScene::travSpill)
+static const uint BVH8_STACK = PT_BVH8_STACK, BVH8_STACK_STRIDE = PT_BVH8_STACK + 1;
+static const uint T8_BLOCK = 256, T8_CHUNK = 64, T8_LANES = 4, T8_GROUPS_PER_BLOCK = T8_BLOCK / T8_LANES, T8_SPILL_DEPTH = 96;
+static const uint T8_MAX_BLOCKS = 256 * 6 * 4;     // persistent waves stride over 64-ray chunks
 
 struct TexInfo { uint w, h, mipLevels, _pad; unsigned long long base; uint mipOffset[16]; };   // offsets in texels relative to base
 
@@ -83,6 +87,7 @@ struct DeviceScene {
     TexInfo envTex; uint envEnabled; float3x4 envToWorld, envToLocal; float3 envColorMultiplier;
     LightTable lights;
     const BvhNode* nodes; const Bvh8Node* nodes8; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
+    uint2* travSpill;          // T8_MAX_BLOCKS x T8_GROUPS_PER_BLOCK x T8_SPILL_DEPTH stack-tail entries
 };
 
 struct HitInfo { float t; uint prim; float u, v; };

@@ -268,7 +268,6 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
     }
 }
 
-static const uint T8_MAX_BLOCKS = 256 * 6 * 4;     // persistent waves stride over 64-ray chunks
 static inline uint grid_for(uint count, uint block, uint maxBlocks) { uint g = (count + block - 1) / block; if (g < 1) g = 1; if (g > maxBlocks) g = maxBlocks; return g; }
 
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st) {
