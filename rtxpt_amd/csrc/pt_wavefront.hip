@@ -76,7 +76,10 @@ __global__ void __launch_bounds__(T8_BLOCK) k_extend(DeviceScene sc, PathPool po
                  for (int q = 0; q < 8; q++) wave_add64(ctr.ev[q], &wc->eventsExt[q]); }
 }
 
-__global__ void __launch_bounds__(256) k_shade(PathKernelContext k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
+#ifndef PT_SHADE_MIN_BLOCKS
+#define PT_SHADE_MIN_BLOCKS 1
+#endif
+__global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PathKernelContext k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
                                                uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc) {
     const uint count = *countInPtr;
     uint i = blockIdx.x * 256u + threadIdx.x;
