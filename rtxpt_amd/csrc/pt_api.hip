@@ -186,6 +186,8 @@ int finalize_geometry(pt_context* c) {
             for (uint t = 0; t < gd.numIndices / 3; t++) c->primInfo.push_back(ptk::make_uint2(subInst, t));
         }
     }
+    if (c->primInfo.size() > 0x7FFFFFFull / 3ull * 2ull)      // traversal addresses triangles with 32-bit byte offsets (48 B records) and 28-bit leaf references
+        return fail(c, PT_ERROR_UNSUPPORTED, "more than 89 M triangles per scene are not supported by the traversal kernels");
     c->numTris = (uint)c->primInfo.size();
     hipStream_t st = c->stream;
     PT_CHECK_HIP(c, c->dIndices.upload(c->indices, st)); PT_CHECK_HIP(c, c->dPositions.upload(c->positions, st)); PT_CHECK_HIP(c, c->dUvs.upload(c->uvs, st));

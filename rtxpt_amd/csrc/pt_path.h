@@ -356,7 +356,7 @@ struct PathKernelContext {
     static void AccumulatePathRadiance(PathState& path, float3 radiance) { float4 L = path.GetL(); path.SetL(make_float4(L.x + radiance.x, L.y + radiance.y, L.z + radiance.z, L.w + 0.f)); }
 
     // PathTracer.hlsli:407-503
-    void HandleMiss(PathState& path, float3 rayDir, float rayT) const {
+    __attribute__((always_inline)) void HandleMiss(PathState& path, float3 rayDir, float rayT) const {
         UpdatePathTravelled(path, rayT);
         float3 environmentEmission = make_float3(0.f);
         NEEBSDFMISInfo misInfo = NEEBSDFMISInfo::Unpack16bit(path.GetPackedMISInfo());
@@ -514,7 +514,7 @@ struct PathKernelContext {
         return false;
     }
     // PathTracer.hlsli:505-762 (reference mode), shadow test deferred through `req`
-    void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req) const {
+    __attribute__((always_inline)) void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req) const {
         req.valid = false;
         const float3 rayOrigin = path.origin, rayDir = path.dir;
         UpdatePathTravelled(path, hit.t);

@@ -24,6 +24,12 @@ struct Traverse8Counters { uint nodeVisits, triTests, leafVisits, iters, leafBlo
 static const uint T8_RAY_STRIDE = 9, T8_RAYBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_RAY_STRIDE;   // per-wave LDS parking lot for a chunk's rays (odd stride)
 static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 
+#ifndef T8_EXTEND_MIN_BLOCKS
+#define T8_EXTEND_MIN_BLOCKS 5    // 256-thread blocks per CU the register allocator must leave room for in k_extend (= waves per SIMD)
+#endif
+#ifndef T8_LEAF_QUEUE
+#define T8_LEAF_QUEUE 2         // postponed leaves a ray may hold (1..3) before it has to wait for the wave's next leaf block (A/B: within noise on extend, -4 % on shadow)
+#endif
 #ifndef T8_LEAF_BATCH
 #define T8_LEAF_BATCH 8         // quads (of 16) that must hold a postponed leaf before the wave runs the leaf block (17 = only when a quad is blocked; A/B in profiles/)
 #endif
@@ -56,12 +62,13 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     const uint lane = threadIdx.x & 63u, q = lane & 3u, gl = lane & ~3u;
     const uint grp = threadIdx.x >> 2;
     uint2* stack = stackBase + grp * BVH8_STACK_STRIDE;
-    uint2* spill = sc.travSpill + (size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH;
     const uint wavesPerBlock = T8_BLOCK / 64u;
     const uint waveId = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), numWaves = gridDim.x * wavesPerBlock;
     const char* nodesBase = reinterpret_cast<const char*>(sc.nodes8);
-    const char* nodesLane = nodesBase + 16u + 24u * q;                                     // this lane's child pair in node 0
-    const char* trisLane = reinterpret_cast<const char*>(sc.tris) + 48u * q;               // this lane's first-round triangle in leaf range 0
+    const char* trisBase = reinterpret_cast<const char*>(sc.tris);
+    // 32-bit byte offsets from the (uniform, SGPR) buffer bases: global_load takes saddr + 32-bit voffset, which saves 64-bit address
+    // arithmetic and a VGPR pair per pointer (limits: 32 M BVH8 nodes, 89 M triangles per scene — checked at build time)
+    const uint laneChildOff = 16u + 24u * q, laneTriOff = 48u * q;
     const uint INF_BITS = 0x7F800000u;
 
     // chunk cursor: wave-uniform, kept in SGPRs (readfirstlane); the first refill advances to chunk `waveId`
@@ -82,10 +89,11 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     // `pend` a postponed leaf; the postponed leaf is tested while the next inner node is already being intersected. The result does
     // not depend on the visiting order (min t, ties to the lower primitive id).
     uint cur = BVH_EMPTY, pend = BVH_EMPTY, sp = 0, tag = 0;
+    uint pend1 = BVH_EMPTY, pend2 = BVH_EMPTY;          // younger postponed leaves (T8_LEAF_QUEUE > 1): pend is tested first
 
     auto stackStore = [&](uint idx, uint ref, uint tbits) {
         if (idx < BVH8_STACK) stack[idx] = make_uint2(ref, tbits);
-        else spill[idx - BVH8_STACK] = make_uint2(ref, tbits);
+        else sc.travSpill[(size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (idx - BVH8_STACK)] = make_uint2(ref, tbits);      // rare: address built on demand
     };
 
     while (true) {
@@ -124,7 +132,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                     tag = slot[6]; tmin = __uint_as_float(slot[7]); tmax = __uint_as_float(slot[8]);
                     ix = t8_rcp_dir(d.x); iy = t8_rcp_dir(d.y); iz = t8_rcp_dir(d.z);
                     bestT = tmax; bestPrim = 0xFFFFFFFFu; mine.prim = 0xFFFFFFFFu;
-                    cur = 0u; pend = BVH_EMPTY; sp = 0u; active = true;
+                    cur = 0u; pend = BVH_EMPTY; pend1 = BVH_EMPTY; pend2 = BVH_EMPTY; sp = 0u; active = true;
                 }
                 chunkPos = (uint)__builtin_amdgcn_readfirstlane((int)(chunkPos + ((n < avail) ? n : avail)));
             }
@@ -137,7 +145,9 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
         // The leaf block is run when T8_LEAF_BATCH quads have a leaf waiting, or when some quad cannot advance without it (its node
         // slot holds a second leaf, or is empty with an empty stack). Meanwhile the descent continues against a slightly stale closest distance.
         const bool leafReady = active && (pend != BVH_EMPTY);
-        const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT);
+        // blocked: the node slot holds a leaf and the queue is full, or the descent is finished (empty node slot, empty stack) and only leaves remain
+        const bool queueFull = (T8_LEAF_QUEUE == 1) ? true : ((T8_LEAF_QUEUE == 2) ? (pend1 != BVH_EMPTY) : (pend2 != BVH_EMPTY));
+        const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT) && (cur == BVH_EMPTY || queueFull);
         const bool runLeaves = ((uint)__popcll(t8_ballot(leafReady && q == 0u)) >= (uint)T8_LEAF_BATCH) || (t8_ballot(leafBlocked) != 0ull);
         const bool leaf = leafReady && runLeaves;
         if (COUNT && leaf && q == 0u) ctr.leafVisits++;
@@ -145,9 +155,9 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
 
         // ---- inner node: lane q tests children 2q and 2q+1
         if (inner) {
-            const char* np = nodesLane + (size_t)cur * 128u;
-            const u32x4 hdr = *reinterpret_cast<const u32x4*>(nodesBase + (size_t)cur * 128u);
-            const Bvh8ChildPair ch = *reinterpret_cast<const Bvh8ChildPair*>(np);
+            const uint nodeOff = cur * 128u;
+            const u32x4 hdr = *reinterpret_cast<const u32x4*>(nodesBase + nodeOff);
+            const Bvh8ChildPair ch = *reinterpret_cast<const Bvh8ChildPair*>(nodesBase + (nodeOff + laneChildOff));
             if (COUNT && q == 0u) ctr.nodeVisits++;
             const float sx = __uint_as_float((hdr.w << 23) & INF_BITS), sy = __uint_as_float((hdr.w << 15) & INF_BITS), sz = __uint_as_float((hdr.w << 7) & INF_BITS);
             const float nx = __uint_as_float(hdr.x), ny = __uint_as_float(hdr.y), nz = __uint_as_float(hdr.z);
@@ -192,7 +202,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
         // ---- postponed leaf: lane q tests triangles q, q + 4 (two rounds when the leaf holds more than 4)
         if (leaf) {
             const uint cnt = (pend & 7u) + 1u;
-            const char* tp0 = trisLane + (size_t)((pend & 0x7FFFFFFFu) >> 3) * 48u;
+            const uint triOff0 = ((pend & 0x7FFFFFFFu) >> 3) * 48u + laneTriOff;
             float lt = __uint_as_float(INF_BITS), lu = 0.f, lv = 0.f; uint lp = 0xFFFFFFFFu;      // this lane's best candidate of this leaf
             bool alphaRan = false;
 #pragma unroll 1
@@ -200,7 +210,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 const bool doit = (q + T8_LANES * r) < cnt;
                 if (r > 0u && t8_ballot(doit) == 0ull) break;
                 if (doit) {
-                    const char* tp = tp0 + (size_t)(T8_LANES * 48u) * r;
+                    const char* tp = trisBase + (triOff0 + (T8_LANES * 48u) * r);
                     const f32x4 ta = *reinterpret_cast<const f32x4*>(tp), tb = *reinterpret_cast<const f32x4*>(tp + 16), tc = *reinterpret_cast<const f32x4*>(tp + 32);
                     TriRecord tr; tr.v0 = make_float3(ta.x, ta.y, ta.z); tr.prim = __float_as_uint(ta.w);
                     tr.e1 = make_float3(tb.x, tb.y, tb.z); tr.flags = __float_as_uint(tb.w); tr.e2 = make_float3(tc.x, tc.y, tc.z);
@@ -220,7 +230,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 }
             }
             const bool cand = (lp != 0xFFFFFFFFu);
-            pend = BVH_EMPTY;
+            pend = pend1; pend1 = pend2; pend2 = BVH_EMPTY;
             uint candBits = quad_bits(t8_ballot(cand), gl);
             T8_EVENT(4, alphaRan); T8_EVENT(5, candBits != 0u);
             if (candBits) {
@@ -228,7 +238,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                     if (q == (uint)__ffs((int)candBits) - 1u) { HitInfo h; h.t = lt; h.prim = lp; h.u = lu; h.v = lv; commit(tag, h); }
                     active = false;
                 } else {
-                    if (cand) { mine.t = lt; mine.prim = lp; mine.u = lu; mine.v = lv; }      // beats the quad's best, hence this lane's earlier find too
+                    if (cand) { mine.prim = lp; mine.u = lu; mine.v = lv; }      // beats the quad's best, hence this lane's earlier find too
                     // lexicographic min of (t, prim) over the quad: 2 butterfly steps, branch-free
                     float tk = lt; uint pk = lp;
                     {   float ot = dpp_f<DPP_QP_XOR1>(tk); uint op = dpp_u<DPP_QP_XOR1>(pk);
@@ -243,19 +253,23 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
         if (COUNT) tc3 = __builtin_readcyclecounter();
         // ---- slot bookkeeping: a leaf reached by the descent moves to the free leaf slot; an empty node slot pops the stack
         if (active) {
-            if ((cur & BVH_LEAF_BIT) && cur != BVH_EMPTY && pend == BVH_EMPTY) { pend = cur; cur = BVH_EMPTY; }
+            if ((cur & BVH_LEAF_BIT) && cur != BVH_EMPTY) {
+                if (pend == BVH_EMPTY) { pend = cur; cur = BVH_EMPTY; }
+                else if (T8_LEAF_QUEUE > 1 && pend1 == BVH_EMPTY) { pend1 = cur; cur = BVH_EMPTY; }
+                else if (T8_LEAF_QUEUE > 2 && pend2 == BVH_EMPTY) { pend2 = cur; cur = BVH_EMPTY; }
+            }
             if (cur == BVH_EMPTY) {
                 T8_EVENT(6, true);
                 while (sp > 0u) {
                     T8_EVENT(7, true);
                     sp--;
-                    uint2 e = (sp < BVH8_STACK) ? stack[sp] : spill[sp - BVH8_STACK];
+                    uint2 e = (sp < BVH8_STACK) ? stack[sp] : sc.travSpill[(size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (sp - BVH8_STACK)];
                     if (ANYHIT || __uint_as_float(e.y) <= bestT) { cur = e.x; break; }
                 }
                 if (cur == BVH_EMPTY && pend == BVH_EMPTY) {          // nothing left: report
                     if (ANYHIT) { if (q == 0u) { HitInfo h; h.t = tmax; h.prim = 0xFFFFFFFFu; h.u = h.v = 0.f; commit(tag, h); } }
                     else if (bestPrim == 0xFFFFFFFFu) { if (q == 0u) { HitInfo h; h.t = bestT; h.prim = 0xFFFFFFFFu; h.u = h.v = 0.f; commit(tag, h); } }
-                    else if (mine.prim == bestPrim) commit(tag, mine);
+                    else if (mine.prim == bestPrim) { mine.t = bestT; commit(tag, mine); }      // (t of the winning lane == the quad's best t)
                     active = false;
                 }
             }

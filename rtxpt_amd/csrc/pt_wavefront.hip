@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool 
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(T8_BLOCK) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc) {
+__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
 #ifdef T8_EXPERIMENT_DUMMY_LDS
