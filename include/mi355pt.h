@@ -126,6 +126,17 @@ typedef struct PtFrameStats {
     uint32_t pathsTraced, _pad;
 } PtFrameStats;
 
+/* Tone mapping constants (Rtxpt/ToneMapper/ToneMapping_cb.h:30-45) with the colour transform as the 3x3 that `mul(color, M)` uses
+   (Rtxpt/ToneMapper/ToneMapping.ps.hlsli:164); 80 bytes. pt_default_tonemap fills the reference defaults (ToneMappingPasses.h:36-53). */
+typedef struct PtToneMapParams {
+    float    whiteScale, whiteMaxLuminance;
+    uint32_t toneMapOperator;               /* 0 Linear, 1 Reinhard, 2 ReinhardModified, 3 HejiHableAlu, 4 HableUc2, 5 Aces (ToneMapping_cb.h:17-25) */
+    uint32_t clamped;
+    uint32_t autoExposure; float avgLuminance, autoExposureLumValueMin, autoExposureLumValueMax;   /* TONEMAPPING_AUTOEXPOSURE_CPU: the host supplies avgLuminance */
+    float    colorTransform[9];             /* row-major, result_j = sum_i color_i * M[i][j] */
+    uint32_t enabled, _pad0, _pad1;
+} PtToneMapParams;
+
 /* --- entry points (reference seam each one replaces) -------------------------------------------------------------- */
 
 /* DeviceManager creation + Sample::Init (Rtxpt/SampleCommon/SampleBaseApp.cpp:63-140, Rtxpt/Sample.cpp:136) */
@@ -165,6 +176,17 @@ int32_t pt_reset_accumulation(pt_context* ctx);                                 
 /* AccumulatedRadiance read-back (SaveTextureToFile seam): full-frame RGBA32F on the host; pixels of other shards are zero. */
 int32_t pt_map_radiance(pt_context* ctx, const float** rgba32f, size_t* rowPitchBytes);
 int32_t pt_unmap_radiance(pt_context* ctx);
+
+/* Display path. pt_default_tonemap: ToneMappingParameters defaults + UpdateColorTransform with manual exposure
+   (Rtxpt/ToneMapper/ToneMappingPasses.h:36-53, ToneMappingPasses.cpp:428-441): exposureCompensation in stops, filmSpeed/shutter/fNumber as in the UI.
+   pt_tonemap: ToneMappingPass::Render into the SRGBA8_UNORM LdrColor target (ToneMapping.ps.hlsli:136-174, RenderTargets.cpp:241) of THIS
+   context's accumulation buffer; rgba8 receives width*height*4 bytes (R,G,B,A; rows top to bottom).
+   pt_write_png / pt_write_bmp: the screenshot writers behind --captureSimple/--capturePath (Rtxpt/SampleCommon/CaptureScriptManager.cpp:29-60,
+   Rtxpt/Sample.cpp:2295); host only, no context needed. */
+int32_t pt_default_tonemap(PtToneMapParams* out, float exposureCompensation, float filmSpeed, float shutter, float fNumber);
+int32_t pt_tonemap(pt_context* ctx, const PtToneMapParams* params, uint8_t* rgba8, size_t bytes);
+int32_t pt_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+int32_t pt_write_bmp(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 
 /* --- multi-GPU tile sharding (new; no reference analogue) ------------------------------------------- */
 /* number of pixels this shard owns and the packed RGBA32F byte size */

@@ -180,3 +180,22 @@ class Oracle:
 
 def num_threads():
     return int(lib().ptref_num_threads())
+
+
+TONEMAP_DTYPE = np.dtype([("whiteScale", "<f4"), ("whiteMaxLuminance", "<f4"), ("toneMapOperator", "<u4"), ("clamped", "<u4"),
+                          ("autoExposure", "<u4"), ("avgLuminance", "<f4"), ("autoExposureLumValueMin", "<f4"), ("autoExposureLumValueMax", "<f4"),
+                          ("colorTransform", "<f4", (9,)), ("enabled", "<u4"), ("_pad0", "<u4"), ("_pad1", "<u4")])
+
+
+def tonemap(rgba, params):
+    """ptref_tonemap: (..., 4) float32 radiance -> (..., 4) uint8 sRGB through the restated ToneMapping.ps.hlsli."""
+    L = lib()
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    n = a.size // 4
+    out = np.empty(n, dtype=np.uint32)
+    p = np.ascontiguousarray(params)
+    L.ptref_tonemap.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    L.ptref_tonemap.restype = None
+    L.ptref_tonemap(a.ctypes.data_as(ctypes.c_void_p), n, p.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    return out.view(np.uint8).reshape(a.shape[:-1] + (4,))
+

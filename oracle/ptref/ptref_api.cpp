@@ -9,6 +9,7 @@
 //   Rtxpt/Lighting/Distant/EnvMapImportanceSamplingBaker.hlsl:57-90   importance/radiance map (1024^2, 16 taps per texel)
 //   Rtxpt/ProcessingPasses/AccumulationPass.hlsl:36-66 + Rtxpt/Sample.cpp:2770-2778   accumulation lerp, weight 1/(n+1)
 #include "pathtracer.h"
+#include "tonemap.h"
 #include <cstdio>
 #include <cstdlib>
 #ifdef _OPENMP
@@ -504,6 +505,11 @@ void ptref_bsdf_probe(const float* params, int thin, int diffuseModel, const flo
 void ptref_camera_ray(void* h, uint32_t px, uint32_t py, uint32_t sampleIndex, float* out6) {
     Context* c = (Context*)h; PathTracer pt(c->sc, c->S, c->cam, sampleIndex, 0); float3 o, d; pt.computeCameraRay(px, py, o, d);
     out6[0] = o.x; out6[1] = o.y; out6[2] = o.z; out6[3] = d.x; out6[4] = d.y; out6[5] = d.z;
+}
+
+// display path: n RGBA32F pixels -> n packed sRGB RGBA8 (tonemap.h)
+void ptref_tonemap(const float* rgba, uint32_t n, const ToneMapParams* p, uint32_t* out) {
+    for (uint32_t i = 0; i < n; i++) out[i] = tm_pixel(*p, make_float4(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3]));
 }
 
 } // extern "C"

@@ -28,6 +28,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
+    "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp",
 ]
 
 
@@ -94,6 +95,37 @@ def load_library():
 
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+TONEMAP_DTYPE = np.dtype([("whiteScale", "<f4"), ("whiteMaxLuminance", "<f4"), ("toneMapOperator", "<u4"), ("clamped", "<u4"),
+                          ("autoExposure", "<u4"), ("avgLuminance", "<f4"), ("autoExposureLumValueMin", "<f4"), ("autoExposureLumValueMax", "<f4"),
+                          ("colorTransform", "<f4", (9,)), ("enabled", "<u4"), ("_pad0", "<u4"), ("_pad1", "<u4")])
+assert TONEMAP_DTYPE.itemsize == 80
+TONEMAP_OPERATORS = {"linear": 0, "reinhard": 1, "reinhard_modified": 2, "heji_hable_alu": 3, "hable_uc2": 4, "aces": 5}
+
+
+def default_tonemap(exposure_compensation=0.0, film_speed=100.0, shutter=1.0, f_number=1.0, **kw):
+    """pt_default_tonemap: ToneMappingParameters defaults + manual-exposure colour transform (ToneMappingPasses.h:36-53, .cpp:428-441). No device needed."""
+    L = load_library()
+    t = np.zeros((), dtype=TONEMAP_DTYPE)
+    L.pt_default_tonemap.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float]
+    r = L.pt_default_tonemap(_p(t), exposure_compensation, film_speed, shutter, f_number)
+    if r != 0:
+        raise PtError(r, "pt_default_tonemap")
+    for k, v in kw.items():
+        t[k] = TONEMAP_OPERATORS[v] if (k == "toneMapOperator" and isinstance(v, str)) else v
+    return t
+
+
+def write_image(path, rgba8):
+    """pt_write_png / pt_write_bmp by extension (the reference's screenshot formats). rgba8: (H, W, 4) uint8."""
+    L = load_library()
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    fn = L.pt_write_bmp if path.lower().endswith(".bmp") else L.pt_write_png
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    r = fn(path.encode(), _p(a), a.shape[1], a.shape[0])
+    if r != 0:
+        raise PtError(r, "write_image " + path)
 
 
 def bridge_camera(width, height, pos, direction, up, fov_y, near_z=0.01, far_z=1e5, focal_distance=10.0, aperture_radius=0.0, jitter=(0.0, 0.0)):
@@ -203,6 +235,14 @@ class PathTracer:
         img = np.ctypeslib.as_array(ptr, shape=(self.height, self.width, 4)).copy()
         self.L.pt_unmap_radiance(self.h)
         return img
+
+    def tonemap(self, params=None):
+        """pt_tonemap: the accumulation buffer through ToneMappingPass into sRGB RGBA8 -> (H, W, 4) uint8."""
+        t = default_tonemap() if params is None else params
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self.L.pt_tonemap.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self._chk(self.L.pt_tonemap(self.h, _p(t), _p(out), out.nbytes), "pt_tonemap")
+        return out
 
     # ---- multi-GPU shard plumbing (device pointers come from torch tensors)
     def shard_info(self):

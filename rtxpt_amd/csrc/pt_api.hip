@@ -653,6 +653,36 @@ int32_t pt_map_radiance(pt_context* c, const float** rgba, size_t* pitch) {
 }
 int32_t pt_unmap_radiance(pt_context* c) { return c ? PT_OK : PT_ERROR_INVALID_ARGUMENT; }
 
+int32_t pt_default_tonemap(PtToneMapParams* out, float exposureCompensation, float filmSpeed, float shutter, float fNumber) {
+    if (!out || !(shutter > 0.f) || !(fNumber > 0.f)) return PT_ERROR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    out->whiteScale = 5.1f; out->whiteMaxLuminance = 1.0f; out->toneMapOperator = 5u; out->clamped = 1u; out->enabled = 1u;      // ToneMappingPasses.h:36-53
+    out->autoExposure = 0u; out->avgLuminance = 1.0f; out->autoExposureLumValueMin = exp2f(-16.0f); out->autoExposureLumValueMax = exp2f(16.0f);   // ToneMappingPasses.cpp:337-338
+    // UpdateColorTransform (ToneMappingPasses.cpp:428-441), white balance off => identity * exposureScale * manualExposureScale
+    float exposureScale = powf(2.f, exposureCompensation);
+    float manualExposureScale = ((1.f / 100.f) * filmSpeed) / (shutter * fNumber * fNumber);
+    float s = exposureScale * manualExposureScale;
+    out->colorTransform[0] = s; out->colorTransform[4] = s; out->colorTransform[8] = s;
+    return PT_OK;
+}
+int32_t pt_tonemap(pt_context* c, const PtToneMapParams* params, uint8_t* rgba8, size_t bytes) {
+    if (!c || !params || !rgba8) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    size_t n = (size_t)c->width * c->height;
+    if (bytes < n * 4) return fail(c, PT_ERROR_INVALID_ARGUMENT, "rgba8 buffer too small");
+    if (params->toneMapOperator > 5u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "unknown tone map operator");
+    (void)hipSetDevice(c->device);
+    static_assert(sizeof(PtToneMapParams) == sizeof(ptk::ToneMapParams), "tone map parameter layout");
+    ptk::ToneMapParams p; memcpy(&p, params, sizeof(p));
+    DevBuf<uint> d; PT_CHECK_HIP(c, d.resize(n));
+    launch_tonemap(c->dAccum.p, (uint)n, p, d.p, c->stream);
+    PT_CHECK_HIP(c, hipMemcpyAsync(rgba8, d.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    PT_CHECK_HIP(c, hipGetLastError());
+    d.free();
+    return PT_OK;
+}
+
 int32_t pt_shard_info(pt_context* c, uint32_t* numOwned, size_t* bytes) {
     if (!c || !c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
     if (numOwned) *numOwned = (uint32_t)c->owned.size(); if (bytes) *bytes = c->owned.size() * 16;

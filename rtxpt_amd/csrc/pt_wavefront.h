@@ -11,6 +11,7 @@
 // Queue appends use one atomic per wave64: ballot -> popcount prefix -> lane-0 atomicAdd -> broadcast.
 #pragma once
 #include "pt_path.h"
+#include "pt_tonemap.h"
 #include <hip/hip_runtime.h>
 
 namespace ptk {
@@ -34,6 +35,7 @@ void launch_unpack(float4* accum, const uint* pixels, uint num, uint width, cons
 void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, float4* out, hipStream_t st);
 void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const uint* subInstTriOffset, uint numEmissiveSubInst, uint totalTris, uint lightBase,
                           PolymorphicLightInfo* lights, PolymorphicLightInfoEx* lightsEx, hipStream_t st);
+void launch_tonemap(const float4* accum, uint num, const ToneMapParams& p, uint* outRgba8, hipStream_t st);
 void launch_probe(const PathKernelContext& k, int kind, const void* dIn, void* dOut, uint n, hipStream_t st);
 
 } // namespace ptk

@@ -273,6 +273,14 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
 
 static inline uint grid_for(uint count, uint block, uint maxBlocks) { uint g = (count + block - 1) / block; if (g < 1) g = 1; if (g > maxBlocks) g = maxBlocks; return g; }
 
+// ToneMappingPass::Render + SRGBA8 store (ToneMapping.ps.hlsli:136-174): one thread per pixel, streaming 16 B in / 4 B out
+__global__ void __launch_bounds__(256) k_tonemap(const float4* __restrict__ accum, uint num, ToneMapParams p, uint* __restrict__ out) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i < num) out[i] = tm_pixel(p, accum[i]);
+}
+void launch_tonemap(const float4* accum, uint num, const ToneMapParams& p, uint* outRgba8, hipStream_t st) {
+    hipLaunchKernelGGL(k_tonemap, dim3((num + 255) / 256), dim3(256), 0, st, accum, num, p, outRgba8);
+}
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st) {
     uint total = numOwned * spp;
     hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, st, k, pool, ownedPixels, numOwned, sampleFirst, spp, queue);
