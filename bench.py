@@ -155,18 +155,19 @@ def main():
 
 
 def cpu_baseline(sc, cam, S, W, H):
-    """The CPU oracle (a port: RTXPT has no CPU path) on a bounded sample of the SAME workload: a 960x540 block of
-    the 4K frame, 4 accumulated samples, all host cores (OpenMP). Reported per ray so that it is resolution independent."""
+    """The CPU oracle (a port: RTXPT has no CPU path) on a bounded sample of the SAME workload: a 1920x1080 centre block
+    of the 4K frame, 4 accumulated samples, all host cores (OpenMP), about 10 s of CPU work on the 128-thread GPU-box host. Reported per ray so that it is resolution independent."""
     from oracle import ptref
     from rtxpt_amd import scenes
     o = ptref.Oracle(); o.set_scene(sc); o.set_camera(scenes.bridge_camera(W, H, **cam)); o.set_settings(S); o.resize(W, H)
     t0 = time.perf_counter(); o.L.ptref_prepare(o.h); prep = time.perf_counter() - t0
-    x0, y0 = W // 2 - 480, H // 2 - 270
-    t0 = time.perf_counter(); o.render(0, 4, rect=(x0, y0, x0 + 960, y0 + 540)); dt = time.perf_counter() - t0
+    bw, bh = min(W, 1920), min(H, 1080)
+    x0, y0 = (W - bw) // 2, (H - bh) // 2
+    t0 = time.perf_counter(); o.render(0, 4, rect=(x0, y0, x0 + bw, y0 + bh)); dt = time.perf_counter() - t0
     c = o.counters()
     rays = c["extendRays"] + c["shadowRays"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": ptref.num_threads(), "kind": "port",
-            "sample": "960x540 centre block of the 4K frame, 4 spp, %d rays in %.2f s (SAH BVH build + light bake %.1f s not included)" % (rays, dt, prep)}
+            "sample": "%dx%d centre block of the %dx%d frame, 4 spp, %d rays in %.2f s (SAH BVH build + light bake %.1f s not included)" % (bw, bh, W, H, rays, dt, prep)}
 
 
 if __name__ == "__main__":
