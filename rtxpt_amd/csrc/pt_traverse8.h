@@ -91,9 +91,14 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     uint cur = BVH_EMPTY, pend = BVH_EMPTY, sp = 0, tag = 0;
     uint pend1 = BVH_EMPTY, pend2 = BVH_EMPTY;          // younger postponed leaves (T8_LEAF_QUEUE > 1): pend is tested first
 
+    // LDS for the top BVH8_STACK entries, global memory behind them. The tail store is non-temporal on purpose: it keeps the compiler from
+    // merging the two paths into one flat_store through a generic pointer (seen in the ISA), which would put every push on the slow flat path.
     auto stackStore = [&](uint idx, uint ref, uint tbits) {
         if (idx < BVH8_STACK) stack[idx] = make_uint2(ref, tbits);
-        else sc.travSpill[(size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (idx - BVH8_STACK)] = make_uint2(ref, tbits);      // rare: address built on demand
+        else {
+            unsigned long long* tail = reinterpret_cast<unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (idx - BVH8_STACK)));
+            __builtin_nontemporal_store(((unsigned long long)tbits << 32) | ref, tail);
+        }
     };
 
     while (true) {
@@ -263,7 +268,12 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 while (sp > 0u) {
                     T8_EVENT(7, true);
                     sp--;
-                    uint2 e = (sp < BVH8_STACK) ? stack[sp] : sc.travSpill[(size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (sp - BVH8_STACK)];
+                    uint2 e;
+                    if (sp < BVH8_STACK) e = stack[sp];
+                    else {      // (non-temporal for the same reason as in stackStore: keeps this a global load, not a flat one)
+                        unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (sp - BVH8_STACK))));
+                        e = make_uint2((uint)w, (uint)(w >> 32));
+                    }
                     if (ANYHIT || __uint_as_float(e.y) <= bestT) { cur = e.x; break; }
                 }
                 if (cur == BVH_EMPTY && pend == BVH_EMPTY) {          // nothing left: report
