@@ -7,6 +7,7 @@
 //   k_bounds        bottom-up AABB propagation, one atomic ticket per inner node (agent-scope fences: inner nodes are
 //                   finished by whichever workgroup arrives second, possibly on another XCD)
 //   k_emit          collapse sub-trees of <= 4 triangles into leaves and write BVH2 nodes (both child boxes per node)
+//   k_alpha_records per leaf-order triangle: texture coordinates + alpha texture + cutoff for the traversal's alpha test
 //   k_collapse8     level by level: greedily open the largest-area inner child until 8 children -> quantised 128 B BVH8 nodes
 // Refit (animated instances / deformed vertices, same topology) re-runs k_tri_setup, k_bounds, k_emit only.
 #pragma once
@@ -25,6 +26,7 @@ struct BvhBuildBuffers {
     float4* boxLmin; float4* boxLmax; float4* boxRmin; float4* boxRmax;
     uint* sceneBounds;          // 6 ordered-uint encoded floats (min xyz, max xyz)
     BvhNode* nodes;
+    AlphaRec* alphaRecs;        // leaf order, parallel to triSorted
     Bvh8Node* nodes8; uint* levelA; uint* levelB; uint* wideCounter; uint numNodes8, collapseLevels;
     void* sortTemp; size_t sortTempBytes;
     uint capacity;

@@ -69,13 +69,18 @@ struct __attribute__((packed, aligned(4))) u32x3p { uint x, y, z; };   // 12-byt
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
 #ifndef PT_BVH8_STACK
-#define PT_BVH8_STACK 32
+#define PT_BVH8_STACK 28
 #endif
 // traversal launch geometry (pt_traverse8.h): 256-thread blocks, 4 lanes per ray -> 64 rays in flight per block, each with an LDS stack of
 // BVH8_STACK entries (odd stride: quads land on different banks) and a T8_SPILL_DEPTH-entry tail in global memory (DeviceScene::travSpill)
 static const uint BVH8_STACK = PT_BVH8_STACK, BVH8_STACK_STRIDE = PT_BVH8_STACK + 1;
 static const uint T8_BLOCK = 256, T8_CHUNK = 64, T8_LANES = 4, T8_GROUPS_PER_BLOCK = T8_BLOCK / T8_LANES, T8_SPILL_DEPTH = 96;
 static const uint T8_MAX_BLOCKS = 256 * 6 * 4;     // persistent waves stride over 64-ray chunks
+
+// per leaf-order triangle slot: what the alpha test needs, resolved at build time (texture coordinates of the 3 vertices, alpha texture, cutoff);
+// tex == ~0: not alpha tested. Saves the primInfo -> subInstance -> index -> uv chain (7 dependent loads) inside the traversal loop.
+struct AlphaRec { float2 t0, t1, t2; uint tex; float cutoff; };
+static_assert(sizeof(AlphaRec) == 32, "AlphaRec must be 32 bytes");
 
 struct TexInfo { uint w, h, mipLevels, _pad; unsigned long long base; uint mipOffset[16]; };   // offsets in texels relative to base
 
@@ -87,6 +92,7 @@ struct DeviceScene {
     TexInfo envTex; uint envEnabled; float3x4 envToWorld, envToLocal; float3 envColorMultiplier;
     LightTable lights;
     const BvhNode* nodes; const Bvh8Node* nodes8; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
+    const AlphaRec* alphaRecs; // one per TriRecord slot (leaf order)
     uint2* travSpill;          // T8_MAX_BLOCKS x T8_GROUPS_PER_BLOCK x T8_SPILL_DEPTH stack-tail entries
 };
 
@@ -174,6 +180,34 @@ static inline bool alpha_test(const DeviceScene& sc, uint prim, float u, float v
     float2 tc = (t0 * b0 + t1 * u) + t2 * v;
     float opacity = sample_bilinear(sc, sc.textures[si.AlphaTextureIndex()], 0, tc).w;
     return opacity >= si.AlphaCutoff();
+}
+
+// the same test from the build-time record of triangle slot `slot` (identical arithmetic on identical operands: only the .w channel of
+// sample_bilinear at mip 0 is evaluated, and the texture coordinates / cutoff come from the AlphaRec instead of the vertex streams)
+static inline bool alpha_test_slot(const DeviceScene& sc, uint slot, float u, float v) {
+    const AlphaRec r = sc.alphaRecs[slot];
+    if (r.tex == 0xFFFFFFFFu) return true;
+    float b0 = 1.0f - (u + v);
+    float2 uv = (r.t0 * b0 + r.t1 * u) + r.t2 * v;
+    const TexInfo& t = sc.textures[r.tex];
+    uint mw = t.w; if (mw < 1u) mw = 1u;
+    uint mh = t.h; if (mh < 1u) mh = 1u;
+    float fx = uv.x * (float)mw - 0.5f, fy = uv.y * (float)mh - 0.5f;
+    float flx = floorf(fx), fly = floorf(fy);
+    float ax = fx - flx, ay = fy - fly;
+    flx = flx - floorf(flx / (float)mw) * (float)mw; fly = fly - floorf(fly / (float)mh) * (float)mh;
+    int x0 = (int)flx, y0 = (int)fly, x1 = x0 + 1, y1 = y0 + 1;
+    if (x0 < 0) x0 += (int)mw; if (x1 >= (int)mw) x1 -= (int)mw;
+    if (y0 < 0) y0 += (int)mh; if (y1 >= (int)mh) y1 -= (int)mh;
+    x0 = x0 < 0 ? 0 : (x0 >= (int)mw ? (int)mw - 1 : x0); x1 = x1 < 0 ? 0 : (x1 >= (int)mw ? (int)mw - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 >= (int)mh ? (int)mh - 1 : y0); y1 = y1 < 0 ? 0 : (y1 >= (int)mh ? (int)mh - 1 : y1);
+    // 32-bit texel offsets inside the texture (a single mip is far below 4 G texels) keep the address arithmetic and register use small
+    const float* texw = reinterpret_cast<const float*>(sc.texels + (t.base + t.mipOffset[0])) + 3;      // the .w channel
+    const uint r0 = (uint)y0 * mw, r1 = (uint)y1 * mw;
+    float w00 = texw[4u * (r0 + (uint)x0)], w10 = texw[4u * (r0 + (uint)x1)];
+    float w01 = texw[4u * (r1 + (uint)x0)], w11 = texw[4u * (r1 + (uint)x1)];
+    float opacity = lerpf(lerpf(w00, w10, ax), lerpf(w01, w11, ax), ay);
+    return opacity >= r.cutoff;
 }
 
 #pragma clang force_cuda_host_device end

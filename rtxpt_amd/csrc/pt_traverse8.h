@@ -50,6 +50,7 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __u
 
 struct __attribute__((packed, aligned(8))) Bvh8ChildPair { uint refA, q0A, q1A, refB, q0B, q1B; };   // this lane's two 12 B child slots (24 B, 8-byte aligned)
 
+// FIXED_RANGE: every ray of the launch has tmin = 0, tmax = kMaxRayTravel (extend rays), whatever fetch() reports.
 // Src: uint fetch(uint i, float3& o, float3& d, float& tmin, float& tmax) -> user tag (e.g. path index); called once per ray by one lane; tmin >= 0
 // Dst: void commit(uint tag, const HitInfo& h) ; called by ONE lane of the quad (closest: best hit or prim == ~0; any-hit: prim != ~0 when occluded)
 //
@@ -57,8 +58,8 @@ struct __attribute__((packed, aligned(8))) Bvh8ChildPair { uint refA, q0A, q1A, 
 // arithmetic (v_pk_fma/add/mul_f32 — the box test has no parity constraint, only conservativeness), integer sort keys (entry distance
 // bits with the child index in the low 3 bits: unique, so a rank is 7 compares), and hit attributes that stay in the lane that found
 // them instead of being broadcast.
-template <bool ANYHIT, bool COUNT, class Src, class Dst>
-__device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint count, uint2* stackBase, uint* rayBufBase, Src fetch, Dst commit, Traverse8Counters& ctr, uint* overflowFlag) {
+template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, class Src, class Dst>
+__device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint count, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Traverse8Counters& ctr, uint* overflowFlag) {
     const uint lane = threadIdx.x & 63u, q = lane & 3u, gl = lane & ~3u;
     const uint grp = threadIdx.x >> 2;
     uint2* stack = stackBase + grp * BVH8_STACK_STRIDE;
@@ -82,9 +83,9 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     bool active = false;
     float3 o = make_float3(0.f), d = make_float3(0.f);
     float ix = 0.f, iy = 0.f, iz = 0.f;
-    float tmin = 0.f, tmax = 0.f;
+    float tmin = 0.f, tmax = FIXED_RANGE ? kMaxRayTravel : 0.f;
     float bestT = 0.f; uint bestPrim = 0xFFFFFFFFu;           // quad-uniform closest hit so far
-    HitInfo mine; mine.t = 0.f; mine.prim = 0xFFFFFFFFu; mine.u = mine.v = 0.f;   // the best hit THIS lane found (attributes never leave the lane)
+    uint minePrim = 0xFFFFFFFFu;                              // the best hit THIS lane found; its barycentrics wait in LDS (mineUV) and never travel between lanes
     // Two work slots per ray so that one loop iteration advances BOTH an inner node and a leaf: `cur` is the node being descended,
     // `pend` a postponed leaf; the postponed leaf is tested while the next inner node is already being intersected. The result does
     // not depend on the visiting order (min t, ties to the lower primitive id).
@@ -134,9 +135,10 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                     const uint* slot = rayBuf + (((chunkPos & (T8_CHUNK - 1u)) + rank) * T8_RAY_STRIDE);
                     o = make_float3(__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]));
                     d = make_float3(__uint_as_float(slot[3]), __uint_as_float(slot[4]), __uint_as_float(slot[5]));
-                    tag = slot[6]; tmin = __uint_as_float(slot[7]); tmax = __uint_as_float(slot[8]);
+                    tag = slot[6];
+                    if (!FIXED_RANGE) { tmin = __uint_as_float(slot[7]); tmax = __uint_as_float(slot[8]); }      // FIXED_RANGE: [0, kMaxRayTravel] stays a compile-time constant (2 VGPRs)
                     ix = t8_rcp_dir(d.x); iy = t8_rcp_dir(d.y); iz = t8_rcp_dir(d.z);
-                    bestT = tmax; bestPrim = 0xFFFFFFFFu; mine.prim = 0xFFFFFFFFu;
+                    bestT = tmax; bestPrim = 0xFFFFFFFFu; minePrim = 0xFFFFFFFFu;
                     cur = 0u; pend = BVH_EMPTY; pend1 = BVH_EMPTY; pend2 = BVH_EMPTY; sp = 0u; active = true;
                 }
                 chunkPos = (uint)__builtin_amdgcn_readfirstlane((int)(chunkPos + ((n < avail) ? n : avail)));
@@ -225,10 +227,10 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                         bool c;
                         if (ANYHIT) {
                             c = true;
-                            if (tr.flags & 1u) { if (COUNT && !(tr.flags & 2u)) alphaRan = true; c = !(tr.flags & 2u) && alpha_test(sc, tr.prim, u, v); }      // AlphaTestVisibilityRay (BridgeDonut:981-989)
+                            if (tr.flags & 1u) { if (COUNT && !(tr.flags & 2u)) alphaRan = true; c = !(tr.flags & 2u) && alpha_test_slot(sc, ((pend & 0x7FFFFFFFu) >> 3) + q + T8_LANES * r, u, v); }      // AlphaTestVisibilityRay (BridgeDonut:981-989)
                         } else {
                             c = ((t < bestT) || (t == bestT && tr.prim < bestPrim)) && ((t < lt) || (t == lt && tr.prim < lp));
-                            if (c && (tr.flags & 1u)) { if (COUNT) alphaRan = true; c = alpha_test(sc, tr.prim, u, v); }
+                            if (c && (tr.flags & 1u)) { if (COUNT) alphaRan = true; c = alpha_test_slot(sc, ((pend & 0x7FFFFFFFu) >> 3) + q + T8_LANES * r, u, v); }
                         }
                         if (c) { lt = t; lp = tr.prim; lu = u; lv = v; }
                     }
@@ -240,10 +242,10 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
             T8_EVENT(4, alphaRan); T8_EVENT(5, candBits != 0u);
             if (candBits) {
                 if (ANYHIT) {
-                    if (q == (uint)__ffs((int)candBits) - 1u) { HitInfo h; h.t = lt; h.prim = lp; h.u = lu; h.v = lv; commit(tag, h); }
+                    if (q == (uint)__ffs((int)candBits) - 1u) { HitInfo h; h.t = lt; h.prim = lp; h.u = h.v = 0.f; commit(tag, h); }      // (occlusion queries carry no barycentrics)
                     active = false;
                 } else {
-                    if (cand) { mine.prim = lp; mine.u = lu; mine.v = lv; }      // beats the quad's best, hence this lane's earlier find too
+                    if (cand) { minePrim = lp; mineUV[threadIdx.x] = make_float2(lu, lv); }      // beats the quad's best, hence this lane's earlier find too
                     // lexicographic min of (t, prim) over the quad: 2 butterfly steps, branch-free
                     float tk = lt; uint pk = lp;
                     {   float ot = dpp_f<DPP_QP_XOR1>(tk); uint op = dpp_u<DPP_QP_XOR1>(pk);
@@ -279,7 +281,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 if (cur == BVH_EMPTY && pend == BVH_EMPTY) {          // nothing left: report
                     if (ANYHIT) { if (q == 0u) { HitInfo h; h.t = tmax; h.prim = 0xFFFFFFFFu; h.u = h.v = 0.f; commit(tag, h); } }
                     else if (bestPrim == 0xFFFFFFFFu) { if (q == 0u) { HitInfo h; h.t = bestT; h.prim = 0xFFFFFFFFu; h.u = h.v = 0.f; commit(tag, h); } }
-                    else if (mine.prim == bestPrim) { mine.t = bestT; commit(tag, mine); }      // (t of the winning lane == the quad's best t)
+                    else if (minePrim == bestPrim) { float2 uv = mineUV[threadIdx.x]; HitInfo h; h.t = bestT; h.prim = bestPrim; h.u = uv.x; h.v = uv.y; commit(tag, h); }
                     active = false;
                 }
             }

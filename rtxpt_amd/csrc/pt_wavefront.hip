@@ -57,6 +57,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
+    __shared__ float2 mineUV[T8_BLOCK];
 #ifdef T8_EXPERIMENT_DUMMY_LDS
     __shared__ uint dummyLds[T8_EXPERIMENT_DUMMY_LDS]; dummyLds[threadIdx.x] = threadIdx.x; if (*countPtr == 0xFFFFFFFFu) wc->overflow = dummyLds[threadIdx.x ^ 1];
 #endif
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
         return p;
     };
     auto commit = [&](uint p, const HitInfo& h) { pool.hit[p] = make_uint4(asuint(h.t), h.prim, asuint(h.u), asuint(h.v)); };
-    traverse8_persistent<false, COUNT>(sc, count, stack, rayBuf, fetch, commit, ctr, &wc->overflow);
+    traverse8_persistent<false, COUNT, true>(sc, count, stack, rayBuf, mineUV, fetch, commit, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); wave_add64(ctr.leafVisits, &wc->leafVisitsExt); wave_add64(ctr.iters, &wc->itersExt); wave_add64(ctr.leafBlocks, &wc->leafBlocksExt);
                  if ((threadIdx.x & 63u) == 0u) for (int q = 0; q < 4; q++) atomicAdd(&wc->phaseCycExt[q], ctr.cyc[q]);
                  for (int q = 0; q < 8; q++) wave_add64(ctr.ev[q], &wc->eventsExt[q]); }
@@ -111,6 +112,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(T8_BLOCK) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
+    __shared__ float2 mineUV[T8_BLOCK];
 #ifdef T8_EXPERIMENT_DUMMY_LDS
     __shared__ uint dummyLds[T8_EXPERIMENT_DUMMY_LDS]; dummyLds[threadIdx.x] = threadIdx.x; if (*countPtr == 0xFFFFFFFFu) wc->overflow = dummyLds[threadIdx.x ^ 1];
 #endif
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(T8_BLOCK) k_shadow(DeviceScene sc, PathPool po
         c.z = pack45[0]; c.w = pack45[1];
         pool.s2[p] = c;
     };
-    traverse8_persistent<true, COUNT>(sc, count, stack, rayBuf, fetch, commit, ctr, &wc->overflow);
+    traverse8_persistent<true, COUNT, false>(sc, count, stack, rayBuf, mineUV, fetch, commit, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsSh); wave_add64(ctr.triTests, &wc->triTestsSh); wave_add64(ctr.leafVisits, &wc->leafVisitsSh); wave_add64(ctr.iters, &wc->itersSh); }
 }
 
@@ -155,6 +157,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PathPool pool, const uint* _
 __global__ void __launch_bounds__(T8_BLOCK) k_trace_probe(DeviceScene sc, const float4* __restrict__ rays, uint n, float4* __restrict__ outClosest, uint* __restrict__ outVisible, uint* overflow) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
+    __shared__ float2 mineUV[T8_BLOCK];
     Traverse8Counters ctr; ctr.nodeVisits = 0; ctr.triTests = 0; ctr.leafVisits = 0; ctr.iters = 0; ctr.leafBlocks = 0; for (int q = 0; q < 8; q++) ctr.ev[q] = 0u; ctr.cyc[0] = ctr.cyc[1] = ctr.cyc[2] = ctr.cyc[3] = 0ull;
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax) -> uint {
         float4 a = rays[2 * i], b = rays[2 * i + 1];
@@ -163,10 +166,10 @@ __global__ void __launch_bounds__(T8_BLOCK) k_trace_probe(DeviceScene sc, const 
     };
     if (outClosest) {
         auto commit = [&](uint i, const HitInfo& h) { outClosest[i] = make_float4(h.t, asfloat(h.prim), h.u, h.v); };
-        traverse8_persistent<false, false>(sc, n, stack, rayBuf, fetch, commit, ctr, overflow);
+        traverse8_persistent<false, false, false>(sc, n, stack, rayBuf, mineUV, fetch, commit, ctr, overflow);
     } else {
         auto commit = [&](uint i, const HitInfo& h) { outVisible[i] = (h.prim == 0xFFFFFFFFu) ? 1u : 0u; };
-        traverse8_persistent<true, false>(sc, n, stack, rayBuf, fetch, commit, ctr, overflow);
+        traverse8_persistent<true, false, false>(sc, n, stack, rayBuf, mineUV, fetch, commit, ctr, overflow);
     }
 }
 
