@@ -225,7 +225,7 @@ static void bake_env_quads(Scene& sc) {
     }
 }
 
-void bake_lights(Scene& sc, bool neeEnabled) {
+void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
     sc.lights.clear(); sc.lightsEx.clear(); sc.proxyCounters.clear(); sc.proxyIndices.clear(); sc.envLookup.clear(); sc.envLookupDim = 0;
     for (size_t i = 0; i < sc.subInstances.size(); i++) sc.subInstances[i].EmissiveLightMappingOffset = 0xFFFFFFFFu;
     if (neeEnabled) {
@@ -286,7 +286,7 @@ void bake_lights(Scene& sc, bool neeEnabled) {
         sc.proxyCounters.assign(N, 0);
         for (uint i = 0; i < N; i++) {
             uint c = 0;
-            if (w[i] > 0) c = (uint)ceilf(((float)(budget - N) * w[i]) / weightSum);
+            if (w[i] > 0) c = (importanceSamplingType == 0) ? 1u : (uint)ceilf(((float)(budget - N) * w[i]) / weightSum);   // LightsBaker.hlsl:920-923 (type 0 = uniform: 1 proxy per light)
             c = std::min(c, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1);
             sc.proxyCounters[i] = c;
             for (uint k = 0; k < c; k++) sc.proxyIndices.push_back(i);
@@ -373,13 +373,13 @@ void ptref_set_lights(void* h, const PolymorphicLightInfo* base, const Polymorph
     c->lightsDirty = true;
 }
 void ptref_set_camera(void* h, const PathTracerCameraData* cam) { ((Context*)h)->cam = *cam; }
-void ptref_set_settings(void* h, const PtSettings* s) { Context* c = (Context*)h; if (c->S.NEEEnabled != s->NEEEnabled) c->lightsDirty = true; c->S = *s; }
+void ptref_set_settings(void* h, const PtSettings* s) { Context* c = (Context*)h; if (c->S.NEEEnabled != s->NEEEnabled || c->S.NEEType != s->NEEType) c->lightsDirty = true; c->S = *s; }
 void ptref_resize(void* h, uint32_t w, uint32_t hgt) { Context* c = (Context*)h; c->w = w; c->h = hgt; c->accum.assign((size_t)w * hgt, make_float4(0, 0, 0, 0)); c->accumCount = 0; }
 void ptref_reset_accumulation(void* h) { Context* c = (Context*)h; std::fill(c->accum.begin(), c->accum.end(), make_float4(0, 0, 0, 0)); c->accumCount = 0; memset(&c->ctr, 0, sizeof(c->ctr)); }
 
 static void prepare(Context* c) {
     if (c->geomDirty) { finalize_geometry(c->sc); build_bvh(c->sc); c->geomDirty = false; c->lightsDirty = true; }
-    if (c->lightsDirty) { bake_lights(c->sc, c->S.NEEEnabled != 0); c->lightsDirty = false; }
+    if (c->lightsDirty) { bake_lights(c->sc, c->S.NEEEnabled != 0, c->S.NEEType); c->lightsDirty = false; }
 }
 void ptref_prepare(void* h) { prepare((Context*)h); }
 

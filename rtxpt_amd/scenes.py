@@ -230,10 +230,12 @@ class SceneBuilder:
                     np.asarray(color_multiplier, np.float32))
 
     def finish(self):
+        def cat(parts, dtype, shape):          # an empty scene (no geometry at all) is legal: every ray misses
+            return np.concatenate(parts).astype(dtype) if parts else np.zeros(shape, dtype)
         sc = {
-            "indices": np.concatenate(self.indices).astype(np.uint32), "positions": np.concatenate(self.positions).astype(np.float32),
-            "uvs": np.concatenate(self.uvs).astype(np.float32), "normals": np.concatenate(self.normals).astype(np.uint32),
-            "tangents": np.concatenate(self.tangents).astype(np.uint32),
+            "indices": cat(self.indices, np.uint32, (0,)), "positions": cat(self.positions, np.float32, (0, 3)),
+            "uvs": cat(self.uvs, np.float32, (0, 2)), "normals": cat(self.normals, np.uint32, (0,)),
+            "tangents": cat(self.tangents, np.uint32, (0,)),
             "geometries": np.array(self.geometries, dtype=GEOMETRY_DTYPE), "meshes": np.array(self.meshes, dtype=MESH_DTYPE),
             "instances": np.array(self.instances, dtype=INSTANCE_DTYPE), "materials": np.array(self.materials, dtype=MATERIAL_DTYPE),
             "textures": self.textures, "env": self.env,
