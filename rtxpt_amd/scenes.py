@@ -457,6 +457,10 @@ def bistro_like(scale=1.0, seed=SEED_BASE + 3, tex_size=1024, animated=False):
     leaf_mats = [b.add_material(make_material(base=(1, 1, 1), roughness=0.7, ior=1.4, base_tex=leaf_w[i], alpha_cutoff=0.5, diff_transmission=0.0)) for i in range(4)]
     clutter_mats = [b.add_material(make_material(base=tuple(0.15 + 0.75 * rng.random(3)), roughness=float(0.15 + 0.5 * rng.random()), metalness=1.0 if i % 3 == 0 else 0.0, ior=1.5)) for i in range(8)]
     glass_mats = [b.add_material(make_material(base=(0.9, 0.95, 0.97), roughness=0.0, ior=1.5, transmission=0.9, thin=True)) for i in range(4)]
+    if animated:      # C5: two of the glass slots become a nested-dielectric pair (solid glass, priority 2, around a liquid, priority 1)
+        b.materials[glass_mats[2]] = make_material(base=(0.97, 0.98, 0.98), roughness=0.0, ior=1.5, transmission=1.0, thin=False, nested_priority=2)
+        b.materials[glass_mats[3]] = make_material(base=(0.95, 0.6, 0.3), roughness=0.0, ior=1.33, transmission=1.0, thin=False, nested_priority=1,
+                                                  att_color=(0.9, 0.5, 0.2), att_dist=0.5)
     le = 10.0 ** rng.uniform(1.0, 4.0, 16)
     em_mats = [b.add_material(make_material(base=(0.8, 0.8, 0.8), emissive=tuple(float(le[i]) * np.array([1.0, 0.82 + 0.15 * rng.random(), 0.5 + 0.4 * rng.random()])), roughness=1.0, ior=1.5)) for i in range(16)]
     assert len(b.materials) == 64
@@ -617,11 +621,47 @@ def bistro_like(scale=1.0, seed=SEED_BASE + 3, tex_size=1024, animated=False):
         b.add_geometry(p, i, em_mats[int(m)], uv=uv, normal=n, tangent=t)
     b.add_instance(b.end_mesh())
 
+    deform = None
+    if animated:
+        # --- C5: 20 nested-dielectric props (a glass box holding a liquid box) along the street
+        cp, ci, cuv, cn, ct = unit_cube()
+        b.begin_mesh()
+        b.add_geometry(cp, ci, glass_mats[2], uv=cuv, normal=cn, tangent=ct)
+        b.add_geometry(cp * np.array([0.8, 0.7, 0.8], np.float32) + np.array([0, -0.1, 0], np.float32), ci, glass_mats[3], uv=cuv, normal=cn, tangent=ct)
+        prop_mesh = b.end_mesh()
+        for k in range(20):
+            sz = float(rng.uniform(0.5, 1.2))
+            b.add_instance(prop_mesh, trs((float(rng.uniform(8, L - 8)), 0.5 * sz + 0.01, float(rng.uniform(z0 + 3.0, z1 - 3.0))), rot_y=float(rng.uniform(0, 6.283)), scale=(sz, sz, sz)))
+        # --- C5: one deforming mesh of ~50 k triangles (a banner across the street, displaced every frame -> vertex refit)
+        ng = max(4, int(round(158 * math.sqrt(max(scale, 1e-4)))))
+        gu, gv = np.meshgrid(np.linspace(0, 1, ng + 1, dtype=np.float32), np.linspace(0, 1, ng + 1, dtype=np.float32), indexing="ij")
+        pos = np.stack([30.0 + 0.0 * gu, 6.0 + 6.0 * gv, z0 + 1.0 + (z1 - z0 - 2.0) * gu], -1).reshape(-1, 3).astype(np.float32)
+        ii = (np.arange(ng)[:, None] * (ng + 1) + np.arange(ng)[None, :]).reshape(-1)
+        idx = np.stack([ii, ii + 1, ii + ng + 2, ii, ii + ng + 2, ii + ng + 1], 1).reshape(-1).astype(np.uint32)
+        nrm = np.tile(np.array([[1.0, 0.0, 0.0]], np.float32), (pos.shape[0], 1))
+        tan = np.tile(np.array([[0.0, 0.0, 1.0, 1.0]], np.float32), (pos.shape[0], 1))
+        b.begin_mesh()
+        first_vertex = b.nv
+        b.add_geometry(pos, idx, mats[24], uv=np.stack([gu, gv], -1).reshape(-1, 2) * 4.0, normal=nrm, tangent=tan)
+        b.add_instance(b.end_mesh())
+        deform = dict(first_vertex=first_vertex, rest=pos.copy(), u=gu.reshape(-1).copy(), v=gv.reshape(-1).copy())
+
     b.set_environment(sky_equirect(sun_dir=(0.25, 0.75, -0.35), sun_radiance=2e4), color_multiplier=(1, 1, 1))
     sc = b.finish()
-    sc["anim"] = dict(clutter_instances=clutter_instances, tree_instances=tree_instances)
+    sc["anim"] = dict(clutter_instances=clutter_instances, tree_instances=tree_instances, deform=deform)
     cam = dict(pos=(4.0, 1.7, 20.0), direction=(1.0, 0.12, 0.05), up=(0, 1, 0), fov_y=math.radians(60.0), near_z=0.05, far_z=1000.0, focal_distance=10.0)
     return sc, cam
+
+
+def animate_positions(sc, t):
+    """C5 deforming mesh ("1 skinned-like mesh of 50 k tris displaced per frame"): the banner ripples along x; same
+    topology, so the library refits. Returns the full position array for pt_animate."""
+    d = sc["anim"]["deform"]
+    pos = sc["positions"].copy()
+    p = d["rest"].copy()
+    p[:, 0] += (0.35 * np.sin(6.0 * d["u"] + 1.3 * t) * np.sin(3.0 * d["v"] + 0.7 * t)).astype(np.float32)
+    pos[d["first_vertex"]:d["first_vertex"] + p.shape[0]] = p
+    return pos
 
 
 def animate_instances(sc, t):

@@ -228,6 +228,26 @@ def test_refit_equals_rebuild_and_oracle():
     assert np.array_equal(c[..., :3], o2.radiance()[..., :3])
 
 
+def test_c5_animated_frames_refit_nested_dielectrics():
+    """BASELINE config C5 at a small scale: per frame the 40 clutter groups move rigidly and the banner mesh deforms (refit only), the camera
+    looks at the nested-dielectric props; three consecutive frames equal an oracle that is rebuilt from scratch for every frame."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.bistro_like(scale=0.01, tex_size=64, animated=True)
+    cam = dict(cam, pos=(20.0, 2.5, 20.0), direction=(1.0, -0.08, 0.02))
+    S = scenes.default_settings(nestedDielectricsQuality=2); w, h = 192, 108
+    camd = scenes.bridge_camera(w, h, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(w, h)
+    for frame, t in enumerate((0.0, 0.4, 0.8)):
+        inst, pos = scenes.animate_instances(sc, t), scenes.animate_positions(sc, t)
+        g.animate(instances=inst, positions=pos, rebuild=False)
+        g.reset_accumulation(); st = g.render(frame * 2, 2)
+        sc_t = dict(sc); sc_t["positions"] = pos
+        o = ptref.Oracle(); o.set_scene(sc_t); o.set_instances(inst); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.render(frame * 2, 2)
+        assert np.array_equal(g.radiance()[..., :3], o.radiance()[..., :3]), "frame %d" % frame
+        assert st["extendRays"] == o.counters()["extendRays"]
+    assert g.build_stats()["refitMs"] > 0
+
+
 def test_tile_shards_reassemble_bit_exact():
     """2-way pixel-tile sharding on one GPU: each shard traces only its tiles; pack -> (gather) -> unpack reproduces the
     single-context frame bit-for-bit (RNG keyed on absolute pixel + sample index)."""
