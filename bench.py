@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="triangle-count scale of the bistro-like generator (1.0 = 2.8 M triangles)")
     ap.add_argument("--tex", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-kernels", action="store_true", help="run every step with PT_DEVICE_SERIAL_KERNELS semantics (for rocprofv3 kernel traces: launches never overlap)")
     args = ap.parse_args()
 
     import torch
@@ -67,6 +68,7 @@ def main():
     camd = scenes.bridge_camera(W, H, **cam)
     g = pt.PathTracer(device=local_rank, shard_rank=rank, shard_count=world)
     g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(W, H)
+    g.set_serial_kernels(args.serial_kernels)
     n_owned, packed_bytes = g.shard_info()
     counts = [parallel.shard_pixels(W, H, r, world).size for r in range(world)] if world > 1 else [n_owned]
     send = torch.empty((n_owned, 4), dtype=torch.float32, device="cuda")
@@ -104,15 +106,25 @@ def main():
     else:
         rays_total = rays_local
 
-    # roofline of the dominant kernel (k_extend): one extra, untimed step with the in-kernel BVH counters enabled gives the mean
-    # node visits / triangle tests per ray; the kernel time comes from the HIP events recorded on the library's stream in the TIMED steps
+    # roofline of the dominant kernel (k_extend). In the timed region pt_render pipelines two half-frame batches on two streams, so launches of
+    # different kernels overlap and a per-launch HIP-event duration there measures "k_extend while sharing the GPU". The launch duration the
+    # roofline needs is therefore measured live right after the timed region, on the same context, with the overlap switched off
+    # (pt_set_serial_kernels): ROOF_STEPS steps, HIP events on the library's stream around every launch. One more step with the in-kernel BVH
+    # counters compiled in gives the mean node visits / triangle tests per ray.
+    ROOF_STEPS = 2
+    g.set_serial_kernels(True)
+    serial = []
+    for _ in range(ROOF_STEPS):
+        g.reset_accumulation(); serial.append(g.render(0, SPP))
     g.set_counters(True); g.reset_accumulation(); cst = g.render(0, SPP); g.set_counters(False)
+    g.set_serial_kernels(args.serial_kernels)
     nodes_per_ext = cst["nodeVisitsExtend"] / max(1, cst["extendRays"]); tris_per_ext = cst["triTestsExtend"] / max(1, cst["extendRays"])
     nodes_per_sh = cst["nodeVisitsShadow"] / max(1, cst["shadowRays"]); tris_per_sh = cst["triTestsShadow"] / max(1, cst["shadowRays"])
-    ext_ms = sum(s["extendKernelMs"] for s in stats); ext_launches = sum(s["extendLaunches"] for s in stats); ext_rays = sum(s["extendRays"] for s in stats)
+    ext_ms = sum(s["extendKernelMs"] for s in serial); ext_launches = sum(s["extendLaunches"] for s in serial); ext_rays = sum(s["extendRays"] for s in serial)
     bytes_per_ext = B_EXTEND_FIXED + nodes_per_ext * B_NODE + tris_per_ext * B_TRI
     ext_gbs = ext_rays * bytes_per_ext / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-    sh_ms = sum(s["shadowKernelMs"] for s in stats); shade_ms = sum(s["shadeKernelMs"] for s in stats)
+    sh_ms = sum(s["shadowKernelMs"] for s in serial); shade_ms = sum(s["shadeKernelMs"] for s in serial)
+    serial_ms = sum(s["gpuMilliseconds"] for s in serial) / ROOF_STEPS
 
     # HBM traffic of one k_extend launch from the PMC passes (tools/pmc_traffic.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): the counters
     # cannot be read from inside this process, so the committed summary of the same workload is quoted (null when the workload differs)
@@ -130,11 +142,13 @@ def main():
             "config": {"workload": "C3 bistro-like street canyon, %d triangles, 64 materials, 32 textures %d^2, %d emissive-triangle + env-quad lights, %dx%d, %d spp, 8 bounces, NEE 5 candidates + RR"
                                    % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP),
                        "parallelism": "pixel-tile shard x%d + 1 gather" % world, "rays_per_step": rays_total / args.steps,
-                       "extend_rays_per_step": ext_rays / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
+                       "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_ray": bytes_per_ext, "node_visits_per_ray": nodes_per_ext, "tri_tests_per_ray": tris_per_ext,
                          "avg_launch_ms": ext_ms / max(1, ext_launches), "launches": ext_launches,
-                         "kernel_ms_per_step": {"k_extend": ext_ms / args.steps, "k_shade": shade_ms / args.steps, "k_shadow": sh_ms / args.steps},
+                         "kernel_ms_per_step": {"k_extend": ext_ms / ROOF_STEPS, "k_shade": shade_ms / ROOF_STEPS, "k_shadow": sh_ms / ROOF_STEPS},
+                         "measured_on": "%d serial-kernel steps after the timed region (launches do not overlap); serial frame %.1f ms vs pipelined %.1f ms" % (ROOF_STEPS, serial_ms, elapsed / args.steps * 1e3),
+                         "overlapped_kernel_ms_per_step": {"k_extend": sum(s["extendKernelMs"] for s in stats) / args.steps, "k_shade": sum(s["shadeKernelMs"] for s in stats) / args.steps, "k_shadow": sum(s["shadowKernelMs"] for s in stats) / args.steps},
                          "shadow_node_visits_per_ray": nodes_per_sh, "shadow_tri_tests_per_ray": tris_per_sh,
                          "leaf_visits_per_ray": cst["leafVisitsExtend"] / max(1, cst["extendRays"]),
                          "wave_iterations_per_ray": cst["waveItersExtend"] / max(1, cst["extendRays"]),

@@ -110,8 +110,9 @@ typedef struct PtSettings {
 typedef struct PtDeviceDesc {
     int32_t  deviceOrdinal;                 /* HIP device of this context (one context per GPU / process) */
     uint32_t shardRank, shardCount;         /* pixel-tile shard of this context: tile t belongs to rank morton(t) % shardCount */
-    uint32_t flags;
+    uint32_t flags;                         /* PT_DEVICE_* */
 } PtDeviceDesc;
+#define PT_DEVICE_SERIAL_KERNELS 1u         /* one batch, one stream: kernels of a pt_render call never overlap (profiling / per-kernel timing) */
 
 typedef struct PtFrameStats {
     uint64_t extendRays, shadowRays, hits;                  /* "rays" of the Mrays/s metric = extendRays + shadowRays */
@@ -214,6 +215,9 @@ int32_t pt_probe(pt_context* ctx, int32_t kind, const void* in, size_t inBytes, 
 int32_t pt_get_build_stats(pt_context* ctx, double* buildMs, double* refitMs, double* lightBakeMs);
 /* enable in-kernel BVH node/triangle counters (slower); default off */
 int32_t pt_set_counters(pt_context* ctx, int32_t enable);
+/* runtime form of PT_DEVICE_SERIAL_KERNELS: 1 = pt_render uses one batch on one stream (kernels never overlap: clean per-kernel HIP-event /
+   rocprofv3 durations), 0 = two pipelined half-frame batches (default) */
+int32_t pt_set_serial_kernels(pt_context* ctx, int32_t enable);
 
 #ifdef __cplusplus
 }

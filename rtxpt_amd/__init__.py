@@ -28,7 +28,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp",
+    "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels",
 ]
 
 
@@ -144,10 +144,11 @@ def bridge_camera(width, height, pos, direction, up, fov_y, near_z=0.01, far_z=1
 class PathTracer:
     """One pt_context (one GPU). Method names follow the C-ABI; the call order follows Sample::Render."""
 
-    def __init__(self, device=0, shard_rank=0, shard_count=1):
+    def __init__(self, device=0, shard_rank=0, shard_count=1, serial_kernels=False):
+        """serial_kernels: PT_DEVICE_SERIAL_KERNELS — pt_render runs one batch on one stream (clean per-kernel timings) instead of two pipelined half-frame batches."""
         self.L = load_library()
         self.h = ctypes.c_void_p()
-        desc = PtDeviceDesc(device, shard_rank, shard_count, 0)
+        desc = PtDeviceDesc(device, shard_rank, shard_count, 1 if serial_kernels else 0)
         r = self.L.pt_create(ctypes.byref(desc), ctypes.byref(self.h))
         if r != PT_OK:
             raise PtError(r, "pt_create failed (no HIP device? this library has no CPU path)")
@@ -235,6 +236,9 @@ class PathTracer:
         img = np.ctypeslib.as_array(ptr, shape=(self.height, self.width, 4)).copy()
         self.L.pt_unmap_radiance(self.h)
         return img
+
+    def set_serial_kernels(self, enable):
+        self._chk(self.L.pt_set_serial_kernels(self.h, 1 if enable else 0), "pt_set_serial_kernels")
 
     def tonemap(self, params=None):
         """pt_tonemap: the accumulation buffer through ToneMappingPass into sRGB RGBA8 -> (H, W, 4) uint8."""

@@ -50,6 +50,7 @@ static const uint TILE = 32;
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
+    hipStream_t stream2 = nullptr; WaveCounters* hostCounters = nullptr; bool serialKernels = false;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -144,7 +145,7 @@ int upload_textures(pt_context* c) {
 
 void refresh_scene_view(pt_context* c) {
     DeviceScene& d = c->dsc;
-    if (!c->dTravSpill.p) (void)c->dTravSpill.resize((size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH);   // traversal stack tails (302 MB of 288 GB)
+    if (!c->dTravSpill.p) (void)c->dTravSpill.resize(2 * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH);   // traversal stack tails, one region per pipelined batch (2 x 302 MB of 288 GB)
     d.travSpill = c->dTravSpill.p;
     d.indices = c->dIndices.p; d.positions = c->dPositions.p; d.uvs = c->dUvs.p; d.normals = c->dNormals.p; d.tangents = c->dTangents.p;
     d.geometries = c->dGeometries.p; d.instances = c->dInstances.p; d.subInstances = c->dSubInstances.p; d.subInstToInstGeom = c->dSubInstToInstGeom.p;
@@ -375,10 +376,13 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     c->device = dev; c->shardRank = desc ? desc->shardRank : 0; c->shardCount = (desc && desc->shardCount) ? desc->shardCount : 1;
     if (c->shardRank >= c->shardCount) { delete c; return PT_ERROR_INVALID_ARGUMENT; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
+    if (hipHostMalloc(&c->hostCounters, 2 * sizeof(WaveCounters), hipHostMallocDefault) != hipSuccess) { delete c; return PT_ERROR_HIP; }
+    c->serialKernels = desc && (desc->flags & PT_DEVICE_SERIAL_KERNELS);
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
     const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.f);
-    if (c->dCounters.resize(1) != hipSuccess) { delete c; return PT_ERROR_HIP; }
+    if (c->dCounters.resize(2) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     *out = c;
     return PT_OK;
 }
@@ -390,7 +394,7 @@ int32_t pt_destroy(pt_context* c) {
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
     c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free();
-    (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->stream2); (void)hipHostFree(c->hostCounters);
     delete c;
     return PT_OK;
 }
@@ -589,58 +593,108 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     uint numOwned = (uint)c->owned.size();
     if ((unsigned long long)numOwned * count > 0xF0000000ull) return fail(c, PT_ERROR_INVALID_ARGUMENT, "too many paths in one pt_render call");
     uint total = numOwned * count;
-    hipStream_t st = c->stream;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (total == 0) { c->accumCount += count; return PT_OK; }
     r = ensure_pool(c, total); if (r != PT_OK) return r;
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
-    PathPool pool = {c->dS0.p, c->dS1.p, c->dS2.p, c->dS3.p, c->dS4.p, c->dHit.p};
-    ShadowQueue sq = {c->dSq0.p, c->dSq1.p, c->dSq2.p};
-    WaveCounters* wc = c->dCounters.p;
-    WaveCounters hwc; memset(&hwc, 0, sizeof(hwc)); hwc.extendCount[0] = total;
-    std::vector<hipEvent_t> ev; auto mark = [&]() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; };
-    struct Span { size_t a, b; int kind; }; std::vector<Span> spans;
-    size_t t0 = mark();
-    PT_CHECK_HIP(c, hipMemcpyAsync(wc, &hwc, sizeof(hwc), hipMemcpyHostToDevice, st));
-    launch_generate(k, pool, c->dOwned.p, numOwned, first, count, c->dQueue[0].p, st);
-    uint cur = 0, active = total, iterations = 0; unsigned long long extendRays = 0, shadowRays = 0;
+
+    // The owned pixels are traced as two independent half-frame batches on two streams. Paths never interact, so this changes nothing in the
+    // result; it lets the latency-bound k_shade of one batch overlap the VALU-bound traversal of the other and hides the ~0.5 ms drain at the
+    // end of every launch (measured with two contexts on one GPU: 246 -> 228 ms per C3 frame). Small frames and PT_DEVICE_SERIAL_KERNELS use one batch.
+    struct Batch {
+        uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
+        PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k;
+        uint cur = 0, active = 0, iterations = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false;
+        std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
+        size_t mark() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
+    };
+    const uint numBatches = (c->serialKernels || total < (1u << 21)) ? 1u : 2u;
+    Batch B[2];
+    for (uint b = 0; b < numBatches; b++) {
+        Batch& t = B[b];
+        t.pixFirst = (uint)((unsigned long long)numOwned * b / numBatches); t.numPix = (uint)((unsigned long long)numOwned * (b + 1) / numBatches) - t.pixFirst;
+        t.total = t.numPix * count; t.base = t.pixFirst * count; t.st = b ? c->stream2 : c->stream; t.wc = c->dCounters.p + b; t.hwc = c->hostCounters + b;
+        t.pool = PathPool{c->dS0.p + t.base, c->dS1.p + t.base, c->dS2.p + t.base, c->dS3.p + t.base, c->dS4.p + t.base, c->dHit.p + t.base};
+        t.sq = ShadowQueue{c->dSq0.p + t.base, c->dSq1.p + t.base, c->dSq2.p + t.base};
+        t.queue[0] = c->dQueue[0].p + t.base; t.queue[1] = c->dQueue[1].p + t.base;
+        t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
+        t.k = k; t.k.sc = t.sc;
+        memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
+        t.active = t.total;
+    }
+    if (numBatches == 2) PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // uploads issued on the main stream (prepare) must be visible to the second stream
+    hipEvent_t frame0, frame1; PT_CHECK_HIP(c, hipEventCreate(&frame0)); PT_CHECK_HIP(c, hipEventCreate(&frame1));
+    PT_CHECK_HIP(c, hipEventRecord(frame0, c->stream));
+    for (uint b = 0; b < numBatches; b++) {
+        Batch& t = B[b];
+        t.t0 = t.mark();
+        PT_CHECK_HIP(c, hipMemcpyAsync(t.wc, t.hwc, sizeof(WaveCounters), hipMemcpyHostToDevice, t.st));
+        launch_generate(t.k, t.pool, c->dOwned.p + t.pixFirst, t.numPix, first, count, t.queue[0], t.st);
+    }
     // upper bound on extend passes: bounceCount+1 vertices plus rejected (nested dielectric) re-traces
     uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u));
-    while (active && iterations < maxIter) {
-        uint nxt = cur ^ 1u;
-        uint zero2[2] = {0u, 0u};
-        PT_CHECK_HIP(c, hipMemcpyAsync(&wc->extendCount[nxt], &zero2[0], 4, hipMemcpyHostToDevice, st));
-        PT_CHECK_HIP(c, hipMemcpyAsync(&wc->shadowCount, &zero2[1], 4, hipMemcpyHostToDevice, st));
-        size_t a = mark(); launch_extend(c->dsc, pool, c->dQueue[cur].p, &wc->extendCount[cur], active, wc, c->countersEnabled, st); size_t b = mark(); spans.push_back({a, b, 0});
-        launch_shade(k, pool, c->dQueue[cur].p, &wc->extendCount[cur], active, c->dQueue[nxt].p, &wc->extendCount[nxt], sq, wc, st); size_t d = mark(); spans.push_back({b, d, 1});
-        extendRays += active;
-        PT_CHECK_HIP(c, hipMemcpyAsync(&hwc, wc, 16, hipMemcpyDeviceToHost, st));
-        PT_CHECK_HIP(c, hipStreamSynchronize(st));
-        uint nShadow = hwc.shadowCount;
-        if (nShadow) { size_t e = mark(); launch_shadow(c->dsc, pool, sq, &wc->shadowCount, nShadow, wc, c->countersEnabled, st); size_t f = mark(); spans.push_back({e, f, 2}); shadowRays += nShadow; }
-        active = hwc.extendCount[nxt]; cur = nxt; iterations++;
+    bool any = true;
+    while (any) {
+        // phase 1: every live batch queues extend + shade and the read-back of its queue counts
+        for (uint b = 0; b < numBatches; b++) {
+            Batch& t = B[b];
+            t.waiting = false;
+            if (!t.active || t.iterations >= maxIter) continue;
+            uint nxt = t.cur ^ 1u;
+            PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->extendCount[nxt], 0, 4, t.st));
+            PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st));
+            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0});
+            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1});
+            t.extendRays += t.active;
+            PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
+            t.waiting = true;
+        }
+        // phase 2: as each batch's counts arrive, queue its shadow rays; the other batch keeps the GPU busy meanwhile
+        any = false;
+        for (uint b = 0; b < numBatches; b++) {
+            Batch& t = B[b];
+            if (!t.waiting) continue;
+            PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
+            uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
+            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2}); t.shadowRays += nShadow; }
+            t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
+            if (t.active && t.iterations < maxIter) any = true;
+        }
     }
-    launch_accumulate(pool, c->dOwned.p, numOwned, count, c->dAccum.p, c->accumCount, c->width, st);
-    size_t t1 = mark();
-    PT_CHECK_HIP(c, hipMemcpyAsync(&hwc, wc, sizeof(hwc), hipMemcpyDeviceToHost, st));
-    PT_CHECK_HIP(c, hipStreamSynchronize(st));
+    for (uint b = 0; b < numBatches; b++) {
+        Batch& t = B[b];
+        launch_accumulate(t.pool, c->dOwned.p + t.pixFirst, t.numPix, count, c->dAccum.p, c->accumCount, c->width, t.st);
+        t.t1 = t.mark();
+        PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, sizeof(WaveCounters), hipMemcpyDeviceToHost, t.st));
+    }
+    for (uint b = 0; b < numBatches; b++) PT_CHECK_HIP(c, hipStreamSynchronize(B[b].st));
+    PT_CHECK_HIP(c, hipEventRecord(frame1, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     PT_CHECK_HIP(c, hipGetLastError());
-    if (hwc.overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal stack overflow (raise T8_SPILL_DEPTH)");
+    bool overflow = false;
+    for (uint b = 0; b < numBatches; b++) overflow = overflow || B[b].hwc->overflow;
     c->accumCount += count;
     if (stats) {
-        float ms = 0; (void)hipEventElapsedTime(&ms, ev[t0], ev[t1]); stats->gpuMilliseconds = ms;
-        for (auto& s : spans) { float m = 0; (void)hipEventElapsedTime(&m, ev[s.a], ev[s.b]); if (s.kind == 0) { stats->extendKernelMs += m; stats->extendLaunches++; } else if (s.kind == 1) stats->shadeKernelMs += m; else stats->shadowKernelMs += m; }
-        stats->extendRays = extendRays; stats->shadowRays = shadowRays; stats->hits = hwc.hits; stats->nodeVisitsExtend = hwc.nodeVisitsExt; stats->triTestsExtend = hwc.triTestsExt;
-        stats->nodeVisitsShadow = hwc.nodeVisitsSh; stats->triTestsShadow = hwc.triTestsSh;
-        stats->leafVisitsExtend = hwc.leafVisitsExt; stats->waveItersExtend = hwc.itersExt; stats->leafVisitsShadow = hwc.leafVisitsSh; stats->waveItersShadow = hwc.itersSh;
-        for (int q = 0; q < 4; q++) stats->extendPhaseCycles[q] = hwc.phaseCycExt[q];
-        stats->leafBlocksExtend = hwc.leafBlocksExt;
-        for (int q = 0; q < 8; q++) stats->extendEvents[q] = hwc.eventsExt[q]; stats->iterations = iterations; stats->pathsTraced = total;
+        // whole-call time: from the first batch's start to the later batch's end (both streams were idle before and are drained now)
+        float ms = 0; (void)hipEventElapsedTime(&ms, frame0, frame1); stats->gpuMilliseconds = ms;
+        for (uint b = 0; b < numBatches; b++) {
+            Batch& t = B[b]; const WaveCounters& h = *t.hwc;
+            for (auto& sp : t.spans) { float m = 0; (void)hipEventElapsedTime(&m, t.ev[sp.a], t.ev[sp.b]); if (sp.kind == 0) { stats->extendKernelMs += m; stats->extendLaunches++; } else if (sp.kind == 1) stats->shadeKernelMs += m; else stats->shadowKernelMs += m; }
+            stats->extendRays += t.extendRays; stats->shadowRays += t.shadowRays; stats->hits += h.hits; stats->nodeVisitsExtend += h.nodeVisitsExt; stats->triTestsExtend += h.triTestsExt;
+            stats->nodeVisitsShadow += h.nodeVisitsSh; stats->triTestsShadow += h.triTestsSh;
+            stats->leafVisitsExtend += h.leafVisitsExt; stats->waveItersExtend += h.itersExt; stats->leafVisitsShadow += h.leafVisitsSh; stats->waveItersShadow += h.itersSh;
+            for (int q = 0; q < 4; q++) stats->extendPhaseCycles[q] += h.phaseCycExt[q];
+            stats->leafBlocksExtend += h.leafBlocksExt;
+            for (int q = 0; q < 8; q++) stats->extendEvents[q] += h.eventsExt[q];
+            if (t.iterations > stats->iterations) stats->iterations = t.iterations;
+        }
+        stats->pathsTraced = total;
     }
-    for (auto e : ev) (void)hipEventDestroy(e);
+    for (uint b = 0; b < numBatches; b++) for (auto e : B[b].ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(frame0); (void)hipEventDestroy(frame1);
+    if (overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal stack overflow (raise T8_SPILL_DEPTH)");
     return PT_OK;
 }
-
 int32_t pt_map_radiance(pt_context* c, const float** rgba, size_t* pitch) {
     if (!c || !rgba) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
@@ -773,5 +827,6 @@ int32_t pt_probe(pt_context* c, int32_t kind, const void* in, size_t inBytes, vo
 }
 int32_t pt_get_build_stats(pt_context* c, double* b, double* r, double* l) { if (!c) return PT_ERROR_INVALID_ARGUMENT; if (b) *b = c->buildMs; if (r) *r = c->refitMs; if (l) *l = c->lightBakeMs; return PT_OK; }
 int32_t pt_set_counters(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->countersEnabled = enable != 0; return PT_OK; }
+int32_t pt_set_serial_kernels(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->serialKernels = enable != 0; return PT_OK; }
 
 } // extern "C"
