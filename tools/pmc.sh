@@ -2,7 +2,7 @@
 # developer profiling: one rocprofv3 --pmc pass per counter group over a 1-step bench run (usage: tools/pmc.sh <outdir> [bench args])
 # counters are collected WITHOUT any trace domain other than --kernel-trace (gpurun policy)
 OUT=${1:-gpurun_out/pmc}; shift
-ARGS=${@:---steps 1 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 1 --warmup 1 --no-cpu-baseline --serial-kernels}
 mkdir -p $OUT; OUT=$(realpath $OUT); REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 i=0

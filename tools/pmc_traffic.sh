@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT -o t$i -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/t$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT -o t$i -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --serial-kernels > $OUT/t$i.log 2>&1
 done
 cd $REPO && python - $OUT <<'PY'
 import csv, glob, json, sys, collections
