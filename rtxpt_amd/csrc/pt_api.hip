@@ -45,12 +45,15 @@ template <typename T> struct DevBuf {
 struct HostTexture { uint w, h, mipLevels; std::vector<std::vector<ptk::float4>> mips; };
 
 static const uint TILE = 32;
+#ifndef PT_PIPELINE_BATCHES
+#define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3: 1: 241 ms, 2: 218, 3: 205, 4: 199, 5: 210, 6: 230)
+#endif
 
 } // namespace
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
-    hipStream_t stream2 = nullptr; WaveCounters* hostCounters = nullptr; bool serialKernels = false;   // second half-frame batch (pt_render pipelines two batches)
+    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -145,7 +148,7 @@ int upload_textures(pt_context* c) {
 
 void refresh_scene_view(pt_context* c) {
     DeviceScene& d = c->dsc;
-    if (!c->dTravSpill.p) (void)c->dTravSpill.resize(2 * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH);   // traversal stack tails, one region per pipelined batch (2 x 302 MB of 288 GB)
+    if (!c->dTravSpill.p) (void)c->dTravSpill.resize(PT_PIPELINE_BATCHES * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH);   // traversal stack tails, one region per pipelined batch (4 x 302 MB of 288 GB)
     d.travSpill = c->dTravSpill.p;
     d.indices = c->dIndices.p; d.positions = c->dPositions.p; d.uvs = c->dUvs.p; d.normals = c->dNormals.p; d.tangents = c->dTangents.p;
     d.geometries = c->dGeometries.p; d.instances = c->dInstances.p; d.subInstances = c->dSubInstances.p; d.subInstToInstGeom = c->dSubInstToInstGeom.p;
@@ -376,13 +379,14 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     c->device = dev; c->shardRank = desc ? desc->shardRank : 0; c->shardCount = (desc && desc->shardCount) ? desc->shardCount : 1;
     if (c->shardRank >= c->shardCount) { delete c; return PT_ERROR_INVALID_ARGUMENT; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
-    if (hipHostMalloc(&c->hostCounters, 2 * sizeof(WaveCounters), hipHostMallocDefault) != hipSuccess) { delete c; return PT_ERROR_HIP; }
+    c->streams[0] = c->stream;
+    for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) if (hipStreamCreateWithFlags(&c->streams[b], hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
+    if (hipHostMalloc(&c->hostCounters, PT_PIPELINE_BATCHES * sizeof(WaveCounters), hipHostMallocDefault) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     c->serialKernels = desc && (desc->flags & PT_DEVICE_SERIAL_KERNELS);
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
     const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.f);
-    if (c->dCounters.resize(2) != hipSuccess) { delete c; return PT_ERROR_HIP; }
+    if (c->dCounters.resize(PT_PIPELINE_BATCHES) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     *out = c;
     return PT_OK;
 }
@@ -394,7 +398,8 @@ int32_t pt_destroy(pt_context* c) {
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
     c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free();
-    (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->stream2); (void)hipHostFree(c->hostCounters);
+    for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
+    (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
     delete c;
     return PT_OK;
 }
@@ -598,9 +603,10 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     r = ensure_pool(c, total); if (r != PT_OK) return r;
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
 
-    // The owned pixels are traced as two independent half-frame batches on two streams. Paths never interact, so this changes nothing in the
+    // The owned pixels are traced as up to PT_PIPELINE_BATCHES independent sub-frame batches, each on its own stream. Paths never interact, so this changes nothing in the
     // result; it lets the latency-bound k_shade of one batch overlap the VALU-bound traversal of the other and hides the ~0.5 ms drain at the
-    // end of every launch (measured with two contexts on one GPU: 246 -> 228 ms per C3 frame). Small frames and PT_DEVICE_SERIAL_KERNELS use one batch.
+    // end of every launch (C3: 241 ms with one batch, 199 ms with four). The batches advance in lockstep (queue all, then service each as its counts arrive): an
+    // event-driven variant that re-queued each batch independently was 7 % slower. Small frames use fewer batches, PT_DEVICE_SERIAL_KERNELS one.
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k;
@@ -608,12 +614,12 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         size_t mark() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
-    const uint numBatches = (c->serialKernels || total < (1u << 21)) ? 1u : 2u;
-    Batch B[2];
+    const uint numBatches = (c->serialKernels || total < (1u << 21)) ? 1u : ((total < (1u << 23)) ? 2u : PT_PIPELINE_BATCHES);
+    Batch B[PT_PIPELINE_BATCHES];
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
         t.pixFirst = (uint)((unsigned long long)numOwned * b / numBatches); t.numPix = (uint)((unsigned long long)numOwned * (b + 1) / numBatches) - t.pixFirst;
-        t.total = t.numPix * count; t.base = t.pixFirst * count; t.st = b ? c->stream2 : c->stream; t.wc = c->dCounters.p + b; t.hwc = c->hostCounters + b;
+        t.total = t.numPix * count; t.base = t.pixFirst * count; t.st = c->streams[b]; t.wc = c->dCounters.p + b; t.hwc = c->hostCounters + b;
         t.pool = PathPool{c->dS0.p + t.base, c->dS1.p + t.base, c->dS2.p + t.base, c->dS3.p + t.base, c->dS4.p + t.base, c->dHit.p + t.base};
         t.sq = ShadowQueue{c->dSq0.p + t.base, c->dSq1.p + t.base, c->dSq2.p + t.base};
         t.queue[0] = c->dQueue[0].p + t.base; t.queue[1] = c->dQueue[1].p + t.base;
@@ -622,7 +628,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
         t.active = t.total;
     }
-    if (numBatches == 2) PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // uploads issued on the main stream (prepare) must be visible to the second stream
+    if (numBatches > 1) PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // uploads issued on the main stream (prepare) must be visible to the second stream
     hipEvent_t frame0, frame1; PT_CHECK_HIP(c, hipEventCreate(&frame0)); PT_CHECK_HIP(c, hipEventCreate(&frame1));
     PT_CHECK_HIP(c, hipEventRecord(frame0, c->stream));
     for (uint b = 0; b < numBatches; b++) {
