@@ -59,7 +59,7 @@ class PtFrameStats(ctypes.Structure):
     _fields_ = [("extendRays", ctypes.c_uint64), ("shadowRays", ctypes.c_uint64), ("hits", ctypes.c_uint64),
                 ("nodeVisitsExtend", ctypes.c_uint64), ("triTestsExtend", ctypes.c_uint64), ("nodeVisitsShadow", ctypes.c_uint64), ("triTestsShadow", ctypes.c_uint64),
                 ("leafVisitsExtend", ctypes.c_uint64), ("waveItersExtend", ctypes.c_uint64), ("leafVisitsShadow", ctypes.c_uint64), ("waveItersShadow", ctypes.c_uint64),
-                ("extendPhaseCycles", ctypes.c_uint64 * 4), ("leafBlocksExtend", ctypes.c_uint64), ("extendEvents", ctypes.c_uint64 * 8),
+                ("extendPhaseCycles", ctypes.c_uint64 * 4), ("leafBlocksExtend", ctypes.c_uint64), ("waveItersMaxExtend", ctypes.c_uint64), ("extendRayIterHist", ctypes.c_uint64 * 16), ("longRayCount", ctypes.c_uint32), ("_padLong", ctypes.c_uint32), ("longRays", (ctypes.c_float * 8) * 32), ("extendEvents", ctypes.c_uint64 * 8),
                 ("gpuMilliseconds", ctypes.c_double), ("extendKernelMs", ctypes.c_double), ("shadeKernelMs", ctypes.c_double), ("shadowKernelMs", ctypes.c_double),
                 ("extendLaunches", ctypes.c_uint32), ("iterations", ctypes.c_uint32), ("pathsTraced", ctypes.c_uint32), ("_pad", ctypes.c_uint32)]
 

@@ -45,7 +45,14 @@ template <typename T> struct DevBuf {
 struct HostTexture { uint w, h, mipLevels; std::vector<std::vector<ptk::float4>> mips; };
 
 static const uint TILE = 32;
+static const uint TASK_QUEUE_CAPACITY = 1u << 21;      // sub-tree tasks per queue (2 queues per pipelined batch, 16 B each); a full queue only disables further splitting
+#ifndef PT_SHARD_TILE_GROUP
+#define PT_SHARD_TILE_GROUP 1      // consecutive Morton-ordered 32x32 tiles dealt to the same rank (locality vs load balance)
+#endif
 #ifndef PT_PIPELINE_BATCHES
+#ifndef PT_PIPELINE_FULL_AT
+#define PT_PIPELINE_FULL_AT (1u << 23)
+#endif
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3: 1: 241 ms, 2: 218, 3: 205, 4: 199, 5: 210, 6: 230)
 #endif
 
@@ -68,7 +75,7 @@ struct pt_context {
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
-    DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill;
+    DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
     BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0;
     DeviceScene dsc;
@@ -117,7 +124,7 @@ void build_shards(pt_context* c) {
     uint order = 0;
     for (auto& t : tiles) {
         uint tX = t.second % tx, tY = t.second / tx;
-        std::vector<uint>& dst = c->shardPixels[order % c->shardCount];
+        std::vector<uint>& dst = c->shardPixels[(order / PT_SHARD_TILE_GROUP) % c->shardCount];
         order++;
         for (uint by = 0; by < TILE; by += 8) for (uint bx = 0; bx < TILE; bx += 8)
             for (uint y = 0; y < 8; y++) for (uint x = 0; x < 8; x++) {
@@ -359,6 +366,8 @@ int ensure_pool(pt_context* c, uint n) {
     PT_CHECK_HIP(c, c->dS0.resize(n)); PT_CHECK_HIP(c, c->dS1.resize(n)); PT_CHECK_HIP(c, c->dS2.resize(n)); PT_CHECK_HIP(c, c->dS3.resize(n)); PT_CHECK_HIP(c, c->dS4.resize(n));
     PT_CHECK_HIP(c, c->dHit.resize(n)); PT_CHECK_HIP(c, c->dQueue[0].resize(n)); PT_CHECK_HIP(c, c->dQueue[1].resize(n));
     PT_CHECK_HIP(c, c->dSq0.resize(n)); PT_CHECK_HIP(c, c->dSq1.resize(n)); PT_CHECK_HIP(c, c->dSq2.resize(n));
+    PT_CHECK_HIP(c, c->dBestKey.resize(n)); PT_CHECK_HIP(c, c->dResolveList.resize(n));
+    PT_CHECK_HIP(c, c->dTaskQ.resize((size_t)PT_PIPELINE_BATCHES * 2 * TASK_QUEUE_CAPACITY)); PT_CHECK_HIP(c, c->dTravCounts.resize(PT_PIPELINE_BATCHES * 4));
     c->poolCapacity = n;
     return PT_OK;
 }
@@ -397,7 +406,7 @@ int32_t pt_destroy(pt_context* c) {
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
     c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
-    c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free();
+    c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
     delete c;
@@ -609,12 +618,12 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     // event-driven variant that re-queued each batch independently was 7 % slower. Small frames use fewer batches, PT_DEVICE_SERIAL_KERNELS one.
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
-        PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k;
+        PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
         uint cur = 0, active = 0, iterations = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false;
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         size_t mark() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
-    const uint numBatches = (c->serialKernels || total < (1u << 21)) ? 1u : ((total < (1u << 23)) ? 2u : PT_PIPELINE_BATCHES);
+    const uint numBatches = (c->serialKernels || total < (1u << 21)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? 2u : PT_PIPELINE_BATCHES);
     Batch B[PT_PIPELINE_BATCHES];
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
@@ -625,6 +634,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.queue[0] = c->dQueue[0].p + t.base; t.queue[1] = c->dQueue[1].p + t.base;
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;
+        t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + 4 * b;
+        t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + t.base; t.aux.resolveList = c->dResolveList.p + t.base; t.aux.primToSlot = c->bvh.primToSlot;
         memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
         t.active = t.total;
     }
@@ -649,7 +660,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             uint nxt = t.cur ^ 1u;
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->extendCount[nxt], 0, 4, t.st));
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st));
-            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0});
+            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0});
             launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1});
             t.extendRays += t.active;
             PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
@@ -662,7 +673,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (!t.waiting) continue;
             PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
             uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
-            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2}); t.shadowRays += nShadow; }
+            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.aux, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2}); t.shadowRays += nShadow; }
             t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
             if (t.active && t.iterations < maxIter) any = true;
         }
@@ -690,15 +701,17 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             stats->nodeVisitsShadow += h.nodeVisitsSh; stats->triTestsShadow += h.triTestsSh;
             stats->leafVisitsExtend += h.leafVisitsExt; stats->waveItersExtend += h.itersExt; stats->leafVisitsShadow += h.leafVisitsSh; stats->waveItersShadow += h.itersSh;
             for (int q = 0; q < 4; q++) stats->extendPhaseCycles[q] += h.phaseCycExt[q];
-            stats->leafBlocksExtend += h.leafBlocksExt;
+            stats->leafBlocksExtend += h.leafBlocksExt; if (h.itersMaxExt > stats->waveItersMaxExtend) stats->waveItersMaxExtend = h.itersMaxExt;
             for (int q = 0; q < 8; q++) stats->extendEvents[q] += h.eventsExt[q];
+            for (int q = 0; q < 16; q++) stats->extendRayIterHist[q] += h.rayIterHistExt[q];
+            for (uint q = 0; q < h.longRayCount && q < 32u && stats->longRayCount < 32u; q++) { memcpy(stats->longRays[stats->longRayCount], h.longRays[q], 32); stats->longRayCount++; }
             if (t.iterations > stats->iterations) stats->iterations = t.iterations;
         }
         stats->pathsTraced = total;
     }
     for (uint b = 0; b < numBatches; b++) for (auto e : B[b].ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(frame0); (void)hipEventDestroy(frame1);
-    if (overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal stack overflow (raise T8_SPILL_DEPTH)");
+    if (overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
     return PT_OK;
 }
 int32_t pt_map_radiance(pt_context* c, const float** rgba, size_t* pitch) {

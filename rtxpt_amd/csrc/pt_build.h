@@ -27,6 +27,7 @@ struct BvhBuildBuffers {
     uint* sceneBounds;          // 6 ordered-uint encoded floats (min xyz, max xyz)
     BvhNode* nodes;
     AlphaRec* alphaRecs;        // leaf order, parallel to triSorted
+    uint* primToSlot;           // global primitive id -> leaf-order slot (k_resolve_extend looks the winning triangle up by primitive)
     Bvh8Node* nodes8; uint* levelA; uint* levelB; uint* wideCounter; uint numNodes8, collapseLevels;
     void* sortTemp; size_t sortTempBytes;
     uint capacity;

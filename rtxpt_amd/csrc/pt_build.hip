@@ -239,9 +239,10 @@ __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ n
 }
 
 // AlphaTestImpl's inputs (BridgeDonut:929-971) gathered once per triangle instead of once per candidate hit
-__global__ void __launch_bounds__(256) k_alpha_records(DeviceScene sc, const TriRecord* __restrict__ triSorted, uint n, AlphaRec* __restrict__ recs) {
+__global__ void __launch_bounds__(256) k_alpha_records(DeviceScene sc, const TriRecord* __restrict__ triSorted, uint n, AlphaRec* __restrict__ recs, uint* __restrict__ primToSlot) {
     uint i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
+    primToSlot[triSorted[i].prim] = i;
     AlphaRec r; r.t0 = r.t1 = r.t2 = make_float2(0.f, 0.f); r.tex = 0xFFFFFFFFu; r.cutoff = 0.f;
     TriRecord tr = triSorted[i];
     if (tr.flags & 1u) {
@@ -268,7 +269,7 @@ hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
     PT_HIP_TRY(hipMalloc(&b.tickets, 4 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.boxLmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxLmax, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmax, 16 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.sceneBounds, 32)); PT_HIP_TRY(hipMalloc(&b.nodes, sizeof(BvhNode) * (size_t)n));
-    PT_HIP_TRY(hipMalloc(&b.alphaRecs, sizeof(AlphaRec) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.nodes8, sizeof(Bvh8Node) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelA, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelB, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.wideCounter, 16));
+    PT_HIP_TRY(hipMalloc(&b.alphaRecs, sizeof(AlphaRec) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.primToSlot, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.nodes8, sizeof(Bvh8Node) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelA, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelB, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.wideCounter, 16));
     size_t tmp = 0;
     PT_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64));
     b.sortTempBytes = tmp; PT_HIP_TRY(hipMalloc(&b.sortTemp, tmp ? tmp : 16));
@@ -276,7 +277,7 @@ hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
 }
 void bvh_free(BvhBuildBuffers& b) {
     void* ps[] = {b.triWorld, b.triSorted, b.keys, b.keysSorted, b.prims, b.primsSorted, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast, b.tickets,
-                  b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter, b.alphaRecs};
+                  b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter, b.alphaRecs, b.primToSlot};
     for (void* p : ps) if (p) (void)hipFree(p);
     __builtin_memset(&b, 0, sizeof(b));
 }
@@ -284,7 +285,7 @@ static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, const DeviceScene& sc,
     uint g = (n + 255u) / 256u;
     PT_HIP_TRY(hipMemsetAsync(b.tickets, 0, 4 * (size_t)(n < 2 ? 2 : n), st));
     hipLaunchKernelGGL(k_bounds, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.childL, b.parent, b.leafParent, b.tickets, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax);
-    hipLaunchKernelGGL(k_alpha_records, dim3(g), dim3(256), 0, st, sc, b.triSorted, n, b.alphaRecs);
+    hipLaunchKernelGGL(k_alpha_records, dim3(g), dim3(256), 0, st, sc, b.triSorted, n, b.alphaRecs, b.primToSlot);
     hipLaunchKernelGGL(k_emit, dim3(g), dim3(256), 0, st, n, b.childL, b.childR, b.rangeFirst, b.rangeLast, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes);
     // BVH8 collapse, level by level (the per-level node count comes back to the host: a build step, not the hot path)
     uint init[4] = {0u, 0u, 1u, 0u};                       // levelA[0] = (wide 0, bvh2 root 0); counter = {next wide index = 1, out count = 0}

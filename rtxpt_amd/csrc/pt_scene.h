@@ -97,6 +97,9 @@ struct DeviceScene {
 };
 
 struct HitInfo { float t; uint prim; float u, v; };
+// a sub-tree of one ray's traversal handed to a follow-up launch (straggler splitting, pt_traverse8.h): 16 B
+struct TravTask { uint tag, ref, tbits, _pad; };
+struct TravTaskOut { TravTask* tasks; uint* count; uint capacity; };
 
 // ---- texture sampling: wrap addressing, texel centres at (i+0.5)/dim, bilinear per mip, linear between mips
 static inline const float4& tex_texel(const DeviceScene& sc, const TexInfo& t, uint mip, int x, int y) {

@@ -19,13 +19,18 @@
 
 namespace ptk {
 
-struct Traverse8Counters { uint nodeVisits, triTests, leafVisits, iters, leafBlocks; uint ev[8]; unsigned long long cyc[4]; };
+struct Traverse8Counters { uint nodeVisits, triTests, leafVisits, iters, leafBlocks; uint ev[8]; unsigned long long cyc[4]; unsigned long long* rayIterHist; uint* longRayCount; float* longRays; };
+
 #define T8_EVENT(k, cond) do { if (COUNT) { unsigned long long m_ = t8_ballot(cond); if (m_ && lane == (uint)__ffsll((long long)m_) - 1u) ctr.ev[k]++; } } while (0)
-static const uint T8_RAY_STRIDE = 9, T8_RAYBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_RAY_STRIDE;   // per-wave LDS parking lot for a chunk's rays (odd stride)
+static const uint T8_RAY_STRIDE = 9, T8_TASK_STRIDE = 11;                                              // per-wave LDS parking lot for a chunk's rays / tasks (odd strides)
+static const uint T8_RAYBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_RAY_STRIDE, T8_TASKBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_TASK_STRIDE;
 static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 
 #ifndef T8_EXTEND_MIN_BLOCKS
 #define T8_EXTEND_MIN_BLOCKS 5    // 256-thread blocks per CU the register allocator must leave room for in k_extend (= waves per SIMD)
+#endif
+#ifndef T8_TAIL_ITERS
+#define T8_TAIL_ITERS 64         // loop iterations a wave keeps going after its last chunk before it splits what is still in flight into tasks
 #endif
 #ifndef T8_LEAF_QUEUE
 #define T8_LEAF_QUEUE 2         // postponed leaves a ray may hold (1..3) before it has to wait for the wave's next leaf block (A/B: within noise on extend, -4 % on shadow)
@@ -51,15 +56,21 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __u
 struct __attribute__((packed, aligned(8))) Bvh8ChildPair { uint refA, q0A, q1A, refB, q0B, q1B; };   // this lane's two 12 B child slots (24 B, 8-byte aligned)
 
 // FIXED_RANGE: every ray of the launch has tmin = 0, tmax = kMaxRayTravel (extend rays), whatever fetch() reports.
-// Src: uint fetch(uint i, float3& o, float3& d, float& tmin, float& tmax) -> user tag (e.g. path index); called once per ray by one lane; tmin >= 0
+// TASKS: the work items are sub-trees of rays (TravTask) instead of whole rays: fetch() also reports the start node and the ray's best hit so far.
+// CAN_SPLIT: straggler handling. One ray is a serial chain on one quad, and C3 has ~300 rays (of 10^8) that need 10^3..10^4 iterations (rays
+//   running along the street inside the tree crowns): alone they kept a launch alive for up to 20 ms and cost 15-25 % of the frame and half of
+//   the 8-GPU scaling. So a wave that has been out of fresh rays for T8_TAIL_ITERS iterations stops: every ray still in flight is cut into its
+//   pending sub-trees (node slot, postponed leaves, stack entries), which go to a task queue together with the best hit so far (publish()),
+//   and a follow-up launch spreads them over the whole GPU. The result is the minimum over all sub-trees, so nothing changes in the image.
+// Src: uint fetch(uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> user tag (e.g. path
+//        index); called once per item by one lane; tmin >= 0. Rays: startRef = 0, bestT0 = tmax, bestPrim0 = ~0.
 // Dst: void commit(uint tag, const HitInfo& h) ; called by ONE lane of the quad (closest: best hit or prim == ~0; any-hit: prim != ~0 when occluded)
+// Pub: void publish(uint tag, float bestT, uint bestPrim) ; called by one lane for every ray that is split (CAN_SPLIT only)
 //
-// The step is written for instruction count: one 16 B header + one 24 B child-pair load per lane, packed-fp32 decode and slab
-// arithmetic (v_pk_fma/add/mul_f32 — the box test has no parity constraint, only conservativeness), integer sort keys (entry distance
-// bits with the child index in the low 3 bits: unique, so a rank is 7 compares), and hit attributes that stay in the lane that found
-// them instead of being broadcast.
-template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, class Src, class Dst>
-__device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint count, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Traverse8Counters& ctr, uint* overflowFlag) {
+template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, class Src, class Dst, class Pub>
+__device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint count, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
+                                                     Traverse8Counters& ctr, uint* overflowFlag) {
+    const uint RAY_STRIDE = TASKS ? T8_TASK_STRIDE : T8_RAY_STRIDE;
     const uint lane = threadIdx.x & 63u, q = lane & 3u, gl = lane & ~3u;
     const uint grp = threadIdx.x >> 2;
     uint2* stack = stackBase + grp * BVH8_STACK_STRIDE;
@@ -76,9 +87,10 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     const uint numWavesU = (uint)__builtin_amdgcn_readfirstlane((int)numWaves);
     uint chunk = (uint)__builtin_amdgcn_readfirstlane((int)(waveId - numWaves)), chunkPos = 0u, chunkEnd = 0u;
     bool exhausted = (waveId * T8_CHUNK >= count) || !sc.rootIsValid;
-    uint* rayBuf = rayBufBase + (threadIdx.x >> 6) * (T8_CHUNK * T8_RAY_STRIDE);
+    uint* rayBuf = rayBufBase + (threadIdx.x >> 6) * (T8_CHUNK * RAY_STRIDE);
+    uint tailIters = 0u; bool waveDry = false;                // wave-uniform: a refill found the chunk list empty / iterations since then (CAN_SPLIT)
     if (!sc.rootIsValid && waveId == 0 && count) {            // empty scene: every ray misses
-        for (uint i = lane; i < count; i += 64u) { float3 o, d; float a, b; uint tag = fetch(i, o, d, a, b); HitInfo h; h.t = b; h.prim = 0xFFFFFFFFu; h.u = h.v = 0.f; commit(tag, h); }
+        for (uint i = lane; i < count; i += 64u) { float3 o, d; float a, b, bt; uint sr, bp; uint tag = fetch(i, o, d, a, b, sr, bt, bp); HitInfo h; h.t = b; h.prim = 0xFFFFFFFFu; h.u = h.v = 0.f; commit(tag, h); }
     }
     bool active = false;
     float3 o = make_float3(0.f), d = make_float3(0.f);
@@ -90,6 +102,8 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     // `pend` a postponed leaf; the postponed leaf is tested while the next inner node is already being intersected. The result does
     // not depend on the visiting order (min t, ties to the lower primitive id).
     uint cur = BVH_EMPTY, pend = BVH_EMPTY, sp = 0, tag = 0;
+    uint rayIters = 0;                                        // (counters build) iterations spent on the current ray
+    float taskT0 = 0.f; uint taskPrim0 = 0xFFFFFFFFu;         // (TASKS) the ray's best hit when the task was fetched
     uint pend1 = BVH_EMPTY, pend2 = BVH_EMPTY;          // younger postponed leaves (T8_LEAF_QUEUE > 1): pend is tested first
 
     // LDS for the top BVH8_STACK entries, global memory behind them. The tail store is non-temporal on purpose: it keeps the compiler from
@@ -102,6 +116,8 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
         }
     };
 
+    bool splitNow = false;
+  for (;;) {
     while (true) {
         unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
         if (COUNT) tc0 = __builtin_readcyclecounter();
@@ -118,35 +134,49 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 chunkPos = chunk * T8_CHUNK; chunkEnd = (chunkPos + T8_CHUNK < count) ? chunkPos + T8_CHUNK : count;
                 if (chunkPos >= count) { chunkPos = chunkEnd = count; }
                 if (chunkPos + lane < chunkEnd) {
-                    float3 ro, rd; float rtmin, rtmax;
-                    uint rtag = fetch(chunkPos + lane, ro, rd, rtmin, rtmax);
-                    uint* slot = rayBuf + lane * T8_RAY_STRIDE;
+                    float3 ro, rd; float rtmin, rtmax, rbestT; uint rstart, rbestPrim;
+                    uint rtag = fetch(chunkPos + lane, ro, rd, rtmin, rtmax, rstart, rbestT, rbestPrim);
+                    uint* slot = rayBuf + lane * RAY_STRIDE;
                     slot[0] = __float_as_uint(ro.x); slot[1] = __float_as_uint(ro.y); slot[2] = __float_as_uint(ro.z);
                     slot[3] = __float_as_uint(rd.x); slot[4] = __float_as_uint(rd.y); slot[5] = __float_as_uint(rd.z);
-                    slot[6] = rtag; slot[7] = __float_as_uint(rtmin); slot[8] = __float_as_uint(rtmax);
+                    slot[6] = rtag; slot[7] = __float_as_uint(TASKS ? rtmax : rtmin); slot[8] = TASKS ? __float_as_uint(rbestT) : __float_as_uint(rtmax);
+                    if (TASKS) { slot[9] = rbestPrim; slot[10] = rstart; }      // (tasks: tmin is 0)
                 }
             }
             uint avail = chunkEnd - chunkPos;
-            if (avail == 0u) { if (need) exhausted = true; }
+            if (avail == 0u) { if (need) exhausted = true; waveDry = true; }
             else {
                 uint rank = (uint)__popcll(needMask & ((1ull << gl) - 1ull));        // rank of my quad among the needing quads
                 uint n = (uint)__popcll(needMask);
                 if (need && rank < avail) {
-                    const uint* slot = rayBuf + (((chunkPos & (T8_CHUNK - 1u)) + rank) * T8_RAY_STRIDE);
+                    const uint* slot = rayBuf + (((chunkPos & (T8_CHUNK - 1u)) + rank) * RAY_STRIDE);
                     o = make_float3(__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]));
                     d = make_float3(__uint_as_float(slot[3]), __uint_as_float(slot[4]), __uint_as_float(slot[5]));
                     tag = slot[6];
-                    if (!FIXED_RANGE) { tmin = __uint_as_float(slot[7]); tmax = __uint_as_float(slot[8]); }      // FIXED_RANGE: [0, kMaxRayTravel] stays a compile-time constant (2 VGPRs)
                     ix = t8_rcp_dir(d.x); iy = t8_rcp_dir(d.y); iz = t8_rcp_dir(d.z);
-                    bestT = tmax; bestPrim = 0xFFFFFFFFu; minePrim = 0xFFFFFFFFu;
-                    cur = 0u; pend = BVH_EMPTY; pend1 = BVH_EMPTY; pend2 = BVH_EMPTY; sp = 0u; active = true;
+                    if (TASKS) {
+                        if (!FIXED_RANGE) tmax = __uint_as_float(slot[7]);
+                        bestT = taskT0 = __uint_as_float(slot[8]); bestPrim = taskPrim0 = slot[9]; cur = slot[10];
+                    } else {
+                        if (!FIXED_RANGE) { tmin = __uint_as_float(slot[7]); tmax = __uint_as_float(slot[8]); }      // FIXED_RANGE: [0, kMaxRayTravel] stays a compile-time constant (2 VGPRs)
+                        bestT = tmax; bestPrim = 0xFFFFFFFFu; cur = 0u;
+                    }
+                    minePrim = 0xFFFFFFFFu; rayIters = 0u;
+                    pend = BVH_EMPTY; pend1 = BVH_EMPTY; pend2 = BVH_EMPTY; sp = 0u; active = true;
                 }
                 chunkPos = (uint)__builtin_amdgcn_readfirstlane((int)(chunkPos + ((n < avail) ? n : avail)));
             }
         }
         if (t8_ballot(active) == 0ull) { if (t8_ballot(!exhausted) == 0ull) break; else continue; }
 
+        // ---- straggler splitting (after the loop, see below): out of fresh work for T8_TAIL_ITERS iterations -> stop and hand over what is in flight
+        if (CAN_SPLIT) {
+            if (waveDry) tailIters++;
+            if (tailIters > (uint)T8_TAIL_ITERS) { splitNow = true; break; }
+        }
+
         if (COUNT && lane == 0u) ctr.iters++;
+        if (COUNT && active) rayIters++;
         if (COUNT) tc1 = __builtin_readcyclecounter();
         const bool inner = active && !(cur & BVH_LEAF_BIT);
         // The leaf block is run when T8_LEAF_BATCH quads have a leaf waiting, or when some quad cannot advance without it (its node
@@ -245,7 +275,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                     if (q == (uint)__ffs((int)candBits) - 1u) { HitInfo h; h.t = lt; h.prim = lp; h.u = h.v = 0.f; commit(tag, h); }      // (occlusion queries carry no barycentrics)
                     active = false;
                 } else {
-                    if (cand) { minePrim = lp; mineUV[threadIdx.x] = make_float2(lu, lv); }      // beats the quad's best, hence this lane's earlier find too
+                    if (cand && !TASKS) { minePrim = lp; mineUV[threadIdx.x] = make_float2(lu, lv); }      // beats the quad's best, hence this lane's earlier find too
                     // lexicographic min of (t, prim) over the quad: 2 butterfly steps, branch-free
                     float tk = lt; uint pk = lp;
                     {   float ot = dpp_f<DPP_QP_XOR1>(tk); uint op = dpp_u<DPP_QP_XOR1>(pk);
@@ -279,7 +309,15 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                     if (ANYHIT || __uint_as_float(e.y) <= bestT) { cur = e.x; break; }
                 }
                 if (cur == BVH_EMPTY && pend == BVH_EMPTY) {          // nothing left: report
-                    if (ANYHIT) { if (q == 0u) { HitInfo h; h.t = tmax; h.prim = 0xFFFFFFFFu; h.u = h.v = 0.f; commit(tag, h); } }
+                    if (COUNT && q == 0u && ctr.rayIterHist) {
+                        if (rayIters > 2048u) { uint k = atomicAdd(ctr.longRayCount, 1u); if (k < 32u) { float* r = ctr.longRays + 8u * k; r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = (float)rayIters; r[7] = __uint_as_float(tag); } }
+                        uint bin = 31u - (uint)__clz((int)(rayIters | 1u)); atomicAdd(&ctr.rayIterHist[bin < 15u ? bin : 15u], 1ull);
+                    }
+                    if (TASKS) {                                     // a sub-tree reports only an improvement over what the ray already had
+                        if (ANYHIT) { /* visible sub-tree: nothing to report */ }
+                        else if (q == 0u && (bestPrim != taskPrim0 || bestT != taskT0)) { HitInfo h; h.t = bestT; h.prim = bestPrim; h.u = h.v = 0.f; commit(tag, h); }
+                    }
+                    else if (ANYHIT) { if (q == 0u) { HitInfo h; h.t = tmax; h.prim = 0xFFFFFFFFu; h.u = h.v = 0.f; commit(tag, h); } }
                     else if (bestPrim == 0xFFFFFFFFu) { if (q == 0u) { HitInfo h; h.t = bestT; h.prim = 0xFFFFFFFFu; h.u = h.v = 0.f; commit(tag, h); } }
                     else if (minePrim == bestPrim) { float2 uv = mineUV[threadIdx.x]; HitInfo h; h.t = bestT; h.prim = bestPrim; h.u = uv.x; h.v = uv.y; commit(tag, h); }
                     active = false;
@@ -288,6 +326,38 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
         }
         if (COUNT) { unsigned long long tc4 = __builtin_readcyclecounter(); ctr.cyc[0] += tc1 - tc0; ctr.cyc[1] += tc2 - tc1; ctr.cyc[2] += tc3 - tc2; ctr.cyc[3] += tc4 - tc3; }
     }
+    if (!CAN_SPLIT || !splitNow) break;
+    // ---- every ray still in flight becomes a list of sub-tree tasks: node slot, postponed leaves, stack entries (outside the loop: the loop
+    //      body's temporaries are dead here, so this rare path does not cost the hot kernel registers)
+    {
+        const uint nSlots = (cur != BVH_EMPTY ? 1u : 0u) + (pend != BVH_EMPTY ? 1u : 0u) + (pend1 != BVH_EMPTY ? 1u : 0u) + (pend2 != BVH_EMPTY ? 1u : 0u);
+        const uint n = active ? nSlots + sp : 0u;
+        uint base = 0u;
+        if (q == 0u && n) base = atomicAdd(taskOut.count, n);
+        base = dpp_u<0x00>(base);                                   // quad_perm [0,0,0,0]: lane 0 of the quad
+        const bool fits = n && (base + n <= taskOut.capacity);
+        if (active && !fits && q == 0u) atomicOr(overflowFlag, 2u);      // a full task queue is reported as an error by pt_render (raise TASK_QUEUE_CAPACITY)
+        if (active && fits) {
+            uint* tq = reinterpret_cast<uint*>(taskOut.tasks);      // scalar dword stores: no 4-register TravTask temporary
+            if (q == 0u) {
+                uint k = base;
+                if (cur != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = cur; tq[4u * k + 2u] = 0u; k++; }
+                if (pend != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = pend; tq[4u * k + 2u] = 0u; k++; }
+                if (pend1 != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = pend1; tq[4u * k + 2u] = 0u; k++; }
+                if (pend2 != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = pend2; tq[4u * k + 2u] = 0u; k++; }
+                publish(tag, bestT, bestPrim);
+            }
+            for (uint i = q; i < sp; i += T8_LANES) {
+                uint2 e;
+                if (i < BVH8_STACK) e = stack[i];
+                else { unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (i - BVH8_STACK)))); e = make_uint2((uint)w, (uint)(w >> 32)); }
+                const uint k = base + nSlots + i;
+                tq[4u * k] = tag; tq[4u * k + 1u] = e.x; tq[4u * k + 2u] = e.y;
+            }
+        }
+        break;
+    }
+  }
 }
 
 } // namespace ptk

@@ -20,14 +20,19 @@ struct PathPool { uint4* s0; uint4* s1; uint4* s2; uint4* s3; uint4* s4; uint4* 
 struct ShadowQueue { float4* q0; float4* q1; float4* q2; };
 struct WaveCounters {           // device-resident counters / stats (one 256 B block)
     uint extendCount[2]; uint shadowCount; uint overflow;
-    unsigned long long hits, nodeVisitsExt, triTestsExt, nodeVisitsSh, triTestsSh, leafVisitsExt, itersExt, leafVisitsSh, itersSh, phaseCycExt[4], leafBlocksExt, eventsExt[8];
+    unsigned long long hits, nodeVisitsExt, triTestsExt, nodeVisitsSh, triTestsSh, leafVisitsExt, itersExt, leafVisitsSh, itersSh, phaseCycExt[4], leafBlocksExt, eventsExt[8], itersMaxExt, rayIterHistExt[16]; uint longRayCount, _padLong; float longRays[32][8];
 };
 
+// straggler splitting (pt_traverse8.h): per pipelined batch, two task queues (ping-pong), the per-ray merge keys and the list of rays to resolve.
+// counts = {taskCount[0], taskCount[1], resolveCount}. bestKey: closest hit = float bits of t << 32 | primitive (atomicMin = min t, ties to the
+// lower primitive id); occlusion = 0 visible so far / 1 occluded.
+struct TravAux { TravTask* taskQ[2]; uint* counts; uint taskCap; unsigned long long* bestKey; uint* resolveList; const uint* primToSlot; };
+
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st);
-void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st);
+void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr,
                   ShadowQueue sq, WaveCounters* wc, hipStream_t st);
-void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st);
+void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st);
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st);
 void launch_pack(const float4* accum, const uint* ownedPixels, uint numOwned, uint width, float4* dst, hipStream_t st);

@@ -53,8 +53,14 @@ __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool 
     queue[i] = i;
 }
 
+__device__ __forceinline__ void t8_counters_init(Traverse8Counters& ctr) {
+    ctr.nodeVisits = 0; ctr.triTests = 0; ctr.leafVisits = 0; ctr.iters = 0; ctr.leafBlocks = 0; for (int q = 0; q < 8; q++) ctr.ev[q] = 0u; ctr.cyc[0] = ctr.cyc[1] = ctr.cyc[2] = ctr.cyc[3] = 0ull;
+    ctr.rayIterHist = nullptr; ctr.longRayCount = nullptr; ctr.longRays = nullptr;
+}
+__device__ __forceinline__ unsigned long long t8_hit_key(float t, uint prim) { return ((unsigned long long)__float_as_uint(t) << 32) | prim; }      // t > 0: bits order like the value
+
 template <bool COUNT>
-__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc) {
+__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
     __shared__ float2 mineUV[T8_BLOCK];
@@ -62,19 +68,69 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
     __shared__ uint dummyLds[T8_EXPERIMENT_DUMMY_LDS]; dummyLds[threadIdx.x] = threadIdx.x; if (*countPtr == 0xFFFFFFFFu) wc->overflow = dummyLds[threadIdx.x ^ 1];
 #endif
     const uint count = *countPtr;
-    Traverse8Counters ctr; ctr.nodeVisits = 0; ctr.triTests = 0; ctr.leafVisits = 0; ctr.iters = 0; ctr.leafBlocks = 0; for (int q = 0; q < 8; q++) ctr.ev[q] = 0u; ctr.cyc[0] = ctr.cyc[1] = ctr.cyc[2] = ctr.cyc[3] = 0ull;
-    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax) -> uint {
+    Traverse8Counters ctr; t8_counters_init(ctr);
+    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
         uint p = queue[i];
         uint4 a = pool.s0[p], b = pool.s1[p];
         o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)); d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
-        tmin = 0.0f; tmax = kMaxRayTravel;
+        tmin = 0.0f; tmax = kMaxRayTravel; startRef = 0u; bestT0 = kMaxRayTravel; bestPrim0 = 0xFFFFFFFFu;
         return p;
     };
     auto commit = [&](uint p, const HitInfo& h) { pool.hit[p] = make_uint4(asuint(h.t), h.prim, asuint(h.u), asuint(h.v)); };
-    traverse8_persistent<false, COUNT, true>(sc, count, stack, rayBuf, mineUV, fetch, commit, ctr, &wc->overflow);
-    if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); wave_add64(ctr.leafVisits, &wc->leafVisitsExt); wave_add64(ctr.iters, &wc->itersExt); wave_add64(ctr.leafBlocks, &wc->leafBlocksExt);
+    // a split ray: its best hit so far seeds the merge key, the resolve pass will write pool.hit (k_resolve_extend)
+    auto publish = [&](uint p, float bestT, uint bestPrim) { aux.bestKey[p] = t8_hit_key(bestT, bestPrim); aux.resolveList[atomicAdd(&aux.counts[2], 1u)] = p; };
+    if (COUNT) { ctr.rayIterHist = wc->rayIterHistExt; ctr.longRayCount = &wc->longRayCount; ctr.longRays = &wc->longRays[0][0]; }
+    traverse8_persistent<false, COUNT, true, false, true>(sc, count, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); wave_add64(ctr.leafVisits, &wc->leafVisitsExt); wave_add64(ctr.iters, &wc->itersExt); wave_add64(ctr.leafBlocks, &wc->leafBlocksExt); if ((threadIdx.x & 63u) == 0u) atomicMax(&wc->itersMaxExt, (unsigned long long)ctr.iters);
                  if ((threadIdx.x & 63u) == 0u) for (int q = 0; q < 4; q++) atomicAdd(&wc->phaseCycExt[q], ctr.cyc[q]);
                  for (int q = 0; q < 8; q++) wave_add64(ctr.ev[q], &wc->eventsExt[q]); }
+}
+
+// sub-trees of split extend rays: reads queue IN; unless FINAL, stragglers among the sub-trees are split again into the other queue.
+// Task i of the launch is queue entry (i % 64) * ceil(count / 64) + i / 64: the sub-trees of one ray sit next to each other in the queue and
+// would otherwise land in one 64-item chunk, i.e. on one wave.
+template <int IN, bool FINAL>
+__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks(DeviceScene sc, PathPool pool, WaveCounters* wc, TravAux aux) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
+    __shared__ uint rayBuf[T8_TASKBUF_WORDS];
+    uint count = aux.counts[IN]; if (count > aux.taskCap) count = aux.taskCap;
+    if (count == 0u) return;
+    const TravTask* tasks = aux.taskQ[IN];
+    const uint per = (count + 63u) / 64u;
+    Traverse8Counters ctr; t8_counters_init(ctr);
+    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
+        const uint j = (i & 63u) * per + (i >> 6);
+        TravTask t = tasks[j < count ? j : 0u];
+        if (j >= count) t.tbits = 0x7F800000u;                                        // padding of the transposed index space: an empty task
+        uint4 a = pool.s0[t.tag], b = pool.s1[t.tag];
+        o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)); d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
+        unsigned long long key = aux.bestKey[t.tag];
+        tmin = 0.0f; tmax = kMaxRayTravel; bestT0 = __uint_as_float((uint)(key >> 32)); bestPrim0 = (uint)key;
+        startRef = (__uint_as_float(t.tbits) <= bestT0) ? t.ref : BVH_EMPTY;            // a sub-tree behind the current best hit is dropped here
+        return t.tag;
+    };
+    auto commit = [&](uint p, const HitInfo& h) { atomicMin(&aux.bestKey[p], t8_hit_key(h.t, h.prim)); };
+    auto publish = [&](uint p, float bestT, uint bestPrim) { if (bestPrim != 0xFFFFFFFFu) atomicMin(&aux.bestKey[p], t8_hit_key(bestT, bestPrim)); };
+    traverse8_persistent<false, false, true, true, !FINAL>(sc, per * 64u, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[IN ^ 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+}
+
+// split extend rays: the merged key -> hit record; the barycentrics come from re-intersecting the winning triangle (same arithmetic, same operands)
+__global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool pool, TravAux aux) {
+    const uint n = aux.counts[2];
+    for (uint i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        uint p = aux.resolveList[i];
+        unsigned long long key = aux.bestKey[p];
+        uint prim = (uint)key;
+        uint4 out = make_uint4((uint)(key >> 32), prim, 0u, 0u);
+        if (prim != 0xFFFFFFFFu) {
+            uint4 a = pool.s0[p], b = pool.s1[p];
+            float3 o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)), d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
+            float t, u = 0.f, v = 0.f;
+            (void)intersect_tri(sc.tris[aux.primToSlot[prim]], o, d, 0.0f, kMaxRayTravel, t, u, v);
+            out.z = asuint(u); out.w = asuint(v);
+        }
+        pool.hit[p] = out;
+    }
 }
 
 #ifndef PT_SHADE_MIN_BLOCKS
@@ -108,36 +164,67 @@ __global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PathKernelCo
     wave_add64(isHit ? 1ull : 0ull, &wc->hits);
 }
 
+__device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, uint i) {           // visible == the deferred NEE contribution lands (BridgeDonut:1026)
+    float4 r = sq.q2[i];
+    uint p = asuint(sq.q1[i].w);
+    uint4 c = pool.s2[p];
+    uint pack45[2] = {c.z, c.w};
+    PathKernelContext::ResolveShadow(pack45, make_float3(r.x, r.y, r.z));
+    c.z = pack45[0]; c.w = pack45[1];
+    pool.s2[p] = c;
+}
+
 template <bool COUNT>
-__global__ void __launch_bounds__(T8_BLOCK) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc) {
+__global__ void __launch_bounds__(T8_BLOCK) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
-    __shared__ float2 mineUV[T8_BLOCK];
 #ifdef T8_EXPERIMENT_DUMMY_LDS
     __shared__ uint dummyLds[T8_EXPERIMENT_DUMMY_LDS]; dummyLds[threadIdx.x] = threadIdx.x; if (*countPtr == 0xFFFFFFFFu) wc->overflow = dummyLds[threadIdx.x ^ 1];
 #endif
     const uint count = *countPtr;
-    Traverse8Counters ctr; ctr.nodeVisits = 0; ctr.triTests = 0; ctr.leafVisits = 0; ctr.iters = 0; ctr.leafBlocks = 0; for (int q = 0; q < 8; q++) ctr.ev[q] = 0u; ctr.cyc[0] = ctr.cyc[1] = ctr.cyc[2] = ctr.cyc[3] = 0ull;
-    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax) -> uint {
+    Traverse8Counters ctr; t8_counters_init(ctr);
+    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
         float4 a = sq.q0[i], b = sq.q1[i];
-        o = make_float3(a.x, a.y, a.z); d = make_float3(b.x, b.y, b.z); tmin = 0.0f; tmax = a.w;
+        o = make_float3(a.x, a.y, a.z); d = make_float3(b.x, b.y, b.z); tmin = 0.0f; tmax = a.w; startRef = 0u; bestT0 = a.w; bestPrim0 = 0xFFFFFFFFu;
         return i;
     };
-    auto commit = [&](uint i, const HitInfo& h) {
-        if (h.prim != 0xFFFFFFFFu) return;                 // occluded; visible == nothing committed (BridgeDonut:1026)
-        float4 r = sq.q2[i];
-        uint p = asuint(sq.q1[i].w);
-        uint4 c = pool.s2[p];
-        uint pack45[2] = {c.z, c.w};
-        PathKernelContext::ResolveShadow(pack45, make_float3(r.x, r.y, r.z));
-        c.z = pack45[0]; c.w = pack45[1];
-        pool.s2[p] = c;
-    };
-    traverse8_persistent<true, COUNT, false>(sc, count, stack, rayBuf, mineUV, fetch, commit, ctr, &wc->overflow);
+    auto commit = [&](uint i, const HitInfo& h) { if (h.prim == 0xFFFFFFFFu) shadow_visible(pool, sq, i); };      // occluded: nothing is committed
+    // a split shadow ray: "visible so far"; its sub-trees may set the flag, k_resolve_shadow applies the contribution if none did
+    auto publish = [&](uint i, float, uint) { aux.bestKey[i] = 0ull; aux.resolveList[atomicAdd(&aux.counts[2], 1u)] = i; };
+    traverse8_persistent<true, COUNT, false, false, true>(sc, count, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsSh); wave_add64(ctr.triTests, &wc->triTestsSh); wave_add64(ctr.leafVisits, &wc->leafVisitsSh); wave_add64(ctr.iters, &wc->itersSh); }
 }
 
-// CommitPixel + AccumulationPass (PathTracer.hlsli:165-169, AccumulationPass.hlsl:36-66): samples folded in order with weight 1/(n+1)
+template <int IN, bool FINAL>
+__global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, ShadowQueue sq, WaveCounters* wc, TravAux aux) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
+    __shared__ uint rayBuf[T8_TASKBUF_WORDS];
+    uint count = aux.counts[IN]; if (count > aux.taskCap) count = aux.taskCap;
+    if (count == 0u) return;
+    const TravTask* tasks = aux.taskQ[IN];
+    const uint per = (count + 63u) / 64u;
+    Traverse8Counters ctr; t8_counters_init(ctr);
+    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
+        const uint j = (i & 63u) * per + (i >> 6);
+        TravTask t = tasks[j < count ? j : 0u];
+        float4 a = sq.q0[t.tag], b = sq.q1[t.tag];
+        o = make_float3(a.x, a.y, a.z); d = make_float3(b.x, b.y, b.z); tmin = 0.0f; tmax = a.w; bestT0 = a.w; bestPrim0 = 0xFFFFFFFFu;
+        startRef = (j < count && aux.bestKey[t.tag] == 0ull) ? t.ref : BVH_EMPTY;        // padding, or another sub-tree already found an occluder
+        return t.tag;
+    };
+    auto commit = [&](uint i, const HitInfo& h) { if (h.prim != 0xFFFFFFFFu) aux.bestKey[i] = 1ull; };
+    auto publish = [&](uint, float, uint) {};
+    traverse8_persistent<true, false, false, true, !FINAL>(sc, per * 64u, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[IN ^ 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+}
+
+__global__ void __launch_bounds__(256) k_resolve_shadow(PathPool pool, ShadowQueue sq, TravAux aux) {
+    const uint n = aux.counts[2];
+    for (uint k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        uint i = aux.resolveList[k];
+        if (aux.bestKey[i] == 0ull) shadow_visible(pool, sq, i);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_accumulate(PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint spp, float4* __restrict__ accum, uint accumCountBase, uint width) {
     uint kpx = blockIdx.x * 256u + threadIdx.x;
     if (kpx >= numOwned) return;
@@ -158,18 +245,19 @@ __global__ void __launch_bounds__(T8_BLOCK) k_trace_probe(DeviceScene sc, const 
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
     __shared__ float2 mineUV[T8_BLOCK];
-    Traverse8Counters ctr; ctr.nodeVisits = 0; ctr.triTests = 0; ctr.leafVisits = 0; ctr.iters = 0; ctr.leafBlocks = 0; for (int q = 0; q < 8; q++) ctr.ev[q] = 0u; ctr.cyc[0] = ctr.cyc[1] = ctr.cyc[2] = ctr.cyc[3] = 0ull;
-    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax) -> uint {
+    Traverse8Counters ctr; t8_counters_init(ctr);
+    auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
         float4 a = rays[2 * i], b = rays[2 * i + 1];
-        o = make_float3(a.x, a.y, a.z); d = make_float3(b.x, b.y, b.z); tmin = a.w; tmax = b.w;
+        o = make_float3(a.x, a.y, a.z); d = make_float3(b.x, b.y, b.z); tmin = a.w; tmax = b.w; startRef = 0u; bestT0 = b.w; bestPrim0 = 0xFFFFFFFFu;
         return i;
     };
+    auto publish = [&](uint, float, uint) {};
     if (outClosest) {
         auto commit = [&](uint i, const HitInfo& h) { outClosest[i] = make_float4(h.t, asfloat(h.prim), h.u, h.v); };
-        traverse8_persistent<false, false, false>(sc, n, stack, rayBuf, mineUV, fetch, commit, ctr, overflow);
+        traverse8_persistent<false, false, false, false, false>(sc, n, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
     } else {
         auto commit = [&](uint i, const HitInfo& h) { outVisible[i] = (h.prim == 0xFFFFFFFFu) ? 1u : 0u; };
-        traverse8_persistent<true, false, false>(sc, n, stack, rayBuf, mineUV, fetch, commit, ctr, overflow);
+        traverse8_persistent<true, false, false, false, false>(sc, n, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
     }
 }
 
@@ -288,18 +376,32 @@ void launch_generate(const PathKernelContext& k, PathPool pool, const uint* owne
     uint total = numOwned * spp;
     hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, st, k, pool, ownedPixels, numOwned, sampleFirst, spp, queue);
 }
-void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st) {
+// task rounds + resolve pass of one traversal launch; all counts live on the device, so the grids are fixed (empty rounds return at once)
+static const uint T8_TASK_BLOCKS = 256 * 6, T8_RESOLVE_BLOCKS = 256;
+void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
     uint g = grid_for(count, T8_BLOCK, T8_MAX_BLOCKS);
-    if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc);
-    else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc);
+    (void)hipMemsetAsync(aux.counts, 0, 12, st);
+    if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux);
+    else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux);
+    hipLaunchKernelGGL((k_extend_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 0 -> 1
+    (void)hipMemsetAsync(aux.counts, 0, 4, st);
+    hipLaunchKernelGGL((k_extend_tasks<1, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 1 -> 0
+    hipLaunchKernelGGL((k_extend_tasks<0, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);       // queue 0, to the end
+    hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
 }
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, hipStream_t st) {
     hipLaunchKernelGGL(k_shade, dim3((countIn + 255) / 256), dim3(256), 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
 }
-void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, hipStream_t st) {
+void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
     uint g = grid_for(count, T8_BLOCK, T8_MAX_BLOCKS);
-    if (counters) hipLaunchKernelGGL((k_shadow<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc);
-    else hipLaunchKernelGGL((k_shadow<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc);
+    (void)hipMemsetAsync(aux.counts, 0, 12, st);
+    if (counters) hipLaunchKernelGGL((k_shadow<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);
+    else hipLaunchKernelGGL((k_shadow<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);
+    hipLaunchKernelGGL((k_shadow_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    (void)hipMemsetAsync(aux.counts, 0, 4, st);
+    hipLaunchKernelGGL((k_shadow_tasks<1, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    hipLaunchKernelGGL((k_shadow_tasks<0, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    hipLaunchKernelGGL(k_resolve_shadow, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
 }
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3((numOwned + 255) / 256), dim3(256), 0, st, pool, ownedPixels, numOwned, spp, accum, accumCountBase, width);

@@ -1,0 +1,26 @@
+"""developer probe: per-rank frame time of an N-way tile-sharded C3 frame (what each GPU does in the multi-GPU bench): max and mean over ranks."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rtxpt_amd as pt
+from rtxpt_amd import scenes
+W, H, SPP = 3840, 2160, 4
+sc, cam = scenes.bistro_like(scale=1.0, tex_size=1024)
+camd = scenes.bridge_camera(W, H, **cam)
+worlds = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]
+base = None
+for world in worlds:
+    times, rays = [], []
+    for rank in range(world):
+        g = pt.PathTracer(device=0, shard_rank=rank, shard_count=world)
+        g.set_scene(sc); g.set_camera(camd); g.set_settings(scenes.default_settings()); g.resize(W, H)
+        g.reset_accumulation(); g.render(0, SPP)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            g.reset_accumulation(); st = g.render(0, SPP)
+        torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / 2); rays.append(st["extendRays"] + st["shadowRays"])
+        del g
+    print("   per rank ms:", " ".join("%.1f" % (t * 1e3) for t in times)); print("   per rank Mrays:", " ".join("%.1f" % (r / 1e6) for r in rays))
+    base = base or max(times)
+    print("world %d: frame time per rank max %.1f mean %.1f min %.1f ms; rays per rank max %.1fM min %.1fM; speed-up vs 1 GPU %.2f (efficiency %.2f)" % (
+        world, max(times) * 1e3, sum(times) / world * 1e3, min(times) * 1e3, max(rays) / 1e6, min(rays) / 1e6, base / max(times), base / max(times) / world))
