@@ -51,7 +51,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 21;      // sub-tree tasks per que
 #endif
 #ifndef PT_PIPELINE_BATCHES
 #ifndef PT_PIPELINE_FULL_AT
-#define PT_PIPELINE_FULL_AT (1u << 23)
+#define PT_PIPELINE_FULL_AT (1u << 21)      // paths per pt_render call from which all PT_PIPELINE_BATCHES are used (one rank of an 8-way sharded 4K frame has 4.1 M)
 #endif
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3: 1: 241 ms, 2: 218, 3: 205, 4: 199, 5: 210, 6: 230)
 #endif
@@ -623,7 +623,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         size_t mark() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
-    const uint numBatches = (c->serialKernels || total < (1u << 21)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? 2u : PT_PIPELINE_BATCHES);
+    const uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? 2u : PT_PIPELINE_BATCHES);
     Batch B[PT_PIPELINE_BATCHES];
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];

@@ -30,7 +30,7 @@ static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 #define T8_EXTEND_MIN_BLOCKS 5    // 256-thread blocks per CU the register allocator must leave room for in k_extend (= waves per SIMD)
 #endif
 #ifndef T8_TAIL_ITERS
-#define T8_TAIL_ITERS 64         // loop iterations a wave keeps going after its last chunk before it splits what is still in flight into tasks
+#define T8_TAIL_ITERS 32         // loop iterations a wave keeps going after its last chunk before it splits what is still in flight into tasks
 #endif
 #ifndef T8_LEAF_QUEUE
 #define T8_LEAF_QUEUE 2         // postponed leaves a ray may hold (1..3) before it has to wait for the wave's next leaf block (A/B: within noise on extend, -4 % on shadow)
