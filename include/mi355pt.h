@@ -121,7 +121,7 @@ typedef struct PtFrameStats {
     uint64_t extendPhaseCycles[4];          /* s_memtime cycles summed over waves: refill, inner block, leaf block, slot bookkeeping */
     uint64_t leafBlocksExtend;              /* iterations in which the wave executed the leaf block */
     uint64_t waveItersMaxExtend;            /* longest traversal loop of any single wave in any extend launch (tail indicator) */
-    uint64_t extendRayIterHist[16];         /* extend rays by traversal iterations: bin k counts rays with 2^k <= iterations < 2^(k+1) (counters build) */
+    uint64_t extendRayIterHist[16];         /* extend rays (or their sub-tree tasks) that needed >= 128 loop iterations: bin k (7..15) counts 2^k <= iterations < 2^(k+1) (counters build) */
     uint32_t longRayCount, _padLong;        /* (counters build) sample of extend rays that needed more than 2048 iterations: origin, dir, iterations, tag */
     float    longRays[32][8];
     uint64_t extendEvents[8];               /* wave-level block executions: refill, chunk load, inner, leaf, alpha test, hit reduction, pop loop, pop trips */

@@ -311,7 +311,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 if (cur == BVH_EMPTY && pend == BVH_EMPTY) {          // nothing left: report
                     if (COUNT && q == 0u && ctr.rayIterHist) {
                         if (rayIters > 2048u) { uint k = atomicAdd(ctr.longRayCount, 1u); if (k < 32u) { float* r = ctr.longRays + 8u * k; r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = (float)rayIters; r[7] = __uint_as_float(tag); } }
-                        uint bin = 31u - (uint)__clz((int)(rayIters | 1u)); atomicAdd(&ctr.rayIterHist[bin < 15u ? bin : 15u], 1ull);
+                        if (rayIters >= 128u) { uint bin = 31u - (uint)__clz((int)rayIters); atomicAdd(&ctr.rayIterHist[bin < 15u ? bin : 15u], 1ull); }      // only the tail is histogrammed (bins 7..15): 10^8 atomics on 16 words would dominate the counters step
                     }
                     if (TASKS) {                                     // a sub-tree reports only an improvement over what the ray already had
                         if (ANYHIT) { /* visible sub-tree: nothing to report */ }
