@@ -386,7 +386,9 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
     hipLaunchKernelGGL((k_extend_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 0 -> 1
     (void)hipMemsetAsync(aux.counts, 0, 4, st);
     hipLaunchKernelGGL((k_extend_tasks<1, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 1 -> 0
-    hipLaunchKernelGGL((k_extend_tasks<0, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);       // queue 0, to the end
+    (void)hipMemsetAsync(aux.counts + 1, 0, 4, st);
+    hipLaunchKernelGGL((k_extend_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 0 -> 1
+    hipLaunchKernelGGL((k_extend_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);       // queue 1, to the end
     hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
 }
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, hipStream_t st) {
@@ -400,7 +402,9 @@ void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const u
     hipLaunchKernelGGL((k_shadow_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     (void)hipMemsetAsync(aux.counts, 0, 4, st);
     hipLaunchKernelGGL((k_shadow_tasks<1, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
-    hipLaunchKernelGGL((k_shadow_tasks<0, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    (void)hipMemsetAsync(aux.counts + 1, 0, 4, st);
+    hipLaunchKernelGGL((k_shadow_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    hipLaunchKernelGGL((k_shadow_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     hipLaunchKernelGGL(k_resolve_shadow, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
 }
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
