@@ -54,7 +54,7 @@ static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
 struct BvhNode { float3 lmin, lmax, rmin, rmax; uint left, right, _pad0, _pad1; };           // child ref: bit31 = leaf (first<<3 | count-1)
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 #ifndef PT_BVH_MAX_LEAF
-#define PT_BVH_MAX_LEAF 8
+#define PT_BVH_MAX_LEAF 4
 #endif
 static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_LEAF = PT_BVH_MAX_LEAF, BVH_STACK = 64;
 // BVH8 node, 128 B = one cache line: the 8 lanes of a ray's lane group each fetch one 12 B child slot plus the shared 16 B header, so a
