@@ -45,17 +45,17 @@ template <typename T> struct DevBuf {
 struct HostTexture { uint w, h, mipLevels; std::vector<std::vector<ptk::float4>> mips; };
 
 static const uint TILE = 32;
-static const uint TASK_QUEUE_CAPACITY = 1u << 21;      // sub-tree tasks per queue (2 queues per pipelined batch, 16 B each); a full queue only disables further splitting
+static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per queue (2 queues per pipelined batch, 16 B each)
 #ifndef PT_SHARD_TILE_GROUP
 #define PT_SHARD_TILE_GROUP 1      // consecutive Morton-ordered 32x32 tiles dealt to the same rank (locality vs load balance)
 #endif
-#ifndef PT_PIPELINE_BATCHES
 #ifndef PT_PIPELINE_FULL_AT
 #define PT_PIPELINE_FULL_AT (1u << 21)      // paths per pt_render call from which all PT_PIPELINE_BATCHES are used (one rank of an 8-way sharded 4K frame has 4.1 M)
 #endif
-#define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3: 1: 241 ms, 2: 218, 3: 205, 4: 199, 5: 210, 6: 230)
+#ifndef PT_PIPELINE_BATCHES
+#define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
 #endif
-
+// a full task queue is reported as an error (pt_render), it does not silently disable splitting
 } // namespace
 
 struct pt_context {
