@@ -1,7 +1,7 @@
 // mi355pt — cooperative BVH8 traversal for wave64: a wave carries 16 rays, each owned by a QUAD of lanes; lane q of a quad tests
 // children 2q and 2q+1 of the current 128-byte node (one cache-line lookup per node per ray), the hit children are ranked by entry
 // distance with quad-permute DPP compares, the nearest is followed directly and the rest go to the quad's stack in LDS (deep entries
-// spill to a global-memory tail). Leaves hand their (up to 8) triangles to the 4 lanes in two rounds. Quads refill independently from
+// spill to a global-memory tail). Leaves hand their triangles (up to 4 by default: one round; up to 8: two) to the 4 lanes. Quads refill independently from
 // the wave's 64-ray chunk (persistent threads), so a long ray never holds 63 idle lanes hostage. Replaces RayQuery::TraceRayInline /
 // the DXR any-hit visibility query (PathTracerBridgeDonut.hlsli:993-1055). Results are traversal-order free (min t, ties to the lower
 // primitive id).
