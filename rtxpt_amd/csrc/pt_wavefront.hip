@@ -64,9 +64,6 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
     __shared__ float2 mineUV[T8_BLOCK];
-#ifdef T8_EXPERIMENT_DUMMY_LDS
-    __shared__ uint dummyLds[T8_EXPERIMENT_DUMMY_LDS]; dummyLds[threadIdx.x] = threadIdx.x; if (*countPtr == 0xFFFFFFFFu) wc->overflow = dummyLds[threadIdx.x ^ 1];
-#endif
     const uint count = *countPtr;
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
@@ -178,9 +175,6 @@ template <bool COUNT>
 __global__ void __launch_bounds__(T8_BLOCK) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
-#ifdef T8_EXPERIMENT_DUMMY_LDS
-    __shared__ uint dummyLds[T8_EXPERIMENT_DUMMY_LDS]; dummyLds[threadIdx.x] = threadIdx.x; if (*countPtr == 0xFFFFFFFFu) wc->overflow = dummyLds[threadIdx.x ^ 1];
-#endif
     const uint count = *countPtr;
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
