@@ -75,7 +75,10 @@ static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
 // BVH8_STACK entries (odd stride: quads land on different banks) and a T8_SPILL_DEPTH-entry tail in global memory (DeviceScene::travSpill)
 static const uint BVH8_STACK = PT_BVH8_STACK, BVH8_STACK_STRIDE = PT_BVH8_STACK + 1;
 static const uint T8_BLOCK = 256, T8_CHUNK = 64, T8_LANES = 4, T8_GROUPS_PER_BLOCK = T8_BLOCK / T8_LANES, T8_SPILL_DEPTH = 96;
-static const uint T8_MAX_BLOCKS = 256 * 6 * 4;     // persistent waves stride over 64-ray chunks
+#ifndef PT_T8_MAX_BLOCKS
+#define PT_T8_MAX_BLOCKS (256 * 6 * 4)
+#endif
+static const uint T8_MAX_BLOCKS = PT_T8_MAX_BLOCKS;     // persistent waves stride over 64-ray chunks
 
 // per leaf-order triangle slot: what the alpha test needs, resolved at build time (texture coordinates of the 3 vertices, alpha texture, cutoff);
 // tex == ~0: not alpha tested. Saves the primInfo -> subInstance -> index -> uv chain (7 dependent loads) inside the traversal loop.
