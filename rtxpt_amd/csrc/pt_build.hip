@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ n
     if (nInner) { wbase = atomicAdd(&counter[0], nInner); obase = atomicAdd(&counter[1], nInner); }
     Bvh8Node out;
     out.ox = mn.x; out.oy = mn.y; out.oz = mn.z; out.exps = ex | (ey << 8) | (ez << 16) | (n << 24);
-    out._pad[0] = out._pad[1] = out._pad[2] = out._pad[3] = 0;
+    out._pad[0] = __float_as_uint(sx); out._pad[1] = __float_as_uint(sy); out._pad[2] = __float_as_uint(sz); out._pad[3] = 0;      // the scales again, as floats (traversal reads these; exps stays for tools)
     uint inner = 0;
     for (uint k = 0; k < 8u; k++) {
         if (k >= n) { out.c[k].ref = BVH_EMPTY; out.c[k].q0 = 0x00FFFFFFu; out.c[k].q1 = 0u; continue; }     // inverted box

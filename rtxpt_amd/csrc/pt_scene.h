@@ -61,7 +61,7 @@ static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_L
 // whole node costs one line lookup per group instead of four 16 B gathers per lane. Child boxes are 8-bit quantised relative to the node
 // origin with power-of-two scales (conservative: decoded lo <= true lo, decoded hi >= true hi, verified with the decode arithmetic itself).
 struct Bvh8Child { uint ref, q0, q1; };                       // q0 = qlo.x | qlo.y<<8 | qlo.z<<16 | qhi.x<<24, q1 = qhi.y | qhi.z<<8
-struct Bvh8Node { float ox, oy, oz; uint exps; Bvh8Child c[8]; uint _pad[4]; };   // exps = ex | ey<<8 | ez<<16 | childCount<<24 (scale = 2^(e-127))
+struct Bvh8Node { float ox, oy, oz; uint exps; Bvh8Child c[8]; uint _pad[4]; };   // exps = ex | ey<<8 | ez<<16 | childCount<<24 (scale = 2^(e-127)); _pad[0..2] = the three scales as floats
 typedef uint u32x4 __attribute__((ext_vector_type(4)));      // 16-byte aligned vector loads (global_load_dwordx4)
 typedef uint u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // v_pk_*_f32 operands

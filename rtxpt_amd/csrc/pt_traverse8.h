@@ -29,6 +29,9 @@ static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 #ifndef T8_EXTEND_MIN_BLOCKS
 #define T8_EXTEND_MIN_BLOCKS 5    // 256-thread blocks per CU the register allocator must leave room for in k_extend (= waves per SIMD)
 #endif
+#ifndef T8_FAST_INNER
+#define T8_FAST_INNER 1          // near/far planes by byte permute, float scales from the node tail, quad hit count by DPP adds
+#endif
 #ifndef T8_TAIL_ITERS
 #define T8_TAIL_ITERS 32         // loop iterations a wave keeps going after its last chunk before it splits what is still in flight into tasks
 #endif
@@ -95,6 +98,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     bool active = false;
     float3 o = make_float3(0.f), d = make_float3(0.f);
     float ix = 0.f, iy = 0.f, iz = 0.f;
+    uint selN = 0u, selF = 0u;                                // (T8_FAST_INNER) byte selectors of the near / far planes for this ray's direction signs
     float tmin = 0.f, tmax = FIXED_RANGE ? kMaxRayTravel : 0.f;
     float bestT = 0.f; uint bestPrim = 0xFFFFFFFFu;           // quad-uniform closest hit so far
     uint minePrim = 0xFFFFFFFFu;                              // the best hit THIS lane found; its barycentrics wait in LDS (mineUV) and never travel between lanes
@@ -154,6 +158,12 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                     d = make_float3(__uint_as_float(slot[3]), __uint_as_float(slot[4]), __uint_as_float(slot[5]));
                     tag = slot[6];
                     ix = t8_rcp_dir(d.x); iy = t8_rcp_dir(d.y); iz = t8_rcp_dir(d.z);
+#if T8_FAST_INNER
+                    {   // child bytes: q0 = lo.x lo.y lo.z hi.x (selector values 0..3), q1 = hi.y hi.z (4, 5)
+                        const uint nxb = ix < 0.f ? 3u : 0u, fxb = ix < 0.f ? 0u : 3u, nyb = iy < 0.f ? 4u : 1u, fyb = iy < 0.f ? 1u : 4u, nzb = iz < 0.f ? 5u : 2u, fzb = iz < 0.f ? 2u : 5u;
+                        selN = nxb | (nyb << 8) | (nzb << 16) | (fxb << 24); selF = fyb | (fzb << 8);
+                    }
+#endif
                     if (TASKS) {
                         if (!FIXED_RANGE) tmax = __uint_as_float(slot[7]);
                         bestT = taskT0 = __uint_as_float(slot[8]); bestPrim = taskPrim0 = slot[9]; cur = slot[10];
@@ -196,8 +206,24 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
             const u32x4 hdr = *reinterpret_cast<const u32x4*>(nodesBase + nodeOff);
             const Bvh8ChildPair ch = *reinterpret_cast<const Bvh8ChildPair*>(nodesBase + (nodeOff + laneChildOff));
             if (COUNT && q == 0u) ctr.nodeVisits++;
-            const float sx = __uint_as_float((hdr.w << 23) & INF_BITS), sy = __uint_as_float((hdr.w << 15) & INF_BITS), sz = __uint_as_float((hdr.w << 7) & INF_BITS);
             const float nx = __uint_as_float(hdr.x), ny = __uint_as_float(hdr.y), nz = __uint_as_float(hdr.z);
+#if T8_FAST_INNER
+            // scales as floats from the node's last 16 bytes (one more 16 B load per quad, 6 VALU decode instructions fewer)
+            const f32x4 scl = *reinterpret_cast<const f32x4*>(nodesBase + (nodeOff + 112u));
+            const float sx = scl.x, sy = scl.y, sz = scl.z;
+            // the ray's direction signs pick the near / far plane of every axis up front (two byte permutes per child instead of six min/max):
+            // N = near.x | near.y | near.z | far.x, F = far.y | far.z
+            auto slab = [&](uint q0, uint q1, float& tn, float& tf) {
+                const uint N = __builtin_amdgcn_perm(q1, q0, selN), F = __builtin_amdgcn_perm(q1, q0, selF);
+                f32x2 px = __builtin_elementwise_fma((f32x2){(float)(N & 0xFFu), (float)(N >> 24)}, (f32x2){sx, sx}, (f32x2){nx, nx});
+                f32x2 py = __builtin_elementwise_fma((f32x2){(float)((N >> 8) & 0xFFu), (float)(F & 0xFFu)}, (f32x2){sy, sy}, (f32x2){ny, ny});
+                f32x2 pz = __builtin_elementwise_fma((f32x2){(float)((N >> 16) & 0xFFu), (float)((F >> 8) & 0xFFu)}, (f32x2){sz, sz}, (f32x2){nz, nz});
+                f32x2 tx = (px - (f32x2){o.x, o.x}) * (f32x2){ix, ix}, ty = (py - (f32x2){o.y, o.y}) * (f32x2){iy, iy}, tz = (pz - (f32x2){o.z, o.z}) * (f32x2){iz, iz};
+                tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+                tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, bestT));
+            };
+#else
+            const float sx = __uint_as_float((hdr.w << 23) & INF_BITS), sy = __uint_as_float((hdr.w << 15) & INF_BITS), sz = __uint_as_float((hdr.w << 7) & INF_BITS);
             // {lo, hi} pairs per axis: plane = fma(code, scale, origin) (the builder verified conservativeness with this exact expression)
             auto slab = [&](uint q0, uint q1, float& tn, float& tf) {
                 f32x2 px = __builtin_elementwise_fma((f32x2){(float)(q0 & 0xFFu), (float)(q0 >> 24)}, (f32x2){sx, sx}, (f32x2){nx, nx});
@@ -207,13 +233,19 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin));
                 tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), bestT));
             };
+#endif
             float tnA, tfA, tnB, tfB;
             slab(ch.q0A, ch.q1A, tnA, tfA); slab(ch.q0B, ch.q1B, tnB, tfB);
             const bool hitA = (ch.refA != BVH_EMPTY) && (tnA <= tfA * 1.0000012f), hitB = (ch.refB != BVH_EMPTY) && (tnB <= tfB * 1.0000012f);
             // integer sort keys: tn >= 0 so its bits order like the value; the low 3 mantissa bits carry the child index (unique keys, ties to the lower child)
             const uint tbA = __float_as_uint(tnA) & ~7u, tbB = __float_as_uint(tnB) & ~7u;
             const uint keyA = (hitA ? tbA : INF_BITS) | (2u * q), keyB = (hitB ? tbB : INF_BITS) | (2u * q + 1u);
+#if T8_FAST_INNER
+            uint nhit = (hitA ? 1u : 0u) + (hitB ? 1u : 0u);                  // quad sum by two DPP adds (the ballot route costs two 64-bit shifts)
+            nhit += dpp_u<DPP_QP_XOR1>(nhit); nhit += dpp_u<DPP_QP_XOR2>(nhit);
+#else
             const uint nhit = (uint)__popc(quad_bits(t8_ballot(hitA), gl) | (quad_bits(t8_ballot(hitB), gl) << 4));
+#endif
             const uint a1 = dpp_u<DPP_QP_XOR1>(keyA), a2 = dpp_u<DPP_QP_XOR2>(keyA), a3 = dpp_u<DPP_QP_XOR3>(keyA);
             const uint b1 = dpp_u<DPP_QP_XOR1>(keyB), b2 = dpp_u<DPP_QP_XOR2>(keyB), b3 = dpp_u<DPP_QP_XOR3>(keyB);
             uint rankA = (keyB < keyA) ? 1u : 0u, rankB = (keyA < keyB) ? 1u : 0u;
