@@ -182,6 +182,19 @@ int32_t pt_reset_accumulation(pt_context* ctx);                                 
 int32_t pt_map_radiance(pt_context* ctx, const float** rgba32f, size_t* rowPitchBytes);
 int32_t pt_unmap_radiance(pt_context* ctx);
 
+/* RTXPT `.material.json` (the part the reference tree defines completely): PTMaterial::Read + PTMaterial::FillData
+   (Rtxpt/Materials/MaterialsBaker.cpp:150-259, 516-591; defaults Rtxpt/Materials/MaterialsBaker.h:126-193). Host only, no context needed.
+   textureWords[5]: packed PTMaterialData texture words (baseLOD << 24 | mipLevels << 16 | texture index, GetBindlessTextureIndex :487-509) of the
+   Base / OcclusionRoughnessMetallic / Normal / Emissive / Transmission textures the caller has loaded for the document's "path" entries, or
+   0xFFFFFFFF for a texture that is absent (its flag is then cleared, as in the reference). info (optional) receives what does not live in
+   PTMaterialData: the five texture paths / sRGB / NormalMap flags and EnableAlphaTesting, ExcludeFromNEE, SkipRender, UseDonutEmissiveIntensity. */
+typedef struct PtMaterialJsonInfo {
+    char     texturePath[5][256];
+    uint32_t textureSRGB[5], textureNormalMap[5];
+    uint32_t enableAlphaTesting, excludeFromNEE, skipRender, useDonutEmissiveIntensity;
+} PtMaterialJsonInfo;
+int32_t pt_material_from_json(const char* jsonText, const uint32_t textureWords[5], PTMaterialData* out, PtMaterialJsonInfo* info);
+
 /* Display path. pt_default_tonemap: ToneMappingParameters defaults + UpdateColorTransform with manual exposure
    (Rtxpt/ToneMapper/ToneMappingPasses.h:36-53, ToneMappingPasses.cpp:428-441): exposureCompensation in stops, filmSpeed/shutter/fNumber as in the UI.
    pt_tonemap: ToneMappingPass::Render into the SRGBA8_UNORM LdrColor target (ToneMapping.ps.hlsli:136-174, RenderTargets.cpp:241) of THIS

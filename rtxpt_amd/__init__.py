@@ -28,7 +28,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels",
+    "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json",
 ]
 
 
@@ -115,6 +115,28 @@ def default_tonemap(exposure_compensation=0.0, film_speed=100.0, shutter=1.0, f_
     for k, v in kw.items():
         t[k] = TONEMAP_OPERATORS[v] if (k == "toneMapOperator" and isinstance(v, str)) else v
     return t
+
+
+class PtMaterialJsonInfo(ctypes.Structure):
+    _fields_ = [("texturePath", (ctypes.c_char * 256) * 5), ("textureSRGB", ctypes.c_uint32 * 5), ("textureNormalMap", ctypes.c_uint32 * 5),
+                ("enableAlphaTesting", ctypes.c_uint32), ("excludeFromNEE", ctypes.c_uint32), ("skipRender", ctypes.c_uint32), ("useDonutEmissiveIntensity", ctypes.c_uint32)]
+
+
+def material_from_json(text, texture_words=(0xFFFFFFFF,) * 5):
+    """pt_material_from_json: an RTXPT `.material.json` document -> (PTMaterialData record as numpy scalar, info dict). No device needed.
+    texture_words: packed texture words of the Base / ORM / Normal / Emissive / Transmission textures (0xFFFFFFFF = not loaded)."""
+    from . import scenes
+    L = load_library()
+    out = np.zeros((), dtype=scenes.MATERIAL_DTYPE)
+    info = PtMaterialJsonInfo()
+    words = (ctypes.c_uint32 * 5)(*[int(w) & 0xFFFFFFFF for w in texture_words])
+    L.pt_material_from_json.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    r = L.pt_material_from_json(text.encode() if isinstance(text, str) else text, words, _p(out), ctypes.byref(info))
+    if r != 0:
+        raise PtError(r, "pt_material_from_json")
+    return out, {"texturePath": [bytes(info.texturePath[i]).split(b"\0")[0].decode() for i in range(5)], "textureSRGB": list(info.textureSRGB),
+                 "textureNormalMap": list(info.textureNormalMap), "enableAlphaTesting": bool(info.enableAlphaTesting), "excludeFromNEE": bool(info.excludeFromNEE),
+                 "skipRender": bool(info.skipRender), "useDonutEmissiveIntensity": bool(info.useDonutEmissiveIntensity)}
 
 
 def write_image(path, rgba8):

@@ -289,6 +289,89 @@ struct Loader {
     }
 };
 
+// ---------------------------------------------------------------- RTXPT .material.json -> PTMaterialData
+// PTMaterial defaults (MaterialsBaker.h:126-193), Read (MaterialsBaker.cpp:150-259: a missing key keeps the default) and FillData (:516-591)
+struct PTMaterialHost {
+    float BaseOrDiffuseColor[3] = {1, 1, 1}, SpecularColor[3] = {0, 0, 0}, EmissiveColor[3] = {0, 0, 0};
+    float EmissiveIntensity = 1.f, Metalness = 0.f, Roughness = 0.f, Opacity = 1.f, TransmissionFactor = 0.f, DiffuseTransmissionFactor = 0.f, NormalTextureScale = 1.f, IoR = 1.5f;
+    bool UseSpecularGlossModel = false, EnableBaseTexture = true, EnableOcclusionRoughnessMetallicTexture = true, EnableNormalTexture = true, EnableEmissiveTexture = true,
+         EnableTransmissionTexture = true, EnableAlphaTesting = false, EnableTransmission = false, MetalnessInRedChannel = false, ThinSurface = false, ExcludeFromNEE = false,
+         PSDExclude = true, EnableAsAnalyticLightProxy = false, IgnoreMeshTangentSpace = false, UseDonutEmissiveIntensity = false, SkipRender = false;
+    float AlphaCutoff = 0.5f; int PSDDominantDeltaLobe = -1, PSDBlockMotionVectorsAtSurfaceType = 0, NestedPriority = 14;
+    float VolumeAttenuationDistance = 3.402823466e+38f, VolumeAttenuationColor[3] = {1, 1, 1}, ShadowNoLFadeout = 0.f;
+};
+void jload(const JValue& o, const char* k, float& v) { const JValue* j = o.get(k); if (j && j->type == JValue::Num) v = (float)j->num; }
+void jload(const JValue& o, const char* k, int& v) { const JValue* j = o.get(k); if (j && j->type == JValue::Num) v = (int)j->num; }
+void jload(const JValue& o, const char* k, bool& v) { const JValue* j = o.get(k); if (j && j->type == JValue::Bool) v = j->b; else if (j && j->type == JValue::Num) v = j->num != 0; }
+void jload3(const JValue& o, const char* k, float v[3]) { const JValue* j = o.get(k); if (j && j->type == JValue::Arr && j->arr.size() >= 3) for (int i = 0; i < 3; i++) if (j->arr[i].type == JValue::Num) v[i] = (float)j->arr[i].num; }
+
+} // namespace
+
+extern "C" int32_t pt_material_from_json(const char* jsonText, const uint32_t textureWords[5], PTMaterialData* out, PtMaterialJsonInfo* info) {
+    if (!jsonText || !out) return PT_ERROR_INVALID_ARGUMENT;
+    JParser jp{jsonText, jsonText + strlen(jsonText)};
+    JValue root = jp.parse();
+    if (!jp.ok || root.type != JValue::Obj) return PT_ERROR_IO;
+    PTMaterialHost m;
+#define PT_LOAD_FIELD(NAME) jload(root, #NAME, m.NAME)
+    jload3(root, "BaseOrDiffuseColor", m.BaseOrDiffuseColor); jload3(root, "SpecularColor", m.SpecularColor); jload3(root, "EmissiveColor", m.EmissiveColor);
+    PT_LOAD_FIELD(EmissiveIntensity); PT_LOAD_FIELD(Metalness); PT_LOAD_FIELD(Roughness); PT_LOAD_FIELD(Opacity); PT_LOAD_FIELD(TransmissionFactor); PT_LOAD_FIELD(DiffuseTransmissionFactor);
+    PT_LOAD_FIELD(NormalTextureScale); PT_LOAD_FIELD(IoR); PT_LOAD_FIELD(UseSpecularGlossModel); PT_LOAD_FIELD(EnableBaseTexture); PT_LOAD_FIELD(EnableOcclusionRoughnessMetallicTexture);
+    PT_LOAD_FIELD(EnableNormalTexture); PT_LOAD_FIELD(EnableEmissiveTexture); PT_LOAD_FIELD(EnableTransmissionTexture); PT_LOAD_FIELD(EnableAlphaTesting); PT_LOAD_FIELD(AlphaCutoff);
+    PT_LOAD_FIELD(EnableTransmission); PT_LOAD_FIELD(MetalnessInRedChannel); PT_LOAD_FIELD(ThinSurface); PT_LOAD_FIELD(ExcludeFromNEE); PT_LOAD_FIELD(PSDExclude);
+    PT_LOAD_FIELD(PSDBlockMotionVectorsAtSurfaceType); PT_LOAD_FIELD(PSDDominantDeltaLobe); PT_LOAD_FIELD(NestedPriority); PT_LOAD_FIELD(VolumeAttenuationDistance);
+    jload3(root, "VolumeAttenuationColor", m.VolumeAttenuationColor); PT_LOAD_FIELD(ShadowNoLFadeout); PT_LOAD_FIELD(EnableAsAnalyticLightProxy); PT_LOAD_FIELD(IgnoreMeshTangentSpace);
+    PT_LOAD_FIELD(UseDonutEmissiveIntensity); PT_LOAD_FIELD(SkipRender);
+#undef PT_LOAD_FIELD
+    static const char* texNames[5] = {"BaseTexture", "OcclusionRoughnessMetallicTexture", "NormalTexture", "EmissiveTexture", "TransmissionTexture"};
+    bool loaded[5];
+    if (info) memset(info, 0, sizeof(*info));
+    for (int t = 0; t < 5; t++) {
+        const JValue* tj = root.get(texNames[t]);
+        std::string path = (tj && tj->type == JValue::Obj) ? tj->strOr("path", "") : std::string();
+        // "Loaded" in the reference = the texture object exists; here: the document names a path AND the caller supplied a texture word for it
+        loaded[t] = !path.empty() && textureWords && textureWords[t] != 0xFFFFFFFFu;
+        if (info && tj && tj->type == JValue::Obj) {
+            strncpy(info->texturePath[t], path.c_str(), 255);
+            bool b = false; jload(*tj, "sRGB", b); info->textureSRGB[t] = b; b = false; jload(*tj, "NormalMap", b); info->textureNormalMap[t] = b;
+        }
+    }
+    // ---- FillData (MaterialsBaker.cpp:516-591)
+    memset(out, 0, sizeof(*out));
+    uint32_t f = 0;
+    if (m.UseSpecularGlossModel) f |= 0x00000001u;
+    if (loaded[0] && m.EnableBaseTexture) f |= 0x00000008u;
+    if (loaded[1] && m.EnableOcclusionRoughnessMetallicTexture) f |= 0x00000004u;
+    if (loaded[3] && m.EnableEmissiveTexture) f |= 0x00000010u;
+    if (loaded[2] && m.EnableNormalTexture) f |= 0x00000020u;
+    if (loaded[4] && m.EnableTransmissionTexture && m.EnableTransmission) f |= 0x00000080u;
+    if (m.MetalnessInRedChannel) f |= 0x00000100u;
+    if (m.ThinSurface || !m.EnableTransmission) f |= 0x00000200u;          // no transmission => thin surface
+    if (m.PSDExclude) f |= 0x00000400u;
+    if (m.PSDBlockMotionVectorsAtSurfaceType % 2) f |= (1u << 13);
+    if (m.PSDBlockMotionVectorsAtSurfaceType / 2) f |= (1u << 14);
+    if (m.EnableAsAnalyticLightProxy) f |= 0x00000800u;
+    if (m.IgnoreMeshTangentSpace) f |= (1u << 12);
+    for (int i = 0; i < 3; i++) { out->BaseOrDiffuseColor[i] = m.BaseOrDiffuseColor[i]; out->SpecularColor[i] = m.SpecularColor[i]; out->EmissiveColor[i] = m.EmissiveColor[i] * m.EmissiveIntensity;
+                                  out->AttenuationColor[i] = m.VolumeAttenuationColor[i]; }
+    out->Roughness = m.Roughness; out->Metalness = m.Metalness; out->NormalTextureScale = m.NormalTextureScale;
+    out->TransmissionFactor = m.EnableTransmission ? m.TransmissionFactor : 0.f; out->DiffuseTransmissionFactor = m.EnableTransmission ? m.DiffuseTransmissionFactor : 0.f;
+    out->Opacity = m.Opacity; out->AlphaCutoff = m.AlphaCutoff; out->IoR = m.IoR; out->AttenuationDistance = m.VolumeAttenuationDistance;
+    auto texWord = [&](int t, uint32_t bit) -> uint32_t { if (!(f & bit) || !loaded[t]) { f &= ~bit; return 0xFFFFFFFFu; } return textureWords[t]; };      // GetBindlessTextureIndex
+    out->BaseOrDiffuseTextureIndex = texWord(0, 0x00000008u); out->MetalRoughOrSpecularTextureIndex = texWord(1, 0x00000004u); out->EmissiveTextureIndex = texWord(3, 0x00000010u);
+    out->NormalTextureIndex = texWord(2, 0x00000020u); out->TransmissionTextureIndex = texWord(4, 0x00000080u); out->OcclusionTextureIndex = 0;
+    int np = m.NestedPriority < 14 ? m.NestedPriority : 14; if (np < 0) np = 0;
+    f |= (uint32_t)np << 28;
+    int lobe = m.PSDDominantDeltaLobe + 1; lobe = lobe < 0 ? 0 : (lobe > 7 ? 7 : lobe);
+    f |= (uint32_t)lobe << 24;
+    out->Flags = f;
+    out->ShadowNoLFadeout = m.ShadowNoLFadeout < 0.f ? 0.f : (m.ShadowNoLFadeout > 0.25f ? 0.25f : m.ShadowNoLFadeout);
+    out->_padding0 = 42; out->_padding1 = 42.f;       // (the reference writes 42 into both padding words)
+    if (info) { info->enableAlphaTesting = m.EnableAlphaTesting; info->excludeFromNEE = m.ExcludeFromNEE; info->skipRender = m.SkipRender; info->useDonutEmissiveIntensity = m.UseDonutEmissiveIntensity; }
+    return PT_OK;
+}
+
+namespace {
 } // namespace
 
 extern "C" int32_t pt_load_scene_gltf(pt_context* ctx, const char* path) {

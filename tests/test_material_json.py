@@ -1,0 +1,91 @@
+"""`.material.json` import (the part the reference tree defines completely): pt_material_from_json against an independent
+Python restatement of PTMaterial defaults (MaterialsBaker.h:126-193), Read (MaterialsBaker.cpp:150-259) and FillData (:516-591). CPU only."""
+import json
+
+import numpy as np
+import pytest
+
+import rtxpt_amd as pt
+
+F_SPECGLOSS, F_MR_TEX, F_BASE_TEX, F_EMISSIVE_TEX, F_NORMAL_TEX, F_TRANS_TEX = 0x1, 0x4, 0x8, 0x10, 0x20, 0x80
+F_METAL_RED, F_THIN, F_PSD_EXCLUDE, F_PROXY, F_IGNORE_TANGENT, F_MV_B0, F_MV_B1 = 0x100, 0x200, 0x400, 0x800, 1 << 12, 1 << 13, 1 << 14
+DEFAULTS = dict(BaseOrDiffuseColor=[1, 1, 1], SpecularColor=[0, 0, 0], EmissiveColor=[0, 0, 0], EmissiveIntensity=1.0, Metalness=0.0, Roughness=0.0, Opacity=1.0,
+                TransmissionFactor=0.0, DiffuseTransmissionFactor=0.0, NormalTextureScale=1.0, IoR=1.5, UseSpecularGlossModel=False, EnableBaseTexture=True,
+                EnableOcclusionRoughnessMetallicTexture=True, EnableNormalTexture=True, EnableEmissiveTexture=True, EnableTransmissionTexture=True,
+                EnableAlphaTesting=False, AlphaCutoff=0.5, EnableTransmission=False, MetalnessInRedChannel=False, ThinSurface=False, ExcludeFromNEE=False,
+                PSDExclude=True, PSDDominantDeltaLobe=-1, PSDBlockMotionVectorsAtSurfaceType=0, NestedPriority=14, VolumeAttenuationDistance=3.402823466e+38,
+                VolumeAttenuationColor=[1, 1, 1], ShadowNoLFadeout=0.0, EnableAsAnalyticLightProxy=False, IgnoreMeshTangentSpace=False,
+                UseDonutEmissiveIntensity=False, SkipRender=False)
+TEX = ["BaseTexture", "OcclusionRoughnessMetallicTexture", "NormalTexture", "EmissiveTexture", "TransmissionTexture"]
+
+
+def fill_data(doc, words):
+    m = dict(DEFAULTS); m.update({k: v for k, v in doc.items() if k in DEFAULTS})
+    loaded = [bool(doc.get(t, {}).get("path")) and words[i] != 0xFFFFFFFF for i, t in enumerate(TEX)]
+    f = 0
+    f |= F_SPECGLOSS if m["UseSpecularGlossModel"] else 0
+    f |= F_BASE_TEX if loaded[0] and m["EnableBaseTexture"] else 0
+    f |= F_MR_TEX if loaded[1] and m["EnableOcclusionRoughnessMetallicTexture"] else 0
+    f |= F_EMISSIVE_TEX if loaded[3] and m["EnableEmissiveTexture"] else 0
+    f |= F_NORMAL_TEX if loaded[2] and m["EnableNormalTexture"] else 0
+    f |= F_TRANS_TEX if loaded[4] and m["EnableTransmissionTexture"] and m["EnableTransmission"] else 0
+    f |= F_METAL_RED if m["MetalnessInRedChannel"] else 0
+    f |= F_THIN if (m["ThinSurface"] or not m["EnableTransmission"]) else 0
+    f |= F_PSD_EXCLUDE if m["PSDExclude"] else 0
+    f |= F_MV_B0 if m["PSDBlockMotionVectorsAtSurfaceType"] % 2 else 0
+    f |= F_MV_B1 if m["PSDBlockMotionVectorsAtSurfaceType"] // 2 else 0
+    f |= F_PROXY if m["EnableAsAnalyticLightProxy"] else 0
+    f |= F_IGNORE_TANGENT if m["IgnoreMeshTangentSpace"] else 0
+    f |= min(max(m["NestedPriority"], 0), 14) << 28
+    f |= min(max(m["PSDDominantDeltaLobe"] + 1, 0), 7) << 24
+    w = lambda i, bit: words[i] if (f & bit) and loaded[i] else 0xFFFFFFFF
+    et = m["EnableTransmission"]
+    return dict(Flags=f, BaseOrDiffuseColor=m["BaseOrDiffuseColor"], SpecularColor=m["SpecularColor"],
+                EmissiveColor=[np.float32(c) * np.float32(m["EmissiveIntensity"]) for c in m["EmissiveColor"]],
+                Roughness=m["Roughness"], Metalness=m["Metalness"], NormalTextureScale=m["NormalTextureScale"], TransmissionFactor=m["TransmissionFactor"] if et else 0.0,
+                DiffuseTransmissionFactor=m["DiffuseTransmissionFactor"] if et else 0.0, Opacity=m["Opacity"], AlphaCutoff=m["AlphaCutoff"], IoR=m["IoR"],
+                AttenuationColor=m["VolumeAttenuationColor"], AttenuationDistance=m["VolumeAttenuationDistance"], ShadowNoLFadeout=min(max(m["ShadowNoLFadeout"], 0.0), 0.25),
+                BaseOrDiffuseTextureIndex=w(0, F_BASE_TEX), MetalRoughOrSpecularTextureIndex=w(1, F_MR_TEX), EmissiveTextureIndex=w(3, F_EMISSIVE_TEX),
+                NormalTextureIndex=w(2, F_NORMAL_TEX), TransmissionTextureIndex=w(4, F_TRANS_TEX), _padding0=42, _padding1=42.0)
+
+
+CASES = {
+    "defaults": ({}, [0xFFFFFFFF] * 5),
+    "glass_in_liquid": ({"version": 1, "EnableTransmission": True, "TransmissionFactor": 0.95, "IoR": 1.33, "ThinSurface": False, "NestedPriority": 3, "Roughness": 0.02,
+                         "VolumeAttenuationDistance": 0.25, "VolumeAttenuationColor": [0.9, 0.4, 0.1], "PSDDominantDeltaLobe": 0, "PSDExclude": False}, [0xFFFFFFFF] * 5),
+    "textured_lamp": ({"BaseTexture": {"sRGB": True, "NormalMap": False, "path": "textures/lamp_base.png"}, "NormalTexture": {"sRGB": False, "NormalMap": True, "path": "textures/lamp_n.png"},
+                       "EmissiveTexture": {"sRGB": True, "path": "textures/lamp_e.png"}, "OcclusionRoughnessMetallicTexture": {"path": "textures/lamp_orm.png"},
+                       "EmissiveColor": [1.0, 0.8, 0.5], "EmissiveIntensity": 250.0, "Metalness": 1.0, "Roughness": 0.35, "MetalnessInRedChannel": True, "EnableNormalTexture": False,
+                       "ExcludeFromNEE": True, "ShadowNoLFadeout": 0.6, "PSDBlockMotionVectorsAtSurfaceType": 3, "IgnoreMeshTangentSpace": True},
+                      [0x14090003, 0x14090004, 0x14090005, 0xFFFFFFFF, 0xFFFFFFFF]),
+    "foliage": ({"BaseTexture": {"sRGB": True, "path": "leaf.png"}, "EnableAlphaTesting": True, "AlphaCutoff": 0.33, "DiffuseTransmissionFactor": 0.4, "EnableTransmission": False,
+                 "TransmissionTexture": {"path": "leaf_t.png"}, "NestedPriority": 99, "PSDDominantDeltaLobe": 12, "SkipRender": True, "UseDonutEmissiveIntensity": True,
+                 "EnableAsAnalyticLightProxy": True, "UseSpecularGlossModel": True, "SpecularColor": [0.04, 0.05, 0.06]}, [0x0A050007, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0x0A050009]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_material_json_matches_fill_data(name):
+    doc, words = CASES[name]
+    got, info = pt.material_from_json(json.dumps(doc), words)
+    want = fill_data(doc, words)
+    for k, v in want.items():
+        g = got[k]
+        if isinstance(v, (list, tuple)):
+            assert np.array_equal(np.asarray(g, np.float32), np.asarray(v, np.float32)), k
+        elif isinstance(v, float):
+            assert np.float32(g) == np.float32(v), k
+        else:
+            assert int(g) == int(v), (k, hex(int(g)), hex(int(v)))
+    assert info["enableAlphaTesting"] == bool(doc.get("EnableAlphaTesting", False)) and info["excludeFromNEE"] == bool(doc.get("ExcludeFromNEE", False))
+    assert info["skipRender"] == bool(doc.get("SkipRender", False)) and info["useDonutEmissiveIntensity"] == bool(doc.get("UseDonutEmissiveIntensity", False))
+    for i, t in enumerate(TEX):
+        assert info["texturePath"][i] == doc.get(t, {}).get("path", "")
+        assert bool(info["textureSRGB"][i]) == bool(doc.get(t, {}).get("sRGB", False)) and bool(info["textureNormalMap"][i]) == bool(doc.get(t, {}).get("NormalMap", False))
+
+
+def test_material_json_rejects_garbage():
+    with pytest.raises(pt.PtError):
+        pt.material_from_json("{ not json", [0xFFFFFFFF] * 5)
+    with pytest.raises(pt.PtError):
+        pt.material_from_json("[1, 2, 3]", [0xFFFFFFFF] * 5)
