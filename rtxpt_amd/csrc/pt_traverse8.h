@@ -35,6 +35,9 @@ static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 #ifndef T8_TAIL_ITERS
 #define T8_TAIL_ITERS 32         // loop iterations a wave keeps going after its last chunk before it splits what is still in flight into tasks
 #endif
+#ifndef T8_TAIL_ITERS_TASKS
+#define T8_TAIL_ITERS_TASKS 8    // the same for task rounds: sub-trees are short, and every round of every launch pays this tail once
+#endif
 #ifndef T8_LEAF_QUEUE
 #define T8_LEAF_QUEUE 2         // postponed leaves a ray may hold (1..3) before it has to wait for the wave's next leaf block (A/B: within noise on extend, -4 % on shadow)
 #endif
@@ -182,7 +185,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
         // ---- straggler splitting (after the loop, see below): out of fresh work for T8_TAIL_ITERS iterations -> stop and hand over what is in flight
         if (CAN_SPLIT) {
             if (waveDry) tailIters++;
-            if (tailIters > (uint)T8_TAIL_ITERS) { splitNow = true; break; }
+            if (tailIters > (uint)(TASKS ? T8_TAIL_ITERS_TASKS : T8_TAIL_ITERS)) { splitNow = true; break; }
         }
 
         if (COUNT && lane == 0u) ctr.iters++;

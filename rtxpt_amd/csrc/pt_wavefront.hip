@@ -371,7 +371,10 @@ void launch_generate(const PathKernelContext& k, PathPool pool, const uint* owne
     hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, st, k, pool, ownedPixels, numOwned, sampleFirst, spp, queue);
 }
 // task rounds + resolve pass of one traversal launch; all counts live on the device, so the grids are fixed (empty rounds return at once)
-static const uint T8_TASK_BLOCKS = 256 * 6, T8_RESOLVE_BLOCKS = 256;
+#ifndef T8_TASK_BLOCKS_N
+#define T8_TASK_BLOCKS_N 512        // task rounds hold thousands of sub-trees, not millions
+#endif
+static const uint T8_TASK_BLOCKS = T8_TASK_BLOCKS_N, T8_RESOLVE_BLOCKS = 256;
 void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
     uint g = grid_for(count, T8_BLOCK, T8_MAX_BLOCKS);
     (void)hipMemsetAsync(aux.counts, 0, 12, st);
