@@ -50,6 +50,8 @@ def gather_packed(packed, rank, world, dist, counts):
     if rank == 0:
         recv = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, gather_list=recv, dst=0)
+        if send.is_cuda:      # the collective only orders torch's stream; pt_unpack_shard reads these buffers on the library's own stream
+            torch.cuda.current_stream(send.device).synchronize()
         return [recv[r][: counts[r]] for r in range(world)]
     dist.gather(send, gather_list=None, dst=0)
     return None
