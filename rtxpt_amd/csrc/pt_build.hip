@@ -2,6 +2,10 @@
 #include "pt_build.h"
 #include <rocprim/rocprim.hpp>
 
+#ifndef PT_RANGE_TABLE_MAX_TRIS
+#define PT_RANGE_TABLE_MAX_TRIS (16u << 20)     // above this the n log n sparse table (32 B x n x log2 n) gives way to the ticket-based k_bounds
+#endif
+
 namespace ptk {
 
 #define PT_HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
@@ -129,6 +133,43 @@ __global__ void __launch_bounds__(256) k_bounds(const TriRecord* __restrict__ tr
         childRef = node;
         node = parent[node];
     }
+}
+
+// ---- node bounds by range queries (see pt_build.h)
+__global__ void __launch_bounds__(256) k_leaf_boxes(const TriRecord* __restrict__ triWorld, const uint* __restrict__ primsSorted, uint n, TriRecord* __restrict__ triSorted,
+                                                    float4* __restrict__ rmin, float4* __restrict__ rmax) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    TriRecord tr = triWorld[primsSorted[i]];
+    triSorted[i] = tr;
+    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
+    float3 mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+    rmin[i] = make_float4(mn.x, mn.y, mn.z, 0.f); rmax[i] = make_float4(mx.x, mx.y, mx.z, 0.f);
+}
+__global__ void __launch_bounds__(256) k_range_level(uint n, uint half, const float4* __restrict__ pmin, const float4* __restrict__ pmax, float4* __restrict__ omin, float4* __restrict__ omax) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i + 2u * half > n) return;                          // entry i of this level covers [i, i + 2*half)
+    float4 a = pmin[i], b = pmin[i + half], c = pmax[i], d = pmax[i + half];
+    omin[i] = make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), 0.f);
+    omax[i] = make_float4(fmaxf(c.x, d.x), fmaxf(c.y, d.y), fmaxf(c.z, d.z), 0.f);
+}
+__device__ __forceinline__ void range_box(const float4* __restrict__ rmin, const float4* __restrict__ rmax, uint n, uint a, uint b, float4& mn, float4& mx) {
+    uint len = b - a + 1u, k = 31u - (uint)__clz((int)len);
+    size_t base = (size_t)k * n; uint j = b + 1u - (1u << k);
+    float4 m0 = rmin[base + a], m1 = rmin[base + j], x0 = rmax[base + a], x1 = rmax[base + j];
+    mn = make_float4(fminf(m0.x, m1.x), fminf(m0.y, m1.y), fminf(m0.z, m1.z), 0.f);
+    mx = make_float4(fmaxf(x0.x, x1.x), fmaxf(x0.y, x1.y), fmaxf(x0.z, x1.z), 0.f);
+}
+__global__ void __launch_bounds__(256) k_node_boxes(uint n, const uint* __restrict__ childL, const uint* __restrict__ rangeFirst, const uint* __restrict__ rangeLast,
+                                                    const float4* __restrict__ rmin, const float4* __restrict__ rmax,
+                                                    float4* __restrict__ boxLmin, float4* __restrict__ boxLmax, float4* __restrict__ boxRmin, float4* __restrict__ boxRmax) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (n == 1u) { if (i == 0u) { boxLmin[0] = rmin[0]; boxLmax[0] = rmax[0]; } return; }
+    if (i >= n - 1u) return;
+    uint first = rangeFirst[i], last = rangeLast[i], gamma = childL[i] & 0x7FFFFFFFu;      // Karras: the left child ends at the split position, which is its own index
+    float4 mn, mx;
+    range_box(rmin, rmax, n, first, gamma, mn, mx); boxLmin[i] = mn; boxLmax[i] = mx;
+    range_box(rmin, rmax, n, gamma + 1u, last, mn, mx); boxRmin[i] = mn; boxRmax[i] = mx;
 }
 
 __device__ __forceinline__ void pad_box(float3& mn, float3& mx, float scenePad) {
@@ -269,6 +310,7 @@ hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
     PT_HIP_TRY(hipMalloc(&b.tickets, 4 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.boxLmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxLmax, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmax, 16 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.sceneBounds, 32)); PT_HIP_TRY(hipMalloc(&b.nodes, sizeof(BvhNode) * (size_t)n));
+    if (n <= PT_RANGE_TABLE_MAX_TRIS) { b.rangeLevels = 32u - (uint)__builtin_clz(n); PT_HIP_TRY(hipMalloc(&b.rangeMin, 16 * (size_t)n * b.rangeLevels)); PT_HIP_TRY(hipMalloc(&b.rangeMax, 16 * (size_t)n * b.rangeLevels)); }
     PT_HIP_TRY(hipMalloc(&b.alphaRecs, sizeof(AlphaRec) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.primToSlot, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.nodes8, sizeof(Bvh8Node) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelA, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelB, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.wideCounter, 16));
     size_t tmp = 0;
     PT_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64));
@@ -277,14 +319,21 @@ hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
 }
 void bvh_free(BvhBuildBuffers& b) {
     void* ps[] = {b.triWorld, b.triSorted, b.keys, b.keysSorted, b.prims, b.primsSorted, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast, b.tickets,
-                  b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter, b.alphaRecs, b.primToSlot};
+                  b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter, b.alphaRecs, b.primToSlot, b.rangeMin, b.rangeMax};
     for (void* p : ps) if (p) (void)hipFree(p);
     __builtin_memset(&b, 0, sizeof(b));
 }
 static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {
     uint g = (n + 255u) / 256u;
-    PT_HIP_TRY(hipMemsetAsync(b.tickets, 0, 4 * (size_t)(n < 2 ? 2 : n), st));
-    hipLaunchKernelGGL(k_bounds, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.childL, b.parent, b.leafParent, b.tickets, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax);
+    if (b.rangeMin) {
+        hipLaunchKernelGGL(k_leaf_boxes, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.rangeMin, b.rangeMax);
+        for (uint k = 1; k < b.rangeLevels && (1u << k) <= n; k++)
+            hipLaunchKernelGGL(k_range_level, dim3(g), dim3(256), 0, st, n, 1u << (k - 1), b.rangeMin + (size_t)(k - 1) * n, b.rangeMax + (size_t)(k - 1) * n, b.rangeMin + (size_t)k * n, b.rangeMax + (size_t)k * n);
+        hipLaunchKernelGGL(k_node_boxes, dim3(g), dim3(256), 0, st, n, b.childL, b.rangeFirst, b.rangeLast, b.rangeMin, b.rangeMax, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax);
+    } else {
+        PT_HIP_TRY(hipMemsetAsync(b.tickets, 0, 4 * (size_t)(n < 2 ? 2 : n), st));
+        hipLaunchKernelGGL(k_bounds, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.childL, b.parent, b.leafParent, b.tickets, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax);
+    }
     hipLaunchKernelGGL(k_alpha_records, dim3(g), dim3(256), 0, st, sc, b.triSorted, n, b.alphaRecs, b.primToSlot);
     hipLaunchKernelGGL(k_emit, dim3(g), dim3(256), 0, st, n, b.childL, b.childR, b.rangeFirst, b.rangeLast, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes);
     // BVH8 collapse, level by level (the per-level node count comes back to the host: a build step, not the hot path)
