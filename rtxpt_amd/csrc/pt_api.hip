@@ -828,7 +828,7 @@ int32_t pt_get_scene_info(pt_context* c, uint32_t* nTris, uint32_t* nNodes, uint
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
     int r = prepare(c); if (r != PT_OK) return r;
-    if (nTris) *nTris = c->numTris; if (nNodes) *nNodes = c->numTris ? c->numTris - 1 : 0; if (nInst) *nInst = (uint32_t)c->instances.size(); if (nMat) *nMat = (uint32_t)c->materials.size();
+    if (nTris) *nTris = c->numTris; if (nNodes) *nNodes = c->numTris ? c->bvh.numNodes8 : 0;      /* BVH8 nodes */ if (nInst) *nInst = (uint32_t)c->instances.size(); if (nMat) *nMat = (uint32_t)c->materials.size();
     return PT_OK;
 }
 int32_t pt_probe(pt_context* c, int32_t kind, const void* in, size_t inBytes, void* out, size_t outBytes, uint32_t n) {
