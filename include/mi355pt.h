@@ -99,7 +99,7 @@ typedef struct PtSettings {
     float    texLODBias;
     float    fireflyFilterThreshold;        /* 0 = disabled */
     float    envMapDiffuseSampleMIPLevel;
-    uint32_t NEEEnabled, NEEType, NEECandidateSamples, NEEFullSamples;
+    uint32_t NEEEnabled, NEEType, NEECandidateSamples, NEEFullSamples;   /* NEEFullSamples: 0..63 (clamped like RTXPT_LIGHTING_MAX_SAMPLE_COUNT); 1 is the fast path */
     uint32_t enableRussianRoulette;
     uint32_t nestedDielectricsQuality;      /* RTXPT_NESTED_DIELECTRICS_QUALITY 0/1/2 */
     uint32_t enableLDSamplerForBSDF;

@@ -84,7 +84,7 @@ struct pt_context {
     std::vector<float> hostRadiance; bool countersEnabled = false;
     bool geomDirty = true, lightsDirty = true, texDirty = true;
     double buildMs = 0, refitMs = 0, lightBakeMs = 0;
-    uint poolCapacity = 0;
+    uint poolCapacity = 0; size_t shadowCapacity = 0;
 };
 
 namespace {
@@ -361,14 +361,17 @@ int prepare(pt_context* c) {
     if (c->lightsDirty) { int r = bake_lights(c); if (r != PT_OK) return r; }
     return PT_OK;
 }
-int ensure_pool(pt_context* c, uint n) {
-    if (n <= c->poolCapacity) return PT_OK;
+int ensure_pool(pt_context* c, uint n, uint shadowPerPath) {      // shadowPerPath: shadow-queue entries a path vertex may emit (NEEFullSamples)
+    if (n <= c->poolCapacity && (size_t)n * shadowPerPath <= c->shadowCapacity) return PT_OK;
+    if (n < c->poolCapacity) n = c->poolCapacity;
+    const size_t ns = (size_t)n * shadowPerPath;
+    if (ns > 0xF0000000ull) return fail(c, PT_ERROR_INVALID_ARGUMENT, "too many shadow-queue entries in one pt_render call (paths x NEEFullSamples)");
     PT_CHECK_HIP(c, c->dS0.resize(n)); PT_CHECK_HIP(c, c->dS1.resize(n)); PT_CHECK_HIP(c, c->dS2.resize(n)); PT_CHECK_HIP(c, c->dS3.resize(n)); PT_CHECK_HIP(c, c->dS4.resize(n));
     PT_CHECK_HIP(c, c->dHit.resize(n)); PT_CHECK_HIP(c, c->dQueue[0].resize(n)); PT_CHECK_HIP(c, c->dQueue[1].resize(n));
-    PT_CHECK_HIP(c, c->dSq0.resize(n)); PT_CHECK_HIP(c, c->dSq1.resize(n)); PT_CHECK_HIP(c, c->dSq2.resize(n));
-    PT_CHECK_HIP(c, c->dBestKey.resize(n)); PT_CHECK_HIP(c, c->dResolveList.resize(n));
+    PT_CHECK_HIP(c, c->dSq0.resize(ns)); PT_CHECK_HIP(c, c->dSq1.resize(ns)); PT_CHECK_HIP(c, c->dSq2.resize(ns));
+    PT_CHECK_HIP(c, c->dBestKey.resize(ns)); PT_CHECK_HIP(c, c->dResolveList.resize(ns));
     PT_CHECK_HIP(c, c->dTaskQ.resize((size_t)PT_PIPELINE_BATCHES * 2 * TASK_QUEUE_CAPACITY)); PT_CHECK_HIP(c, c->dTravCounts.resize(PT_PIPELINE_BATCHES * 4));
-    c->poolCapacity = n;
+    c->poolCapacity = n; c->shadowCapacity = ns;
     return PT_OK;
 }
 
@@ -544,7 +547,6 @@ int32_t pt_default_settings(::PtSettings* s) {
 }
 int32_t pt_set_settings(pt_context* c, const ::PtSettings* s) {
     if (!c || !s) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
-    if (s->NEEEnabled && s->NEEFullSamples != 1) return fail(c, PT_ERROR_UNSUPPORTED, "NEEFullSamples must be 1 (one shadow-queue entry per path vertex)");
     if (s->NEEType > 1) return fail(c, PT_ERROR_UNSUPPORTED, "NEEType 2 (NEE-AT temporal feedback) is out of scope; use 0 (uniform) or 1 (power)");
     if (s->NEECandidateSamples == 0 || s->NEECandidateSamples > 63) return fail(c, PT_ERROR_INVALID_ARGUMENT, "NEECandidateSamples must be in [1,63]");
     if (s->nestedDielectricsQuality > 2 || (s->diffuseBrdf != 0 && s->diffuseBrdf != 2) || s->bounceCount > 96) return fail(c, PT_ERROR_INVALID_ARGUMENT, "setting out of range");
@@ -609,8 +611,12 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     uint total = numOwned * count;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (total == 0) { c->accumCount += count; return PT_OK; }
-    r = ensure_pool(c, total); if (r != PT_OK) return r;
+    const uint neeSamples = c->S.NEEFullSamples < 63u ? c->S.NEEFullSamples : 63u;          // min(RTXPT_LIGHTING_MAX_SAMPLE_COUNT, NEEFullSamples), PathTracerNEE.hlsli:312
+    const uint shadowGroup = (c->S.NEEEnabled && neeSamples > 1u) ? neeSamples : 0u;            // 0: one shadow-queue entry per path vertex, written by k_shade itself
+    const uint shadowPerPath = shadowGroup ? shadowGroup : 1u;
+    r = ensure_pool(c, total, shadowPerPath); if (r != PT_OK) return r;
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
+    if (neeSamples == 0u) k.S.NEEEnabled = 0;            // `applyNEE &= fullSamples > 0` (PathTracerNEE.hlsli:322): the vertices behave as without NEE; the light tables stay as baked
 
     // The owned pixels are traced as up to PT_PIPELINE_BATCHES independent sub-frame batches, each on its own stream. Paths never interact, so this changes nothing in the
     // result; it lets the latency-bound k_shade of one batch overlap the VALU-bound traversal of the other and hides the ~0.5 ms drain at the
@@ -630,12 +636,13 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.pixFirst = (uint)((unsigned long long)numOwned * b / numBatches); t.numPix = (uint)((unsigned long long)numOwned * (b + 1) / numBatches) - t.pixFirst;
         t.total = t.numPix * count; t.base = t.pixFirst * count; t.st = c->streams[b]; t.wc = c->dCounters.p + b; t.hwc = c->hostCounters + b;
         t.pool = PathPool{c->dS0.p + t.base, c->dS1.p + t.base, c->dS2.p + t.base, c->dS3.p + t.base, c->dS4.p + t.base, c->dHit.p + t.base};
-        t.sq = ShadowQueue{c->dSq0.p + t.base, c->dSq1.p + t.base, c->dSq2.p + t.base};
+        const size_t sbase = (size_t)t.base * shadowPerPath;
+        t.sq = ShadowQueue{c->dSq0.p + sbase, c->dSq1.p + sbase, c->dSq2.p + sbase, shadowGroup};
         t.queue[0] = c->dQueue[0].p + t.base; t.queue[1] = c->dQueue[1].p + t.base;
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;
         t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + 4 * b;
-        t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + t.base; t.aux.resolveList = c->dResolveList.p + t.base; t.aux.primToSlot = c->bvh.primToSlot;
+        t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
         memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
         t.active = t.total;
     }
@@ -673,7 +680,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (!t.waiting) continue;
             PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
             uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
-            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.aux, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2}); t.shadowRays += nShadow; }
+            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.aux, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2}); if (!shadowGroup) t.shadowRays += nShadow; }
             t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
             if (t.active && t.iterations < maxIter) any = true;
         }
@@ -697,7 +704,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b]; const WaveCounters& h = *t.hwc;
             for (auto& sp : t.spans) { float m = 0; (void)hipEventElapsedTime(&m, t.ev[sp.a], t.ev[sp.b]); if (sp.kind == 0) { stats->extendKernelMs += m; stats->extendLaunches++; } else if (sp.kind == 1) stats->shadeKernelMs += m; else stats->shadowKernelMs += m; }
-            stats->extendRays += t.extendRays; stats->shadowRays += t.shadowRays; stats->hits += h.hits; stats->nodeVisitsExtend += h.nodeVisitsExt; stats->triTestsExtend += h.triTestsExt;
+            stats->extendRays += t.extendRays; stats->shadowRays += shadowGroup ? h.shadowValid : t.shadowRays; stats->hits += h.hits; stats->nodeVisitsExtend += h.nodeVisitsExt; stats->triTestsExtend += h.triTestsExt;
             stats->nodeVisitsShadow += h.nodeVisitsSh; stats->triTestsShadow += h.triTestsSh;
             stats->leafVisitsExtend += h.leafVisitsExt; stats->waveItersExtend += h.itersExt; stats->leafVisitsShadow += h.leafVisitsSh; stats->waveItersShadow += h.itersSh;
             for (int q = 0; q < 4; q++) stats->extendPhaseCycles[q] += h.phaseCycExt[q];

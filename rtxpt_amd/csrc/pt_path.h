@@ -123,6 +123,9 @@ struct LightSample {
 struct SurfaceData { ShadingData shadingData; StandardBSDF bsdf; float interiorIoR; uint neeTriangleLightIndex; };
 // what k_shade hands to the shadow queue (the deferred half of ProcessLightSample)
 struct ShadowRequest { bool valid; float3 origin, dir; float tmax; float3 radiance; };
+// NEEFullSamples != 1 (HandleNEE_MultipleSamples, PathTracerNEE.hlsli:277-301): every path vertex that applies NEE reserves a group of fullSamples
+// consecutive shadow-queue entries (sample s at base + s, samples without a light marked tmax < 0) and k_resolve_nee folds the visible ones in sample order.
+struct ShadowSink { float4* q0; float4* q1; float4* q2; uint* count; unsigned long long* valid; uint pathIndex; };
 
 // PathTracerHelpers.hlsli:164-219
 static inline float ComputeRayConeSpreadAngleExpansionByScatterPDF(float bsdfScatterPdf, float growthFactor) {
@@ -468,40 +471,57 @@ struct PathKernelContext {
         cand.Li = cand.Li * (1.0f / (candWeight / weightSum));
         return cand;
     }
-    // HandleNEE (PathTracerNEE.hlsli:303-346) with ProcessLightSample (:185-275) split at the visibility ray. NEEFullSamples == 1.
-    uint HandleNEE(const PathState& pre, const ShadingData& sd, const StandardBSDF& bsdf, UniformSampleSequenceGenerator& sg, ShadowRequest& req) const {
+    // HandleNEE (PathTracerNEE.hlsli:303-346) / HandleNEE_MultipleSamples (:277-301) with ProcessLightSample (:185-275) split at the visibility ray.
+    // MULTI == false is NEEFullSamples == 1: the one request goes back to k_shade through `req`. MULTI: the requests are written to the sink's group.
+    template <bool MULTI>
+    uint HandleNEE(const PathState& pre, const ShadingData& sd, const StandardBSDF& bsdf, UniformSampleSequenceGenerator& sg, ShadowRequest& req, const ShadowSink* sink) const {
         req.valid = false;
         LightSampler lightSampler; lightSampler.T = &sc.lights;
-        const uint fullSamples = 1;
+        const uint fullSamples = MULTI ? (S.NEEFullSamples < 63u ? S.NEEFullSamples : 63u) : 1u;      // min(RTXPT_LIGHTING_MAX_SAMPLE_COUNT, NEEFullSamples)
         bool hasNonDeltaLobes = (bsdf.getLobes() & Lobe_NonDelta) != 0;
-        bool applyNEE = hasNonDeltaLobes && !lightSampler.IsEmpty();
+        bool applyNEE = hasNonDeltaLobes && !lightSampler.IsEmpty() && fullSamples > 0;
         if (!applyNEE) return NEEBSDFMISInfo::empty().Pack16bit();
         uint candidateSampleCount = S.NEECandidateSamples;
         NEEBSDFMISInfo info; info.LightSamplingEnabled = true; info.LightSamplingIsSSC = false; info.CandidateSamples = candidateSampleCount; info.FullSamples = fullSamples;
-        LightSample ls = GenerateLightSample(lightSampler, sd, bsdf, candidateSampleCount, sg);
-        if (ls.Valid()) {
-            float faceSide = dot(sd.N, ls.Direction) >= 0 ? 1.f : -1.f;
-            float3 o = ComputeRayOrigin(sd.posW, sd.faceNCorrected * faceSide);
-            float fadeOut = (sd.shadowNoLFadeout > 0) ? saturate((dot(ls.Direction, sd.vertexN) - sd.shadowNoLFadeout) / (2.0f * sd.shadowNoLFadeout)) : 1.0f;
-            float globalCount = (float)candidateSampleCount;
-            float thisPdf = ls.SelectionPdf, otherPdf = 0.f, thisCount = globalCount;
-            float wrsMIS = EvalMIS_Balance(1, thisPdf, 1, otherPdf);
-            wrsMIS = wrsMIS / thisCount;
-            float scatterPdfForDir = bsdf.evalPdf(sd, ls.Direction);
-            float lightAvgPdf = (thisPdf + otherPdf) * (float)fullSamples;
-            float pathMIS = EvalMIS_Balance(1, lightAvgPdf * ls.SolidAnglePdf, 1, ls.LightSampleableByBSDF ? scatterPdfForDir : 0.f);
-            float3 Li = ls.Li * (fadeOut * wrsMIS * pathMIS / (float)fullSamples);
-            float4 bsdfThp = bsdf.eval(sd, ls.Direction);
-            float3 radiance = xyz(bsdfThp) * Li;
-            float radianceAvg = Average(radiance);
-            if (S.fireflyFilterThreshold != 0) {
-                float pdf = ls.SelectionPdf * ls.SolidAnglePdf;
-                float k = ComputeNewScatterFireflyFilterK(pre.GetFireflyFilterK(), pdf, 1.0f);
-                radiance = radiance * FireflyFilterShort(radianceAvg, S.fireflyFilterThreshold, k);
+        uint base = 0, numValid = 0;
+        if (MULTI) base = __hip_atomic_fetch_add(sink->count, fullSamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint s = 0; s < fullSamples; s++) {
+            LightSample ls = GenerateLightSample(lightSampler, sd, bsdf, candidateSampleCount, sg);
+            bool valid = ls.Valid();
+            if (valid) {
+                float faceSide = dot(sd.N, ls.Direction) >= 0 ? 1.f : -1.f;
+                float3 o = ComputeRayOrigin(sd.posW, sd.faceNCorrected * faceSide);
+                float fadeOut = (sd.shadowNoLFadeout > 0) ? saturate((dot(ls.Direction, sd.vertexN) - sd.shadowNoLFadeout) / (2.0f * sd.shadowNoLFadeout)) : 1.0f;
+                float globalCount = (float)candidateSampleCount;
+                float thisPdf = ls.SelectionPdf, otherPdf = 0.f, thisCount = globalCount;
+                float wrsMIS = EvalMIS_Balance(1, thisPdf, 1, otherPdf);
+                wrsMIS = wrsMIS / thisCount;
+                float scatterPdfForDir = bsdf.evalPdf(sd, ls.Direction);
+                float lightAvgPdf = (thisPdf + otherPdf) * (float)fullSamples;
+                float pathMIS = EvalMIS_Balance(1, lightAvgPdf * ls.SolidAnglePdf, 1, ls.LightSampleableByBSDF ? scatterPdfForDir : 0.f);
+                float3 Li = ls.Li * (fadeOut * wrsMIS * pathMIS / (float)fullSamples);
+                float4 bsdfThp = bsdf.eval(sd, ls.Direction);
+                float3 radiance = xyz(bsdfThp) * Li;
+                float radianceAvg = Average(radiance);
+                if (S.fireflyFilterThreshold != 0) {
+                    float pdf = ls.SelectionPdf * ls.SolidAnglePdf;
+                    float k = ComputeNewScatterFireflyFilterK(pre.GetFireflyFilterK(), pdf, 1.0f);
+                    radiance = radiance * FireflyFilterShort(radianceAvg, S.fireflyFilterThreshold, k);
+                }
+                radiance = radiance * pre.GetThp();
+                if (MULTI) {
+                    sink->q0[base + s] = make_float4(o.x, o.y, o.z, ls.Distance * 0.9985f);
+                    sink->q1[base + s] = make_float4(ls.Direction.x, ls.Direction.y, ls.Direction.z, asfloat(sink->pathIndex));
+                    sink->q2[base + s] = make_float4(radiance.x, radiance.y, radiance.z, 0.f);
+                    numValid++;
+                } else { req.valid = true; req.origin = o; req.dir = ls.Direction; req.tmax = ls.Distance * 0.9985f; req.radiance = radiance; }
+            } else if (MULTI) {                 // no light sample: an entry that no traversal step accepts and that contributes nothing
+                sink->q0[base + s] = make_float4(0.f, 0.f, 0.f, -1.0f);
+                sink->q1[base + s] = make_float4(0.57735026f, 0.57735026f, 0.57735026f, asfloat(sink->pathIndex));
+                sink->q2[base + s] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            radiance = radiance * pre.GetThp();
-            req.valid = true; req.origin = o; req.dir = ls.Direction; req.tmax = ls.Distance * 0.9985f; req.radiance = radiance;
         }
+        if (MULTI && numValid) (void)__hip_atomic_fetch_add(sink->valid, (unsigned long long)numValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return info.Pack16bit();
     }
     bool HandleRussianRoulette(PathState& path, UniformSampleSequenceGenerator& sg) const {             // PathTracer.hlsli:182-208
@@ -514,7 +534,8 @@ struct PathKernelContext {
         return false;
     }
     // PathTracer.hlsli:505-762 (reference mode), shadow test deferred through `req`
-    __attribute__((always_inline)) void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req) const {
+    template <bool MULTI>
+    __attribute__((always_inline)) void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req, const ShadowSink* sink) const {
         req.valid = false;
         const float3 rayOrigin = path.origin, rayDir = path.dir;
         UpdatePathTravelled(path, hit.t);
@@ -547,7 +568,7 @@ struct PathKernelContext {
         UniformSampleSequenceGenerator uniformSG = UniformSampleSequenceGenerator::make(vb, SGES_Base);
         const PathState preScatterPath = path;
         bool scatterValid = GenerateScatterRay(sd, bsdf, path, vb);
-        uint misPacked = S.NEEEnabled ? HandleNEE(preScatterPath, sd, bsdf, uniformSG, req) : NEEBSDFMISInfo::empty().Pack16bit();
+        uint misPacked = S.NEEEnabled ? HandleNEE<MULTI>(preScatterPath, sd, bsdf, uniformSG, req, sink) : NEEBSDFMISInfo::empty().Pack16bit();
         path.SetPackedMISInfo_ThpRuRuCorrection(misPacked, path.GetThpRuRuCorrection());
         if (!scatterValid) path.terminate();
         bool shouldTerminate = HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces));
@@ -555,14 +576,18 @@ struct PathKernelContext {
         if (shouldTerminate) path.setFlag(PF_terminateAtNextBounce);
     }
     // the deferred half: NEEResult::AccumulateRadiance (fp16, PathTracerTypes.hlsli:170-207) then AccumulatePathRadiance (PathTracer.hlsli:722-746)
-    static void ResolveShadow(uint pack45[2], float3 radiance) {
-        uint r0 = Fp32ToFp16(make_float2(0.f + radiance.x, 0.f + radiance.y)), r1 = Fp32ToFp16(make_float2(0.f + radiance.z, 0.f));
-        float2 a = Fp16ToFp32(r0), b = Fp16ToFp32(r1);
+    static void NeeAccumulate(uint nee[2], float3 radiance) {                       // NEEResult::AccumulateRadiance (the spec-average lane is not used in reference mode)
+        float2 a = Fp16ToFp32(nee[0]), b = Fp16ToFp32(nee[1]);
+        nee[0] = Fp32ToFp16(make_float2(a.x + radiance.x, a.y + radiance.y)); nee[1] = Fp32ToFp16(make_float2(b.x + radiance.z, b.y + 0.f));
+    }
+    static void NeeCommit(uint pack45[2], const uint nee[2]) {                      // HandleHit: `if any(neeResult > 0) AccumulatePathRadiance`
+        float2 a = Fp16ToFp32(nee[0]), b = Fp16ToFp32(nee[1]);
         if (!(a.x > 0 || a.y > 0 || b.x > 0)) return;
         float2 l0 = Fp16ToFp32(pack45[0]), l1 = Fp16ToFp32(pack45[1]);
         pack45[0] = Fp32ToFp16NoClamp(make_float2(clampf(l0.x + a.x, 0, HLF_MAX), clampf(l0.y + a.y, 0, HLF_MAX)));
         pack45[1] = Fp32ToFp16NoClamp(make_float2(clampf(l1.x + b.x, 0, HLF_MAX), clampf(l1.y + 0.f, 0, HLF_MAX)));
     }
+    static void ResolveShadow(uint pack45[2], float3 radiance) { uint nee[2] = {0u, 0u}; NeeAccumulate(nee, radiance); NeeCommit(pack45, nee); }
 };
 
 #pragma clang force_cuda_host_device end

@@ -17,10 +17,11 @@
 namespace ptk {
 
 struct PathPool { uint4* s0; uint4* s1; uint4* s2; uint4* s3; uint4* s4; uint4* hit; };
-struct ShadowQueue { float4* q0; float4* q1; float4* q2; };
+struct ShadowQueue { float4* q0; float4* q1; float4* q2; uint group; };        // group: 0 = one entry per path vertex (NEEFullSamples 1), else entries come in groups of `group` (pt_path.h ShadowSink)
 struct WaveCounters {           // device-resident counters / stats (one 256 B block)
     uint extendCount[2]; uint shadowCount; uint overflow;
     unsigned long long hits, nodeVisitsExt, triTestsExt, nodeVisitsSh, triTestsSh, leafVisitsExt, itersExt, leafVisitsSh, itersSh, phaseCycExt[4], leafBlocksExt, eventsExt[8], itersMaxExt, rayIterHistExt[16]; uint longRayCount, _padLong; float longRays[32][8];
+    unsigned long long shadowValid;     // grouped shadow queue: entries that carry a light sample (= shadow rays in the reference's sense)
 };
 
 // straggler splitting (pt_traverse8.h): per pipelined batch, two task queues (ping-pong), the per-ray merge keys and the list of rays to resolve.

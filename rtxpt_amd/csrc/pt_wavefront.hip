@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
 #ifndef PT_SHADE_MIN_BLOCKS
 #define PT_SHADE_MIN_BLOCKS 1
 #endif
+template <bool MULTI>
 __global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PathKernelContext k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
                                                uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc) {
     const uint count = *countInPtr;
@@ -146,14 +147,18 @@ __global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PathKernelCo
         uint4 hr = pool.hit[p];
         HitInfo h; h.t = asfloat(hr.x); h.prim = hr.y; h.u = asfloat(hr.z); h.v = asfloat(hr.w);
         if (h.prim == 0xFFFFFFFFu) k.HandleMiss(path, path.dir, kMaxRayTravel);
-        else { isHit = true; k.HandleHit(path, h, req); }
+        else {
+            isHit = true;
+            if (MULTI) { ShadowSink sink{sq.q0, sq.q1, sq.q2, &wc->shadowCount, &wc->shadowValid, p}; k.HandleHit<true>(path, h, req, &sink); }
+            else k.HandleHit<false>(path, h, req, nullptr);
+        }
         store_path(pool, p, path);
         alive = path.isActive();
     }
     uint slot = wave_append(alive, countOutPtr);
     if (alive) queueOut[slot] = p;
-    uint sslot = wave_append(req.valid, &wc->shadowCount);
-    if (req.valid) {
+    uint sslot = MULTI ? 0u : wave_append(req.valid, &wc->shadowCount);
+    if (!MULTI && req.valid) {
         sq.q0[sslot] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
         sq.q1[sslot] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
         sq.q2[sslot] = make_float4(req.radiance.x, req.radiance.y, req.radiance.z, 0.f);
@@ -161,7 +166,9 @@ __global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PathKernelCo
     wave_add64(isHit ? 1ull : 0ull, &wc->hits);
 }
 
+template <bool GROUPED>
 __device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, uint i) {           // visible == the deferred NEE contribution lands (BridgeDonut:1026)
+    if (GROUPED) { reinterpret_cast<float*>(sq.q2 + i)[3] = 1.0f; return; }                      // grouped queue: only mark, k_resolve_nee folds the group in sample order
     float4 r = sq.q2[i];
     uint p = asuint(sq.q1[i].w);
     uint4 c = pool.s2[p];
@@ -171,7 +178,7 @@ __device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, ui
     pool.s2[p] = c;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool GROUPED>
 __global__ void __launch_bounds__(T8_BLOCK) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
@@ -182,7 +189,7 @@ __global__ void __launch_bounds__(T8_BLOCK) k_shadow(DeviceScene sc, PathPool po
         o = make_float3(a.x, a.y, a.z); d = make_float3(b.x, b.y, b.z); tmin = 0.0f; tmax = a.w; startRef = 0u; bestT0 = a.w; bestPrim0 = 0xFFFFFFFFu;
         return i;
     };
-    auto commit = [&](uint i, const HitInfo& h) { if (h.prim == 0xFFFFFFFFu) shadow_visible(pool, sq, i); };      // occluded: nothing is committed
+    auto commit = [&](uint i, const HitInfo& h) { if (h.prim == 0xFFFFFFFFu) shadow_visible<GROUPED>(pool, sq, i); };      // occluded: nothing is committed
     // a split shadow ray: "visible so far"; its sub-trees may set the flag, k_resolve_shadow applies the contribution if none did
     auto publish = [&](uint i, float, uint) { aux.bestKey[i] = 0ull; aux.resolveList[atomicAdd(&aux.counts[2], 1u)] = i; };
     traverse8_persistent<true, COUNT, false, false, true>(sc, count, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
@@ -211,11 +218,32 @@ __global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, Shado
     traverse8_persistent<true, false, false, true, !FINAL>(sc, per * 64u, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[IN ^ 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
 }
 
+template <bool GROUPED>
 __global__ void __launch_bounds__(256) k_resolve_shadow(PathPool pool, ShadowQueue sq, TravAux aux) {
     const uint n = aux.counts[2];
     for (uint k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
         uint i = aux.resolveList[k];
-        if (aux.bestKey[i] == 0ull) shadow_visible(pool, sq, i);
+        if (aux.bestKey[i] == 0ull) shadow_visible<GROUPED>(pool, sq, i);
+    }
+}
+
+// NEEFullSamples != 1: NEEResult accumulates the visible samples of a path vertex in sample order (fp16, PathTracerTypes.hlsli:170-207), then the
+// vertex adds the sum to the path once (PathTracer.hlsli:722-746). One thread per group of the shadow queue.
+__global__ void __launch_bounds__(256) k_resolve_nee(PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr) {
+    const uint groups = *countPtr / sq.group;
+    for (uint g = blockIdx.x * 256u + threadIdx.x; g < groups; g += gridDim.x * 256u) {
+        const uint first = g * sq.group;
+        uint nee[2] = {0u, 0u};
+        for (uint s = 0; s < sq.group; s++) {
+            float4 r = sq.q2[first + s];
+            if (r.w != 0.f) PathKernelContext::NeeAccumulate(nee, make_float3(r.x, r.y, r.z));
+        }
+        uint p = asuint(sq.q1[first].w);
+        uint4 c = pool.s2[p];
+        uint pack45[2] = {c.z, c.w};
+        PathKernelContext::NeeCommit(pack45, nee);
+        c.z = pack45[0]; c.w = pack45[1];
+        pool.s2[p] = c;
     }
 }
 
@@ -389,20 +417,24 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
     hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
 }
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, hipStream_t st) {
-    hipLaunchKernelGGL(k_shade, dim3((countIn + 255) / 256), dim3(256), 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+    if (sq.group) hipLaunchKernelGGL((k_shade<true>), dim3((countIn + 255) / 256), dim3(256), 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+    else hipLaunchKernelGGL((k_shade<false>), dim3((countIn + 255) / 256), dim3(256), 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
 }
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
     uint g = grid_for(count, T8_BLOCK, T8_MAX_BLOCKS);
     (void)hipMemsetAsync(aux.counts, 0, 12, st);
-    if (counters) hipLaunchKernelGGL((k_shadow<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);
-    else hipLaunchKernelGGL((k_shadow<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);
+    if (sq.group) hipLaunchKernelGGL((k_shadow<false, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);       // (no traversal counters in the grouped mode)
+    else if (counters) hipLaunchKernelGGL((k_shadow<true, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);
+    else hipLaunchKernelGGL((k_shadow<false, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);
     hipLaunchKernelGGL((k_shadow_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     (void)hipMemsetAsync(aux.counts, 0, 4, st);
     hipLaunchKernelGGL((k_shadow_tasks<1, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     (void)hipMemsetAsync(aux.counts + 1, 0, 4, st);
     hipLaunchKernelGGL((k_shadow_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     hipLaunchKernelGGL((k_shadow_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
-    hipLaunchKernelGGL(k_resolve_shadow, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
+    if (sq.group) hipLaunchKernelGGL((k_resolve_shadow<true>), dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
+    else hipLaunchKernelGGL((k_resolve_shadow<false>), dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
+    if (sq.group) hipLaunchKernelGGL(k_resolve_nee, dim3(grid_for(count / sq.group, 256, 4096)), dim3(256), 0, st, pool, sq, countPtr);
 }
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3((numOwned + 255) / 256), dim3(256), 0, st, pool, ownedPixels, numOwned, spp, accum, accumCountBase, width);

@@ -77,6 +77,23 @@ def test_degenerate_settings(kw):
     _both(sc, cam, scenes.default_settings(**kw), 96, 54, first=0, count=2)
 
 
+@pytest.mark.parametrize("full", [0, 2, 3, 8, 100])
+def test_nee_multiple_full_samples(full):
+    """HandleNEE_MultipleSamples (PathTracerNEE.hlsli:277-301): grouped shadow queue, fp16 NEEResult accumulation in sample order; 100 clamps to 63."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.cornell_box("C2")
+    g, o, st = _both(sc, cam, scenes.default_settings(NEEFullSamples=full), 96, 54, first=1, count=2)
+    if full == 0: assert st["shadowRays"] == 0
+    # the bistro-like scene: alpha-tested occluders, emissive triangles + environment quads, stragglers split into sub-tree tasks
+    if full in (2, 8):
+        sc3, cam3 = scenes.bistro_like(scale=0.02, tex_size=128)
+        _both(sc3, cam3, scenes.default_settings(NEEFullSamples=full, NEECandidateSamples=3), 128, 72, first=0, count=1)
+    # switching back to one sample on the same context returns to the ungrouped queue
+    S1 = scenes.default_settings(); g.set_settings(S1); g.reset_accumulation(); g.render(1, 2)
+    o.set_settings(S1); o.reset_accumulation(); o.render(1, 2)
+    assert (g.radiance().view(np.uint32) == o.radiance().view(np.uint32)).all()
+
+
 def _overlap_scene(n_tris, seed):
     """n_tris large triangles through one region: every BVH level overlaps, so a central ray has to keep most children of every node."""
     pt, scenes, parallel, ptref = _imports()

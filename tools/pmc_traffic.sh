@@ -15,7 +15,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in sorted(glob.glob(d + "/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = "k_extend" if "k_extend<false>" in k or "k_extendILb0" in k else "k_shadow" if "k_shadow<false>" in k or "k_shadowILb0" in k else "k_shade" if "k_shade" in k else None
+        k = "k_extend" if "k_extend<false>" in k or "k_extendILb0" in k else "k_shadow" if "k_shadow<false, false>" in k or "k_shadowILb0ELb0" in k else "k_shade" if "k_shade" in k else None
         if not k: continue
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add((f, r["Dispatch_Id"]))
 out = {}
