@@ -60,7 +60,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
-    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; uint* hostSnapshots = nullptr; hipEvent_t snapEvents[PT_PIPELINE_BATCHES][2] = {}; bool serialKernels = false;   // second half-frame batch (pt_render pipelines two batches)
+    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -394,8 +394,6 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     c->streams[0] = c->stream;
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) if (hipStreamCreateWithFlags(&c->streams[b], hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     if (hipHostMalloc(&c->hostCounters, PT_PIPELINE_BATCHES * sizeof(WaveCounters), hipHostMallocDefault) != hipSuccess) { delete c; return PT_ERROR_HIP; }
-    if (hipHostMalloc(&c->hostSnapshots, PT_PIPELINE_BATCHES * 2 * 16, hipHostMallocDefault) != hipSuccess) { delete c; return PT_ERROR_HIP; }
-    for (int b = 0; b < PT_PIPELINE_BATCHES; b++) for (int q = 0; q < 2; q++) if (hipEventCreateWithFlags(&c->snapEvents[b][q], hipEventDisableTiming) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     c->serialKernels = desc && (desc->flags & PT_DEVICE_SERIAL_KERNELS);
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
@@ -413,7 +411,7 @@ int32_t pt_destroy(pt_context* c) {
     c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
-    (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters); (void)hipHostFree(c->hostSnapshots); for (int b = 0; b < PT_PIPELINE_BATCHES; b++) for (int q = 0; q < 2; q++) if (c->snapEvents[b][q]) (void)hipEventDestroy(c->snapEvents[b][q]);
+    (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
     delete c;
     return PT_OK;
 }
@@ -627,7 +625,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
-        uint cur = 0, bound = 0, iterations = 0, queued = 0, absorbed = 0, snapNext[2] = {0, 0}; unsigned long long extendRays = 0, shadowRays = 0;
+        uint cur = 0, active = 0, iterations = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false;
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         size_t mark() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
@@ -646,7 +644,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + 4 * b;
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
         memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
-        t.bound = t.total; t.extendRays = t.total; t.iterations = 1;
+        t.active = t.total;
     }
     if (numBatches > 1) PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // uploads issued on the main stream (prepare) must be visible to the second stream
     hipEvent_t frame0, frame1; PT_CHECK_HIP(c, hipEventCreate(&frame0)); PT_CHECK_HIP(c, hipEventCreate(&frame1));
@@ -659,41 +657,34 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     }
     // upper bound on extend passes: bounceCount+1 vertices plus rejected (nested dielectric) re-traces
     uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u));
-    // Run-ahead loop. Every kernel takes its item count from device memory, so the host only needs an upper bound for the grid sizes and a stop
-    // signal. Pass i of a batch (extend, shade, shadow) is queued without waiting for anything; its queue counts are copied to a pinned snapshot
-    // that is read two passes later, when it has long arrived: the number of live paths only shrinks, so the count after pass i bounds pass i+2,
-    // and a batch stops one (empty) pass after its queue ran dry. No stream ever waits for the host.
-    auto absorb = [&](Batch& t, uint b) -> int {                    // read the snapshot of pass t.absorbed
-        const uint i = t.absorbed, slot = i & 1u;
-        hipError_t e = hipEventSynchronize(c->snapEvents[b][slot]); if (e != hipSuccess) return (int)e;
-        const uint* sn = c->hostSnapshots + (b * 2u + slot) * 4u;     // {extendCount[0], extendCount[1], shadowCount, overflow}
-        const uint nextActive = sn[t.snapNext[slot]];
-        t.shadowRays += sn[2];
-        if (i + 1u < t.queued && nextActive) { t.extendRays += nextActive; t.iterations++; }
-        if (nextActive < t.bound) t.bound = nextActive;
-        t.absorbed++;
-        return 0;
-    };
-    for (uint it = 0; it < maxIter; it++) {
-        bool any = false;
+    bool any = true;
+    while (any) {
+        // phase 1: every live batch queues extend + shade and the read-back of its queue counts
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b];
-            if (t.bound == 0u) continue;
-            if (it >= 2u) { PT_CHECK_HIP(c, (hipError_t)absorb(t, b)); if (t.bound == 0u) continue; }      // feedback from pass it-2 (pass it-1 may still run, on an empty queue)
-            any = true;
-            const uint nxt = t.cur ^ 1u;
+            t.waiting = false;
+            if (!t.active || t.iterations >= maxIter) continue;
+            uint nxt = t.cur ^ 1u;
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->extendCount[nxt], 0, 4, t.st));
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st));
-            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.bound, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0});
-            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.bound, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1});
-            if (k.S.NEEEnabled) { launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, t.bound * shadowPerPath, t.wc, c->countersEnabled, t.aux, t.st); size_t e3 = t.mark(); t.spans.push_back({e2, e3, 2}); }
-            PT_CHECK_HIP(c, hipMemcpyAsync(c->hostSnapshots + (b * 2u + (it & 1u)) * 4u, t.wc, 16, hipMemcpyDeviceToHost, t.st));
-            PT_CHECK_HIP(c, hipEventRecord(c->snapEvents[b][it & 1u], t.st));
-            t.snapNext[it & 1u] = nxt; t.cur = nxt; t.queued++;
+            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0});
+            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1});
+            t.extendRays += t.active;
+            PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
+            t.waiting = true;
         }
-        if (!any) break;
+        // phase 2: as each batch's counts arrive, queue its shadow rays; the other batch keeps the GPU busy meanwhile
+        any = false;
+        for (uint b = 0; b < numBatches; b++) {
+            Batch& t = B[b];
+            if (!t.waiting) continue;
+            PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
+            uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
+            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.aux, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2}); if (!shadowGroup) t.shadowRays += nShadow; }
+            t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
+            if (t.active && t.iterations < maxIter) any = true;
+        }
     }
-    for (uint b = 0; b < numBatches; b++) while (B[b].absorbed < B[b].queued) PT_CHECK_HIP(c, (hipError_t)absorb(B[b], b));      // the last one or two passes of every batch
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
         launch_accumulate(t.pool, c->dOwned.p + t.pixFirst, t.numPix, count, c->dAccum.p, c->accumCount, c->width, t.st);
