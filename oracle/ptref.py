@@ -62,6 +62,47 @@ def refpin():
     return L
 
 
+_PIN_HLSL = os.path.join(os.path.dirname(_PIN), "librefpin_hlsl.so")
+
+
+def refpin_hlsl():
+    """Functions of the reference's .hlsli files compiled verbatim (oracle/refpin/hlsl_tu.py); None when unavailable."""
+    if not os.path.exists(_PIN_HLSL):
+        if os.path.isdir("/root/reference/Rtxpt/Shaders"):
+            build()
+        if not os.path.exists(_PIN_HLSL):
+            return None
+    return ctypes.CDLL(_PIN_HLSL)
+
+
+def pin_call(fn, inputs, reference=False):
+    """Evaluates pinned function `fn` (oracle/refpin/pin_fns.h) on rows of float32 inputs: the oracle's restatement, or the reference text itself."""
+    L = refpin_hlsl() if reference else lib()
+    if L is None:
+        return None
+    nin, nout = PIN_ARITY[fn]
+    a = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, nin)
+    out = np.zeros((a.shape[0], nout), np.float32)
+    f = L.refhlsl_call if reference else L.ptref_pin_call
+    f(ctypes.c_int(fn), a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(a.shape[0]), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def _pin_table():
+    """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "refpin", "pin_fns.h")).read()
+    names = re.findall(r"^\s*PIN_(\w+)(?:\s*=\s*0)?,", text, re.M)
+    names = [n for n in names if n != "COUNT"]
+    ar = re.search(r"kPinArity\[PIN_COUNT\]\[2\] = \{[^\n]*\n(.*?)\n\};", text, re.S).group(1)
+    pairs = [(int(a), int(b)) for a, b in re.findall(r"\{(\d+),\s*(\d+)\}", ar)]
+    assert len(names) == len(pairs), (len(names), len(pairs))
+    return names, pairs
+
+
+PIN_NAMES, PIN_ARITY = _pin_table()
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 

@@ -10,6 +10,7 @@
 //   Rtxpt/ProcessingPasses/AccumulationPass.hlsl:36-66 + Rtxpt/Sample.cpp:2770-2778   accumulation lerp, weight 1/(n+1)
 #include "pathtracer.h"
 #include "tonemap.h"
+#include "../refpin/pin_fns.h"
 #include <cstdio>
 #include <cstdlib>
 #ifdef _OPENMP
@@ -512,4 +513,38 @@ void ptref_tonemap(const float* rgba, uint32_t n, const ToneMapParams* p, uint32
     for (uint32_t i = 0; i < n; i++) out[i] = tm_pixel(*p, make_float4(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3]));
 }
 
+// the oracle's restatement of the functions pinned against reference text (oracle/refpin/pin_fns.h; tests/test_oracle_refpin_hlsl.py)
+void ptref_pin_call(int fn, const float* in, unsigned n, float* out) {
+    const int ni = kPinArity[fn][0], no = kPinArity[fn][1];
+    for (unsigned k = 0; k < n; k++) {
+        const float* a = in + (size_t)k * ni; float* o = out + (size_t)k * no;
+        switch (fn) {
+        case PIN_evalFresnelSchlick: o[0] = evalFresnelSchlick(a[0], a[1], a[2]); break;
+        case PIN_evalFresnelSchlick3: { float3 r = evalFresnelSchlick(make_float3(a[0], a[1], a[2]), a[3], a[4]); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case PIN_evalFresnelDielectric: { float ct = 0.f; o[0] = evalFresnelDielectric(a[0], a[1], ct); o[1] = ct; } break;
+        case PIN_evalNdfGGX: o[0] = evalNdfGGX(a[0], a[1]); break;
+        case PIN_evalPdfGGX_BVNDF: o[0] = evalPdfGGX_BVNDF(a[0], make_float3(a[1], a[2], a[3]), make_float3(a[4], a[5], a[6])); break;
+        case PIN_sampleGGX_BVNDF: { float3 r = sampleGGX_BVNDF(a[0], make_float3(a[1], a[2], a[3]), make_float2(a[4], a[5])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case PIN_evalLambdaGGX: o[0] = evalLambdaGGX(a[0], a[1]); break;
+        case PIN_evalMaskingSmithGGXCorrelated: o[0] = evalMaskingSmithGGXCorrelated(a[0], a[1], a[2]); break;
+        case PIN_ndir_to_oct_equal_area_unorm: { float2 r = ndir_to_oct_equal_area_unorm(make_float3(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; } break;
+        case PIN_oct_to_ndir_equal_area_unorm: { float3 r = oct_to_ndir_equal_area_unorm(make_float2(a[0], a[1])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case PIN_sample_disk: { float2 r = sample_disk(make_float2(a[0], a[1])); o[0] = r.x; o[1] = r.y; } break;
+        case PIN_sample_disk_concentric: { float2 r = sample_disk_concentric(make_float2(a[0], a[1])); o[0] = r.x; o[1] = r.y; } break;
+        case PIN_sample_cosine_hemisphere_concentric: { float pdf = 0.f; float3 r = sample_cosine_hemisphere_concentric(make_float2(a[0], a[1]), pdf); o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf; } break;
+        case PIN_perp_stark: { float3 r = perp_stark(make_float3(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case PIN_ComputeRayOrigin: { float3 r = ComputeRayOrigin(make_float3(a[0], a[1], a[2]), make_float3(a[3], a[4], a[5])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case PIN_FastSqrt: o[0] = FastSqrt(a[0]); break;
+        case PIN_FastACos: o[0] = FastACos(a[0]); break;
+        case PIN_ComputeRayConeSpreadAngleExpansionByScatterPDF: o[0] = ComputeRayConeSpreadAngleExpansionByScatterPDF(a[0], a[1]); break;
+        case PIN_ComputeNewScatterFireflyFilterK: o[0] = ComputeNewScatterFireflyFilterK(a[0], a[1], a[2]); break;
+        case PIN_FireflyFilter: { float3 r = FireflyFilter(make_float3(a[0], a[1], a[2]), a[3], a[4]); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case PIN_FireflyFilterShort: o[0] = FireflyFilterShort(a[0], a[1], a[2]); break;
+        case PIN_ComputeLowGrazingAngleFalloff: o[0] = ComputeLowGrazingAngleFalloff(make_float3(a[0], a[1], a[2]), make_float3(a[3], a[4], a[5]), a[6], a[7]); break;
+        default: break;
+        }
+    }
+}
+
 } // extern "C"
+

@@ -1,0 +1,140 @@
+// ORACLE pin (test infrastructure only): the HLSL vocabulary that lets g++ compile functions taken verbatim from the reference's .hlsli files
+// (oracle/refpin/hlsl_tu.py streams them from /root/reference into the compiler; nothing is copied into this repo).
+//
+// Everything whose result HLSL leaves to the implementation is mapped to the oracle's arithmetic contract (oracle/ptref/vec.h, dmath.h):
+// dot/normalize/length summation order, 1/sqrt for rsqrt, the dm_* transcendental functions, pow(x, 5) as repeated products, mad() unfused,
+// software fp16. What the pin therefore checks is the *restatement*: operation order, constants, branches and clamps of every pinned function.
+#pragma once
+#include <cstdint>
+#include <cmath>
+#include <type_traits>
+#include "../ptref/vec.h"
+#include "../ptref/dmath.h"
+
+namespace hl {
+typedef uint32_t uint;
+namespace P = ptref;
+
+template <class T> struct v2 { T x, y; v2() : x(), y() {} v2(T s) : x(s), y(s) {} v2(T a, T b) : x(a), y(b) {}
+    template <class U> explicit v2(const v2<U>& o) : x((T)o.x), y((T)o.y) {}
+    v2& xy_() { return *this; } v2 yx_() const { return v2(y, x); } v2 xx_() const { return v2(x, x); } };
+template <class T> struct v3 { T x, y, z; v3() : x(), y(), z() {} v3(T s) : x(s), y(s), z(s) {} v3(T a, T b, T c) : x(a), y(b), z(c) {}
+    v3(v2<T> a, T c) : x(a.x), y(a.y), z(c) {}
+    template <class A, class B, class C, class = typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value && std::is_arithmetic<C>::value && !(std::is_same<A, T>::value && std::is_same<B, T>::value && std::is_same<C, T>::value)>::type>
+    v3(A a, B b, C c) : x((T)a), y((T)b), z((T)c) {}
+    template <class U> explicit v3(const v3<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z) {}
+    v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> yx_() const { return v2<T>(y, x); } v2<T> xz_() const { return v2<T>(x, z); } v2<T> yz_() const { return v2<T>(y, z); }
+    v3& xyz_() { return *this; } const v3& xyz_() const { return *this; } v3& rgb_() { return *this; } const v3& rgb_() const { return *this; } };
+template <class T> struct v4 { T x, y, z, w; v4() : x(), y(), z(), w() {} v4(T s) : x(s), y(s), z(s), w(s) {} v4(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}
+    v4(v3<T> a, T d) : x(a.x), y(a.y), z(a.z), w(d) {} v4(v2<T> a, v2<T> b) : x(a.x), y(a.y), z(b.x), w(b.y) {}
+    v3<T>& xyz_() { return *reinterpret_cast<v3<T>*>(this); } v3<T> xyz_() const { return v3<T>(x, y, z); } v3<T>& rgb_() { return xyz_(); } v3<T> rgb_() const { return xyz_(); }
+    v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> zw_() const { return v2<T>(z, w); } };
+
+typedef v2<float> float2; typedef v3<float> float3; typedef v4<float> float4;
+typedef v2<int> int2; typedef v3<int> int3; typedef v4<int> int4;
+typedef v2<uint> uint2; typedef v3<uint> uint3; typedef v4<uint> uint4;
+typedef v2<bool> bool2; typedef v3<bool> bool3; typedef v4<bool> bool4;
+typedef float lpfloat; typedef float2 lpfloat2; typedef float3 lpfloat3; typedef float4 lpfloat4;      // RTXPT_LP_TYPES_USE_16BIT_PRECISION 0 (the build both sides of the parity fence restate)
+typedef uint lpuint;
+
+// scalar operand of a mixed vector/scalar expression: HLSL converts it to the vector's component type
+template <class T, class S> using if_arith = typename std::enable_if<std::is_arithmetic<S>::value, T>::type;
+
+#define HL_BINOP(op) \
+    template <class T> v2<T> operator op(v2<T> a, v2<T> b) { return v2<T>(a.x op b.x, a.y op b.y); } \
+    template <class T> v3<T> operator op(v3<T> a, v3<T> b) { return v3<T>(a.x op b.x, a.y op b.y, a.z op b.z); } \
+    template <class T> v4<T> operator op(v4<T> a, v4<T> b) { return v4<T>(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w); } \
+    template <class T, class S> if_arith<v2<T>, S> operator op(v2<T> a, S b) { return a op v2<T>((T)b); } \
+    template <class T, class S> if_arith<v3<T>, S> operator op(v3<T> a, S b) { return a op v3<T>((T)b); } \
+    template <class T, class S> if_arith<v4<T>, S> operator op(v4<T> a, S b) { return a op v4<T>((T)b); } \
+    template <class T, class S> if_arith<v2<T>, S> operator op(S a, v2<T> b) { return v2<T>((T)a) op b; } \
+    template <class T, class S> if_arith<v3<T>, S> operator op(S a, v3<T> b) { return v3<T>((T)a) op b; } \
+    template <class T, class S> if_arith<v4<T>, S> operator op(S a, v4<T> b) { return v4<T>((T)a) op b; } \
+    template <class T, class S> v2<T>& operator op##=(v2<T>& a, S b) { a = a op b; return a; } \
+    template <class T, class S> v3<T>& operator op##=(v3<T>& a, S b) { a = a op b; return a; } \
+    template <class T, class S> v4<T>& operator op##=(v4<T>& a, S b) { a = a op b; return a; }
+HL_BINOP(+) HL_BINOP(-) HL_BINOP(*) HL_BINOP(/)
+#undef HL_BINOP
+template <class T> v2<T> operator-(v2<T> a) { return v2<T>(-a.x, -a.y); }
+template <class T> v3<T> operator-(v3<T> a) { return v3<T>(-a.x, -a.y, -a.z); }
+template <class T> v4<T> operator-(v4<T> a) { return v4<T>(-a.x, -a.y, -a.z, -a.w); }
+#define HL_CMP(op) \
+    template <class T> bool2 operator op(v2<T> a, v2<T> b) { return bool2(a.x op b.x, a.y op b.y); } \
+    template <class T> bool3 operator op(v3<T> a, v3<T> b) { return bool3(a.x op b.x, a.y op b.y, a.z op b.z); } \
+    template <class T, class S> if_arith<bool2, S> operator op(v2<T> a, S b) { return a op v2<T>((T)b); } \
+    template <class T, class S> if_arith<bool3, S> operator op(v3<T> a, S b) { return a op v3<T>((T)b); }
+HL_CMP(<) HL_CMP(>) HL_CMP(<=) HL_CMP(>=) HL_CMP(==) HL_CMP(!=)
+#undef HL_CMP
+static inline bool any(bool2 b) { return b.x || b.y; } static inline bool any(bool3 b) { return b.x || b.y || b.z; }
+static inline bool all(bool2 b) { return b.x && b.y; } static inline bool all(bool3 b) { return b.x && b.y && b.z; }
+static inline bool any(float3 v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f; }
+template <class T> T select(bool c, T a, T b) { return c ? a : b; }
+template <class T> v2<T> select(bool2 c, v2<T> a, v2<T> b) { return v2<T>(c.x ? a.x : b.x, c.y ? a.y : b.y); }
+template <class T> v3<T> select(bool3 c, v3<T> a, v3<T> b) { return v3<T>(c.x ? a.x : b.x, c.y ? a.y : b.y, c.z ? a.z : b.z); }
+
+// ---- component-wise lifting of scalar functions
+#define HL_LIFT1(name) \
+    static inline float2 name(float2 a) { return float2(name(a.x), name(a.y)); } \
+    static inline float3 name(float3 a) { return float3(name(a.x), name(a.y), name(a.z)); } \
+    static inline float4 name(float4 a) { return float4(name(a.x), name(a.y), name(a.z), name(a.w)); }
+#define HL_LIFT2(name) \
+    static inline float2 name(float2 a, float2 b) { return float2(name(a.x, b.x), name(a.y, b.y)); } \
+    static inline float3 name(float3 a, float3 b) { return float3(name(a.x, b.x), name(a.y, b.y), name(a.z, b.z)); } \
+    static inline float4 name(float4 a, float4 b) { return float4(name(a.x, b.x), name(a.y, b.y), name(a.z, b.z), name(a.w, b.w)); } \
+    template <class S> if_arith<float2, S> name(float2 a, S b) { return name(a, float2((float)b)); } \
+    template <class S> if_arith<float3, S> name(float3 a, S b) { return name(a, float3((float)b)); } \
+    template <class S> if_arith<float3, S> name(S a, float3 b) { return name(float3((float)a), b); }
+
+// min / max: (a < b) ? a : b like the oracle's fminf_/fmaxf_; integer pairs stay integer
+template <class A, class B> typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value && !(std::is_integral<A>::value && std::is_integral<B>::value), float>::type
+    min(A a, B b) { return P::fminf_((float)a, (float)b); }
+template <class A, class B> typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value && !(std::is_integral<A>::value && std::is_integral<B>::value), float>::type
+    max(A a, B b) { return P::fmaxf_((float)a, (float)b); }
+template <class A, class B> typename std::enable_if<std::is_integral<A>::value && std::is_integral<B>::value, A>::type min(A a, B b) { return (a < (A)b) ? a : (A)b; }
+template <class A, class B> typename std::enable_if<std::is_integral<A>::value && std::is_integral<B>::value, A>::type max(A a, B b) { return (a > (A)b) ? a : (A)b; }
+HL_LIFT2(min) HL_LIFT2(max)
+static inline float abs(float v) { return fabsf(v); } static inline int abs(int v) { return v < 0 ? -v : v; } HL_LIFT1(abs)
+static inline float saturate(float v) { return P::saturate(v); } HL_LIFT1(saturate)
+template <class A, class B, class C> float clamp(A v, B lo, C hi) { return P::clampf((float)v, (float)lo, (float)hi); }
+static inline float3 clamp(float3 v, float lo, float hi) { return float3(clamp(v.x, lo, hi), clamp(v.y, lo, hi), clamp(v.z, lo, hi)); }
+static inline float3 clamp(float3 v, float3 lo, float3 hi) { return float3(clamp(v.x, lo.x, hi.x), clamp(v.y, lo.y, hi.y), clamp(v.z, lo.z, hi.z)); }
+static inline float sign(float v) { return P::signf_(v); } HL_LIFT1(sign)
+static inline float sqrt(float v) { return P::sqrtf_(v); } HL_LIFT1(sqrt)
+static inline float rsqrt(float v) { return 1.0f / P::sqrtf_(v); }
+static inline float rcp(float v) { return 1.0f / v; }
+static inline float floor(float v) { return P::dm_floor(v); } HL_LIFT1(floor)
+static inline float frac(float v) { return v - P::dm_floor(v); } HL_LIFT1(frac)
+static inline float sin(float v) { return P::dm_sin(v); } static inline float cos(float v) { return P::dm_cos(v); }
+static inline void sincos(float v, float& s, float& c) { P::dm_sincos(v, s, c); }
+static inline float exp2(float v) { return P::dm_exp2(v); } static inline float log2(float v) { return P::dm_log2(v); }
+static inline float exp(float v) { return P::dm_exp(v); } static inline float log(float v) { return P::dm_log(v); } HL_LIFT1(exp) HL_LIFT1(log)
+static inline float atan2(float y, float x) { return P::dm_atan2(y, x); }
+template <class E> float pow(float x, E e) { return ((float)e == 5.0f) ? P::dm_pow5(x) : P::dm_pow(x, (float)e); }      // pow(x, 5): the oracle's (x²·x²)·x
+template <class E> float3 pow(float3 x, E e) { return float3(pow(x.x, e), pow(x.y, e), pow(x.z, e)); }
+static inline float mad(float a, float b, float c) { return a * b + c; }                                                // unfused (-ffp-contract=off)
+static inline float lerp(float a, float b, float t) { return P::lerpf(a, b, t); }
+static inline float3 lerp(float3 a, float3 b, float t) { return a + (b - a) * t; }
+static inline float3 lerp(float3 a, float3 b, float3 t) { return a + (b - a) * t; }
+static inline float dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
+static inline float dot(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float3 cross(float3 a, float3 b) { return float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline float length(float2 a) { return sqrt(dot(a, a)); } static inline float length(float3 a) { return sqrt(dot(a, a)); }
+static inline float3 normalize(float3 a) { float il = 1.0f / sqrt(dot(a, a)); return a * il; }
+static inline float2 normalize(float2 a) { float il = 1.0f / sqrt(dot(a, a)); return a * il; }
+static inline bool isnan(float v) { return v != v; } static inline bool isinf(float v) { return std::isinf(v); }
+static inline uint asuint(float f) { return P::asuint(f); } static inline uint asuint(uint u) { return u; } static inline uint asuint(int i) { return (uint)i; }
+static inline int asint(float f) { return P::asint(f); } static inline int asint(uint u) { return (int)u; }
+static inline float asfloat(uint u) { return P::asfloat(u); } static inline float asfloat(int i) { return P::asfloat(i); } static inline float asfloat(float f) { return f; }
+static inline int3 asint(float3 v) { return int3(asint(v.x), asint(v.y), asint(v.z)); }
+static inline uint3 asuint(float3 v) { return uint3(asuint(v.x), asuint(v.y), asuint(v.z)); }
+static inline float3 asfloat(int3 v) { return float3(asfloat(v.x), asfloat(v.y), asfloat(v.z)); }
+static inline float3 asfloat(uint3 v) { return float3(asfloat(v.x), asfloat(v.y), asfloat(v.z)); }
+static inline uint f32tof16(float f) { return P::f32tof16(f); } static inline float f16tof32(uint h) { return P::f16tof32(h); }
+static inline uint2 f32tof16(float2 f) { return uint2(f32tof16(f.x), f32tof16(f.y)); }
+static inline float2 f16tof32(uint2 h) { return float2(f16tof32(h.x), f16tof32(h.y)); }
+static inline uint countbits(uint v) { return (uint)__builtin_popcount(v); }
+static inline uint firstbithigh(uint v) { return v ? 31u - (uint)__builtin_clz(v) : 0xFFFFFFFFu; }
+static inline uint reversebits(uint v) { uint r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
+#undef HL_LIFT1
+#undef HL_LIFT2
+} // namespace hl

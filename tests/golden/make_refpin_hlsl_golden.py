@@ -1,0 +1,18 @@
+"""Generates tests/golden/refpin_hlsl_golden.npz: outputs of functions of the reference's .hlsli files, compiled verbatim from
+/root/reference through oracle/refpin (hlsl_tu.py + hlsl_shim.h -> oracle/_ref/librefpin_hlsl.so), on the seeded inputs of tests/pin_inputs.py.
+Run in the build container only (the GPU box has no /root/reference, hence the committed fixture):   python tests/golden/make_refpin_hlsl_golden.py"""
+import os, sys
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import ptref
+import pin_inputs
+
+assert ptref.refpin_hlsl() is not None, "librefpin_hlsl.so needs /root/reference"
+out = {}
+for fn, name in enumerate(ptref.PIN_NAMES):
+    a = pin_inputs.rows(name, 256, 0x5EED0100 + fn)
+    out["in_" + name] = a
+    out["out_" + name] = ptref.pin_call(fn, a, reference=True)
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "refpin_hlsl_golden.npz"), **out)
+print("wrote %d functions" % len(ptref.PIN_NAMES))

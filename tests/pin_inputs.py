@@ -1,0 +1,49 @@
+"""Seeded input rows for the functions pinned against reference text (oracle/refpin/pin_fns.h): shared by the golden generator
+(tests/golden/make_refpin_hlsl_golden.py) and tests/test_oracle_refpin_hlsl.py. Each generator covers the function's domain plus its edges."""
+import numpy as np
+
+
+def _unit(rng, n, upper=False):
+    v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    if upper: v[:, 2] = np.abs(v[:, 2])
+    return v
+
+
+def _axes():
+    return np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [0.70710678, 0.70710678, 0], [0.57735027, 0.57735027, 0.57735027],
+                     [0, 0.70710678, -0.70710678]], np.float64)
+
+
+def _logu(rng, n, lo, hi):
+    return np.exp(rng.uniform(np.log(lo), np.log(hi), n))
+
+
+def rows(name, n, seed):
+    rng = np.random.default_rng(seed)
+    u2 = lambda: np.vstack([rng.uniform(0, 1, (n - 6, 2)), [[0, 0], [0.5, 0.5], [0.999999, 0.999999], [0.25, 0.75], [0.5, 0.1], [0, 0.5]]])
+    alpha = lambda k: np.concatenate([rng.uniform(0.0064, 1.0, k - 2), [0.0064, 1.0]])
+    if name == "evalFresnelSchlick": a = np.column_stack([rng.uniform(0, 1, n), rng.uniform(0, 1, n), rng.uniform(-0.1, 1.1, n)])
+    elif name == "evalFresnelSchlick3": a = np.column_stack([rng.uniform(0, 1, (n, 3)), rng.uniform(0, 1, n), rng.uniform(-0.1, 1.1, n)])
+    elif name == "evalFresnelDielectric": a = np.column_stack([rng.uniform(0.4, 2.5, n), rng.uniform(-1, 1, n)])
+    elif name == "evalNdfGGX": a = np.column_stack([alpha(n), rng.uniform(0, 1, n)])
+    elif name == "evalPdfGGX_BVNDF": a = np.column_stack([alpha(n), _unit(rng, n, True), _unit(rng, n, True)])
+    elif name == "sampleGGX_BVNDF": a = np.column_stack([alpha(n), _unit(rng, n, True), u2()])
+    elif name == "evalLambdaGGX": a = np.column_stack([rng.uniform(0, 1, n), rng.uniform(-0.2, 1, n)])
+    elif name == "evalMaskingSmithGGXCorrelated": a = np.column_stack([alpha(n), rng.uniform(-0.1, 1, n), rng.uniform(-0.1, 1, n)])
+    elif name in ("ndir_to_oct_equal_area_unorm", "perp_stark"): a = np.vstack([_unit(rng, n - 9), _axes()])
+    elif name == "oct_to_ndir_equal_area_unorm": a = np.vstack([rng.uniform(0, 1, (n - 6, 2)), [[0, 0], [1, 1], [0.5, 0.5], [0, 1], [0.5, 0], [1, 0.25]]])
+    elif name in ("sample_disk", "sample_disk_concentric", "sample_cosine_hemisphere_concentric"): a = u2()
+    elif name == "ComputeRayOrigin":
+        p = _logu(rng, (n, 3), 1e-4, 1e3) * rng.choice([-1.0, 1.0], (n, 3)); p[:4] = [[0, 0, 0], [0.0625, -0.0625, 1], [1e-9, 5, -5], [0.06, 0.07, -0.06]]
+        a = np.column_stack([p, _unit(rng, n)])
+    elif name == "FastSqrt": a = np.concatenate([rng.uniform(0, 4, n - 3), [0, 1, 4]])[:, None]
+    elif name == "FastACos": a = np.concatenate([rng.uniform(-1, 1, n - 3), [-1, 0, 1]])[:, None]
+    elif name == "ComputeRayConeSpreadAngleExpansionByScatterPDF": a = np.column_stack([_logu(rng, n, 1e-3, 1e4), rng.choice([0.3, 1.0], n)])
+    elif name == "ComputeNewScatterFireflyFilterK":
+        pdf = _logu(rng, n, 1e-3, 1e4); pdf[:3] = 0
+        a = np.column_stack([_logu(rng, n, 1e-5, 1), pdf, rng.uniform(0, 1, n)])
+    elif name == "FireflyFilter": a = np.column_stack([_logu(rng, (n, 3), 1e-3, 1e4), _logu(rng, n, 0.1, 100), _logu(rng, n, 1e-5, 1)])
+    elif name == "FireflyFilterShort": a = np.column_stack([_logu(rng, n, 1e-3, 1e4), _logu(rng, n, 0.1, 100), _logu(rng, n, 1e-5, 1)])
+    elif name == "ComputeLowGrazingAngleFalloff": a = np.column_stack([_unit(rng, n), _unit(rng, n), rng.uniform(0, 0.5, n), rng.uniform(0.01, 1, n)])
+    else: raise KeyError(name)
+    return np.ascontiguousarray(a, dtype=np.float32)

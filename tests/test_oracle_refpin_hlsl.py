@@ -1,0 +1,46 @@
+"""Oracle pinning, second layer: functions of the reference's .hlsli files compiled VERBATIM (oracle/refpin/hlsl_tu.py streams them from
+/root/reference through the HLSL-vocabulary shim hlsl_shim.h) against the oracle's restatement of the same functions, bit for bit.
+
+  * test_restatement_matches_reference_golden: the committed fixture (tests/golden/refpin_hlsl_golden.npz, made by make_refpin_hlsl_golden.py
+    from the reference text) — runs everywhere, also where /root/reference does not exist.
+  * test_restatement_matches_live_reference: 20 000 fresh rows per function against the live library, where it can be built.
+
+The shim maps what HLSL leaves to the implementation (transcendentals, dot/normalize summation order, mad, pow(x,5), fp16 conversion) to the
+oracle's arithmetic contract, so a mismatch here is a restatement error: wrong operation order, constant, branch or clamp."""
+import os, sys
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import ptref
+import pin_inputs
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_hlsl_golden.npz")
+
+
+def _same(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b)))
+
+
+@pytest.mark.parametrize("fn", range(len(ptref.PIN_NAMES)), ids=ptref.PIN_NAMES)
+def test_restatement_matches_reference_golden(fn):
+    name = ptref.PIN_NAMES[fn]
+    g = np.load(GOLDEN)
+    assert ("in_" + name) in g.files, "regenerate tests/golden/refpin_hlsl_golden.npz (make_refpin_hlsl_golden.py)"
+    a, want = g["in_" + name], g["out_" + name]
+    assert np.array_equal(a, pin_inputs.rows(name, 256, 0x5EED0100 + fn)), "input generator drifted from the fixture"
+    got = ptref.pin_call(fn, a)
+    ok = _same(got, want)
+    assert ok.all(), "%s: %d of %d rows differ, first: in=%s oracle=%s reference=%s" % (name, int((~ok).any(1).sum()), len(a), a[(~ok).any(1)][0], got[(~ok).any(1)][0], want[(~ok).any(1)][0])
+
+
+@pytest.mark.parametrize("fn", range(len(ptref.PIN_NAMES)), ids=ptref.PIN_NAMES)
+def test_restatement_matches_live_reference(fn):
+    if ptref.refpin_hlsl() is None:
+        pytest.skip("librefpin_hlsl.so not available (no /root/reference on this machine)")
+    name = ptref.PIN_NAMES[fn]
+    a = pin_inputs.rows(name, 20000, 0xA11CE + fn)
+    got, want = ptref.pin_call(fn, a), ptref.pin_call(fn, a, reference=True)
+    ok = _same(got, want)
+    assert ok.all(), "%s: %d of %d rows differ, first: in=%s oracle=%s reference=%s" % (name, int((~ok).any(1).sum()), len(a), a[(~ok).any(1)][0], got[(~ok).any(1)][0], want[(~ok).any(1)][0])
