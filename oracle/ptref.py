@@ -88,6 +88,21 @@ def pin_call(fn, inputs, reference=False):
     return out
 
 
+def bsdf_probe(rows, reference=False):
+    """Whole-BSDF probe over rows of tests/pin_inputs.bsdf_cases: the oracle's StandardBSDF, or the reference's BxDF.hlsli text (FalcorBSDF)."""
+    L = refpin_hlsl() if reference else lib()
+    if L is None:
+        return None
+    f = L.refhlsl_bsdf_probe if reference else L.ptref_bsdf_probe
+    rows = np.ascontiguousarray(rows, np.float32)
+    out = np.zeros((rows.shape[0], 10), np.float32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for i in range(rows.shape[0]):
+        r = rows[i]
+        f(vp(r[:14].copy()), int(r[14]), int(r[15]), vp(r[16:19].copy()), vp(r[19:22].copy()), int(r[22]), vp(out[i]))
+    return out
+
+
 def _pin_table():
     """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
     import re

@@ -7,6 +7,7 @@
 #pragma once
 #include <cstdint>
 #include <cmath>
+#include <cfloat>
 #include <type_traits>
 #include "../ptref/vec.h"
 #include "../ptref/dmath.h"

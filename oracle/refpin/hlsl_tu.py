@@ -6,7 +6,9 @@
 
 The only edits made to the reference text are the ones C++ syntax forces:
   * `out T x` / `inout T x` parameters become `T& x`; the `in` qualifier is dropped
-  * vector swizzles `.xy` `.yx` `.xyz` `.rgb` ... become member calls `.xy_()` (hlsl_shim.h); `_alpha.xx` (a swizzle on a scalar) becomes float2(_alpha, _alpha)
+  * vector swizzles `.xy` `.yx` `.xyz` `.rgb` ... become member calls `.xy_()` (hlsl_shim.h); swizzles on scalars (`_alpha.xx`, `(expr).xxx`,
+    `packedData.x`) become constructor calls / the scalar itself
+  * `const` is dropped from by-value parameters (HLSL methods are not const-qualified)
   * `[unroll]`-style attributes are dropped
 usage: hlsl_tu.py /root/reference > tu.cpp"""
 import os, re, sys
@@ -14,7 +16,13 @@ import os, re, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SHADERS = "Rtxpt/Shaders/PathTracer"
 
-# (file, what): what = list of function / struct names taken from that file, in emission order. "#K_" = every `#define K_*` of the file.
+# (file, what): what = list of items taken from that file, in emission order:
+#   "name"            every file-scope function definition of that name (overloads included)
+#   "#K_"             every `#define K_*` of the file, as a float constant
+#   "pp"              every preprocessor line of the file except #include (configuration headers)
+#   "struct Name"     that struct / enum class definition; "struct Name -method" drops a member function (one that needs types outside the pin)
+#   "range A..B"      the file from the first line matching regex A up to (not including) the first later line matching regex B
+#   "text ..."        emitted as is (namespace brackets, macro switches)
 PLAN = [
     ("Utils/Math/MathConstants.hlsli", ["#K_"]),
     ("Utils/Utils.hlsli", ["FastSqrt", "FastACos", "Luminance", "Average"]),
@@ -24,6 +32,15 @@ PLAN = [
                                       "sample_cosine_hemisphere_concentric", "perp_stark"]),
     ("PathTracerHelpers.hlsli", ["ComputeRayOrigin", "ComputeLowGrazingAngleFalloff", "ComputeRayConeSpreadAngleExpansionByScatterPDF",
                                  "ComputeNewScatterFireflyFilterK", "FireflyFilter", "FireflyFilterShort"]),
+    # ---- the whole standard BSDF (FalcorBSDF and its four lobes), once per diffuse model
+    ("Utils/Math/MathConstants.hlsli", ["range static const float\\s+cFloatOneMinusEpsilon..^\\s*$"]),
+    ("Rendering/Materials/LobeType.hlsli", ["struct LobeType"]),
+    ("Scene/Material/MaterialData.hlsli", ["range #define EXTRACT_BITS..^struct", "struct MaterialHeader"]),
+    ("Scene/ShadingData.hlsli", ["struct ShadingData"]),
+    ("Rendering/Materials/BxDFConfig.hlsli", ["text #define DiffuseBrdf 0", "pp", "text namespace lambert {"]),
+    ("Rendering/Materials/BxDF.hlsli", ["range static const float kMinCosTheta..^struct FalcorBSDF", "struct FalcorBSDF -evalDeltaLobes", "text } // lambert"]),
+    ("Rendering/Materials/BxDFConfig.hlsli", ["text #undef DiffuseBrdf", "text #define DiffuseBrdf 2", "text namespace frostbite {"]),
+    ("Rendering/Materials/BxDF.hlsli", ["range static const float kMinCosTheta..^struct FalcorBSDF", "struct FalcorBSDF -evalDeltaLobes", "text } // frostbite"]),
 ]
 SKIP_SIGNATURE = re.compile(r"\bhalf\d?\b|\bmin16\w+|\bfloat16_t\d?\b")       # overloads in types the fp32 build never uses
 
@@ -63,10 +80,47 @@ def extract_function(text, name, path):
     return found
 
 
+def match_brace(text, i):
+    depth = 0
+    while True:
+        c = text[i]
+        if c == "{": depth += 1
+        elif c == "}":
+            depth -= 1
+            if depth == 0: return i
+        i += 1
+
+
+def extract_struct(text, spec, path):
+    parts = spec.split()
+    name, drop = parts[0], [p[1:] for p in parts[1:] if p.startswith("-")]
+    m = re.search(r"^[ \t]*(?:struct|enum class|enum)\s+" + re.escape(name) + r"\b[^{;]*\{", text, re.M)
+    if not m: raise SystemExit("hlsl_tu.py: struct %s not found in %s" % (name, path))
+    end = match_brace(text, m.end() - 1)
+    body = text[m.start():end + 1] + ";"
+    for d in drop:
+        k = re.search(r"^[ \t]*[A-Za-z_][\w<>]*\s+" + re.escape(d) + r"\s*\([^)]*\)\s*\{", body, re.M)
+        if not k: raise SystemExit("hlsl_tu.py: member %s of %s not found in %s" % (d, name, path))
+        body = body[:k.start()] + body[match_brace(body, k.end() - 1) + 1:]
+    return body
+
+
+def extract_range(text, spec, path):
+    a, b = spec.split("..", 1)
+    lines = text.split("\n")
+    i0 = next((i for i, l in enumerate(lines) if re.search(a, l)), None)
+    if i0 is None: raise SystemExit("hlsl_tu.py: range start /%s/ not found in %s" % (a, path))
+    i1 = next((i for i in range(i0 + 1, len(lines)) if re.search(b, lines[i])), len(lines))
+    return "\n".join(l for l in lines[i0:i1] if not re.match(r"\s*#\s*include", l))
+
+
 def to_cpp(code):
     code = re.sub(r"\b(?:inout|out)\s+(const\s+)?([A-Za-z_]\w*)\s+([A-Za-z_]\w*)", lambda m: "%s%s& %s" % (m.group(1) or "", m.group(2), m.group(3)), code)
     code = re.sub(r"([(,]\s*)in\s+(?=(?:const\s+)?[A-Za-z_]\w*\s+[A-Za-z_]\w*)", r"\1", code)
+    code = re.sub(r"\bconst\s+(?=[A-Za-z_]\w*\s+[A-Za-z_]\w*\s*[,)])", "", code)        # by-value parameters: HLSL calls non-const methods on them
     code = re.sub(r"\b_alpha\.xx\b", "float2(_alpha, _alpha)", code)
+    code = re.sub(r"(\((?:[^()]|\([^()]*\))*\))\.xxx\b", r"float3(\1)", code)              # `(scalar expression).xxx`
+    code = re.sub(r"\bpackedData\.x\b", "packedData", code)                               # `.x` of a scalar
     code = re.sub(r"\.(xy|yx|xx|xz|yz|zw|xyz|rgb)\b", r".\1_()", code)
     code = re.sub(r"^[ \t]*\[(?:unroll|loop|branch|flatten|mutating|forceinline)[^\]]*\][ \t]*", "", code, flags=re.M)
     return code
@@ -84,6 +138,11 @@ def main():
                 for m in re.finditer(r"^[ \t]*#define[ \t]+(" + re.escape(name[1:]) + r"\w*)[ \t]+(\S+)", text, re.M):
                     w("static const float %s = %s;\n" % (m.group(1), m.group(2)))
                 continue
+            if name.startswith("text "): w(name[5:] + "\n"); continue
+            if name == "pp":
+                w("\n".join(l for l in text.split("\n") if re.match(r"\s*#", l) and not re.match(r"\s*#\s*include", l)) + "\n"); continue
+            if name.startswith("struct "): w("// ---- %s : %s\n" % (rel, name)); w(to_cpp(extract_struct(text, name[7:], rel))); w("\n"); continue
+            if name.startswith("range "): w("// ---- %s : %s\n" % (rel, name)); w(to_cpp(extract_range(text, name[6:], rel))); w("\n"); continue
             for body in extract_function(text, name, rel):
                 w("// ---- %s : %s\n" % (rel, name)); w(to_cpp(body)); w("\n")
     w("} // namespace hl\n")

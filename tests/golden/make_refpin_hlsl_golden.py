@@ -14,5 +14,7 @@ for fn, name in enumerate(ptref.PIN_NAMES):
     a = pin_inputs.rows(name, 256, 0x5EED0100 + fn)
     out["in_" + name] = a
     out["out_" + name] = ptref.pin_call(fn, a, reference=True)
+out["bsdf_in"] = pin_inputs.bsdf_cases(3000, 0x5EED0200)
+out["bsdf_out"] = ptref.bsdf_probe(out["bsdf_in"], reference=True)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "refpin_hlsl_golden.npz"), **out)
 print("wrote %d functions" % len(ptref.PIN_NAMES))

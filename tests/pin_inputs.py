@@ -47,3 +47,27 @@ def rows(name, n, seed):
     elif name == "ComputeLowGrazingAngleFalloff": a = np.column_stack([_unit(rng, n), _unit(rng, n), rng.uniform(0, 0.5, n), rng.uniform(0.01, 1, n)])
     else: raise KeyError(name)
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def bsdf_cases(n, seed):
+    """Rows for the whole-BSDF pin: [14 material params, thin, diffuseModel, wi.xyz, w.xyz (direction for eval / random numbers for sample), mode].
+    Materials span every lobe mix: metals, dielectrics, delta (roughness below the GGX clamp), diffuse / specular transmission, eta on both sides of 1."""
+    rng = np.random.default_rng(seed)
+    R = np.zeros((n, 23), np.float32)
+    for i in range(n):
+        kind = rng.integers(0, 8)
+        diffuse = rng.uniform(0, 1, 3); spec = rng.uniform(0, 1, 3) if kind in (1, 5) else np.full(3, rng.choice([0.0, 0.04, 0.08]))
+        rough = rng.choice([0.0, 0.05, 0.079, 0.081, 0.3, 0.7, 1.0]) if rng.random() < 0.4 else rng.uniform(0, 1)
+        metallic = [0, 1, 0, rng.uniform(0, 1), 0, 1, 0, rng.uniform(0, 1)][kind]
+        trans = rng.uniform(0, 1, 3)
+        dtrans = [0, 0, rng.uniform(0, 1), 0, 1, 0, rng.uniform(0, 1), 0][kind]
+        strans = [0, 0, 0, rng.uniform(0, 1), 0, 0, rng.uniform(0, 1), 1][kind]
+        eta = rng.choice([1.0, 1 / 1.5, 1.5, 1 / 1.33, 1.33]) if rng.random() < 0.7 else rng.uniform(0.5, 2.0)
+        if kind == 0 and rng.random() < 0.3: diffuse[:] = 0
+        wi = _unit(rng, 1, upper=rng.random() < 0.85)[0]
+        mode = int(rng.integers(0, 2))
+        w = _unit(rng, 1)[0] if mode == 0 else rng.uniform(0, 1, 3)
+        if mode == 1 and rng.random() < 0.05: w[2] = rng.choice([0.0, 0.999999])
+        R[i, :14] = list(diffuse) + list(spec) + [rough, metallic] + list(trans) + [dtrans, strans, eta]
+        R[i, 14] = rng.integers(0, 2); R[i, 15] = rng.choice([0, 2]); R[i, 16:19] = wi; R[i, 19:22] = w; R[i, 22] = mode
+    return R

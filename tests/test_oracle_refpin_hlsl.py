@@ -44,3 +44,27 @@ def test_restatement_matches_live_reference(fn):
     got, want = ptref.pin_call(fn, a), ptref.pin_call(fn, a, reference=True)
     ok = _same(got, want)
     assert ok.all(), "%s: %d of %d rows differ, first: in=%s oracle=%s reference=%s" % (name, int((~ok).any(1).sum()), len(a), a[(~ok).any(1)][0], got[(~ok).any(1)][0], want[(~ok).any(1)][0])
+
+
+def _bsdf_report(rows, got, want):
+    ok = _same(got, want).all(1)
+    bad = np.flatnonzero(~ok)
+    return ok, "whole BSDF: %d of %d cases differ; first: case=%s oracle=%s reference=%s" % (len(bad), len(rows), rows[bad[0]] if len(bad) else None, got[bad[0]] if len(bad) else None, want[bad[0]] if len(bad) else None)
+
+
+def test_whole_bsdf_matches_reference_golden():
+    """FalcorBSDF eval / evalPdf / getLobes / sample of BxDF.hlsli:55-970 (both DiffuseBrdf settings), compiled from the reference text, vs the oracle's StandardBSDF."""
+    g = np.load(GOLDEN)
+    rows, want = g["bsdf_in"], g["bsdf_out"]
+    assert np.array_equal(rows, pin_inputs.bsdf_cases(3000, 0x5EED0200)), "input generator drifted from the fixture"
+    ok, msg = _bsdf_report(rows, ptref.bsdf_probe(rows), want)
+    assert ok.all(), msg
+    assert (want[rows[:, 22] == 1][:, 9] == 1).sum() > 500 and (want[rows[:, 22] == 0][:, 4] > 0).sum() > 300      # the fixture exercises valid samples and non-zero pdfs
+
+
+def test_whole_bsdf_matches_live_reference():
+    if ptref.refpin_hlsl() is None:
+        pytest.skip("librefpin_hlsl.so not available (no /root/reference on this machine)")
+    rows = pin_inputs.bsdf_cases(40000, 0xB5DF)
+    ok, msg = _bsdf_report(rows, ptref.bsdf_probe(rows), ptref.bsdf_probe(rows, reference=True))
+    assert ok.all(), msg
