@@ -103,6 +103,19 @@ def bsdf_probe(rows, reference=False):
     return out
 
 
+def sample_streams(cases, reference=False):
+    """cases: uint32 rows [packedPixel, vertexIndex, sampleIndex, effectSeed, kind, n<=8] -> float32 [len(cases), 8] (unused slots 0)."""
+    L = refpin_hlsl() if reference else lib()
+    if L is None:
+        return None
+    f = L.refhlsl_sample_stream if reference else L.ptref_sample_stream
+    out = np.zeros((len(cases), 8), np.float32)
+    for i, c in enumerate(cases):
+        f(ctypes.c_uint32(int(c[0])), ctypes.c_uint32(int(c[1])), ctypes.c_uint32(int(c[2])), ctypes.c_uint32(int(c[3])), ctypes.c_int(int(c[4])), ctypes.c_uint32(int(c[5])),
+          out[i].ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
 def _pin_table():
     """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
     import re

@@ -29,7 +29,8 @@ template <class T> struct v3 { T x, y, z; v3() : x(), y(), z() {} v3(T s) : x(s)
 template <class T> struct v4 { T x, y, z, w; v4() : x(), y(), z(), w() {} v4(T s) : x(s), y(s), z(s), w(s) {} v4(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}
     v4(v3<T> a, T d) : x(a.x), y(a.y), z(a.z), w(d) {} v4(v2<T> a, v2<T> b) : x(a.x), y(a.y), z(b.x), w(b.y) {}
     v3<T>& xyz_() { return *reinterpret_cast<v3<T>*>(this); } v3<T> xyz_() const { return v3<T>(x, y, z); } v3<T>& rgb_() { return xyz_(); } v3<T> rgb_() const { return xyz_(); }
-    v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> zw_() const { return v2<T>(z, w); } };
+    v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> zw_() const { return v2<T>(z, w); }
+    T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
 
 typedef v2<float> float2; typedef v3<float> float3; typedef v4<float> float4;
 typedef v2<int> int2; typedef v3<int> int3; typedef v4<int> int4;

@@ -9,7 +9,7 @@ The only edits made to the reference text are the ones C++ syntax forces:
   * vector swizzles `.xy` `.yx` `.xyz` `.rgb` ... become member calls `.xy_()` (hlsl_shim.h); swizzles on scalars (`_alpha.xx`, `(expr).xxx`,
     `packedData.x`) become constructor calls / the scalar itself
   * `const` is dropped from by-value parameters (HLSL methods are not const-qualified)
-  * `[unroll]`-style attributes are dropped
+  * `[unroll]`-style attributes and the `uniform` parameter qualifier are dropped
 usage: hlsl_tu.py /root/reference > tu.cpp"""
 import os, re, sys
 
@@ -32,6 +32,11 @@ PLAN = [
                                       "sample_cosine_hemisphere_concentric", "perp_stark"]),
     ("PathTracerHelpers.hlsli", ["ComputeRayOrigin", "ComputeLowGrazingAngleFalloff", "ComputeRayConeSpreadAngleExpansionByScatterPDF",
                                  "ComputeNewScatterFireflyFilterK", "FireflyFilter", "FireflyFilterShort"]),
+    # ---- the stateless sample generators (integer RNG streams: must match bit for bit)
+    ("Utils/NoiseAndSequences.hlsli", ["range #define\\s+SOBOL_MAX_DIMENSIONS..^\\s*$", "Hash32", "Hash32Combine", "Hash32ToFloat", "bhos_sobol", "bhos_reverse_bits", "bhos_owen_hash", "bhos_owen_scramble"]),
+    ("Utils/SampleGenerators.hlsli", ["struct SampleGeneratorEffectSeed"]),
+    ("Utils/StatelessSampleGenerators.hlsli", ["struct SampleGeneratorVertexBase", "struct SampleSequenceGenerator", "struct UniformSampleSequenceGenerator"]),
+    ("Utils/SampleGenerators.hlsli", ["sampleNext1D"]),
     # ---- the whole standard BSDF (FalcorBSDF and its four lobes), once per diffuse model
     ("Utils/Math/MathConstants.hlsli", ["range static const float\\s+cFloatOneMinusEpsilon..^\\s*$"]),
     ("Rendering/Materials/LobeType.hlsli", ["struct LobeType"]),
@@ -72,6 +77,8 @@ def extract_function(text, name, path):
                 if depth == 0: break
             i += 1
         body = text[m.start():i + 1]
+        head = text[:m.start()].rstrip().rsplit("\n", 1)[-1]
+        if re.match(r"\s*template\s*<", head): body = head + "\n" + body      # function templates: the template line sits above the signature
         if SKIP_SIGNATURE.search(m.group(0)): continue
         sig = re.sub(r"\s+", " ", m.group(0).replace("lpfloat", "float"))
         if sig in seen: continue                      # the lpfloat overload of an fp32 build is the same function twice
@@ -122,7 +129,8 @@ def to_cpp(code):
     code = re.sub(r"(\((?:[^()]|\([^()]*\))*\))\.xxx\b", r"float3(\1)", code)              # `(scalar expression).xxx`
     code = re.sub(r"\bpackedData\.x\b", "packedData", code)                               # `.x` of a scalar
     code = re.sub(r"\.(xy|yx|xx|xz|yz|zw|xyz|rgb)\b", r".\1_()", code)
-    code = re.sub(r"^[ \t]*\[(?:unroll|loop|branch|flatten|mutating|forceinline)[^\]]*\][ \t]*", "", code, flags=re.M)
+    code = re.sub(r"\[(?:unroll|loop|branch|flatten|mutating|forceinline)(?:\([^)]*\))?\][ \t]*", "", code)
+    code = re.sub(r"\buniform\s+(?=uint|int|float)", "", code)
     return code
 
 

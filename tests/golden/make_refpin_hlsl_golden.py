@@ -16,5 +16,7 @@ for fn, name in enumerate(ptref.PIN_NAMES):
     out["out_" + name] = ptref.pin_call(fn, a, reference=True)
 out["bsdf_in"] = pin_inputs.bsdf_cases(3000, 0x5EED0200)
 out["bsdf_out"] = ptref.bsdf_probe(out["bsdf_in"], reference=True)
+out["stream_in"] = pin_inputs.stream_cases(4000, 0x5EED0300)
+out["stream_out"] = ptref.sample_streams(out["stream_in"], reference=True)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "refpin_hlsl_golden.npz"), **out)
 print("wrote %d functions" % len(ptref.PIN_NAMES))

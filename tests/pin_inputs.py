@@ -71,3 +71,14 @@ def bsdf_cases(n, seed):
         R[i, :14] = list(diffuse) + list(spec) + [rough, metallic] + list(trans) + [dtrans, strans, eta]
         R[i, 14] = rng.integers(0, 2); R[i, 15] = rng.choice([0, 2]); R[i, 16:19] = wi; R[i, 19:22] = w; R[i, 22] = mode
     return R
+
+
+def stream_cases(n, seed):
+    """uint32 rows [packedPixel, vertexIndex, sampleIndex, effectSeed, kind, count] for the stateless sample generators (kinds: see ptref_sample_stream)."""
+    rng = np.random.default_rng(seed)
+    C = np.zeros((n, 6), np.uint32)
+    C[:, 0] = (rng.integers(0, 3840, n) << 16) | rng.integers(0, 2160, n)
+    C[:, 1] = rng.integers(0, 40, n); C[:, 2] = np.where(rng.random(n) < 0.2, rng.integers(0, 2**32, n, dtype=np.uint64), rng.integers(0, 4096, n)).astype(np.uint32)
+    C[:, 3] = rng.choice([0, 1, 2, 3, 5, 6], n); C[:, 4] = rng.integers(0, 5, n)
+    C[:, 5] = np.where(C[:, 4] < 2, rng.integers(1, 5, n), rng.integers(1, 9, n))
+    return C

@@ -68,3 +68,22 @@ def test_whole_bsdf_matches_live_reference():
     rows = pin_inputs.bsdf_cases(40000, 0xB5DF)
     ok, msg = _bsdf_report(rows, ptref.bsdf_probe(rows), ptref.bsdf_probe(rows, reference=True))
     assert ok.all(), msg
+
+
+def test_sample_generators_match_reference_golden():
+    """SampleGeneratorVertexBase / SampleSequenceGenerator (Burley hash-Owen-Sobol) / UniformSampleSequenceGenerator / sampleNext1D of
+    StatelessSampleGenerators.hlsli + SampleGenerators.hlsli, compiled from the reference text: integer streams, bit for bit."""
+    g = np.load(GOLDEN)
+    cases, want = g["stream_in"], g["stream_out"]
+    assert np.array_equal(cases, pin_inputs.stream_cases(4000, 0x5EED0300)), "input generator drifted from the fixture"
+    got = ptref.sample_streams(cases)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%d streams differ" % int((got != want).any(1).sum())
+    assert ((want >= 0) & (want < 1)).all() and len(np.unique(want[:, 0])) > 3900
+
+
+def test_sample_generators_match_live_reference():
+    if ptref.refpin_hlsl() is None:
+        pytest.skip("librefpin_hlsl.so not available (no /root/reference on this machine)")
+    cases = pin_inputs.stream_cases(60000, 0x57EA)
+    got, want = ptref.sample_streams(cases), ptref.sample_streams(cases, reference=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%d streams differ" % int((got != want).any(1).sum())
