@@ -116,6 +116,22 @@ def sample_streams(cases, reference=False):
     return out
 
 
+LIGHT_PROBE_IO = {0: (3, 5), 1: (12, 12), 2: (17, 12), 3: (18, 1), 4: (3, 4)}      # words in / out per kind (oracle/refpin/hlsl_wrappers.inc)
+
+
+def light_probe(kind, words, reference=False):
+    """Polymorphic-light probe over rows of 32-bit words (floats as their bit patterns)."""
+    L = refpin_hlsl() if reference else lib()
+    if L is None:
+        return None
+    ni, no = LIGHT_PROBE_IO[kind]
+    a = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, ni)
+    out = np.zeros((a.shape[0], no), np.uint32)
+    f = L.refhlsl_light_probe if reference else L.ptref_light_probe
+    f(ctypes.c_int(kind), a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(a.shape[0]), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
 def _pin_table():
     """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
     import re

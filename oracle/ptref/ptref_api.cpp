@@ -546,5 +546,46 @@ void ptref_pin_call(int fn, const float* in, unsigned n, float* out) {
     }
 }
 
+// lights: the oracle's side of refhlsl_light_probe (oracle/refpin/hlsl_wrappers.inc documents the kinds); environment transform = identity
+static PolymorphicLightInfoFull pin_info(const uint32_t* w) {
+    PolymorphicLightInfoFull li; memset(&li, 0, sizeof(li));
+    li.Base.Center = make_float3(asfloat(w[0]), asfloat(w[1]), asfloat(w[2])); li.Base.ColorTypeAndFlags = w[3]; li.Base.Direction1 = w[4]; li.Base.Direction2 = w[5]; li.Base.Scalars = w[6]; li.Base.LogRadiance = w[7];
+    li.Extended.IesProfileIndex = w[8]; li.Extended.PrimaryAxis = w[9]; li.Extended.CosConeAngleAndSoftness = w[10]; li.Extended.UniqueID = w[11];
+    return li;
+}
+void ptref_light_probe(int kind, const uint32_t* in, unsigned n, uint32_t* out) {
+    static const int NI[5] = {3, 12, 17, 18, 3}, NO[5] = {5, 12, 12, 1, 4};
+    const float3x4 I = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}};
+    for (unsigned k = 0; k < n; k++) {
+        const uint32_t* a = in + (size_t)k * NI[kind]; uint32_t* o = out + (size_t)k * NO[kind];
+        if (kind == 0) {
+            PolymorphicLightInfo b; memset(&b, 0, sizeof(b));
+            PackLightColor(make_float3(asfloat(a[0]), asfloat(a[1]), asfloat(a[2])), b);
+            float3 c = UnpackLightColor(b);
+            o[0] = b.ColorTypeAndFlags; o[1] = b.LogRadiance; o[2] = asuint(c.x); o[3] = asuint(c.y); o[4] = asuint(c.z);
+        } else if (kind == 1) {
+            TriangleLight t; t.base = make_float3(asfloat(a[0]), asfloat(a[1]), asfloat(a[2])); t.edge1 = make_float3(asfloat(a[3]), asfloat(a[4]), asfloat(a[5])); t.edge2 = make_float3(asfloat(a[6]), asfloat(a[7]), asfloat(a[8]));
+            t.radiance = make_float3(asfloat(a[9]), asfloat(a[10]), asfloat(a[11])); t.normal = make_float3(0.f); t.surfaceArea = 0;
+            PolymorphicLightInfoFull li = t.Store(7u);
+            o[0] = asuint(li.Base.Center.x); o[1] = asuint(li.Base.Center.y); o[2] = asuint(li.Base.Center.z); o[3] = li.Base.ColorTypeAndFlags; o[4] = li.Base.Direction1; o[5] = li.Base.Direction2; o[6] = li.Base.Scalars; o[7] = li.Base.LogRadiance;
+            o[8] = li.Extended.IesProfileIndex; o[9] = li.Extended.PrimaryAxis; o[10] = li.Extended.CosConeAngleAndSoftness; o[11] = li.Extended.UniqueID;
+        } else if (kind == 2) {
+            PolymorphicLightInfoFull li = pin_info(a);
+            PolymorphicLightSample s = PolymorphicLight_CalcSample(li, make_float2(asfloat(a[12]), asfloat(a[13])), make_float3(asfloat(a[14]), asfloat(a[15]), asfloat(a[16])), I);
+            o[0] = asuint(s.Position.x); o[1] = asuint(s.Position.y); o[2] = asuint(s.Position.z); o[3] = asuint(s.Normal.x); o[4] = asuint(s.Normal.y); o[5] = asuint(s.Normal.z);
+            o[6] = asuint(s.Radiance.x); o[7] = asuint(s.Radiance.y); o[8] = asuint(s.Radiance.z); o[9] = asuint(s.SolidAnglePdf); o[10] = s.LightSampleableByBSDF ? 1u : 0u;
+            o[11] = asuint(PolymorphicLight_GetPower(li));
+        } else if (kind == 3) {
+            TriangleLight t = TriangleLight::Create(pin_info(a));
+            o[0] = asuint(t.CalcSolidAnglePdfForMIS(make_float3(asfloat(a[12]), asfloat(a[13]), asfloat(a[14])), make_float3(asfloat(a[15]), asfloat(a[16]), asfloat(a[17]))));
+        } else {
+            uint p = NDirToOctUnorm32(make_float3(asfloat(a[0]), asfloat(a[1]), asfloat(a[2])));
+            float3 d = OctToNDirUnorm32(p);
+            o[0] = p; o[1] = asuint(d.x); o[2] = asuint(d.y); o[3] = asuint(d.z);
+        }
+    }
+}
+
 } // extern "C"
+
 

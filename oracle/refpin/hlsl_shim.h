@@ -16,17 +16,17 @@ namespace hl {
 typedef uint32_t uint;
 namespace P = ptref;
 
-template <class T> struct v2 { T x, y; v2() : x(), y() {} v2(T s) : x(s), y(s) {} v2(T a, T b) : x(a), y(b) {}
+template <class T> struct v2 { union { struct { T x, y; }; struct { T r, g; }; }; v2() : x(), y() {} v2(T s) : x(s), y(s) {} v2(T a, T b) : x(a), y(b) {}
     template <class U> explicit v2(const v2<U>& o) : x((T)o.x), y((T)o.y) {}
     v2& xy_() { return *this; } v2 yx_() const { return v2(y, x); } v2 xx_() const { return v2(x, x); } };
-template <class T> struct v3 { T x, y, z; v3() : x(), y(), z() {} v3(T s) : x(s), y(s), z(s) {} v3(T a, T b, T c) : x(a), y(b), z(c) {}
+template <class T> struct v3 { union { struct { T x, y, z; }; struct { T r, g, b; }; }; v3() : x(), y(), z() {} v3(T s) : x(s), y(s), z(s) {} v3(T a, T b, T c) : x(a), y(b), z(c) {}
     v3(v2<T> a, T c) : x(a.x), y(a.y), z(c) {}
     template <class A, class B, class C, class = typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value && std::is_arithmetic<C>::value && !(std::is_same<A, T>::value && std::is_same<B, T>::value && std::is_same<C, T>::value)>::type>
     v3(A a, B b, C c) : x((T)a), y((T)b), z((T)c) {}
-    template <class U> explicit v3(const v3<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z) {}
+    template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v3(const v3<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z) {}       // HLSL converts between component types implicitly
     v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> yx_() const { return v2<T>(y, x); } v2<T> xz_() const { return v2<T>(x, z); } v2<T> yz_() const { return v2<T>(y, z); }
     v3& xyz_() { return *this; } const v3& xyz_() const { return *this; } v3& rgb_() { return *this; } const v3& rgb_() const { return *this; } };
-template <class T> struct v4 { T x, y, z, w; v4() : x(), y(), z(), w() {} v4(T s) : x(s), y(s), z(s), w(s) {} v4(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}
+template <class T> struct v4 { union { struct { T x, y, z, w; }; struct { T r, g, b, a; }; }; v4() : x(), y(), z(), w() {} v4(T s) : x(s), y(s), z(s), w(s) {} v4(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}
     v4(v3<T> a, T d) : x(a.x), y(a.y), z(a.z), w(d) {} v4(v2<T> a, v2<T> b) : x(a.x), y(a.y), z(b.x), w(b.y) {}
     v3<T>& xyz_() { return *reinterpret_cast<v3<T>*>(this); } v3<T> xyz_() const { return v3<T>(x, y, z); } v3<T>& rgb_() { return xyz_(); } v3<T> rgb_() const { return xyz_(); }
     v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> zw_() const { return v2<T>(z, w); }
@@ -67,11 +67,19 @@ template <class T> v4<T> operator-(v4<T> a) { return v4<T>(-a.x, -a.y, -a.z, -a.
     template <class T, class S> if_arith<bool3, S> operator op(v3<T> a, S b) { return a op v3<T>((T)b); }
 HL_CMP(<) HL_CMP(>) HL_CMP(<=) HL_CMP(>=) HL_CMP(==) HL_CMP(!=)
 #undef HL_CMP
+#define HL_INTOP(op) \
+    template <class T, class S> if_arith<v2<T>, S> operator op(v2<T> a, S b) { return v2<T>(a.x op (T)b, a.y op (T)b); } \
+    template <class T, class S> if_arith<v3<T>, S> operator op(v3<T> a, S b) { return v3<T>(a.x op (T)b, a.y op (T)b, a.z op (T)b); } \
+    template <class T> v2<T> operator op(v2<T> a, v2<T> b) { return v2<T>(a.x op b.x, a.y op b.y); } \
+    template <class T> v3<T> operator op(v3<T> a, v3<T> b) { return v3<T>(a.x op b.x, a.y op b.y, a.z op b.z); }
+HL_INTOP(&) HL_INTOP(|) HL_INTOP(>>) HL_INTOP(<<)
+#undef HL_INTOP
 static inline bool any(bool2 b) { return b.x || b.y; } static inline bool any(bool3 b) { return b.x || b.y || b.z; }
 static inline bool all(bool2 b) { return b.x && b.y; } static inline bool all(bool3 b) { return b.x && b.y && b.z; }
 static inline bool any(float3 v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f; }
 template <class T> T select(bool c, T a, T b) { return c ? a : b; }
 template <class T> v2<T> select(bool2 c, v2<T> a, v2<T> b) { return v2<T>(c.x ? a.x : b.x, c.y ? a.y : b.y); }
+template <class S> if_arith<float2, S> select(bool2 c, S a, S b) { return float2(c.x ? (float)a : (float)b, c.y ? (float)a : (float)b); }
 template <class T> v3<T> select(bool3 c, v3<T> a, v3<T> b) { return v3<T>(c.x ? a.x : b.x, c.y ? a.y : b.y, c.z ? a.z : b.z); }
 
 // ---- component-wise lifting of scalar functions
@@ -113,7 +121,9 @@ static inline float exp(float v) { return P::dm_exp(v); } static inline float lo
 static inline float atan2(float y, float x) { return P::dm_atan2(y, x); }
 template <class E> float pow(float x, E e) { return ((float)e == 5.0f) ? P::dm_pow5(x) : P::dm_pow(x, (float)e); }      // pow(x, 5): the oracle's (x²·x²)·x
 template <class E> float3 pow(float3 x, E e) { return float3(pow(x.x, e), pow(x.y, e), pow(x.z, e)); }
+template <class E> float4 pow(float4 x, E e) { return float4(pow(x.x, e), pow(x.y, e), pow(x.z, e), pow(x.w, e)); }
 static inline float mad(float a, float b, float c) { return a * b + c; }                                                // unfused (-ffp-contract=off)
+static inline float smoothstep(float a, float b, float x) { float t = saturate((x - a) / (b - a)); return t * t * (3.0f - 2.0f * t); }
 static inline float lerp(float a, float b, float t) { return P::lerpf(a, b, t); }
 static inline float3 lerp(float3 a, float3 b, float t) { return a + (b - a) * t; }
 static inline float3 lerp(float3 a, float3 b, float3 t) { return a + (b - a) * t; }
@@ -133,6 +143,8 @@ static inline float3 asfloat(int3 v) { return float3(asfloat(v.x), asfloat(v.y),
 static inline float3 asfloat(uint3 v) { return float3(asfloat(v.x), asfloat(v.y), asfloat(v.z)); }
 static inline uint f32tof16(float f) { return P::f32tof16(f); } static inline float f16tof32(uint h) { return P::f16tof32(h); }
 static inline uint2 f32tof16(float2 f) { return uint2(f32tof16(f.x), f32tof16(f.y)); }
+static inline uint3 f32tof16(float3 f) { return uint3(f32tof16(f.x), f32tof16(f.y), f32tof16(f.z)); }
+static inline float3 f16tof32(uint3 h) { return float3(f16tof32(h.x), f16tof32(h.y), f16tof32(h.z)); }
 static inline float2 f16tof32(uint2 h) { return float2(f16tof32(h.x), f16tof32(h.y)); }
 static inline uint countbits(uint v) { return (uint)__builtin_popcount(v); }
 static inline uint firstbithigh(uint v) { return v ? 31u - (uint)__builtin_clz(v) : 0xFFFFFFFFu; }

@@ -37,6 +37,14 @@ PLAN = [
     ("Utils/SampleGenerators.hlsli", ["struct SampleGeneratorEffectSeed"]),
     ("Utils/StatelessSampleGenerators.hlsli", ["struct SampleGeneratorVertexBase", "struct SampleSequenceGenerator", "struct UniformSampleSequenceGenerator"]),
     ("Utils/SampleGenerators.hlsli", ["sampleNext1D"]),
+    # ---- polymorphic lights: packing, sphere / triangle / environment-quad sampling and MIS pdfs
+    ("Utils/Utils.hlsli", ["sq", "OctWrap", "Encode_Oct", "Decode_Oct", "NDirToOctUnorm32", "OctToNDirUnorm32"]),
+    ("Utils/Geometry.hlsli", ["BranchlessONB", "SampleTriangleUniform", "pdfAtoW"]),
+    ("Utils/Packing.hlsli", ["range #define PACK_UFLOAT_TEMPLATE..^uint Pack_R11G11B10"]),
+    ("Lighting/PolymorphicLight.h", ["range #define DISTANT_LIGHT_DISTANCE..#endif // __POLYMORPHIC_LIGHT_H__"]),
+    ("Lighting/PolymorphicLightPTConfig.h", ["pp"]),
+    ("Lighting/LightShaping.hlsli", ["range ^struct LightShaping..#endif // LIGHT_SHAPING_HLSLI"]),
+    ("Lighting/PolymorphicLight.hlsli", ["range #define FLT_EPSILON_MINI..#endif // __POLYMORPHIC_LIGHT_HLSLI__ -Eval"]),
     # ---- the whole standard BSDF (FalcorBSDF and its four lobes), once per diffuse model
     ("Utils/Math/MathConstants.hlsli", ["range static const float\\s+cFloatOneMinusEpsilon..^\\s*$"]),
     ("Rendering/Materials/LobeType.hlsli", ["struct LobeType"]),
@@ -112,13 +120,24 @@ def extract_struct(text, spec, path):
     return body
 
 
-def extract_range(text, spec, path):
+def extract_range(text, spec, path, raw=None):
+    drop = [w[1:] for w in spec.split() if w.startswith("-")]
+    spec = " ".join(w for w in spec.split(" ") if not (w.startswith("-") and w[1:] in drop))
     a, b = spec.split("..", 1)
     lines = text.split("\n")
-    i0 = next((i for i, l in enumerate(lines) if re.search(a, l)), None)
+    marks = (raw if raw is not None else text).split("\n")             # markers may sit in comments; comment stripping keeps the line structure
+    assert len(marks) == len(lines)
+    i0 = next((i for i, l in enumerate(marks) if re.search(a, l)), None)
     if i0 is None: raise SystemExit("hlsl_tu.py: range start /%s/ not found in %s" % (a, path))
-    i1 = next((i for i in range(i0 + 1, len(lines)) if re.search(b, lines[i])), len(lines))
-    return "\n".join(l for l in lines[i0:i1] if not re.match(r"\s*#\s*include", l))
+    i1 = next((i for i in range(i0 + 1, len(marks)) if re.search(b, marks[i])), None)
+    if i1 is None: raise SystemExit("hlsl_tu.py: range end /%s/ not found in %s" % (b, path))
+    body = "\n".join(l for l in lines[i0:i1] if not re.match(r"\s*#\s*include", l))
+    for d in drop:                                     # functions that need declarations outside the pin
+        while True:
+            k = re.search(r"^[ \t]*[A-Za-z_][\w<>]*\s+" + re.escape(d) + r"\s*\([^)]*\)\s*\{", body, re.M)
+            if not k: break
+            body = body[:k.start()] + body[match_brace(body, k.end() - 1) + 1:]
+    return body
 
 
 def to_cpp(code):
@@ -126,6 +145,8 @@ def to_cpp(code):
     code = re.sub(r"([(,]\s*)in\s+(?=(?:const\s+)?[A-Za-z_]\w*\s+[A-Za-z_]\w*)", r"\1", code)
     code = re.sub(r"\bconst\s+(?=[A-Za-z_]\w*\s+[A-Za-z_]\w*\s*[,)])", "", code)        # by-value parameters: HLSL calls non-const methods on them
     code = re.sub(r"\b_alpha\.xx\b", "float2(_alpha, _alpha)", code)
+    code = re.sub(r"\b(radiance|unpackedRadiance)\.xxx\b", r"float3(\1)", code)           # scalars by declaration in the reference text
+    code = re.sub(r"\(\s*([A-Z]\w*)\s*\)\s*0\b(?!\.)", r"\1()", code)                        # `(Struct)0`: zero initialisation
     code = re.sub(r"(\((?:[^()]|\([^()]*\))*\))\.xxx\b", r"float3(\1)", code)              # `(scalar expression).xxx`
     code = re.sub(r"\bpackedData\.x\b", "packedData", code)                               # `.x` of a scalar
     code = re.sub(r"\.(xy|yx|xx|xz|yz|zw|xyz|rgb)\b", r".\1_()", code)
@@ -140,7 +161,8 @@ def main():
     w('// generated by oracle/refpin/hlsl_tu.py -- never written to disk\n#include "%s/hlsl_shim.h"\nnamespace hl {\n' % HERE)
     for rel, names in PLAN:
         path = os.path.join(ref, SHADERS, rel)
-        text = strip_comments(open(path, encoding="latin-1").read())
+        raw = open(path, encoding="latin-1").read()
+        text = strip_comments(raw)
         for name in names:
             if name.startswith("#"):
                 for m in re.finditer(r"^[ \t]*#define[ \t]+(" + re.escape(name[1:]) + r"\w*)[ \t]+(\S+)", text, re.M):
@@ -150,7 +172,7 @@ def main():
             if name == "pp":
                 w("\n".join(l for l in text.split("\n") if re.match(r"\s*#", l) and not re.match(r"\s*#\s*include", l)) + "\n"); continue
             if name.startswith("struct "): w("// ---- %s : %s\n" % (rel, name)); w(to_cpp(extract_struct(text, name[7:], rel))); w("\n"); continue
-            if name.startswith("range "): w("// ---- %s : %s\n" % (rel, name)); w(to_cpp(extract_range(text, name[6:], rel))); w("\n"); continue
+            if name.startswith("range "): w("// ---- %s : %s\n" % (rel, name)); w(to_cpp(extract_range(text, name[6:], rel, raw))); w("\n"); continue
             for body in extract_function(text, name, rel):
                 w("// ---- %s : %s\n" % (rel, name)); w(to_cpp(body)); w("\n")
     w("} // namespace hl\n")

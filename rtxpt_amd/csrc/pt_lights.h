@@ -135,9 +135,12 @@ struct TriangleLight {
         PolymorphicLightInfoFull li; __builtin_memset(&li, 0, sizeof(li));
         PackLightColor(radiance, li.Base);
         li.Base.Center = base + ((edge1 + edge2) / 3.0f);
-        li.Base.Direction1 = (f32tof16(edge1.x) & 0xffffu) | (f32tof16(edge2.x) << 16);
-        li.Base.Direction2 = (f32tof16(edge1.y) & 0xffffu) | (f32tof16(edge2.y) << 16);
-        li.Base.Scalars    = (f32tof16(edge1.z) & 0xffffu) | (f32tof16(edge2.z) << 16);
+        // Reference quirk, kept on purpose (PolymorphicLight.hlsli:511-514): the packed words pass through a `float3 edges` temporary, i.e. a numeric
+        // uint -> float -> uint round trip that keeps only the 24 leading bits of each word. The fp16 of edge2 (high half) survives, the fp16 of
+        // edge1 (low half) keeps its sign, exponent and 2-3 mantissa bits. This is what LightsBaker.hlsl:699 stores and every NEE sample reads back.
+        li.Base.Direction1 = (uint)(float)((f32tof16(edge1.x) & 0xffffu) | (f32tof16(edge2.x) << 16));
+        li.Base.Direction2 = (uint)(float)((f32tof16(edge1.y) & 0xffffu) | (f32tof16(edge2.y) << 16));
+        li.Base.Scalars    = (uint)(float)((f32tof16(edge1.z) & 0xffffu) | (f32tof16(edge2.z) << 16));
         li.Base.ColorTypeAndFlags |= (uint)kTriangle << kPolymorphicLightTypeShift;
         li.Extended.UniqueID = uniqueID;
         return li;
@@ -172,6 +175,14 @@ struct TriangleLight {
     }
     float GetPower() const { return surfaceArea * K_PI * Luminance(radiance); }
 };
+
+// LightShaping.hlsli:161-174
+static inline float getShapingFluxFactor(const LightShaping& shaping) {
+    if (!shaping.isSpot) return 1.0f;
+    float solidAngleOverTwoPi = (1.0f - shaping.cosConeAngle);
+    solidAngleOverTwoPi *= lerpf(1.0f, 0.5f, shaping.cosConeSoftness);
+    return solidAngleOverTwoPi * 0.5f;
+}
 
 // PolymorphicLight.hlsli:93-259 (sampling + MIS pdf only; proxy-mesh Eval is N3)
 struct SphereLight {
@@ -214,7 +225,7 @@ struct SphereLight {
         ls.LightSampleableByBSDF = false;
         return ls;
     }
-    float GetPower() const { return 4 * K_PI * sq(radius) * K_PI * Luminance(radiance); }  // shaping flux factor = 1 for unshaped
+    float GetPower() const { return 4 * K_PI * sq(radius) * K_PI * Luminance(radiance) * getShapingFluxFactor(shaping); }       // PolymorphicLight.hlsli:224-232
 };
 
 // PolymorphicLight.hlsli:562-640. ToWorld uses the env map transform (PathTracerNEE.hlsli:16-33).

@@ -18,5 +18,9 @@ out["bsdf_in"] = pin_inputs.bsdf_cases(3000, 0x5EED0200)
 out["bsdf_out"] = ptref.bsdf_probe(out["bsdf_in"], reference=True)
 out["stream_in"] = pin_inputs.stream_cases(4000, 0x5EED0300)
 out["stream_out"] = ptref.sample_streams(out["stream_in"], reference=True)
+lights = pin_inputs.light_inputs(512, 0x5EED0400, lambda kind, w: ptref.light_probe(kind, w, reference=True))
+for kind, words in lights.items():
+    out["light%d_in" % kind] = words
+    out["light%d_out" % kind] = ptref.light_probe(kind, words, reference=True)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "refpin_hlsl_golden.npz"), **out)
 print("wrote %d functions" % len(ptref.PIN_NAMES))

@@ -82,3 +82,44 @@ def stream_cases(n, seed):
     C[:, 3] = rng.choice([0, 1, 2, 3, 5, 6], n); C[:, 4] = rng.integers(0, 5, n)
     C[:, 5] = np.where(C[:, 4] < 2, rng.integers(1, 5, n), rng.integers(1, 9, n))
     return C
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _f16(x):
+    return np.asarray(x, np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)      # round-to-nearest-even, as the oracle's f32tof16
+
+
+def light_inputs(n, seed, probe):
+    """Input rows (uint32 words) for the five light probes. `probe(kind, words)` evaluates a probe (used to obtain packed colours, triangle records and
+    oct-encoded axes for the records of kind 2 / 3, so the test data depends only on the implementation under test being self-consistent)."""
+    rng = np.random.default_rng(seed)
+    rad = _logu(rng, (n, 3), 1e-3, 1e5).astype(np.float32); rad[:3] = [[0, 0, 0], [1, 1, 1], [0, 5, 0]]; rad[3:8, rng.integers(0, 3)] = 0
+    k0 = _bits(rad)
+    base = rng.uniform(-50, 50, (n, 3)); e1 = rng.normal(size=(n, 3)) * _logu(rng, (n, 1), 1e-2, 5); e2 = rng.normal(size=(n, 3)) * _logu(rng, (n, 1), 1e-2, 5)
+    e2[:2] = e1[:2] * 2                                                   # degenerate triangles
+    k1 = _bits(np.column_stack([base, e1, e2, rad]))
+    tri = probe(1, k1)
+    col = probe(0, k0)
+    viewer = rng.uniform(-60, 60, (n, 3)); u = np.vstack([rng.uniform(0, 1, (n - 3, 2)), [[0, 0], [0.999999, 0.999999], [0.5, 0.5]]])
+    # sphere records: centre, radius (fp16), colour, optional spot shaping
+    axis = probe(4, _bits(_unit(rng, n)))[:, 0]
+    sph = np.zeros((n, 12), np.uint32)
+    c = rng.uniform(-30, 30, (n, 3)); sph[:, 0:3] = _bits(c)
+    spot = rng.random(n) < 0.5; minf = rng.random(n) < 0.3
+    sph[:, 3] = col[:, 0] | (0 << 24) | np.where(spot, 1 << 28, 0).astype(np.uint32) | np.where(spot & minf, 1 << 30, 0).astype(np.uint32)
+    sph[:, 6] = _f16(_logu(rng, n, 1e-2, 10)); sph[:, 7] = col[:, 1]
+    sph[:, 9] = axis; sph[:, 10] = _f16(rng.uniform(-0.5, 0.99, n)) | (_f16(rng.uniform(0.0, 0.5, n)) << 16); sph[:, 11] = 11
+    vs = viewer.copy(); vs[:4] = c[:4] + 1e-3                             # viewers inside the sphere
+    # environment quads: node (x, y) of a dim x dim equal-area octahedral grid
+    env = np.zeros((n, 12), np.uint32)
+    dim = 2 ** rng.integers(0, 9, n); nx = (rng.random(n) * dim).astype(np.uint32); ny = (rng.random(n) * dim).astype(np.uint32)
+    env[:, 3] = col[:, 0] | (5 << 24); env[:, 4] = (nx << 16) | ny; env[:, 5] = dim.astype(np.uint32) << 16; env[:, 6] = _bits(rng.uniform(0, 1, n)); env[:, 7] = col[:, 1]; env[:, 11] = 13
+    recs = np.vstack([tri, sph, env]); rnd = np.vstack([u, u, u]); vw = np.vstack([viewer, vs, viewer])
+    k2 = np.column_stack([recs, _bits(rnd), _bits(vw)])
+    smp = probe(2, k2[:n])[:, 0:3]                                        # sample positions on the triangles
+    k3 = np.column_stack([tri, _bits(viewer), smp])
+    k4 = _bits(np.vstack([_unit(rng, n - 9), _axes()]))
+    return {0: k0, 1: k1, 2: k2, 3: k3, 4: k4}

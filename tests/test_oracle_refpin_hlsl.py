@@ -87,3 +87,37 @@ def test_sample_generators_match_live_reference():
     cases = pin_inputs.stream_cases(60000, 0x57EA)
     got, want = ptref.sample_streams(cases), ptref.sample_streams(cases, reference=True)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%d streams differ" % int((got != want).any(1).sum())
+
+
+LIGHT_KINDS = {0: "PackColor/UnpackColor", 1: "TriangleLight::Store", 2: "PolymorphicLight::CalcSample+GetPower (triangle, sphere+shaping, environment quad)",
+               3: "TriangleLight::CalcSolidAnglePdfForMIS", 4: "NDirToOctUnorm32/OctToNDirUnorm32"}
+
+
+def _words_equal(got, want):
+    g, w = got.view(np.float32), want.view(np.float32)
+    return (got == want) | (np.isnan(g) & np.isnan(w))
+
+
+@pytest.mark.parametrize("kind", sorted(LIGHT_KINDS), ids=lambda k: "kind%d" % k)
+def test_lights_match_reference_golden(kind):
+    """PolymorphicLight.hlsli:93-259, 399-520, 562-640, 643-676, 762-792, LightShaping.hlsli:16-99, Utils.hlsli:127-152, Packing.hlsli:17-51 compiled from the reference text."""
+    g = np.load(GOLDEN)
+    words, want = g["light%d_in" % kind], g["light%d_out" % kind]
+    got = ptref.light_probe(kind, words)
+    ok = _words_equal(got, want)
+    bad = np.flatnonzero(~ok.all(1))
+    assert ok.all(), "%s: %d of %d rows differ; first row %d: oracle=%s reference=%s" % (LIGHT_KINDS[kind], len(bad), len(words), bad[0], got[bad[0]], want[bad[0]])
+    if kind == 2:
+        pdf = want[:, 9].view(np.float32)
+        assert (pdf[:512] > 0).sum() > 100 and (pdf[512:1024] > 0).sum() > 400 and (pdf[1024:] > 0).all()      # triangles facing the viewer, spheres, environment quads
+
+
+def test_lights_match_live_reference():
+    if ptref.refpin_hlsl() is None:
+        pytest.skip("librefpin_hlsl.so not available (no /root/reference on this machine)")
+    inputs = pin_inputs.light_inputs(20000, 0x11647, lambda kind, w: ptref.light_probe(kind, w))       # records built with the oracle's own packing ...
+    for kind, words in inputs.items():
+        got, want = ptref.light_probe(kind, words), ptref.light_probe(kind, words, reference=True)    # ... must read back identically through the reference text
+        ok = _words_equal(got, want)
+        bad = np.flatnonzero(~ok.all(1))
+        assert ok.all(), "%s: %d of %d rows differ; first row %d: in=%s oracle=%s reference=%s" % (LIGHT_KINDS[kind], len(bad), len(words), bad[0], words[bad[0]], got[bad[0]], want[bad[0]])
