@@ -1,0 +1,59 @@
+// ORACLE pin (test infrastructure only): what the integrator translation unit needs beyond hlsl_shim.h — the compile-time configuration the
+// reference's pipeline baker passes as shader macros (Sample.cpp:988-1040; reference mode with the §8a parity knobs), and stand-ins for GPU
+// resource types and the debug context.
+#pragma once
+#define row_major
+#define PATH_TRACER_MODE                                PATH_TRACER_MODE_REFERENCE
+#define NON_PATH_TRACING_PASS                           0
+#define __SHADER_TARGET_MAJOR                           0
+#define __SHADER_TARGET_MINOR                           0
+#define ENABLE_DEBUG_SURFACE_VIZ                        0
+#define ENABLE_DEBUG_LINES_VIZ                          0
+#define PT_NEE_ENABLED                                  1
+#define PT_USE_RESTIR_DI                                0
+#define PT_USE_RESTIR_GI                                0
+#define RTXPT_USE_APPROXIMATE_MIS                       0
+#define RTXPT_DISCARD_NON_NEE_LIGHTING                  0
+#define RTXPT_DISCARD_NEE_LIGHTING                      0
+#define RTXPT_LP_TYPES_USE_16BIT_PRECISION              0
+#define RTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF   1
+#define NEEAT_BAKER_ONLY                                0
+#ifndef PT_ENABLE_RUSSIAN_ROULETTE
+#define PT_ENABLE_RUSSIAN_ROULETTE                      1
+#endif
+#ifndef RTXPT_FIREFLY_FILTER
+#define RTXPT_FIREFLY_FILTER                            1
+#endif
+#ifndef RTXPT_NESTED_DIELECTRICS_QUALITY
+#define RTXPT_NESTED_DIELECTRICS_QUALITY                1
+#endif
+namespace hl {
+struct RayDesc { float3 Origin; float TMin; float3 Direction; float TMax; };
+struct SamplerState {};
+template <class T> struct Texture2D { T SampleLevel(SamplerState, float2, float) const { return T(); } T SampleGrad(SamplerState, float2, float2, float2) const { return T(); } T Load(int3) const { return T(); } T operator[](uint2) const { return T(); }
+    void GetDimensions(uint& w, uint& h) const { w = h = 1; } void GetDimensions(uint, uint& w, uint& h, uint& l) const { w = h = l = 1; } };
+template <class T> struct TextureCube { T SampleLevel(SamplerState, float3, float) const { return T(); } };
+template <class T> struct RWTexture2D { T dummy; T& operator[](uint2) { return dummy; } T operator[](uint2) const { return dummy; } void GetDimensions(uint& w, uint& h) const { w = h = 1; } };
+template <class T> struct RWTexture2DArray { T dummy; T& operator[](uint3) { return dummy; } T operator[](uint3) const { return dummy; } };
+template <class T> struct RWTexture3D { T dummy; T& operator[](uint3) { return dummy; } };
+template <class T> struct StructuredBuffer { const T* p = nullptr; const T& operator[](uint i) const { return p[i]; } };
+template <class T> struct RWStructuredBuffer { T* p = nullptr; T& operator[](uint i) const { return p[i]; } };
+template <class T> struct Buffer { const T* p = nullptr; T operator[](uint i) const { return p[i]; } };
+template <class T> struct RWBuffer { T* p = nullptr; T& operator[](uint i) const { return p[i]; } };
+struct ByteAddressBuffer { const uint* p = nullptr; uint Load(uint o) const { return p[o / 4]; } };
+struct RWByteAddressBuffer { uint* p = nullptr; uint Load(uint o) const { return p[o / 4]; } void Store(uint o, uint v) const { p[o / 4] = v; } };
+struct RaytracingAccelerationStructure {};
+static const uint RAY_FLAG_NONE = 0, RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH = 4, RAY_FLAG_CULL_NON_OPAQUE = 0x80;
+template <uint F, uint G = 0> struct RayQuery {};
+struct TriangleHit { uint instanceIndex, geometryIndex, primitiveIndex; float2 barycentrics; };
+struct PackedHitInfo { uint4 d; };
+// PathTracerDebug.hlsli's context: the integrator only ever calls into it behind ENABLE_DEBUG_* switches that are off here
+struct DebugContext { bool IsDebugPixel() const { return false; } bool IsDebugPixel(uint2) const { return false; } void Reset(uint) {} void Reset(uint2, int) {} };
+static inline void DebugCross(float3, float, float4) {}
+struct ExplicitRayConesLodTextureSampler {}; struct ExplicitLodTextureSampler {};           // Scene/Material/TextureSampler.hlsli: texture fetches belong to the bridge
+static inline float max3(float a, float b, float c) { return max(a, max(b, c)); }              // Utils/ColorHelpers.hlsli:19-27
+static inline float max3(float3 v) { return max3(v.x, v.y, v.z); }
+// DXR system values of the closest-hit shader HandleHit runs in: set by the driver loop before each call
+static thread_local uint g_hitInstanceIndex = 0, g_hitGeometryIndex = 0, g_hitPrimitiveIndex = 0;
+static inline uint InstanceIndex() { return g_hitInstanceIndex; } static inline uint GeometryIndex() { return g_hitGeometryIndex; } static inline uint PrimitiveIndex() { return g_hitPrimitiveIndex; }
+} // namespace hl

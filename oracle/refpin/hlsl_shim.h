@@ -17,17 +17,22 @@ typedef uint32_t uint;
 namespace P = ptref;
 
 template <class T> struct v2 { union { struct { T x, y; }; struct { T r, g; }; }; v2() : x(), y() {} v2(T s) : x(s), y(s) {} v2(T a, T b) : x(a), y(b) {}
-    template <class U> explicit v2(const v2<U>& o) : x((T)o.x), y((T)o.y) {}
-    v2& xy_() { return *this; } v2 yx_() const { return v2(y, x); } v2 xx_() const { return v2(x, x); } };
+    template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v2(const v2<U>& o) : x((T)o.x), y((T)o.y) {}
+    v2& xy_() { return *this; } const v2& xy_() const { return *this; } v2 yx_() const { return v2(y, x); } v2 xx_() const { return v2(x, x); }
+    T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
 template <class T> struct v3 { union { struct { T x, y, z; }; struct { T r, g, b; }; }; v3() : x(), y(), z() {} v3(T s) : x(s), y(s), z(s) {} v3(T a, T b, T c) : x(a), y(b), z(c) {}
-    v3(v2<T> a, T c) : x(a.x), y(a.y), z(c) {}
+    v3(v2<T> a, T c) : x(a.x), y(a.y), z(c) {} v3(T a, v2<T> b) : x(a), y(b.x), z(b.y) {}
     template <class A, class B, class C, class = typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value && std::is_arithmetic<C>::value && !(std::is_same<A, T>::value && std::is_same<B, T>::value && std::is_same<C, T>::value)>::type>
     v3(A a, B b, C c) : x((T)a), y((T)b), z((T)c) {}
     template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v3(const v3<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z) {}       // HLSL converts between component types implicitly
     v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> yx_() const { return v2<T>(y, x); } v2<T> xz_() const { return v2<T>(x, z); } v2<T> yz_() const { return v2<T>(y, z); }
-    v3& xyz_() { return *this; } const v3& xyz_() const { return *this; } v3& rgb_() { return *this; } const v3& rgb_() const { return *this; } };
+    v3& xyz_() { return *this; } const v3& xyz_() const { return *this; } v3& rgb_() { return *this; } const v3& rgb_() const { return *this; }
+    T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
 template <class T> struct v4 { union { struct { T x, y, z, w; }; struct { T r, g, b, a; }; }; v4() : x(), y(), z(), w() {} v4(T s) : x(s), y(s), z(s), w(s) {} v4(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}
-    v4(v3<T> a, T d) : x(a.x), y(a.y), z(a.z), w(d) {} v4(v2<T> a, v2<T> b) : x(a.x), y(a.y), z(b.x), w(b.y) {}
+    v4(v3<T> a, T d) : x(a.x), y(a.y), z(a.z), w(d) {} v4(v2<T> a, v2<T> b) : x(a.x), y(a.y), z(b.x), w(b.y) {} v4(v2<T> a, T c, T d) : x(a.x), y(a.y), z(c), w(d) {}
+    template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v4(const v4<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z), w((T)o.w) {}
+    v4& rgba_() { return *this; } const v4& rgba_() const { return *this; }
+    v4& xyzw_() { return *this; } const v4& xyzw_() const { return *this; } v3<T> xyw_() const { return v3<T>(x, y, w); } v3<T> xzw_() const { return v3<T>(x, z, w); } v3<T> yzw_() const { return v3<T>(y, z, w); } v4 wzyx_() const { return v4(w, z, y, x); }
     v3<T>& xyz_() { return *reinterpret_cast<v3<T>*>(this); } v3<T> xyz_() const { return v3<T>(x, y, z); } v3<T>& rgb_() { return xyz_(); } v3<T> rgb_() const { return xyz_(); }
     v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> zw_() const { return v2<T>(z, w); }
     T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
@@ -42,27 +47,31 @@ typedef uint lpuint;
 // scalar operand of a mixed vector/scalar expression: HLSL converts it to the vector's component type
 template <class T, class S> using if_arith = typename std::enable_if<std::is_arithmetic<S>::value, T>::type;
 
+template <class A, class B> using ctype = typename std::common_type<A, B>::type;
 #define HL_BINOP(op) \
-    template <class T> v2<T> operator op(v2<T> a, v2<T> b) { return v2<T>(a.x op b.x, a.y op b.y); } \
-    template <class T> v3<T> operator op(v3<T> a, v3<T> b) { return v3<T>(a.x op b.x, a.y op b.y, a.z op b.z); } \
-    template <class T> v4<T> operator op(v4<T> a, v4<T> b) { return v4<T>(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w); } \
+    template <class A, class B> v2<ctype<A, B>> operator op(v2<A> a, v2<B> b) { typedef ctype<A, B> C; return v2<C>((C)a.x op (C)b.x, (C)a.y op (C)b.y); } \
+    template <class A, class B> v3<ctype<A, B>> operator op(v3<A> a, v3<B> b) { typedef ctype<A, B> C; return v3<C>((C)a.x op (C)b.x, (C)a.y op (C)b.y, (C)a.z op (C)b.z); } \
+    template <class A, class B> v4<ctype<A, B>> operator op(v4<A> a, v4<B> b) { typedef ctype<A, B> C; return v4<C>((C)a.x op (C)b.x, (C)a.y op (C)b.y, (C)a.z op (C)b.z, (C)a.w op (C)b.w); } \
     template <class T, class S> if_arith<v2<T>, S> operator op(v2<T> a, S b) { return a op v2<T>((T)b); } \
     template <class T, class S> if_arith<v3<T>, S> operator op(v3<T> a, S b) { return a op v3<T>((T)b); } \
     template <class T, class S> if_arith<v4<T>, S> operator op(v4<T> a, S b) { return a op v4<T>((T)b); } \
     template <class T, class S> if_arith<v2<T>, S> operator op(S a, v2<T> b) { return v2<T>((T)a) op b; } \
     template <class T, class S> if_arith<v3<T>, S> operator op(S a, v3<T> b) { return v3<T>((T)a) op b; } \
     template <class T, class S> if_arith<v4<T>, S> operator op(S a, v4<T> b) { return v4<T>((T)a) op b; } \
-    template <class T, class S> v2<T>& operator op##=(v2<T>& a, S b) { a = a op b; return a; } \
-    template <class T, class S> v3<T>& operator op##=(v3<T>& a, S b) { a = a op b; return a; } \
-    template <class T, class S> v4<T>& operator op##=(v4<T>& a, S b) { a = a op b; return a; }
+    template <class T, class S> v2<T>& operator op##=(v2<T>& a, S b) { a = v2<T>(a op b); return a; } \
+    template <class T, class S> v3<T>& operator op##=(v3<T>& a, S b) { a = v3<T>(a op b); return a; } \
+    template <class T, class S> v4<T>& operator op##=(v4<T>& a, S b) { a = v4<T>(a op b); return a; }
 HL_BINOP(+) HL_BINOP(-) HL_BINOP(*) HL_BINOP(/)
 #undef HL_BINOP
+template <class T> v2<T> operator+(v2<T> a) { return a; } template <class T> v3<T> operator+(v3<T> a) { return a; }
 template <class T> v2<T> operator-(v2<T> a) { return v2<T>(-a.x, -a.y); }
 template <class T> v3<T> operator-(v3<T> a) { return v3<T>(-a.x, -a.y, -a.z); }
 template <class T> v4<T> operator-(v4<T> a) { return v4<T>(-a.x, -a.y, -a.z, -a.w); }
 #define HL_CMP(op) \
     template <class T> bool2 operator op(v2<T> a, v2<T> b) { return bool2(a.x op b.x, a.y op b.y); } \
     template <class T> bool3 operator op(v3<T> a, v3<T> b) { return bool3(a.x op b.x, a.y op b.y, a.z op b.z); } \
+    template <class T> bool4 operator op(v4<T> a, v4<T> b) { return bool4(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w); } \
+    template <class T, class S> if_arith<bool4, S> operator op(v4<T> a, S b) { return a op v4<T>((T)b); } \
     template <class T, class S> if_arith<bool2, S> operator op(v2<T> a, S b) { return a op v2<T>((T)b); } \
     template <class T, class S> if_arith<bool3, S> operator op(v3<T> a, S b) { return a op v3<T>((T)b); }
 HL_CMP(<) HL_CMP(>) HL_CMP(<=) HL_CMP(>=) HL_CMP(==) HL_CMP(!=)
@@ -70,11 +79,14 @@ HL_CMP(<) HL_CMP(>) HL_CMP(<=) HL_CMP(>=) HL_CMP(==) HL_CMP(!=)
 #define HL_INTOP(op) \
     template <class T, class S> if_arith<v2<T>, S> operator op(v2<T> a, S b) { return v2<T>(a.x op (T)b, a.y op (T)b); } \
     template <class T, class S> if_arith<v3<T>, S> operator op(v3<T> a, S b) { return v3<T>(a.x op (T)b, a.y op (T)b, a.z op (T)b); } \
+    template <class T, class S> if_arith<v4<T>, S> operator op(v4<T> a, S b) { return v4<T>(a.x op (T)b, a.y op (T)b, a.z op (T)b, a.w op (T)b); } \
     template <class T> v2<T> operator op(v2<T> a, v2<T> b) { return v2<T>(a.x op b.x, a.y op b.y); } \
-    template <class T> v3<T> operator op(v3<T> a, v3<T> b) { return v3<T>(a.x op b.x, a.y op b.y, a.z op b.z); }
+    template <class T> v3<T> operator op(v3<T> a, v3<T> b) { return v3<T>(a.x op b.x, a.y op b.y, a.z op b.z); } \
+    template <class T> v4<T> operator op(v4<T> a, v4<T> b) { return v4<T>(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w); }
 HL_INTOP(&) HL_INTOP(|) HL_INTOP(>>) HL_INTOP(<<)
 #undef HL_INTOP
 static inline bool any(bool2 b) { return b.x || b.y; } static inline bool any(bool3 b) { return b.x || b.y || b.z; }
+static inline bool any(bool4 b) { return b.x || b.y || b.z || b.w; } static inline bool all(bool4 b) { return b.x && b.y && b.z && b.w; }
 static inline bool all(bool2 b) { return b.x && b.y; } static inline bool all(bool3 b) { return b.x && b.y && b.z; }
 static inline bool any(float3 v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f; }
 template <class T> T select(bool c, T a, T b) { return c ? a : b; }
@@ -105,9 +117,13 @@ template <class A, class B> typename std::enable_if<std::is_integral<A>::value &
 HL_LIFT2(min) HL_LIFT2(max)
 static inline float abs(float v) { return fabsf(v); } static inline int abs(int v) { return v < 0 ? -v : v; } HL_LIFT1(abs)
 static inline float saturate(float v) { return P::saturate(v); } HL_LIFT1(saturate)
-template <class A, class B, class C> float clamp(A v, B lo, C hi) { return P::clampf((float)v, (float)lo, (float)hi); }
-static inline float3 clamp(float3 v, float lo, float hi) { return float3(clamp(v.x, lo, hi), clamp(v.y, lo, hi), clamp(v.z, lo, hi)); }
+template <class A, class B, class C> typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value && std::is_arithmetic<C>::value, float>::type
+    clamp(A v, B lo, C hi) { return P::clampf((float)v, (float)lo, (float)hi); }
+template <class B, class C> if_arith<float2, B> clamp(float2 v, B lo, C hi) { return float2(clamp(v.x, lo, hi), clamp(v.y, lo, hi)); }
+template <class B, class C> if_arith<float3, B> clamp(float3 v, B lo, C hi) { return float3(clamp(v.x, lo, hi), clamp(v.y, lo, hi), clamp(v.z, lo, hi)); }
+template <class B, class C> if_arith<float4, B> clamp(float4 v, B lo, C hi) { return float4(clamp(v.x, lo, hi), clamp(v.y, lo, hi), clamp(v.z, lo, hi), clamp(v.w, lo, hi)); }
 static inline float3 clamp(float3 v, float3 lo, float3 hi) { return float3(clamp(v.x, lo.x, hi.x), clamp(v.y, lo.y, hi.y), clamp(v.z, lo.z, hi.z)); }
+static inline float4 clamp(float4 v, float4 lo, float4 hi) { return float4(clamp(v.x, lo.x, hi.x), clamp(v.y, lo.y, hi.y), clamp(v.z, lo.z, hi.z), clamp(v.w, lo.w, hi.w)); }
 static inline float sign(float v) { return P::signf_(v); } HL_LIFT1(sign)
 static inline float sqrt(float v) { return P::sqrtf_(v); } HL_LIFT1(sqrt)
 static inline float rsqrt(float v) { return 1.0f / P::sqrtf_(v); }
@@ -122,7 +138,8 @@ static inline float atan2(float y, float x) { return P::dm_atan2(y, x); }
 template <class E> float pow(float x, E e) { return ((float)e == 5.0f) ? P::dm_pow5(x) : P::dm_pow(x, (float)e); }      // pow(x, 5): the oracle's (x²·x²)·x
 template <class E> float3 pow(float3 x, E e) { return float3(pow(x.x, e), pow(x.y, e), pow(x.z, e)); }
 template <class E> float4 pow(float4 x, E e) { return float4(pow(x.x, e), pow(x.y, e), pow(x.z, e), pow(x.w, e)); }
-static inline float mad(float a, float b, float c) { return a * b + c; }                                                // unfused (-ffp-contract=off)
+static inline float mad(float a, float b, float c) { return a * b + c; }
+static inline float3 mad(float3 a, float3 b, float3 c) { return a * b + c; }                                                // unfused (-ffp-contract=off)
 static inline float smoothstep(float a, float b, float x) { float t = saturate((x - a) / (b - a)); return t * t * (3.0f - 2.0f * t); }
 static inline float lerp(float a, float b, float t) { return P::lerpf(a, b, t); }
 static inline float3 lerp(float3 a, float3 b, float t) { return a + (b - a) * t; }
@@ -143,12 +160,31 @@ static inline float3 asfloat(int3 v) { return float3(asfloat(v.x), asfloat(v.y),
 static inline float3 asfloat(uint3 v) { return float3(asfloat(v.x), asfloat(v.y), asfloat(v.z)); }
 static inline uint f32tof16(float f) { return P::f32tof16(f); } static inline float f16tof32(uint h) { return P::f16tof32(h); }
 static inline uint2 f32tof16(float2 f) { return uint2(f32tof16(f.x), f32tof16(f.y)); }
+static inline uint4 f32tof16(float4 f) { return uint4(f32tof16(f.x), f32tof16(f.y), f32tof16(f.z), f32tof16(f.w)); }
+static inline float4 f16tof32(uint4 h) { return float4(f16tof32(h.x), f16tof32(h.y), f16tof32(h.z), f16tof32(h.w)); }
 static inline uint3 f32tof16(float3 f) { return uint3(f32tof16(f.x), f32tof16(f.y), f32tof16(f.z)); }
 static inline float3 f16tof32(uint3 h) { return float3(f16tof32(h.x), f16tof32(h.y), f16tof32(h.z)); }
 static inline float2 f16tof32(uint2 h) { return float2(f16tof32(h.x), f16tof32(h.y)); }
 static inline uint countbits(uint v) { return (uint)__builtin_popcount(v); }
 static inline uint firstbithigh(uint v) { return v ? 31u - (uint)__builtin_clz(v) : 0xFFFFFFFFu; }
 static inline uint reversebits(uint v) { uint r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
+// ---- matrices (row-major, rows are vectors): only what the integrator's helpers touch
+struct float3x4;
+struct float3x3 { float3 r[3]; float3x3() {} float3x3(const float3x4& M); float3x3(float3 a, float3 b, float3 c) { r[0] = a; r[1] = b; r[2] = c; }
+    float3x3(float a, float b, float c, float d, float e, float f, float g, float h, float i) { r[0] = float3(a, b, c); r[1] = float3(d, e, f); r[2] = float3(g, h, i); }
+    float3& operator[](uint i) { return r[i]; } const float3& operator[](uint i) const { return r[i]; } };
+struct float3x4 { float4 r[3]; float4& operator[](uint i) { return r[i]; } const float4& operator[](uint i) const { return r[i]; } };
+struct float4x4 { float4 r[4]; float4& operator[](uint i) { return r[i]; } const float4& operator[](uint i) const { return r[i]; } };
+struct float2x2 { float2 r[2]; float2x2() {} float2x2(float a, float b, float c, float d) { r[0] = float2(a, b); r[1] = float2(c, d); } float2& operator[](uint i) { return r[i]; } const float2& operator[](uint i) const { return r[i]; } };
+struct float2x3 { float3 r[2]; float3& operator[](uint i) { return r[i]; } const float3& operator[](uint i) const { return r[i]; } };
+inline float3x3::float3x3(const float3x4& M) { r[0] = M.r[0].xyz_(); r[1] = M.r[1].xyz_(); r[2] = M.r[2].xyz_(); }
+static inline float2 mul(float2x2 M, float2 v) { return float2(dot(M.r[0], v), dot(M.r[1], v)); }
+static inline float3 mul(float3x3 M, float3 v) { return float3(dot(M.r[0], v), dot(M.r[1], v), dot(M.r[2], v)); }
+static inline float3 mul(float3 v, float3x3 M) { return float3((v.x * M.r[0].x + v.y * M.r[1].x) + v.z * M.r[2].x, (v.x * M.r[0].y + v.y * M.r[1].y) + v.z * M.r[2].y, (v.x * M.r[0].z + v.y * M.r[1].z) + v.z * M.r[2].z); }
+static inline float3x3 mul(float3x3 A, float3x3 B) { float3x3 R; for (int i = 0; i < 3; i++) R.r[i] = mul(A.r[i], B); return R; }
+static inline float3x3 transpose(float3x3 M) { return float3x3(float3(M.r[0].x, M.r[1].x, M.r[2].x), float3(M.r[0].y, M.r[1].y, M.r[2].y), float3(M.r[0].z, M.r[1].z, M.r[2].z)); }
+static inline float determinant(float3x3 M) { return dot(M.r[0], cross(M.r[1], M.r[2])); }
+template <class T> T ddx(T) { return T(); } template <class T> T ddy(T) { return T(); }       // pixel-shader derivatives: no meaning here, never executed
 #undef HL_LIFT1
 #undef HL_LIFT2
 } // namespace hl

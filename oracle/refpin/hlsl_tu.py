@@ -8,7 +8,8 @@ The only edits made to the reference text are the ones C++ syntax forces:
   * `out T x` / `inout T x` parameters become `T& x`; the `in` qualifier is dropped
   * vector swizzles `.xy` `.yx` `.xyz` `.rgb` ... become member calls `.xy_()` (hlsl_shim.h); swizzles on scalars (`_alpha.xx`, `(expr).xxx`,
     `packedData.x`) become constructor calls / the scalar itself
-  * `const` is dropped from by-value parameters (HLSL methods are not const-qualified)
+  * `const` is dropped from by-value parameters (HLSL methods are not const-qualified); `this.` becomes `this->`; `: register(...)`, `row_major`,
+    `precise` and leading `::` are dropped; untyped `Texture2D` becomes `Texture2D<float4>`
   * `[unroll]`-style attributes and the `uniform` parameter qualifier are dropped
 usage: hlsl_tu.py /root/reference > tu.cpp"""
 import os, re, sys
@@ -141,21 +142,85 @@ def extract_range(text, spec, path, raw=None):
 
 
 def to_cpp(code):
-    code = re.sub(r"\b(?:inout|out)\s+(const\s+)?([A-Za-z_]\w*)\s+([A-Za-z_]\w*)", lambda m: "%s%s& %s" % (m.group(1) or "", m.group(2), m.group(3)), code)
-    code = re.sub(r"([(,]\s*)in\s+(?=(?:const\s+)?[A-Za-z_]\w*\s+[A-Za-z_]\w*)", r"\1", code)
-    code = re.sub(r"\bconst\s+(?=[A-Za-z_]\w*\s+[A-Za-z_]\w*\s*[,)])", "", code)        # by-value parameters: HLSL calls non-const methods on them
-    code = re.sub(r"\b_alpha\.xx\b", "float2(_alpha, _alpha)", code)
-    code = re.sub(r"\b(radiance|unpackedRadiance)\.xxx\b", r"float3(\1)", code)           # scalars by declaration in the reference text
-    code = re.sub(r"\(\s*([A-Z]\w*)\s*\)\s*0\b(?!\.)", r"\1()", code)                        # `(Struct)0`: zero initialisation
-    code = re.sub(r"(\((?:[^()]|\([^()]*\))*\))\.xxx\b", r"float3(\1)", code)              # `(scalar expression).xxx`
+    # parameters
+    code = re.sub(r"\b(?:inout|out)\s+(const\s+)?([A-Za-z_][\w:]*)\s+([A-Za-z_]\w*)\s*\[([^\]]+)\]", lambda m: "%s%s (&%s)[%s]" % (m.group(1) or "", m.group(2), m.group(3), m.group(4)), code)
+    code = re.sub(r"\b(?:inout|out)\s+(const\s+)?([A-Za-z_][\w:]*(?:\s*<[^<>]*>)?)\s+([A-Za-z_]\w*)", lambda m: "%s%s& %s" % (m.group(1) or "", m.group(2), m.group(3)), code)
+    code = re.sub(r"([(,]\s*(?:const\s+)?)in\s+(?=(?:const\s+)?[A-Za-z_]\w*\s+[A-Za-z_]\w*)", r"\1", code)
+    code = re.sub(r"\bconst\s+(?=[A-Za-z_][\w:]*\s+[A-Za-z_]\w*\s*[,)])", "", code)        # by-value parameters: HLSL calls non-const methods on them
+    code = re.sub(r"\bconst\s+(?=[A-Z]\w*\s+[A-Za-z_]\w*\s*=)", "", code)                  # `const Struct local = ...` likewise
+    code = re.sub(r"\bthis\.", "this->", code)
+    # swizzles on scalars (literals, named scalars, parenthesised / call expressions) become constructor calls ...
+    code = re.sub(r"(?<![\w.])(\d+\.\d*f?|\.\d+f?|\d+)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)     # `0.5.xx`, `0.xxx`
+    code = re.sub(r"\b(HLF_MAX|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
+    code = re.sub(r"((?:\b[A-Za-z_][\w.]*)?\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\))\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\bpackedData\.x\b", "packedData", code)                               # `.x` of a scalar
-    code = re.sub(r"\.(xy|yx|xx|xz|yz|zw|xyz|rgb)\b", r".\1_()", code)
+    # ... swizzles on vectors become member calls
+    code = re.sub(r"\.(xy|yx|xx|xz|yz|zw|xyz|rgb|rgba|xyw|xzw|yzw|xyzw|wzyx)\b", r".\1_()", code)
+    code = re.sub(r"\(\s*([A-Z]\w*)\s*\)\s*0\b(?!\.)", r"\1()", code)                        # `(Struct)0`: zero initialisation
     code = re.sub(r"\[(?:unroll|loop|branch|flatten|mutating|forceinline)(?:\([^)]*\))?\][ \t]*", "", code)
-    code = re.sub(r"\buniform\s+(?=uint|int|float)", "", code)
+    code = re.sub(r"\buniform\s+(?=uint|int|float|bool)", "", code)
+    code = re.sub(r":\s*register\s*\([^)]*\)", "", code)                                     # resource bindings
+    code = re.sub(r"\b(Texture2D|TextureCube|RWTexture2D|RWTexture2DArray)\b(?!\s*<)", r"\1<float4>", code)         # untyped resource = float4 elements
+    code = re.sub(r"\b(row_major|precise|nointerpolation|globallycoherent)[ \t]+", "", code)
+    code = re.sub(r"(?<![\w:>)])::(?=[A-Za-z_])", "", code)                                  # `::name` (global scope): everything lives in one namespace here
     return code
 
 
+# ---- second translation unit: the integrator. Whole files, in the order the preprocessor would visit them (includes are resolved here so that
+# every file's text goes through to_cpp); files on the deny list are replaced by the stubs of hlsl_pt_stubs.h.
+PT_ROOTS = ["../PathTracerBridge.hlsli", "PathTracer.hlsli"]
+PT_DENY = ("ShaderDebug.hlsl", "PathTracerDebug.hlsli", "STFSamplerState.hlsli", "Xoshiro.hlsli", "SplitMix64.hlsli", "BitTricks.hlsli",
+           "TextureSampler.hlsli", "HitInfo.hlsli", "HitInfoType.hlsli", "PackedFormats.hlsli", "FormatConversion.hlsli", "ColorHelpers.hlsli", "Quaternion.hlsli", "ShadingUtils.hlsli", "SceneTypes.hlsli")
+# files of which only some items are needed (the rest uses matrix member syntax / half types / pixel-shader intrinsics that the pin has no use for)
+PT_PICK = {
+    "MathHelpers.hlsli": ["ndir_to_oct_equal_area_unorm", "oct_to_ndir_equal_area_unorm", "sample_disk", "sample_disk_concentric", "sample_cosine_hemisphere_concentric",
+                          "sample_cosine_hemisphere_polar", "perp_stark", "sqr"],
+}
+
+
+def emit_file(path, w, done):
+    path = os.path.normpath(path)
+    if path in done: return
+    done.add(path)
+    raw = open(path, encoding="latin-1").read()
+    text = strip_comments(raw)
+    if os.path.basename(path) in PT_PICK:
+        w("// ======== %s (selected items)\n" % os.path.basename(path))
+        for name in PT_PICK[os.path.basename(path)]:
+            for body in extract_function(text, name, path): w(to_cpp(body) + "\n")
+        return
+    text = re.sub(r"!\s*defined\s*\(\s*__cplusplus\s*\)", "1", text)
+    text = re.sub(r"defined\s*\(\s*__cplusplus\s*\)", "0", text)
+    text = re.sub(r"^([ \t]*)#\s*ifdef\s+__cplusplus\b", r"\1#if 0", text, flags=re.M)
+    text = re.sub(r"^([ \t]*)#\s*ifndef\s+__cplusplus\b", r"\1#if 1", text, flags=re.M)
+    w("// ======== %s\n" % os.path.relpath(path, os.path.join(REF, SHADERS)))
+    chunk = []
+    def flush():
+        if chunk: w(to_cpp("\n".join(chunk)) + "\n"); del chunk[:]
+    for line in text.split("\n"):
+        m = re.match(r'\s*#\s*include\s*"([^"]+)"', line)
+        if not m: chunk.append(line); continue
+        flush()
+        inc = os.path.join(os.path.dirname(path), m.group(1))
+        if os.path.basename(inc) in PT_DENY or not os.path.exists(inc): w("// (not part of the pin: %s)\n" % m.group(1)); continue
+        emit_file(inc, w, done)
+    flush()
+
+
+def main_pt(ref):
+    global REF
+    REF = ref
+    w = sys.stdout.write
+    w('// generated by oracle/refpin/hlsl_tu.py --integrator -- never written to disk\n#include "%s/hlsl_shim.h"\n#include "%s/hlsl_pt_stubs.h"\nnamespace hl {\n' % (HERE, HERE))
+    done = set()
+    for r in PT_ROOTS: emit_file(os.path.join(ref, SHADERS, r), w, done)
+    w("} // namespace hl\n")
+    w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
+
+
 def main():
+    if "--integrator" in sys.argv:
+        sys.argv.remove("--integrator"); return main_pt(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     w = sys.stdout.write
     w('// generated by oracle/refpin/hlsl_tu.py -- never written to disk\n#include "%s/hlsl_shim.h"\nnamespace hl {\n' % HERE)
