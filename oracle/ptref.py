@@ -132,6 +132,48 @@ def light_probe(kind, words, reference=False):
     return out
 
 
+_pin_pt = {}
+
+
+def pt_variant(settings=None):
+    """The shader-macro combination (Sample.cpp:988-1040) that corresponds to a PtSettings record: (DiffuseBrdf, RR, firefly filter, nested quality, LD sampler, NEE)."""
+    if settings is None:
+        return (2, 1, 1, 1, 1, 1)
+    g = lambda k: int(np.asarray(settings[k]).reshape(-1)[0])
+    return (g("diffuseBrdf"), 1 if g("enableRussianRoulette") else 0, 1 if float(np.asarray(settings["fireflyFilterThreshold"]).reshape(-1)[0]) != 0 else 0,
+            g("nestedDielectricsQuality"), 1 if g("enableLDSamplerForBSDF") else 0, 1 if g("NEEEnabled") else 0)
+
+
+def refpin_pt(variant=(2, 1, 1, 1, 1, 1)):
+    """The reference's integrator text (PathTracer.hlsli & its include closure) compiled over the oracle's scene services, for one macro combination;
+    exports the whole ptref_* API plus refpt_render. Built on demand from /root/reference (oracle/refpin/hlsl_tu.py --integrator); None when unavailable."""
+    if variant in _pin_pt:
+        return _pin_pt[variant]
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(os.path.dirname(_PIN), "librefpin_pt_%d%d%d%d%d%d.so" % variant)
+    srcs = [os.path.join(here, "refpin", f) for f in ("hlsl_tu.py", "hlsl_shim.h", "hlsl_pt_stubs.h", "hlsl_pt_wrappers.inc")] + [os.path.join(here, "ptref", f) for f in os.listdir(os.path.join(here, "ptref"))]
+    stale = not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs)
+    if stale:
+        if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
+            if not os.path.exists(path):
+                _pin_pt[variant] = None
+                return None
+        else:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            d = "-DDiffuseBrdf=%d -DPT_ENABLE_RUSSIAN_ROULETTE=%d -DRTXPT_FIREFLY_FILTER=%d -DRTXPT_NESTED_DIELECTRICS_QUALITY=%d -DRTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF=%d -DPT_NEE_ENABLED=%d" % variant
+            cmd = ("python3 %s/refpin/hlsl_tu.py --integrator /root/reference | g++ -O2 -std=c++17 -fPIC -shared -fopenmp -mfma -ffp-contract=off -fno-fast-math "
+                   "-fsingle-precision-constant %s -I%s/refpin -x c++ - -o %s" % (here, d, here, path))
+            r = subprocess.run(["bash", "-o", "pipefail", "-c", cmd], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("librefpin_pt build failed:\n" + r.stderr[-3000:])
+    L = ctypes.CDLL(path)
+    L.ptref_create.restype = ctypes.c_void_p
+    L.ptref_radiance.restype = ctypes.POINTER(ctypes.c_float)
+    L.ptref_num_tris.restype = ctypes.c_uint32
+    _pin_pt[variant] = L
+    return L
+
+
 def _pin_table():
     """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
     import re
@@ -154,8 +196,14 @@ def _p(a):
 class Oracle:
     """Mirrors the call order of Sample::Render: set scene -> set camera/settings -> render(sample range) -> radiance."""
 
-    def __init__(self):
-        self.L = lib()
+    def __init__(self, reference_integrator=False, settings=None):
+        """reference_integrator=True: the same oracle scene services, but the path between the hits runs the REFERENCE'S integrator text
+        (oracle/_ref/librefpin_pt_*.so, oracle/refpin/hlsl_pt_wrappers.inc), compiled for the shader-macro combination `settings` stand for;
+        only where that library can be built."""
+        self.reference_integrator = reference_integrator
+        self.L = refpin_pt(pt_variant(settings)) if reference_integrator else lib()
+        if self.L is None:
+            raise RuntimeError("librefpin_pt.so not available (needs /root/reference)")
         self.h = ctypes.c_void_p(self.L.ptref_create())
         self.w = self.h_ = 0
 
@@ -209,7 +257,10 @@ class Oracle:
         self.L.ptref_reset_accumulation(self.h)
 
     def render(self, first, n, rect=None):
-        if rect is None:
+        if self.reference_integrator:
+            if rect is None: self.L.refpt_render(self.h, first, n)
+            else: self.L.refpt_render_rect(self.h, first, n, *rect)
+        elif rect is None:
             self.L.ptref_render(self.h, first, n)
         else:
             self.L.ptref_render_rect(self.h, first, n, *rect)

@@ -1,6 +1,7 @@
 // ORACLE pin (test infrastructure only): what the integrator translation unit needs beyond hlsl_shim.h — the compile-time configuration the
 // reference's pipeline baker passes as shader macros (Sample.cpp:988-1040; reference mode with the §8a parity knobs), and stand-ins for GPU
-// resource types and the debug context.
+// resource types and the debug context. The switches that are shader macros in the reference but run-time settings in the oracle (diffuse BRDF model,
+// Russian roulette, firefly filter, nested-dielectrics quality, LD sampler, NEE) come in as -D flags: one library per combination (oracle/ptref.py refpin_pt).
 #pragma once
 #define row_major
 #define PATH_TRACER_MODE                                PATH_TRACER_MODE_REFERENCE
@@ -9,14 +10,18 @@
 #define __SHADER_TARGET_MINOR                           0
 #define ENABLE_DEBUG_SURFACE_VIZ                        0
 #define ENABLE_DEBUG_LINES_VIZ                          0
+#ifndef PT_NEE_ENABLED
 #define PT_NEE_ENABLED                                  1
+#endif
 #define PT_USE_RESTIR_DI                                0
 #define PT_USE_RESTIR_GI                                0
 #define RTXPT_USE_APPROXIMATE_MIS                       0
 #define RTXPT_DISCARD_NON_NEE_LIGHTING                  0
 #define RTXPT_DISCARD_NEE_LIGHTING                      0
 #define RTXPT_LP_TYPES_USE_16BIT_PRECISION              0
+#ifndef RTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF
 #define RTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF   1
+#endif
 #define NEEAT_BAKER_ONLY                                0
 #ifndef PT_ENABLE_RUSSIAN_ROULETTE
 #define PT_ENABLE_RUSSIAN_ROULETTE                      1
@@ -30,10 +35,16 @@
 namespace hl {
 struct RayDesc { float3 Origin; float TMin; float3 Direction; float TMax; };
 struct SamplerState {};
-template <class T> struct Texture2D { T SampleLevel(SamplerState, float2, float) const { return T(); } T SampleGrad(SamplerState, float2, float2, float2) const { return T(); } T Load(int3) const { return T(); } T operator[](uint2) const { return T(); }
-    void GetDimensions(uint& w, uint& h) const { w = h = 1; } void GetDimensions(uint, uint& w, uint& h, uint& l) const { w = h = l = 1; } };
-template <class T> struct TextureCube { T SampleLevel(SamplerState, float3, float) const { return T(); } };
-template <class T> struct RWTexture2D { T dummy; T& operator[](uint2) { return dummy; } T operator[](uint2) const { return dummy; } void GetDimensions(uint& w, uint& h) const { w = h = 1; } };
+// resources that the driver binds carry a pointer (+ pitch); unbound ones read as zero / swallow writes
+template <class T> struct Texture2D { const T* p = nullptr; uint w = 0, h = 0;
+    T SampleLevel(SamplerState, float2, float) const { return T(); } T SampleGrad(SamplerState, float2, float2, float2) const { return T(); }
+    T Load(int3 c) const { return (p && (uint)c.x < w && (uint)c.y < h) ? p[(uint)c.y * w + (uint)c.x] : T(); }          // out-of-range loads return 0 (D3D)
+    T Load(uint3 c) const { return Load(int3((int)c.x, (int)c.y, (int)c.z)); } T operator[](uint2 c) const { return Load(int3((int)c.x, (int)c.y, 0)); }
+    void GetDimensions(uint& ow, uint& oh) const { ow = w; oh = h; } void GetDimensions(uint, uint& ow, uint& oh, uint& l) const { ow = w; oh = h; l = 1; } };
+template <class T> struct TextureCube { T (*fetch)(const void*, float3, float) = nullptr; const void* ctx = nullptr;
+    T SampleLevel(SamplerState, float3 dir, float lod) const { return fetch ? fetch(ctx, dir, lod) : T(); } };
+template <class T> struct RWTexture2D { T* p = nullptr; uint w = 0; T dummy = T();
+    T& operator[](uint2 c) { return p ? p[c.y * w + c.x] : dummy; } T operator[](uint2 c) const { return p ? p[c.y * w + c.x] : dummy; } void GetDimensions(uint& ow, uint& oh) const { ow = w; oh = 1; } };
 template <class T> struct RWTexture2DArray { T dummy; T& operator[](uint3) { return dummy; } T operator[](uint3) const { return dummy; } };
 template <class T> struct RWTexture3D { T dummy; T& operator[](uint3) { return dummy; } };
 template <class T> struct StructuredBuffer { const T* p = nullptr; const T& operator[](uint i) const { return p[i]; } };

@@ -211,7 +211,7 @@ def main_pt(ref):
     global REF
     REF = ref
     w = sys.stdout.write
-    w('// generated by oracle/refpin/hlsl_tu.py --integrator -- never written to disk\n#include "%s/hlsl_shim.h"\n#include "%s/hlsl_pt_stubs.h"\nnamespace hl {\n' % (HERE, HERE))
+    w('// generated by oracle/refpin/hlsl_tu.py --integrator -- never written to disk\n#include "%s/hlsl_shim.h"\n#include "%s/../ptref/ptref_api.cpp"      // the oracle (scene services for the Bridge): before any reference macro exists\n#include "%s/hlsl_pt_stubs.h"\nnamespace hl {\n' % (HERE, HERE, HERE))
     done = set()
     for r in PT_ROOTS: emit_file(os.path.join(ref, SHADERS, r), w, done)
     w("} // namespace hl\n")

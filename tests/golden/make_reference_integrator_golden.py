@@ -1,0 +1,21 @@
+"""Generates tests/golden/reference_integrator_golden.npz: linear-radiance frames rendered by the REFERENCE'S integrator text (PathTracer.hlsli,
+PathTracerNEE.hlsli, PathTracerNestedDielectrics.hlsli, LightSampler.hlsli, PolymorphicLight.hlsli, EnvMap.hlsli, PathState.hlsli, BxDF.hlsli ...
+compiled from /root/reference by oracle/refpin/hlsl_tu.py --integrator) over the oracle's scene services, for the cases of tests/pin_scenes.py.
+Run in the build container only (the GPU box has no /root/reference):   python tests/golden/make_reference_integrator_golden.py"""
+import os, sys
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from rtxpt_amd import scenes
+from oracle import ptref
+import pin_scenes
+
+out = {}
+for name, (make, S, w, h, first, n) in pin_scenes.cases().items():
+    sc, cam = make()
+    o = ptref.Oracle(reference_integrator=True, settings=S)
+    o.set_scene(sc); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(S); o.resize(w, h); o.render(first, n)
+    out[name] = o.radiance(); c = o.counters()
+    out[name + "_rays"] = np.array([c["extendRays"], c["shadowRays"]], np.uint64)
+    print(name, out[name].shape, out[name + "_rays"])
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_integrator_golden.npz"), **out)

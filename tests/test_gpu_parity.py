@@ -302,3 +302,25 @@ def test_full_size_properties_1080p():
         orow = ptref.Oracle(); orow.set_scene(sc); orow.set_camera(camd); orow.set_settings(S); orow.resize(w, h)
         orow.render(0, 4, rect=(0, y0, w, y0 + 1))
         assert np.array_equal(a[y0, :, :3], orow.radiance()[y0, :, :3]), y0
+
+
+def _pin_cases():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pin_scenes
+    return pin_scenes.cases()
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "bistro_like", "bistro_like_c5"])
+def test_product_matches_reference_integrator_golden(name):
+    """The HIP path against frames rendered by the REFERENCE'S integrator source text (tests/golden/reference_integrator_golden.npz, made in the build
+    container by compiling PathTracer.hlsli & co. over the oracle's scene services — tests/test_oracle_refpin_integrator.py). No oracle call here."""
+    pt, scenes, parallel, ptref = _imports()
+    make, S, w, h, first, n = _pin_cases()[name]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_integrator_golden.npz"))
+    sc, cam = make()
+    t = pt.PathTracer(); t.set_scene(sc); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.set_settings(S); t.resize(w, h); st = t.render(first, n)
+    got, want = t.radiance(), g[name]
+    bad = (got.view(np.uint32) != want.view(np.uint32)).any(-1)
+    assert not bad.any(), "%s: %d of %d pixels differ from the reference-text frame" % (name, int(bad.sum()), bad.size)
+    assert (st["extendRays"], st["shadowRays"]) == tuple(int(v) for v in g[name + "_rays"])
