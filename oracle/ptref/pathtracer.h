@@ -8,6 +8,9 @@
 //   Rtxpt/Shaders/PathTracer/PathTracerHelpers.hlsli:126-153 (thin lens), :164-219 (ray-cone growth, firefly filter)
 //   Rtxpt/Shaders/PathTracer/Rendering/Materials/TexLODHelpers.hlsli:57-161 (RayCone, triangle LOD)
 //   Rtxpt/Shaders/PathTracerBridgeDonut.hlsli:152-256,280-428,543-564,612-853,871-887 (Bridge::*)
+// Pinning: this integrator is compared, frame for frame and bit for bit, with the reference's own integrator text compiled over the same scene
+// services (oracle/refpin/hlsl_tu.py --integrator, tests/test_oracle_refpin_integrator.py); leaf functions, BSDF, lights and RNG separately
+// (tests/test_oracle_refpin_hlsl.py, tests/test_oracle_kat.py). Unpinned: the Donut side of loadSurface and DXR traversal.
 // Fixed parity knobs (SURVEY.md §8a "parity knobs"): PATH_TRACER_MODE_REFERENCE, NEEType=1 (power, no local sampler,
 // no temporal feedback), full MIS (RTXPT_USE_APPROXIMATE_MIS=0), lpfloat=fp32, no ReSTIR, no stable planes, no STF.
 #pragma once
