@@ -151,7 +151,7 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1)):
         return _pin_pt[variant]
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(os.path.dirname(_PIN), "librefpin_pt_%d%d%d%d%d%d.so" % variant)
-    srcs = [os.path.join(here, "refpin", f) for f in ("hlsl_tu.py", "hlsl_shim.h", "hlsl_pt_stubs.h", "hlsl_pt_wrappers.inc")] + [os.path.join(here, "ptref", f) for f in os.listdir(os.path.join(here, "ptref"))]
+    srcs = [os.path.join(here, "refpin", f) for f in ("hlsl_tu.py", "hlsl_shim.h", "hlsl_pt_stubs.h", "hlsl_pt_bridge_stubs.h", "hlsl_pt_wrappers.inc")] + [os.path.join(here, "ptref", f) for f in os.listdir(os.path.join(here, "ptref"))]
     stale = not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs)
     if stale:
         if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
@@ -162,7 +162,7 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1)):
             os.makedirs(os.path.dirname(path), exist_ok=True)
             d = "-DDiffuseBrdf=%d -DPT_ENABLE_RUSSIAN_ROULETTE=%d -DRTXPT_FIREFLY_FILTER=%d -DRTXPT_NESTED_DIELECTRICS_QUALITY=%d -DRTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF=%d -DPT_NEE_ENABLED=%d" % variant
             cmd = ("python3 %s/refpin/hlsl_tu.py --integrator /root/reference | g++ -O2 -std=c++17 -fPIC -shared -fopenmp -mfma -ffp-contract=off -fno-fast-math "
-                   "-fsingle-precision-constant %s -I%s/refpin -x c++ - -o %s" % (here, d, here, path))
+                   "-fsingle-precision-constant -fpermissive -w %s -I%s/refpin -x c++ - -o %s" % (here, d, here, path))
             r = subprocess.run(["bash", "-o", "pipefail", "-c", cmd], capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("librefpin_pt build failed:\n" + r.stderr[-3000:])
@@ -172,6 +172,17 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1)):
     L.ptref_num_tris.restype = ctypes.c_uint32
     _pin_pt[variant] = L
     return L
+
+
+def surface_probe(oracle_ctx, prims, uv_dir_cone):
+    """Bridge::loadSurface of the reference text (PathTracerBridgeDonut.hlsli:612-853 and what it calls) next to the oracle's loadSurface for the same hits.
+    oracle_ctx: an Oracle(reference_integrator=True) with a scene; prims: global triangle ids; uv_dir_cone: rows [u, v, dir.xyz, coneWidth, coneSpread].
+    Returns (reference, oracle) as uint32 [n, 44]."""
+    prims = np.ascontiguousarray(prims, np.uint32); a = np.ascontiguousarray(uv_dir_cone, np.float32).reshape(-1, 7)
+    R = np.zeros((len(prims), 44), np.uint32); Q = np.zeros((len(prims), 44), np.uint32)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    oracle_ctx.L.refpt_surface_probe(oracle_ctx.h, ctypes.c_uint32(len(prims)), vp(prims), vp(a), vp(R), vp(Q))
+    return R, Q
 
 
 def _pin_table():

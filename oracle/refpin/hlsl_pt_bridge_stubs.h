@@ -1,0 +1,41 @@
+// ORACLE pin (test infrastructure only): what PathTracerBridgeDonut.hlsli takes from outside the reference tree, so that ITS OWN text
+// (getGeometryFromHit, sampleGeometryMaterialRTXPT, EvaluateSceneMaterialRTXPT, ApplyNormalMapRTXPT, Bridge::loadSurface, createTextureSampler,
+// computeCameraRay, loadIoR, loadHomogeneousVolumeData, CreateLightSampler ...) can be compiled and run:
+//   * the Donut side (NVIDIA-RTX/Donut, an un-vendored submodule: donut/shaders/bindless.h, utils.hlsli, scene_material.hlsli) — data layouts and
+//     helpers restated from their use in the reference; these few lines are NOT pinned, everything that calls them is;
+//   * the resource bindings (Bindings/*.hlsli) as globals the driver fills from the oracle's scene.
+// Included inside namespace hl, after the integrator text.
+#define ENABLE_METAL_ROUGH_RECONSTRUCTION 1      // PathTracerBridgeDonut.hlsli:15
+struct InstanceData { float3x4 transform; float3x4 prevTransform; uint firstGeometryIndex, firstGeometryInstanceIndex, numGeometries, flags; };   // BridgeDonut:166-168, 628-631, 674
+struct GeometryData { uint indexBufferIndex, vertexBufferIndex, indexOffset, positionOffset, prevPositionOffset, texCoord1Offset, normalOffset, tangentOffset, materialIndex; };   // BridgeDonut:170-243
+struct GeometryDebugData { int ommIndexBufferIndex; uint ommIndexBufferOffset; };
+static const uint c_SizeOfTriangleIndices = 12, c_SizeOfPosition = 12, c_SizeOfTexcoord = 8, c_SizeOfNormal = 4;
+static const float3 c_DielectricSpecular = float3(0.04f, 0.04f, 0.04f);
+static const uint MaterialFlags_UseBaseOrDiffuseTexture = PTMaterialFlags_UseBaseOrDiffuseTexture;
+struct MaterialTextureSample { float4 baseOrDiffuse, metalRoughOrSpecular, normal, emissive, occlusion, transmission; };
+static inline MaterialTextureSample DefaultMaterialTextures() { MaterialTextureSample t; t.baseOrDiffuse = float4(1, 1, 1, 1); t.metalRoughOrSpecular = float4(1, 1, 1, 1); t.normal = float4(0.5f, 0.5f, 1.0f, 0.f);
+    t.emissive = float4(1, 1, 1, 1); t.occlusion = float4(1, 1, 1, 1); t.transmission = float4(1, 1, 1, 1); return t; }
+static inline void ConvertSpecularGlossToMetalRough(float3, float3, float3& baseColor, float& metalness) { baseColor = float3(0, 0, 0); metalness = 0; }      // spec-gloss materials are rejected upstream
+static inline float3 interpolate(const float3 v[3], float3 b) { return (v[0] * b.x + v[1] * b.y) + v[2] * b.z; }
+static inline float2 interpolate(const float2 v[3], float3 b) { return (v[0] * b.x + v[1] * b.y) + v[2] * b.z; }
+static inline float4 interpolate(const float4 v[3], float3 b) { return (v[0] * b.x + v[1] * b.y) + v[2] * b.z; }
+static inline float square(float v) { return v * v; }
+static inline uint NonUniformResourceIndex(uint i) { return i; }
+static inline float4 mul(float3x4 M, float4 v) { return float4(dot(M.r[0], v), dot(M.r[1], v), dot(M.r[2], v), 0.f); }      // `mul(transform, float4(p, w)).xyz`; dot4 = ((x+y)+z)+w below
+struct OpacityMicroMapDebugInfo { bool hasOmmAttachment; float3 opacityStateDebugColor; static OpacityMicroMapDebugInfo initDefault() { OpacityMicroMapDebugInfo d; d.hasOmmAttachment = false; d.opacityStateDebugColor = float3(0, 0, 0); return d; } };
+struct DonutGeometrySample;
+static OpacityMicroMapDebugInfo loadOmmDebugInfo(const DonutGeometrySample&, uint, float2) { return OpacityMicroMapDebugInfo::initDefault(); }
+static void surfaceDebugViz(uint2, PathTracer::SurfaceData, float2, float3, RayCone, int, OpacityMicroMapDebugInfo, uint, DebugContext) {}
+// ---- bindings (Bindings/SceneBindings.hlsli, LightingBindings.hlsli, SamplerBindings.hlsli, ShaderResourceBindings.hlsli), filled by the driver per frame
+struct BindlessBuffers { const ByteAddressBuffer* b = nullptr; ByteAddressBuffer operator[](uint i) const { return b[i]; } };
+struct BindlessTextures { const Texture2D<float4>* t = nullptr; Texture2D<float4> operator[](uint i) const { return t[i]; } };
+struct SampleConstantsPin { PathTracerConstants ptConsts; EnvMapSceneParams envMapSceneParams; EnvMapImportanceSamplingParams envMapImportanceSamplingParams; uint MaterialCount; };
+struct SampleMiniConstantsPin { uint4 params; };
+static SampleConstantsPin g_Const; static SampleMiniConstantsPin g_MiniConst;
+static StructuredBuffer<InstanceData> t_InstanceData; static StructuredBuffer<GeometryData> t_GeometryData; static StructuredBuffer<GeometryDebugData> t_GeometryDebugData;
+static StructuredBuffer<SubInstanceData> t_SubInstanceData; static StructuredBuffer<PTMaterialData> t_PTMaterialData;
+static BindlessBuffers t_BindlessBuffers; static BindlessTextures t_BindlessTextures; static SamplerState s_MaterialSampler, s_EnvironmentMapSampler, s_EnvironmentMapImportanceSampler;
+static TextureCube<float4> t_EnvironmentMap; static Texture2D<float> t_EnvironmentMapImportanceMap;
+static StructuredBuffer<LightingControlData> t_LightsCB; static StructuredBuffer<PolymorphicLightInfo> t_Lights; static StructuredBuffer<PolymorphicLightInfoEx> t_LightsEx;
+static Buffer<uint> t_LightProxyCounters, t_LightProxyIndices, t_LightLocalSamplingBuffer; static Texture2D<uint> t_EnvLookupMap;
+static RWTexture2D<float> u_LightFeedbackTotalWeight; static RWTexture2D<uint> u_LightFeedbackCandidates;

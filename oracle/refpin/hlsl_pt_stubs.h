@@ -36,11 +36,14 @@ namespace hl {
 struct RayDesc { float3 Origin; float TMin; float3 Direction; float TMax; };
 struct SamplerState {};
 // resources that the driver binds carry a pointer (+ pitch); unbound ones read as zero / swallow writes
-template <class T> struct Texture2D { const T* p = nullptr; uint w = 0, h = 0;
-    T SampleLevel(SamplerState, float2, float) const { return T(); } T SampleGrad(SamplerState, float2, float2, float2) const { return T(); }
+template <class T> struct Texture2D { const T* p = nullptr; uint w = 0, h = 0; const ptref::Texture* tex = nullptr;      // tex: a material texture, filtered by the oracle's explicit trilinear fetch
+    T Sample(SamplerState, float2 uv) const { return sample_level(uv, 0.f); } T SampleLevel(SamplerState, float2 uv, float lod) const { return sample_level(uv, lod); } T SampleGrad(SamplerState, float2, float2, float2) const { return T(); }
+    T sample_level(float2 uv, float lod) const;
     T Load(int3 c) const { return (p && (uint)c.x < w && (uint)c.y < h) ? p[(uint)c.y * w + (uint)c.x] : T(); }          // out-of-range loads return 0 (D3D)
     T Load(uint3 c) const { return Load(int3((int)c.x, (int)c.y, (int)c.z)); } T operator[](uint2 c) const { return Load(int3((int)c.x, (int)c.y, 0)); }
-    void GetDimensions(uint& ow, uint& oh) const { ow = w; oh = h; } void GetDimensions(uint, uint& ow, uint& oh, uint& l) const { ow = w; oh = h; l = 1; } };
+    void GetDimensions(uint& ow, uint& oh) const { ow = tex ? tex->w : w; oh = tex ? tex->h : h; } void GetDimensions(uint, uint& ow, uint& oh, uint& l) const { GetDimensions(ow, oh); l = tex ? tex->mipLevels : 1; } };
+template <class T> T Texture2D<T>::sample_level(float2, float) const { return T(); }
+template <> inline float4 Texture2D<float4>::sample_level(float2 uv, float lod) const { if (!tex) return float4(); ptref::float4 c = ptref::sample_trilinear(*tex, ptref::make_float2(uv.x, uv.y), lod); return float4(c.x, c.y, c.z, c.w); }
 template <class T> struct TextureCube { T (*fetch)(const void*, float3, float) = nullptr; const void* ctx = nullptr;
     T SampleLevel(SamplerState, float3 dir, float lod) const { return fetch ? fetch(ctx, dir, lod) : T(); } };
 template <class T> struct RWTexture2D { T* p = nullptr; uint w = 0; T dummy = T();
@@ -51,17 +54,20 @@ template <class T> struct StructuredBuffer { const T* p = nullptr; const T& oper
 template <class T> struct RWStructuredBuffer { T* p = nullptr; T& operator[](uint i) const { return p[i]; } };
 template <class T> struct Buffer { const T* p = nullptr; T operator[](uint i) const { return p[i]; } };
 template <class T> struct RWBuffer { T* p = nullptr; T& operator[](uint i) const { return p[i]; } };
-struct ByteAddressBuffer { const uint* p = nullptr; uint Load(uint o) const { return p[o / 4]; } };
+struct ByteAddressBuffer { const unsigned char* p = nullptr;
+    uint Load(uint o) const { uint v; memcpy(&v, p + o, 4); return v; } uint2 Load2(uint o) const { return uint2(Load(o), Load(o + 4)); } uint3 Load3(uint o) const { return uint3(Load(o), Load(o + 4), Load(o + 8)); } };
 struct RWByteAddressBuffer { uint* p = nullptr; uint Load(uint o) const { return p[o / 4]; } void Store(uint o, uint v) const { p[o / 4] = v; } };
 struct RaytracingAccelerationStructure {};
 static const uint RAY_FLAG_NONE = 0, RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH = 4, RAY_FLAG_CULL_NON_OPAQUE = 0x80;
 template <uint F, uint G = 0> struct RayQuery {};
-struct TriangleHit { uint instanceIndex, geometryIndex, primitiveIndex; float2 barycentrics; };
+struct GeometryInstanceIDPin { uint inst = 0, geom = 0; uint getInstanceIndex() const { return inst; } uint getGeometryIndex() const { return geom; } };
+struct TriangleHit { GeometryInstanceIDPin instanceID; uint primitiveIndex = 0; float2 barycentrics; };
 struct PackedHitInfo { uint4 d; };
 // PathTracerDebug.hlsli's context: the integrator only ever calls into it behind ENABLE_DEBUG_* switches that are off here
-struct DebugContext { bool IsDebugPixel() const { return false; } bool IsDebugPixel(uint2) const { return false; } void Reset(uint) {} void Reset(uint2, int) {} };
+struct DebugConstantsPin { uint exploreDeltaTree = 0; };
+struct DebugContext { DebugConstantsPin constants; uint2 pixelPos; bool IsDebugPixel() const { return false; } bool IsDebugPixel(uint2) const { return false; } void Reset(uint) {} void Reset(uint2, int) {} void SetPickedMaterial(uint) {}
+    template <class... A> void DrawDebugViz(A...) {} };
 static inline void DebugCross(float3, float, float4) {}
-struct ExplicitRayConesLodTextureSampler {}; struct ExplicitLodTextureSampler {};           // Scene/Material/TextureSampler.hlsli: texture fetches belong to the bridge
 static inline float max3(float a, float b, float c) { return max(a, max(b, c)); }              // Utils/ColorHelpers.hlsli:19-27
 static inline float max3(float3 v) { return max3(v.x, v.y, v.z); }
 // DXR system values of the closest-hit shader HandleHit runs in: set by the driver loop before each call

@@ -18,23 +18,25 @@ namespace P = ptref;
 
 template <class T> struct v2 { union { struct { T x, y; }; struct { T r, g; }; }; v2() : x(), y() {} v2(T s) : x(s), y(s) {} v2(T a, T b) : x(a), y(b) {}
     template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v2(const v2<U>& o) : x((T)o.x), y((T)o.y) {}
-    v2& xy_() { return *this; } const v2& xy_() const { return *this; } v2 yx_() const { return v2(y, x); } v2 xx_() const { return v2(x, x); }
+    v2& xy_() { return *this; } const v2& xy_() const { return *this; } const v2 yx_() const { return v2(y, x); } const v2 xx_() const { return v2(x, x); }
     T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
 template <class T> struct v3 { union { struct { T x, y, z; }; struct { T r, g, b; }; }; v3() : x(), y(), z() {} v3(T s) : x(s), y(s), z(s) {} v3(T a, T b, T c) : x(a), y(b), z(c) {}
     v3(v2<T> a, T c) : x(a.x), y(a.y), z(c) {} v3(T a, v2<T> b) : x(a), y(b.x), z(b.y) {}
     template <class A, class B, class C, class = typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value && std::is_arithmetic<C>::value && !(std::is_same<A, T>::value && std::is_same<B, T>::value && std::is_same<C, T>::value)>::type>
     v3(A a, B b, C c) : x((T)a), y((T)b), z((T)c) {}
     template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v3(const v3<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z) {}       // HLSL converts between component types implicitly
-    v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> yx_() const { return v2<T>(y, x); } v2<T> xz_() const { return v2<T>(x, z); } v2<T> yz_() const { return v2<T>(y, z); }
+    v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } const v2<T> xy_() const { return v2<T>(x, y); } const v2<T> yx_() const { return v2<T>(y, x); } const v2<T> xz_() const { return v2<T>(x, z); } const v2<T> yz_() const { return v2<T>(y, z); }
+    v2<T>& yz_() { return *reinterpret_cast<v2<T>*>(&y); }
     v3& xyz_() { return *this; } const v3& xyz_() const { return *this; } v3& rgb_() { return *this; } const v3& rgb_() const { return *this; }
     T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
 template <class T> struct v4 { union { struct { T x, y, z, w; }; struct { T r, g, b, a; }; }; v4() : x(), y(), z(), w() {} v4(T s) : x(s), y(s), z(s), w(s) {} v4(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}
     v4(v3<T> a, T d) : x(a.x), y(a.y), z(a.z), w(d) {} v4(v2<T> a, v2<T> b) : x(a.x), y(a.y), z(b.x), w(b.y) {} v4(v2<T> a, T c, T d) : x(a.x), y(a.y), z(c), w(d) {}
     template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v4(const v4<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z), w((T)o.w) {}
+    v2<T>& zw_() { return *reinterpret_cast<v2<T>*>(&z); } v3<T>& yzw_() { return *reinterpret_cast<v3<T>*>(&y); }
     v4& rgba_() { return *this; } const v4& rgba_() const { return *this; }
-    v4& xyzw_() { return *this; } const v4& xyzw_() const { return *this; } v3<T> xyw_() const { return v3<T>(x, y, w); } v3<T> xzw_() const { return v3<T>(x, z, w); } v3<T> yzw_() const { return v3<T>(y, z, w); } v4 wzyx_() const { return v4(w, z, y, x); }
-    v3<T>& xyz_() { return *reinterpret_cast<v3<T>*>(this); } v3<T> xyz_() const { return v3<T>(x, y, z); } v3<T>& rgb_() { return xyz_(); } v3<T> rgb_() const { return xyz_(); }
-    v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } v2<T> xy_() const { return v2<T>(x, y); } v2<T> zw_() const { return v2<T>(z, w); }
+    v4& xyzw_() { return *this; } const v4& xyzw_() const { return *this; } const v3<T> xyw_() const { return v3<T>(x, y, w); } const v3<T> xzw_() const { return v3<T>(x, z, w); } const v3<T> yzw_() const { return v3<T>(y, z, w); } const v4 wzyx_() const { return v4(w, z, y, x); }
+    v3<T>& xyz_() { return *reinterpret_cast<v3<T>*>(this); } const v3<T> xyz_() const { return v3<T>(x, y, z); } v3<T>& rgb_() { return xyz_(); } const v3<T> rgb_() const { return xyz_(); }
+    v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } const v2<T> xy_() const { return v2<T>(x, y); } const v2<T> zw_() const { return v2<T>(z, w); }
     T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
 
 typedef v2<float> float2; typedef v3<float> float3; typedef v4<float> float4;
@@ -146,6 +148,7 @@ static inline float3 lerp(float3 a, float3 b, float t) { return a + (b - a) * t;
 static inline float3 lerp(float3 a, float3 b, float3 t) { return a + (b - a) * t; }
 static inline float dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
 static inline float dot(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float dot(float4 a, float4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
 static inline float3 cross(float3 a, float3 b) { return float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 static inline float length(float2 a) { return sqrt(dot(a, a)); } static inline float length(float3 a) { return sqrt(dot(a, a)); }
 static inline float3 normalize(float3 a) { float il = 1.0f / sqrt(dot(a, a)); return a * il; }
@@ -156,6 +159,7 @@ static inline int asint(float f) { return P::asint(f); } static inline int asint
 static inline float asfloat(uint u) { return P::asfloat(u); } static inline float asfloat(int i) { return P::asfloat(i); } static inline float asfloat(float f) { return f; }
 static inline int3 asint(float3 v) { return int3(asint(v.x), asint(v.y), asint(v.z)); }
 static inline uint3 asuint(float3 v) { return uint3(asuint(v.x), asuint(v.y), asuint(v.z)); }
+static inline float2 asfloat(uint2 v) { return float2(asfloat(v.x), asfloat(v.y)); }
 static inline float3 asfloat(int3 v) { return float3(asfloat(v.x), asfloat(v.y), asfloat(v.z)); }
 static inline float3 asfloat(uint3 v) { return float3(asfloat(v.x), asfloat(v.y), asfloat(v.z)); }
 static inline uint f32tof16(float f) { return P::f32tof16(f); } static inline float f16tof32(uint h) { return P::f16tof32(h); }

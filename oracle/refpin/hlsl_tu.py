@@ -152,6 +152,7 @@ def to_cpp(code):
     # swizzles on scalars (literals, named scalars, parenthesised / call expressions) become constructor calls ...
     code = re.sub(r"(?<![\w.])(\d+\.\d*f?|\.\d+f?|\d+)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)     # `0.5.xx`, `0.xxx`
     code = re.sub(r"\b(HLF_MAX|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
+    code = re.sub(r"\b((?:\w+\.)?AttenuationDistance)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"((?:\b[A-Za-z_][\w.]*)?\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\))\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\bpackedData\.x\b", "packedData", code)                               # `.x` of a scalar
     # ... swizzles on vectors become member calls
@@ -170,7 +171,7 @@ def to_cpp(code):
 # every file's text goes through to_cpp); files on the deny list are replaced by the stubs of hlsl_pt_stubs.h.
 PT_ROOTS = ["../PathTracerBridge.hlsli", "PathTracer.hlsli"]
 PT_DENY = ("ShaderDebug.hlsl", "PathTracerDebug.hlsli", "STFSamplerState.hlsli", "Xoshiro.hlsli", "SplitMix64.hlsli", "BitTricks.hlsli",
-           "TextureSampler.hlsli", "HitInfo.hlsli", "HitInfoType.hlsli", "PackedFormats.hlsli", "FormatConversion.hlsli", "ColorHelpers.hlsli", "Quaternion.hlsli", "ShadingUtils.hlsli", "SceneTypes.hlsli")
+           "HitInfo.hlsli", "HitInfoType.hlsli", "PackedFormats.hlsli", "FormatConversion.hlsli", "ColorHelpers.hlsli", "Quaternion.hlsli", "SceneTypes.hlsli")
 # files of which only some items are needed (the rest uses matrix member syntax / half types / pixel-shader intrinsics that the pin has no use for)
 PT_PICK = {
     "MathHelpers.hlsli": ["ndir_to_oct_equal_area_unorm", "oct_to_ndir_equal_area_unorm", "sample_disk", "sample_disk_concentric", "sample_cosine_hemisphere_concentric",
@@ -214,6 +215,18 @@ def main_pt(ref):
     w('// generated by oracle/refpin/hlsl_tu.py --integrator -- never written to disk\n#include "%s/hlsl_shim.h"\n#include "%s/../ptref/ptref_api.cpp"      // the oracle (scene services for the Bridge): before any reference macro exists\n#include "%s/hlsl_pt_stubs.h"\nnamespace hl {\n' % (HERE, HERE, HERE))
     done = set()
     for r in PT_ROOTS: emit_file(os.path.join(ref, SHADERS, r), w, done)
+    # the RTXPT side of the Donut bridge (PathTracerBridgeDonut.hlsli): geometry fetch, material evaluation, loadSurface and the small accessors.
+    # What it includes from Donut itself (un-vendored submodule) is restated in hlsl_pt_stubs.h ("donut side"); the ray-query functions stay with the driver.
+    for extra in ("../PathTracer/Materials/MaterialPT.h", "../SubInstanceData.h", "../PathTracer/Materials/MaterialTypes.hlsli", "../Libraries/MicroRng.hlsli"):
+        emit_file(os.path.join(ref, SHADERS, extra), w, done)
+    w('#include "%s/hlsl_pt_bridge_stubs.h"\n' % HERE)
+    bpath = os.path.join(ref, "Rtxpt/Shaders/PathTracerBridgeDonut.hlsli")
+    braw = open(bpath, encoding="latin-1").read(); btext = strip_comments(braw)
+    for spec in ("^enum DonutGeometryAttributes..^static OpacityMicroMapDebugInfo loadOmmDebugInfo",
+                 "^uint Bridge::getSampleIndex..^// 2\\.5D motion vectors",
+                 "^EnvMap Bridge::CreateEnvMap..^void Bridge::ExportSurfaceInit"):
+        w("// ======== PathTracerBridgeDonut.hlsli : %s\n" % spec)
+        w(to_cpp(extract_range(btext, spec, "PathTracerBridgeDonut.hlsli", braw)) + "\n")
     w("} // namespace hl\n")
     w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
 

@@ -252,17 +252,17 @@ struct PathKernelContext {
                 if (dot(n[k], objFlatN) < 0.f) n[k] = -n[k];
             }
             geometryNormal = (n[0] * bary.x + n[1] * bary.y) + n[2] * bary.z;
-            geometryNormal = SafeNormalize(xform_vector(M, geometryNormal));
+            geometryNormal = SafeNormalize(xform_direction4(M, geometryNormal));
         }
         float4 tangent = make_float4(0, 0, 0, 0);
         if (g.flags & GEOM_HAS_TANGENT) {
             float4 tg[3];
             for (int k = 0; k < 3; k++) tg[k] = Unpack_RGBA8_SNORM(sc.tangents[vi[k]]);
             float3 t3 = (xyz(tg[0]) * bary.x + xyz(tg[1]) * bary.y) + xyz(tg[2]) * bary.z;
-            t3 = SafeNormalize(xform_vector(M, t3));
+            t3 = SafeNormalize(xform_direction4(M, t3));
             tangent = make_float4(t3, tg[0].w);
         }
-        float3 flatNormal = SafeNormalize(xform_vector(M, objFlatN));
+        float3 flatNormal = SafeNormalize(xform_direction4(M, objFlatN));
         bool frontFacing = dot(-rayDir, flatNormal) >= 0.0f;
         if (!(g.flags & GEOM_HAS_NORMAL)) geometryNormal = flatNormal;
         float3 posW = xform_point(M, objPos);

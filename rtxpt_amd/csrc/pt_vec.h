@@ -109,6 +109,13 @@ static inline float3 xform_point(const float3x4& M, float3 p) {
                        ((M.m[4] * p.x + M.m[5] * p.y) + M.m[6] * p.z) + M.m[7],
                        ((M.m[8] * p.x + M.m[9] * p.y) + M.m[10] * p.z) + M.m[11]);
 }
+// mul(M, float4(v, 0.0)).xyz as the reference writes it for normals and tangents (BridgeDonut:230, 246, 251): the fourth term is M[i][3] * 0, which
+// turns a -0 component into +0 (and is the only difference to xform_vector)
+static inline float3 xform_direction4(const float3x4& M, float3 v) {
+    return make_float3(((M.m[0] * v.x + M.m[1] * v.y) + M.m[2] * v.z) + M.m[3] * 0.0f,
+                       ((M.m[4] * v.x + M.m[5] * v.y) + M.m[6] * v.z) + M.m[7] * 0.0f,
+                       ((M.m[8] * v.x + M.m[9] * v.y) + M.m[10] * v.z) + M.m[11] * 0.0f);
+}
 static inline float3 xform_vector(const float3x4& M, float3 v) {
     return make_float3((M.m[0] * v.x + M.m[1] * v.y) + M.m[2] * v.z,
                        (M.m[4] * v.x + M.m[5] * v.y) + M.m[6] * v.z,

@@ -48,3 +48,24 @@ def test_oracle_matches_live_reference_integrator(name):
     want, rays_ref = _oracle_frame(name, reference=True)
     got, rays = _oracle_frame(name)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and rays == rays_ref
+
+
+@pytest.mark.parametrize("name", ["c2", "bistro_like", "bistro_like_c5"])
+def test_load_surface_matches_reference_text(name):
+    """Bridge::loadSurface and everything RTXPT-side below it (getGeometryFromHit, sampleGeometryMaterialRTXPT, EvaluateSceneMaterialRTXPT,
+    ApplyNormalMapRTXPT, createTextureSampler + ray-cone LOD, computeTangentSpace / adjustShadingNormal, emissive light index) compiled from
+    PathTracerBridgeDonut.hlsli, against the oracle's loadSurface: ShadingData + StandardBSDFData + interior IoR + light index, 44 words per hit."""
+    if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
+        pytest.skip("no /root/reference on this machine")
+    make, S, w, h, first, n = CASES[name]
+    sc, cam = make()
+    o = ptref.Oracle(reference_integrator=True, settings=S); o.set_scene(sc); o.set_settings(S); o.resize(8, 8)
+    o.L.ptref_num_tris.restype = __import__("ctypes").c_uint32
+    nt = o.L.ptref_num_tris(o.h)
+    rng = np.random.default_rng(0x5F + len(name)); k = 20000
+    prims = rng.integers(0, nt, k); u = rng.uniform(0, 1, k); v = rng.uniform(0, 1, k) * (1 - u)
+    d = rng.normal(size=(k, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    R, Q = ptref.surface_probe(o, prims, np.column_stack([u, v, d, rng.uniform(0, 0.5, k), rng.uniform(0, 0.01, k)]))
+    bad = (R != Q).any(1)
+    assert not bad.any(), "%d of %d surfaces differ (first: hit %d, words %s)" % (int(bad.sum()), k, int(np.flatnonzero(bad)[0]), np.flatnonzero(R[bad][0] != Q[bad][0]))
+    assert len(np.unique(R[:, 23])) > 1 or name == "c2"       # several materials were hit
