@@ -334,6 +334,19 @@ TONEMAP_DTYPE = np.dtype([("whiteScale", "<f4"), ("whiteMaxLuminance", "<f4"), (
                           ("colorTransform", "<f4", (9,)), ("enabled", "<u4"), ("_pad0", "<u4"), ("_pad1", "<u4")])
 
 
+def tonemap_linear(rgba, params, reference=False):
+    """applyToneMapping before the SRGBA8 store, as floats: the oracle's tm_apply, or ToneMapping.ps.hlsli itself (librefpin_hlsl.so)."""
+    L = refpin_hlsl() if reference else lib()
+    if L is None:
+        return None
+    a = np.ascontiguousarray(rgba, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros_like(a)
+    p = np.ascontiguousarray(params)
+    f = L.refhlsl_tonemap if reference else L.ptref_tonemap_linear
+    f(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(a.shape[0]), p.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
 def tonemap(rgba, params):
     """ptref_tonemap: (..., 4) float32 radiance -> (..., 4) uint8 sRGB through the restated ToneMapping.ps.hlsli."""
     L = lib()

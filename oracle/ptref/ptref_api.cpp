@@ -586,6 +586,12 @@ void ptref_light_probe(int kind, const uint32_t* in, unsigned n, uint32_t* out) 
     }
 }
 
+// display path before the SRGBA8 store: tm_apply (tonemap.h) as floats, the oracle's side of refhlsl_tonemap
+void ptref_tonemap_linear(const float* rgba, uint32_t n, const ToneMapParams* p, float* out) {
+    for (uint32_t i = 0; i < n; i++) { float3 c = tm_apply(*p, make_float3(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2])); out[4 * i] = c.x; out[4 * i + 1] = c.y; out[4 * i + 2] = c.z; out[4 * i + 3] = rgba[4 * i + 3]; }
+}
+
 } // extern "C"
+
 
 

@@ -34,7 +34,6 @@
 #endif
 namespace hl {
 struct RayDesc { float3 Origin; float TMin; float3 Direction; float TMax; };
-struct SamplerState {};
 // resources that the driver binds carry a pointer (+ pitch); unbound ones read as zero / swallow writes
 template <class T> struct Texture2D { const T* p = nullptr; uint w = 0, h = 0; const ptref::Texture* tex = nullptr;      // tex: a material texture, filtered by the oracle's explicit trilinear fetch
     T Sample(SamplerState, float2 uv) const { return sample_level(uv, 0.f); } T SampleLevel(SamplerState, float2 uv, float lod) const { return sample_level(uv, lod); } T SampleGrad(SamplerState, float2, float2, float2) const { return T(); }

@@ -138,8 +138,9 @@ static inline float exp2(float v) { return P::dm_exp2(v); } static inline float 
 static inline float exp(float v) { return P::dm_exp(v); } static inline float log(float v) { return P::dm_log(v); } HL_LIFT1(exp) HL_LIFT1(log)
 static inline float atan2(float y, float x) { return P::dm_atan2(y, x); }
 template <class E> float pow(float x, E e) { return ((float)e == 5.0f) ? P::dm_pow5(x) : P::dm_pow(x, (float)e); }      // pow(x, 5): the oracle's (x²·x²)·x
-template <class E> float3 pow(float3 x, E e) { return float3(pow(x.x, e), pow(x.y, e), pow(x.z, e)); }
-template <class E> float4 pow(float4 x, E e) { return float4(pow(x.x, e), pow(x.y, e), pow(x.z, e), pow(x.w, e)); }
+template <class E> if_arith<float3, E> pow(float3 x, E e) { return float3(pow(x.x, e), pow(x.y, e), pow(x.z, e)); }
+static inline float3 pow(float3 x, float3 e) { return float3(pow(x.x, e.x), pow(x.y, e.y), pow(x.z, e.z)); }
+template <class E> if_arith<float4, E> pow(float4 x, E e) { return float4(pow(x.x, e), pow(x.y, e), pow(x.z, e), pow(x.w, e)); }
 static inline float mad(float a, float b, float c) { return a * b + c; }
 static inline float3 mad(float3 a, float3 b, float3 c) { return a * b + c; }                                                // unfused (-ffp-contract=off)
 static inline float smoothstep(float a, float b, float x) { float t = saturate((x - a) / (b - a)); return t * t * (3.0f - 2.0f * t); }
@@ -189,6 +190,7 @@ static inline float3x3 mul(float3x3 A, float3x3 B) { float3x3 R; for (int i = 0;
 static inline float3x3 transpose(float3x3 M) { return float3x3(float3(M.r[0].x, M.r[1].x, M.r[2].x), float3(M.r[0].y, M.r[1].y, M.r[2].y), float3(M.r[0].z, M.r[1].z, M.r[2].z)); }
 static inline float determinant(float3x3 M) { return dot(M.r[0], cross(M.r[1], M.r[2])); }
 template <class T> T ddx(T) { return T(); } template <class T> T ddy(T) { return T(); }       // pixel-shader derivatives: no meaning here, never executed
+struct SamplerState {};
 #undef HL_LIFT1
 #undef HL_LIFT2
 } // namespace hl

@@ -46,6 +46,11 @@ PLAN = [
     ("Lighting/PolymorphicLightPTConfig.h", ["pp"]),
     ("Lighting/LightShaping.hlsli", ["range ^struct LightShaping..#endif // LIGHT_SHAPING_HLSLI"]),
     ("Lighting/PolymorphicLight.hlsli", ["range #define FLT_EPSILON_MINI..#endif // __POLYMORPHIC_LIGHT_HLSLI__ -Eval"]),
+    # ---- display path: ToneMapping.ps.hlsli whole, over a colour "texture" that holds one pixel
+    ("@Rtxpt/ToneMapper/ToneMapping_cb.h", ["range ^#define TONEMAPPING_AUTOEXPOSURE_CPU..^#endif // TONEMAPPING_CB_H"]),
+    ("@Rtxpt/ToneMapper/ToneMapping.ps.hlsli", ["text struct PinColorTexture { float4 texel; float4 Sample(SamplerState, float2) const { return texel; } float4 SampleLevel(SamplerState, float2, float) const { return texel; } };",
+                                                "text static PinColorTexture gColorTex, gLuminanceTex; static SamplerState gColorSampler, gLuminanceTexSampler;",
+                                                "range ^static const float kExposureKey..^#endif //__TONE_MAPPING_PS_HLSLI__"]),
     # ---- the whole standard BSDF (FalcorBSDF and its four lobes), once per diffuse model
     ("Utils/Math/MathConstants.hlsli", ["range static const float\\s+cFloatOneMinusEpsilon..^\\s*$"]),
     ("Rendering/Materials/LobeType.hlsli", ["struct LobeType"]),
@@ -153,7 +158,7 @@ def to_cpp(code):
     code = re.sub(r"(?<![\w.])(\d+\.\d*f?|\.\d+f?|\d+)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)     # `0.5.xx`, `0.xxx`
     code = re.sub(r"\b(HLF_MAX|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\b((?:\w+\.)?AttenuationDistance)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
-    code = re.sub(r"((?:\b[A-Za-z_][\w.]*)?\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\))\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
+    code = re.sub(r"((?:\b[A-Za-z_][\w.]*)?\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\))\.(xx|xxx|xxxx|rr|rrr|rrrr)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\bpackedData\.x\b", "packedData", code)                               # `.x` of a scalar
     # ... swizzles on vectors become member calls
     code = re.sub(r"\.(xy|yx|xx|xz|yz|zw|xyz|rgb|rgba|xyw|xzw|yzw|xyzw|wzyx)\b", r".\1_()", code)
@@ -163,6 +168,7 @@ def to_cpp(code):
     code = re.sub(r":\s*register\s*\([^)]*\)", "", code)                                     # resource bindings
     code = re.sub(r"\b(Texture2D|TextureCube|RWTexture2D|RWTexture2DArray)\b(?!\s*<)", r"\1<float4>", code)         # untyped resource = float4 elements
     code = re.sub(r"\b(row_major|precise|nointerpolation|globallycoherent)[ \t]+", "", code)
+    code = re.sub(r"\bcbuffer\s+\w+\s*\{([^{}]*)\}\s*;?", r"static \1", code)                  # a constant buffer is its members, as globals
     code = re.sub(r"(?<![\w:>)])::(?=[A-Za-z_])", "", code)                                  # `::name` (global scope): everything lives in one namespace here
     return code
 
@@ -238,7 +244,7 @@ def main():
     w = sys.stdout.write
     w('// generated by oracle/refpin/hlsl_tu.py -- never written to disk\n#include "%s/hlsl_shim.h"\nnamespace hl {\n' % HERE)
     for rel, names in PLAN:
-        path = os.path.join(ref, SHADERS, rel)
+        path = os.path.join(ref, rel[1:]) if rel.startswith("@") else os.path.join(ref, SHADERS, rel)      # "@": relative to the reference root
         raw = open(path, encoding="latin-1").read()
         text = strip_comments(raw)
         for name in names:

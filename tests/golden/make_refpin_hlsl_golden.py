@@ -22,5 +22,7 @@ lights = pin_inputs.light_inputs(512, 0x5EED0400, lambda kind, w: ptref.light_pr
 for kind, words in lights.items():
     out["light%d_in" % kind] = words
     out["light%d_out" % kind] = ptref.light_probe(kind, words, reference=True)
+tm = pin_inputs.tonemap_cases(0x5EED0500, ptref.TONEMAP_DTYPE)
+out["tonemap_out"] = np.stack([ptref.tonemap_linear(rgba, p, reference=True) for p, rgba in tm])
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "refpin_hlsl_golden.npz"), **out)
 print("wrote %d functions" % len(ptref.PIN_NAMES))

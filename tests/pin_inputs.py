@@ -123,3 +123,19 @@ def light_inputs(n, seed, probe):
     k3 = np.column_stack([tri, _bits(viewer), smp])
     k4 = _bits(np.vstack([_unit(rng, n - 9), _axes()]))
     return {0: k0, 1: k1, 2: k2, 3: k3, 4: k4}
+
+
+def tonemap_cases(seed, dtype):
+    """(params record, rgba rows) per case: the six operators x {manual exposure, CPU auto exposure, disabled, unclamped} with a random colour transform."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for op in range(6):
+        for variant in range(4):
+            p = np.zeros((), dtype=dtype)
+            p["whiteScale"] = rng.uniform(2, 12); p["whiteMaxLuminance"] = rng.uniform(0.5, 4); p["toneMapOperator"] = op; p["clamped"] = 0 if variant == 3 else 1
+            p["autoExposure"] = 1 if variant == 1 else 0; p["avgLuminance"] = rng.uniform(0.01, 2); p["autoExposureLumValueMin"] = 2.0 ** -4; p["autoExposureLumValueMax"] = 2.0 ** 4
+            M = np.eye(3) * rng.uniform(0.2, 3) + rng.uniform(-0.05, 0.05, (3, 3)); p["colorTransform"] = M.reshape(-1)
+            p["enabled"] = 0 if variant == 2 else 1
+            rgba = np.column_stack([_logu(rng, (400, 3), 1e-4, 50), rng.uniform(0, 1, 400)]).astype(np.float32); rgba[:3, :3] = [[0, 0, 0], [1, 1, 1], [0.004, 0.003, 0.005]]
+            cases.append((p, rgba))
+    return cases

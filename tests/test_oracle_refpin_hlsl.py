@@ -121,3 +121,22 @@ def test_lights_match_live_reference():
         ok = _words_equal(got, want)
         bad = np.flatnonzero(~ok.all(1))
         assert ok.all(), "%s: %d of %d rows differ; first row %d: in=%s oracle=%s reference=%s" % (LIGHT_KINDS[kind], len(bad), len(words), bad[0], words[bad[0]], got[bad[0]], want[bad[0]])
+
+
+def test_tonemapping_matches_reference_golden():
+    """applyToneMapping of ToneMapper/ToneMapping.ps.hlsli (six operators, CPU auto exposure, colour transform, clamp) compiled from the reference text,
+    against the oracle's tm_apply — the floats that go into the SRGBA8 store."""
+    g = np.load(GOLDEN)
+    cases = pin_inputs.tonemap_cases(0x5EED0500, ptref.TONEMAP_DTYPE)
+    for k, (p, rgba) in enumerate(cases):
+        got = ptref.tonemap_linear(rgba, p)
+        ok = _same(got, g["tonemap_out"][k])
+        assert ok.all(), "operator %d variant %d: %d of %d pixels differ" % (k // 4, k % 4, int((~ok).any(1).sum()), len(rgba))
+
+
+def test_tonemapping_matches_live_reference():
+    if ptref.refpin_hlsl() is None:
+        pytest.skip("librefpin_hlsl.so not available (no /root/reference on this machine)")
+    for k, (p, rgba) in enumerate(pin_inputs.tonemap_cases(0x70E3, ptref.TONEMAP_DTYPE)):
+        ok = _same(ptref.tonemap_linear(rgba, p), ptref.tonemap_linear(rgba, p, reference=True))
+        assert ok.all(), "operator %d variant %d: %d of %d pixels differ" % (k // 4, k % 4, int((~ok).any(1).sum()), len(rgba))
