@@ -230,6 +230,7 @@ def main_pt(ref):
     braw = open(bpath, encoding="latin-1").read(); btext = strip_comments(braw)
     for spec in ("^enum DonutGeometryAttributes..^static OpacityMicroMapDebugInfo loadOmmDebugInfo",
                  "^uint Bridge::getSampleIndex..^// 2\\.5D motion vectors",
+                 "^bool AlphaTestImpl..^bool Bridge::traceVisibilityRay",
                  "^EnvMap Bridge::CreateEnvMap..^void Bridge::ExportSurfaceInit"):
         w("// ======== PathTracerBridgeDonut.hlsli : %s\n" % spec)
         w(to_cpp(extract_range(btext, spec, "PathTracerBridgeDonut.hlsli", braw)) + "\n")

@@ -69,3 +69,22 @@ def test_load_surface_matches_reference_text(name):
     bad = (R != Q).any(1)
     assert not bad.any(), "%d of %d surfaces differ (first: hit %d, words %s)" % (int(bad.sum()), k, int(np.flatnonzero(bad)[0]), np.flatnonzero(R[bad][0] != Q[bad][0]))
     assert len(np.unique(R[:, 23])) > 1 or name == "c2"       # several materials were hit
+
+
+def test_alpha_tests_match_reference_text():
+    """AlphaTestImpl + Bridge::AlphaTest / AlphaTestVisibilityRay (PathTracerBridgeDonut.hlsli:929-989) against the candidate filter of the oracle's traversal."""
+    if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
+        pytest.skip("no /root/reference on this machine")
+    import ctypes
+    make, S, w, h, first, n = CASES["bistro_like"]
+    sc, cam = make()
+    o = ptref.Oracle(reference_integrator=True, settings=S); o.set_scene(sc); o.set_settings(S); o.resize(8, 8)
+    o.L.ptref_num_tris.restype = ctypes.c_uint32
+    nt = o.L.ptref_num_tris(o.h)
+    rng = np.random.default_rng(0xA1FA); k = 60000
+    prims = rng.integers(0, nt, k).astype(np.uint32); u = rng.uniform(0, 1, k); v = rng.uniform(0, 1, k) * (1 - u)
+    uv = np.ascontiguousarray(np.column_stack([u, v]), np.float32); out = np.zeros((k, 4), np.uint32)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    o.L.refpt_alpha_probe(o.h, ctypes.c_uint32(k), vp(prims), vp(uv), vp(out))
+    assert np.array_equal(out[:, 0], out[:, 2]) and np.array_equal(out[:, 1], out[:, 3])
+    assert 0 < out[:, 0].sum() < k and (out[:, 1] <= out[:, 0]).all()        # some candidates are rejected; visibility rays reject at least as many
