@@ -41,7 +41,7 @@ def test_oracle_matches_reference_integrator_golden(name):
     assert want[..., :3].max() > 0
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c2_nested2_norr_nold", "bistro_like_c5"])
+@pytest.mark.parametrize("name", list(CASES))
 def test_oracle_matches_live_reference_integrator(name):
     if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
         pytest.skip("no /root/reference on this machine: the reference-text integrator cannot be built here")
@@ -88,3 +88,33 @@ def test_alpha_tests_match_reference_text():
     o.L.refpt_alpha_probe(o.h, ctypes.c_uint32(k), vp(prims), vp(uv), vp(out))
     assert np.array_equal(out[:, 0], out[:, 2]) and np.array_equal(out[:, 1], out[:, 3])
     assert 0 < out[:, 0].sum() < k and (out[:, 1] <= out[:, 0]).all()        # some candidates are rejected; visibility rays reject at least as many
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24, 25, 26, 27, 28, 29, 30])
+def test_random_scene_camera_settings_against_reference_text(seed):
+    """The fuzz generator of tests/test_gpu_fuzz.py (random bistro-like scene, camera incl. depth of field, bounce limits, NEE type and candidate count,
+    RR, nested-dielectrics quality, firefly filter, LOD bias, LD sampler, diffuse model), oracle integrator vs the reference's integrator text."""
+    if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
+        pytest.skip("no /root/reference on this machine")
+    import math
+    rng = np.random.default_rng(0xF00D + seed)
+    sc, cam = scenes.bistro_like(scale=float(rng.uniform(0.004, 0.012)), seed=scenes.SEED_BASE + 100 + seed, tex_size=int(rng.choice([32, 64, 128])), animated=bool(rng.integers(0, 2)))
+    yaw, pitch = rng.uniform(0, 2 * math.pi), rng.uniform(-0.5, 0.6)
+    cam = dict(cam, pos=(float(rng.uniform(5, 110)), float(rng.uniform(0.5, 18.0)), float(rng.uniform(10.0, 30.0))),
+               direction=(math.cos(yaw) * math.cos(pitch), math.sin(pitch), math.sin(yaw) * math.cos(pitch)), fov_y=float(rng.uniform(0.5, 1.4)),
+               aperture_radius=float(rng.choice([0.0, 0.02])), focal_distance=float(rng.uniform(3.0, 30.0)))
+    S = scenes.default_settings(bounceCount=int(rng.integers(1, 9)), diffuseBounceCount=int(rng.integers(1, 9)), NEEType=int(rng.integers(0, 2)),
+                                NEECandidateSamples=int(rng.integers(1, 8)), NEEFullSamples=int(rng.choice([1, 1, 2])), enableRussianRoulette=int(rng.integers(0, 2)),
+                                nestedDielectricsQuality=int(rng.integers(0, 3)), fireflyFilterThreshold=float(rng.choice([0.0, 0.5])),
+                                texLODBias=float(rng.uniform(-2.0, 1.0)), enableLDSamplerForBSDF=int(rng.integers(0, 2)), diffuseBrdf=int(rng.choice([0, 2])))
+    w, h = int(rng.integers(40, 120)), int(rng.integers(30, 70))
+    first, count = int(rng.integers(0, 50)), int(rng.integers(1, 3))
+    camd = scenes.bridge_camera(w, h, **cam)
+    frames = []
+    for reference in (False, True):
+        o = ptref.Oracle(reference_integrator=True, settings=S) if reference else ptref.Oracle()
+        o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.render(first, count)
+        c = o.counters(); frames.append((o.radiance(), c["extendRays"], c["shadowRays"]))
+    (a, ea, sa), (b, eb, sb) = frames
+    bad = int((a.view(np.uint32) != b.view(np.uint32)).any(-1).sum())
+    assert bad == 0 and (ea, sa) == (eb, sb), "%d of %d pixels differ, rays %s vs %s (seed %d, variant %s)" % (bad, w * h, (ea, sa), (eb, sb), seed, ptref.pt_variant(S))
