@@ -185,6 +185,23 @@ def surface_probe(oracle_ctx, prims, uv_dir_cone):
     return R, Q
 
 
+def lightbake_probe(kind, words, pyramid=None, color_mul=(1.0, 1.0, 1.0), distant_vs_local=0.0002, reference=False):
+    """Light-baker functions (oracle/refpin/hlsl_wrappers.inc refhlsl_lightbake_probe). kind 0: 12-word light records -> ComputeWeight bits;
+    kind 1: rows [dim, x, y, lightIndex, depthLimit] over an importance pyramid (list of (d, d, 4) float32 arrays, finest first) -> 5 words."""
+    L = refpin_hlsl() if reference else lib()
+    if L is None:
+        return None
+    ni, no = (12, 1) if kind == 0 else (5, 5)
+    a = np.ascontiguousarray(words, np.uint32).reshape(-1, ni); out = np.zeros((a.shape[0], no), np.uint32)
+    pyr = [np.ascontiguousarray(m, np.float32) for m in (pyramid or [])]
+    ptrs = (ctypes.c_void_p * max(1, len(pyr)))(*[m.ctypes.data for m in pyr]) if pyr else (ctypes.c_void_p * 1)()
+    dims = np.array([m.shape[0] for m in pyr] or [0], np.uint32); cm = np.array(color_mul, np.float32)
+    f = L.refhlsl_lightbake_probe if reference else L.ptref_lightbake_probe
+    f(ctypes.c_int(kind), a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(a.shape[0]), out.ctypes.data_as(ctypes.c_void_p), ptrs, dims.ctypes.data_as(ctypes.c_void_p),
+      ctypes.c_uint32(len(pyr)), cm.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(distant_vs_local))
+    return out
+
+
 def _pin_table():
     """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
     import re

@@ -179,6 +179,19 @@ static uint qt_weight(const EnvImportance& im, uint dim, uint x, uint y, uint li
     uint v = (uint)(FastSqrt(ret) * 100 + 0.5f); if (v > 0x000FFFFFu) v = 0x000FFFFFu;
     return (v << 12) | lightIndex;
 }
+static float4 env_radiance_and_weight(const EnvImportance& im, float3 colorMultiplier, float distantVsLocal, uint dim, uint x, uint y) {   // EnvironmentComputeRadianceAndWeight (LightsBaker.hlsl:167-178)
+    uint mipLevel = im.mipCount - firstbithigh(dim) - 1;
+    float areaMul = (float)(1u << (mipLevel * 2));
+    float4 value = im.mips[mipLevel][(size_t)y * dim + x];
+    float weight = areaMul * fmaxf_(0.f, value.w * Average(colorMultiplier) * distantVsLocal);
+    return make_float4(xyz(value) * colorMultiplier, weight);
+}
+static float light_weight(const PolymorphicLightInfoFull& lf) {                        // ComputeWeight (LightsBaker.hlsl:738-751)
+    float flux = PolymorphicLight_GetPower(lf);
+    float wt = dm_pow(flux, 0.8f);
+    if (wt < RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD) wt = 0;
+    return wt;
+}
 struct QTNode { uint dim, x, y; };
 static void qt_subdivide(const EnvImportance& im, std::vector<QTNode>& nodes, std::vector<uint>& packed, uint subdivisions, uint depthLimit) {
     for (uint si = 0; si < subdivisions; si++) {
@@ -208,11 +221,8 @@ static void bake_env_quads(Scene& sc) {
         qt_subdivide(im, nodes, pk, QT_BOOST_SUBDIV, 0);
         for (uint li = 0; li < QT_BOOST_MULT; li++) {
             EnvironmentQuadLight e; e.NodeDim = nodes[li].dim; e.NodeX = nodes[li].x; e.NodeY = nodes[li].y;
-            uint mipLevel = im.mipCount - firstbithigh(e.NodeDim) - 1;          // EnvironmentComputeRadianceAndWeight
-            float areaMul = (float)(1u << (mipLevel * 2));
-            float4 value = im.mips[mipLevel][(size_t)e.NodeY * e.NodeDim + e.NodeX];
-            e.Weight = areaMul * fmaxf_(0.f, value.w * Average(sc.env.colorMultiplier) * distantVsLocal);
-            e.Radiance = xyz(value) * sc.env.colorMultiplier;
+            float4 rw = env_radiance_and_weight(im, sc.env.colorMultiplier, distantVsLocal, e.NodeDim, e.NodeX, e.NodeY);
+            e.Weight = rw.w; e.Radiance = xyz(rw);
             uint uniqueID = 0;
             PolymorphicLightInfoFull lf = e.Store(uniqueID);
             float2 sub = make_float2(((float)e.NodeX + 0.5f) / (float)e.NodeDim, ((float)e.NodeY + 0.5f) / (float)e.NodeDim);
@@ -278,9 +288,8 @@ void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
         std::vector<float> w(N); float weightSum = 0.f;
         for (uint i = 0; i < N; i++) {
             PolymorphicLightInfoFull lf; lf.Base = sc.lights[i]; lf.Extended = sc.lightsEx[i];
-            float flux = PolymorphicLight_GetPower(lf);
-            float wt = dm_pow(flux, 0.8f);
-            if (!(wt >= RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD)) wt = 0;
+            float wt = light_weight(lf);
+            if (!(wt == wt)) wt = 0;                    // (a NaN flux cannot pass `lightWeight > 0` in ComputeProxyCounts either)
             w[i] = wt; weightSum += wt;
         }
         uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
@@ -591,7 +600,24 @@ void ptref_tonemap_linear(const float* rgba, uint32_t n, const ToneMapParams* p,
     for (uint32_t i = 0; i < n; i++) { float3 c = tm_apply(*p, make_float3(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2])); out[4 * i] = c.x; out[4 * i + 1] = c.y; out[4 * i + 2] = c.z; out[4 * i + 3] = rgba[4 * i + 3]; }
 }
 
+// light baking: the oracle's side of refhlsl_lightbake_probe. mips: pyramid of float4 (rgb mean radiance, w importance), mip l has dims[l]^2 texels.
+// kind 0: rows [12-word light record] -> ComputeWeight. kind 1: rows [dim, x, y, lightIndex, depthLimit] -> [QT weight word, radiance rgb, weight] (5 words)
+void ptref_lightbake_probe(int kind, const uint32_t* in, unsigned n, uint32_t* out, const float* const* mips, const uint32_t* dims, uint32_t mipCount, const float* colorMul, float distantVsLocal) {
+    EnvImportance im; im.mipCount = mipCount; im.dim = dims ? dims[0] : 0;
+    if (kind == 1) { im.mips.resize(mipCount); for (uint32_t l = 0; l < mipCount; l++) { im.mips[l].resize((size_t)dims[l] * dims[l]); memcpy(im.mips[l].data(), mips[l], im.mips[l].size() * 16); } }
+    for (unsigned k = 0; k < n; k++) {
+        if (kind == 0) out[k] = asuint(light_weight(pin_info(in + 12 * k)));
+        else {
+            const uint32_t* a = in + 5 * k; uint32_t* o = out + 5 * k;
+            o[0] = qt_weight(im, a[0], a[1], a[2], a[3], a[4]);
+            float4 rw = env_radiance_and_weight(im, make_float3(colorMul[0], colorMul[1], colorMul[2]), distantVsLocal, a[0], a[1], a[2]);
+            o[1] = asuint(rw.x); o[2] = asuint(rw.y); o[3] = asuint(rw.z); o[4] = asuint(rw.w);
+        }
+    }
+}
+
 } // extern "C"
+
 
 
 

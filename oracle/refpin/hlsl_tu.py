@@ -46,6 +46,13 @@ PLAN = [
     ("Lighting/PolymorphicLightPTConfig.h", ["pp"]),
     ("Lighting/LightShaping.hlsli", ["range ^struct LightShaping..#endif // LIGHT_SHAPING_HLSLI"]),
     ("Lighting/PolymorphicLight.hlsli", ["range #define FLT_EPSILON_MINI..#endif // __POLYMORPHIC_LIGHT_HLSLI__ -Eval"]),
+    # ---- light baking, the per-light / per-node functions of the LightsBaker compute passes (the passes themselves use group-shared memory and atomics)
+    ("Lighting/LightingConfig.h", ["text #define STATIC_ASSERT(X)", "range ^#define RTXPT_LIGHTING_MAX_LIGHTS..^#endif // #define __LIGHTING_CONFIG_H__"]),
+    ("@Rtxpt/Lighting/LightsBaker.hlsl", ["text struct PinEnvMapParams { float3 ColorMultiplier; }; struct PinBakerConsts { uint EnvMapImportanceMapMIPCount; PinEnvMapParams EnvMapParams; float DistantVsLocalRelativeImportance; };",
+                                          "text struct PinImportanceMap { const float4* const* mips; const uint* dims; float4 Load(int3 c) const { return mips[c.z][(uint)c.y * dims[c.z] + (uint)c.x]; } };",
+                                          "text static PinBakerConsts g_bakerConsts; static PinImportanceMap t_envRadianceAndImportanceMap;",
+                                          "EnvironmentComputeRadianceAndWeight", "range ^#define PACK_20F_12UI..^uint EnvironmentComputeWeightForQTBuild", "EnvironmentComputeWeightForQTBuild",
+                                          "EQTNodePack", "EQTNodeUnpack", "ComputeWeight"]),
     # ---- display path: ToneMapping.ps.hlsli whole, over a colour "texture" that holds one pixel
     ("@Rtxpt/ToneMapper/ToneMapping_cb.h", ["range ^#define TONEMAPPING_AUTOEXPOSURE_CPU..^#endif // TONEMAPPING_CB_H"]),
     ("@Rtxpt/ToneMapper/ToneMapping.ps.hlsli", ["text struct PinColorTexture { float4 texel; float4 Sample(SamplerState, float2) const { return texel; } float4 SampleLevel(SamplerState, float2, float) const { return texel; } };",

@@ -24,5 +24,8 @@ for kind, words in lights.items():
     out["light%d_out" % kind] = ptref.light_probe(kind, words, reference=True)
 tm = pin_inputs.tonemap_cases(0x5EED0500, ptref.TONEMAP_DTYPE)
 out["tonemap_out"] = np.stack([ptref.tonemap_linear(rgba, p, reference=True) for p, rgba in tm])
+k0, pyr, k1 = pin_inputs.lightbake_inputs(0x5EED0600, lights[2][:, :12])
+out["lightbake0_out"] = ptref.lightbake_probe(0, k0, reference=True)
+out["lightbake1_out"] = ptref.lightbake_probe(1, k1, pyr, (0.7, 1.3, 0.9), 0.0002, reference=True)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "refpin_hlsl_golden.npz"), **out)
 print("wrote %d functions" % len(ptref.PIN_NAMES))

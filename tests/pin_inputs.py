@@ -139,3 +139,15 @@ def tonemap_cases(seed, dtype):
             rgba = np.column_stack([_logu(rng, (400, 3), 1e-4, 50), rng.uniform(0, 1, 400)]).astype(np.float32); rgba[:3, :3] = [[0, 0, 0], [1, 1, 1], [0.004, 0.003, 0.005]]
             cases.append((p, rgba))
     return cases
+
+
+def lightbake_inputs(seed, light_records):
+    """(kind-0 rows = the given light records, pyramid, kind-1 rows): a random importance pyramid (64^2 down to 1^2) and every kind of node query."""
+    rng = np.random.default_rng(seed)
+    pyr = [np.concatenate([_logu(rng, (d, d, 3), 1e-3, 1e3), _logu(rng, (d, d, 1), 1e-5, 1e4)], axis=2).astype(np.float32) for d in (64, 32, 16, 8, 4, 2, 1)]
+    pyr[2][:2, :2, 3] = 0.0
+    rows = []
+    for k in range(3000):
+        lg = int(rng.integers(0, 7)); dim = 1 << lg
+        rows.append([dim, int(rng.integers(0, dim)), int(rng.integers(0, dim)), int(rng.integers(0, 4096)), int(rng.integers(0, 7))])
+    return np.ascontiguousarray(light_records, np.uint32), pyr, np.array(rows, np.uint32)

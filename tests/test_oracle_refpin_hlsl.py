@@ -140,3 +140,24 @@ def test_tonemapping_matches_live_reference():
     for k, (p, rgba) in enumerate(pin_inputs.tonemap_cases(0x70E3, ptref.TONEMAP_DTYPE)):
         ok = _same(ptref.tonemap_linear(rgba, p), ptref.tonemap_linear(rgba, p, reference=True))
         assert ok.all(), "operator %d variant %d: %d of %d pixels differ" % (k // 4, k % 4, int((~ok).any(1).sum()), len(rgba))
+
+
+def test_lightbake_functions_match_reference_golden():
+    """Lighting/LightsBaker.hlsl per-light / per-node functions compiled from the reference text: ComputeWeight (flux^0.8 + threshold), environment quad-tree
+    node weight (PACK_20F_12UI) and node radiance / weight. (The passes around them use group-shared memory and float atomics whose order the GPU does
+    not fix, so the baked tables themselves cannot be pinned bit for bit.)"""
+    g = np.load(GOLDEN)
+    k0, pyr, k1 = pin_inputs.lightbake_inputs(0x5EED0600, g["light2_in"][:, :12])
+    assert np.array_equal(ptref.lightbake_probe(0, k0), g["lightbake0_out"])
+    got = ptref.lightbake_probe(1, k1, pyr, (0.7, 1.3, 0.9), 0.0002)
+    assert np.array_equal(got, g["lightbake1_out"]), "%d node rows differ" % int((got != g["lightbake1_out"]).any(1).sum())
+    assert (g["lightbake0_out"].view(np.float32) > 0).sum() > 1000 and len(np.unique(g["lightbake1_out"][:, 0] >> 12)) > 100
+
+
+def test_lightbake_functions_match_live_reference():
+    if ptref.refpin_hlsl() is None:
+        pytest.skip("librefpin_hlsl.so not available (no /root/reference on this machine)")
+    recs = pin_inputs.light_inputs(8000, 0xBA4E, lambda kind, w: ptref.light_probe(kind, w))[2][:, :12]
+    k0, pyr, k1 = pin_inputs.lightbake_inputs(0xBA4F, recs)
+    assert np.array_equal(ptref.lightbake_probe(0, k0), ptref.lightbake_probe(0, k0, reference=True))
+    assert np.array_equal(ptref.lightbake_probe(1, k1, pyr, (1.1, 0.4, 2.0), 0.0002), ptref.lightbake_probe(1, k1, pyr, (1.1, 0.4, 2.0), 0.0002, reference=True))
