@@ -3,6 +3,26 @@
 from rtxpt_amd import scenes
 
 
+def with_sphere_lights(make):
+    """The scene of `make` plus four analytic sphere lights (two of them spot-shaped), packed with the oracle's PackColor / oct encoding (pt_set_lights path)."""
+    import numpy as np
+    from oracle import ptref
+    def build():
+        sc, cam = make()
+        pos = np.array([[0.15, 0.45, 0.2], [0.42, 0.5, 0.35], [0.28, 0.3, 0.1], [0.1, 0.2, 0.45]], np.float32)
+        rad = np.array([[40, 30, 10], [5, 20, 40], [60, 60, 60], [30, 5, 5]], np.float32); radius = np.array([0.02, 0.03, 0.015, 0.025], np.float32)
+        col = ptref.light_probe(0, rad.view(np.uint32))
+        axis = ptref.light_probe(4, np.array([[0, -1, 0], [0.3, -0.9, 0.1], [0, -1, 0], [0, 0, 1]], np.float32).view(np.uint32))[:, 0]
+        f16 = lambda x: np.asarray(x, np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
+        base = np.zeros((4, 8), np.uint32); ex = np.zeros((4, 4), np.uint32)
+        base[:, 0:3] = pos.view(np.uint32); spot = np.array([0, 1, 1, 0], np.uint32)
+        base[:, 3] = col[:, 0] | (0 << 24) | (spot << 28) | (np.array([0, 0, 1, 0], np.uint32) << 30); base[:, 6] = f16(radius); base[:, 7] = col[:, 1]
+        ex[:, 1] = axis; ex[:, 2] = f16([0, 0.7, 0.85, 0]) | (f16([0, 0.2, 0.1, 0]) << 16); ex[:, 3] = np.arange(4) + 100
+        sc = dict(sc); sc["lights"] = (base, ex)
+        return sc, cam
+    return build
+
+
 def cases():
     c2 = lambda: scenes.cornell_box("C2")
     return {
@@ -13,6 +33,7 @@ def cases():
         "c2_nee_off": (c2, scenes.default_settings(NEEEnabled=0), 64, 36, 0, 2),
         "c2_nested2_norr_nold": (c2, scenes.default_settings(nestedDielectricsQuality=2, enableRussianRoulette=0, enableLDSamplerForBSDF=0), 64, 36, 0, 2),
         "c2_nested0_uniform": (c2, scenes.default_settings(nestedDielectricsQuality=0, NEEType=0), 64, 36, 0, 2),
+        "c2_sphere_lights": (with_sphere_lights(c2), scenes.default_settings(), 64, 36, 0, 2),                     # analytic lights (pt_set_lights): spheres, spot shaping
         "bistro_like": (lambda: scenes.bistro_like(scale=0.02, tex_size=128), scenes.default_settings(), 96, 54, 0, 2),      # alpha test, textures, normal maps, emissive triangles, env quads
         "bistro_like_c5": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), scenes.default_settings(), 96, 54, 0, 2),   # + nested-dielectric props
     }
