@@ -23,6 +23,17 @@ def with_sphere_lights(make):
     return build
 
 
+def with_excluded_geometry(make, which=(-1, -2)):
+    """The scene of `make` with some geometries flagged ExcludeFromNEE (shadow rays pass through them, AccelerationStructureUtil.h:35-104, BridgeDonut:981-989)."""
+    def build():
+        sc, cam = make()
+        sc = dict(sc); g = sc["geometries"].copy()
+        for k in which: g["geomFlags"][k] |= scenes.GEOMF_EXCLUDE_FROM_NEE
+        sc["geometries"] = g
+        return sc, cam
+    return build
+
+
 def cases():
     c2 = lambda: scenes.cornell_box("C2")
     return {
@@ -34,6 +45,7 @@ def cases():
         "c2_nested2_norr_nold": (c2, scenes.default_settings(nestedDielectricsQuality=2, enableRussianRoulette=0, enableLDSamplerForBSDF=0), 64, 36, 0, 2),
         "c2_nested0_uniform": (c2, scenes.default_settings(nestedDielectricsQuality=0, NEEType=0), 64, 36, 0, 2),
         "c2_sphere_lights": (with_sphere_lights(c2), scenes.default_settings(), 64, 36, 0, 2),                     # analytic lights (pt_set_lights): spheres, spot shaping
+        "c2_exclude_from_nee": (with_excluded_geometry(c2), scenes.default_settings(), 64, 36, 0, 2),              # ExcludeFromNEE geometry: invisible to shadow rays
         "bistro_like": (lambda: scenes.bistro_like(scale=0.02, tex_size=128), scenes.default_settings(), 96, 54, 0, 2),      # alpha test, textures, normal maps, emissive triangles, env quads
         "bistro_like_c5": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), scenes.default_settings(), 96, 54, 0, 2),   # + nested-dielectric props
     }

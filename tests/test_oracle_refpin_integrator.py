@@ -71,12 +71,14 @@ def test_load_surface_matches_reference_text(name):
     assert len(np.unique(R[:, 23])) > 1 or name == "c2"       # several materials were hit
 
 
-def test_alpha_tests_match_reference_text():
-    """AlphaTestImpl + Bridge::AlphaTest / AlphaTestVisibilityRay (PathTracerBridgeDonut.hlsli:929-989) against the candidate filter of the oracle's traversal."""
+@pytest.mark.parametrize("name", ["bistro_like", "c2_exclude_from_nee"])
+def test_alpha_tests_match_reference_text(name):
+    """AlphaTestImpl + Bridge::AlphaTest / AlphaTestVisibilityRay (PathTracerBridgeDonut.hlsli:929-989) against the candidate filter of the oracle's traversal:
+    alpha-tested foliage (bistro-like) and ExcludeFromNEE geometry (Cornell boxes)."""
     if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
         pytest.skip("no /root/reference on this machine")
     import ctypes
-    make, S, w, h, first, n = CASES["bistro_like"]
+    make, S, w, h, first, n = CASES[name]
     sc, cam = make()
     o = ptref.Oracle(reference_integrator=True, settings=S); o.set_scene(sc); o.set_settings(S); o.resize(8, 8)
     o.L.ptref_num_tris.restype = ctypes.c_uint32
@@ -87,7 +89,8 @@ def test_alpha_tests_match_reference_text():
     vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
     o.L.refpt_alpha_probe(o.h, ctypes.c_uint32(k), vp(prims), vp(uv), vp(out))
     assert np.array_equal(out[:, 0], out[:, 2]) and np.array_equal(out[:, 1], out[:, 3])
-    assert 0 < out[:, 0].sum() < k and (out[:, 1] <= out[:, 0]).all()        # some candidates are rejected; visibility rays reject at least as many
+    assert 0 < out[:, 1].sum() < k and (out[:, 1] <= out[:, 0]).all()        # some candidates are rejected; visibility rays reject at least as many
+    if name == "c2_exclude_from_nee": assert out[:, 0].all() and not out[:, 1].all()      # excluded boxes: solid for scatter rays, transparent for shadow rays
 
 
 @pytest.mark.parametrize("seed", [21, 22, 23, 24, 25, 26, 27, 28, 29, 30])
