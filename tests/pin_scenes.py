@@ -34,6 +34,21 @@ def with_excluded_geometry(make, which=(-1, -2)):
     return build
 
 
+def with_rotated_environment(make, yaw=0.9, pitch=0.35, tint=(1.4, 0.8, 0.6)):
+    """The scene of `make` with its environment rotated and tinted (EnvMapSceneParams Transform / InvTransform / ColorMultiplier, EnvMap.hlsli:54-93)."""
+    import math
+    import numpy as np
+    def build():
+        sc, cam = make()
+        rgb, tw, cm = sc["env"]
+        cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]); Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        R = (Ry @ Rx).astype(np.float32)
+        sc = dict(sc); sc["env"] = (rgb, np.concatenate([R, np.zeros((3, 1), np.float32)], axis=1).reshape(-1).astype(np.float32), np.asarray(tint, np.float32))
+        return sc, cam
+    return build
+
+
 def cases():
     c2 = lambda: scenes.cornell_box("C2")
     return {
@@ -46,6 +61,7 @@ def cases():
         "c2_nested0_uniform": (c2, scenes.default_settings(nestedDielectricsQuality=0, NEEType=0), 64, 36, 0, 2),
         "c2_sphere_lights": (with_sphere_lights(c2), scenes.default_settings(), 64, 36, 0, 2),                     # analytic lights (pt_set_lights): spheres, spot shaping
         "c2_exclude_from_nee": (with_excluded_geometry(c2), scenes.default_settings(), 64, 36, 0, 2),              # ExcludeFromNEE geometry: invisible to shadow rays
+        "c2_env_rotated_mip2": (with_rotated_environment(c2), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 64, 36, 5, 2),   # env transform + tint, diffuse-bounce env MIP 2 (the UI default)
         "bistro_like": (lambda: scenes.bistro_like(scale=0.02, tex_size=128), scenes.default_settings(), 96, 54, 0, 2),      # alpha test, textures, normal maps, emissive triangles, env quads
         "bistro_like_c5": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), scenes.default_settings(), 96, 54, 0, 2),   # + nested-dielectric props
     }
