@@ -49,6 +49,19 @@ def with_rotated_environment(make, yaw=0.9, pitch=0.35, tint=(1.4, 0.8, 0.6)):
     return build
 
 
+def with_mirrored_instance(make, index=0, width=0.5528):
+    """The scene of `make` with one instance mirrored in x (negative determinant: flipped winding for the light baker, LightsBaker.hlsl:669-683, and for
+    the face normals) and stretched a little in y (non-uniform scale through the normal / tangent transforms)."""
+    import numpy as np
+    def build():
+        sc, cam = make()
+        sc = dict(sc); inst = sc["instances"].copy()
+        inst["transform"][index] = np.array([-1, 0, 0, width, 0, 1.05, 0, 0, 0, 0, 1, 0], np.float32).reshape(inst["transform"][index].shape)
+        sc["instances"] = inst
+        return sc, cam
+    return build
+
+
 def cases():
     c2 = lambda: scenes.cornell_box("C2")
     return {
@@ -62,6 +75,7 @@ def cases():
         "c2_sphere_lights": (with_sphere_lights(c2), scenes.default_settings(), 64, 36, 0, 2),                     # analytic lights (pt_set_lights): spheres, spot shaping
         "c2_exclude_from_nee": (with_excluded_geometry(c2), scenes.default_settings(), 64, 36, 0, 2),              # ExcludeFromNEE geometry: invisible to shadow rays
         "c2_env_rotated_mip2": (with_rotated_environment(c2), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 64, 36, 5, 2),   # env transform + tint, diffuse-bounce env MIP 2 (the UI default)
+        "c2_mirrored_room": (with_mirrored_instance(c2), scenes.default_settings(), 64, 36, 0, 2),                 # negative-determinant instance holding the quad light
         "bistro_like": (lambda: scenes.bistro_like(scale=0.02, tex_size=128), scenes.default_settings(), 96, 54, 0, 2),      # alpha test, textures, normal maps, emissive triangles, env quads
         "bistro_like_c5": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), scenes.default_settings(), 96, 54, 0, 2),   # + nested-dielectric props
     }
