@@ -62,6 +62,28 @@ def with_mirrored_instance(make, index=0, width=0.5528):
     return build
 
 
+def with_material_zoo(make):
+    """The bistro-like scene with material features no generator switches on by itself: metal-rough texture with metalness in the red channel,
+    transmission texture (thick and thin), diffuse transmission, ShadowNoLFadeout, IgnoreMeshTangentSpace on a normal-mapped material, an emissive
+    texture on the lamps (light baking + emissive hits), a normal texture scale != 1."""
+    import numpy as np
+    def build():
+        sc, cam = make()
+        sc = dict(sc); m = sc["materials"].copy()
+        tex = lambda k: m["BaseOrDiffuseTextureIndex"][k]                  # packed texture words of the textured facade materials 0..23
+        for k in (1, 9, 17): m["MetalRoughOrSpecularTextureIndex"][k] = tex(k + 1); m["Flags"][k] |= 0x4; m["Metalness"][k] = 0.8
+        for k in (9, 17): m["Flags"][k] |= 0x100                          # MetalnessInRedChannel
+        for k in (2, 10): m["TransmissionTextureIndex"][k] = tex(k + 2); m["Flags"][k] |= 0x80; m["TransmissionFactor"][k] = 0.7
+        m["Flags"][10] &= ~np.uint32(0x200); m["IoR"][10] = 1.3           # not thin: refracting
+        for k in (3, 11): m["DiffuseTransmissionFactor"][k] = 0.6
+        for k in (4, 12, 25, 26): m["ShadowNoLFadeout"][k] = 0.15
+        m["Flags"][5] |= (1 << 12); m["NormalTextureScale"][6] = 0.5; m["NormalTextureScale"][7] = 1.7
+        for k in range(48, 64, 3): m["EmissiveTextureIndex"][k] = tex(k % 24); m["Flags"][k] |= 0x10
+        sc["materials"] = m
+        return sc, cam
+    return build
+
+
 def cases():
     c2 = lambda: scenes.cornell_box("C2")
     return {
@@ -77,5 +99,6 @@ def cases():
         "c2_env_rotated_mip2": (with_rotated_environment(c2), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 64, 36, 5, 2),   # env transform + tint, diffuse-bounce env MIP 2 (the UI default)
         "c2_mirrored_room": (with_mirrored_instance(c2), scenes.default_settings(), 64, 36, 0, 2),                 # negative-determinant instance holding the quad light
         "bistro_like": (lambda: scenes.bistro_like(scale=0.02, tex_size=128), scenes.default_settings(), 96, 54, 0, 2),      # alpha test, textures, normal maps, emissive triangles, env quads
+        "bistro_like_material_zoo": (with_material_zoo(lambda: scenes.bistro_like(scale=0.02, tex_size=128)), scenes.default_settings(), 96, 54, 2, 2),
         "bistro_like_c5": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), scenes.default_settings(), 96, 54, 0, 2),   # + nested-dielectric props
     }

@@ -311,7 +311,7 @@ def _pin_cases():
     return pin_scenes.cases()
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5"])
 def test_product_matches_reference_integrator_golden(name):
     """The HIP path against frames rendered by the REFERENCE'S integrator source text (tests/golden/reference_integrator_golden.npz, made in the build
     container by compiling PathTracer.hlsli & co. over the oracle's scene services — tests/test_oracle_refpin_integrator.py). No oracle call here."""

@@ -50,7 +50,7 @@ def test_oracle_matches_live_reference_integrator(name):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and rays == rays_ref
 
 
-@pytest.mark.parametrize("name", ["c2", "bistro_like", "bistro_like_c5"])
+@pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5"])
 def test_load_surface_matches_reference_text(name):
     """Bridge::loadSurface and everything RTXPT-side below it (getGeometryFromHit, sampleGeometryMaterialRTXPT, EvaluateSceneMaterialRTXPT,
     ApplyNormalMapRTXPT, createTextureSampler + ray-cone LOD, computeTangentSpace / adjustShadingNormal, emissive light index) compiled from
