@@ -144,23 +144,24 @@ def pt_variant(settings=None):
             g("nestedDielectricsQuality"), 1 if g("enableLDSamplerForBSDF") else 0, 1 if g("NEEEnabled") else 0)
 
 
-def refpin_pt(variant=(2, 1, 1, 1, 1, 1)):
+def refpin_pt(variant=(2, 1, 1, 1, 1, 1), lp16=False):
     """The reference's integrator text (PathTracer.hlsli & its include closure) compiled over the oracle's scene services, for one macro combination;
     exports the whole ptref_* API plus refpt_render. Built on demand from /root/reference (oracle/refpin/hlsl_tu.py --integrator); None when unavailable."""
-    if variant in _pin_pt:
-        return _pin_pt[variant]
+    key = tuple(variant) + (bool(lp16),)
+    if key in _pin_pt:
+        return _pin_pt[key]
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(os.path.dirname(_PIN), "librefpin_pt_%d%d%d%d%d%d.so" % variant)
+    path = os.path.join(os.path.dirname(_PIN), "librefpin_pt_%d%d%d%d%d%d%s.so" % (tuple(variant) + ("_lp16" if lp16 else "",)))
     srcs = [os.path.join(here, "refpin", f) for f in ("hlsl_tu.py", "hlsl_shim.h", "hlsl_pt_stubs.h", "hlsl_pt_bridge_stubs.h", "hlsl_pt_wrappers.inc")] + [os.path.join(here, "ptref", f) for f in os.listdir(os.path.join(here, "ptref"))]
     stale = not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs)
     if stale:
         if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
             if not os.path.exists(path):
-                _pin_pt[variant] = None
+                _pin_pt[key] = None
                 return None
         else:
             os.makedirs(os.path.dirname(path), exist_ok=True)
-            d = "-DDiffuseBrdf=%d -DPT_ENABLE_RUSSIAN_ROULETTE=%d -DRTXPT_FIREFLY_FILTER=%d -DRTXPT_NESTED_DIELECTRICS_QUALITY=%d -DRTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF=%d -DPT_NEE_ENABLED=%d" % variant
+            d = "-DDiffuseBrdf=%d -DPT_ENABLE_RUSSIAN_ROULETTE=%d -DRTXPT_FIREFLY_FILTER=%d -DRTXPT_NESTED_DIELECTRICS_QUALITY=%d -DRTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF=%d -DPT_NEE_ENABLED=%d" % tuple(variant) + (" -DRTXPT_LP_TYPES_USE_16BIT_PRECISION=1" if lp16 else "")
             cmd = ("python3 %s/refpin/hlsl_tu.py --integrator /root/reference | g++ -O2 -std=c++17 -fPIC -shared -fopenmp -mfma -ffp-contract=off -fno-fast-math "
                    "-fsingle-precision-constant -fpermissive -w %s -I%s/refpin -x c++ - -o %s" % (here, d, here, path))
             r = subprocess.run(["bash", "-o", "pipefail", "-c", cmd], capture_output=True, text=True)
@@ -170,7 +171,7 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1)):
     L.ptref_create.restype = ctypes.c_void_p
     L.ptref_radiance.restype = ctypes.POINTER(ctypes.c_float)
     L.ptref_num_tris.restype = ctypes.c_uint32
-    _pin_pt[variant] = L
+    _pin_pt[key] = L
     return L
 
 
@@ -224,12 +225,12 @@ def _p(a):
 class Oracle:
     """Mirrors the call order of Sample::Render: set scene -> set camera/settings -> render(sample range) -> radiance."""
 
-    def __init__(self, reference_integrator=False, settings=None):
+    def __init__(self, reference_integrator=False, settings=None, lp16=False):
         """reference_integrator=True: the same oracle scene services, but the path between the hits runs the REFERENCE'S integrator text
         (oracle/_ref/librefpin_pt_*.so, oracle/refpin/hlsl_pt_wrappers.inc), compiled for the shader-macro combination `settings` stand for;
         only where that library can be built."""
         self.reference_integrator = reference_integrator
-        self.L = refpin_pt(pt_variant(settings)) if reference_integrator else lib()
+        self.L = refpin_pt(pt_variant(settings), lp16=lp16) if reference_integrator else lib()      # lp16: the reference's 16-bit lp-type build (measurement only, tools/lp16_deviation.py)
         if self.L is None:
             raise RuntimeError("librefpin_pt.so not available (needs /root/reference)")
         self.h = ctypes.c_void_p(self.L.ptref_create())

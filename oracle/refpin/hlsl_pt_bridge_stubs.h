@@ -15,7 +15,7 @@ static const uint MaterialFlags_UseBaseOrDiffuseTexture = PTMaterialFlags_UseBas
 struct MaterialTextureSample { float4 baseOrDiffuse, metalRoughOrSpecular, normal, emissive, occlusion, transmission; };
 static inline MaterialTextureSample DefaultMaterialTextures() { MaterialTextureSample t; t.baseOrDiffuse = float4(1, 1, 1, 1); t.metalRoughOrSpecular = float4(1, 1, 1, 1); t.normal = float4(0.5f, 0.5f, 1.0f, 0.f);
     t.emissive = float4(1, 1, 1, 1); t.occlusion = float4(1, 1, 1, 1); t.transmission = float4(1, 1, 1, 1); return t; }
-static inline void ConvertSpecularGlossToMetalRough(float3, float3, float3& baseColor, float& metalness) { baseColor = float3(0, 0, 0); metalness = 0; }      // spec-gloss materials are rejected upstream
+template <class C3, class C1> static inline void ConvertSpecularGlossToMetalRough(float3, float3, C3& baseColor, C1& metalness) { baseColor = C3(0); metalness = C1(0); }      // spec-gloss materials are rejected upstream
 static inline float3 interpolate(const float3 v[3], float3 b) { return (v[0] * b.x + v[1] * b.y) + v[2] * b.z; }
 static inline float2 interpolate(const float2 v[3], float3 b) { return (v[0] * b.x + v[1] * b.y) + v[2] * b.z; }
 static inline float4 interpolate(const float4 v[3], float3 b) { return (v[0] * b.x + v[1] * b.y) + v[2] * b.z; }

@@ -18,7 +18,9 @@
 #define RTXPT_USE_APPROXIMATE_MIS                       0
 #define RTXPT_DISCARD_NON_NEE_LIGHTING                  0
 #define RTXPT_DISCARD_NEE_LIGHTING                      0
+#ifndef RTXPT_LP_TYPES_USE_16BIT_PRECISION
 #define RTXPT_LP_TYPES_USE_16BIT_PRECISION              0
+#endif
 #ifndef RTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF
 #define RTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF   1
 #endif

@@ -16,11 +16,15 @@ namespace hl {
 typedef uint32_t uint;
 namespace P = ptref;
 
-template <class T> struct v2 { union { struct { T x, y; }; struct { T r, g; }; }; v2() : x(), y() {} v2(T s) : x(s), y(s) {} v2(T a, T b) : x(a), y(b) {}
+struct half_t;
+template <class S> struct is_num : std::integral_constant<bool, std::is_arithmetic<S>::value || std::is_same<S, half_t>::value> {};
+template <class T> struct v2 { union { struct { T x, y; }; struct { T r, g; }; }; v2() : x(), y() {} template <class S, class = typename std::enable_if<is_num<S>::value && !std::is_same<S, T>::value>::type> v2(S s) : x((T)s), y((T)s) {}
+    v2(T s) : x(s), y(s) {} v2(T a, T b) : x(a), y(b) {}
     template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v2(const v2<U>& o) : x((T)o.x), y((T)o.y) {}
     v2& xy_() { return *this; } const v2& xy_() const { return *this; } const v2 yx_() const { return v2(y, x); } const v2 xx_() const { return v2(x, x); }
     T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
-template <class T> struct v3 { union { struct { T x, y, z; }; struct { T r, g, b; }; }; v3() : x(), y(), z() {} v3(T s) : x(s), y(s), z(s) {} v3(T a, T b, T c) : x(a), y(b), z(c) {}
+template <class T> struct v3 { union { struct { T x, y, z; }; struct { T r, g, b; }; }; v3() : x(), y(), z() {} template <class S, class = typename std::enable_if<is_num<S>::value && !std::is_same<S, T>::value>::type> v3(S s) : x((T)s), y((T)s), z((T)s) {}
+    v3(T s) : x(s), y(s), z(s) {} v3(T a, T b, T c) : x(a), y(b), z(c) {}
     v3(v2<T> a, T c) : x(a.x), y(a.y), z(c) {} v3(T a, v2<T> b) : x(a), y(b.x), z(b.y) {}
     template <class A, class B, class C, class = typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value && std::is_arithmetic<C>::value && !(std::is_same<A, T>::value && std::is_same<B, T>::value && std::is_same<C, T>::value)>::type>
     v3(A a, B b, C c) : x((T)a), y((T)b), z((T)c) {}
@@ -29,7 +33,8 @@ template <class T> struct v3 { union { struct { T x, y, z; }; struct { T r, g, b
     v2<T>& yz_() { return *reinterpret_cast<v2<T>*>(&y); }
     v3& xyz_() { return *this; } const v3& xyz_() const { return *this; } v3& rgb_() { return *this; } const v3& rgb_() const { return *this; }
     T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
-template <class T> struct v4 { union { struct { T x, y, z, w; }; struct { T r, g, b, a; }; }; v4() : x(), y(), z(), w() {} v4(T s) : x(s), y(s), z(s), w(s) {} v4(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}
+template <class T> struct v4 { union { struct { T x, y, z, w; }; struct { T r, g, b, a; }; }; v4() : x(), y(), z(), w() {} template <class S, class = typename std::enable_if<is_num<S>::value && !std::is_same<S, T>::value>::type> v4(S s) : x((T)s), y((T)s), z((T)s), w((T)s) {}
+    v4(T s) : x(s), y(s), z(s), w(s) {} v4(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}
     v4(v3<T> a, T d) : x(a.x), y(a.y), z(a.z), w(d) {} v4(v2<T> a, v2<T> b) : x(a.x), y(a.y), z(b.x), w(b.y) {} v4(v2<T> a, T c, T d) : x(a.x), y(a.y), z(c), w(d) {}
     template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v4(const v4<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z), w((T)o.w) {}
     v2<T>& zw_() { return *reinterpret_cast<v2<T>*>(&z); } v3<T>& yzw_() { return *reinterpret_cast<v3<T>*>(&y); }
@@ -43,23 +48,48 @@ typedef v2<float> float2; typedef v3<float> float3; typedef v4<float> float4;
 typedef v2<int> int2; typedef v3<int> int3; typedef v4<int> int4;
 typedef v2<uint> uint2; typedef v3<uint> uint3; typedef v4<uint> uint4;
 typedef v2<bool> bool2; typedef v3<bool> bool3; typedef v4<bool> bool4;
+#if defined(RTXPT_LP_TYPES_USE_16BIT_PRECISION) && RTXPT_LP_TYPES_USE_16BIT_PRECISION
+// float16_t for the reference's default build (lp types in 16 bits): a float that is rounded to binary16 after every operation. Used only to MEASURE how
+// far that build is from the fp32 build both sides of the parity fence restate (tools/lp16_deviation.py); half x float promotes to float as in HLSL.
+struct half_t { float v; half_t() : v(0.f) {} half_t(float f) : v(P::f16tof32(P::f32tof16(f))) {} half_t(double f) : half_t((float)f) {} half_t(int i) : half_t((float)i) {} half_t(uint i) : half_t((float)i) {}
+    half_t(bool b) : v(b ? 1.f : 0.f) {} operator float() const { return v; } };
+#define HL_HALFOP(op) static inline half_t operator op(half_t a, half_t b) { return half_t(a.v op b.v); } \
+    static inline half_t operator op(half_t a, int b) { return half_t(a.v op (float)b); } static inline half_t operator op(int a, half_t b) { return half_t((float)a op b.v); } \
+    static inline half_t& operator op##=(half_t& a, half_t b) { a = half_t(a.v op b.v); return a; } static inline half_t& operator op##=(half_t& a, float b) { a = half_t(a.v op b); return a; }
+HL_HALFOP(+) HL_HALFOP(-) HL_HALFOP(*) HL_HALFOP(/)
+#undef HL_HALFOP
+static inline half_t operator-(half_t a) { half_t r; r.v = -a.v; return r; }
+} // namespace hl
+namespace std { template <> struct common_type<hl::half_t, hl::half_t> { typedef hl::half_t type; }; template <> struct common_type<hl::half_t, float> { typedef float type; }; template <> struct common_type<float, hl::half_t> { typedef float type; }; }
+namespace hl {
+typedef half_t float16_t; typedef v2<half_t> float16_t2; typedef v3<half_t> float16_t3; typedef v4<half_t> float16_t4; typedef v2<uint16_t> uint16_t2; typedef v3<uint16_t> uint16_t3; typedef v4<uint16_t> uint16_t4;
+typedef half_t lpfloat; typedef float16_t2 lpfloat2; typedef float16_t3 lpfloat3; typedef float16_t4 lpfloat4; typedef uint16_t lpuint;
+struct float3x3; typedef float3x3 float16_t3x3;
+static inline half_t min(half_t a, half_t b) { return (a.v < b.v) ? a : b; } static inline half_t max(half_t a, half_t b) { return (a.v > b.v) ? a : b; }
+static inline half_t abs(half_t a) { half_t r; r.v = fabsf(a.v); return r; } static inline half_t saturate(half_t a) { return half_t(P::saturate(a.v)); }
+static inline float min(float a, half_t b) { return P::fminf_(a, b.v); } static inline float min(half_t a, float b) { return P::fminf_(a.v, b); }
+static inline float max(float a, half_t b) { return P::fmaxf_(a, b.v); } static inline float max(half_t a, float b) { return P::fmaxf_(a.v, b); }
+#else
 typedef float lpfloat; typedef float2 lpfloat2; typedef float3 lpfloat3; typedef float4 lpfloat4;      // RTXPT_LP_TYPES_USE_16BIT_PRECISION 0 (the build both sides of the parity fence restate)
 typedef uint lpuint;
+#endif
 
 // scalar operand of a mixed vector/scalar expression: HLSL converts it to the vector's component type
-template <class T, class S> using if_arith = typename std::enable_if<std::is_arithmetic<S>::value, T>::type;
+template <class T, class S> using if_arith = typename std::enable_if<is_num<S>::value, T>::type;
 
 template <class A, class B> using ctype = typename std::common_type<A, B>::type;
+// vector (component T) with a scalar S: integers and literals adopt T (HLSL literal rules), a float scalar promotes a half vector to float
+template <class T, class S> using stype = typename std::conditional<std::is_same<S, float>::value || std::is_same<S, double>::value, ctype<T, float>, T>::type;
 #define HL_BINOP(op) \
     template <class A, class B> v2<ctype<A, B>> operator op(v2<A> a, v2<B> b) { typedef ctype<A, B> C; return v2<C>((C)a.x op (C)b.x, (C)a.y op (C)b.y); } \
     template <class A, class B> v3<ctype<A, B>> operator op(v3<A> a, v3<B> b) { typedef ctype<A, B> C; return v3<C>((C)a.x op (C)b.x, (C)a.y op (C)b.y, (C)a.z op (C)b.z); } \
     template <class A, class B> v4<ctype<A, B>> operator op(v4<A> a, v4<B> b) { typedef ctype<A, B> C; return v4<C>((C)a.x op (C)b.x, (C)a.y op (C)b.y, (C)a.z op (C)b.z, (C)a.w op (C)b.w); } \
-    template <class T, class S> if_arith<v2<T>, S> operator op(v2<T> a, S b) { return a op v2<T>((T)b); } \
-    template <class T, class S> if_arith<v3<T>, S> operator op(v3<T> a, S b) { return a op v3<T>((T)b); } \
-    template <class T, class S> if_arith<v4<T>, S> operator op(v4<T> a, S b) { return a op v4<T>((T)b); } \
-    template <class T, class S> if_arith<v2<T>, S> operator op(S a, v2<T> b) { return v2<T>((T)a) op b; } \
-    template <class T, class S> if_arith<v3<T>, S> operator op(S a, v3<T> b) { return v3<T>((T)a) op b; } \
-    template <class T, class S> if_arith<v4<T>, S> operator op(S a, v4<T> b) { return v4<T>((T)a) op b; } \
+    template <class T, class S> if_arith<v2<stype<T, S>>, S> operator op(v2<T> a, S b) { typedef stype<T, S> C; return v2<C>(a) op v2<C>((C)b); } \
+    template <class T, class S> if_arith<v3<stype<T, S>>, S> operator op(v3<T> a, S b) { typedef stype<T, S> C; return v3<C>(a) op v3<C>((C)b); } \
+    template <class T, class S> if_arith<v4<stype<T, S>>, S> operator op(v4<T> a, S b) { typedef stype<T, S> C; return v4<C>(a) op v4<C>((C)b); } \
+    template <class T, class S> if_arith<v2<stype<T, S>>, S> operator op(S a, v2<T> b) { typedef stype<T, S> C; return v2<C>((C)a) op v2<C>(b); } \
+    template <class T, class S> if_arith<v3<stype<T, S>>, S> operator op(S a, v3<T> b) { typedef stype<T, S> C; return v3<C>((C)a) op v3<C>(b); } \
+    template <class T, class S> if_arith<v4<stype<T, S>>, S> operator op(S a, v4<T> b) { typedef stype<T, S> C; return v4<C>((C)a) op v4<C>(b); } \
     template <class T, class S> v2<T>& operator op##=(v2<T>& a, S b) { a = v2<T>(a op b); return a; } \
     template <class T, class S> v3<T>& operator op##=(v3<T>& a, S b) { a = v3<T>(a op b); return a; } \
     template <class T, class S> v4<T>& operator op##=(v4<T>& a, S b) { a = v4<T>(a op b); return a; }
@@ -147,6 +177,9 @@ static inline float smoothstep(float a, float b, float x) { float t = saturate((
 static inline float lerp(float a, float b, float t) { return P::lerpf(a, b, t); }
 static inline float3 lerp(float3 a, float3 b, float t) { return a + (b - a) * t; }
 static inline float3 lerp(float3 a, float3 b, float3 t) { return a + (b - a) * t; }
+#if defined(RTXPT_LP_TYPES_USE_16BIT_PRECISION) && RTXPT_LP_TYPES_USE_16BIT_PRECISION
+template <class A, class B> v3<ctype<A, B>> lerp(v3<A> a, v3<B> b, half_t t) { typedef ctype<A, B> C; return v3<C>(a) + (v3<C>(b) - v3<C>(a)) * t; }
+#endif
 static inline float dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
 static inline float dot(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 static inline float dot(float4 a, float4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }

@@ -161,6 +161,9 @@ def to_cpp(code):
     code = re.sub(r"\bconst\s+(?=[A-Za-z_][\w:]*\s+[A-Za-z_]\w*\s*[,)])", "", code)        # by-value parameters: HLSL calls non-const methods on them
     code = re.sub(r"\bconst\s+(?=[A-Z]\w*\s+[A-Za-z_]\w*\s*=)", "", code)                  # `const Struct local = ...` likewise
     code = re.sub(r"\bthis\.", "this->", code)
+    # `cond ? float : lpfloat`: HLSL promotes, C++ wants one type (no-ops in the fp32 build)
+    code = code.replace("alpha < kMinGGXAlpha ? 0.f : dataRoughness", "alpha < kMinGGXAlpha ? 0.f : (float)dataRoughness")
+    code = code.replace("(applyMIS)?(path.GetBsdfScatterPdf()):(0.0)", "(applyMIS)?((float)path.GetBsdfScatterPdf()):(0.0)")
     # swizzles on scalars (literals, named scalars, parenthesised / call expressions) become constructor calls ...
     code = re.sub(r"(?<![\w.])(\d+\.\d*f?|\.\d+f?|\d+)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)     # `0.5.xx`, `0.xxx`
     code = re.sub(r"\b(HLF_MAX|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
