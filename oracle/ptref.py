@@ -203,6 +203,29 @@ def lightbake_probe(kind, words, pyramid=None, color_mul=(1.0, 1.0, 1.0), distan
     return out
 
 
+_PIN_MAT = os.path.join(os.path.dirname(_PIN), "librefpin_mat.so")
+
+
+def reference_material_from_json(text, textures):
+    """The reference's PTMaterial::Read + FillData (Rtxpt/Materials/MaterialsBaker.cpp, compiled as it stands: oracle/refpin/mat_stubs.h) on one
+    `.material.json` document. textures: {file name: packed texture word} = what the texture cache could load. Returns (128 bytes PTMaterialData,
+    [EnableAlphaTesting, ExcludeFromNEE, SkipRender, UseDonutEmissiveIntensity], 5 paths, 5 (sRGB, NormalMap) pairs) or None when unavailable."""
+    if not os.path.exists(_PIN_MAT):
+        if os.path.isdir("/root/reference/Rtxpt/Shaders"):
+            build()
+        if not os.path.exists(_PIN_MAT):
+            return None
+    L = ctypes.CDLL(_PIN_MAT)
+    names = list(textures)
+    cn = (ctypes.c_char_p * max(1, len(names)))(*[n.encode() for n in names]) if names else (ctypes.c_char_p * 1)()
+    cw = (ctypes.c_uint32 * max(1, len(names)))(*[int(textures[n]) & 0xFFFFFFFF for n in names]) if names else (ctypes.c_uint32 * 1)()
+    out = (ctypes.c_uint8 * 128)(); flags = (ctypes.c_uint32 * 4)(); paths = ctypes.create_string_buffer(5 * 256); sn = (ctypes.c_uint32 * 10)()
+    r = L.refmat_from_json(text.encode(), cn, cw, ctypes.c_int(len(names)), out, flags, paths, sn)
+    if r != 0:
+        raise ValueError("reference parser rejected the document")
+    return bytes(out), [int(f) for f in flags], [paths.raw[256 * i:256 * i + 256].split(b"\0")[0].decode() for i in range(5)], [(int(sn[2 * i]), int(sn[2 * i + 1])) for i in range(5)]
+
+
 def _pin_table():
     """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
     import re

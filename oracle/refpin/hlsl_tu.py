@@ -88,7 +88,7 @@ def strip_comments(text):
 def extract_function(text, name, path):
     """every definition `<type> name(<params>) {...}` at file scope, overloads included"""
     found, seen = [], set()
-    for m in re.finditer(r"^[ \t]*((?:static\s+|inline\s+|const\s+)*[A-Za-z_]\w*)\s+" + re.escape(name) + r"\s*\(([^)]*)\)\s*\{", text, re.M):
+    for m in re.finditer(r"^[ \t]*((?:static\s+|inline\s+|const\s+)*[A-Za-z_]\w*)\s+" + re.escape(name) + r"\s*\(([^)]*)\)\s*(?:const\s*)?\{", text, re.M):
         depth, i = 0, m.end() - 1
         while True:
             c = text[i]
@@ -248,7 +248,25 @@ def main_pt(ref):
     w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
 
 
+def main_materials(ref):
+    """third translation unit: plain C++ of the reference (Rtxpt/Materials/MaterialsBaker.{h,cpp}, PathTracer/Materials/MaterialPT.h) over mat_stubs.h"""
+    w = sys.stdout.write
+    w('// generated by oracle/refpin/hlsl_tu.py --materials -- never written to disk\n#include "%s/mat_stubs.h"\n' % HERE)
+    w("using namespace hl;\n")
+    mp = strip_comments(open(os.path.join(ref, "Rtxpt/Shaders/PathTracer/Materials/MaterialPT.h"), encoding="latin-1").read())
+    w("\n".join(l for l in mp.split("\n") if not re.match(r"\s*#\s*include", l)) + "\n")
+    hraw = open(os.path.join(ref, "Rtxpt/Materials/MaterialsBaker.h"), encoding="latin-1").read(); h = strip_comments(hraw)
+    w(extract_struct(h, "PTTexture", "MaterialsBaker.h") + "\n")
+    w(extract_struct(h, "PTMaterial", "MaterialsBaker.h") + "\n")
+    c = strip_comments(open(os.path.join(ref, "Rtxpt/Materials/MaterialsBaker.cpp"), encoding="latin-1").read())
+    for name in ("GetBindlessTextureIndex", "PTMaterial::IsEmissive", "PTMaterial::FillData", "PTMaterial::Read"):
+        for body in extract_function(c, name, "MaterialsBaker.cpp"): w(body + "\n")
+    w(open(os.path.join(HERE, "mat_wrappers.inc")).read())
+
+
 def main():
+    if "--materials" in sys.argv:
+        sys.argv.remove("--materials"); return main_materials(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
     if "--integrator" in sys.argv:
         sys.argv.remove("--integrator"); return main_pt(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"

@@ -1,6 +1,7 @@
 """`.material.json` import (the part the reference tree defines completely): pt_material_from_json against an independent
 Python restatement of PTMaterial defaults (MaterialsBaker.h:126-193), Read (MaterialsBaker.cpp:150-259) and FillData (:516-591). CPU only."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -89,3 +90,48 @@ def test_material_json_rejects_garbage():
         pt.material_from_json("{ not json", [0xFFFFFFFF] * 5)
     with pytest.raises(pt.PtError):
         pt.material_from_json("[1, 2, 3]", [0xFFFFFFFF] * 5)
+
+
+def _random_document(rng):
+    """A `.material.json` document with a random subset of fields, including out-of-range and wrongly typed ones."""
+    doc = {}
+    num = lambda lo, hi: float(np.float32(rng.uniform(lo, hi)))
+    fields = {"BaseOrDiffuseColor": lambda: [num(0, 1) for _ in range(3)], "SpecularColor": lambda: [num(0, 1) for _ in range(3)], "EmissiveColor": lambda: [num(0, 4) for _ in range(3)],
+              "EmissiveIntensity": lambda: num(0, 500), "Metalness": lambda: num(0, 1), "Roughness": lambda: num(0, 1), "Opacity": lambda: num(0, 1), "TransmissionFactor": lambda: num(0, 1),
+              "DiffuseTransmissionFactor": lambda: num(0, 1), "NormalTextureScale": lambda: num(0.2, 2), "IoR": lambda: num(1, 2.5), "AlphaCutoff": lambda: num(0, 1),
+              "VolumeAttenuationDistance": lambda: num(0.01, 10), "VolumeAttenuationColor": lambda: [num(0, 1) for _ in range(3)], "ShadowNoLFadeout": lambda: num(-0.1, 0.6),
+              "PSDDominantDeltaLobe": lambda: int(rng.integers(-3, 12)), "PSDBlockMotionVectorsAtSurfaceType": lambda: int(rng.integers(0, 4)), "NestedPriority": lambda: int(rng.integers(0, 40))}
+    for b in ("UseSpecularGlossModel", "EnableBaseTexture", "EnableOcclusionRoughnessMetallicTexture", "EnableNormalTexture", "EnableEmissiveTexture", "EnableTransmissionTexture", "EnableAlphaTesting",
+              "EnableTransmission", "MetalnessInRedChannel", "ThinSurface", "ExcludeFromNEE", "PSDExclude", "EnableAsAnalyticLightProxy", "IgnoreMeshTangentSpace", "UseDonutEmissiveIntensity", "SkipRender"):
+        fields[b] = lambda: bool(rng.integers(0, 2))
+    for k, f in fields.items():
+        if rng.random() < 0.55: doc[k] = f()
+    if rng.random() < 0.3: doc["Roughness"] = "rough"                # wrong kind: the field keeps its default
+    if rng.random() < 0.2: doc["BaseOrDiffuseColor"] = [0.5, 0.5]      # wrong length
+    words, textures = [0xFFFFFFFF] * 5, {}
+    for i, t in enumerate(TEX):
+        if rng.random() < 0.5:
+            name = "tex_%d_%d.png" % (i, int(rng.integers(0, 100)))
+            doc[t] = {"path": "textures/" + name, "sRGB": bool(rng.integers(0, 2)), "NormalMap": bool(rng.integers(0, 2))}
+            if rng.random() < 0.8:        # the loader found it
+                words[i] = (int(rng.integers(4, 25)) << 24) | (int(rng.integers(1, 13)) << 16) | int(rng.integers(0, 4000)); textures[name] = words[i]
+    return doc, words, textures
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_material_json_matches_reference_text(seed):
+    """pt_material_from_json against the reference's own PTMaterial::Read + FillData + GetBindlessTextureIndex (Rtxpt/Materials/MaterialsBaker.{h,cpp} compiled as
+    they stand over Donut / jsoncpp stand-ins, oracle/refpin/mat_stubs.h): all 128 bytes of PTMaterialData and the fields outside it."""
+    from oracle import ptref
+    rng = np.random.default_rng(0x3A7 + seed)
+    doc, words, textures = (CASES[sorted(CASES)[seed]][0], CASES[sorted(CASES)[seed]][1], None) if seed < len(CASES) else _random_document(rng)
+    if textures is None:
+        textures = {os.path.basename(doc[t]["path"]): words[i] for i, t in enumerate(TEX) if t in doc and words[i] != 0xFFFFFFFF}
+    ref = ptref.reference_material_from_json(json.dumps(doc), textures)
+    if ref is None:
+        pytest.skip("librefpin_mat.so not available (no /root/reference on this machine)")
+    got, info = pt.material_from_json(json.dumps(doc), words)
+    assert got.tobytes() == ref[0], [(n, got[n], np.frombuffer(ref[0], got.dtype)[0][n]) for n in got.dtype.names if np.asarray(got[n]).tobytes() != np.asarray(np.frombuffer(ref[0], got.dtype)[0][n]).tobytes()]
+    assert [int(info["enableAlphaTesting"]), int(info["excludeFromNEE"]), int(info["skipRender"]), int(info["useDonutEmissiveIntensity"])] == ref[1]
+    assert info["texturePath"] == ref[2]
+    assert [(int(bool(a)), int(bool(b))) for a, b in zip(info["textureSRGB"], info["textureNormalMap"])] == [(int(bool(a)), int(bool(b))) for a, b in ref[3]]
