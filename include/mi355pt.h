@@ -195,6 +195,18 @@ typedef struct PtMaterialJsonInfo {
 } PtMaterialJsonInfo;
 int32_t pt_material_from_json(const char* jsonText, const uint32_t textureWords[5], PTMaterialData* out, PtMaterialJsonInfo* info);
 
+/* Analytic lights as the host of the reference describes them: a Donut PointLight / SpotLight with RTXPT's LightExtension. pt_convert_light is
+   LightsBaker::ConvertLight (Rtxpt/Lighting/LightsBaker.cpp:456-556): radius > 0 gives a sphere light (radiance = color * intensity / (pi r^2)); a spot
+   adds cone shaping (cos outer angle, softness = 1 - inner / |outer|; outerAngle < 0 selects the minimum-falloff variant). radius == 0 gives a
+   point-type record, which the path tracer's light set does not sample (PolymorphicLightPTConfig.h:17-22) and pt_set_lights rejects. Host only. */
+typedef struct PtAnalyticLightDesc {
+    uint32_t type;                 /* 0 point, 1 spot */
+    float    position[3], direction[3];
+    float    color[3], intensity, radius;
+    float    innerAngle, outerAngle;          /* degrees, spot only */
+} PtAnalyticLightDesc;
+int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo* base, PolymorphicLightInfoEx* ex);
+
 /* Display path. pt_default_tonemap: ToneMappingParameters defaults + UpdateColorTransform with manual exposure
    (Rtxpt/ToneMapper/ToneMappingPasses.h:36-53, ToneMappingPasses.cpp:428-441): exposureCompensation in stops, filmSpeed/shutter/fNumber as in the UI.
    pt_tonemap: ToneMappingPass::Render into the SRGBA8_UNORM LdrColor target (ToneMapping.ps.hlsli:136-174, RenderTargets.cpp:241) of THIS

@@ -226,6 +226,20 @@ def reference_material_from_json(text, textures):
     return bytes(out), [int(f) for f in flags], [paths.raw[256 * i:256 * i + 256].split(b"\0")[0].decode() for i in range(5)], [(int(sn[2 * i]), int(sn[2 * i + 1])) for i in range(5)]
 
 
+def reference_convert_light(desc_words):
+    """LightsBaker::ConvertLight (Rtxpt/Lighting/LightsBaker.cpp:456-556 and its helpers, compiled as they stand) on one light. desc_words: the 15 words of the
+    product's PtAnalyticLightDesc. Returns (8 words, 4 words), "assert" for what the reference asserts on (spot with radius 0), or None when unavailable."""
+    if not os.path.exists(_PIN_MAT):
+        if os.path.isdir("/root/reference/Rtxpt/Shaders"):
+            build()
+        if not os.path.exists(_PIN_MAT):
+            return None
+    L = ctypes.CDLL(_PIN_MAT)
+    d = np.ascontiguousarray(desc_words, np.uint32); base = np.zeros(8, np.uint32); ex = np.zeros(4, np.uint32)
+    r = L.reflight_convert(d.ctypes.data_as(ctypes.c_void_p), base.ctypes.data_as(ctypes.c_void_p), ex.ctypes.data_as(ctypes.c_void_p))
+    return "assert" if r == 2 else (base, ex)
+
+
 def _pin_table():
     """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
     import re

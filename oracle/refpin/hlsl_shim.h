@@ -31,6 +31,7 @@ template <class T> struct v3 { union { struct { T x, y, z; }; struct { T r, g, b
     template <class U, class = typename std::enable_if<!std::is_same<U, T>::value>::type> v3(const v3<U>& o) : x((T)o.x), y((T)o.y), z((T)o.z) {}       // HLSL converts between component types implicitly
     v2<T>& xy_() { return *reinterpret_cast<v2<T>*>(this); } const v2<T> xy_() const { return v2<T>(x, y); } const v2<T> yx_() const { return v2<T>(y, x); } const v2<T> xz_() const { return v2<T>(x, z); } const v2<T> yz_() const { return v2<T>(y, z); }
     v2<T>& yz_() { return *reinterpret_cast<v2<T>*>(&y); }
+    const v2<T> xy() const { return v2<T>(x, y); }          // Donut's dm::float3 spelling (host code)
     v3& xyz_() { return *this; } const v3& xyz_() const { return *this; } v3& rgb_() { return *this; } const v3& rgb_() const { return *this; }
     T& operator[](uint i) { return (&x)[i]; } T operator[](uint i) const { return (&x)[i]; } };
 template <class T> struct v4 { union { struct { T x, y, z, w; }; struct { T r, g, b, a; }; }; v4() : x(), y(), z(), w() {} template <class S, class = typename std::enable_if<is_num<S>::value && !std::is_same<S, T>::value>::type> v4(S s) : x((T)s), y((T)s), z((T)s), w((T)s) {}

@@ -261,6 +261,13 @@ def main_materials(ref):
     c = strip_comments(open(os.path.join(ref, "Rtxpt/Materials/MaterialsBaker.cpp"), encoding="latin-1").read())
     for name in ("GetBindlessTextureIndex", "PTMaterial::IsEmissive", "PTMaterial::FillData", "PTMaterial::Read"):
         for body in extract_function(c, name, "MaterialsBaker.cpp"): w(body + "\n")
+    # LightsBaker.cpp: the host-side light conversion (ConvertLight and the helpers it calls), over Donut light stand-ins
+    pl = strip_comments(open(os.path.join(ref, SHADERS, "Lighting/PolymorphicLight.h"), encoding="latin-1").read())
+    w("\n".join(l for l in pl.split("\n") if not re.match(r"\s*#\s*include", l)) + "\n")
+    w(open(os.path.join(HERE, "light_stubs.inc")).read())
+    lb = strip_comments(open(os.path.join(ref, "Rtxpt/Lighting/LightsBaker.cpp"), encoding="latin-1").read())
+    for name in ("floatToUInt", "FLOAT3_to_R8G8B8_UNORM", "packLightColor", "OctWrap", "Encode_Oct", "NDirToOctUnorm32", "fp32ToFp16", "ConvertLight"):
+        for body in extract_function(lb, name, "LightsBaker.cpp"): w(body + "\n")
     w(open(os.path.join(HERE, "mat_wrappers.inc")).read())
 
 

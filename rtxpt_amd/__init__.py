@@ -28,7 +28,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json",
+    "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
 ]
 
 
@@ -137,6 +137,25 @@ def material_from_json(text, texture_words=(0xFFFFFFFF,) * 5):
     return out, {"texturePath": [bytes(info.texturePath[i]).split(b"\0")[0].decode() for i in range(5)], "textureSRGB": list(info.textureSRGB),
                  "textureNormalMap": list(info.textureNormalMap), "enableAlphaTesting": bool(info.enableAlphaTesting), "excludeFromNEE": bool(info.excludeFromNEE),
                  "skipRender": bool(info.skipRender), "useDonutEmissiveIntensity": bool(info.useDonutEmissiveIntensity)}
+
+
+class PtAnalyticLightDesc(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_uint32), ("position", ctypes.c_float * 3), ("direction", ctypes.c_float * 3), ("color", ctypes.c_float * 3), ("intensity", ctypes.c_float),
+                ("radius", ctypes.c_float), ("innerAngle", ctypes.c_float), ("outerAngle", ctypes.c_float)]
+
+
+def convert_light(kind, position, color, intensity, radius, direction=(0.0, -1.0, 0.0), inner_angle=0.0, outer_angle=0.0):
+    """pt_convert_light (LightsBaker::ConvertLight): kind "point" / "spot" -> (8 words PolymorphicLightInfo, 4 words PolymorphicLightInfoEx) as uint32 arrays. No device needed."""
+    L = load_library()
+    d = PtAnalyticLightDesc(); d.type = {"point": 0, "spot": 1}[kind]
+    d.position[:] = [float(x) for x in position]; d.direction[:] = [float(x) for x in direction]; d.color[:] = [float(x) for x in color]
+    d.intensity, d.radius, d.innerAngle, d.outerAngle = float(intensity), float(radius), float(inner_angle), float(outer_angle)
+    base = np.zeros(8, np.uint32); ex = np.zeros(4, np.uint32)
+    L.pt_convert_light.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    r = L.pt_convert_light(ctypes.byref(d), _p(base), _p(ex))
+    if r != 0:
+        raise PtError(r, "pt_convert_light")
+    return base, ex
 
 
 def write_image(path, rgba8):
