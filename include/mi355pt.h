@@ -209,11 +209,17 @@ int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo*
 
 /* Display path. pt_default_tonemap: ToneMappingParameters defaults + UpdateColorTransform with manual exposure
    (Rtxpt/ToneMapper/ToneMappingPasses.h:36-53, ToneMappingPasses.cpp:428-441): exposureCompensation in stops, filmSpeed/shutter/fNumber as in the UI.
+   pt_tonemap_color_transform: the same UpdateColorTransform preceded by UpdateWhiteBalanceTransform (ToneMappingPasses.cpp:392-401) — with
+   whiteBalance != 0 the von Kries / CAT02 matrix of calculateWhiteBalanceTransformRGB_Rec709(whitePoint in kelvin, 1667..25000;
+   Rtxpt/ToneMapper/ColorUtils.h:128-197) is folded into params->colorTransform; with params->autoExposure set the manual exposure factor is 1
+   as in the reference. Only colorTransform is written. Host only.
    pt_tonemap: ToneMappingPass::Render into the SRGBA8_UNORM LdrColor target (ToneMapping.ps.hlsli:136-174, RenderTargets.cpp:241) of THIS
    context's accumulation buffer; rgba8 receives width*height*4 bytes (R,G,B,A; rows top to bottom).
    pt_write_png / pt_write_bmp: the screenshot writers behind --captureSimple/--capturePath (Rtxpt/SampleCommon/CaptureScriptManager.cpp:29-60,
    Rtxpt/Sample.cpp:2295); host only, no context needed. */
 int32_t pt_default_tonemap(PtToneMapParams* out, float exposureCompensation, float filmSpeed, float shutter, float fNumber);
+int32_t pt_tonemap_color_transform(PtToneMapParams* params, uint32_t whiteBalance, float whitePoint, float exposureCompensation, float filmSpeed,
+                                   float shutter, float fNumber);
 int32_t pt_tonemap(pt_context* ctx, const PtToneMapParams* params, uint8_t* rgba8, size_t bytes);
 int32_t pt_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 int32_t pt_write_bmp(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);

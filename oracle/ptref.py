@@ -240,6 +240,23 @@ def reference_convert_light(desc_words):
     return "assert" if r == 2 else (base, ex)
 
 
+def reference_color_transform(white_balance, white_point, auto_exposure, exposure_compensation, film_speed, shutter, f_number):
+    """ToneMappingPass::UpdateWhiteBalanceTransform + UpdateColorTransform (Rtxpt/ToneMapper/ToneMappingPasses.cpp:392-441) over ColorUtils.h, compiled as they
+    stand on Donut math stand-ins (oracle/refpin/color_stubs.inc); returns the nine floats in constant-buffer order (:344-347), or None when unavailable."""
+    if not os.path.exists(_PIN_MAT):
+        if os.path.isdir("/root/reference/Rtxpt/Shaders"):
+            build()
+        if not os.path.exists(_PIN_MAT):
+            return None
+    L = ctypes.CDLL(_PIN_MAT)
+    if not hasattr(L, "refcolor_transform"):
+        return None
+    out = np.zeros(9, np.float32)
+    L.refcolor_transform.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int] + [ctypes.c_float] * 4 + [ctypes.c_void_p]
+    L.refcolor_transform(int(white_balance), white_point, int(auto_exposure), exposure_compensation, film_speed, shutter, f_number, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
 def _pin_table():
     """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
     import re

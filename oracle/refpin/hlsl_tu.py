@@ -269,6 +269,14 @@ def main_materials(ref):
     for name in ("floatToUInt", "FLOAT3_to_R8G8B8_UNORM", "packLightColor", "OctWrap", "Encode_Oct", "NDirToOctUnorm32", "fp32ToFp16", "ConvertLight"):
         for body in extract_function(lb, name, "LightsBaker.cpp"): w(body + "\n")
     w(open(os.path.join(HERE, "mat_wrappers.inc")).read())
+    # ToneMapper host side: ColorUtils.h whole + the two ToneMappingPass members that build the colour transform, over Donut math stand-ins
+    w(open(os.path.join(HERE, "color_stubs.inc")).read())
+    cu = strip_comments(open(os.path.join(ref, "Rtxpt/ToneMapper/ColorUtils.h"), encoding="latin-1").read())
+    w("\n".join(l for l in cu.split("\n") if not re.match(r"\s*#\s*(include|pragma)", l)) + "\n")
+    tp = strip_comments(open(os.path.join(ref, "Rtxpt/ToneMapper/ToneMappingPasses.cpp"), encoding="latin-1").read())
+    for name in ("ToneMappingPass::UpdateWhiteBalanceTransform", "ToneMappingPass::UpdateColorTransform"):
+        for body in extract_function(tp, name, "ToneMappingPasses.cpp"): w(body + "\n")
+    w(open(os.path.join(HERE, "color_wrappers.inc")).read())
 
 
 def main():

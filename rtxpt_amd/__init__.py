@@ -29,6 +29,7 @@ EXPORTS = [
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
     "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
+    "pt_tonemap_color_transform",
 ]
 
 
@@ -115,6 +116,17 @@ def default_tonemap(exposure_compensation=0.0, film_speed=100.0, shutter=1.0, f_
     for k, v in kw.items():
         t[k] = TONEMAP_OPERATORS[v] if (k == "toneMapOperator" and isinstance(v, str)) else v
     return t
+
+
+def tonemap_color_transform(params, white_balance=False, white_point=6500.0, exposure_compensation=0.0, film_speed=100.0, shutter=1.0, f_number=1.0):
+    """pt_tonemap_color_transform: UpdateWhiteBalanceTransform + UpdateColorTransform (ToneMappingPasses.cpp:392-441, ColorUtils.h:128-197) written into
+    params["colorTransform"] (a TONEMAP_DTYPE record, modified in place and returned). No device needed."""
+    L = load_library()
+    L.pt_tonemap_color_transform.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_float] * 5
+    r = L.pt_tonemap_color_transform(_p(params), 1 if white_balance else 0, white_point, exposure_compensation, film_speed, shutter, f_number)
+    if r != 0:
+        raise PtError(r, "pt_tonemap_color_transform")
+    return params
 
 
 class PtMaterialJsonInfo(ctypes.Structure):
