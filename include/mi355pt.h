@@ -207,6 +207,48 @@ typedef struct PtAnalyticLightDesc {
 } PtAnalyticLightDesc;
 int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo* base, PolymorphicLightInfoEx* ex);
 
+/* RTXPT `.scene.json` asset folders. pt_scene_json_import reads what ExtendedScene::LoadWithThreadPool + Sample::SceneLoaded +
+   MaterialsBaker::CreateFromScene consume (Rtxpt/SampleCommon/ExtendedScene.cpp:104-143, 203-375; Rtxpt/Sample.cpp:457-479, 520-640;
+   Rtxpt/Materials/MaterialsBaker.cpp:707-748, 857-864) into a HOST-side import object — no device needed — that pt_scene_import_apply hands to a
+   context through pt_set_materials / pt_set_geometry / pt_set_instances / pt_set_lights:
+     "models"  glTF / GLB files, relative to the scene file; "graph" nodes with name / translation / rotation (xyzw) / scaling / model / type /
+     children; leaves EnvironmentLight {radianceScale, textureIndex, rotation, path}, PointLight / SpotLight (Donut keys color, intensity, radius,
+     range, innerAngle, outerAngle + RTXPT's proxyMeshNodes) -> pt_convert_light records in scene-graph order with the invisible ones dropped
+     (|color * intensity| <= 1e-7, Sample.cpp:567-573), PerspectiveCamera(Ex) {verticalFov, zNear + the exposure keys}, SampleSettings (seven keys);
+     `<media>/Materials/[<scene>/][<model>.]<material>.material.json` overrides in the reference's candidate order, through pt_material_from_json
+     (a document replaces the glTF material as a whole; SkipRender removes the geometries, EnableAlphaTesting / ExcludeFromNEE set their flags).
+   The file format of the graph itself and the light / camera keys belong to Donut (donut/engine/Scene.cpp, SceneGraph.cpp), which the reference
+   tree does not vendor: they are restated from Donut's published sources. Not imported: DirectionalLight (LightsBaker skips it too), animations,
+   glTF-embedded cameras / lights, analytic-light proxies (counted in info), textures other than 8-bit PNG (counted in texturesNotLoaded, the
+   material then renders untextured as when the reference fails to load one). The environment map is reported, not loaded (.exr / .dds). */
+typedef struct pt_scene_import pt_scene_import;
+typedef struct PtSceneCameraDesc {          /* Sample::UpdateCameraFromScene inputs: LookAt(position, position + direction, up) */
+    float    position[3], direction[3], up[3];
+    float    verticalFov, zNear;            /* radians; Donut defaults 1.0 / 1.0 */
+    uint32_t exposureMask;                  /* bit 0 enableAutoExposure, 1 exposureCompensation, 2 exposureValue, 3 exposureValueMin, 4 exposureValueMax present */
+    uint32_t enableAutoExposure; float exposureCompensation, exposureValue, exposureValueMin, exposureValueMax;
+    char     name[64];
+} PtSceneCameraDesc;
+typedef struct PtSceneJsonInfo {
+    uint32_t numModels, numGeometries, numMeshes, numInstances, numMaterials, numTextures, numLights, numCameras;
+    uint32_t materialOverrides, texturesNotLoaded, lightsDropped, lightProxies, skippedGeometries, directionalLights;
+    uint32_t hasEnvironment; float envRadianceScale[3]; float envRotation; int32_t envTextureIndex; char envPath[260];
+    uint32_t settingsMask;                  /* bit i: key i of SampleSettings::Load present (realtimeMode, enableAnimations, startingCamera, realtimeFireflyFilter, maxBounces, maxDiffuseBounces, textureMIPBias) */
+    uint32_t realtimeMode, enableAnimations; int32_t startingCamera; float realtimeFireflyFilter; int32_t maxBounces, maxDiffuseBounces; float textureMIPBias;
+    int32_t  selectedCamera;                /* startingCamera when present and valid, else the last camera (Sample.cpp:590-603, 618-619); -1 without cameras */
+} PtSceneJsonInfo;
+/* mediaPath: the folder that holds "Materials/" (NULL: the scene file's folder). Errors: PT_ERROR_IO (unreadable / malformed file or model). */
+int32_t pt_scene_json_import(const char* scenePath, const char* mediaPath, pt_scene_import** out, PtSceneJsonInfo* info);
+void    pt_scene_import_free(pt_scene_import* scene);
+/* copies of the imported arrays, up to `capacity` records; return the number available (negative: error) */
+int32_t pt_scene_import_cameras(const pt_scene_import* scene, PtSceneCameraDesc* out, uint32_t capacity);
+int32_t pt_scene_import_lights(const pt_scene_import* scene, PolymorphicLightInfo* base, PolymorphicLightInfoEx* ex, uint32_t capacity);
+int32_t pt_scene_import_instances(const pt_scene_import* scene, PtInstanceDesc* out, uint32_t capacity);
+int32_t pt_scene_import_geometries(const pt_scene_import* scene, PtGeometryDesc* out, uint32_t capacity);
+int32_t pt_scene_import_materials(const pt_scene_import* scene, PTMaterialData* out, uint32_t capacity);
+/* pt_set_materials + pt_set_geometry + pt_set_instances + pt_set_lights on ctx (camera, environment and settings stay with the caller) */
+int32_t pt_scene_import_apply(pt_context* ctx, const pt_scene_import* scene);
+
 /* Display path. pt_default_tonemap: ToneMappingParameters defaults + UpdateColorTransform with manual exposure
    (Rtxpt/ToneMapper/ToneMappingPasses.h:36-53, ToneMappingPasses.cpp:428-441): exposureCompensation in stops, filmSpeed/shutter/fNumber as in the UI.
    pt_tonemap_color_transform: the same UpdateColorTransform preceded by UpdateWhiteBalanceTransform (ToneMappingPasses.cpp:392-401) — with

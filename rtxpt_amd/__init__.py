@@ -29,7 +29,8 @@ EXPORTS = [
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
     "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
-    "pt_tonemap_color_transform",
+    "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
+    "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply",
 ]
 
 
@@ -170,6 +171,60 @@ def convert_light(kind, position, color, intensity, radius, direction=(0.0, -1.0
     return base, ex
 
 
+SCENE_CAMERA_DTYPE = np.dtype([("position", "<f4", 3), ("direction", "<f4", 3), ("up", "<f4", 3), ("verticalFov", "<f4"), ("zNear", "<f4"), ("exposureMask", "<u4"),
+                               ("enableAutoExposure", "<u4"), ("exposureCompensation", "<f4"), ("exposureValue", "<f4"), ("exposureValueMin", "<f4"),
+                               ("exposureValueMax", "<f4"), ("name", "S64")])
+SCENE_JSON_INFO_DTYPE = np.dtype([("numModels", "<u4"), ("numGeometries", "<u4"), ("numMeshes", "<u4"), ("numInstances", "<u4"), ("numMaterials", "<u4"), ("numTextures", "<u4"),
+                                  ("numLights", "<u4"), ("numCameras", "<u4"), ("materialOverrides", "<u4"), ("texturesNotLoaded", "<u4"), ("lightsDropped", "<u4"),
+                                  ("lightProxies", "<u4"), ("skippedGeometries", "<u4"), ("directionalLights", "<u4"), ("hasEnvironment", "<u4"),
+                                  ("envRadianceScale", "<f4", 3), ("envRotation", "<f4"), ("envTextureIndex", "<i4"), ("envPath", "S260"), ("settingsMask", "<u4"),
+                                  ("realtimeMode", "<u4"), ("enableAnimations", "<u4"), ("startingCamera", "<i4"), ("realtimeFireflyFilter", "<f4"), ("maxBounces", "<i4"),
+                                  ("maxDiffuseBounces", "<i4"), ("textureMIPBias", "<f4"), ("selectedCamera", "<i4")])
+assert SCENE_CAMERA_DTYPE.itemsize == 132 and SCENE_JSON_INFO_DTYPE.itemsize == 376
+
+
+class SceneImport:
+    """pt_scene_json_import: an RTXPT `.scene.json` asset folder read on the host (ExtendedScene + Sample::SceneLoaded + MaterialsBaker::Load). No device
+    needed; PathTracer.apply_scene_import hands it to a context."""
+
+    def __init__(self, scene_path, media_path=None):
+        from . import scenes
+        self.L = load_library()
+        self.h = ctypes.c_void_p()
+        self.info = np.zeros((), dtype=SCENE_JSON_INFO_DTYPE)
+        self.L.pt_scene_json_import.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]
+        r = self.L.pt_scene_json_import(str(scene_path).encode(), None if media_path is None else str(media_path).encode(), ctypes.byref(self.h), _p(self.info))
+        if r != 0:
+            raise PtError(r, "pt_scene_json_import")
+        self.L.pt_scene_import_free.argtypes = [ctypes.c_void_p]; self.L.pt_scene_import_free.restype = None
+
+        def fetch(fn, dtype, n):
+            a = np.zeros(max(int(n), 1), dtype=dtype)
+            f = getattr(self.L, fn); f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+            got = f(self.h, _p(a), int(n))
+            assert got == n, (fn, got, n)
+            return a[:n]
+        I = self.info
+        self.cameras = fetch("pt_scene_import_cameras", SCENE_CAMERA_DTYPE, I["numCameras"])
+        self.instances = fetch("pt_scene_import_instances", scenes.INSTANCE_DTYPE, I["numInstances"])
+        self.geometries = fetch("pt_scene_import_geometries", scenes.GEOMETRY_DTYPE, I["numGeometries"])
+        self.materials = fetch("pt_scene_import_materials", scenes.MATERIAL_DTYPE, I["numMaterials"])
+        n = int(I["numLights"]); self.lights = np.zeros((max(n, 1), 8), np.uint32); self.lights_ex = np.zeros((max(n, 1), 4), np.uint32)
+        self.L.pt_scene_import_lights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        assert self.L.pt_scene_import_lights(self.h, _p(self.lights), _p(self.lights_ex), n) == n
+        self.lights, self.lights_ex = self.lights[:n], self.lights_ex[:n]
+
+    def close(self):
+        if self.h:
+            self.L.pt_scene_import_free(self.h); self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def write_image(path, rgba8):
     """pt_write_png / pt_write_bmp by extension (the reference's screenshot formats). rgba8: (H, W, 4) uint8."""
     L = load_library()
@@ -227,6 +282,11 @@ class PathTracer:
     # ---- scene
     def load_scene_gltf(self, path):
         self._chk(self.L.pt_load_scene_gltf(self.h, path.encode()), "pt_load_scene_gltf")
+
+    def apply_scene_import(self, imp):
+        """pt_scene_import_apply: materials, geometry, instances and analytic lights of a SceneImport (camera / environment / settings stay with the caller)."""
+        self.L.pt_scene_import_apply.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self.L.pt_scene_import_apply(self.h, imp.h), "pt_scene_import_apply")
 
     def set_scene(self, sc):
         """sc: dict from rtxpt_amd.scenes (same arrays the oracle receives)."""

@@ -140,7 +140,7 @@ struct Loader {
     std::vector<uint32_t> indices; std::vector<float> positions, uvs; std::vector<uint32_t> normals, tangents;
     std::vector<PtGeometryDesc> geoms; std::vector<PtMeshDesc> meshes; std::vector<PtInstanceDesc> instances; std::vector<PTMaterialData> materials;
     std::vector<std::vector<uint8_t>> texPixels; std::vector<PtTextureDesc> texDescs; std::map<std::pair<int, int>, uint32_t> texCache;   // (image, srgb) -> texture word
-    std::vector<int> meshMap;
+    std::vector<int> meshMap; std::vector<M4> instanceWorld;      // instanceWorld: the double-precision local-to-world of each instance (scene-graph import composes in double)
 
     bool accessor(int idx, std::vector<double>& out, int& comps) {
         const JValue* accs = root.get("accessors"); if (!accs || idx < 0 || (size_t)idx >= accs->size()) { err = "bad accessor index"; return false; }
@@ -283,7 +283,7 @@ struct Loader {
         if (mesh >= 0 && (size_t)mesh < meshMap.size() && meshMap[mesh] >= 0) {
             PtInstanceDesc inst; memset(&inst, 0, sizeof(inst)); inst.meshIndex = (uint32_t)meshMap[mesh];
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) inst.transform[r * 4 + c] = (float)world.m[c * 4 + r];   // column-major 4x4 -> row-major 3x4
-            instances.push_back(inst);
+            instances.push_back(inst); instanceWorld.push_back(world);
         }
         if (const JValue* ch = n.get("children")) for (auto& c : ch->arr) visit((int)c.num, world, depth + 1);
     }
@@ -374,11 +374,11 @@ extern "C" int32_t pt_material_from_json(const char* jsonText, const uint32_t te
 namespace {
 } // namespace
 
-extern "C" int32_t pt_load_scene_gltf(pt_context* ctx, const char* path) {
-    if (!ctx || !path) return PT_ERROR_INVALID_ARGUMENT;
+namespace {
+// one glTF / GLB file -> Loader arrays (materials, textures, geometry, meshes, instances of the default scene)
+int32_t load_gltf_file(const char* path, Loader& L) {
     std::vector<uint8_t> file;
     if (!read_file(path, file)) return PT_ERROR_IO;
-    Loader L; L.ctx = ctx;
     std::string sp(path); size_t slash = sp.find_last_of('/'); L.baseDir = slash == std::string::npos ? "" : sp.substr(0, slash + 1);
     const char* jb = (const char*)file.data(); size_t jn = file.size(); std::vector<uint8_t> glbBin;
     if (file.size() >= 20 && !memcmp(file.data(), "glTF", 4)) {                       // GLB container
@@ -398,6 +398,15 @@ extern "C" int32_t pt_load_scene_gltf(pt_context* ctx, const char* path) {
     int sceneIdx = L.root.intOr("scene", 0); const JValue* scenes = L.root.get("scenes");
     if (scenes && (size_t)sceneIdx < scenes->size()) { if (const JValue* ns = scenes->arr[sceneIdx].get("nodes")) for (auto& n : ns->arr) L.visit((int)n.num, m4_identity(), 0); }
     else if (const JValue* nodes = L.root.get("nodes")) for (size_t i = 0; i < nodes->size(); i++) L.visit((int)i, m4_identity(), 0);
+    return PT_OK;
+}
+} // namespace
+
+extern "C" int32_t pt_load_scene_gltf(pt_context* ctx, const char* path) {
+    if (!ctx || !path) return PT_ERROR_INVALID_ARGUMENT;
+    Loader L; L.ctx = ctx;
+    int32_t lr = load_gltf_file(path, L);
+    if (lr != PT_OK) return lr;
     if (L.instances.empty() || L.geoms.empty()) return PT_ERROR_IO;
     for (size_t i = 0; i < L.texDescs.size(); i++) L.texDescs[i].pixels = L.texPixels[i].data();
     int32_t r = pt_set_materials(ctx, L.materials.data(), (uint32_t)L.materials.size(), L.texDescs.data(), (uint32_t)L.texDescs.size());
@@ -407,4 +416,256 @@ extern "C" int32_t pt_load_scene_gltf(pt_context* ctx, const char* path) {
     r = pt_set_geometry(ctx, &gb, L.geoms.data(), (uint32_t)L.geoms.size(), L.meshes.data(), (uint32_t)L.meshes.size());
     if (r != PT_OK) return r;
     return pt_set_instances(ctx, L.instances.data(), (uint32_t)L.instances.size());
+}
+
+// ================================================================ RTXPT `.scene.json` asset folders
+// ExtendedScene leaves (Rtxpt/SampleCommon/ExtendedScene.cpp:104-143, 313-375), what Sample::SceneLoaded does with them (Rtxpt/Sample.cpp:457-479,
+// 520-640) and MaterialsBaker::Load's override lookup (Rtxpt/Materials/MaterialsBaker.cpp:707-748, 857-864). The graph format and the Donut light /
+// camera keys are restated from Donut's published Scene.cpp / SceneGraph.cpp (not vendored in the reference tree); Sample::SaveCurrentCamera
+// (Rtxpt/Sample.cpp:925-962) shows the same keys from the reference's side.
+struct pt_scene_import {
+    std::vector<uint32_t> indices; std::vector<float> positions, uvs; std::vector<uint32_t> normals, tangents;
+    std::vector<PtGeometryDesc> geoms; std::vector<PtMeshDesc> meshes; std::vector<PtInstanceDesc> instances; std::vector<PTMaterialData> materials;
+    std::vector<std::vector<uint8_t>> texPixels; std::vector<PtTextureDesc> texDescs;
+    std::vector<PolymorphicLightInfo> lights; std::vector<PolymorphicLightInfoEx> lightsEx; std::vector<PtSceneCameraDesc> cameras;
+    PtSceneJsonInfo info;
+};
+
+namespace {
+bool jvec(const JValue* v, double* out, int n) {               // Donut's `>>` for vectors: an array of n numbers, or one number broadcast
+    if (!v) return false;
+    if (v->type == JValue::Num) { for (int i = 0; i < n; i++) out[i] = v->num; return true; }
+    if (v->type != JValue::Arr || (int)v->arr.size() != n) return false;
+    for (int i = 0; i < n; i++) if (v->arr[i].type != JValue::Num) return false;
+    for (int i = 0; i < n; i++) out[i] = v->arr[i].num;
+    return true;
+}
+std::string file_stem(const std::string& path) {
+    size_t slash = path.find_last_of('/'); std::string f = slash == std::string::npos ? path : path.substr(slash + 1);
+    size_t dot = f.find_last_of('.'); return dot == std::string::npos ? f : f.substr(0, dot);
+}
+struct ModelSlot { bool loaded = false; int32_t status = PT_OK; uint32_t firstMesh = 0; std::vector<int> meshRemap; std::vector<uint32_t> instMesh; std::vector<M4> instWorld; };
+
+struct SceneReader {
+    pt_scene_import& S; std::string sceneDir, mediaDir, sceneStem; std::vector<std::string> modelPaths; std::vector<ModelSlot> slots; int32_t err = PT_OK;
+    explicit SceneReader(pt_scene_import& s) : S(s) {}
+
+    uint32_t add_png_texture(const std::string& file, bool srgb) {
+        std::vector<uint8_t> bytes; uint32_t w, h; std::vector<uint8_t> rgba;
+        if (!read_file(file, bytes) || !decode_png(bytes, w, h, rgba)) return 0xFFFFFFFFu;
+        uint32_t index = (uint32_t)S.texDescs.size(); S.texPixels.push_back(std::move(rgba));
+        PtTextureDesc d; d.width = w; d.height = h; d.format = srgb ? PT_TEX_RGBA8_SRGB : PT_TEX_RGBA8_UNORM; d.pixels = nullptr; S.texDescs.push_back(d);
+        return pack_texture_word(index, w, h);
+    }
+    // MaterialsBaker::Load: the four candidates in order; returns false when there is no document for this material
+    bool material_override(const std::string& modelName, const std::string& name, PTMaterialData& out, PtMaterialJsonInfo& mi) {
+        if (name.empty()) return false;
+        const std::string base = mediaDir + "Materials/", ext = ".material.json";
+        const std::string cand[4] = {base + sceneStem + "/" + modelName + "." + name + ext, base + sceneStem + "/" + name + ext, base + modelName + "." + name + ext, base + name + ext};
+        for (int c = 0; c < 4; c++) {
+            std::vector<uint8_t> text;
+            if (!read_file(cand[c], text)) continue;
+            text.push_back(0);
+            PTMaterialData probe;
+            if (pt_material_from_json((const char*)text.data(), nullptr, &probe, &mi) != PT_OK) continue;        // LoadJsonFromFile failed: next candidate
+            uint32_t words[5];
+            for (int t = 0; t < 5; t++) {
+                words[t] = 0xFFFFFFFFu;
+                if (!mi.texturePath[t][0]) continue;
+                words[t] = add_png_texture(mediaDir + mi.texturePath[t], mi.textureSRGB[t] != 0);
+                if (words[t] == 0xFFFFFFFFu) S.info.texturesNotLoaded++;
+            }
+            if (pt_material_from_json((const char*)text.data(), words, &out, &mi) != PT_OK) return false;
+            return true;
+        }
+        return false;
+    }
+    // load models[k] once: append its textures, materials (with overrides), geometry and meshes; remember its instances for every node that uses it
+    ModelSlot& model(size_t k) {
+        ModelSlot& slot = slots[k];
+        if (slot.loaded) return slot;
+        slot.loaded = true;
+        Loader L; L.ctx = nullptr;
+        std::string path = sceneDir + modelPaths[k];
+        slot.status = load_gltf_file(path.c_str(), L);
+        if (slot.status != PT_OK) return slot;
+        const uint32_t texOffset = (uint32_t)S.texDescs.size(), matOffset = (uint32_t)S.materials.size();
+        for (size_t i = 0; i < L.texDescs.size(); i++) { S.texDescs.push_back(L.texDescs[i]); S.texPixels.push_back(std::move(L.texPixels[i])); }
+        const JValue* mats = L.root.get("materials"); const std::string modelName = file_stem(modelPaths[k]);
+        std::vector<int> geomFlagOverride(L.materials.size(), -1); std::vector<bool> skip(L.materials.size(), false);
+        for (size_t i = 0; i < L.materials.size(); i++) {
+            PTMaterialData m = L.materials[i];
+            uint32_t* words[6] = {&m.BaseOrDiffuseTextureIndex, &m.MetalRoughOrSpecularTextureIndex, &m.EmissiveTextureIndex, &m.NormalTextureIndex, &m.OcclusionTextureIndex, &m.TransmissionTextureIndex};
+            for (auto w : words) if (*w != 0xFFFFFFFFu) *w = (*w & 0xFFFF0000u) | ((*w & 0xFFFFu) + texOffset);
+            std::string name = (mats && i < mats->size()) ? mats->arr[i].strOr("name", "") : std::string();
+            PTMaterialData ov; PtMaterialJsonInfo mi;
+            if (material_override(modelName, name, ov, mi)) {
+                m = ov; S.info.materialOverrides++;
+                geomFlagOverride[i] = (mi.enableAlphaTesting ? PT_GEOMF_ALPHA_TESTED : 0) | (mi.excludeFromNEE ? PT_GEOMF_EXCLUDE_FROM_NEE : 0);
+                skip[i] = mi.skipRender != 0;
+            }
+            S.materials.push_back(m);
+        }
+        const uint32_t indexOffset = (uint32_t)S.indices.size(), vertexOffset = (uint32_t)(S.positions.size() / 3);
+        S.indices.insert(S.indices.end(), L.indices.begin(), L.indices.end());
+        S.positions.insert(S.positions.end(), L.positions.begin(), L.positions.end()); S.uvs.insert(S.uvs.end(), L.uvs.begin(), L.uvs.end());
+        S.normals.insert(S.normals.end(), L.normals.begin(), L.normals.end()); S.tangents.insert(S.tangents.end(), L.tangents.begin(), L.tangents.end());
+        slot.firstMesh = (uint32_t)S.meshes.size(); slot.meshRemap.assign(L.meshes.size(), -1);
+        for (size_t mi = 0; mi < L.meshes.size(); mi++) {
+            PtMeshDesc md; md.firstGeometry = (uint32_t)S.geoms.size(); md.numGeometries = 0;
+            for (uint32_t g = 0; g < L.meshes[mi].numGeometries; g++) {
+                PtGeometryDesc gd = L.geoms[L.meshes[mi].firstGeometry + g];
+                if (skip[gd.materialIndex]) { S.info.skippedGeometries++; continue; }                    // SkipRender: the reference gives these a NaN transform (AccelerationStructureUtil.h:62-72)
+                if (geomFlagOverride[gd.materialIndex] >= 0) gd.geomFlags = (uint32_t)geomFlagOverride[gd.materialIndex];
+                gd.indexOffset += indexOffset; gd.vertexOffset += vertexOffset; gd.materialIndex += matOffset;
+                S.geoms.push_back(gd); md.numGeometries++;
+            }
+            if (md.numGeometries) { slot.meshRemap[mi] = (int)S.meshes.size(); S.meshes.push_back(md); }
+        }
+        for (size_t i = 0; i < L.instances.size(); i++) {
+            int mesh = slot.meshRemap[L.instances[i].meshIndex];
+            if (mesh < 0) continue;
+            slot.instMesh.push_back((uint32_t)mesh); slot.instWorld.push_back(L.instanceWorld[i]);
+        }
+        S.info.numModels++;
+        return slot;
+    }
+    void instantiate(size_t k, const M4& world) {
+        if (k >= modelPaths.size()) { err = PT_ERROR_IO; return; }
+        ModelSlot& slot = model(k);
+        if (slot.status != PT_OK) { err = slot.status; return; }
+        for (size_t i = 0; i < slot.instMesh.size(); i++) {
+            M4 w = m4_mul(world, slot.instWorld[i]);
+            PtInstanceDesc inst; memset(&inst, 0, sizeof(inst)); inst.meshIndex = slot.instMesh[i];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) inst.transform[r * 4 + c] = (float)w.m[c * 4 + r];
+            S.instances.push_back(inst);
+        }
+    }
+    void leaf(const JValue& n, const std::string& type, const M4& world) {
+        PtSceneJsonInfo& I = S.info;
+        const double zx = world.m[8], zy = world.m[9], zz = world.m[10];                    // image of the local Z axis
+        if (type == "EnvironmentLight") {                                                    // ExtendedScene.cpp:104-110; the first one wins (FindEnvironmentLight :295-305)
+            if (I.hasEnvironment) return;
+            I.hasEnvironment = 1; I.envRadianceScale[0] = I.envRadianceScale[1] = I.envRadianceScale[2] = 1.f; I.envTextureIndex = -1; I.envRotation = 0.f;
+            double v[3]; if (jvec(n.get("radianceScale"), v, 3)) for (int i = 0; i < 3; i++) I.envRadianceScale[i] = (float)v[i];
+            const JValue* j = n.get("textureIndex"); if (j && j->type == JValue::Num) I.envTextureIndex = (int32_t)j->num;
+            j = n.get("rotation"); if (j && j->type == JValue::Num) I.envRotation = (float)j->num;
+            std::string p = n.strOr("path", ""); strncpy(I.envPath, p.c_str(), sizeof(I.envPath) - 1);
+        } else if (type == "PointLight" || type == "SpotLight") {
+            PtAnalyticLightDesc d; memset(&d, 0, sizeof(d));
+            d.type = type == "SpotLight" ? 1u : 0u; d.color[0] = d.color[1] = d.color[2] = 1.f; d.intensity = 1.f; d.radius = 0.f; d.innerAngle = 180.f; d.outerAngle = 180.f;   // Donut defaults
+            double v[3]; if (jvec(n.get("color"), v, 3)) for (int i = 0; i < 3; i++) d.color[i] = (float)v[i];
+            jload(n, "intensity", d.intensity); jload(n, "radius", d.radius);
+            if (d.type == 1u) { jload(n, "innerAngle", d.innerAngle); jload(n, "outerAngle", d.outerAngle); }
+            if (const JValue* px = n.get("proxyMeshNodes")) I.lightProxies += (uint32_t)px->size();
+            float cx = d.color[0] * d.intensity, cy = d.color[1] * d.intensity, cz = d.color[2] * d.intensity;
+            if (sqrtf(cx * cx + cy * cy + cz * cz) <= 1e-7f) { I.lightsDropped++; return; }     // Sample.cpp:567-573
+            double len = sqrt(zx * zx + zy * zy + zz * zz); if (!(len > 0)) len = 1;
+            for (int i = 0; i < 3; i++) d.position[i] = (float)world.m[12 + i];
+            d.direction[0] = (float)(-zx / len); d.direction[1] = (float)(-zy / len); d.direction[2] = (float)(-zz / len);      // Light::GetDirection: -Z of the node
+            PolymorphicLightInfo b; PolymorphicLightInfoEx e;
+            int32_t r = pt_convert_light(&d, &b, &e);
+            if (r != PT_OK) { err = r; return; }
+            S.lights.push_back(b); S.lightsEx.push_back(e);
+        } else if (type == "DirectionalLight") { I.directionalLights++; }                    // not part of the baked light set (LightsBaker.cpp:600)
+        else if (type == "PerspectiveCamera" || type == "PerspectiveCameraEx") {           // ExtendedScene.cpp:329-338 + Sample::UpdateCameraFromScene
+            PtSceneCameraDesc c; memset(&c, 0, sizeof(c)); c.verticalFov = 1.f; c.zNear = 1.f;
+            jload(n, "verticalFov", c.verticalFov); jload(n, "zNear", c.zNear);
+            for (int i = 0; i < 3; i++) { c.position[i] = (float)world.m[12 + i]; c.up[i] = (float)world.m[4 + i]; }
+            c.direction[0] = (float)-zx; c.direction[1] = (float)-zy; c.direction[2] = (float)-zz;       // row 2 of scaling(1,1,-1) * localToWorld
+            bool b = false; if (const JValue* j = n.get("enableAutoExposure")) if (j->type == JValue::Bool || j->type == JValue::Num) { jload(n, "enableAutoExposure", b); c.enableAutoExposure = b; c.exposureMask |= 1u; }
+            static const char* keys[4] = {"exposureCompensation", "exposureValue", "exposureValueMin", "exposureValueMax"}; float* dst[4] = {&c.exposureCompensation, &c.exposureValue, &c.exposureValueMin, &c.exposureValueMax};
+            for (int k = 0; k < 4; k++) if (const JValue* j = n.get(keys[k])) if (j->type == JValue::Num) { *dst[k] = (float)j->num; c.exposureMask |= 2u << k; }
+            std::string name = n.strOr("name", ""); strncpy(c.name, name.c_str(), sizeof(c.name) - 1);
+            S.cameras.push_back(c);
+        } else if (type == "SampleSettings") {                                               // ExtendedScene.cpp:347-356 (the last node wins, :243-247)
+            I.settingsMask = 0;
+            bool b;
+            if (const JValue* j = n.get("realtimeMode")) if (j->type == JValue::Bool) { b = j->b; I.realtimeMode = b; I.settingsMask |= 1u; }
+            if (const JValue* j = n.get("enableAnimations")) if (j->type == JValue::Bool) { b = j->b; I.enableAnimations = b; I.settingsMask |= 2u; }
+            if (const JValue* j = n.get("startingCamera")) if (j->type == JValue::Num) { I.startingCamera = (int32_t)j->num; I.settingsMask |= 4u; }
+            if (const JValue* j = n.get("realtimeFireflyFilter")) if (j->type == JValue::Num) { I.realtimeFireflyFilter = (float)j->num; I.settingsMask |= 8u; }
+            if (const JValue* j = n.get("maxBounces")) if (j->type == JValue::Num) { I.maxBounces = (int32_t)j->num; I.settingsMask |= 16u; }
+            if (const JValue* j = n.get("maxDiffuseBounces")) if (j->type == JValue::Num) { I.maxDiffuseBounces = (int32_t)j->num; I.settingsMask |= 32u; }
+            if (const JValue* j = n.get("textureMIPBias")) if (j->type == JValue::Num) { I.textureMIPBias = (float)j->num; I.settingsMask |= 64u; }
+        }
+        // GameSettings, unknown types: nothing the path tracer consumes
+    }
+    void node(const JValue& n, const M4& parent, int depth) {
+        if (err != PT_OK || depth > 256) return;
+        if (n.type == JValue::Str) {                                                         // a bare string names a model
+            for (size_t k = 0; k < modelPaths.size(); k++) if (modelPaths[k] == n.str) { instantiate(k, parent); return; }
+            err = PT_ERROR_IO; return;
+        }
+        if (n.type != JValue::Obj) return;
+        double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
+        jvec(n.get("translation"), t, 3); jvec(n.get("scaling"), s, 3);
+        if (const JValue* r = n.get("rotation")) { if (r->type == JValue::Arr) jvec(r, q, 4); }     // (EnvironmentLight's scalar "rotation" is a leaf property, not a node rotation)
+        else if (n.get("euler")) { err = PT_ERROR_UNSUPPORTED; return; }
+        M4 world = m4_mul(parent, m4_trs(t, q, s));
+        if (const JValue* m = n.get("model")) {
+            if (m->type == JValue::Num) instantiate((size_t)m->num, world);
+            else if (m->type == JValue::Str) { bool found = false; for (size_t k = 0; k < modelPaths.size(); k++) if (modelPaths[k] == m->str) { instantiate(k, world); found = true; break; } if (!found) err = PT_ERROR_IO; }
+        }
+        if (const JValue* ty = n.get("type")) if (ty->type == JValue::Str) leaf(n, ty->str, world);
+        if (const JValue* ch = n.get("children")) for (auto& c : ch->arr) node(c, world, depth + 1);
+    }
+};
+} // namespace
+
+extern "C" int32_t pt_scene_json_import(const char* scenePath, const char* mediaPath, pt_scene_import** out, PtSceneJsonInfo* info) {
+    if (!scenePath || !out) return PT_ERROR_INVALID_ARGUMENT;
+    *out = nullptr;
+    std::vector<uint8_t> file;
+    if (!read_file(scenePath, file)) return PT_ERROR_IO;
+    JParser jp; jp.p = (const char*)file.data(); jp.e = jp.p + file.size(); JValue root = jp.parse();
+    if (!jp.ok || root.type != JValue::Obj) return PT_ERROR_IO;
+    std::unique_ptr<pt_scene_import> S(new pt_scene_import()); memset(&S->info, 0, sizeof(S->info)); S->info.selectedCamera = -1; S->info.envTextureIndex = -1;
+    SceneReader R(*S);
+    std::string sp(scenePath); size_t slash = sp.find_last_of('/'); R.sceneDir = slash == std::string::npos ? "" : sp.substr(0, slash + 1);
+    R.mediaDir = mediaPath ? std::string(mediaPath) : R.sceneDir; if (!R.mediaDir.empty() && R.mediaDir.back() != '/') R.mediaDir += '/';
+    R.sceneStem = file_stem(sp);                                                             // "bistro.scene.json" -> "bistro.scene": filename().stem() strips one extension (MaterialsBaker.cpp:862)
+    if (const JValue* models = root.get("models")) for (auto& m : models->arr) { if (m.type != JValue::Str) return PT_ERROR_IO; R.modelPaths.push_back(m.str); }
+    R.slots.resize(R.modelPaths.size());
+    if (const JValue* graph = root.get("graph")) for (auto& n : graph->arr) R.node(n, m4_identity(), 0);
+    if (R.err != PT_OK) return R.err;
+    PtSceneJsonInfo& I = S->info;
+    I.numGeometries = (uint32_t)S->geoms.size(); I.numMeshes = (uint32_t)S->meshes.size(); I.numInstances = (uint32_t)S->instances.size(); I.numMaterials = (uint32_t)S->materials.size();
+    I.numTextures = (uint32_t)S->texDescs.size(); I.numLights = (uint32_t)S->lights.size(); I.numCameras = (uint32_t)S->cameras.size();
+    if (I.numCameras) I.selectedCamera = ((I.settingsMask & 4u) && I.startingCamera >= 0 && (uint32_t)I.startingCamera < I.numCameras) ? I.startingCamera : (int32_t)I.numCameras - 1;
+    for (size_t i = 0; i < S->texDescs.size(); i++) S->texDescs[i].pixels = S->texPixels[i].data();
+    if (info) *info = I;
+    *out = S.release();
+    return PT_OK;
+}
+extern "C" void pt_scene_import_free(pt_scene_import* scene) { delete scene; }
+#define PT_IMPORT_COPY(FN, TYPE, VEC) \
+    extern "C" int32_t FN(const pt_scene_import* scene, TYPE* out, uint32_t capacity) { \
+        if (!scene || (capacity && !out)) return -PT_ERROR_INVALID_ARGUMENT; \
+        size_t n = scene->VEC.size() < capacity ? scene->VEC.size() : capacity; \
+        if (n) memcpy(out, scene->VEC.data(), n * sizeof(TYPE)); \
+        return (int32_t)scene->VEC.size(); }
+PT_IMPORT_COPY(pt_scene_import_cameras, PtSceneCameraDesc, cameras)
+PT_IMPORT_COPY(pt_scene_import_instances, PtInstanceDesc, instances)
+PT_IMPORT_COPY(pt_scene_import_geometries, PtGeometryDesc, geoms)
+PT_IMPORT_COPY(pt_scene_import_materials, PTMaterialData, materials)
+#undef PT_IMPORT_COPY
+extern "C" int32_t pt_scene_import_lights(const pt_scene_import* scene, PolymorphicLightInfo* base, PolymorphicLightInfoEx* ex, uint32_t capacity) {
+    if (!scene || (capacity && (!base || !ex))) return -PT_ERROR_INVALID_ARGUMENT;
+    size_t n = scene->lights.size() < capacity ? scene->lights.size() : capacity;
+    if (n) { memcpy(base, scene->lights.data(), n * sizeof(PolymorphicLightInfo)); memcpy(ex, scene->lightsEx.data(), n * sizeof(PolymorphicLightInfoEx)); }
+    return (int32_t)scene->lights.size();
+}
+extern "C" int32_t pt_scene_import_apply(pt_context* ctx, const pt_scene_import* S) {
+    if (!ctx || !S) return PT_ERROR_INVALID_ARGUMENT;
+    if (S->instances.empty() || S->geoms.empty()) return PT_ERROR_IO;
+    int32_t r = pt_set_materials(ctx, S->materials.data(), (uint32_t)S->materials.size(), S->texDescs.data(), (uint32_t)S->texDescs.size());
+    if (r != PT_OK) return r;
+    PtGeometryBuffers gb; gb.indices = S->indices.data(); gb.numIndices = (uint32_t)S->indices.size(); gb.positions = S->positions.data(); gb.uvs = S->uvs.data();
+    gb.normals = S->normals.data(); gb.tangents = S->tangents.data(); gb.numVertices = (uint32_t)(S->positions.size() / 3);
+    r = pt_set_geometry(ctx, &gb, S->geoms.data(), (uint32_t)S->geoms.size(), S->meshes.data(), (uint32_t)S->meshes.size());
+    if (r != PT_OK) return r;
+    r = pt_set_instances(ctx, S->instances.data(), (uint32_t)S->instances.size());
+    if (r != PT_OK) return r;
+    return pt_set_lights(ctx, S->lights.data(), S->lightsEx.data(), (uint32_t)S->lights.size());
 }

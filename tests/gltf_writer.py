@@ -38,7 +38,8 @@ def write_gltf(sc, path):
         return len(accessors) - 1
 
     materials = []
-    for m in sc["materials"]:
+    names = sc.get("material_names")
+    for mi_, m in enumerate(sc["materials"]):
         flags = int(m["Flags"])
         j = {"pbrMetallicRoughness": {"baseColorFactor": [float(x) for x in m["BaseOrDiffuseColor"]] + [1.0], "metallicFactor": float(m["Metalness"]), "roughnessFactor": float(m["Roughness"])},
              "emissiveFactor": [1.0, 1.0, 1.0] if any(m["EmissiveColor"] > 0) else [0.0, 0.0, 0.0], "extensions": {"KHR_materials_ior": {"ior": float(m["IoR"])}}}
@@ -50,6 +51,8 @@ def write_gltf(sc, path):
             j["extensions"]["KHR_materials_transmission"] = {"transmissionFactor": float(m["TransmissionFactor"])}
             if not (flags & 0x200):
                 j["extensions"]["KHR_materials_volume"] = {"thicknessFactor": 1.0, "attenuationDistance": float(m["AttenuationDistance"]), "attenuationColor": [float(x) for x in m["AttenuationColor"]]}
+        if names is not None:
+            j["name"] = names[mi_]
         materials.append(j)
     meshes = []
     for (fg, ng) in sc["meshes"]:

@@ -1,0 +1,204 @@
+"""RTXPT `.scene.json` asset folders through pt_scene_json_import — host only, no device. The leaves and what Sample::SceneLoaded does with
+them follow the reference tree (ExtendedScene.cpp:104-143, 313-375; Sample.cpp:457-479, 520-640; MaterialsBaker.cpp:707-748, 857-864); the graph format is
+Donut's (restated, see include/mi355pt.h). Checks are against independent numpy compositions, pt_convert_light / pt_material_from_json (each pinned to the
+reference text elsewhere), and — on the GPU — against the same scene handed over through the raw-buffer entry points."""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import rtxpt_amd as pt
+from rtxpt_amd import scenes
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gltf_writer import write_gltf
+
+NAMES = ["white", "red", "green", "light", "glass", "gold"]
+
+
+def trs_matrix(t=(0, 0, 0), q=(0, 0, 0, 1), s=(1, 1, 1)):
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float64)
+    M = np.eye(4); M[:3, :3] = R * np.asarray(s, np.float64)[None, :]; M[:3, 3] = t
+    return M
+
+
+def make_folder(tmp_path, graph, overrides=None, scene_name="test.scene.json", textures=None):
+    media = tmp_path / "media"; (media / "Models").mkdir(parents=True, exist_ok=True)
+    sc, cam = scenes.cornell_box("C2")
+    sc["material_names"] = NAMES
+    write_gltf(sc, str(media / "Models" / "cornell.gltf"))
+    for rel, doc in (overrides or {}).items():
+        f = media / "Materials" / rel; f.parent.mkdir(parents=True, exist_ok=True); f.write_text(json.dumps(doc))
+    for rel, rgba in (textures or {}).items():
+        f = media / rel; f.parent.mkdir(parents=True, exist_ok=True); pt.write_image(str(f), rgba)
+    (media / scene_name).write_text(json.dumps({"models": ["Models/cornell.gltf"], "graph": graph}))
+    return media, sc, cam
+
+
+Q_Y90 = (0.0, math.sin(math.pi / 4), 0.0, math.cos(math.pi / 4))
+GRAPH = [
+    {"name": "room", "model": 0, "translation": [1.0, 2.0, 3.0], "rotation": list(Q_Y90), "scaling": 2.0},
+    {"name": "group", "translation": [10.0, 0.0, 0.0], "children": [{"name": "room2", "model": 0, "scaling": [1.0, 0.5, 1.0]}, "Models/cornell.gltf"]},
+    {"name": "Lights", "translation": [0.0, 1.0, 0.0], "children": [
+        {"name": "spot", "type": "SpotLight", "translation": [0.2, 0.3, 0.1], "rotation": [0.7071067811865476, 0.0, 0.0, 0.7071067811865476], "color": [1.0, 0.8, 0.6], "intensity": 50.0,
+         "radius": 0.05, "innerAngle": 20.0, "outerAngle": 45.0, "proxyMeshNodes": ["/room"]},
+        {"name": "off", "type": "PointLight", "intensity": 0.0, "radius": 0.1},
+        {"name": "bulb", "type": "PointLight", "translation": [0.1, 0.1, 0.1], "color": 0.5, "intensity": 20.0, "radius": 0.02},
+        {"name": "sun", "type": "DirectionalLight", "irradiance": 3.0}]},
+    {"name": "Cameras", "children": [
+        {"name": "Default", "type": "PerspectiveCameraEx", "translation": [0.278, 0.273, -0.8], "rotation": [0.0, 1.0, 0.0, 0.0], "verticalFov": 0.6859, "zNear": 0.01,
+         "enableAutoExposure": False, "exposureCompensation": 1.5, "exposureValue": -2.0},
+        {"name": "Second", "type": "PerspectiveCamera", "translation": [0.0, 1.0, 5.0]}]},
+    {"name": "Sky", "type": "EnvironmentLight", "path": "EnvironmentMaps/sky.exr", "radianceScale": [2.0, 2.0, 1.5], "rotation": 0.25},
+    {"name": "Sky2", "type": "EnvironmentLight", "path": "ignored.exr"},
+    {"name": "Settings", "type": "SampleSettings", "maxBounces": 7, "startingCamera": 0, "realtimeFireflyFilter": 0.5, "enableAnimations": True},
+    {"name": "Game", "type": "GameSettings", "anything": 1},
+]
+
+
+def test_scene_graph_instances_lights_cameras(tmp_path):
+    media, sc, cam = make_folder(tmp_path, GRAPH)
+    imp = pt.SceneImport(media / "test.scene.json")
+    I = imp.info
+    base = sc["instances"]
+    assert I["numModels"] == 1 and I["numInstances"] == 3 * len(base) and I["numMeshes"] == len(sc["meshes"]) and I["numGeometries"] == len(sc["geometries"])
+    assert I["numMaterials"] == len(sc["materials"]) + 1 and I["materialOverrides"] == 0 and I["numTextures"] == 0
+    # instances: node world (double) x glTF instance matrix, then fp32
+    worlds = [trs_matrix((1, 2, 3), Q_Y90, (2, 2, 2)), trs_matrix((10, 0, 0)) @ trs_matrix(s=(1, 0.5, 1)), trs_matrix((10, 0, 0))]
+    k = 0
+    for W in worlds:
+        for inst in base:
+            m = np.eye(4); m[:3, :] = inst["transform"].reshape(3, 4).astype(np.float64)
+            want = (W @ m)[:3, :].astype(np.float32).reshape(-1)
+            got = imp.instances[k]["transform"]
+            assert np.allclose(got, want, rtol=0, atol=1e-6 * max(1.0, np.abs(want).max())), (k, got, want)
+            assert imp.instances[k]["meshIndex"] == inst["meshIndex"]
+            k += 1
+    assert np.array_equal(imp.geometries["materialIndex"], sc["geometries"]["materialIndex"])
+    # lights: scene-graph order, invisible one dropped, directional not baked; records == pt_convert_light on the node's world position / -Z axis
+    assert I["numLights"] == 2 and I["lightsDropped"] == 1 and I["directionalLights"] == 1 and I["lightProxies"] == 1
+    Wl = trs_matrix((0, 1, 0)) @ trs_matrix((0.2, 0.3, 0.1), (0.7071067811865476, 0, 0, 0.7071067811865476))
+    z = Wl[:3, 2]; d = -z / np.linalg.norm(z)
+    b, e = pt.convert_light("spot", Wl[:3, 3].astype(np.float32), (1.0, 0.8, 0.6), 50.0, 0.05, d.astype(np.float32), 20.0, 45.0)
+    assert np.array_equal(imp.lights[0], b) and np.array_equal(imp.lights_ex[0], e)
+    assert np.allclose(d, (0, 1, 0), atol=1e-12)              # +90 degrees about X turns -Z into +Y
+    b, e = pt.convert_light("point", (0.1, 1.1, 0.1), (0.5, 0.5, 0.5), 20.0, 0.02, (0.0, 0.0, -1.0), 180.0, 180.0)
+    assert np.array_equal(imp.lights[1], b) and np.array_equal(imp.lights_ex[1], e)
+    # cameras (Sample::UpdateCameraFromScene): a half turn about Y makes the glTF-style -Z camera look along +Z
+    assert I["numCameras"] == 2 and I["selectedCamera"] == 0
+    c0, c1 = imp.cameras
+    assert c0["name"] == b"Default" and np.allclose(c0["position"], (0.278, 0.273, -0.8)) and np.allclose(c0["direction"], (0, 0, 1), atol=1e-7) and np.allclose(c0["up"], (0, 1, 0), atol=1e-7)
+    assert abs(c0["verticalFov"] - 0.6859) < 1e-7 and abs(c0["zNear"] - 0.01) < 1e-9
+    assert c0["exposureMask"] == 0b00111 and c0["enableAutoExposure"] == 0 and c0["exposureCompensation"] == 1.5 and c0["exposureValue"] == -2.0
+    assert c1["exposureMask"] == 0 and c1["verticalFov"] == 1.0 and c1["zNear"] == 1.0 and np.allclose(c1["direction"], (0, 0, -1)) and np.allclose(c1["position"], (0, 1, 5))
+    # environment: first EnvironmentLight wins; settings: the seven SampleSettings keys
+    assert I["hasEnvironment"] == 1 and I["envPath"] == b"EnvironmentMaps/sky.exr" and np.allclose(I["envRadianceScale"], (2, 2, 1.5)) and I["envRotation"] == 0.25 and I["envTextureIndex"] == -1
+    assert I["settingsMask"] == (2 | 4 | 8 | 16) and I["maxBounces"] == 7 and I["startingCamera"] == 0 and I["realtimeFireflyFilter"] == 0.5 and I["enableAnimations"] == 1
+    imp.close()
+
+
+def test_selected_camera_defaults_to_last(tmp_path):
+    g = [n for n in GRAPH if not (isinstance(n, dict) and n.get("type") == "SampleSettings")]
+    media, _, _ = make_folder(tmp_path, g)
+    imp = pt.SceneImport(media / "test.scene.json")
+    assert imp.info["settingsMask"] == 0 and imp.info["selectedCamera"] == 1
+    g2 = g + [{"type": "SampleSettings", "startingCamera": 5}]
+    media, _, _ = make_folder(tmp_path, g2)
+    assert pt.SceneImport(media / "test.scene.json").info["selectedCamera"] == 1            # out of range: fall back to the last camera
+
+
+def test_material_overrides_follow_reference_candidate_order(tmp_path):
+    checker = np.zeros((4, 8, 4), np.uint8); checker[..., 3] = 255; checker[::2, ::2, :3] = 255
+    red_doc = {"BaseOrDiffuseColor": [0.1, 0.2, 0.3], "Roughness": 0.25, "EnableAlphaTesting": True, "AlphaCutoff": 0.3, "ExcludeFromNEE": True,
+               "BaseTexture": {"path": "Textures/checker.png", "sRGB": True}, "NormalTexture": {"path": "Textures/missing.dds", "NormalMap": True}}
+    overrides = {
+        "test.scene/cornell.red.material.json": red_doc,                                    # candidate 0 beats the three below
+        "test.scene/red.material.json": {"Roughness": 0.9},
+        "cornell.red.material.json": {"Roughness": 0.8},
+        "red.material.json": {"Roughness": 0.7},
+        "cornell.green.material.json": {"Metalness": 1.0, "Roughness": 0.125},             # candidate 2 beats candidate 3
+        "green.material.json": {"Metalness": 0.0},
+        "gold.material.json": {"SkipRender": True},                                         # shared, unqualified
+        "test.scene/white.material.json": "not an object",                                  # unreadable document: falls through to the next candidate
+        "white.material.json": {"IoR": 1.33, "EnableTransmission": True, "TransmissionFactor": 0.5, "NestedPriority": 3},
+    }
+    media, sc, _ = make_folder(tmp_path, [{"model": 0}], overrides, textures={"Textures/checker.png": checker})
+    imp = pt.SceneImport(media / "test.scene.json")
+    I = imp.info
+    assert I["materialOverrides"] == 4 and I["numTextures"] == 1 and I["texturesNotLoaded"] == 1 and I["skippedGeometries"] == 1
+    word = scenes.pack_texture_word(0, 8, 4)
+    want, info = pt.material_from_json(json.dumps(red_doc), (word, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF))
+    assert imp.materials[1].tobytes() == want.tobytes() and info["enableAlphaTesting"] and info["excludeFromNEE"]
+    assert imp.materials[1]["BaseOrDiffuseTextureIndex"] == word and imp.materials[1]["NormalTextureIndex"] == 0xFFFFFFFF
+    assert imp.materials[2].tobytes() == pt.material_from_json(json.dumps(overrides["cornell.green.material.json"]))[0].tobytes()
+    assert imp.materials[0].tobytes() == pt.material_from_json(json.dumps(overrides["white.material.json"]))[0].tobytes()
+    # untouched materials keep the glTF import (emissive light, glass)
+    assert np.allclose(imp.materials[3]["EmissiveColor"], sc["materials"][3]["EmissiveColor"]) and imp.materials[4]["TransmissionFactor"] == 1.0
+    # geometry flags follow the document; the SkipRender material's geometry (the tall box) is gone together with its mesh and instance
+    g = imp.geometries
+    assert all(g["geomFlags"][g["materialIndex"] == 1] == 3) and all(g["geomFlags"][g["materialIndex"] == 0] == 0)
+    assert I["numGeometries"] == len(sc["geometries"]) - 1 and I["numMeshes"] == len(sc["meshes"]) - 1 and I["numInstances"] == len(sc["instances"]) - 1
+    assert 5 not in set(g["materialIndex"].tolist())
+    # the scene-specialised folder is named after filename().stem(): "other.scene.json" -> Materials/other.scene/
+    media2, _, _ = make_folder(tmp_path / "b", [{"model": 0}], overrides, scene_name="other.scene.json")
+    imp2 = pt.SceneImport(media2 / "other.scene.json")
+    assert imp2.materials[1].tobytes() == pt.material_from_json(json.dumps({"Roughness": 0.8}))[0].tobytes()
+
+
+def test_media_path_argument_and_errors(tmp_path):
+    media, _, _ = make_folder(tmp_path, [{"model": 0}], {"red.material.json": {"Roughness": 0.7}})
+    elsewhere = tmp_path / "elsewhere"; (elsewhere / "Materials").mkdir(parents=True)
+    (elsewhere / "Materials" / "red.material.json").write_text(json.dumps({"Roughness": 0.33}))
+    assert abs(pt.SceneImport(media / "test.scene.json").materials[1]["Roughness"] - 0.7) < 1e-7
+    assert abs(pt.SceneImport(media / "test.scene.json", elsewhere).materials[1]["Roughness"] - 0.33) < 1e-7
+    for bad, code in (([{"model": 3}], 4), ([{"model": "nope.gltf"}], 4), (["nope.gltf"], 4), ([{"model": 0, "euler": [0, 1, 0]}], 5)):
+        m, _, _ = make_folder(tmp_path / "bad", bad)
+        with pytest.raises(pt.PtError) as e:
+            pt.SceneImport(m / "test.scene.json")
+        assert e.value.code == code, (bad, e.value.code)
+    # a light without radius converts to the point-type record, as in the reference; it is pt_set_lights (pt_scene_import_apply) that refuses it
+    m, _, _ = make_folder(tmp_path / "pointlight", [{"type": "SpotLight", "radius": 0.0, "intensity": 1.0}])
+    pl = pt.SceneImport(m / "test.scene.json")
+    assert pl.info["numLights"] == 1 and (int(pl.lights[0][3]) >> 24) & 0xF == 4
+    (media / "broken.scene.json").write_text("{ \"models\": [")
+    with pytest.raises(pt.PtError):
+        pt.SceneImport(media / "broken.scene.json")
+    with pytest.raises(pt.PtError):
+        pt.SceneImport(media / "missing.scene.json")
+    (media / "empty.scene.json").write_text(json.dumps({"models": [], "graph": []}))
+    e = pt.SceneImport(media / "empty.scene.json")
+    assert e.info["numInstances"] == 0 and e.info["selectedCamera"] == -1 and e.info["hasEnvironment"] == 0
+
+
+@pytest.mark.gpu
+def test_scene_json_frame_equals_raw_buffer_frame(tmp_path):
+    """The imported folder renders the same frame as the same scene handed over through pt_set_* (materials as the glTF import makes them, lights through
+    pt_convert_light, camera from the scene's camera node)."""
+    graph = [{"model": 0},
+             {"name": "bulb", "type": "PointLight", "translation": [0.27, 0.4, 0.28], "color": [1.0, 0.9, 0.7], "intensity": 3.0, "radius": 0.03},
+             {"name": "Default", "type": "PerspectiveCameraEx", "translation": [0.278, 0.273, -0.8], "rotation": [0.0, 1.0, 0.0, 0.0], "verticalFov": math.radians(39.3), "zNear": 0.01}]
+    media, sc, cam = make_folder(tmp_path, graph)
+    imp = pt.SceneImport(media / "test.scene.json")
+    c = imp.cameras[imp.info["selectedCamera"]]
+    W = H = 96
+    camera = pt.bridge_camera(W, H, c["position"], c["direction"], c["up"], float(c["verticalFov"]), near_z=float(c["zNear"]), far_z=100.0, focal_distance=1.0)
+    frames = []
+    for use_import in (True, False):
+        p = pt.PathTracer()
+        if use_import:
+            p.apply_scene_import(imp)
+        else:
+            p.load_scene_gltf(str(media / "Models" / "cornell.gltf"))
+            b, e = pt.convert_light("point", (0.27, 0.4, 0.28), (1.0, 0.9, 0.7), 3.0, 0.03, (0.0, 0.0, -1.0), 180.0, 180.0)
+            p._chk(p.L.pt_set_lights(p.h, pt._p(b), pt._p(e), 1), "pt_set_lights")
+        p.set_settings(p.default_settings()); p.resize(W, H); p.set_camera(camera)
+        p.render(0, 4)
+        frames.append(p.radiance().copy()); p.close()
+    assert np.isfinite(frames[0]).all() and frames[0][..., :3].max() > 0
+    assert np.array_equal(frames[0], frames[1])
