@@ -246,6 +246,9 @@ int32_t pt_scene_import_lights(const pt_scene_import* scene, PolymorphicLightInf
 int32_t pt_scene_import_instances(const pt_scene_import* scene, PtInstanceDesc* out, uint32_t capacity);
 int32_t pt_scene_import_geometries(const pt_scene_import* scene, PtGeometryDesc* out, uint32_t capacity);
 int32_t pt_scene_import_materials(const pt_scene_import* scene, PTMaterialData* out, uint32_t capacity);
+/* SampleSettings -> PtSettings as Sample::SceneLoaded applies them (Sample.cpp:613-629): maxBounces, maxDiffuseBounces, textureMIPBias overwrite
+   bounceCount, diffuseBounceCount, texLODBias when the scene names them; everything else in *settings is left alone. */
+int32_t pt_scene_import_settings(const pt_scene_import* scene, PtSettings* settings);
 /* pt_set_materials + pt_set_geometry + pt_set_instances + pt_set_lights on ctx (camera, environment and settings stay with the caller) */
 int32_t pt_scene_import_apply(pt_context* ctx, const pt_scene_import* scene);
 

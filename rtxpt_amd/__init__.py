@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
     "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
-    "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply",
+    "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings",
 ]
 
 
@@ -213,6 +213,14 @@ class SceneImport:
         self.L.pt_scene_import_lights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         assert self.L.pt_scene_import_lights(self.h, _p(self.lights), _p(self.lights_ex), n) == n
         self.lights, self.lights_ex = self.lights[:n], self.lights_ex[:n]
+
+    def apply_settings(self, settings):
+        """pt_scene_import_settings: the scene's SampleSettings keys written over a SETTINGS_DTYPE record (in place)."""
+        self.L.pt_scene_import_settings.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        r = self.L.pt_scene_import_settings(self.h, _p(settings))
+        if r != 0:
+            raise PtError(r, "pt_scene_import_settings")
+        return settings
 
     def close(self):
         if self.h:

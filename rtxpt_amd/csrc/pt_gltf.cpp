@@ -656,6 +656,16 @@ extern "C" int32_t pt_scene_import_lights(const pt_scene_import* scene, Polymorp
     if (n) { memcpy(base, scene->lights.data(), n * sizeof(PolymorphicLightInfo)); memcpy(ex, scene->lightsEx.data(), n * sizeof(PolymorphicLightInfoEx)); }
     return (int32_t)scene->lights.size();
 }
+// Sample::SceneLoaded, Rtxpt/Sample.cpp:613-629: m_ui.BounceCount / DiffuseBounceCount / TexLODBias = value_or(current). realtimeMode, enableAnimations and
+// realtimeFireflyFilter steer the realtime path and the animation clock, which the reference-mode settings block does not hold.
+extern "C" int32_t pt_scene_import_settings(const pt_scene_import* S, PtSettings* settings) {
+    if (!S || !settings) return PT_ERROR_INVALID_ARGUMENT;
+    const PtSceneJsonInfo& I = S->info;
+    if ((I.settingsMask & 16u) && I.maxBounces >= 0) settings->bounceCount = (uint32_t)I.maxBounces;
+    if ((I.settingsMask & 32u) && I.maxDiffuseBounces >= 0) settings->diffuseBounceCount = (uint32_t)I.maxDiffuseBounces;
+    if (I.settingsMask & 64u) settings->texLODBias = I.textureMIPBias;
+    return PT_OK;
+}
 extern "C" int32_t pt_scene_import_apply(pt_context* ctx, const pt_scene_import* S) {
     if (!ctx || !S) return PT_ERROR_INVALID_ARGUMENT;
     if (S->instances.empty() || S->geoms.empty()) return PT_ERROR_IO;

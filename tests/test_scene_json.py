@@ -100,6 +100,9 @@ def test_scene_graph_instances_lights_cameras(tmp_path):
     # environment: first EnvironmentLight wins; settings: the seven SampleSettings keys
     assert I["hasEnvironment"] == 1 and I["envPath"] == b"EnvironmentMaps/sky.exr" and np.allclose(I["envRadianceScale"], (2, 2, 1.5)) and I["envRotation"] == 0.25 and I["envTextureIndex"] == -1
     assert I["settingsMask"] == (2 | 4 | 8 | 16) and I["maxBounces"] == 7 and I["startingCamera"] == 0 and I["realtimeFireflyFilter"] == 0.5 and I["enableAnimations"] == 1
+    st = scenes.default_settings(); before = st.copy()
+    imp.apply_settings(st)
+    assert st["bounceCount"] == 7 and st["diffuseBounceCount"] == before["diffuseBounceCount"] and st["texLODBias"] == before["texLODBias"]
     imp.close()
 
 
