@@ -266,6 +266,11 @@ int32_t pt_default_tonemap(PtToneMapParams* out, float exposureCompensation, flo
 int32_t pt_tonemap_color_transform(PtToneMapParams* params, uint32_t whiteBalance, float whitePoint, float exposureCompensation, float filmSpeed,
                                    float shutter, float fNumber);
 int32_t pt_tonemap(pt_context* ctx, const PtToneMapParams* params, uint8_t* rgba8, size_t bytes);
+/* Auto exposure, the luminance capture of ToneMappingPass::Render (ToneMappingPasses.cpp:78-97, 225-288; luminance_ps.hlsl:10-26; capture_cs,
+   ToneMapping.hlsl:25-34): log2(max(1e-4, luminance)) of THIS context's accumulation buffer drawn through the linear sampler into a target of
+   power-of-two-lowered size, averaged down its mip chain; avgLuminance = exp2(last mip) is what TONEMAPPING_AUTOEXPOSURE_CPU puts into
+   ToneMappingConstants::avgLuminance (the reference reads it back with a lag of a few frames; here it is the current image). */
+int32_t pt_average_luminance(pt_context* ctx, float* avgLuminance);
 int32_t pt_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 int32_t pt_write_bmp(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 

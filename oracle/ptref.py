@@ -257,6 +257,22 @@ def reference_color_transform(white_balance, white_point, auto_exposure, exposur
     return out
 
 
+def average_luminance(rgba):
+    """ORACLE (numpy float64) of the auto-exposure luminance capture: ToneMappingPasses.cpp:78-97 (target lowered to powers of two), luminance_ps.hlsl:10-26
+    (log2(max(1e-4, dot(color, (0.299, 0.587, 0.114)))) of the colour target through the linear sampler, clamp addressing), mip chain of 2x2 averages down to 1x1
+    (for power-of-two sides: the plain mean), capture_cs (ToneMapping.hlsl:25-34) and exp2 on the host (ToneMappingPasses.cpp:284). rgba: (H, W, 4)."""
+    img = np.asarray(rgba, np.float64)[..., :3]
+    H, W = img.shape[:2]
+    LW, LH = 1 << int(np.floor(np.log2(W))), 1 << int(np.floor(np.log2(H)))
+    sx = (np.arange(LW) + 0.5) / LW * W - 0.5; sy = (np.arange(LH) + 0.5) / LH * H - 0.5
+    x0 = np.floor(sx); y0 = np.floor(sy); fx = (sx - x0)[None, :, None]; fy = (sy - y0)[:, None, None]
+    xa = np.clip(x0.astype(int), 0, W - 1); xb = np.clip(x0.astype(int) + 1, 0, W - 1); ya = np.clip(y0.astype(int), 0, H - 1); yb = np.clip(y0.astype(int) + 1, 0, H - 1)
+    top = img[ya][:, xa] * (1 - fx) + img[ya][:, xb] * fx; bot = img[yb][:, xa] * (1 - fx) + img[yb][:, xb] * fx
+    col = top * (1 - fy) + bot * fy
+    lum = col @ np.array([0.299, 0.587, 0.114])
+    return float(2.0 ** np.mean(np.log2(np.maximum(1e-4, lum))))
+
+
 def _pin_table():
     """(names, arities) parsed from oracle/refpin/pin_fns.h so that Python never holds a second copy of the table"""
     import re

@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
     "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
-    "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings",
+    "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
 ]
 
 
@@ -370,6 +370,13 @@ class PathTracer:
         return out
 
     # ---- multi-GPU shard plumbing (device pointers come from torch tensors)
+    def average_luminance(self):
+        """pt_average_luminance: the auto-exposure luminance capture (ToneMappingPasses.cpp:225-288) of the current accumulation buffer."""
+        v = ctypes.c_float(0.0)
+        self.L.pt_average_luminance.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        self._chk(self.L.pt_average_luminance(self.h, ctypes.byref(v)), "pt_average_luminance")
+        return float(v.value)
+
     def shard_info(self):
         n, b = ctypes.c_uint32(), ctypes.c_size_t()
         self._chk(self.L.pt_shard_info(self.h, ctypes.byref(n), ctypes.byref(b)), "pt_shard_info")

@@ -745,6 +745,21 @@ int32_t pt_default_tonemap(PtToneMapParams* out, float exposureCompensation, flo
     out->colorTransform[0] = s; out->colorTransform[4] = s; out->colorTransform[8] = s;
     return PT_OK;
 }
+int32_t pt_average_luminance(pt_context* c, float* avgLuminance) {
+    if (!c || !avgLuminance) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    (void)hipSetDevice(c->device);
+    size_t n = (size_t)ptk::tm_pow2_floor(c->width) * ptk::tm_pow2_floor(c->height);
+    DevBuf<float> d; PT_CHECK_HIP(c, d.resize(2 * n));
+    float* result = nullptr; float logLum = 0.f;
+    launch_average_log_luminance(c->dAccum.p, c->width, c->height, d.p, &result, c->stream);
+    PT_CHECK_HIP(c, hipMemcpyAsync(&logLum, result, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    PT_CHECK_HIP(c, hipGetLastError());
+    d.free();
+    *avgLuminance = exp2f(logLum);                      // ToneMappingPasses.cpp:284
+    return PT_OK;
+}
 int32_t pt_tonemap(pt_context* c, const PtToneMapParams* params, uint8_t* rgba8, size_t bytes) {
     if (!c || !params || !rgba8) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");

@@ -69,5 +69,28 @@ static inline uint tm_pixel(const ToneMapParams& p, float4 radiance) {       // 
     return tm_srgb8(c.x) | (tm_srgb8(c.y) << 8) | (tm_srgb8(c.z) << 16) | ((uint)(a * 255.0f + 0.5f) << 24);
 }
 
+// ---- auto exposure, luminance capture (ToneMappingPasses.cpp:78-97, 225-288): the colour target is drawn into a power-of-two-lowered R32F target as
+// log2(max(1e-4, luminance)) (luminance_ps.hlsl:10-26, linear sampler at the quad's uv), the mip chain is generated and the last (1x1) mip is read back;
+// avgLuminance = exp2 of it. The sampler's bilinear filter and Donut's MipMapGenPass (2x2 averages) are restated in fp32; texture units use fixed-point
+// weights, so parity with the reference here is to tolerance, not bit-exact.
+static inline uint tm_pow2_floor(uint v) { uint r = 1u; while ((r << 1) != 0u && (r << 1) <= v) r <<= 1; return r; }
+static inline float tm_log_luminance_texel(const float4* accum, uint W, uint H, uint LW, uint LH, uint x, uint y) {
+    float u = ((float)x + 0.5f) / (float)LW, v = ((float)y + 0.5f) / (float)LH;
+    float sx = u * (float)W - 0.5f, sy = v * (float)H - 0.5f;
+    float bx = floorf(sx), by = floorf(sy), fx = sx - bx, fy = sy - by;
+    int x0 = (int)bx, y0 = (int)by, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > (int)W - 1 ? (int)W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > (int)W - 1 ? (int)W - 1 : x1);          // clamp addressing
+    y0 = y0 < 0 ? 0 : (y0 > (int)H - 1 ? (int)H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > (int)H - 1 ? (int)H - 1 : y1);
+    float4 a = accum[(size_t)y0 * W + x0], b = accum[(size_t)y0 * W + x1], c = accum[(size_t)y1 * W + x0], d = accum[(size_t)y1 * W + x1];
+    float3 top = make_float3(a.x, a.y, a.z) * (1.0f - fx) + make_float3(b.x, b.y, b.z) * fx, bot = make_float3(c.x, c.y, c.z) * (1.0f - fx) + make_float3(d.x, d.y, d.z) * fx;
+    float3 col = top * (1.0f - fy) + bot * fy;
+    float lum = (col.x * 0.299f + col.y * 0.587f) + col.z * 0.114f;
+    return dm_log2(fmaxf_(0.0001f, lum));
+}
+static inline float tm_mip_texel(const float* src, uint w, uint h, uint x, uint y) {            // one texel of the next mip: 2x2 average, edge texels repeat when a side is already 1
+    uint x0 = 2u * x, y0 = 2u * y, x1 = x0 + 1u < w ? x0 + 1u : w - 1u, y1 = y0 + 1u < h ? y0 + 1u : h - 1u;
+    return ((src[(size_t)y0 * w + x0] + src[(size_t)y0 * w + x1]) * 0.5f + (src[(size_t)y1 * w + x0] + src[(size_t)y1 * w + x1]) * 0.5f) * 0.5f;
+}
+
 #pragma clang force_cuda_host_device end
 } // namespace ptk

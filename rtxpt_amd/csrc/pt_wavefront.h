@@ -42,6 +42,8 @@ void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, fl
 void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const uint* subInstTriOffset, uint numEmissiveSubInst, uint totalTris, uint lightBase,
                           PolymorphicLightInfo* lights, PolymorphicLightInfoEx* lightsEx, hipStream_t st);
 void launch_tonemap(const float4* accum, uint num, const ToneMapParams& p, uint* outRgba8, hipStream_t st);
+// scratch: 2 * pow2floor(W) * pow2floor(H) floats; *result points at the 1x1 mip inside scratch once the stream has drained
+void launch_average_log_luminance(const float4* accum, uint W, uint H, float* scratch, float** result, hipStream_t st);
 void launch_probe(const PathKernelContext& k, int kind, const void* dIn, void* dOut, uint n, hipStream_t st);
 
 } // namespace ptk

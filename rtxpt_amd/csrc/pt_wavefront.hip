@@ -394,6 +394,26 @@ __global__ void __launch_bounds__(256) k_tonemap(const float4* __restrict__ accu
 void launch_tonemap(const float4* accum, uint num, const ToneMapParams& p, uint* outRgba8, hipStream_t st) {
     hipLaunchKernelGGL(k_tonemap, dim3((num + 255) / 256), dim3(256), 0, st, accum, num, p, outRgba8);
 }
+// auto-exposure luminance capture: log-luminance target, then its mip chain down to 1x1 (ping-pong between the two halves of `scratch`)
+__global__ void __launch_bounds__(256) k_log_luminance(const float4* __restrict__ accum, uint W, uint H, uint LW, uint LH, float* __restrict__ out) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i < LW * LH) out[i] = tm_log_luminance_texel(accum, W, H, LW, LH, i % LW, i / LW);
+}
+__global__ void __launch_bounds__(256) k_luminance_mip(const float* __restrict__ src, uint w, uint h, uint ow, uint oh, float* __restrict__ dst) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i < ow * oh) dst[i] = tm_mip_texel(src, w, h, i % ow, i / ow);
+}
+void launch_average_log_luminance(const float4* accum, uint W, uint H, float* scratch, float** result, hipStream_t st) {
+    uint w = tm_pow2_floor(W), h = tm_pow2_floor(H);
+    float* a = scratch; float* b = scratch + (size_t)w * h;
+    hipLaunchKernelGGL(k_log_luminance, dim3((w * h + 255) / 256), dim3(256), 0, st, accum, W, H, w, h, a);
+    while (w > 1u || h > 1u) {
+        uint ow = w > 1u ? w / 2u : 1u, oh = h > 1u ? h / 2u : 1u;
+        hipLaunchKernelGGL(k_luminance_mip, dim3((ow * oh + 255) / 256), dim3(256), 0, st, a, w, h, ow, oh, b);
+        float* t = a; a = b; b = t; w = ow; h = oh;
+    }
+    *result = a;
+}
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st) {
     uint total = numOwned * spp;
     hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, st, k, pool, ownedPixels, numOwned, sampleFirst, spp, queue);

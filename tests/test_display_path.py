@@ -149,3 +149,43 @@ def test_gpu_tonemap_equals_oracle_for_every_operator(tmp_path):
     shot = str(tmp_path / "c2.png")
     pt.write_image(shot, g.tonemap())
     assert (_decode_png(shot) == ptref.tonemap(rad, pt.default_tonemap())).all()
+
+
+def test_oracle_average_luminance_properties():
+    """The oracle of the luminance capture on images whose answer is known: a constant image, the 1e-4 floor, a power-of-two image (no resampling: the
+    geometric mean of the luminances), and a non-power-of-two one against a direct per-texel evaluation."""
+    assert abs(ptref.average_luminance(np.full((37, 91, 4), 0.5, np.float32)) - 0.5) < 1e-12
+    assert abs(ptref.average_luminance(np.zeros((16, 16, 4), np.float32)) - 1e-4) < 1e-15
+    rng = np.random.default_rng(3)
+    img = np.exp(rng.uniform(-6, 3, size=(32, 64, 4))).astype(np.float32)
+    lum = img[..., :3].astype(np.float64) @ np.array([0.299, 0.587, 0.114])
+    assert abs(ptref.average_luminance(img) / np.exp(np.mean(np.log(lum))) - 1) < 1e-12
+    img = np.exp(rng.uniform(-6, 3, size=(5, 7, 4))).astype(np.float32)       # 7x5 -> 4x4 target
+    acc = 0.0
+    for y in range(4):
+        for x in range(4):
+            sx, sy = (x + 0.5) / 4 * 7 - 0.5, (y + 0.5) / 4 * 5 - 0.5
+            x0, y0 = int(np.floor(sx)), int(np.floor(sy)); fx, fy = sx - x0, sy - y0
+            px = lambda yy, xx: img[min(max(yy, 0), 4), min(max(xx, 0), 6), :3].astype(np.float64)
+            c = (px(y0, x0) * (1 - fx) + px(y0, x0 + 1) * fx) * (1 - fy) + (px(y0 + 1, x0) * (1 - fx) + px(y0 + 1, x0 + 1) * fx) * fy
+            acc += np.log2(max(1e-4, c @ np.array([0.299, 0.587, 0.114])))
+    assert abs(ptref.average_luminance(img) / 2.0 ** (acc / 16) - 1) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(96, 64), (100, 70), (64, 33), (1, 1), (257, 3)])
+def test_gpu_average_luminance_matches_oracle(size):
+    """pt_average_luminance (k_log_luminance + k_luminance_mip) against the float64 oracle. Tolerance 2e-5 relative: the kernel works in fp32 (bilinear
+    weights, dm_log2, pairwise averages), and the reference's own texture-unit filter is fixed-point, so this quantity is defined to tolerance only."""
+    from rtxpt_amd import scenes
+    sc, cam = scenes.cornell_box("C2")
+    W, H = size
+    g = pt.PathTracer(device=0)
+    g.set_scene(sc); g.set_camera(scenes.bridge_camera(W, H, **cam)); g.set_settings(scenes.config_settings("C2")); g.resize(W, H)
+    g.render(0, 2)
+    rad = g.radiance()
+    got, want = g.average_luminance(), ptref.average_luminance(rad)
+    assert np.isfinite(got) and got > 0 and abs(got / want - 1) < 2e-5, (size, got, want)
+    # and it feeds the tone mapper the way TONEMAPPING_AUTOEXPOSURE_CPU does
+    t = pt.default_tonemap(autoExposure=1, avgLuminance=got)
+    assert (g.tonemap(t) == ptref.tonemap(rad, t)).all()
