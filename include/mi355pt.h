@@ -222,6 +222,7 @@ int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo*
    glTF-embedded cameras / lights, analytic-light proxies (counted in info), textures other than 8-bit PNG (counted in texturesNotLoaded, the
    material then renders untextured as when the reference fails to load one). The environment map is reported, not loaded (.exr / .dds). */
 typedef struct pt_scene_import pt_scene_import;
+typedef struct PtToneMappingParameters PtToneMappingParameters;      /* defined with the display path below */
 typedef struct PtSceneCameraDesc {          /* Sample::UpdateCameraFromScene inputs: LookAt(position, position + direction, up) */
     float    position[3], direction[3], up[3];
     float    verticalFov, zNear;            /* radians; Donut defaults 1.0 / 1.0 */
@@ -249,6 +250,11 @@ int32_t pt_scene_import_materials(const pt_scene_import* scene, PTMaterialData* 
 /* SampleSettings -> PtSettings as Sample::SceneLoaded applies them (Sample.cpp:613-629): maxBounces, maxDiffuseBounces, textureMIPBias overwrite
    bounceCount, diffuseBounceCount, texLODBias when the scene names them; everything else in *settings is left alone. */
 int32_t pt_scene_import_settings(const pt_scene_import* scene, PtSettings* settings);
+/* The tone-mapping block after a scene load: Sample::SceneLoaded sets exposureCompensation = 2, exposureValue = 0 ("sensible defaults",
+   Sample.cpp:547-549), then — when the scene has a camera — Sample::UpdateCameraFromScene (:467-478) overwrites autoExposure, exposureCompensation,
+   exposureValue, exposureValueMin / Max with the camera node's keys or, for a missing key, the ToneMappingParameters DEFAULT (so a camera without
+   exposure keys resets the compensation to 0). cameraIndex < 0: the import's selected camera. The other members of *ui are left alone. */
+int32_t pt_scene_import_tone_mapping(const pt_scene_import* scene, int32_t cameraIndex, PtToneMappingParameters* ui);
 /* pt_set_materials + pt_set_geometry + pt_set_instances + pt_set_lights on ctx (camera, environment and settings stay with the caller) */
 int32_t pt_scene_import_apply(pt_context* ctx, const pt_scene_import* scene);
 
@@ -266,6 +272,23 @@ int32_t pt_default_tonemap(PtToneMapParams* out, float exposureCompensation, flo
 int32_t pt_tonemap_color_transform(PtToneMapParams* params, uint32_t whiteBalance, float whitePoint, float exposureCompensation, float filmSpeed,
                                    float shutter, float fNumber);
 int32_t pt_tonemap(pt_context* ctx, const PtToneMapParams* params, uint8_t* rgba8, size_t bytes);
+/* The tone mapper's UI block (ToneMappingParameters, ToneMappingPasses.h:36-53; the reference keeps it in m_ui.ToneMappingParams) and
+   ToneMappingPass::PreRender + the constant fill of ::Render on it (ToneMappingPasses.cpp:186-193, 316-348, 373-441): exposureValue is clamped to the
+   range shutter x fNumber^2 allows; in aperture priority (exposureMode 0, the default) the shutter is DERIVED as 2^EV / fNumber^2 and `shutter` is
+   ignored, in shutter priority fNumber = sqrt(2^EV / shutter); then white balance and exposure scales as in pt_tonemap_color_transform; the
+   auto-exposure luminance limits are exp2(exposureValueMin/Max) with auto exposure, exp2(-/+16) without. avgLuminance: pt_average_luminance (only
+   read when autoExposure is set); enabled: m_ui.EnableToneMapping. Host only. */
+typedef struct PtToneMappingParameters {
+    uint32_t exposureMode;                  /* 0 AperturePriority, 1 ShutterPriority */
+    uint32_t toneMapOperator;               /* ToneMapperOperator, default Aces (5) */
+    uint32_t autoExposure;
+    float    exposureCompensation, exposureValue, filmSpeed, fNumber, shutter;
+    uint32_t whiteBalance; float whitePoint, whiteMaxLuminance, whiteScale;
+    uint32_t clamped;
+    float    exposureValueMin, exposureValueMax;
+} PtToneMappingParameters;
+int32_t pt_default_tone_mapping_parameters(PtToneMappingParameters* out);
+int32_t pt_tonemap_from_parameters(const PtToneMappingParameters* ui, float avgLuminance, uint32_t enabled, PtToneMapParams* out);
 /* Auto exposure, the luminance capture of ToneMappingPass::Render (ToneMappingPasses.cpp:78-97, 225-288; luminance_ps.hlsl:10-26; capture_cs,
    ToneMapping.hlsl:25-34): log2(max(1e-4, luminance)) of THIS context's accumulation buffer drawn through the linear sampler into a target of
    power-of-two-lowered size, averaged down its mip chain; avgLuminance = exp2(last mip) is what TONEMAPPING_AUTOEXPOSURE_CPU puts into

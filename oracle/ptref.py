@@ -257,6 +257,34 @@ def reference_color_transform(white_balance, white_point, auto_exposure, exposur
     return out
 
 
+def reference_tonemap_constants(ui_words, avg_luminance, enabled):
+    """ToneMappingPass::PreRender (SetParameters, UpdateExposureValue, UpdateWhiteBalanceTransform, UpdateColorTransform) and the constant fill of ::Render
+    (Rtxpt/ToneMapper/ToneMappingPasses.cpp:186-193, 316-348, 373-441), compiled as they stand, on the 15 words of the product's PtToneMappingParameters.
+    Returns the first 21 words of ToneMappingConstants (8 scalars, 3x4 colour transform, enabled), or None when unavailable."""
+    if not os.path.exists(_PIN_MAT):
+        if os.path.isdir("/root/reference/Rtxpt/Shaders"):
+            build()
+        if not os.path.exists(_PIN_MAT):
+            return None
+    L = ctypes.CDLL(_PIN_MAT)
+    if not hasattr(L, "reftonemap_constants"):
+        return None
+    u = np.ascontiguousarray(ui_words, np.uint32); out = np.zeros(21, np.uint32)
+    L.reftonemap_constants.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+    L.reftonemap_constants(u.ctypes.data_as(ctypes.c_void_p), avg_luminance, int(enabled), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def reference_tonemap_defaults():
+    """ToneMappingParameters{} of the reference (ToneMappingPasses.h:36-53) as the 15 words of PtToneMappingParameters, or None when unavailable."""
+    if not os.path.exists(_PIN_MAT):
+        return None
+    L = ctypes.CDLL(_PIN_MAT)
+    if not hasattr(L, "reftonemap_defaults"):
+        return None
+    out = np.zeros(15, np.uint32); L.reftonemap_defaults(out.ctypes.data_as(ctypes.c_void_p)); return out
+
+
 def average_luminance(rgba):
     """ORACLE (numpy float64) of the auto-exposure luminance capture: ToneMappingPasses.cpp:78-97 (target lowered to powers of two), luminance_ps.hlsl:10-26
     (log2(max(1e-4, dot(color, (0.299, 0.587, 0.114)))) of the colour target through the linear sampler, clamp addressing), mip chain of 2x2 averages down to 1x1

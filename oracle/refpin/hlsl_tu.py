@@ -273,9 +273,21 @@ def main_materials(ref):
     w(open(os.path.join(HERE, "color_stubs.inc")).read())
     cu = strip_comments(open(os.path.join(ref, "Rtxpt/ToneMapper/ColorUtils.h"), encoding="latin-1").read())
     w("\n".join(l for l in cu.split("\n") if not re.match(r"\s*#\s*(include|pragma)", l)) + "\n")
-    tp = strip_comments(open(os.path.join(ref, "Rtxpt/ToneMapper/ToneMappingPasses.cpp"), encoding="latin-1").read())
-    for name in ("ToneMappingPass::UpdateWhiteBalanceTransform", "ToneMappingPass::UpdateColorTransform"):
+    cb = strip_comments(open(os.path.join(ref, "Rtxpt/ToneMapper/ToneMapping_cb.h"), encoding="latin-1").read())
+    th = strip_comments(open(os.path.join(ref, "Rtxpt/ToneMapper/ToneMappingPasses.h"), encoding="latin-1").read())
+    w("\n".join(l for l in cb.split("\n") if re.match(r"\s*#\s*define\s+TONEMAPPING_(AUTOEXPOSURE_CPU|EXPOSURE_KEY)\b", l)) + "\n")
+    for text, name, path in ((cb, "ToneMapperOperator", "ToneMapping_cb.h"), (cb, "ToneMappingConstants", "ToneMapping_cb.h"), (th, "ExposureMode", "ToneMappingPasses.h"),
+                             (th, "ToneMappingParameters", "ToneMappingPasses.h")):
+        w(extract_struct(text, name, path) + "\n")
+    w("COLORPIN_TONEMAPPINGPASS\n")
+    traw = open(os.path.join(ref, "Rtxpt/ToneMapper/ToneMappingPasses.cpp"), encoding="latin-1").read(); tp = strip_comments(traw)
+    for name in ("ToneMappingPass::SetParameters", "ToneMappingPass::UpdateExposureValue", "ToneMappingPass::UpdateWhiteBalanceTransform", "ToneMappingPass::UpdateColorTransform",
+                 "ToneMappingPass::PreRender"):
         for body in extract_function(tp, name, "ToneMappingPasses.cpp"): w(body + "\n")
+    # the constant-buffer fill inside ToneMappingPass::Render, as a member function of the stand-in
+    w("ToneMappingConstants ToneMappingPass::FillConstants(uint viewIndex, bool enabled) {\n")
+    w(extract_range(tp, r"ToneMappingConstants toneMappingConsts = \{\};..commandList->writeBuffer\(m_ToneMappingCB", "ToneMappingPasses.cpp", traw) + "\n")
+    w("    return toneMappingConsts;\n}\n")
     w(open(os.path.join(HERE, "color_wrappers.inc")).read())
 
 

@@ -31,6 +31,7 @@ EXPORTS = [
     "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
+    "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
 ]
 
 
@@ -116,6 +117,36 @@ def default_tonemap(exposure_compensation=0.0, film_speed=100.0, shutter=1.0, f_
         raise PtError(r, "pt_default_tonemap")
     for k, v in kw.items():
         t[k] = TONEMAP_OPERATORS[v] if (k == "toneMapOperator" and isinstance(v, str)) else v
+    return t
+
+
+TONE_MAPPING_PARAMETERS_DTYPE = np.dtype([("exposureMode", "<u4"), ("toneMapOperator", "<u4"), ("autoExposure", "<u4"), ("exposureCompensation", "<f4"), ("exposureValue", "<f4"),
+                                          ("filmSpeed", "<f4"), ("fNumber", "<f4"), ("shutter", "<f4"), ("whiteBalance", "<u4"), ("whitePoint", "<f4"), ("whiteMaxLuminance", "<f4"),
+                                          ("whiteScale", "<f4"), ("clamped", "<u4"), ("exposureValueMin", "<f4"), ("exposureValueMax", "<f4")])
+assert TONE_MAPPING_PARAMETERS_DTYPE.itemsize == 60
+
+
+def default_tone_mapping_parameters(**kw):
+    """pt_default_tone_mapping_parameters: ToneMappingParameters{} (ToneMappingPasses.h:36-53) as a TONE_MAPPING_PARAMETERS_DTYPE record. No device needed."""
+    L = load_library()
+    u = np.zeros((), dtype=TONE_MAPPING_PARAMETERS_DTYPE)
+    L.pt_default_tone_mapping_parameters.argtypes = [ctypes.c_void_p]
+    r = L.pt_default_tone_mapping_parameters(_p(u))
+    if r != 0:
+        raise PtError(r, "pt_default_tone_mapping_parameters")
+    for k, v in kw.items():
+        u[k] = TONEMAP_OPERATORS[v] if (k == "toneMapOperator" and isinstance(v, str)) else v
+    return u
+
+
+def tonemap_from_parameters(ui, avg_luminance=1.0, enabled=True):
+    """pt_tonemap_from_parameters: ToneMappingPass::PreRender + the constant fill of ::Render on a ToneMappingParameters block -> TONEMAP_DTYPE record."""
+    L = load_library()
+    t = np.zeros((), dtype=TONEMAP_DTYPE)
+    L.pt_tonemap_from_parameters.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]
+    r = L.pt_tonemap_from_parameters(_p(ui), avg_luminance, 1 if enabled else 0, _p(t))
+    if r != 0:
+        raise PtError(r, "pt_tonemap_from_parameters")
     return t
 
 
@@ -213,6 +244,15 @@ class SceneImport:
         self.L.pt_scene_import_lights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         assert self.L.pt_scene_import_lights(self.h, _p(self.lights), _p(self.lights_ex), n) == n
         self.lights, self.lights_ex = self.lights[:n], self.lights_ex[:n]
+
+    def tone_mapping(self, ui=None, camera=-1):
+        """pt_scene_import_tone_mapping: Sample::SceneLoaded's exposure defaults + Sample::UpdateCameraFromScene on a ToneMappingParameters record."""
+        ui = default_tone_mapping_parameters() if ui is None else ui
+        self.L.pt_scene_import_tone_mapping.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        r = self.L.pt_scene_import_tone_mapping(self.h, int(camera), _p(ui))
+        if r != 0:
+            raise PtError(r, "pt_scene_import_tone_mapping")
+        return ui
 
     def apply_settings(self, settings):
         """pt_scene_import_settings: the scene's SampleSettings keys written over a SETTINGS_DTYPE record (in place)."""

@@ -581,8 +581,8 @@ struct SceneReader {
         } else if (type == "SampleSettings") {                                               // ExtendedScene.cpp:347-356 (the last node wins, :243-247)
             I.settingsMask = 0;
             bool b;
-            if (const JValue* j = n.get("realtimeMode")) if (j->type == JValue::Bool) { b = j->b; I.realtimeMode = b; I.settingsMask |= 1u; }
-            if (const JValue* j = n.get("enableAnimations")) if (j->type == JValue::Bool) { b = j->b; I.enableAnimations = b; I.settingsMask |= 2u; }
+            if (const JValue* j = n.get("realtimeMode")) if (j->type == JValue::Bool || j->type == JValue::Num) { b = false; jload(n, "realtimeMode", b); I.realtimeMode = b; I.settingsMask |= 1u; }
+            if (const JValue* j = n.get("enableAnimations")) if (j->type == JValue::Bool || j->type == JValue::Num) { b = false; jload(n, "enableAnimations", b); I.enableAnimations = b; I.settingsMask |= 2u; }
             if (const JValue* j = n.get("startingCamera")) if (j->type == JValue::Num) { I.startingCamera = (int32_t)j->num; I.settingsMask |= 4u; }
             if (const JValue* j = n.get("realtimeFireflyFilter")) if (j->type == JValue::Num) { I.realtimeFireflyFilter = (float)j->num; I.settingsMask |= 8u; }
             if (const JValue* j = n.get("maxBounces")) if (j->type == JValue::Num) { I.maxBounces = (int32_t)j->num; I.settingsMask |= 16u; }
@@ -664,6 +664,20 @@ extern "C" int32_t pt_scene_import_settings(const pt_scene_import* S, PtSettings
     if ((I.settingsMask & 16u) && I.maxBounces >= 0) settings->bounceCount = (uint32_t)I.maxBounces;
     if ((I.settingsMask & 32u) && I.maxDiffuseBounces >= 0) settings->diffuseBounceCount = (uint32_t)I.maxDiffuseBounces;
     if (I.settingsMask & 64u) settings->texLODBias = I.textureMIPBias;
+    return PT_OK;
+}
+extern "C" int32_t pt_scene_import_tone_mapping(const pt_scene_import* S, int32_t cameraIndex, PtToneMappingParameters* ui) {
+    if (!S || !ui) return PT_ERROR_INVALID_ARGUMENT;
+    ui->exposureCompensation = 2.0f; ui->exposureValue = 0.0f;                                  // Sample.cpp:547-549
+    if (cameraIndex < 0) cameraIndex = S->info.selectedCamera;
+    if (cameraIndex < 0) return PT_OK;                                                          // no camera in the scene
+    if ((size_t)cameraIndex >= S->cameras.size()) return PT_ERROR_INVALID_ARGUMENT;
+    const PtSceneCameraDesc& c = S->cameras[(size_t)cameraIndex];                               // every camera leaf is a PerspectiveCameraEx (ExtendedScene.cpp:126-129)
+    ui->autoExposure = (c.exposureMask & 1u) ? c.enableAutoExposure : 0u;
+    ui->exposureCompensation = (c.exposureMask & 2u) ? c.exposureCompensation : 0.0f;
+    ui->exposureValue = (c.exposureMask & 4u) ? c.exposureValue : 0.0f;
+    ui->exposureValueMin = (c.exposureMask & 8u) ? c.exposureValueMin : -16.0f;
+    ui->exposureValueMax = (c.exposureMask & 16u) ? c.exposureValueMax : 16.0f;
     return PT_OK;
 }
 extern "C" int32_t pt_scene_import_apply(pt_context* ctx, const pt_scene_import* S) {

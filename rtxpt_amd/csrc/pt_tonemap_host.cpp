@@ -54,3 +54,36 @@ extern "C" int32_t pt_tonemap_color_transform(PtToneMapParams* params, uint32_t 
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) params->colorTransform[i * 3 + j] = wb.m[j][i] * exposureScale * manualExposureScale;
     return PT_OK;
 }
+
+// ---- ToneMappingParameters (the UI block, ToneMappingPasses.h:36-53) -> the constants ToneMappingPass::Render uploads: PreRender :186-193 =
+// SetParameters :373-390, UpdateExposureValue :402-427 (EV clamped to the range its inputs allow; in aperture priority — the default — the shutter is
+// DERIVED from EV and fNumber, the UI's shutter value is overwritten), UpdateWhiteBalanceTransform, UpdateColorTransform; then the constant-buffer fill
+// :316-348.
+extern "C" int32_t pt_default_tone_mapping_parameters(PtToneMappingParameters* p) {
+    if (!p) return PT_ERROR_INVALID_ARGUMENT;
+    memset(p, 0, sizeof(*p));
+    p->exposureMode = 0u; p->toneMapOperator = 5u; p->autoExposure = 0u; p->exposureCompensation = 0.f; p->exposureValue = 0.f; p->filmSpeed = 100.f; p->fNumber = 1.f; p->shutter = 1.f;
+    p->whiteBalance = 0u; p->whitePoint = 6500.f; p->whiteMaxLuminance = 1.f; p->whiteScale = 5.1f; p->clamped = 1u; p->exposureValueMin = -16.f; p->exposureValueMax = 16.f;
+    return PT_OK;
+}
+extern "C" int32_t pt_tonemap_from_parameters(const PtToneMappingParameters* ui, float avgLuminance, uint32_t enabled, PtToneMapParams* out) {
+    if (!ui || !out || ui->exposureMode > 1u || ui->toneMapOperator > 5u) return PT_ERROR_INVALID_ARGUMENT;
+    auto clampf = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
+    const float kShutterMin = 0.001f, kShutterMax = 10000.f, kFNumberMin = 0.1f, kFNumberMax = 100.f;
+    const float kExposureValueMin = log2f(kShutterMin * kFNumberMin * kFNumberMin), kExposureValueMax = log2f(kShutterMax * kFNumberMax * kFNumberMax);
+    float ev = clampf(ui->exposureValue, kExposureValueMin, kExposureValueMax), shutter = ui->shutter, fNumber = ui->fNumber;
+    if (ui->exposureMode == 0u) { shutter = powf(2.f, ev) / (fNumber * fNumber); shutter = clampf(shutter, kShutterMin, kShutterMax); }
+    else { fNumber = sqrtf(powf(2.f, ev) / shutter); fNumber = clampf(fNumber, kFNumberMin, kFNumberMax); }
+    memset(out, 0, sizeof(*out));
+    out->whiteScale = ui->whiteScale; out->whiteMaxLuminance = ui->whiteMaxLuminance; out->clamped = ui->clamped ? 1u : 0u; out->toneMapOperator = ui->toneMapOperator;
+    out->autoExposure = ui->autoExposure ? 1u : 0u; out->avgLuminance = avgLuminance;
+    out->autoExposureLumValueMin = exp2f(ui->autoExposure ? ui->exposureValueMin : -16.0f); out->autoExposureLumValueMax = exp2f(ui->autoExposure ? ui->exposureValueMax : 16.0f);
+    out->enabled = enabled ? 1u : 0u;
+    M3 wb;
+    if (ui->whiteBalance) wb = whiteBalanceTransformRGB_Rec709(ui->whitePoint);
+    else { memset(&wb, 0, sizeof(wb)); wb.m[0][0] = wb.m[1][1] = wb.m[2][2] = 1.f; }
+    float exposureScale = powf(2.f, ui->exposureCompensation), manualExposureScale = 1.f;
+    if (!ui->autoExposure) manualExposureScale = ((1.f / 100.f) * ui->filmSpeed) / (shutter * fNumber * fNumber);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out->colorTransform[i * 3 + j] = wb.m[j][i] * exposureScale * manualExposureScale;
+    return PT_OK;
+}

@@ -3,6 +3,7 @@ ColorUtils.h / ToneMappingPasses.cpp text (oracle/_ref/librefpin_mat.so, built f
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import ptref
 
 
@@ -19,5 +20,14 @@ def cases():
 if __name__ == "__main__":
     c = cases()
     out = np.stack([ptref.reference_color_transform(int(r[0]), r[1], int(r[2]), r[3], r[4], r[5], r[6]) for r in c])
-    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "color_transform_golden.npz"), cases=c, transform=out)
+    # the whole UI block through ToneMappingPass::PreRender + the constant fill (same generator as tests/test_color_transform.py::_random_ui, same seed)
+    import rtxpt_amd as pt
+    from test_color_transform import _random_ui, _ui_words
+    rng = np.random.default_rng(20260925)
+    consts = []
+    for _ in range(300):
+        u = _random_ui(rng); avg = float(np.float32(rng.uniform(0.01, 4))); en = int(rng.integers(0, 2))
+        consts.append(ptref.reference_tonemap_constants(_ui_words(u), avg, en))
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "color_transform_golden.npz"), cases=c, transform=out,
+                        ui_defaults=ptref.reference_tonemap_defaults(), ui_constants=np.stack(consts))
     print(out.shape, out[1].reshape(3, 3))

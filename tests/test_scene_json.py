@@ -100,6 +100,13 @@ def test_scene_graph_instances_lights_cameras(tmp_path):
     # environment: first EnvironmentLight wins; settings: the seven SampleSettings keys
     assert I["hasEnvironment"] == 1 and I["envPath"] == b"EnvironmentMaps/sky.exr" and np.allclose(I["envRadianceScale"], (2, 2, 1.5)) and I["envRotation"] == 0.25 and I["envTextureIndex"] == -1
     assert I["settingsMask"] == (2 | 4 | 8 | 16) and I["maxBounces"] == 7 and I["startingCamera"] == 0 and I["realtimeFireflyFilter"] == 0.5 and I["enableAnimations"] == 1
+    # tone-mapping block after the load (Sample.cpp:547-549 + UpdateCameraFromScene :467-478)
+    ui = imp.tone_mapping(pt.default_tone_mapping_parameters(exposureValueMin=-3.0, whiteScale=7.0))
+    assert ui["autoExposure"] == 0 and ui["exposureCompensation"] == 1.5 and ui["exposureValue"] == -2.0 and ui["exposureValueMin"] == -16.0 and ui["exposureValueMax"] == 16.0 and ui["whiteScale"] == 7.0
+    ui = imp.tone_mapping(pt.default_tone_mapping_parameters(exposureCompensation=5.0, autoExposure=1), camera=1)      # a camera without exposure keys resets to the defaults
+    assert ui["autoExposure"] == 0 and ui["exposureCompensation"] == 0.0 and ui["exposureValue"] == 0.0
+    with pytest.raises(pt.PtError):
+        imp.tone_mapping(camera=7)
     st = scenes.default_settings(); before = st.copy()
     imp.apply_settings(st)
     assert st["bounceCount"] == 7 and st["diffuseBounceCount"] == before["diffuseBounceCount"] and st["texLODBias"] == before["texLODBias"]
@@ -176,6 +183,7 @@ def test_media_path_argument_and_errors(tmp_path):
         pt.SceneImport(media / "missing.scene.json")
     (media / "empty.scene.json").write_text(json.dumps({"models": [], "graph": []}))
     e = pt.SceneImport(media / "empty.scene.json")
+    assert e.tone_mapping()["exposureCompensation"] == 2.0 and e.tone_mapping(pt.default_tone_mapping_parameters(exposureValue=3.0))["exposureValue"] == 0.0      # no camera: the "sensible defaults"
     assert e.info["numInstances"] == 0 and e.info["selectedCamera"] == -1 and e.info["hasEnvironment"] == 0
 
 
