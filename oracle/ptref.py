@@ -275,6 +275,31 @@ def reference_tonemap_constants(ui_words, avg_luminance, enabled):
     return out
 
 
+def reference_scene_leaves(text):
+    """The leaves of a `.scene.json` graph through the reference's own ExtendedSceneTypeFactory::CreateLeaf and Load functions (ExtendedScene.cpp), then the
+    scene-dependent part of Sample::SceneLoaded / UpdateCameraFromScene (Sample.cpp:457-479, 547-549, 566-573, 613-629), compiled as they stand over Donut
+    stand-ins (oracle/refpin/scene_stubs.inc). Returns a dict, or None when unavailable."""
+    if not os.path.exists(_PIN_MAT):
+        if os.path.isdir("/root/reference/Rtxpt/Shaders"):
+            build()
+        if not os.path.exists(_PIN_MAT):
+            return None
+    L = ctypes.CDLL(_PIN_MAT)
+    if not hasattr(L, "refscene_leaves"):
+        return None
+    I = np.zeros(16, np.int32); F = np.zeros(24, np.float32); lights = np.zeros((16, 12), np.uint32); path = ctypes.create_string_buffer(260)
+    L.refscene_leaves.argtypes = [ctypes.c_char_p] + [ctypes.c_void_p] * 4
+    r = L.refscene_leaves(text.encode(), I.ctypes.data_as(ctypes.c_void_p), F.ctypes.data_as(ctypes.c_void_p), lights.ctypes.data_as(ctypes.c_void_p), path)
+    if r != 0:
+        raise RuntimeError("refscene_leaves: %d" % r)
+    return {"numLights": int(I[0]), "numCameras": int(I[1]), "hasEnvironment": int(I[2]), "envTextureIndex": int(I[3]), "selectedCameraIndex": int(I[4]), "realtimeMode": int(I[5]),
+            "enableAnimations": int(I[6]), "realtimeFireflyFilterEnabled": int(I[7]), "bounceCount": int(I[8]), "diffuseBounceCount": int(I[9]), "autoExposure": int(I[10]),
+            "proxies": int(I[11]), "directional": int(I[12]), "envRadianceScale": F[0:3].copy(), "envRotation": float(F[3]), "envPath": path.value.decode(),
+            "cameraPos": F[4:7].copy(), "cameraTarget": F[7:10].copy(), "cameraUp": F[10:13].copy(), "verticalFov": float(F[13]), "zNear": float(F[14]),
+            "exposureCompensation": float(F[15]), "exposureValue": float(F[16]), "exposureValueMin": float(F[17]), "exposureValueMax": float(F[18]),
+            "realtimeFireflyFilterThreshold": float(F[19]), "texLODBias": float(F[20]), "lights": lights[:min(int(I[0]), 16)].copy()}
+
+
 def reference_tonemap_defaults():
     """ToneMappingParameters{} of the reference (ToneMappingPasses.h:36-53) as the 15 words of PtToneMappingParameters, or None when unavailable."""
     if not os.path.exists(_PIN_MAT):

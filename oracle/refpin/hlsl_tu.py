@@ -122,7 +122,7 @@ def match_brace(text, i):
 def extract_struct(text, spec, path):
     parts = spec.split()
     name, drop = parts[0], [p[1:] for p in parts[1:] if p.startswith("-")]
-    m = re.search(r"^[ \t]*(?:struct|enum class|enum)\s+" + re.escape(name) + r"\b[^{;]*\{", text, re.M)
+    m = re.search(r"^[ \t]*(?:struct|class|enum class|enum)\s+" + re.escape(name) + r"\b[^{;]*\{", text, re.M)
     if not m: raise SystemExit("hlsl_tu.py: struct %s not found in %s" % (name, path))
     end = match_brace(text, m.end() - 1)
     body = text[m.start():end + 1] + ";"
@@ -288,6 +288,26 @@ def main_materials(ref):
     w("ToneMappingConstants ToneMappingPass::FillConstants(uint viewIndex, bool enabled) {\n")
     w(extract_range(tp, r"ToneMappingConstants toneMappingConsts = \{\};..commandList->writeBuffer\(m_ToneMappingCB", "ToneMappingPasses.cpp", traw) + "\n")
     w("    return toneMappingConsts;\n}\n")
+    # scene leaves: ExtendedScene.{h,cpp} classes + Load functions + CreateLeaf + FindEnvironmentLight, and the ranges of Sample.cpp that consume them
+    w(open(os.path.join(HERE, "scene_stubs.inc")).read())
+    eh = strip_comments(open(os.path.join(ref, "Rtxpt/SampleCommon/ExtendedScene.h"), encoding="latin-1").read()).replace("[[nodiscard]]", "")
+    for name in ("LightSamplerLink", "LightExtension", "SpotLightEx", "PointLightEx", "EnvironmentLight", "PerspectiveCameraEx", "SampleSettings"):
+        w(extract_struct(eh, name, "ExtendedScene.h") + "\n")
+    w("SCENEPIN_EXTRA_LEAVES\n")
+    ecraw = open(os.path.join(ref, "Rtxpt/SampleCommon/ExtendedScene.cpp"), encoding="latin-1").read(); ec = strip_comments(ecraw)
+    for name in ("LightExtension::Load", "SpotLightEx::Load", "PointLightEx::Load", "EnvironmentLight::Load", "PerspectiveCameraEx::Load", "SampleSettings::Load"):
+        for body in extract_function(ec, name, "ExtendedScene.cpp"): w(body + "\n")
+    w(extract_range(ec, r"ExtendedSceneTypeFactory::CreateLeaf\(..ExtendedSceneTypeFactory::CreateMesh\(\)", "ExtendedScene.cpp", ecraw) + "\n")
+    w(extract_range(ec, r"^std::shared_ptr<EnvironmentLight> FindEnvironmentLight..^void EnvironmentLight::FillLightConstants", "ExtendedScene.cpp", ecraw) + "\n")
+    sc = strip_comments(open(os.path.join(ref, "Rtxpt/SampleCommon/SampleCommon.cpp"), encoding="latin-1").read())
+    w(extract_range(sc, r"^std::vector<std::string> JsonLoadStringVector..^uint64_t GetEstimatedTextureSize", "SampleCommon.cpp") + "\n")
+    w(open(os.path.join(HERE, "scene_wrappers.inc")).read())
+    smraw = open(os.path.join(ref, "Rtxpt/Sample.cpp"), encoding="latin-1").read(); sm = strip_comments(smraw)
+    for body in extract_function(sm, "Sample::UpdateCameraFromScene", "Sample.cpp"): w(body + "\n")
+    w("void Sample::SensibleDefaults() {\n" + extract_range(sm, r"m_ui\.ToneMappingParams\.exposureCompensation = 2\.0f;..std::shared_ptr<EnvironmentLight> envLight = FindEnvironmentLight", "Sample.cpp", smraw) + "\n}\n")
+    w("void Sample::CleanUpLights() {\n" + extract_range(sm, r"for \(int i = \(int\)m_lights\.size\(\)..if\( m_envMapLocalPath != \"\" \)", "Sample.cpp", smraw) + "\n}\n")
+    w("void Sample::ApplySettings() {\n" + extract_range(sm, r"std::shared_ptr<SampleSettings> settings = m_scene->GetSampleSettingsNode\(\);..if \(m_cmdLine\.stopAnimations\)", "Sample.cpp", smraw) + "\n}\n")
+    w(open(os.path.join(HERE, "scene_driver.inc")).read())
     w(open(os.path.join(HERE, "color_wrappers.inc")).read())
 
 

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <filesystem>
 #include <map>
+#include <optional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -19,6 +20,8 @@ namespace Json {
 struct Value {
     enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
     bool b = false; double num = 0; std::string str; std::vector<Value> arr; std::map<std::string, Value> obj;
+    bool isArray() const { return kind == Array; } size_t size() const { return arr.size(); } std::string asString() const { return str; }
+    std::vector<Value>::const_iterator begin() const { return arr.begin(); } std::vector<Value>::const_iterator end() const { return arr.end(); }
     bool empty() const { return kind == Null || (kind == Array && arr.empty()) || (kind == Object && obj.empty()); }
     Value operator[](const std::string& k) const { if (kind != Object) return Value(); auto it = obj.find(k); return it == obj.end() ? Value() : it->second; }
 };

@@ -213,3 +213,95 @@ def test_scene_json_frame_equals_raw_buffer_frame(tmp_path):
         frames.append(p.radiance().copy()); p.close()
     assert np.isfinite(frames[0]).all() and frames[0][..., :3].max() > 0
     assert np.array_equal(frames[0], frames[1])
+
+
+# ---- the reference-tree half of the import against the reference's own text
+def _random_leaf_graph(rng):
+    def maybe(p=0.6):
+        return rng.random() < p
+
+    def f(lo, hi):
+        return float(np.float32(rng.uniform(lo, hi)))
+    nodes = []
+    for _ in range(int(rng.integers(0, 7))):
+        kind = ["SpotLight", "PointLight", "DirectionalLight"][int(rng.integers(0, 3))]
+        n = {"name": "l%d" % len(nodes), "type": kind}
+        if maybe(): n["color"] = [f(0, 2), f(0, 2), f(0, 2)] if maybe(0.7) else f(0, 2)
+        if maybe(0.8): n["intensity"] = 0.0 if maybe(0.15) else f(0.1, 100)
+        if kind != "DirectionalLight" or maybe(0.2): n["radius"] = f(0.01, 0.5)
+        elif maybe(): n["irradiance"] = 0.0 if maybe(0.3) else f(0.1, 5)
+        if maybe(): n["innerAngle"] = f(1, 40)
+        if maybe(): n["outerAngle"] = f(41, 120) * (-1.0 if maybe(0.2) else 1.0)
+        if maybe(0.3): n["proxyMeshNodes"] = ["/a", "/b"][:int(rng.integers(1, 3))]
+        if kind == "SpotLight" and "radius" not in n: n["radius"] = f(0.01, 0.5)       # the reference asserts on spots without radius
+        nodes.append(n)
+    for _ in range(int(rng.integers(0, 4))):
+        n = {"name": "c%d" % len(nodes), "type": ["PerspectiveCamera", "PerspectiveCameraEx"][int(rng.integers(0, 2))], "translation": [f(-5, 5), f(-5, 5), f(-5, 5)]}
+        if maybe(): n["verticalFov"] = f(0.2, 2.0)
+        if maybe(): n["zNear"] = f(0.001, 1.0)
+        if maybe(0.5): n["enableAutoExposure"] = bool(maybe(0.5)) if maybe(0.8) else 1
+        for k in ("exposureCompensation", "exposureValue", "exposureValueMin", "exposureValueMax"):
+            if maybe(0.4): n[k] = f(-8, 8)
+        nodes.append(n)
+    for _ in range(int(rng.integers(0, 3))):
+        n = {"type": "EnvironmentLight", "path": "env%d.exr" % len(nodes)}
+        if maybe(): n["radianceScale"] = [f(0, 4), f(0, 4), f(0, 4)] if maybe(0.5) else f(0, 4)
+        if maybe(): n["rotation"] = f(0, 6.28)
+        if maybe(0.3): n["textureIndex"] = int(rng.integers(0, 5))
+        nodes.append(n)
+    for _ in range(int(rng.integers(0, 3))):
+        n = {"type": "SampleSettings"}
+        if maybe(0.4): n["realtimeMode"] = bool(maybe(0.5))
+        if maybe(0.4): n["enableAnimations"] = bool(maybe(0.5))
+        if maybe(0.5): n["startingCamera"] = int(rng.integers(0, 4))
+        if maybe(0.4): n["realtimeFireflyFilter"] = f(0.05, 2)
+        if maybe(0.5): n["maxBounces"] = int(rng.integers(1, 40))
+        if maybe(0.5): n["maxDiffuseBounces"] = int(rng.integers(0, 6))
+        if maybe(0.4): n["textureMIPBias"] = f(-2, 2)
+        nodes.append(n)
+    nodes.append({"type": "GameSettings", "x": 1}); nodes.append({"type": "SomethingElse"})
+    order = rng.permutation(len(nodes))
+    nodes = [nodes[i] for i in order]
+    # nest a few under a group node to exercise the traversal order
+    if len(nodes) > 3:
+        k = int(rng.integers(1, len(nodes) - 1))
+        nodes = nodes[:k] + [{"name": "group", "children": nodes[k:k + 2]}] + nodes[k + 2:]
+    return nodes
+
+
+def test_scene_leaves_match_reference_text(tmp_path):
+    from oracle import ptref
+    if ptref.reference_scene_leaves(json.dumps({"graph": []})) is None:
+        pytest.skip("oracle/_ref/librefpin_mat.so not built (no /root/reference here)")
+    rng = np.random.default_rng(2026)
+    (tmp_path / "m").mkdir()
+    for case in range(300):
+        graph = _random_leaf_graph(rng)
+        doc = json.dumps({"models": [], "graph": graph})
+        path = tmp_path / "m" / "leaves.scene.json"; path.write_text(doc)
+        ref = ptref.reference_scene_leaves(doc)
+        imp = pt.SceneImport(path); I = imp.info
+        ctx = (case, doc)
+        assert I["numLights"] == ref["numLights"] and I["directionalLights"] >= ref["directional"] and I["lightProxies"] == ref["proxies"], ctx
+        n = min(int(I["numLights"]), 16)
+        assert np.array_equal(np.concatenate([imp.lights, imp.lights_ex], axis=1)[:n], ref["lights"][:n]), ctx
+        assert I["numCameras"] == ref["numCameras"] and I["hasEnvironment"] == ref["hasEnvironment"], ctx
+        if ref["hasEnvironment"]:
+            assert bytes(I["envPath"]).split(b"\0")[0].decode() == ref["envPath"] and np.array_equal(I["envRadianceScale"], ref["envRadianceScale"]) and I["envRotation"] == ref["envRotation"] and I["envTextureIndex"] == ref["envTextureIndex"], ctx
+        # settings as Sample::SceneLoaded applies them to the reference's UI defaults (BounceCount 20, DiffuseBounceCount 2, TexLODBias -1)
+        st = scenes.default_settings(); st["bounceCount"], st["diffuseBounceCount"], st["texLODBias"] = 20, 2, -1.0
+        imp.apply_settings(st)
+        assert st["bounceCount"] == ref["bounceCount"] and st["diffuseBounceCount"] == ref["diffuseBounceCount"] and st["texLODBias"] == np.float32(ref["texLODBias"]), ctx
+        assert (int(I["realtimeMode"]) if I["settingsMask"] & 1 else 1) == ref["realtimeMode"] and (int(I["enableAnimations"]) if I["settingsMask"] & 2 else 0) == ref["enableAnimations"], ctx
+        if I["settingsMask"] & 8:
+            assert I["realtimeFireflyFilter"] == np.float32(ref["realtimeFireflyFilterThreshold"]), ctx
+        assert (int(I["startingCamera"]) + 1 if I["settingsMask"] & 4 else 0) == ref["selectedCameraIndex"], ctx
+        # camera + tone-mapping block of the camera the reference ends up on
+        if I["numCameras"]:
+            c = imp.cameras[int(I["selectedCamera"])]
+            assert np.array_equal(c["position"], ref["cameraPos"]) and np.array_equal(c["position"] + c["direction"], ref["cameraTarget"]) and np.array_equal(c["up"], ref["cameraUp"]), ctx
+            assert c["verticalFov"] == np.float32(ref["verticalFov"]) and c["zNear"] == np.float32(ref["zNear"]), ctx
+        ui = imp.tone_mapping()
+        assert (int(ui["autoExposure"]), float(ui["exposureCompensation"]), float(ui["exposureValue"]), float(ui["exposureValueMin"]), float(ui["exposureValueMax"])) == \
+            (ref["autoExposure"], ref["exposureCompensation"], ref["exposureValue"], ref["exposureValueMin"], ref["exposureValueMax"]), ctx
+        imp.close()
