@@ -220,7 +220,10 @@ int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo*
    The file format of the graph itself and the light / camera keys belong to Donut (donut/engine/Scene.cpp, SceneGraph.cpp), which the reference
    tree does not vendor: they are restated from Donut's published sources. Not imported: DirectionalLight (LightsBaker skips it too), animations,
    glTF-embedded cameras / lights, analytic-light proxies (counted in info), textures other than 8-bit PNG (counted in texturesNotLoaded, the
-   material then renders untextured as when the reference fails to load one). The environment map is reported, not loaded (.exr / .dds). */
+   material then renders untextured as when the reference fails to load one). The environment map is reported, not loaded (.exr / .dds). NOTE: of
+   an EnvironmentLight the reference application consumes only `path` (Sample.cpp:552-553); radianceScale / rotation / textureIndex are read by
+   EnvironmentLight::Load but never used — tint, intensity and rotation of the environment come from the UI block (EnvironmentMapRuntimeParameters,
+   reset to identity on every scene load, Sample.cpp:554, 1936-1948). They are reported for completeness; to match the reference do not apply them. */
 typedef struct pt_scene_import pt_scene_import;
 typedef struct PtToneMappingParameters PtToneMappingParameters;      /* defined with the display path below */
 typedef struct PtSceneCameraDesc {          /* Sample::UpdateCameraFromScene inputs: LookAt(position, position + direction, up) */
