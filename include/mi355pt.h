@@ -198,7 +198,8 @@ int32_t pt_material_from_json(const char* jsonText, const uint32_t textureWords[
 /* Analytic lights as the host of the reference describes them: a Donut PointLight / SpotLight with RTXPT's LightExtension. pt_convert_light is
    LightsBaker::ConvertLight (Rtxpt/Lighting/LightsBaker.cpp:456-556): radius > 0 gives a sphere light (radiance = color * intensity / (pi r^2)); a spot
    adds cone shaping (cos outer angle, softness = 1 - inner / |outer|; outerAngle < 0 selects the minimum-falloff variant). radius == 0 gives a
-   point-type record, which the path tracer's light set does not sample (PolymorphicLightPTConfig.h:17-22) and pt_set_lights rejects. Host only. */
+   point-type record; the path tracer's light set has that type compiled out (PolymorphicLightPTConfig.h:17-22), so pt_set_lights carries it as the
+   reference does: a slot in the light buffer with no power and empty samples (uniform light selection still lands on it). Host only. */
 typedef struct PtAnalyticLightDesc {
     uint32_t type;                 /* 0 point, 1 spot */
     float    position[3], direction[3];

@@ -83,12 +83,33 @@ def build_library(verbose=False):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process. PyTorch-ROCm ships its own libamdhip64.so; were libmi355pt.so loaded first it would bind /opt/rocm's copy, a later
+    `import torch` would bring a second runtime into the process, and whichever of the two initialises second no longer finds the device (seen on the
+    MI355X box: load_library(); import torch; torch.cuda.is_available(); pt_create -> PT_ERROR_NO_DEVICE). Loading torch's copy first — without importing
+    torch — makes both resolve to it by SONAME, in either import order. Without torch installed, /opt/rocm's copy is used as linked."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen libmi355pt.so. Raises if it has not been built: the product path never falls back to anything else."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libmi355pt.so is missing (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C rtxpt_amd/csrc`." % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(LIB_PATH)
         L.pt_get_last_error.restype = ctypes.c_char_p
         L.pt_get_last_error.argtypes = [ctypes.c_void_p]

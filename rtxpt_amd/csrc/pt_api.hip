@@ -501,7 +501,9 @@ int32_t pt_set_lights(pt_context* c, const ::PolymorphicLightInfo* lights, const
         PolymorphicLightInfoFull f; memcpy(&f.Base, &lights[i], 32);
         if (ex) memcpy(&f.Extended, &ex[i], 16); else memset(&f.Extended, 0, 16);
         uint type = DecodeLightType(f.Base);
-        if (type != kSphere) return fail(c, PT_ERROR_UNSUPPORTED, "only sphere analytic lights are enabled (PolymorphicLightPTConfig.h:17-22)");
+        // sphere lights are the enabled analytic type; a point-type record (ConvertLight of a light without radius) has its type compiled out in the
+        // reference (PolymorphicLightPTConfig.h:17-22) and is carried as the reference carries it: a slot in the buffer with no power and empty samples
+        if (type != kSphere && type != kPoint) return fail(c, PT_ERROR_UNSUPPORTED, "only sphere (and inert point-type) analytic light records are accepted (PolymorphicLightPTConfig.h:17-22)");
         c->analyticLights.push_back(f);
     }
     c->lightsDirty = true;

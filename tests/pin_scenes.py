@@ -23,6 +23,22 @@ def with_sphere_lights(make):
     return build
 
 
+def with_point_light_record(make):
+    """The scene of `make` (which already has analytic lights) plus the record LightsBaker::ConvertLight makes of a point light WITHOUT radius: a point-type
+    PolymorphicLight. The path tracer's light set has that type compiled out (PolymorphicLightPTConfig.h:17-22: "handled by sphere"), so the record is inert —
+    no power, empty samples — but it still occupies a slot of the light buffer, which uniform light selection (NEEType 0) notices."""
+    import numpy as np
+    import rtxpt_amd as pt
+    def build():
+        sc, cam = make()
+        base, ex = sc["lights"]
+        b, e = pt.convert_light("point", (0.3, 0.4, 0.3), (1.0, 0.5, 0.25), 80.0, 0.0)
+        assert (int(b[3]) >> 24) & 0xF == 4
+        sc = dict(sc); sc["lights"] = (np.concatenate([base[:2], b[None, :], base[2:]]), np.concatenate([ex[:2], e[None, :], ex[2:]]))
+        return sc, cam
+    return build
+
+
 def with_excluded_geometry(make, which=(-1, -2)):
     """The scene of `make` with some geometries flagged ExcludeFromNEE (shadow rays pass through them, AccelerationStructureUtil.h:35-104, BridgeDonut:981-989)."""
     def build():
@@ -95,6 +111,7 @@ def cases():
         "c2_nested2_norr_nold": (c2, scenes.default_settings(nestedDielectricsQuality=2, enableRussianRoulette=0, enableLDSamplerForBSDF=0), 64, 36, 0, 2),
         "c2_nested0_uniform": (c2, scenes.default_settings(nestedDielectricsQuality=0, NEEType=0), 64, 36, 0, 2),
         "c2_sphere_lights": (with_sphere_lights(c2), scenes.default_settings(), 64, 36, 0, 2),                     # analytic lights (pt_set_lights): spheres, spot shaping
+        "c2_point_light_record_uniform": (with_point_light_record(with_sphere_lights(c2)), scenes.default_settings(NEEType=0), 64, 36, 0, 2),   # inert point-type record in the buffer
         "c2_exclude_from_nee": (with_excluded_geometry(c2), scenes.default_settings(), 64, 36, 0, 2),              # ExcludeFromNEE geometry: invisible to shadow rays
         "c2_env_rotated_mip2": (with_rotated_environment(c2), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 64, 36, 5, 2),   # env transform + tint, diffuse-bounce env MIP 2 (the UI default)
         "c2_mirrored_room": (with_mirrored_instance(c2), scenes.default_settings(), 64, 36, 0, 2),                 # negative-determinant instance holding the quad light

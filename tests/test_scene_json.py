@@ -172,7 +172,7 @@ def test_media_path_argument_and_errors(tmp_path):
         with pytest.raises(pt.PtError) as e:
             pt.SceneImport(m / "test.scene.json")
         assert e.value.code == code, (bad, e.value.code)
-    # a light without radius converts to the point-type record, as in the reference; it is pt_set_lights (pt_scene_import_apply) that refuses it
+    # a light without radius converts to the point-type record, as in the reference (inert in the path tracer's light set, but it keeps its slot)
     m, _, _ = make_folder(tmp_path / "pointlight", [{"type": "SpotLight", "radius": 0.0, "intensity": 1.0}])
     pl = pt.SceneImport(m / "test.scene.json")
     assert pl.info["numLights"] == 1 and (int(pl.lights[0][3]) >> 24) & 0xF == 4
