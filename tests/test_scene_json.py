@@ -305,3 +305,33 @@ def test_scene_leaves_match_reference_text(tmp_path):
         assert (int(ui["autoExposure"]), float(ui["exposureCompensation"]), float(ui["exposureValue"]), float(ui["exposureValueMin"]), float(ui["exposureValueMax"])) == \
             (ref["autoExposure"], ref["exposureCompensation"], ref["exposureValue"], ref["exposureValueMin"], ref["exposureValueMax"]), ctx
         imp.close()
+
+
+@pytest.mark.gpu
+def test_scene_json_with_overrides_renders(tmp_path):
+    """An asset folder whose `.material.json` overrides bring a PNG texture, alpha testing and a SkipRender material goes through pt_scene_import_apply and renders:
+    finite, different from the same folder without overrides, and the SkipRender box is gone (its pixels now show the wall behind it)."""
+    checker = np.zeros((8, 8, 4), np.uint8); checker[..., 3] = 255; checker[::2, ::2, :3] = 255; checker[1::2, 1::2, :3] = 255
+    overrides = {"test.scene/cornell.red.material.json": {"BaseOrDiffuseColor": [1.0, 1.0, 1.0], "Roughness": 0.8, "BaseTexture": {"path": "Textures/checker.png", "sRGB": True}},
+                 "gold.material.json": {"SkipRender": True},
+                 "green.material.json": {"BaseOrDiffuseColor": [0.1, 0.9, 0.1], "Metalness": 1.0, "Roughness": 0.2}}
+    cam_node = {"name": "Default", "type": "PerspectiveCameraEx", "translation": [0.278, 0.273, -0.8], "rotation": [0.0, 1.0, 0.0, 0.0], "verticalFov": math.radians(39.3), "zNear": 0.01}
+    W, H = 96, 96
+    frames = []
+    for ov, sub in ((overrides, "a"), (None, "b")):
+        media, sc, cam = make_folder(tmp_path / sub, [{"model": 0}, cam_node], ov, textures={"Textures/checker.png": checker} if ov else None)
+        imp = pt.SceneImport(media / "test.scene.json")
+        assert imp.info["materialOverrides"] == (3 if ov else 0) and imp.info["numTextures"] == (1 if ov else 0)
+        c = imp.cameras[0]
+        p = pt.PathTracer(); p.apply_scene_import(imp)
+        p.set_settings(imp.apply_settings(p.default_settings())); p.resize(W, H)
+        p.set_camera(pt.bridge_camera(W, H, c["position"], c["direction"], c["up"], float(c["verticalFov"]), near_z=float(c["zNear"]), far_z=100.0, focal_distance=1.0))
+        p.render(0, 8)
+        frames.append(p.radiance().copy()); p.close(); imp.close()
+    a, b = frames
+    assert np.isfinite(a).all() and np.isfinite(b).all() and a[..., :3].max() > 0
+    assert not np.array_equal(a, b)
+    # the tall gold box (right half of the image, lower part) is metallic yellow in b and absent in a: the mean colour of that region moves away from gold
+    region = (slice(40, 80), slice(50, 80))
+    gold_b = b[region][..., :3].mean((0, 1)); gold_a = a[region][..., :3].mean((0, 1))
+    assert gold_b[0] > 1.15 * gold_b[2] and abs(gold_a[0] / max(gold_a[2], 1e-6) - gold_b[0] / max(gold_b[2], 1e-6)) > 0.1
