@@ -335,3 +335,30 @@ def test_scene_json_with_overrides_renders(tmp_path):
     region = (slice(40, 80), slice(50, 80))
     gold_b = b[region][..., :3].mean((0, 1)); gold_a = a[region][..., :3].mean((0, 1))
     assert gold_b[0] > 1.15 * gold_b[2] and abs(gold_a[0] / max(gold_a[2], 1e-6) - gold_b[0] / max(gold_b[2], 1e-6)) > 0.1
+
+
+def test_scene_json_parser_survives_damaged_documents(tmp_path):
+    """Truncated and byte-flipped scene / material documents must come back as an error code or a clean import, never as a crash."""
+    media, _, _ = make_folder(tmp_path, GRAPH, {"red.material.json": {"Roughness": 0.7, "BaseTexture": {"path": "Textures/none.png"}}})
+    good = (media / "test.scene.json").read_bytes()
+    mat = (media / "Materials" / "red.material.json").read_bytes()
+    rng = np.random.default_rng(99)
+    ok = bad = 0
+    for i in range(400):
+        doc = bytearray(good)
+        mode = i % 4
+        if mode == 0:
+            doc = doc[:int(rng.integers(0, len(doc)))]
+        elif mode == 1:
+            for _ in range(int(rng.integers(1, 6))):
+                doc[int(rng.integers(0, len(doc)))] = int(rng.integers(32, 127))
+        elif mode == 2:
+            a = int(rng.integers(0, len(doc))); b = min(len(doc), a + int(rng.integers(1, 40))); del doc[a:b]
+        else:
+            m = bytearray(mat); m[int(rng.integers(0, len(m)))] = int(rng.integers(32, 127)); (media / "Materials" / "red.material.json").write_bytes(bytes(m))
+        (media / "fuzz.scene.json").write_bytes(bytes(doc))
+        try:
+            imp = pt.SceneImport(media / "fuzz.scene.json"); imp.close(); ok += 1
+        except pt.PtError as e:
+            assert e.code in (1, 4, 5), e.code; bad += 1
+    assert ok > 0 and bad > 0
