@@ -161,14 +161,22 @@ def main():
             "build": g.build_stats(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, cam, S, W, H)
+            # the oracle's block of the very frame the timed steps rendered doubles as the parity check of the benchmarked configuration
+            out["cpu_baseline"], block, rect = cpu_baseline(sc, cam, S, W, H, SPP)
+            g.reset_accumulation(); g.render(0, SPP)
+            got = g.radiance()[rect[1]:rect[3], rect[0]:rect[2], :3]
+            diff = int((got.view(np.uint32) != block.view(np.uint32)).any(-1).sum())
+            out["parity"] = {"rel_l2": float(np.linalg.norm(got.astype(np.float64) - block) / max(np.linalg.norm(block.astype(np.float64)), 1e-30)),
+                             "differing_pixels": diff, "pixels": int(block.shape[0] * block.shape[1]),
+                             "block": "x %d..%d, y %d..%d of the %dx%d frame, %d spp (the cpu_baseline sample)" % (rect[0], rect[2], rect[1], rect[3], W, H, SPP),
+                             "against": "oracle/ptref (pinned to the reference's integrator text, tests/test_oracle_refpin_integrator.py)", "tolerance": "bit-exact expected; north_star allows 1e-3 relative L2"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(sc, cam, S, W, H):
+def cpu_baseline(sc, cam, S, W, H, SPP):
     """The CPU oracle (a port: RTXPT has no CPU path) on a bounded sample of the SAME workload: a 1920x1080 centre block
     of the 4K frame, 4 accumulated samples, all host cores (OpenMP), about 10 s of CPU work on the 128-thread GPU-box host. Reported per ray so that it is resolution independent."""
     from oracle import ptref
@@ -177,11 +185,13 @@ def cpu_baseline(sc, cam, S, W, H):
     t0 = time.perf_counter(); o.L.ptref_prepare(o.h); prep = time.perf_counter() - t0
     bw, bh = min(W, 1920), min(H, 1080)
     x0, y0 = (W - bw) // 2, (H - bh) // 2
-    t0 = time.perf_counter(); o.render(0, 4, rect=(x0, y0, x0 + bw, y0 + bh)); dt = time.perf_counter() - t0
+    rect = (x0, y0, x0 + bw, y0 + bh)
+    t0 = time.perf_counter(); o.render(0, SPP, rect=rect); dt = time.perf_counter() - t0
     c = o.counters()
     rays = c["extendRays"] + c["shadowRays"]
+    block = o.radiance()[y0:y0 + bh, x0:x0 + bw, :3].copy()
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": ptref.num_threads(), "kind": "port",
-            "sample": "%dx%d centre block of the %dx%d frame, 4 spp, %d rays in %.2f s (SAH BVH build + light bake %.1f s not included)" % (bw, bh, W, H, rays, dt, prep)}
+            "sample": "%dx%d centre block of the %dx%d frame, %d spp, %d rays in %.2f s (SAH BVH build + light bake %.1f s not included)" % (bw, bh, W, H, SPP, rays, dt, prep)}, block, rect
 
 
 if __name__ == "__main__":

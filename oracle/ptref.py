@@ -408,6 +408,10 @@ class Oracle:
     def reset_accumulation(self):
         self.L.ptref_reset_accumulation(self.h)
 
+    def set_brute_force(self, enable):
+        """Diagnostics: every ray query tests every triangle (the definition any BVH has to reproduce)."""
+        self.L.ptref_set_brute_force(self.h, int(enable))
+
     def render(self, first, n, rect=None):
         if self.reference_integrator:
             if rect is None: self.L.refpt_render(self.h, first, n)

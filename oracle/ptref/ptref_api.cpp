@@ -62,19 +62,24 @@ void finalize_geometry(Scene& sc) {
                 float3 p0 = xform_point(M, sc.positions[gd.vertexOffset + idx[0]]);
                 float3 p1 = xform_point(M, sc.positions[gd.vertexOffset + idx[1]]);
                 float3 p2 = xform_point(M, sc.positions[gd.vertexOffset + idx[2]]);
-                Triangle tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.subInstance = subInst; tr.triIndex = t; tr.flags = triFlags;
+                Triangle tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.subInstance = subInst; tr.triIndex = t; tr.flags = triFlags; tr.pad = 0.f;
                 sc.tris.push_back(tr);
             }
         }
         running += m.numGeometries;
     }
+    // the triangles' own padded boxes (scene.h tri_box_accepts): pad from the scene bounds, over the vertices the intersection test reconstructs
+    float3 smn = make_float3(3.0e38f), smx = make_float3(-3.0e38f);
+    for (const Triangle& t : sc.tris) { float3 q1 = t.v0 + t.e1, q2 = t.v0 + t.e2; smn = min3v(smn, min3v(t.v0, min3v(q1, q2))); smx = max3v(smx, max3v(t.v0, max3v(q1, q2))); }
+    const float scenePad = sc.tris.empty() ? 0.f : scene_pad(smn, smx);
+    for (Triangle& t : sc.tris) { float3 q1 = t.v0 + t.e1, q2 = t.v0 + t.e2; t.pad = tri_pad(min3v(t.v0, min3v(q1, q2)), max3v(t.v0, max3v(q1, q2)), scenePad); }
 }
 
 // ---- binned SAH BVH2
 struct BuildPrim { float3 bmin, bmax, c; };
-static void tri_bounds(const Triangle& t, float3& mn, float3& mx) {
+static void tri_bounds(const Triangle& t, float3& mn, float3& mx) {      // the PADDED box of the hit definition: every node box contains it
     float3 p1 = t.v0 + t.e1, p2 = t.v0 + t.e2;
-    mn = min3v(t.v0, min3v(p1, p2)); mx = max3v(t.v0, max3v(p1, p2));
+    mn = min3v(t.v0, min3v(p1, p2)) - make_float3(t.pad); mx = max3v(t.v0, max3v(p1, p2)) + make_float3(t.pad);
 }
 static float half_area(float3 mn, float3 mx) { float3 e = mx - mn; return e.x * e.y + e.y * e.z + e.z * e.x; }
 static void subdivide(Scene& sc, std::vector<BuildPrim>& prims, uint nodeIdx, uint first, uint count) {
@@ -385,6 +390,7 @@ void ptref_set_lights(void* h, const PolymorphicLightInfo* base, const Polymorph
 void ptref_set_camera(void* h, const PathTracerCameraData* cam) { ((Context*)h)->cam = *cam; }
 void ptref_set_settings(void* h, const PtSettings* s) { Context* c = (Context*)h; if (c->S.NEEEnabled != s->NEEEnabled || c->S.NEEType != s->NEEType) c->lightsDirty = true; c->S = *s; }
 void ptref_resize(void* h, uint32_t w, uint32_t hgt) { Context* c = (Context*)h; c->w = w; c->h = hgt; c->accum.assign((size_t)w * hgt, make_float4(0, 0, 0, 0)); c->accumCount = 0; }
+void ptref_set_brute_force(void* h, int enable) { ((Context*)h)->sc.bruteForce = enable; }      // diagnostics: O(triangles) per ray
 void ptref_reset_accumulation(void* h) { Context* c = (Context*)h; std::fill(c->accum.begin(), c->accum.end(), make_float4(0, 0, 0, 0)); c->accumCount = 0; memset(&c->ctr, 0, sizeof(c->ctr)); }
 
 static void prepare(Context* c) {

@@ -11,6 +11,8 @@
 // Texture filtering (fixed-function in the reference) is restated as explicit wrap-mode bilinear/trilinear on a box-filtered
 // mip chain; the environment is sampled from the source lat-long image (the EnvMapBaker cube conversion is out of scope).
 #pragma once
+#include <functional>
+#include <cstdio>
 #include "lights.h"
 #include <vector>
 #include <algorithm>
@@ -140,7 +142,7 @@ struct EnvMap {
 };
 
 // ---- the scene
-struct Triangle { float3 v0, e1, e2; uint subInstance, triIndex, flags; };   // world space; flags bit0 = non-opaque (alpha tested), bit1 = exclude from NEE
+struct Triangle { float3 v0, e1, e2; uint subInstance, triIndex, flags; float pad; };   // world space; flags bit0 = non-opaque (alpha tested), bit1 = exclude from NEE; pad: tri_box_accepts
 struct Scene {
     std::vector<uint> indices; std::vector<float3> positions; std::vector<float2> uvs; std::vector<uint> normals, tangents;
     std::vector<GeometryDesc> geometries; std::vector<MeshDesc> meshes; std::vector<InstanceDesc> instances;
@@ -159,13 +161,14 @@ struct Scene {
     // BVH2
     struct Node { float3 bmin; uint leftFirst; float3 bmax; uint count; };   // count==0: inner (children leftFirst, leftFirst+1)
     std::vector<Node> nodes; std::vector<uint> triOrder;
+    int bruteForce = 0;                                     // ptref_set_brute_force: every query tests every triangle (the definition the BVH must reproduce; diagnostics)
 };
 
 static_assert(sizeof(SubInstanceData) == 32, "SubInstanceData must be 32 bytes");
 struct HitInfo { float t; uint prim; float u, v; };      // prim = global triangle index, 0xFFFFFFFF = miss
 
 // Moeller-Trumbore; both sides; accepts tmin < t < tmax. (u,v) are the DXR barycentrics of vertices 1 and 2.
-static inline bool intersect_tri(const Triangle& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
+static inline bool intersect_tri_mt(const Triangle& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
     // explicitly fused products: fmaf is exactly specified, so host and device agree bit for bit, and the test costs 9 mul + 18 fma + 1 division
     float3 pvec = make_float3(fmaf(d.y, tr.e2.z, -(d.z * tr.e2.y)), fmaf(d.z, tr.e2.x, -(d.x * tr.e2.z)), fmaf(d.x, tr.e2.y, -(d.y * tr.e2.x)));
     float det = fmaf(tr.e1.z, pvec.z, fmaf(tr.e1.y, pvec.y, tr.e1.x * pvec.x));
@@ -179,6 +182,32 @@ static inline bool intersect_tri(const Triangle& tr, float3 o, float3 d, float t
     if (v < 0.0f || u + v > 1.0f) return false;
     t = fmaf(tr.e2.z, qvec.z, fmaf(tr.e2.y, qvec.y, tr.e2.x * qvec.x)) * inv;
     return (t > tmin) && (t < tmax);
+}
+// The second half of the hit definition (see rtxpt_amd/csrc/pt_scene.h for the argument): fp32 Moeller-Trumbore reports hits outside badly
+// conditioned triangles (grazing rays, slivers), and whether a box above the triangle lets the ray through would then decide the closest hit. A hit
+// only counts if t lies in the slab interval of the triangle's own padded bounding box, computed as every box test above it computes its interval:
+// (plane - o) * inv, inv = ray_safe_rcp(d). Monotone rounding + nested boxes => no conservative BVH can cull an accepted hit.
+static inline float ray_safe_rcp(float d) {
+    float a = fabsf(d);
+    float s = (a < 7.888609e-31f) ? 7.888609e-31f : a;
+    return 1.0f / ((d < 0.0f) ? -s : s);
+}
+static inline float tri_pad(float3 mn, float3 mx, float scenePad) {
+    float3 e = mx - mn;
+    return 2e-5f * fmaxf_(e.x, fmaxf_(e.y, e.z)) + scenePad;
+}
+static inline float scene_pad(float3 smn, float3 smx) { return 2e-6f * length(smx - smn); }
+static inline bool tri_box_accepts(const Triangle& tr, float3 o, float3 inv, float t) {
+    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
+    float3 mn = min3v(tr.v0, min3v(q1, q2)) - make_float3(tr.pad), mx = max3v(tr.v0, max3v(q1, q2)) + make_float3(tr.pad);
+    float ax = (mn.x - o.x) * inv.x, bx = (mx.x - o.x) * inv.x, ay = (mn.y - o.y) * inv.y, by = (mx.y - o.y) * inv.y, az = (mn.z - o.z) * inv.z, bz = (mx.z - o.z) * inv.z;
+    float tn = fmaxf_(fmaxf_(fminf_(ax, bx), fminf_(ay, by)), fminf_(az, bz));
+    float tf = fminf_(fminf_(fmaxf_(ax, bx), fmaxf_(ay, by)), fmaxf_(az, bz));
+    return (tn <= t) && (t <= tf);
+}
+static inline bool intersect_tri(const Triangle& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
+    if (!intersect_tri_mt(tr, o, d, tmin, tmax, t, u, v)) return false;
+    return tri_box_accepts(tr, o, make_float3(ray_safe_rcp(d.x), ray_safe_rcp(d.y), ray_safe_rcp(d.z)), t);
 }
 
 // BridgeDonut:929-971 AlphaTestImpl — base-colour texture alpha at mip 0 vs the 8-bit quantised cutoff
@@ -206,11 +235,44 @@ static inline bool slab(const Scene::Node& n, float3 o, float3 id, float tmax) {
     return (tmx * 1.00001f + 1e-6f >= tmn * 0.99999f - 1e-6f) && (tmn * 0.99999f - 1e-6f < tmax) && (tmx * 1.00001f + 1e-6f > 0.0f);
 }
 
+static inline HitInfo trace_closest_bruteforce(const Scene& sc, float3 o, float3 d, float tmin, float tmax);
+// diagnostics (bruteForce == 2): the slab numbers of every node on the way to the triangle the BVH query missed
+static void debug_report_miss(const Scene& sc, float3 o, float3 d, float tmax, uint gotPrim, float gotT, uint wantPrim, float wantT) {
+    fprintf(stderr, "BVH != brute force: o %.9g %.9g %.9g d %.9g %.9g %.9g tmax %.9g | bvh prim %u t %.9g | brute prim %u t %.9g\n", o.x, o.y, o.z, d.x, d.y, d.z, tmax, gotPrim, gotT, wantPrim, wantT);
+    if (wantPrim == 0xFFFFFFFFu) return;
+    float3 id = make_float3(ray_safe_rcp(d.x), ray_safe_rcp(d.y), ray_safe_rcp(d.z));
+    std::vector<uint> chain; std::vector<std::pair<uint, int>> st; st.push_back({0u, 0});      // depth-first search for the leaf holding wantPrim
+    std::vector<uint> path;
+    std::function<bool(uint)> find = [&](uint ni) -> bool {
+        const Scene::Node& n = sc.nodes[ni]; path.push_back(ni);
+        if (n.count) { for (uint i = 0; i < n.count; i++) if (sc.triOrder[n.leftFirst + i] == wantPrim) return true; path.pop_back(); return false; }
+        if (find(n.leftFirst) || find(n.leftFirst + 1)) return true;
+        path.pop_back(); return false;
+    };
+    find(0);
+    for (uint ni : path) {
+        const Scene::Node& n = sc.nodes[ni];
+        fprintf(stderr, "   node %u box [%.9g %.9g %.9g | %.9g %.9g %.9g] slab(tmax=wantT*1.001) %d tx %.9g %.9g ty %.9g %.9g tz %.9g %.9g\n", ni, n.bmin.x, n.bmin.y, n.bmin.z, n.bmax.x, n.bmax.y, n.bmax.z,
+                (int)slab(n, o, id, wantT * 1.001f), (n.bmin.x - o.x) * id.x, (n.bmax.x - o.x) * id.x, (n.bmin.y - o.y) * id.y, (n.bmax.y - o.y) * id.y, (n.bmin.z - o.z) * id.z, (n.bmax.z - o.z) * id.z);
+    }
+    const Triangle& tr = sc.tris[wantPrim];
+    fprintf(stderr, "   tri v0 %.9g %.9g %.9g e1 %.9g %.9g %.9g e2 %.9g %.9g %.9g\n", tr.v0.x, tr.v0.y, tr.v0.z, tr.e1.x, tr.e1.y, tr.e1.z, tr.e2.x, tr.e2.y, tr.e2.z);
+}
 // closest hit (BridgeDonut:1029-1055 traceScatterRay): RAY_FLAG_NONE, alpha test on non-opaque candidates
 static inline HitInfo trace_closest(const Scene& sc, float3 o, float3 d, float tmin, float tmax, uint64_t* nodeVisits = 0, uint64_t* triTests = 0) {
     HitInfo h; h.t = tmax; h.prim = 0xFFFFFFFFu; h.u = h.v = 0;
     if (sc.nodes.empty()) return h;
-    float3 id = make_float3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (sc.bruteForce == 1) {
+        for (uint p = 0; p < sc.tris.size(); p++) {
+            float t, u, v;
+            if (!intersect_tri(sc.tris[p], o, d, tmin, tmax, t, u, v)) continue;
+            if (!(t < h.t || (t == h.t && p < h.prim))) continue;
+            if ((sc.tris[p].flags & 1u) && !AlphaTest(sc, sc.tris[p], u, v)) continue;
+            h.t = t; h.prim = p; h.u = u; h.v = v;
+        }
+        return h;
+    }
+    float3 id = make_float3(ray_safe_rcp(d.x), ray_safe_rcp(d.y), ray_safe_rcp(d.z));
     uint stack[128]; int sp = 0; stack[sp++] = 0;
     while (sp) {
         const Scene::Node& n = sc.nodes[stack[--sp]];
@@ -229,12 +291,26 @@ static inline HitInfo trace_closest(const Scene& sc, float3 o, float3 d, float t
             }
         } else { stack[sp++] = n.leftFirst; stack[sp++] = n.leftFirst + 1; }
     }
+    if (sc.bruteForce == 2) {                              // diagnostics: report every query the BVH answers differently from the exhaustive loop
+        HitInfo b = trace_closest_bruteforce(sc, o, d, tmin, tmax);
+        if (b.prim != h.prim || b.t != h.t) debug_report_miss(sc, o, d, tmax, h.prim, h.t, b.prim, b.t);
+    }
     return h;
 }
 // any hit (BridgeDonut:993-1027 traceVisibilityRay): returns true when VISIBLE (nothing committed)
 static inline bool trace_visibility(const Scene& sc, float3 o, float3 d, float tmin, float tmax, uint64_t* nodeVisits = 0, uint64_t* triTests = 0) {
     if (sc.nodes.empty()) return true;
-    float3 id = make_float3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (sc.bruteForce == 1) {
+        for (uint p = 0; p < sc.tris.size(); p++) {
+            const Triangle& tr = sc.tris[p];
+            float t, u, v;
+            if (!intersect_tri(tr, o, d, tmin, tmax, t, u, v)) continue;
+            if (tr.flags & 1u) { if (tr.flags & 2u) continue; if (!AlphaTest(sc, tr, u, v)) continue; }
+            return false;
+        }
+        return true;
+    }
+    float3 id = make_float3(ray_safe_rcp(d.x), ray_safe_rcp(d.y), ray_safe_rcp(d.z));
     uint stack[128]; int sp = 0; stack[sp++] = 0;
     while (sp) {
         const Scene::Node& n = sc.nodes[stack[--sp]];
@@ -253,6 +329,15 @@ static inline bool trace_visibility(const Scene& sc, float3 o, float3 d, float t
                 return false;
             }
         } else { stack[sp++] = n.leftFirst; stack[sp++] = n.leftFirst + 1; }
+    }
+    if (sc.bruteForce == 2) {
+        for (uint p = 0; p < sc.tris.size(); p++) {
+            const Triangle& tr = sc.tris[p];
+            float t, u, v;
+            if (!intersect_tri(tr, o, d, tmin, tmax, t, u, v)) continue;
+            if (tr.flags & 1u) { if (tr.flags & 2u) continue; if (!AlphaTest(sc, tr, u, v)) continue; }
+            debug_report_miss(sc, o, d, tmax, 0xFFFFFFFFu, tmax, p, t); break;
+        }
     }
     return true;
 }

@@ -77,7 +77,7 @@ struct pt_context {
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
-    BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0;
+    BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0; uint bvhBuilder = BVH_BUILDER_PLOC;
     DeviceScene dsc;
     // frame state
     ptk::PtSettings S; ptk::PathTracerCameraData cam; uint width = 0, height = 0, accumCount = 0; std::vector<uint> owned; std::vector<std::vector<uint>> shardPixels;
@@ -155,8 +155,7 @@ int upload_textures(pt_context* c) {
 
 void refresh_scene_view(pt_context* c) {
     DeviceScene& d = c->dsc;
-    if (!c->dTravSpill.p) (void)c->dTravSpill.resize(PT_PIPELINE_BATCHES * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH);   // traversal stack tails, one region per pipelined batch (4 x 302 MB of 288 GB)
-    d.travSpill = c->dTravSpill.p;
+    d.travSpill = c->dTravSpill.p;                           // allocated (and checked) by finalize_geometry
     d.indices = c->dIndices.p; d.positions = c->dPositions.p; d.uvs = c->dUvs.p; d.normals = c->dNormals.p; d.tangents = c->dTangents.p;
     d.geometries = c->dGeometries.p; d.instances = c->dInstances.p; d.subInstances = c->dSubInstances.p; d.subInstToInstGeom = c->dSubInstToInstGeom.p;
     d.materials = c->dMaterials.p; d.materialCount = (uint)c->materials.size(); d.textures = c->dTexInfos.p; d.texels = c->dTexels.p;
@@ -208,6 +207,8 @@ int finalize_geometry(pt_context* c) {
     PT_CHECK_HIP(c, c->dPrimInfo.upload(c->primInfo, st)); PT_CHECK_HIP(c, c->dMaterials.upload(c->materials, st));
     if (c->bvhAllocated && c->bvh.capacity < c->numTris) { bvh_free(c->bvh); c->bvhAllocated = false; }
     if (!c->bvhAllocated) { PT_CHECK_HIP(c, bvh_alloc(c->bvh, c->numTris)); c->bvhAllocated = true; }
+    c->bvh.builder = c->bvhBuilder;
+    if (!c->dTravSpill.p) PT_CHECK_HIP(c, c->dTravSpill.resize(PT_PIPELINE_BATCHES * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH));   // traversal stack tails, one region per pipelined batch (4 x 302 MB of 288 GB)
     refresh_scene_view(c);
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, st));
@@ -395,6 +396,7 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) if (hipStreamCreateWithFlags(&c->streams[b], hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     if (hipHostMalloc(&c->hostCounters, PT_PIPELINE_BATCHES * sizeof(WaveCounters), hipHostMallocDefault) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     c->serialKernels = desc && (desc->flags & PT_DEVICE_SERIAL_KERNELS);
+    { const char* e = getenv("MI355PT_BVH_BUILDER"); if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; }      // developer A/B switch; PLOC is the default
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
     const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.f);

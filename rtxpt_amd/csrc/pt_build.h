@@ -3,7 +3,10 @@
 //   k_tri_setup     one thread per triangle: instance transform -> world-space TriRecord + scene bounds (wave-reduced atomics)
 //   k_morton        63-bit Morton code of the centroid (21 bits / axis)
 //   rocprim sort    (code, primitive) pairs — library radix sort, build step only
-//   k_karras        Karras 2012 hierarchy over the sorted codes (duplicate codes split on the index bits)
+//   k_ploc_*        (default) PLOC, Meister & Bittner 2018: mutual-nearest-neighbour merging of the Morton-ordered clusters inside a window of
+//                   PT_PLOC_RADIUS, ~70 data-parallel passes; leaves are then renumbered in depth-first order so that every node covers a
+//                   contiguous leaf range again. Half the SAH cost of the Karras tree on C3 (tools/bvh_lab), 40 % fewer node visits per ray
+//   k_karras        (PT_BVH_BUILDER=karras) Karras 2012 hierarchy over the sorted codes (duplicate codes split on the index bits)
 //   k_leaf_boxes / k_range_level / k_node_boxes
 //                   node bounds WITHOUT inter-thread hand-offs: every Karras node covers a contiguous range of sorted leaves, so its two child
 //                   boxes are two range-min/max queries on a sparse table over the leaf boxes (log2 n fully parallel passes, 2 GB for 2.8 M
@@ -18,6 +21,8 @@
 #include <hip/hip_runtime.h>
 
 namespace ptk {
+
+enum : uint { BVH_BUILDER_PLOC = 0, BVH_BUILDER_KARRAS = 1 };
 
 struct BvhBuildBuffers {
     TriRecord* triWorld;        // by global primitive id
@@ -34,6 +39,10 @@ struct BvhBuildBuffers {
     uint* primToSlot;           // global primitive id -> leaf-order slot (k_resolve_extend looks the winning triangle up by primitive)
     Bvh8Node* nodes8; uint* levelA; uint* levelB; uint* wideCounter; uint numNodes8, collapseLevels;
     void* sortTemp; size_t sortTempBytes;
+    // PLOC work arrays (node ids while building: leaves 0..n-1 in Morton order, inner nodes n..2n-2 in creation order)
+    uint* plocCl[2]; uint* plocNN; unsigned long long* plocFlags; unsigned long long* plocOffs; uint* plocChildA; uint* plocChildB; uint* plocCnt; uint* plocParent; uint* plocFirst; uint* plocCounts;
+    void* scanTemp; size_t scanTempBytes; uint plocPasses;
+    uint builder;               // BVH_BUILDER_PLOC (default) or BVH_BUILDER_KARRAS
     uint capacity;
 };
 

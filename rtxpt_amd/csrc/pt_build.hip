@@ -2,6 +2,9 @@
 #include "pt_build.h"
 #include <rocprim/rocprim.hpp>
 
+#ifndef PT_PLOC_RADIUS
+#define PT_PLOC_RADIUS 16      // PLOC search window to either side (tools/bvh_lab: SAH cost 154 / 147 / 143 for 8 / 16 / 32 on C3; Karras 283)
+#endif
 #ifndef PT_RANGE_TABLE_MAX_TRIS
 #define PT_RANGE_TABLE_MAX_TRIS (16u << 20)     // above this the n log n sparse table (32 B x n x log2 n) gives way to the ticket-based k_bounds
 #endif
@@ -33,7 +36,7 @@ __global__ void __launch_bounds__(256) k_tri_setup(DeviceScene sc, uint numTris,
         float3 p2 = xform_point(inst.transform, make_float3(P[3 * i2], P[3 * i2 + 1], P[3 * i2 + 2]));
         bool alphaTested = (si.FlagsAndAlphaInfo & SubInstanceData::Flags_AlphaTested) != 0;
         bool excl = (si.FlagsAndAlphaInfo & SubInstanceData::Flags_ExcludeFromNEE) != 0;
-        TriRecord tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.prim = p; tr.flags = (alphaTested ? 1u : 0u) | (excl ? 3u : 0u); tr._pad = 0;
+        TriRecord tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.prim = p; tr.flags = (alphaTested ? 1u : 0u) | (excl ? 3u : 0u); tr.pad = 0.f;      // set once the scene bounds are known (k_leaf_boxes / k_bounds)
         triWorld[p] = tr;
         // bounds from the SAME vertices traversal reconstructs (v0, v0+e1, v0+e2)
         float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
@@ -106,15 +109,19 @@ __global__ void __launch_bounds__(256) k_karras(const unsigned long long* __rest
     if (i == 0) parent[0] = 0xFFFFFFFFu;
 }
 
+__device__ __forceinline__ float scene_pad_of(const uint* __restrict__ sceneBounds) {
+    return scene_pad(make_float3(dec_float(sceneBounds[0]), dec_float(sceneBounds[1]), dec_float(sceneBounds[2])), make_float3(dec_float(sceneBounds[3]), dec_float(sceneBounds[4]), dec_float(sceneBounds[5])));
+}
 __global__ void __launch_bounds__(256) k_bounds(const TriRecord* __restrict__ triWorld, const uint* __restrict__ primsSorted, uint n, TriRecord* __restrict__ triSorted,
                                                 const uint* __restrict__ childL, const uint* __restrict__ parent, const uint* __restrict__ leafParent, uint* __restrict__ tickets,
-                                                float4* boxLmin, float4* boxLmax, float4* boxRmin, float4* boxRmax) {
+                                                float4* boxLmin, float4* boxLmax, float4* boxRmin, float4* boxRmax, const uint* __restrict__ sceneBounds) {
     uint i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     TriRecord tr = triWorld[primsSorted[i]];
-    triSorted[i] = tr;
     float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
     float3 mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+    tr.pad = tri_pad(mn, mx, scene_pad_of(sceneBounds));
+    triSorted[i] = tr;
     if (n == 1) { boxLmin[0] = make_float4(mn.x, mn.y, mn.z, 0.f); boxLmax[0] = make_float4(mx.x, mx.y, mx.z, 0.f); return; }
     uint childRef = i | BVH_LEAF_BIT;
     uint node = leafParent[i];
@@ -135,15 +142,118 @@ __global__ void __launch_bounds__(256) k_bounds(const TriRecord* __restrict__ tr
     }
 }
 
-// ---- node bounds by range queries (see pt_build.h)
-__global__ void __launch_bounds__(256) k_leaf_boxes(const TriRecord* __restrict__ triWorld, const uint* __restrict__ primsSorted, uint n, TriRecord* __restrict__ triSorted,
-                                                    float4* __restrict__ rmin, float4* __restrict__ rmax) {
+
+// ---- PLOC (Meister & Bittner, "Parallel Locally-Ordered Clustering for Bounding Volume Hierarchy Construction", TVCG 2018), the default builder:
+// the Morton-sorted triangles are the initial clusters; every pass each cluster looks PT_PLOC_RADIUS neighbours to either side for the partner that
+// gives the smallest merged surface area, mutual nearest neighbours merge, and the cluster list is compacted with a prefix sum (order preserved), until
+// one cluster is left. Everything is deterministic: ties go to the lower index, node numbers come from the prefix sum, no atomics.
+// Against the Karras tree over the same codes this halves the SAH cost on C3 (283 -> 143, tools/bvh_lab) because neighbours are chosen by the
+// boxes they actually produce, not by the bit pattern of their centroids.
+// Node ids while building: leaves 0..n-1 (Morton position), inner nodes n.. in creation order (children before parents; the last one is the root).
+__global__ void __launch_bounds__(256) k_ploc_init(const TriRecord* __restrict__ triWorld, const uint* __restrict__ primsSorted, uint n, float4* __restrict__ cbMin, float4* __restrict__ cbMax,
+                                                   uint* __restrict__ cl, uint* __restrict__ nodeCnt) {
     uint i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     TriRecord tr = triWorld[primsSorted[i]];
-    triSorted[i] = tr;
     float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
     float3 mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+    cbMin[i] = make_float4(mn.x, mn.y, mn.z, 0.f); cbMax[i] = make_float4(mx.x, mx.y, mx.z, 0.f);
+    cl[i] = i; nodeCnt[i] = 1u;
+}
+__device__ __forceinline__ float merged_area(float4 amn, float4 amx, float4 bmn, float4 bmx) {
+    float ex = fmaxf(amx.x, bmx.x) - fminf(amn.x, bmn.x), ey = fmaxf(amx.y, bmx.y) - fminf(amn.y, bmn.y), ez = fmaxf(amx.z, bmx.z) - fminf(amn.z, bmn.z);
+    return ex * ey + ey * ez + ez * ex;                      // symmetric in (a, b) bit for bit: mutual nearest neighbours see the same number
+}
+// nearest neighbour inside the window; the block's clusters and a halo of PT_PLOC_RADIUS on either side are staged through LDS
+__global__ void __launch_bounds__(256) k_ploc_nn(const float4* __restrict__ cbMin, const float4* __restrict__ cbMax, uint m, uint* __restrict__ nn) {
+    __shared__ float4 smn[256 + 2 * PT_PLOC_RADIUS], smx[256 + 2 * PT_PLOC_RADIUS];
+    const int base = (int)(blockIdx.x * 256u) - PT_PLOC_RADIUS;
+    for (uint k = threadIdx.x; k < 256u + 2u * PT_PLOC_RADIUS; k += 256u) {
+        int g = base + (int)k;
+        if (g >= 0 && g < (int)m) { smn[k] = cbMin[g]; smx[k] = cbMax[g]; }
+    }
+    __syncthreads();
+    const uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint li = threadIdx.x + PT_PLOC_RADIUS;
+    const float4 amn = smn[li], amx = smx[li];
+    const int lo = ((int)i - PT_PLOC_RADIUS < 0) ? 0 : (int)i - PT_PLOC_RADIUS, hi = ((int)i + PT_PLOC_RADIUS > (int)m - 1) ? (int)m - 1 : (int)i + PT_PLOC_RADIUS;
+    float best = 3.0e38f; uint bj = i;
+    for (int j = lo; j <= hi; j++) {
+        if (j == (int)i) continue;
+        const float a = merged_area(amn, amx, smn[j - base], smx[j - base]);
+        if (a < best) { best = a; bj = (uint)j; }           // strict: ties stay with the lower index
+    }
+    nn[i] = bj;
+}
+// flags[i] = keep (low word: this slot survives into the next list) | creates (high word: this slot becomes a new inner node)
+__global__ void __launch_bounds__(256) k_ploc_mark(const uint* __restrict__ nn, uint m, unsigned long long* __restrict__ flags) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint j = nn[i];
+    const bool mutual = (j != i) && (nn[j] == i);
+    const bool keep = !(mutual && i > j), creates = mutual && i < j;
+    flags[i] = (keep ? 1ull : 0ull) | (creates ? (1ull << 32) : 0ull);
+}
+__global__ void __launch_bounds__(256) k_ploc_emit(const uint* __restrict__ cl, const float4* __restrict__ cbMin, const float4* __restrict__ cbMax, const uint* __restrict__ nn,
+                                                   const unsigned long long* __restrict__ flags, const unsigned long long* __restrict__ offs, uint m, uint n, uint nodeBase,
+                                                   uint* __restrict__ clN, float4* __restrict__ cbMinN, float4* __restrict__ cbMaxN, uint* __restrict__ childA, uint* __restrict__ childB,
+                                                   uint* __restrict__ nodeCnt, uint* __restrict__ nodeParent, uint* __restrict__ counts) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const unsigned long long f = flags[i], o = offs[i];
+    if (i == m - 1u) { counts[0] = (uint)o + (uint)(f & 1ull); counts[1] = (uint)(o >> 32) + (uint)(f >> 32); }      // next list length, nodes created in this pass
+    if (!(f & 1ull)) return;
+    const uint pos = (uint)o;
+    if (f >> 32) {
+        const uint j = nn[i], a = cl[i], b = cl[j], id = nodeBase + (uint)(o >> 32);
+        childA[id - n] = a; childB[id - n] = b; nodeCnt[id] = nodeCnt[a] + nodeCnt[b];
+        nodeParent[a] = id; nodeParent[b] = id | 0x80000000u;                       // bit 31: "I am the right child"
+        const float4 amn = cbMin[i], amx = cbMax[i], bmn = cbMin[j], bmx = cbMax[j];
+        clN[pos] = id;
+        cbMinN[pos] = make_float4(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z), 0.f);
+        cbMaxN[pos] = make_float4(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z), 0.f);
+    } else { clN[pos] = cl[i]; cbMinN[pos] = cbMin[i]; cbMaxN[pos] = cbMax[i]; }
+}
+// depth-first position of every node's first leaf: walking up, every time the node sits in a right sub-tree the left sibling's leaves come first
+__global__ void __launch_bounds__(256) k_ploc_first(uint n, const uint* __restrict__ nodeParent, const uint* __restrict__ childA, const uint* __restrict__ nodeCnt, uint* __restrict__ first) {
+    uint x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= 2u * n - 1u) return;
+    uint pos = 0u, node = x;
+    const uint root = 2u * n - 2u;
+    while (node != root) {
+        const uint p = nodeParent[node], pid = p & 0x7FFFFFFFu;
+        if (p >> 31) pos += nodeCnt[childA[pid - n]];
+        node = pid;
+    }
+    first[x] = pos;
+}
+// final numbering, the one every later stage uses (as after k_karras): inner node 0 is the root, leaves are referenced by their depth-first position
+__global__ void __launch_bounds__(256) k_ploc_finish(uint n, const uint* __restrict__ first, const uint* __restrict__ nodeParent, const uint* __restrict__ childA, const uint* __restrict__ childB,
+                                                     const uint* __restrict__ nodeCnt, const uint* __restrict__ primsMorton, uint* __restrict__ primsFinal,
+                                                     uint* __restrict__ childL, uint* __restrict__ childR, uint* __restrict__ parent, uint* __restrict__ leafParent,
+                                                     uint* __restrict__ rangeFirst, uint* __restrict__ rangeLast) {
+    uint x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= 2u * n - 1u) return;
+    const uint root = 2u * n - 2u;
+    if (x < n) { const uint pos = first[x]; primsFinal[pos] = primsMorton[x]; leafParent[pos] = root - (nodeParent[x] & 0x7FFFFFFFu); return; }
+    const uint id = root - x, a = childA[x - n], b = childB[x - n], f = first[x];
+    childL[id] = (a < n) ? (first[a] | BVH_LEAF_BIT) : (root - a);
+    childR[id] = (b < n) ? (first[b] | BVH_LEAF_BIT) : (root - b);
+    rangeFirst[id] = f; rangeLast[id] = f + nodeCnt[x] - 1u;
+    parent[id] = (x == root) ? 0xFFFFFFFFu : (root - (nodeParent[x] & 0x7FFFFFFFu));
+}
+
+// ---- node bounds by range queries (see pt_build.h)
+__global__ void __launch_bounds__(256) k_leaf_boxes(const TriRecord* __restrict__ triWorld, const uint* __restrict__ primsSorted, uint n, TriRecord* __restrict__ triSorted,
+                                                    float4* __restrict__ rmin, float4* __restrict__ rmax, const uint* __restrict__ sceneBounds) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    TriRecord tr = triWorld[primsSorted[i]];
+    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
+    float3 mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+    tr.pad = tri_pad(mn, mx, scene_pad_of(sceneBounds));      // the triangle's own padded box is the innermost box of the hit definition (pt_scene.h tri_box_accepts)
+    triSorted[i] = tr;
     rmin[i] = make_float4(mn.x, mn.y, mn.z, 0.f); rmax[i] = make_float4(mx.x, mx.y, mx.z, 0.f);
 }
 __global__ void __launch_bounds__(256) k_range_level(uint n, uint half, const float4* __restrict__ pmin, const float4* __restrict__ pmax, float4* __restrict__ omin, float4* __restrict__ omax) {
@@ -166,15 +276,17 @@ __global__ void __launch_bounds__(256) k_node_boxes(uint n, const uint* __restri
     uint i = blockIdx.x * 256u + threadIdx.x;
     if (n == 1u) { if (i == 0u) { boxLmin[0] = rmin[0]; boxLmax[0] = rmax[0]; } return; }
     if (i >= n - 1u) return;
-    uint first = rangeFirst[i], last = rangeLast[i], gamma = childL[i] & 0x7FFFFFFFu;      // Karras: the left child ends at the split position, which is its own index
+    const uint first = rangeFirst[i], last = rangeLast[i], cl = childL[i];
+    const uint gamma = (cl & BVH_LEAF_BIT) ? (cl & 0x7FFFFFFFu) : rangeLast[cl];      // the left child covers [first, gamma] (leaves are in depth-first order for both builders)
     float4 mn, mx;
     range_box(rmin, rmax, n, first, gamma, mn, mx); boxLmin[i] = mn; boxLmax[i] = mx;
     range_box(rmin, rmax, n, gamma + 1u, last, mn, mx); boxRmin[i] = mn; boxRmax[i] = mx;
 }
 
+// node boxes are padded with the expression that pads the triangles' own boxes (tri_pad): the pad grows with the extent, so a node's padded box
+// contains the padded boxes of everything below it — the containment the hit definition rests on
 __device__ __forceinline__ void pad_box(float3& mn, float3& mx, float scenePad) {
-    float3 e = mx - mn;
-    float pad = 2e-5f * fmaxf(e.x, fmaxf(e.y, e.z)) + scenePad;
+    float pad = tri_pad(mn, mx, scenePad);
     mn = mn - make_float3(pad); mx = mx + make_float3(pad);
 }
 __global__ void __launch_bounds__(256) k_emit(uint n, const uint* __restrict__ childL, const uint* __restrict__ childR, const uint* __restrict__ rangeFirst,
@@ -183,7 +295,7 @@ __global__ void __launch_bounds__(256) k_emit(uint n, const uint* __restrict__ c
     uint i = blockIdx.x * 256u + threadIdx.x;
     float3 smn = make_float3(dec_float(sceneBounds[0]), dec_float(sceneBounds[1]), dec_float(sceneBounds[2]));
     float3 smx = make_float3(dec_float(sceneBounds[3]), dec_float(sceneBounds[4]), dec_float(sceneBounds[5]));
-    float scenePad = 1e-7f * length(smx - smn);
+    float scenePad = scene_pad(smn, smx);
     if (n == 1) {
         if (i == 0) {
             BvhNode nd; float4 a = boxLmin[0], b = boxLmax[0];
@@ -298,7 +410,13 @@ __global__ void __launch_bounds__(256) k_alpha_records(DeviceScene sc, const Tri
     recs[i] = r;
 }
 
+static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris);
 hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
+    hipError_t e = bvh_alloc_all(b, numTris);
+    if (e != hipSuccess) bvh_free(b);                        // no partial allocations survive a failure
+    return e;
+}
+static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris) {
     __builtin_memset(&b, 0, sizeof(b));
     uint n = numTris < 2 ? 2 : numTris;
     b.capacity = n;
@@ -315,24 +433,34 @@ hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
     size_t tmp = 0;
     PT_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64));
     b.sortTempBytes = tmp; PT_HIP_TRY(hipMalloc(&b.sortTemp, tmp ? tmp : 16));
+    // PLOC work arrays (cluster boxes ping-pong through boxLmin/boxLmax and boxRmin/boxRmax, which the bounds stage overwrites afterwards)
+    PT_HIP_TRY(hipMalloc(&b.plocCl[0], 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocCl[1], 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocNN, 4 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.plocFlags, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocOffs, 8 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.plocChildA, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocChildB, 4 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.plocCnt, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocParent, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocFirst, 8 * (size_t)n));
+    PT_HIP_TRY(hipMalloc(&b.plocCounts, 16));
+    tmp = 0;
+    PT_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, b.plocFlags, b.plocOffs, 0ull, (size_t)n, rocprim::plus<unsigned long long>()));
+    b.scanTempBytes = tmp; PT_HIP_TRY(hipMalloc(&b.scanTemp, tmp ? tmp : 16));
     return hipSuccess;
 }
 void bvh_free(BvhBuildBuffers& b) {
     void* ps[] = {b.triWorld, b.triSorted, b.keys, b.keysSorted, b.prims, b.primsSorted, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast, b.tickets,
-                  b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter, b.alphaRecs, b.primToSlot, b.rangeMin, b.rangeMax};
+                  b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter, b.alphaRecs, b.primToSlot, b.rangeMin, b.rangeMax,
+                  b.plocCl[0], b.plocCl[1], b.plocNN, b.plocFlags, b.plocOffs, b.plocChildA, b.plocChildB, b.plocCnt, b.plocParent, b.plocFirst, b.plocCounts, b.scanTemp};
     for (void* p : ps) if (p) (void)hipFree(p);
     __builtin_memset(&b, 0, sizeof(b));
 }
 static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {
     uint g = (n + 255u) / 256u;
     if (b.rangeMin) {
-        hipLaunchKernelGGL(k_leaf_boxes, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.rangeMin, b.rangeMax);
+        hipLaunchKernelGGL(k_leaf_boxes, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.rangeMin, b.rangeMax, b.sceneBounds);
         for (uint k = 1; k < b.rangeLevels && (1u << k) <= n; k++)
             hipLaunchKernelGGL(k_range_level, dim3(g), dim3(256), 0, st, n, 1u << (k - 1), b.rangeMin + (size_t)(k - 1) * n, b.rangeMax + (size_t)(k - 1) * n, b.rangeMin + (size_t)k * n, b.rangeMax + (size_t)k * n);
         hipLaunchKernelGGL(k_node_boxes, dim3(g), dim3(256), 0, st, n, b.childL, b.rangeFirst, b.rangeLast, b.rangeMin, b.rangeMax, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax);
     } else {
         PT_HIP_TRY(hipMemsetAsync(b.tickets, 0, 4 * (size_t)(n < 2 ? 2 : n), st));
-        hipLaunchKernelGGL(k_bounds, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.childL, b.parent, b.leafParent, b.tickets, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax);
+        hipLaunchKernelGGL(k_bounds, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.childL, b.parent, b.leafParent, b.tickets, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds);
     }
     hipLaunchKernelGGL(k_alpha_records, dim3(g), dim3(256), 0, st, sc, b.triSorted, n, b.alphaRecs, b.primToSlot);
     hipLaunchKernelGGL(k_emit, dim3(g), dim3(256), 0, st, n, b.childL, b.childR, b.rangeFirst, b.rangeLast, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes);
@@ -354,6 +482,35 @@ static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, const DeviceScene& sc,
     b.collapseLevels = levels;
     return hipGetLastError();
 }
+// PLOC passes; every pass reads the new list length back (a build step, not the hot path: ~70 passes of 4 small launches at 2.8 M triangles)
+static hipError_t bvh_ploc(BvhBuildBuffers& b, uint n, hipStream_t st) {
+    float4* cbMin[2] = {b.boxLmin, b.boxRmin}; float4* cbMax[2] = {b.boxLmax, b.boxRmax};
+    hipLaunchKernelGGL(k_ploc_init, dim3((n + 255u) / 256u), dim3(256), 0, st, b.triWorld, b.primsSorted, n, cbMin[0], cbMax[0], b.plocCl[0], b.plocCnt);
+    uint m = n, nodeBase = n, cur = 0, passes = 0;
+    while (m > 1u) {
+        const uint g = (m + 255u) / 256u;
+        hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(256), 0, st, cbMin[cur], cbMax[cur], m, b.plocNN);
+        hipLaunchKernelGGL(k_ploc_mark, dim3(g), dim3(256), 0, st, b.plocNN, m, b.plocFlags);
+        size_t tmp = b.scanTempBytes;
+        PT_HIP_TRY(rocprim::exclusive_scan(b.scanTemp, tmp, b.plocFlags, b.plocOffs, 0ull, (size_t)m, rocprim::plus<unsigned long long>(), st));
+        hipLaunchKernelGGL(k_ploc_emit, dim3(g), dim3(256), 0, st, b.plocCl[cur], cbMin[cur], cbMax[cur], b.plocNN, b.plocFlags, b.plocOffs, m, n, nodeBase,
+                           b.plocCl[cur ^ 1u], cbMin[cur ^ 1u], cbMax[cur ^ 1u], b.plocChildA, b.plocChildB, b.plocCnt, b.plocParent, b.plocCounts);
+        uint host[2] = {0u, 0u};
+        PT_HIP_TRY(hipMemcpyAsync(host, b.plocCounts, 8, hipMemcpyDeviceToHost, st));
+        PT_HIP_TRY(hipStreamSynchronize(st));
+        if (host[0] >= m || host[1] == 0u) return hipErrorUnknown;            // every pass merges at least the globally closest pair
+        m = host[0]; nodeBase += host[1]; cur ^= 1u;
+        if (++passes > 100000u) return hipErrorUnknown;
+    }
+    b.plocPasses = passes;
+    if (nodeBase != 2u * n - 1u) return hipErrorUnknown;
+    const uint gAll = (2u * n - 1u + 255u) / 256u;
+    hipLaunchKernelGGL(k_ploc_first, dim3(gAll), dim3(256), 0, st, n, b.plocParent, b.plocChildA, b.plocCnt, b.plocFirst);
+    hipLaunchKernelGGL(k_ploc_finish, dim3(gAll), dim3(256), 0, st, n, b.plocFirst, b.plocParent, b.plocChildA, b.plocChildB, b.plocCnt, b.primsSorted, b.prims,
+                       b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast);
+    PT_HIP_TRY(hipMemcpyAsync(b.primsSorted, b.prims, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));      // leaf order = depth-first order from here on
+    return hipGetLastError();
+}
 hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {
     if (n == 0) return hipSuccess;
     uint g = (n + 255u) / 256u;
@@ -362,7 +519,10 @@ hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStrea
     hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, st, b.triWorld, n, b.sceneBounds, b.keys, b.prims);
     size_t tmp = b.sortTempBytes;
     PT_HIP_TRY(rocprim::radix_sort_pairs(b.sortTemp, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64, st));
-    if (n > 1) hipLaunchKernelGGL(k_karras, dim3(g), dim3(256), 0, st, b.keysSorted, (int)n, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast);
+    if (n > 1) {
+        if (b.builder == BVH_BUILDER_KARRAS) hipLaunchKernelGGL(k_karras, dim3(g), dim3(256), 0, st, b.keysSorted, (int)n, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast);
+        else PT_HIP_TRY(bvh_ploc(b, n, st));
+    }
     return bvh_bounds_and_emit(b, sc, n, st);
 }
 hipError_t bvh_refit(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {

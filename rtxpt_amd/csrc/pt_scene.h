@@ -49,7 +49,7 @@ struct MeshDesc { uint firstGeometry, numGeometries; };
 struct InstanceDesc { float3x4 transform; uint meshIndex; uint _pad[3]; };
 static_assert(sizeof(InstanceDesc) == 64, "InstanceDesc must be 64 bytes");
 
-struct TriRecord { float3 v0; uint prim; float3 e1; uint flags; float3 e2; uint _pad; };    // flags bit0 non-opaque, bit1 exclude from NEE
+struct TriRecord { float3 v0; uint prim; float3 e1; uint flags; float3 e2; float pad; };    // flags bit0 non-opaque, bit1 exclude from NEE; pad: see tri_box_accepts
 static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
 struct BvhNode { float3 lmin, lmax, rmin, rmax; uint left, right, _pad0, _pad1; };           // child ref: bit31 = leaf (first<<3 | count-1)
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
@@ -160,7 +160,7 @@ static inline float3 env_eval_local(const DeviceScene& sc, float3 localDir, floa
 }
 
 // ---- ray / triangle (Moeller-Trumbore, both sides, tmin < t < tmax); (u,v) = DXR barycentrics of vertices 1,2
-static inline bool intersect_tri(const TriRecord& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
+static inline bool intersect_tri_mt(const TriRecord& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
     // explicitly fused products: fmaf is exactly specified, so host and device agree bit for bit, and the test costs 9 mul + 18 fma + 1 division
     float3 pvec = make_float3(fmaf(d.y, tr.e2.z, -(d.z * tr.e2.y)), fmaf(d.z, tr.e2.x, -(d.x * tr.e2.z)), fmaf(d.x, tr.e2.y, -(d.y * tr.e2.x)));
     float det = fmaf(tr.e1.z, pvec.z, fmaf(tr.e1.y, pvec.y, tr.e1.x * pvec.x));
@@ -174,6 +174,35 @@ static inline bool intersect_tri(const TriRecord& tr, float3 o, float3 d, float 
     if (v < 0.0f || u + v > 1.0f) return false;
     t = fmaf(tr.e2.z, qvec.z, fmaf(tr.e2.y, qvec.y, tr.e2.x * qvec.x)) * inv;
     return (t > tmin) && (t < tmax);
+}
+// The second half of the hit definition. Moeller-Trumbore in fp32 reports hits OUTSIDE the triangle when it is badly conditioned (a grazing ray,
+// a 120 m x 0.3 mm sliver: up to decimetres outside), and a box test above the triangle then decides whether the "hit" exists: the closest hit
+// would depend on the BVH (found at 4K on C3: 8 pixels of 2 M where the oracle's BVH and the exhaustive loop disagree). So a hit only counts if it
+// lies inside the triangle's own padded bounding box AS THE RAY SEES IT: the slab interval [tn, tf] of that box, computed with exactly the
+// arithmetic every BVH node above it uses ((plane - o) * inv with inv = ray_safe_rcp(d), correctly rounded), must contain t. Rounding is monotone,
+// every ancestor box contains this box (pad grows with the extent, see tri_pad / pad_box), hence every ancestor's interval contains [tn, tf] and
+// therefore t: no conservative BVH over these boxes can cull an accepted hit, and the result equals the exhaustive loop bit for bit.
+static inline float ray_safe_rcp(float d) {                // correctly rounded 1/d with |d| clamped away from 0 (no inf, no NaN in the slab arithmetic)
+    float a = fabsf(d);
+    float s = (a < 7.888609e-31f) ? 7.888609e-31f : a;
+    return 1.0f / ((d < 0.0f) ? -s : s);
+}
+static inline float tri_pad(float3 mn, float3 mx, float scenePad) {      // the same expression pads every BVH node box (pt_build.hip pad_box)
+    float3 e = mx - mn;
+    return 2e-5f * fmaxf_(e.x, fmaxf_(e.y, e.z)) + scenePad;
+}
+static inline float scene_pad(float3 smn, float3 smx) { return 2e-6f * length(smx - smn); }
+static inline bool tri_box_accepts(const TriRecord& tr, float3 o, float3 inv, float t) {
+    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
+    float3 mn = min3v(tr.v0, min3v(q1, q2)) - make_float3(tr.pad), mx = max3v(tr.v0, max3v(q1, q2)) + make_float3(tr.pad);
+    float ax = (mn.x - o.x) * inv.x, bx = (mx.x - o.x) * inv.x, ay = (mn.y - o.y) * inv.y, by = (mx.y - o.y) * inv.y, az = (mn.z - o.z) * inv.z, bz = (mx.z - o.z) * inv.z;
+    float tn = fmaxf_(fmaxf_(fminf_(ax, bx), fminf_(ay, by)), fminf_(az, bz));
+    float tf = fminf_(fminf_(fmaxf_(ax, bx), fmaxf_(ay, by)), fmaxf_(az, bz));
+    return (tn <= t) && (t <= tf);
+}
+static inline bool intersect_tri(const TriRecord& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
+    if (!intersect_tri_mt(tr, o, d, tmin, tmax, t, u, v)) return false;
+    return tri_box_accepts(tr, o, make_float3(ray_safe_rcp(d.x), ray_safe_rcp(d.y), ray_safe_rcp(d.z)), t);
 }
 // AlphaTestImpl (BridgeDonut:929-971)
 static inline bool alpha_test(const DeviceScene& sc, uint prim, float u, float v) {

@@ -45,10 +45,20 @@ static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 #define T8_LEAF_BATCH 8         // quads (of 16) that must hold a postponed leaf before the wave runs the leaf block (17 = only when a quad is blocked; A/B in profiles/)
 #endif
 
-__device__ __forceinline__ float t8_rcp_dir(float d) {     // v_rcp_f32 (1 ulp): the slab test is only required to be conservative, see the tf padding
-    float a = fabsf(d);
-    float s = (a < 7.888609e-31f) ? 7.888609e-31f : a;
-    return __builtin_amdgcn_rcpf((d < 0.0f) ? -s : s);
+// the ray's reciprocal direction is the correctly rounded one of the hit definition (pt_scene.h tri_box_accepts): inner nodes and the triangle's own
+// box are then tested with the same arithmetic, which is what makes the closest hit independent of the tree (three divisions per ray, not per node)
+__device__ __forceinline__ float t8_rcp_dir(float d) { return ray_safe_rcp(d); }
+// tri_box_accepts (pt_scene.h) with the hardware's min/max (v_min3/v_max3 instead of compare + select pairs: 41 instead of 71 VALU instructions). The
+// operands are finite here — Moeller-Trumbore has already accepted the triangle, so neither the ray nor the vertices hold a NaN — and on finite
+// operands minNum / maxNum differ from `(a < b) ? a : b` only in the sign of a zero, which no comparison below can see: same boolean, bit for bit.
+__device__ __forceinline__ bool t8_tri_box_accepts(const TriRecord& tr, float3 o, float ix, float iy, float iz, float t) {
+    const float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
+    const float mnx = fminf(tr.v0.x, fminf(q1.x, q2.x)) - tr.pad, mny = fminf(tr.v0.y, fminf(q1.y, q2.y)) - tr.pad, mnz = fminf(tr.v0.z, fminf(q1.z, q2.z)) - tr.pad;
+    const float mxx = fmaxf(tr.v0.x, fmaxf(q1.x, q2.x)) + tr.pad, mxy = fmaxf(tr.v0.y, fmaxf(q1.y, q2.y)) + tr.pad, mxz = fmaxf(tr.v0.z, fmaxf(q1.z, q2.z)) + tr.pad;
+    const float ax = (mnx - o.x) * ix, bx = (mxx - o.x) * ix, ay = (mny - o.y) * iy, by = (mxy - o.y) * iy, az = (mnz - o.z) * iz, bz = (mxz - o.z) * iz;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return (tn <= t) && (t <= tf);
 }
 __device__ __forceinline__ unsigned long long t8_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // v_cmp straight into an SGPR pair
 __device__ __forceinline__ uint quad_bits(unsigned long long m, uint gl) { return (uint)(m >> gl) & 0xFu; }
@@ -160,7 +170,12 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                     o = make_float3(__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]));
                     d = make_float3(__uint_as_float(slot[3]), __uint_as_float(slot[4]), __uint_as_float(slot[5]));
                     tag = slot[6];
-                    ix = t8_rcp_dir(d.x); iy = t8_rcp_dir(d.y); iz = t8_rcp_dir(d.z);
+                    {   // three correctly rounded divisions per ray: lane q of the quad does component q, quad-permute broadcasts hand the results round
+                        const float mine = t8_rcp_dir(q == 0u ? d.x : (q == 1u ? d.y : d.z));
+                        ix = __uint_as_float((uint)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mine), 0x00, 0xF, 0xF, true));      // quad_perm [0,0,0,0]
+                        iy = __uint_as_float((uint)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mine), 0x55, 0xF, 0xF, true));      // quad_perm [1,1,1,1]
+                        iz = __uint_as_float((uint)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mine), 0xAA, 0xF, 0xF, true));      // quad_perm [2,2,2,2]
+                    }
 #if T8_FAST_INNER
                     {   // child bytes: q0 = lo.x lo.y lo.z hi.x (selector values 0..3), q1 = hi.y hi.z (4, 5)
                         const uint nxb = ix < 0.f ? 3u : 0u, fxb = ix < 0.f ? 0u : 3u, nyb = iy < 0.f ? 4u : 1u, fyb = iy < 0.f ? 1u : 4u, nzb = iz < 0.f ? 5u : 2u, fzb = iz < 0.f ? 2u : 5u;
@@ -285,16 +300,17 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                     const char* tp = trisBase + (triOff0 + (T8_LANES * 48u) * r);
                     const f32x4 ta = *reinterpret_cast<const f32x4*>(tp), tb = *reinterpret_cast<const f32x4*>(tp + 16), tc = *reinterpret_cast<const f32x4*>(tp + 32);
                     TriRecord tr; tr.v0 = make_float3(ta.x, ta.y, ta.z); tr.prim = __float_as_uint(ta.w);
-                    tr.e1 = make_float3(tb.x, tb.y, tb.z); tr.flags = __float_as_uint(tb.w); tr.e2 = make_float3(tc.x, tc.y, tc.z);
+                    tr.e1 = make_float3(tb.x, tb.y, tb.z); tr.flags = __float_as_uint(tb.w); tr.e2 = make_float3(tc.x, tc.y, tc.z); tr.pad = tc.w;
                     if (COUNT) ctr.triTests++;
                     float t, u, v;
-                    if (intersect_tri(tr, o, d, tmin, tmax, t, u, v)) {
+                    if (intersect_tri_mt(tr, o, d, tmin, tmax, t, u, v)) {
                         bool c;
                         if (ANYHIT) {
-                            c = true;
-                            if (tr.flags & 1u) { if (COUNT && !(tr.flags & 2u)) alphaRan = true; c = !(tr.flags & 2u) && alpha_test_slot(sc, ((pend & 0x7FFFFFFFu) >> 3) + q + T8_LANES * r, u, v); }      // AlphaTestVisibilityRay (BridgeDonut:981-989)
+                            c = t8_tri_box_accepts(tr, o, ix, iy, iz, t);
+                            if (c && (tr.flags & 1u)) { if (COUNT && !(tr.flags & 2u)) alphaRan = true; c = !(tr.flags & 2u) && alpha_test_slot(sc, ((pend & 0x7FFFFFFFu) >> 3) + q + T8_LANES * r, u, v); }      // AlphaTestVisibilityRay (BridgeDonut:981-989)
                         } else {
                             c = ((t < bestT) || (t == bestT && tr.prim < bestPrim)) && ((t < lt) || (t == lt && tr.prim < lp));
+                            if (c) c = t8_tri_box_accepts(tr, o, ix, iy, iz, t);      // only a candidate that would become the best needs the second half of the hit definition
                             if (c && (tr.flags & 1u)) { if (COUNT) alphaRan = true; c = alpha_test_slot(sc, ((pend & 0x7FFFFFFFu) >> 3) + q + T8_LANES * r, u, v); }
                         }
                         if (c) { lt = t; lp = tr.prim; lu = u; lv = v; }

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
             uint4 a = pool.s0[p], b = pool.s1[p];
             float3 o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)), d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
             float t, u = 0.f, v = 0.f;
-            (void)intersect_tri(sc.tris[aux.primToSlot[prim]], o, d, 0.0f, kMaxRayTravel, t, u, v);
+            (void)intersect_tri_mt(sc.tris[aux.primToSlot[prim]], o, d, 0.0f, kMaxRayTravel, t, u, v);      // the winner was accepted by the traversal; only (u, v) are needed
             out.z = asuint(u); out.w = asuint(v);
         }
         pool.hit[p] = out;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, ui
 }
 
 template <bool COUNT, bool GROUPED>
-__global__ void __launch_bounds__(T8_BLOCK) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
+__global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : 6) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
     const uint count = *countPtr;

@@ -441,6 +441,51 @@ def _boxes(c, h, yaw):
     return C, A2, B2
 
 
+def sliver_stress(n_strips=400, seed=SEED_BASE + 9):
+    """Geometry on which fp32 Moeller-Trumbore is badly conditioned: 120 m x 0.3 mm strips (aspect 4e5, as the roof tiles of bistro_like at scale 1),
+    needle triangles, large walls, small axis-aligned quads; with rays that graze them. Used to check that the closest hit does not depend on the BVH
+    (the hit definition of pt_scene.h: tri_box_accepts). Returns (scene dict, rays (n,8) float32: origin, tmin, direction, tmax)."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    m = b.add_material(make_material(base=(0.7, 0.7, 0.7)))
+    b.begin_mesh()
+    tq = (np.arange(n_strips) + 0.5) / n_strips
+    cq = np.stack([np.full(n_strips, 60.0), 25.0 + tq * 3.6, 8.0 - tq * 8.0], 1)
+    aq = np.tile([[60.0, 0, 0]], (n_strips, 1)); hw = 0.6 * 8.0 / 30000
+    bq = np.tile([[0, hw * 0.45, -hw]], (n_strips, 1))
+    p, i, uv, n, t = _quads(cq, aq, bq); b.add_geometry(p, i, m, uv=uv, normal=n, tangent=t)
+    # needles in random orientation
+    k = n_strips
+    c = rng.uniform((5, 1, 10), (115, 20, 30), (k, 3)); u = rng.normal(size=(k, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    w = np.cross(u, rng.normal(size=(k, 3))); w /= np.linalg.norm(w, axis=1, keepdims=True)
+    p, i, uv, n, t = _quads(c, u * rng.uniform(2, 30, (k, 1)), w * rng.uniform(1e-4, 1e-3, (k, 1))); b.add_geometry(p, i, m, uv=uv, normal=n, tangent=t)
+    # big walls + small axis-aligned quads
+    p, i, uv, n, t = quad((0, 0, 8), (0, 25, 8), (120, 25, 8), (120, 0, 8)); b.add_geometry(p, i, m, uv=uv, normal=n, tangent=t)
+    p, i, uv, n, t = quad((0, 0, 0), (0, 0, 40), (120, 0, 40), (120, 0, 0)); b.add_geometry(p, i, m, uv=uv, normal=n, tangent=t)
+    c = rng.uniform((5, 1, 10), (115, 20, 30), (k, 3)); s = rng.uniform(0.03, 0.12, k)
+    p, i, uv, n, t = _quads(c, np.stack([s, 0 * s, 0 * s], 1), np.stack([0 * s, 0 * s, s], 1)); b.add_geometry(p, i, m, uv=uv, normal=n, tangent=t)
+    b.add_instance(b.end_mesh())
+    sc = b.finish()
+    # rays: towards random points on (and just beyond the ends of) the strips / needles, from far away, many of them grazing
+    P = sc["positions"]; I = sc["indices"].reshape(-1, 3)
+    nr = 400000
+    tri = rng.integers(0, I.shape[0], nr)
+    bary = rng.dirichlet((1, 1, 1), nr).astype(np.float32)
+    overshoot = np.where(rng.random(nr) < 0.5, rng.uniform(-0.02, 0.02, nr), 0.0)[:, None]      # half the targets lie just outside an edge
+    v0, v1, v2 = P[I[tri, 0]], P[I[tri, 1]], P[I[tri, 2]]
+    target = v0 * bary[:, 0:1] + v1 * bary[:, 1:2] + v2 * bary[:, 2:3] + (v1 - v0) * overshoot
+    nrm = np.cross(v1 - v0, v2 - v0); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+    tang = (v1 - v0) / np.maximum(np.linalg.norm(v1 - v0, axis=1, keepdims=True), 1e-30)
+    graze = 10.0 ** rng.uniform(-4, 0, nr)[:, None]                                             # |cos| between the ray and the plane normal
+    dirv = nrm * graze + tang * np.sqrt(np.maximum(0.0, 1 - graze * graze)) * np.where(rng.random(nr) < 0.5, 1.0, -1.0)[:, None]
+    dirv += rng.normal(size=(nr, 3)) * 1e-3 * (rng.random(nr) < 0.5)[:, None]
+    dirv /= np.linalg.norm(dirv, axis=1, keepdims=True)
+    dist = rng.uniform(0.5, 90.0, nr)[:, None]
+    org = target - dirv * dist
+    rays = np.concatenate([org, np.zeros((nr, 1)), dirv, np.full((nr, 1), 1e15)], 1).astype(np.float32)
+    return sc, rays
+
+
 def bistro_like(scale=1.0, seed=SEED_BASE + 3, tex_size=1024, animated=False):
     """Street canyon 120 x 40 x 25 m: ~2.8 M triangles at scale=1 (60 % long thin facade quads, 25 % alpha-tested foliage cards,
     15 % clutter boxes), 2000 emissive triangles, 64 materials, 32 textures, sky environment. `scale` shrinks the triangle counts

@@ -7,6 +7,8 @@
     global-memory tail (pt_traverse8.h: BVH8_STACK + T8_SPILL_DEPTH) — closest hits and visibility must still equal the oracle
   * degenerate triangles (zero area, duplicated vertices) and rays parallel to triangles / starting on them
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -154,3 +156,29 @@ def test_degenerate_triangles_and_grazing_rays():
     vg, _ = g.trace_visibility(rays); vo = o.trace_visibility(rays)
     assert np.array_equal(vg, vo)
     assert hg[0, 1].view(np.uint32) == 0 and hg[1, 1].view(np.uint32) == 3 and hg[5, 1].view(np.uint32) == 0xFFFFFFFF
+
+
+def test_closest_hit_equals_exhaustive_loop_on_badly_conditioned_geometry():
+    """The HIP traversal (both builders) against the oracle's exhaustive loop on the sliver / grazing-ray stress set: identical hit records, i.e. the
+    closest hit does not depend on the tree above the triangles (pt_scene.h tri_box_accepts)."""
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    from oracle import ptref
+    sc, rays = scenes.sliver_stress()
+    o = ptref.Oracle(); o.set_scene(sc); o.set_settings(scenes.default_settings())
+    want_bvh = o.trace_closest(rays)
+    nb = 40000
+    want_brute = o.trace_closest(rays[:nb], brute=True)
+    assert np.array_equal(want_bvh[:nb].view(np.uint32), want_brute.view(np.uint32))
+    vis_o = o.trace_visibility(rays)
+    for builder in ("ploc", "karras"):
+        os.environ["MI355PT_BVH_BUILDER"] = builder
+        try:
+            g = pt.PathTracer(); g.set_scene(sc); g.set_settings(scenes.default_settings())
+            got, _ = g.trace_closest(rays)
+            vis_g, _ = g.trace_visibility(rays)
+        finally:
+            os.environ.pop("MI355PT_BVH_BUILDER", None)
+        same = (got.view(np.uint32) == want_bvh.view(np.uint32)).all(1)
+        assert same.all(), "%s: %d of %d closest-hit records differ" % (builder, int((~same).sum()), same.size)
+        assert np.array_equal(vis_g, vis_o), builder

@@ -1,0 +1,85 @@
+"""GPU parity at BASELINE.json's FULL sizes (run with -m gpu): the configuration bench.py times — C3, 2.8 M triangles, 3840x2160, 4 spp, 8 bounces —
+and C5 (the animated variant: per-frame refit + nested dielectrics) are compared with the oracle on complete pixel rows and on a pixel block, bit for
+bit, plus the size-independent properties (accumulation associativity, finite non-negative radiance, ray budget). These are the sizes at which 32-bit
+node / triangle offsets, the 2 GB sparse table of the BVH builder, the 4-batch pipeline and the multi-round straggler splitting are exercised; the
+small-scale tests in test_gpu_parity.py never reach them."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H, SPP = 3840, 2160, 4
+
+
+def _imports():
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    from oracle import ptref
+    return pt, scenes, ptref
+
+
+def _oracle_rects(o, rects, first, n):
+    out = []
+    for r in rects:
+        o.reset_accumulation(); o.render(first, n, rect=r)
+        out.append(o.radiance()[r[1]:r[3], r[0]:r[2], :3].copy())
+    return out
+
+
+def test_c3_full_size_4k_rows_and_block_bit_exact():
+    """BASELINE configs[2] = bench.py's workload at full size: 9 complete rows of the 4K frame and a 256x128 block around the frame centre are
+    bit-identical to the oracle; ray counts of a sub-frame equal the oracle's."""
+    pt, scenes, ptref = _imports()
+    sc, cam = scenes.bistro_like(scale=1.0, tex_size=1024)
+    S = scenes.default_settings()
+    camd = scenes.bridge_camera(W, H, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(W, H)
+    st = g.render(0, SPP); a = g.radiance()
+    assert np.isfinite(a).all() and (a >= 0).all() and np.all(a[..., 3] == 1.0)
+    assert st["pathsTraced"] == W * H * SPP
+    assert st["extendRays"] <= 10 * st["pathsTraced"] and st["shadowRays"] <= st["extendRays"]
+    # accumulation is associative over pt_render calls (bit-exact) at this size too
+    g.reset_accumulation(); g.render(0, 1); g.render(1, 3)
+    assert np.array_equal(a, g.radiance())
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(W, H)
+    rows = list(range(7, H, 256))
+    rects = [(0, y, W, y + 1) for y in rows] + [(W // 2 - 128, H // 2 - 64, W // 2 + 128, H // 2 + 64)]
+    want = _oracle_rects(o, rects, 0, SPP)
+    for r, wnt in zip(rects, want):
+        got = a[r[1]:r[3], r[0]:r[2], :3]
+        bad = int((got.view(np.uint32) != wnt.view(np.uint32)).any(-1).sum())
+        assert bad == 0, "rect %s: %d pixels differ" % (r, bad)
+    # ray counts: the same frame at 1/6 resolution per axis is small enough for a whole-frame oracle render
+    w2, h2 = W // 6, H // 6
+    camd2 = scenes.bridge_camera(w2, h2, **cam)
+    g.set_camera(camd2); g.resize(w2, h2); st2 = g.render(0, SPP)
+    o.set_camera(camd2); o.resize(w2, h2); o.reset_accumulation(); o.render(0, SPP)      # (reset also clears the oracle's ray counters)
+    c = o.counters()
+    assert np.array_equal(g.radiance(), o.radiance())
+    assert (st2["extendRays"], st2["shadowRays"], st2["hits"]) == (c["extendRays"], c["shadowRays"], c["hits"])
+
+
+def test_c5_full_size_4k_animated_refit_rows_bit_exact():
+    """BASELINE configs[4] on one GPU at full size: two animated frames (rigid clutter groups + deforming banner; refit only, no rebuild) with
+    nestedDielectricsQuality 2; per frame 5 complete rows equal an oracle rebuilt from scratch for that frame."""
+    pt, scenes, ptref = _imports()
+    sc, cam = scenes.bistro_like(scale=1.0, tex_size=1024, animated=True)
+    S = scenes.default_settings(nestedDielectricsQuality=2)
+    camd = scenes.bridge_camera(W, H, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(W, H)
+    for frame, t in enumerate((0.0, 0.6)):
+        inst, pos = scenes.animate_instances(sc, t), scenes.animate_positions(sc, t)
+        g.animate(instances=inst, positions=pos, rebuild=False)
+        g.reset_accumulation(); st = g.render(frame * SPP, SPP); a = g.radiance()
+        assert np.isfinite(a).all() and (a >= 0).all()
+        sc_t = dict(sc); sc_t["positions"] = pos
+        o = ptref.Oracle(); o.set_scene(sc_t); o.set_instances(inst); o.set_camera(camd); o.set_settings(S); o.resize(W, H)
+        rects = [(0, y, W, y + 1) for y in range(11 + 37 * frame, H, 512)]
+        for r, wnt in zip(rects, _oracle_rects(o, rects, frame * SPP, SPP)):
+            got = a[r[1]:r[3], r[0]:r[2], :3]
+            bad = int((got.view(np.uint32) != wnt.view(np.uint32)).any(-1).sum())
+            assert bad == 0, "frame %d rect %s: %d pixels differ" % (frame, r, bad)
+        o.close()
+    assert g.build_stats()["refitMs"] > 0

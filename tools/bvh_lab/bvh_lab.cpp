@@ -1,0 +1,298 @@
+// developer tool (CPU only, not part of the product or the oracle): how much would a better tree buy the BVH8 traversal?
+// Builds the scene's BVH with several builders (Morton LBVH as pt_build.hip does, PLOC, binned top-down SAH), collapses each to BVH8 with the
+// product's greedy rule or a cost-driven rule, and counts node visits / leaf visits / triangle tests per ray of a nearest-first traversal with the
+// product's pruning rules over a set of path-like rays (camera rays + cosine-distributed bounces). Input: tools/bvh_lab/dump_tris.py.
+//   g++ -O3 -march=native -fopenmp -std=c++17 tools/bvh_lab/bvh_lab.cpp -o /tmp/bvh_lab && /tmp/bvh_lab /tmp/bvh_lab_tris.bin
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <vector>
+#include <omp.h>
+
+struct V3 { float x, y, z; };
+static inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+static inline V3 vmin(V3 a, V3 b) { return {std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)}; }
+static inline V3 vmax(V3 a, V3 b) { return {std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)}; }
+static inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static inline V3 normalize(V3 a) { float l = std::sqrt(dot(a, a)); return a * (1.0f / l); }
+struct Box { V3 mn{3e38f, 3e38f, 3e38f}, mx{-3e38f, -3e38f, -3e38f};
+    void grow(V3 p) { mn = vmin(mn, p); mx = vmax(mx, p); }
+    void grow(const Box& b) { mn = vmin(mn, b.mn); mx = vmax(mx, b.mx); }
+    float area() const { V3 e = mx - mn; return e.x * e.y + e.y * e.z + e.z * e.x; } };
+static inline Box unite(const Box& a, const Box& b) { Box r = a; r.grow(b); return r; }
+struct Tri { V3 v0, e1, e2; };
+
+struct Node { Box box; int l = -1, r = -1; int first = 0, count = 0; };      // count > 0: leaf over order[first .. first+count)
+struct Bvh2 { std::vector<Node> nodes; std::vector<int> order; int root = 0; };
+
+static std::vector<Tri> tris; static std::vector<Box> tbox; static std::vector<V3> tcen;
+
+static uint64_t expand21(uint32_t v) { uint64_t x = v & 0x1FFFFF; x = (x | x << 32) & 0x1F00000000FFFFull; x = (x | x << 16) & 0x1F0000FF0000FFull; x = (x | x << 8) & 0x100F00F00F00F00Full; x = (x | x << 4) & 0x10C30C30C30C30C3ull; x = (x | x << 2) & 0x1249249249249249ull; return x; }
+static std::vector<int> morton_order(std::vector<uint64_t>* keysOut = nullptr) {
+    Box sb; for (auto& b : tbox) sb.grow(b);
+    V3 ext = sb.mx - sb.mn; int n = (int)tris.size();
+    std::vector<uint64_t> keys(n);
+    for (int i = 0; i < n; i++) {
+        V3 c = tcen[i];
+        auto q = [](float s) { return (uint32_t)std::min(std::max(s * 2097152.0f, 0.0f), 2097151.0f); };
+        keys[i] = (expand21(q((c.x - sb.mn.x) / ext.x)) << 2) | (expand21(q((c.y - sb.mn.y) / ext.y)) << 1) | expand21(q((c.z - sb.mn.z) / ext.z));
+    }
+    std::vector<int> ord(n); std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return keys[a] < keys[b]; });
+    if (keysOut) { keysOut->resize(n); for (int i = 0; i < n; i++) (*keysOut)[i] = keys[ord[i]]; }
+    return ord;
+}
+
+// ---- LBVH (same topology as Karras over sorted 63-bit codes: split at the highest differing bit; ties split on the index)
+static Bvh2 build_lbvh() {
+    Bvh2 b; std::vector<uint64_t> keys; b.order = morton_order(&keys); int n = (int)tris.size();
+    b.nodes.reserve(2 * n);
+    auto delta = [&](int i, int j) -> int { if (keys[i] == keys[j]) return 64 + __builtin_clz((uint32_t)i ^ (uint32_t)j); return __builtin_clzll(keys[i] ^ keys[j]); };
+    std::function<int(int, int)> rec = [&](int lo, int hi) -> int {
+        int id = (int)b.nodes.size(); b.nodes.emplace_back();
+        if (lo == hi) { Node& nd = b.nodes[id]; nd.first = lo; nd.count = 1; nd.box = tbox[b.order[lo]]; return id; }
+        int d = delta(lo, hi), s = lo, step = hi - lo;       // largest s in [lo, hi) with delta(lo, s) > d
+        do { step = (step + 1) >> 1; int ns = s + step; if (ns < hi && delta(lo, ns) > d) s = ns; } while (step > 1);
+        int l = rec(lo, s), r = rec(s + 1, hi);
+        Node& nd = b.nodes[id]; nd.l = l; nd.r = r; nd.box = unite(b.nodes[l].box, b.nodes[r].box); nd.first = lo; nd.count = 0;
+        return id;
+    };
+    b.root = rec(0, n - 1);
+    return b;
+}
+
+// ---- PLOC (Meister & Bittner 2018): nearest-neighbour merging of Morton-ordered clusters within a window of `radius`
+static Bvh2 build_ploc(int radius) {
+    Bvh2 b; std::vector<int> mord = morton_order(); int n = (int)tris.size();
+    b.nodes.resize(n); b.nodes.reserve(2 * n);
+    std::vector<int> cl(n), nn(n), nxt; cl.reserve(n);
+    for (int i = 0; i < n; i++) { Node& nd = b.nodes[i]; nd.first = mord[i]; nd.count = 1; nd.box = tbox[mord[i]]; cl[i] = i; }      // first = triangle id for now
+    int m = n, iters = 0;
+    while (m > 1) {
+        #pragma omp parallel for schedule(static)
+        for (int i = 0; i < m; i++) {
+            float best = 3e38f; int bj = -1; const Box& bi = b.nodes[cl[i]].box;
+            for (int j = std::max(0, i - radius); j <= std::min(m - 1, i + radius); j++) if (j != i) { float a = unite(bi, b.nodes[cl[j]].box).area(); if (a < best) { best = a; bj = j; } }
+            nn[i] = bj;
+        }
+        nxt.clear();
+        for (int i = 0; i < m; i++) {
+            int j = nn[i];
+            if (nn[j] == i) { if (i < j) { int id = (int)b.nodes.size(); b.nodes.emplace_back(); Node& nd = b.nodes[id]; nd.l = cl[i]; nd.r = cl[j]; nd.box = unite(b.nodes[cl[i]].box, b.nodes[cl[j]].box); nxt.push_back(id); } }
+            else nxt.push_back(cl[i]);
+        }
+        cl.swap(nxt); m = (int)cl.size(); iters++;
+    }
+    b.root = cl[0];
+    // DFS order of the leaves -> contiguous ranges
+    b.order.clear(); b.order.reserve(n);
+    std::vector<int> st{b.root}; std::vector<int> post;
+    std::function<void(int)> dfs = [&](int id) { Node& nd = b.nodes[id]; if (nd.count) { int t = nd.first; nd.first = (int)b.order.size(); b.order.push_back(t); return; } int f = (int)b.order.size(); dfs(nd.l); dfs(nd.r); nd.first = f; };
+    // iterative to avoid deep recursion
+    { struct F { int id, stage; }; std::vector<F> s{{b.root, 0}};
+      while (!s.empty()) { F f = s.back(); s.pop_back(); Node& nd = b.nodes[f.id];
+        if (nd.count) { int t = nd.first; nd.first = (int)b.order.size(); b.order.push_back(t); continue; }
+        if (f.stage == 0) { nd.first = (int)b.order.size(); s.push_back({nd.r, 0}); s.push_back({nd.l, 0}); } } }
+    fprintf(stderr, "  ploc r=%d: %d iterations\n", radius, iters);
+    return b;
+}
+
+// ---- binned top-down SAH (object splits), to single-triangle leaves
+static Bvh2 build_sah(int bins) {
+    Bvh2 b; int n = (int)tris.size(); b.order.resize(n); std::iota(b.order.begin(), b.order.end(), 0); b.nodes.reserve(2 * n);
+    struct Job { int id, lo, hi; };
+    b.nodes.emplace_back(); std::vector<Job> jobs{{0, 0, n}};
+    while (!jobs.empty()) {
+        Job j = jobs.back(); jobs.pop_back();
+        Box nb, cb; for (int i = j.lo; i < j.hi; i++) { nb.grow(tbox[b.order[i]]); cb.grow(tcen[b.order[i]]); }
+        b.nodes[j.id].box = nb; b.nodes[j.id].first = j.lo;
+        int cnt = j.hi - j.lo;
+        if (cnt == 1) { b.nodes[j.id].count = 1; continue; }
+        float bestCost = 3e38f; int bestAxis = -1, bestBin = -1;
+        for (int ax = 0; ax < 3; ax++) {
+            float lo = (&cb.mn.x)[ax], hi = (&cb.mx.x)[ax]; if (!(hi > lo)) continue;
+            std::vector<Box> bb(bins); std::vector<int> bc(bins, 0); float k = bins / (hi - lo);
+            for (int i = j.lo; i < j.hi; i++) { int t = b.order[i]; int bi = std::min(bins - 1, (int)(((&tcen[t].x)[ax] - lo) * k)); bb[bi].grow(tbox[t]); bc[bi]++; }
+            std::vector<float> ra(bins); Box acc; int c = 0;
+            for (int i = bins - 1; i > 0; i--) { acc.grow(bb[i]); c += bc[i]; ra[i] = c ? acc.area() * c : 3e38f; }
+            acc = Box(); c = 0;
+            for (int i = 0; i < bins - 1; i++) { acc.grow(bb[i]); c += bc[i]; if (!c || c == cnt) continue; float cost = acc.area() * c + ra[i + 1]; if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = i; } }
+        }
+        int mid;
+        if (bestAxis < 0) mid = j.lo + cnt / 2;
+        else { float lo = (&cb.mn.x)[bestAxis], hi = (&cb.mx.x)[bestAxis], k = bins / (hi - lo);
+               mid = (int)(std::partition(b.order.begin() + j.lo, b.order.begin() + j.hi, [&](int t) { return std::min(bins - 1, (int)(((&tcen[t].x)[bestAxis] - lo) * k)) <= bestBin; }) - b.order.begin());
+               if (mid == j.lo || mid == j.hi) mid = j.lo + cnt / 2; }
+        int l = (int)b.nodes.size(); b.nodes.emplace_back(); int r = (int)b.nodes.size(); b.nodes.emplace_back();
+        b.nodes[j.id].l = l; b.nodes[j.id].r = r;
+        jobs.push_back({l, j.lo, mid}); jobs.push_back({r, mid, j.hi});
+    }
+    b.root = 0;
+    return b;
+}
+
+static int subtree_tris(const Bvh2& b, int id, std::vector<int>& cnt) { const Node& nd = b.nodes[id]; if (nd.count) return cnt[id] = nd.count; return cnt[id] = subtree_tris(b, nd.l, cnt) + subtree_tris(b, nd.r, cnt); }
+static double sah_cost2(const Bvh2& b) { double c = 0; double ra = b.nodes[b.root].box.area(); for (auto& nd : b.nodes) c += nd.box.area() / ra * (nd.count ? nd.count : 1.0); return c; }
+
+// ---- BVH8
+struct Wide { Box cb[8]; int ref[8]; int n = 0; };     // ref >= 0: wide node; ref < 0: leaf ~ref = first<<4 | (count-1)
+struct Bvh8 { std::vector<Wide> nodes; std::vector<int> order; };
+
+// mode 0: the product's rule (leaf = sub-tree of <= maxLeaf triangles; open the largest-area inner child until 8 children)
+// mode 1: cost-driven (Ylitie et al. 2017 dynamic programme; every wide-node visit and every leaf visit costs 1 x area)
+static Bvh8 collapse(const Bvh2& b, int maxLeaf, int mode) {
+    Bvh8 w; w.order = b.order; int N = (int)b.nodes.size();
+    std::vector<int> cnt(N, 0);
+    {   // iterative post-order for counts
+        std::vector<int> st{b.root}, po; while (!st.empty()) { int id = st.back(); st.pop_back(); po.push_back(id); if (!b.nodes[id].count) { st.push_back(b.nodes[id].l); st.push_back(b.nodes[id].r); } }
+        for (int k = (int)po.size() - 1; k >= 0; k--) { int id = po[k]; cnt[id] = b.nodes[id].count ? b.nodes[id].count : cnt[b.nodes[id].l] + cnt[b.nodes[id].r]; }
+        if (mode == 1) {
+            // C[id][i], i = 1..7: min cost of representing sub-tree id with at most i roots; D[j], j = 2..8: split j roots over the two children
+            std::vector<std::array<float, 8>> C(N); std::vector<std::array<signed char, 9>> dk(N); std::vector<std::array<signed char, 8>> kind(N);      // kind: 0 single root, 1 distribute, 2 as with one root fewer
+            for (int k = (int)po.size() - 1; k >= 0; k--) {
+                int id = po[k]; const Node& nd = b.nodes[id]; float A = nd.box.area();
+                if (cnt[id] <= maxLeaf) { for (int i = 1; i <= 7; i++) { C[id][i] = A; kind[id][i] = 0; } continue; }
+                float D[9];
+                for (int j = 2; j <= 8; j++) { D[j] = 3e38f; for (int a = 1; a < j; a++) { if (a > 7 || j - a > 7) continue; float c = C[nd.l][a] + C[nd.r][j - a]; if (c < D[j]) { D[j] = c; dk[id][j] = (signed char)a; } } }
+                C[id][1] = A + D[8]; kind[id][1] = 0;
+                for (int i = 2; i <= 7; i++) { C[id][i] = C[id][i - 1]; kind[id][i] = 2; if (D[i] < C[id][i]) { C[id][i] = D[i]; kind[id][i] = 1; } }
+            }
+            struct Job { int wide, id; }; w.nodes.emplace_back(); std::vector<Job> jobs{{0, b.root}};
+            while (!jobs.empty()) {
+                Job j = jobs.back(); jobs.pop_back();
+                std::vector<int> roots;
+                std::function<void(int, int)> place = [&](int id, int i) {          // sub-tree id with budget i
+                    while (kind[id][i] == 2) i--;
+                    if (kind[id][i] == 0) { roots.push_back(id); return; }
+                    int a = dk[id][i]; place(b.nodes[id].l, a); place(b.nodes[id].r, i - a);
+                };
+                { int a = dk[j.id][8]; place(b.nodes[j.id].l, a); place(b.nodes[j.id].r, 8 - a); }
+                Wide wn; wn.n = 0;
+                for (int id : roots) {
+                    if (wn.n >= 8) { fprintf(stderr, "collapse: too many roots\n"); exit(1); }
+                    wn.cb[wn.n] = b.nodes[id].box;
+                    if (cnt[id] <= maxLeaf) wn.ref[wn.n] = ~((b.nodes[id].first << 4) | (cnt[id] - 1));
+                    else { int nw = (int)w.nodes.size(); w.nodes.emplace_back(); wn.ref[wn.n] = nw; jobs.push_back({nw, id}); }
+                    wn.n++;
+                }
+                w.nodes[j.wide] = wn;
+            }
+            return w;
+        }
+    }
+    struct Job { int wide, id; }; w.nodes.emplace_back(); std::vector<Job> jobs{{0, b.root}};
+    while (!jobs.empty()) {
+        Job j = jobs.back(); jobs.pop_back();
+        int ids[8]; int n = 0; ids[n++] = b.nodes[j.id].l; ids[n++] = b.nodes[j.id].r;
+        while (n < 8) { int best = -1; float ba = -1; for (int k = 0; k < n; k++) if (cnt[ids[k]] > maxLeaf) { float a = b.nodes[ids[k]].box.area(); if (a > ba) { ba = a; best = k; } }
+            if (best < 0) break; int id = ids[best]; ids[best] = b.nodes[id].l; ids[n++] = b.nodes[id].r; }
+        Wide wn; wn.n = n;
+        for (int k = 0; k < n; k++) { int id = ids[k]; wn.cb[k] = b.nodes[id].box;
+            if (cnt[id] <= maxLeaf) wn.ref[k] = ~((b.nodes[id].first << 4) | (cnt[id] - 1));
+            else { int nw = (int)w.nodes.size(); w.nodes.emplace_back(); wn.ref[k] = nw; jobs.push_back({nw, id}); } }
+        w.nodes[j.wide] = wn;
+    }
+    return w;
+}
+
+struct Ray { V3 o, d; };
+struct Hit { float t; int prim; };
+struct Ctr { uint64_t nodes = 0, leaves = 0, tris = 0, rays = 0; };
+
+static inline bool isect(const Tri& tr, V3 o, V3 d, float tmax, float& t) {
+    V3 p = cross(d, tr.e2); float det = dot(tr.e1, p); if (det == 0.f) return false; float inv = 1.f / det;
+    V3 tv = o - tr.v0; float u = dot(tv, p) * inv; if (u < 0.f || u > 1.f) return false;
+    V3 q = cross(tv, tr.e1); float v = dot(d, q) * inv; if (v < 0.f || u + v > 1.f) return false;
+    t = dot(tr.e2, q) * inv; return t > 0.f && t < tmax;
+}
+static Hit trace8(const Bvh8& w, const Ray& r, Ctr& c) {
+    Hit h{1e30f, -1}; V3 id{1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z};
+    struct E { int ref; float t; }; E stack[256]; int sp = 0; int cur = 0; bool have = true;
+    c.rays++;
+    while (true) {
+        if (!have) { bool got = false; while (sp) { E e = stack[--sp]; if (e.t <= h.t) { cur = e.ref; got = true; break; } } if (!got) break; }
+        have = false;
+        if (cur >= 0) {
+            const Wide& n = w.nodes[cur]; c.nodes++;
+            E hits[8]; int nh = 0;
+            for (int k = 0; k < n.n; k++) {
+                const Box& b = n.cb[k];
+                float tx1 = (b.mn.x - r.o.x) * id.x, tx2 = (b.mx.x - r.o.x) * id.x, ty1 = (b.mn.y - r.o.y) * id.y, ty2 = (b.mx.y - r.o.y) * id.y, tz1 = (b.mn.z - r.o.z) * id.z, tz2 = (b.mx.z - r.o.z) * id.z;
+                float tn = std::max(std::max(std::min(tx1, tx2), std::min(ty1, ty2)), std::max(std::min(tz1, tz2), 0.f));
+                float tf = std::min(std::min(std::max(tx1, tx2), std::max(ty1, ty2)), std::min(std::max(tz1, tz2), h.t));
+                if (tn <= tf) hits[nh++] = {n.ref[k], tn};
+            }
+            if (!nh) continue;
+            std::sort(hits, hits + nh, [](const E& a, const E& b) { return a.t < b.t; });
+            for (int k = nh - 1; k >= 1; k--) stack[sp++] = hits[k];
+            cur = hits[0].ref; have = true;
+        } else {
+            int code = ~cur, first = code >> 4, cnt = (code & 15) + 1; c.leaves++; c.tris += cnt;
+            for (int k = 0; k < cnt; k++) { int t = w.order[first + k]; float tt; if (isect(tris[t], r.o, r.d, h.t, tt)) { h.t = tt; h.prim = t; } }
+        }
+    }
+    return h;
+}
+
+static uint32_t rng_state = 12345u;
+static inline float frand(uint32_t& s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return (s >> 8) * (1.0f / 16777216.0f); }
+
+int main(int argc, char** argv) {
+    const char* path = argc > 1 ? argv[1] : "/tmp/bvh_lab_tris.bin";
+    int nPaths = argc > 2 ? atoi(argv[2]) : 150000;
+    FILE* f = fopen(path, "rb"); if (!f) { perror(path); return 1; }
+    uint32_t n; if (fread(&n, 4, 1, f) != 1) return 1; std::vector<float> raw((size_t)n * 9); if (fread(raw.data(), 36, n, f) != n) return 1; fclose(f);
+    tris.resize(n); tbox.resize(n); tcen.resize(n);
+    for (uint32_t i = 0; i < n; i++) { V3 a{raw[9 * i], raw[9 * i + 1], raw[9 * i + 2]}, b{raw[9 * i + 3], raw[9 * i + 4], raw[9 * i + 5]}, c{raw[9 * i + 6], raw[9 * i + 7], raw[9 * i + 8]};
+        tris[i] = {a, b - a, c - a}; Box bx; bx.grow(a); bx.grow(b); bx.grow(c); tbox[i] = bx; tcen[i] = a + ((b - a) + (c - a)) * (1.0f / 3.0f); }
+    fprintf(stderr, "%u triangles\n", n);
+
+    // rays: camera rays + cosine bounces over the baseline tree
+    Bvh2 lb = build_lbvh(); Bvh8 base = collapse(lb, 4, 0);
+    std::vector<Ray> rays;
+    { V3 pos{4.0f, 1.7f, 20.0f}, dir = normalize(V3{1.0f, 0.12f, 0.05f}), up{0, 1, 0}; V3 U = normalize(cross(dir, up)), Vv = normalize(cross(U, dir)); float th = std::tan(0.5f * 1.0471975512f), asp = 16.f / 9.f;
+      uint32_t s = 777u; Ctr dummy;
+      for (int p = 0; p < nPaths; p++) {
+          float sx = frand(s) * 2 - 1, sy = frand(s) * 2 - 1;
+          Ray r{pos, normalize(dir + U * (sx * th * asp) + Vv * (sy * th))};
+          for (int bounce = 0; bounce < 9; bounce++) {
+              rays.push_back(r);
+              Hit h = trace8(base, r, dummy); if (h.prim < 0) break;
+              if (bounce >= 2 && frand(s) > 0.75f) break;
+              const Tri& tr = tris[h.prim]; V3 ng = normalize(cross(tr.e1, tr.e2)); if (dot(ng, r.d) > 0) ng = ng * -1.f;
+              V3 hp = r.o + r.d * h.t + ng * 1e-4f;
+              float u1 = frand(s), u2 = frand(s), rr = std::sqrt(u1), ph = 6.2831853f * u2; V3 t1 = normalize(std::fabs(ng.x) > 0.5f ? cross(ng, V3{0, 1, 0}) : cross(ng, V3{1, 0, 0})), t2 = cross(ng, t1);
+              r = {hp, normalize(t1 * (rr * std::cos(ph)) + t2 * (rr * std::sin(ph)) + ng * std::sqrt(std::max(0.f, 1 - u1)))};
+          }
+      } }
+    fprintf(stderr, "%zu rays\n", rays.size());
+    auto eval = [&](const char* name, const Bvh2& b2, int maxLeaf, int mode) {
+        Bvh8 w = collapse(b2, maxLeaf, mode);
+        Ctr tot; uint64_t N = 0, L = 0, T = 0;
+        #pragma omp parallel
+        { Ctr c;
+          #pragma omp for schedule(dynamic, 1024)
+          for (size_t i = 0; i < rays.size(); i++) trace8(w, rays[i], c);
+          #pragma omp critical
+          { N += c.nodes; L += c.leaves; T += c.tris; } }
+        size_t nl = 0, nch = 0; for (auto& wn : w.nodes) { nch += wn.n; for (int k = 0; k < wn.n; k++) nl += wn.ref[k] < 0; }
+        printf("%-34s sah2 %8.2f | wide nodes %8zu fill %.2f leaves %8zu tris/leaf %.2f | per ray: nodes %6.2f leaves %6.2f tris %6.2f  (nodes+leaves %6.2f)\n", name, sah_cost2(b2), w.nodes.size(), (double)nch / w.nodes.size(), nl, (double)n / nl,
+               (double)N / rays.size(), (double)L / rays.size(), (double)T / rays.size(), (double)(N + L) / rays.size());
+        fflush(stdout);
+    };
+    eval("lbvh greedy leaf4 (product)", lb, 4, 0);
+    eval("lbvh cost-driven leaf4", lb, 4, 1);
+    eval("lbvh greedy leaf8", lb, 8, 0);
+    for (int r : {8, 32}) { Bvh2 p = build_ploc(r); char nm[64]; snprintf(nm, 64, "ploc r=%d greedy leaf4", r); eval(nm, p, 4, 0); snprintf(nm, 64, "ploc r=%d cost-driven leaf4", r); eval(nm, p, 4, 1); }
+    { Bvh2 s = build_sah(32); eval("binned sah greedy leaf4", s, 4, 0); eval("binned sah cost-driven leaf4", s, 4, 1); eval("binned sah cost-driven leaf8", s, 8, 1); }
+    return 0;
+}
