@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 # algorithmic bytes: extend ray 52 B fixed + BVH: 128 B per BVH8 node visit + 48 B per triangle test
 B_EXTEND_FIXED, B_NODE, B_TRI, B_SHADE, B_SHADOW_FIXED = 52.0, 128.0, 48.0, 656.0, 80.0
+COUNTERS_FILE = "r02_counters.json"     # rocprofv3 --pmc summary of this workload (tools/profile_round.sh), quoted in roofline{}
 
 
 def main():
@@ -39,6 +40,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="triangle-count scale of the bistro-like generator (1.0 = 2.8 M triangles)")
     ap.add_argument("--tex", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-roofline-steps", action="store_true", help="profiling runs (tools/profile_round.sh): only the timed steps, no extra serial / counter steps")
     ap.add_argument("--serial-kernels", action="store_true", help="run every step with PT_DEVICE_SERIAL_KERNELS semantics (for rocprofv3 kernel traces: launches never overlap)")
     args = ap.parse_args()
 
@@ -106,11 +108,18 @@ def main():
     else:
         rays_total = rays_local
 
-    # roofline of the dominant kernel (k_extend). In the timed region pt_render pipelines two half-frame batches on two streams, so launches of
+    # roofline of the dominant kernel (k_extend). In the timed region pt_render pipelines four sub-frame batches on four streams, so launches of
     # different kernels overlap and a per-launch HIP-event duration there measures "k_extend while sharing the GPU". The launch duration the
     # roofline needs is therefore measured live right after the timed region, on the same context, with the overlap switched off
     # (pt_set_serial_kernels): ROOF_STEPS steps, HIP events on the library's stream around every launch. One more step with the in-kernel BVH
     # counters compiled in gives the mean node visits / triangle tests per ray.
+    if args.skip_roofline_steps:
+        if rank == 0:
+            print(json.dumps({"metric": "Mrays/s (profiling run)", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True}))
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
     ROOF_STEPS = 2
     g.set_serial_kernels(True)
     serial = []
@@ -122,16 +131,24 @@ def main():
     nodes_per_sh = cst["nodeVisitsShadow"] / max(1, cst["shadowRays"]); tris_per_sh = cst["triTestsShadow"] / max(1, cst["shadowRays"])
     ext_ms = sum(s["extendKernelMs"] for s in serial); ext_launches = sum(s["extendLaunches"] for s in serial); ext_rays = sum(s["extendRays"] for s in serial)
     bytes_per_ext = B_EXTEND_FIXED + nodes_per_ext * B_NODE + tris_per_ext * B_TRI
+    bytes_per_sh = B_SHADOW_FIXED + nodes_per_sh * B_NODE + tris_per_sh * B_TRI
     ext_gbs = ext_rays * bytes_per_ext / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
     sh_ms = sum(s["shadowKernelMs"] for s in serial); shade_ms = sum(s["shadeKernelMs"] for s in serial)
     serial_ms = sum(s["gpuMilliseconds"] for s in serial) / ROOF_STEPS
+    # whole frame, SURVEY.md 8(d): extend + shade x 656 B + shadow, against the wall time of the pipelined frame
+    frame_bytes = cst["extendRays"] * bytes_per_ext + cst["hits"] * B_SHADE + cst["shadowRays"] * bytes_per_sh
+    frame_gbs = frame_bytes / (elapsed / args.steps) / 1e9
 
-    # HBM traffic of one k_extend launch from the PMC passes (tools/pmc_traffic.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): the counters
-    # cannot be read from inside this process, so the committed summary of the same workload is quoted (null when the workload differs)
-    traffic, traffic_src = None, None
-    tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tp) and (W, H, SPP, args.scale, args.tex, world) == (3840, 2160, 4, 1.0, 1024, 1):
-        tj = json.load(open(tp)); traffic = tj["k_extend"]["hbm_bytes_per_launch"]; traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    # What bounds the kernel is a counter question, and the counters cannot be read from inside this process: the committed summary of the same
+    # workload (tools/profile_round.sh -> profiles/rNN_counters.json, rocprofv3 --pmc in separate passes) is quoted, null when the workload differs.
+    traffic = hbm_counter_gbs = valu = l2 = None; counters_src = None; bound = "unknown (no counter summary for this workload)"
+    cp = os.path.join(ROOT, "profiles", COUNTERS_FILE)
+    if os.path.exists(cp) and (W, H, SPP, args.scale, args.tex, world) == (3840, 2160, 4, 1.0, 1024, 1):
+        cj = json.load(open(cp))["groups"]["extend"]; counters_src = "profiles/" + COUNTERS_FILE + " (tools/profile_round.sh)"
+        traffic = cj["hbm_bytes_per_launch"]; hbm_counter_gbs = cj["hbm_counter_gbs"]; l2 = cj["l2_hit_rate"]
+        valu = {"busy": cj["valu_busy"], "lane_utilisation": cj["lane_utilisation"], "valu_instructions_per_vmem_read": cj["valu_per_vmem_read"],
+                "wait_any_share_of_wave_cycles": cj["wait_any_share_of_wave_cycles"]}
+        bound = "valu" if (cj["valu_busy"] or 0) > 0.6 and (hbm_counter_gbs or 0) < 0.5 * HBM_PEAK_GBS else ("hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else "latency")
 
     if rank == 0:
         info = g.scene_info()
@@ -143,7 +160,12 @@ def main():
                                    % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP),
                        "parallelism": "pixel-tile shard x%d + 1 gather" % world, "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            # `frac` is the prescribed figure: algorithmic bytes / launch time / 8 TB/s. `bound` is what the counters say limits the kernel:
+            # the BVH is served from L1/L2, HBM itself carries `hbm_counter_gbs`, and the VALU issue slots are what is full.
+            "roofline": {"bound": bound, "prescribed_bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic, "hbm_counter_gbs": hbm_counter_gbs, "l2_hit_rate": l2, "valu": valu, "counters_source": counters_src,
+                         "whole_frame": {"algorithmic_bytes_per_step": frame_bytes, "achieved": frame_gbs, "frac": frame_gbs / HBM_PEAK_GBS,
+                                         "terms": "extend rays x (52 + 128 nodes + 48 tris) + hits x 656 + shadow rays x (80 + 128 nodes + 48 tris), over the pipelined step time"},
                          "bytes_per_ray": bytes_per_ext, "node_visits_per_ray": nodes_per_ext, "tri_tests_per_ray": tris_per_ext,
                          "avg_launch_ms": ext_ms / max(1, ext_launches), "launches": ext_launches,
                          "kernel_ms_per_step": {"k_extend": ext_ms / ROOF_STEPS, "k_shade": shade_ms / ROOF_STEPS, "k_shadow": sh_ms / ROOF_STEPS},

@@ -428,7 +428,11 @@ int32_t pt_set_geometry(pt_context* c, const PtGeometryBuffers* b, const PtGeome
         if ((geoms[g].flags & PT_GEOM_HAS_UV) && !b->uvs) return fail(c, PT_ERROR_INVALID_ARGUMENT, "geometry has uv flag but no uv stream");
         if ((geoms[g].flags & PT_GEOM_HAS_NORMAL) && !b->normals) return fail(c, PT_ERROR_INVALID_ARGUMENT, "geometry has normal flag but no normal stream");
         if ((geoms[g].flags & PT_GEOM_HAS_TANGENT) && !b->tangents) return fail(c, PT_ERROR_INVALID_ARGUMENT, "geometry has tangent flag but no tangent stream");
+        const uint32_t* idx = b->indices + geoms[g].indexOffset;      // an out-of-range index would be an out-of-bounds read on the device
+        for (uint32_t k = 0; k < geoms[g].numIndices; k++) if (idx[k] >= geoms[g].numVertices) return fail(c, PT_ERROR_INVALID_ARGUMENT, "index outside the geometry's vertex range");
     }
+    for (uint32_t m = 0; m < nMeshes; m++)
+        if ((size_t)meshes[m].firstGeometry + meshes[m].numGeometries > nGeoms) return fail(c, PT_ERROR_INVALID_ARGUMENT, "mesh references geometries outside the supplied array");
     uint nv = b->numVertices;
     c->indices.assign(b->indices, b->indices + b->numIndices);
     c->positions.assign(b->positions, b->positions + 3 * (size_t)nv);
@@ -453,6 +457,7 @@ int32_t pt_set_materials(pt_context* c, const ::PTMaterialData* mats, uint32_t n
     for (uint32_t i = 0; i < nTex; i++) {
         const PtTextureDesc& d = tex[i];
         if (!d.pixels || !d.width || !d.height || d.format > 2) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad texture descriptor");
+        if (d.width > 32768u || d.height > 32768u) return fail(c, PT_ERROR_UNSUPPORTED, "textures above 32768 texels per side are not supported (16 mip levels)");
         HostTexture t; t.w = d.width; t.h = d.height; t.mips.resize(1); t.mips[0].resize((size_t)d.width * d.height);
         for (size_t k = 0; k < (size_t)d.width * d.height; k++) {
             ptk::float4 v;

@@ -5,6 +5,7 @@
 // Output goes through the same raw-buffer entry points the bakers use (pt_set_materials / pt_set_geometry / pt_set_instances).
 #include "../../include/mi355pt.h"
 #include <zlib.h>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,25 +28,31 @@ struct JValue {
     size_t size() const { return type == Arr ? arr.size() : 0; }
 };
 struct JParser {
-    const char* p; const char* e; bool ok = true;
+    const char* p; const char* e; bool ok = true; int depth = 0;
     void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++; }
+    bool lit(const char* w, size_t n) { if ((size_t)(e - p) < n || memcmp(p, w, n)) return false; p += n; return true; }
     JValue parse() {
         ws(); JValue v;
         if (p >= e) { ok = false; return v; }
-        if (*p == '{') { p++; v.type = JValue::Obj; ws(); if (p < e && *p == '}') { p++; return v; }
-            while (ok) { ws(); JValue k = parse(); if (k.type != JValue::Str) { ok = false; break; } ws(); if (p >= e || *p != ':') { ok = false; break; } p++;
-                JValue val = parse(); v.obj.emplace_back(k.str, std::move(val)); ws(); if (p < e && *p == ',') { p++; continue; } if (p < e && *p == '}') { p++; break; } ok = false; }
-            return v; }
-        if (*p == '[') { p++; v.type = JValue::Arr; ws(); if (p < e && *p == ']') { p++; return v; }
-            while (ok) { v.arr.push_back(parse()); ws(); if (p < e && *p == ',') { p++; continue; } if (p < e && *p == ']') { p++; break; } ok = false; }
-            return v; }
+        if (*p == '{' || *p == '[') {
+            if (++depth > 512) { ok = false; return v; }          // nesting cap: a "[[[[..." document must not overflow the stack
+            if (*p == '{') { p++; v.type = JValue::Obj; ws(); if (p < e && *p == '}') { p++; depth--; return v; }
+                while (ok) { ws(); JValue k = parse(); if (!ok || k.type != JValue::Str) { ok = false; break; } ws(); if (p >= e || *p != ':') { ok = false; break; } p++;
+                    JValue val = parse(); v.obj.emplace_back(k.str, std::move(val)); ws(); if (p < e && *p == ',') { p++; continue; } if (p < e && *p == '}') { p++; break; } ok = false; }
+            } else { p++; v.type = JValue::Arr; ws(); if (p < e && *p == ']') { p++; depth--; return v; }
+                while (ok) { v.arr.push_back(parse()); ws(); if (p < e && *p == ',') { p++; continue; } if (p < e && *p == ']') { p++; break; } ok = false; } }
+            depth--; return v; }
         if (*p == '"') { p++; v.type = JValue::Str;
-            while (p < e && *p != '"') { if (*p == '\\' && p + 1 < e) { p++; char c = *p; if (c == 'n') v.str += '\n'; else if (c == 't') v.str += '\t'; else if (c == 'u') { p += 4; v.str += '?'; } else v.str += c; p++; } else v.str += *p++; }
+            while (p < e && *p != '"') { if (*p == '\\' && p + 1 < e) { p++; char c = *p; if (c == 'n') v.str += '\n'; else if (c == 't') v.str += '\t'; else if (c == 'u') { if (e - p < 5) { ok = false; return v; } p += 4; v.str += '?'; } else v.str += c; p++; } else v.str += *p++; }
             if (p < e) p++; else ok = false; return v; }
-        if (!strncmp(p, "true", 4)) { p += 4; v.type = JValue::Bool; v.b = true; return v; }
-        if (!strncmp(p, "false", 5)) { p += 5; v.type = JValue::Bool; v.b = false; return v; }
-        if (!strncmp(p, "null", 4)) { p += 4; return v; }
-        char* end = nullptr; v.num = strtod(p, &end); if (end == p) { ok = false; return v; } p = end; v.type = JValue::Num; return v;
+        if (lit("true", 4)) { v.type = JValue::Bool; v.b = true; return v; }
+        if (lit("false", 5)) { v.type = JValue::Bool; v.b = false; return v; }
+        if (lit("null", 4)) return v;
+        // a number: copy its characters (at most 63) so that strtod never reads past the buffer, which need not be NUL-terminated
+        char buf[64]; size_t n = 0;
+        while (p + n < e && n < 63 && (isdigit((unsigned char)p[n]) || p[n] == '-' || p[n] == '+' || p[n] == '.' || p[n] == 'e' || p[n] == 'E')) { buf[n] = p[n]; n++; }
+        buf[n] = 0;
+        char* end = nullptr; v.num = strtod(buf, &end); if (end == buf) { ok = false; return v; } p += (end - buf); v.type = JValue::Num; return v;
     }
 };
 
@@ -75,7 +82,7 @@ bool decode_png(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::ve
     while (p + 8 <= d.size()) {
         uint32_t len = be32(p); std::string type((const char*)&d[p + 4], 4); p += 8;
         if (p + len + 4 > d.size()) return false;
-        if (type == "IHDR") { w = be32(p); h = be32(p + 4); depth = d[p + 8]; ctype = d[p + 9]; interlace = d[p + 12]; }
+        if (type == "IHDR") { if (len != 13) return false; w = be32(p); h = be32(p + 4); depth = d[p + 8]; ctype = d[p + 9]; interlace = d[p + 12]; }
         else if (type == "PLTE") plte.assign(d.begin() + p, d.begin() + p + len);
         else if (type == "tRNS") trns.assign(d.begin() + p, d.begin() + p + len);
         else if (type == "IDAT") idat.insert(idat.end(), d.begin() + p, d.begin() + p + len);
@@ -83,6 +90,7 @@ bool decode_png(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::ve
         p += len + 4;
     }
     if (!w || !h || depth != 8 || interlace) return false;
+    if (w > 32768u || h > 32768u) return false;            // (16 mip levels; also keeps every size below in range)
     int ch = (ctype == 0) ? 1 : (ctype == 2) ? 3 : (ctype == 3) ? 1 : (ctype == 4) ? 2 : (ctype == 6) ? 4 : 0;
     if (!ch) return false;
     size_t stride = (size_t)w * ch; std::vector<uint8_t> raw((stride + 1) * h);
@@ -135,6 +143,51 @@ uint32_t pack_texture_word(uint32_t index, uint32_t w, uint32_t h) {   // Materi
     return (baseLOD << 24) | (mips << 16) | (index & 0xFFFF);
 }
 
+// ---------------------------------------------------------------- RTXPT .material.json -> PTMaterialData
+// PTMaterial defaults (MaterialsBaker.h:126-193), Read (MaterialsBaker.cpp:150-259: a missing key keeps the default) and FillData (:516-591)
+struct PTMaterialHost {
+    float BaseOrDiffuseColor[3] = {1, 1, 1}, SpecularColor[3] = {0, 0, 0}, EmissiveColor[3] = {0, 0, 0};
+    float EmissiveIntensity = 1.f, Metalness = 0.f, Roughness = 0.f, Opacity = 1.f, TransmissionFactor = 0.f, DiffuseTransmissionFactor = 0.f, NormalTextureScale = 1.f, IoR = 1.5f;
+    bool UseSpecularGlossModel = false, EnableBaseTexture = true, EnableOcclusionRoughnessMetallicTexture = true, EnableNormalTexture = true, EnableEmissiveTexture = true,
+         EnableTransmissionTexture = true, EnableAlphaTesting = false, EnableTransmission = false, MetalnessInRedChannel = false, ThinSurface = false, ExcludeFromNEE = false,
+         PSDExclude = true, EnableAsAnalyticLightProxy = false, IgnoreMeshTangentSpace = false, UseDonutEmissiveIntensity = false, SkipRender = false;
+    float AlphaCutoff = 0.5f; int PSDDominantDeltaLobe = -1, PSDBlockMotionVectorsAtSurfaceType = 0, NestedPriority = 14;
+    float VolumeAttenuationDistance = 3.402823466e+38f, VolumeAttenuationColor[3] = {1, 1, 1}, ShadowNoLFadeout = 0.f;
+};
+// PTMaterial::FillData (MaterialsBaker.cpp:516-591) + GetBindlessTextureIndex: shared by the .material.json path and the glTF import
+void fill_data(const PTMaterialHost& m, const bool loaded[5], const uint32_t textureWords[5], PTMaterialData* out) {
+    memset(out, 0, sizeof(*out));
+    uint32_t f = 0;
+    if (m.UseSpecularGlossModel) f |= 0x00000001u;
+    if (loaded[0] && m.EnableBaseTexture) f |= 0x00000008u;
+    if (loaded[1] && m.EnableOcclusionRoughnessMetallicTexture) f |= 0x00000004u;
+    if (loaded[3] && m.EnableEmissiveTexture) f |= 0x00000010u;
+    if (loaded[2] && m.EnableNormalTexture) f |= 0x00000020u;
+    if (loaded[4] && m.EnableTransmissionTexture && m.EnableTransmission) f |= 0x00000080u;
+    if (m.MetalnessInRedChannel) f |= 0x00000100u;
+    if (m.ThinSurface || !m.EnableTransmission) f |= 0x00000200u;          // no transmission => thin surface
+    if (m.PSDExclude) f |= 0x00000400u;
+    if (m.PSDBlockMotionVectorsAtSurfaceType % 2) f |= (1u << 13);
+    if (m.PSDBlockMotionVectorsAtSurfaceType / 2) f |= (1u << 14);
+    if (m.EnableAsAnalyticLightProxy) f |= 0x00000800u;
+    if (m.IgnoreMeshTangentSpace) f |= (1u << 12);
+    for (int i = 0; i < 3; i++) { out->BaseOrDiffuseColor[i] = m.BaseOrDiffuseColor[i]; out->SpecularColor[i] = m.SpecularColor[i]; out->EmissiveColor[i] = m.EmissiveColor[i] * m.EmissiveIntensity;
+                                  out->AttenuationColor[i] = m.VolumeAttenuationColor[i]; }
+    out->Roughness = m.Roughness; out->Metalness = m.Metalness; out->NormalTextureScale = m.NormalTextureScale;
+    out->TransmissionFactor = m.EnableTransmission ? m.TransmissionFactor : 0.f; out->DiffuseTransmissionFactor = m.EnableTransmission ? m.DiffuseTransmissionFactor : 0.f;
+    out->Opacity = m.Opacity; out->AlphaCutoff = m.AlphaCutoff; out->IoR = m.IoR; out->AttenuationDistance = m.VolumeAttenuationDistance;
+    auto texWord = [&](int t, uint32_t bit) -> uint32_t { if (!(f & bit) || !loaded[t]) { f &= ~bit; return 0xFFFFFFFFu; } return textureWords[t]; };      // GetBindlessTextureIndex
+    out->BaseOrDiffuseTextureIndex = texWord(0, 0x00000008u); out->MetalRoughOrSpecularTextureIndex = texWord(1, 0x00000004u); out->EmissiveTextureIndex = texWord(3, 0x00000010u);
+    out->NormalTextureIndex = texWord(2, 0x00000020u); out->TransmissionTextureIndex = texWord(4, 0x00000080u); out->OcclusionTextureIndex = 0;
+    int np = m.NestedPriority < 14 ? m.NestedPriority : 14; if (np < 0) np = 0;
+    f |= (uint32_t)np << 28;
+    int lobe = m.PSDDominantDeltaLobe + 1; lobe = lobe < 0 ? 0 : (lobe > 7 ? 7 : lobe);
+    f |= (uint32_t)lobe << 24;
+    out->Flags = f;
+    out->ShadowNoLFadeout = m.ShadowNoLFadeout < 0.f ? 0.f : (m.ShadowNoLFadeout > 0.25f ? 0.25f : m.ShadowNoLFadeout);
+    out->_padding0 = 42; out->_padding1 = 42.f;       // (the reference writes 42 into both padding words)
+}
+
 struct Loader {
     pt_context* ctx; std::string baseDir; JValue root; std::vector<std::vector<uint8_t>> buffers; std::string err;
     std::vector<uint32_t> indices; std::vector<float> positions, uvs; std::vector<uint32_t> normals, tangents;
@@ -152,12 +205,15 @@ struct Loader {
         int bv = a.intOr("bufferView", -1); const JValue* bvs = root.get("bufferViews");
         if (!bvs || bv < 0 || (size_t)bv >= bvs->size()) { err = "accessor without bufferView"; return false; }
         const JValue& v = bvs->arr[bv];
-        int buf = v.intOr("buffer", 0); size_t off = (size_t)v.numOr("byteOffset", 0) + (size_t)a.numOr("byteOffset", 0);
+        const double bvOff = v.numOr("byteOffset", 0), acOff = a.numOr("byteOffset", 0), bvStride = v.numOr("byteStride", 0);
+        if (count < 0 || !(bvOff >= 0) || !(acOff >= 0) || !(bvStride >= 0) || bvOff > 4.0e12 || acOff > 4.0e12 || bvStride > 65536.0) { err = "accessor with a negative or absurd count / offset / stride"; return false; }
+        int buf = v.intOr("buffer", 0); size_t off = (size_t)bvOff + (size_t)acOff;
         int csz = (ct == 5120 || ct == 5121) ? 1 : (ct == 5122 || ct == 5123) ? 2 : (ct == 5125 || ct == 5126) ? 4 : 0;
         if (!csz || buf < 0 || (size_t)buf >= buffers.size()) { err = "unsupported component type"; return false; }
         size_t stride = (size_t)v.numOr("byteStride", 0); if (!stride) stride = (size_t)csz * comps;
         const std::vector<uint8_t>& b = buffers[buf];
-        if (count && off + stride * (size_t)(count - 1) + (size_t)csz * comps > b.size()) { err = "accessor out of range"; return false; }
+        const size_t elem = (size_t)csz * comps;
+        if (count && (off > b.size() || elem > b.size() - off || (size_t)(count - 1) > (b.size() - off - elem) / stride)) { err = "accessor out of range"; return false; }
         out.resize((size_t)count * comps);
         for (int i = 0; i < count; i++) for (int k = 0; k < comps; k++) {
             const uint8_t* p = &b[off + stride * i + (size_t)csz * k]; double val;
@@ -190,47 +246,42 @@ struct Loader {
         PtTextureDesc d; d.width = w; d.height = h; d.format = srgb ? PT_TEX_RGBA8_SRGB : PT_TEX_RGBA8_UNORM; d.pixels = nullptr; texDescs.push_back(d);
         uint32_t word = pack_texture_word(index, w, h); texCache[key] = word; return word;
     }
+    // MaterialsBaker::ImportFromDonut (MaterialsBaker.cpp:660-705) over what Donut's glTF importer puts into donut::engine::Material, then
+    // PTMaterial::FillData. The reference takes from the glTF document: the five textures, base colour / opacity, emissive colour and strength,
+    // metalness, roughness, alpha cutoff, transmission factor, normal scale, and the domain (alpha tested / transmissive). It does NOT import the index
+    // of refraction (`//materialPT->IoR = material.ior`), the diffuse transmission factor or any volume attenuation: those stay at the PTMaterial
+    // defaults (1.5, 0, white / FLT_MAX), ThinSurface stays false — a KHR_materials_transmission material is a refracting solid of priority 14 —
+    // and so they do here (KHR_materials_ior / KHR_materials_volume are read past).
     void importMaterials() {
         const JValue* mats = root.get("materials"); size_t n = mats ? mats->size() : 0;
         for (size_t i = 0; i <= n; i++) {            // one extra default material for primitives without one
-            PTMaterialData m; memset(&m, 0, sizeof(m));
-            m.BaseOrDiffuseColor[0] = m.BaseOrDiffuseColor[1] = m.BaseOrDiffuseColor[2] = 1.f; m.Opacity = 1.f; m.Roughness = 1.f; m.Metalness = 1.f; m.NormalTextureScale = 1.f;
-            m.AlphaCutoff = 0.5f; m.IoR = 1.5f; m.AttenuationColor[0] = m.AttenuationColor[1] = m.AttenuationColor[2] = 1.f; m.AttenuationDistance = 3.402823466e+38f;
-            m.BaseOrDiffuseTextureIndex = m.MetalRoughOrSpecularTextureIndex = m.EmissiveTextureIndex = m.NormalTextureIndex = m.OcclusionTextureIndex = m.TransmissionTextureIndex = 0xFFFFFFFFu;
-            m._padding0 = 42; m._padding1 = 42.f;
-            uint32_t flags = 0; bool enableTransmission = false; float emissiveStrength = 1.f;
+            PTMaterialHost m; m.Roughness = 1.f; m.Metalness = 1.f;          // glTF pbrMetallicRoughness defaults (Donut fills its Material from the document)
+            uint32_t words[5] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};      // base, metal-rough, normal, emissive, transmission
             if (i == n) { m.Metalness = 0.f; }
             else {
                 const JValue& j = mats->arr[i];
                 if (const JValue* pbr = j.get("pbrMetallicRoughness")) {
                     if (const JValue* c = pbr->get("baseColorFactor")) if (c->size() >= 3) { for (int k = 0; k < 3; k++) m.BaseOrDiffuseColor[k] = (float)c->arr[k].num; if (c->size() > 3) m.Opacity = (float)c->arr[3].num; }
                     m.Metalness = (float)pbr->numOr("metallicFactor", 1.0); m.Roughness = (float)pbr->numOr("roughnessFactor", 1.0);
-                    uint32_t t = texture(pbr->get("baseColorTexture"), true); if (t != 0xFFFFFFFFu) { m.BaseOrDiffuseTextureIndex = t; flags |= 0x8; }
-                    t = texture(pbr->get("metallicRoughnessTexture"), false); if (t != 0xFFFFFFFFu) { m.MetalRoughOrSpecularTextureIndex = t; flags |= 0x4; }
+                    words[0] = texture(pbr->get("baseColorTexture"), true); words[1] = texture(pbr->get("metallicRoughnessTexture"), false);
                 }
                 if (const JValue* e = j.get("emissiveFactor")) if (e->size() >= 3) for (int k = 0; k < 3; k++) m.EmissiveColor[k] = (float)e->arr[k].num;
-                { uint32_t t = texture(j.get("emissiveTexture"), true); if (t != 0xFFFFFFFFu) { m.EmissiveTextureIndex = t; flags |= 0x10; } }
-                if (const JValue* nt = j.get("normalTexture")) { uint32_t t = texture(nt, false); if (t != 0xFFFFFFFFu) { m.NormalTextureIndex = t; flags |= 0x20; m.NormalTextureScale = (float)nt->numOr("scale", 1.0); } }
+                words[3] = texture(j.get("emissiveTexture"), true);
+                if (const JValue* nt = j.get("normalTexture")) { words[2] = texture(nt, false); if (words[2] != 0xFFFFFFFFu) m.NormalTextureScale = (float)nt->numOr("scale", 1.0); }
                 m.AlphaCutoff = (float)j.numOr("alphaCutoff", 0.5);
+                m.EnableAlphaTesting = j.strOr("alphaMode", "OPAQUE") == "MASK";                 // MaterialDomain::AlphaTested
                 if (const JValue* ext = j.get("extensions")) {
-                    if (const JValue* es = ext->get("KHR_materials_emissive_strength")) emissiveStrength = (float)es->numOr("emissiveStrength", 1.0);
+                    if (const JValue* es = ext->get("KHR_materials_emissive_strength")) m.EmissiveIntensity = (float)es->numOr("emissiveStrength", 1.0);
                     if (const JValue* tr = ext->get("KHR_materials_transmission")) {
-                        m.TransmissionFactor = (float)tr->numOr("transmissionFactor", 0.0); enableTransmission = m.TransmissionFactor > 0.f;
-                        uint32_t t = texture(tr->get("transmissionTexture"), false); if (t != 0xFFFFFFFFu) { m.TransmissionTextureIndex = t; flags |= 0x80; enableTransmission = true; }
-                    }
-                    if (const JValue* ior = ext->get("KHR_materials_ior")) m.IoR = (float)ior->numOr("ior", 1.5);
-                    if (const JValue* vol = ext->get("KHR_materials_volume")) {
-                        m.ThicknessFactor = (float)vol->numOr("thicknessFactor", 0.0); m.AttenuationDistance = (float)vol->numOr("attenuationDistance", 3.402823466e+38);
-                        if (const JValue* ac = vol->get("attenuationColor")) if (ac->size() >= 3) for (int k = 0; k < 3; k++) m.AttenuationColor[k] = (float)ac->arr[k].num;
+                        m.TransmissionFactor = (float)tr->numOr("transmissionFactor", 0.0);
+                        words[4] = texture(tr->get("transmissionTexture"), false);
+                        m.EnableTransmission = m.TransmissionFactor > 0.f || words[4] != 0xFFFFFFFFu;      // MaterialDomain::Transmissive*
                     }
                 }
             }
-            for (int k = 0; k < 3; k++) m.EmissiveColor[k] *= emissiveStrength;              // EmissiveColor * EmissiveIntensity (FillData)
-            if (!enableTransmission) { m.TransmissionFactor = 0.f; m.DiffuseTransmissionFactor = 0.f; flags &= ~0x80u; }
-            bool thickVolume = enableTransmission && m.ThicknessFactor > 0.f;                 // ThinSurface unless a volume is declared; forced when transmission is off (:543-544)
-            if (!thickVolume) flags |= 0x200;
-            m.Flags = flags;
-            materials.push_back(m);
+            bool loaded[5]; for (int t = 0; t < 5; t++) loaded[t] = words[t] != 0xFFFFFFFFu;
+            PTMaterialData d; fill_data(m, loaded, words, &d);
+            materials.push_back(d);
         }
     }
     bool importMeshes() {
@@ -289,17 +340,6 @@ struct Loader {
     }
 };
 
-// ---------------------------------------------------------------- RTXPT .material.json -> PTMaterialData
-// PTMaterial defaults (MaterialsBaker.h:126-193), Read (MaterialsBaker.cpp:150-259: a missing key keeps the default) and FillData (:516-591)
-struct PTMaterialHost {
-    float BaseOrDiffuseColor[3] = {1, 1, 1}, SpecularColor[3] = {0, 0, 0}, EmissiveColor[3] = {0, 0, 0};
-    float EmissiveIntensity = 1.f, Metalness = 0.f, Roughness = 0.f, Opacity = 1.f, TransmissionFactor = 0.f, DiffuseTransmissionFactor = 0.f, NormalTextureScale = 1.f, IoR = 1.5f;
-    bool UseSpecularGlossModel = false, EnableBaseTexture = true, EnableOcclusionRoughnessMetallicTexture = true, EnableNormalTexture = true, EnableEmissiveTexture = true,
-         EnableTransmissionTexture = true, EnableAlphaTesting = false, EnableTransmission = false, MetalnessInRedChannel = false, ThinSurface = false, ExcludeFromNEE = false,
-         PSDExclude = true, EnableAsAnalyticLightProxy = false, IgnoreMeshTangentSpace = false, UseDonutEmissiveIntensity = false, SkipRender = false;
-    float AlphaCutoff = 0.5f; int PSDDominantDeltaLobe = -1, PSDBlockMotionVectorsAtSurfaceType = 0, NestedPriority = 14;
-    float VolumeAttenuationDistance = 3.402823466e+38f, VolumeAttenuationColor[3] = {1, 1, 1}, ShadowNoLFadeout = 0.f;
-};
 void jload(const JValue& o, const char* k, float& v) { const JValue* j = o.get(k); if (j && j->type == JValue::Num) v = (float)j->num; }
 void jload(const JValue& o, const char* k, int& v) { const JValue* j = o.get(k); if (j && j->type == JValue::Num) v = (int)j->num; }
 void jload(const JValue& o, const char* k, bool& v) { const JValue* j = o.get(k); if (j && j->type == JValue::Bool) v = j->b; else if (j && j->type == JValue::Num) v = j->num != 0; }
@@ -307,7 +347,11 @@ void jload3(const JValue& o, const char* k, float v[3]) { const JValue* j = o.ge
 
 } // namespace
 
+static int32_t material_from_json_impl(const char* jsonText, const uint32_t textureWords[5], PTMaterialData* out, PtMaterialJsonInfo* info);
 extern "C" int32_t pt_material_from_json(const char* jsonText, const uint32_t textureWords[5], PTMaterialData* out, PtMaterialJsonInfo* info) {
+    try { return material_from_json_impl(jsonText, textureWords, out, info); } catch (...) { return PT_ERROR_IO; }      // no exception crosses the C ABI
+}
+static int32_t material_from_json_impl(const char* jsonText, const uint32_t textureWords[5], PTMaterialData* out, PtMaterialJsonInfo* info) {
     if (!jsonText || !out) return PT_ERROR_INVALID_ARGUMENT;
     JParser jp{jsonText, jsonText + strlen(jsonText)};
     JValue root = jp.parse();
@@ -336,37 +380,7 @@ extern "C" int32_t pt_material_from_json(const char* jsonText, const uint32_t te
             bool b = false; jload(*tj, "sRGB", b); info->textureSRGB[t] = b; b = false; jload(*tj, "NormalMap", b); info->textureNormalMap[t] = b;
         }
     }
-    // ---- FillData (MaterialsBaker.cpp:516-591)
-    memset(out, 0, sizeof(*out));
-    uint32_t f = 0;
-    if (m.UseSpecularGlossModel) f |= 0x00000001u;
-    if (loaded[0] && m.EnableBaseTexture) f |= 0x00000008u;
-    if (loaded[1] && m.EnableOcclusionRoughnessMetallicTexture) f |= 0x00000004u;
-    if (loaded[3] && m.EnableEmissiveTexture) f |= 0x00000010u;
-    if (loaded[2] && m.EnableNormalTexture) f |= 0x00000020u;
-    if (loaded[4] && m.EnableTransmissionTexture && m.EnableTransmission) f |= 0x00000080u;
-    if (m.MetalnessInRedChannel) f |= 0x00000100u;
-    if (m.ThinSurface || !m.EnableTransmission) f |= 0x00000200u;          // no transmission => thin surface
-    if (m.PSDExclude) f |= 0x00000400u;
-    if (m.PSDBlockMotionVectorsAtSurfaceType % 2) f |= (1u << 13);
-    if (m.PSDBlockMotionVectorsAtSurfaceType / 2) f |= (1u << 14);
-    if (m.EnableAsAnalyticLightProxy) f |= 0x00000800u;
-    if (m.IgnoreMeshTangentSpace) f |= (1u << 12);
-    for (int i = 0; i < 3; i++) { out->BaseOrDiffuseColor[i] = m.BaseOrDiffuseColor[i]; out->SpecularColor[i] = m.SpecularColor[i]; out->EmissiveColor[i] = m.EmissiveColor[i] * m.EmissiveIntensity;
-                                  out->AttenuationColor[i] = m.VolumeAttenuationColor[i]; }
-    out->Roughness = m.Roughness; out->Metalness = m.Metalness; out->NormalTextureScale = m.NormalTextureScale;
-    out->TransmissionFactor = m.EnableTransmission ? m.TransmissionFactor : 0.f; out->DiffuseTransmissionFactor = m.EnableTransmission ? m.DiffuseTransmissionFactor : 0.f;
-    out->Opacity = m.Opacity; out->AlphaCutoff = m.AlphaCutoff; out->IoR = m.IoR; out->AttenuationDistance = m.VolumeAttenuationDistance;
-    auto texWord = [&](int t, uint32_t bit) -> uint32_t { if (!(f & bit) || !loaded[t]) { f &= ~bit; return 0xFFFFFFFFu; } return textureWords[t]; };      // GetBindlessTextureIndex
-    out->BaseOrDiffuseTextureIndex = texWord(0, 0x00000008u); out->MetalRoughOrSpecularTextureIndex = texWord(1, 0x00000004u); out->EmissiveTextureIndex = texWord(3, 0x00000010u);
-    out->NormalTextureIndex = texWord(2, 0x00000020u); out->TransmissionTextureIndex = texWord(4, 0x00000080u); out->OcclusionTextureIndex = 0;
-    int np = m.NestedPriority < 14 ? m.NestedPriority : 14; if (np < 0) np = 0;
-    f |= (uint32_t)np << 28;
-    int lobe = m.PSDDominantDeltaLobe + 1; lobe = lobe < 0 ? 0 : (lobe > 7 ? 7 : lobe);
-    f |= (uint32_t)lobe << 24;
-    out->Flags = f;
-    out->ShadowNoLFadeout = m.ShadowNoLFadeout < 0.f ? 0.f : (m.ShadowNoLFadeout > 0.25f ? 0.25f : m.ShadowNoLFadeout);
-    out->_padding0 = 42; out->_padding1 = 42.f;       // (the reference writes 42 into both padding words)
+    fill_data(m, loaded, textureWords, out);      // FillData (MaterialsBaker.cpp:516-591)
     if (info) { info->enableAlphaTesting = m.EnableAlphaTesting; info->excludeFromNEE = m.ExcludeFromNEE; info->skipRender = m.SkipRender; info->useDonutEmissiveIntensity = m.UseDonutEmissiveIntensity; }
     return PT_OK;
 }
@@ -402,7 +416,11 @@ int32_t load_gltf_file(const char* path, Loader& L) {
 }
 } // namespace
 
+static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path);
 extern "C" int32_t pt_load_scene_gltf(pt_context* ctx, const char* path) {
+    try { return load_scene_gltf_impl(ctx, path); } catch (...) { return PT_ERROR_IO; }      // bad_alloc / length_error on a damaged file: an error code, not an abort
+}
+static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path) {
     if (!ctx || !path) return PT_ERROR_INVALID_ARGUMENT;
     Loader L; L.ctx = ctx;
     int32_t lr = load_gltf_file(path, L);
@@ -613,9 +631,13 @@ struct SceneReader {
 };
 } // namespace
 
+static int32_t scene_json_import_impl(const char* scenePath, const char* mediaPath, pt_scene_import** out, PtSceneJsonInfo* info);
 extern "C" int32_t pt_scene_json_import(const char* scenePath, const char* mediaPath, pt_scene_import** out, PtSceneJsonInfo* info) {
     if (!scenePath || !out) return PT_ERROR_INVALID_ARGUMENT;
     *out = nullptr;
+    try { return scene_json_import_impl(scenePath, mediaPath, out, info); } catch (...) { *out = nullptr; return PT_ERROR_IO; }
+}
+static int32_t scene_json_import_impl(const char* scenePath, const char* mediaPath, pt_scene_import** out, PtSceneJsonInfo* info) {
     std::vector<uint8_t> file;
     if (!read_file(scenePath, file)) return PT_ERROR_IO;
     JParser jp; jp.p = (const char*)file.data(); jp.e = jp.p + file.size(); JValue root = jp.parse();

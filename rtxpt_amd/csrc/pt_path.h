@@ -149,6 +149,10 @@ static inline float FireflyFilterShort(float signalAverage, float threshold, flo
     float t = threshold * fireflyFilterK;
     return (signalAverage > t) ? (1.0f / signalAverage * t) : 1.0f;
 }
+// PathTracerHelpers.hlsli:48-52
+static inline float ComputeLowGrazingAngleFalloff(float3 lightDirection, float3 n, float falloffFrom, float falloffRange) {
+    return saturate((dot(lightDirection, n) - falloffFrom) / falloffRange);
+}
 // TexLODHelpers.hlsli:129-143
 static inline float computeRayConeTriangleLODValue(const float3 v[3], const float2 t[3], const float3x4& M) {
     float2 tx10 = t[1] - t[0], tx20 = t[2] - t[0];
@@ -491,7 +495,7 @@ struct PathKernelContext {
             if (valid) {
                 float faceSide = dot(sd.N, ls.Direction) >= 0 ? 1.f : -1.f;
                 float3 o = ComputeRayOrigin(sd.posW, sd.faceNCorrected * faceSide);
-                float fadeOut = (sd.shadowNoLFadeout > 0) ? saturate((dot(ls.Direction, sd.vertexN) - sd.shadowNoLFadeout) / (2.0f * sd.shadowNoLFadeout)) : 1.0f;
+                float fadeOut = (sd.shadowNoLFadeout > 0) ? ComputeLowGrazingAngleFalloff(ls.Direction, sd.vertexN, sd.shadowNoLFadeout, 2.0f * sd.shadowNoLFadeout) : 1.0f;
                 float globalCount = (float)candidateSampleCount;
                 float thisPdf = ls.SelectionPdf, otherPdf = 0.f, thisCount = globalCount;
                 float wrsMIS = EvalMIS_Balance(1, thisPdf, 1, otherPdf);

@@ -380,6 +380,53 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
     case 4: { const uint* p = reinterpret_cast<const uint*>(in) + 3 * i;                                   // camera ray: px, py, sampleIndex
         PathState ps = k.generate(p[0], p[1], p[2]);
         out[6 * i] = ps.origin.x; out[6 * i + 1] = ps.origin.y; out[6 * i + 2] = ps.origin.z; out[6 * i + 3] = ps.dir.x; out[6 * i + 4] = ps.dir.y; out[6 * i + 5] = ps.dir.z; } break;
+    case 5: { const float* a = in + 9 * i + 1; int fn = (int)in[9 * i]; float* o = out + 4 * i; o[0] = o[1] = o[2] = o[3] = 0.f;      // leaf functions pinned to the reference text (tests/golden/refpin_hlsl_golden.npz): (fn, 8 args) -> 4 results
+        switch (fn) {
+        case 0: o[0] = evalFresnelSchlick(a[0], a[1], a[2]); break;
+        case 1: { float3 r = evalFresnelSchlick(make_float3(a[0], a[1], a[2]), a[3], a[4]); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 2: { float ct = 0.f; o[0] = evalFresnelDielectric(a[0], a[1], ct); o[1] = ct; } break;
+        case 3: o[0] = evalNdfGGX(a[0], a[1]); break;
+        case 4: o[0] = evalPdfGGX_BVNDF(a[0], make_float3(a[1], a[2], a[3]), make_float3(a[4], a[5], a[6])); break;
+        case 5: { float3 r = sampleGGX_BVNDF(a[0], make_float3(a[1], a[2], a[3]), make_float2(a[4], a[5])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 6: o[0] = evalLambdaGGX(a[0], a[1]); break;
+        case 7: o[0] = evalMaskingSmithGGXCorrelated(a[0], a[1], a[2]); break;
+        case 8: { float2 r = ndir_to_oct_equal_area_unorm(make_float3(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; } break;
+        case 9: { float3 r = oct_to_ndir_equal_area_unorm(make_float2(a[0], a[1])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 10: { float2 r = sample_disk(make_float2(a[0], a[1])); o[0] = r.x; o[1] = r.y; } break;
+        case 11: { float2 r = sample_disk_concentric(make_float2(a[0], a[1])); o[0] = r.x; o[1] = r.y; } break;
+        case 12: { float pdf = 0.f; float3 r = sample_cosine_hemisphere_concentric(make_float2(a[0], a[1]), pdf); o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf; } break;
+        case 13: { float3 r = perp_stark(make_float3(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 14: { float3 r = ComputeRayOrigin(make_float3(a[0], a[1], a[2]), make_float3(a[3], a[4], a[5])); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 15: o[0] = FastSqrt(a[0]); break;
+        case 16: o[0] = FastACos(a[0]); break;
+        case 17: o[0] = ComputeRayConeSpreadAngleExpansionByScatterPDF(a[0], a[1]); break;
+        case 18: o[0] = ComputeNewScatterFireflyFilterK(a[0], a[1], a[2]); break;
+        case 19: { float3 r = FireflyFilter(make_float3(a[0], a[1], a[2]), a[3], a[4]); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 20: o[0] = FireflyFilterShort(a[0], a[1], a[2]); break;
+        case 21: o[0] = ComputeLowGrazingAngleFalloff(make_float3(a[0], a[1], a[2]), make_float3(a[3], a[4], a[5]), a[6], a[7]); break;
+        default: break;
+        } } break;
+    case 6: { const uint* a = reinterpret_cast<const uint*>(in) + 19 * i + 1; const uint lk = reinterpret_cast<const uint*>(in)[19 * i]; uint* o = reinterpret_cast<uint*>(out) + 12 * i;      // polymorphic lights: (kind, 18 words) -> 12 words
+        for (int q = 0; q < 12; q++) o[q] = 0u;
+        const float3x4 I = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}};
+        auto info = [&](const uint* w) { PolymorphicLightInfoFull li; __builtin_memset(&li, 0, sizeof(li));
+            li.Base.Center = make_float3(asfloat(w[0]), asfloat(w[1]), asfloat(w[2])); li.Base.ColorTypeAndFlags = w[3]; li.Base.Direction1 = w[4]; li.Base.Direction2 = w[5]; li.Base.Scalars = w[6]; li.Base.LogRadiance = w[7];
+            li.Extended.IesProfileIndex = w[8]; li.Extended.PrimaryAxis = w[9]; li.Extended.CosConeAngleAndSoftness = w[10]; li.Extended.UniqueID = w[11]; return li; };
+        if (lk == 0u) { PolymorphicLightInfo b; __builtin_memset(&b, 0, sizeof(b)); PackLightColor(make_float3(asfloat(a[0]), asfloat(a[1]), asfloat(a[2])), b); float3 c = UnpackLightColor(b);
+            o[0] = b.ColorTypeAndFlags; o[1] = b.LogRadiance; o[2] = asuint(c.x); o[3] = asuint(c.y); o[4] = asuint(c.z); }
+        else if (lk == 1u) { TriangleLight t; t.base = make_float3(asfloat(a[0]), asfloat(a[1]), asfloat(a[2])); t.edge1 = make_float3(asfloat(a[3]), asfloat(a[4]), asfloat(a[5])); t.edge2 = make_float3(asfloat(a[6]), asfloat(a[7]), asfloat(a[8]));
+            t.radiance = make_float3(asfloat(a[9]), asfloat(a[10]), asfloat(a[11])); t.normal = make_float3(0.f); t.surfaceArea = 0;
+            PolymorphicLightInfoFull li = t.Store(7u);
+            o[0] = asuint(li.Base.Center.x); o[1] = asuint(li.Base.Center.y); o[2] = asuint(li.Base.Center.z); o[3] = li.Base.ColorTypeAndFlags; o[4] = li.Base.Direction1; o[5] = li.Base.Direction2; o[6] = li.Base.Scalars; o[7] = li.Base.LogRadiance;
+            o[8] = li.Extended.IesProfileIndex; o[9] = li.Extended.PrimaryAxis; o[10] = li.Extended.CosConeAngleAndSoftness; o[11] = li.Extended.UniqueID; }
+        else if (lk == 2u) { PolymorphicLightInfoFull li = info(a);
+            PolymorphicLightSample sm = PolymorphicLight_CalcSample(li, make_float2(asfloat(a[12]), asfloat(a[13])), make_float3(asfloat(a[14]), asfloat(a[15]), asfloat(a[16])), I);
+            o[0] = asuint(sm.Position.x); o[1] = asuint(sm.Position.y); o[2] = asuint(sm.Position.z); o[3] = asuint(sm.Normal.x); o[4] = asuint(sm.Normal.y); o[5] = asuint(sm.Normal.z);
+            o[6] = asuint(sm.Radiance.x); o[7] = asuint(sm.Radiance.y); o[8] = asuint(sm.Radiance.z); o[9] = asuint(sm.SolidAnglePdf); o[10] = sm.LightSampleableByBSDF ? 1u : 0u; o[11] = asuint(PolymorphicLight_GetPower(li)); }
+        else if (lk == 3u) { TriangleLight t = TriangleLight::Create(info(a));
+            o[0] = asuint(t.CalcSolidAnglePdfForMIS(make_float3(asfloat(a[12]), asfloat(a[13]), asfloat(a[14])), make_float3(asfloat(a[15]), asfloat(a[16]), asfloat(a[17])))); }
+        else { uint pk = NDirToOctUnorm32(make_float3(asfloat(a[0]), asfloat(a[1]), asfloat(a[2]))); float3 d = OctToNDirUnorm32(pk); o[0] = pk; o[1] = asuint(d.x); o[2] = asuint(d.y); o[3] = asuint(d.z); }
+        } break;
     default: break;
     }
 }

@@ -11,7 +11,8 @@ def _unpack_snorm8(v, n):
     for k in range(n):
         b = ((v >> (8 * k)) & 0xFF).astype(np.int32)
         b = np.where(b > 127, b - 256, b)
-        out[:, k] = np.clip(b / 127.0, -1, 1)
+        # a quarter step away from zero: the importer packs with (int)(c * 127.0f), a truncation, and q / 127 * 127 may land just below q
+        out[:, k] = np.clip((b + 0.25 * np.sign(b)) / 127.0, -1, 1)
     return out
 
 

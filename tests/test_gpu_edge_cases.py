@@ -182,3 +182,22 @@ def test_closest_hit_equals_exhaustive_loop_on_badly_conditioned_geometry():
         same = (got.view(np.uint32) == want_bvh.view(np.uint32)).all(1)
         assert same.all(), "%s: %d of %d closest-hit records differ" % (builder, int((~same).sum()), same.size)
         assert np.array_equal(vis_g, vis_o), builder
+
+
+def test_raw_buffer_abi_rejects_out_of_range_indices_and_mesh_ranges():
+    """pt_set_geometry validates what the device would otherwise read out of bounds: an index beyond the geometry's vertex range, a mesh that names
+    geometries outside the array. pt_set_materials refuses textures beyond 32768 texels per side (TexInfo holds 16 mip offsets)."""
+    import ctypes
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    sc, cam = scenes.cornell_box("C1")
+    g = pt.PathTracer()
+    bad = dict(sc); bad["indices"] = sc["indices"].copy(); bad["indices"][5] = 10 ** 6
+    with pytest.raises(pt.PtError):
+        g.set_scene(bad)
+    bad = dict(sc); bad["meshes"] = sc["meshes"].copy(); bad["meshes"]["numGeometries"][0] = len(sc["geometries"]) + 3
+    with pytest.raises(pt.PtError):
+        g.set_scene(bad)
+    g.set_scene(sc)                                    # the context is still usable
+    g.set_camera(scenes.bridge_camera(32, 32, **cam)); g.set_settings(scenes.config_settings("C1")); g.resize(32, 32); g.render(0, 1)
+    assert np.isfinite(g.radiance()).all()

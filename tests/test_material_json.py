@@ -135,3 +135,43 @@ def test_material_json_matches_reference_text(seed):
     assert [int(info["enableAlphaTesting"]), int(info["excludeFromNEE"]), int(info["skipRender"]), int(info["useDonutEmissiveIntensity"])] == ref[1]
     assert info["texturePath"] == ref[2]
     assert [(int(bool(a)), int(bool(b))) for a, b in zip(info["textureSRGB"], info["textureNormalMap"])] == [(int(bool(a)), int(bool(b))) for a, b in ref[3]]
+
+
+def test_gltf_transmission_material_is_a_refracting_solid(tmp_path):
+    """MaterialsBaker::ImportFromDonut (MaterialsBaker.cpp:660-705) never derives ThinSurface from a glTF document and imports neither the index of
+    refraction (`//materialPT->IoR = material.ior`) nor a volume: a plain KHR_materials_transmission material is a refracting solid with the PTMaterial
+    defaults (IoR 1.5, nested priority 14, white / FLT_MAX attenuation), whatever KHR_materials_ior / KHR_materials_volume say; a material without
+    transmission is a thin surface (FillData: `ThinSurface || !EnableTransmission`)."""
+    import json
+    import numpy as np
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from gltf_writer import write_gltf
+    sc, cam = scenes.cornell_box("C2")
+    gltf = tmp_path / "m.gltf"
+    write_gltf(sc, str(gltf))
+    doc = json.loads(gltf.read_text())
+    doc["materials"] = [
+        {"name": "glass", "pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.95, 1.0, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.05},
+         "extensions": {"KHR_materials_transmission": {"transmissionFactor": 0.9}}},
+        {"name": "glass_with_ior_and_volume", "extensions": {"KHR_materials_transmission": {"transmissionFactor": 1.0}, "KHR_materials_ior": {"ior": 1.9},
+                                                          "KHR_materials_volume": {"thicknessFactor": 0.0, "attenuationDistance": 0.25, "attenuationColor": [0.2, 0.4, 0.8]}}},
+        {"name": "opaque", "pbrMetallicRoughness": {"roughnessFactor": 0.4}, "extensions": {"KHR_materials_ior": {"ior": 1.2}}},
+    ] + doc["materials"][3:]
+    gltf.write_text(json.dumps(doc))
+    (tmp_path / "m.scene.json").write_text(json.dumps({"models": ["m.gltf"], "graph": [{"model": 0}]}))
+    m = pt.SceneImport(tmp_path / "m.scene.json").materials
+    THIN, PRIORITY14, PSD_EXCLUDE = 0x200, 14 << 28, 0x400
+    for k in (0, 1):
+        assert not (int(m[k]["Flags"]) & THIN) and (int(m[k]["Flags"]) >> 28) == 14 and int(m[k]["Flags"]) & PSD_EXCLUDE
+        assert m[k]["IoR"] == np.float32(1.5) and m[k]["AttenuationDistance"] == np.float32(3.402823466e38) and np.all(m[k]["AttenuationColor"] == 1.0)
+        assert m[k]["DiffuseTransmissionFactor"] == 0.0
+    assert m[0]["TransmissionFactor"] == np.float32(0.9) and m[1]["TransmissionFactor"] == np.float32(1.0)
+    assert int(m[2]["Flags"]) & THIN and m[2]["TransmissionFactor"] == 0.0 and m[2]["IoR"] == np.float32(1.5)
+    # the same through the reference's own FillData (compiled from MaterialsBaker.cpp where the reference tree is present): a PTMaterial with these fields
+    words = (0xFFFFFFFF,) * 5
+    ref, _ = pt.material_from_json(json.dumps({"BaseOrDiffuseColor": [0.9, 0.95, 1.0], "Metalness": 0.0, "Roughness": 0.05, "TransmissionFactor": 0.9, "EnableTransmission": True}), words)
+    for f in ("Flags", "IoR", "TransmissionFactor", "Roughness", "Metalness", "AttenuationDistance"):
+        assert ref[f] == m[0][f], f

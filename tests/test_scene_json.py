@@ -362,3 +362,45 @@ def test_scene_json_parser_survives_damaged_documents(tmp_path):
         except pt.PtError as e:
             assert e.code in (1, 4, 5), e.code; bad += 1
     assert ok > 0 and bad > 0
+
+
+def test_hostile_gltf_documents_return_error_codes(tmp_path):
+    """File-controlled sizes never reach an allocation or a read unchecked, and no exception crosses the C ABI: a negative accessor count, offsets beyond the
+    buffer, a wrong IHDR length, absurd PNG sizes, a truncated number at the end of the buffer and 100 000 nested brackets all come back as error codes
+    (the host process would abort on an exception escaping through ctypes)."""
+    import struct, zlib
+    media, sc, cam = make_folder(tmp_path, [{"model": 0}])
+    gltf = media / "Models" / "cornell.gltf"
+    good = json.loads(gltf.read_text())
+
+    def expect_error(doc_text, name="bad"):
+        (media / "Models" / (name + ".gltf")).write_text(doc_text)
+        (media / (name + ".scene.json")).write_text(json.dumps({"models": ["Models/%s.gltf" % name], "graph": [{"model": 0}]}))
+        with pytest.raises(pt.PtError):
+            pt.SceneImport(media / (name + ".scene.json"))
+    for mutate in (lambda d: d["accessors"][0].__setitem__("count", -1),
+                   lambda d: d["accessors"][0].__setitem__("count", 2 ** 31 - 1),
+                   lambda d: d["accessors"][0].__setitem__("byteOffset", -8),
+                   lambda d: d["bufferViews"][0].__setitem__("byteOffset", 1e18),
+                   lambda d: d["bufferViews"][0].__setitem__("byteStride", -4)):
+        d = json.loads(json.dumps(good)); mutate(d); expect_error(json.dumps(d))
+    expect_error("[" * 100000)
+    expect_error('{"asset": {"version": "2.0"}, "x": 12')                    # ends inside a number
+    expect_error('{"a": "\\u12')                                           # ends inside an escape
+    # PNG with a short IHDR / absurd dimensions is "texture not loaded", not a crash
+    def png(ihdr):
+        def chunk(t, b):
+            return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b"")
+    for k, ihdr in enumerate((struct.pack(">II", 4, 4), struct.pack(">IIBBBBB", 0x7FFFFFFF, 0x7FFFFFFF, 8, 6, 0, 0, 0), struct.pack(">IIBBBBB", 60000, 60000, 8, 6, 0, 0, 0))):
+        (media / "Models" / ("t%d.png" % k)).write_bytes(png(ihdr))
+        d = json.loads(json.dumps(good)); d["images"] = [{"uri": "t%d.png" % k}]; d["textures"] = [{"source": 0}]
+        d["materials"][0]["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0}
+        (media / "Models" / "png.gltf").write_text(json.dumps(d))
+        (media / "png.scene.json").write_text(json.dumps({"models": ["Models/png.gltf"], "graph": [{"model": 0}]}))
+        imp = pt.SceneImport(media / "png.scene.json")
+        assert imp.info["numTextures"] == 0
+    # pt_material_from_json on the same kinds of damage
+    for text in ("[" * 100000, '{"Roughness": 0.', '{"Name": "\\u'):
+        with pytest.raises(pt.PtError):
+            pt.material_from_json(text)
