@@ -72,19 +72,40 @@ def main():
     g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(W, H)
     g.set_serial_kernels(args.serial_kernels)
     n_owned, packed_bytes = g.shard_info()
-    counts = [parallel.shard_pixels(W, H, r, world).size for r in range(world)] if world > 1 else [n_owned]
-    send = torch.empty((n_owned, 4), dtype=torch.float32, device="cuda")
+    # the frame gather is the library's own (pt_comm_init + pt_gather: un-padded ncclSend / ncclRecv on the library's stream); torch.distributed only
+    # carries the 128-byte unique id. Should the communicator not come up on this node, the bench falls back to a torch.distributed gather of the packed
+    # tiles and says so in the JSON line (`config.gather`) — every rank takes the same branch.
+    gather_mode = "none (1 GPU)"
+    counts = send = None
+    if world > 1:
+        ok = 1
+        try:
+            idt = torch.tensor(list(pt.comm_unique_id()) if rank == 0 else [0] * pt.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+            dist.broadcast(idt, 0)
+            g.comm_init(bytes(idt.cpu().tolist()), rank, world)
+        except Exception as e:      # noqa: BLE001
+            ok = 0; err = repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda"); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            gather_mode = "pt_gather: RCCL ncclSend/ncclRecv of the un-padded tile buffers on the library's stream"
+        else:
+            gather_mode = "torch.distributed.gather of padded tile buffers (pt_comm_init failed on some rank%s)" % ((": " + err) if not ok else "")
+            counts = [parallel.shard_pixels(W, H, r, world).size for r in range(world)]
+            send = torch.empty((n_owned, 4), dtype=torch.float32, device="cuda")
 
     def step():
         g.reset_accumulation()
         st = g.render(0, SPP)
         if world > 1:
-            g.pack_shard(send.data_ptr(), packed_bytes)
-            got = parallel.gather_packed(send, rank, world, dist, counts)
-            if rank == 0:
-                for r in range(1, world):
-                    buf = got[r].contiguous()
-                    g.unpack_shard(buf.data_ptr(), buf.numel() * 4, r)
+            if send is None:
+                g.gather()
+            else:
+                g.pack_shard(send.data_ptr(), packed_bytes)
+                got = parallel.gather_packed(send, rank, world, dist, counts)
+                if rank == 0:
+                    for r in range(1, world):
+                        buf = got[r].contiguous()
+                        g.unpack_shard(buf.data_ptr(), buf.numel() * 4, r)
         return st
 
     def fence():
@@ -158,7 +179,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3 bistro-like street canyon, %d triangles, 64 materials, 32 textures %d^2, %d emissive-triangle + env-quad lights, %dx%d, %d spp, 8 bounces, NEE 5 candidates + RR"
                                    % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP),
-                       "parallelism": "pixel-tile shard x%d + 1 gather" % world, "rays_per_step": rays_total / args.steps,
+                       "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
             # `frac` is the prescribed figure: algorithmic bytes / launch time / 8 TB/s. `bound` is what the counters say limits the kernel:
             # the BVH is served from L1/L2, HBM itself carries `hbm_counter_gbs`, and the VALU issue slots are what is full.

@@ -312,6 +312,35 @@ int32_t pt_unpack_shard(pt_context* ctx, const void* devicePtrSrc, size_t bytes,
 /* the accumulation buffer as a device pointer (RGBA32F, width*height) for zero-copy consumers */
 int32_t pt_device_radiance(pt_context* ctx, void** devicePtr);
 
+/* --- the frame gather itself (north_star: "a single RCCL gather of the radiance buffer over xGMI"; no reference analogue: RTXPT is single-GPU,
+ *     Rtxpt/SampleCommon/CommandLine.cpp:41 only selects an adapter). One process per GPU, each with a context created with its shardRank / shardCount.
+ *     The collective lives behind the C ABI so that a C++ host needs neither torch nor its own RCCL code:
+ *       rank 0:  pt_comm_unique_id(id)  -> the host hands the 128 bytes to the other ranks by its own means (MPI_Bcast, a file, torch.distributed)
+ *       all:     pt_comm_init(ctx, id, rank, world)        ncclCommInitRank on the context's device (collective)
+ *       frame:   pt_render(...) ; pt_gather(ctx)           every rank's tiles -> rank 0's accumulation buffer
+ *     pt_gather packs the rank's tiles and issues UN-PADDED point-to-point transfers (rank r: one ncclSend of its own byte count; rank 0: the
+ *     matching ncclRecv's inside one ncclGroupStart/End, then one unpack kernel) on the library's own stream, asynchronously: the next call that
+ *     reads the frame (pt_map_radiance, pt_tonemap, ...) is ordered behind it. RCCL is bound at run time (dlopen of the librccl.so already in the
+ *     process, else the system one; MI355PT_RCCL_LIB overrides), so the library has no link-time dependency on it. */
+#define PT_COMM_ID_BYTES 128
+int32_t pt_comm_unique_id(void* id128);
+int32_t pt_comm_init(pt_context* ctx, const void* id128, uint32_t rank, uint32_t world);
+int32_t pt_comm_destroy(pt_context* ctx);
+int32_t pt_gather(pt_context* ctx);
+/* host only, no device: the pixel ids (x<<16 | y) `rank` of `world` owns in a width x height frame, in pack order (32x32 tiles in Morton order dealt
+ * round-robin, 8x8 blocks inside a tile). count receives the number of owned pixels (also when pixels is NULL or capacity too small). */
+int32_t pt_shard_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t* pixels, uint32_t capacity, uint32_t* count);
+/* the same gather protocol over HOST memory and a caller-supplied point-to-point transport (MPI, sockets, gloo in the CPU tests): rgba is the
+ * full width x height RGBA32F frame of this rank (only its own tiles need to be valid); on return rank 0's frame holds every rank's tiles. */
+typedef struct PtTransport {
+    void* user;
+    int32_t (*send)(void* user, const void* buf, size_t bytes, uint32_t peer);      /* blocking or queued until group_end; 0 = ok */
+    int32_t (*recv)(void* user, void* buf, size_t bytes, uint32_t peer);
+    int32_t (*group_begin)(void* user);                                             /* may be NULL */
+    int32_t (*group_end)(void* user);                                               /* may be NULL */
+} PtTransport;
+int32_t pt_gather_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* rgba, const PtTransport* transport);
+
 /* --- probes used by the parity tests and bench.py (not part of the reference seam) --------------------------------- */
 /* closest-hit / any-hit queries through the same BVH + kernels the renderer uses. rays: n x 8 floats (o.xyz,tmin,d.xyz,tmax);
  * closest out: n x 4 (t, prim bits, u, v) with prim 0xFFFFFFFF on miss; visibility out: n x u32 (1 = visible) */

@@ -32,6 +32,7 @@ EXPORTS = [
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
+    "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host",
 ]
 
 
@@ -101,6 +102,79 @@ def _share_hip_runtime_with_torch():
             ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         except OSError:
             pass
+
+
+def _share_rccl_with_torch():
+    """One RCCL per process, for the same reason as the HIP runtime: libmi355pt.so binds RCCL at run time (dlopen, RTLD_NOLOAD first), so loading torch's
+    copy before pt_comm_unique_id / pt_comm_init makes the library and torch.distributed use the same one whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """pt_comm_unique_id: 128 bytes created on rank 0; hand them to the other ranks (torch.distributed broadcast, MPI, a file) and call PathTracer.comm_init everywhere."""
+    _share_rccl_with_torch()
+    L = load_library()
+    buf = (ctypes.c_ubyte * COMM_ID_BYTES)()
+    r = L.pt_comm_unique_id(buf)
+    if r != 0:
+        raise PtError(r, "pt_comm_unique_id")
+    return bytes(buf)
+
+
+def shard_layout(width, height, rank, world):
+    """pt_shard_layout: packed pixel ids (x<<16|y) owned by `rank`, in pack order (host only)."""
+    L = load_library()
+    n = ctypes.c_uint32()
+    r = L.pt_shard_layout(width, height, rank, world, None, 0, ctypes.byref(n))
+    if r != 0:
+        raise PtError(r, "pt_shard_layout")
+    out = np.zeros(n.value, np.uint32)
+    r = L.pt_shard_layout(width, height, rank, world, _p(out), n.value, None)
+    if r != 0:
+        raise PtError(r, "pt_shard_layout")
+    return out
+
+
+class PtTransport(ctypes.Structure):
+    SEND = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32)
+    RECV = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32)
+    GROUP = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p)
+    _fields_ = [("user", ctypes.c_void_p), ("send", SEND), ("recv", RECV), ("group_begin", GROUP), ("group_end", GROUP)]
+
+
+def gather_host(width, height, rank, world, rgba, send, recv):
+    """pt_gather_host: the library's gather protocol over host memory and the caller's point-to-point transport.
+    send(ptr, nbytes, peer) / recv(ptr, nbytes, peer) are Python callables taking raw addresses; rgba: (h, w, 4) float32, modified in place on rank 0."""
+    L = load_library()
+    assert rgba.dtype == np.float32 and rgba.flags["C_CONTIGUOUS"] and rgba.shape == (height, width, 4)
+
+    def _wrap(fn):
+        def cb(user, buf, nbytes, peer):
+            try:
+                fn(buf, nbytes, peer); return 0
+            except Exception:      # an exception must not unwind through the C frames
+                import traceback; traceback.print_exc(); return 1
+        return cb
+    t = PtTransport(None, PtTransport.SEND(_wrap(send)), PtTransport.RECV(_wrap(recv)), PtTransport.GROUP(), PtTransport.GROUP())
+    r = L.pt_gather_host(width, height, rank, world, _p(rgba), ctypes.byref(t))
+    if r != 0:
+        raise PtError(r, "pt_gather_host")
+    return rgba
 
 
 def load_library():
@@ -450,6 +524,19 @@ class PathTracer:
         self._chk(self.L.pt_unpack_shard(self.h, ctypes.c_void_p(device_ptr), ctypes.c_size_t(nbytes), rank), "pt_unpack_shard")
 
     # ---- probes
+    def comm_init(self, unique_id, rank, world):
+        """pt_comm_init (collective): the RCCL communicator of the frame gather on this context's device."""
+        _share_rccl_with_torch()
+        buf = (ctypes.c_ubyte * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._chk(self.L.pt_comm_init(self.h, buf, rank, world), "pt_comm_init")
+
+    def gather(self):
+        """pt_gather (collective): every rank's tiles -> rank 0's accumulation buffer, on the library's stream."""
+        self._chk(self.L.pt_gather(self.h), "pt_gather")
+
+    def comm_destroy(self):
+        self._chk(self.L.pt_comm_destroy(self.h), "pt_comm_destroy")
+
     def trace_closest(self, rays):
         rays = np.ascontiguousarray(rays, np.float32)
         out = np.zeros((rays.shape[0], 4), np.float32)

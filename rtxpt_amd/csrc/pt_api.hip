@@ -5,6 +5,8 @@
 #include "../../include/mi355pt.h"
 #include "pt_wavefront.h"
 #include "pt_build.h"
+#include <rccl/rccl.h>      // types only: the functions are bound at run time (dlopen), see pt_comm_init
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -52,6 +54,9 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #ifndef PT_PIPELINE_FULL_AT
 #define PT_PIPELINE_FULL_AT (1u << 21)      // paths per pt_render call from which all PT_PIPELINE_BATCHES are used (one rank of an 8-way sharded 4K frame has 4.1 M)
 #endif
+#ifndef PT_PIPELINE_MID_BATCHES
+#define PT_PIPELINE_MID_BATCHES 2      // batches between 1 M paths and PT_PIPELINE_FULL_AT
+#endif
 #ifndef PT_PIPELINE_BATCHES
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
 #endif
@@ -85,6 +90,8 @@ struct pt_context {
     bool geomDirty = true, lightsDirty = true, texDirty = true;
     double buildMs = 0, refitMs = 0, lightBakeMs = 0;
     uint poolCapacity = 0; size_t shadowCapacity = 0;
+    // frame gather (pt_comm_init / pt_gather)
+    ncclComm_t comm = nullptr; uint commRank = 0, commWorld = 0; DevBuf<ptk::float4> dGatherSend, dGatherRecv; DevBuf<uint> dGatherPixels; std::vector<size_t> gatherCounts; uint gatherW = 0, gatherH = 0;
 };
 
 namespace {
@@ -115,25 +122,61 @@ uint morton2(uint x, uint y) {
 }
 // pixel ownership: 32x32 tiles, tile t -> rank morton(t) % shardCount; inside a tile pixels are listed in 8x8 blocks so that the
 // 64 lanes of a wave start as an 8x8 screen block (coherent primary rays)
-void build_shards(pt_context* c) {
-    c->shardPixels.assign(c->shardCount, std::vector<uint>());
-    uint tx = (c->width + TILE - 1) / TILE, ty = (c->height + TILE - 1) / TILE;
+void shard_pixel_lists(uint width, uint height, uint world, std::vector<std::vector<uint>>& out) {
+    out.assign(world, std::vector<uint>());
+    uint tx = (width + TILE - 1) / TILE, ty = (height + TILE - 1) / TILE;
     std::vector<std::pair<uint, uint>> tiles;
     for (uint y = 0; y < ty; y++) for (uint x = 0; x < tx; x++) tiles.push_back({morton2(x, y), y * tx + x});
     std::sort(tiles.begin(), tiles.end());
     uint order = 0;
     for (auto& t : tiles) {
         uint tX = t.second % tx, tY = t.second / tx;
-        std::vector<uint>& dst = c->shardPixels[(order / PT_SHARD_TILE_GROUP) % c->shardCount];
+        std::vector<uint>& dst = out[(order / PT_SHARD_TILE_GROUP) % world];
         order++;
         for (uint by = 0; by < TILE; by += 8) for (uint bx = 0; bx < TILE; bx += 8)
             for (uint y = 0; y < 8; y++) for (uint x = 0; x < 8; x++) {
                 uint px = tX * TILE + bx + x, py = tY * TILE + by + y;
-                if (px < c->width && py < c->height) dst.push_back((px << 16) | py);
+                if (px < width && py < height) dst.push_back((px << 16) | py);
             }
     }
+}
+void build_shards(pt_context* c) {
+    shard_pixel_lists(c->width, c->height, c->shardCount, c->shardPixels);
     c->owned = c->shardPixels[c->shardRank];
 }
+
+// ---- RCCL, bound at run time. One process may already hold a librccl.so (PyTorch ships its own): RTLD_NOLOAD finds that copy first, so that a single
+// RCCL runs on the single HIP runtime of the process; a plain C++ host gets the system library.
+struct RcclApi {
+    void* lib = nullptr; bool tried = false; std::string error;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load() {
+        if (tried) return lib != nullptr;
+        tried = true;
+        const char* env = getenv("MI355PT_RCCL_LIB");
+        if (env && *env) lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { const char* e = dlerror(); error = std::string("librccl.so not found: ") + (e ? e : ""); return false; }
+#define PT_RCCL_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); if (!field) { error = std::string("librccl.so lacks ") + name; lib = nullptr; return false; }
+        PT_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") PT_RCCL_SYM(CommInitRank, "ncclCommInitRank") PT_RCCL_SYM(CommDestroy, "ncclCommDestroy") PT_RCCL_SYM(Send, "ncclSend")
+        PT_RCCL_SYM(Recv, "ncclRecv") PT_RCCL_SYM(GroupStart, "ncclGroupStart") PT_RCCL_SYM(GroupEnd, "ncclGroupEnd") PT_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef PT_RCCL_SYM
+        return true;
+    }
+};
+RcclApi g_rccl;
+#define PT_CHECK_NCCL(c, expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return fail(c, PT_ERROR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); } while (0)
 
 int upload_textures(pt_context* c) {
     std::vector<ptk::float4> pool; c->texInfos.clear();
@@ -407,6 +450,8 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
 int32_t pt_destroy(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free();
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
@@ -638,7 +683,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         size_t mark() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
-    const uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? 2u : PT_PIPELINE_BATCHES);
+    const uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
     Batch B[PT_PIPELINE_BATCHES];
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
@@ -875,6 +920,97 @@ int32_t pt_probe(pt_context* c, int32_t kind, const void* in, size_t inBytes, vo
     di.free(); dout.free();
     return PT_OK;
 }
+// ---- the frame gather (include/mi355pt.h "the frame gather itself")
+int32_t pt_shard_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t* pixels, uint32_t capacity, uint32_t* count) {
+    if (!width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
+    std::vector<std::vector<uint>> lists; shard_pixel_lists(width, height, world, lists);
+    const std::vector<uint>& mine = lists[rank];
+    if (count) *count = (uint32_t)mine.size();
+    if (pixels) { if (capacity < mine.size()) return PT_ERROR_INVALID_ARGUMENT; if (!mine.empty()) memcpy(pixels, mine.data(), 4 * mine.size()); }
+    return PT_OK;
+}
+int32_t pt_comm_unique_id(void* id128) {
+    if (!id128) return PT_ERROR_INVALID_ARGUMENT;
+    if (!g_rccl.load()) return PT_ERROR_HIP;
+    static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id; if (g_rccl.GetUniqueId(&id) != ncclSuccess) return PT_ERROR_HIP;
+    memcpy(id128, &id, sizeof(id));
+    return PT_OK;
+}
+int32_t pt_comm_init(pt_context* c, const void* id128, uint32_t rank, uint32_t world) {
+    if (!c || !id128) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
+    if (rank != c->shardRank || world != c->shardCount) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_comm_init: rank / world must equal the context's shardRank / shardCount");
+    if (!g_rccl.load()) return fail(c, PT_ERROR_HIP, g_rccl.error);
+    (void)hipSetDevice(c->device);
+    if (c->comm) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+    PT_CHECK_NCCL(c, g_rccl.CommInitRank(&c->comm, (int)world, id, (int)rank));
+    c->commRank = rank; c->commWorld = world; c->gatherW = c->gatherH = 0;
+    return PT_OK;
+}
+int32_t pt_comm_destroy(pt_context* c) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (c->comm && g_rccl.lib) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)g_rccl.CommDestroy(c->comm); }
+    c->comm = nullptr;
+    return PT_OK;
+}
+int32_t pt_gather(pt_context* c) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    if (c->shardCount == 1) return PT_OK;                                       // nothing to gather
+    if (!c->comm) return fail(c, PT_ERROR_NOT_READY, "pt_comm_init first");
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    if (c->gatherW != c->width || c->gatherH != c->height) {                    // per-size state: counts of every rank; on rank 0 the other ranks' pixel lists on the device
+        c->gatherCounts.assign(c->shardCount, 0);
+        std::vector<uint> others;
+        for (uint r = 0; r < c->shardCount; r++) { c->gatherCounts[r] = c->shardPixels[r].size(); if (r != 0 && c->shardRank == 0) others.insert(others.end(), c->shardPixels[r].begin(), c->shardPixels[r].end()); }
+        if (c->shardRank == 0) { PT_CHECK_HIP(c, c->dGatherPixels.upload(others, st)); PT_CHECK_HIP(c, c->dGatherRecv.resize(others.size())); PT_CHECK_HIP(c, hipStreamSynchronize(st)); }
+        else PT_CHECK_HIP(c, c->dGatherSend.resize(c->owned.size()));
+        c->gatherW = c->width; c->gatherH = c->height;
+    }
+    if (c->shardRank != 0) {
+        const size_t n = c->owned.size();
+        if (n) {
+            launch_pack(c->dAccum.p, c->dOwned.p, (uint)n, c->width, c->dGatherSend.p, st);
+            PT_CHECK_NCCL(c, g_rccl.Send(c->dGatherSend.p, 4 * n, ncclFloat, 0, c->comm, st));
+        }
+        return PT_OK;
+    }
+    size_t off = 0, total = 0;
+    PT_CHECK_NCCL(c, g_rccl.GroupStart());
+    for (uint r = 1; r < c->shardCount; r++) {
+        const size_t n = c->gatherCounts[r];
+        if (n) { ncclResult_t rr = g_rccl.Recv(c->dGatherRecv.p + off, 4 * n, ncclFloat, (int)r, c->comm, st); if (rr != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(c, PT_ERROR_HIP, std::string("ncclRecv: ") + g_rccl.GetErrorString(rr)); } }
+        off += n;
+    }
+    PT_CHECK_NCCL(c, g_rccl.GroupEnd());
+    total = off;
+    if (total) launch_unpack(c->dAccum.p, c->dGatherPixels.p, (uint)total, c->width, c->dGatherRecv.p, st);
+    return PT_OK;
+}
+int32_t pt_gather_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* rgba, const PtTransport* t) {
+    if (!rgba || !t || !t->send || !t->recv || !width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
+    if (world == 1) return PT_OK;
+    try {
+        std::vector<std::vector<uint>> lists; shard_pixel_lists(width, height, world, lists);
+        auto at = [&](uint px) { return rgba + 4 * ((size_t)(px & 0xFFFFu) * width + (px >> 16)); };
+        if (rank != 0) {
+            const std::vector<uint>& mine = lists[rank];
+            std::vector<float> sendbuf(4 * mine.size());
+            for (size_t i = 0; i < mine.size(); i++) memcpy(&sendbuf[4 * i], at(mine[i]), 16);
+            if (!mine.empty() && t->send(t->user, sendbuf.data(), 16 * mine.size(), 0) != 0) return PT_ERROR_IO;
+            return PT_OK;
+        }
+        std::vector<std::vector<float>> recvbuf(world);
+        if (t->group_begin && t->group_begin(t->user) != 0) return PT_ERROR_IO;
+        for (uint r = 1; r < world; r++) { recvbuf[r].resize(4 * lists[r].size()); if (!lists[r].empty() && t->recv(t->user, recvbuf[r].data(), 16 * lists[r].size(), r) != 0) return PT_ERROR_IO; }
+        if (t->group_end && t->group_end(t->user) != 0) return PT_ERROR_IO;
+        for (uint r = 1; r < world; r++) for (size_t i = 0; i < lists[r].size(); i++) memcpy(at(lists[r][i]), &recvbuf[r][4 * i], 16);
+        return PT_OK;
+    } catch (...) { return PT_ERROR_IO; }
+}
+
 int32_t pt_get_build_stats(pt_context* c, double* b, double* r, double* l) { if (!c) return PT_ERROR_INVALID_ARGUMENT; if (b) *b = c->buildMs; if (r) *r = c->refitMs; if (l) *l = c->lightBakeMs; return PT_OK; }
 int32_t pt_set_counters(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->countersEnabled = enable != 0; return PT_OK; }
 int32_t pt_set_serial_kernels(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->serialKernels = enable != 0; return PT_OK; }

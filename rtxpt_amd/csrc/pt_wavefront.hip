@@ -7,6 +7,12 @@
 
 namespace ptk {
 
+#ifndef T8_CHUNKS_PER_WAVE_MIN
+#define T8_CHUNKS_PER_WAVE_MIN 1     // small launches: fewer waves, each working through this many 64-ray chunks (idle quads refill from the next chunk)
+#endif
+#ifndef T8_TASK_BLOCKS_N
+#define T8_TASK_BLOCKS_N 512        // blocks of a task-round launch: task rounds hold thousands of sub-trees, not millions
+#endif
 
 __device__ __forceinline__ uint lane_id() { return __lane_id(); }
 // one atomic per wave: returns this lane's slot if `pred`, garbage otherwise
@@ -83,6 +89,13 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
                  for (int q = 0; q < 8; q++) wave_add64(ctr.ev[q], &wc->eventsExt[q]); }
 }
 
+// Task rounds hold hundreds to thousands of sub-trees, far fewer than the launch has quads. A 64-item chunk would put them on count/64 waves (one rank of
+// an 8-way sharded frame: ~90 us per round on a handful of waves, 40 % on top of k_extend itself); with few tasks a chunk carries only 16 real ones —
+// one per quad — and 48 empty slots that cost an iteration each, so the sub-trees spread over 4x as many waves.
+#ifndef T8_TASK_SPREAD
+#define T8_TASK_SPREAD 1
+#endif
+__device__ __forceinline__ uint t8_tasks_per_chunk(uint count) { return (!T8_TASK_SPREAD || count > 16u * 4u * T8_TASK_BLOCKS_N) ? 64u : 16u; }
 // sub-trees of split extend rays: reads queue IN; unless FINAL, stragglers among the sub-trees are split again into the other queue.
 // Task i of the launch is queue entry (i % 64) * ceil(count / 64) + i / 64: the sub-trees of one ray sit next to each other in the queue and
 // would otherwise land in one 64-item chunk, i.e. on one wave.
@@ -93,12 +106,13 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks
     uint count = aux.counts[IN]; if (count > aux.taskCap) count = aux.taskCap;
     if (count == 0u) return;
     const TravTask* tasks = aux.taskQ[IN];
-    const uint per = (count + 63u) / 64u;
+    const uint real = t8_tasks_per_chunk(count), per = (count + real - 1u) / real;
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
-        const uint j = (i & 63u) * per + (i >> 6);
-        TravTask t = tasks[j < count ? j : 0u];
-        if (j >= count) t.tbits = 0x7F800000u;                                        // padding of the transposed index space: an empty task
+        const uint lane = i & 63u, j = lane * per + (i >> 6);
+        const bool pad = lane >= real || j >= count;                                  // padding of the transposed index space: an empty task
+        TravTask t = tasks[pad ? 0u : j];
+        if (pad) t.tbits = 0x7F800000u;
         uint4 a = pool.s0[t.tag], b = pool.s1[t.tag];
         o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)); d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
         unsigned long long key = aux.bestKey[t.tag];
@@ -203,14 +217,15 @@ __global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, Shado
     uint count = aux.counts[IN]; if (count > aux.taskCap) count = aux.taskCap;
     if (count == 0u) return;
     const TravTask* tasks = aux.taskQ[IN];
-    const uint per = (count + 63u) / 64u;
+    const uint real = t8_tasks_per_chunk(count), per = (count + real - 1u) / real;
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
-        const uint j = (i & 63u) * per + (i >> 6);
-        TravTask t = tasks[j < count ? j : 0u];
+        const uint lane = i & 63u, j = lane * per + (i >> 6);
+        const bool pad = lane >= real || j >= count;
+        TravTask t = tasks[pad ? 0u : j];
         float4 a = sq.q0[t.tag], b = sq.q1[t.tag];
         o = make_float3(a.x, a.y, a.z); d = make_float3(b.x, b.y, b.z); tmin = 0.0f; tmax = a.w; bestT0 = a.w; bestPrim0 = 0xFFFFFFFFu;
-        startRef = (j < count && aux.bestKey[t.tag] == 0ull) ? t.ref : BVH_EMPTY;        // padding, or another sub-tree already found an occluder
+        startRef = (!pad && aux.bestKey[t.tag] == 0ull) ? t.ref : BVH_EMPTY;              // padding, or another sub-tree already found an occluder
         return t.tag;
     };
     auto commit = [&](uint i, const HitInfo& h) { if (h.prim != 0xFFFFFFFFu) aux.bestKey[i] = 1ull; };
@@ -466,12 +481,9 @@ void launch_generate(const PathKernelContext& k, PathPool pool, const uint* owne
     hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, st, k, pool, ownedPixels, numOwned, sampleFirst, spp, queue);
 }
 // task rounds + resolve pass of one traversal launch; all counts live on the device, so the grids are fixed (empty rounds return at once)
-#ifndef T8_TASK_BLOCKS_N
-#define T8_TASK_BLOCKS_N 512        // task rounds hold thousands of sub-trees, not millions
-#endif
 static const uint T8_TASK_BLOCKS = T8_TASK_BLOCKS_N, T8_RESOLVE_BLOCKS = 256;
 void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
-    uint g = grid_for(count, T8_BLOCK, T8_MAX_BLOCKS);
+    uint g = grid_for(count, T8_BLOCK * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);
     (void)hipMemsetAsync(aux.counts, 0, 12, st);
     if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux);
     else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux);
@@ -488,7 +500,7 @@ void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn
     else hipLaunchKernelGGL((k_shade<false>), dim3((countIn + 255) / 256), dim3(256), 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
 }
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
-    uint g = grid_for(count, T8_BLOCK, T8_MAX_BLOCKS);
+    uint g = grid_for(count, T8_BLOCK * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);
     (void)hipMemsetAsync(aux.counts, 0, 12, st);
     if (sq.group) hipLaunchKernelGGL((k_shadow<false, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);       // (no traversal counters in the grouped mode)
     else if (counters) hipLaunchKernelGGL((k_shadow<true, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);

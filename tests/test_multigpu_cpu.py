@@ -20,15 +20,30 @@ def fake_radiance(px):
 
 
 def _worker(rank, world, port, w, h, q):
+    """Each rank fills only its own tiles of a host frame, then the LIBRARY's gather protocol (pt_gather_host: the layout, packing, un-padded
+    point-to-point transfers and unpacking pt_gather runs over RCCL) moves them to rank 0 over a gloo transport supplied as C callbacks."""
+    import ctypes
+    import rtxpt_amd as pt
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    px = parallel.shard_pixels(w, h, rank, world)
-    counts = [parallel.shard_pixels(w, h, r, world).size for r in range(world)]
-    packed = torch.from_numpy(fake_radiance(px))
-    got = parallel.gather_packed(packed, rank, world, dist, counts)
+    px = pt.shard_layout(w, h, rank, world)
+    assert np.array_equal(px, parallel.shard_pixels(w, h, rank, world))          # the numpy mirror agrees with the library
+    frame = np.full((h, w, 4), -7.0, np.float32)                                  # poison: nothing but the owned tiles is valid on this rank
+    frame[(px & 0xFFFF).astype(np.int64), (px >> 16).astype(np.int64)] = fake_radiance(px)
+    sent = []
+
+    def send(ptr, nbytes, peer):
+        t = torch.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=torch.uint8).clone()
+        sent.append(nbytes); dist.send(t, dst=peer)
+
+    def recv(ptr, nbytes, peer):
+        t = torch.empty(nbytes, dtype=torch.uint8); dist.recv(t, src=peer)
+        ctypes.memmove(ptr, t.data_ptr(), nbytes)
+    pt.gather_host(w, h, rank, world, frame, send, recv)
+    if rank != 0:
+        assert sent == [16 * px.size]                                             # exactly the rank's own bytes: no padding to the largest shard
     if rank == 0:
-        img = parallel.assemble(w, h, world, [g.numpy() for g in got])
-        q.put(img)
+        q.put(frame)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -37,13 +52,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("size", [(100, 70), (256, 144)])
-def test_tile_shard_gather_world2(size):
+@pytest.mark.parametrize("size,world", [((100, 70), 2), ((256, 144), 2), ((200, 120), 3)])
+def test_tile_shard_gather_through_the_c_entry_point(size, world):
     w, h = size
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, w, h, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, q)) for r in range(world)]
     for p in procs:
         p.start()
     img = q.get(timeout=120)
@@ -60,8 +75,10 @@ def test_shards_partition_the_frame(world):
     w, h = 200, 120
     seen = np.zeros((h, w), np.int32)
     sizes = []
+    import rtxpt_amd as pt
     for r in range(world):
         px = parallel.shard_pixels(w, h, r, world)
+        assert np.array_equal(px, pt.shard_layout(w, h, r, world))
         seen[(px & 0xFFFF).astype(np.int64), (px >> 16).astype(np.int64)] += 1
         sizes.append(px.size)
     assert np.all(seen == 1)
