@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="triangle-count scale of the bistro-like generator (1.0 = 2.8 M triangles)")
     ap.add_argument("--tex", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32-lp-types", action="store_true", help="RTXPT_LP_TYPES_USE_16BIT_PRECISION 0 instead of the reference's default build (lp types in binary16)")
     ap.add_argument("--skip-roofline-steps", action="store_true", help="profiling runs (tools/profile_round.sh): only the timed steps, no extra serial / counter steps")
     ap.add_argument("--serial-kernels", action="store_true", help="run every step with PT_DEVICE_SERIAL_KERNELS semantics (for rocprofv3 kernel traces: launches never overlap)")
     args = ap.parse_args()
@@ -65,7 +66,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     sc, cam = scenes.bistro_like(scale=args.scale, tex_size=args.tex)
-    S = scenes.default_settings()                 # 8 bounces, NEE (emissive triangles + env quads), Russian roulette
+    S = scenes.default_settings(useFp16Types=0 if args.fp32_lp_types else 1)      # 8 bounces, NEE (emissive triangles + env quads), Russian roulette; lp types as the reference ships them
     W, H, SPP = args.width, args.height, args.spp
     camd = scenes.bridge_camera(W, H, **cam)
     g = pt.PathTracer(device=local_rank, shard_rank=rank, shard_count=world)
@@ -177,8 +178,8 @@ def main():
             "metric": "Mrays/s at 4K 4spp 8-bounce bistro-like (extend + shadow rays / wall time of pt_render)",
             "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3 bistro-like street canyon, %d triangles, 64 materials, 32 textures %d^2, %d emissive-triangle + env-quad lights, %dx%d, %d spp, 8 bounces, NEE 5 candidates + RR"
-                                   % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP),
+            "config": {"workload": "C3 bistro-like street canyon, %d triangles, 64 materials, 32 textures %d^2, %d emissive-triangle + env-quad lights, %dx%d, %d spp, 8 bounces, NEE 5 candidates + RR, lp types %s"
+                                   % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP, "fp32" if args.fp32_lp_types else "binary16 (reference default)"),
                        "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
             # `frac` is the prescribed figure: algorithmic bytes / launch time / 8 TB/s. `bound` is what the counters say limits the kernel:
@@ -224,7 +225,7 @@ def cpu_baseline(sc, cam, S, W, H, SPP):
     of the 4K frame, 4 accumulated samples, all host cores (OpenMP), about 10 s of CPU work on the 128-thread GPU-box host. Reported per ray so that it is resolution independent."""
     from oracle import ptref
     from rtxpt_amd import scenes
-    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(scenes.bridge_camera(W, H, **cam)); o.set_settings(S); o.resize(W, H)
+    o = ptref.Oracle(lp16=bool(int(S["useFp16Types"]))); o.set_scene(sc); o.set_camera(scenes.bridge_camera(W, H, **cam)); o.set_settings(S); o.resize(W, H)
     t0 = time.perf_counter(); o.L.ptref_prepare(o.h); prep = time.perf_counter() - t0
     bw, bh = min(W, 1920), min(H, 1080)
     x0, y0 = (W - bw) // 2, (H - bh) // 2

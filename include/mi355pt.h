@@ -104,7 +104,9 @@ typedef struct PtSettings {
     uint32_t nestedDielectricsQuality;      /* RTXPT_NESTED_DIELECTRICS_QUALITY 0/1/2 */
     uint32_t enableLDSamplerForBSDF;
     uint32_t diffuseBrdf;                   /* 0 Lambert, 2 Frostbite */
-    uint32_t _pad[2];
+    uint32_t useFp16Types;                  /* the reference's "Use explicit fp16 types" (SampleUI.h:182 UseFp16Types, Sample.cpp:1035 RTXPT_LP_TYPES_USE_16BIT_PRECISION):
+                                               1 = lpfloat is binary16 — the reference's DEFAULT build, and what pt_default_settings returns; 0 = lpfloat is fp32 */
+    uint32_t _pad;
 } PtSettings;
 
 typedef struct PtDeviceDesc {

@@ -29,6 +29,20 @@ def _load(path):
 
 
 _lib = None
+_lib16 = None
+_LIB16 = os.path.join(_HERE, "_ref", "libptref_lp16.so")
+
+
+def lib16():
+    """The restatement of the reference's DEFAULT build: lp types in 16 bits (oracle/Makefile: -DPT_LP16=1). Same API as lib()."""
+    global _lib16
+    if _lib16 is None:
+        L = _load(_LIB16)
+        L.ptref_create.restype = ctypes.c_void_p
+        L.ptref_radiance.restype = ctypes.POINTER(ctypes.c_float)
+        L.ptref_num_tris.restype = ctypes.c_uint32
+        _lib16 = L
+    return _lib16
 
 
 def lib():
@@ -161,7 +175,7 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1), lp16=False):
                 return None
         else:
             os.makedirs(os.path.dirname(path), exist_ok=True)
-            d = "-DDiffuseBrdf=%d -DPT_ENABLE_RUSSIAN_ROULETTE=%d -DRTXPT_FIREFLY_FILTER=%d -DRTXPT_NESTED_DIELECTRICS_QUALITY=%d -DRTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF=%d -DPT_NEE_ENABLED=%d" % tuple(variant) + (" -DRTXPT_LP_TYPES_USE_16BIT_PRECISION=1" if lp16 else "")
+            d = "-DDiffuseBrdf=%d -DPT_ENABLE_RUSSIAN_ROULETTE=%d -DRTXPT_FIREFLY_FILTER=%d -DRTXPT_NESTED_DIELECTRICS_QUALITY=%d -DRTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF=%d -DPT_NEE_ENABLED=%d" % tuple(variant) + (" -DRTXPT_LP_TYPES_USE_16BIT_PRECISION=1 -DPT_LP16=1" if lp16 else "")
             cmd = ("python3 %s/refpin/hlsl_tu.py --integrator /root/reference | g++ -O2 -std=c++17 -fPIC -shared -fopenmp -mfma -ffp-contract=off -fno-fast-math "
                    "-fsingle-precision-constant -fpermissive -w %s -I%s/refpin -x c++ - -o %s" % (here, d, here, path))
             r = subprocess.run(["bash", "-o", "pipefail", "-c", cmd], capture_output=True, text=True)
@@ -178,9 +192,9 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1), lp16=False):
 def surface_probe(oracle_ctx, prims, uv_dir_cone):
     """Bridge::loadSurface of the reference text (PathTracerBridgeDonut.hlsli:612-853 and what it calls) next to the oracle's loadSurface for the same hits.
     oracle_ctx: an Oracle(reference_integrator=True) with a scene; prims: global triangle ids; uv_dir_cone: rows [u, v, dir.xyz, coneWidth, coneSpread].
-    Returns (reference, oracle) as uint32 [n, 44]."""
+    Returns (reference, oracle) as uint32 [n, 45]."""
     prims = np.ascontiguousarray(prims, np.uint32); a = np.ascontiguousarray(uv_dir_cone, np.float32).reshape(-1, 7)
-    R = np.zeros((len(prims), 44), np.uint32); Q = np.zeros((len(prims), 44), np.uint32)
+    R = np.zeros((len(prims), 45), np.uint32); Q = np.zeros((len(prims), 45), np.uint32)
     vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
     oracle_ctx.L.refpt_surface_probe(oracle_ctx.h, ctypes.c_uint32(len(prims)), vp(prims), vp(a), vp(R), vp(Q))
     return R, Q
@@ -353,7 +367,8 @@ class Oracle:
         (oracle/_ref/librefpin_pt_*.so, oracle/refpin/hlsl_pt_wrappers.inc), compiled for the shader-macro combination `settings` stand for;
         only where that library can be built."""
         self.reference_integrator = reference_integrator
-        self.L = refpin_pt(pt_variant(settings), lp16=lp16) if reference_integrator else lib()      # lp16: the reference's 16-bit lp-type build (measurement only, tools/lp16_deviation.py)
+        self.lp16 = bool(lp16)
+        self.L = refpin_pt(pt_variant(settings), lp16=lp16) if reference_integrator else (lib16() if lp16 else lib())      # lp16: the reference's default build, lp types in 16 bits
         if self.L is None:
             raise RuntimeError("librefpin_pt.so not available (needs /root/reference)")
         self.h = ctypes.c_void_p(self.L.ptref_create())
@@ -398,6 +413,9 @@ class Oracle:
         self.L.ptref_set_camera(self.h, _p(self._cam))
 
     def set_settings(self, s):
+        want16 = bool(int(np.asarray(s["useFp16Types"]).reshape(-1)[0])) if "useFp16Types" in (np.asarray(s).dtype.names or ()) else False
+        if not self.reference_integrator and want16 != self.lp16:
+            raise ValueError("settings ask for useFp16Types=%d but this Oracle was created with lp16=%s (two libraries: Oracle(lp16=True) restates the 16-bit build)" % (want16, self.lp16))
         self._set = np.ascontiguousarray(s)
         self.L.ptref_set_settings(self.h, _p(self._set))
 
@@ -462,6 +480,13 @@ class Oracle:
         self.L.ptref_get_subinstances(self.h, ctypes.byref(n), None)
         out = np.zeros((n.value, 8), np.uint32)
         self.L.ptref_get_subinstances(self.h, None, _p(out))
+        return out
+
+    def surface_probe(self, prims, uv_dir_cone):
+        """loadSurface of this library's build on given hits: uint32 [n, 45] (layout of refpt_surface_probe). prims: global triangle ids; rows [u, v, dir.xyz, coneWidth, coneSpread]."""
+        prims = np.ascontiguousarray(prims, np.uint32); a = np.ascontiguousarray(uv_dir_cone, np.float32).reshape(-1, 7)
+        out = np.zeros((len(prims), 45), np.uint32)
+        self.L.ptref_surface_probe(self.h, ctypes.c_uint32(len(prims)), _p(prims), _p(a), _p(out))
         return out
 
     def camera_ray(self, px, py, sample_index):

@@ -12,7 +12,12 @@
 // services (oracle/refpin/hlsl_tu.py --integrator, tests/test_oracle_refpin_integrator.py); leaf functions, BSDF, lights and RNG separately
 // (tests/test_oracle_refpin_hlsl.py, tests/test_oracle_kat.py). Unpinned: the Donut side of loadSurface and DXR traversal.
 // Fixed parity knobs (SURVEY.md §8a "parity knobs"): PATH_TRACER_MODE_REFERENCE, NEEType=1 (power, no local sampler,
-// no temporal feedback), full MIS (RTXPT_USE_APPROXIMATE_MIS=0), lpfloat=fp32, no ReSTIR, no stable planes, no STF.
+// no temporal feedback), full MIS (RTXPT_USE_APPROXIMATE_MIS=0), no ReSTIR, no stable planes, no STF.
+// lp types: both builds of the reference are restated. PT_LP16 = 0 is RTXPT_LP_TYPES_USE_16BIT_PRECISION 0; PT_LP16 = 1 (libptref_lp16.so) is the
+// reference's default (SampleUI.h:182, Sample.cpp:1035): every value the reference declares lpfloat / lpfloat3 is rounded to binary16 where it is
+// converted, and the operations the reference performs between lp values are half operations (LPOps, vec.h) — MaterialProperties
+// (BridgeDonut:311-380), the BSDF inputs of Bridge::loadSurface (:732-790), ShadingData::IoR / emission / shadowNoLFadeout, SurfaceData::interiorIoR,
+// updateOutsideIoR / loadIoR (:855-869), the emission terms and FireflyFilter (PathTracer.hlsli:438-480, 593-660, PathTracerHelpers.hlsli:206-213).
 #pragma once
 #include "bsdf.h"
 #include "rng.h"
@@ -20,6 +25,10 @@
 
 namespace ptref {
 
+#ifndef PT_LP16
+#define PT_LP16 0          // 1: the reference's default build, lp types in 16 bits (libptref_lp16.so)
+#endif
+typedef LPOps<PT_LP16 != 0> LP;
 static const float kMaxRayTravel = 1e15f;                 // Config.h
 static const float kSpecularRoughnessThreshold = 0.25f;   // PathTracer.hlsli:23
 static const float c_DielectricSpecular = 0.04f;          // Donut material_cb.h (absent; value per glTF spec)
@@ -44,7 +53,8 @@ struct PtSettings {
     uint  nestedDielectricsQuality;       // RTXPT_NESTED_DIELECTRICS_QUALITY (0,1,2)
     uint  enableLDSamplerForBSDF;         // RTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF
     uint  diffuseBrdf;                    // DiffuseBrdf: 0 Lambert, 2 Frostbite
-    uint  _pad[2];
+    uint  useFp16Types;                   // which build of the lp types the caller asked for; THIS library restates the one PT_LP16 names (libptref.so / libptref_lp16.so)
+    uint  _pad;
 };
 static_assert(sizeof(PtSettings) == 64, "PtSettings layout");
 
@@ -174,12 +184,12 @@ static inline float ComputeNewScatterFireflyFilterK(float currentK, float bounce
     const float k = 32;
     float p = k / (k + angle * angle);
     p *= FastSqrt(lobeP);
-    return fmaxf_(minK, currentK * p);
+    return LP::r(fmaxf_(minK, currentK * p));               // returns lpfloat: the NEE path uses the value before it is ever packed
 }
-static inline float3 FireflyFilter(float3 signalIn, float threshold, float fireflyFilterK) {
-    float t = threshold * fireflyFilterK;
-    float maxR = Average(signalIn);
-    if (maxR > t) signalIn = signalIn / maxR * t;
+static inline float3 FireflyFilter(float3 signalIn, float threshold, float fireflyFilterK) {      // lpfloat3 (lpfloat3, lpfloat, lpfloat): all three are lp values
+    float t = LP::mul(threshold, fireflyFilterK);
+    float maxR = LP::average3(signalIn);
+    if (maxR > t) signalIn = LP::mul3(LP::div3(signalIn, maxR), t);
     return signalIn;
 }
 static inline float FireflyFilterShort(float signalAverage, float threshold, float fireflyFilterK) {
@@ -328,14 +338,15 @@ struct PathTracer {
         if (hasUV && (material.Flags & PTMaterialFlags_UseTransmissionTexture)) texTrans = sampleTexture(material.TransmissionTextureIndex, lambda, texcoord);
 
         float3 mGeometryNormal = normalize(geometryNormal), mShadingNormal = mGeometryNormal;
-        float3 baseColor = material.BaseOrDiffuseColor * xyz(texBase);
-        float roughness = material.Roughness * texMR.y;
-        float metalness = (material.Flags & PTMaterialFlags_MetalnessInRedChannel) ? material.Metalness * texMR.x : material.Metalness * texMR.z;
-        float transmission = material.TransmissionFactor, diffuseTransmission = material.DiffuseTransmissionFactor;
-        if (material.Flags & PTMaterialFlags_UseTransmissionTexture) { transmission *= texTrans.x; diffuseTransmission *= texTrans.x; }
-        float3 emissiveColor = material.EmissiveColor;
-        if (material.Flags & PTMaterialFlags_UseEmissiveTexture) emissiveColor = emissiveColor * xyz(texEmissive);
-        float matIoR = material.IoR;
+        // MaterialProperties holds lp values: a conversion lpfloat(x) per assignment, half operations between lp operands
+        float3 baseColor = LP::r3(material.BaseOrDiffuseColor * xyz(texBase));
+        float roughness = LP::r(material.Roughness * texMR.y);
+        float metalness = LP::r((material.Flags & PTMaterialFlags_MetalnessInRedChannel) ? material.Metalness * texMR.x : material.Metalness * texMR.z);
+        float transmission = LP::r(material.TransmissionFactor), diffuseTransmission = LP::r(material.DiffuseTransmissionFactor);
+        if (material.Flags & PTMaterialFlags_UseTransmissionTexture) { transmission = LP::mul(transmission, LP::r(texTrans.x)); diffuseTransmission = LP::mul(diffuseTransmission, LP::r(texTrans.x)); }
+        float3 emissiveColor = LP::r3(material.EmissiveColor);
+        if (material.Flags & PTMaterialFlags_UseEmissiveTexture) emissiveColor = LP::mul3(emissiveColor, LP::r3(xyz(texEmissive)));
+        float matIoR = LP::r(material.IoR);
         if (hasUV && (material.Flags & PTMaterialFlags_UseNormalTexture)) {          // ApplyNormalMapRTXPT (BridgeDonut:280-309)
             float sqT = dot(xyz(tangent), xyz(tangent));
             if (sqT != 0 && tangent.w != 0) {
@@ -363,20 +374,20 @@ struct PathTracer {
         { uint pr = 1 + (material.Flags >> PTMaterialFlags_NestedPriorityShift); sd.mtl.setNestedPriority(pr < InteriorList::kMaxNestedPriority ? pr : InteriorList::kMaxNestedPriority); }
         sd.mtl.setThinSurface(thin);
         adjustShadingNormal(sd, tangent, true, ignoreTangent);
-        sd.shadowNoLFadeout = material.ShadowNoLFadeout;
+        sd.shadowNoLFadeout = LP::r(material.ShadowNoLFadeout);
 
-        float bsdfSpecTrans = transmission * (1 - metalness), bsdfDiffTrans = diffuseTransmission * (1 - metalness);
+        float bsdfSpecTrans = LP::mul(transmission, LP::sub(1, metalness)), bsdfDiffTrans = LP::mul(diffuseTransmission, LP::sub(1, metalness));      // lp * (1 - lp)
         sd.mtl.setActiveLobes(Lobe_All);
-        float f = (matIoR - 1.f) / (matIoR + 1.f);
+        float f = (matIoR - 1.f) / (matIoR + 1.f);                        // lp op float literal: float arithmetic
         float F0 = f * f;
-        StandardBSDFData bd;
-        bd.diffuse = lerp3(baseColor, make_float3(0.f), metalness);
-        bd.specular = lerp3(make_float3(F0), baseColor, metalness);
+        StandardBSDFData bd;                                              // the fields are lp values (BxDF.hlsli:625-634); FalcorBSDF computes from them in float
+        bd.diffuse = LP::lerp3(baseColor, make_float3(0.f), metalness);
+        bd.specular = LP::lerp3(make_float3(LP::r(F0)), baseColor, metalness);
         bd.roughness = roughness; bd.metallic = metalness;
         bd.transmission = baseColor; bd.diffuseTransmission = bsdfDiffTrans; bd.specularTransmission = bsdfSpecTrans;
         sd.IoR = 1.f;
-        bd.eta = sd.IoR / matIoR;
-        if (!sd.mtl.isThinSurface() && !sd.frontFacing) bd.eta = matIoR / sd.IoR;
+        bd.eta = LP::div(sd.IoR, matIoR);
+        if (!sd.mtl.isThinSurface() && !sd.frontFacing) bd.eta = LP::div(matIoR, sd.IoR);
 
         SurfaceData ret;
         ret.neeTriangleLightIndex = RTXPT_INVALID_LIGHT_INDEX; ret.neeAnalyticLightIndex = RTXPT_INVALID_LIGHT_INDEX;
@@ -388,7 +399,7 @@ struct PathTracer {
         ret.shadingData = sd; ret.bsdf.data = bd; ret.bsdf.diffuseModel = (int)S.diffuseBrdf; ret.interiorIoR = matIoR;
         return ret;
     }
-    float loadIoR(uint materialID) const { return (materialID >= sc.materials.size()) ? 1.0f : sc.materials[materialID].IoR; }   // BridgeDonut:863-869
+    float loadIoR(uint materialID) const { return (materialID >= sc.materials.size()) ? 1.0f : LP::r(sc.materials[materialID].IoR); }   // BridgeDonut:863-869 (returns lpfloat)
     float3 volumeTransmittance(uint materialID, float t) const {                                                                   // BridgeDonut:871-887
         if (materialID >= sc.materials.size()) return make_float3(1.f);
         const PTMaterialData& m = sc.materials[materialID];
@@ -421,9 +432,10 @@ struct PathTracer {
                 uint envIdx = lightSampler.LookupEnvLightByDirection(localDir);
                 misWeight = lightSampler.ComputeBSDFMISForEnvironmentQuad(envIdx, bsdfScatterPdf, misInfo.FullSamples);
             }
-            environmentEmission = misWeight * Le;
+            environmentEmission = LP::r3(misWeight * Le);
         }
-        if (S.fireflyFilterThreshold != 0) environmentEmission = FireflyFilter(environmentEmission, S.fireflyFilterThreshold, path.GetFireflyFilterK());
+        const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);
+        if (baseFFThreshold != 0) environmentEmission = FireflyFilter(environmentEmission, baseFFThreshold, path.GetFireflyFilterK());
         if (any_gt0(environmentEmission)) AccumulatePathRadiance(path, path.GetThp() * environmentEmission);
         path.setFlag(PF_hit, false);
         path.terminate();
@@ -453,7 +465,7 @@ struct PathTracer {
         }
         float outsideIoR = ComputeOutsideIoR(path.interiorList, sfd.shadingData.materialID, sfd.shadingData.frontFacing);
         sfd.shadingData.IoR = outsideIoR;                                          // Bridge::updateOutsideIoR (BridgeDonut:855-861)
-        sfd.bsdf.data.eta = sfd.shadingData.frontFacing ? (sfd.shadingData.IoR / sfd.interiorIoR) : (sfd.interiorIoR / sfd.shadingData.IoR);
+        sfd.bsdf.data.eta = sfd.shadingData.frontFacing ? LP::div(sfd.shadingData.IoR, sfd.interiorIoR) : LP::div(sfd.interiorIoR, sfd.shadingData.IoR);
         return true;
     }
 
@@ -596,10 +608,11 @@ struct PathTracer {
             float bsdfScatterPdf = path.GetBsdfScatterPdf();
             if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0)
                 misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(sfd.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.FullSamples);
-            surfaceEmission = sd.emission * misWeight;
+            surfaceEmission = LP::r3(sd.emission * misWeight);
         }
         if (any_gt0(surfaceEmission)) {
-            if (S.fireflyFilterThreshold != 0) surfaceEmission = FireflyFilter(surfaceEmission, S.fireflyFilterThreshold, path.GetFireflyFilterK());
+            const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);
+            if (baseFFThreshold != 0) surfaceEmission = FireflyFilter(surfaceEmission, baseFFThreshold, path.GetFireflyFilterK());
             if (any_gt0(surfaceEmission)) AccumulatePathRadiance(path, path.GetThp() * surfaceEmission);
         }
         if (path.isTerminatingAtNextBounce()) { path.terminate(); return; }

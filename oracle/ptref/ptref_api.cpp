@@ -529,6 +529,23 @@ void ptref_tonemap(const float* rgba, uint32_t n, const ToneMapParams* p, uint32
 }
 
 // the oracle's restatement of the functions pinned against reference text (oracle/refpin/pin_fns.h; tests/test_oracle_refpin_hlsl.py)
+// loadSurface of THIS library's build (fp32 or lp16) as 45 words per hit — the layout of refpt_surface_probe (oracle/refpin/hlsl_pt_wrappers.inc): the device's
+// loadSurface is compared with it (tests/test_gpu_parity.py). rows: [u, v, dir.xyz, coneWidth, coneSpread]
+void ptref_surface_probe(void* h, uint32_t n, const uint32_t* prims, const float* uvDirCone, uint32_t* out) {
+    Context* c = (Context*)h; prepare(c);
+    PathTracer svc(c->sc, c->S, c->cam, 0, nullptr);
+    for (uint32_t k = 0; k < n; k++) {
+        const float* a = uvDirCone + 7 * k;
+        RayCone rc = RayCone::make(a[5], a[6]);
+        SurfaceData q = svc.loadSurface(prims[k], a[0], a[1], make_float3(a[2], a[3], a[4]), rc);
+        uint32_t* o = out + 45 * k; const ShadingData& s = q.shadingData; const StandardBSDFData& b = q.bsdf.data;
+        auto put3 = [&](float3 v) { *o++ = asuint(v.x); *o++ = asuint(v.y); *o++ = asuint(v.z); };
+        put3(s.posW); put3(s.faceNCorrected); put3(s.V); put3(s.N); put3(s.T); put3(s.B); put3(s.vertexN);
+        *o++ = s.frontFacing; *o++ = s.mtl.packedData; *o++ = s.materialID; *o++ = asuint(s.IoR); *o++ = asuint(s.shadowNoLFadeout); put3(s.emission);
+        put3(b.diffuse); *o++ = asuint(b.roughness); put3(b.specular); *o++ = asuint(b.metallic); put3(b.transmission);
+        *o++ = asuint(b.diffuseTransmission); *o++ = asuint(b.specularTransmission); *o++ = asuint(b.eta); *o++ = asuint(q.interiorIoR); *o++ = q.neeTriangleLightIndex;
+    }
+}
 void ptref_pin_call(int fn, const float* in, unsigned n, float* out) {
     const int ni = kPinArity[fn][0], no = kPinArity[fn][1];
     for (unsigned k = 0; k < n; k++) {

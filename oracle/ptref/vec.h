@@ -179,6 +179,26 @@ static inline uint Fp32ToFp16(float2 v) {
 }
 static inline uint Fp32ToFp16NoClamp(float2 v) { return (f32tof16(v.y) << 16) | (f32tof16(v.x) & 0xffffu); }
 static inline float2 Fp16ToFp32(uint r) { return make_float2(f16tof32(r & 0xffffu), f16tof32(r >> 16)); }
+// ---- "lp" types of the reference's 16-bit build (Utils.hlsli:28-48: lpfloat = float16_t when RTXPT_LP_TYPES_USE_16BIT_PRECISION, the reference's default —
+// SampleUI.h:182 UseFp16Types = true, Sample.cpp:1035). A value of an lp type is kept in a float that holds a binary16 number; LPOps<true>::r() is the
+// conversion lpfloat(x), and the arithmetic helpers are the half-typed operators (one rounding to nearest even after every operation, as float16_t
+// arithmetic under -enable-16bit-types; an exactly computed fp32 result rounded once to binary16 equals the native half operation for + - * /, since
+// 24 >= 2 * 11 + 2). LPOps<false> is the fp32 build: every helper is the plain float expression it stands for.
+template <bool LP16> struct LPOps {
+    static inline float r(float x) { return LP16 ? f16tof32(f32tof16(x)) : x; }
+    static inline float add(float a, float b) { return r(a + b); }
+    static inline float sub(float a, float b) { return r(a - b); }
+    static inline float mul(float a, float b) { return r(a * b); }
+    static inline float div(float a, float b) { return r(a / b); }       // fp32 quotient (correctly rounded), one rounding to binary16
+    static inline float3 r3(float3 v) { return make_float3(r(v.x), r(v.y), r(v.z)); }
+    static inline float3 mul3(float3 a, float3 b) { return make_float3(mul(a.x, b.x), mul(a.y, b.y), mul(a.z, b.z)); }
+    static inline float3 mul3(float3 a, float b) { return make_float3(mul(a.x, b), mul(a.y, b), mul(a.z, b)); }
+    static inline float3 div3(float3 a, float b) { return make_float3(div(a.x, b), div(a.y, b), div(a.z, b)); }
+    static inline float lerp(float a, float b, float t) { return add(a, mul(sub(b, a), t)); }                       // HLSL lerp: x + s*(y-x), every operation in half
+    static inline float3 lerp3(float3 a, float3 b, float t) { return make_float3(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t)); }
+    static inline float average3(float3 v) { return div(add(add(v.x, v.y), v.z), 3.0f); }       // the lpfloat3 overload of Average (Utils.hlsli:62-67): (x + y + z) / 3.0 in half
+};
+
 
 // Packing.hlsli:17-51, 127-167
 static inline uint Pack_R8_UFLOAT(float r, float d = 0.5f) { return (uint)floorf(r * 255.0f + d) & 255u; }

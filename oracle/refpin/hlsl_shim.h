@@ -54,8 +54,13 @@ typedef v2<bool> bool2; typedef v3<bool> bool3; typedef v4<bool> bool4;
 // far that build is from the fp32 build both sides of the parity fence restate (tools/lp16_deviation.py); half x float promotes to float as in HLSL.
 struct half_t { float v; half_t() : v(0.f) {} half_t(float f) : v(P::f16tof32(P::f32tof16(f))) {} half_t(double f) : half_t((float)f) {} half_t(int i) : half_t((float)i) {} half_t(uint i) : half_t((float)i) {}
     half_t(bool b) : v(b ? 1.f : 0.f) {} operator float() const { return v; } };
+// scalar typing rules of HLSL: half op half -> half; an int or an unsuffixed floating literal (a C++ double here) adapts to the half operand; a float
+// operand — a float variable or an `f`-suffixed literal — promotes the half to float (exact-match overloads: nothing is left to -fpermissive)
 #define HL_HALFOP(op) static inline half_t operator op(half_t a, half_t b) { return half_t(a.v op b.v); } \
     static inline half_t operator op(half_t a, int b) { return half_t(a.v op (float)b); } static inline half_t operator op(int a, half_t b) { return half_t((float)a op b.v); } \
+    static inline half_t operator op(half_t a, uint b) { return half_t(a.v op (float)b); } static inline half_t operator op(uint a, half_t b) { return half_t((float)a op b.v); } \
+    static inline half_t operator op(half_t a, double b) { return half_t(a.v op half_t(b).v); } static inline half_t operator op(double a, half_t b) { return half_t(half_t(a).v op b.v); } \
+    static inline float operator op(half_t a, float b) { return a.v op b; } static inline float operator op(float a, half_t b) { return a op b.v; } \
     static inline half_t& operator op##=(half_t& a, half_t b) { a = half_t(a.v op b.v); return a; } static inline half_t& operator op##=(half_t& a, float b) { a = half_t(a.v op b); return a; }
 HL_HALFOP(+) HL_HALFOP(-) HL_HALFOP(*) HL_HALFOP(/)
 #undef HL_HALFOP

@@ -596,14 +596,14 @@ int32_t pt_default_settings(::PtSettings* s) {
     memset(s, 0, sizeof(*s));
     s->bounceCount = 8; s->diffuseBounceCount = 8; s->perPixelJitterAAScale = 1.0f; s->texLODBias = -1.0f; s->fireflyFilterThreshold = 0.f; s->envMapDiffuseSampleMIPLevel = 0.f;
     s->NEEEnabled = 1; s->NEEType = 1; s->NEECandidateSamples = 5; s->NEEFullSamples = 1; s->enableRussianRoulette = 1; s->nestedDielectricsQuality = 1;
-    s->enableLDSamplerForBSDF = 1; s->diffuseBrdf = 2;
+    s->enableLDSamplerForBSDF = 1; s->diffuseBrdf = 2; s->useFp16Types = 1;      // SampleUI.h:182: UseFp16Types = true
     return PT_OK;
 }
 int32_t pt_set_settings(pt_context* c, const ::PtSettings* s) {
     if (!c || !s) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
     if (s->NEEType > 1) return fail(c, PT_ERROR_UNSUPPORTED, "NEEType 2 (NEE-AT temporal feedback) is out of scope; use 0 (uniform) or 1 (power)");
     if (s->NEECandidateSamples == 0 || s->NEECandidateSamples > 63) return fail(c, PT_ERROR_INVALID_ARGUMENT, "NEECandidateSamples must be in [1,63]");
-    if (s->nestedDielectricsQuality > 2 || (s->diffuseBrdf != 0 && s->diffuseBrdf != 2) || s->bounceCount > 96) return fail(c, PT_ERROR_INVALID_ARGUMENT, "setting out of range");
+    if (s->nestedDielectricsQuality > 2 || (s->diffuseBrdf != 0 && s->diffuseBrdf != 2) || s->bounceCount > 96 || s->useFp16Types > 1) return fail(c, PT_ERROR_INVALID_ARGUMENT, "setting out of range");
     if (c->S.NEEEnabled != s->NEEEnabled || c->S.NEEType != s->NEEType) c->lightsDirty = true;
     memcpy(&c->S, s, sizeof(c->S));
     return PT_OK;
@@ -910,6 +910,7 @@ int32_t pt_get_scene_info(pt_context* c, uint32_t* nTris, uint32_t* nNodes, uint
 int32_t pt_probe(pt_context* c, int32_t kind, const void* in, size_t inBytes, void* out, size_t outBytes, uint32_t n) {
     if (!c || !in || !out || !n) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad argument");
     (void)hipSetDevice(c->device);
+    if (kind == 8) { int r = prepare(c); if (r != PT_OK) return r; }      // the surface probe reads the scene
     DevBuf<unsigned char> di, dout;
     PT_CHECK_HIP(c, di.upload((const unsigned char*)in, inBytes, c->stream)); PT_CHECK_HIP(c, dout.resize(outBytes));
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;

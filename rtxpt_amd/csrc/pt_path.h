@@ -33,7 +33,7 @@ struct PathTracerCameraData {
 static_assert(sizeof(PathTracerCameraData) == 112, "PathTracerCameraData layout");
 struct PtSettings {
     uint bounceCount, diffuseBounceCount; float perPixelJitterAAScale, texLODBias, fireflyFilterThreshold, envMapDiffuseSampleMIPLevel;
-    uint NEEEnabled, NEEType, NEECandidateSamples, NEEFullSamples, enableRussianRoulette, nestedDielectricsQuality, enableLDSamplerForBSDF, diffuseBrdf, _pad[2];
+    uint NEEEnabled, NEEType, NEECandidateSamples, NEEFullSamples, enableRussianRoulette, nestedDielectricsQuality, enableLDSamplerForBSDF, diffuseBrdf, useFp16Types, _pad;      // useFp16Types: lp types in 16 bits (the reference's default build)
 };
 static_assert(sizeof(PtSettings) == 64, "PtSettings layout");
 
@@ -131,18 +131,19 @@ struct ShadowSink { float4* q0; float4* q1; float4* q2; uint* count; unsigned lo
 static inline float ComputeRayConeSpreadAngleExpansionByScatterPDF(float bsdfScatterPdf, float growthFactor) {
     return growthFactor * 2.0f * FastACos(fmaxf_(-1.0f, 1.0f - (1.0f / bsdfScatterPdf) / (2.0f * K_PI)));
 }
-static inline float ComputeNewScatterFireflyFilterK(float currentK, float bouncePDF, float lobeP) {
+// LP = LPOps<false> / LPOps<true> (pt_vec.h): the reference's two builds of its "lp" types (fp32 / binary16, the default)
+template <class LP> static inline float ComputeNewScatterFireflyFilterK(float currentK, float bouncePDF, float lobeP) {
     const float minK = 0.00001f;
     float angle = (bouncePDF == 0) ? 0.f : ComputeRayConeSpreadAngleExpansionByScatterPDF(bouncePDF, 1.0f);
     const float k = 32;
     float p = k / (k + angle * angle);
     p *= FastSqrt(lobeP);
-    return fmaxf_(minK, currentK * p);
+    return LP::r(fmaxf_(minK, currentK * p));               // returns lpfloat: the NEE path uses the value before it is ever packed
 }
-static inline float3 FireflyFilter(float3 signalIn, float threshold, float fireflyFilterK) {
-    float t = threshold * fireflyFilterK;
-    float maxR = Average(signalIn);
-    if (maxR > t) signalIn = signalIn / maxR * t;
+template <class LP> static inline float3 FireflyFilter(float3 signalIn, float threshold, float fireflyFilterK) {      // lpfloat3 (lpfloat3, lpfloat, lpfloat): all three are lp values
+    float t = LP::mul(threshold, fireflyFilterK);
+    float maxR = LP::average3(signalIn);
+    if (maxR > t) signalIn = LP::mul3(LP::div3(signalIn, maxR), t);
     return signalIn;
 }
 static inline float FireflyFilterShort(float signalAverage, float threshold, float fireflyFilterK) {
@@ -163,7 +164,9 @@ static inline float computeRayConeTriangleLODValue(const float3 v[3], const floa
     return 0.5f * RayCone::SafeLog2(Ta / Pa);
 }
 
-struct PathKernelContext {
+// LP16: which build of the reference's lp types this instance restates (PtSettings::useFp16Types selects it at launch; the data members are the same)
+template <bool LP16> struct PathKernelContextT {
+    typedef LPOps<LP16> LP;
     DeviceScene sc; PtSettings S; PathTracerCameraData cam;
 
     bool HasFinishedSurfaceBounces(uint vertexIndex, uint diffuseBounces) const {      // PathTracer.hlsli:40-45
@@ -288,14 +291,15 @@ struct PathKernelContext {
         if (hasUV && (mflags & PTMaterialFlags_UseTransmissionTexture)) texTrans = sampleTexture(material.TransmissionTextureIndex, lambda, texcoord);
 
         float3 mGeometryNormal = normalize(geometryNormal), mShadingNormal = mGeometryNormal;
-        float3 baseColor = material.BaseOrDiffuseColor * xyz(texBase);
-        float roughness = material.Roughness * texMR.y;
-        float metalness = (mflags & PTMaterialFlags_MetalnessInRedChannel) ? material.Metalness * texMR.x : material.Metalness * texMR.z;
-        float transmission = material.TransmissionFactor, diffuseTransmission = material.DiffuseTransmissionFactor;
-        if (mflags & PTMaterialFlags_UseTransmissionTexture) { transmission *= texTrans.x; diffuseTransmission *= texTrans.x; }
-        float3 emissiveColor = material.EmissiveColor;
-        if (mflags & PTMaterialFlags_UseEmissiveTexture) emissiveColor = emissiveColor * xyz(texEmissive);
-        float matIoR = material.IoR;
+        // MaterialProperties holds lp values: a conversion lpfloat(x) per assignment, half operations between lp operands
+        float3 baseColor = LP::r3(material.BaseOrDiffuseColor * xyz(texBase));
+        float roughness = LP::r(material.Roughness * texMR.y);
+        float metalness = LP::r((mflags & PTMaterialFlags_MetalnessInRedChannel) ? material.Metalness * texMR.x : material.Metalness * texMR.z);
+        float transmission = LP::r(material.TransmissionFactor), diffuseTransmission = LP::r(material.DiffuseTransmissionFactor);
+        if (mflags & PTMaterialFlags_UseTransmissionTexture) { transmission = LP::mul(transmission, LP::r(texTrans.x)); diffuseTransmission = LP::mul(diffuseTransmission, LP::r(texTrans.x)); }
+        float3 emissiveColor = LP::r3(material.EmissiveColor);
+        if (mflags & PTMaterialFlags_UseEmissiveTexture) emissiveColor = LP::mul3(emissiveColor, LP::r3(xyz(texEmissive)));
+        float matIoR = LP::r(material.IoR);
         if (hasUV && (mflags & PTMaterialFlags_UseNormalTexture)) {                                   // ApplyNormalMapRTXPT
             float sqT = dot(xyz(tangent), xyz(tangent));
             if (sqT != 0 && tangent.w != 0) {
@@ -323,19 +327,19 @@ struct PathKernelContext {
         { uint pr = 1 + (mflags >> PTMaterialFlags_NestedPriorityShift); sd.mtl.setNestedPriority(pr < InteriorList::kMaxNestedPriority ? pr : InteriorList::kMaxNestedPriority); }
         sd.mtl.setThinSurface(thin);
         adjustShadingNormal(sd, tangent, true, ignoreTangent);
-        sd.shadowNoLFadeout = material.ShadowNoLFadeout;
-        float bsdfSpecTrans = transmission * (1 - metalness), bsdfDiffTrans = diffuseTransmission * (1 - metalness);
+        sd.shadowNoLFadeout = LP::r(material.ShadowNoLFadeout);
+        float bsdfSpecTrans = LP::mul(transmission, LP::sub(1, metalness)), bsdfDiffTrans = LP::mul(diffuseTransmission, LP::sub(1, metalness));      // lp * (1 - lp)
         sd.mtl.setActiveLobes(Lobe_All);
         float f = (matIoR - 1.f) / (matIoR + 1.f);
         float F0 = f * f;
         StandardBSDFData bd;
-        bd.diffuse = lerp3(baseColor, make_float3(0.f), metalness);
-        bd.specular = lerp3(make_float3(F0), baseColor, metalness);
+        bd.diffuse = LP::lerp3(baseColor, make_float3(0.f), metalness);          // StandardBSDFData holds lp values (BxDF.hlsli:625-634); FalcorBSDF computes from them in float
+        bd.specular = LP::lerp3(make_float3(LP::r(F0)), baseColor, metalness);
         bd.roughness = roughness; bd.metallic = metalness;
         bd.transmission = baseColor; bd.diffuseTransmission = bsdfDiffTrans; bd.specularTransmission = bsdfSpecTrans;
         sd.IoR = 1.f;
-        bd.eta = sd.IoR / matIoR;
-        if (!sd.mtl.isThinSurface() && !sd.frontFacing) bd.eta = matIoR / sd.IoR;
+        bd.eta = LP::div(sd.IoR, matIoR);
+        if (!sd.mtl.isThinSurface() && !sd.frontFacing) bd.eta = LP::div(matIoR, sd.IoR);
         SurfaceData ret;
         ret.neeTriangleLightIndex = RTXPT_INVALID_LIGHT_INDEX;
         if (sd.frontFacing && any_gt0(emissiveColor)) {
@@ -346,7 +350,7 @@ struct PathKernelContext {
         ret.shadingData = sd; ret.bsdf.data = bd; ret.bsdf.diffuseModel = (int)S.diffuseBrdf; ret.interiorIoR = matIoR;
         return ret;
     }
-    float loadIoR(uint materialID) const { return (materialID >= sc.materialCount) ? 1.0f : sc.materials[materialID].IoR; }
+    float loadIoR(uint materialID) const { return (materialID >= sc.materialCount) ? 1.0f : LP::r(sc.materials[materialID].IoR); }      // (returns lpfloat)
     float3 volumeTransmittance(uint materialID, float t) const {                                        // BridgeDonut:871-887
         if (materialID >= sc.materialCount) return make_float3(1.f);
         const PTMaterialData& m = sc.materials[materialID];
@@ -378,9 +382,10 @@ struct PathKernelContext {
                 uint envIdx = lightSampler.LookupEnvLightByDirection(localDir);
                 misWeight = lightSampler.ComputeBSDFMISForEnvironmentQuad(envIdx, bsdfScatterPdf, misInfo.FullSamples);
             }
-            environmentEmission = misWeight * Le;
+            environmentEmission = LP::r3(misWeight * Le);
         }
-        if (S.fireflyFilterThreshold != 0) environmentEmission = FireflyFilter(environmentEmission, S.fireflyFilterThreshold, path.GetFireflyFilterK());
+        const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);
+        if (baseFFThreshold != 0) environmentEmission = FireflyFilter<LP>(environmentEmission, baseFFThreshold, path.GetFireflyFilterK());
         if (any_gt0(environmentEmission)) AccumulatePathRadiance(path, path.GetThp() * environmentEmission);
         path.setFlag(PF_hit, false);
         path.terminate();
@@ -408,7 +413,7 @@ struct PathKernelContext {
         }
         float outsideIoR = ComputeOutsideIoR(path.interiorList, sfd.shadingData.materialID, sfd.shadingData.frontFacing);
         sfd.shadingData.IoR = outsideIoR;
-        sfd.bsdf.data.eta = sfd.shadingData.frontFacing ? (sfd.shadingData.IoR / sfd.interiorIoR) : (sfd.interiorIoR / sfd.shadingData.IoR);
+        sfd.bsdf.data.eta = sfd.shadingData.frontFacing ? LP::div(sfd.shadingData.IoR, sfd.interiorIoR) : LP::div(sfd.interiorIoR, sfd.shadingData.IoR);
         return true;
     }
     // PathTracer.hlsli:217-380
@@ -442,7 +447,7 @@ struct PathKernelContext {
             path.setFlag(PF_deltaOnlyPath, false);
             path.rayCone = RayCone::make(path.rayCone.getWidth(), fminf_(path.rayCone.getSpreadAngle() + ComputeRayConeSpreadAngleExpansionByScatterPDF(bs.pdf, 0.3f), 2.0f * K_PI));
         }
-        float fireflyFilterK = ComputeNewScatterFireflyFilterK(path.GetFireflyFilterK(), bs.pdf, bs.lobeP);
+        float fireflyFilterK = ComputeNewScatterFireflyFilterK<LP>(path.GetFireflyFilterK(), bs.pdf, bs.lobeP);
         path.SetFireflyFilterK_BsdfScatterPdf(fireflyFilterK, bs.pdf);
         path.setFlag(PF_enableThreadReorder, true);
         return true;
@@ -509,7 +514,7 @@ struct PathKernelContext {
                 float radianceAvg = Average(radiance);
                 if (S.fireflyFilterThreshold != 0) {
                     float pdf = ls.SelectionPdf * ls.SolidAnglePdf;
-                    float k = ComputeNewScatterFireflyFilterK(pre.GetFireflyFilterK(), pdf, 1.0f);
+                    float k = ComputeNewScatterFireflyFilterK<LP>(pre.GetFireflyFilterK(), pdf, 1.0f);
                     radiance = radiance * FireflyFilterShort(radianceAvg, S.fireflyFilterThreshold, k);
                 }
                 radiance = radiance * pre.GetThp();
@@ -559,10 +564,11 @@ struct PathKernelContext {
                 LightSampler lightSampler; lightSampler.T = &sc.lights;
                 misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(sfd.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.FullSamples);
             }
-            surfaceEmission = sd.emission * misWeight;
+            surfaceEmission = LP::r3(sd.emission * misWeight);
         }
         if (any_gt0(surfaceEmission)) {
-            if (S.fireflyFilterThreshold != 0) surfaceEmission = FireflyFilter(surfaceEmission, S.fireflyFilterThreshold, path.GetFireflyFilterK());
+            const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);
+            if (baseFFThreshold != 0) surfaceEmission = FireflyFilter<LP>(surfaceEmission, baseFFThreshold, path.GetFireflyFilterK());
             if (any_gt0(surfaceEmission)) AccumulatePathRadiance(path, path.GetThp() * surfaceEmission);
         }
         if (path.isTerminatingAtNextBounce()) { path.terminate(); return; }
@@ -593,6 +599,7 @@ struct PathKernelContext {
     }
     static void ResolveShadow(uint pack45[2], float3 radiance) { uint nee[2] = {0u, 0u}; NeeAccumulate(nee, radiance); NeeCommit(pack45, nee); }
 };
+typedef PathKernelContextT<false> PathKernelContext;      // the fp32 build of the lp types; PathKernelContextT<true> has the same data members
 
 #pragma clang force_cuda_host_device end
 } // namespace ptk

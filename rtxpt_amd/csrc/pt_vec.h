@@ -135,6 +135,14 @@ static inline float det3(const float3x4& M) {
 }
 
 // ---- fp16 (binary16) <-> fp32, round-to-nearest-even, denormals preserved
+// On the device these are the conversion instructions (v_cvt_f16_f32 / v_cvt_f32_f16: IEEE round-to-nearest-even, overflow to infinity, binary16
+// denormals kept — the kernels run with the default float mode, which never flushes 16-bit denormals): the same function as the software routine
+// below, which is what the host side and the oracle execute (tests/test_gpu_parity.py::test_leaf_functions_bit_exact compares the two on 40 000 values
+// including the denormal range, the overflow boundary 65519.9 / 65520 and the tie 2^-25). One instruction instead of ~20, and far fewer registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+static inline uint f32tof16(float f) { _Float16 h = (_Float16)f; unsigned short b; __builtin_memcpy(&b, &h, 2); return (uint)b; }
+static inline float f16tof32(uint h) { unsigned short b = (unsigned short)(h & 0xffffu); _Float16 x; __builtin_memcpy(&x, &b, 2); return (float)x; }
+#else
 static inline uint f32tof16(float f) {
     uint x = asuint(f);
     uint sign = (x >> 16) & 0x8000u;
@@ -176,6 +184,7 @@ static inline float f16tof32(uint h) {
     if (e == 31u) return asfloat(sign | 0x7f800000u | (m << 13));
     return asfloat(sign | ((e + 112u) << 23) | (m << 13));
 }
+#endif
 static const float HLF_MAX = 65504.0f;
 // Packing.hlsli:206-232
 static inline uint Fp32ToFp16(float2 v) {
@@ -184,6 +193,37 @@ static inline uint Fp32ToFp16(float2 v) {
 }
 static inline uint Fp32ToFp16NoClamp(float2 v) { return (f32tof16(v.y) << 16) | (f32tof16(v.x) & 0xffffu); }
 static inline float2 Fp16ToFp32(uint r) { return make_float2(f16tof32(r & 0xffffu), f16tof32(r >> 16)); }
+// ---- "lp" types of the reference's 16-bit build (Utils.hlsli:28-48: lpfloat = float16_t when RTXPT_LP_TYPES_USE_16BIT_PRECISION, the reference's default —
+// SampleUI.h:182 UseFp16Types = true, Sample.cpp:1035). A value of an lp type is kept in a float that holds a binary16 number; LPOps<true>::r() is the
+// conversion lpfloat(x), and the arithmetic helpers are the half-typed operators (one rounding to nearest even after every operation, as float16_t
+// arithmetic under -enable-16bit-types; an exactly computed fp32 result rounded once to binary16 equals the native half operation for + - * /, since
+// 24 >= 2 * 11 + 2). LPOps<false> is the fp32 build: every helper is the plain float expression it stands for.
+template <bool LP16> struct LPOps {
+    // lpfloat(x) of a float expression rounds TWICE: the expression to fp32, then fp32 to binary16. On the device the compiler would otherwise select the
+    // mixed-precision v_fma_mixlo_f16 for lpfloat(a * b), which rounds the exact product straight to binary16 — a different number once in ~8000 products
+    // (seen as single pixels; tests/test_gpu_reference_goldens.py::test_device_half_operators_are_ieee_binary16). The empty asm makes x a materialised fp32.
+    static inline float r(float x) {
+        if (!LP16) return x;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(x));
+#endif
+        return f16tof32(f32tof16(x));
+    }
+    static inline float add(float a, float b) { return r(a + b); }
+    static inline float sub(float a, float b) { return r(a - b); }
+    static inline float mul(float a, float b) { return r(a * b); }
+    // the quotient is formed in fp32 (correctly rounded) and rounded once to binary16; without the fence in r() the compiler folds
+    // fptrunc(fdiv(fpext a, fpext b)) into a half division, whose expansion (v_rcp_f16 for 1 / x) is within one ulp but not correctly rounded
+    static inline float div(float a, float b) { return r(a / b); }       // (r() keeps the fp32 quotient opaque, see there)
+    static inline float3 r3(float3 v) { return make_float3(r(v.x), r(v.y), r(v.z)); }
+    static inline float3 mul3(float3 a, float3 b) { return make_float3(mul(a.x, b.x), mul(a.y, b.y), mul(a.z, b.z)); }
+    static inline float3 mul3(float3 a, float b) { return make_float3(mul(a.x, b), mul(a.y, b), mul(a.z, b)); }
+    static inline float3 div3(float3 a, float b) { return make_float3(div(a.x, b), div(a.y, b), div(a.z, b)); }
+    static inline float lerp(float a, float b, float t) { return add(a, mul(sub(b, a), t)); }                       // HLSL lerp: x + s*(y-x), every operation in half
+    static inline float3 lerp3(float3 a, float3 b, float t) { return make_float3(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t)); }
+    static inline float average3(float3 v) { return div(add(add(v.x, v.y), v.z), 3.0f); }       // the lpfloat3 overload of Average (Utils.hlsli:62-67): (x + y + z) / 3.0 in half
+};
+
 
 // Packing.hlsli:17-51, 127-167
 static inline uint Pack_R8_UFLOAT(float r, float d = 0.5f) { return (uint)floorf(r * 255.0f + d) & 255u; }

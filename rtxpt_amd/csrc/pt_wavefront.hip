@@ -147,8 +147,9 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
 #ifndef PT_SHADE_MIN_BLOCKS
 #define PT_SHADE_MIN_BLOCKS 1
 #endif
-template <bool MULTI>
-__global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PathKernelContext k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
+// PKC: PathKernelContextT<false> (lp types in fp32) or PathKernelContextT<true> (the reference's default build, lp types in binary16)
+template <bool MULTI, class PKC>
+__global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
                                                uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc) {
     const uint count = *countInPtr;
     uint i = blockIdx.x * 256u + threadIdx.x;
@@ -163,8 +164,8 @@ __global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PathKernelCo
         if (h.prim == 0xFFFFFFFFu) k.HandleMiss(path, path.dir, kMaxRayTravel);
         else {
             isHit = true;
-            if (MULTI) { ShadowSink sink{sq.q0, sq.q1, sq.q2, &wc->shadowCount, &wc->shadowValid, p}; k.HandleHit<true>(path, h, req, &sink); }
-            else k.HandleHit<false>(path, h, req, nullptr);
+            if (MULTI) { ShadowSink sink{sq.q0, sq.q1, sq.q2, &wc->shadowCount, &wc->shadowValid, p}; k.template HandleHit<true>(path, h, req, &sink); }
+            else k.template HandleHit<false>(path, h, req, nullptr);
         }
         store_path(pool, p, path);
         alive = path.isActive();
@@ -415,8 +416,8 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
         case 15: o[0] = FastSqrt(a[0]); break;
         case 16: o[0] = FastACos(a[0]); break;
         case 17: o[0] = ComputeRayConeSpreadAngleExpansionByScatterPDF(a[0], a[1]); break;
-        case 18: o[0] = ComputeNewScatterFireflyFilterK(a[0], a[1], a[2]); break;
-        case 19: { float3 r = FireflyFilter(make_float3(a[0], a[1], a[2]), a[3], a[4]); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+        case 18: o[0] = ComputeNewScatterFireflyFilterK<LPOps<false>>(a[0], a[1], a[2]); break;
+        case 19: { float3 r = FireflyFilter<LPOps<false>>(make_float3(a[0], a[1], a[2]), a[3], a[4]); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
         case 20: o[0] = FireflyFilterShort(a[0], a[1], a[2]); break;
         case 21: o[0] = ComputeLowGrazingAngleFalloff(make_float3(a[0], a[1], a[2]), make_float3(a[3], a[4], a[5]), a[6], a[7]); break;
         default: break;
@@ -442,6 +443,24 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
             o[0] = asuint(t.CalcSolidAnglePdfForMIS(make_float3(asfloat(a[12]), asfloat(a[13]), asfloat(a[14])), make_float3(asfloat(a[15]), asfloat(a[16]), asfloat(a[17])))); }
         else { uint pk = NDirToOctUnorm32(make_float3(asfloat(a[0]), asfloat(a[1]), asfloat(a[2]))); float3 d = OctToNDirUnorm32(pk); o[0] = pk; o[1] = asuint(d.x); o[2] = asuint(d.y); o[3] = asuint(d.z); }
         } break;
+    case 8: { const float* a = in + 8 * i; uint* o = reinterpret_cast<uint*>(out) + 45 * i;      // loadSurface: (prim bits, u, v, dir.xyz, coneWidth, coneSpread) -> 45 words (layout of the oracle's surface probe)
+        RayCone rc = RayCone::make(a[6], a[7]);
+        auto emit = [&](const SurfaceData& q) {
+            const ShadingData& s = q.shadingData; const StandardBSDFData& b = q.bsdf.data;
+            auto put3 = [&](float3 v) { *o++ = asuint(v.x); *o++ = asuint(v.y); *o++ = asuint(v.z); };
+            put3(s.posW); put3(s.faceNCorrected); put3(s.V); put3(s.N); put3(s.T); put3(s.B); put3(s.vertexN);
+            *o++ = s.frontFacing ? 1u : 0u; *o++ = s.mtl.packedData; *o++ = s.materialID; *o++ = asuint(s.IoR); *o++ = asuint(s.shadowNoLFadeout); put3(s.emission);
+            put3(b.diffuse); *o++ = asuint(b.roughness); put3(b.specular); *o++ = asuint(b.metallic); put3(b.transmission);
+            *o++ = asuint(b.diffuseTransmission); *o++ = asuint(b.specularTransmission); *o++ = asuint(b.eta); *o++ = asuint(q.interiorIoR); *o++ = q.neeTriangleLightIndex; };
+        if (k.S.useFp16Types) { PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16)); emit(k16.loadSurface(asuint(a[0]), a[1], a[2], make_float3(a[3], a[4], a[5]), rc)); }
+        else emit(k.loadSurface(asuint(a[0]), a[1], a[2], make_float3(a[3], a[4], a[5]), rc));
+        } break;
+    case 7: { const float* a = in + 4 * i; const int op = (int)a[0]; typedef LPOps<true> H; float r = 0.f;      // the half-typed operators of the lp16 build: (op, a, b, c) -> result
+        switch (op) { case 0: r = H::r(a[1]); break; case 1: r = H::add(H::r(a[1]), H::r(a[2])); break; case 2: r = H::sub(H::r(a[1]), H::r(a[2])); break; case 3: r = H::mul(H::r(a[1]), H::r(a[2])); break;
+                      case 4: r = H::div(H::r(a[1]), H::r(a[2])); break; case 5: r = H::lerp(H::r(a[1]), H::r(a[2]), H::r(a[3])); break;
+                      case 7: r = H::r(a[1] * a[2]); break; case 8: r = H::r(H::r(a[1]) * a[2]); break; case 9: r = H::r(a[1] + a[2]); break; case 10: r = H::r(a[1] / a[2]); break;      // lpfloat(float expression)
+                      default: r = H::average3(make_float3(H::r(a[1]), H::r(a[2]), H::r(a[3]))); break; }
+        out[i] = r; } break;
     default: break;
     }
 }
@@ -496,8 +515,16 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
     hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
 }
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, hipStream_t st) {
-    if (sq.group) hipLaunchKernelGGL((k_shade<true>), dim3((countIn + 255) / 256), dim3(256), 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
-    else hipLaunchKernelGGL((k_shade<false>), dim3((countIn + 255) / 256), dim3(256), 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+    const dim3 g((countIn + 255) / 256), b(256);
+    if (k.S.useFp16Types) {          // the reference's default build of its lp types (binary16): same context data, the other instantiation of the shading code
+        static_assert(sizeof(PathKernelContextT<true>) == sizeof(PathKernelContext), "the two lp builds share one context layout");
+        PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16));
+        if (sq.group) hipLaunchKernelGGL((k_shade<true, PathKernelContextT<true>>), g, b, 0, st, k16, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+        else hipLaunchKernelGGL((k_shade<false, PathKernelContextT<true>>), g, b, 0, st, k16, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+    } else {
+        if (sq.group) hipLaunchKernelGGL((k_shade<true, PathKernelContext>), g, b, 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+        else hipLaunchKernelGGL((k_shade<false, PathKernelContext>), g, b, 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+    }
 }
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
     uint g = grid_for(count, T8_BLOCK * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);

@@ -43,7 +43,7 @@ SETTINGS_DTYPE = np.dtype([
     ("fireflyFilterThreshold", "<f4"), ("envMapDiffuseSampleMIPLevel", "<f4"),
     ("NEEEnabled", "<u4"), ("NEEType", "<u4"), ("NEECandidateSamples", "<u4"), ("NEEFullSamples", "<u4"),
     ("enableRussianRoulette", "<u4"), ("nestedDielectricsQuality", "<u4"), ("enableLDSamplerForBSDF", "<u4"), ("diffuseBrdf", "<u4"),
-    ("_pad", "<u4", 2),
+    ("useFp16Types", "<u4"), ("_pad", "<u4"),
 ])
 assert SETTINGS_DTYPE.itemsize == 64
 
@@ -73,6 +73,8 @@ def default_settings(**kw):
     s["nestedDielectricsQuality"] = 1
     s["enableLDSamplerForBSDF"] = 1
     s["diffuseBrdf"] = 2                      # Frostbite (BxDFConfig.hlsli:24)
+    s["useFp16Types"] = 0                     # lp types: 0 = fp32 build, 1 = binary16 — the reference's default (SampleUI.h:182), which pt_default_settings returns. The
+    #                                           helper keeps 0 so that the fp32 fixtures stay what they are; the lp16 cases ask for 1 explicitly (tests/pin_scenes.py)
     for k, v in kw.items():
         s[k] = v
     return s

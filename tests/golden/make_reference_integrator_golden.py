@@ -10,12 +10,13 @@ from rtxpt_amd import scenes
 from oracle import ptref
 import pin_scenes
 
-out = {}
-for name, (make, S, w, h, first, n) in pin_scenes.cases().items():
-    sc, cam = make()
-    o = ptref.Oracle(reference_integrator=True, settings=S)
-    o.set_scene(sc); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(S); o.resize(w, h); o.render(first, n)
-    out[name] = o.radiance(); c = o.counters()
-    out[name + "_rays"] = np.array([c["extendRays"], c["shadowRays"]], np.uint64)
-    print(name, out[name].shape, out[name + "_rays"])
-np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_integrator_golden.npz"), **out)
+for lp16, cases, fname in ((False, pin_scenes.cases(), "reference_integrator_golden.npz"), (True, pin_scenes.cases_lp16(), "reference_integrator_golden_lp16.npz")):
+    out = {}            # lp16: the reference text compiled with RTXPT_LP_TYPES_USE_16BIT_PRECISION=1 (its default build) over hlsl_shim.h's binary16 type
+    for name, (make, S, w, h, first, n) in cases.items():
+        sc, cam = make()
+        o = ptref.Oracle(reference_integrator=True, settings=S, lp16=lp16)
+        o.set_scene(sc); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(S); o.resize(w, h); o.render(first, n)
+        out[name] = o.radiance(); c = o.counters()
+        out[name + "_rays"] = np.array([c["extendRays"], c["shadowRays"]], np.uint64)
+        print("lp16" if lp16 else "fp32", name, out[name].shape, out[name + "_rays"])
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), fname), **out)

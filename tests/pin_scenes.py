@@ -119,3 +119,17 @@ def cases():
         "bistro_like_material_zoo": (with_material_zoo(lambda: scenes.bistro_like(scale=0.02, tex_size=128)), scenes.default_settings(), 96, 54, 2, 2),
         "bistro_like_c5": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), scenes.default_settings(), 96, 54, 0, 2),   # + nested-dielectric props
     }
+
+
+def cases_lp16():
+    """The same cases in the reference's DEFAULT build (useFp16Types = 1: lp types in binary16, SampleUI.h:182 / Sample.cpp:1035), plus two in which the
+    firefly filter — whose arithmetic is all-half in that build (PathTracerHelpers.hlsli:206-213, the lpfloat3 overload of Average) — meets textured
+    emitters, environment hits and many lamps."""
+    out = {}
+    for name, (make, S, w, h, first, n) in cases().items():
+        S = S.copy(); S["useFp16Types"] = 1
+        out[name] = (make, S, w, h, first, n)
+    bl = lambda: scenes.bistro_like(scale=0.02, tex_size=128)
+    out["bistro_like_firefly"] = (bl, scenes.default_settings(fireflyFilterThreshold=0.7, useFp16Types=1), 96, 54, 1, 2)
+    out["bistro_like_material_zoo_firefly"] = (with_material_zoo(bl), scenes.default_settings(fireflyFilterThreshold=1.5, envMapDiffuseSampleMIPLevel=2.0, useFp16Types=1), 96, 54, 4, 2)
+    return out

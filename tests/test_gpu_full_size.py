@@ -66,7 +66,7 @@ def test_c5_full_size_4k_animated_refit_rows_bit_exact():
     nestedDielectricsQuality 2; per frame 5 complete rows equal an oracle rebuilt from scratch for that frame."""
     pt, scenes, ptref = _imports()
     sc, cam = scenes.bistro_like(scale=1.0, tex_size=1024, animated=True)
-    S = scenes.default_settings(nestedDielectricsQuality=2)
+    S = scenes.default_settings(nestedDielectricsQuality=2, useFp16Types=1)      # the reference's default build of the lp types (C3 above runs the fp32 build)
     camd = scenes.bridge_camera(W, H, **cam)
     g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(W, H)
     for frame, t in enumerate((0.0, 0.6)):
@@ -75,7 +75,7 @@ def test_c5_full_size_4k_animated_refit_rows_bit_exact():
         g.reset_accumulation(); st = g.render(frame * SPP, SPP); a = g.radiance()
         assert np.isfinite(a).all() and (a >= 0).all()
         sc_t = dict(sc); sc_t["positions"] = pos
-        o = ptref.Oracle(); o.set_scene(sc_t); o.set_instances(inst); o.set_camera(camd); o.set_settings(S); o.resize(W, H)
+        o = ptref.Oracle(lp16=True); o.set_scene(sc_t); o.set_instances(inst); o.set_camera(camd); o.set_settings(S); o.resize(W, H)
         rects = [(0, y, W, y + 1) for y in range(11 + 37 * frame, H, 512)]
         for r, wnt in zip(rects, _oracle_rects(o, rects, frame * SPP, SPP)):
             got = a[r[1]:r[3], r[0]:r[2], :3]

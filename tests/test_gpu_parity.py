@@ -331,3 +331,57 @@ def test_product_matches_reference_integrator_golden(name):
     bad = (got.view(np.uint32) != want.view(np.uint32)).any(-1)
     assert not bad.any(), "%s: %d of %d pixels differ from the reference-text frame" % (name, int(bad.sum()), bad.size)
     assert (st["extendRays"], st["shadowRays"]) == tuple(int(v) for v in g[name + "_rays"])
+
+
+def _pin_cases_lp16():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pin_scenes
+    return pin_scenes.cases_lp16()
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "bistro_like_firefly", "bistro_like_material_zoo_firefly"])
+def test_product_lp16_matches_reference_integrator_golden(name):
+    """PtSettings.useFp16Types = 1 — the reference's DEFAULT build (lp types in binary16; SampleUI.h:182, Sample.cpp:1035) and what pt_default_settings returns —
+    against frames rendered by the reference's integrator text compiled that way (tests/golden/reference_integrator_golden_lp16.npz). No oracle call here."""
+    pt, scenes, parallel, ptref = _imports()
+    make, S, w, h, first, n = _pin_cases_lp16()[name]
+    assert int(S["useFp16Types"]) == 1
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_integrator_golden_lp16.npz"))
+    sc, cam = make()
+    t = pt.PathTracer(); t.set_scene(sc); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.set_settings(S); t.resize(w, h); st = t.render(first, n)
+    got, want = t.radiance(), g[name]
+    bad = (got.view(np.uint32) != want.view(np.uint32)).any(-1)
+    assert not bad.any(), "%s (lp16): %d of %d pixels differ from the reference-text frame" % (name, int(bad.sum()), bad.size)
+    assert (st["extendRays"], st["shadowRays"]) == tuple(int(v) for v in g[name + "_rays"])
+
+
+def test_c_default_settings_are_the_reference_default_build():
+    pt, scenes, parallel, ptref = _imports()
+    t = pt.PathTracer()
+    assert int(t.default_settings()["useFp16Types"]) == 1
+
+
+@pytest.mark.parametrize("lp16", [False, True], ids=["fp32", "lp16"])
+@pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5"])
+def test_device_load_surface_matches_oracle(name, lp16):
+    """Bridge::loadSurface on the device (geometry gather, material evaluation with its lp types, textures, normal map, tangent frame, BSDF inputs, emissive light
+    index) against the oracle's — which is pinned to PathTracerBridgeDonut.hlsli compiled from the reference in both builds of the lp types
+    (tests/test_oracle_refpin_integrator.py::test_load_surface_matches_reference_text) — on 20 000 random hits per scene, 45 words each."""
+    pt, scenes, parallel, ptref = _imports()
+    make, S, w, h, first, n = (_pin_cases_lp16() if lp16 else _pin_cases())[name]
+    sc, cam = make()
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(S); g.set_camera(scenes.bridge_camera(w, h, **cam)); g.resize(w, h)
+    o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_settings(S); o.resize(8, 8)
+    nt = o.num_tris()
+    rng = np.random.default_rng(0x5F + len(name)); k = 20000
+    prims = rng.integers(0, nt, k).astype(np.uint32); u = rng.uniform(0, 1, k); v = rng.uniform(0, 1, k) * (1 - u)
+    d = rng.normal(size=(k, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rows7 = np.column_stack([u, v, d, rng.uniform(0, 0.5, k), rng.uniform(0, 0.01, k)]).astype(np.float32)
+    want = o.surface_probe(prims, rows7)
+    rows8 = np.zeros((k, 8), np.float32); rows8[:, 0] = prims.view(np.float32); rows8[:, 1:] = rows7
+    got = g.probe(8, rows8, (k, 45), out_dtype=np.uint32)
+    bad = (got != want)
+    assert not bad.any(), "%d of %d surfaces differ; per word %s; first: hit %d device %s oracle %s" % (
+        int(bad.any(1).sum()), k, {i: int(bad[:, i].sum()) for i in range(45) if bad[:, i].any()}, int(np.flatnonzero(bad.any(1))[0]),
+        got[bad.any(1)][0][bad[bad.any(1)][0]].view(np.float32), want[bad.any(1)][0][bad[bad.any(1)][0]].view(np.float32))

@@ -67,3 +67,36 @@ def test_device_polymorphic_lights_match_reference_text(tracer, kind):
     wf, gf = want.view(np.float32), got.view(np.float32)
     ok = (got == want) | (np.isnan(wf) & np.isnan(gf))
     assert ok.all(), "light probe %d: %d of %d rows differ from the reference text; first: in=%s device=%s reference=%s" % (kind, int((~ok).any(1).sum()), len(a), a[(~ok).any(1)][0], got[(~ok).any(1)][0], want[(~ok).any(1)][0])
+
+
+def test_device_half_operators_are_ieee_binary16(tracer):
+    """LPOps<true> on the device (the half-typed operators of the reference's default build: a float rounded to binary16 after every operation, conversions by
+    v_cvt_f16_f32) against numpy's float16 arithmetic on 60 000 operand sets per operator, including the binary16 denormal range, values around the overflow
+    boundary and exact ties. numpy evaluates a half operation in float and rounds once, which is the correctly rounded half result (24 >= 2 * 11 + 2)."""
+    rng = np.random.default_rng(0x16F10A7)
+    n = 60000
+    def operands():
+        mag = np.where(rng.random(n) < 0.35, 10.0 ** rng.uniform(-9, -3, n), 10.0 ** rng.uniform(-3, 5, n))
+        return (mag * np.where(rng.random(n) < 0.3, -1.0, 1.0)).astype(np.float32)
+    h = lambda x: x.astype(np.float16)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        # lpfloat(<float expression>): the fp32 result is rounded to fp32 first and then to binary16 — two roundings, exactly what HLSL's float -> float16_t cast
+        # of a float expression does. (A mixed-precision multiply-add that rounds the exact product straight to binary16 differs once in ~8000 products.)
+        for op, name in ((7, "lpfloat(a*b)"), (8, "lpfloat(half*b)"), (9, "lpfloat(a+b)"), (10, "lpfloat(a/b)")):
+            a, b = operands(), operands()
+            fa = h(a).astype(np.float32) if op == 8 else a
+            want = [fa * b, fa * b, a + b, a / b][op - 7].astype(np.float16).astype(np.float32)
+            rows = np.stack([np.full(n, op, np.float32), a, b, b], 1)
+            got = tracer.probe(7, rows, (n,))
+            ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            assert ok.all(), "%s: %d of %d differ; first: a=%r b=%r device=%r numpy=%r" % (name, int((~ok).sum()), n, a[~ok][0], b[~ok][0], got[~ok][0], want[~ok][0])
+        for op, name in enumerate(("round", "add", "sub", "mul", "div", "lerp", "average3")):
+            a, b, c = operands(), operands(), operands()
+            if op == 5: c = rng.random(n).astype(np.float32)
+            if op == 4: a[: n // 3] = 1.0                 # 1 / x: the pattern a compiler likes to turn into a reciprocal instruction (one ulp, not correctly rounded)
+            ha, hb, hc = h(a), h(b), h(c)
+            want = [ha, ha + hb, ha - hb, ha * hb, ha / hb, ha + (hb - ha) * hc, ((ha + hb) + hc) / np.float16(3.0)][op].astype(np.float32)
+            rows = np.stack([np.full(n, op, np.float32), a, b, c], 1)
+            got = tracer.probe(7, rows, (n,))
+            ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            assert ok.all(), "%s: %d of %d differ; first: a=%r b=%r c=%r device=%r numpy=%r" % (name, int((~ok).sum()), n, a[~ok][0], b[~ok][0], c[~ok][0], got[~ok][0], want[~ok][0])

@@ -66,7 +66,7 @@ def test_bridge_camera_matches_reference_golden(lib, golden):
 def test_default_settings(lib):
     s = np.zeros((), dtype=scenes.SETTINGS_DTYPE)
     assert lib.pt_default_settings(s.ctypes.data_as(ctypes.c_void_p)) == 0
-    d = scenes.default_settings()
+    d = scenes.default_settings(useFp16Types=1)          # the C entry point returns the reference's default build of the lp types (SampleUI.h:182)
     for n in scenes.SETTINGS_DTYPE.names:
         assert np.array_equal(s[n], d[n]), n
     assert lib.pt_default_settings(None) == 1
