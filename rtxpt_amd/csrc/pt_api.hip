@@ -5,6 +5,7 @@
 #include "../../include/mi355pt.h"
 #include "pt_wavefront.h"
 #include "pt_build.h"
+#include <rocprim/rocprim.hpp>
 #include <rccl/rccl.h>      // types only: the functions are bound at run time (dlopen), see pt_comm_init
 #include <dlfcn.h>
 #include <algorithm>
@@ -74,7 +75,8 @@ struct pt_context {
     float3x4 envToWorld, envToLocal; ptk::float3 envColorMul;
     std::vector<PolymorphicLightInfoFull> analyticLights;
     std::vector<SubInstanceData> subInstances; std::vector<ptk::uint2> subInstToInstGeom; std::vector<ptk::uint2> primInfo;
-    std::vector<ptk::PolymorphicLightInfo> lights; std::vector<ptk::PolymorphicLightInfoEx> lightsEx; std::vector<uint> proxyCounters, proxyIndices, envLookup; uint envLookupDim = 0;
+    std::vector<ptk::PolymorphicLightInfo> lights; std::vector<ptk::PolymorphicLightInfoEx> lightsEx; std::vector<uint> envLookup; uint envLookupDim = 0; uint numProxies = 0, envLightsBaked = 0;      // (light weights / proxy table live on the device only)
+    DevBuf<float> dLightW; DevBuf<uint> dProxyOffsets; void* dScanTemp = nullptr; size_t scanTempBytes = 0;
     // device
     DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
@@ -204,7 +206,7 @@ void refresh_scene_view(pt_context* c) {
     d.materials = c->dMaterials.p; d.materialCount = (uint)c->materials.size(); d.textures = c->dTexInfos.p; d.texels = c->dTexels.p;
     d.envTex = c->envTexInfo; d.envEnabled = c->envEnabled ? 1u : 0u; d.envToWorld = c->envToWorld; d.envToLocal = c->envToLocal; d.envColorMultiplier = c->envColorMul;
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
-    d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = (uint)c->proxyIndices.size();
+    d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
     d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
     d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
 }
@@ -342,13 +344,18 @@ int bake_env_quads(pt_context* c) {
     }
     return PT_OK;
 }
-int bake_lights(pt_context* c) {
+// geometryOnly: the instances / vertices moved but materials, environment, analytic lights and settings did not (pt_animate): the environment quad-tree
+// lights are kept, only the emissive triangles are re-baked, and everything downstream (weights, proxy counts, proxy table) runs on the device.
+int bake_lights(pt_context* c, bool geometryOnly = false) {
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
-    c->lights.clear(); c->lightsEx.clear(); c->proxyCounters.clear(); c->proxyIndices.clear(); c->envLookup.clear(); c->envLookupDim = 0;
+    const bool keepEnv = geometryOnly && c->S.NEEEnabled && c->envEnabled && c->envLightsBaked == QT_TOTAL && c->lights.size() >= QT_TOTAL;
+    if (!keepEnv) { c->lights.clear(); c->lightsEx.clear(); c->envLookup.clear(); c->envLookupDim = 0; c->envLightsBaked = 0; }
+    else { c->lights.resize(QT_TOTAL); c->lightsEx.resize(QT_TOTAL); }
+    c->numProxies = 0;
     for (auto& si : c->subInstances) si.EmissiveLightMappingOffset = 0xFFFFFFFFu;
     if (c->S.NEEEnabled) {
-        if (c->envEnabled) { c->lights.resize(QT_TOTAL); c->lightsEx.resize(QT_TOTAL); int r = bake_env_quads(c); if (r != PT_OK) return r; }
+        if (c->envEnabled && !keepEnv) { c->lights.resize(QT_TOTAL); c->lightsEx.resize(QT_TOTAL); int r = bake_env_quads(c); if (r != PT_OK) return r; c->envLightsBaked = QT_TOTAL; }
         for (auto& a : c->analyticLights) { c->lights.push_back(a.Base); c->lightsEx.push_back(a.Extended); }
         // emissive triangles: host decides the layout (LightsBaker.cpp:663-827), the GPU bakes the records (LightsBaker.hlsl:544-716)
         std::vector<uint> list, offsets; uint total = 0; uint lightBase = (uint)c->lights.size();
@@ -361,37 +368,42 @@ int bake_lights(pt_context* c) {
             c->subInstances[s].EmissiveLightMappingOffset = lightBase + total;
             list.push_back((uint)s); offsets.push_back(total); total += ntri;
         }
-        c->lights.resize((size_t)lightBase + total); c->lightsEx.resize((size_t)lightBase + total);
-        PT_CHECK_HIP(c, c->dLights.resize(c->lights.size())); PT_CHECK_HIP(c, c->dLightsEx.resize(c->lightsEx.size()));
+        c->lights.resize((size_t)lightBase + total); c->lightsEx.resize((size_t)lightBase + total);      // (the emissive part of the host mirror only holds the size)
+        const uint N = (uint)c->lights.size();
+        PT_CHECK_HIP(c, c->dLights.resize(N)); PT_CHECK_HIP(c, c->dLightsEx.resize(N));
+        if (lightBase && !keepEnv) {                       // environment quads + analytic lights: computed on the host, static under animation
+            PT_CHECK_HIP(c, hipMemcpyAsync(c->dLights.p, c->lights.data(), sizeof(ptk::PolymorphicLightInfo) * lightBase, hipMemcpyHostToDevice, c->stream));
+            PT_CHECK_HIP(c, hipMemcpyAsync(c->dLightsEx.p, c->lightsEx.data(), sizeof(ptk::PolymorphicLightInfoEx) * lightBase, hipMemcpyHostToDevice, c->stream));
+        } else if (keepEnv && lightBase > QT_TOTAL) {
+            PT_CHECK_HIP(c, hipMemcpyAsync(c->dLights.p + QT_TOTAL, c->lights.data() + QT_TOTAL, sizeof(ptk::PolymorphicLightInfo) * (lightBase - QT_TOTAL), hipMemcpyHostToDevice, c->stream));
+            PT_CHECK_HIP(c, hipMemcpyAsync(c->dLightsEx.p + QT_TOTAL, c->lightsEx.data() + QT_TOTAL, sizeof(ptk::PolymorphicLightInfoEx) * (lightBase - QT_TOTAL), hipMemcpyHostToDevice, c->stream));
+        }
         if (total) {
-            PT_CHECK_HIP(c, c->dEmissiveList.upload(list, c->stream)); PT_CHECK_HIP(c, c->dEmissiveOffsets.upload(offsets, c->stream));
+            if (!geometryOnly || c->dEmissiveList.n < list.size()) { PT_CHECK_HIP(c, c->dEmissiveList.upload(list, c->stream)); PT_CHECK_HIP(c, c->dEmissiveOffsets.upload(offsets, c->stream)); }
             launch_bake_emissive(c->dsc, c->dEmissiveList.p, c->dEmissiveOffsets.p, (uint)list.size(), total, lightBase, c->dLights.p, c->dLightsEx.p, c->stream);
-            PT_CHECK_HIP(c, hipMemcpyAsync(c->lights.data() + lightBase, c->dLights.p + lightBase, sizeof(ptk::PolymorphicLightInfo) * total, hipMemcpyDeviceToHost, c->stream));
-            PT_CHECK_HIP(c, hipMemcpyAsync(c->lightsEx.data() + lightBase, c->dLightsEx.p + lightBase, sizeof(ptk::PolymorphicLightInfoEx) * total, hipMemcpyDeviceToHost, c->stream));
+        }
+        // ComputeWeights + ComputeProxyCounts + proxy fill (LightsBaker.hlsl:738-751, 836-948) on the device; NEEType 0 = uniform (1 proxy per light)
+        if (N) {
+            const uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
+            const size_t proxyCapacity = (size_t)budget + N;                       // sum of ceil((budget - N) w_i / W) <= budget - N + N
+            PT_CHECK_HIP(c, c->dLightW.resize(N + 1)); PT_CHECK_HIP(c, c->dProxyCounters.resize(N)); PT_CHECK_HIP(c, c->dProxyOffsets.resize(N)); PT_CHECK_HIP(c, c->dProxyIndices.resize(proxyCapacity));
+            launch_light_weights(c->dLights.p, c->dLightsEx.p, N, c->dLightW.p, c->dLightW.p + N, budget, c->S.NEEType == 0, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1, c->dProxyCounters.p, c->stream);
+            size_t need = 0;
+            PT_CHECK_HIP(c, rocprim::exclusive_scan(nullptr, need, c->dProxyCounters.p, c->dProxyOffsets.p, 0u, (size_t)N, rocprim::plus<uint>(), c->stream));
+            if (need > c->scanTempBytes) { if (c->dScanTemp) (void)hipFree(c->dScanTemp); c->dScanTemp = nullptr; PT_CHECK_HIP(c, hipMalloc(&c->dScanTemp, need)); c->scanTempBytes = need; }
+            need = c->scanTempBytes;
+            PT_CHECK_HIP(c, rocprim::exclusive_scan(c->dScanTemp, need, c->dProxyCounters.p, c->dProxyOffsets.p, 0u, (size_t)N, rocprim::plus<uint>(), c->stream));
+            launch_light_proxy_fill(c->dProxyCounters.p, c->dProxyOffsets.p, N, c->dProxyIndices.p, (uint)proxyCapacity, c->stream);
+            uint last[2] = {0u, 0u};                           // the proxy count is a field of the by-value scene view: one 8-byte read-back
+            PT_CHECK_HIP(c, hipMemcpyAsync(&last[0], c->dProxyOffsets.p + (N - 1), 4, hipMemcpyDeviceToHost, c->stream));
+            PT_CHECK_HIP(c, hipMemcpyAsync(&last[1], c->dProxyCounters.p + (N - 1), 4, hipMemcpyDeviceToHost, c->stream));
             PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+            c->numProxies = last[0] + last[1];
+            if (c->numProxies > proxyCapacity) return fail(c, PT_ERROR_HIP, "light proxy table overflow");
         }
-        // ComputeWeights + ComputeProxyCounts (LightsBaker.hlsl:738-751, 836-948); NEEType 0 = uniform (1 proxy per light)
-        uint N = (uint)c->lights.size();
-        std::vector<float> w(N); float weightSum = 0.f;
-        for (uint i = 0; i < N; i++) {
-            PolymorphicLightInfoFull lf; lf.Base = c->lights[i]; lf.Extended = c->lightsEx[i];
-            float wt = dm_pow(PolymorphicLight_GetPower(lf), 0.8f);
-            if (!(wt >= RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD)) wt = 0;
-            w[i] = wt; weightSum += wt;
-        }
-        uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
-        c->proxyCounters.assign(N, 0);
-        for (uint i = 0; i < N; i++) {
-            uint cnt = 0;
-            if (w[i] > 0) cnt = (c->S.NEEType == 0) ? 1u : (uint)ceilf(((float)(budget - N) * w[i]) / weightSum);
-            cnt = std::min(cnt, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1);
-            c->proxyCounters[i] = cnt;
-            for (uint k = 0; k < cnt; k++) c->proxyIndices.push_back(i);
-        }
-    }
-    PT_CHECK_HIP(c, c->dLights.upload(c->lights, c->stream)); PT_CHECK_HIP(c, c->dLightsEx.upload(c->lightsEx, c->stream));
-    PT_CHECK_HIP(c, c->dProxyCounters.upload(c->proxyCounters, c->stream)); PT_CHECK_HIP(c, c->dProxyIndices.upload(c->proxyIndices, c->stream));
-    PT_CHECK_HIP(c, c->dEnvLookup.upload(c->envLookup, c->stream)); PT_CHECK_HIP(c, c->dSubInstances.upload(c->subInstances, c->stream));
+    } else { PT_CHECK_HIP(c, c->dLights.resize(1)); PT_CHECK_HIP(c, c->dLightsEx.resize(1)); }
+    if (!keepEnv) PT_CHECK_HIP(c, c->dEnvLookup.upload(c->envLookup, c->stream));
+    PT_CHECK_HIP(c, c->dSubInstances.upload(c->subInstances, c->stream));
     PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); c->lightBakeMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -451,7 +463,7 @@ int32_t pt_destroy(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
-    c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free();
+    c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free(); c->dLightW.free(); c->dProxyOffsets.free(); if (c->dScanTemp) (void)hipFree(c->dScanTemp);
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
@@ -651,7 +663,7 @@ int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, co
     c->lightsDirty = true;                    // emissive triangle lights move with the geometry (Sample.cpp:1170-1198)
     c->accumCount = 0;                        // any scene change resets accumulation in reference mode
     PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)c->width * c->height, c->stream));
-    return bake_lights(c);
+    return bake_lights(c, !c->lightsDirty);     // geometry moved, nothing else: environment lights kept, emissive re-bake + weights + proxy table on the device
 }
 
 int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* stats) {
@@ -883,12 +895,12 @@ int32_t pt_get_lights(pt_context* c, uint32_t* nLights, uint32_t* nProxies, void
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
     int r = prepare(c); if (r != PT_OK) return r;
-    if (nLights) *nLights = (uint32_t)c->lights.size(); if (nProxies) *nProxies = (uint32_t)c->proxyIndices.size(); if (envDim) *envDim = c->envLookupDim;
+    if (nLights) *nLights = (uint32_t)c->lights.size(); if (nProxies) *nProxies = c->numProxies; if (envDim) *envDim = c->envLookupDim;
     // read back from the DEVICE copies: this is what the kernels sample from
     if (lights && c->lights.size()) PT_CHECK_HIP(c, hipMemcpy(lights, c->dLights.p, 32 * c->lights.size(), hipMemcpyDeviceToHost));
     if (lightsEx && c->lights.size()) PT_CHECK_HIP(c, hipMemcpy(lightsEx, c->dLightsEx.p, 16 * c->lights.size(), hipMemcpyDeviceToHost));
     if (pc && c->lights.size()) PT_CHECK_HIP(c, hipMemcpy(pc, c->dProxyCounters.p, 4 * c->lights.size(), hipMemcpyDeviceToHost));
-    if (pi && c->proxyIndices.size()) PT_CHECK_HIP(c, hipMemcpy(pi, c->dProxyIndices.p, 4 * c->proxyIndices.size(), hipMemcpyDeviceToHost));
+    if (pi && c->numProxies) PT_CHECK_HIP(c, hipMemcpy(pi, c->dProxyIndices.p, 4 * (size_t)c->numProxies, hipMemcpyDeviceToHost));
     if (envLookup && c->envLookup.size()) PT_CHECK_HIP(c, hipMemcpy(envLookup, c->dEnvLookup.p, 4 * c->envLookup.size(), hipMemcpyDeviceToHost));
     return PT_OK;
 }

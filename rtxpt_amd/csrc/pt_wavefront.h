@@ -41,6 +41,9 @@ void launch_unpack(float4* accum, const uint* pixels, uint num, uint width, cons
 void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, float4* out, hipStream_t st);
 void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const uint* subInstTriOffset, uint numEmissiveSubInst, uint totalTris, uint lightBase,
                           PolymorphicLightInfo* lights, PolymorphicLightInfoEx* lightsEx, hipStream_t st);
+// light weights (power^0.8), their in-order sum, proxy counts; then (after an exclusive scan of the counts by the caller) the proxy index fill
+void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, float* sum, uint budget, bool uniform, uint maxPerLight, uint* counts, hipStream_t st);
+void launch_light_proxy_fill(const uint* counts, const uint* offsets, uint n, uint* proxies, uint capacity, hipStream_t st);
 void launch_tonemap(const float4* accum, uint num, const ToneMapParams& p, uint* outRgba8, hipStream_t st);
 // scratch: 2 * pow2floor(W) * pow2floor(H) floats; *result points at the 1x1 mip inside scratch once the stream has drained
 void launch_average_log_luminance(const float4* accum, uint W, uint H, float* scratch, float** result, hipStream_t st);

@@ -557,6 +557,45 @@ void launch_unpack(float4* accum, const uint* pixels, uint num, uint width, cons
 void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, float4* out, hipStream_t st) {
     hipLaunchKernelGGL(k_env_importance, dim3((dim * dim + 255) / 256), dim3(256), 0, st, sc, dim, sx, sy, out);
 }
+// ---- light weights and the sampling-proxy table on the device (ComputeWeights / ComputeProxyCounts / the proxy fill of LightsBaker.hlsl:738-751, 836-948), so that
+// a per-frame re-bake of animated emissives (C5) needs no D2H / host loop / H2D. Arithmetic = the host loop it replaces (and the oracle's): weight = power^0.8 with
+// the deterministic pow, thresholded; the weight SUM is taken in light order by ONE lane, because a float sum is only reproducible in a fixed order (7 k lights:
+// ~10 us; the table limit of 512 k lights: ~1 ms); counts = ceil((budget - N) * w / sum), capped; offsets by an exclusive scan (integers); the fill is per proxy.
+__global__ void __launch_bounds__(256) k_light_weights(const PolymorphicLightInfo* __restrict__ lights, const PolymorphicLightInfoEx* __restrict__ lightsEx, uint n, float* __restrict__ w) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= n) return;
+    PolymorphicLightInfoFull lf; lf.Base = lights[i]; lf.Extended = lightsEx[i];
+    float wt = dm_pow(PolymorphicLight_GetPower(lf), 0.8f);
+    if (!(wt >= 1e-8f)) wt = 0.f;                         // RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD
+    w[i] = wt;
+}
+__global__ void k_light_weight_sum(const float* __restrict__ w, uint n, float* __restrict__ sum) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { float s = 0.f; for (uint i = 0; i < n; i++) s += w[i]; *sum = s; }
+}
+__global__ void __launch_bounds__(256) k_light_proxy_counts(const float* __restrict__ w, uint n, const float* __restrict__ sum, uint budget, uint uniform, uint maxPerLight, uint* __restrict__ counts) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= n) return;
+    uint cnt = 0;
+    if (w[i] > 0) cnt = uniform ? 1u : (uint)ceilf(((float)(budget - n) * w[i]) / *sum);
+    counts[i] = cnt < maxPerLight ? cnt : maxPerLight;
+}
+// one thread per proxy slot: the light whose [offset, offset + count) range holds the slot (binary search over the scanned offsets)
+__global__ void __launch_bounds__(256) k_light_proxy_fill(const uint* __restrict__ counts, const uint* __restrict__ offsets, uint n, uint* __restrict__ proxies, uint capacity) {
+    const uint p = blockIdx.x * 256u + threadIdx.x;
+    const uint total = offsets[n - 1u] + counts[n - 1u];
+    if (p >= total || p >= capacity) return;
+    uint lo = 0u, hi = n;                                  // last light with offset <= p (lights without proxies share their successor's offset: skipped by taking the last)
+    while (hi - lo > 1u) { uint mid = (lo + hi) >> 1; if (offsets[mid] <= p) lo = mid; else hi = mid; }
+    proxies[p] = lo;
+}
+void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, float* sum, uint budget, bool uniform, uint maxPerLight, uint* counts, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_light_weights, dim3((n + 255) / 256), dim3(256), 0, st, lights, lightsEx, n, w);
+    hipLaunchKernelGGL(k_light_weight_sum, dim3(1), dim3(64), 0, st, w, n, sum);
+    hipLaunchKernelGGL(k_light_proxy_counts, dim3((n + 255) / 256), dim3(256), 0, st, w, n, sum, budget, uniform ? 1u : 0u, maxPerLight, counts);
+}
+void launch_light_proxy_fill(const uint* counts, const uint* offsets, uint n, uint* proxies, uint capacity, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_light_proxy_fill, dim3((capacity + 255) / 256), dim3(256), 0, st, counts, offsets, n, proxies, capacity);
+}
 void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const uint* subInstTriOffset, uint numEmissiveSubInst, uint totalTris, uint lightBase,
                           PolymorphicLightInfo* lights, PolymorphicLightInfoEx* lightsEx, hipStream_t st) {
     if (!totalTris) return;
