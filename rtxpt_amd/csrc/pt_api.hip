@@ -660,10 +660,11 @@ int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, co
     PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); if (rebuild) c->buildMs = ms; else c->refitMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const bool lightsWereDirty = c->lightsDirty;      // something besides the geometry changed since the last bake (environment, analytic lights, NEE settings)
     c->lightsDirty = true;                    // emissive triangle lights move with the geometry (Sample.cpp:1170-1198)
     c->accumCount = 0;                        // any scene change resets accumulation in reference mode
     PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)c->width * c->height, c->stream));
-    return bake_lights(c, !c->lightsDirty);     // geometry moved, nothing else: environment lights kept, emissive re-bake + weights + proxy table on the device
+    return bake_lights(c, !lightsWereDirty);     // geometry moved, nothing else: environment lights kept, emissive re-bake + weights + proxy table on the device
 }
 
 int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* stats) {

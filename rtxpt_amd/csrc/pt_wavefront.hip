@@ -568,8 +568,18 @@ __global__ void __launch_bounds__(256) k_light_weights(const PolymorphicLightInf
     if (!(wt >= 1e-8f)) wt = 0.f;                         // RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD
     w[i] = wt;
 }
-__global__ void k_light_weight_sum(const float* __restrict__ w, uint n, float* __restrict__ sum) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { float s = 0.f; for (uint i = 0; i < n; i++) s += w[i]; *sum = s; }
+// the sum in light order: the block stages 256 weights at a time in LDS (coalesced loads), lane 0 adds them one after the other
+__global__ void __launch_bounds__(256) k_light_weight_sum(const float* __restrict__ w, uint n, float* __restrict__ sum) {
+    __shared__ float stage[256];
+    float s = 0.f;
+    for (uint base = 0; base < n; base += 256u) {
+        const uint i = base + threadIdx.x;
+        stage[threadIdx.x] = (i < n) ? w[i] : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint m = (n - base < 256u) ? n - base : 256u; for (uint k = 0; k < m; k++) s += stage[k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *sum = s;
 }
 __global__ void __launch_bounds__(256) k_light_proxy_counts(const float* __restrict__ w, uint n, const float* __restrict__ sum, uint budget, uint uniform, uint maxPerLight, uint* __restrict__ counts) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= n) return;
@@ -589,7 +599,7 @@ __global__ void __launch_bounds__(256) k_light_proxy_fill(const uint* __restrict
 void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, float* sum, uint budget, bool uniform, uint maxPerLight, uint* counts, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_light_weights, dim3((n + 255) / 256), dim3(256), 0, st, lights, lightsEx, n, w);
-    hipLaunchKernelGGL(k_light_weight_sum, dim3(1), dim3(64), 0, st, w, n, sum);
+    hipLaunchKernelGGL(k_light_weight_sum, dim3(1), dim3(256), 0, st, w, n, sum);
     hipLaunchKernelGGL(k_light_proxy_counts, dim3((n + 255) / 256), dim3(256), 0, st, w, n, sum, budget, uniform ? 1u : 0u, maxPerLight, counts);
 }
 void launch_light_proxy_fill(const uint* counts, const uint* offsets, uint n, uint* proxies, uint capacity, hipStream_t st) {
