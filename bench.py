@@ -66,6 +66,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     sc, cam = scenes.bistro_like(scale=args.scale, tex_size=args.tex)
+    sc["env_cube_dim"] = 2048                    # EnvMapBaker's cube resolution for an image source (EnvMapBaker.cpp:374-375)
     S = scenes.default_settings(useFp16Types=0 if args.fp32_lp_types else 1)      # 8 bounces, NEE (emissive triangles + env quads), Russian roulette; lp types as the reference ships them
     W, H, SPP = args.width, args.height, args.spp
     camd = scenes.bridge_camera(W, H, **cam)

@@ -91,6 +91,10 @@ typedef struct PtTextureDesc { uint32_t width, height, format; const void* pixel
 /* EnvMapSceneParams (Rtxpt/Shaders/PathTracer/Lighting/EnvMap.hlsli:22-30): local->world rotation and colour multiplier. */
 typedef struct PtEnvMapSceneParams { float Transform[12]; float ColorMultiplier[3]; float Enabled; } PtEnvMapSceneParams;
 
+/* EMB_DirectionalLight (Rtxpt/Lighting/Distant/EnvMapBaker.hlsl:20-26): ColorIntensity.rgb = colour, .a = irradiance-like intensity; Direction = the direction
+ * the light travels (the disc is drawn at -Direction); AngularSize in radians. */
+typedef struct PtEnvDirectionalLight { float ColorIntensity[4]; float Direction[3]; float AngularSize; } PtEnvDirectionalLight;
+
 /* Subset of PathTracerConstants (PathTracerShared.h:45-103) plus the shader macros Sample::FillPTPipelineGlobalMacros pushes
  * (Rtxpt/Sample.cpp:988-1042) that affect the reference-mode estimator. Defaults: pt_default_settings(). */
 typedef struct PtSettings {
@@ -161,6 +165,12 @@ int32_t pt_set_instances(pt_context* ctx, const PtInstanceDesc* instances, uint3
 int32_t pt_set_materials(pt_context* ctx, const PTMaterialData* materials, uint32_t numMaterials, const PtTextureDesc* textures, uint32_t numTextures);
 /* EnvMapBaker source + EnvMapSceneParams (Rtxpt/Sample.cpp:1364-1388,1939): lat-long float RGB image, row 0 at +Y. width==0 disables. */
 int32_t pt_set_environment(pt_context* ctx, const float* rgbLatLong, uint32_t width, uint32_t height, const PtEnvMapSceneParams* params);
+/* EnvMapBaker::Update (Rtxpt/Lighting/Distant/EnvMapBaker.cpp:298-343, 425-620; EnvMapBaker.hlsl:194-246, 268-371): the path tracer and the light baker do
+ * not sample the lat-long source but the RGBA16F cube the baker makes of it: cubeDim^2 x 6 texels (2048 for an image source, 0 = keep), solid-angle weighted
+ * mips down to 8x8, radiance x 1/4 (c_envMapRadianceScale, Sample.cpp:88 - the host compensates in ColorMultiplier: Sample.cpp:1939-1940) clamped to the
+ * fp16 range, and the scene's directional lights drawn into it as anti-aliased discs (Sample::UpdateLighting, Sample.cpp:1361-1388). At most 16 lights
+ * (EMB_MAXDIRLIGHTS). The bake runs on the device at the next pt_render / pt_prepare. */
+int32_t pt_set_environment_bake(pt_context* ctx, uint32_t cubeDim, const PtEnvDirectionalLight* directionalLights, uint32_t numDirectionalLights);
 /* analytic lights already converted by the host (LightsBaker.cpp:456-556 ConvertLight); emissive triangles are baked automatically */
 int32_t pt_set_lights(pt_context* ctx, const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint32_t numLights);
 
@@ -351,6 +361,9 @@ int32_t pt_trace_visibility(pt_context* ctx, const float* rays, uint32_t n, uint
 /* light table / sub-instance read-back; pass NULL pointers to query sizes */
 int32_t pt_get_lights(pt_context* ctx, uint32_t* numLights, uint32_t* numProxies, void* lights32B, void* lightsEx16B, uint32_t* proxyCounters,
                       uint32_t* proxyIndices, uint32_t* envLookup, uint32_t* envLookupDim);
+/* the baked environment cube as the kernels sample it (EnvMapBaker's m_cubemap, EnvMapBaker.cpp:298-343): 8 bytes per RGBA16F texel, mips one after the
+ * other (dim, dim/2 .. 8), face-major (+X -X +Y -Y +Z -Z) within a mip. texels8B may be NULL to query the sizes. */
+int32_t pt_get_env_cube(pt_context* ctx, uint32_t* texelCount, uint32_t* dim, uint32_t* mipLevels, void* texels8B, uint32_t capacityTexels);
 int32_t pt_get_subinstances(pt_context* ctx, uint32_t* count, void* out32B);
 int32_t pt_get_scene_info(pt_context* ctx, uint32_t* numTriangles, uint32_t* numBvhNodes, uint32_t* numInstances, uint32_t* numMaterials);
 /* device-side evaluation of leaf functions for known-answer tests (kind: see pt_probe.h values in rtxpt_amd/csrc/pt_api.hip) */

@@ -397,7 +397,12 @@ class Oracle:
         L.ptref_set_instances(h, _p(sc["instances"]), len(sc["instances"]))
         if sc.get("env") is not None:
             rgb, tw, cm = sc["env"]
-            L.ptref_set_environment(h, _p(rgb), rgb.shape[1], rgb.shape[0], _p(tw), _p(cm))
+            # EnvMapSceneParams::ColorMultiplier as Sample.cpp:1936-1948 fills it: tint * intensity / c_envMapRadianceScale (the cube holds radiance * 1/4)
+            cm4 = (np.asarray(cm, np.float32) * np.float32(4.0)).astype(np.float32)
+            L.ptref_set_environment(h, _p(rgb), rgb.shape[1], rgb.shape[0], _p(tw), _p(cm4))
+            dl = sc.get("env_directional_lights")
+            dl = np.ascontiguousarray(dl, np.float32).reshape(-1, 8) if dl is not None else np.zeros((0, 8), np.float32)
+            L.ptref_set_environment_bake(h, int(sc.get("env_cube_dim", 256)), _p(dl) if len(dl) else None, len(dl))
         else:
             L.ptref_set_environment(h, None, 0, 0, None, None)
         if sc.get("lights") is not None:
@@ -480,6 +485,23 @@ class Oracle:
         self.L.ptref_get_subinstances(self.h, ctypes.byref(n), None)
         out = np.zeros((n.value, 8), np.uint32)
         self.L.ptref_get_subinstances(self.h, None, _p(out))
+        return out
+
+    def env_cube(self, reference=False):
+        """The RGBA16F environment cube as uint32 [texels, 2] plus (dim, mipLevels); reference=True: baked by the reference's EnvMapBaker.hlsl text
+        (needs an Oracle(reference_integrator=True) library)."""
+        dim, lv = ctypes.c_uint32(), ctypes.c_uint32()
+        n = self.L.ptref_get_env_cube(self.h, None, 0, ctypes.byref(dim), ctypes.byref(lv))
+        out = np.zeros((n, 2), np.uint32)
+        if n:
+            if reference: self.L.refpt_env_bake(self.h, _p(out), n)
+            else: self.L.ptref_get_env_cube(self.h, _p(out), n, None, None)
+        return out, dim.value, lv.value
+
+    def env_eval(self, dirs_lod):
+        """EnvMap::EvalLocal (cube fetch x ColorMultiplier) on rows (localDir.xyz, lod) -> float32 [n, 3]."""
+        a = np.ascontiguousarray(dirs_lod, np.float32).reshape(-1, 4); out = np.zeros((a.shape[0], 3), np.float32)
+        self.L.ptref_env_eval(self.h, _p(a), ctypes.c_uint32(a.shape[0]), _p(out))
         return out
 
     def surface_probe(self, prims, uv_dir_cone):

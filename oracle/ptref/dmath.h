@@ -15,6 +15,7 @@ static const float K_2PI    = 6.28318530717958647692f;
 static const float K_PI_2   = 1.57079632679489661923f;
 static const float K_PI_4   = 0.785398163397448309616f;
 static const float K_1_PI   = 0.318309886183790671538f;
+static const float K_1_2PI  = 0.159154943091895335769f;
 static const float K_2_PI   = 0.636619772367581343076f;
 static const float FLT_MAX_ = 3.402823466e+38f;
 static const float FLT_MIN_ = 1.175494351e-38f;
@@ -129,6 +130,8 @@ static inline float dm_atan2(float y, float x) {
     if (x < 0.0f) a = K_PI - a;
     return (y < 0.0f) ? -a : a;
 }
+// acos through atan2: stays inside the deterministic function set (EnvMapBaker.hlsl, world_to_latlong_map)
+static inline float dm_acos(float x) { return dm_atan2(sqrtf_(fmaxf_(0.0f, 1.0f - x * x)), x); }
 
 // Utils.hlsli:486-499 — bit-trick approximations that are PART of the reference maths (ray cone / firefly K)
 static inline float FastSqrt(float x) { return asfloat(0x1fbd1df5 + (asint(x) >> 1)); }

@@ -144,6 +144,46 @@ void build_bvh(Scene& sc) {
     subdivide(sc, prims, 0, 0, n);
 }
 
+// ---- the environment cube (EnvMapBaker: BaseLayerCS + MIPReduceCS, EnvMapBaker.hlsl:194-246, 268-371; EnvMapBaker.cpp:298-343, 540-620)
+static float4 env_generate_texel(const EnvMap& e, uint px, uint py, uint face, uint dim) {      // GenerateTexel (:194-246), equirectangular source, no procedural sky
+    float3 envCol = e.SampleSource(CubemapGetDirectionFor(face, make_float2(((float)px + 0.0f + 0.5f) / (float)dim, ((float)py + 0.0f + 0.5f) / (float)dim)));
+    for (const EnvDirectionalLight& l : e.dirLights) envCol = envCol + EnvComputeLightContribution(px, py, face, l, dim);
+    envCol = envCol * kEnvMapRadianceScale;
+    envCol = clamp3(envCol, 0.0f, HLF_MAX);
+    return make_float4(envCol.x, envCol.y, envCol.z, 1.0f);
+}
+static void bake_env_cube(EnvMap& e) {
+    const uint dim = e.cubeDim, levels = env_cube_mip_levels(dim);
+    EnvCube& c = e.cube; memset(&c, 0, sizeof(c)); c.dim = dim; c.mipLevels = levels;
+    size_t total = 0; for (uint l = 0; l < levels; l++) { c.mipOffset[l] = (uint)total; total += 6ull * (dim >> l) * (dim >> l); }
+    e.cubeTexels.assign(total, make_uint2(0, 0)); c.texels = e.cubeTexels.data();
+    uint2* T = e.cubeTexels.data();
+    auto at = [&](uint mip, uint face, uint x, uint y) -> uint2& { uint d = dim >> mip; return T[c.mipOffset[mip] + ((size_t)face * d + y) * d + x]; };
+    auto reduce = [](float4 e00, float4 e01, float4 e10, float4 e11, float4 wsa) {      // solid-angle weighted 2x2 average, summation order of the shader
+        float wsum = wsa.x + wsa.y + wsa.z + wsa.w;
+        float4 s = (e00 * wsa.x + e01 * wsa.y) + e10 * wsa.z + e11 * wsa.w;
+        return make_float4(s.x / wsum, s.y / wsum, s.z / wsum, s.w / wsum);
+    };
+    const uint h = dim / 2;
+#pragma omp parallel for schedule(dynamic, 4) collapse(2)
+    for (int face = 0; face < 6; face++) for (int y = 0; y < (int)h; y++) for (uint x = 0; x < h; x++) {          // BaseLayerCS: 4 texels of mip 0 + their mip-1 texel (from the unrounded values)
+        float4 e00 = env_generate_texel(e, 2 * x, 2 * y, face, dim), e01 = env_generate_texel(e, 2 * x, 2 * y + 1, face, dim),
+               e10 = env_generate_texel(e, 2 * x + 1, 2 * y, face, dim), e11 = env_generate_texel(e, 2 * x + 1, 2 * y + 1, face, dim);
+        at(0, face, 2 * x, 2 * y) = env_pack_rgba16f(e00); at(0, face, 2 * x, 2 * y + 1) = env_pack_rgba16f(e01);
+        at(0, face, 2 * x + 1, 2 * y) = env_pack_rgba16f(e10); at(0, face, 2 * x + 1, 2 * y + 1) = env_pack_rgba16f(e11);
+        if (levels > 1) at(1, face, x, y) = env_pack_rgba16f(reduce(e00, e01, e10, e11, CubemapTexelSolidAngle4((float)dim, 2 * x, 2 * y)));
+    }
+    for (uint l = 2; l < levels; l++) {                                                      // MIPReduceCS: from the stored (fp16) texels of the level above
+        const uint d = dim >> l;
+#pragma omp parallel for schedule(static) collapse(2)
+        for (int face = 0; face < 6; face++) for (int y = 0; y < (int)d; y++) for (uint x = 0; x < d; x++)
+            at(l, face, x, y) = env_pack_rgba16f(reduce(env_unpack_rgba16f(at(l - 1, face, 2 * x, 2 * y)), env_unpack_rgba16f(at(l - 1, face, 2 * x, 2 * y + 1)),
+                                                       env_unpack_rgba16f(at(l - 1, face, 2 * x + 1, 2 * y)), env_unpack_rgba16f(at(l - 1, face, 2 * x + 1, 2 * y + 1)),
+                                                       CubemapTexelSolidAngle4((float)(d * 2), 2 * x, 2 * y)));
+    }
+    e.cubeDirty = false;
+}
+
 // ---- environment importance map + quad tree (host restatement of the baker compute passes)
 struct EnvImportance { uint dim, mipCount; std::vector<std::vector<float4> > mips; };   // rgb = mean radiance, w = mean (lum+avg)/2
 static void build_env_importance(const Scene& sc, EnvImportance& im) {
@@ -157,7 +197,7 @@ static void build_env_importance(const Scene& sc, EnvImportance& im) {
         for (uint j = 0; j < sy; j++) for (uint i = 0; i < sx; i++) {
             float2 p = make_float2(((float)(x * sx + i) + 0.5f) / (float)dimS, ((float)((uint)y * sy + j) + 0.5f) / (float)(im.dim * sy));
             float3 dir = oct_to_ndir_equal_area_unorm(p);
-            float3 radiance = xyz(sample_trilinear(sc.env.tex, [&]{ float2 uv = EnvMap::dir_to_latlong(dir); float mh = (float)sc.env.tex.h; uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh); return uv; }(), 0.f));
+            float3 radiance = xyz(env_cube_sample_level(sc.env.cube, dir, 0.f));          // t_EnvMapCube.SampleLevel(s_LinearWrap, dir, 0) (EnvMapImportanceSamplingBaker.hlsl:77)
             L += (Luminance(radiance) + Average(radiance)) * 0.5f;
             R += radiance;
         }
@@ -380,7 +420,32 @@ void ptref_set_environment(void* h, const float* rgb, uint32_t w, uint32_t hgt, 
         e.toLocal = inv;
     }
     if (colorMul) e.colorMultiplier = make_float3(colorMul[0], colorMul[1], colorMul[2]);
-    c->lightsDirty = true;
+    e.cubeDirty = true; c->lightsDirty = true;
+}
+// cube resolution (EnvMapBaker::m_targetResolution: 2048 for an image source) and the directional lights baked into it (Sample::UpdateLighting, Sample.cpp:1361-1388)
+void ptref_set_environment_bake(void* h, uint32_t cubeDim, const EnvDirectionalLight* lights, uint32_t n) {
+    Context* c = (Context*)h; EnvMap& e = c->sc.env;
+    if (cubeDim) e.cubeDim = cubeDim;
+    e.dirLights.assign(lights, lights + (lights ? n : 0));
+    e.cubeDirty = true; c->lightsDirty = true;
+}
+// the baked cube (runs the bake if it is due): 2 words per RGBA16F texel, mips one after the other, face-major within a mip. Returns the texel count.
+uint32_t ptref_get_env_cube(void* h, uint32_t* out, uint32_t capacity, uint32_t* dim, uint32_t* mipLevels) {
+    Context* c = (Context*)h; EnvMap& e = c->sc.env;
+    if (!e.enabled) return 0;
+    if (e.cubeDirty) { bake_env_cube(e); c->lightsDirty = true; }
+    if (dim) *dim = e.cube.dim; if (mipLevels) *mipLevels = e.cube.mipLevels;
+    if (out && capacity >= e.cubeTexels.size()) memcpy(out, e.cubeTexels.data(), e.cubeTexels.size() * sizeof(uint2));
+    return (uint32_t)e.cubeTexels.size();
+}
+// EnvMap::EvalLocal on the baked cube: rows (localDir.xyz, lod) -> rgb (twin of the product's pt_probe kind 9)
+void ptref_env_eval(void* h, const float* in, uint32_t n, float* out) {
+    Context* c = (Context*)h; EnvMap& e = c->sc.env;
+    if (e.enabled && e.cubeDirty) { bake_env_cube(e); c->lightsDirty = true; }
+    for (uint32_t i = 0; i < n; i++) {
+        float3 r = e.enabled ? e.EvalLocal(make_float3(in[4 * i], in[4 * i + 1], in[4 * i + 2]), in[4 * i + 3]) : make_float3(0.f);
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
 }
 void ptref_set_lights(void* h, const PolymorphicLightInfo* base, const PolymorphicLightInfoEx* ex, uint32_t n) {
     Context* c = (Context*)h; c->sc.analyticLights.clear();
@@ -395,6 +460,7 @@ void ptref_reset_accumulation(void* h) { Context* c = (Context*)h; std::fill(c->
 
 static void prepare(Context* c) {
     if (c->geomDirty) { finalize_geometry(c->sc); build_bvh(c->sc); c->geomDirty = false; c->lightsDirty = true; }
+    if (c->sc.env.enabled && c->sc.env.cubeDirty) { bake_env_cube(c->sc.env); c->lightsDirty = true; }      // the light baker's importance map is made from the cube
     if (c->lightsDirty) { bake_lights(c->sc, c->S.NEEEnabled != 0, c->S.NEEType); c->lightsDirty = false; }
 }
 void ptref_prepare(void* h) { prepare((Context*)h); }

@@ -14,6 +14,7 @@
 #include <functional>
 #include <cstdio>
 #include "lights.h"
+#include "envcube.h"
 #include <vector>
 #include <algorithm>
 
@@ -116,29 +117,21 @@ static inline float4 sample_trilinear(const Texture& t, float2 uv, float lambda)
     return lerp4(a, b, f);
 }
 
-// ---- environment: lat-long RGB image (row 0 = +Y pole), bilinear + mips; EnvMap.hlsli:54-93 semantics for transform/multiplier
+// ---- environment: the host hands over a lat-long RGB image (row 0 = +Y pole); the path tracer samples the CUBE EnvMapBaker makes of it (envcube.h);
+// EnvMap.hlsli:54-93 semantics for transform / multiplier
 struct EnvMap {
     bool enabled; Texture tex; float3x4 toWorld, toLocal; float3 colorMultiplier;
+    uint cubeDim = 2048; std::vector<EnvDirectionalLight> dirLights; std::vector<uint2> cubeTexels; EnvCube cube; bool cubeDirty = true;
     float3 ToLocal(float3 dir) const { return mul_vec_mat3(dir, toLocal); }
     float3 ToWorld(float3 dir) const { return mul_vec_mat3(dir, toWorld); }
-    // direction -> lat-long uv (MathHelpers.hlsli:92-104 world_to_latlong_map convention: +Y up, u from atan2(x,-z))
-    static float2 dir_to_latlong(float3 d) {
-        float phi = dm_atan2(d.x, -d.z);                          // [-pi, pi]
-        float u = phi * (0.5f * K_1_PI) + 0.5f;
-        float yc = clampf(d.y, -1.0f, 1.0f);
-        // acos(y)/pi through atan2 to stay within the deterministic function set
-        float theta = dm_atan2(sqrtf_(fmaxf_(0.0f, 1.0f - yc * yc)), yc);
-        return make_float2(u, theta * K_1_PI);
-    }
-    float3 EvalLocal(float3 localDir, float lod) const {
-        float2 uv = dir_to_latlong(localDir);
-        // clamp v so that bilinear taps do not wrap over the poles
-        uint mip = (uint)clampf(lod, 0.0f, (float)(tex.mipLevels - 1));
-        float mh = (float)std::max(1u, tex.h >> mip);
+    // SampleSource (EnvMapBaker.hlsl:98-110): the equirectangular source through a linear sampler, wrap in u, clamp in v, mip 0
+    float3 SampleSource(float3 direction) const {
+        float2 uv = world_to_latlong_map(direction);
+        float mh = (float)tex.h;
         uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh);
-        float4 c = sample_trilinear(tex, uv, lod);
-        return xyz(c) * colorMultiplier;
+        return xyz(sample_bilinear(tex, 0, uv));
     }
+    float3 EvalLocal(float3 localDir, float lod) const { return xyz(env_cube_sample_level(cube, localDir, lod)) * colorMultiplier; }      // EnvMap.hlsli:82-85
 };
 
 // ---- the scene

@@ -30,6 +30,8 @@ static inline float4 make_float4(float x, float y, float z, float w) { float4 r 
 static inline float4 make_float4(float3 v, float w) { float4 r = {v.x, v.y, v.z, w}; return r; }
 static inline float3 xyz(float4 v) { return make_float3(v.x, v.y, v.z); }
 
+static inline uint4 make_uint4(uint x, uint y, uint z, uint w) { uint4 r = {x, y, z, w}; return r; }
+static inline uint2 make_uint2(uint x, uint y) { uint2 r = {x, y}; return r; }
 static inline uint asuint(float f) { uint u; memcpy(&u, &f, 4); return u; }
 static inline int asint(float f) { int u; memcpy(&u, &f, 4); return u; }
 static inline float asfloat(uint u) { float f; memcpy(&f, &u, 4); return f; }

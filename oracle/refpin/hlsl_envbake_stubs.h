@@ -1,0 +1,26 @@
+// ORACLE pin (test infrastructure only): what Rtxpt/Lighting/Distant/EnvMapBaker.hlsl binds, as stand-ins, so that its BaseLayerCS / MIPReduceCS text
+// (and GenerateTexel, SampleSource, ComputeLightContribution, CubemapGetDirectionFor, CubemapTexelSolidAngle4 under them) compiles as C++ and runs
+// over the oracle's environment source image. Included inside namespace hl::embake by hlsl_tu.py --integrator, after struct EMB_DirectionalLight.
+//   * the constant buffer without the procedural-sky block (ProcSkyEnabled stays 0: an image source, EnvMapBaker.cpp:425-470)
+//   * t_SrcEquirectangularEnvMap + s_EquiRectSampler (linear, wrap u / clamp v: EnvMapBaker.cpp:92-98): the oracle's bilinear fetch with the v clamp
+//   * the RGBA16_FLOAT cube UAVs: a store rounds to binary16 (round-to-nearest-even), a load widens
+struct PinEMBConsts { EMB_DirectionalLight DirectionalLights[EMB_MAXDIRLIGHTS]; float3 ScaleColor; uint DirectionalLightCount, CubeDim, CubeDimLowRes, ProcSkyEnabled, BackgroundSourceType; };
+static PinEMBConsts g_Const;
+struct PinEquirect { const ptref::Texture* tex = nullptr;
+    float4 SampleLevel(SamplerState, float2 uv, float) const {
+        ptref::float2 q = ptref::make_float2(uv.x, uv.y); const float mh = (float)tex->h;
+        q.y = ptref::clampf(q.y, 0.5f / mh, 1.0f - 0.5f / mh);
+        ptref::float4 c = ptref::sample_bilinear(*tex, 0, q); return float4(c.x, c.y, c.z, c.w); } };
+struct PinCubeSrc { float4 SampleLevel(SamplerState, float3, float) const { return float4(0.f, 0.f, 0.f, 0.f); } };
+struct PinCubeUAV { ptref::uint2* texels = nullptr; uint dim = 0;
+    struct Ref { ptref::uint2* p;
+        void operator=(float4 v) { *p = ptref::env_pack_rgba16f(ptref::make_float4(v.x, v.y, v.z, v.w)); }
+        operator float4() const { ptref::float4 c = ptref::env_unpack_rgba16f(*p); return float4(c.x, c.y, c.z, c.w); }
+        float4 operator*(float w) const { return float4(*this) * w; } };
+    Ref operator[](uint3 c) { return Ref{texels + ((size_t)c.z * dim + c.y) * dim + c.x}; }
+    void GetDimensions(uint& w, uint& h, uint& e) const { w = dim; h = dim; e = 6; } };
+static PinCubeUAV u_EnvMapCubeFacesDst0, u_EnvMapCubeFacesDst1, u_EnvMapCubeFacesDst, u_EnvMapCubeFacesSrc;
+static PinEquirect t_SrcEquirectangularEnvMap; static PinCubeSrc t_SrcCubemapEnvMap; static int t_LowResPrePassCube;
+static SamplerState s_Point, s_Linear, s_EquiRectSampler;
+static inline int GetProcSkyContext() { return 0; }                                             // never reached: ProcSkyEnabled == 0
+template <class... A> static inline float3 ProceduralSky(A...) { return float3(0.f, 0.f, 0.f); }

@@ -172,7 +172,7 @@ static inline float sin(float v) { return P::dm_sin(v); } static inline float co
 static inline void sincos(float v, float& s, float& c) { P::dm_sincos(v, s, c); }
 static inline float exp2(float v) { return P::dm_exp2(v); } static inline float log2(float v) { return P::dm_log2(v); }
 static inline float exp(float v) { return P::dm_exp(v); } static inline float log(float v) { return P::dm_log(v); } HL_LIFT1(exp) HL_LIFT1(log)
-static inline float atan2(float y, float x) { return P::dm_atan2(y, x); }
+static inline float atan2(float y, float x) { return P::dm_atan2(y, x); } static inline float acos(float v) { return P::dm_acos(v); }
 template <class E> float pow(float x, E e) { return ((float)e == 5.0f) ? P::dm_pow5(x) : P::dm_pow(x, (float)e); }      // pow(x, 5): the oracle's (x²·x²)·x
 template <class E> if_arith<float3, E> pow(float3 x, E e) { return float3(pow(x.x, e), pow(x.y, e), pow(x.z, e)); }
 static inline float3 pow(float3 x, float3 e) { return float3(pow(x.x, e.x), pow(x.y, e.y), pow(x.z, e.z)); }

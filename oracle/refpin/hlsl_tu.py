@@ -166,7 +166,7 @@ def to_cpp(code):
     code = code.replace("(applyMIS)?(path.GetBsdfScatterPdf()):(0.0)", "(applyMIS)?((float)path.GetBsdfScatterPdf()):(0.0)")
     # swizzles on scalars (literals, named scalars, parenthesised / call expressions) become constructor calls ...
     code = re.sub(r"(?<![\w.])(\d+\.\d*f?|\.\d+f?|\d+)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)     # `0.5.xx`, `0.xxx`
-    code = re.sub(r"\b(HLF_MAX|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
+    code = re.sub(r"\b(HLF_MAX|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE|fp16Max|destinationRes|cubeDim)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\b((?:\w+\.)?AttenuationDistance)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"((?:\b[A-Za-z_][\w.]*)?\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\))\.(xx|xxx|xxxx|rr|rrr|rrrr)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\bpackedData\.x\b", "packedData", code)                               # `.x` of a scalar
@@ -176,6 +176,7 @@ def to_cpp(code):
     code = re.sub(r"\[(?:unroll|loop|branch|flatten|mutating|forceinline)(?:\([^)]*\))?\][ \t]*", "", code)
     code = re.sub(r"\buniform\s+(?=uint|int|float|bool)", "", code)
     code = re.sub(r":\s*register\s*\([^)]*\)", "", code)                                     # resource bindings
+    code = re.sub(r"\s*:\s*SV_\w+", "", code)                                                # system-value semantics of entry-point parameters
     code = re.sub(r"\b(Texture2D|TextureCube|RWTexture2D|RWTexture2DArray)\b(?!\s*<)", r"\1<float4>", code)         # untyped resource = float4 elements
     code = re.sub(r"\b(row_major|precise|nointerpolation|globallycoherent)[ \t]+", "", code)
     code = re.sub(r"\bcbuffer\s+\w+\s*\{([^{}]*)\}\s*;?", r"static \1", code)                  # a constant buffer is its members, as globals
@@ -191,7 +192,7 @@ PT_DENY = ("ShaderDebug.hlsl", "PathTracerDebug.hlsli", "STFSamplerState.hlsli",
 # files of which only some items are needed (the rest uses matrix member syntax / half types / pixel-shader intrinsics that the pin has no use for)
 PT_PICK = {
     "MathHelpers.hlsli": ["ndir_to_oct_equal_area_unorm", "oct_to_ndir_equal_area_unorm", "sample_disk", "sample_disk_concentric", "sample_cosine_hemisphere_concentric",
-                          "sample_cosine_hemisphere_polar", "perp_stark", "sqr"],
+                          "sample_cosine_hemisphere_polar", "perp_stark", "sqr", "world_to_latlong_map"],
 }
 
 
@@ -244,6 +245,16 @@ def main_pt(ref):
                  "^EnvMap Bridge::CreateEnvMap..^void Bridge::ExportSurfaceInit"):
         w("// ======== PathTracerBridgeDonut.hlsli : %s\n" % spec)
         w(to_cpp(extract_range(btext, spec, "PathTracerBridgeDonut.hlsli", braw)) + "\n")
+    # EnvMapBaker.hlsl: the cube bake (BaseLayerCS, MIPReduceCS and everything they call) over the stand-in bindings of hlsl_envbake_stubs.h
+    epath = os.path.join(ref, "Rtxpt/Lighting/Distant/EnvMapBaker.hlsl")
+    etext = strip_comments(open(epath, encoding="latin-1").read())
+    w("// ======== EnvMapBaker.hlsl (selected items)\nnamespace embake {\n" + re.search(r"^#define\s+EMB_MAXDIRLIGHTS\b.*$", etext, re.M).group(0) + "\n")
+    w(to_cpp(extract_struct(etext, "EMB_DirectionalLight", "EnvMapBaker.hlsl")) + "\n")
+    w('#include "%s/hlsl_envbake_stubs.h"\n' % HERE)
+    for name in ("CubemapGetDirectionFor", "SampleSource", "SphereQuadrantArea", "CubemapTexelSolidAngle", "CubemapTexelSolidAngle4", "ComputeLightContribution", "GenerateTexel",
+                 "BaseLayerCS", "MIPReduceCS"):
+        for body in extract_function(etext, name, "EnvMapBaker.hlsl"): w(to_cpp(body) + "\n")
+    w("} // namespace embake\n")
     w("} // namespace hl\n")
     w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
 

@@ -24,9 +24,9 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 # every symbol include/mi355pt.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
-    "pt_set_environment", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_set_environment", "pt_set_environment_bake", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
-    "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_subinstances",
+    "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
     "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
@@ -444,8 +444,13 @@ class PathTracer:
         self._chk(self.L.pt_set_instances(self.h, _p(sc["instances"]), len(sc["instances"])), "pt_set_instances")
         if sc.get("env") is not None:
             rgb, tw, cm = sc["env"]
-            p = PtEnvMapSceneParams((ctypes.c_float * 12)(*tw.tolist()), (ctypes.c_float * 3)(*cm.tolist()), 1.0)
+            # EnvMapSceneParams::ColorMultiplier as Sample.cpp:1936-1948 fills it: tint * intensity / c_envMapRadianceScale (the cube holds radiance * 1/4)
+            cm4 = (np.asarray(cm, np.float32) * np.float32(4.0)).astype(np.float32)
+            p = PtEnvMapSceneParams((ctypes.c_float * 12)(*tw.tolist()), (ctypes.c_float * 3)(*cm4.tolist()), 1.0)
             self._chk(self.L.pt_set_environment(self.h, _p(rgb), rgb.shape[1], rgb.shape[0], ctypes.byref(p)), "pt_set_environment")
+            dl = sc.get("env_directional_lights")       # rows of EMB_DirectionalLight: colour rgb, intensity, direction xyz, angular size
+            dl = np.ascontiguousarray(dl, np.float32).reshape(-1, 8) if dl is not None else np.zeros((0, 8), np.float32)
+            self._chk(self.L.pt_set_environment_bake(self.h, int(sc.get("env_cube_dim", 256)), _p(dl) if len(dl) else None, len(dl)), "pt_set_environment_bake")
         else:
             self._chk(self.L.pt_set_environment(self.h, None, 0, 0, None), "pt_set_environment")
         if sc.get("lights") is not None:
@@ -561,6 +566,14 @@ class PathTracer:
         el = np.zeros(dim.value * dim.value, np.uint32)
         self._chk(self.L.pt_get_lights(self.h, None, None, _p(lights), _p(ex), _p(pc), _p(pi), _p(el), None), "pt_get_lights")
         return dict(lights=lights, lightsEx=ex, proxyCounters=pc, proxyIndices=pi, envLookup=el, envLookupDim=dim.value)
+
+    def env_cube(self):
+        """pt_get_env_cube: the baked RGBA16F environment cube as uint32 [texels, 2] plus (dim, mipLevels)."""
+        n, dim, lv = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._chk(self.L.pt_get_env_cube(self.h, ctypes.byref(n), ctypes.byref(dim), ctypes.byref(lv), None, 0), "pt_get_env_cube")
+        out = np.zeros((n.value, 2), np.uint32)
+        if n.value: self._chk(self.L.pt_get_env_cube(self.h, None, None, None, _p(out), n.value), "pt_get_env_cube")
+        return out, dim.value, lv.value
 
     def subinstances(self):
         n = ctypes.c_uint32()

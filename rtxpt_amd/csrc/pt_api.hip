@@ -73,6 +73,7 @@ struct pt_context {
     std::vector<GeometryDesc> geometries; std::vector<MeshDesc> meshes; std::vector<InstanceDesc> instances;
     std::vector<ptk::PTMaterialData> materials; std::vector<HostTexture> textures; HostTexture envTex; bool envEnabled = false;
     float3x4 envToWorld, envToLocal; ptk::float3 envColorMul;
+    uint envCubeDim = 2048; std::vector<ptk::EnvDirectionalLight> envDirLights; bool envCubeDirty = true; ptk::EnvCube envCube;      // EnvMapBaker state (pt_set_environment_bake)
     std::vector<PolymorphicLightInfoFull> analyticLights;
     std::vector<SubInstanceData> subInstances; std::vector<ptk::uint2> subInstToInstGeom; std::vector<ptk::uint2> primInfo;
     std::vector<ptk::PolymorphicLightInfo> lights; std::vector<ptk::PolymorphicLightInfoEx> lightsEx; std::vector<uint> envLookup; uint envLookupDim = 0; uint numProxies = 0, envLightsBaked = 0;      // (light weights / proxy table live on the device only)
@@ -81,6 +82,7 @@ struct pt_context {
     DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
+    DevBuf<ptk::uint2> dEnvCube; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights;
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
@@ -204,6 +206,7 @@ void refresh_scene_view(pt_context* c) {
     d.indices = c->dIndices.p; d.positions = c->dPositions.p; d.uvs = c->dUvs.p; d.normals = c->dNormals.p; d.tangents = c->dTangents.p;
     d.geometries = c->dGeometries.p; d.instances = c->dInstances.p; d.subInstances = c->dSubInstances.p; d.subInstToInstGeom = c->dSubInstToInstGeom.p;
     d.materials = c->dMaterials.p; d.materialCount = (uint)c->materials.size(); d.textures = c->dTexInfos.p; d.texels = c->dTexels.p;
+    d.envCube = c->envCube; d.envCube.texels = c->dEnvCube.p;
     d.envTex = c->envTexInfo; d.envEnabled = c->envEnabled ? 1u : 0u; d.envToWorld = c->envToWorld; d.envToLocal = c->envToLocal; d.envColorMultiplier = c->envColorMul;
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
@@ -411,8 +414,21 @@ int bake_lights(pt_context* c, bool geometryOnly = false) {
     c->lightsDirty = false;
     return PT_OK;
 }
+// EnvMapBaker::Update (EnvMapBaker.cpp:425-620): lat-long source + directional lights -> the RGBA16F cube the path tracer and the light baker sample
+int bake_env_cube(pt_context* c) {
+    ptk::EnvCube& e = c->envCube; memset(&e, 0, sizeof(e)); e.dim = c->envCubeDim; e.mipLevels = ptk::env_cube_mip_levels(e.dim);
+    size_t total = 0; for (uint l = 0; l < e.mipLevels; l++) { e.mipOffset[l] = (uint)total; total += 6ull * (e.dim >> l) * (e.dim >> l); }
+    PT_CHECK_HIP(c, c->dEnvCube.resize(total));
+    PT_CHECK_HIP(c, c->dEnvDirLights.upload(c->envDirLights, c->stream));
+    refresh_scene_view(c);
+    launch_env_cube_bake(c->dsc, c->dEnvDirLights.p, (uint)c->envDirLights.size(), c->dEnvCube.p, c->dsc.envCube, c->stream);
+    PT_CHECK_HIP(c, hipGetLastError());
+    c->envCubeDirty = false; c->lightsDirty = true;
+    return PT_OK;
+}
 int prepare(pt_context* c) {
-    if (c->texDirty) { int r = upload_textures(c); if (r != PT_OK) return r; refresh_scene_view(c); c->lightsDirty = true; }
+    if (c->texDirty) { int r = upload_textures(c); if (r != PT_OK) return r; refresh_scene_view(c); c->lightsDirty = true; c->envCubeDirty = true; }
+    if (c->envEnabled && c->envCubeDirty) { int r = bake_env_cube(c); if (r != PT_OK) return r; }
     if (c->geomDirty) { int r = finalize_geometry(c); if (r != PT_OK) return r; }
     if (c->lightsDirty) { int r = bake_lights(c); if (r != PT_OK) return r; }
     return PT_OK;
@@ -467,7 +483,7 @@ int32_t pt_destroy(pt_context* c) {
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
-    c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
+    c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
@@ -547,7 +563,7 @@ int32_t pt_set_environment(pt_context* c, const float* rgb, uint32_t w, uint32_t
     if (c->envEnabled) {
         HostTexture& t = c->envTex; t.w = w; t.h = h; t.mips.clear(); t.mips.resize(1); t.mips[0].resize((size_t)w * h);
         for (size_t i = 0; i < (size_t)w * h; i++) t.mips[0][i] = ptk::make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.f);
-        build_mips(t);
+        t.mipLevels = 1;                                   // the bake reads mip 0 only (EnvMapBaker.hlsl:98-110: SampleLevel(.., 0))
     }
     if (params) {
         memcpy(c->envToWorld.m, params->Transform, 48);
@@ -556,6 +572,16 @@ int32_t pt_set_environment(pt_context* c, const float* rgb, uint32_t w, uint32_t
         c->envColorMul = ptk::make_float3(params->ColorMultiplier[0], params->ColorMultiplier[1], params->ColorMultiplier[2]);
     }
     c->texDirty = true; c->lightsDirty = true;
+    return PT_OK;
+}
+int32_t pt_set_environment_bake(pt_context* c, uint32_t cubeDim, const PtEnvDirectionalLight* lights, uint32_t n) {
+    if (!c || (!lights && n)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
+    if (cubeDim && (cubeDim < 16u || cubeDim > 8192u || (cubeDim & (cubeDim - 1u)))) return fail(c, PT_ERROR_INVALID_ARGUMENT, "cube resolution must be a power of two in [16, 8192]");
+    if (n > 16u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "at most 16 directional lights are baked into the environment cube (EnvMapBaker.hlsl: EMB_MAXDIRLIGHTS)");
+    if (cubeDim) c->envCubeDim = cubeDim;
+    static_assert(sizeof(PtEnvDirectionalLight) == sizeof(ptk::EnvDirectionalLight), "EnvDirectionalLight layout");
+    c->envDirLights.resize(n); if (n) memcpy(c->envDirLights.data(), lights, sizeof(ptk::EnvDirectionalLight) * n);
+    c->envCubeDirty = true; c->lightsDirty = true;
     return PT_OK;
 }
 int32_t pt_set_lights(pt_context* c, const ::PolymorphicLightInfo* lights, const ::PolymorphicLightInfoEx* ex, uint32_t n) {
@@ -905,6 +931,20 @@ int32_t pt_get_lights(pt_context* c, uint32_t* nLights, uint32_t* nProxies, void
     if (envLookup && c->envLookup.size()) PT_CHECK_HIP(c, hipMemcpy(envLookup, c->dEnvLookup.p, 4 * c->envLookup.size(), hipMemcpyDeviceToHost));
     return PT_OK;
 }
+int32_t pt_get_env_cube(pt_context* c, uint32_t* texelCount, uint32_t* dim, uint32_t* mipLevels, void* texels8B, uint32_t capacityTexels) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    size_t n = 0;
+    if (c->envEnabled) { const uint last = c->envCube.mipLevels - 1u, d = c->envCube.dim >> last; n = (size_t)c->envCube.mipOffset[last] + 6ull * d * d; }
+    if (texelCount) *texelCount = (uint32_t)n; if (dim) *dim = c->envEnabled ? c->envCube.dim : 0; if (mipLevels) *mipLevels = c->envEnabled ? c->envCube.mipLevels : 0;
+    if (texels8B && n) {
+        if (capacityTexels < n) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_get_env_cube: buffer too small");
+        PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        PT_CHECK_HIP(c, hipMemcpy(texels8B, c->dEnvCube.p, 8 * n, hipMemcpyDeviceToHost));
+    }
+    return PT_OK;
+}
 int32_t pt_get_subinstances(pt_context* c, uint32_t* count, void* out) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
@@ -923,7 +963,7 @@ int32_t pt_get_scene_info(pt_context* c, uint32_t* nTris, uint32_t* nNodes, uint
 int32_t pt_probe(pt_context* c, int32_t kind, const void* in, size_t inBytes, void* out, size_t outBytes, uint32_t n) {
     if (!c || !in || !out || !n) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad argument");
     (void)hipSetDevice(c->device);
-    if (kind == 8) { int r = prepare(c); if (r != PT_OK) return r; }      // the surface probe reads the scene
+    if (kind == 8 || kind == 9) { int r = prepare(c); if (r != PT_OK) return r; }      // the surface and environment probes read the scene
     DevBuf<unsigned char> di, dout;
     PT_CHECK_HIP(c, di.upload((const unsigned char*)in, inBytes, c->stream)); PT_CHECK_HIP(c, dout.resize(outBytes));
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;

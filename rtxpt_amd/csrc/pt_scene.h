@@ -11,6 +11,7 @@
 // The reference gets traversal from the DXR driver (Rtxpt/Shaders/PathTracerBridgeDonut.hlsli:993-1055); here it is explicit.
 #pragma once
 #include "pt_lights.h"
+#include "pt_envcube.h"
 
 namespace ptk {
 #pragma clang force_cuda_host_device begin
@@ -92,7 +93,8 @@ struct DeviceScene {
     const GeometryDesc* geometries; const InstanceDesc* instances; const SubInstanceData* subInstances; const uint2* subInstToInstGeom;
     const PTMaterialData* materials; uint materialCount;
     const TexInfo* textures; const float4* texels;
-    TexInfo envTex; uint envEnabled; float3x4 envToWorld, envToLocal; float3 envColorMultiplier;
+    TexInfo envTex; uint envEnabled; float3x4 envToWorld, envToLocal; float3 envColorMultiplier;      // envTex: the lat-long source (read by the cube bake only)
+    EnvCube envCube;           // what the path tracer samples: EnvMapBaker's RGBA16F cube + mips (pt_envcube.h)
     LightTable lights;
     const BvhNode* nodes; const Bvh8Node* nodes8; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
     const AlphaRec* alphaRecs; // one per TriRecord slot (leaf order)
@@ -141,22 +143,16 @@ static inline float4 sample_trilinear(const DeviceScene& sc, const TexInfo& t, f
     float4 b = sample_bilinear(sc, t, m1, uv);
     return lerp4(a, b, f);
 }
-// EnvMap.hlsli:54-93 on the source lat-long image (world_to_latlong_map, MathHelpers.hlsli:92-104)
-static inline float2 dir_to_latlong(float3 d) {
-    float phi = dm_atan2(d.x, -d.z);
-    float u = phi * (0.5f * K_1_PI) + 0.5f;
-    float yc = clampf(d.y, -1.0f, 1.0f);
-    float theta = dm_atan2(sqrtf_(fmaxf_(0.0f, 1.0f - yc * yc)), yc);
-    return make_float2(u, theta * K_1_PI);
-}
-static inline float3 env_eval_local(const DeviceScene& sc, float3 localDir, float lod) {
-    float2 uv = dir_to_latlong(localDir);
-    uint mip = (uint)clampf(lod, 0.0f, (float)(sc.envTex.mipLevels - 1));
-    uint mhu = sc.envTex.h >> mip; if (mhu < 1u) mhu = 1u;
-    float mh = (float)mhu;
+// SampleSource (EnvMapBaker.hlsl:98-110): the equirectangular source through a linear sampler (wrap in u, clamp in v), mip 0
+static inline float3 env_sample_source(const DeviceScene& sc, float3 direction) {
+    float2 uv = world_to_latlong_map(direction);
+    float mh = (float)sc.envTex.h;
     uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh);
-    float4 c = sample_trilinear(sc, sc.envTex, uv, lod);
-    return xyz(c) * sc.envColorMultiplier;
+    return xyz(sample_bilinear(sc, sc.envTex, 0, uv));
+}
+// EnvMap::EvalLocal (EnvMap.hlsli:82-85): TextureCube.SampleLevel on the baked cube
+static inline float3 env_eval_local(const DeviceScene& sc, float3 localDir, float lod) {
+    return xyz(env_cube_sample_level(sc.envCube, localDir, lod)) * sc.envColorMultiplier;
 }
 
 // ---- ray / triangle (Moeller-Trumbore, both sides, tmin < t < tmax); (u,v) = DXR barycentrics of vertices 1,2

@@ -308,7 +308,47 @@ __global__ void __launch_bounds__(256) k_unpack(float4* __restrict__ accum, cons
     uint px = pixels[i]; accum[(px & 0xFFFFu) * width + (px >> 16)] = src[i];
 }
 
-// BuildMIPDescentImportanceMapCS (Rtxpt/Lighting/Distant/EnvMapImportanceSamplingBaker.hlsl:57-90) on the lat-long source
+// ---- EnvMapBaker on the device (EnvMapBaker.hlsl:194-246, 268-371; pt_envcube.h): BaseLayerCS makes four texels of mip 0 and their mip-1 texel per thread,
+// MIPReduceCS the further levels from the stored (fp16) texels; solid-angle weighted, summation order of the shader
+__device__ __forceinline__ float4 env_generate_texel(const DeviceScene& sc, const EnvDirectionalLight* __restrict__ lights, uint nLights, uint px, uint py, uint face, uint dim) {
+    float3 envCol = env_sample_source(sc, CubemapGetDirectionFor(face, make_float2(((float)px + 0.0f + 0.5f) / (float)dim, ((float)py + 0.0f + 0.5f) / (float)dim)));
+    for (uint i = 0; i < nLights; i++) envCol = envCol + EnvComputeLightContribution(px, py, face, lights[i], dim);
+    envCol = envCol * kEnvMapRadianceScale;
+    envCol = clamp3(envCol, 0.0f, HLF_MAX);
+    return make_float4(envCol.x, envCol.y, envCol.z, 1.0f);
+}
+__device__ __forceinline__ float4 env_reduce(float4 e00, float4 e01, float4 e10, float4 e11, float4 wsa) {
+    float wsum = wsa.x + wsa.y + wsa.z + wsa.w;
+    float4 s = (e00 * wsa.x + e01 * wsa.y) + e10 * wsa.z + e11 * wsa.w;
+    return make_float4(s.x / wsum, s.y / wsum, s.z / wsum, s.w / wsum);
+}
+__global__ void __launch_bounds__(256) k_env_cube_base(DeviceScene sc, const EnvDirectionalLight* __restrict__ lights, uint nLights, uint2* __restrict__ texels, EnvCube cube) {
+    const uint dim = cube.dim, h = dim / 2u;
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= 6u * h * h) return;
+    const uint face = i / (h * h), r = i - face * h * h, y = r / h, x = r - y * h;
+    float4 e00 = env_generate_texel(sc, lights, nLights, 2 * x, 2 * y, face, dim), e01 = env_generate_texel(sc, lights, nLights, 2 * x, 2 * y + 1, face, dim),
+           e10 = env_generate_texel(sc, lights, nLights, 2 * x + 1, 2 * y, face, dim), e11 = env_generate_texel(sc, lights, nLights, 2 * x + 1, 2 * y + 1, face, dim);
+    uint2* m0 = texels + cube.mipOffset[0] + (size_t)face * dim * dim;
+    m0[(size_t)(2 * y) * dim + 2 * x] = env_pack_rgba16f(e00); m0[(size_t)(2 * y + 1) * dim + 2 * x] = env_pack_rgba16f(e01);
+    m0[(size_t)(2 * y) * dim + 2 * x + 1] = env_pack_rgba16f(e10); m0[(size_t)(2 * y + 1) * dim + 2 * x + 1] = env_pack_rgba16f(e11);
+    if (cube.mipLevels > 1u) texels[cube.mipOffset[1] + ((size_t)face * h + y) * h + x] = env_pack_rgba16f(env_reduce(e00, e01, e10, e11, CubemapTexelSolidAngle4((float)dim, 2 * x, 2 * y)));
+}
+__global__ void __launch_bounds__(256) k_env_cube_mip(uint2* __restrict__ texels, EnvCube cube, uint level) {
+    const uint d = cube.dim >> level, s = d * 2u;
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= 6u * d * d) return;
+    const uint face = i / (d * d), r = i - face * d * d, y = r / d, x = r - y * d;
+    const uint2* src = texels + cube.mipOffset[level - 1u] + (size_t)face * s * s;
+    texels[cube.mipOffset[level] + ((size_t)face * d + y) * d + x] = env_pack_rgba16f(env_reduce(
+        env_unpack_rgba16f(src[(size_t)(2 * y) * s + 2 * x]), env_unpack_rgba16f(src[(size_t)(2 * y + 1) * s + 2 * x]),
+        env_unpack_rgba16f(src[(size_t)(2 * y) * s + 2 * x + 1]), env_unpack_rgba16f(src[(size_t)(2 * y + 1) * s + 2 * x + 1]), CubemapTexelSolidAngle4((float)s, 2 * x, 2 * y)));
+}
+void launch_env_cube_bake(const DeviceScene& sc, const EnvDirectionalLight* lights, uint nLights, uint2* texels, const EnvCube& cube, hipStream_t st) {
+    const uint h = cube.dim / 2u;
+    hipLaunchKernelGGL(k_env_cube_base, dim3((6u * h * h + 255u) / 256u), dim3(256), 0, st, sc, lights, nLights, texels, cube);
+    for (uint l = 2; l < cube.mipLevels; l++) { const uint d = cube.dim >> l; hipLaunchKernelGGL(k_env_cube_mip, dim3((6u * d * d + 255u) / 256u), dim3(256), 0, st, texels, cube, l); }
+}
+
+// BuildMIPDescentImportanceMapCS (Rtxpt/Lighting/Distant/EnvMapImportanceSamplingBaker.hlsl:57-90) on the baked cube
 __global__ void __launch_bounds__(256) k_env_importance(DeviceScene sc, uint dim, uint sx, uint sy, float4* __restrict__ out) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= dim * dim) return;
     uint x = i % dim, y = i / dim;
@@ -317,8 +357,7 @@ __global__ void __launch_bounds__(256) k_env_importance(DeviceScene sc, uint dim
     for (uint j = 0; j < sy; j++) for (uint ii = 0; ii < sx; ii++) {
         float2 p = make_float2(((float)(x * sx + ii) + 0.5f) / (float)(dim * sx), ((float)(y * sy + j) + 0.5f) / (float)(dim * sy));
         float3 dir = oct_to_ndir_equal_area_unorm(p);
-        float2 uv = dir_to_latlong(dir); float mh = (float)sc.envTex.h; uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh);
-        float3 radiance = xyz(sample_trilinear(sc, sc.envTex, uv, 0.f));
+        float3 radiance = xyz(env_cube_sample_level(sc.envCube, dir, 0.f));          // t_EnvMapCube.SampleLevel(s_LinearWrap, dir, 0) (:77)
         L += (Luminance(radiance) + Average(radiance)) * 0.5f;
         R += radiance;
     }
@@ -461,6 +500,9 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
                       case 7: r = H::r(a[1] * a[2]); break; case 8: r = H::r(H::r(a[1]) * a[2]); break; case 9: r = H::r(a[1] + a[2]); break; case 10: r = H::r(a[1] / a[2]); break;      // lpfloat(float expression)
                       default: r = H::average3(make_float3(H::r(a[1]), H::r(a[2]), H::r(a[3]))); break; }
         out[i] = r; } break;
+    case 9: { const float* a = in + 4 * i; float* o = out + 3 * i;                                       // EnvMap::EvalLocal on the baked cube: (localDir.xyz, lod)
+        float3 r = k.sc.envEnabled ? env_eval_local(k.sc, make_float3(a[0], a[1], a[2]), a[3]) : make_float3(0.f);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
     default: break;
     }
 }

@@ -65,6 +65,40 @@ def with_rotated_environment(make, yaw=0.9, pitch=0.35, tint=(1.4, 0.8, 0.6)):
     return build
 
 
+def with_sun_discs(make, cube_dim=None):
+    """The scene of `make` with two directional lights baked into its environment cube (Sample::UpdateLighting hands the scene's DirectionalLights to
+    EnvMapBaker::Update, Sample.cpp:1361-1388; EnvMapBaker.hlsl:166-192 draws them as anti-aliased discs): a small bright sun and a wide dim disc.
+    Rows: colour rgb, intensity, direction the light travels in, angular size [rad]."""
+    import numpy as np
+    def build():
+        sc, cam = make()
+        sc = dict(sc)
+        d0 = -np.array([0.35, 0.8, -0.45]) / np.linalg.norm([0.35, 0.8, -0.45]); d1 = -np.array([-0.5, 0.6, 0.62]) / np.linalg.norm([-0.5, 0.6, 0.62])
+        sc["env_directional_lights"] = np.array([[1.0, 0.92, 0.8, 2.5, d0[0], d0[1], d0[2], 0.05], [0.3, 0.5, 1.0, 0.8, d1[0], d1[1], d1[2], 0.6]], np.float32)
+        if cube_dim: sc["env_cube_dim"] = cube_dim
+        return sc, cam
+    return build
+
+
+def env_cube_cases():
+    """Environment-bake inputs (a tiny scene carrying the source image, the cube resolution and the directional lights): the smallest cube (16: two levels),
+    a 32 cube with two discs, a 64 cube of a source with an HDR sun that exceeds the fp16 range after scaling (the clamp to HLF_MAX)."""
+    import numpy as np
+    def scene(src, dim, lights=None):
+        sc, _ = scenes.cornell_box("C2")
+        sc = dict(sc); rgb, tw, cm = sc["env"]
+        sc["env"] = (src, tw, cm); sc["env_cube_dim"] = dim
+        if lights is not None: sc["env_directional_lights"] = np.asarray(lights, np.float32)
+        return sc
+    d0 = -np.array([0.35, 0.8, -0.45]) / np.linalg.norm([0.35, 0.8, -0.45]); d1 = -np.array([-0.5, 0.6, 0.62]) / np.linalg.norm([-0.5, 0.6, 0.62]); d2 = np.array([0.0, 0.0, 1.0])
+    lights = [[1.0, 0.92, 0.8, 2.5, d0[0], d0[1], d0[2], 0.09], [0.3, 0.5, 1.0, 0.8, d1[0], d1[1], d1[2], 0.6], [1.0, 0.2, 0.1, 0.3, d2[0], d2[1], d2[2], 3.0]]
+    return {
+        "sky_16": scene(scenes.sky_equirect(128, 64), 16),
+        "sky_32_discs": scene(scenes.sky_equirect(256, 128), 32, lights),
+        "sky_64_hdr_sun": scene(scenes.sky_equirect(512, 256, sun_radiance=4e5, sun_deg=3.0), 64, lights[:1]),
+    }
+
+
 def with_mirrored_instance(make, index=0, width=0.5528):
     """The scene of `make` with one instance mirrored in x (negative determinant: flipped winding for the light baker, LightsBaker.hlsl:669-683, and for
     the face normals) and stretched a little in y (non-uniform scale through the normal / tangent transforms)."""
@@ -114,9 +148,11 @@ def cases():
         "c2_point_light_record_uniform": (with_point_light_record(with_sphere_lights(c2)), scenes.default_settings(NEEType=0), 64, 36, 0, 2),   # inert point-type record in the buffer
         "c2_exclude_from_nee": (with_excluded_geometry(c2), scenes.default_settings(), 64, 36, 0, 2),              # ExcludeFromNEE geometry: invisible to shadow rays
         "c2_env_rotated_mip2": (with_rotated_environment(c2), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 64, 36, 5, 2),   # env transform + tint, diffuse-bounce env MIP 2 (the UI default)
+        "c2_sun_discs": (with_sun_discs(c2), scenes.default_settings(), 64, 36, 2, 2),                             # directional lights baked into the environment cube
         "c2_mirrored_room": (with_mirrored_instance(c2), scenes.default_settings(), 64, 36, 0, 2),                 # negative-determinant instance holding the quad light
         "bistro_like": (lambda: scenes.bistro_like(scale=0.02, tex_size=128), scenes.default_settings(), 96, 54, 0, 2),      # alpha test, textures, normal maps, emissive triangles, env quads
         "bistro_like_material_zoo": (with_material_zoo(lambda: scenes.bistro_like(scale=0.02, tex_size=128)), scenes.default_settings(), 96, 54, 2, 2),
+        "bistro_like_sun_discs_cube512": (with_sun_discs(lambda: scenes.bistro_like(scale=0.02, tex_size=128), cube_dim=512), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 96, 54, 6, 2),
         "bistro_like_c5": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), scenes.default_settings(), 96, 54, 0, 2),   # + nested-dielectric props
     }
 

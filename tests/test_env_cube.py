@@ -1,0 +1,141 @@
+"""The environment cube: EnvMapBaker's lat-long -> RGBA16F cube bake, restated by the oracle (oracle/ptref/envcube.h,
+ptref_api.cpp bake_env_cube), against the reference's own EnvMapBaker.hlsl text.
+
+  * test_oracle_cube_matches_reference_text_golden: committed cubes (tests/golden/env_cube_golden.npz) baked by BaseLayerCS / MIPReduceCS of the reference
+    text — runs everywhere, bit for bit.
+  * test_oracle_cube_matches_live_reference_text: the same comparison on further inputs where /root/reference exists.
+  * properties: alpha, fp16 range clamp, a constant source stays constant through the mips, the energy of a baked disc, cube addressing at texel centres.
+The cube FETCH (TextureCube.SampleLevel: face selection, bilinear taps clamped to the face, trilinear between mips) is hardware behaviour the reference
+has no text for; it is restated once in envcube.h and shared by the oracle and the reference-text integrator (hlsl_pt_wrappers.inc env_fetch)."""
+import os, sys
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rtxpt_amd import scenes
+from oracle import ptref
+import pin_scenes
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "env_cube_golden.npz")
+CASES = pin_scenes.env_cube_cases()
+HAVE_REF = os.path.isdir("/root/reference/Rtxpt/Shaders")
+
+
+def _cube(sc, reference=False):
+    o = ptref.Oracle(reference_integrator=True, settings=scenes.default_settings()) if reference else ptref.Oracle()
+    o.set_scene(sc)
+    return o.env_cube(reference=reference), o
+
+
+def _half(cube):
+    return cube.view(np.float16).astype(np.float32).reshape(-1, 4)
+
+
+def _mip_slices(dim, levels):
+    out, off = [], 0
+    for l in range(levels):
+        d = dim >> l; out.append((off, off + 6 * d * d, d)); off += 6 * d * d
+    return out
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_cube_matches_reference_text_golden(name):
+    g = np.load(GOLDEN)
+    (cube, dim, levels), _ = _cube(CASES[name])
+    assert (dim, levels) == tuple(int(v) for v in g[name + "_dim"])
+    bad = (cube != g[name]).any(-1)
+    assert not bad.any(), "%s: %d of %d texels differ from the reference-text bake" % (name, int(bad.sum()), bad.size)
+    h = _half(cube)
+    assert np.all(h[:, 3] == 1.0) and np.isfinite(h).all() and (h >= 0).all() and h[:, :3].max() > 0
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="no /root/reference on this machine: the reference text cannot be compiled here")
+@pytest.mark.parametrize("dim,nlights,seed", [(16, 0, 1), (32, 3, 2), (128, 2, 3)])
+def test_oracle_cube_matches_live_reference_text(dim, nlights, seed):
+    rng = np.random.default_rng(seed)
+    sc = dict(CASES["sky_32_discs"]); rgb, tw, cm = sc["env"]
+    src = (rng.random((96, 192, 3), np.float32) ** 4 * 40.0).astype(np.float32)          # noisy HDR source: every bilinear tap matters
+    d = rng.normal(size=(3, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    lights = np.concatenate([rng.random((3, 3)), rng.random((3, 1)) * 3, d, np.array([[0.02], [0.3], [1.2]])], axis=1).astype(np.float32)
+    sc["env"] = (src, tw, cm); sc["env_cube_dim"] = dim; sc["env_directional_lights"] = lights[:nlights] if nlights else None
+    (a, da, la), o = _cube(sc, reference=True)
+    (b, _, _) = o.env_cube(reference=False)
+    assert np.array_equal(a, b) and da == dim and la == {16: 2, 32: 3, 128: 5}[dim]
+
+
+def test_cube_clamps_to_fp16_range_and_scales_by_quarter():
+    """GenerateTexel: radiance x c_envMapRadianceScale (1/4, Sample.cpp:88) clamped to [0, HLF_MAX] (EnvMapBaker.hlsl:236-242)."""
+    sc = dict(CASES["sky_16"]); rgb, tw, cm = sc["env"]
+    src = np.full((32, 64, 3), 8.0, np.float32); src[:16] = 1e6
+    sc["env"] = (src, tw, cm); sc["env_cube_dim"] = 32
+    (cube, dim, levels), _ = _cube(sc)
+    h = _half(cube); sl = _mip_slices(dim, levels)
+    top = h[sl[0][0]:sl[0][1]].reshape(6, dim, dim, 4)
+    assert np.all(top[3, :, :, :3] == 2.0)                       # -Y face: 8 x 1/4
+    assert np.all(top[2, :, :, :3] == 65504.0)                   # +Y face: clamped
+    assert h.max() == 65504.0 and np.isfinite(h).all()
+
+
+def test_constant_source_stays_constant_through_the_mips():
+    sc = dict(CASES["sky_16"]); rgb, tw, cm = sc["env"]
+    sc["env"] = (np.full((16, 32, 3), 1.7, np.float32) * np.array([1.0, 2.0, 3.0], np.float32), tw, cm); sc["env_cube_dim"] = 64
+    (cube, dim, levels), _ = _cube(sc)
+    h = _half(cube); want = np.array([1.7, 3.4, 5.1], np.float32) * 0.25
+    for a, b, d in _mip_slices(dim, levels):
+        assert np.abs(h[a:b, :3] / want - 1.0).max() < 2e-3, d         # fp16 rounding of the weighted mean of equal values: 1 ulp at most
+    assert levels == 4 and (dim >> (levels - 1)) == 8                  # mips stop at 8x8 (EnvMapBaker.cpp:318-320)
+
+
+def test_baked_disc_carries_the_lights_energy():
+    """ComputeLightContribution draws radiance = colour x intensity / solidAngle(disc): integrated over the cube's texels (x4 to undo the radiance scale)
+    the disc returns colour x intensity, within the coverage approximation the reference documents as 'not physically correct' (EnvMapBaker.hlsl:164-165)."""
+    sc = dict(CASES["sky_16"]); rgb, tw, cm = sc["env"]
+    d = np.array([0.3, -0.7, 0.2]); d /= np.linalg.norm(d)
+    base = dict(sc); base["env"] = (np.zeros((16, 32, 3), np.float32), tw, cm); base["env_cube_dim"] = 256
+    lit = dict(base); lit["env_directional_lights"] = np.array([[1.0, 0.5, 0.25, 2.0, d[0], d[1], d[2], 0.25]], np.float32)
+    (cube, dim, levels), _ = _cube(lit)
+    h = _half(cube)[:6 * dim * dim, :3].reshape(6, dim, dim, 3).astype(np.float64)
+    c = (np.arange(dim) + 0.5) * 2.0 / dim - 1.0
+    area = lambda x, y: np.arctan2(x * y, np.sqrt(x * x + y * y + 1.0))
+    x0, x1 = c - 1.0 / dim, c + 1.0 / dim
+    sa = area(x0[None, :], x0[:, None]) - area(x0[None, :], x1[:, None]) - area(x1[None, :], x0[:, None]) + area(x1[None, :], x1[:, None])
+    assert abs(6 * sa.sum() - 4 * np.pi) < 1e-9
+    e = (h * sa[None, :, :, None]).sum(axis=(0, 1, 2)) * 4.0
+    assert np.allclose(e, np.array([1.0, 0.5, 0.25]) * 2.0, rtol=0.06), e
+    # and the disc sits where the light comes from (-Direction)
+    f, y, x = np.unravel_index(np.argmax(h[..., 0]), h.shape[:3])
+    assert f == 2 and -d[1] > max(abs(d[0]), abs(d[2]))              # +Y face
+
+
+def test_cube_fetch_at_texel_centres_and_integer_lods_returns_the_texel():
+    """TextureCube.SampleLevel restated (envcube.h): a direction through a texel centre at an integer lod reads exactly that texel; lod clamps to the chain."""
+    sc = CASES["sky_32_discs"]
+    (cube, dim, levels), o = _cube(sc)
+    h = _half(cube); cm4 = np.asarray(sc["env"][2], np.float32) * np.float32(4.0)
+    rng = np.random.default_rng(5)
+    rows, want = [], []
+    for a, b, d in _mip_slices(dim, levels):
+        lod = int(np.log2(dim // d))
+        for _ in range(64):
+            f, y, x = int(rng.integers(6)), int(rng.integers(d)), int(rng.integers(d))
+            cx, cy = (x + 0.5) * 2.0 / d - 1.0, 1.0 - (y + 0.5) * 2.0 / d
+            dirv = [(1, cy, -cx), (-1, cy, cx), (cx, 1, -cy), (cx, -1, cy), (cx, cy, 1), (-cx, cy, -1)][f]
+            rows.append([dirv[0] * 3.0, dirv[1] * 3.0, dirv[2] * 3.0, float(lod)])       # unnormalised: the fetch only uses ratios
+            want.append(h[a + (f * d + y) * d + x, :3] * cm4)
+    got = o.env_eval(np.array(rows, np.float32))
+    assert np.allclose(got, np.array(want, np.float32), rtol=2e-6, atol=0)
+    far = o.env_eval(np.array([[0.2, 0.9, 0.1, 50.0], [0.2, 0.9, 0.1, float(levels - 1)], [0.2, 0.9, 0.1, -3.0], [0.2, 0.9, 0.1, 0.0]], np.float32))
+    assert np.array_equal(far[0], far[1]) and np.array_equal(far[2], far[3])
+
+
+def test_cube_fetch_is_continuous_across_face_edges():
+    """Bilinear taps are clamped to the face the direction selects (no cross-face filtering in this restatement); across an edge the two faces' border
+    texels are neighbours in the source image, so the fetch may step by at most their difference — and must never read outside the cube."""
+    sc = CASES["sky_32_discs"]
+    _, o = _cube(sc)
+    t = np.linspace(-1.0, 1.0, 257, dtype=np.float32)
+    eps = np.float32(1e-3)
+    a = o.env_eval(np.stack([np.ones_like(t), t, np.full_like(t, 1.0 - eps), np.zeros_like(t)], 1))      # just on the +X side of the +X/+Z edge
+    b = o.env_eval(np.stack([np.full_like(t, 1.0 - eps), t, np.ones_like(t), np.zeros_like(t)], 1))      # just on the +Z side
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert np.abs(a - b).max() <= 0.35 * max(a.max(), b.max())

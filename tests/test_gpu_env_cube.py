@@ -1,0 +1,91 @@
+"""GPU parity of the environment-cube bake (run with -m gpu): k_env_cube_base / k_env_cube_mip and the device cube fetch against the oracle and against
+the committed reference-text cubes (tests/golden/env_cube_golden.npz), bit for bit; then the sizes the bench uses (2048: EnvMapBaker's resolution for an
+image source)."""
+import os, sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "env_cube_golden.npz")
+
+
+def _imports():
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    from oracle import ptref
+    import pin_scenes
+    return pt, scenes, ptref, pin_scenes
+
+
+@pytest.mark.parametrize("name", ["sky_16", "sky_32_discs", "sky_64_hdr_sun"])
+def test_device_cube_matches_reference_text_golden_and_oracle(name):
+    pt, scenes, ptref, pin_scenes = _imports()
+    sc = pin_scenes.env_cube_cases()[name]
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(scenes.default_settings())
+    cube, dim, levels = g.env_cube()
+    gold = np.load(GOLDEN)
+    assert (dim, levels) == tuple(int(v) for v in gold[name + "_dim"])
+    bad = (cube != gold[name]).any(-1)
+    assert not bad.any(), "%s: %d of %d texels differ from the reference-text bake" % (name, int(bad.sum()), bad.size)
+    o = ptref.Oracle(); o.set_scene(sc)
+    assert np.array_equal(cube, o.env_cube()[0])
+
+
+def test_device_cube_fetch_matches_oracle():
+    """EnvMap::EvalLocal on the device (pt_probe kind 9) == the oracle's, on random directions and lods (fractional, negative, beyond the chain), on
+    directions along face edges and corners, and on axis-aligned ones."""
+    pt, scenes, ptref, pin_scenes = _imports()
+    sc = pin_scenes.env_cube_cases()["sky_64_hdr_sun"]
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(scenes.default_settings())
+    o = ptref.Oracle(); o.set_scene(sc)
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    lod = (rng.random(20000) * 6.0 - 1.0).astype(np.float32); lod[::7] = np.floor(lod[::7])
+    edge = np.array([[1, 1, 0.3], [1, -1, 0.3], [1, 1, 1], [-1, 1, -1], [0, 0, 1], [0, 1, 0], [-1, 0, 0], [1, 0.999999, 0.2], [0.5, 0.5, 0.5000001], [1e-20, 1, 1e-20]], np.float32)
+    rows = np.concatenate([np.concatenate([d, lod[:, None]], 1), np.concatenate([edge, np.zeros((len(edge), 1), np.float32)], 1),
+                           np.concatenate([edge, np.full((len(edge), 1), 1.5, np.float32)], 1)]).astype(np.float32)
+    got = g.probe(9, rows, (len(rows), 3))
+    want = o.env_eval(rows)
+    bad = (got.view(np.uint32) != want.view(np.uint32)).any(-1)
+    assert not bad.any(), "%d of %d fetches differ; first %s: %s vs %s" % (int(bad.sum()), len(rows), rows[bad][0], got[bad][0], want[bad][0])
+
+
+def test_device_cube_2048_with_discs_matches_oracle_and_rebakes_on_change():
+    """EnvMapBaker's resolution for an image source (2048, EnvMapBaker.cpp:303) with directional lights: 28 M texels equal the oracle's; changing the lights
+    re-bakes (and the environment quad-tree lights with it); a frame rendered afterwards equals the oracle's."""
+    pt, scenes, ptref, pin_scenes = _imports()
+    make, S, w, h, first, n = pin_scenes.cases()["c2_sun_discs"]
+    sc, cam = make(); sc = dict(sc); sc["env_cube_dim"] = 2048
+    camd = scenes.bridge_camera(w, h, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(w, h)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)
+    cube, dim, levels = g.env_cube()
+    assert (dim, levels) == (2048, 9) and cube.shape[0] == sum(6 * (2048 >> l) ** 2 for l in range(9))
+    assert np.array_equal(cube, o.env_cube()[0])
+    g.render(first, n); o.render(first, n)
+    assert np.array_equal(g.radiance().view(np.uint32), o.radiance().view(np.uint32))
+    lights0 = g.lights()
+    sc2 = dict(sc); sc2["env_directional_lights"] = sc["env_directional_lights"][:1] * np.array([1, 1, 1, 3.0, 1, 1, 1, 2.0], np.float32)
+    g.set_scene(sc2); o.set_scene(sc2)
+    assert np.array_equal(g.env_cube()[0], o.env_cube()[0]) and not np.array_equal(g.env_cube()[0], cube)
+    lights1 = g.lights()
+    assert not np.array_equal(lights0["lights"][:100], lights1["lights"][:100])              # the quad-tree lights are made from the cube
+    g.reset_accumulation(); o.reset_accumulation(); g.render(first, n); o.render(first, n)
+    assert np.array_equal(g.radiance().view(np.uint32), o.radiance().view(np.uint32))
+
+
+def test_environment_bake_argument_validation():
+    pt, scenes, ptref, pin_scenes = _imports()
+    import ctypes
+    g = pt.PathTracer()
+    lights = (ctypes.c_float * (8 * 17))()
+    assert g.L.pt_set_environment_bake(g.h, 100, None, 0) != 0            # not a power of two
+    assert g.L.pt_set_environment_bake(g.h, 8, None, 0) != 0              # below the 8x8 mip floor
+    assert g.L.pt_set_environment_bake(g.h, 16384, None, 0) != 0
+    assert g.L.pt_set_environment_bake(g.h, 256, None, 2) != 0            # lights missing
+    assert g.L.pt_set_environment_bake(g.h, 256, lights, 17) != 0         # EMB_MAXDIRLIGHTS
+    assert g.L.pt_set_environment_bake(g.h, 0, lights, 16) == 0           # 0 keeps the resolution
+    assert g.L.pt_set_environment_bake(g.h, 256, None, 0) == 0
+    n = ctypes.c_uint32(7)
+    assert g.L.pt_get_env_cube(g.h, ctypes.byref(n), None, None, None, 0) == 0 and n.value == 0      # no environment set: no cube
