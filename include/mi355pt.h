@@ -171,6 +171,10 @@ int32_t pt_set_environment(pt_context* ctx, const float* rgbLatLong, uint32_t wi
  * fp16 range, and the scene's directional lights drawn into it as anti-aliased discs (Sample::UpdateLighting, Sample.cpp:1361-1388). At most 16 lights
  * (EMB_MAXDIRLIGHTS). The bake runs on the device at the next pt_render / pt_prepare. */
 int32_t pt_set_environment_bake(pt_context* ctx, uint32_t cubeDim, const PtEnvDirectionalLight* directionalLights, uint32_t numDirectionalLights);
+/* Sample::UpdateLighting (Rtxpt/Sample.cpp:1361-1388), the host step in front of EnvMapBaker::Update: world-space directional lights -> the records
+ * pt_set_environment_bake takes. AngularSize is raised to pi / (cubeDim / 2) (smaller discs cannot be drawn into the cube), Direction is taken into the
+ * environment's local frame with params->Transform (NULL: identity) so the disc keeps its world direction under an environment rotation. No device needed. */
+int32_t pt_env_bake_lights(const PtEnvDirectionalLight* worldLights, uint32_t numLights, const PtEnvMapSceneParams* params, uint32_t cubeDim, PtEnvDirectionalLight* out);
 /* analytic lights already converted by the host (LightsBaker.cpp:456-556 ConvertLight); emissive triangles are baked automatically */
 int32_t pt_set_lights(pt_context* ctx, const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint32_t numLights);
 
@@ -231,7 +235,7 @@ int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo*
      `<media>/Materials/[<scene>/][<model>.]<material>.material.json` overrides in the reference's candidate order, through pt_material_from_json
      (a document replaces the glTF material as a whole; SkipRender removes the geometries, EnableAlphaTesting / ExcludeFromNEE set their flags).
    The file format of the graph itself and the light / camera keys belong to Donut (donut/engine/Scene.cpp, SceneGraph.cpp), which the reference
-   tree does not vendor: they are restated from Donut's published sources. Not imported: DirectionalLight (LightsBaker skips it too), animations,
+   tree does not vendor: they are restated from Donut's published sources. DirectionalLight leaves are returned by pt_scene_import_directional_lights. Not imported: animations,
    glTF-embedded cameras / lights, analytic-light proxies (counted in info), textures other than 8-bit PNG (counted in texturesNotLoaded, the
    material then renders untextured as when the reference fails to load one). The environment map is reported, not loaded (.exr / .dds). NOTE: of
    an EnvironmentLight the reference application consumes only `path` (Sample.cpp:552-553); radianceScale / rotation / textureIndex are read by
@@ -261,6 +265,11 @@ void    pt_scene_import_free(pt_scene_import* scene);
 /* copies of the imported arrays, up to `capacity` records; return the number available (negative: error) */
 int32_t pt_scene_import_cameras(const pt_scene_import* scene, PtSceneCameraDesc* out, uint32_t capacity);
 int32_t pt_scene_import_lights(const pt_scene_import* scene, PolymorphicLightInfo* base, PolymorphicLightInfoEx* ex, uint32_t capacity);
+/* DirectionalLight leaves (Donut keys color, irradiance, angularSize [deg]) as EMB_DirectionalLight records in WORLD space: ColorIntensity = (color,
+   irradiance), Direction = the node's -Z, AngularSize = radians(clamp(angularSize, 0, 90)) (DirectionalLight::FillLightConstants, restated from Donut's
+   published sources; the reference reads the same fields: Rtxpt/RTXDI/PrepareLightsPass.cpp:246-249). LightsBaker does not take them (LightsBaker.cpp:600):
+   they go through pt_env_bake_lights into pt_set_environment_bake. */
+int32_t pt_scene_import_directional_lights(const pt_scene_import* scene, PtEnvDirectionalLight* out, uint32_t capacity);
 int32_t pt_scene_import_instances(const pt_scene_import* scene, PtInstanceDesc* out, uint32_t capacity);
 int32_t pt_scene_import_geometries(const pt_scene_import* scene, PtGeometryDesc* out, uint32_t capacity);
 int32_t pt_scene_import_materials(const pt_scene_import* scene, PTMaterialData* out, uint32_t capacity);

@@ -24,13 +24,13 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 # every symbol include/mi355pt.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
-    "pt_set_environment", "pt_set_environment_bake", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_set_environment", "pt_set_environment_bake", "pt_env_bake_lights", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
     "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
-    "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
+    "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host",
 ]
@@ -283,6 +283,19 @@ class PtAnalyticLightDesc(ctypes.Structure):
                 ("radius", ctypes.c_float), ("innerAngle", ctypes.c_float), ("outerAngle", ctypes.c_float)]
 
 
+def env_bake_lights(world_lights, cube_dim, transform=None):
+    """pt_env_bake_lights (Sample::UpdateLighting): world-space rows of EMB_DirectionalLight -> the rows pt_set_environment_bake takes (angular size raised to
+    what the cube resolves, direction in the environment's local frame). transform: the 12 floats of EnvMapSceneParams.Transform or None. No device needed."""
+    L = load_library()
+    a = np.ascontiguousarray(world_lights, np.float32).reshape(-1, 8); out = np.zeros_like(a)
+    p = None
+    if transform is not None:
+        p = PtEnvMapSceneParams((ctypes.c_float * 12)(*np.asarray(transform, np.float32).tolist()), (ctypes.c_float * 3)(1.0, 1.0, 1.0), 1.0)
+    r = L.pt_env_bake_lights(_p(a) if len(a) else None, len(a), ctypes.byref(p) if p is not None else None, int(cube_dim), _p(out) if len(a) else None)
+    if r != PT_OK: raise PtError(r, "pt_env_bake_lights")
+    return out
+
+
 def convert_light(kind, position, color, intensity, radius, direction=(0.0, -1.0, 0.0), inner_angle=0.0, outer_angle=0.0):
     """pt_convert_light (LightsBaker::ConvertLight): kind "point" / "spot" -> (8 words PolymorphicLightInfo, 4 words PolymorphicLightInfoEx) as uint32 arrays. No device needed."""
     L = load_library()
@@ -339,6 +352,11 @@ class SceneImport:
         self.L.pt_scene_import_lights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         assert self.L.pt_scene_import_lights(self.h, _p(self.lights), _p(self.lights_ex), n) == n
         self.lights, self.lights_ex = self.lights[:n], self.lights_ex[:n]
+        self.L.pt_scene_import_directional_lights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        nd = self.L.pt_scene_import_directional_lights(self.h, None, 0)
+        self.directional_lights = np.zeros((max(nd, 1), 8), np.float32)      # rows of EMB_DirectionalLight in world space: colour rgb, irradiance, direction xyz, angular size [rad]
+        assert self.L.pt_scene_import_directional_lights(self.h, _p(self.directional_lights), nd) == nd
+        self.directional_lights = self.directional_lights[:nd]
 
     def tone_mapping(self, ui=None, camera=-1):
         """pt_scene_import_tone_mapping: Sample::SceneLoaded's exposure defaults + Sample::UpdateCameraFromScene on a ToneMappingParameters record."""

@@ -446,6 +446,7 @@ struct pt_scene_import {
     std::vector<PtGeometryDesc> geoms; std::vector<PtMeshDesc> meshes; std::vector<PtInstanceDesc> instances; std::vector<PTMaterialData> materials;
     std::vector<std::vector<uint8_t>> texPixels; std::vector<PtTextureDesc> texDescs;
     std::vector<PolymorphicLightInfo> lights; std::vector<PolymorphicLightInfoEx> lightsEx; std::vector<PtSceneCameraDesc> cameras;
+    std::vector<PtEnvDirectionalLight> directionalLights;
     PtSceneJsonInfo info;
 };
 
@@ -585,7 +586,20 @@ struct SceneReader {
             int32_t r = pt_convert_light(&d, &b, &e);
             if (r != PT_OK) { err = r; return; }
             S.lights.push_back(b); S.lightsEx.push_back(e);
-        } else if (type == "DirectionalLight") { I.directionalLights++; }                    // not part of the baked light set (LightsBaker.cpp:600)
+        } else if (type == "DirectionalLight") {                                             // not part of LightsBaker's light set (LightsBaker.cpp:600): baked into the environment cube
+            I.directionalLights++;                                                           // (Sample::UpdateLighting, Sample.cpp:1361-1388). Donut keys: color, irradiance, angularSize [deg]
+            PtEnvDirectionalLight d; memset(&d, 0, sizeof(d));
+            float color[3] = {1.f, 1.f, 1.f}, irradiance = 1.f, angularSize = 0.f;
+            double v[3]; if (jvec(n.get("color"), v, 3)) for (int i = 0; i < 3; i++) color[i] = (float)v[i];
+            jload(n, "irradiance", irradiance); jload(n, "angularSize", angularSize);
+            float cx = color[0] * irradiance, cy = color[1] * irradiance, cz = color[2] * irradiance;
+            if (sqrtf(cx * cx + cy * cy + cz * cz) <= 1e-7f) { I.lightsDropped++; return; }     // Sample.cpp:567-573
+            double len = sqrt(zx * zx + zy * zy + zz * zz); if (!(len > 0)) len = 1;
+            d.ColorIntensity[0] = color[0]; d.ColorIntensity[1] = color[1]; d.ColorIntensity[2] = color[2]; d.ColorIntensity[3] = irradiance;      // DirectionalLight::FillLightConstants
+            d.Direction[0] = (float)(-zx / len); d.Direction[1] = (float)(-zy / len); d.Direction[2] = (float)(-zz / len);
+            d.AngularSize = std::min(std::max(angularSize, 0.f), 90.f) * (3.141592654f / 180.f);
+            S.directionalLights.push_back(d);
+        }
         else if (type == "PerspectiveCamera" || type == "PerspectiveCameraEx") {           // ExtendedScene.cpp:329-338 + Sample::UpdateCameraFromScene
             PtSceneCameraDesc c; memset(&c, 0, sizeof(c)); c.verticalFov = 1.f; c.zNear = 1.f;
             jload(n, "verticalFov", c.verticalFov); jload(n, "zNear", c.zNear);
@@ -677,6 +691,12 @@ extern "C" int32_t pt_scene_import_lights(const pt_scene_import* scene, Polymorp
     size_t n = scene->lights.size() < capacity ? scene->lights.size() : capacity;
     if (n) { memcpy(base, scene->lights.data(), n * sizeof(PolymorphicLightInfo)); memcpy(ex, scene->lightsEx.data(), n * sizeof(PolymorphicLightInfoEx)); }
     return (int32_t)scene->lights.size();
+}
+extern "C" int32_t pt_scene_import_directional_lights(const pt_scene_import* scene, PtEnvDirectionalLight* out, uint32_t capacity) {
+    if (!scene || (capacity && !out)) return -PT_ERROR_INVALID_ARGUMENT;
+    size_t n = scene->directionalLights.size() < capacity ? scene->directionalLights.size() : capacity;
+    if (n) memcpy(out, scene->directionalLights.data(), n * sizeof(PtEnvDirectionalLight));
+    return (int32_t)scene->directionalLights.size();
 }
 // Sample::SceneLoaded, Rtxpt/Sample.cpp:613-629: m_ui.BounceCount / DiffuseBounceCount / TexLODBias = value_or(current). realtimeMode, enableAnimations and
 // realtimeFireflyFilter steer the realtime path and the animation clock, which the reference-mode settings block does not hold.

@@ -97,3 +97,21 @@ extern "C" int32_t pt_convert_light(const PtAnalyticLightDesc* l, PolymorphicLig
     *base = p; *ex = e;
     return PT_OK;
 }
+
+// Sample::UpdateLighting (Rtxpt/Sample.cpp:1361-1388): the scene's directional lights as EnvMapBaker takes them. The angular size is raised to what the cube
+// can resolve (pi / (cubeDim / 2)), and the direction goes into the environment's local frame (`rotationTransform.transformVector`, which is what the
+// shader's EnvMap::ToLocal computes with InvTransform: EnvMap.hlsli:78-81) so that the disc keeps its world direction when the environment is rotated.
+extern "C" int32_t pt_env_bake_lights(const PtEnvDirectionalLight* world, uint32_t n, const PtEnvMapSceneParams* params, uint32_t cubeDim, PtEnvDirectionalLight* out) {
+    if ((n && (!world || !out)) || !cubeDim) return PT_ERROR_INVALID_ARGUMENT;
+    const float minAngularSize = PI_f / ((float)cubeDim / 2.0f);
+    for (uint32_t i = 0; i < n; i++) {
+        PtEnvDirectionalLight l = world[i];
+        l.AngularSize = std::max(l.AngularSize, minAngularSize);
+        if (params) {                                 // InvTransform = transpose of the rotation in Transform (row r of Transform: params->Transform[4 r .. 4 r + 2])
+            const float* T = params->Transform; const float x = world[i].Direction[0], y = world[i].Direction[1], z = world[i].Direction[2];
+            for (int j = 0; j < 3; j++) l.Direction[j] = (x * T[4 * j + 0] + y * T[4 * j + 1]) + z * T[4 * j + 2];       // mul(dir, (float3x3)InvTransform), InvTransform[i][j] = Transform[j][i]
+        }
+        out[i] = l;
+    }
+    return PT_OK;
+}

@@ -202,8 +202,9 @@ def test_gltf_import_equals_raw_buffers(tmp_path):
     a = pt.PathTracer(); a.set_scene(sc2); a.set_camera(camd); a.set_settings(S); a.resize(w, h); a.render(0, 2)
     b = pt.PathTracer(); b.load_scene_gltf(path)
     rgb, tw, cm = sc["env"]
-    p = pt.PtEnvMapSceneParams((ctypes.c_float * 12)(*tw.tolist()), (ctypes.c_float * 3)(*cm.tolist()), 1.0)
+    p = pt.PtEnvMapSceneParams((ctypes.c_float * 12)(*tw.tolist()), (ctypes.c_float * 3)(*(cm * np.float32(4.0)).tolist()), 1.0)      # intensity / c_envMapRadianceScale (Sample.cpp:1939)
     assert b.L.pt_set_environment(b.h, rgb.ctypes.data_as(ctypes.c_void_p), rgb.shape[1], rgb.shape[0], ctypes.byref(p)) == 0
+    assert b.L.pt_set_environment_bake(b.h, 256, None, 0) == 0                     # the cube resolution set_scene uses for `a` (the C default is EnvMapBaker's 2048)
     b.set_camera(camd); b.set_settings(S); b.resize(w, h); b.render(0, 2)
     assert b.scene_info()["triangles"] == a.scene_info()["triangles"]
     assert np.array_equal(a.subinstances(), b.subinstances())

@@ -90,6 +90,8 @@ def test_scene_graph_instances_lights_cameras(tmp_path):
     assert np.allclose(d, (0, 1, 0), atol=1e-12)              # +90 degrees about X turns -Z into +Y
     b, e = pt.convert_light("point", (0.1, 1.1, 0.1), (0.5, 0.5, 0.5), 20.0, 0.02, (0.0, 0.0, -1.0), 180.0, 180.0)
     assert np.array_equal(imp.lights[1], b) and np.array_equal(imp.lights_ex[1], e)
+    # the directional light is handed out as an EMB_DirectionalLight record (world space) for the environment-cube bake: Donut defaults colour 1, angularSize 0
+    assert imp.directional_lights.shape == (1, 8) and np.array_equal(imp.directional_lights[0], np.array([1, 1, 1, 3.0, 0, 0, -1, 0], np.float32))
     # cameras (Sample::UpdateCameraFromScene): a half turn about Y makes the glTF-style -Z camera look along +Z
     assert I["numCameras"] == 2 and I["selectedCamera"] == 0
     c0, c1 = imp.cameras
@@ -283,6 +285,7 @@ def test_scene_leaves_match_reference_text(tmp_path):
         imp = pt.SceneImport(path); I = imp.info
         ctx = (case, doc)
         assert I["numLights"] == ref["numLights"] and I["directionalLights"] >= ref["directional"] and I["lightProxies"] == ref["proxies"], ctx
+        assert len(imp.directional_lights) == ref["directional"], ctx            # the ones Sample::SceneLoaded's clean-up keeps (Sample.cpp:563-570)
         n = min(int(I["numLights"]), 16)
         assert np.array_equal(np.concatenate([imp.lights, imp.lights_ex], axis=1)[:n], ref["lights"][:n]), ctx
         assert I["numCameras"] == ref["numCameras"] and I["hasEnvironment"] == ref["hasEnvironment"], ctx
@@ -404,3 +407,30 @@ def test_hostile_gltf_documents_return_error_codes(tmp_path):
     for text in ("[" * 100000, '{"Roughness": 0.', '{"Name": "\\u'):
         with pytest.raises(pt.PtError):
             pt.material_from_json(text)
+
+
+def test_directional_light_records_and_bake_helper(tmp_path):
+    """DirectionalLight leaves -> EMB_DirectionalLight rows (colour, irradiance, the node's -Z, radians(clamp(angularSize, 0, 90))); pt_env_bake_lights is
+    Sample::UpdateLighting's preprocessing (Sample.cpp:1361-1388): angular size raised to pi / (cubeDim / 2), direction into the environment's local frame."""
+    graph = [{"name": "sun", "type": "DirectionalLight", "rotation": [0.7071067811865476, 0.0, 0.0, 0.7071067811865476], "color": [1.0, 0.9, 0.8], "irradiance": 2.5, "angularSize": 0.53},
+             {"name": "wide", "type": "DirectionalLight", "rotation": list(Q_Y90), "angularSize": 400.0},
+             {"name": "dark", "type": "DirectionalLight", "irradiance": 0.0}]
+    path = tmp_path / "d.scene.json"; path.write_text(json.dumps({"models": [], "graph": graph}))
+    imp = pt.SceneImport(path)
+    assert imp.info["directionalLights"] == 3 and imp.info["lightsDropped"] == 1
+    d = imp.directional_lights
+    assert d.shape == (2, 8)
+    assert np.array_equal(d[0, :4], np.array([1.0, 0.9, 0.8, 2.5], np.float32)) and np.allclose(d[0, 4:7], (0, 1, 0), atol=1e-7) and abs(d[0, 7] - math.radians(0.53)) < 1e-8
+    assert np.allclose(d[1, 4:7], (-1, 0, 0), atol=1e-7) and abs(d[1, 7] - math.pi / 2) < 1e-6          # clamped to 90 degrees; +90 degrees about Y turns -Z into -X
+    out = pt.env_bake_lights(d, 2048)
+    assert np.array_equal(out[:, :7], d[:, :7])
+    assert out[0, 7] == d[0, 7] > np.float32(3.141592654) / np.float32(1024.0) and out[1, 7] == d[1, 7]            # a 0.53 degree sun is wider than three 2048-cube texels
+    assert pt.env_bake_lights(d, 256)[0, 7] == np.float32(3.141592654) / np.float32(128.0)                  # a 0.53 degree sun cannot be drawn into a 256 cube: widened
+    # rotated environment: the baked direction is EnvMap::ToLocal(direction) = mul(dir, (float3x3)InvTransform), InvTransform = Transform^T for a rotation
+    yaw = 0.7; R = np.array([[math.cos(yaw), 0, math.sin(yaw)], [0, 1, 0], [-math.sin(yaw), 0, math.cos(yaw)]])
+    T = np.concatenate([R, np.zeros((3, 1))], axis=1).astype(np.float32).reshape(-1)
+    rot = pt.env_bake_lights(d, 2048, transform=T)
+    assert np.allclose(rot[:, 4:7], d[:, 4:7].astype(np.float64) @ np.asarray(R, np.float64).T, atol=1e-6)
+    assert np.allclose(np.linalg.norm(rot[:, 4:7], axis=1), 1.0, atol=1e-6)
+    with pytest.raises(pt.PtError):
+        pt.env_bake_lights(d, 0)
