@@ -171,7 +171,10 @@ def main():
         traffic = cj["hbm_bytes_per_launch"]; hbm_counter_gbs = cj["hbm_counter_gbs"]; l2 = cj["l2_hit_rate"]
         valu = {"busy": cj["valu_busy"], "lane_utilisation": cj["lane_utilisation"], "valu_instructions_per_vmem_read": cj["valu_per_vmem_read"],
                 "wait_any_share_of_wave_cycles": cj["wait_any_share_of_wave_cycles"]}
-        bound = "valu" if (cj["valu_busy"] or 0) > 0.6 and (hbm_counter_gbs or 0) < 0.5 * HBM_PEAK_GBS else ("hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else "latency")
+        # HBM runs at ~15 % of peak, and VALU issue is not the limit either: a build of k_extend with 18 % fewer VALU instructions (same rays, nodes, triangles)
+        # is no faster while one resident wave per SIMD less costs 7 % (profiles/r02k_isa_experiments.txt). What is left is the latency of each ray's dependent
+        # chain (node fetch -> slab test -> child sort -> next node) times the waves in flight.
+        bound = "hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else "latency"
 
     if rank == 0:
         info = g.scene_info()
@@ -187,6 +190,7 @@ def main():
             # the BVH is served from L1/L2, HBM itself carries `hbm_counter_gbs`, and the VALU issue slots are what is full.
             "roofline": {"bound": bound, "prescribed_bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "hbm_counter_gbs": hbm_counter_gbs, "l2_hit_rate": l2, "valu": valu, "counters_source": counters_src,
+                         "bound_evidence": "profiles/r02k_isa_experiments.txt: -18 % VALU instructions = 0 % time, 6 -> 5 waves per SIMD = +7 % time, HBM at 15 % of peak",
                          "whole_frame": {"algorithmic_bytes_per_step": frame_bytes, "achieved": frame_gbs, "frac": frame_gbs / HBM_PEAK_GBS,
                                          "terms": "extend rays x (52 + 128 nodes + 48 tris) + hits x 656 + shadow rays x (80 + 128 nodes + 48 tris), over the pipelined step time"},
                          "bytes_per_ray": bytes_per_ext, "node_visits_per_ray": nodes_per_ext, "tri_tests_per_ray": tris_per_ext,

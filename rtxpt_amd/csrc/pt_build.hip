@@ -3,7 +3,7 @@
 #include <rocprim/rocprim.hpp>
 
 #ifndef PT_PLOC_RADIUS
-#define PT_PLOC_RADIUS 16      // PLOC search window to either side (tools/bvh_lab: SAH cost 154 / 147 / 143 for 8 / 16 / 32 on C3; Karras 283)
+#define PT_PLOC_RADIUS 32      // PLOC search window to either side (tools/bvh_lab: SAH cost 154 / 147 / 143 for 8 / 16 / 32 on C3; Karras 283; on the GPU 32 is +1.7 % Mrays/s over 16, profiles/r02k_isa_experiments.txt)
 #endif
 #ifndef PT_RANGE_TABLE_MAX_TRIS
 #define PT_RANGE_TABLE_MAX_TRIS (16u << 20)     // above this the n log n sparse table (32 B x n x log2 n) gives way to the ticket-based k_bounds

@@ -99,7 +99,9 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     const uint laneChildOff = 16u + 24u * q, laneTriOff = 48u * q;
     const uint INF_BITS = 0x7F800000u;
 
-    // chunk cursor: wave-uniform, kept in SGPRs (readfirstlane); the first refill advances to chunk `waveId`
+    // chunk cursor: wave-uniform, kept in SGPRs (readfirstlane); the first refill advances to chunk `waveId`. Chunks are dealt round robin over all waves
+    // of the launch: giving every XCD (blocks b with b % 8 == x) one contiguous eighth of the queue, so that its private L2 sees one band of the frame,
+    // was 3 % SLOWER on C3 (profiles/r02k_isa_experiments.txt): the bands differ in cost and the rays of later bounces are incoherent anyway.
     const uint numWavesU = (uint)__builtin_amdgcn_readfirstlane((int)numWaves);
     uint chunk = (uint)__builtin_amdgcn_readfirstlane((int)(waveId - numWaves)), chunkPos = 0u, chunkEnd = 0u;
     bool exhausted = (waveId * T8_CHUNK >= count) || !sc.rootIsValid;
@@ -133,9 +135,11 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
         }
     };
 
-    bool splitNow = false;
-  for (;;) {
-    while (true) {
+    // One back edge, one exit (`stop` is wave-uniform). With a `continue` and two `break`s the compiler kept two copies of the loop-carried ray state and
+    // moved one into the other at the top and at the bottom of every iteration (20 of ~340 VALU instructions, tools/isa_stats.sh); the single-exit form
+    // also needs 2 VGPRs fewer (78), and is 2 % (k_extend) / 7 % (k_shadow) faster. See DESIGN.md 4 "What the ISA experiments of round 2 say".
+    bool splitNow = false, stop = false;
+    while (!stop) {
         unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
         if (COUNT) tc0 = __builtin_readcyclecounter();
         // ---- refill idle quads from the wave's current chunk
@@ -195,13 +199,15 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 chunkPos = (uint)__builtin_amdgcn_readfirstlane((int)(chunkPos + ((n < avail) ? n : avail)));
             }
         }
-        if (t8_ballot(active) == 0ull) { if (t8_ballot(!exhausted) == 0ull) break; else continue; }
+        bool run = t8_ballot(active) != 0ull;                       // wave-uniform
+        if (!run) { if (t8_ballot(!exhausted) == 0ull) stop = true; }
 
         // ---- straggler splitting (after the loop, see below): out of fresh work for T8_TAIL_ITERS iterations -> stop and hand over what is in flight
-        if (CAN_SPLIT) {
+        else if (CAN_SPLIT) {
             if (waveDry) tailIters++;
-            if (tailIters > (uint)(TASKS ? T8_TAIL_ITERS_TASKS : T8_TAIL_ITERS)) { splitNow = true; break; }
+            if (tailIters > (uint)(TASKS ? T8_TAIL_ITERS_TASKS : T8_TAIL_ITERS)) { splitNow = true; stop = true; run = false; }
         }
+        if (run) {
 
         if (COUNT && lane == 0u) ctr.iters++;
         if (COUNT && active) rayIters++;
@@ -376,8 +382,9 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
             }
         }
         if (COUNT) { unsigned long long tc4 = __builtin_readcyclecounter(); ctr.cyc[0] += tc1 - tc0; ctr.cyc[1] += tc2 - tc1; ctr.cyc[2] += tc3 - tc2; ctr.cyc[3] += tc4 - tc3; }
+        }       // run
     }
-    if (!CAN_SPLIT || !splitNow) break;
+    if (CAN_SPLIT && splitNow)
     // ---- every ray still in flight becomes a list of sub-tree tasks: node slot, postponed leaves, stack entries (outside the loop: the loop
     //      body's temporaries are dead here, so this rare path does not cost the hot kernel registers)
     {
@@ -406,9 +413,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 tq[4u * k] = tag; tq[4u * k + 1u] = e.x; tq[4u * k + 2u] = e.y;
             }
         }
-        break;
     }
-  }
 }
 
 } // namespace ptk
