@@ -119,6 +119,11 @@ typedef struct PtDeviceDesc {
     uint32_t flags;                         /* PT_DEVICE_* */
 } PtDeviceDesc;
 #define PT_DEVICE_SERIAL_KERNELS 1u         /* one batch, one stream: kernels of a pt_render call never overlap (profiling / per-kernel timing) */
+#define PT_DEVICE_PREFER_FAST_BUILD 2u      /* scene builds (pt_set_geometry / pt_set_instances / pt_load_scene_gltf) use the device-side PLOC builder (15 ms at
+                                               2.8 M triangles) instead of the default: AccelStructBuildFlags::PreferFastTrace as the reference sets it
+                                               (Rtxpt/Sample.cpp:1093) = binned-SAH topology on the host's cores, 14-18 % fewer node visits per ray, a few
+                                               hundred ms. pt_animate(rebuild = 1) always builds fast; refits keep the topology they find. The image does
+                                               not depend on the tree. */
 
 typedef struct PtFrameStats {
     uint64_t extendRays, shadowRays, hits;                  /* "rays" of the Mrays/s metric = extendRays + shadowRays */

@@ -86,7 +86,7 @@ struct pt_context {
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
-    BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0; uint bvhBuilder = BVH_BUILDER_PLOC;
+    BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0; uint bvhBuilder = BVH_BUILDER_SAH;
     DeviceScene dsc;
     // frame state
     ptk::PtSettings S; ptk::PathTracerCameraData cam; uint width = 0, height = 0, accumCount = 0; std::vector<uint> owned; std::vector<std::vector<uint>> shardPixels;
@@ -467,7 +467,10 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) if (hipStreamCreateWithFlags(&c->streams[b], hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     if (hipHostMalloc(&c->hostCounters, PT_PIPELINE_BATCHES * sizeof(WaveCounters), hipHostMallocDefault) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     c->serialKernels = desc && (desc->flags & PT_DEVICE_SERIAL_KERNELS);
-    { const char* e = getenv("MI355PT_BVH_BUILDER"); if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; }      // developer A/B switch; PLOC is the default
+    // scene builds prefer fast trace (binned SAH, as the reference asks of its driver: Sample.cpp:1093) unless the host asks for fast builds; pt_animate's rebuilds are always PLOC
+    c->bvhBuilder = (desc && (desc->flags & PT_DEVICE_PREFER_FAST_BUILD)) ? BVH_BUILDER_PLOC : BVH_BUILDER_SAH;
+    { const char* e = getenv("MI355PT_BVH_BUILDER");        // developer A/B switch
+      if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; }
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
     const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.f);
@@ -682,7 +685,10 @@ int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, co
     refresh_scene_view(c);
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
-    if (rebuild) PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, c->stream)); else PT_CHECK_HIP(c, bvh_refit(c->bvh, c->dsc, c->numTris, c->stream));
+    if (rebuild) {                                     // a rebuild between animated frames prefers a fast build: PLOC on the device (15 ms at 2.8 M triangles)
+        if (c->bvh.builder == BVH_BUILDER_SAH) c->bvh.builder = BVH_BUILDER_PLOC;
+        PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, c->stream));
+    } else PT_CHECK_HIP(c, bvh_refit(c->bvh, c->dsc, c->numTris, c->stream));
     PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); if (rebuild) c->buildMs = ms; else c->refitMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

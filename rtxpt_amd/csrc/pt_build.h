@@ -6,6 +6,8 @@
 //   k_ploc_*        (default) PLOC, Meister & Bittner 2018: mutual-nearest-neighbour merging of the Morton-ordered clusters inside a window of
 //                   PT_PLOC_RADIUS, ~70 data-parallel passes; leaves are then renumbered in depth-first order so that every node covers a
 //                   contiguous leaf range again. Half the SAH cost of the Karras tree on C3 (tools/bvh_lab), 40 % fewer node visits per ray
+//   pt_build_sah    (BVH_BUILDER_SAH, "prefer fast trace": what the reference asks its driver for, Sample.cpp:1093) binned-SAH topology built on the host's
+//                   cores from the world-space triangle boxes; bounds, leaves, collapse and refit below are shared. 14-18 % fewer node visits than PLOC
 //   k_karras        (PT_BVH_BUILDER=karras) Karras 2012 hierarchy over the sorted codes (duplicate codes split on the index bits)
 //   k_leaf_boxes / k_range_level / k_node_boxes
 //                   node bounds WITHOUT inter-thread hand-offs: every Karras node covers a contiguous range of sorted leaves, so its two child
@@ -22,7 +24,7 @@
 
 namespace ptk {
 
-enum : uint { BVH_BUILDER_PLOC = 0, BVH_BUILDER_KARRAS = 1 };
+enum : uint { BVH_BUILDER_PLOC = 0, BVH_BUILDER_KARRAS = 1, BVH_BUILDER_SAH = 2 };      // SAH: topology by pt_build_sah.cpp on the host ("prefer fast trace")
 
 struct BvhBuildBuffers {
     TriRecord* triWorld;        // by global primitive id
@@ -42,7 +44,9 @@ struct BvhBuildBuffers {
     // PLOC work arrays (node ids while building: leaves 0..n-1 in Morton order, inner nodes n..2n-2 in creation order)
     uint* plocCl[2]; uint* plocNN; unsigned long long* plocFlags; unsigned long long* plocOffs; uint* plocChildA; uint* plocChildB; uint* plocCnt; uint* plocParent; uint* plocFirst; uint* plocCounts;
     void* scanTemp; size_t scanTempBytes; uint plocPasses;
-    uint builder;               // BVH_BUILDER_PLOC (default) or BVH_BUILDER_KARRAS
+    uint builder;               // BVH_BUILDER_PLOC ("prefer fast build"), BVH_BUILDER_SAH ("prefer fast trace") or BVH_BUILDER_KARRAS (developer A/B)
+    uint* absorb;               // BVH_BUILDER_SAH: per inner node, 1 = the cost-driven BVH8 collapse opens it inside its parent's wide node (pt_build_sah.cpp)
+    float hostBuildMs;          // BVH_BUILDER_SAH: the host part of the last build (read-back + SAH topology + upload)
     uint capacity;
 };
 

@@ -1,5 +1,8 @@
 // mi355pt — GPU LBVH build / refit kernels. See pt_build.h for the pipeline.
 #include "pt_build.h"
+#include "pt_build_sah.h"
+#include <chrono>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 #ifndef PT_PLOC_RADIUS
@@ -291,7 +294,8 @@ __device__ __forceinline__ void pad_box(float3& mn, float3& mx, float scenePad) 
 }
 __global__ void __launch_bounds__(256) k_emit(uint n, const uint* __restrict__ childL, const uint* __restrict__ childR, const uint* __restrict__ rangeFirst,
                                               const uint* __restrict__ rangeLast, const float4* __restrict__ boxLmin, const float4* __restrict__ boxLmax,
-                                              const float4* __restrict__ boxRmin, const float4* __restrict__ boxRmax, const uint* __restrict__ sceneBounds, BvhNode* __restrict__ nodes) {
+                                              const float4* __restrict__ boxRmin, const float4* __restrict__ boxRmax, const uint* __restrict__ sceneBounds, BvhNode* __restrict__ nodes,
+                                              const uint* __restrict__ absorb) {
     uint i = blockIdx.x * 256u + threadIdx.x;
     float3 smn = make_float3(dec_float(sceneBounds[0]), dec_float(sceneBounds[1]), dec_float(sceneBounds[2]));
     float3 smx = make_float3(dec_float(sceneBounds[3]), dec_float(sceneBounds[4]), dec_float(sceneBounds[5]));
@@ -309,19 +313,20 @@ __global__ void __launch_bounds__(256) k_emit(uint n, const uint* __restrict__ c
     uint cnt = rangeLast[i] - rangeFirst[i] + 1u;
     if (i != 0u && cnt <= BVH_MAX_LEAF) return;            // collapsed into its parent's leaf reference
     uint refs[2] = {childL[i], childR[i]};
-    uint outRef[2];
+    uint outRef[2], open = 0u;                              // open bit k: the cost-driven collapse opens child k inside this node's wide node (BVH_BUILDER_SAH)
     for (int k = 0; k < 2; k++) {
         uint r = refs[k];
         if (r & BVH_LEAF_BIT) outRef[k] = BVH_LEAF_BIT | ((r & 0x7FFFFFFFu) << 3) | 0u;
         else {
             uint c = rangeLast[r] - rangeFirst[r] + 1u;
             outRef[k] = (c <= BVH_MAX_LEAF) ? (BVH_LEAF_BIT | (rangeFirst[r] << 3) | (c - 1u)) : r;
+            if (absorb && c > BVH_MAX_LEAF && absorb[r]) open |= 1u << k;
         }
     }
     BvhNode nd; float4 a = boxLmin[i], b = boxLmax[i], c = boxRmin[i], d = boxRmax[i];
     nd.lmin = make_float3(a.x, a.y, a.z); nd.lmax = make_float3(b.x, b.y, b.z); nd.rmin = make_float3(c.x, c.y, c.z); nd.rmax = make_float3(d.x, d.y, d.z);
     pad_box(nd.lmin, nd.lmax, scenePad); pad_box(nd.rmin, nd.rmax, scenePad);
-    nd.left = outRef[0]; nd.right = outRef[1]; nd._pad0 = nd._pad1 = 0;
+    nd.left = outRef[0]; nd.right = outRef[1]; nd._pad0 = open; nd._pad1 = 0;
     nodes[i] = nd;
 }
 __global__ void k_init_bounds(uint* sceneBounds) {
@@ -340,21 +345,25 @@ __device__ __forceinline__ uint pow2_exp_ge(float s) {          // biased expone
 }
 __device__ __forceinline__ float q_decode(float o, uint q, float s) { return fmaf((float)q, s, o); }   // identical expression in traversal (v_pk_fma_f32)
 __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ nodes2, const uint* __restrict__ levelIn, uint nIn, uint* __restrict__ levelOut,
-                                                   uint* __restrict__ counter, Bvh8Node* __restrict__ nodes8) {
+                                                   uint* __restrict__ counter, Bvh8Node* __restrict__ nodes8, uint costDriven) {
     uint i = blockIdx.x * 128u + threadIdx.x;
     if (i >= nIn) return;
     uint wide = levelIn[2 * i], r = levelIn[2 * i + 1];
     float3 cmn[8], cmx[8]; uint cref[8]; uint n = 0;
+    uint openMask = 0u;                                     // costDriven: children the host's dynamic programme opens inside this wide node (BvhNode._pad0 of their parent)
     { BvhNode nd = nodes2[r];
-      if (nd.left != BVH_EMPTY) { cmn[n] = nd.lmin; cmx[n] = nd.lmax; cref[n] = nd.left; n++; }
-      if (nd.right != BVH_EMPTY) { cmn[n] = nd.rmin; cmx[n] = nd.rmax; cref[n] = nd.right; n++; } }
+      if (nd.left != BVH_EMPTY) { cmn[n] = nd.lmin; cmx[n] = nd.lmax; cref[n] = nd.left; if (nd._pad0 & 1u) openMask |= 1u << n; n++; }
+      if (nd.right != BVH_EMPTY) { cmn[n] = nd.rmin; cmx[n] = nd.rmax; cref[n] = nd.right; if (nd._pad0 & 2u) openMask |= 1u << n; n++; } }
     while (n < 8u) {
-        int best = -1; float bestA = -1.f;
-        for (uint k = 0; k < n; k++) if (!(cref[k] & BVH_LEAF_BIT)) { float a = box_area(cmn[k], cmx[k]); if (a > bestA) { bestA = a; best = (int)k; } }
+        int best = -1;
+        if (costDriven) { if (openMask) best = __ffs((int)openMask) - 1; }
+        else { float bestA = -1.f; for (uint k = 0; k < n; k++) if (!(cref[k] & BVH_LEAF_BIT)) { float a = box_area(cmn[k], cmx[k]); if (a > bestA) { bestA = a; best = (int)k; } } }
         if (best < 0) break;
         BvhNode nd = nodes2[cref[best]];
-        cmn[best] = nd.lmin; cmx[best] = nd.lmax; cref[best] = nd.left;
-        cmn[n] = nd.rmin; cmx[n] = nd.rmax; cref[n] = nd.right; n++;
+        openMask &= ~(1u << best);
+        cmn[best] = nd.lmin; cmx[best] = nd.lmax; cref[best] = nd.left; if (nd._pad0 & 1u) openMask |= 1u << best;
+        cmn[n] = nd.rmin; cmx[n] = nd.rmax; cref[n] = nd.right; if (nd._pad0 & 2u) openMask |= 1u << n;
+        n++;
     }
     float3 mn = cmn[0], mx = cmx[0];
     for (uint k = 1; k < n; k++) { mn = min3v(mn, cmn[k]); mx = max3v(mx, cmx[k]); }
@@ -438,7 +447,7 @@ static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris) {
     PT_HIP_TRY(hipMalloc(&b.plocFlags, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocOffs, 8 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.plocChildA, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocChildB, 4 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.plocCnt, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocParent, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocFirst, 8 * (size_t)n));
-    PT_HIP_TRY(hipMalloc(&b.plocCounts, 16));
+    PT_HIP_TRY(hipMalloc(&b.plocCounts, 16)); PT_HIP_TRY(hipMalloc(&b.absorb, 4 * (size_t)n));
     tmp = 0;
     PT_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, b.plocFlags, b.plocOffs, 0ull, (size_t)n, rocprim::plus<unsigned long long>()));
     b.scanTempBytes = tmp; PT_HIP_TRY(hipMalloc(&b.scanTemp, tmp ? tmp : 16));
@@ -447,7 +456,7 @@ static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris) {
 void bvh_free(BvhBuildBuffers& b) {
     void* ps[] = {b.triWorld, b.triSorted, b.keys, b.keysSorted, b.prims, b.primsSorted, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast, b.tickets,
                   b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter, b.alphaRecs, b.primToSlot, b.rangeMin, b.rangeMax,
-                  b.plocCl[0], b.plocCl[1], b.plocNN, b.plocFlags, b.plocOffs, b.plocChildA, b.plocChildB, b.plocCnt, b.plocParent, b.plocFirst, b.plocCounts, b.scanTemp};
+                  b.plocCl[0], b.plocCl[1], b.plocNN, b.plocFlags, b.plocOffs, b.plocChildA, b.plocChildB, b.plocCnt, b.plocParent, b.plocFirst, b.plocCounts, b.scanTemp, b.absorb};
     for (void* p : ps) if (p) (void)hipFree(p);
     __builtin_memset(&b, 0, sizeof(b));
 }
@@ -463,14 +472,16 @@ static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, const DeviceScene& sc,
         hipLaunchKernelGGL(k_bounds, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.childL, b.parent, b.leafParent, b.tickets, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds);
     }
     hipLaunchKernelGGL(k_alpha_records, dim3(g), dim3(256), 0, st, sc, b.triSorted, n, b.alphaRecs, b.primToSlot);
-    hipLaunchKernelGGL(k_emit, dim3(g), dim3(256), 0, st, n, b.childL, b.childR, b.rangeFirst, b.rangeLast, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes);
+    const bool costDriven = b.builder == BVH_BUILDER_SAH && b.absorb != nullptr;      // (a refit finds the builder that made the topology)
+    hipLaunchKernelGGL(k_emit, dim3(g), dim3(256), 0, st, n, b.childL, b.childR, b.rangeFirst, b.rangeLast, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes,
+                       costDriven ? b.absorb : (const uint*)nullptr);
     // BVH8 collapse, level by level (the per-level node count comes back to the host: a build step, not the hot path)
     uint init[4] = {0u, 0u, 1u, 0u};                       // levelA[0] = (wide 0, bvh2 root 0); counter = {next wide index = 1, out count = 0}
     PT_HIP_TRY(hipMemcpyAsync(b.levelA, init, 8, hipMemcpyHostToDevice, st));
     PT_HIP_TRY(hipMemcpyAsync(b.wideCounter, init + 2, 8, hipMemcpyHostToDevice, st));
     uint nIn = 1, levels = 0; uint* in = b.levelA; uint* out = b.levelB;
     while (nIn) {
-        hipLaunchKernelGGL(k_collapse8, dim3((nIn + 127u) / 128u), dim3(128), 0, st, b.nodes, in, nIn, out, b.wideCounter, b.nodes8);
+        hipLaunchKernelGGL(k_collapse8, dim3((nIn + 127u) / 128u), dim3(128), 0, st, b.nodes, in, nIn, out, b.wideCounter, b.nodes8, costDriven ? 1u : 0u);
         uint host[2];
         PT_HIP_TRY(hipMemcpyAsync(host, b.wideCounter, 8, hipMemcpyDeviceToHost, st));
         PT_HIP_TRY(hipStreamSynchronize(st));
@@ -511,11 +522,37 @@ static hipError_t bvh_ploc(BvhBuildBuffers& b, uint n, hipStream_t st) {
     PT_HIP_TRY(hipMemcpyAsync(b.primsSorted, b.prims, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));      // leaf order = depth-first order from here on
     return hipGetLastError();
 }
+// "prefer fast trace": the topology comes from the host's binned-SAH build over the world-space triangles k_tri_setup has just written
+static hipError_t bvh_sah(BvhBuildBuffers& b, uint n, hipStream_t st) {
+    std::vector<TriRecord> tw(n);
+    PT_HIP_TRY(hipMemcpyAsync(tw.data(), b.triWorld, sizeof(TriRecord) * (size_t)n, hipMemcpyDeviceToHost, st));
+    PT_HIP_TRY(hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<SahTri> st3(n);
+    for (uint i = 0; i < n; i++) {
+        const TriRecord& t = tw[i]; const float3 q1 = t.v0 + t.e1, q2 = t.v0 + t.e2; SahTri& o = st3[i];
+        const float a[3] = {t.v0.x, t.v0.y, t.v0.z}, p[3] = {q1.x, q1.y, q1.z}, q[3] = {q2.x, q2.y, q2.z}, e1[3] = {t.e1.x, t.e1.y, t.e1.z}, e2[3] = {t.e2.x, t.e2.y, t.e2.z};
+        for (int k = 0; k < 3; k++) { o.mn[k] = fminf(a[k], fminf(p[k], q[k])); o.mx[k] = fmaxf(a[k], fmaxf(p[k], q[k])); o.c[k] = a[k] + (e1[k] + e2[k]) * (1.0f / 3.0f); }
+    }
+    std::vector<uint> order(n), cl(n), cr(n), rf(n), rl(n), par(n), lp(n), ab(n);
+    bvh_sah_topology(st3.data(), n, SahTopology{order.data(), cl.data(), cr.data(), rf.data(), rl.data(), par.data(), lp.data(), ab.data()}, BVH_MAX_LEAF, 0u);
+    PT_HIP_TRY(hipMemcpyAsync(b.absorb, ab.data(), 4 * (size_t)(n - 1u), hipMemcpyHostToDevice, st));
+    const size_t inner = 4 * (size_t)(n - 1u);
+    PT_HIP_TRY(hipMemcpyAsync(b.primsSorted, order.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st)); PT_HIP_TRY(hipMemcpyAsync(b.leafParent, lp.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    PT_HIP_TRY(hipMemcpyAsync(b.childL, cl.data(), inner, hipMemcpyHostToDevice, st)); PT_HIP_TRY(hipMemcpyAsync(b.childR, cr.data(), inner, hipMemcpyHostToDevice, st));
+    PT_HIP_TRY(hipMemcpyAsync(b.rangeFirst, rf.data(), inner, hipMemcpyHostToDevice, st)); PT_HIP_TRY(hipMemcpyAsync(b.rangeLast, rl.data(), inner, hipMemcpyHostToDevice, st));
+    PT_HIP_TRY(hipMemcpyAsync(b.parent, par.data(), inner, hipMemcpyHostToDevice, st));
+    PT_HIP_TRY(hipStreamSynchronize(st));                       // (the host vectors go out of scope)
+    b.hostBuildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return hipSuccess;
+}
 hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {
     if (n == 0) return hipSuccess;
     uint g = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, st, b.sceneBounds);
     hipLaunchKernelGGL(k_tri_setup, dim3(g), dim3(256), 0, st, sc, n, b.triWorld, b.sceneBounds);
+    b.hostBuildMs = 0.f;
+    if (b.builder == BVH_BUILDER_SAH && n > 1) { PT_HIP_TRY(bvh_sah(b, n, st)); return bvh_bounds_and_emit(b, sc, n, st); }
     hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, st, b.triWorld, n, b.sceneBounds, b.keys, b.prims);
     size_t tmp = b.sortTempBytes;
     PT_HIP_TRY(rocprim::radix_sort_pairs(b.sortTemp, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64, st));

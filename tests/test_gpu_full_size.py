@@ -83,3 +83,9 @@ def test_c5_full_size_4k_animated_refit_rows_bit_exact():
             assert bad == 0, "frame %d rect %s: %d pixels differ" % (frame, r, bad)
         o.close()
     assert g.build_stats()["refitMs"] > 0
+    # a rebuild between animated frames takes the fast builder (PLOC on the device), whatever made the first tree; the frame does not depend on it
+    inst, pos = scenes.animate_instances(sc, 0.6), scenes.animate_positions(sc, 0.6)
+    g.animate(instances=inst, positions=pos, rebuild=True)
+    assert g.build_stats()["buildMs"] < 100.0
+    g.reset_accumulation(); g.render(SPP, SPP)
+    assert np.array_equal(a, g.radiance())
