@@ -70,7 +70,7 @@ struct __attribute__((packed, aligned(4))) u32x3p { uint x, y, z; };   // 12-byt
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
 #ifndef PT_BVH8_STACK
-#define PT_BVH8_STACK 28
+#define PT_BVH8_STACK 16          // (8 blocks of 256 threads per CU need <= 20 KB of LDS each: 17 x 8 B x 64 quads + the chunk parking lot; 12 entries: -0.6 %, 8: -6 %)
 #endif
 // traversal launch geometry (pt_traverse8.h): 256-thread blocks, 4 lanes per ray -> 64 rays in flight per block, each with an LDS stack of
 // BVH8_STACK entries (odd stride: quads land on different banks) and a T8_SPILL_DEPTH-entry tail in global memory (DeviceScene::travSpill)

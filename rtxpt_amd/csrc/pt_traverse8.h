@@ -27,7 +27,11 @@ static const uint T8_RAYBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_RAY_STRIDE,
 static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 
 #ifndef T8_EXTEND_MIN_BLOCKS
-#define T8_EXTEND_MIN_BLOCKS 5    // 256-thread blocks per CU the register allocator must leave room for in k_extend (= waves per SIMD)
+#define T8_EXTEND_MIN_BLOCKS 8    // waves per SIMD the register allocator must leave room for in k_extend (64 VGPRs, 2 spilled outside the loop): the kernel is latency
+                                  // bound and every wave in flight counts — 6 -> 7 -> 8 waves: 1161 -> 1187 -> 1239 Mrays/s (profiles/r02n_occupancy_ab.txt)
+#endif
+#ifndef T8_SHADOW_MIN_WAVES
+#define T8_SHADOW_MIN_WAVES 8     // the same for k_shadow
 #endif
 #ifndef T8_FAST_INNER
 #define T8_FAST_INNER 1          // near/far planes by byte permute, float scales from the node tail, quad hit count by DPP adds

@@ -194,7 +194,7 @@ __device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, ui
 }
 
 template <bool COUNT, bool GROUPED>
-__global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : 6) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
+__global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
     const uint count = *countPtr;
