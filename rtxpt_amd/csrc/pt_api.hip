@@ -767,7 +767,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->extendCount[nxt], 0, 4, t.st));
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st));
             size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0});
-            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1});
+            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, reinterpret_cast<uint*>(t.aux.bestKey) /* the straggler keys and counts are idle between k_resolve_extend and the shadow launch */, t.aux.counts, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1});
             t.extendRays += t.active;
             PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
             t.waiting = true;

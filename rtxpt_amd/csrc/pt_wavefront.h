@@ -31,8 +31,9 @@ struct TravAux { TravTask* taskQ[2]; uint* counts; uint taskCap; unsigned long l
 
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st);
 void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
+// classScratch (2 x countIn words) + classCount (3 words): k_classify's output, memory that is free between the extend and the shadow launches of a bounce; null = shade in queue order
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr,
-                  ShadowQueue sq, WaveCounters* wc, hipStream_t st);
+                  ShadowQueue sq, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st);
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st);
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st);

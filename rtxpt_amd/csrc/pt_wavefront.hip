@@ -147,17 +147,50 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
 #ifndef PT_SHADE_MIN_BLOCKS
 #define PT_SHADE_MIN_BLOCKS 1
 #endif
+#ifndef PT_SHADE_CLASSES
+#define PT_SHADE_CLASSES 1      // 1: k_classify sorts the bounce's paths into {hit that goes on, hit that terminates after its emission, miss} before k_shade
+#endif
+
+// Path classes for k_shade. A shading wave lives ~90 us, nearly all of it waiting on dependent loads, and as long as ONE lane runs the whole of HandleHit (surface,
+// scatter, light sampling) the wave stays for all of it — while 13 % of a bounce's paths are misses and ~20 % are hits that terminate right after their emission
+// term (PF_terminateAtNextBounce). k_classify makes the classes contiguous (continuing hits from the front of one array, terminating hits from its back, misses
+// in a second one; one atomic per class per 1024 paths), so all but two waves of a launch are of one class and the short classes leave early. Radiance, queues
+// and counters do not depend on the order in which paths are shaded.
+__global__ void __launch_bounds__(1024) k_classify(PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr, uint* __restrict__ classQ, uint* __restrict__ classCount) {
+    __shared__ uint waveCnt[16][3]; __shared__ uint blockBase[3];
+    const uint count = *countInPtr, i = blockIdx.x * 1024u + threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint p = 0, cls = 3u;                                     // 0 continuing hit, 1 terminating hit, 2 miss, 3 out of range
+    if (i < count) {
+        p = queueIn[i];
+        const uint prim = reinterpret_cast<const uint*>(pool.hit)[4u * (size_t)p + 1u], flags = reinterpret_cast<const uint*>(pool.s4)[4u * (size_t)p + 2u];
+        cls = (prim == 0xFFFFFFFFu) ? 2u : (((flags >> kVertexIndexBitCount) & PF_terminateAtNextBounce) ? 1u : 0u);
+    }
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cls == 0u), m1 = __builtin_amdgcn_ballot_w64(cls == 1u), m2 = __builtin_amdgcn_ballot_w64(cls == 2u);
+    if (lane == 0u) { waveCnt[wave][0] = (uint)__popcll(m0); waveCnt[wave][1] = (uint)__popcll(m1); waveCnt[wave][2] = (uint)__popcll(m2); }
+    __syncthreads();
+    if (threadIdx.x < 3u) { uint tot = 0; for (uint w = 0; w < 16u; w++) { uint c = waveCnt[w][threadIdx.x]; waveCnt[w][threadIdx.x] = tot; tot += c; } blockBase[threadIdx.x] = tot ? atomicAdd(&classCount[threadIdx.x], tot) : 0u; }
+    __syncthreads();
+    if (cls > 2u) return;
+    const unsigned long long mine = cls == 0u ? m0 : (cls == 1u ? m1 : m2);
+    const uint rank = blockBase[cls] + waveCnt[wave][cls] + (uint)__popcll(mine & ((1ull << lane) - 1ull));
+    // continuing hits from the front of [0, count), terminating hits from its back (they cannot meet: together they are at most count), misses in [count, 2 count)
+    classQ[cls == 0u ? rank : (cls == 1u ? count - 1u - rank : count + rank)] = p;
+}
+
 // PKC: PathKernelContextT<false> (lp types in fp32) or PathKernelContextT<true> (the reference's default build, lp types in binary16)
 template <bool MULTI, class PKC>
 __global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
-                                               uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc) {
+                                               uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, const uint* __restrict__ classCount) {
     const uint count = *countInPtr;
     uint i = blockIdx.x * 256u + threadIdx.x;
     bool inRange = i < count;
     bool alive = false; bool isHit = false; uint p = 0;
     ShadowRequest req; req.valid = false;
     if (inRange) {
-        p = queueIn[i];
+        if (classCount) {                                     // queueIn = k_classify's arrays: thread i takes the i-th path of the order {continuing, terminating, miss}
+            const uint nGo = classCount[0], nEnd = classCount[1];
+            p = queueIn[i < nGo ? i : (i < nGo + nEnd ? count - 1u - (i - nGo) : count + (i - nGo - nEnd))];
+        } else p = queueIn[i];
         PathState path = load_path(pool, p);
         uint4 hr = pool.hit[p];
         HitInfo h; h.t = asfloat(hr.x); h.prim = hr.y; h.u = asfloat(hr.z); h.v = asfloat(hr.w);
@@ -556,16 +589,22 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
     hipLaunchKernelGGL((k_extend_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);       // queue 1, to the end
     hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
 }
-void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, hipStream_t st) {
+void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc,
+                  uint* classScratch, uint* classCount, hipStream_t st) {
     const dim3 g((countIn + 255) / 256), b(256);
+    if (PT_SHADE_CLASSES && classScratch) {                   // (scratch: 2 x countIn words; classCount: 3 words, both free between the extend and the shadow launches)
+        (void)hipMemsetAsync(classCount, 0, 12, st);
+        hipLaunchKernelGGL(k_classify, dim3((countIn + 1023) / 1024), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
+        queueIn = classScratch;
+    } else classCount = nullptr;
     if (k.S.useFp16Types) {          // the reference's default build of its lp types (binary16): same context data, the other instantiation of the shading code
         static_assert(sizeof(PathKernelContextT<true>) == sizeof(PathKernelContext), "the two lp builds share one context layout");
         PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16));
-        if (sq.group) hipLaunchKernelGGL((k_shade<true, PathKernelContextT<true>>), g, b, 0, st, k16, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
-        else hipLaunchKernelGGL((k_shade<false, PathKernelContextT<true>>), g, b, 0, st, k16, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+        if (sq.group) hipLaunchKernelGGL((k_shade<true, PathKernelContextT<true>>), g, b, 0, st, k16, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
+        else hipLaunchKernelGGL((k_shade<false, PathKernelContextT<true>>), g, b, 0, st, k16, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
     } else {
-        if (sq.group) hipLaunchKernelGGL((k_shade<true, PathKernelContext>), g, b, 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
-        else hipLaunchKernelGGL((k_shade<false, PathKernelContext>), g, b, 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc);
+        if (sq.group) hipLaunchKernelGGL((k_shade<true, PathKernelContext>), g, b, 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
+        else hipLaunchKernelGGL((k_shade<false, PathKernelContext>), g, b, 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
     }
 }
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
