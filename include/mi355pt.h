@@ -242,7 +242,7 @@ int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo*
    The file format of the graph itself and the light / camera keys belong to Donut (donut/engine/Scene.cpp, SceneGraph.cpp), which the reference
    tree does not vendor: they are restated from Donut's published sources. DirectionalLight leaves are returned by pt_scene_import_directional_lights. Not imported: animations,
    glTF-embedded cameras / lights, analytic-light proxies (counted in info), textures other than 8-bit PNG (counted in texturesNotLoaded, the
-   material then renders untextured as when the reference fails to load one). The environment map is reported, not loaded (.exr / .dds). NOTE: of
+   material then renders untextured as when the reference fails to load one). The environment map is reported (envPath), not loaded: pt_image_read_float reads .exr / .hdr files for pt_set_environment (.dds is not read). NOTE: of
    an EnvironmentLight the reference application consumes only `path` (Sample.cpp:552-553); radianceScale / rotation / textureIndex are read by
    EnvironmentLight::Load but never used — tint, intensity and rotation of the environment come from the UI block (EnvironmentMapRuntimeParameters,
    reset to identity on every scene load, Sample.cpp:554, 1936-1948). They are reported for completeness; to match the reference do not apply them. */
@@ -325,6 +325,13 @@ int32_t pt_tonemap_from_parameters(const PtToneMappingParameters* ui, float avgL
    power-of-two-lowered size, averaged down its mip chain; avgLuminance = exp2(last mip) is what TONEMAPPING_AUTOEXPOSURE_CPU puts into
    ToneMappingConstants::avgLuminance (the reference reads it back with a lag of a few frames; here it is the current image). */
 int32_t pt_average_luminance(pt_context* ctx, float* avgLuminance);
+/* Float images for the environment source. The reference takes .exr / .hdr / .dds environment maps (Rtxpt/Sample.cpp:116) through Donut's TextureCache
+   (EnvMapBaker.cpp:392-415; Donut is not vendored: the formats are read from their published specifications). OpenEXR: single-part scan-line files with
+   half or float R G B (or Y) channels, compression NONE / RLE / ZIPS / ZIP; Radiance .hdr: 32-bit_rle_rgbe, "-Y h +X w". *rgb: width x height x 3 floats, top
+   row first (what pt_set_environment takes), allocated by the library, released with pt_image_free. PT_ERROR_IO: unreadable or malformed;
+   PT_ERROR_UNSUPPORTED: tiled / multi-part / deep EXR, PIZ / PXR24 / B44 / DWA compression, sub-sampled or integer channels, .dds, other orientations. */
+int32_t pt_image_read_float(const char* path, uint32_t* width, uint32_t* height, float** rgb);
+void    pt_image_free(float* rgb);
 int32_t pt_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 int32_t pt_write_bmp(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -281,6 +281,20 @@ def material_from_json(text, texture_words=(0xFFFFFFFF,) * 5):
 class PtAnalyticLightDesc(ctypes.Structure):
     _fields_ = [("type", ctypes.c_uint32), ("position", ctypes.c_float * 3), ("direction", ctypes.c_float * 3), ("color", ctypes.c_float * 3), ("intensity", ctypes.c_float),
                 ("radius", ctypes.c_float), ("innerAngle", ctypes.c_float), ("outerAngle", ctypes.c_float)]
+
+
+def read_float_image(path):
+    """pt_image_read_float: an OpenEXR (scan-line; none / RLE / ZIPS / ZIP) or Radiance .hdr file as float32 [h, w, 3], top row first. No device needed."""
+    L = load_library()
+    w, h = ctypes.c_uint32(), ctypes.c_uint32(); p = ctypes.POINTER(ctypes.c_float)()
+    L.pt_image_read_float.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.POINTER(ctypes.c_float))]
+    L.pt_image_free.argtypes = [ctypes.POINTER(ctypes.c_float)]; L.pt_image_free.restype = None
+    r = L.pt_image_read_float(str(path).encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(p))
+    if r != PT_OK: raise PtError(r, "pt_image_read_float(%s)" % path)
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    finally:
+        L.pt_image_free(p)
 
 
 def env_bake_lights(world_lights, cube_dim, transform=None):

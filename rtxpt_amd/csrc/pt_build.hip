@@ -523,7 +523,7 @@ static hipError_t bvh_ploc(BvhBuildBuffers& b, uint n, hipStream_t st) {
     return hipGetLastError();
 }
 // "prefer fast trace": the topology comes from the host's binned-SAH build over the world-space triangles k_tri_setup has just written
-static hipError_t bvh_sah(BvhBuildBuffers& b, uint n, hipStream_t st) {
+static hipError_t bvh_sah(BvhBuildBuffers& b, uint n, hipStream_t st) try {
     std::vector<TriRecord> tw(n);
     PT_HIP_TRY(hipMemcpyAsync(tw.data(), b.triWorld, sizeof(TriRecord) * (size_t)n, hipMemcpyDeviceToHost, st));
     PT_HIP_TRY(hipStreamSynchronize(st));
@@ -545,14 +545,17 @@ static hipError_t bvh_sah(BvhBuildBuffers& b, uint n, hipStream_t st) {
     PT_HIP_TRY(hipStreamSynchronize(st));                       // (the host vectors go out of scope)
     b.hostBuildMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return hipSuccess;
-}
+} catch (...) { return hipErrorOutOfMemory; }      // host allocation or thread creation failed: the caller falls back to the device-side builder
 hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {
     if (n == 0) return hipSuccess;
     uint g = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, st, b.sceneBounds);
     hipLaunchKernelGGL(k_tri_setup, dim3(g), dim3(256), 0, st, sc, n, b.triWorld, b.sceneBounds);
     b.hostBuildMs = 0.f;
-    if (b.builder == BVH_BUILDER_SAH && n > 1) { PT_HIP_TRY(bvh_sah(b, n, st)); return bvh_bounds_and_emit(b, sc, n, st); }
+    if (b.builder == BVH_BUILDER_SAH && n > 1) {
+        if (bvh_sah(b, n, st) == hipSuccess) return bvh_bounds_and_emit(b, sc, n, st);
+        (void)hipGetLastError(); b.builder = BVH_BUILDER_PLOC;      // no host memory / threads for the fast-trace topology: build it on the device instead
+    }
     hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, st, b.triWorld, n, b.sceneBounds, b.keys, b.prims);
     size_t tmp = b.sortTempBytes;
     PT_HIP_TRY(rocprim::radix_sort_pairs(b.sortTemp, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64, st));

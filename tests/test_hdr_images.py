@@ -1,0 +1,164 @@
+"""pt_image_read_float (the environment source files the reference takes — .exr / .hdr, Rtxpt/Sample.cpp:116 — read without Donut): CPU only.
+  * a third-party file: tests/golden/cpython_imghdr_python.exr (CPython's own imghdr test image: 16x16, half A B G R, uncompressed) against a numpy decode of its bytes;
+  * files written here from the published layouts — OpenEXR scan-line with NONE / RLE / ZIPS / ZIP blocks (zlib + the byte predictor / de-interleave of ImfZip),
+    half and float channels in any order, a data window that does not start at 0, luminance-only; Radiance RGBE flat and run-length;
+  * what must be refused (PIZ, tiled, multi-part, sub-sampled channels) and 600 damaged files that must fail cleanly."""
+import os, struct, sys, zlib
+import numpy as np
+import pytest
+
+import rtxpt_amd as pt
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cpython_imghdr_python.exr")
+
+
+def _attr(name, typ, val):
+    return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(val)) + val
+
+
+def _exr_transform(raw):
+    """ImfZip / ImfRle: reorder into (even bytes, odd bytes), then delta-encode"""
+    a = np.frombuffer(raw, np.uint8); t = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+    d = t.copy(); d[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
+    return d.astype(np.uint8).tobytes()
+
+
+def _exr_rle(data):
+    out = bytearray(); i = 0; n = len(data)
+    while i < n:
+        j = i
+        while j + 1 < n and data[j + 1] == data[i] and j - i < 126: j += 1
+        if j - i >= 2:
+            out += struct.pack("b", j - i) + bytes([data[i]]); i = j + 1
+        else:
+            k = i
+            while k < n and k - i < 127 and not (k + 2 < n and data[k] == data[k + 1] == data[k + 2]): k += 1
+            out += struct.pack("b", -(k - i)) + data[i:k]; i = k
+    return bytes(out)
+
+
+def write_exr(path, chans, comp, origin=(0, 0), version=2, extra_attrs=b""):
+    """chans: {name: float32 or float16 array [h, w]}; comp: 0 none, 1 RLE, 2 ZIPS, 3 ZIP"""
+    names = sorted(chans); h, w = chans[names[0]].shape
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 1 if chans[n].dtype == np.float16 else 2, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    x0, y0 = origin
+    hdr = struct.pack("<ii", 20000630, version) + _attr("channels", "chlist", chlist) + _attr("compression", "compression", bytes([comp])) + \
+        _attr("dataWindow", "box2i", struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)) + _attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + \
+        _attr("lineOrder", "lineOrder", b"\0") + _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + \
+        _attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + extra_attrs + b"\0"
+    lpb = 16 if comp == 3 else 1
+    blocks = []
+    for yb in range(0, h, lpb):
+        raw = b"".join(chans[n][y].tobytes() for y in range(yb, min(h, yb + lpb)) for n in names)
+        if comp == 0: data = raw
+        else:
+            t = _exr_transform(raw); data = _exr_rle(t) if comp == 1 else zlib.compress(t)
+            if len(data) >= len(raw): data = raw
+        blocks.append(struct.pack("<ii", y0 + yb, len(data)) + data)
+    off = len(hdr) + 8 * len(blocks); table = b""
+    for b in blocks: table += struct.pack("<Q", off); off += len(b)
+    open(path, "wb").write(hdr + table + b"".join(blocks))
+
+
+def write_hdr(path, rgbe, rle):
+    h, w = rgbe.shape[:2]
+    out = bytearray(b"#?RADIANCE\n# written by tests/test_hdr_images.py\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y %d +X %d\n" % (h, w))
+    for y in range(h):
+        if not rle: out += rgbe[y].tobytes(); continue
+        out += bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            row = rgbe[y, :, c]; x = 0
+            while x < w:
+                r = 1
+                while x + r < w and row[x + r] == row[x] and r < 127: r += 1
+                if r >= 4: out += bytes([128 + r, row[x]]); x += r
+                else:
+                    k = x
+                    while k < w and k - x < 128 and not (k + 3 < w and row[k] == row[k + 1] == row[k + 2] == row[k + 3]): k += 1
+                    out += bytes([k - x]) + row[x:k].tobytes(); x = k
+    open(path, "wb").write(bytes(out))
+
+
+def test_third_party_exr_equals_a_numpy_decode_of_its_bytes():
+    d = open(GOLD, "rb").read()
+    a = pt.read_float_image(GOLD)
+    assert a.shape == (16, 16, 3) and 0.0 <= a.min() and a.max() == 1.0
+    # its header (parsed by hand once: 331 bytes, channels A B G R half, uncompressed, 16 lines) -> offset table of 16 x 8 bytes -> per line: y, size, A | B | G | R rows
+    p = 331 + 16 * 8; want = np.zeros((16, 16, 3), np.float32)
+    for y in range(16):
+        yy, size = struct.unpack_from("<ii", d, p); assert size == 16 * 2 * 4; p += 8
+        row = np.frombuffer(d, np.float16, 64, p).astype(np.float32).reshape(4, 16); p += size
+        want[yy, :, 0], want[yy, :, 1], want[yy, :, 2] = row[3], row[2], row[1]
+    assert np.array_equal(a, want)
+
+
+@pytest.mark.parametrize("comp", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_exr_round_trip(tmp_path, comp, dtype):
+    rng = np.random.default_rng(comp * 7 + (1 if dtype == np.float16 else 2))
+    h, w = 37, 53                                           # not a multiple of the 16-line ZIP block
+    img = (rng.random((h, w, 3), np.float32) ** 3 * 200.0).astype(dtype)
+    img[5:9, 10:40] = dtype(1.5)                            # runs, so that the RLE and ZIP blocks really are smaller than the raw ones
+    chans = {"R": img[..., 0], "G": img[..., 1], "B": img[..., 2], "A": np.ones((h, w), dtype), "Z": rng.random((h, w), np.float32)}
+    path = tmp_path / "t.exr"; write_exr(path, chans, comp, origin=(-3, 11))
+    got = pt.read_float_image(path)
+    assert got.shape == (h, w, 3) and np.array_equal(got, img.astype(np.float32))
+
+
+def test_exr_luminance_only_and_long_names(tmp_path):
+    y = np.linspace(0, 4, 20 * 8, dtype=np.float32).reshape(8, 20).astype(np.float16)
+    write_exr(tmp_path / "y.exr", {"Y": y}, 2, version=2 | 0x400)
+    got = pt.read_float_image(tmp_path / "y.exr")
+    assert np.array_equal(got[..., 0], y.astype(np.float32)) and np.array_equal(got[..., 0], got[..., 2])
+
+
+@pytest.mark.parametrize("rle", [False, True])
+def test_radiance_hdr(tmp_path, rle):
+    rng = np.random.default_rng(3)
+    h, w = 12, 40
+    rgbe = rng.integers(0, 256, (h, w, 4)).astype(np.uint8); rgbe[..., 3] = rng.integers(120, 140, (h, w)); rgbe[2, 5:30] = (10, 20, 30, 129); rgbe[4, 0] = (9, 9, 9, 0)
+    write_hdr(tmp_path / "t.hdr", rgbe, rle)
+    got = pt.read_float_image(tmp_path / "t.hdr")
+    want = rgbe[..., :3].astype(np.float32) * np.exp2(rgbe[..., 3:4].astype(np.float32) - 136.0); want[rgbe[..., 3] == 0] = 0
+    assert np.array_equal(got, want.astype(np.float32))
+
+
+def test_refused_files(tmp_path):
+    img = np.ones((4, 4), np.float16)
+    def code(path):
+        with pytest.raises(pt.PtError) as e: pt.read_float_image(path)
+        return e.value.code
+    write_exr(tmp_path / "piz.exr", {"R": img, "G": img, "B": img}, 0); d = bytearray(open(tmp_path / "piz.exr", "rb").read())
+    i = d.index(b"compression\0compression\0") + 24 + 4; d[i] = 4; open(tmp_path / "piz.exr", "wb").write(d)
+    assert code(tmp_path / "piz.exr") == 5                  # PT_ERROR_UNSUPPORTED
+    write_exr(tmp_path / "tiled.exr", {"R": img, "G": img, "B": img}, 0, version=2 | 0x200); assert code(tmp_path / "tiled.exr") == 5
+    write_exr(tmp_path / "multi.exr", {"R": img, "G": img, "B": img}, 0, version=2 | 0x1000); assert code(tmp_path / "multi.exr") == 5
+    write_exr(tmp_path / "nocolour.exr", {"Z": img.astype(np.float32)}, 0); assert code(tmp_path / "nocolour.exr") == 5
+    open(tmp_path / "junk.bin", "wb").write(b"not an image at all"); assert code(tmp_path / "junk.bin") == 5
+    assert code(tmp_path / "missing.exr") == 4              # PT_ERROR_IO
+    open(tmp_path / "empty.exr", "wb").write(b""); assert code(tmp_path / "empty.exr") in (4, 5)
+
+
+def test_damaged_files_fail_cleanly(tmp_path):
+    rng = np.random.default_rng(11)
+    img = (rng.random((20, 24, 3), np.float32) * 5).astype(np.float16)
+    srcs = []
+    for comp in (0, 1, 3):
+        p = tmp_path / ("s%d.exr" % comp); write_exr(p, {"R": img[..., 0], "G": img[..., 1], "B": img[..., 2]}, comp); srcs.append(open(p, "rb").read())
+    rgbe = rng.integers(0, 256, (6, 16, 4)).astype(np.uint8); write_hdr(tmp_path / "s.hdr", rgbe, True); srcs.append(open(tmp_path / "s.hdr", "rb").read())
+    ok = 0
+    for k in range(600):
+        d = bytearray(srcs[k % len(srcs)])
+        kind = k % 3
+        if kind == 0: d = d[:int(rng.integers(0, len(d)))]                                             # truncated
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 6))): d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))      # flipped bytes
+        else:
+            i = int(rng.integers(0, len(d) - 4)); d[i:i + 4] = struct.pack("<i", int(rng.integers(-2 ** 31, 2 ** 31 - 1)))      # a wild 32-bit field
+        path = tmp_path / "d.bin"; open(path, "wb").write(d)
+        try:
+            a = pt.read_float_image(path); ok += 1
+            assert a.ndim == 3 and a.shape[2] == 3 and a.shape[0] <= 32768 and a.shape[1] <= 32768
+        except pt.PtError as e:
+            assert e.code in (4, 5)
+    assert ok > 0                                            # (some mutations only touch pixel data)
