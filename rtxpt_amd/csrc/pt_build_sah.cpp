@@ -250,7 +250,7 @@ void bvh_sah_topology(const SahTri* tris, uint n, const SahTopology& out, uint m
     if (n == 0u) return;
     Builder b; b.tri = tris; b.n = n; b.out = out; b.maxLeaf = maxLeaf ? maxLeaf : 1u;
     unsigned hw = std::thread::hardware_concurrency(); if (!hw) hw = 8;
-    b.threads = threads ? threads : std::min(hw, 48u);               // the build is bound by gathers from the triangle array; beyond a few dozen threads the sync costs more than it buys
+    b.threads = threads ? threads : std::min(hw, 32u);               // the build is bound by gathers from the triangle array; beyond a few dozen threads the sync costs more than it buys (and 8 ranks of a node build at once)
     if (b.threads > n / 4096u + 1u) b.threads = n / 4096u + 1u;
     Pool pool(b.threads); b.pool = &pool;
     b.run();
