@@ -718,7 +718,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     if (neeSamples == 0u) k.S.NEEEnabled = 0;            // `applyNEE &= fullSamples > 0` (PathTracerNEE.hlsli:322): the vertices behave as without NEE; the light tables stay as baked
 
     // The owned pixels are traced as up to PT_PIPELINE_BATCHES independent sub-frame batches, each on its own stream. Paths never interact, so this changes nothing in the
-    // result; it lets the latency-bound k_shade of one batch overlap the VALU-bound traversal of the other and hides the ~0.5 ms drain at the
+    // result; it lets the k_shade of one batch (3 waves per SIMD, mostly waiting on memory) overlap the traversal of the others and hides the ~0.5 ms drain at the
     // end of every launch (C3: 241 ms with one batch, 199 ms with four). The batches advance in lockstep (queue all, then service each as its counts arrive): an
     // event-driven variant that re-queued each batch independently was 7 % slower. Small frames use fewer batches, PT_DEVICE_SERIAL_KERNELS one.
     struct Batch {
