@@ -498,6 +498,13 @@ class Oracle:
             else: self.L.ptref_get_env_cube(self.h, _p(out), n, None, None)
         return out, dim.value, lv.value
 
+    def env_importance(self, dim, reference=False):
+        """Level 0 of the radiance / importance map (EnvMapImportanceSamplingBaker.hlsl BuildMIPDescentImportanceMapCS, RGBA16F store) as float32 [dim, dim, 4];
+        reference=True: computed by the reference's shader text (needs an Oracle(reference_integrator=True) library)."""
+        out = np.zeros((dim, dim, 4), np.float32)
+        (self.L.refpt_env_importance if reference else self.L.ptref_get_env_importance)(self.h, ctypes.c_uint32(dim), _p(out))
+        return out
+
     def env_eval(self, dirs_lod):
         """EnvMap::EvalLocal (cube fetch x ColorMultiplier) on rows (localDir.xyz, lod) -> float32 [n, 3]."""
         a = np.ascontiguousarray(dirs_lod, np.float32).reshape(-1, 4); out = np.zeros((a.shape[0], 3), np.float32)

@@ -186,8 +186,8 @@ static void bake_env_cube(EnvMap& e) {
 
 // ---- environment importance map + quad tree (host restatement of the baker compute passes)
 struct EnvImportance { uint dim, mipCount; std::vector<std::vector<float4> > mips; };   // rgb = mean radiance, w = mean (lum+avg)/2
-static void build_env_importance(const Scene& sc, EnvImportance& im) {
-    im.dim = EMISB_IMPORTANCE_MAP_DIM; im.mipCount = 11; im.mips.resize(im.mipCount);
+static void build_env_importance(const Scene& sc, EnvImportance& im, uint dim = EMISB_IMPORTANCE_MAP_DIM, uint mipCount = 11) {
+    im.dim = dim; im.mipCount = mipCount; im.mips.resize(im.mipCount);
     const uint sx = 4, sy = EMISB_SAMPLES / 4; const uint dimS = im.dim * sx;
     im.mips[0].resize((size_t)im.dim * im.dim);
     const float invSamples = 1.f / (float)(sx * sy);
@@ -201,7 +201,8 @@ static void build_env_importance(const Scene& sc, EnvImportance& im) {
             L += (Luminance(radiance) + Average(radiance)) * 0.5f;
             R += radiance;
         }
-        im.mips[0][(size_t)y * im.dim + x] = make_float4(R.x * invSamples, R.y * invSamples, R.z * invSamples, L * invSamples);
+        // u_RadianceMap is an RGBA16_FLOAT texture (EnvMapImportanceSamplingBaker.cpp:170): the store rounds to binary16
+        im.mips[0][(size_t)y * im.dim + x] = env_round_rgba16f(make_float4(R.x * invSamples, R.y * invSamples, R.z * invSamples, L * invSamples));
     }
     for (uint l = 1; l < im.mipCount; l++) {
         uint pd = im.dim >> (l - 1), d = im.dim >> l;
@@ -209,7 +210,7 @@ static void build_env_importance(const Scene& sc, EnvImportance& im) {
         for (uint y = 0; y < d; y++) for (uint x = 0; x < d; x++) {
             const std::vector<float4>& p = im.mips[l - 1];
             float4 s = (p[(size_t)(2 * y) * pd + 2 * x] + p[(size_t)(2 * y) * pd + 2 * x + 1]) + (p[(size_t)(2 * y + 1) * pd + 2 * x] + p[(size_t)(2 * y + 1) * pd + 2 * x + 1]);
-            im.mips[l][(size_t)y * d + x] = s * 0.25f;
+            im.mips[l][(size_t)y * d + x] = env_round_rgba16f(s * 0.25f);      // MipMapGenPass MODE_COLOR (Donut, not vendored: restated as the 2x2 mean of the stored texels, stored as binary16)
         }
     }
 }
@@ -437,6 +438,14 @@ uint32_t ptref_get_env_cube(void* h, uint32_t* out, uint32_t capacity, uint32_t*
     if (dim) *dim = e.cube.dim; if (mipLevels) *mipLevels = e.cube.mipLevels;
     if (out && capacity >= e.cubeTexels.size()) memcpy(out, e.cubeTexels.data(), e.cubeTexels.size() * sizeof(uint2));
     return (uint32_t)e.cubeTexels.size();
+}
+// level 0 of the radiance / importance map the environment quad tree is built from (dim x dim float4; the light baker uses EMISB_IMPORTANCE_MAP_DIM = 1024)
+void ptref_get_env_importance(void* h, uint32_t dim, float* out) {
+    Context* c = (Context*)h; EnvMap& e = c->sc.env;
+    if (!e.enabled) return;
+    if (e.cubeDirty) { bake_env_cube(e); c->lightsDirty = true; }
+    EnvImportance im; build_env_importance(c->sc, im, dim, 1);
+    memcpy(out, im.mips[0].data(), sizeof(float4) * (size_t)dim * dim);
 }
 // EnvMap::EvalLocal on the baked cube: rows (localDir.xyz, lod) -> rgb (twin of the product's pt_probe kind 9)
 void ptref_env_eval(void* h, const float* in, uint32_t n, float* out) {

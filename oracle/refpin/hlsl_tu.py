@@ -166,7 +166,7 @@ def to_cpp(code):
     code = code.replace("(applyMIS)?(path.GetBsdfScatterPdf()):(0.0)", "(applyMIS)?((float)path.GetBsdfScatterPdf()):(0.0)")
     # swizzles on scalars (literals, named scalars, parenthesised / call expressions) become constructor calls ...
     code = re.sub(r"(?<![\w.])(\d+\.\d*f?|\.\d+f?|\d+)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)     # `0.5.xx`, `0.xxx`
-    code = re.sub(r"\b(HLF_MAX|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE|fp16Max|destinationRes|cubeDim)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
+    code = re.sub(r"\b(HLF_MAX|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE|fp16Max|destinationRes|cubeDim|invSamples)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\b((?:\w+\.)?AttenuationDistance)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"((?:\b[A-Za-z_][\w.]*)?\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\))\.(xx|xxx|xxxx|rr|rrr|rrrr)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\bpackedData\.x\b", "packedData", code)                               # `.x` of a scalar
@@ -255,6 +255,14 @@ def main_pt(ref):
                  "BaseLayerCS", "MIPReduceCS"):
         for body in extract_function(etext, name, "EnvMapBaker.hlsl"): w(to_cpp(body) + "\n")
     w("} // namespace embake\n")
+    # EnvMapImportanceSamplingBaker.hlsl: the radiance / importance map pass the light baker's environment quad tree is built from
+    ipath = os.path.join(ref, "Rtxpt/Lighting/Distant/EnvMapImportanceSamplingBaker.hlsl")
+    itext = strip_comments(open(ipath, encoding="latin-1").read())
+    w("// ======== EnvMapImportanceSamplingBaker.hlsl (selected items)\nnamespace emisb {\n")
+    w(to_cpp(extract_struct(itext, "EnvMapImportanceSamplingBakerConstants", "EnvMapImportanceSamplingBaker.hlsl")) + "\n")
+    w('#include "%s/hlsl_emisb_stubs.h"\n' % HERE)
+    for body in extract_function(itext, "BuildMIPDescentImportanceMapCS", "EnvMapImportanceSamplingBaker.hlsl"): w(to_cpp(body) + "\n")
+    w("} // namespace emisb\n")
     w("} // namespace hl\n")
     w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
 

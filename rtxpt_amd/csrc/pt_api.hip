@@ -314,7 +314,7 @@ int bake_env_quads(pt_context* c) {
         const std::vector<ptk::float4>& p = im.mips[l - 1];
         for (uint y = 0; y < d; y++) for (uint x = 0; x < d; x++) {
             ptk::float4 s = (p[(size_t)(2 * y) * pd + 2 * x] + p[(size_t)(2 * y) * pd + 2 * x + 1]) + (p[(size_t)(2 * y + 1) * pd + 2 * x] + p[(size_t)(2 * y + 1) * pd + 2 * x + 1]);
-            im.mips[l][(size_t)y * d + x] = s * 0.25f;
+            im.mips[l][(size_t)y * d + x] = ptk::env_round_rgba16f(s * 0.25f);      // MipMapGenPass MODE_COLOR (Donut, not vendored: the 2x2 mean of the stored texels, stored as binary16)
         }
     }
     std::vector<QTNode> base; std::vector<uint> packed;

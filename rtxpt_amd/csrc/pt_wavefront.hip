@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(256) k_env_importance(DeviceScene sc, uint dim
         L += (Luminance(radiance) + Average(radiance)) * 0.5f;
         R += radiance;
     }
-    out[i] = make_float4(R.x * invSamples, R.y * invSamples, R.z * invSamples, L * invSamples);
+    out[i] = env_round_rgba16f(make_float4(R.x * invSamples, R.y * invSamples, R.z * invSamples, L * invSamples));      // u_RadianceMap is RGBA16_FLOAT (EnvMapImportanceSamplingBaker.cpp:170)
 }
 
 // BakeEmissiveTriangles (Rtxpt/Lighting/LightsBaker.hlsl:544-716): one thread per emissive triangle, output in sub-instance order

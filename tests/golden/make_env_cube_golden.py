@@ -16,5 +16,6 @@ for name, sc in pin_scenes.env_cube_cases().items():
     o = ptref.Oracle(reference_integrator=True, settings=S); o.set_scene(sc)
     cube, dim, levels = o.env_cube(reference=True)
     out[name] = cube; out[name + "_dim"] = np.array([dim, levels], np.uint32)
+    out[name + "_importance64"] = o.env_importance(64, reference=True)        # BuildMIPDescentImportanceMapCS of EnvMapImportanceSamplingBaker.hlsl over that cube (RGBA16F store)
     print(name, dim, levels, cube.shape)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "env_cube_golden.npz"), **out)

@@ -63,6 +63,24 @@ def test_oracle_cube_matches_live_reference_text(dim, nlights, seed):
     assert np.array_equal(a, b) and da == dim and la == {16: 2, 32: 3, 128: 5}[dim]
 
 
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_importance_map_matches_reference_text_golden(name):
+    """Level 0 of the radiance / importance map the environment quad-tree lights are made from: BuildMIPDescentImportanceMapCS of the reference's
+    EnvMapImportanceSamplingBaker.hlsl (4 x 4 cube fetches per texel through the equal-area octahedral map, the RGBA16_FLOAT store) == the oracle's, bit for bit."""
+    g = np.load(GOLDEN)
+    (_, _, _), o = _cube(CASES[name])
+    got = o.env_importance(64)
+    assert np.array_equal(got.view(np.uint32), g[name + "_importance64"].view(np.uint32))
+    assert np.array_equal(got, got.astype(np.float16).astype(np.float32)) and got[..., 3].min() > 0          # every value is a binary16 value
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="no /root/reference on this machine: the reference text cannot be compiled here")
+def test_oracle_importance_map_matches_live_reference_text():
+    (_, _, _), o = _cube(CASES["sky_64_hdr_sun"], reference=True)
+    for dim in (32, 256):
+        assert np.array_equal(o.env_importance(dim).view(np.uint32), o.env_importance(dim, reference=True).view(np.uint32))
+
+
 def test_cube_clamps_to_fp16_range_and_scales_by_quarter():
     """GenerateTexel: radiance x c_envMapRadianceScale (1/4, Sample.cpp:88) clamped to [0, HLF_MAX] (EnvMapBaker.hlsl:236-242)."""
     sc = dict(CASES["sky_16"]); rgb, tw, cm = sc["env"]
