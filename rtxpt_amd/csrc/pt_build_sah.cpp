@@ -36,10 +36,13 @@ struct Bins { B3 box[3][kBins]; uint cnt[3][kBins]; void reset() { for (int a = 
 struct Pool {
     unsigned T; std::vector<std::thread> th; const std::function<void(unsigned)>* job = nullptr;
     std::atomic<unsigned long long> gen{0}; std::atomic<unsigned> pending{0}; std::atomic<bool> quit{false};
-    explicit Pool(unsigned n) : T(n) { for (unsigned t = 1; t < T; t++) th.emplace_back([this, t] { unsigned long long seen = 0;
-        for (;;) { unsigned spins = 0;
-                   while (gen.load(std::memory_order_acquire) == seen) { if (quit.load(std::memory_order_relaxed)) return; if (++spins > 2000u) std::this_thread::yield(); }
-                   seen++; (*job)(t); pending.fetch_sub(1, std::memory_order_acq_rel); } }); }
+    explicit Pool(unsigned n) : T(n) {
+        try { for (unsigned t = 1; t < T; t++) th.emplace_back([this, t] { unsigned long long seen = 0;
+            for (;;) { unsigned spins = 0;
+                       while (gen.load(std::memory_order_acquire) == seen) { if (quit.load(std::memory_order_relaxed)) return; if (++spins > 2000u) std::this_thread::yield(); }
+                       seen++; (*job)(t); pending.fetch_sub(1, std::memory_order_acq_rel); } }); }
+        catch (...) { quit.store(true); for (auto& x : th) x.join(); throw; }      // a thread could not be created: release the ones that were (the caller falls back)
+    }
     ~Pool() { quit.store(true); for (auto& x : th) x.join(); }
     void run(const std::function<void(unsigned)>& f) {
         if (T == 1) { f(0); return; }

@@ -79,7 +79,7 @@ int32_t read_exr(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H, 
     if (ch.empty() || comp < 0 || !haveDw) return PT_ERROR_IO;
     if (comp > 3) return PT_ERROR_UNSUPPORTED;                                      // 0 none, 1 RLE, 2 ZIPS, 3 ZIP; PIZ / PXR24 / B44 / DWA are not read
     const long long w = (long long)dw[2] - dw[0] + 1, h = (long long)dw[3] - dw[1] + 1;
-    if (w <= 0 || h <= 0 || w > 32768 || h > 32768) return PT_ERROR_IO;
+    if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || w * h > (1ll << 28)) return PT_ERROR_IO;      // (a damaged data window must not turn into a 12 GB allocation)
     size_t lineBytes = 0; int idx[3] = {-1, -1, -1}, yIdx = -1; std::vector<size_t> chOff(ch.size());
     for (size_t k = 0; k < ch.size(); k++) {
         if (ch[k].xs != 1 || ch[k].ys != 1) return PT_ERROR_UNSUPPORTED;            // sub-sampled (luminance / chroma) channels
@@ -91,6 +91,7 @@ int32_t read_exr(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H, 
     for (int k = 0; k < 3; k++) if (ch[(size_t)idx[k]].type == 0) return PT_ERROR_UNSUPPORTED;      // uint channels carry ids, not radiance
     const unsigned linesPerBlock = comp == 3 ? 16u : 1u;
     const size_t blocks = ((size_t)h + linesPerBlock - 1) / linesPerBlock;
+    if (blocks * 8 > d.size()) return PT_ERROR_IO;                                   // the offset table alone would not fit the file
     std::vector<unsigned long long> offs(blocks); for (auto& o : offs) o = r.u64();
     if (!r.ok) return PT_ERROR_IO;
     W = (uint32_t)w; H = (uint32_t)h; rgb.assign((size_t)w * h * 3, 0.f);
@@ -127,7 +128,8 @@ int32_t read_rgbe(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H,
     (void)fmt;
     if (!line(s)) return PT_ERROR_IO;
     long h = 0, w = 0; if (sscanf(s.c_str(), "-Y %ld +X %ld", &h, &w) != 2) return PT_ERROR_UNSUPPORTED;      // other orientations are legal but not written by the tools in use
-    if (w <= 0 || h <= 0 || w > 32768 || h > 32768) return PT_ERROR_IO;
+    if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || (long long)w * h > (1ll << 28)) return PT_ERROR_IO;
+    if ((size_t)h > d.size()) return PT_ERROR_IO;                                    // every scan line takes at least a byte
     W = (uint32_t)w; H = (uint32_t)h; rgb.assign((size_t)w * h * 3, 0.f);
     std::vector<unsigned char> sl((size_t)w * 4);
     for (long y = 0; y < h; y++) {
