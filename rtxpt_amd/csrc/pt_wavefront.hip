@@ -7,6 +7,9 @@
 
 namespace ptk {
 
+#ifndef PT_SAMPLE_MINOR
+#define PT_SAMPLE_MINOR 1       // 1: the samples of a pixel are neighbours in the path pool (pixel-major), 0: all pixels of sample 0, then of sample 1, ...
+#endif
 #ifndef T8_CHUNKS_PER_WAVE_MIN
 #define T8_CHUNKS_PER_WAVE_MIN 1     // small launches: fewer waves, each working through this many 64-ray chunks (idle quads refill from the next chunk)
 #endif
@@ -53,7 +56,11 @@ __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool 
     uint i = blockIdx.x * 256u + threadIdx.x;
     uint total = numOwned * spp;
     if (i >= total) return;
+#if PT_SAMPLE_MINOR
+    uint kpx = i / spp, s = i - kpx * spp, px = ownedPixels[kpx];      // the samples of a pixel are neighbours in the pool: a 64-path chunk is 16 pixels x 4 samples
+#else
     uint s = i / numOwned, px = ownedPixels[i - s * numOwned];
+#endif
     PathState p = k.generate(px >> 16, px & 0xFFFFu, sampleFirst + s);
     store_path(pool, i, p);
     queue[i] = i;
@@ -303,7 +310,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PathPool pool, const uint* _
     uint addr = (px & 0xFFFFu) * width + (px >> 16);
     float4 acc = accum[addr];
     for (uint s = 0; s < spp; s++) {
-        uint4 c = pool.s2[s * numOwned + kpx];
+        uint4 c = pool.s2[PT_SAMPLE_MINOR ? kpx * spp + s : s * numOwned + kpx];
         float2 l0 = Fp16ToFp32(c.z), l1 = Fp16ToFp32(c.w);
         float4 col = make_float4(l0.x, l0.y, l1.x, 1.0f);
         float blend = 1.0f / (float)(accumCountBase + s + 1u);
