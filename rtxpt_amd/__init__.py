@@ -23,7 +23,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 
 # every symbol include/mi355pt.h declares
 EXPORTS = [
-    "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
+    "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
     "pt_set_environment", "pt_set_environment_bake", "pt_env_bake_lights", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
@@ -281,6 +281,34 @@ def material_from_json(text, texture_words=(0xFFFFFFFF,) * 5):
 class PtAnalyticLightDesc(ctypes.Structure):
     _fields_ = [("type", ctypes.c_uint32), ("position", ctypes.c_float * 3), ("direction", ctypes.c_float * 3), ("color", ctypes.c_float * 3), ("intensity", ctypes.c_float),
                 ("radius", ctypes.c_float), ("innerAngle", ctypes.c_float), ("outerAngle", ctypes.c_float)]
+
+
+class GltfAnimation:
+    """pt_gltf_animation_*: the animations of a .gltf / .glb file, evaluated on the host into the instance transforms pt_animate takes."""
+    def __init__(self, path):
+        self.L = load_library(); self.h = ctypes.c_void_p(); n = ctypes.c_uint32(); d = ctypes.c_float()
+        self.L.pt_gltf_animation_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_float)]
+        self.L.pt_gltf_animation_instances.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint32]
+        self.L.pt_gltf_animation_free.argtypes = [ctypes.c_void_p]; self.L.pt_gltf_animation_free.restype = None
+        r = self.L.pt_gltf_animation_load(str(path).encode(), ctypes.byref(self.h), ctypes.byref(n), ctypes.byref(d))
+        if r != PT_OK: raise PtError(r, "pt_gltf_animation_load(%s)" % path)
+        self.count, self.duration = n.value, d.value
+
+    def instances(self, t, animation=0):
+        """INSTANCE_DTYPE array of the scene's instances at time t [s]"""
+        from . import scenes
+        n = self.L.pt_gltf_animation_instances(self.h, animation, float(t), None, 0)
+        if n < 0: raise PtError(-n, "pt_gltf_animation_instances")
+        out = np.zeros(n, scenes.INSTANCE_DTYPE)
+        if n: assert self.L.pt_gltf_animation_instances(self.h, animation, float(t), _p(out), n) == n
+        return out
+
+    def close(self):
+        if self.h: self.L.pt_gltf_animation_free(self.h); self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
 
 
 def read_float_image(path):

@@ -194,6 +194,8 @@ struct Loader {
     std::vector<PtGeometryDesc> geoms; std::vector<PtMeshDesc> meshes; std::vector<PtInstanceDesc> instances; std::vector<PTMaterialData> materials;
     std::vector<std::vector<uint8_t>> texPixels; std::vector<PtTextureDesc> texDescs; std::map<std::pair<int, int>, uint32_t> texCache;   // (image, srgb) -> texture word
     std::vector<int> meshMap; std::vector<M4> instanceWorld;      // instanceWorld: the double-precision local-to-world of each instance (scene-graph import composes in double)
+    struct NodeTRS { bool has[3]; double t[3], q[4], s[3]; };      // animation: per node, the channels that replace its translation / rotation / scale (pt_gltf_animation)
+    const std::vector<NodeTRS>* nodeOverride = nullptr;
 
     bool accessor(int idx, std::vector<double>& out, int& comps) {
         const JValue* accs = root.get("accessors"); if (!accs || idx < 0 || (size_t)idx >= accs->size()) { err = "bad accessor index"; return false; }
@@ -321,12 +323,15 @@ struct Loader {
     void visit(int node, const M4& parent, int depth) {
         const JValue* nodes = root.get("nodes"); if (!nodes || node < 0 || (size_t)node >= nodes->size() || depth > 256) return;
         const JValue& n = nodes->arr[node]; M4 local = m4_identity();
-        if (const JValue* mx = n.get("matrix")) { if (mx->size() == 16) for (int i = 0; i < 16; i++) local.m[i] = mx->arr[i].num; }
+        const NodeTRS* ov = (nodeOverride && (size_t)node < nodeOverride->size()) ? &(*nodeOverride)[(size_t)node] : nullptr;
+        const bool animated = ov && (ov->has[0] || ov->has[1] || ov->has[2]);
+        if (const JValue* mx = n.get("matrix"); mx && !animated) { if (mx->size() == 16) for (int i = 0; i < 16; i++) local.m[i] = mx->arr[i].num; }      // (glTF: an animated node has TRS properties, not a matrix)
         else {
             double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
             if (const JValue* v = n.get("translation")) if (v->size() == 3) for (int i = 0; i < 3; i++) t[i] = v->arr[i].num;
             if (const JValue* v = n.get("rotation")) if (v->size() == 4) for (int i = 0; i < 4; i++) q[i] = v->arr[i].num;
             if (const JValue* v = n.get("scale")) if (v->size() == 3) for (int i = 0; i < 3; i++) s[i] = v->arr[i].num;
+            if (ov) { if (ov->has[0]) memcpy(t, ov->t, sizeof(t)); if (ov->has[1]) memcpy(q, ov->q, sizeof(q)); if (ov->has[2]) memcpy(s, ov->s, sizeof(s)); }
             local = m4_trs(t, q, s);
         }
         M4 world = m4_mul(parent, local);
@@ -434,6 +439,100 @@ static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path) {
     r = pt_set_geometry(ctx, &gb, L.geoms.data(), (uint32_t)L.geoms.size(), L.meshes.data(), (uint32_t)L.meshes.size());
     if (r != PT_OK) return r;
     return pt_set_instances(ctx, L.instances.data(), (uint32_t)L.instances.size());
+}
+
+// ================================================================ glTF animations (SURVEY.md 8f N2 leftovers)
+// The reference animates through Donut's scene graph (Sample::Animate, Rtxpt/Sample.cpp:785-811 -> Scene::Animate, SceneGraphAnimation: not vendored); what a glTF file
+// says about its animations is defined by the glTF 2.0 specification, which is what is implemented here: samplers with LINEAR (spherical for rotations), STEP and
+// CUBICSPLINE interpolation over node translation / rotation / scale channels, time clamped to the sampler's key range. Morph-target weights and skins are not read.
+struct pt_gltf_animation {
+    Loader L; bool parsed = false;
+    struct Sampler { std::vector<double> in, out; int comps = 0; int mode = 0; };      // mode 0 LINEAR, 1 STEP, 2 CUBICSPLINE
+    struct Channel { int sampler, node, path; };                                       // path 0 translation, 1 rotation, 2 scale
+    struct Anim { std::vector<Sampler> samplers; std::vector<Channel> channels; double duration = 0; };
+    std::vector<Anim> anims;
+};
+namespace {
+void quat_normalize(double q[4]) { double l = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]); if (l > 0) for (int i = 0; i < 4; i++) q[i] /= l; }
+void sample_channel(const pt_gltf_animation::Sampler& sp, int path, double t, double* v) {
+    const int n = path == 1 ? 4 : 3; const size_t keys = sp.in.size();
+    const size_t stride = sp.mode == 2 ? (size_t)n * 3 : (size_t)n, valueAt = sp.mode == 2 ? (size_t)n : 0;      // CUBICSPLINE stores in-tangent, value, out-tangent per key
+    auto value = [&](size_t k, double* o) { for (int i = 0; i < n; i++) o[i] = sp.out[k * stride + valueAt + (size_t)i]; };
+    if (keys == 1 || t <= sp.in[0]) { value(0, v); if (path == 1) quat_normalize(v); return; }
+    if (t >= sp.in[keys - 1]) { value(keys - 1, v); if (path == 1) quat_normalize(v); return; }
+    size_t k = 0; while (k + 2 < keys && sp.in[k + 1] <= t) k++;
+    const double t0 = sp.in[k], t1 = sp.in[k + 1], dt = t1 - t0, u = dt > 0 ? (t - t0) / dt : 0.0;
+    double a[4], b[4]; value(k, a); value(k + 1, b);
+    if (sp.mode == 1) { memcpy(v, a, sizeof(double) * (size_t)n); }
+    else if (sp.mode == 2) {
+        const double u2 = u * u, u3 = u2 * u;
+        for (int i = 0; i < n; i++) { const double m0 = sp.out[k * stride + (size_t)n * 2 + (size_t)i] * dt, m1 = sp.out[(k + 1) * stride + (size_t)i] * dt;      // out-tangent of key k, in-tangent of key k + 1
+            v[i] = (2 * u3 - 3 * u2 + 1) * a[i] + (u3 - 2 * u2 + u) * m0 + (-2 * u3 + 3 * u2) * b[i] + (u3 - u2) * m1; }
+    } else if (path == 1) {                                                              // spherical linear interpolation along the shorter arc
+        double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        if (d < 0) { d = -d; for (int i = 0; i < 4; i++) b[i] = -b[i]; }
+        if (d > 0.9995) for (int i = 0; i < 4; i++) v[i] = a[i] + u * (b[i] - a[i]);
+        else { const double th = acos(d), sn = sin(th), wa = sin((1 - u) * th) / sn, wb = sin(u * th) / sn; for (int i = 0; i < 4; i++) v[i] = wa * a[i] + wb * b[i]; }
+    } else for (int i = 0; i < n; i++) v[i] = a[i] + u * (b[i] - a[i]);
+    if (path == 1) quat_normalize(v);
+}
+int32_t gltf_animation_load_impl(const char* path, pt_gltf_animation** out, uint32_t* numAnimations, float* duration) {
+    if (!path || !out) return PT_ERROR_INVALID_ARGUMENT;
+    *out = nullptr; if (numAnimations) *numAnimations = 0; if (duration) *duration = 0.f;
+    std::unique_ptr<pt_gltf_animation> A(new pt_gltf_animation()); A->L.ctx = nullptr;
+    int32_t r = load_gltf_file(path, A->L); if (r != PT_OK) return r;
+    if (const JValue* anims = A->L.root.get("animations")) for (auto& ja : anims->arr) {
+        pt_gltf_animation::Anim an;
+        if (const JValue* ss = ja.get("samplers")) for (auto& js : ss->arr) {
+            pt_gltf_animation::Sampler sp; int c = 0;
+            if (!A->L.accessor(js.intOr("input", -1), sp.in, c) || c != 1 || sp.in.empty()) return PT_ERROR_IO;
+            if (!A->L.accessor(js.intOr("output", -1), sp.out, sp.comps)) return PT_ERROR_IO;
+            for (size_t k = 1; k < sp.in.size(); k++) if (!(sp.in[k] >= sp.in[k - 1])) return PT_ERROR_IO;      // key times must not decrease
+            std::string m = js.strOr("interpolation", "LINEAR"); sp.mode = m == "STEP" ? 1 : m == "CUBICSPLINE" ? 2 : 0;
+            an.samplers.push_back(std::move(sp));
+        }
+        if (const JValue* cs = ja.get("channels")) for (auto& jc : cs->arr) {
+            const JValue* tg = jc.get("target"); if (!tg) continue;
+            std::string pth = tg->strOr("path", ""); int pi = pth == "translation" ? 0 : pth == "rotation" ? 1 : pth == "scale" ? 2 : -1;
+            int node = tg->intOr("node", -1), smp = jc.intOr("sampler", -1);
+            if (pi < 0 || node < 0) continue;                                            // (weights, or a channel without a node: ignored as the specification allows)
+            if (smp < 0 || (size_t)smp >= an.samplers.size()) return PT_ERROR_IO;
+            const pt_gltf_animation::Sampler& sp = an.samplers[(size_t)smp]; const size_t n = pi == 1 ? 4 : 3;
+            if ((size_t)sp.comps != n || sp.out.size() != sp.in.size() * n * (sp.mode == 2 ? 3u : 1u)) return PT_ERROR_IO;
+            an.channels.push_back({smp, node, pi}); if (sp.in.back() > an.duration) an.duration = sp.in.back();
+        }
+        A->anims.push_back(std::move(an));
+    }
+    if (numAnimations) *numAnimations = (uint32_t)A->anims.size();
+    if (duration) for (auto& an : A->anims) if ((float)an.duration > *duration) *duration = (float)an.duration;
+    *out = A.release();
+    return PT_OK;
+}
+} // namespace
+extern "C" int32_t pt_gltf_animation_load(const char* path, pt_gltf_animation** out, uint32_t* numAnimations, float* duration) {
+    try { return gltf_animation_load_impl(path, out, numAnimations, duration); } catch (...) { if (out) *out = nullptr; return PT_ERROR_IO; }
+}
+extern "C" void pt_gltf_animation_free(pt_gltf_animation* a) { delete a; }
+extern "C" int32_t pt_gltf_animation_instances(pt_gltf_animation* a, uint32_t animation, float t, PtInstanceDesc* out, uint32_t capacity) {
+    if (!a || (capacity && !out)) return -PT_ERROR_INVALID_ARGUMENT;
+    try {
+        const JValue* nodes = a->L.root.get("nodes"); const size_t nn = nodes ? nodes->size() : 0;
+        std::vector<Loader::NodeTRS> ov(nn); for (auto& o : ov) { o.has[0] = o.has[1] = o.has[2] = false; }
+        if (animation < a->anims.size()) for (auto& c : a->anims[animation].channels) {
+            if ((size_t)c.node >= nn) continue;
+            Loader::NodeTRS& o = ov[(size_t)c.node]; double v[4] = {0, 0, 0, 1};
+            sample_channel(a->anims[animation].samplers[(size_t)c.sampler], c.path, (double)t, v);
+            o.has[c.path] = true; if (c.path == 0) memcpy(o.t, v, 24); else if (c.path == 1) memcpy(o.q, v, 32); else memcpy(o.s, v, 24);
+        }
+        Loader& L = a->L; L.instances.clear(); L.instanceWorld.clear(); L.nodeOverride = &ov;
+        int sceneIdx = L.root.intOr("scene", 0); const JValue* scenes = L.root.get("scenes");
+        if (scenes && (size_t)sceneIdx < scenes->size()) { if (const JValue* ns = scenes->arr[sceneIdx].get("nodes")) for (auto& n : ns->arr) L.visit((int)n.num, m4_identity(), 0); }
+        else if (nodes) for (size_t i = 0; i < nodes->size(); i++) L.visit((int)i, m4_identity(), 0);
+        L.nodeOverride = nullptr;
+        const size_t n = L.instances.size() < capacity ? L.instances.size() : capacity;
+        if (n) memcpy(out, L.instances.data(), n * sizeof(PtInstanceDesc));
+        return (int32_t)L.instances.size();
+    } catch (...) { a->L.nodeOverride = nullptr; return -PT_ERROR_IO; }
 }
 
 // ================================================================ RTXPT `.scene.json` asset folders

@@ -213,6 +213,53 @@ def test_gltf_import_equals_raw_buffers(tmp_path):
     assert np.array_equal(b.radiance(), o.radiance())
 
 
+def test_gltf_animation_drives_pt_animate(tmp_path):
+    """pt_gltf_animation_* -> pt_animate (Sample::Animate seam): the file's rest pose is what pt_load_scene_gltf built, and a frame rendered after
+    pt_animate(instances at t) equals the oracle's frame of the scene with those instance transforms."""
+    pt, scenes, parallel, ptref = _imports()
+    from tests.gltf_writer import write_gltf
+    sc, cam = scenes.cornell_box("C2")
+    path = tmp_path / "cornell.gltf"
+    write_gltf(sc, str(path))
+    doc = json.loads(path.read_text()); k = len(doc["nodes"]) - 1
+    t34 = sc["instances"]["transform"][k].reshape(3, 4)
+    scl = np.linalg.norm(t34[:, :3].astype(np.float64), axis=0); ang = float(np.arctan2(t34[0, 2] / scl[2], t34[0, 0] / scl[0]))      # the tall box: scale, then a turn about y
+    qy = lambda a: [0.0, float(np.sin(a / 2)), 0.0, float(np.cos(a / 2))]
+    doc["nodes"][k] = {"mesh": doc["nodes"][k]["mesh"], "translation": [float(v) for v in t34[:, 3]], "rotation": qy(ang), "scale": [float(v) for v in scl]}
+    keys = np.array([0.0, 1.0, 2.0], np.float32); tr = (t34[:, 3][None, :] + np.array([[0, 0, 0], [0.1, 0.05, 0], [0.1, 0.2, -0.1]], np.float32)).astype(np.float32)
+    q = np.array([qy(ang), qy(ang + 0.6), qy(ang + 1.2)], np.float32)
+    blob = keys.tobytes() + tr.tobytes() + q.tobytes(); (tmp_path / "anim.bin").write_bytes(blob)
+    nb, nv, na = len(doc["buffers"]), len(doc["bufferViews"]), len(doc["accessors"])
+    doc["buffers"].append({"uri": "anim.bin", "byteLength": len(blob)})
+    doc["bufferViews"] += [{"buffer": nb, "byteOffset": 0, "byteLength": 12}, {"buffer": nb, "byteOffset": 12, "byteLength": 36}, {"buffer": nb, "byteOffset": 48, "byteLength": 48}]
+    doc["accessors"] += [{"bufferView": nv, "componentType": 5126, "count": 3, "type": "SCALAR", "min": [0.0], "max": [2.0]}, {"bufferView": nv + 1, "componentType": 5126, "count": 3, "type": "VEC3"},
+                         {"bufferView": nv + 2, "componentType": 5126, "count": 3, "type": "VEC4"}]
+    doc["animations"] = [{"samplers": [{"input": na, "output": na + 1}, {"input": na, "output": na + 2}],
+                          "channels": [{"sampler": 0, "target": {"node": k, "path": "translation"}}, {"sampler": 1, "target": {"node": k, "path": "rotation"}}]}]
+    path.write_text(json.dumps(doc))
+    an = pt.GltfAnimation(path)
+    assert an.count == 1 and an.duration == 2.0
+    rest = an.instances(0.0)
+    assert np.array_equal(rest["meshIndex"], sc["instances"]["meshIndex"]) and np.array_equal(rest["transform"][:k], sc["instances"]["transform"][:k])
+    assert np.allclose(rest["transform"][k], sc["instances"]["transform"][k], rtol=0, atol=1e-6)
+    S = scenes.config_settings("C2"); w, h = 160, 96
+    camd = scenes.bridge_camera(w, h, **cam)
+    g = pt.PathTracer(); g.load_scene_gltf(str(path))
+    rgb, tw, cm = sc["env"]
+    p = pt.PtEnvMapSceneParams((ctypes.c_float * 12)(*tw.tolist()), (ctypes.c_float * 3)(*(cm * np.float32(4.0)).tolist()), 1.0)
+    assert g.L.pt_set_environment(g.h, rgb.ctypes.data_as(ctypes.c_void_p), rgb.shape[1], rgb.shape[0], ctypes.byref(p)) == 0
+    assert g.L.pt_set_environment_bake(g.h, 256, None, 0) == 0
+    g.set_camera(camd); g.set_settings(S); g.resize(w, h); g.render(0, 1); first = g.radiance().copy()
+    inst = an.instances(1.4)
+    assert not np.array_equal(inst["transform"][k], rest["transform"][k]) and np.array_equal(inst["transform"][:k], rest["transform"][:k])
+    g.animate(instances=inst, rebuild=False); g.render(0, 2)
+    assert not np.array_equal(g.radiance(), first)
+    (tmp_path / "c.scene.json").write_text(json.dumps({"models": ["cornell.gltf"], "graph": [{"model": 0}]}))
+    sc2 = dict(sc); sc2["materials"] = pt.SceneImport(tmp_path / "c.scene.json").materials.copy()
+    o = ptref.Oracle(); o.set_scene(sc2); o.set_instances(inst); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.render(0, 2)
+    assert np.array_equal(g.radiance(), o.radiance())
+
+
 def test_refit_equals_rebuild_and_oracle():
     """pt_animate: instance motion -> LBVH refit; refit, full rebuild and the oracle (fresh SAH build) agree bit-for-bit."""
     pt, scenes, parallel, ptref = _imports()
