@@ -78,6 +78,26 @@ struct RayCone {
     }
 };
 // TexLODHelpers.hlsli:129-143
+// Donut's ConvertSpecularGlossToMetalRough (donut/shaders/scene_material.hlsli, un-vendored), called by EvaluateSceneMaterialRTXPT for
+// PTMaterialFlags_UseSpecularGlossModel materials (PathTracerBridgeDonut.hlsli:318-333; ENABLE_METAL_ROUGH_RECONSTRUCTION 1, :15, :772-774): restated from the
+// algorithm it follows, the Khronos KHR_materials_pbrSpecularGlossiness "convert-between-workflows" sample (solveMetallic + the two base-colour estimates blended
+// by metallic^2, perceived brightness = sqrt(0.299 r^2 + 0.587 g^2 + 0.114 b^2), dielectric specular 0.04). UNPINNED: the function's own text is outside the tree.
+static inline float GetPerceivedBrightness(float3 c) { return sqrtf_((0.299f * c.x * c.x + 0.587f * c.y * c.y) + 0.114f * c.z * c.z); }
+static inline void ConvertSpecularGlossToMetalRough(float3 diffuseColor, float3 specularColor, float3& baseColor, float& metalness) {
+    const float epsilon = 1e-6f, dielectricSpecular = 0.04f;
+    float diffuseBrightness = GetPerceivedBrightness(diffuseColor), specularBrightness = GetPerceivedBrightness(specularColor);
+    float oneMinusSpecularStrength = 1.0f - fmaxf_(specularColor.x, fmaxf_(specularColor.y, specularColor.z));
+    metalness = 0.0f;
+    if (!(specularBrightness < dielectricSpecular)) {
+        float b = (diffuseBrightness * oneMinusSpecularStrength / (1.0f - dielectricSpecular) + specularBrightness) - 2.0f * dielectricSpecular;
+        float c = dielectricSpecular - specularBrightness;
+        float D = fmaxf_(b * b - 4.0f * dielectricSpecular * c, 0.0f);
+        metalness = saturate((-b + sqrtf_(D)) / (2.0f * dielectricSpecular));
+    }
+    float3 baseColorFromDiffuse = diffuseColor * (oneMinusSpecularStrength / (1.0f - dielectricSpecular) / fmaxf_(1.0f - metalness, epsilon));
+    float3 baseColorFromSpecular = (specularColor - make_float3(dielectricSpecular * (1.0f - metalness))) * (1.0f / fmaxf_(metalness, epsilon));
+    baseColor = saturate3(lerp3(baseColorFromDiffuse, baseColorFromSpecular, metalness * metalness));
+}
 static inline float computeRayConeTriangleLODValue(const float3 v[3], const float2 t[3], const float3x4& M) {
     float2 tx10 = t[1] - t[0], tx20 = t[2] - t[0];
     float Ta = fabsf(tx10.x * tx20.y - tx20.x * tx10.y);
@@ -342,6 +362,12 @@ struct PathTracer {
         float3 baseColor = LP::r3(material.BaseOrDiffuseColor * xyz(texBase));
         float roughness = LP::r(material.Roughness * texMR.y);
         float metalness = LP::r((material.Flags & PTMaterialFlags_MetalnessInRedChannel) ? material.Metalness * texMR.x : material.Metalness * texMR.z);
+        if (material.Flags & PTMaterialFlags_UseSpecularGlossModel) {                                  // EvaluateSceneMaterialRTXPT, BridgeDonut:318-333: float colours in, lp base colour / metalness out
+            float3 bc; float mt;
+            ConvertSpecularGlossToMetalRough(material.BaseOrDiffuseColor * xyz(texBase), material.SpecularColor * xyz(texMR), bc, mt);
+            baseColor = LP::r3(bc); metalness = LP::r(mt);
+            roughness = LP::r(1.0f - texMR.w * (1.0f - material.Roughness));
+        }
         float transmission = LP::r(material.TransmissionFactor), diffuseTransmission = LP::r(material.DiffuseTransmissionFactor);
         if (material.Flags & PTMaterialFlags_UseTransmissionTexture) { transmission = LP::mul(transmission, LP::r(texTrans.x)); diffuseTransmission = LP::mul(diffuseTransmission, LP::r(texTrans.x)); }
         float3 emissiveColor = LP::r3(material.EmissiveColor);

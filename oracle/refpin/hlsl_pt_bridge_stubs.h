@@ -15,7 +15,24 @@ static const uint MaterialFlags_UseBaseOrDiffuseTexture = PTMaterialFlags_UseBas
 struct MaterialTextureSample { float4 baseOrDiffuse, metalRoughOrSpecular, normal, emissive, occlusion, transmission; };
 static inline MaterialTextureSample DefaultMaterialTextures() { MaterialTextureSample t; t.baseOrDiffuse = float4(1, 1, 1, 1); t.metalRoughOrSpecular = float4(1, 1, 1, 1); t.normal = float4(0.5f, 0.5f, 1.0f, 0.f);
     t.emissive = float4(1, 1, 1, 1); t.occlusion = float4(1, 1, 1, 1); t.transmission = float4(1, 1, 1, 1); return t; }
-template <class C3, class C1> static inline void ConvertSpecularGlossToMetalRough(float3, float3, C3& baseColor, C1& metalness) { baseColor = C3(0); metalness = C1(0); }      // spec-gloss materials are rejected upstream
+// Donut's ConvertSpecularGlossToMetalRough: NOT pinned (its text is outside the tree) — the Khronos KHR_materials_pbrSpecularGlossiness conversion sample it follows, restated;
+// what IS pinned through it is the reference's own call site (EvaluateSceneMaterialRTXPT's spec-gloss branch, the lp conversions of its out arguments, loadSurface downstream).
+static inline float GetPerceivedBrightness(float3 c) { return sqrt((0.299f * c.x * c.x + 0.587f * c.y * c.y) + 0.114f * c.z * c.z); }
+template <class C3, class C1> static inline void ConvertSpecularGlossToMetalRough(float3 diffuseColor, float3 specularColor, C3& baseColor, C1& metalness) {
+    const float epsilon = 1e-6f, dielectricSpecular = 0.04f;
+    float diffuseBrightness = GetPerceivedBrightness(diffuseColor), specularBrightness = GetPerceivedBrightness(specularColor);
+    float oneMinusSpecularStrength = 1.0f - max(specularColor.x, max(specularColor.y, specularColor.z));
+    float m = 0.0f;
+    if (!(specularBrightness < dielectricSpecular)) {
+        float b = (diffuseBrightness * oneMinusSpecularStrength / (1.0f - dielectricSpecular) + specularBrightness) - 2.0f * dielectricSpecular;
+        float c = dielectricSpecular - specularBrightness;
+        float D = max(b * b - 4.0f * dielectricSpecular * c, 0.0f);
+        m = saturate((-b + sqrt(D)) / (2.0f * dielectricSpecular));
+    }
+    float3 fromDiffuse = diffuseColor * (oneMinusSpecularStrength / (1.0f - dielectricSpecular) / max(1.0f - m, epsilon));
+    float3 fromSpecular = (specularColor - float3(dielectricSpecular * (1.0f - m))) * (1.0f / max(m, epsilon));
+    baseColor = C3(saturate(lerp(fromDiffuse, fromSpecular, m * m))); metalness = C1(m);
+}
 static inline float3 interpolate(const float3 v[3], float3 b) { return (v[0] * b.x + v[1] * b.y) + v[2] * b.z; }
 static inline float2 interpolate(const float2 v[3], float3 b) { return (v[0] * b.x + v[1] * b.y) + v[2] * b.z; }
 static inline float4 interpolate(const float4 v[3], float3 b) { return (v[0] * b.x + v[1] * b.y) + v[2] * b.z; }

@@ -555,7 +555,6 @@ int32_t pt_set_materials(pt_context* c, const ::PTMaterialData* mats, uint32_t n
             !chk(PTMaterialFlags_UseNormalTexture, mm.NormalTextureIndex) || !chk(PTMaterialFlags_UseMetalRoughOrSpecularTexture, mm.MetalRoughOrSpecularTextureIndex) ||
             !chk(PTMaterialFlags_UseTransmissionTexture, mm.TransmissionTextureIndex))
             return fail(c, PT_ERROR_INVALID_ARGUMENT, "material references a missing texture");
-        if (mm.Flags & PTMaterialFlags_UseSpecularGlossModel) return fail(c, PT_ERROR_UNSUPPORTED, "specular-gloss materials are not supported");
     }
     c->texDirty = true; c->geomDirty = true;
     return PT_OK;

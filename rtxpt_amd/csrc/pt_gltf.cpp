@@ -274,6 +274,16 @@ struct Loader {
                 m.EnableAlphaTesting = j.strOr("alphaMode", "OPAQUE") == "MASK";                 // MaterialDomain::AlphaTested
                 if (const JValue* ext = j.get("extensions")) {
                     if (const JValue* es = ext->get("KHR_materials_emissive_strength")) m.EmissiveIntensity = (float)es->numOr("emissiveStrength", 1.0);
+                    // KHR_materials_pbrSpecularGlossiness (what Bistro ships): Donut's importer prefers it over pbrMetallicRoughness and fills useSpecularGlossModel, the
+                    // diffuse / specular colours, roughness = 1 - glossiness and BOTH textures as sRGB (ImportFromDonut, MaterialsBaker.cpp:669-670, 698)
+                    if (const JValue* sg = ext->get("KHR_materials_pbrSpecularGlossiness")) {
+                        m.UseSpecularGlossModel = true; m.Metalness = 0.f; m.Opacity = 1.f;
+                        for (int k = 0; k < 3; k++) { m.BaseOrDiffuseColor[k] = 1.f; m.SpecularColor[k] = 1.f; }
+                        if (const JValue* c = sg->get("diffuseFactor")) if (c->size() >= 3) { for (int k = 0; k < 3; k++) m.BaseOrDiffuseColor[k] = (float)c->arr[k].num; if (c->size() > 3) m.Opacity = (float)c->arr[3].num; }
+                        if (const JValue* c = sg->get("specularFactor")) if (c->size() >= 3) for (int k = 0; k < 3; k++) m.SpecularColor[k] = (float)c->arr[k].num;
+                        m.Roughness = 1.f - (float)sg->numOr("glossinessFactor", 1.0);
+                        words[0] = texture(sg->get("diffuseTexture"), true); words[1] = texture(sg->get("specularGlossinessTexture"), true);
+                    }
                     if (const JValue* tr = ext->get("KHR_materials_transmission")) {
                         m.TransmissionFactor = (float)tr->numOr("transmissionFactor", 0.0);
                         words[4] = texture(tr->get("transmissionTexture"), false);

@@ -134,6 +134,29 @@ def with_material_zoo(make):
     return build
 
 
+def with_spec_gloss(make, textured=True):
+    """The scene of `make` with most materials switched to the specular-glossiness model (KHR_materials_pbrSpecularGlossiness as Donut imports it, what Bistro
+    ships): diffuse colour stays, specular colour from dark dielectric (below 0.04: metalness 0 branch) to coloured metal, roughness = 1 - glossiness, and —
+    on textured materials — a specular-glossiness texture (rgb scales the specular colour, alpha the glossiness). Every fourth material stays metal-rough."""
+    import numpy as np
+    def build():
+        sc, cam = make()
+        sc = dict(sc); m = sc["materials"].copy(); rng = np.random.default_rng(77)
+        for k in range(len(m)):
+            if k % 4 == 3: continue
+            m["Flags"][k] |= 0x1
+            kind = k % 3
+            spec = (rng.uniform(0.0, 0.035, 3), rng.uniform(0.04, 0.3, 3), rng.uniform(0.5, 1.0, 3))[kind]
+            m["SpecularColor"][k] = spec.astype(np.float32)
+            if kind == 2: m["BaseOrDiffuseColor"][k] = (m["BaseOrDiffuseColor"][k] * np.float32(0.05)).astype(np.float32)      # a metal: hardly any diffuse
+            m["Roughness"][k] = np.float32(rng.uniform(0.05, 0.9)); m["Metalness"][k] = 0
+            if textured and (m["Flags"][k] & 0x8) and k % 2 == 0:
+                m["MetalRoughOrSpecularTextureIndex"][k] = m["BaseOrDiffuseTextureIndex"][(k + 1) % 24 if (m["Flags"][(k + 1) % 24] & 0x8) else k]; m["Flags"][k] |= 0x4
+        sc["materials"] = m
+        return sc, cam
+    return build
+
+
 def cases():
     c2 = lambda: scenes.cornell_box("C2")
     return {
@@ -153,6 +176,8 @@ def cases():
         "bistro_like": (lambda: scenes.bistro_like(scale=0.02, tex_size=128), scenes.default_settings(), 96, 54, 0, 2),      # alpha test, textures, normal maps, emissive triangles, env quads
         "bistro_like_material_zoo": (with_material_zoo(lambda: scenes.bistro_like(scale=0.02, tex_size=128)), scenes.default_settings(), 96, 54, 2, 2),
         "bistro_like_sun_discs_cube512": (with_sun_discs(lambda: scenes.bistro_like(scale=0.02, tex_size=128), cube_dim=512), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 96, 54, 6, 2),
+        "c2_spec_gloss": (with_spec_gloss(c2), scenes.default_settings(), 64, 36, 1, 2),                            # PTMaterialFlags_UseSpecularGlossModel: metal-rough reconstruction
+        "bistro_like_spec_gloss": (with_spec_gloss(lambda: scenes.bistro_like(scale=0.02, tex_size=128)), scenes.default_settings(), 96, 54, 3, 2),      # + specular-glossiness textures
         "bistro_like_c5": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), scenes.default_settings(), 96, 54, 0, 2),   # + nested-dielectric props
     }
 
