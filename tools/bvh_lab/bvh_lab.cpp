@@ -140,6 +140,110 @@ static Bvh2 build_sah(int bins) {
     return b;
 }
 
+
+// ---- SBVH (Stich et al. 2009): binned object splits + chopped-binning spatial splits with reference unsplitting, to single-reference leaves.
+// alpha: spatial splits are tried when the object split's children overlap by more than alpha x the root area; budget: at most `budget` x n references.
+static Box isect_box(const Box& a, const Box& b) { Box r; r.mn = vmax(a.mn, b.mn); r.mx = vmin(a.mx, b.mx); return r; }
+static inline bool box_valid(const Box& b) { return b.mn.x <= b.mx.x && b.mn.y <= b.mx.y && b.mn.z <= b.mx.z; }
+static Box clip_tri(int t, int ax, float lo, float hi, const Box& cur) {
+    V3 a = tris[t].v0, poly[2][10]; poly[0][0] = a; poly[0][1] = a + tris[t].e1; poly[0][2] = a + tris[t].e2; int np = 3, src = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        float plane = pass ? hi : lo, sgn = pass ? -1.f : 1.f; V3* in = poly[src]; V3* out = poly[src ^ 1]; int no = 0;
+        for (int i = 0; i < np; i++) {
+            V3 p = in[i], q = in[(i + 1) % np]; float dp = sgn * ((&p.x)[ax] - plane), dq = sgn * ((&q.x)[ax] - plane);
+            if (dp >= 0) out[no++] = p;
+            if ((dp > 0 && dq < 0) || (dp < 0 && dq > 0)) { float u = dp / (dp - dq); V3 x = p + (q - p) * u; (&x.x)[ax] = plane; out[no++] = x; }
+        }
+        np = no; src ^= 1; if (!np) break;
+    }
+    Box r; for (int i = 0; i < np; i++) r.grow(poly[src][i]);
+    return isect_box(r, cur);
+}
+struct Ref { Box b; int tri; };
+static Bvh2 build_sbvh(int bins, float alpha, float budget) {
+    Bvh2 b; int n = (int)tris.size(); b.nodes.reserve(3 * n); b.order.reserve((size_t)(n * budget) + 16);
+    std::vector<Ref> all(n); Box rootBox; for (int i = 0; i < n; i++) { all[i] = {tbox[i], i}; rootBox.grow(tbox[i]); }
+    const float rootArea = rootBox.area(); size_t totalRefs = n, maxRefs = (size_t)(n * budget); size_t nSpatial = 0;
+    struct Job { int id; std::vector<Ref> refs; };
+    b.nodes.emplace_back(); std::vector<Job> jobs; jobs.push_back({0, std::move(all)});
+    while (!jobs.empty()) {
+        Job j = std::move(jobs.back()); jobs.pop_back();
+        std::vector<Ref>& R = j.refs; int cnt = (int)R.size();
+        Box nb, cb; for (auto& r : R) { nb.grow(r.b); cb.grow((r.b.mn + r.b.mx) * 0.5f); }
+        b.nodes[j.id].box = nb;
+        if (cnt == 1) { b.nodes[j.id].first = (int)b.order.size(); b.nodes[j.id].count = 1; b.order.push_back(R[0].tri); continue; }
+        // object split
+        float objCost = 3e38f; int objAxis = -1, objBin = -1; Box objL, objR;
+        for (int ax = 0; ax < 3; ax++) {
+            float lo = (&cb.mn.x)[ax], hi = (&cb.mx.x)[ax]; if (!(hi > lo)) continue;
+            std::vector<Box> bb(bins); std::vector<int> bc(bins, 0); float k = bins / (hi - lo);
+            for (auto& r : R) { int bi = std::min(bins - 1, (int)((((&r.b.mn.x)[ax] + (&r.b.mx.x)[ax]) * 0.5f - lo) * k)); bb[bi].grow(r.b); bc[bi]++; }
+            std::vector<float> ra(bins); std::vector<Box> rb(bins); Box acc; int c = 0;
+            for (int i = bins - 1; i > 0; i--) { acc.grow(bb[i]); c += bc[i]; ra[i] = c ? acc.area() * c : 3e38f; rb[i] = acc; }
+            acc = Box(); c = 0;
+            for (int i = 0; i < bins - 1; i++) { acc.grow(bb[i]); c += bc[i]; if (!c || c == cnt) continue; float cost = acc.area() * c + ra[i + 1]; if (cost < objCost) { objCost = cost; objAxis = ax; objBin = i; objL = acc; objR = rb[i + 1]; } }
+        }
+        // spatial split
+        float spCost = 3e38f; int spAxis = -1; float spPos = 0;
+        bool trySpatial = totalRefs < maxRefs && cnt > 1;
+        if (trySpatial && objAxis >= 0) { Box ov = isect_box(objL, objR); trySpatial = box_valid(ov) && ov.area() / rootArea > alpha; }
+        if (trySpatial) {
+            for (int ax = 0; ax < 3; ax++) {
+                float lo = (&nb.mn.x)[ax], hi = (&nb.mx.x)[ax]; if (!(hi > lo)) continue;
+                std::vector<Box> bb(bins); std::vector<int> en(bins, 0), ex(bins, 0); float k = bins / (hi - lo), w = (hi - lo) / bins;
+                for (auto& r : R) {
+                    int b0 = std::min(bins - 1, std::max(0, (int)(((&r.b.mn.x)[ax] - lo) * k))), b1 = std::min(bins - 1, std::max(b0, (int)(((&r.b.mx.x)[ax] - lo) * k)));
+                    en[b0]++; ex[b1]++;
+                    if (b0 == b1) { bb[b0].grow(r.b); continue; }
+                    for (int bi = b0; bi <= b1; bi++) { Box c = clip_tri(r.tri, ax, lo + bi * w, bi == bins - 1 ? hi : lo + (bi + 1) * w, r.b); if (box_valid(c)) bb[bi].grow(c); }
+                }
+                std::vector<float> ra(bins); Box acc; int c = 0;
+                for (int i = bins - 1; i > 0; i--) { acc.grow(bb[i]); c += ex[i]; ra[i] = c ? acc.area() * c : 3e38f; }
+                acc = Box(); c = 0;
+                for (int i = 0; i < bins - 1; i++) { acc.grow(bb[i]); c += en[i]; if (!c) continue; float cost = acc.area() * c + ra[i + 1]; if (ra[i + 1] < 3e38f && cost < spCost) { spCost = cost; spAxis = ax; spPos = lo + (i + 1) * w; } }
+            }
+        }
+        std::vector<Ref> L, Rr;
+        if (spAxis >= 0 && spCost < objCost) {
+            // partition with reference unsplitting
+            Box lb, rbx; int nl = 0, nr = 0; std::vector<int> straddle;
+            for (int i = 0; i < cnt; i++) { const Ref& r = R[i];
+                if ((&r.b.mx.x)[spAxis] <= spPos) { lb.grow(r.b); nl++; L.push_back(r); }
+                else if ((&r.b.mn.x)[spAxis] >= spPos) { rbx.grow(r.b); nr++; Rr.push_back(r); }
+                else straddle.push_back(i); }
+            for (int i : straddle) { const Ref& r = R[i];
+                Box cl = clip_tri(r.tri, spAxis, (&nb.mn.x)[spAxis], spPos, r.b), cr = clip_tri(r.tri, spAxis, spPos, (&nb.mx.x)[spAxis], r.b);
+                bool vl = box_valid(cl), vr = box_valid(cr);
+                if (!vl && !vr) { L.push_back(r); lb.grow(r.b); nl++; continue; }
+                if (!vl) { Rr.push_back({cr, r.tri}); rbx.grow(cr); nr++; continue; }
+                if (!vr) { L.push_back({cl, r.tri}); lb.grow(cl); nl++; continue; }
+                Box lbs = unite(lb, cl), rbs = unite(rbx, cr), lbu = unite(lb, r.b), rbu = unite(rbx, r.b);
+                float cSplit = lbs.area() * (nl + 1) + rbs.area() * (nr + 1), cLeft = lbu.area() * (nl + 1) + rbx.area() * nr, cRight = lb.area() * nl + rbu.area() * (nr + 1);
+                if (nl == 0 && !box_valid(lb)) cRight = 3e38f; if (nr == 0 && !box_valid(rbx)) cLeft = 3e38f;
+                if (cSplit <= cLeft && cSplit <= cRight) { L.push_back({cl, r.tri}); Rr.push_back({cr, r.tri}); lb = lbs; rbx = rbs; nl++; nr++; totalRefs++; }
+                else if (cLeft <= cRight) { L.push_back(r); lb = lbu; nl++; }
+                else { Rr.push_back(r); rbx = rbu; nr++; } }
+            if (L.empty() || Rr.empty() || ((int)L.size() == cnt && (int)Rr.size() == cnt)) { L.clear(); Rr.clear(); }
+            else nSpatial++;
+        }
+        if (L.empty()) {
+            if (objAxis >= 0) { float lo = (&cb.mn.x)[objAxis], hi = (&cb.mx.x)[objAxis], k = bins / (hi - lo);
+                for (auto& r : R) { int bi = std::min(bins - 1, (int)((((&r.b.mn.x)[objAxis] + (&r.b.mx.x)[objAxis]) * 0.5f - lo) * k)); (bi <= objBin ? L : Rr).push_back(r); } }
+            if (L.empty() || Rr.empty()) { L.assign(R.begin(), R.begin() + cnt / 2); Rr.assign(R.begin() + cnt / 2, R.end()); }
+        }
+        { std::vector<Ref>().swap(R); }
+        int l = (int)b.nodes.size(); b.nodes.emplace_back(); int r = (int)b.nodes.size(); b.nodes.emplace_back();
+        b.nodes[j.id].l = l; b.nodes[j.id].r = r;
+        jobs.push_back({r, std::move(Rr)}); jobs.push_back({l, std::move(L)});
+    }
+    // leaves were appended in DFS order (left first): ranges are contiguous; fix `first` of inner nodes
+    { std::vector<int> st{0}, po; while (!st.empty()) { int id = st.back(); st.pop_back(); po.push_back(id); if (!b.nodes[id].count) { st.push_back(b.nodes[id].l); st.push_back(b.nodes[id].r); } }
+      for (int k = (int)po.size() - 1; k >= 0; k--) { Node& nd = b.nodes[po[k]]; if (!nd.count) nd.first = b.nodes[nd.l].first; } }
+    b.root = 0;
+    fprintf(stderr, "  sbvh alpha %g: %zu references for %d triangles (x%.3f), %zu spatial splits\n", alpha, b.order.size(), n, (double)b.order.size() / n, nSpatial);
+    return b;
+}
+
 static int subtree_tris(const Bvh2& b, int id, std::vector<int>& cnt) { const Node& nd = b.nodes[id]; if (nd.count) return cnt[id] = nd.count; return cnt[id] = subtree_tris(b, nd.l, cnt) + subtree_tris(b, nd.r, cnt); }
 static double sah_cost2(const Bvh2& b) { double c = 0; double ra = b.nodes[b.root].box.area(); for (auto& nd : b.nodes) c += nd.box.area() / ra * (nd.count ? nd.count : 1.0); return c; }
 
@@ -289,10 +393,13 @@ int main(int argc, char** argv) {
                (double)N / rays.size(), (double)L / rays.size(), (double)T / rays.size(), (double)(N + L) / rays.size());
         fflush(stdout);
     };
+    if (!getenv("LAB_SKIP_BASE")) {
     eval("lbvh greedy leaf4 (product)", lb, 4, 0);
     eval("lbvh cost-driven leaf4", lb, 4, 1);
     eval("lbvh greedy leaf8", lb, 8, 0);
     for (int r : {16, 64}) { Bvh2 p = build_ploc(r); char nm[64]; snprintf(nm, 64, "ploc r=%d greedy leaf4", r); eval(nm, p, 4, 0); snprintf(nm, 64, "ploc r=%d cost-driven leaf4", r); eval(nm, p, 4, 1); }
+    }
     if (getenv("LAB_SAH")) { Bvh2 s = build_sah(32); eval("binned sah greedy leaf4", s, 4, 0); eval("binned sah cost-driven leaf4", s, 4, 1); eval("binned sah cost-driven leaf8", s, 8, 1); }
+    if (getenv("LAB_SBVH")) for (float al : {1e-5f, 1e-6f}) { Bvh2 s = build_sbvh(32, al, 1.5f); char nm[64]; snprintf(nm, 64, "sbvh a=%g cost-driven leaf4", al); eval(nm, s, 4, 1); }
     return 0;
 }
