@@ -54,6 +54,16 @@ int main(int argc, char** argv) {
         kids += fr.size();
         for (uint c : fr) if (!isLeaf(c)) roots.push_back(c);
     }
-    printf("ok %zu %zu\n", wide, kids);
+    unsigned long long h = 1469598103934665603ull;                      // FNV-1a over the whole topology: equal trees for equal inputs, whatever the thread count
+    auto mix = [&](const std::vector<uint>& v, size_t k) { for (size_t i = 0; i < k; i++) { h ^= v[i]; h *= 1099511628211ull; } };
+    mix(order, n); mix(cl, n - 1); mix(cr, n - 1); mix(rf, n - 1); mix(rl, n - 1); mix(par, n - 1); mix(lp, n); mix(ab, n - 1);
+    // surface-area cost of the binary tree over the generated boxes (inner nodes, relative to the root): what the optimiser lowers
+    std::vector<float> bmn((size_t)(n - 1) * 3), bmx((size_t)(n - 1) * 3); std::vector<uint> po; { std::vector<uint> s2{0u}; while (!s2.empty()) { uint id = s2.back(); s2.pop_back(); po.push_back(id); if (!(cl[id] >> 31)) s2.push_back(cl[id]); if (!(cr[id] >> 31)) s2.push_back(cr[id]); } }
+    double cost = 0, rootArea = 0;
+    for (size_t k = po.size(); k-- > 0;) { uint id = po[k]; float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+        for (uint c : {cl[id], cr[id]}) for (int a = 0; a < 3; a++) { float lo = (c >> 31) ? t[order[c & 0x7FFFFFFFu]].mn[a] : bmn[(size_t)c * 3 + a], hi = (c >> 31) ? t[order[c & 0x7FFFFFFFu]].mx[a] : bmx[(size_t)c * 3 + a]; mn[a] = std::fmin(mn[a], lo); mx[a] = std::fmax(mx[a], hi); }
+        for (int a = 0; a < 3; a++) { bmn[(size_t)id * 3 + a] = mn[a]; bmx[(size_t)id * 3 + a] = mx[a]; }
+        double ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2], ar = ex * ey + ey * ez + ez * ex; cost += ar; if (id == 0) rootArea = ar; }
+    printf("ok %zu %zu %016llx %.4f\n", wide, kids, h, rootArea > 0 ? cost / rootArea : 0.0);
     return 0;
 }

@@ -2,7 +2,7 @@
 // Builds the scene's BVH with several builders (Morton LBVH as pt_build.hip does, PLOC, binned top-down SAH), collapses each to BVH8 with the
 // product's greedy rule or a cost-driven rule, and counts node visits / leaf visits / triangle tests per ray of a nearest-first traversal with the
 // product's pruning rules over a set of path-like rays (camera rays + cosine-distributed bounces). Input: tools/bvh_lab/dump_tris.py.
-//   g++ -O3 -march=native -fopenmp -std=c++17 tools/bvh_lab/bvh_lab.cpp -o /tmp/bvh_lab && /tmp/bvh_lab /tmp/bvh_lab_tris.bin
+//   g++ -O3 -march=native -fopenmp -std=c++17 tools/bvh_lab/bvh_lab.cpp rtxpt_amd/csrc/pt_build_sah.cpp -lpthread -o /tmp/bvh_lab && /tmp/bvh_lab /tmp/bvh_lab_tris.bin
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -14,6 +14,7 @@
 #include <numeric>
 #include <vector>
 #include <omp.h>
+#include "../../rtxpt_amd/csrc/pt_build_sah.h"      // LAB_PRODUCT: the product's host builder (link rtxpt_amd/csrc/pt_build_sah.cpp)
 
 struct V3 { float x, y, z; };
 static inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -247,6 +248,74 @@ static Bvh2 build_sbvh(int bins, float alpha, float budget) {
 static int subtree_tris(const Bvh2& b, int id, std::vector<int>& cnt) { const Node& nd = b.nodes[id]; if (nd.count) return cnt[id] = nd.count; return cnt[id] = subtree_tris(b, nd.l, cnt) + subtree_tris(b, nd.r, cnt); }
 static double sah_cost2(const Bvh2& b) { double c = 0; double ra = b.nodes[b.root].box.area(); for (auto& nd : b.nodes) c += nd.box.area() / ra * (nd.count ? nd.count : 1.0); return c; }
 
+
+// ---- insertion-based optimisation (Bittner et al. 2013; the search of Meister & Bittner 2018): take a node out of the tree, look for the position where
+// putting it back costs the least surface area (branch and bound from the root), put it there. No duplicated references, the leaf set is unchanged.
+static void renumber_dfs(Bvh2& b) {
+    std::vector<int> ord; ord.reserve(b.order.size());
+    std::vector<int> st{b.root}; std::vector<int> po;
+    while (!st.empty()) { int id = st.back(); st.pop_back(); po.push_back(id); Node& nd = b.nodes[id]; if (nd.count) { int t = b.order[nd.first]; nd.first = (int)ord.size(); ord.push_back(t); } else { st.push_back(nd.r); st.push_back(nd.l); } }
+    for (int k = (int)po.size() - 1; k >= 0; k--) { Node& nd = b.nodes[po[k]]; if (!nd.count) nd.first = b.nodes[nd.l].first; }
+    b.order.swap(ord);
+}
+static void optimize_reinsert(Bvh2& b, int passes, float fraction) {
+    int N = (int)b.nodes.size(); std::vector<int> parent(N, -1);
+    for (int i = 0; i < N; i++) if (!b.nodes[i].count) { parent[b.nodes[i].l] = i; parent[b.nodes[i].r] = i; }
+    auto refit_up = [&](int a) { while (a >= 0) { Node& nd = b.nodes[a]; Box nb = unite(b.nodes[nd.l].box, b.nodes[nd.r].box); nd.box = nb; a = parent[a]; } };
+    uint32_t rs = 99u; size_t moved = 0;
+    for (int pass = 0; pass < passes; pass++) {
+        // candidates: the nodes whose parent's box is much larger than their own (area of parent - area), top `fraction`
+        std::vector<std::pair<float, int>> cand; cand.reserve(N);
+        for (int i = 0; i < N; i++) { int p = parent[i]; if (p < 0 || parent[p] < 0) continue; cand.push_back({b.nodes[p].box.area() - b.nodes[i].box.area() * 0.0f + b.nodes[p].box.area() * 0.f + (b.nodes[p].box.area()), i}); }
+        size_t take = (size_t)(cand.size() * fraction); if (take < 1) take = 1;
+        std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), [](auto& a, auto& c) { return a.first > c.first; });
+        for (size_t ci = 0; ci < take; ci++) {
+            int x = cand[ci].second, p = parent[x]; if (p < 0) continue; int g = parent[p]; if (g < 0) continue;
+            int s = b.nodes[p].l == x ? b.nodes[p].r : b.nodes[p].l;
+            // remove x and p: s takes p's place under g
+            (b.nodes[g].l == p ? b.nodes[g].l : b.nodes[g].r) = s; parent[s] = g; refit_up(g);
+            const Box xb = b.nodes[x].box; const float xa = xb.area();
+            // branch and bound from the root
+            struct Q { float induced; int id; }; auto cmp = [](const Q& a, const Q& c) { return a.induced > c.induced; };
+            std::vector<Q> heap; heap.push_back({0.f, b.root}); float best = 3e38f; int bestNode = -1;
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end(), cmp); Q q = heap.back(); heap.pop_back();
+                if (q.induced + xa >= best) break;
+                const Node& nd = b.nodes[q.id]; float direct = unite(nd.box, xb).area(); float tot = q.induced + direct;
+                if (tot < best) { best = tot; bestNode = q.id; }
+                float ind = tot - nd.box.area();
+                if (!nd.count && ind + xa < best) { heap.push_back({ind, nd.l}); std::push_heap(heap.begin(), heap.end(), cmp); heap.push_back({ind, nd.r}); std::push_heap(heap.begin(), heap.end(), cmp); }
+            }
+            // insert: p becomes the parent of (bestNode, x) where bestNode was
+            int n = bestNode, np = parent[n];
+            if (np < 0) { b.root = p; parent[p] = -1; } else { (b.nodes[np].l == n ? b.nodes[np].l : b.nodes[np].r) = p; parent[p] = np; }
+            b.nodes[p].l = n; b.nodes[p].r = x; parent[n] = p; parent[x] = p; refit_up(p);
+            moved += n != s;
+        }
+        fprintf(stderr, "  reinsert pass %d: %zu candidates, %zu moved so far, sah %.2f\n", pass, take, moved, sah_cost2(b));
+    }
+    (void)rs;
+    renumber_dfs(b);
+}
+
+
+// the product's "prefer fast trace" topology (pt_build_sah.cpp) as a lab tree
+static Bvh2 build_product() {
+    int n = (int)tris.size(); std::vector<ptk::SahTri> t(n);
+    for (int i = 0; i < n; i++) { t[i] = {{tbox[i].mn.x, tbox[i].mn.y, tbox[i].mn.z}, {tbox[i].mx.x, tbox[i].mx.y, tbox[i].mx.z}, {tcen[i].x, tcen[i].y, tcen[i].z}}; }
+    std::vector<uint> order(n), cl(n), cr(n), rf(n), rl(n), par(n), lp(n), ab(n);
+    double t0 = omp_get_wtime();
+    ptk::bvh_sah_topology(t.data(), (uint)n, ptk::SahTopology{order.data(), cl.data(), cr.data(), rf.data(), rl.data(), par.data(), lp.data(), ab.data()}, 4u, 0u);
+    fprintf(stderr, "  product builder: %.3f s\n", omp_get_wtime() - t0);
+    Bvh2 b; b.order.assign(order.begin(), order.end()); b.nodes.resize(2 * (size_t)n - 1);
+    for (int q = 0; q < n; q++) { Node& nd = b.nodes[n - 1 + q]; nd.first = q; nd.count = 1; nd.box = tbox[order[q]]; }
+    auto id = [&](uint ref) { return (ref >> 31) ? (int)(n - 1 + (ref & 0x7FFFFFFFu)) : (int)ref; };
+    for (int i = 0; i < n - 1; i++) { Node& nd = b.nodes[i]; nd.l = id(cl[i]); nd.r = id(cr[i]); nd.first = (int)rf[i]; nd.count = 0; }
+    std::vector<int> st{0}, po; while (!st.empty()) { int k = st.back(); st.pop_back(); po.push_back(k); if (!b.nodes[k].count) { st.push_back(b.nodes[k].l); st.push_back(b.nodes[k].r); } }
+    for (int k = (int)po.size() - 1; k >= 0; k--) { Node& nd = b.nodes[po[k]]; if (!nd.count) nd.box = unite(b.nodes[nd.l].box, b.nodes[nd.r].box); }
+    b.root = 0; return b;
+}
+
 // ---- BVH8
 struct Wide { Box cb[8]; int ref[8]; int n = 0; };     // ref >= 0: wide node; ref < 0: leaf ~ref = first<<4 | (count-1)
 struct Bvh8 { std::vector<Wide> nodes; std::vector<int> order; };
@@ -400,6 +469,9 @@ int main(int argc, char** argv) {
     for (int r : {16, 64}) { Bvh2 p = build_ploc(r); char nm[64]; snprintf(nm, 64, "ploc r=%d greedy leaf4", r); eval(nm, p, 4, 0); snprintf(nm, 64, "ploc r=%d cost-driven leaf4", r); eval(nm, p, 4, 1); }
     }
     if (getenv("LAB_SAH")) { Bvh2 s = build_sah(32); eval("binned sah greedy leaf4", s, 4, 0); eval("binned sah cost-driven leaf4", s, 4, 1); eval("binned sah cost-driven leaf8", s, 8, 1); }
+    if (getenv("LAB_PRODUCT")) { Bvh2 s = build_product(); eval("product builder cost-driven leaf4", s, 4, 1); }
+    if (getenv("LAB_REINS")) { Bvh2 s = build_sah(32); eval("binned sah cost-driven leaf4", s, 4, 1);
+        for (int it = 0; it < 3; it++) { optimize_reinsert(s, 2, 0.25f); char nm[64]; snprintf(nm, 64, "sah + reinsertion x%d cost leaf4", 2 * (it + 1)); eval(nm, s, 4, 1); } }
     if (getenv("LAB_SBVH")) for (float al : {1e-5f, 1e-6f}) { Bvh2 s = build_sbvh(32, al, 1.5f); char nm[64]; snprintf(nm, 64, "sbvh a=%g cost-driven leaf4", al); eval(nm, s, 4, 1); }
     return 0;
 }
