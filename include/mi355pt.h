@@ -286,6 +286,9 @@ int32_t pt_scene_import_directional_lights(const pt_scene_import* scene, PtEnvDi
 int32_t pt_scene_import_instances(const pt_scene_import* scene, PtInstanceDesc* out, uint32_t capacity);
 int32_t pt_scene_import_geometries(const pt_scene_import* scene, PtGeometryDesc* out, uint32_t capacity);
 int32_t pt_scene_import_materials(const pt_scene_import* scene, PTMaterialData* out, uint32_t capacity);
+/* texture `index` (0 .. PtSceneJsonInfo.numTextures - 1; the low 16 bits of a material's texture word) as decoded: RGBA8 texels of the top level; out->pixels points
+   into the import object and lives as long as it does */
+int32_t pt_scene_import_texture(const pt_scene_import* scene, uint32_t index, PtTextureDesc* out);
 /* SampleSettings -> PtSettings as Sample::SceneLoaded applies them (Sample.cpp:613-629): maxBounces, maxDiffuseBounces, textureMIPBias overwrite
    bounceCount, diffuseBounceCount, texLODBias when the scene names them; everything else in *settings is left alone. */
 int32_t pt_scene_import_settings(const pt_scene_import* scene, PtSettings* settings);
@@ -337,9 +340,16 @@ int32_t pt_average_luminance(pt_context* ctx, float* avgLuminance);
    (EnvMapBaker.cpp:392-415; Donut is not vendored: the formats are read from their published specifications). OpenEXR: single-part scan-line files with
    half or float R G B (or Y) channels, compression NONE / RLE / ZIPS / ZIP; Radiance .hdr: 32-bit_rle_rgbe, "-Y h +X w". *rgb: width x height x 3 floats, top
    row first (what pt_set_environment takes), allocated by the library, released with pt_image_free. PT_ERROR_IO: unreadable or malformed;
-   PT_ERROR_UNSUPPORTED: tiled / multi-part / deep EXR, PIZ / PXR24 / B44 / DWA compression, sub-sampled or integer channels, .dds, other orientations. */
+   PT_ERROR_UNSUPPORTED: tiled / multi-part / deep EXR, PIZ / PXR24 / B44 / DWA compression, sub-sampled or integer channels, other orientations.
+   A .dds with RGBA16F / RGBA32F pixels is read too (alpha dropped); 8-bit and block-compressed .dds files are textures, not environment sources: pt_image_read_dds. */
 int32_t pt_image_read_float(const char* path, uint32_t* width, uint32_t* height, float** rgb);
 void    pt_image_free(float* rgb);
+/* .dds textures: the reference's material pipeline prefers `x.dds` next to `x.png` (MaterialsBaker.cpp:178-191; its compression script writes BC7, SampleCommon.cpp:
+   700-730) and Donut's TextureCache decodes them. Top mip level of a 2D .dds as RGBA8 (*format = PT_TEX_RGBA8_UNORM / PT_TEX_RGBA8_SRGB per the file's DXGI format)
+   or, for R16G16B16A16_FLOAT / R32G32B32A32_FLOAT files, RGBA32F (*format = PT_TEX_RGBA32F): what PtTextureDesc takes. Block formats BC1 / BC2 / BC3 / BC4 / BC5 /
+   BC7, uncompressed RGBA8 / BGRA8 / BGRX8; legacy FourCC and DX10 headers. *pixels is allocated by the library: pt_image_free((float*)pixels).
+   PT_ERROR_IO: unreadable / truncated; PT_ERROR_UNSUPPORTED: BC6H, cube maps, volumes, arrays, other formats. */
+int32_t pt_image_read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);
 int32_t pt_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 int32_t pt_write_bmp(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 

@@ -19,6 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355PT_LIB", os.path.join(_HERE, "libmi355pt.so"))   # MI355PT_LIB: developer A/B builds only
 
 PT_OK = 0
+PT_ERROR_INVALID_ARGUMENT, PT_ERROR_NO_DEVICE, PT_ERROR_HIP, PT_ERROR_IO, PT_ERROR_UNSUPPORTED, PT_ERROR_NOT_READY = 1, 2, 3, 4, 5, 6
+PT_TEX_RGBA8_UNORM, PT_TEX_RGBA8_SRGB, PT_TEX_RGBA32F = 0, 1, 2
 STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3: "PT_ERROR_HIP", 4: "PT_ERROR_IO", 5: "PT_ERROR_UNSUPPORTED", 6: "PT_ERROR_NOT_READY"}
 
 # every symbol include/mi355pt.h declares
@@ -28,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -311,12 +313,28 @@ class GltfAnimation:
         except Exception: pass
 
 
+def read_dds(path):
+    """pt_image_read_dds: the top mip level of a 2D .dds file. Returns (pixels, format): uint8 [h, w, 4] with PT_TEX_RGBA8_UNORM / PT_TEX_RGBA8_SRGB, or
+    float32 [h, w, 4] with PT_TEX_RGBA32F. No device needed."""
+    L = load_library()
+    w, h, fmt = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(); p = ctypes.c_void_p()
+    L.pt_image_read_dds.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_void_p)]
+    L.pt_image_free.argtypes = [ctypes.c_void_p]; L.pt_image_free.restype = None
+    r = L.pt_image_read_dds(str(path).encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(fmt), ctypes.byref(p))
+    if r != PT_OK: raise PtError(r, "pt_image_read_dds(%s)" % path)
+    try:
+        ct, dt = (ctypes.c_float, np.float32) if fmt.value == 2 else (ctypes.c_uint8, np.uint8)
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ct)), shape=(h.value, w.value, 4)).astype(dt, copy=True), int(fmt.value)
+    finally:
+        L.pt_image_free(p)
+
+
 def read_float_image(path):
     """pt_image_read_float: an OpenEXR (scan-line; none / RLE / ZIPS / ZIP) or Radiance .hdr file as float32 [h, w, 3], top row first. No device needed."""
     L = load_library()
     w, h = ctypes.c_uint32(), ctypes.c_uint32(); p = ctypes.POINTER(ctypes.c_float)()
     L.pt_image_read_float.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.POINTER(ctypes.c_float))]
-    L.pt_image_free.argtypes = [ctypes.POINTER(ctypes.c_float)]; L.pt_image_free.restype = None
+    L.pt_image_free.argtypes = [ctypes.c_void_p]; L.pt_image_free.restype = None
     r = L.pt_image_read_float(str(path).encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(p))
     if r != PT_OK: raise PtError(r, "pt_image_read_float(%s)" % path)
     try:
@@ -399,6 +417,14 @@ class SceneImport:
         self.directional_lights = np.zeros((max(nd, 1), 8), np.float32)      # rows of EMB_DirectionalLight in world space: colour rgb, irradiance, direction xyz, angular size [rad]
         assert self.L.pt_scene_import_directional_lights(self.h, _p(self.directional_lights), nd) == nd
         self.directional_lights = self.directional_lights[:nd]
+
+    def texture(self, index):
+        """pt_scene_import_texture: the decoded top level of imported texture `index` as (uint8 [h, w, 4], format)."""
+        d = PtTextureDesc()
+        self.L.pt_scene_import_texture.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        r = self.L.pt_scene_import_texture(self.h, int(index), ctypes.byref(d))
+        if r != 0: raise PtError(r, "pt_scene_import_texture(%d)" % index)
+        return np.ctypeslib.as_array(ctypes.cast(d.pixels, ctypes.POINTER(ctypes.c_uint8)), shape=(d.height, d.width, 4)).copy(), int(d.format)
 
     def tone_mapping(self, ui=None, camera=-1):
         """pt_scene_import_tone_mapping: Sample::SceneLoaded's exposure defaults + Sample::UpdateCameraFromScene on a ToneMappingParameters record."""

@@ -578,9 +578,20 @@ struct SceneReader {
     pt_scene_import& S; std::string sceneDir, mediaDir, sceneStem; std::vector<std::string> modelPaths; std::vector<ModelSlot> slots; int32_t err = PT_OK;
     explicit SceneReader(pt_scene_import& s) : S(s) {}
 
+    // PTMaterial::Read's loadTexture (MaterialsBaker.cpp:166-193): a `.dds` next to a `.png` wins (the reference's compression script puts BC7 files there); the sRGB flag
+    // comes from the material document, not from the file
     uint32_t add_png_texture(const std::string& file, bool srgb) {
         std::vector<uint8_t> bytes; uint32_t w, h; std::vector<uint8_t> rgba;
-        if (!read_file(file, bytes) || !decode_png(bytes, w, h, rgba)) return 0xFFFFFFFFu;
+        std::string ext = file.size() >= 4 ? file.substr(file.size() - 4) : std::string(); for (char& ch : ext) ch = (char)tolower((unsigned char)ch);
+        std::string dds = ext == ".dds" ? file : std::string();
+        if (ext == ".png") { std::string cand = file.substr(0, file.size() - 4) + ".dds"; if (FILE* f = fopen(cand.c_str(), "rb")) { fclose(f); dds = cand; } }
+        if (!dds.empty()) {
+            uint32_t fmt = 0; void* px = nullptr;
+            if (pt_image_read_dds(dds.c_str(), &w, &h, &fmt, &px) != PT_OK) return 0xFFFFFFFFu;
+            if (fmt == PT_TEX_RGBA32F) { pt_image_free((float*)px); return 0xFFFFFFFFu; }              // (float textures are environment sources, not material inputs)
+            rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px);
+        }
+        else if (!read_file(file, bytes) || !decode_png(bytes, w, h, rgba)) return 0xFFFFFFFFu;
         uint32_t index = (uint32_t)S.texDescs.size(); S.texPixels.push_back(std::move(rgba));
         PtTextureDesc d; d.width = w; d.height = h; d.format = srgb ? PT_TEX_RGBA8_SRGB : PT_TEX_RGBA8_UNORM; d.pixels = nullptr; S.texDescs.push_back(d);
         return pack_texture_word(index, w, h);
@@ -795,6 +806,11 @@ PT_IMPORT_COPY(pt_scene_import_instances, PtInstanceDesc, instances)
 PT_IMPORT_COPY(pt_scene_import_geometries, PtGeometryDesc, geoms)
 PT_IMPORT_COPY(pt_scene_import_materials, PTMaterialData, materials)
 #undef PT_IMPORT_COPY
+extern "C" int32_t pt_scene_import_texture(const pt_scene_import* scene, uint32_t index, PtTextureDesc* out) {
+    if (!scene || !out || index >= scene->texDescs.size()) return PT_ERROR_INVALID_ARGUMENT;
+    *out = scene->texDescs[index]; out->pixels = scene->texPixels[index].data();
+    return PT_OK;
+}
 extern "C" int32_t pt_scene_import_lights(const pt_scene_import* scene, PolymorphicLightInfo* base, PolymorphicLightInfoEx* ex, uint32_t capacity) {
     if (!scene || (capacity && (!base || !ex))) return -PT_ERROR_INVALID_ARGUMENT;
     size_t n = scene->lights.size() < capacity ? scene->lights.size() : capacity;

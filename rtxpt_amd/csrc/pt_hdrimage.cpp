@@ -159,6 +159,11 @@ extern "C" int32_t pt_image_read_float(const char* path, uint32_t* width, uint32
         std::vector<float> rgb; uint32_t w = 0, h = 0; int32_t r;
         if (d.size() >= 4 && d[0] == 0x76 && d[1] == 0x2f && d[2] == 0x31 && d[3] == 0x01) r = read_exr(d, w, h, rgb);
         else if (d.size() >= 2 && d[0] == '#' && d[1] == '?') r = read_rgbe(d, w, h, rgb);
+        else if (d.size() >= 4 && !memcmp(d.data(), "DDS ", 4)) {          // float .dds (RGBA16F / RGBA32F, what the reference's "save baked cube" and nvtt write for HDR images): pt_dds.cpp
+            uint32_t fmt = 0; void* px = nullptr; r = pt_image_read_dds(path, &w, &h, &fmt, &px);
+            if (r == PT_OK && fmt != PT_TEX_RGBA32F) { free(px); return PT_ERROR_UNSUPPORTED; }      // an 8-bit image is no environment source
+            if (r == PT_OK) { rgb.resize((size_t)w * h * 3u); const float* q = (const float*)px; for (size_t i = 0; i < (size_t)w * h; i++) { rgb[3 * i] = q[4 * i]; rgb[3 * i + 1] = q[4 * i + 1]; rgb[3 * i + 2] = q[4 * i + 2]; } free(px); }
+        }
         else return PT_ERROR_UNSUPPORTED;
         if (r != PT_OK) return r;
         float* out = (float*)malloc(rgb.size() * sizeof(float)); if (!out) return PT_ERROR_HIP;

@@ -125,6 +125,27 @@ def test_selected_camera_defaults_to_last(tmp_path):
     assert pt.SceneImport(media / "test.scene.json").info["selectedCamera"] == 1            # out of range: fall back to the last camera
 
 
+def test_dds_next_to_png_wins(tmp_path):
+    """PTMaterial::Read's loadTexture (MaterialsBaker.cpp:178-191): `x.dds` beside `x.png` replaces it — the BC7 files the reference's compression script writes; the sRGB flag
+    stays the document's. A `.dds` named directly is read too."""
+    import struct
+    checker = np.zeros((4, 8, 4), np.uint8); checker[..., 3] = 255; checker[::2, ::2, :3] = 255
+    doc = {"BaseTexture": {"path": "Textures/checker.png", "sRGB": True}, "EmissiveTexture": {"path": "Textures/glow.dds", "sRGB": False}}
+    media, sc, _ = make_folder(tmp_path, [{"model": 0}], {"red.material.json": doc}, textures={"Textures/checker.png": checker})
+    rng = np.random.default_rng(2); blocks = rng.integers(0, 256, 3 * 2 * 16, dtype=np.uint8); blocks[0::16] |= 1          # 12 x 8 BC7 (mode 0 blocks)
+    hdr = lambda w, h, dx: b"DDS " + struct.pack("<7I", 124, 0x1007, h, w, 0, 0, 1) + b"\0" * 44 + struct.pack("<2I4s5I", 32, 4, b"DX10", 0, 0, 0, 0, 0) + struct.pack("<5I", 0x1000, 0, 0, 0, 0) + struct.pack("<5I", dx, 3, 0, 1, 0)
+    (media / "Textures" / "checker.dds").write_bytes(hdr(12, 8, 98) + blocks.tobytes())
+    glow = rng.integers(0, 256, (5, 3, 4), dtype=np.uint8); (media / "Textures" / "glow.dds").write_bytes(hdr(3, 5, 28) + glow.tobytes())
+    imp = pt.SceneImport(media / "test.scene.json")
+    assert imp.info["numTextures"] == 2 and imp.info["texturesNotLoaded"] == 0
+    px, fmt = imp.texture(0); want, _ = pt.read_dds(media / "Textures" / "checker.dds")
+    assert fmt == pt.PT_TEX_RGBA8_SRGB and px.shape == (8, 12, 4) and np.array_equal(px, want)
+    assert imp.materials[1]["BaseOrDiffuseTextureIndex"] == scenes.pack_texture_word(0, 12, 8)
+    px, fmt = imp.texture(1)
+    assert fmt == pt.PT_TEX_RGBA8_UNORM and np.array_equal(px, glow) and imp.materials[1]["EmissiveTextureIndex"] == scenes.pack_texture_word(1, 3, 5)
+    with pytest.raises(pt.PtError): imp.texture(2)
+
+
 def test_material_overrides_follow_reference_candidate_order(tmp_path):
     checker = np.zeros((4, 8, 4), np.uint8); checker[..., 3] = 255; checker[::2, ::2, :3] = 255
     red_doc = {"BaseOrDiffuseColor": [0.1, 0.2, 0.3], "Roughness": 0.25, "EnableAlphaTesting": True, "AlphaCutoff": 0.3, "ExcludeFromNEE": True,
