@@ -7,11 +7,13 @@ from rtxpt_amd import scenes
 W, H, SPP = 3840, 2160, 4
 sc, cam = scenes.bistro_like(scale=1.0, tex_size=1024)
 camd = scenes.bridge_camera(W, H, **cam)
+MAXR = int(os.environ.get("SHARD_PROBE_RANKS", "0"))          # > 0: time only this many evenly spaced ranks per world size (every rank costs a scene build)
 worlds = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]
 base = None
 for world in worlds:
     times, rays = [], []
-    for rank in range(world):
+    ranks = list(range(world)) if not MAXR or world <= MAXR else sorted({int(round(i * (world - 1) / (MAXR - 1))) for i in range(MAXR)}) if MAXR > 1 else [0]
+    for rank in ranks:
         g = pt.PathTracer(device=0, shard_rank=rank, shard_count=world)
         g.set_scene(sc); g.set_camera(camd); g.set_settings(scenes.default_settings()); g.resize(W, H)
         g.reset_accumulation(); g.render(0, SPP)
@@ -20,7 +22,7 @@ for world in worlds:
             g.reset_accumulation(); st = g.render(0, SPP)
         torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / 2); rays.append(st["extendRays"] + st["shadowRays"])
         del g
-    print("   per rank ms:", " ".join("%.1f" % (t * 1e3) for t in times)); print("   per rank Mrays:", " ".join("%.1f" % (r / 1e6) for r in rays))
+    print("   ranks timed:", ranks); print("   per rank ms:", " ".join("%.1f" % (t * 1e3) for t in times)); print("   per rank Mrays:", " ".join("%.1f" % (r / 1e6) for r in rays))
     base = base or max(times)
     print("world %d: frame time per rank max %.1f mean %.1f min %.1f ms; rays per rank max %.1fM min %.1fM; speed-up vs 1 GPU %.2f (efficiency %.2f)" % (
-        world, max(times) * 1e3, sum(times) / world * 1e3, min(times) * 1e3, max(rays) / 1e6, min(rays) / 1e6, base / max(times), base / max(times) / world))
+        world, max(times) * 1e3, sum(times) / len(times) * 1e3, min(times) * 1e3, max(rays) / 1e6, min(rays) / 1e6, base / max(times), base / max(times) / world))
