@@ -350,6 +350,11 @@ void    pt_image_free(float* rgb);
    BC7, uncompressed RGBA8 / BGRA8 / BGRX8; legacy FourCC and DX10 headers. *pixels is allocated by the library: pt_image_free((float*)pixels).
    PT_ERROR_IO: unreadable / truncated; PT_ERROR_UNSUPPORTED: BC6H, cube maps, volumes, arrays, other formats. */
 int32_t pt_image_read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);
+/* JPEG images of glTF files (Donut's TextureCache gives them to stb_image): a baseline / extended / progressive Huffman stream of 8-bit greyscale or YCbCr (or
+   Adobe-RGB) samples in memory -> RGBA8, top row first, alpha 255; *rgba8 is allocated by the library: pt_image_free((float*)rgba8). The samples are the IJG
+   reference decoder's (islow IDCT, fancy up-sampling): any conforming decoder, stb_image included, may differ from another by a unit per sample.
+   PT_ERROR_IO: not a JPEG this reader handles (arithmetic coding, 12 bits, CMYK, damaged). pt_load_scene_gltf / pt_scene_json_import use it for image/jpeg. */
+int32_t pt_image_read_jpeg(const void* bytes, size_t size, uint32_t* width, uint32_t* height, void** rgba8);
 int32_t pt_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 int32_t pt_write_bmp(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 

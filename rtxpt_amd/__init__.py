@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -325,6 +325,20 @@ def read_dds(path):
     try:
         ct, dt = (ctypes.c_float, np.float32) if fmt.value == 2 else (ctypes.c_uint8, np.uint8)
         return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ct)), shape=(h.value, w.value, 4)).astype(dt, copy=True), int(fmt.value)
+    finally:
+        L.pt_image_free(p)
+
+
+def read_jpeg(data):
+    """pt_image_read_jpeg: a JPEG stream (bytes, or a path) as uint8 [h, w, 4]. No device needed."""
+    if not isinstance(data, (bytes, bytearray)): data = open(data, "rb").read()
+    L = load_library(); w, h = ctypes.c_uint32(), ctypes.c_uint32(); p = ctypes.c_void_p()
+    L.pt_image_read_jpeg.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_void_p)]
+    L.pt_image_free.argtypes = [ctypes.c_void_p]; L.pt_image_free.restype = None
+    r = L.pt_image_read_jpeg(bytes(data), len(data), ctypes.byref(w), ctypes.byref(h), ctypes.byref(p))
+    if r != PT_OK: raise PtError(r, "pt_image_read_jpeg")
+    try:
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(h.value, w.value, 4)).copy()
     finally:
         L.pt_image_free(p)
 

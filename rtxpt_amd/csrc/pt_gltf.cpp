@@ -242,7 +242,11 @@ struct Loader {
             file.assign(buffers[buf].begin() + off, buffers[buf].begin() + off + len);
         }
         uint32_t w, h; std::vector<uint8_t> rgba;
-        if (!decode_png(file, w, h, rgba)) return 0xFFFFFFFFu;          // unsupported image formats are treated as "texture not loaded"
+        if (file.size() > 2 && file[0] == 0xFF && file[1] == 0xD8) {      // image/jpeg (pt_jpeg.cpp)
+            void* px = nullptr; if (pt_image_read_jpeg(file.data(), file.size(), &w, &h, &px) != PT_OK) return 0xFFFFFFFFu;
+            rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px);
+        }
+        else if (!decode_png(file, w, h, rgba)) return 0xFFFFFFFFu;      // other image formats are treated as "texture not loaded"
         uint32_t index = (uint32_t)texDescs.size();
         texPixels.push_back(std::move(rgba));
         PtTextureDesc d; d.width = w; d.height = h; d.format = srgb ? PT_TEX_RGBA8_SRGB : PT_TEX_RGBA8_UNORM; d.pixels = nullptr; texDescs.push_back(d);
@@ -591,7 +595,12 @@ struct SceneReader {
             if (fmt == PT_TEX_RGBA32F) { pt_image_free((float*)px); return 0xFFFFFFFFu; }              // (float textures are environment sources, not material inputs)
             rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px);
         }
-        else if (!read_file(file, bytes) || !decode_png(bytes, w, h, rgba)) return 0xFFFFFFFFu;
+        else {
+            if (!read_file(file, bytes)) return 0xFFFFFFFFu;
+            if (bytes.size() > 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) { void* px = nullptr; if (pt_image_read_jpeg(bytes.data(), bytes.size(), &w, &h, &px) != PT_OK) return 0xFFFFFFFFu;
+                                                                              rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px); }
+            else if (!decode_png(bytes, w, h, rgba)) return 0xFFFFFFFFu;
+        }
         uint32_t index = (uint32_t)S.texDescs.size(); S.texPixels.push_back(std::move(rgba));
         PtTextureDesc d; d.width = w; d.height = h; d.format = srgb ? PT_TEX_RGBA8_SRGB : PT_TEX_RGBA8_UNORM; d.pixels = nullptr; S.texDescs.push_back(d);
         return pack_texture_word(index, w, h);
