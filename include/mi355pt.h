@@ -272,7 +272,7 @@ typedef struct PtSceneJsonInfo {
     int32_t  selectedCamera;                /* startingCamera when present and valid, else the last camera (Sample.cpp:590-603, 618-619); -1 without cameras */
 } PtSceneJsonInfo;
 /* mediaPath: the folder that holds "Materials/" (NULL: the scene file's folder). Errors: PT_ERROR_IO (unreadable / malformed file or
-   model, unknown model reference), PT_ERROR_UNSUPPORTED (a node with an "euler" rotation: Donut's Euler convention is not restated, quaternions only). */
+   model, unknown model reference). A node's "euler" rotation follows Donut's rotationQuat: about the fixed x axis first, then y, then z (unpinned: Donut is not vendored). */
 int32_t pt_scene_json_import(const char* scenePath, const char* mediaPath, pt_scene_import** out, PtSceneJsonInfo* info);
 void    pt_scene_import_free(pt_scene_import* scene);
 /* copies of the imported arrays, up to `capacity` records; return the number available (negative: error) */

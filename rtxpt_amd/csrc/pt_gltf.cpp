@@ -762,7 +762,18 @@ struct SceneReader {
         double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
         jvec(n.get("translation"), t, 3); jvec(n.get("scaling"), s, 3);
         if (const JValue* r = n.get("rotation")) { if (r->type == JValue::Arr) jvec(r, q, 4); }     // (EnvironmentLight's scalar "rotation" is a leaf property, not a node rotation)
-        else if (n.get("euler")) { err = PT_ERROR_UNSUPPORTED; return; }
+        else if (const JValue* e = n.get("euler")) {
+            // Donut's dm::rotationQuat(euler) (core/math/quat.h; un-vendored — GameMisc.cpp:53-61 shows the reference's own use of it): half-angle quaternions about x, y and z
+            // multiplied qZ * qY * qX, i.e. the rotation about the fixed x axis is applied first, then y, then z. UNPINNED (restated from Donut's published header).
+            double a[3] = {0, 0, 0}; jvec(e, a, 3);
+            const double cx = cos(0.5 * a[0]), sx = sin(0.5 * a[0]), cy = cos(0.5 * a[1]), sy = sin(0.5 * a[1]), cz = cos(0.5 * a[2]), sz = sin(0.5 * a[2]);
+            auto mul = [](const double* p, const double* r, double* o) {      // Hamilton product, (w, x, y, z)
+                o[0] = p[0] * r[0] - p[1] * r[1] - p[2] * r[2] - p[3] * r[3]; o[1] = p[0] * r[1] + p[1] * r[0] + p[2] * r[3] - p[3] * r[2];
+                o[2] = p[0] * r[2] - p[1] * r[3] + p[2] * r[0] + p[3] * r[1]; o[3] = p[0] * r[3] + p[1] * r[2] - p[2] * r[1] + p[3] * r[0]; };
+            const double qx[4] = {cx, sx, 0, 0}, qy[4] = {cy, 0, sy, 0}, qz[4] = {cz, 0, 0, sz}; double zy[4], w[4];
+            mul(qz, qy, zy); mul(zy, qx, w);
+            q[0] = w[1]; q[1] = w[2]; q[2] = w[3]; q[3] = w[0];
+        }
         M4 world = m4_mul(parent, m4_trs(t, q, s));
         if (const JValue* m = n.get("model")) {
             if (m->type == JValue::Num) instantiate((size_t)m->num, world);

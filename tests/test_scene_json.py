@@ -184,13 +184,29 @@ def test_material_overrides_follow_reference_candidate_order(tmp_path):
     assert imp2.materials[1].tobytes() == pt.material_from_json(json.dumps({"Roughness": 0.8}))[0].tobytes()
 
 
+def test_euler_rotations_follow_donuts_rotation_quat(tmp_path):
+    """A node's "euler" key (Donut's dm::rotationQuat, the function the reference's own GameMisc.cpp:53-61 calls for the same key): about the fixed x axis first, then y, then z;
+    "rotation" wins when both are present."""
+    a, b, c = 0.3, -1.1, 2.0
+    rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]]); ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    media, sc, _ = make_folder(tmp_path, [{"model": 0, "euler": [a, b, c], "translation": [1, 2, 3]}, {"model": 0, "euler": [a, b, c], "rotation": [0, 0, 0, 1]}])
+    imp = pt.SceneImport(media / "test.scene.json"); n = len(sc["instances"])
+    R = rz @ ry @ rx
+    for k in range(n):
+        base = np.eye(4); base[:3] = sc["instances"]["transform"][k].reshape(3, 4)
+        M = np.eye(4); M[:3, :3] = R; M[:3, 3] = [1, 2, 3]
+        assert np.allclose(imp.instances["transform"][k].reshape(3, 4), (M @ base)[:3], atol=2e-6)
+        assert np.allclose(imp.instances["transform"][n + k].reshape(3, 4), base[:3], atol=1e-7)
+
+
 def test_media_path_argument_and_errors(tmp_path):
     media, _, _ = make_folder(tmp_path, [{"model": 0}], {"red.material.json": {"Roughness": 0.7}})
     elsewhere = tmp_path / "elsewhere"; (elsewhere / "Materials").mkdir(parents=True)
     (elsewhere / "Materials" / "red.material.json").write_text(json.dumps({"Roughness": 0.33}))
     assert abs(pt.SceneImport(media / "test.scene.json").materials[1]["Roughness"] - 0.7) < 1e-7
     assert abs(pt.SceneImport(media / "test.scene.json", elsewhere).materials[1]["Roughness"] - 0.33) < 1e-7
-    for bad, code in (([{"model": 3}], 4), ([{"model": "nope.gltf"}], 4), (["nope.gltf"], 4), ([{"model": 0, "euler": [0, 1, 0]}], 5)):
+    for bad, code in (([{"model": 3}], 4), ([{"model": "nope.gltf"}], 4), (["nope.gltf"], 4)):
         m, _, _ = make_folder(tmp_path / "bad", bad)
         with pytest.raises(pt.PtError) as e:
             pt.SceneImport(m / "test.scene.json")
