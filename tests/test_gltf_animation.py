@@ -111,3 +111,40 @@ def test_animation_of_a_file_without_animations_and_of_damaged_files(tmp_path):
     doc = json.loads(path.read_text()); doc["accessors"][2]["count"] = 4000; (tmp_path / "bad3.gltf").write_text(json.dumps(doc))
     with pytest.raises(pt.PtError): pt.GltfAnimation(tmp_path / "bad3.gltf")
     with pytest.raises(pt.PtError): pt.GltfAnimation(tmp_path / "missing.gltf")
+
+
+def test_damaged_animation_documents_never_crash(tmp_path):
+    """Random damage to the animation part of the document (indices, counts, types, paths, truncated buffers): an error code or a valid answer, never a crash."""
+    path, M = _write(tmp_path); good = json.loads(path.read_text()); rng = np.random.default_rng(12); blob = (tmp_path / "a.bin").read_bytes()
+    def mutate(v, depth=0):
+        if isinstance(v, dict):
+            k = list(v)[int(rng.integers(0, len(v)))] if v else None
+            if k is None: return v
+            if rng.random() < 0.3: v.pop(k)
+            else: v[k] = mutate(v[k], depth + 1)
+            return v
+        if isinstance(v, list):
+            if not v: return v
+            i = int(rng.integers(0, len(v)))
+            if rng.random() < 0.2: v.pop(i)
+            else: v[i] = mutate(v[i], depth + 1)
+            return v
+        r = rng.random()
+        return [-1, 0, 7, 10 ** 9, 2.5, "x", None, [], {}, True][int(rng.integers(0, 10))] if r < 0.8 else v
+    ok = 0
+    for k in range(300):
+        doc = json.loads(json.dumps(good))
+        for _ in range(int(rng.integers(1, 4))):
+            key = ["animations", "accessors", "bufferViews", "nodes"][int(rng.integers(0, 4))]; doc[key] = mutate(doc[key])
+        (tmp_path / "m.gltf").write_text(json.dumps(doc))
+        if k % 10 == 0: (tmp_path / "a.bin").write_bytes(blob[: int(rng.integers(0, len(blob)))])
+        else: (tmp_path / "a.bin").write_bytes(blob)
+        try:
+            an = pt.GltfAnimation(tmp_path / "m.gltf")
+            for a in range(min(an.count, 3)):
+                try: an.instances(float(rng.uniform(-1, 3)), animation=a)
+                except pt.PtError: pass
+            an.close(); ok += 1
+        except pt.PtError:
+            pass
+    assert ok > 20          # (many mutations leave a loadable file)
