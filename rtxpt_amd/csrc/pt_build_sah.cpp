@@ -250,8 +250,8 @@ struct Builder {
                             for (size_t k = 0; k < path.size(); k++) { B3 u = pbox[k]; u.grow(xb); stay += u.area() - pbox[k].area(); }
                             { B3 u = box[s]; u.grow(xb); stay += u.area(); }
                             heap.clear(); heap.push_back({0.f, path.back(), (int)path.size() - 1});
-                            float best = FLT_MAX; uint bestNode = s;
-                            while (!heap.empty()) {
+                            float best = FLT_MAX; uint bestNode = s; uint steps = 0;
+                            while (!heap.empty() && ++steps <= 8192u) {      // (branch and bound ends far earlier on real scenes; the cap bounds the time on adversarial ones)
                                 std::pop_heap(heap.begin(), heap.end(), cmp); const Q q = heap.back(); heap.pop_back();
                                 if (q.induced + xa >= best) break;
                                 const B3& nb = q.path >= 0 ? pbox[(size_t)q.path] : box[q.node];
