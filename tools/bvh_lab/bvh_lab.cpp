@@ -472,6 +472,7 @@ int main(int argc, char** argv) {
     if (getenv("LAB_PRODUCT")) { Bvh2 s = build_product(); eval("product builder cost-driven leaf4", s, 4, 1); }
     if (getenv("LAB_REINS")) { Bvh2 s = build_sah(32); eval("binned sah cost-driven leaf4", s, 4, 1);
         for (int it = 0; it < 3; it++) { optimize_reinsert(s, 2, 0.25f); char nm[64]; snprintf(nm, 64, "sah + reinsertion x%d cost leaf4", 2 * (it + 1)); eval(nm, s, 4, 1); } }
+    if (getenv("LAB_SBVH_REINS")) { Bvh2 s = build_sbvh(32, 1e-5f, 1.5f); eval("sbvh cost-driven leaf4", s, 4, 1); optimize_reinsert(s, 2, 0.25f); eval("sbvh + reinsertion x2 cost leaf4", s, 4, 1); }
     if (getenv("LAB_SBVH")) for (float al : {1e-5f, 1e-6f}) { Bvh2 s = build_sbvh(32, al, 1.5f); char nm[64]; snprintf(nm, 64, "sbvh a=%g cost-driven leaf4", al); eval(nm, s, 4, 1); }
     return 0;
 }
