@@ -183,7 +183,7 @@ struct Builder {
             else (r.right ? out.childR : out.childL)[pid] = node_id(r.mid - 1u);
         }
         uint root = node_id(top[0].mid - 1u);
-        if (optimisePasses) optimise(root, optimisePasses, getenv("MI355PT_SAH_FRACTION") ? (float)atof(getenv("MI355PT_SAH_FRACTION")) : 0.25f);
+        if (optimisePasses) optimise(root, optimisePasses, 0.25f);
         relabel_root(root);
         if (out.absorb) choose_wide_nodes();
     }
