@@ -121,3 +121,14 @@ def test_damaged_and_unsupported_files(tmp_path):
         try: pt.read_dds(tmp_path / "r.dds")
         except pt.PtError: pass
     with pytest.raises(pt.PtError): pt.read_dds(tmp_path / "missing.dds")
+
+
+def test_committed_bc7_tables_are_what_the_generator_produces(tmp_path):
+    """rtxpt_amd/csrc/pt_bcn_tables.h is generated (tools/gen_bcn_tables.py reads the BC7 partition / anchor tables off Pillow's decoder): regenerating gives the committed file."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    committed = open(os.path.join(root, "rtxpt_amd", "csrc", "pt_bcn_tables.h")).read()
+    src = open(os.path.join(root, "tools", "gen_bcn_tables.py")).read().replace('os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rtxpt_amd", "csrc", "pt_bcn_tables.h")', repr(str(tmp_path / "t.h")))
+    (tmp_path / "gen.py").write_text(src)
+    subprocess.run([sys.executable, str(tmp_path / "gen.py")], check=True, capture_output=True)
+    assert (tmp_path / "t.h").read_text() == committed
