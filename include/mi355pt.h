@@ -74,7 +74,10 @@ typedef struct PtGeometryDesc {
 enum { PT_GEOM_HAS_UV = 1, PT_GEOM_HAS_NORMAL = 2, PT_GEOM_HAS_TANGENT = 4 };
 enum { PT_GEOMF_ALPHA_TESTED = 1, PT_GEOMF_EXCLUDE_FROM_NEE = 2 };
 typedef struct PtMeshDesc { uint32_t firstGeometry, numGeometries; } PtMeshDesc;            /* one BLAS in the reference */
-typedef struct PtInstanceDesc { float transform[12]; uint32_t meshIndex; uint32_t _pad[3]; } PtInstanceDesc;   /* row-major 3x4, InstanceData.transform */
+typedef struct PtInstanceDesc { float transform[12]; uint32_t meshIndex; uint32_t analyticProxyLight; uint32_t _pad[2]; } PtInstanceDesc;   /* row-major 3x4, InstanceData.transform */
+/* analyticProxyLight: 0 = none; k + 1 = the instance's geometries whose material has EnableAsAnalyticLightProxy stand in for record k of pt_set_lights — a path that
+   hits them adds that sphere light's radiance, MIS-weighted against its NEE samples (SubInstanceData.AnalyticProxyLightIndex, LightsBaker.cpp:718-753: the light
+   leaf above the mesh node, or the light whose proxyMeshNodes names it; PathTracer.hlsli:636-648; LightSampler.hlsli:363-390). Sphere lights only, as in the reference. */
 
 typedef struct PtGeometryBuffers {
     const uint32_t* indices;   uint32_t numIndices;

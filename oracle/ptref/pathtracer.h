@@ -417,6 +417,7 @@ struct PathTracer {
 
         SurfaceData ret;
         ret.neeTriangleLightIndex = RTXPT_INVALID_LIGHT_INDEX; ret.neeAnalyticLightIndex = RTXPT_INVALID_LIGHT_INDEX;
+        if (material.Flags & PTMaterialFlags_EnableAsAnalyticLightProxy) ret.neeAnalyticLightIndex = si.AnalyticProxyLightIndex;      // BridgeDonut:828-829
         if (sd.frontFacing && any_gt0(emissiveColor)) {
             sd.emission = emissiveColor;
             uint baseIndex = si.EmissiveLightMappingOffset;
@@ -635,6 +636,12 @@ struct PathTracer {
             if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0)
                 misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(sfd.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.FullSamples);
             surfaceEmission = LP::r3(sd.emission * misWeight);
+        }
+        if (sfd.neeAnalyticLightIndex != RTXPT_INVALID_LIGHT_INDEX) {                  // PathTracer.hlsli:636-648: the mesh stands in for an analytic (sphere) light
+            const float bsdfPdf = misInfo.LightSamplingEnabled ? LP::r(path.GetBsdfScatterPdf()) : 0.0f; float3 add;
+            if (lightSampler.ComputeAnalyticLightProxyContribution(sfd.neeAnalyticLightIndex, bsdfPdf, rayOrigin, rayDir, misInfo.FullSamples, add)) {
+                add = LP::r3(add); surfaceEmission = make_float3(LP::add(surfaceEmission.x, add.x), LP::add(surfaceEmission.y, add.y), LP::add(surfaceEmission.z, add.z));
+            }
         }
         if (any_gt0(surfaceEmission)) {
             const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);

@@ -284,10 +284,16 @@ static void bake_env_quads(Scene& sc) {
 
 void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
     sc.lights.clear(); sc.lightsEx.clear(); sc.proxyCounters.clear(); sc.proxyIndices.clear(); sc.envLookup.clear(); sc.envLookupDim = 0;
-    for (size_t i = 0; i < sc.subInstances.size(); i++) sc.subInstances[i].EmissiveLightMappingOffset = 0xFFFFFFFFu;
+    for (size_t i = 0; i < sc.subInstances.size(); i++) { sc.subInstances[i].EmissiveLightMappingOffset = 0xFFFFFFFFu; sc.subInstances[i].AnalyticProxyLightIndex = 0xFFFFFFFFu; }
     if (neeEnabled) {
         if (sc.env.enabled) { sc.lights.resize(QT_TOTAL); sc.lightsEx.resize(QT_TOTAL); bake_env_quads(sc); }
+        const uint analyticBase = (uint)sc.lights.size();
         for (size_t i = 0; i < sc.analyticLights.size(); i++) { sc.lights.push_back(sc.analyticLights[i].Base); sc.lightsEx.push_back(sc.analyticLights[i].Extended); }
+        for (size_t s = 0; s < sc.subInstances.size(); s++) {          // analytic light proxies (LightsBaker.cpp:718-753)
+            const uint proxy = sc.instances[sc.subInstToInstGeom[s].x].analyticProxyLight;
+            if (proxy && proxy <= sc.analyticLights.size() && (sc.materials[sc.subInstances[s].GlobalGeometryIndex_PTMaterialDataIndex & 0xFFFFu].Flags & PTMaterialFlags_EnableAsAnalyticLightProxy))
+                sc.subInstances[s].AnalyticProxyLightIndex = analyticBase + proxy - 1u;
+        }
         // emissive triangles, in sub-instance order (LightsBaker.cpp:663-827 + LightsBaker.hlsl:544-716)
         for (size_t s = 0; s < sc.subInstances.size(); s++) {
             SubInstanceData& si = sc.subInstances[s];

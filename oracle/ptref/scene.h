@@ -62,7 +62,7 @@ struct GeometryDesc {
 };
 enum : uint { GEOM_HAS_UV = 1, GEOM_HAS_NORMAL = 2, GEOM_HAS_TANGENT = 4, GEOMF_ALPHA_TESTED = 1, GEOMF_EXCLUDE_FROM_NEE = 2 };
 struct MeshDesc { uint firstGeometry, numGeometries; };
-struct InstanceDesc { float3x4 transform; uint meshIndex; uint _pad[3]; };
+struct InstanceDesc { float3x4 transform; uint meshIndex; uint analyticProxyLight; uint _pad[2]; };      // analyticProxyLight: 0 = none, k + 1 = stands in for analytic light k
 
 // ---- textures: RGBA float texels, full mip chain (box filter), wrap addressing
 struct Texture {

@@ -356,10 +356,17 @@ int bake_lights(pt_context* c, bool geometryOnly = false) {
     if (!keepEnv) { c->lights.clear(); c->lightsEx.clear(); c->envLookup.clear(); c->envLookupDim = 0; c->envLightsBaked = 0; }
     else { c->lights.resize(QT_TOTAL); c->lightsEx.resize(QT_TOTAL); }
     c->numProxies = 0;
-    for (auto& si : c->subInstances) si.EmissiveLightMappingOffset = 0xFFFFFFFFu;
+    for (auto& si : c->subInstances) { si.EmissiveLightMappingOffset = 0xFFFFFFFFu; si.AnalyticProxyLightIndex = 0xFFFFFFFFu; }
     if (c->S.NEEEnabled) {
         if (c->envEnabled && !keepEnv) { c->lights.resize(QT_TOTAL); c->lightsEx.resize(QT_TOTAL); int r = bake_env_quads(c); if (r != PT_OK) return r; c->envLightsBaked = QT_TOTAL; }
+        const uint analyticBase = (uint)c->lights.size();
         for (auto& a : c->analyticLights) { c->lights.push_back(a.Base); c->lightsEx.push_back(a.Extended); }
+        // analytic light proxies (LightsBaker.cpp:718-753): a mesh instance that stands in for an analytic light carries that light's index in its sub-instances
+        for (size_t s = 0; s < c->subInstances.size(); s++) {
+            const uint proxy = c->instances[c->subInstToInstGeom[s].x].analyticProxyLight;
+            if (proxy && proxy <= c->analyticLights.size() && (c->materials[c->subInstances[s].GlobalGeometryIndex_PTMaterialDataIndex & 0xFFFFu].Flags & PTMaterialFlags_EnableAsAnalyticLightProxy))
+                c->subInstances[s].AnalyticProxyLightIndex = analyticBase + proxy - 1u;
+        }
         // emissive triangles: host decides the layout (LightsBaker.cpp:663-827), the GPU bakes the records (LightsBaker.hlsl:544-716)
         std::vector<uint> list, offsets; uint total = 0; uint lightBase = (uint)c->lights.size();
         for (size_t s = 0; s < c->subInstances.size(); s++) {

@@ -184,7 +184,7 @@ static inline float getShapingFluxFactor(const LightShaping& shaping) {
     return solidAngleOverTwoPi * 0.5f;
 }
 
-// PolymorphicLight.hlsli:93-259 (sampling + MIS pdf only; proxy-mesh Eval is N3)
+// PolymorphicLight.hlsli:93-259
 struct SphereLight {
     float3 position; float radius; float3 radiance; LightShaping shaping;
     static SphereLight Create(const PolymorphicLightInfoFull& li) {
@@ -224,6 +224,34 @@ struct SphereLight {
         ls.SolidAnglePdf = 1.0f / (2.0f * K_PI * (1.0f - cosThetaMax));
         ls.LightSampleableByBSDF = false;
         return ls;
+    }
+    // Geometry.hlsli:85-115 (IntersectRaySphere: analytic, smallest non-negative root; rayDir normalised) + PolymorphicLight.hlsli:190-220
+    static bool IntersectRaySphere(float3 rayOrigin, float3 rayDir, float3 sphereCenter, float sphereRadius, float3& outHitPoint) {
+        float3 oc = rayOrigin - sphereCenter;
+        float a = 1.0f;
+        float b = 2.0f * dot(oc, rayDir);
+        float c = dot(oc, oc) - sphereRadius * sphereRadius;
+        float discriminant = b * b - 4.0f * a * c;
+        if (discriminant < 0.0f) { outHitPoint = make_float3(0.f); return false; }
+        float sqrtDisc = sqrtf_(discriminant);
+        float t1 = (-b - sqrtDisc) / (2.0f * a), t2 = (-b + sqrtDisc) / (2.0f * a);
+        float t = (t1 >= 0.0f) ? t1 : ((t2 >= 0.0f) ? t2 : -1.0f);
+        if (t < 0.0f) { outHitPoint = make_float3(0.f); return false; }
+        outHitPoint = rayOrigin + rayDir * t;
+        return true;
+    }
+    bool Eval(float3 rayPos, float3 rayDir, float3& outRadiance, float3& outLightSamplePosition) const {      // a path that hit the light's proxy mesh (analytic light proxies)
+        const float3 lightVector = position - rayPos;
+        if (dot(lightVector, lightVector) < sq(radius)) return false;
+        if (!IntersectRaySphere(rayPos, rayDir, position, radius, outLightSamplePosition)) return false;
+        outRadiance = radiance * evaluateLightShaping(shaping, rayPos, position);
+        return true;
+    }
+    float CalcSolidAnglePdfForMIS(float3 viewerPosition, float3 /*lightSamplePosition*/) const {
+        const float3 lightVector = position - viewerPosition;
+        const float sinThetaMax2 = sq(radius) / dot(lightVector, lightVector);
+        const float cosThetaMax = sqrtf_(fmaxf_(0.0f, 1.0f - sinThetaMax2));
+        return 1.0f / (2.0f * K_PI * (1.0f - cosThetaMax));
     }
     float GetPower() const { return 4 * K_PI * sq(radius) * K_PI * Luminance(radiance) * getShapingFluxFactor(shaping); }       // PolymorphicLight.hlsli:224-232
 };
@@ -324,6 +352,18 @@ struct LightSampler {
         TriangleLight tl = TriangleLight::Create(LoadLight(lightIndex));
         float solidAnglePdf = tl.CalcSolidAnglePdfForMIS(viewerPosition, lightSamplePosition);
         return ComputeLightVsBSDF_MIS_ForBSDF(lightIndex, bsdfPdf, solidAnglePdf, fullSamples);
+    }
+    // :363-390 (sphere lights only; localCandidates are NEE-AT's, 0 here; exact MIS, RTXPT_USE_APPROXIMATE_MIS 0). Returns false when nothing is added.
+    bool ComputeAnalyticLightProxyContribution(uint analyticLightIndex, float bsdfPdf, float3 previousVertex, float3 rayDir, uint fullSamples, float3& contribution) const {
+        PolymorphicLightInfoFull lightInfo = LoadLight(analyticLightIndex);
+        if (DecodeLightType(lightInfo.Base) != kSphere) return false;
+        SphereLight sphereLight = SphereLight::Create(lightInfo);
+        float3 radiance, lightSamplePosition;
+        if (!sphereLight.Eval(previousVertex, rayDir, radiance, lightSamplePosition)) return false;
+        float mis = 1.0f;
+        if (bsdfPdf != 0) mis = ComputeLightVsBSDF_MIS_ForBSDF(analyticLightIndex, bsdfPdf, sphereLight.CalcSolidAnglePdfForMIS(previousVertex, lightSamplePosition), fullSamples);
+        contribution = radiance * mis;
+        return true;
     }
     // :347-362
     float ComputeBSDFMISForEnvironmentQuad(uint lightIndex, float bsdfPdf, uint fullSamples) const {

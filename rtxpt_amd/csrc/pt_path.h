@@ -120,7 +120,7 @@ struct LightSample {
     float3 Li; float Distance; float3 Direction; uint LightIndex; float SelectionPdf, SolidAnglePdf; bool LightSampleableByBSDF;
     bool Valid() const { return any_gt0(Li); }
 };
-struct SurfaceData { ShadingData shadingData; StandardBSDF bsdf; float interiorIoR; uint neeTriangleLightIndex; };
+struct SurfaceData { ShadingData shadingData; StandardBSDF bsdf; float interiorIoR; uint neeTriangleLightIndex; uint neeAnalyticLightIndex; };
 // what k_shade hands to the shadow queue (the deferred half of ProcessLightSample)
 struct ShadowRequest { bool valid; float3 origin, dir; float tmax; float3 radiance; };
 // NEEFullSamples != 1 (HandleNEE_MultipleSamples, PathTracerNEE.hlsli:277-301): every path vertex that applies NEE reserves a group of fullSamples
@@ -367,7 +367,8 @@ template <bool LP16> struct PathKernelContextT {
         bd.eta = LP::div(sd.IoR, matIoR);
         if (!sd.mtl.isThinSurface() && !sd.frontFacing) bd.eta = LP::div(matIoR, sd.IoR);
         SurfaceData ret;
-        ret.neeTriangleLightIndex = RTXPT_INVALID_LIGHT_INDEX;
+        ret.neeTriangleLightIndex = RTXPT_INVALID_LIGHT_INDEX; ret.neeAnalyticLightIndex = RTXPT_INVALID_LIGHT_INDEX;
+        if (mflags & PTMaterialFlags_EnableAsAnalyticLightProxy) ret.neeAnalyticLightIndex = si.AnalyticProxyLightIndex;      // BridgeDonut:828-829
         if (sd.frontFacing && any_gt0(emissiveColor)) {
             sd.emission = emissiveColor;
             uint baseIndex = si.EmissiveLightMappingOffset;
@@ -591,6 +592,13 @@ template <bool LP16> struct PathKernelContextT {
                 misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(sfd.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.FullSamples);
             }
             surfaceEmission = LP::r3(sd.emission * misWeight);
+        }
+        if (sfd.neeAnalyticLightIndex != RTXPT_INVALID_LIGHT_INDEX) {                  // PathTracer.hlsli:636-648: the mesh stands in for an analytic (sphere) light
+            LightSampler lightSampler; lightSampler.T = &sc.lights;
+            const float bsdfPdf = misInfo.LightSamplingEnabled ? LP::r(path.GetBsdfScatterPdf()) : 0.0f; float3 add;
+            if (lightSampler.ComputeAnalyticLightProxyContribution(sfd.neeAnalyticLightIndex, bsdfPdf, rayOrigin, rayDir, misInfo.FullSamples, add)) {
+                add = LP::r3(add); surfaceEmission = make_float3(LP::add(surfaceEmission.x, add.x), LP::add(surfaceEmission.y, add.y), LP::add(surfaceEmission.z, add.z));
+            }
         }
         if (any_gt0(surfaceEmission)) {
             const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);

@@ -21,7 +21,7 @@ enum : uint {
     PTMaterialFlags_UseSpecularGlossModel = 0x1, PTMaterialFlags_UseMetalRoughOrSpecularTexture = 0x4,
     PTMaterialFlags_UseBaseOrDiffuseTexture = 0x8, PTMaterialFlags_UseEmissiveTexture = 0x10, PTMaterialFlags_UseNormalTexture = 0x20,
     PTMaterialFlags_UseTransmissionTexture = 0x80, PTMaterialFlags_MetalnessInRedChannel = 0x100, PTMaterialFlags_ThinSurface = 0x200,
-    PTMaterialFlags_IgnoreMeshTangentSpace = 1u << 12, PTMaterialFlags_NestedPriorityShift = 28,
+    PTMaterialFlags_EnableAsAnalyticLightProxy = 0x800, PTMaterialFlags_IgnoreMeshTangentSpace = 1u << 12, PTMaterialFlags_NestedPriorityShift = 28,
 };
 // MaterialPT.h:45-77
 struct PTMaterialData {
@@ -47,7 +47,7 @@ static_assert(sizeof(SubInstanceData) == 32, "SubInstanceData must be 32 bytes")
 struct GeometryDesc { uint indexOffset, numIndices, vertexOffset, numVertices, flags, materialIndex, geomFlags, _pad; };
 enum : uint { GEOM_HAS_UV = 1, GEOM_HAS_NORMAL = 2, GEOM_HAS_TANGENT = 4, GEOMF_ALPHA_TESTED = 1, GEOMF_EXCLUDE_FROM_NEE = 2 };
 struct MeshDesc { uint firstGeometry, numGeometries; };
-struct InstanceDesc { float3x4 transform; uint meshIndex; uint _pad[3]; };
+struct InstanceDesc { float3x4 transform; uint meshIndex; uint analyticProxyLight; uint _pad[2]; };      // analyticProxyLight: 0 = none, k + 1 = stands in for analytic light k (SubInstanceData.AnalyticProxyLightIndex)
 static_assert(sizeof(InstanceDesc) == 64, "InstanceDesc must be 64 bytes");
 
 struct TriRecord { float3 v0; uint prim; float3 e1; uint flags; float3 e2; float pad; };    // flags bit0 non-opaque, bit1 exclude from NEE; pad: see tri_box_accepts

@@ -30,7 +30,7 @@ assert MATERIAL_DTYPE.itemsize == 128
 GEOMETRY_DTYPE = np.dtype([("indexOffset", "<u4"), ("numIndices", "<u4"), ("vertexOffset", "<u4"), ("numVertices", "<u4"),
                            ("flags", "<u4"), ("materialIndex", "<u4"), ("geomFlags", "<u4"), ("_pad", "<u4")])
 MESH_DTYPE = np.dtype([("firstGeometry", "<u4"), ("numGeometries", "<u4")])
-INSTANCE_DTYPE = np.dtype([("transform", "<f4", 12), ("meshIndex", "<u4"), ("_pad", "<u4", 3)])
+INSTANCE_DTYPE = np.dtype([("transform", "<f4", 12), ("meshIndex", "<u4"), ("analyticProxyLight", "<u4"), ("_pad", "<u4", 2)])
 CAMERA_DTYPE = np.dtype([
     ("PosW", "<f4", 3), ("NearZ", "<f4"), ("DirectionW", "<f4", 3), ("PixelConeSpreadAngle", "<f4"),
     ("CameraU", "<f4", 3), ("FarZ", "<f4"), ("CameraV", "<f4", 3), ("FocalDistance", "<f4"),
@@ -225,7 +225,7 @@ class SceneBuilder:
 
     def add_instance(self, mesh, transform=None):
         t = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32) if transform is None else np.asarray(transform, np.float32).reshape(12)
-        self.instances.append((t, mesh, (0, 0, 0)))
+        self.instances.append((t, mesh, 0, (0, 0)))
 
     def set_environment(self, rgb, to_world=None, color_multiplier=(1, 1, 1)):
         self.env = (np.ascontiguousarray(rgb, dtype=np.float32), np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32) if to_world is None else np.asarray(to_world, np.float32),

@@ -23,6 +23,25 @@ def with_sphere_lights(make):
     return build
 
 
+def with_light_proxy(make, instance=-2, light=0, radius=0.06):
+    """The scene of `make` (which has analytic sphere lights) with one mesh instance standing in for one of them (analytic light proxies: LightsBaker.cpp:718-753,
+    PathTracer.hlsli:636-648): the light is moved to the centre of that instance's bounds and given a radius that fills a good part of it, the instance's materials get
+    EnableAsAnalyticLightProxy (other users of those materials carry the flag without a light: no effect), and instance.analyticProxyLight names the light."""
+    import numpy as np
+    def build():
+        sc, cam = make()
+        sc = dict(sc); inst = sc["instances"].copy(); mats = sc["materials"].copy(); base, ex = sc["lights"]; base = base.copy()
+        k = instance % len(inst); m = sc["meshes"][inst["meshIndex"][k]]; T = inst["transform"][k].reshape(3, 4); pts = []
+        for g in sc["geometries"][m["firstGeometry"]: m["firstGeometry"] + m["numGeometries"]]:
+            p = sc["positions"][g["vertexOffset"]: g["vertexOffset"] + g["numVertices"]]; pts.append(p @ T[:, :3].T + T[:, 3]); mats["Flags"][g["materialIndex"]] |= 0x800
+        pts = np.concatenate(pts); centre = ((pts.min(0) + pts.max(0)) * 0.5).astype(np.float32)
+        base[light, 0:3] = centre.view(np.uint32); base[light, 6] = (base[light, 6] & 0xFFFF0000) | int(np.float16(radius).view(np.uint16))
+        inst["analyticProxyLight"][k] = light + 1
+        sc["instances"] = inst; sc["materials"] = mats; sc["lights"] = (base, ex)
+        return sc, cam
+    return build
+
+
 def with_point_light_record(make):
     """The scene of `make` (which already has analytic lights) plus the record LightsBaker::ConvertLight makes of a point light WITHOUT radius: a point-type
     PolymorphicLight. The path tracer's light set has that type compiled out (PolymorphicLightPTConfig.h:17-22: "handled by sphere"), so the record is inert —
@@ -169,6 +188,7 @@ def cases():
         "c2_nested0_uniform": (c2, scenes.default_settings(nestedDielectricsQuality=0, NEEType=0), 64, 36, 0, 2),
         "c2_sphere_lights": (with_sphere_lights(c2), scenes.default_settings(), 64, 36, 0, 2),                     # analytic lights (pt_set_lights): spheres, spot shaping
         "c2_point_light_record_uniform": (with_point_light_record(with_sphere_lights(c2)), scenes.default_settings(NEEType=0), 64, 36, 0, 2),   # inert point-type record in the buffer
+        "c2_sphere_light_proxy": (with_light_proxy(with_sphere_lights(c2)), scenes.default_settings(), 64, 36, 4, 2),   # a mesh standing in for an analytic light: SphereLight::Eval + MIS on hit
         "c2_exclude_from_nee": (with_excluded_geometry(c2), scenes.default_settings(), 64, 36, 0, 2),              # ExcludeFromNEE geometry: invisible to shadow rays
         "c2_env_rotated_mip2": (with_rotated_environment(c2), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 64, 36, 5, 2),   # env transform + tint, diffuse-bounce env MIP 2 (the UI default)
         "c2_sun_discs": (with_sun_discs(c2), scenes.default_settings(), 64, 36, 2, 2),                             # directional lights baked into the environment cube

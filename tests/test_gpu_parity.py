@@ -260,6 +260,25 @@ def test_gltf_animation_drives_pt_animate(tmp_path):
     assert np.array_equal(g.radiance(), o.radiance())
 
 
+def test_analytic_light_proxy_tables_and_frames():
+    """Analytic light proxies (PtInstanceDesc.analyticProxyLight -> SubInstanceData.AnalyticProxyLightIndex, LightsBaker.cpp:718-753): the sub-instance table and the frame equal
+    the oracle's; the link survives pt_animate; a proxy index beyond the light list, or a flagged material without a link, is inert."""
+    pt, scenes, parallel, ptref = _imports()
+    make, S, w, h, first, n = _pin_cases()["c2_sphere_light_proxy"]
+    sc, cam = make(); camd = scenes.bridge_camera(w, h, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(w, h); g.render(first, n)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.render(first, n)
+    si = g.subinstances()
+    assert np.array_equal(si, o.subinstances()) and (si[:, 3] != 0xFFFFFFFF).sum() >= 1
+    assert np.array_equal(g.radiance(), o.radiance())
+    inst = sc["instances"].copy(); inst["transform"][1][3] += 0.02                       # move the proxy instance: refit, the link stays
+    g.animate(instances=inst, rebuild=False); g.reset_accumulation(); g.render(first, n)
+    o2 = ptref.Oracle(); o2.set_scene(sc); o2.set_instances(inst); o2.set_camera(camd); o2.set_settings(S); o2.resize(w, h); o2.render(first, n)
+    assert np.array_equal(g.radiance(), o2.radiance()) and np.array_equal(g.subinstances(), o2.subinstances())
+    inst["analyticProxyLight"][1] = 99                                                   # no such light: inert
+    g.animate(instances=inst, rebuild=False); g.render(first, 1); assert (g.subinstances()[:, 3] == 0xFFFFFFFF).all()
+
+
 def test_refit_equals_rebuild_and_oracle():
     """pt_animate: instance motion -> LBVH refit; refit, full rebuild and the oracle (fresh SAH build) agree bit-for-bit."""
     pt, scenes, parallel, ptref = _imports()
@@ -366,7 +385,7 @@ def _pin_cases():
     return pin_scenes.cases()
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy"])
 def test_product_matches_reference_integrator_golden(name):
     """The HIP path against frames rendered by the REFERENCE'S integrator source text (tests/golden/reference_integrator_golden.npz, made in the build
     container by compiling PathTracer.hlsli & co. over the oracle's scene services — tests/test_oracle_refpin_integrator.py). No oracle call here."""
@@ -388,7 +407,7 @@ def _pin_cases_lp16():
     return pin_scenes.cases_lp16()
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "bistro_like_firefly", "bistro_like_material_zoo_firefly", "c2_spec_gloss", "bistro_like_spec_gloss"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "bistro_like_firefly", "bistro_like_material_zoo_firefly", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy"])
 def test_product_lp16_matches_reference_integrator_golden(name):
     """PtSettings.useFp16Types = 1 — the reference's DEFAULT build (lp types in binary16; SampleUI.h:182, Sample.cpp:1035) and what pt_default_settings returns —
     against frames rendered by the reference's integrator text compiled that way (tests/golden/reference_integrator_golden_lp16.npz). No oracle call here."""
@@ -411,7 +430,7 @@ def test_c_default_settings_are_the_reference_default_build():
 
 
 @pytest.mark.parametrize("lp16", [False, True], ids=["fp32", "lp16"])
-@pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss"])
+@pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy"])
 def test_device_load_surface_matches_oracle(name, lp16):
     """Bridge::loadSurface on the device (geometry gather, material evaluation with its lp types, textures, normal map, tangent frame, BSDF inputs, emissive light
     index) against the oracle's — which is pinned to PathTracerBridgeDonut.hlsli compiled from the reference in both builds of the lp types

@@ -77,7 +77,7 @@ def test_oracle_lp16_matches_live_reference_integrator(name):
 
 
 @pytest.mark.parametrize("lp16", [False, True], ids=["fp32", "lp16"])
-@pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss"])
+@pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy"])
 def test_load_surface_matches_reference_text(name, lp16):
     """Bridge::loadSurface and everything RTXPT-side below it (getGeometryFromHit, sampleGeometryMaterialRTXPT, EvaluateSceneMaterialRTXPT,
     ApplyNormalMapRTXPT, createTextureSampler + ray-cone LOD, computeTangentSpace / adjustShadingNormal, emissive light index) compiled from
