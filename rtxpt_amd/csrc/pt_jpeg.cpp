@@ -84,6 +84,7 @@ bool read_markers_and_scans(Decoder& d, std::vector<uint8_t>& rgba) {
             if (sawSOF || len < 8) return false; sawSOF = true; d.progressive = m == 0xC2;
             int prec = seg[0]; d.height = (seg[1] << 8) | seg[2]; d.width = (seg[3] << 8) | seg[4]; d.ncomp = seg[5];
             if (prec != 8 || d.width <= 0 || d.height <= 0 || d.width > 32768 || d.height > 32768 || (d.ncomp != 1 && d.ncomp != 3) || len < 8 + 3 * d.ncomp) return false;
+            if ((size_t)d.width * (size_t)d.height / 1024u > (size_t)(d.end - d.p) + 65536u) return false;      // a header that promises far more pixels than the stream could hold (even a flat image needs a few bits per block): no giant allocations for a tiny file
             for (int c = 0; c < d.ncomp; c++) { Comp& k = d.comp[c]; k.id = seg[6 + 3 * c]; k.h = seg[7 + 3 * c] >> 4; k.v = seg[7 + 3 * c] & 15; k.tq = seg[8 + 3 * c];
                 if (k.h < 1 || k.h > 2 || k.v < 1 || k.v > 2 || k.tq > 3) return false; if (k.h > d.hmax) d.hmax = k.h; if (k.v > d.vmax) d.vmax = k.v; }
             if (d.ncomp == 1) { d.comp[0].h = d.comp[0].v = 1; d.hmax = d.vmax = 1; }
