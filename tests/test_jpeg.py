@@ -55,6 +55,10 @@ def test_damaged_streams_fail_cleanly():
         b = bytes(b[: int(rng.integers(4, len(b) + 1))])
         try: img = pt.read_jpeg(b); assert img.ndim == 3
         except pt.PtError: pass
+    big = bytearray(good); i = good.index(b"\xff\xc2"); big[i + 5:i + 9] = bytes([0x7F, 0xFF, 0x7F, 0xFF])          # the same stream claiming 32767 x 32767 pixels: refused before any allocation
+    import time; t0 = time.time()
+    with pytest.raises(pt.PtError): pt.read_jpeg(bytes(big))
+    assert time.time() - t0 < 1.0
     for junk in (b"", b"\xff", b"\xff\xd8", b"\xff\xd8\xff\xd9", b"not a jpeg at all", good[:200]):
         with pytest.raises(pt.PtError): pt.read_jpeg(junk)
 
