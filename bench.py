@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--tex", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32-lp-types", action="store_true", help="RTXPT_LP_TYPES_USE_16BIT_PRECISION 0 instead of the reference's default build (lp types in binary16)")
+    ap.add_argument("--no-env-compression", action="store_true", help="sample the uncompressed RGBA16F environment cube (the reference on Vulkan) instead of the BC6H one (its D3D12 default)")
     ap.add_argument("--skip-roofline-steps", action="store_true", help="profiling runs (tools/profile_round.sh): only the timed steps, no extra serial / counter steps")
     ap.add_argument("--serial-kernels", action="store_true", help="run every step with PT_DEVICE_SERIAL_KERNELS semantics (for rocprofv3 kernel traces: launches never overlap)")
     args = ap.parse_args()
@@ -67,6 +68,7 @@ def main():
 
     sc, cam = scenes.bistro_like(scale=args.scale, tex_size=args.tex)
     sc["env_cube_dim"] = 2048                    # EnvMapBaker's cube resolution for an image source (EnvMapBaker.cpp:374-375)
+    sc["env_compression"] = 0 if args.no_env_compression else 1      # ... and its BC6U compression of that cube, on by default on D3D12 (EnvMapBaker.h:157,193): bake-time only
     S = scenes.default_settings(useFp16Types=0 if args.fp32_lp_types else 1)      # 8 bounces, NEE (emissive triangles + env quads), Russian roulette; lp types as the reference ships them
     W, H, SPP = args.width, args.height, args.spp
     camd = scenes.bridge_camera(W, H, **cam)
@@ -182,8 +184,9 @@ def main():
             "metric": "Mrays/s at 4K 4spp 8-bounce bistro-like (extend + shadow rays / wall time of pt_render)",
             "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3 bistro-like street canyon, %d triangles, 64 materials, 32 textures %d^2, %d emissive-triangle + env-quad lights, %dx%d, %d spp, 8 bounces, NEE 5 candidates + RR, lp types %s"
-                                   % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP, "fp32" if args.fp32_lp_types else "binary16 (reference default)"),
+            "config": {"workload": "C3 bistro-like street canyon, %d triangles, 64 materials, 32 textures %d^2, %d emissive-triangle + env-quad lights, %dx%d, %d spp, 8 bounces, NEE 5 candidates + RR, lp types %s, environment cube %s"
+                                   % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP, "fp32" if args.fp32_lp_types else "binary16 (reference default)",
+                                      "RGBA16F" if args.no_env_compression else "2048 BC6H (reference default on D3D12)"),
                        "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
             # `frac` is the prescribed figure: algorithmic bytes / launch time / 8 TB/s. `bound` is what the counters say limits the kernel:

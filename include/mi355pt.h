@@ -187,6 +187,11 @@ int32_t pt_set_environment(pt_context* ctx, const float* rgbLatLong, uint32_t wi
  * fp16 range, and the scene's directional lights drawn into it as anti-aliased discs (Sample::UpdateLighting, Sample.cpp:1361-1388). At most 16 lights
  * (EMB_MAXDIRLIGHTS). The bake runs on the device at the next pt_render / pt_prepare. */
 int32_t pt_set_environment_bake(pt_context* ctx, uint32_t cubeDim, const PtEnvDirectionalLight* directionalLights, uint32_t numDirectionalLights);
+/* EnvMapBaker's BC6U compression of the cube (EnvMapBaker.cpp:593-633, BC6UCompress.hlsl; m_compressionQuality = 1 and enabled by default on D3D12, off on Vulkan): with
+ * quality 1 ("Fast": one-region mode 11) every level goes through the reference's encoder and the BC6H_UF16 decode the texture unit applies, and the path tracer samples the
+ * result (≈ 0.5 % per texel, 2e-3 relative L2 on an environment-lit frame); the light baker's importance map keeps reading the uncompressed cube, as there. 0 = off (the
+ * library's default, the reference on Vulkan); 2 ("Quality", two-region modes) is PT_ERROR_UNSUPPORTED. */
+int32_t pt_set_environment_compression(pt_context* ctx, uint32_t quality);
 /* Sample::UpdateLighting (Rtxpt/Sample.cpp:1361-1388), the host step in front of EnvMapBaker::Update: world-space directional lights -> the records
  * pt_set_environment_bake takes. AngularSize is raised to pi / (cubeDim / 2) (smaller discs cannot be drawn into the cube), Direction is taken into the
  * environment's local frame with params->Transform (NULL: identity) so the disc keeps its world direction under an environment rotation. No device needed. */

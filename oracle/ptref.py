@@ -189,6 +189,26 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1), lp16=False):
     return L
 
 
+def bc6_encode(texels, reference=False):
+    """BC6UCompress.hlsl's EncodeP1 (the cube compressor's "Fast" mode) on blocks of 16 RGB texels, float32 [n, 16, 3] -> uint32 [n, 4]; reference=True: the reference's
+    own text (librefpin_pt), otherwise the oracle's restatement."""
+    t = np.ascontiguousarray(texels, np.float32).reshape(-1, 48); out = np.zeros((len(t), 4), np.uint32)
+    if reference:
+        L = refpin_pt()
+        if L is None: return None
+        L.refpt_bc6_encode(t.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(t)), out.ctypes.data_as(ctypes.c_void_p))
+    else:
+        lib().ptref_bc6_encode(t.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(t)), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def bc6_decode(blocks):
+    """BC6H_UF16 mode-11 blocks, uint32 [n, 4] -> the half bit patterns a fetch returns, uint32 [n, 16, 3]."""
+    b = np.ascontiguousarray(blocks, np.uint32).reshape(-1, 4); out = np.zeros((len(b), 16, 3), np.uint32)
+    lib().ptref_bc6_decode(b.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(b)), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
 def surface_probe(oracle_ctx, prims, uv_dir_cone):
     """Bridge::loadSurface of the reference text (PathTracerBridgeDonut.hlsli:612-853 and what it calls) next to the oracle's loadSurface for the same hits.
     oracle_ctx: an Oracle(reference_integrator=True) with a scene; prims: global triangle ids; uv_dir_cone: rows [u, v, dir.xyz, coneWidth, coneSpread].
@@ -403,6 +423,7 @@ class Oracle:
             dl = sc.get("env_directional_lights")
             dl = np.ascontiguousarray(dl, np.float32).reshape(-1, 8) if dl is not None else np.zeros((0, 8), np.float32)
             L.ptref_set_environment_bake(h, int(sc.get("env_cube_dim", 256)), _p(dl) if len(dl) else None, len(dl))
+            L.ptref_set_environment_compression(h, int(sc.get("env_compression", 0)))
         else:
             L.ptref_set_environment(h, None, 0, 0, None, None)
         if sc.get("lights") is not None:

@@ -181,6 +181,15 @@ static void bake_env_cube(EnvMap& e) {
                                                        env_unpack_rgba16f(at(l - 1, face, 2 * x + 1, 2 * y)), env_unpack_rgba16f(at(l - 1, face, 2 * x + 1, 2 * y + 1)),
                                                        CubemapTexelSolidAngle4((float)(d * 2), 2 * x, 2 * y)));
     }
+    e.cubeSource = c; e.cubeTexelsSource.clear();
+    if (e.cubeCompression) {                                                                 // the compressed cube the path tracer samples; the uncompressed one stays for the importance map
+        e.cubeTexelsSource = e.cubeTexels; e.cubeSource.texels = e.cubeTexelsSource.data();
+        for (uint l = 0; l < levels; l++) {
+            const uint d = dim >> l, nb = d / 4u; uint2* level = T + c.mipOffset[l];
+#pragma omp parallel for schedule(static) collapse(2)
+            for (int face = 0; face < 6; face++) for (int by = 0; by < (int)nb; by++) for (uint bx = 0; bx < nb; bx++) env_cube_bc6_round_trip_block(level, d, (uint)face, bx, (uint)by);
+        }
+    }
     e.cubeDirty = false;
 }
 
@@ -197,7 +206,7 @@ static void build_env_importance(const Scene& sc, EnvImportance& im, uint dim = 
         for (uint j = 0; j < sy; j++) for (uint i = 0; i < sx; i++) {
             float2 p = make_float2(((float)(x * sx + i) + 0.5f) / (float)dimS, ((float)((uint)y * sy + j) + 0.5f) / (float)(im.dim * sy));
             float3 dir = oct_to_ndir_equal_area_unorm(p);
-            float3 radiance = xyz(env_cube_sample_level(sc.env.cube, dir, 0.f));          // t_EnvMapCube.SampleLevel(s_LinearWrap, dir, 0) (EnvMapImportanceSamplingBaker.hlsl:77)
+            float3 radiance = xyz(env_cube_sample_level(sc.env.cubeSource, dir, 0.f));          // t_EnvMapCube.SampleLevel(s_LinearWrap, dir, 0) (EnvMapImportanceSamplingBaker.hlsl:77)
             L += (Luminance(radiance) + Average(radiance)) * 0.5f;
             R += radiance;
         }
@@ -430,6 +439,7 @@ void ptref_set_environment(void* h, const float* rgb, uint32_t w, uint32_t hgt, 
     e.cubeDirty = true; c->lightsDirty = true;
 }
 // cube resolution (EnvMapBaker::m_targetResolution: 2048 for an image source) and the directional lights baked into it (Sample::UpdateLighting, Sample.cpp:1361-1388)
+void ptref_set_environment_compression(void* h, uint32_t quality) { Context* c = (Context*)h; c->sc.env.cubeCompression = quality ? 1u : 0u; c->sc.env.cubeDirty = true; c->lightsDirty = true; }
 void ptref_set_environment_bake(void* h, uint32_t cubeDim, const EnvDirectionalLight* lights, uint32_t n) {
     Context* c = (Context*)h; EnvMap& e = c->sc.env;
     if (cubeDim) e.cubeDim = cubeDim;
@@ -444,6 +454,13 @@ uint32_t ptref_get_env_cube(void* h, uint32_t* out, uint32_t capacity, uint32_t*
     if (dim) *dim = e.cube.dim; if (mipLevels) *mipLevels = e.cube.mipLevels;
     if (out && capacity >= e.cubeTexels.size()) memcpy(out, e.cubeTexels.data(), e.cubeTexels.size() * sizeof(uint2));
     return (uint32_t)e.cubeTexels.size();
+}
+// the cube compressor: BC6UCompress.hlsl's EncodeP1 restated (envcube.h) on n blocks of 16 RGB texels -> 4 words each; and the mode-11 decode -> 16 x 3 half bit patterns
+void ptref_bc6_encode(const float* texels, uint32_t n, uint32_t* out) {
+    for (uint32_t k = 0; k < n; k++) { float3 t[16]; for (int i = 0; i < 16; i++) t[i] = make_float3(texels[48 * k + 3 * i], texels[48 * k + 3 * i + 1], texels[48 * k + 3 * i + 2]); bc6_encode_p1(t, out + 4 * k); }
+}
+void ptref_bc6_decode(const uint32_t* blocks, uint32_t n, uint32_t* halfBits) {
+    for (uint32_t k = 0; k < n; k++) { uint hb[16][3]; bc6_decode_mode11(blocks + 4 * k, hb); for (int i = 0; i < 16; i++) for (int c = 0; c < 3; c++) halfBits[48 * k + 3 * i + c] = hb[i][c]; }
 }
 // level 0 of the radiance / importance map the environment quad tree is built from (dim x dim float4; the light baker uses EMISB_IMPORTANCE_MAP_DIM = 1024)
 void ptref_get_env_importance(void* h, uint32_t dim, float* out) {

@@ -122,6 +122,9 @@ static inline float4 sample_trilinear(const Texture& t, float2 uv, float lambda)
 struct EnvMap {
     bool enabled; Texture tex; float3x4 toWorld, toLocal; float3 colorMultiplier;
     uint cubeDim = 2048; std::vector<EnvDirectionalLight> dirLights; std::vector<uint2> cubeTexels; EnvCube cube; bool cubeDirty = true;
+    // BC6H round trip (EnvMapBaker.cpp:593-633): `cube` is what the path tracer samples — the decoded compressed cube when cubeCompression != 0 — while the importance map keeps
+    // reading the uncompressed texels (`cubeSource`, :635)
+    uint cubeCompression = 0; std::vector<uint2> cubeTexelsSource; EnvCube cubeSource;
     float3 ToLocal(float3 dir) const { return mul_vec_mat3(dir, toLocal); }
     float3 ToWorld(float3 dir) const { return mul_vec_mat3(dir, toWorld); }
     // SampleSource (EnvMapBaker.hlsl:98-110): the equirectangular source through a linear sampler, wrap in u, clamp in v, mip 0

@@ -171,6 +171,7 @@ static inline float frac(float v) { return v - P::dm_floor(v); } HL_LIFT1(frac)
 static inline float sin(float v) { return P::dm_sin(v); } static inline float cos(float v) { return P::dm_cos(v); }
 static inline void sincos(float v, float& s, float& c) { P::dm_sincos(v, s, c); }
 static inline float exp2(float v) { return P::dm_exp2(v); } static inline float log2(float v) { return P::dm_log2(v); }
+static inline float3 exp2(float3 v) { return float3(exp2(v.x), exp2(v.y), exp2(v.z)); } static inline float3 log2(float3 v) { return float3(log2(v.x), log2(v.y), log2(v.z)); }
 static inline float exp(float v) { return P::dm_exp(v); } static inline float log(float v) { return P::dm_log(v); } HL_LIFT1(exp) HL_LIFT1(log)
 static inline float atan2(float y, float x) { return P::dm_atan2(y, x); } static inline float acos(float v) { return P::dm_acos(v); }
 template <class E> float pow(float x, E e) { return ((float)e == 5.0f) ? P::dm_pow5(x) : P::dm_pow(x, (float)e); }      // pow(x, 5): the oracle's (x²·x²)·x

@@ -263,6 +263,13 @@ def main_pt(ref):
     w('#include "%s/hlsl_emisb_stubs.h"\n' % HERE)
     for body in extract_function(itext, "BuildMIPDescentImportanceMapCS", "EnvMapImportanceSamplingBaker.hlsl"): w(to_cpp(body) + "\n")
     w("} // namespace emisb\n")
+    # BC6UCompress.hlsl: the cube compressor's one-region encoder (QUALITY 0 = "Fast", EnvMapBaker's default on D3D12), EncodeP1 and what it calls
+    cpath = os.path.join(ref, "Rtxpt/Lighting/Distant/BC6UCompress.hlsl")
+    ctext = strip_comments(open(cpath, encoding="latin-1").read())
+    w("// ======== BC6UCompress.hlsl (selected items)\nnamespace bc6u {\n#define INSET_COLOR_BBOX 1\n#define OPTIMIZE_ENDPOINTS 1\n#define LUMINANCE_WEIGHTS 1\nstatic const float HALF_MAX = 65504.0f;\n")
+    for name in ("CalcMSLE", "Quantize10", "Unquantize10", "FinishUnquantize", "Swap", "ComputeIndex4", "InsetColorBBoxP1", "OptimizeEndpointsP1", "EncodeP1"):
+        for body in extract_function(ctext, name, "BC6UCompress.hlsl"): w(to_cpp(body) + "\n")
+    w("} // namespace bc6u\n")
     w("} // namespace hl\n")
     w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
 

@@ -26,7 +26,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 # every symbol include/mi355pt.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
-    "pt_set_environment", "pt_set_environment_bake", "pt_env_bake_lights", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_env_bake_lights", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
@@ -552,6 +552,7 @@ class PathTracer:
             dl = sc.get("env_directional_lights")       # rows of EMB_DirectionalLight: colour rgb, intensity, direction xyz, angular size
             dl = np.ascontiguousarray(dl, np.float32).reshape(-1, 8) if dl is not None else np.zeros((0, 8), np.float32)
             self._chk(self.L.pt_set_environment_bake(self.h, int(sc.get("env_cube_dim", 256)), _p(dl) if len(dl) else None, len(dl)), "pt_set_environment_bake")
+            self._chk(self.L.pt_set_environment_compression(self.h, int(sc.get("env_compression", 0))), "pt_set_environment_compression")
         else:
             self._chk(self.L.pt_set_environment(self.h, None, 0, 0, None), "pt_set_environment")
         if sc.get("lights") is not None:

@@ -82,7 +82,7 @@ struct pt_context {
     DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
-    DevBuf<ptk::uint2> dEnvCube; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights;
+    DevBuf<ptk::uint2> dEnvCube, dEnvCubeSource; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights; uint envCompression = 0;      // envCompression: EnvMapBaker's BC6U compression (0 off, 1 fast)
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
@@ -207,6 +207,7 @@ void refresh_scene_view(pt_context* c) {
     d.geometries = c->dGeometries.p; d.instances = c->dInstances.p; d.subInstances = c->dSubInstances.p; d.subInstToInstGeom = c->dSubInstToInstGeom.p;
     d.materials = c->dMaterials.p; d.materialCount = (uint)c->materials.size(); d.textures = c->dTexInfos.p; d.texels = c->dTexels.p;
     d.envCube = c->envCube; d.envCube.texels = c->dEnvCube.p;
+    d.envCubeSource = d.envCube; if (c->envCompression && c->dEnvCubeSource.p) d.envCubeSource.texels = c->dEnvCubeSource.p;
     d.envTex = c->envTexInfo; d.envEnabled = c->envEnabled ? 1u : 0u; d.envToWorld = c->envToWorld; d.envToLocal = c->envToLocal; d.envColorMultiplier = c->envColorMul;
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
@@ -429,6 +430,12 @@ int bake_env_cube(pt_context* c) {
     PT_CHECK_HIP(c, c->dEnvDirLights.upload(c->envDirLights, c->stream));
     refresh_scene_view(c);
     launch_env_cube_bake(c->dsc, c->dEnvDirLights.p, (uint)c->envDirLights.size(), c->dEnvCube.p, c->dsc.envCube, c->stream);
+    if (c->envCompression) {          // EnvMapBaker.cpp:593-633: the path tracer samples the BC6H cube, the importance baker keeps the uncompressed one
+        PT_CHECK_HIP(c, c->dEnvCubeSource.resize(total));
+        PT_CHECK_HIP(c, hipMemcpyAsync(c->dEnvCubeSource.p, c->dEnvCube.p, sizeof(ptk::uint2) * total, hipMemcpyDeviceToDevice, c->stream));
+        launch_env_cube_compress(c->dEnvCube.p, c->dsc.envCube, c->stream);
+    } else c->dEnvCubeSource.free();
+    refresh_scene_view(c);
     PT_CHECK_HIP(c, hipGetLastError());
     c->envCubeDirty = false; c->lightsDirty = true;
     return PT_OK;
@@ -493,7 +500,7 @@ int32_t pt_destroy(pt_context* c) {
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
-    c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
+    c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
@@ -591,6 +598,12 @@ int32_t pt_set_environment_bake(pt_context* c, uint32_t cubeDim, const PtEnvDire
     static_assert(sizeof(PtEnvDirectionalLight) == sizeof(ptk::EnvDirectionalLight), "EnvDirectionalLight layout");
     c->envDirLights.resize(n); if (n) memcpy(c->envDirLights.data(), lights, sizeof(ptk::EnvDirectionalLight) * n);
     c->envCubeDirty = true; c->lightsDirty = true;
+    return PT_OK;
+}
+int32_t pt_set_environment_compression(pt_context* c, uint32_t quality) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (quality > 1u) return fail(c, PT_ERROR_UNSUPPORTED, "BC6U compression quality 2 (two-region modes) is not restated; 0 = off, 1 = fast (the reference's default on D3D12)");
+    if (c->envCompression != quality) { c->envCompression = quality; c->envCubeDirty = true; c->lightsDirty = true; }
     return PT_OK;
 }
 int32_t pt_set_lights(pt_context* c, const ::PolymorphicLightInfo* lights, const ::PolymorphicLightInfoEx* ex, uint32_t n) {

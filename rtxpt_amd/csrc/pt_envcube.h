@@ -10,7 +10,7 @@ namespace ptk {
 // 166-246, 268-371; EnvMapBaker.cpp:298-343, 425-620; Rtxpt/Shaders/PathTracer/Lighting/EnvMap.hlsli:54-93): a cube of RGBA16F texels with a solid-angle
 // weighted mip chain down to 8x8, the scene's directional lights rasterised into it as anti-aliased discs, radiance scaled by c_envMapRadianceScale = 1/4
 // (Sample.cpp:88; the host compensates in EnvMapSceneParams::ColorMultiplier, :1936-1948) and clamped to the fp16 range. The reference may additionally
-// BC6H-compress the cube (lossy, disabled on Vulkan): the uncompressed RGBA16F path is restated.
+// BC6H-compress the cube (lossy; on by default on D3D12, off on Vulkan): restated too, as a round trip through its encoder and the BC6H decode at bake time (below).
 // Layout in memory: RGBA16F texels packed into uint2 (x | y<<16, z | w<<16), [mip][face][y][x]; faces +X -X +Y -Y +Z -Z.
 // What the texture unit does is implementation-defined and restated as: face = major axis (ties x, y, z in that order), bilinear taps clamped to the face
 // (no filtering across face edges), linear interpolation between the two nearest mips.
@@ -82,6 +82,89 @@ static inline uint2 env_pack_rgba16f(float4 v) { return make_uint2((f32tof16(v.y
 static inline float4 env_unpack_rgba16f(uint2 t) { return make_float4(f16tof32(t.x & 0xffffu), f16tof32(t.x >> 16), f16tof32(t.y & 0xffffu), f16tof32(t.y >> 16)); }
 static inline float4 env_round_rgba16f(float4 v) { return env_unpack_rgba16f(env_pack_rgba16f(v)); }      // what a store to the RGBA16_FLOAT cube keeps
 
+// ---- BC6H round trip of the cube (EnvMapBaker.cpp:593-633: on D3D12 the reference compresses every mip of the finished RGBA16F cube with BC6UCompress.hlsl — Narkowicz'
+// GPURealTimeBC6H, "Fast" = QUALITY 0 = one-region mode 11 only, m_compressionQuality = 1 by default — and the path tracer samples the compressed cube; the importance
+// map keeps reading the uncompressed one, :635). EncodeP1 is restated below (BC6UCompress.hlsl:58-69, 117-141, 163-167, 179-202, 235-277, 324-416; log2 / exp2 / rcp through
+// the deterministic library); the decode is the BC6H_UF16 rule of the D3D11 functional specification for mode 11 (10-bit endpoints, no transform, 4-bit indices, the index
+// of texel 0 one bit short): unquantise ((c << 16) + 0x8000) >> 10 with 0 and 1023 pinned to 0 and 0xFFFF, interpolate (a (64 - w) + b w + 32) >> 6, finish (x 31) >> 6.
+static inline float bc6_half_bits(float x) { return (float)f32tof16(x); }                              // `float v = f32tof16(x)`: the half's bit pattern as a number
+static inline uint bc6_index4(float texelPos, float endPoint0Pos, float endPoint1Pos) {               // ComputeIndex4
+    float r = (texelPos - endPoint0Pos) / (endPoint1Pos - endPoint0Pos);
+    return (uint)clampf(r * 14.93333f + 0.03333f + 0.5f, 0.0f, 15.0f);
+}
+static inline float3 bc6_quantize10(float3 x) { return make_float3((bc6_half_bits(x.x) * 1024.0f) / (0x7bff + 1.0f), (bc6_half_bits(x.y) * 1024.0f) / (0x7bff + 1.0f), (bc6_half_bits(x.z) * 1024.0f) / (0x7bff + 1.0f)); }
+static inline float3 bc6_log2p1(float3 v) { return make_float3(dm_log2(v.x + 1.0f), dm_log2(v.y + 1.0f), dm_log2(v.z + 1.0f)); }
+static inline float3 bc6_exp2m1(float3 v) { return make_float3(dm_exp2(v.x) - 1.0f, dm_exp2(v.y) - 1.0f, dm_exp2(v.z) - 1.0f); }
+static inline float bc6_sel_min(float cur, float texel, float block) { float c = (texel == block) ? cur : texel; return fminf_(cur, c); }
+static inline float bc6_sel_max(float cur, float texel, float block) { float c = (texel == block) ? cur : texel; return fmaxf_(cur, c); }
+static inline void bc6_encode_p1(const float3 texels[16], uint block[4]) {
+    float3 blockMin = texels[0], blockMax = texels[0];
+    for (uint i = 1; i < 16; ++i) { blockMin = min3v(blockMin, texels[i]); blockMax = max3v(blockMax, texels[i]); }
+    const float3 blockMinNonInset = blockMin, blockMaxNonInset = blockMax;
+    {   // InsetColorBBoxP1
+        float3 rmin = blockMax, rmax = blockMin;
+        for (uint i = 0; i < 16; ++i) {
+            rmin = make_float3(bc6_sel_min(rmin.x, texels[i].x, blockMin.x), bc6_sel_min(rmin.y, texels[i].y, blockMin.y), bc6_sel_min(rmin.z, texels[i].z, blockMin.z));
+            rmax = make_float3(bc6_sel_max(rmax.x, texels[i].x, blockMax.x), bc6_sel_max(rmax.y, texels[i].y, blockMax.y), bc6_sel_max(rmax.z, texels[i].z, blockMax.z));
+        }
+        float3 logRMax = bc6_log2p1(rmax), logRMin = bc6_log2p1(rmin), logMax = bc6_log2p1(blockMax), logMin = bc6_log2p1(blockMin);
+        float3 ext = (logMax - logMin) * (1.0f / 32.0f);
+        logMin = logMin + min3v(logRMin - logMin, ext);
+        logMax = logMax - min3v(logMax - logRMax, ext);
+        blockMin = bc6_exp2m1(logMin); blockMax = bc6_exp2m1(logMax);
+    }
+    {   // OptimizeEndpointsP1
+        float3 dir = blockMax - blockMin; dir = dir / ((dir.x + dir.y) + dir.z);
+        float e0 = bc6_half_bits(dot(blockMin, dir)), e1 = bc6_half_bits(dot(blockMax, dir));
+        float3 alphaTexelSum = make_float3(0.f), betaTexelSum = make_float3(0.f); float alphaBetaSum = 0.0f, alphaSqSum = 0.0f, betaSqSum = 0.0f;
+        for (int i = 0; i < 16; i++) {
+            float texelPos = bc6_half_bits(dot(texels[i], dir));
+            uint texelIndex = bc6_index4(texelPos, e0, e1);
+            float beta = saturate((float)texelIndex / 15.0f), alpha = 1.0f - beta;
+            float3 texelF16 = make_float3(bc6_half_bits(texels[i].x), bc6_half_bits(texels[i].y), bc6_half_bits(texels[i].z));
+            alphaTexelSum = alphaTexelSum + texelF16 * alpha; betaTexelSum = betaTexelSum + texelF16 * beta;
+            alphaBetaSum += alpha * beta; alphaSqSum += alpha * alpha; betaSqSum += beta * beta;
+        }
+        float det = alphaSqSum * betaSqSum - alphaBetaSum * alphaBetaSum;
+        if (fabsf(det) > 0.00001f) {
+            float detRcp = 1.0f / det;
+            float3 a = (alphaTexelSum * betaSqSum - betaTexelSum * alphaBetaSum) * detRcp, b = (betaTexelSum * alphaSqSum - alphaTexelSum * alphaBetaSum) * detRcp;
+            auto back = [](float v) { return f16tof32((uint)clampf(v, 0.0f, 65504.0f)); };               // f16tof32(clamp(.., 0, HALF_MAX)): the float is converted to the uint bit pattern
+            float3 mn = make_float3(back(a.x), back(a.y), back(a.z)), mx = make_float3(back(b.x), back(b.y), back(b.z));
+            blockMin = make_float3(clampf(mn.x, blockMinNonInset.x, blockMaxNonInset.x), clampf(mn.y, blockMinNonInset.y, blockMaxNonInset.y), clampf(mn.z, blockMinNonInset.z, blockMaxNonInset.z));
+            blockMax = make_float3(clampf(mx.x, blockMinNonInset.x, blockMaxNonInset.x), clampf(mx.y, blockMinNonInset.y, blockMaxNonInset.y), clampf(mx.z, blockMinNonInset.z, blockMaxNonInset.z));
+        }
+    }
+    float3 dir = blockMax - blockMin; dir = dir / ((dir.x + dir.y) + dir.z);
+    float3 endpoint0 = bc6_quantize10(blockMin), endpoint1 = bc6_quantize10(blockMax);
+    float e0 = bc6_half_bits(dot(blockMin, dir)), e1 = bc6_half_bits(dot(blockMax, dir));
+    if (bc6_index4(bc6_half_bits(dot(texels[0], dir)), e0, e1) > 7u) { float t = e0; e0 = e1; e1 = t; float3 t3 = endpoint0; endpoint0 = endpoint1; endpoint1 = t3; }
+    uint idx[16];
+    for (uint i = 0; i < 16; ++i) idx[i] = bc6_index4(bc6_half_bits(dot(texels[i], dir)), e0, e1);
+    uint x = 0x03u, y = 0u, z = 0u, w = 0u;
+    x |= (uint)endpoint0.x << 5; x |= (uint)endpoint0.y << 15; x |= (uint)endpoint0.z << 25; y |= (uint)endpoint0.z >> 7;
+    y |= (uint)endpoint1.x << 3; y |= (uint)endpoint1.y << 13; y |= (uint)endpoint1.z << 23; z |= (uint)endpoint1.z >> 9;
+    z |= idx[0] << 1; z |= idx[1] << 4; z |= idx[2] << 8; z |= idx[3] << 12; z |= idx[4] << 16; z |= idx[5] << 20; z |= idx[6] << 24; z |= idx[7] << 28;
+    for (uint i = 8; i < 16; ++i) w |= idx[i] << (4u * (i - 8u));
+    block[0] = x; block[1] = y; block[2] = z; block[3] = w;
+}
+static inline uint bc6_unquantize10(uint c) { return c == 0u ? 0u : (c == 1023u ? 0xFFFFu : ((c << 16) + 0x8000u) >> 10); }
+static inline void bc6_decode_mode11(const uint block[4], uint halfBits[16][3]) {        // -> the half bit patterns a BC6H_UF16 fetch returns (alpha reads 1)
+    const uint x = block[0], y = block[1], z = block[2], w = block[3];
+    const uint e0[3] = {(x >> 5) & 1023u, (x >> 15) & 1023u, ((x >> 25) | (y << 7)) & 1023u}, e1[3] = {(y >> 3) & 1023u, (y >> 13) & 1023u, ((y >> 23) | (z << 9)) & 1023u};
+    const uint weights[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+    for (uint i = 0; i < 16; ++i) {
+        const uint id = i == 0u ? (z >> 1) & 7u : (i < 8u ? (z >> (4u * i)) & 15u : (w >> (4u * (i - 8u))) & 15u), wt = weights[id];
+        for (uint c = 0; c < 3; ++c) { const uint a = bc6_unquantize10(e0[c]), b = bc6_unquantize10(e1[c]); halfBits[i][c] = (((a * (64u - wt) + b * wt + 32u) >> 6) * 31u) >> 6; }
+    }
+}
+// one 4x4 block of a cube level through the encoder and the decoder, in place (texel (bx*4 + i%4, by*4 + i/4) is texels[i], CSMain's gather order)
+static inline void env_cube_bc6_round_trip_block(uint2* level, uint dim, uint face, uint bx, uint by) {
+    float3 texels[16];
+    for (uint i = 0; i < 16; ++i) { float4 t = env_unpack_rgba16f(level[((size_t)face * dim + (by * 4u + i / 4u)) * dim + (bx * 4u + i % 4u)]); texels[i] = xyz(t); }
+    uint block[4], hb[16][3]; bc6_encode_p1(texels, block); bc6_decode_mode11(block, hb);
+    for (uint i = 0; i < 16; ++i) level[((size_t)face * dim + (by * 4u + i / 4u)) * dim + (bx * 4u + i % 4u)] = make_uint2(hb[i][0] | (hb[i][1] << 16), hb[i][2] | (0x3C00u << 16));
+}
 static inline float4 env_cube_texel(const EnvCube& c, uint mip, uint face, int x, int y) {
     int d = (int)(c.dim >> mip);
     x = x < 0 ? 0 : (x >= d ? d - 1 : x); y = y < 0 ? 0 : (y >= d ? d - 1 : y);

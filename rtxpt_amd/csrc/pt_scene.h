@@ -95,6 +95,7 @@ struct DeviceScene {
     const TexInfo* textures; const float4* texels;
     TexInfo envTex; uint envEnabled; float3x4 envToWorld, envToLocal; float3 envColorMultiplier;      // envTex: the lat-long source (read by the cube bake only)
     EnvCube envCube;           // what the path tracer samples: EnvMapBaker's RGBA16F cube + mips (pt_envcube.h)
+    EnvCube envCubeSource;     // the uncompressed cube the importance map is built from (EnvMapBaker.cpp:635); the same texels as envCube unless the BC6H round trip is on
     LightTable lights;
     const BvhNode* nodes; const Bvh8Node* nodes8; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
     const AlphaRec* alphaRecs; // one per TriRecord slot (leaf order)

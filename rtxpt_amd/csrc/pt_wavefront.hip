@@ -382,6 +382,15 @@ __global__ void __launch_bounds__(256) k_env_cube_mip(uint2* __restrict__ texels
         env_unpack_rgba16f(src[(size_t)(2 * y) * s + 2 * x]), env_unpack_rgba16f(src[(size_t)(2 * y + 1) * s + 2 * x]),
         env_unpack_rgba16f(src[(size_t)(2 * y) * s + 2 * x + 1]), env_unpack_rgba16f(src[(size_t)(2 * y + 1) * s + 2 * x + 1]), CubemapTexelSolidAngle4((float)s, 2 * x, 2 * y)));
 }
+// BC6UCompress.hlsl CSMain (QUALITY 0) + the texture unit's BC6H_UF16 decode, in place: one thread per 4x4 block of one cube level (pt_envcube.h)
+__global__ void __launch_bounds__(64) k_env_cube_bc6(uint2* __restrict__ level, uint dim) {
+    const uint nb = dim / 4u; uint i = blockIdx.x * 64u + threadIdx.x; if (i >= 6u * nb * nb) return;
+    const uint face = i / (nb * nb), r = i - face * nb * nb, by = r / nb, bx = r - by * nb;
+    env_cube_bc6_round_trip_block(level, dim, face, bx, by);
+}
+void launch_env_cube_compress(uint2* texels, const EnvCube& cube, hipStream_t st) {
+    for (uint l = 0; l < cube.mipLevels; l++) { const uint d = cube.dim >> l, nb = d / 4u; hipLaunchKernelGGL(k_env_cube_bc6, dim3((6u * nb * nb + 63u) / 64u), dim3(64), 0, st, texels + cube.mipOffset[l], d); }
+}
 void launch_env_cube_bake(const DeviceScene& sc, const EnvDirectionalLight* lights, uint nLights, uint2* texels, const EnvCube& cube, hipStream_t st) {
     const uint h = cube.dim / 2u;
     hipLaunchKernelGGL(k_env_cube_base, dim3((6u * h * h + 255u) / 256u), dim3(256), 0, st, sc, lights, nLights, texels, cube);
@@ -397,7 +406,7 @@ __global__ void __launch_bounds__(256) k_env_importance(DeviceScene sc, uint dim
     for (uint j = 0; j < sy; j++) for (uint ii = 0; ii < sx; ii++) {
         float2 p = make_float2(((float)(x * sx + ii) + 0.5f) / (float)(dim * sx), ((float)(y * sy + j) + 0.5f) / (float)(dim * sy));
         float3 dir = oct_to_ndir_equal_area_unorm(p);
-        float3 radiance = xyz(env_cube_sample_level(sc.envCube, dir, 0.f));          // t_EnvMapCube.SampleLevel(s_LinearWrap, dir, 0) (:77)
+        float3 radiance = xyz(env_cube_sample_level(sc.envCubeSource, dir, 0.f));    // t_EnvMapCube.SampleLevel(s_LinearWrap, dir, 0) (:77) — the uncompressed cube (EnvMapBaker.cpp:635)
         L += (Luminance(radiance) + Average(radiance)) * 0.5f;
         R += radiance;
     }

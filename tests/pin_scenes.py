@@ -84,7 +84,7 @@ def with_rotated_environment(make, yaw=0.9, pitch=0.35, tint=(1.4, 0.8, 0.6)):
     return build
 
 
-def with_sun_discs(make, cube_dim=None):
+def with_sun_discs(make, cube_dim=None, compression=0):
     """The scene of `make` with two directional lights baked into its environment cube (Sample::UpdateLighting hands the scene's DirectionalLights to
     EnvMapBaker::Update, Sample.cpp:1361-1388; EnvMapBaker.hlsl:166-192 draws them as anti-aliased discs): a small bright sun and a wide dim disc.
     Rows: colour rgb, intensity, direction the light travels in, angular size [rad]."""
@@ -95,6 +95,7 @@ def with_sun_discs(make, cube_dim=None):
         d0 = -np.array([0.35, 0.8, -0.45]) / np.linalg.norm([0.35, 0.8, -0.45]); d1 = -np.array([-0.5, 0.6, 0.62]) / np.linalg.norm([-0.5, 0.6, 0.62])
         sc["env_directional_lights"] = np.array([[1.0, 0.92, 0.8, 2.5, d0[0], d0[1], d0[2], 0.05], [0.3, 0.5, 1.0, 0.8, d1[0], d1[1], d1[2], 0.6]], np.float32)
         if cube_dim: sc["env_cube_dim"] = cube_dim
+        if compression: sc["env_compression"] = compression
         return sc, cam
     return build
 
@@ -115,6 +116,9 @@ def env_cube_cases():
         "sky_16": scene(scenes.sky_equirect(128, 64), 16),
         "sky_32_discs": scene(scenes.sky_equirect(256, 128), 32, lights),
         "sky_64_hdr_sun": scene(scenes.sky_equirect(512, 256, sun_radiance=4e5, sun_deg=3.0), 64, lights[:1]),
+        # ... and through EnvMapBaker's BC6U compression ("Fast", its D3D12 default): BC6UCompress.hlsl's EncodeP1 + the BC6H_UF16 decode, every level
+        "sky_32_discs_bc6": dict(scene(scenes.sky_equirect(256, 128), 32, lights), env_compression=1),
+        "sky_64_hdr_sun_bc6": dict(scene(scenes.sky_equirect(512, 256, sun_radiance=4e5, sun_deg=3.0), 64, lights[:1]), env_compression=1),
     }
 
 
@@ -192,6 +196,7 @@ def cases():
         "c2_exclude_from_nee": (with_excluded_geometry(c2), scenes.default_settings(), 64, 36, 0, 2),              # ExcludeFromNEE geometry: invisible to shadow rays
         "c2_env_rotated_mip2": (with_rotated_environment(c2), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 64, 36, 5, 2),   # env transform + tint, diffuse-bounce env MIP 2 (the UI default)
         "c2_sun_discs": (with_sun_discs(c2), scenes.default_settings(), 64, 36, 2, 2),                             # directional lights baked into the environment cube
+        "c2_sun_discs_bc6": (with_sun_discs(c2, compression=1), scenes.default_settings(envMapDiffuseSampleMIPLevel=2.0), 64, 36, 7, 2),   # the BC6H-compressed cube (EnvMapBaker's D3D12 default)
         "c2_mirrored_room": (with_mirrored_instance(c2), scenes.default_settings(), 64, 36, 0, 2),                 # negative-determinant instance holding the quad light
         "bistro_like": (lambda: scenes.bistro_like(scale=0.02, tex_size=128), scenes.default_settings(), 96, 54, 0, 2),      # alpha test, textures, normal maps, emissive triangles, env quads
         "bistro_like_material_zoo": (with_material_zoo(lambda: scenes.bistro_like(scale=0.02, tex_size=128)), scenes.default_settings(), 96, 54, 2, 2),

@@ -157,3 +157,50 @@ def test_cube_fetch_is_continuous_across_face_edges():
     b = o.env_eval(np.stack([np.full_like(t, 1.0 - eps), t, np.ones_like(t), np.zeros_like(t)], 1))      # just on the +Z side
     assert np.isfinite(a).all() and np.isfinite(b).all()
     assert np.abs(a - b).max() <= 0.35 * max(a.max(), b.max())
+
+
+# ---- EnvMapBaker's BC6U compression of the cube (EnvMapBaker.cpp:593-633; BC6UCompress.hlsl "Fast" = EncodeP1, one-region mode 11) --------------------------------------
+
+def test_bc6_encoder_matches_reference_text_golden():
+    """The oracle's EncodeP1 against blocks encoded by the reference's BC6UCompress.hlsl text (committed; 1 600 blocks of eight kinds incl. flat and black ones)."""
+    g = np.load(GOLDEN)
+    got = ptref.bc6_encode(g["bc6_texels"])
+    bad = (got != g["bc6_blocks"]).any(1)
+    assert not bad.any(), "%d of %d blocks differ" % (int(bad.sum()), len(bad))
+    assert ((got[:, 0] & 31) == 3).all()                                    # mode 11
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="no /root/reference on this machine: the reference text cannot be compiled here")
+def test_bc6_encoder_matches_live_reference_text():
+    rng = np.random.default_rng(44)
+    T = (rng.uniform(0, 1, (3000, 1, 3)) * 10 ** rng.uniform(-3, 3.5, (3000, 1, 1)) * rng.uniform(0.2, 1.8, (3000, 16, 3)) ** rng.integers(1, 4, (3000, 1, 1))).astype(np.float16).astype(np.float32)
+    T[::17] = T[::17, :1]                                                     # flat blocks
+    assert np.array_equal(ptref.bc6_encode(T), ptref.bc6_encode(T, reference=True))
+
+
+def test_bc6_mode11_decode_against_an_independent_decoder():
+    """What a BC6H_UF16 fetch returns for the encoder's blocks: the oracle's decode against Pillow's BC6H decoder — which outputs 8 bits (clamp to [0, 1], x 255, truncated),
+    so this checks bit layout, unquantisation and interpolation at that resolution (the blocks are white noise: how close a round trip stays is checked on cubes below)."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io, struct
+    rng = np.random.default_rng(5); n = 1024
+    T = (rng.uniform(0, 1.2, (n, 1, 3)) * rng.uniform(0.3, 1.0, (n, 16, 3))).astype(np.float16).astype(np.float32)
+    blk = ptref.bc6_encode(T)
+    mine = ptref.bc6_decode(blk).astype(np.uint16).view(np.float16).astype(np.float32).reshape(n, 16, 3)
+    hdr = b"DDS " + struct.pack("<7I", 124, 0x1007, 128, 128, 0, 0, 1) + b"\0" * 44 + struct.pack("<2I4s5I", 32, 4, b"DX10", 0, 0, 0, 0, 0) + struct.pack("<5I", 0x1000, 0, 0, 0, 0) + struct.pack("<5I", 95, 3, 0, 1, 0)
+    im = np.asarray(PIL.open(io.BytesIO(hdr + blk.tobytes())).convert("RGB")).astype(int)
+    pil = im.reshape(32, 4, 32, 4, 3).transpose(0, 2, 1, 3, 4).reshape(n, 16, 3)
+    assert np.array_equal(np.floor(np.clip(mine, 0, 1) * 255).astype(int), pil)
+
+
+@pytest.mark.parametrize("name", ["sky_32_discs_bc6", "sky_64_hdr_sun_bc6"])
+def test_compressed_cube_and_importance_map(name):
+    """With compression on, the sampled cube is the reference-text bake sent through the encoder text and the decode (committed golden); the importance map is built from the
+    UNCOMPRESSED cube (EnvMapBaker.cpp:635) and therefore equals the uncompressed case's."""
+    g = np.load(GOLDEN); sc = CASES[name]
+    (cube, dim, levels), o = _cube(sc)
+    assert np.array_equal(cube, g[name]) and (cube != g[name[:-4]]).any(-1).mean() > 0.9
+    h = _half(cube); assert np.all(h[:, 3] == 1.0) and np.isfinite(h).all() and (h >= 0).all()
+    assert np.array_equal(o.env_importance(64), g[name[:-4] + "_importance64"]) and np.array_equal(g[name + "_importance64"], g[name[:-4] + "_importance64"])
+    rel = np.abs(_half(cube)[:, :3] - _half(g[name[:-4]])[:, :3]) / (_half(g[name[:-4]])[:, :3] + 1e-3)
+    assert np.median(rel) < 0.02

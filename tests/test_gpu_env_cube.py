@@ -18,7 +18,7 @@ def _imports():
     return pt, scenes, ptref, pin_scenes
 
 
-@pytest.mark.parametrize("name", ["sky_16", "sky_32_discs", "sky_64_hdr_sun"])
+@pytest.mark.parametrize("name", ["sky_16", "sky_32_discs", "sky_64_hdr_sun", "sky_32_discs_bc6", "sky_64_hdr_sun_bc6"])
 def test_device_cube_matches_reference_text_golden_and_oracle(name):
     pt, scenes, ptref, pin_scenes = _imports()
     sc = pin_scenes.env_cube_cases()[name]
@@ -89,3 +89,24 @@ def test_environment_bake_argument_validation():
     assert g.L.pt_set_environment_bake(g.h, 256, None, 0) == 0
     n = ctypes.c_uint32(7)
     assert g.L.pt_get_env_cube(g.h, ctypes.byref(n), None, None, None, 0) == 0 and n.value == 0      # no environment set: no cube
+
+
+def test_compressed_cube_frames_and_switching():
+    """pt_set_environment_compression: the frame with the BC6H cube equals the oracle's (and the reference-text golden), the light tables do not change (the importance map reads the
+    uncompressed cube), switching back restores the uncompressed frame, quality 2 is refused."""
+    pt, scenes, ptref, pin_scenes = _imports()
+    make, S, w, h, first, n = pin_scenes.cases()["c2_sun_discs_bc6"]
+    sc, cam = make(); camd = scenes.bridge_camera(w, h, **cam)
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(w, h); g.render(first, n)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.render(first, n)
+    on = g.radiance().copy()
+    assert np.array_equal(on, o.radiance()) and np.array_equal(g.env_cube()[0], o.env_cube()[0])
+    lights_on = g.light_tables() if hasattr(g, "light_tables") else None
+    assert g.L.pt_set_environment_compression(g.h, 0) == 0
+    g.reset_accumulation(); g.render(first, n); off = g.radiance().copy()
+    sc0 = dict(sc); sc0["env_compression"] = 0
+    o0 = ptref.Oracle(); o0.set_scene(sc0); o0.set_camera(camd); o0.set_settings(S); o0.resize(w, h); o0.render(first, n)
+    assert np.array_equal(off, o0.radiance()) and not np.array_equal(on, off)
+    assert g.L.pt_set_environment_compression(g.h, 1) == 0
+    g.reset_accumulation(); g.render(first, n); assert np.array_equal(g.radiance(), on)
+    assert g.L.pt_set_environment_compression(g.h, 2) == pt.PT_ERROR_UNSUPPORTED

@@ -385,7 +385,7 @@ def _pin_cases():
     return pin_scenes.cases()
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy", "c2_sun_discs_bc6"])
 def test_product_matches_reference_integrator_golden(name):
     """The HIP path against frames rendered by the REFERENCE'S integrator source text (tests/golden/reference_integrator_golden.npz, made in the build
     container by compiling PathTracer.hlsli & co. over the oracle's scene services — tests/test_oracle_refpin_integrator.py). No oracle call here."""
@@ -407,7 +407,7 @@ def _pin_cases_lp16():
     return pin_scenes.cases_lp16()
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "bistro_like_firefly", "bistro_like_material_zoo_firefly", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c2_firefly", "c2_nee3", "c2_nee_off", "c2_nested2_norr_nold", "c2_nested0_uniform", "c2_sphere_lights", "c2_exclude_from_nee", "c2_env_rotated_mip2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "bistro_like_firefly", "bistro_like_material_zoo_firefly", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy", "c2_sun_discs_bc6"])
 def test_product_lp16_matches_reference_integrator_golden(name):
     """PtSettings.useFp16Types = 1 — the reference's DEFAULT build (lp types in binary16; SampleUI.h:182, Sample.cpp:1035) and what pt_default_settings returns —
     against frames rendered by the reference's integrator text compiled that way (tests/golden/reference_integrator_golden_lp16.npz). No oracle call here."""
@@ -430,7 +430,7 @@ def test_c_default_settings_are_the_reference_default_build():
 
 
 @pytest.mark.parametrize("lp16", [False, True], ids=["fp32", "lp16"])
-@pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy"])
+@pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy", "c2_sun_discs_bc6"])
 def test_device_load_surface_matches_oracle(name, lp16):
     """Bridge::loadSurface on the device (geometry gather, material evaluation with its lp types, textures, normal map, tangent frame, BSDF inputs, emissive light
     index) against the oracle's — which is pinned to PathTracerBridgeDonut.hlsli compiled from the reference in both builds of the lp types
