@@ -413,7 +413,8 @@ int32_t pt_trace_visibility(pt_context* ctx, const float* rays, uint32_t n, uint
 /* light table / sub-instance read-back; pass NULL pointers to query sizes */
 int32_t pt_get_lights(pt_context* ctx, uint32_t* numLights, uint32_t* numProxies, void* lights32B, void* lightsEx16B, uint32_t* proxyCounters,
                       uint32_t* proxyIndices, uint32_t* envLookup, uint32_t* envLookupDim);
-/* the baked environment cube as the kernels sample it (EnvMapBaker's m_cubemap, EnvMapBaker.cpp:298-343): 8 bytes per RGBA16F texel, mips one after the
+/* the baked environment cube as the kernels sample it (EnvMapBaker::GetEnvMapCube: m_cubemap, or — with pt_set_environment_compression — the decoded texels of m_cubemapBC6H;
+ * EnvMapBaker.cpp:298-343, 593-633): 8 bytes per RGBA16F texel, mips one after the
  * other (dim, dim/2 .. 8), face-major (+X -X +Y -Y +Z -Z) within a mip. texels8B may be NULL to query the sizes. */
 int32_t pt_get_env_cube(pt_context* ctx, uint32_t* texelCount, uint32_t* dim, uint32_t* mipLevels, void* texels8B, uint32_t capacityTexels);
 int32_t pt_get_subinstances(pt_context* ctx, uint32_t* count, void* out32B);
