@@ -358,6 +358,7 @@ void    pt_image_free(float* rgb);
    BC7, uncompressed RGBA8 / BGRA8 / BGRX8; legacy FourCC and DX10 headers. *pixels is allocated by the library: pt_image_free((float*)pixels).
    PT_ERROR_IO: unreadable / truncated; PT_ERROR_UNSUPPORTED: BC6H, cube maps, volumes, arrays, other formats. */
 int32_t pt_image_read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);
+int32_t pt_image_read_dds_memory(const void* bytes, size_t size, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);   /* the same from memory (glTF images: MSFT_texture_dds) */
 /* JPEG images of glTF files (Donut's TextureCache gives them to stb_image): a baseline / extended / progressive Huffman stream of 8-bit greyscale or YCbCr (or
    Adobe-RGB) samples in memory -> RGBA8, top row first, alpha 255; *rgba8 is allocated by the library: pt_image_free((float*)rgba8). The samples are the IJG
    reference decoder's (islow IDCT, fancy up-sampling): any conforming decoder, stb_image included, may differ from another by a unit per sample.

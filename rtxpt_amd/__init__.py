@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",

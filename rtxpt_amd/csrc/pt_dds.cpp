@@ -93,11 +93,18 @@ float half_to_float(uint16_t h) {
 
 enum Kind { K_NONE, K_BC1, K_BC2, K_BC3, K_BC4, K_BC5, K_BC7, K_RGBA8, K_BGRA8, K_BGRX8, K_RGBA16F, K_RGBA32F };
 
+struct Bytes { const uint8_t* p; size_t n; size_t size() const { return n; } const uint8_t* data() const { return p; } const uint8_t& operator[](size_t i) const { return p[i]; } };
+int32_t read_dds_bytes(const Bytes& d, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);
 int32_t read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels) {
     if (!path || !width || !height || !format || !pixels) return PT_ERROR_INVALID_ARGUMENT;
     *pixels = nullptr; *width = *height = 0; *format = PT_TEX_RGBA8_UNORM;
     FILE* f = fopen(path, "rb"); if (!f) return PT_ERROR_IO;
     std::vector<uint8_t> d; { uint8_t buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) { d.insert(d.end(), buf, buf + n); if (d.size() > ((size_t)1 << 31)) { fclose(f); return PT_ERROR_IO; } } fclose(f); }
+    return read_dds_bytes(Bytes{d.data(), d.size()}, width, height, format, pixels);
+}
+int32_t read_dds_bytes(const Bytes& d, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels) {
+    if (!d.p || !width || !height || !format || !pixels) return PT_ERROR_INVALID_ARGUMENT;
+    *pixels = nullptr; *width = *height = 0; *format = PT_TEX_RGBA8_UNORM;
     if (d.size() < 128 || memcmp(d.data(), "DDS ", 4) != 0 || rd32(&d[4]) != 124u || rd32(&d[76]) != 32u) return PT_ERROR_IO;
     const uint32_t h = rd32(&d[12]), w = rd32(&d[16]), depth = rd32(&d[24]), hflags = rd32(&d[8]), pfFlags = rd32(&d[80]), cc = rd32(&d[84]), bitCount = rd32(&d[88]);
     const uint32_t rmask = rd32(&d[92]), gmask = rd32(&d[96]), bmask = rd32(&d[100]), amask = rd32(&d[104]), caps2 = rd32(&d[112]);
@@ -160,6 +167,9 @@ int32_t read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* 
 
 } // namespace
 
+extern "C" int32_t pt_image_read_dds_memory(const void* bytes, size_t size, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels) {
+    try { return read_dds_bytes(Bytes{(const uint8_t*)bytes, size}, width, height, format, pixels); } catch (...) { if (pixels) *pixels = nullptr; return PT_ERROR_IO; }
+}
 extern "C" int32_t pt_image_read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels) {
     try { return read_dds(path, width, height, format, pixels); } catch (...) { if (pixels) *pixels = nullptr; return PT_ERROR_IO; }
 }

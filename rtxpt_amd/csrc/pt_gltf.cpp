@@ -231,7 +231,9 @@ struct Loader {
         if (!texRef) return 0xFFFFFFFFu;
         int ti = texRef->intOr("index", -1); const JValue* texs = root.get("textures"); const JValue* imgs = root.get("images");
         if (!texs || !imgs || ti < 0 || (size_t)ti >= texs->size()) return 0xFFFFFFFFu;
-        int img = texs->arr[ti].intOr("source", -1); if (img < 0 || (size_t)img >= imgs->size()) return 0xFFFFFFFFu;
+        int img = texs->arr[ti].intOr("source", -1);
+        if (const JValue* ext = texs->arr[ti].get("extensions")) if (const JValue* dds = ext->get("MSFT_texture_dds")) { int s = dds->intOr("source", -1); if (s >= 0) img = s; }      // Donut's importer prefers the .dds image (what Bistro's glTF carries)
+        if (img < 0 || (size_t)img >= imgs->size()) return 0xFFFFFFFFu;
         auto key = std::make_pair(img, srgb ? 1 : 0); auto it = texCache.find(key); if (it != texCache.end()) return it->second;
         const JValue& im = imgs->arr[img]; std::vector<uint8_t> file;
         if (im.get("uri")) { if (!load_uri(baseDir, im.strOr("uri", ""), file)) return 0xFFFFFFFFu; }
@@ -242,7 +244,12 @@ struct Loader {
             file.assign(buffers[buf].begin() + off, buffers[buf].begin() + off + len);
         }
         uint32_t w, h; std::vector<uint8_t> rgba;
-        if (file.size() > 2 && file[0] == 0xFF && file[1] == 0xD8) {      // image/jpeg (pt_jpeg.cpp)
+        if (file.size() > 4 && !memcmp(file.data(), "DDS ", 4)) {          // image/vnd-ms.dds (pt_dds.cpp); the sRGB-ness is the texture slot's, as for the other formats
+            uint32_t fmt = 0; void* px = nullptr; if (pt_image_read_dds_memory(file.data(), file.size(), &w, &h, &fmt, &px) != PT_OK) return 0xFFFFFFFFu;
+            if (fmt == PT_TEX_RGBA32F) { pt_image_free((float*)px); return 0xFFFFFFFFu; }
+            rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px);
+        }
+        else if (file.size() > 2 && file[0] == 0xFF && file[1] == 0xD8) {      // image/jpeg (pt_jpeg.cpp)
             void* px = nullptr; if (pt_image_read_jpeg(file.data(), file.size(), &w, &h, &px) != PT_OK) return 0xFFFFFFFFu;
             rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px);
         }

@@ -132,3 +132,27 @@ def test_committed_bc7_tables_are_what_the_generator_produces(tmp_path):
     (tmp_path / "gen.py").write_text(src)
     subprocess.run([sys.executable, str(tmp_path / "gen.py")], check=True, capture_output=True)
     assert (tmp_path / "t.h").read_text() == committed
+
+
+def test_gltf_msft_texture_dds(tmp_path):
+    """MSFT_texture_dds (what Bistro's glTF carries; Donut's importer prefers the extension's image): the .dds image wins over `source`, also without a `source`; BC7 payload."""
+    import json, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from gltf_writer import write_gltf
+    from rtxpt_amd import scenes
+    sc, cam = scenes.cornell_box("C2")
+    write_gltf(sc, str(tmp_path / "c.gltf"))
+    rng = np.random.default_rng(8); blocks = rng.integers(0, 256, 4 * 2 * 16, dtype=np.uint8); blocks[0::16] |= 1
+    (tmp_path / "base.dds").write_bytes(_dds(blocks.tobytes(), 16, 8, dxgi=98))
+    Image.fromarray(np.full((4, 4, 3), 200, np.uint8), "RGB").save(tmp_path / "base.png")
+    doc = json.loads((tmp_path / "c.gltf").read_text())
+    doc["images"] = [{"uri": "base.png"}, {"uri": "base.dds"}]
+    doc["textures"] = [{"source": 0, "extensions": {"MSFT_texture_dds": {"source": 1}}}, {"extensions": {"MSFT_texture_dds": {"source": 1}}}]
+    doc["materials"][0].setdefault("pbrMetallicRoughness", {})["baseColorTexture"] = {"index": 0}; doc["materials"][1]["emissiveTexture"] = {"index": 1}
+    (tmp_path / "c.gltf").write_text(json.dumps(doc)); (tmp_path / "c.scene.json").write_text(json.dumps({"models": ["c.gltf"], "graph": [{"model": 0}]}))
+    imp = pt.SceneImport(tmp_path / "c.scene.json")
+    assert imp.info["numTextures"] == 1 and imp.info["texturesNotLoaded"] == 0            # one image, one sRGB flag: one texture (both slots are sRGB slots)
+    px, fmt = imp.texture(0); want, _ = pt.read_dds(tmp_path / "base.dds")
+    assert px.shape == (8, 16, 4) and np.array_equal(px, want) and fmt == pt.PT_TEX_RGBA8_SRGB
+    word = scenes.pack_texture_word(0, 16, 8)
+    assert imp.materials[0]["BaseOrDiffuseTextureIndex"] == word and imp.materials[1]["EmissiveTextureIndex"] == word
