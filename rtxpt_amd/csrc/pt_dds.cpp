@@ -40,8 +40,9 @@ void decode_alpha_block(const uint8_t* b, uint8_t out[16]) {
 }
 
 // ---- BPTC / BC7
-struct BitReader { const uint8_t* p; uint32_t pos = 0;
-    uint32_t get(uint32_t n) { uint32_t v = 0; for (uint32_t i = 0; i < n; i++, pos++) v |= (uint32_t)((p[pos >> 3] >> (pos & 7u)) & 1u) << i; return v; } };
+struct BitReader { unsigned __int128 v; uint32_t pos = 0;                      // the 128-bit block, least significant bit first
+    explicit BitReader(const uint8_t* p) { unsigned long long lo, hi; memcpy(&lo, p, 8); memcpy(&hi, p + 8, 8); v = ((unsigned __int128)hi << 64) | lo; }
+    uint32_t get(uint32_t n) { if (!n) return 0u; uint32_t r = (uint32_t)(v >> pos) & ((1u << n) - 1u); pos += n; return r; } };
 struct Bc7Mode { uint8_t subsets, partitionBits, rotationBits, indexSelBits, colorBits, alphaBits, endpointP, sharedP, indexBits, index2Bits; };
 const Bc7Mode kModes[8] = {{3, 4, 0, 0, 4, 0, 1, 0, 3, 0}, {2, 6, 0, 0, 6, 0, 0, 1, 3, 0}, {3, 6, 0, 0, 5, 0, 0, 0, 2, 0}, {2, 6, 0, 0, 7, 0, 1, 0, 2, 0},
                            {1, 0, 2, 1, 5, 6, 0, 0, 2, 3}, {1, 0, 2, 0, 7, 8, 0, 0, 2, 2}, {1, 0, 0, 0, 7, 7, 1, 0, 4, 0}, {2, 6, 0, 0, 5, 5, 1, 0, 2, 0}};
@@ -51,7 +52,7 @@ inline uint8_t bc7_lerp(uint32_t a, uint32_t b, uint32_t w) { return (uint8_t)((
 void decode_bc7_block(const uint8_t* b, uint8_t out[16][4]) {
     uint32_t mode = 0; while (mode < 8 && !((b[0] >> mode) & 1u)) mode++;
     if (mode == 8) { memset(out, 0, 64); return; }                                     // reserved: decodes to transparent black
-    const Bc7Mode& m = kModes[mode]; BitReader r{b}; r.pos = mode + 1u;
+    const Bc7Mode& m = kModes[mode]; BitReader r(b); r.pos = mode + 1u;
     const uint32_t partition = r.get(m.partitionBits), rotation = r.get(m.rotationBits), indexSel = r.get(m.indexSelBits);
     uint32_t ep[6][4];                                                                 // endpoint 2 s + e of subset s, channels RGBA
     const uint32_t nEp = 2u * m.subsets;
