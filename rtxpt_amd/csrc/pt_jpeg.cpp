@@ -47,9 +47,10 @@ struct Decoder {
             bitbuf |= (uint32_t)b << (24 - bitcnt); bitcnt += 8;
         }
     }
-    int getbits(int n) { if (!n) return 0; if (bitcnt < n) fill(); int v = (int)(bitbuf >> (32 - n)); bitbuf <<= n; bitcnt -= n; return v; }
+    int getbits(int n) { if (n <= 0) return 0; if (n > 16) { fail = true; return 0; }      // (a size category beyond 16 bits only comes out of a damaged table)
+                         if (bitcnt < n) fill(); int v = (int)(bitbuf >> (32 - n)); bitbuf <<= n; bitcnt -= n; return v; }
     int getbit() { return getbits(1); }
-    static int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }
+    static int extend(int v, int n) { return (n < 1 || n > 16) ? 0 : (v < (1 << (n - 1)) ? v - (1 << n) + 1 : v); }
     int decode(const Huff& h) {
         int32_t code = 0;
         for (int l = 1; l <= 16; l++) { code = (code << 1) | getbit(); if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + (code - h.mincode[l])]; }
@@ -120,12 +121,12 @@ bool Decoder::decode_scan() {
     auto block = [&](Comp& k, int bx, int by) -> int16_t* { return &k.coef[((size_t)by * k.bw + bx) * 64]; };
     auto decode_block = [&](Comp& k, int16_t* b, int ci) {
         if (!progressive) {
-            int t = decode(dc[k.td]); int diff = t ? extend(getbits(t), t) : 0; pred[ci] += diff; b[0] = (int16_t)pred[ci];
+            int t = decode(dc[k.td]); int diff = (t > 0 && t <= 16) ? extend(getbits(t), t) : 0; pred[ci] = (int)((unsigned)pred[ci] + (unsigned)diff); b[0] = (int16_t)pred[ci];
             for (int i = 1; i < 64;) { int rs = decode(ac[k.ta]), r = rs >> 4, s = rs & 15; if (!s) { if (r != 15) break; i += 16; continue; } i += r; if (i > 63) { fail = true; break; } b[kZigZag[i]] = (int16_t)extend(getbits(s), s); i++; }
             return;
         }
         if (ss == 0) {                                               // DC scan
-            if (!ah) { int t = decode(dc[k.td]); int diff = t ? extend(getbits(t), t) : 0; pred[ci] += diff; b[0] = (int16_t)(pred[ci] * (1 << al)); }
+            if (!ah) { int t = decode(dc[k.td]); int diff = (t > 0 && t <= 16) ? extend(getbits(t), t) : 0; pred[ci] = (int)((unsigned)pred[ci] + (unsigned)diff); b[0] = (int16_t)((unsigned)pred[ci] << al); }
             else if (getbit()) b[0] = (int16_t)(b[0] | (1 << al));
             return;
         }
@@ -133,7 +134,7 @@ bool Decoder::decode_scan() {
             if (eobrun > 0) { eobrun--; return; }
             for (int i = ss; i <= se;) { int rs = decode(ac[k.ta]), r = rs >> 4, s = rs & 15;
                 if (!s) { if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += getbits(r); break; } i += 16; continue; }
-                i += r; if (i > 63) { fail = true; break; } b[kZigZag[i]] = (int16_t)(extend(getbits(s), s) * (1 << al)); i++; }
+                i += r; if (i > 63) { fail = true; break; } b[kZigZag[i]] = (int16_t)((unsigned)extend(getbits(s), s) << al); i++; }
             return;
         }
         // AC refinement
@@ -171,37 +172,38 @@ bool Decoder::decode_scan() {
 }
 
 // jidctint.c "islow": Loeffler-Ligtenberg-Moschytz, 13-bit constants, two extra bits kept through the column pass
-inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+typedef long long i64;      // the butterflies in 64 bits: identical to the 32-bit reference arithmetic on every valid stream, defined behaviour on hostile ones
+inline uint8_t clamp8(i64 v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 void idct_islow(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) {
     const int C_BITS = 13, P1 = 2;
-    const int F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
-    int ws[64], dq[64];
-    for (int k = 0; k < 64; k++) { long v = (long)in[k] * (long)q[k]; dq[k] = (int)(v < -32767 ? -32767 : (v > 32767 ? 32767 : v)); }      // (a valid 8-bit stream stays far inside; a hostile one must not overflow the fixed-point butterflies)
+    const i64 F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+    i64 ws[64], dq[64];
+    for (int k = 0; k < 64; k++) { long v = (long)in[k] * (long)q[k]; dq[k] = v < -32767 ? -32767 : (v > 32767 ? 32767 : v); }      // (a valid 8-bit stream stays far inside; a hostile one must not overflow the fixed-point butterflies)
     for (int c = 0; c < 8; c++) {
-        const int* i = dq + c; int* w = ws + c;
-        if (!i[8] && !i[16] && !i[24] && !i[32] && !i[40] && !i[48] && !i[56]) { int dcv = i[0] * (1 << P1); for (int r = 0; r < 8; r++) w[8 * r] = dcv; continue; }
-        int z2 = i[16], z3 = i[48];
-        int z1 = (z2 + z3) * F0_541, t2 = z1 + z3 * (-F1_847), t3 = z1 + z2 * F0_765;
+        const i64* i = dq + c; i64* w = ws + c;
+        if (!i[8] && !i[16] && !i[24] && !i[32] && !i[40] && !i[48] && !i[56]) { i64 dcv = i[0] * (1 << P1); for (int r = 0; r < 8; r++) w[8 * r] = dcv; continue; }
+        i64 z2 = i[16], z3 = i[48];
+        i64 z1 = (z2 + z3) * F0_541, t2 = z1 + z3 * (-F1_847), t3 = z1 + z2 * F0_765;
         z2 = i[0]; z3 = i[32];
-        int t0 = (z2 + z3) * (1 << C_BITS), t1 = (z2 - z3) * (1 << C_BITS);
-        int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+        i64 t0 = (z2 + z3) * (1 << C_BITS), t1 = (z2 - z3) * (1 << C_BITS);
+        i64 t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
         t0 = i[56]; t1 = i[40]; t2 = i[24]; t3 = i[8];
-        z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; int z4 = t1 + t3, z5 = (z3 + z4) * F1_175;
+        z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; i64 z4 = t1 + t3, z5 = (z3 + z4) * F1_175;
         t0 *= F0_298; t1 *= F2_053; t2 *= F3_072; t3 *= F1_501; z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
         z3 += z5; z4 += z5; t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
-        const int sh = C_BITS - P1, rnd = 1 << (sh - 1);
+        const int sh = C_BITS - P1; const i64 rnd = 1ll << (sh - 1);
         w[0] = (t10 + t3 + rnd) >> sh; w[56] = (t10 - t3 + rnd) >> sh; w[8] = (t11 + t2 + rnd) >> sh; w[48] = (t11 - t2 + rnd) >> sh;
         w[16] = (t12 + t1 + rnd) >> sh; w[40] = (t12 - t1 + rnd) >> sh; w[24] = (t13 + t0 + rnd) >> sh; w[32] = (t13 - t0 + rnd) >> sh;
     }
     for (int r = 0; r < 8; r++) {
-        const int* w = ws + 8 * r; uint8_t* o = out + r * stride;
-        const int sh = C_BITS + P1 + 3, rnd = 1 << (sh - 1);
-        int z2 = w[2], z3 = w[6];
-        int z1 = (z2 + z3) * F0_541, t2 = z1 + z3 * (-F1_847), t3 = z1 + z2 * F0_765;
-        int t0 = (w[0] + w[4]) * (1 << C_BITS), t1 = (w[0] - w[4]) * (1 << C_BITS);
-        int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+        const i64* w = ws + 8 * r; uint8_t* o = out + r * stride;
+        const int sh = C_BITS + P1 + 3; const i64 rnd = 1ll << (sh - 1);
+        i64 z2 = w[2], z3 = w[6];
+        i64 z1 = (z2 + z3) * F0_541, t2 = z1 + z3 * (-F1_847), t3 = z1 + z2 * F0_765;
+        i64 t0 = (w[0] + w[4]) * (1 << C_BITS), t1 = (w[0] - w[4]) * (1 << C_BITS);
+        i64 t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
         t0 = w[7]; t1 = w[5]; t2 = w[3]; t3 = w[1];
-        z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; int z4 = t1 + t3, z5 = (z3 + z4) * F1_175;
+        z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; i64 z4 = t1 + t3, z5 = (z3 + z4) * F1_175;
         t0 *= F0_298; t1 *= F2_053; t2 *= F3_072; t3 *= F1_501; z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
         z3 += z5; z4 += z5; t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
         o[0] = clamp8(((t10 + t3 + rnd) >> sh) + 128); o[7] = clamp8(((t10 - t3 + rnd) >> sh) + 128); o[1] = clamp8(((t11 + t2 + rnd) >> sh) + 128); o[6] = clamp8(((t11 - t2 + rnd) >> sh) + 128);
