@@ -89,29 +89,57 @@ bool decode_png(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::ve
         else if (type == "IEND") break;
         p += len + 4;
     }
-    if (!w || !h || depth != 8 || interlace) return false;
+    if (!w || !h || interlace > 1) return false;
     if (w > 32768u || h > 32768u) return false;            // (16 mip levels; also keeps every size below in range)
     int ch = (ctype == 0) ? 1 : (ctype == 2) ? 3 : (ctype == 3) ? 1 : (ctype == 4) ? 2 : (ctype == 6) ? 4 : 0;
     if (!ch) return false;
-    size_t stride = (size_t)w * ch; std::vector<uint8_t> raw((stride + 1) * h);
+    // bit depths per colour type (PNG specification, table 11.1): grey 1 2 4 8 16, RGB 8 16, palette 1 2 4 8, grey + alpha 8 16, RGBA 8 16. 16-bit samples are reduced to
+    // their high byte (what stb_image hands Donut for an 8-bit texture request); sub-byte grey levels are scaled to 0..255.
+    const bool depthOk = depth == 8 || (depth == 16 && ctype != 3) || ((depth == 1 || depth == 2 || depth == 4) && (ctype == 0 || ctype == 3));
+    if (!depthOk) return false;
+    const size_t bitsPerPixel = (size_t)ch * depth, filterBpp = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1;
+    // passes: the whole image, or Adam7's seven reduced images (xStart, yStart, xStep, yStep), each filtered on its own
+    static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    size_t rawSize = 0; const int nPass = interlace ? 7 : 1;
+    auto passDims = [&](int p, uint32_t& pw, uint32_t& ph) { if (!interlace) { pw = w; ph = h; return; } pw = (w > (uint32_t)adam7[p][0]) ? (w - adam7[p][0] + adam7[p][2] - 1) / adam7[p][2] : 0; ph = (h > (uint32_t)adam7[p][1]) ? (h - adam7[p][1] + adam7[p][3] - 1) / adam7[p][3] : 0; };
+    for (int p = 0; p < nPass; p++) { uint32_t pw, ph; passDims(p, pw, ph); if (pw && ph) rawSize += (((size_t)pw * bitsPerPixel + 7) / 8 + 1) * ph; }
+    std::vector<uint8_t> raw(rawSize);
     uLongf outLen = (uLongf)raw.size();
     if (uncompress(raw.data(), &outLen, idat.data(), (uLong)idat.size()) != Z_OK || outLen != raw.size()) return false;
-    std::vector<uint8_t> img(stride * h);
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t* in = &raw[(stride + 1) * y]; uint8_t ft = in[0]; in++;
-        uint8_t* out = &img[stride * y]; const uint8_t* prev = y ? &img[stride * (y - 1)] : nullptr;
-        for (size_t x = 0; x < stride; x++) {
-            int a = x >= (size_t)ch ? out[x - ch] : 0, b = prev ? prev[x] : 0, c = (prev && x >= (size_t)ch) ? prev[x - ch] : 0, v = in[x];
-            switch (ft) { case 0: break; case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
-                case 4: { int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); } break; default: return false; }
-            out[x] = (uint8_t)v;
+    std::vector<uint16_t> img((size_t)w * h * ch);          // samples as stored (indices, grey levels, 16-bit values): the colour key of tRNS compares these
+    size_t rp = 0; std::vector<uint8_t> cur, prev;
+    for (int p = 0; p < nPass; p++) {
+        uint32_t pw, ph; passDims(p, pw, ph); if (!pw || !ph) continue;
+        const size_t stride = ((size_t)pw * bitsPerPixel + 7) / 8; cur.assign(stride, 0); prev.assign(stride, 0);
+        for (uint32_t y = 0; y < ph; y++) {
+            const uint8_t* in = &raw[rp]; const uint8_t ft = in[0]; in++; rp += stride + 1;
+            for (size_t x = 0; x < stride; x++) {
+                int a = x >= filterBpp ? cur[x - filterBpp] : 0, b = prev[x], c = x >= filterBpp ? prev[x - filterBpp] : 0, v = in[x];
+                switch (ft) { case 0: break; case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
+                    case 4: { int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); } break; default: return false; }
+                cur[x] = (uint8_t)v;
+            }
+            const uint32_t oy = interlace ? (uint32_t)adam7[p][1] + y * adam7[p][3] : y;
+            for (uint32_t x = 0; x < pw; x++) {
+                const uint32_t ox = interlace ? (uint32_t)adam7[p][0] + x * adam7[p][2] : x; uint16_t* o = &img[((size_t)oy * w + ox) * ch];
+                for (int k = 0; k < ch; k++) {
+                    const size_t si = (size_t)x * ch + k;
+                    if (depth == 8) o[k] = cur[si]; else if (depth == 16) o[k] = (uint16_t)((cur[2 * si] << 8) | cur[2 * si + 1]);
+                    else { const size_t bit = si * depth; o[k] = (uint16_t)((cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1)); }
+                }
+            }
+            cur.swap(prev);
         }
     }
+    auto to8 = [&](uint16_t v) -> uint8_t { return depth == 16 ? (uint8_t)(v >> 8) : (depth == 8 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1))); };
+    auto key = [&](size_t o) -> uint16_t { return o + 1 < trns.size() ? (uint16_t)((trns[o] << 8) | trns[o + 1]) : 0; };
     rgba.resize((size_t)w * h * 4);
     for (size_t i = 0; i < (size_t)w * h; i++) {
-        uint8_t r, g, b, a = 255; const uint8_t* s = &img[i * ch];
-        if (ctype == 0) { r = g = b = s[0]; } else if (ctype == 2) { r = s[0]; g = s[1]; b = s[2]; } else if (ctype == 4) { r = g = b = s[0]; a = s[1]; }
-        else if (ctype == 6) { r = s[0]; g = s[1]; b = s[2]; a = s[3]; }
+        uint8_t r, g, b, a = 255; const uint16_t* s = &img[i * ch];
+        if (ctype == 0) { r = g = b = to8(s[0]); if (trns.size() >= 2 && s[0] == key(0)) a = 0; }
+        else if (ctype == 2) { r = to8(s[0]); g = to8(s[1]); b = to8(s[2]); if (trns.size() >= 6 && s[0] == key(0) && s[1] == key(2) && s[2] == key(4)) a = 0; }
+        else if (ctype == 4) { r = g = b = to8(s[0]); a = to8(s[1]); }
+        else if (ctype == 6) { r = to8(s[0]); g = to8(s[1]); b = to8(s[2]); a = to8(s[3]); }
         else { size_t k = s[0]; if (k * 3 + 2 >= plte.size()) return false; r = plte[k * 3]; g = plte[k * 3 + 1]; b = plte[k * 3 + 2]; if (k < trns.size()) a = trns[k]; }
         rgba[i * 4] = r; rgba[i * 4 + 1] = g; rgba[i * 4 + 2] = b; rgba[i * 4 + 3] = a;
     }
