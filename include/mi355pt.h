@@ -257,7 +257,7 @@ int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo*
      (a document replaces the glTF material as a whole; SkipRender removes the geometries, EnableAlphaTesting / ExcludeFromNEE set their flags).
    The file format of the graph itself and the light / camera keys belong to Donut (donut/engine/Scene.cpp, SceneGraph.cpp), which the reference
    tree does not vendor: they are restated from Donut's published sources. DirectionalLight leaves are returned by pt_scene_import_directional_lights. Not imported: animations,
-   glTF-embedded cameras / lights, analytic-light proxies (counted in info), textures other than 8-bit PNG (counted in texturesNotLoaded, the
+   glTF-embedded cameras / lights, analytic-light proxies (counted in info), textures other than PNG, JPEG and .dds files (counted in texturesNotLoaded, the
    material then renders untextured as when the reference fails to load one). The environment map is reported (envPath), not loaded: pt_image_read_float reads .exr / .hdr files for pt_set_environment (.dds is not read). NOTE: of
    an EnvironmentLight the reference application consumes only `path` (Sample.cpp:552-553); radianceScale / rotation / textureIndex are read by
    EnvironmentLight::Load but never used — tint, intensity and rotation of the environment come from the UI block (EnvironmentMapRuntimeParameters,
