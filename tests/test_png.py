@@ -99,3 +99,13 @@ def test_invalid_depths_and_damaged_files_are_textures_not_loaded(tmp_path):
         os.makedirs(media / "Textures", exist_ok=True); (media / "Textures" / "t.png").write_bytes(data)
         imp = pt.SceneImport(media / "test.scene.json")
         assert imp.info["texturesNotLoaded"] == 1 and imp.info["numTextures"] == 0
+
+
+def test_screenshot_writers_are_read_back_by_an_independent_reader(tmp_path):
+    """pt_write_png / pt_write_bmp (the reference's screenshot formats, CaptureScriptManager.cpp:29-60): Pillow reads back exactly what was written."""
+    rng = np.random.default_rng(17)
+    for (w, h) in ((1, 1), (7, 5), (64, 33)):
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8); img[..., 3] = 255
+        pt.write_image(str(tmp_path / "s.png"), img); pt.write_image(str(tmp_path / "s.bmp"), img)
+        assert np.array_equal(np.asarray(PIL.open(tmp_path / "s.png").convert("RGBA")), img)
+        assert np.array_equal(np.asarray(PIL.open(tmp_path / "s.bmp").convert("RGB")), img[..., :3])
