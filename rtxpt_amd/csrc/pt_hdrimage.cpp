@@ -127,7 +127,10 @@ int32_t read_rgbe(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H,
     for (;;) { if (!line(s)) return PT_ERROR_IO; if (s.empty()) break; if (s.compare(0, 7, "FORMAT=") == 0) { if (s != "FORMAT=32-bit_rle_rgbe") return PT_ERROR_UNSUPPORTED; fmt = true; } }
     (void)fmt;
     if (!line(s)) return PT_ERROR_IO;
-    long h = 0, w = 0; if (sscanf(s.c_str(), "-Y %ld +X %ld", &h, &w) != 2) return PT_ERROR_UNSUPPORTED;      // other orientations are legal but not written by the tools in use
+    // resolution string: "-Y h +X w" is the standard orientation (top row first, left to right); the flipped variants are read too, the transposed ones ("+X w -Y h" ...) are not
+    long h = 0, w = 0; char sy = 0, sx = 0;
+    if (sscanf(s.c_str(), "%cY %ld %cX %ld", &sy, &h, &sx, &w) != 4 || (sy != '-' && sy != '+') || (sx != '-' && sx != '+')) return PT_ERROR_UNSUPPORTED;
+    const bool flipY = sy == '+', flipX = sx == '-';
     if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || (long long)w * h > (1ll << 28)) return PT_ERROR_IO;
     if ((size_t)h > d.size()) return PT_ERROR_IO;                                    // every scan line takes at least a byte
     W = (uint32_t)w; H = (uint32_t)h; rgb.assign((size_t)w * h * 3, 0.f);
@@ -141,8 +144,8 @@ int32_t read_rgbe(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H,
                     if (cnt > 128) { cnt -= 128; if (cnt == 0 || x + cnt > (unsigned long)w || i >= d.size()) return PT_ERROR_IO; unsigned char v = d[i++]; for (unsigned k = 0; k < cnt; k++) sl[(size_t)(x++) * 4 + (size_t)c] = v; }
                     else { if (cnt == 0 || x + cnt > (unsigned long)w || i + cnt > d.size()) return PT_ERROR_IO; for (unsigned k = 0; k < cnt; k++) sl[(size_t)(x++) * 4 + (size_t)c] = d[i++]; } } }
         } else { if (i + (size_t)w * 4 > d.size()) return PT_ERROR_IO; memcpy(sl.data(), d.data() + i, (size_t)w * 4); i += (size_t)w * 4; }
-        float* o = &rgb[(size_t)y * (size_t)w * 3];
-        for (long x = 0; x < w; x++) { const unsigned char* p = &sl[(size_t)x * 4];
+        float* o = &rgb[(size_t)(flipY ? h - 1 - y : y) * (size_t)w * 3];
+        for (long x = 0; x < w; x++) { const unsigned char* p = &sl[(size_t)(flipX ? w - 1 - x : x) * 4];
             if (p[3] == 0) { o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = 0.f; }
             else { const float f = ldexpf(1.0f, (int)p[3] - (128 + 8)); o[3 * x] = (float)p[0] * f; o[3 * x + 1] = (float)p[1] * f; o[3 * x + 2] = (float)p[2] * f; } }      // (stb_image / Radiance: mantissa x 2^(e - 136), no +0.5)
     }

@@ -162,3 +162,14 @@ def test_damaged_files_fail_cleanly(tmp_path):
         except pt.PtError as e:
             assert e.code in (4, 5)
     assert ok > 0                                            # (some mutations only touch pixel data)
+
+
+def test_radiance_flipped_orientations(tmp_path):
+    """The resolution string's sign letters: "+Y" stores the bottom row first, "-X" right to left; the transposed forms are refused."""
+    rng = np.random.default_rng(31); rgbe = rng.integers(1, 256, (5, 9, 4), dtype=np.uint8)
+    write_hdr(tmp_path / "std.hdr", rgbe, False); std = pt.read_float_image(tmp_path / "std.hdr")
+    raw = open(tmp_path / "std.hdr", "rb").read()
+    for res, want in ((b"+Y 5 +X 9", std[::-1]), (b"-Y 5 -X 9", std[:, ::-1]), (b"+Y 5 -X 9", std[::-1, ::-1])):
+        (tmp_path / "o.hdr").write_bytes(raw.replace(b"-Y 5 +X 9", res)); assert np.array_equal(pt.read_float_image(tmp_path / "o.hdr"), want)
+    (tmp_path / "t.hdr").write_bytes(raw.replace(b"-Y 5 +X 9", b"+X 9 -Y 5"))
+    with pytest.raises(pt.PtError): pt.read_float_image(tmp_path / "t.hdr")
