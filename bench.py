@@ -179,20 +179,21 @@ def main():
         bound = "hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else "latency"
 
     if rank == 0:
-        info = g.scene_info()
+        info = g.scene_info(); bvh = g.bvh_info()
         out = {
             "metric": "Mrays/s at 4K 4spp 8-bounce bistro-like (extend + shadow rays / wall time of pt_render)",
             "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3 bistro-like street canyon, %d triangles, 64 materials, 32 textures %d^2, %d emissive-triangle + env-quad lights, %dx%d, %d spp, 8 bounces, NEE 5 candidates + RR, lp types %s, environment cube %s"
+            "config": {"workload": "C3 bistro-like street canyon, %d triangles, 64 materials, 32 textures %d^2, %d emissive-triangle + env-quad lights, %dx%d, %d spp, 8 bounces, NEE 5 candidates + RR, lp types %s, environment cube %s; BVH builder=%s, built on %s, buildMs %.1f (host part %.1f), %d wide nodes"
                                    % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP, "fp32" if args.fp32_lp_types else "binary16 (reference default)",
-                                      "RGBA16F" if args.no_env_compression else "2048 BC6H (reference default on D3D12)"),
+                                      "RGBA16F" if args.no_env_compression else "2048 BC6H (reference default on D3D12)", bvh["builderName"], bvh["builtOn"], bvh["buildMs"], bvh["hostMs"], bvh["numWideNodes"]),
+                       "bvh": bvh,
                        "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
             # `frac` is the prescribed figure: algorithmic bytes / launch time / 8 TB/s. `bound` is what the counters say limits the kernel:
             # the BVH is served from L1/L2, HBM itself carries `hbm_counter_gbs`, and the VALU issue slots are what is full.
             "roofline": {"bound": bound, "prescribed_bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "hbm_counter_gbs": hbm_counter_gbs, "l2_hit_rate": l2, "valu": valu, "counters_source": counters_src,
+                         "traffic": traffic, "traffic_source": "quoted from the committed rocprofv3 --pmc summary (counters_source), not measured in this run", "hbm_counter_gbs": hbm_counter_gbs, "l2_hit_rate": l2, "valu": valu, "counters_source": counters_src,
                          "bound_evidence": "profiles/r02k_isa_experiments.txt: -18 % VALU instructions = 0 % time, 6 -> 5 waves per SIMD = +7 % time, HBM at 15 % of peak",
                          "whole_frame": {"algorithmic_bytes_per_step": frame_bytes, "achieved": frame_gbs, "frac": frame_gbs / HBM_PEAK_GBS,
                                          "terms": "extend rays x (52 + 128 nodes + 48 tris) + hits x 656 + shadow rays x (80 + 128 nodes + 48 tris), over the pipelined step time"},

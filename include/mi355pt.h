@@ -179,7 +179,9 @@ int32_t pt_set_geometry(pt_context* ctx, const PtGeometryBuffers* buffers, const
                         const PtMeshDesc* meshes, uint32_t numMeshes);
 int32_t pt_set_instances(pt_context* ctx, const PtInstanceDesc* instances, uint32_t numInstances);
 int32_t pt_set_materials(pt_context* ctx, const PTMaterialData* materials, uint32_t numMaterials, const PtTextureDesc* textures, uint32_t numTextures);
-/* EnvMapBaker source + EnvMapSceneParams (Rtxpt/Sample.cpp:1364-1388,1939): lat-long float RGB image, row 0 at +Y. width==0 disables. */
+/* EnvMapBaker source + EnvMapSceneParams (Rtxpt/Sample.cpp:1364-1388,1939): lat-long float RGB image, row 0 at +Y. width==0 disables.
+ * params->ColorMultiplier is the reference's own: tint * intensity / c_envMapRadianceScale (Sample.cpp:1939-1940; the baked cube holds radiance x 1/4, so a
+ * multiplier of 4 renders the image's radiance as supplied). params == NULL means identity orientation and exactly that: ColorMultiplier = 1 / c_envMapRadianceScale. */
 int32_t pt_set_environment(pt_context* ctx, const float* rgbLatLong, uint32_t width, uint32_t height, const PtEnvMapSceneParams* params);
 /* EnvMapBaker::Update (Rtxpt/Lighting/Distant/EnvMapBaker.cpp:298-343, 425-620; EnvMapBaker.hlsl:194-246, 268-371): the path tracer and the light baker do
  * not sample the lat-long source but the RGBA16F cube the baker makes of it: cubeDim^2 x 6 texels (2048 for an image source, 0 = keep), solid-angle weighted
@@ -424,6 +426,11 @@ int32_t pt_get_scene_info(pt_context* ctx, uint32_t* numTriangles, uint32_t* num
 int32_t pt_probe(pt_context* ctx, int32_t kind, const void* in, size_t inBytes, void* out, size_t outBytes, uint32_t n);
 /* BVH build/refit timing of the last geometry update, milliseconds */
 int32_t pt_get_build_stats(pt_context* ctx, double* buildMs, double* refitMs, double* lightBakeMs);
+/* which builder made the tree the kernels traverse, and where it ran. builder: 0 = PLOC (device, "prefer fast build"), 1 = Karras radix tree (device, developer A/B),
+ * 2 = binned SAH + insertion-based optimisation on the host's cores ("prefer fast trace", topology only; bounds / collapse / refit on the device),
+ * 3 = PLOC + parallel re-insertion + cost-driven wide nodes, all on the device ("prefer fast trace"). hostMs: the host part of the last build (0 for device builders). */
+typedef struct PtBvhInfo { uint32_t builder; uint32_t builtOnDevice; uint32_t numTriangles; uint32_t numWideNodes; uint32_t collapseLevels; uint32_t optimiserPasses; float hostMs; float buildMs; } PtBvhInfo;
+int32_t pt_get_bvh_info(pt_context* ctx, PtBvhInfo* out);
 /* enable in-kernel BVH node/triangle counters (slower); default off */
 int32_t pt_set_counters(pt_context* ctx, int32_t enable);
 /* runtime form of PT_DEVICE_SERIAL_KERNELS: 1 = pt_render uses one batch on one stream (kernels never overlap: clean per-kernel HIP-event /

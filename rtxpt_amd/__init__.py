@@ -29,7 +29,7 @@ EXPORTS = [
     "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_env_bake_lights", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
-    "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_set_counters",
+    "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
     "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
@@ -693,6 +693,18 @@ class PathTracer:
         a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         self._chk(self.L.pt_get_build_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "pt_get_build_stats")
         return dict(buildMs=a.value, refitMs=b.value, lightBakeMs=c.value)
+
+    def bvh_info(self):
+        """pt_get_bvh_info: which builder made the tree and where it ran."""
+        class PtBvhInfo(ctypes.Structure):
+            _fields_ = [("builder", ctypes.c_uint32), ("builtOnDevice", ctypes.c_uint32), ("numTriangles", ctypes.c_uint32), ("numWideNodes", ctypes.c_uint32),
+                        ("collapseLevels", ctypes.c_uint32), ("optimiserPasses", ctypes.c_uint32), ("hostMs", ctypes.c_float), ("buildMs", ctypes.c_float)]
+        o = PtBvhInfo()
+        self._chk(self.L.pt_get_bvh_info(self.h, ctypes.byref(o)), "pt_get_bvh_info")
+        names = {0: "PLOC", 1: "Karras radix tree", 2: "binned SAH + re-insertion (host)", 3: "PLOC + parallel re-insertion + cost-driven wide nodes"}
+        d = {k: getattr(o, k) for k, _ in PtBvhInfo._fields_}
+        d["builderName"] = names.get(o.builder, "?"); d["builtOn"] = "device" if o.builtOnDevice else "host"
+        return d
 
     def probe(self, kind, inp, out_shape, out_dtype=np.float32):
         inp = np.ascontiguousarray(inp)

@@ -147,6 +147,7 @@ void shard_pixel_lists(uint width, uint height, uint world, std::vector<std::vec
 void build_shards(pt_context* c) {
     shard_pixel_lists(c->width, c->height, c->shardCount, c->shardPixels);
     c->owned = c->shardPixels[c->shardRank];
+    c->gatherW = c->gatherH = 0;                // pt_gather's per-rank counts and pixel lists follow the shard lists, not only the frame size
 }
 
 // ---- RCCL, bound at run time. One process may already hold a librccl.so (PyTorch ships its own): RTLD_NOLOAD finds that copy first, so that a single
@@ -390,7 +391,7 @@ int bake_lights(pt_context* c, bool geometryOnly = false) {
             PT_CHECK_HIP(c, hipMemcpyAsync(c->dLightsEx.p + QT_TOTAL, c->lightsEx.data() + QT_TOTAL, sizeof(ptk::PolymorphicLightInfoEx) * (lightBase - QT_TOTAL), hipMemcpyHostToDevice, c->stream));
         }
         if (total) {
-            if (!geometryOnly || c->dEmissiveList.n < list.size()) { PT_CHECK_HIP(c, c->dEmissiveList.upload(list, c->stream)); PT_CHECK_HIP(c, c->dEmissiveOffsets.upload(offsets, c->stream)); }
+            PT_CHECK_HIP(c, c->dEmissiveList.upload(list, c->stream)); PT_CHECK_HIP(c, c->dEmissiveOffsets.upload(offsets, c->stream));      // (a few KB; always: the list is not keyed on a capacity)
             launch_bake_emissive(c->dsc, c->dEmissiveList.p, c->dEmissiveOffsets.p, (uint)list.size(), total, lightBase, c->dLights.p, c->dLightsEx.p, c->stream);
         }
         // ComputeWeights + ComputeProxyCounts + proxy fill (LightsBaker.hlsl:738-751, 836-948) on the device; NEEType 0 = uniform (1 proxy per light)
@@ -487,7 +488,7 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
       if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; }
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
-    const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.f);
+    const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale);      // no params = tint 1, intensity 1: the cube holds radiance x 1/4
     if (c->dCounters.resize(PT_PIPELINE_BATCHES) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     *out = c;
     return PT_OK;
@@ -586,6 +587,9 @@ int32_t pt_set_environment(pt_context* c, const float* rgb, uint32_t w, uint32_t
         memset(&c->envToLocal, 0, sizeof(float3x4));
         for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) c->envToLocal.m[r * 4 + k] = c->envToWorld.m[k * 4 + r];   // rotation inverse = transpose
         c->envColorMul = ptk::make_float3(params->ColorMultiplier[0], params->ColorMultiplier[1], params->ColorMultiplier[2]);
+    } else {                                               // no params: identity orientation, the supplied radiance as it is (ColorMultiplier = 1 / c_envMapRadianceScale undoes the cube's 1/4)
+        const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48);
+        c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale);
     }
     c->texDirty = true; c->lightsDirty = true;
     return PT_OK;
@@ -744,7 +748,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
         uint cur = 0, active = 0, iterations = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false;
-        std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
+        std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; uint items; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         size_t mark() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
     const uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
@@ -785,8 +789,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             uint nxt = t.cur ^ 1u;
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->extendCount[nxt], 0, 4, t.st));
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st));
-            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0});
-            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, reinterpret_cast<uint*>(t.aux.bestKey) /* the straggler keys and counts are idle between k_resolve_extend and the shadow launch */, t.aux.counts, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1});
+            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0, t.active});
+            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, reinterpret_cast<uint*>(t.aux.bestKey) /* the straggler keys and counts are idle between k_resolve_extend and the shadow launch */, t.aux.counts, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1, t.active});
             t.extendRays += t.active;
             PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
             t.waiting = true;
@@ -798,7 +802,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (!t.waiting) continue;
             PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
             uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
-            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.aux, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2}); if (!shadowGroup) t.shadowRays += nShadow; }
+            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.aux, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
             t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
             if (t.active && t.iterations < maxIter) any = true;
         }
@@ -833,6 +837,12 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (t.iterations > stats->iterations) stats->iterations = t.iterations;
         }
         stats->pathsTraced = total;
+    }
+    if (getenv("MI355PT_PASS_LOG")) {        // developer probe: the launch sequence of every batch with item counts and HIP-event durations (stderr)
+        for (uint b = 0; b < numBatches; b++) { Batch& t = B[b]; float whole = 0; (void)hipEventElapsedTime(&whole, t.ev[t.t0], t.ev[t.t1]);
+            fprintf(stderr, "[pass log] batch %u of %u: %u paths, %u passes, %.3f ms from first to last event\n", b, numBatches, t.total, t.iterations, whole);
+            for (auto& sp : t.spans) { float m = 0, at = 0; (void)hipEventElapsedTime(&m, t.ev[sp.a], t.ev[sp.b]); (void)hipEventElapsedTime(&at, t.ev[t.t0], t.ev[sp.a]);
+                fprintf(stderr, "[pass log]   b%u %-6s %9u items  start %8.3f ms  %7.3f ms\n", b, sp.kind == 0 ? "extend" : (sp.kind == 1 ? "shade" : "shadow"), sp.items, at, m); } }
     }
     for (uint b = 0; b < numBatches; b++) for (auto e : B[b].ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(frame0); (void)hipEventDestroy(frame1);
@@ -1036,10 +1046,27 @@ int32_t pt_comm_destroy(pt_context* c) {
 int32_t pt_gather(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
-    if (c->shardCount == 1) return PT_OK;                                       // nothing to gather
+    if (c->shardCount == 1 && !c->comm) return PT_OK;                           // nothing to gather
     if (!c->comm) return fail(c, PT_ERROR_NOT_READY, "pt_comm_init first");
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
+    if (c->shardCount == 1) {
+        // a world of one WITH a communicator: the whole protocol as a loop-back — pack, ncclSend to self + ncclRecv from self inside one group, unpack — so that
+        // the run-time-bound RCCL path can be exercised (and checked) on a one-GPU box. The frame is poisoned between pack and unpack: what pt_map_radiance
+        // returns afterwards has been through RCCL.
+        const size_t n = c->owned.size();
+        if (!n) return PT_OK;
+        PT_CHECK_HIP(c, c->dGatherSend.resize(n)); PT_CHECK_HIP(c, c->dGatherRecv.resize(n));
+        launch_pack(c->dAccum.p, c->dOwned.p, (uint)n, c->width, c->dGatherSend.p, st);
+        PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0xFF, sizeof(ptk::float4) * (size_t)c->width * c->height, st));
+        PT_CHECK_NCCL(c, g_rccl.GroupStart());
+        ncclResult_t rs = g_rccl.Send(c->dGatherSend.p, 4 * n, ncclFloat, 0, c->comm, st);
+        ncclResult_t rr = (rs == ncclSuccess) ? g_rccl.Recv(c->dGatherRecv.p, 4 * n, ncclFloat, 0, c->comm, st) : rs;
+        ncclResult_t re = g_rccl.GroupEnd();
+        if (rr != ncclSuccess || re != ncclSuccess) return fail(c, PT_ERROR_HIP, std::string("pt_gather loop-back: ") + g_rccl.GetErrorString(rr != ncclSuccess ? rr : re));
+        launch_unpack(c->dAccum.p, c->dOwned.p, (uint)n, c->width, c->dGatherRecv.p, st);
+        return PT_OK;
+    }
     if (c->gatherW != c->width || c->gatherH != c->height) {                    // per-size state: counts of every rank; on rank 0 the other ranks' pixel lists on the device
         c->gatherCounts.assign(c->shardCount, 0);
         std::vector<uint> others;
@@ -1091,6 +1118,15 @@ int32_t pt_gather_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t 
 }
 
 int32_t pt_get_build_stats(pt_context* c, double* b, double* r, double* l) { if (!c) return PT_ERROR_INVALID_ARGUMENT; if (b) *b = c->buildMs; if (r) *r = c->refitMs; if (l) *l = c->lightBakeMs; return PT_OK; }
+int32_t pt_get_bvh_info(pt_context* c, PtBvhInfo* out) {
+    if (!c || !out) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    memset(out, 0, sizeof(*out));
+    out->builder = c->bvh.builder; out->builtOnDevice = (c->bvh.builder == BVH_BUILDER_SAH && c->bvh.hostBuildMs > 0.f) ? 0u : 1u; out->numTriangles = c->numTris;
+    out->numWideNodes = c->numTris ? c->bvh.numNodes8 : 0u; out->collapseLevels = c->bvh.collapseLevels; out->optimiserPasses = c->bvh.optimiserPasses; out->hostMs = c->bvh.hostBuildMs; out->buildMs = (float)c->buildMs;
+    return PT_OK;
+}
 int32_t pt_set_counters(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->countersEnabled = enable != 0; return PT_OK; }
 int32_t pt_set_serial_kernels(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->serialKernels = enable != 0; return PT_OK; }
 

@@ -47,6 +47,7 @@ struct BvhBuildBuffers {
     uint builder;               // BVH_BUILDER_PLOC ("prefer fast build"), BVH_BUILDER_SAH ("prefer fast trace") or BVH_BUILDER_KARRAS (developer A/B)
     uint* absorb;               // BVH_BUILDER_SAH: per inner node, 1 = the cost-driven BVH8 collapse opens it inside its parent's wide node (pt_build_sah.cpp)
     float hostBuildMs;          // BVH_BUILDER_SAH: the host part of the last build (read-back + SAH topology + upload)
+    uint optimiserPasses;       // re-insertion passes the last build ran (host: pt_build_sah.cpp; device: BVH_BUILDER_PLOC_OPT)
     uint capacity;
 };
 

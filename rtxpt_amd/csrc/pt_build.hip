@@ -535,7 +535,7 @@ static hipError_t bvh_sah(BvhBuildBuffers& b, uint n, hipStream_t st) try {
         for (int k = 0; k < 3; k++) { o.mn[k] = fminf(a[k], fminf(p[k], q[k])); o.mx[k] = fmaxf(a[k], fmaxf(p[k], q[k])); o.c[k] = a[k] + (e1[k] + e2[k]) * (1.0f / 3.0f); }
     }
     std::vector<uint> order(n), cl(n), cr(n), rf(n), rl(n), par(n), lp(n), ab(n);
-    bvh_sah_topology(st3.data(), n, SahTopology{order.data(), cl.data(), cr.data(), rf.data(), rl.data(), par.data(), lp.data(), ab.data()}, BVH_MAX_LEAF, 0u);
+    b.optimiserPasses = bvh_sah_topology(st3.data(), n, SahTopology{order.data(), cl.data(), cr.data(), rf.data(), rl.data(), par.data(), lp.data(), ab.data()}, BVH_MAX_LEAF, 0u);
     PT_HIP_TRY(hipMemcpyAsync(b.absorb, ab.data(), 4 * (size_t)(n - 1u), hipMemcpyHostToDevice, st));
     const size_t inner = 4 * (size_t)(n - 1u);
     PT_HIP_TRY(hipMemcpyAsync(b.primsSorted, order.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st)); PT_HIP_TRY(hipMemcpyAsync(b.leafParent, lp.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -551,7 +551,7 @@ hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStrea
     uint g = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, st, b.sceneBounds);
     hipLaunchKernelGGL(k_tri_setup, dim3(g), dim3(256), 0, st, sc, n, b.triWorld, b.sceneBounds);
-    b.hostBuildMs = 0.f;
+    b.hostBuildMs = 0.f; b.optimiserPasses = 0u;
     if (b.builder == BVH_BUILDER_SAH && n > 1) {
         if (bvh_sah(b, n, st) == hipSuccess) return bvh_bounds_and_emit(b, sc, n, st);
         (void)hipGetLastError(); b.builder = BVH_BUILDER_PLOC;      // no host memory / threads for the fast-trace topology: build it on the device instead

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -39,19 +40,22 @@ struct Bins { B3 box[3][kBins]; uint cnt[3][kBins]; void reset() { for (int a = 
 struct Pool {
     unsigned T; std::vector<std::thread> th; const std::function<void(unsigned)>* job = nullptr;
     std::atomic<unsigned long long> gen{0}; std::atomic<unsigned> pending{0}; std::atomic<bool> quit{false};
+    std::mutex errLock; std::exception_ptr err;                 // first exception thrown by a job on any thread (allocation failures happen inside the workers): run() rethrows it on the caller's thread
+    void guarded(unsigned t) { try { (*job)(t); } catch (...) { std::lock_guard<std::mutex> g(errLock); if (!err) err = std::current_exception(); } }
     explicit Pool(unsigned n) : T(n) {
         try { for (unsigned t = 1; t < T; t++) th.emplace_back([this, t] { unsigned long long seen = 0;
             for (;;) { unsigned spins = 0;
                        while (gen.load(std::memory_order_acquire) == seen) { if (quit.load(std::memory_order_relaxed)) return; if (++spins > 2000u) std::this_thread::yield(); }
-                       seen++; (*job)(t); pending.fetch_sub(1, std::memory_order_acq_rel); } }); }
+                       seen++; guarded(t); pending.fetch_sub(1, std::memory_order_acq_rel); } }); }
         catch (...) { quit.store(true); for (auto& x : th) x.join(); throw; }      // a thread could not be created: release the ones that were (the caller falls back)
     }
     ~Pool() { quit.store(true); for (auto& x : th) x.join(); }
     void run(const std::function<void(unsigned)>& f) {
         if (T == 1) { f(0); return; }
         job = &f; pending.store(T - 1, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release);
-        f(0);
+        guarded(0);
         unsigned spins = 0; while (pending.load(std::memory_order_acquire) != 0u) if (++spins > 2000u) std::this_thread::yield();
+        if (err) { std::exception_ptr e = err; err = nullptr; std::rethrow_exception(e); }      // every worker has finished the job: the caller (bvh_sah) falls back to the device builder
     }
 };
 
@@ -374,8 +378,8 @@ struct Builder {
 
 } // namespace
 
-void bvh_sah_topology(const SahTri* tris, uint n, const SahTopology& out, uint maxLeaf, unsigned threads) {
-    if (n == 0u) return;
+uint bvh_sah_topology(const SahTri* tris, uint n, const SahTopology& out, uint maxLeaf, unsigned threads) {
+    if (n == 0u) return 0u;
     Builder b; b.tri = tris; b.n = n; b.out = out; b.maxLeaf = maxLeaf ? maxLeaf : 1u;
     unsigned hw = std::thread::hardware_concurrency(); if (!hw) hw = 8;
     b.threads = threads ? threads : std::min(hw, 32u);               // the build is bound by gathers from the triangle array; beyond a few dozen threads the sync costs more than it buys (and 8 ranks of a node build at once)
@@ -383,6 +387,7 @@ void bvh_sah_topology(const SahTri* tris, uint n, const SahTopology& out, uint m
     if (const char* e = getenv("MI355PT_SAH_OPTIMISE")) b.optimisePasses = (uint)atoi(e);      // developer A/B: 0 = the plain binned-SAH tree
     Pool pool(b.threads); b.pool = &pool;
     b.run();
+    return n >= 8u ? b.optimisePasses : 0u;
 }
 
 } // namespace ptk

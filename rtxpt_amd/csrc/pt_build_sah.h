@@ -9,5 +9,6 @@ struct SahTri { float mn[3], mx[3], c[3]; };                        // box and c
 struct SahTopology { uint* order; uint* childL; uint* childR; uint* rangeFirst; uint* rangeLast; uint* parent; uint* leafParent; uint* absorb; };
 // maxLeaf: sub-trees of at most this many triangles become one leaf (k_emit's rule). With out.absorb the wide-node assignment is chosen too: the dynamic
 // programme of Ylitie, Karras & Laine 2017 (every wide-node visit and every leaf visit costs its surface area) instead of "open the largest child".
-void bvh_sah_topology(const SahTri* tris, uint n, const SahTopology& out, uint maxLeaf, unsigned threads /* 0 = the hardware's threads, at most 32 */);
+// Returns the number of re-insertion passes that ran.
+uint bvh_sah_topology(const SahTri* tris, uint n, const SahTopology& out, uint maxLeaf, unsigned threads /* 0 = the hardware's threads, at most 32 */);
 }

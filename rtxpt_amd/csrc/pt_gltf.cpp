@@ -1,7 +1,7 @@
 // mi355pt — glTF 2.0 scene import behind pt_load_scene_gltf (Sample::LoadScene + SceneLoaded, Rtxpt/Sample.cpp:447-560;
 // material import mirrors MaterialsBaker::ImportFromDonut + PTMaterial::FillData, Rtxpt/Materials/MaterialsBaker.cpp:516-591, 660-705).
 // The reference delegates glTF parsing to Donut/cgltf (absent); this is a self-contained reader: JSON, external/base64
-// buffers, accessors (float / normalised integer), node hierarchy (matrix or TRS), PNG textures (8-bit, non-interlaced) via zlib.
+// buffers, accessors (float / normalised integer), node hierarchy (matrix or TRS), PNG (all colour types, bit depths, Adam7) via zlib, JPEG and .dds textures.
 // Output goes through the same raw-buffer entry points the bakers use (pt_set_materials / pt_set_geometry / pt_set_instances).
 #include "../../include/mi355pt.h"
 #include <zlib.h>
@@ -16,6 +16,8 @@
 #include <vector>
 
 namespace {
+
+struct PxGuard { void* p; ~PxGuard() { if (p) pt_image_free((float*)p); } };      // frees a decoder's buffer even when the copy out of it throws
 
 // ---------------------------------------------------------------- minimal JSON
 struct JValue {
@@ -73,7 +75,7 @@ bool load_uri(const std::string& baseDir, const std::string& uri, std::vector<ui
     return read_file(baseDir + uri, out);
 }
 
-// ---------------------------------------------------------------- PNG (8-bit, non-interlaced; gray / gray+alpha / RGB / RGBA / palette)
+// ---------------------------------------------------------------- PNG (every colour type and bit depth of the specification, Adam7 interlacing; output RGBA8)
 bool decode_png(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba) {
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (d.size() < 8 || memcmp(d.data(), sig, 8)) return false;
@@ -103,6 +105,7 @@ bool decode_png(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::ve
     size_t rawSize = 0; const int nPass = interlace ? 7 : 1;
     auto passDims = [&](int p, uint32_t& pw, uint32_t& ph) { if (!interlace) { pw = w; ph = h; return; } pw = (w > (uint32_t)adam7[p][0]) ? (w - adam7[p][0] + adam7[p][2] - 1) / adam7[p][2] : 0; ph = (h > (uint32_t)adam7[p][1]) ? (h - adam7[p][1] + adam7[p][3] - 1) / adam7[p][3] : 0; };
     for (int p = 0; p < nPass; p++) { uint32_t pw, ph; passDims(p, pw, ph); if (pw && ph) rawSize += (((size_t)pw * bitsPerPixel + 7) / 8 + 1) * ph; }
+    if (rawSize / 1032u > idat.size() + 64u) return false;      // deflate expands at most 1032 : 1: a header that promises more than the stream can hold is damaged (no 16 GB allocation for a 100-byte file)
     std::vector<uint8_t> raw(rawSize);
     uLongf outLen = (uLongf)raw.size();
     if (uncompress(raw.data(), &outLen, idat.data(), (uLong)idat.size()) != Z_OK || outLen != raw.size()) return false;
@@ -267,19 +270,21 @@ struct Loader {
         if (im.get("uri")) { if (!load_uri(baseDir, im.strOr("uri", ""), file)) return 0xFFFFFFFFu; }
         else {
             int bv = im.intOr("bufferView", -1); const JValue* bvs = root.get("bufferViews"); if (!bvs || bv < 0 || (size_t)bv >= bvs->size()) return 0xFFFFFFFFu;
-            const JValue& v = bvs->arr[bv]; int buf = v.intOr("buffer", 0); size_t off = (size_t)v.numOr("byteOffset", 0), len = (size_t)v.numOr("byteLength", 0);
-            if ((size_t)buf >= buffers.size() || off + len > buffers[buf].size()) return 0xFFFFFFFFu;
+            const JValue& v = bvs->arr[bv]; int buf = v.intOr("buffer", 0); const double dOff = v.numOr("byteOffset", 0), dLen = v.numOr("byteLength", 0);
+            if (buf < 0 || (size_t)buf >= buffers.size() || !(dOff >= 0) || !(dLen >= 0) || dOff > 4e12 || dLen > 4e12) return 0xFFFFFFFFu;      // (NaN, negative and huge values never reach the casts)
+            const size_t off = (size_t)dOff, len = (size_t)dLen, have = buffers[buf].size();
+            if (off > have || len > have - off) return 0xFFFFFFFFu;                                                                    // no sum that could wrap
             file.assign(buffers[buf].begin() + off, buffers[buf].begin() + off + len);
         }
         uint32_t w, h; std::vector<uint8_t> rgba;
         if (file.size() > 4 && !memcmp(file.data(), "DDS ", 4)) {          // image/vnd-ms.dds (pt_dds.cpp); the sRGB-ness is the texture slot's, as for the other formats
             uint32_t fmt = 0; void* px = nullptr; if (pt_image_read_dds_memory(file.data(), file.size(), &w, &h, &fmt, &px) != PT_OK) return 0xFFFFFFFFu;
             if (fmt == PT_TEX_RGBA32F) { pt_image_free((float*)px); return 0xFFFFFFFFu; }
-            rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px);
+            { PxGuard guard{px}; rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); }
         }
         else if (file.size() > 2 && file[0] == 0xFF && file[1] == 0xD8) {      // image/jpeg (pt_jpeg.cpp)
             void* px = nullptr; if (pt_image_read_jpeg(file.data(), file.size(), &w, &h, &px) != PT_OK) return 0xFFFFFFFFu;
-            rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px);
+            { PxGuard guard{px}; rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); }
         }
         else if (!decode_png(file, w, h, rgba)) return 0xFFFFFFFFu;      // other image formats are treated as "texture not loaded"
         uint32_t index = (uint32_t)texDescs.size();
@@ -628,12 +633,12 @@ struct SceneReader {
             uint32_t fmt = 0; void* px = nullptr;
             if (pt_image_read_dds(dds.c_str(), &w, &h, &fmt, &px) != PT_OK) return 0xFFFFFFFFu;
             if (fmt == PT_TEX_RGBA32F) { pt_image_free((float*)px); return 0xFFFFFFFFu; }              // (float textures are environment sources, not material inputs)
-            rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px);
+            { PxGuard guard{px}; rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); }
         }
         else {
             if (!read_file(file, bytes)) return 0xFFFFFFFFu;
             if (bytes.size() > 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) { void* px = nullptr; if (pt_image_read_jpeg(bytes.data(), bytes.size(), &w, &h, &px) != PT_OK) return 0xFFFFFFFFu;
-                                                                              rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); pt_image_free((float*)px); }
+                                                                              { PxGuard guard{px}; rgba.assign((const uint8_t*)px, (const uint8_t*)px + (size_t)w * h * 4u); } }
             else if (!decode_png(bytes, w, h, rgba)) return 0xFFFFFFFFu;
         }
         uint32_t index = (uint32_t)S.texDescs.size(); S.texPixels.push_back(std::move(rgba));

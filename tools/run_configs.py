@@ -19,7 +19,7 @@ def gpu_run(sc, cam, S, w, h, spp, frames=5, warmup=2, animate=None):
             ms.append(st["gpuMilliseconds"] + (refit[-1] if animate is not None else 0.0)); rays = st["extendRays"] + st["shadowRays"]
     m = float(np.median(ms))
     out = {"ms_per_frame": m, "rays_per_frame": int(rays), "mrays_per_s": rays / m / 1e3, "extend_rays": int(st["extendRays"]), "shadow_rays": int(st["shadowRays"]),
-           "build_ms": g.build_stats()["buildMs"]}
+           "build_ms": g.build_stats()["buildMs"], "bvh": g.bvh_info()}
     if animate is not None:
         out["refit_ms"] = float(np.median(refit[warmup:]))
     return out
@@ -32,11 +32,11 @@ def main():
     res["C1"] = {"gpu": gpu_run(sc, cam, scenes.config_settings("C1"), 256, 256, 1)}
     sc, cam = scenes.cornell_box("C2")
     res["C2"] = {"gpu": gpu_run(sc, cam, scenes.config_settings("C2"), 1920, 1080, 4)}
-    sc, cam = scenes.bistro_like()
-    res["C3"] = {"gpu": gpu_run(sc, cam, scenes.default_settings(), 3840, 2160, 4)}
-    res["C4"] = {"gpu": gpu_run(sc, cam, scenes.default_settings(), 3840, 2160, 16, frames=2, warmup=1)}
-    sc, cam = scenes.bistro_like(animated=True)
-    res["C5"] = {"gpu": gpu_run(sc, cam, scenes.default_settings(), 3840, 2160, 4, animate=True)}
+    sc, cam = scenes.bistro_like(); sc["env_cube_dim"] = 2048; sc["env_compression"] = 1      # as bench.py
+    res["C3"] = {"gpu": gpu_run(sc, cam, scenes.default_settings(useFp16Types=1), 3840, 2160, 4)}
+    res["C4"] = {"gpu": gpu_run(sc, cam, scenes.default_settings(useFp16Types=1), 3840, 2160, 16, frames=2, warmup=1)}
+    sc, cam = scenes.bistro_like(animated=True); sc["env_cube_dim"] = 2048; sc["env_compression"] = 1
+    res["C5"] = {"gpu": gpu_run(sc, cam, scenes.default_settings(useFp16Types=1, nestedDielectricsQuality=2), 3840, 2160, 4, animate=True)}
     print(json.dumps(res, indent=1))
 
 

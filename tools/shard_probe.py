@@ -4,18 +4,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import rtxpt_amd as pt
 from rtxpt_amd import scenes
-W, H, SPP = 3840, 2160, 4
+W, H, SPP = 3840, 2160, int(os.environ.get("SHARD_PROBE_SPP", "4"))
 sc, cam = scenes.bistro_like(scale=1.0, tex_size=1024)
+sc["env_cube_dim"] = 2048; sc["env_compression"] = 1      # as bench.py: EnvMapBaker's cube for an image source, BC6H on (the reference's D3D12 default)
 camd = scenes.bridge_camera(W, H, **cam)
 MAXR = int(os.environ.get("SHARD_PROBE_RANKS", "0"))          # > 0: time only this many evenly spaced ranks per world size (every rank costs a scene build)
 worlds = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]
+print("shard probe: %dx%d, %d spp" % (W, H, SPP))
 base = None
 for world in worlds:
     times, rays = [], []
     ranks = list(range(world)) if not MAXR or world <= MAXR else sorted({int(round(i * (world - 1) / (MAXR - 1))) for i in range(MAXR)}) if MAXR > 1 else [0]
     for rank in ranks:
         g = pt.PathTracer(device=0, shard_rank=rank, shard_count=world)
-        g.set_scene(sc); g.set_camera(camd); g.set_settings(scenes.default_settings()); g.resize(W, H)
+        g.set_scene(sc); g.set_camera(camd); g.set_settings(scenes.default_settings(useFp16Types=1)); g.resize(W, H)
         g.reset_accumulation(); g.render(0, SPP)
         t0 = time.perf_counter()
         for _ in range(2):
