@@ -81,7 +81,7 @@ struct pt_context {
     // device
     DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
-    DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
+    DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
     DevBuf<ptk::uint2> dEnvCube, dEnvCubeSource; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights; uint envCompression = 0;      // envCompression: EnvMapBaker's BC6U compression (0 off, 1 fast)
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
@@ -213,7 +213,7 @@ void refresh_scene_view(pt_context* c) {
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
     d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
-    d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
+    d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.shadeTris = c->dShadeTris.p; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
 }
 
 // SubInstanceData fill (Rtxpt/Materials/MaterialsBaker.cpp:960-1017) + primitive table; then GPU LBVH build
@@ -258,12 +258,14 @@ int finalize_geometry(pt_context* c) {
     if (c->bvhAllocated && c->bvh.capacity < c->numTris) { bvh_free(c->bvh); c->bvhAllocated = false; }
     if (!c->bvhAllocated) { PT_CHECK_HIP(c, bvh_alloc(c->bvh, c->numTris)); c->bvhAllocated = true; }
     c->bvh.builder = c->bvhBuilder;
+    PT_CHECK_HIP(c, c->dShadeTris.resize(c->numTris));
     if (!c->dTravSpill.p) PT_CHECK_HIP(c, c->dTravSpill.resize(PT_PIPELINE_BATCHES * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH));   // traversal stack tails, one region per pipelined batch (4 x 302 MB of 288 GB)
     refresh_scene_view(c);
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, st));
     PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, st));
     PT_CHECK_HIP(c, hipEventRecord(e1, st));
+    launch_shade_tris(c->dsc, c->numTris, c->dShadeTris.p, st);
     PT_CHECK_HIP(c, hipStreamSynchronize(st));
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); c->buildMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     c->geomDirty = false; c->lightsDirty = true;
@@ -457,7 +459,7 @@ int ensure_pool(pt_context* c, uint n, uint shadowPerPath) {      // shadowPerPa
     PT_CHECK_HIP(c, c->dHit.resize(n)); PT_CHECK_HIP(c, c->dQueue[0].resize(n)); PT_CHECK_HIP(c, c->dQueue[1].resize(n));
     PT_CHECK_HIP(c, c->dSq0.resize(ns)); PT_CHECK_HIP(c, c->dSq1.resize(ns)); PT_CHECK_HIP(c, c->dSq2.resize(ns));
     PT_CHECK_HIP(c, c->dBestKey.resize(ns)); PT_CHECK_HIP(c, c->dResolveList.resize(ns));
-    PT_CHECK_HIP(c, c->dTaskQ.resize((size_t)PT_PIPELINE_BATCHES * 2 * TASK_QUEUE_CAPACITY)); PT_CHECK_HIP(c, c->dTravCounts.resize(PT_PIPELINE_BATCHES * 4));
+    PT_CHECK_HIP(c, c->dTaskQ.resize((size_t)PT_PIPELINE_BATCHES * 2 * TASK_QUEUE_CAPACITY)); PT_CHECK_HIP(c, c->dTravCounts.resize(PT_PIPELINE_BATCHES * PASS_COUNTERS));
     c->poolCapacity = n; c->shadowCapacity = ns;
     return PT_OK;
 }
@@ -501,7 +503,7 @@ int32_t pt_destroy(pt_context* c) {
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
-    c->dPrimInfo.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
+    c->dPrimInfo.free(); c->dShadeTris.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
@@ -706,6 +708,7 @@ int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, co
         PT_CHECK_HIP(c, c->dPositions.upload(c->positions, c->stream));
     }
     refresh_scene_view(c);
+    if (positions) launch_shade_tris(c->dsc, c->numTris, c->dShadeTris.p, c->stream);      // the shading records hold object-space vertices: deformed meshes rewrite them, rigid motion does not
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
     if (rebuild) {                                     // a rebuild between animated frames prefers a fast build: PLOC on the device (15 ms at 2.8 M triangles)
@@ -763,7 +766,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.queue[0] = c->dQueue[0].p + t.base; t.queue[1] = c->dQueue[1].p + t.base;
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;
-        t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + 4 * b;
+        t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + PASS_COUNTERS * b;
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
         memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
         t.active = t.total;
@@ -789,8 +792,9 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             uint nxt = t.cur ^ 1u;
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->extendCount[nxt], 0, 4, t.st));
             PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st));
+            launch_pass_reset(t.aux.counts, t.st);      // the pass's traversal / class counters: one reset instead of one in front of every launch
             size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0, t.active});
-            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, reinterpret_cast<uint*>(t.aux.bestKey) /* the straggler keys and counts are idle between k_resolve_extend and the shadow launch */, t.aux.counts, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1, t.active});
+            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, reinterpret_cast<uint*>(t.aux.bestKey) /* the straggler keys are idle between k_resolve_extend and the shadow launch */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1, t.active});
             t.extendRays += t.active;
             PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
             t.waiting = true;
@@ -802,7 +806,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (!t.waiting) continue;
             PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
             uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
-            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.aux, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
+            TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
+            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, auxShadow, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
             t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
             if (t.active && t.iterations < maxIter) any = true;
         }

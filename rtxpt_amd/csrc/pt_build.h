@@ -55,6 +55,8 @@ hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris);
 void bvh_free(BvhBuildBuffers& b);
 // full build: fills b.triSorted / b.nodes; scene must already reference primInfo/instances/geometries/streams
 hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint numTris, hipStream_t stream);
+// flat per-primitive shading records (pt_scene.h ShadeTri); rebuilt when the geometry is (re)set or its vertices are deformed
+void launch_shade_tris(const DeviceScene& sc, uint numTris, ShadeTri* out, hipStream_t stream);
 hipError_t bvh_refit(BvhBuildBuffers& b, const DeviceScene& sc, uint numTris, hipStream_t stream);
 
 } // namespace ptk

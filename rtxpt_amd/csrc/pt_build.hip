@@ -419,6 +419,30 @@ __global__ void __launch_bounds__(256) k_alpha_records(DeviceScene sc, const Tri
     recs[i] = r;
 }
 
+// the flat shading records (pt_scene.h ShadeTri): one thread per global primitive walks the chain loadSurface used to walk per hit
+__global__ void __launch_bounds__(256) k_shade_tris(DeviceScene sc, uint numTris, ShadeTri* __restrict__ out) {
+    uint p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= numTris) return;
+    const uint2 pi = sc.primInfo[p];
+    const uint2 ig = sc.subInstToInstGeom[pi.x];
+    const GeometryDesc& g = sc.geometries[ig.y];
+    const uint* idx = sc.indices + g.indexOffset + 3u * pi.y;
+    const uint v0 = g.vertexOffset + idx[0], v1 = g.vertexOffset + idx[1], v2 = g.vertexOffset + idx[2];
+    const float* P = sc.positions;
+    ShadeTri r; __builtin_memset(&r, 0, sizeof(r));
+    r.instance = ig.x; r.subInstance = pi.x; r.triangleIndex = pi.y;
+    r.materialAndFlags = (sc.subInstances[pi.x].GlobalGeometryIndex_PTMaterialDataIndex & 0xFFFFu) | (g.flags << 16);
+    r.p0 = make_float3(P[3 * v0], P[3 * v0 + 1], P[3 * v0 + 2]); r.p1 = make_float3(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]); r.p2 = make_float3(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
+    if (g.flags & GEOM_HAS_UV) { r.t0 = sc.uvs[v0]; r.t1 = sc.uvs[v1]; r.t2 = sc.uvs[v2]; }
+    if (g.flags & GEOM_HAS_NORMAL) { r.n0 = sc.normals[v0]; r.n1 = sc.normals[v1]; r.n2 = sc.normals[v2]; }
+    if (g.flags & GEOM_HAS_TANGENT) { r.g0 = sc.tangents[v0]; r.g1 = sc.tangents[v1]; r.g2 = sc.tangents[v2]; }
+    uint4* o = reinterpret_cast<uint4*>(out + p); const uint4* src = reinterpret_cast<const uint4*>(&r);
+    for (int k = 0; k < 8; k++) o[k] = src[k];
+}
+void launch_shade_tris(const DeviceScene& sc, uint numTris, ShadeTri* out, hipStream_t st) {
+    if (numTris) hipLaunchKernelGGL(k_shade_tris, dim3((numTris + 255u) / 256u), dim3(256), 0, st, sc, numTris, out);
+}
+
 static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris);
 hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
     hipError_t e = bvh_alloc_all(b, numTris);

@@ -15,6 +15,9 @@
 #include "pt_rng.h"
 #include "pt_scene.h"
 
+#ifndef PT_SHADE_TRI
+#define PT_SHADE_TRI 1          // 1: loadSurface reads the flat 128-byte ShadeTri record of the hit primitive; 0: the five-hop gather through primInfo / sub-instance / geometry / index / vertex streams
+#endif
 #ifndef PT_SHADE_NOINLINE
 #define PT_SHADE_NOINLINE
 #endif
@@ -252,11 +255,44 @@ template <bool LP16> struct PathKernelContextT {
     }
     // Bridge::loadSurface (BridgeDonut:612-853): the divergent gather of the pipeline
     SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone) const {
+#if PT_SHADE_TRI
+        // one 128-byte line per primitive (pt_scene.h ShadeTri) instead of primInfo -> subInstToInstGeom -> {instance, subInstance, geometry} -> indices -> vertex streams
+        const uint4* rec = reinterpret_cast<const uint4*>(sc.shadeTris + prim);
+        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];      // seven independent 16-byte loads of one line
+        const uint subInst = r0.y, triangleIndex = r0.z, materialIndex = r0.w & 0xFFFFu;
+        struct { uint flags; } g; g.flags = r0.w >> 16;
+        const float3x4& M = sc.instances[r0.x].transform;
+        float3 bary = make_float3(1.0f - (bu + bv), bu, bv);
+        float3 vp[3] = {make_float3(asfloat(r1.x), asfloat(r1.y), asfloat(r1.z)), make_float3(asfloat(r1.w), asfloat(r2.x), asfloat(r2.y)), make_float3(asfloat(r2.z), asfloat(r2.w), asfloat(r3.x))};
+        float2 vt[3] = {make_float2(0, 0), make_float2(0, 0), make_float2(0, 0)};
+        float3 objPos = (vp[0] * bary.x + vp[1] * bary.y) + vp[2] * bary.z;
+        float2 texcoord = make_float2(0, 0);
+        if (g.flags & GEOM_HAS_UV) {
+            vt[0] = make_float2(asfloat(r3.y), asfloat(r3.z)); vt[1] = make_float2(asfloat(r3.w), asfloat(r4.x)); vt[2] = make_float2(asfloat(r4.y), asfloat(r4.z));
+            texcoord = (vt[0] * bary.x + vt[1] * bary.y) + vt[2] * bary.z;
+        }
+        float3 objFlatN = SafeNormalize(cross(vp[1] - vp[0], vp[2] - vp[0]));
+        float3 geometryNormal = make_float3(0.f);
+        if (g.flags & GEOM_HAS_NORMAL) {
+            const uint pn[3] = {r4.w, r5.x, r5.y};
+            float3 n[3];
+            for (int k = 0; k < 3; k++) {
+                n[k] = normalize(Unpack_RGB8_SNORM(pn[k]));
+                if (dot(n[k], objFlatN) < 0.f) n[k] = -n[k];
+            }
+            geometryNormal = (n[0] * bary.x + n[1] * bary.y) + n[2] * bary.z;
+            geometryNormal = SafeNormalize(xform_direction4(M, geometryNormal));
+        }
+        float4 tangent = make_float4(0, 0, 0, 0);
+        if (g.flags & GEOM_HAS_TANGENT) {
+            const uint pg[3] = {r5.z, r5.w, r6.x};
+            float4 tg[3];
+#else      // the gather as the reference's bridge walks it (developer A/B)
         uint2 pinfo = sc.primInfo[prim];
         uint subInst = pinfo.x, triangleIndex = pinfo.y;
         uint2 ig = sc.subInstToInstGeom[subInst];
         const InstanceDesc& inst = sc.instances[ig.x];
-        const SubInstanceData& si = sc.subInstances[subInst];
+        const uint materialIndex = sc.subInstances[subInst].GlobalGeometryIndex_PTMaterialDataIndex & 0xFFFFu;
         const GeometryDesc& g = sc.geometries[ig.y];
         const float3x4& M = inst.transform;
         float3 bary = make_float3(1.0f - (bu + bv), bu, bv);
@@ -284,7 +320,9 @@ template <bool LP16> struct PathKernelContextT {
         float4 tangent = make_float4(0, 0, 0, 0);
         if (g.flags & GEOM_HAS_TANGENT) {
             float4 tg[3];
-            for (int k = 0; k < 3; k++) tg[k] = Unpack_RGBA8_SNORM(sc.tangents[vi[k]]);
+            const uint pg[3] = {sc.tangents[vi[0]], sc.tangents[vi[1]], sc.tangents[vi[2]]};
+#endif
+            for (int k = 0; k < 3; k++) tg[k] = Unpack_RGBA8_SNORM(pg[k]);
             float3 t3 = (xyz(tg[0]) * bary.x + xyz(tg[1]) * bary.y) + xyz(tg[2]) * bary.z;
             t3 = SafeNormalize(xform_direction4(M, t3));
             tangent = make_float4(t3, tg[0].w);
@@ -298,7 +336,6 @@ template <bool LP16> struct PathKernelContextT {
 
         ShadingData sd; __builtin_memset(&sd, 0, sizeof(sd));
         sd.posW = posW; sd.V = -rayDir; sd.N = geometryNormal;
-        uint materialIndex = si.GlobalGeometryIndex_PTMaterialDataIndex & 0xFFFFu;
         const PTMaterialData& material = sc.materials[materialIndex];
         const uint mflags = material.Flags;
         float4 texBase = make_float4(1, 1, 1, 1), texEmissive = make_float4(1, 1, 1, 1), texNormal = make_float4(0.5f, 0.5f, 1.0f, 0.f),
@@ -368,10 +405,10 @@ template <bool LP16> struct PathKernelContextT {
         if (!sd.mtl.isThinSurface() && !sd.frontFacing) bd.eta = LP::div(matIoR, sd.IoR);
         SurfaceData ret;
         ret.neeTriangleLightIndex = RTXPT_INVALID_LIGHT_INDEX; ret.neeAnalyticLightIndex = RTXPT_INVALID_LIGHT_INDEX;
-        if (mflags & PTMaterialFlags_EnableAsAnalyticLightProxy) ret.neeAnalyticLightIndex = si.AnalyticProxyLightIndex;      // BridgeDonut:828-829
+        if (mflags & PTMaterialFlags_EnableAsAnalyticLightProxy) ret.neeAnalyticLightIndex = sc.subInstances[subInst].AnalyticProxyLightIndex;      // BridgeDonut:828-829
         if (sd.frontFacing && any_gt0(emissiveColor)) {
             sd.emission = emissiveColor;
-            uint baseIndex = si.EmissiveLightMappingOffset;
+            uint baseIndex = sc.subInstances[subInst].EmissiveLightMappingOffset;      // (the light links are re-baked with the lights: read from the sub-instance, by emissive hits only)
             if (baseIndex != 0xFFFFFFFFu) ret.neeTriangleLightIndex = baseIndex + triangleIndex;
         }
         ret.shadingData = sd; ret.bsdf.data = bd; ret.bsdf.diffuseModel = (int)S.diffuseBrdf; ret.interiorIoR = matIoR;

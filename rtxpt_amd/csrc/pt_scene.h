@@ -88,6 +88,22 @@ static_assert(sizeof(AlphaRec) == 32, "AlphaRec must be 32 bytes");
 
 struct TexInfo { uint w, h, mipLevels, _pad; unsigned long long base; uint mipOffset[16]; };   // offsets in texels relative to base
 
+// Flat shading record, one 128 B line per global primitive (instance triangle): everything Bridge::loadSurface gathers through
+// primInfo -> subInstToInstGeom -> {instance, subInstance, geometry} -> indices -> 4 vertex streams (five dependent hops, ~20 scattered loads) sits in
+// one line that the hit's primitive id addresses directly, so all of it is in flight at once. The vertex data stay in OBJECT space and the instance is
+// looked up by index (1 365 instances: cache resident), so the arithmetic of loadSurface — and a rigid animation — is untouched; deformed vertices rewrite
+// the records (k_shade_tris, 0.3 ms at 2.8 M triangles). The two light links live in the sub-instance (re-baked with the lights) and are read only by
+// emissive / proxy hits.
+struct ShadeTri {
+    uint instance, subInstance, triangleIndex, materialAndFlags;      // words 0-3; materialAndFlags = material index | GeometryDesc::flags << 16
+    float3 p0, p1, p2;            // words  4-12: object-space positions
+    float2 t0, t1, t2;            // words 13-18: texture coordinates (zero without GEOM_HAS_UV)
+    uint n0, n1, n2;              // words 19-21: RGBA8_SNORM normals
+    uint g0, g1, g2;              // words 22-24: RGBA8_SNORM tangents
+    uint _pad[7];
+};
+static_assert(sizeof(ShadeTri) == 128, "ShadeTri must be one 128-byte line");
+
 struct DeviceScene {
     const uint* indices; const float* positions; const float2* uvs; const uint* normals; const uint* tangents;
     const GeometryDesc* geometries; const InstanceDesc* instances; const SubInstanceData* subInstances; const uint2* subInstToInstGeom;
@@ -99,6 +115,7 @@ struct DeviceScene {
     LightTable lights;
     const BvhNode* nodes; const Bvh8Node* nodes8; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
     const AlphaRec* alphaRecs; // one per TriRecord slot (leaf order)
+    const ShadeTri* shadeTris; // one per global primitive id (pt_build.hip k_shade_tris)
     uint2* travSpill;          // T8_MAX_BLOCKS x T8_GROUPS_PER_BLOCK x T8_SPILL_DEPTH stack-tail entries
 };
 

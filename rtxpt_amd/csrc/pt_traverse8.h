@@ -88,7 +88,7 @@ struct __attribute__((packed, aligned(8))) Bvh8ChildPair { uint refA, q0A, q1A, 
 // Pub: void publish(uint tag, float bestT, uint bestPrim) ; called by one lane for every ray that is split (CAN_SPLIT only)
 //
 template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, class Src, class Dst, class Pub>
-__device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint count, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
+__device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
                                                      Traverse8Counters& ctr, uint* overflowFlag) {
     const uint RAY_STRIDE = TASKS ? T8_TASK_STRIDE : T8_RAY_STRIDE;
     const uint lane = threadIdx.x & 63u, q = lane & 3u, gl = lane & ~3u;
@@ -108,7 +108,10 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
     // was 3 % SLOWER on C3 (profiles/r02k_isa_experiments.txt): the bands differ in cost and the rays of later bounces are incoherent anyway.
     const uint numWavesU = (uint)__builtin_amdgcn_readfirstlane((int)numWaves);
     uint chunk = (uint)__builtin_amdgcn_readfirstlane((int)(waveId - numWaves)), chunkPos = 0u, chunkEnd = 0u;
-    bool exhausted = (waveId * T8_CHUNK >= count) || !sc.rootIsValid;
+    // rays a wave takes per chunk (16 .. T8_CHUNK, wave-uniform): a launch too small to fill the GPU with 64-ray chunks hands every wave fewer rays, down to one per
+    // quad, so that all of its rays are in flight at once instead of four in a row per quad (a 64-ray chunk is ~0.2 ms of dependent fetches however small the launch)
+    const uint rpc = (uint)__builtin_amdgcn_readfirstlane((int)raysPerChunk);
+    bool exhausted = (waveId * rpc >= count) || !sc.rootIsValid;
     uint* rayBuf = rayBufBase + (threadIdx.x >> 6) * (T8_CHUNK * RAY_STRIDE);
     uint tailIters = 0u; bool waveDry = false;                // wave-uniform: a refill found the chunk list empty / iterations since then (CAN_SPLIT)
     if (!sc.rootIsValid && waveId == 0 && count) {            // empty scene: every ray misses
@@ -156,7 +159,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 // next 64-ray chunk: every lane fetches one ray and parks it in LDS, so the two dependent global loads of a fetch are paid once
                 // per chunk by the whole wave instead of at every refill event
                 chunk += numWavesU;
-                chunkPos = chunk * T8_CHUNK; chunkEnd = (chunkPos + T8_CHUNK < count) ? chunkPos + T8_CHUNK : count;
+                chunkPos = chunk * rpc; chunkEnd = (chunkPos + rpc < count) ? chunkPos + rpc : count;
                 if (chunkPos >= count) { chunkPos = chunkEnd = count; }
                 if (chunkPos + lane < chunkEnd) {
                     float3 ro, rd; float rtmin, rtmax, rbestT; uint rstart, rbestPrim;
@@ -174,7 +177,7 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
                 uint rank = (uint)__popcll(needMask & ((1ull << gl) - 1ull));        // rank of my quad among the needing quads
                 uint n = (uint)__popcll(needMask);
                 if (need && rank < avail) {
-                    const uint* slot = rayBuf + (((chunkPos & (T8_CHUNK - 1u)) + rank) * RAY_STRIDE);
+                    const uint* slot = rayBuf + (((chunkPos - chunk * rpc) + rank) * RAY_STRIDE);
                     o = make_float3(__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]));
                     d = make_float3(__uint_as_float(slot[3]), __uint_as_float(slot[4]), __uint_as_float(slot[5]));
                     tag = slot[6];

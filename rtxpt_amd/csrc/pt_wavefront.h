@@ -25,16 +25,22 @@ struct WaveCounters {           // device-resident counters / stats (one 256 B b
 };
 
 // straggler splitting (pt_traverse8.h): per pipelined batch, two task queues (ping-pong), the per-ray merge keys and the list of rays to resolve.
-// counts = {taskCount[0], taskCount[1], resolveCount}. bestKey: closest hit = float bits of t << 32 | primitive (atomicMin = min t, ties to the
+// bestKey: closest hit = float bits of t << 32 | primitive (atomicMin = min t, ties to the
 // lower primitive id); occlusion = 0 visible so far / 1 occluded.
+// counts: TRAV_COUNTERS words per traversal launch, one counter per producer so that nothing has to be reset between the launches of a pass —
+//   [0] sub-trees split off by k_extend / k_shadow (task queue 0), [1..3] by task rounds 0..2 (queues 1, 0, 1), [TRAV_RESOLVE] rays to resolve.
+// pt_render keeps one PASS_COUNTERS block per batch — {extend launch, shadow launch, k_classify's three class counts} — and zeroes it once per pass.
+static const uint TRAV_COUNTERS = 5, TRAV_RESOLVE = 4, PASS_COUNTERS = 16, PASS_SHADOW_OFFSET = 5, PASS_CLASS_OFFSET = 10;
 struct TravAux { TravTask* taskQ[2]; uint* counts; uint taskCap; unsigned long long* bestKey; uint* resolveList; const uint* primToSlot; };
 
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st);
 void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
-// classScratch (2 x countIn words) + classCount (3 words): k_classify's output, memory that is free between the extend and the shadow launches of a bounce; null = shade in queue order
+// classScratch (2 x countIn words: memory that is free between the extend and the shadow launches of a bounce) + classCount (3 words, zero on entry): k_classify's output; null = shade in queue order
+// launch_extend / launch_shade / launch_shadow expect the pass's counter block zeroed by the caller (launch_pass_reset)
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr,
                   ShadowQueue sq, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st);
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
+void launch_pass_reset(uint* passCounters, hipStream_t st);      // one memset of the batch's PASS_COUNTERS words
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st);
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st);
 void launch_pack(const float4* accum, const uint* ownedPixels, uint numOwned, uint width, float4* dst, hipStream_t st);

@@ -73,7 +73,7 @@ __device__ __forceinline__ void t8_counters_init(Traverse8Counters& ctr) {
 __device__ __forceinline__ unsigned long long t8_hit_key(float t, uint prim) { return ((unsigned long long)__float_as_uint(t) << 32) | prim; }      // t > 0: bits order like the value
 
 template <bool COUNT>
-__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
+__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux, uint rpc) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
     __shared__ float2 mineUV[T8_BLOCK];
@@ -88,9 +88,9 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
     };
     auto commit = [&](uint p, const HitInfo& h) { pool.hit[p] = make_uint4(asuint(h.t), h.prim, asuint(h.u), asuint(h.v)); };
     // a split ray: its best hit so far seeds the merge key, the resolve pass will write pool.hit (k_resolve_extend)
-    auto publish = [&](uint p, float bestT, uint bestPrim) { aux.bestKey[p] = t8_hit_key(bestT, bestPrim); aux.resolveList[atomicAdd(&aux.counts[2], 1u)] = p; };
+    auto publish = [&](uint p, float bestT, uint bestPrim) { aux.bestKey[p] = t8_hit_key(bestT, bestPrim); aux.resolveList[atomicAdd(&aux.counts[TRAV_RESOLVE], 1u)] = p; };
     if (COUNT) { ctr.rayIterHist = wc->rayIterHistExt; ctr.longRayCount = &wc->longRayCount; ctr.longRays = &wc->longRays[0][0]; }
-    traverse8_persistent<false, COUNT, true, false, true>(sc, count, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    traverse8_persistent<false, COUNT, true, false, true>(sc, count, rpc, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); wave_add64(ctr.leafVisits, &wc->leafVisitsExt); wave_add64(ctr.iters, &wc->itersExt); wave_add64(ctr.leafBlocks, &wc->leafBlocksExt); if ((threadIdx.x & 63u) == 0u) atomicMax(&wc->itersMaxExt, (unsigned long long)ctr.iters);
                  if ((threadIdx.x & 63u) == 0u) for (int q = 0; q < 4; q++) atomicAdd(&wc->phaseCycExt[q], ctr.cyc[q]);
                  for (int q = 0; q < 8; q++) wave_add64(ctr.ev[q], &wc->eventsExt[q]); }
@@ -103,14 +103,16 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
 #define T8_TASK_SPREAD 1
 #endif
 __device__ __forceinline__ uint t8_tasks_per_chunk(uint count) { return (!T8_TASK_SPREAD || count > 16u * 4u * T8_TASK_BLOCKS_N) ? 64u : 16u; }
-// sub-trees of split extend rays: reads queue IN; unless FINAL, stragglers among the sub-trees are split again into the other queue.
+// sub-trees of split extend rays, round STAGE (0..3) of a traversal launch: reads queue STAGE & 1 (count: counts[STAGE]); unless it is the final round, stragglers among
+// the sub-trees are split again into the other queue (count: counts[STAGE + 1]). One counter per round: the whole block is zeroed once per pass (pt_wavefront.h TravAux).
 // Task i of the launch is queue entry (i % 64) * ceil(count / 64) + i / 64: the sub-trees of one ray sit next to each other in the queue and
 // would otherwise land in one 64-item chunk, i.e. on one wave.
-template <int IN, bool FINAL>
+template <int STAGE>
 __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks(DeviceScene sc, PathPool pool, WaveCounters* wc, TravAux aux) {
+    constexpr int IN = STAGE & 1; constexpr bool FINAL = STAGE == 3;
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_TASKBUF_WORDS];
-    uint count = aux.counts[IN]; if (count > aux.taskCap) count = aux.taskCap;
+    uint count = aux.counts[STAGE]; if (count > aux.taskCap) count = aux.taskCap;
     if (count == 0u) return;
     const TravTask* tasks = aux.taskQ[IN];
     const uint real = t8_tasks_per_chunk(count), per = (count + real - 1u) / real;
@@ -129,12 +131,12 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks
     };
     auto commit = [&](uint p, const HitInfo& h) { atomicMin(&aux.bestKey[p], t8_hit_key(h.t, h.prim)); };
     auto publish = [&](uint p, float bestT, uint bestPrim) { if (bestPrim != 0xFFFFFFFFu) atomicMin(&aux.bestKey[p], t8_hit_key(bestT, bestPrim)); };
-    traverse8_persistent<false, false, true, true, !FINAL>(sc, per * 64u, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[IN ^ 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+    traverse8_persistent<false, false, true, true, !FINAL>(sc, per * 64u, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
 }
 
 // split extend rays: the merged key -> hit record; the barycentrics come from re-intersecting the winning triangle (same arithmetic, same operands)
 __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool pool, TravAux aux) {
-    const uint n = aux.counts[2];
+    const uint n = aux.counts[TRAV_RESOLVE];
     for (uint i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         uint p = aux.resolveList[i];
         unsigned long long key = aux.bestKey[p];
@@ -234,7 +236,7 @@ __device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, ui
 }
 
 template <bool COUNT, bool GROUPED>
-__global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux) {
+__global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux, uint rpc) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
     const uint count = *countPtr;
@@ -246,16 +248,17 @@ __global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_s
     };
     auto commit = [&](uint i, const HitInfo& h) { if (h.prim == 0xFFFFFFFFu) shadow_visible<GROUPED>(pool, sq, i); };      // occluded: nothing is committed
     // a split shadow ray: "visible so far"; its sub-trees may set the flag, k_resolve_shadow applies the contribution if none did
-    auto publish = [&](uint i, float, uint) { aux.bestKey[i] = 0ull; aux.resolveList[atomicAdd(&aux.counts[2], 1u)] = i; };
-    traverse8_persistent<true, COUNT, false, false, true>(sc, count, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    auto publish = [&](uint i, float, uint) { aux.bestKey[i] = 0ull; aux.resolveList[atomicAdd(&aux.counts[TRAV_RESOLVE], 1u)] = i; };
+    traverse8_persistent<true, COUNT, false, false, true>(sc, count, rpc, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsSh); wave_add64(ctr.triTests, &wc->triTestsSh); wave_add64(ctr.leafVisits, &wc->leafVisitsSh); wave_add64(ctr.iters, &wc->itersSh); }
 }
 
-template <int IN, bool FINAL>
+template <int STAGE>
 __global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, ShadowQueue sq, WaveCounters* wc, TravAux aux) {
+    constexpr int IN = STAGE & 1; constexpr bool FINAL = STAGE == 3;
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_TASKBUF_WORDS];
-    uint count = aux.counts[IN]; if (count > aux.taskCap) count = aux.taskCap;
+    uint count = aux.counts[STAGE]; if (count > aux.taskCap) count = aux.taskCap;
     if (count == 0u) return;
     const TravTask* tasks = aux.taskQ[IN];
     const uint real = t8_tasks_per_chunk(count), per = (count + real - 1u) / real;
@@ -271,12 +274,12 @@ __global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, Shado
     };
     auto commit = [&](uint i, const HitInfo& h) { if (h.prim != 0xFFFFFFFFu) aux.bestKey[i] = 1ull; };
     auto publish = [&](uint, float, uint) {};
-    traverse8_persistent<true, false, false, true, !FINAL>(sc, per * 64u, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[IN ^ 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+    traverse8_persistent<true, false, false, true, !FINAL>(sc, per * 64u, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
 }
 
 template <bool GROUPED>
 __global__ void __launch_bounds__(256) k_resolve_shadow(PathPool pool, ShadowQueue sq, TravAux aux) {
-    const uint n = aux.counts[2];
+    const uint n = aux.counts[TRAV_RESOLVE];
     for (uint k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
         uint i = aux.resolveList[k];
         if (aux.bestKey[i] == 0ull) shadow_visible<GROUPED>(pool, sq, i);
@@ -332,10 +335,10 @@ __global__ void __launch_bounds__(T8_BLOCK) k_trace_probe(DeviceScene sc, const 
     auto publish = [&](uint, float, uint) {};
     if (outClosest) {
         auto commit = [&](uint i, const HitInfo& h) { outClosest[i] = make_float4(h.t, asfloat(h.prim), h.u, h.v); };
-        traverse8_persistent<false, false, false, false, false>(sc, n, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
+        traverse8_persistent<false, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
     } else {
         auto commit = [&](uint i, const HitInfo& h) { outVisible[i] = (h.prim == 0xFFFFFFFFu) ? 1u : 0u; };
-        traverse8_persistent<true, false, false, false, false>(sc, n, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
+        traverse8_persistent<true, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
     }
 }
 
@@ -556,6 +559,16 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
     }
 }
 
+#ifndef T8_ADAPTIVE_CHUNKS
+#define T8_ADAPTIVE_CHUNKS 1        // 1: launches below (resident waves x 64) rays use shorter chunks (see traverse8_persistent), 0: always 64 rays per chunk
+#endif
+// rays per chunk of a traversal launch: the waves the GPU can hold (256 CUs x 4 SIMDs x 8 waves) should cover the launch in one go, 16 .. 64 rays each, in steps of 16
+static inline uint rays_per_chunk(uint count) {
+    if (!T8_ADAPTIVE_CHUNKS) return T8_CHUNK;
+    const uint resident = 256u * 4u * 8u;
+    uint r = ((count + resident - 1u) / resident + 15u) & ~15u;
+    return r < 16u ? 16u : (r > T8_CHUNK ? T8_CHUNK : r);
+}
 static inline uint grid_for(uint count, uint block, uint maxBlocks) { uint g = (count + block - 1) / block; if (g < 1) g = 1; if (g > maxBlocks) g = maxBlocks; return g; }
 
 // ToneMappingPass::Render + SRGBA8 store (ToneMapping.ps.hlsli:136-174): one thread per pixel, streaming 16 B in / 4 B out
@@ -593,23 +606,20 @@ void launch_generate(const PathKernelContext& k, PathPool pool, const uint* owne
 // task rounds + resolve pass of one traversal launch; all counts live on the device, so the grids are fixed (empty rounds return at once)
 static const uint T8_TASK_BLOCKS = T8_TASK_BLOCKS_N, T8_RESOLVE_BLOCKS = 256;
 void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
-    uint g = grid_for(count, T8_BLOCK * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);
-    (void)hipMemsetAsync(aux.counts, 0, 12, st);
-    if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux);
-    else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux);
-    hipLaunchKernelGGL((k_extend_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 0 -> 1
-    (void)hipMemsetAsync(aux.counts, 0, 4, st);
-    hipLaunchKernelGGL((k_extend_tasks<1, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 1 -> 0
-    (void)hipMemsetAsync(aux.counts + 1, 0, 4, st);
-    hipLaunchKernelGGL((k_extend_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 0 -> 1
-    hipLaunchKernelGGL((k_extend_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);       // queue 1, to the end
+    const uint rpc = rays_per_chunk(count);
+    uint g = grid_for(count, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);
+    if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
+    else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
+    hipLaunchKernelGGL((k_extend_tasks<0>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 0 -> 1
+    hipLaunchKernelGGL((k_extend_tasks<1>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 1 -> 0
+    hipLaunchKernelGGL((k_extend_tasks<2>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 0 -> 1
+    hipLaunchKernelGGL((k_extend_tasks<3>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 1, to the end
     hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
 }
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc,
                   uint* classScratch, uint* classCount, hipStream_t st) {
     const dim3 g((countIn + 255) / 256), b(256);
-    if (PT_SHADE_CLASSES && classScratch) {                   // (scratch: 2 x countIn words; classCount: 3 words, both free between the extend and the shadow launches)
-        (void)hipMemsetAsync(classCount, 0, 12, st);
+    if (PT_SHADE_CLASSES && classScratch) {                   // (scratch: 2 x countIn words, free between the extend and the shadow launches; classCount: 3 words, zeroed with the pass's traversal counters)
         hipLaunchKernelGGL(k_classify, dim3((countIn + 1023) / 1024), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
         queueIn = classScratch;
     } else classCount = nullptr;
@@ -624,21 +634,20 @@ void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn
     }
 }
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
-    uint g = grid_for(count, T8_BLOCK * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);
-    (void)hipMemsetAsync(aux.counts, 0, 12, st);
-    if (sq.group) hipLaunchKernelGGL((k_shadow<false, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);       // (no traversal counters in the grouped mode)
-    else if (counters) hipLaunchKernelGGL((k_shadow<true, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);
-    else hipLaunchKernelGGL((k_shadow<false, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux);
-    hipLaunchKernelGGL((k_shadow_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
-    (void)hipMemsetAsync(aux.counts, 0, 4, st);
-    hipLaunchKernelGGL((k_shadow_tasks<1, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
-    (void)hipMemsetAsync(aux.counts + 1, 0, 4, st);
-    hipLaunchKernelGGL((k_shadow_tasks<0, false>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
-    hipLaunchKernelGGL((k_shadow_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    const uint rpc = rays_per_chunk(count);
+    uint g = grid_for(count, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);
+    if (sq.group) hipLaunchKernelGGL((k_shadow<false, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);       // (no traversal counters in the grouped mode)
+    else if (counters) hipLaunchKernelGGL((k_shadow<true, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);
+    else hipLaunchKernelGGL((k_shadow<false, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);
+    hipLaunchKernelGGL((k_shadow_tasks<0>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    hipLaunchKernelGGL((k_shadow_tasks<1>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    hipLaunchKernelGGL((k_shadow_tasks<2>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    hipLaunchKernelGGL((k_shadow_tasks<3>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     if (sq.group) hipLaunchKernelGGL((k_resolve_shadow<true>), dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
     else hipLaunchKernelGGL((k_resolve_shadow<false>), dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
     if (sq.group) hipLaunchKernelGGL(k_resolve_nee, dim3(grid_for(count / sq.group, 256, 4096)), dim3(256), 0, st, pool, sq, countPtr);
 }
+void launch_pass_reset(uint* passCounters, hipStream_t st) { (void)hipMemsetAsync(passCounters, 0, 4u * PASS_COUNTERS, st); }
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3((numOwned + 255) / 256), dim3(256), 0, st, pool, ownedPixels, numOwned, spp, accum, accumCountBase, width);
 }

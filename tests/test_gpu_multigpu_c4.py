@@ -39,7 +39,8 @@ def test_c4_ranks_0_and_7_of_8_match_the_oracle_at_16_spp():
         # accumulation over calls is associative at this size too: 16 = 4 + 12
         g.reset_accumulation(); g.render(0, 4); g.render(4, 12)
         assert np.array_equal(a, g.radiance())
-        for y in (5 + 32 * rank, 1083, 2100 - 32 * rank):                      # three complete rows: the oracle renders the row, the comparison takes the rank's pixels of it
+        ys = (px & 0xFFFF).astype(np.int64)
+        for y in (int(ys[7]), int(ys[ys.size // 2]) + 3, int(ys[-1]) - 5):       # three complete rows through the rank's first, middle and last tile: the oracle renders the row, the comparison takes the rank's pixels of it
             o.reset_accumulation(); o.render(0, SPP, rect=(0, y, W, y + 1))
             want = o.radiance()[y, :, :3]; got = a[y, :, :3]; m = own[y]
             assert m.any()
