@@ -156,6 +156,12 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
 #ifndef PT_SHADE_MIN_BLOCKS
 #define PT_SHADE_MIN_BLOCKS 1
 #endif
+#ifndef PT_SHADE_BLOCK_APPEND
+#define PT_SHADE_BLOCK_APPEND 1      // 1: k_shade appends to the extend / shadow queues with one atomic per block and counter, 0: one per wave
+#endif
+#ifndef PT_SHADE_PROBE
+#define PT_SHADE_PROBE 0
+#endif
 #ifndef PT_SHADE_CLASSES
 #define PT_SHADE_CLASSES 1      // 1: k_classify sorts the bounce's paths into {hit that goes on, hit that terminates after its emission, miss} before k_shade
 #endif
@@ -203,15 +209,46 @@ __global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathP
         PathState path = load_path(pool, p);
         uint4 hr = pool.hit[p];
         HitInfo h; h.t = asfloat(hr.x); h.prim = hr.y; h.u = asfloat(hr.z); h.v = asfloat(hr.w);
+#if PT_SHADE_PROBE == 1          // timing probes (developer builds only, the image is wrong by design): 1 = stream the path state through, nothing else
+        if (h.prim != 0xFFFFFFFFu) { isHit = true; path.sceneLength += h.t; } path.terminate();
+#elif PT_SHADE_PROBE == 2        // 2 = the surface gather (record, instance, material, textures) and nothing after it
+        if (h.prim != 0xFFFFFFFFu) { isHit = true; SurfaceData sfd = k.loadSurface(h.prim, h.u, h.v, path.dir, path.rayCone); path.origin = sfd.shadingData.posW + sfd.shadingData.N * sfd.bsdf.data.roughness + sfd.bsdf.data.diffuse + sfd.shadingData.T; } path.terminate();
+#else
         if (h.prim == 0xFFFFFFFFu) k.HandleMiss(path, path.dir, kMaxRayTravel);
         else {
             isHit = true;
             if (MULTI) { ShadowSink sink{sq.q0, sq.q1, sq.q2, &wc->shadowCount, &wc->shadowValid, p}; k.template HandleHit<true>(path, h, req, &sink); }
             else k.template HandleHit<false>(path, h, req, nullptr);
         }
+#endif
         store_path(pool, p, path);
         alive = path.isActive();
     }
+#if PT_SHADE_BLOCK_APPEND
+    // Queue appends, one atomic per BLOCK and counter: the four waves' counts meet in LDS, thread 0 reserves both ranges. A launch of 33 M paths has 518 k waves; one
+    // returning atomic per wave on each of three words — all waves of the GPU on the same three addresses — is what the kernel waited for (same-address atomics
+    // serialise in the L2: ~10^8 per second and address). The hit count needs no atomic at all when the paths were classified: it is the size of two classes.
+    __shared__ uint sCnt[4][2]; __shared__ uint sBase[2];
+    const uint wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned long long mAlive = __builtin_amdgcn_ballot_w64(alive), mReq = __builtin_amdgcn_ballot_w64(!MULTI && req.valid);
+    if (lane == 0u) { sCnt[wave][0] = (uint)__popcll(mAlive); sCnt[wave][1] = (uint)__popcll(mReq); }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        uint tot = 0; for (uint w = 0; w < 4u; w++) { const uint c = sCnt[w][threadIdx.x]; sCnt[w][threadIdx.x] = tot; tot += c; }
+        sBase[threadIdx.x] = tot ? atomicAdd(threadIdx.x == 0u ? countOutPtr : &wc->shadowCount, tot) : 0u;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (alive) queueOut[sBase[0] + sCnt[wave][0] + (uint)__popcll(mAlive & below)] = p;
+    if (!MULTI && req.valid) {
+        const uint sslot = sBase[1] + sCnt[wave][1] + (uint)__popcll(mReq & below);
+        sq.q0[sslot] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
+        sq.q1[sslot] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
+        sq.q2[sslot] = make_float4(req.radiance.x, req.radiance.y, req.radiance.z, 0.f);
+    }
+    if (classCount) { if (blockIdx.x == 0u && threadIdx.x == 0u) atomicAdd(&wc->hits, (unsigned long long)classCount[0] + classCount[1]); }
+    else wave_add64(isHit ? 1ull : 0ull, &wc->hits);
+#else
     uint slot = wave_append(alive, countOutPtr);
     if (alive) queueOut[slot] = p;
     uint sslot = MULTI ? 0u : wave_append(req.valid, &wc->shadowCount);
@@ -221,6 +258,7 @@ __global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathP
         sq.q2[sslot] = make_float4(req.radiance.x, req.radiance.y, req.radiance.z, 0.f);
     }
     wave_add64(isHit ? 1ull : 0ull, &wc->hits);
+#endif
 }
 
 template <bool GROUPED>
