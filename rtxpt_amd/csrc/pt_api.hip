@@ -81,7 +81,7 @@ struct pt_context {
     // device
     DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
-    DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::MatTexRef> dMatTex; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
+    DevBuf<ptk::AlphaPlane> dAlphaPlanes; DevBuf<unsigned char> dAlphaPool; DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::MatTexRef> dMatTex; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
     DevBuf<ptk::uint2> dEnvCube, dEnvCubeSource; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights; uint envCompression = 0;      // envCompression: EnvMapBaker's BC6U compression (0 off, 1 fast)
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
@@ -194,6 +194,21 @@ int upload_textures(pt_context* c) {
     for (auto& t : c->textures) c->texInfos.push_back(add(t));
     memset(&c->envTexInfo, 0, sizeof(TexInfo));
     if (c->envEnabled) c->envTexInfo = add(c->envTex);
+    // alpha planes (pt_scene.h AlphaPlane): the opacity channel of every texture's mip 0 on its own, a byte per texel where every value is k / 255
+    std::vector<ptk::AlphaPlane> planes(std::max<size_t>(1, c->textures.size())); std::vector<unsigned char> apool;
+    memset(planes.data(), 0, sizeof(ptk::AlphaPlane) * planes.size());
+    for (size_t ti = 0; ti < c->textures.size(); ti++) {
+        const HostTexture& t = c->textures[ti]; const std::vector<ptk::float4>& m0 = t.mips[0];
+        bool bytes = true;
+        for (size_t k = 0; k < m0.size() && bytes; k++) { const float a = m0[k].w; const int q = (a >= 0.f && a <= 1.f) ? (int)(a * 255.0f + 0.5f) : -1; bytes = q >= 0 && (float)q / 255.0f == a; }
+        while (apool.size() % 16u) apool.push_back(0);
+        if (apool.size() + m0.size() * (bytes ? 1u : 4u) > 0xFFFFFFF0ull) return fail(c, PT_ERROR_UNSUPPORTED, "alpha planes above 4 GB are not supported");
+        ptk::AlphaPlane& ap = planes[ti]; ap.wh = (t.w & 0xFFFFu) | (t.h << 16); ap.offset = (uint)apool.size(); ap.fmt = bytes ? 0u : 1u;
+        if (bytes) for (size_t k = 0; k < m0.size(); k++) apool.push_back((unsigned char)(int)(m0[k].w * 255.0f + 0.5f));
+        else { const size_t at = apool.size(); apool.resize(at + 4u * m0.size()); for (size_t k = 0; k < m0.size(); k++) memcpy(&apool[at + 4u * k], &m0[k].w, 4); }
+    }
+    while (apool.size() % 16u || apool.empty()) apool.push_back(0);
+    PT_CHECK_HIP(c, c->dAlphaPlanes.upload(planes, c->stream)); PT_CHECK_HIP(c, c->dAlphaPool.upload(apool, c->stream));
     PT_CHECK_HIP(c, c->dTexels.upload(pool, c->stream));
     PT_CHECK_HIP(c, c->dTexInfos.upload(c->texInfos, c->stream));
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
@@ -233,7 +248,7 @@ void refresh_scene_view(pt_context* c) {
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
     d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
-    d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.shadeTris = c->dShadeTris.p; d.matTex = c->dMatTex.p; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
+    d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.alphaPlanes = c->dAlphaPlanes.p; d.alphaPool = c->dAlphaPool.p; d.shadeTris = c->dShadeTris.p; d.matTex = c->dMatTex.p; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
 }
 
 // SubInstanceData fill (Rtxpt/Materials/MaterialsBaker.cpp:960-1017) + primitive table; then GPU LBVH build
@@ -525,7 +540,7 @@ int32_t pt_destroy(pt_context* c) {
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
-    c->dPrimInfo.free(); c->dShadeTris.free(); c->dMatTex.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
+    c->dPrimInfo.free(); c->dShadeTris.free(); c->dMatTex.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);

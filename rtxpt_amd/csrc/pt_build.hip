@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256) k_alpha_records(DeviceScene sc, const Tri
     uint i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     primToSlot[triSorted[i].prim] = i;
-    AlphaRec r; r.t0 = r.t1 = r.t2 = make_float2(0.f, 0.f); r.tex = 0xFFFFFFFFu; r.cutoff = 0.f;
+    AlphaRec r; r.t0 = r.t1 = r.t2 = make_float2(0.f, 0.f); r.tex = 0xFFFFFFFFu; r.cutoff = 0.f; r.wh = r.plane = r.fmt = r._pad = 0u;
     TriRecord tr = triSorted[i];
     if (tr.flags & 1u) {
         uint2 pi = sc.primInfo[tr.prim];
@@ -414,6 +414,7 @@ __global__ void __launch_bounds__(256) k_alpha_records(DeviceScene sc, const Tri
             const uint* idx = sc.indices + si.IndexOffset + pi.y * 3;
             r.t0 = sc.uvs[si.TexCoord1Offset + idx[0]]; r.t1 = sc.uvs[si.TexCoord1Offset + idx[1]]; r.t2 = sc.uvs[si.TexCoord1Offset + idx[2]];
             r.tex = si.AlphaTextureIndex(); r.cutoff = si.AlphaCutoff();
+            const AlphaPlane ap = sc.alphaPlanes[r.tex]; r.wh = ap.wh; r.plane = ap.offset; r.fmt = ap.fmt;
         }
     }
     recs[i] = r;

@@ -83,8 +83,14 @@ static const uint T8_MAX_BLOCKS = PT_T8_MAX_BLOCKS;     // persistent waves stri
 
 // per leaf-order triangle slot: what the alpha test needs, resolved at build time (texture coordinates of the 3 vertices, alpha texture, cutoff);
 // tex == ~0: not alpha tested. Saves the primInfo -> subInstance -> index -> uv chain (7 dependent loads) inside the traversal loop.
-struct AlphaRec { float2 t0, t1, t2; uint tex; float cutoff; };
-static_assert(sizeof(AlphaRec) == 32, "AlphaRec must be 32 bytes");
+// Since round 3 the record also says where the opacity values are (size and offset of the texture's ALPHA PLANE, below): the test is one record fetch and one
+// fetch of four opacities, not record -> TexInfo -> texels.
+struct AlphaRec { float2 t0, t1, t2; uint tex; float cutoff; uint wh; uint plane; uint fmt; uint _pad; };      // wh = w | h << 16 of mip 0; plane: byte offset into the alpha pool; fmt: 0 = u8, 1 = f32
+static_assert(sizeof(AlphaRec) == 48, "AlphaRec must be 48 bytes");
+// The alpha plane of a texture: the .w channel of its mip 0 on its own — one BYTE per texel where every opacity is k / 255 (8-bit sources: the float the shading
+// path reads is (float)k / 255.0f, and the test forms exactly that quotient again), a float per texel otherwise. 16 x (4 x) smaller than the RGBA32F texels and
+// contiguous: the alpha masks of a scene stay in the L2 while the traversal runs, and the four opacities of a test come from two lines instead of four.
+struct AlphaPlane { uint wh, offset, fmt, _pad; };
 
 struct TexInfo { uint w, h, mipLevels, _pad; unsigned long long base; uint mipOffset[16]; };   // offsets in texels relative to base
 
@@ -121,6 +127,7 @@ struct DeviceScene {
     LightTable lights;
     const BvhNode* nodes; const Bvh8Node* nodes8; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
     const AlphaRec* alphaRecs; // one per TriRecord slot (leaf order)
+    const AlphaPlane* alphaPlanes; const unsigned char* alphaPool;      // per texture (pt_api.hip upload_textures); read by k_alpha_records and the traversal's alpha test
     const ShadeTri* shadeTris; // one per global primitive id (pt_build.hip k_shade_tris)
     const MatTexRef* matTex;   // five per material (pt_api.hip build_mat_tex)
     uint2* travSpill;          // T8_MAX_BLOCKS x T8_GROUPS_PER_BLOCK x T8_SPILL_DEPTH stack-tail entries
@@ -285,16 +292,24 @@ static inline bool alpha_test(const DeviceScene& sc, uint prim, float u, float v
     return opacity >= si.AlphaCutoff();
 }
 
+#ifndef PT_ALPHA_LUT
+#define PT_ALPHA_LUT 1      // 1: the opacity k / 255 of a byte plane comes from a 256-entry constant table, 0: from a division (A/B: the four divisions cost 4 % of k_extend)
+#endif
+#if PT_ALPHA_LUT
+// k / 255.0f for k = 0..255 as a table (the quotients are formed by the compiler: IEEE division, the same floats the upload computes)
+struct Unorm8Table { float v[256]; constexpr Unorm8Table() : v() { for (int k = 0; k < 256; k++) v[k] = (float)k / 255.0f; } };
+__device__ __constant__ const Unorm8Table kUnorm8Table{};
+static inline float unorm8_to_float(unsigned char k) { return kUnorm8Table.v[k]; }
+#endif
 // the same test from the build-time record of triangle slot `slot` (identical arithmetic on identical operands: only the .w channel of
-// sample_bilinear at mip 0 is evaluated, and the texture coordinates / cutoff come from the AlphaRec instead of the vertex streams)
+// sample_bilinear at mip 0 is evaluated; the texture coordinates, cutoff and the place of the opacities come from the AlphaRec instead of the vertex streams / TexInfo)
 static inline bool alpha_test_slot(const DeviceScene& sc, uint slot, float u, float v) {
     const AlphaRec r = sc.alphaRecs[slot];
     if (r.tex == 0xFFFFFFFFu) return true;
     float b0 = 1.0f - (u + v);
     float2 uv = (r.t0 * b0 + r.t1 * u) + r.t2 * v;
-    const TexInfo& t = sc.textures[r.tex];
-    uint mw = t.w; if (mw < 1u) mw = 1u;
-    uint mh = t.h; if (mh < 1u) mh = 1u;
+    uint mw = r.wh & 0xFFFFu; if (mw < 1u) mw = 1u;
+    uint mh = r.wh >> 16; if (mh < 1u) mh = 1u;
     float fx = uv.x * (float)mw - 0.5f, fy = uv.y * (float)mh - 0.5f;
     float flx = floorf(fx), fly = floorf(fy);
     float ax = fx - flx, ay = fy - fly;
@@ -304,11 +319,19 @@ static inline bool alpha_test_slot(const DeviceScene& sc, uint slot, float u, fl
     if (y0 < 0) y0 += (int)mh; if (y1 >= (int)mh) y1 -= (int)mh;
     x0 = x0 < 0 ? 0 : (x0 >= (int)mw ? (int)mw - 1 : x0); x1 = x1 < 0 ? 0 : (x1 >= (int)mw ? (int)mw - 1 : x1);
     y0 = y0 < 0 ? 0 : (y0 >= (int)mh ? (int)mh - 1 : y0); y1 = y1 < 0 ? 0 : (y1 >= (int)mh ? (int)mh - 1 : y1);
-    // 32-bit texel offsets inside the texture (a single mip is far below 4 G texels) keep the address arithmetic and register use small
-    const float* texw = reinterpret_cast<const float*>(sc.texels + (t.base + t.mipOffset[0])) + 3;      // the .w channel
     const uint r0 = (uint)y0 * mw, r1 = (uint)y1 * mw;
-    float w00 = texw[4u * (r0 + (uint)x0)], w10 = texw[4u * (r0 + (uint)x1)];
-    float w01 = texw[4u * (r1 + (uint)x0)], w11 = texw[4u * (r1 + (uint)x1)];
+    float w00, w10, w01, w11;
+    if (r.fmt == 0u) {          // opacities k / 255: the quotient the texture upload formed (correctly rounded division on both sides)
+        const unsigned char* a = sc.alphaPool + r.plane;
+#if PT_ALPHA_LUT
+        w00 = unorm8_to_float(a[r0 + (uint)x0]); w10 = unorm8_to_float(a[r0 + (uint)x1]); w01 = unorm8_to_float(a[r1 + (uint)x0]); w11 = unorm8_to_float(a[r1 + (uint)x1]);
+#else
+        w00 = (float)a[r0 + (uint)x0] / 255.0f; w10 = (float)a[r0 + (uint)x1] / 255.0f; w01 = (float)a[r1 + (uint)x0] / 255.0f; w11 = (float)a[r1 + (uint)x1] / 255.0f;
+#endif
+    } else {
+        const float* a = reinterpret_cast<const float*>(sc.alphaPool + r.plane);
+        w00 = a[r0 + (uint)x0]; w10 = a[r0 + (uint)x1]; w01 = a[r1 + (uint)x0]; w11 = a[r1 + (uint)x1];
+    }
     float opacity = lerpf(lerpf(w00, w10, ax), lerpf(w01, w11, ax), ay);
     return opacity >= r.cutoff;
 }

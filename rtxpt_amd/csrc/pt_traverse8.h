@@ -216,6 +216,10 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
         }
         if (run) {
 
+#ifdef T8_PROBE_VNOPS          // developer probe: T8_PROBE_VNOPS extra VALU issue slots per wave iteration (is the loop VALU-issue bound?)
+#pragma unroll
+        for (int k_ = 0; k_ < T8_PROBE_VNOPS; k_++) asm volatile("v_nop");
+#endif
         if (COUNT && lane == 0u) ctr.iters++;
         if (COUNT && active) rayIters++;
         if (COUNT) tc1 = __builtin_readcyclecounter();
