@@ -122,11 +122,13 @@ typedef struct PtDeviceDesc {
     uint32_t flags;                         /* PT_DEVICE_* */
 } PtDeviceDesc;
 #define PT_DEVICE_SERIAL_KERNELS 1u         /* one batch, one stream: kernels of a pt_render call never overlap (profiling / per-kernel timing) */
-#define PT_DEVICE_PREFER_FAST_BUILD 2u      /* scene builds (pt_set_geometry / pt_set_instances / pt_load_scene_gltf) use the device-side PLOC builder (15 ms at
+#define PT_DEVICE_PREFER_FAST_BUILD 2u      /* scene builds (pt_set_geometry / pt_set_instances / pt_load_scene_gltf) use the plain device-side PLOC builder (15 ms at
                                                2.8 M triangles) instead of the default: AccelStructBuildFlags::PreferFastTrace as the reference sets it
-                                               (Rtxpt/Sample.cpp:1093) = binned-SAH topology on the host's cores, 14-18 % fewer node visits per ray, a few
-                                               hundred ms. pt_animate(rebuild = 1) always builds fast; refits keep the topology they find. The image does
-                                               not depend on the tree. */
+                                               (Rtxpt/Sample.cpp:1093) = PLOC + 12 passes of parallel re-insertion + cost-driven wide nodes, all on the device
+                                               (81 ms at 2.8 M triangles, 24 % more rays per second than plain PLOC). pt_animate(rebuild = 1) always builds fast;
+                                               refits keep the topology they find. The image does not depend on the tree. */
+#define PT_DEVICE_HOST_SAH_BUILDER 4u       /* the fast-trace tree of round 2 instead: binned-SAH topology + insertion-based optimisation on the host's cores
+                                               (1.8 s at 2.8 M triangles, the same trace speed within 0.2 %); bounds, collapse and refit on the device as always */
 
 typedef struct PtFrameStats {
     uint64_t extendRays, shadowRays, hits;                  /* "rays" of the Mrays/s metric = extendRays + shadowRays */

@@ -495,12 +495,13 @@ def bridge_camera(width, height, pos, direction, up, fov_y, near_z=0.01, far_z=1
 class PathTracer:
     """One pt_context (one GPU). Method names follow the C-ABI; the call order follows Sample::Render."""
 
-    def __init__(self, device=0, shard_rank=0, shard_count=1, serial_kernels=False, prefer_fast_build=False):
+    def __init__(self, device=0, shard_rank=0, shard_count=1, serial_kernels=False, prefer_fast_build=False, host_sah_builder=False):
         """serial_kernels: PT_DEVICE_SERIAL_KERNELS — pt_render runs one batch on one stream (clean per-kernel timings) instead of two pipelined half-frame batches.
-        prefer_fast_build: PT_DEVICE_PREFER_FAST_BUILD — scene builds use the device-side PLOC builder instead of the host's binned-SAH topology (prefer fast trace)."""
+        prefer_fast_build: PT_DEVICE_PREFER_FAST_BUILD — scene builds use the plain device-side PLOC builder instead of the default fast-trace tree (PLOC + parallel
+        re-insertion + cost-driven wide nodes, on the device); host_sah_builder: PT_DEVICE_HOST_SAH_BUILDER — round 2's binned SAH + re-insertion on the host's cores."""
         self.L = load_library()
         self.h = ctypes.c_void_p()
-        desc = PtDeviceDesc(device, shard_rank, shard_count, (1 if serial_kernels else 0) | (2 if prefer_fast_build else 0))
+        desc = PtDeviceDesc(device, shard_rank, shard_count, (1 if serial_kernels else 0) | (2 if prefer_fast_build else 0) | (4 if host_sah_builder else 0))
         r = self.L.pt_create(ctypes.byref(desc), ctypes.byref(self.h))
         if r != PT_OK:
             raise PtError(r, "pt_create failed (no HIP device? this library has no CPU path)")

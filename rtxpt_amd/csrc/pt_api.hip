@@ -293,6 +293,7 @@ int finalize_geometry(pt_context* c) {
     if (c->bvhAllocated && c->bvh.capacity < c->numTris) { bvh_free(c->bvh); c->bvhAllocated = false; }
     if (!c->bvhAllocated) { PT_CHECK_HIP(c, bvh_alloc(c->bvh, c->numTris)); c->bvhAllocated = true; }
     c->bvh.builder = c->bvhBuilder;
+    { const char* e = getenv("MI355PT_REINSERT_PASSES"); c->bvh.riPasses = e ? (uint)atoi(e) : 12u; }      // BVH_BUILDER_PLOC_OPT: parallel re-insertion passes (MI355X, C3: 8 passes = 1463 Mrays/s in 63 ms, 12 = 1477 in 81 ms, 16 = 1476 in 98 ms; host SAH + re-insertion 1479 in 1824 ms — profiles/r03k_device_reinsertion_sweep.txt)
     PT_CHECK_HIP(c, c->dShadeTris.resize(c->numTris));
     if (!c->dTravSpill.p) PT_CHECK_HIP(c, c->dTravSpill.resize(PT_PIPELINE_BATCHES * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH));   // traversal stack tails, one region per pipelined batch (4 x 302 MB of 288 GB)
     refresh_scene_view(c);
@@ -521,10 +522,11 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) if (hipStreamCreateWithFlags(&c->streams[b], hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     if (hipHostMalloc(&c->hostCounters, PT_PIPELINE_BATCHES * sizeof(WaveCounters), hipHostMallocDefault) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     c->serialKernels = desc && (desc->flags & PT_DEVICE_SERIAL_KERNELS);
-    // scene builds prefer fast trace (binned SAH, as the reference asks of its driver: Sample.cpp:1093) unless the host asks for fast builds; pt_animate's rebuilds are always PLOC
-    c->bvhBuilder = (desc && (desc->flags & PT_DEVICE_PREFER_FAST_BUILD)) ? BVH_BUILDER_PLOC : BVH_BUILDER_SAH;
+    // scene builds prefer fast trace, as the reference asks of its driver (Sample.cpp:1093): PLOC + parallel re-insertion + cost-driven wide nodes, all on the device (round 3;
+    // PT_DEVICE_HOST_SAH_BUILDER: round 2's host-side binned SAH + re-insertion) unless the host asks for fast builds; pt_animate's rebuilds are always plain PLOC
+    c->bvhBuilder = (desc && (desc->flags & PT_DEVICE_PREFER_FAST_BUILD)) ? BVH_BUILDER_PLOC : ((desc && (desc->flags & PT_DEVICE_HOST_SAH_BUILDER)) ? BVH_BUILDER_SAH : BVH_BUILDER_PLOC_OPT);
     { const char* e = getenv("MI355PT_BVH_BUILDER");        // developer A/B switch
-      if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; }
+      if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; else if (e && (!strcmp(e, "ploc_opt") || !strcmp(e, "device"))) c->bvhBuilder = BVH_BUILDER_PLOC_OPT; }
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
     const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale);      // no params = tint 1, intensity 1: the cube holds radiance x 1/4
@@ -749,7 +751,7 @@ int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, co
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
     if (rebuild) {                                     // a rebuild between animated frames prefers a fast build: PLOC on the device (15 ms at 2.8 M triangles)
-        if (c->bvh.builder == BVH_BUILDER_SAH) c->bvh.builder = BVH_BUILDER_PLOC;
+        if (c->bvh.builder == BVH_BUILDER_SAH || c->bvh.builder == BVH_BUILDER_PLOC_OPT) c->bvh.builder = BVH_BUILDER_PLOC;
         PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, c->stream));
     } else PT_CHECK_HIP(c, bvh_refit(c->bvh, c->dsc, c->numTris, c->stream));
     PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));

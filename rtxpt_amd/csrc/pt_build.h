@@ -24,7 +24,7 @@
 
 namespace ptk {
 
-enum : uint { BVH_BUILDER_PLOC = 0, BVH_BUILDER_KARRAS = 1, BVH_BUILDER_SAH = 2 };      // SAH: topology by pt_build_sah.cpp on the host ("prefer fast trace")
+enum : uint { BVH_BUILDER_PLOC = 0, BVH_BUILDER_KARRAS = 1, BVH_BUILDER_SAH = 2, BVH_BUILDER_PLOC_OPT = 3 };      // SAH: topology by pt_build_sah.cpp on the host; PLOC_OPT: PLOC + re-insertion passes + cost-driven wide nodes, all on the device (both "prefer fast trace")
 
 struct BvhBuildBuffers {
     TriRecord* triWorld;        // by global primitive id
@@ -47,6 +47,10 @@ struct BvhBuildBuffers {
     uint builder;               // BVH_BUILDER_PLOC ("prefer fast build"), BVH_BUILDER_SAH ("prefer fast trace") or BVH_BUILDER_KARRAS (developer A/B)
     uint* absorb;               // BVH_BUILDER_SAH: per inner node, 1 = the cost-driven BVH8 collapse opens it inside its parent's wide node (pt_build_sah.cpp)
     float hostBuildMs;          // BVH_BUILDER_SAH: the host part of the last build (read-back + SAH topology + upload)
+    void* riScratch; size_t riScratchBytes; uint riPasses, riLevels;      // BVH_BUILDER_PLOC_OPT: scratch of the parallel re-insertion, passes to run (pt_api: 10), depth of the tree it left
+    uint wideDpPending;         // BVH_BUILDER_PLOC_OPT: the next bounds stage runs the device-side wide-node programme (a build; refits keep the flags they find)
+    uint wideFlagsValid;        // BVH_BUILDER_PLOC_OPT: absorb[] holds the programme's flags (0: the collapse opens the largest child)
+    uint wideLevels;            // depth of the binary tree above the wide tree's leaves (levels of the last device-side wide-node programme)
     uint optimiserPasses;       // re-insertion passes the last build ran (host: pt_build_sah.cpp; device: BVH_BUILDER_PLOC_OPT)
     uint capacity;
 };

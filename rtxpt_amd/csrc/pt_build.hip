@@ -1,6 +1,8 @@
 // mi355pt — GPU LBVH build / refit kernels. See pt_build.h for the pipeline.
 #include "pt_build.h"
 #include "pt_build_sah.h"
+#include "pt_build_wide.h"
+#include "pt_build_reinsert.h"
 #include <chrono>
 #include <vector>
 #include <rocprim/rocprim.hpp>
@@ -444,6 +446,72 @@ void launch_shade_tris(const DeviceScene& sc, uint numTris, ShadeTri* out, hipSt
     if (numTris) hipLaunchKernelGGL(k_shade_tris, dim3((numTris + 255u) / 256u), dim3(256), 0, st, sc, numTris, out);
 }
 
+// ---- cost-driven wide-node assignment on the device (pt_build_wide.h): the inner nodes above the wide tree's leaves are numbered breadth first (one launch per level,
+// children appended with one atomic per block), the dynamic programme runs over the levels bottom-up, the marking top-down. ~3 launches per level of a tree ~50 deep.
+__global__ void __launch_bounds__(256) k_wide_levels(const uint* __restrict__ levelIn, uint nIn, const uint* __restrict__ childL, const uint* __restrict__ childR,
+                                                     const uint* __restrict__ rangeFirst, const uint* __restrict__ rangeLast, uint maxLeaf, uint* __restrict__ levelOut, uint* __restrict__ counter) {
+    __shared__ uint sCnt[4]; __shared__ uint sBase;
+    const uint i = blockIdx.x * 256u + threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint kids[2]; uint nk = 0;
+    if (i < nIn) {
+        const uint id = levelIn[i];
+        if (rangeLast[id] - rangeFirst[id] + 1u > maxLeaf) {          // below a leaf of the wide tree nothing is decided
+            const uint L = childL[id], R = childR[id];
+            if (!(L & BVH_LEAF_BIT)) kids[nk++] = L;
+            if (!(R & BVH_LEAF_BIT)) kids[nk++] = R;
+        }
+    }
+    // exclusive prefix of nk over the block: per-wave by two ballots, per-block through LDS
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(nk >= 1u), m2 = __builtin_amdgcn_ballot_w64(nk >= 2u), below = (1ull << lane) - 1ull;
+    const uint inWave = (uint)__popcll(m1 & below) + (uint)__popcll(m2 & below);
+    if (lane == 0u) sCnt[wave] = (uint)__popcll(m1) + (uint)__popcll(m2);
+    __syncthreads();
+    if (threadIdx.x == 0u) { uint tot = 0; for (uint w = 0; w < 4u; w++) { const uint c = sCnt[w]; sCnt[w] = tot; tot += c; } sBase = tot ? atomicAdd(counter, tot) : 0u; }
+    __syncthreads();
+    const uint at = sBase + sCnt[wave] + inWave;
+    for (uint k = 0; k < nk; k++) levelOut[at + k] = kids[k];
+}
+__global__ void __launch_bounds__(256) k_wide_dp(const uint* __restrict__ level, uint nIn, const uint* __restrict__ childL, const uint* __restrict__ childR, const uint* __restrict__ rangeFirst,
+                                                 const uint* __restrict__ rangeLast, uint maxLeaf, const float4* __restrict__ boxLmin, const float4* __restrict__ boxLmax,
+                                                 const float4* __restrict__ boxRmin, const float4* __restrict__ boxRmax, float* __restrict__ C, unsigned long long* __restrict__ dec) {
+    const uint i = blockIdx.x * 256u + threadIdx.x; if (i >= nIn) return;
+    const uint id = level[i];
+    const float4 a = boxLmin[id], b = boxLmax[id], c = boxRmin[id], d = boxRmax[id];
+    const float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {b.x, b.y, b.z}, rmn[3] = {c.x, c.y, c.z}, rmx[3] = {d.x, d.y, d.z};
+    wide_dp_node(id, childL[id], childR[id], rangeLast[id] - rangeFirst[id] + 1u, maxLeaf, lmn, lmx, rmn, rmx, C, dec);
+}
+__global__ void __launch_bounds__(256) k_wide_mark(const uint* __restrict__ level, uint nIn, const uint* __restrict__ childL, const uint* __restrict__ childR, const uint* __restrict__ rangeFirst,
+                                                   const uint* __restrict__ rangeLast, uint maxLeaf, const unsigned long long* __restrict__ dec, uint* __restrict__ absorb, uint* __restrict__ state) {
+    const uint i = blockIdx.x * 256u + threadIdx.x; if (i >= nIn) return;
+    const uint id = level[i];
+    wide_mark_node(id, state[id], childL[id], childR[id], rangeLast[id] - rangeFirst[id] + 1u, maxLeaf, dec, absorb, state);
+}
+// needs the child boxes of k_node_boxes (boxLmin .. boxRmax); scratch: levelA (breadth-first order), levelB (states), the dead sparse table (C), plocFlags (decisions)
+static hipError_t bvh_wide_nodes(BvhBuildBuffers& b, uint n, hipStream_t st) {
+    if (n < 2u || !b.rangeMin) return hipErrorInvalidValue;
+    uint* order = b.levelA; uint* state = b.levelB; float* C = reinterpret_cast<float*>(b.rangeMin); unsigned long long* dec = b.plocFlags;
+    PT_HIP_TRY(hipMemsetAsync(b.absorb, 0, 4 * (size_t)n, st)); PT_HIP_TRY(hipMemsetAsync(state, 0, 4 * (size_t)n, st));
+    const uint first[2] = {0u, wide_state(8u, true)};                          // order[0] = the root; its state: a wide node with the whole budget
+    PT_HIP_TRY(hipMemcpyAsync(order, &first[0], 4, hipMemcpyHostToDevice, st)); PT_HIP_TRY(hipMemcpyAsync(state, &first[1], 4, hipMemcpyHostToDevice, st));
+    std::vector<uint> start{0u}, count{1u};
+    for (;;) {                                                                  // breadth-first numbering, one level per launch (the level size comes back: a build step)
+        const uint s0 = start.back(), c0 = count.back();
+        if ((size_t)s0 + c0 > n) return hipErrorUnknown;
+        PT_HIP_TRY(hipMemsetAsync(b.wideCounter, 0, 4, st));
+        hipLaunchKernelGGL(k_wide_levels, dim3((c0 + 255u) / 256u), dim3(256), 0, st, order + s0, c0, b.childL, b.childR, b.rangeFirst, b.rangeLast, BVH_MAX_LEAF, order + s0 + c0, b.wideCounter);
+        uint next = 0; PT_HIP_TRY(hipMemcpyAsync(&next, b.wideCounter, 4, hipMemcpyDeviceToHost, st)); PT_HIP_TRY(hipStreamSynchronize(st));
+        if (!next) break;
+        start.push_back(s0 + c0); count.push_back(next);
+        if (start.size() > 100000u) return hipErrorUnknown;
+    }
+    for (size_t d = start.size(); d-- > 0;)
+        hipLaunchKernelGGL(k_wide_dp, dim3((count[d] + 255u) / 256u), dim3(256), 0, st, order + start[d], count[d], b.childL, b.childR, b.rangeFirst, b.rangeLast, BVH_MAX_LEAF, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, C, dec);
+    for (size_t d = 0; d < start.size(); d++)
+        hipLaunchKernelGGL(k_wide_mark, dim3((count[d] + 255u) / 256u), dim3(256), 0, st, order + start[d], count[d], b.childL, b.childR, b.rangeFirst, b.rangeLast, BVH_MAX_LEAF, dec, b.absorb, state);
+    b.wideLevels = (uint)start.size();
+    return hipGetLastError();
+}
+
 static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris);
 hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris) {
     hipError_t e = bvh_alloc_all(b, numTris);
@@ -473,6 +541,7 @@ static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris) {
     PT_HIP_TRY(hipMalloc(&b.plocChildA, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocChildB, 4 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.plocCnt, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocParent, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.plocFirst, 8 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.plocCounts, 16)); PT_HIP_TRY(hipMalloc(&b.absorb, 4 * (size_t)n));
+    b.riScratchBytes = 176ull * (size_t)n + (64u << 10); PT_HIP_TRY(hipMalloc(&b.riScratch, b.riScratchBytes));      // parallel re-insertion (bvh_reinsert): ~160 bytes per triangle
     tmp = 0;
     PT_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, b.plocFlags, b.plocOffs, 0ull, (size_t)n, rocprim::plus<unsigned long long>()));
     b.scanTempBytes = tmp; PT_HIP_TRY(hipMalloc(&b.scanTemp, tmp ? tmp : 16));
@@ -481,7 +550,7 @@ static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris) {
 void bvh_free(BvhBuildBuffers& b) {
     void* ps[] = {b.triWorld, b.triSorted, b.keys, b.keysSorted, b.prims, b.primsSorted, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast, b.tickets,
                   b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter, b.alphaRecs, b.primToSlot, b.rangeMin, b.rangeMax,
-                  b.plocCl[0], b.plocCl[1], b.plocNN, b.plocFlags, b.plocOffs, b.plocChildA, b.plocChildB, b.plocCnt, b.plocParent, b.plocFirst, b.plocCounts, b.scanTemp, b.absorb};
+                  b.plocCl[0], b.plocCl[1], b.plocNN, b.plocFlags, b.plocOffs, b.plocChildA, b.plocChildB, b.plocCnt, b.plocParent, b.plocFirst, b.plocCounts, b.scanTemp, b.absorb, b.riScratch};
     for (void* p : ps) if (p) (void)hipFree(p);
     __builtin_memset(&b, 0, sizeof(b));
 }
@@ -497,7 +566,11 @@ static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, const DeviceScene& sc,
         hipLaunchKernelGGL(k_bounds, dim3(g), dim3(256), 0, st, b.triWorld, b.primsSorted, n, b.triSorted, b.childL, b.parent, b.leafParent, b.tickets, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds);
     }
     hipLaunchKernelGGL(k_alpha_records, dim3(g), dim3(256), 0, st, sc, b.triSorted, n, b.alphaRecs, b.primToSlot);
-    const bool costDriven = b.builder == BVH_BUILDER_SAH && b.absorb != nullptr;      // (a refit finds the builder that made the topology)
+    if (b.wideDpPending) {                                  // BVH_BUILDER_PLOC_OPT build: the wide-node programme over the boxes just written; without the sparse table (huge scenes) the collapse stays greedy
+        b.wideDpPending = 0u;
+        if (n > 1u && b.rangeMin && bvh_wide_nodes(b, n, st) == hipSuccess) b.wideFlagsValid = 1u; else { (void)hipGetLastError(); b.wideFlagsValid = 0u; }
+    }
+    const bool costDriven = ((b.builder == BVH_BUILDER_SAH) || (b.builder == BVH_BUILDER_PLOC_OPT && b.wideFlagsValid)) && b.absorb != nullptr;      // (a refit finds the builder that made the topology)
     hipLaunchKernelGGL(k_emit, dim3(g), dim3(256), 0, st, n, b.childL, b.childR, b.rangeFirst, b.rangeLast, b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes,
                        costDriven ? b.absorb : (const uint*)nullptr);
     // BVH8 collapse, level by level (the per-level node count comes back to the host: a build step, not the hot path)
@@ -518,6 +591,7 @@ static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, const DeviceScene& sc,
     b.collapseLevels = levels;
     return hipGetLastError();
 }
+static hipError_t bvh_reinsert(BvhBuildBuffers& b, uint n, uint passes, hipStream_t st);
 // PLOC passes; every pass reads the new list length back (a build step, not the hot path: ~70 passes of 4 small launches at 2.8 M triangles)
 static hipError_t bvh_ploc(BvhBuildBuffers& b, uint n, hipStream_t st) {
     float4* cbMin[2] = {b.boxLmin, b.boxRmin}; float4* cbMax[2] = {b.boxLmax, b.boxRmax};
@@ -540,11 +614,139 @@ static hipError_t bvh_ploc(BvhBuildBuffers& b, uint n, hipStream_t st) {
     }
     b.plocPasses = passes;
     if (nodeBase != 2u * n - 1u) return hipErrorUnknown;
+    if (b.builder == BVH_BUILDER_PLOC_OPT && b.riPasses) PT_HIP_TRY(bvh_reinsert(b, n, b.riPasses, st));      // insertion-based optimisation of the finished tree ("prefer fast trace")
     const uint gAll = (2u * n - 1u + 255u) / 256u;
     hipLaunchKernelGGL(k_ploc_first, dim3(gAll), dim3(256), 0, st, n, b.plocParent, b.plocChildA, b.plocCnt, b.plocFirst);
     hipLaunchKernelGGL(k_ploc_finish, dim3(gAll), dim3(256), 0, st, n, b.plocFirst, b.plocParent, b.plocChildA, b.plocChildB, b.plocCnt, b.primsSorted, b.prims,
                        b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast);
     PT_HIP_TRY(hipMemcpyAsync(b.primsSorted, b.prims, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));      // leaf order = depth-first order from here on
+    return hipGetLastError();
+}
+// ---- parallel re-insertion on the PLOC tree (pt_build_reinsert.h), in PLOC's node numbering: leaves 0 .. n - 1 in Morton order, inner nodes n .. 2n - 2, root 2n - 2.
+// Scratch (b.riScratch, 160 bytes per triangle): parent / left / right, boxes, per-node proposals (gain, target, pivot), locks, the keys of the moving nodes, a
+// breadth-first numbering of the tree (rebuilt every pass: it orders the refit) and its level bounds.
+struct RiDevice { RiTree t; float* gain; uint* target; uint* pivot; unsigned long long* lock; unsigned long long* moving; uint* ok; uint* bfs; uint* bounds; uint* cursor; };
+static const uint RI_MAX_LEVELS = 1024;
+__global__ void __launch_bounds__(256) k_ri_init(uint n, const uint* __restrict__ nodeParent, const uint* __restrict__ childA, const uint* __restrict__ childB,
+                                                 const TriRecord* __restrict__ triWorld, const uint* __restrict__ primsMorton, RiTree t) {
+    const uint x = blockIdx.x * 256u + threadIdx.x; if (x >= t.N) return;
+    t.par[x] = (x == t.N - 1u) ? RI_NONE : (nodeParent[x] & 0x7FFFFFFFu);
+    if (x < n) {
+        t.left[x] = RI_NONE; t.right[x] = RI_NONE;
+        const TriRecord tr = triWorld[primsMorton[x]];
+        const float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2, mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+        RiBox b; b.mn[0] = mn.x; b.mn[1] = mn.y; b.mn[2] = mn.z; b.mx[0] = mx.x; b.mx[1] = mx.y; b.mx[2] = mx.z; ri_store(t, x, b);
+    } else { t.left[x] = childA[x - n]; t.right[x] = childB[x - n]; }
+}
+// one level of the breadth-first numbering: the children of level d's inner nodes are appended behind the cursor (one atomic per block); bounds[d], bounds[d + 1] delimit level d
+__global__ void __launch_bounds__(256) k_ri_bfs(RiTree t, uint* __restrict__ bfs, const uint* __restrict__ bounds, uint d, uint* __restrict__ cursor) {
+    __shared__ uint sCnt[4]; __shared__ uint sBase;
+    const uint start = bounds[d], end = bounds[d + 1u], wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint base = start + blockIdx.x * 256u; base < end; base += gridDim.x * 256u) {
+        const uint i = base + threadIdx.x; uint l = RI_NONE, r = RI_NONE;
+        if (i < end) { const uint id = bfs[i]; l = t.left[id]; r = t.right[id]; }
+        const bool has = l != RI_NONE;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+        if (lane == 0u) sCnt[wave] = 2u * (uint)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0u) { uint tot = 0; for (uint w = 0; w < 4u; w++) { const uint c = sCnt[w]; sCnt[w] = tot; tot += c; } sBase = tot ? atomicAdd(cursor, tot) : 0u; }
+        __syncthreads();
+        if (has) { const uint at = sBase + sCnt[wave] + 2u * (uint)__popcll(m & ((1ull << lane) - 1ull)); bfs[at] = l; bfs[at + 1u] = r; }
+        __syncthreads();
+    }
+}
+__global__ void k_ri_close(uint* __restrict__ bounds, uint d, const uint* __restrict__ cursor) { if (threadIdx.x == 0u && blockIdx.x == 0u) bounds[d + 2u] = *cursor; }      // level d + 1 ends where the cursor stands
+// boxes (and leaf counts) of one level's inner nodes from their children: launched from the deepest level up
+__global__ void __launch_bounds__(256) k_ri_refit(RiTree t, const uint* __restrict__ bfs, const uint* __restrict__ bounds, uint d, uint* __restrict__ cnt) {
+    const uint start = bounds[d], end = bounds[d + 1u];
+    for (uint i = start + blockIdx.x * 256u + threadIdx.x; i < end; i += gridDim.x * 256u) {
+        const uint id = bfs[i];
+        if (t.left[id] == RI_NONE) { if (cnt) cnt[id] = 1u; continue; }
+        ri_refit_node(t, id);
+        if (cnt) cnt[id] = cnt[t.left[id]] + cnt[t.right[id]];
+    }
+}
+__global__ void __launch_bounds__(256) k_ri_search(RiDevice r) {
+    const uint x = blockIdx.x * 256u + threadIdx.x; if (x >= r.t.N) return;
+    uint target, pivot; const float gain = ri_search(r.t, x, 0.0f, target, pivot);
+    bool propose = target != RI_NONE;
+    if (propose) propose = gain > 1e-6f * ri_area(ri_load(r.t, r.t.par[x]));
+    r.gain[x] = gain; r.target[x] = propose ? target : RI_NONE; r.pivot[x] = pivot; r.lock[x] = 0ull; r.moving[x] = 0ull; r.ok[x] = 0u;
+}
+__global__ void __launch_bounds__(256) k_ri_lock(RiDevice r) {
+    const uint x = blockIdx.x * 256u + threadIdx.x; if (x >= r.t.N || r.target[x] == RI_NONE) return;
+    const unsigned long long key = ri_key(r.gain[x], x);
+    (void)ri_for_links(r.t, x, r.target[x], [&](uint a) { atomicMax(&r.lock[a], key); return true; });
+}
+__global__ void __launch_bounds__(256) k_ri_check(RiDevice r) {
+    const uint x = blockIdx.x * 256u + threadIdx.x; if (x >= r.t.N || r.target[x] == RI_NONE) return;
+    const unsigned long long key = ri_key(r.gain[x], x);
+    if (ri_for_links(r.t, x, r.target[x], [&](uint a) { return r.lock[a] == key; })) { r.ok[x] = 1u; r.moving[x] = key; }
+}
+__global__ void __launch_bounds__(256) k_ri_ring(RiDevice r) {
+    const uint x = blockIdx.x * 256u + threadIdx.x; if (x >= r.t.N || r.ok[x] != 1u) return;
+    if (ri_gives_way(r.t, x, r.target[x], r.pivot[x], r.moving, ri_key(r.gain[x], x))) r.ok[x] = 2u;
+}
+__global__ void __launch_bounds__(256) k_ri_apply(RiDevice r, uint* __restrict__ applied) {
+    const uint x = blockIdx.x * 256u + threadIdx.x;
+    const bool go = x < r.t.N && r.ok[x] == 1u;
+    if (go) ri_apply(r.t, x, r.target[x]);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(go);
+    if (m && (threadIdx.x & 63u) == 0u) atomicAdd(applied, (uint)__popcll(m));
+}
+// back into the arrays k_ploc_first / k_ploc_finish read: children, parent with the "I am the right child" bit, leaf counts (written by the last refit)
+__global__ void __launch_bounds__(256) k_ri_export(RiTree t, uint n, uint* __restrict__ nodeParent, uint* __restrict__ childA, uint* __restrict__ childB) {
+    const uint x = blockIdx.x * 256u + threadIdx.x; if (x >= t.N) return;
+    if (x >= n) { childA[x - n] = t.left[x]; childB[x - n] = t.right[x]; }
+    const uint p = t.par[x];
+    nodeParent[x] = (p == RI_NONE) ? 0u : (p | ((t.right[p] == x) ? 0x80000000u : 0u));
+}
+// the breadth-first numbering of the whole tree; returns the number of levels (reads the level bounds back every 64 levels: a build step)
+static hipError_t ri_levels(const RiDevice& r, uint& levels, hipStream_t st) {
+    const uint N = r.t.N; const uint first[3] = {0u, 1u, 1u}; const uint root = N - 1u;
+    PT_HIP_TRY(hipMemcpyAsync(r.bfs, &root, 4, hipMemcpyHostToDevice, st)); PT_HIP_TRY(hipMemcpyAsync(r.bounds, first, 8, hipMemcpyHostToDevice, st)); PT_HIP_TRY(hipMemcpyAsync(r.cursor, &first[2], 4, hipMemcpyHostToDevice, st));
+    std::vector<uint> hb(RI_MAX_LEVELS + 2u);
+    for (uint d0 = 0; d0 < RI_MAX_LEVELS; d0 += 64u) {
+        for (uint d = d0; d < d0 + 64u; d++) {
+            hipLaunchKernelGGL(k_ri_bfs, dim3(1024), dim3(256), 0, st, r.t, r.bfs, r.bounds, d, r.cursor);
+            hipLaunchKernelGGL(k_ri_close, dim3(1), dim3(64), 0, st, r.bounds, d, r.cursor);
+        }
+        PT_HIP_TRY(hipMemcpyAsync(hb.data(), r.bounds, 4 * (size_t)(d0 + 66u), hipMemcpyDeviceToHost, st)); PT_HIP_TRY(hipStreamSynchronize(st));
+        for (uint d = d0; d < d0 + 64u; d++) if (hb[d + 1u] == hb[d]) { levels = d; return (hb[d] == N) ? hipSuccess : hipErrorUnknown; }      // an empty level: every node is numbered (or the tree is broken)
+    }
+    return hipErrorUnknown;
+}
+static void ri_refit_all(const RiDevice& r, uint levels, uint* cnt, hipStream_t st) {
+    for (uint d = levels; d-- > 0u;) hipLaunchKernelGGL(k_ri_refit, dim3(1024), dim3(256), 0, st, r.t, r.bfs, r.bounds, d, cnt);
+}
+static hipError_t bvh_reinsert(BvhBuildBuffers& b, uint n, uint passes, hipStream_t st) {
+    if (!b.riScratch || n < 64u) return hipSuccess;
+    const uint N = 2u * n - 1u; char* base = static_cast<char*>(b.riScratch); size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base + off; off += (bytes + 255u) & ~(size_t)255u; return p; };
+    RiDevice r;
+    r.t.N = N; r.t.par = (uint*)take(4ull * N); r.t.left = (uint*)take(4ull * N); r.t.right = (uint*)take(4ull * N); r.t.box = (float*)take(32ull * N);
+    r.gain = (float*)take(4ull * N); r.target = (uint*)take(4ull * N); r.pivot = (uint*)take(4ull * N); r.lock = (unsigned long long*)take(8ull * N); r.moving = (unsigned long long*)take(8ull * N);
+    r.ok = (uint*)take(4ull * N); r.bfs = (uint*)take(4ull * N); r.bounds = (uint*)take(4ull * (RI_MAX_LEVELS + 4u)); r.cursor = (uint*)take(256);
+    if (off > b.riScratchBytes) return hipErrorInvalidValue;
+    const uint g = (N + 255u) / 256u;
+    hipLaunchKernelGGL(k_ri_init, dim3(g), dim3(256), 0, st, n, b.plocParent, b.plocChildA, b.plocChildB, b.triWorld, b.primsSorted, r.t);
+    uint levels = 0; PT_HIP_TRY(ri_levels(r, levels, st));
+    ri_refit_all(r, levels, nullptr, st);
+    uint done = 0;
+    for (uint pass = 0; pass < passes; pass++) {
+        hipLaunchKernelGGL(k_ri_search, dim3(g), dim3(256), 0, st, r);
+        hipLaunchKernelGGL(k_ri_lock, dim3(g), dim3(256), 0, st, r);
+        hipLaunchKernelGGL(k_ri_check, dim3(g), dim3(256), 0, st, r);
+        hipLaunchKernelGGL(k_ri_ring, dim3(g), dim3(256), 0, st, r);
+        PT_HIP_TRY(hipMemsetAsync(r.cursor + 1, 0, 4, st));
+        hipLaunchKernelGGL(k_ri_apply, dim3(g), dim3(256), 0, st, r, r.cursor + 1);
+        PT_HIP_TRY(ri_levels(r, levels, st));                       // (also the check that the tree is still one tree: every node numbered exactly once)
+        ri_refit_all(r, levels, (pass + 1u == passes) ? b.plocCnt : nullptr, st);
+        done++;
+    }
+    if (!passes) ri_refit_all(r, levels, b.plocCnt, st);
+    hipLaunchKernelGGL(k_ri_export, dim3(g), dim3(256), 0, st, r.t, n, b.plocParent, b.plocChildA, b.plocChildB);
+    b.optimiserPasses = done; b.riLevels = levels;
     return hipGetLastError();
 }
 // "prefer fast trace": the topology comes from the host's binned-SAH build over the world-space triangles k_tri_setup has just written
@@ -576,11 +778,12 @@ hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStrea
     uint g = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, st, b.sceneBounds);
     hipLaunchKernelGGL(k_tri_setup, dim3(g), dim3(256), 0, st, sc, n, b.triWorld, b.sceneBounds);
-    b.hostBuildMs = 0.f; b.optimiserPasses = 0u;
+    b.hostBuildMs = 0.f; b.optimiserPasses = 0u; b.wideDpPending = 0u; b.wideFlagsValid = 0u;
     if (b.builder == BVH_BUILDER_SAH && n > 1) {
         if (bvh_sah(b, n, st) == hipSuccess) return bvh_bounds_and_emit(b, sc, n, st);
         (void)hipGetLastError(); b.builder = BVH_BUILDER_PLOC;      // no host memory / threads for the fast-trace topology: build it on the device instead
     }
+    b.wideDpPending = (b.builder == BVH_BUILDER_PLOC_OPT && n > 1) ? 1u : 0u; b.wideFlagsValid = 0u;
     hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, st, b.triWorld, n, b.sceneBounds, b.keys, b.prims);
     size_t tmp = b.sortTempBytes;
     PT_HIP_TRY(rocprim::radix_sort_pairs(b.sortTemp, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64, st));

@@ -44,3 +44,35 @@ def test_insertion_optimiser_lowers_the_surface_area_cost(checker):
     for mode in (0, 3):                          # uniform soup (binned SAH is already close: a fraction of a percent); boxes of many sizes piled on 27 centres (-18 %)
         plain, opt = run(0, mode), run(3, mode)
         assert opt < plain * (1.0 if mode == 0 else 0.9), (mode, plain, opt)
+
+
+@pytest.fixture(scope="module")
+def wide_checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("wide") / "bvh_wide_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(HERE, "bvh_wide_check.cpp"), os.path.join(ROOT, "rtxpt_amd", "csrc", "pt_build_sah.cpp"), "-o", exe], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("n,mode,seed", [(2, 0, 1), (3, 0, 1), (4, 0, 2), (5, 0, 1), (9, 0, 2), (33, 3, 3), (1000, 0, 3), (20000, 3, 4), (20000, 2, 5), (150000, 0, 6)])
+def test_device_wide_node_programme_marks_what_the_host_marks(wide_checker, n, mode, seed):
+    """rtxpt_amd/csrc/pt_build_wide.h — the per-node functions k_wide_dp / k_wide_mark run on the device, level by level over a breadth-first numbering — against the
+    host builder's choose_wide_nodes on the same topology: the same inner nodes are opened inside their parent's wide node."""
+    r = subprocess.run([wide_checker, str(n), str(mode), str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+@pytest.fixture(scope="module")
+def reinsert_checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("reinsert") / "bvh_reinsert_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(HERE, "bvh_reinsert_check.cpp"), "-o", exe], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("n,mode,passes,seed", [(2, 0, 2, 1), (3, 0, 2, 1), (5, 0, 3, 1), (64, 0, 4, 2), (1000, 0, 6, 3), (20000, 1, 6, 4), (20000, 2, 6, 5), (60000, 0, 8, 6)])
+def test_device_reinsertion_passes_keep_one_tree_and_lower_the_cost(reinsert_checker, n, mode, passes, seed):
+    """rtxpt_amd/csrc/pt_build_reinsert.h — the per-node functions of the device-side optimiser (parallel re-insertion after Meister & Bittner 2018), scheduled as
+    pt_build.hip schedules its kernels: after every pass the links form one tree with every node in it once, and the surface-area cost never rises."""
+    r = subprocess.run([reinsert_checker, str(n), str(mode), str(passes), str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+    before, after = (float(v) for v in r.stdout.split()[1:3])
+    assert after <= before and (n < 64 or after < 0.8 * before)

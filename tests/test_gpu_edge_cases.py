@@ -159,7 +159,7 @@ def test_degenerate_triangles_and_grazing_rays():
 
 
 def test_closest_hit_equals_exhaustive_loop_on_badly_conditioned_geometry():
-    """The HIP traversal (every builder: binned SAH on the host with the cost-driven wide-node assignment, PLOC, Karras) against the oracle's exhaustive loop on the sliver / grazing-ray stress set: identical hit records, i.e. the
+    """The HIP traversal (every builder: PLOC + parallel re-insertion + cost-driven wide nodes on the device, binned SAH on the host, plain PLOC, Karras) against the oracle's exhaustive loop on the sliver / grazing-ray stress set: identical hit records, i.e. the
     closest hit does not depend on the tree above the triangles (pt_scene.h tri_box_accepts)."""
     import rtxpt_amd as pt
     from rtxpt_amd import scenes
@@ -171,10 +171,13 @@ def test_closest_hit_equals_exhaustive_loop_on_badly_conditioned_geometry():
     want_brute = o.trace_closest(rays[:nb], brute=True)
     assert np.array_equal(want_bvh[:nb].view(np.uint32), want_brute.view(np.uint32))
     vis_o = o.trace_visibility(rays)
-    for builder in ("sah", "ploc", "karras", "flag"):          # sah: the default (prefer fast trace); flag: PT_DEVICE_PREFER_FAST_BUILD selects PLOC through the ABI
-        if builder != "flag": os.environ["MI355PT_BVH_BUILDER"] = builder
+    for builder in ("default", "sah", "ploc", "karras", "flag", "hostflag"):          # default: PLOC + parallel re-insertion + cost-driven wide nodes on the device (prefer fast trace); sah: round 2's host builder; flag / hostflag: PT_DEVICE_PREFER_FAST_BUILD / PT_DEVICE_HOST_SAH_BUILDER through the ABI
+        if builder not in ("flag", "hostflag", "default"): os.environ["MI355PT_BVH_BUILDER"] = builder
         try:
-            g = pt.PathTracer(prefer_fast_build=(builder == "flag")); g.set_scene(sc); g.set_settings(scenes.default_settings())
+            g = pt.PathTracer(prefer_fast_build=(builder == "flag"), host_sah_builder=(builder == "hostflag")); g.set_scene(sc); g.set_settings(scenes.default_settings())
+            info = g.bvh_info()
+            assert info["builder"] == {"default": 3, "sah": 2, "ploc": 0, "karras": 1, "flag": 0, "hostflag": 2}[builder] and info["builtOn"] == ("host" if builder in ("sah", "hostflag") else "device")
+            if builder == "default": assert info["optimiserPasses"] == 12
             got, _ = g.trace_closest(rays)
             vis_g, _ = g.trace_visibility(rays)
         finally:

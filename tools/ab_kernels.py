@@ -18,12 +18,13 @@ for _ in range(3):
 rays = st["extendRays"] + st["shadowRays"]
 g.set_serial_kernels(True); g.reset_accumulation(); g.render(0, SPP); g.reset_accumulation(); os.environ["MI355PT_PASS_LOG"] = "1"; s = g.render(0, SPP); del os.environ["MI355PT_PASS_LOG"]
 chk = float(np.float64(g.radiance()[..., :3]).sum())
-print("frame %%.2f ms %%.1f Mrays/s | serial: frame %%.2f extend %%.2f shade %%.2f shadow %%.2f | checksum %%.6f" %% (min(ms), rays / min(ms) / 1e3, s["gpuMilliseconds"], s["extendKernelMs"], s["shadeKernelMs"], s["shadowKernelMs"], chk))
+bi = g.bvh_info()
+print("frame %%.2f ms %%.1f Mrays/s | serial: frame %%.2f extend %%.2f shade %%.2f shadow %%.2f | checksum %%.6f | %%s on %%s, build %%.1f ms (host %%.1f), %%d wide nodes" %% (min(ms), rays / min(ms) / 1e3, s["gpuMilliseconds"], s["extendKernelMs"], s["shadeKernelMs"], s["shadowKernelMs"], chk, bi["builderName"], bi["builtOn"], bi["buildMs"], bi["hostMs"], bi["numWideNodes"]))
 ''' % ROOT
 libs = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "gpurun_ab", "lib_*.so")))
 for lib in libs:
     r = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, MI355PT_LIB=os.path.abspath(lib)), capture_output=True, text=True)
     out = [l for l in r.stdout.splitlines() if l.startswith("frame")]
-    print("%-28s %s" % (os.path.basename(lib), out[-1] if out else ("FAILED: " + r.stderr[-300:])), flush=True)
+    print("%-28s %s%s" % (os.path.basename(lib), (os.environ.get("AB_LABEL", "") + " ") if os.environ.get("AB_LABEL") else "", out[-1] if out else ("FAILED: " + r.stderr[-300:])), flush=True)
     if os.environ.get("AB_PASSES"):
         for l in [l for l in r.stderr.splitlines() if l.startswith("[pass log]   ")][:int(os.environ["AB_PASSES"])]: print("      " + l[13:], flush=True)

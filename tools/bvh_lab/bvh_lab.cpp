@@ -15,6 +15,7 @@
 #include <vector>
 #include <omp.h>
 #include "../../rtxpt_amd/csrc/pt_build_sah.h"      // LAB_PRODUCT: the product's host builder (link rtxpt_amd/csrc/pt_build_sah.cpp)
+#include "../../rtxpt_amd/csrc/pt_build_reinsert.h" // LAB_PARALLEL_REINS: the product's device-side optimiser, run on the CPU
 
 struct V3 { float x, y, z; };
 static inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -299,6 +300,41 @@ static void optimize_reinsert(Bvh2& b, int passes, float fraction) {
 }
 
 
+// ---- the device-side optimiser (pt_build_reinsert.h: search / lock / check / apply over all nodes) run pass by pass on the CPU, exactly as k_reinsert_* run it
+static void optimize_parallel_reinsert(Bvh2& b, int passes, float fraction) {
+    const uint N = (uint)b.nodes.size();
+    std::vector<uint> par(N, ptk::RI_NONE), left(N, ptk::RI_NONE), right(N, ptk::RI_NONE); std::vector<float> box(8 * (size_t)N, 0.f);
+    for (uint i = 0; i < N; i++) { const Node& nd = b.nodes[i]; if (!nd.count) { left[i] = (uint)nd.l; right[i] = (uint)nd.r; par[nd.l] = i; par[nd.r] = i; }
+        float* q = &box[8 * (size_t)i]; q[0] = nd.box.mn.x; q[1] = nd.box.mn.y; q[2] = nd.box.mn.z; q[4] = nd.box.mx.x; q[5] = nd.box.mx.y; q[6] = nd.box.mx.z; }
+    ptk::RiTree t{par.data(), left.data(), right.data(), box.data(), N};
+    std::vector<float> gain(N); std::vector<uint> target(N), pivot(N); std::vector<unsigned long long> lock(N); std::vector<unsigned char> ok(N);
+    for (int pass = 0; pass < passes; pass++) {
+        float thr = 0.f;
+        if (fraction < 1.f) { std::vector<float> pa; pa.reserve(N); for (uint i = 0; i < N; i++) { uint p = par[i]; if (p != ptk::RI_NONE && par[p] != ptk::RI_NONE) pa.push_back(ptk::ri_area(ptk::ri_load(t, p))); }
+            size_t k = (size_t)(pa.size() * fraction); if (k < 1) k = 1; std::nth_element(pa.begin(), pa.begin() + (k - 1), pa.end(), [](float a, float c) { return a > c; }); thr = pa[k - 1]; }
+        unsigned long long steps = 0, maxSteps = 0; size_t proposed = 0, applied = 0;
+        #pragma omp parallel for schedule(dynamic, 4096) reduction(+:steps, proposed) reduction(max:maxSteps)
+        for (uint x = 0; x < N; x++) { uint st = 0; gain[x] = ptk::ri_search(t, x, thr, target[x], pivot[x], &st); steps += st; if (st > maxSteps) maxSteps = st;
+            if (!(gain[x] > 1e-6f * ptk::ri_area(ptk::ri_load(t, par[x] == ptk::RI_NONE ? x : par[x])))) target[x] = ptk::RI_NONE; else proposed++; }
+        std::fill(lock.begin(), lock.end(), 0ull);
+        for (uint x = 0; x < N; x++) if (target[x] != ptk::RI_NONE) { const unsigned long long key = ptk::ri_key(gain[x], x); ptk::ri_for_links(t, x, target[x], [&](uint a) { if (lock[a] < key) lock[a] = key; return true; }); }
+        std::vector<unsigned long long> moving(N, 0ull);
+        for (uint x = 0; x < N; x++) { ok[x] = 0; if (target[x] != ptk::RI_NONE) { const unsigned long long key = ptk::ri_key(gain[x], x); ok[x] = ptk::ri_for_links(t, x, target[x], [&](uint a) { return lock[a] == key; }) ? 1 : 0; if (ok[x]) moving[x] = key; } }
+        size_t gaveWay = 0;
+        for (uint x = 0; x < N; x++) if (ok[x] && ptk::ri_gives_way(t, x, target[x], pivot[x], moving.data(), ptk::ri_key(gain[x], x))) { ok[x] = 2; gaveWay++; }
+        for (uint x = 0; x < N; x++) if (ok[x] == 1) { ptk::ri_apply(t, x, target[x]); applied++; }
+        { // refit everything bottom-up (levels of a breadth-first numbering, deepest first) and check that the tree is still one tree
+          std::vector<uint> bfs{(uint)b.root}; for (size_t k = 0; k < bfs.size(); k++) { uint id = bfs[k]; if (left[id] != ptk::RI_NONE) { bfs.push_back(left[id]); bfs.push_back(right[id]); } }
+          if (bfs.size() != N) { fprintf(stderr, "TREE BROKEN: %zu of %u nodes reachable\n", bfs.size(), N); exit(1); }
+          for (size_t k = bfs.size(); k-- > 0;) if (left[bfs[k]] != ptk::RI_NONE) ptk::ri_refit_node(t, bfs[k]); }
+        (void)gaveWay;
+        double c = 0; for (uint i = 0; i < N; i++) if (left[i] != ptk::RI_NONE) c += ptk::ri_area(ptk::ri_load(t, i));
+        fprintf(stderr, "  parallel reinsertion pass %d: %zu proposed, %zu applied, %.1f search steps per node (max %llu), inner area / root area %.2f\n", pass, proposed, applied, (double)steps / N, maxSteps, c / ptk::ri_area(ptk::ri_load(t, (uint)b.root)));
+    }
+    for (uint i = 0; i < N; i++) { Node& nd = b.nodes[i]; if (!nd.count) { nd.l = (int)left[i]; nd.r = (int)right[i]; } const float* q = &box[8 * (size_t)i]; nd.box.mn = {q[0], q[1], q[2]}; nd.box.mx = {q[4], q[5], q[6]}; }
+    renumber_dfs(b);
+}
+
 // the product's "prefer fast trace" topology (pt_build_sah.cpp) as a lab tree
 static Bvh2 build_product() {
     int n = (int)tris.size(); std::vector<ptk::SahTri> t(n);
@@ -472,6 +508,8 @@ int main(int argc, char** argv) {
     if (getenv("LAB_PRODUCT")) { Bvh2 s = build_product(); eval("product builder cost-driven leaf4", s, 4, 1); }
     if (getenv("LAB_REINS")) { Bvh2 s = build_sah(32); eval("binned sah cost-driven leaf4", s, 4, 1);
         for (int it = 0; it < 3; it++) { optimize_reinsert(s, 2, 0.25f); char nm[64]; snprintf(nm, 64, "sah + reinsertion x%d cost leaf4", 2 * (it + 1)); eval(nm, s, 4, 1); } }
+    if (getenv("LAB_PARALLEL_REINS")) { Bvh2 s = build_ploc(32); eval("ploc r=32 cost-driven leaf4", s, 4, 1); const float frac = getenv("LAB_FRACTION") ? (float)atof(getenv("LAB_FRACTION")) : 1.0f;
+        for (int it = 0; it < (getenv("LAB_ROUNDS") ? atoi(getenv("LAB_ROUNDS")) : 4); it++) { optimize_parallel_reinsert(s, 2, frac); char nm[64]; snprintf(nm, 64, "ploc + parallel reinsertion x%d", 2 * (it + 1)); eval(nm, s, 4, 1); } }
     if (getenv("LAB_SBVH_REINS")) { Bvh2 s = build_sbvh(32, 1e-5f, 1.5f); eval("sbvh cost-driven leaf4", s, 4, 1); optimize_reinsert(s, 2, 0.25f); eval("sbvh + reinsertion x2 cost leaf4", s, 4, 1); }
     if (getenv("LAB_SBVH")) for (float al : {1e-5f, 1e-6f}) { Bvh2 s = build_sbvh(32, al, 1.5f); char nm[64]; snprintf(nm, 64, "sbvh a=%g cost-driven leaf4", al); eval(nm, s, 4, 1); }
     return 0;
