@@ -81,7 +81,7 @@ struct pt_context {
     // device
     DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
-    DevBuf<ptk::AlphaPlane> dAlphaPlanes; DevBuf<unsigned char> dAlphaPool; DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::MatTexRef> dMatTex; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
+    DevBuf<ptk::AlphaPlane> dAlphaPlanes; DevBuf<unsigned char> dAlphaPool; DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
     DevBuf<ptk::uint2> dEnvCube, dEnvCubeSource; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights; uint envCompression = 0;      // envCompression: EnvMapBaker's BC6U compression (0 off, 1 fast)
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
@@ -91,7 +91,7 @@ struct pt_context {
     // frame state
     ptk::PtSettings S; ptk::PathTracerCameraData cam; uint width = 0, height = 0, accumCount = 0; std::vector<uint> owned; std::vector<std::vector<uint>> shardPixels;
     std::vector<float> hostRadiance; bool countersEnabled = false;
-    bool geomDirty = true, lightsDirty = true, texDirty = true, matTexDirty = true;
+    bool geomDirty = true, lightsDirty = true, texDirty = true;
     double buildMs = 0, refitMs = 0, lightBakeMs = 0;
     uint poolCapacity = 0; size_t shadowCapacity = 0;
     // frame gather (pt_comm_init / pt_gather)
@@ -216,26 +216,6 @@ int upload_textures(pt_context* c) {
     return PT_OK;
 }
 
-// MatTexRef (pt_scene.h): size, level count and pool offset of the five texture slots of every material; follows the texture pool and the material table
-int build_mat_tex(pt_context* c) {
-    std::vector<ptk::MatTexRef> refs(std::max<size_t>(1, c->materials.size() * 5u));
-    memset(refs.data(), 0, sizeof(ptk::MatTexRef) * refs.size());
-    for (size_t m = 0; m < c->materials.size(); m++) {
-        const ptk::PTMaterialData& mm = c->materials[m];
-        const uint words[5] = {mm.BaseOrDiffuseTextureIndex, mm.EmissiveTextureIndex, mm.NormalTextureIndex, mm.MetalRoughOrSpecularTextureIndex, mm.TransmissionTextureIndex};
-        const uint flags[5] = {PTMaterialFlags_UseBaseOrDiffuseTexture, PTMaterialFlags_UseEmissiveTexture, PTMaterialFlags_UseNormalTexture, PTMaterialFlags_UseMetalRoughOrSpecularTexture, PTMaterialFlags_UseTransmissionTexture};
-        for (int k = 0; k < 5; k++) {
-            ptk::MatTexRef& r = refs[m * 5u + k]; r.wh = 1u | (1u << 16); r.mipLevels = 1u; r.base = 0u;      // a slot the material does not use: a 1 x 1 texture at texel 0 (never filtered)
-            const uint ti = words[k] & 0xFFFFu;
-            if (!(mm.Flags & flags[k]) || ti >= c->texInfos.size()) continue;
-            const TexInfo& t = c->texInfos[ti];
-            if (t.base + t.mipOffset[0] > 0xFFFFFFFFull) return fail(c, PT_ERROR_UNSUPPORTED, "texture pool above 2^32 texels (64 GB) is not supported");
-            r.wh = (t.w & 0xFFFFu) | (t.h << 16); r.mipLevels = t.mipLevels; r.base = (uint)(t.base + t.mipOffset[0]);
-        }
-    }
-    PT_CHECK_HIP(c, c->dMatTex.upload(refs, c->stream));
-    return PT_OK;
-}
 void refresh_scene_view(pt_context* c) {
     DeviceScene& d = c->dsc;
     d.travSpill = c->dTravSpill.p;                           // allocated (and checked) by finalize_geometry
@@ -248,7 +228,7 @@ void refresh_scene_view(pt_context* c) {
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
     d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
-    d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.alphaPlanes = c->dAlphaPlanes.p; d.alphaPool = c->dAlphaPool.p; d.shadeTris = c->dShadeTris.p; d.matTex = c->dMatTex.p; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
+    d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.alphaPlanes = c->dAlphaPlanes.p; d.alphaPool = c->dAlphaPool.p; d.shadeTris = c->dShadeTris.p; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
 }
 
 // SubInstanceData fill (Rtxpt/Materials/MaterialsBaker.cpp:960-1017) + primitive table; then GPU LBVH build
@@ -480,11 +460,9 @@ int bake_env_cube(pt_context* c) {
     return PT_OK;
 }
 int prepare(pt_context* c) {
-    if (c->texDirty) { int r = upload_textures(c); if (r != PT_OK) return r; refresh_scene_view(c); c->lightsDirty = true; c->envCubeDirty = true; c->matTexDirty = true; }
+    if (c->texDirty) { int r = upload_textures(c); if (r != PT_OK) return r; refresh_scene_view(c); c->lightsDirty = true; c->envCubeDirty = true; }
     if (c->envEnabled && c->envCubeDirty) { int r = bake_env_cube(c); if (r != PT_OK) return r; }
-    const bool tablesChanged = c->geomDirty || c->matTexDirty;
     if (c->geomDirty) { int r = finalize_geometry(c); if (r != PT_OK) return r; }
-    if (tablesChanged) { int r = build_mat_tex(c); if (r != PT_OK) return r; c->matTexDirty = false; refresh_scene_view(c); }
     if (c->lightsDirty) { int r = bake_lights(c); if (r != PT_OK) return r; }
     return PT_OK;
 }
@@ -542,7 +520,7 @@ int32_t pt_destroy(pt_context* c) {
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
-    c->dPrimInfo.free(); c->dShadeTris.free(); c->dMatTex.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
+    c->dPrimInfo.free(); c->dShadeTris.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);

@@ -18,12 +18,6 @@
 #ifndef PT_SHADE_TRI
 #define PT_SHADE_TRI 1          // 1: loadSurface reads the flat 128-byte ShadeTri record of the hit primitive; 0: the five-hop gather through primInfo / sub-instance / geometry / index / vertex streams
 #endif
-#ifndef PT_TEX_BATCH
-#define PT_TEX_BATCH 0          // 1: loadSurface requests the texels of the material's base / normal / metal-rough slots together (pt_scene.h tex_gather_*), 0: slot after slot
-#endif
-#ifndef PT_NEE_PREFETCH
-#define PT_NEE_PREFETCH 0       // 1: GenerateLightSample requests the light data of the next two candidates before it evaluates the current one
-#endif
 #ifndef PT_SHADE_NOINLINE
 #define PT_SHADE_NOINLINE
 #endif
@@ -347,44 +341,9 @@ template <bool LP16> struct PathKernelContextT {
         float4 texBase = make_float4(1, 1, 1, 1), texEmissive = make_float4(1, 1, 1, 1), texNormal = make_float4(0.5f, 0.5f, 1.0f, 0.f),
                texMR = make_float4(1, 1, 1, 1), texTrans = make_float4(1, 1, 1, 1);
         bool hasUV = (g.flags & GEOM_HAS_UV) != 0;
-#if PT_TEX_BATCH
-        // Every texture slot of the material in one round trip: the slots' sizes and pool offsets (MatTexRef) arrive with the material, all addresses are formed, all
-        // texels requested, then filtered — instead of TexInfo -> mip texels -> next mip texels per slot, slot after slot (up to 15 dependent round trips per hit).
-        // The common slots (base colour, normal, metal-rough / specular) are gathered together; the rare ones (emissive, transmission) keep the plain path.
-        {
-            const MatTexRef* mt = sc.matTex + materialIndex * 5u;
-            const bool eB = hasUV && (mflags & PTMaterialFlags_UseBaseOrDiffuseTexture), eN = hasUV && (mflags & PTMaterialFlags_UseNormalTexture),
-                       eM = hasUV && (mflags & PTMaterialFlags_UseMetalRoughOrSpecularTexture);
-            const TexGather gB = tex_gather_prepare(mt[0], material.BaseOrDiffuseTextureIndex, lambda, texcoord, eB);
-            const TexGather gN = tex_gather_prepare(mt[2], material.NormalTextureIndex, lambda, texcoord, eN);
-            const TexGather gM = tex_gather_prepare(mt[3], material.MetalRoughOrSpecularTextureIndex, lambda, texcoord, eM);
-#if PT_TEX_BATCH == 2      // level by level: the finer level of all three slots in flight, then the coarser one (half the registers, two round trips)
-            float4 tB[4], tN[4], tM[4];
-            for (int k = 0; k < 4; k++) tB[k] = sc.texels[gB.o[k]];
-            for (int k = 0; k < 4; k++) tN[k] = sc.texels[gN.o[k]];
-            for (int k = 0; k < 4; k++) tM[k] = sc.texels[gM.o[k]];
-            const float4 aB = tex_gather_level(tB, gB.ax0, gB.ay0), aN = tex_gather_level(tN, gN.ax0, gN.ay0), aM = tex_gather_level(tM, gM.ax0, gM.ay0);
-            for (int k = 0; k < 4; k++) tB[k] = sc.texels[gB.o[4 + k]];
-            for (int k = 0; k < 4; k++) tN[k] = sc.texels[gN.o[4 + k]];
-            for (int k = 0; k < 4; k++) tM[k] = sc.texels[gM.o[4 + k]];
-            if (eB) texBase = gB.two ? lerp4(aB, tex_gather_level(tB, gB.ax1, gB.ay1), gB.f) : aB;
-            if (eN) texNormal = gN.two ? lerp4(aN, tex_gather_level(tN, gN.ax1, gN.ay1), gN.f) : aN;
-            if (eM) texMR = gM.two ? lerp4(aM, tex_gather_level(tM, gM.ax1, gM.ay1), gM.f) : aM;
-#else
-            float4 tB[8], tN[8], tM[8];
-            for (int k = 0; k < 8; k++) tB[k] = sc.texels[gB.o[k]];
-            for (int k = 0; k < 8; k++) tN[k] = sc.texels[gN.o[k]];
-            for (int k = 0; k < 8; k++) tM[k] = sc.texels[gM.o[k]];
-            if (eB) texBase = tex_gather_finish(gB, tB);
-            if (eN) texNormal = tex_gather_finish(gN, tN);
-            if (eM) texMR = tex_gather_finish(gM, tM);
-#endif
-        }
-#else
         if (hasUV && (mflags & PTMaterialFlags_UseBaseOrDiffuseTexture)) texBase = sampleTexture(material.BaseOrDiffuseTextureIndex, lambda, texcoord);
         if (hasUV && (mflags & PTMaterialFlags_UseNormalTexture)) texNormal = sampleTexture(material.NormalTextureIndex, lambda, texcoord);
         if (hasUV && (mflags & PTMaterialFlags_UseMetalRoughOrSpecularTexture)) texMR = sampleTexture(material.MetalRoughOrSpecularTextureIndex, lambda, texcoord);
-#endif
         if (hasUV && (mflags & PTMaterialFlags_UseEmissiveTexture)) texEmissive = sampleTexture(material.EmissiveTextureIndex, lambda, texcoord);
         if (hasUV && (mflags & PTMaterialFlags_UseTransmissionTexture)) texTrans = sampleTexture(material.TransmissionTextureIndex, lambda, texcoord);
 
@@ -561,39 +520,11 @@ template <bool LP16> struct PathKernelContextT {
     LightSample GenerateLightSample(const LightSampler& lightSampler, const ShadingData& sd, const StandardBSDF& bsdf, uint candidateSampleCount, UniformSampleSequenceGenerator& sg) const {
         LightSample cand; __builtin_memset(&cand, 0, sizeof(cand));
         float weightSum = 0, candWeight = 0;
-#if PT_NEE_PREFETCH
-        // The light of candidate i is two dependent gathers away (sampling proxy -> light record + proxy counter), and the candidates only depend on the hash chain
-        // of the sample generator, not on one another: the proxy of candidate i + 2 and the record of candidate i + 1 are requested before candidate i is evaluated,
-        // so their latency hides behind its arithmetic. Same draws, same table entries, same operations as the plain loop below.
-        const LightTable& LT = *lightSampler.T; const uint total = LT.SamplingProxyCount;
-        auto proxyOf = [&](uint state) -> uint {                  // LightSampler::SampleGlobal's table lookup for the draw that follows `state`
-            uint bits = Hash32(state); float r = (float)(bits >> 8) / 16777216.0f;
-            uint idx = (uint)(r * (float)total); if (idx > total - 1) idx = total - 1;
-            return LT.ProxyIndices[idx];
-        };
-        auto skipCandidate = [](uint s) -> uint { return Hash32(Hash32(Hash32(Hash32(s)))); };      // a candidate draws four numbers: light, 2 x position, reservoir
-        uint ahead = sg.m_currentHash;
-        uint liNext = candidateSampleCount > 0 ? proxyOf(ahead) : 0u; ahead = skipCandidate(ahead);
-        uint liNext2 = candidateSampleCount > 1 ? proxyOf(ahead) : 0u; ahead = skipCandidate(ahead);
-        PolymorphicLightInfo baseNext; __builtin_memset(&baseNext, 0, sizeof(baseNext)); uint ctrNext = 0u;
-        if (candidateSampleCount > 0) { baseNext = LT.Lights[liNext]; ctrNext = LT.ProxyCounters[liNext]; }
-#endif
         for (uint i = 0; i < candidateSampleCount; i++) {
             float selectionPdf = 0;
             float rnd = sampleNext1D(sg);
-#if PT_NEE_PREFETCH
-            (void)rnd;
-            const uint lightIndex = liNext; const uint ctr = ctrNext;
-            PolymorphicLightInfoFull li; li.Base = baseNext; __builtin_memset(&li.Extended, 0, sizeof(li.Extended));
-            liNext = liNext2;
-            if (i + 1 < candidateSampleCount) { baseNext = LT.Lights[liNext]; ctrNext = LT.ProxyCounters[liNext]; }
-            if (i + 2 < candidateSampleCount) { liNext2 = proxyOf(ahead); ahead = skipCandidate(ahead); }
-            selectionPdf = (float)ctr / (float)total;
-            if (li.Base.HasLightShaping()) li.Extended = LT.LightsEx[lightIndex];
-#else
             uint lightIndex = lightSampler.SampleGlobal(rnd, selectionPdf);
             PolymorphicLightInfoFull li = lightSampler.LoadLight(lightIndex);
-#endif
             float2 interior = sampleNext2D(sg);
             PolymorphicLightSample ls = PolymorphicLight_CalcSample(li, interior, sd.posW, sc.envToWorld);
             LightSample c;

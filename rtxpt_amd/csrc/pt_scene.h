@@ -94,12 +94,6 @@ struct AlphaPlane { uint wh, offset, fmt, _pad; };
 
 struct TexInfo { uint w, h, mipLevels, _pad; unsigned long long base; uint mipOffset[16]; };   // offsets in texels relative to base
 
-// What sample_trilinear needs of a material's five texture slots (base, emissive, normal, metal-rough / specular, transmission), 16 B per slot, addressed by
-// the MATERIAL index: it arrives in the same round trip as the material itself, so the texel addresses of all slots can be formed — and all texels requested — at
-// once, instead of TexInfo -> mip 0 texels -> mip 1 texels per slot, one slot after the other. Mip offsets are recomputed (a sum over the levels above).
-struct MatTexRef { uint wh; uint mipLevels; uint base; uint _pad; };      // wh = w | h << 16 (sides up to 32768), base = first texel of mip 0 in the pool (the pool is limited to 2^32 texels = 64 GB)
-static_assert(sizeof(MatTexRef) == 16, "MatTexRef must be 16 bytes");
-
 // Flat shading record, one 128 B line per global primitive (instance triangle): everything Bridge::loadSurface gathers through
 // primInfo -> subInstToInstGeom -> {instance, subInstance, geometry} -> indices -> 4 vertex streams (five dependent hops, ~20 scattered loads) sits in
 // one line that the hit's primitive id addresses directly, so all of it is in flight at once. The vertex data stay in OBJECT space and the instance is
@@ -129,7 +123,6 @@ struct DeviceScene {
     const AlphaRec* alphaRecs; // one per TriRecord slot (leaf order)
     const AlphaPlane* alphaPlanes; const unsigned char* alphaPool;      // per texture (pt_api.hip upload_textures); read by k_alpha_records and the traversal's alpha test
     const ShadeTri* shadeTris; // one per global primitive id (pt_build.hip k_shade_tris)
-    const MatTexRef* matTex;   // five per material (pt_api.hip build_mat_tex)
     uint2* travSpill;          // T8_MAX_BLOCKS x T8_GROUPS_PER_BLOCK x T8_SPILL_DEPTH stack-tail entries
 };
 
@@ -174,53 +167,6 @@ static inline float4 sample_trilinear(const DeviceScene& sc, const TexInfo& t, f
     if (f == 0.0f || m1 == m0) return a;
     float4 b = sample_bilinear(sc, t, m1, uv);
     return lerp4(a, b, f);
-}
-// ---- the same trilinear sample in three steps, so that a caller can prepare several samples, request all their texels, and only then filter (k_shade: every
-// texture slot of a material in one round trip). tex_gather_prepare + the eight loads + tex_gather_finish perform exactly the operations of sample_trilinear /
-// sample_bilinear / tex_texel on exactly the same operands; a disabled slot reads texel 0 of the pool eight times and its result is discarded.
-struct TexGather { uint o[8]; float ax0, ay0, ax1, ay1, f; bool two; };      // o: texel indices into the pool
-static inline uint tex_mip_offset(uint w, uint h, uint mip) {      // upload_textures' running sum: mip l holds max(1, w >> l) x max(1, h >> l) texels
-    uint off = 0;
-    for (uint l = 0; l < mip; l++) { uint mw = w >> l, mh = h >> l; off += (mw < 1u ? 1u : mw) * (mh < 1u ? 1u : mh); }
-    return off;
-}
-static inline void tex_gather_bilinear(uint w, uint h, uint base, uint mip, float2 uv, uint* o, float& ax, float& ay) {
-    uint mw = w >> mip; if (mw < 1u) mw = 1u;
-    uint mh = h >> mip; if (mh < 1u) mh = 1u;
-    float fx = uv.x * (float)mw - 0.5f, fy = uv.y * (float)mh - 0.5f;
-    float flx = floorf(fx), fly = floorf(fy);
-    ax = fx - flx; ay = fy - fly;
-    flx = flx - floorf(flx / (float)mw) * (float)mw; fly = fly - floorf(fly / (float)mh) * (float)mh;
-    int x0 = (int)flx, y0 = (int)fly;
-    auto wrapx = [&](int x) { int xi = x; if (xi < 0) xi += (int)mw; else if (xi >= (int)mw) xi -= (int)mw; return xi < 0 ? 0 : (xi >= (int)mw ? (int)mw - 1 : xi); };
-    auto wrapy = [&](int y) { int yi = y; if (yi < 0) yi += (int)mh; else if (yi >= (int)mh) yi -= (int)mh; return yi < 0 ? 0 : (yi >= (int)mh ? (int)mh - 1 : yi); };
-    const uint m = base + tex_mip_offset(w, h, mip);
-    const uint xa = (uint)wrapx(x0), xb = (uint)wrapx(x0 + 1), ya = (uint)wrapy(y0), yb = (uint)wrapy(y0 + 1);
-    o[0] = m + ya * mw + xa; o[1] = m + ya * mw + xb;
-    o[2] = m + yb * mw + xa; o[3] = m + yb * mw + xb;
-}
-static inline TexGather tex_gather_prepare(const MatTexRef& t, uint textureIndexAndInfo, float lambdaNoDims, float2 uv, bool enabled) {
-    TexGather g;
-    const uint w = t.wh & 0xFFFFu, h = t.wh >> 16;
-    const uint baseLOD = textureIndexAndInfo >> 24, wordMips = (textureIndexAndInfo >> 16) & 0xFFu;
-    float lambda = 0.5f * (float)baseLOD + lambdaNoDims;                      // sampleTexture (BridgeDonut:270-278)
-    lambda = fminf_(lambda, fmaxf_((float)wordMips - 5.0f, 0.0f));
-    float maxl = (float)(t.mipLevels - 1);                                     // sample_trilinear
-    float l = clampf(lambda, 0.0f, maxl);
-    float l0 = floorf(l);
-    uint m0 = (uint)l0, m1 = m0 + 1; if (m1 > t.mipLevels - 1) m1 = t.mipLevels - 1;
-    g.f = l - l0; g.two = !(g.f == 0.0f || m1 == m0);
-    tex_gather_bilinear(w, h, t.base, m0, uv, g.o, g.ax0, g.ay0);
-    tex_gather_bilinear(w, h, t.base, m1, uv, g.o + 4, g.ax1, g.ay1);
-    if (!enabled) for (int k = 0; k < 8; k++) g.o[k] = 0u;
-    return g;
-}
-static inline float4 tex_gather_level(const float4* t, float ax, float ay) { return lerp4(lerp4(t[0], t[1], ax), lerp4(t[2], t[3], ax), ay); }      // one level's bilinear filter
-static inline float4 tex_gather_finish(const TexGather& g, const float4* t) {
-    float4 a = lerp4(lerp4(t[0], t[1], g.ax0), lerp4(t[2], t[3], g.ax0), g.ay0);
-    if (!g.two) return a;
-    float4 b = lerp4(lerp4(t[4], t[5], g.ax1), lerp4(t[6], t[7], g.ax1), g.ay1);
-    return lerp4(a, b, g.f);
 }
 // SampleSource (EnvMapBaker.hlsl:98-110): the equirectangular source through a linear sampler (wrap in u, clamp in v), mip 0
 static inline float3 env_sample_source(const DeviceScene& sc, float3 direction) {
