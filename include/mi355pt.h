@@ -261,8 +261,10 @@ int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo*
      (a document replaces the glTF material as a whole; SkipRender removes the geometries, EnableAlphaTesting / ExcludeFromNEE set their flags).
    The file format of the graph itself and the light / camera keys belong to Donut (donut/engine/Scene.cpp, SceneGraph.cpp), which the reference
    tree does not vendor: they are restated from Donut's published sources. DirectionalLight leaves are returned by pt_scene_import_directional_lights. Not imported: animations,
-   glTF-embedded cameras / lights, analytic-light proxies (counted in info), textures other than PNG, JPEG and .dds files (counted in texturesNotLoaded, the
-   material then renders untextured as when the reference fails to load one). The environment map is reported (envPath), not loaded: pt_image_read_float reads .exr / .hdr files for pt_set_environment (.dds is not read). NOTE: of
+   glTF-embedded cameras / lights, textures other than PNG, JPEG and .dds files (counted in texturesNotLoaded, the
+   material then renders untextured as when the reference fails to load one). A point / spot light's "proxyMeshNodes" (ExtendedScene.cpp:46, 246-263) are resolved
+   as Donut's SceneGraph::FindNode resolves them — '/'-separated node names from the root, a model's own root node named after its file — and the mesh instances at those
+   nodes come out with analyticProxyLight set (LightsBaker.cpp:718-753). The environment map is reported (envPath), not loaded: pt_image_read_float reads .exr / .hdr files for pt_set_environment (.dds is not read). NOTE: of
    an EnvironmentLight the reference application consumes only `path` (Sample.cpp:552-553); radianceScale / rotation / textureIndex are read by
    EnvironmentLight::Load but never used — tint, intensity and rotation of the environment come from the UI block (EnvironmentMapRuntimeParameters,
    reset to identity on every scene load, Sample.cpp:554, 1936-1948). They are reported for completeness; to match the reference do not apply them. */
@@ -282,6 +284,7 @@ typedef struct PtSceneJsonInfo {
     uint32_t settingsMask;                  /* bit i: key i of SampleSettings::Load present (realtimeMode, enableAnimations, startingCamera, realtimeFireflyFilter, maxBounces, maxDiffuseBounces, textureMIPBias) */
     uint32_t realtimeMode, enableAnimations; int32_t startingCamera; float realtimeFireflyFilter; int32_t maxBounces, maxDiffuseBounces; float textureMIPBias;
     int32_t  selectedCamera;                /* startingCamera when present and valid, else the last camera (Sample.cpp:590-603, 618-619); -1 without cameras */
+    uint32_t lightProxiesResolved;          /* mesh instances linked to the point / spot light that names their node in "proxyMeshNodes" (PtInstanceDesc.analyticProxyLight) */
 } PtSceneJsonInfo;
 /* mediaPath: the folder that holds "Materials/" (NULL: the scene file's folder). Errors: PT_ERROR_IO (unreadable / malformed file or
    model, unknown model reference). A node's "euler" rotation follows Donut's rotationQuat: about the fixed x axis first, then y, then z (unpinned: Donut is not vendored). */

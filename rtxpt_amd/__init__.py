@@ -392,8 +392,8 @@ SCENE_JSON_INFO_DTYPE = np.dtype([("numModels", "<u4"), ("numGeometries", "<u4")
                                   ("lightProxies", "<u4"), ("skippedGeometries", "<u4"), ("directionalLights", "<u4"), ("hasEnvironment", "<u4"),
                                   ("envRadianceScale", "<f4", 3), ("envRotation", "<f4"), ("envTextureIndex", "<i4"), ("envPath", "S260"), ("settingsMask", "<u4"),
                                   ("realtimeMode", "<u4"), ("enableAnimations", "<u4"), ("startingCamera", "<i4"), ("realtimeFireflyFilter", "<f4"), ("maxBounces", "<i4"),
-                                  ("maxDiffuseBounces", "<i4"), ("textureMIPBias", "<f4"), ("selectedCamera", "<i4")])
-assert SCENE_CAMERA_DTYPE.itemsize == 132 and SCENE_JSON_INFO_DTYPE.itemsize == 376
+                                  ("maxDiffuseBounces", "<i4"), ("textureMIPBias", "<f4"), ("selectedCamera", "<i4"), ("lightProxiesResolved", "<u4")])
+assert SCENE_CAMERA_DTYPE.itemsize == 132 and SCENE_JSON_INFO_DTYPE.itemsize == 380
 
 
 class SceneImport:

@@ -225,6 +225,7 @@ struct Loader {
     std::vector<PtGeometryDesc> geoms; std::vector<PtMeshDesc> meshes; std::vector<PtInstanceDesc> instances; std::vector<PTMaterialData> materials;
     std::vector<std::vector<uint8_t>> texPixels; std::vector<PtTextureDesc> texDescs; std::map<std::pair<int, int>, uint32_t> texCache;   // (image, srgb) -> texture word
     std::vector<int> meshMap; std::vector<M4> instanceWorld;      // instanceWorld: the double-precision local-to-world of each instance (scene-graph import composes in double)
+    std::vector<std::string> instancePath;                         // the names of the glTF nodes from a scene root down to the instance's node, '/'-separated (what Donut's SceneGraph::FindNode walks)
     struct NodeTRS { bool has[3]; double t[3], q[4], s[3]; };      // animation: per node, the channels that replace its translation / rotation / scale (pt_gltf_animation)
     const std::vector<NodeTRS>* nodeOverride = nullptr;
 
@@ -374,9 +375,10 @@ struct Loader {
         }
         return true;
     }
-    void visit(int node, const M4& parent, int depth) {
+    void visit(int node, const M4& parent, int depth, const std::string& parentPath = std::string()) {
         const JValue* nodes = root.get("nodes"); if (!nodes || node < 0 || (size_t)node >= nodes->size() || depth > 256) return;
         const JValue& n = nodes->arr[node]; M4 local = m4_identity();
+        const std::string path = parentPath.empty() ? n.strOr("name", "") : parentPath + "/" + n.strOr("name", "");
         const NodeTRS* ov = (nodeOverride && (size_t)node < nodeOverride->size()) ? &(*nodeOverride)[(size_t)node] : nullptr;
         const bool animated = ov && (ov->has[0] || ov->has[1] || ov->has[2]);
         if (const JValue* mx = n.get("matrix"); mx && !animated) { if (mx->size() == 16) for (int i = 0; i < 16; i++) local.m[i] = mx->arr[i].num; }      // (glTF: an animated node has TRS properties, not a matrix)
@@ -393,9 +395,9 @@ struct Loader {
         if (mesh >= 0 && (size_t)mesh < meshMap.size() && meshMap[mesh] >= 0) {
             PtInstanceDesc inst; memset(&inst, 0, sizeof(inst)); inst.meshIndex = (uint32_t)meshMap[mesh];
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) inst.transform[r * 4 + c] = (float)world.m[c * 4 + r];   // column-major 4x4 -> row-major 3x4
-            instances.push_back(inst); instanceWorld.push_back(world);
+            instances.push_back(inst); instanceWorld.push_back(world); instancePath.push_back(path);
         }
-        if (const JValue* ch = n.get("children")) for (auto& c : ch->arr) visit((int)c.num, world, depth + 1);
+        if (const JValue* ch = n.get("children")) for (auto& c : ch->arr) visit((int)c.num, world, depth + 1, path);
     }
 };
 
@@ -578,7 +580,7 @@ extern "C" int32_t pt_gltf_animation_instances(pt_gltf_animation* a, uint32_t an
             sample_channel(a->anims[animation].samplers[(size_t)c.sampler], c.path, (double)t, v);
             o.has[c.path] = true; if (c.path == 0) memcpy(o.t, v, 24); else if (c.path == 1) memcpy(o.q, v, 32); else memcpy(o.s, v, 24);
         }
-        Loader& L = a->L; L.instances.clear(); L.instanceWorld.clear(); L.nodeOverride = &ov;
+        Loader& L = a->L; L.instances.clear(); L.instanceWorld.clear(); L.instancePath.clear(); L.nodeOverride = &ov;
         int sceneIdx = L.root.intOr("scene", 0); const JValue* scenes = L.root.get("scenes");
         if (scenes && (size_t)sceneIdx < scenes->size()) { if (const JValue* ns = scenes->arr[sceneIdx].get("nodes")) for (auto& n : ns->arr) L.visit((int)n.num, m4_identity(), 0); }
         else if (nodes) for (size_t i = 0; i < nodes->size(); i++) L.visit((int)i, m4_identity(), 0);
@@ -616,7 +618,7 @@ std::string file_stem(const std::string& path) {
     size_t slash = path.find_last_of('/'); std::string f = slash == std::string::npos ? path : path.substr(slash + 1);
     size_t dot = f.find_last_of('.'); return dot == std::string::npos ? f : f.substr(0, dot);
 }
-struct ModelSlot { bool loaded = false; int32_t status = PT_OK; uint32_t firstMesh = 0; std::vector<int> meshRemap; std::vector<uint32_t> instMesh; std::vector<M4> instWorld; };
+struct ModelSlot { bool loaded = false; int32_t status = PT_OK; uint32_t firstMesh = 0; std::vector<int> meshRemap; std::vector<uint32_t> instMesh; std::vector<M4> instWorld; std::vector<std::string> instPath; };
 
 struct SceneReader {
     pt_scene_import& S; std::string sceneDir, mediaDir, sceneStem; std::vector<std::string> modelPaths; std::vector<ModelSlot> slots; int32_t err = PT_OK;
@@ -713,20 +715,36 @@ struct SceneReader {
         for (size_t i = 0; i < L.instances.size(); i++) {
             int mesh = slot.meshRemap[L.instances[i].meshIndex];
             if (mesh < 0) continue;
-            slot.instMesh.push_back((uint32_t)mesh); slot.instWorld.push_back(L.instanceWorld[i]);
+            slot.instMesh.push_back((uint32_t)mesh); slot.instWorld.push_back(L.instanceWorld[i]); slot.instPath.push_back(i < L.instancePath.size() ? L.instancePath[i] : std::string());
         }
         S.info.numModels++;
         return slot;
     }
-    void instantiate(size_t k, const M4& world) {
+    // Scene-graph paths (Donut SceneGraph::FindNode, un-vendored: restated from its published source, UNPINNED): node names joined by '/', a leading '/' = from the root.
+    // A model hangs below its graph node as a root node named after the model file, the glTF scene's nodes below that.
+    std::vector<std::string> instancePaths;                        // parallel to S.instances
+    struct PendingProxy { uint32_t light; std::string path; }; std::vector<PendingProxy> pendingProxies;
+    static std::string file_name_of(const std::string& p) { size_t k = p.find_last_of("/\\"); return k == std::string::npos ? p : p.substr(k + 1); }
+    void instantiate(size_t k, const M4& world, const std::string& nodePath = std::string()) {
         if (k >= modelPaths.size()) { err = PT_ERROR_IO; return; }
         ModelSlot& slot = model(k);
         if (slot.status != PT_OK) { err = slot.status; return; }
         for (size_t i = 0; i < slot.instMesh.size(); i++) {
+            instancePaths.push_back(nodePath + "/" + file_name_of(modelPaths[k]) + (i < slot.instPath.size() && !slot.instPath[i].empty() ? "/" + slot.instPath[i] : std::string()));
             M4 w = m4_mul(world, slot.instWorld[i]);
             PtInstanceDesc inst; memset(&inst, 0, sizeof(inst)); inst.meshIndex = slot.instMesh[i];
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) inst.transform[r * 4 + c] = (float)w.m[c * 4 + r];
             S.instances.push_back(inst);
+        }
+    }
+    // ExtendedScene::ProcessNodesRecursive (ExtendedScene.cpp:246-263) + LightsBaker::Update (LightsBaker.cpp:718-753): the mesh instance a point / spot light names in
+    // "proxyMeshNodes" stands in for that light (PtInstanceDesc.analyticProxyLight). Only a path that ends at a node holding a mesh instance links, as there.
+    void resolve_proxies() {
+        for (const PendingProxy& pp : pendingProxies) {
+            std::string want = pp.path; while (!want.empty() && want[0] == '/') want.erase(0, 1);
+            std::vector<std::string> parts; { size_t a = 0; while (a <= want.size()) { size_t b = want.find('/', a); if (b == std::string::npos) b = want.size(); std::string c = want.substr(a, b - a); if (c == "..") { if (!parts.empty()) parts.pop_back(); } else if (!c.empty() && c != ".") parts.push_back(c); a = b + 1; } }
+            std::string norm; for (auto& c : parts) norm += "/" + c;
+            for (size_t i = 0; i < instancePaths.size() && i < S.instances.size(); i++) if (instancePaths[i] == norm) { S.instances[i].analyticProxyLight = pp.light + 1u; S.info.lightProxiesResolved++; }
         }
     }
     void leaf(const JValue& n, const std::string& type, const M4& world) {
@@ -745,7 +763,8 @@ struct SceneReader {
             double v[3]; if (jvec(n.get("color"), v, 3)) for (int i = 0; i < 3; i++) d.color[i] = (float)v[i];
             jload(n, "intensity", d.intensity); jload(n, "radius", d.radius);
             if (d.type == 1u) { jload(n, "innerAngle", d.innerAngle); jload(n, "outerAngle", d.outerAngle); }
-            if (const JValue* px = n.get("proxyMeshNodes")) I.lightProxies += (uint32_t)px->size();
+            const JValue* px = n.get("proxyMeshNodes");
+            if (px) I.lightProxies += (uint32_t)px->size();
             float cx = d.color[0] * d.intensity, cy = d.color[1] * d.intensity, cz = d.color[2] * d.intensity;
             if (sqrtf(cx * cx + cy * cy + cz * cz) <= 1e-7f) { I.lightsDropped++; return; }     // Sample.cpp:567-573
             double len = sqrt(zx * zx + zy * zy + zz * zz); if (!(len > 0)) len = 1;
@@ -754,6 +773,7 @@ struct SceneReader {
             PolymorphicLightInfo b; PolymorphicLightInfoEx e;
             int32_t r = pt_convert_light(&d, &b, &e);
             if (r != PT_OK) { err = r; return; }
+            if (px) for (auto& q : px->arr) if (q.type == JValue::Str) pendingProxies.push_back({(uint32_t)S.lights.size(), q.str});      // JsonLoadStringVector: the strings of the array
             S.lights.push_back(b); S.lightsEx.push_back(e);
         } else if (type == "DirectionalLight") {                                             // not part of LightsBaker's light set (LightsBaker.cpp:600): baked into the environment cube
             I.directionalLights++;                                                           // (Sample::UpdateLighting, Sample.cpp:1361-1388). Donut keys: color, irradiance, angularSize [deg]
@@ -792,10 +812,10 @@ struct SceneReader {
         }
         // GameSettings, unknown types: nothing the path tracer consumes
     }
-    void node(const JValue& n, const M4& parent, int depth) {
+    void node(const JValue& n, const M4& parent, int depth, const std::string& parentPath = std::string()) {
         if (err != PT_OK || depth > 256) return;
         if (n.type == JValue::Str) {                                                         // a bare string names a model
-            for (size_t k = 0; k < modelPaths.size(); k++) if (modelPaths[k] == n.str) { instantiate(k, parent); return; }
+            for (size_t k = 0; k < modelPaths.size(); k++) if (modelPaths[k] == n.str) { instantiate(k, parent, parentPath); return; }
             err = PT_ERROR_IO; return;
         }
         if (n.type != JValue::Obj) return;
@@ -815,12 +835,13 @@ struct SceneReader {
             q[0] = w[1]; q[1] = w[2]; q[2] = w[3]; q[3] = w[0];
         }
         M4 world = m4_mul(parent, m4_trs(t, q, s));
+        const std::string path = parentPath + "/" + n.strOr("name", "");
         if (const JValue* m = n.get("model")) {
-            if (m->type == JValue::Num) instantiate((size_t)m->num, world);
-            else if (m->type == JValue::Str) { bool found = false; for (size_t k = 0; k < modelPaths.size(); k++) if (modelPaths[k] == m->str) { instantiate(k, world); found = true; break; } if (!found) err = PT_ERROR_IO; }
+            if (m->type == JValue::Num) instantiate((size_t)m->num, world, path);
+            else if (m->type == JValue::Str) { bool found = false; for (size_t k = 0; k < modelPaths.size(); k++) if (modelPaths[k] == m->str) { instantiate(k, world, path); found = true; break; } if (!found) err = PT_ERROR_IO; }
         }
         if (const JValue* ty = n.get("type")) if (ty->type == JValue::Str) leaf(n, ty->str, world);
-        if (const JValue* ch = n.get("children")) for (auto& c : ch->arr) node(c, world, depth + 1);
+        if (const JValue* ch = n.get("children")) for (auto& c : ch->arr) node(c, world, depth + 1, path);
     }
 };
 } // namespace
@@ -844,6 +865,7 @@ static int32_t scene_json_import_impl(const char* scenePath, const char* mediaPa
     if (const JValue* models = root.get("models")) for (auto& m : models->arr) { if (m.type != JValue::Str) return PT_ERROR_IO; R.modelPaths.push_back(m.str); }
     R.slots.resize(R.modelPaths.size());
     if (const JValue* graph = root.get("graph")) for (auto& n : graph->arr) R.node(n, m4_identity(), 0);
+    R.resolve_proxies();
     if (R.err != PT_OK) return R.err;
     PtSceneJsonInfo& I = S->info;
     I.numGeometries = (uint32_t)S->geoms.size(); I.numMeshes = (uint32_t)S->meshes.size(); I.numInstances = (uint32_t)S->instances.size(); I.numMaterials = (uint32_t)S->materials.size();

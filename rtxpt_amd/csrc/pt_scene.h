@@ -123,6 +123,7 @@ struct DeviceScene {
     const AlphaRec* alphaRecs; // one per TriRecord slot (leaf order)
     const AlphaPlane* alphaPlanes; const unsigned char* alphaPool;      // per texture (pt_api.hip upload_textures); read by k_alpha_records and the traversal's alpha test
     const ShadeTri* shadeTris; // one per global primitive id (pt_build.hip k_shade_tris)
+    const uint* primToSlot;    // global primitive id -> leaf-order slot (probes; the traversal's resolve pass takes it from TravAux)
     uint2* travSpill;          // T8_MAX_BLOCKS x T8_GROUPS_PER_BLOCK x T8_SPILL_DEPTH stack-tail entries
 };
 

@@ -590,6 +590,10 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
                       case 7: r = H::r(a[1] * a[2]); break; case 8: r = H::r(H::r(a[1]) * a[2]); break; case 9: r = H::r(a[1] + a[2]); break; case 10: r = H::r(a[1] / a[2]); break;      // lpfloat(float expression)
                       default: r = H::average3(make_float3(H::r(a[1]), H::r(a[2]), H::r(a[3]))); break; }
         out[i] = r; } break;
+    case 10: { const uint* a = reinterpret_cast<const uint*>(in) + 3 * i; uint* o = reinterpret_cast<uint*>(out) + 2 * i;      // the traversal's alpha test: (primitive, u, v) -> (scatter ray accepts, visibility ray accepts)
+        const uint slot = k.sc.primToSlot[a[0]]; const TriRecord tr = k.sc.tris[slot];      // AlphaTestImpl / Bridge::AlphaTest / AlphaTestVisibilityRay (BridgeDonut:929-989) as the leaf block applies them
+        const bool solid = !(tr.flags & 1u) || alpha_test_slot(k.sc, slot, asfloat(a[1]), asfloat(a[2]));
+        o[0] = solid ? 1u : 0u; o[1] = (!(tr.flags & 1u) || (!(tr.flags & 2u) && solid)) ? 1u : 0u; } break;
     case 9: { const float* a = in + 4 * i; float* o = out + 3 * i;                                       // EnvMap::EvalLocal on the baked cube: (localDir.xyz, lod)
         float3 r = k.sc.envEnabled ? env_eval_local(k.sc, make_float3(a[0], a[1], a[2]), a[3]) : make_float3(0.f);
         o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;

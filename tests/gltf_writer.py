@@ -74,7 +74,7 @@ def write_gltf(sc, path):
     for inst in sc["instances"]:
         t = inst["transform"].reshape(3, 4)
         m4 = np.eye(4, dtype=np.float64); m4[:3, :] = t
-        nodes.append({"mesh": int(inst["meshIndex"]), "matrix": [float(x) for x in m4.T.reshape(-1)]})
+        nodes.append({"name": "instance%d" % len(nodes), "mesh": int(inst["meshIndex"]), "matrix": [float(x) for x in m4.T.reshape(-1)]})
     doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": list(range(len(nodes)))}], "nodes": nodes, "meshes": meshes, "materials": materials,
            "accessors": accessors, "bufferViews": views, "buffers": [{"uri": os.path.basename(bin_path), "byteLength": len(blob)}],
            "extensionsUsed": ["KHR_materials_ior", "KHR_materials_emissive_strength", "KHR_materials_transmission", "KHR_materials_volume"]}

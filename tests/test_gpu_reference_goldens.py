@@ -100,3 +100,53 @@ def test_device_half_operators_are_ieee_binary16(tracer):
             got = tracer.probe(7, rows, (n,))
             ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
             assert ok.all(), "%s: %d of %d differ; first: a=%r b=%r c=%r device=%r numpy=%r" % (name, int((~ok).sum()), n, a[~ok][0], b[~ok][0], c[~ok][0], got[~ok][0], want[~ok][0])
+
+
+DEVICE_PATH_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "device_path_golden.npz")
+
+
+def _pin_case(name, lp16):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pin_scenes
+    return (pin_scenes.cases_lp16() if lp16 else pin_scenes.cases())[name]
+
+
+@pytest.mark.parametrize("lp16", [False, True], ids=["fp32", "lp16"])
+@pytest.mark.parametrize("name", ["c2", "bistro_like", "bistro_like_material_zoo", "c2_spec_gloss"])
+def test_device_load_surface_matches_reference_text(name, lp16):
+    """Bridge::loadSurface on the device — since round 3 through the flat 128-byte ShadeTri record of the hit primitive (pt_scene.h, k_shade_tris) — against
+    the outputs of PathTracerBridgeDonut.hlsli:612-853 compiled from the reference (tests/golden/make_device_path_golden.py): 2 500 random hits per scene,
+    45 words each, both builds of the lp types. No oracle code runs."""
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    g = np.load(DEVICE_PATH_GOLDEN); tag = "surface_%s_%s" % (name, "lp16" if lp16 else "fp32")
+    prims, rows, want = g[tag + "_prims"], g[tag + "_rows"], g[tag + "_out"]
+    make, S, w, h, first, n = _pin_case(name, lp16)
+    sc, cam = make()
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h)
+    rows8 = np.zeros((len(prims), 8), np.float32); rows8[:, 0] = prims.view(np.float32); rows8[:, 1:] = rows
+    got = t.probe(8, rows8, (len(prims), 45), out_dtype=np.uint32)
+    bad = (got != want).any(1)
+    assert not bad.any(), "%d of %d surfaces differ from the reference text; first: hit %d, words %s" % (int(bad.sum()), len(prims), int(np.flatnonzero(bad)[0]), np.flatnonzero(got[bad][0] != want[bad][0]))
+    t.close()
+
+
+@pytest.mark.parametrize("name", ["bistro_like", "c2_exclude_from_nee"])
+def test_device_alpha_test_matches_reference_text(name):
+    """The traversal's alpha test on the device — since round 3 against per-texture alpha planes (byte opacities) through a self-contained AlphaRec — against
+    Bridge::AlphaTest / AlphaTestVisibilityRay (PathTracerBridgeDonut.hlsli:929-989) compiled from the reference: 20 000 random candidates per scene, the answer for
+    scatter rays and for visibility rays (ExcludeFromNEE geometry lets those through)."""
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    g = np.load(DEVICE_PATH_GOLDEN)
+    prims, uv, want = g["alpha_%s_prims" % name], g["alpha_%s_uv" % name], g["alpha_%s_out" % name]
+    make, S, w, h, first, n = _pin_case(name, False)
+    sc, cam = make()
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h)
+    rows = np.zeros((len(prims), 3), np.uint32); rows[:, 0] = prims; rows[:, 1:] = uv.view(np.uint32)
+    got = t.probe(10, rows, (len(prims), 2), out_dtype=np.uint32)
+    bad = (got != want).any(1)
+    assert not bad.any(), "%d of %d alpha tests differ from the reference text; first: primitive %d uv %s device %s reference %s" % (int(bad.sum()), len(prims), int(prims[bad][0]), uv[bad][0], got[bad][0], want[bad][0])
+    assert 0 < int(want[:, 1].sum()) < len(prims)
+    t.close()

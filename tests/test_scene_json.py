@@ -471,3 +471,25 @@ def test_directional_light_records_and_bake_helper(tmp_path):
     assert np.allclose(np.linalg.norm(rot[:, 4:7], axis=1), 1.0, atol=1e-6)
     with pytest.raises(pt.PtError):
         pt.env_bake_lights(d, 0)
+
+
+def test_proxy_mesh_nodes_link_instances_to_their_light(tmp_path):
+    """A point / spot light's "proxyMeshNodes" (ExtendedScene.cpp:46, 246-263): Donut's SceneGraph::FindNode walks '/'-separated node names from the root, the model
+    hangs below its graph node as a node named after the model file with the glTF nodes below it; the mesh instance found there stands in for the light
+    (LightsBaker.cpp:718-753) — PtInstanceDesc.analyticProxyLight = light index + 1, counted from the lights that survive the visibility clean-up. Paths that end at a
+    node without a mesh instance (the graph node itself), unknown paths and the proxies of a dropped light link nothing."""
+    graph = [
+        {"name": "room", "model": 0},
+        {"name": "group", "children": [{"name": "room2", "model": 0}]},
+        {"name": "Lights", "children": [
+            {"name": "off", "type": "PointLight", "intensity": 0.0, "radius": 0.1, "proxyMeshNodes": ["/room/cornell.gltf/instance0"]},
+            {"name": "bulb", "type": "PointLight", "color": 0.5, "intensity": 20.0, "radius": 0.02, "proxyMeshNodes": ["/group/room2/cornell.gltf/instance1", "/room", "/nowhere/x"]},
+            {"name": "spot", "type": "SpotLight", "intensity": 5.0, "radius": 0.05, "proxyMeshNodes": ["/room/cornell.gltf/../cornell.gltf/instance2", "room/cornell.gltf/instance0"]}]},
+    ]
+    media, sc, cam = make_folder(tmp_path, graph)
+    imp = pt.SceneImport(media / "test.scene.json")
+    I = imp.info; n = len(sc["instances"])
+    assert I["numLights"] == 2 and I["lightsDropped"] == 1 and I["lightProxies"] == 6 and I["lightProxiesResolved"] == 3
+    link = imp.instances["analyticProxyLight"]
+    want = np.zeros(2 * n, np.uint32); want[n + 1] = 1; want[2] = 2; want[0] = 2          # bulb = light 0 -> 1, spot = light 1 -> 2 (".." and a relative path resolve too)
+    assert np.array_equal(link, want), (link, want)
