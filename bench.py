@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 # algorithmic bytes: extend ray 52 B fixed + BVH: 128 B per BVH8 node visit + 48 B per triangle test
 B_EXTEND_FIXED, B_NODE, B_TRI, B_SHADE, B_SHADOW_FIXED = 52.0, 128.0, 48.0, 656.0, 80.0
-COUNTERS_FILE = "r02zz_counters.json"     # rocprofv3 --pmc summary of this workload (tools/profile_round.sh), quoted in roofline{}
+COUNTERS_FILE = "r03z_counters.json"     # rocprofv3 --pmc summary of this workload (tools/profile_round.sh), quoted in roofline{}
 
 
 def main():
@@ -173,10 +173,11 @@ def main():
         traffic = cj["hbm_bytes_per_launch"]; hbm_counter_gbs = cj["hbm_counter_gbs"]; l2 = cj["l2_hit_rate"]
         valu = {"busy": cj["valu_busy"], "lane_utilisation": cj["lane_utilisation"], "valu_instructions_per_vmem_read": cj["valu_per_vmem_read"],
                 "wait_any_share_of_wave_cycles": cj["wait_any_share_of_wave_cycles"]}
-        # HBM runs at ~15 % of peak, and VALU issue is not the limit either: a build of k_extend with 18 % fewer VALU instructions (same rays, nodes, triangles)
-        # is no faster while one resident wave per SIMD less costs 7 % (profiles/r02k_isa_experiments.txt). What is left is the latency of each ray's dependent
-        # chain (node fetch -> slab test -> child sort -> next node) times the waves in flight.
-        bound = "hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else "latency"
+        # Round 3: what is full is the VALU issue port. Extra v_nop issue slots in the traversal loop lengthen k_extend one for one (+10 % slots = +9 % time,
+        # +20 % = +21 %, profiles/r03i_valu_bound_probe.txt), and SQ_INSTS_VALU per SIMD and cycle sits at the 1/4 a 16-lane SIMD can issue for wave64.
+        vps = cj.get("valu_instr_per_simd_cycle") or 0.0
+        bound = "hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else ("valu" if vps >= 0.24 else "latency")
+        valu["instructions_per_simd_cycle"] = vps
 
     if rank == 0:
         info = g.scene_info(); bvh = g.bvh_info()
@@ -191,10 +192,10 @@ def main():
                        "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
             # `frac` is the prescribed figure: algorithmic bytes / launch time / 8 TB/s. `bound` is what the counters say limits the kernel:
-            # the BVH is served from L1/L2, HBM itself carries `hbm_counter_gbs`, and the VALU issue slots are what is full.
+            # the BVH is served from L1/L2, HBM itself carries `hbm_counter_gbs`, and the VALU issue slots are what is full (`bound`: "valu").
             "roofline": {"bound": bound, "prescribed_bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "quoted from the committed rocprofv3 --pmc summary (counters_source), not measured in this run", "hbm_counter_gbs": hbm_counter_gbs, "l2_hit_rate": l2, "valu": valu, "counters_source": counters_src,
-                         "bound_evidence": "profiles/r02k_isa_experiments.txt: -18 % VALU instructions = 0 % time, 6 -> 5 waves per SIMD = +7 % time, HBM at 15 % of peak",
+                         "bound_evidence": "profiles/r03i_valu_bound_probe.txt: +10 % / +20 % VALU issue slots (v_nop) in the traversal loop = +9 % / +21 % k_extend time; HBM at ~16 % of peak",
                          "whole_frame": {"algorithmic_bytes_per_step": frame_bytes, "achieved": frame_gbs, "frac": frame_gbs / HBM_PEAK_GBS,
                                          "terms": "extend rays x (52 + 128 nodes + 48 tris) + hits x 656 + shadow rays x (80 + 128 nodes + 48 tris), over the pipelined step time"},
                          "bytes_per_ray": bytes_per_ext, "node_visits_per_ray": nodes_per_ext, "tri_tests_per_ray": tris_per_ext,

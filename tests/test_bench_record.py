@@ -1,9 +1,9 @@
-"""The committed bench line of the round (profiles/r02zz_bench.json, produced by `python bench.py` on an MI355X) carries every field the bench contract asks for, and its
+"""The committed bench line of the round (profiles/r03z_bench.json, produced by `python bench.py` on an MI355X) carries every field the bench contract asks for, and its
 roofline figures are consistent with each other and with the committed rocprofv3 summaries. CPU only: nothing is run, the records are read."""
 import csv, json, os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REC = os.path.join(ROOT, "profiles", "r02zz_bench.json")
+REC = os.path.join(ROOT, "profiles", "r03z_bench.json")
 
 
 def test_bench_line_has_the_contract_fields_and_consistent_numbers():
@@ -17,13 +17,13 @@ def test_bench_line_has_the_contract_fields_and_consistent_numbers():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches"):
         assert k in r, k
-    assert r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["bound"] in ("hbm", "latency", "mfma")
+    assert r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["bound"] in ("hbm", "valu", "latency", "mfma")
     # achieved = algorithmic bytes per launch / average launch time
     bytes_per_launch = r["bytes_per_ray"] * d["config"]["extend_rays_per_step"] / (r["launches"] / 2)          # (the launches of the two serial-kernel steps)
     assert abs(bytes_per_launch / (r["avg_launch_ms"] * 1e-3) / 1e9 - r["achieved"]) < 0.02 * r["achieved"]
     # the counter file it quotes exists and says the same
     src = r["counters_source"].split(" ")[0]; c = json.load(open(os.path.join(ROOT, src)))["groups"]["extend"] if os.path.exists(os.path.join(ROOT, src)) else None
-    c = c or json.load(open(os.path.join(ROOT, "profiles", "r02x_counters.json")))["groups"]["extend"]
+    c = c or json.load(open(os.path.join(ROOT, "profiles", "r03z_counters.json")))["groups"]["extend"]
     assert 0.5 < r["traffic"] / c["hbm_bytes_per_launch"] < 2.0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"): assert k in cb, k
@@ -33,7 +33,7 @@ def test_bench_line_has_the_contract_fields_and_consistent_numbers():
 
 def test_kernel_trace_summary_agrees_with_the_bench_line():
     d = json.loads(open(REC).read().strip().splitlines()[-1]); r = d["roofline"]
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02zz_serial_kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03z_serial_kernel_stats.csv"))))
     ext = [x for x in rows if x["Name"].startswith("void ptk::k_extend<false>")][0]
     avg_ms = float(ext["AverageNs"]) * 1e-6
     assert int(ext["Calls"]) == 27 and abs(avg_ms - r["avg_launch_ms"]) < 0.05 * r["avg_launch_ms"]          # rocprofv3's average k_extend launch vs bench.py's own HIP events
