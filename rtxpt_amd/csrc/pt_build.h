@@ -6,8 +6,11 @@
 //   k_ploc_*        (default) PLOC, Meister & Bittner 2018: mutual-nearest-neighbour merging of the Morton-ordered clusters inside a window of
 //                   PT_PLOC_RADIUS, ~70 data-parallel passes; leaves are then renumbered in depth-first order so that every node covers a
 //                   contiguous leaf range again. Half the SAH cost of the Karras tree on C3 (tools/bvh_lab), 40 % fewer node visits per ray
-//   pt_build_sah    (BVH_BUILDER_SAH, "prefer fast trace": what the reference asks its driver for, Sample.cpp:1093) binned-SAH topology built on the host's
+//   pt_build_sah    (BVH_BUILDER_SAH, round 2's "prefer fast trace" builder, now behind PT_DEVICE_HOST_SAH_BUILDER) binned-SAH topology built on the host's
 //                   cores from the world-space triangle boxes; bounds, leaves, collapse and refit below are shared. 14-18 % fewer node visits than PLOC
+//   k_ri_*          (BVH_BUILDER_PLOC_OPT, the default: "prefer fast trace" on the device) parallel re-insertion on the finished PLOC tree (pt_build_reinsert.h): per pass search /
+//                   lock / check / ring test / apply + a level-ordered refit of the whole tree; twelve passes, 4.4 ms each at 2.8 M triangles
+//   k_wide_*        the cost-driven wide-node assignment (pt_build_wide.h) over the levels of a breadth-first numbering: which inner nodes a BVH8 node opens
 //   k_karras        (PT_BVH_BUILDER=karras) Karras 2012 hierarchy over the sorted codes (duplicate codes split on the index bits)
 //   k_leaf_boxes / k_range_level / k_node_boxes
 //                   node bounds WITHOUT inter-thread hand-offs: every Karras node covers a contiguous range of sorted leaves, so its two child

@@ -27,8 +27,9 @@ static const uint T8_RAYBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_RAY_STRIDE,
 static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 
 #ifndef T8_EXTEND_MIN_BLOCKS
-#define T8_EXTEND_MIN_BLOCKS 8    // waves per SIMD the register allocator must leave room for in k_extend (64 VGPRs, 2 spilled outside the loop): the kernel is latency
-                                  // bound and every wave in flight counts — 6 -> 7 -> 8 waves: 1161 -> 1187 -> 1239 Mrays/s (profiles/r02n_occupancy_ab.txt)
+#define T8_EXTEND_MIN_BLOCKS 8    // waves per SIMD the register allocator must leave room for in k_extend (64 VGPRs, 2 spilled outside the loop): 6 -> 7 -> 8 waves were
+                                  // 1161 -> 1187 -> 1239 Mrays/s in round 2 (profiles/r02n_occupancy_ab.txt). At 8 waves the loop is VALU-issue bound (round 3: extra v_nop
+                                  // slots lengthen it one for one, profiles/r03i_valu_bound_probe.txt): from here on instructions per ray count, not waves in flight
 #endif
 #ifndef T8_SHADOW_MIN_WAVES
 #define T8_SHADOW_MIN_WAVES 8     // the same for k_shadow

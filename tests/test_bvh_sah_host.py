@@ -68,7 +68,7 @@ def reinsert_checker(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("n,mode,passes,seed", [(2, 0, 2, 1), (3, 0, 2, 1), (5, 0, 3, 1), (64, 0, 4, 2), (1000, 0, 6, 3), (20000, 1, 6, 4), (20000, 2, 6, 5), (60000, 0, 8, 6)])
+@pytest.mark.parametrize("n,mode,passes,seed", [(2, 0, 2, 1), (3, 0, 2, 1), (5, 0, 3, 1), (64, 0, 4, 2), (1000, 0, 6, 3), (4000, 1, 6, 4), (4000, 2, 6, 5), (8000, 0, 8, 6)])
 def test_device_reinsertion_passes_keep_one_tree_and_lower_the_cost(reinsert_checker, n, mode, passes, seed):
     """rtxpt_amd/csrc/pt_build_reinsert.h — the per-node functions of the device-side optimiser (parallel re-insertion after Meister & Bittner 2018), scheduled as
     pt_build.hip schedules its kernels: after every pass the links form one tree with every node in it once, and the surface-area cost never rises."""
