@@ -321,8 +321,7 @@ void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
                 float3 p2 = xform_point(inst.transform, sc.positions[g.vertexOffset + idx[2]]);
                 float3 radiance = mat.EmissiveColor;
                 if ((mat.Flags & PTMaterialFlags_UseEmissiveTexture) && (g.flags & GEOM_HAS_UV)) {
-                    // reference: anisotropic SampleGrad at the centroid (LightsBaker.hlsl:591-650); restated as a trilinear tap whose LOD
-                    // comes from the longer of the two gradient axes
+                    // reference: anisotropic SampleGrad at the centroid (LightsBaker.hlsl:591-650): scene.h sample_grad_anisotropic
                     float2 uv0 = sc.uvs[g.vertexOffset + idx[0]], uv1 = sc.uvs[g.vertexOffset + idx[1]], uv2 = sc.uvs[g.vertexOffset + idx[2]];
                     float2 e0 = uv1 - uv0, e1 = uv2 - uv1, e2 = uv0 - uv2;
                     float l0 = length(e0), l1 = length(e1), l2 = length(e2);
@@ -330,10 +329,8 @@ void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
                     if (l0 < l1 && l0 < l2) { shortE = e0; longE1 = e1; longE2 = e2; } else if (l1 < l2) { shortE = e1; longE1 = e2; longE2 = e0; } else { shortE = e2; longE1 = e0; longE2 = e1; }
                     float2 sg = shortE * (2.0f / 3.0f); float2 lg = (longE1 + longE2) * (1.0f / 3.0f);
                     const Texture& tex = sc.textures[mat.EmissiveTextureIndex & 0xFFFFu];
-                    float fw = fmaxf_(length(make_float2(sg.x * (float)tex.w, sg.y * (float)tex.h)), length(make_float2(lg.x * (float)tex.w, lg.y * (float)tex.h)));
-                    float lod = RayCone::SafeLog2(fw);
                     float2 c = (uv0 + uv1 + uv2) * (1.0f / 3.0f);
-                    radiance = radiance * xyz(sample_trilinear(tex, c, lod));
+                    radiance = radiance * xyz(sample_grad_anisotropic(tex, c, sg, lg));
                 }
                 radiance = max3v(radiance, make_float3(0.f));
                 TriangleLight tl; tl.base = p0;

@@ -117,6 +117,27 @@ static inline float4 sample_trilinear(const Texture& t, float2 uv, float lambda)
     return lerp4(a, b, f);
 }
 
+// Texture2D.SampleGrad through an anisotropic sampler (Donut's m_AnisotropicWrapSampler, maxAnisotropy 16), as the emissive-triangle bake asks for it
+// (LightsBaker.hlsl:647). What a texture unit does with two gradients is implementation defined; restated in the formulation of EXT_texture_filter_anisotropic
+// (UNPINNED: there is no reference text for it): Px, Py = the gradients' lengths in texels, N = min(ceil(Pmax / Pmin), 16) trilinear taps at LOD log2(Pmax / N),
+// spaced evenly along the longer gradient and averaged. The bake's own gradients are collinear with a 2 : 1 length ratio (its long gradient is -shortEdge / 3: the
+// UV edges sum to zero), so it always takes two taps, one level finer than a single tap at the longer gradient's LOD (tests/test_emissive_bake_anisotropy.py).
+static inline float4 sample_grad_anisotropic(const Texture& t, float2 uv, float2 gx, float2 gy) {
+    const float lx = length(make_float2(gx.x * (float)t.w, gx.y * (float)t.h)), ly = length(make_float2(gy.x * (float)t.w, gy.y * (float)t.h));
+    const float pmax = fmaxf_(lx, ly), pmin = fminf_(lx, ly);
+    const float2 major = (lx >= ly) ? gx : gy;
+    float n = (pmin > 0.f) ? ceilf(pmax / pmin) : 16.0f;
+    n = clampf(n, 1.0f, 16.0f);
+    const float lod = (pmax > 0.f) ? dm_log2(clampf(pmax / n, FLT_MIN_, FLT_MAX_)) : 0.0f;
+    float4 sum = make_float4(0, 0, 0, 0);
+    const uint taps = (uint)n;
+    for (uint i = 0; i < taps; i++) {
+        const float o = ((float)i + 0.5f) / n - 0.5f;
+        sum = sum + sample_trilinear(t, make_float2(uv.x + major.x * o, uv.y + major.y * o), lod);
+    }
+    return make_float4(sum.x / n, sum.y / n, sum.z / n, sum.w / n);
+}
+
 // ---- environment: the host hands over a lat-long RGB image (row 0 = +Y pole); the path tracer samples the CUBE EnvMapBaker makes of it (envcube.h);
 // EnvMap.hlsli:54-93 semantics for transform / multiplier
 struct EnvMap {

@@ -480,10 +480,8 @@ __global__ void __launch_bounds__(256) k_bake_emissive(DeviceScene sc, const uin
         if (l0 < l1 && l0 < l2) { shortE = e0; longE1 = e1; longE2 = e2; } else if (l1 < l2) { shortE = e1; longE1 = e2; longE2 = e0; } else { shortE = e2; longE1 = e0; longE2 = e1; }
         float2 sg = shortE * (2.0f / 3.0f); float2 lg = (longE1 + longE2) * (1.0f / 3.0f);
         const TexInfo& tex = sc.textures[mat.EmissiveTextureIndex & 0xFFFFu];
-        float fw = fmaxf_(length(make_float2(sg.x * (float)tex.w, sg.y * (float)tex.h)), length(make_float2(lg.x * (float)tex.w, lg.y * (float)tex.h)));
-        float lod = RayCone::SafeLog2(fw);
         float2 c = (uv0 + uv1 + uv2) * (1.0f / 3.0f);
-        radiance = radiance * xyz(sample_trilinear(sc, tex, c, lod));
+        radiance = radiance * xyz(sample_grad_anisotropic(sc, tex, c, sg, lg));      // emissiveTexture.SampleGrad(s_materialSampler, centerUV, shortGradient, longGradient) (:647)
     }
     radiance = max3v(radiance, make_float3(0.f));
     bool isFlipped = det3(inst.transform) < 0.f;
