@@ -43,6 +43,9 @@ static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 #ifndef T8_TAIL_ITERS_TASKS
 #define T8_TAIL_ITERS_TASKS 8    // the same for task rounds: sub-trees are short, and every round of every launch pays this tail once
 #endif
+#ifndef T8_ANYHIT_UNORDERED
+#define T8_ANYHIT_UNORDERED 1     // 1: occlusion queries number a node's hit children by child index instead of ranking them by entry distance
+#endif
 #ifndef T8_LEAF_QUEUE
 #define T8_LEAF_QUEUE 2         // postponed leaves a ray may hold (1..3) before it has to wait for the wave's next leaf block (A/B: within noise on extend, -4 % on shadow)
 #endif
@@ -282,13 +285,22 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
 #else
             const uint nhit = (uint)__popc(quad_bits(t8_ballot(hitA), gl) | (quad_bits(t8_ballot(hitB), gl) << 4));
 #endif
+            uint rankA, rankB;
+            if (ANYHIT && T8_ANYHIT_UNORDERED) {
+                // an occlusion query has no use for a front-to-back order — a visible ray visits every node its segment touches whatever the order, an occluded one stops at the
+                // first occluder it happens to meet: the hit children are numbered by child index (the quad's eight hit bits and a popcount instead of twelve key comparisons)
+                const uint bitsA = quad_bits(t8_ballot(hitA), gl), bitsB = quad_bits(t8_ballot(hitB), gl);
+                const uint all = (bitsA & 1u) | ((bitsB & 1u) << 1) | ((bitsA & 2u) << 1) | ((bitsB & 2u) << 2) | ((bitsA & 4u) << 2) | ((bitsB & 4u) << 3) | ((bitsA & 8u) << 3) | ((bitsB & 8u) << 4);      // bit 2q = child 2q (lane q's A), bit 2q + 1 = its B
+                rankA = (uint)__popc(all & ((1u << (2u * q)) - 1u)); rankB = (uint)__popc(all & ((2u << (2u * q)) - 1u));
+            } else {
             const uint a1 = dpp_u<DPP_QP_XOR1>(keyA), a2 = dpp_u<DPP_QP_XOR2>(keyA), a3 = dpp_u<DPP_QP_XOR3>(keyA);
             const uint b1 = dpp_u<DPP_QP_XOR1>(keyB), b2 = dpp_u<DPP_QP_XOR2>(keyB), b3 = dpp_u<DPP_QP_XOR3>(keyB);
-            uint rankA = (keyB < keyA) ? 1u : 0u, rankB = (keyA < keyB) ? 1u : 0u;
+            rankA = (keyB < keyA) ? 1u : 0u; rankB = (keyA < keyB) ? 1u : 0u;
             rankA += (a1 < keyA) ? 1u : 0u; rankA += (a2 < keyA) ? 1u : 0u; rankA += (a3 < keyA) ? 1u : 0u;
             rankA += (b1 < keyA) ? 1u : 0u; rankA += (b2 < keyA) ? 1u : 0u; rankA += (b3 < keyA) ? 1u : 0u;
             rankB += (a1 < keyB) ? 1u : 0u; rankB += (a2 < keyB) ? 1u : 0u; rankB += (a3 < keyB) ? 1u : 0u;
             rankB += (b1 < keyB) ? 1u : 0u; rankB += (b2 < keyB) ? 1u : 0u; rankB += (b3 < keyB) ? 1u : 0u;
+            }
             // the nearest child's reference reaches every lane through an AND butterfly (only the hit child of rank 0 contributes; no hit -> BVH_EMPTY)
             uint next = (hitA && rankA == 0u) ? ch.refA : ((hitB && rankB == 0u) ? ch.refB : BVH_EMPTY);
             next &= dpp_u<DPP_QP_XOR1>(next); next &= dpp_u<DPP_QP_XOR2>(next);
