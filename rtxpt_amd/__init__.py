@@ -25,7 +25,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 
 # every symbol include/mi355pt.h declares
 EXPORTS = [
-    "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
+    "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_positions", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
     "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_env_bake_lights", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
@@ -303,6 +303,15 @@ class GltfAnimation:
         if n < 0: raise PtError(-n, "pt_gltf_animation_instances")
         out = np.zeros(n, scenes.INSTANCE_DTYPE)
         if n: assert self.L.pt_gltf_animation_instances(self.h, animation, float(t), _p(out), n) == n
+        return out
+
+    def positions(self, t, animation=0):
+        """pt_gltf_animation_positions: float32 [vertices, 3], the file's vertex stream with every skinned primitive posed at time t [s] (pt_animate's `positions`)."""
+        self.L.pt_gltf_animation_positions.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint32]
+        n = self.L.pt_gltf_animation_positions(self.h, animation, float(t), None, 0)
+        if n < 0: raise PtError(-n, "pt_gltf_animation_positions")
+        out = np.zeros((n, 3), np.float32)
+        if n: assert self.L.pt_gltf_animation_positions(self.h, animation, float(t), _p(out), n) == n
         return out
 
     def close(self):

@@ -153,6 +153,29 @@ bool decode_png(const std::vector<uint8_t>& d, uint32_t& w, uint32_t& h, std::ve
 struct M4 { double m[16]; };
 M4 m4_identity() { M4 r; memset(&r, 0, sizeof(r)); r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1; return r; }
 M4 m4_mul(const M4& a, const M4& b) { M4 r; for (int c = 0; c < 4; c++) for (int rr = 0; rr < 4; rr++) { double s = 0; for (int k = 0; k < 4; k++) s += a.m[k * 4 + rr] * b.m[c * 4 + k]; r.m[c * 4 + rr] = s; } return r; }
+bool m4_inverse(const M4& a, M4& out) {          // general 4 x 4 inverse (column major), cofactor expansion; false for a singular matrix
+    const double* m = a.m; double inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (!(det != 0.0) || !std::isfinite(det)) return false;
+    for (int i = 0; i < 16; i++) out.m[i] = inv[i] / det;
+    return true;
+}
 M4 m4_trs(const double t[3], const double q[4], const double s[3]) {
     double x = q[0], y = q[1], z = q[2], w = q[3];
     M4 r = m4_identity();
@@ -226,6 +249,8 @@ struct Loader {
     std::vector<std::vector<uint8_t>> texPixels; std::vector<PtTextureDesc> texDescs; std::map<std::pair<int, int>, uint32_t> texCache;   // (image, srgb) -> texture word
     std::vector<int> meshMap; std::vector<M4> instanceWorld;      // instanceWorld: the double-precision local-to-world of each instance (scene-graph import composes in double)
     std::vector<std::string> instancePath;                         // the names of the glTF nodes from a scene root down to the instance's node, '/'-separated (what Donut's SceneGraph::FindNode walks)
+    std::vector<uint16_t> joints; std::vector<float> weights;      // JOINTS_0 / WEIGHTS_0, four per vertex (zeros for an unskinned primitive): read by pt_gltf_animation_positions
+    struct SkinnedInstance { int node, skin, mesh; }; std::vector<SkinnedInstance> skinned; std::vector<M4> nodeWorld; bool recordWorlds = false;      // filled by visit() when recordWorlds
     struct NodeTRS { bool has[3]; double t[3], q[4], s[3]; };      // animation: per node, the channels that replace its translation / rotation / scale (pt_gltf_animation)
     const std::vector<NodeTRS>* nodeOverride = nullptr;
 
@@ -350,12 +375,14 @@ struct Loader {
             for (auto& pr : prims->arr) {
                 if (pr.intOr("mode", 4) != 4) continue;
                 const JValue* at = pr.get("attributes"); if (!at || !at->get("POSITION")) continue;
-                std::vector<double> P, N, T, UV, I; int c;
+                std::vector<double> P, N, T, UV, I, J, Wt; int c;
                 if (!accessor(at->intOr("POSITION", -1), P, c) || c != 3) { if (err.empty()) err = "POSITION must be VEC3"; return false; }
                 uint32_t nv = (uint32_t)(P.size() / 3), flags = 0;
                 if (at->get("NORMAL")) { if (!accessor(at->intOr("NORMAL", -1), N, c) || c != 3 || N.size() / 3 != nv) return false; flags |= PT_GEOM_HAS_NORMAL; }
                 if (at->get("TANGENT")) { if (!accessor(at->intOr("TANGENT", -1), T, c) || c != 4 || T.size() / 4 != nv) return false; flags |= PT_GEOM_HAS_TANGENT; }
                 if (at->get("TEXCOORD_0")) { if (!accessor(at->intOr("TEXCOORD_0", -1), UV, c) || c != 2 || UV.size() / 2 != nv) return false; flags |= PT_GEOM_HAS_UV; }
+                const bool hasSkin = at->get("JOINTS_0") && at->get("WEIGHTS_0");
+                if (hasSkin) { if (!accessor(at->intOr("JOINTS_0", -1), J, c) || c != 4 || J.size() / 4 != nv) return false; if (!accessor(at->intOr("WEIGHTS_0", -1), Wt, c) || c != 4 || Wt.size() / 4 != nv) return false; }
                 if (pr.get("indices")) { if (!accessor(pr.intOr("indices", -1), I, c) || c != 1) return false; } else { I.resize(nv); for (uint32_t k = 0; k < nv; k++) I[k] = k; }
                 uint32_t ni = (uint32_t)(I.size() / 3) * 3;
                 PtGeometryDesc g; memset(&g, 0, sizeof(g));
@@ -368,6 +395,7 @@ struct Loader {
                     float uv[2] = {0, 0}; if (flags & PT_GEOM_HAS_UV) { uv[0] = (float)UV[2 * k]; uv[1] = (float)UV[2 * k + 1]; } uvs.push_back(uv[0]); uvs.push_back(uv[1]);
                     float nn[3] = {0, 0, 0}; if (flags & PT_GEOM_HAS_NORMAL) { nn[0] = (float)N[3 * k]; nn[1] = (float)N[3 * k + 1]; nn[2] = (float)N[3 * k + 2]; } normals.push_back(pack_snorm8(nn, 3));
                     float tt[4] = {0, 0, 0, 0}; if (flags & PT_GEOM_HAS_TANGENT) { for (int q = 0; q < 4; q++) tt[q] = (float)T[4 * k + q]; } tangents.push_back(pack_snorm8(tt, 4));
+                    for (int q = 0; q < 4; q++) { const double jv = hasSkin ? J[4 * k + q] : 0.0; joints.push_back((uint16_t)(jv >= 0 && jv <= 65535.0 ? jv : 0)); weights.push_back(hasSkin ? (float)Wt[4 * k + q] : 0.f); }
                 }
                 geoms.push_back(g);
             }
@@ -392,6 +420,8 @@ struct Loader {
         }
         M4 world = m4_mul(parent, local);
         int mesh = n.intOr("mesh", -1);
+        if (recordWorlds) { if (nodeWorld.size() < nodes->size()) nodeWorld.resize(nodes->size(), m4_identity()); nodeWorld[(size_t)node] = world;
+                            if (mesh >= 0 && (size_t)mesh < meshMap.size() && meshMap[mesh] >= 0 && n.intOr("skin", -1) >= 0) skinned.push_back({node, n.intOr("skin", -1), meshMap[mesh]}); }
         if (mesh >= 0 && (size_t)mesh < meshMap.size() && meshMap[mesh] >= 0) {
             PtInstanceDesc inst; memset(&inst, 0, sizeof(inst)); inst.meshIndex = (uint32_t)meshMap[mesh];
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) inst.transform[r * 4 + c] = (float)world.m[c * 4 + r];   // column-major 4x4 -> row-major 3x4
@@ -569,6 +599,47 @@ extern "C" int32_t pt_gltf_animation_load(const char* path, pt_gltf_animation** 
     try { return gltf_animation_load_impl(path, out, numAnimations, duration); } catch (...) { if (out) *out = nullptr; return PT_ERROR_IO; }
 }
 extern "C" void pt_gltf_animation_free(pt_gltf_animation* a) { delete a; }
+// Skinned meshes (glTF 2.0 skins; Donut's SkinnedMeshInstance in the reference: Sample.cpp:1065, 1170-1198 rewrites the instance's vertex buffer every frame and updates its
+// BLAS): the posed object-space positions of the WHOLE vertex stream — the `positions` argument of pt_animate. A vertex of a skinned primitive becomes
+// SUM_k w_k (inverse(meshNodeWorld) * jointWorld_k * inverseBind_k) p, the joint matrices of the specification with the mesh node's own transform taken out (the instance keeps it).
+// Normals and tangents keep their bind pose (pt_animate takes positions only). A mesh shared by several skinned nodes takes the pose of the last one.
+extern "C" int32_t pt_gltf_animation_positions(pt_gltf_animation* a, uint32_t animation, float t, float* out, uint32_t capacityVertices) {
+    if (!a || (capacityVertices && !out)) return -PT_ERROR_INVALID_ARGUMENT;
+    try {
+        Loader& L = a->L; const uint32_t nv = (uint32_t)(L.positions.size() / 3);
+        if (capacityVertices < nv) return (int32_t)nv;                                     // (query: the number of vertices)
+        memcpy(out, L.positions.data(), sizeof(float) * L.positions.size());
+        const JValue* skins = L.root.get("skins"); if (!skins || !skins->size()) return (int32_t)nv;
+        L.recordWorlds = true; L.skinned.clear(); L.nodeWorld.clear();
+        std::vector<PtInstanceDesc> scratch(1); int32_t r = pt_gltf_animation_instances(a, animation, t, scratch.data(), 0);      // evaluates the channels and walks the nodes
+        L.recordWorlds = false; if (r < 0) return r;
+        for (const Loader::SkinnedInstance& si : L.skinned) {
+            if ((size_t)si.skin >= skins->size() || (size_t)si.mesh >= L.meshes.size()) continue;
+            const JValue& sk = skins->arr[(size_t)si.skin]; const JValue* jl = sk.get("joints"); if (!jl || !jl->size()) continue;
+            std::vector<double> ibm; int comps = 0; const bool haveIbm = sk.get("inverseBindMatrices") && L.accessor(sk.intOr("inverseBindMatrices", -1), ibm, comps) && comps == 16 && ibm.size() == 16 * jl->size();
+            M4 invMesh; if (!m4_inverse(L.nodeWorld[(size_t)si.node], invMesh)) continue;
+            std::vector<M4> jm(jl->size());
+            for (size_t k = 0; k < jl->size(); k++) {
+                const int jn = (int)jl->arr[k].num; M4 w = (jn >= 0 && (size_t)jn < L.nodeWorld.size()) ? L.nodeWorld[(size_t)jn] : m4_identity();
+                M4 b = m4_identity(); if (haveIbm) memcpy(b.m, &ibm[16 * k], sizeof(b.m));
+                jm[k] = m4_mul(invMesh, m4_mul(w, b));
+            }
+            const PtMeshDesc& md = L.meshes[(size_t)si.mesh];
+            for (uint32_t g = 0; g < md.numGeometries; g++) {
+                const PtGeometryDesc& gd = L.geoms[md.firstGeometry + g];
+                for (uint32_t v = gd.vertexOffset; v < gd.vertexOffset + gd.numVertices; v++) {
+                    const float* wgt = &L.weights[4 * (size_t)v]; const uint16_t* jnt = &L.joints[4 * (size_t)v];
+                    if (!(wgt[0] + wgt[1] + wgt[2] + wgt[3] > 0.f)) continue;                 // an unskinned primitive of the mesh keeps its bind pose
+                    const double p[3] = {L.positions[3 * (size_t)v], L.positions[3 * (size_t)v + 1], L.positions[3 * (size_t)v + 2]}; double q[3] = {0, 0, 0};
+                    for (int k = 0; k < 4; k++) { if (wgt[k] == 0.f || jnt[k] >= jm.size()) continue; const double* m = jm[jnt[k]].m;
+                        for (int rr = 0; rr < 3; rr++) q[rr] += (double)wgt[k] * (m[rr] * p[0] + m[4 + rr] * p[1] + m[8 + rr] * p[2] + m[12 + rr]); }
+                    for (int rr = 0; rr < 3; rr++) out[3 * (size_t)v + rr] = (float)q[rr];
+                }
+            }
+        }
+        return (int32_t)nv;
+    } catch (...) { a->L.recordWorlds = false; a->L.nodeOverride = nullptr; return -PT_ERROR_IO; }
+}
 extern "C" int32_t pt_gltf_animation_instances(pt_gltf_animation* a, uint32_t animation, float t, PtInstanceDesc* out, uint32_t capacity) {
     if (!a || (capacity && !out)) return -PT_ERROR_INVALID_ARGUMENT;
     try {
