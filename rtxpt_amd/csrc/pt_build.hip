@@ -614,7 +614,9 @@ static hipError_t bvh_ploc(BvhBuildBuffers& b, uint n, hipStream_t st) {
     }
     b.plocPasses = passes;
     if (nodeBase != 2u * n - 1u) return hipErrorUnknown;
-    if (b.builder == BVH_BUILDER_PLOC_OPT && b.riPasses) PT_HIP_TRY(bvh_reinsert(b, n, b.riPasses, st));      // insertion-based optimisation of the finished tree ("prefer fast trace")
+    if (b.builder == BVH_BUILDER_PLOC_OPT && b.riPasses && bvh_reinsert(b, n, b.riPasses, st) != hipSuccess) {      // insertion-based optimisation of the finished tree ("prefer fast trace")
+        (void)hipGetLastError(); b.optimiserPasses = 0u;      // (a tree deeper than RI_MAX_LEVELS: the optimiser works on copies until its last kernel, the PLOC tree is intact and is used as it is)
+    }
     const uint gAll = (2u * n - 1u + 255u) / 256u;
     hipLaunchKernelGGL(k_ploc_first, dim3(gAll), dim3(256), 0, st, n, b.plocParent, b.plocChildA, b.plocCnt, b.plocFirst);
     hipLaunchKernelGGL(k_ploc_finish, dim3(gAll), dim3(256), 0, st, n, b.plocFirst, b.plocParent, b.plocChildA, b.plocChildB, b.plocCnt, b.primsSorted, b.prims,
