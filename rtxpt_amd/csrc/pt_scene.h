@@ -69,13 +69,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));   // v_pk_*_f32 operand
 struct __attribute__((packed, aligned(4))) u32x3p { uint x, y, z; };   // 12-byte child slot load (global_load_dwordx3)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
+#ifndef PT_T8_LANES
+#define PT_T8_LANES 2             // lanes per ray in the traversal kernels: 2 (pt_traverse8p.h, the default since round 3) or 4 (pt_traverse8.h)
+#endif
+#ifndef PT_T8_CHUNK
+#define PT_T8_CHUNK (PT_T8_LANES == 2 ? 32 : 64)      // rays a wave parks in LDS per chunk fetch (<= 64: one per lane)
+#endif
 #ifndef PT_BVH8_STACK
-#define PT_BVH8_STACK 16          // (8 blocks of 256 threads per CU need <= 20 KB of LDS each: 17 x 8 B x 64 quads + the chunk parking lot; 12 entries: -0.6 %, 8: -6 %)
+#define PT_BVH8_STACK (PT_T8_LANES == 2 ? 13 : 16)         // (8 blocks of 256 threads per CU need <= 20 KB of LDS each: 17 x 8 B x 64 quads + the chunk parking lot; 12 entries: -0.6 %, 8: -6 %)
 #endif
 // traversal launch geometry (pt_traverse8.h): 256-thread blocks, 4 lanes per ray -> 64 rays in flight per block, each with an LDS stack of
 // BVH8_STACK entries (odd stride: quads land on different banks) and a T8_SPILL_DEPTH-entry tail in global memory (DeviceScene::travSpill)
 static const uint BVH8_STACK = PT_BVH8_STACK, BVH8_STACK_STRIDE = PT_BVH8_STACK + 1;
-static const uint T8_BLOCK = 256, T8_CHUNK = 64, T8_LANES = 4, T8_GROUPS_PER_BLOCK = T8_BLOCK / T8_LANES, T8_SPILL_DEPTH = 96;
+static const uint T8_BLOCK = 256, T8_CHUNK = PT_T8_CHUNK, T8_LANES = PT_T8_LANES, T8_GROUPS_PER_WAVE = 64 / PT_T8_LANES, T8_GROUPS_PER_BLOCK = T8_BLOCK / T8_LANES, T8_SPILL_DEPTH = 96;
 #ifndef PT_T8_MAX_BLOCKS
 #define PT_T8_MAX_BLOCKS (256 * 6 * 4)
 #endif

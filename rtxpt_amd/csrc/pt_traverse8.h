@@ -22,17 +22,20 @@ namespace ptk {
 struct Traverse8Counters { uint nodeVisits, triTests, leafVisits, iters, leafBlocks; uint ev[8]; unsigned long long cyc[4]; unsigned long long* rayIterHist; uint* longRayCount; float* longRays; };
 
 #define T8_EVENT(k, cond) do { if (COUNT) { unsigned long long m_ = t8_ballot(cond); if (m_ && lane == (uint)__ffsll((long long)m_) - 1u) ctr.ev[k]++; } } while (0)
-static const uint T8_RAY_STRIDE = 9, T8_TASK_STRIDE = 11;                                              // per-wave LDS parking lot for a chunk's rays / tasks (odd strides)
+#ifndef T8_PARK_RCP
+#define T8_PARK_RCP 1           // (pairs build) 1: the ray's three reciprocals are formed once by the lane that fetches it and parked with it in LDS, 0: at every refill
+#endif
+static const uint T8_RAY_STRIDE = (PT_T8_LANES == 2 && T8_PARK_RCP) ? 13 : 9, T8_TASK_STRIDE = (PT_T8_LANES == 2 && T8_PARK_RCP) ? 15 : 11;                                              // per-wave LDS parking lot for a chunk's rays / tasks (odd strides)
 static const uint T8_RAYBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_RAY_STRIDE, T8_TASKBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_TASK_STRIDE;
 static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 
 #ifndef T8_EXTEND_MIN_BLOCKS
-#define T8_EXTEND_MIN_BLOCKS 8    // waves per SIMD the register allocator must leave room for in k_extend (64 VGPRs, 2 spilled outside the loop): 6 -> 7 -> 8 waves were
+#define T8_EXTEND_MIN_BLOCKS (PT_T8_LANES == 2 ? 7 : 8)   // waves per SIMD the register allocator must leave room for in k_extend (64 VGPRs, 2 spilled outside the loop): 6 -> 7 -> 8 waves were
                                   // 1161 -> 1187 -> 1239 Mrays/s in round 2 (profiles/r02n_occupancy_ab.txt). At 8 waves the loop is VALU-issue bound (round 3: extra v_nop
                                   // slots lengthen it one for one, profiles/r03i_valu_bound_probe.txt): from here on instructions per ray count, not waves in flight
 #endif
 #ifndef T8_SHADOW_MIN_WAVES
-#define T8_SHADOW_MIN_WAVES 8     // the same for k_shadow
+#define T8_SHADOW_MIN_WAVES (PT_T8_LANES == 2 ? 7 : 8)    // the same for k_shadow
 #endif
 #ifndef T8_FAST_INNER
 #define T8_FAST_INNER 1          // near/far planes by byte permute, float scales from the node tail, quad hit count by DPP adds
@@ -47,10 +50,10 @@ static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 #define T8_ANYHIT_UNORDERED 1     // 1: occlusion queries number a node's hit children by child index instead of ranking them by entry distance
 #endif
 #ifndef T8_LEAF_QUEUE
-#define T8_LEAF_QUEUE 2         // postponed leaves a ray may hold (1..3) before it has to wait for the wave's next leaf block (A/B: within noise on extend, -4 % on shadow)
+#define T8_LEAF_QUEUE (PT_T8_LANES == 2 ? 3 : 2)        // postponed leaves a ray may hold (1..3) before it has to wait for the wave's next leaf block (A/B: within noise on extend, -4 % on shadow)
 #endif
 #ifndef T8_LEAF_BATCH
-#define T8_LEAF_BATCH 8         // quads (of 16) that must hold a postponed leaf before the wave runs the leaf block (17 = only when a quad is blocked; A/B in profiles/)
+#define T8_LEAF_BATCH (PT_T8_LANES == 2 ? 20u : 8u)        // quads (of 16) that must hold a postponed leaf before the wave runs the leaf block (17 = only when a quad is blocked; A/B in profiles/)
 #endif
 
 // the ray's reciprocal direction is the correctly rounded one of the hit definition (pt_scene.h tri_box_accepts): inner nodes and the triangle's own
@@ -91,6 +94,7 @@ struct __attribute__((packed, aligned(8))) Bvh8ChildPair { uint refA, q0A, q1A, 
 // Dst: void commit(uint tag, const HitInfo& h) ; called by ONE lane of the quad (closest: best hit or prim == ~0; any-hit: prim != ~0 when occluded)
 // Pub: void publish(uint tag, float bestT, uint bestPrim) ; called by one lane for every ray that is split (CAN_SPLIT only)
 //
+#if PT_T8_LANES == 4
 template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, class Src, class Dst, class Pub>
 __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
                                                      Traverse8Counters& ctr, uint* overflowFlag) {
@@ -439,5 +443,6 @@ __device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint
         }
     }
 }
+#endif      // PT_T8_LANES == 4
 
 } // namespace ptk

@@ -1,0 +1,354 @@
+// mi355pt — cooperative BVH8 traversal for wave64, two lanes per ray: a wave carries 32 rays, each owned by a PAIR of lanes; lane h of a pair tests
+// children 4h .. 4h + 3 of the current 128-byte node (48 contiguous bytes: three 16-byte loads) and triangles h, h + 2 of a leaf.
+//
+// Why pairs (round 3): with four lanes per ray (pt_traverse8.h) the loop is VALU-issue bound at 8 waves per SIMD — extra v_nop slots lengthen k_extend one
+// for one (profiles/r03i_valu_bound_probe.txt) — and a wave64 VALU instruction costs its four cycles whatever the lanes do. Of the ~325 VALU instructions of an
+// average wave iteration only the slab tests (~50) and the triangle tests (~110 when the leaf block runs) are work that belongs to a child or a triangle;
+// the rest — refill, child ranking, stack, slot bookkeeping, the alpha test's addressing, the hit reduction — is per-RAY work that every lane of the ray's
+// group repeats. Two lanes per ray halve the replicated share per ray: per lane the slab and triangle work doubles (four children, two triangle rounds), per
+// wave iteration the instruction count rises by about a third, and the iteration advances 32 rays instead of 16.
+// Same interface, same results as traverse8_persistent (the closest hit is traversal-order free: min t, ties to the lower primitive id; an occlusion query
+// reports whether any accepted hit exists), same straggler splitting; see pt_traverse8.h for the description of Src / Dst / Pub and of the template flags.
+#pragma once
+#include "pt_traverse8.h"
+
+namespace ptk {
+
+#define DPP_PAIR_LO 0xA0      // quad_perm [0,0,2,2]: lane 0 of the pair
+#define DPP_PAIR_HI 0xF5      // quad_perm [1,1,3,3]: lane 1 of the pair
+__device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { return (uint)(m >> pl) & 0x3u; }
+
+#ifndef T8_POP2
+#define T8_POP2 0
+#endif
+#if PT_T8_LANES == 2
+template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, class Src, class Dst, class Pub>
+__device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
+                                                Traverse8Counters& ctr, uint* overflowFlag) {
+    static_assert(T8_LANES == 2u, "traverse8_pairs is the two-lanes-per-ray build");
+    const uint RAY_STRIDE = TASKS ? T8_TASK_STRIDE : T8_RAY_STRIDE;
+    const uint lane = threadIdx.x & 63u, h = lane & 1u, pl = lane & ~1u;
+    const uint grp = threadIdx.x >> 1;
+    uint2* stack = stackBase + grp * BVH8_STACK_STRIDE;
+    const uint wavesPerBlock = T8_BLOCK / 64u;
+    const uint waveId = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), numWaves = gridDim.x * wavesPerBlock;
+    const char* nodesBase = reinterpret_cast<const char*>(sc.nodes8);
+    const char* trisBase = reinterpret_cast<const char*>(sc.tris);
+    const uint laneChildOff = 16u + 48u * h, laneTriOff = 48u * h;
+    const uint INF_BITS = 0x7F800000u;
+
+    const uint numWavesU = (uint)__builtin_amdgcn_readfirstlane((int)numWaves);
+    uint chunk = (uint)__builtin_amdgcn_readfirstlane((int)(waveId - numWaves)), chunkPos = 0u, chunkEnd = 0u;
+    const uint rpc = (uint)__builtin_amdgcn_readfirstlane((int)raysPerChunk);
+    bool exhausted = (waveId * rpc >= count) || !sc.rootIsValid;
+    uint* rayBuf = rayBufBase + (threadIdx.x >> 6) * (T8_CHUNK * RAY_STRIDE);
+    uint tailIters = 0u; bool waveDry = false;
+    if (!sc.rootIsValid && waveId == 0 && count) {            // empty scene: every ray misses
+        for (uint i = lane; i < count; i += 64u) { float3 o, d; float a, b, bt; uint sr, bp; uint tag = fetch(i, o, d, a, b, sr, bt, bp); HitInfo hh; hh.t = b; hh.prim = 0xFFFFFFFFu; hh.u = hh.v = 0.f; commit(tag, hh); }
+    }
+    bool active = false;
+    float3 o = make_float3(0.f), d = make_float3(0.f);
+    float ix = 0.f, iy = 0.f, iz = 0.f;
+    uint selN = 0u, selF = 0u;
+    float tmin = 0.f, tmax = FIXED_RANGE ? kMaxRayTravel : 0.f;
+    float bestT = 0.f; uint bestPrim = 0xFFFFFFFFu;
+    uint minePrim = 0xFFFFFFFFu;
+    uint cur = BVH_EMPTY, pend = BVH_EMPTY, sp = 0, tag = 0;
+    uint rayIters = 0;
+    float taskT0 = 0.f; uint taskPrim0 = 0xFFFFFFFFu;
+    uint pend1 = BVH_EMPTY, pend2 = BVH_EMPTY;
+
+    auto stackStore = [&](uint idx, uint ref, uint tbits) {
+        if (idx < BVH8_STACK) stack[idx] = make_uint2(ref, tbits);
+        else {
+            unsigned long long* tail = reinterpret_cast<unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (idx - BVH8_STACK)));
+            __builtin_nontemporal_store(((unsigned long long)tbits << 32) | ref, tail);
+        }
+    };
+
+    bool splitNow = false, stop = false;
+    while (!stop) {
+        unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
+        if (COUNT) tc0 = __builtin_readcyclecounter();
+        // ---- refill idle pairs from the wave's current chunk
+        bool need = !active && !exhausted;
+        unsigned long long needMask = t8_ballot(need && h == 0u);
+        if (needMask) {
+            T8_EVENT(0, true);
+            if (chunkPos >= chunkEnd) {
+                T8_EVENT(1, true);
+                chunk += numWavesU;
+                chunkPos = chunk * rpc; chunkEnd = (chunkPos + rpc < count) ? chunkPos + rpc : count;
+                if (chunkPos >= count) { chunkPos = chunkEnd = count; }
+                if (chunkPos + lane < chunkEnd) {
+                    float3 ro, rd; float rtmin, rtmax, rbestT; uint rstart, rbestPrim;
+                    uint rtag = fetch(chunkPos + lane, ro, rd, rtmin, rtmax, rstart, rbestT, rbestPrim);
+                    uint* slot = rayBuf + lane * RAY_STRIDE;
+                    slot[0] = __float_as_uint(ro.x); slot[1] = __float_as_uint(ro.y); slot[2] = __float_as_uint(ro.z);
+                    slot[3] = __float_as_uint(rd.x); slot[4] = __float_as_uint(rd.y); slot[5] = __float_as_uint(rd.z);
+                    slot[6] = rtag; slot[7] = __float_as_uint(TASKS ? rtmax : rtmin); slot[8] = TASKS ? __float_as_uint(rbestT) : __float_as_uint(rtmax);
+                    if (TASKS) { slot[9] = rbestPrim; slot[10] = rstart; }
+                    if (T8_PARK_RCP) { slot[RAY_STRIDE - 3u] = __float_as_uint(t8_rcp_dir(rd.x)); slot[RAY_STRIDE - 2u] = __float_as_uint(t8_rcp_dir(rd.y)); slot[RAY_STRIDE - 1u] = __float_as_uint(t8_rcp_dir(rd.z)); }
+                }
+            }
+            uint avail = chunkEnd - chunkPos;
+            if (avail == 0u) { if (need) exhausted = true; waveDry = true; }
+            else {
+                uint rank = (uint)__popcll(needMask & ((1ull << pl) - 1ull));
+                uint n = (uint)__popcll(needMask);
+                if (need && rank < avail) {
+                    const uint* slot = rayBuf + (((chunkPos - chunk * rpc) + rank) * RAY_STRIDE);
+                    o = make_float3(__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]));
+                    d = make_float3(__uint_as_float(slot[3]), __uint_as_float(slot[4]), __uint_as_float(slot[5]));
+                    tag = slot[6];
+                    if (T8_PARK_RCP) { ix = __uint_as_float(slot[RAY_STRIDE - 3u]); iy = __uint_as_float(slot[RAY_STRIDE - 2u]); iz = __uint_as_float(slot[RAY_STRIDE - 1u]); }
+                    else {   // three correctly rounded divisions per ray: lane 0 does x, lane 1 does y, both do z
+                        const float mine = t8_rcp_dir(h == 0u ? d.x : d.y);
+                        ix = __uint_as_float((uint)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mine), DPP_PAIR_LO, 0xF, 0xF, true));
+                        iy = __uint_as_float((uint)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mine), DPP_PAIR_HI, 0xF, 0xF, true));
+                        iz = t8_rcp_dir(d.z);
+                    }
+                    {   // child bytes: q0 = lo.x lo.y lo.z hi.x (selector values 0..3), q1 = hi.y hi.z (4, 5)
+                        const uint nxb = ix < 0.f ? 3u : 0u, fxb = ix < 0.f ? 0u : 3u, nyb = iy < 0.f ? 4u : 1u, fyb = iy < 0.f ? 1u : 4u, nzb = iz < 0.f ? 5u : 2u, fzb = iz < 0.f ? 2u : 5u;
+                        selN = nxb | (nyb << 8) | (nzb << 16) | (fxb << 24); selF = fyb | (fzb << 8);
+                    }
+                    if (TASKS) {
+                        if (!FIXED_RANGE) tmax = __uint_as_float(slot[7]);
+                        bestT = taskT0 = __uint_as_float(slot[8]); bestPrim = taskPrim0 = slot[9]; cur = slot[10];
+                    } else {
+                        if (!FIXED_RANGE) { tmin = __uint_as_float(slot[7]); tmax = __uint_as_float(slot[8]); }
+                        bestT = tmax; bestPrim = 0xFFFFFFFFu; cur = 0u;
+                    }
+                    minePrim = 0xFFFFFFFFu; rayIters = 0u;
+                    pend = BVH_EMPTY; pend1 = BVH_EMPTY; pend2 = BVH_EMPTY; sp = 0u; active = true;
+                }
+                chunkPos = (uint)__builtin_amdgcn_readfirstlane((int)(chunkPos + ((n < avail) ? n : avail)));
+            }
+        }
+        bool run = t8_ballot(active) != 0ull;
+        if (!run) { if (t8_ballot(!exhausted) == 0ull) stop = true; }
+        else if (CAN_SPLIT) {
+            if (waveDry) tailIters++;
+            if (tailIters > (uint)(TASKS ? T8_TAIL_ITERS_TASKS : T8_TAIL_ITERS)) { splitNow = true; stop = true; run = false; }
+        }
+        if (run) {
+#ifdef T8_PROBE_VNOPS
+#pragma unroll
+        for (int k_ = 0; k_ < T8_PROBE_VNOPS; k_++) asm volatile("v_nop");
+#endif
+        if (COUNT && lane == 0u) ctr.iters++;
+        if (COUNT && active) rayIters++;
+        if (COUNT) tc1 = __builtin_readcyclecounter();
+        const bool inner = active && !(cur & BVH_LEAF_BIT);
+        const bool leafReady = active && (pend != BVH_EMPTY);
+        const bool queueFull = (T8_LEAF_QUEUE == 1) ? true : ((T8_LEAF_QUEUE == 2) ? (pend1 != BVH_EMPTY) : (pend2 != BVH_EMPTY));
+        const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT) && (cur == BVH_EMPTY || queueFull);
+        const bool runLeaves = ((uint)__popcll(t8_ballot(leafReady && h == 0u)) >= (uint)T8_LEAF_BATCH) || (t8_ballot(leafBlocked) != 0ull);
+        const bool leaf = leafReady && runLeaves;
+        if (COUNT && leaf && h == 0u) ctr.leafVisits++;
+        T8_EVENT(2, inner); T8_EVENT(3, leaf);
+
+        // ---- inner node: lane h tests children 4h .. 4h + 3
+        if (inner) {
+            const uint nodeOff = cur * 128u;
+            const u32x4 hdr = *reinterpret_cast<const u32x4*>(nodesBase + nodeOff);
+            const u32x4 c0 = *reinterpret_cast<const u32x4*>(nodesBase + (nodeOff + laneChildOff));
+            const u32x4 c1 = *reinterpret_cast<const u32x4*>(nodesBase + (nodeOff + laneChildOff + 16u));
+            const u32x4 c2 = *reinterpret_cast<const u32x4*>(nodesBase + (nodeOff + laneChildOff + 32u));
+            const f32x4 scl = *reinterpret_cast<const f32x4*>(nodesBase + (nodeOff + 112u));
+            if (COUNT && h == 0u) ctr.nodeVisits++;
+            const float nx = __uint_as_float(hdr.x), ny = __uint_as_float(hdr.y), nz = __uint_as_float(hdr.z);
+            const float sx = scl.x, sy = scl.y, sz = scl.z;
+            auto slab = [&](uint q0, uint q1, float& tn, float& tf) {
+                const uint N = __builtin_amdgcn_perm(q1, q0, selN), F = __builtin_amdgcn_perm(q1, q0, selF);
+                f32x2 px = __builtin_elementwise_fma((f32x2){(float)(N & 0xFFu), (float)(N >> 24)}, (f32x2){sx, sx}, (f32x2){nx, nx});
+                f32x2 py = __builtin_elementwise_fma((f32x2){(float)((N >> 8) & 0xFFu), (float)(F & 0xFFu)}, (f32x2){sy, sy}, (f32x2){ny, ny});
+                f32x2 pz = __builtin_elementwise_fma((f32x2){(float)((N >> 16) & 0xFFu), (float)((F >> 8) & 0xFFu)}, (f32x2){sz, sz}, (f32x2){nz, nz});
+                f32x2 tx = (px - (f32x2){o.x, o.x}) * (f32x2){ix, ix}, ty = (py - (f32x2){o.y, o.y}) * (f32x2){iy, iy}, tz = (pz - (f32x2){o.z, o.z}) * (f32x2){iz, iz};
+                tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+                tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, bestT));
+            };
+            uint ref[4] = {c0.x, c0.w, c1.z, c2.y};
+            // integer sort keys: tn >= 0 so its bits order like the value; the low 3 mantissa bits carry the child index (unique keys, ties to the lower child);
+            // a child that is not hit gets +inf. The stack entry's distance is the key without its index bits.
+            uint key[4]; bool hit[4];
+            {   float tn, tf;
+                slab(c0.y, c0.z, tn, tf); hit[0] = (ref[0] != BVH_EMPTY) && (tn <= tf * 1.0000012f); key[0] = (hit[0] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h);
+                slab(c1.x, c1.y, tn, tf); hit[1] = (ref[1] != BVH_EMPTY) && (tn <= tf * 1.0000012f); key[1] = (hit[1] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 1u);
+                slab(c1.w, c2.x, tn, tf); hit[2] = (ref[2] != BVH_EMPTY) && (tn <= tf * 1.0000012f); key[2] = (hit[2] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 2u);
+                slab(c2.z, c2.w, tn, tf); hit[3] = (ref[3] != BVH_EMPTY) && (tn <= tf * 1.0000012f); key[3] = (hit[3] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 3u);
+            }
+            uint nhit, rank[4];
+            if (ANYHIT && T8_ANYHIT_UNORDERED) {
+                // an occlusion query has no use for a front-to-back order: the hit children are numbered by child index
+                const uint own = (hit[0] ? 1u : 0u) | (hit[1] ? 2u : 0u) | (hit[2] ? 4u : 0u) | (hit[3] ? 8u : 0u);
+                const uint oth = dpp_u<DPP_QP_XOR1>(own);
+                const uint all = h ? (oth | (own << 4)) : (own | (oth << 4));
+                nhit = (uint)__popc(all);
+                const uint below = (1u << (4u * h)) - 1u;            // children of the other lane that come first
+#pragma unroll
+                for (int k = 0; k < 4; k++) rank[k] = (uint)__popc(all & (below | (((1u << k) - 1u) << (4u * h))));
+            } else {
+                nhit = (hit[0] ? 1u : 0u) + (hit[1] ? 1u : 0u) + (hit[2] ? 1u : 0u) + (hit[3] ? 1u : 0u);
+                nhit += dpp_u<DPP_QP_XOR1>(nhit);
+                // rank = number of keys below mine: six compares among my own four (each decides two ranks), sixteen against the other lane's
+                rank[0] = 3u; rank[1] = 2u; rank[2] = 1u; rank[3] = 0u;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = i + 1; j < 4; j++) { const uint c = (key[i] < key[j]) ? 1u : 0u; rank[j] += c; rank[i] -= c; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint ok = dpp_u<DPP_QP_XOR1>(key[j]);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) rank[k] += (ok < key[k]) ? 1u : 0u;
+                }
+            }
+            uint next = BVH_EMPTY;
+#pragma unroll
+            for (int k = 0; k < 4; k++) next = (hit[k] && rank[k] == 0u) ? ref[k] : next;
+            next &= dpp_u<DPP_QP_XOR1>(next);
+            if (nhit > 1u) {
+                if (sp + nhit - 1u > BVH8_STACK + T8_SPILL_DEPTH) { if (h == 0u) atomicOr(overflowFlag, 1u); }
+                else {      // far to near: nearest on top
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (hit[k] && rank[k] > 0u) stackStore(sp + (nhit - 1u - rank[k]), ref[k], key[k] & ~7u);
+                    sp += nhit - 1u;
+                }
+            }
+            cur = next;
+        }
+
+        if (COUNT) { tc2 = __builtin_readcyclecounter(); if (t8_ballot(leaf) != 0ull && lane == 0u) ctr.leafBlocks++; }
+        // ---- postponed leaf: lane h tests triangles h, h + 2 (h + 4, h + 6 when leaves hold up to 8)
+        if (leaf) {
+            const uint cnt = (pend & 7u) + 1u;
+            const uint slot0 = (pend & 0x7FFFFFFFu) >> 3;
+            const uint triOff0 = slot0 * 48u + laneTriOff;
+            float lt = __uint_as_float(INF_BITS), lu = 0.f, lv = 0.f; uint lp = 0xFFFFFFFFu;
+            bool alphaRan = false;
+#pragma unroll 1
+            for (uint r = 0; r < T8_LEAF_ROUNDS; r++) {
+                const bool doit = (h + T8_LANES * r) < cnt;
+                if (r > 0u && t8_ballot(doit) == 0ull) break;
+                if (doit) {
+                    const char* tp = trisBase + (triOff0 + (T8_LANES * 48u) * r);
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(tp), tb4 = *reinterpret_cast<const f32x4*>(tp + 16), tc = *reinterpret_cast<const f32x4*>(tp + 32);
+                    TriRecord tr; tr.v0 = make_float3(ta.x, ta.y, ta.z); tr.prim = __float_as_uint(ta.w);
+                    tr.e1 = make_float3(tb4.x, tb4.y, tb4.z); tr.flags = __float_as_uint(tb4.w); tr.e2 = make_float3(tc.x, tc.y, tc.z); tr.pad = tc.w;
+                    if (COUNT) ctr.triTests++;
+                    float t, u, v;
+                    if (intersect_tri_mt(tr, o, d, tmin, tmax, t, u, v)) {
+                        bool c;
+                        if (ANYHIT) {
+                            c = t8_tri_box_accepts(tr, o, ix, iy, iz, t);
+                            if (c && (tr.flags & 1u)) { if (COUNT && !(tr.flags & 2u)) alphaRan = true; c = !(tr.flags & 2u) && alpha_test_slot(sc, slot0 + h + T8_LANES * r, u, v); }      // AlphaTestVisibilityRay (BridgeDonut:981-989)
+                        } else {
+                            c = ((t < bestT) || (t == bestT && tr.prim < bestPrim)) && ((t < lt) || (t == lt && tr.prim < lp));
+                            if (c) c = t8_tri_box_accepts(tr, o, ix, iy, iz, t);
+                            if (c && (tr.flags & 1u)) { if (COUNT) alphaRan = true; c = alpha_test_slot(sc, slot0 + h + T8_LANES * r, u, v); }
+                        }
+                        if (c) { lt = t; lp = tr.prim; lu = u; lv = v; }
+                    }
+                }
+            }
+            const bool cand = (lp != 0xFFFFFFFFu);
+            pend = pend1; pend1 = pend2; pend2 = BVH_EMPTY;
+            uint candBits = pair_bits(t8_ballot(cand), pl);
+            T8_EVENT(4, alphaRan); T8_EVENT(5, candBits != 0u);
+            if (candBits) {
+                if (ANYHIT) {
+                    if (h == (uint)__ffs((int)candBits) - 1u) { HitInfo hh; hh.t = lt; hh.prim = lp; hh.u = hh.v = 0.f; commit(tag, hh); }
+                    active = false;
+                } else {
+                    if (cand && !TASKS) { minePrim = lp; mineUV[threadIdx.x] = make_float2(lu, lv); }
+                    float tk = lt; uint pk = lp;      // lexicographic min of (t, prim) over the pair
+                    {   float ot = dpp_f<DPP_QP_XOR1>(tk); uint op = dpp_u<DPP_QP_XOR1>(pk);
+                        bool take = (ot < tk) || (ot == tk && op < pk); tk = take ? ot : tk; pk = take ? op : pk; }
+                    bestT = tk; bestPrim = pk;
+                }
+            }
+        }
+
+        if (COUNT) tc3 = __builtin_readcyclecounter();
+        // ---- slot bookkeeping: a leaf reached by the descent moves to the free leaf slot; an empty node slot pops the stack
+        if (active) {
+            if ((cur & BVH_LEAF_BIT) && cur != BVH_EMPTY) {
+                if (pend == BVH_EMPTY) { pend = cur; cur = BVH_EMPTY; }
+                else if (T8_LEAF_QUEUE > 1 && pend1 == BVH_EMPTY) { pend1 = cur; cur = BVH_EMPTY; }
+                else if (T8_LEAF_QUEUE > 2 && pend2 == BVH_EMPTY) { pend2 = cur; cur = BVH_EMPTY; }
+            }
+            if (cur == BVH_EMPTY) {
+                T8_EVENT(6, true);
+                while (sp > 0u) {
+                    T8_EVENT(7, true);
+#if T8_POP2
+                    // two entries per trip while both lie in LDS: a ray that has just found a hit usually pops a run of entries that are now behind it
+                    if (!ANYHIT && sp >= 2u && sp <= BVH8_STACK) {
+                        const uint2 e1 = stack[sp - 1u], e0 = stack[sp - 2u];
+                        if (__uint_as_float(e1.y) <= bestT) { cur = e1.x; sp -= 1u; break; }
+                        if (__uint_as_float(e0.y) <= bestT) { cur = e0.x; sp -= 2u; break; }
+                        sp -= 2u; continue;
+                    }
+#endif
+                    sp--;
+                    uint2 e;
+                    if (sp < BVH8_STACK) e = stack[sp];
+                    else {
+                        unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (sp - BVH8_STACK))));
+                        e = make_uint2((uint)w, (uint)(w >> 32));
+                    }
+                    if (ANYHIT || __uint_as_float(e.y) <= bestT) { cur = e.x; break; }
+                }
+                if (cur == BVH_EMPTY && pend == BVH_EMPTY) {          // nothing left: report
+                    if (COUNT && h == 0u && ctr.rayIterHist) {
+                        if (rayIters > 2048u) { uint k = atomicAdd(ctr.longRayCount, 1u); if (k < 32u) { float* r = ctr.longRays + 8u * k; r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = (float)rayIters; r[7] = __uint_as_float(tag); } }
+                        if (rayIters >= 128u) { uint bin = 31u - (uint)__clz((int)rayIters); atomicAdd(&ctr.rayIterHist[bin < 15u ? bin : 15u], 1ull); }
+                    }
+                    if (TASKS) {
+                        if (ANYHIT) { /* visible sub-tree: nothing to report */ }
+                        else if (h == 0u && (bestPrim != taskPrim0 || bestT != taskT0)) { HitInfo hh; hh.t = bestT; hh.prim = bestPrim; hh.u = hh.v = 0.f; commit(tag, hh); }
+                    }
+                    else if (ANYHIT) { if (h == 0u) { HitInfo hh; hh.t = tmax; hh.prim = 0xFFFFFFFFu; hh.u = hh.v = 0.f; commit(tag, hh); } }
+                    else if (bestPrim == 0xFFFFFFFFu) { if (h == 0u) { HitInfo hh; hh.t = bestT; hh.prim = 0xFFFFFFFFu; hh.u = hh.v = 0.f; commit(tag, hh); } }
+                    else if (minePrim == bestPrim) { float2 uv = mineUV[threadIdx.x]; HitInfo hh; hh.t = bestT; hh.prim = bestPrim; hh.u = uv.x; hh.v = uv.y; commit(tag, hh); }
+                    active = false;
+                }
+            }
+        }
+        if (COUNT) { unsigned long long tc4 = __builtin_readcyclecounter(); ctr.cyc[0] += tc1 - tc0; ctr.cyc[1] += tc2 - tc1; ctr.cyc[2] += tc3 - tc2; ctr.cyc[3] += tc4 - tc3; }
+        }       // run
+    }
+    if (CAN_SPLIT && splitNow)
+    // ---- every ray still in flight becomes a list of sub-tree tasks: node slot, postponed leaves, stack entries
+    {
+        const uint nSlots = (cur != BVH_EMPTY ? 1u : 0u) + (pend != BVH_EMPTY ? 1u : 0u) + (pend1 != BVH_EMPTY ? 1u : 0u) + (pend2 != BVH_EMPTY ? 1u : 0u);
+        const uint n = active ? nSlots + sp : 0u;
+        uint base = 0u;
+        if (h == 0u && n) base = atomicAdd(taskOut.count, n);
+        base = dpp_u<DPP_PAIR_LO>(base);
+        const bool fits = n && (base + n <= taskOut.capacity);
+        if (active && !fits && h == 0u) atomicOr(overflowFlag, 2u);
+        if (active && fits) {
+            uint* tq = reinterpret_cast<uint*>(taskOut.tasks);
+            if (h == 0u) {
+                uint k = base;
+                if (cur != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = cur; tq[4u * k + 2u] = 0u; k++; }
+                if (pend != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = pend; tq[4u * k + 2u] = 0u; k++; }
+                if (pend1 != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = pend1; tq[4u * k + 2u] = 0u; k++; }
+                if (pend2 != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = pend2; tq[4u * k + 2u] = 0u; k++; }
+                publish(tag, bestT, bestPrim);
+            }
+            for (uint i = h; i < sp; i += T8_LANES) {
+                uint2 e;
+                if (i < BVH8_STACK) e = stack[i];
+                else { unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (i - BVH8_STACK)))); e = make_uint2((uint)w, (uint)(w >> 32)); }
+                const uint k = base + nSlots + i;
+                tq[4u * k] = tag; tq[4u * k + 1u] = e.x; tq[4u * k + 2u] = e.y;
+            }
+        }
+    }
+}
+#endif      // PT_T8_LANES == 2
+
+} // namespace ptk

@@ -4,6 +4,12 @@
 // kernel over a compacted queue, so every wave starts full regardless of how many paths died in the previous bounce.
 #include "pt_wavefront.h"
 #include "pt_traverse8.h"
+#include "pt_traverse8p.h"
+#if PT_T8_LANES == 2
+#define T8_TRAVERSE traverse8_pairs
+#else
+#define T8_TRAVERSE traverse8_persistent
+#endif
 
 namespace ptk {
 
@@ -90,7 +96,7 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
     // a split ray: its best hit so far seeds the merge key, the resolve pass will write pool.hit (k_resolve_extend)
     auto publish = [&](uint p, float bestT, uint bestPrim) { aux.bestKey[p] = t8_hit_key(bestT, bestPrim); aux.resolveList[atomicAdd(&aux.counts[TRAV_RESOLVE], 1u)] = p; };
     if (COUNT) { ctr.rayIterHist = wc->rayIterHistExt; ctr.longRayCount = &wc->longRayCount; ctr.longRays = &wc->longRays[0][0]; }
-    traverse8_persistent<false, COUNT, true, false, true>(sc, count, rpc, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<false, COUNT, true, false, true>(sc, count, rpc, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); wave_add64(ctr.leafVisits, &wc->leafVisitsExt); wave_add64(ctr.iters, &wc->itersExt); wave_add64(ctr.leafBlocks, &wc->leafBlocksExt); if ((threadIdx.x & 63u) == 0u) atomicMax(&wc->itersMaxExt, (unsigned long long)ctr.iters);
                  if ((threadIdx.x & 63u) == 0u) for (int q = 0; q < 4; q++) atomicAdd(&wc->phaseCycExt[q], ctr.cyc[q]);
                  for (int q = 0; q < 8; q++) wave_add64(ctr.ev[q], &wc->eventsExt[q]); }
@@ -102,7 +108,7 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
 #ifndef T8_TASK_SPREAD
 #define T8_TASK_SPREAD 1
 #endif
-__device__ __forceinline__ uint t8_tasks_per_chunk(uint count) { return (!T8_TASK_SPREAD || count > 16u * 4u * T8_TASK_BLOCKS_N) ? 64u : 16u; }
+__device__ __forceinline__ uint t8_tasks_per_chunk(uint count) { return (!T8_TASK_SPREAD || count > T8_GROUPS_PER_WAVE * 4u * T8_TASK_BLOCKS_N || T8_GROUPS_PER_WAVE > T8_CHUNK) ? T8_CHUNK : T8_GROUPS_PER_WAVE; }
 // sub-trees of split extend rays, round STAGE (0..3) of a traversal launch: reads queue STAGE & 1 (count: counts[STAGE]); unless it is the final round, stragglers among
 // the sub-trees are split again into the other queue (count: counts[STAGE + 1]). One counter per round: the whole block is zeroed once per pass (pt_wavefront.h TravAux).
 // Task i of the launch is queue entry (i % 64) * ceil(count / 64) + i / 64: the sub-trees of one ray sit next to each other in the queue and
@@ -118,7 +124,7 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks
     const uint real = t8_tasks_per_chunk(count), per = (count + real - 1u) / real;
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
-        const uint lane = i & 63u, j = lane * per + (i >> 6);
+        const uint lane = i % T8_CHUNK, j = lane * per + i / T8_CHUNK;
         const bool pad = lane >= real || j >= count;                                  // padding of the transposed index space: an empty task
         TravTask t = tasks[pad ? 0u : j];
         if (pad) t.tbits = 0x7F800000u;
@@ -131,7 +137,7 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks
     };
     auto commit = [&](uint p, const HitInfo& h) { atomicMin(&aux.bestKey[p], t8_hit_key(h.t, h.prim)); };
     auto publish = [&](uint p, float bestT, uint bestPrim) { if (bestPrim != 0xFFFFFFFFu) atomicMin(&aux.bestKey[p], t8_hit_key(bestT, bestPrim)); };
-    traverse8_persistent<false, false, true, true, !FINAL>(sc, per * 64u, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<false, false, true, true, !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
 }
 
 // split extend rays: the merged key -> hit record; the barycentrics come from re-intersecting the winning triangle (same arithmetic, same operands)
@@ -287,7 +293,7 @@ __global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_s
     auto commit = [&](uint i, const HitInfo& h) { if (h.prim == 0xFFFFFFFFu) shadow_visible<GROUPED>(pool, sq, i); };      // occluded: nothing is committed
     // a split shadow ray: "visible so far"; its sub-trees may set the flag, k_resolve_shadow applies the contribution if none did
     auto publish = [&](uint i, float, uint) { aux.bestKey[i] = 0ull; aux.resolveList[atomicAdd(&aux.counts[TRAV_RESOLVE], 1u)] = i; };
-    traverse8_persistent<true, COUNT, false, false, true>(sc, count, rpc, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<true, COUNT, false, false, true>(sc, count, rpc, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsSh); wave_add64(ctr.triTests, &wc->triTestsSh); wave_add64(ctr.leafVisits, &wc->leafVisitsSh); wave_add64(ctr.iters, &wc->itersSh); }
 }
 
@@ -302,7 +308,7 @@ __global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, Shado
     const uint real = t8_tasks_per_chunk(count), per = (count + real - 1u) / real;
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
-        const uint lane = i & 63u, j = lane * per + (i >> 6);
+        const uint lane = i % T8_CHUNK, j = lane * per + i / T8_CHUNK;
         const bool pad = lane >= real || j >= count;
         TravTask t = tasks[pad ? 0u : j];
         float4 a = sq.q0[t.tag], b = sq.q1[t.tag];
@@ -312,7 +318,7 @@ __global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, Shado
     };
     auto commit = [&](uint i, const HitInfo& h) { if (h.prim != 0xFFFFFFFFu) aux.bestKey[i] = 1ull; };
     auto publish = [&](uint, float, uint) {};
-    traverse8_persistent<true, false, false, true, !FINAL>(sc, per * 64u, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<true, false, false, true, !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
 }
 
 template <bool GROUPED>
@@ -373,10 +379,10 @@ __global__ void __launch_bounds__(T8_BLOCK) k_trace_probe(DeviceScene sc, const 
     auto publish = [&](uint, float, uint) {};
     if (outClosest) {
         auto commit = [&](uint i, const HitInfo& h) { outClosest[i] = make_float4(h.t, asfloat(h.prim), h.u, h.v); };
-        traverse8_persistent<false, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
+        T8_TRAVERSE<false, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
     } else {
         auto commit = [&](uint i, const HitInfo& h) { outVisible[i] = (h.prim == 0xFFFFFFFFu) ? 1u : 0u; };
-        traverse8_persistent<true, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
+        T8_TRAVERSE<true, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
     }
 }
 
@@ -606,8 +612,9 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
 static inline uint rays_per_chunk(uint count) {
     if (!T8_ADAPTIVE_CHUNKS) return T8_CHUNK;
     const uint resident = 256u * 4u * 8u;
-    uint r = ((count + resident - 1u) / resident + 15u) & ~15u;
-    return r < 16u ? 16u : (r > T8_CHUNK ? T8_CHUNK : r);
+    const uint step = T8_GROUPS_PER_WAVE;                   // one ray per lane group
+    uint r = ((count + resident - 1u) / resident + step - 1u) / step * step;
+    return r < step ? (step > T8_CHUNK ? T8_CHUNK : step) : (r > T8_CHUNK ? T8_CHUNK : r);
 }
 static inline uint grid_for(uint count, uint block, uint maxBlocks) { uint g = (count + block - 1) / block; if (g < 1) g = 1; if (g > maxBlocks) g = maxBlocks; return g; }
 
