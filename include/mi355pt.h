@@ -170,15 +170,16 @@ const char* pt_get_last_error(pt_context* ctx);
 int32_t pt_load_scene_gltf(pt_context* ctx, const char* path);
 /* glTF 2.0 animations of the file pt_load_scene_gltf read (Sample::Animate -> Scene::Animate, Rtxpt/Sample.cpp:785-811; Donut's SceneGraphAnimation is not
    vendored: samplers and channels are evaluated as the glTF specification defines them — LINEAR (spherical for rotations) / STEP / CUBICSPLINE over node
-   translation / rotation / scale, time clamped to the key range; no morph weights; skins: pt_gltf_animation_positions). pt_gltf_animation_instances returns the number of instances and
+   translation / rotation / scale / weights, time clamped to the key range; skins and morph targets: pt_gltf_animation_positions). pt_gltf_animation_instances returns the number of instances and
    writes up to `capacity` transforms in the order pt_load_scene_gltf created them: the `instances` argument of pt_animate. Host only, no device. */
 typedef struct pt_gltf_animation pt_gltf_animation;
 int32_t pt_gltf_animation_load(const char* path, pt_gltf_animation** out, uint32_t* numAnimations, float* durationSeconds);
 int32_t pt_gltf_animation_instances(pt_gltf_animation* anim, uint32_t animation, float timeSeconds, PtInstanceDesc* out, uint32_t capacity);
-/* glTF skins at the same time (Donut's SkinnedMeshInstance: the reference rewrites a skinned instance's vertices every frame and updates its BLAS, Sample.cpp:1065,
+/* glTF skins and morph targets at the same time (Donut's SkinnedMeshInstance: the reference rewrites a skinned instance's vertices every frame and updates its BLAS, Sample.cpp:1065,
    1170-1198): the object-space positions of the file's whole vertex stream with every skinned primitive posed, SUM_k w_k (inverse(meshNode) * joint_k * inverseBind_k) p —
    the `positions` argument of pt_animate (refit, or rebuild). Returns the vertex count; with capacityVertices below it nothing is written. Normals / tangents keep the
-   bind pose; a mesh shared by several skinned nodes takes the last node's pose; no morph targets. Host only. */
+   bind pose; a mesh shared by several nodes takes the last node's pose. Morph targets (primitive.targets, POSITION displacements) are applied before the skin:
+   p = base + SUM_i w_i target_i, the weights from the animation's "weights" channel, else the node's, else the mesh's. Host only. */
 int32_t pt_gltf_animation_positions(pt_gltf_animation* anim, uint32_t animation, float timeSeconds, float* positionsXYZ, uint32_t capacityVertices);
 void    pt_gltf_animation_free(pt_gltf_animation* anim);
 /* raw-buffer path: the same data the bakers upload (GeometryData/InstanceData/PTMaterialData/SubInstanceData, Rtxpt/Sample.cpp:2319-2384) */

@@ -251,6 +251,10 @@ struct Loader {
     std::vector<std::string> instancePath;                         // the names of the glTF nodes from a scene root down to the instance's node, '/'-separated (what Donut's SceneGraph::FindNode walks)
     std::vector<uint16_t> joints; std::vector<float> weights;      // JOINTS_0 / WEIGHTS_0, four per vertex (zeros for an unskinned primitive): read by pt_gltf_animation_positions
     struct SkinnedInstance { int node, skin, mesh; }; std::vector<SkinnedInstance> skinned; std::vector<M4> nodeWorld; bool recordWorlds = false;      // filled by visit() when recordWorlds
+    // morph targets (glTF 2.0 3.7.2.2): per geometry the POSITION displacements of its targets (count x numVertices x 3 floats from `first`), per imported mesh its default weights;
+    // meshNodes: every (node, mesh) pair visit() met while recordWorlds — read by pt_gltf_animation_positions
+    struct GeomMorph { size_t first; uint32_t count; }; std::vector<GeomMorph> geomMorph; std::vector<float> morphDeltas; std::vector<std::vector<double>> meshWeights;
+    struct MeshNode { int node, mesh; }; std::vector<MeshNode> meshNodes;
     struct NodeTRS { bool has[3]; double t[3], q[4], s[3]; };      // animation: per node, the channels that replace its translation / rotation / scale (pt_gltf_animation)
     const std::vector<NodeTRS>* nodeOverride = nullptr;
 
@@ -385,6 +389,15 @@ struct Loader {
                 if (hasSkin) { if (!accessor(at->intOr("JOINTS_0", -1), J, c) || c != 4 || J.size() / 4 != nv) return false; if (!accessor(at->intOr("WEIGHTS_0", -1), Wt, c) || c != 4 || Wt.size() / 4 != nv) return false; }
                 if (pr.get("indices")) { if (!accessor(pr.intOr("indices", -1), I, c) || c != 1) return false; } else { I.resize(nv); for (uint32_t k = 0; k < nv; k++) I[k] = k; }
                 uint32_t ni = (uint32_t)(I.size() / 3) * 3;
+                GeomMorph gm{morphDeltas.size(), 0u};
+                if (const JValue* tg = pr.get("targets")) for (auto& tj : tg->arr) {
+                    std::vector<double> D;
+                    if (tj.get("POSITION")) { if (!accessor(tj.intOr("POSITION", -1), D, c) || c != 3 || D.size() / 3 != nv) { if (err.empty()) err = "morph target POSITION must be VEC3, one per vertex"; return false; } }
+                    else D.assign(3 * (size_t)nv, 0.0);                                  // a target without positions displaces nothing here (normals and tangents keep their base values)
+                    for (double x : D) morphDeltas.push_back((float)x);
+                    gm.count++;
+                }
+                geomMorph.push_back(gm);
                 PtGeometryDesc g; memset(&g, 0, sizeof(g));
                 g.indexOffset = (uint32_t)indices.size(); g.numIndices = ni; g.vertexOffset = (uint32_t)(positions.size() / 3); g.numVertices = nv; g.flags = flags;
                 int mat = pr.intOr("material", -1); g.materialIndex = (mat >= 0 && (size_t)mat < nMat) ? (uint32_t)mat : (uint32_t)nMat;
@@ -399,7 +412,8 @@ struct Loader {
                 }
                 geoms.push_back(g);
             }
-            if (geoms.size() > firstGeom) { PtMeshDesc md; md.firstGeometry = firstGeom; md.numGeometries = (uint32_t)geoms.size() - firstGeom; meshMap[mi] = (int)meshes.size(); meshes.push_back(md); }
+            if (geoms.size() > firstGeom) { PtMeshDesc md; md.firstGeometry = firstGeom; md.numGeometries = (uint32_t)geoms.size() - firstGeom; meshMap[mi] = (int)meshes.size(); meshes.push_back(md);
+                std::vector<double> w; if (const JValue* jw = ms->arr[mi].get("weights")) for (auto& x : jw->arr) w.push_back(x.num); meshWeights.push_back(std::move(w)); }
         }
         return true;
     }
@@ -421,6 +435,7 @@ struct Loader {
         M4 world = m4_mul(parent, local);
         int mesh = n.intOr("mesh", -1);
         if (recordWorlds) { if (nodeWorld.size() < nodes->size()) nodeWorld.resize(nodes->size(), m4_identity()); nodeWorld[(size_t)node] = world;
+                            if (mesh >= 0 && (size_t)mesh < meshMap.size() && meshMap[mesh] >= 0) meshNodes.push_back({node, meshMap[mesh]});
                             if (mesh >= 0 && (size_t)mesh < meshMap.size() && meshMap[mesh] >= 0 && n.intOr("skin", -1) >= 0) skinned.push_back({node, n.intOr("skin", -1), meshMap[mesh]}); }
         if (mesh >= 0 && (size_t)mesh < meshMap.size() && meshMap[mesh] >= 0) {
             PtInstanceDesc inst; memset(&inst, 0, sizeof(inst)); inst.meshIndex = (uint32_t)meshMap[mesh];
@@ -530,11 +545,11 @@ static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path) {
 // ================================================================ glTF animations (SURVEY.md 8f N2 leftovers)
 // The reference animates through Donut's scene graph (Sample::Animate, Rtxpt/Sample.cpp:785-811 -> Scene::Animate, SceneGraphAnimation: not vendored); what a glTF file
 // says about its animations is defined by the glTF 2.0 specification, which is what is implemented here: samplers with LINEAR (spherical for rotations), STEP and
-// CUBICSPLINE interpolation over node translation / rotation / scale channels, time clamped to the sampler's key range. Morph-target weights and skins are not read.
+// CUBICSPLINE interpolation over node translation / rotation / scale / weights channels, time clamped to the sampler's key range. Skins and morph targets: pt_gltf_animation_positions.
 struct pt_gltf_animation {
     Loader L; bool parsed = false;
     struct Sampler { std::vector<double> in, out; int comps = 0; int mode = 0; };      // mode 0 LINEAR, 1 STEP, 2 CUBICSPLINE
-    struct Channel { int sampler, node, path; };                                       // path 0 translation, 1 rotation, 2 scale
+    struct Channel { int sampler, node, path; };                                       // path 0 translation, 1 rotation, 2 scale, 3 weights (morph targets)
     struct Anim { std::vector<Sampler> samplers; std::vector<Channel> channels; double duration = 0; };
     std::vector<Anim> anims;
 };
@@ -562,6 +577,24 @@ void sample_channel(const pt_gltf_animation::Sampler& sp, int path, double t, do
     } else for (int i = 0; i < n; i++) v[i] = a[i] + u * (b[i] - a[i]);
     if (path == 1) quat_normalize(v);
 }
+// a "weights" channel: n scalars per key (n = the number of morph targets of the node's mesh), same three interpolation modes
+bool sample_weights(const pt_gltf_animation::Sampler& sp, size_t n, double t, std::vector<double>& v) {
+    const size_t keys = sp.in.size(), stride = sp.mode == 2 ? n * 3 : n, valueAt = sp.mode == 2 ? n : 0;
+    if (!n || !keys || sp.out.size() != keys * stride) return false;
+    v.assign(n, 0.0);
+    auto value = [&](size_t k, size_t i) { return sp.out[k * stride + valueAt + i]; };
+    if (keys == 1 || t <= sp.in[0]) { for (size_t i = 0; i < n; i++) v[i] = value(0, i); return true; }
+    if (t >= sp.in[keys - 1]) { for (size_t i = 0; i < n; i++) v[i] = value(keys - 1, i); return true; }
+    size_t k = 0; while (k + 2 < keys && sp.in[k + 1] <= t) k++;
+    const double t0 = sp.in[k], t1 = sp.in[k + 1], dt = t1 - t0, u = dt > 0 ? (t - t0) / dt : 0.0, u2 = u * u, u3 = u2 * u;
+    for (size_t i = 0; i < n; i++) {
+        const double a = value(k, i), b = value(k + 1, i);
+        if (sp.mode == 1) v[i] = a;
+        else if (sp.mode == 2) { const double m0 = sp.out[k * stride + n * 2 + i] * dt, m1 = sp.out[(k + 1) * stride + i] * dt; v[i] = (2 * u3 - 3 * u2 + 1) * a + (u3 - 2 * u2 + u) * m0 + (-2 * u3 + 3 * u2) * b + (u3 - u2) * m1; }
+        else v[i] = a + u * (b - a);
+    }
+    return true;
+}
 int32_t gltf_animation_load_impl(const char* path, pt_gltf_animation** out, uint32_t* numAnimations, float* duration) {
     if (!path || !out) return PT_ERROR_INVALID_ARGUMENT;
     *out = nullptr; if (numAnimations) *numAnimations = 0; if (duration) *duration = 0.f;
@@ -579,10 +612,14 @@ int32_t gltf_animation_load_impl(const char* path, pt_gltf_animation** out, uint
         }
         if (const JValue* cs = ja.get("channels")) for (auto& jc : cs->arr) {
             const JValue* tg = jc.get("target"); if (!tg) continue;
-            std::string pth = tg->strOr("path", ""); int pi = pth == "translation" ? 0 : pth == "rotation" ? 1 : pth == "scale" ? 2 : -1;
+            std::string pth = tg->strOr("path", ""); int pi = pth == "translation" ? 0 : pth == "rotation" ? 1 : pth == "scale" ? 2 : pth == "weights" ? 3 : -1;
             int node = tg->intOr("node", -1), smp = jc.intOr("sampler", -1);
-            if (pi < 0 || node < 0) continue;                                            // (weights, or a channel without a node: ignored as the specification allows)
+            if (pi < 0 || node < 0) continue;                                            // (an unknown path, or a channel without a node: ignored as the specification allows)
             if (smp < 0 || (size_t)smp >= an.samplers.size()) return PT_ERROR_IO;
+            if (pi == 3) {                                                               // scalars, (number of targets) per key: checked against the mesh when the weights are evaluated
+                const pt_gltf_animation::Sampler& spw = an.samplers[(size_t)smp]; if (spw.comps != 1) return PT_ERROR_IO;
+                an.channels.push_back({smp, node, pi}); if (spw.in.back() > an.duration) an.duration = spw.in.back(); continue;
+            }
             const pt_gltf_animation::Sampler& sp = an.samplers[(size_t)smp]; const size_t n = pi == 1 ? 4 : 3;
             if ((size_t)sp.comps != n || sp.out.size() != sp.in.size() * n * (sp.mode == 2 ? 3u : 1u)) return PT_ERROR_IO;
             an.channels.push_back({smp, node, pi}); if (sp.in.back() > an.duration) an.duration = sp.in.back();
@@ -602,18 +639,44 @@ extern "C" void pt_gltf_animation_free(pt_gltf_animation* a) { delete a; }
 // Skinned meshes (glTF 2.0 skins; Donut's SkinnedMeshInstance in the reference: Sample.cpp:1065, 1170-1198 rewrites the instance's vertex buffer every frame and updates its
 // BLAS): the posed object-space positions of the WHOLE vertex stream — the `positions` argument of pt_animate. A vertex of a skinned primitive becomes
 // SUM_k w_k (inverse(meshNodeWorld) * jointWorld_k * inverseBind_k) p, the joint matrices of the specification with the mesh node's own transform taken out (the instance keeps it).
-// Normals and tangents keep their bind pose (pt_animate takes positions only). A mesh shared by several skinned nodes takes the pose of the last one.
+// Morph targets (primitive.targets, POSITION displacements) are applied before the skin: p = base + SUM_i w_i target_i with the weights of the animation's "weights"
+// channel, else of the node, else of the mesh. Normals and tangents keep their bind pose (pt_animate takes positions only). A mesh shared by several nodes takes the pose of the last one.
 extern "C" int32_t pt_gltf_animation_positions(pt_gltf_animation* a, uint32_t animation, float t, float* out, uint32_t capacityVertices) {
     if (!a || (capacityVertices && !out)) return -PT_ERROR_INVALID_ARGUMENT;
     try {
         Loader& L = a->L; const uint32_t nv = (uint32_t)(L.positions.size() / 3);
         if (capacityVertices < nv) return (int32_t)nv;                                     // (query: the number of vertices)
         memcpy(out, L.positions.data(), sizeof(float) * L.positions.size());
-        const JValue* skins = L.root.get("skins"); if (!skins || !skins->size()) return (int32_t)nv;
-        L.recordWorlds = true; L.skinned.clear(); L.nodeWorld.clear();
+        const JValue* skins = L.root.get("skins"); const bool haveSkins = skins && skins->size();
+        if (!haveSkins && L.morphDeltas.empty()) return (int32_t)nv;
+        L.recordWorlds = true; L.skinned.clear(); L.nodeWorld.clear(); L.meshNodes.clear();
         std::vector<PtInstanceDesc> scratch(1); int32_t r = pt_gltf_animation_instances(a, animation, t, scratch.data(), 0);      // evaluates the channels and walks the nodes
         L.recordWorlds = false; if (r < 0) return r;
-        for (const Loader::SkinnedInstance& si : L.skinned) {
+        // morph targets first (the specification applies them before the skin): p = base + SUM_i w_i * target_i. Weights: the animation's "weights" channel of the node,
+        // else the node's own `weights`, else the mesh's
+        if (!L.morphDeltas.empty()) {
+            const JValue* nodes = L.root.get("nodes");
+            for (const Loader::MeshNode& mn : L.meshNodes) {
+                if ((size_t)mn.mesh >= L.meshes.size()) continue;
+                const PtMeshDesc& md = L.meshes[(size_t)mn.mesh];
+                uint32_t nT = 0; for (uint32_t g = 0; g < md.numGeometries; g++) if (L.geomMorph[md.firstGeometry + g].count > nT) nT = L.geomMorph[md.firstGeometry + g].count;
+                if (!nT) continue;
+                std::vector<double> w;
+                if (animation < a->anims.size()) for (auto& c : a->anims[animation].channels) if (c.path == 3 && c.node == mn.node) sample_weights(a->anims[animation].samplers[(size_t)c.sampler], nT, (double)t, w);
+                if (w.empty() && nodes && (size_t)mn.node < nodes->size()) if (const JValue* jw = nodes->arr[(size_t)mn.node].get("weights")) for (auto& x : jw->arr) w.push_back(x.num);
+                if (w.empty()) w = L.meshWeights[(size_t)mn.mesh];
+                w.resize(nT, 0.0);
+                for (uint32_t g = 0; g < md.numGeometries; g++) {
+                    const PtGeometryDesc& gd = L.geoms[md.firstGeometry + g]; const Loader::GeomMorph& gm = L.geomMorph[md.firstGeometry + g];
+                    for (uint32_t v = 0; v < gd.numVertices; v++) for (int rr = 0; rr < 3; rr++) {
+                        double p = L.positions[3 * (size_t)(gd.vertexOffset + v) + rr];
+                        for (uint32_t i = 0; i < gm.count; i++) p += w[i] * (double)L.morphDeltas[gm.first + ((size_t)i * gd.numVertices + v) * 3 + rr];
+                        out[3 * (size_t)(gd.vertexOffset + v) + rr] = (float)p;
+                    }
+                }
+            }
+        }
+        if (haveSkins) for (const Loader::SkinnedInstance& si : L.skinned) {
             if ((size_t)si.skin >= skins->size() || (size_t)si.mesh >= L.meshes.size()) continue;
             const JValue& sk = skins->arr[(size_t)si.skin]; const JValue* jl = sk.get("joints"); if (!jl || !jl->size()) continue;
             std::vector<double> ibm; int comps = 0; const bool haveIbm = sk.get("inverseBindMatrices") && L.accessor(sk.intOr("inverseBindMatrices", -1), ibm, comps) && comps == 16 && ibm.size() == 16 * jl->size();
@@ -630,7 +693,7 @@ extern "C" int32_t pt_gltf_animation_positions(pt_gltf_animation* a, uint32_t an
                 for (uint32_t v = gd.vertexOffset; v < gd.vertexOffset + gd.numVertices; v++) {
                     const float* wgt = &L.weights[4 * (size_t)v]; const uint16_t* jnt = &L.joints[4 * (size_t)v];
                     if (!(wgt[0] + wgt[1] + wgt[2] + wgt[3] > 0.f)) continue;                 // an unskinned primitive of the mesh keeps its bind pose
-                    const double p[3] = {L.positions[3 * (size_t)v], L.positions[3 * (size_t)v + 1], L.positions[3 * (size_t)v + 2]}; double q[3] = {0, 0, 0};
+                    const double p[3] = {out[3 * (size_t)v], out[3 * (size_t)v + 1], out[3 * (size_t)v + 2]}; double q[3] = {0, 0, 0};      // (the morphed position)
                     for (int k = 0; k < 4; k++) { if (wgt[k] == 0.f || jnt[k] >= jm.size()) continue; const double* m = jm[jnt[k]].m;
                         for (int rr = 0; rr < 3; rr++) q[rr] += (double)wgt[k] * (m[rr] * p[0] + m[4 + rr] * p[1] + m[8 + rr] * p[2] + m[12 + rr]); }
                     for (int rr = 0; rr < 3; rr++) out[3 * (size_t)v + rr] = (float)q[rr];
@@ -646,7 +709,7 @@ extern "C" int32_t pt_gltf_animation_instances(pt_gltf_animation* a, uint32_t an
         const JValue* nodes = a->L.root.get("nodes"); const size_t nn = nodes ? nodes->size() : 0;
         std::vector<Loader::NodeTRS> ov(nn); for (auto& o : ov) { o.has[0] = o.has[1] = o.has[2] = false; }
         if (animation < a->anims.size()) for (auto& c : a->anims[animation].channels) {
-            if ((size_t)c.node >= nn) continue;
+            if ((size_t)c.node >= nn || c.path > 2) continue;
             Loader::NodeTRS& o = ov[(size_t)c.node]; double v[4] = {0, 0, 0, 1};
             sample_channel(a->anims[animation].samplers[(size_t)c.sampler], c.path, (double)t, v);
             o.has[c.path] = true; if (c.path == 0) memcpy(o.t, v, 24); else if (c.path == 1) memcpy(o.q, v, 32); else memcpy(o.s, v, 24);
