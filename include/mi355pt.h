@@ -206,6 +206,35 @@ int32_t pt_set_environment_compression(pt_context* ctx, uint32_t quality);
  * pt_set_environment_bake takes. AngularSize is raised to pi / (cubeDim / 2) (smaller discs cannot be drawn into the cube), Direction is taken into the
  * environment's local frame with params->Transform (NULL: identity) so the disc keeps its world direction under an environment rotation. No device needed. */
 int32_t pt_env_bake_lights(const PtEnvDirectionalLight* worldLights, uint32_t numLights, const PtEnvMapSceneParams* params, uint32_t cubeDim, PtEnvDirectionalLight* out);
+/* The procedural sky as the cube's source (EnvMapBaker.cpp:372-375, 422, 454-470, 516-533; EnvMapBaker.hlsl:228-236, 247-265; SampleProceduralSky.hlsli,
+ * precomputed_sky.hlsli): with it the base layer adds ProceduralSky() — Bruneton's precomputed atmosphere, the sun disc and ray-marched clouds from a half-resolution
+ * pre-pass cube — to whatever pt_set_environment's image (none: black) and the directional lights give. The constants are the shader's own constant block; the
+ * look-up textures are the host's (the reference loads transmittance_earth / inscatter_earth / irradiance_earth / clouds .dds; its noise texture is bound but
+ * never sampled): RGBA float texels, d = 1 for the 2-D ones. The reference bakes a sky at cubeDim 1024 (pt_set_environment_bake).
+ *   consts == NULL: the sky is switched off;  textures == NULL: the textures of the previous call stay (per-frame constants: time of day, clouds).
+ * Without a pt_set_environment call the environment is enabled with the identity orientation and ColorMultiplier = 1 / c_envMapRadianceScale. */
+typedef struct PtAtmosphereParameters {                /* precomputed_sky.hlsli:23-35 */
+    float StarIrradiance[3], StarAngularDiameter, RayleightScatteringRGB[3], PlanetSurfaceRadius, MieScatteringRGB[3], PlanetAtmosphereRadius;
+    float MieHenyeyGreensteinG, SqDistanceToHorizontalBoundary, AtmosphereHeight, reserved;
+} PtAtmosphereParameters;
+typedef struct PtProceduralSkyConstants {              /* SampleProceduralSky.hlsli:18-46 */
+    PtAtmosphereParameters SkyParams;
+    float FinalRadianceMultiplier[3], _padding3, SunDir[3], CloudsTime, GroundAlbedo[3], SunAngularDiameter;
+    float _padding0, _padding1, sun_solid_angle, _padding2, physical_sky_ground_radiance[3], cloud_density_offset;
+    float sky_transmittance, sky_phase_g, sky_amb_phase_g, sky_scattering;
+} PtProceduralSkyConstants;
+typedef struct PtSkyTexture { const float* rgba; uint32_t width, height, depth, _pad; } PtSkyTexture;
+typedef struct PtProceduralSkyTextures { PtSkyTexture transmittance, scattering, irradiance, clouds; } PtProceduralSkyTextures;
+int32_t pt_set_procedural_sky(pt_context* ctx, const PtProceduralSkyConstants* consts, const PtProceduralSkyTextures* textures);
+/* SampleProceduralSky::Update (Rtxpt/Lighting/Distant/SampleProceduralSky.cpp:67-153) and the members it reads (SampleProceduralSky.h:70-86): scene time and the
+ * preset name of the environment path ("==PROCEDURAL_SKY==", "..._MORNING==", "..._MIDDAY==", "..._EVENING==", "..._DAWN==", "..._PITCHBLACK==", SampleCommon.h:62-67)
+ * -> the constant block. `state` carries the two low-pass filtered times of day and the last scene time between calls (zero it once); params NULL = the
+ * reference's defaults. Returns 1 when the constants differ from the previous call's (the cube must be re-baked), 0 when not, < 0 on error. Host only. */
+typedef struct PtProceduralSkyParams { float colorTint[3], brightness, sunBrightness, cloudsMovementSpeed, timeOfDayMovementSpeed, sunTimeOfDayOffset, sunEastWestRotation,
+                                       sunAngularDiameterDeg, cloudDensityOffset, cloudTransmittance, cloudScattering; } PtProceduralSkyParams;
+typedef struct PtProceduralSkyState { double lastSceneTime; float timeOfDayL1, timeOfDayL2; PtProceduralSkyConstants lastConstants; } PtProceduralSkyState;
+void pt_procedural_sky_default_params(PtProceduralSkyParams* out);
+int32_t pt_procedural_sky_update(PtProceduralSkyState* state, const PtProceduralSkyParams* params, double sceneTime, const char* preset, int32_t forceInstantUpdate, PtProceduralSkyConstants* out);
 /* analytic lights already converted by the host (LightsBaker.cpp:456-556 ConvertLight); emissive triangles are baked automatically */
 int32_t pt_set_lights(pt_context* ctx, const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint32_t numLights);
 

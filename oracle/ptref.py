@@ -426,9 +426,27 @@ class Oracle:
             L.ptref_set_environment_compression(h, int(sc.get("env_compression", 0)))
         else:
             L.ptref_set_environment(h, None, 0, 0, None, None)
+        if sc.get("sky") is not None:
+            self.set_procedural_sky(sc["sky"]["consts"], sc["sky"].get("textures"))
+            if sc.get("env") is None: L.ptref_set_environment_bake(h, int(sc.get("env_cube_dim", 256)), None, 0)
         if sc.get("lights") is not None:
             base, ex = sc["lights"]
             L.ptref_set_lights(h, _p(base), _p(ex), len(base))
+
+    def set_procedural_sky(self, consts, textures=None):
+        import ctypes
+        if consts is None: self.L.ptref_set_procedural_sky(self.h, None, None, None); return
+        cbuf = np.frombuffer(bytes(consts), np.float32).copy() if isinstance(consts, ctypes.Structure) else np.ascontiguousarray(consts, np.float32).reshape(40)
+        if textures is None: self.L.ptref_set_procedural_sky(self.h, _p(cbuf), None, None); return
+        arrs = [np.ascontiguousarray(a, np.float32) for a in textures]
+        dims = np.array([[a.shape[-2], a.shape[-3], a.shape[0] if a.ndim == 4 else 1] for a in arrs], np.uint32)
+        ptrs = (ctypes.c_void_p * 4)(*[a.ctypes.data for a in arrs])
+        self.L.ptref_set_procedural_sky(self.h, _p(cbuf), ptrs, _p(dims))
+
+    def sky_eval(self, mode, rows):
+        """mode 0: ProceduralSkyLowRes (x, y, face, direction) -> (n, 4); 1: atmosphere + sun (.., direction) -> (n, 3); 2: GetSkyRadianceToPoint (.., point) -> (n, 6)"""
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 6); out = np.zeros((len(rows), (4, 3, 6)[mode]), np.float32)
+        self.L.ptref_sky_eval(self.h, int(mode), len(rows), _p(rows), _p(out)); return out
 
     def set_instances(self, inst):
         self._inst = inst

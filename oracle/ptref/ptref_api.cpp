@@ -148,6 +148,12 @@ void build_bvh(Scene& sc) {
 static float4 env_generate_texel(const EnvMap& e, uint px, uint py, uint face, uint dim) {      // GenerateTexel (:194-246), equirectangular source, no procedural sky
     float3 envCol = e.SampleSource(CubemapGetDirectionFor(face, make_float2(((float)px + 0.0f + 0.5f) / (float)dim, ((float)py + 0.0f + 0.5f) / (float)dim)));
     for (const EnvDirectionalLight& l : e.dirLights) envCol = envCol + EnvComputeLightContribution(px, py, face, l, dim);
+    if (e.skyEnabled) {                                       // g_Const.ProcSkyEnabled (EnvMapBaker.hlsl:224-236): toLocal swaps y and z
+        const float3 cubeDir = CubemapGetDirectionFor(face, make_float2(((float)px + 0.5f) / (float)dim, ((float)py + 0.5f) / (float)dim));
+        const float3 cubeDirRight = CubemapGetDirectionFor(face, make_float2((((float)px + 1.0f) + 0.5f) / (float)dim, ((float)py + 0.5f) / (float)dim)) - cubeDir;
+        const float3 cubeDirBottom = CubemapGetDirectionFor(face, make_float2(((float)px + 0.5f) / (float)dim, (((float)py + 1.0f) + 0.5f) / (float)dim)) - cubeDir;
+        envCol = envCol + ProceduralSky(make_float3(cubeDir.x, cubeDir.z, cubeDir.y), e.sky, e.skyLowRes, cubeDir, cubeDirRight, cubeDirBottom);
+    }
     envCol = envCol * kEnvMapRadianceScale;
     envCol = clamp3(envCol, 0.0f, HLF_MAX);
     return make_float4(envCol.x, envCol.y, envCol.z, 1.0f);
@@ -165,6 +171,16 @@ static void bake_env_cube(EnvMap& e) {
         return make_float4(s.x / wsum, s.y / wsum, s.z / wsum, s.w / wsum);
     };
     const uint h = dim / 2;
+    if (e.skyEnabled) {                                                                      // LowResPrePassLayerCS (EnvMapBaker.hlsl:247-265): the clouds at half resolution, RGBA16F
+        for (int i = 0; i < 4; i++) (i == 0 ? e.sky.Transmittance : i == 1 ? e.sky.Scatter : i == 2 ? e.sky.Irradiance : e.sky.Clouds).texels = e.skyTex[i].data();
+        e.skyLowResTexels.assign(6ull * h * h, make_uint2(0, 0));
+        memset(&e.skyLowRes, 0, sizeof(e.skyLowRes)); e.skyLowRes.texels = e.skyLowResTexels.data(); e.skyLowRes.dim = h; e.skyLowRes.mipLevels = 1;
+#pragma omp parallel for schedule(dynamic, 4) collapse(2)
+        for (int face = 0; face < 6; face++) for (int y = 0; y < (int)h; y++) for (uint x = 0; x < h; x++) {
+            const float3 d = CubemapGetDirectionFor((uint)face, make_float2(((float)x + 0.5f) / (float)h, ((float)y + 0.5f) / (float)h));
+            e.skyLowResTexels[((size_t)face * h + (uint)y) * h + x] = env_pack_rgba16f(ProceduralSkyLowRes(x, (uint)y, (uint)face, make_float3(d.x, d.z, d.y), e.sky));
+        }
+    }
 #pragma omp parallel for schedule(dynamic, 4) collapse(2)
     for (int face = 0; face < 6; face++) for (int y = 0; y < (int)h; y++) for (uint x = 0; x < h; x++) {          // BaseLayerCS: 4 texels of mip 0 + their mip-1 texel (from the unrounded values)
         float4 e00 = env_generate_texel(e, 2 * x, 2 * y, face, dim), e01 = env_generate_texel(e, 2 * x, 2 * y + 1, face, dim),
@@ -419,7 +435,8 @@ void ptref_clear_textures(void* h) { ((Context*)h)->sc.textures.clear(); }
 // lat-long float RGB, row 0 at +Y; transform: 12 floats local->world (row major 3x4), colorMultiplier rgb; w==0 disables
 void ptref_set_environment(void* h, const float* rgb, uint32_t w, uint32_t hgt, const float* toWorld, const float* colorMul) {
     Context* c = (Context*)h; EnvMap& e = c->sc.env;
-    e.enabled = (w != 0);
+    e.enabled = (w != 0) || e.skyEnabled;
+    if (!w) { e.tex.w = e.tex.h = 0; e.tex.mips.clear(); }
     if (w) {
         e.tex.w = w; e.tex.h = hgt; e.tex.mips.clear(); e.tex.mips.resize(1); e.tex.mips[0].resize((size_t)w * hgt);
         for (size_t i = 0; i < (size_t)w * hgt; i++) e.tex.mips[0][i] = make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.f);
@@ -434,6 +451,34 @@ void ptref_set_environment(void* h, const float* rgb, uint32_t w, uint32_t hgt, 
     }
     if (colorMul) e.colorMultiplier = make_float3(colorMul[0], colorMul[1], colorMul[2]);
     e.cubeDirty = true; c->lightsDirty = true;
+}
+// the procedural sky (rtxpt_amd: pt_set_procedural_sky): 40 floats of constants (SampleProceduralSky.hlsli:18-46), four RGBA float textures (dims: w, h, d each); consts == null switches it off
+void ptref_set_procedural_sky(void* h, const float* consts, const float* const* rgba, const uint32_t* dims) {
+    Context* c = (Context*)h; EnvMap& e = c->sc.env;
+    if (!consts) { if (e.skyEnabled) { e.skyEnabled = false; if (!e.tex.w) e.enabled = false; } e.cubeDirty = true; c->lightsDirty = true; return; }
+    memcpy(&e.sky.Consts, consts, sizeof(ProceduralSkyConstants));
+    SkyTexture* dst[4] = {&e.sky.Transmittance, &e.sky.Scatter, &e.sky.Irradiance, &e.sky.Clouds};
+    if (rgba) for (int i = 0; i < 4; i++) {
+        const size_t n = (size_t)dims[3 * i] * dims[3 * i + 1] * dims[3 * i + 2];
+        e.skyTex[i].resize(n); memcpy(e.skyTex[i].data(), rgba[i], n * sizeof(float4));
+        dst[i]->texels = e.skyTex[i].data(); dst[i]->w = dims[3 * i]; dst[i]->h = dims[3 * i + 1]; dst[i]->d = dims[3 * i + 2]; dst[i]->_pad = 0;
+    }
+    if (!e.enabled) { if (!e.tex.w) { const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(e.toWorld.m, I, 48); memcpy(e.toLocal.m, I, 48); e.colorMultiplier = make_float3(1.0f / kEnvMapRadianceScale); } e.enabled = true; }
+    e.skyEnabled = true; e.cubeDirty = true; c->lightsDirty = true;
+}
+// the sky's two texel functions on their own (fixtures, the reference-text pin): mode 0 = ProceduralSkyLowRes -> 4 floats, mode 1 = ProceduralSky's atmosphere + sun
+// opening (sky_sun_and_atmosphere) -> 3 floats, mode 2 = GetSkyRadianceToPoint -> radiance, transmittance (6 floats); in: n x (x, y, face as floats, then a direction / point xyz)
+void ptref_sky_eval(void* h, uint32_t mode, uint32_t n, const float* in, float* out) {
+    Context* c = (Context*)h; EnvMap& e = c->sc.env;
+    for (int i = 0; i < 4; i++) (i == 0 ? e.sky.Transmittance : i == 1 ? e.sky.Scatter : i == 2 ? e.sky.Irradiance : e.sky.Clouds).texels = e.skyTex[i].data();
+    const float3 camera = make_float3(0.0f, 0.0f, 6360.1f);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int k = 0; k < (int)n; k++) {
+        const float* a = in + 6 * (size_t)k; const float3 d = make_float3(a[3], a[4], a[5]);
+        if (mode == 0) { float4 r = ProceduralSkyLowRes((uint)a[0], (uint)a[1], (uint)a[2], d, e.sky); float* o = out + 4 * (size_t)k; o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
+        else if (mode == 1) { float3 r = sky_sun_and_atmosphere(e.sky, camera, d); float* o = out + 3 * (size_t)k; o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+        else { float3 t; float3 r = GetSkyRadianceToPoint(e.sky.Consts.SkyParams, e.sky.Transmittance, e.sky.Scatter, camera, d, e.sky.Consts.SunDir, t); float* o = out + 6 * (size_t)k; o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = t.x; o[4] = t.y; o[5] = t.z; }
+    }
 }
 // cube resolution (EnvMapBaker::m_targetResolution: 2048 for an image source) and the directional lights baked into it (Sample::UpdateLighting, Sample.cpp:1361-1388)
 void ptref_set_environment_compression(void* h, uint32_t quality) { Context* c = (Context*)h; c->sc.env.cubeCompression = quality ? 1u : 0u; c->sc.env.cubeDirty = true; c->lightsDirty = true; }

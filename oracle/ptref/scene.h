@@ -15,6 +15,7 @@
 #include <cstdio>
 #include "lights.h"
 #include "envcube.h"
+#include "sky.h"
 #include <vector>
 #include <algorithm>
 
@@ -146,10 +147,13 @@ struct EnvMap {
     // BC6H round trip (EnvMapBaker.cpp:593-633): `cube` is what the path tracer samples — the decoded compressed cube when cubeCompression != 0 — while the importance map keeps
     // reading the uncompressed texels (`cubeSource`, :635)
     uint cubeCompression = 0; std::vector<uint2> cubeTexelsSource; EnvCube cubeSource;
+    // the procedural sky as (additional) source of the bake (EnvMapBaker.hlsl:228-236, 247-265; sky.h): constants, the four look-up textures, the half-resolution cloud pre-pass cube
+    bool skyEnabled = false; ProceduralSkyContext sky; std::vector<float4> skyTex[4]; std::vector<uint2> skyLowResTexels; EnvCube skyLowRes;
     float3 ToLocal(float3 dir) const { return mul_vec_mat3(dir, toLocal); }
     float3 ToWorld(float3 dir) const { return mul_vec_mat3(dir, toWorld); }
     // SampleSource (EnvMapBaker.hlsl:98-110): the equirectangular source through a linear sampler, wrap in u, clamp in v, mip 0
     float3 SampleSource(float3 direction) const {
+        if (!tex.w) return make_float3(0.f, 0.f, 0.f);      // BackgroundSourceType 0: no image (a procedural sky alone)
         float2 uv = world_to_latlong_map(direction);
         float mh = (float)tex.h;
         uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh);

@@ -38,13 +38,16 @@ namespace hl {
 struct RayDesc { float3 Origin; float TMin; float3 Direction; float TMax; };
 // resources that the driver binds carry a pointer (+ pitch); unbound ones read as zero / swallow writes
 template <class T> struct Texture2D { const T* p = nullptr; uint w = 0, h = 0; const ptref::Texture* tex = nullptr;      // tex: a material texture, filtered by the oracle's explicit trilinear fetch
+    const ptref::SkyTexture* lut = nullptr;                                                                                 // lut: a look-up texture of the procedural sky (linear, wrap: ptref::sky_sample2d)
     T Sample(SamplerState, float2 uv) const { return sample_level(uv, 0.f); } T SampleLevel(SamplerState, float2 uv, float lod) const { return sample_level(uv, lod); } T SampleGrad(SamplerState, float2, float2, float2) const { return T(); }
     T sample_level(float2 uv, float lod) const;
     T Load(int3 c) const { return (p && (uint)c.x < w && (uint)c.y < h) ? p[(uint)c.y * w + (uint)c.x] : T(); }          // out-of-range loads return 0 (D3D)
     T Load(uint3 c) const { return Load(int3((int)c.x, (int)c.y, (int)c.z)); } T operator[](uint2 c) const { return Load(int3((int)c.x, (int)c.y, 0)); }
     void GetDimensions(uint& ow, uint& oh) const { ow = tex ? tex->w : w; oh = tex ? tex->h : h; } void GetDimensions(uint, uint& ow, uint& oh, uint& l) const { GetDimensions(ow, oh); l = tex ? tex->mipLevels : 1; } };
 template <class T> T Texture2D<T>::sample_level(float2, float) const { return T(); }
-template <> inline float4 Texture2D<float4>::sample_level(float2 uv, float lod) const { if (!tex) return float4(); ptref::float4 c = ptref::sample_trilinear(*tex, ptref::make_float2(uv.x, uv.y), lod); return float4(c.x, c.y, c.z, c.w); }
+template <> inline float4 Texture2D<float4>::sample_level(float2 uv, float lod) const { if (lut) { ptref::float4 c = ptref::sky_sample2d(*lut, uv.x, uv.y); return float4(c.x, c.y, c.z, c.w); } if (!tex) return float4(); ptref::float4 c = ptref::sample_trilinear(*tex, ptref::make_float2(uv.x, uv.y), lod); return float4(c.x, c.y, c.z, c.w); }
+struct Texture3D { const ptref::SkyTexture* lut = nullptr;                                                                  // the sky's in-scatter and cloud volumes (linear, wrap: ptref::sky_sample3d)
+    float4 SampleLevel(SamplerState, float3 uvw, float) const { if (!lut) return float4(); ptref::float4 c = ptref::sky_sample3d(*lut, ptref::make_float3(uvw.x, uvw.y, uvw.z)); return float4(c.x, c.y, c.z, c.w); } };
 template <class T> struct TextureCube { T (*fetch)(const void*, float3, float) = nullptr; const void* ctx = nullptr;
     T SampleLevel(SamplerState, float3 dir, float lod) const { return fetch ? fetch(ctx, dir, lod) : T(); } };
 template <class T> struct RWTexture2D { T* p = nullptr; uint w = 0; T dummy = T();

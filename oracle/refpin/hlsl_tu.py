@@ -245,14 +245,16 @@ def main_pt(ref):
                  "^EnvMap Bridge::CreateEnvMap..^void Bridge::ExportSurfaceInit"):
         w("// ======== PathTracerBridgeDonut.hlsli : %s\n" % spec)
         w(to_cpp(extract_range(btext, spec, "PathTracerBridgeDonut.hlsli", braw)) + "\n")
-    # EnvMapBaker.hlsl: the cube bake (BaseLayerCS, MIPReduceCS and everything they call) over the stand-in bindings of hlsl_envbake_stubs.h
+    # the procedural sky (SampleProceduralSky.hlsli and, through its include, precomputed_sky.hlsli): whole files, ahead of the baker that calls them
+    emit_file(os.path.join(ref, "Rtxpt/Lighting/Distant/SampleProceduralSky.hlsli"), w, done)
+    # EnvMapBaker.hlsl: the cube bake (LowResPrePassLayerCS, BaseLayerCS, MIPReduceCS and everything they call) over the stand-in bindings of hlsl_envbake_stubs.h
     epath = os.path.join(ref, "Rtxpt/Lighting/Distant/EnvMapBaker.hlsl")
     etext = strip_comments(open(epath, encoding="latin-1").read())
     w("// ======== EnvMapBaker.hlsl (selected items)\nnamespace embake {\n" + re.search(r"^#define\s+EMB_MAXDIRLIGHTS\b.*$", etext, re.M).group(0) + "\n")
     w(to_cpp(extract_struct(etext, "EMB_DirectionalLight", "EnvMapBaker.hlsl")) + "\n")
     w('#include "%s/hlsl_envbake_stubs.h"\n' % HERE)
-    for name in ("CubemapGetDirectionFor", "SampleSource", "SphereQuadrantArea", "CubemapTexelSolidAngle", "CubemapTexelSolidAngle4", "ComputeLightContribution", "GenerateTexel",
-                 "BaseLayerCS", "MIPReduceCS"):
+    for name in ("CubemapGetDirectionFor", "SampleSource", "SphereQuadrantArea", "CubemapTexelSolidAngle", "CubemapTexelSolidAngle4", "ComputeLightContribution", "GetProcSkyContext", "GenerateTexel",
+                 "LowResPrePassLayerCS", "BaseLayerCS", "MIPReduceCS"):
         for body in extract_function(etext, name, "EnvMapBaker.hlsl"): w(to_cpp(body) + "\n")
     w("} // namespace embake\n")
     # EnvMapImportanceSamplingBaker.hlsl: the radiance / importance map pass the light baker's environment quad tree is built from

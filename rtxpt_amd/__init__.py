@@ -26,7 +26,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 # every symbol include/mi355pt.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_positions", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
-    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_env_bake_lights", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
@@ -55,6 +55,59 @@ class PtTextureDesc(ctypes.Structure):
 
 class PtEnvMapSceneParams(ctypes.Structure):
     _fields_ = [("Transform", ctypes.c_float * 12), ("ColorMultiplier", ctypes.c_float * 3), ("Enabled", ctypes.c_float)]
+
+
+class PtProceduralSkyConstants(ctypes.Structure):      # SampleProceduralSky.hlsli:18-46 (40 floats; as_array() gives them as numpy)
+    _fields_ = [("StarIrradiance", ctypes.c_float * 3), ("StarAngularDiameter", ctypes.c_float), ("RayleightScatteringRGB", ctypes.c_float * 3), ("PlanetSurfaceRadius", ctypes.c_float),
+                ("MieScatteringRGB", ctypes.c_float * 3), ("PlanetAtmosphereRadius", ctypes.c_float), ("MieHenyeyGreensteinG", ctypes.c_float), ("SqDistanceToHorizontalBoundary", ctypes.c_float),
+                ("AtmosphereHeight", ctypes.c_float), ("reserved", ctypes.c_float),
+                ("FinalRadianceMultiplier", ctypes.c_float * 3), ("_padding3", ctypes.c_float), ("SunDir", ctypes.c_float * 3), ("CloudsTime", ctypes.c_float),
+                ("GroundAlbedo", ctypes.c_float * 3), ("SunAngularDiameter", ctypes.c_float), ("_padding0", ctypes.c_float), ("_padding1", ctypes.c_float), ("sun_solid_angle", ctypes.c_float),
+                ("_padding2", ctypes.c_float), ("physical_sky_ground_radiance", ctypes.c_float * 3), ("cloud_density_offset", ctypes.c_float),
+                ("sky_transmittance", ctypes.c_float), ("sky_phase_g", ctypes.c_float), ("sky_amb_phase_g", ctypes.c_float), ("sky_scattering", ctypes.c_float)]
+
+    def as_array(self): return np.frombuffer(bytes(self), np.float32).copy()
+
+
+class PtSkyTexture(ctypes.Structure):
+    _fields_ = [("rgba", ctypes.c_void_p), ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("depth", ctypes.c_uint32), ("_pad", ctypes.c_uint32)]
+
+
+class PtProceduralSkyTextures(ctypes.Structure):
+    _fields_ = [("transmittance", PtSkyTexture), ("scattering", PtSkyTexture), ("irradiance", PtSkyTexture), ("clouds", PtSkyTexture)]
+
+
+class PtProceduralSkyParams(ctypes.Structure):         # SampleProceduralSky.h:70-82
+    _fields_ = [("colorTint", ctypes.c_float * 3), ("brightness", ctypes.c_float), ("sunBrightness", ctypes.c_float), ("cloudsMovementSpeed", ctypes.c_float), ("timeOfDayMovementSpeed", ctypes.c_float),
+                ("sunTimeOfDayOffset", ctypes.c_float), ("sunEastWestRotation", ctypes.c_float), ("sunAngularDiameterDeg", ctypes.c_float), ("cloudDensityOffset", ctypes.c_float),
+                ("cloudTransmittance", ctypes.c_float), ("cloudScattering", ctypes.c_float)]
+
+
+class PtProceduralSkyState(ctypes.Structure):
+    _fields_ = [("lastSceneTime", ctypes.c_double), ("timeOfDayL1", ctypes.c_float), ("timeOfDayL2", ctypes.c_float), ("lastConstants", PtProceduralSkyConstants)]
+
+
+def _sky_textures(textures):
+    """four float32 arrays, (h, w, 4) or (d, h, w, 4): transmittance, scattering, irradiance, clouds -> (PtProceduralSkyTextures, the arrays kept alive)"""
+    keep, t = [], PtProceduralSkyTextures()
+    for name, a in zip(("transmittance", "scattering", "irradiance", "clouds"), textures):
+        a = np.ascontiguousarray(a, np.float32); assert a.shape[-1] == 4 and a.ndim in (3, 4)
+        d = a.shape[0] if a.ndim == 4 else 1
+        setattr(t, name, PtSkyTexture(a.ctypes.data, a.shape[-2], a.shape[-3], d, 0)); keep.append(a)
+    return t, keep
+
+
+def procedural_sky_default_params(lib=None):
+    L = lib or load_library(); p = PtProceduralSkyParams(); L.pt_procedural_sky_default_params(ctypes.byref(p)); return p
+
+
+def procedural_sky_update(state, scene_time, preset="==PROCEDURAL_SKY==", params=None, force_instant=False, lib=None):
+    """SampleProceduralSky::Update: -> (PtProceduralSkyConstants, changed). `state`: a PtProceduralSkyState kept between calls (PtProceduralSkyState() to start)."""
+    L = lib or load_library(); out = PtProceduralSkyConstants()
+    L.pt_procedural_sky_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_char_p, ctypes.c_int32, ctypes.c_void_p]; L.pt_procedural_sky_update.restype = ctypes.c_int32
+    r = L.pt_procedural_sky_update(ctypes.byref(state), ctypes.byref(params) if params is not None else None, float(scene_time), preset.encode() if preset is not None else None, 1 if force_instant else 0, ctypes.byref(out))
+    if r < 0: raise RuntimeError("pt_procedural_sky_update failed: %s" % STATUS.get(-r, r))
+    return out, bool(r)
 
 
 class PtDeviceDesc(ctypes.Structure):
@@ -565,9 +618,20 @@ class PathTracer:
             self._chk(self.L.pt_set_environment_compression(self.h, int(sc.get("env_compression", 0))), "pt_set_environment_compression")
         else:
             self._chk(self.L.pt_set_environment(self.h, None, 0, 0, None), "pt_set_environment")
+        if sc.get("sky") is not None:                   # {"consts": PtProceduralSkyConstants or 40 floats, "textures": four arrays}: the procedural sky as the cube's source
+            self.set_procedural_sky(sc["sky"]["consts"], sc["sky"].get("textures"))
+            if sc.get("env") is None: self._chk(self.L.pt_set_environment_bake(self.h, int(sc.get("env_cube_dim", 256)), None, 0), "pt_set_environment_bake")
         if sc.get("lights") is not None:
             base, ex = sc["lights"]
             self._chk(self.L.pt_set_lights(self.h, _p(base), _p(ex), len(base)), "pt_set_lights")
+
+    def set_procedural_sky(self, consts, textures=None):
+        """consts: PtProceduralSkyConstants / 40 float32 values / None (off); textures: four float32 arrays (transmittance, scattering, irradiance, clouds) or None (keep)"""
+        if consts is None: self._chk(self.L.pt_set_procedural_sky(self.h, None, None), "pt_set_procedural_sky"); return
+        cbuf = np.frombuffer(bytes(consts), np.float32).copy() if isinstance(consts, ctypes.Structure) else np.ascontiguousarray(consts, np.float32).reshape(40)
+        t = keep = None
+        if textures is not None: t, keep = _sky_textures(textures)
+        self._chk(self.L.pt_set_procedural_sky(self.h, _p(cbuf), ctypes.byref(t) if t is not None else None), "pt_set_procedural_sky")
 
     def animate(self, instances=None, positions=None, rebuild=False):
         self._chk(self.L.pt_animate(self.h, _p(instances), 0 if instances is None else len(instances), _p(positions), 0 if positions is None else positions.shape[0],

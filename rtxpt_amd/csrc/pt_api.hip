@@ -82,6 +82,7 @@ struct pt_context {
     DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::AlphaPlane> dAlphaPlanes; DevBuf<unsigned char> dAlphaPool; DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
+    bool skyEnabled = false; ptk::ProceduralSkyContext sky; DevBuf<ptk::float4> dSkyTex[4]; DevBuf<ptk::ProceduralSkyContext> dSky; DevBuf<ptk::uint2> dSkyLowRes;      // pt_set_procedural_sky
     DevBuf<ptk::uint2> dEnvCube, dEnvCubeSource; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights; uint envCompression = 0;      // envCompression: EnvMapBaker's BC6U compression (0 off, 1 fast)
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
@@ -193,7 +194,7 @@ int upload_textures(pt_context* c) {
     };
     for (auto& t : c->textures) c->texInfos.push_back(add(t));
     memset(&c->envTexInfo, 0, sizeof(TexInfo));
-    if (c->envEnabled) c->envTexInfo = add(c->envTex);
+    if (c->envEnabled && c->envTex.w) c->envTexInfo = add(c->envTex);      // (a procedural sky alone has no image)
     // alpha planes (pt_scene.h AlphaPlane): the opacity channel of every texture's mip 0 on its own, a byte per texel where every value is k / 255
     std::vector<ptk::AlphaPlane> planes(std::max<size_t>(1, c->textures.size())); std::vector<unsigned char> apool;
     memset(planes.data(), 0, sizeof(ptk::AlphaPlane) * planes.size());
@@ -223,6 +224,7 @@ void refresh_scene_view(pt_context* c) {
     d.geometries = c->dGeometries.p; d.instances = c->dInstances.p; d.subInstances = c->dSubInstances.p; d.subInstToInstGeom = c->dSubInstToInstGeom.p;
     d.materials = c->dMaterials.p; d.materialCount = (uint)c->materials.size(); d.textures = c->dTexInfos.p; d.texels = c->dTexels.p;
     d.envCube = c->envCube; d.envCube.texels = c->dEnvCube.p;
+    d.sky = c->skyEnabled ? c->dSky.p : nullptr; memset(&d.skyLowRes, 0, sizeof(d.skyLowRes)); d.skyLowRes.texels = c->dSkyLowRes.p; d.skyLowRes.dim = c->envCubeDim / 2u; d.skyLowRes.mipLevels = 1u;
     d.envCubeSource = d.envCube; if (c->envCompression && c->dEnvCubeSource.p) d.envCubeSource.texels = c->dEnvCubeSource.p;
     d.envTex = c->envTexInfo; d.envEnabled = c->envEnabled ? 1u : 0u; d.envToWorld = c->envToWorld; d.envToLocal = c->envToLocal; d.envColorMultiplier = c->envColorMul;
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
@@ -447,6 +449,11 @@ int bake_env_cube(pt_context* c) {
     size_t total = 0; for (uint l = 0; l < e.mipLevels; l++) { e.mipOffset[l] = (uint)total; total += 6ull * (e.dim >> l) * (e.dim >> l); }
     PT_CHECK_HIP(c, c->dEnvCube.resize(total));
     PT_CHECK_HIP(c, c->dEnvDirLights.upload(c->envDirLights, c->stream));
+    if (c->skyEnabled) {          // constants + texture views for the kernels, and room for the half-resolution cloud pre-pass
+        ptk::ProceduralSkyContext h = c->sky; h.Transmittance.texels = c->dSkyTex[0].p; h.Scatter.texels = c->dSkyTex[1].p; h.Irradiance.texels = c->dSkyTex[2].p; h.Clouds.texels = c->dSkyTex[3].p;
+        PT_CHECK_HIP(c, c->dSky.resize(1)); PT_CHECK_HIP(c, hipMemcpyAsync(c->dSky.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream)); PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // (h is a local)
+        PT_CHECK_HIP(c, c->dSkyLowRes.resize(6ull * (e.dim / 2u) * (e.dim / 2u)));
+    }
     refresh_scene_view(c);
     launch_env_cube_bake(c->dsc, c->dEnvDirLights.p, (uint)c->envDirLights.size(), c->dEnvCube.p, c->dsc.envCube, c->stream);
     if (c->envCompression) {          // EnvMapBaker.cpp:593-633: the path tracer samples the BC6H cube, the importance baker keeps the uncompressed one
@@ -596,7 +603,8 @@ int32_t pt_set_materials(pt_context* c, const ::PTMaterialData* mats, uint32_t n
 int32_t pt_set_environment(pt_context* c, const float* rgb, uint32_t w, uint32_t h, const PtEnvMapSceneParams* params) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     c->envEnabled = (w != 0 && h != 0 && rgb && (!params || params->Enabled != 0.f));
-    if (c->envEnabled) {
+    if (!c->envEnabled) { c->envTex.w = c->envTex.h = 0; c->envTex.mips.clear(); if (c->skyEnabled && (!params || params->Enabled != 0.f)) c->envEnabled = true; }      // (a procedural sky needs no image)
+    else {
         HostTexture& t = c->envTex; t.w = w; t.h = h; t.mips.clear(); t.mips.resize(1); t.mips[0].resize((size_t)w * h);
         for (size_t i = 0; i < (size_t)w * h; i++) t.mips[0][i] = ptk::make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.f);
         t.mipLevels = 1;                                   // the bake reads mip 0 only (EnvMapBaker.hlsl:98-110: SampleLevel(.., 0))
@@ -611,6 +619,33 @@ int32_t pt_set_environment(pt_context* c, const float* rgb, uint32_t w, uint32_t
         c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale);
     }
     c->texDirty = true; c->lightsDirty = true;
+    return PT_OK;
+}
+int32_t pt_set_procedural_sky(pt_context* c, const PtProceduralSkyConstants* consts, const PtProceduralSkyTextures* tex) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    static_assert(sizeof(PtProceduralSkyConstants) == sizeof(ptk::ProceduralSkyConstants), "ProceduralSkyConstants layout");
+    if (!consts) {
+        if (c->skyEnabled) { c->skyEnabled = false; if (!c->envTex.w) c->envEnabled = false; c->envCubeDirty = true; c->lightsDirty = true; c->texDirty = true; }
+        return PT_OK;
+    }
+    if (tex) {
+        const PtSkyTexture* t[4] = {&tex->transmittance, &tex->scattering, &tex->irradiance, &tex->clouds}; ptk::SkyTexture* dst[4] = {&c->sky.Transmittance, &c->sky.Scatter, &c->sky.Irradiance, &c->sky.Clouds};
+        for (int i = 0; i < 4; i++) {
+            if (!t[i]->rgba || !t[i]->width || !t[i]->height || !t[i]->depth || t[i]->width > 4096u || t[i]->height > 4096u || t[i]->depth > 4096u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "procedural sky: every look-up texture needs RGBA float texels and sizes in [1, 4096]");
+            if ((i == 0 || i == 2) && t[i]->depth != 1u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "procedural sky: the transmittance and irradiance textures are 2-D (depth 1)");
+        }
+        for (int i = 0; i < 4; i++) {
+            const size_t n = (size_t)t[i]->width * t[i]->height * t[i]->depth;
+            PT_CHECK_HIP(c, c->dSkyTex[i].resize(n)); PT_CHECK_HIP(c, hipMemcpy(c->dSkyTex[i].p, t[i]->rgba, n * sizeof(ptk::float4), hipMemcpyHostToDevice));
+            dst[i]->texels = nullptr; dst[i]->w = t[i]->width; dst[i]->h = t[i]->height; dst[i]->d = t[i]->depth; dst[i]->_pad = 0u;
+        }
+    } else if (!c->dSkyTex[0].p) return fail(c, PT_ERROR_INVALID_ARGUMENT, "procedural sky: no look-up textures have been set yet");
+    memcpy(&c->sky.Consts, consts, sizeof(ptk::ProceduralSkyConstants));
+    if (!c->envEnabled) {          // a sky without pt_set_environment: identity orientation, the baked radiance as it is
+        if (!c->envTex.w) { const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale); }
+        c->envEnabled = true; c->texDirty = true;
+    }
+    c->skyEnabled = true; c->envCubeDirty = true; c->lightsDirty = true;
     return PT_OK;
 }
 int32_t pt_set_environment_bake(pt_context* c, uint32_t cubeDim, const PtEnvDirectionalLight* lights, uint32_t n) {

@@ -12,6 +12,7 @@
 #pragma once
 #include "pt_lights.h"
 #include "pt_envcube.h"
+#include "pt_sky.h"
 
 namespace ptk {
 #pragma clang force_cuda_host_device begin
@@ -123,6 +124,8 @@ struct DeviceScene {
     const TexInfo* textures; const float4* texels;
     TexInfo envTex; uint envEnabled; float3x4 envToWorld, envToLocal; float3 envColorMultiplier;      // envTex: the lat-long source (read by the cube bake only)
     EnvCube envCube;           // what the path tracer samples: EnvMapBaker's RGBA16F cube + mips (pt_envcube.h)
+    const ProceduralSkyContext* sky;      // device copy of the procedural sky (constants + the four look-up textures), or null: the cube is baked from the image alone (pt_sky.h)
+    EnvCube skyLowRes;         // the sky's half-resolution cloud pre-pass cube (one level; EnvMapBaker.cpp:318-324 m_cubemapLowRes)
     EnvCube envCubeSource;     // the uncompressed cube the importance map is built from (EnvMapBaker.cpp:635); the same texels as envCube unless the BC6H round trip is on
     LightTable lights;
     const BvhNode* nodes; const Bvh8Node* nodes8; const TriRecord* tris; const uint2* primInfo; uint numTris, rootIsValid;
@@ -197,6 +200,7 @@ static inline float4 sample_grad_anisotropic(const DeviceScene& sc, const TexInf
 }
 // SampleSource (EnvMapBaker.hlsl:98-110): the equirectangular source through a linear sampler (wrap in u, clamp in v), mip 0
 static inline float3 env_sample_source(const DeviceScene& sc, float3 direction) {
+    if (!sc.envTex.w) return make_float3(0.f, 0.f, 0.f);      // BackgroundSourceType 0: no image (a procedural sky alone)
     float2 uv = world_to_latlong_map(direction);
     float mh = (float)sc.envTex.h;
     uv.y = clampf(uv.y, 0.5f / mh, 1.0f - 0.5f / mh);

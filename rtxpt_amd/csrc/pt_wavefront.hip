@@ -400,6 +400,12 @@ __global__ void __launch_bounds__(256) k_unpack(float4* __restrict__ accum, cons
 __device__ __forceinline__ float4 env_generate_texel(const DeviceScene& sc, const EnvDirectionalLight* __restrict__ lights, uint nLights, uint px, uint py, uint face, uint dim) {
     float3 envCol = env_sample_source(sc, CubemapGetDirectionFor(face, make_float2(((float)px + 0.0f + 0.5f) / (float)dim, ((float)py + 0.0f + 0.5f) / (float)dim)));
     for (uint i = 0; i < nLights; i++) envCol = envCol + EnvComputeLightContribution(px, py, face, lights[i], dim);
+    if (sc.sky) {                                       // g_Const.ProcSkyEnabled (EnvMapBaker.hlsl:224-236): toLocal swaps y and z
+        const float3 cubeDir = CubemapGetDirectionFor(face, make_float2(((float)px + 0.5f) / (float)dim, ((float)py + 0.5f) / (float)dim));
+        const float3 cubeDirRight = CubemapGetDirectionFor(face, make_float2((((float)px + 1.0f) + 0.5f) / (float)dim, ((float)py + 0.5f) / (float)dim)) - cubeDir;
+        const float3 cubeDirBottom = CubemapGetDirectionFor(face, make_float2(((float)px + 0.5f) / (float)dim, (((float)py + 1.0f) + 0.5f) / (float)dim)) - cubeDir;
+        envCol = envCol + ProceduralSky(make_float3(cubeDir.x, cubeDir.z, cubeDir.y), *sc.sky, sc.skyLowRes, cubeDir, cubeDirRight, cubeDirBottom);
+    }
     envCol = envCol * kEnvMapRadianceScale;
     envCol = clamp3(envCol, 0.0f, HLF_MAX);
     return make_float4(envCol.x, envCol.y, envCol.z, 1.0f);
@@ -408,6 +414,13 @@ __device__ __forceinline__ float4 env_reduce(float4 e00, float4 e01, float4 e10,
     float wsum = wsa.x + wsa.y + wsa.z + wsa.w;
     float4 s = (e00 * wsa.x + e01 * wsa.y) + e10 * wsa.z + e11 * wsa.w;
     return make_float4(s.x / wsum, s.y / wsum, s.z / wsum, s.w / wsum);
+}
+// LowResPrePassLayerCS (EnvMapBaker.hlsl:247-265): the clouds of the procedural sky at half the cube's resolution, one thread per texel, RGBA16F
+__global__ void __launch_bounds__(256) k_env_sky_lowres(DeviceScene sc, uint2* __restrict__ texels, uint res) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= 6u * res * res) return;
+    const uint face = i / (res * res), r = i - face * res * res, y = r / res, x = r - y * res;
+    const float3 direction = CubemapGetDirectionFor(face, make_float2(((float)x + 0.5f) / (float)res, ((float)y + 0.5f) / (float)res));
+    texels[i] = env_pack_rgba16f(ProceduralSkyLowRes(x, y, face, make_float3(direction.x, direction.z, direction.y), *sc.sky));
 }
 __global__ void __launch_bounds__(256) k_env_cube_base(DeviceScene sc, const EnvDirectionalLight* __restrict__ lights, uint nLights, uint2* __restrict__ texels, EnvCube cube) {
     const uint dim = cube.dim, h = dim / 2u;
@@ -440,6 +453,7 @@ void launch_env_cube_compress(uint2* texels, const EnvCube& cube, hipStream_t st
 }
 void launch_env_cube_bake(const DeviceScene& sc, const EnvDirectionalLight* lights, uint nLights, uint2* texels, const EnvCube& cube, hipStream_t st) {
     const uint h = cube.dim / 2u;
+    if (sc.sky) hipLaunchKernelGGL(k_env_sky_lowres, dim3((6u * h * h + 255u) / 256u), dim3(256), 0, st, sc, const_cast<uint2*>(sc.skyLowRes.texels), h);
     hipLaunchKernelGGL(k_env_cube_base, dim3((6u * h * h + 255u) / 256u), dim3(256), 0, st, sc, lights, nLights, texels, cube);
     for (uint l = 2; l < cube.mipLevels; l++) { const uint d = cube.dim >> l; hipLaunchKernelGGL(k_env_cube_mip, dim3((6u * d * d + 255u) / 256u), dim3(256), 0, st, texels, cube, l); }
 }

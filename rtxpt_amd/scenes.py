@@ -720,3 +720,37 @@ def animate_instances(sc, t):
         tr[11] += 0.5 * math.cos(0.5 * t + 1.3 * k)
         inst["transform"][idx] = tr
     return inst
+
+
+def procedural_sky_textures(seed=SEED_BASE + 21, clouds=(64, 64, 16)):
+    """Synthetic stand-ins for the four look-up textures of the procedural sky (the reference loads q2rtx_env/{transmittance,inscatter,irradiance}_earth.dds and
+    clouds.dds, which no checkout carries): the sizes precomputed_sky.hlsli expects — transmittance 256x64, in-scatter (8*32)x128x32, irradiance 64x16 — smooth,
+    positive and of plausible magnitude, and a tileable cloud volume. float32 RGBA arrays: (h, w, 4) or (d, h, w, 4)."""
+    rng = np.random.default_rng(seed)
+    u = (np.arange(256, dtype=np.float64) + 0.5) / 256.0; v = (np.arange(64, dtype=np.float64) + 0.5) / 64.0
+    depth = (0.15 + 3.0 * (1.0 - u[None, :]) ** 2) * (1.0 - 0.6 * v[:, None])                       # optical depth: long near the horizon (u -> 0), short at altitude
+    tr = np.exp(-depth[..., None] * np.array([0.35, 0.8, 1.9])[None, None, :])
+    transmittance = np.concatenate([tr, np.ones((64, 256, 1))], -1).astype(np.float32)
+    x = (np.arange(256, dtype=np.float64) + 0.5) / 256.0; y = (np.arange(128, dtype=np.float64) + 0.5) / 128.0; z = (np.arange(32, dtype=np.float64) + 0.5) / 32.0
+    X, Y, Z = x[None, None, :], y[None, :, None], z[:, None, None]
+    mus = (X * 8.0) % 1.0                                                                            # eight nu slices side by side, mu_s inside each
+    horizon = np.exp(-((Y - 0.5) / 0.08) ** 2)
+    ray = 60.0 * (0.02 + 0.25 * horizon + 0.05 * Y) * (0.2 + 0.8 * mus) * (1.0 - 0.7 * Z)
+    sc = ray[..., None] * np.array([0.18, 0.42, 1.0])[None, None, None, :]
+    mie = 60.0 * (0.01 + 0.3 * horizon) * (0.2 + 0.8 * mus) * (1.0 - 0.7 * Z) * 0.18                         # alpha: the red channel of the single Mie scattering
+    scattering = np.concatenate([sc, mie[..., None] * np.ones((32, 128, 256, 1))], -1).astype(np.float32)
+    iu = (np.arange(64, dtype=np.float64) + 0.5) / 64.0; iv = (np.arange(16, dtype=np.float64) + 0.5) / 16.0
+    irr = 40.0 * (0.02 + 0.3 * np.clip(iu[None, :] * 2.0 - 0.8, 0.0, 1.0)) * (1.0 + 0.2 * iv[:, None])
+    irradiance = np.concatenate([irr[..., None] * np.array([0.7, 0.85, 1.0])[None, None, :], np.ones((16, 64, 1))], -1).astype(np.float32)
+    cw, ch, cd = clouds
+    cx = np.arange(cw)[None, None, :] / cw; cy = np.arange(ch)[None, :, None] / ch; cz = np.arange(cd)[:, None, None] / cd
+    vol = np.zeros((cd, ch, cw, 4))
+    for c in range(2):                                                                               # tileable: integer frequencies only
+        acc = np.zeros((cd, ch, cw))
+        for k in range(6):
+            fx, fy, fz = rng.integers(1, 6, 3); ph = rng.uniform(0, 2 * np.pi, 3)
+            acc += np.sin(2 * np.pi * fx * cx + ph[0]) * np.sin(2 * np.pi * fy * cy + ph[1]) * np.cos(2 * np.pi * fz * cz + ph[2]) / (1.0 + k)
+        acc = (acc - acc.min()) / (acc.max() - acc.min())
+        vol[..., c] = acc * np.sin(np.pi * np.clip(cz + 0.5 / cd, 0, 1)) if c == 0 else acc              # density falls off towards the layer's bottom and top
+    vol[..., 3] = 1.0
+    return [transmittance, scattering, irradiance, vol.astype(np.float32)]

@@ -100,6 +100,12 @@ def with_sun_discs(make, cube_dim=None, compression=0):
     return build
 
 
+_SKY_TEX = []
+def _sky_textures():
+    if not _SKY_TEX: _SKY_TEX.extend(scenes.procedural_sky_textures())
+    return _SKY_TEX
+
+
 def env_cube_cases():
     """Environment-bake inputs (a tiny scene carrying the source image, the cube resolution and the directional lights): the smallest cube (16: two levels),
     a 32 cube with two discs, a 64 cube of a source with an HDR sun that exceeds the fp16 range after scaling (the clamp to HLF_MAX)."""
@@ -112,7 +118,16 @@ def env_cube_cases():
         return sc
     d0 = -np.array([0.35, 0.8, -0.45]) / np.linalg.norm([0.35, 0.8, -0.45]); d1 = -np.array([-0.5, 0.6, 0.62]) / np.linalg.norm([-0.5, 0.6, 0.62]); d2 = np.array([0.0, 0.0, 1.0])
     lights = [[1.0, 0.92, 0.8, 2.5, d0[0], d0[1], d0[2], 0.09], [0.3, 0.5, 1.0, 0.8, d1[0], d1[1], d1[2], 0.6], [1.0, 0.2, 0.1, 0.3, d2[0], d2[1], d2[2], 3.0]]
+    def procsky(preset, time, dim, image=False, **kw):      # the procedural sky as source (EnvMapBaker.hlsl:228-236, 247-265), alone or on top of an image and discs
+        import rtxpt_amd as pt
+        consts, _ = pt.procedural_sky_update(pt.PtProceduralSkyState(), time, preset, force_instant=True)
+        sc = scene(scenes.sky_equirect(128, 64), dim, lights[:1] if image else None)
+        if not image: sc["env"] = None
+        sc["sky"] = {"consts": consts.as_array(), "textures": _sky_textures()}
+        sc.update(kw); return sc
     return {
+        "procsky_64_midday": procsky("==PROCEDURAL_SKY_MIDDAY==", 0.0, 64),
+        "procsky_32_clock_image_discs_bc6": procsky("==PROCEDURAL_SKY==", 41000.0, 32, image=True, env_compression=1),
         "sky_16": scene(scenes.sky_equirect(128, 64), 16),
         "sky_32_discs": scene(scenes.sky_equirect(256, 128), 32, lights),
         "sky_64_hdr_sun": scene(scenes.sky_equirect(512, 256, sun_radiance=4e5, sun_deg=3.0), 64, lights[:1]),

@@ -18,7 +18,7 @@ def _imports():
     return pt, scenes, ptref, pin_scenes
 
 
-@pytest.mark.parametrize("name", ["sky_16", "sky_32_discs", "sky_64_hdr_sun", "sky_32_discs_bc6", "sky_64_hdr_sun_bc6"])
+@pytest.mark.parametrize("name", ["sky_16", "sky_32_discs", "sky_64_hdr_sun", "sky_32_discs_bc6", "sky_64_hdr_sun_bc6", "procsky_64_midday", "procsky_32_clock_image_discs_bc6"])
 def test_device_cube_matches_reference_text_golden_and_oracle(name):
     pt, scenes, ptref, pin_scenes = _imports()
     sc = pin_scenes.env_cube_cases()[name]
@@ -110,3 +110,34 @@ def test_compressed_cube_frames_and_switching():
     assert g.L.pt_set_environment_compression(g.h, 1) == 0
     g.reset_accumulation(); g.render(first, n); assert np.array_equal(g.radiance(), on)
     assert g.L.pt_set_environment_compression(g.h, 2) == pt.PT_ERROR_UNSUPPORTED
+
+
+def test_procedural_sky_cube_at_1024_and_a_frame_lit_by_it():
+    """EnvMapBaker's resolution for a procedural sky (1024, EnvMapBaker.cpp:374-375): k_env_sky_lowres + the sky term of the base layer equal the oracle's cube
+    (6.3 M texels x 8 levels, pinned to the reference text on the CPU side); a frame lit by the sky alone equals the oracle's; updating the constants
+    without textures re-bakes; switching the sky off leaves no environment."""
+    pt, scenes, ptref, pin_scenes = _imports()
+    consts, _ = pt.procedural_sky_update(pt.PtProceduralSkyState(), 0.0, "==PROCEDURAL_SKY_MIDDAY==", force_instant=True)
+    sc, cam = scenes.cornell_box("C2"); sc = dict(sc); sc["env"] = None
+    sc["sky"] = {"consts": consts, "textures": pin_scenes._sky_textures()}; sc["env_cube_dim"] = 1024
+    S = scenes.config_settings("C2")
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(S)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_settings(S)
+    cube, dim, levels = g.env_cube(); want, d2, l2 = o.env_cube()
+    assert (dim, levels) == (1024, 8) == (d2, l2)
+    bad = (cube != want).any(-1)
+    assert not bad.any(), "%d of %d texels differ" % (int(bad.sum()), bad.size)
+    assert cube.view(np.float16).astype(np.float32).reshape(-1, 4)[:, :3].max() > 1000.0      # the sun disc
+    w, h = 96, 64; camd = scenes.bridge_camera(w, h, **cam)
+    g.set_camera(camd); g.resize(w, h); g.render(0, 2)
+    o.set_camera(camd); o.resize(w, h); o.render(0, 2)
+    a, b = g.radiance(), o.radiance()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a[..., :3].max() > 0
+    # evening constants, textures kept: the cube follows
+    c2, _ = pt.procedural_sky_update(pt.PtProceduralSkyState(), 0.0, "==PROCEDURAL_SKY_EVENING==", force_instant=True)
+    g.set_procedural_sky(c2); o.set_procedural_sky(c2)
+    cube2 = g.env_cube()[0]
+    assert (cube2 != cube).any() and np.array_equal(cube2, o.env_cube()[0])
+    g.set_procedural_sky(None); g.reset_accumulation(); g.render(0, 1)
+    assert g.env_cube()[1] == 0                                                               # no image, no sky: the environment is off
+    g.close(); o.close()
