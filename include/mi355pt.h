@@ -200,7 +200,8 @@ int32_t pt_set_environment_bake(pt_context* ctx, uint32_t cubeDim, const PtEnvDi
 /* EnvMapBaker's BC6U compression of the cube (EnvMapBaker.cpp:593-633, BC6UCompress.hlsl; m_compressionQuality = 1 and enabled by default on D3D12, off on Vulkan): with
  * quality 1 ("Fast": one-region mode 11) every level goes through the reference's encoder and the BC6H_UF16 decode the texture unit applies, and the path tracer samples the
  * result (≈ 0.5 % per texel, 2e-3 relative L2 on an environment-lit frame); the light baker's importance map keeps reading the uncompressed cube, as there. 0 = off (the
- * library's default, the reference on Vulkan); 2 ("Quality", two-region modes) is PT_ERROR_UNSUPPORTED. */
+ * library's default, the reference on Vulkan); 2 = "Quality" (QUALITY 1: the best of the 32 two-region partitions in modes 7.6 / 9.5 replaces the one-region block where its error
+ * estimate is lower). */
 int32_t pt_set_environment_compression(pt_context* ctx, uint32_t quality);
 /* Sample::UpdateLighting (Rtxpt/Sample.cpp:1361-1388), the host step in front of EnvMapBaker::Update: world-space directional lights -> the records
  * pt_set_environment_bake takes. AngularSize is raised to pi / (cubeDim / 2) (smaller discs cannot be drawn into the cube), Direction is taken into the

@@ -189,21 +189,21 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1), lp16=False):
     return L
 
 
-def bc6_encode(texels, reference=False):
-    """BC6UCompress.hlsl's EncodeP1 (the cube compressor's "Fast" mode) on blocks of 16 RGB texels, float32 [n, 16, 3] -> uint32 [n, 4]; reference=True: the reference's
-    own text (librefpin_pt), otherwise the oracle's restatement."""
+def bc6_encode(texels, reference=False, quality=False):
+    """BC6UCompress.hlsl's EncodeP1 (the cube compressor's "Fast" mode; quality=True: CSMain with QUALITY 1, EncodeP1 + the best two-region partition) on blocks of
+    16 RGB texels, float32 [n, 16, 3] -> uint32 [n, 4]; reference=True: the reference's own text (librefpin_pt), otherwise the oracle's restatement."""
     t = np.ascontiguousarray(texels, np.float32).reshape(-1, 48); out = np.zeros((len(t), 4), np.uint32)
     if reference:
         L = refpin_pt()
         if L is None: return None
-        L.refpt_bc6_encode(t.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(t)), out.ctypes.data_as(ctypes.c_void_p))
+        (L.refpt_bc6_encode_quality if quality else L.refpt_bc6_encode)(t.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(t)), out.ctypes.data_as(ctypes.c_void_p))
     else:
-        lib().ptref_bc6_encode(t.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(t)), out.ctypes.data_as(ctypes.c_void_p))
+        (lib().ptref_bc6_encode_quality if quality else lib().ptref_bc6_encode)(t.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(t)), out.ctypes.data_as(ctypes.c_void_p))
     return out
 
 
 def bc6_decode(blocks):
-    """BC6H_UF16 mode-11 blocks, uint32 [n, 4] -> the half bit patterns a fetch returns, uint32 [n, 16, 3]."""
+    """BC6H_UF16 blocks of the modes the cube compressor writes (11; 7.6 and 9.5 with two regions), uint32 [n, 4] -> the half bit patterns a fetch returns, uint32 [n, 16, 3]."""
     b = np.ascontiguousarray(blocks, np.uint32).reshape(-1, 4); out = np.zeros((len(b), 16, 3), np.uint32)
     lib().ptref_bc6_decode(b.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(len(b)), out.ctypes.data_as(ctypes.c_void_p))
     return out

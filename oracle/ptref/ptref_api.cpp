@@ -203,7 +203,7 @@ static void bake_env_cube(EnvMap& e) {
         for (uint l = 0; l < levels; l++) {
             const uint d = dim >> l, nb = d / 4u; uint2* level = T + c.mipOffset[l];
 #pragma omp parallel for schedule(static) collapse(2)
-            for (int face = 0; face < 6; face++) for (int by = 0; by < (int)nb; by++) for (uint bx = 0; bx < nb; bx++) env_cube_bc6_round_trip_block(level, d, (uint)face, bx, (uint)by);
+            for (int face = 0; face < 6; face++) for (int by = 0; by < (int)nb; by++) for (uint bx = 0; bx < nb; bx++) env_cube_bc6_round_trip_block(level, d, (uint)face, bx, (uint)by, e.cubeCompression);
         }
     }
     e.cubeDirty = false;
@@ -481,7 +481,7 @@ void ptref_sky_eval(void* h, uint32_t mode, uint32_t n, const float* in, float* 
     }
 }
 // cube resolution (EnvMapBaker::m_targetResolution: 2048 for an image source) and the directional lights baked into it (Sample::UpdateLighting, Sample.cpp:1361-1388)
-void ptref_set_environment_compression(void* h, uint32_t quality) { Context* c = (Context*)h; c->sc.env.cubeCompression = quality ? 1u : 0u; c->sc.env.cubeDirty = true; c->lightsDirty = true; }
+void ptref_set_environment_compression(void* h, uint32_t quality) { Context* c = (Context*)h; c->sc.env.cubeCompression = quality > 2u ? 2u : quality; c->sc.env.cubeDirty = true; c->lightsDirty = true; }
 void ptref_set_environment_bake(void* h, uint32_t cubeDim, const EnvDirectionalLight* lights, uint32_t n) {
     Context* c = (Context*)h; EnvMap& e = c->sc.env;
     if (cubeDim) e.cubeDim = cubeDim;
@@ -501,8 +501,11 @@ uint32_t ptref_get_env_cube(void* h, uint32_t* out, uint32_t capacity, uint32_t*
 void ptref_bc6_encode(const float* texels, uint32_t n, uint32_t* out) {
     for (uint32_t k = 0; k < n; k++) { float3 t[16]; for (int i = 0; i < 16; i++) t[i] = make_float3(texels[48 * k + 3 * i], texels[48 * k + 3 * i + 1], texels[48 * k + 3 * i + 2]); bc6_encode_p1(t, out + 4 * k); }
 }
+void ptref_bc6_encode_quality(const float* texels, uint32_t n, uint32_t* out) {      // QUALITY 1: EncodeP1 + the best two-region partition
+    for (uint32_t k = 0; k < n; k++) { float3 t[16]; for (int i = 0; i < 16; i++) t[i] = make_float3(texels[48 * k + 3 * i], texels[48 * k + 3 * i + 1], texels[48 * k + 3 * i + 2]); bc6_encode_quality(t, out + 4 * k); }
+}
 void ptref_bc6_decode(const uint32_t* blocks, uint32_t n, uint32_t* halfBits) {
-    for (uint32_t k = 0; k < n; k++) { uint hb[16][3]; bc6_decode_mode11(blocks + 4 * k, hb); for (int i = 0; i < 16; i++) for (int c = 0; c < 3; c++) halfBits[48 * k + 3 * i + c] = hb[i][c]; }
+    for (uint32_t k = 0; k < n; k++) { uint hb[16][3]; bc6_decode(blocks + 4 * k, hb); for (int i = 0; i < 16; i++) for (int c = 0; c < 3; c++) halfBits[48 * k + 3 * i + c] = hb[i][c]; }
 }
 // level 0 of the radiance / importance map the environment quad tree is built from (dim x dim float4; the light baker uses EMISB_IMPORTANCE_MAP_DIM = 1024)
 void ptref_get_env_importance(void* h, uint32_t dim, float* out) {

@@ -269,7 +269,8 @@ def main_pt(ref):
     cpath = os.path.join(ref, "Rtxpt/Lighting/Distant/BC6UCompress.hlsl")
     ctext = strip_comments(open(cpath, encoding="latin-1").read())
     w("// ======== BC6UCompress.hlsl (selected items)\nnamespace bc6u {\n#define INSET_COLOR_BBOX 1\n#define OPTIMIZE_ENDPOINTS 1\n#define LUMINANCE_WEIGHTS 1\nstatic const float HALF_MAX = 65504.0f;\n")
-    for name in ("CalcMSLE", "Quantize10", "Unquantize10", "FinishUnquantize", "Swap", "ComputeIndex4", "InsetColorBBoxP1", "OptimizeEndpointsP1", "EncodeP1"):
+    for name in ("CalcMSLE", "PatternFixupID", "Pattern", "Quantize7", "Quantize9", "Quantize10", "Unquantize7", "Unquantize9", "Unquantize10", "FinishUnquantize", "Swap", "ComputeIndex3", "ComputeIndex4", "SignExtend",
+                 "InsetColorBBoxP1", "OptimizeEndpointsP1", "OptimizeEndpointsP2", "EncodeP1", "DistToLineSq", "EvaluateP2Pattern", "EncodeP2Pattern"):
         for body in extract_function(ctext, name, "BC6UCompress.hlsl"): w(to_cpp(body) + "\n")
     w("} // namespace bc6u\n")
     w("} // namespace hl\n")

@@ -459,7 +459,7 @@ int bake_env_cube(pt_context* c) {
     if (c->envCompression) {          // EnvMapBaker.cpp:593-633: the path tracer samples the BC6H cube, the importance baker keeps the uncompressed one
         PT_CHECK_HIP(c, c->dEnvCubeSource.resize(total));
         PT_CHECK_HIP(c, hipMemcpyAsync(c->dEnvCubeSource.p, c->dEnvCube.p, sizeof(ptk::uint2) * total, hipMemcpyDeviceToDevice, c->stream));
-        launch_env_cube_compress(c->dEnvCube.p, c->dsc.envCube, c->stream);
+        launch_env_cube_compress(c->dEnvCube.p, c->dsc.envCube, c->envCompression, c->stream);
     } else c->dEnvCubeSource.free();
     refresh_scene_view(c);
     PT_CHECK_HIP(c, hipGetLastError());
@@ -660,7 +660,7 @@ int32_t pt_set_environment_bake(pt_context* c, uint32_t cubeDim, const PtEnvDire
 }
 int32_t pt_set_environment_compression(pt_context* c, uint32_t quality) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
-    if (quality > 1u) return fail(c, PT_ERROR_UNSUPPORTED, "BC6U compression quality 2 (two-region modes) is not restated; 0 = off, 1 = fast (the reference's default on D3D12)");
+    if (quality > 2u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "BC6U compression: 0 = off, 1 = fast (the reference's default on D3D12), 2 = quality (two-region modes)");
     if (c->envCompression != quality) { c->envCompression = quality; c->envCubeDirty = true; c->lightsDirty = true; }
     return PT_OK;
 }

@@ -47,7 +47,7 @@ void launch_pack(const float4* accum, const uint* ownedPixels, uint numOwned, ui
 void launch_unpack(float4* accum, const uint* pixels, uint num, uint width, const float4* src, hipStream_t st);
 // EnvMapBaker: lat-long source (sc.envTex) + directional lights -> RGBA16F cube with mips (cube.mipOffset / dim / mipLevels filled by the caller)
 void launch_env_cube_bake(const DeviceScene& sc, const EnvDirectionalLight* lights, uint nLights, uint2* texels, const EnvCube& cube, hipStream_t st);
-void launch_env_cube_compress(uint2* texels, const EnvCube& cube, hipStream_t st);      // every level through BC6UCompress.hlsl's EncodeP1 and the BC6H decode, in place
+void launch_env_cube_compress(uint2* texels, const EnvCube& cube, uint quality, hipStream_t st);      // every level through BC6UCompress.hlsl's encoder (quality 1: EncodeP1; 2: + the two-region modes) and the BC6H decode, in place
 void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, float4* out, hipStream_t st);
 void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const uint* subInstTriOffset, uint numEmissiveSubInst, uint totalTris, uint lightBase,
                           PolymorphicLightInfo* lights, PolymorphicLightInfoEx* lightsEx, hipStream_t st);

@@ -443,13 +443,13 @@ __global__ void __launch_bounds__(256) k_env_cube_mip(uint2* __restrict__ texels
         env_unpack_rgba16f(src[(size_t)(2 * y) * s + 2 * x + 1]), env_unpack_rgba16f(src[(size_t)(2 * y + 1) * s + 2 * x + 1]), CubemapTexelSolidAngle4((float)s, 2 * x, 2 * y)));
 }
 // BC6UCompress.hlsl CSMain (QUALITY 0) + the texture unit's BC6H_UF16 decode, in place: one thread per 4x4 block of one cube level (pt_envcube.h)
-__global__ void __launch_bounds__(64) k_env_cube_bc6(uint2* __restrict__ level, uint dim) {
+__global__ void __launch_bounds__(64) k_env_cube_bc6(uint2* __restrict__ level, uint dim, uint quality) {
     const uint nb = dim / 4u; uint i = blockIdx.x * 64u + threadIdx.x; if (i >= 6u * nb * nb) return;
     const uint face = i / (nb * nb), r = i - face * nb * nb, by = r / nb, bx = r - by * nb;
-    env_cube_bc6_round_trip_block(level, dim, face, bx, by);
+    env_cube_bc6_round_trip_block(level, dim, face, bx, by, quality);
 }
-void launch_env_cube_compress(uint2* texels, const EnvCube& cube, hipStream_t st) {
-    for (uint l = 0; l < cube.mipLevels; l++) { const uint d = cube.dim >> l, nb = d / 4u; hipLaunchKernelGGL(k_env_cube_bc6, dim3((6u * nb * nb + 63u) / 64u), dim3(64), 0, st, texels + cube.mipOffset[l], d); }
+void launch_env_cube_compress(uint2* texels, const EnvCube& cube, uint quality, hipStream_t st) {
+    for (uint l = 0; l < cube.mipLevels; l++) { const uint d = cube.dim >> l, nb = d / 4u; hipLaunchKernelGGL(k_env_cube_bc6, dim3((6u * nb * nb + 63u) / 64u), dim3(64), 0, st, texels + cube.mipOffset[l], d, quality); }
 }
 void launch_env_cube_bake(const DeviceScene& sc, const EnvDirectionalLight* lights, uint nLights, uint2* texels, const EnvCube& cube, hipStream_t st) {
     const uint h = cube.dim / 2u;

@@ -33,5 +33,6 @@ for k in range(1600):
     blocks.append(np.clip(t, 0, 65504))
 T = np.array(blocks, np.float32).astype(np.float16).astype(np.float32)
 out["bc6_texels"] = T; out["bc6_blocks"] = ptref.bc6_encode(T, reference=True)
+out["bc6_blocks_quality"] = ptref.bc6_encode(T, reference=True, quality=True)       # CSMain with QUALITY 1: EncodeP1, EvaluateP2Pattern over the 32 partitions, EncodeP2Pattern
 print("bc6 blocks", out["bc6_blocks"].shape)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "env_cube_golden.npz"), **out)

@@ -134,6 +134,9 @@ def env_cube_cases():
         # ... and through EnvMapBaker's BC6U compression ("Fast", its D3D12 default): BC6UCompress.hlsl's EncodeP1 + the BC6H_UF16 decode, every level
         "sky_32_discs_bc6": dict(scene(scenes.sky_equirect(256, 128), 32, lights), env_compression=1),
         "sky_64_hdr_sun_bc6": dict(scene(scenes.sky_equirect(512, 256, sun_radiance=4e5, sun_deg=3.0), 64, lights[:1]), env_compression=1),
+        # ... and with "Quality" (QUALITY 1: the best of the 32 two-region partitions in modes 7.6 / 9.5 where its error estimate beats the one-region block)
+        "sky_32_discs_bc6q": dict(scene(scenes.sky_equirect(256, 128), 32, lights), env_compression=2),
+        "sky_64_hdr_sun_bc6q": dict(scene(scenes.sky_equirect(512, 256, sun_radiance=4e5, sun_deg=3.0), 64, lights[:1]), env_compression=2),
     }
 
 

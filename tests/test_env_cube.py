@@ -170,6 +170,55 @@ def test_bc6_encoder_matches_reference_text_golden():
     assert ((got[:, 0] & 31) == 3).all()                                    # mode 11
 
 
+def test_bc6_quality_encoder_matches_reference_text_golden():
+    """QUALITY 1 (the reference's "Quality" setting): EncodeP1, then the best-scoring of the 32 two-region partitions encoded in modes 7.6 / 9.5 where its estimate is lower —
+    against blocks from the reference's text (committed). A fair share of the blocks takes a two-region mode, in both of them."""
+    g = np.load(GOLDEN)
+    got = ptref.bc6_encode(g["bc6_texels"], quality=True)
+    bad = (got != g["bc6_blocks_quality"]).any(1)
+    assert not bad.any(), "%d of %d blocks differ" % (int(bad.sum()), len(bad))
+    m76, m95, m11 = ((got[:, 0] & 3) == 1), ((got[:, 0] & 31) == 0xE), ((got[:, 0] & 31) == 3)
+    assert (m76 | m95 | m11).all() and m76.sum() > 100 and m95.sum() > 50 and m11.sum() > 500
+    assert np.array_equal(got[m11], g["bc6_blocks"][m11])                        # where one region wins, the block is the "Fast" one
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="no /root/reference on this machine: the reference text cannot be compiled here")
+def test_bc6_quality_encoder_matches_live_reference_text():
+    rng = np.random.default_rng(45); n = 2000
+    T = np.zeros((n, 16, 3), np.float32)
+    for k in range(n):                                                            # two colour regions behind a random straight edge, a little noise, HDR scale
+        c0, c1 = rng.uniform(0, 1, 3), rng.uniform(0, 1, 3); a = rng.uniform(0, 2 * np.pi); off = rng.uniform(-1.5, 1.5)
+        side = ((np.arange(16) % 4 - 1.5) * np.cos(a) + (np.arange(16) // 4 - 1.5) * np.sin(a)) > off
+        T[k] = np.where(side[:, None], c0, c1) * rng.uniform(0.9, 1.1, (16, 3)) * 10 ** rng.uniform(-2, 3)
+    T = T.astype(np.float16).astype(np.float32); T[::19] = T[::19, :1]
+    a, b = ptref.bc6_encode(T, quality=True), ptref.bc6_encode(T, reference=True, quality=True)
+    assert np.array_equal(a, b) and ((a[:, 0] & 31) != 3).mean() > 0.3
+
+
+def test_bc6_two_region_decode_against_an_independent_decoder():
+    """The decode of the modes QUALITY 1 adds (7.6: 2-bit mode field 01; 9.5: 01110 — delta endpoints, partition table, 3-bit indices, two anchor texels) against Pillow's
+    BC6H decoder at its 8-bit resolution, on blocks made of two colour regions; and the round trip is closer to the source than the one-region mode's."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io, struct
+    rng = np.random.default_rng(7); n = 1024
+    T = np.zeros((n, 16, 3), np.float32)
+    for k in range(n):
+        c0, c1 = rng.uniform(0, 1, 3), rng.uniform(0, 1, 3); a = rng.uniform(0, 2 * np.pi); off = rng.uniform(-1, 1)
+        side = ((np.arange(16) % 4 - 1.5) * np.cos(a) + (np.arange(16) // 4 - 1.5) * np.sin(a)) > off
+        T[k] = np.clip(np.where(side[:, None], c0, c1) * rng.uniform(0.9, 1.1, (16, 3)), 0, 1)
+    T = T.astype(np.float16).astype(np.float32)
+    blk = ptref.bc6_encode(T, quality=True)
+    two = (blk[:, 0] & 31) != 3
+    assert ((blk[:, 0] & 3) == 1).sum() > 100 and ((blk[:, 0] & 31) == 0xE).sum() > 100
+    mine = ptref.bc6_decode(blk).astype(np.uint16).view(np.float16).astype(np.float32).reshape(n, 16, 3)
+    hdr = b"DDS " + struct.pack("<7I", 124, 0x1007, 128, 128, 0, 0, 1) + b"\0" * 44 + struct.pack("<2I4s5I", 32, 4, b"DX10", 0, 0, 0, 0, 0) + struct.pack("<5I", 0x1000, 0, 0, 0, 0) + struct.pack("<5I", 95, 3, 0, 1, 0)
+    im = np.asarray(PIL.open(io.BytesIO(hdr + blk.tobytes())).convert("RGB")).astype(int)
+    pil = im.reshape(32, 4, 32, 4, 3).transpose(0, 2, 1, 3, 4).reshape(n, 16, 3)
+    assert np.array_equal(np.floor(np.clip(mine, 0, 1) * 255).astype(int), pil)
+    fast = ptref.bc6_decode(ptref.bc6_encode(T)).astype(np.uint16).view(np.float16).astype(np.float32).reshape(n, 16, 3)
+    assert np.abs(mine[two] - T[two]).mean() < 0.8 * np.abs(fast[two] - T[two]).mean()
+
+
 @pytest.mark.skipif(not HAVE_REF, reason="no /root/reference on this machine: the reference text cannot be compiled here")
 def test_bc6_encoder_matches_live_reference_text():
     rng = np.random.default_rng(44)
@@ -193,14 +242,14 @@ def test_bc6_mode11_decode_against_an_independent_decoder():
     assert np.array_equal(np.floor(np.clip(mine, 0, 1) * 255).astype(int), pil)
 
 
-@pytest.mark.parametrize("name", ["sky_32_discs_bc6", "sky_64_hdr_sun_bc6"])
+@pytest.mark.parametrize("name", ["sky_32_discs_bc6", "sky_64_hdr_sun_bc6", "sky_32_discs_bc6q", "sky_64_hdr_sun_bc6q"])
 def test_compressed_cube_and_importance_map(name):
     """With compression on, the sampled cube is the reference-text bake sent through the encoder text and the decode (committed golden); the importance map is built from the
     UNCOMPRESSED cube (EnvMapBaker.cpp:635) and therefore equals the uncompressed case's."""
-    g = np.load(GOLDEN); sc = CASES[name]
+    g = np.load(GOLDEN); sc = CASES[name]; base = name.rsplit("_bc6", 1)[0]
     (cube, dim, levels), o = _cube(sc)
-    assert np.array_equal(cube, g[name]) and (cube != g[name[:-4]]).any(-1).mean() > 0.9
+    assert np.array_equal(cube, g[name]) and (cube != g[base]).any(-1).mean() > 0.9
     h = _half(cube); assert np.all(h[:, 3] == 1.0) and np.isfinite(h).all() and (h >= 0).all()
-    assert np.array_equal(o.env_importance(64), g[name[:-4] + "_importance64"]) and np.array_equal(g[name + "_importance64"], g[name[:-4] + "_importance64"])
-    rel = np.abs(_half(cube)[:, :3] - _half(g[name[:-4]])[:, :3]) / (_half(g[name[:-4]])[:, :3] + 1e-3)
+    assert np.array_equal(o.env_importance(64), g[base + "_importance64"]) and np.array_equal(g[name + "_importance64"], g[base + "_importance64"])
+    rel = np.abs(_half(cube)[:, :3] - _half(g[base])[:, :3]) / (_half(g[base])[:, :3] + 1e-3)
     assert np.median(rel) < 0.02

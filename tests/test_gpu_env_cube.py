@@ -18,7 +18,7 @@ def _imports():
     return pt, scenes, ptref, pin_scenes
 
 
-@pytest.mark.parametrize("name", ["sky_16", "sky_32_discs", "sky_64_hdr_sun", "sky_32_discs_bc6", "sky_64_hdr_sun_bc6", "procsky_64_midday", "procsky_32_clock_image_discs_bc6"])
+@pytest.mark.parametrize("name", ["sky_16", "sky_32_discs", "sky_64_hdr_sun", "sky_32_discs_bc6", "sky_64_hdr_sun_bc6", "sky_32_discs_bc6q", "sky_64_hdr_sun_bc6q", "procsky_64_midday", "procsky_32_clock_image_discs_bc6"])
 def test_device_cube_matches_reference_text_golden_and_oracle(name):
     pt, scenes, ptref, pin_scenes = _imports()
     sc = pin_scenes.env_cube_cases()[name]
@@ -109,7 +109,12 @@ def test_compressed_cube_frames_and_switching():
     assert np.array_equal(off, o0.radiance()) and not np.array_equal(on, off)
     assert g.L.pt_set_environment_compression(g.h, 1) == 0
     g.reset_accumulation(); g.render(first, n); assert np.array_equal(g.radiance(), on)
-    assert g.L.pt_set_environment_compression(g.h, 2) == pt.PT_ERROR_UNSUPPORTED
+    assert g.L.pt_set_environment_compression(g.h, 2) == 0                                    # "Quality": the two-region modes
+    g.reset_accumulation(); g.render(first, n); q = g.radiance().copy()
+    sc2 = dict(sc); sc2["env_compression"] = 2
+    o2 = ptref.Oracle(); o2.set_scene(sc2); o2.set_camera(camd); o2.set_settings(S); o2.resize(w, h); o2.render(first, n)
+    assert np.array_equal(q, o2.radiance()) and np.array_equal(g.env_cube()[0], o2.env_cube()[0]) and not np.array_equal(q, on)
+    assert g.L.pt_set_environment_compression(g.h, 3) == pt.PT_ERROR_INVALID_ARGUMENT
 
 
 def test_procedural_sky_cube_at_1024_and_a_frame_lit_by_it():
