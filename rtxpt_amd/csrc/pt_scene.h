@@ -55,9 +55,12 @@ struct TriRecord { float3 v0; uint prim; float3 e1; uint flags; float3 e2; float
 static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
 struct BvhNode { float3 lmin, lmax, rmin, rmax; uint left, right, _pad0, _pad1; };           // child ref: bit31 = leaf (first<<3 | count-1)
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
-#ifndef PT_BVH_MAX_LEAF
-#define PT_BVH_MAX_LEAF 4
+#ifndef PT_T8_LANES
+#define PT_T8_LANES 2             // lanes per ray in the traversal kernels: 2 (pt_traverse8p.h, the default since round 3) or 4 (pt_traverse8.h)
 #endif
+#ifndef PT_BVH_MAX_LEAF
+#define PT_BVH_MAX_LEAF (PT_T8_LANES == 2 ? 2 : 4)      // triangles per leaf = lanes per ray: a leaf is tested in one round. With pairs, 2 instead of 4: k_extend 48.3 -> 43.6 ms, k_shadow 14.0 -> 12.2 ms
+#endif                                                  // (1: 50.6 / 13.6 ms; 3: 46.1 / 13.3; 6: 51.9 / 15.3 — profiles/r03u_leafsize_ab*.txt)
 static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_LEAF = PT_BVH_MAX_LEAF, BVH_STACK = 64;
 // BVH8 node, 128 B = one cache line: the 8 lanes of a ray's lane group each fetch one 12 B child slot plus the shared 16 B header, so a
 // whole node costs one line lookup per group instead of four 16 B gathers per lane. Child boxes are 8-bit quantised relative to the node
@@ -70,9 +73,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));   // v_pk_*_f32 operand
 struct __attribute__((packed, aligned(4))) u32x3p { uint x, y, z; };   // 12-byte child slot load (global_load_dwordx3)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
-#ifndef PT_T8_LANES
-#define PT_T8_LANES 2             // lanes per ray in the traversal kernels: 2 (pt_traverse8p.h, the default since round 3) or 4 (pt_traverse8.h)
-#endif
 #ifndef PT_T8_CHUNK
 #define PT_T8_CHUNK (PT_T8_LANES == 2 ? 32 : 64)      // rays a wave parks in LDS per chunk fetch (<= 64: one per lane)
 #endif
