@@ -202,7 +202,6 @@ def main():
                          "avg_launch_ms": ext_ms / max(1, ext_launches), "launches": ext_launches,
                          "kernel_ms_per_step": {"k_extend": ext_ms / ROOF_STEPS, "k_shade": shade_ms / ROOF_STEPS, "k_shadow": sh_ms / ROOF_STEPS},
                          "measured_on": "%d serial-kernel steps after the timed region (launches do not overlap); serial frame %.1f ms vs pipelined %.1f ms" % (ROOF_STEPS, serial_ms, elapsed / args.steps * 1e3),
-                         "overlapped_kernel_ms_per_step": {"k_extend": sum(s["extendKernelMs"] for s in stats) / args.steps, "k_shade": sum(s["shadeKernelMs"] for s in stats) / args.steps, "k_shadow": sum(s["shadowKernelMs"] for s in stats) / args.steps},
                          "shadow_node_visits_per_ray": nodes_per_sh, "shadow_tri_tests_per_ray": tris_per_sh,
                          "leaf_visits_per_ray": cst["leafVisitsExtend"] / max(1, cst["extendRays"]),
                          "wave_iterations_per_ray": cst["waveItersExtend"] / max(1, cst["extendRays"]),

@@ -142,7 +142,8 @@ typedef struct PtFrameStats {
     float    longRays[32][8];
     uint64_t extendEvents[8];               /* wave-level block executions: refill, chunk load, inner, leaf, alpha test, hit reduction, pop loop, pop trips */
     double   gpuMilliseconds;                               /* whole pt_render call, HIP events */
-    double   extendKernelMs, shadeKernelMs, shadowKernelMs; /* summed per-kernel HIP-event time */
+    double   extendKernelMs, shadeKernelMs, shadowKernelMs; /* summed per-launch HIP-event time: filled for serial-kernel frames (pt_set_serial_kernels), counter builds and under
+                                                               MI355PT_PASS_LOG; zero for pipelined frames, whose launches carry no events (ten API calls per pass and batch) */
     uint32_t extendLaunches, iterations;
     uint32_t pathsTraced, _pad;
 } PtFrameStats;

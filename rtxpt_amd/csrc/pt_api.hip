@@ -804,7 +804,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
         uint cur = 0, active = 0, iterations = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false;
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; uint items; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
-        size_t mark() { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
+        bool timed = false;      // per-launch HIP events: only when somebody reads them (serial-kernel steps, the pass log) — ten API calls per pass and batch otherwise
+        size_t mark() { if (!timed) return 0; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
     const uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
     Batch B[PT_PIPELINE_BATCHES];
@@ -820,6 +821,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.k = k; t.k.sc = t.sc;
         t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + PASS_COUNTERS * b;
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
+        t.timed = c->serialKernels || c->countersEnabled || getenv("MI355PT_PASS_LOG") != nullptr;
         memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
         t.active = t.total;
     }
@@ -842,11 +844,9 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             t.waiting = false;
             if (!t.active || t.iterations >= maxIter) continue;
             uint nxt = t.cur ^ 1u;
-            PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->extendCount[nxt], 0, 4, t.st));
-            PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st));
-            launch_pass_reset(t.aux.counts, t.st);      // the pass's traversal / class counters: one reset instead of one in front of every launch
-            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); t.spans.push_back({e0, e1, 0, t.active});
-            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, reinterpret_cast<uint*>(t.aux.bestKey) /* the straggler keys are idle between k_resolve_extend and the shadow launch */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); t.spans.push_back({e1, e2, 1, t.active});
+            launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch
+            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
+            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, reinterpret_cast<uint*>(t.aux.bestKey) /* the straggler keys are idle between k_resolve_extend and the shadow launch */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
             t.extendRays += t.active;
             PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
             t.waiting = true;
@@ -859,7 +859,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
             uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
             TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
-            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, auxShadow, t.st); size_t s1 = t.mark(); t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
+            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
             t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
             if (t.active && t.iterations < maxIter) any = true;
         }
@@ -882,7 +882,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         float ms = 0; (void)hipEventElapsedTime(&ms, frame0, frame1); stats->gpuMilliseconds = ms;
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b]; const WaveCounters& h = *t.hwc;
-            for (auto& sp : t.spans) { float m = 0; (void)hipEventElapsedTime(&m, t.ev[sp.a], t.ev[sp.b]); if (sp.kind == 0) { stats->extendKernelMs += m; stats->extendLaunches++; } else if (sp.kind == 1) stats->shadeKernelMs += m; else stats->shadowKernelMs += m; }
+            for (auto& sp : t.spans) { float m = 0; (void)hipEventElapsedTime(&m, t.ev[sp.a], t.ev[sp.b]); if (sp.kind == 0) stats->extendKernelMs += m; else if (sp.kind == 1) stats->shadeKernelMs += m; else stats->shadowKernelMs += m; }      // (zero in pipelined frames: no per-launch events there)
+            stats->extendLaunches += t.iterations;
             stats->extendRays += t.extendRays; stats->shadowRays += shadowGroup ? h.shadowValid : t.shadowRays; stats->hits += h.hits; stats->nodeVisitsExtend += h.nodeVisitsExt; stats->triTestsExtend += h.triTestsExt;
             stats->nodeVisitsShadow += h.nodeVisitsSh; stats->triTestsShadow += h.triTestsSh;
             stats->leafVisitsExtend += h.leafVisitsExt; stats->waveItersExtend += h.itersExt; stats->leafVisitsShadow += h.leafVisitsSh; stats->waveItersShadow += h.itersSh;
@@ -896,7 +897,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         stats->pathsTraced = total;
     }
     if (getenv("MI355PT_PASS_LOG")) {        // developer probe: the launch sequence of every batch with item counts and HIP-event durations (stderr)
-        for (uint b = 0; b < numBatches; b++) { Batch& t = B[b]; float whole = 0; (void)hipEventElapsedTime(&whole, t.ev[t.t0], t.ev[t.t1]);
+        for (uint b = 0; b < numBatches; b++) { Batch& t = B[b]; float whole = 0; if (!t.timed) continue; (void)hipEventElapsedTime(&whole, t.ev[t.t0], t.ev[t.t1]);
             fprintf(stderr, "[pass log] batch %u of %u: %u paths, %u passes, %.3f ms from first to last event\n", b, numBatches, t.total, t.iterations, whole);
             for (auto& sp : t.spans) { float m = 0, at = 0; (void)hipEventElapsedTime(&m, t.ev[sp.a], t.ev[sp.b]); (void)hipEventElapsedTime(&at, t.ev[t.t0], t.ev[sp.a]);
                 fprintf(stderr, "[pass log]   b%u %-6s %9u items  start %8.3f ms  %7.3f ms\n", b, sp.kind == 0 ? "extend" : (sp.kind == 1 ? "shade" : "shadow"), sp.items, at, m); } }

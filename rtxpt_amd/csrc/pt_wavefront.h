@@ -40,7 +40,7 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr,
                   ShadowQueue sq, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st);
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
-void launch_pass_reset(uint* passCounters, hipStream_t st);      // one memset of the batch's PASS_COUNTERS words
+void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st);      // one launch: the batch's PASS_COUNTERS words and the two queue counters the pass refills
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st);
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st);
 void launch_pack(const float4* accum, const uint* ownedPixels, uint numOwned, uint width, float4* dst, hipStream_t st);

@@ -19,6 +19,9 @@ namespace ptk {
 #ifndef T8_CHUNKS_PER_WAVE_MIN
 #define T8_CHUNKS_PER_WAVE_MIN 1     // small launches: fewer waves, each working through this many 64-ray chunks (idle quads refill from the next chunk)
 #endif
+#ifndef T8_SHORT_TAIL_BELOW
+#define T8_SHORT_TAIL_BELOW 32768u    // traversal launches of at most this many rays run two task rounds instead of four (launch_extend)
+#endif
 #ifndef T8_TASK_BLOCKS_N
 #define T8_TASK_BLOCKS_N 512        // blocks of a task-round launch: task rounds hold thousands of sub-trees, not millions
 #endif
@@ -113,9 +116,9 @@ __device__ __forceinline__ uint t8_tasks_per_chunk(uint count) { return (!T8_TAS
 // the sub-trees are split again into the other queue (count: counts[STAGE + 1]). One counter per round: the whole block is zeroed once per pass (pt_wavefront.h TravAux).
 // Task i of the launch is queue entry (i % 64) * ceil(count / 64) + i / 64: the sub-trees of one ray sit next to each other in the queue and
 // would otherwise land in one 64-item chunk, i.e. on one wave.
-template <int STAGE>
+template <int STAGE, bool FINAL = (STAGE == 3)>
 __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks(DeviceScene sc, PathPool pool, WaveCounters* wc, TravAux aux) {
-    constexpr int IN = STAGE & 1; constexpr bool FINAL = STAGE == 3;
+    constexpr int IN = STAGE & 1;
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_TASKBUF_WORDS];
     uint count = aux.counts[STAGE]; if (count > aux.taskCap) count = aux.taskCap;
@@ -297,9 +300,9 @@ __global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_s
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsSh); wave_add64(ctr.triTests, &wc->triTestsSh); wave_add64(ctr.leafVisits, &wc->leafVisitsSh); wave_add64(ctr.iters, &wc->itersSh); }
 }
 
-template <int STAGE>
+template <int STAGE, bool FINAL = (STAGE == 3)>
 __global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, ShadowQueue sq, WaveCounters* wc, TravAux aux) {
-    constexpr int IN = STAGE & 1; constexpr bool FINAL = STAGE == 3;
+    constexpr int IN = STAGE & 1;
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_TASKBUF_WORDS];
     uint count = aux.counts[STAGE]; if (count > aux.taskCap) count = aux.taskCap;
@@ -671,6 +674,12 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
     uint g = grid_for(count, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);
     if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
     else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
+    if (count <= T8_SHORT_TAIL_BELOW) {      // a small launch holds few stragglers and short ones: two task rounds (split once more, then finish) instead of four — late bounces are
+        hipLaunchKernelGGL((k_extend_tasks<0>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);             // bound by the host's launch rate, not by the GPU
+        hipLaunchKernelGGL((k_extend_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);
+        hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
+        return;
+    }
     hipLaunchKernelGGL((k_extend_tasks<0>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 0 -> 1
     hipLaunchKernelGGL((k_extend_tasks<1>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 1 -> 0
     hipLaunchKernelGGL((k_extend_tasks<2>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 0 -> 1
@@ -701,14 +710,23 @@ void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const u
     else if (counters) hipLaunchKernelGGL((k_shadow<true, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);
     else hipLaunchKernelGGL((k_shadow<false, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);
     hipLaunchKernelGGL((k_shadow_tasks<0>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    if (count <= T8_SHORT_TAIL_BELOW) hipLaunchKernelGGL((k_shadow_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);      // (as launch_extend: two rounds for a small launch)
+    else {
     hipLaunchKernelGGL((k_shadow_tasks<1>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     hipLaunchKernelGGL((k_shadow_tasks<2>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     hipLaunchKernelGGL((k_shadow_tasks<3>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
+    }
     if (sq.group) hipLaunchKernelGGL((k_resolve_shadow<true>), dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
     else hipLaunchKernelGGL((k_resolve_shadow<false>), dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
     if (sq.group) hipLaunchKernelGGL(k_resolve_nee, dim3(grid_for(count / sq.group, 256, 4096)), dim3(256), 0, st, pool, sq, countPtr);
 }
-void launch_pass_reset(uint* passCounters, hipStream_t st) { (void)hipMemsetAsync(passCounters, 0, 4u * PASS_COUNTERS, st); }
+// start of a pass: the batch's PASS_COUNTERS words and the two queue counters the pass refills, zeroed by one launch (three memsets were three launches)
+__global__ void __launch_bounds__(64) k_pass_begin(uint* __restrict__ passCounters, uint* __restrict__ nextCount, uint* __restrict__ shadowCount) {
+    if (threadIdx.x < PASS_COUNTERS) passCounters[threadIdx.x] = 0u;
+    if (threadIdx.x == 32u) *nextCount = 0u;
+    if (threadIdx.x == 33u) *shadowCount = 0u;
+}
+void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st) { static_assert(PASS_COUNTERS <= 32u, "k_pass_begin"); hipLaunchKernelGGL(k_pass_begin, dim3(1), dim3(64), 0, st, passCounters, nextCount, shadowCount); }
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3((numOwned + 255) / 256), dim3(256), 0, st, pool, ownedPixels, numOwned, spp, accum, accumCountBase, width);
 }
