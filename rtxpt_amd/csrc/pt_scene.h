@@ -84,8 +84,10 @@ static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
 static const uint BVH8_STACK = PT_BVH8_STACK, BVH8_STACK_STRIDE = PT_BVH8_STACK + 1;
 static const uint T8_BLOCK = 256, T8_CHUNK = PT_T8_CHUNK, T8_LANES = PT_T8_LANES, T8_GROUPS_PER_WAVE = 64 / PT_T8_LANES, T8_GROUPS_PER_BLOCK = T8_BLOCK / T8_LANES, T8_SPILL_DEPTH = 96;
 #ifndef PT_T8_MAX_BLOCKS
-#define PT_T8_MAX_BLOCKS (PT_T8_LANES == 2 ? 256 * 7 : 256 * 6 * 4)      // pairs: exactly the blocks the GPU holds (7 per CU: LDS); 2x / 3x / 4x that were 0.2 / 1.7 / 3.7 % slower on the
-                                                                          // full frame and 4-7 % slower on one rank of an 8-way sharded frame (profiles/r03w_maxblocks_ab.txt)
+#define PT_T8_MAX_BLOCKS (PT_T8_LANES == 2 ? 256 * 7 * 3 : 256 * 6 * 4)  // upper bound of a traversal grid (sizes the stack-tail memory). Pairs: the GPU holds 256 x 7 blocks (LDS). A frame
+                                                                          // of several pipelined batches launches exactly that many per batch — 2x / 3x / 4x were 0.2 / 1.7 / 3.7 % slower on the full frame and
+                                                                          // 4-7 % on one rank of an 8-way shard (profiles/r03w_maxblocks_ab.txt): the other batches fill the gaps —, a launch that has the GPU to
+                                                                          // itself three times that: the blocks that finish early are replaced (TravAux::maxBlocks)
 #endif
 static const uint T8_MAX_BLOCKS = PT_T8_MAX_BLOCKS;     // persistent waves stride over 64-ray chunks
 

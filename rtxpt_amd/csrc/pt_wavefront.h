@@ -31,7 +31,7 @@ struct WaveCounters {           // device-resident counters / stats (one 256 B b
 //   [0] sub-trees split off by k_extend / k_shadow (task queue 0), [1..3] by task rounds 0..2 (queues 1, 0, 1), [TRAV_RESOLVE] rays to resolve.
 // pt_render keeps one PASS_COUNTERS block per batch — {extend launch, shadow launch, k_classify's three class counts} — and zeroes it once per pass.
 static const uint TRAV_COUNTERS = 5, TRAV_RESOLVE = 4, PASS_COUNTERS = 16, PASS_SHADOW_OFFSET = 5, PASS_CLASS_OFFSET = 10;
-struct TravAux { TravTask* taskQ[2]; uint* counts; uint taskCap; unsigned long long* bestKey; uint* resolveList; const uint* primToSlot; };
+struct TravAux { TravTask* taskQ[2]; uint* counts; uint taskCap; unsigned long long* bestKey; uint* resolveList; const uint* primToSlot; uint maxBlocks; };      // maxBlocks: grid bound of the traversal launches (0: T8_MAX_BLOCKS)
 
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st);
 void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);

@@ -671,7 +671,7 @@ void launch_generate(const PathKernelContext& k, PathPool pool, const uint* owne
 static const uint T8_TASK_BLOCKS = T8_TASK_BLOCKS_N, T8_RESOLVE_BLOCKS = 256;
 void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
     const uint rpc = rays_per_chunk(count);
-    uint g = grid_for(count, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);
+    uint g = grid_for(count, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, (aux.maxBlocks && aux.maxBlocks < T8_MAX_BLOCKS) ? aux.maxBlocks : T8_MAX_BLOCKS);
     if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
     else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
     if (count <= T8_SHORT_TAIL_BELOW) {      // a small launch holds few stragglers and short ones: two task rounds (split once more, then finish) instead of four — late bounces are
@@ -705,7 +705,7 @@ void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn
 }
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
     const uint rpc = rays_per_chunk(count);
-    uint g = grid_for(count, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, T8_MAX_BLOCKS);
+    uint g = grid_for(count, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, (aux.maxBlocks && aux.maxBlocks < T8_MAX_BLOCKS) ? aux.maxBlocks : T8_MAX_BLOCKS);
     if (sq.group) hipLaunchKernelGGL((k_shadow<false, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);       // (no traversal counters in the grouped mode)
     else if (counters) hipLaunchKernelGGL((k_shadow<true, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);
     else hipLaunchKernelGGL((k_shadow<false, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);
