@@ -176,7 +176,8 @@ def main():
         # Round 3: what is full is the VALU issue port. Extra v_nop issue slots in the traversal loop lengthen k_extend one for one (+10 % slots = +9 % time,
         # +20 % = +21 %, profiles/r03i_valu_bound_probe.txt), and SQ_INSTS_VALU per SIMD and cycle sits at the 1/4 a 16-lane SIMD can issue for wave64.
         vps = cj.get("valu_instr_per_simd_cycle") or 0.0
-        bound = "hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else ("valu" if vps >= 0.24 else "latency")
+        busy = cj.get("valu_busy") or 0.0       # SQ_ACTIVE_INST_VALU per SIMD and cycle: the share of cycles in which the VALU is occupied
+        bound = "hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else ("valu" if (vps >= 0.22 or busy >= 0.85) else "latency")      # wave64 on a 16-lane SIMD issues at most 0.25 VALU instructions per cycle
         valu["instructions_per_simd_cycle"] = vps
 
     if rank == 0:

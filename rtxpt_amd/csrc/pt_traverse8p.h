@@ -18,6 +18,14 @@ namespace ptk {
 #define DPP_PAIR_HI 0xF5      // quad_perm [1,1,3,3]: lane 1 of the pair
 __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { return (uint)(m >> pl) & 0x3u; }
 
+#ifndef T8_EMPTY_SLOT_CHECK
+#define T8_EMPTY_SLOT_CHECK 0    // 0: an empty child slot needs no test of its own — the builder writes it as an inverted box (lo = 255, hi = 0 on every axis: pt_build.hip k_collapse8),
+#endif                           //    which no ray's slab interval enters; were it ever "hit" (a node of zero extent), its reference is BVH_EMPTY, which the slot bookkeeping skips
+#if T8_EMPTY_SLOT_CHECK
+#define T8_HIT(ref, tn, tf) (((ref) != BVH_EMPTY) && ((tn) <= (tf) * 1.0000012f))
+#else
+#define T8_HIT(ref, tn, tf) ((tn) <= (tf) * 1.0000012f)
+#endif
 #ifndef T8_POP2
 #define T8_POP2 0
 #endif
@@ -173,10 +181,10 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
             // a child that is not hit gets +inf. The stack entry's distance is the key without its index bits.
             uint key[4]; bool hit[4];
             {   float tn, tf;
-                slab(c0.y, c0.z, tn, tf); hit[0] = (ref[0] != BVH_EMPTY) && (tn <= tf * 1.0000012f); key[0] = (hit[0] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h);
-                slab(c1.x, c1.y, tn, tf); hit[1] = (ref[1] != BVH_EMPTY) && (tn <= tf * 1.0000012f); key[1] = (hit[1] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 1u);
-                slab(c1.w, c2.x, tn, tf); hit[2] = (ref[2] != BVH_EMPTY) && (tn <= tf * 1.0000012f); key[2] = (hit[2] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 2u);
-                slab(c2.z, c2.w, tn, tf); hit[3] = (ref[3] != BVH_EMPTY) && (tn <= tf * 1.0000012f); key[3] = (hit[3] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 3u);
+                slab(c0.y, c0.z, tn, tf); hit[0] = T8_HIT(ref[0], tn, tf); key[0] = (hit[0] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h);
+                slab(c1.x, c1.y, tn, tf); hit[1] = T8_HIT(ref[1], tn, tf); key[1] = (hit[1] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 1u);
+                slab(c1.w, c2.x, tn, tf); hit[2] = T8_HIT(ref[2], tn, tf); key[2] = (hit[2] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 2u);
+                slab(c2.z, c2.w, tn, tf); hit[3] = T8_HIT(ref[3], tn, tf); key[3] = (hit[3] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 3u);
             }
             uint nhit, rank[4];
             if (ANYHIT && T8_ANYHIT_UNORDERED) {
