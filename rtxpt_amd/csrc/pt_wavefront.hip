@@ -162,6 +162,9 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
     }
 }
 
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 256       // threads per k_shade block (the queue appends meet per block: one atomic per block and counter)
+#endif
 #ifndef PT_SHADE_MIN_BLOCKS
 #define PT_SHADE_MIN_BLOCKS 1
 #endif
@@ -203,10 +206,10 @@ __global__ void __launch_bounds__(1024) k_classify(PathPool pool, const uint* __
 
 // PKC: PathKernelContextT<false> (lp types in fp32) or PathKernelContextT<true> (the reference's default build, lp types in binary16)
 template <bool MULTI, class PKC>
-__global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
+__global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
                                                uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, const uint* __restrict__ classCount) {
     const uint count = *countInPtr;
-    uint i = blockIdx.x * 256u + threadIdx.x;
+    uint i = blockIdx.x * (uint)PT_SHADE_BLOCK + threadIdx.x;
     bool inRange = i < count;
     bool alive = false; bool isHit = false; uint p = 0;
     ShadowRequest req; req.valid = false;
@@ -237,13 +240,13 @@ __global__ void __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathP
     // Queue appends, one atomic per BLOCK and counter: the four waves' counts meet in LDS, thread 0 reserves both ranges. A launch of 33 M paths has 518 k waves; one
     // returning atomic per wave on each of three words — all waves of the GPU on the same three addresses — is what the kernel waited for (same-address atomics
     // serialise in the L2: ~10^8 per second and address). The hit count needs no atomic at all when the paths were classified: it is the size of two classes.
-    __shared__ uint sCnt[4][2]; __shared__ uint sBase[2];
+    __shared__ uint sCnt[PT_SHADE_BLOCK / 64][2]; __shared__ uint sBase[2];
     const uint wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const unsigned long long mAlive = __builtin_amdgcn_ballot_w64(alive), mReq = __builtin_amdgcn_ballot_w64(!MULTI && req.valid);
     if (lane == 0u) { sCnt[wave][0] = (uint)__popcll(mAlive); sCnt[wave][1] = (uint)__popcll(mReq); }
     __syncthreads();
     if (threadIdx.x < 2u) {
-        uint tot = 0; for (uint w = 0; w < 4u; w++) { const uint c = sCnt[w][threadIdx.x]; sCnt[w][threadIdx.x] = tot; tot += c; }
+        uint tot = 0; for (uint w = 0; w < (uint)(PT_SHADE_BLOCK / 64); w++) { const uint c = sCnt[w][threadIdx.x]; sCnt[w][threadIdx.x] = tot; tot += c; }
         sBase[threadIdx.x] = tot ? atomicAdd(threadIdx.x == 0u ? countOutPtr : &wc->shadowCount, tot) : 0u;
     }
     __syncthreads();
@@ -688,7 +691,7 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
 }
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc,
                   uint* classScratch, uint* classCount, hipStream_t st) {
-    const dim3 g((countIn + 255) / 256), b(256);
+    const dim3 g((countIn + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), b(PT_SHADE_BLOCK);
     if (PT_SHADE_CLASSES && classScratch) {                   // (scratch: 2 x countIn words, free between the extend and the shadow launches; classCount: 3 words, zeroed with the pass's traversal counters)
         hipLaunchKernelGGL(k_classify, dim3((countIn + 1023) / 1024), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
         queueIn = classScratch;
