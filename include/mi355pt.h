@@ -400,7 +400,8 @@ void    pt_image_free(float* rgb);
    700-730) and Donut's TextureCache decodes them. Top mip level of a 2D .dds as RGBA8 (*format = PT_TEX_RGBA8_UNORM / PT_TEX_RGBA8_SRGB per the file's DXGI format)
    or, for R16G16B16A16_FLOAT / R32G32B32A32_FLOAT files, RGBA32F (*format = PT_TEX_RGBA32F): what PtTextureDesc takes. Block formats BC1 / BC2 / BC3 / BC4 / BC5 /
    BC7, uncompressed RGBA8 / BGRA8 / BGRX8; legacy FourCC and DX10 headers. *pixels is allocated by the library: pt_image_free((float*)pixels).
-   PT_ERROR_IO: unreadable / truncated; PT_ERROR_UNSUPPORTED: BC6H, cube maps, volumes, arrays, other formats. */
+   PT_ERROR_IO: unreadable / truncated; PT_ERROR_UNSUPPORTED: cube maps, volumes, arrays, other formats. BC6H (UF16 / SF16, all fourteen modes) decodes to
+   PT_TEX_RGBA32F texels. */
 int32_t pt_image_read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);
 int32_t pt_image_read_dds_memory(const void* bytes, size_t size, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);   /* the same from memory (glTF images: MSFT_texture_dds) */
 /* JPEG images of glTF files (Donut's TextureCache gives them to stb_image): a baseline / extended / progressive Huffman stream of 8-bit greyscale or YCbCr (or

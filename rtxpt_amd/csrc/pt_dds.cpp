@@ -5,7 +5,7 @@
 //   BC7 decodes exactly as specified (the format leaves no freedom); BC1-BC3 colour interpolation is the "ideal" (2 c0 + c1 + 1) / 3 rule, which hardware is
 //   allowed to approximate; only the top mip level is read (the library builds its own chain, as for .png files).
 // Read: legacy FourCC DXT1 / DXT3 / DXT5 / ATI1 / BC4U / ATI2 / BC5U / 113 (RGBA16F) / 116 (RGBA32F), uncompressed 32-bit RGBA / BGRA / BGRX masks, and the DX10 header
-// with BC1 / BC2 / BC3 / BC4 / BC5 / BC7 (TYPELESS, UNORM, SRGB), R8G8B8A8, B8G8R8A8, R16G16B16A16_FLOAT, R32G32B32A32_FLOAT. Not read (PT_ERROR_UNSUPPORTED): BC6H, cube maps,
+// with BC1 / BC2 / BC3 / BC4 / BC5 / BC7 (TYPELESS, UNORM, SRGB), R8G8B8A8, B8G8R8A8, R16G16B16A16_FLOAT, R32G32B32A32_FLOAT, BC6H (UF16 and SF16, all fourteen modes: float RGBA out). Not read (PT_ERROR_UNSUPPORTED): cube maps,
 // volumes, arrays, signed BC4 / BC5.
 #include "../../include/mi355pt.h"
 #include "pt_bcn_tables.h"
@@ -92,8 +92,80 @@ float half_to_float(uint16_t h) {
     float f; memcpy(&f, &u, 4); return f;
 }
 
-enum Kind { K_NONE, K_BC1, K_BC2, K_BC3, K_BC4, K_BC5, K_BC7, K_RGBA8, K_BGRA8, K_BGRX8, K_RGBA16F, K_RGBA32F };
+enum Kind { K_NONE, K_BC1, K_BC2, K_BC3, K_BC4, K_BC5, K_BC7, K_RGBA8, K_BGRA8, K_BGRX8, K_RGBA16F, K_RGBA32F, K_BC6U, K_BC6S };
 
+// ---- BC6H (BPTC float), unsigned (UF16) and signed (SF16): fourteen modes; the endpoint fields of each mode are scattered over bits 2 / 5 .. 76 (two regions) or .. 64 (one region)
+// as listed below in bit order — field names of the published format: r/g/b = channel, w x y z = endpoints 0 1 2 3, "n" or "n-m" = bit(s) of that field, ascending bit positions.
+// Two-region modes carry a 5-bit partition at bits 77-81 and 3-bit indices from bit 82, one-region modes 4-bit indices from bit 65; anchor texels have one bit fewer.
+// Endpoints 1-3 of the transformed modes are deltas (sign-extended) to endpoint 0, the sum wrapping within its width; unquantisation, interpolation (weights x / 64) and
+// the final x 31 / 64 (unsigned) or x 31 / 32 (signed) are the format's. Checked against Pillow's decoder on random blocks of every mode (tests/test_dds.py); the
+// two-region modes 7.6 / 9.5 and mode 11 also against the reference's own encoder (pt_envcube.h).
+struct Bc6Mode { uint8_t modeBits, modeValue, regions, transformed, prec, dr, dg, db; const char* layout; };
+const Bc6Mode kBc6Modes[14] = {
+    {2, 0x00, 2, 1, 10, 5, 5, 5, "gy4 by4 bz4 rw0-9 gw0-9 bw0-9 rx0-4 gz4 gy0-3 gx0-4 bz0 gz0-3 bx0-4 bz1 by0-3 ry0-4 bz2 rz0-4 bz3"},
+    {2, 0x01, 2, 1, 7, 6, 6, 6, "gy5 gz4 gz5 rw0-6 bz0 bz1 by4 gw0-6 by5 bz2 gy4 bw0-6 bz3 bz5 bz4 rx0-5 gy0-3 gx0-5 gz0-3 bx0-5 by0-3 ry0-5 rz0-5"},
+    {5, 0x02, 2, 1, 11, 5, 4, 4, "rw0-9 gw0-9 bw0-9 rx0-4 rw10 gy0-3 gx0-3 gw10 bz0 gz0-3 bx0-3 bw10 bz1 by0-3 ry0-4 bz2 rz0-4 bz3"},
+    {5, 0x06, 2, 1, 11, 4, 5, 4, "rw0-9 gw0-9 bw0-9 rx0-3 rw10 gz4 gy0-3 gx0-4 gw10 gz0-3 bx0-3 bw10 bz1 by0-3 ry0-3 bz0 bz2 rz0-3 gy4 bz3"},
+    {5, 0x0A, 2, 1, 11, 4, 4, 5, "rw0-9 gw0-9 bw0-9 rx0-3 rw10 by4 gy0-3 gx0-3 gw10 bz0 gz0-3 bx0-4 bw10 by0-3 ry0-3 bz1 bz2 rz0-3 bz4 bz3"},
+    {5, 0x0E, 2, 1, 9, 5, 5, 5, "rw0-8 by4 gw0-8 gy4 bw0-8 bz4 rx0-4 gz4 gy0-3 gx0-4 bz0 gz0-3 bx0-4 bz1 by0-3 ry0-4 bz2 rz0-4 bz3"},
+    {5, 0x12, 2, 1, 8, 6, 5, 5, "rw0-7 gz4 by4 gw0-7 bz2 gy4 bw0-7 bz3 bz4 rx0-5 gy0-3 gx0-4 bz0 gz0-3 bx0-4 bz1 by0-3 ry0-5 rz0-5"},
+    {5, 0x16, 2, 1, 8, 5, 6, 5, "rw0-7 bz0 by4 gw0-7 gy5 gy4 bw0-7 gz5 bz4 rx0-4 gz4 gy0-3 gx0-5 gz0-3 bx0-4 bz1 by0-3 ry0-4 bz2 rz0-4 bz3"},
+    {5, 0x1A, 2, 1, 8, 5, 5, 6, "rw0-7 bz1 by4 gw0-7 by5 gy4 bw0-7 bz5 bz4 rx0-4 gz4 gy0-3 gx0-4 bz0 gz0-3 bx0-5 by0-3 ry0-4 bz2 rz0-4 bz3"},
+    {5, 0x1E, 2, 0, 6, 6, 6, 6, "rw0-5 gz4 bz0 bz1 by4 gw0-5 gy5 by5 bz2 gy4 bw0-5 gz5 bz3 bz5 bz4 rx0-5 gy0-3 gx0-5 gz0-3 bx0-5 by0-3 ry0-5 rz0-5"},
+    {5, 0x03, 1, 0, 10, 10, 10, 10, "rw0-9 gw0-9 bw0-9 rx0-9 gx0-9 bx0-9"},
+    {5, 0x07, 1, 1, 11, 9, 9, 9, "rw0-9 gw0-9 bw0-9 rx0-8 rw10 gx0-8 gw10 bx0-8 bw10"},
+    {5, 0x0B, 1, 1, 12, 8, 8, 8, "rw0-9 gw0-9 bw0-9 rx0-7 rw11 rw10 gx0-7 gw11 gw10 bx0-7 bw11 bw10"},
+    {5, 0x0F, 1, 1, 16, 4, 4, 4, "rw0-9 gw0-9 bw0-9 rx0-3 rw15 rw14 rw13 rw12 rw11 rw10 gx0-3 gw15 gw14 gw13 gw12 gw11 gw10 bx0-3 bw15 bw14 bw13 bw12 bw11 bw10"},
+};
+inline uint32_t bc6_bit(const uint8_t* b, uint32_t i) { return (b[i >> 3] >> (i & 7u)) & 1u; }
+inline int32_t bc6_sext(uint32_t v, uint32_t bits) { return (bits < 32u && (v & (1u << (bits - 1u)))) ? (int32_t)(v | ~((1u << bits) - 1u)) : (int32_t)v; }
+inline int32_t bc6_unquantize(int32_t c, uint32_t bits, bool isSigned) {
+    if (!isSigned) { if (bits >= 15u) return c; if (c == 0) return 0; if (c == (int32_t)((1u << bits) - 1u)) return 0xFFFF; return (int32_t)((((uint32_t)c << 16) + 0x8000u) >> bits); }
+    if (bits >= 16u) return c;
+    const bool neg = c < 0; uint32_t a = (uint32_t)(neg ? -c : c), u;
+    if (a == 0u) u = 0u; else if (a >= (1u << (bits - 1u)) - 1u) u = 0x7FFFu; else u = ((a << 15) + 0x4000u) >> (bits - 1u);
+    return neg ? -(int32_t)u : (int32_t)u;
+}
+// one 16-byte block -> 16 texels of 3 half-float bit patterns (a reserved mode decodes to zero, as the format prescribes)
+void decode_bc6h_block(const uint8_t* b, bool isSigned, uint16_t out[16][3]) {
+    memset(out, 0, sizeof(uint16_t) * 48);
+    const uint32_t m2 = b[0] & 3u, m5 = b[0] & 31u; const Bc6Mode* M = nullptr;
+    for (const Bc6Mode& k : kBc6Modes) if ((k.modeBits == 2 && k.modeValue == m2) || (k.modeBits == 5 && m2 >= 2u && k.modeValue == m5)) { M = &k; break; }
+    if (!M) return;
+    int32_t e[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    uint32_t pos = M->modeBits;
+    for (const char* s = M->layout; *s;) {                                        // "<channel><endpoint><lo>[-<hi>]"
+        while (*s == ' ') s++; if (!*s) break;
+        const int ch = *s == 'r' ? 0 : (*s == 'g' ? 1 : 2); s++;
+        const int ep = *s == 'w' ? 0 : (*s == 'x' ? 1 : (*s == 'y' ? 2 : 3)); s++;
+        uint32_t lo = 0; while (*s >= '0' && *s <= '9') lo = lo * 10u + (uint32_t)(*s++ - '0');
+        uint32_t hi = lo; if (*s == '-') { s++; hi = 0; while (*s >= '0' && *s <= '9') hi = hi * 10u + (uint32_t)(*s++ - '0'); }
+        for (uint32_t j = lo; j <= hi; j++) e[ep][ch] |= (int32_t)(bc6_bit(b, pos++) << j);
+    }
+    const uint32_t P = M->prec, D[3] = {M->dr, M->dg, M->db}, nEp = M->regions * 2u;
+    for (int c = 0; c < 3; c++) {
+        if (isSigned) e[0][c] = bc6_sext((uint32_t)e[0][c], P);
+        for (uint32_t k = 1; k < nEp; k++) {
+            if (M->transformed) { const int32_t v = (e[0][c] + bc6_sext((uint32_t)e[k][c], D[c])) & (int32_t)((1u << P) - 1u); e[k][c] = isSigned ? bc6_sext((uint32_t)v, P) : v; }
+            else if (isSigned) e[k][c] = bc6_sext((uint32_t)e[k][c], D[c]);
+        }
+        for (uint32_t k = 0; k < nEp; k++) e[k][c] = bc6_unquantize(e[k][c], P, isSigned);
+    }
+    static const uint8_t w3[8] = {0, 9, 18, 27, 37, 46, 55, 64}, w4[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+    uint32_t partition = 0, ipos = 65u, anchor = 0u;
+    if (M->regions == 2) { for (uint32_t j = 0; j < 5u; j++) partition |= bc6_bit(b, 77u + j) << j; ipos = 82u; anchor = ptbcn::kAnchor2[partition]; }
+    for (uint32_t i = 0; i < 16u; i++) {
+        const uint32_t region = M->regions == 2 ? (ptbcn::kPartition2[partition] >> i) & 1u : 0u;
+        uint32_t nb = M->regions == 2 ? 3u : 4u; if (i == 0u || (M->regions == 2 && i == anchor)) nb--;
+        uint32_t idx = 0; for (uint32_t j = 0; j < nb; j++) idx |= bc6_bit(b, ipos++) << j;
+        const int32_t wt = M->regions == 2 ? w3[idx] : w4[idx];
+        for (int c = 0; c < 3; c++) {
+            const int32_t a = e[2u * region][c], bb = e[2u * region + 1u][c], v = (a * (64 - wt) + bb * wt + 32) >> 6;
+            if (!isSigned) out[i][c] = (uint16_t)((v * 31) >> 6);
+            else { const int32_t f = v < 0 ? -(((-v) * 31) >> 5) : (v * 31) >> 5; out[i][c] = f < 0 ? (uint16_t)(0x8000u | (uint32_t)(-f)) : (uint16_t)f; }
+        }
+    }
+}
 struct Bytes { const uint8_t* p; size_t n; size_t size() const { return n; } const uint8_t* data() const { return p; } const uint8_t& operator[](size_t i) const { return p[i]; } };
 int32_t read_dds_bytes(const Bytes& d, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);
 int32_t read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels) {
@@ -122,7 +194,8 @@ int32_t read_dds_bytes(const Bytes& d, uint32_t* width, uint32_t* height, uint32
         case 97: case 98: k = K_BC7; break; case 99: k = K_BC7; srgb = true; break;
         case 27: case 28: k = K_RGBA8; break; case 29: k = K_RGBA8; srgb = true; break; case 87: k = K_BGRA8; break; case 91: k = K_BGRA8; srgb = true; break;
         case 10: k = K_RGBA16F; break; case 2: k = K_RGBA32F; break;
-        default: return PT_ERROR_UNSUPPORTED;                                             // BC6H (95, 96), signed RGTC (81, 84), everything else
+        case 94: case 95: k = K_BC6U; break; case 96: k = K_BC6S; break;                   // BC6H_TYPELESS / _UF16, _SF16
+        default: return PT_ERROR_UNSUPPORTED;                                             // signed RGTC (81, 84), everything else
         }
     } else if (pfFlags & 0x4u) {
         if (cc == fourcc('D', 'X', 'T', '1')) k = K_BC1; else if (cc == fourcc('D', 'X', 'T', '3') || cc == fourcc('D', 'X', 'T', '2')) k = K_BC2;
@@ -136,7 +209,7 @@ int32_t read_dds_bytes(const Bytes& d, uint32_t* width, uint32_t* height, uint32
     } else return PT_ERROR_UNSUPPORTED;
     const size_t bw = (w + 3u) / 4u, bh = (h + 3u) / 4u, npx = (size_t)w * h;
     size_t need = 0;
-    switch (k) { case K_BC1: case K_BC4: need = bw * bh * 8u; break; case K_BC2: case K_BC3: case K_BC5: case K_BC7: need = bw * bh * 16u; break;
+    switch (k) { case K_BC1: case K_BC4: need = bw * bh * 8u; break; case K_BC2: case K_BC3: case K_BC5: case K_BC7: case K_BC6U: case K_BC6S: need = bw * bh * 16u; break;
                  case K_RGBA8: case K_BGRA8: case K_BGRX8: need = npx * 4u; break; case K_RGBA16F: need = npx * 8u; break; case K_RGBA32F: need = npx * 16u; break; default: break; }
     if (d.size() < off + need) return PT_ERROR_IO;
     const uint8_t* src = d.data() + off;
@@ -144,6 +217,15 @@ int32_t read_dds_bytes(const Bytes& d, uint32_t* width, uint32_t* height, uint32
         float* out = (float*)malloc(npx * 16u); if (!out) return PT_ERROR_IO;
         if (k == K_RGBA32F) memcpy(out, src, npx * 16u);
         else for (size_t i = 0; i < npx * 4u; i++) out[i] = half_to_float((uint16_t)(src[2 * i] | (src[2 * i + 1] << 8)));
+        *pixels = out; *format = PT_TEX_RGBA32F; *width = w; *height = h; return PT_OK;
+    }
+    if (k == K_BC6U || k == K_BC6S) {                    // HDR blocks: float RGBA out, alpha 1
+        float* out = (float*)malloc(npx * 16u); if (!out) return PT_ERROR_IO;
+        for (size_t by = 0; by < bh; by++) for (size_t bx = 0; bx < bw; bx++) {
+            uint16_t hb[16][3]; decode_bc6h_block(src + (by * bw + bx) * 16u, k == K_BC6S, hb);
+            for (uint32_t y = 0; y < 4u; y++) for (uint32_t x = 0; x < 4u; x++) { const size_t X = bx * 4u + x, Y = by * 4u + y; if (X >= w || Y >= h) continue;
+                float* o = out + (Y * w + X) * 4u; for (int c = 0; c < 3; c++) o[c] = half_to_float(hb[y * 4u + x][c]); o[3] = 1.0f; }
+        }
         *pixels = out; *format = PT_TEX_RGBA32F; *width = w; *height = h; return PT_OK;
     }
     uint8_t* out = (uint8_t*)malloc(npx * 4u); if (!out) return PT_ERROR_IO;
