@@ -58,6 +58,9 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #ifndef PT_PIPELINE_MID_BATCHES
 #define PT_PIPELINE_MID_BATCHES 2      // batches between 1 M paths and PT_PIPELINE_FULL_AT
 #endif
+#ifndef PT_CLASSIFY_FROM
+#define PT_CLASSIFY_FROM 65536u     // passes with fewer paths skip k_classify (class-ordered shading pays through coherence, which a handful of waves do not have)
+#endif
 #ifndef PT_PIPELINE_BATCHES
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
 #endif
@@ -847,7 +850,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             uint nxt = t.cur ^ 1u;
             launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch
             size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
-            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, reinterpret_cast<uint*>(t.aux.bestKey) /* the straggler keys are idle between k_resolve_extend and the shadow launch */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
+            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
             t.extendRays += t.active;
             PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
             t.waiting = true;
