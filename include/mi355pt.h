@@ -239,6 +239,19 @@ void pt_procedural_sky_default_params(PtProceduralSkyParams* out);
 int32_t pt_procedural_sky_update(PtProceduralSkyState* state, const PtProceduralSkyParams* params, double sceneTime, const char* preset, int32_t forceInstantUpdate, PtProceduralSkyConstants* out);
 /* analytic lights already converted by the host (LightsBaker.cpp:456-556 ConvertLight); emissive triangles are baked automatically */
 int32_t pt_set_lights(pt_context* ctx, const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint32_t numLights);
+/* NEE-AT, the path tracer's side (NEEType 2; Rtxpt/Shaders/PathTracer/Lighting/LightSampler.hlsli:51-93,120-180,184-200,242-268,318-332,411-420, PathTracerNEE.hlsli:88-161,
+ * 199-273). Replaces the bindings t_LightLocalSamplingBuffer (t17), u_LightFeedbackTotalWeight (u20), u_LightFeedbackCandidates (u21) of Sample.cpp:2338-2342 and the
+ * LightingControlData fields LocalSamplingTileJitter / LocalSamplingResolution / LocalToGlobalSampleRatio / ScreenSpaceVsWorldSpaceThreshold / TemporalFeedbackRequired
+ * (LightsBaker.cpp:1055-1075). `table`: resX * resY tiles of 8 x 8 pixels (LightingConfig.h:27-31), 128 packed entries each — light index << 9 | (proxies of that light in the
+ * tile - 1), sorted by light index (LightingTypes.hlsli:172-175) — what LightsBaker's ProcessFeedbackHistory passes write; NULL removes the local layer. With a table, the
+ * candidates [globalCount, NEECandidateSamples) of a screen-space-coherent vertex (ray-cone width / path length < threshold; LightsBaker.h:240 uses 0.3) are drawn from the
+ * pixel's tile, and every MIS weight uses both samplers' pdfs. temporalFeedback != 0: every visible NEE sample is offered to its pixel's feedback reservoir (weight =
+ * contribution / globalPdf^0.65); needs NEEFullSamples 1. The baker that turns feedback into the next frame's tables is the host's (remainder). */
+int32_t pt_set_local_light_sampling(pt_context* ctx, const uint32_t* table, uint32_t resX, uint32_t resY, uint32_t jitterX, uint32_t jitterY, float localToGlobalSampleRatio,
+                                    float screenSpaceVsWorldSpaceThreshold, int32_t temporalFeedback);
+/* the feedback reservoirs the last pt_render call filled: one plane of width x height slots per sample of the call (sample = 0 .. sampleCount-1), cleared at the start of the
+ * call (total weight 0, candidate 0xFFFFFFFF); candidate = light index | 0x80000000 when the vertex was screen-space coherent (LightingTypes.hlsli:184-320) */
+int32_t pt_get_light_feedback(pt_context* ctx, uint32_t sample, float* totalWeight, uint32_t* candidates);
 
 /* BridgeCamera (PathTracerShared.h:109-141) */
 int32_t pt_bridge_camera(uint32_t viewportWidth, uint32_t viewportHeight, const float camPos[3], const float camDir[3], const float camUp[3], float fovY,

@@ -443,6 +443,20 @@ class Oracle:
         ptrs = (ctypes.c_void_p * 4)(*[a.ctypes.data for a in arrs])
         self.L.ptref_set_procedural_sky(self.h, _p(cbuf), ptrs, _p(dims))
 
+    def set_local_light_sampling(self, table=None, jitter=(0, 0), ratio=0.65, ssc_threshold=0.3, feedback=False):
+        """NEE-AT inputs; table: uint32 [tilesY, tilesX, 128] packed entries or None"""
+        import ctypes
+        f = self.L.ptref_set_local_light_sampling
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_uint32] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_int]; f.restype = None
+        if table is None: f(self.h, None, 0, 0, 0, 0, float(ratio), float(ssc_threshold), 1 if feedback else 0); return
+        t = np.ascontiguousarray(table, np.uint32); assert t.ndim == 3 and t.shape[2] == 128
+        f(self.h, _p(t), t.shape[1], t.shape[0], int(jitter[0]), int(jitter[1]), float(ratio), float(ssc_threshold), 1 if feedback else 0)
+
+    def light_feedback(self, sample=0):
+        w = np.zeros((self.h_, self.w), np.float32); c = np.zeros((self.h_, self.w), np.uint32)
+        if not self.L.ptref_get_light_feedback(self.h, int(sample), _p(w), _p(c)): raise RuntimeError("no feedback for that sample")
+        return w, c
+
     def sky_eval(self, mode, rows):
         """mode 0: ProceduralSkyLowRes (x, y, face, direction) -> (n, 4); 1: atmosphere + sun (.., direction) -> (n, 3); 2: GetSkyRadianceToPoint (.., point) -> (n, 6)"""
         rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 6); out = np.zeros((len(rows), (4, 3, 6)[mode]), np.float32)

@@ -317,10 +317,96 @@ struct LightTable {
     uint TotalLightCount, SamplingProxyCount;
     const uint* EnvLookupMap; uint EnvLookupDim;       // equal-area-octahedral texel -> env quad light index
     float3x4 EnvToWorld, WorldToEnv;
+    // NEE-AT (NEEType 2): the screen-tile local samplers and the feedback switch (LightingTypes.hlsli:78-123: LocalSamplingTileJitter, LocalSamplingResolution,
+    // LocalToGlobalSampleRatio, ScreenSpaceVsWorldSpaceThreshold, TemporalFeedbackRequired). LocalSamplingBuffer == null: no local layer (ratio 0).
+    const uint* LocalSamplingBuffer; uint LocalResX, LocalResY, LocalJitterX, LocalJitterY;
+    float LocalToGlobalSampleRatio, ScreenSpaceVsWorldSpaceThreshold; uint TemporalFeedbackRequired;
 };
-// LightSampler.hlsli:100-146, 400-432 (NEEType==1 "power": global sampler only, local count == 0)
+// LightingConfig.h:27-31 (the "default" tier) and LightingTypes.hlsli:148-180
+static const uint RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE = 8, RTXPT_LIGHTING_LOCAL_PROXY_COUNT = 128, RTXPT_LIGHTING_LOCAL_PROXY_BINARY_SEARCH_STEPS = 8;
+static inline uint ComputeCandidateSampleLocalCount(float localToGlobalRatio, uint totalCandidateSamples) { return (uint)((float)(totalCandidateSamples - 1u) * localToGlobalRatio + 0.75f); }
+static inline uint PackMiniListLightAndCount(uint globalLightIndex, uint counter) { return ((globalLightIndex & 0x007FFFFFu) << 9) | ((counter - 1u) & 0x1FFu); }
+static inline void UnpackMiniListLightAndCount(uint value, uint& globalLightIndex, uint& counter) { globalLightIndex = value >> 9; counter = (value & 0x1FFu) + 1u; }
+static inline uint UnpackMiniListLight(uint value) { return value >> 9; }
+static inline uint LLSB_ComputeBaseAddress(uint tileX, uint tileY, uint resX) { return (tileX + tileY * resX) * RTXPT_LIGHTING_LOCAL_PROXY_COUNT; }
+// LightingAlgorithms.hlsli:654-682: the tile's entries are sorted by light index; returns the packed entry or RTXPT_INVALID_LIGHT_INDEX
+static inline uint LocalLightBinarySearch(const uint* storageBuffer, uint tileAddress, uint globalLightIndexToFind, uint localLightCount, uint steps) {
+    uint indexLeft = tileAddress, indexRight = tileAddress + localLightCount - 1u;
+    for (uint i = 0u; i < steps; ++i) {
+        uint indexMiddle = (indexLeft + indexRight) >> 1;
+        uint value = storageBuffer[indexMiddle];
+        uint keyMiddle = UnpackMiniListLight(value);
+        if (keyMiddle < globalLightIndexToFind) indexLeft = indexMiddle + 1u;
+        else if (keyMiddle > globalLightIndexToFind) indexRight = indexMiddle - 1u;
+        else return value;
+    }
+    return RTXPT_INVALID_LIGHT_INDEX;
+}
+// LightingTypes.hlsli:184-320 LightFeedbackReservoir: one slot per pixel, "how much this pixel wanted which light" (the input of next frame's local samplers)
+static const uint LFR_SCREEN_SPACE_COHERENT_FLAG = 0x80000000u;
+static const float LFR_MAX_WEIGHT = 1e12f;
+static inline void LightFeedbackReservoir_Add(float& slotTotalWeight, uint& slotCandidate, float randomValue, uint candidateIndex, float candidateWeight, bool candidateIsScreenSpaceCoherent) {
+    candidateWeight = fminf_(LFR_MAX_WEIGHT, candidateWeight);
+    float totalWeight = slotTotalWeight;
+    totalWeight += candidateWeight;
+    slotTotalWeight = fminf_(LFR_MAX_WEIGHT, totalWeight);
+    float threshold = saturate(candidateWeight / totalWeight);
+    if (candidateIsScreenSpaceCoherent) candidateIndex |= LFR_SCREEN_SPACE_COHERENT_FLAG;
+    if (randomValue < threshold) slotCandidate = candidateIndex;
+}
+// LightSampler.hlsli:29-110 (make), :100-180 (the two samplers and their pdfs), :222-270, :318-345, :400-432. NEEType 0 / 1: the global sampler only
+// (LocalToGlobalSampleRatio 0 -> local count 0); NEEType 2 (NEE-AT): candidates [globalCount, total) are drawn from the pixel's tile.
 struct LightSampler {
     const LightTable* T;
+    uint LocalSamplingTilePos; bool IsScreenSpaceCoherent;
+    static bool IsScreenSpaceCoherentHeuristic(const LightTable& t, float rayConeWidth, float totalPathLength) {      // :45-49
+        float rayConeWidthOverTotalPathTravel = rayConeWidth / totalPathLength;
+        return rayConeWidthOverTotalPathTravel < t.ScreenSpaceVsWorldSpaceThreshold;
+    }
+    static LightSampler make(const LightTable& t, uint pixelX, uint pixelY, bool isScreenSpaceCoherent) {            // :51-93
+        LightSampler ls; ls.T = &t; ls.IsScreenSpaceCoherent = isScreenSpaceCoherent;
+        ls.LocalSamplingTilePos = LLSB_ComputeBaseAddress((pixelX + t.LocalJitterX) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE, (pixelY + t.LocalJitterY) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE, t.LocalResX);
+        return ls;
+    }
+    bool IsTemporalFeedbackRequired() const { return T->TemporalFeedbackRequired != 0; }
+    uint SampleLocal(float rnd, float& pdf) const {                                                                  // :120-138
+        const uint localProxyCount = RTXPT_LIGHTING_LOCAL_PROXY_COUNT;
+        uint indexInIndex = (uint)(rnd * (float)localProxyCount);
+        if (indexInIndex > localProxyCount - 1u) indexInIndex = localProxyCount - 1u;
+        uint lightIndex, proxyCount;
+        UnpackMiniListLightAndCount(T->LocalSamplingBuffer[LocalSamplingTilePos + indexInIndex], lightIndex, proxyCount);
+        pdf = (float)proxyCount / (float)localProxyCount;
+        return lightIndex;
+    }
+    float SampleLocalPDF(uint lightIndex) const {                                                                    // :146-180
+        uint packedValue = LocalLightBinarySearch(T->LocalSamplingBuffer, LocalSamplingTilePos, lightIndex, RTXPT_LIGHTING_LOCAL_PROXY_COUNT, RTXPT_LIGHTING_LOCAL_PROXY_BINARY_SEARCH_STEPS);
+        if (packedValue == RTXPT_INVALID_LIGHT_INDEX) return 0.0f;
+        uint lightIndexR, proxyCountR;
+        UnpackMiniListLightAndCount(packedValue, lightIndexR, proxyCountR);
+        return (float)proxyCountR / (float)RTXPT_LIGHTING_LOCAL_PROXY_COUNT;
+    }
+    void GetCandidateSampleCounts(uint totalCandidateSamples, uint& localCount, uint& globalCount) const {           // :411-420
+        localCount = (IsScreenSpaceCoherent && T->LocalSamplingBuffer) ? ComputeCandidateSampleLocalCount(T->LocalToGlobalSampleRatio, totalCandidateSamples) : 0u;
+        globalCount = totalCandidateSamples - localCount;
+    }
+    // :242-268: the pdf of the sampler the sample was drawn from, the pdf the other sampler gives the same light, and the number of candidates each drew
+    void ComputeLightSelectionPdfs(float selectionPdf, uint lightIndex, bool fromLocalDistribution, uint localCandidateCount, uint globalCandidateCount,
+                                   float& thisPdf, float& otherPdf, float& thisCount, float& otherCount) const {
+        thisPdf = selectionPdf;
+        if (fromLocalDistribution) { otherPdf = SampleGlobalPDF(lightIndex); thisCount = (float)localCandidateCount; otherCount = (float)globalCandidateCount; }
+        else {
+            thisCount = (float)globalCandidateCount;
+            if (localCandidateCount != 0) { otherPdf = SampleLocalPDF(lightIndex); otherCount = (float)localCandidateCount; }
+            else { otherPdf = 0; otherCount = 0; }
+        }
+    }
+    // :184-200 InsertFeedbackFromNEE: the weight the reservoir receives (RTXPT_LIGHTING_SCREEN_SPACE_COHERENT_FEEDBACK_BIAS is 1.0)
+    float FeedbackWeightFromNEE(uint lightIndex, float pixelRadianceContributionAvg) const {
+        float feedbackWeight = pixelRadianceContributionAvg;
+        feedbackWeight /= dm_pow(SampleGlobalPDF(lightIndex), 0.65f);
+        if (IsScreenSpaceCoherent) feedbackWeight *= 1.0f;
+        return feedbackWeight;
+    }
     bool IsEmpty() const { return T->SamplingProxyCount == 0; }
     uint SampleGlobal(float rnd, float& pdf) const {
         uint total = T->SamplingProxyCount;
@@ -336,36 +422,39 @@ struct LightSampler {
         if (f.Base.HasLightShaping()) f.Extended = T->LightsEx[index];
         return f;
     }
-    // :318-332 (localCount == 0 => localPdf == 0)
-    float ComputeLightVsBSDF_MIS_ForBSDF(uint lightIndex, float bsdfPdf, float solidAnglePdf, uint fullSampleCount) const {
+    // :318-332
+    float ComputeLightVsBSDF_MIS_ForBSDF(uint lightIndex, float bsdfPdf, float solidAnglePdf, uint candidateSampleCount, uint fullSampleCount) const {
+        uint localCount, globalCount;
+        GetCandidateSampleCounts(candidateSampleCount, localCount, globalCount);
         float globalPdf = SampleGlobalPDF(lightIndex);
-        float lightAvgPdf = (0.0f + globalPdf) * (float)fullSampleCount;
+        float localPdf = (localCount > 0) ? SampleLocalPDF(lightIndex) : 0.0f;
+        float lightAvgPdf = (localPdf + globalPdf) * (float)fullSampleCount;
         return EvalMIS_Balance(1, bsdfPdf, 1, lightAvgPdf * solidAnglePdf);
     }
     // :334-345
-    float ComputeBSDFMISForEmissiveTriangle(uint lightIndex, float bsdfPdf, float3 viewerPosition, float3 lightSamplePosition, uint fullSamples) const {
+    float ComputeBSDFMISForEmissiveTriangle(uint lightIndex, float bsdfPdf, float3 viewerPosition, float3 lightSamplePosition, uint candidateSampleCount, uint fullSamples) const {
         if (bsdfPdf == 0 || lightIndex == RTXPT_INVALID_LIGHT_INDEX) return 1;
         TriangleLight tl = TriangleLight::Create(LoadLight(lightIndex));
         float solidAnglePdf = tl.CalcSolidAnglePdfForMIS(viewerPosition, lightSamplePosition);
-        return ComputeLightVsBSDF_MIS_ForBSDF(lightIndex, bsdfPdf, solidAnglePdf, fullSamples);
+        return ComputeLightVsBSDF_MIS_ForBSDF(lightIndex, bsdfPdf, solidAnglePdf, candidateSampleCount, fullSamples);
     }
-    // :363-390 (sphere lights only; localCandidates are NEE-AT's, 0 here; exact MIS, RTXPT_USE_APPROXIMATE_MIS 0). Returns false when nothing is added.
-    bool ComputeAnalyticLightProxyContribution(uint analyticLightIndex, float bsdfPdf, float3 previousVertex, float3 rayDir, uint fullSamples, float3& contribution) const {
+    // :363-390 (sphere lights only; exact MIS, RTXPT_USE_APPROXIMATE_MIS 0). Returns false when nothing is added.
+    bool ComputeAnalyticLightProxyContribution(uint analyticLightIndex, float bsdfPdf, float3 previousVertex, float3 rayDir, uint candidateSamples, uint fullSamples, float3& contribution) const {
         PolymorphicLightInfoFull lightInfo = LoadLight(analyticLightIndex);
         if (DecodeLightType(lightInfo.Base) != kSphere) return false;
         SphereLight sphereLight = SphereLight::Create(lightInfo);
         float3 radiance, lightSamplePosition;
         if (!sphereLight.Eval(previousVertex, rayDir, radiance, lightSamplePosition)) return false;
         float mis = 1.0f;
-        if (bsdfPdf != 0) mis = ComputeLightVsBSDF_MIS_ForBSDF(analyticLightIndex, bsdfPdf, sphereLight.CalcSolidAnglePdfForMIS(previousVertex, lightSamplePosition), fullSamples);
+        if (bsdfPdf != 0) mis = ComputeLightVsBSDF_MIS_ForBSDF(analyticLightIndex, bsdfPdf, sphereLight.CalcSolidAnglePdfForMIS(previousVertex, lightSamplePosition), candidateSamples, fullSamples);
         contribution = radiance * mis;
         return true;
     }
     // :347-362
-    float ComputeBSDFMISForEnvironmentQuad(uint lightIndex, float bsdfPdf, uint fullSamples) const {
+    float ComputeBSDFMISForEnvironmentQuad(uint lightIndex, float bsdfPdf, uint candidateSampleCount, uint fullSamples) const {
         if (bsdfPdf == 0 || lightIndex == RTXPT_INVALID_LIGHT_INDEX) return 1;
         EnvironmentQuadLight eq = EnvironmentQuadLight::Create(LoadLight(lightIndex));
-        return ComputeLightVsBSDF_MIS_ForBSDF(lightIndex, bsdfPdf, eq.CalcSolidAnglePdfForMIS(), fullSamples);
+        return ComputeLightVsBSDF_MIS_ForBSDF(lightIndex, bsdfPdf, eq.CalcSolidAnglePdfForMIS(), candidateSampleCount, fullSamples);
     }
     // :423-432
     uint LookupEnvLightByDirection(float3 localDir) const {

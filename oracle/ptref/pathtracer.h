@@ -223,10 +223,11 @@ static inline float ComputeLowGrazingAngleFalloff(float3 lightDirection, float3 
 struct PathTracer {
     const Scene& sc; PtSettings S; PathTracerCameraData cam; uint sampleIndex;   // Bridge::getSampleIndex() = sampleBaseIndex + subSampleIndex
     RayCounters* counters;
-    LightSampler lightSampler;
+    float* fbTotalWeight = nullptr; uint* fbCandidates = nullptr; uint fbWidth = 0;      // NEE-AT feedback reservoirs of this sample (one slot per pixel), or null
 
     PathTracer(const Scene& scene, const PtSettings& s, const PathTracerCameraData& c, uint sidx, RayCounters* ctr)
-        : sc(scene), S(s), cam(c), sampleIndex(sidx), counters(ctr) { lightSampler.T = &scene.lightTable; }
+        : sc(scene), S(s), cam(c), sampleIndex(sidx), counters(ctr) {}
+    LightSampler CreateLightSampler(uint pathId, bool isScreenSpaceCoherent) const { return LightSampler::make(sc.lightTable, pathId >> 16, pathId & 0xFFFFu, isScreenSpaceCoherent); }      // BridgeDonut:1075-1084
 
     // PathTracer.hlsli:40-45
     bool HasFinishedSurfaceBounces(uint vertexIndex, uint diffuseBounces) const {
@@ -456,8 +457,9 @@ struct PathTracer {
             float misWeight = 1.0f;
             float bsdfScatterPdf = path.GetBsdfScatterPdf();
             if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0) {
+                LightSampler lightSampler = CreateLightSampler(path.id, misInfo.LightSamplingIsSSC);
                 uint envIdx = lightSampler.LookupEnvLightByDirection(localDir);
-                misWeight = lightSampler.ComputeBSDFMISForEnvironmentQuad(envIdx, bsdfScatterPdf, misInfo.FullSamples);
+                misWeight = lightSampler.ComputeBSDFMISForEnvironmentQuad(envIdx, bsdfScatterPdf, misInfo.CandidateSamples, misInfo.FullSamples);
             }
             environmentEmission = LP::r3(misWeight * Le);
         }
@@ -534,13 +536,16 @@ struct PathTracer {
     }
 
     // PathTracerNEE.hlsli:88-161
-    LightSample GenerateLightSample(const ShadingData& sd, const StandardBSDF& bsdf, uint candidateSampleCount, UniformSampleSequenceGenerator& sg) const {
+    LightSample GenerateLightSample(const LightSampler& lightSampler, const ShadingData& sd, const StandardBSDF& bsdf, uint candidateSampleCount, UniformSampleSequenceGenerator& sg) const {
         LightSample cand; memset(&cand, 0, sizeof(cand));
         float weightSum = 0, candWeight = 0;
+        uint localCount, globalCount;
+        lightSampler.GetCandidateSampleCounts(candidateSampleCount, localCount, globalCount);
         for (uint i = 0; i < candidateSampleCount; i++) {
+            const bool sampleIsLocal = i >= globalCount;
             float selectionPdf = 0;
             float rnd = sampleNext1D(sg);
-            uint lightIndex = lightSampler.SampleGlobal(rnd, selectionPdf);          // globalCount == candidateSampleCount (NEEType 1)
+            uint lightIndex = sampleIsLocal ? lightSampler.SampleLocal(rnd, selectionPdf) : lightSampler.SampleGlobal(rnd, selectionPdf);
             PolymorphicLightInfoFull li = lightSampler.LoadLight(lightIndex);
             float2 interior = sampleNext2D(sg);
             PolymorphicLightSample ls = PolymorphicLight_CalcSample(li, interior, sd.posW, sc.env.toWorld);
@@ -551,7 +556,7 @@ struct PathTracer {
             float3 surfToLight = ls.Position - sd.posW;
             c.Distance = length(surfToLight);
             c.Direction = surfToLight / fmaxf_(c.Distance, 1e-7f);
-            c.LightIndex = lightIndex; c.SelectionPdf = selectionPdf; c.LightSampleableByBSDF = ls.LightSampleableByBSDF; c.FromLocalDistribution = false;
+            c.LightIndex = lightIndex; c.SelectionPdf = selectionPdf; c.LightSampleableByBSDF = ls.LightSampleableByBSDF; c.FromLocalDistribution = sampleIsLocal;
             float wrsWeight = max3(c.Li) * bsdf.evalPdf(sd, c.Direction);          // EvalSampleWeight (:41-50)
             float r = sampleNext1D(sg);
             weightSum += wrsWeight;                                                 // NEEWeightedReservoirSampler::Add (:70-80)
@@ -563,16 +568,17 @@ struct PathTracer {
     }
     // PathTracerNEE.hlsli:166-275 (ProcessLightSample) + :277-346
     NEEResult HandleNEE(const PathState& pre, const ShadingData& sd, const StandardBSDF& bsdf, UniformSampleSequenceGenerator& sg) const {
+        const LightSampler lightSampler = CreateLightSampler(pre.id, LightSampler::IsScreenSpaceCoherentHeuristic(sc.lightTable, pre.rayCone.getWidth(), pre.sceneLength));      // :306
         uint fullSamples = S.NEEFullSamples < 63u ? S.NEEFullSamples : 63u;
         bool hasNonDeltaLobes = (bsdf.getLobes() & Lobe_NonDelta) != 0;
         bool applyNEE = hasNonDeltaLobes && !lightSampler.IsEmpty() && fullSamples > 0;
         if (!applyNEE) return NEEResult::empty();
         uint candidateSampleCount = S.NEECandidateSamples;
         NEEResult result = NEEResult::empty();
-        result.BSDFMISInfo.LightSamplingEnabled = true; result.BSDFMISInfo.LightSamplingIsSSC = false;
+        result.BSDFMISInfo.LightSamplingEnabled = true; result.BSDFMISInfo.LightSamplingIsSSC = lightSampler.IsScreenSpaceCoherent;
         result.BSDFMISInfo.CandidateSamples = candidateSampleCount; result.BSDFMISInfo.FullSamples = fullSamples;
         for (uint s = 0; s < fullSamples; s++) {
-            LightSample ls = GenerateLightSample(sd, bsdf, candidateSampleCount, sg);
+            LightSample ls = GenerateLightSample(lightSampler, sd, bsdf, candidateSampleCount, sg);
             bool visible = false;
             if (ls.Valid()) {
                 float faceSide = dot(sd.N, ls.Direction) >= 0 ? 1.f : -1.f;                        // ComputeVisibilityRay (:166-182)
@@ -582,8 +588,10 @@ struct PathTracer {
             }
             if (!visible) continue;
             float fadeOut = (sd.shadowNoLFadeout > 0) ? ComputeLowGrazingAngleFalloff(ls.Direction, sd.vertexN, sd.shadowNoLFadeout, 2.0f * sd.shadowNoLFadeout) : 1.0f;
-            float globalCount = (float)candidateSampleCount;
-            float thisPdf = ls.SelectionPdf, otherPdf = 0.f, thisCount = globalCount;              // ComputeLightSelectionPdfs: local count 0
+            uint localCount, globalCount;
+            lightSampler.GetCandidateSampleCounts(candidateSampleCount, localCount, globalCount);
+            float thisPdf, otherPdf, thisCount, otherCount;                                          // the inner (WRS) MIS between the two samplers (:217-224)
+            lightSampler.ComputeLightSelectionPdfs(ls.SelectionPdf, ls.LightIndex, ls.FromLocalDistribution, localCount, globalCount, thisPdf, otherPdf, thisCount, otherCount);
             float wrsMIS = EvalMIS_Balance(1, thisPdf, 1, otherPdf);
             wrsMIS = wrsMIS / thisCount;
             float scatterPdfForDir = bsdf.evalPdf(sd, ls.Direction);
@@ -603,6 +611,12 @@ struct PathTracer {
             radiance = radiance * preThp;
             specAvg *= Average(preThp);
             result.AccumulateRadiance(radiance, specAvg);
+            if (ls.LightIndex != RTXPT_INVALID_LIGHT_INDEX && lightSampler.IsTemporalFeedbackRequired()) {      // :266-273, LightSampler.hlsli:184-200
+                float feedbackWeight = lightSampler.FeedbackWeightFromNEE(ls.LightIndex, radianceAvg * Average(preThp));
+                float rnd = sampleNext1D(sg);
+                if (fbTotalWeight) { const uint slot = (pre.id & 0xFFFFu) * fbWidth + (pre.id >> 16);
+                    LightFeedbackReservoir_Add(fbTotalWeight[slot], fbCandidates[slot], rnd, ls.LightIndex, feedbackWeight, lightSampler.IsScreenSpaceCoherent); }
+            }
         }
         return result;
     }
@@ -630,16 +644,17 @@ struct PathTracer {
         const ShadingData& sd = sfd.shadingData; const StandardBSDF& bsdf = sfd.bsdf;
         float3 surfaceEmission = make_float3(0.f);
         NEEBSDFMISInfo misInfo = NEEBSDFMISInfo::Unpack16bit(path.GetPackedMISInfo());
+        const LightSampler lightSampler = CreateLightSampler(path.id, misInfo.LightSamplingIsSSC);      // "configured same as it was at previous vertex" (PathTracer.hlsli:617,639)
         if (any_gt0(sd.emission)) {
             float misWeight = 1.0f;
             float bsdfScatterPdf = path.GetBsdfScatterPdf();
             if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0)
-                misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(sfd.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.FullSamples);
+                misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(sfd.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.CandidateSamples, misInfo.FullSamples);
             surfaceEmission = LP::r3(sd.emission * misWeight);
         }
         if (sfd.neeAnalyticLightIndex != RTXPT_INVALID_LIGHT_INDEX) {                  // PathTracer.hlsli:636-648: the mesh stands in for an analytic (sphere) light
             const float bsdfPdf = misInfo.LightSamplingEnabled ? LP::r(path.GetBsdfScatterPdf()) : 0.0f; float3 add;
-            if (lightSampler.ComputeAnalyticLightProxyContribution(sfd.neeAnalyticLightIndex, bsdfPdf, rayOrigin, rayDir, misInfo.FullSamples, add)) {
+            if (lightSampler.ComputeAnalyticLightProxyContribution(sfd.neeAnalyticLightIndex, bsdfPdf, rayOrigin, rayDir, misInfo.CandidateSamples, misInfo.FullSamples, add)) {
                 add = LP::r3(add); surfaceEmission = make_float3(LP::add(surfaceEmission.x, add.x), LP::add(surfaceEmission.y, add.y), LP::add(surfaceEmission.z, add.z));
             }
         }

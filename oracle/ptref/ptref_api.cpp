@@ -380,11 +380,17 @@ void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
     T.Lights = sc.lights.data(); T.LightsEx = sc.lightsEx.data(); T.ProxyCounters = sc.proxyCounters.data(); T.ProxyIndices = sc.proxyIndices.data();
     T.TotalLightCount = (uint)sc.lights.size(); T.SamplingProxyCount = (uint)sc.proxyIndices.size();
     T.EnvLookupMap = sc.envLookup.data(); T.EnvLookupDim = sc.envLookupDim; T.EnvToWorld = sc.env.toWorld; T.WorldToEnv = sc.env.toLocal;
+    sc.bindLocalSampling();
 }
 
 struct Context {
     Scene sc; PtSettings S; PathTracerCameraData cam; uint w, h; std::vector<float4> accum; uint accumCount; RayCounters ctr;
     bool geomDirty, lightsDirty;
+    std::vector<float> fbWeight; std::vector<uint> fbCand; uint fbSamples = 0;      // NEE-AT feedback reservoirs of the last render call: one plane of w x h slots per sample
+    void beginFeedback(uint n) {      // LightFeedbackReservoir::Clear for every slot
+        fbSamples = 0; if (!sc.feedbackRequired) return;
+        fbWeight.assign((size_t)w * h * n, 0.0f); fbCand.assign((size_t)w * h * n, 0xFFFFFFFFu); fbSamples = n;
+    }
 };
 
 } // namespace ptref
@@ -546,6 +552,7 @@ void ptref_prepare(void* h) { prepare((Context*)h); }
 // Restricting to a pixel rectangle is an oracle-only convenience for bounded-time checks.
 void ptref_render_rect(void* h, uint32_t first, uint32_t n, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
     Context* c = (Context*)h; prepare(c);
+    c->beginFeedback(n);
     for (uint32_t s = 0; s < n; s++) {
         uint32_t sampleIndex = first + s;
         float blend = 1.0f / (float)(c->accumCount + 1);
@@ -554,6 +561,7 @@ void ptref_render_rect(void* h, uint32_t first, uint32_t n, uint32_t x0, uint32_
         {
             RayCounters local; memset(&local, 0, sizeof(local));
             PathTracer pt(c->sc, c->S, c->cam, sampleIndex, &local);
+            if (c->fbSamples) { pt.fbTotalWeight = c->fbWeight.data() + (size_t)c->w * c->h * s; pt.fbCandidates = c->fbCand.data() + (size_t)c->w * c->h * s; pt.fbWidth = c->w; }
 #pragma omp for schedule(dynamic, 1) nowait
             for (int y = (int)y0; y < (int)y1; y++) for (uint32_t x = x0; x < x1; x++) {
                 float4 col = pt.tracePixel(x, (uint32_t)y);
@@ -568,6 +576,20 @@ void ptref_render_rect(void* h, uint32_t first, uint32_t n, uint32_t x0, uint32_
         c->ctr.triTestsExt += total.triTestsExt; c->ctr.nodeVisitsSh += total.nodeVisitsSh; c->ctr.triTestsSh += total.triTestsSh;
         c->accumCount++;
     }
+}
+// NEE-AT, the path tracer's side (LightSampler.hlsli; the table is what LightsBaker's feedback passes write: tiles of 8 x 8 pixels, 128 packed entries each, sorted by light index)
+void ptref_set_local_light_sampling(void* h, const uint32_t* table, uint32_t resX, uint32_t resY, uint32_t jitterX, uint32_t jitterY, float ratio, float sscThreshold, int feedback) {
+    Context* c = (Context*)h; Scene& sc = c->sc;
+    if (table) { sc.localTable.assign(table, table + (size_t)resX * resY * RTXPT_LIGHTING_LOCAL_PROXY_COUNT); sc.localResX = resX; sc.localResY = resY; sc.localJitterX = jitterX; sc.localJitterY = jitterY; }
+    else { sc.localTable.clear(); sc.localResX = sc.localResY = sc.localJitterX = sc.localJitterY = 0; }
+    sc.localRatio = ratio; sc.sscThreshold = sscThreshold; sc.feedbackRequired = feedback != 0;
+    sc.bindLocalSampling();
+}
+int ptref_get_light_feedback(void* h, uint32_t sample, float* totalWeight, uint32_t* candidates) {
+    Context* c = (Context*)h; if (sample >= c->fbSamples) return 0;
+    const size_t plane = (size_t)c->w * c->h;
+    memcpy(totalWeight, c->fbWeight.data() + plane * sample, 4 * plane); memcpy(candidates, c->fbCand.data() + plane * sample, 4 * plane);
+    return 1;
 }
 void ptref_render(void* h, uint32_t first, uint32_t n) { Context* c = (Context*)h; ptref_render_rect(h, first, n, 0, 0, c->w, c->h); }
 const float* ptref_radiance(void* h) { return (const float*)((Context*)h)->accum.data(); }

@@ -179,6 +179,13 @@ struct Scene {
     std::vector<uint> proxyCounters, proxyIndices, envLookup; uint envLookupDim;
     std::vector<PolymorphicLightInfoFull> analyticLights;   // supplied by the host (pt_set_lights)
     LightTable lightTable;
+    // NEE-AT inputs (ptref_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback switch
+    std::vector<uint> localTable; uint localResX = 0, localResY = 0, localJitterX = 0, localJitterY = 0; float localRatio = 0.f, sscThreshold = 0.f; bool feedbackRequired = false;
+    void bindLocalSampling() {
+        LightTable& T = lightTable;
+        T.LocalSamplingBuffer = localResX ? localTable.data() : nullptr; T.LocalResX = localResX; T.LocalResY = localResY; T.LocalJitterX = localJitterX; T.LocalJitterY = localJitterY;
+        T.LocalToGlobalSampleRatio = localResX ? localRatio : 0.f; T.ScreenSpaceVsWorldSpaceThreshold = sscThreshold; T.TemporalFeedbackRequired = feedbackRequired ? 1u : 0u;
+    }
     // BVH2
     struct Node { float3 bmin; uint leftFirst; float3 bmax; uint count; };   // count==0: inner (children leftFirst, leftFirst+1)
     std::vector<Node> nodes; std::vector<uint> triOrder;

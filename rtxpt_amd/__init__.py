@@ -26,7 +26,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 # every symbol include/mi355pt.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_positions", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
-    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
@@ -632,6 +632,21 @@ class PathTracer:
         t = keep = None
         if textures is not None: t, keep = _sky_textures(textures)
         self._chk(self.L.pt_set_procedural_sky(self.h, _p(cbuf), ctypes.byref(t) if t is not None else None), "pt_set_procedural_sky")
+
+    def set_local_light_sampling(self, table=None, jitter=(0, 0), ratio=0.65, ssc_threshold=0.3, feedback=False):
+        """NEE-AT inputs (pt_set_local_light_sampling). table: uint32 [tilesY, tilesX, 128] packed entries (light << 9 | count - 1, sorted per tile) or None (no local layer)"""
+        f = self.L.pt_set_local_light_sampling
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_uint32] * 4 + [ctypes.c_float, ctypes.c_float, ctypes.c_int32]; f.restype = ctypes.c_int32
+        if table is None: self._chk(f(self.h, None, 0, 0, 0, 0, float(ratio), float(ssc_threshold), 1 if feedback else 0), "pt_set_local_light_sampling"); return
+        t = np.ascontiguousarray(table, np.uint32)
+        if t.ndim != 3 or t.shape[2] != 128: raise ValueError("local sampling table: uint32 [tilesY, tilesX, 128]")
+        self._chk(f(self.h, _p(t), t.shape[1], t.shape[0], int(jitter[0]), int(jitter[1]), float(ratio), float(ssc_threshold), 1 if feedback else 0), "pt_set_local_light_sampling")
+
+    def light_feedback(self, sample=0):
+        """the feedback reservoirs sample `sample` of the last render() call filled: (total weight float32 [H, W], candidate uint32 [H, W])"""
+        w = np.zeros((self.height, self.width), np.float32); c = np.zeros((self.height, self.width), np.uint32)
+        self._chk(self.L.pt_get_light_feedback(self.h, int(sample), _p(w), _p(c)), "pt_get_light_feedback")
+        return w, c
 
     def animate(self, instances=None, positions=None, rebuild=False):
         self._chk(self.L.pt_animate(self.h, _p(instances), 0 if instances is None else len(instances), _p(positions), 0 if positions is None else positions.shape[0],

@@ -88,6 +88,9 @@ struct pt_context {
     bool skyEnabled = false; ptk::ProceduralSkyContext sky; DevBuf<ptk::float4> dSkyTex[4]; DevBuf<ptk::ProceduralSkyContext> dSky; DevBuf<ptk::uint2> dSkyLowRes;      // pt_set_procedural_sky
     DevBuf<ptk::uint2> dEnvCube, dEnvCubeSource; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights; uint envCompression = 0;      // envCompression: EnvMapBaker's BC6U compression (0 off, 1 fast)
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
+    // NEE-AT (pt_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback reservoirs of the last pt_render call (one plane per sample)
+    DevBuf<uint> dLocalTable; uint localResX = 0, localResY = 0, localJitterX = 0, localJitterY = 0, localMaxLight = 0; float localRatio = 0.f, sscThreshold = 0.f; bool feedbackRequired = false;
+    DevBuf<float> dFbWeight; DevBuf<uint> dFbCand; DevBuf<ptk::float4> dSq3; uint fbSamples = 0;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
     BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0; uint bvhBuilder = BVH_BUILDER_SAH;
@@ -233,6 +236,8 @@ void refresh_scene_view(pt_context* c) {
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
     d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
+    d.lights.LocalSamplingBuffer = c->localResX ? c->dLocalTable.p : nullptr; d.lights.LocalResX = c->localResX; d.lights.LocalResY = c->localResY; d.lights.LocalJitterX = c->localJitterX; d.lights.LocalJitterY = c->localJitterY;
+    d.lights.LocalToGlobalSampleRatio = c->localResX ? c->localRatio : 0.f; d.lights.ScreenSpaceVsWorldSpaceThreshold = c->sscThreshold; d.lights.TemporalFeedbackRequired = c->feedbackRequired ? 1u : 0u;
     d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.alphaPlanes = c->dAlphaPlanes.p; d.alphaPool = c->dAlphaPool.p; d.shadeTris = c->dShadeTris.p; d.primToSlot = c->bvh.primToSlot; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
 }
 
@@ -667,6 +672,37 @@ int32_t pt_set_environment_compression(pt_context* c, uint32_t quality) {
     if (c->envCompression != quality) { c->envCompression = quality; c->envCubeDirty = true; c->lightsDirty = true; }
     return PT_OK;
 }
+int32_t pt_set_local_light_sampling(pt_context* c, const uint32_t* table, uint32_t resX, uint32_t resY, uint32_t jitterX, uint32_t jitterY, float localToGlobalSampleRatio,
+                                    float screenSpaceVsWorldSpaceThreshold, int32_t temporalFeedback) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    const uint N = ptk::RTXPT_LIGHTING_LOCAL_PROXY_COUNT, TILE_PX = ptk::RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE;
+    if (!(localToGlobalSampleRatio >= 0.f && localToGlobalSampleRatio <= 0.95f)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "LocalToGlobalSampleRatio: 0 .. 0.95 (SampleUI.cpp:750)");
+    if (table) {
+        if (!resX || !resY || jitterX >= TILE_PX || jitterY >= TILE_PX) return fail(c, PT_ERROR_INVALID_ARGUMENT, "local sampling table: resolution in tiles of 8 x 8 pixels, jitter below the tile size");
+        uint maxLight = 0;
+        for (size_t t = 0; t < (size_t)resX * resY; t++) for (uint k = 0; k < N; k++) {      // SampleLocalPDF searches the tile by light index (LightingAlgorithms.hlsli:654): the entries must be sorted
+            const uint light = table[t * N + k] >> 9;
+            if (k && light < (table[t * N + k - 1] >> 9)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "local sampling table: a tile's entries must be sorted by light index");
+            if (light > maxLight) maxLight = light;
+        }
+        PT_CHECK_HIP(c, c->dLocalTable.upload(table, (size_t)resX * resY * N, c->stream));
+        PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        c->localResX = resX; c->localResY = resY; c->localJitterX = jitterX; c->localJitterY = jitterY; c->localMaxLight = maxLight;
+    } else { c->localResX = c->localResY = c->localJitterX = c->localJitterY = c->localMaxLight = 0; }
+    c->localRatio = localToGlobalSampleRatio; c->sscThreshold = screenSpaceVsWorldSpaceThreshold; c->feedbackRequired = temporalFeedback != 0;
+    refresh_scene_view(c);
+    return PT_OK;
+}
+int32_t pt_get_light_feedback(pt_context* c, uint32_t sample, float* totalWeight, uint32_t* candidates) {
+    if (!c || !totalWeight || !candidates) return PT_ERROR_INVALID_ARGUMENT;
+    if (sample >= c->fbSamples) return fail(c, PT_ERROR_NOT_READY, "no feedback for that sample: pt_set_local_light_sampling(temporalFeedback = 1), then pt_render");
+    (void)hipSetDevice(c->device);
+    const size_t plane = (size_t)c->width * c->height;
+    PT_CHECK_HIP(c, hipMemcpy(totalWeight, c->dFbWeight.p + plane * sample, 4 * plane, hipMemcpyDeviceToHost));
+    PT_CHECK_HIP(c, hipMemcpy(candidates, c->dFbCand.p + plane * sample, 4 * plane, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
 int32_t pt_set_lights(pt_context* c, const ::PolymorphicLightInfo* lights, const ::PolymorphicLightInfoEx* ex, uint32_t n) {
     if (!c || (!lights && n)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
     c->analyticLights.clear();
@@ -722,7 +758,9 @@ int32_t pt_default_settings(::PtSettings* s) {
 }
 int32_t pt_set_settings(pt_context* c, const ::PtSettings* s) {
     if (!c || !s) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
-    if (s->NEEType > 1) return fail(c, PT_ERROR_UNSUPPORTED, "NEEType 2 (NEE-AT temporal feedback) is out of scope; use 0 (uniform) or 1 (power)");
+    // NEEType 2 (NEE-AT): the global table is built as for type 1 (LightsBaker.hlsl:920-923 treats every type but 0 alike; the feedback-weighted boost of the
+    // global proxies belongs to the baker's feedback passes, which the host does not have yet); the local layer and the feedback come from pt_set_local_light_sampling
+    if (s->NEEType > 2) return fail(c, PT_ERROR_INVALID_ARGUMENT, "NEEType: 0 (uniform), 1 (power) or 2 (NEE-AT)");
     if (s->NEECandidateSamples == 0 || s->NEECandidateSamples > 63) return fail(c, PT_ERROR_INVALID_ARGUMENT, "NEECandidateSamples must be in [1,63]");
     if (s->nestedDielectricsQuality > 2 || (s->diffuseBrdf != 0 && s->diffuseBrdf != 2) || s->bounceCount > 96 || s->useFp16Types > 1) return fail(c, PT_ERROR_INVALID_ARGUMENT, "setting out of range");
     if (c->S.NEEEnabled != s->NEEEnabled || c->S.NEEType != s->NEEType) c->lightsDirty = true;
@@ -795,6 +833,20 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     const uint shadowGroup = (c->S.NEEEnabled && neeSamples > 1u) ? neeSamples : 0u;            // 0: one shadow-queue entry per path vertex, written by k_shade itself
     const uint shadowPerPath = shadowGroup ? shadowGroup : 1u;
     r = ensure_pool(c, total, shadowPerPath); if (r != PT_OK) return r;
+    if (c->localResX) {                     // NEE-AT local layer: every pixel's (jittered) tile must exist, and a table can only name lights that were baked
+        const uint TILE_PX = ptk::RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE;
+        if ((c->width - 1u + c->localJitterX) / TILE_PX >= c->localResX || (c->height - 1u + c->localJitterY) / TILE_PX >= c->localResY) return fail(c, PT_ERROR_INVALID_ARGUMENT, "local sampling table smaller than the frame");
+        if (c->localMaxLight >= c->lights.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "local sampling table names a light index beyond the baked light table");
+    }
+    const bool feedback = c->feedbackRequired && c->S.NEEEnabled && neeSamples != 0u;
+    c->fbSamples = 0;
+    if (feedback) {
+        if (shadowGroup) return fail(c, PT_ERROR_INVALID_ARGUMENT, "NEE-AT temporal feedback needs NEEFullSamples 1 (the reference's default): the feedback draw of one light sample shifts the random numbers of the next");
+        const size_t plane = (size_t)c->width * c->height;
+        PT_CHECK_HIP(c, c->dSq3.resize(c->shadowCapacity)); PT_CHECK_HIP(c, c->dFbWeight.resize(plane * count)); PT_CHECK_HIP(c, c->dFbCand.resize(plane * count));
+        PT_CHECK_HIP(c, hipMemsetAsync(c->dFbWeight.p, 0, 4 * plane * count, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dFbCand.p, 0xFF, 4 * plane * count, c->stream));      // LightFeedbackReservoir::Clear
+        PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    }
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
     if (neeSamples == 0u) k.S.NEEEnabled = 0;            // `applyNEE &= fullSamples > 0` (PathTracerNEE.hlsli:322): the vertices behave as without NEE; the light tables stay as baked
 
@@ -818,7 +870,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.total = t.numPix * count; t.base = t.pixFirst * count; t.st = c->streams[b]; t.wc = c->dCounters.p + b; t.hwc = c->hostCounters + b;
         t.pool = PathPool{c->dS0.p + t.base, c->dS1.p + t.base, c->dS2.p + t.base, c->dS3.p + t.base, c->dS4.p + t.base, c->dHit.p + t.base};
         const size_t sbase = (size_t)t.base * shadowPerPath;
-        t.sq = ShadowQueue{c->dSq0.p + sbase, c->dSq1.p + sbase, c->dSq2.p + sbase, shadowGroup};
+        t.sq = ShadowQueue{c->dSq0.p + sbase, c->dSq1.p + sbase, c->dSq2.p + sbase, shadowGroup, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+        if (feedback) { t.sq.q3 = c->dSq3.p + sbase; t.sq.fbTotalWeight = c->dFbWeight.p; t.sq.fbCandidates = c->dFbCand.p; t.sq.fbWidth = c->width; t.sq.fbPlane = c->width * c->height; t.sq.fbSampleFirst = first; }
         t.queue[0] = c->dQueue[0].p + t.base; t.queue[1] = c->dQueue[1].p + t.base;
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;
@@ -881,6 +934,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     bool overflow = false;
     for (uint b = 0; b < numBatches; b++) overflow = overflow || B[b].hwc->overflow;
     c->accumCount += count;
+    if (feedback) c->fbSamples = count;
     if (stats) {
         // whole-call time: from the first batch's start to the later batch's end (both streams were idle before and are drained now)
         float ms = 0; (void)hipEventElapsedTime(&ms, frame0, frame1); stats->gpuMilliseconds = ms;

@@ -120,12 +120,16 @@ struct NEEBSDFMISInfo {
     uint Pack16bit() const { return ((LightSamplingEnabled ? 1u : 0u) << 15) | ((LightSamplingIsSSC ? 1u : 0u) << 13) | ((CandidateSamples & 0x3F) << 6) | (FullSamples & 0x3F); }
 };
 struct LightSample {
-    float3 Li; float Distance; float3 Direction; uint LightIndex; float SelectionPdf, SolidAnglePdf; bool LightSampleableByBSDF;
+    float3 Li; float Distance; float3 Direction; uint LightIndex; float SelectionPdf, SolidAnglePdf; bool LightSampleableByBSDF, FromLocalDistribution;
     bool Valid() const { return any_gt0(Li); }
 };
 struct SurfaceData { ShadingData shadingData; StandardBSDF bsdf; float interiorIoR; uint neeTriangleLightIndex; uint neeAnalyticLightIndex; };
 // what k_shade hands to the shadow queue (the deferred half of ProcessLightSample)
-struct ShadowRequest { bool valid; float3 origin, dir; float tmax; float3 radiance; };
+// NEE-AT feedback (TemporalFeedbackRequired, NEEFullSamples 1): ProcessLightSample draws one more random number and writes the pixel's feedback reservoir only when the
+// light is VISIBLE (PathTracerNEE.hlsli:266-273), and the same generator then serves Russian roulette (PathTracer.hlsli:757-759). k_shade therefore works out both
+// continuations: the path is stored as "not visible"; fbLight / fbWeight / fbRandom are the reservoir update and rrFix what the visible case changes on the path
+// (bit 0: the roulette outcomes differ, bit 1: terminate-at-next-bounce in the visible case, bits 16-31: the fp16 roulette correction of the visible case).
+struct ShadowRequest { bool valid; float3 origin, dir; float tmax; float3 radiance; uint fbLight; float fbWeight, fbRandom; uint rrFix; };
 // NEEFullSamples != 1 (HandleNEE_MultipleSamples, PathTracerNEE.hlsli:277-301): every path vertex that applies NEE reserves a group of fullSamples
 // consecutive shadow-queue entries (sample s at base + s, samples without a light marked tmax < 0) and k_resolve_nee folds the visible ones in sample order.
 struct ShadowSink { float4* q0; float4* q1; float4* q2; uint* count; unsigned long long* valid; uint pathIndex; };
@@ -431,11 +435,13 @@ template <bool LP16> struct PathKernelContextT {
     static void AccumulatePathRadiance(PathState& path, float3 radiance) { float4 L = path.GetL(); path.SetL(make_float4(L.x + radiance.x, L.y + radiance.y, L.z + radiance.z, L.w + 0.f)); }
 
     // PathTracer.hlsli:407-503
+    // NEEAT == false (NEEType 0 / 1, the kernels every frame without a local table runs): "screen-space coherent" is a compile-time false, the local sampler folds away
+    template <bool NEEAT>
     __attribute__((always_inline)) void HandleMiss(PathState& path, float3 rayDir, float rayT) const {
         UpdatePathTravelled(path, rayT);
         float3 environmentEmission = make_float3(0.f);
         NEEBSDFMISInfo misInfo = NEEBSDFMISInfo::Unpack16bit(path.GetPackedMISInfo());
-        LightSampler lightSampler; lightSampler.T = &sc.lights;
+        LightSampler lightSampler = LightSampler::make(sc.lights, path.id >> 16, path.id & 0xFFFFu, NEEAT && misInfo.LightSamplingIsSSC);
         if (sc.envEnabled) {
             float mipLevel = (path.getCounter(PC_DiffuseBounces) > 1) ? S.envMapDiffuseSampleMIPLevel : 0.f;
             float3 localDir = mul_vec_mat3(rayDir, sc.envToLocal);
@@ -444,7 +450,7 @@ template <bool LP16> struct PathKernelContextT {
             float bsdfScatterPdf = path.GetBsdfScatterPdf();
             if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0) {
                 uint envIdx = lightSampler.LookupEnvLightByDirection(localDir);
-                misWeight = lightSampler.ComputeBSDFMISForEnvironmentQuad(envIdx, bsdfScatterPdf, misInfo.FullSamples);
+                misWeight = lightSampler.ComputeBSDFMISForEnvironmentQuad(envIdx, bsdfScatterPdf, misInfo.CandidateSamples, misInfo.FullSamples);
             }
             environmentEmission = LP::r3(misWeight * Le);
         }
@@ -520,10 +526,13 @@ template <bool LP16> struct PathKernelContextT {
     LightSample GenerateLightSample(const LightSampler& lightSampler, const ShadingData& sd, const StandardBSDF& bsdf, uint candidateSampleCount, UniformSampleSequenceGenerator& sg) const {
         LightSample cand; __builtin_memset(&cand, 0, sizeof(cand));
         float weightSum = 0, candWeight = 0;
+        uint localCount, globalCount;
+        lightSampler.GetCandidateSampleCounts(candidateSampleCount, localCount, globalCount);
         for (uint i = 0; i < candidateSampleCount; i++) {
+            const bool sampleIsLocal = i >= globalCount;
             float selectionPdf = 0;
             float rnd = sampleNext1D(sg);
-            uint lightIndex = lightSampler.SampleGlobal(rnd, selectionPdf);
+            uint lightIndex = sampleIsLocal ? lightSampler.SampleLocal(rnd, selectionPdf) : lightSampler.SampleGlobal(rnd, selectionPdf);
             PolymorphicLightInfoFull li = lightSampler.LoadLight(lightIndex);
             float2 interior = sampleNext2D(sg);
             PolymorphicLightSample ls = PolymorphicLight_CalcSample(li, interior, sd.posW, sc.envToWorld);
@@ -534,7 +543,7 @@ template <bool LP16> struct PathKernelContextT {
             float3 surfToLight = ls.Position - sd.posW;
             c.Distance = length(surfToLight);
             c.Direction = surfToLight / fmaxf_(c.Distance, 1e-7f);
-            c.LightIndex = lightIndex; c.SelectionPdf = selectionPdf; c.LightSampleableByBSDF = ls.LightSampleableByBSDF;
+            c.LightIndex = lightIndex; c.SelectionPdf = selectionPdf; c.LightSampleableByBSDF = ls.LightSampleableByBSDF; c.FromLocalDistribution = sampleIsLocal;
             float wrsWeight = max3(c.Li) * bsdf.evalPdf(sd, c.Direction);
             float r = sampleNext1D(sg);
             weightSum += wrsWeight;
@@ -546,16 +555,16 @@ template <bool LP16> struct PathKernelContextT {
     }
     // HandleNEE (PathTracerNEE.hlsli:303-346) / HandleNEE_MultipleSamples (:277-301) with ProcessLightSample (:185-275) split at the visibility ray.
     // MULTI == false is NEEFullSamples == 1: the one request goes back to k_shade through `req`. MULTI: the requests are written to the sink's group.
-    template <bool MULTI>
+    template <bool MULTI, bool NEEAT>
     uint HandleNEE(const PathState& pre, const ShadingData& sd, const StandardBSDF& bsdf, UniformSampleSequenceGenerator& sg, ShadowRequest& req, const ShadowSink* sink) const {
-        req.valid = false;
-        LightSampler lightSampler; lightSampler.T = &sc.lights;
+        req.valid = false; req.fbLight = RTXPT_INVALID_LIGHT_INDEX; req.rrFix = 0u;
+        const LightSampler lightSampler = LightSampler::make(sc.lights, pre.id >> 16, pre.id & 0xFFFFu, NEEAT && LightSampler::IsScreenSpaceCoherentHeuristic(sc.lights, pre.rayCone.getWidth(), pre.sceneLength));
         const uint fullSamples = MULTI ? (S.NEEFullSamples < 63u ? S.NEEFullSamples : 63u) : 1u;      // min(RTXPT_LIGHTING_MAX_SAMPLE_COUNT, NEEFullSamples)
         bool hasNonDeltaLobes = (bsdf.getLobes() & Lobe_NonDelta) != 0;
         bool applyNEE = hasNonDeltaLobes && !lightSampler.IsEmpty() && fullSamples > 0;
         if (!applyNEE) return NEEBSDFMISInfo::empty().Pack16bit();
         uint candidateSampleCount = S.NEECandidateSamples;
-        NEEBSDFMISInfo info; info.LightSamplingEnabled = true; info.LightSamplingIsSSC = false; info.CandidateSamples = candidateSampleCount; info.FullSamples = fullSamples;
+        NEEBSDFMISInfo info; info.LightSamplingEnabled = true; info.LightSamplingIsSSC = lightSampler.IsScreenSpaceCoherent; info.CandidateSamples = candidateSampleCount; info.FullSamples = fullSamples;
         uint base = 0, numValid = 0;
         if (MULTI) base = __hip_atomic_fetch_add(sink->count, fullSamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (uint s = 0; s < fullSamples; s++) {
@@ -565,8 +574,10 @@ template <bool LP16> struct PathKernelContextT {
                 float faceSide = dot(sd.N, ls.Direction) >= 0 ? 1.f : -1.f;
                 float3 o = ComputeRayOrigin(sd.posW, sd.faceNCorrected * faceSide);
                 float fadeOut = (sd.shadowNoLFadeout > 0) ? ComputeLowGrazingAngleFalloff(ls.Direction, sd.vertexN, sd.shadowNoLFadeout, 2.0f * sd.shadowNoLFadeout) : 1.0f;
-                float globalCount = (float)candidateSampleCount;
-                float thisPdf = ls.SelectionPdf, otherPdf = 0.f, thisCount = globalCount;
+                uint localCount, globalCount;
+                lightSampler.GetCandidateSampleCounts(candidateSampleCount, localCount, globalCount);
+                float thisPdf, otherPdf, thisCount, otherCount;
+                lightSampler.ComputeLightSelectionPdfs(ls.SelectionPdf, ls.LightIndex, ls.FromLocalDistribution, localCount, globalCount, thisPdf, otherPdf, thisCount, otherCount);
                 float wrsMIS = EvalMIS_Balance(1, thisPdf, 1, otherPdf);
                 wrsMIS = wrsMIS / thisCount;
                 float scatterPdfForDir = bsdf.evalPdf(sd, ls.Direction);
@@ -582,6 +593,11 @@ template <bool LP16> struct PathKernelContextT {
                     radiance = radiance * FireflyFilterShort(radianceAvg, S.fireflyFilterThreshold, k);
                 }
                 radiance = radiance * pre.GetThp();
+                if (NEEAT && !MULTI && lightSampler.IsTemporalFeedbackRequired()) {      // the reservoir update of the visible case (:246-273; radianceAvg is the value before the firefly filter)
+                    req.fbLight = ls.LightIndex | (lightSampler.IsScreenSpaceCoherent ? LFR_SCREEN_SPACE_COHERENT_FLAG : 0u);
+                    req.fbWeight = lightSampler.FeedbackWeightFromNEE(ls.LightIndex, radianceAvg * Average(pre.GetThp()));
+                    UniformSampleSequenceGenerator after = sg; req.fbRandom = sampleNext1D(after);
+                }
                 if (MULTI) {
                     sink->q0[base + s] = make_float4(o.x, o.y, o.z, ls.Distance * 0.9985f);
                     sink->q1[base + s] = make_float4(ls.Direction.x, ls.Direction.y, ls.Direction.z, asfloat(sink->pathIndex));
@@ -607,7 +623,7 @@ template <bool LP16> struct PathKernelContextT {
         return false;
     }
     // PathTracer.hlsli:505-762 (reference mode), shadow test deferred through `req`
-    template <bool MULTI>
+    template <bool MULTI, bool NEEAT>
     __attribute__((always_inline)) void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req, const ShadowSink* sink) const {
         req.valid = false;
         const float3 rayOrigin = path.origin, rayDir = path.dir;
@@ -625,15 +641,15 @@ template <bool LP16> struct PathKernelContextT {
             float misWeight = 1.0f;
             float bsdfScatterPdf = path.GetBsdfScatterPdf();
             if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0) {
-                LightSampler lightSampler; lightSampler.T = &sc.lights;
-                misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(sfd.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.FullSamples);
+                LightSampler lightSampler = LightSampler::make(sc.lights, path.id >> 16, path.id & 0xFFFFu, NEEAT && misInfo.LightSamplingIsSSC);
+                misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(sfd.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.CandidateSamples, misInfo.FullSamples);
             }
             surfaceEmission = LP::r3(sd.emission * misWeight);
         }
         if (sfd.neeAnalyticLightIndex != RTXPT_INVALID_LIGHT_INDEX) {                  // PathTracer.hlsli:636-648: the mesh stands in for an analytic (sphere) light
-            LightSampler lightSampler; lightSampler.T = &sc.lights;
+            LightSampler lightSampler = LightSampler::make(sc.lights, path.id >> 16, path.id & 0xFFFFu, NEEAT && misInfo.LightSamplingIsSSC);
             const float bsdfPdf = misInfo.LightSamplingEnabled ? LP::r(path.GetBsdfScatterPdf()) : 0.0f; float3 add;
-            if (lightSampler.ComputeAnalyticLightProxyContribution(sfd.neeAnalyticLightIndex, bsdfPdf, rayOrigin, rayDir, misInfo.FullSamples, add)) {
+            if (lightSampler.ComputeAnalyticLightProxyContribution(sfd.neeAnalyticLightIndex, bsdfPdf, rayOrigin, rayDir, misInfo.CandidateSamples, misInfo.FullSamples, add)) {
                 add = LP::r3(add); surfaceEmission = make_float3(LP::add(surfaceEmission.x, add.x), LP::add(surfaceEmission.y, add.y), LP::add(surfaceEmission.z, add.z));
             }
         }
@@ -649,11 +665,17 @@ template <bool LP16> struct PathKernelContextT {
         UniformSampleSequenceGenerator uniformSG = UniformSampleSequenceGenerator::make(vb, SGES_Base);
         const PathState preScatterPath = path;
         bool scatterValid = GenerateScatterRay(sd, bsdf, path, vb);
-        uint misPacked = S.NEEEnabled ? HandleNEE<MULTI>(preScatterPath, sd, bsdf, uniformSG, req, sink) : NEEBSDFMISInfo::empty().Pack16bit();
+        uint misPacked = S.NEEEnabled ? HandleNEE<MULTI, NEEAT>(preScatterPath, sd, bsdf, uniformSG, req, sink) : NEEBSDFMISInfo::empty().Pack16bit();
         path.SetPackedMISInfo_ThpRuRuCorrection(misPacked, path.GetThpRuRuCorrection());
         if (!scatterValid) path.terminate();
         bool shouldTerminate = HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces));
-        shouldTerminate |= HandleRussianRoulette(path, uniformSG);
+        if (NEEAT && req.fbLight != RTXPT_INVALID_LIGHT_INDEX) {       // feedback pending on the visibility test: the visible case has drawn one more number before the roulette
+            UniformSampleSequenceGenerator sgVisible = uniformSG; (void)sampleNext1D(sgVisible);
+            PathState visiblePath = path;
+            const bool terminateVisible = shouldTerminate | HandleRussianRoulette(visiblePath, sgVisible);
+            shouldTerminate |= HandleRussianRoulette(path, uniformSG);
+            req.rrFix = (terminateVisible != shouldTerminate ? 1u : 0u) | (terminateVisible ? 2u : 0u) | ((visiblePath.pack1 & 0xFFFFu) << 16);
+        } else shouldTerminate |= HandleRussianRoulette(path, uniformSG);
         if (shouldTerminate) path.setFlag(PF_terminateAtNextBounce);
     }
     // the deferred half: NEEResult::AccumulateRadiance (fp16, PathTracerTypes.hlsli:170-207) then AccumulatePathRadiance (PathTracer.hlsli:722-746)

@@ -17,7 +17,9 @@
 namespace ptk {
 
 struct PathPool { uint4* s0; uint4* s1; uint4* s2; uint4* s3; uint4* s4; uint4* hit; };
-struct ShadowQueue { float4* q0; float4* q1; float4* q2; uint group; };        // group: 0 = one entry per path vertex (NEEFullSamples 1), else entries come in groups of `group` (pt_path.h ShadowSink)
+struct ShadowQueue { float4* q0; float4* q1; float4* q2; uint group;           // group: 0 = one entry per path vertex (NEEFullSamples 1), else entries come in groups of `group` (pt_path.h ShadowSink)
+    // NEE-AT feedback (null: off): q3 = {weight, random, light | SSC flag, roulette fix-up} per entry (pt_path.h ShadowRequest); the sub-frame's feedback reservoirs, one slot per pixel
+    float4* q3; float* fbTotalWeight; uint* fbCandidates; uint fbWidth, fbPlane, fbSampleFirst; };      // slot = (sample - fbSampleFirst) * fbPlane + y * fbWidth + x
 struct WaveCounters {           // device-resident counters / stats (one 256 B block)
     uint extendCount[2]; uint shadowCount; uint overflow;
     unsigned long long hits, nodeVisitsExt, triTestsExt, nodeVisitsSh, triTestsSh, leafVisitsExt, itersExt, leafVisitsSh, itersSh, phaseCycExt[4], leafBlocksExt, eventsExt[8], itersMaxExt, rayIterHistExt[16]; uint longRayCount, _padLong; float longRays[32][8];

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(1024) k_classify(PathPool pool, const uint* __
 }
 
 // PKC: PathKernelContextT<false> (lp types in fp32) or PathKernelContextT<true> (the reference's default build, lp types in binary16)
-template <bool MULTI, class PKC>
+template <bool MULTI, class PKC, bool NEEAT>
 __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
                                                uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, const uint* __restrict__ classCount) {
     const uint count = *countInPtr;
@@ -226,11 +226,11 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
 #elif PT_SHADE_PROBE == 2        // 2 = the surface gather (record, instance, material, textures) and nothing after it
         if (h.prim != 0xFFFFFFFFu) { isHit = true; SurfaceData sfd = k.loadSurface(h.prim, h.u, h.v, path.dir, path.rayCone); path.origin = sfd.shadingData.posW + sfd.shadingData.N * sfd.bsdf.data.roughness + sfd.bsdf.data.diffuse + sfd.shadingData.T; } path.terminate();
 #else
-        if (h.prim == 0xFFFFFFFFu) k.HandleMiss(path, path.dir, kMaxRayTravel);
+        if (h.prim == 0xFFFFFFFFu) k.template HandleMiss<NEEAT>(path, path.dir, kMaxRayTravel);
         else {
             isHit = true;
-            if (MULTI) { ShadowSink sink{sq.q0, sq.q1, sq.q2, &wc->shadowCount, &wc->shadowValid, p}; k.template HandleHit<true>(path, h, req, &sink); }
-            else k.template HandleHit<false>(path, h, req, nullptr);
+            if (MULTI) { ShadowSink sink{sq.q0, sq.q1, sq.q2, &wc->shadowCount, &wc->shadowValid, p}; k.template HandleHit<true, NEEAT>(path, h, req, &sink); }
+            else k.template HandleHit<false, NEEAT>(path, h, req, nullptr);
         }
 #endif
         store_path(pool, p, path);
@@ -257,6 +257,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
         sq.q0[sslot] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
         sq.q1[sslot] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
         sq.q2[sslot] = make_float4(req.radiance.x, req.radiance.y, req.radiance.z, 0.f);
+        if (NEEAT && sq.q3) sq.q3[sslot] = make_float4(req.fbWeight, req.fbRandom, asfloat(req.fbLight), asfloat(req.rrFix));
     }
     if (classCount) { if (blockIdx.x == 0u && threadIdx.x == 0u) atomicAdd(&wc->hits, (unsigned long long)classCount[0] + classCount[1]); }
     else wave_add64(isHit ? 1ull : 0ull, &wc->hits);
@@ -268,6 +269,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
         sq.q0[sslot] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
         sq.q1[sslot] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
         sq.q2[sslot] = make_float4(req.radiance.x, req.radiance.y, req.radiance.z, 0.f);
+        if (NEEAT && sq.q3) sq.q3[sslot] = make_float4(req.fbWeight, req.fbRandom, asfloat(req.fbLight), asfloat(req.rrFix));
     }
     wave_add64(isHit ? 1ull : 0ull, &wc->hits);
 #endif
@@ -283,6 +285,22 @@ __device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, ui
     PathKernelContext::ResolveShadow(pack45, make_float3(r.x, r.y, r.z));
     c.z = pack45[0]; c.w = pack45[1];
     pool.s2[p] = c;
+    if (sq.q3) {                                              // NEE-AT: the visible light feeds the pixel's reservoir (LightSampler.hlsli:184-200), and the path continues as k_shade worked out for this case
+        const float4 f = sq.q3[i];
+        const uint light = asuint(f.z), fix = asuint(f.w);
+        if (light != RTXPT_INVALID_LIGHT_INDEX) {
+            uint4 e = pool.s4[p];
+            const uint id = pool.s0[p].w, slot = (e.w - sq.fbSampleFirst) * sq.fbPlane + (id & 0xFFFFu) * sq.fbWidth + (id >> 16);
+            float total = sq.fbTotalWeight[slot]; uint cand = sq.fbCandidates[slot];
+            LightFeedbackReservoir_Add(total, cand, f.y, light & ~LFR_SCREEN_SPACE_COHERENT_FLAG, f.x, (light & LFR_SCREEN_SPACE_COHERENT_FLAG) != 0u);
+            sq.fbTotalWeight[slot] = total; sq.fbCandidates[slot] = cand;
+            if (fix & 1u) {
+                const uint bit = (uint)PF_terminateAtNextBounce << kVertexIndexBitCount;
+                if (fix & 2u) e.z |= bit; else { e.z &= ~bit; e.y = (e.y & 0xFFFF0000u) | (fix >> 16); }
+                pool.s4[p] = e;
+            }
+        }
+    }
 }
 
 template <bool COUNT, bool GROUPED>
@@ -696,15 +714,18 @@ void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn
         hipLaunchKernelGGL(k_classify, dim3((countIn + 1023) / 1024), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
         queueIn = classScratch;
     } else classCount = nullptr;
+    // NEE-AT (a local sampling table and / or temporal feedback, pt_set_local_light_sampling) runs its own instantiations: the frames without it keep their kernels unchanged
+    const bool neeat = k.sc.lights.LocalSamplingBuffer != nullptr || k.sc.lights.TemporalFeedbackRequired != 0u;
+#define PT_LAUNCH_SHADE(MULTI, PKC, CTX) do { if (neeat) hipLaunchKernelGGL((k_shade<MULTI, PKC, true>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount); \
+                                              else hipLaunchKernelGGL((k_shade<MULTI, PKC, false>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount); } while (0)
     if (k.S.useFp16Types) {          // the reference's default build of its lp types (binary16): same context data, the other instantiation of the shading code
         static_assert(sizeof(PathKernelContextT<true>) == sizeof(PathKernelContext), "the two lp builds share one context layout");
         PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16));
-        if (sq.group) hipLaunchKernelGGL((k_shade<true, PathKernelContextT<true>>), g, b, 0, st, k16, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
-        else hipLaunchKernelGGL((k_shade<false, PathKernelContextT<true>>), g, b, 0, st, k16, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
+        if (sq.group) PT_LAUNCH_SHADE(true, PathKernelContextT<true>, k16); else PT_LAUNCH_SHADE(false, PathKernelContextT<true>, k16);
     } else {
-        if (sq.group) hipLaunchKernelGGL((k_shade<true, PathKernelContext>), g, b, 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
-        else hipLaunchKernelGGL((k_shade<false, PathKernelContext>), g, b, 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
+        if (sq.group) PT_LAUNCH_SHADE(true, PathKernelContext, k); else PT_LAUNCH_SHADE(false, PathKernelContext, k);
     }
+#undef PT_LAUNCH_SHADE
 }
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
     const uint rpc = rays_per_chunk(count);

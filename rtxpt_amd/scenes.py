@@ -754,3 +754,22 @@ def procedural_sky_textures(seed=SEED_BASE + 21, clouds=(64, 64, 16)):
         vol[..., c] = acc * np.sin(np.pi * np.clip(cz + 0.5 / cd, 0, 1)) if c == 0 else acc              # density falls off towards the layer's bottom and top
     vol[..., 3] = 1.0
     return [transmittance, scattering, irradiance, vol.astype(np.float32)]
+
+
+def synthetic_local_light_tables(num_lights, width, height, seed=1, hot=6, jitter=(0, 0)):
+    """A stand-in for what LightsBaker's feedback passes write (NEE-AT local samplers, LightsBaker.hlsl:1129-1855 — not built here): for every screen tile of
+    8 x 8 pixels, 128 proxies drawn from a few tile-specific "hot" lights plus a uniform tail, sorted by light index and packed as light << 9 | (count - 1)
+    (LightingTypes.hlsli:172-175). Returns uint32 [tilesY, tilesX, 128]; the resolution covers the frame for any tile jitter below 8."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    tx, ty = (width + 7 + 7) // 8, (height + 7 + 7) // 8
+    out = np.zeros((ty, tx, 128), np.uint32)
+    for y in range(ty):
+        for x in range(tx):
+            hots = rng.integers(0, num_lights, size=hot)
+            picks = np.where(rng.random(128) < 0.75, hots[rng.integers(0, hot, size=128)], rng.integers(0, num_lights, size=128))
+            picks = np.sort(picks.astype(np.uint32))
+            lights, counts = np.unique(picks, return_counts=True)
+            cnt = dict(zip(lights.tolist(), counts.tolist()))
+            out[y, x] = np.array([(int(l) << 9) | (cnt[int(l)] - 1) for l in picks], np.uint32)
+    return out

@@ -237,3 +237,30 @@ def cases_lp16():
     out["bistro_like_firefly"] = (bl, scenes.default_settings(fireflyFilterThreshold=0.7, useFp16Types=1), 96, 54, 1, 2)
     out["bistro_like_material_zoo_firefly"] = (with_material_zoo(bl), scenes.default_settings(fireflyFilterThreshold=1.5, envMapDiffuseSampleMIPLevel=2.0, useFp16Types=1), 96, 54, 4, 2)
     return out
+
+
+def neeat_cases():
+    """NEE-AT, the path tracer's side (NEEType 2; SURVEY.md §8 row N4, first part): frames traced with screen-tile local samplers and / or temporal feedback.
+    name -> (make, settings, w, h, first, n, dict(table_seed | None, jitter, ratio, ssc_threshold, feedback)). The tables are synthetic stand-ins for the
+    baker's output (scenes.synthetic_local_light_tables); what is pinned is everything the path tracer does with them."""
+    c2 = lambda: scenes.cornell_box("C2")
+    bl = lambda: scenes.bistro_like(scale=0.02, tex_size=128)
+    d = scenes.default_settings
+    return {
+        # the reference's defaults: ratio 0.65 (SampleUI.h:159), threshold 0.3 (LightsBaker.h:240), NEEFullSamples 1, feedback on
+        "bistro_like_neeat": (bl, d(NEEType=2), 96, 54, 0, 2, dict(table_seed=5, jitter=(3, 5), ratio=0.65, ssc_threshold=0.3, feedback=True)),
+        "bistro_like_neeat_lp16": (bl, d(NEEType=2, useFp16Types=1), 96, 54, 1, 2, dict(table_seed=6, jitter=(7, 0), ratio=0.65, ssc_threshold=0.3, feedback=True)),
+        # local layer without feedback and with NEEFullSamples 3 (grouped shadow queue), nearly all candidates local
+        "c2_neeat_table_only_nee3": (c2, d(NEEType=2, NEEFullSamples=3), 64, 36, 0, 2, dict(table_seed=7, jitter=(0, 0), ratio=0.95, ssc_threshold=0.3, feedback=False)),
+        # feedback without a local layer (the first frames of a run, before the baker has produced tables), analytic lights, firefly filter
+        "c2_sphere_lights_neeat_feedback_only": (with_sphere_lights(c2), d(NEEType=2, fireflyFilterThreshold=2.5), 64, 36, 2, 2, dict(table_seed=None, jitter=(0, 0), ratio=0.65, ssc_threshold=0.3, feedback=True)),
+        # every vertex screen-space coherent (threshold above any cone-width ratio), no Russian roulette, one candidate sample (all global: (1 - 1) * ratio + 0.75 -> 0)
+        "bistro_like_c5_neeat_all_ssc": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), d(NEEType=2, enableRussianRoulette=0, NEECandidateSamples=1), 96, 54, 0, 2, dict(table_seed=8, jitter=(1, 1), ratio=0.65, ssc_threshold=1e9, feedback=True)),
+        # no vertex coherent (threshold 0): the table is bound but never sampled; many candidates
+        "bistro_like_neeat_none_ssc": (bl, d(NEEType=2, NEECandidateSamples=9), 96, 54, 3, 1, dict(table_seed=9, jitter=(2, 6), ratio=0.5, ssc_threshold=0.0, feedback=True)),
+    }
+
+
+def neeat_table(opts, num_lights, w, h):
+    if opts["table_seed"] is None: return None
+    return scenes.synthetic_local_light_tables(num_lights, w, h, seed=opts["table_seed"], jitter=opts["jitter"])
