@@ -166,7 +166,7 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1), lp16=False):
         return _pin_pt[key]
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(os.path.dirname(_PIN), "librefpin_pt_%d%d%d%d%d%d%s.so" % (tuple(variant) + ("_lp16" if lp16 else "",)))
-    srcs = [os.path.join(here, "refpin", f) for f in ("hlsl_tu.py", "hlsl_shim.h", "hlsl_pt_stubs.h", "hlsl_pt_bridge_stubs.h", "hlsl_pt_wrappers.inc")] + [os.path.join(here, "ptref", f) for f in os.listdir(os.path.join(here, "ptref"))]
+    srcs = [os.path.join(here, "refpin", f) for f in ("hlsl_tu.py", "hlsl_shim.h", "hlsl_pt_stubs.h", "hlsl_pt_bridge_stubs.h", "hlsl_pt_wrappers.inc", "hlsl_lbfb_stubs.h", "hlsl_envbake_stubs.h", "hlsl_emisb_stubs.h")] + [os.path.join(here, "ptref", f) for f in os.listdir(os.path.join(here, "ptref"))]
     stale = not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs)
     if stale:
         if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
@@ -456,6 +456,22 @@ class Oracle:
         w = np.zeros((self.h_, self.w), np.float32); c = np.zeros((self.h_, self.w), np.uint32)
         if not self.L.ptref_get_light_feedback(self.h, int(sample), _p(w), _p(c)): raise RuntimeError("no feedback for that sample")
         return w, c
+
+    def set_neeat(self, enable=True, global_feedback_weight=0.75, ratio=0.65, ssc_threshold=0.3, prefilter=True):
+        """NEE-AT with the baker in the loop: every sample of render() is a frame (feedback passes, then the path tracer)"""
+        import ctypes
+        f = self.L.ptref_set_neeat; f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int]; f.restype = None
+        f(self.h, 1 if enable else 0, float(global_feedback_weight), float(ratio), float(ssc_threshold), 1 if prefilter else 0)
+
+    def neeat_reset(self): self.L.ptref_neeat_reset(self.h)
+
+    def neeat_tables(self):
+        """(tile table uint32 [tilesY, tilesX, 128], jitter (x, y), global proxy counters) of the last frame"""
+        txy = np.zeros(2, np.uint32); jxy = np.zeros(2, np.uint32)
+        if not self.L.ptref_neeat_get_tables(self.h, _p(txy), _p(jxy), None, None): raise RuntimeError("no NEE-AT frame yet")
+        t = np.zeros((int(txy[1]), int(txy[0]), 128), np.uint32); pc = np.zeros(len(self.lights()["lights"]), np.uint32)
+        self.L.ptref_neeat_get_tables(self.h, None, None, _p(t), _p(pc))
+        return t, (int(jxy[0]), int(jxy[1])), pc
 
     def sky_eval(self, mode, rows):
         """mode 0: ProceduralSkyLowRes (x, y, face, direction) -> (n, 4); 1: atmosphere + sun (.., direction) -> (n, 3); 2: GetSkyRadianceToPoint (.., point) -> (n, 6)"""

@@ -1,0 +1,226 @@
+// ORACLE (test infrastructure only) — NEE-AT, the light baker's feedback passes: last frame's per-pixel feedback reservoirs -> this frame's
+// screen-tile local samplers and the usage counts that re-weight the global sampler. CPU restatement of LightsBaker.hlsl:1062-1855, :753-830, :880-948, :118-162,
+// LightsBaker.cpp:943-962, 985-1075, 1335-1420, MicroRng.hlsli and LightingTypes.hlsli:184-320; pinned against that text by tests/test_neeat_baker.py
+// (oracle/refpin/hlsl_lbfb_stubs.h runs the reference's passes thread by thread). See rtxpt_amd/csrc/pt_neeat.h for the order of a frame and the three stated differences
+// (history read at the same pixel, PreFilter from a snapshot, identity light remap).
+#pragma once
+#include "lights.h"
+
+namespace ptref {
+
+// Shaders/Libraries/MicroRng.hlsli:12-62
+struct MicroRng {
+    uint N;
+    static MicroRng make(uint x, uint y, uint seedValueA, uint seedValueB) {
+        MicroRng r; r.N = ((x << 16) | y) ^ 0x9e3779b9u;
+        r.N = r.N ^ (seedValueA + (r.N << 6) + (r.N >> 2));
+        r.N = r.N ^ (seedValueB + (r.N << 6) + (r.N >> 2));
+        return r;
+    }
+    uint Next() { N ^= N >> 16; N *= 0x21f0aaadu; N ^= N >> 15; N *= 0xf35a2d97u; N ^= N >> 15; return N; }
+    float NextFloat() { return (float)(Next() >> 8) / 16777216.0f; }
+};
+
+// the bindings of the passes (LightsBaker.cpp FillBindings) and the per-frame constants (:1004-1075)
+struct NeeAtFrame {
+    uint W, H;                          // FeedbackResolution (= the frame)
+    uint BW, BH;                        // BlendedFeedbackResolution = div_ceil(W, 2) x div_ceil(H, 2)   (RTXPT_NEEAT_EARLY_FEEDBACK_TILE_SIZE 2, LightsBaker.cpp:324)
+    uint tilesX, tilesY;                // LocalSamplingResolution = div_ceil(W, 8) + 1 x div_ceil(H, 8) + 1 (LightsBaker.cpp:338-341)
+    uint jitterX, jitterY, jitterPrevX, jitterPrevY;
+    uint updateCounter; float dropoff;  // BakerConstants.UpdateCounter, ReservoirHistoryDropoff (0.005)
+    uint totalLightCount, historicTotalLightCount, samplingProxyCount;
+    uint lastFrameFeedbackAvailable, lastFrameLocalSamplesAvailable;
+    float* fbW; uint* fbC;              // u_feedbackTotalWeight / u_feedbackCandidates (W x H)
+    float* scW; uint* scC;              // ...Scratch (W x H)
+    float* blW; uint* blC;              // ...Blended (BW x BH)
+    uint* local;                        // u_localSamplingBuffer (tilesX x tilesY x 128)
+    const uint* proxies;                // u_lightSamplingProxies (the global sampler, "only for filling in the gaps")
+    uint* perLightCounters;             // u_perLightProxyCounters: totalLightCount + 1 words, the last one counts the pixels without a valid candidate
+};
+static const uint NEEAT_EARLY_FEEDBACK_TILE_SIZE = 2, NEEAT_WINDOW_SIZE = 8, NEEAT_TOP_UP_SAMPLES = RTXPT_LIGHTING_LOCAL_PROXY_COUNT - NEEAT_WINDOW_SIZE * NEEAT_WINDOW_SIZE;
+
+// LightFeedbackReservoir on a (weight, candidate) slot pair (LightingTypes.hlsli:184-320)
+static inline void lfr_clear(float& w, uint& c) { w = 0.0f; c = RTXPT_INVALID_LIGHT_INDEX; }                       // Clear: SetTotalWeight(0); SetCandidate(invalid, false)
+static inline void lfr_clone_from(float& w, uint& c, float otherW, uint otherC, float scale) {                        // :199-209
+    if (otherW > 0) { w = fminf_(LFR_MAX_WEIGHT, otherW * scale); c = otherC; } else lfr_clear(w, c);
+}
+static inline void lfr_merge(float& w, uint& c, float randomValue, float otherW, uint otherC, float otherScale) {     // :299-312
+    float otherTotalWeight = fminf_(LFR_MAX_WEIGHT, otherW * otherScale);
+    if (otherTotalWeight > 0) {
+        uint lightIndex = otherC;
+        if (lightIndex != RTXPT_INVALID_LIGHT_INDEX) {
+            bool ssc = (lightIndex & LFR_SCREEN_SPACE_COHERENT_FLAG) != 0;
+            lightIndex &= ~LFR_SCREEN_SPACE_COHERENT_FLAG;
+            LightFeedbackReservoir_Add(w, c, randomValue, lightIndex, otherTotalWeight, ssc);
+        }
+    }
+}
+static inline uint neeat_remap_past_to_current(const NeeAtFrame& F, uint historicLightIndex) {                        // LightsBaker.hlsl:1062-1090 with an identity table
+    uint lightIndex = RTXPT_INVALID_LIGHT_INDEX;
+    if (historicLightIndex != RTXPT_INVALID_LIGHT_INDEX) {
+        lightIndex = (historicLightIndex < F.historicTotalLightCount) ? historicLightIndex : RTXPT_INVALID_LIGHT_INDEX;
+        if (lightIndex != RTXPT_INVALID_LIGHT_INDEX && lightIndex >= F.totalLightCount) lightIndex = RTXPT_INVALID_LIGHT_INDEX;
+    }
+    return lightIndex;
+}
+static inline uint neeat_sample_light_global(const NeeAtFrame& F, MicroRng& rng) {                                    // :1314-1321
+    float rnd = rng.NextFloat();
+    uint total = F.samplingProxyCount;
+    uint idx = (uint)(rnd * (float)total);
+    if (idx > total - 1u) idx = total - 1u;
+    return F.proxies[idx];
+}
+static inline int neeat_mirror(int c, int maxRes) {                                                                   // MirrorCoord, :1323-1328 (one axis)
+    int r = c >= 0 ? c : -c;
+    r = r < maxRes ? r : 2 * maxRes - 2 - r;
+    return r < 0 ? 0 : (r > maxRes - 1 ? maxRes - 1 : r);
+}
+static inline uint neeat_lsb_address(const NeeAtFrame& F, uint tileX, uint tileY, uint index) { return LLSB_ComputeBaseAddress(tileX, tileY, F.tilesX) + index; }
+
+// ProcessFeedbackHistoryPreFilter (:1129-1180) for one pixel; srcW / srcC: the feedback as it was before the pass
+static inline void neeat_prefilter_pixel(const NeeAtFrame& F, const float* srcW, const uint* srcC, int x, int y) {
+    const float kCenterMultiplier = 48, kLikenessMultiplier = 128;
+    auto load = [&](int px, int py, uint& idx, float& wgt) {                                                         // LocalReservoir::LoadWithBoundsCheck
+        px = px < 0 ? 0 : (px > (int)F.W - 1 ? (int)F.W - 1 : px); py = py < 0 ? 0 : (py > (int)F.H - 1 ? (int)F.H - 1 : py);
+        idx = srcC[(uint)py * F.W + (uint)px]; wgt = srcW[(uint)py * F.W + (uint)px];
+        if (idx == RTXPT_INVALID_LIGHT_INDEX) wgt = 0;
+    };
+    auto isSSC = [](uint idx) { return idx != RTXPT_INVALID_LIGHT_INDEX && (idx & LFR_SCREEN_SPACE_COHERENT_FLAG) != 0; };
+    uint cIdx; float cW; load(x, y, cIdx, cW);
+    const bool centerIsSSC = isSSC(cIdx), centerIsNotEmpty = cIdx != RTXPT_INVALID_LIGHT_INDEX;
+    uint kIdx[9]; float kW[9], cdf[9]; uint n = 0; float totalWeightSum = 0;
+    for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+        load(x + dx, y + dy, kIdx[n], kW[n]);
+        float weightMul = (dx == 0 && dy == 0) ? kCenterMultiplier : 1.0f;
+        weightMul *= (centerIsSSC == isSSC(kIdx[n]) && centerIsNotEmpty) ? kLikenessMultiplier : 1.0f;
+        totalWeightSum += kW[n] * weightMul;
+        cdf[n] = totalWeightSum; n++;
+    }
+    MicroRng rng = MicroRng::make((uint)x, (uint)y, F.updateCounter, 7);
+    float rnd = rng.NextFloat();
+    int pick = 8;
+    for (int i = 0; i < 8; i++) if (rnd < (cdf[i] / totalWeightSum)) { pick = i; break; }
+    F.fbC[(uint)y * F.W + (uint)x] = kIdx[pick]; F.fbW[(uint)y * F.W + (uint)x] = fminf_(LFR_MAX_WEIGHT, kW[pick]);       // LocalReservoir::Store
+}
+// ProcessFeedbackHistoryP0 (:1185-1311) for one pixel: returns the slot of u_perLightProxyCounters this pixel counts in (the caller adds 1 atomically)
+static inline uint neeat_p0_pixel(const NeeAtFrame& F, uint x, uint y) {
+    uint lightIndexAll = RTXPT_INVALID_LIGHT_INDEX;
+    float& w = F.fbW[y * F.W + x]; uint& c = F.fbC[y * F.W + x];
+    if (w != 0) {                                                     // !IsEmpty()
+        uint candidateIndex = c; bool ssc = false;                    // GetCandidate
+        if (candidateIndex != RTXPT_INVALID_LIGHT_INDEX) { ssc = (candidateIndex & LFR_SCREEN_SPACE_COHERENT_FLAG) != 0; candidateIndex &= ~LFR_SCREEN_SPACE_COHERENT_FLAG; }
+        candidateIndex = neeat_remap_past_to_current(F, candidateIndex);
+        lightIndexAll = candidateIndex;
+        if (!ssc) candidateIndex = RTXPT_INVALID_LIGHT_INDEX;         // world-space coherent candidates are stripped from the reservoir
+        c = candidateIndex | (ssc ? LFR_SCREEN_SPACE_COHERENT_FLAG : 0u);
+        if (candidateIndex == RTXPT_INVALID_LIGHT_INDEX) lfr_clear(w, c);
+    }
+    return lightIndexAll < F.totalLightCount ? lightIndexAll : F.totalLightCount;
+}
+// ProcessFeedbackHistoryP1a (:1379-1452) for one low-resolution pixel
+static inline void neeat_p1a_pixel(const NeeAtFrame& F, uint lx, uint ly) {
+    MicroRng rng = MicroRng::make(lx, ly, F.updateCounter, 3);
+    float& w = F.blW[ly * F.BW + lx]; uint& c = F.blC[ly * F.BW + lx];
+    lfr_clear(w, c);
+    if (F.lastFrameFeedbackAvailable) {
+        const int expandMargin = 1, T = (int)NEEAT_EARLY_FEEDBACK_TILE_SIZE;
+        for (int x = -expandMargin; x < T + expandMargin; x++) for (int y = -expandMargin; y < T + expandMargin; y++) {
+            int px = (int)lx * T + x, py = (int)ly * T + y;
+            px = px < 0 ? 0 : (px > (int)F.W - 1 ? (int)F.W - 1 : px); py = py < 0 ? 0 : (py > (int)F.H - 1 ? (int)F.H - 1 : py);
+            float baseWeight = 1.0f;
+            if (x < 0 || y < 0 || x >= T || y >= T) baseWeight = F.dropoff;
+            const float sw = F.fbW[(uint)py * F.W + (uint)px]; const uint sc = F.fbC[(uint)py * F.W + (uint)px];      // Reproject: the same pixel
+            if (sw != 0) { float rnd = rng.NextFloat(); lfr_merge(w, c, rnd, sw, sc, baseWeight); }
+        }
+    }
+    if (c == RTXPT_INVALID_LIGHT_INDEX) c = neeat_sample_light_global(F, rng);      // "always has valid light indices even when it's empty"
+}
+// ProcessFeedbackHistoryP1b (:1455-1528) for one pixel
+static inline void neeat_p1b_pixel(const NeeAtFrame& F, uint x, uint y) {
+    MicroRng rng = MicroRng::make(x, y, F.updateCounter, 4);
+    float& w = F.scW[y * F.W + x]; uint& c = F.scC[y * F.W + x];
+    if (F.lastFrameFeedbackAvailable) lfr_clone_from(w, c, F.fbW[y * F.W + x], F.fbC[y * F.W + x], 1.0f);
+    else { lfr_clear(w, c); c = neeat_sample_light_global(F, rng); return; }
+    const uint lx = x / NEEAT_EARLY_FEEDBACK_TILE_SIZE, ly = y / NEEAT_EARLY_FEEDBACK_TILE_SIZE;
+    const float bw = F.blW[ly * F.BW + lx]; const uint bc = F.blC[ly * F.BW + lx];
+    if (bw != 0) { float rnd = rng.NextFloat(); lfr_merge(w, c, rnd, bw, bc, F.dropoff); }
+    if (c == RTXPT_INVALID_LIGHT_INDEX) {
+        uint res = RTXPT_INVALID_LIGHT_INDEX;
+        if (F.lastFrameLocalSamplesAvailable) {                                                          // SampleLightLocalHistoric (:1332-1345)
+            const uint tx = (x + F.jitterPrevX) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE, ty = (y + F.jitterPrevY) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE;
+            const uint idx = rng.Next() % RTXPT_LIGHTING_LOCAL_PROXY_COUNT;
+            res = neeat_remap_past_to_current(F, UnpackMiniListLight(F.local[neeat_lsb_address(F, tx, ty, idx)]));
+        }
+        if (res == RTXPT_INVALID_LIGHT_INDEX) res = neeat_sample_light_global(F, rng);
+        c = res;
+    }
+}
+// FillTile (:1531-1598): the tile's 128 unsorted entries
+static inline void neeat_fill_tile(const NeeAtFrame& F, uint tx, uint ty) {
+    const int margin = ((int)NEEAT_WINDOW_SIZE - (int)RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE) / 2;
+    const int cellX = (int)(tx * RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE) - (int)F.jitterX, cellY = (int)(ty * RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE) - (int)F.jitterY;
+    uint n = 0;
+    for (int x = 0; x < (int)NEEAT_WINDOW_SIZE; x++) for (int y = 0; y < (int)NEEAT_WINDOW_SIZE; y++) {
+        const int sx = neeat_mirror(cellX - margin + x, (int)F.W), sy = neeat_mirror(cellY - margin + y, (int)F.H);
+        F.local[neeat_lsb_address(F, tx, ty, n++)] = PackMiniListLightAndCount(F.scC[(uint)sy * F.W + (uint)sx], 1);
+    }
+    MicroRng rng = MicroRng::make(tx, ty, F.updateCounter, 5);
+    const float centerX = (float)cellX + (float)RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE * 0.5f, centerY = (float)cellY + (float)RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE * 0.5f;
+    const float radius = (float)NEEAT_WINDOW_SIZE * 4.0f;
+    for (uint i = 0; i < NEEAT_TOP_UP_SAMPLES; i++) {
+        const float r0 = rng.NextFloat(), r1 = rng.NextFloat();                                          // NextFloat2: x first
+        const float ox = (r0 - 0.5f) * radius, oy = (r1 - 0.5f) * radius;
+        const int sx = neeat_mirror((int)((centerX + ox) + 0.5f), (int)F.W), sy = neeat_mirror((int)((centerY + oy) + 0.5f), (int)F.H);
+        const uint lx = (uint)sx / NEEAT_EARLY_FEEDBACK_TILE_SIZE, ly = (uint)sy / NEEAT_EARLY_FEEDBACK_TILE_SIZE;
+        F.local[neeat_lsb_address(F, tx, ty, n++)] = PackMiniListLightAndCount(F.blC[ly * F.BW + lx], 1);
+    }
+}
+// ProcessFeedbackHistoryP3 (:1774-1854) for one tile, serially: sort the light indices, then every entry carries its light's number of entries. (The reference sorts with a
+// 64-thread bitonic network and counts runs with a pointer-jumping scan; any correct sort gives this output.)
+static inline void neeat_sort_tile(uint* tile) {
+    const uint N = RTXPT_LIGHTING_LOCAL_PROXY_COUNT;
+    uint key[RTXPT_LIGHTING_LOCAL_PROXY_COUNT];
+    for (uint i = 0; i < N; i++) key[i] = UnpackMiniListLight(tile[i]);
+    for (uint i = 1; i < N; i++) { uint k = key[i]; int j = (int)i - 1; while (j >= 0 && key[j] > k) { key[j + 1] = key[j]; j--; } key[j + 1] = k; }
+    for (uint i = 0; i < N;) { uint j = i; while (j < N && key[j] == key[i]) j++; for (uint k = i; k < j; k++) tile[k] = PackMiniListLightAndCount(key[i], j - i); i = j; }
+}
+// ClearFeedbackHistory (:774-830) for one pixel
+static inline void neeat_clear_pixel(const NeeAtFrame& F, uint x, uint y) {
+    float& w = F.fbW[y * F.W + x]; uint& c = F.fbC[y * F.W + x];
+    if (F.lastFrameFeedbackAvailable) {
+        const float dropOffFactor = F.dropoff;
+        lfr_clone_from(w, c, F.scW[y * F.W + x], F.scC[y * F.W + x], dropOffFactor);
+        const int offs[4][2] = {{-1, 0}, {+1, 0}, {0, -1}, {0, +1}};
+        MicroRng rng = MicroRng::make(x, y, F.updateCounter, 6);
+        for (int i = 0; i < 4; i++) {
+            int sx = (int)x + offs[i][0], sy = (int)y + offs[i][1];
+            sx = sx < 0 ? 0 : (sx > (int)F.W - 1 ? (int)F.W - 1 : sx); sy = sy < 0 ? 0 : (sy > (int)F.H - 1 ? (int)F.H - 1 : sy);
+            const float sw = F.scW[(uint)sy * F.W + (uint)sx]; const uint sc = F.scC[(uint)sy * F.W + (uint)sx];
+            if (sw != 0) { float rnd = rng.NextFloat(); lfr_merge(w, c, rnd, sw, sc, dropOffFactor * dropOffFactor); }
+        }
+        if (w < 1e-12f) lfr_clear(w, c);
+    } else lfr_clear(w, c);
+}
+// ComputeProxyCounts' weight (:898-915): the baked weight pulled towards what last frame's paths asked for
+static inline float neeat_feedback_light_weight(float lightWeight, uint usageCount, float weightSum, uint totalMaxFeedbackCount, uint invalidCount, float globalFeedbackUseWeight) {
+    uint validFeedbackCount = totalMaxFeedbackCount - invalidCount;
+    float denom = (float)validFeedbackCount; if (!(denom > 1.0f)) denom = 1.0f;                     // (float)max(1.0, validFeedbackCount)
+    float feedbackWeight = (float)usageCount * weightSum / denom;
+    return lightWeight + (feedbackWeight - lightWeight) * globalFeedbackUseWeight;                   // lerp
+}
+// ImportanceBooster's second term (:137-147) with ImportanceBoostIntensityDelta = 64 (LightsBaker.h:245-246): a light that got brighter than 1.1 x its last weight is boosted
+static inline float neeat_intensity_delta_boost(float boostedWeight, float historicWeight, float intensityDeltaMul) {
+    float delta = boostedWeight - historicWeight * 1.1f;
+    if (delta > 0) boostedWeight += intensityDeltaMul * delta;
+    return boostedWeight;
+}
+// LightsBaker::UpdateLocalJitter (LightsBaker.cpp:943-962): the R2 sequence, restarted every 1024 updates
+static inline void neeat_advance_jitter(uint updateCounter, float jitterF[2], uint jitter[2]) {
+    if ((updateCounter % 1024u) == 0u) { jitterF[0] = 0.f; jitterF[1] = 0.f; }
+    const float g = 1.32471795724474602596f, a1 = 1.0f / g, a2 = 1.0f / (g * g);
+    jitterF[0] = jitterF[0] + a1; jitterF[0] = jitterF[0] - (float)(int)jitterF[0];                 // fmodf(v, 1) for v >= 0
+    jitterF[1] = jitterF[1] + a2; jitterF[1] = jitterF[1] - (float)(int)jitterF[1];
+    for (int k = 0; k < 2; k++) { uint v = (uint)(jitterF[k] * (float)RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE); jitter[k] = v > RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE - 1u ? RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE - 1u : v; }
+}
+
+} // namespace ptref

@@ -10,6 +10,7 @@
 //   Rtxpt/ProcessingPasses/AccumulationPass.hlsl:36-66 + Rtxpt/Sample.cpp:2770-2778   accumulation lerp, weight 1/(n+1)
 #include "pathtracer.h"
 #include "tonemap.h"
+#include "neeat.h"
 #include "../refpin/pin_fns.h"
 #include <cstdio>
 #include <cstdlib>
@@ -307,6 +308,8 @@ static void bake_env_quads(Scene& sc) {
     }
 }
 
+void bind_light_table(Scene& sc);
+void build_light_proxies(Scene& sc, uint importanceSamplingType, const std::vector<float>& w, const uint* usage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight);
 void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
     sc.lights.clear(); sc.lightsEx.clear(); sc.proxyCounters.clear(); sc.proxyIndices.clear(); sc.envLookup.clear(); sc.envLookupDim = 0;
     for (size_t i = 0; i < sc.subInstances.size(); i++) { sc.subInstances[i].EmissiveLightMappingOffset = 0xFFFFFFFFu; sc.subInstances[i].AnalyticProxyLightIndex = 0xFFFFFFFFu; }
@@ -357,25 +360,37 @@ void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
                 sc.lights.push_back(lf.Base); sc.lightsEx.push_back(lf.Extended);
             }
         }
-        // weights + proxies (LightsBaker.hlsl:738-751, 836-948); NEEType 1: no frustum/intensity boosts, no feedback
+        // weights (LightsBaker.hlsl:738-751, 836-878; no frustum boost) — the proxies follow in build_light_proxies
         uint N = (uint)sc.lights.size();
-        std::vector<float> w(N); float weightSum = 0.f;
+        sc.lightWeights.assign(N, 0.f);
         for (uint i = 0; i < N; i++) {
             PolymorphicLightInfoFull lf; lf.Base = sc.lights[i]; lf.Extended = sc.lightsEx[i];
             float wt = light_weight(lf);
             if (!(wt == wt)) wt = 0;                    // (a NaN flux cannot pass `lightWeight > 0` in ComputeProxyCounts either)
-            w[i] = wt; weightSum += wt;
+            sc.lightWeights[i] = wt;
         }
-        uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
-        sc.proxyCounters.assign(N, 0);
-        for (uint i = 0; i < N; i++) {
-            uint c = 0;
-            if (w[i] > 0) c = (importanceSamplingType == 0) ? 1u : (uint)ceilf(((float)(budget - N) * w[i]) / weightSum);   // LightsBaker.hlsl:920-923 (type 0 = uniform: 1 proxy per light)
-            c = std::min(c, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1);
-            sc.proxyCounters[i] = c;
-            for (uint k = 0; k < c; k++) sc.proxyIndices.push_back(i);
-        }
+        build_light_proxies(sc, importanceSamplingType, sc.lightWeights, nullptr, 0, 0.f);
+    } else bind_light_table(sc);
+}
+// ComputeProxyCounts + the proxy fill (LightsBaker.hlsl:880-948, 1009-1060). usage != null (NEE-AT with last frame's feedback): the weights are pulled towards the counts P0 took
+void build_light_proxies(Scene& sc, uint importanceSamplingType, const std::vector<float>& w, const uint* usage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight) {
+    const uint N = (uint)sc.lights.size();
+    float weightSum = 0.f;
+    for (uint i = 0; i < N; i++) weightSum += w[i];
+    uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
+    sc.proxyCounters.assign(N, 0); sc.proxyIndices.clear();
+    for (uint i = 0; i < N; i++) {
+        float lightWeight = w[i];
+        if (usage) lightWeight = neeat_feedback_light_weight(lightWeight, usage[i], weightSum, totalMaxFeedbackCount, usage[N], globalFeedbackUseWeight);
+        uint c = 0;
+        if (lightWeight > 0) c = (importanceSamplingType == 0) ? 1u : (uint)ceilf(((float)(budget - N) * lightWeight) / weightSum);   // LightsBaker.hlsl:920-923 (type 0 = uniform: 1 proxy per light)
+        c = std::min(c, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1);
+        sc.proxyCounters[i] = c;
+        for (uint k = 0; k < c; k++) sc.proxyIndices.push_back(i);
     }
+    bind_light_table(sc);
+}
+void bind_light_table(Scene& sc) {
     LightTable& T = sc.lightTable;
     T.Lights = sc.lights.data(); T.LightsEx = sc.lightsEx.data(); T.ProxyCounters = sc.proxyCounters.data(); T.ProxyIndices = sc.proxyIndices.data();
     T.TotalLightCount = (uint)sc.lights.size(); T.SamplingProxyCount = (uint)sc.proxyIndices.size();
@@ -383,9 +398,35 @@ void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
     sc.bindLocalSampling();
 }
 
+// NEE-AT run state: what LightsBaker keeps between frames (LightsBaker.h:225-260) and the textures / buffers its feedback passes bind
+struct NeeAtState {
+    bool enabled = false; float globalFeedbackWeight = 0.75f, localRatio = 0.65f, sscThreshold = 0.3f, dropoff = 0.005f, intensityDeltaMul = 64.0f; bool preFilter = true;      // SampleUI.h:158-159, LightsBaker.h:240-253
+    uint updateCounter = 0; float jitterF[2] = {0, 0}; uint jitter[2] = {0, 0}, prevJitter[2] = {0, 0};
+    bool feedbackFilled = false, lastFeedbackAvailable = false; uint historicTotalLightCount = 0;
+    uint W = 0, H = 0; std::vector<float> fbW, scW, blW, histWeights, curWeights; std::vector<uint> fbC, scC, blC, local, counters;
+    void reset() { updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; historicTotalLightCount = 0; W = H = 0; histWeights.clear(); }
+};
+// the passes as the oracle restates them (neeat.h), one call per pixel / low-resolution pixel / tile in the order a dispatch would enumerate them (the order does not matter:
+// every pass reads what the previous one wrote and writes only its own slot). The reference-text harness (refpin/hlsl_pt_wrappers.inc) supplies the same interface.
+struct OracleNeeAtPasses {
+    void prefilter(const NeeAtFrame& F) {
+        std::vector<float> sw(F.fbW, F.fbW + (size_t)F.W * F.H); std::vector<uint> sc(F.fbC, F.fbC + (size_t)F.W * F.H);
+        for (uint y = 0; y < F.H; y++) for (uint x = 0; x < F.W; x++) neeat_prefilter_pixel(F, sw.data(), sc.data(), (int)x, (int)y);
+    }
+    void p0(const NeeAtFrame& F, uint totalThreads) {
+        for (uint y = 0; y < F.H; y++) for (uint x = 0; x < F.W; x++) F.perLightCounters[neeat_p0_pixel(F, x, y)]++;
+        F.perLightCounters[F.totalLightCount] += totalThreads - F.W * F.H;      // the threads beyond the frame count as "no valid feedback" (LightsBaker.hlsl:1283-1305)
+    }
+    void p1a(const NeeAtFrame& F) { for (uint y = 0; y < F.BH; y++) for (uint x = 0; x < F.BW; x++) neeat_p1a_pixel(F, x, y); }
+    void p1b(const NeeAtFrame& F) { for (uint y = 0; y < F.H; y++) for (uint x = 0; x < F.W; x++) neeat_p1b_pixel(F, x, y); }
+    void p2(const NeeAtFrame& F) { for (uint y = 0; y < F.tilesY; y++) for (uint x = 0; x < F.tilesX; x++) neeat_fill_tile(F, x, y); }
+    void p3(const NeeAtFrame& F) { for (uint t = 0; t < F.tilesX * F.tilesY; t++) neeat_sort_tile(F.local + (size_t)t * RTXPT_LIGHTING_LOCAL_PROXY_COUNT); }
+    void clear(const NeeAtFrame& F) { for (uint y = 0; y < F.H; y++) for (uint x = 0; x < F.W; x++) neeat_clear_pixel(F, x, y); }
+};
+
 struct Context {
     Scene sc; PtSettings S; PathTracerCameraData cam; uint w, h; std::vector<float4> accum; uint accumCount; RayCounters ctr;
-    bool geomDirty, lightsDirty;
+    bool geomDirty, lightsDirty; NeeAtState neeat;
     std::vector<float> fbWeight; std::vector<uint> fbCand; uint fbSamples = 0;      // NEE-AT feedback reservoirs of the last render call: one plane of w x h slots per sample
     void beginFeedback(uint n) {      // LightFeedbackReservoir::Clear for every slot
         fbSamples = 0; if (!sc.feedbackRequired) return;
@@ -548,20 +589,66 @@ static void prepare(Context* c) {
 }
 void ptref_prepare(void* h) { prepare((Context*)h); }
 
+// One frame of LightsBaker::UpdateBegin + UpdateEnd for the NEE-AT layer (LightsBaker.cpp:943-962, 985-1075, 1186-1213, 1335-1420), ahead of the frame's path tracing:
+// the light set is already baked (static between bakes); what changes from frame to frame is the global proxy table (usage feedback), the tile tables and the jitter.
+extern "C++" {
+template <class Passes> static void neeat_frame(Context* c, Passes& P) {
+    NeeAtState& st = c->neeat; Scene& sc = c->sc;
+    const uint N = (uint)sc.lights.size();
+    if (st.W != c->w || st.H != c->h) {             // (re)create the textures: LightsBaker::CreateRenderPasses (LightsBaker.cpp:300-345)
+        st.W = c->w; st.H = c->h; const size_t px = (size_t)st.W * st.H, bpx = (size_t)((st.W + 1) / 2) * ((st.H + 1) / 2), tiles = (size_t)((st.W + 7) / 8 + 1) * ((st.H + 7) / 8 + 1);
+        st.fbW.assign(px, 0.f); st.fbC.assign(px, 0xFFFFFFFFu); st.scW.assign(px, 0.f); st.scC.assign(px, 0xFFFFFFFFu); st.blW.assign(bpx, 0.f); st.blC.assign(bpx, 0xFFFFFFFFu);
+        st.local.assign(tiles * RTXPT_LIGHTING_LOCAL_PROXY_COUNT, 0u); st.feedbackFilled = false; st.lastFeedbackAvailable = false;
+    }
+    // ---- UpdateBegin
+    st.prevJitter[0] = st.jitter[0]; st.prevJitter[1] = st.jitter[1];
+    neeat_advance_jitter(st.updateCounter, st.jitterF, st.jitter);
+    st.updateCounter++;
+    const bool lastFrameLocalSamplesAvailable = st.lastFeedbackAvailable;      // "if last frame had temporal feedback, it will have had built local (tile) sampling"
+    const bool lastFrameFeedbackAvailable = st.feedbackFilled;
+    NeeAtFrame F; memset(&F, 0, sizeof(F));
+    F.W = st.W; F.H = st.H; F.BW = (st.W + 1) / 2; F.BH = (st.H + 1) / 2; F.tilesX = (st.W + 7) / 8 + 1; F.tilesY = (st.H + 7) / 8 + 1;
+    F.jitterX = st.jitter[0]; F.jitterY = st.jitter[1]; F.jitterPrevX = st.prevJitter[0]; F.jitterPrevY = st.prevJitter[1];
+    F.updateCounter = st.updateCounter; F.dropoff = st.dropoff; F.totalLightCount = N; F.historicTotalLightCount = st.historicTotalLightCount; st.historicTotalLightCount = N;
+    F.lastFrameFeedbackAvailable = lastFrameFeedbackAvailable ? 1u : 0u; F.lastFrameLocalSamplesAvailable = (lastFrameLocalSamplesAvailable && lastFrameFeedbackAvailable) ? 1u : 0u;
+    F.fbW = st.fbW.data(); F.fbC = st.fbC.data(); F.scW = st.scW.data(); F.scC = st.scC.data(); F.blW = st.blW.data(); F.blC = st.blC.data(); F.local = st.local.data();
+    st.counters.assign(N + 1, 0u); F.perLightCounters = st.counters.data();                                    // ResetLightProxyCounters
+    const uint totalMaxFeedbackCount = lastFrameFeedbackAvailable ? ((st.W + 7) / 8) * ((st.H + 7) / 8) * 64u : 0u;
+    if (lastFrameFeedbackAvailable) { if (st.preFilter) P.prefilter(F); P.p0(F, totalMaxFeedbackCount); }
+    st.curWeights = sc.lightWeights;                                                                            // ComputeWeights: the baked weight, boosted where a light got brighter
+    if (lastFrameFeedbackAvailable && st.intensityDeltaMul > 0)
+        for (uint i = 0; i < N; i++) st.curWeights[i] = neeat_intensity_delta_boost(st.curWeights[i], i < st.histWeights.size() ? st.histWeights[i] : 0.f, st.intensityDeltaMul);
+    build_light_proxies(sc, c->S.NEEType, st.curWeights, lastFrameFeedbackAvailable ? st.counters.data() : nullptr, totalMaxFeedbackCount, lastFrameFeedbackAvailable ? st.globalFeedbackWeight : 0.f);
+    st.histWeights = st.curWeights;
+    st.lastFeedbackAvailable = lastFrameFeedbackAvailable;
+    F.samplingProxyCount = (uint)sc.proxyIndices.size(); F.proxies = sc.proxyIndices.data();
+    // ---- UpdateEnd
+    P.p1a(F); P.p1b(F); P.p2(F); P.p3(F); P.clear(F);
+    st.feedbackFilled = true;
+    // what the path tracer binds this frame (LightingControlData: ratio 0 until feedback exists)
+    sc.localTable = st.local; sc.localResX = F.tilesX; sc.localResY = F.tilesY; sc.localJitterX = st.jitter[0]; sc.localJitterY = st.jitter[1];
+    sc.localRatio = lastFrameFeedbackAvailable ? st.localRatio : 0.f; sc.sscThreshold = st.sscThreshold; sc.feedbackRequired = true;
+    sc.bindLocalSampling();
+}
+} // extern "C++"
+
 // Sample::Render for n accumulated frames starting at sample index `first` (Sample.cpp:1416-1450, 2770-2778).
 // Restricting to a pixel rectangle is an oracle-only convenience for bounded-time checks.
 void ptref_render_rect(void* h, uint32_t first, uint32_t n, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
     Context* c = (Context*)h; prepare(c);
+    if (c->neeat.enabled) c->sc.feedbackRequired = true;
     c->beginFeedback(n);
     for (uint32_t s = 0; s < n; s++) {
         uint32_t sampleIndex = first + s;
+        if (c->neeat.enabled) { OracleNeeAtPasses passes; neeat_frame(c, passes); }      // every sample is a frame: baker, then the path tracer
         float blend = 1.0f / (float)(c->accumCount + 1);
         RayCounters total; memset(&total, 0, sizeof(total));
 #pragma omp parallel
         {
             RayCounters local; memset(&local, 0, sizeof(local));
             PathTracer pt(c->sc, c->S, c->cam, sampleIndex, &local);
-            if (c->fbSamples) { pt.fbTotalWeight = c->fbWeight.data() + (size_t)c->w * c->h * s; pt.fbCandidates = c->fbCand.data() + (size_t)c->w * c->h * s; pt.fbWidth = c->w; }
+            if (c->neeat.enabled) { pt.fbTotalWeight = c->neeat.fbW.data(); pt.fbCandidates = c->neeat.fbC.data(); pt.fbWidth = c->w; }      // the run's own reservoirs: they carry the 0.5 % the Clear pass kept
+            else if (c->fbSamples) { pt.fbTotalWeight = c->fbWeight.data() + (size_t)c->w * c->h * s; pt.fbCandidates = c->fbCand.data() + (size_t)c->w * c->h * s; pt.fbWidth = c->w; }
 #pragma omp for schedule(dynamic, 1) nowait
             for (int y = (int)y0; y < (int)y1; y++) for (uint32_t x = x0; x < x1; x++) {
                 float4 col = pt.tracePixel(x, (uint32_t)y);
@@ -575,7 +662,26 @@ void ptref_render_rect(void* h, uint32_t first, uint32_t n, uint32_t x0, uint32_
         c->ctr.extendRays += total.extendRays; c->ctr.shadowRays += total.shadowRays; c->ctr.hits += total.hits; c->ctr.nodeVisitsExt += total.nodeVisitsExt;
         c->ctr.triTestsExt += total.triTestsExt; c->ctr.nodeVisitsSh += total.nodeVisitsSh; c->ctr.triTestsSh += total.triTestsSh;
         c->accumCount++;
+        if (c->neeat.enabled && c->fbSamples) { const size_t plane = (size_t)c->w * c->h;      // a copy per frame, for the tests
+            memcpy(c->fbWeight.data() + plane * s, c->neeat.fbW.data(), 4 * plane); memcpy(c->fbCand.data() + plane * s, c->neeat.fbC.data(), 4 * plane); }
     }
+}
+// NEE-AT with the baker in the loop: every sample of a render call is one frame (LightsBaker::UpdateBegin / UpdateEnd, then the path tracer); enable = 0 leaves whatever
+// ptref_set_local_light_sampling set. reset: forget the history (a new run).
+void ptref_set_neeat(void* h, int enable, float globalFeedbackWeight, float localToGlobalRatio, float sscThreshold, int preFilter) {
+    Context* c = (Context*)h; NeeAtState& st = c->neeat;
+    if (st.enabled && !enable) { Scene& sc = c->sc; sc.localTable.clear(); sc.localResX = sc.localResY = 0; sc.localRatio = 0; sc.feedbackRequired = false; sc.bindLocalSampling(); c->lightsDirty = true; }
+    st.enabled = enable != 0; st.globalFeedbackWeight = globalFeedbackWeight; st.localRatio = localToGlobalRatio; st.sscThreshold = sscThreshold; st.preFilter = preFilter != 0;
+}
+void ptref_neeat_reset(void* h) { ((Context*)h)->neeat.reset(); }
+// the tile tables and the jitter the last frame was traced with, and the global proxy counters
+int ptref_neeat_get_tables(void* h, uint32_t* tilesXY, uint32_t* jitterXY, uint32_t* table, uint32_t* proxyCounters) {
+    Context* c = (Context*)h; const NeeAtState& st = c->neeat; if (!st.W) return 0;
+    if (tilesXY) { tilesXY[0] = (st.W + 7) / 8 + 1; tilesXY[1] = (st.H + 7) / 8 + 1; }
+    if (jitterXY) { jitterXY[0] = st.jitter[0]; jitterXY[1] = st.jitter[1]; }
+    if (table) memcpy(table, st.local.data(), 4 * st.local.size());
+    if (proxyCounters) memcpy(proxyCounters, c->sc.proxyCounters.data(), 4 * c->sc.proxyCounters.size());
+    return 1;
 }
 // NEE-AT, the path tracer's side (LightSampler.hlsli; the table is what LightsBaker's feedback passes write: tiles of 8 x 8 pixels, 128 packed entries each, sorted by light index)
 void ptref_set_local_light_sampling(void* h, const uint32_t* table, uint32_t resX, uint32_t resY, uint32_t jitterX, uint32_t jitterY, float ratio, float sscThreshold, int feedback) {

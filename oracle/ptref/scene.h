@@ -176,7 +176,7 @@ struct Scene {
     std::vector<Triangle> tris;
     // lights
     std::vector<PolymorphicLightInfo> lights; std::vector<PolymorphicLightInfoEx> lightsEx;
-    std::vector<uint> proxyCounters, proxyIndices, envLookup; uint envLookupDim;
+    std::vector<uint> proxyCounters, proxyIndices, envLookup; uint envLookupDim; std::vector<float> lightWeights;      // lightWeights: ComputeWeight per light, kept for the per-frame proxy rebuild of NEE-AT
     std::vector<PolymorphicLightInfoFull> analyticLights;   // supplied by the host (pt_set_lights)
     LightTable lightTable;
     // NEE-AT inputs (ptref_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback switch

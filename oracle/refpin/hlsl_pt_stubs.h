@@ -50,8 +50,9 @@ struct Texture3D { const ptref::SkyTexture* lut = nullptr;                      
     float4 SampleLevel(SamplerState, float3 uvw, float) const { if (!lut) return float4(); ptref::float4 c = ptref::sky_sample3d(*lut, ptref::make_float3(uvw.x, uvw.y, uvw.z)); return float4(c.x, c.y, c.z, c.w); } };
 template <class T> struct TextureCube { T (*fetch)(const void*, float3, float) = nullptr; const void* ctx = nullptr;
     T SampleLevel(SamplerState, float3 dir, float lod) const { return fetch ? fetch(ctx, dir, lod) : T(); } };
-template <class T> struct RWTexture2D { T* p = nullptr; uint w = 0; T dummy = T();
-    T& operator[](uint2 c) { return p ? p[c.y * w + c.x] : dummy; } T operator[](uint2 c) const { return p ? p[c.y * w + c.x] : dummy; } void GetDimensions(uint& ow, uint& oh) const { ow = w; oh = 1; } };
+template <class T> struct RWTexture2D { T* p = nullptr; uint w = 0; T dummy = T(); uint h = 0;      // h != 0: bounds-checked like a UAV (out-of-range writes dropped, reads 0)
+    bool in(uint2 c) const { return p && (h == 0 || (c.x < w && c.y < h)); }
+    T& operator[](uint2 c) { if (in(c)) return p[c.y * w + c.x]; dummy = T(); return dummy; } T operator[](uint2 c) const { return in(c) ? p[c.y * w + c.x] : T(); } void GetDimensions(uint& ow, uint& oh) const { ow = w; oh = 1; } };
 template <class T> struct RWTexture2DArray { T dummy; T& operator[](uint3) { return dummy; } T operator[](uint3) const { return dummy; } };
 template <class T> struct RWTexture3D { T dummy; T& operator[](uint3) { return dummy; } };
 template <class T> struct StructuredBuffer { const T* p = nullptr; const T& operator[](uint i) const { return p[i]; } };

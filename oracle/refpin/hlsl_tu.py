@@ -161,6 +161,8 @@ def to_cpp(code):
     code = re.sub(r"\bconst\s+(?=[A-Za-z_][\w:]*\s+[A-Za-z_]\w*\s*[,)])", "", code)        # by-value parameters: HLSL calls non-const methods on them
     code = re.sub(r"\bconst\s+(?=[A-Z]\w*\s+[A-Za-z_]\w*\s*=)", "", code)                  # `const Struct local = ...` likewise
     code = re.sub(r"\bthis\.", "this->", code)
+    # `float2(NextFloat(), NextFloat())`: HLSL evaluates constructor arguments left to right, C++ leaves the order open (gcc: right to left)
+    code = code.replace("return float2(NextFloat(), NextFloat());", "{ float nf0 = NextFloat(); float nf1 = NextFloat(); return float2(nf0, nf1); }")
     # `cond ? float : lpfloat`: HLSL promotes, C++ wants one type (no-ops in the fp32 build)
     code = code.replace("alpha < kMinGGXAlpha ? 0.f : dataRoughness", "alpha < kMinGGXAlpha ? 0.f : (float)dataRoughness")
     code = code.replace("(applyMIS)?(path.GetBsdfScatterPdf()):(0.0)", "(applyMIS)?((float)path.GetBsdfScatterPdf()):(0.0)")
@@ -273,6 +275,24 @@ def main_pt(ref):
                  "InsetColorBBoxP1", "OptimizeEndpointsP1", "OptimizeEndpointsP2", "EncodeP1", "DistToLineSq", "EvaluateP2Pattern", "EncodeP2Pattern"):
         for body in extract_function(ctext, name, "BC6UCompress.hlsl"): w(to_cpp(body) + "\n")
     w("} // namespace bc6u\n")
+    # LightsBaker.hlsl: the NEE-AT feedback passes (last frame's reservoirs -> this frame's tile tables and usage counts) over the stand-in bindings of hlsl_lbfb_stubs.h
+    lpath = os.path.join(ref, "Rtxpt/Lighting/LightsBaker.hlsl")
+    ltext = strip_comments(open(lpath, encoding="latin-1").read())
+    ltext = re.sub(r"(?<![\w.])([01])\.xx\b", r"int2(\1,\1)", ltext)      # `0.xx` / `1.xx` next to int2 operands: integer splats (to_cpp would make them float2)
+    ltext = re.sub(r"\b(RTXPT_NEEAT_EARLY_FEEDBACK_TILE_SIZE|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE)\.xx\b", r"int2(\1,\1)", ltext)
+    w("// ======== LightsBaker.hlsl (NEE-AT feedback passes)\nnamespace lbfb {\n")
+    w('#include "%s/hlsl_lbfb_stubs.h"\n' % HERE)
+    for name in ("RemapPastToCurrent",):
+        for body in extract_function(ltext, name, "LightsBaker.hlsl"): w(to_cpp(body) + "\n")
+    w(to_cpp(extract_struct(ltext, "LocalReservoir", "LightsBaker.hlsl")) + "\n")
+    w("groupshared LocalReservoir g_tile[32][32];\n")
+    for name in ("ProcessFeedbackHistoryPreFilter", "ProcessFeedbackHistoryP0", "SampleLightGlobal", "MirrorCoord", "LSB_Address", "SampleLightLocalHistoric", "ConvertMotionVectorToPixelSpace", "Reproject",
+                 "ProcessFeedbackHistoryP1a", "ProcessFeedbackHistoryP1b", "FillTile", "ProcessFeedbackHistoryP2", "InsertOneBit"):
+        for body in extract_function(ltext, name, "LightsBaker.hlsl"): w(to_cpp(body) + "\n")
+    w("groupshared uint g_localData[RTXPT_LIGHTING_LOCAL_PROXY_COUNT];\ngroupshared uint g_localDataRangeLR[RTXPT_LIGHTING_LOCAL_PROXY_COUNT];\n")
+    for name in ("LastScanAndWriteOut", "ProcessFeedbackHistoryP3", "ClearFeedbackHistory"):
+        for body in extract_function(ltext, name, "LightsBaker.hlsl"): w(to_cpp(body) + "\n")
+    w("} // namespace lbfb\n")
     w("} // namespace hl\n")
     w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
 
