@@ -252,6 +252,16 @@ int32_t pt_set_local_light_sampling(pt_context* ctx, const uint32_t* table, uint
 /* the feedback reservoirs the last pt_render call filled: one plane of width x height slots per sample of the call (sample = 0 .. sampleCount-1), cleared at the start of the
  * call (total weight 0, candidate 0xFFFFFFFF); candidate = light index | 0x80000000 when the vertex was screen-space coherent (LightingTypes.hlsli:184-320) */
 int32_t pt_get_light_feedback(pt_context* ctx, uint32_t sample, float* totalWeight, uint32_t* candidates);
+/* NEE-AT with the light baker in the loop (the reference's default sampler, CommandLine.h:42; LightsBaker::UpdateBegin / UpdateEnd, Rtxpt/Lighting/LightsBaker.cpp:964-1420, and the
+ * ProcessFeedbackHistory* / ClearFeedbackHistory / ComputeProxyCounts passes of LightsBaker.hlsl:753-830, 880-948, 1062-1855): while enabled, every sample of pt_render is one
+ * frame — last frame's feedback re-weights the global proxy table (globalTemporalFeedbackWeight, SampleUI.h:158) and becomes this frame's tile tables (sampled with
+ * localToGlobalSampleRatio, :159, once feedback exists), then the frame is traced and fills the reservoirs again. History is read at the same pixel (no motion vectors on this
+ * path: exact for the still camera of an accumulation run; call pt_neeat_reset after a camera cut). Needs NEEFullSamples 1, NEEType 2 is the matching setting (the global table
+ * is built as for type 1). preFilter: LightsBaker.h:251 m_importanceBoost_PreFilter (default on). The frustum importance boost (LightsBaker.h:247-249) is not applied.
+ * pt_get_light_feedback(0, ...) returns the run's reservoirs after the last frame; pt_get_neeat_tables the tile tables and jitter that frame was traced with. */
+int32_t pt_set_neeat(pt_context* ctx, int32_t enable, float globalTemporalFeedbackWeight, float localToGlobalSampleRatio, float screenSpaceVsWorldSpaceThreshold, int32_t preFilter);
+int32_t pt_neeat_reset(pt_context* ctx);                                                      /* LightsBaker::BakeSettings::ResetFeedback */
+int32_t pt_get_neeat_tables(pt_context* ctx, uint32_t tilesXY[2], uint32_t jitterXY[2], uint32_t* table, uint32_t tableCapacityWords);
 
 /* BridgeCamera (PathTracerShared.h:109-141) */
 int32_t pt_bridge_camera(uint32_t viewportWidth, uint32_t viewportHeight, const float camPos[3], const float camDir[3], const float camUp[3], float fovY,

@@ -329,12 +329,14 @@ static inline uint PackMiniListLightAndCount(uint globalLightIndex, uint counter
 static inline void UnpackMiniListLightAndCount(uint value, uint& globalLightIndex, uint& counter) { globalLightIndex = value >> 9; counter = (value & 0x1FFu) + 1u; }
 static inline uint UnpackMiniListLight(uint value) { return value >> 9; }
 static inline uint LLSB_ComputeBaseAddress(uint tileX, uint tileY, uint resX) { return (tileX + tileY * resX) * RTXPT_LIGHTING_LOCAL_PROXY_COUNT; }
-// LightingAlgorithms.hlsli:654-682: the tile's entries are sorted by light index; returns the packed entry or RTXPT_INVALID_LIGHT_INDEX
-static inline uint LocalLightBinarySearch(const uint* storageBuffer, uint tileAddress, uint globalLightIndexToFind, uint localLightCount, uint steps) {
+// LightingAlgorithms.hlsli:654-682: the tile's entries are sorted by light index; returns the packed entry or RTXPT_INVALID_LIGHT_INDEX. The search may step outside the
+// buffer — in the very first tile `indexRight = indexMiddle - 1` wraps below zero when the light sorts before every entry — where a D3D typed-buffer load returns 0
+// and the reference carries on; bufferWords restates that (and a light index 0 can then be "found" outside, exactly as there).
+static inline uint LocalLightBinarySearch(const uint* storageBuffer, uint bufferWords, uint tileAddress, uint globalLightIndexToFind, uint localLightCount, uint steps) {
     uint indexLeft = tileAddress, indexRight = tileAddress + localLightCount - 1u;
     for (uint i = 0u; i < steps; ++i) {
         uint indexMiddle = (indexLeft + indexRight) >> 1;
-        uint value = storageBuffer[indexMiddle];
+        uint value = indexMiddle < bufferWords ? storageBuffer[indexMiddle] : 0u;
         uint keyMiddle = UnpackMiniListLight(value);
         if (keyMiddle < globalLightIndexToFind) indexLeft = indexMiddle + 1u;
         else if (keyMiddle > globalLightIndexToFind) indexRight = indexMiddle - 1u;
@@ -379,7 +381,7 @@ struct LightSampler {
         return lightIndex;
     }
     float SampleLocalPDF(uint lightIndex) const {                                                                    // :146-180
-        uint packedValue = LocalLightBinarySearch(T->LocalSamplingBuffer, LocalSamplingTilePos, lightIndex, RTXPT_LIGHTING_LOCAL_PROXY_COUNT, RTXPT_LIGHTING_LOCAL_PROXY_BINARY_SEARCH_STEPS);
+        uint packedValue = LocalLightBinarySearch(T->LocalSamplingBuffer, T->LocalResX * T->LocalResY * RTXPT_LIGHTING_LOCAL_PROXY_COUNT, LocalSamplingTilePos, lightIndex, RTXPT_LIGHTING_LOCAL_PROXY_COUNT, RTXPT_LIGHTING_LOCAL_PROXY_BINARY_SEARCH_STEPS);
         if (packedValue == RTXPT_INVALID_LIGHT_INDEX) return 0.0f;
         uint lightIndexR, proxyCountR;
         UnpackMiniListLightAndCount(packedValue, lightIndexR, proxyCountR);

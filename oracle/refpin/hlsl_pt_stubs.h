@@ -57,7 +57,7 @@ template <class T> struct RWTexture2DArray { T dummy; T& operator[](uint3) { ret
 template <class T> struct RWTexture3D { T dummy; T& operator[](uint3) { return dummy; } };
 template <class T> struct StructuredBuffer { const T* p = nullptr; const T& operator[](uint i) const { return p[i]; } };
 template <class T> struct RWStructuredBuffer { T* p = nullptr; T& operator[](uint i) const { return p[i]; } };
-template <class T> struct Buffer { const T* p = nullptr; T operator[](uint i) const { return p[i]; } };
+template <class T> struct Buffer { const T* p = nullptr; uint n = 0; T operator[](uint i) const { return (n && i >= n) ? T() : p[i]; } };      // n != 0: loads beyond the buffer return 0 (D3D typed-buffer behaviour)
 template <class T> struct RWBuffer { T* p = nullptr; T& operator[](uint i) const { return p[i]; } };
 struct ByteAddressBuffer { const unsigned char* p = nullptr;
     uint Load(uint o) const { uint v; memcpy(&v, p + o, 4); return v; } uint2 Load2(uint o) const { return uint2(Load(o), Load(o + 4)); } uint3 Load3(uint o) const { return uint3(Load(o), Load(o + 4), Load(o + 8)); } };

@@ -91,6 +91,15 @@ struct pt_context {
     // NEE-AT (pt_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback reservoirs of the last pt_render call (one plane per sample)
     DevBuf<uint> dLocalTable; uint localResX = 0, localResY = 0, localJitterX = 0, localJitterY = 0, localMaxLight = 0; float localRatio = 0.f, sscThreshold = 0.f; bool feedbackRequired = false;
     DevBuf<float> dFbWeight; DevBuf<uint> dFbCand; DevBuf<ptk::float4> dSq3; uint fbSamples = 0;
+    // NEE-AT with the baker in the loop (pt_set_neeat): what LightsBaker keeps between frames (LightsBaker.h:225-260) and the textures / buffers its feedback passes bind
+    struct NeeAt {
+        bool enabled = false; float globalFeedbackWeight = 0.75f, localRatio = 0.65f, sscThreshold = 0.3f, dropoff = 0.005f, intensityDeltaMul = 64.0f; bool preFilter = true;
+        uint updateCounter = 0; float jitterF[2] = {0, 0}; uint jitter[2] = {0, 0}, prevJitter[2] = {0, 0};
+        bool feedbackFilled = false, lastFeedbackAvailable = false; uint historicTotalLightCount = 0, W = 0, H = 0, nHist = 0;
+        DevBuf<float> fbW, scW, blW, snapW, curW, histW; DevBuf<uint> fbC, scC, blC, snapC, local, counters;
+        void reset() { updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
+        void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); }
+    } neeat;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
     BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0; uint bvhBuilder = BVH_BUILDER_SAH;
@@ -236,7 +245,7 @@ void refresh_scene_view(pt_context* c) {
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
     d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
-    d.lights.LocalSamplingBuffer = c->localResX ? c->dLocalTable.p : nullptr; d.lights.LocalResX = c->localResX; d.lights.LocalResY = c->localResY; d.lights.LocalJitterX = c->localJitterX; d.lights.LocalJitterY = c->localJitterY;
+    d.lights.LocalSamplingBuffer = c->localResX ? (c->neeat.enabled ? c->neeat.local.p : c->dLocalTable.p) : nullptr; d.lights.LocalResX = c->localResX; d.lights.LocalResY = c->localResY; d.lights.LocalJitterX = c->localJitterX; d.lights.LocalJitterY = c->localJitterY;
     d.lights.LocalToGlobalSampleRatio = c->localResX ? c->localRatio : 0.f; d.lights.ScreenSpaceVsWorldSpaceThreshold = c->sscThreshold; d.lights.TemporalFeedbackRequired = c->feedbackRequired ? 1u : 0u;
     d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.alphaPlanes = c->dAlphaPlanes.p; d.alphaPool = c->dAlphaPool.p; d.shadeTris = c->dShadeTris.p; d.primToSlot = c->bvh.primToSlot; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
 }
@@ -379,6 +388,28 @@ int bake_env_quads(pt_context* c) {
 }
 // geometryOnly: the instances / vertices moved but materials, environment, analytic lights and settings did not (pt_animate): the environment quad-tree
 // lights are kept, only the emissive triangles are re-baked, and everything downstream (weights, proxy counts, proxy table) runs on the device.
+// ComputeProxyCounts + the proxy fill (LightsBaker.hlsl:880-948, 1009-1060) from the weights in dWeights[0 .. N) (dWeights[N] receives their sum). usage != null: NEE-AT's
+// feedback term. Leaves numProxies and the scene view current.
+int build_light_proxies(pt_context* c, float* dWeights, const uint* dUsage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight) {
+    const uint N = (uint)c->lights.size(); if (!N) return PT_OK;
+    const uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
+    const size_t proxyCapacity = (size_t)budget + N;                       // sum of ceil((budget - N) w_i / W) <= budget - N + N (the feedback lerp keeps the weights' sum at W)
+    PT_CHECK_HIP(c, c->dProxyCounters.resize(N)); PT_CHECK_HIP(c, c->dProxyOffsets.resize(N)); PT_CHECK_HIP(c, c->dProxyIndices.resize(proxyCapacity));
+    launch_light_proxy_counts(dWeights, N, dWeights + N, budget, c->S.NEEType == 0, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1, c->dProxyCounters.p, dUsage, totalMaxFeedbackCount, globalFeedbackUseWeight, c->stream);
+    size_t need = 0;
+    PT_CHECK_HIP(c, rocprim::exclusive_scan(nullptr, need, c->dProxyCounters.p, c->dProxyOffsets.p, 0u, (size_t)N, rocprim::plus<uint>(), c->stream));
+    if (need > c->scanTempBytes) { if (c->dScanTemp) (void)hipFree(c->dScanTemp); c->dScanTemp = nullptr; PT_CHECK_HIP(c, hipMalloc(&c->dScanTemp, need)); c->scanTempBytes = need; }
+    need = c->scanTempBytes;
+    PT_CHECK_HIP(c, rocprim::exclusive_scan(c->dScanTemp, need, c->dProxyCounters.p, c->dProxyOffsets.p, 0u, (size_t)N, rocprim::plus<uint>(), c->stream));
+    launch_light_proxy_fill(c->dProxyCounters.p, c->dProxyOffsets.p, N, c->dProxyIndices.p, (uint)proxyCapacity, c->stream);
+    uint last[2] = {0u, 0u};                           // the proxy count is a field of the by-value scene view: one 8-byte read-back
+    PT_CHECK_HIP(c, hipMemcpyAsync(&last[0], c->dProxyOffsets.p + (N - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipMemcpyAsync(&last[1], c->dProxyCounters.p + (N - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    c->numProxies = last[0] + last[1];
+    if (c->numProxies > proxyCapacity) return fail(c, PT_ERROR_HIP, "light proxy table overflow");
+    return PT_OK;
+}
 int bake_lights(pt_context* c, bool geometryOnly = false) {
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
@@ -426,20 +457,10 @@ int bake_lights(pt_context* c, bool geometryOnly = false) {
         if (N) {
             const uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
             const size_t proxyCapacity = (size_t)budget + N;                       // sum of ceil((budget - N) w_i / W) <= budget - N + N
-            PT_CHECK_HIP(c, c->dLightW.resize(N + 1)); PT_CHECK_HIP(c, c->dProxyCounters.resize(N)); PT_CHECK_HIP(c, c->dProxyOffsets.resize(N)); PT_CHECK_HIP(c, c->dProxyIndices.resize(proxyCapacity));
-            launch_light_weights(c->dLights.p, c->dLightsEx.p, N, c->dLightW.p, c->dLightW.p + N, budget, c->S.NEEType == 0, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1, c->dProxyCounters.p, c->stream);
-            size_t need = 0;
-            PT_CHECK_HIP(c, rocprim::exclusive_scan(nullptr, need, c->dProxyCounters.p, c->dProxyOffsets.p, 0u, (size_t)N, rocprim::plus<uint>(), c->stream));
-            if (need > c->scanTempBytes) { if (c->dScanTemp) (void)hipFree(c->dScanTemp); c->dScanTemp = nullptr; PT_CHECK_HIP(c, hipMalloc(&c->dScanTemp, need)); c->scanTempBytes = need; }
-            need = c->scanTempBytes;
-            PT_CHECK_HIP(c, rocprim::exclusive_scan(c->dScanTemp, need, c->dProxyCounters.p, c->dProxyOffsets.p, 0u, (size_t)N, rocprim::plus<uint>(), c->stream));
-            launch_light_proxy_fill(c->dProxyCounters.p, c->dProxyOffsets.p, N, c->dProxyIndices.p, (uint)proxyCapacity, c->stream);
-            uint last[2] = {0u, 0u};                           // the proxy count is a field of the by-value scene view: one 8-byte read-back
-            PT_CHECK_HIP(c, hipMemcpyAsync(&last[0], c->dProxyOffsets.p + (N - 1), 4, hipMemcpyDeviceToHost, c->stream));
-            PT_CHECK_HIP(c, hipMemcpyAsync(&last[1], c->dProxyCounters.p + (N - 1), 4, hipMemcpyDeviceToHost, c->stream));
-            PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
-            c->numProxies = last[0] + last[1];
-            if (c->numProxies > proxyCapacity) return fail(c, PT_ERROR_HIP, "light proxy table overflow");
+            (void)budget; (void)proxyCapacity;
+            PT_CHECK_HIP(c, c->dLightW.resize(N + 1));
+            launch_light_weights(c->dLights.p, c->dLightsEx.p, N, c->dLightW.p, c->stream);
+            int pr = build_light_proxies(c, c->dLightW.p, nullptr, 0u, 0.f); if (pr != PT_OK) return pr;
         }
     } else { PT_CHECK_HIP(c, c->dLights.resize(1)); PT_CHECK_HIP(c, c->dLightsEx.resize(1)); }
     if (!keepEnv) PT_CHECK_HIP(c, c->dEnvLookup.upload(c->envLookup, c->stream));
@@ -495,6 +516,50 @@ int ensure_pool(pt_context* c, uint n, uint shadowPerPath) {      // shadowPerPa
     return PT_OK;
 }
 
+// One frame of LightsBaker::UpdateBegin + UpdateEnd for the NEE-AT layer (LightsBaker.cpp:943-962, 985-1075, 1186-1213, 1335-1420) ahead of the frame's path tracing; the
+// order and the constants are spelled out in pt_neeat.h. The light set is the baked one; what changes per frame is the global proxy table, the tile tables and the jitter.
+int neeat_frame(pt_context* c) {
+    pt_context::NeeAt& st = c->neeat;
+    const uint N = (uint)c->lights.size();
+    if (!N) return fail(c, PT_ERROR_NOT_READY, "NEE-AT needs lights (an environment, emissive triangles or analytic lights)");
+    NeeAtFrame F; memset(&F, 0, sizeof(F));
+    F.W = c->width; F.H = c->height; F.BW = (F.W + 1) / 2; F.BH = (F.H + 1) / 2; F.tilesX = (F.W + 7) / 8 + 1; F.tilesY = (F.H + 7) / 8 + 1;
+    const size_t px = (size_t)F.W * F.H, bpx = (size_t)F.BW * F.BH, tiles = (size_t)F.tilesX * F.tilesY;
+    if (st.W != F.W || st.H != F.H) {               // (re)create the textures: LightsBaker::CreateRenderPasses (LightsBaker.cpp:300-345)
+        st.W = F.W; st.H = F.H; st.feedbackFilled = false; st.lastFeedbackAvailable = false;
+        PT_CHECK_HIP(c, st.fbW.resize(px)); PT_CHECK_HIP(c, st.fbC.resize(px)); PT_CHECK_HIP(c, st.scW.resize(px)); PT_CHECK_HIP(c, st.scC.resize(px)); PT_CHECK_HIP(c, st.snapW.resize(px)); PT_CHECK_HIP(c, st.snapC.resize(px));
+        PT_CHECK_HIP(c, st.blW.resize(bpx)); PT_CHECK_HIP(c, st.blC.resize(bpx)); PT_CHECK_HIP(c, st.local.resize(tiles * RTXPT_LIGHTING_LOCAL_PROXY_COUNT));
+        PT_CHECK_HIP(c, hipMemsetAsync(st.fbW.p, 0, 4 * px, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(st.fbC.p, 0xFF, 4 * px, c->stream));
+    }
+    // ---- UpdateBegin
+    st.prevJitter[0] = st.jitter[0]; st.prevJitter[1] = st.jitter[1];
+    neeat_advance_jitter(st.updateCounter, st.jitterF, st.jitter);
+    st.updateCounter++;
+    const bool lastFrameLocalSamplesAvailable = st.lastFeedbackAvailable, lastFrameFeedbackAvailable = st.feedbackFilled;
+    F.jitterX = st.jitter[0]; F.jitterY = st.jitter[1]; F.jitterPrevX = st.prevJitter[0]; F.jitterPrevY = st.prevJitter[1];
+    F.updateCounter = st.updateCounter; F.dropoff = st.dropoff; F.totalLightCount = N; F.historicTotalLightCount = st.historicTotalLightCount; st.historicTotalLightCount = N;
+    F.lastFrameFeedbackAvailable = lastFrameFeedbackAvailable ? 1u : 0u; F.lastFrameLocalSamplesAvailable = (lastFrameLocalSamplesAvailable && lastFrameFeedbackAvailable) ? 1u : 0u;
+    F.fbW = st.fbW.p; F.fbC = st.fbC.p; F.scW = st.scW.p; F.scC = st.scC.p; F.blW = st.blW.p; F.blC = st.blC.p; F.local = st.local.p;
+    PT_CHECK_HIP(c, st.counters.resize(N + 1)); PT_CHECK_HIP(c, hipMemsetAsync(st.counters.p, 0, 4 * (size_t)(N + 1), c->stream)); F.perLightCounters = st.counters.p;      // ResetLightProxyCounters
+    const uint totalMaxFeedbackCount = lastFrameFeedbackAvailable ? ((F.W + 7) / 8) * ((F.H + 7) / 8) * 64u : 0u;
+    if (lastFrameFeedbackAvailable) launch_neeat_begin(F, st.snapW.p, st.snapC.p, st.preFilter, totalMaxFeedbackCount, c->stream);
+    PT_CHECK_HIP(c, st.curW.resize(N + 1)); PT_CHECK_HIP(c, st.histW.resize(N));
+    launch_neeat_boost_weights(c->dLightW.p, (lastFrameFeedbackAvailable && st.intensityDeltaMul > 0) ? st.histW.p : nullptr, st.nHist, N, st.intensityDeltaMul, st.curW.p, c->stream);
+    int r = build_light_proxies(c, st.curW.p, lastFrameFeedbackAvailable ? st.counters.p : nullptr, totalMaxFeedbackCount, lastFrameFeedbackAvailable ? st.globalFeedbackWeight : 0.f); if (r != PT_OK) return r;
+    PT_CHECK_HIP(c, hipMemcpyAsync(st.histW.p, st.curW.p, 4 * (size_t)N, hipMemcpyDeviceToDevice, c->stream)); st.nHist = N;
+    st.lastFeedbackAvailable = lastFrameFeedbackAvailable;
+    F.samplingProxyCount = c->numProxies; F.proxies = c->dProxyIndices.p;
+    // ---- UpdateEnd
+    launch_neeat_end(F, c->stream);
+    st.feedbackFilled = true;
+    // what the path tracer binds this frame (the local layer is sampled only once feedback exists: LightsBaker.cpp:1048)
+    c->localResX = F.tilesX; c->localResY = F.tilesY; c->localJitterX = st.jitter[0]; c->localJitterY = st.jitter[1]; c->localMaxLight = 0;
+    c->localRatio = lastFrameFeedbackAvailable ? st.localRatio : 0.f; c->sscThreshold = st.sscThreshold; c->feedbackRequired = true;
+    refresh_scene_view(c);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -531,6 +596,7 @@ int32_t pt_destroy(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    c->neeat.free(); c->dLocalTable.free(); c->dFbWeight.free(); c->dFbCand.free(); c->dSq3.free();
     c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free(); c->dLightW.free(); c->dProxyOffsets.free(); if (c->dScanTemp) (void)hipFree(c->dScanTemp);
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
@@ -696,11 +762,40 @@ int32_t pt_set_local_light_sampling(pt_context* c, const uint32_t* table, uint32
 }
 int32_t pt_get_light_feedback(pt_context* c, uint32_t sample, float* totalWeight, uint32_t* candidates) {
     if (!c || !totalWeight || !candidates) return PT_ERROR_INVALID_ARGUMENT;
-    if (sample >= c->fbSamples) return fail(c, PT_ERROR_NOT_READY, "no feedback for that sample: pt_set_local_light_sampling(temporalFeedback = 1), then pt_render");
+    if (sample >= c->fbSamples) return fail(c, PT_ERROR_NOT_READY, "no feedback for that sample: pt_set_local_light_sampling(temporalFeedback = 1) or pt_set_neeat, then pt_render");
     (void)hipSetDevice(c->device);
     const size_t plane = (size_t)c->width * c->height;
-    PT_CHECK_HIP(c, hipMemcpy(totalWeight, c->dFbWeight.p + plane * sample, 4 * plane, hipMemcpyDeviceToHost));
-    PT_CHECK_HIP(c, hipMemcpy(candidates, c->dFbCand.p + plane * sample, 4 * plane, hipMemcpyDeviceToHost));
+    const float* w = c->neeat.enabled ? c->neeat.fbW.p : c->dFbWeight.p + plane * sample; const uint* cand = c->neeat.enabled ? c->neeat.fbC.p : c->dFbCand.p + plane * sample;
+    PT_CHECK_HIP(c, hipMemcpy(totalWeight, w, 4 * plane, hipMemcpyDeviceToHost));
+    PT_CHECK_HIP(c, hipMemcpy(candidates, cand, 4 * plane, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+int32_t pt_set_neeat(pt_context* c, int32_t enable, float globalTemporalFeedbackWeight, float localToGlobalSampleRatio, float screenSpaceVsWorldSpaceThreshold, int32_t preFilter) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (enable && (!(globalTemporalFeedbackWeight >= 0.f && globalTemporalFeedbackWeight <= 0.95f) || !(localToGlobalSampleRatio >= 0.f && localToGlobalSampleRatio <= 0.95f)))
+        return fail(c, PT_ERROR_INVALID_ARGUMENT, "global feedback weight and local-to-global ratio: 0 .. 0.95 (SampleUI.cpp:747-750)");
+    (void)hipSetDevice(c->device);
+    pt_context::NeeAt& st = c->neeat;
+    if (st.enabled && !enable) {                 // back to the plain global sampler: no local layer, no feedback, the proxy table of the bake
+        c->localResX = c->localResY = c->localJitterX = c->localJitterY = c->localMaxLight = 0; c->localRatio = 0.f; c->feedbackRequired = false; c->lightsDirty = true;
+    }
+    st.enabled = enable != 0; st.globalFeedbackWeight = globalTemporalFeedbackWeight; st.localRatio = localToGlobalSampleRatio; st.sscThreshold = screenSpaceVsWorldSpaceThreshold; st.preFilter = preFilter != 0;
+    refresh_scene_view(c);
+    return PT_OK;
+}
+int32_t pt_neeat_reset(pt_context* c) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->neeat.reset(); return PT_OK; }
+int32_t pt_get_neeat_tables(pt_context* c, uint32_t tilesXY[2], uint32_t jitterXY[2], uint32_t* table, uint32_t tableCapacityWords) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    const pt_context::NeeAt& st = c->neeat;
+    if (!st.enabled || !st.W) return fail(c, PT_ERROR_NOT_READY, "no NEE-AT frame yet: pt_set_neeat, then pt_render");
+    (void)hipSetDevice(c->device);
+    const uint tx = (st.W + 7) / 8 + 1, ty = (st.H + 7) / 8 + 1;
+    if (tilesXY) { tilesXY[0] = tx; tilesXY[1] = ty; }
+    if (jitterXY) { jitterXY[0] = st.jitter[0]; jitterXY[1] = st.jitter[1]; }
+    if (table) {
+        if ((size_t)tableCapacityWords < (size_t)tx * ty * RTXPT_LIGHTING_LOCAL_PROXY_COUNT) return fail(c, PT_ERROR_INVALID_ARGUMENT, "table buffer too small");
+        PT_CHECK_HIP(c, hipMemcpy(table, st.local.p, 4 * (size_t)tx * ty * RTXPT_LIGHTING_LOCAL_PROXY_COUNT, hipMemcpyDeviceToHost));
+    }
     return PT_OK;
 }
 int32_t pt_set_lights(pt_context* c, const ::PolymorphicLightInfo* lights, const ::PolymorphicLightInfoEx* ex, uint32_t n) {
@@ -824,6 +919,22 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     if (!count) return PT_OK;
     (void)hipSetDevice(c->device);
     int r = prepare(c); if (r != PT_OK) return r;
+    if (c->neeat.enabled && c->S.NEEEnabled && c->S.NEEFullSamples != 0u) {      // NEE-AT with the baker in the loop: every sample is a frame — baker passes, then the path tracer
+        if (c->shardCount > 1) return fail(c, PT_ERROR_UNSUPPORTED, "NEE-AT's feedback passes read neighbouring pixels: not with pixel-tile shards");
+        if (count > 1) {
+            PtFrameStats total; memset(&total, 0, sizeof(total));
+            for (uint32_t s = 0; s < count; s++) {
+                PtFrameStats one; r = pt_render(c, first + s, 1, &one); if (r != PT_OK) return r;
+                total.gpuMilliseconds += one.gpuMilliseconds; total.extendRays += one.extendRays; total.shadowRays += one.shadowRays; total.hits += one.hits; total.extendLaunches += one.extendLaunches;
+                total.extendKernelMs += one.extendKernelMs; total.shadeKernelMs += one.shadeKernelMs; total.shadowKernelMs += one.shadowKernelMs;
+                total.nodeVisitsExtend += one.nodeVisitsExtend; total.triTestsExtend += one.triTestsExtend; total.nodeVisitsShadow += one.nodeVisitsShadow; total.triTestsShadow += one.triTestsShadow;
+                if (one.iterations > total.iterations) total.iterations = one.iterations;
+            }
+            if (stats) *stats = total;
+            return PT_OK;
+        }
+        r = neeat_frame(c); if (r != PT_OK) return r;
+    }
     uint numOwned = (uint)c->owned.size();
     if ((unsigned long long)numOwned * count > 0xF0000000ull) return fail(c, PT_ERROR_INVALID_ARGUMENT, "too many paths in one pt_render call");
     uint total = numOwned * count;
@@ -843,8 +954,11 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     if (feedback) {
         if (shadowGroup) return fail(c, PT_ERROR_INVALID_ARGUMENT, "NEE-AT temporal feedback needs NEEFullSamples 1 (the reference's default): the feedback draw of one light sample shifts the random numbers of the next");
         const size_t plane = (size_t)c->width * c->height;
-        PT_CHECK_HIP(c, c->dSq3.resize(c->shadowCapacity)); PT_CHECK_HIP(c, c->dFbWeight.resize(plane * count)); PT_CHECK_HIP(c, c->dFbCand.resize(plane * count));
-        PT_CHECK_HIP(c, hipMemsetAsync(c->dFbWeight.p, 0, 4 * plane * count, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dFbCand.p, 0xFF, 4 * plane * count, c->stream));      // LightFeedbackReservoir::Clear
+        PT_CHECK_HIP(c, c->dSq3.resize(c->shadowCapacity));
+        if (!c->neeat.enabled) {      // (with the baker in the loop the run's own reservoirs are the target: they carry what the Clear pass kept)
+            PT_CHECK_HIP(c, c->dFbWeight.resize(plane * count)); PT_CHECK_HIP(c, c->dFbCand.resize(plane * count));
+            PT_CHECK_HIP(c, hipMemsetAsync(c->dFbWeight.p, 0, 4 * plane * count, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dFbCand.p, 0xFF, 4 * plane * count, c->stream));      // LightFeedbackReservoir::Clear
+        }
         PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     }
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
@@ -871,7 +985,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.pool = PathPool{c->dS0.p + t.base, c->dS1.p + t.base, c->dS2.p + t.base, c->dS3.p + t.base, c->dS4.p + t.base, c->dHit.p + t.base};
         const size_t sbase = (size_t)t.base * shadowPerPath;
         t.sq = ShadowQueue{c->dSq0.p + sbase, c->dSq1.p + sbase, c->dSq2.p + sbase, shadowGroup, nullptr, nullptr, nullptr, 0u, 0u, 0u};
-        if (feedback) { t.sq.q3 = c->dSq3.p + sbase; t.sq.fbTotalWeight = c->dFbWeight.p; t.sq.fbCandidates = c->dFbCand.p; t.sq.fbWidth = c->width; t.sq.fbPlane = c->width * c->height; t.sq.fbSampleFirst = first; }
+        if (feedback) { t.sq.q3 = c->dSq3.p + sbase; t.sq.fbTotalWeight = c->neeat.enabled ? c->neeat.fbW.p : c->dFbWeight.p; t.sq.fbCandidates = c->neeat.enabled ? c->neeat.fbC.p : c->dFbCand.p; t.sq.fbWidth = c->width; t.sq.fbPlane = c->width * c->height; t.sq.fbSampleFirst = first; }
         t.queue[0] = c->dQueue[0].p + t.base; t.queue[1] = c->dQueue[1].p + t.base;
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;

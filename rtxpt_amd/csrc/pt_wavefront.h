@@ -11,6 +11,7 @@
 // Queue appends use one atomic per wave64: ballot -> popcount prefix -> lane-0 atomicAdd -> broadcast.
 #pragma once
 #include "pt_path.h"
+#include "pt_neeat.h"
 #include "pt_tonemap.h"
 #include <hip/hip_runtime.h>
 
@@ -54,7 +55,12 @@ void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, fl
 void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const uint* subInstTriOffset, uint numEmissiveSubInst, uint totalTris, uint lightBase,
                           PolymorphicLightInfo* lights, PolymorphicLightInfoEx* lightsEx, hipStream_t st);
 // light weights (power^0.8), their in-order sum, proxy counts; then (after an exclusive scan of the counts by the caller) the proxy index fill
-void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, float* sum, uint budget, bool uniform, uint maxPerLight, uint* counts, hipStream_t st);
+void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, hipStream_t st);      // ComputeWeight per light
+// weight sum (in light order) + ComputeProxyCounts; usage != null: NEE-AT's feedback term (n + 1 usage counts, the last one = pixels without valid feedback)
+void launch_light_proxy_counts(const float* w, uint n, float* sum, uint budget, bool uniform, uint maxPerLight, uint* counts, const uint* usage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight, hipStream_t st);
+void launch_neeat_boost_weights(const float* base, const float* hist, uint nHist, uint n, float mul, float* cur, hipStream_t st);
+void launch_neeat_begin(const NeeAtFrame& F, float* snapW, uint* snapC, bool preFilter, uint totalThreads, hipStream_t st);
+void launch_neeat_end(const NeeAtFrame& F, hipStream_t st);
 void launch_light_proxy_fill(const uint* counts, const uint* offsets, uint n, uint* proxies, uint capacity, hipStream_t st);
 void launch_tonemap(const float4* accum, uint num, const ToneMapParams& p, uint* outRgba8, hipStream_t st);
 // scratch: 2 * pow2floor(W) * pow2floor(H) floats; *result points at the 1x1 mip inside scratch once the stream has drained

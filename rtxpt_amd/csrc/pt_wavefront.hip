@@ -790,12 +790,57 @@ __global__ void __launch_bounds__(256) k_light_weight_sum(const float* __restric
     }
     if (threadIdx.x == 0) *sum = s;
 }
-__global__ void __launch_bounds__(256) k_light_proxy_counts(const float* __restrict__ w, uint n, const float* __restrict__ sum, uint budget, uint uniform, uint maxPerLight, uint* __restrict__ counts) {
+// usage != null (NEE-AT, last frame left feedback): the weight is pulled towards the number of pixels that asked for the light (pt_neeat.h neeat_feedback_light_weight)
+__global__ void __launch_bounds__(256) k_light_proxy_counts(const float* __restrict__ w, uint n, const float* __restrict__ sum, uint budget, uint uniform, uint maxPerLight, uint* __restrict__ counts,
+                                                            const uint* __restrict__ usage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= n) return;
+    float lightWeight = w[i];
+    if (usage) lightWeight = neeat_feedback_light_weight(lightWeight, usage[i], *sum, totalMaxFeedbackCount, usage[n], globalFeedbackUseWeight);
     uint cnt = 0;
-    if (w[i] > 0) cnt = uniform ? 1u : (uint)ceilf(((float)(budget - n) * w[i]) / *sum);
+    if (lightWeight > 0) cnt = uniform ? 1u : (uint)ceilf(((float)(budget - n) * lightWeight) / *sum);
     counts[i] = cnt < maxPerLight ? cnt : maxPerLight;
 }
+// ComputeWeights of a NEE-AT frame: the baked weight, boosted where the light got brighter than 1.1 x what it weighed last frame (ImportanceBooster, LightsBaker.hlsl:137-147)
+__global__ void __launch_bounds__(256) k_neeat_boost_weights(const float* __restrict__ base, const float* __restrict__ hist, uint nHist, uint n, float mul, float* __restrict__ cur) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= n) return;
+    cur[i] = hist ? neeat_intensity_delta_boost(base[i], i < nHist ? hist[i] : 0.f, mul) : base[i];
+}
+// ---- NEE-AT feedback passes (pt_neeat.h): one thread per pixel / low-resolution pixel / tile; every pass reads what the previous one wrote and writes only its own slot
+__global__ void __launch_bounds__(256) k_neeat_prefilter(NeeAtFrame F, const float* __restrict__ snapW, const uint* __restrict__ snapC) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= F.W * F.H) return;
+    neeat_prefilter_pixel(F, snapW, snapC, (int)(i % F.W), (int)(i / F.W));
+}
+__global__ void __launch_bounds__(256) k_neeat_p0(NeeAtFrame F, uint totalThreads) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0u && totalThreads > F.W * F.H) atomicAdd(&F.perLightCounters[F.totalLightCount], totalThreads - F.W * F.H);      // the dispatch's threads beyond the frame count as "no valid feedback"
+    if (i >= F.W * F.H) return;
+    atomicAdd(&F.perLightCounters[neeat_p0_pixel(F, i % F.W, i / F.W)], 1u);
+}
+__global__ void __launch_bounds__(256) k_neeat_p1a(NeeAtFrame F) { uint i = blockIdx.x * 256u + threadIdx.x; if (i < F.BW * F.BH) neeat_p1a_pixel(F, i % F.BW, i / F.BW); }
+__global__ void __launch_bounds__(256) k_neeat_p1b(NeeAtFrame F) { uint i = blockIdx.x * 256u + threadIdx.x; if (i < F.W * F.H) neeat_p1b_pixel(F, i % F.W, i / F.W); }
+__global__ void __launch_bounds__(64) k_neeat_p2(NeeAtFrame F) { uint i = blockIdx.x * 64u + threadIdx.x; if (i < F.tilesX * F.tilesY) neeat_fill_tile(F, i % F.tilesX, i / F.tilesX); }
+// P3: one 64-lane block per tile. The 128 light indices are sorted in LDS with a bitonic network (compare-exchange pairs as in MiniEngine's Bitonic32PreSortCS, which
+// the reference cites: element `hi` = lane with a one inserted at bit j, partner = hi ^ (first step of a merge ? k - 1 : j)); then every entry finds the ends of its run.
+__global__ void __launch_bounds__(64) k_neeat_p3(NeeAtFrame F) {
+    __shared__ uint key[RTXPT_LIGHTING_LOCAL_PROXY_COUNT];
+    const uint N = RTXPT_LIGHTING_LOCAL_PROXY_COUNT, t = threadIdx.x;
+    uint* tile = F.local + (size_t)blockIdx.x * N;
+    key[t] = UnpackMiniListLight(tile[t]); key[t + N / 2] = UnpackMiniListLight(tile[t + N / 2]);
+    __syncthreads();
+    for (uint k = 2; k <= N; k <<= 1) for (uint j = k / 2; j > 0; j >>= 1) {
+        const uint mask = j - 1u, hi = ((t & ~mask) << 1) | (t & mask) | j, lo = hi ^ (k == 2u * j ? k - 1u : j);
+        const uint a = key[lo], b = key[hi];
+        if (a > b) { key[lo] = b; key[hi] = a; }
+        __syncthreads();
+    }
+    for (uint e = t; e < N; e += N / 2) {
+        const uint v = key[e]; uint l = e, r = e;
+        while (l > 0u && key[l - 1u] == v) l--;
+        while (r + 1u < N && key[r + 1u] == v) r++;
+        tile[e] = PackMiniListLightAndCount(v, r - l + 1u);
+    }
+}
+__global__ void __launch_bounds__(256) k_neeat_clear(NeeAtFrame F) { uint i = blockIdx.x * 256u + threadIdx.x; if (i < F.W * F.H) neeat_clear_pixel(F, i % F.W, i / F.W); }
 // one thread per proxy slot: the light whose [offset, offset + count) range holds the slot (binary search over the scanned offsets)
 __global__ void __launch_bounds__(256) k_light_proxy_fill(const uint* __restrict__ counts, const uint* __restrict__ offsets, uint n, uint* __restrict__ proxies, uint capacity) {
     const uint p = blockIdx.x * 256u + threadIdx.x;
@@ -805,11 +850,39 @@ __global__ void __launch_bounds__(256) k_light_proxy_fill(const uint* __restrict
     while (hi - lo > 1u) { uint mid = (lo + hi) >> 1; if (offsets[mid] <= p) lo = mid; else hi = mid; }
     proxies[p] = lo;
 }
-void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, float* sum, uint budget, bool uniform, uint maxPerLight, uint* counts, hipStream_t st) {
+void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_light_weights, dim3((n + 255) / 256), dim3(256), 0, st, lights, lightsEx, n, w);
+}
+void launch_light_proxy_counts(const float* w, uint n, float* sum, uint budget, bool uniform, uint maxPerLight, uint* counts, const uint* usage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_light_weights, dim3((n + 255) / 256), dim3(256), 0, st, lights, lightsEx, n, w);
     hipLaunchKernelGGL(k_light_weight_sum, dim3(1), dim3(256), 0, st, w, n, sum);
-    hipLaunchKernelGGL(k_light_proxy_counts, dim3((n + 255) / 256), dim3(256), 0, st, w, n, sum, budget, uniform ? 1u : 0u, maxPerLight, counts);
+    hipLaunchKernelGGL(k_light_proxy_counts, dim3((n + 255) / 256), dim3(256), 0, st, w, n, sum, budget, uniform ? 1u : 0u, maxPerLight, counts, usage, totalMaxFeedbackCount, globalFeedbackUseWeight);
+}
+void launch_neeat_boost_weights(const float* base, const float* hist, uint nHist, uint n, float mul, float* cur, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_neeat_boost_weights, dim3((n + 255) / 256), dim3(256), 0, st, base, hist, nHist, n, mul, cur);
+}
+// UpdateBegin's feedback half: PreFilter from a snapshot of the reservoirs (snapW / snapC: W x H scratch), then P0's counts. The counters are expected zeroed (totalLightCount + 1 words).
+void launch_neeat_begin(const NeeAtFrame& F, float* snapW, uint* snapC, bool preFilter, uint totalThreads, hipStream_t st) {
+    const uint px = F.W * F.H;
+    if (preFilter) {
+        (void)hipMemcpyAsync(snapW, F.fbW, 4ull * px, hipMemcpyDeviceToDevice, st); (void)hipMemcpyAsync(snapC, F.fbC, 4ull * px, hipMemcpyDeviceToDevice, st);
+        hipLaunchKernelGGL(k_neeat_prefilter, dim3((px + 255) / 256), dim3(256), 0, st, F, snapW, snapC);
+        if (getenv("MI355PT_NEEAT_DEBUG")) fprintf(stderr, "[neeat] prefilter: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
+    }
+    hipLaunchKernelGGL(k_neeat_p0, dim3((px + 255) / 256), dim3(256), 0, st, F, totalThreads);
+    if (getenv("MI355PT_NEEAT_DEBUG")) fprintf(stderr, "[neeat] p0: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
+}
+// UpdateEnd: blended reservoirs, one candidate per pixel, the tiles (fill, sort + count), and the reservoirs cleared down to what the next frame keeps
+void launch_neeat_end(const NeeAtFrame& F, hipStream_t st) {
+    const uint px = F.W * F.H, bpx = F.BW * F.BH, tiles = F.tilesX * F.tilesY;
+    const bool dbg = getenv("MI355PT_NEEAT_DEBUG") != nullptr;
+#define NEEAT_DBG(what) do { if (dbg) { hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[neeat] %s: %s\n", what, hipGetErrorString(e)); } } while (0)
+    hipLaunchKernelGGL(k_neeat_p1a, dim3((bpx + 255) / 256), dim3(256), 0, st, F); NEEAT_DBG("p1a");
+    hipLaunchKernelGGL(k_neeat_p1b, dim3((px + 255) / 256), dim3(256), 0, st, F); NEEAT_DBG("p1b");
+    hipLaunchKernelGGL(k_neeat_p2, dim3((tiles + 63) / 64), dim3(64), 0, st, F); NEEAT_DBG("p2");
+    hipLaunchKernelGGL(k_neeat_p3, dim3(tiles), dim3(64), 0, st, F); NEEAT_DBG("p3");
+    hipLaunchKernelGGL(k_neeat_clear, dim3((px + 255) / 256), dim3(256), 0, st, F); NEEAT_DBG("clear");
+#undef NEEAT_DBG
 }
 void launch_light_proxy_fill(const uint* counts, const uint* offsets, uint n, uint* proxies, uint capacity, hipStream_t st) {
     if (!n) return;

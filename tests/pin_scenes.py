@@ -264,3 +264,18 @@ def neeat_cases():
 def neeat_table(opts, num_lights, w, h):
     if opts["table_seed"] is None: return None
     return scenes.synthetic_local_light_tables(num_lights, w, h, seed=opts["table_seed"], jitter=opts["jitter"])
+
+
+def neeat_loop_cases():
+    """NEE-AT with the light baker in the loop (pt_set_neeat): name -> (make, settings, w, h, frames, dict(global_feedback_weight, ratio, ssc_threshold, prefilter)).
+    Every frame = LightsBaker's feedback passes, then one sample of the path tracer; the fixtures hold the reference text's output of every frame."""
+    c2 = lambda: scenes.cornell_box("C2")
+    bl = lambda: scenes.bistro_like(scale=0.02, tex_size=128)
+    d = scenes.default_settings
+    dflt = dict(global_feedback_weight=0.75, ratio=0.65, ssc_threshold=0.3, prefilter=True)
+    return {
+        "bistro_like_loop": (bl, d(NEEType=2), 96, 54, 4, dflt),                                                                   # the reference's defaults
+        "c2_sphere_lights_loop_lp16": (with_sphere_lights(c2), d(NEEType=2, useFp16Types=1, fireflyFilterThreshold=2.5), 61, 35, 3, dflt),      # odd frame size: partial tiles, partial low-res pixels
+        "bistro_like_c5_loop_nofilter": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), d(NEEType=2, NEECandidateSamples=3), 96, 54, 3,
+                                         dict(global_feedback_weight=0.3, ratio=0.9, ssc_threshold=0.5, prefilter=False)),
+    }

@@ -1,0 +1,78 @@
+"""NEE-AT with the light baker in the loop, on the device (run with -m gpu): pt_set_neeat.
+
+Every frame = the feedback passes as kernels (k_neeat_*: PreFilter from a snapshot, P0 with atomic usage counts, the proxy table rebuilt with the feedback term, P1a, P1b,
+tile fill, bitonic sort + run lengths in LDS, Clear), then the wavefront path tracer with the deferred feedback insert.
+  * against the REFERENCE TEXT's runs (tests/golden/neeat_loop_golden.npz), every frame: tile tables, jitter, global proxy counters, feedback reservoirs, and the frame;
+  * against the oracle; one pt_render call tracing all frames against frame-by-frame calls; reset / disable."""
+import os, sys
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from rtxpt_amd import scenes
+import pin_scenes
+import make_neeat_loop_golden as loop
+from test_neeat_baker import compare, golden
+
+pytestmark = pytest.mark.gpu
+CASES = pin_scenes.neeat_loop_cases()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_device_run_matches_reference_text(name):
+    want = golden(name)
+    got = loop.run_device(name)
+    assert set(got) == set(want)
+    compare(name, got, want)
+
+
+def test_device_run_matches_oracle():
+    name = "c2_sphere_lights_loop_lp16"
+    compare(name, loop.run_device(name), loop.run_oracle(name, False))
+
+
+@pytest.mark.parametrize("name", ["bistro_like_loop", "bistro_like_c5_loop_nofilter"])
+def test_one_call_equals_frame_by_frame(name):
+    want = golden(name)
+    got = loop.run_device(name, one_call=True)
+    compare(name, got, want, keys=list(got))
+
+
+def test_reset_and_disable():
+    import rtxpt_amd as pt
+    make, S, w, h, frames, opts = CASES["bistro_like_loop"]
+    sc, cam = make()
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h)
+    t.render(0, 1); plain = t.radiance().copy(); t.reset_accumulation()
+    with pytest.raises(Exception): t.neeat_tables()
+    t.set_neeat(True, **opts); t.render(0, 2); first = t.radiance().copy(); t1 = t.neeat_tables()[0].copy(); t.reset_accumulation()
+    t.neeat_reset(); t.render(0, 2)
+    assert np.array_equal(first.view(np.uint32), t.radiance().view(np.uint32)) and np.array_equal(t1, t.neeat_tables()[0])
+    t.reset_accumulation(); t.render(0, 2)
+    assert not np.array_equal(t1, t.neeat_tables()[0])
+    t.set_neeat(False); t.reset_accumulation(); t.render(0, 1)
+    assert np.array_equal(plain.view(np.uint32), t.radiance().view(np.uint32))
+    with pytest.raises(Exception, match="0.95"): t.set_neeat(True, ratio=1.0)
+    S3 = S.copy(); S3["NEEFullSamples"] = 2; t.set_neeat(True, **opts); t.set_settings(S3)
+    with pytest.raises(Exception, match="NEEFullSamples 1"): t.render(0, 1)
+    t.close()
+
+
+def test_full_hd_run_is_sane():
+    """1920 x 1080, 3 frames: the kernels at a size where the tile grid (241 x 136) and the feedback planes are not toys; tables sorted, counts consistent, jitter in range"""
+    import rtxpt_amd as pt
+    sc, cam = scenes.bistro_like(scale=0.05, tex_size=256)
+    S = scenes.default_settings(NEEType=2)
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(1920, 1080, **cam)); t.resize(1920, 1080); t.set_neeat(True)
+    t.render(0, 3)
+    tab, jit = t.neeat_tables(); fw, fc = t.light_feedback(0)
+    n = len(t.lights()["lights"])
+    assert tab.shape == (136, 241, 128) and max(jit) < 8
+    lights, counts = tab >> 9, (tab & 0x1FF) + 1
+    assert lights.max() < n and (np.diff(lights.astype(np.int64), axis=-1) >= 0).all()
+    run_start = np.concatenate([np.ones(lights.shape[:2] + (1,), bool), lights[..., 1:] != lights[..., :-1]], -1)
+    assert (counts[run_start].astype(np.int64).reshape(-1).sum() == 128 * 136 * 241)      # the runs of a tile add up to its 128 entries
+    assert (fw > 0).mean() > 0.5 and ((fc != 0xFFFFFFFF) == (fw > 0)).all() and (fc[fc != 0xFFFFFFFF] & 0x7FFFFFFF).max() < n
+    assert np.isfinite(t.radiance()).all() and t.radiance()[..., :3].mean() > 0
+    t.close()
