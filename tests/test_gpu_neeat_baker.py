@@ -76,3 +76,26 @@ def test_full_hd_run_is_sane():
     assert (fw > 0).mean() > 0.5 and ((fc != 0xFFFFFFFF) == (fw > 0)).all() and (fc[fc != 0xFFFFFFFF] & 0x7FFFFFFF).max() < n
     assert np.isfinite(t.radiance()).all() and t.radiance()[..., :3].mean() > 0
     t.close()
+
+
+@pytest.mark.parametrize("w,h,frames", [(640, 360, 3), (1440, 810, 2)], ids=["640x360", "1440x810_pipelined_batches"])
+def test_device_run_matches_oracle_at_size(w, h, frames):
+    """The same run on the oracle and on the device at sizes where the device works with thousands of tiles, atomics under contention and (1440 x 810: 1.17 M paths) several
+    sub-frame batches on their own streams writing one set of feedback reservoirs: tile tables, jitter, proxy counters, reservoirs and the accumulated frame, bit for bit."""
+    import rtxpt_amd as pt
+    from oracle import ptref
+    sc, cam = scenes.bistro_like(scale=0.05, tex_size=128)
+    S = scenes.default_settings(NEEType=2, useFp16Types=1)
+    camd = scenes.bridge_camera(w, h, **cam)
+    o = ptref.Oracle(lp16=True); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.set_neeat(True)
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(camd); t.resize(w, h); t.set_neeat(True)
+    for f in range(frames):
+        o.render(f, 1); t.render(f, 1)
+        to, jo, pco = o.neeat_tables(); td, jd = t.neeat_tables()
+        assert jo == jd and np.array_equal(to, td), "frame %d: tile tables" % f
+        assert np.array_equal(pco, t.lights()["proxyCounters"]), "frame %d: global proxy counters" % f
+        (wo, co), (wd, cd) = o.light_feedback(0), t.light_feedback(0)
+        assert np.array_equal(wo.view(np.uint32), wd.view(np.uint32)) and np.array_equal(co, cd), "frame %d: feedback reservoirs" % f
+    bad = (o.radiance().view(np.uint32) != t.radiance().view(np.uint32)).any(-1)
+    assert not bad.any(), "%d of %d pixels differ" % (int(bad.sum()), bad.size)
+    t.close()
