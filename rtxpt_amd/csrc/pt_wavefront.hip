@@ -810,23 +810,37 @@ __global__ void __launch_bounds__(256) k_neeat_prefilter(NeeAtFrame F, const flo
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= F.W * F.H) return;
     neeat_prefilter_pixel(F, snapW, snapC, (int)(i % F.W), (int)(i / F.W));
 }
-// P0's counts: neighbouring pixels mostly ask for the same few lights, and same-address atomics serialise in the L2 — the lanes of a wave that count the same light are merged
-// first (the reference does the same with WaveMatch, LightsBaker.hlsl:1287-1305): one atomic per distinct light and wave
-__global__ void __launch_bounds__(256) k_neeat_p0(NeeAtFrame F, uint totalThreads) {
-    const uint i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
-    if (i == 0u && totalThreads > F.W * F.H) atomicAdd(&F.perLightCounters[F.totalLightCount], totalThreads - F.W * F.H);      // the dispatch's threads beyond the frame count as "no valid feedback"
-    const uint NONE = 0xFFFFFFFFu;
-    // a wave covers an 8 x 8 pixel block (not 64 pixels of a row): neighbours in both directions share their lights, fewer distinct values to merge
-    const uint blocksX = (F.W + 7u) / 8u, wave = i >> 6, px = (wave % blocksX) * 8u + (lane & 7u), py = (wave / blocksX) * 8u + (lane >> 3);
+// P0's counts: neighbouring pixels mostly ask for the same few lights, and same-address atomics serialise in the L2. Two merges before anything reaches memory (the
+// reference merges equal lanes with WaveMatch, LightsBaker.hlsl:1287-1305): the lanes of a wave (an 8 x 8 pixel block) that count the same light become one entry, and the
+// sixteen waves of a block (32 x 32 pixels) add their entries into a small LDS hash table that is flushed once — one global atomic per distinct light and 32 x 32 pixels.
+static const uint NEEAT_P0_TABLE = 512u;      // LDS hash slots per block (a full table falls back to a global atomic per entry)
+__global__ void __launch_bounds__(1024) k_neeat_p0(NeeAtFrame F, uint totalThreads) {
+    __shared__ uint hKey[NEEAT_P0_TABLE]; __shared__ uint hCnt[NEEAT_P0_TABLE];
+    const uint NONE = 0xFFFFFFFFu, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint k = threadIdx.x; k < NEEAT_P0_TABLE; k += 1024u) { hKey[k] = NONE; hCnt[k] = 0u; }
+    if (blockIdx.x == 0u && threadIdx.x == 0u && totalThreads > F.W * F.H) atomicAdd(&F.perLightCounters[F.totalLightCount], totalThreads - F.W * F.H);      // the dispatch's threads beyond the frame count as "no valid feedback"
+    __syncthreads();
+    const uint regionsX = (F.W + 31u) / 32u;
+    const uint px = (blockIdx.x % regionsX) * 32u + (wave & 3u) * 8u + (lane & 7u), py = (blockIdx.x / regionsX) * 32u + (wave >> 2) * 8u + (lane >> 3);
     const uint slot = (px < F.W && py < F.H) ? neeat_p0_pixel(F, px, py) : NONE;
     unsigned long long active = __builtin_amdgcn_ballot_w64(slot != NONE);
     while (active) {
         const uint leader = (uint)__builtin_ctzll(active);
         const uint v = (uint)__builtin_amdgcn_readlane((int)slot, (int)leader);
         const unsigned long long same = __builtin_amdgcn_ballot_w64(slot == v);
-        if (lane == leader) atomicAdd(&F.perLightCounters[v], (uint)__popcll(same));
+        if (lane == leader) {
+            const uint n = (uint)__popcll(same);
+            uint h = (v * 2654435761u) >> 23; bool placed = false;                 // 9-bit multiplicative hash, linear probing
+            for (uint probe = 0; probe < 16u && !placed; probe++, h = (h + 1u) & (NEEAT_P0_TABLE - 1u)) {
+                const uint prev = atomicCAS(&hKey[h], NONE, v);
+                if (prev == NONE || prev == v) { atomicAdd(&hCnt[h], n); placed = true; }
+            }
+            if (!placed) atomicAdd(&F.perLightCounters[v], n);
+        }
         active &= ~same;
     }
+    __syncthreads();
+    for (uint k = threadIdx.x; k < NEEAT_P0_TABLE; k += 1024u) if (hKey[k] != NONE) atomicAdd(&F.perLightCounters[hKey[k]], hCnt[k]);
 }
 __global__ void __launch_bounds__(256) k_neeat_p1a(NeeAtFrame F) { uint i = blockIdx.x * 256u + threadIdx.x; if (i < F.BW * F.BH) neeat_p1a_pixel(F, i % F.BW, i / F.BW); }
 __global__ void __launch_bounds__(256) k_neeat_p1b(NeeAtFrame F) { uint i = blockIdx.x * 256u + threadIdx.x; if (i < F.W * F.H) neeat_p1b_pixel(F, i % F.W, i / F.W); }
@@ -881,7 +895,7 @@ void launch_neeat_begin(const NeeAtFrame& F, float* snapW, uint* snapC, bool pre
         hipLaunchKernelGGL(k_neeat_prefilter, dim3((px + 255) / 256), dim3(256), 0, st, F, snapW, snapC);
         if (getenv("MI355PT_NEEAT_DEBUG")) fprintf(stderr, "[neeat] prefilter: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
     }
-    hipLaunchKernelGGL(k_neeat_p0, dim3((((F.W + 7) / 8) * ((F.H + 7) / 8) * 64 + 255) / 256), dim3(256), 0, st, F, totalThreads);
+    hipLaunchKernelGGL(k_neeat_p0, dim3(((F.W + 31) / 32) * ((F.H + 31) / 32)), dim3(1024), 0, st, F, totalThreads);
     if (getenv("MI355PT_NEEAT_DEBUG")) fprintf(stderr, "[neeat] p0: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
 }
 // UpdateEnd: blended reservoirs, one candidate per pixel, the tiles (fill, sort + count), and the reservoirs cleared down to what the next frame keeps

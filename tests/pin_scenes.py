@@ -256,6 +256,9 @@ def neeat_cases():
         "c2_sphere_lights_neeat_feedback_only": (with_sphere_lights(c2), d(NEEType=2, fireflyFilterThreshold=2.5), 64, 36, 2, 2, dict(table_seed=None, jitter=(0, 0), ratio=0.65, ssc_threshold=0.3, feedback=True)),
         # every vertex screen-space coherent (threshold above any cone-width ratio), no Russian roulette, one candidate sample (all global: (1 - 1) * ratio + 0.75 -> 0)
         "bistro_like_c5_neeat_all_ssc": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), d(NEEType=2, enableRussianRoulette=0, NEECandidateSamples=1), 96, 54, 0, 2, dict(table_seed=8, jitter=(1, 1), ratio=0.65, ssc_threshold=1e9, feedback=True)),
+        # a mesh standing in for an analytic light (SphereLight::Eval on hit, MIS with both samplers' pdfs), rotated tinted environment at MIP 2, NEEFullSamples 2 without feedback
+        "c2_sphere_light_proxy_neeat_nee2": (with_rotated_environment(with_light_proxy(with_sphere_lights(c2))), d(NEEType=2, NEEFullSamples=2, envMapDiffuseSampleMIPLevel=2.0), 64, 36, 4, 2,
+                                             dict(table_seed=11, jitter=(5, 2), ratio=0.65, ssc_threshold=0.3, feedback=False)),
         # no vertex coherent (threshold 0): the table is bound but never sampled; many candidates
         "bistro_like_neeat_none_ssc": (bl, d(NEEType=2, NEECandidateSamples=9), 96, 54, 3, 1, dict(table_seed=9, jitter=(2, 6), ratio=0.5, ssc_threshold=0.0, feedback=True)),
     }

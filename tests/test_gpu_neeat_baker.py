@@ -99,3 +99,10 @@ def test_device_run_matches_oracle_at_size(w, h, frames):
     bad = (o.radiance().view(np.uint32) != t.radiance().view(np.uint32)).any(-1)
     assert not bad.any(), "%d of %d pixels differ" % (int(bad.sum()), bad.size)
     t.close()
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 2), (8, 8), (9, 17), (33, 5)], ids=["1x1", "3x2", "8x8", "9x17", "33x5"])
+def test_tiny_frames_device_matches_oracle(w, h):
+    from test_neeat_baker import _tiny_run
+    a, b = _tiny_run("device", w, h), _tiny_run("oracle", w, h)
+    for f, (x, y) in enumerate(zip(a, b)): compare("%dx%d frame %d" % (w, h, f), x, y)

@@ -80,3 +80,32 @@ def test_reset_and_disable():
     assert not np.array_equal(t1, o.neeat_tables()[0])
     o.set_neeat(False); o.reset_accumulation(); o.render(0, 1)               # off: the plain global sampler again
     assert np.array_equal(plain.view(np.uint32), o.radiance().view(np.uint32))
+
+
+def _tiny_run(kind, w, h, frames=4):
+    """kind: 'oracle' | 'reference' | 'device'. Cornell box C2 at frame sizes around and below one tile (8 x 8) and one low-resolution pixel (2 x 2)."""
+    sc, cam = scenes.cornell_box("C2"); S = scenes.default_settings(NEEType=2); camd = scenes.bridge_camera(w, h, **cam)
+    if kind == "device":
+        import rtxpt_amd as pt
+        t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(camd); t.resize(w, h); t.set_neeat(True)
+    else:
+        from oracle import ptref
+        t = ptref.Oracle(reference_integrator=(kind == "reference"), settings=S); t.set_scene(sc); t.set_camera(camd); t.set_settings(S); t.resize(w, h); t.set_neeat(True)
+    out = []
+    for f in range(frames):
+        t.render(f, 1); tab = t.neeat_tables(); fw, fc = t.light_feedback(0)
+        out.append(dict(radiance=t.radiance().copy(), table=tab[0], jitter=np.array(tab[1], np.uint32), fbw=fw, fbc=fc, counters=t.lights()["proxyCounters"]))
+    t.close()
+    return out
+
+
+TINY = [(1, 1), (3, 2), (8, 8), (9, 17), (33, 5)]
+
+
+@pytest.mark.parametrize("w,h", TINY, ids=["%dx%d" % s for s in TINY])
+def test_tiny_frames_oracle_matches_live_reference_text(w, h):
+    """Mirror coordinates, clamped neighbourhoods, partial tiles and a jittered grid larger than the frame: the restatement against the text where the edge handling is everything"""
+    if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
+        pytest.skip("no /root/reference on this machine")
+    a, b = _tiny_run("oracle", w, h), _tiny_run("reference", w, h)
+    for f, (x, y) in enumerate(zip(a, b)): compare("%dx%d frame %d" % (w, h, f), x, y)
