@@ -595,6 +595,10 @@ extern "C++" {
 template <class Passes> static void neeat_frame(Context* c, Passes& P) {
     NeeAtState& st = c->neeat; Scene& sc = c->sc;
     const uint N = (uint)sc.lights.size();
+    if (!N || sc.proxyIndices.empty()) {            // nothing to sample: NEE does not run, the frame is traced without a local layer
+        sc.localTable.clear(); sc.localResX = sc.localResY = 0; sc.localRatio = 0.f; sc.feedbackRequired = false; st.feedbackFilled = st.lastFeedbackAvailable = false; sc.bindLocalSampling(); return;
+    }
+    if (st.historicTotalLightCount && st.historicTotalLightCount != N) st.feedbackFilled = st.lastFeedbackAvailable = false;      // another light set: its indices mean nothing to the old reservoirs and tiles
     if (st.W != c->w || st.H != c->h) {             // (re)create the textures: LightsBaker::CreateRenderPasses (LightsBaker.cpp:300-345)
         st.W = c->w; st.H = c->h; const size_t px = (size_t)st.W * st.H, bpx = (size_t)((st.W + 1) / 2) * ((st.H + 1) / 2), tiles = (size_t)((st.W + 7) / 8 + 1) * ((st.H + 7) / 8 + 1);
         st.fbW.assign(px, 0.f); st.fbC.assign(px, 0xFFFFFFFFu); st.scW.assign(px, 0.f); st.scC.assign(px, 0xFFFFFFFFu); st.blW.assign(bpx, 0.f); st.blC.assign(bpx, 0xFFFFFFFFu);
@@ -662,7 +666,7 @@ void ptref_render_rect(void* h, uint32_t first, uint32_t n, uint32_t x0, uint32_
         c->ctr.extendRays += total.extendRays; c->ctr.shadowRays += total.shadowRays; c->ctr.hits += total.hits; c->ctr.nodeVisitsExt += total.nodeVisitsExt;
         c->ctr.triTestsExt += total.triTestsExt; c->ctr.nodeVisitsSh += total.nodeVisitsSh; c->ctr.triTestsSh += total.triTestsSh;
         c->accumCount++;
-        if (c->neeat.enabled && c->fbSamples) { const size_t plane = (size_t)c->w * c->h;      // a copy per frame, for the tests
+        if (c->neeat.enabled && c->fbSamples && c->neeat.fbW.size() == (size_t)c->w * c->h) { const size_t plane = (size_t)c->w * c->h;      // a copy per frame, for the tests
             memcpy(c->fbWeight.data() + plane * s, c->neeat.fbW.data(), 4 * plane); memcpy(c->fbCand.data() + plane * s, c->neeat.fbC.data(), 4 * plane); }
     }
 }

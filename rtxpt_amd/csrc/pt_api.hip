@@ -521,7 +521,11 @@ int ensure_pool(pt_context* c, uint n, uint shadowPerPath) {      // shadowPerPa
 int neeat_frame(pt_context* c) {
     pt_context::NeeAt& st = c->neeat;
     const uint N = (uint)c->lights.size();
-    if (!N) return fail(c, PT_ERROR_NOT_READY, "NEE-AT needs lights (an environment, emissive triangles or analytic lights)");
+    if (!N || !c->numProxies) {                     // nothing to sample (no lights, or all of them dark): NEE does not run (LightSampler::IsEmpty), the frame is traced without a local layer
+        c->localResX = c->localResY = c->localJitterX = c->localJitterY = c->localMaxLight = 0; c->localRatio = 0.f; c->feedbackRequired = false; st.feedbackFilled = st.lastFeedbackAvailable = false;
+        refresh_scene_view(c); return PT_OK;
+    }
+    if (st.historicTotalLightCount && st.historicTotalLightCount != N) st.feedbackFilled = st.lastFeedbackAvailable = false;      // another light set: its indices mean nothing to the old reservoirs and tiles
     NeeAtFrame F; memset(&F, 0, sizeof(F));
     F.W = c->width; F.H = c->height; F.BW = (F.W + 1) / 2; F.BH = (F.H + 1) / 2; F.tilesX = (F.W + 7) / 8 + 1; F.tilesY = (F.H + 7) / 8 + 1;
     const size_t px = (size_t)F.W * F.H, bpx = (size_t)F.BW * F.BH, tiles = (size_t)F.tilesX * F.tilesY;
@@ -741,6 +745,7 @@ int32_t pt_set_environment_compression(pt_context* c, uint32_t quality) {
 int32_t pt_set_local_light_sampling(pt_context* c, const uint32_t* table, uint32_t resX, uint32_t resY, uint32_t jitterX, uint32_t jitterY, float localToGlobalSampleRatio,
                                     float screenSpaceVsWorldSpaceThreshold, int32_t temporalFeedback) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (c->neeat.enabled) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_set_neeat is on: the baker in the loop writes the tile tables itself (pt_set_neeat(ctx, 0, ...) first)");
     (void)hipSetDevice(c->device);
     const uint N = ptk::RTXPT_LIGHTING_LOCAL_PROXY_COUNT, TILE_PX = ptk::RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE;
     if (!(localToGlobalSampleRatio >= 0.f && localToGlobalSampleRatio <= 0.95f)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "LocalToGlobalSampleRatio: 0 .. 0.95 (SampleUI.cpp:750)");

@@ -106,3 +106,29 @@ def test_tiny_frames_device_matches_oracle(w, h):
     from test_neeat_baker import _tiny_run
     a, b = _tiny_run("device", w, h), _tiny_run("oracle", w, h)
     for f, (x, y) in enumerate(zip(a, b)): compare("%dx%d frame %d" % (w, h, f), x, y)
+
+
+def test_edge_states():
+    """No lights at all (NEE cannot run: the frames equal the plain ones and nothing is read from tables that do not exist); the manual table setter is refused while the
+    baker runs the loop; a different light set (here: the analytic lights removed) restarts the feedback history instead of reading stale indices."""
+    import rtxpt_amd as pt
+    sc, cam = scenes.cornell_box("C1"); sc = dict(sc); sc["env"] = None
+    dark = dict(sc); m = sc["materials"].copy(); m["EmissiveColor"][:] = 0; dark["materials"] = m
+    S = scenes.config_settings("C1").copy(); S["NEEType"] = 2
+    t = pt.PathTracer(); t.set_scene(dark); t.set_settings(S); t.set_camera(scenes.bridge_camera(48, 48, **cam)); t.resize(48, 48)
+    if len(t.lights()["lights"]) == 0:
+        t.render(0, 2); plain = t.radiance().copy(); t.reset_accumulation()
+        t.set_neeat(True); t.render(0, 2)
+        assert np.array_equal(plain.view(np.uint32), t.radiance().view(np.uint32))
+    t.close()
+    make, S2, w, h, frames, opts = CASES["c2_sphere_lights_loop_lp16"]
+    sc2, cam2 = make()
+    t = pt.PathTracer(); t.set_scene(sc2); t.set_settings(S2); t.set_camera(scenes.bridge_camera(w, h, **cam2)); t.resize(w, h); t.set_neeat(True, **opts)
+    t.render(0, 2)
+    with pytest.raises(Exception, match="pt_set_neeat is on"): t.set_local_light_sampling(np.zeros((6, 9, 128), np.uint32))
+    n0 = len(t.lights()["lights"])
+    sc3 = dict(sc2); sc3["lights"] = (sc2["lights"][0][:1], sc2["lights"][1][:1]); t.set_scene(sc3)      # fewer analytic lights: another light set
+    t.render(2, 2)
+    n1 = len(t.lights()["lights"]); assert n1 < n0
+    tab, _ = t.neeat_tables(); assert (tab >> 9).max() < n1 and np.isfinite(t.radiance()).all()
+    t.close()
