@@ -132,3 +132,28 @@ def test_edge_states():
     n1 = len(t.lights()["lights"]); assert n1 < n0
     tab, _ = t.neeat_tables(); assert (tab >> 9).max() < n1 and np.isfinite(t.radiance()).all()
     t.close()
+
+
+def test_animated_run_keeps_its_history():
+    """NEE-AT across animated frames (C5's seam: pt_animate -> refit + emissive re-bake between frames): the light set keeps its order, so the reservoirs and tiles of the last
+    frame stay meaningful — device (refit, device-side re-bake) == oracle (instances set, everything rebuilt) on every frame."""
+    import rtxpt_amd as pt
+    from oracle import ptref
+    sc, cam = scenes.bistro_like(scale=0.01, tex_size=64, animated=True)
+    S = scenes.default_settings(NEEType=2, nestedDielectricsQuality=2); w, h = 128, 72
+    camd = scenes.bridge_camera(w, h, **cam)
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(camd); t.resize(w, h); t.set_neeat(True)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.set_neeat(True)
+    filled = []
+    for f in range(4):
+        inst = scenes.animate_instances(sc, 0.35 * f)
+        t.animate(instances=inst, rebuild=False); o.set_instances(inst); o.reset_accumulation()      # (pt_animate restarts the accumulation, as any scene change does in reference mode)
+        t.render(f, 1); o.render(f, 1)
+        (td, jd), (to, jo, pco) = t.neeat_tables(), o.neeat_tables()
+        assert jd == jo and np.array_equal(td, to) and np.array_equal(pco, t.lights()["proxyCounters"]), "frame %d" % f
+        (wd, cd), (wo, co) = t.light_feedback(0), o.light_feedback(0)
+        assert np.array_equal(wd.view(np.uint32), wo.view(np.uint32)) and np.array_equal(cd, co), "frame %d: reservoirs" % f
+        filled.append(int((wd > 0).sum()))
+    assert filled[-1] > filled[0]                      # the history carried over the animated frames (a restart would look like frame 0 again)
+    assert np.array_equal(t.radiance().view(np.uint32), o.radiance().view(np.uint32))
+    t.close()
