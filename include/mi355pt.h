@@ -262,6 +262,13 @@ int32_t pt_get_light_feedback(pt_context* ctx, uint32_t sample, float* totalWeig
 int32_t pt_set_neeat(pt_context* ctx, int32_t enable, float globalTemporalFeedbackWeight, float localToGlobalSampleRatio, float screenSpaceVsWorldSpaceThreshold, int32_t preFilter);
 int32_t pt_neeat_reset(pt_context* ctx);                                                      /* LightsBaker::BakeSettings::ResetFeedback */
 int32_t pt_get_neeat_tables(pt_context* ctx, uint32_t tilesXY[2], uint32_t jitterXY[2], uint32_t* table, uint32_t tableCapacityWords);
+/* Tile-sharded frames (PtDeviceDesc.shardCount > 1; no reference analogue): a rank traces and feeds back for its own pixels, the baker's passes read whole neighbourhoods, so
+ * between two frames every rank needs the other ranks' reservoirs (8 bytes per pixel) and then runs the same deterministic passes as everybody else — same tables and proxy
+ * counts on every rank, the same as the unsharded run. With a communicator (pt_comm_init) pt_render does the exchange itself (RCCL point-to-point in one group, un-padded, on
+ * the library's stream). Without one the host moves the buffers after every frame: pt_neeat_pack_feedback (the rank's own pixels, pt_pack_shard's order, device memory) ->
+ * the host's transport -> pt_neeat_unpack_feedback(rank r's buffer, r) on every other rank, before their next pt_render. */
+int32_t pt_neeat_pack_feedback(pt_context* ctx, void* dstDevice, size_t bytes);
+int32_t pt_neeat_unpack_feedback(pt_context* ctx, const void* srcDevice, size_t bytes, uint32_t rank);
 
 /* BridgeCamera (PathTracerShared.h:109-141) */
 int32_t pt_bridge_camera(uint32_t viewportWidth, uint32_t viewportHeight, const float camPos[3], const float camDir[3], const float camUp[3], float fovY,

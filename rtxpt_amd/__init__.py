@@ -26,7 +26,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 # every symbol include/mi355pt.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_positions", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
-    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_neeat_reset", "pt_get_neeat_tables", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_neeat_reset", "pt_get_neeat_tables", "pt_neeat_pack_feedback", "pt_neeat_unpack_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
@@ -656,6 +656,14 @@ class PathTracer:
         t = np.zeros((int(txy[1]), int(txy[0]), 128), np.uint32)
         self._chk(self.L.pt_get_neeat_tables(self.h, None, None, _p(t), t.size), "pt_get_neeat_tables")
         return t, (int(jxy[0]), int(jxy[1]))
+
+    def neeat_pack_feedback(self, device_ptr, nbytes):
+        self.L.pt_neeat_pack_feedback.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self._chk(self.L.pt_neeat_pack_feedback(self.h, ctypes.c_void_p(device_ptr), nbytes), "pt_neeat_pack_feedback")
+
+    def neeat_unpack_feedback(self, device_ptr, nbytes, rank):
+        self.L.pt_neeat_unpack_feedback.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+        self._chk(self.L.pt_neeat_unpack_feedback(self.h, ctypes.c_void_p(device_ptr), nbytes, rank), "pt_neeat_unpack_feedback")
 
     def light_feedback(self, sample=0):
         """the feedback reservoirs sample `sample` of the last render() call filled: (total weight float32 [H, W], candidate uint32 [H, W])"""

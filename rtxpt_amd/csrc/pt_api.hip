@@ -97,8 +97,9 @@ struct pt_context {
         uint updateCounter = 0; float jitterF[2] = {0, 0}; uint jitter[2] = {0, 0}, prevJitter[2] = {0, 0};
         bool feedbackFilled = false, lastFeedbackAvailable = false; uint historicTotalLightCount = 0, W = 0, H = 0, nHist = 0;
         DevBuf<float> fbW, scW, blW, snapW, curW, histW; DevBuf<uint> fbC, scC, blC, snapC, local, counters;
+        DevBuf<ptk::uint2> xSend, xRecv; DevBuf<uint> xPixels; uint xW = 0, xH = 0;      // tile-sharded frames: the exchange of the owned pixels' reservoirs between frames
         void reset() { updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
-        void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); }
+        void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); xSend.free(); xRecv.free(); xPixels.free(); }
     } neeat;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
@@ -516,6 +517,35 @@ int ensure_pool(pt_context* c, uint n, uint shadowPerPath) {      // shadowPerPa
     return PT_OK;
 }
 
+// Tile-sharded frames (pt_create with shardCount > 1): a rank traces, and feeds back for, its own pixels only, but the baker's passes read whole neighbourhoods. Between two
+// frames every rank therefore receives the other ranks' reservoirs (8 bytes per pixel: 66 MB for a 4K frame) and then runs the same deterministic passes on the same
+// planes as everybody else: identical tables and proxy counts on all ranks, identical to the unsharded run. With a communicator (pt_comm_init) the exchange is RCCL point-to-point
+// inside one group, un-padded like pt_gather; without one the host moves the packed buffers (pt_neeat_pack_feedback / pt_neeat_unpack_feedback).
+int neeat_exchange_feedback(pt_context* c) {
+    pt_context::NeeAt& st = c->neeat;
+    if (c->shardCount == 1 || !c->comm || !st.feedbackFilled || st.W != c->width || st.H != c->height) return PT_OK;
+    hipStream_t s = c->stream;
+    if (st.xW != c->width || st.xH != c->height) {
+        std::vector<uint> others; for (uint r = 0; r < c->shardCount; r++) if (r != c->shardRank) others.insert(others.end(), c->shardPixels[r].begin(), c->shardPixels[r].end());
+        PT_CHECK_HIP(c, st.xPixels.upload(others, s)); PT_CHECK_HIP(c, st.xRecv.resize(others.size())); PT_CHECK_HIP(c, st.xSend.resize(c->owned.size())); PT_CHECK_HIP(c, hipStreamSynchronize(s));
+        st.xW = c->width; st.xH = c->height;
+    }
+    const size_t n = c->owned.size();
+    launch_pack_feedback(st.fbW.p, st.fbC.p, c->dOwned.p, (uint)n, c->width, st.xSend.p, s);
+    PT_CHECK_NCCL(c, g_rccl.GroupStart());
+    size_t off = 0; ncclResult_t bad = ncclSuccess;
+    for (uint r = 0; r < c->shardCount && bad == ncclSuccess; r++) {
+        if (r == c->shardRank) continue;
+        const size_t m = c->shardPixels[r].size();
+        if (n) bad = g_rccl.Send(st.xSend.p, 2 * n, ncclFloat, (int)r, c->comm, s);
+        if (m && bad == ncclSuccess) bad = g_rccl.Recv(st.xRecv.p + off, 2 * m, ncclFloat, (int)r, c->comm, s);
+        off += m;
+    }
+    ncclResult_t ge = g_rccl.GroupEnd();
+    if (bad != ncclSuccess || ge != ncclSuccess) return fail(c, PT_ERROR_HIP, std::string("NEE-AT feedback exchange: ") + g_rccl.GetErrorString(bad != ncclSuccess ? bad : ge));
+    launch_unpack_feedback(st.fbW.p, st.fbC.p, st.xPixels.p, (uint)off, c->width, st.xRecv.p, s);
+    return PT_OK;
+}
 // One frame of LightsBaker::UpdateBegin + UpdateEnd for the NEE-AT layer (LightsBaker.cpp:943-962, 985-1075, 1186-1213, 1335-1420) ahead of the frame's path tracing; the
 // order and the constants are spelled out in pt_neeat.h. The light set is the baked one; what changes per frame is the global proxy table, the tile tables and the jitter.
 int neeat_frame(pt_context* c) {
@@ -788,6 +818,28 @@ int32_t pt_set_neeat(pt_context* c, int32_t enable, float globalTemporalFeedback
     refresh_scene_view(c);
     return PT_OK;
 }
+// the owned pixels' reservoirs as (weight bits, candidate) pairs, 8 bytes per pixel in the order of the rank's pixel list — pt_pack_shard's order; device pointers
+int32_t pt_neeat_pack_feedback(pt_context* c, void* dst, size_t bytes) {
+    if (!c || !dst) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->neeat.enabled || !c->neeat.W || c->neeat.W != c->width || c->neeat.H != c->height) return fail(c, PT_ERROR_NOT_READY, "no NEE-AT frame yet: pt_set_neeat, then pt_render");
+    if (bytes < c->owned.size() * 8) return fail(c, PT_ERROR_INVALID_ARGUMENT, "destination too small");
+    (void)hipSetDevice(c->device);
+    launch_pack_feedback(c->neeat.fbW.p, c->neeat.fbC.p, c->dOwned.p, (uint)c->owned.size(), c->width, (ptk::uint2*)dst, c->stream);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+int32_t pt_neeat_unpack_feedback(pt_context* c, const void* src, size_t bytes, uint32_t rank) {
+    if (!c || !src || rank >= c->shardCount) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->neeat.enabled || !c->neeat.W || c->neeat.W != c->width || c->neeat.H != c->height) return fail(c, PT_ERROR_NOT_READY, "no NEE-AT frame yet: pt_set_neeat, then pt_render");
+    const std::vector<uint>& px = c->shardPixels[rank];
+    if (bytes < px.size() * 8) return fail(c, PT_ERROR_INVALID_ARGUMENT, "source too small");
+    (void)hipSetDevice(c->device);
+    DevBuf<uint> tmp; PT_CHECK_HIP(c, tmp.upload(px, c->stream));
+    launch_unpack_feedback(c->neeat.fbW.p, c->neeat.fbC.p, tmp.p, (uint)px.size(), c->width, (const ptk::uint2*)src, c->stream);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    tmp.free();
+    return PT_OK;
+}
 int32_t pt_neeat_reset(pt_context* c) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->neeat.reset(); return PT_OK; }
 int32_t pt_get_neeat_tables(pt_context* c, uint32_t tilesXY[2], uint32_t jitterXY[2], uint32_t* table, uint32_t tableCapacityWords) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
@@ -925,7 +977,6 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     (void)hipSetDevice(c->device);
     int r = prepare(c); if (r != PT_OK) return r;
     if (c->neeat.enabled && c->S.NEEEnabled && c->S.NEEFullSamples != 0u) {      // NEE-AT with the baker in the loop: every sample is a frame — baker passes, then the path tracer
-        if (c->shardCount > 1) return fail(c, PT_ERROR_UNSUPPORTED, "NEE-AT's feedback passes read neighbouring pixels: not with pixel-tile shards");
         if (count > 1) {
             PtFrameStats total; memset(&total, 0, sizeof(total));
             for (uint32_t s = 0; s < count; s++) {
@@ -938,6 +989,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (stats) *stats = total;
             return PT_OK;
         }
+        r = neeat_exchange_feedback(c); if (r != PT_OK) return r;      // (tile shards with a communicator; a host without one exchanges through pt_neeat_pack / unpack_feedback)
         r = neeat_frame(c); if (r != PT_OK) return r;
     }
     uint numOwned = (uint)c->owned.size();

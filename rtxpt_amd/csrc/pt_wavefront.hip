@@ -757,6 +757,21 @@ void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, ui
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_probe, dim3(grid_for(n, T8_BLOCK, T8_MAX_BLOCKS)), dim3(T8_BLOCK), 0, st, sc, rays, n, outClosest, outVisible, overflow);
 }
+// the NEE-AT feedback reservoirs of a list of pixels as (weight bits, candidate) pairs: what the ranks of a tile-sharded frame exchange between frames
+__global__ void __launch_bounds__(256) k_pack_feedback(const float* __restrict__ fbW, const uint* __restrict__ fbC, const uint* __restrict__ pixels, uint num, uint width, uint2* __restrict__ dst) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= num) return;
+    const uint px = pixels[i], slot = (px & 0xFFFFu) * width + (px >> 16); dst[i] = make_uint2(__float_as_uint(fbW[slot]), fbC[slot]);
+}
+__global__ void __launch_bounds__(256) k_unpack_feedback(float* __restrict__ fbW, uint* __restrict__ fbC, const uint* __restrict__ pixels, uint num, uint width, const uint2* __restrict__ src) {
+    uint i = blockIdx.x * 256u + threadIdx.x; if (i >= num) return;
+    const uint px = pixels[i], slot = (px & 0xFFFFu) * width + (px >> 16); fbW[slot] = __uint_as_float(src[i].x); fbC[slot] = src[i].y;
+}
+void launch_pack_feedback(const float* fbW, const uint* fbC, const uint* pixels, uint num, uint width, uint2* dst, hipStream_t st) {
+    if (num) hipLaunchKernelGGL(k_pack_feedback, dim3((num + 255) / 256), dim3(256), 0, st, fbW, fbC, pixels, num, width, dst);
+}
+void launch_unpack_feedback(float* fbW, uint* fbC, const uint* pixels, uint num, uint width, const uint2* src, hipStream_t st) {
+    if (num) hipLaunchKernelGGL(k_unpack_feedback, dim3((num + 255) / 256), dim3(256), 0, st, fbW, fbC, pixels, num, width, src);
+}
 void launch_pack(const float4* accum, const uint* pixels, uint num, uint width, float4* dst, hipStream_t st) {
     hipLaunchKernelGGL(k_pack, dim3((num + 255) / 256), dim3(256), 0, st, accum, pixels, num, width, dst);
 }

@@ -157,3 +157,38 @@ def test_animated_run_keeps_its_history():
     assert filled[-1] > filled[0]                      # the history carried over the animated frames (a restart would look like frame 0 again)
     assert np.array_equal(t.radiance().view(np.uint32), o.radiance().view(np.uint32))
     t.close()
+
+
+def test_tile_sharded_run_equals_the_unsharded_run():
+    """Three ranks of a tile-sharded frame on one device, the host moving the packed reservoirs between frames (pt_neeat_pack_feedback -> pt_neeat_unpack_feedback; with a
+    communicator pt_render does the same through RCCL): every rank ends up with the unsharded run's tile tables, proxy counters and reservoirs on every frame, and the
+    gathered frame is the unsharded frame."""
+    import torch
+    import rtxpt_amd as pt
+    sc, cam = scenes.bistro_like(scale=0.02, tex_size=128)
+    S = scenes.default_settings(NEEType=2, useFp16Types=1); w, h, frames, world = 200, 120, 3, 3
+    camd = scenes.bridge_camera(w, h, **cam)
+    def ctx(rank, count):
+        t = pt.PathTracer(shard_rank=rank, shard_count=count); t.set_scene(sc); t.set_settings(S); t.set_camera(camd); t.resize(w, h); t.set_neeat(True); return t
+    one = ctx(0, 1); ranks = [ctx(r, world) for r in range(world)]
+    owned = [r.shard_info() for r in ranks]
+    assert sum(n for n, _ in owned) == w * h
+    for f in range(frames):
+        one.render(f, 1)
+        for r in ranks: r.render(f, 1)
+        bufs = []
+        for r, (n, _) in zip(ranks, owned):
+            b = torch.empty((n, 2), dtype=torch.int32, device="cuda"); r.neeat_pack_feedback(b.data_ptr(), 8 * n); bufs.append(b)
+        for i, r in enumerate(ranks):
+            for j in range(world):
+                if j != i: r.neeat_unpack_feedback(bufs[j].data_ptr(), 8 * owned[j][0], j)
+        t1, j1 = one.neeat_tables(); w1, c1 = one.light_feedback(0); p1 = one.lights()["proxyCounters"]
+        for i, r in enumerate(ranks):
+            tr, jr = r.neeat_tables(); wr, cr = r.light_feedback(0)
+            assert jr == j1 and np.array_equal(tr, t1) and np.array_equal(r.lights()["proxyCounters"], p1), "frame %d rank %d: tables / counters" % (f, i)
+            assert np.array_equal(wr.view(np.uint32), w1.view(np.uint32)) and np.array_equal(cr, c1), "frame %d rank %d: reservoirs" % (f, i)
+    for j in range(1, world):            # the frame gather: ranks 1.. into rank 0
+        n, nbytes = owned[j]; b = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        ranks[j].pack_shard(b.data_ptr(), nbytes); ranks[0].unpack_shard(b.data_ptr(), nbytes, j)
+    assert np.array_equal(ranks[0].radiance().view(np.uint32), one.radiance().view(np.uint32))
+    for t in ranks + [one]: t.close()
