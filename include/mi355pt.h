@@ -480,6 +480,9 @@ typedef struct PtTransport {
     int32_t (*group_end)(void* user);                                               /* may be NULL */
 } PtTransport;
 int32_t pt_gather_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* rgba, const PtTransport* transport);
+/* the NEE-AT feedback exchange of tile-sharded frames over HOST memory and the same transport: totalWeight / candidates are this rank's full width x height planes
+ * (only its own tiles need to be valid); on return every rank holds every rank's reservoirs. Pairs of ranks meet in rank order, the lower one sends first. */
+int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* totalWeight, uint32_t* candidates, const PtTransport* transport);
 
 /* --- probes used by the parity tests and bench.py (not part of the reference seam) --------------------------------- */
 /* closest-hit / any-hit queries through the same BVH + kernels the renderer uses. rays: n x 8 floats (o.xyz,tmin,d.xyz,tmax);

@@ -34,7 +34,7 @@ EXPORTS = [
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
-    "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host",
+    "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host", "pt_neeat_exchange_host",
 ]
 
 
@@ -230,6 +230,24 @@ def gather_host(width, height, rank, world, rgba, send, recv):
     if r != 0:
         raise PtError(r, "pt_gather_host")
     return rgba
+
+
+def neeat_exchange_host(width, height, rank, world, total_weight, candidates, send, recv):
+    """pt_neeat_exchange_host: all ranks end up with all ranks' feedback reservoirs; (h, w) float32 / uint32 planes, modified in place; send / recv as in gather_host"""
+    L = load_library()
+    assert total_weight.dtype == np.float32 and candidates.dtype == np.uint32 and total_weight.shape == candidates.shape == (height, width)
+
+    def _wrap(fn):
+        def cb(user, buf, nbytes, peer):
+            try:
+                fn(buf, nbytes, peer); return 0
+            except Exception:
+                import traceback; traceback.print_exc(); return 1
+        return cb
+    t = PtTransport(None, PtTransport.SEND(_wrap(send)), PtTransport.RECV(_wrap(recv)), PtTransport.GROUP(), PtTransport.GROUP())
+    r = L.pt_neeat_exchange_host(width, height, rank, world, _p(total_weight), _p(candidates), ctypes.byref(t))
+    if r != 0:
+        raise PtError(r, "pt_neeat_exchange_host")
 
 
 def load_library():

@@ -1382,6 +1382,30 @@ int32_t pt_gather(pt_context* c) {
     if (total) launch_unpack(c->dAccum.p, c->dGatherPixels.p, (uint)total, c->width, c->dGatherRecv.p, st);
     return PT_OK;
 }
+// The NEE-AT feedback exchange of tile-sharded frames (neeat_exchange_feedback) over HOST memory and the caller's transport: every rank sends the reservoirs of its own
+// pixels to every other rank and receives theirs. Pairs meet in rank order (the lower rank sends first), so blocking transports cannot deadlock.
+int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* totalWeight, uint32_t* candidates, const PtTransport* t) {
+    if (!totalWeight || !candidates || !t || !t->send || !t->recv || !width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
+    if (world == 1) return PT_OK;
+    try {
+        std::vector<std::vector<uint>> lists; shard_pixel_lists(width, height, world, lists);
+        auto slot = [&](uint px) { return (size_t)(px & 0xFFFFu) * width + (px >> 16); };
+        const std::vector<uint>& mine = lists[rank];
+        std::vector<uint> sendbuf(2 * mine.size()), recvbuf;
+        for (size_t i = 0; i < mine.size(); i++) { memcpy(&sendbuf[2 * i], &totalWeight[slot(mine[i])], 4); sendbuf[2 * i + 1] = candidates[slot(mine[i])]; }
+        for (uint p = 0; p < world; p++) {
+            if (p == rank) continue;
+            recvbuf.resize(2 * lists[p].size());
+            for (int step = 0; step < 2; step++) {
+                const bool sendNow = (rank < p) == (step == 0);
+                if (sendNow) { if (!mine.empty() && t->send(t->user, sendbuf.data(), 8 * mine.size(), p) != 0) return PT_ERROR_IO; }
+                else if (!lists[p].empty() && t->recv(t->user, recvbuf.data(), 8 * lists[p].size(), p) != 0) return PT_ERROR_IO;
+            }
+            for (size_t i = 0; i < lists[p].size(); i++) { memcpy(&totalWeight[slot(lists[p][i])], &recvbuf[2 * i], 4); candidates[slot(lists[p][i])] = recvbuf[2 * i + 1]; }
+        }
+        return PT_OK;
+    } catch (...) { return PT_ERROR_IO; }
+}
 int32_t pt_gather_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* rgba, const PtTransport* t) {
     if (!rgba || !t || !t->send || !t->recv || !width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
     if (world == 1) return PT_OK;

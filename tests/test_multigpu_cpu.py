@@ -83,3 +83,41 @@ def test_shards_partition_the_frame(world):
         sizes.append(px.size)
     assert np.all(seen == 1)
     assert max(sizes) - min(sizes) <= 2 * 32 * 32          # interleaved tiles balance the pixel counts
+
+
+def _neeat_worker(rank, world, port, w, h, q):
+    """NEE-AT on tile-sharded frames: between two frames every rank needs every rank's feedback reservoirs (pt_neeat_exchange_host = the protocol pt_render runs over RCCL)."""
+    import ctypes
+    import rtxpt_amd as pt
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    px = pt.shard_layout(w, h, rank, world); yy, xx = (px & 0xFFFF).astype(np.int64), (px >> 16).astype(np.int64)
+    weight = np.full((h, w), -3.0, np.float32); cand = np.full((h, w), 0xDEADBEEF, np.uint32)          # poison outside the owned tiles
+    weight[yy, xx] = (xx * 0.25 + yy).astype(np.float32); cand[yy, xx] = (xx * 7919 + yy * 104729).astype(np.uint32) | np.uint32(0x80000000) * (xx & 1).astype(np.uint32)
+    sent = []
+
+    def send(ptr, nbytes, peer):
+        t = torch.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=torch.uint8).clone(); sent.append((peer, nbytes)); dist.send(t, dst=peer)
+
+    def recv(ptr, nbytes, peer):
+        t = torch.empty(nbytes, dtype=torch.uint8); dist.recv(t, src=peer); ctypes.memmove(ptr, t.data_ptr(), nbytes)
+    pt.neeat_exchange_host(w, h, rank, world, weight, cand, send, recv)
+    assert sorted(sent) == [(p, 8 * px.size) for p in range(world) if p != rank]      # its own pixels, un-padded, once to every other rank
+    q.put((rank, weight, cand))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("size,world", [((100, 70), 2), ((200, 120), 3)])
+def test_neeat_feedback_exchange_through_the_c_entry_point(size, world):
+    w, h = size
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_neeat_worker, args=(r, world, port, w, h, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    want_w = (xx * 0.25 + yy).astype(np.float32); want_c = (xx * 7919 + yy * 104729).astype(np.uint32) | np.uint32(0x80000000) * (xx & 1).astype(np.uint32)
+    for rank, weight, cand in got:
+        assert np.array_equal(weight, want_w) and np.array_equal(cand, want_c), "rank %d" % rank
