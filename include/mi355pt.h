@@ -239,6 +239,12 @@ void pt_procedural_sky_default_params(PtProceduralSkyParams* out);
 int32_t pt_procedural_sky_update(PtProceduralSkyState* state, const PtProceduralSkyParams* params, double sceneTime, const char* preset, int32_t forceInstantUpdate, PtProceduralSkyConstants* out);
 /* analytic lights already converted by the host (LightsBaker.cpp:456-556 ConvertLight); emissive triangles are baked automatically */
 int32_t pt_set_lights(pt_context* ctx, const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint32_t numLights);
+/* The frustum term of LightsBaker's ImportanceBooster (Rtxpt/Lighting/LightsBaker.hlsl:108-136, LightsBaker.cpp:884-925 UpdateFrustumConsts; on by default in the reference for every
+ * NEEType: LightsBaker.h:247-249, multiplier 8, fade distance 5): a light inside the camera frustum weighs 1 + mul times as much in the global proxy table, one within the fade distance
+ * of it proportionally less, environment lights half the boost. viewProjRowMajor16 is the matrix the reference hands its baker — BakeSettings::ViewProjMatrix =
+ * IView::GetViewProjectionMatrix() of Donut (row vectors: clip = p * M); NULL or mul 0 turns the term off (the state after pt_create). Call it whenever the camera moves:
+ * only the weights and the proxy table are rebuilt (0.2 ms), not the lights. */
+int32_t pt_set_light_importance_boost(pt_context* ctx, const float* viewProjRowMajor16, float frustumMul, float frustumFadeDistance);
 /* NEE-AT, the path tracer's side (NEEType 2; Rtxpt/Shaders/PathTracer/Lighting/LightSampler.hlsli:51-93,120-180,184-200,242-268,318-332,411-420, PathTracerNEE.hlsli:88-161,
  * 199-273). Replaces the bindings t_LightLocalSamplingBuffer (t17), u_LightFeedbackTotalWeight (u20), u_LightFeedbackCandidates (u21) of Sample.cpp:2338-2342 and the
  * LightingControlData fields LocalSamplingTileJitter / LocalSamplingResolution / LocalToGlobalSampleRatio / ScreenSpaceVsWorldSpaceThreshold / TemporalFeedbackRequired

@@ -240,6 +240,33 @@ def lightbake_probe(kind, words, pyramid=None, color_mul=(1.0, 1.0, 1.0), distan
 _PIN_MAT = os.path.join(os.path.dirname(_PIN), "librefpin_mat.so")
 
 
+def frustum_planes(view_proj, reference=False):
+    """LightsBaker::UpdateFrustumConsts' five normalised clip planes of a row-vector view-projection matrix (float32 [5, 4]); reference=True: the reference's C++ text
+    (librefpin_mat.so), otherwise the oracle's restatement (neeat.h light_frustum_planes_from_viewproj). None when the reference library is unavailable."""
+    m = np.ascontiguousarray(view_proj, np.float32).reshape(16); out = np.zeros((5, 4), np.float32)
+    if reference:
+        if not os.path.exists(_PIN_MAT):
+            if os.path.isdir("/root/reference/Rtxpt/Shaders"): build()
+            if not os.path.exists(_PIN_MAT): return None
+        ctypes.CDLL(_PIN_MAT).reflight_frustum_planes(_p(m), _p(out))
+    else:
+        lib().ptref_frustum_planes(_p(m), _p(out))
+    return out
+
+
+def importance_boost(lights12, planes, mul, fade, weights, hist=None, delta_mul=0.0, reference=False):
+    """LightsBaker.hlsl ImportanceBooster on n lights (uint32 [n, 12]: PolymorphicLightInfo + Ex): frustum term with the given planes, then the intensity-delta term against
+    last frame's weights `hist` (None: off). reference=True: the reference's text (librefpin_pt), otherwise the oracle's restatement."""
+    l = np.ascontiguousarray(lights12, np.uint32).reshape(-1, 12); pl = np.ascontiguousarray(planes, np.float32).reshape(20); wt = np.ascontiguousarray(weights, np.float32)
+    h = None if hist is None else np.ascontiguousarray(hist, np.float32); out = np.zeros(len(l), np.float32)
+    L = refpin_pt() if reference else lib()
+    if L is None: return None
+    f = L.refpt_importance_boost if reference else L.ptref_importance_boost
+    f.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]; f.restype = None
+    f(len(l), _p(l), _p(pl), float(mul), float(fade), float(delta_mul), _p(h), _p(wt), _p(out))
+    return out
+
+
 def reference_material_from_json(text, textures):
     """The reference's PTMaterial::Read + FillData (Rtxpt/Materials/MaterialsBaker.cpp, compiled as it stands: oracle/refpin/mat_stubs.h) on one
     `.material.json` document. textures: {file name: packed texture word} = what the texture cache could load. Returns (128 bytes PTMaterialData,
@@ -456,6 +483,13 @@ class Oracle:
         w = np.zeros((self.h_, self.w), np.float32); c = np.zeros((self.h_, self.w), np.uint32)
         if not self.L.ptref_get_light_feedback(self.h, int(sample), _p(w), _p(c)): raise RuntimeError("no feedback for that sample")
         return w, c
+
+    def set_light_importance_boost(self, view_proj=None, mul=8.0, fade_distance=5.0):
+        """ImportanceBooster's frustum term; view_proj: the host's 4 x 4 view-projection matrix (row vectors: clip = p @ M) or None (off)"""
+        import ctypes
+        f = self.L.ptref_set_light_importance_boost; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float]; f.restype = None
+        m = None if view_proj is None else np.ascontiguousarray(view_proj, np.float32).reshape(16)
+        f(self.h, _p(m), float(mul), float(fade_distance))
 
     def set_neeat(self, enable=True, global_feedback_weight=0.75, ratio=0.65, ssc_threshold=0.3, prefilter=True):
         """NEE-AT with the baker in the loop: every sample of render() is a frame (feedback passes, then the path tracer)"""

@@ -360,14 +360,14 @@ void bake_lights(Scene& sc, bool neeEnabled, uint importanceSamplingType) {
                 sc.lights.push_back(lf.Base); sc.lightsEx.push_back(lf.Extended);
             }
         }
-        // weights (LightsBaker.hlsl:738-751, 836-878; no frustum boost) — the proxies follow in build_light_proxies
+        // weights (LightsBaker.hlsl:738-751, 836-878, 118-136) — the proxies follow in build_light_proxies
         uint N = (uint)sc.lights.size();
         sc.lightWeights.assign(N, 0.f);
         for (uint i = 0; i < N; i++) {
             PolymorphicLightInfoFull lf; lf.Base = sc.lights[i]; lf.Extended = sc.lightsEx[i];
             float wt = light_weight(lf);
             if (!(wt == wt)) wt = 0;                    // (a NaN flux cannot pass `lightWeight > 0` in ComputeProxyCounts either)
-            sc.lightWeights[i] = wt;
+            sc.lightWeights[i] = light_importance_frustum_boost(sc.lightBoost, lf, wt);      // ImportanceBooster, frustum term (off unless a view-projection matrix was supplied)
         }
         build_light_proxies(sc, importanceSamplingType, sc.lightWeights, nullptr, 0, 0.f);
     } else bind_light_table(sc);
@@ -677,6 +677,23 @@ void ptref_set_neeat(void* h, int enable, float globalFeedbackWeight, float loca
     if (st.enabled && !enable) { Scene& sc = c->sc; sc.localTable.clear(); sc.localResX = sc.localResY = 0; sc.localRatio = 0; sc.feedbackRequired = false; sc.bindLocalSampling(); c->lightsDirty = true; }
     st.enabled = enable != 0; st.globalFeedbackWeight = globalFeedbackWeight; st.localRatio = localToGlobalRatio; st.sscThreshold = sscThreshold; st.preFilter = preFilter != 0;
 }
+// ImportanceBooster's frustum term: the host's view-projection matrix (row-vector convention, 16 floats row-major; null: off), LightsBaker.h:247-249 defaults mul 8, fade 5
+void ptref_set_light_importance_boost(void* h, const float* viewProj16, float mul, float fadeDistance) {
+    Context* c = (Context*)h; LightFrustumBoost b; memset(&b, 0, sizeof(b));
+    if (viewProj16 && mul > 0) { light_frustum_planes_from_viewproj(viewProj16, b.planes); b.mul = mul; b.fadeDistance = fadeDistance; }
+    c->sc.lightBoost = b; c->lightsDirty = true;
+}
+// probes for the pins: ImportanceBooster (frustum term, then intensity delta) on n lights, and UpdateFrustumConsts' planes
+void ptref_importance_boost(uint32_t n, const uint32_t* lights12, const float* planes20, float mul, float fade, float intensityDeltaMul, const float* hist, const float* unboosted, float* out) {
+    LightFrustumBoost b; memcpy(b.planes, planes20, sizeof(b.planes)); b.mul = mul; b.fadeDistance = fade;
+    for (uint32_t i = 0; i < n; i++) {
+        PolymorphicLightInfoFull lf; memcpy(&lf.Base, lights12 + 12 * i, 32); memcpy(&lf.Extended, lights12 + 12 * i + 8, 16);
+        float wt = light_importance_frustum_boost(b, lf, unboosted[i]);
+        if (hist && intensityDeltaMul > 0) wt = neeat_intensity_delta_boost(wt, hist[i], intensityDeltaMul);
+        out[i] = wt;
+    }
+}
+void ptref_frustum_planes(const float* m16, float* out20) { float p[5][4]; light_frustum_planes_from_viewproj(m16, p); memcpy(out20, p, sizeof(p)); }
 void ptref_neeat_reset(void* h) { ((Context*)h)->neeat.reset(); }
 // the tile tables and the jitter the last frame was traced with, and the global proxy counters
 int ptref_neeat_get_tables(void* h, uint32_t* tilesXY, uint32_t* jitterXY, uint32_t* table, uint32_t* proxyCounters) {

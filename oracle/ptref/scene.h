@@ -14,6 +14,7 @@
 #include <functional>
 #include <cstdio>
 #include "lights.h"
+#include "neeat.h"
 #include "envcube.h"
 #include "sky.h"
 #include <vector>
@@ -178,7 +179,7 @@ struct Scene {
     std::vector<PolymorphicLightInfo> lights; std::vector<PolymorphicLightInfoEx> lightsEx;
     std::vector<uint> proxyCounters, proxyIndices, envLookup; uint envLookupDim; std::vector<float> lightWeights;      // lightWeights: ComputeWeight per light, kept for the per-frame proxy rebuild of NEE-AT
     std::vector<PolymorphicLightInfoFull> analyticLights;   // supplied by the host (pt_set_lights)
-    LightTable lightTable;
+    LightTable lightTable; LightFrustumBoost lightBoost = {};      // lightBoost: ImportanceBooster's frustum term (mul 0: off)
     // NEE-AT inputs (ptref_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback switch
     std::vector<uint> localTable; uint localResX = 0, localResY = 0, localJitterX = 0, localJitterY = 0; float localRatio = 0.f, sscThreshold = 0.f; bool feedbackRequired = false;
     void bindLocalSampling() {

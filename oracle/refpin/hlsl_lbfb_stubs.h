@@ -24,7 +24,7 @@ static LightsBakerConstants g_bakerConstants;      // (LightingControlData carri
 #define g_controlInfo u_controlBuffer[0]
 static RWTexture2D<float> u_feedbackTotalWeight, u_feedbackTotalWeightScratch, u_feedbackTotalWeightBlended, u_historyDepth;
 static RWTexture2D<uint> u_feedbackCandidates, u_feedbackCandidatesScratch, u_feedbackCandidatesBlended;
-static RWBuffer<uint> u_perLightProxyCounters, u_lightSamplingProxies, u_localSamplingBuffer, u_historyRemapPastToCurrent;
+static RWBuffer<uint> u_perLightProxyCounters, u_lightSamplingProxies, u_localSamplingBuffer, u_historyRemapPastToCurrent, u_historyRemapCurrentToPast; static RWBuffer<float> u_lightWeights;
 struct PinDepth { float operator[](int2) const { return 1.0f; } float operator[](uint2) const { return 1.0f; } };
 struct PinMotion { float3 operator[](int2) const { return float3(0, 0, 0); } };
 static PinDepth t_depthBuffer; static PinMotion t_motionVectors;

@@ -282,7 +282,7 @@ def main_pt(ref):
     ltext = re.sub(r"\b(RTXPT_NEEAT_EARLY_FEEDBACK_TILE_SIZE|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE)\.xx\b", r"int2(\1,\1)", ltext)
     w("// ======== LightsBaker.hlsl (NEE-AT feedback passes)\nnamespace lbfb {\n")
     w('#include "%s/hlsl_lbfb_stubs.h"\n' % HERE)
-    for name in ("RemapPastToCurrent",):
+    for name in ("RemapPastToCurrent", "DistanceFromFrustum", "ImportanceBooster"):
         for body in extract_function(ltext, name, "LightsBaker.hlsl"): w(to_cpp(body) + "\n")
     w(to_cpp(extract_struct(ltext, "LocalReservoir", "LightsBaker.hlsl")) + "\n")
     w("groupshared LocalReservoir g_tile[32][32];\n")
@@ -317,6 +317,16 @@ def main_materials(ref):
     lb = strip_comments(open(os.path.join(ref, "Rtxpt/Lighting/LightsBaker.cpp"), encoding="latin-1").read())
     for name in ("floatToUInt", "FLOAT3_to_R8G8B8_UNORM", "packLightColor", "OctWrap", "Encode_Oct", "NDirToOctUnorm32", "fp32ToFp16", "ConvertLight"):
         for body in extract_function(lb, name, "LightsBaker.cpp"): w(body + "\n")
+    # LightsBaker::UpdateFrustumConsts: the plane extraction and normalisation (its text between the declaration of frustPlanes and the far plane), over Donut vector stand-ins
+    lbraw = open(os.path.join(ref, "Rtxpt/Lighting/LightsBaker.cpp"), encoding="latin-1").read()
+    w("namespace frustumpin {\nstruct float3 { float x, y, z; };\nstruct float4 { float x, y, z, w; float4() : x(0), y(0), z(0), w(0) {} float4(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}\n"
+      "    float3 xyz() const { return float3{x, y, z}; } float4 operator*(float s) const { return float4(x * s, y * s, z * s, w * s); } };\n"
+      "static inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }\n"
+      "struct Column { const float* m; int c; float operator[](int row) const { return m[4 * row + c]; } };\nstruct Matrix { const float* m; Column col(int c) const { return Column{m, c}; } };\nstruct Settings { Matrix ViewProjMatrix; };\n"
+      "static void planes(const float* m16, float* out20) {\n    Settings settings{Matrix{m16}};\n")
+    w(extract_range(lb, r"float4 frustPlanes\[6\];..// compute far plane", "LightsBaker.cpp", lbraw) + "\n")
+    w("    for (int i = 0; i < 5; i++) { out20[4 * i] = frustPlanes[i].x; out20[4 * i + 1] = frustPlanes[i].y; out20[4 * i + 2] = frustPlanes[i].z; out20[4 * i + 3] = frustPlanes[i].w; }\n}\n} // namespace frustumpin\n"
+      'extern "C" void reflight_frustum_planes(const float* m16, float* out20) { frustumpin::planes(m16, out20); }\n')
     w(open(os.path.join(HERE, "mat_wrappers.inc")).read())
     # ToneMapper host side: ColorUtils.h whole + the two ToneMappingPass members that build the colour transform, over Donut math stand-ins
     w(open(os.path.join(HERE, "color_stubs.inc")).read())

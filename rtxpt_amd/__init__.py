@@ -26,7 +26,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 # every symbol include/mi355pt.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_positions", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
-    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_neeat_reset", "pt_get_neeat_tables", "pt_neeat_pack_feedback", "pt_neeat_unpack_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_light_importance_boost", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_neeat_reset", "pt_get_neeat_tables", "pt_neeat_pack_feedback", "pt_neeat_unpack_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
@@ -659,6 +659,12 @@ class PathTracer:
         t = np.ascontiguousarray(table, np.uint32)
         if t.ndim != 3 or t.shape[2] != 128: raise ValueError("local sampling table: uint32 [tilesY, tilesX, 128]")
         self._chk(f(self.h, _p(t), t.shape[1], t.shape[0], int(jitter[0]), int(jitter[1]), float(ratio), float(ssc_threshold), 1 if feedback else 0), "pt_set_local_light_sampling")
+
+    def set_light_importance_boost(self, view_proj=None, mul=8.0, fade_distance=5.0):
+        """pt_set_light_importance_boost: the frustum term of LightsBaker's ImportanceBooster; view_proj: the host's 4 x 4 view-projection matrix (row vectors: clip = p @ M) or None (off)"""
+        f = self.L.pt_set_light_importance_boost; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float]; f.restype = ctypes.c_int32
+        m = None if view_proj is None else np.ascontiguousarray(view_proj, np.float32).reshape(16)
+        self._chk(f(self.h, _p(m), float(mul), float(fade_distance)), "pt_set_light_importance_boost")
 
     def set_neeat(self, enable=True, global_feedback_weight=0.75, ratio=0.65, ssc_threshold=0.3, prefilter=True):
         """NEE-AT with the light baker in the loop (pt_set_neeat): every sample of render() becomes a frame — feedback passes, then the path tracer"""

@@ -91,6 +91,7 @@ struct pt_context {
     // NEE-AT (pt_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback reservoirs of the last pt_render call (one plane per sample)
     DevBuf<uint> dLocalTable; uint localResX = 0, localResY = 0, localJitterX = 0, localJitterY = 0, localMaxLight = 0; float localRatio = 0.f, sscThreshold = 0.f; bool feedbackRequired = false;
     DevBuf<float> dFbWeight; DevBuf<uint> dFbCand; DevBuf<ptk::float4> dSq3; uint fbSamples = 0;
+    ptk::LightFrustumBoost lightBoost = {}; bool weightsDirty = false;      // pt_set_light_importance_boost: ImportanceBooster's frustum term (mul 0: off)
     // NEE-AT with the baker in the loop (pt_set_neeat): what LightsBaker keeps between frames (LightsBaker.h:225-260) and the textures / buffers its feedback passes bind
     struct NeeAt {
         bool enabled = false; float globalFeedbackWeight = 0.75f, localRatio = 0.65f, sscThreshold = 0.3f, dropoff = 0.005f, intensityDeltaMul = 64.0f; bool preFilter = true;
@@ -460,7 +461,7 @@ int bake_lights(pt_context* c, bool geometryOnly = false) {
             const size_t proxyCapacity = (size_t)budget + N;                       // sum of ceil((budget - N) w_i / W) <= budget - N + N
             (void)budget; (void)proxyCapacity;
             PT_CHECK_HIP(c, c->dLightW.resize(N + 1));
-            launch_light_weights(c->dLights.p, c->dLightsEx.p, N, c->dLightW.p, c->stream);
+            launch_light_weights(c->dLights.p, c->dLightsEx.p, N, c->dLightW.p, c->lightBoost, c->stream);
             int pr = build_light_proxies(c, c->dLightW.p, nullptr, 0u, 0.f); if (pr != PT_OK) return pr;
         }
     } else { PT_CHECK_HIP(c, c->dLights.resize(1)); PT_CHECK_HIP(c, c->dLightsEx.resize(1)); }
@@ -501,6 +502,12 @@ int prepare(pt_context* c) {
     if (c->envEnabled && c->envCubeDirty) { int r = bake_env_cube(c); if (r != PT_OK) return r; }
     if (c->geomDirty) { int r = finalize_geometry(c); if (r != PT_OK) return r; }
     if (c->lightsDirty) { int r = bake_lights(c); if (r != PT_OK) return r; }
+    else if (c->weightsDirty && !c->lights.empty()) {      // the camera moved under a frustum boost: weights and proxies only (the lights themselves do not depend on it)
+        launch_light_weights(c->dLights.p, c->dLightsEx.p, (uint)c->lights.size(), c->dLightW.p, c->lightBoost, c->stream);
+        int r = build_light_proxies(c, c->dLightW.p, nullptr, 0u, 0.f); if (r != PT_OK) return r;
+        refresh_scene_view(c);
+    }
+    c->weightsDirty = false;
     return PT_OK;
 }
 int ensure_pool(pt_context* c, uint n, uint shadowPerPath) {      // shadowPerPath: shadow-queue entries a path vertex may emit (NEEFullSamples)
@@ -853,6 +860,14 @@ int32_t pt_get_neeat_tables(pt_context* c, uint32_t tilesXY[2], uint32_t jitterX
         if ((size_t)tableCapacityWords < (size_t)tx * ty * RTXPT_LIGHTING_LOCAL_PROXY_COUNT) return fail(c, PT_ERROR_INVALID_ARGUMENT, "table buffer too small");
         PT_CHECK_HIP(c, hipMemcpy(table, st.local.p, 4 * (size_t)tx * ty * RTXPT_LIGHTING_LOCAL_PROXY_COUNT, hipMemcpyDeviceToHost));
     }
+    return PT_OK;
+}
+int32_t pt_set_light_importance_boost(pt_context* c, const float* viewProjRowMajor16, float frustumMul, float frustumFadeDistance) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (viewProjRowMajor16 && !(frustumMul >= 0.f && frustumFadeDistance >= 0.f)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "frustum boost: multiplier and fade distance must not be negative");
+    ptk::LightFrustumBoost b; memset(&b, 0, sizeof(b));
+    if (viewProjRowMajor16 && frustumMul > 0.f) { ptk::light_frustum_planes_from_viewproj(viewProjRowMajor16, b.planes); b.mul = frustumMul; b.fadeDistance = frustumFadeDistance; }
+    if (memcmp(&b, &c->lightBoost, sizeof(b)) != 0) { c->lightBoost = b; c->weightsDirty = true; }
     return PT_OK;
 }
 int32_t pt_set_lights(pt_context* c, const ::PolymorphicLightInfo* lights, const ::PolymorphicLightInfoEx* ex, uint32_t n) {

@@ -225,6 +225,43 @@ static inline float neeat_feedback_light_weight(float lightWeight, uint usageCou
     float feedbackWeight = (float)usageCount * weightSum / denom;
     return lightWeight + (feedbackWeight - lightWeight) * globalFeedbackUseWeight;                   // lerp
 }
+// ImportanceBooster's first term (LightsBaker.hlsl:108-136; LightsBaker.h:247-249: on by default, mul 8, fade distance 5) for EVERY NEEType: a light inside the camera
+// frustum weighs 1 + mul times as much, one within the fade distance of it proportionally less; environment lights have no position and get half the boost. The five
+// planes (left, right, top, bottom, near; normalised, inside = dot(p, n) - w > 0) come from the host's view-projection matrix (light_frustum_planes_from_viewproj).
+struct LightFrustumBoost { float planes[5][4]; float mul, fadeDistance; };      // mul 0: off
+static inline float light_distance_from_frustum(const LightFrustumBoost& B, float3 position) {
+    float distMin = 0;
+    for (int i = 0; i < 5; i++) {
+        float dist = dot(position, make_float3(B.planes[i][0], B.planes[i][1], B.planes[i][2])) - B.planes[i][3];
+        distMin = fminf_(distMin, dist);
+    }
+    return fmaxf_(0.f, -distMin);
+}
+static inline float light_importance_frustum_boost(const LightFrustumBoost& B, const PolymorphicLightInfoFull& light, float unboostedWeight) {
+    float boostedWeight = unboostedWeight;
+    if (B.mul > 0) {
+        float boostK = 0;
+        const uint type = DecodeLightType(light.Base);
+        if (type == kEnvironmentQuad || type == kEnvironment || type == kDirectional) boostK = 0.5f;
+        else boostK = saturate(1 - light_distance_from_frustum(B, light.Base.Center) / fmaxf_(1e-5f, B.fadeDistance));
+        boostedWeight *= 1 + B.mul * boostK;
+    }
+    return boostedWeight;
+}
+// LightsBaker::UpdateFrustumConsts (LightsBaker.cpp:884-925): the clip planes of a row-vector view-projection matrix M (clip = p * M, Donut's convention; vp(row, col) =
+// M[row][col], m = 16 floats row-major), each scaled by 1 / sqrt(|n|^2)
+static inline void light_frustum_planes_from_viewproj(const float* m, float planes[5][4]) {
+    auto vp = [&](int row, int col) { return m[4 * row + col]; };
+    const int sign[5] = {+1, -1, -1, +1, -1}, col[5] = {0, 0, 1, 1, 2};
+    for (int i = 0; i < 5; i++) {
+        float p[4];
+        if (sign[i] > 0) { p[0] = vp(0, 3) + vp(0, col[i]); p[1] = vp(1, 3) + vp(1, col[i]); p[2] = vp(2, 3) + vp(2, col[i]); p[3] = -(vp(3, 3) + vp(3, col[i])); }
+        else { p[0] = vp(0, 3) - vp(0, col[i]); p[1] = vp(1, 3) - vp(1, col[i]); p[2] = vp(2, 3) - vp(2, col[i]); p[3] = -(vp(3, 3) - vp(3, col[i])); }
+        float lengthSq = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+        float scale = lengthSq > 0.f ? (1.0f / sqrtf_(lengthSq)) : 0.f;
+        for (int k = 0; k < 4; k++) planes[i][k] = p[k] * scale;
+    }
+}
 // ImportanceBooster's second term (:137-147) with ImportanceBoostIntensityDelta = 64 (LightsBaker.h:245-246): a light that got brighter than 1.1 x its last weight is boosted
 static inline float neeat_intensity_delta_boost(float boostedWeight, float historicWeight, float intensityDeltaMul) {
     float delta = boostedWeight - historicWeight * 1.1f;

@@ -57,7 +57,7 @@ void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, fl
 void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const uint* subInstTriOffset, uint numEmissiveSubInst, uint totalTris, uint lightBase,
                           PolymorphicLightInfo* lights, PolymorphicLightInfoEx* lightsEx, hipStream_t st);
 // light weights (power^0.8), their in-order sum, proxy counts; then (after an exclusive scan of the counts by the caller) the proxy index fill
-void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, hipStream_t st);      // ComputeWeight per light
+void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, const LightFrustumBoost& boost, hipStream_t st);      // ComputeWeight (+ the frustum boost) per light
 // weight sum (in light order) + ComputeProxyCounts; usage != null: NEE-AT's feedback term (n + 1 usage counts, the last one = pixels without valid feedback)
 void launch_light_proxy_counts(const float* w, uint n, float* sum, uint budget, bool uniform, uint maxPerLight, uint* counts, const uint* usage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight, hipStream_t st);
 void launch_neeat_boost_weights(const float* base, const float* hist, uint nHist, uint n, float mul, float* cur, hipStream_t st);

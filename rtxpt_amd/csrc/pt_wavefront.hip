@@ -785,12 +785,12 @@ void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, fl
 // a per-frame re-bake of animated emissives (C5) needs no D2H / host loop / H2D. Arithmetic = the host loop it replaces (and the oracle's): weight = power^0.8 with
 // the deterministic pow, thresholded; the weight SUM is taken in light order by ONE lane, because a float sum is only reproducible in a fixed order (7 k lights:
 // ~10 us; the table limit of 512 k lights: ~1 ms); counts = ceil((budget - N) * w / sum), capped; offsets by an exclusive scan (integers); the fill is per proxy.
-__global__ void __launch_bounds__(256) k_light_weights(const PolymorphicLightInfo* __restrict__ lights, const PolymorphicLightInfoEx* __restrict__ lightsEx, uint n, float* __restrict__ w) {
+__global__ void __launch_bounds__(256) k_light_weights(const PolymorphicLightInfo* __restrict__ lights, const PolymorphicLightInfoEx* __restrict__ lightsEx, uint n, float* __restrict__ w, LightFrustumBoost boost) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= n) return;
     PolymorphicLightInfoFull lf; lf.Base = lights[i]; lf.Extended = lightsEx[i];
     float wt = dm_pow(PolymorphicLight_GetPower(lf), 0.8f);
     if (!(wt >= 1e-8f)) wt = 0.f;                         // RTXPT_LIGHTING_MIN_WEIGHT_THRESHOLD
-    w[i] = wt;
+    w[i] = light_importance_frustum_boost(boost, lf, wt);      // ImportanceBooster, frustum term (off unless the host supplied its view-projection matrix)
 }
 // the sum in light order: the block stages 256 weights at a time in LDS (coalesced loads), lane 0 adds them one after the other
 __global__ void __launch_bounds__(256) k_light_weight_sum(const float* __restrict__ w, uint n, float* __restrict__ sum) {
@@ -891,8 +891,8 @@ __global__ void __launch_bounds__(256) k_light_proxy_fill(const uint* __restrict
     while (hi - lo > 1u) { uint mid = (lo + hi) >> 1; if (offsets[mid] <= p) lo = mid; else hi = mid; }
     proxies[p] = lo;
 }
-void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_light_weights, dim3((n + 255) / 256), dim3(256), 0, st, lights, lightsEx, n, w);
+void launch_light_weights(const PolymorphicLightInfo* lights, const PolymorphicLightInfoEx* lightsEx, uint n, float* w, const LightFrustumBoost& boost, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_light_weights, dim3((n + 255) / 256), dim3(256), 0, st, lights, lightsEx, n, w, boost);
 }
 void launch_light_proxy_counts(const float* w, uint n, float* sum, uint budget, bool uniform, uint maxPerLight, uint* counts, const uint* usage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight, hipStream_t st) {
     if (!n) return;

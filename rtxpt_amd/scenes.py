@@ -773,3 +773,15 @@ def synthetic_local_light_tables(num_lights, width, height, seed=1, hot=6, jitte
             cnt = dict(zip(lights.tolist(), counts.tolist()))
             out[y, x] = np.array([(int(l) << 9) | (cnt[int(l)] - 1) for l in picks], np.uint32)
     return out
+
+
+def view_projection(width, height, pos, direction, up, fov_y, near_z=0.01, **_unused):
+    """A view-projection matrix of the kind Donut's PlanarView::GetViewProjectionMatrix returns (row vectors: clip = [x y z 1] @ M; reverse-Z, infinite far plane), for the
+    camera arguments bridge_camera takes: what a host passes to pt_set_light_importance_boost. float32 [4, 4]."""
+    f = np.asarray(direction, np.float64); f = f / np.linalg.norm(f)
+    r = np.cross(np.asarray(up, np.float64), f); r = r / np.linalg.norm(r)
+    u = np.cross(f, r); p = np.asarray(pos, np.float64)
+    view = np.array([[r[0], u[0], f[0], 0.0], [r[1], u[1], f[1], 0.0], [r[2], u[2], f[2], 0.0], [-r.dot(p), -u.dot(p), -f.dot(p), 1.0]])
+    ys = 1.0 / np.tan(0.5 * fov_y); xs = ys * height / width
+    proj = np.array([[xs, 0, 0, 0], [0, ys, 0, 0], [0, 0, 0, 1.0], [0, 0, near_z, 0]])
+    return (view @ proj).astype(np.float32)
