@@ -267,6 +267,23 @@ def importance_boost(lights12, planes, mul, fade, weights, hist=None, delta_mul=
     return out
 
 
+def proxy_counts(weights, usage=None, total_max_feedback=0, global_feedback_weight=0.0, sampling_type=1, reference=False):
+    """LightsBaker.hlsl ComputeProxyCounts: per-light proxy counts (uint32 [n]) and their total from the light weights; usage: n + 1 counts of last frame's feedback (NEE-AT) or
+    None. reference=True: the reference's text dispatched in groups of 128 threads (librefpin_pt), otherwise the oracle's build_light_proxies. The weight sum is taken in light
+    order on both sides (the reference accumulates it with a float atomic, i.e. in no particular order)."""
+    w = np.ascontiguousarray(weights, np.float32); n = len(w); u = None if usage is None else np.ascontiguousarray(usage, np.uint32); counts = np.zeros(n, np.uint32); ws = ctypes.c_float(0)
+    f = lib().ptref_proxy_counts; f.restype = ctypes.c_uint32
+    f.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]
+    total = f(n, _p(w), ctypes.byref(ws), _p(u), int(total_max_feedback), float(global_feedback_weight), int(sampling_type), _p(counts))
+    if not reference: return counts, int(total)
+    L = refpin_pt()
+    if L is None: return None
+    g = L.refpt_proxy_counts; g.restype = ctypes.c_uint32
+    g.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]
+    rc = np.zeros(n, np.uint32); rt = g(n, _p(w), ws, _p(u), int(total_max_feedback), float(global_feedback_weight), int(sampling_type), _p(rc))
+    return rc, int(rt)
+
+
 def reference_material_from_json(text, textures):
     """The reference's PTMaterial::Read + FillData (Rtxpt/Materials/MaterialsBaker.cpp, compiled as it stands: oracle/refpin/mat_stubs.h) on one
     `.material.json` document. textures: {file name: packed texture word} = what the texture cache could load. Returns (128 bytes PTMaterialData,

@@ -693,6 +693,15 @@ void ptref_importance_boost(uint32_t n, const uint32_t* lights12, const float* p
         out[i] = wt;
     }
 }
+// ComputeProxyCounts as bake_lights / neeat_frame run it (build_light_proxies): counts out, returns SamplingProxyCount; weightSumOut: the sum the counts were made with (light order)
+uint32_t ptref_proxy_counts(uint32_t n, const float* weights, float* weightSumOut, const uint32_t* usage, uint32_t totalMaxFeedbackCount, float globalFeedbackUseWeight, uint32_t importanceSamplingType, uint32_t* counts) {
+    Scene sc; sc.lights.resize(n); sc.lightsEx.resize(n); sc.envLookupDim = 0;
+    std::vector<float> w(weights, weights + n);
+    build_light_proxies(sc, importanceSamplingType, w, usage, totalMaxFeedbackCount, globalFeedbackUseWeight);
+    memcpy(counts, sc.proxyCounters.data(), 4 * (size_t)n);
+    float s = 0.f; for (uint32_t i = 0; i < n; i++) s += weights[i]; if (weightSumOut) *weightSumOut = s;
+    return (uint32_t)sc.proxyIndices.size();
+}
 void ptref_frustum_planes(const float* m16, float* out20) { float p[5][4]; light_frustum_planes_from_viewproj(m16, p); memcpy(out20, p, sizeof(p)); }
 void ptref_neeat_reset(void* h) { ((Context*)h)->neeat.reset(); }
 // the tile tables and the jitter the last frame was traced with, and the global proxy counters

@@ -24,7 +24,7 @@ static LightsBakerConstants g_bakerConstants;      // (LightingControlData carri
 #define g_controlInfo u_controlBuffer[0]
 static RWTexture2D<float> u_feedbackTotalWeight, u_feedbackTotalWeightScratch, u_feedbackTotalWeightBlended, u_historyDepth;
 static RWTexture2D<uint> u_feedbackCandidates, u_feedbackCandidatesScratch, u_feedbackCandidatesBlended;
-static RWBuffer<uint> u_perLightProxyCounters, u_lightSamplingProxies, u_localSamplingBuffer, u_historyRemapPastToCurrent, u_historyRemapCurrentToPast; static RWBuffer<float> u_lightWeights;
+static RWBuffer<uint> u_perLightProxyCounters, u_lightSamplingProxies, u_localSamplingBuffer, u_historyRemapPastToCurrent, u_historyRemapCurrentToPast; static RWBuffer<float> u_lightWeights; static RWBuffer<uint> u_scratchList;
 struct PinDepth { float operator[](int2) const { return 1.0f; } float operator[](uint2) const { return 1.0f; } };
 struct PinMotion { float3 operator[](int2) const { return float3(0, 0, 0); } };
 static PinDepth t_depthBuffer; static PinMotion t_motionVectors;
@@ -43,6 +43,7 @@ struct GroupRunner {
 };
 static GroupRunner* g_group = nullptr;
 static void GroupMemoryBarrierWithGroupSync() { GroupRunner* g = g_group; swapcontext(&g->ctx[g->cur], &g->sched); }
+static void AllMemoryBarrierWithGroupSync() { GroupMemoryBarrierWithGroupSync(); }
 static void group_trampoline() { GroupRunner* g = g_group; g->body(g->cur); g->done[g->cur] = 1; swapcontext(&g->ctx[g->cur], &g->sched); }
 // runs body(thread) for thread = 0 .. n-1 as one group; atBarrier(k) is called once every thread has reached its k-th barrier (k = 1, 2, ...)
 static void run_group(uint n, std::function<void(uint)> body, std::function<void(uint)> atBarrier = nullptr) {

@@ -290,7 +290,7 @@ def main_pt(ref):
                  "ProcessFeedbackHistoryP1a", "ProcessFeedbackHistoryP1b", "FillTile", "ProcessFeedbackHistoryP2", "InsertOneBit"):
         for body in extract_function(ltext, name, "LightsBaker.hlsl"): w(to_cpp(body) + "\n")
     w("groupshared uint g_localData[RTXPT_LIGHTING_LOCAL_PROXY_COUNT];\ngroupshared uint g_localDataRangeLR[RTXPT_LIGHTING_LOCAL_PROXY_COUNT];\n")
-    for name in ("LastScanAndWriteOut", "ProcessFeedbackHistoryP3", "ClearFeedbackHistory"):
+    for name in ("LastScanAndWriteOut", "ProcessFeedbackHistoryP3", "ClearFeedbackHistory", "ComputeProxyCounts"):
         for body in extract_function(ltext, name, "LightsBaker.hlsl"): w(to_cpp(body) + "\n")
     w("} // namespace lbfb\n")
     w("} // namespace hl\n")

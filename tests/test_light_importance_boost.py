@@ -75,3 +75,22 @@ def test_boost_moves_proxies_towards_the_view():
     centre = lights[:, 0:3].view(np.float32)
     inside = ((centre @ pl[:, :3].T - pl[:, 3]) > 0).all(1) & (((lights[:, 3] >> 24) & 0xF) == 1)      # emissive triangles inside the frustum (PolymorphicLightType kTriangle = 1)
     assert inside.sum() > 10 and boosted[inside].sum() > plain[inside].sum() and not np.array_equal(plain, boosted)
+
+
+def test_proxy_counts_match_reference_hlsl_text():
+    """ComputeProxyCounts (LightsBaker.hlsl:880-948): the budget formula and, for NEE-AT, the lerp towards last frame's usage counts — the text dispatched in groups of 128
+    threads with its barrier, against build_light_proxies"""
+    if not HAVE_REF: pytest.skip("no /root/reference on this machine")
+    rng = np.random.default_rng(21)
+    for n in (1, 127, 128, 129, 5000):
+        w = (rng.uniform(0, 1, n) ** 6 * 50).astype(np.float32); w[rng.random(n) < 0.2] = 0
+        if not (w > 0).any(): w[0] = 1.0
+        for typ in (0, 1, 2):
+            a, b = ptref.proxy_counts(w, sampling_type=typ), ptref.proxy_counts(w, sampling_type=typ, reference=True)
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1], (n, typ)
+        pixels = 96 * 54; usage = np.zeros(n + 1, np.uint32)
+        picks = rng.choice(n, size=pixels // 2, p=(w + 1e-3) / (w + 1e-3).sum()); np.add.at(usage, picks, 1); usage[n] = 64 * 12 * 7 - usage[:n].sum()
+        for g in (0.0, 0.3, 0.75, 0.95):
+            a, b = ptref.proxy_counts(w, usage, 64 * 12 * 7, g, 2), ptref.proxy_counts(w, usage, 64 * 12 * 7, g, 2, reference=True)
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1], (n, g)
+        assert not np.array_equal(ptref.proxy_counts(w, usage, 64 * 12 * 7, 0.75, 2)[0], ptref.proxy_counts(w, sampling_type=2)[0]) or n == 1
