@@ -266,6 +266,11 @@ int32_t pt_get_light_feedback(pt_context* ctx, uint32_t sample, float* totalWeig
  * is built as for type 1). preFilter: LightsBaker.h:251 m_importanceBoost_PreFilter (default on). The frustum importance boost (LightsBaker.h:247-249) is not applied.
  * pt_get_light_feedback(0, ...) returns the run's reservoirs after the last frame; pt_get_neeat_tables the tile tables and jitter that frame was traced with. */
 int32_t pt_set_neeat(pt_context* ctx, int32_t enable, float globalTemporalFeedbackWeight, float localToGlobalSampleRatio, float screenSpaceVsWorldSpaceThreshold, int32_t preFilter);
+/* PlanarViewConstants::matWorldToClip of the frame (Donut; row vectors: clip = p * M, 16 floats row-major) — what Bridge::ExportSurface / ExportNonSurface project the path's last
+ * vertex with when the reference-mode path tracer "dumps guide buffers" (PathTracer.hlsli:487, 684; PathTracerBridgeDonut.hlsli:1105-1140). Of those buffers this path keeps the depth,
+ * because NEE-AT's Reproject (LightsBaker.hlsl:1348-1375; motion vectors are zero in reference mode) tests it: a pixel whose last two frames exported depths more than 1.5 x apart counts
+ * as disoccluded and its feedback is not blended. NULL (the state after pt_create): nothing is exported, every pixel counts as valid. */
+int32_t pt_set_view_projection(pt_context* ctx, const float* worldToClipRowMajor16);
 int32_t pt_neeat_reset(pt_context* ctx);                                                      /* LightsBaker::BakeSettings::ResetFeedback */
 int32_t pt_get_neeat_tables(pt_context* ctx, uint32_t tilesXY[2], uint32_t jitterXY[2], uint32_t* table, uint32_t tableCapacityWords);
 /* Tile-sharded frames (PtDeviceDesc.shardCount > 1; no reference analogue): a rank traces and feeds back for its own pixels, the baker's passes read whole neighbourhoods, so

@@ -508,6 +508,12 @@ class Oracle:
         m = None if view_proj is None else np.ascontiguousarray(view_proj, np.float32).reshape(16)
         f(self.h, _p(m), float(mul), float(fade_distance))
 
+    def set_view_projection(self, world_to_clip=None):
+        import ctypes
+        f = self.L.ptref_set_view_projection; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]; f.restype = None
+        m = None if world_to_clip is None else np.ascontiguousarray(world_to_clip, np.float32).reshape(16)
+        f(self.h, _p(m))
+
     def set_neeat(self, enable=True, global_feedback_weight=0.75, ratio=0.65, ssc_threshold=0.3, prefilter=True):
         """NEE-AT with the baker in the loop: every sample of render() is a frame (feedback passes, then the path tracer)"""
         import ctypes

@@ -2,7 +2,7 @@
 // screen-tile local samplers and the usage counts that re-weight the global sampler. CPU restatement of LightsBaker.hlsl:1062-1855, :753-830, :880-948, :118-162,
 // LightsBaker.cpp:943-962, 985-1075, 1335-1420, MicroRng.hlsli and LightingTypes.hlsli:184-320; pinned against that text by tests/test_neeat_baker.py
 // (oracle/refpin/hlsl_lbfb_stubs.h runs the reference's passes thread by thread). See rtxpt_amd/csrc/pt_neeat.h for the order of a frame and the three stated differences
-// (history read at the same pixel, PreFilter from a snapshot, identity light remap).
+// (PreFilter from a snapshot, identity light remap; reference-mode reprojection — zero motion vectors, depth test on the exported path-end depth — is restated).
 #pragma once
 #include "lights.h"
 
@@ -36,6 +36,7 @@ struct NeeAtFrame {
     uint* local;                        // u_localSamplingBuffer (tilesX x tilesY x 128)
     const uint* proxies;                // u_lightSamplingProxies (the global sampler, "only for filling in the gaps")
     uint* perLightCounters;             // u_perLightProxyCounters: totalLightCount + 1 words, the last one counts the pixels without a valid candidate
+    const float* depth; float* historyDepth; float depthDisocclusionThreshold;      // t_depthBuffer (what the last traced frame exported), u_historyDepth (the frame before), 1.5 (LightsBaker.h:255)
 };
 static const uint NEEAT_EARLY_FEEDBACK_TILE_SIZE = 2, NEEAT_WINDOW_SIZE = 8, NEEAT_TOP_UP_SAMPLES = RTXPT_LIGHTING_LOCAL_PROXY_COUNT - NEEAT_WINDOW_SIZE * NEEAT_WINDOW_SIZE;
 
@@ -74,6 +75,14 @@ static inline int neeat_mirror(int c, int maxRes) {                             
     int r = c >= 0 ? c : -c;
     r = r < maxRes ? r : 2 * maxRes - 2 - r;
     return r < 0 ? 0 : (r > maxRes - 1 ? maxRes - 1 : r);
+}
+// Reproject (LightsBaker.hlsl:1348-1375) in reference mode: the motion vectors are zero (Sample.cpp:2494), so history is looked up at the same pixel — int(float(pixel) + 0.5) —
+// and what remains is the depth test between the last two exported frames. The export is the clip depth of each path's LAST vertex (PathTracer.hlsli:487, 684), not of the
+// primary hit, so the test fires wherever two consecutive paths ended at depths more than 1.5 x apart; without a world-to-clip matrix both depths are 0, 0 / 0 compares false, and
+// every pixel is valid. Returns false if "disoccluded".
+static inline bool neeat_reproject(const NeeAtFrame& F, uint x, uint y) {
+    const float historicDepth = F.historyDepth[y * F.W + x], currentDepth = F.depth[y * F.W + x];
+    return !(fmaxf_(historicDepth / currentDepth, currentDepth / historicDepth) > F.depthDisocclusionThreshold);
 }
 static inline uint neeat_lsb_address(const NeeAtFrame& F, uint tileX, uint tileY, uint index) { return LLSB_ComputeBaseAddress(tileX, tileY, F.tilesX) + index; }
 
@@ -129,7 +138,8 @@ static inline void neeat_p1a_pixel(const NeeAtFrame& F, uint lx, uint ly) {
             px = px < 0 ? 0 : (px > (int)F.W - 1 ? (int)F.W - 1 : px); py = py < 0 ? 0 : (py > (int)F.H - 1 ? (int)F.H - 1 : py);
             float baseWeight = 1.0f;
             if (x < 0 || y < 0 || x >= T || y >= T) baseWeight = F.dropoff;
-            const float sw = F.fbW[(uint)py * F.W + (uint)px]; const uint sc = F.fbC[(uint)py * F.W + (uint)px];      // Reproject: the same pixel
+            if (!neeat_reproject(F, (uint)px, (uint)py)) continue;
+            const float sw = F.fbW[(uint)py * F.W + (uint)px]; const uint sc = F.fbC[(uint)py * F.W + (uint)px];
             if (sw != 0) { float rnd = rng.NextFloat(); lfr_merge(w, c, rnd, sw, sc, baseWeight); }
         }
     }
@@ -139,14 +149,15 @@ static inline void neeat_p1a_pixel(const NeeAtFrame& F, uint lx, uint ly) {
 static inline void neeat_p1b_pixel(const NeeAtFrame& F, uint x, uint y) {
     MicroRng rng = MicroRng::make(x, y, F.updateCounter, 4);
     float& w = F.scW[y * F.W + x]; uint& c = F.scC[y * F.W + x];
-    if (F.lastFrameFeedbackAvailable) lfr_clone_from(w, c, F.fbW[y * F.W + x], F.fbC[y * F.W + x], 1.0f);
+    const bool reprojectionValid = neeat_reproject(F, x, y);
+    if (F.lastFrameFeedbackAvailable) lfr_clone_from(w, c, F.fbW[y * F.W + x], F.fbC[y * F.W + x], reprojectionValid ? 1.0f : 0.0f);
     else { lfr_clear(w, c); c = neeat_sample_light_global(F, rng); return; }
     const uint lx = x / NEEAT_EARLY_FEEDBACK_TILE_SIZE, ly = y / NEEAT_EARLY_FEEDBACK_TILE_SIZE;
     const float bw = F.blW[ly * F.BW + lx]; const uint bc = F.blC[ly * F.BW + lx];
     if (bw != 0) { float rnd = rng.NextFloat(); lfr_merge(w, c, rnd, bw, bc, F.dropoff); }
     if (c == RTXPT_INVALID_LIGHT_INDEX) {
         uint res = RTXPT_INVALID_LIGHT_INDEX;
-        if (F.lastFrameLocalSamplesAvailable) {                                                          // SampleLightLocalHistoric (:1332-1345)
+        if (reprojectionValid && F.lastFrameLocalSamplesAvailable) {                                     // SampleLightLocalHistoric (:1332-1345); "no point ... if reprojection isn't valid"
             const uint tx = (x + F.jitterPrevX) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE, ty = (y + F.jitterPrevY) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE;
             const uint idx = rng.Next() % RTXPT_LIGHTING_LOCAL_PROXY_COUNT;
             res = neeat_remap_past_to_current(F, UnpackMiniListLight(F.local[neeat_lsb_address(F, tx, ty, idx)]));
@@ -187,6 +198,7 @@ static inline void neeat_sort_tile(uint* tile) {
 // ClearFeedbackHistory (:774-830) for one pixel
 static inline void neeat_clear_pixel(const NeeAtFrame& F, uint x, uint y) {
     float& w = F.fbW[y * F.W + x]; uint& c = F.fbC[y * F.W + x];
+    F.historyDepth[y * F.W + x] = F.depth[y * F.W + x];
     if (F.lastFrameFeedbackAvailable) {
         const float dropOffFactor = F.dropoff;
         lfr_clone_from(w, c, F.scW[y * F.W + x], F.scC[y * F.W + x], dropOffFactor);

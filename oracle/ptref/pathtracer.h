@@ -227,6 +227,10 @@ struct PathTracer {
 
     PathTracer(const Scene& scene, const PtSettings& s, const PathTracerCameraData& c, uint sidx, RayCounters* ctr)
         : sc(scene), S(s), cam(c), sampleIndex(sidx), counters(ctr) {}
+    // the reference-mode guide-buffer dump, of which only the depth is kept (NEE-AT's disocclusion test reads it)
+    void ExportDepth(const PathState& path, float3 virtualWorldPos) const {
+        sc.lightTable.DepthExport[(path.id & 0xFFFFu) * sc.lightTable.DepthWidth + (path.id >> 16)] = LightTable_ClipDepth(sc.lightTable, virtualWorldPos);
+    }
     LightSampler CreateLightSampler(uint pathId, bool isScreenSpaceCoherent) const { return LightSampler::make(sc.lightTable, pathId >> 16, pathId & 0xFFFFu, isScreenSpaceCoherent); }      // BridgeDonut:1075-1084
 
     // PathTracer.hlsli:40-45
@@ -465,6 +469,7 @@ struct PathTracer {
         }
         const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);
         if (baseFFThreshold != 0) environmentEmission = FireflyFilter(environmentEmission, baseFFThreshold, path.GetFireflyFilterK());
+        if (sc.lightTable.DepthExport) ExportDepth(path, path.origin + rayDir * rayT);      // Bridge::ExportNonSurface(path, rayOrigin + rayDir * rayTCurrent, 0) (PathTracer.hlsli:487)
         if (any_gt0(environmentEmission)) AccumulatePathRadiance(path, path.GetThp() * environmentEmission);
         path.setFlag(PF_hit, false);
         path.terminate();
@@ -662,6 +667,10 @@ struct PathTracer {
             const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);
             if (baseFFThreshold != 0) surfaceEmission = FireflyFilter(surfaceEmission, baseFFThreshold, path.GetFireflyFilterK());
             if (any_gt0(surfaceEmission)) AccumulatePathRadiance(path, path.GetThp() * surfaceEmission);
+        }
+        if (sc.lightTable.DepthExport) {                            // Bridge::ExportSurface(path, surfaceData, path.GetSceneLength(), 0) (PathTracer.hlsli:684, BridgeDonut:1105-1118)
+            float3 co, cd; computeCameraRay(path.id >> 16, path.id & 0xFFFFu, co, cd);
+            ExportDepth(path, co + cd * path.sceneLength);
         }
         if (path.isTerminatingAtNextBounce()) { path.terminate(); return; }
         float rr = path.GetThpRuRuCorrection();

@@ -403,7 +403,7 @@ struct NeeAtState {
     bool enabled = false; float globalFeedbackWeight = 0.75f, localRatio = 0.65f, sscThreshold = 0.3f, dropoff = 0.005f, intensityDeltaMul = 64.0f; bool preFilter = true;      // SampleUI.h:158-159, LightsBaker.h:240-253
     uint updateCounter = 0; float jitterF[2] = {0, 0}; uint jitter[2] = {0, 0}, prevJitter[2] = {0, 0};
     bool feedbackFilled = false, lastFeedbackAvailable = false; uint historicTotalLightCount = 0;
-    uint W = 0, H = 0; std::vector<float> fbW, scW, blW, histWeights, curWeights; std::vector<uint> fbC, scC, blC, local, counters;
+    uint W = 0, H = 0; std::vector<float> fbW, scW, blW, histWeights, curWeights, depth, histDepth; std::vector<uint> fbC, scC, blC, local, counters;      // depth: the last traced frame's export; histDepth: the one before
     void reset() { updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; historicTotalLightCount = 0; W = H = 0; histWeights.clear(); }
 };
 // the passes as the oracle restates them (neeat.h), one call per pixel / low-resolution pixel / tile in the order a dispatch would enumerate them (the order does not matter:
@@ -602,7 +602,7 @@ template <class Passes> static void neeat_frame(Context* c, Passes& P) {
     if (st.W != c->w || st.H != c->h) {             // (re)create the textures: LightsBaker::CreateRenderPasses (LightsBaker.cpp:300-345)
         st.W = c->w; st.H = c->h; const size_t px = (size_t)st.W * st.H, bpx = (size_t)((st.W + 1) / 2) * ((st.H + 1) / 2), tiles = (size_t)((st.W + 7) / 8 + 1) * ((st.H + 7) / 8 + 1);
         st.fbW.assign(px, 0.f); st.fbC.assign(px, 0xFFFFFFFFu); st.scW.assign(px, 0.f); st.scC.assign(px, 0xFFFFFFFFu); st.blW.assign(bpx, 0.f); st.blC.assign(bpx, 0xFFFFFFFFu);
-        st.local.assign(tiles * RTXPT_LIGHTING_LOCAL_PROXY_COUNT, 0u); st.feedbackFilled = false; st.lastFeedbackAvailable = false;
+        st.local.assign(tiles * RTXPT_LIGHTING_LOCAL_PROXY_COUNT, 0u); st.feedbackFilled = false; st.lastFeedbackAvailable = false; st.depth.assign(px, 0.f); st.histDepth.assign(px, 0.f);
     }
     // ---- UpdateBegin
     st.prevJitter[0] = st.jitter[0]; st.prevJitter[1] = st.jitter[1];
@@ -616,6 +616,7 @@ template <class Passes> static void neeat_frame(Context* c, Passes& P) {
     F.updateCounter = st.updateCounter; F.dropoff = st.dropoff; F.totalLightCount = N; F.historicTotalLightCount = st.historicTotalLightCount; st.historicTotalLightCount = N;
     F.lastFrameFeedbackAvailable = lastFrameFeedbackAvailable ? 1u : 0u; F.lastFrameLocalSamplesAvailable = (lastFrameLocalSamplesAvailable && lastFrameFeedbackAvailable) ? 1u : 0u;
     F.fbW = st.fbW.data(); F.fbC = st.fbC.data(); F.scW = st.scW.data(); F.scC = st.scC.data(); F.blW = st.blW.data(); F.blC = st.blC.data(); F.local = st.local.data();
+    F.depth = st.depth.data(); F.historyDepth = st.histDepth.data(); F.depthDisocclusionThreshold = 1.5f;
     st.counters.assign(N + 1, 0u); F.perLightCounters = st.counters.data();                                    // ResetLightProxyCounters
     const uint totalMaxFeedbackCount = lastFrameFeedbackAvailable ? ((st.W + 7) / 8) * ((st.H + 7) / 8) * 64u : 0u;
     if (lastFrameFeedbackAvailable) { if (st.preFilter) P.prefilter(F); P.p0(F, totalMaxFeedbackCount); }
@@ -628,6 +629,8 @@ template <class Passes> static void neeat_frame(Context* c, Passes& P) {
     F.samplingProxyCount = (uint)sc.proxyIndices.size(); F.proxies = sc.proxyIndices.data();
     // ---- UpdateEnd
     P.p1a(F); P.p1b(F); P.p2(F); P.p3(F); P.clear(F);
+    std::fill(st.depth.begin(), st.depth.end(), 0.f);             // Bridge::ExportSurfaceInit of every pixel of the frame about to be traced
+    sc.depthExport = sc.haveClip ? st.depth.data() : nullptr; sc.depthWidth = st.W;
     st.feedbackFilled = true;
     // what the path tracer binds this frame (LightingControlData: ratio 0 until feedback exists)
     sc.localTable = st.local; sc.localResX = F.tilesX; sc.localResY = F.tilesY; sc.localJitterX = st.jitter[0]; sc.localJitterY = st.jitter[1];
@@ -704,6 +707,13 @@ uint32_t ptref_proxy_counts(uint32_t n, const float* weights, float* weightSumOu
 }
 void ptref_frustum_planes(const float* m16, float* out20) { float p[5][4]; light_frustum_planes_from_viewproj(m16, p); memcpy(out20, p, sizeof(p)); }
 void ptref_neeat_reset(void* h) { ((Context*)h)->neeat.reset(); }
+// PlanarViewConstants::matWorldToClip (row vectors, 16 floats row-major; null: no export): what the reference-mode guide-buffer dump projects the path's last vertex with
+void ptref_set_view_projection(void* h, const float* m16) {
+    Scene& sc = ((Context*)h)->sc;
+    if (m16) { memcpy(sc.worldToClip, m16, 64); for (int r = 0; r < 4; r++) { sc.clipZ[r] = m16[4 * r + 2]; sc.clipW[r] = m16[4 * r + 3]; } sc.haveClip = true; }
+    else { memset(sc.worldToClip, 0, 64); memset(sc.clipZ, 0, 16); memset(sc.clipW, 0, 16); sc.haveClip = false; sc.depthExport = nullptr; }
+    sc.bindLocalSampling();
+}
 // the tile tables and the jitter the last frame was traced with, and the global proxy counters
 int ptref_neeat_get_tables(void* h, uint32_t* tilesXY, uint32_t* jitterXY, uint32_t* table, uint32_t* proxyCounters) {
     Context* c = (Context*)h; const NeeAtState& st = c->neeat; if (!st.W) return 0;

@@ -182,9 +182,11 @@ struct Scene {
     LightTable lightTable; LightFrustumBoost lightBoost = {};      // lightBoost: ImportanceBooster's frustum term (mul 0: off)
     // NEE-AT inputs (ptref_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback switch
     std::vector<uint> localTable; uint localResX = 0, localResY = 0, localJitterX = 0, localJitterY = 0; float localRatio = 0.f, sscThreshold = 0.f; bool feedbackRequired = false;
+    float* depthExport = nullptr; uint depthWidth = 0; float clipZ[4] = {0, 0, 0, 0}, clipW[4] = {0, 0, 0, 0}; bool haveClip = false; float worldToClip[16] = {0};      // ptref_set_view_projection; the plane is the run's (NeeAtState)
     void bindLocalSampling() {
         LightTable& T = lightTable;
         T.LocalSamplingBuffer = localResX ? localTable.data() : nullptr; T.LocalResX = localResX; T.LocalResY = localResY; T.LocalJitterX = localJitterX; T.LocalJitterY = localJitterY;
+        T.DepthExport = depthExport; T.DepthWidth = depthWidth; memcpy(T.ClipZ, clipZ, 16); memcpy(T.ClipW, clipW, 16);
         T.LocalToGlobalSampleRatio = localResX ? localRatio : 0.f; T.ScreenSpaceVsWorldSpaceThreshold = sscThreshold; T.TemporalFeedbackRequired = feedbackRequired ? 1u : 0u;
     }
     // BVH2

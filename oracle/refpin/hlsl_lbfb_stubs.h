@@ -25,9 +25,8 @@ static LightsBakerConstants g_bakerConstants;      // (LightingControlData carri
 static RWTexture2D<float> u_feedbackTotalWeight, u_feedbackTotalWeightScratch, u_feedbackTotalWeightBlended, u_historyDepth;
 static RWTexture2D<uint> u_feedbackCandidates, u_feedbackCandidatesScratch, u_feedbackCandidatesBlended;
 static RWBuffer<uint> u_perLightProxyCounters, u_lightSamplingProxies, u_localSamplingBuffer, u_historyRemapPastToCurrent, u_historyRemapCurrentToPast; static RWBuffer<float> u_lightWeights; static RWBuffer<uint> u_scratchList;
-struct PinDepth { float operator[](int2) const { return 1.0f; } float operator[](uint2) const { return 1.0f; } };
 struct PinMotion { float3 operator[](int2) const { return float3(0, 0, 0); } };
-static PinDepth t_depthBuffer; static PinMotion t_motionVectors;
+static RWTexture2D<float> t_depthBuffer; static PinMotion t_motionVectors;      // the depth the path tracer exported last frame; motion vectors: zero in reference mode (Sample.cpp:2494)
 static inline void InterlockedAdd(uint& dst, uint v) { dst += v; }
 // integer vector helpers the passes use (HLSL: clamp on int2; int against uint compares as uint)
 using hl::clamp;

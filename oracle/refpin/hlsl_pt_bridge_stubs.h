@@ -46,7 +46,10 @@ static void surfaceDebugViz(uint2, PathTracer::SurfaceData, float2, float3, RayC
 // ---- bindings (Bindings/SceneBindings.hlsli, LightingBindings.hlsli, SamplerBindings.hlsli, ShaderResourceBindings.hlsli), filled by the driver per frame
 struct BindlessBuffers { const ByteAddressBuffer* b = nullptr; ByteAddressBuffer operator[](uint i) const { return b[i]; } };
 struct BindlessTextures { const Texture2D<float4>* t = nullptr; Texture2D<float4> operator[](uint i) const { return t[i]; } };
-struct SampleConstantsPin { PathTracerConstants ptConsts; EnvMapSceneParams envMapSceneParams; EnvMapImportanceSamplingParams envMapImportanceSamplingParams; uint MaterialCount; };
+struct PlanarViewPin { float4x4 matWorldToClip; };      // donut PlanarViewConstants: the one member the guide-buffer dump reads
+static inline float4 mul(float4 v, float4x4 M) { return float4(((v.x * M.r[0].x + v.y * M.r[1].x) + v.z * M.r[2].x) + v.w * M.r[3].x, ((v.x * M.r[0].y + v.y * M.r[1].y) + v.z * M.r[2].y) + v.w * M.r[3].y,
+    ((v.x * M.r[0].z + v.y * M.r[1].z) + v.z * M.r[2].z) + v.w * M.r[3].z, ((v.x * M.r[0].w + v.y * M.r[1].w) + v.z * M.r[2].w) + v.w * M.r[3].w); }
+struct SampleConstantsPin { PlanarViewPin view; PathTracerConstants ptConsts; EnvMapSceneParams envMapSceneParams; EnvMapImportanceSamplingParams envMapImportanceSamplingParams; uint MaterialCount; };
 struct SampleMiniConstantsPin { uint4 params; };
 static SampleConstantsPin g_Const; static SampleMiniConstantsPin g_MiniConst;
 static StructuredBuffer<InstanceData> t_InstanceData; static StructuredBuffer<GeometryData> t_GeometryData; static StructuredBuffer<GeometryDebugData> t_GeometryDebugData;
@@ -56,3 +59,4 @@ static TextureCube<float4> t_EnvironmentMap; static Texture2D<float> t_Environme
 static StructuredBuffer<LightingControlData> t_LightsCB; static StructuredBuffer<PolymorphicLightInfo> t_Lights; static StructuredBuffer<PolymorphicLightInfoEx> t_LightsEx;
 static Buffer<uint> t_LightProxyCounters, t_LightProxyIndices, t_LightLocalSamplingBuffer; static Texture2D<uint> t_EnvLookupMap;
 static RWTexture2D<float> u_LightFeedbackTotalWeight; static RWTexture2D<uint> u_LightFeedbackCandidates;
+static RWTexture2D<float> u_Depth, u_SpecularHitT; static RWTexture2D<float4> u_MotionVectors; static RWTexture2D<uint> u_Throughput;      // the guide buffers (only u_Depth is backed by memory, when a world-to-clip matrix was set)

@@ -244,7 +244,8 @@ def main_pt(ref):
     for spec in ("^enum DonutGeometryAttributes..^static OpacityMicroMapDebugInfo loadOmmDebugInfo",
                  "^uint Bridge::getSampleIndex..^// 2\\.5D motion vectors",
                  "^bool AlphaTestImpl..^bool Bridge::traceVisibilityRay",
-                 "^EnvMap Bridge::CreateEnvMap..^void Bridge::ExportSurfaceInit"):
+                 "^EnvMap Bridge::CreateEnvMap..^void Bridge::ExportSurfaceInit",
+                 "^void Bridge::ExportSurfaceInit..^void Bridge::ExportSpecHitTStart"):      # the reference-mode guide-buffer dump: ExportSurfaceInit, ExportSurface, ExportNonSurface
         w("// ======== PathTracerBridgeDonut.hlsli : %s\n" % spec)
         w(to_cpp(extract_range(btext, spec, "PathTracerBridgeDonut.hlsli", braw)) + "\n")
     # the procedural sky (SampleProceduralSky.hlsli and, through its include, precomputed_sky.hlsli): whole files, ahead of the baker that calls them

@@ -26,7 +26,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 # every symbol include/mi355pt.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_positions", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
-    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_light_importance_boost", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_neeat_reset", "pt_get_neeat_tables", "pt_neeat_pack_feedback", "pt_neeat_unpack_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_light_importance_boost", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_set_view_projection", "pt_neeat_reset", "pt_get_neeat_tables", "pt_neeat_pack_feedback", "pt_neeat_unpack_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
@@ -665,6 +665,12 @@ class PathTracer:
         f = self.L.pt_set_light_importance_boost; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float]; f.restype = ctypes.c_int32
         m = None if view_proj is None else np.ascontiguousarray(view_proj, np.float32).reshape(16)
         self._chk(f(self.h, _p(m), float(mul), float(fade_distance)), "pt_set_light_importance_boost")
+
+    def set_view_projection(self, world_to_clip=None):
+        """pt_set_view_projection: the host's world-to-clip matrix (row vectors), for the depth the reference-mode path tracer exports and NEE-AT's disocclusion test reads"""
+        f = self.L.pt_set_view_projection; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]; f.restype = ctypes.c_int32
+        m = None if world_to_clip is None else np.ascontiguousarray(world_to_clip, np.float32).reshape(16)
+        self._chk(f(self.h, _p(m)), "pt_set_view_projection")
 
     def set_neeat(self, enable=True, global_feedback_weight=0.75, ratio=0.65, ssc_threshold=0.3, prefilter=True):
         """NEE-AT with the light baker in the loop (pt_set_neeat): every sample of render() becomes a frame — feedback passes, then the path tracer"""

@@ -98,9 +98,10 @@ struct pt_context {
         uint updateCounter = 0; float jitterF[2] = {0, 0}; uint jitter[2] = {0, 0}, prevJitter[2] = {0, 0};
         bool feedbackFilled = false, lastFeedbackAvailable = false; uint historicTotalLightCount = 0, W = 0, H = 0, nHist = 0;
         DevBuf<float> fbW, scW, blW, snapW, curW, histW; DevBuf<uint> fbC, scC, blC, snapC, local, counters;
+        DevBuf<float> depth, histDepth; bool haveClip = false; float clipZ[4] = {0, 0, 0, 0}, clipW[4] = {0, 0, 0, 0};      // the exported depth of the last traced frame / of the one before; columns 2 and 3 of pt_set_view_projection's matrix
         DevBuf<ptk::uint2> xSend, xRecv; DevBuf<uint> xPixels; uint xW = 0, xH = 0;      // tile-sharded frames: the exchange of the owned pixels' reservoirs between frames
-        void reset() { updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
-        void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); xSend.free(); xRecv.free(); xPixels.free(); }
+        void reset() { W = H = 0; updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
+        void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); xSend.free(); xRecv.free(); xPixels.free(); depth.free(); histDepth.free(); }
     } neeat;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
@@ -248,6 +249,8 @@ void refresh_scene_view(pt_context* c) {
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
     d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
     d.lights.LocalSamplingBuffer = c->localResX ? (c->neeat.enabled ? c->neeat.local.p : c->dLocalTable.p) : nullptr; d.lights.LocalResX = c->localResX; d.lights.LocalResY = c->localResY; d.lights.LocalJitterX = c->localJitterX; d.lights.LocalJitterY = c->localJitterY;
+    d.lights.DepthExport = (c->neeat.enabled && c->neeat.haveClip && c->neeat.W == c->width && c->neeat.H == c->height) ? c->neeat.depth.p : nullptr; d.lights.DepthWidth = c->width;
+    memcpy(d.lights.ClipZ, c->neeat.clipZ, 16); memcpy(d.lights.ClipW, c->neeat.clipW, 16);
     d.lights.LocalToGlobalSampleRatio = c->localResX ? c->localRatio : 0.f; d.lights.ScreenSpaceVsWorldSpaceThreshold = c->sscThreshold; d.lights.TemporalFeedbackRequired = c->feedbackRequired ? 1u : 0u;
     d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.alphaPlanes = c->dAlphaPlanes.p; d.alphaPool = c->dAlphaPool.p; d.shadeTris = c->dShadeTris.p; d.primToSlot = c->bvh.primToSlot; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
 }
@@ -571,6 +574,8 @@ int neeat_frame(pt_context* c) {
         PT_CHECK_HIP(c, st.fbW.resize(px)); PT_CHECK_HIP(c, st.fbC.resize(px)); PT_CHECK_HIP(c, st.scW.resize(px)); PT_CHECK_HIP(c, st.scC.resize(px)); PT_CHECK_HIP(c, st.snapW.resize(px)); PT_CHECK_HIP(c, st.snapC.resize(px));
         PT_CHECK_HIP(c, st.blW.resize(bpx)); PT_CHECK_HIP(c, st.blC.resize(bpx)); PT_CHECK_HIP(c, st.local.resize(tiles * RTXPT_LIGHTING_LOCAL_PROXY_COUNT));
         PT_CHECK_HIP(c, hipMemsetAsync(st.fbW.p, 0, 4 * px, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(st.fbC.p, 0xFF, 4 * px, c->stream));
+        PT_CHECK_HIP(c, st.depth.resize(px)); PT_CHECK_HIP(c, st.histDepth.resize(px));
+        PT_CHECK_HIP(c, hipMemsetAsync(st.depth.p, 0, 4 * px, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(st.histDepth.p, 0, 4 * px, c->stream));
     }
     // ---- UpdateBegin
     st.prevJitter[0] = st.jitter[0]; st.prevJitter[1] = st.jitter[1];
@@ -581,6 +586,7 @@ int neeat_frame(pt_context* c) {
     F.updateCounter = st.updateCounter; F.dropoff = st.dropoff; F.totalLightCount = N; F.historicTotalLightCount = st.historicTotalLightCount; st.historicTotalLightCount = N;
     F.lastFrameFeedbackAvailable = lastFrameFeedbackAvailable ? 1u : 0u; F.lastFrameLocalSamplesAvailable = (lastFrameLocalSamplesAvailable && lastFrameFeedbackAvailable) ? 1u : 0u;
     F.fbW = st.fbW.p; F.fbC = st.fbC.p; F.scW = st.scW.p; F.scC = st.scC.p; F.blW = st.blW.p; F.blC = st.blC.p; F.local = st.local.p;
+    F.depth = st.depth.p; F.historyDepth = st.histDepth.p; F.depthDisocclusionThreshold = 1.5f;
     PT_CHECK_HIP(c, st.counters.resize(N + 1)); PT_CHECK_HIP(c, hipMemsetAsync(st.counters.p, 0, 4 * (size_t)(N + 1), c->stream)); F.perLightCounters = st.counters.p;      // ResetLightProxyCounters
     const uint totalMaxFeedbackCount = lastFrameFeedbackAvailable ? ((F.W + 7) / 8) * ((F.H + 7) / 8) * 64u : 0u;
     if (lastFrameFeedbackAvailable) launch_neeat_begin(F, st.snapW.p, st.snapC.p, st.preFilter, totalMaxFeedbackCount, c->stream);
@@ -592,6 +598,7 @@ int neeat_frame(pt_context* c) {
     F.samplingProxyCount = c->numProxies; F.proxies = c->dProxyIndices.p;
     // ---- UpdateEnd
     launch_neeat_end(F, c->stream);
+    PT_CHECK_HIP(c, hipMemsetAsync(st.depth.p, 0, 4 * px, c->stream));      // Bridge::ExportSurfaceInit of every pixel of the frame about to be traced
     st.feedbackFilled = true;
     // what the path tracer binds this frame (the local layer is sampled only once feedback exists: LightsBaker.cpp:1048)
     c->localResX = F.tilesX; c->localResY = F.tilesY; c->localJitterX = st.jitter[0]; c->localJitterY = st.jitter[1]; c->localMaxLight = 0;
@@ -845,6 +852,14 @@ int32_t pt_neeat_unpack_feedback(pt_context* c, const void* src, size_t bytes, u
     launch_unpack_feedback(c->neeat.fbW.p, c->neeat.fbC.p, tmp.p, (uint)px.size(), c->width, (const ptk::uint2*)src, c->stream);
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     tmp.free();
+    return PT_OK;
+}
+int32_t pt_set_view_projection(pt_context* c, const float* worldToClipRowMajor16) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    pt_context::NeeAt& st = c->neeat;
+    if (worldToClipRowMajor16) { for (int r = 0; r < 4; r++) { st.clipZ[r] = worldToClipRowMajor16[4 * r + 2]; st.clipW[r] = worldToClipRowMajor16[4 * r + 3]; } st.haveClip = true; }
+    else { memset(st.clipZ, 0, 16); memset(st.clipW, 0, 16); st.haveClip = false; }
+    refresh_scene_view(c);
     return PT_OK;
 }
 int32_t pt_neeat_reset(pt_context* c) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->neeat.reset(); return PT_OK; }

@@ -325,7 +325,16 @@ struct LightTable {
     // LocalToGlobalSampleRatio, ScreenSpaceVsWorldSpaceThreshold, TemporalFeedbackRequired). LocalSamplingBuffer == null: no local layer (ratio 0).
     const uint* LocalSamplingBuffer; uint LocalResX, LocalResY, LocalJitterX, LocalJitterY;
     float LocalToGlobalSampleRatio, ScreenSpaceVsWorldSpaceThreshold; uint TemporalFeedbackRequired;
+    // the guide buffer the reference-mode path tracer leaves behind for the baker's disocclusion test (Bridge::ExportSurface / ExportNonSurface, BridgeDonut:1105-1140): clip-space
+    // depth of the path's last vertex, one float per pixel; ClipZ / ClipW = columns 2 and 3 of the host's world-to-clip matrix (row vectors). DepthExport == null: nothing is written.
+    float* DepthExport; uint DepthWidth; float ClipZ[4], ClipW[4];
 };
+// `mul(float4(p, 1), matWorldToClip)`: z and w of the row vector times the matrix, each as ((x + y) + z) + w
+static inline float LightTable_ClipDepth(const LightTable& t, float3 p) {
+    float z = ((p.x * t.ClipZ[0] + p.y * t.ClipZ[1]) + p.z * t.ClipZ[2]) + 1.0f * t.ClipZ[3];
+    float w = ((p.x * t.ClipW[0] + p.y * t.ClipW[1]) + p.z * t.ClipW[2]) + 1.0f * t.ClipW[3];
+    return z / w;
+}
 // LightingConfig.h:27-31 (the "default" tier) and LightingTypes.hlsli:148-180
 static const uint RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE = 8, RTXPT_LIGHTING_LOCAL_PROXY_COUNT = 128, RTXPT_LIGHTING_LOCAL_PROXY_BINARY_SEARCH_STEPS = 8;
 static inline uint ComputeCandidateSampleLocalCount(float localToGlobalRatio, uint totalCandidateSamples) { return (uint)((float)(totalCandidateSamples - 1u) * localToGlobalRatio + 0.75f); }

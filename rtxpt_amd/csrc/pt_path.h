@@ -201,6 +201,29 @@ template <bool LP16> struct PathKernelContextT {
         return diffuseBounces > S.diffuseBounceCount;
     }
     // EmptyPathInitialize + SetupPathPrimaryRay + Bridge::computeCameraRay (PathTracer.hlsli:47-119, BridgeDonut:543-564, PathTracerHelpers.hlsli:126-153)
+    // Bridge::computeCameraRay (BridgeDonut:543-564) for a pixel and sample index: origin on the near plane and direction
+    void computeCameraRay(uint px, uint py, uint sampleIndex, float3& o, float3& d) const {
+        SampleGeneratorVertexBase vb = SampleGeneratorVertexBase::make((px << 16) | py, 0, sampleIndex);
+        SampleSequenceGenerator sg = SampleSequenceGenerator::make(vb);
+        float2 r0 = sampleNext2D(sg);
+        float2 subPixelOffset = make_float2(cam.Jitter.x + (r0.x - 0.5f) * S.perPixelJitterAAScale, cam.Jitter.y + (r0.y - 0.5f) * S.perPixelJitterAAScale);
+        float2 dof = sampleNext2D(sg);
+        float2 pp = make_float2(((float)px + 0.5f + -subPixelOffset.x) / (float)cam.ViewportSize.x, ((float)py + 0.5f + subPixelOffset.y) / (float)cam.ViewportSize.y);
+        float2 ndc = make_float2(2.f * pp.x + -1.f, -2.f * pp.y + 1.f);
+        float3 org = cam.PosW;
+        float3 dir = (ndc.x * cam.CameraU + ndc.y * cam.CameraV) + cam.CameraW;
+        float2 ap = sample_disk(dof);
+        float3 rayTarget = org + dir;
+        org = org + cam.ApertureRadius * (ap.x * normalize(cam.CameraU) + ap.y * normalize(cam.CameraV));
+        dir = normalize(rayTarget - org);
+        float invCos = 1.f / dot(normalize(cam.CameraW), dir);
+        float tMin = cam.NearZ * invCos;
+        o = org + dir * tMin; d = dir;
+    }
+    // the reference-mode guide-buffer dump (PathTracer.hlsli:487, 684 -> Bridge::ExportNonSurface / ExportSurface): only the depth is kept, for NEE-AT's disocclusion test
+    void ExportDepth(const PathState& path, float3 virtualWorldPos) const {
+        sc.lights.DepthExport[(path.id & 0xFFFFu) * sc.lights.DepthWidth + (path.id >> 16)] = LightTable_ClipDepth(sc.lights, virtualWorldPos);
+    }
     PathState generate(uint px, uint py, uint sampleIndex) const {
         PathState p; __builtin_memset(&p, 0, sizeof(p));
         p.id = (px << 16) | py; p.sampleIndex = sampleIndex;
@@ -456,6 +479,7 @@ template <bool LP16> struct PathKernelContextT {
         }
         const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);
         if (baseFFThreshold != 0) environmentEmission = FireflyFilter<LP>(environmentEmission, baseFFThreshold, path.GetFireflyFilterK());
+        if (NEEAT && sc.lights.DepthExport) ExportDepth(path, path.origin + rayDir * rayT);      // ExportNonSurface(path, rayOrigin + rayDir * rayTCurrent, 0)
         if (any_gt0(environmentEmission)) AccumulatePathRadiance(path, path.GetThp() * environmentEmission);
         path.setFlag(PF_hit, false);
         path.terminate();
@@ -657,6 +681,10 @@ template <bool LP16> struct PathKernelContextT {
             const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);
             if (baseFFThreshold != 0) surfaceEmission = FireflyFilter<LP>(surfaceEmission, baseFFThreshold, path.GetFireflyFilterK());
             if (any_gt0(surfaceEmission)) AccumulatePathRadiance(path, path.GetThp() * surfaceEmission);
+        }
+        if (NEEAT && sc.lights.DepthExport) {                     // ExportSurface(path, surfaceData, path.GetSceneLength(), 0): the camera ray of this pixel and sample, at the path's length
+            float3 co, cd; computeCameraRay(path.id >> 16, path.id & 0xFFFFu, path.sampleIndex, co, cd);
+            ExportDepth(path, co + cd * path.sceneLength);
         }
         if (path.isTerminatingAtNextBounce()) { path.terminate(); return; }
         float rr = path.GetThpRuRuCorrection();

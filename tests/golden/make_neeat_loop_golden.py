@@ -21,12 +21,20 @@ def _collect(name, frames, step):
     return out
 
 
+def _extras(t, opts, w, h, cam):
+    o = dict(opts); vp = o.pop("view_projection", False); boost = o.pop("importance_boost", False)
+    M = scenes.view_projection(w, h, **cam)
+    if vp: t.set_view_projection(M)
+    if boost: t.set_light_importance_boost(M)
+    t.set_neeat(True, **o)
+
+
 def run_oracle(name, reference):
     from oracle import ptref
     make, S, w, h, frames, opts = pin_scenes.neeat_loop_cases()[name]
     sc, cam = make()
     o = ptref.Oracle(reference_integrator=reference, settings=S, lp16=bool(S["useFp16Types"]))
-    o.set_scene(sc); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(S); o.resize(w, h); o.set_neeat(True, **opts)
+    o.set_scene(sc); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(S); o.resize(w, h); _extras(o, opts, w, h, cam)
     def step(f):
         o.render(f, 1); t, j, pc = o.neeat_tables(); fw, fc = o.light_feedback(0)
         return o.radiance(), t, j, pc, fw, fc
@@ -37,7 +45,7 @@ def run_device(name, one_call=False):
     import rtxpt_amd as pt
     make, S, w, h, frames, opts = pin_scenes.neeat_loop_cases()[name]
     sc, cam = make()
-    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h); t.set_neeat(True, **opts)
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h); _extras(t, opts, w, h, cam)
     if one_call:
         t.render(0, frames); tab, j = t.neeat_tables(); fw, fc = t.light_feedback(0)
         out = {name: t.radiance(), "%s_table%d" % (name, frames - 1): tab, "%s_jitter%d" % (name, frames - 1): np.array(j, np.uint32), "%s_fbw%d" % (name, frames - 1): fw, "%s_fbc%d" % (name, frames - 1): fc}

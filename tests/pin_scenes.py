@@ -281,4 +281,7 @@ def neeat_loop_cases():
         "c2_sphere_lights_loop_lp16": (with_sphere_lights(c2), d(NEEType=2, useFp16Types=1, fireflyFilterThreshold=2.5), 61, 35, 3, dflt),      # odd frame size: partial tiles, partial low-res pixels
         "bistro_like_c5_loop_nofilter": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), d(NEEType=2, NEECandidateSamples=3), 96, 54, 3,
                                          dict(global_feedback_weight=0.3, ratio=0.9, ssc_threshold=0.5, prefilter=False)),
+        # with the host's world-to-clip matrix: the path tracer exports the clip depth of every path's last vertex and the baker's Reproject tests it (frame 1: everything
+        # "disoccluded" against the cleared history, later frames: wherever two consecutive paths ended 1.5 x apart) — and the frustum importance boost on top
+        "bistro_like_loop_depth_boost": (bl, d(NEEType=2, useFp16Types=1), 96, 54, 5, dict(dflt, view_projection=True, importance_boost=True)),
     }

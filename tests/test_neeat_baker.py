@@ -41,7 +41,7 @@ def test_oracle_run_matches_reference_text_golden(name):
     frames = CASES[name][4]
     # the run does what it is for: tables start as draws from the global sampler and concentrate once feedback exists; the global table follows the usage counts
     distinct = [np.mean([len(np.unique(t >> 9)) for t in want["%s_table%d" % (name, f)].reshape(-1, 128)]) for f in range(frames)]
-    assert distinct[-1] < distinct[0] or name == "bistro_like_loop"
+    assert distinct[-1] < distinct[0] or name.startswith("bistro_like_loop")
     assert not np.array_equal(want["%s_counters0" % name], want["%s_counters1" % name])
     for f in range(frames):
         t = want["%s_table%d" % (name, f)]; lights, counts = t >> 9, (t & 0x1FF) + 1
