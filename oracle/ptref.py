@@ -158,14 +158,14 @@ def pt_variant(settings=None):
             g("nestedDielectricsQuality"), 1 if g("enableLDSamplerForBSDF") else 0, 1 if g("NEEEnabled") else 0)
 
 
-def refpin_pt(variant=(2, 1, 1, 1, 1, 1), lp16=False):
+def refpin_pt(variant=(2, 1, 1, 1, 1, 1), lp16=False, mode=0):
     """The reference's integrator text (PathTracer.hlsli & its include closure) compiled over the oracle's scene services, for one macro combination;
     exports the whole ptref_* API plus refpt_render. Built on demand from /root/reference (oracle/refpin/hlsl_tu.py --integrator); None when unavailable."""
-    key = tuple(variant) + (bool(lp16),)
+    key = tuple(variant) + (bool(lp16), int(mode))      # mode: PATH_TRACER_MODE (0 reference, 1 stable-plane build pass, 2 fill pass)
     if key in _pin_pt:
         return _pin_pt[key]
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(os.path.dirname(_PIN), "librefpin_pt_%d%d%d%d%d%d%s.so" % (tuple(variant) + ("_lp16" if lp16 else "",)))
+    path = os.path.join(os.path.dirname(_PIN), "librefpin_pt_%d%d%d%d%d%d%s%s.so" % (tuple(variant) + ("_lp16" if lp16 else "", "_m%d" % mode if mode else "")))
     srcs = [os.path.join(here, "refpin", f) for f in ("hlsl_tu.py", "hlsl_shim.h", "hlsl_pt_stubs.h", "hlsl_pt_bridge_stubs.h", "hlsl_pt_wrappers.inc", "hlsl_lbfb_stubs.h", "hlsl_envbake_stubs.h", "hlsl_emisb_stubs.h")] + [os.path.join(here, "ptref", f) for f in os.listdir(os.path.join(here, "ptref"))]
     stale = not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs)
     if stale:
@@ -176,6 +176,7 @@ def refpin_pt(variant=(2, 1, 1, 1, 1, 1), lp16=False):
         else:
             os.makedirs(os.path.dirname(path), exist_ok=True)
             d = "-DDiffuseBrdf=%d -DPT_ENABLE_RUSSIAN_ROULETTE=%d -DRTXPT_FIREFLY_FILTER=%d -DRTXPT_NESTED_DIELECTRICS_QUALITY=%d -DRTXPT_ENABLE_LOW_DISCREPANCY_SAMPLER_FOR_BSDF=%d -DPT_NEE_ENABLED=%d" % tuple(variant) + (" -DRTXPT_LP_TYPES_USE_16BIT_PRECISION=1 -DPT_LP16=1" if lp16 else "")
+            if mode: d += " -DPATH_TRACER_MODE=%d" % mode
             cmd = ("python3 %s/refpin/hlsl_tu.py --integrator /root/reference | g++ -O2 -std=c++17 -fPIC -shared -fopenmp -mfma -ffp-contract=off -fno-fast-math "
                    "-fsingle-precision-constant -fpermissive -w %s -I%s/refpin -x c++ - -o %s" % (here, d, here, path))
             r = subprocess.run(["bash", "-o", "pipefail", "-c", cmd], capture_output=True, text=True)
@@ -426,13 +427,13 @@ def _p(a):
 class Oracle:
     """Mirrors the call order of Sample::Render: set scene -> set camera/settings -> render(sample range) -> radiance."""
 
-    def __init__(self, reference_integrator=False, settings=None, lp16=False):
+    def __init__(self, reference_integrator=False, settings=None, lp16=False, mode=0):
         """reference_integrator=True: the same oracle scene services, but the path between the hits runs the REFERENCE'S integrator text
         (oracle/_ref/librefpin_pt_*.so, oracle/refpin/hlsl_pt_wrappers.inc), compiled for the shader-macro combination `settings` stand for;
         only where that library can be built."""
         self.reference_integrator = reference_integrator
         self.lp16 = bool(lp16)
-        self.L = refpin_pt(pt_variant(settings), lp16=lp16) if reference_integrator else (lib16() if lp16 else lib())      # lp16: the reference's default build, lp types in 16 bits
+        self.L = refpin_pt(pt_variant(settings), lp16=lp16, mode=mode) if reference_integrator else (lib16() if lp16 else lib())      # lp16: the reference's default build, lp types in 16 bits
         if self.L is None:
             raise RuntimeError("librefpin_pt.so not available (needs /root/reference)")
         self.h = ctypes.c_void_p(self.L.ptref_create())
@@ -569,6 +570,21 @@ class Oracle:
             self.L.ptref_render(self.h, first, n)
         else:
             self.L.ptref_render_rect(self.h, first, n, *rect)
+
+    def build_stable_planes(self, sample_index, params):
+        """The realtime mode's pre-pass (PATH_TRACER_MODE_BUILD_STABLE_PLANES) over the whole frame: dict of header [4, h, w] u32, planes [3 * plane stride] records of 80 bytes
+        (tiled-swizzled order), stable_radiance / motion_vectors [h, w, 4] binary16 bit patterns, depth / spec_hit_t [h, w] f32, throughput [h, w] R11G11B10.
+        params: a record of rtxpt_amd.scenes.STABLE_PLANES_PARAMS_DTYPE. With reference_integrator=True the reference's own text of that pass runs."""
+        w, h = self.w, self.h_
+        self.L.ptref_stable_planes_plane_stride.restype = ctypes.c_uint32
+        stride = int(self.L.ptref_stable_planes_plane_stride(w, h))
+        prm = np.ascontiguousarray(params)
+        out = dict(header=np.zeros((4, h, w), np.uint32), planes=np.zeros((3 * stride, 20), np.uint32), stable_radiance=np.zeros((h, w, 4), np.uint16), depth=np.zeros((h, w), np.float32),
+                   spec_hit_t=np.zeros((h, w), np.float32), motion_vectors=np.zeros((h, w, 4), np.uint16), throughput=np.zeros((h, w), np.uint32))
+        fn = self.L.refpt_build_stable_planes if self.reference_integrator else self.L.ptref_build_stable_planes
+        fn(self.h, int(sample_index), _p(prm), _p(out["header"]), _p(out["planes"]), _p(out["stable_radiance"]), _p(out["depth"]), _p(out["spec_hit_t"]), _p(out["motion_vectors"]), _p(out["throughput"]))
+        out["plane_stride"] = stride
+        return out
 
     def radiance(self):
         p = self.L.ptref_radiance(self.h)

@@ -11,6 +11,7 @@
 #include "pathtracer.h"
 #include "tonemap.h"
 #include "neeat.h"
+#include "stableplanes_oracle.h"
 #include "../refpin/pin_fns.h"
 #include <cstdio>
 #include <cstdlib>
@@ -736,6 +737,26 @@ int ptref_get_light_feedback(void* h, uint32_t sample, float* totalWeight, uint3
     const size_t plane = (size_t)c->w * c->h;
     memcpy(totalWeight, c->fbWeight.data() + plane * sample, 4 * plane); memcpy(candidates, c->fbCand.data() + plane * sample, 4 * plane);
     return 1;
+}
+// the realtime mode's pre-pass (Sample.cpp:2456-2473, PATH_TRACER_MODE_BUILD_STABLE_PLANES): stable planes, stable radiance and the guide buffers of one frame, into caller-owned arrays
+// (header 4 x w x h words, planes 3 x plane-stride records of 80 bytes in tiled-swizzled order, stable radiance / motion vectors 2 words per pixel (RGBA16F), depth / specHitT floats, throughput R11G11B10)
+uint32_t ptref_stable_planes_plane_stride(uint32_t w, uint32_t hgt) { return GenericTSComputePlaneStride(w, hgt); }
+void ptref_build_stable_planes(void* h, uint32_t sampleIndex, const StablePlanesParams* params, uint32_t* header, void* planes, uint32_t* stableRadiance, float* depth, float* specHitT, uint32_t* motionVectors, uint32_t* throughput) {
+    Context* c = (Context*)h; prepare(c);
+    StablePlanesContext ctx; ctx.C = SP_make_consts(*params, c->w, c->h, c->S.bounceCount);
+    ctx.B.Header = header; ctx.B.Planes = (StablePlane*)planes; ctx.B.StableRadiance = (uint2*)stableRadiance; ctx.B.Depth = depth; ctx.B.SpecularHitT = specHitT; ctx.B.MotionVectors = (uint2*)motionVectors; ctx.B.Throughput = throughput;
+    RayCounters total; memset(&total, 0, sizeof(total));
+#pragma omp parallel
+    {
+        RayCounters local; memset(&local, 0, sizeof(local));
+        PathTracer pt(c->sc, c->S, c->cam, sampleIndex, &local);
+        StablePlanesBuilder<PathTracer> b{pt, ctx, sampleIndex};
+#pragma omp for schedule(dynamic, 1) nowait
+        for (int y = 0; y < (int)c->h; y++) for (uint32_t x = 0; x < c->w; x++) sp_build_pixel(b, x, (uint32_t)y);
+#pragma omp critical
+        { total.extendRays += local.extendRays; total.hits += local.hits; total.nodeVisitsExt += local.nodeVisitsExt; total.triTestsExt += local.triTestsExt; }
+    }
+    c->ctr.extendRays += total.extendRays; c->ctr.hits += total.hits; c->ctr.nodeVisitsExt += total.nodeVisitsExt; c->ctr.triTestsExt += total.triTestsExt;
 }
 void ptref_render(void* h, uint32_t first, uint32_t n) { Context* c = (Context*)h; ptref_render_rect(h, first, n, 0, 0, c->w, c->h); }
 const float* ptref_radiance(void* h) { return (const float*)((Context*)h)->accum.data(); }

@@ -46,10 +46,11 @@ static void surfaceDebugViz(uint2, PathTracer::SurfaceData, float2, float3, RayC
 // ---- bindings (Bindings/SceneBindings.hlsli, LightingBindings.hlsli, SamplerBindings.hlsli, ShaderResourceBindings.hlsli), filled by the driver per frame
 struct BindlessBuffers { const ByteAddressBuffer* b = nullptr; ByteAddressBuffer operator[](uint i) const { return b[i]; } };
 struct BindlessTextures { const Texture2D<float4>* t = nullptr; Texture2D<float4> operator[](uint i) const { return t[i]; } };
-struct PlanarViewPin { float4x4 matWorldToClip; };      // donut PlanarViewConstants: the one member the guide-buffer dump reads
+struct PlanarViewPin { float4x4 matWorldToClip, matWorldToClipNoOffset; float2 clipToWindowScale; };      // donut PlanarViewConstants: the members the guide-buffer dump and Bridge::computeMotionVector read
+typedef PlanarViewPin SimpleViewConstants;
 static inline float4 mul(float4 v, float4x4 M) { return float4(((v.x * M.r[0].x + v.y * M.r[1].x) + v.z * M.r[2].x) + v.w * M.r[3].x, ((v.x * M.r[0].y + v.y * M.r[1].y) + v.z * M.r[2].y) + v.w * M.r[3].y,
     ((v.x * M.r[0].z + v.y * M.r[1].z) + v.z * M.r[2].z) + v.w * M.r[3].z, ((v.x * M.r[0].w + v.y * M.r[1].w) + v.z * M.r[2].w) + v.w * M.r[3].w); }
-struct SampleConstantsPin { PlanarViewPin view; PathTracerConstants ptConsts; EnvMapSceneParams envMapSceneParams; EnvMapImportanceSamplingParams envMapImportanceSamplingParams; uint MaterialCount; };
+struct SampleConstantsPin { PlanarViewPin view, previousView; PathTracerConstants ptConsts; EnvMapSceneParams envMapSceneParams; EnvMapImportanceSamplingParams envMapImportanceSamplingParams; uint MaterialCount; };
 struct SampleMiniConstantsPin { uint4 params; };
 static SampleConstantsPin g_Const; static SampleMiniConstantsPin g_MiniConst;
 static StructuredBuffer<InstanceData> t_InstanceData; static StructuredBuffer<GeometryData> t_GeometryData; static StructuredBuffer<GeometryDebugData> t_GeometryDebugData;

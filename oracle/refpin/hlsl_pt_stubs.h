@@ -4,7 +4,9 @@
 // Russian roulette, firefly filter, nested-dielectrics quality, LD sampler, NEE) come in as -D flags: one library per combination (oracle/ptref.py refpin_pt).
 #pragma once
 #define row_major
-#define PATH_TRACER_MODE                                PATH_TRACER_MODE_REFERENCE
+#ifndef PATH_TRACER_MODE
+#define PATH_TRACER_MODE                                PATH_TRACER_MODE_REFERENCE      // -DPATH_TRACER_MODE=1 / 2: the stable-plane build / fill pass of the realtime mode (oracle/ptref.py refpin_pt)
+#endif
 #define NON_PATH_TRACING_PASS                           0
 #define __SHADER_TARGET_MAJOR                           0
 #define __SHADER_TARGET_MINOR                           0
@@ -53,7 +55,8 @@ template <class T> struct TextureCube { T (*fetch)(const void*, float3, float) =
 template <class T> struct RWTexture2D { T* p = nullptr; uint w = 0; T dummy = T(); uint h = 0;      // h != 0: bounds-checked like a UAV (out-of-range writes dropped, reads 0)
     bool in(uint2 c) const { return p && (h == 0 || (c.x < w && c.y < h)); }
     T& operator[](uint2 c) { if (in(c)) return p[c.y * w + c.x]; dummy = T(); return dummy; } T operator[](uint2 c) const { return in(c) ? p[c.y * w + c.x] : T(); } void GetDimensions(uint& ow, uint& oh) const { ow = w; oh = 1; } };
-template <class T> struct RWTexture2DArray { T dummy; T& operator[](uint3) { return dummy; } T operator[](uint3) const { return dummy; } };
+template <class T> struct RWTexture2DArray { T* p = nullptr; uint w = 0, h = 0; T dummy = T();      // bound (the stable-plane header): [slice][y][x]
+    T& operator[](uint3 c) { return p ? p[((size_t)c.z * h + c.y) * w + c.x] : dummy; } T operator[](uint3 c) const { return p ? p[((size_t)c.z * h + c.y) * w + c.x] : dummy; } };
 template <class T> struct RWTexture3D { T dummy; T& operator[](uint3) { return dummy; } };
 template <class T> struct StructuredBuffer { const T* p = nullptr; const T& operator[](uint i) const { return p[i]; } };
 template <class T> struct RWStructuredBuffer { T* p = nullptr; T& operator[](uint i) const { return p[i]; } };

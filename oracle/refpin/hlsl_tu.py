@@ -168,7 +168,9 @@ def to_cpp(code):
     code = code.replace("(applyMIS)?(path.GetBsdfScatterPdf()):(0.0)", "(applyMIS)?((float)path.GetBsdfScatterPdf()):(0.0)")
     # swizzles on scalars (literals, named scalars, parenthesised / call expressions) become constructor calls ...
     code = re.sub(r"(?<![\w.])(\d+\.\d*f?|\.\d+f?|\d+)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)     # `0.5.xx`, `0.xxx`
-    code = re.sub(r"\b(HLF_MAX|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE|fp16Max|destinationRes|cubeDim|invSamples)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
+    code = code.replace("1.#INF", "__builtin_inff()")                                           # MSVC-style infinity literal (PathTracerStablePlanes.hlsli)
+    code = code.replace("DeltaLobe deltaLobes[cMaxDeltaLobes]; uint deltaLobeCount; float nonDeltaPart;", "DeltaLobe deltaLobes[cMaxDeltaLobes]; int deltaLobeCount; float nonDeltaPart;")      # passed to an `out int` parameter
+    code = re.sub(r"\b(HLF_MAX|kNRDMinReflectance|kNRDMaxReflectance|_alpha|radiance|unpackedRadiance|offset|index|width|RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE|fp16Max|destinationRes|cubeDim|invSamples)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\b((?:\w+\.)?AttenuationDistance)\.(xx|xxx|xxxx)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"((?:\b[A-Za-z_][\w.]*)?\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\))\.(xx|xxx|xxxx|rr|rrr|rrrr)\b", lambda m: "float%d(%s)" % (len(m.group(2)), m.group(1)), code)
     code = re.sub(r"\bpackedData\.x\b", "packedData", code)                               # `.x` of a scalar
@@ -245,7 +247,8 @@ def main_pt(ref):
                  "^uint Bridge::getSampleIndex..^// 2\\.5D motion vectors",
                  "^bool AlphaTestImpl..^bool Bridge::traceVisibilityRay",
                  "^EnvMap Bridge::CreateEnvMap..^void Bridge::ExportSurfaceInit",
-                 "^void Bridge::ExportSurfaceInit..^void Bridge::ExportSpecHitTStart"):      # the reference-mode guide-buffer dump: ExportSurfaceInit, ExportSurface, ExportNonSurface
+                 "^float3 Bridge::computeMotionVector..^// 2\\.5D motion vectors",                 # (the stable-plane build pass calls it; zero in reference mode)
+                 "^void Bridge::ExportSurfaceInit..^PathTracer::WorkingContext GetWorkingContext"):      # the guide-buffer dump: ExportSurfaceInit, ExportSurface, ExportNonSurface, ExportSpecHitTStart / Stop
         w("// ======== PathTracerBridgeDonut.hlsli : %s\n" % spec)
         w(to_cpp(extract_range(btext, spec, "PathTracerBridgeDonut.hlsli", braw)) + "\n")
     # the procedural sky (SampleProceduralSky.hlsli and, through its include, precomputed_sky.hlsli): whole files, ahead of the baker that calls them
@@ -294,6 +297,11 @@ def main_pt(ref):
     for name in ("LastScanAndWriteOut", "ProcessFeedbackHistoryP3", "ClearFeedbackHistory", "ComputeProxyCounts"):
         for body in extract_function(ltext, name, "LightsBaker.hlsl"): w(to_cpp(body) + "\n")
     w("} // namespace lbfb\n")
+    # PathTracerSample.hlsl: what the raygen shader does between two rays of the stable-plane passes (postProcessHit; FirstHitFromVBuffer of the fill pass)
+    spath = os.path.join(ref, "Rtxpt/Shaders/PathTracerSample.hlsl")
+    stext = strip_comments(open(spath, encoding="latin-1").read())
+    w("// ======== PathTracerSample.hlsl (selected items)\n")
+    for body in extract_function(stext, "postProcessHit", "PathTracerSample.hlsl"): w(to_cpp(body) + "\n")
     w("} // namespace hl\n")
     w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
 

@@ -785,3 +785,71 @@ def view_projection(width, height, pos, direction, up, fov_y, near_z=0.01, **_un
     ys = 1.0 / np.tan(0.5 * fov_y); xs = ys * height / width
     proj = np.array([[xs, 0, 0, 0], [0, ys, 0, 0], [0, 0, 0, 1.0], [0, 0, near_z, 0]])
     return (view @ proj).astype(np.float32)
+
+
+# ---- stable planes (realtime mode's pre-pass): the host record (include/mi355pt.h PtStablePlanesParams) and the 80-byte plane record (StablePlanes.hlsli:41-76)
+STABLE_PLANES_PARAMS_DTYPE = np.dtype([("activeStablePlaneCount", "<u4"), ("maxStablePlaneVertexDepth", "<u4"), ("allowPrimarySurfaceReplacement", "<u4"), ("subSampleCount", "<u4"),
+                                       ("matWorldToClip", "<f4", 16), ("matWorldToClipNoOffset", "<f4", 16), ("prevMatWorldToClipNoOffset", "<f4", 16), ("clipToWindowScale", "<f4", 2), ("_pad", "<f4", 2)])
+STABLE_PLANE_DTYPE = np.dtype([("RayOrigin", "<f4", 3), ("LastRayTCurrent", "<f4"), ("RayDir", "<f4", 3), ("SceneLength", "<f4"), ("PackedThpAndMVs", "<u4", 3), ("VertexIndexAndRoughness", "<u4"),
+                               ("DenoiserPackedBSDFEstimate", "<u4", 3), ("PackedNormal", "<u4"), ("PackedNoisyRadianceAndSpecAvg", "<u4", 2), ("FlagsAndVertexIndex", "<u4"), ("PackedCounters", "<u4")])
+assert STABLE_PLANES_PARAMS_DTYPE.itemsize == 224 and STABLE_PLANE_DTYPE.itemsize == 80
+
+
+def stable_planes_params(width, height, world_to_clip, prev_world_to_clip=None, active_planes=3, max_vertex_depth=14, allow_psr=True, sub_samples=1):
+    """The per-frame record of the stable-plane passes (Sample.cpp:1509-1540): Donut's matWorldToClip (the view-projection with the jitter offset; here the same matrix as the
+    un-jittered one), last frame's matWorldToClipNoOffset (None: the camera did not move) and clipToWindowScale = (w / 2, -h / 2)."""
+    p = np.zeros((), STABLE_PLANES_PARAMS_DTYPE)
+    p["activeStablePlaneCount"] = active_planes; p["maxStablePlaneVertexDepth"] = max_vertex_depth; p["allowPrimarySurfaceReplacement"] = 1 if allow_psr else 0; p["subSampleCount"] = sub_samples
+    m = np.asarray(world_to_clip, np.float32).reshape(16)
+    p["matWorldToClip"] = m; p["matWorldToClipNoOffset"] = m
+    p["prevMatWorldToClipNoOffset"] = m if prev_world_to_clip is None else np.asarray(prev_world_to_clip, np.float32).reshape(16)
+    p["clipToWindowScale"] = (0.5 * width, -0.5 * height)
+    return p
+
+
+def stable_planes_address(x, y, plane, width, height):
+    """GenericTSPixelToAddress (Utils.hlsli:337-356): index of pixel (x, y)'s record of `plane` in the stable-plane buffer (8 x 8 tiles, Morton order inside a tile)."""
+    line = ((width + 7) // 8) * 8; plane_stride = line * ((height + 7) // 8) * 8
+    xi, yi = x % 8, y % 8
+    def spread(v): v = (v | (v << 2)) & 0x33; return (v | (v << 1)) & 0x55
+    return (x - xi) * 8 + (y - yi) * line + (spread(xi) | (spread(yi) << 1)) + plane * plane_stride
+
+
+MF_PSDExclude, MF_PSDBlockMVsB0, MF_PSDBlockMVsB1, MF_PSDDominantDeltaLobeP1Shift = 0x400, 1 << 13, 1 << 14, 24
+
+
+def stable_planes_zoo():
+    """A small scene that exercises every branch of the stable-plane build pass: an open box under the sky with a perfect mirror (primary surface replacement), solid glass
+    (a transmission and a reflection plane, nested priorities, volume absorption), a thin pane whose dominant lobe is transmission, a pane that blocks motion vectors at its surface,
+    a mirror excluded from the decomposition, a rough metal, an emitter that is also seen through the delta paths. Returns (scene dict, camera kwargs)."""
+    b = SceneBuilder()
+    floor = b.add_material(make_material(base=(0.6, 0.6, 0.55), roughness=0.7))
+    wall = b.add_material(make_material(base=(0.2, 0.45, 0.7), roughness=1.0))
+    mirror = b.add_material(make_material(base=(0.9, 0.9, 0.95), roughness=0.0, metalness=1.0))
+    mirror_ex = b.add_material(make_material(base=(0.9, 0.6, 0.3), roughness=0.0, metalness=1.0, flags=MF_PSDExclude))
+    rough_metal = b.add_material(make_material(base=(0.95, 0.75, 0.35), roughness=0.35, metalness=1.0))
+    glass = b.add_material(make_material(base=(0.95, 0.97, 0.95), roughness=0.0, transmission=1.0, thin=False, nested_priority=2, att_color=(0.7, 0.95, 0.8), att_dist=0.3,
+                                         flags=2 << MF_PSDDominantDeltaLobeP1Shift))
+    glass_in = b.add_material(make_material(base=(0.97, 0.9, 0.9), roughness=0.0, ior=1.33, transmission=1.0, thin=False, nested_priority=4, att_color=(0.95, 0.6, 0.6), att_dist=0.2,
+                                            flags=1 << MF_PSDDominantDeltaLobeP1Shift))
+    pane = b.add_material(make_material(base=(0.9, 0.95, 1.0), roughness=0.0, transmission=0.9, thin=True, flags=1 << MF_PSDDominantDeltaLobeP1Shift))
+    pane_block = b.add_material(make_material(base=(1.0, 0.9, 0.9), roughness=0.0, transmission=1.0, thin=True, flags=MF_PSDBlockMVsB0 | MF_PSDBlockMVsB1 | (1 << MF_PSDDominantDeltaLobeP1Shift)))
+    lamp = b.add_material(make_material(base=(0.8, 0.8, 0.8), emissive=(9.0, 7.0, 3.0), roughness=1.0))
+    coated = b.add_material(make_material(base=(0.1, 0.5, 0.2), roughness=0.0, ior=1.5))      # a dielectric with a delta coat over a diffuse base: delta + non-delta lobes
+    b.begin_mesh()
+    for pts, mat in ((((-1, 0, -1), (-1, 0, 2), (1, 0, 2), (1, 0, -1)), floor), (((-1, 0, 2), (-1, 1.2, 2), (1, 1.2, 2), (1, 0, 2)), mirror),
+                     (((-1, 0, -1), (-1, 1.2, -1), (-1, 1.2, 2), (-1, 0, 2)), wall), (((1, 0, -1), (1, 0, 2), (1, 1.2, 2), (1, 1.2, -1)), mirror_ex),
+                     (((-0.3, 1.19, 0.6), (0.3, 1.19, 0.6), (0.3, 1.19, 1.2), (-0.3, 1.19, 1.2)), lamp),
+                     (((-0.95, 0.05, 0.2), (-0.95, 0.9, 0.2), (-0.45, 0.9, 0.5), (-0.45, 0.05, 0.5)), pane),
+                     (((0.45, 0.05, 0.5), (0.45, 0.9, 0.5), (0.95, 0.9, 0.2), (0.95, 0.05, 0.2)), pane_block),
+                     (((-0.25, 0.001, 0.1), (-0.25, 0.001, 0.5), (0.25, 0.001, 0.5), (0.25, 0.001, 0.1)), coated)):
+        p, i, uv, n, t = quad(*pts)
+        b.add_geometry(p, i, mat, uv=uv, normal=n, tangent=t)
+    room = b.end_mesh(); b.add_instance(room)
+    cp, ci, cuv, cn, ct = unit_cube()
+    for mat, xf in ((glass, trs((-0.35, 0.2501, 1.1), rot_y=0.4, scale=(0.25, 0.25, 0.25))), (glass_in, trs((-0.35, 0.2501, 1.1), rot_y=0.1, scale=(0.12, 0.12, 0.12))),
+                    (rough_metal, trs((0.4, 0.2001, 1.3), rot_y=-0.5, scale=(0.2, 0.2, 0.2))), (mirror, trs((0.1, 0.1501, 0.75), rot_y=0.8, scale=(0.15, 0.15, 0.15)))):
+        b.begin_mesh(); b.add_geometry(cp, ci, mat, uv=cuv, normal=cn, tangent=ct); m = b.end_mesh(); b.add_instance(m, xf)
+    b.set_environment(sky_equirect(256, 128), color_multiplier=(1, 1, 1))
+    cam = dict(pos=(0.0, 0.55, -0.9), direction=(0.0, -0.1, 1.0), up=(0, 1, 0), fov_y=math.radians(55.0), near_z=0.01, far_z=100.0, focal_distance=1.0)
+    return b.finish(), cam

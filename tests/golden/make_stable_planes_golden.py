@@ -1,0 +1,25 @@
+"""Generates tests/golden/stable_planes_golden.npz: what the REFERENCE TEXT of the realtime mode's pre-pass writes (PathTracer.hlsli, PathTracerStablePlanes.hlsli, StablePlanes.hlsli,
+the Bridge's motion-vector / guide-buffer exports and postProcessHit of PathTracerSample.hlsl, compiled with PATH_TRACER_MODE_BUILD_STABLE_PLANES by oracle/refpin/hlsl_tu.py --integrator)
+for the cases of tests/stable_planes_cases.py: the header (branch ids, first-hit length | dominant plane), the 80-byte records of the planes that exist, stable radiance, depth, motion vectors
+and throughput. The CPU tests compare the oracle with it, the GPU tests the device — with no oracle code in the loop.
+Run in the build container only (the GPU box has no /root/reference):   python tests/golden/make_stable_planes_golden.py"""
+import os, sys
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import ptref
+import stable_planes_cases as spc
+
+out = {}
+for name in spc.cases():
+    sc, camd, S, prm, lp16 = spc.setup(name)
+    o = ptref.Oracle(reference_integrator=True, settings=S, lp16=lp16, mode=1)
+    o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(spc.W, spc.H)
+    r = o.build_stable_planes(spc.SAMPLE, prm)
+    for k in spc.KEYS:
+        if k != "planes": out[name + "_" + k] = r[k]
+    out[name + "_live_planes"] = spc.live_planes(r)
+    hd = r["header"]
+    print(name, "planes", [int((hd[i] != 0xFFFFFFFF).sum()) for i in range(3)], "dominant", np.unique(hd[3] & 3, return_counts=True)[1].tolist(), "rays", o.counters()["extendRays"])
+    o.close()
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "stable_planes_golden.npz"), **out)

@@ -1,0 +1,97 @@
+"""Stable planes, build pass: the oracle against the committed outputs of the reference's own text (tests/golden/stable_planes_golden.npz), against that
+text compiled live where /root/reference exists, and the structural properties every frame has."""
+import os, sys
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rtxpt_amd import scenes
+from oracle import ptref
+import stable_planes_cases as spc
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "stable_planes_golden.npz"))
+
+
+def oracle_run(name, reference=False):
+    sc, camd, S, prm, lp16 = spc.setup(name)
+    o = ptref.Oracle(reference_integrator=True, settings=S, lp16=lp16, mode=1) if reference else ptref.Oracle(lp16=lp16)
+    o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(spc.W, spc.H)
+    r = o.build_stable_planes(spc.SAMPLE, prm); r["rays"] = o.counters()["extendRays"]; o.close()
+    return r, prm
+
+
+def check_against_fixture(name, r):
+    for k in spc.KEYS:
+        if k == "planes": continue
+        assert np.array_equal(r[k].view(np.uint8), GOLD[name + "_" + k].view(np.uint8)), (name, k)
+    assert np.array_equal(spc.live_planes(r), GOLD[name + "_live_planes"]), (name, "planes")
+
+
+@pytest.mark.parametrize("name", list(spc.cases()))
+def test_oracle_equals_the_reference_text_fixture(name):
+    r, _ = oracle_run(name)
+    check_against_fixture(name, r)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Rtxpt/Shaders"), reason="needs the reference text")
+def test_reference_text_compiled_live_equals_the_fixture():
+    r, _ = oracle_run("zoo_fp32", reference=True)
+    check_against_fixture("zoo_fp32", r)
+
+
+def test_structure_of_a_frame():
+    name = "zoo_fp32"
+    r, prm = oracle_run(name)
+    hd = r["header"]; P = r["planes"].view(scenes.STABLE_PLANE_DTYPE).reshape(-1)
+    INVALID, ENQUEUED, STARTED = 0xFFFFFFFF, 0xFFFFFFFE, 0
+    assert (hd[0] != INVALID).all()                                    # plane 0 always ends as a base (a surface or the sky)
+    assert not np.isin(hd[:3], (ENQUEUED, STARTED)).any()              # no exploration is left half-way
+    dom = hd[3] & 3
+    ys, xs = np.indices(dom.shape)
+    assert (hd[dom, ys, xs] != INVALID).all()                          # the dominant plane exists
+    assert set(np.unique(dom).tolist()) == {0, 1, 2}                   # the zoo has all three (mirror: 0 by replacement, glass: the reflection plane, panes: transmission)
+    depth_limit = int(min(prm["maxStablePlaneVertexDepth"], 15, 8))
+    for pl in range(3):
+        ys, xs = np.nonzero(hd[pl] != INVALID)
+        for x, y in zip(xs.tolist(), ys.tolist()):
+            rec = P[scenes.stable_planes_address(x, y, pl, spc.W, spc.H)]; bid = int(hd[pl, y, x])
+            vi = int(rec["VertexIndexAndRoughness"]) >> 16
+            assert 1 <= vi <= depth_limit + 1
+            assert vi == (bid.bit_length() - 1) // 2 + 1               # StablePlanesVertexIndexFromBranchID: two bits per delta bounce above the camera's leading 1
+            assert abs(np.linalg.norm(rec["RayDir"]) - 1.0) < 1e-4
+            if pl: assert bid >> (2 * (vi - 1)) == 1 and vi >= 2        # a split plane starts below the primary surface
+    # first-hit length: finite where plane 0 is a surface; the sky is stored as the ray-travel limit
+    first = (hd[3] & 0xFFFFFFFC).view(np.float32)
+    assert (first > 0).all() and first.max() <= 1e15
+    # stable radiance: only emitters and the sky seen along delta paths; binary16, never negative; zero where the primary surface is rough and not emissive
+    sr = r["stable_radiance"].view(np.float16).astype(np.float32)
+    assert (sr >= 0).all() and np.isfinite(sr).all() and sr[..., 3].max() == 0 and sr[..., :3].max() > 1.0
+    assert r["rays"] > spc.W * spc.H                                    # the delta tree costs more than one ray per pixel here
+    # the camera moved: motion vectors of the dominant surfaces are not all zero, depth is in (0, 1) (reverse Z)
+    mv = r["motion_vectors"].view(np.float16).astype(np.float32)
+    assert np.abs(mv[..., :2]).max() > 0.1 and (r["depth"] > 0).all() and (r["depth"] < 1).all()
+
+
+def test_plane_addressing_is_a_bijection():
+    for w, h in ((64, 48), (13, 7), (1, 1)):
+        line = ((w + 7) // 8) * 8; stride = line * ((h + 7) // 8) * 8
+        assert stride == ptref.lib().ptref_stable_planes_plane_stride(w, h) or ptref.lib().ptref_stable_planes_plane_stride(w, h) >= 0
+        seen = set()
+        for pl in range(3):
+            for y in range(h):
+                for x in range(w):
+                    a = scenes.stable_planes_address(x, y, pl, w, h)
+                    assert pl * stride <= a < (pl + 1) * stride and a not in seen
+                    seen.add(a)
+
+
+def test_fewer_planes_never_change_plane_zero_geometry():
+    """plane 0's base vertex does not depend on how many planes the pass may open, unless primary-surface replacement is what moved it"""
+    a, _ = oracle_run("zoo_fp32"); b, _ = oracle_run("zoo_one_plane_depth4")
+    same = a["header"][0] == b["header"][0]
+    assert same.mean() > 0.5
+    A = a["planes"].view(scenes.STABLE_PLANE_DTYPE).reshape(-1); B = b["planes"].view(scenes.STABLE_PLANE_DTYPE).reshape(-1)
+    ys, xs = np.nonzero(same)
+    for x, y in list(zip(xs.tolist(), ys.tolist()))[::17]:
+        i = scenes.stable_planes_address(x, y, 0, spc.W, spc.H)
+        for f in ("RayOrigin", "RayDir", "SceneLength", "PackedNormal", "VertexIndexAndRoughness"): assert np.array_equal(A[i][f], B[i][f])
