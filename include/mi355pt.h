@@ -271,6 +271,37 @@ int32_t pt_set_neeat(pt_context* ctx, int32_t enable, float globalTemporalFeedba
  * because NEE-AT's Reproject (LightsBaker.hlsl:1348-1375; motion vectors are zero in reference mode) tests it: a pixel whose last two frames exported depths more than 1.5 x apart counts
  * as disoccluded and its feedback is not blended. NULL (the state after pt_create): nothing is exported, every pixel counts as valid. */
 int32_t pt_set_view_projection(pt_context* ctx, const float* worldToClipRowMajor16);
+/* ---- Stable planes: the realtime mode's pre-pass (Sample.cpp:2456-2473 dispatches RayGen with PATH_TRACER_MODE_BUILD_STABLE_PLANES once per frame).
+ * From every pixel the pass follows the delta (perfectly specular) lobes only — a Whitted-style tree of at most three branches, PathTracerStablePlanes.hlsli:104-330 — and stops each
+ * branch at the first surface a denoiser can work on: that vertex becomes the branch's "stable plane". Output, as RenderTargets.cpp:60-141, 340-352 declares it:
+ *   header         4 x height x width words: [0..2] the planes' stable branch ids (0xFFFFFFFF: no such plane), [3] asuint(first-hit ray length) & ~3 | dominant plane index
+ *   planes         3 x plane stride records of 80 bytes (PtStablePlane = StablePlanes.hlsli:41-58) at GenericTSPixelToAddress(pixel, plane) (8 x 8 tiles, Morton order inside)
+ *   stableRadiance RGBA16F: emission and sky reached along the delta paths (noise-free; the fill pass does not count it again)
+ *   depth R32F, motionVectors RGBA16F, throughput R11G11B10F: Bridge::ExportSurface / ExportNonSurface for the dominant plane; specularHitT R32F is cleared here and filled by the noisy pass
+ * Not carried over: object motion (the scene keeps no previous-frame positions: motion vectors hold the camera's motion only) and the two automatic motion-vector block types of a
+ * material (PTMaterialFlags_PSDBlockMVsAtSurfaceType 1 / 2 need Donut's per-triangle curvature; "Off" and "Full" are honoured). */
+typedef struct PtStablePlanesParams {
+    uint32_t activeStablePlaneCount;            /* m_ui.StablePlanesActiveCount, 1..3 */
+    uint32_t maxStablePlaneVertexDepth;         /* m_ui.StablePlanesMaxVertexDepth; used as min(min(it, 15), bounceCount) (Sample.cpp:1532) */
+    uint32_t allowPrimarySurfaceReplacement;    /* m_ui.AllowPrimarySurfaceReplacement */
+    uint32_t subSampleCount;                    /* m_ui.ActualSamplesPerPixel(): invSubSampleCount of the noisy passes */
+    float matWorldToClip[16];                   /* PlanarViewConstants of the frame (row vectors, row-major): with the jitter offset, ... */
+    float matWorldToClipNoOffset[16];           /* ... without it, ... */
+    float prevMatWorldToClipNoOffset[16];       /* ... and last frame's */
+    float clipToWindowScale[2];                 /* (width / 2, -height / 2) */
+    float _pad[2];
+} PtStablePlanesParams;
+typedef struct PtStablePlane {                  /* StablePlanes.hlsli:41-58 */
+    float RayOrigin[3]; float LastRayTCurrent; float RayDir[3]; float SceneLength;
+    uint32_t PackedThpAndMVs[3]; uint32_t VertexIndexAndRoughness; uint32_t DenoiserPackedBSDFEstimate[3]; uint32_t PackedNormal;
+    uint32_t PackedNoisyRadianceAndSpecAvg[2]; uint32_t FlagsAndVertexIndex; uint32_t PackedCounters;
+} PtStablePlane;
+int32_t pt_stable_planes_plane_stride(uint32_t width, uint32_t height, uint32_t* stride);     /* GenericTSComputePlaneStride (Utils.hlsli:328-332) */
+/* traces the pass for the context's pixels with the camera ray of sampleIndex (the sub-samples of a realtime frame share it); stats: rays, passes, GPU time */
+int32_t pt_build_stable_planes(pt_context* ctx, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* stats);
+/* copies the last pass's buffers to the host; any pointer may be NULL. planeCapacity in records (>= 3 x plane stride); the two RGBA16F targets as 4 binary16 bit patterns per pixel */
+int32_t pt_get_stable_planes(pt_context* ctx, uint32_t* header, PtStablePlane* planes, size_t planeCapacity, uint16_t* stableRadiance, float* depth, float* specularHitT,
+                             uint16_t* motionVectors, uint32_t* throughput);
 int32_t pt_neeat_reset(pt_context* ctx);                                                      /* LightsBaker::BakeSettings::ResetFeedback */
 int32_t pt_get_neeat_tables(pt_context* ctx, uint32_t tilesXY[2], uint32_t jitterXY[2], uint32_t* table, uint32_t tableCapacityWords);
 /* Tile-sharded frames (PtDeviceDesc.shardCount > 1; no reference analogue): a rank traces and feeds back for its own pixels, the baker's passes read whole neighbourhoods, so

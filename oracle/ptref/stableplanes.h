@@ -358,7 +358,7 @@ static inline SPMaterialInfo SP_material_info(uint flags) {
     return m;
 }
 
-// ---- the BUILD pass over one path vertex. PT is the path tracer of the side that includes this header (PathKernelContextT<LP16> / ptref::PathTracer):
+// ---- the BUILD pass over one path vertex. PT is the path tracer of the side that includes this header (the wavefront kernels' PathKernelContextT<LP16>, or the CPU restatement's PathTracer):
 // loadSurface, HandleNestedDielectrics, volumeTransmittance, UpdatePathTravelled, HasFinishedSurfaceBounces and the scene's materials come from it.
 template <class PT> struct StablePlanesBuilder {
     typedef typename SPTraits<PT>::LP LP;

@@ -34,6 +34,7 @@ EXPORTS = [
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
+    "pt_stable_planes_plane_stride", "pt_build_stable_planes", "pt_get_stable_planes",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host", "pt_neeat_exchange_host",
 ]
 
@@ -671,6 +672,25 @@ class PathTracer:
         f = self.L.pt_set_view_projection; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]; f.restype = ctypes.c_int32
         m = None if world_to_clip is None else np.ascontiguousarray(world_to_clip, np.float32).reshape(16)
         self._chk(f(self.h, _p(m)), "pt_set_view_projection")
+
+    def build_stable_planes(self, sample_index, params):
+        """pt_build_stable_planes + pt_get_stable_planes: the realtime mode's pre-pass over the frame. params: a record of scenes.STABLE_PLANES_PARAMS_DTYPE. Returns a dict of
+        header [4, h, w] u32, planes [3 * plane stride, 20] u32 (records of scenes.STABLE_PLANE_DTYPE, tiled-swizzled order), stable_radiance / motion_vectors [h, w, 4] binary16 bit
+        patterns, depth / spec_hit_t [h, w] f32, throughput [h, w] R11G11B10, plane_stride, stats."""
+        w, h = self.width, self.height
+        f = self.L.pt_stable_planes_plane_stride; f.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]; f.restype = ctypes.c_int32
+        stride = ctypes.c_uint32(0); self._chk(f(w, h, ctypes.byref(stride)), "pt_stable_planes_plane_stride"); stride = int(stride.value)
+        prm = np.ascontiguousarray(params); assert prm.dtype.itemsize == 224
+        st = PtFrameStats()
+        f = self.L.pt_build_stable_planes; f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]; f.restype = ctypes.c_int32
+        self._chk(f(self.h, int(sample_index), _p(prm), ctypes.byref(st)), "pt_build_stable_planes")
+        out = dict(header=np.zeros((4, h, w), np.uint32), planes=np.zeros((3 * stride, 20), np.uint32), stable_radiance=np.zeros((h, w, 4), np.uint16), depth=np.zeros((h, w), np.float32),
+                   spec_hit_t=np.zeros((h, w), np.float32), motion_vectors=np.zeros((h, w, 4), np.uint16), throughput=np.zeros((h, w), np.uint32))
+        f = self.L.pt_get_stable_planes; f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 5; f.restype = ctypes.c_int32
+        self._chk(f(self.h, _p(out["header"]), _p(out["planes"]), 3 * stride, _p(out["stable_radiance"]), _p(out["depth"]), _p(out["spec_hit_t"]), _p(out["motion_vectors"]), _p(out["throughput"])), "pt_get_stable_planes")
+        out["plane_stride"] = stride
+        out["stats"] = st.as_dict()
+        return out
 
     def set_neeat(self, enable=True, global_feedback_weight=0.75, ratio=0.65, ssc_threshold=0.3, prefilter=True):
         """NEE-AT with the light baker in the loop (pt_set_neeat): every sample of render() becomes a frame — feedback passes, then the path tracer"""

@@ -4,6 +4,7 @@
 // There is NO CPU fallback: every entry point that needs the device fails with PT_ERROR_NO_DEVICE / PT_ERROR_HIP.
 #include "../../include/mi355pt.h"
 #include "pt_wavefront.h"
+#include "pt_stableplanes_launch.h"
 #include "pt_build.h"
 #include <rocprim/rocprim.hpp>
 #include <rccl/rccl.h>      // types only: the functions are bound at run time (dlopen), see pt_comm_init
@@ -113,6 +114,8 @@ struct pt_context {
     bool geomDirty = true, lightsDirty = true, texDirty = true;
     double buildMs = 0, refitMs = 0, lightBakeMs = 0;
     uint poolCapacity = 0; size_t shadowCapacity = 0;
+    // stable planes (pt_build_stable_planes): the realtime mode's per-frame buffers (RenderTargets.cpp:60-141, 340-352) of the last pre-pass
+    DevBuf<uint> dSpHeader, dSpThroughput; DevBuf<ptk::StablePlane> dSpPlanes; DevBuf<ptk::uint2> dSpRadiance, dSpMotion; DevBuf<float> dSpDepth, dSpHitT; uint spW = 0, spH = 0;
     // frame gather (pt_comm_init / pt_gather)
     ncclComm_t comm = nullptr; uint commRank = 0, commWorld = 0; DevBuf<ptk::float4> dGatherSend, dGatherRecv; DevBuf<uint> dGatherPixels; std::vector<size_t> gatherCounts; uint gatherW = 0, gatherH = 0;
 };
@@ -644,6 +647,7 @@ int32_t pt_destroy(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    c->dSpHeader.free(); c->dSpThroughput.free(); c->dSpPlanes.free(); c->dSpRadiance.free(); c->dSpMotion.free(); c->dSpDepth.free(); c->dSpHitT.free();
     c->neeat.free(); c->dLocalTable.free(); c->dFbWeight.free(); c->dFbCand.free(); c->dSq3.free();
     c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free(); c->dLightW.free(); c->dProxyOffsets.free(); if (c->dScanTemp) (void)hipFree(c->dScanTemp);
     if (c->bvhAllocated) bvh_free(c->bvh);
@@ -1164,6 +1168,79 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     for (uint b = 0; b < numBatches; b++) for (auto e : B[b].ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(frame0); (void)hipEventDestroy(frame1);
     if (overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
+    return PT_OK;
+}
+static_assert(sizeof(::PtStablePlanesParams) == sizeof(ptk::StablePlanesParams) && sizeof(::PtStablePlane) == sizeof(ptk::StablePlane), "stable-plane ABI");
+int32_t pt_stable_planes_plane_stride(uint32_t width, uint32_t height, uint32_t* stride) { if (!stride) return PT_ERROR_INVALID_ARGUMENT; *stride = ptk::GenericTSComputePlaneStride(width, height); return PT_OK; }
+int32_t pt_build_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* stats) {
+    if (!c || !params) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const uint numOwned = (uint)c->owned.size();
+    r = ensure_pool(c, numOwned ? numOwned : 1u, 1u); if (r != PT_OK) return r;
+    const size_t N = (size_t)c->width * c->height;
+    ptk::StablePlanesParams prm; memcpy(&prm, params, sizeof(prm));
+    StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
+    PT_CHECK_HIP(c, c->dSpHeader.resize(4 * N)); PT_CHECK_HIP(c, c->dSpPlanes.resize((size_t)cStablePlaneCount * sp.C.genericTSPlaneStride)); PT_CHECK_HIP(c, c->dSpRadiance.resize(N)); PT_CHECK_HIP(c, c->dSpMotion.resize(N));
+    PT_CHECK_HIP(c, c->dSpDepth.resize(N)); PT_CHECK_HIP(c, c->dSpHitT.resize(N)); PT_CHECK_HIP(c, c->dSpThroughput.resize(N));
+    if (c->spW != c->width || c->spH != c->height) {      // a new size: nothing of the old frame is meaningful (pixels of other ranks' tiles and the records of planes that do not exist stay zero)
+        PT_CHECK_HIP(c, hipMemsetAsync(c->dSpHeader.p, 0xFF, 16 * N, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpPlanes.p, 0, sizeof(ptk::StablePlane) * cStablePlaneCount * sp.C.genericTSPlaneStride, c->stream));
+        PT_CHECK_HIP(c, hipMemsetAsync(c->dSpRadiance.p, 0, 8 * N, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpMotion.p, 0, 8 * N, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpDepth.p, 0, 4 * N, c->stream));
+        PT_CHECK_HIP(c, hipMemsetAsync(c->dSpHitT.p, 0, 4 * N, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpThroughput.p, 0, 4 * N, c->stream));
+        c->spW = c->width; c->spH = c->height;
+    }
+    sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p; sp.B.Depth = c->dSpDepth.p; sp.B.SpecularHitT = c->dSpHitT.p; sp.B.MotionVectors = c->dSpMotion.p; sp.B.Throughput = c->dSpThroughput.p;
+    if (!numOwned) return PT_OK;
+    PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
+    PathPool pool{c->dS0.p, c->dS1.p, c->dS2.p, c->dS3.p, c->dS4.p, c->dHit.p};
+    uint* queue[2] = {c->dQueue[0].p, c->dQueue[1].p};
+    WaveCounters* wc = c->dCounters.p; WaveCounters* hwc = c->hostCounters;
+    TravAux aux; aux.taskQ[0] = c->dTaskQ.p; aux.taskQ[1] = aux.taskQ[0] + TASK_QUEUE_CAPACITY; aux.counts = c->dTravCounts.p; aux.maxBlocks = 0u;
+    aux.taskCap = TASK_QUEUE_CAPACITY; aux.bestKey = c->dBestKey.p; aux.resolveList = c->dResolveList.p; aux.primToSlot = c->bvh.primToSlot;
+    memset(hwc, 0, sizeof(WaveCounters)); hwc->extendCount[0] = numOwned;
+    hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
+    PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
+    PT_CHECK_HIP(c, hipMemcpyAsync(wc, hwc, sizeof(WaveCounters), hipMemcpyHostToDevice, c->stream));
+    launch_sp_generate(k, sp, pool, c->dOwned.p, numOwned, sampleIndex, queue[0], c->stream);
+    // every pass is one vertex of every pixel that still explores: at most three planes of at most maxStablePlaneVertexDepth + 1 vertices, plus the false hits nested dielectrics reject
+    const uint maxIter = cStablePlaneCount * (sp.C.maxStablePlaneVertexDepth + 2u + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u * (sp.C.maxStablePlaneVertexDepth + 1u) : 0u)));
+    uint cur = 0, active = numOwned, iterations = 0; unsigned long long rays = 0;
+    while (active && iterations < maxIter) {
+        const uint nxt = cur ^ 1u;
+        launch_pass_reset(aux.counts, &wc->extendCount[nxt], &wc->shadowCount, c->stream);
+        launch_extend(c->dsc, pool, queue[cur], &wc->extendCount[cur], active, wc, c->countersEnabled, aux, c->stream);
+        launch_sp_build_shade(k, sp, pool, queue[cur], &wc->extendCount[cur], active, queue[nxt], &wc->extendCount[nxt], sampleIndex, wc, c->stream);
+        rays += active;
+        PT_CHECK_HIP(c, hipMemcpyAsync(hwc, wc, 16, hipMemcpyDeviceToHost, c->stream));
+        PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        active = hwc->extendCount[nxt]; cur = nxt; iterations++;
+    }
+    PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
+    PT_CHECK_HIP(c, hipMemcpyAsync(hwc, wc, sizeof(WaveCounters), hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    PT_CHECK_HIP(c, hipGetLastError());
+    if (stats) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); stats->gpuMilliseconds = ms; stats->extendRays = rays; stats->hits = hwc->hits; stats->iterations = iterations; stats->extendLaunches = iterations; stats->pathsTraced = numOwned;
+                 stats->nodeVisitsExtend = hwc->nodeVisitsExt; stats->triTestsExtend = hwc->triTestsExt; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (hwc->overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
+    if (active) return fail(c, PT_ERROR_HIP, "stable-plane build pass: paths still exploring after the iteration bound");
+    return PT_OK;
+}
+int32_t pt_get_stable_planes(pt_context* c, uint32_t* header, PtStablePlane* planes, size_t planeCapacity, uint16_t* stableRadiance, float* depth, float* specularHitT, uint16_t* motionVectors, uint32_t* throughput) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes");
+    (void)hipSetDevice(c->device);
+    const size_t N = (size_t)c->width * c->height, nPlanes = (size_t)cStablePlaneCount * ptk::GenericTSComputePlaneStride(c->width, c->height);
+    if (planes && planeCapacity < nPlanes) return fail(c, PT_ERROR_INVALID_ARGUMENT, "plane buffer smaller than 3 x the plane stride (pt_stable_planes_plane_stride)");
+    if (header) PT_CHECK_HIP(c, hipMemcpy(header, c->dSpHeader.p, 16 * N, hipMemcpyDeviceToHost));
+    if (planes) PT_CHECK_HIP(c, hipMemcpy(planes, c->dSpPlanes.p, sizeof(ptk::StablePlane) * nPlanes, hipMemcpyDeviceToHost));
+    if (stableRadiance) PT_CHECK_HIP(c, hipMemcpy(stableRadiance, c->dSpRadiance.p, 8 * N, hipMemcpyDeviceToHost));
+    if (depth) PT_CHECK_HIP(c, hipMemcpy(depth, c->dSpDepth.p, 4 * N, hipMemcpyDeviceToHost));
+    if (specularHitT) PT_CHECK_HIP(c, hipMemcpy(specularHitT, c->dSpHitT.p, 4 * N, hipMemcpyDeviceToHost));
+    if (motionVectors) PT_CHECK_HIP(c, hipMemcpy(motionVectors, c->dSpMotion.p, 8 * N, hipMemcpyDeviceToHost));
+    if (throughput) PT_CHECK_HIP(c, hipMemcpy(throughput, c->dSpThroughput.p, 4 * N, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 int32_t pt_map_radiance(pt_context* c, const float** rgba, size_t* pitch) {

@@ -1,0 +1,101 @@
+"""Stable planes, build pass, on the device (run with -m gpu): pt_build_stable_planes / pt_get_stable_planes.
+
+  * against the outputs of the REFERENCE TEXT of that pass (tests/golden/stable_planes_golden.npz), no oracle code in the loop: header, the records of every plane that exists,
+    stable radiance, depth, motion vectors, throughput — bit for bit, fp32 and binary16 lp types, one / two / three planes;
+  * against the oracle at a larger frame and on the Cornell scenes, ray counts included;
+  * a second pass over the same context (the buffers are re-initialised by the pass itself), and what the API refuses.
+(The file sorts after the other GPU tests on purpose: the newest entry point is tested last.)"""
+import os, sys
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rtxpt_amd import scenes
+import stable_planes_cases as spc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stable_planes_golden.npz")
+
+
+def _tracer(sc, camd, S, w, h):
+    import rtxpt_amd as pt
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(camd); t.resize(w, h)
+    return t
+
+
+def _compare(name, got, want_get, live_want):
+    for k in spc.KEYS:
+        if k == "planes": continue
+        a, b = got[k].view(np.uint8), want_get(k).view(np.uint8)
+        assert np.array_equal(a, b), "%s: %s differs in %d of %d bytes" % (name, k, int((a != b).sum()), a.size)
+    assert np.array_equal(spc.live_planes(got), live_want), "%s: plane records differ" % name
+
+
+@pytest.mark.parametrize("name", list(spc.cases()))
+def test_device_matches_reference_text(name):
+    g = np.load(GOLD)
+    sc, camd, S, prm, lp16 = spc.setup(name)
+    t = _tracer(sc, camd, S, spc.W, spc.H)
+    got = t.build_stable_planes(spc.SAMPLE, prm)
+    _compare(name, got, lambda k: g[name + "_" + k], g[name + "_live_planes"])
+    # the pass initialises its own buffers: running it again over the used buffers gives the same frame
+    again = t.build_stable_planes(spc.SAMPLE, prm)
+    _compare(name + " (second pass)", again, lambda k: g[name + "_" + k], g[name + "_live_planes"])
+    t.close()
+
+
+def _oracle_frame(sc, camd, S, prm, w, h, sample, lp16):
+    from oracle import ptref
+    o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)
+    r = o.build_stable_planes(sample, prm); r["rays"] = o.counters()["extendRays"]; r["hits"] = o.counters()["hits"]; o.close()
+    return r
+
+
+def _live(out, w, h):
+    hd = out["header"]; P = out["planes"].reshape(-1, 20); rows = []
+    for pl in range(3):
+        ys, xs = np.nonzero(hd[pl] != 0xFFFFFFFF)
+        for x, y in zip(xs.tolist(), ys.tolist()): rows.append(P[scenes.stable_planes_address(x, y, pl, w, h)])
+    return np.array(rows, np.uint32)
+
+
+@pytest.mark.parametrize("which,lp16,nested", [("zoo", False, 1), ("zoo", True, 2), ("C2", False, 1), ("C1", True, 0)])
+def test_device_matches_oracle(which, lp16, nested):
+    w, h, sample = (200, 120, 2) if which == "zoo" else (96, 96, 0)
+    if which == "zoo": sc, cam = scenes.stable_planes_zoo(); S = scenes.config_settings("C2")
+    else: sc, cam = scenes.cornell_box(which); S = scenes.config_settings(which)
+    S["nestedDielectricsQuality"] = nested
+    if lp16: S["useFp16Types"] = 1
+    camd = scenes.bridge_camera(w, h, **cam)
+    prev = dict(cam); prev["pos"] = tuple(np.asarray(cam["pos"]) + np.array([-0.02, 0.015, 0.01]))
+    prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cam), prev_world_to_clip=scenes.view_projection(w, h, **prev))
+    want = _oracle_frame(sc, camd, S, prm, w, h, sample, lp16)
+    t = _tracer(sc, camd, S, w, h)
+    got = t.build_stable_planes(sample, prm)
+    for k in spc.KEYS:
+        if k == "planes": continue
+        a, b = got[k].view(np.uint8), want[k].view(np.uint8)
+        assert np.array_equal(a, b), "%s: %s differs in %d of %d bytes" % (which, k, int((a != b).sum()), a.size)
+    assert np.array_equal(_live(got, w, h), _live(want, w, h))
+    assert (int(got["stats"]["extendRays"]), int(got["stats"]["hits"])) == (want["rays"], want["hits"])
+    t.close()
+
+
+def test_refusals_and_the_reference_mode_frame_is_untouched():
+    import rtxpt_amd as pt
+    sc, camd, S, prm, lp16 = spc.setup("zoo_fp32")
+    t = _tracer(sc, camd, S, spc.W, spc.H)
+    f = t.L.pt_get_stable_planes
+    hdr = np.zeros((4, spc.H, spc.W), np.uint32)
+    import ctypes
+    f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 5; f.restype = ctypes.c_int32
+    assert f(t.h, hdr.ctypes.data_as(ctypes.c_void_p), None, 0, None, None, None, None, None) != 0      # nothing built yet
+    t.render(0, 2); before = t.radiance().copy()
+    t.build_stable_planes(spc.SAMPLE, prm)                       # shares the path pool and the queues with pt_render, not the accumulation buffer
+    assert np.array_equal(t.radiance().view(np.uint32), before.view(np.uint32))
+    t.render(2, 1)
+    t2 = _tracer(sc, camd, S, spc.W, spc.H); t2.render(0, 3)
+    assert np.array_equal(t.radiance().view(np.uint32), t2.radiance().view(np.uint32))      # and the reference-mode run goes on as if the pre-pass had not happened
+    planes = np.zeros((8, 20), np.uint32)
+    assert f(t.h, None, planes.ctypes.data_as(ctypes.c_void_p), 8, None, None, None, None, None) != 0          # plane buffer too small
+    t.close(); t2.close()
