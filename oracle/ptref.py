@@ -586,6 +586,14 @@ class Oracle:
         out["plane_stride"] = stride
         return out
 
+    def fill_stable_planes(self, sample_index, params, frame):
+        """One sub-sample of the realtime mode's noisy pass (PATH_TRACER_MODE_FILL_STABLE_PLANES) over `frame` (what build_stable_planes returned): the planes' noisy radiance
+        (PackedNoisyRadianceAndSpecAvg) and spec_hit_t are updated in place. With reference_integrator=True (mode=2) the reference's own text of that pass runs."""
+        prm = np.ascontiguousarray(params)
+        fn = self.L.refpt_fill_stable_planes if self.reference_integrator else self.L.ptref_fill_stable_planes
+        fn(self.h, int(sample_index), _p(prm), _p(frame["header"]), _p(frame["planes"]), _p(frame["spec_hit_t"]))
+        return frame
+
     def radiance(self):
         p = self.L.ptref_radiance(self.h)
         return np.ctypeslib.as_array(p, shape=(self.h_, self.w, 4)).copy()

@@ -758,6 +758,26 @@ void ptref_build_stable_planes(void* h, uint32_t sampleIndex, const StablePlanes
     }
     c->ctr.extendRays += total.extendRays; c->ctr.hits += total.hits; c->ctr.nodeVisitsExt += total.nodeVisitsExt; c->ctr.triTestsExt += total.triTestsExt;
 }
+// one sub-sample of the realtime mode's noisy pass (Sample.cpp:2497-2516, PATH_TRACER_MODE_FILL_STABLE_PLANES) over the buffers a build pass left: the planes' noisy radiance and the specular hit distance are updated in place
+void ptref_fill_stable_planes(void* h, uint32_t sampleIndex, const StablePlanesParams* params, uint32_t* header, void* planes, float* specHitT) {
+    Context* c = (Context*)h; prepare(c);
+    StablePlanesContext ctx; ctx.C = SP_make_consts(*params, c->w, c->h, c->S.bounceCount);
+    memset(&ctx.B, 0, sizeof(ctx.B)); ctx.B.Header = header; ctx.B.Planes = (StablePlane*)planes; ctx.B.SpecularHitT = specHitT;
+    RayCounters total; memset(&total, 0, sizeof(total));
+#pragma omp parallel
+    {
+        RayCounters local; memset(&local, 0, sizeof(local));
+        PathTracer pt(c->sc, c->S, c->cam, sampleIndex, &local);
+        StablePlanesFiller<PathTracer> f{pt, ctx, sampleIndex};
+#pragma omp for schedule(dynamic, 1) nowait
+        for (int y = 0; y < (int)c->h; y++) for (uint32_t x = 0; x < c->w; x++) sp_fill_pixel(f, x, (uint32_t)y);
+#pragma omp critical
+        { total.extendRays += local.extendRays; total.shadowRays += local.shadowRays; total.hits += local.hits; total.nodeVisitsExt += local.nodeVisitsExt; total.triTestsExt += local.triTestsExt;
+          total.nodeVisitsSh += local.nodeVisitsSh; total.triTestsSh += local.triTestsSh; }
+    }
+    c->ctr.extendRays += total.extendRays; c->ctr.shadowRays += total.shadowRays; c->ctr.hits += total.hits; c->ctr.nodeVisitsExt += total.nodeVisitsExt; c->ctr.triTestsExt += total.triTestsExt;
+    c->ctr.nodeVisitsSh += total.nodeVisitsSh; c->ctr.triTestsSh += total.triTestsSh;
+}
 void ptref_render(void* h, uint32_t first, uint32_t n) { Context* c = (Context*)h; ptref_render_rect(h, first, n, 0, 0, c->w, c->h); }
 const float* ptref_radiance(void* h) { return (const float*)((Context*)h)->accum.data(); }
 void ptref_get_counters(void* h, uint64_t* out7) { memcpy(out7, &((Context*)h)->ctr, sizeof(RayCounters)); }

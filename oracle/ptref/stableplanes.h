@@ -558,3 +558,293 @@ template <class PT> struct StablePlanesBuilder {
         if (!path.isActive() && (next = sp.FindNextToExplore(px, py, SP_getStablePlaneIndex(path) + 1u)) != -1) sp.ExplorationStart(px, py, (uint)next, path);
     }
 };
+
+// ================================================================================================================================================================================
+// ---- the FILL passes (PATH_TRACER_MODE_FILL_STABLE_PLANES): the noisy path tracer of the realtime mode. A path starts on plane 0 as the build pass left it (FirstHitFromVBuffer),
+// follows the recorded delta tree while its branch id matches (StablePlanesOnScatter), and deposits its radiance — split into a total and a specular average — on the plane it last
+// touched (CommitDenoiserRadiance); emission on the stable branches was already collected by the build pass. One sub-sample per call; the planes' noisy radiance accumulates over the
+// sub-samples of a frame. NEE with one full sample per vertex (the reference's default); the visibility ray is the caller's: HandleHit returns what a visible light adds (SPNeeRequest).
+struct SPNeeRequest { bool valid; float3 origin, dir; float tmax; float4 newL; };      // newL: AccumulatePathRadiance's increment of the path's L, noisy-radiance attenuation applied
+static inline uint2 SP_Fp32ToFp16(float4 v) { return make_uint2(Fp32ToFp16(make_float2(v.x, v.y)), Fp32ToFp16(make_float2(v.z, v.w))); }      // Packing.hlsli Fp32ToFp16(float4): clamped to +-HLF_MAX
+static inline float4 SP_Fp16ToFp32(uint2 v) { float2 a = Fp16ToFp32(v.x), b = Fp16ToFp32(v.y); return make_float4(a.x, a.y, b.x, b.y); }
+static inline uint BSDFSample_getDeltaLobeIndex(uint lobe) { if ((lobe & Lobe_Delta) == 0u) return 0xFFFFFFFFu; return (lobe & Lobe_Transmission) == 0u ? 1u : 0u; }      // IBSDF.hlsli:55-60
+
+template <class PT> struct StablePlanesFiller {
+    typedef typename SPTraits<PT>::LP LP;
+    const PT& pt; StablePlanesContext sp; uint sampleIndex;
+
+    // StablePlanes.hlsli:205-226
+    void CommitDenoiserRadiance(PathState& path) const {
+        const uint px = path.id >> 16, py = path.id & 0xFFFFu, planeIndex = SP_getStablePlaneIndex(path);
+        StablePlane& rec = sp.B.Planes[sp.PixelToAddress(px, py, planeIndex)];
+        float4 accumRadiance = path.GetL();
+        const uint2 existing = make_uint2(rec.PackedNoisyRadianceAndSpecAvg[0], rec.PackedNoisyRadianceAndSpecAvg[1]);
+        if (existing.x != 0 && existing.y != 0) accumRadiance = accumRadiance + SP_Fp16ToFp32(existing);
+        const uint2 pk = SP_Fp32ToFp16(accumRadiance);
+        rec.PackedNoisyRadianceAndSpecAvg[0] = pk.x; rec.PackedNoisyRadianceAndSpecAvg[1] = pk.y;
+        path.SetL(make_float4(0, 0, 0, 0));
+    }
+    // PathTracer.hlsli:139-166 (FILL)
+    void AccumulatePathRadiance(PathState& path, float3 radiance, float specularRadianceAvg, bool stablePlaneOnBranch) const {
+        if (stablePlaneOnBranch) return;      // stable radiance: the build pass has it
+        float4 newL = make_float4(radiance, specularRadianceAvg) * sp.C.invSubSampleCount;
+        path.SetL(path.GetL() + newL);
+    }
+    static void ApplyVisibleLight(PathState& path, const SPNeeRequest& req) { path.SetL(path.GetL() + req.newL); }
+    void ExportSpecHitTStart(const PathState& path) const { sp.B.SpecularHitT[(size_t)(path.id & 0xFFFFu) * sp.C.imageWidth + (path.id >> 16)] = -path.sceneLength; }
+    void ExportSpecHitTStop(const PathState& path) const {
+        float& t = sp.B.SpecularHitT[(size_t)(path.id & 0xFFFFu) * sp.C.imageWidth + (path.id >> 16)];
+        const float denoisingSceneLength = t;
+        if (denoisingSceneLength < 0) t = fmaxf_(0.f, path.sceneLength + denoisingSceneLength);
+    }
+    // PathTracerStablePlanes.hlsli:332-376
+    void StablePlanesOnScatter(PathState& path, uint bsLobe) const {
+        const uint px = path.id >> 16, py = path.id & 0xFFFFu;
+        const bool wasOnStablePlane = path.hasFlag(PF_stablePlaneOnPlane);
+        if (wasOnStablePlane) path.setFlag(PF_stablePlaneBaseScatterDiff, (bsLobe & Lobe_Diffuse) != 0);
+        path.setFlag(PF_stablePlaneOnPlane, false);
+        const uint nextVertexIndex = path.getVertexIndex() + 1u;
+        if (path.hasFlag(PF_stablePlaneOnBranch) && nextVertexIndex <= cStablePlaneMaxVertexIndex) {
+            path.SP_BRANCH_FIELD = StablePlanesAdvanceBranchID(path.SP_BRANCH_FIELD, BSDFSample_getDeltaLobeIndex(bsLobe));
+            bool onStablePath = false;
+            for (uint spi = 0; spi < cStablePlaneCount; spi++) {
+                const uint planeBranchID = sp.GetBranchID(px, py, spi);
+                if (planeBranchID == cStablePlaneInvalidBranchID) continue;
+                if (StablePlaneIsOnPlane(planeBranchID, path.SP_BRANCH_FIELD)) {
+                    CommitDenoiserRadiance(path);
+                    SP_setStablePlaneIndex(path, spi);
+                    path.setFlag(PF_stablePlaneOnDominantBranch, spi == sp.LoadDominantIndex(px, py));
+                    path.setFlag(PF_stablePlaneOnPlane, true);
+                    SP_setCounter(path, SP_PC_BouncesFromStablePlane, 0);
+                    onStablePath = true;
+                    break;
+                }
+                onStablePath |= StablePlaneIsOnStablePath(planeBranchID, StablePlanesVertexIndexFromBranchID(planeBranchID), path.SP_BRANCH_FIELD, nextVertexIndex);
+            }
+            path.setFlag(PF_stablePlaneOnBranch, onStablePath);
+        } else {
+            path.SP_BRANCH_FIELD = cStablePlaneInvalidBranchID;
+            path.setFlag(PF_stablePlaneOnBranch, false);
+            path.incrementCounter(SP_PC_BouncesFromStablePlane);
+        }
+        if (!path.hasFlag(PF_stablePlaneOnPlane)) path.incrementCounter(SP_PC_BouncesFromStablePlane);
+    }
+    // HandleMiss (PathTracer.hlsli:407-503, FILL)
+    void HandleMiss(PathState& path, float3 rayDir, float rayTCurrent) const {
+        pt.UpdatePathTravelled(path, rayTCurrent);
+        if (path.hasFlag(PF_exportSpecHitTQueued)) { ExportSpecHitTStop(path); path.setFlag(PF_exportSpecHitTQueued, false); }
+        float3 environmentEmission = make_float3(0.f);
+        NEEBSDFMISInfo misInfo = NEEBSDFMISInfo::Unpack16bit(path.GetPackedMISInfo());
+        if (SP_env_enabled(pt)) {
+            float mipLevel = (path.getCounter(PC_DiffuseBounces) > 1) ? pt.S.envMapDiffuseSampleMIPLevel : 0.f;
+            float3 localDir = SP_env_to_local(pt, rayDir);
+            float3 Le = SP_env_eval_local(pt, localDir, mipLevel);
+            float misWeight = 1.0f;
+            float bsdfScatterPdf = path.GetBsdfScatterPdf();
+            if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0) {
+                const LightSampler lightSampler = SP_light_sampler(pt, path.id, misInfo.LightSamplingIsSSC);
+                uint environmentQuadLightIndex = lightSampler.LookupEnvLightByDirection(localDir);
+                misWeight = lightSampler.ComputeBSDFMISForEnvironmentQuad(environmentQuadLightIndex, bsdfScatterPdf, misInfo.CandidateSamples, misInfo.FullSamples);
+            }
+            environmentEmission = LP::r3(misWeight * Le);
+        }
+        const float baseFFThreshold = LP::r(pt.S.fireflyFilterThreshold);
+        if (baseFFThreshold != 0) environmentEmission = SP_firefly_filter(pt, environmentEmission, baseFFThreshold, path.GetFireflyFilterK());
+        if (any_gt0(environmentEmission)) {
+            float3 radiance = path.GetThp() * environmentEmission;
+            float specRadianceAvg = path.hasFlag(PF_stablePlaneBaseScatterDiff) ? 0.0f : Average(radiance);
+            AccumulatePathRadiance(path, radiance, specRadianceAvg, path.hasFlag(PF_stablePlaneOnBranch));
+        }
+        path.setFlag(PF_hit, false);
+        path.terminate();
+    }
+    // EmptyPathInitialize + SetupPathPrimaryRay + FirstHitFromVBuffer(path, 0) (PathTracer.hlsli:47-91, PathTracerSample.hlsl:33-94, 206-218); `active` afterwards: the first ray to trace
+    PathState generate(uint px, uint py) const {
+        PathState path; __builtin_memset(&path, 0, sizeof(path));
+        path.id = (px << 16) | py;
+        path.SetThp(make_float3(1.f));
+        path.setFlag(PF_active); path.setFlag(PF_deltaOnlyPath, true);
+        path.rayCone = RayCone::make(0, pt.cam.PixelConeSpreadAngle);
+        path.SetL(make_float4(0, 0, 0, 0));
+        path.SetFireflyFilterK_BsdfScatterPdf(1.0f, 0.0f);
+        path.SetPackedMISInfo_ThpRuRuCorrection(NEEBSDFMISInfo::empty().Pack16bit(), 1.0f);
+        SP_setStablePlaneIndex(path, 0);
+        path.SP_BRANCH_FIELD = 1;
+        if (pt.HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces))) path.setFlag(PF_terminateAtNextBounce);
+        SP_camera_ray(pt, px, py, sampleIndex, path.origin, path.dir);
+        // FirstHitFromVBuffer: the narrowed ray interval [0.99, 1.01] x LastRayTCurrent is a performance hint — the same ray finds the same closest hit over the full interval
+        const StablePlane& rec = sp.B.Planes[sp.PixelToAddress(px, py, 0)];
+        const uint stableBranchID = sp.GetBranchID(px, py, 0);
+        float sceneLength = rec.SceneLength; const float lastRayTCurrent = rec.LastRayTCurrent;
+        const uint vertexIndex = rec.VertexIndexAndRoughness >> 16;
+        const float3 thp = make_float3(f16tof32(rec.PackedThpAndMVs[0] >> 16), f16tof32(rec.PackedThpAndMVs[1] >> 16), f16tof32(rec.PackedThpAndMVs[2] >> 16));
+        bool isMiss = false;
+        if (!SP_isfinite(sceneLength)) { sceneLength = kMaxRayTravel; isMiss = true; }
+        else sceneLength -= lastRayTCurrent;
+        SP_setVertexIndex(path, vertexIndex - 1u);
+        path.dir = rec.RayDir; path.origin = rec.RayOrigin;
+        path.setFlag(PF_stablePlaneOnPlane, true); path.setFlag(PF_stablePlaneOnBranch, true);
+        SP_setStablePlaneIndex(path, 0);
+        path.SP_BRANCH_FIELD = stableBranchID;
+        path.SetThp(thp);
+        path.SetL(make_float4(0, 0, 0, 0));
+        path.setFlag(PF_stablePlaneOnDominantBranch, sp.LoadDominantIndex(px, py) == 0u);
+        SP_setCounter(path, SP_PC_BouncesFromStablePlane, 0);
+        if (pt.HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces))) path.setFlag(PF_terminateAtNextBounce);
+        path.rayCone = path.rayCone.propagateDistance(sceneLength);                   // UpdatePathTravelledLengthOnly
+        path.sceneLength = fminf_(path.sceneLength + sceneLength, kMaxRayTravel);
+        if (isMiss) HandleMiss(path, path.dir, sceneLength);
+        return path;
+    }
+    // GenerateScatterRay (PathTracer.hlsli:217-380, FILL)
+    bool GenerateScatterRay(const ShadingData& sd, const StandardBSDF& bsdf, bool blockMVs, PathState& path, const SampleGeneratorVertexBase& sgBase) const {
+        float4 u;
+        if (pt.S.enableLDSamplerForBSDF && path.getCounter(PC_DiffuseBounces) < kDisableLowDiscrepancySamplingAfterDiffuseBounceCount) u = SampleSequenceGenerator::Generate(3, sgBase, SGES_ScatterBSDF);
+        else u = UniformSampleSequenceGenerator::Generate(3, sgBase, SGES_ScatterBSDF);
+        BSDFSample bs;
+        bool valid = bsdf.sample(sd, u, bs);
+        if (!valid) return false;
+        path.dir = bs.wo;
+        const bool onDominantDenoisingLayer = path.hasFlag(PF_stablePlaneOnPlane) && path.hasFlag(PF_stablePlaneOnDominantBranch);
+        path.SetThp(path.GetThp() * bs.weight);
+        path.clearScatterEventFlags();
+        path.origin = sd.computeNewRayOrigin(bs.isLobe(Lobe_Reflection));
+        const float roughness = bsdf.data.roughness;
+        bool isDiffuse = bs.isLobe(Lobe_DiffuseReflection) || bs.isLobe(Lobe_DiffuseTransmission) || roughness > kSpecularRoughnessThreshold;
+        if (isDiffuse) { if (!(bs.isLobe(Lobe_DiffuseTransmission) && ((path.getVertexIndex() % 2) == 1))) path.incrementCounter(PC_DiffuseBounces); }
+        else path.setFlag(PF_specular);
+        if (bs.isLobe(Lobe_Transmission)) {
+            path.setFlag(PF_transmission);
+            if (pt.S.nestedDielectricsQuality > 0 && !sd.mtl.isThinSurface()) {
+                path.interiorList.handleIntersection(sd.materialID, sd.mtl.getNestedPriority(), sd.frontFacing);
+                path.setFlag(PF_insideDielectricVolume, !path.interiorList.isEmpty());
+            }
+        }
+        if (bs.isLobe(Lobe_Delta)) path.setFlag(PF_delta);
+        else {
+            path.setFlag(PF_deltaOnlyPath, false);
+            path.rayCone = RayCone::make(path.rayCone.getWidth(), fminf_(path.rayCone.getSpreadAngle() + SP_ray_cone_expansion(pt, bs.pdf), 2.0f * K_PI));
+        }
+        const float kSpecularRoughnessThresholdForHitT = 0.35f;
+        const bool isDiffuseForSpecHitT = bs.isLobe(Lobe_DiffuseReflection) || bs.isLobe(Lobe_DiffuseTransmission) || roughness > kSpecularRoughnessThresholdForHitT;
+        if (onDominantDenoisingLayer && !isDiffuseForSpecHitT) {
+            if (!blockMVs) { path.setFlag(PF_exportSpecHitTQueued, true); ExportSpecHitTStart(path); }
+        } else if (path.hasFlag(PF_exportSpecHitTQueued)) {
+            const bool hasNonDeltaLobes = (bsdf.getLobes() & Lobe_NonDelta) != 0;
+            const uint maxHitTSpecBounces = 4;
+            if (hasNonDeltaLobes || path.getCounter(SP_PC_BouncesFromStablePlane) > maxHitTSpecBounces) { ExportSpecHitTStop(path); path.setFlag(PF_exportSpecHitTQueued, false); }
+        }
+        float fireflyFilterK = SP_new_scatter_ffk(pt, path.GetFireflyFilterK(), bs.pdf, bs.lobeP);
+        path.SetFireflyFilterK_BsdfScatterPdf(fireflyFilterK, bs.pdf);
+        StablePlanesOnScatter(path, bs.lobe);
+        path.setFlag(PF_enableThreadReorder, true);
+        return true;
+    }
+    // HandleNEE + ProcessLightSample up to the visibility ray (PathTracerNEE.hlsli:185-275, 303-346), one full sample; returns the packed NEEBSDFMISInfo of the vertex
+    uint HandleNEE(const PathState& pre, const ShadingData& sd, const StandardBSDF& bsdf, UniformSampleSequenceGenerator& sg, SPNeeRequest& req, float4& neeRadianceAndSpecAvg) const {
+        req.valid = false; neeRadianceAndSpecAvg = make_float4(0, 0, 0, 0);
+        const LightSampler lightSampler = SP_light_sampler(pt, pre.id, SP_ssc_heuristic(pt, pre.rayCone.getWidth(), pre.sceneLength));
+        const uint fullSamples = pt.S.NEEFullSamples < 63u ? pt.S.NEEFullSamples : 63u;
+        const bool hasNonDeltaLobes = (bsdf.getLobes() & Lobe_NonDelta) != 0;
+        const bool applyNEE = hasNonDeltaLobes && !lightSampler.IsEmpty() && fullSamples > 0;
+        if (!applyNEE) return NEEBSDFMISInfo::empty().Pack16bit();
+        const uint candidateSampleCount = pt.S.NEECandidateSamples;
+        NEEBSDFMISInfo info; info.LightSamplingEnabled = true; info.LightSamplingIsSSC = lightSampler.IsScreenSpaceCoherent; info.CandidateSamples = candidateSampleCount; info.FullSamples = fullSamples;
+        LightSample ls = pt.GenerateLightSample(lightSampler, sd, bsdf, candidateSampleCount, sg);
+        if (ls.Valid()) {
+            float faceSide = dot(sd.N, ls.Direction) >= 0 ? 1.f : -1.f;
+            req.origin = ComputeRayOrigin(sd.posW, sd.faceNCorrected * faceSide); req.dir = ls.Direction; req.tmax = ls.Distance * 0.9985f; req.valid = true;
+            float fadeOut = (sd.shadowNoLFadeout > 0) ? ComputeLowGrazingAngleFalloff(ls.Direction, sd.vertexN, sd.shadowNoLFadeout, 2.0f * sd.shadowNoLFadeout) : 1.0f;
+            uint localCount, globalCount;
+            lightSampler.GetCandidateSampleCounts(candidateSampleCount, localCount, globalCount);
+            float thisPdf, otherPdf, thisCount, otherCount;
+            lightSampler.ComputeLightSelectionPdfs(ls.SelectionPdf, ls.LightIndex, ls.FromLocalDistribution, localCount, globalCount, thisPdf, otherPdf, thisCount, otherCount);
+            float wrsMIS = EvalMIS_Balance(1, thisPdf, 1, otherPdf);
+            wrsMIS = wrsMIS / thisCount;
+            float scatterPdfForDir = bsdf.evalPdf(sd, ls.Direction);
+            float lightAvgPdf = (thisPdf + otherPdf) * (float)fullSamples;
+            float pathMIS = EvalMIS_Balance(1, lightAvgPdf * ls.SolidAnglePdf, 1, ls.LightSampleableByBSDF ? scatterPdfForDir : 0.f);
+            float3 Li = ls.Li * (fadeOut * wrsMIS * pathMIS / (float)fullSamples);
+            float4 bsdfThp = bsdf.eval(sd, ls.Direction);
+            float3 radiance = xyz(bsdfThp) * Li;
+            float radianceAvg = Average(radiance);
+            float specAvg = bsdfThp.w * Average(Li);
+            if (pt.S.fireflyFilterThreshold != 0) {
+                float pdf = ls.SelectionPdf * ls.SolidAnglePdf;
+                float k = SP_new_scatter_ffk(pt, pre.GetFireflyFilterK(), pdf, 1.0f);
+                radiance = radiance * FireflyFilterShort(radianceAvg, pt.S.fireflyFilterThreshold, k);
+            }
+            float3 preThp = pre.GetThp();
+            radiance = radiance * preThp;
+            specAvg *= Average(preThp);
+            neeRadianceAndSpecAvg = SP_Fp16ToFp32(SP_Fp32ToFp16(make_float4(0, 0, 0, 0) + make_float4(radiance, specAvg)));      // NEEResult::AccumulateRadiance on the empty result, then GetRadianceAndSpecAvg
+        }
+        return info.Pack16bit();
+    }
+    // HandleHit (PathTracer.hlsli:505-762, FILL). req.valid afterwards: trace req's visibility ray and call ApplyVisibleLight if nothing is hit.
+    void HandleHit(PathState& path, float3 rayOrigin, float3 rayDir, uint prim, float rayTCurrent, float bu, float bv, SPNeeRequest& req) const {
+        req.valid = false;
+        pt.UpdatePathTravelled(path, rayTCurrent);
+        SurfaceData surfaceData = pt.loadSurface(prim, bu, bv, rayDir, path.rayCone);
+        const SPMaterialInfo mi = SP_material_info(SP_material_flags(pt, surfaceData.shadingData.materialID));
+        if (pt.S.nestedDielectricsQuality > 0 && !path.interiorList.isEmpty()) {
+            const float3 transmittance = pt.volumeTransmittance(path.interiorList.getTopMaterialID(), rayTCurrent);
+            path.SetThp(path.GetThp() * transmittance);
+        }
+        if (!pt.HandleNestedDielectrics(surfaceData, path)) return;
+        const ShadingData& sd = surfaceData.shadingData; const StandardBSDF& bsdf = surfaceData.bsdf;
+        float3 surfaceEmission = make_float3(0.f);
+        NEEBSDFMISInfo misInfo = NEEBSDFMISInfo::Unpack16bit(path.GetPackedMISInfo());
+        if (any_gt0(sd.emission)) {
+            float misWeight = 1.0f;
+            float bsdfScatterPdf = path.GetBsdfScatterPdf();
+            if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0) {
+                const LightSampler lightSampler = SP_light_sampler(pt, path.id, misInfo.LightSamplingIsSSC);
+                misWeight = lightSampler.ComputeBSDFMISForEmissiveTriangle(surfaceData.neeTriangleLightIndex, bsdfScatterPdf, rayOrigin, sd.posW, misInfo.CandidateSamples, misInfo.FullSamples);
+            }
+            surfaceEmission = LP::r3(sd.emission * misWeight);
+        }
+        if (surfaceData.neeAnalyticLightIndex != RTXPT_INVALID_LIGHT_INDEX) {
+            const LightSampler lightSampler = SP_light_sampler(pt, path.id, misInfo.LightSamplingIsSSC);
+            const float bsdfPdf = misInfo.LightSamplingEnabled ? LP::r(path.GetBsdfScatterPdf()) : 0.0f; float3 add;
+            if (lightSampler.ComputeAnalyticLightProxyContribution(surfaceData.neeAnalyticLightIndex, bsdfPdf, rayOrigin, rayDir, misInfo.CandidateSamples, misInfo.FullSamples, add)) {
+                add = LP::r3(add); surfaceEmission = make_float3(LP::add(surfaceEmission.x, add.x), LP::add(surfaceEmission.y, add.y), LP::add(surfaceEmission.z, add.z));
+            }
+        }
+        if (any_gt0(surfaceEmission)) {
+            const float baseFFThreshold = LP::r(pt.S.fireflyFilterThreshold);
+            if (baseFFThreshold != 0) surfaceEmission = SP_firefly_filter(pt, surfaceEmission, baseFFThreshold, path.GetFireflyFilterK());
+            if (any_gt0(surfaceEmission)) {
+                float3 radiance = path.GetThp() * surfaceEmission;
+                float specRadianceAvg = path.hasFlag(PF_stablePlaneBaseScatterDiff) ? 0.0f : Average(radiance);
+                AccumulatePathRadiance(path, radiance, specRadianceAvg, path.hasFlag(PF_stablePlaneOnBranch));
+            }
+        }
+        if (path.isTerminatingAtNextBounce()) { path.terminate(); return; }      // (StablePlanesHandleHit has no body in this pass)
+        const float rr = path.GetThpRuRuCorrection();
+        path.SetThp(path.GetThp() * make_float3(rr));
+        SampleGeneratorVertexBase vb = SampleGeneratorVertexBase::make(path.id, path.getVertexIndex(), sampleIndex);
+        UniformSampleSequenceGenerator uniformSG = UniformSampleSequenceGenerator::make(vb, SGES_Base);
+        const PathState preScatterPath = path;
+        bool scatterValid = GenerateScatterRay(sd, bsdf, mi.blockMVs, path, vb);
+        float4 neeRadianceAndSpecAvg = make_float4(0, 0, 0, 0);
+        uint packedMIS = NEEBSDFMISInfo::empty().Pack16bit();
+        if (pt.S.NEEEnabled) packedMIS = HandleNEE(preScatterPath, sd, bsdf, uniformSG, req, neeRadianceAndSpecAvg);
+        path.SetPackedMISInfo_ThpRuRuCorrection(packedMIS, path.GetThpRuRuCorrection());
+        if (neeRadianceAndSpecAvg.x > 0 || neeRadianceAndSpecAvg.y > 0 || neeRadianceAndSpecAvg.z > 0 || neeRadianceAndSpecAvg.w > 0) {
+            const int bouncesFromStablePlane = (int)preScatterPath.getCounter(SP_PC_BouncesFromStablePlane) + 1;
+            float3 radiance = xyz(neeRadianceAndSpecAvg);
+            float specRadianceAvg = 0;
+            if (!preScatterPath.hasFlag(PF_stablePlaneBaseScatterDiff)) {
+                bool pathIsDeltaOnlyPath = preScatterPath.hasFlag(PF_deltaOnlyPath);
+                bool specialCondition = (bouncesFromStablePlane == 1) || (pathIsDeltaOnlyPath && bouncesFromStablePlane <= 3);
+                specRadianceAvg = specialCondition ? neeRadianceAndSpecAvg.w : Average(xyz(neeRadianceAndSpecAvg));
+            }
+            req.newL = make_float4(radiance, specRadianceAvg) * sp.C.invSubSampleCount;      // AccumulatePathRadiance(path, radiance, specRadianceAvg, false) once the light is known to be visible
+        } else req.newL = make_float4(0, 0, 0, 0);      // (the visibility ray is traced whatever the sample is worth: the ray counts stay the reference's)
+        if (!scatterValid) path.terminate();
+        bool shouldTerminate = pt.HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces));
+        shouldTerminate |= pt.HandleRussianRoulette(path, uniformSG);
+        if (shouldTerminate) path.setFlag(PF_terminateAtNextBounce);
+    }
+};

@@ -76,6 +76,7 @@ struct DebugConstantsPin { uint exploreDeltaTree = 0; };
 struct DebugContext { DebugConstantsPin constants; uint2 pixelPos; bool IsDebugPixel() const { return false; } bool IsDebugPixel(uint2) const { return false; } void Reset(uint) {} void Reset(uint2, int) {} void SetPickedMaterial(uint) {}
     template <class... A> void DrawDebugViz(A...) {} };
 static inline void DebugCross(float3, float, float4) {}
+static inline bool isfinite(float v) { uint u; memcpy(&u, &v, 4); return (u & 0x7F800000u) != 0x7F800000u; }      // HLSL isfinite (PathTracerSample.hlsl FirstHitFromVBuffer)
 static inline float max3(float a, float b, float c) { return max(a, max(b, c)); }              // Utils/ColorHelpers.hlsli:19-27
 static inline float max3(float3 v) { return max3(v.x, v.y, v.z); }
 // DXR system values of the closest-hit shader HandleHit runs in: set by the driver loop before each call

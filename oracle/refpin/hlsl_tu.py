@@ -302,6 +302,9 @@ def main_pt(ref):
     stext = strip_comments(open(spath, encoding="latin-1").read())
     w("// ======== PathTracerSample.hlsl (selected items)\n")
     for body in extract_function(stext, "postProcessHit", "PathTracerSample.hlsl"): w(to_cpp(body) + "\n")
+    w("#if PATH_TRACER_MODE==PATH_TRACER_MODE_FILL_STABLE_PLANES\n")
+    for body in extract_function(stext, "FirstHitFromVBuffer", "PathTracerSample.hlsl"): w(to_cpp(body) + "\n")
+    w("#endif\n")
     w("} // namespace hl\n")
     w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
 

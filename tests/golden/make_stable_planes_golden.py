@@ -17,8 +17,17 @@ for name in spc.cases():
     o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(spc.W, spc.H)
     r = o.build_stable_planes(spc.SAMPLE, prm)
     for k in spc.KEYS:
-        if k != "planes": out[name + "_" + k] = r[k]
+        if k != "planes": out[name + "_" + k] = r[k].copy()
     out[name + "_live_planes"] = spc.live_planes(r)
+    # the noisy passes over that frame (PATH_TRACER_MODE_FILL_STABLE_PLANES, the other pin library): the planes' noisy radiance | specular average and the specular hit distance
+    f = ptref.Oracle(reference_integrator=True, settings=S, lp16=lp16, mode=2)
+    f.set_scene(sc); f.set_camera(camd); f.set_settings(S); f.resize(spc.W, spc.H)
+    for s in range(spc.SUBSAMPLES): f.fill_stable_planes(spc.SAMPLE + s, prm, r)
+    lp = spc.live_planes(r)
+    assert np.array_equal(np.delete(lp, (16, 17), 1), np.delete(out[name + "_live_planes"], (16, 17), 1)) and np.array_equal(r["header"], out[name + "_header"])      # the pass writes nothing else
+    out[name + "_fill_noisy"] = lp[:, 16:18].copy(); out[name + "_fill_spec_hit_t"] = r["spec_hit_t"]
+    out[name + "_fill_rays"] = np.array([f.counters()["extendRays"], f.counters()["shadowRays"]], np.uint64)
+    print("   fill:", out[name + "_fill_rays"].tolist(), "planes with noisy radiance", int((out[name + "_fill_noisy"] != 0).any(-1).sum())); f.close()
     hd = r["header"]
     print(name, "planes", [int((hd[i] != 0xFFFFFFFF).sum()) for i in range(3)], "dominant", np.unique(hd[3] & 3, return_counts=True)[1].tolist(), "rays", o.counters()["extendRays"])
     o.close()

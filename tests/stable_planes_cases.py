@@ -3,6 +3,7 @@ import numpy as np
 from rtxpt_amd import scenes
 
 W, H, SAMPLE = 64, 48, 5
+SUBSAMPLES = 2      # noisy (fill) passes per frame: sample indices SAMPLE, SAMPLE + 1 (the build pass uses the first one's camera ray)
 KEYS = ("header", "planes", "stable_radiance", "depth", "spec_hit_t", "motion_vectors", "throughput")
 
 
@@ -21,7 +22,7 @@ def setup(name):
     if lp16: S["useFp16Types"] = 1
     camd = scenes.bridge_camera(W, H, **cam)
     prev = dict(cam); prev["pos"] = tuple(np.asarray(cam["pos"]) + np.array([0.03, 0.01, 0.02]))
-    prm = scenes.stable_planes_params(W, H, scenes.view_projection(W, H, **cam), prev_world_to_clip=scenes.view_projection(W, H, **prev), **kw)
+    prm = scenes.stable_planes_params(W, H, scenes.view_projection(W, H, **cam), prev_world_to_clip=scenes.view_projection(W, H, **prev), sub_samples=SUBSAMPLES, **kw)
     return sc, camd, S, prm, lp16
 
 

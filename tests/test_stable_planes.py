@@ -95,3 +95,59 @@ def test_fewer_planes_never_change_plane_zero_geometry():
     for x, y in list(zip(xs.tolist(), ys.tolist()))[::17]:
         i = scenes.stable_planes_address(x, y, 0, spc.W, spc.H)
         for f in ("RayOrigin", "RayDir", "SceneLength", "PackedNormal", "VertexIndexAndRoughness"): assert np.array_equal(A[i][f], B[i][f])
+
+
+# ---- the noisy (fill) passes over the frame the build pass left
+def oracle_fill(name, reference=False):
+    sc, camd, S, prm, lp16 = spc.setup(name)
+    o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(spc.W, spc.H)
+    r = o.build_stable_planes(spc.SAMPLE, prm); built = {k: np.array(v, copy=True) for k, v in r.items() if isinstance(v, np.ndarray)}
+    f = o
+    if reference:
+        f = ptref.Oracle(reference_integrator=True, settings=S, lp16=lp16, mode=2); f.set_scene(sc); f.set_camera(camd); f.set_settings(S); f.resize(spc.W, spc.H)
+    c0 = f.counters()
+    for s in range(spc.SUBSAMPLES): f.fill_stable_planes(spc.SAMPLE + s, prm, r)
+    c1 = f.counters()
+    r["fill_rays"] = (c1["extendRays"] - c0["extendRays"], c1["shadowRays"] - c0["shadowRays"])
+    return r, built
+
+
+def check_fill_against_fixture(name, r, built):
+    lp = spc.live_planes(r)
+    assert np.array_equal(lp[:, 16:18], GOLD[name + "_fill_noisy"]), (name, "noisy radiance | specular average")
+    assert np.array_equal(r["spec_hit_t"].view(np.uint32), GOLD[name + "_fill_spec_hit_t"].view(np.uint32)), (name, "specular hit distance")
+    assert tuple(int(v) for v in GOLD[name + "_fill_rays"]) == r["fill_rays"], (name, "ray counts")
+    assert np.array_equal(np.delete(lp, (16, 17), 1), np.delete(spc.live_planes(built), (16, 17), 1)) and np.array_equal(r["header"], built["header"])      # nothing else is written
+
+
+@pytest.mark.parametrize("name", list(spc.cases()))
+def test_fill_oracle_equals_the_reference_text_fixture(name):
+    r, built = oracle_fill(name)
+    check_fill_against_fixture(name, r, built)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Rtxpt/Shaders"), reason="needs the reference text")
+def test_fill_reference_text_compiled_live_equals_the_fixture():
+    r, built = oracle_fill("zoo_fp32", reference=True)
+    check_fill_against_fixture("zoo_fp32", r, built)
+
+
+def test_fill_deposits_all_noisy_radiance_on_the_planes():
+    """what the two passes leave adds up to a picture: stable radiance + the planes' noisy radiance is the frame a denoiser starts from (StablePlanesContext::GetAllRadiance); on a scene whose
+    pixels never leave plane 0 by a delta bounce and see no emitter directly, it equals the reference-mode estimate of the same sample up to the fp16 packing of the planes"""
+    sc, cam = scenes.cornell_box("C1"); S = scenes.config_settings("C1"); w = h = 32
+    camd = scenes.bridge_camera(w, h, **cam)
+    prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cam), sub_samples=1)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)
+    r = o.build_stable_planes(0, prm); o.fill_stable_planes(0, prm, r)
+    P = r["planes"].view(scenes.STABLE_PLANE_DTYPE).reshape(-1)
+    noisy = np.zeros((h, w, 3), np.float32)
+    for y in range(h):
+        for x in range(w):
+            rec = P[scenes.stable_planes_address(x, y, 0, w, h)]["PackedNoisyRadianceAndSpecAvg"]
+            noisy[y, x] = np.array([rec[0] & 0xFFFF, rec[0] >> 16, rec[1] & 0xFFFF], np.uint16).view(np.float16).astype(np.float32)
+    total = noisy + r["stable_radiance"].view(np.float16).astype(np.float32)[..., :3]
+    o.render(0, 1); ref = o.radiance()[..., :3]
+    assert (r["header"][1:3] == 0xFFFFFFFF).all()                      # all Lambertian: one plane
+    err = np.abs(total - ref); tol = 2e-3 * np.maximum(ref, 1e-3) + 1e-4
+    assert (err <= tol).mean() > 0.99, "%.4f of the pixels within the fp16 packing tolerance" % float((err <= tol).mean())
