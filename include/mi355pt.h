@@ -299,6 +299,12 @@ typedef struct PtStablePlane {                  /* StablePlanes.hlsli:41-58 */
 int32_t pt_stable_planes_plane_stride(uint32_t width, uint32_t height, uint32_t* stride);     /* GenericTSComputePlaneStride (Utils.hlsli:328-332) */
 /* traces the pass for the context's pixels with the camera ray of sampleIndex (the sub-samples of a realtime frame share it); stats: rays, passes, GPU time */
 int32_t pt_build_stable_planes(pt_context* ctx, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* stats);
+/* One sub-sample of the realtime mode's noisy passes (Sample.cpp:2497-2516: RayGen with PATH_TRACER_MODE_FILL_STABLE_PLANES once per sub-sample, sample index sampleBaseIndex + subSampleIndex)
+ * over the buffers pt_build_stable_planes left: every path starts on plane 0 (FirstHitFromVBuffer), follows the recorded delta tree while its branch id matches, and deposits its radiance —
+ * total and specular average, attenuated by 1 / subSampleCount — on the plane it last touched (PtStablePlane.PackedNoisyRadianceAndSpecAvg, four binary16 values); emission along the stable
+ * branches was collected by the build pass and is not counted again. specularHitT is filled for the dominant plane. NEE with one full sample per vertex (NEEFullSamples 0 or 1); NEE-AT's local
+ * sampling tables are honoured, its temporal feedback is not fed (refused while pt_set_neeat / temporalFeedback are on). ReSTIR DI / GI hand-offs do not exist here. */
+int32_t pt_fill_stable_planes(pt_context* ctx, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* stats);
 /* copies the last pass's buffers to the host; any pointer may be NULL. planeCapacity in records (>= 3 x plane stride); the two RGBA16F targets as 4 binary16 bit patterns per pixel */
 int32_t pt_get_stable_planes(pt_context* ctx, uint32_t* header, PtStablePlane* planes, size_t planeCapacity, uint16_t* stableRadiance, float* depth, float* specularHitT,
                              uint16_t* motionVectors, uint32_t* throughput);

@@ -34,7 +34,7 @@ EXPORTS = [
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
-    "pt_stable_planes_plane_stride", "pt_build_stable_planes", "pt_get_stable_planes",
+    "pt_stable_planes_plane_stride", "pt_build_stable_planes", "pt_fill_stable_planes", "pt_get_stable_planes",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host", "pt_neeat_exchange_host",
 ]
 
@@ -690,6 +690,27 @@ class PathTracer:
         self._chk(f(self.h, _p(out["header"]), _p(out["planes"]), 3 * stride, _p(out["stable_radiance"]), _p(out["depth"]), _p(out["spec_hit_t"]), _p(out["motion_vectors"]), _p(out["throughput"])), "pt_get_stable_planes")
         out["plane_stride"] = stride
         out["stats"] = st.as_dict()
+        return out
+
+    def fill_stable_planes(self, sample_index, params, sub_samples=1):
+        """pt_fill_stable_planes for sub_samples consecutive sample indices + pt_get_stable_planes: the realtime mode's noisy passes over the frame build_stable_planes left.
+        Returns the same dict as build_stable_planes (planes with their noisy radiance, spec_hit_t filled), stats summed over the sub-samples."""
+        prm = np.ascontiguousarray(params); assert prm.dtype.itemsize == 224
+        f = self.L.pt_fill_stable_planes; f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]; f.restype = ctypes.c_int32
+        total = {}
+        for s in range(sub_samples):
+            st = PtFrameStats()
+            self._chk(f(self.h, int(sample_index) + s, _p(prm), ctypes.byref(st)), "pt_fill_stable_planes")
+            for k, v in st.as_dict().items():
+                if np.isscalar(v): total[k] = total.get(k, 0) + v
+        w, h = self.width, self.height
+        g = self.L.pt_stable_planes_plane_stride; g.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]; g.restype = ctypes.c_int32
+        stride = ctypes.c_uint32(0); self._chk(g(w, h, ctypes.byref(stride)), "pt_stable_planes_plane_stride"); stride = int(stride.value)
+        out = dict(header=np.zeros((4, h, w), np.uint32), planes=np.zeros((3 * stride, 20), np.uint32), stable_radiance=np.zeros((h, w, 4), np.uint16), depth=np.zeros((h, w), np.float32),
+                   spec_hit_t=np.zeros((h, w), np.float32), motion_vectors=np.zeros((h, w, 4), np.uint16), throughput=np.zeros((h, w), np.uint32))
+        g = self.L.pt_get_stable_planes; g.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 5; g.restype = ctypes.c_int32
+        self._chk(g(self.h, _p(out["header"]), _p(out["planes"]), 3 * stride, _p(out["stable_radiance"]), _p(out["depth"]), _p(out["spec_hit_t"]), _p(out["motion_vectors"]), _p(out["throughput"])), "pt_get_stable_planes")
+        out["plane_stride"] = stride; out["stats"] = total
         return out
 
     def set_neeat(self, enable=True, global_feedback_weight=0.75, ratio=0.65, ssc_threshold=0.3, prefilter=True):

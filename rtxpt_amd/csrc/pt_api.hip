@@ -115,7 +115,7 @@ struct pt_context {
     double buildMs = 0, refitMs = 0, lightBakeMs = 0;
     uint poolCapacity = 0; size_t shadowCapacity = 0;
     // stable planes (pt_build_stable_planes): the realtime mode's per-frame buffers (RenderTargets.cpp:60-141, 340-352) of the last pre-pass
-    DevBuf<uint> dSpHeader, dSpThroughput; DevBuf<ptk::StablePlane> dSpPlanes; DevBuf<ptk::uint2> dSpRadiance, dSpMotion; DevBuf<float> dSpDepth, dSpHitT; uint spW = 0, spH = 0;
+    DevBuf<uint> dSpHeader, dSpThroughput; DevBuf<ptk::StablePlane> dSpPlanes; DevBuf<ptk::uint2> dSpRadiance, dSpMotion; DevBuf<float> dSpDepth, dSpHitT; uint spW = 0, spH = 0; DevBuf<ptk::uint4> dSpMark; DevBuf<ptk::float4> dSpNewL;      // (the last two: scratch of the fill passes)
     // frame gather (pt_comm_init / pt_gather)
     ncclComm_t comm = nullptr; uint commRank = 0, commWorld = 0; DevBuf<ptk::float4> dGatherSend, dGatherRecv; DevBuf<uint> dGatherPixels; std::vector<size_t> gatherCounts; uint gatherW = 0, gatherH = 0;
 };
@@ -647,7 +647,7 @@ int32_t pt_destroy(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
-    c->dSpHeader.free(); c->dSpThroughput.free(); c->dSpPlanes.free(); c->dSpRadiance.free(); c->dSpMotion.free(); c->dSpDepth.free(); c->dSpHitT.free();
+    c->dSpHeader.free(); c->dSpThroughput.free(); c->dSpPlanes.free(); c->dSpRadiance.free(); c->dSpMotion.free(); c->dSpDepth.free(); c->dSpHitT.free(); c->dSpMark.free(); c->dSpNewL.free();
     c->neeat.free(); c->dLocalTable.free(); c->dFbWeight.free(); c->dFbCand.free(); c->dSq3.free();
     c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free(); c->dLightW.free(); c->dProxyOffsets.free(); if (c->dScanTemp) (void)hipFree(c->dScanTemp);
     if (c->bvhAllocated) bvh_free(c->bvh);
@@ -1226,6 +1226,70 @@ int32_t pt_build_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStab
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (hwc->overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
     if (active) return fail(c, PT_ERROR_HIP, "stable-plane build pass: paths still exploring after the iteration bound");
+    return PT_OK;
+}
+int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* stats) {
+    if (!c || !params) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes first");
+    if (c->S.NEEEnabled && c->S.NEEFullSamples > 1u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill pass traces one full NEE sample per vertex (NEEFullSamples 0 or 1, the reference's default)");
+    if (c->neeat.enabled || c->feedbackRequired) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill pass does not feed NEE-AT's reservoirs: switch the temporal feedback off (local sampling tables alone are fine)");
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const uint numOwned = (uint)c->owned.size();
+    if (!numOwned) return PT_OK;
+    r = ensure_pool(c, numOwned, 1u); if (r != PT_OK) return r;
+    const bool freshMark = c->dSpMark.n < numOwned;
+    PT_CHECK_HIP(c, c->dSpMark.resize(numOwned)); PT_CHECK_HIP(c, c->dSpNewL.resize(numOwned));
+    if (freshMark) PT_CHECK_HIP(c, hipMemsetAsync(c->dSpMark.p, 0, sizeof(ptk::uint4) * c->dSpMark.n, c->stream));      // (k_sp_fill_resolve clears what a pass marked)
+    ptk::StablePlanesParams prm; memcpy(&prm, params, sizeof(prm));
+    StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
+    sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p; sp.B.Depth = c->dSpDepth.p; sp.B.SpecularHitT = c->dSpHitT.p; sp.B.MotionVectors = c->dSpMotion.p; sp.B.Throughput = c->dSpThroughput.p;
+    PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
+    PathPool pool{c->dS0.p, c->dS1.p, c->dS2.p, c->dS3.p, c->dS4.p, c->dHit.p};
+    PathPool markPool = pool; markPool.s2 = c->dSpMark.p;
+    ShadowQueue sq{c->dSq0.p, c->dSq1.p, c->dSq2.p, 0u, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    uint* queue[2] = {c->dQueue[0].p, c->dQueue[1].p};
+    WaveCounters* wc = c->dCounters.p; WaveCounters* hwc = c->hostCounters;
+    TravAux aux; aux.taskQ[0] = c->dTaskQ.p; aux.taskQ[1] = aux.taskQ[0] + TASK_QUEUE_CAPACITY; aux.counts = c->dTravCounts.p; aux.maxBlocks = 0u;
+    aux.taskCap = TASK_QUEUE_CAPACITY; aux.bestKey = c->dBestKey.p; aux.resolveList = c->dResolveList.p; aux.primToSlot = c->bvh.primToSlot;
+    TravAux auxShadow = aux; auxShadow.counts = aux.counts + PASS_SHADOW_OFFSET;
+    memset(hwc, 0, sizeof(WaveCounters));
+    hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
+    PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
+    PT_CHECK_HIP(c, hipMemcpyAsync(wc, hwc, sizeof(WaveCounters), hipMemcpyHostToDevice, c->stream));
+    launch_sp_fill_generate(k, sp, pool, c->dOwned.p, numOwned, sampleIndex, queue[0], &wc->extendCount[0], c->stream);
+    PT_CHECK_HIP(c, hipMemcpyAsync(hwc, wc, 16, hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    const uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u)) * (c->S.bounceCount + 1u);
+    uint cur = 0, active = hwc->extendCount[0], iterations = 0; unsigned long long rays = 0, shadowRays = 0;
+    while (active && iterations < maxIter) {
+        const uint nxt = cur ^ 1u;
+        launch_pass_reset(aux.counts, &wc->extendCount[nxt], &wc->shadowCount, c->stream);
+        launch_extend(c->dsc, pool, queue[cur], &wc->extendCount[cur], active, wc, c->countersEnabled, aux, c->stream);
+        launch_sp_fill_shade(k, sp, pool, queue[cur], &wc->extendCount[cur], active, queue[nxt], &wc->extendCount[nxt], sq, c->dSpNewL.p, sampleIndex, wc, c->stream);
+        rays += active;
+        PT_CHECK_HIP(c, hipMemcpyAsync(hwc, wc, 16, hipMemcpyDeviceToHost, c->stream));
+        PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        const uint nShadow = hwc->shadowCount;
+        if (nShadow) {
+            launch_shadow(c->dsc, markPool, sq, &wc->shadowCount, nShadow, wc, c->countersEnabled, auxShadow, c->stream);
+            launch_sp_fill_resolve(pool, c->dSpMark.p, sq, c->dSpNewL.p, &wc->shadowCount, nShadow, c->stream);
+            shadowRays += nShadow;
+        }
+        active = hwc->extendCount[nxt]; cur = nxt; iterations++;
+    }
+    launch_sp_fill_commit(k, sp, pool, numOwned, sampleIndex, c->stream);
+    PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
+    PT_CHECK_HIP(c, hipMemcpyAsync(hwc, wc, sizeof(WaveCounters), hipMemcpyDeviceToHost, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    PT_CHECK_HIP(c, hipGetLastError());
+    if (stats) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); stats->gpuMilliseconds = ms; stats->extendRays = rays; stats->shadowRays = shadowRays; stats->hits = hwc->hits; stats->iterations = iterations; stats->extendLaunches = iterations;
+                 stats->pathsTraced = numOwned; stats->nodeVisitsExtend = hwc->nodeVisitsExt; stats->triTestsExtend = hwc->triTestsExt; stats->nodeVisitsShadow = hwc->nodeVisitsSh; stats->triTestsShadow = hwc->triTestsSh; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (hwc->overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
+    if (active) return fail(c, PT_ERROR_HIP, "stable-plane fill pass: paths still alive after the iteration bound");
     return PT_OK;
 }
 int32_t pt_get_stable_planes(pt_context* c, uint32_t* header, PtStablePlane* planes, size_t planeCapacity, uint16_t* stableRadiance, float* depth, float* specularHitT, uint16_t* motionVectors, uint32_t* throughput) {

@@ -64,6 +64,104 @@ __global__ void __launch_bounds__(256) k_sp_build_shade(PKC k, StablePlanesConte
     if (alive) queueOut[base + (uint)__popcll(mAlive & ((1ull << lane) - 1ull))] = p;
 }
 
+// ---- the noisy (fill) passes: PathTracerSample.hlsl:200-250 with PATH_TRACER_MODE_FILL_STABLE_PLANES, one sub-sample per call of pt_fill_stable_planes.
+// A pass of the host loop is one vertex of every live path, as in reference mode: launch_extend, k_sp_fill_shade (hit / miss shader up to the light sample), launch_shadow, k_sp_fill_resolve.
+// The visibility rays go through the reference mode's own shadow launches, unchanged: their "visible" action adds the entry's radiance to the L words of pool.s2 — here they are handed a
+// scratch copy of that stream and a unit radiance, so a visible entry leaves a mark that k_sp_fill_resolve turns into the float4 increment (total + specular average) this pass needs.
+template <class PKC>
+__global__ void __launch_bounds__(256) k_sp_fill_generate(PKC k, StablePlanesContext sp, PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint sampleIndex, uint* __restrict__ queue, uint* countPtr) {
+    const uint i = blockIdx.x * 256u + threadIdx.x;
+    bool alive = false;
+    if (i < numOwned) {
+        const uint px = ownedPixels[i];
+        const StablePlanesFiller<PKC> f{k, sp, sampleIndex};
+        PathState p = f.generate(px >> 16, px & 0xFFFFu);
+        sp_store_path(pool, i, p);
+        alive = p.isActive();
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
+    const uint lane = threadIdx.x & 63u;
+    uint base = 0;
+    if (lane == 0u && m) base = atomicAdd(countPtr, (uint)__popcll(m));
+    base = __shfl(base, 0);
+    if (alive) queue[base + (uint)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+template <class PKC>
+__global__ void __launch_bounds__(256) k_sp_fill_shade(PKC k, StablePlanesContext sp, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr, uint* __restrict__ queueOut, uint* countOutPtr,
+                                                       ShadowQueue sq, float4* __restrict__ newL, uint sampleIndex, WaveCounters* wc) {
+    const uint count = *countInPtr;
+    const uint i = blockIdx.x * 256u + threadIdx.x;
+    bool alive = false, isHit = false; uint p = 0;
+    SPNeeRequest req; req.valid = false;
+    if (i < count) {
+        p = queueIn[i];
+        PathState path = sp_load_path(pool, p);
+        const uint4 hr = pool.hit[p];
+        const float3 rayOrigin = path.origin, rayDir = path.dir;
+        const StablePlanesFiller<PKC> f{k, sp, sampleIndex};
+        if (hr.y == 0xFFFFFFFFu) f.HandleMiss(path, rayDir, kMaxRayTravel);
+        else { isHit = true; f.HandleHit(path, rayOrigin, rayDir, hr.y, asfloat(hr.x), asfloat(hr.z), asfloat(hr.w), req); }
+        sp_store_path(pool, p, path);
+        alive = path.isActive();
+    }
+    const unsigned long long mAlive = __builtin_amdgcn_ballot_w64(alive), mHit = __builtin_amdgcn_ballot_w64(isHit), mReq = __builtin_amdgcn_ballot_w64(req.valid);
+    const uint lane = threadIdx.x & 63u; const unsigned long long below = (1ull << lane) - 1ull;
+    uint base = 0, sbase = 0;
+    if (lane == 0u) { if (mAlive) base = atomicAdd(countOutPtr, (uint)__popcll(mAlive)); if (mReq) sbase = atomicAdd(&wc->shadowCount, (uint)__popcll(mReq)); if (mHit) atomicAdd(&wc->hits, (unsigned long long)__popcll(mHit)); }
+    base = __shfl(base, 0); sbase = __shfl(sbase, 0);
+    if (alive) queueOut[base + (uint)__popcll(mAlive & below)] = p;
+    if (req.valid) {
+        const uint s = sbase + (uint)__popcll(mReq & below);
+        sq.q0[s] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
+        sq.q1[s] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
+        sq.q2[s] = make_float4(1.0f, 0.f, 0.f, 0.f);      // the mark a visible entry leaves in the scratch L
+        newL[s] = req.newL;
+    }
+}
+// AccumulatePathRadiance of the vertex's light sample, for the entries the shadow launches found visible; the marks are cleared for the next pass
+__global__ void __launch_bounds__(256) k_sp_fill_resolve(PathPool pool, uint4* __restrict__ mark, ShadowQueue sq, const float4* __restrict__ newL, const uint* __restrict__ countPtr) {
+    const uint count = *countPtr;
+    for (uint i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint p = asuint(sq.q1[i].w);
+        const uint4 m = mark[p];
+        if ((m.z | m.w) == 0u) continue;
+        mark[p] = make_uint4(0u, 0u, 0u, 0u);
+        uint4 c = pool.s2[p];
+        PathState t; t.pack45[0] = c.z; t.pack45[1] = c.w;
+        SPNeeRequest req; req.newL = newL[i];
+        t.SetL(t.GetL() + req.newL);
+        c.z = t.pack45[0]; c.w = t.pack45[1];
+        pool.s2[p] = c;
+    }
+}
+// CommitPixel -> CommitDenoiserRadiance for every pixel of the pass
+template <class PKC>
+__global__ void __launch_bounds__(256) k_sp_fill_commit(PKC k, StablePlanesContext sp, PathPool pool, uint numOwned, uint sampleIndex) {
+    const uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= numOwned) return;
+    PathState path = sp_load_path(pool, i);
+    const StablePlanesFiller<PKC> f{k, sp, sampleIndex};
+    f.CommitDenoiserRadiance(path);
+}
+
+#define SP_LAUNCH(KERNEL, G, ...) do { if (k.S.useFp16Types) { PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16)); hipLaunchKernelGGL((KERNEL<PathKernelContextT<true>>), G, dim3(256), 0, st, k16, __VA_ARGS__); } \
+                                        else hipLaunchKernelGGL((KERNEL<PathKernelContext>), G, dim3(256), 0, st, k, __VA_ARGS__); } while (0)
+void launch_sp_fill_generate(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleIndex, uint* queue, uint* countPtr, hipStream_t st) {
+    SP_LAUNCH(k_sp_fill_generate, dim3((numOwned + 255u) / 256u), sp, pool, ownedPixels, numOwned, sampleIndex, queue, countPtr);
+}
+void launch_sp_fill_shade(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, float4* newL,
+                          uint sampleIndex, WaveCounters* wc, hipStream_t st) {
+    SP_LAUNCH(k_sp_fill_shade, dim3((countIn + 255u) / 256u), sp, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, newL, sampleIndex, wc);
+}
+void launch_sp_fill_resolve(PathPool pool, uint4* mark, ShadowQueue sq, const float4* newL, const uint* countPtr, uint count, hipStream_t st) {
+    uint g = (count + 255u) / 256u; if (g > 4096u) g = 4096u; if (g < 1u) g = 1u;
+    hipLaunchKernelGGL(k_sp_fill_resolve, dim3(g), dim3(256), 0, st, pool, mark, sq, newL, countPtr);
+}
+void launch_sp_fill_commit(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, uint numOwned, uint sampleIndex, hipStream_t st) {
+    SP_LAUNCH(k_sp_fill_commit, dim3((numOwned + 255u) / 256u), sp, pool, numOwned, sampleIndex);
+}
+#undef SP_LAUNCH
+
 void launch_sp_generate(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleIndex, uint* queue, hipStream_t st) {
     const dim3 g((numOwned + 255u) / 256u), b(256);
     if (k.S.useFp16Types) { PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16)); hipLaunchKernelGGL((k_sp_generate<PathKernelContextT<true>>), g, b, 0, st, k16, sp, pool, ownedPixels, numOwned, sampleIndex, queue); }

@@ -3,6 +3,8 @@
   * against the outputs of the REFERENCE TEXT of that pass (tests/golden/stable_planes_golden.npz), no oracle code in the loop: header, the records of every plane that exists,
     stable radiance, depth, motion vectors, throughput — bit for bit, fp32 and binary16 lp types, one / two / three planes;
   * against the oracle at a larger frame and on the Cornell scenes, ray counts included;
+  * the noisy (fill) passes over such a frame, pt_fill_stable_planes: the planes' noisy radiance | specular average, the specular hit distance and the ray counts against the
+    reference text's fixture and against the oracle;
   * a second pass over the same context (the buffers are re-initialised by the pass itself), and what the API refuses.
 (The file sorts after the other GPU tests on purpose: the newest entry point is tested last.)"""
 import os, sys
@@ -99,3 +101,61 @@ def test_refusals_and_the_reference_mode_frame_is_untouched():
     planes = np.zeros((8, 20), np.uint32)
     assert f(t.h, None, planes.ctypes.data_as(ctypes.c_void_p), 8, None, None, None, None, None) != 0          # plane buffer too small
     t.close(); t2.close()
+
+
+# ---- the noisy (fill) passes
+@pytest.mark.parametrize("name", list(spc.cases()))
+def test_fill_device_matches_reference_text(name):
+    g = np.load(GOLD)
+    sc, camd, S, prm, lp16 = spc.setup(name)
+    t = _tracer(sc, camd, S, spc.W, spc.H)
+    built = t.build_stable_planes(spc.SAMPLE, prm)
+    got = t.fill_stable_planes(spc.SAMPLE, prm, sub_samples=spc.SUBSAMPLES)
+    lp = spc.live_planes(got)
+    bad = (lp[:, 16:18] != g[name + "_fill_noisy"]).any(-1)
+    assert not bad.any(), "%s: noisy radiance of %d of %d planes differs from the reference text" % (name, int(bad.sum()), bad.size)
+    a, b = got["spec_hit_t"].view(np.uint32), g[name + "_fill_spec_hit_t"].view(np.uint32)
+    assert np.array_equal(a, b), "%s: specular hit distance differs in %d pixels" % (name, int((a != b).sum()))
+    assert (int(got["stats"]["extendRays"]), int(got["stats"]["shadowRays"])) == tuple(int(v) for v in g[name + "_fill_rays"])
+    assert np.array_equal(np.delete(lp, (16, 17), 1), np.delete(spc.live_planes(built), (16, 17), 1)) and np.array_equal(got["header"], built["header"])      # nothing else is written
+    for k in ("stable_radiance", "depth", "motion_vectors", "throughput"): assert np.array_equal(got[k], built[k]), k
+    t.close()
+
+
+@pytest.mark.parametrize("lp16,nested,overrides", [(False, 1, {}), (True, 2, {}), (False, 1, dict(enableRussianRoulette=0, fireflyFilterThreshold=0.0)), (False, 0, dict(NEEEnabled=0))])
+def test_fill_device_matches_oracle(lp16, nested, overrides):
+    from oracle import ptref
+    w, h, sample, subs = 160, 100, 11, 2
+    sc, cam = scenes.stable_planes_zoo(); S = scenes.config_settings("C2")
+    S["nestedDielectricsQuality"] = nested
+    for k, v in overrides.items(): S[k] = v
+    if lp16: S["useFp16Types"] = 1
+    camd = scenes.bridge_camera(w, h, **cam)
+    prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cam), sub_samples=subs)
+    o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)
+    want = o.build_stable_planes(sample, prm); c0 = o.counters()
+    for s in range(subs): o.fill_stable_planes(sample + s, prm, want)
+    c1 = o.counters(); o.close()
+    t = _tracer(sc, camd, S, w, h)
+    t.build_stable_planes(sample, prm)
+    got = t.fill_stable_planes(sample, prm, sub_samples=subs)
+    assert np.array_equal(got["header"], want["header"])
+    assert np.array_equal(_live(got, w, h), _live(want, w, h)), "plane records (noisy radiance included)"
+    assert np.array_equal(got["spec_hit_t"].view(np.uint32), want["spec_hit_t"].view(np.uint32))
+    assert (int(got["stats"]["extendRays"]), int(got["stats"]["shadowRays"])) == (c1["extendRays"] - c0["extendRays"], c1["shadowRays"] - c0["shadowRays"])
+    t.close()
+
+
+def test_fill_refusals():
+    import ctypes
+    sc, camd, S, prm, lp16 = spc.setup("zoo_fp32")
+    t = _tracer(sc, camd, S, spc.W, spc.H)
+    f = t.L.pt_fill_stable_planes; f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]; f.restype = ctypes.c_int32
+    p = np.ascontiguousarray(prm)
+    assert f(t.h, 0, p.ctypes.data_as(ctypes.c_void_p), None) != 0            # no build pass yet
+    t.build_stable_planes(spc.SAMPLE, prm)
+    S2 = S.copy(); S2["NEEFullSamples"] = 3; t.set_settings(S2)
+    assert f(t.h, 0, p.ctypes.data_as(ctypes.c_void_p), None) != 0            # several full NEE samples per vertex
+    t.set_settings(S)
+    assert f(t.h, spc.SAMPLE, p.ctypes.data_as(ctypes.c_void_p), None) == 0
+    t.close()
