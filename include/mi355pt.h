@@ -305,6 +305,8 @@ int32_t pt_build_stable_planes(pt_context* ctx, uint32_t sampleIndex, const PtSt
  * branches was collected by the build pass and is not counted again. specularHitT is filled for the dominant plane. NEE with one full sample per vertex (NEEFullSamples 0 or 1); NEE-AT's local
  * sampling tables are honoured, its temporal feedback is not fed (refused while pt_set_neeat / temporalFeedback are on). ReSTIR DI / GI hand-offs do not exist here. */
 int32_t pt_fill_stable_planes(pt_context* ctx, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* stats);
+/* DenoisingGuidesBaker::DenoiseSpecHitT (Sample.cpp:2544, after the noisy passes of a frame): the 5 x 5 depth-aware fill-in of specularHitT, one ping and one pong (DenoisingGuidesBaker.hlsl:50-113) */
+int32_t pt_denoise_spec_hit_t(pt_context* ctx);
 /* copies the last pass's buffers to the host; any pointer may be NULL. planeCapacity in records (>= 3 x plane stride); the two RGBA16F targets as 4 binary16 bit patterns per pixel */
 int32_t pt_get_stable_planes(pt_context* ctx, uint32_t* header, PtStablePlane* planes, size_t planeCapacity, uint16_t* stableRadiance, float* depth, float* specularHitT,
                              uint16_t* motionVectors, uint32_t* throughput);

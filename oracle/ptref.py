@@ -674,6 +674,14 @@ class Oracle:
         return np.array(o, np.float32)
 
 
+def denoise_spec_hit_t(depth, spec_hit_t, reference=False):
+    """DenoisingGuidesBaker::DenoiseSpecHitT on whole planes (float32 [h, w]): returns the filled-in specular hit distances. reference=True: the reference's compute shader text (any pin library)."""
+    d = np.ascontiguousarray(depth, np.float32); t = np.array(spec_hit_t, np.float32, copy=True, order="C"); h, w = d.shape
+    if reference: refpin_pt().refpt_denoise_spec_hit_t(w, h, _p(d), _p(t))
+    else: lib().ptref_denoise_spec_hit_t(w, h, _p(d), _p(t))
+    return t
+
+
 def num_threads():
     return int(lib().ptref_num_threads())
 

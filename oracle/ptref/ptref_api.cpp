@@ -778,6 +778,12 @@ void ptref_fill_stable_planes(void* h, uint32_t sampleIndex, const StablePlanesP
     c->ctr.extendRays += total.extendRays; c->ctr.shadowRays += total.shadowRays; c->ctr.hits += total.hits; c->ctr.nodeVisitsExt += total.nodeVisitsExt; c->ctr.triTestsExt += total.triTestsExt;
     c->ctr.nodeVisitsSh += total.nodeVisitsSh; c->ctr.triTestsSh += total.triTestsSh;
 }
+// DenoisingGuidesBaker::DenoiseSpecHitT (DenoisingGuidesBaker.cpp:62-84): ping into a scratch plane, pong back
+void ptref_denoise_spec_hit_t(uint32_t w, uint32_t hgt, const float* depth, float* specHitT) {
+    std::vector<float> scratch((size_t)w * hgt);
+    for (uint32_t y = 0; y < hgt; y++) for (uint32_t x = 0; x < w; x++) scratch[(size_t)y * w + x] = SpecHitTNeighbourhood(specHitT, depth, w, hgt, (int)x, (int)y);
+    for (uint32_t y = 0; y < hgt; y++) for (uint32_t x = 0; x < w; x++) specHitT[(size_t)y * w + x] = SpecHitTNeighbourhood(scratch.data(), depth, w, hgt, (int)x, (int)y);
+}
 void ptref_render(void* h, uint32_t first, uint32_t n) { Context* c = (Context*)h; ptref_render_rect(h, first, n, 0, 0, c->w, c->h); }
 const float* ptref_radiance(void* h) { return (const float*)((Context*)h)->accum.data(); }
 void ptref_get_counters(void* h, uint64_t* out7) { memcpy(out7, &((Context*)h)->ctr, sizeof(RayCounters)); }

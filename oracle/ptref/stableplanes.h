@@ -559,6 +559,33 @@ template <class PT> struct StablePlanesBuilder {
     }
 };
 
+// ---- DenoisingGuidesBaker.hlsl:50-113: the 5 x 5 depth-aware fill-in of the specular hit distance (Sample.cpp:2544 runs one ping (main -> scratch) and one pong (scratch -> main) after the noisy passes)
+static inline float SpecHitTNeighbourhood(const float* texSrc, const float* depthTex, uint width, uint height, int px, int py) {
+    const float centerD = depthTex[(size_t)py * width + px];
+    float prevHitT = fmaxf_(0.f, texSrc[(size_t)py * width + px]);
+    const float minSpecHitT = 5e-2f;
+    if (prevHitT < minSpecHitT) prevHitT = 0;
+    const int neigS = 2;
+    float vAvg = prevHitT;
+    float sumW = prevHitT > 0 ? 1.f : 0.f;
+    for (int x = -neigS; x <= +neigS; x++)
+        for (int y = -neigS; y <= +neigS; y++) {
+            if (x == 0 && y == 0) continue;
+            const int nx = px + x, ny = py + y;
+            if (nx >= 0 && ny >= 0 && nx < (int)width && ny < (int)height) {
+                float v = fminf_(texSrc[(size_t)ny * width + nx], HLF_MAX);
+                float d = fmaxf_(0.f, depthTex[(size_t)ny * width + nx]);
+                const float depthThreshold = 0.025f;
+                float weight = v > 0 ? 1.f : 0.f;
+                weight *= (fabsf(d - centerD) <= ((d + centerD) + 1e-5f) * depthThreshold) ? 1.f : 0.f;
+                if (weight > 0) { vAvg += v * weight; sumW += weight; }
+            }
+        }
+    if (sumW == 0) return prevHitT;
+    vAvg /= sumW;
+    return (prevHitT <= 0) ? vAvg : fminf_(prevHitT * 1.5f + 0.5f, vAvg);
+}
+
 // ================================================================================================================================================================================
 // ---- the FILL passes (PATH_TRACER_MODE_FILL_STABLE_PLANES): the noisy path tracer of the realtime mode. A path starts on plane 0 as the build pass left it (FirstHitFromVBuffer),
 // follows the recorded delta tree while its branch id matches (StablePlanesOnScatter), and deposits its radiance — split into a total and a specular average — on the plane it last

@@ -305,6 +305,17 @@ def main_pt(ref):
     w("#if PATH_TRACER_MODE==PATH_TRACER_MODE_FILL_STABLE_PLANES\n")
     for body in extract_function(stext, "FirstHitFromVBuffer", "PathTracerSample.hlsl"): w(to_cpp(body) + "\n")
     w("#endif\n")
+    # DenoisingGuidesBaker.hlsl: the specular-hit-distance fill-in that follows the noisy passes of a realtime frame
+    dpath = os.path.join(ref, "Rtxpt/ProcessingPasses/DenoisingGuidesBaker.hlsl")
+    dtext = strip_comments(open(dpath, encoding="latin-1").read())
+    w("// ======== DenoisingGuidesBaker.hlsl (selected items)\nnamespace dgb {\n")
+    w(to_cpp(extract_struct(dtext, "DenoisingGuidesBakerConstants", "DenoisingGuidesBaker.hlsl")) + "\n")
+    w("template <class T> struct RWTexture2D { T* p = nullptr; uint w = 0, h = 0; T& operator[](int2 c) { return p[(size_t)c.y * w + c.x]; } void GetDimensions(uint& ow, uint& oh) const { ow = w; oh = h; } };      // whole-frame planes\n"
+      "static RWTexture2D<float> u_Depth, u_SpecularHitT, u_ScratchFloat1; static DenoisingGuidesBakerConstants g_denoisingConstants;\n#define MAIN_BUFFER u_SpecularHitT\n#define SCRATCH_BUFFER u_ScratchFloat1\n")
+    for name in ("SpecHitTNeighbourhood", "DenoiseSpecHitT"):
+        for body in extract_function(dtext, name, "DenoisingGuidesBaker.hlsl"):      # (int2 >= uint2: HLSL converts the signed operand)
+            w(to_cpp("\n".join(l for l in body.split("\n") if not re.match(r"\s*#\s*define", l))).replace("any(pixelPos >= uint2(", "any(uint2(pixelPos) >= uint2(") + "\n")
+    w("} // namespace dgb\n")
     w("} // namespace hl\n")
     w(open(os.path.join(HERE, "hlsl_pt_wrappers.inc")).read())
 

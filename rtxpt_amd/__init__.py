@@ -34,7 +34,7 @@ EXPORTS = [
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
-    "pt_stable_planes_plane_stride", "pt_build_stable_planes", "pt_fill_stable_planes", "pt_get_stable_planes",
+    "pt_stable_planes_plane_stride", "pt_build_stable_planes", "pt_fill_stable_planes", "pt_denoise_spec_hit_t", "pt_get_stable_planes",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host", "pt_neeat_exchange_host",
 ]
 
@@ -711,6 +711,15 @@ class PathTracer:
         g = self.L.pt_get_stable_planes; g.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 5; g.restype = ctypes.c_int32
         self._chk(g(self.h, _p(out["header"]), _p(out["planes"]), 3 * stride, _p(out["stable_radiance"]), _p(out["depth"]), _p(out["spec_hit_t"]), _p(out["motion_vectors"]), _p(out["throughput"])), "pt_get_stable_planes")
         out["plane_stride"] = stride; out["stats"] = total
+        return out
+
+    def denoise_spec_hit_t(self):
+        """pt_denoise_spec_hit_t: the fill-in of the specular hit distance that ends a realtime frame's noisy passes; returns spec_hit_t [h, w] f32"""
+        f = self.L.pt_denoise_spec_hit_t; f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_int32
+        self._chk(f(self.h), "pt_denoise_spec_hit_t")
+        out = np.zeros((self.height, self.width), np.float32)
+        g = self.L.pt_get_stable_planes; g.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 5; g.restype = ctypes.c_int32
+        self._chk(g(self.h, None, None, 0, None, None, _p(out), None, None), "pt_get_stable_planes")
         return out
 
     def set_neeat(self, enable=True, global_feedback_weight=0.75, ratio=0.65, ssc_threshold=0.3, prefilter=True):

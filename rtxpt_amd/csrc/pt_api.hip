@@ -115,7 +115,7 @@ struct pt_context {
     double buildMs = 0, refitMs = 0, lightBakeMs = 0;
     uint poolCapacity = 0; size_t shadowCapacity = 0;
     // stable planes (pt_build_stable_planes): the realtime mode's per-frame buffers (RenderTargets.cpp:60-141, 340-352) of the last pre-pass
-    DevBuf<uint> dSpHeader, dSpThroughput; DevBuf<ptk::StablePlane> dSpPlanes; DevBuf<ptk::uint2> dSpRadiance, dSpMotion; DevBuf<float> dSpDepth, dSpHitT; uint spW = 0, spH = 0; DevBuf<ptk::uint4> dSpMark; DevBuf<ptk::float4> dSpNewL;      // (the last two: scratch of the fill passes)
+    DevBuf<uint> dSpHeader, dSpThroughput; DevBuf<ptk::StablePlane> dSpPlanes; DevBuf<ptk::uint2> dSpRadiance, dSpMotion; DevBuf<float> dSpDepth, dSpHitT; uint spW = 0, spH = 0; DevBuf<ptk::uint4> dSpMark; DevBuf<ptk::float4> dSpNewL; DevBuf<float> dSpScratch;      // (the last two: scratch of the fill passes)
     // frame gather (pt_comm_init / pt_gather)
     ncclComm_t comm = nullptr; uint commRank = 0, commWorld = 0; DevBuf<ptk::float4> dGatherSend, dGatherRecv; DevBuf<uint> dGatherPixels; std::vector<size_t> gatherCounts; uint gatherW = 0, gatherH = 0;
 };
@@ -647,7 +647,7 @@ int32_t pt_destroy(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
-    c->dSpHeader.free(); c->dSpThroughput.free(); c->dSpPlanes.free(); c->dSpRadiance.free(); c->dSpMotion.free(); c->dSpDepth.free(); c->dSpHitT.free(); c->dSpMark.free(); c->dSpNewL.free();
+    c->dSpHeader.free(); c->dSpThroughput.free(); c->dSpPlanes.free(); c->dSpRadiance.free(); c->dSpMotion.free(); c->dSpDepth.free(); c->dSpHitT.free(); c->dSpMark.free(); c->dSpNewL.free(); c->dSpScratch.free();
     c->neeat.free(); c->dLocalTable.free(); c->dFbWeight.free(); c->dFbCand.free(); c->dSq3.free();
     c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free(); c->dLightW.free(); c->dProxyOffsets.free(); if (c->dScanTemp) (void)hipFree(c->dScanTemp);
     if (c->bvhAllocated) bvh_free(c->bvh);
@@ -1290,6 +1290,16 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (hwc->overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
     if (active) return fail(c, PT_ERROR_HIP, "stable-plane fill pass: paths still alive after the iteration bound");
+    return PT_OK;
+}
+int32_t pt_denoise_spec_hit_t(pt_context* c) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes, pt_fill_stable_planes");
+    if (c->shardCount > 1) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill-in reads 5 x 5 neighbourhoods: run it on the gathered planes, not on one rank's tiles");
+    (void)hipSetDevice(c->device);
+    PT_CHECK_HIP(c, c->dSpScratch.resize((size_t)c->width * c->height));
+    launch_sp_denoise_spec_hit_t(c->dSpHitT.p, c->dSpDepth.p, c->dSpScratch.p, c->width, c->height, c->stream);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); PT_CHECK_HIP(c, hipGetLastError());
     return PT_OK;
 }
 int32_t pt_get_stable_planes(pt_context* c, uint32_t* header, PtStablePlane* planes, size_t planeCapacity, uint16_t* stableRadiance, float* depth, float* specularHitT, uint16_t* motionVectors, uint32_t* throughput) {

@@ -56,12 +56,17 @@ __global__ void __launch_bounds__(256) k_sp_build_shade(PKC k, StablePlanesConte
         sp_store_path(pool, p, path);
         alive = path.isActive();
     }
+    __shared__ uint sCnt[4][2]; __shared__ uint sBase;      // one atomic per block and counter (see k_sp_fill_shade)
     const unsigned long long mAlive = __builtin_amdgcn_ballot_w64(alive), mHit = __builtin_amdgcn_ballot_w64(isHit);
-    const uint lane = threadIdx.x & 63u;
-    uint base = 0;
-    if (lane == 0u) { if (mAlive) base = atomicAdd(countOutPtr, (uint)__popcll(mAlive)); if (mHit) atomicAdd(&wc->hits, (unsigned long long)__popcll(mHit)); }
-    base = __shfl(base, 0);
-    if (alive) queueOut[base + (uint)__popcll(mAlive & ((1ull << lane) - 1ull))] = p;
+    const uint wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (lane == 0u) { sCnt[wave][0] = (uint)__popcll(mAlive); sCnt[wave][1] = (uint)__popcll(mHit); }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        uint tot = 0; for (uint w = 0; w < 4u; w++) { const uint c = sCnt[w][threadIdx.x]; sCnt[w][threadIdx.x] = tot; tot += c; }
+        if (threadIdx.x == 0u) sBase = tot ? atomicAdd(countOutPtr, tot) : 0u; else if (tot) atomicAdd(&wc->hits, (unsigned long long)tot);
+    }
+    __syncthreads();
+    if (alive) queueOut[sBase + sCnt[wave][0] + (uint)__popcll(mAlive & ((1ull << lane) - 1ull))] = p;
 }
 
 // ---- the noisy (fill) passes: PathTracerSample.hlsl:200-250 with PATH_TRACER_MODE_FILL_STABLE_PLANES, one sub-sample per call of pt_fill_stable_planes.
@@ -104,14 +109,22 @@ __global__ void __launch_bounds__(256) k_sp_fill_shade(PKC k, StablePlanesContex
         sp_store_path(pool, p, path);
         alive = path.isActive();
     }
+    // queue appends with one atomic per BLOCK and counter (the four waves' counts meet in LDS): same-address atomics of every wave of the GPU serialise in the L2 (k_shade's lesson)
+    __shared__ uint sCnt[4][3]; __shared__ uint sBase[3];
     const unsigned long long mAlive = __builtin_amdgcn_ballot_w64(alive), mHit = __builtin_amdgcn_ballot_w64(isHit), mReq = __builtin_amdgcn_ballot_w64(req.valid);
-    const uint lane = threadIdx.x & 63u; const unsigned long long below = (1ull << lane) - 1ull;
-    uint base = 0, sbase = 0;
-    if (lane == 0u) { if (mAlive) base = atomicAdd(countOutPtr, (uint)__popcll(mAlive)); if (mReq) sbase = atomicAdd(&wc->shadowCount, (uint)__popcll(mReq)); if (mHit) atomicAdd(&wc->hits, (unsigned long long)__popcll(mHit)); }
-    base = __shfl(base, 0); sbase = __shfl(sbase, 0);
-    if (alive) queueOut[base + (uint)__popcll(mAlive & below)] = p;
+    const uint wave = threadIdx.x >> 6, lane = threadIdx.x & 63u; const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0u) { sCnt[wave][0] = (uint)__popcll(mAlive); sCnt[wave][1] = (uint)__popcll(mReq); sCnt[wave][2] = (uint)__popcll(mHit); }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        uint tot = 0; for (uint w = 0; w < 4u; w++) { const uint c = sCnt[w][threadIdx.x]; sCnt[w][threadIdx.x] = tot; tot += c; }
+        uint b = 0;
+        if (tot) { if (threadIdx.x == 0u) b = atomicAdd(countOutPtr, tot); else if (threadIdx.x == 1u) b = atomicAdd(&wc->shadowCount, tot); else atomicAdd(&wc->hits, (unsigned long long)tot); }
+        sBase[threadIdx.x] = b;
+    }
+    __syncthreads();
+    if (alive) queueOut[sBase[0] + sCnt[wave][0] + (uint)__popcll(mAlive & below)] = p;
     if (req.valid) {
-        const uint s = sbase + (uint)__popcll(mReq & below);
+        const uint s = sBase[1] + sCnt[wave][1] + (uint)__popcll(mReq & below);
         sq.q0[s] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
         sq.q1[s] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
         sq.q2[s] = make_float4(1.0f, 0.f, 0.f, 0.f);      // the mark a visible entry leaves in the scratch L
@@ -162,6 +175,16 @@ void launch_sp_fill_commit(const PathKernelContext& k, const StablePlanesContext
 }
 #undef SP_LAUNCH
 
+// DenoisingGuidesBaker.hlsl DenoiseSpecHitT: one thread per pixel, src -> dst
+__global__ void __launch_bounds__(256) k_sp_denoise_spec_hit_t(const float* __restrict__ src, const float* __restrict__ depth, float* __restrict__ dst, uint width, uint height) {
+    const uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i < width * height) dst[i] = SpecHitTNeighbourhood(src, depth, width, height, (int)(i % width), (int)(i / width));
+}
+void launch_sp_denoise_spec_hit_t(float* specHitT, const float* depth, float* scratch, uint width, uint height, hipStream_t st) {      // ping (main -> scratch), pong (scratch -> main): DenoisingGuidesBaker.cpp:62-84
+    const dim3 g((width * height + 255u) / 256u);
+    hipLaunchKernelGGL(k_sp_denoise_spec_hit_t, g, dim3(256), 0, st, specHitT, depth, scratch, width, height);
+    hipLaunchKernelGGL(k_sp_denoise_spec_hit_t, g, dim3(256), 0, st, scratch, depth, specHitT, width, height);
+}
 void launch_sp_generate(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleIndex, uint* queue, hipStream_t st) {
     const dim3 g((numOwned + 255u) / 256u), b(256);
     if (k.S.useFp16Types) { PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16)); hipLaunchKernelGGL((k_sp_generate<PathKernelContextT<true>>), g, b, 0, st, k16, sp, pool, ownedPixels, numOwned, sampleIndex, queue); }

@@ -117,6 +117,8 @@ def test_fill_device_matches_reference_text(name):
     a, b = got["spec_hit_t"].view(np.uint32), g[name + "_fill_spec_hit_t"].view(np.uint32)
     assert np.array_equal(a, b), "%s: specular hit distance differs in %d pixels" % (name, int((a != b).sum()))
     assert (int(got["stats"]["extendRays"]), int(got["stats"]["shadowRays"])) == tuple(int(v) for v in g[name + "_fill_rays"])
+    if name == "zoo_fp32":      # DenoiseSpecHitT closes the frame
+        assert np.array_equal(t.denoise_spec_hit_t().view(np.uint32), g[name + "_fill_spec_hit_t_denoised"].view(np.uint32))
     assert np.array_equal(np.delete(lp, (16, 17), 1), np.delete(spc.live_planes(built), (16, 17), 1)) and np.array_equal(got["header"], built["header"])      # nothing else is written
     for k in ("stable_radiance", "depth", "motion_vectors", "throughput"): assert np.array_equal(got[k], built[k]), k
     t.close()
@@ -159,3 +161,28 @@ def test_fill_refusals():
     t.set_settings(S)
     assert f(t.h, spc.SAMPLE, p.ctypes.data_as(ctypes.c_void_p), None) == 0
     t.close()
+
+
+def test_tile_shards_partition_the_frame():
+    """Row e x N4: a rank runs both passes for its own 32 x 32 tiles; the pixels are independent, so the ranks' buffers are disjoint pieces of the unsharded frame"""
+    import rtxpt_amd as pt
+    from rtxpt_amd import parallel
+    sc, camd, S, prm, lp16 = spc.setup("zoo_fp32"); w, h, world = spc.W * 2, spc.H * 2, 3
+    camd = scenes.bridge_camera(w, h, **scenes.stable_planes_zoo()[1]); prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **scenes.stable_planes_zoo()[1]), sub_samples=1)
+    t = _tracer(sc, camd, S, w, h); t.build_stable_planes(3, prm); full = t.fill_stable_planes(3, prm); t.close()
+    P = full["planes"].reshape(-1, 20); seen = np.zeros((h, w), bool)
+    for rank in range(world):
+        g = pt.PathTracer(shard_rank=rank, shard_count=world); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(w, h)
+        g.build_stable_planes(3, prm); part = g.fill_stable_planes(3, prm); g.close()
+        px = parallel.shard_pixels(w, h, rank, world); xs, ys = (px >> 16).astype(np.int64), (px & 0xFFFF).astype(np.int64)
+        assert not seen[ys, xs].any(); seen[ys, xs] = True
+        for k in ("stable_radiance", "depth", "spec_hit_t", "motion_vectors", "throughput"): assert np.array_equal(part[k][ys, xs], full[k][ys, xs]), (rank, k)
+        assert np.array_equal(part["header"][:, ys, xs], full["header"][:, ys, xs])
+        Q = part["planes"].reshape(-1, 20)
+        for pl in range(3):
+            live = full["header"][pl, ys, xs] != 0xFFFFFFFF
+            addr = np.array([scenes.stable_planes_address(int(x), int(y), pl, w, h) for x, y in zip(xs[live], ys[live])], np.int64)
+            assert np.array_equal(Q[addr], P[addr]), (rank, pl)
+        other = ~np.isin(np.arange(w * h), ys * w + xs).reshape(h, w)
+        assert (part["header"][:3][:, other] == 0xFFFFFFFF).all()            # nothing is written for the other ranks' pixels
+    assert seen.all()

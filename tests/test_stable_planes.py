@@ -151,3 +151,20 @@ def test_fill_deposits_all_noisy_radiance_on_the_planes():
     assert (r["header"][1:3] == 0xFFFFFFFF).all()                      # all Lambertian: one plane
     err = np.abs(total - ref); tol = 2e-3 * np.maximum(ref, 1e-3) + 1e-4
     assert (err <= tol).mean() > 0.99, "%.4f of the pixels within the fp16 packing tolerance" % float((err <= tol).mean())
+
+
+# ---- DenoiseSpecHitT: the fill-in that ends the noisy passes
+def test_spec_hit_t_fill_in_equals_the_reference_shader():
+    r, _ = oracle_fill("zoo_fp32")
+    got = ptref.denoise_spec_hit_t(r["depth"], r["spec_hit_t"])
+    assert np.array_equal(got.view(np.uint32), GOLD["zoo_fp32_fill_spec_hit_t_denoised"].view(np.uint32))
+    assert ((got > 0).sum() > (r["spec_hit_t"] > 0).sum())                       # it does fill holes in
+    if os.path.isdir("/root/reference/Rtxpt/Shaders"):
+        ref = ptref.denoise_spec_hit_t(r["depth"], r["spec_hit_t"], reference=True)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    rng = np.random.default_rng(7)                                                  # and on noise: zeros, tiny values, depth edges, a frame that is not a multiple of 8
+    d = rng.uniform(0, 1, (21, 37)).astype(np.float32); d[:, :18] *= 0.01
+    t = np.where(rng.random((21, 37)) < 0.5, 0, rng.uniform(0, 3, (21, 37))).astype(np.float32); t[3, 3] = 0.01; t[5, 7] = 7e4
+    a = ptref.denoise_spec_hit_t(d, t)
+    if os.path.isdir("/root/reference/Rtxpt/Shaders"): assert np.array_equal(a.view(np.uint32), ptref.denoise_spec_hit_t(d, t, reference=True).view(np.uint32))
+    assert a.shape == t.shape and np.isfinite(a).all()
