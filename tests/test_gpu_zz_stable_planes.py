@@ -186,3 +186,32 @@ def test_tile_shards_partition_the_frame():
         other = ~np.isin(np.arange(w * h), ys * w + xs).reshape(h, w)
         assert (part["header"][:3][:, other] == 0xFFFFFFFF).all()            # nothing is written for the other ranks' pixels
     assert seen.all()
+
+
+@pytest.mark.parametrize("name,lp16,local_tables", [("bistro_like", False, False), ("bistro_like", False, True), ("c2_sphere_light_proxy", False, False), ("bistro_like_c5", False, False), ("bistro_like_material_zoo_firefly", True, False)])
+def test_both_passes_on_pin_scenes_match_oracle(name, lp16, local_tables):
+    """textures, alpha test, normal maps, emissive triangles under NEE, analytic lights and their proxy meshes, nested-dielectric props; with NEE-AT's local sampling tables (no feedback)"""
+    import pin_scenes
+    from oracle import ptref
+    make, S, w, h, first, n = (pin_scenes.cases_lp16() if lp16 else pin_scenes.cases())[name]
+    sc, cam = make(); camd = scenes.bridge_camera(w, h, **cam); subs = 2
+    prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cam), sub_samples=subs)
+    t = _tracer(sc, camd, S, w, h)
+    o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)
+    if local_tables:
+        opts = dict(table_seed=5, jitter=(3, 5), ratio=0.65, ssc_threshold=0.3, feedback=False); baked = len(t.lights()["lights"])
+        table = pin_scenes.neeat_table(opts, baked, w, h)
+        t.set_local_light_sampling(table, jitter=opts["jitter"], ratio=opts["ratio"], ssc_threshold=opts["ssc_threshold"], feedback=False)
+        o.set_local_light_sampling(table, jitter=opts["jitter"], ratio=opts["ratio"], ssc_threshold=opts["ssc_threshold"], feedback=False)
+    want = o.build_stable_planes(first, prm); c0 = o.counters()
+    got = t.build_stable_planes(first, prm)
+    for k in spc.KEYS:
+        if k != "planes": assert np.array_equal(got[k].view(np.uint8), want[k].view(np.uint8)), (name, "build", k)
+    assert np.array_equal(_live(got, w, h), _live(want, w, h)), (name, "build planes")
+    for s in range(subs): o.fill_stable_planes(first + s, prm, want)
+    c1 = o.counters(); o.close()
+    got = t.fill_stable_planes(first, prm, sub_samples=subs)
+    assert np.array_equal(_live(got, w, h), _live(want, w, h)), (name, "fill planes")
+    assert np.array_equal(got["spec_hit_t"].view(np.uint32), want["spec_hit_t"].view(np.uint32)), (name, "specular hit distance")
+    assert (int(got["stats"]["extendRays"]), int(got["stats"]["shadowRays"])) == (c1["extendRays"] - c0["extendRays"], c1["shadowRays"] - c0["shadowRays"])
+    t.close()

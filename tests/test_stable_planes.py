@@ -168,3 +168,25 @@ def test_spec_hit_t_fill_in_equals_the_reference_shader():
     a = ptref.denoise_spec_hit_t(d, t)
     if os.path.isdir("/root/reference/Rtxpt/Shaders"): assert np.array_equal(a.view(np.uint32), ptref.denoise_spec_hit_t(d, t, reference=True).view(np.uint32))
     assert a.shape == t.shape and np.isfinite(a).all()
+
+
+# ---- both passes on the pin scenes of the reference-mode suite (textures, alpha test, emissive triangles under NEE, analytic lights and their proxy meshes): oracle == live reference text
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Rtxpt/Shaders"), reason="needs the reference text")
+@pytest.mark.parametrize("name", ["bistro_like", "c2_sphere_light_proxy"])
+def test_both_passes_on_pin_scenes_equal_the_reference_text(name):
+    import pin_scenes
+    make, S, w, h, first, n = pin_scenes.cases()[name]
+    sc, cam = make(); camd = scenes.bridge_camera(w, h, **cam)
+    prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cam), sub_samples=2)
+    outs = []
+    for ref in (False, True):
+        ob = ptref.Oracle(reference_integrator=True, settings=S, mode=1) if ref else ptref.Oracle()
+        of = ptref.Oracle(reference_integrator=True, settings=S, mode=2) if ref else ob
+        for o in {id(ob): ob, id(of): of}.values(): o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)
+        fr = ob.build_stable_planes(first, prm); built = {k: v.copy() for k, v in fr.items() if isinstance(v, np.ndarray)}
+        for s in range(2): of.fill_stable_planes(first + s, prm, fr)
+        outs.append((built, fr, of.counters()["shadowRays"]))
+    (ba, fa, sa), (bb, fb, sb) = outs
+    for k in spc.KEYS: assert np.array_equal(ba[k].view(np.uint8), bb[k].view(np.uint8)), (name, "build", k)
+    for k in ("planes", "spec_hit_t"): assert np.array_equal(fa[k].view(np.uint8), fb[k].view(np.uint8)), (name, "fill", k)
+    assert sa == sb and sa > 0
