@@ -214,6 +214,16 @@ def main():
                          "work_slots_per_quad_iteration": (cst["nodeVisitsExtend"] + cst["leafVisitsExtend"]) / max(1, 16 * cst["waveItersExtend"])},
             "build": g.build_stats(),
         }
+        if world == 1 and not args.skip_roofline_steps:
+            # beyond the headline (after the timed region, not part of `value`): the realtime mode's two path-tracing passes on the same scene and frame size, one sub-sample
+            try:
+                prm = scenes.stable_planes_params(W, H, scenes.view_projection(W, H, **cam), sub_samples=1)
+                g.build_stable_planes(0, prm); b = g.build_stable_planes(1, prm)["stats"]; f = g.fill_stable_planes(1, prm)["stats"]
+                out["realtime_passes"] = {"workload": "stable-plane build pass + one fill sub-sample, %dx%d, same scene (SURVEY.md 8f row N4)" % (W, H),
+                                          "build_ms": b["gpuMilliseconds"], "build_rays": int(b["extendRays"]), "fill_ms": f["gpuMilliseconds"], "fill_rays": int(f["extendRays"]) + int(f["shadowRays"]),
+                                          "fill_mrays_per_s": (int(f["extendRays"]) + int(f["shadowRays"])) / max(f["gpuMilliseconds"], 1e-9) / 1e3}
+            except Exception as e:      # never let the side leg take the bench line down
+                out["realtime_passes"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             # the oracle's block of the very frame the timed steps rendered doubles as the parity check of the benchmarked configuration
             out["cpu_baseline"], block, rect = cpu_baseline(sc, cam, S, W, H, SPP)

@@ -1247,48 +1247,86 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
     StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
     sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p; sp.B.Depth = c->dSpDepth.p; sp.B.SpecularHitT = c->dSpHitT.p; sp.B.MotionVectors = c->dSpMotion.p; sp.B.Throughput = c->dSpThroughput.p;
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
-    PathPool pool{c->dS0.p, c->dS1.p, c->dS2.p, c->dS3.p, c->dS4.p, c->dHit.p};
-    PathPool markPool = pool; markPool.s2 = c->dSpMark.p;
-    ShadowQueue sq{c->dSq0.p, c->dSq1.p, c->dSq2.p, 0u, nullptr, nullptr, nullptr, 0u, 0u, 0u};
-    uint* queue[2] = {c->dQueue[0].p, c->dQueue[1].p};
-    WaveCounters* wc = c->dCounters.p; WaveCounters* hwc = c->hostCounters;
-    TravAux aux; aux.taskQ[0] = c->dTaskQ.p; aux.taskQ[1] = aux.taskQ[0] + TASK_QUEUE_CAPACITY; aux.counts = c->dTravCounts.p; aux.maxBlocks = 0u;
-    aux.taskCap = TASK_QUEUE_CAPACITY; aux.bestKey = c->dBestKey.p; aux.resolveList = c->dResolveList.p; aux.primToSlot = c->bvh.primToSlot;
-    TravAux auxShadow = aux; auxShadow.counts = aux.counts + PASS_SHADOW_OFFSET;
-    memset(hwc, 0, sizeof(WaveCounters));
+    // As pt_render: the pixels are traced as up to PT_PIPELINE_BATCHES independent batches, each on its own stream with its own queues, counters, task queues and slice of the pool, advancing in
+    // lockstep (queue all, then service each as its counts arrive) — the shading of one batch overlaps the traversal of the others and the drain at the end of every launch is hidden.
+    struct Batch { uint pixFirst = 0, numPix = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr; PathPool pool, markPool; ShadowQueue sq; ptk::float4* newL = nullptr; uint* queue[2] = {nullptr, nullptr};
+                   DeviceScene sc; PathKernelContext k; TravAux aux; uint cur = 0, active = 0, iterations = 0; unsigned long long rays = 0, shadowRays = 0; bool waiting = false; };
+    const uint numBatches = (c->serialKernels || numOwned < (1u << 20)) ? 1u : ((numOwned < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
+    Batch B[PT_PIPELINE_BATCHES];
+    for (uint b = 0; b < numBatches; b++) {
+        Batch& t = B[b];
+        t.pixFirst = (uint)((unsigned long long)numOwned * b / numBatches); t.numPix = (uint)((unsigned long long)numOwned * (b + 1) / numBatches) - t.pixFirst;
+        const uint base = t.pixFirst;
+        t.st = c->streams[b]; t.wc = c->dCounters.p + b; t.hwc = c->hostCounters + b;
+        t.pool = PathPool{c->dS0.p + base, c->dS1.p + base, c->dS2.p + base, c->dS3.p + base, c->dS4.p + base, c->dHit.p + base};
+        t.markPool = t.pool; t.markPool.s2 = c->dSpMark.p + base; t.newL = c->dSpNewL.p + base;
+        t.sq = ShadowQueue{c->dSq0.p + base, c->dSq1.p + base, c->dSq2.p + base, 0u, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+        t.queue[0] = c->dQueue[0].p + base; t.queue[1] = c->dQueue[1].p + base;
+        t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
+        t.k = k; t.k.sc = t.sc;
+        t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + PASS_COUNTERS * b;
+        t.aux.maxBlocks = (PT_T8_LANES == 2 && numBatches >= 3u) ? 256u * 7u : 0u;
+        t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + base; t.aux.resolveList = c->dResolveList.p + base; t.aux.primToSlot = c->bvh.primToSlot;
+        memset(t.hwc, 0, sizeof(WaveCounters));
+    }
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // uploads / memsets issued on the main stream (prepare, the marks) must be visible to the batch streams
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
-    PT_CHECK_HIP(c, hipMemcpyAsync(wc, hwc, sizeof(WaveCounters), hipMemcpyHostToDevice, c->stream));
-    launch_sp_fill_generate(k, sp, pool, c->dOwned.p, numOwned, sampleIndex, queue[0], &wc->extendCount[0], c->stream);
-    PT_CHECK_HIP(c, hipMemcpyAsync(hwc, wc, 16, hipMemcpyDeviceToHost, c->stream));
-    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
-    const uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u)) * (c->S.bounceCount + 1u);
-    uint cur = 0, active = hwc->extendCount[0], iterations = 0; unsigned long long rays = 0, shadowRays = 0;
-    while (active && iterations < maxIter) {
-        const uint nxt = cur ^ 1u;
-        launch_pass_reset(aux.counts, &wc->extendCount[nxt], &wc->shadowCount, c->stream);
-        launch_extend(c->dsc, pool, queue[cur], &wc->extendCount[cur], active, wc, c->countersEnabled, aux, c->stream);
-        launch_sp_fill_shade(k, sp, pool, queue[cur], &wc->extendCount[cur], active, queue[nxt], &wc->extendCount[nxt], sq, c->dSpNewL.p, sampleIndex, wc, c->stream);
-        rays += active;
-        PT_CHECK_HIP(c, hipMemcpyAsync(hwc, wc, 16, hipMemcpyDeviceToHost, c->stream));
-        PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
-        const uint nShadow = hwc->shadowCount;
-        if (nShadow) {
-            launch_shadow(c->dsc, markPool, sq, &wc->shadowCount, nShadow, wc, c->countersEnabled, auxShadow, c->stream);
-            launch_sp_fill_resolve(pool, c->dSpMark.p, sq, c->dSpNewL.p, &wc->shadowCount, nShadow, c->stream);
-            shadowRays += nShadow;
-        }
-        active = hwc->extendCount[nxt]; cur = nxt; iterations++;
+    for (uint b = 0; b < numBatches; b++) {
+        Batch& t = B[b];
+        PT_CHECK_HIP(c, hipMemcpyAsync(t.wc, t.hwc, sizeof(WaveCounters), hipMemcpyHostToDevice, t.st));
+        launch_sp_fill_generate(t.k, sp, t.pool, c->dOwned.p + t.pixFirst, t.numPix, sampleIndex, t.queue[0], &t.wc->extendCount[0], t.st);
+        PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
     }
-    launch_sp_fill_commit(k, sp, pool, numOwned, sampleIndex, c->stream);
+    for (uint b = 0; b < numBatches; b++) { PT_CHECK_HIP(c, hipStreamSynchronize(B[b].st)); B[b].active = B[b].hwc->extendCount[0]; }
+    const uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u)) * (c->S.bounceCount + 1u);
+    bool any = true;
+    while (any) {
+        for (uint b = 0; b < numBatches; b++) {      // phase 1: every live batch queues extend + shade and the read-back of its queue counts
+            Batch& t = B[b]; t.waiting = false;
+            if (!t.active || t.iterations >= maxIter) continue;
+            const uint nxt = t.cur ^ 1u;
+            launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st);
+            launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st);
+            launch_sp_fill_shade(t.k, sp, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.newL, sampleIndex, t.wc, t.st);
+            t.rays += t.active;
+            PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
+            t.waiting = true;
+        }
+        any = false;
+        for (uint b = 0; b < numBatches; b++) {      // phase 2: as each batch's counts arrive, its visibility rays and their resolve; the other batches keep the GPU busy meanwhile
+            Batch& t = B[b];
+            if (!t.waiting) continue;
+            PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
+            const uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
+            if (nShadow) {
+                TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
+                launch_shadow(t.sc, t.markPool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, auxShadow, t.st);
+                launch_sp_fill_resolve(t.pool, t.markPool.s2, t.sq, t.newL, &t.wc->shadowCount, nShadow, t.st);
+                t.shadowRays += nShadow;
+            }
+            t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
+            if (t.active && t.iterations < maxIter) any = true;
+        }
+    }
+    for (uint b = 0; b < numBatches; b++) {
+        Batch& t = B[b];
+        launch_sp_fill_commit(t.k, sp, t.pool, t.numPix, sampleIndex, t.st);
+        PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, sizeof(WaveCounters), hipMemcpyDeviceToHost, t.st));
+    }
+    for (uint b = 0; b < numBatches; b++) PT_CHECK_HIP(c, hipStreamSynchronize(B[b].st));
     PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
-    PT_CHECK_HIP(c, hipMemcpyAsync(hwc, wc, sizeof(WaveCounters), hipMemcpyDeviceToHost, c->stream));
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     PT_CHECK_HIP(c, hipGetLastError());
-    if (stats) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); stats->gpuMilliseconds = ms; stats->extendRays = rays; stats->shadowRays = shadowRays; stats->hits = hwc->hits; stats->iterations = iterations; stats->extendLaunches = iterations;
-                 stats->pathsTraced = numOwned; stats->nodeVisitsExtend = hwc->nodeVisitsExt; stats->triTestsExtend = hwc->triTestsExt; stats->nodeVisitsShadow = hwc->nodeVisitsSh; stats->triTestsShadow = hwc->triTestsSh; }
+    bool overflow = false; uint active = 0;
+    if (stats) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); stats->gpuMilliseconds = ms; stats->pathsTraced = numOwned; }
+    for (uint b = 0; b < numBatches; b++) {
+        const Batch& t = B[b]; overflow = overflow || t.hwc->overflow; active += t.active;
+        if (stats) { stats->extendRays += t.rays; stats->shadowRays += t.shadowRays; stats->hits += t.hwc->hits; stats->extendLaunches += t.iterations; if (t.iterations > stats->iterations) stats->iterations = t.iterations;
+                     stats->nodeVisitsExtend += t.hwc->nodeVisitsExt; stats->triTestsExtend += t.hwc->triTestsExt; stats->nodeVisitsShadow += t.hwc->nodeVisitsSh; stats->triTestsShadow += t.hwc->triTestsSh; }
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (hwc->overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
+    if (overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
     if (active) return fail(c, PT_ERROR_HIP, "stable-plane fill pass: paths still alive after the iteration bound");
     return PT_OK;
 }

@@ -215,3 +215,25 @@ def test_both_passes_on_pin_scenes_match_oracle(name, lp16, local_tables):
     assert np.array_equal(got["spec_hit_t"].view(np.uint32), want["spec_hit_t"].view(np.uint32)), (name, "specular hit distance")
     assert (int(got["stats"]["extendRays"]), int(got["stats"]["shadowRays"])) == (c1["extendRays"] - c0["extendRays"], c1["shadowRays"] - c0["shadowRays"])
     t.close()
+
+
+@pytest.mark.parametrize("w,h", [(1280, 880), (2560, 1640)])
+def test_fill_pipelined_batches_equal_the_single_batch(w, h):
+    """frames above a million pixels run the fill pass as two / four pipelined batches (as pt_render does); PT_DEVICE_SERIAL_KERNELS semantics keep one batch: same planes, same ray counts"""
+    import rtxpt_amd as pt
+    sc, cam = scenes.stable_planes_zoo(); S = scenes.config_settings("C2"); S["useFp16Types"] = 1
+    camd = scenes.bridge_camera(w, h, **cam); prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cam), sub_samples=1)
+    res = []
+    for serial in (True, False):
+        t = pt.PathTracer(serial_kernels=serial); t.set_scene(sc); t.set_settings(S); t.set_camera(camd); t.resize(w, h)
+        t.build_stable_planes(4, prm); r = t.fill_stable_planes(4, prm); t.close(); res.append(r)
+    a, b = res
+    assert np.array_equal(a["header"], b["header"]) and np.array_equal(a["spec_hit_t"].view(np.uint32), b["spec_hit_t"].view(np.uint32))
+    live = (a["header"][:3] != 0xFFFFFFFF)
+    A = a["planes"].reshape(-1, 20); Bp = b["planes"].reshape(-1, 20)
+    diff = (A != Bp).any(-1)
+    # only records of planes that exist are written; compare those (the addressing is a bijection, so count them through the header)
+    ys, xs = np.nonzero(live[0]); addr = np.array([scenes.stable_planes_address(int(x), int(y), 0, w, h) for x, y in zip(xs[::97], ys[::97])], np.int64)
+    assert not diff[addr].any()
+    assert int(diff.sum()) == 0, "%d plane records differ between one batch and the pipelined batches" % int(diff.sum())
+    assert (a["stats"]["extendRays"], a["stats"]["shadowRays"]) == (b["stats"]["extendRays"], b["stats"]["shadowRays"])
