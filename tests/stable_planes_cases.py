@@ -34,3 +34,32 @@ def live_planes(out):
         ys, xs = np.nonzero(hd[pl] != 0xFFFFFFFF)
         for x, y in zip(xs.tolist(), ys.tolist()): rows.append(P[scenes.stable_planes_address(x, y, pl, W, H)])
     return np.array(rows, np.uint32)
+
+
+# ---- edge cases (small frames whose sizes are no multiples of the 8 x 8 addressing tiles): (scene maker, settings overrides, params keywords, width, height)
+def _empty_scene():
+    b = scenes.SceneBuilder(); b.set_environment(scenes.sky_equirect(64, 32), color_multiplier=(1, 1, 1)); return b.finish(), scenes.stable_planes_zoo()[1]
+
+
+def _inside_glass():
+    sc, cam = scenes.stable_planes_zoo(); cam = dict(cam); cam["pos"] = (-0.35, 0.25, 1.1); cam["direction"] = (0.3, 0.05, -1.0); return sc, cam
+
+
+def edge_cases():
+    return {"empty_scene": (_empty_scene, {}, {}, 37, 21),                                        # every pixel is a miss on plane 0
+            "no_env_cornell": (lambda: scenes.cornell_box("C1"), {}, {}, 37, 21),                # no environment, no delta lobes anywhere
+            "bounce0": (scenes.stable_planes_zoo, dict(bounceCount=0), {}, 40, 24),              # the path stops at its first vertex
+            "bounce1_depth1": (scenes.stable_planes_zoo, dict(bounceCount=1), dict(max_vertex_depth=1), 40, 24),
+            "depth0": (scenes.stable_planes_zoo, {}, dict(max_vertex_depth=0), 40, 24),          # no delta exploration at all: the primary surface is the plane
+            "planes0_clamped": (scenes.stable_planes_zoo, {}, dict(active_planes=0), 33, 17),    # an out-of-range plane count is clamped to 1
+            "inside_glass": (_inside_glass, dict(nestedDielectricsQuality=1), {}, 40, 24),       # the camera sits in the nested glass cubes: rejected false hits from the first vertex on
+            "diffuse_bounce0": (scenes.stable_planes_zoo, dict(diffuseBounceCount=0), {}, 40, 24)}
+
+
+def edge_setup(name, sub_samples=2):
+    make, over, kw, w, h = edge_cases()[name]
+    sc, cam = make(); S = scenes.config_settings("C2")
+    for k, v in over.items(): S[k] = v
+    camd = scenes.bridge_camera(w, h, **cam)
+    prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cam), sub_samples=sub_samples, **kw)
+    return sc, camd, S, prm, w, h

@@ -237,3 +237,22 @@ def test_fill_pipelined_batches_equal_the_single_batch(w, h):
     assert not diff[addr].any()
     assert int(diff.sum()) == 0, "%d plane records differ between one batch and the pipelined batches" % int(diff.sum())
     assert (a["stats"]["extendRays"], a["stats"]["shadowRays"]) == (b["stats"]["extendRays"], b["stats"]["shadowRays"])
+
+
+@pytest.mark.parametrize("name", list(spc.edge_cases()))
+def test_edge_cases_match_oracle(name):
+    from oracle import ptref
+    sc, camd, S, prm, w, h = spc.edge_setup(name)
+    o = ptref.Oracle(); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)
+    want = o.build_stable_planes(2, prm); wb = {k: v.copy() for k, v in want.items() if isinstance(v, np.ndarray)}
+    for s in range(2): o.fill_stable_planes(2 + s, prm, want)
+    o.close()
+    t = _tracer(sc, camd, S, w, h)
+    got = t.build_stable_planes(2, prm)
+    for k in spc.KEYS:
+        if k != "planes": assert np.array_equal(got[k].view(np.uint8), wb[k].view(np.uint8)), (name, "build", k)
+    assert np.array_equal(_live(got, w, h), _live(wb, w, h)), (name, "build planes")
+    got = t.fill_stable_planes(2, prm, sub_samples=2)
+    assert np.array_equal(_live(got, w, h), _live(want, w, h)), (name, "fill planes")
+    assert np.array_equal(got["spec_hit_t"].view(np.uint32), want["spec_hit_t"].view(np.uint32)), (name, "specular hit distance")
+    t.close()

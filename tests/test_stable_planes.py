@@ -190,3 +190,29 @@ def test_both_passes_on_pin_scenes_equal_the_reference_text(name):
     for k in spc.KEYS: assert np.array_equal(ba[k].view(np.uint8), bb[k].view(np.uint8)), (name, "build", k)
     for k in ("planes", "spec_hit_t"): assert np.array_equal(fa[k].view(np.uint8), fb[k].view(np.uint8)), (name, "fill", k)
     assert sa == sb and sa > 0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Rtxpt/Shaders"), reason="needs the reference text")
+@pytest.mark.parametrize("name", list(spc.edge_cases()))
+def test_edge_cases_equal_the_reference_text(name):
+    sc, camd, S, prm, w, h = spc.edge_setup(name)
+    outs = []
+    for ref in (False, True):
+        ob = ptref.Oracle(reference_integrator=True, settings=S, mode=1) if ref else ptref.Oracle()
+        of = ptref.Oracle(reference_integrator=True, settings=S, mode=2) if ref else ob
+        for o in {id(ob): ob, id(of): of}.values(): o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)
+        fr = ob.build_stable_planes(2, prm); built = {k: v.copy() for k, v in fr.items() if isinstance(v, np.ndarray)}
+        for s in range(2): of.fill_stable_planes(2 + s, prm, fr)
+        outs.append((built, fr))
+    (ba, fa), (bb, fb) = outs
+    for k in spc.KEYS: assert np.array_equal(ba[k].view(np.uint8), bb[k].view(np.uint8)), (name, "build", k)
+    for k in ("planes", "spec_hit_t"): assert np.array_equal(fa[k].view(np.uint8), fb[k].view(np.uint8)), (name, "fill", k)
+    if name in ("empty_scene", "no_env_cornell", "bounce0", "depth0", "planes0_clamped"): assert (ba["header"][1:3] == 0xFFFFFFFF).all()
+
+
+def test_the_two_copies_of_the_shared_header_are_one_text():
+    """pt_stableplanes.h is written once for both sides of the fence (five adapter functions per side); the oracle's copy differs in its two header lines only"""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    a = open(os.path.join(root, "rtxpt_amd", "csrc", "pt_stableplanes.h")).read().split("\n")
+    b = open(os.path.join(root, "oracle", "ptref", "stableplanes.h")).read().split("\n")
+    assert a[2:] == b[2:] and a[:2] != b[:2]
