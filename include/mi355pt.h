@@ -182,6 +182,10 @@ int32_t pt_gltf_animation_instances(pt_gltf_animation* anim, uint32_t animation,
    bind pose; a mesh shared by several nodes takes the last node's pose. Morph targets (primitive.targets, POSITION displacements) are applied before the skin:
    p = base + SUM_i w_i target_i, the weights from the animation's "weights" channel, else the node's, else the mesh's. Host only. */
 int32_t pt_gltf_animation_positions(pt_gltf_animation* anim, uint32_t animation, float timeSeconds, float* positionsXYZ, uint32_t capacityVertices);
+/* the posed NORMAL / TANGENT streams of the same pose (SNORM8 x 3 / x 4, the packing of PtGeometryBuffers; either pointer may be NULL): a skinned vertex's normal is
+   normalize(SUM_k w_k inverse-transpose(J_k) n), its tangent normalize(SUM_k w_k J_k t.xyz) with the handedness kept; unskinned vertices keep theirs; morph targets displace positions only.
+   Returns the number of vertices (capacity 0: a query). -> pt_animate_normals */
+int32_t pt_gltf_animation_normals(pt_gltf_animation* anim, uint32_t animation, float timeSeconds, uint32_t* normalsSnorm8, uint32_t* tangentsSnorm8, uint32_t capacityVertices);
 void    pt_gltf_animation_free(pt_gltf_animation* anim);
 /* raw-buffer path: the same data the bakers upload (GeometryData/InstanceData/PTMaterialData/SubInstanceData, Rtxpt/Sample.cpp:2319-2384) */
 int32_t pt_set_geometry(pt_context* ctx, const PtGeometryBuffers* buffers, const PtGeometryDesc* geometries, uint32_t numGeometries,
@@ -330,6 +334,9 @@ int32_t pt_set_settings(pt_context* ctx, const PtSettings* settings);           
 /* Animate + Scene::Refresh + UpdateSkinnedBLASs/BuildTLAS (Rtxpt/Sample.cpp:785-811,1170-1240): new instance transforms and/or
  * new vertex positions (same topology) -> LBVH refit (or rebuild when rebuild != 0) + emissive light re-bake. Either pointer may be NULL. */
 int32_t pt_animate(pt_context* ctx, const PtInstanceDesc* instances, uint32_t numInstances, const float* positions, uint32_t numVertices, int32_t rebuild);
+/* deformed meshes' vertex normals / tangents (Donut's skinning rewrites them with the positions, Sample.cpp:1170-1198): replaces the packed streams of pt_set_geometry (either may be NULL)
+   and rewrites the shading records; the BVH does not depend on them. Resets the accumulation like pt_animate. */
+int32_t pt_animate_normals(pt_context* ctx, const uint32_t* normalsSnorm8, const uint32_t* tangentsSnorm8, uint32_t numVertices);
 /* BackBufferResizing / RenderTargets::Init (Rtxpt/SampleCommon/RenderTargets.cpp:35-240) */
 int32_t pt_resize(pt_context* ctx, uint32_t width, uint32_t height);
 /* Render -> SampleRenderCode -> PathTrace -> AccumulationPass for samples [first, first+count) (Rtxpt/Sample.cpp:1891-2313, 2438-2559, 2770-2778).

@@ -25,7 +25,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 
 # every symbol include/mi355pt.h declares
 EXPORTS = [
-    "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_positions", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
+    "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_positions", "pt_gltf_animation_normals", "pt_animate_normals", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
     "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_light_importance_boost", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_set_view_projection", "pt_neeat_reset", "pt_get_neeat_tables", "pt_neeat_pack_feedback", "pt_neeat_unpack_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
@@ -385,6 +385,15 @@ class GltfAnimation:
         out = np.zeros((n, 3), np.float32)
         if n: assert self.L.pt_gltf_animation_positions(self.h, animation, float(t), _p(out), n) == n
         return out
+
+    def normals(self, t, animation=0):
+        """pt_gltf_animation_normals: (normals, tangents) uint32 [vertices], the posed NORMAL / TANGENT streams in pt_set_geometry's SNORM8 packing (pt_animate_normals' arguments)."""
+        f = self.L.pt_gltf_animation_normals; f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        n = f(self.h, animation, float(t), None, None, 0)
+        if n < 0: raise PtError(-n, "pt_gltf_animation_normals")
+        nrm, tan = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        if n: assert f(self.h, animation, float(t), _p(nrm), _p(tan), n) == n
+        return nrm, tan
 
     def close(self):
         if self.h: self.L.pt_gltf_animation_free(self.h); self.h = ctypes.c_void_p()
@@ -754,6 +763,13 @@ class PathTracer:
     def animate(self, instances=None, positions=None, rebuild=False):
         self._chk(self.L.pt_animate(self.h, _p(instances), 0 if instances is None else len(instances), _p(positions), 0 if positions is None else positions.shape[0],
                                     1 if rebuild else 0), "pt_animate")
+
+    def animate_normals(self, normals=None, tangents=None):
+        """pt_animate_normals: the deformed meshes' packed vertex normals / tangents (uint32 per vertex, SNORM8) — with pt_animate(positions) a skinned frame is complete"""
+        f = self.L.pt_animate_normals; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]; f.restype = ctypes.c_int32
+        n = len(normals) if normals is not None else len(tangents)
+        a = None if normals is None else np.ascontiguousarray(normals, np.uint32); b = None if tangents is None else np.ascontiguousarray(tangents, np.uint32)
+        self._chk(f(self.h, _p(a), _p(b), n), "pt_animate_normals")
 
     # ---- per-frame state
     def set_camera(self, cam):

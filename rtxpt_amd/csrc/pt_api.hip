@@ -1004,6 +1004,20 @@ int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, co
     return bake_lights(c, !lightsWereDirty);     // geometry moved, nothing else: environment lights kept, emissive re-bake + weights + proxy table on the device
 }
 
+int32_t pt_animate_normals(pt_context* c, const uint32_t* normals, const uint32_t* tangents, uint32_t nVerts) {
+    if (!c || (!normals && !tangents)) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (c->geomDirty || c->texDirty) { int r = prepare(c); if (r != PT_OK) return r; }
+    if ((normals && nVerts != c->normals.size()) || (tangents && nVerts != c->tangents.size())) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate_normals: vertex count must not change");
+    if (normals) { memcpy(c->normals.data(), normals, 4 * (size_t)nVerts); PT_CHECK_HIP(c, c->dNormals.upload(c->normals, c->stream)); }
+    if (tangents) { memcpy(c->tangents.data(), tangents, 4 * (size_t)nVerts); PT_CHECK_HIP(c, c->dTangents.upload(c->tangents, c->stream)); }
+    refresh_scene_view(c);
+    launch_shade_tris(c->dsc, c->numTris, c->dShadeTris.p, c->stream);      // the shading records hold the packed vertex normals and tangents
+    c->accumCount = 0;
+    PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)c->width * c->height, c->stream));
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
 int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* stats) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");

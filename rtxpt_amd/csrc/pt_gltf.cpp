@@ -249,6 +249,7 @@ struct Loader {
     std::vector<std::vector<uint8_t>> texPixels; std::vector<PtTextureDesc> texDescs; std::map<std::pair<int, int>, uint32_t> texCache;   // (image, srgb) -> texture word
     std::vector<int> meshMap; std::vector<M4> instanceWorld;      // instanceWorld: the double-precision local-to-world of each instance (scene-graph import composes in double)
     std::vector<std::string> instancePath;                         // the names of the glTF nodes from a scene root down to the instance's node, '/'-separated (what Donut's SceneGraph::FindNode walks)
+    std::vector<float> normalsF, tangentsF;                        // the bind-pose NORMAL (3 per vertex) / TANGENT (4 per vertex) as floats: read by pt_gltf_animation_normals
     std::vector<uint16_t> joints; std::vector<float> weights;      // JOINTS_0 / WEIGHTS_0, four per vertex (zeros for an unskinned primitive): read by pt_gltf_animation_positions
     struct SkinnedInstance { int node, skin, mesh; }; std::vector<SkinnedInstance> skinned; std::vector<M4> nodeWorld; bool recordWorlds = false;      // filled by visit() when recordWorlds
     // morph targets (glTF 2.0 3.7.2.2): per geometry the POSITION displacements of its targets (count x numVertices x 3 floats from `first`), per imported mesh its default weights;
@@ -406,8 +407,8 @@ struct Loader {
                 for (uint32_t k = 0; k < nv; k++) {
                     positions.push_back((float)P[3 * k]); positions.push_back((float)P[3 * k + 1]); positions.push_back((float)P[3 * k + 2]);
                     float uv[2] = {0, 0}; if (flags & PT_GEOM_HAS_UV) { uv[0] = (float)UV[2 * k]; uv[1] = (float)UV[2 * k + 1]; } uvs.push_back(uv[0]); uvs.push_back(uv[1]);
-                    float nn[3] = {0, 0, 0}; if (flags & PT_GEOM_HAS_NORMAL) { nn[0] = (float)N[3 * k]; nn[1] = (float)N[3 * k + 1]; nn[2] = (float)N[3 * k + 2]; } normals.push_back(pack_snorm8(nn, 3));
-                    float tt[4] = {0, 0, 0, 0}; if (flags & PT_GEOM_HAS_TANGENT) { for (int q = 0; q < 4; q++) tt[q] = (float)T[4 * k + q]; } tangents.push_back(pack_snorm8(tt, 4));
+                    float nn[3] = {0, 0, 0}; if (flags & PT_GEOM_HAS_NORMAL) { nn[0] = (float)N[3 * k]; nn[1] = (float)N[3 * k + 1]; nn[2] = (float)N[3 * k + 2]; } normals.push_back(pack_snorm8(nn, 3)); normalsF.insert(normalsF.end(), nn, nn + 3);
+                    float tt[4] = {0, 0, 0, 0}; if (flags & PT_GEOM_HAS_TANGENT) { for (int q = 0; q < 4; q++) tt[q] = (float)T[4 * k + q]; } tangents.push_back(pack_snorm8(tt, 4)); tangentsF.insert(tangentsF.end(), tt, tt + 4);
                     for (int q = 0; q < 4; q++) { const double jv = hasSkin ? J[4 * k + q] : 0.0; joints.push_back((uint16_t)(jv >= 0 && jv <= 65535.0 ? jv : 0)); weights.push_back(hasSkin ? (float)Wt[4 * k + q] : 0.f); }
                 }
                 geoms.push_back(g);
@@ -640,13 +641,19 @@ extern "C" void pt_gltf_animation_free(pt_gltf_animation* a) { delete a; }
 // BLAS): the posed object-space positions of the WHOLE vertex stream — the `positions` argument of pt_animate. A vertex of a skinned primitive becomes
 // SUM_k w_k (inverse(meshNodeWorld) * jointWorld_k * inverseBind_k) p, the joint matrices of the specification with the mesh node's own transform taken out (the instance keeps it).
 // Morph targets (primitive.targets, POSITION displacements) are applied before the skin: p = base + SUM_i w_i target_i with the weights of the animation's "weights"
-// channel, else of the node, else of the mesh. Normals and tangents keep their bind pose (pt_animate takes positions only). A mesh shared by several nodes takes the pose of the last one.
-extern "C" int32_t pt_gltf_animation_positions(pt_gltf_animation* a, uint32_t animation, float t, float* out, uint32_t capacityVertices) {
-    if (!a || (capacityVertices && !out)) return -PT_ERROR_INVALID_ARGUMENT;
+// channel, else of the node, else of the mesh. Normals and tangents: pt_gltf_animation_normals -> pt_animate_normals. A mesh shared by several nodes takes the pose of the last one.
+// outN / outT (pt_gltf_animation_normals): the posed NORMAL / TANGENT streams in the packing pt_set_geometry takes (SNORM8 x 3 / x 4). A skinned vertex's normal is
+// normalize(SUM_k w_k inverse-transpose(J_k) n), its tangent normalize(SUM_k w_k J_k t.xyz) with the handedness kept (glTF 2.0 3.7.3.3 leaves the normal transform to the
+// implementation; the inverse transpose is the one that keeps normals perpendicular under the non-uniform scales a mesh node may carry). Morph targets displace positions only.
+static int32_t gltf_animation_pose(pt_gltf_animation* a, uint32_t animation, float t, float* out, uint32_t* outN, uint32_t* outT, uint32_t capacityVertices) {
+    if (!a || (capacityVertices && !out && !outN && !outT)) return -PT_ERROR_INVALID_ARGUMENT;
     try {
         Loader& L = a->L; const uint32_t nv = (uint32_t)(L.positions.size() / 3);
         if (capacityVertices < nv) return (int32_t)nv;                                     // (query: the number of vertices)
+        std::vector<float> posScratch; if (!out) { posScratch.resize(L.positions.size()); out = posScratch.data(); }
         memcpy(out, L.positions.data(), sizeof(float) * L.positions.size());
+        if (outN) memcpy(outN, L.normals.data(), sizeof(uint32_t) * nv);
+        if (outT) memcpy(outT, L.tangents.data(), sizeof(uint32_t) * nv);
         const JValue* skins = L.root.get("skins"); const bool haveSkins = skins && skins->size();
         if (!haveSkins && L.morphDeltas.empty()) return (int32_t)nv;
         L.recordWorlds = true; L.skinned.clear(); L.nodeWorld.clear(); L.meshNodes.clear();
@@ -697,11 +704,38 @@ extern "C" int32_t pt_gltf_animation_positions(pt_gltf_animation* a, uint32_t an
                     for (int k = 0; k < 4; k++) { if (wgt[k] == 0.f || jnt[k] >= jm.size()) continue; const double* m = jm[jnt[k]].m;
                         for (int rr = 0; rr < 3; rr++) q[rr] += (double)wgt[k] * (m[rr] * p[0] + m[4 + rr] * p[1] + m[8 + rr] * p[2] + m[12 + rr]); }
                     for (int rr = 0; rr < 3; rr++) out[3 * (size_t)v + rr] = (float)q[rr];
+                    if ((outN && (gd.flags & PT_GEOM_HAS_NORMAL)) || (outT && (gd.flags & PT_GEOM_HAS_TANGENT))) {
+                        double nrm[3] = {0, 0, 0}, tan[3] = {0, 0, 0}; const float* n0 = &L.normalsF[3 * (size_t)v]; const float* t0 = &L.tangentsF[4 * (size_t)v];
+                        for (int k = 0; k < 4; k++) { if (wgt[k] == 0.f || jnt[k] >= jm.size()) continue; const double* m = jm[jnt[k]].m;      // column major: m[4 c + r]
+                            // cofactors of the upper 3 x 3 = det * inverse-transpose
+                            const double c00 = m[5] * m[10] - m[9] * m[6], c01 = m[9] * m[2] - m[1] * m[10], c02 = m[1] * m[6] - m[5] * m[2];      // (rows of the cofactor matrix, indexed [row][col] of M)
+                            const double det = m[0] * c00 + m[4] * c01 + m[8] * c02;
+                            if (det != 0.0) {
+                                const double C[3][3] = {{c00, c01, c02},
+                                                        {m[8] * m[6] - m[4] * m[10], m[0] * m[10] - m[8] * m[2], m[4] * m[2] - m[0] * m[6]},
+                                                        {m[4] * m[9] - m[8] * m[5], m[8] * m[1] - m[0] * m[9], m[0] * m[5] - m[4] * m[1]}};      // C[r][c]: cofactor of M(r, c), M(r, c) = m[4 c + r]; inverse-transpose = C / det
+                                for (int rr = 0; rr < 3; rr++) nrm[rr] += (double)wgt[k] * (C[rr][0] * n0[0] + C[rr][1] * n0[1] + C[rr][2] * n0[2]) / det;
+                            }
+                            for (int rr = 0; rr < 3; rr++) tan[rr] += (double)wgt[k] * (m[rr] * t0[0] + m[4 + rr] * t0[1] + m[8 + rr] * t0[2]);
+                        }
+                        if (outN && (gd.flags & PT_GEOM_HAS_NORMAL)) { const double l = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+                            if (l > 0) { float nn[3] = {(float)(nrm[0] / l), (float)(nrm[1] / l), (float)(nrm[2] / l)}; outN[v] = pack_snorm8(nn, 3); } }
+                        if (outT && (gd.flags & PT_GEOM_HAS_TANGENT)) { const double l = sqrt(tan[0] * tan[0] + tan[1] * tan[1] + tan[2] * tan[2]);
+                            if (l > 0) { float tt[4] = {(float)(tan[0] / l), (float)(tan[1] / l), (float)(tan[2] / l), t0[3]}; outT[v] = pack_snorm8(tt, 4); } }
+                    }
                 }
             }
         }
         return (int32_t)nv;
     } catch (...) { a->L.recordWorlds = false; a->L.nodeOverride = nullptr; return -PT_ERROR_IO; }
+}
+extern "C" int32_t pt_gltf_animation_positions(pt_gltf_animation* a, uint32_t animation, float t, float* out, uint32_t capacityVertices) {
+    if (capacityVertices && !out) return -PT_ERROR_INVALID_ARGUMENT;
+    return gltf_animation_pose(a, animation, t, out, nullptr, nullptr, capacityVertices);
+}
+extern "C" int32_t pt_gltf_animation_normals(pt_gltf_animation* a, uint32_t animation, float t, uint32_t* normals, uint32_t* tangents, uint32_t capacityVertices) {
+    if (capacityVertices && !normals && !tangents) return -PT_ERROR_INVALID_ARGUMENT;
+    return gltf_animation_pose(a, animation, t, nullptr, normals, tangents, capacityVertices);
 }
 extern "C" int32_t pt_gltf_animation_instances(pt_gltf_animation* a, uint32_t animation, float t, PtInstanceDesc* out, uint32_t capacity) {
     if (!a || (capacity && !out)) return -PT_ERROR_INVALID_ARGUMENT;
