@@ -183,7 +183,7 @@ int32_t pt_gltf_animation_instances(pt_gltf_animation* anim, uint32_t animation,
    p = base + SUM_i w_i target_i, the weights from the animation's "weights" channel, else the node's, else the mesh's. Host only. */
 int32_t pt_gltf_animation_positions(pt_gltf_animation* anim, uint32_t animation, float timeSeconds, float* positionsXYZ, uint32_t capacityVertices);
 /* the posed NORMAL / TANGENT streams of the same pose (SNORM8 x 3 / x 4, the packing of PtGeometryBuffers; either pointer may be NULL): a skinned vertex's normal is
-   normalize(SUM_k w_k inverse-transpose(J_k) n), its tangent normalize(SUM_k w_k J_k t.xyz) with the handedness kept; unskinned vertices keep theirs; morph targets displace positions only.
+   normalize(SUM_k w_k inverse-transpose(J_k) n), its tangent normalize(SUM_k w_k J_k t.xyz) with the handedness kept; morph targets' NORMAL / TANGENT displacements are added first (renormalised); other vertices keep theirs.
    Returns the number of vertices (capacity 0: a query). -> pt_animate_normals */
 int32_t pt_gltf_animation_normals(pt_gltf_animation* anim, uint32_t animation, float timeSeconds, uint32_t* normalsSnorm8, uint32_t* tangentsSnorm8, uint32_t capacityVertices);
 void    pt_gltf_animation_free(pt_gltf_animation* anim);

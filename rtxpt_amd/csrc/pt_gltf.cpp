@@ -254,7 +254,7 @@ struct Loader {
     struct SkinnedInstance { int node, skin, mesh; }; std::vector<SkinnedInstance> skinned; std::vector<M4> nodeWorld; bool recordWorlds = false;      // filled by visit() when recordWorlds
     // morph targets (glTF 2.0 3.7.2.2): per geometry the POSITION displacements of its targets (count x numVertices x 3 floats from `first`), per imported mesh its default weights;
     // meshNodes: every (node, mesh) pair visit() met while recordWorlds — read by pt_gltf_animation_positions
-    struct GeomMorph { size_t first; uint32_t count; }; std::vector<GeomMorph> geomMorph; std::vector<float> morphDeltas; std::vector<std::vector<double>> meshWeights;
+    struct GeomMorph { size_t first; uint32_t count; }; std::vector<GeomMorph> geomMorph; std::vector<float> morphDeltas, morphNormalDeltas, morphTangentDeltas; std::vector<std::vector<double>> meshWeights;
     struct MeshNode { int node, mesh; }; std::vector<MeshNode> meshNodes;
     struct NodeTRS { bool has[3]; double t[3], q[4], s[3]; };      // animation: per node, the channels that replace its translation / rotation / scale (pt_gltf_animation)
     const std::vector<NodeTRS>* nodeOverride = nullptr;
@@ -396,6 +396,12 @@ struct Loader {
                     if (tj.get("POSITION")) { if (!accessor(tj.intOr("POSITION", -1), D, c) || c != 3 || D.size() / 3 != nv) { if (err.empty()) err = "morph target POSITION must be VEC3, one per vertex"; return false; } }
                     else D.assign(3 * (size_t)nv, 0.0);                                  // a target without positions displaces nothing here (normals and tangents keep their base values)
                     for (double x : D) morphDeltas.push_back((float)x);
+                    for (int which = 0; which < 2; which++) {      // NORMAL / TANGENT displacements (VEC3 each; absent: zeros), same layout as the positions'
+                        const char* key = which ? "TANGENT" : "NORMAL"; std::vector<double> E;
+                        if (tj.get(key)) { if (!accessor(tj.intOr(key, -1), E, c) || c != 3 || E.size() / 3 != nv) { if (err.empty()) err = "morph target NORMAL / TANGENT must be VEC3, one per vertex"; return false; } }
+                        else E.assign(3 * (size_t)nv, 0.0);
+                        std::vector<float>& dst = which ? morphTangentDeltas : morphNormalDeltas; for (double x : E) dst.push_back((float)x);
+                    }
                     gm.count++;
                 }
                 geomMorph.push_back(gm);
@@ -644,7 +650,8 @@ extern "C" void pt_gltf_animation_free(pt_gltf_animation* a) { delete a; }
 // channel, else of the node, else of the mesh. Normals and tangents: pt_gltf_animation_normals -> pt_animate_normals. A mesh shared by several nodes takes the pose of the last one.
 // outN / outT (pt_gltf_animation_normals): the posed NORMAL / TANGENT streams in the packing pt_set_geometry takes (SNORM8 x 3 / x 4). A skinned vertex's normal is
 // normalize(SUM_k w_k inverse-transpose(J_k) n), its tangent normalize(SUM_k w_k J_k t.xyz) with the handedness kept (glTF 2.0 3.7.3.3 leaves the normal transform to the
-// implementation; the inverse transpose is the one that keeps normals perpendicular under the non-uniform scales a mesh node may carry). Morph targets displace positions only.
+// implementation; the inverse transpose is the one that keeps normals perpendicular under the non-uniform scales a mesh node may carry). Morph targets' NORMAL / TANGENT displacements are added
+// before the skin and the sums renormalised.
 static int32_t gltf_animation_pose(pt_gltf_animation* a, uint32_t animation, float t, float* out, uint32_t* outN, uint32_t* outT, uint32_t capacityVertices) {
     if (!a || (capacityVertices && !out && !outN && !outT)) return -PT_ERROR_INVALID_ARGUMENT;
     try {
@@ -654,6 +661,8 @@ static int32_t gltf_animation_pose(pt_gltf_animation* a, uint32_t animation, flo
         memcpy(out, L.positions.data(), sizeof(float) * L.positions.size());
         if (outN) memcpy(outN, L.normals.data(), sizeof(uint32_t) * nv);
         if (outT) memcpy(outT, L.tangents.data(), sizeof(uint32_t) * nv);
+        std::vector<float> nF, tF; const bool wantNT = outN || outT;      // the morphed (not yet skinned) normals / tangents, where a target displaces them
+        if (wantNT) { nF = L.normalsF; tF = L.tangentsF; }
         const JValue* skins = L.root.get("skins"); const bool haveSkins = skins && skins->size();
         if (!haveSkins && L.morphDeltas.empty()) return (int32_t)nv;
         L.recordWorlds = true; L.skinned.clear(); L.nodeWorld.clear(); L.meshNodes.clear();
@@ -680,6 +689,16 @@ static int32_t gltf_animation_pose(pt_gltf_animation* a, uint32_t animation, flo
                         for (uint32_t i = 0; i < gm.count; i++) p += w[i] * (double)L.morphDeltas[gm.first + ((size_t)i * gd.numVertices + v) * 3 + rr];
                         out[3 * (size_t)(gd.vertexOffset + v) + rr] = (float)p;
                     }
+                    if (wantNT) for (uint32_t v = 0; v < gd.numVertices; v++) {      // n = normalize(base + SUM_i w_i dn_i), likewise the tangent's xyz (glTF 2.0 3.7.2.2); repacked for the unskinned case
+                        const size_t gv = gd.vertexOffset + v; double dn[3] = {0, 0, 0}, dt[3] = {0, 0, 0}; bool anyN = false, anyT = false;
+                        for (uint32_t i = 0; i < gm.count; i++) for (int rr = 0; rr < 3; rr++) {
+                            const float a = L.morphNormalDeltas[gm.first + ((size_t)i * gd.numVertices + v) * 3 + rr], b = L.morphTangentDeltas[gm.first + ((size_t)i * gd.numVertices + v) * 3 + rr];
+                            dn[rr] += w[i] * (double)a; dt[rr] += w[i] * (double)b; anyN = anyN || (a != 0.f && w[i] != 0.0); anyT = anyT || (b != 0.f && w[i] != 0.0); }
+                        if (anyN && (gd.flags & PT_GEOM_HAS_NORMAL)) { double q[3], l = 0; for (int rr = 0; rr < 3; rr++) { q[rr] = L.normalsF[3 * gv + rr] + dn[rr]; l += q[rr] * q[rr]; } l = sqrt(l);
+                            if (l > 0) { for (int rr = 0; rr < 3; rr++) nF[3 * gv + rr] = (float)(q[rr] / l); if (outN) outN[gv] = pack_snorm8(&nF[3 * gv], 3); } }
+                        if (anyT && (gd.flags & PT_GEOM_HAS_TANGENT)) { double q[3], l = 0; for (int rr = 0; rr < 3; rr++) { q[rr] = L.tangentsF[4 * gv + rr] + dt[rr]; l += q[rr] * q[rr]; } l = sqrt(l);
+                            if (l > 0) { for (int rr = 0; rr < 3; rr++) tF[4 * gv + rr] = (float)(q[rr] / l); if (outT) outT[gv] = pack_snorm8(&tF[4 * gv], 4); } }
+                    }
                 }
             }
         }
@@ -705,7 +724,7 @@ static int32_t gltf_animation_pose(pt_gltf_animation* a, uint32_t animation, flo
                         for (int rr = 0; rr < 3; rr++) q[rr] += (double)wgt[k] * (m[rr] * p[0] + m[4 + rr] * p[1] + m[8 + rr] * p[2] + m[12 + rr]); }
                     for (int rr = 0; rr < 3; rr++) out[3 * (size_t)v + rr] = (float)q[rr];
                     if ((outN && (gd.flags & PT_GEOM_HAS_NORMAL)) || (outT && (gd.flags & PT_GEOM_HAS_TANGENT))) {
-                        double nrm[3] = {0, 0, 0}, tan[3] = {0, 0, 0}; const float* n0 = &L.normalsF[3 * (size_t)v]; const float* t0 = &L.tangentsF[4 * (size_t)v];
+                        double nrm[3] = {0, 0, 0}, tan[3] = {0, 0, 0}; const float* n0 = &nF[3 * (size_t)v]; const float* t0 = &tF[4 * (size_t)v];      // (morphed first)
                         for (int k = 0; k < 4; k++) { if (wgt[k] == 0.f || jnt[k] >= jm.size()) continue; const double* m = jm[jnt[k]].m;      // column major: m[4 c + r]
                             // cofactors of the upper 3 x 3 = det * inverse-transpose
                             const double c00 = m[5] * m[10] - m[9] * m[6], c01 = m[9] * m[2] - m[1] * m[10], c02 = m[1] * m[6] - m[5] * m[2];      // (rows of the cofactor matrix, indexed [row][col] of M)

@@ -99,3 +99,33 @@ def test_device_shades_with_the_posed_normals(tmp_path):
     assert np.array_equal(got.view(np.uint32), o.radiance().view(np.uint32))
     t2 = pt.PathTracer(); t2.set_scene(sc2); t2.set_settings(S); t2.set_camera(camd); t2.resize(w, h); t2.render(0, 2)
     assert np.array_equal(got.view(np.uint32), t2.radiance().view(np.uint32)); t2.close()
+
+
+def test_morph_targets_displace_normals_and_tangents(tmp_path):
+    """NORMAL / TANGENT displacements of morph targets (glTF 2.0 3.7.2.2): n = normalize(base + SUM_i w_i dn_i), the node's weights, no skin"""
+    rng = np.random.default_rng(11)
+    P = rng.uniform(-1, 1, (6, 3)).astype(np.float32)
+    N = rng.normal(size=(6, 3)); N = (N / np.linalg.norm(N, axis=1, keepdims=True)).astype(np.float32)
+    T = rng.normal(size=(6, 3)); T = T / np.linalg.norm(T, axis=1, keepdims=True); T = np.concatenate([T, np.array([[1.0], [-1.0]] * 3)], 1).astype(np.float32)
+    DP = rng.uniform(-0.2, 0.2, (6, 3)).astype(np.float32); DN = rng.uniform(-0.6, 0.6, (6, 3)).astype(np.float32); DT = rng.uniform(-0.6, 0.6, (6, 3)).astype(np.float32)
+    I = np.arange(6, dtype=np.uint16)
+    blobs = [P.tobytes(), N.tobytes(), T.tobytes(), DP.tobytes(), DN.tobytes(), DT.tobytes(), I.tobytes()]
+    offs, blob = [], b""
+    for b_ in blobs: blob += b"\0" * ((-len(blob)) % 4); offs.append(len(blob)); blob += b_
+    views = [{"buffer": 0, "byteOffset": o, "byteLength": len(b_)} for o, b_ in zip(offs, blobs)]
+    v3 = lambda i: {"bufferView": i, "componentType": 5126, "count": 6, "type": "VEC3"}
+    acc = [dict(v3(0), min=P.min(0).tolist(), max=P.max(0).tolist()), v3(1), {"bufferView": 2, "componentType": 5126, "count": 6, "type": "VEC4"}, v3(3), v3(4), v3(5), {"bufferView": 6, "componentType": 5123, "count": 6, "type": "SCALAR"}]
+    prim = {"attributes": {"POSITION": 0, "NORMAL": 1, "TANGENT": 2}, "indices": 6, "targets": [{"POSITION": 3, "NORMAL": 4, "TANGENT": 5}]}
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0, 1]}], "nodes": [{"name": "morphed", "mesh": 0, "weights": [0.75]}, {"name": "rest", "mesh": 1}],
+           "meshes": [{"primitives": [prim], "weights": [0.0]}, {"primitives": [prim], "weights": [0.0]}],
+           "accessors": acc, "bufferViews": views, "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}]}
+    f = tmp_path / "morph_normals.gltf"; f.write_text(json.dumps(doc))
+    a = pt.GltfAnimation(f)
+    nrm, tan = a.normals(0.0)
+    en = N.astype(np.float64) + 0.75 * DN; en /= np.linalg.norm(en, axis=1, keepdims=True)
+    et = T[:, :3].astype(np.float64) + 0.75 * DT; et /= np.linalg.norm(et, axis=1, keepdims=True)
+    assert np.abs(_snorm8(nrm[:6])[:, :3] - en).max() <= 1.0 / 127 + 1e-6 and np.abs(_snorm8(tan[:6])[:, :3] - et).max() <= 1.0 / 127 + 1e-6
+    assert np.array_equal(np.sign(_snorm8(tan[:6])[:, 3]), np.sign(T[:, 3]))
+    assert np.abs(_snorm8(nrm[6:])[:, :3] - N).max() <= 1.0 / 127 + 1e-6                 # weight 0: the base streams
+    assert np.allclose(a.positions(0.0)[:6], P.astype(np.float64) + 0.75 * DP, atol=2e-6)
+    a.close()
