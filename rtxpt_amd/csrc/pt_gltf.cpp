@@ -656,7 +656,7 @@ static int32_t gltf_animation_pose(pt_gltf_animation* a, uint32_t animation, flo
     if (!a || (capacityVertices && !out && !outN && !outT)) return -PT_ERROR_INVALID_ARGUMENT;
     try {
         Loader& L = a->L; const uint32_t nv = (uint32_t)(L.positions.size() / 3);
-        if (capacityVertices < nv) return (int32_t)nv;                                     // (query: the number of vertices)
+        if (capacityVertices < nv || nv == 0) return (int32_t)nv;                          // (query: the number of vertices; a file without vertices has nothing to pose)
         std::vector<float> posScratch; if (!out) { posScratch.resize(L.positions.size()); out = posScratch.data(); }
         memcpy(out, L.positions.data(), sizeof(float) * L.positions.size());
         if (outN) memcpy(outN, L.normals.data(), sizeof(uint32_t) * nv);
