@@ -37,3 +37,20 @@ def test_kernel_trace_summary_agrees_with_the_bench_line():
     ext = [x for x in rows if x["Name"].startswith("void ptk::k_extend<false>")][0]
     avg_ms = float(ext["AverageNs"]) * 1e-6
     assert int(ext["Calls"]) == 27 and abs(avg_ms - r["avg_launch_ms"]) < 0.05 * r["avg_launch_ms"]          # rocprofv3's average k_extend launch vs bench.py's own HIP events
+
+
+def test_final_tree_bench_line_and_its_realtime_leg():
+    """profiles/r03zz_bench.json: the bench line of the round's final tree (same traversal / shading object code as r03z's) — the contract fields again, the parity block taken after the
+    realtime leg ran on the same context, and that leg's figures consistent with the stand-alone probe (profiles/r03sq_stable_planes_probe.json: the single-batch fill pass)"""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r03zz_bench.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "realtime_passes"):
+        assert k in d, k
+    assert abs(d["config"]["rays_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6 - d["value"]) < 1e-6 * d["value"]
+    assert d["parity"]["differing_pixels"] == 0 and d["parity"]["pixels"] == 1920 * 1080
+    old = json.loads(open(REC).read().strip().splitlines()[-1])
+    assert abs(d["value"] / old["value"] - 1.0) < 0.02                                  # same kernels, same frame: within run-to-run noise of r03z
+    rt = d["realtime_passes"]; assert "error" not in rt
+    probe = json.load(open(os.path.join(ROOT, "profiles", "r03sq_stable_planes_probe.json")))
+    assert rt["build_rays"] > 3840 * 2160 and abs(rt["build_rays"] / probe["build_pass"]["rays"] - 1.0) < 0.01      # (the build pass of another sample index: the camera jitter moves a few delta paths)
+    assert abs(rt["fill_rays"] / (probe["fill_pass_one_subsample"]["extend_rays"] + probe["fill_pass_one_subsample"]["shadow_rays"]) - 1.0) < 0.01
+    assert rt["fill_ms"] < probe["fill_pass_one_subsample"]["ms"]                       # pipelined batches against the probe's single batch
