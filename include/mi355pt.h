@@ -311,6 +311,9 @@ int32_t pt_build_stable_planes(pt_context* ctx, uint32_t sampleIndex, const PtSt
 int32_t pt_fill_stable_planes(pt_context* ctx, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* stats);
 /* DenoisingGuidesBaker::DenoiseSpecHitT (Sample.cpp:2544, after the noisy passes of a frame): the 5 x 5 depth-aware fill-in of specularHitT, one ping and one pong (DenoisingGuidesBaker.hlsl:50-113) */
 int32_t pt_denoise_spec_hit_t(pt_context* ctx);
+/* PostProcess.hlsl NO_DENOISER_FINAL_MERGE (Sample.cpp:2764-2765: the realtime frame when no denoiser runs): output colour = stable radiance + every existing plane's noisy radiance
+ * (StablePlanesContext::GetAllRadiance), alpha 1 — written into the context's radiance buffer (pt_map_radiance, pt_tonemap, pt_gather read it; it counts as one accumulated sample). */
+int32_t pt_stable_planes_merge(pt_context* ctx);
 /* copies the last pass's buffers to the host; any pointer may be NULL. planeCapacity in records (>= 3 x plane stride); the two RGBA16F targets as 4 binary16 bit patterns per pixel */
 int32_t pt_get_stable_planes(pt_context* ctx, uint32_t* header, PtStablePlane* planes, size_t planeCapacity, uint16_t* stableRadiance, float* depth, float* specularHitT,
                              uint16_t* motionVectors, uint32_t* throughput);

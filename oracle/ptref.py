@@ -674,6 +674,14 @@ class Oracle:
         return np.array(o, np.float32)
 
 
+def stable_planes_merge(frame, reference=False):
+    """PostProcess.hlsl's NO_DENOISER_FINAL_MERGE over a frame of build_stable_planes / fill_stable_planes: stable radiance + every plane's noisy radiance -> float32 [h, w, 4]"""
+    hd = np.ascontiguousarray(frame["header"]); _, h, w = hd.shape; out = np.zeros((h, w, 4), np.float32)
+    pl = np.ascontiguousarray(frame["planes"]); sr = np.ascontiguousarray(frame["stable_radiance"])
+    (refpin_pt().refpt_stable_planes_merge if reference else lib().ptref_stable_planes_merge)(w, h, _p(hd), _p(pl), _p(sr), _p(out))
+    return out
+
+
 def denoise_spec_hit_t(depth, spec_hit_t, reference=False):
     """DenoisingGuidesBaker::DenoiseSpecHitT on whole planes (float32 [h, w]): returns the filled-in specular hit distances. reference=True: the reference's compute shader text (any pin library)."""
     d = np.ascontiguousarray(depth, np.float32); t = np.array(spec_hit_t, np.float32, copy=True, order="C"); h, w = d.shape

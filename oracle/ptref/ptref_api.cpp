@@ -784,6 +784,13 @@ void ptref_denoise_spec_hit_t(uint32_t w, uint32_t hgt, const float* depth, floa
     for (uint32_t y = 0; y < hgt; y++) for (uint32_t x = 0; x < w; x++) scratch[(size_t)y * w + x] = SpecHitTNeighbourhood(specHitT, depth, w, hgt, (int)x, (int)y);
     for (uint32_t y = 0; y < hgt; y++) for (uint32_t x = 0; x < w; x++) specHitT[(size_t)y * w + x] = SpecHitTNeighbourhood(scratch.data(), depth, w, hgt, (int)x, (int)y);
 }
+// PostProcess.hlsl NO_DENOISER_FINAL_MERGE (Sample.cpp:2764-2765): the realtime frame without a denoiser, RGBA32F
+void ptref_stable_planes_merge(uint32_t w, uint32_t hgt, const uint32_t* header, const void* planes, const uint32_t* stableRadiance, float* rgba) {
+    StablePlanesParams p; memset(&p, 0, sizeof(p)); p.activeStablePlaneCount = 3;
+    StablePlanesContext ctx; ctx.C = SP_make_consts(p, w, hgt, 0); memset(&ctx.B, 0, sizeof(ctx.B));
+    ctx.B.Header = (uint32_t*)header; ctx.B.Planes = (StablePlane*)planes; ctx.B.StableRadiance = (uint2*)stableRadiance;
+    for (uint32_t y = 0; y < hgt; y++) for (uint32_t x = 0; x < w; x++) { const float3 c = ctx.GetAllRadiance(x, y); float* o = rgba + 4 * ((size_t)y * w + x); o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = 1.0f; }
+}
 void ptref_render(void* h, uint32_t first, uint32_t n) { Context* c = (Context*)h; ptref_render_rect(h, first, n, 0, 0, c->w, c->h); }
 const float* ptref_radiance(void* h) { return (const float*)((Context*)h)->accum.data(); }
 void ptref_get_counters(void* h, uint64_t* out7) { memcpy(out7, &((Context*)h)->ctr, sizeof(RayCounters)); }

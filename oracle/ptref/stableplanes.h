@@ -325,6 +325,17 @@ struct StablePlanesContext {
         const uint n = C.activeStablePlaneCount < cStablePlaneCount ? C.activeStablePlaneCount : cStablePlaneCount;
         for (uint i = 1; i < n; i++) if (GetBranchID(px, py, i) == cStablePlaneInvalidBranchID) availablePlanes[availableCount++] = (int)i;
     }
+    // StablePlanesContext::GetAllRadiance (StablePlanes.hlsli:262-275): what PostProcess.hlsl's NO_DENOISER_FINAL_MERGE writes to the output colour — the stable radiance plus every existing plane's noisy radiance
+    float3 GetAllRadiance(uint px, uint py) const {
+        float3 pathL = LoadStableRadiance(px, py);
+        for (uint i = 0; i < cStablePlaneCount; i++) {
+            if (GetBranchID(px, py, i) == cStablePlaneInvalidBranchID) continue;
+            const StablePlane& rec = B.Planes[PixelToAddress(px, py, i)];
+            const float2 a = Fp16ToFp32(rec.PackedNoisyRadianceAndSpecAvg[0]), b = Fp16ToFp32(rec.PackedNoisyRadianceAndSpecAvg[1]);
+            pathL = pathL + make_float3(a.x, a.y, b.x);
+        }
+        return pathL;
+    }
     // Bridge::computeMotionVector (BridgeDonut:890-909)
     float3 computeMotionVector(float3 posW, float3 prevPosW) const {
         float4 clipPos = SP_mul_row(posW, C.matWorldToClipNoOffset);

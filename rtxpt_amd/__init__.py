@@ -34,7 +34,7 @@ EXPORTS = [
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
-    "pt_stable_planes_plane_stride", "pt_build_stable_planes", "pt_fill_stable_planes", "pt_denoise_spec_hit_t", "pt_get_stable_planes",
+    "pt_stable_planes_plane_stride", "pt_build_stable_planes", "pt_fill_stable_planes", "pt_denoise_spec_hit_t", "pt_stable_planes_merge", "pt_get_stable_planes",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host", "pt_neeat_exchange_host",
 ]
 
@@ -721,6 +721,12 @@ class PathTracer:
         self._chk(g(self.h, _p(out["header"]), _p(out["planes"]), 3 * stride, _p(out["stable_radiance"]), _p(out["depth"]), _p(out["spec_hit_t"]), _p(out["motion_vectors"]), _p(out["throughput"])), "pt_get_stable_planes")
         out["plane_stride"] = stride; out["stats"] = total
         return out
+
+    def stable_planes_merge(self):
+        """pt_stable_planes_merge: the realtime frame without a denoiser (stable + noisy radiance) into the radiance buffer; returns radiance()"""
+        f = self.L.pt_stable_planes_merge; f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_int32
+        self._chk(f(self.h), "pt_stable_planes_merge")
+        return self.radiance()
 
     def denoise_spec_hit_t(self):
         """pt_denoise_spec_hit_t: the fill-in of the specular hit distance that ends a realtime frame's noisy passes; returns spec_hit_t [h, w] f32"""

@@ -1344,6 +1344,19 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
     if (active) return fail(c, PT_ERROR_HIP, "stable-plane fill pass: paths still alive after the iteration bound");
     return PT_OK;
 }
+int32_t pt_stable_planes_merge(pt_context* c) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes, pt_fill_stable_planes");
+    (void)hipSetDevice(c->device);
+    ptk::StablePlanesParams prm; memset(&prm, 0, sizeof(prm)); prm.activeStablePlaneCount = cStablePlaneCount;
+    StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount); memset(&sp.B, 0, sizeof(sp.B));
+    sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p;
+    const uint numOwned = (uint)c->owned.size();
+    if (numOwned) launch_sp_merge(sp, c->dOwned.p, numOwned, c->dAccum.p, c->stream);
+    c->accumCount = 1;                                    // the buffer now holds one finished frame: pt_map_radiance / pt_tonemap / pt_gather read it, the next pt_render blends into it like into any first sample
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); PT_CHECK_HIP(c, hipGetLastError());
+    return PT_OK;
+}
 int32_t pt_denoise_spec_hit_t(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes, pt_fill_stable_planes");

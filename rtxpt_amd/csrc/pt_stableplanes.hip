@@ -185,6 +185,16 @@ void launch_sp_denoise_spec_hit_t(float* specHitT, const float* depth, float* sc
     hipLaunchKernelGGL(k_sp_denoise_spec_hit_t, g, dim3(256), 0, st, specHitT, depth, scratch, width, height);
     hipLaunchKernelGGL(k_sp_denoise_spec_hit_t, g, dim3(256), 0, st, scratch, depth, specHitT, width, height);
 }
+// PostProcess.hlsl NO_DENOISER_FINAL_MERGE: output colour = (GetAllRadiance, 1)
+__global__ void __launch_bounds__(256) k_sp_merge(StablePlanesContext sp, const uint* __restrict__ ownedPixels, uint numOwned, float4* __restrict__ out) {
+    const uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= numOwned) return;
+    const uint px = ownedPixels[i] >> 16, py = ownedPixels[i] & 0xFFFFu;
+    out[(size_t)py * sp.C.imageWidth + px] = make_float4(sp.GetAllRadiance(px, py), 1.0f);
+}
+void launch_sp_merge(const StablePlanesContext& sp, const uint* ownedPixels, uint numOwned, float4* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_sp_merge, dim3((numOwned + 255u) / 256u), dim3(256), 0, st, sp, ownedPixels, numOwned, out);
+}
 void launch_sp_generate(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleIndex, uint* queue, hipStream_t st) {
     const dim3 g((numOwned + 255u) / 256u), b(256);
     if (k.S.useFp16Types) { PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16)); hipLaunchKernelGGL((k_sp_generate<PathKernelContextT<true>>), g, b, 0, st, k16, sp, pool, ownedPixels, numOwned, sampleIndex, queue); }

@@ -14,4 +14,5 @@ void launch_sp_fill_shade(const PathKernelContext& k, const StablePlanesContext&
 void launch_sp_fill_resolve(PathPool pool, uint4* mark, ShadowQueue sq, const float4* newL, const uint* countPtr, uint count, hipStream_t st);
 void launch_sp_fill_commit(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, uint numOwned, uint sampleIndex, hipStream_t st);
 void launch_sp_denoise_spec_hit_t(float* specHitT, const float* depth, float* scratch, uint width, uint height, hipStream_t st);
+void launch_sp_merge(const StablePlanesContext& sp, const uint* ownedPixels, uint numOwned, float4* out, hipStream_t st);
 } // namespace ptk

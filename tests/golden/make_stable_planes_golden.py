@@ -26,6 +26,7 @@ for name in spc.cases():
     lp = spc.live_planes(r)
     assert np.array_equal(np.delete(lp, (16, 17), 1), np.delete(out[name + "_live_planes"], (16, 17), 1)) and np.array_equal(r["header"], out[name + "_header"])      # the pass writes nothing else
     out[name + "_fill_noisy"] = lp[:, 16:18].copy(); out[name + "_fill_spec_hit_t"] = r["spec_hit_t"]
+    if name == "zoo_fp32": out[name + "_fill_merge"] = ptref.stable_planes_merge(r, reference=True)      # PostProcess.hlsl NO_DENOISER_FINAL_MERGE (GetAllRadiance of StablePlanes.hlsli)
     if name == "zoo_fp32": out[name + "_fill_spec_hit_t_denoised"] = ptref.denoise_spec_hit_t(r["depth"], r["spec_hit_t"], reference=True)      # DenoisingGuidesBaker.hlsl's DenoiseSpecHitT, ping + pong
     out[name + "_fill_rays"] = np.array([f.counters()["extendRays"], f.counters()["shadowRays"]], np.uint64)
     print("   fill:", out[name + "_fill_rays"].tolist(), "planes with noisy radiance", int((out[name + "_fill_noisy"] != 0).any(-1).sum())); f.close()

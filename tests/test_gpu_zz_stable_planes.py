@@ -117,7 +117,8 @@ def test_fill_device_matches_reference_text(name):
     a, b = got["spec_hit_t"].view(np.uint32), g[name + "_fill_spec_hit_t"].view(np.uint32)
     assert np.array_equal(a, b), "%s: specular hit distance differs in %d pixels" % (name, int((a != b).sum()))
     assert (int(got["stats"]["extendRays"]), int(got["stats"]["shadowRays"])) == tuple(int(v) for v in g[name + "_fill_rays"])
-    if name == "zoo_fp32":      # DenoiseSpecHitT closes the frame
+    if name == "zoo_fp32":      # the frame without a denoiser (NO_DENOISER_FINAL_MERGE), then DenoiseSpecHitT closes the frame
+        assert np.array_equal(t.stable_planes_merge().view(np.uint32), g[name + "_fill_merge"].view(np.uint32))
         assert np.array_equal(t.denoise_spec_hit_t().view(np.uint32), g[name + "_fill_spec_hit_t_denoised"].view(np.uint32))
     assert np.array_equal(np.delete(lp, (16, 17), 1), np.delete(spc.live_planes(built), (16, 17), 1)) and np.array_equal(got["header"], built["header"])      # nothing else is written
     for k in ("stable_radiance", "depth", "motion_vectors", "throughput"): assert np.array_equal(got[k], built[k]), k

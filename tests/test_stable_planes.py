@@ -216,3 +216,18 @@ def test_the_two_copies_of_the_shared_header_are_one_text():
     a = open(os.path.join(root, "rtxpt_amd", "csrc", "pt_stableplanes.h")).read().split("\n")
     b = open(os.path.join(root, "oracle", "ptref", "stableplanes.h")).read().split("\n")
     assert a[2:] == b[2:] and a[:2] != b[:2]
+
+
+def test_no_denoiser_final_merge_equals_the_reference_shader():
+    """PostProcess.hlsl's NO_DENOISER_FINAL_MERGE = StablePlanesContext::GetAllRadiance per pixel: the oracle against the committed output of the reference's text, that text live, and the sum spelled out in numpy"""
+    r, _ = oracle_fill("zoo_fp32")
+    got = ptref.stable_planes_merge(r)
+    assert np.array_equal(got.view(np.uint32), GOLD["zoo_fp32_fill_merge"].view(np.uint32))
+    if os.path.isdir("/root/reference/Rtxpt/Shaders"): assert np.array_equal(got.view(np.uint32), ptref.stable_planes_merge(r, reference=True).view(np.uint32))
+    P = r["planes"].view(scenes.STABLE_PLANE_DTYPE).reshape(-1); want = r["stable_radiance"].view(np.float16).astype(np.float32)[..., :3].copy()
+    for pl in range(3):
+        ys, xs = np.nonzero(r["header"][pl] != 0xFFFFFFFF)
+        for x, y in zip(xs.tolist(), ys.tolist()):
+            w = P[scenes.stable_planes_address(x, y, pl, spc.W, spc.H)]["PackedNoisyRadianceAndSpecAvg"]
+            want[y, x] += np.array([w[0] & 0xFFFF, w[0] >> 16, w[1] & 0xFFFF], np.uint16).view(np.float16).astype(np.float32)
+    assert np.array_equal(got[..., :3].view(np.uint32), want.view(np.uint32)) and (got[..., 3] == 1).all()
