@@ -145,7 +145,7 @@ typedef struct PtFrameStats {
     double   extendKernelMs, shadeKernelMs, shadowKernelMs; /* summed per-launch HIP-event time: filled for serial-kernel frames (pt_set_serial_kernels), counter builds and under
                                                                MI355PT_PASS_LOG; zero for pipelined frames, whose launches carry no events (ten API calls per pass and batch) */
     uint32_t extendLaunches, iterations;
-    uint32_t pathsTraced, _pad;
+    uint32_t pathsTraced, tailLaunches;     /* tailLaunches: launches of the tail kernel (pt_set_tail_paths), summed over the batches */
 } PtFrameStats;
 
 /* Tone mapping constants (Rtxpt/ToneMapper/ToneMapping_cb.h:30-45) with the colour transform as the 3x3 that `mul(color, M)` uses
@@ -572,6 +572,12 @@ int32_t pt_set_counters(pt_context* ctx, int32_t enable);
 /* runtime form of PT_DEVICE_SERIAL_KERNELS: 1 = pt_render uses one batch on one stream (kernels never overlap: clean per-kernel HIP-event /
    rocprofv3 durations), 0 = two pipelined half-frame batches (default) */
 int32_t pt_set_serial_kernels(pt_context* ctx, int32_t enable);
+/* The tail kernel: once a batch of pt_render holds at most `maxPaths` live paths, ONE launch runs them to their end — every wave loops trace -> shade -> visibility ->
+   next bounce over 32 paths, the shape of the reference's raygen loop (Rtxpt/Shaders/PathTracerSample.hlsl:200-250) where it fits: few paths, bound by the length of
+   the launch chain of a wavefront pass, not by throughput. 0 = never (every pass is a wavefront pass); default 65536 (environment MI355PT_TAIL_PATHS overrides it at
+   pt_create). The image does not depend on the value (paths do not interact; tests render whole frames through the tail kernel). Ignored for NEEFullSamples > 1,
+   serial-kernel and counter frames. */
+int32_t pt_set_tail_paths(pt_context* ctx, uint32_t maxPaths);
 
 #ifdef __cplusplus
 }

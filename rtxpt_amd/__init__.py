@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -121,7 +121,7 @@ class PtFrameStats(ctypes.Structure):
                 ("leafVisitsExtend", ctypes.c_uint64), ("waveItersExtend", ctypes.c_uint64), ("leafVisitsShadow", ctypes.c_uint64), ("waveItersShadow", ctypes.c_uint64),
                 ("extendPhaseCycles", ctypes.c_uint64 * 4), ("leafBlocksExtend", ctypes.c_uint64), ("waveItersMaxExtend", ctypes.c_uint64), ("extendRayIterHist", ctypes.c_uint64 * 16), ("longRayCount", ctypes.c_uint32), ("_padLong", ctypes.c_uint32), ("longRays", (ctypes.c_float * 8) * 32), ("extendEvents", ctypes.c_uint64 * 8),
                 ("gpuMilliseconds", ctypes.c_double), ("extendKernelMs", ctypes.c_double), ("shadeKernelMs", ctypes.c_double), ("shadowKernelMs", ctypes.c_double),
-                ("extendLaunches", ctypes.c_uint32), ("iterations", ctypes.c_uint32), ("pathsTraced", ctypes.c_uint32), ("_pad", ctypes.c_uint32)]
+                ("extendLaunches", ctypes.c_uint32), ("iterations", ctypes.c_uint32), ("pathsTraced", ctypes.c_uint32), ("tailLaunches", ctypes.c_uint32)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if isinstance(getattr(self, n), ctypes.Array) else getattr(self, n)) for n, _ in self._fields_ if n != "_pad"}
@@ -816,6 +816,10 @@ class PathTracer:
 
     def set_serial_kernels(self, enable):
         self._chk(self.L.pt_set_serial_kernels(self.h, 1 if enable else 0), "pt_set_serial_kernels")
+
+    def set_tail_paths(self, max_paths):
+        """pt_set_tail_paths: batches with at most this many live paths are finished by the tail kernel (0: never)."""
+        self._chk(self.L.pt_set_tail_paths(self.h, int(max_paths)), "pt_set_tail_paths")
 
     def tonemap(self, params=None):
         """pt_tonemap: the accumulation buffer through ToneMappingPass into sRGB RGBA8 -> (H, W, 4) uint8."""

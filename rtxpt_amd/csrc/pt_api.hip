@@ -62,6 +62,9 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #ifndef PT_CLASSIFY_FROM
 #define PT_CLASSIFY_FROM 65536u     // passes with fewer paths skip k_classify (class-ordered shading pays through coherence, which a handful of waves do not have)
 #endif
+#ifndef PT_TAIL_PATHS
+#define PT_TAIL_PATHS 65536u     // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never
+#endif
 #ifndef PT_PIPELINE_BATCHES
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
 #endif
@@ -70,7 +73,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
-    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false;   // second half-frame batch (pt_render pipelines two batches)
+    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -636,6 +639,8 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     c->bvhBuilder = (desc && (desc->flags & PT_DEVICE_PREFER_FAST_BUILD)) ? BVH_BUILDER_PLOC : ((desc && (desc->flags & PT_DEVICE_HOST_SAH_BUILDER)) ? BVH_BUILDER_SAH : BVH_BUILDER_PLOC_OPT);
     { const char* e = getenv("MI355PT_BVH_BUILDER");        // developer A/B switch
       if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; else if (e && (!strcmp(e, "ploc_opt") || !strcmp(e, "device"))) c->bvhBuilder = BVH_BUILDER_PLOC_OPT; }
+    { const char* e = getenv("MI355PT_TAIL_PATHS"); if (e) c->tailBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch (pt_set_tail_paths)
+    { const char* e = getenv("MI355PT_TAIL_DEFER"); if (e) c->tailDefer = (uint)strtoul(e, nullptr, 10); }      // test switch: iterations after which the tail kernel hands a ray back (0: T8_TAIL_DEFER); a small value sends most rays through the hand-back path
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
     const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale);      // no params = tint 1, intensity 1: the cube holds radiance x 1/4
@@ -1076,7 +1081,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
-        uint cur = 0, active = 0, iterations = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false;
+        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false; uint bound = 0;      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; uint items; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         bool timed = false;      // per-launch HIP events: only when somebody reads them (serial-kernel steps, the pass log) — ten API calls per pass and batch otherwise
         size_t mark() { if (!timed) return 0; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
@@ -1112,15 +1117,27 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     }
     // upper bound on extend passes: bounceCount+1 vertices plus rejected (nested dielectric) re-traces
     uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u));
+    // the tail kernel takes over a batch once it holds at most this many paths (0: never). Not in serial-kernel / counter frames (their per-kernel attribution is the point), not with
+    // grouped NEE samples (NEEFullSamples > 1 folds a vertex's samples in k_resolve_nee) and not without a tree (the traversal's empty-scene path is per launch, not per wave)
+    const uint tailBelow = (PT_T8_LANES == 2 && !c->serialKernels && !c->countersEnabled && !shadowGroup && c->dsc.rootIsValid) ? c->tailBelow : 0u;
     bool any = true;
     while (any) {
         // phase 1: every live batch queues extend + shade and the read-back of its queue counts
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b];
             t.waiting = false;
-            if (!t.active || t.iterations >= maxIter) continue;
+            if (!t.active || t.bound >= maxIter) continue;
             uint nxt = t.cur ^ 1u;
             launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch
+            if (tailBelow && t.active <= tailBelow && !t.afterTail) {      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
+                size_t e0 = t.mark(); launch_tail(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, maxIter - t.bound, c->tailDefer, t.aux.maxBlocks, t.st); size_t e1 = t.mark();
+                if (t.timed) t.spans.push_back({e0, e1, 3, t.active});
+                t.tailLaunches++; t.afterTail = true;      // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
+                PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
+                t.waiting = true;
+                continue;
+            }
+            t.afterTail = false; t.bound++;
             size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
             launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
             t.extendRays += t.active;
@@ -1137,7 +1154,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
             if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
             t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
-            if (t.active && t.iterations < maxIter) any = true;
+            if (t.active && t.bound < maxIter) any = true;
         }
     }
     for (uint b = 0; b < numBatches; b++) {
@@ -1159,9 +1176,12 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         float ms = 0; (void)hipEventElapsedTime(&ms, frame0, frame1); stats->gpuMilliseconds = ms;
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b]; const WaveCounters& h = *t.hwc;
-            for (auto& sp : t.spans) { float m = 0; (void)hipEventElapsedTime(&m, t.ev[sp.a], t.ev[sp.b]); if (sp.kind == 0) stats->extendKernelMs += m; else if (sp.kind == 1) stats->shadeKernelMs += m; else stats->shadowKernelMs += m; }      // (zero in pipelined frames: no per-launch events there)
+            for (auto& sp : t.spans) { float m = 0; (void)hipEventElapsedTime(&m, t.ev[sp.a], t.ev[sp.b]); if (sp.kind == 0) stats->extendKernelMs += m; else if (sp.kind == 1) stats->shadeKernelMs += m; else if (sp.kind == 2) stats->shadowKernelMs += m; }      // (zero in pipelined frames: no per-launch events there)
             stats->extendLaunches += t.iterations;
-            stats->extendRays += t.extendRays; stats->shadowRays += shadowGroup ? h.shadowValid : t.shadowRays; stats->hits += h.hits; stats->nodeVisitsExtend += h.nodeVisitsExt; stats->triTestsExtend += h.triTestsExt;
+            stats->extendRays += t.extendRays + h.tailExtendRays; stats->shadowRays += shadowGroup ? h.shadowValid : t.shadowRays + h.tailShadowRays; stats->hits += h.hits; stats->tailLaunches += t.tailLaunches;
+            if (getenv("MI355PT_PASS_LOG") && t.tailLaunches) fprintf(stderr, "[pass log] batch %u: %u tail launches traced %llu + %llu rays, handed back %llu extend stragglers, %llu visibility stragglers, %llu paths at the bounce bound\n", b, t.tailLaunches,
+                (unsigned long long)h.tailExtendRays, (unsigned long long)h.tailShadowRays, (unsigned long long)h.tailHandedBack[0], (unsigned long long)h.tailHandedBack[1], (unsigned long long)h.tailHandedBack[2]);
+            stats->nodeVisitsExtend += h.nodeVisitsExt; stats->triTestsExtend += h.triTestsExt;
             stats->nodeVisitsShadow += h.nodeVisitsSh; stats->triTestsShadow += h.triTestsSh;
             stats->leafVisitsExtend += h.leafVisitsExt; stats->waveItersExtend += h.itersExt; stats->leafVisitsShadow += h.leafVisitsSh; stats->waveItersShadow += h.itersSh;
             for (int q = 0; q < 4; q++) stats->extendPhaseCycles[q] += h.phaseCycExt[q];
@@ -1177,7 +1197,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         for (uint b = 0; b < numBatches; b++) { Batch& t = B[b]; float whole = 0; if (!t.timed) continue; (void)hipEventElapsedTime(&whole, t.ev[t.t0], t.ev[t.t1]);
             fprintf(stderr, "[pass log] batch %u of %u: %u paths, %u passes, %.3f ms from first to last event\n", b, numBatches, t.total, t.iterations, whole);
             for (auto& sp : t.spans) { float m = 0, at = 0; (void)hipEventElapsedTime(&m, t.ev[sp.a], t.ev[sp.b]); (void)hipEventElapsedTime(&at, t.ev[t.t0], t.ev[sp.a]);
-                fprintf(stderr, "[pass log]   b%u %-6s %9u items  start %8.3f ms  %7.3f ms\n", b, sp.kind == 0 ? "extend" : (sp.kind == 1 ? "shade" : "shadow"), sp.items, at, m); } }
+                fprintf(stderr, "[pass log]   b%u %-6s %9u items  start %8.3f ms  %7.3f ms\n", b, sp.kind == 0 ? "extend" : (sp.kind == 1 ? "shade" : (sp.kind == 2 ? "shadow" : "tail")), sp.items, at, m); } }
     }
     for (uint b = 0; b < numBatches; b++) for (auto e : B[b].ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(frame0); (void)hipEventDestroy(frame1);
@@ -1686,5 +1706,6 @@ int32_t pt_get_bvh_info(pt_context* c, PtBvhInfo* out) {
 }
 int32_t pt_set_counters(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->countersEnabled = enable != 0; return PT_OK; }
 int32_t pt_set_serial_kernels(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->serialKernels = enable != 0; return PT_OK; }
+int32_t pt_set_tail_paths(pt_context* c, uint32_t maxPaths) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->tailBelow = maxPaths; return PT_OK; }
 
 } // extern "C"

@@ -30,7 +30,9 @@ __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { retur
 #define T8_POP2 0
 #endif
 #if PT_T8_LANES == 2
-template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, class Src, class Dst, class Pub>
+// DEFER (with CAN_SPLIT): a dry wave keeps going for taskOut.capacity iterations (instead of T8_TAIL_ITERS), and the rays then still in flight are not cut into sub-trees,
+// only reported through publish() — the caller has them traced again elsewhere (the tail kernel, pt_tail.hip, hands their paths back to the host loop). No task queue is touched.
+template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, bool DEFER = false, class Src, class Dst, class Pub>
 __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
                                                 Traverse8Counters& ctr, uint* overflowFlag) {
     static_assert(T8_LANES == 2u, "traverse8_pairs is the two-lanes-per-ray build");
@@ -137,7 +139,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         if (!run) { if (t8_ballot(!exhausted) == 0ull) stop = true; }
         else if (CAN_SPLIT) {
             if (waveDry) tailIters++;
-            if (tailIters > (uint)(TASKS ? T8_TAIL_ITERS_TASKS : T8_TAIL_ITERS)) { splitNow = true; stop = true; run = false; }
+            if (tailIters > (DEFER ? taskOut.capacity : (uint)(TASKS ? T8_TAIL_ITERS_TASKS : T8_TAIL_ITERS))) { splitNow = true; stop = true; run = false; }
         }
         if (run) {
 #ifdef T8_PROBE_VNOPS
@@ -332,6 +334,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
     {
         const uint nSlots = (cur != BVH_EMPTY ? 1u : 0u) + (pend != BVH_EMPTY ? 1u : 0u) + (pend1 != BVH_EMPTY ? 1u : 0u) + (pend2 != BVH_EMPTY ? 1u : 0u);
         const uint n = active ? nSlots + sp : 0u;
+        if (DEFER) { if (active && h == 0u) publish(tag, bestT, bestPrim); return; }
         uint base = 0u;
         if (h == 0u && n) base = atomicAdd(taskOut.count, n);
         base = dpp_u<DPP_PAIR_LO>(base);

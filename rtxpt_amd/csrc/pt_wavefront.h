@@ -25,6 +25,8 @@ struct WaveCounters {           // device-resident counters / stats (one 256 B b
     uint extendCount[2]; uint shadowCount; uint overflow;
     unsigned long long hits, nodeVisitsExt, triTestsExt, nodeVisitsSh, triTestsSh, leafVisitsExt, itersExt, leafVisitsSh, itersSh, phaseCycExt[4], leafBlocksExt, eventsExt[8], itersMaxExt, rayIterHistExt[16]; uint longRayCount, _padLong; float longRays[32][8];
     unsigned long long shadowValid;     // grouped shadow queue: entries that carry a light sample (= shadow rays in the reference's sense)
+    unsigned long long tailExtendRays, tailShadowRays;      // rays the tail kernel traced itself (pt_tail.hip); what it hands back is counted by the launches that trace it
+    unsigned long long tailHandedBack[3];                   // paths the tail kernel handed back: extend stragglers, visibility stragglers, still alive at the bounce bound
 };
 
 // straggler splitting (pt_traverse8.h): per pipelined batch, two task queues (ping-pong), the per-ray merge keys and the list of rays to resolve.
@@ -43,6 +45,9 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr,
                   ShadowQueue sq, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st);
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
+// the late bounces of a batch in one launch: every wave runs 32 paths of queueIn to their end (at most maxBounces bounces each); stragglers and paths beyond the bound come back through
+// queueOut / countOutPtr (and, for visibility rays, the shadow queue / wc->shadowCount). NEEFullSamples 1 only (sq.group == 0); the pass's counters zeroed by the caller as for launch_shade
+void launch_tail(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, uint maxBounces, uint deferIters /* 0: T8_TAIL_DEFER */, uint maxBlocks, hipStream_t st);
 void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st);      // one launch: the batch's PASS_COUNTERS words and the two queue counters the pass refills
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st);
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st);

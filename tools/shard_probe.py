@@ -10,9 +10,10 @@ sc["env_cube_dim"] = 2048; sc["env_compression"] = 1      # as bench.py: EnvMapB
 camd = scenes.bridge_camera(W, H, **cam)
 MAXR = int(os.environ.get("SHARD_PROBE_RANKS", "0"))          # > 0: time only this many evenly spaced ranks per world size (every rank costs a scene build)
 worlds = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]
+TAILS = [int(x) for x in os.environ.get("SHARD_PROBE_TAILS", "").split(",") if x]      # tail-kernel thresholds to A/B on one context per rank (pt_set_tail_paths); empty: the product default only
 print("shard probe: %dx%d, %d spp" % (W, H, SPP))
 base = None
-for world in worlds:
+for world in worlds if not TAILS else []:
     times, rays = [], []
     ranks = list(range(world)) if not MAXR or world <= MAXR else sorted({int(round(i * (world - 1) / (MAXR - 1))) for i in range(MAXR)}) if MAXR > 1 else [0]
     for rank in ranks:
@@ -28,3 +29,19 @@ for world in worlds:
     base = base or max(times)
     print("world %d: frame time per rank max %.1f mean %.1f min %.1f ms; rays per rank max %.1fM min %.1fM; speed-up vs 1 GPU %.2f (efficiency %.2f)" % (
         world, max(times) * 1e3, sum(times) / len(times) * 1e3, min(times) * 1e3, max(rays) / 1e6, min(rays) / 1e6, base / max(times), base / max(times) / world))
+
+for world in worlds if TAILS else []:
+    ranks = list(range(world)) if not MAXR or world <= MAXR else sorted({int(round(i * (world - 1) / (MAXR - 1))) for i in range(MAXR)}) if MAXR > 1 else [0]
+    for rank in ranks:
+        g = pt.PathTracer(device=0, shard_rank=rank, shard_count=world)
+        g.set_scene(sc); g.set_camera(camd); g.set_settings(scenes.default_settings(useFp16Types=1)); g.resize(W, H)
+        g.reset_accumulation(); g.render(0, SPP)
+        for rep in range(2):
+            for tail in TAILS:
+                g.set_tail_paths(tail); g.reset_accumulation(); g.render(0, SPP)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    g.reset_accumulation(); st = g.render(0, SPP)
+                torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 3 * 1e3
+                print("world %d rank %d tail %7d: %.2f ms per frame (gpu %.2f), %d tail launches, %d passes, %.1f Mrays" % (world, rank, tail, ms, st["gpuMilliseconds"], st["tailLaunches"], st["iterations"], (st["extendRays"] + st["shadowRays"]) / 1e6))
+        del g
