@@ -62,6 +62,9 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #ifndef PT_CLASSIFY_FROM
 #define PT_CLASSIFY_FROM 65536u     // passes with fewer paths skip k_classify (class-ordered shading pays through coherence, which a handful of waves do not have)
 #endif
+#ifndef PT_EVENT_LOOP_BELOW
+#define PT_EVENT_LOOP_BELOW 0u     // pt_render calls with fewer paths than this run their batches free (polled), larger ones in lockstep (pt_render). 0 = always lockstep: measured equal or worse at every frame size (profiles/r04i_event_loop_ab.txt)
+#endif
 #ifndef PT_TAIL_PATHS
 #define PT_TAIL_PATHS 65536u     // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never
 #endif
@@ -73,7 +76,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
-    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0;   // second half-frame batch (pt_render pipelines two batches)
+    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0, eventLoopBelow = PT_EVENT_LOOP_BELOW;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -640,6 +643,7 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     { const char* e = getenv("MI355PT_BVH_BUILDER");        // developer A/B switch
       if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; else if (e && (!strcmp(e, "ploc_opt") || !strcmp(e, "device"))) c->bvhBuilder = BVH_BUILDER_PLOC_OPT; }
     { const char* e = getenv("MI355PT_TAIL_PATHS"); if (e) c->tailBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch (pt_set_tail_paths)
+    { const char* e = getenv("MI355PT_EVENT_LOOP_BELOW"); if (e) c->eventLoopBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch
     { const char* e = getenv("MI355PT_TAIL_DEFER"); if (e) c->tailDefer = (uint)strtoul(e, nullptr, 10); }      // test switch: iterations after which the tail kernel hands a ray back (0: T8_TAIL_DEFER); a small value sends most rays through the hand-back path
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
@@ -1081,7 +1085,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
-        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false; uint bound = 0;      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
+        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false; uint bound = 0;      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; uint items; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         bool timed = false;      // per-launch HIP events: only when somebody reads them (serial-kernel steps, the pass log) — ten API calls per pass and batch otherwise
         size_t mark() { if (!timed) return 0; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
@@ -1120,24 +1124,31 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     // the tail kernel takes over a batch once it holds at most this many paths (0: never). Not in serial-kernel / counter frames (their per-kernel attribution is the point), not with
     // grouped NEE samples (NEEFullSamples > 1 folds a vertex's samples in k_resolve_nee) and not without a tree (the traversal's empty-scene path is per launch, not per wave)
     const uint tailBelow = (PT_T8_LANES == 2 && !c->serialKernels && !c->countersEnabled && !shadowGroup && c->dsc.rootIsValid) ? c->tailBelow : 0u;
+    // Lockstep or free-running batches. In lockstep (above) a batch's next half-pass is queued when ALL batches have delivered their counts: on the full frame that keeps one batch's
+    // shading next to the others' traversal (free-running streams drift into running the same kernel at the same time: 7 % slower). A small frame — one rank of a
+    // sharded frame — has passes of a few hundred microseconds whose lengths differ between the batches, and there the wait for the slowest batch is what a stream spends a fifth of
+    // the frame on (profiles/r04h_rank8_gantt.txt: 2.8 of 14 ms). Below PT_EVENT_LOOP_BELOW paths per call the host polls the streams and serves whichever is ready.
+    const bool eventLoop = numBatches > 1 && total < c->eventLoopBelow;
+    const bool passLog = getenv("MI355PT_PASS_LOG") != nullptr;
     bool any = true;
     while (any) {
         // phase 1: every live batch queues extend + shade and the read-back of its queue counts
+        uint wavefrontPasses = 0;
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b];
-            t.waiting = false;
+            if (t.waiting) continue;                        // a tail launch still in flight (below): the batch rejoins the lockstep when it is done
             if (!t.active || t.bound >= maxIter) continue;
             uint nxt = t.cur ^ 1u;
             launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch
             if (tailBelow && t.active <= tailBelow && !t.afterTail) {      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
                 size_t e0 = t.mark(); launch_tail(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, maxIter - t.bound, c->tailDefer, t.aux.maxBlocks, t.st); size_t e1 = t.mark();
                 if (t.timed) t.spans.push_back({e0, e1, 3, t.active});
-                t.tailLaunches++; t.afterTail = true;      // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
+                t.tailLaunches++; t.afterTail = true; t.inTail = true;      // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
                 PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
                 t.waiting = true;
                 continue;
             }
-            t.afterTail = false; t.bound++;
+            t.afterTail = false; t.bound++; wavefrontPasses++;
             size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
             launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
             t.extendRays += t.active;
@@ -1149,8 +1160,17 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b];
             if (!t.waiting) continue;
+            // a tail launch runs for about a millisecond — several of the other batches' passes: while those have wavefront passes to queue, it is only polled
+            if (t.inTail && wavefrontPasses && hipStreamQuery(t.st) == hipErrorNotReady) { any = true; continue; }
+            // free-running batches (small frames, see eventLoop above): whichever batch has its counts back is serviced, the others are polled again in the next sweep
+            if (eventLoop && hipStreamQuery(t.st) == hipErrorNotReady) { any = true; continue; }
             PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
+            t.waiting = false; t.inTail = false;
             uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
+            if (passLog) {      // the pass's straggler counters: sub-trees split off by k_extend and by task rounds 0..2, rays sent to the resolve pass (the previous pass's shadow launch is reported with the next line)
+                uint pc[PASS_COUNTERS]; PT_CHECK_HIP(c, hipMemcpy(pc, t.aux.counts, sizeof(pc), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[pass log]   b%u pass %u: %u paths -> extend splits %u / %u / %u / %u sub-trees, %u rays resolved; %u visibility rays next\n", b, t.iterations, t.active, pc[0], pc[1], pc[2], pc[3], pc[TRAV_RESOLVE], nShadow);
+            }
             TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
             if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
             t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;

@@ -11,7 +11,7 @@ camd = scenes.bridge_camera(W, H, **cam)
 MAXR = int(os.environ.get("SHARD_PROBE_RANKS", "0"))          # > 0: time only this many evenly spaced ranks per world size (every rank costs a scene build)
 worlds = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]
 TAILS = [int(x) for x in os.environ.get("SHARD_PROBE_TAILS", "").split(",") if x]      # tail-kernel thresholds to A/B on one context per rank (pt_set_tail_paths); empty: the product default only
-print("shard probe: %dx%d, %d spp" % (W, H, SPP))
+print("shard probe: %dx%d, %d spp, MI355PT_EVENT_LOOP_BELOW=%s" % (W, H, SPP, os.environ.get("MI355PT_EVENT_LOOP_BELOW", "default")))
 base = None
 for world in worlds if not TAILS else []:
     times, rays = [], []
