@@ -337,6 +337,11 @@ int32_t pt_set_settings(pt_context* ctx, const PtSettings* settings);           
 /* Animate + Scene::Refresh + UpdateSkinnedBLASs/BuildTLAS (Rtxpt/Sample.cpp:785-811,1170-1240): new instance transforms and/or
  * new vertex positions (same topology) -> LBVH refit (or rebuild when rebuild != 0) + emissive light re-bake. Either pointer may be NULL. */
 int32_t pt_animate(pt_context* ctx, const PtInstanceDesc* instances, uint32_t numInstances, const float* positions, uint32_t numVertices, int32_t rebuild);
+/* pt_animate for a host that knows which meshes it deformed — UpdateSkinnedBLASs walks the skinned mesh instances only (Rtxpt/Sample.cpp:1170-1198): `positions` is still the whole
+ * array, but only the vertices [first, first + count) of each (first, count) pair of vertexRanges are read and uploaded, and only the shading records of the geometries those
+ * vertices belong to are rewritten (C5: 1 of 80 geometries; the upload shrinks from 14 MB to 0.3 MB). vertexRanges == NULL: every vertex, i.e. pt_animate. */
+int32_t pt_animate_ranges(pt_context* ctx, const PtInstanceDesc* instances, uint32_t numInstances, const float* positions, uint32_t numVertices,
+                          const uint32_t* vertexRanges, uint32_t numRanges, int32_t rebuild);
 /* deformed meshes' vertex normals / tangents (Donut's skinning rewrites them with the positions, Sample.cpp:1170-1198): replaces the packed streams of pt_set_geometry (either may be NULL)
    and rewrites the shading records; the BVH does not depend on them. Resets the accumulation like pt_animate. */
 int32_t pt_animate_normals(pt_context* ctx, const uint32_t* normalsSnorm8, const uint32_t* tangentsSnorm8, uint32_t numVertices);
@@ -574,7 +579,7 @@ int32_t pt_set_counters(pt_context* ctx, int32_t enable);
 int32_t pt_set_serial_kernels(pt_context* ctx, int32_t enable);
 /* The tail kernel: once a batch of pt_render holds at most `maxPaths` live paths, ONE launch runs them to their end — every wave loops trace -> shade -> visibility ->
    next bounce over 32 paths, the shape of the reference's raygen loop (Rtxpt/Shaders/PathTracerSample.hlsl:200-250) where it fits: few paths, bound by the length of
-   the launch chain of a wavefront pass, not by throughput. 0 = never (every pass is a wavefront pass); default 65536 (environment MI355PT_TAIL_PATHS overrides it at
+   the launch chain of a wavefront pass, not by throughput. 0 = never (every pass is a wavefront pass); default 32768 (environment MI355PT_TAIL_PATHS overrides it at
    pt_create). The image does not depend on the value (paths do not interact; tests render whole frames through the tail kernel). Ignored for NEEFullSamples > 1,
    serial-kernel and counter frames. */
 int32_t pt_set_tail_paths(pt_context* ctx, uint32_t maxPaths);

@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -766,9 +766,15 @@ class PathTracer:
         self._chk(self.L.pt_get_light_feedback(self.h, int(sample), _p(w), _p(c)), "pt_get_light_feedback")
         return w, c
 
-    def animate(self, instances=None, positions=None, rebuild=False):
-        self._chk(self.L.pt_animate(self.h, _p(instances), 0 if instances is None else len(instances), _p(positions), 0 if positions is None else positions.shape[0],
-                                    1 if rebuild else 0), "pt_animate")
+    def animate(self, instances=None, positions=None, rebuild=False, vertex_ranges=None):
+        """pt_animate; vertex_ranges = [(first, count), ...]: pt_animate_ranges — only those vertices of `positions` moved"""
+        if vertex_ranges is None:
+            self._chk(self.L.pt_animate(self.h, _p(instances), 0 if instances is None else len(instances), _p(positions), 0 if positions is None else positions.shape[0],
+                                        1 if rebuild else 0), "pt_animate")
+            return
+        f = self.L.pt_animate_ranges; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32]; f.restype = ctypes.c_int32
+        r = np.ascontiguousarray(np.asarray(vertex_ranges, np.uint32).reshape(-1, 2))
+        self._chk(f(self.h, _p(instances), 0 if instances is None else len(instances), _p(positions), 0 if positions is None else positions.shape[0], _p(r), len(r), 1 if rebuild else 0), "pt_animate_ranges")
 
     def animate_normals(self, normals=None, tangents=None):
         """pt_animate_normals: the deformed meshes' packed vertex normals / tangents (uint32 per vertex, SNORM8) — with pt_animate(positions) a skinned frame is complete"""

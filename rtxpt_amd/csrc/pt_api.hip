@@ -15,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 
 using namespace ptk;
 
@@ -66,7 +67,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #define PT_EVENT_LOOP_BELOW 0u     // pt_render calls with fewer paths than this run their batches free (polled), larger ones in lockstep (pt_render). 0 = always lockstep: measured equal or worse at every frame size (profiles/r04i_event_loop_ab.txt)
 #endif
 #ifndef PT_TAIL_PATHS
-#define PT_TAIL_PATHS 65536u     // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never
+#define PT_TAIL_PATHS 32768u     // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never
 #endif
 #ifndef PT_PIPELINE_BATCHES
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
@@ -85,7 +86,7 @@ struct pt_context {
     float3x4 envToWorld, envToLocal; ptk::float3 envColorMul;
     uint envCubeDim = 2048; std::vector<ptk::EnvDirectionalLight> envDirLights; bool envCubeDirty = true; ptk::EnvCube envCube;      // EnvMapBaker state (pt_set_environment_bake)
     std::vector<PolymorphicLightInfoFull> analyticLights;
-    std::vector<SubInstanceData> subInstances; std::vector<ptk::uint2> subInstToInstGeom; std::vector<ptk::uint2> primInfo;
+    std::vector<SubInstanceData> subInstances; std::vector<ptk::uint2> subInstToInstGeom; std::vector<ptk::uint2> primInfo; std::vector<uint> subInstFirstPrim;
     std::vector<ptk::PolymorphicLightInfo> lights; std::vector<ptk::PolymorphicLightInfoEx> lightsEx; std::vector<uint> envLookup; uint envLookupDim = 0; uint numProxies = 0, envLightsBaked = 0;      // (light weights / proxy table live on the device only)
     DevBuf<float> dLightW; DevBuf<uint> dProxyOffsets; void* dScanTemp = nullptr; size_t scanTempBytes = 0;
     // device
@@ -266,7 +267,7 @@ void refresh_scene_view(pt_context* c) {
 
 // SubInstanceData fill (Rtxpt/Materials/MaterialsBaker.cpp:960-1017) + primitive table; then GPU LBVH build
 int finalize_geometry(pt_context* c) {
-    c->subInstances.clear(); c->subInstToInstGeom.clear(); c->primInfo.clear();
+    c->subInstances.clear(); c->subInstToInstGeom.clear(); c->primInfo.clear(); c->subInstFirstPrim.clear();
     for (size_t i = 0; i < c->instances.size(); i++) {
         if (c->instances[i].meshIndex >= c->meshes.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "instance references a missing mesh");
         const MeshDesc& m = c->meshes[c->instances[i].meshIndex];
@@ -290,7 +291,7 @@ int finalize_geometry(pt_context* c) {
             si.IndexOffset = gd.indexOffset; si.TexCoord1Offset = gd.vertexOffset;
             uint subInst = (uint)c->subInstances.size();
             c->subInstToInstGeom.push_back(ptk::make_uint2((uint)i, gi));
-            c->subInstances.push_back(si);
+            c->subInstances.push_back(si); c->subInstFirstPrim.push_back((uint)c->primInfo.size());
             for (uint t = 0; t < gd.numIndices / 3; t++) c->primInfo.push_back(ptk::make_uint2(subInst, t));
         }
     }
@@ -314,7 +315,7 @@ int finalize_geometry(pt_context* c) {
     PT_CHECK_HIP(c, hipEventRecord(e0, st));
     PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, st));
     PT_CHECK_HIP(c, hipEventRecord(e1, st));
-    launch_shade_tris(c->dsc, c->numTris, c->dShadeTris.p, st);
+    launch_shade_tris(c->dsc, 0u, c->numTris, c->dShadeTris.p, st);
     PT_CHECK_HIP(c, hipStreamSynchronize(st));
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); c->buildMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     c->geomDirty = false; c->lightsDirty = true;
@@ -980,10 +981,14 @@ int32_t pt_reset_accumulation(pt_context* c) {
     PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)c->width * c->height, c->stream));
     return PT_OK;
 }
-int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts, int32_t rebuild) {
+int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts, int32_t rebuild) { return pt_animate_ranges(c, inst, nInst, positions, nVerts, nullptr, 0u, rebuild); }
+int32_t pt_animate_ranges(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts, const uint32_t* vertexRanges, uint32_t nRanges, int32_t rebuild) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
     if (c->geomDirty || c->texDirty) { int r = prepare(c); if (r != PT_OK) return r; }
+    static const bool animLog = getenv("MI355PT_ANIMATE_LOG") != nullptr;      // developer probe: host-side time of every step of the call (stderr)
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tA = now(); double tB = tA, tC = tA, tD = tA, tE = tA;
     if (inst) {
         if (nInst != c->instances.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: instance count must not change");
         for (uint32_t i = 0; i < nInst; i++) if (inst[i].meshIndex != c->instances[i].meshIndex) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: topology must not change");
@@ -992,11 +997,30 @@ int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, co
     }
     if (positions) {
         if ((size_t)nVerts * 3 != c->positions.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: vertex count must not change");
-        memcpy(c->positions.data(), positions, 12 * (size_t)nVerts);
-        PT_CHECK_HIP(c, c->dPositions.upload(c->positions, c->stream));
+        if (vertexRanges) {
+            for (uint32_t r = 0; r < nRanges; r++) if ((unsigned long long)vertexRanges[2 * r] + vertexRanges[2 * r + 1] > nVerts) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate_ranges: vertex range beyond the vertex count");
+            for (uint32_t r = 0; r < nRanges; r++) {
+                const size_t first = 3 * (size_t)vertexRanges[2 * r], count = 3 * (size_t)vertexRanges[2 * r + 1];
+                if (!count) continue;
+                memcpy(c->positions.data() + first, positions + first, 4 * count);
+                PT_CHECK_HIP(c, hipMemcpyAsync(c->dPositions.p + first, c->positions.data() + first, 4 * count, hipMemcpyHostToDevice, c->stream));
+            }
+        } else {
+            memcpy(c->positions.data(), positions, 12 * (size_t)nVerts);
+            PT_CHECK_HIP(c, c->dPositions.upload(c->positions, c->stream));
+        }
     }
+    tB = now();
     refresh_scene_view(c);
-    if (positions) launch_shade_tris(c->dsc, c->numTris, c->dShadeTris.p, c->stream);      // the shading records hold object-space vertices: deformed meshes rewrite them, rigid motion does not
+    if (positions) {      // the shading records hold object-space vertices: deformed meshes rewrite them, rigid motion does not
+        if (!vertexRanges) launch_shade_tris(c->dsc, 0u, c->numTris, c->dShadeTris.p, c->stream);
+        else for (size_t s = 0; s < c->subInstToInstGeom.size(); s++) {      // sub-instances (= primitive ranges) of the geometries that hold a moved vertex
+            const GeometryDesc& gd = c->geometries[c->subInstToInstGeom[s].y];
+            bool touched = false;
+            for (uint32_t r = 0; r < nRanges && !touched; r++) touched = vertexRanges[2 * r + 1] && vertexRanges[2 * r] < gd.vertexOffset + gd.numVertices && gd.vertexOffset < vertexRanges[2 * r] + vertexRanges[2 * r + 1];
+            if (touched) launch_shade_tris(c->dsc, c->subInstFirstPrim[s], gd.numIndices / 3u, c->dShadeTris.p, c->stream);
+        }
+    }
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
     if (rebuild) {                                     // a rebuild between animated frames prefers a fast build: PLOC on the device (15 ms at 2.8 M triangles)
@@ -1004,13 +1028,18 @@ int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, co
         PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, c->stream));
     } else PT_CHECK_HIP(c, bvh_refit(c->bvh, c->dsc, c->numTris, c->stream));
     PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
+    tC = now();
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    tD = now();
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); if (rebuild) c->buildMs = ms; else c->refitMs = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     const bool lightsWereDirty = c->lightsDirty;      // something besides the geometry changed since the last bake (environment, analytic lights, NEE settings)
     c->lightsDirty = true;                    // emissive triangle lights move with the geometry (Sample.cpp:1170-1198)
     c->accumCount = 0;                        // any scene change resets accumulation in reference mode
     PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)c->width * c->height, c->stream));
-    return bake_lights(c, !lightsWereDirty);     // geometry moved, nothing else: environment lights kept, emissive re-bake + weights + proxy table on the device
+    const int32_t rb = bake_lights(c, !lightsWereDirty);     // geometry moved, nothing else: environment lights kept, emissive re-bake + weights + proxy table on the device
+    tE = now();
+    if (animLog) fprintf(stderr, "[animate] copy + upload %.3f ms, launches %.3f ms, wait %.3f ms (refit %.3f ms on the device), light re-bake %.3f ms: %.3f ms\n", tB - tA, tC - tB, tD - tC, ms, tE - tD, tE - tA);
+    return rb;
 }
 
 int32_t pt_animate_normals(pt_context* c, const uint32_t* normals, const uint32_t* tangents, uint32_t nVerts) {
@@ -1021,7 +1050,7 @@ int32_t pt_animate_normals(pt_context* c, const uint32_t* normals, const uint32_
     if (normals) { memcpy(c->normals.data(), normals, 4 * (size_t)nVerts); PT_CHECK_HIP(c, c->dNormals.upload(c->normals, c->stream)); }
     if (tangents) { memcpy(c->tangents.data(), tangents, 4 * (size_t)nVerts); PT_CHECK_HIP(c, c->dTangents.upload(c->tangents, c->stream)); }
     refresh_scene_view(c);
-    launch_shade_tris(c->dsc, c->numTris, c->dShadeTris.p, c->stream);      // the shading records hold the packed vertex normals and tangents
+    launch_shade_tris(c->dsc, 0u, c->numTris, c->dShadeTris.p, c->stream);      // the shading records hold the packed vertex normals and tangents
     c->accumCount = 0;
     PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)c->width * c->height, c->stream));
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));

@@ -20,7 +20,11 @@
 //   k_emit          collapse sub-trees of <= 4 triangles into leaves and write BVH2 nodes (both child boxes per node)
 //   k_alpha_records per leaf-order triangle: texture coordinates + alpha texture + cutoff for the traversal's alpha test
 //   k_collapse8     level by level: greedily open the largest-area inner child until 8 children -> quantised 128 B BVH8 nodes
-// Refit (animated instances / deformed vertices, same topology) re-runs k_tri_setup, k_bounds, k_emit only.
+// Refit (animated instances / deformed vertices, same topology), round 4: k_refit_world (leaf-order triangles straight from a flat source record: instance, three global
+//   vertex indices — one hop instead of five; scene bounds reduced per 1024-thread block before the six atomics) and k_refit8_level, bottom-up over the levels of the WIDE
+//   tree: a wide node's children keep their slots, their boxes are the padded unions of what lies below — triangles of a leaf child, the stored un-padded box of an inner
+//   child — quantised by the expression the collapse uses (bvh8_pack). min / max are exact, so the nodes are the bytes a fresh bounds + emit + collapse over the same
+//   topology writes, without the 21-level sparse table, the BVH2 nodes and the level-by-level host round trips of the collapse: 5.2 -> 0.5 ms at 2.8 M triangles.
 #pragma once
 #include "pt_scene.h"
 #include <hip/hip_runtime.h>
@@ -28,6 +32,9 @@
 namespace ptk {
 
 enum : uint { BVH_BUILDER_PLOC = 0, BVH_BUILDER_KARRAS = 1, BVH_BUILDER_SAH = 2, BVH_BUILDER_PLOC_OPT = 3 };      // SAH: topology by pt_build_sah.cpp on the host; PLOC_OPT: PLOC + re-insertion passes + cost-driven wide nodes, all on the device (both "prefer fast trace")
+
+struct TriSrc { uint instance, i0, i1, i2, prim, flags, _pad0, _pad1; };      // leaf order: what k_tri_setup gathers through primInfo -> subInstToInstGeom -> {instance, geometry, sub-instance} -> indices, resolved once per build
+static const uint BVH_MAX_WIDE_LEVELS = 64;
 
 struct BvhBuildBuffers {
     TriRecord* triWorld;        // by global primitive id
@@ -43,6 +50,9 @@ struct BvhBuildBuffers {
     float4* rangeMin; float4* rangeMax; uint rangeLevels;   // sparse table over the leaf-order triangle boxes: level k, entry i = bounds of leaves [i, i + 2^k)
     uint* primToSlot;           // global primitive id -> leaf-order slot (k_resolve_extend looks the winning triangle up by primitive)
     Bvh8Node* nodes8; uint* levelA; uint* levelB; uint* wideCounter; uint numNodes8, collapseLevels;
+    TriSrc* triSrc;             // leaf order (refit)
+    float4* wideBoxMin; float4* wideBoxMax;      // per wide node: the un-padded box of everything below it (refit: an inner child's box in its parent)
+    uint wideLevelStart[BVH_MAX_WIDE_LEVELS + 1]; uint wideRefitReady;      // wide nodes of collapse level L are [wideLevelStart[L], wideLevelStart[L + 1]): children always lie in a deeper level
     void* sortTemp; size_t sortTempBytes;
     // PLOC work arrays (node ids while building: leaves 0..n-1 in Morton order, inner nodes n..2n-2 in creation order)
     uint* plocCl[2]; uint* plocNN; unsigned long long* plocFlags; unsigned long long* plocOffs; uint* plocChildA; uint* plocChildB; uint* plocCnt; uint* plocParent; uint* plocFirst; uint* plocCounts;
@@ -62,8 +72,8 @@ hipError_t bvh_alloc(BvhBuildBuffers& b, uint numTris);
 void bvh_free(BvhBuildBuffers& b);
 // full build: fills b.triSorted / b.nodes; scene must already reference primInfo/instances/geometries/streams
 hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint numTris, hipStream_t stream);
-// flat per-primitive shading records (pt_scene.h ShadeTri); rebuilt when the geometry is (re)set or its vertices are deformed
-void launch_shade_tris(const DeviceScene& sc, uint numTris, ShadeTri* out, hipStream_t stream);
+// flat per-primitive shading records (pt_scene.h ShadeTri) of primitives [firstPrim, firstPrim + numTris); rebuilt when the geometry is (re)set or its vertices are deformed
+void launch_shade_tris(const DeviceScene& sc, uint firstPrim, uint numTris, ShadeTri* out, hipStream_t stream);
 hipError_t bvh_refit(BvhBuildBuffers& b, const DeviceScene& sc, uint numTris, hipStream_t stream);
 
 } // namespace ptk

@@ -4,6 +4,7 @@
 #include "pt_build_wide.h"
 #include "pt_build_reinsert.h"
 #include <chrono>
+#include <cstdlib>
 #include <vector>
 #include <rocprim/rocprim.hpp>
 
@@ -24,6 +25,20 @@ __device__ __forceinline__ float dec_float(uint u) { uint b = (u & 0x80000000u) 
 __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
 
+// scene bounds: the waves of a block meet in LDS, six atomics per BLOCK (one per wave and word were 264 k same-address atomics per word at 2.8 M triangles — they serialise
+// in the L2 at ~10^8 per second and address: 3 ms of a 5 ms refit, the pattern k_shade had in round 3)
+__device__ __forceinline__ void block_bounds(float3 mn, float3 mx, uint* __restrict__ sceneBounds) {
+    __shared__ float red[16][6];
+    const uint wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, waves = (blockDim.x + 63u) >> 6;
+    float a = wave_min(mn.x), b = wave_min(mn.y), c = wave_min(mn.z), d = wave_max(mx.x), e = wave_max(mx.y), f = wave_max(mx.z);
+    if (lane == 0u) { red[wave][0] = a; red[wave][1] = b; red[wave][2] = c; red[wave][3] = d; red[wave][4] = e; red[wave][5] = f; }
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        float v = red[0][threadIdx.x];
+        for (uint w = 1; w < waves; w++) v = threadIdx.x < 3u ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3u) atomicMin(&sceneBounds[threadIdx.x], enc_float(v)); else atomicMax(&sceneBounds[threadIdx.x], enc_float(v));
+    }
+}
 __global__ void __launch_bounds__(256) k_tri_setup(DeviceScene sc, uint numTris, TriRecord* __restrict__ triWorld, uint* __restrict__ sceneBounds) {
     uint p = blockIdx.x * 256u + threadIdx.x;
     float3 mn = make_float3(3.0e38f), mx = make_float3(-3.0e38f);
@@ -47,11 +62,36 @@ __global__ void __launch_bounds__(256) k_tri_setup(DeviceScene sc, uint numTris,
         float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
         mn = min3v(p0, min3v(q1, q2)); mx = max3v(p0, max3v(q1, q2));
     }
-    float a = wave_min(mn.x), b = wave_min(mn.y), c = wave_min(mn.z), d = wave_max(mx.x), e = wave_max(mx.y), f = wave_max(mx.z);
-    if ((threadIdx.x & 63u) == 0u) {
-        atomicMin(&sceneBounds[0], enc_float(a)); atomicMin(&sceneBounds[1], enc_float(b)); atomicMin(&sceneBounds[2], enc_float(c));
-        atomicMax(&sceneBounds[3], enc_float(d)); atomicMax(&sceneBounds[4], enc_float(e)); atomicMax(&sceneBounds[5], enc_float(f));
+    block_bounds(mn, mx, sceneBounds);
+}
+// ---- refit (pt_build.h): the flat source records, made once per build in leaf order ...
+__global__ void __launch_bounds__(256) k_tri_src(DeviceScene sc, const TriRecord* __restrict__ triSorted, uint n, TriSrc* __restrict__ out) {
+    uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint p = triSorted[i].prim;
+    const uint2 pi = sc.primInfo[p], ig = sc.subInstToInstGeom[pi.x];
+    const GeometryDesc& g = sc.geometries[ig.y];
+    const uint* idx = sc.indices + g.indexOffset + 3u * pi.y;
+    TriSrc r; r.instance = ig.x; r.i0 = g.vertexOffset + idx[0]; r.i1 = g.vertexOffset + idx[1]; r.i2 = g.vertexOffset + idx[2]; r.prim = p; r.flags = triSorted[i].flags; r._pad0 = r._pad1 = 0u;
+    out[i] = r;
+}
+// ... and the world-space triangles of a refit straight from them, in leaf order (the arithmetic of k_tri_setup; the pad follows in k_refit8_level, once the scene bounds are known)
+__global__ void __launch_bounds__(1024) k_refit_world(DeviceScene sc, const TriSrc* __restrict__ src, uint n, TriRecord* __restrict__ triSorted, uint* __restrict__ sceneBounds) {
+    uint i = blockIdx.x * 1024u + threadIdx.x;
+    float3 mn = make_float3(3.0e38f), mx = make_float3(-3.0e38f);
+    if (i < n) {
+        const uint4 a = reinterpret_cast<const uint4*>(src)[2 * (size_t)i], b = reinterpret_cast<const uint4*>(src)[2 * (size_t)i + 1];      // instance i0 i1 i2 | prim flags
+        const InstanceDesc& inst = sc.instances[a.x];
+        const float* P = sc.positions;
+        float3 p0 = xform_point(inst.transform, make_float3(P[3 * a.y], P[3 * a.y + 1], P[3 * a.y + 2]));
+        float3 p1 = xform_point(inst.transform, make_float3(P[3 * a.z], P[3 * a.z + 1], P[3 * a.z + 2]));
+        float3 p2 = xform_point(inst.transform, make_float3(P[3 * a.w], P[3 * a.w + 1], P[3 * a.w + 2]));
+        TriRecord tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.prim = b.x; tr.flags = b.y; tr.pad = 0.f;
+        triSorted[i] = tr;
+        float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
+        mn = min3v(p0, min3v(q1, q2)); mx = max3v(p0, max3v(q1, q2));
     }
+    block_bounds(mn, mx, sceneBounds);
 }
 
 __device__ __forceinline__ unsigned long long expand21(uint v) {
@@ -346,6 +386,40 @@ __device__ __forceinline__ uint pow2_exp_ge(float s) {          // biased expone
     return eb;
 }
 __device__ __forceinline__ float q_decode(float o, uint q, float s) { return fmaf((float)q, s, o); }   // identical expression in traversal (v_pk_fma_f32)
+// header and quantised child bounds of a wide node from its n child boxes (the references are the caller's): origin = the union's minimum, per-axis power-of-two scales so
+// that code 255 reaches the maximum, child codes rounded outwards and checked with the traversal's own decode expression
+__device__ __forceinline__ void bvh8_scales(float3 mn, float3 mx, uint& ex, uint& ey, uint& ez) {
+    ex = pow2_exp_ge((mx.x - mn.x) / 255.0f); ey = pow2_exp_ge((mx.y - mn.y) / 255.0f); ez = pow2_exp_ge((mx.z - mn.z) / 255.0f);
+    // make sure code 255 reaches the node maximum under the decode arithmetic
+    while (q_decode(mn.x, 255u, __uint_as_float(ex << 23)) < mx.x && ex < 254u) ex++;
+    while (q_decode(mn.y, 255u, __uint_as_float(ey << 23)) < mx.y && ey < 254u) ey++;
+    while (q_decode(mn.z, 255u, __uint_as_float(ez << 23)) < mx.z && ez < 254u) ez++;
+}
+__device__ __forceinline__ void bvh8_child_codes(float3 cmn, float3 cmx, float3 org, float sx, float sy, float sz, uint& q0, uint& q1) {
+    float lo[3] = {cmn.x, cmn.y, cmn.z}, hi[3] = {cmx.x, cmx.y, cmx.z}, o[3] = {org.x, org.y, org.z}, sc3[3] = {sx, sy, sz};
+    uint ql[3], qh[3];
+    for (int a = 0; a < 3; a++) {
+        float fl = floorf((lo[a] - o[a]) / sc3[a]); fl = fminf(fmaxf(fl, 0.f), 255.f); uint q = (uint)fl;
+        while (q > 0u && q_decode(o[a], q, sc3[a]) > lo[a]) q--;
+        ql[a] = q;
+        float fh = ceilf((hi[a] - o[a]) / sc3[a]); fh = fminf(fmaxf(fh, 0.f), 255.f); q = (uint)fh;
+        while (q < 255u && q_decode(o[a], q, sc3[a]) < hi[a]) q++;
+        qh[a] = q;
+    }
+    q0 = ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24); q1 = qh[1] | (qh[2] << 8);
+}
+__device__ __forceinline__ void bvh8_pack(Bvh8Node& out, const float3* cmn, const float3* cmx, uint n) {
+    float3 mn = cmn[0], mx = cmx[0];
+    for (uint k = 1; k < n; k++) { mn = min3v(mn, cmn[k]); mx = max3v(mx, cmx[k]); }
+    uint ex, ey, ez; bvh8_scales(mn, mx, ex, ey, ez);
+    float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23), sz = __uint_as_float(ez << 23);
+    out.ox = mn.x; out.oy = mn.y; out.oz = mn.z; out.exps = ex | (ey << 8) | (ez << 16) | (n << 24);
+    out._pad[0] = __float_as_uint(sx); out._pad[1] = __float_as_uint(sy); out._pad[2] = __float_as_uint(sz); out._pad[3] = 0;      // the scales again, as floats (traversal reads these; exps stays for tools)
+    for (uint k = 0; k < 8u; k++) {
+        if (k >= n) { out.c[k].ref = BVH_EMPTY; out.c[k].q0 = 0x00FFFFFFu; out.c[k].q1 = 0u; continue; }     // inverted box
+        bvh8_child_codes(cmn[k], cmx[k], mn, sx, sy, sz, out.c[k].q0, out.c[k].q1);
+    }
+}
 __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ nodes2, const uint* __restrict__ levelIn, uint nIn, uint* __restrict__ levelOut,
                                                    uint* __restrict__ counter, Bvh8Node* __restrict__ nodes8, uint costDriven) {
     uint i = blockIdx.x * 128u + threadIdx.x;
@@ -367,39 +441,58 @@ __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ n
         cmn[n] = nd.rmin; cmx[n] = nd.rmax; cref[n] = nd.right; if (nd._pad0 & 2u) openMask |= 1u << n;
         n++;
     }
-    float3 mn = cmn[0], mx = cmx[0];
-    for (uint k = 1; k < n; k++) { mn = min3v(mn, cmn[k]); mx = max3v(mx, cmx[k]); }
-    uint ex = pow2_exp_ge((mx.x - mn.x) / 255.0f), ey = pow2_exp_ge((mx.y - mn.y) / 255.0f), ez = pow2_exp_ge((mx.z - mn.z) / 255.0f);
-    // make sure code 255 reaches the node maximum under the decode arithmetic
-    while (q_decode(mn.x, 255u, __uint_as_float(ex << 23)) < mx.x && ex < 254u) ex++;
-    while (q_decode(mn.y, 255u, __uint_as_float(ey << 23)) < mx.y && ey < 254u) ey++;
-    while (q_decode(mn.z, 255u, __uint_as_float(ez << 23)) < mx.z && ez < 254u) ez++;
-    float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23), sz = __uint_as_float(ez << 23);
     uint nInner = 0;
     for (uint k = 0; k < n; k++) if (!(cref[k] & BVH_LEAF_BIT)) nInner++;
     uint wbase = 0, obase = 0;
     if (nInner) { wbase = atomicAdd(&counter[0], nInner); obase = atomicAdd(&counter[1], nInner); }
-    Bvh8Node out;
-    out.ox = mn.x; out.oy = mn.y; out.oz = mn.z; out.exps = ex | (ey << 8) | (ez << 16) | (n << 24);
-    out._pad[0] = __float_as_uint(sx); out._pad[1] = __float_as_uint(sy); out._pad[2] = __float_as_uint(sz); out._pad[3] = 0;      // the scales again, as floats (traversal reads these; exps stays for tools)
+    Bvh8Node out; bvh8_pack(out, cmn, cmx, n);
     uint inner = 0;
     for (uint k = 0; k < 8u; k++) {
-        if (k >= n) { out.c[k].ref = BVH_EMPTY; out.c[k].q0 = 0x00FFFFFFu; out.c[k].q1 = 0u; continue; }     // inverted box
-        float lo[3] = {cmn[k].x, cmn[k].y, cmn[k].z}, hi[3] = {cmx[k].x, cmx[k].y, cmx[k].z}, o[3] = {mn.x, mn.y, mn.z}, sc3[3] = {sx, sy, sz};
-        uint ql[3], qh[3];
-        for (int a = 0; a < 3; a++) {
-            float fl = floorf((lo[a] - o[a]) / sc3[a]); fl = fminf(fmaxf(fl, 0.f), 255.f); uint q = (uint)fl;
-            while (q > 0u && q_decode(o[a], q, sc3[a]) > lo[a]) q--;
-            ql[a] = q;
-            float fh = ceilf((hi[a] - o[a]) / sc3[a]); fh = fminf(fmaxf(fh, 0.f), 255.f); q = (uint)fh;
-            while (q < 255u && q_decode(o[a], q, sc3[a]) < hi[a]) q++;
-            qh[a] = q;
-        }
-        out.c[k].q0 = ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24); out.c[k].q1 = qh[1] | (qh[2] << 8);
+        if (k >= n) { out.c[k].ref = BVH_EMPTY; continue; }
         if (cref[k] & BVH_LEAF_BIT) out.c[k].ref = cref[k];
         else { out.c[k].ref = wbase + inner; levelOut[2 * (obase + inner)] = wbase + inner; levelOut[2 * (obase + inner) + 1] = cref[k]; inner++; }
     }
     nodes8[wide] = out;
+}
+// refit of one level of the wide tree (pt_build.h): EIGHT lanes per wide node, one per child slot — the node is one coalesced 128-byte read, every lane forms its child's
+// box (the triangles of a leaf child, the stored un-padded box of an inner child), the node's boxes meet over the eight lanes (xor-shuffles: min / max are exact in any
+// order), every lane quantises and stores its own 12-byte slot. The child slots and references stay as the collapse left them.
+__device__ __forceinline__ float grp8_min(float v) { v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2)); return fminf(v, __shfl_xor(v, 4)); }
+__device__ __forceinline__ float grp8_max(float v) { v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); return fmaxf(v, __shfl_xor(v, 4)); }
+__global__ void __launch_bounds__(256) k_refit8_level(uint first, uint count, Bvh8Node* __restrict__ nodes8, TriRecord* __restrict__ tris, float4* __restrict__ boxMin, float4* __restrict__ boxMax,
+                                                      const uint* __restrict__ sceneBounds) {
+    const uint gi = blockIdx.x * 256u + threadIdx.x, i = gi >> 3, k = gi & 7u;
+    if (i >= count) return;                                 // (whole groups of eight leave together)
+    const uint w = first + i;
+    const float scenePad = scene_pad_of(sceneBounds);
+    uint* nd = reinterpret_cast<uint*>(nodes8 + w);
+    const uint n = nd[3] >> 24, r = nd[4u + 3u * k];
+    const bool valid = k < n;
+    float3 mn = make_float3(3.0e38f), mx = make_float3(-3.0e38f);
+    if (valid) {
+        if (r & BVH_LEAF_BIT) {
+            const uint slot0 = (r & 0x7FFFFFFFu) >> 3, cnt = (r & 7u) + 1u;
+            for (uint j = 0; j < cnt; j++) {
+                const float4* tp = reinterpret_cast<const float4*>(tris + slot0 + j);
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                const float3 v0 = make_float3(ta.x, ta.y, ta.z), q1 = v0 + make_float3(tb.x, tb.y, tb.z), q2 = v0 + make_float3(tc.x, tc.y, tc.z);
+                const float3 tmn = min3v(v0, min3v(q1, q2)), tmx = max3v(v0, max3v(q1, q2));
+                tris[slot0 + j].pad = tri_pad(tmn, tmx, scenePad);      // the triangle's own padded box: innermost box of the hit definition (k_leaf_boxes)
+                mn = min3v(mn, tmn); mx = max3v(mx, tmx);
+            }
+        } else { const float4 a = boxMin[r], b = boxMax[r]; mn = make_float3(a.x, a.y, a.z); mx = make_float3(b.x, b.y, b.z); }
+    }
+    const float3 umn = make_float3(grp8_min(mn.x), grp8_min(mn.y), grp8_min(mn.z)), umx = make_float3(grp8_max(mx.x), grp8_max(mx.y), grp8_max(mx.z));
+    if (k == 0u) { boxMin[w] = make_float4(umn.x, umn.y, umn.z, 0.f); boxMax[w] = make_float4(umx.x, umx.y, umx.z, 0.f); }
+    if (valid) pad_box(mn, mx, scenePad);
+    const float3 nmn = make_float3(grp8_min(mn.x), grp8_min(mn.y), grp8_min(mn.z)), nmx = make_float3(grp8_max(mx.x), grp8_max(mx.y), grp8_max(mx.z));
+    uint ex, ey, ez; bvh8_scales(nmn, nmx, ex, ey, ez);
+    const float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23), sz = __uint_as_float(ez << 23);
+    uint q0 = 0x00FFFFFFu, q1 = 0u;                         // an empty slot: inverted box
+    if (valid) bvh8_child_codes(mn, mx, nmn, sx, sy, sz, q0, q1);
+    nd[4u + 3u * k] = valid ? r : BVH_EMPTY; nd[5u + 3u * k] = q0; nd[6u + 3u * k] = q1;
+    if (k == 0u) { nd[0] = __float_as_uint(nmn.x); nd[1] = __float_as_uint(nmn.y); nd[2] = __float_as_uint(nmn.z); nd[3] = ex | (ey << 8) | (ez << 16) | (n << 24); }
+    if (k == 1u) { nd[28] = __float_as_uint(sx); nd[29] = __float_as_uint(sy); nd[30] = __float_as_uint(sz); nd[31] = 0u; }
 }
 
 // AlphaTestImpl's inputs (BridgeDonut:929-971) gathered once per triangle instead of once per candidate hit
@@ -423,9 +516,10 @@ __global__ void __launch_bounds__(256) k_alpha_records(DeviceScene sc, const Tri
 }
 
 // the flat shading records (pt_scene.h ShadeTri): one thread per global primitive walks the chain loadSurface used to walk per hit
-__global__ void __launch_bounds__(256) k_shade_tris(DeviceScene sc, uint numTris, ShadeTri* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_shade_tris(DeviceScene sc, uint firstPrim, uint numTris, ShadeTri* __restrict__ out) {
     uint p = blockIdx.x * 256u + threadIdx.x;
     if (p >= numTris) return;
+    p += firstPrim;
     const uint2 pi = sc.primInfo[p];
     const uint2 ig = sc.subInstToInstGeom[pi.x];
     const GeometryDesc& g = sc.geometries[ig.y];
@@ -442,8 +536,8 @@ __global__ void __launch_bounds__(256) k_shade_tris(DeviceScene sc, uint numTris
     uint4* o = reinterpret_cast<uint4*>(out + p); const uint4* src = reinterpret_cast<const uint4*>(&r);
     for (int k = 0; k < 8; k++) o[k] = src[k];
 }
-void launch_shade_tris(const DeviceScene& sc, uint numTris, ShadeTri* out, hipStream_t st) {
-    if (numTris) hipLaunchKernelGGL(k_shade_tris, dim3((numTris + 255u) / 256u), dim3(256), 0, st, sc, numTris, out);
+void launch_shade_tris(const DeviceScene& sc, uint firstPrim, uint numTris, ShadeTri* out, hipStream_t st) {
+    if (numTris) hipLaunchKernelGGL(k_shade_tris, dim3((numTris + 255u) / 256u), dim3(256), 0, st, sc, firstPrim, numTris, out);
 }
 
 // ---- cost-driven wide-node assignment on the device (pt_build_wide.h): the inner nodes above the wide tree's leaves are numbered breadth first (one launch per level,
@@ -531,6 +625,7 @@ static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris) {
     PT_HIP_TRY(hipMalloc(&b.boxLmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxLmax, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.boxRmax, 16 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.sceneBounds, 32)); PT_HIP_TRY(hipMalloc(&b.nodes, sizeof(BvhNode) * (size_t)n));
     if (n <= PT_RANGE_TABLE_MAX_TRIS) { b.rangeLevels = 32u - (uint)__builtin_clz(n); PT_HIP_TRY(hipMalloc(&b.rangeMin, 16 * (size_t)n * b.rangeLevels)); PT_HIP_TRY(hipMalloc(&b.rangeMax, 16 * (size_t)n * b.rangeLevels)); }
+    PT_HIP_TRY(hipMalloc(&b.triSrc, sizeof(TriSrc) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.wideBoxMin, 16 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.wideBoxMax, 16 * (size_t)n));
     PT_HIP_TRY(hipMalloc(&b.alphaRecs, sizeof(AlphaRec) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.primToSlot, 4 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.nodes8, sizeof(Bvh8Node) * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelA, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.levelB, 8 * (size_t)n)); PT_HIP_TRY(hipMalloc(&b.wideCounter, 16));
     size_t tmp = 0;
     PT_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, b.keys, b.keysSorted, b.prims, b.primsSorted, (size_t)n, 0, 64));
@@ -550,9 +645,16 @@ static hipError_t bvh_alloc_all(BvhBuildBuffers& b, uint numTris) {
 void bvh_free(BvhBuildBuffers& b) {
     void* ps[] = {b.triWorld, b.triSorted, b.keys, b.keysSorted, b.prims, b.primsSorted, b.childL, b.childR, b.parent, b.leafParent, b.rangeFirst, b.rangeLast, b.tickets,
                   b.boxLmin, b.boxLmax, b.boxRmin, b.boxRmax, b.sceneBounds, b.nodes, b.sortTemp, b.nodes8, b.levelA, b.levelB, b.wideCounter, b.alphaRecs, b.primToSlot, b.rangeMin, b.rangeMax,
-                  b.plocCl[0], b.plocCl[1], b.plocNN, b.plocFlags, b.plocOffs, b.plocChildA, b.plocChildB, b.plocCnt, b.plocParent, b.plocFirst, b.plocCounts, b.scanTemp, b.absorb, b.riScratch};
+                  b.plocCl[0], b.plocCl[1], b.plocNN, b.plocFlags, b.plocOffs, b.plocChildA, b.plocChildB, b.plocCnt, b.plocParent, b.plocFirst, b.plocCounts, b.scanTemp, b.absorb, b.riScratch, b.triSrc, b.wideBoxMin, b.wideBoxMax};
     for (void* p : ps) if (p) (void)hipFree(p);
     __builtin_memset(&b, 0, sizeof(b));
+}
+// bottom-up over the levels of the wide tree: children lie in deeper collapse levels than their parents, and a level's nodes are one index range
+static void bvh_refit_levels(BvhBuildBuffers& b, hipStream_t st) {
+    for (uint l = b.collapseLevels; l-- > 0u;) {
+        const uint first = b.wideLevelStart[l], count = b.wideLevelStart[l + 1u] - first;
+        if (count) hipLaunchKernelGGL(k_refit8_level, dim3((count + 31u) / 32u), dim3(256), 0, st, first, count, b.nodes8, b.triSorted, b.wideBoxMin, b.wideBoxMax, b.sceneBounds);
+    }
 }
 static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStream_t st) {
     uint g = (n + 255u) / 256u;
@@ -578,17 +680,27 @@ static hipError_t bvh_bounds_and_emit(BvhBuildBuffers& b, const DeviceScene& sc,
     PT_HIP_TRY(hipMemcpyAsync(b.levelA, init, 8, hipMemcpyHostToDevice, st));
     PT_HIP_TRY(hipMemcpyAsync(b.wideCounter, init + 2, 8, hipMemcpyHostToDevice, st));
     uint nIn = 1, levels = 0; uint* in = b.levelA; uint* out = b.levelB;
+    b.wideLevelStart[0] = 0u; b.wideLevelStart[1] = 1u;
     while (nIn) {
         hipLaunchKernelGGL(k_collapse8, dim3((nIn + 127u) / 128u), dim3(128), 0, st, b.nodes, in, nIn, out, b.wideCounter, b.nodes8, costDriven ? 1u : 0u);
         uint host[2];
         PT_HIP_TRY(hipMemcpyAsync(host, b.wideCounter, 8, hipMemcpyDeviceToHost, st));
         PT_HIP_TRY(hipStreamSynchronize(st));
         b.numNodes8 = host[0]; nIn = host[1];
+        if (levels + 2u <= BVH_MAX_WIDE_LEVELS) b.wideLevelStart[levels + 2u] = host[0];      // the wide nodes the level just allocated: the next level, [wideLevelStart[levels + 1], host[0])
         uint zero = 0; PT_HIP_TRY(hipMemcpyAsync(b.wideCounter + 1, &zero, 4, hipMemcpyHostToDevice, st));
         uint* t = in; in = out; out = t;
         if (++levels > 4096u) return hipErrorUnknown;
     }
     b.collapseLevels = levels;
+    // what a refit needs (pt_build.h): the flat source records in leaf order and every wide node's un-padded box — the latter by running the refit's own level pass once over the
+    // tree just written (it rewrites the nodes with the bytes they hold: min / max are exact)
+    b.wideRefitReady = 0u;
+    if (levels <= BVH_MAX_WIDE_LEVELS && b.triSrc) {
+        hipLaunchKernelGGL(k_tri_src, dim3(g), dim3(256), 0, st, sc, b.triSorted, n, b.triSrc);
+        bvh_refit_levels(b, st);
+        b.wideRefitReady = 1u;
+    }
     return hipGetLastError();
 }
 static hipError_t bvh_reinsert(BvhBuildBuffers& b, uint n, uint passes, hipStream_t st);
@@ -799,6 +911,12 @@ hipError_t bvh_refit(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStrea
     if (n == 0) return hipSuccess;
     uint g = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, st, b.sceneBounds);
+    static const bool fullRefit = getenv("MI355PT_FULL_REFIT") != nullptr;      // developer A/B switch: round 3's refit (k_tri_setup, sparse table, emit, collapse)
+    if (b.wideRefitReady && !fullRefit) {
+        hipLaunchKernelGGL(k_refit_world, dim3((n + 1023u) / 1024u), dim3(1024), 0, st, sc, b.triSrc, n, b.triSorted, b.sceneBounds);
+        bvh_refit_levels(b, st);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_tri_setup, dim3(g), dim3(256), 0, st, sc, n, b.triWorld, b.sceneBounds);
     return bvh_bounds_and_emit(b, sc, n, st);
 }

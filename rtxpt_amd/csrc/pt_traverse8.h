@@ -46,12 +46,6 @@ static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 #ifndef T8_TAIL_ITERS_TASKS
 #define T8_TAIL_ITERS_TASKS 8    // the same for task rounds: sub-trees are short, and every round of every launch pays this tail once
 #endif
-#ifndef T8_WAVE_SHARE
-#define T8_WAVE_SHARE 0   // work sharing inside a dry wave: idle pairs take stack entries of busy pairs (pt_traverse8p.h SHARE)
-#endif
-#ifndef T8_SHARE_TURNS
-#define T8_SHARE_TURNS 3           // times a dry wave deals the stacks of its busy pairs to its idle pairs (each after a tail limit of iterations) before it splits across waves
-#endif
 #ifndef T8_ANYHIT_UNORDERED
 #define T8_ANYHIT_UNORDERED 1     // 1: occlusion queries number a node's hit children by child index instead of ranking them by entry distance
 #endif
@@ -101,9 +95,9 @@ struct __attribute__((packed, aligned(8))) Bvh8ChildPair { uint refA, q0A, q1A, 
 // Pub: void publish(uint tag, float bestT, uint bestPrim) ; called by one lane for every ray that is split (CAN_SPLIT only)
 //
 #if PT_T8_LANES == 4
-// (DEFER, SHARE and merge belong to the two-lane build, pt_traverse8p.h; accepted and ignored here so that the kernels read the same for both)
-template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, bool DEFER = false, bool SHARE = false, class Src, class Dst, class Pub, class Mrg>
-__device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, Mrg, TravTaskOut taskOut,
+// (DEFER belongs to the two-lane build, pt_traverse8p.h; accepted and ignored here so that the kernels read the same for both)
+template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, bool DEFER = false, class Src, class Dst, class Pub>
+__device__ __forceinline__ void traverse8_persistent(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
                                                      Traverse8Counters& ctr, uint* overflowFlag) {
     const uint RAY_STRIDE = TASKS ? T8_TASK_STRIDE : T8_RAY_STRIDE;
     const uint lane = threadIdx.x & 63u, q = lane & 3u, gl = lane & ~3u;

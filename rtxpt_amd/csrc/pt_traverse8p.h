@@ -32,19 +32,9 @@ __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { retur
 #if PT_T8_LANES == 2
 // DEFER (with CAN_SPLIT): a dry wave keeps going for taskOut.capacity iterations (instead of T8_TAIL_ITERS), and the rays then still in flight are not cut into sub-trees,
 // only reported through publish() — the caller has them traced again elsewhere (the tail kernel, pt_tail.hip, hands their paths back to the host loop). No task queue is touched.
-//
-// SHARE (with CAN_SPLIT, not DEFER): work sharing INSIDE the wave. A ray is a serial chain on one pair of lanes, and the end of every launch — all of a launch that is no
-// larger than the GPU — is a handful of long rays per wave beside idle pairs: a wave lives as long as its longest ray (100+ iterations where the mean is 25), and what
-// the cross-wave splitting below buys comes in rounds of separate launches. Once the wave is dry (no chunk left to refill from), every iteration hands the top stack
-// entry of each busy pair to an idle pair of the same wave: the thief copies the ray (through the chunk parking lot in LDS, free by then), starts at the donated node
-// with the donor's best hit so far and an empty stack, and becomes a donor itself as its stack grows. The parts of a ray report like sub-tree tasks do: the first
-// donation publishes the ray (publish(): merge key seeded, resolve list), every part merges what it finds (merge(): atomicMin on the key / the occlusion flag), the resolve
-// pass the launch runs anyway writes the hit record. No refcounts, no waiting: the result is the minimum over the parts — the traversal's own rule — so the image cannot change.
-// Mrg: void merge(uint tag, const HitInfo& h) ; a partial traversal of a published ray found h (closest: a candidate for the minimum; any-hit: an occluder)
-template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, bool DEFER = false, bool SHARE = false, class Src, class Dst, class Pub, class Mrg>
-__device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, Mrg merge, TravTaskOut taskOut,
+template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, bool DEFER = false, class Src, class Dst, class Pub>
+__device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
                                                 Traverse8Counters& ctr, uint* overflowFlag) {
-    static_assert(!SHARE || (CAN_SPLIT && !DEFER), "work sharing reports through the merge keys of the straggler splitting");
     static_assert(T8_LANES == 2u, "traverse8_pairs is the two-lanes-per-ray build");
     const uint RAY_STRIDE = TASKS ? T8_TASK_STRIDE : T8_RAY_STRIDE;
     const uint lane = threadIdx.x & 63u, h = lane & 1u, pl = lane & ~1u;
@@ -86,10 +76,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         }
     };
 
-    unsigned long long mergedM = 0ull;      // (SHARE; wave-level) pairs whose current work is a PART of a published ray: it reports through merge(), never through commit()
-    uint shareTurns = 0u;
     bool splitNow = false, stop = false;
-    for (;;) {
     while (!stop) {
         unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
         if (COUNT) tc0 = __builtin_readcyclecounter();
@@ -281,7 +268,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
             T8_EVENT(4, alphaRan); T8_EVENT(5, candBits != 0u);
             if (candBits) {
                 if (ANYHIT) {
-                    if (h == (uint)__ffs((int)candBits) - 1u) { HitInfo hh; hh.t = lt; hh.prim = lp; hh.u = hh.v = 0.f; if (SHARE && !TASKS && ((mergedM >> lane) & 1ull)) merge(tag, hh); else commit(tag, hh); }
+                    if (h == (uint)__ffs((int)candBits) - 1u) { HitInfo hh; hh.t = lt; hh.prim = lp; hh.u = hh.v = 0.f; commit(tag, hh); }
                     active = false;
                 } else {
                     if (cand && !TASKS) { minePrim = lp; mineUV[threadIdx.x] = make_float2(lu, lv); }
@@ -332,9 +319,6 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                         if (ANYHIT) { /* visible sub-tree: nothing to report */ }
                         else if (h == 0u && (bestPrim != taskPrim0 || bestT != taskT0)) { HitInfo hh; hh.t = bestT; hh.prim = bestPrim; hh.u = hh.v = 0.f; commit(tag, hh); }
                     }
-                    else if (SHARE && ((mergedM >> lane) & 1ull)) {       // a part of a published ray: a visible part has nothing to report, a closest-hit part its best candidate
-                        if (!ANYHIT && h == 0u && bestPrim != 0xFFFFFFFFu) { HitInfo hh; hh.t = bestT; hh.prim = bestPrim; hh.u = hh.v = 0.f; merge(tag, hh); }
-                    }
                     else if (ANYHIT) { if (h == 0u) { HitInfo hh; hh.t = tmax; hh.prim = 0xFFFFFFFFu; hh.u = hh.v = 0.f; commit(tag, hh); } }
                     else if (bestPrim == 0xFFFFFFFFu) { if (h == 0u) { HitInfo hh; hh.t = bestT; hh.prim = 0xFFFFFFFFu; hh.u = hh.v = 0.f; commit(tag, hh); } }
                     else if (minePrim == bestPrim) { float2 uv = mineUV[threadIdx.x]; HitInfo hh; hh.t = bestT; hh.prim = bestPrim; hh.u = uv.x; hh.v = uv.y; commit(tag, hh); }
@@ -344,59 +328,6 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         }
         if (COUNT) { unsigned long long tc4 = __builtin_readcyclecounter(); ctr.cyc[0] += tc1 - tc0; ctr.cyc[1] += tc2 - tc1; ctr.cyc[2] += tc3 - tc2; ctr.cyc[3] += tc4 - tc3; }
         }       // run
-    }
-    // ---- (SHARE) the wave has been dry for the tail limit: before anything leaves the wave, the busy pairs' stacks are dealt to the wave's own idle pairs (see the header comment),
-    //      T8_SHARE_TURNS times; what is still in flight after the last turn's tail goes to the task queue below
-    if (!(SHARE && splitNow && shareTurns < (uint)T8_SHARE_TURNS)) break;
-    {
-        bool moved = false;
-        for (;;) {      // one stack entry per busy pair and turn, top (nearest) first, until the idle pairs or the stacks run out
-            const unsigned long long idleM = t8_ballot(!active && h == 0u);
-            const unsigned long long donorM = idleM ? t8_ballot(active && sp > 0u && h == 0u) : 0ull;
-            if (!donorM) break;
-            {
-                const uint nD = (uint)__popcll(donorM), nT = (uint)__popcll(idleM), nX = nD < nT ? nD : nT;
-                const unsigned long long belowPl = (1ull << pl) - 1ull;
-                const uint dRank = (uint)__popcll(donorM & belowPl), tRank = (uint)__popcll(idleM & belowPl);
-                const bool gives = active && sp > 0u && dRank < nX, takes = !active && tRank < nX;
-                if (gives) {       // the pair's top stack entry leaves with a copy of the ray; lane 0 writes the record
-                    sp--;
-                    uint2 e;
-                    if (sp < BVH8_STACK) e = stack[sp];
-                    else { unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (sp - BVH8_STACK)))); e = make_uint2((uint)w, (uint)(w >> 32)); }
-                    if (h == 0u) {
-                        uint* slot = rayBuf + dRank * RAY_STRIDE;
-                        slot[0] = __float_as_uint(o.x); slot[1] = __float_as_uint(o.y); slot[2] = __float_as_uint(o.z);
-                        slot[3] = __float_as_uint(d.x); slot[4] = __float_as_uint(d.y); slot[5] = __float_as_uint(d.z);
-                        slot[6] = tag; slot[7] = __float_as_uint(bestT); slot[8] = bestPrim;
-                        slot[9] = (ANYHIT || __uint_as_float(e.y) <= bestT) ? e.x : BVH_EMPTY;      // an entry behind the best hit is dropped here
-                        if (!FIXED_RANGE) { slot[10] = __float_as_uint(tmin); slot[11] = __float_as_uint(tmax); }
-                        if (!TASKS && !((mergedM >> lane) & 1ull)) { publish(tag, bestT, bestPrim); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // first donation of this ray: its key exists before any part can merge into it
-                    }
-                }
-                if (takes) {
-                    const uint* slot = rayBuf + tRank * RAY_STRIDE;
-                    const uint ref = slot[9];
-                    if (ref != BVH_EMPTY) {
-                        o = make_float3(__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]));
-                        d = make_float3(__uint_as_float(slot[3]), __uint_as_float(slot[4]), __uint_as_float(slot[5]));
-                        tag = slot[6]; bestT = __uint_as_float(slot[7]); bestPrim = slot[8];
-                        if (!FIXED_RANGE) { tmin = __uint_as_float(slot[10]); tmax = __uint_as_float(slot[11]); }
-                        ix = t8_rcp_dir(d.x); iy = t8_rcp_dir(d.y); iz = t8_rcp_dir(d.z);
-                        {   const uint nxb = ix < 0.f ? 3u : 0u, fxb = ix < 0.f ? 0u : 3u, nyb = iy < 0.f ? 4u : 1u, fyb = iy < 0.f ? 1u : 4u, nzb = iz < 0.f ? 5u : 2u, fzb = iz < 0.f ? 2u : 5u;
-                            selN = nxb | (nyb << 8) | (nzb << 16) | (fxb << 24); selF = fyb | (fzb << 8); }
-                        if (TASKS) { taskT0 = bestT; taskPrim0 = bestPrim; }
-                        minePrim = 0xFFFFFFFFu; rayIters = 0u;
-                        cur = ref; pend = BVH_EMPTY; pend1 = BVH_EMPTY; pend2 = BVH_EMPTY; sp = 0u; active = true;
-                    }
-                }
-                mergedM |= t8_ballot(gives || (takes && active));
-                moved = true;
-            }
-        }
-        if (!moved) break;      // nothing to deal (no idle pair, or no stack): the cross-wave split below takes what is in flight, as without sharing
-        shareTurns++; splitNow = false; stop = false; tailIters = 0u;
-    }
     }
     if (CAN_SPLIT && splitNow)
     // ---- every ray still in flight becomes a list of sub-tree tasks: node slot, postponed leaves, stack entries
@@ -417,8 +348,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 if (pend != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = pend; tq[4u * k + 2u] = 0u; k++; }
                 if (pend1 != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = pend1; tq[4u * k + 2u] = 0u; k++; }
                 if (pend2 != BVH_EMPTY) { tq[4u * k] = tag; tq[4u * k + 1u] = pend2; tq[4u * k + 2u] = 0u; k++; }
-                if (SHARE && !TASKS && ((mergedM >> lane) & 1ull)) { if (!ANYHIT && bestPrim != 0xFFFFFFFFu) { HitInfo hh; hh.t = bestT; hh.prim = bestPrim; hh.u = hh.v = 0.f; merge(tag, hh); } }      // already published: only its candidate
-                else publish(tag, bestT, bestPrim);
+                publish(tag, bestT, bestPrim);
             }
             for (uint i = h; i < sp; i += T8_LANES) {
                 uint2 e;

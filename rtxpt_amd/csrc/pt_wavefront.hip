@@ -8,10 +8,8 @@
 #include "pt_wavefront_device.h"
 #if PT_T8_LANES == 2
 #define T8_TRAVERSE traverse8_pairs
-#define T8_SHARE (T8_WAVE_SHARE != 0)
 #else
 #define T8_TRAVERSE traverse8_persistent
-#define T8_SHARE false
 #endif
 
 namespace ptk {
@@ -61,8 +59,7 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
     // a split ray: its best hit so far seeds the merge key, the resolve pass will write pool.hit (k_resolve_extend)
     auto publish = [&](uint p, float bestT, uint bestPrim) { aux.bestKey[p] = t8_hit_key(bestT, bestPrim); aux.resolveList[atomicAdd(&aux.counts[TRAV_RESOLVE], 1u)] = p; };
     if (COUNT) { ctr.rayIterHist = wc->rayIterHistExt; ctr.longRayCount = &wc->longRayCount; ctr.longRays = &wc->longRays[0][0]; }
-    auto merge = [&](uint p, const HitInfo& h) { atomicMin(&aux.bestKey[p], t8_hit_key(h.t, h.prim)); };      // a part of a ray that was shared inside its wave
-    T8_TRAVERSE<false, COUNT, true, false, true, false, T8_SHARE>(sc, count, rpc, stack, rayBuf, mineUV, fetch, commit, publish, merge, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<false, COUNT, true, false, true>(sc, count, rpc, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); wave_add64(ctr.leafVisits, &wc->leafVisitsExt); wave_add64(ctr.iters, &wc->itersExt); wave_add64(ctr.leafBlocks, &wc->leafBlocksExt); if ((threadIdx.x & 63u) == 0u) atomicMax(&wc->itersMaxExt, (unsigned long long)ctr.iters);
                  if ((threadIdx.x & 63u) == 0u) for (int q = 0; q < 4; q++) atomicAdd(&wc->phaseCycExt[q], ctr.cyc[q]);
                  for (int q = 0; q < 8; q++) wave_add64(ctr.ev[q], &wc->eventsExt[q]); }
@@ -103,7 +100,7 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks
     };
     auto commit = [&](uint p, const HitInfo& h) { atomicMin(&aux.bestKey[p], t8_hit_key(h.t, h.prim)); };
     auto publish = [&](uint p, float bestT, uint bestPrim) { if (bestPrim != 0xFFFFFFFFu) atomicMin(&aux.bestKey[p], t8_hit_key(bestT, bestPrim)); };
-    T8_TRAVERSE<false, false, true, true, !FINAL, false, T8_SHARE && !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, commit, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<false, false, true, true, !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
 }
 
 // split extend rays: the merged key -> hit record; the barycentrics come from re-intersecting the winning triangle (same arithmetic, same operands)
@@ -280,8 +277,7 @@ __global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_s
     auto commit = [&](uint i, const HitInfo& h) { if (h.prim == 0xFFFFFFFFu) shadow_visible<GROUPED>(pool, sq, i); };      // occluded: nothing is committed
     // a split shadow ray: "visible so far"; its sub-trees may set the flag, k_resolve_shadow applies the contribution if none did
     auto publish = [&](uint i, float, uint) { aux.bestKey[i] = 0ull; aux.resolveList[atomicAdd(&aux.counts[TRAV_RESOLVE], 1u)] = i; };
-    auto merge = [&](uint i, const HitInfo&) { aux.bestKey[i] = 1ull; };      // a part of a shared ray found an occluder
-    T8_TRAVERSE<true, COUNT, false, false, true, false, T8_SHARE>(sc, count, rpc, stack, rayBuf, nullptr, fetch, commit, publish, merge, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<true, COUNT, false, false, true>(sc, count, rpc, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsSh); wave_add64(ctr.triTests, &wc->triTestsSh); wave_add64(ctr.leafVisits, &wc->leafVisitsSh); wave_add64(ctr.iters, &wc->itersSh); }
 }
 
@@ -306,7 +302,7 @@ __global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, Shado
     };
     auto commit = [&](uint i, const HitInfo& h) { if (h.prim != 0xFFFFFFFFu) aux.bestKey[i] = 1ull; };
     auto publish = [&](uint, float, uint) {};
-    T8_TRAVERSE<true, false, false, true, !FINAL, false, T8_SHARE && !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, commit, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<true, false, false, true, !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
 }
 
 template <bool GROUPED>
@@ -367,10 +363,10 @@ __global__ void __launch_bounds__(T8_BLOCK) k_trace_probe(DeviceScene sc, const 
     auto publish = [&](uint, float, uint) {};
     if (outClosest) {
         auto commit = [&](uint i, const HitInfo& h) { outClosest[i] = make_float4(h.t, asfloat(h.prim), h.u, h.v); };
-        T8_TRAVERSE<false, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, commit, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
+        T8_TRAVERSE<false, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
     } else {
         auto commit = [&](uint i, const HitInfo& h) { outVisible[i] = (h.prim == 0xFFFFFFFFu) ? 1u : 0u; };
-        T8_TRAVERSE<true, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, commit, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
+        T8_TRAVERSE<true, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
     }
 }
 

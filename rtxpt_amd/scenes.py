@@ -711,6 +711,12 @@ def animate_positions(sc, t):
     return pos
 
 
+def animated_vertex_ranges(sc):
+    """The vertices animate_positions moves, as (first, count) pairs for pt_animate_ranges: the banner mesh."""
+    d = sc["anim"]["deform"]
+    return [(int(d["first_vertex"]), int(d["rest"].shape[0]))]
+
+
 def animate_instances(sc, t):
     """Rigid keyframed motion of the clutter groups (game props = TLAS instance transforms only)."""
     inst = sc["instances"].copy()

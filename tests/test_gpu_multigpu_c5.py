@@ -1,0 +1,101 @@
+"""BASELINE configs[4] at the split it is stated for — C5: the animated bistro-like scene at 3840x2160, 4 spp, per-frame refit + light re-bake + nested dielectrics (quality 2),
+pixel tiles sharded 8 ways — on the hardware a one-GPU box offers (run with -m gpu):
+  * ranks 0 and 7 of 8 animate (pt_animate: rigid clutter groups + the deforming banner, refit only), render their tiles of two consecutive animated frames and are compared with
+    an oracle that is rebuilt from scratch for that pose, on complete pixel rows of their own tiles, bit for bit; nothing is written outside the tiles;
+  * all 8 shards of an animated frame, each rank refitting its own replica, packed and unpacked through the library's entry points, reassemble to the frame one rank renders alone.
+The refit is round 4's (pt_build.h: flat source records + a bottom-up pass over the wide tree); MI355PT_FULL_REFIT=1 selects round 3's for an A/B."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+W, H, SPP, WORLD = 3840, 2160, 4, 8
+
+
+def _imports():
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes, parallel
+    from oracle import ptref
+    return pt, scenes, parallel, ptref
+
+
+def _scene(scenes):
+    sc, cam = scenes.bistro_like(scale=1.0, tex_size=1024, animated=True)
+    return sc, cam, scenes.default_settings(useFp16Types=1, nestedDielectricsQuality=2)
+
+
+def test_c5_ranks_0_and_7_of_8_animated_frames_match_the_oracle():
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam, S = _scene(scenes)
+    camd = scenes.bridge_camera(W, H, **cam)
+    tracers = {}
+    for rank in (0, 7):
+        g = pt.PathTracer(shard_rank=rank, shard_count=WORLD); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(W, H); tracers[rank] = g
+    for frame, t in enumerate((0.3, 0.6)):
+        inst, pos = scenes.animate_instances(sc, t), scenes.animate_positions(sc, t)
+        sc_t = dict(sc); sc_t["positions"] = pos
+        o = ptref.Oracle(lp16=True); o.set_scene(sc_t); o.set_instances(inst); o.set_camera(camd); o.set_settings(S); o.resize(W, H)
+        for rank, g in tracers.items():
+            g.animate(instances=inst, positions=pos, rebuild=False)
+            assert g.build_stats()["refitMs"] > 0
+            g.reset_accumulation(); st = g.render(frame * SPP, SPP); a = g.radiance()
+            px = parallel.shard_pixels(W, H, rank, WORLD)
+            assert st["pathsTraced"] == px.size * SPP
+            own = np.zeros((H, W), bool); own[(px & 0xFFFF).astype(np.int64), (px >> 16).astype(np.int64)] = True
+            assert np.all(a[~own] == 0.0) and np.isfinite(a).all()
+            ys = (px & 0xFFFF).astype(np.int64)
+            for y in (int(ys[11]), int(ys[ys.size // 2]) + 5):      # a row through the rank's first tiles (sky, roofs) and one through its middle (street, props, banner)
+                o.reset_accumulation(); o.render(frame * SPP, SPP, rect=(0, y, W, y + 1))
+                want = o.radiance()[y, :, :3]; got = a[y, :, :3]; m = own[y]
+                assert m.any()
+                bad = int((got[m].view(np.uint32) != want[m].view(np.uint32)).any(-1).sum())
+                assert bad == 0, "frame %d rank %d row %d: %d of %d owned pixels differ" % (frame, rank, y, bad, int(m.sum()))
+        o.close()
+    for g in tracers.values(): g.close()
+
+
+def test_c5_eight_refitted_shards_reassemble_to_the_single_rank_frame():
+    import torch
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam, S = _scene(scenes)
+    camd = scenes.bridge_camera(W, H, **cam)
+    inst, pos = scenes.animate_instances(sc, 0.5), scenes.animate_positions(sc, 0.5)
+    full = pt.PathTracer(); full.set_scene(sc); full.set_camera(camd); full.set_settings(S); full.resize(W, H)
+    full.animate(instances=inst, positions=pos, rebuild=False); full.render(0, SPP)
+    want = full.radiance(); full.close()
+    packed, root = [], None
+    for rank in range(WORLD):
+        g = pt.PathTracer(shard_rank=rank, shard_count=WORLD); g.set_scene(sc); g.set_camera(camd); g.set_settings(S); g.resize(W, H)
+        g.render(0, 1)                                        # a frame of the rest pose first: the animated frame below is a refit of a tree that has been used
+        g.animate(instances=inst, positions=pos, rebuild=False); g.render(0, SPP)
+        n, nbytes = g.shard_info()
+        buf = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        g.pack_shard(buf.data_ptr(), nbytes); packed.append(buf)
+        if rank == 0: root = g
+        else: g.close()
+    for rank in range(1, WORLD): root.unpack_shard(packed[rank].data_ptr(), packed[rank].numel() * 4, rank)
+    got = root.radiance(); root.close()
+    assert np.array_equal(got, want)
+
+
+def test_animate_ranges_equals_animate():
+    """pt_animate_ranges (the host names the vertices it moved — the banner) gives the frames of pt_animate (every vertex uploaded, every shading record rewritten), on the
+    small-scale C5 scene over three poses; a range that misses the moved vertices leaves the mesh where it was."""
+    pt, scenes, parallel, ptref = _imports()
+    sc, cam = scenes.bistro_like(scale=0.01, tex_size=64, animated=True)
+    cam = dict(cam, pos=(20.0, 2.5, 20.0), direction=(1.0, -0.08, 0.02))
+    S = scenes.default_settings(nestedDielectricsQuality=2, useFp16Types=1); w, h = 192, 108
+    camd = scenes.bridge_camera(w, h, **cam)
+    a = pt.PathTracer(); a.set_scene(sc); a.set_camera(camd); a.set_settings(S); a.resize(w, h)
+    b = pt.PathTracer(); b.set_scene(sc); b.set_camera(camd); b.set_settings(S); b.resize(w, h)
+    ranges = scenes.animated_vertex_ranges(sc)
+    for frame, t in enumerate((0.0, 0.4, 0.8)):
+        inst, pos = scenes.animate_instances(sc, t), scenes.animate_positions(sc, t)
+        a.animate(instances=inst, positions=pos, rebuild=False); a.reset_accumulation(); a.render(frame * 2, 2)
+        b.animate(instances=inst, positions=pos, rebuild=False, vertex_ranges=ranges); b.reset_accumulation(); b.render(frame * 2, 2)
+        assert np.array_equal(a.radiance(), b.radiance()), "frame %d" % frame
+    rest = b.radiance()
+    pos = scenes.animate_positions(sc, 2.0)
+    b.animate(positions=pos, rebuild=False, vertex_ranges=[(0, 8)]); b.reset_accumulation(); b.render(4, 2)      # the banner is not in the range: it stays in the pose of t = 0.8
+    assert np.array_equal(rest, b.radiance())
+    with pytest.raises(Exception): b.animate(positions=pos, rebuild=False, vertex_ranges=[(pos.shape[0] - 4, 8)])
+    a.close(); b.close()

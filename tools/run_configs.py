@@ -26,12 +26,14 @@ def gpu_run(sc, cam, S, w, h, spp, frames=5, warmup=2, animate=None):
 
 
 def main():
-    argparse.ArgumentParser(description=__doc__).parse_args()
+    ap = argparse.ArgumentParser(description=__doc__); ap.add_argument("--only", default="", help="comma-separated subset, e.g. C1,C2"); args = ap.parse_args()
+    only = set(x for x in args.only.split(",") if x)
     res = {}
     sc, cam = scenes.cornell_box("C1")
     res["C1"] = {"gpu": gpu_run(sc, cam, scenes.config_settings("C1"), 256, 256, 1)}
     sc, cam = scenes.cornell_box("C2")
     res["C2"] = {"gpu": gpu_run(sc, cam, scenes.config_settings("C2"), 1920, 1080, 4)}
+    if only and not (only - {"C1", "C2"}): print(json.dumps({k: v for k, v in res.items() if k in only}, indent=1)); return
     sc, cam = scenes.bistro_like(); sc["env_cube_dim"] = 2048; sc["env_compression"] = 1      # as bench.py
     res["C3"] = {"gpu": gpu_run(sc, cam, scenes.default_settings(useFp16Types=1), 3840, 2160, 4)}
     res["C4"] = {"gpu": gpu_run(sc, cam, scenes.default_settings(useFp16Types=1), 3840, 2160, 16, frames=2, warmup=1)}
