@@ -700,6 +700,37 @@ def bistro_like(scale=1.0, seed=SEED_BASE + 3, tex_size=1024, animated=False):
     return sc, cam
 
 
+def closed_icosphere(subdivisions=5, transform=None):
+    """A closed, indexed (shared-vertex) triangle mesh: an icosphere of radius 1 with 20 * 4^subdivisions triangles, one instance under `transform` (default: a rotation about y
+    with a non-uniform scale and an offset, so that the world-space vertices carry rounding). For the watertightness measurement (tests/test_gpu_watertight.py): from inside,
+    every ray must hit. Returns (scene dict, world-space float64 vertices as the float32 transform gives them, triangle index array)."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    V = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]; F = list(f)
+    for _ in range(subdivisions):
+        mid = {}; F2 = []
+        def m(a, b):
+            k = (a, b) if a < b else (b, a)
+            if k not in mid:
+                p = V[a] + V[b]; V.append(p / np.linalg.norm(p)); mid[k] = len(V) - 1
+            return mid[k]
+        for a, b, c in F:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            F2 += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        F = F2
+    P = np.array(V, np.float32); I = np.array(F, np.uint32)
+    b = SceneBuilder()
+    mat = b.add_material(make_material(base=(0.7, 0.7, 0.7), roughness=1.0))
+    b.begin_mesh(); b.add_geometry(P, I.reshape(-1), mat, normal=P); mesh = b.end_mesh()
+    T = trs((0.37, -0.21, 0.53), rot_y=0.731, scale=(1.7, 0.9, 1.3)) if transform is None else np.asarray(transform, np.float32)
+    b.add_instance(mesh, T)
+    M = T.reshape(3, 4).astype(np.float64)
+    W = P.astype(np.float64) @ M[:, :3].T + M[:, 3]
+    return b.finish(), W, I
+
+
 def animate_positions(sc, t):
     """C5 deforming mesh ("1 skinned-like mesh of 50 k tris displaced per frame"): the banner ripples along x; same
     topology, so the library refits. Returns the full position array for pt_animate."""
