@@ -320,8 +320,9 @@ int32_t pt_get_stable_planes(pt_context* ctx, uint32_t* header, PtStablePlane* p
 int32_t pt_neeat_reset(pt_context* ctx);                                                      /* LightsBaker::BakeSettings::ResetFeedback */
 int32_t pt_get_neeat_tables(pt_context* ctx, uint32_t tilesXY[2], uint32_t jitterXY[2], uint32_t* table, uint32_t tableCapacityWords);
 /* Tile-sharded frames (PtDeviceDesc.shardCount > 1; no reference analogue): a rank traces and feeds back for its own pixels, the baker's passes read whole neighbourhoods, so
- * between two frames every rank needs the other ranks' reservoirs (8 bytes per pixel) and then runs the same deterministic passes as everybody else — same tables and proxy
- * counts on every rank, the same as the unsharded run. With a communicator (pt_comm_init) pt_render does the exchange itself (RCCL point-to-point in one group, un-padded, on
+ * between two frames every rank needs the other ranks' reservoirs and exported depth — (weight, candidate, depth): 12 bytes per pixel; the depth is what the baker's
+ * reprojection compares, also across shard borders — and then runs the same deterministic passes as everybody else: same tables and proxy counts on every rank, the same as
+ * the unsharded run, with or without pt_set_view_projection. With a communicator (pt_comm_init) pt_render does the exchange itself (RCCL point-to-point in one group, un-padded, on
  * the library's stream). Without one the host moves the buffers after every frame: pt_neeat_pack_feedback (the rank's own pixels, pt_pack_shard's order, device memory) ->
  * the host's transport -> pt_neeat_unpack_feedback(rank r's buffer, r) on every other rank, before their next pt_render. */
 int32_t pt_neeat_pack_feedback(pt_context* ctx, void* dstDevice, size_t bytes);
@@ -545,9 +546,9 @@ typedef struct PtTransport {
     int32_t (*group_end)(void* user);                                               /* may be NULL */
 } PtTransport;
 int32_t pt_gather_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* rgba, const PtTransport* transport);
-/* the NEE-AT feedback exchange of tile-sharded frames over HOST memory and the same transport: totalWeight / candidates are this rank's full width x height planes
- * (only its own tiles need to be valid); on return every rank holds every rank's reservoirs. Pairs of ranks meet in rank order, the lower one sends first. */
-int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* totalWeight, uint32_t* candidates, const PtTransport* transport);
+/* the NEE-AT feedback exchange of tile-sharded frames over HOST memory and the same transport: totalWeight / candidates / depth are this rank's full width x height planes
+ * (only its own tiles need to be valid); on return every rank holds every rank's reservoirs and exported depth. Pairs of ranks meet in rank order, the lower one sends first. */
+int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* totalWeight, uint32_t* candidates, float* depth, const PtTransport* transport);
 
 /* --- probes used by the parity tests and bench.py (not part of the reference seam) --------------------------------- */
 /* closest-hit / any-hit queries through the same BVH + kernels the renderer uses. rays: n x 8 floats (o.xyz,tmin,d.xyz,tmax);

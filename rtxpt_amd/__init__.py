@@ -233,10 +233,10 @@ def gather_host(width, height, rank, world, rgba, send, recv):
     return rgba
 
 
-def neeat_exchange_host(width, height, rank, world, total_weight, candidates, send, recv):
-    """pt_neeat_exchange_host: all ranks end up with all ranks' feedback reservoirs; (h, w) float32 / uint32 planes, modified in place; send / recv as in gather_host"""
+def neeat_exchange_host(width, height, rank, world, total_weight, candidates, depth, send, recv):
+    """pt_neeat_exchange_host: all ranks end up with all ranks' feedback reservoirs and exported depth; (h, w) float32 / uint32 / float32 planes, modified in place; send / recv as in gather_host"""
     L = load_library()
-    assert total_weight.dtype == np.float32 and candidates.dtype == np.uint32 and total_weight.shape == candidates.shape == (height, width)
+    assert total_weight.dtype == np.float32 and candidates.dtype == np.uint32 and depth.dtype == np.float32 and total_weight.shape == candidates.shape == depth.shape == (height, width)
 
     def _wrap(fn):
         def cb(user, buf, nbytes, peer):
@@ -246,7 +246,7 @@ def neeat_exchange_host(width, height, rank, world, total_weight, candidates, se
                 import traceback; traceback.print_exc(); return 1
         return cb
     t = PtTransport(None, PtTransport.SEND(_wrap(send)), PtTransport.RECV(_wrap(recv)), PtTransport.GROUP(), PtTransport.GROUP())
-    r = L.pt_neeat_exchange_host(width, height, rank, world, _p(total_weight), _p(candidates), ctypes.byref(t))
+    r = L.pt_neeat_exchange_host(width, height, rank, world, _p(total_weight), _p(candidates), _p(depth), ctypes.byref(t))
     if r != 0:
         raise PtError(r, "pt_neeat_exchange_host")
 

@@ -107,7 +107,7 @@ struct pt_context {
         bool feedbackFilled = false, lastFeedbackAvailable = false; uint historicTotalLightCount = 0, W = 0, H = 0, nHist = 0;
         DevBuf<float> fbW, scW, blW, snapW, curW, histW; DevBuf<uint> fbC, scC, blC, snapC, local, counters;
         DevBuf<float> depth, histDepth; bool haveClip = false; float clipZ[4] = {0, 0, 0, 0}, clipW[4] = {0, 0, 0, 0};      // the exported depth of the last traced frame / of the one before; columns 2 and 3 of pt_set_view_projection's matrix
-        DevBuf<ptk::uint2> xSend, xRecv; DevBuf<uint> xPixels; uint xW = 0, xH = 0;      // tile-sharded frames: the exchange of the owned pixels' reservoirs between frames
+        DevBuf<uint> xSend, xRecv; DevBuf<uint> xPixels; uint xW = 0, xH = 0;      // tile-sharded frames: the exchange of the owned pixels' reservoirs between frames
         void reset() { W = H = 0; updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
         void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); xSend.free(); xRecv.free(); xPixels.free(); depth.free(); histDepth.free(); }
     } neeat;
@@ -232,6 +232,7 @@ int upload_textures(pt_context* c) {
         for (size_t k = 0; k < m0.size() && bytes; k++) { const float a = m0[k].w; const int q = (a >= 0.f && a <= 1.f) ? (int)(a * 255.0f + 0.5f) : -1; bytes = q >= 0 && (float)q / 255.0f == a; }
         while (apool.size() % 16u) apool.push_back(0);
         if (apool.size() + m0.size() * (bytes ? 1u : 4u) > 0xFFFFFFF0ull) return fail(c, PT_ERROR_UNSUPPORTED, "alpha planes above 4 GB are not supported");
+        if (t.w > 0xFFFFu || t.h > 0xFFFFu) return fail(c, PT_ERROR_UNSUPPORTED, "textures larger than 65535 texels on a side are not supported (the traversal's alpha test packs the size into 16 + 16 bits)");
         ptk::AlphaPlane& ap = planes[ti]; ap.wh = (t.w & 0xFFFFu) | (t.h << 16); ap.offset = (uint)apool.size(); ap.fmt = bytes ? 0u : 1u;
         if (bytes) for (size_t k = 0; k < m0.size(); k++) apool.push_back((unsigned char)(int)(m0[k].w * 255.0f + 0.5f));
         else { const size_t at = apool.size(); apool.resize(at + 4u * m0.size()); for (size_t k = 0; k < m0.size(); k++) memcpy(&apool[at + 4u * k], &m0[k].w, 4); }
@@ -538,7 +539,8 @@ int ensure_pool(pt_context* c, uint n, uint shadowPerPath) {      // shadowPerPa
 }
 
 // Tile-sharded frames (pt_create with shardCount > 1): a rank traces, and feeds back for, its own pixels only, but the baker's passes read whole neighbourhoods. Between two
-// frames every rank therefore receives the other ranks' reservoirs (8 bytes per pixel: 66 MB for a 4K frame) and then runs the same deterministic passes on the same
+// frames every rank therefore receives the other ranks' reservoirs and exported depth (12 bytes per pixel: 100 MB for a 4K frame; the depth is what the reprojection tests — a
+// pixel another rank traced would otherwise read as depth 0, "valid" by NaN compare, whatever its owner sees) and then runs the same deterministic passes on the same
 // planes as everybody else: identical tables and proxy counts on all ranks, identical to the unsharded run. With a communicator (pt_comm_init) the exchange is RCCL point-to-point
 // inside one group, un-padded like pt_gather; without one the host moves the packed buffers (pt_neeat_pack_feedback / pt_neeat_unpack_feedback).
 int neeat_exchange_feedback(pt_context* c) {
@@ -547,23 +549,23 @@ int neeat_exchange_feedback(pt_context* c) {
     hipStream_t s = c->stream;
     if (st.xW != c->width || st.xH != c->height) {
         std::vector<uint> others; for (uint r = 0; r < c->shardCount; r++) if (r != c->shardRank) others.insert(others.end(), c->shardPixels[r].begin(), c->shardPixels[r].end());
-        PT_CHECK_HIP(c, st.xPixels.upload(others, s)); PT_CHECK_HIP(c, st.xRecv.resize(others.size())); PT_CHECK_HIP(c, st.xSend.resize(c->owned.size())); PT_CHECK_HIP(c, hipStreamSynchronize(s));
+        PT_CHECK_HIP(c, st.xPixels.upload(others, s)); PT_CHECK_HIP(c, st.xRecv.resize(3 * others.size())); PT_CHECK_HIP(c, st.xSend.resize(3 * c->owned.size())); PT_CHECK_HIP(c, hipStreamSynchronize(s));
         st.xW = c->width; st.xH = c->height;
     }
     const size_t n = c->owned.size();
-    launch_pack_feedback(st.fbW.p, st.fbC.p, c->dOwned.p, (uint)n, c->width, st.xSend.p, s);
+    launch_pack_feedback(st.fbW.p, st.fbC.p, st.depth.p, c->dOwned.p, (uint)n, c->width, st.xSend.p, s);
     PT_CHECK_NCCL(c, g_rccl.GroupStart());
     size_t off = 0; ncclResult_t bad = ncclSuccess;
     for (uint r = 0; r < c->shardCount && bad == ncclSuccess; r++) {
         if (r == c->shardRank) continue;
         const size_t m = c->shardPixels[r].size();
-        if (n) bad = g_rccl.Send(st.xSend.p, 2 * n, ncclFloat, (int)r, c->comm, s);
-        if (m && bad == ncclSuccess) bad = g_rccl.Recv(st.xRecv.p + off, 2 * m, ncclFloat, (int)r, c->comm, s);
+        if (n) bad = g_rccl.Send(st.xSend.p, 3 * n, ncclFloat, (int)r, c->comm, s);
+        if (m && bad == ncclSuccess) bad = g_rccl.Recv(st.xRecv.p + 3 * off, 3 * m, ncclFloat, (int)r, c->comm, s);
         off += m;
     }
     ncclResult_t ge = g_rccl.GroupEnd();
     if (bad != ncclSuccess || ge != ncclSuccess) return fail(c, PT_ERROR_HIP, std::string("NEE-AT feedback exchange: ") + g_rccl.GetErrorString(bad != ncclSuccess ? bad : ge));
-    launch_unpack_feedback(st.fbW.p, st.fbC.p, st.xPixels.p, (uint)off, c->width, st.xRecv.p, s);
+    launch_unpack_feedback(st.fbW.p, st.fbC.p, st.depth.p, st.xPixels.p, (uint)off, c->width, st.xRecv.p, s);
     return PT_OK;
 }
 // One frame of LightsBaker::UpdateBegin + UpdateEnd for the NEE-AT layer (LightsBaker.cpp:943-962, 985-1075, 1186-1213, 1335-1420) ahead of the frame's path tracing; the
@@ -826,6 +828,7 @@ int32_t pt_set_local_light_sampling(pt_context* c, const uint32_t* table, uint32
 int32_t pt_get_light_feedback(pt_context* c, uint32_t sample, float* totalWeight, uint32_t* candidates) {
     if (!c || !totalWeight || !candidates) return PT_ERROR_INVALID_ARGUMENT;
     if (sample >= c->fbSamples) return fail(c, PT_ERROR_NOT_READY, "no feedback for that sample: pt_set_local_light_sampling(temporalFeedback = 1) or pt_set_neeat, then pt_render");
+    if (c->neeat.enabled && (!c->neeat.fbW.p || c->neeat.W != c->width || c->neeat.H != c->height)) return fail(c, PT_ERROR_NOT_READY, "no NEE-AT frame of this size yet: pt_render first");
     (void)hipSetDevice(c->device);
     const size_t plane = (size_t)c->width * c->height;
     const float* w = c->neeat.enabled ? c->neeat.fbW.p : c->dFbWeight.p + plane * sample; const uint* cand = c->neeat.enabled ? c->neeat.fbC.p : c->dFbCand.p + plane * sample;
@@ -842,17 +845,18 @@ int32_t pt_set_neeat(pt_context* c, int32_t enable, float globalTemporalFeedback
     if (st.enabled && !enable) {                 // back to the plain global sampler: no local layer, no feedback, the proxy table of the bake
         c->localResX = c->localResY = c->localJitterX = c->localJitterY = c->localMaxLight = 0; c->localRatio = 0.f; c->feedbackRequired = false; c->lightsDirty = true;
     }
+    if (st.enabled != (enable != 0)) c->fbSamples = 0;      // the planes pt_get_light_feedback reads change hands: nothing is valid until the next pt_render
     st.enabled = enable != 0; st.globalFeedbackWeight = globalTemporalFeedbackWeight; st.localRatio = localToGlobalSampleRatio; st.sscThreshold = screenSpaceVsWorldSpaceThreshold; st.preFilter = preFilter != 0;
     refresh_scene_view(c);
     return PT_OK;
 }
-// the owned pixels' reservoirs as (weight bits, candidate) pairs, 8 bytes per pixel in the order of the rank's pixel list — pt_pack_shard's order; device pointers
+// the owned pixels' reservoirs and exported depth as (weight bits, candidate, depth bits) triples, 12 bytes per pixel in the order of the rank's pixel list — pt_pack_shard's order; device pointers
 int32_t pt_neeat_pack_feedback(pt_context* c, void* dst, size_t bytes) {
     if (!c || !dst) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->neeat.enabled || !c->neeat.W || c->neeat.W != c->width || c->neeat.H != c->height) return fail(c, PT_ERROR_NOT_READY, "no NEE-AT frame yet: pt_set_neeat, then pt_render");
-    if (bytes < c->owned.size() * 8) return fail(c, PT_ERROR_INVALID_ARGUMENT, "destination too small");
+    if (bytes < c->owned.size() * 12) return fail(c, PT_ERROR_INVALID_ARGUMENT, "destination too small (12 bytes per owned pixel)");
     (void)hipSetDevice(c->device);
-    launch_pack_feedback(c->neeat.fbW.p, c->neeat.fbC.p, c->dOwned.p, (uint)c->owned.size(), c->width, (ptk::uint2*)dst, c->stream);
+    launch_pack_feedback(c->neeat.fbW.p, c->neeat.fbC.p, c->neeat.depth.p, c->dOwned.p, (uint)c->owned.size(), c->width, (uint*)dst, c->stream);
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }
@@ -860,10 +864,10 @@ int32_t pt_neeat_unpack_feedback(pt_context* c, const void* src, size_t bytes, u
     if (!c || !src || rank >= c->shardCount) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->neeat.enabled || !c->neeat.W || c->neeat.W != c->width || c->neeat.H != c->height) return fail(c, PT_ERROR_NOT_READY, "no NEE-AT frame yet: pt_set_neeat, then pt_render");
     const std::vector<uint>& px = c->shardPixels[rank];
-    if (bytes < px.size() * 8) return fail(c, PT_ERROR_INVALID_ARGUMENT, "source too small");
+    if (bytes < px.size() * 12) return fail(c, PT_ERROR_INVALID_ARGUMENT, "source too small (12 bytes per pixel of that rank)");
     (void)hipSetDevice(c->device);
     DevBuf<uint> tmp; PT_CHECK_HIP(c, tmp.upload(px, c->stream));
-    launch_unpack_feedback(c->neeat.fbW.p, c->neeat.fbC.p, tmp.p, (uint)px.size(), c->width, (const ptk::uint2*)src, c->stream);
+    launch_unpack_feedback(c->neeat.fbW.p, c->neeat.fbC.p, c->neeat.depth.p, tmp.p, (uint)px.size(), c->width, (const uint*)src, c->stream);
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     tmp.free();
     return PT_OK;
@@ -876,7 +880,7 @@ int32_t pt_set_view_projection(pt_context* c, const float* worldToClipRowMajor16
     refresh_scene_view(c);
     return PT_OK;
 }
-int32_t pt_neeat_reset(pt_context* c) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->neeat.reset(); return PT_OK; }
+int32_t pt_neeat_reset(pt_context* c) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->neeat.reset(); c->fbSamples = 0; return PT_OK; }
 int32_t pt_get_neeat_tables(pt_context* c, uint32_t tilesXY[2], uint32_t jitterXY[2], uint32_t* table, uint32_t tableCapacityWords) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     const pt_context::NeeAt& st = c->neeat;
@@ -966,7 +970,7 @@ int32_t pt_set_settings(pt_context* c, const ::PtSettings* s) {
 int32_t pt_resize(pt_context* c, uint32_t w, uint32_t h) {
     if (!c || !w || !h || w > 65535 || h > 65535) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad size");
     (void)hipSetDevice(c->device);
-    c->width = w; c->height = h; c->accumCount = 0;
+    c->width = w; c->height = h; c->accumCount = 0; c->fbSamples = 0;
     build_shards(c);
     PT_CHECK_HIP(c, c->dAccum.resize((size_t)w * h));
     PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)w * h, c->stream));
@@ -1056,6 +1060,20 @@ int32_t pt_animate_normals(pt_context* c, const uint32_t* normals, const uint32_
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }
+// every additive field of PtFrameStats (a call that traces its samples one frame at a time — NEE-AT — reports the sums; maxima stay maxima)
+static void add_frame_stats(PtFrameStats& t, const PtFrameStats& o) {
+    t.extendRays += o.extendRays; t.shadowRays += o.shadowRays; t.hits += o.hits;
+    t.nodeVisitsExtend += o.nodeVisitsExtend; t.triTestsExtend += o.triTestsExtend; t.nodeVisitsShadow += o.nodeVisitsShadow; t.triTestsShadow += o.triTestsShadow;
+    t.leafVisitsExtend += o.leafVisitsExtend; t.waveItersExtend += o.waveItersExtend; t.leafVisitsShadow += o.leafVisitsShadow; t.waveItersShadow += o.waveItersShadow;
+    for (int q = 0; q < 4; q++) t.extendPhaseCycles[q] += o.extendPhaseCycles[q];
+    t.leafBlocksExtend += o.leafBlocksExtend; if (o.waveItersMaxExtend > t.waveItersMaxExtend) t.waveItersMaxExtend = o.waveItersMaxExtend;
+    for (int q = 0; q < 16; q++) t.extendRayIterHist[q] += o.extendRayIterHist[q];
+    for (uint q = 0; q < o.longRayCount && q < 32u && t.longRayCount < 32u; q++) { memcpy(t.longRays[t.longRayCount], o.longRays[q], 32); t.longRayCount++; }
+    for (int q = 0; q < 8; q++) t.extendEvents[q] += o.extendEvents[q];
+    t.gpuMilliseconds += o.gpuMilliseconds; t.extendKernelMs += o.extendKernelMs; t.shadeKernelMs += o.shadeKernelMs; t.shadowKernelMs += o.shadowKernelMs;
+    t.extendLaunches += o.extendLaunches; if (o.iterations > t.iterations) t.iterations = o.iterations;
+    t.pathsTraced += o.pathsTraced; t.tailLaunches += o.tailLaunches;
+}
 int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* stats) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
@@ -1066,11 +1084,9 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         if (count > 1) {
             PtFrameStats total; memset(&total, 0, sizeof(total));
             for (uint32_t s = 0; s < count; s++) {
-                PtFrameStats one; r = pt_render(c, first + s, 1, &one); if (r != PT_OK) return r;
-                total.gpuMilliseconds += one.gpuMilliseconds; total.extendRays += one.extendRays; total.shadowRays += one.shadowRays; total.hits += one.hits; total.extendLaunches += one.extendLaunches;
-                total.extendKernelMs += one.extendKernelMs; total.shadeKernelMs += one.shadeKernelMs; total.shadowKernelMs += one.shadowKernelMs;
-                total.nodeVisitsExtend += one.nodeVisitsExtend; total.triTestsExtend += one.triTestsExtend; total.nodeVisitsShadow += one.nodeVisitsShadow; total.triTestsShadow += one.triTestsShadow;
-                if (one.iterations > total.iterations) total.iterations = one.iterations;
+                PtFrameStats one; r = pt_render(c, first + s, 1, &one);
+                if (r != PT_OK) { if (stats) *stats = total; return r; }      // (the samples before the failing one were accumulated: their counts are reported)
+                add_frame_stats(total, one);
             }
             if (stats) *stats = total;
             return PT_OK;
@@ -1697,26 +1713,26 @@ int32_t pt_gather(pt_context* c) {
     if (total) launch_unpack(c->dAccum.p, c->dGatherPixels.p, (uint)total, c->width, c->dGatherRecv.p, st);
     return PT_OK;
 }
-// The NEE-AT feedback exchange of tile-sharded frames (neeat_exchange_feedback) over HOST memory and the caller's transport: every rank sends the reservoirs of its own
-// pixels to every other rank and receives theirs. Pairs meet in rank order (the lower rank sends first), so blocking transports cannot deadlock.
-int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* totalWeight, uint32_t* candidates, const PtTransport* t) {
-    if (!totalWeight || !candidates || !t || !t->send || !t->recv || !width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
+// The NEE-AT feedback exchange of tile-sharded frames (neeat_exchange_feedback) over HOST memory and the caller's transport: every rank sends the reservoirs and the exported depth of its own
+// pixels (12 bytes each) to every other rank and receives theirs. Pairs meet in rank order (the lower rank sends first), so blocking transports cannot deadlock.
+int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* totalWeight, uint32_t* candidates, float* depth, const PtTransport* t) {
+    if (!totalWeight || !candidates || !depth || !t || !t->send || !t->recv || !width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
     if (world == 1) return PT_OK;
     try {
         std::vector<std::vector<uint>> lists; shard_pixel_lists(width, height, world, lists);
         auto slot = [&](uint px) { return (size_t)(px & 0xFFFFu) * width + (px >> 16); };
         const std::vector<uint>& mine = lists[rank];
-        std::vector<uint> sendbuf(2 * mine.size()), recvbuf;
-        for (size_t i = 0; i < mine.size(); i++) { memcpy(&sendbuf[2 * i], &totalWeight[slot(mine[i])], 4); sendbuf[2 * i + 1] = candidates[slot(mine[i])]; }
+        std::vector<uint> sendbuf(3 * mine.size()), recvbuf;
+        for (size_t i = 0; i < mine.size(); i++) { memcpy(&sendbuf[3 * i], &totalWeight[slot(mine[i])], 4); sendbuf[3 * i + 1] = candidates[slot(mine[i])]; memcpy(&sendbuf[3 * i + 2], &depth[slot(mine[i])], 4); }
         for (uint p = 0; p < world; p++) {
             if (p == rank) continue;
-            recvbuf.resize(2 * lists[p].size());
+            recvbuf.resize(3 * lists[p].size());
             for (int step = 0; step < 2; step++) {
                 const bool sendNow = (rank < p) == (step == 0);
-                if (sendNow) { if (!mine.empty() && t->send(t->user, sendbuf.data(), 8 * mine.size(), p) != 0) return PT_ERROR_IO; }
-                else if (!lists[p].empty() && t->recv(t->user, recvbuf.data(), 8 * lists[p].size(), p) != 0) return PT_ERROR_IO;
+                if (sendNow) { if (!mine.empty() && t->send(t->user, sendbuf.data(), 12 * mine.size(), p) != 0) return PT_ERROR_IO; }
+                else if (!lists[p].empty() && t->recv(t->user, recvbuf.data(), 12 * lists[p].size(), p) != 0) return PT_ERROR_IO;
             }
-            for (size_t i = 0; i < lists[p].size(); i++) { memcpy(&totalWeight[slot(lists[p][i])], &recvbuf[2 * i], 4); candidates[slot(lists[p][i])] = recvbuf[2 * i + 1]; }
+            for (size_t i = 0; i < lists[p].size(); i++) { memcpy(&totalWeight[slot(lists[p][i])], &recvbuf[3 * i], 4); candidates[slot(lists[p][i])] = recvbuf[3 * i + 1]; memcpy(&depth[slot(lists[p][i])], &recvbuf[3 * i + 2], 4); }
         }
         return PT_OK;
     } catch (...) { return PT_ERROR_IO; }

@@ -242,6 +242,15 @@ void fill_data(const PTMaterialHost& m, const bool loaded[5], const uint32_t tex
     out->_padding0 = 42; out->_padding1 = 42.f;       // (the reference writes 42 into both padding words)
 }
 
+// a file without a usable "scenes" entry: its roots are the nodes that are nobody's child (visiting every node as a root would pose a child twice — once under its
+// parent, once with its local transform only — and the second visit would win the recorded world matrices of joints and mesh nodes)
+static std::vector<int> gltf_parentless_nodes(const JValue* nodes) {
+    std::vector<int> roots; if (!nodes) return roots;
+    std::vector<char> hasParent(nodes->size(), 0);
+    for (const JValue& n : nodes->arr) if (const JValue* ch = n.get("children")) for (const JValue& c : ch->arr) { const long k = (long)c.num; if (k >= 0 && (size_t)k < hasParent.size()) hasParent[(size_t)k] = 1; }
+    for (size_t i = 0; i < hasParent.size(); i++) if (!hasParent[i]) roots.push_back((int)i);
+    return roots;
+}
 struct Loader {
     pt_context* ctx; std::string baseDir; JValue root; std::vector<std::vector<uint8_t>> buffers; std::string err;
     std::vector<uint32_t> indices; std::vector<float> positions, uvs; std::vector<uint32_t> normals, tangents;
@@ -524,7 +533,7 @@ int32_t load_gltf_file(const char* path, Loader& L) {
     if (!L.importMeshes()) return PT_ERROR_IO;
     int sceneIdx = L.root.intOr("scene", 0); const JValue* scenes = L.root.get("scenes");
     if (scenes && (size_t)sceneIdx < scenes->size()) { if (const JValue* ns = scenes->arr[sceneIdx].get("nodes")) for (auto& n : ns->arr) L.visit((int)n.num, m4_identity(), 0); }
-    else if (const JValue* nodes = L.root.get("nodes")) for (size_t i = 0; i < nodes->size(); i++) L.visit((int)i, m4_identity(), 0);
+    else for (int r : gltf_parentless_nodes(L.root.get("nodes"))) L.visit(r, m4_identity(), 0);
     return PT_OK;
 }
 } // namespace
@@ -770,7 +779,7 @@ extern "C" int32_t pt_gltf_animation_instances(pt_gltf_animation* a, uint32_t an
         Loader& L = a->L; L.instances.clear(); L.instanceWorld.clear(); L.instancePath.clear(); L.nodeOverride = &ov;
         int sceneIdx = L.root.intOr("scene", 0); const JValue* scenes = L.root.get("scenes");
         if (scenes && (size_t)sceneIdx < scenes->size()) { if (const JValue* ns = scenes->arr[sceneIdx].get("nodes")) for (auto& n : ns->arr) L.visit((int)n.num, m4_identity(), 0); }
-        else if (nodes) for (size_t i = 0; i < nodes->size(); i++) L.visit((int)i, m4_identity(), 0);
+        else for (int r : gltf_parentless_nodes(nodes)) L.visit(r, m4_identity(), 0);
         L.nodeOverride = nullptr;
         const size_t n = L.instances.size() < capacity ? L.instances.size() : capacity;
         if (n) memcpy(out, L.instances.data(), n * sizeof(PtInstanceDesc));

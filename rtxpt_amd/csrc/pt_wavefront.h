@@ -53,8 +53,8 @@ void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, ui
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st);
 void launch_pack(const float4* accum, const uint* ownedPixels, uint numOwned, uint width, float4* dst, hipStream_t st);
 void launch_unpack(float4* accum, const uint* pixels, uint num, uint width, const float4* src, hipStream_t st);
-void launch_pack_feedback(const float* fbW, const uint* fbC, const uint* pixels, uint num, uint width, uint2* dst, hipStream_t st);
-void launch_unpack_feedback(float* fbW, uint* fbC, const uint* pixels, uint num, uint width, const uint2* src, hipStream_t st);
+void launch_pack_feedback(const float* fbW, const uint* fbC, const float* depth, const uint* pixels, uint num, uint width, uint* dst, hipStream_t st);      // 3 words per pixel: weight bits, candidate, depth bits
+void launch_unpack_feedback(float* fbW, uint* fbC, float* depth, const uint* pixels, uint num, uint width, const uint* src, hipStream_t st);
 // EnvMapBaker: lat-long source (sc.envTex) + directional lights -> RGBA16F cube with mips (cube.mipOffset / dim / mipLevels filled by the caller)
 void launch_env_cube_bake(const DeviceScene& sc, const EnvDirectionalLight* lights, uint nLights, uint2* texels, const EnvCube& cube, hipStream_t st);
 void launch_env_cube_compress(uint2* texels, const EnvCube& cube, uint quality, hipStream_t st);      // every level through BC6UCompress.hlsl's encoder (quality 1: EncodeP1; 2: + the two-region modes) and the BC6H decode, in place

@@ -769,20 +769,23 @@ void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, ui
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_probe, dim3(grid_for(n, T8_BLOCK, T8_MAX_BLOCKS)), dim3(T8_BLOCK), 0, st, sc, rays, n, outClosest, outVisible, overflow);
 }
-// the NEE-AT feedback reservoirs of a list of pixels as (weight bits, candidate) pairs: what the ranks of a tile-sharded frame exchange between frames
-__global__ void __launch_bounds__(256) k_pack_feedback(const float* __restrict__ fbW, const uint* __restrict__ fbC, const uint* __restrict__ pixels, uint num, uint width, uint2* __restrict__ dst) {
+// the NEE-AT feedback of a list of pixels as (weight bits, candidate, exported depth bits) triples, 12 bytes per pixel: what the ranks of a tile-sharded frame exchange between
+// frames — the reservoirs AND the depth the baker's reprojection tests (neeat_reproject): a neighbourhood crosses shard borders, so every rank needs every pixel's depth
+__global__ void __launch_bounds__(256) k_pack_feedback(const float* __restrict__ fbW, const uint* __restrict__ fbC, const float* __restrict__ depth, const uint* __restrict__ pixels, uint num, uint width, uint* __restrict__ dst) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= num) return;
-    const uint px = pixels[i], slot = (px & 0xFFFFu) * width + (px >> 16); dst[i] = make_uint2(__float_as_uint(fbW[slot]), fbC[slot]);
+    const uint px = pixels[i], slot = (px & 0xFFFFu) * width + (px >> 16);
+    dst[3u * i] = __float_as_uint(fbW[slot]); dst[3u * i + 1u] = fbC[slot]; dst[3u * i + 2u] = depth ? __float_as_uint(depth[slot]) : 0u;
 }
-__global__ void __launch_bounds__(256) k_unpack_feedback(float* __restrict__ fbW, uint* __restrict__ fbC, const uint* __restrict__ pixels, uint num, uint width, const uint2* __restrict__ src) {
+__global__ void __launch_bounds__(256) k_unpack_feedback(float* __restrict__ fbW, uint* __restrict__ fbC, float* __restrict__ depth, const uint* __restrict__ pixels, uint num, uint width, const uint* __restrict__ src) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= num) return;
-    const uint px = pixels[i], slot = (px & 0xFFFFu) * width + (px >> 16); fbW[slot] = __uint_as_float(src[i].x); fbC[slot] = src[i].y;
+    const uint px = pixels[i], slot = (px & 0xFFFFu) * width + (px >> 16);
+    fbW[slot] = __uint_as_float(src[3u * i]); fbC[slot] = src[3u * i + 1u]; if (depth) depth[slot] = __uint_as_float(src[3u * i + 2u]);
 }
-void launch_pack_feedback(const float* fbW, const uint* fbC, const uint* pixels, uint num, uint width, uint2* dst, hipStream_t st) {
-    if (num) hipLaunchKernelGGL(k_pack_feedback, dim3((num + 255) / 256), dim3(256), 0, st, fbW, fbC, pixels, num, width, dst);
+void launch_pack_feedback(const float* fbW, const uint* fbC, const float* depth, const uint* pixels, uint num, uint width, uint* dst, hipStream_t st) {
+    if (num) hipLaunchKernelGGL(k_pack_feedback, dim3((num + 255) / 256), dim3(256), 0, st, fbW, fbC, depth, pixels, num, width, dst);
 }
-void launch_unpack_feedback(float* fbW, uint* fbC, const uint* pixels, uint num, uint width, const uint2* src, hipStream_t st) {
-    if (num) hipLaunchKernelGGL(k_unpack_feedback, dim3((num + 255) / 256), dim3(256), 0, st, fbW, fbC, pixels, num, width, src);
+void launch_unpack_feedback(float* fbW, uint* fbC, float* depth, const uint* pixels, uint num, uint width, const uint* src, hipStream_t st) {
+    if (num) hipLaunchKernelGGL(k_unpack_feedback, dim3((num + 255) / 256), dim3(256), 0, st, fbW, fbC, depth, pixels, num, width, src);
 }
 void launch_pack(const float4* accum, const uint* pixels, uint num, uint width, float4* dst, hipStream_t st) {
     hipLaunchKernelGGL(k_pack, dim3((num + 255) / 256), dim3(256), 0, st, accum, pixels, num, width, dst);

@@ -87,3 +87,20 @@ def test_files_without_skins_return_their_vertices(tmp_path):
     a = pt.GltfAnimation(tmp_path / "c.gltf")
     assert np.array_equal(a.positions(0.3), sc["positions"])
     a.close()
+
+
+def test_a_file_without_scenes_poses_its_parentless_nodes_only(tmp_path):
+    """No "scenes" entry: the roots are the nodes that are nobody's child. Visiting every node as a root would reach joint j1 a second time with its LOCAL transform only and
+    overwrite the world matrix recorded under its parent chain (root -> j0 -> j1) — the skin would then bend about the wrong pivot — and list the mesh nodes twice."""
+    f, P, W, Wb = _write(tmp_path)
+    doc = json.loads(f.read_text()); del doc["scenes"]; del doc["scene"]
+    doc["nodes"][2]["translation"] = [0.0, 0.25, 0.0]                      # give the joints' parent chain a transform, so that "world" and "local" differ for j1
+    g = tmp_path / "noscenes.gltf"; g.write_text(json.dumps(doc))
+    doc2 = json.loads(f.read_text()); doc2["nodes"][2]["translation"] = [0.0, 0.25, 0.0]
+    h = tmp_path / "withscenes.gltf"; h.write_text(json.dumps(doc2))
+    a, b = pt.GltfAnimation(g), pt.GltfAnimation(h)
+    for t in (0.0, 0.5, 1.0):
+        assert np.array_equal(a.positions(t), b.positions(t)), t
+        ia, ib = a.instances(t), b.instances(t)
+        assert len(ia) == len(ib) == 2 and np.array_equal(ia["transform"], ib["transform"])
+    a.close(); b.close()

@@ -204,3 +204,26 @@ def test_raw_buffer_abi_rejects_out_of_range_indices_and_mesh_ranges():
     g.set_scene(sc)                                    # the context is still usable
     g.set_camera(scenes.bridge_camera(32, 32, **cam)); g.set_settings(scenes.config_settings("C1")); g.resize(32, 32); g.render(0, 1)
     assert np.isfinite(g.radiance()).all()
+
+
+def test_neeat_multi_sample_call_reports_summed_stats_and_feedback_guards():
+    """pt_render(first, count > 1) with the baker in the loop traces one frame per sample: the stats are the sums over the frames (paths traced, ray counts), not those of the
+    last one; and pt_get_light_feedback refuses cleanly while the planes it would read do not exist yet (NEE-AT switched on after a local-table frame, a reset, a resize)."""
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    sc, cam = scenes.bistro_like(scale=0.02, tex_size=64)
+    S = scenes.default_settings(NEEType=2, useFp16Types=1); w, h = 96, 54
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h)
+    t.set_neeat(True)
+    with pytest.raises(Exception): t.light_feedback(0)                      # enabled, nothing rendered yet
+    one = [t.render(s, 1) for s in range(3)]
+    t.neeat_reset(); t.reset_accumulation()
+    with pytest.raises(Exception): t.light_feedback(0)                      # after a reset
+    three = t.render(0, 3)
+    assert three["pathsTraced"] == 3 * w * h
+    for k in ("extendRays", "shadowRays", "hits"): assert three[k] == sum(o[k] for o in one), k
+    t.light_feedback(0)
+    t.resize(64, 36)
+    with pytest.raises(Exception): t.light_feedback(0)                      # another size: no frame of it yet
+    t.render(0, 1); t.light_feedback(0)
+    t.close()

@@ -159,29 +159,37 @@ def test_animated_run_keeps_its_history():
     t.close()
 
 
-def test_tile_sharded_run_equals_the_unsharded_run():
-    """Three ranks of a tile-sharded frame on one device, the host moving the packed reservoirs between frames (pt_neeat_pack_feedback -> pt_neeat_unpack_feedback; with a
-    communicator pt_render does the same through RCCL): every rank ends up with the unsharded run's tile tables, proxy counters and reservoirs on every frame, and the
-    gathered frame is the unsharded frame."""
+@pytest.mark.parametrize("view_projection", [False, True], ids=["same-pixel-history", "view-projection"])
+def test_tile_sharded_run_equals_the_unsharded_run(view_projection):
+    """Three ranks of a tile-sharded frame on one device, the host moving the packed reservoirs and exported depth between frames (pt_neeat_pack_feedback -> pt_neeat_unpack_feedback;
+    with a communicator pt_render does the same through RCCL): every rank ends up with the unsharded run's tile tables, proxy counters and reservoirs on every frame, and the
+    gathered frame is the unsharded frame. With pt_set_view_projection the baker's reprojection compares the exported depth of this frame and the last — also of pixels another
+    rank traced (neighbourhoods cross shard borders): the camera moves between the frames so that pixels do get disoccluded."""
     import torch
     import rtxpt_amd as pt
     sc, cam = scenes.bistro_like(scale=0.02, tex_size=128)
-    S = scenes.default_settings(NEEType=2, useFp16Types=1); w, h, frames, world = 200, 120, 3, 3
-    camd = scenes.bridge_camera(w, h, **cam)
+    S = scenes.default_settings(NEEType=2, useFp16Types=1); w, h, frames, world = 200, 120, 4, 3
+    def camera(f):
+        c = dict(cam)
+        if view_projection: c["pos"] = tuple(np.asarray(cam["pos"], np.float64) + np.array([0.9, 0.05, -0.4]) * f)
+        return c
     def ctx(rank, count):
-        t = pt.PathTracer(shard_rank=rank, shard_count=count); t.set_scene(sc); t.set_settings(S); t.set_camera(camd); t.resize(w, h); t.set_neeat(True); return t
+        t = pt.PathTracer(shard_rank=rank, shard_count=count); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **camera(0))); t.resize(w, h); t.set_neeat(True); return t
     one = ctx(0, 1); ranks = [ctx(r, world) for r in range(world)]
     owned = [r.shard_info() for r in ranks]
     assert sum(n for n, _ in owned) == w * h
     for f in range(frames):
+        for t in [one] + ranks:
+            t.set_camera(scenes.bridge_camera(w, h, **camera(f)))
+            if view_projection: t.set_view_projection(scenes.view_projection(w, h, **camera(f)))
         one.render(f, 1)
         for r in ranks: r.render(f, 1)
         bufs = []
         for r, (n, _) in zip(ranks, owned):
-            b = torch.empty((n, 2), dtype=torch.int32, device="cuda"); r.neeat_pack_feedback(b.data_ptr(), 8 * n); bufs.append(b)
+            b = torch.empty((n, 3), dtype=torch.int32, device="cuda"); r.neeat_pack_feedback(b.data_ptr(), 12 * n); bufs.append(b)
         for i, r in enumerate(ranks):
             for j in range(world):
-                if j != i: r.neeat_unpack_feedback(bufs[j].data_ptr(), 8 * owned[j][0], j)
+                if j != i: r.neeat_unpack_feedback(bufs[j].data_ptr(), 12 * owned[j][0], j)
         t1, j1 = one.neeat_tables(); w1, c1 = one.light_feedback(0); p1 = one.lights()["proxyCounters"]
         for i, r in enumerate(ranks):
             tr, jr = r.neeat_tables(); wr, cr = r.light_feedback(0)

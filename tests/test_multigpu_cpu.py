@@ -92,8 +92,9 @@ def _neeat_worker(rank, world, port, w, h, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     px = pt.shard_layout(w, h, rank, world); yy, xx = (px & 0xFFFF).astype(np.int64), (px >> 16).astype(np.int64)
-    weight = np.full((h, w), -3.0, np.float32); cand = np.full((h, w), 0xDEADBEEF, np.uint32)          # poison outside the owned tiles
+    weight = np.full((h, w), -3.0, np.float32); cand = np.full((h, w), 0xDEADBEEF, np.uint32); depth = np.full((h, w), -7.0, np.float32)          # poison outside the owned tiles
     weight[yy, xx] = (xx * 0.25 + yy).astype(np.float32); cand[yy, xx] = (xx * 7919 + yy * 104729).astype(np.uint32) | np.uint32(0x80000000) * (xx & 1).astype(np.uint32)
+    depth[yy, xx] = (0.5 + xx * 0.001 + yy * 0.37).astype(np.float32)
     sent = []
 
     def send(ptr, nbytes, peer):
@@ -101,9 +102,9 @@ def _neeat_worker(rank, world, port, w, h, q):
 
     def recv(ptr, nbytes, peer):
         t = torch.empty(nbytes, dtype=torch.uint8); dist.recv(t, src=peer); ctypes.memmove(ptr, t.data_ptr(), nbytes)
-    pt.neeat_exchange_host(w, h, rank, world, weight, cand, send, recv)
-    assert sorted(sent) == [(p, 8 * px.size) for p in range(world) if p != rank]      # its own pixels, un-padded, once to every other rank
-    q.put((rank, weight, cand))
+    pt.neeat_exchange_host(w, h, rank, world, weight, cand, depth, send, recv)
+    assert sorted(sent) == [(p, 12 * px.size) for p in range(world) if p != rank]      # its own pixels (weight, candidate, depth), un-padded, once to every other rank
+    q.put((rank, weight, cand, depth))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -119,5 +120,6 @@ def test_neeat_feedback_exchange_through_the_c_entry_point(size, world):
         p.join(60); assert p.exitcode == 0
     yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
     want_w = (xx * 0.25 + yy).astype(np.float32); want_c = (xx * 7919 + yy * 104729).astype(np.uint32) | np.uint32(0x80000000) * (xx & 1).astype(np.uint32)
-    for rank, weight, cand in got:
-        assert np.array_equal(weight, want_w) and np.array_equal(cand, want_c), "rank %d" % rank
+    want_d = (0.5 + xx * 0.001 + yy * 0.37).astype(np.float32)
+    for rank, weight, cand, depth in got:
+        assert np.array_equal(weight, want_w) and np.array_equal(cand, want_c) and np.array_equal(depth, want_d), "rank %d" % rank
