@@ -523,6 +523,23 @@ class Oracle:
 
     def neeat_reset(self): self.L.ptref_neeat_reset(self.h)
 
+    def neeat_feedback(self):
+        """the run's reservoirs as they stand: (total weight float32 [h, w], candidates uint32 [h, w])"""
+        w = np.zeros((self.h_, self.w), np.float32); c = np.zeros((self.h_, self.w), np.uint32)
+        if not self.L.ptref_neeat_get_feedback(self.h, _p(w), _p(c)): raise RuntimeError("no NEE-AT frame yet")
+        return w, c
+
+    def neeat_update_begin(self):
+        """realtime mode: LightsBaker::UpdateBegin, before the frame's build pass (with reference_integrator=True the reference's baker text runs)"""
+        (self.L.refpt_neeat_update_begin if self.reference_integrator else self.L.ptref_neeat_update_begin)(self.h)
+
+    def neeat_update_end(self, depth, motion_vectors):
+        """realtime mode: LightsBaker::UpdateEnd on the build pass's depth [h, w] f32 and screen-space motion vectors [h, w, 4] binary16 bit patterns of THIS frame; the fill passes
+        that follow sample the tiles it leaves and fill the run's reservoirs"""
+        d = np.ascontiguousarray(depth, np.float32); m = np.ascontiguousarray(motion_vectors, np.uint16)
+        assert d.shape == (self.h_, self.w) and m.shape == (self.h_, self.w, 4)
+        (self.L.refpt_neeat_update_end if self.reference_integrator else self.L.ptref_neeat_update_end)(self.h, _p(d), _p(m))
+
     def neeat_tables(self):
         """(tile table uint32 [tilesY, tilesX, 128], jitter (x, y), global proxy counters) of the last frame"""
         txy = np.zeros(2, np.uint32); jxy = np.zeros(2, np.uint32)

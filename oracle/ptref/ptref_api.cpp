@@ -404,8 +404,9 @@ struct NeeAtState {
     bool enabled = false; float globalFeedbackWeight = 0.75f, localRatio = 0.65f, sscThreshold = 0.3f, dropoff = 0.005f, intensityDeltaMul = 64.0f; bool preFilter = true;      // SampleUI.h:158-159, LightsBaker.h:240-253
     uint updateCounter = 0; float jitterF[2] = {0, 0}; uint jitter[2] = {0, 0}, prevJitter[2] = {0, 0};
     bool feedbackFilled = false, lastFeedbackAvailable = false; uint historicTotalLightCount = 0;
+    bool frameOpen = false, frameFeedbackAvailable = false, frameLocalAvailable = false; uint framePrevLightCount = 0;      // between UpdateBegin and UpdateEnd of a frame (realtime mode: the build pass runs in between)
     uint W = 0, H = 0; std::vector<float> fbW, scW, blW, histWeights, curWeights, depth, histDepth; std::vector<uint> fbC, scC, blC, local, counters;      // depth: the last traced frame's export; histDepth: the one before
-    void reset() { updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; historicTotalLightCount = 0; W = H = 0; histWeights.clear(); }
+    void reset() { updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; frameOpen = false; historicTotalLightCount = 0; W = H = 0; histWeights.clear(); }
 };
 // the passes as the oracle restates them (neeat.h), one call per pixel / low-resolution pixel / tile in the order a dispatch would enumerate them (the order does not matter:
 // every pass reads what the previous one wrote and writes only its own slot). The reference-text harness (refpin/hlsl_pt_wrappers.inc) supplies the same interface.
@@ -593,46 +594,58 @@ void ptref_prepare(void* h) { prepare((Context*)h); }
 // One frame of LightsBaker::UpdateBegin + UpdateEnd for the NEE-AT layer (LightsBaker.cpp:943-962, 985-1075, 1186-1213, 1335-1420), ahead of the frame's path tracing:
 // the light set is already baked (static between bakes); what changes from frame to frame is the global proxy table (usage feedback), the tile tables and the jitter.
 extern "C++" {
-template <class Passes> static void neeat_frame(Context* c, Passes& P) {
+// phases: NEEAT_BEGIN = LightsBaker::UpdateBegin (before the frame's G-buffer), NEEAT_END = UpdateEnd (after it, on the frame's depth and motion vectors: Sample.cpp:2491-2494),
+// NEEAT_BOTH = reference mode, where nothing happens in between and UpdateEnd reads what the last traced frame exported (depth == nullptr) with zero motion vectors
+enum { NEEAT_BEGIN = 1, NEEAT_END = 2, NEEAT_BOTH = 3 };
+template <class Passes> static void neeat_frame(Context* c, Passes& P, int phases = NEEAT_BOTH, const float* depth = nullptr, const uint32_t* motion = nullptr) {
     NeeAtState& st = c->neeat; Scene& sc = c->sc;
     const uint N = (uint)sc.lights.size();
     if (!N || sc.proxyIndices.empty()) {            // nothing to sample: NEE does not run, the frame is traced without a local layer
-        sc.localTable.clear(); sc.localResX = sc.localResY = 0; sc.localRatio = 0.f; sc.feedbackRequired = false; st.feedbackFilled = st.lastFeedbackAvailable = false; sc.bindLocalSampling(); return;
+        sc.localTable.clear(); sc.localResX = sc.localResY = 0; sc.localRatio = 0.f; sc.feedbackRequired = false; st.feedbackFilled = st.lastFeedbackAvailable = false; st.frameOpen = false; sc.bindLocalSampling(); return;
     }
-    if (st.historicTotalLightCount && st.historicTotalLightCount != N) st.feedbackFilled = st.lastFeedbackAvailable = false;      // another light set: its indices mean nothing to the old reservoirs and tiles
-    if (st.W != c->w || st.H != c->h) {             // (re)create the textures: LightsBaker::CreateRenderPasses (LightsBaker.cpp:300-345)
-        st.W = c->w; st.H = c->h; const size_t px = (size_t)st.W * st.H, bpx = (size_t)((st.W + 1) / 2) * ((st.H + 1) / 2), tiles = (size_t)((st.W + 7) / 8 + 1) * ((st.H + 7) / 8 + 1);
-        st.fbW.assign(px, 0.f); st.fbC.assign(px, 0xFFFFFFFFu); st.scW.assign(px, 0.f); st.scC.assign(px, 0xFFFFFFFFu); st.blW.assign(bpx, 0.f); st.blC.assign(bpx, 0xFFFFFFFFu);
-        st.local.assign(tiles * RTXPT_LIGHTING_LOCAL_PROXY_COUNT, 0u); st.feedbackFilled = false; st.lastFeedbackAvailable = false; st.depth.assign(px, 0.f); st.histDepth.assign(px, 0.f);
+    if (phases & NEEAT_BEGIN) {
+        if (st.historicTotalLightCount && st.historicTotalLightCount != N) st.feedbackFilled = st.lastFeedbackAvailable = false;      // another light set: its indices mean nothing to the old reservoirs and tiles
+        if (st.W != c->w || st.H != c->h) {             // (re)create the textures: LightsBaker::CreateRenderPasses (LightsBaker.cpp:300-345)
+            st.W = c->w; st.H = c->h; const size_t px = (size_t)st.W * st.H, bpx = (size_t)((st.W + 1) / 2) * ((st.H + 1) / 2), tiles = (size_t)((st.W + 7) / 8 + 1) * ((st.H + 7) / 8 + 1);
+            st.fbW.assign(px, 0.f); st.fbC.assign(px, 0xFFFFFFFFu); st.scW.assign(px, 0.f); st.scC.assign(px, 0xFFFFFFFFu); st.blW.assign(bpx, 0.f); st.blC.assign(bpx, 0xFFFFFFFFu);
+            st.local.assign(tiles * RTXPT_LIGHTING_LOCAL_PROXY_COUNT, 0u); st.feedbackFilled = false; st.lastFeedbackAvailable = false; st.depth.assign(px, 0.f); st.histDepth.assign(px, 0.f);
+        }
+        st.prevJitter[0] = st.jitter[0]; st.prevJitter[1] = st.jitter[1];
+        neeat_advance_jitter(st.updateCounter, st.jitterF, st.jitter);
+        st.updateCounter++;
+        st.frameLocalAvailable = st.lastFeedbackAvailable;      // "if last frame had temporal feedback, it will have had built local (tile) sampling"
+        st.frameFeedbackAvailable = st.feedbackFilled;
+        st.framePrevLightCount = st.historicTotalLightCount; st.historicTotalLightCount = N;
+        st.frameOpen = true;
     }
-    // ---- UpdateBegin
-    st.prevJitter[0] = st.jitter[0]; st.prevJitter[1] = st.jitter[1];
-    neeat_advance_jitter(st.updateCounter, st.jitterF, st.jitter);
-    st.updateCounter++;
-    const bool lastFrameLocalSamplesAvailable = st.lastFeedbackAvailable;      // "if last frame had temporal feedback, it will have had built local (tile) sampling"
-    const bool lastFrameFeedbackAvailable = st.feedbackFilled;
+    if (!st.frameOpen) return;                      // (UpdateEnd without UpdateBegin)
+    const bool lastFrameLocalSamplesAvailable = st.frameLocalAvailable, lastFrameFeedbackAvailable = st.frameFeedbackAvailable;
     NeeAtFrame F; memset(&F, 0, sizeof(F));
     F.W = st.W; F.H = st.H; F.BW = (st.W + 1) / 2; F.BH = (st.H + 1) / 2; F.tilesX = (st.W + 7) / 8 + 1; F.tilesY = (st.H + 7) / 8 + 1;
     F.jitterX = st.jitter[0]; F.jitterY = st.jitter[1]; F.jitterPrevX = st.prevJitter[0]; F.jitterPrevY = st.prevJitter[1];
-    F.updateCounter = st.updateCounter; F.dropoff = st.dropoff; F.totalLightCount = N; F.historicTotalLightCount = st.historicTotalLightCount; st.historicTotalLightCount = N;
+    F.updateCounter = st.updateCounter; F.dropoff = st.dropoff; F.totalLightCount = N; F.historicTotalLightCount = st.framePrevLightCount;
     F.lastFrameFeedbackAvailable = lastFrameFeedbackAvailable ? 1u : 0u; F.lastFrameLocalSamplesAvailable = (lastFrameLocalSamplesAvailable && lastFrameFeedbackAvailable) ? 1u : 0u;
     F.fbW = st.fbW.data(); F.fbC = st.fbC.data(); F.scW = st.scW.data(); F.scC = st.scC.data(); F.blW = st.blW.data(); F.blC = st.blC.data(); F.local = st.local.data();
-    F.depth = st.depth.data(); F.historyDepth = st.histDepth.data(); F.depthDisocclusionThreshold = 1.5f;
-    st.counters.assign(N + 1, 0u); F.perLightCounters = st.counters.data();                                    // ResetLightProxyCounters
+    F.depth = depth ? depth : st.depth.data(); F.motion = (const uint2*)motion; F.historyDepth = st.histDepth.data(); F.depthDisocclusionThreshold = 1.5f;
     const uint totalMaxFeedbackCount = lastFrameFeedbackAvailable ? ((st.W + 7) / 8) * ((st.H + 7) / 8) * 64u : 0u;
-    if (lastFrameFeedbackAvailable) { if (st.preFilter) P.prefilter(F); P.p0(F, totalMaxFeedbackCount); }
-    st.curWeights = sc.lightWeights;                                                                            // ComputeWeights: the baked weight, boosted where a light got brighter
-    if (lastFrameFeedbackAvailable && st.intensityDeltaMul > 0)
-        for (uint i = 0; i < N; i++) st.curWeights[i] = neeat_intensity_delta_boost(st.curWeights[i], i < st.histWeights.size() ? st.histWeights[i] : 0.f, st.intensityDeltaMul);
-    build_light_proxies(sc, c->S.NEEType, st.curWeights, lastFrameFeedbackAvailable ? st.counters.data() : nullptr, totalMaxFeedbackCount, lastFrameFeedbackAvailable ? st.globalFeedbackWeight : 0.f);
-    st.histWeights = st.curWeights;
-    st.lastFeedbackAvailable = lastFrameFeedbackAvailable;
+    if (phases & NEEAT_BEGIN) {
+        st.counters.assign(N + 1, 0u); F.perLightCounters = st.counters.data();                                    // ResetLightProxyCounters
+        if (lastFrameFeedbackAvailable) { if (st.preFilter) P.prefilter(F); P.p0(F, totalMaxFeedbackCount); }
+        st.curWeights = sc.lightWeights;                                                                            // ComputeWeights: the baked weight, boosted where a light got brighter
+        if (lastFrameFeedbackAvailable && st.intensityDeltaMul > 0)
+            for (uint i = 0; i < N; i++) st.curWeights[i] = neeat_intensity_delta_boost(st.curWeights[i], i < st.histWeights.size() ? st.histWeights[i] : 0.f, st.intensityDeltaMul);
+        build_light_proxies(sc, c->S.NEEType, st.curWeights, lastFrameFeedbackAvailable ? st.counters.data() : nullptr, totalMaxFeedbackCount, lastFrameFeedbackAvailable ? st.globalFeedbackWeight : 0.f);
+        st.histWeights = st.curWeights;
+        st.lastFeedbackAvailable = lastFrameFeedbackAvailable;
+    }
+    if (!(phases & NEEAT_END)) return;
+    F.perLightCounters = st.counters.data();
     F.samplingProxyCount = (uint)sc.proxyIndices.size(); F.proxies = sc.proxyIndices.data();
     // ---- UpdateEnd
     P.p1a(F); P.p1b(F); P.p2(F); P.p3(F); P.clear(F);
-    std::fill(st.depth.begin(), st.depth.end(), 0.f);             // Bridge::ExportSurfaceInit of every pixel of the frame about to be traced
-    sc.depthExport = sc.haveClip ? st.depth.data() : nullptr; sc.depthWidth = st.W;
-    st.feedbackFilled = true;
+    if (!depth) std::fill(st.depth.begin(), st.depth.end(), 0.f);             // reference mode: Bridge::ExportSurfaceInit of every pixel of the frame about to be traced
+    sc.depthExport = (sc.haveClip && !depth) ? st.depth.data() : nullptr; sc.depthWidth = st.W;      // (the fill passes of realtime mode export nothing: the build pass wrote this frame's depth)
+    st.feedbackFilled = true; st.frameOpen = false;
     // what the path tracer binds this frame (LightingControlData: ratio 0 until feedback exists)
     sc.localTable = st.local; sc.localResX = F.tilesX; sc.localResY = F.tilesY; sc.localJitterX = st.jitter[0]; sc.localJitterY = st.jitter[1];
     sc.localRatio = lastFrameFeedbackAvailable ? st.localRatio : 0.f; sc.sscThreshold = st.sscThreshold; sc.feedbackRequired = true;
@@ -708,6 +721,10 @@ uint32_t ptref_proxy_counts(uint32_t n, const float* weights, float* weightSumOu
 }
 void ptref_frustum_planes(const float* m16, float* out20) { float p[5][4]; light_frustum_planes_from_viewproj(m16, p); memcpy(out20, p, sizeof(p)); }
 void ptref_neeat_reset(void* h) { ((Context*)h)->neeat.reset(); }
+// realtime mode (Sample.cpp:2438-2516): LightsBaker::UpdateBegin before the build pass, UpdateEnd after it on the frame's depth (float per pixel) and screen-space motion vectors
+// (RGBA16F as the build pass stores them), then the fill passes sample the tiles and fill the reservoirs (ptref_fill_stable_planes). The run's own reservoirs, as in ptref_render.
+void ptref_neeat_update_begin(void* h) { Context* c = (Context*)h; prepare(c); OracleNeeAtPasses passes; neeat_frame(c, passes, NEEAT_BEGIN); }
+void ptref_neeat_update_end(void* h, const float* depth, const uint32_t* motionVectors) { Context* c = (Context*)h; prepare(c); OracleNeeAtPasses passes; neeat_frame(c, passes, NEEAT_END, depth, motionVectors); }
 // PlanarViewConstants::matWorldToClip (row vectors, 16 floats row-major; null: no export): what the reference-mode guide-buffer dump projects the path's last vertex with
 void ptref_set_view_projection(void* h, const float* m16) {
     Scene& sc = ((Context*)h)->sc;
@@ -716,6 +733,11 @@ void ptref_set_view_projection(void* h, const float* m16) {
     sc.bindLocalSampling();
 }
 // the tile tables and the jitter the last frame was traced with, and the global proxy counters
+// the run's own reservoirs as they stand (after a fill pass: what the next frame's UpdateBegin reads)
+int ptref_neeat_get_feedback(void* h, float* totalWeight, uint32_t* candidates) {
+    Context* c = (Context*)h; const NeeAtState& st = c->neeat; if (!st.W || st.fbW.size() != (size_t)st.W * st.H) return 0;
+    memcpy(totalWeight, st.fbW.data(), 4 * st.fbW.size()); memcpy(candidates, st.fbC.data(), 4 * st.fbC.size()); return 1;
+}
 int ptref_neeat_get_tables(void* h, uint32_t* tilesXY, uint32_t* jitterXY, uint32_t* table, uint32_t* proxyCounters) {
     Context* c = (Context*)h; const NeeAtState& st = c->neeat; if (!st.W) return 0;
     if (tilesXY) { tilesXY[0] = (st.W + 7) / 8 + 1; tilesXY[1] = (st.H + 7) / 8 + 1; }
@@ -768,6 +790,7 @@ void ptref_fill_stable_planes(void* h, uint32_t sampleIndex, const StablePlanesP
     {
         RayCounters local; memset(&local, 0, sizeof(local));
         PathTracer pt(c->sc, c->S, c->cam, sampleIndex, &local);
+        if (c->neeat.enabled && c->neeat.fbW.size() == (size_t)c->w * c->h) { pt.fbTotalWeight = c->neeat.fbW.data(); pt.fbCandidates = c->neeat.fbC.data(); pt.fbWidth = c->w; }      // realtime mode with the baker in the loop: the run's own reservoirs
         StablePlanesFiller<PathTracer> f{pt, ctx, sampleIndex};
 #pragma omp for schedule(dynamic, 1) nowait
         for (int y = 0; y < (int)c->h; y++) for (uint32_t x = 0; x < c->w; x++) sp_fill_pixel(f, x, (uint32_t)y);

@@ -602,7 +602,10 @@ static inline float SpecHitTNeighbourhood(const float* texSrc, const float* dept
 // follows the recorded delta tree while its branch id matches (StablePlanesOnScatter), and deposits its radiance — split into a total and a specular average — on the plane it last
 // touched (CommitDenoiserRadiance); emission on the stable branches was already collected by the build pass. One sub-sample per call; the planes' noisy radiance accumulates over the
 // sub-samples of a frame. NEE with one full sample per vertex (the reference's default); the visibility ray is the caller's: HandleHit returns what a visible light adds (SPNeeRequest).
-struct SPNeeRequest { bool valid; float3 origin, dir; float tmax; float4 newL; };      // newL: AccumulatePathRadiance's increment of the path's L, noisy-radiance attenuation applied
+struct SPNeeRequest { bool valid; float3 origin, dir; float tmax; float4 newL;       // newL: AccumulatePathRadiance's increment of the path's L, noisy-radiance attenuation applied
+    // NEE-AT feedback of the visible case (PathTracerNEE.hlsli:266-273; as pt_path.h ShadowRequest): the light (| LFR_SCREEN_SPACE_COHERENT_FLAG) or RTXPT_INVALID_LIGHT_INDEX, its weight, the
+    // random number the reservoir draws, and the Russian-roulette outcome of a path whose light was visible where it differs (bit 0: differs, bit 1: terminates, high half: its RR correction)
+    uint fbLight; float fbWeight, fbRandom; uint rrFix; };
 static inline uint2 SP_Fp32ToFp16(float4 v) { return make_uint2(Fp32ToFp16(make_float2(v.x, v.y)), Fp32ToFp16(make_float2(v.z, v.w))); }      // Packing.hlsli Fp32ToFp16(float4): clamped to +-HLF_MAX
 static inline float4 SP_Fp16ToFp32(uint2 v) { float2 a = Fp16ToFp32(v.x), b = Fp16ToFp32(v.y); return make_float4(a.x, a.y, b.x, b.y); }
 static inline uint BSDFSample_getDeltaLobeIndex(uint lobe) { if ((lobe & Lobe_Delta) == 0u) return 0xFFFFFFFFu; return (lobe & Lobe_Transmission) == 0u ? 1u : 0u; }      // IBSDF.hlsli:55-60
@@ -628,7 +631,20 @@ template <class PT> struct StablePlanesFiller {
         float4 newL = make_float4(radiance, specularRadianceAvg) * sp.C.invSubSampleCount;
         path.SetL(path.GetL() + newL);
     }
-    static void ApplyVisibleLight(PathState& path, const SPNeeRequest& req) { path.SetL(path.GetL() + req.newL); }
+    // the light sample of `req` turned out visible: its radiance lands and — with temporal feedback on — it is offered to the pixel's feedback reservoir (fbTotalWeight / fbCandidates: one slot per
+    // pixel, may be null) and the path continues as the reference's does after drawing that one more random number before the roulette
+    static void ApplyVisibleLight(PathState& path, const SPNeeRequest& req, float* fbTotalWeight = nullptr, uint* fbCandidates = nullptr, uint fbWidth = 0) {
+        path.SetL(path.GetL() + req.newL);
+        if (req.fbLight == RTXPT_INVALID_LIGHT_INDEX) return;
+        if (fbTotalWeight) {
+            const uint slot = (path.id & 0xFFFFu) * fbWidth + (path.id >> 16);
+            LightFeedbackReservoir_Add(fbTotalWeight[slot], fbCandidates[slot], req.fbRandom, req.fbLight & ~LFR_SCREEN_SPACE_COHERENT_FLAG, req.fbWeight, (req.fbLight & LFR_SCREEN_SPACE_COHERENT_FLAG) != 0u);
+        }
+        if (req.rrFix & 1u) {
+            const uint bit = (uint)PF_terminateAtNextBounce << kVertexIndexBitCount;
+            if (req.rrFix & 2u) path.flagsAndVertexIndex |= bit; else { path.flagsAndVertexIndex &= ~bit; path.pack1 = (path.pack1 & 0xFFFF0000u) | (req.rrFix >> 16); }
+        }
+    }
     void ExportSpecHitTStart(const PathState& path) const { sp.B.SpecularHitT[(size_t)(path.id & 0xFFFFu) * sp.C.imageWidth + (path.id >> 16)] = -path.sceneLength; }
     void ExportSpecHitTStop(const PathState& path) const {
         float& t = sp.B.SpecularHitT[(size_t)(path.id & 0xFFFFu) * sp.C.imageWidth + (path.id >> 16)];
@@ -780,7 +796,7 @@ template <class PT> struct StablePlanesFiller {
     }
     // HandleNEE + ProcessLightSample up to the visibility ray (PathTracerNEE.hlsli:185-275, 303-346), one full sample; returns the packed NEEBSDFMISInfo of the vertex
     uint HandleNEE(const PathState& pre, const ShadingData& sd, const StandardBSDF& bsdf, UniformSampleSequenceGenerator& sg, SPNeeRequest& req, float4& neeRadianceAndSpecAvg) const {
-        req.valid = false; neeRadianceAndSpecAvg = make_float4(0, 0, 0, 0);
+        req.valid = false; req.fbLight = RTXPT_INVALID_LIGHT_INDEX; req.fbWeight = req.fbRandom = 0.f; req.rrFix = 0u; neeRadianceAndSpecAvg = make_float4(0, 0, 0, 0);
         const LightSampler lightSampler = SP_light_sampler(pt, pre.id, SP_ssc_heuristic(pt, pre.rayCone.getWidth(), pre.sceneLength));
         const uint fullSamples = pt.S.NEEFullSamples < 63u ? pt.S.NEEFullSamples : 63u;
         const bool hasNonDeltaLobes = (bsdf.getLobes() & Lobe_NonDelta) != 0;
@@ -815,6 +831,11 @@ template <class PT> struct StablePlanesFiller {
             float3 preThp = pre.GetThp();
             radiance = radiance * preThp;
             specAvg *= Average(preThp);
+            if (ls.LightIndex != RTXPT_INVALID_LIGHT_INDEX && lightSampler.IsTemporalFeedbackRequired()) {      // the reservoir update of the visible case (:266-273; radianceAvg is the value before the firefly filter)
+                req.fbLight = ls.LightIndex | (lightSampler.IsScreenSpaceCoherent ? LFR_SCREEN_SPACE_COHERENT_FLAG : 0u);
+                req.fbWeight = lightSampler.FeedbackWeightFromNEE(ls.LightIndex, radianceAvg * Average(preThp));
+                UniformSampleSequenceGenerator after = sg; req.fbRandom = sampleNext1D(after);
+            }
             neeRadianceAndSpecAvg = SP_Fp16ToFp32(SP_Fp32ToFp16(make_float4(0, 0, 0, 0) + make_float4(radiance, specAvg)));      // NEEResult::AccumulateRadiance on the empty result, then GetRadianceAndSpecAvg
         }
         return info.Pack16bit();
@@ -882,7 +903,13 @@ template <class PT> struct StablePlanesFiller {
         } else req.newL = make_float4(0, 0, 0, 0);      // (the visibility ray is traced whatever the sample is worth: the ray counts stay the reference's)
         if (!scatterValid) path.terminate();
         bool shouldTerminate = pt.HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces));
-        shouldTerminate |= pt.HandleRussianRoulette(path, uniformSG);
+        if (req.fbLight != RTXPT_INVALID_LIGHT_INDEX) {       // feedback pending on the visibility test: the visible case has drawn one more number before the roulette (as pt_path.h HandleHit)
+            UniformSampleSequenceGenerator sgVisible = uniformSG; (void)sampleNext1D(sgVisible);
+            PathState visiblePath = path;
+            const bool terminateVisible = shouldTerminate | pt.HandleRussianRoulette(visiblePath, sgVisible);
+            shouldTerminate |= pt.HandleRussianRoulette(path, uniformSG);
+            req.rrFix = (terminateVisible != shouldTerminate ? 1u : 0u) | (terminateVisible ? 2u : 0u) | ((visiblePath.pack1 & 0xFFFFu) << 16);
+        } else shouldTerminate |= pt.HandleRussianRoulette(path, uniformSG);
         if (shouldTerminate) path.setFlag(PF_terminateAtNextBounce);
     }
 };

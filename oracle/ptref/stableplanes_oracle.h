@@ -56,7 +56,7 @@ static inline void sp_fill_pixel(const StablePlanesFiller<PathTracer>& f, uint p
             SPNeeRequest req; f.HandleHit(path, o, d, h.prim, h.t, h.u, h.v, req);
             if (req.valid) {
                 if (counters) counters->shadowRays++;
-                if (trace_visibility(f.pt.sc, req.origin, req.dir, 0.0f, req.tmax, counters ? &counters->nodeVisitsSh : 0, counters ? &counters->triTestsSh : 0)) StablePlanesFiller<PathTracer>::ApplyVisibleLight(path, req);
+                if (trace_visibility(f.pt.sc, req.origin, req.dir, 0.0f, req.tmax, counters ? &counters->nodeVisitsSh : 0, counters ? &counters->triTestsSh : 0)) StablePlanesFiller<PathTracer>::ApplyVisibleLight(path, req, f.pt.fbTotalWeight, f.pt.fbCandidates, f.pt.fbWidth);
             }
         }
     }

@@ -25,8 +25,9 @@ static LightsBakerConstants g_bakerConstants;      // (LightingControlData carri
 static RWTexture2D<float> u_feedbackTotalWeight, u_feedbackTotalWeightScratch, u_feedbackTotalWeightBlended, u_historyDepth;
 static RWTexture2D<uint> u_feedbackCandidates, u_feedbackCandidatesScratch, u_feedbackCandidatesBlended;
 static RWBuffer<uint> u_perLightProxyCounters, u_lightSamplingProxies, u_localSamplingBuffer, u_historyRemapPastToCurrent, u_historyRemapCurrentToPast; static RWBuffer<float> u_lightWeights; static RWBuffer<uint> u_scratchList;
-struct PinMotion { float3 operator[](int2) const { return float3(0, 0, 0); } };
-static RWTexture2D<float> t_depthBuffer; static PinMotion t_motionVectors;      // the depth the path tracer exported last frame; motion vectors: zero in reference mode (Sample.cpp:2494)
+struct PinMotion { const uint* p = nullptr; uint w = 0;      // ScreenMotionVectors as the build pass stored them (RGBA16F, two words per pixel); null: zero — reference mode (Sample.cpp:2494)
+    float3 operator[](int2 c) const { if (!p) return float3(0, 0, 0); const uint* q = p + 2 * ((size_t)c.y * w + (size_t)c.x); return float3(ptref::f16tof32(q[0] & 0xffffu), ptref::f16tof32(q[0] >> 16), ptref::f16tof32(q[1] & 0xffffu)); } };
+static RWTexture2D<float> t_depthBuffer; static PinMotion t_motionVectors;      // reference mode: the depth the path tracer exported last frame, zero motion; realtime mode: the build pass's depth and motion vectors of this frame
 static inline void InterlockedAdd(uint& dst, uint v) { dst += v; }
 // integer vector helpers the passes use (HLSL: clamp on int2; int against uint compares as uint)
 using hl::clamp;

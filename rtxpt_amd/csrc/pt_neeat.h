@@ -12,10 +12,10 @@
 //          P2 (a tile = its 8 x 8 pixels' candidates + 64 blended candidates from a wider disc), P3 (sort by light, count duplicates), Clear (keep 0.5 % of the past)
 //   trace  the frame; visible NEE samples fill the feedback reservoirs again (pt_path.h ShadowRequest, pt_wavefront.hip shadow_visible)
 // What differs from the reference, by necessity:
-//   * nothing about reprojection in REFERENCE mode, which is the mode this path replaces: there the motion vectors are zero (Sample.cpp:2494), history is read at the same
-//     pixel, and Reproject's depth test (:1348-1375) compares what the path tracer itself exported in the last two frames — the clip depth of every path's last vertex
-//     (PathTracer.hlsli:487, 684). Both are restated (neeat_reproject, pt_path.h ExportDepth; the world-to-clip matrix is the host's: pt_set_view_projection). Realtime mode's
-//     motion vectors (a G-buffer pre-pass) are out of scope; a camera cut should be followed by pt_neeat_reset;
+//   * nothing about reprojection: Reproject (:1348-1375) is restated with its motion vectors (neeat_reproject). In REFERENCE mode they are zero (Sample.cpp:2494), history is
+//     read at the same pixel, and the depth test compares what the path tracer itself exported in the last two frames — the clip depth of every path's last vertex
+//     (PathTracer.hlsli:487, 684; pt_path.h ExportDepth; the world-to-clip matrix is the host's: pt_set_view_projection). In REALTIME mode (pt_realtime_frame) the baker's
+//     second half runs between the build pass and the fill passes on the build pass's depth and screen-space motion vectors of the current frame (Sample.cpp:2491-2494);
 //   * PreFilter reads its 3 x 3 neighbourhood from and writes its pick to the SAME textures, groups of 14 x 14 pixels racing with their neighbours' margins (:1129-1180): the
 //     result depends on the order the groups run in. Here every pixel reads the frame's feedback as it was before the pass (a snapshot) — one of the outcomes the
 //     reference can produce, and the only one that does not depend on scheduling;
@@ -54,7 +54,8 @@ struct NeeAtFrame {
     uint* local;                        // u_localSamplingBuffer (tilesX x tilesY x 128)
     const uint* proxies;                // u_lightSamplingProxies (the global sampler, "only for filling in the gaps")
     uint* perLightCounters;             // u_perLightProxyCounters: totalLightCount + 1 words, the last one counts the pixels without a valid candidate
-    const float* depth; float* historyDepth; float depthDisocclusionThreshold;      // t_depthBuffer (what the last traced frame exported), u_historyDepth (the frame before), 1.5 (LightsBaker.h:255)
+    const float* depth; float* historyDepth; float depthDisocclusionThreshold;      // t_depthBuffer (reference mode: what the last traced frame exported; realtime: the build pass's depth of this frame), u_historyDepth (the frame before), 1.5 (LightsBaker.h:255)
+    const uint2* motion;                // t_motionVectors as the build pass stores them (RGBA16F, .xy = screen-space motion in pixels); nullptr = zero (reference mode, Sample.cpp:2494)
 };
 static const uint NEEAT_EARLY_FEEDBACK_TILE_SIZE = 2, NEEAT_WINDOW_SIZE = 8, NEEAT_TOP_UP_SAMPLES = RTXPT_LIGHTING_LOCAL_PROXY_COUNT - NEEAT_WINDOW_SIZE * NEEAT_WINDOW_SIZE;
 
@@ -94,13 +95,30 @@ static inline int neeat_mirror(int c, int maxRes) {                             
     r = r < maxRes ? r : 2 * maxRes - 2 - r;
     return r < 0 ? 0 : (r > maxRes - 1 ? maxRes - 1 : r);
 }
-// Reproject (LightsBaker.hlsl:1348-1375) in reference mode: the motion vectors are zero (Sample.cpp:2494), so history is looked up at the same pixel — int(float(pixel) + 0.5) —
-// and what remains is the depth test between the last two exported frames. The export is the clip depth of each path's LAST vertex (PathTracer.hlsli:487, 684), not of the
-// primary hit, so the test fires wherever two consecutive paths ended at depths more than 1.5 x apart; without a world-to-clip matrix both depths are 0, 0 / 0 compares false, and
-// every pixel is valid. Returns false if "disoccluded".
-static inline bool neeat_reproject(const NeeAtFrame& F, uint x, uint y) {
-    const float historicDepth = F.historyDepth[y * F.W + x], currentDepth = F.depth[y * F.W + x];
-    return !(fmaxf_(historicDepth / currentDepth, currentDepth / historicDepth) > F.depthDisocclusionThreshold);
+// Reproject (LightsBaker.hlsl:1348-1375) with ConvertMotionVectorToPixelSpace (:765-772, PrevOverCurrentViewportSize = 1): where this pixel was last frame — pixel + motion
+// vector, rounded — and whether what was there then is what is here now (the depth of the history frame at the old position against the current depth, 1.5 x apart = disoccluded;
+// off-screen = disoccluded). A disoccluded pixel reads its history at its own position with weight 0.
+//   * REFERENCE mode: the motion vectors are zero (Sample.cpp:2494; F.motion == nullptr), history is read at the same pixel, and the depths are what the path tracer itself
+//     exported in the last two frames — the clip depth of each path's LAST vertex (PathTracer.hlsli:487, 684), so the test fires wherever two consecutive paths ended at depths
+//     more than 1.5 x apart; without a world-to-clip matrix both depths are 0, 0 / 0 compares false, and every pixel is valid;
+//   * REALTIME mode (pt_realtime_frame): F.motion / F.depth are the build pass's ScreenMotionVectors (RGBA16F: .xy in pixels) and Depth of THIS frame (Sample.cpp:2491-2494),
+//     F.historyDepth the depth the Clear pass of the previous frame kept.
+// Returns false if "disoccluded".
+static inline bool neeat_reproject(const NeeAtFrame& F, uint x, uint y, int& hx, int& hy) {
+    float mx = 0.f, my = 0.f;
+    if (F.motion) { const float2 m = Fp16ToFp32(F.motion[y * F.W + x].x); mx = m.x; my = m.y; }
+    const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
+    const float px = (cx + mx) * 1.0f, py = (cy + my) * 1.0f;
+    mx = px - cx; my = py - cy;
+    hx = (int)((float)x + mx + 0.5f); hy = (int)((float)y + my + 0.5f);
+    bool disocclusion = false;
+    if (!(hx >= 0 && hy >= 0 && hx < (int)F.W && hy < (int)F.H)) disocclusion = true;
+    else {
+        const float historicDepth = F.historyDepth[(uint)hy * F.W + (uint)hx], currentDepth = F.depth[y * F.W + x];
+        disocclusion = fmaxf_(historicDepth / currentDepth, currentDepth / historicDepth) > F.depthDisocclusionThreshold;
+    }
+    if (disocclusion) { hx = (int)x; hy = (int)y; }
+    return !disocclusion;
 }
 static inline uint neeat_lsb_address(const NeeAtFrame& F, uint tileX, uint tileY, uint index) { return LLSB_ComputeBaseAddress(tileX, tileY, F.tilesX) + index; }
 
@@ -156,8 +174,9 @@ static inline void neeat_p1a_pixel(const NeeAtFrame& F, uint lx, uint ly) {
             px = px < 0 ? 0 : (px > (int)F.W - 1 ? (int)F.W - 1 : px); py = py < 0 ? 0 : (py > (int)F.H - 1 ? (int)F.H - 1 : py);
             float baseWeight = 1.0f;
             if (x < 0 || y < 0 || x >= T || y >= T) baseWeight = F.dropoff;
-            if (!neeat_reproject(F, (uint)px, (uint)py)) continue;
-            const float sw = F.fbW[(uint)py * F.W + (uint)px]; const uint sc = F.fbC[(uint)py * F.W + (uint)px];
+            int hx, hy;
+            if (!neeat_reproject(F, (uint)px, (uint)py, hx, hy)) continue;
+            const float sw = F.fbW[(uint)hy * F.W + (uint)hx]; const uint sc = F.fbC[(uint)hy * F.W + (uint)hx];
             if (sw != 0) { float rnd = rng.NextFloat(); lfr_merge(w, c, rnd, sw, sc, baseWeight); }
         }
     }
@@ -167,8 +186,9 @@ static inline void neeat_p1a_pixel(const NeeAtFrame& F, uint lx, uint ly) {
 static inline void neeat_p1b_pixel(const NeeAtFrame& F, uint x, uint y) {
     MicroRng rng = MicroRng::make(x, y, F.updateCounter, 4);
     float& w = F.scW[y * F.W + x]; uint& c = F.scC[y * F.W + x];
-    const bool reprojectionValid = neeat_reproject(F, x, y);
-    if (F.lastFrameFeedbackAvailable) lfr_clone_from(w, c, F.fbW[y * F.W + x], F.fbC[y * F.W + x], reprojectionValid ? 1.0f : 0.0f);
+    int hx, hy;
+    const bool reprojectionValid = neeat_reproject(F, x, y, hx, hy);
+    if (F.lastFrameFeedbackAvailable) lfr_clone_from(w, c, F.fbW[(uint)hy * F.W + (uint)hx], F.fbC[(uint)hy * F.W + (uint)hx], reprojectionValid ? 1.0f : 0.0f);
     else { lfr_clear(w, c); c = neeat_sample_light_global(F, rng); return; }
     const uint lx = x / NEEAT_EARLY_FEEDBACK_TILE_SIZE, ly = y / NEEAT_EARLY_FEEDBACK_TILE_SIZE;
     const float bw = F.blW[ly * F.BW + lx]; const uint bc = F.blC[ly * F.BW + lx];
@@ -176,7 +196,7 @@ static inline void neeat_p1b_pixel(const NeeAtFrame& F, uint x, uint y) {
     if (c == RTXPT_INVALID_LIGHT_INDEX) {
         uint res = RTXPT_INVALID_LIGHT_INDEX;
         if (reprojectionValid && F.lastFrameLocalSamplesAvailable) {                                     // SampleLightLocalHistoric (:1332-1345); "no point ... if reprojection isn't valid"
-            const uint tx = (x + F.jitterPrevX) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE, ty = (y + F.jitterPrevY) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE;
+            const uint tx = ((uint)hx + F.jitterPrevX) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE, ty = ((uint)hy + F.jitterPrevY) / RTXPT_LIGHTING_SAMPLING_BUFFER_TILE_SIZE;
             const uint idx = rng.Next() % RTXPT_LIGHTING_LOCAL_PROXY_COUNT;
             res = neeat_remap_past_to_current(F, UnpackMiniListLight(F.local[neeat_lsb_address(F, tx, ty, idx)]));
         }
