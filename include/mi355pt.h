@@ -314,6 +314,12 @@ int32_t pt_denoise_spec_hit_t(pt_context* ctx);
 /* PostProcess.hlsl NO_DENOISER_FINAL_MERGE (Sample.cpp:2764-2765: the realtime frame when no denoiser runs): output colour = stable radiance + every existing plane's noisy radiance
  * (StablePlanesContext::GetAllRadiance), alpha 1 — written into the context's radiance buffer (pt_map_radiance, pt_tonemap, pt_gather read it; it counts as one accumulated sample). */
 int32_t pt_stable_planes_merge(pt_context* ctx);
+/* One frame of the realtime mode with its passes coupled as Sample::PathTrace runs them (Rtxpt/Sample.cpp:2438-2516) and pt_set_neeat on: LightsBaker::UpdateBegin (usage counts, global proxy
+ * table) -> pt_build_stable_planes(sampleIndex) -> LightsBaker::UpdateEnd on THIS frame's depth and screen-space motion vectors — Reproject (LightsBaker.hlsl:1348-1375) finds every pixel's
+ * history where the build pass says it was, and drops it where the depths disagree — -> params->subSampleCount fill passes (sample indices sampleIndex, sampleIndex + 1, ...), whose light samples
+ * come from the tile tables just built and whose visible samples fill the reservoirs the next frame's UpdateBegin reads. Without pt_set_neeat: build + fill passes with the global sampler.
+ * The host calls pt_denoise_spec_hit_t / pt_stable_planes_merge / pt_get_stable_planes afterwards as it needs them. Whole frames only (no tile shards: the baker reads neighbourhoods). */
+int32_t pt_realtime_frame(pt_context* ctx, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* buildStats, PtFrameStats* fillStats);
 /* copies the last pass's buffers to the host; any pointer may be NULL. planeCapacity in records (>= 3 x plane stride); the two RGBA16F targets as 4 binary16 bit patterns per pixel */
 int32_t pt_get_stable_planes(pt_context* ctx, uint32_t* header, PtStablePlane* planes, size_t planeCapacity, uint16_t* stableRadiance, float* depth, float* specularHitT,
                              uint16_t* motionVectors, uint32_t* throughput);

@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_realtime_frame", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -721,6 +721,27 @@ class PathTracer:
         self._chk(g(self.h, _p(out["header"]), _p(out["planes"]), 3 * stride, _p(out["stable_radiance"]), _p(out["depth"]), _p(out["spec_hit_t"]), _p(out["motion_vectors"]), _p(out["throughput"])), "pt_get_stable_planes")
         out["plane_stride"] = stride; out["stats"] = total
         return out
+
+    def get_stable_planes(self):
+        """pt_get_stable_planes: the buffers of the last build / fill / realtime pass (the dict build_stable_planes returns, without stats)"""
+        w, h = self.width, self.height
+        g = self.L.pt_stable_planes_plane_stride; g.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]; g.restype = ctypes.c_int32
+        stride = ctypes.c_uint32(0); self._chk(g(w, h, ctypes.byref(stride)), "pt_stable_planes_plane_stride"); stride = int(stride.value)
+        out = dict(header=np.zeros((4, h, w), np.uint32), planes=np.zeros((3 * stride, 20), np.uint32), stable_radiance=np.zeros((h, w, 4), np.uint16), depth=np.zeros((h, w), np.float32),
+                   spec_hit_t=np.zeros((h, w), np.float32), motion_vectors=np.zeros((h, w, 4), np.uint16), throughput=np.zeros((h, w), np.uint32))
+        g = self.L.pt_get_stable_planes; g.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 5; g.restype = ctypes.c_int32
+        self._chk(g(self.h, _p(out["header"]), _p(out["planes"]), 3 * stride, _p(out["stable_radiance"]), _p(out["depth"]), _p(out["spec_hit_t"]), _p(out["motion_vectors"]), _p(out["throughput"])), "pt_get_stable_planes")
+        out["plane_stride"] = stride
+        return out
+
+    def realtime_frame(self, sample_index, params):
+        """pt_realtime_frame: UpdateBegin -> build pass -> UpdateEnd on this frame's depth and motion vectors -> params.subSampleCount fill passes (with pt_set_neeat: the baker in the loop).
+        Returns (buffers as get_stable_planes, build stats, fill stats)."""
+        prm = np.ascontiguousarray(params); assert prm.dtype.itemsize == 224
+        f = self.L.pt_realtime_frame; f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]; f.restype = ctypes.c_int32
+        b, fl = PtFrameStats(), PtFrameStats()
+        self._chk(f(self.h, int(sample_index), _p(prm), ctypes.byref(b), ctypes.byref(fl)), "pt_realtime_frame")
+        return self.get_stable_planes(), b.as_dict(), fl.as_dict()
 
     def stable_planes_merge(self):
         """pt_stable_planes_merge: the realtime frame without a denoiser (stable + noisy radiance) into the radiance buffer; returns radiance()"""

@@ -105,10 +105,11 @@ struct pt_context {
         bool enabled = false; float globalFeedbackWeight = 0.75f, localRatio = 0.65f, sscThreshold = 0.3f, dropoff = 0.005f, intensityDeltaMul = 64.0f; bool preFilter = true;
         uint updateCounter = 0; float jitterF[2] = {0, 0}; uint jitter[2] = {0, 0}, prevJitter[2] = {0, 0};
         bool feedbackFilled = false, lastFeedbackAvailable = false; uint historicTotalLightCount = 0, W = 0, H = 0, nHist = 0;
+        bool frameOpen = false, frameFeedbackAvailable = false, frameLocalAvailable = false, exportDepth = true; uint framePrevLightCount = 0;      // between UpdateBegin and UpdateEnd of a frame (realtime mode: the build pass runs in between)
         DevBuf<float> fbW, scW, blW, snapW, curW, histW; DevBuf<uint> fbC, scC, blC, snapC, local, counters;
         DevBuf<float> depth, histDepth; bool haveClip = false; float clipZ[4] = {0, 0, 0, 0}, clipW[4] = {0, 0, 0, 0};      // the exported depth of the last traced frame / of the one before; columns 2 and 3 of pt_set_view_projection's matrix
         DevBuf<uint> xSend, xRecv; DevBuf<uint> xPixels; uint xW = 0, xH = 0;      // tile-sharded frames: the exchange of the owned pixels' reservoirs between frames
-        void reset() { W = H = 0; updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
+        void reset() { W = H = 0; updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; frameOpen = false; exportDepth = true; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
         void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); xSend.free(); xRecv.free(); xPixels.free(); depth.free(); histDepth.free(); }
     } neeat;
     DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
@@ -260,7 +261,7 @@ void refresh_scene_view(pt_context* c) {
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
     d.lights.EnvLookupMap = c->dEnvLookup.p; d.lights.EnvLookupDim = c->envLookupDim; d.lights.EnvToWorld = c->envToWorld; d.lights.WorldToEnv = c->envToLocal;
     d.lights.LocalSamplingBuffer = c->localResX ? (c->neeat.enabled ? c->neeat.local.p : c->dLocalTable.p) : nullptr; d.lights.LocalResX = c->localResX; d.lights.LocalResY = c->localResY; d.lights.LocalJitterX = c->localJitterX; d.lights.LocalJitterY = c->localJitterY;
-    d.lights.DepthExport = (c->neeat.enabled && c->neeat.haveClip && c->neeat.W == c->width && c->neeat.H == c->height) ? c->neeat.depth.p : nullptr; d.lights.DepthWidth = c->width;
+    d.lights.DepthExport = (c->neeat.enabled && c->neeat.exportDepth && c->neeat.haveClip && c->neeat.W == c->width && c->neeat.H == c->height) ? c->neeat.depth.p : nullptr; d.lights.DepthWidth = c->width;
     memcpy(d.lights.ClipZ, c->neeat.clipZ, 16); memcpy(d.lights.ClipW, c->neeat.clipW, 16);
     d.lights.LocalToGlobalSampleRatio = c->localResX ? c->localRatio : 0.f; d.lights.ScreenSpaceVsWorldSpaceThreshold = c->sscThreshold; d.lights.TemporalFeedbackRequired = c->feedbackRequired ? 1u : 0u;
     d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.alphaPlanes = c->dAlphaPlanes.p; d.alphaPool = c->dAlphaPool.p; d.shadeTris = c->dShadeTris.p; d.primToSlot = c->bvh.primToSlot; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
@@ -570,48 +571,61 @@ int neeat_exchange_feedback(pt_context* c) {
 }
 // One frame of LightsBaker::UpdateBegin + UpdateEnd for the NEE-AT layer (LightsBaker.cpp:943-962, 985-1075, 1186-1213, 1335-1420) ahead of the frame's path tracing; the
 // order and the constants are spelled out in pt_neeat.h. The light set is the baked one; what changes per frame is the global proxy table, the tile tables and the jitter.
-int neeat_frame(pt_context* c) {
+// phases: NEEAT_BEGIN = LightsBaker::UpdateBegin (before the frame's G-buffer), NEEAT_END = UpdateEnd (after it, on the frame's depth and motion vectors: Sample.cpp:2491-2494; pt_realtime_frame),
+// NEEAT_BOTH = reference mode: nothing happens in between, UpdateEnd reads the depth the last traced frame exported (depth == nullptr) and the motion vectors are zero
+enum { NEEAT_BEGIN = 1, NEEAT_END = 2, NEEAT_BOTH = 3 };
+int neeat_frame(pt_context* c, int phases = NEEAT_BOTH, const float* depth = nullptr, const ptk::uint2* motion = nullptr) {
     pt_context::NeeAt& st = c->neeat;
     const uint N = (uint)c->lights.size();
     if (!N || !c->numProxies) {                     // nothing to sample (no lights, or all of them dark): NEE does not run (LightSampler::IsEmpty), the frame is traced without a local layer
-        c->localResX = c->localResY = c->localJitterX = c->localJitterY = c->localMaxLight = 0; c->localRatio = 0.f; c->feedbackRequired = false; st.feedbackFilled = st.lastFeedbackAvailable = false;
+        c->localResX = c->localResY = c->localJitterX = c->localJitterY = c->localMaxLight = 0; c->localRatio = 0.f; c->feedbackRequired = false; st.feedbackFilled = st.lastFeedbackAvailable = false; st.frameOpen = false;
         refresh_scene_view(c); return PT_OK;
     }
-    if (st.historicTotalLightCount && st.historicTotalLightCount != N) st.feedbackFilled = st.lastFeedbackAvailable = false;      // another light set: its indices mean nothing to the old reservoirs and tiles
     NeeAtFrame F; memset(&F, 0, sizeof(F));
     F.W = c->width; F.H = c->height; F.BW = (F.W + 1) / 2; F.BH = (F.H + 1) / 2; F.tilesX = (F.W + 7) / 8 + 1; F.tilesY = (F.H + 7) / 8 + 1;
     const size_t px = (size_t)F.W * F.H, bpx = (size_t)F.BW * F.BH, tiles = (size_t)F.tilesX * F.tilesY;
-    if (st.W != F.W || st.H != F.H) {               // (re)create the textures: LightsBaker::CreateRenderPasses (LightsBaker.cpp:300-345)
-        st.W = F.W; st.H = F.H; st.feedbackFilled = false; st.lastFeedbackAvailable = false;
-        PT_CHECK_HIP(c, st.fbW.resize(px)); PT_CHECK_HIP(c, st.fbC.resize(px)); PT_CHECK_HIP(c, st.scW.resize(px)); PT_CHECK_HIP(c, st.scC.resize(px)); PT_CHECK_HIP(c, st.snapW.resize(px)); PT_CHECK_HIP(c, st.snapC.resize(px));
-        PT_CHECK_HIP(c, st.blW.resize(bpx)); PT_CHECK_HIP(c, st.blC.resize(bpx)); PT_CHECK_HIP(c, st.local.resize(tiles * RTXPT_LIGHTING_LOCAL_PROXY_COUNT));
-        PT_CHECK_HIP(c, hipMemsetAsync(st.fbW.p, 0, 4 * px, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(st.fbC.p, 0xFF, 4 * px, c->stream));
-        PT_CHECK_HIP(c, st.depth.resize(px)); PT_CHECK_HIP(c, st.histDepth.resize(px));
-        PT_CHECK_HIP(c, hipMemsetAsync(st.depth.p, 0, 4 * px, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(st.histDepth.p, 0, 4 * px, c->stream));
+    if (phases & NEEAT_BEGIN) {
+        if (st.historicTotalLightCount && st.historicTotalLightCount != N) st.feedbackFilled = st.lastFeedbackAvailable = false;      // another light set: its indices mean nothing to the old reservoirs and tiles
+        if (st.W != F.W || st.H != F.H) {               // (re)create the textures: LightsBaker::CreateRenderPasses (LightsBaker.cpp:300-345)
+            st.W = F.W; st.H = F.H; st.feedbackFilled = false; st.lastFeedbackAvailable = false;
+            PT_CHECK_HIP(c, st.fbW.resize(px)); PT_CHECK_HIP(c, st.fbC.resize(px)); PT_CHECK_HIP(c, st.scW.resize(px)); PT_CHECK_HIP(c, st.scC.resize(px)); PT_CHECK_HIP(c, st.snapW.resize(px)); PT_CHECK_HIP(c, st.snapC.resize(px));
+            PT_CHECK_HIP(c, st.blW.resize(bpx)); PT_CHECK_HIP(c, st.blC.resize(bpx)); PT_CHECK_HIP(c, st.local.resize(tiles * RTXPT_LIGHTING_LOCAL_PROXY_COUNT));
+            PT_CHECK_HIP(c, hipMemsetAsync(st.fbW.p, 0, 4 * px, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(st.fbC.p, 0xFF, 4 * px, c->stream));
+            PT_CHECK_HIP(c, st.depth.resize(px)); PT_CHECK_HIP(c, st.histDepth.resize(px));
+            PT_CHECK_HIP(c, hipMemsetAsync(st.depth.p, 0, 4 * px, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(st.histDepth.p, 0, 4 * px, c->stream));
+        }
+        st.prevJitter[0] = st.jitter[0]; st.prevJitter[1] = st.jitter[1];
+        neeat_advance_jitter(st.updateCounter, st.jitterF, st.jitter);
+        st.updateCounter++;
+        st.frameLocalAvailable = st.lastFeedbackAvailable; st.frameFeedbackAvailable = st.feedbackFilled;
+        st.framePrevLightCount = st.historicTotalLightCount; st.historicTotalLightCount = N;
+        st.frameOpen = true;
     }
-    // ---- UpdateBegin
-    st.prevJitter[0] = st.jitter[0]; st.prevJitter[1] = st.jitter[1];
-    neeat_advance_jitter(st.updateCounter, st.jitterF, st.jitter);
-    st.updateCounter++;
-    const bool lastFrameLocalSamplesAvailable = st.lastFeedbackAvailable, lastFrameFeedbackAvailable = st.feedbackFilled;
+    if (!st.frameOpen || st.W != F.W || st.H != F.H) return fail(c, PT_ERROR_NOT_READY, "NEE-AT: UpdateEnd without UpdateBegin of this frame size");
+    const bool lastFrameLocalSamplesAvailable = st.frameLocalAvailable, lastFrameFeedbackAvailable = st.frameFeedbackAvailable;
     F.jitterX = st.jitter[0]; F.jitterY = st.jitter[1]; F.jitterPrevX = st.prevJitter[0]; F.jitterPrevY = st.prevJitter[1];
-    F.updateCounter = st.updateCounter; F.dropoff = st.dropoff; F.totalLightCount = N; F.historicTotalLightCount = st.historicTotalLightCount; st.historicTotalLightCount = N;
+    F.updateCounter = st.updateCounter; F.dropoff = st.dropoff; F.totalLightCount = N; F.historicTotalLightCount = st.framePrevLightCount;
     F.lastFrameFeedbackAvailable = lastFrameFeedbackAvailable ? 1u : 0u; F.lastFrameLocalSamplesAvailable = (lastFrameLocalSamplesAvailable && lastFrameFeedbackAvailable) ? 1u : 0u;
     F.fbW = st.fbW.p; F.fbC = st.fbC.p; F.scW = st.scW.p; F.scC = st.scC.p; F.blW = st.blW.p; F.blC = st.blC.p; F.local = st.local.p;
-    F.depth = st.depth.p; F.historyDepth = st.histDepth.p; F.depthDisocclusionThreshold = 1.5f;
-    PT_CHECK_HIP(c, st.counters.resize(N + 1)); PT_CHECK_HIP(c, hipMemsetAsync(st.counters.p, 0, 4 * (size_t)(N + 1), c->stream)); F.perLightCounters = st.counters.p;      // ResetLightProxyCounters
+    F.depth = depth ? depth : st.depth.p; F.motion = motion; F.historyDepth = st.histDepth.p; F.depthDisocclusionThreshold = 1.5f;
     const uint totalMaxFeedbackCount = lastFrameFeedbackAvailable ? ((F.W + 7) / 8) * ((F.H + 7) / 8) * 64u : 0u;
-    if (lastFrameFeedbackAvailable) launch_neeat_begin(F, st.snapW.p, st.snapC.p, st.preFilter, totalMaxFeedbackCount, c->stream);
-    PT_CHECK_HIP(c, st.curW.resize(N + 1)); PT_CHECK_HIP(c, st.histW.resize(N));
-    launch_neeat_boost_weights(c->dLightW.p, (lastFrameFeedbackAvailable && st.intensityDeltaMul > 0) ? st.histW.p : nullptr, st.nHist, N, st.intensityDeltaMul, st.curW.p, c->stream);
-    int r = build_light_proxies(c, st.curW.p, lastFrameFeedbackAvailable ? st.counters.p : nullptr, totalMaxFeedbackCount, lastFrameFeedbackAvailable ? st.globalFeedbackWeight : 0.f); if (r != PT_OK) return r;
-    PT_CHECK_HIP(c, hipMemcpyAsync(st.histW.p, st.curW.p, 4 * (size_t)N, hipMemcpyDeviceToDevice, c->stream)); st.nHist = N;
-    st.lastFeedbackAvailable = lastFrameFeedbackAvailable;
+    if (phases & NEEAT_BEGIN) {
+        PT_CHECK_HIP(c, st.counters.resize(N + 1)); PT_CHECK_HIP(c, hipMemsetAsync(st.counters.p, 0, 4 * (size_t)(N + 1), c->stream)); F.perLightCounters = st.counters.p;      // ResetLightProxyCounters
+        if (lastFrameFeedbackAvailable) launch_neeat_begin(F, st.snapW.p, st.snapC.p, st.preFilter, totalMaxFeedbackCount, c->stream);
+        PT_CHECK_HIP(c, st.curW.resize(N + 1)); PT_CHECK_HIP(c, st.histW.resize(N));
+        launch_neeat_boost_weights(c->dLightW.p, (lastFrameFeedbackAvailable && st.intensityDeltaMul > 0) ? st.histW.p : nullptr, st.nHist, N, st.intensityDeltaMul, st.curW.p, c->stream);
+        int r = build_light_proxies(c, st.curW.p, lastFrameFeedbackAvailable ? st.counters.p : nullptr, totalMaxFeedbackCount, lastFrameFeedbackAvailable ? st.globalFeedbackWeight : 0.f); if (r != PT_OK) return r;
+        PT_CHECK_HIP(c, hipMemcpyAsync(st.histW.p, st.curW.p, 4 * (size_t)N, hipMemcpyDeviceToDevice, c->stream)); st.nHist = N;
+        st.lastFeedbackAvailable = lastFrameFeedbackAvailable;
+    }
+    if (!(phases & NEEAT_END)) { PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); return PT_OK; }
+    F.perLightCounters = st.counters.p;
     F.samplingProxyCount = c->numProxies; F.proxies = c->dProxyIndices.p;
     // ---- UpdateEnd
     launch_neeat_end(F, c->stream);
-    PT_CHECK_HIP(c, hipMemsetAsync(st.depth.p, 0, 4 * px, c->stream));      // Bridge::ExportSurfaceInit of every pixel of the frame about to be traced
-    st.feedbackFilled = true;
+    if (!depth) PT_CHECK_HIP(c, hipMemsetAsync(st.depth.p, 0, 4 * px, c->stream));      // reference mode: Bridge::ExportSurfaceInit of every pixel of the frame about to be traced
+    st.exportDepth = depth == nullptr;                                                    // (the fill passes of realtime mode export nothing: the build pass wrote this frame's depth)
+    st.feedbackFilled = true; st.frameOpen = false;
     // what the path tracer binds this frame (the local layer is sampled only once feedback exists: LightsBaker.cpp:1048)
     c->localResX = F.tilesX; c->localResY = F.tilesY; c->localJitterX = st.jitter[0]; c->localJitterY = st.jitter[1]; c->localMaxLight = 0;
     c->localRatio = lastFrameFeedbackAvailable ? st.localRatio : 0.f; c->sscThreshold = st.sscThreshold; c->feedbackRequired = true;
@@ -1332,7 +1346,11 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
     if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
     if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes first");
     if (c->S.NEEEnabled && c->S.NEEFullSamples > 1u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill pass traces one full NEE sample per vertex (NEEFullSamples 0 or 1, the reference's default)");
-    if (c->neeat.enabled || c->feedbackRequired) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill pass does not feed NEE-AT's reservoirs: switch the temporal feedback off (local sampling tables alone are fine)");
+    // temporal feedback: with the baker in the loop (pt_set_neeat + pt_realtime_frame) the pass's visible light samples fill the run's reservoirs; a host that runs its own baker
+    // (pt_set_local_light_sampling with temporalFeedback) gets its per-sample planes from pt_render only
+    const bool feedback = c->neeat.enabled && c->feedbackRequired && c->S.NEEEnabled && c->S.NEEFullSamples != 0u;
+    if (c->feedbackRequired && !c->neeat.enabled) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill pass feeds NEE-AT's reservoirs only with the baker in the loop (pt_set_neeat, pt_realtime_frame): switch the temporal feedback of pt_set_local_light_sampling off");
+    if (feedback && (!c->neeat.fbW.p || c->neeat.W != c->width || c->neeat.H != c->height)) return fail(c, PT_ERROR_NOT_READY, "NEE-AT: no baker frame of this size yet (pt_realtime_frame runs it)");
     (void)hipSetDevice(c->device);
     int r = prepare(c); if (r != PT_OK) return r;
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -1341,6 +1359,7 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
     r = ensure_pool(c, numOwned, 1u); if (r != PT_OK) return r;
     const bool freshMark = c->dSpMark.n < numOwned;
     PT_CHECK_HIP(c, c->dSpMark.resize(numOwned)); PT_CHECK_HIP(c, c->dSpNewL.resize(numOwned));
+    if (feedback) PT_CHECK_HIP(c, c->dSq3.resize(c->shadowCapacity));
     if (freshMark) PT_CHECK_HIP(c, hipMemsetAsync(c->dSpMark.p, 0, sizeof(ptk::uint4) * c->dSpMark.n, c->stream));      // (k_sp_fill_resolve clears what a pass marked)
     ptk::StablePlanesParams prm; memcpy(&prm, params, sizeof(prm));
     StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
@@ -1360,6 +1379,9 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
         t.pool = PathPool{c->dS0.p + base, c->dS1.p + base, c->dS2.p + base, c->dS3.p + base, c->dS4.p + base, c->dHit.p + base};
         t.markPool = t.pool; t.markPool.s2 = c->dSpMark.p + base; t.newL = c->dSpNewL.p + base;
         t.sq = ShadowQueue{c->dSq0.p + base, c->dSq1.p + base, c->dSq2.p + base, 0u, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+        // feedback: the fourth word group of an entry and the reservoir planes; the reference mode's shadow kernels then apply the reservoir update and the roulette fix-up of a visible entry
+        // themselves (pt_wavefront.hip shadow_visible; one slot per pixel: plane stride 0)
+        if (feedback) { t.sq.q3 = c->dSq3.p + base; t.sq.fbTotalWeight = c->neeat.fbW.p; t.sq.fbCandidates = c->neeat.fbC.p; t.sq.fbWidth = c->width; t.sq.fbPlane = 0u; t.sq.fbSampleFirst = 0u; }
         t.queue[0] = c->dQueue[0].p + base; t.queue[1] = c->dQueue[1].p + base;
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;
@@ -1427,6 +1449,25 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
     if (active) return fail(c, PT_ERROR_HIP, "stable-plane fill pass: paths still alive after the iteration bound");
+    return PT_OK;
+}
+// The realtime mode's frame with everything coupled (Sample.cpp:2438-2516; pt_set_neeat on): LightsBaker::UpdateBegin -> build pass -> LightsBaker::UpdateEnd on THAT frame's depth and
+// screen-space motion vectors -> the fill passes, which sample the tables just made and fill the reservoirs the next frame's UpdateBegin reads.
+int32_t pt_realtime_frame(pt_context* c, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* buildStats, PtFrameStats* fillStats) {
+    if (!c || !params) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    if (c->shardCount > 1) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_realtime_frame: the baker reads the whole frame's depth, motion vectors and reservoirs — tile-sharded ranks run pt_build_stable_planes / pt_fill_stable_planes and gather the plane buffers (pt_pack_stable_planes)");
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    const bool baker = c->neeat.enabled && c->S.NEEEnabled && c->S.NEEFullSamples != 0u;
+    if (baker) { r = neeat_frame(c, NEEAT_BEGIN); if (r != PT_OK) return r; }
+    r = pt_build_stable_planes(c, sampleIndex, params, buildStats); if (r != PT_OK) return r;
+    if (baker) { r = neeat_frame(c, NEEAT_END, c->dSpDepth.p, c->dSpMotion.p); if (r != PT_OK) return r; }
+    const uint32_t subSamples = params->subSampleCount ? params->subSampleCount : 1u;
+    PtFrameStats total; memset(&total, 0, sizeof(total));
+    for (uint32_t s = 0; s < subSamples; s++) { PtFrameStats one; r = pt_fill_stable_planes(c, sampleIndex + s, params, &one); if (r != PT_OK) return r; add_frame_stats(total, one); }
+    if (fillStats) *fillStats = total;
+    if (baker && c->feedbackRequired) c->fbSamples = 1;      // pt_get_light_feedback(0): the reservoirs as the fill passes left them
     return PT_OK;
 }
 int32_t pt_stable_planes_merge(pt_context* c) {

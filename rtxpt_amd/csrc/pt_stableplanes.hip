@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(256) k_sp_fill_shade(PKC k, StablePlanesContex
         sq.q0[s] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
         sq.q1[s] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
         sq.q2[s] = make_float4(1.0f, 0.f, 0.f, 0.f);      // the mark a visible entry leaves in the scratch L
+        if (sq.q3) sq.q3[s] = make_float4(req.fbWeight, req.fbRandom, asfloat(req.fbLight), asfloat(req.rrFix));      // NEE-AT feedback of the visible case: applied by the shadow kernels (shadow_visible)
         newL[s] = req.newL;
     }
 }

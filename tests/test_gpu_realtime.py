@@ -1,0 +1,56 @@
+"""The realtime mode's coupled frame on the device (run with -m gpu): pt_realtime_frame — LightsBaker::UpdateBegin, the stable-plane build pass, UpdateEnd on that frame's depth and motion
+vectors, the fill passes feeding the feedback reservoirs — against the runs the REFERENCE'S TEXT produced (tests/golden/realtime_golden.npz; no oracle code in the loop): every frame's tile
+tables, jitter, global proxy counters, reservoirs, noisy radiance, specular hit distances, depth, motion vectors and header, bit for bit, and the ray counts of the whole run."""
+import os, sys
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import realtime_cases as rc
+from rtxpt_amd import scenes
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "realtime_golden.npz")
+
+
+def _same(a, b): return np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+
+
+@pytest.mark.parametrize("name", list(rc.cases()))
+def test_device_matches_the_reference_text_run(name):
+    import rtxpt_amd as pt
+    g = np.load(GOLDEN)
+    make, _, w, h, frames, subs, step, kw = rc.cases()[name]; S = rc.settings_for(name)
+    sc, cam = make()
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h); t.set_neeat(True)
+    rays = [0, 0]
+    for f in range(frames):
+        cur, prev = rc.camera(cam, step, f), rc.camera(cam, step, max(f - 1, 0))
+        prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cur), prev_world_to_clip=scenes.view_projection(w, h, **prev), sub_samples=subs, **kw)
+        t.set_camera(scenes.bridge_camera(w, h, **cur))
+        frame, bst, fst = t.realtime_frame(f * subs, prm)
+        rays[0] += int(bst["extendRays"]) + int(fst["extendRays"]); rays[1] += int(fst["shadowRays"])
+        tab, jit = t.neeat_tables(); fw, fc = t.light_feedback(0)
+        got = dict(table=tab, jitter=np.array(jit, np.uint32), counters=t.lights()["proxyCounters"], fbw=fw, fbc=fc, noisy=rc.live_noisy(frame, w, h), spec_hit_t=frame["spec_hit_t"],
+                   depth=frame["depth"], motion_vectors=frame["motion_vectors"], header=frame["header"])
+        for k, v in got.items():
+            want = g["%s_%s%d" % (name, k, f)]
+            assert _same(v, want), "%s frame %d: %s differs (%d of %d words)" % (name, f, k, int((np.asarray(v).view(np.uint8) != np.asarray(want).view(np.uint8)).sum()), np.asarray(want).view(np.uint8).size)
+    assert rays == [int(x) for x in g[name + "_rays"]]
+    t.close()
+
+
+def test_realtime_frame_without_the_baker_and_refusals():
+    """pt_set_neeat off: build + fill with the global sampler == the separate calls; tile shards are refused (the baker reads whole neighbourhoods)."""
+    import rtxpt_amd as pt
+    sc, cam = scenes.stable_planes_zoo(); S = scenes.config_settings("C2"); w, h = 64, 48
+    prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cam), sub_samples=2)
+    a = pt.PathTracer(); a.set_scene(sc); a.set_settings(S); a.set_camera(scenes.bridge_camera(w, h, **cam)); a.resize(w, h)
+    fa, _, _ = a.realtime_frame(3, prm)
+    b = pt.PathTracer(); b.set_scene(sc); b.set_settings(S); b.set_camera(scenes.bridge_camera(w, h, **cam)); b.resize(w, h)
+    b.build_stable_planes(3, prm); fb = b.fill_stable_planes(3, prm, sub_samples=2)
+    for k in ("header", "planes", "spec_hit_t", "depth", "motion_vectors", "stable_radiance", "throughput"): assert _same(fa[k], fb[k]), k
+    a.close(); b.close()
+    c = pt.PathTracer(shard_rank=0, shard_count=2); c.set_scene(sc); c.set_settings(S); c.set_camera(scenes.bridge_camera(w, h, **cam)); c.resize(w, h)
+    with pytest.raises(Exception): c.realtime_frame(0, prm)
+    c.close()
