@@ -314,6 +314,16 @@ int32_t pt_denoise_spec_hit_t(pt_context* ctx);
 /* PostProcess.hlsl NO_DENOISER_FINAL_MERGE (Sample.cpp:2764-2765: the realtime frame when no denoiser runs): output colour = stable radiance + every existing plane's noisy radiance
  * (StablePlanesContext::GetAllRadiance), alpha 1 — written into the context's radiance buffer (pt_map_radiance, pt_tonemap, pt_gather read it; it counts as one accumulated sample). */
 int32_t pt_stable_planes_merge(pt_context* ctx);
+/* Tile-sharded realtime frames (PtDeviceDesc.shardCount > 1; no reference analogue): every rank builds and fills the planes of its own tiles, the rank that denoises or shows the frame needs
+ * them all. Per pixel 284 bytes travel: the four header words, the three 80-byte plane records, stable radiance, depth, specular hit distance, motion vectors, throughput.
+ * pt_gather_stable_planes: with a communicator (pt_comm_init) every rank sends its records to rank 0 — RCCL point-to-point in one group, un-padded, on the library's stream, like pt_gather (a
+ * world of one runs the protocol as a loop-back). Without one the host moves pt_pack_stable_planes' buffer (device memory, pt_stable_planes_shard_bytes(rank) bytes, the rank's pixels in
+ * pt_pack_shard's order) and hands it to pt_unpack_stable_planes(buffer, rank) on the receiving context, which must have run a build pass of that size. pt_denoise_spec_hit_t is then allowed
+ * on a sharded context. (When only the picture is needed: pt_stable_planes_merge on every rank, then pt_gather, moves 16 bytes per pixel instead.) */
+int32_t pt_stable_planes_shard_bytes(pt_context* ctx, uint32_t rank, size_t* bytes);
+int32_t pt_pack_stable_planes(pt_context* ctx, void* dstDevice, size_t bytes);
+int32_t pt_unpack_stable_planes(pt_context* ctx, const void* srcDevice, size_t bytes, uint32_t rank);
+int32_t pt_gather_stable_planes(pt_context* ctx);
 /* One frame of the realtime mode with its passes coupled as Sample::PathTrace runs them (Rtxpt/Sample.cpp:2438-2516) and pt_set_neeat on: LightsBaker::UpdateBegin (usage counts, global proxy
  * table) -> pt_build_stable_planes(sampleIndex) -> LightsBaker::UpdateEnd on THIS frame's depth and screen-space motion vectors — Reproject (LightsBaker.hlsl:1348-1375) finds every pixel's
  * history where the build pass says it was, and drops it where the depths disagree — -> params->subSampleCount fill passes (sample indices sampleIndex, sampleIndex + 1, ...), whose light samples

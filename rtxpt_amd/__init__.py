@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_realtime_frame", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_realtime_frame", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -733,6 +733,22 @@ class PathTracer:
         self._chk(g(self.h, _p(out["header"]), _p(out["planes"]), 3 * stride, _p(out["stable_radiance"]), _p(out["depth"]), _p(out["spec_hit_t"]), _p(out["motion_vectors"]), _p(out["throughput"])), "pt_get_stable_planes")
         out["plane_stride"] = stride
         return out
+
+    def stable_planes_shard_bytes(self, rank):
+        f = self.L.pt_stable_planes_shard_bytes; f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]; f.restype = ctypes.c_int32
+        n = ctypes.c_size_t(0); self._chk(f(self.h, int(rank), ctypes.byref(n)), "pt_stable_planes_shard_bytes"); return int(n.value)
+
+    def pack_stable_planes(self, device_ptr, nbytes):
+        f = self.L.pt_pack_stable_planes; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]; f.restype = ctypes.c_int32
+        self._chk(f(self.h, ctypes.c_void_p(device_ptr), nbytes), "pt_pack_stable_planes")
+
+    def unpack_stable_planes(self, device_ptr, nbytes, rank):
+        f = self.L.pt_unpack_stable_planes; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]; f.restype = ctypes.c_int32
+        self._chk(f(self.h, ctypes.c_void_p(device_ptr), nbytes, int(rank)), "pt_unpack_stable_planes")
+
+    def gather_stable_planes(self):
+        f = self.L.pt_gather_stable_planes; f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_int32
+        self._chk(f(self.h), "pt_gather_stable_planes")
 
     def realtime_frame(self, sample_index, params):
         """pt_realtime_frame: UpdateBegin -> build pass -> UpdateEnd on this frame's depth and motion vectors -> params.subSampleCount fill passes (with pt_set_neeat: the baker in the loop).

@@ -123,7 +123,7 @@ struct pt_context {
     double buildMs = 0, refitMs = 0, lightBakeMs = 0;
     uint poolCapacity = 0; size_t shadowCapacity = 0;
     // stable planes (pt_build_stable_planes): the realtime mode's per-frame buffers (RenderTargets.cpp:60-141, 340-352) of the last pre-pass
-    DevBuf<uint> dSpHeader, dSpThroughput; DevBuf<ptk::StablePlane> dSpPlanes; DevBuf<ptk::uint2> dSpRadiance, dSpMotion; DevBuf<float> dSpDepth, dSpHitT; uint spW = 0, spH = 0; DevBuf<ptk::uint4> dSpMark; DevBuf<ptk::float4> dSpNewL; DevBuf<float> dSpScratch;      // (the last two: scratch of the fill passes)
+    DevBuf<uint> dSpHeader, dSpThroughput; DevBuf<ptk::StablePlane> dSpPlanes; DevBuf<ptk::uint2> dSpRadiance, dSpMotion; DevBuf<float> dSpDepth, dSpHitT; uint spW = 0, spH = 0; DevBuf<ptk::uint4> dSpMark; DevBuf<ptk::float4> dSpNewL; DevBuf<float> dSpScratch; DevBuf<uint> dSpGatherSend, dSpGatherRecv, dSpGatherPixels; bool spGathered = false;      // (the last two: scratch of the fill passes)
     // frame gather (pt_comm_init / pt_gather)
     ncclComm_t comm = nullptr; uint commRank = 0, commWorld = 0; DevBuf<ptk::float4> dGatherSend, dGatherRecv; DevBuf<uint> dGatherPixels; std::vector<size_t> gatherCounts; uint gatherW = 0, gatherH = 0;
 };
@@ -673,7 +673,7 @@ int32_t pt_destroy(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
-    c->dSpHeader.free(); c->dSpThroughput.free(); c->dSpPlanes.free(); c->dSpRadiance.free(); c->dSpMotion.free(); c->dSpDepth.free(); c->dSpHitT.free(); c->dSpMark.free(); c->dSpNewL.free(); c->dSpScratch.free();
+    c->dSpHeader.free(); c->dSpThroughput.free(); c->dSpPlanes.free(); c->dSpRadiance.free(); c->dSpMotion.free(); c->dSpDepth.free(); c->dSpHitT.free(); c->dSpMark.free(); c->dSpNewL.free(); c->dSpScratch.free(); c->dSpGatherSend.free(); c->dSpGatherRecv.free(); c->dSpGatherPixels.free();
     c->neeat.free(); c->dLocalTable.free(); c->dFbWeight.free(); c->dFbCand.free(); c->dSq3.free();
     c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free(); c->dLightW.free(); c->dProxyOffsets.free(); if (c->dScanTemp) (void)hipFree(c->dScanTemp);
     if (c->bvhAllocated) bvh_free(c->bvh);
@@ -1305,6 +1305,7 @@ int32_t pt_build_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStab
         c->spW = c->width; c->spH = c->height;
     }
     sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p; sp.B.Depth = c->dSpDepth.p; sp.B.SpecularHitT = c->dSpHitT.p; sp.B.MotionVectors = c->dSpMotion.p; sp.B.Throughput = c->dSpThroughput.p;
+    c->spGathered = false;
     if (!numOwned) return PT_OK;
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
     PathPool pool{c->dS0.p, c->dS1.p, c->dS2.p, c->dS3.p, c->dS4.p, c->dHit.p};
@@ -1483,10 +1484,89 @@ int32_t pt_stable_planes_merge(pt_context* c) {
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); PT_CHECK_HIP(c, hipGetLastError());
     return PT_OK;
 }
+// ---- the plane buffers of tile-sharded frames (no reference analogue): every rank builds and fills the planes of its own tiles; the rank that denoises or shows the frame needs them all.
+// 284 bytes per pixel (SP_SHARD_WORDS): header, three plane records, stable radiance, depth, specular hit distance, motion vectors, throughput.
+static StablePlanesContext sp_buffers(pt_context* c) {
+    ptk::StablePlanesParams prm; memset(&prm, 0, sizeof(prm)); prm.activeStablePlaneCount = cStablePlaneCount;
+    StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
+    sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p; sp.B.Depth = c->dSpDepth.p; sp.B.SpecularHitT = c->dSpHitT.p; sp.B.MotionVectors = c->dSpMotion.p; sp.B.Throughput = c->dSpThroughput.p;
+    return sp;
+}
+int32_t pt_stable_planes_shard_bytes(pt_context* c, uint32_t rank, size_t* bytes) {
+    if (!c || !bytes || rank >= c->shardCount || !c->width) return PT_ERROR_INVALID_ARGUMENT;
+    *bytes = c->shardPixels[rank].size() * (size_t)SP_SHARD_WORDS * 4u; return PT_OK;
+}
+int32_t pt_pack_stable_planes(pt_context* c, void* dst, size_t bytes) {
+    if (!c || !dst) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes");
+    if (bytes < c->owned.size() * (size_t)SP_SHARD_WORDS * 4u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "destination too small (pt_stable_planes_shard_bytes)");
+    (void)hipSetDevice(c->device);
+    launch_sp_pack(sp_buffers(c), c->dOwned.p, (uint)c->owned.size(), (uint*)dst, false, c->stream);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); PT_CHECK_HIP(c, hipGetLastError());
+    return PT_OK;
+}
+int32_t pt_unpack_stable_planes(pt_context* c, const void* src, size_t bytes, uint32_t rank) {
+    if (!c || !src || rank >= c->shardCount) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes (it allocates the buffers)");
+    const std::vector<uint>& px = c->shardPixels[rank];
+    if (bytes < px.size() * (size_t)SP_SHARD_WORDS * 4u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "source too small (pt_stable_planes_shard_bytes)");
+    (void)hipSetDevice(c->device);
+    DevBuf<uint> tmp; PT_CHECK_HIP(c, tmp.upload(px, c->stream));
+    launch_sp_pack(sp_buffers(c), tmp.p, (uint)px.size(), (uint*)src, true, c->stream);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); PT_CHECK_HIP(c, hipGetLastError());
+    tmp.free();
+    c->spGathered = true;      // (the host says when all ranks are in: pt_denoise_spec_hit_t trusts it from here on)
+    return PT_OK;
+}
+// pt_gather for the plane buffers: every rank sends its tiles' records to rank 0 (RCCL point-to-point inside one group, un-padded, on the library's stream); a world of one with a
+// communicator runs the protocol as a loop-back with the buffers poisoned in between, like pt_gather
+int32_t pt_gather_stable_planes(pt_context* c) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes");
+    if (c->shardCount == 1 && !c->comm) return PT_OK;
+    if (!c->comm) return fail(c, PT_ERROR_NOT_READY, "pt_comm_init first");
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    const StablePlanesContext sp = sp_buffers(c);
+    const size_t W = SP_SHARD_WORDS, n = c->owned.size();
+    if (c->shardCount == 1) {
+        if (!n) return PT_OK;
+        PT_CHECK_HIP(c, c->dSpGatherSend.resize(n * W)); PT_CHECK_HIP(c, c->dSpGatherRecv.resize(n * W));
+        launch_sp_pack(sp, c->dOwned.p, (uint)n, c->dSpGatherSend.p, false, st);
+        const size_t N = (size_t)c->width * c->height;
+        PT_CHECK_HIP(c, hipMemsetAsync(c->dSpHeader.p, 0xEE, 16 * N, st)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpPlanes.p, 0xEE, sizeof(ptk::StablePlane) * cStablePlaneCount * sp.C.genericTSPlaneStride, st));
+        PT_CHECK_HIP(c, hipMemsetAsync(c->dSpRadiance.p, 0xEE, 8 * N, st)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpDepth.p, 0xEE, 4 * N, st)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpHitT.p, 0xEE, 4 * N, st));
+        PT_CHECK_HIP(c, hipMemsetAsync(c->dSpMotion.p, 0xEE, 8 * N, st)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpThroughput.p, 0xEE, 4 * N, st));
+        PT_CHECK_NCCL(c, g_rccl.GroupStart());
+        ncclResult_t rs = g_rccl.Send(c->dSpGatherSend.p, n * W, ncclFloat, 0, c->comm, st);
+        ncclResult_t rr = (rs == ncclSuccess) ? g_rccl.Recv(c->dSpGatherRecv.p, n * W, ncclFloat, 0, c->comm, st) : rs;
+        ncclResult_t re = g_rccl.GroupEnd();
+        if (rr != ncclSuccess || re != ncclSuccess) return fail(c, PT_ERROR_HIP, std::string("pt_gather_stable_planes loop-back: ") + g_rccl.GetErrorString(rr != ncclSuccess ? rr : re));
+        launch_sp_pack(sp, c->dOwned.p, (uint)n, c->dSpGatherRecv.p, true, st);
+        PT_CHECK_HIP(c, hipStreamSynchronize(st));
+        return PT_OK;
+    }
+    if (c->shardRank != 0) {
+        if (n) { PT_CHECK_HIP(c, c->dSpGatherSend.resize(n * W)); launch_sp_pack(sp, c->dOwned.p, (uint)n, c->dSpGatherSend.p, false, st); PT_CHECK_NCCL(c, g_rccl.Send(c->dSpGatherSend.p, n * W, ncclFloat, 0, c->comm, st)); }
+        PT_CHECK_HIP(c, hipStreamSynchronize(st));
+        return PT_OK;
+    }
+    std::vector<uint> others; for (uint r = 1; r < c->shardCount; r++) others.insert(others.end(), c->shardPixels[r].begin(), c->shardPixels[r].end());
+    PT_CHECK_HIP(c, c->dSpGatherPixels.upload(others, st)); PT_CHECK_HIP(c, c->dSpGatherRecv.resize(others.size() * W)); PT_CHECK_HIP(c, hipStreamSynchronize(st));
+    size_t off = 0; ncclResult_t bad = ncclSuccess;
+    PT_CHECK_NCCL(c, g_rccl.GroupStart());
+    for (uint r = 1; r < c->shardCount && bad == ncclSuccess; r++) { const size_t m = c->shardPixels[r].size(); if (m) bad = g_rccl.Recv(c->dSpGatherRecv.p + off * W, m * W, ncclFloat, (int)r, c->comm, st); off += m; }
+    ncclResult_t ge = g_rccl.GroupEnd();
+    if (bad != ncclSuccess || ge != ncclSuccess) return fail(c, PT_ERROR_HIP, std::string("pt_gather_stable_planes: ") + g_rccl.GetErrorString(bad != ncclSuccess ? bad : ge));
+    launch_sp_pack(sp, c->dSpGatherPixels.p, (uint)off, c->dSpGatherRecv.p, true, st);
+    PT_CHECK_HIP(c, hipStreamSynchronize(st));
+    c->spGathered = true;
+    return PT_OK;
+}
 int32_t pt_denoise_spec_hit_t(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes, pt_fill_stable_planes");
-    if (c->shardCount > 1) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill-in reads 5 x 5 neighbourhoods: run it on the gathered planes, not on one rank's tiles");
+    if (c->shardCount > 1 && !c->spGathered) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill-in reads 5 x 5 neighbourhoods: run it on the gathered planes (pt_gather_stable_planes / pt_unpack_stable_planes on rank 0), not on one rank's tiles");
     (void)hipSetDevice(c->device);
     PT_CHECK_HIP(c, c->dSpScratch.resize((size_t)c->width * c->height));
     launch_sp_denoise_spec_hit_t(c->dSpHitT.p, c->dSpDepth.p, c->dSpScratch.p, c->width, c->height, c->stream);

@@ -196,6 +196,29 @@ __global__ void __launch_bounds__(256) k_sp_merge(StablePlanesContext sp, const 
 void launch_sp_merge(const StablePlanesContext& sp, const uint* ownedPixels, uint numOwned, float4* out, hipStream_t st) {
     hipLaunchKernelGGL(k_sp_merge, dim3((numOwned + 255u) / 256u), dim3(256), 0, st, sp, ownedPixels, numOwned, out);
 }
+// The plane buffers of a list of pixels as flat records (tile-sharded frames: what a rank sends to the rank that denoises / shows the frame): SP_SHARD_WORDS words per pixel —
+// the four header words, the three 80-byte StablePlane records (from their tiled-swizzled addresses), stable radiance, depth, specular hit distance, motion vectors, throughput.
+// One wave-friendly layout: thread = (pixel, word), so both sides of the copy are coalesced along the record.
+__global__ void __launch_bounds__(256) k_sp_pack(StablePlanesContext sp, const uint* __restrict__ pixels, uint num, uint* __restrict__ dst, uint unpack) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (size_t)num * SP_SHARD_WORDS) return;
+    const uint k = (uint)(i / SP_SHARD_WORDS), wd = (uint)(i - (size_t)k * SP_SHARD_WORDS);
+    const uint px = pixels[k] >> 16, py = pixels[k] & 0xFFFFu;
+    const size_t pix = (size_t)py * sp.C.imageWidth + px, plane = (size_t)sp.C.imageWidth * sp.C.imageHeight;
+    uint* p;
+    if (wd < 4u) p = sp.B.Header + wd * plane + pix;
+    else if (wd < 64u) { const uint pl = (wd - 4u) / 20u, w = (wd - 4u) % 20u; p = reinterpret_cast<uint*>(sp.B.Planes + sp.PixelToAddress(px, py, pl)) + w; }
+    else if (wd < 66u) p = reinterpret_cast<uint*>(sp.B.StableRadiance + pix) + (wd - 64u);
+    else if (wd == 66u) p = reinterpret_cast<uint*>(sp.B.Depth + pix);
+    else if (wd == 67u) p = reinterpret_cast<uint*>(sp.B.SpecularHitT + pix);
+    else if (wd < 70u) p = reinterpret_cast<uint*>(sp.B.MotionVectors + pix) + (wd - 68u);
+    else p = sp.B.Throughput + pix;
+    if (unpack) *p = dst[i]; else dst[i] = *p;
+}
+void launch_sp_pack(const StablePlanesContext& sp, const uint* pixels, uint num, uint* buf, bool unpack, hipStream_t st) {
+    const size_t n = (size_t)num * SP_SHARD_WORDS;
+    if (n) hipLaunchKernelGGL(k_sp_pack, dim3((uint)((n + 255u) / 256u)), dim3(256), 0, st, sp, pixels, num, buf, unpack ? 1u : 0u);
+}
 void launch_sp_generate(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleIndex, uint* queue, hipStream_t st) {
     const dim3 g((numOwned + 255u) / 256u), b(256);
     if (k.S.useFp16Types) { PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16)); hipLaunchKernelGGL((k_sp_generate<PathKernelContextT<true>>), g, b, 0, st, k16, sp, pool, ownedPixels, numOwned, sampleIndex, queue); }

@@ -15,4 +15,7 @@ void launch_sp_fill_resolve(PathPool pool, uint4* mark, ShadowQueue sq, const fl
 void launch_sp_fill_commit(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, uint numOwned, uint sampleIndex, hipStream_t st);
 void launch_sp_denoise_spec_hit_t(float* specHitT, const float* depth, float* scratch, uint width, uint height, hipStream_t st);
 void launch_sp_merge(const StablePlanesContext& sp, const uint* ownedPixels, uint numOwned, float4* out, hipStream_t st);
+// the plane buffers of `num` pixels <-> flat records of SP_SHARD_WORDS words each (pt_pack_stable_planes / pt_unpack_stable_planes / pt_gather_stable_planes)
+static const uint SP_SHARD_WORDS = 71u;      // header 4 + planes 3 x 20 + stable radiance 2 + depth 1 + specular hit distance 1 + motion vectors 2 + throughput 1
+void launch_sp_pack(const StablePlanesContext& sp, const uint* pixels, uint num, uint* buf, bool unpack, hipStream_t st);
 } // namespace ptk

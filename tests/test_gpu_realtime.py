@@ -54,3 +54,39 @@ def test_realtime_frame_without_the_baker_and_refusals():
     c = pt.PathTracer(shard_rank=0, shard_count=2); c.set_scene(sc); c.set_settings(S); c.set_camera(scenes.bridge_camera(w, h, **cam)); c.resize(w, h)
     with pytest.raises(Exception): c.realtime_frame(0, prm)
     c.close()
+
+
+def test_plane_buffers_of_tile_shards_reassemble():
+    """Three ranks of a tile-sharded realtime frame on one device: each builds and fills the planes of its own tiles; packed, carried to rank 0 and unpacked they are the unsharded frame's
+    buffers — header, every plane record, stable radiance, depth, hit distances, motion vectors, throughput — and the 5 x 5 fill-in of the hit distances, refused on a lone shard, runs on the
+    gathered planes and equals the unsharded result. The RCCL form (pt_gather_stable_planes) runs as a world-of-one loop-back with the buffers poisoned in between."""
+    import torch
+    import rtxpt_amd as pt
+    sc, cam = scenes.stable_planes_zoo(); S = scenes.config_settings("C2"); w, h, world = 96, 72, 3
+    prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cam), sub_samples=1)
+    def ctx(rank, count):
+        t = pt.PathTracer(shard_rank=rank, shard_count=count); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h); return t
+    one = ctx(0, 1); one.build_stable_planes(7, prm); want = one.fill_stable_planes(7, prm)
+    ranks = [ctx(r, world) for r in range(world)]
+    bufs = []
+    for r, t in enumerate(ranks):
+        t.build_stable_planes(7, prm); t.fill_stable_planes(7, prm)
+        n = t.stable_planes_shard_bytes(r); assert n == t.shard_info()[0] * 284
+        b = torch.empty(n // 4, dtype=torch.int32, device="cuda"); t.pack_stable_planes(b.data_ptr(), n); bufs.append(b)
+    with pytest.raises(Exception): ranks[0].denoise_spec_hit_t()
+    for r in range(1, world): ranks[0].unpack_stable_planes(bufs[r].data_ptr(), bufs[r].numel() * 4, r)
+    got = ranks[0].get_stable_planes()
+    for k in ("header", "stable_radiance", "depth", "spec_hit_t", "motion_vectors", "throughput"): assert _same(got[k], want[k]), k
+    assert _same(rc.live_noisy(got, w, h), rc.live_noisy(want, w, h))
+    hd = want["header"]
+    for pl in range(3):
+        ys, xs = np.nonzero(hd[pl] != 0xFFFFFFFF)
+        idx = [scenes.stable_planes_address(x, y, pl, w, h) for x, y in zip(xs.tolist(), ys.tolist())]
+        assert _same(got["planes"][idx], want["planes"][idx]), pl
+    assert _same(ranks[0].denoise_spec_hit_t(), one.denoise_spec_hit_t())
+    # RCCL loop-back on the unsharded context
+    uid = pt.comm_unique_id(); one.comm_init(uid, 0, 1)
+    before = one.get_stable_planes(); one.gather_stable_planes(); after = one.get_stable_planes()
+    for k in ("header", "planes", "stable_radiance", "depth", "spec_hit_t", "motion_vectors", "throughput"): assert _same(before[k], after[k]), k
+    one.comm_destroy()
+    for t in ranks + [one]: t.close()
