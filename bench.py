@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 # algorithmic bytes: extend ray 52 B fixed + BVH: 128 B per BVH8 node visit + 48 B per triangle test
 B_EXTEND_FIXED, B_NODE, B_TRI, B_SHADE, B_SHADOW_FIXED = 52.0, 128.0, 48.0, 656.0, 80.0
-COUNTERS_FILE = "r03z_counters.json"     # rocprofv3 --pmc summary of this workload (tools/profile_round.sh), quoted in roofline{}
+COUNTERS_FILE = "r04z_counters.json"     # rocprofv3 --pmc summary of this workload (tools/profile_round.sh), quoted in roofline{}
 
 
 def main():
@@ -191,7 +191,8 @@ def main():
                                       "RGBA16F" if args.no_env_compression else "2048 BC6H (reference default on D3D12)", bvh["builderName"], bvh["builtOn"], bvh["buildMs"], bvh["hostMs"], bvh["numWideNodes"]),
                        "bvh": bvh,
                        "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "rays_per_step": rays_total / args.steps,
-                       "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP},
+                       "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP,
+                       "tail_kernel_launches_per_step": sum(s["tailLaunches"] for s in stats) / args.steps},
             # `frac` is the prescribed figure: algorithmic bytes / launch time / 8 TB/s. `bound` is what the counters say limits the kernel:
             # the BVH is served from L1/L2, HBM itself carries `hbm_counter_gbs`, and the VALU issue slots are what is full (`bound`: "valu").
             "roofline": {"bound": bound, "prescribed_bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS,
@@ -219,11 +220,18 @@ def main():
             try:
                 prm = scenes.stable_planes_params(W, H, scenes.view_projection(W, H, **cam), sub_samples=1)
                 g.build_stable_planes(0, prm); b = g.build_stable_planes(1, prm)["stats"]; f = g.fill_stable_planes(1, prm)["stats"]
-                out["realtime_passes"] = {"workload": "stable-plane build pass + one fill sub-sample, %dx%d, same scene (SURVEY.md 8f row N4)" % (W, H),
+                out["realtime_passes"] = {"ok": True, "workload": "stable-plane build pass + one fill sub-sample, %dx%d, same scene (SURVEY.md 8f row N4)" % (W, H),
                                           "build_ms": b["gpuMilliseconds"], "build_rays": int(b["extendRays"]), "fill_ms": f["gpuMilliseconds"], "fill_rays": int(f["extendRays"]) + int(f["shadowRays"]),
                                           "fill_mrays_per_s": (int(f["extendRays"]) + int(f["shadowRays"])) / max(f["gpuMilliseconds"], 1e-9) / 1e3}
-            except Exception as e:      # never let the side leg take the bench line down
-                out["realtime_passes"] = {"error": str(e)[:200]}
+                # ... and the coupled frame (pt_realtime_frame with the light baker in the loop: UpdateBegin, build pass, UpdateEnd on the frame's depth + motion vectors, fill pass feeding the reservoirs)
+                g.set_neeat(True)
+                for fr in range(3): g.realtime_frame(fr, prm)
+                t1 = time.perf_counter(); _, bs, fs = g.realtime_frame(3, prm); wall = (time.perf_counter() - t1) * 1e3
+                g.set_neeat(False)
+                out["realtime_passes"]["coupled_frame_with_neeat"] = {"build_ms": bs["gpuMilliseconds"], "fill_ms": fs["gpuMilliseconds"], "fill_rays": int(fs["extendRays"]) + int(fs["shadowRays"]),
+                                                                     "note": "4th frame of a run (history and tile tables exist); baker passes run between the two on the device"}
+            except Exception as e:      # the side leg never takes the bench line down, but it says so: "ok": false
+                out["realtime_passes"] = {"ok": False, "error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             # the oracle's block of the very frame the timed steps rendered doubles as the parity check of the benchmarked configuration
             out["cpu_baseline"], block, rect = cpu_baseline(sc, cam, S, W, H, SPP)

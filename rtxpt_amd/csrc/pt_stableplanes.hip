@@ -93,13 +93,16 @@ __global__ void __launch_bounds__(256) k_sp_fill_generate(PKC k, StablePlanesCon
 }
 template <class PKC>
 __global__ void __launch_bounds__(256) k_sp_fill_shade(PKC k, StablePlanesContext sp, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr, uint* __restrict__ queueOut, uint* countOutPtr,
-                                                       ShadowQueue sq, float4* __restrict__ newL, uint sampleIndex, WaveCounters* wc) {
+                                                       ShadowQueue sq, float4* __restrict__ newL, uint sampleIndex, WaveCounters* wc, const uint* __restrict__ classCount) {
     const uint count = *countInPtr;
     const uint i = blockIdx.x * 256u + threadIdx.x;
     bool alive = false, isHit = false; uint p = 0;
     SPNeeRequest req; req.valid = false;
     if (i < count) {
-        p = queueIn[i];
+        if (classCount) {                                     // queueIn = k_classify's arrays (pt_wavefront.hip): thread i takes the i-th path of the order {continuing hit, terminating hit, miss}
+            const uint nGo = classCount[0], nEnd = classCount[1];
+            p = queueIn[i < nGo ? i : (i < nGo + nEnd ? count - 1u - (i - nGo) : count + (i - nGo - nEnd))];
+        } else p = queueIn[i];
         PathState path = sp_load_path(pool, p);
         const uint4 hr = pool.hit[p];
         const float3 rayOrigin = path.origin, rayDir = path.dir;
@@ -164,8 +167,10 @@ void launch_sp_fill_generate(const PathKernelContext& k, const StablePlanesConte
     SP_LAUNCH(k_sp_fill_generate, dim3((numOwned + 255u) / 256u), sp, pool, ownedPixels, numOwned, sampleIndex, queue, countPtr);
 }
 void launch_sp_fill_shade(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, float4* newL,
-                          uint sampleIndex, WaveCounters* wc, hipStream_t st) {
-    SP_LAUNCH(k_sp_fill_shade, dim3((countIn + 255u) / 256u), sp, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, newL, sampleIndex, wc);
+                          uint sampleIndex, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st) {
+    // class-ordered shading as in reference mode (k_classify): a shading wave lives as long as its longest lane, misses and hits that end after their emission leave early when they sit together
+    if (classScratch) { launch_classify(pool, queueIn, countInPtr, countIn, classScratch, classCount, st); queueIn = classScratch; } else classCount = nullptr;
+    SP_LAUNCH(k_sp_fill_shade, dim3((countIn + 255u) / 256u), sp, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, newL, sampleIndex, wc, (const uint*)classCount);
 }
 void launch_sp_fill_resolve(PathPool pool, uint4* mark, ShadowQueue sq, const float4* newL, const uint* countPtr, uint count, hipStream_t st) {
     uint g = (count + 255u) / 256u; if (g > 4096u) g = 4096u; if (g < 1u) g = 1u;

@@ -10,7 +10,7 @@ void launch_sp_build_shade(const PathKernelContext& k, const StablePlanesContext
 // the fill passes (one sub-sample): generate from plane 0, the pass's shader, the float4 resolve of the visible light samples (mark: a scratch copy of pool.s2 the shadow launches write to), the final commit
 void launch_sp_fill_generate(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleIndex, uint* queue, uint* countPtr, hipStream_t st);
 void launch_sp_fill_shade(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, float4* newL,
-                          uint sampleIndex, WaveCounters* wc, hipStream_t st);
+                          uint sampleIndex, WaveCounters* wc, uint* classScratch /* 2 x countIn words or null */, uint* classCount /* 3 words, zero on entry */, hipStream_t st);
 void launch_sp_fill_resolve(PathPool pool, uint4* mark, ShadowQueue sq, const float4* newL, const uint* countPtr, uint count, hipStream_t st);
 void launch_sp_fill_commit(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, uint numOwned, uint sampleIndex, hipStream_t st);
 void launch_sp_denoise_spec_hit_t(float* specHitT, const float* depth, float* scratch, uint width, uint height, hipStream_t st);

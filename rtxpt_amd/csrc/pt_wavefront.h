@@ -44,6 +44,7 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
 // launch_extend / launch_shade / launch_shadow expect the pass's counter block zeroed by the caller (launch_pass_reset)
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr,
                   ShadowQueue sq, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st);
+void launch_classify(PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* classScratch, uint* classCount, hipStream_t st);      // k_classify: {continuing hit, terminating hit, miss} made contiguous
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
 // the late bounces of a batch in one launch: every wave runs 32 paths of queueIn to their end (at most maxBounces bounces each); stragglers and paths beyond the bound come back through
 // queueOut / countOutPtr (and, for visibility rays, the shadow queue / wc->shadowCount). NEEFullSamples 1 only (sq.group == 0); the pass's counters zeroed by the caller as for launch_shade

@@ -704,6 +704,10 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
     hipLaunchKernelGGL((k_extend_tasks<3>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 1, to the end
     hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
 }
+// k_classify for a caller in another translation unit (the stable-plane fill pass): classScratch 2 x countIn words, classCount 3 words (zero on entry)
+void launch_classify(PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* classScratch, uint* classCount, hipStream_t st) {
+    hipLaunchKernelGGL(k_classify, dim3((countIn + 1023) / 1024), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
+}
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc,
                   uint* classScratch, uint* classCount, hipStream_t st) {
     const dim3 g((countIn + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), b(PT_SHADE_BLOCK);

@@ -28,6 +28,14 @@ def main():
     out = {"width": w, "height": h, "scene": "bistro_like (bench.py's)", "build_pass": {"ms": med(build, "gpuMilliseconds"), "rays": int(build[-1]["extendRays"]), "passes": int(build[-1]["iterations"])},
            "fill_pass_one_subsample": {"ms": med(fill, "gpuMilliseconds"), "extend_rays": int(fill[-1]["extendRays"]), "shadow_rays": int(fill[-1]["shadowRays"]), "passes": int(fill[-1]["iterations"])},
            "reference_mode_one_sample": {"ms": float(ref["gpuMilliseconds"]), "extend_rays": int(ref["extendRays"]), "shadow_rays": int(ref["shadowRays"])}}
+    # the coupled frame with the baker in the loop (pt_realtime_frame, pt_set_neeat): wall time of the call = baker (UpdateBegin + UpdateEnd) + build pass + fill pass
+    import time
+    g.set_neeat(True)
+    for f in range(3): g.realtime_frame(f, prm)
+    walls, b_ms, f_ms = [], [], []
+    for f in range(3, 3 + a.frames):
+        t0 = time.perf_counter(); _, bs, fs = g.realtime_frame(f, prm); walls.append((time.perf_counter() - t0) * 1e3); b_ms.append(bs["gpuMilliseconds"]); f_ms.append(fs["gpuMilliseconds"])
+    out["realtime_frame_with_neeat"] = {"wall_ms_incl_read_back": float(np.median(walls)), "build_ms": float(np.median(b_ms)), "fill_ms": float(np.median(f_ms)), "fill_extend_rays": int(fs["extendRays"]), "fill_shadow_rays": int(fs["shadowRays"])}
     for k in ("build_pass",): out[k]["mrays_per_s"] = out[k]["rays"] / out[k]["ms"] / 1e3
     out["fill_pass_one_subsample"]["mrays_per_s"] = (out["fill_pass_one_subsample"]["extend_rays"] + out["fill_pass_one_subsample"]["shadow_rays"]) / out["fill_pass_one_subsample"]["ms"] / 1e3
     out["reference_mode_one_sample"]["mrays_per_s"] = (out["reference_mode_one_sample"]["extend_rays"] + out["reference_mode_one_sample"]["shadow_rays"]) / out["reference_mode_one_sample"]["ms"] / 1e3
