@@ -408,17 +408,43 @@ __device__ __forceinline__ void bvh8_child_codes(float3 cmn, float3 cmx, float3 
     }
     q0 = ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24); q1 = qh[1] | (qh[2] << 8);
 }
-__device__ __forceinline__ void bvh8_pack(Bvh8Node& out, const float3* cmn, const float3* cmx, uint n) {
+// child k goes to slot slotOf[k] (pt_scene.h PT_OCTANT_SLOTS: the slots are the traversal's visiting order); the other slots are empty
+__device__ __forceinline__ void bvh8_pack(Bvh8Node& out, const float3* cmn, const float3* cmx, uint n, const uint* slotOf) {
     float3 mn = cmn[0], mx = cmx[0];
     for (uint k = 1; k < n; k++) { mn = min3v(mn, cmn[k]); mx = max3v(mx, cmx[k]); }
     uint ex, ey, ez; bvh8_scales(mn, mx, ex, ey, ez);
     float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23), sz = __uint_as_float(ez << 23);
     out.ox = mn.x; out.oy = mn.y; out.oz = mn.z; out.exps = ex | (ey << 8) | (ez << 16) | (n << 24);
     out._pad[0] = __float_as_uint(sx); out._pad[1] = __float_as_uint(sy); out._pad[2] = __float_as_uint(sz); out._pad[3] = 0;      // the scales again, as floats (traversal reads these; exps stays for tools)
-    for (uint k = 0; k < 8u; k++) {
-        if (k >= n) { out.c[k].ref = BVH_EMPTY; out.c[k].q0 = 0x00FFFFFFu; out.c[k].q1 = 0u; continue; }     // inverted box
-        bvh8_child_codes(cmn[k], cmx[k], mn, sx, sy, sz, out.c[k].q0, out.c[k].q1);
+    for (uint k = 0; k < 8u; k++) { out.c[k].ref = BVH_EMPTY; out.c[k].q0 = 0x00FFFFFFu; out.c[k].q1 = 0u; }     // inverted box
+    for (uint k = 0; k < n; k++) bvh8_child_codes(cmn[k], cmx[k], mn, sx, sy, sz, out.c[slotOf[k]].q0, out.c[slotOf[k]].q1);
+}
+// Slots by octant (Ylitie, Karras & Laine 2017, section 3.2): the traversal visits the hit children of a node in the order of (slot XOR ray octant) instead of sorting them by entry
+// distance, so slot s should hold the child that lies furthest towards direction (s & 1 ? + : -, s & 2 ? + : -, s & 4 ? + : -) of the node's centre: a ray with an all-positive
+// direction (octant 0) then meets slot 0 first and slot 7 last, a ray of octant o meets slot o first. Greedy assignment on the 8 x n table of those projections (the paper runs
+// an auction; the order is a heuristic either way — the closest hit does not depend on it).
+__device__ __forceinline__ void bvh8_octant_slots(const float3* cmn, const float3* cmx, uint n, uint* slotOf) {
+#if PT_OCTANT_SLOTS
+    float3 mn = cmn[0], mx = cmx[0];
+    for (uint k = 1; k < n; k++) { mn = min3v(mn, cmn[k]); mx = max3v(mx, cmx[k]); }
+    const float3 nc = mn + mx;                                   // twice the centres throughout
+    uint freeSlots = 0xFFu, todo = (1u << n) - 1u;
+    for (uint round = 0; round < n; round++) {
+        float best = -3.0e38f; uint bk = 0u, bs = 0u;
+        for (uint k = 0; k < n; k++) {
+            if (!(todo & (1u << k))) continue;
+            const float3 v = cmn[k] + cmx[k] - nc;
+            for (uint sl = 0; sl < 8u; sl++) {
+                if (!(freeSlots & (1u << sl))) continue;
+                const float sc = ((sl & 1u) ? v.x : -v.x) + ((sl & 2u) ? v.y : -v.y) + ((sl & 4u) ? v.z : -v.z);
+                if (sc > best) { best = sc; bk = k; bs = sl; }
+            }
+        }
+        slotOf[bk] = bs; todo &= ~(1u << bk); freeSlots &= ~(1u << bs);
     }
+#else
+    for (uint k = 0; k < n; k++) slotOf[k] = k;
+#endif
 }
 __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ nodes2, const uint* __restrict__ levelIn, uint nIn, uint* __restrict__ levelOut,
                                                    uint* __restrict__ counter, Bvh8Node* __restrict__ nodes8, uint costDriven) {
@@ -445,12 +471,12 @@ __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ n
     for (uint k = 0; k < n; k++) if (!(cref[k] & BVH_LEAF_BIT)) nInner++;
     uint wbase = 0, obase = 0;
     if (nInner) { wbase = atomicAdd(&counter[0], nInner); obase = atomicAdd(&counter[1], nInner); }
-    Bvh8Node out; bvh8_pack(out, cmn, cmx, n);
+    uint slotOf[8]; bvh8_octant_slots(cmn, cmx, n, slotOf);
+    Bvh8Node out; bvh8_pack(out, cmn, cmx, n, slotOf);
     uint inner = 0;
-    for (uint k = 0; k < 8u; k++) {
-        if (k >= n) { out.c[k].ref = BVH_EMPTY; continue; }
-        if (cref[k] & BVH_LEAF_BIT) out.c[k].ref = cref[k];
-        else { out.c[k].ref = wbase + inner; levelOut[2 * (obase + inner)] = wbase + inner; levelOut[2 * (obase + inner) + 1] = cref[k]; inner++; }
+    for (uint k = 0; k < n; k++) {
+        if (cref[k] & BVH_LEAF_BIT) out.c[slotOf[k]].ref = cref[k];
+        else { out.c[slotOf[k]].ref = wbase + inner; levelOut[2 * (obase + inner)] = wbase + inner; levelOut[2 * (obase + inner) + 1] = cref[k]; inner++; }
     }
     nodes8[wide] = out;
 }
@@ -467,7 +493,7 @@ __global__ void __launch_bounds__(256) k_refit8_level(uint first, uint count, Bv
     const float scenePad = scene_pad_of(sceneBounds);
     uint* nd = reinterpret_cast<uint*>(nodes8 + w);
     const uint n = nd[3] >> 24, r = nd[4u + 3u * k];
-    const bool valid = k < n;
+    const bool valid = r != BVH_EMPTY;                      // (the children sit in the slots the collapse chose for them, not in the first n)
     float3 mn = make_float3(3.0e38f), mx = make_float3(-3.0e38f);
     if (valid) {
         if (r & BVH_LEAF_BIT) {

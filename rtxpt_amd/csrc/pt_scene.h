@@ -61,6 +61,12 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 #ifndef PT_BVH_MAX_LEAF
 #define PT_BVH_MAX_LEAF (PT_T8_LANES == 2 ? 2 : 4)      // triangles per leaf = lanes per ray: a leaf is tested in one round. With pairs, 2 instead of 4: k_extend 48.3 -> 43.6 ms, k_shadow 14.0 -> 12.2 ms
 #endif                                                  // (1: 50.6 / 13.6 ms; 3: 46.1 / 13.3; 6: 51.9 / 15.3 — profiles/r03u_leafsize_ab*.txt)
+#ifndef PT_OCTANT_SLOTS
+#define PT_OCTANT_SLOTS 0       // 1: the builder places a wide node's children in slots by octant (pt_build.hip bvh8_octant_slots) and the traversal visits the hit children in the order of
+#endif                          //    (slot XOR ray octant) instead of ranking them by entry distance; 0: children in collapse order, 8-key ranking.
+                                //    Round 4 A/B (profiles/r04u_octant_order_ab.txt): 44 VALU instructions fewer in the inner block, but 17.3 instead of 15.0 node visits and 10.9 instead of
+                                //    7.8 triangle tests per extend ray on the bench scene (overlapping boxes of long thin quads: the centroid order is a poor stand-in for the entry distance):
+                                //    k_extend 44.1 -> 55.1 ms. Same frames either way (112 parity tests). Off.
 static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_LEAF = PT_BVH_MAX_LEAF, BVH_STACK = 64;
 // BVH8 node, 128 B = one cache line: the 8 lanes of a ray's lane group each fetch one 12 B child slot plus the shared 16 B header, so a
 // whole node costs one line lookup per group instead of four 16 B gathers per lane. Child boxes are 8-bit quantised relative to the node

@@ -29,6 +29,18 @@ __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { retur
 #ifndef T8_POP2
 #define T8_POP2 0
 #endif
+#ifndef T8_POP_ONCE
+#define T8_POP_ONCE 0        // 1: one pop trip (two entries) per wave iteration instead of a loop until a live entry is found. Round 4 A/B (profiles/r04v_pop_once_ab.txt): pop trips
+#endif                       //    per iteration 3.14 -> 0.97, wave iterations per ray 0.58 -> 0.61, k_extend 43.7 -> 43.2 ms (within noise): the pop loop is not where the phase's time goes. Off.
+// kOctBelow[2 * octant + h]: byte k = the slots that are visited BEFORE slot 4h + k by a ray of that octant, i.e. { s : (s ^ octant) < ((4h + k) ^ octant) }
+static __device__ const uint kOctBelow[16] = {
+#define OB1(o, s) ((((0 ^ (o)) < ((s) ^ (o))) ? 1u : 0u) | (((1 ^ (o)) < ((s) ^ (o))) ? 2u : 0u) | (((2 ^ (o)) < ((s) ^ (o))) ? 4u : 0u) | (((3 ^ (o)) < ((s) ^ (o))) ? 8u : 0u) | \
+                   (((4 ^ (o)) < ((s) ^ (o))) ? 16u : 0u) | (((5 ^ (o)) < ((s) ^ (o))) ? 32u : 0u) | (((6 ^ (o)) < ((s) ^ (o))) ? 64u : 0u) | (((7 ^ (o)) < ((s) ^ (o))) ? 128u : 0u))
+#define OB4(o, h) (OB1(o, 4 * (h)) | (OB1(o, 4 * (h) + 1) << 8) | (OB1(o, 4 * (h) + 2) << 16) | (OB1(o, 4 * (h) + 3) << 24))
+    OB4(0, 0), OB4(0, 1), OB4(1, 0), OB4(1, 1), OB4(2, 0), OB4(2, 1), OB4(3, 0), OB4(3, 1), OB4(4, 0), OB4(4, 1), OB4(5, 0), OB4(5, 1), OB4(6, 0), OB4(6, 1), OB4(7, 0), OB4(7, 1)
+#undef OB4
+#undef OB1
+};
 #if PT_T8_LANES == 2
 // DEFER (with CAN_SPLIT): a dry wave keeps going for taskOut.capacity iterations (instead of T8_TAIL_ITERS), and the rays then still in flight are not cut into sub-trees,
 // only reported through publish() — the caller has them traced again elsewhere (the tail kernel, pt_tail.hip, hands their paths back to the host loop). No task queue is touched.
@@ -59,7 +71,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
     bool active = false;
     float3 o = make_float3(0.f), d = make_float3(0.f);
     float ix = 0.f, iy = 0.f, iz = 0.f;
-    uint selN = 0u, selF = 0u;
+    uint selN = 0u, selF = 0u, below4 = 0u;
     float tmin = 0.f, tmax = FIXED_RANGE ? kMaxRayTravel : 0.f;
     float bestT = 0.f; uint bestPrim = 0xFFFFFFFFu;
     uint minePrim = 0xFFFFFFFFu;
@@ -121,6 +133,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     {   // child bytes: q0 = lo.x lo.y lo.z hi.x (selector values 0..3), q1 = hi.y hi.z (4, 5)
                         const uint nxb = ix < 0.f ? 3u : 0u, fxb = ix < 0.f ? 0u : 3u, nyb = iy < 0.f ? 4u : 1u, fyb = iy < 0.f ? 1u : 4u, nzb = iz < 0.f ? 5u : 2u, fzb = iz < 0.f ? 2u : 5u;
                         selN = nxb | (nyb << 8) | (nzb << 16) | (fxb << 24); selF = fyb | (fzb << 8);
+                        if (PT_OCTANT_SLOTS) below4 = kOctBelow[((ix < 0.f ? 2u : 0u) | (iy < 0.f ? 4u : 0u) | (iz < 0.f ? 8u : 0u)) + h];
                     }
                     if (TASKS) {
                         if (!FIXED_RANGE) tmax = __uint_as_float(slot[7]);
@@ -152,7 +165,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         const bool inner = active && !(cur & BVH_LEAF_BIT);
         const bool leafReady = active && (pend != BVH_EMPTY);
         const bool queueFull = (T8_LEAF_QUEUE == 1) ? true : ((T8_LEAF_QUEUE == 2) ? (pend1 != BVH_EMPTY) : (pend2 != BVH_EMPTY));
-        const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT) && (cur == BVH_EMPTY || queueFull);
+        const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT) && ((cur == BVH_EMPTY && (!T8_POP_ONCE || sp == 0u)) || queueFull);
         const bool runLeaves = ((uint)__popcll(t8_ballot(leafReady && h == 0u)) >= (uint)T8_LEAF_BATCH) || (t8_ballot(leafBlocked) != 0ull);
         const bool leaf = leafReady && runLeaves;
         if (COUNT && leaf && h == 0u) ctr.leafVisits++;
@@ -182,6 +195,13 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
             // integer sort keys: tn >= 0 so its bits order like the value; the low 3 mantissa bits carry the child index (unique keys, ties to the lower child);
             // a child that is not hit gets +inf. The stack entry's distance is the key without its index bits.
             uint key[4]; bool hit[4];
+            if (PT_OCTANT_SLOTS) {      // no ranking keys: the slot order is the visiting order; the stack entry keeps the entry distance for the cull at pop time
+                float tn, tf;
+                slab(c0.y, c0.z, tn, tf); hit[0] = T8_HIT(ref[0], tn, tf); key[0] = __float_as_uint(tn);
+                slab(c1.x, c1.y, tn, tf); hit[1] = T8_HIT(ref[1], tn, tf); key[1] = __float_as_uint(tn);
+                slab(c1.w, c2.x, tn, tf); hit[2] = T8_HIT(ref[2], tn, tf); key[2] = __float_as_uint(tn);
+                slab(c2.z, c2.w, tn, tf); hit[3] = T8_HIT(ref[3], tn, tf); key[3] = __float_as_uint(tn);
+            } else
             {   float tn, tf;
                 slab(c0.y, c0.z, tn, tf); hit[0] = T8_HIT(ref[0], tn, tf); key[0] = (hit[0] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h);
                 slab(c1.x, c1.y, tn, tf); hit[1] = T8_HIT(ref[1], tn, tf); key[1] = (hit[1] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 1u);
@@ -189,6 +209,16 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 slab(c2.z, c2.w, tn, tf); hit[3] = T8_HIT(ref[3], tn, tf); key[3] = (hit[3] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 3u);
             }
             uint nhit, rank[4];
+            if (PT_OCTANT_SLOTS) {
+                // rank of a hit child = the hit children whose (slot ^ octant) is lower: one popcount per child against the ray's table of predecessors
+                const uint own = (hit[0] ? 1u : 0u) | (hit[1] ? 2u : 0u) | (hit[2] ? 4u : 0u) | (hit[3] ? 8u : 0u);
+                const uint oth = dpp_u<DPP_QP_XOR1>(own);
+                const uint all = h ? (oth | (own << 4)) : (own | (oth << 4));
+                nhit = (uint)__popc(all);
+                const uint m = (all * 0x01010101u) & below4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) rank[k] = (uint)__popc(__builtin_amdgcn_ubfe(m, 8u * k, 8u));
+            } else
             if (ANYHIT && T8_ANYHIT_UNORDERED) {
                 // an occlusion query has no use for a front-to-back order: the hit children are numbered by child index
                 const uint own = (hit[0] ? 1u : 0u) | (hit[1] ? 2u : 0u) | (hit[2] ? 4u : 0u) | (hit[3] ? 8u : 0u);
@@ -222,7 +252,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 if (sp + nhit - 1u > BVH8_STACK + T8_SPILL_DEPTH) { if (h == 0u) atomicOr(overflowFlag, 1u); }
                 else {      // far to near: nearest on top
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (hit[k] && rank[k] > 0u) stackStore(sp + (nhit - 1u - rank[k]), ref[k], key[k] & ~7u);
+                    for (int k = 0; k < 4; k++) if (hit[k] && rank[k] > 0u) stackStore(sp + (nhit - 1u - rank[k]), ref[k], PT_OCTANT_SLOTS ? key[k] : (key[k] & ~7u));
                     sp += nhit - 1u;
                 }
             }
@@ -290,6 +320,27 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
             }
             if (cur == BVH_EMPTY) {
                 T8_EVENT(6, true);
+#if T8_POP_ONCE
+                // one trip per wave iteration, two entries per trip while both lie in LDS: a ray whose next entries are behind its hit stays without a node for an iteration
+                // instead of holding the other 31 rays of the wave in the pop loop
+                if (sp > 0u) {
+                    T8_EVENT(7, true);
+                    if (!ANYHIT && sp >= 2u && sp <= BVH8_STACK) {
+                        const uint2 e1 = stack[sp - 1u], e0 = stack[sp - 2u];
+                        const bool k1 = __uint_as_float(e1.y) <= bestT, k0 = __uint_as_float(e0.y) <= bestT;
+                        cur = k1 ? e1.x : (k0 ? e0.x : BVH_EMPTY); sp -= k1 ? 1u : 2u;
+                    } else {
+                        sp--;
+                        uint2 e;
+                        if (sp < BVH8_STACK) e = stack[sp];
+                        else {
+                            unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (sp - BVH8_STACK))));
+                            e = make_uint2((uint)w, (uint)(w >> 32));
+                        }
+                        if (ANYHIT || __uint_as_float(e.y) <= bestT) cur = e.x;
+                    }
+                }
+#else
                 while (sp > 0u) {
                     T8_EVENT(7, true);
 #if T8_POP2
@@ -310,7 +361,8 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     }
                     if (ANYHIT || __uint_as_float(e.y) <= bestT) { cur = e.x; break; }
                 }
-                if (cur == BVH_EMPTY && pend == BVH_EMPTY) {          // nothing left: report
+#endif
+                if (cur == BVH_EMPTY && pend == BVH_EMPTY && (!T8_POP_ONCE || sp == 0u)) {          // nothing left: report
                     if (COUNT && h == 0u && ctr.rayIterHist) {
                         if (rayIters > 2048u) { uint k = atomicAdd(ctr.longRayCount, 1u); if (k < 32u) { float* r = ctr.longRays + 8u * k; r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = (float)rayIters; r[7] = __uint_as_float(tag); } }
                         if (rayIters >= 128u) { uint bin = 31u - (uint)__clz((int)rayIters); atomicAdd(&ctr.rayIterHist[bin < 15u ? bin : 15u], 1ull); }

@@ -239,6 +239,26 @@ def cases_lp16():
     return out
 
 
+def wide_cases():
+    """One notch wider than cases(): 256 x 144 pixels x 4 samples per pin family, in both builds of the lp types — 147 456 paths per frame instead of ~10 000, so that the
+    rarely taken branches of the integrator text (late bounces, Russian roulette survivors, nested-dielectric stacks several levels deep, rejected interior hits, the
+    firefly filter on long paths) are hit thousands of times instead of a handful. name -> (make, settings, w, h, first, n); names ending in _lp16 run the reference's
+    default build (useFp16Types = 1). Fixture: tests/golden/reference_integrator_golden_wide.npz (make_reference_integrator_golden.py)."""
+    c2 = lambda: scenes.cornell_box("C2")
+    bl = lambda: scenes.bistro_like(scale=0.02, tex_size=128)
+    fam = {
+        "c2_wide": (c2, scenes.config_settings("C2"), 256, 144, 0, 4),
+        "bistro_like_wide": (bl, scenes.config_settings("C3"), 256, 144, 0, 4),                                    # the bench configuration's settings: 8 bounces, emissive NEE, RR
+        "bistro_like_material_zoo_wide": (with_material_zoo(bl), scenes.default_settings(fireflyFilterThreshold=1.5, envMapDiffuseSampleMIPLevel=2.0), 256, 144, 4, 4),
+        "bistro_like_c5_wide": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), scenes.default_settings(nestedDielectricsQuality=2), 256, 144, 8, 4),   # nested-dielectric props (C5's scene), quality 2
+    }
+    out = {}
+    for name, (make, S, w, h, first, n) in fam.items():
+        S32 = S.copy(); S32["useFp16Types"] = 0; S16 = S.copy(); S16["useFp16Types"] = 1
+        out[name] = (make, S32, w, h, first, n); out[name + "_lp16"] = (make, S16, w, h, first, n)
+    return out
+
+
 def neeat_cases():
     """NEE-AT, the path tracer's side (NEEType 2; SURVEY.md §8 row N4, first part): frames traced with screen-tile local samplers and / or temporal feedback.
     name -> (make, settings, w, h, first, n, dict(table_seed | None, jitter, ratio, ssc_threshold, feedback)). The tables are synthetic stand-ins for the

@@ -423,6 +423,31 @@ def test_product_lp16_matches_reference_integrator_golden(name):
     assert (st["extendRays"], st["shadowRays"]) == tuple(int(v) for v in g[name + "_rays"])
 
 
+def _wide_cases():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pin_scenes
+    return pin_scenes.wide_cases()
+
+
+@pytest.mark.parametrize("name", ["c2_wide", "c2_wide_lp16", "bistro_like_wide", "bistro_like_wide_lp16", "bistro_like_material_zoo_wide", "bistro_like_material_zoo_wide_lp16",
+                                  "bistro_like_c5_wide", "bistro_like_c5_wide_lp16"])
+@pytest.mark.parametrize("tail", [0, 32768], ids=["wavefront", "tail_kernel"])
+def test_product_matches_wide_reference_integrator_golden(name, tail):
+    """256 x 144 x 4 samples per pin family and lp build, rendered by the reference's integrator text (tests/golden/reference_integrator_golden_wide.npz): the HIP
+    path, with and without the tail kernel, against it — every pixel's bits and the ray counts. No oracle call here."""
+    pt, scenes, parallel, ptref = _imports()
+    make, S, w, h, first, n = _wide_cases()[name]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_integrator_golden_wide.npz"))
+    sc, cam = make()
+    t = pt.PathTracer(); t.set_tail_paths(tail); t.set_scene(sc); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.set_settings(S); t.resize(w, h); st = t.render(first, n)
+    got, want = t.radiance(), g[name]
+    bad = (got.view(np.uint32) != want.view(np.uint32)).any(-1)
+    assert not bad.any(), "%s: %d of %d pixels differ from the reference-text frame" % (name, int(bad.sum()), bad.size)
+    assert (st["extendRays"], st["shadowRays"]) == tuple(int(v) for v in g[name + "_rays"])
+    if tail: assert st["tailLaunches"] > 0
+
+
 def test_c_default_settings_are_the_reference_default_build():
     pt, scenes, parallel, ptref = _imports()
     t = pt.PathTracer()

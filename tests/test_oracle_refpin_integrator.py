@@ -76,6 +76,44 @@ def test_oracle_lp16_matches_live_reference_integrator(name):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and rays == rays_ref
 
 
+WIDE = pin_scenes.wide_cases()
+GOLDEN_WIDE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_integrator_golden_wide.npz")
+
+
+def _wide_frame(name, reference):
+    make, S, w, h, first, n = WIDE[name]
+    lp16 = bool(int(S["useFp16Types"]))
+    sc, cam = make()
+    o = ptref.Oracle(reference_integrator=True, settings=S, lp16=lp16) if reference else ptref.Oracle(lp16=lp16)
+    o.set_scene(sc); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(S); o.resize(w, h); o.render(first, n)
+    c = o.counters()
+    return o.radiance(), (c["extendRays"], c["shadowRays"])
+
+
+@pytest.mark.parametrize("name", list(WIDE))
+def test_oracle_matches_wide_reference_integrator_golden(name):
+    """256 x 144 x 4 samples per pin family and lp build (pin_scenes.wide_cases): 147 456 paths of the reference's integrator text per frame, so the late bounces,
+    the Russian-roulette survivors and the deep nested-dielectric stacks are compared thousands of times, not a handful."""
+    g = np.load(GOLDEN_WIDE)
+    got, rays = _wide_frame(name, reference=False)
+    want = g[name]
+    assert got.shape == want.shape == (144, 256, 4)
+    bad = (got.view(np.uint32) != want.view(np.uint32)).any(-1)
+    assert not bad.any(), "%s: %d of %d pixels differ from the reference-text frame" % (name, int(bad.sum()), bad.size)
+    assert tuple(int(v) for v in g[name + "_rays"]) == rays
+    assert rays[0] > 2 * 256 * 144 * 4 and np.isfinite(want).all()       # deeper than two bounces on average
+
+
+@pytest.mark.parametrize("name", list(WIDE))
+def test_wide_golden_is_the_live_reference_integrator(name):
+    if not os.path.isdir("/root/reference/Rtxpt/Shaders"):
+        pytest.skip("no /root/reference on this machine: the reference-text integrator cannot be built here")
+    g = np.load(GOLDEN_WIDE)
+    want, rays = _wide_frame(name, reference=True)
+    assert np.array_equal(g[name].view(np.uint32), want.view(np.uint32)) and tuple(int(v) for v in g[name + "_rays"]) == rays
+    if name.endswith("_lp16"): assert not np.array_equal(g[name], g[name[:-5]])       # the two builds differ
+
+
 @pytest.mark.parametrize("lp16", [False, True], ids=["fp32", "lp16"])
 @pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy"])
 def test_load_surface_matches_reference_text(name, lp16):
