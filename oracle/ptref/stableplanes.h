@@ -750,6 +750,14 @@ template <class PT> struct StablePlanesFiller {
         if (isMiss) HandleMiss(path, path.dir, sceneLength);
         return path;
     }
+    // FirstHitFromVBuffer's ray interval (PathTracerSample.hlsl:38, 56-58): [0.99, 1.01] x LastRayTCurrent when plane 0 holds a surface, the whole ray otherwise. A performance hint, as
+    // the reference says: the build pass found the closest hit of this very ray over the whole interval at LastRayTCurrent, so the narrowed ray finds the same one. The device's first
+    // traversal launch of the pass uses it (k_extend<., RANGED>); the oracle traces the whole interval.
+    void firstHitInterval(uint px, uint py, float& tmin, float& tmax) const {
+        const StablePlane& rec = sp.B.Planes[sp.PixelToAddress(px, py, 0)];
+        tmin = 0.f; tmax = kMaxRayTravel;
+        if (SP_isfinite(rec.SceneLength)) { tmin = rec.LastRayTCurrent * 0.99f; tmax = rec.LastRayTCurrent * 1.01f; }
+    }
     // GenerateScatterRay (PathTracer.hlsli:217-380, FILL)
     bool GenerateScatterRay(const ShadingData& sd, const StandardBSDF& bsdf, bool blockMVs, PathState& path, const SampleGeneratorVertexBase& sgBase) const {
         float4 u;

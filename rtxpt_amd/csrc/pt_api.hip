@@ -69,6 +69,9 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #ifndef PT_SP_FILL_CLASSES
 #define PT_SP_FILL_CLASSES 1     // the stable-plane fill pass shades in class order (k_classify), like reference mode; 0: queue order (A/B)
 #endif
+#ifndef PT_SP_FILL_RANGED
+#define PT_SP_FILL_RANGED 1      // the fill pass's first traversal launch uses FirstHitFromVBuffer's narrowed ray interval (pt_stableplanes.h firstHitInterval); 0: the whole ray (A/B) — same hits
+#endif
 #ifndef PT_TAIL_PATHS
 #define PT_TAIL_PATHS 32768u     // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never
 #endif
@@ -1412,7 +1415,7 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
             if (!t.active || t.iterations >= maxIter) continue;
             const uint nxt = t.cur ^ 1u;
             launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st);
-            launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st);
+            launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st, /*ranged*/ t.iterations == 0u && PT_SP_FILL_RANGED);
             launch_sp_fill_shade(t.k, sp, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.newL, sampleIndex, t.wc,
                                  (PT_SP_FILL_CLASSES && t.active >= PT_CLASSIFY_FROM) ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr, t.aux.counts + PASS_CLASS_OFFSET, t.st);      // (the straggler keys are idle between k_resolve_extend and the shadow launch, as in pt_render)
             t.rays += t.active;

@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(256) k_sp_build_shade(PKC k, StablePlanesConte
 // The visibility rays go through the reference mode's own shadow launches, unchanged: their "visible" action adds the entry's radiance to the L words of pool.s2 — here they are handed a
 // scratch copy of that stream and a unit radiance, so a visible entry leaves a mark that k_sp_fill_resolve turns into the float4 increment (total + specular average) this pass needs.
 template <class PKC>
-__global__ void __launch_bounds__(256) k_sp_fill_generate(PKC k, StablePlanesContext sp, PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint sampleIndex, uint* __restrict__ queue, uint* countPtr) {
-    const uint i = blockIdx.x * 256u + threadIdx.x;
+__global__ void __launch_bounds__(1024) k_sp_fill_generate(PKC k, StablePlanesContext sp, PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint sampleIndex, uint* __restrict__ queue, uint* countPtr) {
+    const uint i = blockIdx.x * 1024u + threadIdx.x;
     bool alive = false;
     if (i < numOwned) {
         const uint px = ownedPixels[i];
@@ -83,13 +83,18 @@ __global__ void __launch_bounds__(256) k_sp_fill_generate(PKC k, StablePlanesCon
         PathState p = f.generate(px >> 16, px & 0xFFFFu);
         sp_store_path(pool, i, p);
         alive = p.isActive();
+        if (alive) { float t0, t1; f.firstHitInterval(px >> 16, px & 0xFFFFu, t0, t1); pool.hit[i] = make_uint4(asuint(t0), asuint(t1), 0u, 0u); }      // the interval of the pass's first traversal launch (launch_extend(..., ranged)): the hit record is free until that launch fills it
     }
+    // one atomic per 1024-thread block: with one per wave the 130 000 waves of a 4K frame queue up on the counter's L2 line for 1.3 ms — longer than everything else the kernel does
+    // (k_shade's lesson once more; profiles/r04w_fill_kernel_stats_before.csv: 1.36 ms per pass)
+    __shared__ uint sCnt[16]; __shared__ uint sBase;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
-    const uint lane = threadIdx.x & 63u;
-    uint base = 0;
-    if (lane == 0u && m) base = atomicAdd(countPtr, (uint)__popcll(m));
-    base = __shfl(base, 0);
-    if (alive) queue[base + (uint)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    const uint lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0u) sCnt[wave] = (uint)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0u) { uint tot = 0; for (uint w = 0; w < 16u; w++) { const uint c = sCnt[w]; sCnt[w] = tot; tot += c; } sBase = tot ? atomicAdd(countPtr, tot) : 0u; }
+    __syncthreads();
+    if (alive) queue[sBase + sCnt[wave] + (uint)__popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 template <class PKC>
 __global__ void __launch_bounds__(256) k_sp_fill_shade(PKC k, StablePlanesContext sp, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr, uint* __restrict__ queueOut, uint* countOutPtr,
@@ -161,10 +166,11 @@ __global__ void __launch_bounds__(256) k_sp_fill_commit(PKC k, StablePlanesConte
     f.CommitDenoiserRadiance(path);
 }
 
-#define SP_LAUNCH(KERNEL, G, ...) do { if (k.S.useFp16Types) { PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16)); hipLaunchKernelGGL((KERNEL<PathKernelContextT<true>>), G, dim3(256), 0, st, k16, __VA_ARGS__); } \
-                                        else hipLaunchKernelGGL((KERNEL<PathKernelContext>), G, dim3(256), 0, st, k, __VA_ARGS__); } while (0)
+#define SP_LAUNCH_B(KERNEL, G, B, ...) do { if (k.S.useFp16Types) { PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16)); hipLaunchKernelGGL((KERNEL<PathKernelContextT<true>>), G, dim3(B), 0, st, k16, __VA_ARGS__); } \
+                                             else hipLaunchKernelGGL((KERNEL<PathKernelContext>), G, dim3(B), 0, st, k, __VA_ARGS__); } while (0)
+#define SP_LAUNCH(KERNEL, G, ...) SP_LAUNCH_B(KERNEL, G, 256, __VA_ARGS__)
 void launch_sp_fill_generate(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleIndex, uint* queue, uint* countPtr, hipStream_t st) {
-    SP_LAUNCH(k_sp_fill_generate, dim3((numOwned + 255u) / 256u), sp, pool, ownedPixels, numOwned, sampleIndex, queue, countPtr);
+    SP_LAUNCH_B(k_sp_fill_generate, dim3((numOwned + 1023u) / 1024u), 1024, sp, pool, ownedPixels, numOwned, sampleIndex, queue, countPtr);
 }
 void launch_sp_fill_shade(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, float4* newL,
                           uint sampleIndex, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st) {
@@ -180,6 +186,7 @@ void launch_sp_fill_commit(const PathKernelContext& k, const StablePlanesContext
     SP_LAUNCH(k_sp_fill_commit, dim3((numOwned + 255u) / 256u), sp, pool, numOwned, sampleIndex);
 }
 #undef SP_LAUNCH
+#undef SP_LAUNCH_B
 
 // DenoisingGuidesBaker.hlsl DenoiseSpecHitT: one thread per pixel, src -> dst
 __global__ void __launch_bounds__(256) k_sp_denoise_spec_hit_t(const float* __restrict__ src, const float* __restrict__ depth, float* __restrict__ dst, uint width, uint height) {

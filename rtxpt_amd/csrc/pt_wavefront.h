@@ -39,7 +39,7 @@ static const uint TRAV_COUNTERS = 5, TRAV_RESOLVE = 4, PASS_COUNTERS = 16, PASS_
 struct TravAux { TravTask* taskQ[2]; uint* counts; uint taskCap; unsigned long long* bestKey; uint* resolveList; const uint* primToSlot; uint maxBlocks; };      // maxBlocks: grid bound of the traversal launches (0: T8_MAX_BLOCKS)
 
 void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st);
-void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
+void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st, bool ranged = false);      // ranged: the rays' intervals wait in pool.hit[p].xy (k_extend)
 // classScratch (2 x countIn words: memory that is free between the extend and the shadow launches of a bounce) + classCount (3 words, zero on entry): k_classify's output; null = shade in queue order
 // launch_extend / launch_shade / launch_shadow expect the pass's counter block zeroed by the caller (launch_pass_reset)
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr,

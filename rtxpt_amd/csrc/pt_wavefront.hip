@@ -42,8 +42,10 @@ __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool 
     queue[i] = i;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool RANGED = false>
 __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux, uint rpc) {
+    // RANGED: every ray brings its own interval in the first two words of its (not yet written) hit record — the stable-plane fill pass's first launch, FirstHitFromVBuffer
+    // (pt_stableplanes.h firstHitInterval). A ray of such a launch that is cut into sub-trees continues over [0, best hit so far]: the lower bound is a hint, not part of the query.
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
     __shared__ uint rayBuf[T8_RAYBUF_WORDS];
     __shared__ float2 mineUV[T8_BLOCK];
@@ -54,13 +56,14 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
         uint4 a = pool.s0[p], b = pool.s1[p];
         o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)); d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
         tmin = 0.0f; tmax = kMaxRayTravel; startRef = 0u; bestT0 = kMaxRayTravel; bestPrim0 = 0xFFFFFFFFu;
+        if (RANGED) { const uint4 r = pool.hit[p]; tmin = asfloat(r.x); tmax = asfloat(r.y); bestT0 = tmax; }
         return p;
     };
     auto commit = [&](uint p, const HitInfo& h) { pool.hit[p] = make_uint4(asuint(h.t), h.prim, asuint(h.u), asuint(h.v)); };
     // a split ray: its best hit so far seeds the merge key, the resolve pass will write pool.hit (k_resolve_extend)
     auto publish = [&](uint p, float bestT, uint bestPrim) { aux.bestKey[p] = t8_hit_key(bestT, bestPrim); aux.resolveList[atomicAdd(&aux.counts[TRAV_RESOLVE], 1u)] = p; };
     if (COUNT) { ctr.rayIterHist = wc->rayIterHistExt; ctr.longRayCount = &wc->longRayCount; ctr.longRays = &wc->longRays[0][0]; }
-    T8_TRAVERSE<false, COUNT, true, false, true>(sc, count, rpc, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<false, COUNT, !RANGED, false, true>(sc, count, rpc, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); wave_add64(ctr.leafVisits, &wc->leafVisitsExt); wave_add64(ctr.iters, &wc->itersExt); wave_add64(ctr.leafBlocks, &wc->leafBlocksExt); if ((threadIdx.x & 63u) == 0u) atomicMax(&wc->itersMaxExt, (unsigned long long)ctr.iters);
                  if ((threadIdx.x & 63u) == 0u) for (int q = 0; q < 4; q++) atomicAdd(&wc->phaseCycExt[q], ctr.cyc[q]);
                  for (int q = 0; q < 8; q++) wave_add64(ctr.ev[q], &wc->eventsExt[q]); }
@@ -687,10 +690,12 @@ void launch_generate(const PathKernelContext& k, PathPool pool, const uint* owne
 }
 // task rounds + resolve pass of one traversal launch; all counts live on the device, so the grids are fixed (empty rounds return at once)
 static const uint T8_TASK_BLOCKS = T8_TASK_BLOCKS_N, T8_RESOLVE_BLOCKS = 256;
-void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
+void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st, bool ranged) {
     const uint rpc = rays_per_chunk(count);
     uint g = grid_for(count, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, (aux.maxBlocks && aux.maxBlocks < T8_MAX_BLOCKS) ? aux.maxBlocks : T8_MAX_BLOCKS);
-    if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
+    if (ranged) { if (counters) hipLaunchKernelGGL((k_extend<true, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
+                  else hipLaunchKernelGGL((k_extend<false, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc); }
+    else if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
     else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
     if (count <= T8_SHORT_TAIL_BELOW) {      // a small launch holds few stragglers and short ones: two task rounds (split once more, then finish) instead of four — late bounces are
         hipLaunchKernelGGL((k_extend_tasks<0>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);             // bound by the host's launch rate, not by the GPU

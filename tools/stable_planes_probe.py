@@ -9,6 +9,7 @@ from rtxpt_amd import scenes
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__); ap.add_argument("--width", type=int, default=3840); ap.add_argument("--height", type=int, default=2160); ap.add_argument("--frames", type=int, default=3)
+    ap.add_argument("--fill-only", type=int, default=0, help="for rocprofv3 kernel traces: one build pass, then this many fill passes as ONE batch (launches never overlap), nothing else")
     a = ap.parse_args(); w, h = a.width, a.height
     sc, cam = scenes.bistro_like(); sc["env_cube_dim"] = 2048; sc["env_compression"] = 1      # as bench.py
     S = scenes.default_settings(useFp16Types=1)
@@ -19,6 +20,11 @@ def main():
     fb = g.L.pt_build_stable_planes; fb.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]; fb.restype = ctypes.c_int32
     ff = g.L.pt_fill_stable_planes; ff.argtypes = fb.argtypes; ff.restype = ctypes.c_int32
     p = np.ascontiguousarray(prm); build, fill = [], []
+    if a.fill_only:
+        g._chk(fb(g.h, 0, ptr(p), None), "pt_build_stable_planes"); g.set_serial_kernels(True)
+        for f in range(a.fill_only):
+            sf = pt.PtFrameStats(); g._chk(ff(g.h, f, ptr(p), ctypes.byref(sf)), "pt_fill_stable_planes"); fill.append(sf.as_dict())
+        print(json.dumps({"fill_pass_single_batch_ms": [r["gpuMilliseconds"] for r in fill]})); return
     for f in range(a.frames + 1):
         sb, sf = pt.PtFrameStats(), pt.PtFrameStats()
         g._chk(fb(g.h, f, ptr(p), ctypes.byref(sb)), "pt_build_stable_planes"); g._chk(ff(g.h, f, ptr(p), ctypes.byref(sf)), "pt_fill_stable_planes")
