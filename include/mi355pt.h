@@ -359,6 +359,16 @@ int32_t pt_animate(pt_context* ctx, const PtInstanceDesc* instances, uint32_t nu
  * vertices belong to are rewritten (C5: 1 of 80 geometries; the upload shrinks from 14 MB to 0.3 MB). vertexRanges == NULL: every vertex, i.e. pt_animate. */
 int32_t pt_animate_ranges(pt_context* ctx, const PtInstanceDesc* instances, uint32_t numInstances, const float* positions, uint32_t numVertices,
                           const uint32_t* vertexRanges, uint32_t numRanges, int32_t rebuild);
+/* Motion history for the realtime passes. Donut keeps, per scene refresh, every node's previous global transform (SceneGraph::Refresh -> InstanceData.prevTransform) and the previous
+ * positions of the meshes its skinning pass rewrites (GeometryData.prevPositionOffset); Bridge::loadSurface makes prevPosW from them in the stable-plane build pass
+ * (Rtxpt/Shaders/PathTracerBridgeDonut.hlsli:187-199, 619, 631) and PathTracerStablePlanes.hlsli:286 turns prevPosW - posW into the motion vectors' object term.
+ * pt_set_motion_history(ctx, 1): from now on every pt_animate / pt_animate_ranges call is one scene refresh — the pose it finds becomes the previous pose (device-to-device copies
+ * of the instance table and of the vertex ranges that differ), the pose it brings the current one; a call with neither instances nor positions only advances the history (a frame
+ * in which nothing moved: previous = current; no refit, no re-bake). Off (the default, and what reference mode needs): object motion reads as zero, nothing is kept.
+ * pt_set_previous_pose hands the previous pose over directly (a host with its own history; arrays shaped like the scene's, either may be NULL = that part did not move) and
+ * turns the history on. Neither call touches the accumulation or the BVH. */
+int32_t pt_set_motion_history(pt_context* ctx, int32_t enable);
+int32_t pt_set_previous_pose(pt_context* ctx, const PtInstanceDesc* instances, uint32_t numInstances, const float* positions, uint32_t numVertices);
 /* deformed meshes' vertex normals / tangents (Donut's skinning rewrites them with the positions, Sample.cpp:1170-1198): replaces the packed streams of pt_set_geometry (either may be NULL)
    and rewrites the shading records; the BVH does not depend on them. Resets the accumulation like pt_animate. */
 int32_t pt_animate_normals(pt_context* ctx, const uint32_t* normalsSnorm8, const uint32_t* tangentsSnorm8, uint32_t numVertices);

@@ -557,6 +557,13 @@ class Oracle:
         self._inst = inst
         self.L.ptref_set_instances(self.h, _p(inst), len(inst))
 
+    def set_previous_pose(self, instances=None, positions=None):
+        """The previous frame's instance transforms / vertex positions (arrays shaped like the scene's; None = did not move): what the stable-plane build pass's motion vectors
+        see as object motion (Bridge::loadSurface's prevPosW)."""
+        self._prev = (None if instances is None else np.ascontiguousarray(instances), None if positions is None else np.ascontiguousarray(positions, np.float32))
+        self.L.ptref_set_previous_pose(self.h, _p(self._prev[0]) if self._prev[0] is not None else None, 0 if self._prev[0] is None else len(self._prev[0]),
+                                       _p(self._prev[1]) if self._prev[1] is not None else None, 0 if self._prev[1] is None else self._prev[1].shape[0])
+
     def set_camera(self, cam):
         self._cam = np.ascontiguousarray(cam)
         self.L.ptref_set_camera(self.h, _p(self._cam))

@@ -301,6 +301,19 @@ struct PathTracer {
         }
         if (cosTheta <= kCosThetaThreshold || recompute) computeTangentSpace(sd, tangentW, ignoreTangent);
     }
+    // prevPosW of Bridge::loadSurface in the stable-plane build pass (BridgeDonut:187-199, 619, 631): the hit point in the previous frame's pose — the previous positions of the
+    // triangle's vertices (Donut keeps them for skinned meshes; for the others they equal the current ones, which is what interpolating a copy gives) under the previous transform
+    float3 prevPosW(uint prim, float bu, float bv) const {
+        const Triangle& tr = sc.tris[prim];
+        const uint instanceIndex = sc.subInstToInstGeom[tr.subInstance].x;
+        const GeometryDesc& g = sc.geometries[sc.subInstances[tr.subInstance].GlobalGeometryIndex_PTMaterialDataIndex >> 16];
+        const float3x4& M = (sc.prevInstances.size() == sc.instances.size() ? sc.prevInstances : sc.instances)[instanceIndex].transform;
+        const std::vector<float3>& P = sc.prevPositions.size() == sc.positions.size() ? sc.prevPositions : sc.positions;
+        const float3 bary = make_float3(1.0f - (bu + bv), bu, bv);
+        const uint* idx = &sc.indices[g.indexOffset + tr.triIndex * 3];
+        const float3 objPos = (P[g.vertexOffset + idx[0]] * bary.x + P[g.vertexOffset + idx[1]] * bary.y) + P[g.vertexOffset + idx[2]] * bary.z;
+        return xform_point(M, objPos);
+    }
     SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone) const {
         const Triangle& tr = sc.tris[prim];
         uint subInst = tr.subInstance, triangleIndex = tr.triIndex;

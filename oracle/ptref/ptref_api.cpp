@@ -463,6 +463,12 @@ void ptref_set_geometry(void* h, const uint32_t* indices, uint32_t nIdx, const f
     c->geomDirty = true;
 }
 void ptref_set_instances(void* h, const InstanceDesc* inst, uint32_t n) { Context* c = (Context*)h; c->sc.instances.assign(inst, inst + n); c->geomDirty = true; }
+// the previous frame's instance transforms and vertex positions (same counts as the scene's; NULL / 0 = did not move): Bridge::loadSurface's prevPosW in the stable-plane build pass
+void ptref_set_previous_pose(void* h, const InstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts) {
+    Context* c = (Context*)h; Scene& sc = c->sc;
+    if (inst && nInst) sc.prevInstances.assign(inst, inst + nInst); else sc.prevInstances.clear();
+    if (positions && nVerts) { sc.prevPositions.resize(nVerts); memcpy(sc.prevPositions.data(), positions, (size_t)nVerts * 12); } else sc.prevPositions.clear();
+}
 void ptref_set_materials(void* h, const PTMaterialData* m, uint32_t n) { Context* c = (Context*)h; c->sc.materials.assign(m, m + n); c->geomDirty = true; }
 // format: 0 = RGBA8 UNORM, 1 = RGBA8 sRGB (rgb decoded to linear at load, like an _SRGB view), 2 = RGBA32F
 void ptref_add_texture(void* h, uint32_t w, uint32_t hgt, uint32_t format, const void* pixels) {

@@ -170,6 +170,8 @@ struct Scene {
     std::vector<GeometryDesc> geometries; std::vector<MeshDesc> meshes; std::vector<InstanceDesc> instances;
     std::vector<PTMaterialData> materials; std::vector<Texture> textures;
     EnvMap env;
+    // the pose of the frame before (ptref_set_previous_pose; Donut's InstanceData.prevTransform and GeometryData.prevPositionOffset): empty = the scene did not move
+    std::vector<float3> prevPositions; std::vector<InstanceDesc> prevInstances;
     // derived
     std::vector<uint> instFirstSubInstance;                 // InstanceData.firstGeometryInstanceIndex
     std::vector<uint2> subInstToInstGeom;                   // subInstance -> (instanceIndex, global geometry index)

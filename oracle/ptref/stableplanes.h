@@ -431,7 +431,7 @@ template <class PT> struct StablePlanesBuilder {
         return newPath;
     }
     // PathTracerStablePlanes.hlsli:104-330 (BUILD)
-    void StablePlanesHandleHit(PathState& path, float3 rayOrigin, float3 rayDir, float rayTCurrent, const SurfaceData& surfaceData, const SPMaterialInfo& mi, bool pathStopping) const {
+    void StablePlanesHandleHit(PathState& path, float3 rayOrigin, float3 rayDir, float rayTCurrent, const SurfaceData& surfaceData, const SPMaterialInfo& mi, bool pathStopping, float3 prevPosW) const {      // prevPosW: SurfaceData's member in this mode (PathTracerTypes.hlsli:58)
         const uint vertexIndex = path.getVertexIndex();
         const uint currentSPIndex = SP_getStablePlaneIndex(path);
         const uint px = path.id >> 16, py = path.id & 0xFFFFu;
@@ -483,7 +483,7 @@ template <class PT> struct StablePlanesBuilder {
             const bool blockedAtSurface = SP_GetMotionVectorSceneLength(path) != 0;
             float sceneLengthForMVs = blockedAtSurface ? SP_GetMotionVectorSceneLength(path) : path.sceneLength;
             float3 virtualWorldPos = camO + camD * sceneLengthForMVs;
-            float3 worldMotion = make_float3(0.f);      // prevPosW - posW: the scene keeps no previous-frame positions (object motion reads as zero; camera motion comes from the two matrices)
+            float3 worldMotion = prevPosW - surfaceData.shadingData.posW;      // PathTracerStablePlanes.hlsli:286; exactly zero where the scene did not move (the same arithmetic on the same operands)
             float3 virtualWorldMotion = mul(imageXform, worldMotion);
             float3 motionVectors = sp.computeMotionVector(virtualWorldPos, virtualWorldPos + virtualWorldMotion);
             float roughness = saturate(surfaceData.bsdf.data.roughness);
@@ -559,7 +559,7 @@ template <class PT> struct StablePlanesBuilder {
         }
         if (any_gt0(surfaceEmission)) sp.AccumulateStableRadiance(path.id >> 16, path.id & 0xFFFFu, path.GetThp() * surfaceEmission);
         bool pathStopping = path.isTerminatingAtNextBounce();
-        StablePlanesHandleHit(path, rayOrigin, rayDir, rayTCurrent, surfaceData, mi, pathStopping);
+        StablePlanesHandleHit(path, rayOrigin, rayDir, rayTCurrent, surfaceData, mi, pathStopping, pt.prevPosW(prim, bu, bv));
         if (pathStopping) { path.terminate(); return; }
         path.SetThp(path.GetThp() * make_float3(1.0f));      // UpdatePathThroughput(path, GetThpRuRuCorrection()): 1 in this pass
     }

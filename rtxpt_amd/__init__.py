@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_realtime_frame", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -812,6 +812,17 @@ class PathTracer:
         f = self.L.pt_animate_ranges; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32]; f.restype = ctypes.c_int32
         r = np.ascontiguousarray(np.asarray(vertex_ranges, np.uint32).reshape(-1, 2))
         self._chk(f(self.h, _p(instances), 0 if instances is None else len(instances), _p(positions), 0 if positions is None else positions.shape[0], _p(r), len(r), 1 if rebuild else 0), "pt_animate_ranges")
+
+    def set_motion_history(self, enable=True):
+        """pt_set_motion_history: every animate() call is a scene refresh from now on (the pose it finds becomes the previous pose); the stable-plane build pass's motion vectors carry object motion"""
+        f = self.L.pt_set_motion_history; f.argtypes = [ctypes.c_void_p, ctypes.c_int32]; f.restype = ctypes.c_int32
+        self._chk(f(self.h, 1 if enable else 0), "pt_set_motion_history")
+
+    def set_previous_pose(self, instances=None, positions=None):
+        """pt_set_previous_pose: the previous frame's instance transforms / vertex positions handed over directly (None = that part did not move)"""
+        f = self.L.pt_set_previous_pose; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]; f.restype = ctypes.c_int32
+        a = None if instances is None else np.ascontiguousarray(instances); b = None if positions is None else np.ascontiguousarray(positions, np.float32)
+        self._chk(f(self.h, _p(a), 0 if a is None else len(a), _p(b), 0 if b is None else b.shape[0]), "pt_set_previous_pose")
 
     def animate_normals(self, normals=None, tangents=None):
         """pt_animate_normals: the deformed meshes' packed vertex normals / tangents (uint32 per vertex, SNORM8) — with pt_animate(positions) a skinned frame is complete"""

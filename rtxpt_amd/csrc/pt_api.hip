@@ -97,6 +97,7 @@ struct pt_context {
     DevBuf<float> dLightW; DevBuf<uint> dProxyOffsets; void* dScanTemp = nullptr; size_t scanTempBytes = 0;
     // device
     DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
+    DevBuf<float> dPrevPositions; DevBuf<InstanceDesc> dPrevInstances; bool motionHistory = false, prevAllStale = false; std::vector<uint32_t> prevStaleRanges;      // pt_set_motion_history: the previous frame's pose; the (first, count) vertex ranges in which it differs from the current one
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::AlphaPlane> dAlphaPlanes; DevBuf<unsigned char> dAlphaPool; DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
     bool skyEnabled = false; ptk::ProceduralSkyContext sky; DevBuf<ptk::float4> dSkyTex[4]; DevBuf<ptk::ProceduralSkyContext> dSky; DevBuf<ptk::uint2> dSkyLowRes;      // pt_set_procedural_sky
@@ -258,6 +259,8 @@ void refresh_scene_view(pt_context* c) {
     d.travSpill = c->dTravSpill.p;                           // allocated (and checked) by finalize_geometry
     d.indices = c->dIndices.p; d.positions = c->dPositions.p; d.uvs = c->dUvs.p; d.normals = c->dNormals.p; d.tangents = c->dTangents.p;
     d.geometries = c->dGeometries.p; d.instances = c->dInstances.p; d.subInstances = c->dSubInstances.p; d.subInstToInstGeom = c->dSubInstToInstGeom.p;
+    const bool prevPose = c->motionHistory && c->dPrevPositions.p && c->dPrevInstances.p && c->dPrevPositions.n >= c->positions.size() && c->dPrevInstances.n >= c->instances.size();
+    d.prevPositions = prevPose ? c->dPrevPositions.p : nullptr; d.prevInstances = prevPose ? c->dPrevInstances.p : nullptr;
     d.materials = c->dMaterials.p; d.materialCount = (uint)c->materials.size(); d.textures = c->dTexInfos.p; d.texels = c->dTexels.p;
     d.envCube = c->envCube; d.envCube.texels = c->dEnvCube.p;
     d.sky = c->skyEnabled ? c->dSky.p : nullptr; memset(&d.skyLowRes, 0, sizeof(d.skyLowRes)); d.skyLowRes.texels = c->dSkyLowRes.p; d.skyLowRes.dim = c->envCubeDim / 2u; d.skyLowRes.mipLevels = 1u;
@@ -684,7 +687,7 @@ int32_t pt_destroy(pt_context* c) {
     c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free(); c->dLightW.free(); c->dProxyOffsets.free(); if (c->dScanTemp) (void)hipFree(c->dScanTemp);
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
-    c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
+    c->dPrevPositions.free(); c->dPrevInstances.free(); c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
     c->dPrimInfo.free(); c->dShadeTris.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
@@ -1006,10 +1009,60 @@ int32_t pt_reset_accumulation(pt_context* c) {
     return PT_OK;
 }
 int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts, int32_t rebuild) { return pt_animate_ranges(c, inst, nInst, positions, nVerts, nullptr, 0u, rebuild); }
+// Motion history (Donut: SceneGraph::Refresh keeps every node's previous global transform, the skinning pass the previous positions of the meshes it rewrites; InstanceData.prevTransform,
+// GeometryData.prevPositionOffset): with it on, every pt_animate / pt_animate_ranges call is one scene refresh — the pose it finds becomes the previous pose, the pose it brings the
+// current one — and the stable-plane build pass's motion vectors carry the objects' motion (Bridge::loadSurface's prevPosW). A call without instances and positions only advances the
+// history (a frame in which nothing moved: previous = current, no refit). Device-to-device copies of the instance table and of the vertex ranges that differ.
+static int32_t motion_history_sync(pt_context* c) {
+    if (!c->motionHistory) return PT_OK;
+    const bool fresh = c->dPrevPositions.n < c->positions.size() || c->dPrevInstances.n < c->instances.size() || !c->dPrevPositions.p || !c->dPrevInstances.p;
+    PT_CHECK_HIP(c, c->dPrevPositions.resize(c->positions.size())); PT_CHECK_HIP(c, c->dPrevInstances.resize(c->instances.size()));
+    if (c->instances.size()) PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevInstances.p, c->dInstances.p, sizeof(InstanceDesc) * c->instances.size(), hipMemcpyDeviceToDevice, c->stream));
+    if (fresh || c->prevAllStale) { if (c->positions.size()) PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevPositions.p, c->dPositions.p, 4 * c->positions.size(), hipMemcpyDeviceToDevice, c->stream)); }
+    else for (size_t r = 0; r + 1 < c->prevStaleRanges.size(); r += 2) {
+        const size_t first = 3 * (size_t)c->prevStaleRanges[r], count = 3 * (size_t)c->prevStaleRanges[r + 1];
+        if (count) PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevPositions.p + first, c->dPositions.p + first, 4 * count, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->prevAllStale = false; c->prevStaleRanges.clear();
+    return PT_OK;
+}
+int32_t pt_set_motion_history(pt_context* c, int32_t enable) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (!enable) { c->motionHistory = false; c->dPrevPositions.free(); c->dPrevInstances.free(); c->prevStaleRanges.clear(); c->prevAllStale = false; refresh_scene_view(c); return PT_OK; }
+    if (c->geomDirty || c->texDirty) { int r = prepare(c); if (r != PT_OK) return r; }
+    if (!c->motionHistory) { c->motionHistory = true; c->prevAllStale = true; int r = motion_history_sync(c); if (r != PT_OK) return r; }      // previous = current: nothing has moved yet
+    refresh_scene_view(c);
+    return PT_OK;
+}
+// the previous pose handed over directly (a host that keeps its own history, or a test): arrays shaped like the scene's; either may be NULL (= that part did not move). Turns the history on.
+int32_t pt_set_previous_pose(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (c->geomDirty || c->texDirty) { int r = prepare(c); if (r != PT_OK) return r; }
+    if (inst && nInst != c->instances.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_set_previous_pose: instance count differs from the scene's");
+    if (positions && (size_t)nVerts * 3 != c->positions.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_set_previous_pose: vertex count differs from the scene's");
+    c->motionHistory = true; c->prevAllStale = true;
+    int r = motion_history_sync(c); if (r != PT_OK) return r;
+    if (inst) { static_assert(sizeof(PtInstanceDesc) == sizeof(InstanceDesc), "instance layout"); PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevInstances.p, inst, sizeof(InstanceDesc) * nInst, hipMemcpyHostToDevice, c->stream)); }
+    if (positions) { PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevPositions.p, positions, 12 * (size_t)nVerts, hipMemcpyHostToDevice, c->stream)); c->prevAllStale = true; }      // (differs anywhere: the next refresh copies everything)
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    refresh_scene_view(c);
+    return PT_OK;
+}
+
 int32_t pt_animate_ranges(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts, const uint32_t* vertexRanges, uint32_t nRanges, int32_t rebuild) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
     if (c->geomDirty || c->texDirty) { int r = prepare(c); if (r != PT_OK) return r; }
+    if (inst && nInst != c->instances.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: instance count must not change");
+    if (positions && (size_t)nVerts * 3 != c->positions.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: vertex count must not change");
+    if (positions && vertexRanges) for (uint32_t r = 0; r < nRanges; r++) if ((unsigned long long)vertexRanges[2 * r] + vertexRanges[2 * r + 1] > nVerts) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate_ranges: vertex range beyond the vertex count");
+    if (c->motionHistory) {      // one scene refresh: what is current becomes previous (before the uploads below overwrite it)
+        int r = motion_history_sync(c); if (r != PT_OK) return r;
+        if (positions) { if (vertexRanges) c->prevStaleRanges.assign(vertexRanges, vertexRanges + 2 * (size_t)nRanges); else c->prevAllStale = true; }
+        if (!inst && !positions) { PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); refresh_scene_view(c); return PT_OK; }
+    }
     static const bool animLog = getenv("MI355PT_ANIMATE_LOG") != nullptr;      // developer probe: host-side time of every step of the call (stderr)
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tA = now(); double tB = tA, tC = tA, tD = tA, tE = tA;

@@ -280,6 +280,23 @@ template <bool LP16> struct PathKernelContextT {
         }
         if (cosTheta <= kCosThetaThreshold || recompute) computeTangentSpace(sd, tangentW, ignoreTangent);
     }
+    // prevPosW of Bridge::loadSurface in the stable-plane build pass (BridgeDonut:187-199, 619, 631): the hit point in the previous frame's pose — the previous positions of the
+    // triangle's vertices (Donut keeps them for skinned meshes; for the others they equal the current ones, which is what interpolating a copy gives) under the previous transform.
+    // Only the base vertices of the planes ask for it: the reference's own five-hop gather is good enough here.
+    float3 prevPosW(uint prim, float bu, float bv) const {
+        const uint2 pinfo = sc.primInfo[prim];
+        const uint2 ig = sc.subInstToInstGeom[pinfo.x];
+        const GeometryDesc& g = sc.geometries[ig.y];
+        const float3x4& M = (sc.prevInstances ? sc.prevInstances : sc.instances)[ig.x].transform;
+        const float* P = sc.prevPositions ? sc.prevPositions : sc.positions;
+        const float3 bary = make_float3(1.0f - (bu + bv), bu, bv);
+        const uint* idx = sc.indices + g.indexOffset + pinfo.y * 3;
+        const uint vi[3] = {g.vertexOffset + idx[0], g.vertexOffset + idx[1], g.vertexOffset + idx[2]};
+        float3 vp[3];
+        for (int k = 0; k < 3; k++) vp[k] = make_float3(P[3 * vi[k]], P[3 * vi[k] + 1], P[3 * vi[k] + 2]);
+        const float3 objPos = (vp[0] * bary.x + vp[1] * bary.y) + vp[2] * bary.z;
+        return xform_point(M, objPos);
+    }
     // Bridge::loadSurface (BridgeDonut:612-853): the divergent gather of the pipeline
     SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone) const {
 #if PT_SHADE_TRI

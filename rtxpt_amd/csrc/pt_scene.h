@@ -128,6 +128,7 @@ static_assert(sizeof(ShadeTri) == 128, "ShadeTri must be one 128-byte line");
 
 struct DeviceScene {
     const uint* indices; const float* positions; const float2* uvs; const uint* normals; const uint* tangents;
+    const float* prevPositions; const InstanceDesc* prevInstances;      // the previous frame's pose (pt_set_motion_history / pt_set_previous_pose), or null: the stable-plane build pass's object motion
     const GeometryDesc* geometries; const InstanceDesc* instances; const SubInstanceData* subInstances; const uint2* subInstToInstGeom;
     const PTMaterialData* materials; uint materialCount;
     const TexInfo* textures; const float4* texels;

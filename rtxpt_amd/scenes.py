@@ -759,6 +759,25 @@ def animate_instances(sc, t):
     return inst
 
 
+def previous_pose(sc, seed=0):
+    """A previous frame for any scene (tests of the motion vectors' object term): every other instance shifted and turned a little about y, and the vertices of every third
+    geometry displaced by a smooth wave — (instances, positions) shaped like sc["instances"] / sc["positions"], for pt_set_previous_pose / Oracle.set_previous_pose."""
+    rng = np.random.default_rng(1000 + seed)
+    inst = sc["instances"].copy()
+    for i in range(0, len(inst), 2):
+        T = inst["transform"][i].reshape(3, 4).astype(np.float64)
+        a = float(rng.uniform(-0.06, 0.06)); c, s_ = math.cos(a), math.sin(a)
+        R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])
+        T[:, :3] = R @ T[:, :3]; T[:, 3] = R @ T[:, 3] + rng.uniform(-0.05, 0.05, 3)
+        inst["transform"][i] = T.astype(np.float32).reshape(inst["transform"][i].shape)
+    pos = sc["positions"].copy()
+    for g in range(0, len(sc["geometries"]), 3):
+        first, n = int(sc["geometries"]["vertexOffset"][g]), int(sc["geometries"]["numVertices"][g])
+        p = pos[first:first + n]
+        p[:, 1] += (0.02 * np.sin(7.0 * p[:, 0] + 3.0 * p[:, 2] + g)).astype(np.float32)
+    return inst, pos
+
+
 def procedural_sky_textures(seed=SEED_BASE + 21, clouds=(64, 64, 16)):
     """Synthetic stand-ins for the four look-up textures of the procedural sky (the reference loads q2rtx_env/{transmittance,inscatter,irradiance}_earth.dds and
     clouds.dds, which no checkout carries): the sizes precomputed_sky.hlsli expects — transmittance 256x64, in-scatter (8*32)x128x32, irradiance 64x16 — smooth,

@@ -28,8 +28,11 @@ def run_oracle(name, reference):
         t, j, pc = filler.neeat_tables(); fw, fc = filler.neeat_feedback()
         return dict(table=t, jitter=np.array(j, np.uint32), counters=pc, fbw=fw, fbc=fc, noisy=rc.live_noisy(frame, w, h), spec_hit_t=frame["spec_hit_t"], depth=frame["depth"],
                     motion_vectors=frame["motion_vectors"], header=frame["header"])
+    def pose(cur, prev):      # an animated case: the frame's pose into both contexts (a fresh upload: the oracle has no refit), the previous one as the scene's motion history
+        posed = dict(sc); posed["instances"], posed["positions"] = cur
+        for o in ([filler] if builder is filler else [filler, builder]): o.set_scene(posed); o.set_previous_pose(*prev)
     out = rc.run(name, filler.neeat_update_begin, lambda s, prm: builder.build_stable_planes(s, prm), lambda fr: filler.neeat_update_end(fr["depth"], fr["motion_vectors"]),
-                 lambda s, prm, fr: filler.fill_stable_planes(s, prm, fr), read, set_camera)
+                 lambda s, prm, fr: filler.fill_stable_planes(s, prm, fr), read, set_camera, pose)
     out[name + "_rays"] = np.array([filler.counters()["extendRays"] + (0 if builder is filler else builder.counters()["extendRays"]), filler.counters()["shadowRays"]], np.uint64)
     filler.close()
     if builder is not filler: builder.close()

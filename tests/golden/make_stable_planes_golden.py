@@ -33,4 +33,17 @@ for name in spc.cases():
     hd = r["header"]
     print(name, "planes", [int((hd[i] != 0xFFFFFFFF).sum()) for i in range(3)], "dominant", np.unique(hd[3] & 3, return_counts=True)[1].tolist(), "rays", o.counters()["extendRays"])
     o.close()
+# object motion: the same frames with a previous pose in the scene (InstanceData.prevTransform, GeometryData.prevPositionOffset of the pin's bindings) — the build pass only, it is the one that asks
+from rtxpt_amd import scenes
+for name, base in spc.motion_cases().items():
+    sc, camd, S, prm, lp16 = spc.setup(base)
+    o = ptref.Oracle(reference_integrator=True, settings=S, lp16=lp16, mode=1)
+    o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(spc.W, spc.H); o.set_previous_pose(*scenes.previous_pose(sc))
+    r = o.build_stable_planes(spc.SAMPLE, prm)
+    for k in spc.KEYS:
+        if k != "planes": out[name + "_" + k] = r[k].copy()
+    out[name + "_live_planes"] = spc.live_planes(r)
+    moved = (out[name + "_motion_vectors"] != out[base + "_motion_vectors"]).reshape(spc.H, spc.W, -1).any(-1)
+    print(name, "pixels whose motion vectors differ from", base, ":", int(moved.sum()), "of", moved.size); assert moved.sum() > moved.size // 2
+    o.close()
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "stable_planes_golden.npz"), **out)

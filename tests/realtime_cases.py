@@ -20,7 +20,16 @@ def cases():
         "bistro_like_realtime": (bl, d(NEEType=2), 96, 54, 4, 1, (0.35, 0.02, -0.2), {}),                                  # the reference's defaults, one sub-sample
         "bistro_like_realtime_lp16_2sub": (bl, d(NEEType=2, useFp16Types=1), 64, 36, 3, 2, (0.6, 0.0, 0.25), {}),          # binary16 lp types, two sub-samples feeding one reservoir plane
         "zoo_realtime": (scenes.stable_planes_zoo, _zoo_settings(), 64, 48, 3, 1, (0.03, 0.01, 0.02), {}),      # delta trees (mirror, glass): the dominant plane's depth and motion
+        # the scene moves as well (C5's: rigid props, a deforming mesh, nested-dielectric props, emissive triangles that are re-baked every frame): object motion in the motion vectors
+        # (Bridge::loadSurface's prevPosW), so the baker's Reproject follows the objects; "anim_dt" is the scene time per frame (popped before the keywords reach stable_planes_params)
+        "bistro_like_c5_realtime_animated": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), d(NEEType=2, nestedDielectricsQuality=2), 96, 54, 3, 1, (0.2, 0.0, -0.1), {"anim_dt": 0.45}),
     }
+
+
+def poses(sc, kw, frames):
+    """[(instances, positions)] per frame for an animated case, else None; frame f's previous pose is frame f - 1's, frame 0's the scene as uploaded"""
+    if "anim_dt" not in kw: return None
+    return [(scenes.animate_instances(sc, kw["anim_dt"] * f), scenes.animate_positions(sc, kw["anim_dt"] * f)) for f in range(frames)]
 
 
 def camera(cam, step, f):
@@ -39,12 +48,15 @@ def live_noisy(frame, w, h):
 def settings_for(name): return cases()[name][1]
 
 
-def run(name, begin, build, end, fill, read, set_camera):
-    """Drives one case through callbacks (oracle, reference text or device): returns {"<name>_<key><frame>": array}."""
+def run(name, begin, build, end, fill, read, set_camera, pose=None):
+    """Drives one case through callbacks (oracle, reference text or device): returns {"<name>_<key><frame>": array}. pose(current, previous): called before every frame of an
+    animated case with the (instances, positions) pairs of the frame and of the one before."""
     make, _, w, h, frames, subs, step, kw = cases()[name]
     sc, cam = make()
+    P = poses(sc, kw, frames); kw = {k: v for k, v in kw.items() if k != "anim_dt"}
     out = {}
     for f in range(frames):
+        if P is not None: pose(P[f], P[f - 1] if f else (sc["instances"], sc["positions"]))
         cur, prev = camera(cam, step, f), camera(cam, step, max(f - 1, 0))
         prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cur), prev_world_to_clip=scenes.view_projection(w, h, **prev), sub_samples=subs, **kw)
         set_camera(scenes.bridge_camera(w, h, **cur))

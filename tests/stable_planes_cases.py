@@ -26,6 +26,11 @@ def setup(name):
     return sc, camd, S, prm, lp16
 
 
+def motion_cases():
+    """Object motion (Bridge::loadSurface's prevPosW; pt_set_previous_pose / pt_set_motion_history): name -> the case of cases() it adds scenes.previous_pose() to. The camera moves as well."""
+    return {"zoo_object_motion": "zoo_fp32", "zoo_object_motion_lp16": "zoo_lp16"}
+
+
 def live_planes(out):
     """the records of the planes that exist (the others hold whatever the buffer held before: nothing writes them)"""
     hd = out["header"]; P = out["planes"].reshape(-1, 20)

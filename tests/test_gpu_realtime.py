@@ -23,8 +23,11 @@ def test_device_matches_the_reference_text_run(name):
     make, _, w, h, frames, subs, step, kw = rc.cases()[name]; S = rc.settings_for(name)
     sc, cam = make()
     t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h); t.set_neeat(True)
+    P = rc.poses(sc, kw, frames); kw = {k: v for k, v in kw.items() if k != "anim_dt"}
+    if P is not None: t.set_motion_history(True)      # an animated case: every pt_animate is a scene refresh (refit, light re-bake, the pose it finds becomes the previous one)
     rays = [0, 0]
     for f in range(frames):
+        if P is not None: t.animate(P[f][0], P[f][1], vertex_ranges=scenes.animated_vertex_ranges(sc) if f % 2 else None)
         cur, prev = rc.camera(cam, step, f), rc.camera(cam, step, max(f - 1, 0))
         prm = scenes.stable_planes_params(w, h, scenes.view_projection(w, h, **cur), prev_world_to_clip=scenes.view_projection(w, h, **prev), sub_samples=subs, **kw)
         t.set_camera(scenes.bridge_camera(w, h, **cur))

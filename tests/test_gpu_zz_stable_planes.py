@@ -46,6 +46,35 @@ def test_device_matches_reference_text(name):
     t.close()
 
 
+@pytest.mark.parametrize("name", list(spc.motion_cases()))
+def test_object_motion_matches_reference_text(name):
+    """Object motion in the motion vectors (pt_set_previous_pose / pt_set_motion_history; Bridge::loadSurface's prevPosW): the device against the reference text's build pass with a
+    previous pose bound — first handed over directly, then arrived at the way a host does it: the scene uploaded in its previous pose, the history switched on, pt_animate to the
+    current pose (refit), then a refresh in which nothing moves."""
+    g = np.load(GOLD); base = spc.motion_cases()[name]
+    sc, camd, S, prm, lp16 = spc.setup(base)
+    prev_inst, prev_pos = scenes.previous_pose(sc)
+    t = _tracer(sc, camd, S, spc.W, spc.H)
+    _compare(base + " (no history)", t.build_stable_planes(spc.SAMPLE, prm), lambda k: g[base + "_" + k], g[base + "_live_planes"])
+    t.set_previous_pose(prev_inst, prev_pos)
+    _compare(name, t.build_stable_planes(spc.SAMPLE, prm), lambda k: g[name + "_" + k], g[name + "_live_planes"])
+    t.set_motion_history(False)
+    _compare(base + " (history off again)", t.build_stable_planes(spc.SAMPLE, prm), lambda k: g[base + "_" + k], g[base + "_live_planes"])
+    t.close()
+    past = dict(sc); past["instances"] = prev_inst; past["positions"] = prev_pos
+    t = _tracer(past, camd, S, spc.W, spc.H); t.set_motion_history(True)
+    t.animate(sc["instances"], sc["positions"])                           # one refresh: previous = what was there, current = the case's pose (refitted tree)
+    _compare(name + " (pt_animate)", t.build_stable_planes(spc.SAMPLE, prm), lambda k: g[name + "_" + k], g[name + "_live_planes"])
+    t.animate(None, None)                                                  # a frame in which nothing moves: previous = current
+    _compare(base + " (refresh without motion)", t.build_stable_planes(spc.SAMPLE, prm), lambda k: g[base + "_" + k], g[base + "_live_planes"])
+    # ranges: only the geometries scenes.previous_pose displaced are named
+    t.animate(prev_inst, prev_pos); 
+    rngs = [(int(sc["geometries"]["vertexOffset"][k]), int(sc["geometries"]["numVertices"][k])) for k in range(0, len(sc["geometries"]), 3)]
+    t.animate(sc["instances"], sc["positions"], vertex_ranges=rngs)
+    _compare(name + " (pt_animate_ranges)", t.build_stable_planes(spc.SAMPLE, prm), lambda k: g[name + "_" + k], g[name + "_live_planes"])
+    t.close()
+
+
 def _oracle_frame(sc, camd, S, prm, w, h, sample, lp16):
     from oracle import ptref
     o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)

@@ -56,3 +56,26 @@ def test_the_motion_vectors_are_used():
     assert _same(out["%s_table0" % name], g["%s_table0" % name])      # frame 0: no history, nothing to reproject
     for f in range(1, frames): assert not _same(out["%s_table%d" % (name, f)], g["%s_table%d" % (name, f)]), f      # from frame 1 on the reservoirs are fetched from where the pixels were
     o.close()
+
+
+def test_object_motion_is_in_the_animated_run():
+    """The animated case without a previous pose in the scene (object motion reads as zero, the camera's stays): the build pass's motion vectors differ from the committed run from
+    frame 0 on — the fixture's motion vectors do carry the objects' motion — while depth and header, which do not ask for the previous pose, stay."""
+    from oracle import ptref
+    from rtxpt_amd import scenes
+    name = "bistro_like_c5_realtime_animated"
+    make, _, w, h, frames, subs, step, kw = rc.cases()[name]; S = rc.settings_for(name)
+    sc, cam = make()
+    o = ptref.Oracle(lp16=bool(int(S["useFp16Types"]))); o.set_scene(sc); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(S); o.resize(w, h); o.set_neeat(True)
+    def pose(cur, prev):
+        posed = dict(sc); posed["instances"], posed["positions"] = cur; o.set_scene(posed)
+    def read(frame): return dict(motion_vectors=frame["motion_vectors"], depth=frame["depth"], header=frame["header"])
+    out = rc.run(name, o.neeat_update_begin, lambda s, prm: o.build_stable_planes(s, prm), lambda fr: o.neeat_update_end(fr["depth"], fr["motion_vectors"]),
+                 lambda s, prm, fr: o.fill_stable_planes(s, prm, fr), read, o.set_camera, pose)
+    g = np.load(GOLDEN)
+    for f in range(frames):
+        a, b = out["%s_motion_vectors%d" % (name, f)], g["%s_motion_vectors%d" % (name, f)]
+        moved = (np.asarray(a) != np.asarray(b)).reshape(h, w, -1).any(-1)
+        assert 20 < moved.sum() < moved.size // 2, (f, int(moved.sum()))      # the animated props and the banner, not the street
+        assert _same(out["%s_depth%d" % (name, f)], g["%s_depth%d" % (name, f)]) and _same(out["%s_header%d" % (name, f)], g["%s_header%d" % (name, f)])
+    o.close()

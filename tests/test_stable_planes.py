@@ -39,6 +39,33 @@ def test_reference_text_compiled_live_equals_the_fixture():
     check_against_fixture("zoo_fp32", r)
 
 
+@pytest.mark.parametrize("name", list(spc.motion_cases()))
+def test_object_motion_oracle_equals_the_reference_text_fixture(name):
+    """The motion vectors' object term: Bridge::loadSurface's prevPosW (previous vertex positions under the previous instance transform; BridgeDonut:187-199, 631) and
+    PathTracerStablePlanes.hlsli:286. The fixture is the reference text's build pass with InstanceData.prevTransform and GeometryData.prevPositionOffset bound to a previous pose."""
+    base = spc.motion_cases()[name]
+    sc, camd, S, prm, lp16 = spc.setup(base)
+    o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(spc.W, spc.H)
+    still = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in o.build_stable_planes(spc.SAMPLE, prm).items()}
+    check_against_fixture(base, still)                                     # without a previous pose: the frame of the case it is built on
+    o.set_previous_pose(*scenes.previous_pose(sc))
+    r = o.build_stable_planes(spc.SAMPLE, prm)
+    check_against_fixture(name, r)
+    changed = (r["motion_vectors"] != still["motion_vectors"]).reshape(spc.H, spc.W, -1).any(-1)
+    assert changed.sum() > changed.size // 2
+    for k in ("header", "stable_radiance", "depth", "throughput"): assert np.array_equal(r[k].view(np.uint8), still[k].view(np.uint8)), k      # only the motion moves
+    o.set_previous_pose(None, None)                                        # cleared: the still frame again
+    check_against_fixture(base, o.build_stable_planes(spc.SAMPLE, prm)); o.close()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Rtxpt/Shaders"), reason="needs the reference text")
+def test_object_motion_reference_text_compiled_live_equals_the_fixture():
+    name = "zoo_object_motion"; sc, camd, S, prm, lp16 = spc.setup(spc.motion_cases()[name])
+    o = ptref.Oracle(reference_integrator=True, settings=S, lp16=lp16, mode=1); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(spc.W, spc.H)
+    o.set_previous_pose(*scenes.previous_pose(sc))
+    check_against_fixture(name, o.build_stable_planes(spc.SAMPLE, prm)); o.close()
+
+
 def test_structure_of_a_frame():
     name = "zoo_fp32"
     r, prm = oracle_run(name)
