@@ -277,6 +277,7 @@ void refresh_scene_view(pt_context* c) {
 }
 
 // SubInstanceData fill (Rtxpt/Materials/MaterialsBaker.cpp:960-1017) + primitive table; then GPU LBVH build
+static int32_t motion_history_sync(pt_context* c);
 int finalize_geometry(pt_context* c) {
     c->subInstances.clear(); c->subInstToInstGeom.clear(); c->primInfo.clear(); c->subInstFirstPrim.clear();
     for (size_t i = 0; i < c->instances.size(); i++) {
@@ -315,6 +316,7 @@ int finalize_geometry(pt_context* c) {
     PT_CHECK_HIP(c, c->dGeometries.upload(c->geometries, st)); PT_CHECK_HIP(c, c->dInstances.upload(c->instances, st));
     PT_CHECK_HIP(c, c->dSubInstances.upload(c->subInstances, st)); PT_CHECK_HIP(c, c->dSubInstToInstGeom.upload(c->subInstToInstGeom, st));
     PT_CHECK_HIP(c, c->dPrimInfo.upload(c->primInfo, st)); PT_CHECK_HIP(c, c->dMaterials.upload(c->materials, st));
+    if (c->motionHistory) { c->prevAllStale = true; c->prevStaleRanges.clear(); int r = motion_history_sync(c); if (r != PT_OK) return r; }      // a new scene: its history starts here (previous = current)
     if (c->bvhAllocated && c->bvh.capacity < c->numTris) { bvh_free(c->bvh); c->bvhAllocated = false; }
     if (!c->bvhAllocated) { PT_CHECK_HIP(c, bvh_alloc(c->bvh, c->numTris)); c->bvhAllocated = true; }
     c->bvh.builder = c->bvhBuilder;

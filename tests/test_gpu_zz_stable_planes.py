@@ -75,6 +75,18 @@ def test_object_motion_matches_reference_text(name):
     t.close()
 
 
+def test_motion_history_restarts_with_a_new_scene():
+    """History on, then another scene with other array sizes: the previous pose is the new scene's own (no motion), not stale memory of the old one."""
+    g = np.load(GOLD)
+    big, _ = scenes.bistro_like(scale=0.01, tex_size=64, animated=True)
+    sc, camd, S, prm, lp16 = spc.setup("zoo_fp32")
+    t = _tracer(big, camd, S, spc.W, spc.H); t.set_motion_history(True); t.animate(scenes.animate_instances(big, 1.0), scenes.animate_positions(big, 1.0))
+    t.build_stable_planes(spc.SAMPLE, prm)
+    t.set_scene(sc)
+    _compare("zoo_fp32 after a scene change", t.build_stable_planes(spc.SAMPLE, prm), lambda k: g["zoo_fp32_" + k], g["zoo_fp32_live_planes"])
+    t.close()
+
+
 def _oracle_frame(sc, camd, S, prm, w, h, sample, lp16):
     from oracle import ptref
     o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_camera(camd); o.set_settings(S); o.resize(w, h)
