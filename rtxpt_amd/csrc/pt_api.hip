@@ -277,7 +277,20 @@ void refresh_scene_view(pt_context* c) {
 }
 
 // SubInstanceData fill (Rtxpt/Materials/MaterialsBaker.cpp:960-1017) + primitive table; then GPU LBVH build
-static int32_t motion_history_sync(pt_context* c);
+// (pt_set_motion_history, below) previous pose <- current pose, on the device
+static int32_t motion_history_sync(pt_context* c) {
+    if (!c->motionHistory) return PT_OK;
+    const bool fresh = c->dPrevPositions.n < c->positions.size() || c->dPrevInstances.n < c->instances.size() || !c->dPrevPositions.p || !c->dPrevInstances.p;
+    PT_CHECK_HIP(c, c->dPrevPositions.resize(c->positions.size())); PT_CHECK_HIP(c, c->dPrevInstances.resize(c->instances.size()));
+    if (c->instances.size()) PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevInstances.p, c->dInstances.p, sizeof(InstanceDesc) * c->instances.size(), hipMemcpyDeviceToDevice, c->stream));
+    if (fresh || c->prevAllStale) { if (c->positions.size()) PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevPositions.p, c->dPositions.p, 4 * c->positions.size(), hipMemcpyDeviceToDevice, c->stream)); }
+    else for (size_t r = 0; r + 1 < c->prevStaleRanges.size(); r += 2) {
+        const size_t first = 3 * (size_t)c->prevStaleRanges[r], count = 3 * (size_t)c->prevStaleRanges[r + 1];
+        if (count) PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevPositions.p + first, c->dPositions.p + first, 4 * count, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->prevAllStale = false; c->prevStaleRanges.clear();
+    return PT_OK;
+}
 int finalize_geometry(pt_context* c) {
     c->subInstances.clear(); c->subInstToInstGeom.clear(); c->primInfo.clear(); c->subInstFirstPrim.clear();
     for (size_t i = 0; i < c->instances.size(); i++) {
@@ -1015,19 +1028,6 @@ int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, co
 // GeometryData.prevPositionOffset): with it on, every pt_animate / pt_animate_ranges call is one scene refresh — the pose it finds becomes the previous pose, the pose it brings the
 // current one — and the stable-plane build pass's motion vectors carry the objects' motion (Bridge::loadSurface's prevPosW). A call without instances and positions only advances the
 // history (a frame in which nothing moved: previous = current, no refit). Device-to-device copies of the instance table and of the vertex ranges that differ.
-static int32_t motion_history_sync(pt_context* c) {
-    if (!c->motionHistory) return PT_OK;
-    const bool fresh = c->dPrevPositions.n < c->positions.size() || c->dPrevInstances.n < c->instances.size() || !c->dPrevPositions.p || !c->dPrevInstances.p;
-    PT_CHECK_HIP(c, c->dPrevPositions.resize(c->positions.size())); PT_CHECK_HIP(c, c->dPrevInstances.resize(c->instances.size()));
-    if (c->instances.size()) PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevInstances.p, c->dInstances.p, sizeof(InstanceDesc) * c->instances.size(), hipMemcpyDeviceToDevice, c->stream));
-    if (fresh || c->prevAllStale) { if (c->positions.size()) PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevPositions.p, c->dPositions.p, 4 * c->positions.size(), hipMemcpyDeviceToDevice, c->stream)); }
-    else for (size_t r = 0; r + 1 < c->prevStaleRanges.size(); r += 2) {
-        const size_t first = 3 * (size_t)c->prevStaleRanges[r], count = 3 * (size_t)c->prevStaleRanges[r + 1];
-        if (count) PT_CHECK_HIP(c, hipMemcpyAsync(c->dPrevPositions.p + first, c->dPositions.p + first, 4 * count, hipMemcpyDeviceToDevice, c->stream));
-    }
-    c->prevAllStale = false; c->prevStaleRanges.clear();
-    return PT_OK;
-}
 int32_t pt_set_motion_history(pt_context* c, int32_t enable) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
