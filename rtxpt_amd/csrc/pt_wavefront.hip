@@ -147,25 +147,38 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
 // term (PF_terminateAtNextBounce). k_classify makes the classes contiguous (continuing hits from the front of one array, terminating hits from its back, misses
 // in a second one; one atomic per class per 1024 paths), so all but two waves of a launch are of one class and the short classes leave early. Radiance, queues
 // and counters do not depend on the order in which paths are shaded.
+#define PT_CLASSIFY_ITEMS 4u      // paths per thread: 4096 per block, one atomic per class and block (with 1024 per block the 32 000 blocks of a 4K bounce spent 0.3 ms queueing on three L2 lines)
 __global__ void __launch_bounds__(1024) k_classify(PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr, uint* __restrict__ classQ, uint* __restrict__ classCount) {
-    __shared__ uint waveCnt[16][3]; __shared__ uint blockBase[3];
-    const uint count = *countInPtr, i = blockIdx.x * 1024u + threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint p = 0, cls = 3u;                                     // 0 continuing hit, 1 terminating hit, 2 miss, 3 out of range
-    if (i < count) {
-        p = queueIn[i];
-        const uint prim = reinterpret_cast<const uint*>(pool.hit)[4u * (size_t)p + 1u], flags = reinterpret_cast<const uint*>(pool.s4)[4u * (size_t)p + 2u];
-        cls = (prim == 0xFFFFFFFFu) ? 2u : (((flags >> kVertexIndexBitCount) & PF_terminateAtNextBounce) ? 1u : 0u);
+    __shared__ uint waveCnt[PT_CLASSIFY_ITEMS][16][3]; __shared__ uint blockBase[3];
+    const uint count = *countInPtr, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint p[PT_CLASSIFY_ITEMS], cls[PT_CLASSIFY_ITEMS]; unsigned long long mine[PT_CLASSIFY_ITEMS];      // cls: 0 continuing hit, 1 terminating hit, 2 miss, 3 out of range
+#pragma unroll
+    for (uint j = 0; j < PT_CLASSIFY_ITEMS; j++) {
+        const uint i = (blockIdx.x * PT_CLASSIFY_ITEMS + j) * 1024u + threadIdx.x;
+        p[j] = 0u; cls[j] = 3u;
+        if (i < count) {
+            p[j] = queueIn[i];
+            const uint prim = reinterpret_cast<const uint*>(pool.hit)[4u * (size_t)p[j] + 1u], flags = reinterpret_cast<const uint*>(pool.s4)[4u * (size_t)p[j] + 2u];
+            cls[j] = (prim == 0xFFFFFFFFu) ? 2u : (((flags >> kVertexIndexBitCount) & PF_terminateAtNextBounce) ? 1u : 0u);
+        }
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cls[j] == 0u), m1 = __builtin_amdgcn_ballot_w64(cls[j] == 1u), m2 = __builtin_amdgcn_ballot_w64(cls[j] == 2u);
+        if (lane == 0u) { waveCnt[j][wave][0] = (uint)__popcll(m0); waveCnt[j][wave][1] = (uint)__popcll(m1); waveCnt[j][wave][2] = (uint)__popcll(m2); }
+        mine[j] = cls[j] == 0u ? m0 : (cls[j] == 1u ? m1 : m2);
     }
-    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cls == 0u), m1 = __builtin_amdgcn_ballot_w64(cls == 1u), m2 = __builtin_amdgcn_ballot_w64(cls == 2u);
-    if (lane == 0u) { waveCnt[wave][0] = (uint)__popcll(m0); waveCnt[wave][1] = (uint)__popcll(m1); waveCnt[wave][2] = (uint)__popcll(m2); }
     __syncthreads();
-    if (threadIdx.x < 3u) { uint tot = 0; for (uint w = 0; w < 16u; w++) { uint c = waveCnt[w][threadIdx.x]; waveCnt[w][threadIdx.x] = tot; tot += c; } blockBase[threadIdx.x] = tot ? atomicAdd(&classCount[threadIdx.x], tot) : 0u; }
+    if (threadIdx.x < 3u) {      // exclusive prefix over (item, wave) in queue order, then the block's base
+        uint tot = 0;
+        for (uint j = 0; j < PT_CLASSIFY_ITEMS; j++) for (uint w = 0; w < 16u; w++) { const uint c = waveCnt[j][w][threadIdx.x]; waveCnt[j][w][threadIdx.x] = tot; tot += c; }
+        blockBase[threadIdx.x] = tot ? atomicAdd(&classCount[threadIdx.x], tot) : 0u;
+    }
     __syncthreads();
-    if (cls > 2u) return;
-    const unsigned long long mine = cls == 0u ? m0 : (cls == 1u ? m1 : m2);
-    const uint rank = blockBase[cls] + waveCnt[wave][cls] + (uint)__popcll(mine & ((1ull << lane) - 1ull));
-    // continuing hits from the front of [0, count), terminating hits from its back (they cannot meet: together they are at most count), misses in [count, 2 count)
-    classQ[cls == 0u ? rank : (cls == 1u ? count - 1u - rank : count + rank)] = p;
+#pragma unroll
+    for (uint j = 0; j < PT_CLASSIFY_ITEMS; j++) {
+        if (cls[j] > 2u) continue;
+        const uint rank = blockBase[cls[j]] + waveCnt[j][wave][cls[j]] + (uint)__popcll(mine[j] & ((1ull << lane) - 1ull));
+        // continuing hits from the front of [0, count), terminating hits from its back (they cannot meet: together they are at most count), misses in [count, 2 count)
+        classQ[cls[j] == 0u ? rank : (cls[j] == 1u ? count - 1u - rank : count + rank)] = p[j];
+    }
 }
 
 // PKC: PathKernelContextT<false> (lp types in fp32) or PathKernelContextT<true> (the reference's default build, lp types in binary16)
@@ -711,13 +724,13 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
 }
 // k_classify for a caller in another translation unit (the stable-plane fill pass): classScratch 2 x countIn words, classCount 3 words (zero on entry)
 void launch_classify(PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* classScratch, uint* classCount, hipStream_t st) {
-    hipLaunchKernelGGL(k_classify, dim3((countIn + 1023) / 1024), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
+    hipLaunchKernelGGL(k_classify, dim3((countIn + 1024u * PT_CLASSIFY_ITEMS - 1u) / (1024u * PT_CLASSIFY_ITEMS)), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
 }
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc,
                   uint* classScratch, uint* classCount, hipStream_t st) {
     const dim3 g((countIn + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), b(PT_SHADE_BLOCK);
     if (PT_SHADE_CLASSES && classScratch) {                   // (scratch: 2 x countIn words, free between the extend and the shadow launches; classCount: 3 words, zeroed with the pass's traversal counters)
-        hipLaunchKernelGGL(k_classify, dim3((countIn + 1023) / 1024), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
+        hipLaunchKernelGGL(k_classify, dim3((countIn + 1024u * PT_CLASSIFY_ITEMS - 1u) / (1024u * PT_CLASSIFY_ITEMS)), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
         queueIn = classScratch;
     } else classCount = nullptr;
     // NEE-AT (a local sampling table and / or temporal feedback, pt_set_local_light_sampling) runs its own instantiations: the frames without it keep their kernels unchanged
