@@ -29,6 +29,9 @@ __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { retur
 #ifndef T8_POP2
 #define T8_POP2 0
 #endif
+#ifndef T8_REFILL_BATCH
+#define T8_REFILL_BATCH 1u   // idle pairs that must have gathered before the refill block runs. Round 4 A/B (profiles/r04y_refill_batch_ab.txt): 1 / 2 / 4 / 8 = k_extend 43.2 / 43.2 / 43.4 / 44.7 ms —
+#endif                       // what the rarer refill saves, the waiting pairs cost. 1.
 #ifndef T8_POP_ONCE
 #define T8_POP_ONCE 0        // 1: one pop trip (two entries) per wave iteration instead of a loop until a live entry is found. Round 4 A/B (profiles/r04v_pop_once_ab.txt): pop trips
 #endif                       //    per iteration 3.14 -> 0.97, wave iterations per ray 0.58 -> 0.61, k_extend 43.7 -> 43.2 ms (within noise): the pop loop is not where the phase's time goes. Off.
@@ -95,6 +98,9 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         // ---- refill idle pairs from the wave's current chunk
         bool need = !active && !exhausted;
         unsigned long long needMask = t8_ballot(need && h == 0u);
+        // T8_REFILL_BATCH > 1: the refill block (an LDS gather and ~40 instructions for the whole wave, whoever needs it) runs when that many pairs are idle, or when nothing else
+        // would run this iteration — an idle pair waits a few iterations for company
+        if (T8_REFILL_BATCH > 1u && needMask && (uint)__popcll(needMask) < T8_REFILL_BATCH && t8_ballot(active) != 0ull) needMask = 0ull;
         if (needMask) {
             T8_EVENT(0, true);
             if (chunkPos >= chunkEnd) {
