@@ -29,12 +29,10 @@ __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { retur
 #ifndef T8_POP2
 #define T8_POP2 0
 #endif
-#ifndef T8_DENSE_LEAF
-#define T8_DENSE_LEAF 0      // 1 (closest-hit rays only): the leaf block takes (ray, triangle) pairs from ALL postponed leaves of the wave, packed densely over the 64 lanes (see the block below)
-#endif
-#ifndef T8_DENSE_MIN
-#define T8_DENSE_MIN 60u     // lanes' worth of postponed leaves (two per leaf) that must have gathered before the dense leaf block runs
-#endif
+// A dense leaf block was built and measured in round 4 (commit "Dense leaf block ...", profiles/r04y_dense_leaf_ab.txt): the triangles of ALL postponed leaves of the wave numbered by a
+// prefix sum and handed to the 64 lanes in that order, the owning ray read through ds_bpermute, every pair collecting the best of its items. Bit-exact — and k_extend 43.6 -> 49.5 ms
+// (6 waves per SIMD, no spills; 56.7 ms at 7 waves with 24 bytes of scratch): the block is dearer (190 instead of 150 instructions) and hardly rarer (0.55 instead of 0.65 per
+// iteration), because what forces it is not the batch size but the 1.7 rays per iteration that have nothing left but a leaf — they cannot be replaced before it is tested.
 #ifndef T8_REFILL_BATCH
 #define T8_REFILL_BATCH 1u   // idle pairs that must have gathered before the refill block runs. Round 4 A/B (profiles/r04y_refill_batch_ab.txt): 1 / 2 / 4 / 8 = k_extend 43.2 / 43.2 / 43.4 / 44.7 ms —
 #endif                       // what the rarer refill saves, the waiting pairs cost. 1.
@@ -178,11 +176,8 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         const bool leafReady = active && (pend != BVH_EMPTY);
         const bool queueFull = (T8_LEAF_QUEUE == 1) ? true : ((T8_LEAF_QUEUE == 2) ? (pend1 != BVH_EMPTY) : (pend2 != BVH_EMPTY));
         const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT) && ((cur == BVH_EMPTY && (!T8_POP_ONCE || sp == 0u)) || queueFull);
-        constexpr bool DENSE = T8_DENSE_LEAF && !ANYHIT && !TASKS;
-        bool runLeaves;
-        if (DENSE) runLeaves = ((uint)__popcll(t8_ballot(leafReady)) + (uint)__popcll(t8_ballot(active && pend1 != BVH_EMPTY)) + (uint)__popcll(t8_ballot(active && pend2 != BVH_EMPTY)) >= T8_DENSE_MIN) || (t8_ballot(leafBlocked) != 0ull);
-        else runLeaves = ((uint)__popcll(t8_ballot(leafReady && h == 0u)) >= (uint)T8_LEAF_BATCH) || (t8_ballot(leafBlocked) != 0ull);
-        const bool leaf = leafReady && runLeaves && !DENSE;
+        const bool runLeaves = ((uint)__popcll(t8_ballot(leafReady && h == 0u)) >= (uint)T8_LEAF_BATCH) || (t8_ballot(leafBlocked) != 0ull);
+        const bool leaf = leafReady && runLeaves;
         if (COUNT && leaf && h == 0u) ctr.leafVisits++;
         T8_EVENT(2, inner); T8_EVENT(3, leaf);
 
@@ -274,67 +269,6 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
             cur = next;
         }
 
-        if (DENSE && runLeaves) {
-            // ---- dense leaf block (round 4). The pair-per-ray leaf block leaves lanes idle twice over: a leaf of one triangle uses one lane of its pair, and the block runs for the
-            // whole wave whenever 20 of the 32 rays have a leaf waiting. Here every postponed leaf of the wave (up to three per ray) contributes its triangles as work items, the items
-            // are numbered by a prefix sum over the pairs and handed to the lanes in that order — lane j tests item j against the ray of the pair that owns it, which it reads
-            // from the owner's registers (ds_bpermute) — and every pair then collects the best of its own items. Same tests on the same operands as the pair-per-ray block; the closest
-            // hit is a minimum over (t, primitive), so the order cannot matter. The item list (64 words per wave) lives in the second half of mineUV, whose first half holds the
-            // winners' barycentrics per PAIR in this build.
-            const uint cA = leafReady ? (pend & 7u) + 1u : 0u, cB = (active && pend1 != BVH_EMPTY) ? (pend1 & 7u) + 1u : 0u, cC = (active && pend2 != BVH_EMPTY) ? (pend2 & 7u) + 1u : 0u;
-            const uint kItems = cA + cB + cC;
-            const unsigned long long belowPair = (1ull << pl) - 1ull;
-            uint pre = 0u;
-#pragma unroll
-            for (uint b = 0; b < 3u; b++) pre += (uint)__popcll(t8_ballot(((kItems >> b) & 1u) && h == 0u) & belowPair) << b;
-            const bool incl = kItems && (pre + kItems <= 64u);          // pairs are served in lane order; what does not fit stays postponed (the served pairs are empty next time)
-            const unsigned long long inclMask = t8_ballot(incl);
-            const uint total = inclMask ? (uint)__builtin_amdgcn_readlane((int)(pre + kItems), 63 - (int)__clzll((long long)inclMask)) : 0u;
-            uint* wl = reinterpret_cast<uint*>(mineUV + T8_GROUPS_PER_BLOCK) + (threadIdx.x >> 6) * 64u;
-            if (incl) {
-                const uint owner = (lane >> 1) << 27;
-                if (h < cA) wl[pre + h] = owner | (((pend & 0x7FFFFFFFu) >> 3) + h);
-                if (h < cB) wl[pre + cA + h] = owner | (((pend1 & 0x7FFFFFFFu) >> 3) + h);
-                if (h < cC) wl[pre + cA + cB + h] = owner | (((pend2 & 0x7FFFFFFFu) >> 3) + h);
-            }
-            const bool has = lane < total;
-            const uint desc = has ? wl[lane] : 0u;
-            const int src = (int)((desc >> 27) << 3);                  // byte address of the owner pair's first lane for ds_bpermute
-            const uint triSlot = desc & 0x07FFFFFFu;
-            auto pull = [&](int from, uint v) { return (uint)__builtin_amdgcn_ds_bpermute(from, (int)v); };
-            const float3 fo = make_float3(__uint_as_float(pull(src, __float_as_uint(o.x))), __uint_as_float(pull(src, __float_as_uint(o.y))), __uint_as_float(pull(src, __float_as_uint(o.z))));
-            const float3 fd = make_float3(__uint_as_float(pull(src, __float_as_uint(d.x))), __uint_as_float(pull(src, __float_as_uint(d.y))), __uint_as_float(pull(src, __float_as_uint(d.z))));
-            const float fix = __uint_as_float(pull(src, __float_as_uint(ix))), fiy = __uint_as_float(pull(src, __float_as_uint(iy))), fiz = __uint_as_float(pull(src, __float_as_uint(iz)));
-            const float fbestT = __uint_as_float(pull(src, __float_as_uint(bestT))); const uint fbestPrim = pull(src, bestPrim);
-            const float ftmin = FIXED_RANGE ? 0.f : __uint_as_float(pull(src, __float_as_uint(tmin))), ftmax = FIXED_RANGE ? kMaxRayTravel : __uint_as_float(pull(src, __float_as_uint(tmax)));
-            float rt = __uint_as_float(INF_BITS), ru = 0.f, rv = 0.f; uint rp = 0xFFFFFFFFu;
-            if (has) {
-                const char* tp = trisBase + triSlot * 48u;
-                const f32x4 ta = *reinterpret_cast<const f32x4*>(tp), tb4 = *reinterpret_cast<const f32x4*>(tp + 16), tc = *reinterpret_cast<const f32x4*>(tp + 32);
-                TriRecord tr; tr.v0 = make_float3(ta.x, ta.y, ta.z); tr.prim = __float_as_uint(ta.w);
-                tr.e1 = make_float3(tb4.x, tb4.y, tb4.z); tr.flags = __float_as_uint(tb4.w); tr.e2 = make_float3(tc.x, tc.y, tc.z); tr.pad = tc.w;
-                if (COUNT) ctr.triTests++;
-                float t, u, v;
-                if (intersect_tri_mt(tr, fo, fd, ftmin, ftmax, t, u, v)) {
-                    bool c = (t < fbestT) || (t == fbestT && tr.prim < fbestPrim);
-                    if (c) c = t8_tri_box_accepts(tr, fo, fix, fiy, fiz, t);
-                    if (c && (tr.flags & 1u)) c = alpha_test_slot(sc, triSlot, u, v);
-                    if (c) { rt = t; rp = tr.prim; ru = u; rv = v; }
-                }
-            }
-            // every pair collects its own items (both lanes of the pair compute the same)
-            float nb = bestT; uint np = bestPrim, bi = 0xFFFFFFFFu;
-#pragma unroll
-            for (uint i = 0; i < 6u; i++) {
-                const int from = (int)(((pre + i) & 63u) << 2);
-                const float ti = __uint_as_float(pull(from, __float_as_uint(rt))); const uint pi = pull(from, rp);
-                if (incl && i < kItems && ((ti < nb) || (ti == nb && pi < np))) { nb = ti; np = pi; bi = pre + i; }
-            }
-            const float wu = __uint_as_float(pull((int)((bi & 63u) << 2), __float_as_uint(ru))), wv = __uint_as_float(pull((int)((bi & 63u) << 2), __float_as_uint(rv)));
-            if (bi != 0xFFFFFFFFu) { bestT = nb; bestPrim = np; if (h == 0u) { minePrim = np; mineUV[grp] = make_float2(wu, wv); } }
-            if (incl) { pend = BVH_EMPTY; pend1 = BVH_EMPTY; pend2 = BVH_EMPTY; }
-            if (COUNT && lane == 0u) ctr.leafBlocks++;
-        }
         if (COUNT) { tc2 = __builtin_readcyclecounter(); if (t8_ballot(leaf) != 0ull && lane == 0u) ctr.leafBlocks++; }
         // ---- postponed leaf: lane h tests triangles h, h + 2 (h + 4, h + 6 when leaves hold up to 8)
         if (leaf) {
@@ -449,7 +383,6 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     }
                     else if (ANYHIT) { if (h == 0u) { HitInfo hh; hh.t = tmax; hh.prim = 0xFFFFFFFFu; hh.u = hh.v = 0.f; commit(tag, hh); } }
                     else if (bestPrim == 0xFFFFFFFFu) { if (h == 0u) { HitInfo hh; hh.t = bestT; hh.prim = 0xFFFFFFFFu; hh.u = hh.v = 0.f; commit(tag, hh); } }
-                    else if (DENSE) { if (h == 0u) { float2 uv = mineUV[grp]; HitInfo hh; hh.t = bestT; hh.prim = bestPrim; hh.u = uv.x; hh.v = uv.y; commit(tag, hh); } }
                     else if (minePrim == bestPrim) { float2 uv = mineUV[threadIdx.x]; HitInfo hh; hh.t = bestT; hh.prim = bestPrim; hh.u = uv.x; hh.v = uv.y; commit(tag, hh); }
                     active = false;
                 }
