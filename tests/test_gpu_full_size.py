@@ -89,3 +89,43 @@ def test_c5_full_size_4k_animated_refit_rows_bit_exact():
     assert g.build_stats()["buildMs"] < 100.0
     g.reset_accumulation(); g.render(SPP, SPP)
     assert np.array_equal(a, g.radiance())
+
+
+def test_realtime_frames_4k_animated_match_oracle():
+    """The realtime mode's coupled frame (pt_realtime_frame: baker UpdateBegin, build pass, UpdateEnd on the frame's depth + motion vectors, fill pass feeding the reservoirs) at
+    3840x2160 on C5's scene, two frames with the camera and the scene moving in between (pt_set_motion_history, pt_animate_ranges: refit, light re-bake, object motion in the motion
+    vectors): header, depth, motion vectors, specular hit distances, stable radiance, throughput, every live plane record, NEE-AT's tile tables and the reservoirs the fill pass
+    left — all of both frames bit for bit against the oracle. At this size the passes run as four pipelined batches and the fill pass's first launch uses the narrowed ray interval."""
+    pt, scenes, ptref = _imports()
+    sc, cam = scenes.bistro_like(scale=1.0, tex_size=1024, animated=True)
+    S = scenes.default_settings(NEEType=2, nestedDielectricsQuality=2, useFp16Types=1)      # the reference's default build
+    step, dt, frames = (0.35, 0.02, -0.2), 0.45, 2
+    def camera(f): c = dict(cam); c["pos"] = tuple(np.asarray(cam["pos"], np.float64) + np.asarray(step) * f); return c
+    poses = [(scenes.animate_instances(sc, dt * f), scenes.animate_positions(sc, dt * f)) for f in range(frames)]
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(S); g.set_camera(scenes.bridge_camera(W, H, **cam)); g.resize(W, H); g.set_neeat(True); g.set_motion_history(True)
+    o = ptref.Oracle(lp16=bool(int(S["useFp16Types"]))); o.set_scene(sc); o.set_settings(S); o.set_camera(scenes.bridge_camera(W, H, **cam)); o.resize(W, H); o.set_neeat(True)
+    same = lambda a, b: np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+    for f in range(frames):
+        cur, prev = camera(f), camera(max(f - 1, 0))
+        prm = scenes.stable_planes_params(W, H, scenes.view_projection(W, H, **cur), prev_world_to_clip=scenes.view_projection(W, H, **prev), sub_samples=1)
+        camd = scenes.bridge_camera(W, H, **cur)
+        g.animate(poses[f][0], poses[f][1], vertex_ranges=scenes.animated_vertex_ranges(sc) if f else None); g.set_camera(camd)
+        got, bst, fst = g.realtime_frame(f, prm)
+        posed = dict(sc); posed["instances"], posed["positions"] = poses[f]
+        o.set_scene(posed); o.set_previous_pose(*(poses[f - 1] if f else (sc["instances"], sc["positions"]))); o.set_camera(camd)
+        o.neeat_update_begin(); want = o.build_stable_planes(f, prm); o.neeat_update_end(want["depth"], want["motion_vectors"]); o.fill_stable_planes(f, prm, want)
+        for k in ("header", "depth", "motion_vectors", "spec_hit_t", "stable_radiance", "throughput"):
+            assert same(got[k], want[k]), "frame %d: %s differs" % (f, k)
+        hd = want["header"]; P, Q = got["planes"].reshape(-1, 20), want["planes"].reshape(-1, 20)
+        for pl in range(3):      # the records of the planes that exist (sampled: every 7th live pixel of each plane)
+            ys, xs = np.nonzero(hd[pl] != 0xFFFFFFFF); ys, xs = ys[::7], xs[::7]
+            idx = np.array([scenes.stable_planes_address(int(x), int(y), pl, W, H) for x, y in zip(xs, ys)], np.int64)
+            assert same(P[idx], Q[idx]), "frame %d: plane %d records differ" % (f, pl)
+        tab, jit = g.neeat_tables(); wtab, wjit, _ = o.neeat_tables()
+        assert same(tab, wtab) and tuple(int(v) for v in jit) == tuple(int(v) for v in wjit), "frame %d: tile tables" % f
+        fw, fc = g.light_feedback(0); wfw, wfc = o.neeat_feedback()
+        assert same(fw, wfw) and same(fc, wfc), "frame %d: reservoirs" % f
+        mv = np.asarray(want["motion_vectors"]).reshape(H, W, -1)
+        assert (mv[..., :2] != 0).any()
+    assert int(bst["extendRays"]) > W * H and int(fst["shadowRays"]) > 0
+    g.close(); o.close()
