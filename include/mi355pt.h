@@ -330,6 +330,19 @@ int32_t pt_gather_stable_planes(pt_context* ctx);
  * come from the tile tables just built and whose visible samples fill the reservoirs the next frame's UpdateBegin reads. Without pt_set_neeat: build + fill passes with the global sampler.
  * The host calls pt_denoise_spec_hit_t / pt_stable_planes_merge / pt_get_stable_planes afterwards as it needs them. Whole frames only (no tile shards: the baker reads neighbourhoods). */
 int32_t pt_realtime_frame(pt_context* ctx, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* buildStats, PtFrameStats* fillStats);
+/* The realtime frame on TILE SHARDS with NEE-AT (no reference analogue). The baker's passes read whole neighbourhoods of three things a rank has for its own tiles only: last
+ * frame's reservoirs (UpdateBegin), this frame's depth and motion vectors (UpdateEnd). With a communicator (pt_comm_init) pt_realtime_frame exchanges both itself — RCCL
+ * point-to-point in one group, un-padded: 12 bytes per pixel before UpdateBegin, 16 after the build pass — and every rank runs the same baker passes on the same planes: tables,
+ * proxy counts and, after pt_gather_stable_planes, the frame equal the unsharded run's. Without a communicator the host drives the parts and moves the packed buffers:
+ *   pt_neeat_pack_feedback / pt_neeat_unpack_feedback (from the second frame on) -> pt_neeat_update_begin -> pt_build_stable_planes ->
+ *   pt_pack_stable_plane_guides / pt_unpack_stable_plane_guides -> pt_neeat_update_end -> pt_fill_stable_planes.
+ * pt_neeat_update_begin / pt_neeat_update_end are LightsBaker::UpdateBegin / UpdateEnd (Rtxpt/Sample.cpp:1380-1412, 2491-2494) as calls of their own; UpdateEnd reads the depth and
+ * motion vectors the last pt_build_stable_planes left. The guides of a rank: depth, specular hit distance, motion vectors — 16 bytes per pixel in the rank's pixel order
+ * (pt_shard_layout). */
+int32_t pt_neeat_update_begin(pt_context* ctx);
+int32_t pt_neeat_update_end(pt_context* ctx);
+int32_t pt_pack_stable_plane_guides(pt_context* ctx, void* deviceDst, size_t bytes);
+int32_t pt_unpack_stable_plane_guides(pt_context* ctx, const void* deviceSrc, size_t bytes, uint32_t rank);
 /* copies the last pass's buffers to the host; any pointer may be NULL. planeCapacity in records (>= 3 x plane stride); the two RGBA16F targets as 4 binary16 bit patterns per pixel */
 int32_t pt_get_stable_planes(pt_context* ctx, uint32_t* header, PtStablePlane* planes, size_t planeCapacity, uint16_t* stableRadiance, float* depth, float* specularHitT,
                              uint16_t* motionVectors, uint32_t* throughput);

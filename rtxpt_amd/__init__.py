@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_neeat_update_begin", "pt_neeat_update_end", "pt_pack_stable_plane_guides", "pt_unpack_stable_plane_guides", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -745,6 +745,23 @@ class PathTracer:
     def unpack_stable_planes(self, device_ptr, nbytes, rank):
         f = self.L.pt_unpack_stable_planes; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]; f.restype = ctypes.c_int32
         self._chk(f(self.h, ctypes.c_void_p(device_ptr), nbytes, int(rank)), "pt_unpack_stable_planes")
+
+    def pack_stable_plane_guides(self, device_ptr, nbytes):
+        """pt_pack_stable_plane_guides: depth | specular hit distance | motion vectors of this rank's pixels, 16 bytes each (what the other ranks' bakers need of the build pass)"""
+        f = self.L.pt_pack_stable_plane_guides; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]; f.restype = ctypes.c_int32
+        self._chk(f(self.h, ctypes.c_void_p(device_ptr), nbytes), "pt_pack_stable_plane_guides")
+
+    def unpack_stable_plane_guides(self, device_ptr, nbytes, rank):
+        f = self.L.pt_unpack_stable_plane_guides; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]; f.restype = ctypes.c_int32
+        self._chk(f(self.h, ctypes.c_void_p(device_ptr), nbytes, int(rank)), "pt_unpack_stable_plane_guides")
+
+    def neeat_update_begin(self):
+        """pt_neeat_update_begin: LightsBaker::UpdateBegin on its own (the realtime frame in parts)"""
+        f = self.L.pt_neeat_update_begin; f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_int32; self._chk(f(self.h), "pt_neeat_update_begin")
+
+    def neeat_update_end(self):
+        """pt_neeat_update_end: LightsBaker::UpdateEnd on the depth and motion vectors the last build_stable_planes left"""
+        f = self.L.pt_neeat_update_end; f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_int32; self._chk(f(self.h), "pt_neeat_update_end")
 
     def gather_stable_planes(self):
         f = self.L.pt_gather_stable_planes; f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_int32

@@ -1516,16 +1516,90 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
 }
 // The realtime mode's frame with everything coupled (Sample.cpp:2438-2516; pt_set_neeat on): LightsBaker::UpdateBegin -> build pass -> LightsBaker::UpdateEnd on THAT frame's depth and
 // screen-space motion vectors -> the fill passes, which sample the tables just made and fill the reservoirs the next frame's UpdateBegin reads.
+static StablePlanesContext sp_buffers(pt_context* c) {
+    ptk::StablePlanesParams prm; memset(&prm, 0, sizeof(prm)); prm.activeStablePlaneCount = cStablePlaneCount;
+    StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
+    sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p; sp.B.Depth = c->dSpDepth.p; sp.B.SpecularHitT = c->dSpHitT.p; sp.B.MotionVectors = c->dSpMotion.p; sp.B.Throughput = c->dSpThroughput.p;
+    return sp;
+}
+// ---- the realtime frame on tile shards (no reference analogue). The baker's passes read whole neighbourhoods of three things a rank only has for its own tiles: last frame's
+// reservoirs (UpdateBegin resolves them into the history), and this frame's depth and motion vectors (UpdateEnd reprojects through them). So a sharded frame has two exchanges:
+// the reservoirs before UpdateBegin (neeat_exchange_feedback, as between two reference-mode frames) and the build pass's guides — depth and motion vectors, 16 bytes per pixel
+// with the hit-distance word that lies between them — before UpdateEnd; every rank then runs the same deterministic baker passes on the same planes. With a communicator
+// pt_realtime_frame does both itself (RCCL point-to-point in one group, un-padded, like pt_gather); without one the host drives the parts and moves the packed buffers:
+//   pt_neeat_pack / unpack_feedback -> pt_neeat_update_begin -> pt_build_stable_planes -> pt_pack / unpack_stable_plane_guides -> pt_neeat_update_end -> pt_fill_stable_planes
+static int sp_exchange_guides(pt_context* c) {
+    if (c->shardCount == 1 || !c->comm) return PT_OK;
+    hipStream_t s = c->stream;
+    std::vector<uint> others; for (uint r = 0; r < c->shardCount; r++) if (r != c->shardRank) others.insert(others.end(), c->shardPixels[r].begin(), c->shardPixels[r].end());
+    const size_t n = c->owned.size(), W = SP_GUIDE_WORDS;
+    PT_CHECK_HIP(c, c->dSpGatherPixels.upload(others, s)); PT_CHECK_HIP(c, c->dSpGatherRecv.resize(others.size() * W)); PT_CHECK_HIP(c, c->dSpGatherSend.resize(n * W)); PT_CHECK_HIP(c, hipStreamSynchronize(s));
+    const StablePlanesContext sp = sp_buffers(c);
+    launch_sp_pack(sp, c->dOwned.p, (uint)n, c->dSpGatherSend.p, false, s, SP_GUIDE_FIRST, SP_GUIDE_WORDS);
+    PT_CHECK_NCCL(c, g_rccl.GroupStart());
+    size_t off = 0; ncclResult_t bad = ncclSuccess;
+    for (uint r = 0; r < c->shardCount && bad == ncclSuccess; r++) {
+        if (r == c->shardRank) continue;
+        const size_t m = c->shardPixels[r].size();
+        if (n) bad = g_rccl.Send(c->dSpGatherSend.p, n * W, ncclFloat, (int)r, c->comm, s);
+        if (m && bad == ncclSuccess) bad = g_rccl.Recv(c->dSpGatherRecv.p + off * W, m * W, ncclFloat, (int)r, c->comm, s);
+        off += m;
+    }
+    ncclResult_t ge = g_rccl.GroupEnd();
+    if (bad != ncclSuccess || ge != ncclSuccess) return fail(c, PT_ERROR_HIP, std::string("stable-plane guide exchange: ") + g_rccl.GetErrorString(bad != ncclSuccess ? bad : ge));
+    launch_sp_pack(sp, c->dSpGatherPixels.p, (uint)off, c->dSpGatherRecv.p, true, s, SP_GUIDE_FIRST, SP_GUIDE_WORDS);
+    return PT_OK;
+}
+int32_t pt_pack_stable_plane_guides(pt_context* c, void* dst, size_t bytes) {
+    if (!c || !dst) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes");
+    if (bytes < c->owned.size() * (size_t)SP_GUIDE_WORDS * 4u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "destination too small (16 bytes per owned pixel)");
+    (void)hipSetDevice(c->device);
+    launch_sp_pack(sp_buffers(c), c->dOwned.p, (uint)c->owned.size(), (uint*)dst, false, c->stream, SP_GUIDE_FIRST, SP_GUIDE_WORDS);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); PT_CHECK_HIP(c, hipGetLastError());
+    return PT_OK;
+}
+int32_t pt_unpack_stable_plane_guides(pt_context* c, const void* src, size_t bytes, uint32_t rank) {
+    if (!c || !src || rank >= c->shardCount) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes (it allocates the buffers)");
+    const std::vector<uint>& px = c->shardPixels[rank];
+    if (bytes < px.size() * (size_t)SP_GUIDE_WORDS * 4u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "source too small (16 bytes per pixel of that rank)");
+    (void)hipSetDevice(c->device);
+    DevBuf<uint> tmp; PT_CHECK_HIP(c, tmp.upload(px, c->stream));
+    launch_sp_pack(sp_buffers(c), tmp.p, (uint)px.size(), (uint*)src, true, c->stream, SP_GUIDE_FIRST, SP_GUIDE_WORDS);
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); PT_CHECK_HIP(c, hipGetLastError());
+    tmp.free();
+    return PT_OK;
+}
+// LightsBaker::UpdateBegin / UpdateEnd as calls of their own (Rtxpt/Sample.cpp:1380-1412, 2491-2494): what pt_realtime_frame runs around the build pass, for a host that puts something
+// of its own in between (a tile-sharded frame without a communicator: the exchanges above)
+int32_t pt_neeat_update_begin(pt_context* c) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
+    if (!c->neeat.enabled) return fail(c, PT_ERROR_NOT_READY, "pt_set_neeat first");
+    (void)hipSetDevice(c->device);
+    int r = prepare(c); if (r != PT_OK) return r;
+    return neeat_frame(c, NEEAT_BEGIN);
+}
+int32_t pt_neeat_update_end(pt_context* c) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (!c->neeat.enabled) return fail(c, PT_ERROR_NOT_READY, "pt_set_neeat first");
+    if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "UpdateEnd reads the frame's depth and motion vectors: pt_build_stable_planes first");
+    (void)hipSetDevice(c->device);
+    int r = neeat_frame(c, NEEAT_END, c->dSpDepth.p, c->dSpMotion.p); if (r != PT_OK) return r;
+    if (c->feedbackRequired) c->fbSamples = 1;
+    return PT_OK;
+}
 int32_t pt_realtime_frame(pt_context* c, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* buildStats, PtFrameStats* fillStats) {
     if (!c || !params) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
-    if (c->shardCount > 1) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_realtime_frame: the baker reads the whole frame's depth, motion vectors and reservoirs — tile-sharded ranks run pt_build_stable_planes / pt_fill_stable_planes and gather the plane buffers (pt_pack_stable_planes)");
     (void)hipSetDevice(c->device);
     int r = prepare(c); if (r != PT_OK) return r;
     const bool baker = c->neeat.enabled && c->S.NEEEnabled && c->S.NEEFullSamples != 0u;
-    if (baker) { r = neeat_frame(c, NEEAT_BEGIN); if (r != PT_OK) return r; }
+    if (baker && c->shardCount > 1 && !c->comm) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_realtime_frame on tile shards: the baker reads the whole frame's reservoirs, depth and motion vectors — pt_comm_init first, or drive the parts (pt_neeat_update_begin, pt_build_stable_planes, pt_pack / pt_unpack_stable_plane_guides, pt_neeat_update_end, pt_fill_stable_planes)");
+    if (baker) { r = neeat_exchange_feedback(c); if (r != PT_OK) return r; r = neeat_frame(c, NEEAT_BEGIN); if (r != PT_OK) return r; }
     r = pt_build_stable_planes(c, sampleIndex, params, buildStats); if (r != PT_OK) return r;
-    if (baker) { r = neeat_frame(c, NEEAT_END, c->dSpDepth.p, c->dSpMotion.p); if (r != PT_OK) return r; }
+    if (baker) { r = sp_exchange_guides(c); if (r != PT_OK) return r; r = neeat_frame(c, NEEAT_END, c->dSpDepth.p, c->dSpMotion.p); if (r != PT_OK) return r; }
     const uint32_t subSamples = params->subSampleCount ? params->subSampleCount : 1u;
     PtFrameStats total; memset(&total, 0, sizeof(total));
     for (uint32_t s = 0; s < subSamples; s++) { PtFrameStats one; r = pt_fill_stable_planes(c, sampleIndex + s, params, &one); if (r != PT_OK) return r; add_frame_stats(total, one); }
@@ -1548,12 +1622,6 @@ int32_t pt_stable_planes_merge(pt_context* c) {
 }
 // ---- the plane buffers of tile-sharded frames (no reference analogue): every rank builds and fills the planes of its own tiles; the rank that denoises or shows the frame needs them all.
 // 284 bytes per pixel (SP_SHARD_WORDS): header, three plane records, stable radiance, depth, specular hit distance, motion vectors, throughput.
-static StablePlanesContext sp_buffers(pt_context* c) {
-    ptk::StablePlanesParams prm; memset(&prm, 0, sizeof(prm)); prm.activeStablePlaneCount = cStablePlaneCount;
-    StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
-    sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p; sp.B.Depth = c->dSpDepth.p; sp.B.SpecularHitT = c->dSpHitT.p; sp.B.MotionVectors = c->dSpMotion.p; sp.B.Throughput = c->dSpThroughput.p;
-    return sp;
-}
 int32_t pt_stable_planes_shard_bytes(pt_context* c, uint32_t rank, size_t* bytes) {
     if (!c || !bytes || rank >= c->shardCount || !c->width) return PT_ERROR_INVALID_ARGUMENT;
     *bytes = c->shardPixels[rank].size() * (size_t)SP_SHARD_WORDS * 4u; return PT_OK;

@@ -211,10 +211,10 @@ void launch_sp_merge(const StablePlanesContext& sp, const uint* ownedPixels, uin
 // The plane buffers of a list of pixels as flat records (tile-sharded frames: what a rank sends to the rank that denoises / shows the frame): SP_SHARD_WORDS words per pixel —
 // the four header words, the three 80-byte StablePlane records (from their tiled-swizzled addresses), stable radiance, depth, specular hit distance, motion vectors, throughput.
 // One wave-friendly layout: thread = (pixel, word), so both sides of the copy are coalesced along the record.
-__global__ void __launch_bounds__(256) k_sp_pack(StablePlanesContext sp, const uint* __restrict__ pixels, uint num, uint* __restrict__ dst, uint unpack) {
+__global__ void __launch_bounds__(256) k_sp_pack(StablePlanesContext sp, const uint* __restrict__ pixels, uint num, uint* __restrict__ dst, uint unpack, uint firstWord, uint numWords) {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= (size_t)num * SP_SHARD_WORDS) return;
-    const uint k = (uint)(i / SP_SHARD_WORDS), wd = (uint)(i - (size_t)k * SP_SHARD_WORDS);
+    if (i >= (size_t)num * numWords) return;
+    const uint k = (uint)(i / numWords), wd = firstWord + (uint)(i - (size_t)k * numWords);      // (the whole record: 0, SP_SHARD_WORDS; the guides the light baker reads: SP_GUIDE_FIRST, SP_GUIDE_WORDS)
     const uint px = pixels[k] >> 16, py = pixels[k] & 0xFFFFu;
     const size_t pix = (size_t)py * sp.C.imageWidth + px, plane = (size_t)sp.C.imageWidth * sp.C.imageHeight;
     uint* p;
@@ -227,9 +227,9 @@ __global__ void __launch_bounds__(256) k_sp_pack(StablePlanesContext sp, const u
     else p = sp.B.Throughput + pix;
     if (unpack) *p = dst[i]; else dst[i] = *p;
 }
-void launch_sp_pack(const StablePlanesContext& sp, const uint* pixels, uint num, uint* buf, bool unpack, hipStream_t st) {
-    const size_t n = (size_t)num * SP_SHARD_WORDS;
-    if (n) hipLaunchKernelGGL(k_sp_pack, dim3((uint)((n + 255u) / 256u)), dim3(256), 0, st, sp, pixels, num, buf, unpack ? 1u : 0u);
+void launch_sp_pack(const StablePlanesContext& sp, const uint* pixels, uint num, uint* buf, bool unpack, hipStream_t st, uint firstWord, uint numWords) {
+    const size_t n = (size_t)num * numWords;
+    if (n) hipLaunchKernelGGL(k_sp_pack, dim3((uint)((n + 255u) / 256u)), dim3(256), 0, st, sp, pixels, num, buf, unpack ? 1u : 0u, firstWord, numWords);
 }
 void launch_sp_generate(const PathKernelContext& k, const StablePlanesContext& sp, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleIndex, uint* queue, hipStream_t st) {
     const dim3 g((numOwned + 255u) / 256u), b(256);

@@ -17,5 +17,6 @@ void launch_sp_denoise_spec_hit_t(float* specHitT, const float* depth, float* sc
 void launch_sp_merge(const StablePlanesContext& sp, const uint* ownedPixels, uint numOwned, float4* out, hipStream_t st);
 // the plane buffers of `num` pixels <-> flat records of SP_SHARD_WORDS words each (pt_pack_stable_planes / pt_unpack_stable_planes / pt_gather_stable_planes)
 static const uint SP_SHARD_WORDS = 71u;      // header 4 + planes 3 x 20 + stable radiance 2 + depth 1 + specular hit distance 1 + motion vectors 2 + throughput 1
-void launch_sp_pack(const StablePlanesContext& sp, const uint* pixels, uint num, uint* buf, bool unpack, hipStream_t st);
+static const uint SP_GUIDE_FIRST = 66u, SP_GUIDE_WORDS = 4u;      // depth, specular hit distance, motion vectors: what LightsBaker::UpdateEnd reads of a frame (depth + motion; the word in between rides along)
+void launch_sp_pack(const StablePlanesContext& sp, const uint* pixels, uint num, uint* buf, bool unpack, hipStream_t st, uint firstWord = 0u, uint numWords = SP_SHARD_WORDS);
 } // namespace ptk
