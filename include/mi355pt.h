@@ -588,6 +588,11 @@ int32_t pt_gather_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t 
 /* the NEE-AT feedback exchange of tile-sharded frames over HOST memory and the same transport: totalWeight / candidates / depth are this rank's full width x height planes
  * (only its own tiles need to be valid); on return every rank holds every rank's reservoirs and exported depth. Pairs of ranks meet in rank order, the lower one sends first. */
 int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* totalWeight, uint32_t* candidates, float* depth, const PtTransport* transport);
+/* The same protocol for any set of per-pixel planes in HOST memory (what the CPU tests drive, and what a host with its own fabric can model its transfers on): numPlanes row-major
+ * width x height planes of bytesPerPixel[k] bytes per pixel. toRoot = 0: all-to-all — every rank sends the records of its own pixels (the planes' bytes of a pixel back to back, in
+ * pt_shard_layout order) to every other rank: the depth / motion-vector exchange of a tile-sharded realtime frame, with three 4-byte planes pt_neeat_exchange_host. toRoot = 1: to
+ * rank 0 only — the plane-buffer gather. Un-padded; a rank sends exactly its own bytes. */
+int32_t pt_exchange_planes_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, void* const* planes, const uint32_t* bytesPerPixel, uint32_t numPlanes, int32_t toRoot, const PtTransport* transport);
 
 /* --- probes used by the parity tests and bench.py (not part of the reference seam) --------------------------------- */
 /* closest-hit / any-hit queries through the same BVH + kernels the renderer uses. rays: n x 8 floats (o.xyz,tmin,d.xyz,tmax);

@@ -30,7 +30,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_neeat_update_begin", "pt_neeat_update_end", "pt_pack_stable_plane_guides", "pt_unpack_stable_plane_guides", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_exchange_planes_host", "pt_neeat_update_begin", "pt_neeat_update_end", "pt_pack_stable_plane_guides", "pt_unpack_stable_plane_guides", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -249,6 +249,28 @@ def neeat_exchange_host(width, height, rank, world, total_weight, candidates, de
     r = L.pt_neeat_exchange_host(width, height, rank, world, _p(total_weight), _p(candidates), _p(depth), ctypes.byref(t))
     if r != 0:
         raise PtError(r, "pt_neeat_exchange_host")
+
+
+def exchange_planes_host(width, height, rank, world, planes, send, recv, to_root=False):
+    """pt_exchange_planes_host: `planes` = C-contiguous arrays of shape (height, width[, ...]) — any bytes per pixel; all-to-all (every rank ends up with every rank's pixels) or,
+    with to_root, towards rank 0 only; modified in place; send / recv as in gather_host"""
+    L = load_library()
+    for a in planes: assert a.flags["C_CONTIGUOUS"] and a.shape[0] == height and a.shape[1] == width
+    bpp = np.array([a.nbytes // (width * height) for a in planes], np.uint32)
+    ptrs = (ctypes.c_void_p * len(planes))(*[a.ctypes.data for a in planes])
+
+    def _wrap(fn):
+        def cb(user, buf, nbytes, peer):
+            try:
+                fn(buf, nbytes, peer); return 0
+            except Exception:
+                import traceback; traceback.print_exc(); return 1
+        return cb
+    t = PtTransport(None, PtTransport.SEND(_wrap(send)), PtTransport.RECV(_wrap(recv)), PtTransport.GROUP(), PtTransport.GROUP())
+    f = L.pt_exchange_planes_host; f.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p]; f.restype = ctypes.c_int32
+    r = f(width, height, rank, world, ptrs, _p(bpp), len(planes), 1 if to_root else 0, ctypes.byref(t))
+    if r != 0:
+        raise PtError(r, "pt_exchange_planes_host")
 
 
 def load_library():

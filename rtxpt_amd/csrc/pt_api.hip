@@ -1988,6 +1988,35 @@ int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, u
         return PT_OK;
     } catch (...) { return PT_ERROR_IO; }
 }
+// The general form over HOST memory: numPlanes row-major width x height planes of bytesPerPixel[k] bytes per pixel each (depth: 4, motion vectors: 8, a header plane: 4 ...).
+// toRoot = 0: every rank sends the records of its own pixels to every other rank and receives theirs (the guide exchange of a tile-sharded realtime frame; pt_neeat_exchange_host is
+// this with three 4-byte planes). toRoot = 1: every rank sends to rank 0 only (the plane-buffer gather). A record = the planes' bytes of one pixel back to back, in the rank's pixel
+// order (pt_shard_layout); transfers are un-padded; pairs meet in rank order, so blocking transports cannot deadlock.
+int32_t pt_exchange_planes_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, void* const* planes, const uint32_t* bytesPerPixel, uint32_t numPlanes, int32_t toRoot, const PtTransport* t) {
+    if (!planes || !bytesPerPixel || !numPlanes || !t || !t->send || !t->recv || !width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
+    size_t rec = 0; for (uint32_t k = 0; k < numPlanes; k++) { if (!planes[k] || !bytesPerPixel[k]) return PT_ERROR_INVALID_ARGUMENT; rec += bytesPerPixel[k]; }
+    if (world == 1) return PT_OK;
+    try {
+        std::vector<std::vector<uint>> lists; shard_pixel_lists(width, height, world, lists);
+        auto slot = [&](uint px) { return (size_t)(px & 0xFFFFu) * width + (px >> 16); };
+        auto pack = [&](const std::vector<uint>& px, std::vector<unsigned char>& buf) { buf.resize(rec * px.size()); size_t o = 0; for (uint q : px) for (uint32_t k = 0; k < numPlanes; k++) { memcpy(&buf[o], (const unsigned char*)planes[k] + slot(q) * bytesPerPixel[k], bytesPerPixel[k]); o += bytesPerPixel[k]; } };
+        auto unpack = [&](const std::vector<uint>& px, const std::vector<unsigned char>& buf) { size_t o = 0; for (uint q : px) for (uint32_t k = 0; k < numPlanes; k++) { memcpy((unsigned char*)planes[k] + slot(q) * bytesPerPixel[k], &buf[o], bytesPerPixel[k]); o += bytesPerPixel[k]; } };
+        const std::vector<uint>& mine = lists[rank];
+        std::vector<unsigned char> sendbuf, recvbuf; pack(mine, sendbuf);
+        for (uint p = 0; p < world; p++) {
+            if (p == rank) continue;
+            const bool iSend = !toRoot || p == 0u, iRecv = !toRoot || rank == 0u;
+            recvbuf.resize(rec * lists[p].size());
+            for (int step = 0; step < 2; step++) {
+                const bool sendNow = (rank < p) == (step == 0);
+                if (sendNow) { if (iSend && !mine.empty() && t->send(t->user, sendbuf.data(), sendbuf.size(), p) != 0) return PT_ERROR_IO; }
+                else if (iRecv && !lists[p].empty() && t->recv(t->user, recvbuf.data(), recvbuf.size(), p) != 0) return PT_ERROR_IO;
+            }
+            if (iRecv) unpack(lists[p], recvbuf);
+        }
+        return PT_OK;
+    } catch (...) { return PT_ERROR_IO; }
+}
 int32_t pt_gather_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* rgba, const PtTransport* t) {
     if (!rgba || !t || !t->send || !t->recv || !width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
     if (world == 1) return PT_OK;

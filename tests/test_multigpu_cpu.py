@@ -123,3 +123,57 @@ def test_neeat_feedback_exchange_through_the_c_entry_point(size, world):
     want_d = (0.5 + xx * 0.001 + yy * 0.37).astype(np.float32)
     for rank, weight, cand, depth in got:
         assert np.array_equal(weight, want_w) and np.array_equal(cand, want_c) and np.array_equal(depth, want_d), "rank %d" % rank
+
+
+def _planes_worker(rank, world, port, w, h, to_root, q):
+    """The exchanges of a tile-sharded realtime frame over host memory (pt_exchange_planes_host = the protocol of pt_realtime_frame's guide exchange and of pt_gather_stable_planes): planes
+    of 4, 4, 8 and 16 bytes per pixel — depth, hit distance, motion vectors, a header-like plane."""
+    import ctypes
+    import rtxpt_amd as pt
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    px = pt.shard_layout(w, h, rank, world); yy, xx = (px & 0xFFFF).astype(np.int64), (px >> 16).astype(np.int64)
+    full = _full_planes(w, h)
+    mine = [np.full_like(a, 0xEE) for a in full]                      # poison outside the owned tiles
+    for a, b in zip(mine, full): a[yy, xx] = b[yy, xx]
+    sent = []
+
+    def send(ptr, nbytes, peer):
+        t = torch.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=torch.uint8).clone(); sent.append((peer, nbytes)); dist.send(t, dst=peer)
+
+    def recv(ptr, nbytes, peer):
+        t = torch.empty(nbytes, dtype=torch.uint8); dist.recv(t, src=peer); ctypes.memmove(ptr, t.data_ptr(), nbytes)
+    pt.exchange_planes_host(w, h, rank, world, mine, send, recv, to_root=to_root)
+    rec = 4 + 4 + 8 + 16
+    assert sorted(sent) == ([(0, rec * px.size)] if (to_root and rank) else [] if to_root else [(p, rec * px.size) for p in range(world) if p != rank])      # its own records, un-padded
+    q.put((rank, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _full_planes(w, h):
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    depth = (0.5 + xx * 0.001 + yy * 0.37).astype(np.float32); hit = (xx * 3.0 - yy).astype(np.float32)
+    mv = np.stack([(xx * 31 + yy) & 0xFFFF, (yy * 17 + 5) & 0xFFFF, xx & 0xFF, yy & 0xFF], -1).astype(np.uint16)
+    hdr = np.stack([xx * 7919 + yy, xx ^ yy, xx + 1, yy + 2], -1).astype(np.uint32)
+    return [np.ascontiguousarray(a) for a in (depth, hit, mv, hdr)]
+
+
+@pytest.mark.parametrize("size,world,to_root", [((100, 70), 2, False), ((200, 120), 3, False), ((97, 61), 3, True)])
+def test_plane_exchange_through_the_c_entry_point(size, world, to_root):
+    w, h = size
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_planes_worker, args=(r, world, port, w, h, to_root, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    full = _full_planes(w, h)
+    import rtxpt_amd as pt
+    for rank, planes in got:
+        if to_root and rank:      # a sender keeps what it had: its own tiles, poison elsewhere
+            px = pt.shard_layout(w, h, rank, world); yy, xx = (px & 0xFFFF).astype(np.int64), (px >> 16).astype(np.int64)
+            for a, b in zip(planes, full):
+                want = np.full_like(b, 0xEE); want[yy, xx] = b[yy, xx]; assert np.array_equal(a, want), "rank %d" % rank
+        else:
+            for a, b in zip(planes, full): assert np.array_equal(a, b), "rank %d" % rank
