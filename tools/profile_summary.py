@@ -12,9 +12,9 @@ Formulas (gfx94x definitions, the ones rocprofv3 falls back to on gfx950, MI355X
 import csv, glob, json, sys, collections
 
 d = sys.argv[1]
-GROUPS = (("extend", ("k_extend<false>", "k_extend_tasks", "k_resolve_extend")), ("shadow", ("k_shadow<false, false>", "k_shadow_tasks", "k_resolve_shadow")), ("shade", ("k_shade<false", "k_classify")),
+GROUPS = (("extend", ("k_extend<false, false>", "k_extend_tasks", "k_resolve_extend")), ("shadow", ("k_shadow<false, false>", "k_shadow_tasks", "k_resolve_shadow")), ("shade", ("k_shade<false", "k_classify")),
           ("generate", ("k_generate",)), ("accumulate", ("k_accumulate",)))
-MAIN = {"extend": "k_extend<false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false", "generate": "k_generate", "accumulate": "k_accumulate"}
+MAIN = {"extend": "k_extend<false, false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false", "generate": "k_generate", "accumulate": "k_accumulate"}
 
 
 def group_of(name):
