@@ -1,5 +1,6 @@
 """Cases shared by tests/golden/make_reference_integrator_golden.py, tests/test_oracle_refpin_integrator.py and the GPU fixture test: name ->
 (scene factory, settings, width, height, first sample, sample count). Small frames: the point is which code runs, not how many pixels."""
+import numpy as np
 from rtxpt_amd import scenes
 
 
@@ -257,6 +258,22 @@ def wide_cases():
         S32 = S.copy(); S32["useFp16Types"] = 0; S16 = S.copy(); S16["useFp16Types"] = 1
         out[name] = (make, S32, w, h, first, n); out[name + "_lp16"] = (make, S16, w, h, first, n)
     return out
+
+
+def xl_cases():
+    """One more notch for the bench configuration's settings: 1280 x 720 x 4 samples (3 686 400 paths, a ninth of the 4K frame) of the reference's integrator text on the bistro-like
+    scene at scale 0.3, both lp builds. The fixture keeps every sixteenth row and a SHA-256 of the whole frame (tests/golden/reference_integrator_golden_xl.npz)."""
+    bl = lambda: scenes.bistro_like(scale=0.3, tex_size=256)
+    S32 = scenes.config_settings("C3"); S32["useFp16Types"] = 0; S16 = S32.copy(); S16["useFp16Types"] = 1
+    return {"bistro_like_xl": (bl, S32, 1280, 720, 0, 4), "bistro_like_xl_lp16": (bl, S16, 1280, 720, 0, 4)}
+
+
+XL_ROW_STEP = 16
+
+
+def frame_digest(rad):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(rad, np.float32).tobytes()).digest(), np.uint8).copy()
 
 
 def neeat_cases():

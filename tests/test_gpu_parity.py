@@ -448,6 +448,26 @@ def test_product_matches_wide_reference_integrator_golden(name, tail):
     if tail: assert st["tailLaunches"] > 0
 
 
+@pytest.mark.parametrize("name", ["bistro_like_xl", "bistro_like_xl_lp16"])
+def test_product_matches_xl_reference_integrator_golden(name):
+    """1280 x 720 x 4 samples of the reference's integrator text with the bench configuration's settings (tests/golden/reference_integrator_golden_xl.npz: every sixteenth row, a
+    SHA-256 of the whole frame, the ray counts) — the HIP path as the product runs it (pipelined batches, straggler rounds, tail kernel). No oracle call here."""
+    pt, scenes, parallel, ptref = _imports()
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pin_scenes
+    make, S, w, h, first, n = pin_scenes.xl_cases()[name]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_integrator_golden_xl.npz"))
+    sc, cam = make()
+    t = pt.PathTracer(); t.set_tail_paths(32768); t.set_scene(sc); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.set_settings(S); t.resize(w, h); st = t.render(first, n)
+    rad = t.radiance()
+    rows = rad[::pin_scenes.XL_ROW_STEP]
+    bad = (rows.view(np.uint32) != g[name + "_rows"].view(np.uint32)).any(-1)
+    assert not bad.any(), "%s: %d of %d pixels of the kept rows differ from the reference-text frame" % (name, int(bad.sum()), bad.size)
+    assert np.array_equal(pin_scenes.frame_digest(rad), g[name + "_sha256"]), "%s: the frame's digest differs" % name
+    assert (st["extendRays"], st["shadowRays"]) == tuple(int(v) for v in g[name + "_rays"])
+
+
 def test_c_default_settings_are_the_reference_default_build():
     pt, scenes, parallel, ptref = _imports()
     t = pt.PathTracer()

@@ -114,6 +114,26 @@ def test_wide_golden_is_the_live_reference_integrator(name):
     if name.endswith("_lp16"): assert not np.array_equal(g[name], g[name[:-5]])       # the two builds differ
 
 
+XL = pin_scenes.xl_cases()
+GOLDEN_XL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_integrator_golden_xl.npz")
+
+
+@pytest.mark.parametrize("name", list(XL))
+def test_oracle_matches_xl_reference_integrator_golden(name):
+    """1280 x 720 x 4 samples (3.7 M paths, the bench configuration's settings) of the reference's integrator text: the oracle's whole frame by SHA-256, every sixteenth row pixel for
+    pixel, the ray counts."""
+    g = np.load(GOLDEN_XL)
+    make, S, w, h, first, n = XL[name]; lp16 = bool(int(S["useFp16Types"]))
+    sc, cam = make()
+    o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(S); o.resize(w, h); o.render(first, n)
+    rad = o.radiance(); c = o.counters()
+    rows = rad[::pin_scenes.XL_ROW_STEP]
+    bad = (rows.view(np.uint32) != g[name + "_rows"].view(np.uint32)).any(-1)
+    assert not bad.any(), "%s: %d of %d pixels of the kept rows differ from the reference-text frame" % (name, int(bad.sum()), bad.size)
+    assert np.array_equal(pin_scenes.frame_digest(rad), g[name + "_sha256"]), "%s: the frame's digest differs (a pixel outside the kept rows)" % name
+    assert (c["extendRays"], c["shadowRays"]) == tuple(int(v) for v in g[name + "_rays"])
+
+
 @pytest.mark.parametrize("lp16", [False, True], ids=["fp32", "lp16"])
 @pytest.mark.parametrize("name", ["c2", "c2_mirrored_room", "bistro_like", "bistro_like_material_zoo", "bistro_like_c5", "c2_spec_gloss", "bistro_like_spec_gloss", "c2_sphere_light_proxy"])
 def test_load_surface_matches_reference_text(name, lp16):
