@@ -242,6 +242,23 @@ def main():
                              "differing_pixels": diff, "pixels": int(block.shape[0] * block.shape[1]),
                              "block": "x %d..%d, y %d..%d of the %dx%d frame, %d spp (the cpu_baseline sample)" % (rect[0], rect[2], rect[1], rect[3], W, H, SPP),
                              "against": "oracle/ptref (pinned to the reference's integrator text, tests/test_oracle_refpin_integrator.py)", "tolerance": "bit-exact expected; north_star allows 1e-3 relative L2"}
+        # ... and, for the default workload, the whole frame against the REFERENCE'S OWN integrator text: tests/golden/bench_frame_golden.npz holds the SHA-256 of this very frame as
+        # PathTracer.hlsli & co. render it (tests/golden/make_bench_frame_golden.py, made in the build container), every 120th row and the ray counts. No oracle in this comparison.
+        try:
+            gp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "bench_frame_golden.npz")
+            default_workload = (W, H, SPP) == (3840, 2160, 4) and args.scale == 1.0 and args.tex == 1024 and not args.no_env_compression and not args.fp32_lp_types
+            if world == 1 and default_workload and os.path.exists(gp):
+                import hashlib
+                gold = np.load(gp)
+                g.reset_accumulation(); st_ref = g.render(0, SPP); frame = g.radiance()
+                rows = frame[::int(gold["row_step"][0])]
+                out.setdefault("parity", {})["reference_text"] = {
+                    "frame_sha256_equal": bool(np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(frame, np.float32).tobytes()).digest(), np.uint8), gold["sha256"])),
+                    "differing_pixels_in_kept_rows": int((rows.view(np.uint32) != gold["rows"].view(np.uint32)).any(-1).sum()), "kept_rows": int(rows.shape[0]),
+                    "ray_counts_equal": bool((int(st_ref["extendRays"]), int(st_ref["shadowRays"])) == tuple(int(v) for v in gold["rays"])),
+                    "against": "the reference's integrator text (PathTracer.hlsli & co. compiled from the reference tree) rendering this frame: tests/golden/bench_frame_golden.npz"}
+        except Exception as e:      # noqa: BLE001
+            out.setdefault("parity", {})["reference_text"] = {"error": str(e)[:300]}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -129,3 +129,23 @@ def test_realtime_frames_4k_animated_match_oracle():
         assert (mv[..., :2] != 0).any()
     assert int(bst["extendRays"]) > W * H and int(fst["shadowRays"]) > 0
     g.close(); o.close()
+
+
+def test_bench_frame_equals_the_reference_text_frame():
+    """bench.py's default workload at full size against the frame the REFERENCE'S integrator text rendered of it (tests/golden/bench_frame_golden.npz): the SHA-256 of the whole
+    3840x2160 RGBA32F frame, the kept rows pixel for pixel, the ray counts — no oracle in the loop."""
+    import hashlib, sys
+    pt, scenes, ptref = _imports()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import make_bench_frame_golden as gen
+    gold = np.load(os.path.join(root, "tests", "golden", "bench_frame_golden.npz"))
+    sc, cam, S = gen.bench_workload()
+    g = pt.PathTracer(); g.set_tail_paths(32768); g.set_scene(sc); g.set_camera(scenes.bridge_camera(W, H, **cam)); g.set_settings(S); g.resize(W, H)
+    st = g.render(0, SPP); frame = g.radiance()
+    rows = frame[::int(gold["row_step"][0])]
+    bad = int((rows.view(np.uint32) != gold["rows"].view(np.uint32)).any(-1).sum())
+    assert bad == 0, "%d pixels of the kept rows differ" % bad
+    assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(frame, np.float32).tobytes()).digest(), np.uint8), gold["sha256"]), "the frame's digest differs"
+    assert (int(st["extendRays"]), int(st["shadowRays"])) == tuple(int(v) for v in gold["rays"])
+    g.close()
