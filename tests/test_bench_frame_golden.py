@@ -33,3 +33,29 @@ def test_oracle_rows_equal_the_reference_text_frame():
         bad = int((got.view(np.uint32) != g["rows"][k].view(np.uint32)).any(-1).sum())
         assert bad == 0, "row %d: %d pixels differ from the reference-text frame" % (y, bad)
     o.close()
+
+
+CONFIG_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_frames_golden.npz")
+
+
+def test_oracle_equals_the_reference_text_config_frames():
+    """tests/golden/config_frames_golden.npz (BASELINE.json's C1, C2, C4, C5 at full size through the reference's integrator text): the oracle's whole C1 frame by digest, the kept
+    rows of C2, two kept rows of C4 (16 samples) and of an animated C5 pose."""
+    import make_config_frames_golden as cg
+    import pin_scenes
+    g = np.load(CONFIG_GOLD)
+    for name, rows_checked in (("C1", None), ("C2", (0, 1, 2, 3)), ("C4", (1,)), ("C5_t2", (2,))):
+        make, S, w, h, first, n, t = cg.configs()[name]
+        sc, cam = make()
+        o = ptref.Oracle(lp16=bool(int(S["useFp16Types"]))); o.set_scene(cg.posed(sc, t)); o.set_camera(scenes.bridge_camera(w, h, **cam)); o.set_settings(S); o.resize(w, h)
+        if rows_checked is None:
+            o.render(first, n); c = o.counters()
+            assert np.array_equal(pin_scenes.frame_digest(o.radiance()), g[name + "_sha256"]) and (c["extendRays"], c["shadowRays"]) == tuple(int(v) for v in g[name + "_rays"])
+        else:
+            for k in rows_checked:
+                y = cg.rows_of(h)[k]
+                o.reset_accumulation(); o.render(first, n, rect=(0, y, w, y + 1))
+                bad = int((o.radiance()[y].view(np.uint32) != g[name + "_rows"][k].view(np.uint32)).any(-1).sum())
+                assert bad == 0, "%s row %d: %d pixels differ from the reference-text frame" % (name, y, bad)
+        o.close()
+    for name in cg.configs(): assert g[name + "_sha256"].shape == (32,) and np.isfinite(g[name + "_rows"]).all() and int(g[name + "_rays"][0]) > 0

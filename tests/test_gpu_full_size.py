@@ -149,3 +149,29 @@ def test_bench_frame_equals_the_reference_text_frame():
     assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(frame, np.float32).tobytes()).digest(), np.uint8), gold["sha256"]), "the frame's digest differs"
     assert (int(st["extendRays"]), int(st["shadowRays"])) == tuple(int(v) for v in gold["rays"])
     g.close()
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C4", "C5_t1", "C5_t2"])
+def test_config_frames_equal_the_reference_text_frames(name):
+    """BASELINE.json's other configurations at their full sizes (tools/run_configs.py's definitions) against the frames the REFERENCE'S integrator text rendered of them
+    (tests/golden/config_frames_golden.npz): SHA-256 of the whole frame, four rows pixel for pixel, ray counts. C5 reaches its pose the way the product does: pt_animate on the
+    scene as uploaded (refit, light re-bake), the fixture's frame came from a scene built in that pose. No oracle in the loop."""
+    import hashlib, sys
+    pt, scenes, ptref = _imports()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import make_config_frames_golden as gen
+    gold = np.load(os.path.join(root, "tests", "golden", "config_frames_golden.npz"))
+    make, S, w, h, first, n, t = gen.configs()[name]
+    sc, cam = make()
+    g = pt.PathTracer(); g.set_tail_paths(32768); g.set_scene(sc); g.set_camera(scenes.bridge_camera(w, h, **cam)); g.set_settings(S); g.resize(w, h)
+    if t is not None:
+        g.render(first, 1)                                             # (a frame on the rest pose first: the tree the refit starts from is the rest pose's)
+        g.animate(scenes.animate_instances(sc, t), scenes.animate_positions(sc, t), vertex_ranges=scenes.animated_vertex_ranges(sc)); g.reset_accumulation()
+    st = g.render(first, n); frame = g.radiance()
+    rows = frame[gen.rows_of(h)]
+    bad = int((rows.view(np.uint32) != gold[name + "_rows"].view(np.uint32)).any(-1).sum())
+    assert bad == 0, "%s: %d pixels of the kept rows differ" % (name, bad)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(frame, np.float32).tobytes()).digest(), np.uint8), gold[name + "_sha256"]), "%s: the frame's digest differs" % name
+    assert (int(st["extendRays"]), int(st["shadowRays"])) == tuple(int(v) for v in gold[name + "_rays"])
+    g.close()
