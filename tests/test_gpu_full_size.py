@@ -175,3 +175,25 @@ def test_config_frames_equal_the_reference_text_frames(name):
     assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(frame, np.float32).tobytes()).digest(), np.uint8), gold[name + "_sha256"]), "%s: the frame's digest differs" % name
     assert (int(st["extendRays"]), int(st["shadowRays"])) == tuple(int(v) for v in gold[name + "_rays"])
     g.close()
+
+
+def test_realtime_passes_4k_equal_the_reference_text():
+    """The stable-plane build pass and one fill sub-sample at 3840x2160 on C5's scene in an animated pose (previous pose = the rest pose: object motion; the camera moved as well)
+    against what the REFERENCE'S text of those passes produced (tests/golden/realtime_4k_golden.npz: SHA-256 digests of header, depth, motion vectors, stable radiance, throughput,
+    hit distances and of all live plane records after each pass, ray counts). The device reaches the pose through pt_set_motion_history + pt_animate_ranges. No oracle in the loop."""
+    import sys
+    pt, scenes, ptref = _imports()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import make_realtime_4k_golden as gen
+    gold = np.load(os.path.join(root, "tests", "golden", "realtime_4k_golden.npz"))
+    sc, cam, S, prm, pose = gen.workload()
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(S); g.set_camera(scenes.bridge_camera(W, H, **cam)); g.resize(W, H); g.set_motion_history(True)
+    g.animate(pose[0], pose[1], vertex_ranges=scenes.animated_vertex_ranges(sc))
+    built = g.build_stable_planes(gen.SAMPLE, prm)
+    for k, v in gen.digests(built).items(): assert np.array_equal(v, gold["build_" + k]), "build pass: %s differs" % k
+    filled = g.fill_stable_planes(gen.SAMPLE, prm)
+    for k, v in gen.digests(filled).items(): assert np.array_equal(v, gold["fill_" + k]), "fill pass: %s differs" % k
+    assert int(built["stats"]["extendRays"]) == int(gold["build_rays"][0])
+    assert (int(filled["stats"]["extendRays"]), int(filled["stats"]["shadowRays"])) == tuple(int(v) for v in gold["fill_rays"])
+    g.close()
