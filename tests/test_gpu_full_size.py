@@ -197,3 +197,25 @@ def test_realtime_passes_4k_equal_the_reference_text():
     assert int(built["stats"]["extendRays"]) == int(gold["build_rays"][0])
     assert (int(filled["stats"]["extendRays"]), int(filled["stats"]["shadowRays"])) == tuple(int(v) for v in gold["fill_rays"])
     g.close()
+
+
+def test_neeat_4k_equals_the_reference_text():
+    """NEE-AT's path-tracer side at 3840x2160 (NEEType 2, the reference's default sampler; tile tables handed in as a host's baker would) against the REFERENCE'S integrator text
+    (tests/golden/neeat_4k_golden.npz): SHA-256 of the frame and of both samples' reservoir planes, ray counts. No oracle in the loop."""
+    import sys
+    pt, scenes, ptref = _imports()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import make_neeat_4k_golden as gen
+    gold = np.load(os.path.join(root, "tests", "golden", "neeat_4k_golden.npz"))
+    sc, cam, S = gen.workload()
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(S); g.set_camera(scenes.bridge_camera(W, H, **cam)); g.resize(W, H)
+    n_lights = len(g.lights()["lights"]); assert n_lights == int(gold["lights"][0])
+    g.set_local_light_sampling(gen.table(n_lights), jitter=gen.OPTS["jitter"], ratio=gen.OPTS["ratio"], ssc_threshold=gen.OPTS["ssc_threshold"], feedback=gen.OPTS["feedback"])
+    st = g.render(gen.FIRST, gen.N)
+    assert np.array_equal(gen.digest(g.radiance()), gold["frame"]), "the frame's digest differs"
+    for s in range(gen.N):
+        wgt, cand = g.light_feedback(s)
+        assert np.array_equal(gen.digest(wgt), gold["fbw%d" % s]) and np.array_equal(gen.digest(cand), gold["fbc%d" % s]), "reservoirs of sample %d differ" % s
+    assert (int(st["extendRays"]), int(st["shadowRays"])) == tuple(int(v) for v in gold["rays"])
+    g.close()
