@@ -1,7 +1,7 @@
 """Generates tests/golden/realtime_4k_golden.npz: the realtime mode's two path-tracing passes at FULL size through the REFERENCE'S text (PATH_TRACER_MODE_BUILD_STABLE_PLANES and
 PATH_TRACER_MODE_FILL_STABLE_PLANES of PathTracer.hlsli & co., compiled by oracle/refpin/hlsl_tu.py --integrator) — C5's scene (2.86 M triangles) in an animated pose with the rest pose
 as the previous frame (object motion in the motion vectors) and a camera that moved, 3840x2160, the reference's default lp16 build, nested dielectrics quality 2, the global light
-sampler (the baker's text runs thread by thread: minutes at 96x54, days at 4K — NEE-AT at scale is pinned through the oracle, tests/test_gpu_full_size.py): SHA-256 digests of
+sampler (the coupled frame with the baker's text in the loop: make_realtime_coupled_4k_golden.py): SHA-256 digests of
 the header, depth, motion vectors, stable radiance, throughput, specular hit distances and of the live plane records (noisy radiance included), plus the ray counts of both passes.
 tests/test_gpu_full_size.py compares the device with it. Run in the build container only (a few minutes of CPU time):  python tests/golden/make_realtime_4k_golden.py"""
 import hashlib, os, sys, time

@@ -219,3 +219,33 @@ def test_neeat_4k_equals_the_reference_text():
         assert np.array_equal(gen.digest(wgt), gold["fbw%d" % s]) and np.array_equal(gen.digest(cand), gold["fbc%d" % s]), "reservoirs of sample %d differ" % s
     assert (int(st["extendRays"]), int(st["shadowRays"])) == tuple(int(v) for v in gold["rays"])
     g.close()
+
+
+def test_coupled_realtime_frames_4k_equal_the_reference_text():
+    """Two coupled realtime frames at 3840x2160 — baker UpdateBegin, build pass, UpdateEnd on the frame's depth and motion vectors, fill pass feeding the reservoirs — against the
+    REFERENCE'S text with LightsBaker.hlsl run thread by thread (tests/golden/realtime_coupled_4k_golden.npz): per frame the digests of the tile tables, proxy counters, reservoirs
+    and of every plane buffer, the tile jitter, and the ray counts of the run. C5's scene; camera and scene move between the frames (pt_set_motion_history, pt_animate_ranges). No
+    oracle in the loop."""
+    import sys
+    pt, scenes, ptref = _imports()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import make_realtime_coupled_4k_golden as gen
+    import make_realtime_4k_golden as rt
+    gold = np.load(os.path.join(root, "tests", "golden", "realtime_coupled_4k_golden.npz"))
+    sc, cam, S, poses = gen.workload()
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(S); g.set_camera(scenes.bridge_camera(W, H, **cam)); g.resize(W, H); g.set_neeat(True); g.set_motion_history(True)
+    rays = [0, 0]
+    for f in range(gen.FRAMES):
+        prm, camd = gen.params(cam, f)
+        g.animate(poses[f][0], poses[f][1], vertex_ranges=scenes.animated_vertex_ranges(sc) if f else None); g.set_camera(camd)
+        frame, bst, fst = g.realtime_frame(f, prm)
+        rays[0] += int(bst["extendRays"]) + int(fst["extendRays"]); rays[1] += int(fst["shadowRays"])
+        tab, jit = g.neeat_tables(); fw, fc = g.light_feedback(0)
+        assert np.array_equal(rt.digest(tab), gold["table%d" % f]), "frame %d: tile tables" % f
+        assert tuple(int(v) for v in jit) == tuple(int(v) for v in gold["jitter%d" % f]), "frame %d: jitter" % f
+        assert np.array_equal(rt.digest(g.lights()["proxyCounters"]), gold["counters%d" % f]), "frame %d: proxy counters" % f
+        assert np.array_equal(rt.digest(fw), gold["fbw%d" % f]) and np.array_equal(rt.digest(fc), gold["fbc%d" % f]), "frame %d: reservoirs" % f
+        for k, v in rt.digests(frame).items(): assert np.array_equal(v, gold["%s%d" % (k, f)]), "frame %d: %s differs" % (f, k)
+    assert rays == [int(v) for v in gold["rays"]]
+    g.close()
