@@ -249,3 +249,28 @@ def test_coupled_realtime_frames_4k_equal_the_reference_text():
         for k, v in rt.digests(frame).items(): assert np.array_equal(v, gold["%s%d" % (k, f)]), "frame %d: %s differs" % (f, k)
     assert rays == [int(v) for v in gold["rays"]]
     g.close()
+
+
+def test_neeat_loop_4k_equals_the_reference_text():
+    """Reference mode with the reference's default sampler at 3840x2160: three accumulated frames with NEE-AT's baker in the loop (pt_set_neeat, pt_set_view_projection,
+    pt_set_light_importance_boost; one pt_render per frame) against the REFERENCE'S text with LightsBaker.hlsl run thread by thread (tests/golden/neeat_loop_4k_golden.npz): per frame
+    the digests of tile tables, proxy counters, reservoirs and the tile jitter; the accumulated frame's digest; the ray counts. No oracle in the loop."""
+    import sys
+    pt, scenes, ptref = _imports()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import make_neeat_loop_4k_golden as gen
+    import make_realtime_4k_golden as rt
+    gold = np.load(os.path.join(root, "tests", "golden", "neeat_loop_4k_golden.npz"))
+    sc, cam, S = gen.workload()
+    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(S); g.set_camera(scenes.bridge_camera(W, H, **cam)); g.resize(W, H); gen.setup(g, cam)
+    rays = [0, 0]
+    for f in range(gen.FRAMES):
+        st = g.render(f, 1); rays[0] += int(st["extendRays"]); rays[1] += int(st["shadowRays"])
+        tab, jit = g.neeat_tables(); fw, fc = g.light_feedback(0)
+        assert np.array_equal(rt.digest(tab), gold["table%d" % f]) and tuple(int(v) for v in jit) == tuple(int(v) for v in gold["jitter%d" % f]), "frame %d: tile tables / jitter" % f
+        assert np.array_equal(rt.digest(g.lights()["proxyCounters"]), gold["counters%d" % f]), "frame %d: proxy counters" % f
+        assert np.array_equal(rt.digest(fw), gold["fbw%d" % f]) and np.array_equal(rt.digest(fc), gold["fbc%d" % f]), "frame %d: reservoirs" % f
+    assert np.array_equal(rt.digest(g.radiance()), gold["frame"]), "the accumulated frame's digest differs"
+    assert rays == [int(v) for v in gold["rays"]]
+    g.close()
