@@ -35,3 +35,26 @@ def test_device_frame_equals_the_reference_text_frame(key):
             wgt, cand = t.light_feedback(s)
             assert np.array_equal(gen.digest(np.concatenate([wgt.view(np.uint32).ravel(), cand.ravel()])), gold["%s_fb%d" % (key, s)]), "%s: reservoirs of sample %d differ" % (key, s)
     t.close()
+
+
+import make_stable_planes_hd_golden as sph
+SP_GOLD = os.path.join(ROOT, "tests", "golden", "stable_planes_hd_golden.npz")
+
+
+@pytest.mark.parametrize("key", sph.all_cases())
+def test_device_stable_planes_equal_the_reference_text(key):
+    """the stable-plane cases (incl. object motion and the edge cases) at 1920x1080: the build pass and two fill sub-samples against the REFERENCE'S text of those passes
+    (tests/golden/stable_planes_hd_golden.npz: digests of every plane buffer and of all live plane records after each, ray counts)"""
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    gold = np.load(SP_GOLD)
+    sc, cam, S, prm, lp16, prev_pose = sph.setup(key)
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(sph.W, sph.H, **cam)); t.resize(sph.W, sph.H)
+    if prev_pose is not None: t.set_previous_pose(*prev_pose)
+    built = t.build_stable_planes(sph.SAMPLE, prm)
+    for k, v in sph.digests(built).items(): assert np.array_equal(v, gold["%s_build_%s" % (key, k)]), "%s, build pass: %s differs" % (key, k)
+    assert int(built["stats"]["extendRays"]) == int(gold[key + "_build_rays"][0])
+    filled = t.fill_stable_planes(sph.SAMPLE, prm, sub_samples=sph.SUBS)
+    for k, v in sph.digests(filled).items(): assert np.array_equal(v, gold["%s_fill_%s" % (key, k)]), "%s, fill passes: %s differs" % (key, k)
+    assert (int(filled["stats"]["extendRays"]), int(filled["stats"]["shadowRays"])) == tuple(int(v) for v in gold[key + "_fill_rays"])
+    t.close()
