@@ -58,3 +58,21 @@ def test_device_stable_planes_equal_the_reference_text(key):
     for k, v in sph.digests(filled).items(): assert np.array_equal(v, gold["%s_fill_%s" % (key, k)]), "%s, fill passes: %s differs" % (key, k)
     assert (int(filled["stats"]["extendRays"]), int(filled["stats"]["shadowRays"])) == tuple(int(v) for v in gold[key + "_fill_rays"])
     t.close()
+
+
+import make_env_cube_2048_golden as cubes
+CUBE_GOLD = os.path.join(ROOT, "tests", "golden", "env_cube_2048_golden.npz")
+
+
+@pytest.mark.parametrize("name", list(cubes.cases()))
+def test_device_env_cube_2048_equals_the_reference_text(name):
+    """the 2048^2 environment cube with its mips (33.5 M texels) as the device bakes it against the bake of the REFERENCE'S EnvMapBaker text (SHA-256 of the whole cube): the bench's
+    sky with "Fast" BC6U compression, a noisy HDR source uncompressed, sun discs with "Fast" and "Quality" compression"""
+    import rtxpt_amd as pt
+    gold = np.load(CUBE_GOLD)
+    sc = cubes.cases()[name]()
+    t = pt.PathTracer(); t.set_scene(sc)
+    cube, dim, lv = t.env_cube()
+    assert (dim, lv, cube.shape[0]) == tuple(int(v) for v in gold[name + "_dim"])
+    assert np.array_equal(cubes.digest(cube), gold[name]), "%s: the cube's digest differs from the reference text's bake" % name
+    t.close()
