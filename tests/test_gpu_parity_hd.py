@@ -76,3 +76,24 @@ def test_device_env_cube_2048_equals_the_reference_text(name):
     assert (dim, lv, cube.shape[0]) == tuple(int(v) for v in gold[name + "_dim"])
     assert np.array_equal(cubes.digest(cube), gold[name]), "%s: the cube's digest differs from the reference text's bake" % name
     t.close()
+
+
+import make_neeat_loop_hd_golden as nlh
+import pin_scenes as _pins
+NL_GOLD = os.path.join(ROOT, "tests", "golden", "neeat_loop_hd_golden.npz")
+
+
+@pytest.mark.parametrize("name", list(_pins.neeat_loop_cases()))
+def test_device_neeat_runs_equal_the_reference_text(name):
+    """NEE-AT with the light baker in the loop at 1920x1080 (pt_set_neeat; one pt_render per frame) for the option sets of pin_scenes.neeat_loop_cases(), against the REFERENCE'S text
+    with LightsBaker.hlsl run thread by thread (tests/golden/neeat_loop_hd_golden.npz): every frame's tile tables, jitter, proxy counters and reservoirs, the accumulated frame, ray counts"""
+    import rtxpt_amd as pt
+    gold = np.load(NL_GOLD)
+    def make_device(sc, camd, S, w, h):
+        t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(camd); t.resize(w, h)
+        return t, (lambda t: t.lights()["proxyCounters"])
+    got = nlh.run(name, make_device)
+    keys = list(got)
+    assert keys and all(k in gold.files for k in keys)
+    bad = [k for k in keys if not np.array_equal(np.asarray(got[k]), gold[k])]
+    assert not bad, bad[:6]
