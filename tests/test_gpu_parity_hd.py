@@ -97,3 +97,32 @@ def test_device_neeat_runs_equal_the_reference_text(name):
     assert keys and all(k in gold.files for k in keys)
     bad = [k for k in keys if not np.array_equal(np.asarray(got[k]), gold[k])]
     assert not bad, bad[:6]
+
+
+import make_realtime_hd_golden as rth
+import realtime_cases as _rc
+RT_GOLD = os.path.join(ROOT, "tests", "golden", "realtime_hd_golden.npz")
+
+
+@pytest.mark.parametrize("name", list(_rc.cases()))
+def test_device_realtime_runs_equal_the_reference_text(name):
+    """the coupled realtime runs of tests/realtime_cases.py at 1920x1080 (pt_realtime_frame per frame; the animated case through pt_set_motion_history + pt_animate) against the
+    REFERENCE'S text with the baker run thread by thread (tests/golden/realtime_hd_golden.npz): digests of every output of every frame, ray counts"""
+    import rtxpt_amd as pt
+    from rtxpt_amd import scenes
+    gold = np.load(RT_GOLD)
+    sc, cam, S, subs, frames = rth.frames_of(name)
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(rth.W, rth.H, **cam)); t.resize(rth.W, rth.H); t.set_neeat(True)
+    if frames[0][2] is not None: t.set_motion_history(True)
+    rays = [0, 0]
+    for f, (camd, prm, pose, prev) in enumerate(frames):
+        if pose is not None: t.animate(pose[0], pose[1], vertex_ranges=scenes.animated_vertex_ranges(sc) if f % 2 else None)
+        t.set_camera(camd)
+        frame, bst, fst = t.realtime_frame(f * subs, prm)
+        rays[0] += int(bst["extendRays"]) + int(fst["extendRays"]); rays[1] += int(fst["shadowRays"])
+        tab, jit = t.neeat_tables(); fw, fc = t.light_feedback(0)
+        got = rth.record(name, f, frame, tab, jit, t.lights()["proxyCounters"], fw, fc)
+        bad = [k for k, v in got.items() if not np.array_equal(np.asarray(v), gold[k])]
+        assert not bad, "frame %d: %s" % (f, bad)
+    assert rays == [int(v) for v in gold[name + "_rays"]]
+    t.close()
