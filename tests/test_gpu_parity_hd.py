@@ -126,3 +126,25 @@ def test_device_realtime_runs_equal_the_reference_text(name):
         assert not bad, "frame %d: %s" % (f, bad)
     assert rays == [int(v) for v in gold[name + "_rays"]]
     t.close()
+
+
+import fuzz_cases as _fz
+FUZZ_GOLD = os.path.join(ROOT, "tests", "golden", "fuzz_hd_golden.npz")
+
+
+@pytest.mark.parametrize("lp16", [False, True], ids=["fp32", "lp16"])
+@pytest.mark.parametrize("seed", _fz.SEEDS)
+def test_device_fuzz_frame_equals_the_reference_text_frame(seed, lp16):
+    """40 seeded random scene / camera / settings cases at 1280x720 in both lp builds against frames of the REFERENCE'S integrator text (tests/golden/fuzz_hd_golden.npz); animated
+    cases reach their pose through pt_animate (refit for even seeds, rebuild for odd ones) while the fixture's scene was built in that pose"""
+    import rtxpt_amd as pt
+    import make_pin_cases_hd_golden as gen
+    gold = np.load(FUZZ_GOLD); key = "%d_%s" % (seed, "lp16" if lp16 else "fp32")
+    if key not in gold.files: pytest.skip("not in the fixture")
+    sc, camd, S, first, count, pose = _fz.case(seed, lp16)
+    t = pt.PathTracer(); t.set_scene(sc); t.set_camera(camd); t.set_settings(S); t.resize(_fz.W, _fz.H)
+    if pose is not None: t.animate(pose[0], pose[1], rebuild=bool(seed & 1))
+    st = t.render(first, count)
+    assert np.array_equal(gen.digest(t.radiance()), gold[key]), "seed %d: the frame's digest differs from the reference text's" % seed
+    assert (int(st["extendRays"]), int(st["shadowRays"])) == tuple(int(v) for v in gold[key + "_rays"])
+    t.close()
