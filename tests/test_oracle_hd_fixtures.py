@@ -1,5 +1,5 @@
 """The ORACLE against a sample of the at-scale reference-text fixtures (the device is compared with all of them on the GPU box, tests/test_gpu_parity_hd.py and
-tests/test_gpu_full_size.py): three integrator cases and one NEE-AT case at 1920x1080 x 8 samples, two stable-plane cases at 1920x1080 — whole frames by SHA-256, ray counts."""
+tests/test_gpu_full_size.py): two integrator cases and one NEE-AT case at 1920x1080 x 8 samples, a stable-plane case with object motion at 1920x1080 — whole frames by SHA-256, ray counts."""
 import os, sys
 import numpy as np
 import pytest
@@ -12,7 +12,7 @@ import make_pin_cases_hd_golden as gen
 import make_stable_planes_hd_golden as sph
 
 
-@pytest.mark.parametrize("key", ["lp16_bistro_like_material_zoo_firefly", "fp32_c2_sphere_light_proxy", "lp16_c2_nested2_norr_nold", "neeat_bistro_like_neeat_lp16"])
+@pytest.mark.parametrize("key", ["lp16_bistro_like_material_zoo_firefly", "fp32_c2_sphere_light_proxy", "neeat_bistro_like_neeat_lp16"])
 def test_oracle_frame_equals_the_reference_text_frame(key):
     gold = np.load(os.path.join(ROOT, "tests", "golden", "pin_cases_hd_golden.npz"))
     make, S, first, opts = gen.case_setup(key)
@@ -31,7 +31,7 @@ def test_oracle_frame_equals_the_reference_text_frame(key):
     o.close()
 
 
-@pytest.mark.parametrize("key", ["motion_zoo_object_motion_lp16", "edge_inside_glass"])
+@pytest.mark.parametrize("key", ["motion_zoo_object_motion_lp16"])
 def test_oracle_stable_planes_equal_the_reference_text(key):
     gold = np.load(os.path.join(ROOT, "tests", "golden", "stable_planes_hd_golden.npz"))
     sc, cam, S, prm, lp16, prev_pose = sph.setup(key)
