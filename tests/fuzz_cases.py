@@ -28,3 +28,29 @@ def case(seed, lp16):
     if animated:
         t = float(rng.uniform(0, 3)); pose = (scenes.animate_instances(sc, t), scenes.animate_positions(sc, t))
     return sc, scenes.bridge_camera(W, H, **cam), S, first, count, pose
+
+
+SP_SEEDS = list(range(201, 231))
+
+
+def stable_planes_case(seed):
+    """a random stable-plane frame at W x H: (scene, camera struct, settings, params, lp16, previous pose or None, sample index, fill sub-samples)"""
+    rng = np.random.default_rng(0xFACE + seed)
+    zoo = bool(rng.integers(0, 3))                                   # two of three on the delta-tree zoo, the others on the small street scene with nested-dielectric props
+    if zoo:
+        sc, cam = scenes.stable_planes_zoo()
+        cam = dict(cam, pos=tuple(np.asarray(cam["pos"], np.float64) + rng.uniform(-0.35, 0.35, 3)), fov_y=float(rng.uniform(0.6, 1.3)))
+        d = np.asarray(cam["direction"], np.float64) + rng.uniform(-0.25, 0.25, 3); cam["direction"] = tuple(d / np.linalg.norm(d))
+    else:
+        sc, cam = scenes.bistro_like(scale=float(rng.uniform(0.006, 0.02)), seed=scenes.SEED_BASE + 500 + seed, tex_size=64, animated=True)
+    lp16 = bool(rng.integers(0, 2))
+    S = scenes.config_settings("C2")
+    for k, v in dict(bounceCount=int(rng.integers(0, 9)), diffuseBounceCount=int(rng.integers(0, 5)), nestedDielectricsQuality=int(rng.integers(0, 3)), enableRussianRoulette=int(rng.integers(0, 2)),
+                     fireflyFilterThreshold=float(rng.choice([0.0, 0.7, 3.0])), NEEEnabled=int(rng.integers(0, 4) > 0), NEECandidateSamples=int(rng.integers(1, 7)), NEEType=int(rng.integers(0, 2)),
+                     texLODBias=float(rng.uniform(-1.0, 1.0)), useFp16Types=int(lp16)).items(): S[k] = v
+    prev = dict(cam); prev["pos"] = tuple(np.asarray(cam["pos"], np.float64) + rng.uniform(-0.05, 0.05, 3))
+    subs = int(rng.integers(1, 4))
+    prm = scenes.stable_planes_params(W, H, scenes.view_projection(W, H, **cam), prev_world_to_clip=scenes.view_projection(W, H, **prev), sub_samples=subs,
+                                      active_planes=int(rng.integers(1, 4)), max_vertex_depth=int(rng.integers(0, 10)), allow_psr=bool(rng.integers(0, 2)))
+    prev_pose = scenes.previous_pose(sc, seed) if rng.integers(0, 2) else None
+    return sc, scenes.bridge_camera(W, H, **cam), S, prm, lp16, prev_pose, int(rng.integers(0, 40)), subs

@@ -148,3 +148,26 @@ def test_device_fuzz_frame_equals_the_reference_text_frame(seed, lp16):
     assert np.array_equal(gen.digest(t.radiance()), gold[key]), "seed %d: the frame's digest differs from the reference text's" % seed
     assert (int(st["extendRays"]), int(st["shadowRays"])) == tuple(int(v) for v in gold[key + "_rays"])
     t.close()
+
+
+import make_fuzz_sp_hd_golden as fsp
+FUZZ_SP_GOLD = os.path.join(ROOT, "tests", "golden", "fuzz_sp_hd_golden.npz")
+
+
+@pytest.mark.parametrize("seed", _fz.SP_SEEDS)
+def test_device_fuzz_stable_planes_equal_the_reference_text(seed):
+    """30 seeded random stable-plane frames at 1280x720 (random viewpoints, plane counts, vertex depths, settings, previous poses, sub-sample counts) against the REFERENCE'S text of
+    both passes (tests/golden/fuzz_sp_hd_golden.npz)"""
+    import rtxpt_amd as pt
+    gold = np.load(FUZZ_SP_GOLD)
+    if "%d_build_rays" % seed not in gold.files: pytest.skip("not in the fixture")
+    sc, camd, S, prm, lp16, prev_pose, sample, subs = _fz.stable_planes_case(seed)
+    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(camd); t.resize(_fz.W, _fz.H)
+    if prev_pose is not None: t.set_previous_pose(*prev_pose)
+    built = t.build_stable_planes(sample, prm)
+    for k, v in fsp.digests(built).items(): assert np.array_equal(v, gold["%d_build_%s" % (seed, k)]), "seed %d, build pass: %s differs" % (seed, k)
+    assert int(built["stats"]["extendRays"]) == int(gold["%d_build_rays" % seed][0])
+    filled = t.fill_stable_planes(sample, prm, sub_samples=subs)
+    for k, v in fsp.digests(filled).items(): assert np.array_equal(v, gold["%d_fill_%s" % (seed, k)]), "seed %d, fill passes: %s differs" % (seed, k)
+    assert (int(filled["stats"]["extendRays"]), int(filled["stats"]["shadowRays"])) == tuple(int(v) for v in gold["%d_fill_rays" % seed])
+    t.close()
