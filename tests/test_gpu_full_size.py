@@ -274,3 +274,20 @@ def test_neeat_loop_4k_equals_the_reference_text():
     assert np.array_equal(rt.digest(g.radiance()), gold["frame"]), "the accumulated frame's digest differs"
     assert rays == [int(v) for v in gold["rays"]]
     g.close()
+
+
+def test_display_path_4k_equals_the_reference_text():
+    """pt_tonemap of the device's bench frame for the six operators x three exposure compensations and auto exposure against tests/golden/display_4k_golden.npz: the SRGBA8 image of
+    the frame the reference's integrator text rendered, through the reference's ToneMapping.ps.hlsli text (== its restatement on all 8.3 M pixels, asserted when the fixture was made)"""
+    import sys
+    pt, scenes, ptref = _imports()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import make_bench_frame_golden as gen
+    import make_display_4k_golden as disp
+    gold = np.load(os.path.join(root, "tests", "golden", "display_4k_golden.npz"))
+    sc, cam, S = gen.bench_workload()
+    g = pt.PathTracer(); g.set_scene(sc); g.set_camera(scenes.bridge_camera(W, H, **cam)); g.set_settings(S); g.resize(W, H); g.render(0, SPP)
+    for name, kw in disp.parameter_sets().items():
+        assert np.array_equal(disp.digest(g.tonemap(pt.default_tonemap(**kw))), gold[name]), "%s: the LDR image differs" % name
+    g.close()
