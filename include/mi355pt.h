@@ -282,7 +282,7 @@ int32_t pt_set_view_projection(pt_context* ctx, const float* worldToClipRowMajor
  *   planes         3 x plane stride records of 80 bytes (PtStablePlane = StablePlanes.hlsli:41-58) at GenericTSPixelToAddress(pixel, plane) (8 x 8 tiles, Morton order inside)
  *   stableRadiance RGBA16F: emission and sky reached along the delta paths (noise-free; the fill pass does not count it again)
  *   depth R32F, motionVectors RGBA16F, throughput R11G11B10F: Bridge::ExportSurface / ExportNonSurface for the dominant plane; specularHitT R32F is cleared here and filled by the noisy pass
- * Not carried over: object motion (the scene keeps no previous-frame positions: motion vectors hold the camera's motion only) and the two automatic motion-vector block types of a
+ * Object motion enters the motion vectors through pt_set_motion_history / pt_set_previous_pose (below); without them it reads as zero. Not carried over: the two automatic motion-vector block types of a
  * material (PTMaterialFlags_PSDBlockMVsAtSurfaceType 1 / 2 need Donut's per-triangle curvature; "Off" and "Full" are honoured). */
 typedef struct PtStablePlanesParams {
     uint32_t activeStablePlaneCount;            /* m_ui.StablePlanesActiveCount, 1..3 */
@@ -307,7 +307,8 @@ int32_t pt_build_stable_planes(pt_context* ctx, uint32_t sampleIndex, const PtSt
  * over the buffers pt_build_stable_planes left: every path starts on plane 0 (FirstHitFromVBuffer), follows the recorded delta tree while its branch id matches, and deposits its radiance —
  * total and specular average, attenuated by 1 / subSampleCount — on the plane it last touched (PtStablePlane.PackedNoisyRadianceAndSpecAvg, four binary16 values); emission along the stable
  * branches was collected by the build pass and is not counted again. specularHitT is filled for the dominant plane. NEE with one full sample per vertex (NEEFullSamples 0 or 1); NEE-AT's local
- * sampling tables are honoured, its temporal feedback is not fed (refused while pt_set_neeat / temporalFeedback are on). ReSTIR DI / GI hand-offs do not exist here. */
+ * sampling tables are honoured; with pt_set_neeat on (after the frame's baker passes: pt_realtime_frame, or pt_neeat_update_begin / _end) the visible light samples feed the temporal
+ * feedback reservoirs the next frame's UpdateBegin reads. ReSTIR DI / GI hand-offs do not exist here. */
 int32_t pt_fill_stable_planes(pt_context* ctx, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* stats);
 /* DenoisingGuidesBaker::DenoiseSpecHitT (Sample.cpp:2544, after the noisy passes of a frame): the 5 x 5 depth-aware fill-in of specularHitT, one ping and one pong (DenoisingGuidesBaker.hlsl:50-113) */
 int32_t pt_denoise_spec_hit_t(pt_context* ctx);
@@ -328,7 +329,7 @@ int32_t pt_gather_stable_planes(pt_context* ctx);
  * table) -> pt_build_stable_planes(sampleIndex) -> LightsBaker::UpdateEnd on THIS frame's depth and screen-space motion vectors — Reproject (LightsBaker.hlsl:1348-1375) finds every pixel's
  * history where the build pass says it was, and drops it where the depths disagree — -> params->subSampleCount fill passes (sample indices sampleIndex, sampleIndex + 1, ...), whose light samples
  * come from the tile tables just built and whose visible samples fill the reservoirs the next frame's UpdateBegin reads. Without pt_set_neeat: build + fill passes with the global sampler.
- * The host calls pt_denoise_spec_hit_t / pt_stable_planes_merge / pt_get_stable_planes afterwards as it needs them. Whole frames only (no tile shards: the baker reads neighbourhoods). */
+ * The host calls pt_denoise_spec_hit_t / pt_stable_planes_merge / pt_get_stable_planes afterwards as it needs them. On tile shards: next comment. */
 int32_t pt_realtime_frame(pt_context* ctx, uint32_t sampleIndex, const PtStablePlanesParams* params, PtFrameStats* buildStats, PtFrameStats* fillStats);
 /* The realtime frame on TILE SHARDS with NEE-AT (no reference analogue). The baker's passes read whole neighbourhoods of three things a rank has for its own tiles only: last
  * frame's reservoirs (UpdateBegin), this frame's depth and motion vectors (UpdateEnd). With a communicator (pt_comm_init) pt_realtime_frame exchanges both itself — RCCL
