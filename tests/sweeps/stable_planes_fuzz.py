@@ -1,6 +1,6 @@
 """One-off sweep (build container only, needs /root/reference; not collected by pytest): the ORACLE's stable-plane passes against the REFERENCE'S text compiled live, at 960x540, on
 tests/fuzz_cases.stable_planes_case(1000 + seed): random viewpoints, plane counts, vertex depths, settings, previous poses, 1-3 fill sub-samples — every plane buffer and all live
-plane records after the build pass and after the fill passes, ray counts. Round 4: seeds 0..199, all equal.   usage: python tests/sweeps/stable_planes_fuzz.py FIRST LAST"""
+plane records after the build pass and after the fill passes, ray counts. Round 4: seeds 0..699, all equal.   usage: python tests/sweeps/stable_planes_fuzz.py FIRST LAST"""
 import sys, time, numpy as np
 import os
 ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
