@@ -1,7 +1,7 @@
 """One-off sweep (build container only, needs /root/reference; not collected by pytest): the ORACLE against the REFERENCE'S integrator text compiled live, at 960x540, on seeded random
 compositions of the pin scenes' features — Cornell / street / animated street; analytic sphere lights and their proxy meshes, excluded geometry, a mirrored instance, the material zoo,
 spec-gloss materials, rotated environments, sun discs with any compression; random settings incl. NEEType 0 / 1 / 2 (NEE-AT with and without tile tables and feedback) and both lp builds.
-Round 4: seeds 0..1299, all equal (frames, ray counts, reservoirs).   usage: python tests/sweeps/reference_text_fuzz.py FIRST LAST"""
+Round 4: seeds 0..1299 at 960x540 and 2000..2119 at 1920x1080 (SWEEP_W, SWEEP_H), all equal (frames, ray counts, reservoirs).   usage: python tests/sweeps/reference_text_fuzz.py FIRST LAST"""
 import sys, time, math, numpy as np
 import os
 ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 from rtxpt_amd import scenes
 from oracle import ptref
 import pin_scenes as ps
-W,H=960,540
+W,H=int(os.environ.get("SWEEP_W","960")),int(os.environ.get("SWEEP_H","540"))
 def case(seed):
     rng=np.random.default_rng(0xC0FFEE+seed)
     base = rng.integers(0,3)
