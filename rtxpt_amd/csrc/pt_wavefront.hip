@@ -28,10 +28,12 @@ namespace ptk {
 #define T8_TASK_BLOCKS_N 512        // blocks of a task-round launch: task rounds hold thousands of sub-trees, not millions
 #endif
 
-__global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* __restrict__ queue) {
-    uint i = blockIdx.x * 256u + threadIdx.x;
-    uint total = numOwned * spp;
-    if (i >= total) return;
+// Paths [first, first + n) of the batch's pool region (slot i = sample i % spp of owned pixel i / spp) are generated and their indices written to queue[0 .. n). A streaming frame
+// (pt_render, pt_set_stream_paths) generates its paths in slices: `queue` is then the end of a queue that already holds the survivors of the last bounce, and thread 0 adds n to its counter.
+__global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint first, uint n, uint* __restrict__ queue, uint* countPtr) {
+    const uint t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    const uint i = first + t;
 #if PT_SAMPLE_MINOR
     uint kpx = i / spp, s = i - kpx * spp, px = ownedPixels[kpx];      // the samples of a pixel are neighbours in the pool: a 64-path chunk is 16 pixels x 4 samples
 #else
@@ -39,7 +41,8 @@ __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool 
 #endif
     PathState p = k.generate(px >> 16, px & 0xFFFFu, sampleFirst + s);
     store_path(pool, i, p);
-    queue[i] = i;
+    queue[t] = i;
+    if (countPtr && t == 0u) atomicAdd(countPtr, n);
 }
 
 template <bool COUNT, bool RANGED = false>
@@ -697,9 +700,8 @@ void launch_average_log_luminance(const float4* accum, uint W, uint H, float* sc
     }
     *result = a;
 }
-void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint* queue, hipStream_t st) {
-    uint total = numOwned * spp;
-    hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, st, k, pool, ownedPixels, numOwned, sampleFirst, spp, queue);
+void launch_generate(const PathKernelContext& k, PathPool pool, const uint* ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint first, uint n, uint* queue, uint* countPtr, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_generate, dim3((n + 255) / 256), dim3(256), 0, st, k, pool, ownedPixels, numOwned, sampleFirst, spp, first, n, queue, countPtr);
 }
 // task rounds + resolve pass of one traversal launch; all counts live on the device, so the grids are fixed (empty rounds return at once)
 static const uint T8_TASK_BLOCKS = T8_TASK_BLOCKS_N, T8_RESOLVE_BLOCKS = 256;
@@ -778,13 +780,15 @@ void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const u
     else hipLaunchKernelGGL((k_resolve_shadow<false>), dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
     if (sq.group) hipLaunchKernelGGL(k_resolve_nee, dim3(grid_for(count / sq.group, 256, 4096)), dim3(256), 0, st, pool, sq, countPtr);
 }
-// start of a pass: the batch's PASS_COUNTERS words and the two queue counters the pass refills, zeroed by one launch (three memsets were three launches)
-__global__ void __launch_bounds__(64) k_pass_begin(uint* __restrict__ passCounters, uint* __restrict__ nextCount, uint* __restrict__ shadowCount) {
-    if (threadIdx.x < PASS_COUNTERS) passCounters[threadIdx.x] = 0u;
-    if (threadIdx.x == 32u) *nextCount = 0u;
-    if (threadIdx.x == 33u) *shadowCount = 0u;
+// start of a pass: the batch's PASS_COUNTERS words selected by `mask` and the two queue counters the pass refills (either may be null), zeroed by one launch (three memsets were three launches).
+// pt_render with overlapped visibility rays calls it twice per pass: the traversal / class counters and the next extend count before k_extend, the shadow launch's counters and the shadow
+// count before k_shade — the previous bounce's shadow launch (on the batch's second stream) has read them by then.
+__global__ void __launch_bounds__(64) k_pass_begin(uint* __restrict__ passCounters, uint mask, uint* __restrict__ nextCount, uint* __restrict__ shadowCount) {
+    if (threadIdx.x < PASS_COUNTERS && ((mask >> threadIdx.x) & 1u)) passCounters[threadIdx.x] = 0u;
+    if (threadIdx.x == 32u && nextCount) *nextCount = 0u;
+    if (threadIdx.x == 33u && shadowCount) *shadowCount = 0u;
 }
-void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st) { static_assert(PASS_COUNTERS <= 32u, "k_pass_begin"); hipLaunchKernelGGL(k_pass_begin, dim3(1), dim3(64), 0, st, passCounters, nextCount, shadowCount); }
+void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st, uint mask) { static_assert(PASS_COUNTERS <= 32u, "k_pass_begin"); hipLaunchKernelGGL(k_pass_begin, dim3(1), dim3(64), 0, st, passCounters, mask, nextCount, shadowCount); }
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3((numOwned + 255) / 256), dim3(256), 0, st, pool, ownedPixels, numOwned, spp, accum, accumCountBase, width);
 }
