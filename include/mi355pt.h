@@ -636,11 +636,6 @@ int32_t pt_set_tail_paths(pt_context* ctx, uint32_t maxPaths);
    call generated up front), values below 1024 are raised to that; batches 0 = pt_render's size rule, else 1..4 streams. Environment MI355PT_STREAM_PATHS / MI355PT_STREAM_BATCHES
    override the defaults at pt_create. Ignored in serial-kernel and counter frames. */
 int32_t pt_set_stream_paths(pt_context* ctx, uint32_t pathsInFlight, uint32_t batches);
-/* Overlapped visibility rays: 1 = the shadow launch of a bounce (Bridge::traceVisibilityRay for every light sample of the bounce, Rtxpt/Shaders/PathTracerBridgeDonut.hlsli:993-1027)
-   runs on a second stream of its batch while the next bounce's closest-hit launch is traced, and is joined before that bounce is shaded: the visibility rays only add light to paths
-   whose origin / direction / hit record they do not touch. Launch order only — the image does not depend on it (tests/test_gpu_streaming.py). Environment MI355PT_SHADOW_OVERLAP
-   overrides the default at pt_create. Ignored for NEEFullSamples > 1, serial-kernel and counter frames. */
-int32_t pt_set_shadow_overlap(pt_context* ctx, int32_t enable);
 
 #ifdef __cplusplus
 }

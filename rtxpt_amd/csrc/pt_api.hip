@@ -81,9 +81,6 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #ifndef PT_STREAM_BATCHES
 #define PT_STREAM_BATCHES 0u     // batches of a streaming frame (0: the size rule of pt_render)
 #endif
-#ifndef PT_SHADOW_OVERLAP
-#define PT_SHADOW_OVERLAP 0      // 1: the visibility rays of a bounce are traced on the batch's second stream while the next bounce's k_extend runs (pt_render); joined before the next k_shade
-#endif
 #ifndef PT_PIPELINE_BATCHES
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
 #endif
@@ -92,8 +89,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
-    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0, eventLoopBelow = PT_EVENT_LOOP_BELOW, streamPaths = PT_STREAM_PATHS, streamBatches = PT_STREAM_BATCHES;
-    hipStream_t streams2[PT_PIPELINE_BATCHES] = {}; hipEvent_t shadowEv[PT_PIPELINE_BATCHES] = {}; bool shadowOverlap = PT_SHADOW_OVERLAP != 0;      // overlapped visibility rays (pt_render)   // second half-frame batch (pt_render pipelines two batches)
+    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0, eventLoopBelow = PT_EVENT_LOOP_BELOW, streamPaths = PT_STREAM_PATHS, streamBatches = PT_STREAM_BATCHES;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -345,7 +341,7 @@ int finalize_geometry(pt_context* c) {
     c->bvh.builder = c->bvhBuilder;
     { const char* e = getenv("MI355PT_REINSERT_PASSES"); c->bvh.riPasses = e ? (uint)atoi(e) : 12u; }      // BVH_BUILDER_PLOC_OPT: parallel re-insertion passes (MI355X, C3: 8 passes = 1463 Mrays/s in 63 ms, 12 = 1477 in 81 ms, 16 = 1476 in 98 ms; host SAH + re-insertion 1479 in 1824 ms — profiles/r03k_device_reinsertion_sweep.txt)
     PT_CHECK_HIP(c, c->dShadeTris.resize(c->numTris));
-    if (!c->dTravSpill.p) PT_CHECK_HIP(c, c->dTravSpill.resize(2 * PT_PIPELINE_BATCHES * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH));   // traversal stack tails, one region per pipelined batch (4 x 302 MB of 288 GB)
+    if (!c->dTravSpill.p) PT_CHECK_HIP(c, c->dTravSpill.resize(PT_PIPELINE_BATCHES * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH));   // traversal stack tails, one region per pipelined batch (4 x 302 MB of 288 GB)
     refresh_scene_view(c);
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, st));
@@ -567,8 +563,8 @@ int ensure_pool(pt_context* c, uint n, uint shadowPerPath) {      // shadowPerPa
     PT_CHECK_HIP(c, c->dS0.resize(n)); PT_CHECK_HIP(c, c->dS1.resize(n)); PT_CHECK_HIP(c, c->dS2.resize(n)); PT_CHECK_HIP(c, c->dS3.resize(n)); PT_CHECK_HIP(c, c->dS4.resize(n));
     PT_CHECK_HIP(c, c->dHit.resize(n)); PT_CHECK_HIP(c, c->dQueue[0].resize(n)); PT_CHECK_HIP(c, c->dQueue[1].resize(n));
     PT_CHECK_HIP(c, c->dSq0.resize(ns)); PT_CHECK_HIP(c, c->dSq1.resize(ns)); PT_CHECK_HIP(c, c->dSq2.resize(ns));
-    PT_CHECK_HIP(c, c->dBestKey.resize(2 * ns)); PT_CHECK_HIP(c, c->dResolveList.resize(2 * ns));      // (second halves: the shadow launches of overlapped frames, pt_render)
-    PT_CHECK_HIP(c, c->dTaskQ.resize((size_t)PT_PIPELINE_BATCHES * 4 * TASK_QUEUE_CAPACITY)); PT_CHECK_HIP(c, c->dTravCounts.resize(PT_PIPELINE_BATCHES * PASS_COUNTERS));
+    PT_CHECK_HIP(c, c->dBestKey.resize(ns)); PT_CHECK_HIP(c, c->dResolveList.resize(ns));
+    PT_CHECK_HIP(c, c->dTaskQ.resize((size_t)PT_PIPELINE_BATCHES * 2 * TASK_QUEUE_CAPACITY)); PT_CHECK_HIP(c, c->dTravCounts.resize(PT_PIPELINE_BATCHES * PASS_COUNTERS));
     c->poolCapacity = n; c->shadowCapacity = ns;
     return PT_OK;
 }
@@ -697,7 +693,6 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     { const char* e = getenv("MI355PT_EVENT_LOOP_BELOW"); if (e) c->eventLoopBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch
     { const char* e = getenv("MI355PT_STREAM_PATHS"); if (e) c->streamPaths = (uint)strtoul(e, nullptr, 10); }      // developer A/B switches (pt_set_stream_paths)
     { const char* e = getenv("MI355PT_STREAM_BATCHES"); if (e) c->streamBatches = (uint)strtoul(e, nullptr, 10); }
-    { const char* e = getenv("MI355PT_SHADOW_OVERLAP"); if (e) c->shadowOverlap = atoi(e) != 0; }
     { const char* e = getenv("MI355PT_TAIL_DEFER"); if (e) c->tailDefer = (uint)strtoul(e, nullptr, 10); }      // test switch: iterations after which the tail kernel hands a ray back (0: T8_TAIL_DEFER); a small value sends most rays through the hand-back path
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
@@ -719,7 +714,6 @@ int32_t pt_destroy(pt_context* c) {
     c->dPrimInfo.free(); c->dShadeTris.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
-    for (uint b = 0; b < PT_PIPELINE_BATCHES; b++) { if (c->streams2[b]) (void)hipStreamDestroy(c->streams2[b]); if (c->shadowEv[b]) (void)hipEventDestroy(c->shadowEv[b]); }
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
     delete c;
     return PT_OK;
@@ -1219,7 +1213,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
-        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false, shadowPending = false; hipStream_t st2 = nullptr; hipEvent_t shadowEv = nullptr; TravAux auxShadow; DeviceScene scShadow; uint bound = 0, genPos = 0;      // genPos: paths of the batch generated so far (a streaming frame generates in slices)      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
+        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false; uint bound = 0, genPos = 0;      // genPos: paths of the batch generated so far (a streaming frame generates in slices)      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; uint items; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         bool timed = false;      // per-launch HIP events: only when somebody reads them (serial-kernel steps, the pass log) — ten API calls per pass and batch otherwise
         size_t mark() { if (!timed) return 0; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
@@ -1231,9 +1225,6 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     const bool streaming = c->streamPaths && !c->serialKernels && !c->countersEnabled;
     uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
     if (c->streamBatches && !c->serialKernels) numBatches = c->streamBatches < (uint)PT_PIPELINE_BATCHES ? c->streamBatches : (uint)PT_PIPELINE_BATCHES;
-    // Overlapped visibility rays (pt_set_shadow_overlap): a bounce's shadow launch and its straggler rounds only add to the radiance of paths the next k_extend neither reads nor writes
-    // (origin / direction in, hit record out), so they leave the pass's chain: traced on the batch's second stream while the next bounce is extended, joined before the next k_shade.
-    const bool overlap = c->shadowOverlap && !c->serialKernels && !c->countersEnabled && !shadowGroup;
     const uint streamK = streaming ? (c->streamPaths < 1024u ? 1024u : c->streamPaths) : 0xFFFFFFFFu;
     Batch B[PT_PIPELINE_BATCHES];
     for (uint b = 0; b < numBatches; b++) {
@@ -1250,14 +1241,6 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + PASS_COUNTERS * b;
         t.aux.maxBlocks = (PT_T8_LANES == 2 && numBatches >= 3u) ? 256u * 7u : 0u;      // pipelined batches: one GPU-full of blocks each (pt_scene.h PT_T8_MAX_BLOCKS)
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
-        t.auxShadow = t.aux; t.auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET; t.scShadow = t.sc;
-        if (overlap) {      // the shadow launch of bounce i runs next to the extend launch of bounce i + 1: its own task queues, straggler keys, resolve list and stack tails
-            if (!c->streams2[b]) { PT_CHECK_HIP(c, hipStreamCreateWithFlags(&c->streams2[b], hipStreamNonBlocking)); PT_CHECK_HIP(c, hipEventCreateWithFlags(&c->shadowEv[b], hipEventDisableTiming)); }
-            t.st2 = c->streams2[b]; t.shadowEv = c->shadowEv[b];
-            t.auxShadow.taskQ[0] = c->dTaskQ.p + (size_t)(2 * PT_PIPELINE_BATCHES + 2 * b) * TASK_QUEUE_CAPACITY; t.auxShadow.taskQ[1] = t.auxShadow.taskQ[0] + TASK_QUEUE_CAPACITY;
-            t.auxShadow.bestKey = c->dBestKey.p + c->shadowCapacity + sbase; t.auxShadow.resolveList = c->dResolveList.p + c->shadowCapacity + sbase;
-            t.scShadow.travSpill = c->dsc.travSpill + (size_t)(PT_PIPELINE_BATCHES + b) * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
-        }
         t.timed = c->serialKernels || c->countersEnabled || getenv("MI355PT_PASS_LOG") != nullptr;
         t.genPos = t.total < streamK ? t.total : streamK;
         memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.genPos;
@@ -1292,11 +1275,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (t.waiting) continue;                        // a tail launch still in flight (below): the batch rejoins the lockstep when it is done
             if (!t.active || t.bound >= maxIter) continue;
             uint nxt = t.cur ^ 1u;
-            auto join_shadow = [&]() -> hipError_t { if (!t.shadowPending) return hipSuccess; t.shadowPending = false; return hipStreamWaitEvent(t.st, t.shadowEv, 0); };
-            const bool tailPass = tailBelow && t.active <= tailBelow && !t.afterTail && t.genPos == t.total;
-            if (overlap && !tailPass) launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], nullptr, t.st, ~PASS_SHADOW_MASK);      // (the shadow launch's counters and the shadow count: before k_shade, below)
-            else { PT_CHECK_HIP(c, join_shadow()); launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st); }      // the pass's traversal / class counters and the two queue counters it refills: one launch
-            if (tailPass) {      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
+            launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch
+            if (tailBelow && t.active <= tailBelow && !t.afterTail && t.genPos == t.total) {      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
                 size_t e0 = t.mark(); launch_tail(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, maxIter - t.bound, c->tailDefer, t.aux.maxBlocks, t.st); size_t e1 = t.mark();
                 if (t.timed) t.spans.push_back({e0, e1, 3, t.active});
                 t.tailLaunches++; t.afterTail = true; t.inTail = true;      // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
@@ -1306,7 +1286,6 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             }
             t.afterTail = false; if (t.genPos == t.total) t.bound++; wavefrontPasses++;      // (the bounce bound counts from the pass that carries the batch's last fresh paths)
             size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
-            if (overlap) { PT_CHECK_HIP(c, join_shadow()); launch_pass_reset(t.aux.counts, nullptr, &t.wc->shadowCount, t.st, PASS_SHADOW_MASK); }
             launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
             t.extendRays += t.active;
             PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
@@ -1328,11 +1307,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
                 uint pc[PASS_COUNTERS]; PT_CHECK_HIP(c, hipMemcpy(pc, t.aux.counts, sizeof(pc), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[pass log]   b%u pass %u: %u paths -> extend splits %u / %u / %u / %u sub-trees, %u rays resolved; %u visibility rays next\n", b, t.iterations, t.active, pc[0], pc[1], pc[2], pc[3], pc[TRAV_RESOLVE], nShadow);
             }
-            if (nShadow && overlap) {
-                launch_shadow(t.scShadow, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, false, t.auxShadow, t.st2);
-                PT_CHECK_HIP(c, hipEventRecord(t.shadowEv, t.st2)); t.shadowPending = true; t.shadowRays += nShadow;
-            } else
-            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, t.auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
+            TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
+            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
             t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
             if (t.genPos < t.total && t.active < streamK) {      // streaming: fresh paths fill the next extend queue up (k_generate adds them to its device-side count)
                 const uint n = (streamK - t.active < t.total - t.genPos) ? streamK - t.active : t.total - t.genPos;
@@ -1344,7 +1320,6 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     }
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
-        if (t.shadowPending) { PT_CHECK_HIP(c, hipStreamWaitEvent(t.st, t.shadowEv, 0)); t.shadowPending = false; }
         launch_accumulate(t.pool, c->dOwned.p + t.pixFirst, t.numPix, count, c->dAccum.p, c->accumCount, c->width, t.st);
         t.t1 = t.mark();
         PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, sizeof(WaveCounters), hipMemcpyDeviceToHost, t.st));
@@ -2098,7 +2073,6 @@ int32_t pt_get_bvh_info(pt_context* c, PtBvhInfo* out) {
 int32_t pt_set_counters(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->countersEnabled = enable != 0; return PT_OK; }
 int32_t pt_set_serial_kernels(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->serialKernels = enable != 0; return PT_OK; }
 int32_t pt_set_tail_paths(pt_context* c, uint32_t maxPaths) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->tailBelow = maxPaths; return PT_OK; }
-int32_t pt_set_shadow_overlap(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->shadowOverlap = enable != 0; return PT_OK; }
 int32_t pt_set_stream_paths(pt_context* c, uint32_t pathsInFlight, uint32_t batches) { if (!c || batches > (uint32_t)PT_PIPELINE_BATCHES) return PT_ERROR_INVALID_ARGUMENT; c->streamPaths = pathsInFlight; c->streamBatches = batches; return PT_OK; }
 
 } // extern "C"

@@ -35,7 +35,7 @@ struct WaveCounters {           // device-resident counters / stats (one 256 B b
 // counts: TRAV_COUNTERS words per traversal launch, one counter per producer so that nothing has to be reset between the launches of a pass —
 //   [0] sub-trees split off by k_extend / k_shadow (task queue 0), [1..3] by task rounds 0..2 (queues 1, 0, 1), [TRAV_RESOLVE] rays to resolve.
 // pt_render keeps one PASS_COUNTERS block per batch — {extend launch, shadow launch, k_classify's three class counts} — and zeroes it once per pass.
-static const uint TRAV_COUNTERS = 5, TRAV_RESOLVE = 4, PASS_COUNTERS = 16, PASS_SHADOW_OFFSET = 5, PASS_CLASS_OFFSET = 10, PASS_SHADOW_MASK = 0x1Fu << PASS_SHADOW_OFFSET;
+static const uint TRAV_COUNTERS = 5, TRAV_RESOLVE = 4, PASS_COUNTERS = 16, PASS_SHADOW_OFFSET = 5, PASS_CLASS_OFFSET = 10;
 struct TravAux { TravTask* taskQ[2]; uint* counts; uint taskCap; unsigned long long* bestKey; uint* resolveList; const uint* primToSlot; uint maxBlocks; };      // maxBlocks: grid bound of the traversal launches (0: T8_MAX_BLOCKS)
 
 // paths [first, first + n) of the pool region -> queue[0 .. n); countPtr (may be null): the counter of the queue `queue` is the end of, incremented by n (k_generate)
@@ -50,7 +50,7 @@ void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const u
 // the late bounces of a batch in one launch: every wave runs 32 paths of queueIn to their end (at most maxBounces bounces each); stragglers and paths beyond the bound come back through
 // queueOut / countOutPtr (and, for visibility rays, the shadow queue / wc->shadowCount). NEEFullSamples 1 only (sq.group == 0); the pass's counters zeroed by the caller as for launch_shade
 void launch_tail(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, uint maxBounces, uint deferIters /* 0: T8_TAIL_DEFER */, uint maxBlocks, hipStream_t st);
-void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st, uint mask = 0xFFFFFFFFu);      // one launch: the batch's PASS_COUNTERS words and the two queue counters the pass refills
+void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st);      // one launch: the batch's PASS_COUNTERS words and the two queue counters the pass refills
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st);
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st);
 void launch_pack(const float4* accum, const uint* ownedPixels, uint numOwned, uint width, float4* dst, hipStream_t st);

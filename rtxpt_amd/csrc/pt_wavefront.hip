@@ -780,15 +780,13 @@ void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const u
     else hipLaunchKernelGGL((k_resolve_shadow<false>), dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, pool, sq, aux);
     if (sq.group) hipLaunchKernelGGL(k_resolve_nee, dim3(grid_for(count / sq.group, 256, 4096)), dim3(256), 0, st, pool, sq, countPtr);
 }
-// start of a pass: the batch's PASS_COUNTERS words selected by `mask` and the two queue counters the pass refills (either may be null), zeroed by one launch (three memsets were three launches).
-// pt_render with overlapped visibility rays calls it twice per pass: the traversal / class counters and the next extend count before k_extend, the shadow launch's counters and the shadow
-// count before k_shade — the previous bounce's shadow launch (on the batch's second stream) has read them by then.
-__global__ void __launch_bounds__(64) k_pass_begin(uint* __restrict__ passCounters, uint mask, uint* __restrict__ nextCount, uint* __restrict__ shadowCount) {
-    if (threadIdx.x < PASS_COUNTERS && ((mask >> threadIdx.x) & 1u)) passCounters[threadIdx.x] = 0u;
-    if (threadIdx.x == 32u && nextCount) *nextCount = 0u;
-    if (threadIdx.x == 33u && shadowCount) *shadowCount = 0u;
+// start of a pass: the batch's PASS_COUNTERS words and the two queue counters the pass refills, zeroed by one launch (three memsets were three launches)
+__global__ void __launch_bounds__(64) k_pass_begin(uint* __restrict__ passCounters, uint* __restrict__ nextCount, uint* __restrict__ shadowCount) {
+    if (threadIdx.x < PASS_COUNTERS) passCounters[threadIdx.x] = 0u;
+    if (threadIdx.x == 32u) *nextCount = 0u;
+    if (threadIdx.x == 33u) *shadowCount = 0u;
 }
-void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st, uint mask) { static_assert(PASS_COUNTERS <= 32u, "k_pass_begin"); hipLaunchKernelGGL(k_pass_begin, dim3(1), dim3(64), 0, st, passCounters, mask, nextCount, shadowCount); }
+void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st) { static_assert(PASS_COUNTERS <= 32u, "k_pass_begin"); hipLaunchKernelGGL(k_pass_begin, dim3(1), dim3(64), 0, st, passCounters, nextCount, shadowCount); }
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3((numOwned + 255) / 256), dim3(256), 0, st, pool, ownedPixels, numOwned, spp, accum, accumCountBase, width);
 }

@@ -39,20 +39,6 @@ def test_streaming_frames_equal_the_up_front_frame(tail):
     t.close()
 
 
-@pytest.mark.parametrize("tail", [0, 32768])
-def test_overlapped_visibility_rays_equal_the_serial_frame(tail):
-    """pt_set_shadow_overlap: the shadow launch of a bounce on the batch's second stream next to the following bounce's extend launch — same frame, same counts; alone and with streaming."""
-    t = _tracer(); spp = 4
-    t.set_tail_paths(tail); t.set_shadow_overlap(False); t.reset_accumulation(); st = t.render(0, spp)
-    ref = (t.radiance(), st["extendRays"], st["shadowRays"], st["hits"])
-    for batches, k in ((0, 0), (1, 0), (3, 0), (4, 0), (2, 131072)):
-        t.set_shadow_overlap(True); t.set_stream_paths(k, batches); t.reset_accumulation(); st = t.render(0, spp)
-        img = t.radiance()
-        assert np.array_equal(_bits(img), _bits(ref[0])), "batches %d, %d in flight: %d pixels differ" % (batches, k, int((_bits(img) != _bits(ref[0])).any(-1).sum()))
-        assert (st["extendRays"], st["shadowRays"], st["hits"]) == ref[1:]
-    t.close()
-
-
 def test_streaming_continues_an_accumulation():
     """Samples 0..1 up front, then samples 2..5 streamed == samples 0..5 up front: the accumulation weights and the sample indices of streamed slices."""
     t = _tracer(w=512, h=288)
@@ -86,11 +72,11 @@ def test_streaming_neeat_feedback_frame():
     if int(S["NEEFullSamples"]) > 1: pytest.skip("grouped NEE samples")
     sc, cam = make()
     out = []
-    for k in (0, 4096, -1):      # -1: overlapped visibility rays (the reservoir update rides on the shadow launch)
+    for k in (0, 4096):
         t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h)
         baked = len(t.lights()["lights"])
         t.set_local_light_sampling(pin_scenes.neeat_table(opts, baked, w, h), jitter=opts["jitter"], ratio=opts["ratio"], ssc_threshold=opts["ssc_threshold"], feedback=opts["feedback"])
-        t.set_stream_paths(max(k, 0), 1); t.set_shadow_overlap(k < 0); st = t.render(first, n)
+        t.set_stream_paths(k, 1); st = t.render(first, n)
         fb = [t.light_feedback(s) for s in range(n)] if opts["feedback"] else []
         out.append((t.radiance(), st["extendRays"], st["shadowRays"], fb)); t.close()
     for o in out[1:]:

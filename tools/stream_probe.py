@@ -22,7 +22,7 @@ for world in worlds:
     g.reset_accumulation(); g.render(0, SPP)
     ref = None
     for b, k, ov in SWEEP:
-        g.set_shadow_overlap(ov); g.set_stream_paths(k * 1024, b); g.reset_accumulation(); st = g.render(0, SPP)
+        g.set_stream_paths(k * 1024, b); g.reset_accumulation(); st = g.render(0, SPP)
         digest = hashlib.sha256(g.radiance().tobytes()).hexdigest()[:16]; rays = (st["extendRays"], st["shadowRays"])
         if ref is None: ref = (digest, rays)
         best = 1e9; tot = 0.0
