@@ -107,6 +107,33 @@ static inline float computeRayConeTriangleLODValue(const float3 v[3], const floa
     return 0.5f * RayCone::SafeLog2(Ta / Pa);
 }
 
+// TriangleCurvatureApprox_GradN (PathTracerBridgeDonut.hlsli:92-149): a curvature proxy of one triangle in ~1/length units — the RMS gradient of a linear normal field fitted
+// over the triangle in a 2D basis of its (world-space) plane. Feeds the automatic motion-vector block types of Bridge::loadSurface (:704-716).
+static inline float TriangleCurvatureApprox_GradN(const float3 vertexPositions[3], const float3 vertexNormals[3], const float3x4& transform) {
+    const float eps = 1e-8f;
+    float3 e10 = xform_vector(transform, vertexPositions[1] - vertexPositions[0]);      // mul((float3x3)transform, p1 - p0)
+    float e10Len = length(e10);
+    if (e10Len < eps) return 0.0f;
+    float3 e1 = e10 / e10Len;
+    float3 e20 = xform_vector(transform, vertexPositions[2] - vertexPositions[0]);
+    float u2 = dot(e20, e1);
+    float3 t = e20 - e1 * u2;
+    float tLen = length(t);
+    if (tLen < eps) return 0.0f;
+    float3 e2 = t / tLen;
+    float u1 = e10Len;
+    float v2 = dot(e20, e2);
+    float3 dn1 = vertexNormals[1] - vertexNormals[0], dn2 = vertexNormals[2] - vertexNormals[0];
+    float3 a = dn1 / fmaxf_(u1, eps);
+    float denomV = fabsf(v2) < eps ? (v2 >= 0.0f ? eps : -eps) : v2;
+    float3 b = (dn2 - a * u2) / denomV;
+    return sqrtf_(dot(a, a) + dot(b, b));
+}
+// what Bridge::loadSurface hands to its motion-vector block decision (BridgeDonut:704-716): donutGS.curvatureWS (0 for a mesh without vertex normals: the sample is zero-initialised, :164)
+// and abs(dot(rayDir, -N)) with the shading normal BEFORE adjustShadingNormal. Asked for by the stable-plane passes only (null otherwise: nothing is computed).
+struct MVBlockInputs { float curvatureWS, projectionTerm; };
+
+
 // InteriorList.hlsli:28-248 (2 slots)
 struct InteriorList {
     static const uint kNoMaterial = 0xffffffffu, kMaterialMask = (1u << 28) - 1u, kNestedPriorityOffset = 28, kMaxNestedPriority = 15;
@@ -314,7 +341,7 @@ struct PathTracer {
         const float3 objPos = (P[g.vertexOffset + idx[0]] * bary.x + P[g.vertexOffset + idx[1]] * bary.y) + P[g.vertexOffset + idx[2]] * bary.z;
         return xform_point(M, objPos);
     }
-    SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone) const {
+    SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone, MVBlockInputs* mvBlock = nullptr) const {
         const Triangle& tr = sc.tris[prim];
         uint subInst = tr.subInstance, triangleIndex = tr.triIndex;
         uint instanceIndex = sc.subInstToInstGeom[subInst].x;
@@ -334,6 +361,7 @@ struct PathTracer {
             texcoord = (vt[0] * bary.x + vt[1] * bary.y) + vt[2] * bary.z;
         }
         float3 objFlatN = SafeNormalize(cross(vp[1] - vp[0], vp[2] - vp[0]));
+        if (mvBlock) mvBlock->curvatureWS = 0.0f;
         float3 geometryNormal = make_float3(0.f);
         if (g.flags & GEOM_HAS_NORMAL) {
             float3 n[3];
@@ -341,6 +369,7 @@ struct PathTracer {
                 n[k] = normalize(Unpack_RGB8_SNORM(sc.normals[g.vertexOffset + idx[k]]));
                 if (dot(n[k], objFlatN) < 0.f) n[k] = -n[k];                       // FlipIfOpposite
             }
+            if (mvBlock) mvBlock->curvatureWS = TriangleCurvatureApprox_GradN(vp, n, M);
             geometryNormal = (n[0] * bary.x + n[1] * bary.y) + n[2] * bary.z;
             geometryNormal = SafeNormalize(xform_direction4(M, geometryNormal));
         }
@@ -412,6 +441,7 @@ struct PathTracer {
         sd.vertexN = frontFacing ? geometryNormal : -geometryNormal;
         sd.frontFacing = frontFacing;
         sd.N = frontFacing ? mShadingNormal : -mShadingNormal;
+        if (mvBlock) mvBlock->projectionTerm = fabsf(dot(rayDir, -sd.N));
         bool thin = (material.Flags & PTMaterialFlags_ThinSurface) != 0;
         sd.materialID = materialIndex;
         sd.mtl = MaterialHeader::make();

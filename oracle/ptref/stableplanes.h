@@ -358,14 +358,21 @@ struct StablePlanesContext {
         B.Throughput[i] = throughput;
     }
 };
-// what Bridge::loadSurface writes into the material header for the decomposition (BridgeDonut:699-718). The two "auto" motion-vector block types (1, 2) need Donut's per-triangle
-// curvature estimate (donutGS.curvatureWS, un-vendored): only Off (0) and Full (3) are honoured, the automatic types behave as Off.
+// what Bridge::loadSurface writes into the material header for the decomposition (BridgeDonut:699-718). Motion-vector block types: 0 Off, 3 Full, and the two automatic ones —
+// 1 AutoLow, 2 AutoHigh — which block stochastically where the triangle's curvature (TriangleCurvatureApprox_GradN, pt_path.h / pathtracer.h), seen through the ray cone's width at
+// the hit and the angle of incidence, exceeds a threshold jittered per (pixel, vertex, sample) by a MicroRng of its own (BridgeDonut:704-716): no other random stream moves.
 struct SPMaterialInfo { bool psdExclude, blockMVs; uint dominantDeltaLobeP1; };
-static inline SPMaterialInfo SP_material_info(uint flags) {
+static inline SPMaterialInfo SP_material_info(uint flags, const MVBlockInputs& geo, const RayCone& rayCone, uint pathId, uint pathVertexIndex, uint sampleIndex) {
     SPMaterialInfo m; m.psdExclude = (flags & PTMaterialFlags_PSDExcludeBit) != 0;
     m.dominantDeltaLobeP1 = (flags & PTMaterialFlags_PSDDominantDeltaLobeP1Mask) >> PTMaterialFlags_PSDDominantDeltaLobeP1Shift;
     const int blockType = ((flags & PTMaterialFlags_PSDBlockMVsAtSurfaceTypeB0) != 0 ? 1 : 0) + ((flags & PTMaterialFlags_PSDBlockMVsAtSurfaceTypeB1) != 0 ? 2 : 0);
     m.blockMVs = blockType == 3;
+    if (blockType == 1 || blockType == 2) {
+        const float pixelCurvature = (geo.curvatureWS * rayCone.getWidth()) / fmaxf_(geo.projectionTerm, 1e-6f);
+        const float threshold = (blockType == 1) ? 0.03f : 0.0005f;
+        MicroRng rng = MicroRng::make(pathId >> 16, pathId & 0xFFFFu, pathVertexIndex, sampleIndex);
+        m.blockMVs |= pixelCurvature > ((rng.NextFloat() * 0.9f + 0.3f) * threshold);
+    }
     return m;
 }
 
@@ -536,8 +543,9 @@ template <class PT> struct StablePlanesBuilder {
     // HandleHit in the BUILD configuration (PathTracer.hlsli:505-700)
     void HandleHit(PathState& path, float3 rayOrigin, float3 rayDir, uint prim, float rayTCurrent, float bu, float bv) const {
         pt.UpdatePathTravelled(path, rayTCurrent);
-        SurfaceData surfaceData = pt.loadSurface(prim, bu, bv, rayDir, path.rayCone);
-        const SPMaterialInfo mi = SP_material_info(SP_material_flags(pt, surfaceData.shadingData.materialID));
+        MVBlockInputs mvGeo;
+        SurfaceData surfaceData = pt.loadSurface(prim, bu, bv, rayDir, path.rayCone, &mvGeo);
+        const SPMaterialInfo mi = SP_material_info(SP_material_flags(pt, surfaceData.shadingData.materialID), mvGeo, path.rayCone, path.id, path.getVertexIndex(), sampleIndex);
         if (pt.S.nestedDielectricsQuality > 0 && !path.interiorList.isEmpty()) {
             const float3 transmittance = pt.volumeTransmittance(path.interiorList.getTopMaterialID(), rayTCurrent);
             path.SetThp(path.GetThp() * transmittance);
@@ -852,8 +860,9 @@ template <class PT> struct StablePlanesFiller {
     void HandleHit(PathState& path, float3 rayOrigin, float3 rayDir, uint prim, float rayTCurrent, float bu, float bv, SPNeeRequest& req) const {
         req.valid = false;
         pt.UpdatePathTravelled(path, rayTCurrent);
-        SurfaceData surfaceData = pt.loadSurface(prim, bu, bv, rayDir, path.rayCone);
-        const SPMaterialInfo mi = SP_material_info(SP_material_flags(pt, surfaceData.shadingData.materialID));
+        MVBlockInputs mvGeo;
+        SurfaceData surfaceData = pt.loadSurface(prim, bu, bv, rayDir, path.rayCone, &mvGeo);
+        const SPMaterialInfo mi = SP_material_info(SP_material_flags(pt, surfaceData.shadingData.materialID), mvGeo, path.rayCone, path.id, path.getVertexIndex(), sampleIndex);
         if (pt.S.nestedDielectricsQuality > 0 && !path.interiorList.isEmpty()) {
             const float3 transmittance = pt.volumeTransmittance(path.interiorList.getTopMaterialID(), rayTCurrent);
             path.SetThp(path.GetThp() * transmittance);

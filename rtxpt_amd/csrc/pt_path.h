@@ -191,6 +191,32 @@ static inline float computeRayConeTriangleLODValue(const float3 v[3], const floa
     return 0.5f * RayCone::SafeLog2(Ta / Pa);
 }
 
+// TriangleCurvatureApprox_GradN (PathTracerBridgeDonut.hlsli:92-149): a curvature proxy of one triangle in ~1/length units — the RMS gradient of a linear normal field fitted
+// over the triangle in a 2D basis of its (world-space) plane. Feeds the automatic motion-vector block types of Bridge::loadSurface (:704-716).
+static inline float TriangleCurvatureApprox_GradN(const float3 vertexPositions[3], const float3 vertexNormals[3], const float3x4& transform) {
+    const float eps = 1e-8f;
+    float3 e10 = xform_vector(transform, vertexPositions[1] - vertexPositions[0]);      // mul((float3x3)transform, p1 - p0)
+    float e10Len = length(e10);
+    if (e10Len < eps) return 0.0f;
+    float3 e1 = e10 / e10Len;
+    float3 e20 = xform_vector(transform, vertexPositions[2] - vertexPositions[0]);
+    float u2 = dot(e20, e1);
+    float3 t = e20 - e1 * u2;
+    float tLen = length(t);
+    if (tLen < eps) return 0.0f;
+    float3 e2 = t / tLen;
+    float u1 = e10Len;
+    float v2 = dot(e20, e2);
+    float3 dn1 = vertexNormals[1] - vertexNormals[0], dn2 = vertexNormals[2] - vertexNormals[0];
+    float3 a = dn1 / fmaxf_(u1, eps);
+    float denomV = fabsf(v2) < eps ? (v2 >= 0.0f ? eps : -eps) : v2;
+    float3 b = (dn2 - a * u2) / denomV;
+    return sqrtf_(dot(a, a) + dot(b, b));
+}
+// what Bridge::loadSurface hands to its motion-vector block decision (BridgeDonut:704-716): donutGS.curvatureWS (0 for a mesh without vertex normals: the sample is zero-initialised, :164)
+// and abs(dot(rayDir, -N)) with the shading normal BEFORE adjustShadingNormal. Asked for by the stable-plane passes only (null otherwise: nothing is computed).
+struct MVBlockInputs { float curvatureWS, projectionTerm; };
+
 // LP16: which build of the reference's lp types this instance restates (PtSettings::useFp16Types selects it at launch; the data members are the same)
 template <bool LP16> struct PathKernelContextT {
     typedef LPOps<LP16> LP;
@@ -298,7 +324,7 @@ template <bool LP16> struct PathKernelContextT {
         return xform_point(M, objPos);
     }
     // Bridge::loadSurface (BridgeDonut:612-853): the divergent gather of the pipeline
-    SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone) const {
+    SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone, MVBlockInputs* mvBlock = nullptr) const {
 #if PT_SHADE_TRI
         // one 128-byte line per primitive (pt_scene.h ShadeTri) instead of primInfo -> subInstToInstGeom -> {instance, subInstance, geometry} -> indices -> vertex streams
         const uint4* rec = reinterpret_cast<const uint4*>(sc.shadeTris + prim);
@@ -316,6 +342,7 @@ template <bool LP16> struct PathKernelContextT {
             texcoord = (vt[0] * bary.x + vt[1] * bary.y) + vt[2] * bary.z;
         }
         float3 objFlatN = SafeNormalize(cross(vp[1] - vp[0], vp[2] - vp[0]));
+        if (mvBlock) mvBlock->curvatureWS = 0.0f;
         float3 geometryNormal = make_float3(0.f);
         if (g.flags & GEOM_HAS_NORMAL) {
             const uint pn[3] = {r4.w, r5.x, r5.y};
@@ -324,6 +351,7 @@ template <bool LP16> struct PathKernelContextT {
                 n[k] = normalize(Unpack_RGB8_SNORM(pn[k]));
                 if (dot(n[k], objFlatN) < 0.f) n[k] = -n[k];
             }
+            if (mvBlock) mvBlock->curvatureWS = TriangleCurvatureApprox_GradN(vp, n, M);
             geometryNormal = (n[0] * bary.x + n[1] * bary.y) + n[2] * bary.z;
             geometryNormal = SafeNormalize(xform_direction4(M, geometryNormal));
         }
@@ -351,6 +379,7 @@ template <bool LP16> struct PathKernelContextT {
             texcoord = (vt[0] * bary.x + vt[1] * bary.y) + vt[2] * bary.z;
         }
         float3 objFlatN = SafeNormalize(cross(vp[1] - vp[0], vp[2] - vp[0]));
+        if (mvBlock) mvBlock->curvatureWS = 0.0f;
         float3 geometryNormal = make_float3(0.f);
         if (g.flags & GEOM_HAS_NORMAL) {
             float3 n[3];
@@ -358,6 +387,7 @@ template <bool LP16> struct PathKernelContextT {
                 n[k] = normalize(Unpack_RGB8_SNORM(sc.normals[vi[k]]));
                 if (dot(n[k], objFlatN) < 0.f) n[k] = -n[k];
             }
+            if (mvBlock) mvBlock->curvatureWS = TriangleCurvatureApprox_GradN(vp, n, M);
             geometryNormal = (n[0] * bary.x + n[1] * bary.y) + n[2] * bary.z;
             geometryNormal = SafeNormalize(xform_direction4(M, geometryNormal));
         }
@@ -428,6 +458,7 @@ template <bool LP16> struct PathKernelContextT {
         sd.vertexN = frontFacing ? geometryNormal : -geometryNormal;
         sd.frontFacing = frontFacing;
         sd.N = frontFacing ? mShadingNormal : -mShadingNormal;
+        if (mvBlock) mvBlock->projectionTerm = fabsf(dot(rayDir, -sd.N));
         bool thin = (mflags & PTMaterialFlags_ThinSurface) != 0;
         sd.materialID = materialIndex;
         sd.mtl = MaterialHeader::make();

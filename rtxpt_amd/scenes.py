@@ -281,6 +281,24 @@ def unit_cube():
     return np.array(P, np.float32), np.array(I, np.uint32), np.array(UV, np.float32), np.array(N, np.float32), np.array(T, np.float32)
 
 
+def sphere_patch(radius, half_width, n=12):
+    """A square patch of a sphere of the given radius, bulging towards -z around the origin: (n + 1)^2 shared vertices with smooth normals (towards -z, away from the centre
+    at (0, 0, radius)), 2 n^2 triangles wound counter-clockwise seen from -z. For the curvature-driven motion-vector block types (PathTracerBridgeDonut.hlsli:92-149, 704-716).
+    Returns pos, idx, uv, normal, tangent like quad()."""
+    P, UV, N, T, I = [], [], [], [], []
+    for j in range(n + 1):
+        for i in range(n + 1):
+            x, y = (2.0 * i / n - 1.0) * half_width, (2.0 * j / n - 1.0) * half_width
+            z = radius - math.sqrt(radius * radius - x * x - y * y)
+            nrm = np.array([x, y, z - radius], np.float64); nrm /= np.linalg.norm(nrm)
+            P.append((x, y, z)); N.append(nrm); UV.append((i / n, j / n)); T.append((1.0, 0.0, 0.0, 1.0))
+    for j in range(n):
+        for i in range(n):
+            a, b, c, d = j * (n + 1) + i, j * (n + 1) + i + 1, (j + 1) * (n + 1) + i + 1, (j + 1) * (n + 1) + i
+            I += [a, d, c, a, c, b]
+    return np.array(P, np.float32), np.array(I, np.uint32), np.array(UV, np.float32), np.array(N, np.float32), np.array(T, np.float32)
+
+
 def sky_equirect(w=1024, h=512, horizon=(0.9, 0.95, 1.0), zenith=(0.25, 0.45, 0.9), sun_dir=(0.35, 0.8, -0.45), sun_radiance=5e4, sun_deg=1.0, ground=(0.15, 0.14, 0.13)):
     """Analytic gradient sky + sun disc as a lat-long float image. Row 0 = +Y; u from atan2(x,-z)."""
     v = (np.arange(h, dtype=np.float64) + 0.5) / h
@@ -700,10 +718,8 @@ def bistro_like(scale=1.0, seed=SEED_BASE + 3, tex_size=1024, animated=False):
     return sc, cam
 
 
-def closed_icosphere(subdivisions=5, transform=None):
-    """A closed, indexed (shared-vertex) triangle mesh: an icosphere of radius 1 with 20 * 4^subdivisions triangles, one instance under `transform` (default: a rotation about y
-    with a non-uniform scale and an offset, so that the world-space vertices carry rounding). For the watertightness measurement (tests/test_gpu_watertight.py): from inside,
-    every ray must hit. Returns (scene dict, world-space float64 vertices as the float32 transform gives them, triangle index array)."""
+def icosphere_mesh(subdivisions):
+    """(float32 positions on the unit sphere, uint32 triangle index array (n, 3)) of an icosphere with 20 * 4^subdivisions triangles and shared vertices"""
     t = (1.0 + 5.0 ** 0.5) / 2.0
     v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
     f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
@@ -720,7 +736,14 @@ def closed_icosphere(subdivisions=5, transform=None):
             ab, bc, ca = m(a, b), m(b, c), m(c, a)
             F2 += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
         F = F2
-    P = np.array(V, np.float32); I = np.array(F, np.uint32)
+    return np.array(V, np.float32), np.array(F, np.uint32)
+
+
+def closed_icosphere(subdivisions=5, transform=None):
+    """A closed, indexed (shared-vertex) triangle mesh: an icosphere of radius 1 with 20 * 4^subdivisions triangles, one instance under `transform` (default: a rotation about y
+    with a non-uniform scale and an offset, so that the world-space vertices carry rounding). For the watertightness measurement (tests/test_gpu_watertight.py): from inside,
+    every ray must hit. Returns (scene dict, world-space float64 vertices as the float32 transform gives them, triangle index array)."""
+    P, I = icosphere_mesh(subdivisions)
     b = SceneBuilder()
     mat = b.add_material(make_material(base=(0.7, 0.7, 0.7), roughness=1.0))
     b.begin_mesh(); b.add_geometry(P, I.reshape(-1), mat, normal=P); mesh = b.end_mesh()
@@ -874,8 +897,12 @@ def stable_planes_address(x, y, plane, width, height):
 MF_PSDExclude, MF_PSDBlockMVsB0, MF_PSDBlockMVsB1, MF_PSDDominantDeltaLobeP1Shift = 0x400, 1 << 13, 1 << 14, 24
 
 
-def stable_planes_zoo():
-    """A small scene that exercises every branch of the stable-plane build pass: an open box under the sky with a perfect mirror (primary surface replacement), solid glass
+def stable_planes_zoo(auto_mv=None):
+    """auto_mv (None: the scene of the committed fixtures, unchanged): adds curved surfaces whose materials use the AUTOMATIC motion-vector block types of Bridge::loadSurface
+    (PathTracerBridgeDonut.hlsli:704-716) — a gently curved mirror (AutoLow: the pixel curvature straddles the jittered threshold), a nearly flat thin glass pane whose 8-bit vertex
+    normals make some triangles flat and others stepped (AutoHigh), a small solid glass sphere (AutoLow, always above the threshold). auto_mv = "off" / "full" builds the same
+    geometry with block type 0 / 3 on all three (what the automatic types must differ from).
+    A small scene that exercises every branch of the stable-plane build pass: an open box under the sky with a perfect mirror (primary surface replacement), solid glass
     (a transmission and a reflection plane, nested priorities, volume absorption), a thin pane whose dominant lobe is transmission, a pane that blocks motion vectors at its surface,
     a mirror excluded from the decomposition, a rough metal, an emitter that is also seen through the delta paths. Returns (scene dict, camera kwargs)."""
     b = SceneBuilder()
@@ -906,6 +933,16 @@ def stable_planes_zoo():
     for mat, xf in ((glass, trs((-0.35, 0.2501, 1.1), rot_y=0.4, scale=(0.25, 0.25, 0.25))), (glass_in, trs((-0.35, 0.2501, 1.1), rot_y=0.1, scale=(0.12, 0.12, 0.12))),
                     (rough_metal, trs((0.4, 0.2001, 1.3), rot_y=-0.5, scale=(0.2, 0.2, 0.2))), (mirror, trs((0.1, 0.1501, 0.75), rot_y=0.8, scale=(0.15, 0.15, 0.15)))):
         b.begin_mesh(); b.add_geometry(cp, ci, mat, uv=cuv, normal=cn, tangent=ct); m = b.end_mesh(); b.add_instance(m, xf)
+    if auto_mv is not None:
+        lo, hi = {"auto": (MF_PSDBlockMVsB0, MF_PSDBlockMVsB1), "off": (0, 0), "full": (MF_PSDBlockMVsB0 | MF_PSDBlockMVsB1,) * 2}[auto_mv]
+        mirror_lo = b.add_material(make_material(base=(0.92, 0.92, 0.85), roughness=0.0, metalness=1.0, flags=lo))
+        pane_hi = b.add_material(make_material(base=(0.95, 1.0, 0.95), roughness=0.0, transmission=1.0, thin=True, flags=hi | (1 << MF_PSDDominantDeltaLobeP1Shift)))
+        glass_lo = b.add_material(make_material(base=(0.9, 0.95, 1.0), roughness=0.0, transmission=1.0, thin=False, nested_priority=3, att_color=(0.8, 0.9, 1.0), att_dist=0.4,
+                                                flags=lo | (2 << MF_PSDDominantDeltaLobeP1Shift)))
+        for (pp, ii, uu, nn, tt), mat, xf in ((sphere_patch(1.0, 0.3, 10), mirror_lo, trs((0.0, 0.62, 1.6), rot_y=0.15)), (sphere_patch(8.0, 0.22, 14), pane_hi, trs((0.05, 0.42, 0.25), rot_y=-0.2))):
+            b.begin_mesh(); b.add_geometry(pp, ii, mat, uv=uu, normal=nn, tangent=tt); m = b.end_mesh(); b.add_instance(m, xf)
+        sp, si = icosphere_mesh(2)
+        b.begin_mesh(); b.add_geometry(sp, si.reshape(-1), glass_lo, normal=sp); m = b.end_mesh(); b.add_instance(m, trs((0.55, 0.2, 0.9), scale=(0.12, 0.12, 0.12)))
     b.set_environment(sky_equirect(256, 128), color_multiplier=(1, 1, 1))
     cam = dict(pos=(0.0, 0.55, -0.9), direction=(0.0, -0.1, 1.0), up=(0, 1, 0), fov_y=math.radians(55.0), near_z=0.01, far_z=100.0, focal_distance=1.0)
     return b.finish(), cam

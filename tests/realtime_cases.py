@@ -20,6 +20,8 @@ def cases():
         "bistro_like_realtime": (bl, d(NEEType=2), 96, 54, 4, 1, (0.35, 0.02, -0.2), {}),                                  # the reference's defaults, one sub-sample
         "bistro_like_realtime_lp16_2sub": (bl, d(NEEType=2, useFp16Types=1), 64, 36, 3, 2, (0.6, 0.0, 0.25), {}),          # binary16 lp types, two sub-samples feeding one reservoir plane
         "zoo_realtime": (scenes.stable_planes_zoo, _zoo_settings(), 64, 48, 3, 1, (0.03, 0.01, 0.02), {}),      # delta trees (mirror, glass): the dominant plane's depth and motion
+        # the automatic motion-vector block types (AutoLow / AutoHigh, PathTracerBridgeDonut.hlsli:704-716) on curved mirrors and panes: where the planes stop following the delta path
+        "zoo_auto_mv_realtime": (lambda: scenes.stable_planes_zoo("auto"), _zoo_settings(), 64, 48, 3, 1, (0.03, 0.01, 0.02), {}),
         # the scene moves as well (C5's: rigid props, a deforming mesh, nested-dielectric props, emissive triangles that are re-baked every frame): object motion in the motion vectors
         # (Bridge::loadSurface's prevPosW), so the baker's Reproject follows the objects; "anim_dt" is the scene time per frame (popped before the keywords reach stable_planes_params)
         "bistro_like_c5_realtime_animated": (lambda: scenes.bistro_like(scale=0.01, tex_size=64, animated=True), d(NEEType=2, nestedDielectricsQuality=2), 96, 54, 3, 1, (0.2, 0.0, -0.1), {"anim_dt": 0.45}),

@@ -8,15 +8,18 @@ KEYS = ("header", "planes", "stable_radiance", "depth", "spec_hit_t", "motion_ve
 
 
 def cases():
-    """name -> (lp16, settings overrides, stable_planes_params keywords)"""
+    """name -> (lp16, settings overrides, stable_planes_params keywords[, scenes.stable_planes_zoo's auto_mv])"""
     return {"zoo_fp32": (False, {}, {}), "zoo_lp16": (True, {}, {}), "zoo_two_planes_no_psr": (False, {}, dict(active_planes=2, allow_psr=False)),
-            "zoo_one_plane_depth4": (False, {}, dict(active_planes=1, max_vertex_depth=4))}
+            "zoo_one_plane_depth4": (False, {}, dict(active_planes=1, max_vertex_depth=4)),
+            # the automatic motion-vector block types of Bridge::loadSurface (AutoLow / AutoHigh, PathTracerBridgeDonut.hlsli:92-149, 704-716): curved surfaces whose pixel curvature
+            # straddles the per-(pixel, vertex, sample) jittered thresholds
+            "zoo_auto_mv": (False, {}, {}, "auto"), "zoo_auto_mv_lp16": (True, {}, {}, "auto")}
 
 
 def setup(name):
     """(scene, bridge camera, settings, params) of a case: the camera moved a little since the last frame, so the motion vectors are not zero"""
-    lp16, over, kw = cases()[name]
-    sc, cam = scenes.stable_planes_zoo()
+    lp16, over, kw = cases()[name][:3]
+    sc, cam = scenes.stable_planes_zoo(*cases()[name][3:])
     S = scenes.config_settings("C2")
     for k, v in over.items(): S[k] = v
     if lp16: S["useFp16Types"] = 1
