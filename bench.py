@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 # algorithmic bytes: extend ray 52 B fixed + BVH: 128 B per BVH8 node visit + 48 B per triangle test
 B_EXTEND_FIXED, B_NODE, B_TRI, B_SHADE, B_SHADOW_FIXED = 52.0, 128.0, 48.0, 656.0, 80.0
-COUNTERS_FILE = "r04z_counters.json"     # rocprofv3 --pmc summary of this workload (tools/profile_round.sh), quoted in roofline{}
+COUNTERS_FILE = "r05z_counters.json"     # rocprofv3 --pmc summary of this workload (tools/profile_round.sh), quoted in roofline{} — only if it was collected on the kernels that run here (kernel_source_sha256)
 
 
 def main():
@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--no-env-compression", action="store_true", help="sample the uncompressed RGBA16F environment cube (the reference on Vulkan) instead of the BC6H one (its D3D12 default)")
     ap.add_argument("--skip-roofline-steps", action="store_true", help="profiling runs (tools/profile_round.sh): only the timed steps, no extra serial / counter steps")
     ap.add_argument("--serial-kernels", action="store_true", help="run every step with PT_DEVICE_SERIAL_KERNELS semantics (for rocprofv3 kernel traces: launches never overlap)")
+    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
+                    help="N > 1: 'rccl' = one rank per GPU, the frame gather is pt_gather over RCCL (the measurement). 'host' = REHEARSAL of the multi-rank code path on fewer GPUs than "
+                         "ranks: the ranks share the visible devices (rank % device count), the process group is gloo, the tiles travel through pt_gather_host (the library's own gather "
+                         "protocol over a host transport) — every line of the N > 1 branch runs, the timing is not a scaling number and the JSON line says so")
     args = ap.parse_args()
 
     import torch
@@ -59,12 +63,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the library has no CPU path")
+    host_transport = world > 1 and args.transport == "host"
+    if host_transport:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if host_transport else "cuda"      # where the small reductions (flags, times, ray counts) live: gloo reduces host tensors
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if host_transport:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     sc, cam = scenes.bistro_like(scale=args.scale, tex_size=args.tex)
     sc["env_cube_dim"] = 2048                    # EnvMapBaker's cube resolution for an image source (EnvMapBaker.cpp:374-375)
@@ -81,7 +92,17 @@ def main():
     # tiles and says so in the JSON line (`config.gather`) — every rank takes the same branch.
     gather_mode = "none (1 GPU)"
     counts = send = None
-    if world > 1:
+    host_frame = None
+    if host_transport:
+        import ctypes
+        gather_mode = "REHEARSAL: pt_gather_host (the library's gather protocol: layout, packing, un-padded point-to-point transfers, unpacking) over a gloo transport; %d ranks on %d device(s)" % (world, torch.cuda.device_count())
+
+        def _send(ptr, nbytes, peer):
+            dist.send(torch.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=torch.uint8).clone(), dst=peer)
+
+        def _recv(ptr, nbytes, peer):
+            t = torch.empty(nbytes, dtype=torch.uint8); dist.recv(t, src=peer); ctypes.memmove(ptr, t.data_ptr(), nbytes)
+    elif world > 1:
         ok = 1
         try:
             idt = torch.tensor(list(pt.comm_unique_id()) if rank == 0 else [0] * pt.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
@@ -100,7 +121,11 @@ def main():
     def step():
         g.reset_accumulation()
         st = g.render(0, SPP)
-        if world > 1:
+        if host_transport:
+            nonlocal host_frame
+            host_frame = g.radiance()      # this rank's accumulation buffer (its own tiles are valid), then the library's gather towards rank 0 through the host
+            pt.gather_host(W, H, rank, world, host_frame, _send, _recv)
+        elif world > 1:
             if send is None:
                 g.gather()
             else:
@@ -125,7 +150,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     rays_local = float(sum(s["extendRays"] + s["shadowRays"] for s in stats))
-    tl = torch.tensor([elapsed, rays_local], dtype=torch.float64, device="cuda")
+    tl = torch.tensor([elapsed, rays_local], dtype=torch.float64, device=red_dev)
     if world > 1:
         tmax = tl[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rsum = tl[1:2].clone(); dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
@@ -168,8 +193,11 @@ def main():
     # workload (tools/profile_round.sh -> profiles/rNN_counters.json, rocprofv3 --pmc in separate passes) is quoted, null when the workload differs.
     traffic = hbm_counter_gbs = valu = l2 = None; counters_src = None; bound = "unknown (no counter summary for this workload)"
     cp = os.path.join(ROOT, "profiles", COUNTERS_FILE)
-    if os.path.exists(cp) and (W, H, SPP, args.scale, args.tex, world) == (3840, 2160, 4, 1.0, 1024, 1):
-        cj = json.load(open(cp))["groups"]["extend"]; counters_src = "profiles/" + COUNTERS_FILE + " (tools/profile_round.sh)"
+    digest = pt.kernel_source_digest()
+    if os.path.exists(cp) and (W, H, SPP, args.scale, args.tex, world) == (3840, 2160, 4, 1.0, 1024, 1) and json.load(open(cp)).get("kernel_source_sha256") != digest:
+        bound = "unknown (profiles/%s was collected on other kernel sources than the ones this library was built from: re-run tools/profile_round.sh)" % COUNTERS_FILE
+    elif os.path.exists(cp) and (W, H, SPP, args.scale, args.tex, world) == (3840, 2160, 4, 1.0, 1024, 1):
+        cj = json.load(open(cp))["groups"]["extend"]; counters_src = "profiles/" + COUNTERS_FILE + " (tools/profile_round.sh; kernel_source_sha256 matches the kernels of this run)"
         traffic = cj["hbm_bytes_per_launch"]; hbm_counter_gbs = cj["hbm_counter_gbs"]; l2 = cj["l2_hit_rate"]
         valu = {"busy": cj["valu_busy"], "lane_utilisation": cj["lane_utilisation"], "valu_instructions_per_vmem_read": cj["valu_per_vmem_read"],
                 "wait_any_share_of_wave_cycles": cj["wait_any_share_of_wave_cycles"]}
@@ -190,7 +218,8 @@ def main():
                                    % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP, "fp32" if args.fp32_lp_types else "binary16 (reference default)",
                                       "RGBA16F" if args.no_env_compression else "2048 BC6H (reference default on D3D12)", bvh["builderName"], bvh["builtOn"], bvh["buildMs"], bvh["hostMs"], bvh["numWideNodes"]),
                        "bvh": bvh,
-                       "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "rays_per_step": rays_total / args.steps,
+                       "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "transport": args.transport if world > 1 else "none",
+                       "rehearsal": bool(host_transport), "kernel_source_sha256": digest, "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP,
                        "tail_kernel_launches_per_step": sum(s["tailLaunches"] for s in stats) / args.steps},
             # `frac` is the prescribed figure: algorithmic bytes / launch time / 8 TB/s. `bound` is what the counters say limits the kernel:
@@ -257,6 +286,16 @@ def main():
                     "differing_pixels_in_kept_rows": int((rows.view(np.uint32) != gold["rows"].view(np.uint32)).any(-1).sum()), "kept_rows": int(rows.shape[0]),
                     "ray_counts_equal": bool((int(st_ref["extendRays"]), int(st_ref["shadowRays"])) == tuple(int(v) for v in gold["rays"])),
                     "against": "the reference's integrator text (PathTracer.hlsli & co. compiled from the reference tree) rendering this frame: tests/golden/bench_frame_golden.npz"}
+            if world > 1 and default_workload and os.path.exists(gp):      # N > 1: the frame rank 0 holds after the last timed step's gather (all ranks' tiles), against the same digest
+                import hashlib
+                gold = np.load(gp)
+                frame = host_frame if host_transport else g.radiance()
+                rows = frame[::int(gold["row_step"][0])]
+                out.setdefault("parity", {})["reference_text_gathered_frame"] = {
+                    "frame_sha256_equal": bool(np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(frame, np.float32).tobytes()).digest(), np.uint8), gold["sha256"])),
+                    "differing_pixels_in_kept_rows": int((rows.view(np.uint32) != gold["rows"].view(np.uint32)).any(-1).sum()), "kept_rows": int(rows.shape[0]),
+                    "ray_counts_equal": bool(int(round(rays_total / args.steps)) == int(gold["rays"][0]) + int(gold["rays"][1])),
+                    "against": "tests/golden/bench_frame_golden.npz (the reference's integrator text rendering this frame), the %d ranks' tiles as gathered on rank 0" % world}
         except Exception as e:      # noqa: BLE001
             out.setdefault("parity", {})["reference_text"] = {"error": str(e)[:300]}
         print(json.dumps(out))

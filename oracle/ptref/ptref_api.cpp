@@ -64,24 +64,23 @@ void finalize_geometry(Scene& sc) {
                 float3 p0 = xform_point(M, sc.positions[gd.vertexOffset + idx[0]]);
                 float3 p1 = xform_point(M, sc.positions[gd.vertexOffset + idx[1]]);
                 float3 p2 = xform_point(M, sc.positions[gd.vertexOffset + idx[2]]);
-                Triangle tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.subInstance = subInst; tr.triIndex = t; tr.flags = triFlags; tr.pad = 0.f;
+                Triangle tr; tr.v0 = p0; tr.v1 = p1; tr.v2 = p2; tr.subInstance = subInst; tr.triIndex = t; tr.flags = triFlags; tr.pad = 0.f;
                 sc.tris.push_back(tr);
             }
         }
         running += m.numGeometries;
     }
-    // the triangles' own padded boxes (scene.h tri_box_accepts): pad from the scene bounds, over the vertices the intersection test reconstructs
+    // the triangles' own padded boxes (scene.h tri_box_accepts): pad from the scene bounds
     float3 smn = make_float3(3.0e38f), smx = make_float3(-3.0e38f);
-    for (const Triangle& t : sc.tris) { float3 q1 = t.v0 + t.e1, q2 = t.v0 + t.e2; smn = min3v(smn, min3v(t.v0, min3v(q1, q2))); smx = max3v(smx, max3v(t.v0, max3v(q1, q2))); }
+    for (const Triangle& t : sc.tris) { smn = min3v(smn, min3v(t.v0, min3v(t.v1, t.v2))); smx = max3v(smx, max3v(t.v0, max3v(t.v1, t.v2))); }
     const float scenePad = sc.tris.empty() ? 0.f : scene_pad(smn, smx);
-    for (Triangle& t : sc.tris) { float3 q1 = t.v0 + t.e1, q2 = t.v0 + t.e2; t.pad = tri_pad(min3v(t.v0, min3v(q1, q2)), max3v(t.v0, max3v(q1, q2)), scenePad); }
+    for (Triangle& t : sc.tris) t.pad = tri_pad(min3v(t.v0, min3v(t.v1, t.v2)), max3v(t.v0, max3v(t.v1, t.v2)), scenePad);
 }
 
 // ---- binned SAH BVH2
 struct BuildPrim { float3 bmin, bmax, c; };
 static void tri_bounds(const Triangle& t, float3& mn, float3& mx) {      // the PADDED box of the hit definition: every node box contains it
-    float3 p1 = t.v0 + t.e1, p2 = t.v0 + t.e2;
-    mn = min3v(t.v0, min3v(p1, p2)) - make_float3(t.pad); mx = max3v(t.v0, max3v(p1, p2)) + make_float3(t.pad);
+    mn = min3v(t.v0, min3v(t.v1, t.v2)) - make_float3(t.pad); mx = max3v(t.v0, max3v(t.v1, t.v2)) + make_float3(t.pad);
 }
 static float half_area(float3 mn, float3 mx) { float3 e = mx - mn; return e.x * e.y + e.y * e.z + e.z * e.x; }
 static void subdivide(Scene& sc, std::vector<BuildPrim>& prims, uint nodeIdx, uint first, uint count) {

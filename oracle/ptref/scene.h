@@ -164,7 +164,7 @@ struct EnvMap {
 };
 
 // ---- the scene
-struct Triangle { float3 v0, e1, e2; uint subInstance, triIndex, flags; float pad; };   // world space; flags bit0 = non-opaque (alpha tested), bit1 = exclude from NEE; pad: tri_box_accepts
+struct Triangle { float3 v0, v1, v2; uint subInstance, triIndex, flags; float pad; };   // world-space vertices (shared vertices of a mesh are the same floats in every triangle that uses them); flags bit0 = non-opaque (alpha tested), bit1 = exclude from NEE; pad: tri_box_accepts
 struct Scene {
     std::vector<uint> indices; std::vector<float3> positions; std::vector<float2> uvs; std::vector<uint> normals, tangents;
     std::vector<GeometryDesc> geometries; std::vector<MeshDesc> meshes; std::vector<InstanceDesc> instances;
@@ -200,46 +200,63 @@ struct Scene {
 static_assert(sizeof(SubInstanceData) == 32, "SubInstanceData must be 32 bytes");
 struct HitInfo { float t; uint prim; float u, v; };      // prim = global triangle index, 0xFFFFFFFF = miss
 
-// Moeller-Trumbore; both sides; accepts tmin < t < tmax. (u,v) are the DXR barycentrics of vertices 1 and 2.
-static inline bool intersect_tri_mt(const Triangle& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
-    // explicitly fused products: fmaf is exactly specified, so host and device agree bit for bit, and the test costs 9 mul + 18 fma + 1 division
-    float3 pvec = make_float3(fmaf(d.y, tr.e2.z, -(d.z * tr.e2.y)), fmaf(d.z, tr.e2.x, -(d.x * tr.e2.z)), fmaf(d.x, tr.e2.y, -(d.y * tr.e2.x)));
-    float det = fmaf(tr.e1.z, pvec.z, fmaf(tr.e1.y, pvec.y, tr.e1.x * pvec.x));
-    if (det == 0.0f) return false;
-    float inv = 1.0f / det;
-    float3 tvec = o - tr.v0;
-    u = fmaf(tvec.z, pvec.z, fmaf(tvec.y, pvec.y, tvec.x * pvec.x)) * inv;
-    if (u < 0.0f || u > 1.0f) return false;
-    float3 qvec = make_float3(fmaf(tvec.y, tr.e1.z, -(tvec.z * tr.e1.y)), fmaf(tvec.z, tr.e1.x, -(tvec.x * tr.e1.z)), fmaf(tvec.x, tr.e1.y, -(tvec.y * tr.e1.x)));
-    v = fmaf(d.z, qvec.z, fmaf(d.y, qvec.y, d.x * qvec.x)) * inv;
-    if (v < 0.0f || u + v > 1.0f) return false;
-    t = fmaf(tr.e2.z, qvec.z, fmaf(tr.e2.y, qvec.y, tr.e2.x * qvec.x)) * inv;
-    return (t > tmin) && (t < tmax);
-}
-// The second half of the hit definition (see rtxpt_amd/csrc/pt_scene.h for the argument): fp32 Moeller-Trumbore reports hits outside badly
-// conditioned triangles (grazing rays, slivers), and whether a box above the triangle lets the ray through would then decide the closest hit. A hit
-// only counts if t lies in the slab interval of the triangle's own padded bounding box, computed as every box test above it computes its interval:
-// (plane - o) * inv, inv = ray_safe_rcp(d). Monotone rounding + nested boxes => no conservative BVH can cull an accepted hit.
-static inline float ray_safe_rcp(float d) {
+// ---- The hit definition, first half: a WATERTIGHT ray / triangle test (Woop, Benthin, Wald: "Watertight Ray/Triangle Intersection", JCGT 2013), both sides, tmin < t < tmax;
+// (u, v) = the DXR barycentrics of vertices 1 and 2. DXR promises that a ray cannot slip between two triangles that share an edge or a vertex (what Bridge::traceScatterRay /
+// traceVisibilityRay inherit from the API, PathTracerBridgeDonut.hlsli:993-1055). The vertices are translated to the ray origin and sheared into the ray's own frame (kz = the
+// axis of the largest |d|, kx / ky the next two in cyclic order): a vertex's 2D position then depends on the vertex and the ray only, never on the triangle it is tested for.
+// The three edge functions are formed WITHOUT fused products — a * b - c * d negates exactly when the edge is walked the other way, and round(p) - round(q) has the sign of
+// p - q whenever it is not zero — and a zero is resolved by the exact residuals of the two products (fmaf(a, b, -p) is the error of p, exactly): every triangle around an edge or
+// a vertex sees the same signs, a point on the boundary belongs to both sides, nothing falls between. Sz is the ray's correctly rounded reciprocal (ray_safe_rcp: the traversal
+// holds it anyway; kz is the dominant axis, so the clamp never acts). Same text on both sides of the parity fence (rtxpt_amd/csrc/pt_scene.h).
+static inline float ray_safe_rcp(float d) {                // correctly rounded 1/d with |d| clamped away from 0 (no inf, no NaN in the slab arithmetic)
     float a = fabsf(d);
     float s = (a < 7.888609e-31f) ? 7.888609e-31f : a;
     return 1.0f / ((d < 0.0f) ? -s : s);
 }
+static inline float wt_edge(float ax, float ay, float bx, float by) {      // the edge function ax * by - ay * bx with an exact sign
+    const float p = ax * by, q = ay * bx;
+    float e = p - q;
+    if (e == 0.0f) e = fmaf(ax, by, -p) - fmaf(ay, bx, -q);                // p == q: the difference of the two rounding errors IS the exact value
+    return e;
+}
+static inline bool intersect_tri_wt(float3 v0, float3 v1, float3 v2, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
+    const float adx = fabsf(d.x), ady = fabsf(d.y), adz = fabsf(d.z);
+    const int kz = (adz > adx && adz > ady) ? 2 : ((ady > adx) ? 1 : 0);      // ties go to the lower axis
+    const float3 A = v0 - o, B = v1 - o, C = v2 - o;
+    float Akx, Aky, Akz, Bkx, Bky, Bkz, Ckx, Cky, Ckz, dkx, dky, dkz;
+    if (kz == 2) { Akx = A.x; Aky = A.y; Akz = A.z; Bkx = B.x; Bky = B.y; Bkz = B.z; Ckx = C.x; Cky = C.y; Ckz = C.z; dkx = d.x; dky = d.y; dkz = d.z; }
+    else if (kz == 1) { Akx = A.z; Aky = A.x; Akz = A.y; Bkx = B.z; Bky = B.x; Bkz = B.y; Ckx = C.z; Cky = C.x; Ckz = C.y; dkx = d.z; dky = d.x; dkz = d.y; }
+    else { Akx = A.y; Aky = A.z; Akz = A.x; Bkx = B.y; Bky = B.z; Bkz = B.x; Ckx = C.y; Cky = C.z; Ckz = C.x; dkx = d.y; dky = d.z; dkz = d.x; }
+    const float Sz = ray_safe_rcp(dkz), Sx = dkx * Sz, Sy = dky * Sz;
+    const float Ax = fmaf(-Sx, Akz, Akx), Ay = fmaf(-Sy, Akz, Aky), Bx = fmaf(-Sx, Bkz, Bkx), By = fmaf(-Sy, Bkz, Bky), Cx = fmaf(-Sx, Ckz, Ckx), Cy = fmaf(-Sy, Ckz, Cky);
+    const float U = wt_edge(Cx, Cy, Bx, By), V = wt_edge(Ax, Ay, Cx, Cy), W = wt_edge(Bx, By, Ax, Ay);
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    const float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
+    const float T = fmaf(W, Cz, fmaf(V, Bz, U * Az));
+    const float inv = 1.0f / det;
+    t = T * inv; u = V * inv; v = W * inv;
+    return (t > tmin) && (t < tmax);
+}
+// The second half of the hit definition (see rtxpt_amd/csrc/pt_scene.h for the argument): whether a box above the triangle lets the ray through must not decide the closest
+// hit. A hit only counts if t lies in the slab interval of the triangle's own padded bounding box, computed as every box test above it computes its interval:
+// (plane - o) * inv, inv = ray_safe_rcp(d). Monotone rounding + nested boxes => no conservative BVH can cull an accepted hit. (The watertight test places t within a few
+// roundings of the triangle's plane, the pad is 10 - 100 x wider: the box never takes back what the first half found — tests/test_gpu_watertight.py counts escapes: 0.)
 static inline float tri_pad(float3 mn, float3 mx, float scenePad) {
     float3 e = mx - mn;
     return 2e-5f * fmaxf_(e.x, fmaxf_(e.y, e.z)) + scenePad;
 }
 static inline float scene_pad(float3 smn, float3 smx) { return 2e-6f * length(smx - smn); }
 static inline bool tri_box_accepts(const Triangle& tr, float3 o, float3 inv, float t) {
-    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
-    float3 mn = min3v(tr.v0, min3v(q1, q2)) - make_float3(tr.pad), mx = max3v(tr.v0, max3v(q1, q2)) + make_float3(tr.pad);
+    float3 mn = min3v(tr.v0, min3v(tr.v1, tr.v2)) - make_float3(tr.pad), mx = max3v(tr.v0, max3v(tr.v1, tr.v2)) + make_float3(tr.pad);
     float ax = (mn.x - o.x) * inv.x, bx = (mx.x - o.x) * inv.x, ay = (mn.y - o.y) * inv.y, by = (mx.y - o.y) * inv.y, az = (mn.z - o.z) * inv.z, bz = (mx.z - o.z) * inv.z;
     float tn = fmaxf_(fmaxf_(fminf_(ax, bx), fminf_(ay, by)), fminf_(az, bz));
     float tf = fminf_(fminf_(fmaxf_(ax, bx), fmaxf_(ay, by)), fmaxf_(az, bz));
     return (tn <= t) && (t <= tf);
 }
 static inline bool intersect_tri(const Triangle& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
-    if (!intersect_tri_mt(tr, o, d, tmin, tmax, t, u, v)) return false;
+    if (!intersect_tri_wt(tr.v0, tr.v1, tr.v2, o, d, tmin, tmax, t, u, v)) return false;
     return tri_box_accepts(tr, o, make_float3(ray_safe_rcp(d.x), ray_safe_rcp(d.y), ray_safe_rcp(d.z)), t);
 }
 
@@ -289,7 +306,7 @@ static void debug_report_miss(const Scene& sc, float3 o, float3 d, float tmax, u
                 (int)slab(n, o, id, wantT * 1.001f), (n.bmin.x - o.x) * id.x, (n.bmax.x - o.x) * id.x, (n.bmin.y - o.y) * id.y, (n.bmax.y - o.y) * id.y, (n.bmin.z - o.z) * id.z, (n.bmax.z - o.z) * id.z);
     }
     const Triangle& tr = sc.tris[wantPrim];
-    fprintf(stderr, "   tri v0 %.9g %.9g %.9g e1 %.9g %.9g %.9g e2 %.9g %.9g %.9g\n", tr.v0.x, tr.v0.y, tr.v0.z, tr.e1.x, tr.e1.y, tr.e1.z, tr.e2.x, tr.e2.y, tr.e2.z);
+    fprintf(stderr, "   tri v0 %.9g %.9g %.9g v1 %.9g %.9g %.9g v2 %.9g %.9g %.9g\n", tr.v0.x, tr.v0.y, tr.v0.z, tr.v1.x, tr.v1.y, tr.v1.z, tr.v2.x, tr.v2.y, tr.v2.z);
 }
 // closest hit (BridgeDonut:1029-1055 traceScatterRay): RAY_FLAG_NONE, alpha test on non-opaque candidates
 static inline HitInfo trace_closest(const Scene& sc, float3 o, float3 d, float tmin, float tmax, uint64_t* nodeVisits = 0, uint64_t* triTests = 0) {

@@ -273,6 +273,17 @@ def exchange_planes_host(width, height, rank, world, planes, send, recv, to_root
         raise PtError(r, "pt_exchange_planes_host")
 
 
+def kernel_source_digest():
+    """SHA-256 over the kernel sources of the library (rtxpt_amd/csrc/*.h and *.hip, names and contents, in name order): what ties a rocprofv3 counter summary under
+    profiles/ to the kernels a bench.py run executes (tools/profile_round.sh writes it, bench.py compares it before quoting `bound` / `traffic`)."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def load_library():
     """dlopen libmi355pt.so. Raises if it has not been built: the product path never falls back to anything else."""
     global _lib

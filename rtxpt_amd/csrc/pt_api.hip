@@ -136,7 +136,7 @@ struct pt_context {
     double buildMs = 0, refitMs = 0, lightBakeMs = 0;
     uint poolCapacity = 0; size_t shadowCapacity = 0;
     // stable planes (pt_build_stable_planes): the realtime mode's per-frame buffers (RenderTargets.cpp:60-141, 340-352) of the last pre-pass
-    DevBuf<uint> dSpHeader, dSpThroughput; DevBuf<ptk::StablePlane> dSpPlanes; DevBuf<ptk::uint2> dSpRadiance, dSpMotion; DevBuf<float> dSpDepth, dSpHitT; uint spW = 0, spH = 0; DevBuf<ptk::uint4> dSpMark; DevBuf<ptk::float4> dSpNewL; DevBuf<float> dSpScratch; DevBuf<uint> dSpGatherSend, dSpGatherRecv, dSpGatherPixels; bool spGathered = false;      // (the last two: scratch of the fill passes)
+    DevBuf<uint> dSpHeader, dSpThroughput; DevBuf<ptk::StablePlane> dSpPlanes; DevBuf<ptk::uint2> dSpRadiance, dSpMotion; DevBuf<float> dSpDepth, dSpHitT; uint spW = 0, spH = 0; DevBuf<ptk::uint4> dSpMark; DevBuf<ptk::float4> dSpNewL; DevBuf<float> dSpScratch; DevBuf<uint> dSpGatherSend, dSpGatherRecv, dSpGatherPixels; uint spGatherW = 0, spGatherH = 0; bool spGathered = false;      // (the last two: scratch of the fill passes)
     // frame gather (pt_comm_init / pt_gather)
     ncclComm_t comm = nullptr; uint commRank = 0, commWorld = 0; DevBuf<ptk::float4> dGatherSend, dGatherRecv; DevBuf<uint> dGatherPixels; std::vector<size_t> gatherCounts; uint gatherW = 0, gatherH = 0;
 };
@@ -190,7 +190,7 @@ void shard_pixel_lists(uint width, uint height, uint world, std::vector<std::vec
 void build_shards(pt_context* c) {
     shard_pixel_lists(c->width, c->height, c->shardCount, c->shardPixels);
     c->owned = c->shardPixels[c->shardRank];
-    c->gatherW = c->gatherH = 0;                // pt_gather's per-rank counts and pixel lists follow the shard lists, not only the frame size
+    c->gatherW = c->gatherH = 0; c->spGatherW = c->spGatherH = 0;                // pt_gather's (and the stable-plane guide exchange's) per-rank counts and pixel lists follow the shard lists, not only the frame size
 }
 
 // ---- RCCL, bound at run time. One process may already hold a librccl.so (PyTorch ships its own): RTLD_NOLOAD finds that copy first, so that a single
@@ -279,7 +279,7 @@ void refresh_scene_view(pt_context* c) {
     d.lights.DepthExport = (c->neeat.enabled && c->neeat.exportDepth && c->neeat.haveClip && c->neeat.W == c->width && c->neeat.H == c->height) ? c->neeat.depth.p : nullptr; d.lights.DepthWidth = c->width;
     memcpy(d.lights.ClipZ, c->neeat.clipZ, 16); memcpy(d.lights.ClipW, c->neeat.clipW, 16);
     d.lights.LocalToGlobalSampleRatio = c->localResX ? c->localRatio : 0.f; d.lights.ScreenSpaceVsWorldSpaceThreshold = c->sscThreshold; d.lights.TemporalFeedbackRequired = c->feedbackRequired ? 1u : 0u;
-    d.nodes = c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.alphaPlanes = c->dAlphaPlanes.p; d.alphaPool = c->dAlphaPool.p; d.shadeTris = c->dShadeTris.p; d.primToSlot = c->bvh.primToSlot; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
+    d.nodes = c->bvh.bvh2Stale ? nullptr : c->bvh.nodes; d.nodes8 = c->bvh.nodes8; d.tris = c->bvh.triSorted; d.alphaRecs = c->bvh.alphaRecs; d.alphaPlanes = c->dAlphaPlanes.p; d.alphaPool = c->dAlphaPool.p; d.shadeTris = c->dShadeTris.p; d.primToSlot = c->bvh.primToSlot; d.primInfo = c->dPrimInfo.p; d.numTris = c->numTris; d.rootIsValid = c->numTris ? 1u : 0u;
 }
 
 // SubInstanceData fill (Rtxpt/Materials/MaterialsBaker.cpp:960-1017) + primitive table; then GPU LBVH build
@@ -1068,6 +1068,8 @@ int32_t pt_animate_ranges(pt_context* c, const PtInstanceDesc* inst, uint32_t nI
     if (inst && nInst != c->instances.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: instance count must not change");
     if (positions && (size_t)nVerts * 3 != c->positions.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: vertex count must not change");
     if (positions && vertexRanges) for (uint32_t r = 0; r < nRanges; r++) if ((unsigned long long)vertexRanges[2 * r] + vertexRanges[2 * r + 1] > nVerts) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate_ranges: vertex range beyond the vertex count");
+    if (inst) for (uint32_t i = 0; i < nInst; i++) if (inst[i].meshIndex != c->instances[i].meshIndex) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: topology must not change");
+    // (every argument is validated by now: a rejected call must not advance the motion history — the next build pass would report zero object motion for what moved last frame)
     if (c->motionHistory) {      // one scene refresh: what is current becomes previous (before the uploads below overwrite it)
         int r = motion_history_sync(c); if (r != PT_OK) return r;
         if (positions) { if (vertexRanges) c->prevStaleRanges.assign(vertexRanges, vertexRanges + 2 * (size_t)nRanges); else c->prevAllStale = true; }
@@ -1077,15 +1079,11 @@ int32_t pt_animate_ranges(pt_context* c, const PtInstanceDesc* inst, uint32_t nI
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tA = now(); double tB = tA, tC = tA, tD = tA, tE = tA;
     if (inst) {
-        if (nInst != c->instances.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: instance count must not change");
-        for (uint32_t i = 0; i < nInst; i++) if (inst[i].meshIndex != c->instances[i].meshIndex) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: topology must not change");
         memcpy(c->instances.data(), inst, sizeof(InstanceDesc) * nInst);
         PT_CHECK_HIP(c, c->dInstances.upload(c->instances, c->stream));
     }
     if (positions) {
-        if ((size_t)nVerts * 3 != c->positions.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: vertex count must not change");
         if (vertexRanges) {
-            for (uint32_t r = 0; r < nRanges; r++) if ((unsigned long long)vertexRanges[2 * r] + vertexRanges[2 * r + 1] > nVerts) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate_ranges: vertex range beyond the vertex count");
             for (uint32_t r = 0; r < nRanges; r++) {
                 const size_t first = 3 * (size_t)vertexRanges[2 * r], count = 3 * (size_t)vertexRanges[2 * r + 1];
                 if (!count) continue;
@@ -1114,6 +1112,7 @@ int32_t pt_animate_ranges(pt_context* c, const PtInstanceDesc* inst, uint32_t nI
         if (c->bvh.builder == BVH_BUILDER_SAH || c->bvh.builder == BVH_BUILDER_PLOC_OPT) c->bvh.builder = BVH_BUILDER_PLOC;
         PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, c->stream));
     } else PT_CHECK_HIP(c, bvh_refit(c->bvh, c->dsc, c->numTris, c->stream));
+    c->dsc.nodes = c->bvh.bvh2Stale ? nullptr : c->bvh.nodes;      // (a fast refit leaves the BVH2 behind: nothing may read it until the next full build, pt_build.h bvh2Stale)
     PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
     tC = now();
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
@@ -1239,7 +1238,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;
         t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + PASS_COUNTERS * b;
-        t.aux.maxBlocks = (PT_T8_LANES == 2 && numBatches >= 3u) ? 256u * 7u : 0u;      // pipelined batches: one GPU-full of blocks each (pt_scene.h PT_T8_MAX_BLOCKS)
+        t.aux.maxBlocks = (numBatches >= 3u) ? 256u * 7u : 0u;      // pipelined batches: one GPU-full of blocks each (pt_scene.h PT_T8_MAX_BLOCKS)
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
         t.timed = c->serialKernels || c->countersEnabled || getenv("MI355PT_PASS_LOG") != nullptr;
         t.genPos = t.total < streamK ? t.total : streamK;
@@ -1259,7 +1258,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u));
     // the tail kernel takes over a batch once it holds at most this many paths (0: never). Not in serial-kernel / counter frames (their per-kernel attribution is the point), not with
     // grouped NEE samples (NEEFullSamples > 1 folds a vertex's samples in k_resolve_nee) and not without a tree (the traversal's empty-scene path is per launch, not per wave)
-    const uint tailBelow = (PT_T8_LANES == 2 && !c->serialKernels && !c->countersEnabled && !shadowGroup && c->dsc.rootIsValid) ? c->tailBelow : 0u;
+    const uint tailBelow = (!c->serialKernels && !c->countersEnabled && !shadowGroup && c->dsc.rootIsValid) ? c->tailBelow : 0u;
     // Lockstep or free-running batches. In lockstep (above) a batch's next half-pass is queued when ALL batches have delivered their counts: on the full frame that keeps one batch's
     // shading next to the others' traversal (free-running streams drift into running the same kernel at the same time: 7 % slower). A small frame — one rank of a
     // sharded frame — has passes of a few hundred microseconds whose lengths differ between the batches, and there the wait for the slowest batch is what a stream spends a fifth of
@@ -1363,6 +1362,9 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     for (uint b = 0; b < numBatches; b++) for (auto e : B[b].ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(frame0); (void)hipEventDestroy(frame1);
     if (overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
+    // The pass bound (maxIter) is a safety net, never what ends a path: a path ends by its own bounce / rejected-hit counters (PathTracer.hlsli:40-45, PathTracerNestedDielectrics.hlsli).
+    // Were a path still alive here, the set of dropped paths — the image — would depend on how the passes were composed (tail threshold, streaming): reported, not swallowed.
+    for (uint b = 0; b < numBatches; b++) if (B[b].active) return fail(c, PT_ERROR_HIP, "pt_render: paths still alive at the pass bound (bounceCount + 2 + the nested-dielectric allowance): the bound must be raised");
     return PT_OK;
 }
 static_assert(sizeof(::PtStablePlanesParams) == sizeof(ptk::StablePlanesParams) && sizeof(::PtStablePlane) == sizeof(ptk::StablePlane), "stable-plane ABI");
@@ -1469,7 +1471,7 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;
         t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + PASS_COUNTERS * b;
-        t.aux.maxBlocks = (PT_T8_LANES == 2 && numBatches >= 3u) ? 256u * 7u : 0u;
+        t.aux.maxBlocks = (numBatches >= 3u) ? 256u * 7u : 0u;
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + base; t.aux.resolveList = c->dResolveList.p + base; t.aux.primToSlot = c->bvh.primToSlot;
         memset(t.hwc, 0, sizeof(WaveCounters));
     }
@@ -1552,9 +1554,12 @@ static StablePlanesContext sp_buffers(pt_context* c) {
 static int sp_exchange_guides(pt_context* c) {
     if (c->shardCount == 1 || !c->comm) return PT_OK;
     hipStream_t s = c->stream;
-    std::vector<uint> others; for (uint r = 0; r < c->shardCount; r++) if (r != c->shardRank) others.insert(others.end(), c->shardPixels[r].begin(), c->shardPixels[r].end());
     const size_t n = c->owned.size(), W = SP_GUIDE_WORDS;
-    PT_CHECK_HIP(c, c->dSpGatherPixels.upload(others, s)); PT_CHECK_HIP(c, c->dSpGatherRecv.resize(others.size() * W)); PT_CHECK_HIP(c, c->dSpGatherSend.resize(n * W)); PT_CHECK_HIP(c, hipStreamSynchronize(s));
+    if (c->spGatherW != c->width || c->spGatherH != c->height) {      // the other ranks' pixel list and the staging buffers: once per frame size, not per realtime frame (the shard layout is a function of the size)
+        std::vector<uint> others; for (uint r = 0; r < c->shardCount; r++) if (r != c->shardRank) others.insert(others.end(), c->shardPixels[r].begin(), c->shardPixels[r].end());
+        PT_CHECK_HIP(c, c->dSpGatherPixels.upload(others, s)); PT_CHECK_HIP(c, c->dSpGatherRecv.resize(others.size() * W)); PT_CHECK_HIP(c, c->dSpGatherSend.resize(n * W)); PT_CHECK_HIP(c, hipStreamSynchronize(s));
+        c->spGatherW = c->width; c->spGatherH = c->height;
+    }
     const StablePlanesContext sp = sp_buffers(c);
     launch_sp_pack(sp, c->dOwned.p, (uint)n, c->dSpGatherSend.p, false, s, SP_GUIDE_FIRST, SP_GUIDE_WORDS);
     PT_CHECK_NCCL(c, g_rccl.GroupStart());

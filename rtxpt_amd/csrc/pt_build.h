@@ -52,7 +52,10 @@ struct BvhBuildBuffers {
     Bvh8Node* nodes8; uint* levelA; uint* levelB; uint* wideCounter; uint numNodes8, collapseLevels;
     TriSrc* triSrc;             // leaf order (refit)
     float4* wideBoxMin; float4* wideBoxMax;      // per wide node: the un-padded box of everything below it (refit: an inner child's box in its parent)
-    uint wideLevelStart[BVH_MAX_WIDE_LEVELS + 1]; uint wideRefitReady;      // wide nodes of collapse level L are [wideLevelStart[L], wideLevelStart[L + 1]): children always lie in a deeper level
+    uint wideLevelStart[BVH_MAX_WIDE_LEVELS + 1]; uint wideRefitReady;
+    bool bvh2Stale = false;      // set by the fast refit (k_refit_world + k_refit8_level): triWorld, the BVH2 `nodes` and the range tables still hold the pose of the last full build — anything that reads them
+                                 // (tools, a BVH2 probe, re-insertion) must rebuild first; the traversal reads triSorted / nodes8 only. pt_api.hip publishes dsc.nodes = null while this is set.
+         // wide nodes of collapse level L are [wideLevelStart[L], wideLevelStart[L + 1]): children always lie in a deeper level
     void* sortTemp; size_t sortTempBytes;
     // PLOC work arrays (node ids while building: leaves 0..n-1 in Morton order, inner nodes n..2n-2 in creation order)
     uint* plocCl[2]; uint* plocNN; unsigned long long* plocFlags; unsigned long long* plocOffs; uint* plocChildA; uint* plocChildB; uint* plocCnt; uint* plocParent; uint* plocFirst; uint* plocCounts;

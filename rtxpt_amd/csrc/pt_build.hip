@@ -56,11 +56,8 @@ __global__ void __launch_bounds__(256) k_tri_setup(DeviceScene sc, uint numTris,
         float3 p2 = xform_point(inst.transform, make_float3(P[3 * i2], P[3 * i2 + 1], P[3 * i2 + 2]));
         bool alphaTested = (si.FlagsAndAlphaInfo & SubInstanceData::Flags_AlphaTested) != 0;
         bool excl = (si.FlagsAndAlphaInfo & SubInstanceData::Flags_ExcludeFromNEE) != 0;
-        TriRecord tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.prim = p; tr.flags = (alphaTested ? 1u : 0u) | (excl ? 3u : 0u); tr.pad = 0.f;      // set once the scene bounds are known (k_leaf_boxes / k_bounds)
-        triWorld[p] = tr;
-        // bounds from the SAME vertices traversal reconstructs (v0, v0+e1, v0+e2)
-        float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
-        mn = min3v(p0, min3v(q1, q2)); mx = max3v(p0, max3v(q1, q2));
+        triWorld[p] = tri_record(p0, p1, p2, p, (alphaTested ? 1u : 0u) | (excl ? 3u : 0u), 0.f);      // (the pad is set once the scene bounds are known: k_leaf_boxes / k_bounds)
+        mn = min3v(p0, min3v(p1, p2)); mx = max3v(p0, max3v(p1, p2));
     }
     block_bounds(mn, mx, sceneBounds);
 }
@@ -86,10 +83,8 @@ __global__ void __launch_bounds__(1024) k_refit_world(DeviceScene sc, const TriS
         float3 p0 = xform_point(inst.transform, make_float3(P[3 * a.y], P[3 * a.y + 1], P[3 * a.y + 2]));
         float3 p1 = xform_point(inst.transform, make_float3(P[3 * a.z], P[3 * a.z + 1], P[3 * a.z + 2]));
         float3 p2 = xform_point(inst.transform, make_float3(P[3 * a.w], P[3 * a.w + 1], P[3 * a.w + 2]));
-        TriRecord tr; tr.v0 = p0; tr.e1 = p1 - p0; tr.e2 = p2 - p0; tr.prim = b.x; tr.flags = b.y; tr.pad = 0.f;
-        triSorted[i] = tr;
-        float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
-        mn = min3v(p0, min3v(q1, q2)); mx = max3v(p0, max3v(q1, q2));
+        triSorted[i] = tri_record(p0, p1, p2, b.x, b.y, 0.f);
+        mn = min3v(p0, min3v(p1, p2)); mx = max3v(p0, max3v(p1, p2));
     }
     block_bounds(mn, mx, sceneBounds);
 }
@@ -111,7 +106,7 @@ __global__ void __launch_bounds__(256) k_morton(const TriRecord* __restrict__ tr
     float3 mx = make_float3(dec_float(sceneBounds[3]), dec_float(sceneBounds[4]), dec_float(sceneBounds[5]));
     float3 ext = mx - mn;
     TriRecord tr = triWorld[p];
-    float3 c = tr.v0 + (tr.e1 + tr.e2) * (1.0f / 3.0f);
+    const float3 v0 = tri_v0(tr), c = v0 + ((tri_v1(tr) - v0) + (tri_v2(tr) - v0)) * (1.0f / 3.0f);
     float sx = ext.x > 0.f ? (c.x - mn.x) / ext.x : 0.f, sy = ext.y > 0.f ? (c.y - mn.y) / ext.y : 0.f, sz = ext.z > 0.f ? (c.z - mn.z) / ext.z : 0.f;
     uint qx = (uint)fminf(fmaxf(sx * 2097152.0f, 0.0f), 2097151.0f), qy = (uint)fminf(fmaxf(sy * 2097152.0f, 0.0f), 2097151.0f), qz = (uint)fminf(fmaxf(sz * 2097152.0f, 0.0f), 2097151.0f);
     keys[p] = (expand21(qx) << 2) | (expand21(qy) << 1) | expand21(qz);
@@ -163,8 +158,7 @@ __global__ void __launch_bounds__(256) k_bounds(const TriRecord* __restrict__ tr
     uint i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     TriRecord tr = triWorld[primsSorted[i]];
-    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
-    float3 mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+    float3 mn, mx; tri_bounds(tr, mn, mx);
     tr.pad = tri_pad(mn, mx, scene_pad_of(sceneBounds));
     triSorted[i] = tr;
     if (n == 1) { boxLmin[0] = make_float4(mn.x, mn.y, mn.z, 0.f); boxLmax[0] = make_float4(mx.x, mx.y, mx.z, 0.f); return; }
@@ -200,8 +194,7 @@ __global__ void __launch_bounds__(256) k_ploc_init(const TriRecord* __restrict__
     uint i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     TriRecord tr = triWorld[primsSorted[i]];
-    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
-    float3 mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+    float3 mn, mx; tri_bounds(tr, mn, mx);
     cbMin[i] = make_float4(mn.x, mn.y, mn.z, 0.f); cbMax[i] = make_float4(mx.x, mx.y, mx.z, 0.f);
     cl[i] = i; nodeCnt[i] = 1u;
 }
@@ -295,8 +288,7 @@ __global__ void __launch_bounds__(256) k_leaf_boxes(const TriRecord* __restrict_
     uint i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     TriRecord tr = triWorld[primsSorted[i]];
-    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
-    float3 mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+    float3 mn, mx; tri_bounds(tr, mn, mx);
     tr.pad = tri_pad(mn, mx, scene_pad_of(sceneBounds));      // the triangle's own padded box is the innermost box of the hit definition (pt_scene.h tri_box_accepts)
     triSorted[i] = tr;
     rmin[i] = make_float4(mn.x, mn.y, mn.z, 0.f); rmax[i] = make_float4(mx.x, mx.y, mx.z, 0.f);
@@ -408,7 +400,7 @@ __device__ __forceinline__ void bvh8_child_codes(float3 cmn, float3 cmx, float3 
     }
     q0 = ql[0] | (ql[1] << 8) | (ql[2] << 16) | (qh[0] << 24); q1 = qh[1] | (qh[2] << 8);
 }
-// child k goes to slot slotOf[k] (pt_scene.h PT_OCTANT_SLOTS: the slots are the traversal's visiting order); the other slots are empty
+// child k goes to slot slotOf[k]; the other slots are empty
 __device__ __forceinline__ void bvh8_pack(Bvh8Node& out, const float3* cmn, const float3* cmx, uint n, const uint* slotOf) {
     float3 mn = cmn[0], mx = cmx[0];
     for (uint k = 1; k < n; k++) { mn = min3v(mn, cmn[k]); mx = max3v(mx, cmx[k]); }
@@ -418,33 +410,6 @@ __device__ __forceinline__ void bvh8_pack(Bvh8Node& out, const float3* cmn, cons
     out._pad[0] = __float_as_uint(sx); out._pad[1] = __float_as_uint(sy); out._pad[2] = __float_as_uint(sz); out._pad[3] = 0;      // the scales again, as floats (traversal reads these; exps stays for tools)
     for (uint k = 0; k < 8u; k++) { out.c[k].ref = BVH_EMPTY; out.c[k].q0 = 0x00FFFFFFu; out.c[k].q1 = 0u; }     // inverted box
     for (uint k = 0; k < n; k++) bvh8_child_codes(cmn[k], cmx[k], mn, sx, sy, sz, out.c[slotOf[k]].q0, out.c[slotOf[k]].q1);
-}
-// Slots by octant (Ylitie, Karras & Laine 2017, section 3.2): the traversal visits the hit children of a node in the order of (slot XOR ray octant) instead of sorting them by entry
-// distance, so slot s should hold the child that lies furthest towards direction (s & 1 ? + : -, s & 2 ? + : -, s & 4 ? + : -) of the node's centre: a ray with an all-positive
-// direction (octant 0) then meets slot 0 first and slot 7 last, a ray of octant o meets slot o first. Greedy assignment on the 8 x n table of those projections (the paper runs
-// an auction; the order is a heuristic either way — the closest hit does not depend on it).
-__device__ __forceinline__ void bvh8_octant_slots(const float3* cmn, const float3* cmx, uint n, uint* slotOf) {
-#if PT_OCTANT_SLOTS
-    float3 mn = cmn[0], mx = cmx[0];
-    for (uint k = 1; k < n; k++) { mn = min3v(mn, cmn[k]); mx = max3v(mx, cmx[k]); }
-    const float3 nc = mn + mx;                                   // twice the centres throughout
-    uint freeSlots = 0xFFu, todo = (1u << n) - 1u;
-    for (uint round = 0; round < n; round++) {
-        float best = -3.0e38f; uint bk = 0u, bs = 0u;
-        for (uint k = 0; k < n; k++) {
-            if (!(todo & (1u << k))) continue;
-            const float3 v = cmn[k] + cmx[k] - nc;
-            for (uint sl = 0; sl < 8u; sl++) {
-                if (!(freeSlots & (1u << sl))) continue;
-                const float sc = ((sl & 1u) ? v.x : -v.x) + ((sl & 2u) ? v.y : -v.y) + ((sl & 4u) ? v.z : -v.z);
-                if (sc > best) { best = sc; bk = k; bs = sl; }
-            }
-        }
-        slotOf[bk] = bs; todo &= ~(1u << bk); freeSlots &= ~(1u << bs);
-    }
-#else
-    for (uint k = 0; k < n; k++) slotOf[k] = k;
-#endif
 }
 __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ nodes2, const uint* __restrict__ levelIn, uint nIn, uint* __restrict__ levelOut,
                                                    uint* __restrict__ counter, Bvh8Node* __restrict__ nodes8, uint costDriven) {
@@ -471,7 +436,7 @@ __global__ void __launch_bounds__(128) k_collapse8(const BvhNode* __restrict__ n
     for (uint k = 0; k < n; k++) if (!(cref[k] & BVH_LEAF_BIT)) nInner++;
     uint wbase = 0, obase = 0;
     if (nInner) { wbase = atomicAdd(&counter[0], nInner); obase = atomicAdd(&counter[1], nInner); }
-    uint slotOf[8]; bvh8_octant_slots(cmn, cmx, n, slotOf);
+    uint slotOf[8]; for (uint k = 0; k < n; k++) slotOf[k] = k;      // children in collapse order (slots by octant — Ylitie et al. 2017 — were measured in round 4 and lost: +25 % on k_extend, profiles/r04u_octant_order_ab.txt)
     Bvh8Node out; bvh8_pack(out, cmn, cmx, n, slotOf);
     uint inner = 0;
     for (uint k = 0; k < n; k++) {
@@ -500,9 +465,9 @@ __global__ void __launch_bounds__(256) k_refit8_level(uint first, uint count, Bv
             const uint slot0 = (r & 0x7FFFFFFFu) >> 3, cnt = (r & 7u) + 1u;
             for (uint j = 0; j < cnt; j++) {
                 const float4* tp = reinterpret_cast<const float4*>(tris + slot0 + j);
-                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                const float3 v0 = make_float3(ta.x, ta.y, ta.z), q1 = v0 + make_float3(tb.x, tb.y, tb.z), q2 = v0 + make_float3(tc.x, tc.y, tc.z);
-                const float3 tmn = min3v(v0, min3v(q1, q2)), tmx = max3v(v0, max3v(q1, q2));
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];      // x0 x1 x2 | y0 y1 y2 | z0 z1 z2 (pt_scene.h TriRecord)
+                const float3 tmn = make_float3(fminf_(ta.x, fminf_(ta.y, ta.z)), fminf_(tb.x, fminf_(tb.y, tb.z)), fminf_(tc.x, fminf_(tc.y, tc.z)));
+                const float3 tmx = make_float3(fmaxf_(ta.x, fmaxf_(ta.y, ta.z)), fmaxf_(tb.x, fmaxf_(tb.y, tb.z)), fmaxf_(tc.x, fmaxf_(tc.y, tc.z)));
                 tris[slot0 + j].pad = tri_pad(tmn, tmx, scenePad);      // the triangle's own padded box: innermost box of the hit definition (k_leaf_boxes)
                 mn = min3v(mn, tmn); mx = max3v(mx, tmx);
             }
@@ -774,7 +739,7 @@ __global__ void __launch_bounds__(256) k_ri_init(uint n, const uint* __restrict_
     if (x < n) {
         t.left[x] = RI_NONE; t.right[x] = RI_NONE;
         const TriRecord tr = triWorld[primsMorton[x]];
-        const float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2, mn = min3v(tr.v0, min3v(q1, q2)), mx = max3v(tr.v0, max3v(q1, q2));
+        float3 mn, mx; tri_bounds(tr, mn, mx);
         RiBox b; b.mn[0] = mn.x; b.mn[1] = mn.y; b.mn[2] = mn.z; b.mx[0] = mx.x; b.mx[1] = mx.y; b.mx[2] = mx.z; ri_store(t, x, b);
     } else { t.left[x] = childA[x - n]; t.right[x] = childB[x - n]; }
 }
@@ -897,9 +862,9 @@ static hipError_t bvh_sah(BvhBuildBuffers& b, uint n, hipStream_t st) try {
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<SahTri> st3(n);
     for (uint i = 0; i < n; i++) {
-        const TriRecord& t = tw[i]; const float3 q1 = t.v0 + t.e1, q2 = t.v0 + t.e2; SahTri& o = st3[i];
-        const float a[3] = {t.v0.x, t.v0.y, t.v0.z}, p[3] = {q1.x, q1.y, q1.z}, q[3] = {q2.x, q2.y, q2.z}, e1[3] = {t.e1.x, t.e1.y, t.e1.z}, e2[3] = {t.e2.x, t.e2.y, t.e2.z};
-        for (int k = 0; k < 3; k++) { o.mn[k] = fminf(a[k], fminf(p[k], q[k])); o.mx[k] = fmaxf(a[k], fmaxf(p[k], q[k])); o.c[k] = a[k] + (e1[k] + e2[k]) * (1.0f / 3.0f); }
+        const TriRecord& t = tw[i]; SahTri& o = st3[i];
+        const float* ax[3] = {t.x, t.y, t.z};
+        for (int k = 0; k < 3; k++) { const float* a = ax[k]; o.mn[k] = fminf(a[0], fminf(a[1], a[2])); o.mx[k] = fmaxf(a[0], fmaxf(a[1], a[2])); o.c[k] = a[0] + ((a[1] - a[0]) + (a[2] - a[0])) * (1.0f / 3.0f); }
     }
     std::vector<uint> order(n), cl(n), cr(n), rf(n), rl(n), par(n), lp(n), ab(n);
     b.optimiserPasses = bvh_sah_topology(st3.data(), n, SahTopology{order.data(), cl.data(), cr.data(), rf.data(), rl.data(), par.data(), lp.data(), ab.data()}, BVH_MAX_LEAF, 0u);
@@ -918,7 +883,7 @@ hipError_t bvh_build(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStrea
     uint g = (n + 255u) / 256u;
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, st, b.sceneBounds);
     hipLaunchKernelGGL(k_tri_setup, dim3(g), dim3(256), 0, st, sc, n, b.triWorld, b.sceneBounds);
-    b.hostBuildMs = 0.f; b.optimiserPasses = 0u; b.wideDpPending = 0u; b.wideFlagsValid = 0u;
+    b.hostBuildMs = 0.f; b.optimiserPasses = 0u; b.wideDpPending = 0u; b.wideFlagsValid = 0u; b.bvh2Stale = false;
     if (b.builder == BVH_BUILDER_SAH && n > 1) {
         if (bvh_sah(b, n, st) == hipSuccess) return bvh_bounds_and_emit(b, sc, n, st);
         (void)hipGetLastError(); b.builder = BVH_BUILDER_PLOC;      // no host memory / threads for the fast-trace topology: build it on the device instead
@@ -941,9 +906,11 @@ hipError_t bvh_refit(BvhBuildBuffers& b, const DeviceScene& sc, uint n, hipStrea
     if (b.wideRefitReady && !fullRefit) {
         hipLaunchKernelGGL(k_refit_world, dim3((n + 1023u) / 1024u), dim3(1024), 0, st, sc, b.triSrc, n, b.triSorted, b.sceneBounds);
         bvh_refit_levels(b, st);
+        b.bvh2Stale = true;      // only triSorted, nodes8 and the wide boxes follow the pose: triWorld, the BVH2 nodes and the range tables keep the last full build's (pt_build.h)
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_tri_setup, dim3(g), dim3(256), 0, st, sc, n, b.triWorld, b.sceneBounds);
+    b.bvh2Stale = false;
     return bvh_bounds_and_emit(b, sc, n, st);
 }
 

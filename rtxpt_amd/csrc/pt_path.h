@@ -695,15 +695,9 @@ template <bool LP16> struct PathKernelContextT {
         return false;
     }
     // PathTracer.hlsli:505-762 (reference mode), shadow test deferred through `req`
-    // PART (round 4, the split of k_shade at NEE — pt_wavefront.hip k_nee / k_shade<..., PART_SCATTER>): PART_ALL is the vertex as the reference writes it. PART_NEE stops after
-    // HandleNEE and leaves only `req` behind (it runs on a copy of the path, BEFORE the scatter kernel rewrites the pool's state): the surface, the nested-dielectric decision and
-    // the pre-scatter throughput are formed again rather than handed over — no hand-off record at all. PART_SCATTER is the vertex without the light sample: HandleNEE's two
-    // visible effects on the path — the MIS record and the position of the uniform sample stream the roulette reads next — are computed directly (the stream advances by
-    // 4 numbers per candidate: light index, two for the point on the light, the reservoir draw; PathTracerNEE.hlsli:88-161). MULTI == false, NEEAT == false only.
-    enum : int { PART_ALL = 0, PART_SCATTER = 1, PART_NEE = 2 };
-    template <bool MULTI, bool NEEAT, int PART = PART_ALL>
+    // (a split of this vertex at NEE — a light-sample kernel and a scatter kernel — was built and measured in round 4: 21.5 -> 27.5 ms, profiles/r04p_shade_split_ab.txt; history: af4c2b2)
+    template <bool MULTI, bool NEEAT>
     __attribute__((always_inline)) void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req, const ShadowSink* sink) const {
-        static_assert(PART == PART_ALL || (!MULTI && !NEEAT), "the split kernels exist for NEEFullSamples 1 without NEE-AT");
         req.valid = false;
         const float3 rayOrigin = path.origin, rayDir = path.dir;
         UpdatePathTravelled(path, hit.t);
@@ -716,7 +710,7 @@ template <bool LP16> struct PathKernelContextT {
         const ShadingData& sd = sfd.shadingData; const StandardBSDF& bsdf = sfd.bsdf;
         float3 surfaceEmission = make_float3(0.f);
         NEEBSDFMISInfo misInfo = NEEBSDFMISInfo::Unpack16bit(path.GetPackedMISInfo());
-        if (PART != PART_NEE && any_gt0(sd.emission)) {
+        if (any_gt0(sd.emission)) {
             float misWeight = 1.0f;
             float bsdfScatterPdf = path.GetBsdfScatterPdf();
             if (misInfo.LightSamplingEnabled && bsdfScatterPdf != 0) {
@@ -725,14 +719,14 @@ template <bool LP16> struct PathKernelContextT {
             }
             surfaceEmission = LP::r3(sd.emission * misWeight);
         }
-        if (PART != PART_NEE && sfd.neeAnalyticLightIndex != RTXPT_INVALID_LIGHT_INDEX) {                  // PathTracer.hlsli:636-648: the mesh stands in for an analytic (sphere) light
+        if (sfd.neeAnalyticLightIndex != RTXPT_INVALID_LIGHT_INDEX) {                  // PathTracer.hlsli:636-648: the mesh stands in for an analytic (sphere) light
             LightSampler lightSampler = LightSampler::make(sc.lights, path.id >> 16, path.id & 0xFFFFu, NEEAT && misInfo.LightSamplingIsSSC);
             const float bsdfPdf = misInfo.LightSamplingEnabled ? LP::r(path.GetBsdfScatterPdf()) : 0.0f; float3 add;
             if (lightSampler.ComputeAnalyticLightProxyContribution(sfd.neeAnalyticLightIndex, bsdfPdf, rayOrigin, rayDir, misInfo.CandidateSamples, misInfo.FullSamples, add)) {
                 add = LP::r3(add); surfaceEmission = make_float3(LP::add(surfaceEmission.x, add.x), LP::add(surfaceEmission.y, add.y), LP::add(surfaceEmission.z, add.z));
             }
         }
-        if (PART != PART_NEE && any_gt0(surfaceEmission)) {
+        if (any_gt0(surfaceEmission)) {
             const float baseFFThreshold = LP::r(S.fireflyFilterThreshold);
             if (baseFFThreshold != 0) surfaceEmission = FireflyFilter<LP>(surfaceEmission, baseFFThreshold, path.GetFireflyFilterK());
             if (any_gt0(surfaceEmission)) AccumulatePathRadiance(path, path.GetThp() * surfaceEmission);
@@ -746,21 +740,9 @@ template <bool LP16> struct PathKernelContextT {
         path.SetThp(path.GetThp() * make_float3(rr));
         SampleGeneratorVertexBase vb = SampleGeneratorVertexBase::make(path.id, path.getVertexIndex(), path.sampleIndex);
         UniformSampleSequenceGenerator uniformSG = UniformSampleSequenceGenerator::make(vb, SGES_Base);
-        if (PART == PART_NEE) { if (S.NEEEnabled) (void)HandleNEE<MULTI, NEEAT>(path, sd, bsdf, uniformSG, req, sink); return; }
         const PathState preScatterPath = path;
         bool scatterValid = GenerateScatterRay(sd, bsdf, path, vb);
-        uint misPacked;
-        if (PART == PART_SCATTER) {
-            misPacked = NEEBSDFMISInfo::empty().Pack16bit();
-            if (S.NEEEnabled) {
-                const LightSampler lightSampler = LightSampler::make(sc.lights, preScatterPath.id >> 16, preScatterPath.id & 0xFFFFu, false);
-                if ((bsdf.getLobes() & Lobe_NonDelta) != 0 && !lightSampler.IsEmpty()) {
-                    NEEBSDFMISInfo info; info.LightSamplingEnabled = true; info.LightSamplingIsSSC = lightSampler.IsScreenSpaceCoherent; info.CandidateSamples = S.NEECandidateSamples; info.FullSamples = 1u;
-                    misPacked = info.Pack16bit();
-                    for (uint i = 0; i < 4u * S.NEECandidateSamples; i++) (void)uniformSG.Next();
-                }
-            }
-        } else misPacked = S.NEEEnabled ? HandleNEE<MULTI, NEEAT>(preScatterPath, sd, bsdf, uniformSG, req, sink) : NEEBSDFMISInfo::empty().Pack16bit();
+        const uint misPacked = S.NEEEnabled ? HandleNEE<MULTI, NEEAT>(preScatterPath, sd, bsdf, uniformSG, req, sink) : NEEBSDFMISInfo::empty().Pack16bit();
         path.SetPackedMISInfo_ThpRuRuCorrection(misPacked, path.GetThpRuRuCorrection());
         if (!scatterValid) path.terminate();
         bool shouldTerminate = HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces));

@@ -3,7 +3,7 @@
 // HBM layout (all resident for the life of the scene; sized for 288 GB, nothing is streamed):
 //   vertex streams   indices u32 | positions float3 | uvs float2 | normals,tangents RGBA8_SNORM      (object space, as uploaded)
 //   GeometryDesc 32 B, InstanceDesc 64 B, SubInstanceData 32 B (Rtxpt/Shaders/SubInstanceData.h:23-46), PTMaterialData 128 B
-//   TriRecord 48 B   world-space v0/e1/e2 + global primitive id + flags, stored in BVH leaf order (one contiguous run per leaf)
+//   TriRecord 48 B   the three world-space vertices, one 16-byte group per AXIS (x0 x1 x2 | prim, y0 y1 y2 | flags, z0 z1 z2 | pad), in BVH leaf order (one contiguous run per leaf)
 //   BvhNode 64 B     BVH2 node holding BOTH child boxes (one 64 B fetch decides both children) + two child references
 //   primInfo 8 B     global primitive id -> (subInstance, triangle index)
 //   texel pool       RGBA32F texels of every mip of every texture (mips built on the host in float so that device == oracle)
@@ -51,22 +51,27 @@ struct MeshDesc { uint firstGeometry, numGeometries; };
 struct InstanceDesc { float3x4 transform; uint meshIndex; uint analyticProxyLight; uint _pad[2]; };      // analyticProxyLight: 0 = none, k + 1 = stands in for analytic light k (SubInstanceData.AnalyticProxyLightIndex)
 static_assert(sizeof(InstanceDesc) == 64, "InstanceDesc must be 64 bytes");
 
-struct TriRecord { float3 v0; uint prim; float3 e1; uint flags; float3 e2; float pad; };    // flags bit0 non-opaque, bit1 exclude from NEE; pad: see tri_box_accepts
+// One 16-byte group per axis: the watertight test (intersect_tri_wt) wants the vertices' coordinates in the ray's axis order (kx, ky, kz), and with this layout that permutation
+// is the ORDER OF THREE LOADS (group kx, group ky, group kz) instead of eighteen selects. Vertices are stored as such — a vertex shared by two triangles is the same three floats
+// in both records, which is what the test's edge decisions rest on (the round-4 record held v0, v1 - v0, v2 - v0).
+struct TriRecord { float x[3]; uint prim; float y[3]; uint flags; float z[3]; float pad; };    // flags bit0 non-opaque, bit1 exclude from NEE; pad: see tri_box_accepts
+static inline TriRecord tri_record(float3 p0, float3 p1, float3 p2, uint prim, uint flags, float pad) {
+    TriRecord t; t.x[0] = p0.x; t.x[1] = p1.x; t.x[2] = p2.x; t.prim = prim; t.y[0] = p0.y; t.y[1] = p1.y; t.y[2] = p2.y; t.flags = flags; t.z[0] = p0.z; t.z[1] = p1.z; t.z[2] = p2.z; t.pad = pad; return t;
+}
+static inline float3 tri_v0(const TriRecord& t) { return make_float3(t.x[0], t.y[0], t.z[0]); }
+static inline float3 tri_v1(const TriRecord& t) { return make_float3(t.x[1], t.y[1], t.z[1]); }
+static inline float3 tri_v2(const TriRecord& t) { return make_float3(t.x[2], t.y[2], t.z[2]); }
+static inline void tri_bounds(const TriRecord& t, float3& mn, float3& mx) {      // the unpadded box of the three vertices
+    mn = make_float3(fminf_(t.x[0], fminf_(t.x[1], t.x[2])), fminf_(t.y[0], fminf_(t.y[1], t.y[2])), fminf_(t.z[0], fminf_(t.z[1], t.z[2])));
+    mx = make_float3(fmaxf_(t.x[0], fmaxf_(t.x[1], t.x[2])), fmaxf_(t.y[0], fmaxf_(t.y[1], t.y[2])), fmaxf_(t.z[0], fmaxf_(t.z[1], t.z[2])));
+}
 static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
 struct BvhNode { float3 lmin, lmax, rmin, rmax; uint left, right, _pad0, _pad1; };           // child ref: bit31 = leaf (first<<3 | count-1)
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
-#ifndef PT_T8_LANES
-#define PT_T8_LANES 2             // lanes per ray in the traversal kernels: 2 (pt_traverse8p.h, the default since round 3) or 4 (pt_traverse8.h)
-#endif
+#define PT_T8_LANES 2             // lanes per ray in the traversal kernels (pt_traverse8p.h; the four-lane kernel of rounds 1-3 is in the history)
 #ifndef PT_BVH_MAX_LEAF
-#define PT_BVH_MAX_LEAF (PT_T8_LANES == 2 ? 2 : 4)      // triangles per leaf = lanes per ray: a leaf is tested in one round. With pairs, 2 instead of 4: k_extend 48.3 -> 43.6 ms, k_shadow 14.0 -> 12.2 ms
+#define PT_BVH_MAX_LEAF 2         // triangles per leaf = lanes per ray: a leaf is tested in one round. With pairs, 2 instead of 4: k_extend 48.3 -> 43.6 ms, k_shadow 14.0 -> 12.2 ms
 #endif                                                  // (1: 50.6 / 13.6 ms; 3: 46.1 / 13.3; 6: 51.9 / 15.3 — profiles/r03u_leafsize_ab*.txt)
-#ifndef PT_OCTANT_SLOTS
-#define PT_OCTANT_SLOTS 0       // 1: the builder places a wide node's children in slots by octant (pt_build.hip bvh8_octant_slots) and the traversal visits the hit children in the order of
-#endif                          //    (slot XOR ray octant) instead of ranking them by entry distance; 0: children in collapse order, 8-key ranking.
-                                //    Round 4 A/B (profiles/r04u_octant_order_ab.txt): 44 VALU instructions fewer in the inner block, but 17.3 instead of 15.0 node visits and 10.9 instead of
-                                //    7.8 triangle tests per extend ray on the bench scene (overlapping boxes of long thin quads: the centroid order is a poor stand-in for the entry distance):
-                                //    k_extend 44.1 -> 55.1 ms. Same frames either way (112 parity tests). Off.
 static const uint BVH_LEAF_BIT = 0x80000000u, BVH_EMPTY = 0xFFFFFFFFu, BVH_MAX_LEAF = PT_BVH_MAX_LEAF, BVH_STACK = 64;
 // BVH8 node, 128 B = one cache line: the 8 lanes of a ray's lane group each fetch one 12 B child slot plus the shared 16 B header, so a
 // whole node costs one line lookup per group instead of four 16 B gathers per lane. Child boxes are 8-bit quantised relative to the node
@@ -80,17 +85,17 @@ struct __attribute__((packed, aligned(4))) u32x3p { uint x, y, z; };   // 12-byt
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node must be 128 bytes");
 #ifndef PT_T8_CHUNK
-#define PT_T8_CHUNK (PT_T8_LANES == 2 ? 32 : 64)      // rays a wave parks in LDS per chunk fetch (<= 64: one per lane)
+#define PT_T8_CHUNK 32      // rays a wave parks in LDS per chunk fetch (one per lane pair)
 #endif
 #ifndef PT_BVH8_STACK
-#define PT_BVH8_STACK (PT_T8_LANES == 2 ? 13 : 16)         // (8 blocks of 256 threads per CU need <= 20 KB of LDS each: 17 x 8 B x 64 quads + the chunk parking lot; 12 entries: -0.6 %, 8: -6 %)
+#define PT_BVH8_STACK 13         // (7 blocks of 256 threads per CU: 14 x 8 B x 128 pairs + the chunk parking lot per block; 12 entries: -0.6 %, 8: -6 %)
 #endif
-// traversal launch geometry (pt_traverse8.h): 256-thread blocks, 4 lanes per ray -> 64 rays in flight per block, each with an LDS stack of
+// traversal launch geometry (pt_traverse8p.h): 256-thread blocks, 2 lanes per ray -> 128 rays in flight per block, each with an LDS stack of
 // BVH8_STACK entries (odd stride: quads land on different banks) and a T8_SPILL_DEPTH-entry tail in global memory (DeviceScene::travSpill)
 static const uint BVH8_STACK = PT_BVH8_STACK, BVH8_STACK_STRIDE = PT_BVH8_STACK + 1;
 static const uint T8_BLOCK = 256, T8_CHUNK = PT_T8_CHUNK, T8_LANES = PT_T8_LANES, T8_GROUPS_PER_WAVE = 64 / PT_T8_LANES, T8_GROUPS_PER_BLOCK = T8_BLOCK / T8_LANES, T8_SPILL_DEPTH = 96;
 #ifndef PT_T8_MAX_BLOCKS
-#define PT_T8_MAX_BLOCKS (PT_T8_LANES == 2 ? 256 * 7 * 3 : 256 * 6 * 4)  // upper bound of a traversal grid (sizes the stack-tail memory). Pairs: the GPU holds 256 x 7 blocks (LDS). A frame
+#define PT_T8_MAX_BLOCKS (256 * 7 * 3)  // upper bound of a traversal grid (sizes the stack-tail memory). The GPU holds 256 x 7 blocks (LDS). A frame
                                                                           // of several pipelined batches launches exactly that many per batch — 2x / 3x / 4x were 0.2 / 1.7 / 3.7 % slower on the full frame and
                                                                           // 4-7 % on one rank of an 8-way shard (profiles/r03w_maxblocks_ab.txt): the other batches fill the gaps —, a launch that has the GPU to
                                                                           // itself three times that: the blocks that finish early are replaced (TravAux::maxBlocks)
@@ -221,51 +226,70 @@ static inline float3 env_eval_local(const DeviceScene& sc, float3 localDir, floa
     return xyz(env_cube_sample_level(sc.envCube, localDir, lod)) * sc.envColorMultiplier;
 }
 
-// ---- ray / triangle (Moeller-Trumbore, both sides, tmin < t < tmax); (u,v) = DXR barycentrics of vertices 1,2
-static inline bool intersect_tri_mt(const TriRecord& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
-    // explicitly fused products: fmaf is exactly specified, so host and device agree bit for bit, and the test costs 9 mul + 18 fma + 1 division
-    float3 pvec = make_float3(fmaf(d.y, tr.e2.z, -(d.z * tr.e2.y)), fmaf(d.z, tr.e2.x, -(d.x * tr.e2.z)), fmaf(d.x, tr.e2.y, -(d.y * tr.e2.x)));
-    float det = fmaf(tr.e1.z, pvec.z, fmaf(tr.e1.y, pvec.y, tr.e1.x * pvec.x));
-    if (det == 0.0f) return false;
-    float inv = 1.0f / det;
-    float3 tvec = o - tr.v0;
-    u = fmaf(tvec.z, pvec.z, fmaf(tvec.y, pvec.y, tvec.x * pvec.x)) * inv;
-    if (u < 0.0f || u > 1.0f) return false;
-    float3 qvec = make_float3(fmaf(tvec.y, tr.e1.z, -(tvec.z * tr.e1.y)), fmaf(tvec.z, tr.e1.x, -(tvec.x * tr.e1.z)), fmaf(tvec.x, tr.e1.y, -(tvec.y * tr.e1.x)));
-    v = fmaf(d.z, qvec.z, fmaf(d.y, qvec.y, d.x * qvec.x)) * inv;
-    if (v < 0.0f || u + v > 1.0f) return false;
-    t = fmaf(tr.e2.z, qvec.z, fmaf(tr.e2.y, qvec.y, tr.e2.x * qvec.x)) * inv;
-    return (t > tmin) && (t < tmax);
-}
-// The second half of the hit definition. Moeller-Trumbore in fp32 reports hits OUTSIDE the triangle when it is badly conditioned (a grazing ray,
-// a 120 m x 0.3 mm sliver: up to decimetres outside), and a box test above the triangle then decides whether the "hit" exists: the closest hit
-// would depend on the BVH (found at 4K on C3: 8 pixels of 2 M where the oracle's BVH and the exhaustive loop disagree). So a hit only counts if it
-// lies inside the triangle's own padded bounding box AS THE RAY SEES IT: the slab interval [tn, tf] of that box, computed with exactly the
-// arithmetic every BVH node above it uses ((plane - o) * inv with inv = ray_safe_rcp(d), correctly rounded), must contain t. Rounding is monotone,
-// every ancestor box contains this box (pad grows with the extent, see tri_pad / pad_box), hence every ancestor's interval contains [tn, tf] and
-// therefore t: no conservative BVH over these boxes can cull an accepted hit, and the result equals the exhaustive loop bit for bit.
+// ---- The hit definition, first half: a WATERTIGHT ray / triangle test (Woop, Benthin, Wald: "Watertight Ray/Triangle Intersection", JCGT 2013), both sides, tmin < t < tmax;
+// (u, v) = the DXR barycentrics of vertices 1 and 2. DXR promises that a ray cannot slip between two triangles that share an edge or a vertex (what Bridge::traceScatterRay /
+// traceVisibilityRay inherit from the API, PathTracerBridgeDonut.hlsli:993-1055). The vertices are translated to the ray origin and sheared into the ray's own frame (kz = the
+// axis of the largest |d|, kx / ky the next two in cyclic order): a vertex's 2D position then depends on the vertex and the ray only, never on the triangle it is tested for.
+// The three edge functions are formed WITHOUT fused products — a * b - c * d negates exactly when the edge is walked the other way, and round(p) - round(q) has the sign of
+// p - q whenever it is not zero — and a zero is resolved by the exact residuals of the two products (fmaf(a, b, -p) is the error of p, exactly): every triangle around an edge or
+// a vertex sees the same signs, a point on the boundary belongs to both sides, nothing falls between. Sz is the ray's correctly rounded reciprocal (ray_safe_rcp: the traversal
+// holds it anyway; kz is the dominant axis, so the clamp never acts). Same text on both sides of the parity fence (the CPU restatement the tests check against holds it too); the traversal's leaf block (pt_traverse8p.h) performs the same operations on the same operands, with the axis
+// permutation done by the order of its loads.
 static inline float ray_safe_rcp(float d) {                // correctly rounded 1/d with |d| clamped away from 0 (no inf, no NaN in the slab arithmetic)
     float a = fabsf(d);
     float s = (a < 7.888609e-31f) ? 7.888609e-31f : a;
     return 1.0f / ((d < 0.0f) ? -s : s);
 }
-static inline float tri_pad(float3 mn, float3 mx, float scenePad) {      // the same expression pads every BVH node box (pt_build.hip pad_box)
+static inline float wt_edge(float ax, float ay, float bx, float by) {      // the edge function ax * by - ay * bx with an exact sign
+    const float p = ax * by, q = ay * bx;
+    float e = p - q;
+    if (e == 0.0f) e = fmaf(ax, by, -p) - fmaf(ay, bx, -q);                // p == q: the difference of the two rounding errors IS the exact value
+    return e;
+}
+static inline bool intersect_tri_wt(float3 v0, float3 v1, float3 v2, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
+    const float adx = fabsf(d.x), ady = fabsf(d.y), adz = fabsf(d.z);
+    const int kz = (adz > adx && adz > ady) ? 2 : ((ady > adx) ? 1 : 0);      // ties go to the lower axis
+    const float3 A = v0 - o, B = v1 - o, C = v2 - o;
+    float Akx, Aky, Akz, Bkx, Bky, Bkz, Ckx, Cky, Ckz, dkx, dky, dkz;
+    if (kz == 2) { Akx = A.x; Aky = A.y; Akz = A.z; Bkx = B.x; Bky = B.y; Bkz = B.z; Ckx = C.x; Cky = C.y; Ckz = C.z; dkx = d.x; dky = d.y; dkz = d.z; }
+    else if (kz == 1) { Akx = A.z; Aky = A.x; Akz = A.y; Bkx = B.z; Bky = B.x; Bkz = B.y; Ckx = C.z; Cky = C.x; Ckz = C.y; dkx = d.z; dky = d.x; dkz = d.y; }
+    else { Akx = A.y; Aky = A.z; Akz = A.x; Bkx = B.y; Bky = B.z; Bkz = B.x; Ckx = C.y; Cky = C.z; Ckz = C.x; dkx = d.y; dky = d.z; dkz = d.x; }
+    const float Sz = ray_safe_rcp(dkz), Sx = dkx * Sz, Sy = dky * Sz;
+    const float Ax = fmaf(-Sx, Akz, Akx), Ay = fmaf(-Sy, Akz, Aky), Bx = fmaf(-Sx, Bkz, Bkx), By = fmaf(-Sy, Bkz, Bky), Cx = fmaf(-Sx, Ckz, Ckx), Cy = fmaf(-Sy, Ckz, Cky);
+    const float U = wt_edge(Cx, Cy, Bx, By), V = wt_edge(Ax, Ay, Cx, Cy), W = wt_edge(Bx, By, Ax, Ay);
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    const float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
+    const float T = fmaf(W, Cz, fmaf(V, Bz, U * Az));
+    const float inv = 1.0f / det;
+    t = T * inv; u = V * inv; v = W * inv;
+    return (t > tmin) && (t < tmax);
+}
+// The second half of the hit definition. Whether a box above the triangle lets the ray through must not decide the closest hit (a 120 m x 0.3 mm sliver seen at a grazing angle
+// is found by the triangle test at a t that a conservative fp32 box test may or may not admit: found at 4K on C3 in round 1, 8 pixels of 2 M where two BVHs disagreed). So a hit
+// only counts if it lies inside the triangle's own padded bounding box AS THE RAY SEES IT: the slab interval [tn, tf] of that box, computed with exactly the arithmetic every BVH
+// node above it uses ((plane - o) * inv with inv = ray_safe_rcp(d), correctly rounded), must contain t. Rounding is monotone, every ancestor box contains this box (pad grows with
+// the extent, see tri_pad / pad_box), hence every ancestor's interval contains [tn, tf] and therefore t: no conservative BVH over these boxes can cull an accepted hit, and the
+// result equals the exhaustive loop bit for bit. (The watertight test places t within a few
+// roundings of the triangle's plane, the pad is 10 - 100 x wider: the box never takes back what the first half found — tests/test_gpu_watertight.py counts escapes: 0.)
+static inline float tri_pad(float3 mn, float3 mx, float scenePad) {
     float3 e = mx - mn;
     return 2e-5f * fmaxf_(e.x, fmaxf_(e.y, e.z)) + scenePad;
 }
 static inline float scene_pad(float3 smn, float3 smx) { return 2e-6f * length(smx - smn); }
 static inline bool tri_box_accepts(const TriRecord& tr, float3 o, float3 inv, float t) {
-    float3 q1 = tr.v0 + tr.e1, q2 = tr.v0 + tr.e2;
-    float3 mn = min3v(tr.v0, min3v(q1, q2)) - make_float3(tr.pad), mx = max3v(tr.v0, max3v(q1, q2)) + make_float3(tr.pad);
+    float3 mn, mx; tri_bounds(tr, mn, mx); mn = mn - make_float3(tr.pad); mx = mx + make_float3(tr.pad);
     float ax = (mn.x - o.x) * inv.x, bx = (mx.x - o.x) * inv.x, ay = (mn.y - o.y) * inv.y, by = (mx.y - o.y) * inv.y, az = (mn.z - o.z) * inv.z, bz = (mx.z - o.z) * inv.z;
     float tn = fmaxf_(fmaxf_(fminf_(ax, bx), fminf_(ay, by)), fminf_(az, bz));
     float tf = fminf_(fminf_(fmaxf_(ax, bx), fmaxf_(ay, by)), fmaxf_(az, bz));
     return (tn <= t) && (t <= tf);
 }
 static inline bool intersect_tri(const TriRecord& tr, float3 o, float3 d, float tmin, float tmax, float& t, float& u, float& v) {
-    if (!intersect_tri_mt(tr, o, d, tmin, tmax, t, u, v)) return false;
+    if (!intersect_tri_wt(tri_v0(tr), tri_v1(tr), tri_v2(tr), o, d, tmin, tmax, t, u, v)) return false;
     return tri_box_accepts(tr, o, make_float3(ray_safe_rcp(d.x), ray_safe_rcp(d.y), ray_safe_rcp(d.z)), t);
 }
+
 // AlphaTestImpl (BridgeDonut:929-971)
 static inline bool alpha_test(const DeviceScene& sc, uint prim, float u, float v) {
     uint2 pi = sc.primInfo[prim];

@@ -21,8 +21,6 @@
 #include "pt_traverse8p.h"
 #include "pt_wavefront_device.h"
 
-#if PT_T8_LANES == 2
-
 namespace ptk {
 
 #ifndef T8_TAIL_DEFER
@@ -162,6 +160,3 @@ void launch_tail(const PathKernelContext& k, PathPool pool, const uint* queueIn,
 }
 
 } // namespace ptk
-#else
-namespace ptk { void launch_tail(const PathKernelContext&, PathPool, const uint*, const uint*, uint, uint*, uint*, ShadowQueue, WaveCounters*, uint, uint, uint, hipStream_t) {} }      // (the four-lane build has no tail kernel: pt_render never asks for it)
-#endif

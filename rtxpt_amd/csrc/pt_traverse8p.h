@@ -1,5 +1,5 @@
 // mi355pt — cooperative BVH8 traversal for wave64, two lanes per ray: a wave carries 32 rays, each owned by a PAIR of lanes; lane h of a pair tests
-// children 4h .. 4h + 3 of the current 128-byte node (48 contiguous bytes: three 16-byte loads) and triangles h, h + 2 of a leaf.
+// children 4h .. 4h + 3 of the current 128-byte node (48 contiguous bytes: three 16-byte loads) and triangle h of a leaf.
 //
 // Why pairs (round 3): with four lanes per ray (pt_traverse8.h) the loop is VALU-issue bound at 8 waves per SIMD — extra v_nop slots lengthen k_extend one
 // for one (profiles/r03i_valu_bound_probe.txt) — and a wave64 VALU instruction costs its four cycles whatever the lanes do. Of the ~325 VALU instructions of an
@@ -26,29 +26,8 @@ __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { retur
 #else
 #define T8_HIT(ref, tn, tf) ((tn) <= (tf) * 1.0000012f)
 #endif
-#ifndef T8_POP2
-#define T8_POP2 0
-#endif
-// A dense leaf block was built and measured in round 4 (commit "Dense leaf block ...", profiles/r04y_dense_leaf_ab.txt): the triangles of ALL postponed leaves of the wave numbered by a
-// prefix sum and handed to the 64 lanes in that order, the owning ray read through ds_bpermute, every pair collecting the best of its items. Bit-exact — and k_extend 43.6 -> 49.5 ms
-// (6 waves per SIMD, no spills; 56.7 ms at 7 waves with 24 bytes of scratch): the block is dearer (190 instead of 150 instructions) and hardly rarer (0.55 instead of 0.65 per
-// iteration), because what forces it is not the batch size but the 1.7 rays per iteration that have nothing left but a leaf — they cannot be replaced before it is tested.
-#ifndef T8_REFILL_BATCH
-#define T8_REFILL_BATCH 1u   // idle pairs that must have gathered before the refill block runs. Round 4 A/B (profiles/r04y_refill_batch_ab.txt): 1 / 2 / 4 / 8 = k_extend 43.2 / 43.2 / 43.4 / 44.7 ms —
-#endif                       // what the rarer refill saves, the waiting pairs cost. 1.
-#ifndef T8_POP_ONCE
-#define T8_POP_ONCE 0        // 1: one pop trip (two entries) per wave iteration instead of a loop until a live entry is found. Round 4 A/B (profiles/r04v_pop_once_ab.txt): pop trips
-#endif                       //    per iteration 3.14 -> 0.97, wave iterations per ray 0.58 -> 0.61, k_extend 43.7 -> 43.2 ms (within noise): the pop loop is not where the phase's time goes. Off.
-// kOctBelow[2 * octant + h]: byte k = the slots that are visited BEFORE slot 4h + k by a ray of that octant, i.e. { s : (s ^ octant) < ((4h + k) ^ octant) }
-static __device__ const uint kOctBelow[16] = {
-#define OB1(o, s) ((((0 ^ (o)) < ((s) ^ (o))) ? 1u : 0u) | (((1 ^ (o)) < ((s) ^ (o))) ? 2u : 0u) | (((2 ^ (o)) < ((s) ^ (o))) ? 4u : 0u) | (((3 ^ (o)) < ((s) ^ (o))) ? 8u : 0u) | \
-                   (((4 ^ (o)) < ((s) ^ (o))) ? 16u : 0u) | (((5 ^ (o)) < ((s) ^ (o))) ? 32u : 0u) | (((6 ^ (o)) < ((s) ^ (o))) ? 64u : 0u) | (((7 ^ (o)) < ((s) ^ (o))) ? 128u : 0u))
-#define OB4(o, h) (OB1(o, 4 * (h)) | (OB1(o, 4 * (h) + 1) << 8) | (OB1(o, 4 * (h) + 2) << 16) | (OB1(o, 4 * (h) + 3) << 24))
-    OB4(0, 0), OB4(0, 1), OB4(1, 0), OB4(1, 1), OB4(2, 0), OB4(2, 1), OB4(3, 0), OB4(3, 1), OB4(4, 0), OB4(4, 1), OB4(5, 0), OB4(5, 1), OB4(6, 0), OB4(6, 1), OB4(7, 0), OB4(7, 1)
-#undef OB4
-#undef OB1
-};
-#if PT_T8_LANES == 2
+// Measured and removed (history: commit af4c2b2 has the code; numbers in DESIGN.md §4): a dense leaf block (profiles/r04y_dense_leaf_ab.txt, +13 %), batched refills
+// (r04y_refill_batch_ab.txt), one pop trip per iteration (r04v_pop_once_ab.txt), two entries per pop trip, octant-ordered child slots (r04u_octant_order_ab.txt, +25 %).
 // DEFER (with CAN_SPLIT): a dry wave keeps going for taskOut.capacity iterations (instead of T8_TAIL_ITERS), and the rays then still in flight are not cut into sub-trees,
 // only reported through publish() — the caller has them traced again elsewhere (the tail kernel, pt_tail.hip, hands their paths back to the host loop). No task queue is touched.
 template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, bool DEFER = false, class Src, class Dst, class Pub>
@@ -76,9 +55,10 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         for (uint i = lane; i < count; i += 64u) { float3 o, d; float a, b, bt; uint sr, bp; uint tag = fetch(i, o, d, a, b, sr, bt, bp); HitInfo hh; hh.t = b; hh.prim = 0xFFFFFFFFu; hh.u = hh.v = 0.f; commit(tag, hh); }
     }
     bool active = false;
-    float3 o = make_float3(0.f), d = make_float3(0.f);
+    float3 o = make_float3(0.f);
+    float Sx = 0.f, Sy = 0.f; uint axes = 0u;      // the ray's shear (d[kx] / d[kz], d[ky] / d[kz]) and the byte offsets of the record groups of its axes kx | ky << 8 | kz << 16 (leaf block)
     float ix = 0.f, iy = 0.f, iz = 0.f;
-    uint selN = 0u, selF = 0u, below4 = 0u;
+    uint selN = 0u, selF = 0u;
     float tmin = 0.f, tmax = FIXED_RANGE ? kMaxRayTravel : 0.f;
     float bestT = 0.f; uint bestPrim = 0xFFFFFFFFu;
     uint minePrim = 0xFFFFFFFFu;
@@ -87,8 +67,11 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
     float taskT0 = 0.f; uint taskPrim0 = 0xFFFFFFFFu;
     uint pend1 = BVH_EMPTY, pend2 = BVH_EMPTY;
 
-    auto stackStore = [&](uint idx, uint ref, uint tbits) {
-        if (idx < BVH8_STACK) stack[idx] = make_uint2(ref, tbits);
+    // sb: the pair's stack base. The caller forms it anew for every node that pushes (stack_base(): two instructions) instead of keeping it across the loop: the loop is one
+    // register short since the watertight leaf block, and the allocator's choice was to spill exactly this value — a scratch load and a full vmcnt(0) wait at every push.
+    auto stack_base = [&]() -> uint2* { uint g_ = threadIdx.x >> 1; asm volatile("" : "+v"(g_)); return stackBase + g_ * BVH8_STACK_STRIDE; };
+    auto stackStore = [&](uint2* sb, uint idx, uint ref, uint tbits) {
+        if (idx < BVH8_STACK) sb[idx] = make_uint2(ref, tbits);
         else {
             unsigned long long* tail = reinterpret_cast<unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (idx - BVH8_STACK)));
             __builtin_nontemporal_store(((unsigned long long)tbits << 32) | ref, tail);
@@ -102,9 +85,6 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         // ---- refill idle pairs from the wave's current chunk
         bool need = !active && !exhausted;
         unsigned long long needMask = t8_ballot(need && h == 0u);
-        // T8_REFILL_BATCH > 1: the refill block (an LDS gather and ~40 instructions for the whole wave, whoever needs it) runs when that many pairs are idle, or when nothing else
-        // would run this iteration — an idle pair waits a few iterations for company
-        if (T8_REFILL_BATCH > 1u && needMask && (uint)__popcll(needMask) < T8_REFILL_BATCH && t8_ballot(active) != 0ull) needMask = 0ull;
         if (needMask) {
             T8_EVENT(0, true);
             if (chunkPos >= chunkEnd) {
@@ -117,10 +97,17 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     uint rtag = fetch(chunkPos + lane, ro, rd, rtmin, rtmax, rstart, rbestT, rbestPrim);
                     uint* slot = rayBuf + lane * RAY_STRIDE;
                     slot[0] = __float_as_uint(ro.x); slot[1] = __float_as_uint(ro.y); slot[2] = __float_as_uint(ro.z);
-                    slot[3] = __float_as_uint(rd.x); slot[4] = __float_as_uint(rd.y); slot[5] = __float_as_uint(rd.z);
+                    // what the leaf block needs of the direction (intersect_tri_wt, pt_scene.h), formed once by the fetching lane: kz = the axis of the largest |d| (ties to the lower
+                    // axis), kx / ky the next two in cyclic order; Sz = the reciprocal of d[kz], Sx = d[kx] * Sz, Sy = d[ky] * Sz. The direction itself is not kept.
+                    const float rix = t8_rcp_dir(rd.x), riy = t8_rcp_dir(rd.y), riz = t8_rcp_dir(rd.z);
+                    const float adx = fabsf(rd.x), ady = fabsf(rd.y), adz = fabsf(rd.z);
+                    const bool rk2 = adz > adx && adz > ady, rk1 = !rk2 && ady > adx;
+                    const float rSz = rk2 ? riz : (rk1 ? riy : rix);
+                    slot[3] = __float_as_uint((rk2 ? rd.x : (rk1 ? rd.z : rd.y)) * rSz); slot[4] = __float_as_uint((rk2 ? rd.y : (rk1 ? rd.x : rd.z)) * rSz);
+                    slot[5] = rk2 ? (0u | (16u << 8) | (32u << 16)) : (rk1 ? (32u | (0u << 8) | (16u << 16)) : (16u | (32u << 8) | (0u << 16)));
                     slot[6] = rtag; slot[7] = __float_as_uint(TASKS ? rtmax : rtmin); slot[8] = TASKS ? __float_as_uint(rbestT) : __float_as_uint(rtmax);
                     if (TASKS) { slot[9] = rbestPrim; slot[10] = rstart; }
-                    if (T8_PARK_RCP) { slot[RAY_STRIDE - 3u] = __float_as_uint(t8_rcp_dir(rd.x)); slot[RAY_STRIDE - 2u] = __float_as_uint(t8_rcp_dir(rd.y)); slot[RAY_STRIDE - 1u] = __float_as_uint(t8_rcp_dir(rd.z)); }
+                    slot[RAY_STRIDE - 3u] = __float_as_uint(rix); slot[RAY_STRIDE - 2u] = __float_as_uint(riy); slot[RAY_STRIDE - 1u] = __float_as_uint(riz);
                 }
             }
             uint avail = chunkEnd - chunkPos;
@@ -131,19 +118,12 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 if (need && rank < avail) {
                     const uint* slot = rayBuf + (((chunkPos - chunk * rpc) + rank) * RAY_STRIDE);
                     o = make_float3(__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]));
-                    d = make_float3(__uint_as_float(slot[3]), __uint_as_float(slot[4]), __uint_as_float(slot[5]));
+                    Sx = __uint_as_float(slot[3]); Sy = __uint_as_float(slot[4]); axes = slot[5];
                     tag = slot[6];
-                    if (T8_PARK_RCP) { ix = __uint_as_float(slot[RAY_STRIDE - 3u]); iy = __uint_as_float(slot[RAY_STRIDE - 2u]); iz = __uint_as_float(slot[RAY_STRIDE - 1u]); }
-                    else {   // three correctly rounded divisions per ray: lane 0 does x, lane 1 does y, both do z
-                        const float mine = t8_rcp_dir(h == 0u ? d.x : d.y);
-                        ix = __uint_as_float((uint)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mine), DPP_PAIR_LO, 0xF, 0xF, true));
-                        iy = __uint_as_float((uint)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mine), DPP_PAIR_HI, 0xF, 0xF, true));
-                        iz = t8_rcp_dir(d.z);
-                    }
+                    ix = __uint_as_float(slot[RAY_STRIDE - 3u]); iy = __uint_as_float(slot[RAY_STRIDE - 2u]); iz = __uint_as_float(slot[RAY_STRIDE - 1u]);
                     {   // child bytes: q0 = lo.x lo.y lo.z hi.x (selector values 0..3), q1 = hi.y hi.z (4, 5)
                         const uint nxb = ix < 0.f ? 3u : 0u, fxb = ix < 0.f ? 0u : 3u, nyb = iy < 0.f ? 4u : 1u, fyb = iy < 0.f ? 1u : 4u, nzb = iz < 0.f ? 5u : 2u, fzb = iz < 0.f ? 2u : 5u;
                         selN = nxb | (nyb << 8) | (nzb << 16) | (fxb << 24); selF = fyb | (fzb << 8);
-                        if (PT_OCTANT_SLOTS) below4 = kOctBelow[((ix < 0.f ? 2u : 0u) | (iy < 0.f ? 4u : 0u) | (iz < 0.f ? 8u : 0u)) + h];
                     }
                     if (TASKS) {
                         if (!FIXED_RANGE) tmax = __uint_as_float(slot[7]);
@@ -175,7 +155,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         const bool inner = active && !(cur & BVH_LEAF_BIT);
         const bool leafReady = active && (pend != BVH_EMPTY);
         const bool queueFull = (T8_LEAF_QUEUE == 1) ? true : ((T8_LEAF_QUEUE == 2) ? (pend1 != BVH_EMPTY) : (pend2 != BVH_EMPTY));
-        const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT) && ((cur == BVH_EMPTY && (!T8_POP_ONCE || sp == 0u)) || queueFull);
+        const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT) && (cur == BVH_EMPTY || queueFull);
         const bool runLeaves = ((uint)__popcll(t8_ballot(leafReady && h == 0u)) >= (uint)T8_LEAF_BATCH) || (t8_ballot(leafBlocked) != 0ull);
         const bool leaf = leafReady && runLeaves;
         if (COUNT && leaf && h == 0u) ctr.leafVisits++;
@@ -205,13 +185,6 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
             // integer sort keys: tn >= 0 so its bits order like the value; the low 3 mantissa bits carry the child index (unique keys, ties to the lower child);
             // a child that is not hit gets +inf. The stack entry's distance is the key without its index bits.
             uint key[4]; bool hit[4];
-            if (PT_OCTANT_SLOTS) {      // no ranking keys: the slot order is the visiting order; the stack entry keeps the entry distance for the cull at pop time
-                float tn, tf;
-                slab(c0.y, c0.z, tn, tf); hit[0] = T8_HIT(ref[0], tn, tf); key[0] = __float_as_uint(tn);
-                slab(c1.x, c1.y, tn, tf); hit[1] = T8_HIT(ref[1], tn, tf); key[1] = __float_as_uint(tn);
-                slab(c1.w, c2.x, tn, tf); hit[2] = T8_HIT(ref[2], tn, tf); key[2] = __float_as_uint(tn);
-                slab(c2.z, c2.w, tn, tf); hit[3] = T8_HIT(ref[3], tn, tf); key[3] = __float_as_uint(tn);
-            } else
             {   float tn, tf;
                 slab(c0.y, c0.z, tn, tf); hit[0] = T8_HIT(ref[0], tn, tf); key[0] = (hit[0] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h);
                 slab(c1.x, c1.y, tn, tf); hit[1] = T8_HIT(ref[1], tn, tf); key[1] = (hit[1] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 1u);
@@ -219,16 +192,6 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 slab(c2.z, c2.w, tn, tf); hit[3] = T8_HIT(ref[3], tn, tf); key[3] = (hit[3] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h + 3u);
             }
             uint nhit, rank[4];
-            if (PT_OCTANT_SLOTS) {
-                // rank of a hit child = the hit children whose (slot ^ octant) is lower: one popcount per child against the ray's table of predecessors
-                const uint own = (hit[0] ? 1u : 0u) | (hit[1] ? 2u : 0u) | (hit[2] ? 4u : 0u) | (hit[3] ? 8u : 0u);
-                const uint oth = dpp_u<DPP_QP_XOR1>(own);
-                const uint all = h ? (oth | (own << 4)) : (own | (oth << 4));
-                nhit = (uint)__popc(all);
-                const uint m = (all * 0x01010101u) & below4;
-#pragma unroll
-                for (int k = 0; k < 4; k++) rank[k] = (uint)__popc(__builtin_amdgcn_ubfe(m, 8u * k, 8u));
-            } else
             if (ANYHIT && T8_ANYHIT_UNORDERED) {
                 // an occlusion query has no use for a front-to-back order: the hit children are numbered by child index
                 const uint own = (hit[0] ? 1u : 0u) | (hit[1] ? 2u : 0u) | (hit[2] ? 4u : 0u) | (hit[3] ? 8u : 0u);
@@ -261,8 +224,9 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
             if (nhit > 1u) {
                 if (sp + nhit - 1u > BVH8_STACK + T8_SPILL_DEPTH) { if (h == 0u) atomicOr(overflowFlag, 1u); }
                 else {      // far to near: nearest on top
+                    uint2* sb = stack_base();
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (hit[k] && rank[k] > 0u) stackStore(sp + (nhit - 1u - rank[k]), ref[k], PT_OCTANT_SLOTS ? key[k] : (key[k] & ~7u));
+                    for (int k = 0; k < 4; k++) if (hit[k] && rank[k] > 0u) stackStore(sb, sp + (nhit - 1u - rank[k]), ref[k], key[k] & ~7u);
                     sp += nhit - 1u;
                 }
             }
@@ -270,35 +234,67 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         }
 
         if (COUNT) { tc2 = __builtin_readcyclecounter(); if (t8_ballot(leaf) != 0ull && lane == 0u) ctr.leafBlocks++; }
-        // ---- postponed leaf: lane h tests triangles h, h + 2 (h + 4, h + 6 when leaves hold up to 8)
+        // ---- postponed leaf: lane h tests triangle h (h + 2, ... when leaves hold more than two). The watertight test of pt_scene.h (intersect_tri_wt) on the same operands: the
+        // axis permutation (kx, ky, kz) is the ORDER in which the record's three 16-byte groups are loaded; the ray's own quantities are selected once per leaf block.
         if (leaf) {
             const uint cnt = (pend & 7u) + 1u;
             const uint slot0 = (pend & 0x7FFFFFFFu) >> 3;
             const uint triOff0 = slot0 * 48u + laneTriOff;
             float lt = __uint_as_float(INF_BITS), lu = 0.f, lv = 0.f; uint lp = 0xFFFFFFFFu;
             bool alphaRan = false;
+            const uint gx = axes & 0xFFu, gy = (axes >> 8) & 0xFFu, gz = axes >> 16;          // byte offsets of the groups of axes kx, ky, kz
+            const bool k2 = gz == 32u, k1 = gz == 16u;                                      // kz = 2 / 1 / 0
+            const float okx = k2 ? o.x : (k1 ? o.z : o.y), oky = k2 ? o.y : (k1 ? o.x : o.z), okz = k2 ? o.z : (k1 ? o.y : o.x);
+            const float Sz = k2 ? iz : (k1 ? iy : ix);                                       // ix / iy / iz = ray_safe_rcp of the direction's components
 #pragma unroll 1
             for (uint r = 0; r < T8_LEAF_ROUNDS; r++) {
                 const bool doit = (h + T8_LANES * r) < cnt;
                 if (r > 0u && t8_ballot(doit) == 0ull) break;
                 if (doit) {
-                    const char* tp = trisBase + (triOff0 + (T8_LANES * 48u) * r);
-                    const f32x4 ta = *reinterpret_cast<const f32x4*>(tp), tb4 = *reinterpret_cast<const f32x4*>(tp + 16), tc = *reinterpret_cast<const f32x4*>(tp + 32);
-                    TriRecord tr; tr.v0 = make_float3(ta.x, ta.y, ta.z); tr.prim = __float_as_uint(ta.w);
-                    tr.e1 = make_float3(tb4.x, tb4.y, tb4.z); tr.flags = __float_as_uint(tb4.w); tr.e2 = make_float3(tc.x, tc.y, tc.z); tr.pad = tc.w;
+                    const uint toff = triOff0 + (T8_LANES * 48u) * r;      // (32-bit byte offsets from the SGPR base: global_load ... saddr)
+                    // twelve bytes per group (global_load_dwordx3): the fourth word is not needed here, and a 16-byte destination whose last register the allocator then reuses for the next
+                    // load's address makes that load wait for this one — two memory latencies in a row instead of one (seen in the ISA, measured: +10 % on k_extend)
+                    struct __attribute__((packed, aligned(4))) f32x3p { float x, y, z; };
+                    const f32x3p g0 = *reinterpret_cast<const f32x3p*>(trisBase + (toff + gx)), g1 = *reinterpret_cast<const f32x3p*>(trisBase + (toff + gy)), g2 = *reinterpret_cast<const f32x3p*>(trisBase + (toff + gz));
                     if (COUNT) ctr.triTests++;
-                    float t, u, v;
-                    if (intersect_tri_mt(tr, o, d, tmin, tmax, t, u, v)) {
-                        bool c;
-                        if (ANYHIT) {
-                            c = t8_tri_box_accepts(tr, o, ix, iy, iz, t);
-                            if (c && (tr.flags & 1u)) { if (COUNT && !(tr.flags & 2u)) alphaRan = true; c = !(tr.flags & 2u) && alpha_test_slot(sc, slot0 + h + T8_LANES * r, u, v); }      // AlphaTestVisibilityRay (BridgeDonut:981-989)
-                        } else {
-                            c = ((t < bestT) || (t == bestT && tr.prim < bestPrim)) && ((t < lt) || (t == lt && tr.prim < lp));
-                            if (c) c = t8_tri_box_accepts(tr, o, ix, iy, iz, t);
-                            if (c && (tr.flags & 1u)) { if (COUNT) alphaRan = true; c = alpha_test_slot(sc, slot0 + h + T8_LANES * r, u, v); }
+                    // intersect_tri_wt's arithmetic, two values per instruction where the operands already sit in neighbouring registers (vertices 0 and 1 of a loaded group):
+                    // packed fp32 operations round each half like the scalar ones
+                    const f32x2 ABkz = (f32x2){g2.x, g2.y} - (f32x2){okz, okz}; const float Ckz = g2.z - okz;
+                    const f32x2 ABx = __builtin_elementwise_fma((f32x2){-Sx, -Sx}, ABkz, (f32x2){g0.x, g0.y} - (f32x2){okx, okx}), ABy = __builtin_elementwise_fma((f32x2){-Sy, -Sy}, ABkz, (f32x2){g1.x, g1.y} - (f32x2){oky, oky});
+                    const float Cx = fmaf(-Sx, Ckz, g0.z - okx), Cy = fmaf(-Sy, Ckz, g1.z - oky);
+                    const float Ax = ABx.x, Bx = ABx.y, Ay = ABy.x, By = ABy.y, Akz = ABkz.x, Bkz = ABkz.y;
+                    const f32x2 m1 = ABx * (f32x2){Cy, Cy}, m2 = ABy * (f32x2){Cx, Cx};      // (Ax Cy, Bx Cy), (Ay Cx, By Cx)
+                    float V = m1.x - m2.x, U = m2.y - m1.y, W = Bx * Ay - By * Ax;            // U = Cx By - Cy Bx, V = Ax Cy - Ay Cx, W = Bx Ay - By Ax
+                    if (U == 0.0f || V == 0.0f || W == 0.0f) {      // on an edge or a vertex (or a degenerate triangle): the exact sign from the products' rounding errors (wt_edge)
+                        if (U == 0.0f) U = fmaf(Cx, By, -(Cx * By)) - fmaf(Cy, Bx, -(Cy * Bx));
+                        if (V == 0.0f) V = fmaf(Ax, Cy, -(Ax * Cy)) - fmaf(Ay, Cx, -(Ay * Cx));
+                        if (W == 0.0f) W = fmaf(Bx, Ay, -(Bx * Ay)) - fmaf(By, Ax, -(By * Ax));
+                    }
+                    const float det = (U + V) + W;
+                    // no edge function negative, or none positive (pt_scene.h writes it as !((U < 0 || V < 0 || W < 0) && (U > 0 || V > 0 || W > 0)): the same boolean for numbers; a NaN
+                    // ends as "no hit" either way, through t); without short-circuits: v_min3, v_max3 and three compares, no branch
+                    const bool inside = ((fminf(U, fminf(V, W)) >= 0.0f) | (fmaxf(U, fmaxf(V, W)) <= 0.0f)) & (det != 0.0f);
+                    if (inside) {
+                        const float T = fmaf(W, Sz * Ckz, fmaf(V, Sz * Bkz, U * (Sz * Akz)));
+                        const float inv = 1.0f / det;
+                        const float t = T * inv, u = V * inv, v = W * inv;
+                        if (t > tmin && t < tmax) {
+                            // a candidate (about one test in six): the record again, in its own order this time — prim rides with the x group, flags with y, pad with z. Reloaded (the line
+                            // is in the L1) instead of kept: twelve registers that the loop does not have — with them live across the test the kernels spill inside the loop.
+                            uint off2 = toff; asm volatile("" : "+v"(off2));      // (an address the compiler cannot match with the loads above)
+                            const f32x4 rx = *reinterpret_cast<const f32x4*>(trisBase + off2), ry = *reinterpret_cast<const f32x4*>(trisBase + (off2 + 16u)), rz = *reinterpret_cast<const f32x4*>(trisBase + (off2 + 32u));
+                            const uint prim = __float_as_uint(rx.w), flags = __float_as_uint(ry.w);
+                            bool c;
+                            if (ANYHIT) {
+                                c = t8_tri_box_accepts(rx, ry, rz, rz.w, o.x, o.y, o.z, ix, iy, iz, t);
+                                if (c && (flags & 1u)) { if (COUNT && !(flags & 2u)) alphaRan = true; c = !(flags & 2u) && alpha_test_slot(sc, slot0 + h + T8_LANES * r, u, v); }      // AlphaTestVisibilityRay (BridgeDonut:981-989)
+                            } else {
+                                c = ((t < bestT) || (t == bestT && prim < bestPrim)) && ((t < lt) || (t == lt && prim < lp));
+                                if (c) c = t8_tri_box_accepts(rx, ry, rz, rz.w, o.x, o.y, o.z, ix, iy, iz, t);
+                                if (c && (flags & 1u)) { if (COUNT) alphaRan = true; c = alpha_test_slot(sc, slot0 + h + T8_LANES * r, u, v); }
+                            }
+                            if (c) { lt = t; lp = prim; lu = u; lv = v; }
                         }
-                        if (c) { lt = t; lp = tr.prim; lu = u; lv = v; }
                     }
                 }
             }
@@ -330,38 +326,8 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
             }
             if (cur == BVH_EMPTY) {
                 T8_EVENT(6, true);
-#if T8_POP_ONCE
-                // one trip per wave iteration, two entries per trip while both lie in LDS: a ray whose next entries are behind its hit stays without a node for an iteration
-                // instead of holding the other 31 rays of the wave in the pop loop
-                if (sp > 0u) {
-                    T8_EVENT(7, true);
-                    if (!ANYHIT && sp >= 2u && sp <= BVH8_STACK) {
-                        const uint2 e1 = stack[sp - 1u], e0 = stack[sp - 2u];
-                        const bool k1 = __uint_as_float(e1.y) <= bestT, k0 = __uint_as_float(e0.y) <= bestT;
-                        cur = k1 ? e1.x : (k0 ? e0.x : BVH_EMPTY); sp -= k1 ? 1u : 2u;
-                    } else {
-                        sp--;
-                        uint2 e;
-                        if (sp < BVH8_STACK) e = stack[sp];
-                        else {
-                            unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (sp - BVH8_STACK))));
-                            e = make_uint2((uint)w, (uint)(w >> 32));
-                        }
-                        if (ANYHIT || __uint_as_float(e.y) <= bestT) cur = e.x;
-                    }
-                }
-#else
                 while (sp > 0u) {
                     T8_EVENT(7, true);
-#if T8_POP2
-                    // two entries per trip while both lie in LDS: a ray that has just found a hit usually pops a run of entries that are now behind it
-                    if (!ANYHIT && sp >= 2u && sp <= BVH8_STACK) {
-                        const uint2 e1 = stack[sp - 1u], e0 = stack[sp - 2u];
-                        if (__uint_as_float(e1.y) <= bestT) { cur = e1.x; sp -= 1u; break; }
-                        if (__uint_as_float(e0.y) <= bestT) { cur = e0.x; sp -= 2u; break; }
-                        sp -= 2u; continue;
-                    }
-#endif
                     sp--;
                     uint2 e;
                     if (sp < BVH8_STACK) e = stack[sp];
@@ -371,10 +337,9 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     }
                     if (ANYHIT || __uint_as_float(e.y) <= bestT) { cur = e.x; break; }
                 }
-#endif
-                if (cur == BVH_EMPTY && pend == BVH_EMPTY && (!T8_POP_ONCE || sp == 0u)) {          // nothing left: report
+                if (cur == BVH_EMPTY && pend == BVH_EMPTY) {          // nothing left: report
                     if (COUNT && h == 0u && ctr.rayIterHist) {
-                        if (rayIters > 2048u) { uint k = atomicAdd(ctr.longRayCount, 1u); if (k < 32u) { float* r = ctr.longRays + 8u * k; r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = (float)rayIters; r[7] = __uint_as_float(tag); } }
+                        if (rayIters > 2048u) { uint k = atomicAdd(ctr.longRayCount, 1u); if (k < 32u) { float* r = ctr.longRays + 8u * k; r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = Sx; r[4] = Sy; r[5] = __uint_as_float(axes); r[6] = (float)rayIters; r[7] = __uint_as_float(tag); } }
                         if (rayIters >= 128u) { uint bin = 31u - (uint)__clz((int)rayIters); atomicAdd(&ctr.rayIterHist[bin < 15u ? bin : 15u], 1ull); }
                     }
                     if (TASKS) {
@@ -422,6 +387,5 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         }
     }
 }
-#endif      // PT_T8_LANES == 2
 
 } // namespace ptk

@@ -7,11 +7,7 @@
 #include "pt_traverse8p.h"
 #include "pt_wavefront_device.h"
 #include <cstdlib>
-#if PT_T8_LANES == 2
 #define T8_TRAVERSE traverse8_pairs
-#else
-#define T8_TRAVERSE traverse8_persistent
-#endif
 
 namespace ptk {
 
@@ -122,7 +118,7 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
             uint4 a = pool.s0[p], b = pool.s1[p];
             float3 o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)), d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
             float t, u = 0.f, v = 0.f;
-            (void)intersect_tri_mt(sc.tris[aux.primToSlot[prim]], o, d, 0.0f, kMaxRayTravel, t, u, v);      // the winner was accepted by the traversal; only (u, v) are needed
+            const TriRecord tr = sc.tris[aux.primToSlot[prim]]; (void)intersect_tri_wt(tri_v0(tr), tri_v1(tr), tri_v2(tr), o, d, 0.0f, kMaxRayTravel, t, u, v);      // the winner was accepted by the traversal; only (u, v) are needed
             out.z = asuint(u); out.w = asuint(v);
         }
         pool.hit[p] = out;
@@ -185,43 +181,7 @@ __global__ void __launch_bounds__(1024) k_classify(PathPool pool, const uint* __
 }
 
 // PKC: PathKernelContextT<false> (lp types in fp32) or PathKernelContextT<true> (the reference's default build, lp types in binary16)
-// The split of k_shade at NEE (round 4; A/B switch MI355PT_SHADE_SPLIT / PT_SHADE_SPLIT, OFF by default — see DESIGN.md §4 for the numbers): k_nee forms the light sample and the
-// visibility request of every continuing hit on the bounce's UNCHANGED path state, k_shade<..., PART_SCATTER> then runs the vertex without the light sample. The surface is
-// formed twice instead of handed over (pt_path.h HandleHit: PART). One thread per path of k_classify's "continuing hit" class, or of the whole queue when it was not classified.
-#ifndef PT_NEE_MIN_BLOCKS
-#define PT_NEE_MIN_BLOCKS 1
-#endif
-template <class PKC>
-__global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_NEE_MIN_BLOCKS) k_nee(PKC k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr, ShadowQueue sq, WaveCounters* wc,
-                                                                           const uint* __restrict__ classCount) {
-    const uint count = classCount ? classCount[0] : *countInPtr;
-    const uint i = blockIdx.x * (uint)PT_SHADE_BLOCK + threadIdx.x;
-    ShadowRequest req; req.valid = false; uint p = 0;
-    if (i < count) {
-        p = queueIn[i];
-        const uint4 hr = pool.hit[p];
-        if (hr.y != 0xFFFFFFFFu) {
-            PathState path = load_path(pool, p);
-            HitInfo h; h.t = asfloat(hr.x); h.prim = hr.y; h.u = asfloat(hr.z); h.v = asfloat(hr.w);
-            k.template HandleHit<false, false, PKC::PART_NEE>(path, h, req, nullptr);
-        }
-    }
-    __shared__ uint sCnt[PT_SHADE_BLOCK / 64]; __shared__ uint sBase;
-    const uint wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const unsigned long long mReq = __builtin_amdgcn_ballot_w64(req.valid);
-    if (lane == 0u) sCnt[wave] = (uint)__popcll(mReq);
-    __syncthreads();
-    if (threadIdx.x == 0u) { uint tot = 0; for (uint w = 0; w < (uint)(PT_SHADE_BLOCK / 64); w++) { const uint c = sCnt[w]; sCnt[w] = tot; tot += c; } sBase = tot ? atomicAdd(&wc->shadowCount, tot) : 0u; }
-    __syncthreads();
-    if (req.valid) {
-        const uint sslot = sBase + sCnt[wave] + (uint)__popcll(mReq & ((1ull << lane) - 1ull));
-        sq.q0[sslot] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
-        sq.q1[sslot] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
-        sq.q2[sslot] = make_float4(req.radiance.x, req.radiance.y, req.radiance.z, 0.f);
-    }
-}
-
-template <bool MULTI, class PKC, bool NEEAT, int PART = 0>
+template <bool MULTI, class PKC, bool NEEAT>
 __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
                                                uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, const uint* __restrict__ classCount) {
     const uint count = *countInPtr;
@@ -246,7 +206,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
         else {
             isHit = true;
             if (MULTI) { ShadowSink sink{sq.q0, sq.q1, sq.q2, &wc->shadowCount, &wc->shadowValid, p}; k.template HandleHit<true, NEEAT>(path, h, req, &sink); }
-            else k.template HandleHit<false, NEEAT, PART>(path, h, req, nullptr);
+            else k.template HandleHit<false, NEEAT>(path, h, req, nullptr);
         }
 #endif
         store_path(pool, p, path);
@@ -737,21 +697,6 @@ void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn
     } else classCount = nullptr;
     // NEE-AT (a local sampling table and / or temporal feedback, pt_set_local_light_sampling) runs its own instantiations: the frames without it keep their kernels unchanged
     const bool neeat = k.sc.lights.LocalSamplingBuffer != nullptr || k.sc.lights.TemporalFeedbackRequired != 0u;
-#ifndef PT_SHADE_SPLIT
-#define PT_SHADE_SPLIT 0
-#endif
-    static const bool split = []() { const char* e = getenv("MI355PT_SHADE_SPLIT"); return e ? atoi(e) != 0 : PT_SHADE_SPLIT != 0; }();
-    if (split && !sq.group && !neeat && k.S.NEEEnabled) {      // k_nee on the unchanged state, then the vertex without the light sample
-        if (k.S.useFp16Types) {
-            PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16));
-            hipLaunchKernelGGL((k_nee<PathKernelContextT<true>>), g, b, 0, st, k16, pool, queueIn, countInPtr, sq, wc, classCount);
-            hipLaunchKernelGGL((k_shade<false, PathKernelContextT<true>, false, PathKernelContextT<true>::PART_SCATTER>), g, b, 0, st, k16, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
-        } else {
-            hipLaunchKernelGGL((k_nee<PathKernelContext>), g, b, 0, st, k, pool, queueIn, countInPtr, sq, wc, classCount);
-            hipLaunchKernelGGL((k_shade<false, PathKernelContext, false, PathKernelContext::PART_SCATTER>), g, b, 0, st, k, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount);
-        }
-        return;
-    }
 #define PT_LAUNCH_SHADE(MULTI, PKC, CTX) do { if (neeat) hipLaunchKernelGGL((k_shade<MULTI, PKC, true>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount); \
                                               else hipLaunchKernelGGL((k_shade<MULTI, PKC, false>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount); } while (0)
     if (k.S.useFp16Types) {          // the reference's default build of its lp types (binary16): same context data, the other instantiation of the shading code

@@ -104,19 +104,19 @@ def test_neeat_frames_through_the_tail_kernel(name):
 
 
 def test_mixed_frames_do_not_depend_on_the_threshold():
-    """A frame of 0.9 M paths in pipelined batches: all-wavefront == product default (65536) == an early hand-over (300 000) == a late one (2 000), ray counts included."""
+    """A frame of 0.9 M paths in pipelined batches: all-wavefront == the product default (32768) == 65536 == an early hand-over (300 000) == a late one (2 000), ray counts included."""
     import rtxpt_amd as pt
     from rtxpt_amd import scenes
     sc, cam = scenes.bistro_like(scale=0.05, tex_size=128)
     w, h, spp = 640, 360, 4
     t = pt.PathTracer(); t.set_scene(sc); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.set_settings(scenes.default_settings(useFp16Types=1)); t.resize(w, h)
     frames = {}
-    for tail in (0, 65536, 300000, 2000):
+    for tail in (0, 32768, 65536, 300000, 2000):
         t.set_tail_paths(tail); t.reset_accumulation(); st = t.render(0, spp)
         frames[tail] = (t.radiance(), st["extendRays"], st["shadowRays"], st["hits"], st["tailLaunches"])
     t.close()
     ref = frames[0]; assert ref[4] == 0
-    for tail in (65536, 300000, 2000):
+    for tail in (32768, 65536, 300000, 2000):
         f = frames[tail]
         assert f[4] >= 1, "threshold %d: no tail launch" % tail
         assert np.array_equal(_bits(f[0]), _bits(ref[0])), "threshold %d: %d pixels differ" % (tail, int((_bits(f[0]) != _bits(ref[0])).any(-1).sum()))

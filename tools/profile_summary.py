@@ -9,7 +9,7 @@ Formulas (gfx94x definitions, the ones rocprofv3 falls back to on gfx950, MI355X
   hbm_bytes        = (2 * FETCH_SIZE + WRITE_SIZE) * 1024      FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); WRITE_SIZE uncalibrated;
                      Infinity-Cache hits are counted as traffic
   l2_hit_rate      = TCC_HIT / (TCC_HIT + TCC_MISS)"""
-import csv, glob, json, sys, collections
+import os, csv, glob, json, sys, collections
 
 d = sys.argv[1]
 GROUPS = (("extend", ("k_extend<false, false>", "k_extend_tasks", "k_resolve_extend")), ("shadow", ("k_shadow<false, false>", "k_shadow_tasks", "k_resolve_shadow")), ("shade", ("k_shade<false", "k_classify")),
@@ -45,7 +45,11 @@ for f in glob.glob(d + "/**/stats_kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Name"].replace("void ptk::", "").replace("ptk::", "").split("(")[0]
         stats[n] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) * 1e-6, "total_ms": float(r["TotalDurationNs"]) * 1e-6, "percent": float(r["Percentage"])}
-out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc (separate passes), 1 serial-kernel step of bench.py's default workload", "kernel_trace_stats": stats, "groups": {}}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rtxpt_amd
+out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc (separate passes), 1 serial-kernel step of bench.py's default workload",
+       "kernel_source_sha256": rtxpt_amd.kernel_source_digest(),      # bench.py quotes these counters only for the kernels they were collected on
+       "kernel_trace_stats": stats, "groups": {}}
 for g, _ in GROUPS:
     c = cnt[g]
     if not c:
