@@ -474,6 +474,8 @@ int32_t pt_scene_import_directional_lights(const pt_scene_import* scene, PtEnvDi
 int32_t pt_scene_import_instances(const pt_scene_import* scene, PtInstanceDesc* out, uint32_t capacity);
 int32_t pt_scene_import_geometries(const pt_scene_import* scene, PtGeometryDesc* out, uint32_t capacity);
 int32_t pt_scene_import_materials(const pt_scene_import* scene, PTMaterialData* out, uint32_t capacity);
+/* the imported vertex positions (object space, three floats per vertex, the order PtGeometryDesc.vertexOffset indexes); returns the vertex count (capacity 0: a query) */
+int32_t pt_scene_import_vertices(const pt_scene_import* scene, float* positions, uint32_t capacityVertices);
 /* texture `index` (0 .. PtSceneJsonInfo.numTextures - 1; the low 16 bits of a material's texture word) as decoded: RGBA8 texels of the top level; out->pixels points
    into the import object and lives as long as it does */
 int32_t pt_scene_import_texture(const pt_scene_import* scene, uint32_t index, PtTextureDesc* out);

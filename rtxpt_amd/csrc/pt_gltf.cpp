@@ -265,25 +265,55 @@ struct Loader {
     // meshNodes: every (node, mesh) pair visit() met while recordWorlds — read by pt_gltf_animation_positions
     struct GeomMorph { size_t first; uint32_t count; }; std::vector<GeomMorph> geomMorph; std::vector<float> morphDeltas, morphNormalDeltas, morphTangentDeltas; std::vector<std::vector<double>> meshWeights;
     struct MeshNode { int node, mesh; }; std::vector<MeshNode> meshNodes;
+    // KHR_lights_punctual (visit()): Donut's glTF importer turns the extension's lights into the scene-graph leaves RTXPT then bakes (DirectionalLight -> the environment cube,
+    // Sample.cpp:1361-1388; PointLight / SpotLight -> LightsBaker's analytic lights through PointLightEx / SpotLightEx, Rtxpt/SampleCommon/ExtendedScene.cpp:54-143). Donut is not
+    // vendored: the mapping is the extension's own definition over Donut's light members as the .scene.json leaves use them (UNPINNED) — color, intensity (point / spot: luminous
+    // intensity -> `intensity`; directional: illuminance -> `irradiance`), spot cone angles in degrees, radius 0, angular size 0; the light points along its node's -Z.
+    struct PunctualRaw { int type; float color[3], intensity, inner, outer; M4 world; };      // type 0 point, 1 spot, 2 directional; world: the light node's local-to-world inside this file
+    std::vector<PunctualRaw> punctual; uint32_t punctualDropped = 0;
+    void punctual_light(int index, const M4& world) {
+        const JValue* rext = root.get("extensions"); const JValue* kl = rext ? rext->get("KHR_lights_punctual") : nullptr; const JValue* lights = kl ? kl->get("lights") : nullptr;
+        if (!lights || index < 0 || (size_t)index >= lights->size()) return;
+        const JValue& l = lights->arr[index]; const std::string type = l.strOr("type", "");
+        PunctualRaw r; r.type = type == "directional" ? 2 : (type == "spot" ? 1 : (type == "point" ? 0 : -1)); if (r.type < 0) return;
+        r.color[0] = r.color[1] = r.color[2] = 1.f; if (const JValue* c = l.get("color")) if (c->size() == 3) for (int i = 0; i < 3; i++) r.color[i] = (float)c->arr[i].num;
+        r.intensity = (float)l.numOr("intensity", 1.0); r.inner = 180.f; r.outer = 180.f; r.world = world;
+        const float cx = r.color[0] * r.intensity, cy = r.color[1] * r.intensity, cz = r.color[2] * r.intensity;
+        if (sqrtf(cx * cx + cy * cy + cz * cz) <= 1e-7f) { punctualDropped++; return; }      // Sample.cpp:567-573: invisible lights are dropped
+        if (r.type == 1) { const JValue* sp = l.get("spot"); r.inner = (float)((sp ? sp->numOr("innerConeAngle", 0.0) : 0.0) * (180.0 / 3.14159265358979323846)); r.outer = (float)((sp ? sp->numOr("outerConeAngle", 0.78539816339744831) : 0.78539816339744831) * (180.0 / 3.14159265358979323846)); }
+        punctual.push_back(r);
+    }
+    // the records the lights become under `parent` (identity for a bare glTF file, the model node's transform in a .scene.json graph)
+    static void emit_punctual(const PunctualRaw& l, const M4& parent, std::vector<PtAnalyticLightDesc>& analytic, std::vector<PtEnvDirectionalLight>& directional) {
+        const M4 w = m4_mul(parent, l.world);
+        const double zx = w.m[8], zy = w.m[9], zz = w.m[10]; double len = sqrt(zx * zx + zy * zy + zz * zz); if (!(len > 0)) len = 1;
+        if (l.type == 2) {
+            PtEnvDirectionalLight d; memset(&d, 0, sizeof(d));
+            d.ColorIntensity[0] = l.color[0]; d.ColorIntensity[1] = l.color[1]; d.ColorIntensity[2] = l.color[2]; d.ColorIntensity[3] = l.intensity;
+            d.Direction[0] = (float)(-zx / len); d.Direction[1] = (float)(-zy / len); d.Direction[2] = (float)(-zz / len); d.AngularSize = 0.f;
+            directional.push_back(d);
+        } else {
+            PtAnalyticLightDesc d; memset(&d, 0, sizeof(d));
+            d.type = (uint32_t)l.type; for (int i = 0; i < 3; i++) { d.color[i] = l.color[i]; d.position[i] = (float)w.m[12 + i]; }
+            d.intensity = l.intensity; d.radius = 0.f; d.innerAngle = l.inner; d.outerAngle = l.outer;
+            d.direction[0] = (float)(-zx / len); d.direction[1] = (float)(-zy / len); d.direction[2] = (float)(-zz / len);
+            analytic.push_back(d);
+        }
+    }
     struct NodeTRS { bool has[3]; double t[3], q[4], s[3]; };      // animation: per node, the channels that replace its translation / rotation / scale (pt_gltf_animation)
     const std::vector<NodeTRS>* nodeOverride = nullptr;
 
-    bool accessor(int idx, std::vector<double>& out, int& comps) {
-        const JValue* accs = root.get("accessors"); if (!accs || idx < 0 || (size_t)idx >= accs->size()) { err = "bad accessor index"; return false; }
-        const JValue& a = accs->arr[idx];
-        int ct = a.intOr("componentType", 0), count = a.intOr("count", 0); std::string type = a.strOr("type", "");
-        comps = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 0;
-        bool normalized = a.get("normalized") && a.get("normalized")->b;
-        if (!comps || a.get("sparse")) { err = "unsupported accessor"; return false; }
-        int bv = a.intOr("bufferView", -1); const JValue* bvs = root.get("bufferViews");
+    // `count` elements of `comps` components of type `ct` from bufferView `bv` (+ byteOffset acOff) into out; tight = ignore the view's byteStride (sparse indices / values are tightly packed)
+    bool read_view(int bv, double acOff, int ct, int comps, int count, bool normalized, bool tight, std::vector<double>& out) {
+        const JValue* bvs = root.get("bufferViews");
         if (!bvs || bv < 0 || (size_t)bv >= bvs->size()) { err = "accessor without bufferView"; return false; }
         const JValue& v = bvs->arr[bv];
-        const double bvOff = v.numOr("byteOffset", 0), acOff = a.numOr("byteOffset", 0), bvStride = v.numOr("byteStride", 0);
+        const double bvOff = v.numOr("byteOffset", 0), bvStride = v.numOr("byteStride", 0);
         if (count < 0 || !(bvOff >= 0) || !(acOff >= 0) || !(bvStride >= 0) || bvOff > 4.0e12 || acOff > 4.0e12 || bvStride > 65536.0) { err = "accessor with a negative or absurd count / offset / stride"; return false; }
         int buf = v.intOr("buffer", 0); size_t off = (size_t)bvOff + (size_t)acOff;
         int csz = (ct == 5120 || ct == 5121) ? 1 : (ct == 5122 || ct == 5123) ? 2 : (ct == 5125 || ct == 5126) ? 4 : 0;
         if (!csz || buf < 0 || (size_t)buf >= buffers.size()) { err = "unsupported component type"; return false; }
-        size_t stride = (size_t)v.numOr("byteStride", 0); if (!stride) stride = (size_t)csz * comps;
+        size_t stride = tight ? 0 : (size_t)bvStride; if (!stride) stride = (size_t)csz * comps;
         const std::vector<uint8_t>& b = buffers[buf];
         const size_t elem = (size_t)csz * comps;
         if (count && (off > b.size() || elem > b.size() - off || (size_t)(count - 1) > (b.size() - off - elem) / stride)) { err = "accessor out of range"; return false; }
@@ -295,6 +325,35 @@ struct Loader {
                 case 5123: { uint16_t s; memcpy(&s, p, 2); val = s; if (normalized) val /= 65535.0; } break;
                 case 5125: { uint32_t s; memcpy(&s, p, 4); val = s; } break; default: { float f; memcpy(&f, p, 4); val = f; } break; }
             out[(size_t)i * comps + k] = val;
+        }
+        return true;
+    }
+    bool accessor(int idx, std::vector<double>& out, int& comps) {
+        const JValue* accs = root.get("accessors"); if (!accs || idx < 0 || (size_t)idx >= accs->size()) { err = "bad accessor index"; return false; }
+        const JValue& a = accs->arr[idx];
+        int ct = a.intOr("componentType", 0), count = a.intOr("count", 0); std::string type = a.strOr("type", "");
+        comps = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 0;
+        bool normalized = a.get("normalized") && a.get("normalized")->b;
+        if (!comps) { err = "unsupported accessor"; return false; }
+        const JValue* sparse = a.get("sparse");
+        if (count < 0 || count > (1 << 28)) { err = "accessor with a negative or absurd count / offset / stride"; return false; }
+        if (a.get("bufferView")) { if (!read_view(a.intOr("bufferView", -1), a.numOr("byteOffset", 0), ct, comps, count, normalized, false, out)) return false; }
+        else if (sparse) out.assign((size_t)count * comps, 0.0);      // glTF 2.0, 3.6.2.3: a sparse accessor without a bufferView starts from zeros
+        else { err = "accessor without bufferView"; return false; }
+        if (sparse) {      // sparse.count elements are replaced: sparse.indices (tightly packed u8 / u16 / u32) name them, sparse.values (tightly packed, the accessor's type) hold them.
+            // cgltf — what Donut's importer reads glTF with — resolves sparse accessors when it unpacks floats (cgltf_accessor_unpack_floats), so the reference accepts such files
+            const int n = sparse->intOr("count", 0); const JValue* ind = sparse->get("indices"); const JValue* val = sparse->get("values");
+            if (n < 0 || n > count || !ind || !val) { err = "malformed sparse accessor"; return false; }
+            const int ict = ind->intOr("componentType", 0);
+            if (ict != 5121 && ict != 5123 && ict != 5125) { err = "malformed sparse accessor"; return false; }
+            std::vector<double> idxs, vals;
+            if (!read_view(ind->intOr("bufferView", -1), ind->numOr("byteOffset", 0), ict, 1, n, false, true, idxs)) return false;
+            if (!read_view(val->intOr("bufferView", -1), val->numOr("byteOffset", 0), ct, comps, n, normalized, true, vals)) return false;
+            for (int i = 0; i < n; i++) {
+                const double at = idxs[(size_t)i];
+                if (!(at >= 0) || at >= (double)count) { err = "sparse accessor index out of range"; return false; }
+                for (int k = 0; k < comps; k++) out[(size_t)at * comps + k] = vals[(size_t)i * comps + k];
+            }
         }
         return true;
     }
@@ -458,6 +517,7 @@ struct Loader {
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) inst.transform[r * 4 + c] = (float)world.m[c * 4 + r];   // column-major 4x4 -> row-major 3x4
             instances.push_back(inst); instanceWorld.push_back(world); instancePath.push_back(path);
         }
+        if (const JValue* ext = n.get("extensions")) if (const JValue* lp = ext->get("KHR_lights_punctual")) punctual_light(lp->intOr("light", -1), world);
         if (const JValue* ch = n.get("children")) for (auto& c : ch->arr) visit((int)c.num, world, depth + 1, path);
     }
 };
@@ -555,7 +615,19 @@ static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path) {
     gb.normals = L.normals.data(); gb.tangents = L.tangents.data(); gb.numVertices = (uint32_t)(L.positions.size() / 3);
     r = pt_set_geometry(ctx, &gb, L.geoms.data(), (uint32_t)L.geoms.size(), L.meshes.data(), (uint32_t)L.meshes.size());
     if (r != PT_OK) return r;
-    return pt_set_instances(ctx, L.instances.data(), (uint32_t)L.instances.size());
+    r = pt_set_instances(ctx, L.instances.data(), (uint32_t)L.instances.size());
+    if (r != PT_OK) return r;
+    // KHR_lights_punctual: point / spot lights become the context's analytic lights (what LightsBaker collects from the scene graph), directional ones the environment baker's list
+    // (drawn into the cube at the next bake; cube size kept). A file without the extension leaves both as the host set them.
+    std::vector<PtAnalyticLightDesc> analytic; std::vector<PtEnvDirectionalLight> directional;
+    for (const Loader::PunctualRaw& l : L.punctual) Loader::emit_punctual(l, m4_identity(), analytic, directional);
+    if (!analytic.empty()) {
+        std::vector<PolymorphicLightInfo> base(analytic.size()); std::vector<PolymorphicLightInfoEx> ex(analytic.size());
+        for (size_t i = 0; i < analytic.size(); i++) { r = pt_convert_light(&analytic[i], &base[i], &ex[i]); if (r != PT_OK) return r; }
+        r = pt_set_lights(ctx, base.data(), ex.data(), (uint32_t)base.size()); if (r != PT_OK) return r;
+    }
+    if (!directional.empty()) { r = pt_set_environment_bake(ctx, 0u, directional.data(), (uint32_t)std::min<size_t>(directional.size(), 16)); if (r != PT_OK) return r; }
+    return PT_OK;
 }
 
 // ================================================================ glTF animations (SURVEY.md 8f N2 leftovers)
@@ -814,7 +886,8 @@ std::string file_stem(const std::string& path) {
     size_t slash = path.find_last_of('/'); std::string f = slash == std::string::npos ? path : path.substr(slash + 1);
     size_t dot = f.find_last_of('.'); return dot == std::string::npos ? f : f.substr(0, dot);
 }
-struct ModelSlot { bool loaded = false; int32_t status = PT_OK; uint32_t firstMesh = 0; std::vector<int> meshRemap; std::vector<uint32_t> instMesh; std::vector<M4> instWorld; std::vector<std::string> instPath; };
+struct ModelSlot { bool loaded = false; int32_t status = PT_OK; uint32_t firstMesh = 0; std::vector<int> meshRemap; std::vector<uint32_t> instMesh; std::vector<M4> instWorld; std::vector<std::string> instPath;
+                   std::vector<Loader::PunctualRaw> punctual; };      // punctual: the model file's KHR_lights_punctual lights (in its own space)
 
 struct SceneReader {
     pt_scene_import& S; std::string sceneDir, mediaDir, sceneStem; std::vector<std::string> modelPaths; std::vector<ModelSlot> slots; int32_t err = PT_OK;
@@ -913,6 +986,7 @@ struct SceneReader {
             if (mesh < 0) continue;
             slot.instMesh.push_back((uint32_t)mesh); slot.instWorld.push_back(L.instanceWorld[i]); slot.instPath.push_back(i < L.instancePath.size() ? L.instancePath[i] : std::string());
         }
+        slot.punctual = L.punctual; S.info.lightsDropped += L.punctualDropped;
         S.info.numModels++;
         return slot;
     }
@@ -932,6 +1006,11 @@ struct SceneReader {
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) inst.transform[r * 4 + c] = (float)w.m[c * 4 + r];
             S.instances.push_back(inst);
         }
+        // the model's KHR_lights_punctual lights hang below the model node like its meshes: LightsBaker's list / the environment baker's list grow in scene-graph order
+        std::vector<PtAnalyticLightDesc> analytic; std::vector<PtEnvDirectionalLight> directional;
+        for (const Loader::PunctualRaw& l : slot.punctual) Loader::emit_punctual(l, world, analytic, directional);
+        for (const PtAnalyticLightDesc& d : analytic) { PolymorphicLightInfo b; PolymorphicLightInfoEx e; int32_t r = pt_convert_light(&d, &b, &e); if (r != PT_OK) { err = r; return; } S.lights.push_back(b); S.lightsEx.push_back(e); }
+        for (const PtEnvDirectionalLight& d : directional) { S.directionalLights.push_back(d); S.info.directionalLights++; }
     }
     // ExtendedScene::ProcessNodesRecursive (ExtendedScene.cpp:246-263) + LightsBaker::Update (LightsBaker.cpp:718-753): the mesh instance a point / spot light names in
     // "proxyMeshNodes" stands in for that light (PtInstanceDesc.analyticProxyLight). Only a path that ends at a node holding a mesh instance links, as there.
@@ -1084,6 +1163,12 @@ PT_IMPORT_COPY(pt_scene_import_instances, PtInstanceDesc, instances)
 PT_IMPORT_COPY(pt_scene_import_geometries, PtGeometryDesc, geoms)
 PT_IMPORT_COPY(pt_scene_import_materials, PTMaterialData, materials)
 #undef PT_IMPORT_COPY
+extern "C" int32_t pt_scene_import_vertices(const pt_scene_import* scene, float* positions, uint32_t capacityVertices) {      // the imported POSITION stream (object space, xyz per vertex)
+    if (!scene || (capacityVertices && !positions)) return -PT_ERROR_INVALID_ARGUMENT;
+    const size_t nv = scene->positions.size() / 3, n = nv < capacityVertices ? nv : capacityVertices;
+    if (n) memcpy(positions, scene->positions.data(), n * 12u);
+    return (int32_t)nv;
+}
 extern "C" int32_t pt_scene_import_texture(const pt_scene_import* scene, uint32_t index, PtTextureDesc* out) {
     if (!scene || !out || index >= scene->texDescs.size()) return PT_ERROR_INVALID_ARGUMENT;
     *out = scene->texDescs[index]; out->pixels = scene->texPixels[index].data();
