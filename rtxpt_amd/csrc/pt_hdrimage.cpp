@@ -1,8 +1,8 @@
 // mi355pt — float image files for the environment source. The reference takes ".exr", ".hdr" and ".dds" environment maps (Rtxpt/Sample.cpp:116) through
 // Donut's TextureCache (EnvMapBaker.cpp:392-415), which is not vendored in the reference tree: the two HDR formats are read here from their published
 // specifications. Host code, no device.
-//   OpenEXR: single-part scan-line files, channels R G B (or Y) of type half or float, compression NONE / RLE / ZIPS / ZIP. Tiled, multi-part and deep
-//            files and the PIZ / PXR24 / B44 / DWA codecs are reported as PT_ERROR_UNSUPPORTED.
+//   OpenEXR: single-part scan-line files, channels R G B (or Y) of type half or float, compression NONE / RLE / ZIPS / ZIP / PIZ (the default of most HDRI
+//            tools). Tiled, multi-part and deep files and the PXR24 / B44 / DWA codecs are reported as PT_ERROR_UNSUPPORTED.
 //   Radiance .hdr: "#?RADIANCE" / "#?RGBE", FORMAT=32-bit_rle_rgbe, -Y h +X w; flat and new-style run-length scan lines.
 // Output: width x height x 3 floats, top row first (the first scan line of either format is the top of the picture).
 #include "../../include/mi355pt.h"
@@ -54,6 +54,146 @@ bool exr_rle_decode(const unsigned char* in, size_t nin, std::vector<unsigned ch
     return out.size() == want;
 }
 
+
+// ---- OpenEXR's PIZ codec, decode side (ImfPizCompressor.cpp, ImfHuf.cpp, ImfWav.cpp of the OpenEXR library, restated from the published format): per block of up to 32 scan
+// lines — a bitmap of the 16-bit values that occur (-> a reverse lookup table), then a Huffman-coded stream (canonical codes, lengths packed in 6 bits with zero runs, one
+// run-length symbol) of the block's 16-bit words, channel by channel, each channel plane wavelet-transformed (two-dimensional Haar with 14- or 16-bit modular arithmetic).
+const int HUF_ENCBITS = 16, HUF_DECBITS = 14, HUF_ENCSIZE = (1 << HUF_ENCBITS) + 1, HUF_DECSIZE = 1 << HUF_DECBITS, HUF_DECMASK = HUF_DECSIZE - 1;
+struct HufDec { int len = 0; unsigned lit = 0; std::vector<unsigned> p; };
+struct BitIn { const unsigned char* in; const unsigned char* end; unsigned long long c = 0; int lc = 0;
+    bool getChar() { if (in >= end) return false; c = (c << 8) | *in++; lc += 8; return true; }
+    bool getBits(int n, unsigned& out) { while (lc < n) if (!getChar()) return false; lc -= n; out = (unsigned)((c >> lc) & ((1ull << n) - 1ull)); return true; } };
+bool huf_unpack_table(BitIn& b, int im, int iM, std::vector<unsigned long long>& hcode) {
+    for (; im <= iM; im++) {
+        unsigned l; if (!b.getBits(6, l)) return false;
+        hcode[(size_t)im] = l;
+        if (l == 63u) { unsigned z; if (!b.getBits(8, z)) return false; int zerun = (int)z + 6; if (im + zerun > iM + 1) return false; while (zerun--) hcode[(size_t)im++] = 0; im--; }
+        else if (l >= 59u) { int zerun = (int)l - 59 + 2; if (im + zerun > iM + 1) return false; while (zerun--) hcode[(size_t)im++] = 0; im--; }
+    }
+    // canonical codes from the lengths (hufCanonicalCodeTable): code = hcode >> 6, length = hcode & 63
+    unsigned long long n[59]; for (auto& v : n) v = 0;
+    for (int i = 0; i < HUF_ENCSIZE; i++) { if (hcode[(size_t)i] > 58) return false; n[hcode[(size_t)i]] += 1; }
+    unsigned long long c = 0;
+    for (int i = 58; i > 0; --i) { const unsigned long long nc = (c + n[i]) >> 1; n[i] = c; c = nc; }
+    for (int i = 0; i < HUF_ENCSIZE; i++) { const int l = (int)hcode[(size_t)i]; if (l > 0) hcode[(size_t)i] = (unsigned long long)l | (n[l]++ << 6); }
+    return true;
+}
+bool huf_uncompress(const unsigned char* data, size_t nData, std::vector<unsigned short>& out, size_t nRaw) {
+    out.clear(); if (nRaw == 0) return true;
+    if (nData < 20) return false;
+    auto u32 = [&](size_t o) { unsigned v; memcpy(&v, data + o, 4); return v; };
+    const unsigned im = u32(0), iM = u32(4), nBits = u32(12);
+    if (im >= (unsigned)HUF_ENCSIZE || iM >= (unsigned)HUF_ENCSIZE || im > iM) return false;
+    std::vector<unsigned long long> hcode((size_t)HUF_ENCSIZE, 0ull);
+    BitIn tb{data + 20, data + nData};
+    if (!huf_unpack_table(tb, (int)im, (int)iM, hcode)) return false;
+    const unsigned char* ptr = tb.in;
+    if ((unsigned long long)nBits > 8ull * (unsigned long long)(data + nData - ptr)) return false;
+    std::vector<HufDec> dec((size_t)HUF_DECSIZE);
+    for (unsigned s = im; s <= iM; s++) {      // hufBuildDecTable
+        const unsigned long long c = hcode[s] >> 6; const int l = (int)(hcode[s] & 63);
+        if (l == 0) continue;
+        if (c >> l) return false;
+        if (l > HUF_DECBITS) { HufDec& pl = dec[(size_t)(c >> (l - HUF_DECBITS))]; if (pl.len) return false; pl.lit++; pl.p.push_back(s); }
+        else { size_t first = (size_t)(c << (HUF_DECBITS - l)); for (size_t i = 0; i < ((size_t)1 << (HUF_DECBITS - l)); i++) { HufDec& pl = dec[first + i]; if (pl.len || !pl.p.empty()) return false; pl.len = l; pl.lit = s; } }
+    }
+    out.reserve(nRaw);
+    BitIn b{ptr, ptr + (nBits + 7u) / 8u};
+    const unsigned rlc = iM;
+    auto getCode = [&](unsigned po) -> bool {
+        if (po == rlc) {
+            if (b.lc < 8 && !b.getChar()) return false;
+            b.lc -= 8; const unsigned cs = (unsigned)((b.c >> b.lc) & 0xFFu);
+            if (out.empty() || out.size() + cs > nRaw) return false;
+            const unsigned short sv = out.back(); out.insert(out.end(), cs, sv);
+        } else { if (out.size() >= nRaw) return false; out.push_back((unsigned short)po); }
+        return true;
+    };
+    while (b.in < b.end) {
+        b.getChar();
+        while (b.lc >= HUF_DECBITS) {
+            const HufDec& pl = dec[(size_t)((b.c >> (b.lc - HUF_DECBITS)) & (unsigned long long)HUF_DECMASK)];
+            if (pl.len) { b.lc -= pl.len; if (!getCode(pl.lit)) return false; }
+            else {
+                if (pl.p.empty()) return false;
+                size_t j = 0;
+                for (; j < pl.p.size(); j++) {
+                    const int l = (int)(hcode[pl.p[j]] & 63);
+                    while (b.lc < l && b.in < b.end) b.getChar();
+                    if (b.lc >= l && (hcode[pl.p[j]] >> 6) == ((b.c >> (b.lc - l)) & ((1ull << l) - 1ull))) { b.lc -= l; if (!getCode(pl.p[j])) return false; break; }
+                }
+                if (j == pl.p.size()) return false;
+            }
+        }
+    }
+    const int i = (8 - (int)nBits) & 7; b.c >>= i; b.lc -= i;
+    while (b.lc > 0) {
+        const HufDec& pl = dec[(size_t)((b.c << (HUF_DECBITS - b.lc)) & (unsigned long long)HUF_DECMASK)];
+        if (!pl.len || pl.len > b.lc) return false;
+        b.lc -= pl.len; if (!getCode(pl.lit)) return false;
+    }
+    return out.size() == nRaw;
+}
+inline void wdec14(unsigned short l, unsigned short h, unsigned short& a, unsigned short& b) {
+    const short ls = (short)l, hs = (short)h; const int hi = hs, ai = ls + (hi & 1) + (hi >> 1);
+    a = (unsigned short)(short)ai; b = (unsigned short)(short)(ai - hi);
+}
+inline void wdec16(unsigned short l, unsigned short h, unsigned short& a, unsigned short& b) {
+    const int m = l, d = h, bb = (m - (d >> 1)) & 0xFFFF, aa = (d + bb - 0x8000) & 0xFFFF;
+    b = (unsigned short)bb; a = (unsigned short)aa;
+}
+void wav2_decode(unsigned short* in, int nx, int ox, int ny, int oy, unsigned short mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx; int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1; p2 = p; p >>= 1;
+    while (p >= 1) {
+        unsigned short* py = in; unsigned short* ey = in + (ptrdiff_t)oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        unsigned short i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            unsigned short* px = py; unsigned short* ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                unsigned short* p01 = px + ox1; unsigned short* p10 = px + oy1; unsigned short* p11 = p10 + ox1;
+                if (w14) { wdec14(*px, *p10, i00, i10); wdec14(*p01, *p11, i01, i11); wdec14(i00, i01, *px, *p01); wdec14(i10, i11, *p10, *p11); }
+                else { wdec16(*px, *p10, i00, i10); wdec16(*p01, *p11, i01, i11); wdec16(i00, i01, *px, *p01); wdec16(i10, i11, *p10, *p11); }
+            }
+            if (nx & p) { unsigned short* p10 = px + oy1; if (w14) wdec14(*px, *p10, i00, *p10); else wdec16(*px, *p10, i00, *p10); *px = i00; }
+        }
+        if (ny & p) {
+            unsigned short* px = py; unsigned short* ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) { unsigned short* p01 = px + ox1; if (w14) wdec14(*px, *p01, i00, *p01); else wdec16(*px, *p01, i00, *p01); *px = i00; }
+        }
+        p2 = p; p >>= 1;
+    }
+}
+// one PIZ block -> the block's scan lines in the file's own (uncompressed) layout: per line, channel after channel. words[k]: 16-bit words per pixel of channel k (half 1, float / uint 2)
+bool exr_piz_decode(const unsigned char* src, size_t size, size_t w, size_t lines, const std::vector<int>& words, std::vector<unsigned char>& raw) {
+    size_t perLine = 0; for (int k : words) perLine += (size_t)k * w;
+    const size_t total = perLine * lines;
+    if (size < 4) return false;
+    unsigned short minNZ, maxNZ; memcpy(&minNZ, src, 2); memcpy(&maxNZ, src + 2, 2);
+    std::vector<unsigned char> bitmap(8192, 0); size_t at = 4;
+    if (maxNZ >= 8192) return false;
+    if (minNZ <= maxNZ) { const size_t n = (size_t)maxNZ - minNZ + 1; if (at + n > size) return false; memcpy(bitmap.data() + minNZ, src + at, n); at += n; }
+    std::vector<unsigned short> lut(65536, 0); size_t k = 0;
+    for (unsigned i = 0; i < 65536u; i++) if (i == 0 || (bitmap[i >> 3] & (1u << (i & 7u)))) lut[k++] = (unsigned short)i;
+    const unsigned short maxValue = (unsigned short)(k - 1);
+    if (at + 4 > size) return false;
+    int length; memcpy(&length, src + at, 4); at += 4;
+    if (length < 0 || at + (size_t)length > size) return false;
+    std::vector<unsigned short> tmp;
+    if (!huf_uncompress(src + at, (size_t)length, tmp, total)) return false;
+    size_t chStart = 0;
+    for (int wk : words) { for (int j = 0; j < wk; j++) wav2_decode(tmp.data() + chStart + (size_t)j, (int)w, wk, (int)lines, (int)(w * (size_t)wk), maxValue); chStart += (size_t)wk * w * lines; }
+    for (auto& v : tmp) v = lut[v];
+    raw.resize(total * 2);
+    std::vector<size_t> cur(words.size()); { size_t o = 0; for (size_t c = 0; c < words.size(); c++) { cur[c] = o; o += (size_t)words[c] * w * lines; } }
+    unsigned char* o = raw.data();
+    for (size_t y = 0; y < lines; y++) for (size_t c = 0; c < words.size(); c++) { const size_t n = (size_t)words[c] * w; memcpy(o, tmp.data() + cur[c], n * 2); cur[c] += n; o += n * 2; }
+    return true;
+}
+
 int32_t read_exr(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H, std::vector<float>& rgb) {
     Rd r{d.data(), d.size(), 0, true};
     if (d.size() < 8 || (unsigned)r.i32() != 20000630u) return PT_ERROR_IO;
@@ -77,7 +217,7 @@ int32_t read_exr(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H, 
         else if (name == "lineOrder") lineOrder = a.u8();
     }
     if (ch.empty() || comp < 0 || !haveDw) return PT_ERROR_IO;
-    if (comp > 3) return PT_ERROR_UNSUPPORTED;                                      // 0 none, 1 RLE, 2 ZIPS, 3 ZIP; PIZ / PXR24 / B44 / DWA are not read
+    if (comp > 4) return PT_ERROR_UNSUPPORTED;                                      // 0 none, 1 RLE, 2 ZIPS, 3 ZIP, 4 PIZ; PXR24 / B44 / DWA are not read
     const long long w = (long long)dw[2] - dw[0] + 1, h = (long long)dw[3] - dw[1] + 1;
     if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || w * h > (1ll << 28)) return PT_ERROR_IO;      // (a damaged data window must not turn into a 12 GB allocation)
     size_t lineBytes = 0; int idx[3] = {-1, -1, -1}, yIdx = -1; std::vector<size_t> chOff(ch.size());
@@ -89,7 +229,8 @@ int32_t read_exr(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H, 
     }
     if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0) { if (yIdx < 0) return PT_ERROR_UNSUPPORTED; idx[0] = idx[1] = idx[2] = yIdx; }
     for (int k = 0; k < 3; k++) if (ch[(size_t)idx[k]].type == 0) return PT_ERROR_UNSUPPORTED;      // uint channels carry ids, not radiance
-    const unsigned linesPerBlock = comp == 3 ? 16u : 1u;
+    const unsigned linesPerBlock = comp == 3 ? 16u : (comp == 4 ? 32u : 1u);
+    std::vector<int> pizWords; for (auto& c : ch) pizWords.push_back(c.type == 1 ? 1 : 2);
     const size_t blocks = ((size_t)h + linesPerBlock - 1) / linesPerBlock;
     if (blocks * 8 > d.size()) return PT_ERROR_IO;                                   // the offset table alone would not fit the file
     std::vector<unsigned long long> offs(blocks); for (auto& o : offs) o = r.u64();
@@ -107,6 +248,7 @@ int32_t read_exr(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H, 
         if ((size_t)size == want) raw.assign(src, src + want);                      // stored as is (also what the codecs fall back to when they do not shrink the block)
         else if (comp == 0) return PT_ERROR_IO;
         else if (comp == 1) { if (!exr_rle_decode(src, (size_t)size, tmp, want)) return PT_ERROR_IO; exr_unpredict_interleave(tmp, raw); }
+        else if (comp == 4) { if (!exr_piz_decode(src, (size_t)size, (size_t)w, lines, pizWords, raw) || raw.size() != want) return PT_ERROR_IO; }
         else { tmp.resize(want); uLongf got = (uLongf)want; if (uncompress(tmp.data(), &got, src, (uLong)size) != Z_OK || got != want) return PT_ERROR_IO; exr_unpredict_interleave(tmp, raw); }
         for (size_t l = 0; l < lines; l++) {
             const unsigned char* line = raw.data() + l * lineBytes; float* o = &rgb[((size_t)(y0 + (long long)l) * (size_t)w) * 3];

@@ -37,8 +37,125 @@ def _exr_rle(data):
     return bytes(out)
 
 
+# ---- a PIZ encoder for the tests (OpenEXR's ImfPizCompressor / ImfHuf / ImfWav, encode side, written independently of the decoder in pt_hdrimage.cpp): value bitmap + forward
+# lookup table, two-dimensional Haar wavelet per channel plane (14-bit or 16-bit modular arithmetic), Huffman coding with canonical codes and one run-length symbol
+def _s16(v): v &= 0xFFFF; return v - 0x10000 if v & 0x8000 else v
+
+
+def _wenc14(a, b):
+    a_, b_ = _s16(a), _s16(b); return ((a_ + b_) >> 1) & 0xFFFF, (a_ - b_) & 0xFFFF
+
+
+def _wenc16(a, b):
+    ao = (a + 0x8000) & 0xFFFF; m = (ao + b) >> 1; d = ao - b
+    if d < 0: m = (m + 0x8000) & 0xFFFF
+    return m, d & 0xFFFF
+
+
+def _wav2_encode(buf, base, nx, ox, ny, oy, mx):
+    enc = _wenc14 if mx < (1 << 14) else _wenc16
+    n = min(nx, ny); p, p2 = 1, 2
+    while p2 <= n:
+        oy1, oy2, ox1, ox2 = oy * p, oy * p2, ox * p, ox * p2
+        py = base; ey = base + oy * (ny - p2)
+        while py <= ey:
+            px = py; ex = py + ox * (nx - p2)
+            while px <= ex:
+                p01, p10 = px + ox1, px + oy1; p11 = p10 + ox1
+                i00, i01 = enc(buf[px], buf[p01]); i10, i11 = enc(buf[p10], buf[p11])
+                buf[px], buf[p10] = enc(i00, i10); buf[p01], buf[p11] = enc(i01, i11)
+                px += ox2
+            if nx & p:
+                p10 = px + oy1; buf[px], buf[p10] = enc(buf[px], buf[p10])
+            py += oy2
+        if ny & p:
+            px = py; ex = py + ox * (nx - p2)
+            while px <= ex:
+                p01 = px + ox1; buf[px], buf[p01] = enc(buf[px], buf[p01]); px += ox2
+        p, p2 = p2, p2 << 1
+
+
+class _Bits:
+    def __init__(self): self.out = bytearray(); self.c = 0; self.lc = 0; self.n = 0
+
+    def put(self, nbits, bits):
+        self.c = (self.c << nbits) | bits; self.lc += nbits; self.n += nbits
+        while self.lc >= 8: self.lc -= 8; self.out.append((self.c >> self.lc) & 0xFF)
+        self.c &= (1 << self.lc) - 1
+
+    def flush(self):
+        if self.lc: self.out.append((self.c << (8 - self.lc)) & 0xFF); self.c = 0; self.lc = 0
+        return bytes(self.out)
+
+
+def _huf_compress(words, use_runs=True):
+    import heapq
+    freq = {}
+    for v in words: freq[v] = freq.get(v, 0) + 1
+    im = min(freq); iM = max(freq) + 1; freq[iM] = 1                      # the run-length symbol
+    heap = [(f, i, (s,)) for i, (s, f) in enumerate(sorted(freq.items()))]; heapq.heapify(heap); length = {s: 0 for s in freq}; k = len(heap)
+    if len(heap) == 1: length[heap[0][2][0]] = 1
+    while len(heap) > 1:
+        f1, _, s1 = heapq.heappop(heap); f2, _, s2 = heapq.heappop(heap)
+        for s_ in s1 + s2: length[s_] += 1
+        heapq.heappush(heap, (f1 + f2, k, s1 + s2)); k += 1
+    assert max(length.values()) <= 58
+    # canonical codes from the lengths alone (hufCanonicalCodeTable)
+    n = [0] * 59
+    for s_ in range(65537): n[length.get(s_, 0)] += 1
+    c = 0
+    for i in range(58, 0, -1): nc = (c + n[i]) >> 1; n[i] = c; c = nc
+    code = {}
+    for s_ in range(im, iM + 1):
+        l = length.get(s_, 0)
+        if l: code[s_] = n[l]; n[l] += 1
+    tb = _Bits(); s_ = im                                                 # hufPackEncTable: 6-bit lengths, zero runs
+    while s_ <= iM:
+        l = length.get(s_, 0)
+        if l == 0:
+            z = 1
+            while s_ + z <= iM and z < 255 + 6 and length.get(s_ + z, 0) == 0: z += 1
+            if z >= 2:
+                if z >= 6: tb.put(6, 63); tb.put(8, z - 6)
+                else: tb.put(6, 59 + z - 2)
+                s_ += z; continue
+        tb.put(6, l); s_ += 1
+    table = tb.flush()
+    db = _Bits(); i = 0; nw = len(words)
+    while i < nw:
+        v = words[i]; r = 0
+        while use_runs and i + r + 1 < nw and words[i + r + 1] == v and r < 255: r += 1
+        if r and length[v] + length[iM] + 8 < length[v] * r:
+            db.put(length[v], code[v]); db.put(length[iM], code[iM]); db.put(8, r)
+        else:
+            for _ in range(r + 1): db.put(length[v], code[v])
+        i += r + 1
+    nbits = db.n; data = db.flush()
+    return struct.pack("<IIIII", im, iM, len(table), nbits, 0) + table + data
+
+
+def _piz_block(lines, names, chans, use_runs=True):
+    """lines: the y range of the block; returns the PIZ payload (or the raw bytes when PIZ does not shrink them)"""
+    raw = b"".join(chans[n][y].tobytes() for y in lines for n in names)
+    planes = []                                                            # channel after channel: [y][x][16-bit words of the pixel]
+    for n in names: planes.append(np.concatenate([np.frombuffer(chans[n][y].tobytes(), np.uint16) for y in lines]))
+    allw = np.concatenate(planes)
+    present = np.zeros(65536, bool); present[allw] = True
+    bitmap = np.packbits(present, bitorder="little")
+    present[0] = True; fwd = np.cumsum(present) - 1; maxv = int(fwd[-1])   # zero is always in the table
+    nz = np.nonzero(bitmap)[0]; lo, hi = (int(nz[0]), int(nz[-1])) if nz.size else (8191, 0)
+    buf = [int(v) for v in fwd[allw]]; base = 0; w = chans[names[0]].shape[1]
+    for n, pl in zip(names, planes):
+        wk = 1 if chans[n].dtype == np.float16 else 2
+        for j in range(wk): _wav2_encode(buf, base + j, w, wk, len(lines), w * wk, maxv)
+        base += pl.size
+    huf = _huf_compress(buf, use_runs)
+    out = struct.pack("<HH", lo, hi) + (bitmap[lo:hi + 1].tobytes() if lo <= hi else b"") + struct.pack("<i", len(huf)) + huf
+    return out if len(out) < len(raw) else raw
+
+
 def write_exr(path, chans, comp, origin=(0, 0), version=2, extra_attrs=b""):
-    """chans: {name: float32 or float16 array [h, w]}; comp: 0 none, 1 RLE, 2 ZIPS, 3 ZIP"""
+    """chans: {name: float32 or float16 array [h, w]}; comp: 0 none, 1 RLE, 2 ZIPS, 3 ZIP, 4 PIZ"""
     names = sorted(chans); h, w = chans[names[0]].shape
     chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 1 if chans[n].dtype == np.float16 else 2, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
     x0, y0 = origin
@@ -46,11 +163,12 @@ def write_exr(path, chans, comp, origin=(0, 0), version=2, extra_attrs=b""):
         _attr("dataWindow", "box2i", struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)) + _attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + \
         _attr("lineOrder", "lineOrder", b"\0") + _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + \
         _attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + extra_attrs + b"\0"
-    lpb = 16 if comp == 3 else 1
+    lpb = 16 if comp == 3 else (32 if comp == 4 else 1)
     blocks = []
     for yb in range(0, h, lpb):
         raw = b"".join(chans[n][y].tobytes() for y in range(yb, min(h, yb + lpb)) for n in names)
         if comp == 0: data = raw
+        elif comp == 4: data = _piz_block(range(yb, min(h, yb + lpb)), names, chans)
         else:
             t = _exr_transform(raw); data = _exr_rle(t) if comp == 1 else zlib.compress(t)
             if len(data) >= len(raw): data = raw
@@ -105,6 +223,40 @@ def test_exr_round_trip(tmp_path, comp, dtype):
     assert got.shape == (h, w, 3) and np.array_equal(got, img.astype(np.float32))
 
 
+@pytest.mark.parametrize("case", ["half_runs", "float_noise", "half_16bit_wavelet", "tiny", "one_line_blocks"])
+def test_exr_piz_round_trip(tmp_path, case):
+    """PIZ (compression 4, 32-line blocks): the decoder in pt_hdrimage.cpp against the independent encoder above — flat regions (the run-length symbol), fp32 channels (two 16-bit
+    planes per pixel), a block with more than 2^14 distinct values (the 16-bit wavelet), images smaller than the wavelet's first level, a height that leaves a one-line last block."""
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    if case == "half_runs":
+        h, w = 70, 45; img = (rng.random((h, w, 3), np.float32) ** 2 * 30.0).astype(np.float16); img[10:50, 5:40] = np.float16(0.75); extra = {"A": np.ones((h, w), np.float16)}
+    elif case == "float_noise":
+        h, w = 40, 33; img = (rng.random((h, w, 3), np.float32) * 1e3).astype(np.float32); extra = {"Z": rng.random((h, w), np.float32)}
+    elif case == "half_16bit_wavelet":
+        h, w = 33, 700; img = rng.integers(0, 0x7BFF, (h, w, 3)).astype(np.uint16).view(np.float16); extra = {}
+    elif case == "tiny":
+        h, w = 3, 2; img = (rng.random((h, w, 3), np.float32)).astype(np.float16); extra = {}
+    else:
+        h, w = 65, 17; img = (rng.random((h, w, 3), np.float32) * 4.0).astype(np.float16); img[:, 3:9] = np.float16(2.0); extra = {}
+    chans = {"R": img[..., 0], "G": img[..., 1], "B": img[..., 2]}; chans.update(extra)
+    path = tmp_path / "p.exr"; write_exr(path, chans, 4, origin=(2, -5))
+    raw_size = sum(c.nbytes for c in chans.values())
+    if case == "half_runs": assert os.path.getsize(path) < raw_size      # the blocks really are PIZ-coded, not stored
+    got = pt.read_float_image(path)
+    assert got.shape == (h, w, 3) and np.array_equal(got.view(np.uint32), img.astype(np.float32).view(np.uint32))
+
+
+def test_exr_piz_damaged_blocks_fail_cleanly(tmp_path):
+    rng = np.random.default_rng(5); h, w = 40, 30
+    img = (rng.random((h, w, 3), np.float32) * 8.0).astype(np.float16); img[:, :10] = np.float16(1.0)
+    path = tmp_path / "p.exr"; write_exr(path, {"R": img[..., 0], "G": img[..., 1], "B": img[..., 2]}, 4)
+    d = bytearray(open(path, "rb").read())
+    for k in range(40):      # flip bytes inside the coded data: an error code or a (wrong) picture, never a crash
+        e = bytearray(d); e[len(e) - 1 - int(rng.integers(0, len(e) // 2))] ^= int(rng.integers(1, 256)); q = tmp_path / ("d%d.exr" % k); open(q, "wb").write(bytes(e))
+        try: pt.read_float_image(q)
+        except pt.PtError: pass
+
+
 def test_exr_luminance_only_and_long_names(tmp_path):
     y = np.linspace(0, 4, 20 * 8, dtype=np.float32).reshape(8, 20).astype(np.float16)
     write_exr(tmp_path / "y.exr", {"Y": y}, 2, version=2 | 0x400)
@@ -128,9 +280,9 @@ def test_refused_files(tmp_path):
     def code(path):
         with pytest.raises(pt.PtError) as e: pt.read_float_image(path)
         return e.value.code
-    write_exr(tmp_path / "piz.exr", {"R": img, "G": img, "B": img}, 0); d = bytearray(open(tmp_path / "piz.exr", "rb").read())
-    i = d.index(b"compression\0compression\0") + 24 + 4; d[i] = 4; open(tmp_path / "piz.exr", "wb").write(d)
-    assert code(tmp_path / "piz.exr") == 5                  # PT_ERROR_UNSUPPORTED
+    write_exr(tmp_path / "pxr24.exr", {"R": img, "G": img, "B": img}, 0); d = bytearray(open(tmp_path / "pxr24.exr", "rb").read())
+    i = d.index(b"compression\0compression\0") + 24 + 4; d[i] = 5; open(tmp_path / "pxr24.exr", "wb").write(d)      # PXR24 (B44, DWA likewise): lossy codecs nobody keeps radiance in
+    assert code(tmp_path / "pxr24.exr") == 5                # PT_ERROR_UNSUPPORTED
     write_exr(tmp_path / "tiled.exr", {"R": img, "G": img, "B": img}, 0, version=2 | 0x200); assert code(tmp_path / "tiled.exr") == 5
     write_exr(tmp_path / "multi.exr", {"R": img, "G": img, "B": img}, 0, version=2 | 0x1000); assert code(tmp_path / "multi.exr") == 5
     write_exr(tmp_path / "nocolour.exr", {"Z": img.astype(np.float32)}, 0); assert code(tmp_path / "nocolour.exr") == 5
