@@ -1,18 +1,12 @@
-// mi355pt — cooperative BVH8 traversal for wave64: a wave carries 16 rays, each owned by a QUAD of lanes; lane q of a quad tests
-// children 2q and 2q+1 of the current 128-byte node (one cache-line lookup per node per ray), the hit children are ranked by entry
-// distance with quad-permute DPP compares, the nearest is followed directly and the rest go to the quad's stack in LDS (deep entries
-// spill to a global-memory tail). Leaves hand their triangles (up to 4 by default: one round; up to 8: two) to the 4 lanes. Quads refill independently from
-// the wave's 64-ray chunk (persistent threads), so a long ray never holds 63 idle lanes hostage. Replaces RayQuery::TraceRayInline /
-// the DXR any-hit visibility query (PathTracerBridgeDonut.hlsli:993-1055). Results are traversal-order free (min t, ties to the lower
-// primitive id).
+// mi355pt — cooperative BVH8 traversal for wave64: what the traversal kernel (pt_traverse8p.h: two lanes per ray, 32 rays per wave) shares with its callers — counters, tuning
+// constants, the candidate's box test, DPP helpers and the description of the template interface. Replaces RayQuery::TraceRayInline / the DXR any-hit visibility query
+// (PathTracerBridgeDonut.hlsli:993-1055). Results are traversal-order free (min t, ties to the lower primitive id).
 //
-// How the shape was arrived at on MI355X (profiles/r01a_*, r01b_*):
+// How the shape was arrived at on MI355X (profiles/r01a_*, r01b_*, r03s_*):
 //  * one ray per lane over BVH2 was bound by divergent 16-byte gathers through the per-CU texture-address path (33 % L2 misses but only
 //    ~0.4 TB/s of HBM traffic): 4 line lookups per lane per node. Cooperative 128 B nodes cut line lookups per ray by ~6-9x.
-//  * 8 lanes per ray / 1 child per lane then turned out VALU-issue bound: at 6 waves per SIMD SQ_ACTIVE_INST_VALU covers 93 % of the
-//    kernel time, and halving the occupancy (profiles/r01b_occupancy_experiment.txt) showed the latency side saturating exactly there.
-//    Every per-ray scalar (addresses, stack, control) is replicated over the lanes of its group, so the cure is fewer lanes per ray:
-//    4 lanes x 2 children per lane keeps the one-line-per-node access pattern and halves the replicated work.
+//  * 8 lanes per ray / 1 child per lane then turned out VALU-issue bound: every per-ray scalar (addresses, stack, control) is replicated over the lanes of its
+//    group, so the cure is fewer lanes per ray: 4 lanes x 2 children per lane (rounds 1-3), then 2 lanes x 4 children (round 3 on; the four-lane kernel is in the history).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pt_scene.h"

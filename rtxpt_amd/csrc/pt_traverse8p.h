@@ -1,14 +1,14 @@
 // mi355pt — cooperative BVH8 traversal for wave64, two lanes per ray: a wave carries 32 rays, each owned by a PAIR of lanes; lane h of a pair tests
 // children 4h .. 4h + 3 of the current 128-byte node (48 contiguous bytes: three 16-byte loads) and triangle h of a leaf.
 //
-// Why pairs (round 3): with four lanes per ray (pt_traverse8.h) the loop is VALU-issue bound at 8 waves per SIMD — extra v_nop slots lengthen k_extend one
+// Why pairs (round 3): with four lanes per ray (the kernel of rounds 1-3, in the history) the loop is VALU-issue bound at 8 waves per SIMD — extra v_nop slots lengthen k_extend one
 // for one (profiles/r03i_valu_bound_probe.txt) — and a wave64 VALU instruction costs its four cycles whatever the lanes do. Of the ~325 VALU instructions of an
 // average wave iteration only the slab tests (~50) and the triangle tests (~110 when the leaf block runs) are work that belongs to a child or a triangle;
 // the rest — refill, child ranking, stack, slot bookkeeping, the alpha test's addressing, the hit reduction — is per-RAY work that every lane of the ray's
 // group repeats. Two lanes per ray halve the replicated share per ray: per lane the slab and triangle work doubles (four children, two triangle rounds), per
 // wave iteration the instruction count rises by about a third, and the iteration advances 32 rays instead of 16.
-// Same interface, same results as traverse8_persistent (the closest hit is traversal-order free: min t, ties to the lower primitive id; an occlusion query
-// reports whether any accepted hit exists), same straggler splitting; see pt_traverse8.h for the description of Src / Dst / Pub and of the template flags.
+// The closest hit is traversal-order free (min t, ties to the lower primitive id); an occlusion query reports whether any accepted hit exists. Straggler splitting, Src / Dst / Pub
+// and the template flags: pt_traverse8.h.
 #pragma once
 #include "pt_traverse8.h"
 

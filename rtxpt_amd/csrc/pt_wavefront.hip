@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
 }
 
 #ifndef T8_ADAPTIVE_CHUNKS
-#define T8_ADAPTIVE_CHUNKS 1        // 1: launches below (resident waves x 64) rays use shorter chunks (see traverse8_persistent), 0: always 64 rays per chunk
+#define T8_ADAPTIVE_CHUNKS 1        // 1: launches below (resident waves x 64) rays use shorter chunks (see traverse8_pairs), 0: always 64 rays per chunk
 #endif
 // rays per chunk of a traversal launch: the waves the GPU can hold (256 CUs x 4 SIMDs x 8 waves) should cover the launch in one go, 16 .. 64 rays each, in steps of 16
 static inline uint rays_per_chunk(uint count) {

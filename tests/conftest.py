@@ -18,6 +18,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "tail_once(configuration): in a module of TAIL_BOTH_WAYS, run this test in the named tail-kernel configuration only")
 
 
 @pytest.fixture(scope="session")
@@ -35,7 +36,8 @@ def golden():
 
 def pytest_generate_tests(metafunc):
     if metafunc.module.__name__.split(".")[-1] in TAIL_BOTH_WAYS and "tail_configuration" in metafunc.fixturenames:
-        metafunc.parametrize("tail_configuration", ["tail_off", "tail_default"], indirect=True)
+        once = metafunc.definition.get_closest_marker("tail_once")      # @pytest.mark.tail_once("tail_default"): a long test that runs in ONE configuration (the named one)
+        metafunc.parametrize("tail_configuration", [once.args[0]] if once else ["tail_off", "tail_default"], indirect=True)
 
 
 @pytest.fixture(autouse=True)

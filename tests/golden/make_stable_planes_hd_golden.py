@@ -41,8 +41,8 @@ def setup(key):
         prm = scenes.stable_planes_params(W, H, scenes.view_projection(W, H, **cam), sub_samples=SUBS, **kw)
     else:
         base = spc.motion_cases()[name] if kind == "motion" else name
-        lp16, over, kw = spc.cases()[base]
-        sc, cam = scenes.stable_planes_zoo(); S = scenes.config_settings("C2")
+        lp16, over, kw = spc.cases()[base][:3]
+        sc, cam = scenes.stable_planes_zoo(*spc.cases()[base][3:]); S = scenes.config_settings("C2")
         for k, v in over.items(): S[k] = v
         if lp16: S["useFp16Types"] = 1
         prev = dict(cam); prev["pos"] = tuple(np.asarray(cam["pos"]) + np.array([0.03, 0.01, 0.02]))
