@@ -212,6 +212,10 @@ int32_t pt_set_environment_compression(pt_context* ctx, uint32_t quality);
  * pt_set_environment_bake takes. AngularSize is raised to pi / (cubeDim / 2) (smaller discs cannot be drawn into the cube), Direction is taken into the
  * environment's local frame with params->Transform (NULL: identity) so the disc keeps its world direction under an environment rotation. No device needed. */
 int32_t pt_env_bake_lights(const PtEnvDirectionalLight* worldLights, uint32_t numLights, const PtEnvMapSceneParams* params, uint32_t cubeDim, PtEnvDirectionalLight* out);
+/* The same step inside the library, for directional lights that belong to the LOADED SCENE (pt_load_scene_gltf hands a file's KHR_lights_punctual directional lights over this way):
+ * world-space records, converted with pt_env_bake_lights' arithmetic at every cube bake — with that bake's cube size and the environment's current orientation — and drawn into the
+ * cube after the lights of pt_set_environment_bake (16 in all). n = 0 removes them. */
+int32_t pt_set_scene_directional_lights(pt_context* ctx, const PtEnvDirectionalLight* worldLights, uint32_t numLights);
 /* The procedural sky as the cube's source (EnvMapBaker.cpp:372-375, 422, 454-470, 516-533; EnvMapBaker.hlsl:228-236, 247-265; SampleProceduralSky.hlsli,
  * precomputed_sky.hlsli): with it the base layer adds ProceduralSky() — Bruneton's precomputed atmosphere, the sun disc and ray-marched clouds from a half-resolution
  * pre-pass cube — to whatever pt_set_environment's image (none: black) and the directional lights give. The constants are the shader's own constant block; the

@@ -32,7 +32,7 @@ EXPORTS = [
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
     "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_set_stream_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_exchange_planes_host", "pt_neeat_update_begin", "pt_neeat_update_end", "pt_pack_stable_plane_guides", "pt_unpack_stable_plane_guides", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
-    "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_vertices", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
+    "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_vertices", "pt_set_scene_directional_lights", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
     "pt_stable_planes_plane_stride", "pt_build_stable_planes", "pt_fill_stable_planes", "pt_denoise_spec_hit_t", "pt_stable_planes_merge", "pt_get_stable_planes",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host", "pt_neeat_exchange_host",

@@ -96,7 +96,8 @@ struct pt_context {
     std::vector<GeometryDesc> geometries; std::vector<MeshDesc> meshes; std::vector<InstanceDesc> instances;
     std::vector<ptk::PTMaterialData> materials; std::vector<HostTexture> textures; HostTexture envTex; bool envEnabled = false;
     float3x4 envToWorld, envToLocal; ptk::float3 envColorMul;
-    uint envCubeDim = 2048; std::vector<ptk::EnvDirectionalLight> envDirLights; bool envCubeDirty = true; ptk::EnvCube envCube;      // EnvMapBaker state (pt_set_environment_bake)
+    uint envCubeDim = 2048; std::vector<ptk::EnvDirectionalLight> envDirLights, sceneDirLights; bool envCubeDirty = true;      // sceneDirLights: world-space lights of the loaded scene (pt_set_scene_directional_lights), converted at bake time
+    ptk::EnvCube envCube;      // EnvMapBaker state (pt_set_environment_bake)
     std::vector<PolymorphicLightInfoFull> analyticLights;
     std::vector<SubInstanceData> subInstances; std::vector<ptk::uint2> subInstToInstGeom; std::vector<ptk::uint2> primInfo; std::vector<uint> subInstFirstPrim;
     std::vector<ptk::PolymorphicLightInfo> lights; std::vector<ptk::PolymorphicLightInfoEx> lightsEx; std::vector<uint> envLookup; uint envLookupDim = 0; uint numProxies = 0, envLightsBaked = 0;      // (light weights / proxy table live on the device only)
@@ -524,14 +525,23 @@ int bake_env_cube(pt_context* c) {
     ptk::EnvCube& e = c->envCube; memset(&e, 0, sizeof(e)); e.dim = c->envCubeDim; e.mipLevels = ptk::env_cube_mip_levels(e.dim);
     size_t total = 0; for (uint l = 0; l < e.mipLevels; l++) { e.mipOffset[l] = (uint)total; total += 6ull * (e.dim >> l) * (e.dim >> l); }
     PT_CHECK_HIP(c, c->dEnvCube.resize(total));
-    PT_CHECK_HIP(c, c->dEnvDirLights.upload(c->envDirLights, c->stream));
+    // the lights drawn into the cube: what the host handed over in the environment's frame (pt_set_environment_bake), then the loaded scene's own directional lights, taken there by
+    // Sample::UpdateLighting's step (pt_env_bake_lights) with THIS bake's cube size and the environment's current orientation; EMB_MAXDIRLIGHTS in all
+    std::vector<ptk::EnvDirectionalLight> dirLights = c->envDirLights;
+    if (!c->sceneDirLights.empty()) {
+        PtEnvMapSceneParams prm; memset(&prm, 0, sizeof(prm)); memcpy(prm.Transform, c->envToWorld.m, 48); prm.Enabled = 1.f;
+        std::vector<ptk::EnvDirectionalLight> conv(c->sceneDirLights.size());
+        if (pt_env_bake_lights(reinterpret_cast<const PtEnvDirectionalLight*>(c->sceneDirLights.data()), (uint32_t)conv.size(), &prm, e.dim, reinterpret_cast<PtEnvDirectionalLight*>(conv.data())) != PT_OK) return fail(c, PT_ERROR_INVALID_ARGUMENT, "scene directional lights");
+        for (auto& l : conv) if (dirLights.size() < 16u) dirLights.push_back(l);
+    }
+    PT_CHECK_HIP(c, c->dEnvDirLights.upload(dirLights, c->stream));
     if (c->skyEnabled) {          // constants + texture views for the kernels, and room for the half-resolution cloud pre-pass
         ptk::ProceduralSkyContext h = c->sky; h.Transmittance.texels = c->dSkyTex[0].p; h.Scatter.texels = c->dSkyTex[1].p; h.Irradiance.texels = c->dSkyTex[2].p; h.Clouds.texels = c->dSkyTex[3].p;
         PT_CHECK_HIP(c, c->dSky.resize(1)); PT_CHECK_HIP(c, hipMemcpyAsync(c->dSky.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream)); PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // (h is a local)
         PT_CHECK_HIP(c, c->dSkyLowRes.resize(6ull * (e.dim / 2u) * (e.dim / 2u)));
     }
     refresh_scene_view(c);
-    launch_env_cube_bake(c->dsc, c->dEnvDirLights.p, (uint)c->envDirLights.size(), c->dEnvCube.p, c->dsc.envCube, c->stream);
+    launch_env_cube_bake(c->dsc, c->dEnvDirLights.p, (uint)dirLights.size(), c->dEnvCube.p, c->dsc.envCube, c->stream);
     if (c->envCompression) {          // EnvMapBaker.cpp:593-633: the path tracer samples the BC6H cube, the importance baker keeps the uncompressed one
         PT_CHECK_HIP(c, c->dEnvCubeSource.resize(total));
         PT_CHECK_HIP(c, hipMemcpyAsync(c->dEnvCubeSource.p, c->dEnvCube.p, sizeof(ptk::uint2) * total, hipMemcpyDeviceToDevice, c->stream));
@@ -839,6 +849,13 @@ int32_t pt_set_environment_bake(pt_context* c, uint32_t cubeDim, const PtEnvDire
     if (cubeDim) c->envCubeDim = cubeDim;
     static_assert(sizeof(PtEnvDirectionalLight) == sizeof(ptk::EnvDirectionalLight), "EnvDirectionalLight layout");
     c->envDirLights.resize(n); if (n) memcpy(c->envDirLights.data(), lights, sizeof(ptk::EnvDirectionalLight) * n);
+    c->envCubeDirty = true; c->lightsDirty = true;
+    return PT_OK;
+}
+int32_t pt_set_scene_directional_lights(pt_context* c, const PtEnvDirectionalLight* worldLights, uint32_t n) {
+    if (!c || (!worldLights && n)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
+    if (n > 16u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "at most 16 directional lights are baked into the environment cube (EnvMapBaker.hlsl: EMB_MAXDIRLIGHTS)");
+    c->sceneDirLights.resize(n); if (n) memcpy(c->sceneDirLights.data(), worldLights, sizeof(ptk::EnvDirectionalLight) * n);
     c->envCubeDirty = true; c->lightsDirty = true;
     return PT_OK;
 }
@@ -1239,6 +1256,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.k = k; t.k.sc = t.sc;
         t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + PASS_COUNTERS * b;
         t.aux.maxBlocks = (numBatches >= 3u) ? 256u * 7u : 0u;      // pipelined batches: one GPU-full of blocks each (pt_scene.h PT_T8_MAX_BLOCKS)
+        { static const uint blocksOverride = []() { const char* e = getenv("MI355PT_MAX_BLOCKS"); return e ? (uint)strtoul(e, nullptr, 10) : 0u; }(); if (blocksOverride) t.aux.maxBlocks = blocksOverride; }      // developer A/B switch
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
         t.timed = c->serialKernels || c->countersEnabled || getenv("MI355PT_PASS_LOG") != nullptr;
         t.genPos = t.total < streamK ? t.total : streamK;

@@ -617,8 +617,8 @@ static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path) {
     if (r != PT_OK) return r;
     r = pt_set_instances(ctx, L.instances.data(), (uint32_t)L.instances.size());
     if (r != PT_OK) return r;
-    // KHR_lights_punctual: point / spot lights become the context's analytic lights (what LightsBaker collects from the scene graph), directional ones the environment baker's list
-    // (drawn into the cube at the next bake; cube size kept). A file without the extension leaves both as the host set them.
+    // KHR_lights_punctual: point / spot lights become the context's analytic lights (what LightsBaker collects from the scene graph), directional ones the scene's list for the
+    // environment bake (pt_set_scene_directional_lights: Sample::UpdateLighting's conversion runs at bake time). A file without the extension leaves both as the host set them.
     std::vector<PtAnalyticLightDesc> analytic; std::vector<PtEnvDirectionalLight> directional;
     for (const Loader::PunctualRaw& l : L.punctual) Loader::emit_punctual(l, m4_identity(), analytic, directional);
     if (!analytic.empty()) {
@@ -626,7 +626,7 @@ static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path) {
         for (size_t i = 0; i < analytic.size(); i++) { r = pt_convert_light(&analytic[i], &base[i], &ex[i]); if (r != PT_OK) return r; }
         r = pt_set_lights(ctx, base.data(), ex.data(), (uint32_t)base.size()); if (r != PT_OK) return r;
     }
-    if (!directional.empty()) { r = pt_set_environment_bake(ctx, 0u, directional.data(), (uint32_t)std::min<size_t>(directional.size(), 16)); if (r != PT_OK) return r; }
+    if (!directional.empty()) { r = pt_set_scene_directional_lights(ctx, directional.data(), (uint32_t)std::min<size_t>(directional.size(), 16)); if (r != PT_OK) return r; }
     return PT_OK;
 }
 

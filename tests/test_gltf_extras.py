@@ -11,6 +11,7 @@ import struct
 import sys
 
 import numpy as np
+import pytest
 
 import rtxpt_amd as pt
 from rtxpt_amd import scenes
@@ -130,4 +131,58 @@ def test_texture_transform_is_read_past(tmp_path):
     media, sc = _folder(tmp_path, patch)
     imp = pt.SceneImport(media / "t.scene.json")      # (the texture index names no texture: "not loaded", as for any missing image; the transform changes nothing)
     assert imp.info["numGeometries"] == len(sc["geometries"])
+    imp.close()
+
+
+@pytest.mark.gpu
+def test_gltf_punctual_lights_reach_the_context(tmp_path):
+    """pt_load_scene_gltf on a file with KHR_lights_punctual: the frame equals, bit for bit, the frame of the same scene with the same lights handed over by hand — the point / spot records
+    through pt_set_lights (scene dict key "lights"), the directional light through Sample::UpdateLighting's host step (pt_env_bake_lights) into pt_set_environment_bake — under a ROTATED
+    environment, so that the conversion the library performs at bake time (pt_set_scene_directional_lights) is seen to use the environment's orientation and the bake's cube size."""
+    import ctypes
+    q = (math.sin(0.4), 0.0, 0.0, math.cos(0.4))
+    media = tmp_path / "m"; media.mkdir()
+    sc, cam = scenes.cornell_box("C2")
+    path = media / "lit.gltf"; write_gltf(sc, str(path))
+    doc = json.loads(path.read_text())
+    doc["extensions"] = {"KHR_lights_punctual": {"lights": [{"type": "point", "color": [1.0, 0.6, 0.3], "intensity": 3.0}, {"type": "spot", "intensity": 8.0, "spot": {"innerConeAngle": 0.3, "outerConeAngle": 0.7}},
+                                                             {"type": "directional", "color": [0.9, 0.95, 1.0], "intensity": 2.0}]}}
+    n0 = len(doc["nodes"])
+    doc["nodes"] += [{"name": "bulb", "translation": [0.2, 0.4, 0.2], "extensions": {"KHR_lights_punctual": {"light": 0}}},
+                     {"name": "spot", "translation": [0.3, 0.5, 0.1], "rotation": list(q), "extensions": {"KHR_lights_punctual": {"light": 1}}},
+                     {"name": "sun", "rotation": list(q), "extensions": {"KHR_lights_punctual": {"light": 2}}}]
+    doc["scenes"][0]["nodes"] += [n0, n0 + 1, n0 + 2]
+    path.write_text(json.dumps(doc))
+    (media / "c.scene.json").write_text(json.dumps({"models": ["lit.gltf"], "graph": [{"model": 0}]}))
+    imp = pt.SceneImport(media / "c.scene.json")
+    assert imp.info["numLights"] == 2 and imp.directional_lights.shape[0] == 1
+    S = scenes.config_settings("C2"); w, h = 160, 96
+    camd = scenes.bridge_camera(w, h, **cam)
+    rgb, tw, cm = sc["env"]
+    c_, s_ = math.cos(0.7), math.sin(0.7)
+    rot = np.array([c_, 0, s_, 0, 0, 1, 0, 0, -s_, 0, c_, 0], np.float32)      # the environment rotated about y
+    prm = pt.PtEnvMapSceneParams((ctypes.c_float * 12)(*rot.tolist()), (ctypes.c_float * 3)(*(cm * np.float32(4.0)).tolist()), 1.0)
+    CUBE = 128
+
+    def environment(t, baked_lights):
+        assert t.L.pt_set_environment(t.h, rgb.ctypes.data_as(ctypes.c_void_p), rgb.shape[1], rgb.shape[0], ctypes.byref(prm)) == 0
+        n = 0 if baked_lights is None else baked_lights.shape[0]
+        assert t.L.pt_set_environment_bake(t.h, CUBE, baked_lights.ctypes.data_as(ctypes.c_void_p) if n else None, n) == 0
+    # by hand: the imported buffers, the import object's light records, the directional light converted by the host step
+    conv = np.zeros((1, 8), np.float32); wl = np.ascontiguousarray(imp.directional_lights, np.float32)
+    f = pt.load_library().pt_env_bake_lights; f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    assert f(wl.ctypes.data_as(ctypes.c_void_p), 1, ctypes.byref(prm), CUBE, conv.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert not np.allclose(conv[0, 4:7], wl[0, 4:7])      # (the rotation does act on the direction)
+    sc2 = dict(sc); sc2["materials"] = imp.materials.copy(); sc2["lights"] = (imp.lights.copy(), imp.lights_ex.copy()); sc2["env"] = None
+    a = pt.PathTracer(); a.set_scene(sc2); environment(a, conv); a.set_camera(camd); a.set_settings(S); a.resize(w, h); a.render(0, 2)
+    # through the loader
+    b = pt.PathTracer(); environment(b, None); b.load_scene_gltf(str(path)); b.set_camera(camd); b.set_settings(S); b.resize(w, h); b.render(0, 2)
+    la, lb = a.lights(), b.lights()
+    assert np.array_equal(la["lights"], lb["lights"]) and np.array_equal(la["lightsEx"], lb["lightsEx"])
+    assert np.array_equal(a.radiance(), b.radiance())
+    # ... and the lights do something: without them the frame differs
+    sc3 = dict(sc2); sc3["lights"] = None
+    c = pt.PathTracer(); c.set_scene(sc3); environment(c, None); c.set_camera(camd); c.set_settings(S); c.resize(w, h); c.render(0, 2)
+    assert not np.array_equal(a.radiance(), c.radiance())
+    for t in (a, b, c): t.close()
     imp.close()
