@@ -63,9 +63,6 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #ifndef PT_CLASSIFY_FROM
 #define PT_CLASSIFY_FROM 65536u     // passes with fewer paths skip k_classify (class-ordered shading pays through coherence, which a handful of waves do not have)
 #endif
-#ifndef PT_EVENT_LOOP_BELOW
-#define PT_EVENT_LOOP_BELOW 0u     // pt_render calls with fewer paths than this run their batches free (polled), larger ones in lockstep (pt_render). 0 = always lockstep: measured equal or worse at every frame size (profiles/r04i_event_loop_ab.txt)
-#endif
 #ifndef PT_SP_FILL_CLASSES
 #define PT_SP_FILL_CLASSES 1     // the stable-plane fill pass shades in class order (k_classify), like reference mode; 0: queue order (A/B)
 #endif
@@ -89,7 +86,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
-    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0, eventLoopBelow = PT_EVENT_LOOP_BELOW, streamPaths = PT_STREAM_PATHS, streamBatches = PT_STREAM_BATCHES;   // second half-frame batch (pt_render pipelines two batches)
+    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0, streamPaths = PT_STREAM_PATHS, streamBatches = PT_STREAM_BATCHES;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -700,7 +697,6 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     { const char* e = getenv("MI355PT_BVH_BUILDER");        // developer A/B switch
       if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; else if (e && (!strcmp(e, "ploc_opt") || !strcmp(e, "device"))) c->bvhBuilder = BVH_BUILDER_PLOC_OPT; }
     { const char* e = getenv("MI355PT_TAIL_PATHS"); if (e) c->tailBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch (pt_set_tail_paths)
-    { const char* e = getenv("MI355PT_EVENT_LOOP_BELOW"); if (e) c->eventLoopBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch
     { const char* e = getenv("MI355PT_STREAM_PATHS"); if (e) c->streamPaths = (uint)strtoul(e, nullptr, 10); }      // developer A/B switches (pt_set_stream_paths)
     { const char* e = getenv("MI355PT_STREAM_BATCHES"); if (e) c->streamBatches = (uint)strtoul(e, nullptr, 10); }
     { const char* e = getenv("MI355PT_TAIL_DEFER"); if (e) c->tailDefer = (uint)strtoul(e, nullptr, 10); }      // test switch: iterations after which the tail kernel hands a ray back (0: T8_TAIL_DEFER); a small value sends most rays through the hand-back path
@@ -1255,7 +1251,10 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;
         t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + PASS_COUNTERS * b;
-        t.aux.maxBlocks = (numBatches >= 3u) ? 256u * 7u : 0u;      // pipelined batches: one GPU-full of blocks each (pt_scene.h PT_T8_MAX_BLOCKS)
+        // pipelined batches: one GPU-full of blocks per traversal launch (pt_scene.h PT_T8_MAX_BLOCKS) — and fewer for the launches of a small frame (one rank of a sharded frame): every wave
+        // then works through more chunks before it runs dry and fewer of its rays are cut into sub-trees; the other batches keep the GPU full. profiles/r05q_grid_cap_ab.txt:
+        // a rank of eight (4.1 M paths) 896 blocks -1 ... -3 %, a rank of four / two 1120 blocks -1 %, the full frame (33 M paths) +1 % with either: hence by size.
+        t.aux.maxBlocks = (numBatches >= 3u) ? (total < (6u << 20) ? 256u * 7u / 2u : (total < (24u << 20) ? 256u * 35u / 8u : 256u * 7u)) : 0u;
         { static const uint blocksOverride = []() { const char* e = getenv("MI355PT_MAX_BLOCKS"); return e ? (uint)strtoul(e, nullptr, 10) : 0u; }(); if (blocksOverride) t.aux.maxBlocks = blocksOverride; }      // developer A/B switch
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
         t.timed = c->serialKernels || c->countersEnabled || getenv("MI355PT_PASS_LOG") != nullptr;
@@ -1277,11 +1276,9 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     // the tail kernel takes over a batch once it holds at most this many paths (0: never). Not in serial-kernel / counter frames (their per-kernel attribution is the point), not with
     // grouped NEE samples (NEEFullSamples > 1 folds a vertex's samples in k_resolve_nee) and not without a tree (the traversal's empty-scene path is per launch, not per wave)
     const uint tailBelow = (!c->serialKernels && !c->countersEnabled && !shadowGroup && c->dsc.rootIsValid) ? c->tailBelow : 0u;
-    // Lockstep or free-running batches. In lockstep (above) a batch's next half-pass is queued when ALL batches have delivered their counts: on the full frame that keeps one batch's
-    // shading next to the others' traversal (free-running streams drift into running the same kernel at the same time: 7 % slower). A small frame — one rank of a
-    // sharded frame — has passes of a few hundred microseconds whose lengths differ between the batches, and there the wait for the slowest batch is what a stream spends a fifth of
-    // the frame on (profiles/r04h_rank8_gantt.txt: 2.8 of 14 ms). Below PT_EVENT_LOOP_BELOW paths per call the host polls the streams and serves whichever is ready.
-    const bool eventLoop = numBatches > 1 && total < c->eventLoopBelow;
+    // Batches run in lockstep: a batch's next half-pass is queued when ALL batches have delivered their counts, which keeps one batch's shading next to the others' traversal
+    // (free-running streams drift into running the same kernel at the same time: 7 % slower on the full frame and no gain on a rank of a sharded frame, DESIGN.md §4,
+    // profiles/r04i_event_loop_ab.txt).
     const bool passLog = getenv("MI355PT_PASS_LOG") != nullptr;
     bool any = true;
     while (any) {
@@ -1315,8 +1312,6 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (!t.waiting) continue;
             // a tail launch runs for about a millisecond — several of the other batches' passes: while those have wavefront passes to queue, it is only polled
             if (t.inTail && wavefrontPasses && hipStreamQuery(t.st) == hipErrorNotReady) { any = true; continue; }
-            // free-running batches (small frames, see eventLoop above): whichever batch has its counts back is serviced, the others are polled again in the next sweep
-            if (eventLoop && hipStreamQuery(t.st) == hipErrorNotReady) { any = true; continue; }
             PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
             t.waiting = false; t.inTail = false;
             uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
