@@ -437,8 +437,10 @@ int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo*
      `<media>/Materials/[<scene>/][<model>.]<material>.material.json` overrides in the reference's candidate order, through pt_material_from_json
      (a document replaces the glTF material as a whole; SkipRender removes the geometries, EnableAlphaTesting / ExcludeFromNEE set their flags).
    The file format of the graph itself and the light / camera keys belong to Donut (donut/engine/Scene.cpp, SceneGraph.cpp), which the reference
-   tree does not vendor: they are restated from Donut's published sources. DirectionalLight leaves are returned by pt_scene_import_directional_lights. Not imported: animations,
-   glTF-embedded cameras / lights, textures other than PNG, JPEG and .dds files (counted in texturesNotLoaded, the
+   tree does not vendor: they are restated from Donut's published sources. DirectionalLight leaves are returned by pt_scene_import_directional_lights. A model file's own
+   KHR_lights_punctual lights and perspective cameras hang below its model node like its meshes (lights: as the graph's leaves of the same kind; cameras: plain PerspectiveCamera
+   leaves, exposureMask bit 31, which leave the tone-mapping block alone; orthographic cameras are not listed). Not imported: animations,
+   textures other than PNG, JPEG and .dds files (counted in texturesNotLoaded, the
    material then renders untextured as when the reference fails to load one). A point / spot light's "proxyMeshNodes" (ExtendedScene.cpp:46, 246-263) are resolved
    as Donut's SceneGraph::FindNode resolves them — '/'-separated node names from the root, a model's own root node named after its file — and the mesh instances at those
    nodes come out with analyticProxyLight set (LightsBaker.cpp:718-753). The environment map is reported (envPath), not loaded: pt_image_read_float reads .exr / .hdr files for pt_set_environment (.dds is not read). NOTE: of
@@ -450,7 +452,7 @@ typedef struct PtToneMappingParameters PtToneMappingParameters;      /* defined 
 typedef struct PtSceneCameraDesc {          /* Sample::UpdateCameraFromScene inputs: LookAt(position, position + direction, up) */
     float    position[3], direction[3], up[3];
     float    verticalFov, zNear;            /* radians; Donut defaults 1.0 / 1.0 */
-    uint32_t exposureMask;                  /* bit 0 enableAutoExposure, 1 exposureCompensation, 2 exposureValue, 3 exposureValueMin, 4 exposureValueMax present */
+    uint32_t exposureMask;                  /* bit 0 enableAutoExposure, 1 exposureCompensation, 2 exposureValue, 3 exposureValueMin, 4 exposureValueMax present; bit 31: a glTF file's own camera */
     uint32_t enableAutoExposure; float exposureCompensation, exposureValue, exposureValueMin, exposureValueMax;
     char     name[64];
 } PtSceneCameraDesc;

@@ -283,6 +283,25 @@ struct Loader {
         if (r.type == 1) { const JValue* sp = l.get("spot"); r.inner = (float)((sp ? sp->numOr("innerConeAngle", 0.0) : 0.0) * (180.0 / 3.14159265358979323846)); r.outer = (float)((sp ? sp->numOr("outerConeAngle", 0.78539816339744831) : 0.78539816339744831) * (180.0 / 3.14159265358979323846)); }
         punctual.push_back(r);
     }
+    // A glTF file's own cameras (glTF 2.0 3.10): Donut's importer hangs a PerspectiveCamera leaf {verticalFov = yfov, zNear = znear} on the node (un-vendored: restated, UNPINNED), and
+    // the application lists it with the graph's other cameras (Sample.cpp:580-597). An orthographic camera is not a PerspectiveCamera and is not listed here.
+    struct CameraRaw { float yfov, znear; M4 world; std::string name; };
+    std::vector<CameraRaw> cameras;
+    void gltf_camera(int index, const M4& world, const std::string& nodeName) {
+        const JValue* cams = root.get("cameras"); if (!cams || index < 0 || (size_t)index >= cams->size()) return;
+        const JValue& c = cams->arr[index]; const JValue* pp = c.get("perspective");
+        if (c.strOr("type", "") != "perspective" || !pp) return;
+        CameraRaw r; r.yfov = (float)pp->numOr("yfov", 1.0); r.znear = (float)pp->numOr("znear", 1.0); r.world = world; r.name = c.strOr("name", nodeName.c_str());
+        cameras.push_back(r);
+    }
+    // Sample::UpdateCameraFromScene's inputs (Sample.cpp:457-463) of a camera under `parent`: position, row 2 (view direction) and row 1 (up) of scaling(1, 1, -1) * localToWorld
+    static PtSceneCameraDesc emit_camera(const CameraRaw& c, const M4& parent) {
+        const M4 w = m4_mul(parent, c.world);
+        PtSceneCameraDesc d; memset(&d, 0, sizeof(d)); d.verticalFov = c.yfov; d.zNear = c.znear; d.exposureMask = 0x80000000u;      // a plain PerspectiveCamera: no exposure keys to apply
+        for (int i = 0; i < 3; i++) { d.position[i] = (float)w.m[12 + i]; d.up[i] = (float)w.m[4 + i]; d.direction[i] = (float)-w.m[8 + i]; }
+        strncpy(d.name, c.name.c_str(), sizeof(d.name) - 1);
+        return d;
+    }
     // the records the lights become under `parent` (identity for a bare glTF file, the model node's transform in a .scene.json graph)
     static void emit_punctual(const PunctualRaw& l, const M4& parent, std::vector<PtAnalyticLightDesc>& analytic, std::vector<PtEnvDirectionalLight>& directional) {
         const M4 w = m4_mul(parent, l.world);
@@ -518,6 +537,7 @@ struct Loader {
             instances.push_back(inst); instanceWorld.push_back(world); instancePath.push_back(path);
         }
         if (const JValue* ext = n.get("extensions")) if (const JValue* lp = ext->get("KHR_lights_punctual")) punctual_light(lp->intOr("light", -1), world);
+        if (n.get("camera")) gltf_camera(n.intOr("camera", -1), world, n.strOr("name", ""));
         if (const JValue* ch = n.get("children")) for (auto& c : ch->arr) visit((int)c.num, world, depth + 1, path);
     }
 };
@@ -887,7 +907,7 @@ std::string file_stem(const std::string& path) {
     size_t dot = f.find_last_of('.'); return dot == std::string::npos ? f : f.substr(0, dot);
 }
 struct ModelSlot { bool loaded = false; int32_t status = PT_OK; uint32_t firstMesh = 0; std::vector<int> meshRemap; std::vector<uint32_t> instMesh; std::vector<M4> instWorld; std::vector<std::string> instPath;
-                   std::vector<Loader::PunctualRaw> punctual; };      // punctual: the model file's KHR_lights_punctual lights (in its own space)
+                   std::vector<Loader::PunctualRaw> punctual; std::vector<Loader::CameraRaw> cameras; };      // punctual: the model file's KHR_lights_punctual lights (in its own space)
 
 struct SceneReader {
     pt_scene_import& S; std::string sceneDir, mediaDir, sceneStem; std::vector<std::string> modelPaths; std::vector<ModelSlot> slots; int32_t err = PT_OK;
@@ -986,7 +1006,7 @@ struct SceneReader {
             if (mesh < 0) continue;
             slot.instMesh.push_back((uint32_t)mesh); slot.instWorld.push_back(L.instanceWorld[i]); slot.instPath.push_back(i < L.instancePath.size() ? L.instancePath[i] : std::string());
         }
-        slot.punctual = L.punctual; S.info.lightsDropped += L.punctualDropped;
+        slot.punctual = L.punctual; S.info.lightsDropped += L.punctualDropped; slot.cameras = L.cameras;
         S.info.numModels++;
         return slot;
     }
@@ -1011,6 +1031,7 @@ struct SceneReader {
         for (const Loader::PunctualRaw& l : slot.punctual) Loader::emit_punctual(l, world, analytic, directional);
         for (const PtAnalyticLightDesc& d : analytic) { PolymorphicLightInfo b; PolymorphicLightInfoEx e; int32_t r = pt_convert_light(&d, &b, &e); if (r != PT_OK) { err = r; return; } S.lights.push_back(b); S.lightsEx.push_back(e); }
         for (const PtEnvDirectionalLight& d : directional) { S.directionalLights.push_back(d); S.info.directionalLights++; }
+        for (const Loader::CameraRaw& c : slot.cameras) S.cameras.push_back(Loader::emit_camera(c, world));       // the model's own cameras, in scene-graph order with the graph's
     }
     // ExtendedScene::ProcessNodesRecursive (ExtendedScene.cpp:246-263) + LightsBaker::Update (LightsBaker.cpp:718-753): the mesh instance a point / spot light names in
     // "proxyMeshNodes" stands in for that light (PtInstanceDesc.analyticProxyLight). Only a path that ends at a node holding a mesh instance links, as there.
@@ -1202,7 +1223,8 @@ extern "C" int32_t pt_scene_import_tone_mapping(const pt_scene_import* S, int32_
     if (cameraIndex < 0) cameraIndex = S->info.selectedCamera;
     if (cameraIndex < 0) return PT_OK;                                                          // no camera in the scene
     if ((size_t)cameraIndex >= S->cameras.size()) return PT_ERROR_INVALID_ARGUMENT;
-    const PtSceneCameraDesc& c = S->cameras[(size_t)cameraIndex];                               // every camera leaf is a PerspectiveCameraEx (ExtendedScene.cpp:126-129)
+    const PtSceneCameraDesc& c = S->cameras[(size_t)cameraIndex];                               // a camera leaf of the graph is a PerspectiveCameraEx (ExtendedScene.cpp:126-129);
+    if (c.exposureMask & 0x80000000u) return PT_OK;                                             // a glTF file's own camera is a plain PerspectiveCamera: the cast fails, nothing is overwritten (Sample.cpp:465-466)
     ui->autoExposure = (c.exposureMask & 1u) ? c.enableAutoExposure : 0u;
     ui->exposureCompensation = (c.exposureMask & 2u) ? c.exposureCompensation : 0.0f;
     ui->exposureValue = (c.exposureMask & 4u) ? c.exposureValue : 0.0f;

@@ -27,7 +27,9 @@ __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { retur
 #define T8_HIT(ref, tn, tf) ((tn) <= (tf) * 1.0000012f)
 #endif
 // Measured and removed (history: commit af4c2b2 has the code; numbers in DESIGN.md §4): a dense leaf block (profiles/r04y_dense_leaf_ab.txt, +13 %), batched refills
-// (r04y_refill_batch_ab.txt), one pop trip per iteration (r04v_pop_once_ab.txt), two entries per pop trip, octant-ordered child slots (r04u_octant_order_ab.txt, +25 %).
+// (r04y_refill_batch_ab.txt), one pop trip per iteration (r04v_pop_once_ab.txt), two entries per pop trip, octant-ordered child slots (r04u_octant_order_ab.txt, +25 %);
+// round 5: a ray with nothing left but postponed leaves waiting one or three iterations (or for a second / fourth such ray) before it forces the leaf block — the block then runs in
+// 0.50 instead of 0.65 of the iterations and the rays take 0.63 instead of 0.58 iterations: k_extend unchanged (profiles/r05s_leaf_patience_ab.txt).
 // DEFER (with CAN_SPLIT): a dry wave keeps going for taskOut.capacity iterations (instead of T8_TAIL_ITERS), and the rays then still in flight are not cut into sub-trees,
 // only reported through publish() — the caller has them traced again elsewhere (the tail kernel, pt_tail.hip, hands their paths back to the host loop). No task queue is touched.
 template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, bool DEFER = false, class Src, class Dst, class Pub>
@@ -273,7 +275,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     const float det = (U + V) + W;
                     // no edge function negative, or none positive (pt_scene.h writes it as !((U < 0 || V < 0 || W < 0) && (U > 0 || V > 0 || W > 0)): the same boolean for numbers; a NaN
                     // ends as "no hit" either way, through t); without short-circuits: v_min3, v_max3 and three compares, no branch
-                    const bool inside = ((fminf(U, fminf(V, W)) >= 0.0f) | (fmaxf(U, fmaxf(V, W)) <= 0.0f)) & (det != 0.0f);
+                    const bool inside = (bool)(((int)(fminf(U, fminf(V, W)) >= 0.0f) | (int)(fmaxf(U, fmaxf(V, W)) <= 0.0f)) & (int)(det != 0.0f));
                     if (inside) {
                         const float T = fmaf(W, Sz * Ckz, fmaf(V, Sz * Bkz, U * (Sz * Akz)));
                         const float inv = 1.0f / det;

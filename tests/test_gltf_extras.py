@@ -124,6 +124,38 @@ def test_khr_lights_punctual(tmp_path):
     imp.close()
 
 
+def test_gltf_embedded_cameras(tmp_path):
+    """A glTF file's own perspective cameras join the graph's camera list in scene-graph order, under the model node's transform; they are plain PerspectiveCamera leaves:
+    Sample::UpdateCameraFromScene (Sample.cpp:457-478) takes pose, fov and near plane from them and leaves the tone-mapping block alone. Orthographic ones are not listed."""
+    q = (0.0, math.sin(0.4), 0.0, math.cos(0.4))      # about y
+
+    def patch(doc, blob):
+        doc["cameras"] = [{"type": "perspective", "name": "hero", "perspective": {"yfov": 0.7, "znear": 0.05, "zfar": 100.0, "aspectRatio": 1.5}},
+                          {"type": "orthographic", "orthographic": {"xmag": 1.0, "ymag": 1.0, "znear": 0.1, "zfar": 10.0}},
+                          {"type": "perspective", "perspective": {"yfov": 1.1, "znear": 0.2}}]
+        n0 = len(doc["nodes"])
+        doc["nodes"] += [{"name": "dolly", "translation": [0.0, 1.0, 2.0], "rotation": list(q), "children": [n0 + 1, n0 + 2]},
+                         {"name": "cam_a", "translation": [0.5, 0.0, 0.0], "camera": 0}, {"name": "ortho", "camera": 1}, {"name": "cam_b", "camera": 2}]
+        doc["scenes"][0]["nodes"] += [n0, n0 + 3]
+    graph = [{"name": "first", "type": "PerspectiveCameraEx", "translation": [0.0, 2.0, 0.0], "verticalFov": 0.9, "exposureCompensation": 1.5},
+             {"name": "room", "model": 0, "translation": [5.0, 0.0, 0.0], "scaling": 2.0}]
+    media, _ = _folder(tmp_path, patch, graph)
+    imp = pt.SceneImport(media / "t.scene.json")
+    W = trs_matrix((5, 0, 0), s=(2, 2, 2)); dolly = W @ trs_matrix((0, 1, 2), q)
+    cams = imp.cameras
+    assert imp.info["numCameras"] == 3 and imp.info["selectedCamera"] == 2
+    assert [bytes(c["name"]).split(b"\0")[0].decode() for c in cams] == ["first", "hero", "cam_b"]
+    for c, M, fov, zn in ((cams[1], dolly @ trs_matrix((0.5, 0, 0)), 0.7, 0.05), (cams[2], W, 1.1, 0.2)):
+        assert np.allclose(c["position"], M[:3, 3], atol=1e-6) and np.allclose(c["direction"], -M[:3, 2], atol=1e-6) and np.allclose(c["up"], M[:3, 1], atol=1e-6)
+        assert c["verticalFov"] == np.float32(fov) and c["zNear"] == np.float32(zn) and int(c["exposureMask"]) == 0x80000000
+    ui = pt.default_tone_mapping_parameters(); ui["exposureValueMin"] = -3.0
+    imp.tone_mapping(ui, camera=0)
+    assert ui["exposureCompensation"] == 1.5 and ui["exposureValueMin"] == -16.0       # a PerspectiveCameraEx: its keys, defaults for the missing ones
+    ui["exposureValueMin"] = -3.0; imp.tone_mapping(ui)                                # the selected camera is a glTF camera: only SceneLoaded's two resets
+    assert ui["exposureCompensation"] == 2.0 and ui["exposureValue"] == 0.0 and ui["exposureValueMin"] == -3.0
+    imp.close()
+
+
 def test_texture_transform_is_read_past(tmp_path):
     def patch(doc, blob):
         doc["extensionsUsed"].append("KHR_texture_transform")
