@@ -43,9 +43,6 @@ static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 #ifndef T8_LEAF_QUEUE
 #define T8_LEAF_QUEUE 3        // postponed leaves a ray may hold (1..3) before it has to wait for the wave's next leaf block (A/B: within noise on extend, -4 % on shadow)
 #endif
-#ifndef T8_LEAF_BATCH
-#define T8_LEAF_BATCH 20u        // quads (of 16) that must hold a postponed leaf before the wave runs the leaf block (17 = only when a quad is blocked; A/B in profiles/)
-#endif
 
 // the ray's reciprocal direction is the correctly rounded one of the hit definition (pt_scene.h tri_box_accepts): inner nodes and the triangle's own
 // box are then tested with the same arithmetic, which is what makes the closest hit independent of the tree (three divisions per ray, not per node)

@@ -52,7 +52,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
     const uint rpc = (uint)__builtin_amdgcn_readfirstlane((int)raysPerChunk);
     bool exhausted = (waveId * rpc >= count) || !sc.rootIsValid;
     uint* rayBuf = rayBufBase + (threadIdx.x >> 6) * (T8_CHUNK * RAY_STRIDE);
-    uint tailIters = 0u; bool waveDry = false;
+    uint tailIters = 0u, waveDry = 0u;      // wave-uniform, kept as scalars: the number of iterations since the wave found its queue empty
     if (!sc.rootIsValid && waveId == 0 && count) {            // empty scene: every ray misses
         for (uint i = lane; i < count; i += 64u) { float3 o, d; float a, b, bt; uint sr, bp; uint tag = fetch(i, o, d, a, b, sr, bt, bp); HitInfo hh; hh.t = b; hh.prim = 0xFFFFFFFFu; hh.u = hh.v = 0.f; commit(tag, hh); }
     }
@@ -72,10 +72,13 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
     // sb: the pair's stack base. The caller forms it anew for every node that pushes (stack_base(): two instructions) instead of keeping it across the loop: the loop is one
     // register short since the watertight leaf block, and the allocator's choice was to spill exactly this value — a scratch load and a full vmcnt(0) wait at every push.
     auto stack_base = [&]() -> uint2* { uint g_ = threadIdx.x >> 1; asm volatile("" : "+v"(g_)); return stackBase + g_ * BVH8_STACK_STRIDE; };
+    // the pair's stack tail in global memory (entries BVH8_STACK and up: rare). Formed where it is used, for the same reason: hoisted out of the loop, the address is the value the
+    // allocator spills.
+    auto spill_slot = [&](uint idx) -> uint2* { uint g_ = threadIdx.x >> 1; asm volatile("" : "+v"(g_)); return sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + g_) * T8_SPILL_DEPTH + (idx - BVH8_STACK)); };
     auto stackStore = [&](uint2* sb, uint idx, uint ref, uint tbits) {
         if (idx < BVH8_STACK) sb[idx] = make_uint2(ref, tbits);
         else {
-            unsigned long long* tail = reinterpret_cast<unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (idx - BVH8_STACK)));
+            unsigned long long* tail = reinterpret_cast<unsigned long long*>(spill_slot(idx));
             __builtin_nontemporal_store(((unsigned long long)tbits << 32) | ref, tail);
         }
     };
@@ -113,8 +116,8 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 }
             }
             uint avail = chunkEnd - chunkPos;
-            if (avail == 0u) { if (need) exhausted = true; waveDry = true; }
-            else {
+            if (avail == 0u) { if (need) exhausted = true; waveDry = 1u; }
+            {
                 uint rank = (uint)__popcll(needMask & ((1ull << pl) - 1ull));
                 uint n = (uint)__popcll(needMask);
                 if (need && rank < avail) {
@@ -143,7 +146,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         bool run = t8_ballot(active) != 0ull;
         if (!run) { if (t8_ballot(!exhausted) == 0ull) stop = true; }
         else if (CAN_SPLIT) {
-            if (waveDry) tailIters++;
+            tailIters += waveDry;
             if (tailIters > (DEFER ? taskOut.capacity : (uint)(TASKS ? T8_TAIL_ITERS_TASKS : T8_TAIL_ITERS))) { splitNow = true; stop = true; run = false; }
         }
         if (run) {
@@ -158,7 +161,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         const bool leafReady = active && (pend != BVH_EMPTY);
         const bool queueFull = (T8_LEAF_QUEUE == 1) ? true : ((T8_LEAF_QUEUE == 2) ? (pend1 != BVH_EMPTY) : (pend2 != BVH_EMPTY));
         const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT) && (cur == BVH_EMPTY || queueFull);
-        const bool runLeaves = ((uint)__popcll(t8_ballot(leafReady && h == 0u)) >= (uint)T8_LEAF_BATCH) || (t8_ballot(leafBlocked) != 0ull);
+        const bool runLeaves = t8_ballot(leafBlocked) != 0ull;      // (a second trigger — "n pairs hold a postponed leaf" — never paid: profiles/r05o_leaf_batch_ab.txt, r05t_refill_flat_ab.txt)
         const bool leaf = leafReady && runLeaves;
         if (COUNT && leaf && h == 0u) ctr.leafVisits++;
         T8_EVENT(2, inner); T8_EVENT(3, leaf);
@@ -334,7 +337,7 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     uint2 e;
                     if (sp < BVH8_STACK) e = stack[sp];
                     else {
-                        unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + grp) * T8_SPILL_DEPTH + (sp - BVH8_STACK))));
+                        unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(spill_slot(sp)));
                         e = make_uint2((uint)w, (uint)(w >> 32));
                     }
                     if (ANYHIT || __uint_as_float(e.y) <= bestT) { cur = e.x; break; }
