@@ -16,7 +16,7 @@ namespace ptk {
 struct Traverse8Counters { uint nodeVisits, triTests, leafVisits, iters, leafBlocks; uint ev[8]; unsigned long long cyc[4]; unsigned long long* rayIterHist; uint* longRayCount; float* longRays; };
 
 #define T8_EVENT(k, cond) do { if (COUNT) { unsigned long long m_ = t8_ballot(cond); if (m_ && lane == (uint)__ffsll((long long)m_) - 1u) ctr.ev[k]++; } } while (0)
-static const uint T8_RAY_STRIDE = 13, T8_TASK_STRIDE = 15;      // origin, shear + axes, tag, interval | best hit, (task: best primitive, start node,) the three reciprocals                                              // per-wave LDS parking lot for a chunk's rays / tasks (odd strides)
+static const uint T8_RAY_STRIDE = 13, T8_TASK_STRIDE = 15;      // origin, shear + axes, tag, interval (fixed-range launches: the slab test's byte selectors) | best hit, (task: best primitive, start node,) the three reciprocals                                              // per-wave LDS parking lot for a chunk's rays / tasks (odd strides)
 static const uint T8_RAYBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_RAY_STRIDE, T8_TASKBUF_WORDS = (T8_BLOCK / 64u) * T8_CHUNK * T8_TASK_STRIDE;
 static const uint T8_LEAF_ROUNDS = (BVH_MAX_LEAF + T8_LANES - 1u) / T8_LANES;
 

@@ -110,7 +110,11 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     const float rSz = rk2 ? riz : (rk1 ? riy : rix);
                     slot[3] = __float_as_uint((rk2 ? rd.x : (rk1 ? rd.z : rd.y)) * rSz); slot[4] = __float_as_uint((rk2 ? rd.y : (rk1 ? rd.x : rd.z)) * rSz);
                     slot[5] = rk2 ? (0u | (16u << 8) | (32u << 16)) : (rk1 ? (32u | (0u << 8) | (16u << 16)) : (16u | (32u << 8) | (0u << 16)));
-                    slot[6] = rtag; slot[7] = __float_as_uint(TASKS ? rtmax : rtmin); slot[8] = TASKS ? __float_as_uint(rbestT) : __float_as_uint(rtmax);
+                    slot[6] = rtag;
+                    if (FIXED_RANGE && !TASKS) {      // the interval's two words are free (every ray of the launch has [0, kMaxRayTravel]): they carry the byte selectors of the slab test
+                        const uint nxb = rix < 0.f ? 3u : 0u, fxb = rix < 0.f ? 0u : 3u, nyb = riy < 0.f ? 4u : 1u, fyb = riy < 0.f ? 1u : 4u, nzb = riz < 0.f ? 5u : 2u, fzb = riz < 0.f ? 2u : 5u;
+                        slot[7] = nxb | (nyb << 8) | (nzb << 16) | (fxb << 24); slot[8] = fyb | (fzb << 8);
+                    } else { slot[7] = __float_as_uint(TASKS ? rtmax : rtmin); slot[8] = TASKS ? __float_as_uint(rbestT) : __float_as_uint(rtmax); }
                     if (TASKS) { slot[9] = rbestPrim; slot[10] = rstart; }
                     slot[RAY_STRIDE - 3u] = __float_as_uint(rix); slot[RAY_STRIDE - 2u] = __float_as_uint(riy); slot[RAY_STRIDE - 1u] = __float_as_uint(riz);
                 }
@@ -126,7 +130,8 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     Sx = __uint_as_float(slot[3]); Sy = __uint_as_float(slot[4]); axes = slot[5];
                     tag = slot[6];
                     ix = __uint_as_float(slot[RAY_STRIDE - 3u]); iy = __uint_as_float(slot[RAY_STRIDE - 2u]); iz = __uint_as_float(slot[RAY_STRIDE - 1u]);
-                    {   // child bytes: q0 = lo.x lo.y lo.z hi.x (selector values 0..3), q1 = hi.y hi.z (4, 5)
+                    if (FIXED_RANGE && !TASKS) { selN = slot[7]; selF = slot[8]; }
+                    else {   // child bytes: q0 = lo.x lo.y lo.z hi.x (selector values 0..3), q1 = hi.y hi.z (4, 5)
                         const uint nxb = ix < 0.f ? 3u : 0u, fxb = ix < 0.f ? 0u : 3u, nyb = iy < 0.f ? 4u : 1u, fyb = iy < 0.f ? 1u : 4u, nzb = iz < 0.f ? 5u : 2u, fzb = iz < 0.f ? 2u : 5u;
                         selN = nxb | (nyb << 8) | (nzb << 16) | (fxb << 24); selF = fyb | (fzb << 8);
                     }
@@ -324,10 +329,12 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         if (COUNT) tc3 = __builtin_readcyclecounter();
         // ---- slot bookkeeping: a leaf reached by the descent moves to the free leaf slot; an empty node slot pops the stack
         if (active) {
-            if ((cur & BVH_LEAF_BIT) && cur != BVH_EMPTY) {
-                if (pend == BVH_EMPTY) { pend = cur; cur = BVH_EMPTY; }
-                else if (T8_LEAF_QUEUE > 1 && pend1 == BVH_EMPTY) { pend1 = cur; cur = BVH_EMPTY; }
-                else if (T8_LEAF_QUEUE > 2 && pend2 == BVH_EMPTY) { pend2 = cur; cur = BVH_EMPTY; }
+            {   // the first free leaf slot takes the leaf: compares and selects, no branches (profiles/r05u_queue_select_ab.txt)
+                const bool isLeaf = (cur & BVH_LEAF_BIT) && cur != BVH_EMPTY;
+                const bool e0 = pend == BVH_EMPTY, e1 = (T8_LEAF_QUEUE > 1) && pend1 == BVH_EMPTY, e2 = (T8_LEAF_QUEUE > 2) && pend2 == BVH_EMPTY;
+                const bool to0 = isLeaf && e0, to1 = isLeaf && !e0 && e1, to2 = isLeaf && !e0 && !e1 && e2;
+                pend = to0 ? cur : pend; pend1 = to1 ? cur : pend1; pend2 = to2 ? cur : pend2;
+                cur = (to0 || to1 || to2) ? BVH_EMPTY : cur;
             }
             if (cur == BVH_EMPTY) {
                 T8_EVENT(6, true);
