@@ -120,6 +120,9 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 }
             }
             uint avail = chunkEnd - chunkPos;
+            // Two statements, not if / else: with "queue empty -> flags, else -> take a ray" every loop-carried value of the ray is a three-way phi at the join, which the compiler
+            // lowers as a copy of the loop's registers out to temporaries and back on every pass through this block (38 v_mov). An empty queue simply makes the take condition
+            // below false (rank < 0) and the cursor advance zero (profiles/r05t_refill_flat_ab.txt: k_extend 46.2 -> 45.1 ms).
             if (avail == 0u) { if (need) exhausted = true; waveDry = 1u; }
             {
                 uint rank = (uint)__popcll(needMask & ((1ull << pl) - 1ull));
