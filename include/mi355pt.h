@@ -196,6 +196,11 @@ int32_t pt_set_materials(pt_context* ctx, const PTMaterialData* materials, uint3
  * params->ColorMultiplier is the reference's own: tint * intensity / c_envMapRadianceScale (Sample.cpp:1939-1940; the baked cube holds radiance x 1/4, so a
  * multiplier of 4 renders the image's radiance as supplied). params == NULL means identity orientation and exactly that: ColorMultiplier = 1 / c_envMapRadianceScale. */
 int32_t pt_set_environment(pt_context* ctx, const float* rgbLatLong, uint32_t width, uint32_t height, const PtEnvMapSceneParams* params);
+/* The same with a CUBE map as the source image (EnvMapBaker.cpp:399-411: a loaded texture with six array slices becomes m_loadedSourceBackgroundTextureCubemap;
+ * EnvMapBaker.hlsl:98-110 BackgroundSourceType 2: t_SrcCubemapEnvMap.SampleLevel(s_Linear, direction, 0) — e.g. a cube the reference itself saved as .dds): six faces of
+ * dim x dim RGBA float texels in D3D's face order +X -X +Y -Y +Z -Z, top row first (what pt_image_read_dds_cube returns). Kept as the RGBA16F texels a BC6H / RGBA16F file
+ * decodes to; sampled bilinearly within the face the direction looks at. One source at a time: this call replaces a lat-long image and vice versa; dim == 0 disables. */
+int32_t pt_set_environment_cube(pt_context* ctx, const float* rgbaFaces, uint32_t dim, const PtEnvMapSceneParams* params);
 /* EnvMapBaker::Update (Rtxpt/Lighting/Distant/EnvMapBaker.cpp:298-343, 425-620; EnvMapBaker.hlsl:194-246, 268-371): the path tracer and the light baker do
  * not sample the lat-long source but the RGBA16F cube the baker makes of it: cubeDim^2 x 6 texels (2048 for an image source, 0 = keep), solid-angle weighted
  * mips down to 8x8, radiance x 1/4 (c_envMapRadianceScale, Sample.cpp:88 - the host compensates in ColorMultiplier: Sample.cpp:1939-1940) clamped to the
@@ -544,10 +549,15 @@ void    pt_image_free(float* rgb);
    700-730) and Donut's TextureCache decodes them. Top mip level of a 2D .dds as RGBA8 (*format = PT_TEX_RGBA8_UNORM / PT_TEX_RGBA8_SRGB per the file's DXGI format)
    or, for R16G16B16A16_FLOAT / R32G32B32A32_FLOAT files, RGBA32F (*format = PT_TEX_RGBA32F): what PtTextureDesc takes. Block formats BC1 / BC2 / BC3 / BC4 / BC5 /
    BC7, uncompressed RGBA8 / BGRA8 / BGRX8; legacy FourCC and DX10 headers. *pixels is allocated by the library: pt_image_free((float*)pixels).
-   PT_ERROR_IO: unreadable / truncated; PT_ERROR_UNSUPPORTED: cube maps, volumes, arrays, other formats. BC6H (UF16 / SF16, all fourteen modes) decodes to
+   PT_ERROR_IO: unreadable / truncated; PT_ERROR_UNSUPPORTED: cube maps (pt_image_read_dds_cube reads those), volumes, arrays, other formats. BC6H (UF16 / SF16, all fourteen modes) decodes to
    PT_TEX_RGBA32F texels. */
 int32_t pt_image_read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);
 int32_t pt_image_read_dds_memory(const void* bytes, size_t size, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);   /* the same from memory (glTF images: MSFT_texture_dds) */
+/* a cube-map .dds as an environment source (Sample.cpp:116 lists .dds files of the environment-map folder; EnvMapBaker.cpp:399-411): the top level of all six faces of a
+   R16G16B16A16_FLOAT / R32G32B32A32_FLOAT / BC6H (UF16, SF16) cube — legacy DDSCAPS2_CUBEMAP with all faces or a DX10 header with the TEXTURECUBE flag — as
+   6 x dim x dim RGBA floats in the file's (= D3D's) face order: what pt_set_environment_cube takes. Released with pt_image_free. PT_ERROR_UNSUPPORTED: a 2D file, a partial
+   cube, cube arrays, other formats. */
+int32_t pt_image_read_dds_cube(const char* path, uint32_t* dim, float** rgbaFaces);
 /* JPEG images of glTF files (Donut's TextureCache gives them to stb_image): a baseline / extended / progressive Huffman stream of 8-bit greyscale or YCbCr (or
    Adobe-RGB) samples in memory -> RGBA8, top row first, alpha 255; *rgba8 is allocated by the library: pt_image_free((float*)rgba8). The samples are the IJG
    reference decoder's (islow IDCT, fancy up-sampling): any conforming decoder, stb_image included, may differ from another by a unit per sample.

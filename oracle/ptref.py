@@ -460,11 +460,14 @@ class Oracle:
         L.ptref_set_geometry(h, _p(sc["indices"]), sc["indices"].size, _p(sc["positions"]), _p(sc["uvs"]), _p(sc["normals"]), _p(sc["tangents"]),
                              sc["positions"].shape[0], _p(sc["geometries"]), len(sc["geometries"]), _p(sc["meshes"]), len(sc["meshes"]))
         L.ptref_set_instances(h, _p(sc["instances"]), len(sc["instances"]))
-        if sc.get("env") is not None:
-            rgb, tw, cm = sc["env"]
+        if sc.get("env") is not None or sc.get("env_cube_source") is not None:
+            rgb, tw, cm = sc["env"] if sc.get("env") is not None else sc["env_cube_source"]      # "env_cube_source": (faces float32 [6, d, d, 4], transform, colour multiplier)
             # EnvMapSceneParams::ColorMultiplier as Sample.cpp:1936-1948 fills it: tint * intensity / c_envMapRadianceScale (the cube holds radiance * 1/4)
             cm4 = (np.asarray(cm, np.float32) * np.float32(4.0)).astype(np.float32)
-            L.ptref_set_environment(h, _p(rgb), rgb.shape[1], rgb.shape[0], _p(tw), _p(cm4))
+            if sc.get("env") is not None: L.ptref_set_environment(h, _p(rgb), rgb.shape[1], rgb.shape[0], _p(tw), _p(cm4))
+            else:
+                faces = np.ascontiguousarray(rgb, np.float32); assert faces.ndim == 4 and faces.shape[0] == 6 and faces.shape[1] == faces.shape[2] and faces.shape[3] == 4
+                L.ptref_set_environment_cube(h, _p(faces), faces.shape[1], _p(tw), _p(cm4))
             dl = sc.get("env_directional_lights")
             dl = np.ascontiguousarray(dl, np.float32).reshape(-1, 8) if dl is not None else np.zeros((0, 8), np.float32)
             L.ptref_set_environment_bake(h, int(sc.get("env_cube_dim", 256)), _p(dl) if len(dl) else None, len(dl))
@@ -473,7 +476,7 @@ class Oracle:
             L.ptref_set_environment(h, None, 0, 0, None, None)
         if sc.get("sky") is not None:
             self.set_procedural_sky(sc["sky"]["consts"], sc["sky"].get("textures"))
-            if sc.get("env") is None: L.ptref_set_environment_bake(h, int(sc.get("env_cube_dim", 256)), None, 0)
+            if sc.get("env") is None and sc.get("env_cube_source") is None: L.ptref_set_environment_bake(h, int(sc.get("env_cube_dim", 256)), None, 0)
         if sc.get("lights") is not None:
             base, ex = sc["lights"]
             L.ptref_set_lights(h, _p(base), _p(ex), len(base))

@@ -487,8 +487,25 @@ void ptref_add_texture(void* h, uint32_t w, uint32_t hgt, uint32_t format, const
 }
 void ptref_clear_textures(void* h) { ((Context*)h)->sc.textures.clear(); }
 // lat-long float RGB, row 0 at +Y; transform: 12 floats local->world (row major 3x4), colorMultiplier rgb; w==0 disables
+// the image as a cube map (rtxpt_amd: pt_set_environment_cube): six faces of dim x dim RGBA floats, D3D face order; kept as RGBA16F texels. One image source at a time.
+void ptref_set_environment_cube(void* h, const float* rgbaFaces, uint32_t dim, const float* toWorld, const float* colorMul) {
+    Context* c = (Context*)h; EnvMap& e = c->sc.env;
+    e.tex.w = e.tex.h = 0; e.tex.mips.clear();
+    e.enabled = (dim != 0) || e.skyEnabled;
+    e.imageCubeDim = dim; e.imageCube.resize(6ull * dim * dim);
+    for (size_t i = 0; i < e.imageCube.size(); i++) e.imageCube[i] = env_pack_rgba16f(make_float4(rgbaFaces[4 * i], rgbaFaces[4 * i + 1], rgbaFaces[4 * i + 2], rgbaFaces[4 * i + 3]));
+    if (toWorld) {
+        memcpy(e.toWorld.m, toWorld, 48);
+        float3x4 inv; memset(&inv, 0, sizeof(inv));
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) inv.m[r * 4 + k] = e.toWorld.m[k * 4 + r];
+        e.toLocal = inv;
+    }
+    if (colorMul) e.colorMultiplier = make_float3(colorMul[0], colorMul[1], colorMul[2]);
+    e.cubeDirty = true; c->lightsDirty = true;
+}
 void ptref_set_environment(void* h, const float* rgb, uint32_t w, uint32_t hgt, const float* toWorld, const float* colorMul) {
     Context* c = (Context*)h; EnvMap& e = c->sc.env;
+    e.imageCubeDim = 0; e.imageCube.clear();
     e.enabled = (w != 0) || e.skyEnabled;
     if (!w) { e.tex.w = e.tex.h = 0; e.tex.mips.clear(); }
     if (w) {
@@ -509,7 +526,7 @@ void ptref_set_environment(void* h, const float* rgb, uint32_t w, uint32_t hgt, 
 // the procedural sky (rtxpt_amd: pt_set_procedural_sky): 40 floats of constants (SampleProceduralSky.hlsli:18-46), four RGBA float textures (dims: w, h, d each); consts == null switches it off
 void ptref_set_procedural_sky(void* h, const float* consts, const float* const* rgba, const uint32_t* dims) {
     Context* c = (Context*)h; EnvMap& e = c->sc.env;
-    if (!consts) { if (e.skyEnabled) { e.skyEnabled = false; if (!e.tex.w) e.enabled = false; } e.cubeDirty = true; c->lightsDirty = true; return; }
+    if (!consts) { if (e.skyEnabled) { e.skyEnabled = false; if (!e.hasImage()) e.enabled = false; } e.cubeDirty = true; c->lightsDirty = true; return; }
     memcpy(&e.sky.Consts, consts, sizeof(ProceduralSkyConstants));
     SkyTexture* dst[4] = {&e.sky.Transmittance, &e.sky.Scatter, &e.sky.Irradiance, &e.sky.Clouds};
     if (rgba) for (int i = 0; i < 4; i++) {
@@ -517,7 +534,7 @@ void ptref_set_procedural_sky(void* h, const float* consts, const float* const* 
         e.skyTex[i].resize(n); memcpy(e.skyTex[i].data(), rgba[i], n * sizeof(float4));
         dst[i]->texels = e.skyTex[i].data(); dst[i]->w = dims[3 * i]; dst[i]->h = dims[3 * i + 1]; dst[i]->d = dims[3 * i + 2]; dst[i]->_pad = 0;
     }
-    if (!e.enabled) { if (!e.tex.w) { const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(e.toWorld.m, I, 48); memcpy(e.toLocal.m, I, 48); e.colorMultiplier = make_float3(1.0f / kEnvMapRadianceScale); } e.enabled = true; }
+    if (!e.enabled) { if (!e.hasImage()) { const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(e.toWorld.m, I, 48); memcpy(e.toLocal.m, I, 48); e.colorMultiplier = make_float3(1.0f / kEnvMapRadianceScale); } e.enabled = true; }
     e.skyEnabled = true; e.cubeDirty = true; c->lightsDirty = true;
 }
 // the sky's two texel functions on their own (fixtures, the reference-text pin): mode 0 = ProceduralSkyLowRes -> 4 floats, mode 1 = ProceduralSky's atmosphere + sun

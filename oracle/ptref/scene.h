@@ -150,10 +150,15 @@ struct EnvMap {
     uint cubeCompression = 0; std::vector<uint2> cubeTexelsSource; EnvCube cubeSource;
     // the procedural sky as (additional) source of the bake (EnvMapBaker.hlsl:228-236, 247-265; sky.h): constants, the four look-up textures, the half-resolution cloud pre-pass cube
     bool skyEnabled = false; ProceduralSkyContext sky; std::vector<float4> skyTex[4]; std::vector<uint2> skyLowResTexels; EnvCube skyLowRes;
+    // the image as a CUBE map instead of a lat-long image (ptref_set_environment_cube; EnvMapBaker.cpp:399-411, EnvMapBaker.hlsl BackgroundSourceType 2): 6 x dim x dim RGBA16F texels
+    std::vector<uint2> imageCube; uint imageCubeDim = 0;
+    EnvCube imageCubeView() const { EnvCube v; memset(&v, 0, sizeof(v)); v.texels = imageCube.data(); v.dim = imageCubeDim; v.mipLevels = 1u; return v; }
+    bool hasImage() const { return tex.w != 0u || imageCubeDim != 0u; }
     float3 ToLocal(float3 dir) const { return mul_vec_mat3(dir, toLocal); }
     float3 ToWorld(float3 dir) const { return mul_vec_mat3(dir, toWorld); }
     // SampleSource (EnvMapBaker.hlsl:98-110): the equirectangular source through a linear sampler, wrap in u, clamp in v, mip 0
     float3 SampleSource(float3 direction) const {
+        if (imageCubeDim) return xyz(env_cube_sample_level(imageCubeView(), direction, 0.0f));      // BackgroundSourceType 2: t_SrcCubemapEnvMap.SampleLevel(s_Linear, direction, 0)
         if (!tex.w) return make_float3(0.f, 0.f, 0.f);      // BackgroundSourceType 0: no image (a procedural sky alone)
         float2 uv = world_to_latlong_map(direction);
         float mh = (float)tex.h;

@@ -26,7 +26,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERROR_INVALID_ARGUMENT", 2: "PT_ERROR_NO_DEVICE", 3
 # every symbol include/mi355pt.h declares
 EXPORTS = [
     "pt_create", "pt_destroy", "pt_get_last_error", "pt_load_scene_gltf", "pt_gltf_animation_load", "pt_gltf_animation_instances", "pt_gltf_animation_positions", "pt_gltf_animation_normals", "pt_animate_normals", "pt_gltf_animation_free", "pt_set_geometry", "pt_set_instances", "pt_set_materials",
-    "pt_set_environment", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_light_importance_boost", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_set_view_projection", "pt_neeat_reset", "pt_get_neeat_tables", "pt_neeat_pack_feedback", "pt_neeat_unpack_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
+    "pt_set_environment", "pt_set_environment_cube", "pt_image_read_dds_cube", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_light_importance_boost", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_set_view_projection", "pt_neeat_reset", "pt_get_neeat_tables", "pt_neeat_pack_feedback", "pt_neeat_unpack_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
@@ -452,6 +452,21 @@ def read_dds(path):
         L.pt_image_free(p)
 
 
+def read_dds_cube(path):
+    """pt_image_read_dds_cube: the six faces (top level) of a float / BC6H cube-map .dds as float32 [6, dim, dim, 4] in D3D's face order — an environment source for
+    the scene key "env_cube_source" (pt_set_environment_cube). No device needed."""
+    L = load_library()
+    dim = ctypes.c_uint32(); p = ctypes.c_void_p()
+    L.pt_image_read_dds_cube.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_void_p)]
+    L.pt_image_free.argtypes = [ctypes.c_void_p]; L.pt_image_free.restype = None
+    r = L.pt_image_read_dds_cube(str(path).encode(), ctypes.byref(dim), ctypes.byref(p))
+    if r != PT_OK: raise PtError(r, "pt_image_read_dds_cube(%s)" % path)
+    try:
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(6, dim.value, dim.value, 4)).astype(np.float32, copy=True)
+    finally:
+        L.pt_image_free(p)
+
+
 def read_jpeg(data):
     """pt_image_read_jpeg: a JPEG stream (bytes, or a path) as uint8 [h, w, 4]. No device needed."""
     if not isinstance(data, (bytes, bytearray)): data = open(data, "rb").read()
@@ -671,12 +686,16 @@ class PathTracer:
                                sc["normals"].ctypes.data, sc["tangents"].ctypes.data, sc["positions"].shape[0])
         self._chk(self.L.pt_set_geometry(self.h, ctypes.byref(gb), _p(sc["geometries"]), len(sc["geometries"]), _p(sc["meshes"]), len(sc["meshes"])), "pt_set_geometry")
         self._chk(self.L.pt_set_instances(self.h, _p(sc["instances"]), len(sc["instances"])), "pt_set_instances")
-        if sc.get("env") is not None:
-            rgb, tw, cm = sc["env"]
+        if sc.get("env") is not None or sc.get("env_cube_source") is not None:
+            rgb, tw, cm = sc["env"] if sc.get("env") is not None else sc["env_cube_source"]      # "env_cube_source": (faces float32 [6, d, d, 4], transform, colour multiplier) — a cube map as the image
             # EnvMapSceneParams::ColorMultiplier as Sample.cpp:1936-1948 fills it: tint * intensity / c_envMapRadianceScale (the cube holds radiance * 1/4)
             cm4 = (np.asarray(cm, np.float32) * np.float32(4.0)).astype(np.float32)
             p = PtEnvMapSceneParams((ctypes.c_float * 12)(*tw.tolist()), (ctypes.c_float * 3)(*cm4.tolist()), 1.0)
-            self._chk(self.L.pt_set_environment(self.h, _p(rgb), rgb.shape[1], rgb.shape[0], ctypes.byref(p)), "pt_set_environment")
+            if sc.get("env") is not None:
+                self._chk(self.L.pt_set_environment(self.h, _p(rgb), rgb.shape[1], rgb.shape[0], ctypes.byref(p)), "pt_set_environment")
+            else:
+                faces = np.ascontiguousarray(rgb, np.float32); assert faces.ndim == 4 and faces.shape[0] == 6 and faces.shape[1] == faces.shape[2] and faces.shape[3] == 4
+                self._chk(self.L.pt_set_environment_cube(self.h, _p(faces), faces.shape[1], ctypes.byref(p)), "pt_set_environment_cube")
             dl = sc.get("env_directional_lights")       # rows of EMB_DirectionalLight: colour rgb, intensity, direction xyz, angular size
             dl = np.ascontiguousarray(dl, np.float32).reshape(-1, 8) if dl is not None else np.zeros((0, 8), np.float32)
             self._chk(self.L.pt_set_environment_bake(self.h, int(sc.get("env_cube_dim", 256)), _p(dl) if len(dl) else None, len(dl)), "pt_set_environment_bake")
@@ -685,7 +704,7 @@ class PathTracer:
             self._chk(self.L.pt_set_environment(self.h, None, 0, 0, None), "pt_set_environment")
         if sc.get("sky") is not None:                   # {"consts": PtProceduralSkyConstants or 40 floats, "textures": four arrays}: the procedural sky as the cube's source
             self.set_procedural_sky(sc["sky"]["consts"], sc["sky"].get("textures"))
-            if sc.get("env") is None: self._chk(self.L.pt_set_environment_bake(self.h, int(sc.get("env_cube_dim", 256)), None, 0), "pt_set_environment_bake")
+            if sc.get("env") is None and sc.get("env_cube_source") is None: self._chk(self.L.pt_set_environment_bake(self.h, int(sc.get("env_cube_dim", 256)), None, 0), "pt_set_environment_bake")
         if sc.get("lights") is not None:
             base, ex = sc["lights"]
             self._chk(self.L.pt_set_lights(self.h, _p(base), _p(ex), len(base)), "pt_set_lights")

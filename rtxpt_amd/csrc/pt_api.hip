@@ -105,6 +105,7 @@ struct pt_context {
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::AlphaPlane> dAlphaPlanes; DevBuf<unsigned char> dAlphaPool; DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
     bool skyEnabled = false; ptk::ProceduralSkyContext sky; DevBuf<ptk::float4> dSkyTex[4]; DevBuf<ptk::ProceduralSkyContext> dSky; DevBuf<ptk::uint2> dSkyLowRes;      // pt_set_procedural_sky
+    DevBuf<ptk::uint2> dEnvImageCube; uint envImageCubeDim = 0;      // pt_set_environment_cube: the environment image as a cube map (RGBA16F), uploaded by the setter
     DevBuf<ptk::uint2> dEnvCube, dEnvCubeSource; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights; uint envCompression = 0;      // envCompression: EnvMapBaker's BC6U compression (0 off, 1 fast)
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
     // NEE-AT (pt_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback reservoirs of the last pt_render call (one plane per sample)
@@ -269,6 +270,7 @@ void refresh_scene_view(pt_context* c) {
     d.envCube = c->envCube; d.envCube.texels = c->dEnvCube.p;
     d.sky = c->skyEnabled ? c->dSky.p : nullptr; memset(&d.skyLowRes, 0, sizeof(d.skyLowRes)); d.skyLowRes.texels = c->dSkyLowRes.p; d.skyLowRes.dim = c->envCubeDim / 2u; d.skyLowRes.mipLevels = 1u;
     d.envCubeSource = d.envCube; if (c->envCompression && c->dEnvCubeSource.p) d.envCubeSource.texels = c->dEnvCubeSource.p;
+    d.envImageCube = c->envImageCubeDim ? c->dEnvImageCube.p : nullptr; d.envImageCubeDim = c->envImageCubeDim; d._padEnvImageCube = 0u;
     d.envTex = c->envTexInfo; d.envEnabled = c->envEnabled ? 1u : 0u; d.envToWorld = c->envToWorld; d.envToLocal = c->envToLocal; d.envColorMultiplier = c->envColorMul;
     d.lights.Lights = c->dLights.p; d.lights.LightsEx = c->dLightsEx.p; d.lights.ProxyCounters = c->dProxyCounters.p; d.lights.ProxyIndices = c->dProxyIndices.p;
     d.lights.TotalLightCount = (uint)c->lights.size(); d.lights.SamplingProxyCount = c->numProxies;
@@ -717,7 +719,7 @@ int32_t pt_destroy(pt_context* c) {
     if (c->bvhAllocated) bvh_free(c->bvh);
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dPrevPositions.free(); c->dPrevInstances.free(); c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
-    c->dPrimInfo.free(); c->dShadeTris.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
+    c->dPrimInfo.free(); c->dShadeTris.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvImageCube.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
@@ -790,15 +792,8 @@ int32_t pt_set_materials(pt_context* c, const ::PTMaterialData* mats, uint32_t n
     c->texDirty = true; c->geomDirty = true;
     return PT_OK;
 }
-int32_t pt_set_environment(pt_context* c, const float* rgb, uint32_t w, uint32_t h, const PtEnvMapSceneParams* params) {
-    if (!c) return PT_ERROR_INVALID_ARGUMENT;
-    c->envEnabled = (w != 0 && h != 0 && rgb && (!params || params->Enabled != 0.f));
-    if (!c->envEnabled) { c->envTex.w = c->envTex.h = 0; c->envTex.mips.clear(); if (c->skyEnabled && (!params || params->Enabled != 0.f)) c->envEnabled = true; }      // (a procedural sky needs no image)
-    else {
-        HostTexture& t = c->envTex; t.w = w; t.h = h; t.mips.clear(); t.mips.resize(1); t.mips[0].resize((size_t)w * h);
-        for (size_t i = 0; i < (size_t)w * h; i++) t.mips[0][i] = ptk::make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.f);
-        t.mipLevels = 1;                                   // the bake reads mip 0 only (EnvMapBaker.hlsl:98-110: SampleLevel(.., 0))
-    }
+// orientation and colour multiplier of the environment (EnvMapSceneParams), shared by the two image setters
+static void set_env_params(pt_context* c, const PtEnvMapSceneParams* params) {
     if (params) {
         memcpy(c->envToWorld.m, params->Transform, 48);
         memset(&c->envToLocal, 0, sizeof(float3x4));
@@ -808,14 +803,43 @@ int32_t pt_set_environment(pt_context* c, const float* rgb, uint32_t w, uint32_t
         const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48);
         c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale);
     }
-    c->texDirty = true; c->lightsDirty = true;
+}
+static bool env_has_image(const pt_context* c) { return c->envTex.w != 0u || c->envImageCubeDim != 0u; }
+int32_t pt_set_environment(pt_context* c, const float* rgb, uint32_t w, uint32_t h, const PtEnvMapSceneParams* params) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    c->envImageCubeDim = 0; c->dEnvImageCube.free();          // one image source at a time: a lat-long image replaces a cube-map source
+    c->envEnabled = (w != 0 && h != 0 && rgb && (!params || params->Enabled != 0.f));
+    if (!c->envEnabled) { c->envTex.w = c->envTex.h = 0; c->envTex.mips.clear(); if (c->skyEnabled && (!params || params->Enabled != 0.f)) c->envEnabled = true; }      // (a procedural sky needs no image)
+    else {
+        HostTexture& t = c->envTex; t.w = w; t.h = h; t.mips.clear(); t.mips.resize(1); t.mips[0].resize((size_t)w * h);
+        for (size_t i = 0; i < (size_t)w * h; i++) t.mips[0][i] = ptk::make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.f);
+        t.mipLevels = 1;                                   // the bake reads mip 0 only (EnvMapBaker.hlsl:98-110: SampleLevel(.., 0))
+    }
+    set_env_params(c, params);
+    c->texDirty = true; c->lightsDirty = true; c->envCubeDirty = true;
+    return PT_OK;
+}
+int32_t pt_set_environment_cube(pt_context* c, const float* rgbaFaces, uint32_t dim, const PtEnvMapSceneParams* params) {
+    if (!c) return PT_ERROR_INVALID_ARGUMENT;
+    if (dim > 16384u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "cube-map source: at most 16384 texels per side");
+    c->envTex.w = c->envTex.h = 0; c->envTex.mips.clear();    // one image source at a time
+    c->envEnabled = (dim != 0 && rgbaFaces && (!params || params->Enabled != 0.f));
+    if (!c->envEnabled) { c->envImageCubeDim = 0; c->dEnvImageCube.free(); if (c->skyEnabled && (!params || params->Enabled != 0.f)) c->envEnabled = true; }
+    else {                                                 // stored as the RGBA16F texels a BC6H / RGBA16F cube file decodes to (a RGBA32F file is rounded to them)
+        const size_t n = 6ull * dim * dim; std::vector<ptk::uint2> h(n);
+        for (size_t i = 0; i < n; i++) h[i] = ptk::env_pack_rgba16f(ptk::make_float4(rgbaFaces[4 * i], rgbaFaces[4 * i + 1], rgbaFaces[4 * i + 2], rgbaFaces[4 * i + 3]));
+        PT_CHECK_HIP(c, c->dEnvImageCube.resize(n)); PT_CHECK_HIP(c, hipMemcpy(c->dEnvImageCube.p, h.data(), n * sizeof(ptk::uint2), hipMemcpyHostToDevice));
+        c->envImageCubeDim = dim;
+    }
+    set_env_params(c, params);
+    c->texDirty = true; c->lightsDirty = true; c->envCubeDirty = true;
     return PT_OK;
 }
 int32_t pt_set_procedural_sky(pt_context* c, const PtProceduralSkyConstants* consts, const PtProceduralSkyTextures* tex) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     static_assert(sizeof(PtProceduralSkyConstants) == sizeof(ptk::ProceduralSkyConstants), "ProceduralSkyConstants layout");
     if (!consts) {
-        if (c->skyEnabled) { c->skyEnabled = false; if (!c->envTex.w) c->envEnabled = false; c->envCubeDirty = true; c->lightsDirty = true; c->texDirty = true; }
+        if (c->skyEnabled) { c->skyEnabled = false; if (!env_has_image(c)) c->envEnabled = false; c->envCubeDirty = true; c->lightsDirty = true; c->texDirty = true; }
         return PT_OK;
     }
     if (tex) {
@@ -832,7 +856,7 @@ int32_t pt_set_procedural_sky(pt_context* c, const PtProceduralSkyConstants* con
     } else if (!c->dSkyTex[0].p) return fail(c, PT_ERROR_INVALID_ARGUMENT, "procedural sky: no look-up textures have been set yet");
     memcpy(&c->sky.Consts, consts, sizeof(ptk::ProceduralSkyConstants));
     if (!c->envEnabled) {          // a sky without pt_set_environment: identity orientation, the baked radiance as it is
-        if (!c->envTex.w) { const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale); }
+        if (!env_has_image(c)) { const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale); }
         c->envEnabled = true; c->texDirty = true;
     }
     c->skyEnabled = true; c->envCubeDirty = true; c->lightsDirty = true;

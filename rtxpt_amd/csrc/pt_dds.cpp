@@ -166,6 +166,20 @@ void decode_bc6h_block(const uint8_t* b, bool isSigned, uint16_t out[16][3]) {
         }
     }
 }
+// one level of a float-capable format (RGBA16F / RGBA32F / BC6H) as RGBA32F texels, alpha 1 for the block format
+enum FloatKind { FK_RGBA16F, FK_RGBA32F, FK_BC6U, FK_BC6S };
+static size_t float_level_bytes(FloatKind k, size_t w, size_t h) { return k == FK_RGBA16F ? w * h * 8u : (k == FK_RGBA32F ? w * h * 16u : ((w + 3u) / 4u) * ((h + 3u) / 4u) * 16u); }
+static void decode_float_level(FloatKind k, const uint8_t* src, size_t w, size_t h, float* out) {
+    const size_t npx = w * h;
+    if (k == FK_RGBA32F) { memcpy(out, src, npx * 16u); return; }
+    if (k == FK_RGBA16F) { for (size_t i = 0; i < npx * 4u; i++) out[i] = half_to_float((uint16_t)(src[2 * i] | (src[2 * i + 1] << 8))); return; }
+    const size_t bw = (w + 3u) / 4u, bh = (h + 3u) / 4u;
+    for (size_t by = 0; by < bh; by++) for (size_t bx = 0; bx < bw; bx++) {
+        uint16_t hb[16][3]; decode_bc6h_block(src + (by * bw + bx) * 16u, k == FK_BC6S, hb);
+        for (uint32_t y = 0; y < 4u; y++) for (uint32_t x = 0; x < 4u; x++) { const size_t X = bx * 4u + x, Y = by * 4u + y; if (X >= w || Y >= h) continue;
+            float* o = out + (Y * w + X) * 4u; for (int c = 0; c < 3; c++) o[c] = half_to_float(hb[y * 4u + x][c]); o[3] = 1.0f; }
+    }
+}
 struct Bytes { const uint8_t* p; size_t n; size_t size() const { return n; } const uint8_t* data() const { return p; } const uint8_t& operator[](size_t i) const { return p[i]; } };
 int32_t read_dds_bytes(const Bytes& d, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels);
 int32_t read_dds(const char* path, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels) {
@@ -213,19 +227,9 @@ int32_t read_dds_bytes(const Bytes& d, uint32_t* width, uint32_t* height, uint32
                  case K_RGBA8: case K_BGRA8: case K_BGRX8: need = npx * 4u; break; case K_RGBA16F: need = npx * 8u; break; case K_RGBA32F: need = npx * 16u; break; default: break; }
     if (d.size() < off + need) return PT_ERROR_IO;
     const uint8_t* src = d.data() + off;
-    if (k == K_RGBA16F || k == K_RGBA32F) {
+    if (k == K_RGBA16F || k == K_RGBA32F || k == K_BC6U || k == K_BC6S) {      // float texels out (HDR blocks: alpha 1)
         float* out = (float*)malloc(npx * 16u); if (!out) return PT_ERROR_IO;
-        if (k == K_RGBA32F) memcpy(out, src, npx * 16u);
-        else for (size_t i = 0; i < npx * 4u; i++) out[i] = half_to_float((uint16_t)(src[2 * i] | (src[2 * i + 1] << 8)));
-        *pixels = out; *format = PT_TEX_RGBA32F; *width = w; *height = h; return PT_OK;
-    }
-    if (k == K_BC6U || k == K_BC6S) {                    // HDR blocks: float RGBA out, alpha 1
-        float* out = (float*)malloc(npx * 16u); if (!out) return PT_ERROR_IO;
-        for (size_t by = 0; by < bh; by++) for (size_t bx = 0; bx < bw; bx++) {
-            uint16_t hb[16][3]; decode_bc6h_block(src + (by * bw + bx) * 16u, k == K_BC6S, hb);
-            for (uint32_t y = 0; y < 4u; y++) for (uint32_t x = 0; x < 4u; x++) { const size_t X = bx * 4u + x, Y = by * 4u + y; if (X >= w || Y >= h) continue;
-                float* o = out + (Y * w + X) * 4u; for (int c = 0; c < 3; c++) o[c] = half_to_float(hb[y * 4u + x][c]); o[3] = 1.0f; }
-        }
+        decode_float_level(k == K_RGBA16F ? FK_RGBA16F : (k == K_RGBA32F ? FK_RGBA32F : (k == K_BC6U ? FK_BC6U : FK_BC6S)), src, w, h, out);
         *pixels = out; *format = PT_TEX_RGBA32F; *width = w; *height = h; return PT_OK;
     }
     uint8_t* out = (uint8_t*)malloc(npx * 4u); if (!out) return PT_ERROR_IO;
@@ -248,8 +252,46 @@ int32_t read_dds_bytes(const Bytes& d, uint32_t* width, uint32_t* height, uint32
     return PT_OK;
 }
 
+// A cube-map .dds as an environment SOURCE (EnvMapBaker.cpp:399-411: a loaded texture with arraySize 6 becomes m_loadedSourceBackgroundTextureCubemap, BackgroundSourceType 2):
+// all six faces (legacy DDSCAPS2_CUBEMAP_ALLFACES or a DX10 header with the TEXTURECUBE flag), float-capable formats only, the top level of every face.
+int32_t read_dds_cube_bytes(const Bytes& d, uint32_t* dim, float** rgba) {
+    if (!d.p || !dim || !rgba) return PT_ERROR_INVALID_ARGUMENT;
+    *rgba = nullptr; *dim = 0;
+    if (d.size() < 128 || memcmp(d.data(), "DDS ", 4) != 0 || rd32(&d[4]) != 124u || rd32(&d[76]) != 32u) return PT_ERROR_IO;
+    const uint32_t h = rd32(&d[12]), w = rd32(&d[16]), hflags = rd32(&d[8]), pfFlags = rd32(&d[80]), cc = rd32(&d[84]), caps2 = rd32(&d[112]);
+    uint32_t mips = (hflags & 0x20000u) ? rd32(&d[28]) : 1u; if (mips == 0u) mips = 1u;
+    if (w == 0 || w != h || w > 16384u || mips > 15u) return (w != h) ? PT_ERROR_UNSUPPORTED : PT_ERROR_IO;
+    size_t off = 128; FloatKind k; bool cube = (caps2 & 0x200u) != 0u;
+    if (cube && (caps2 & 0xFC00u) != 0xFC00u) return PT_ERROR_UNSUPPORTED;                                   // a partial cube (not all six faces)
+    if ((pfFlags & 0x4u) && cc == fourcc('D', 'X', '1', '0')) {
+        if (d.size() < 148) return PT_ERROR_IO;
+        const uint32_t dxgi = rd32(&d[128]), rdim = rd32(&d[132]), misc = rd32(&d[136]), arr = rd32(&d[140]); off = 148;
+        if (rdim != 3u || !(misc & 0x4u) || arr != 1u) return PT_ERROR_UNSUPPORTED;                           // one cube: 2D resource, TEXTURECUBE, array size 1 (x 6 faces)
+        cube = true;
+        switch (dxgi) { case 10: k = FK_RGBA16F; break; case 2: k = FK_RGBA32F; break; case 94: case 95: k = FK_BC6U; break; case 96: k = FK_BC6S; break; default: return PT_ERROR_UNSUPPORTED; }
+    } else if (pfFlags & 0x4u) { if (cc == 113u) k = FK_RGBA16F; else if (cc == 116u) k = FK_RGBA32F; else return PT_ERROR_UNSUPPORTED; }
+    else return PT_ERROR_UNSUPPORTED;
+    if (!cube) return PT_ERROR_UNSUPPORTED;                                                                   // a 2D file: pt_image_read_dds / pt_image_read_float
+    size_t faceBytes = 0; for (uint32_t l = 0; l < mips; l++) { const size_t lw = (w >> l) ? (w >> l) : 1u; faceBytes += float_level_bytes(k, lw, lw); }
+    if (d.size() < off + 6u * faceBytes) return PT_ERROR_IO;
+    const size_t npx = (size_t)w * w;
+    float* out = (float*)malloc(6u * npx * 16u); if (!out) return PT_ERROR_IO;
+    for (uint32_t f = 0; f < 6u; f++) decode_float_level(k, d.data() + off + f * faceBytes, w, w, out + f * npx * 4u);      // faces in the file's (= D3D's) order: +X -X +Y -Y +Z -Z
+    *rgba = out; *dim = w;
+    return PT_OK;
+}
+
 } // namespace
 
+extern "C" int32_t pt_image_read_dds_cube(const char* path, uint32_t* dim, float** rgbaFaces) {
+    if (!path || !dim || !rgbaFaces) return PT_ERROR_INVALID_ARGUMENT;
+    *rgbaFaces = nullptr; *dim = 0;
+    try {
+        FILE* f = fopen(path, "rb"); if (!f) return PT_ERROR_IO;
+        std::vector<uint8_t> d; { uint8_t buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) { d.insert(d.end(), buf, buf + n); if (d.size() > ((size_t)1 << 32)) { fclose(f); return PT_ERROR_IO; } } fclose(f); }
+        return read_dds_cube_bytes(Bytes{d.data(), d.size()}, dim, rgbaFaces);
+    } catch (...) { *rgbaFaces = nullptr; return PT_ERROR_IO; }
+}
 extern "C" int32_t pt_image_read_dds_memory(const void* bytes, size_t size, uint32_t* width, uint32_t* height, uint32_t* format, void** pixels) {
     try { return read_dds_bytes(Bytes{(const uint8_t*)bytes, size}, width, height, format, pixels); } catch (...) { if (pixels) *pixels = nullptr; return PT_ERROR_IO; }
 }

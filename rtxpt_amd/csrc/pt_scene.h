@@ -149,6 +149,7 @@ struct DeviceScene {
     const ShadeTri* shadeTris; // one per global primitive id (pt_build.hip k_shade_tris)
     const uint* primToSlot;    // global primitive id -> leaf-order slot (probes; the traversal's resolve pass takes it from TravAux)
     uint2* travSpill;          // T8_MAX_BLOCKS x T8_GROUPS_PER_BLOCK x T8_SPILL_DEPTH stack-tail entries
+    const uint2* envImageCube; uint envImageCubeDim, _padEnvImageCube;      // the environment image given as a CUBE map instead of a lat-long image (pt_set_environment_cube): 6 x dim x dim RGBA16F texels, read by the cube bake only
 };
 
 struct HitInfo { float t; uint prim; float u, v; };
@@ -213,8 +214,12 @@ static inline float4 sample_grad_anisotropic(const DeviceScene& sc, const TexInf
     }
     return make_float4(sum.x / n, sum.y / n, sum.z / n, sum.w / n);
 }
-// SampleSource (EnvMapBaker.hlsl:98-110): the equirectangular source through a linear sampler (wrap in u, clamp in v), mip 0
+// SampleSource (EnvMapBaker.hlsl:98-110): the equirectangular source through a linear sampler (wrap in u, clamp in v), mip 0 — or the cube-map source through the cube fetch
 static inline float3 env_sample_source(const DeviceScene& sc, float3 direction) {
+    if (sc.envImageCubeDim) {                                  // BackgroundSourceType 2: t_SrcCubemapEnvMap.SampleLevel(s_Linear, direction, 0)
+        EnvCube src; src.texels = sc.envImageCube; src.dim = sc.envImageCubeDim; src.mipLevels = 1u; src._pad = 0u; src.mipOffset[0] = 0u;
+        return xyz(env_cube_sample_level(src, direction, 0.0f));
+    }
     if (!sc.envTex.w) return make_float3(0.f, 0.f, 0.f);      // BackgroundSourceType 0: no image (a procedural sky alone)
     float2 uv = world_to_latlong_map(direction);
     float mh = (float)sc.envTex.h;

@@ -126,7 +126,14 @@ def env_cube_cases():
         if not image: sc["env"] = None
         sc["sky"] = {"consts": consts.as_array(), "textures": _sky_textures()}
         sc.update(kw); return sc
+    def cubesrc(srcDim, dim, seed, nlights=0, **kw):      # a CUBE map as the source image (EnvMapBaker.hlsl SampleSource, BackgroundSourceType 2; pt_set_environment_cube): noisy HDR faces, every tap matters
+        rng = np.random.default_rng(seed)
+        faces = np.concatenate([(rng.random((6, srcDim, srcDim, 3), np.float32) ** 4 * 40.0).astype(np.float32), np.ones((6, srcDim, srcDim, 1), np.float32)], axis=-1)
+        sc = scene(scenes.sky_equirect(128, 64), dim, lights[:nlights] if nlights else None); _, tw, cm = sc["env"]
+        sc["env"] = None; sc["env_cube_source"] = (faces, tw, cm); sc.update(kw); return sc
     return {
+        "cubesrc_32_discs": cubesrc(24, 32, 11, nlights=2),
+        "cubesrc_64_bc6": cubesrc(80, 64, 12, env_compression=1),
         "procsky_64_midday": procsky("==PROCEDURAL_SKY_MIDDAY==", 0.0, 64),
         "procsky_32_clock_image_discs_bc6": procsky("==PROCEDURAL_SKY==", 41000.0, 32, image=True, env_compression=1),
         "sky_16": scene(scenes.sky_equirect(128, 64), 16),

@@ -63,6 +63,61 @@ def test_oracle_cube_matches_live_reference_text(dim, nlights, seed):
     assert np.array_equal(a, b) and da == dim and la == {16: 2, 32: 3, 128: 5}[dim]
 
 
+@pytest.mark.skipif(not HAVE_REF, reason="no /root/reference on this machine: the reference text cannot be compiled here")
+@pytest.mark.parametrize("srcDim,dim,nlights,seed", [(8, 16, 0, 1), (33, 32, 3, 2), (128, 64, 1, 3)])
+def test_oracle_cube_from_a_cube_map_source_matches_live_reference_text(srcDim, dim, nlights, seed):
+    """BackgroundSourceType 2 (EnvMapBaker.hlsl:105-106): the image is a cube map (pt_set_environment_cube / scene key "env_cube_source")."""
+    rng = np.random.default_rng(seed)
+    sc = dict(CASES["cubesrc_32_discs"]); _, tw, cm = sc["env_cube_source"]
+    faces = np.concatenate([(rng.random((6, srcDim, srcDim, 3), np.float32) ** 4 * 900.0).astype(np.float32), rng.random((6, srcDim, srcDim, 1), np.float32)], axis=-1)
+    d = rng.normal(size=(3, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    lights = np.concatenate([rng.random((3, 3)), rng.random((3, 1)) * 3, d, np.array([[0.02], [0.3], [1.2]])], axis=1).astype(np.float32)
+    sc["env_cube_source"] = (faces, tw, cm); sc["env_cube_dim"] = dim; sc["env_directional_lights"] = lights[:nlights] if nlights else None
+    (a, da, _), o = _cube(sc, reference=True)
+    (b, _, _) = o.env_cube(reference=False)
+    assert np.array_equal(a, b) and da == dim and a.any()
+
+
+def _dds_header(d, mips=1, dx10=None, caps2=0xFE00, fourcc=113):
+    import struct
+    flags = 0x1007 | (0x20000 if mips > 1 else 0)
+    cc = b"DX10" if dx10 is not None else struct.pack("<I", fourcc)
+    h = b"DDS " + struct.pack("<7I", 124, flags, d, d, 0, 0, mips) + b"\0" * 44 + struct.pack("<2I4s5I", 32, 4, cc, 0, 0, 0, 0, 0) + struct.pack("<5I", 0x1008, caps2, 0, 0, 0)
+    if dx10 is not None: h += struct.pack("<5I", dx10[0], 3, dx10[1], dx10[2], 0)
+    return h
+
+
+def test_dds_cube_reader(tmp_path):
+    """pt_image_read_dds_cube: the top level of all six faces — legacy FourCC 113 (RGBA16F) with the cube caps, a DX10 RGBA32F cube with a mip chain per face,
+    a BC6H_UF16 cube (blocks from the library's own encoder, decoded like the 2D reader does); 2D files, partial cubes and cube arrays are refused."""
+    import rtxpt_amd as pt
+    rng = np.random.default_rng(9); d = 12
+    faces = (rng.random((6, d, d, 4), np.float32) * 30.0).astype(np.float16)
+    (tmp_path / "a.dds").write_bytes(_dds_header(d) + faces.tobytes())
+    assert np.array_equal(pt.read_dds_cube(tmp_path / "a.dds"), faces.astype(np.float32))
+    f32 = (rng.random((6, d, d, 4), np.float32) * 1e5).astype(np.float32); body = b""
+    for f in range(6):                                    # every face carries its own mip chain (12, 6, 3, 1): the reader takes the first level and steps over the rest
+        body += f32[f].tobytes() + b"".join(np.full((max(d >> l, 1), max(d >> l, 1), 4), 7.0 + l, np.float32).tobytes() for l in range(1, 4))
+    (tmp_path / "b.dds").write_bytes(_dds_header(d, mips=4, dx10=(2, 0x4, 1)) + body)
+    assert np.array_equal(pt.read_dds_cube(tmp_path / "b.dds"), f32)
+    from oracle import ptref
+    T = np.clip(rng.random((6 * 9, 16, 3), np.float32) * 20.0, 0, 65504).astype(np.float16).astype(np.float32)      # 3 x 3 blocks per face
+    blocks = ptref.bc6_encode(T)
+    (tmp_path / "c.dds").write_bytes(_dds_header(d, dx10=(95, 0x4, 1)) + blocks.astype(np.uint32).tobytes())
+    got = pt.read_dds_cube(tmp_path / "c.dds")
+    (tmp_path / "c2d.dds").write_bytes(_dds_header(d, dx10=(95, 0, 1), caps2=0)[:12] + np.array([d * 6], np.uint32).tobytes() + _dds_header(d, dx10=(95, 0, 1), caps2=0)[16:] + blocks.astype(np.uint32).tobytes())
+    flat, fmt = pt.read_dds(tmp_path / "c2d.dds")         # the same blocks as one 12 x 72 image: the 2D reader's decode
+    assert fmt == 2 and np.array_equal(got.reshape(6 * d, d, 4), flat) and np.all(got[..., 3] == 1.0)
+    for name, data in (("flat.dds", _dds_header(d, caps2=0) + faces[0].tobytes()), ("partial.dds", _dds_header(d, caps2=0x0600) + faces[:1].tobytes()),
+                       ("array.dds", _dds_header(d, dx10=(10, 0x4, 2)) + faces.tobytes() * 2), ("rgba8.dds", _dds_header(d, dx10=(28, 0x4, 1)) + bytes(6 * d * d * 4))):
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(pt.PtError) as e: pt.read_dds_cube(tmp_path / name)
+        assert e.value.code == pt.PT_ERROR_UNSUPPORTED, name
+    (tmp_path / "short.dds").write_bytes(_dds_header(d) + faces.tobytes()[:-8])
+    with pytest.raises(pt.PtError) as e: pt.read_dds_cube(tmp_path / "short.dds")
+    assert e.value.code == pt.PT_ERROR_IO
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_oracle_importance_map_matches_reference_text_golden(name):
     """Level 0 of the radiance / importance map the environment quad-tree lights are made from: BuildMIPDescentImportanceMapCS of the reference's

@@ -18,7 +18,7 @@ def _imports():
     return pt, scenes, ptref, pin_scenes
 
 
-@pytest.mark.parametrize("name", ["sky_16", "sky_32_discs", "sky_64_hdr_sun", "sky_32_discs_bc6", "sky_64_hdr_sun_bc6", "sky_32_discs_bc6q", "sky_64_hdr_sun_bc6q", "procsky_64_midday", "procsky_32_clock_image_discs_bc6"])
+@pytest.mark.parametrize("name", ["cubesrc_32_discs", "cubesrc_64_bc6", "sky_16", "sky_32_discs", "sky_64_hdr_sun", "sky_32_discs_bc6", "sky_64_hdr_sun_bc6", "sky_32_discs_bc6q", "sky_64_hdr_sun_bc6q", "procsky_64_midday", "procsky_32_clock_image_discs_bc6"])
 def test_device_cube_matches_reference_text_golden_and_oracle(name):
     pt, scenes, ptref, pin_scenes = _imports()
     sc = pin_scenes.env_cube_cases()[name]
@@ -115,6 +115,38 @@ def test_compressed_cube_frames_and_switching():
     o2 = ptref.Oracle(); o2.set_scene(sc2); o2.set_camera(camd); o2.set_settings(S); o2.resize(w, h); o2.render(first, n)
     assert np.array_equal(q, o2.radiance()) and np.array_equal(g.env_cube()[0], o2.env_cube()[0]) and not np.array_equal(q, on)
     assert g.L.pt_set_environment_compression(g.h, 3) == pt.PT_ERROR_INVALID_ARGUMENT
+
+
+def test_cube_map_source_frame_and_switching(tmp_path):
+    """pt_set_environment_cube (EnvMapBaker.hlsl BackgroundSourceType 2): a frame lit by an environment whose image is a cube map read back from a .dds file equals the oracle's,
+    cube and light tables included; a lat-long image replaces the cube source and the other way round; dim 0 switches the environment off."""
+    import struct
+    pt, scenes, ptref, pin_scenes = _imports()
+    make, S, w, h, first, n = pin_scenes.cases()["c2"]
+    sc, cam = make(); sc = dict(sc); camd = scenes.bridge_camera(w, h, **cam)
+    rgb, tw, cm = sc["env"]
+    rng = np.random.default_rng(5); d = 40
+    faces = np.concatenate([(rng.random((6, d, d, 3), np.float32) ** 3 * 6.0).astype(np.float16).astype(np.float32), np.ones((6, d, d, 1), np.float32)], axis=-1)
+    hdr = b"DDS " + struct.pack("<7I", 124, 0x1007, d, d, d * 8, 0, 1) + b"\0" * 44 + struct.pack("<2I4s5I", 32, 4, struct.pack("<I", 113), 0, 0, 0, 0, 0) + struct.pack("<5I", 0x1008, 0xFE00, 0, 0, 0)
+    (tmp_path / "sky.dds").write_bytes(hdr + faces.astype(np.float16).tobytes())
+    got = pt.read_dds_cube(tmp_path / "sky.dds")
+    assert np.array_equal(got, faces)
+    sc_cube = dict(sc); sc_cube["env"] = None; sc_cube["env_cube_source"] = (got, tw, cm); sc_cube["env_cube_dim"] = 128
+    g = pt.PathTracer(); g.set_scene(sc_cube); g.set_camera(camd); g.set_settings(S); g.resize(w, h); g.render(first, n)
+    o = ptref.Oracle(); o.set_scene(sc_cube); o.set_camera(camd); o.set_settings(S); o.resize(w, h); o.render(first, n)
+    a = g.radiance().copy()
+    assert np.array_equal(g.env_cube()[0], o.env_cube()[0]) and np.array_equal(a, o.radiance()) and float(a[..., :3].sum()) > 0
+    sc_ll = dict(sc); sc_ll["env_cube_dim"] = 128
+    g.set_scene(sc_ll); g.reset_accumulation(); g.render(first, n); b = g.radiance().copy()
+    o2 = ptref.Oracle(); o2.set_scene(sc_ll); o2.set_camera(camd); o2.set_settings(S); o2.resize(w, h); o2.render(first, n)
+    assert np.array_equal(b, o2.radiance()) and not np.array_equal(a, b)
+    g.set_scene(sc_cube); g.reset_accumulation(); g.render(first, n)
+    assert np.array_equal(g.radiance(), a)
+    assert g.L.pt_set_environment_cube(g.h, None, 0, None) == 0
+    g.reset_accumulation(); g.render(first, n); dark = g.radiance().copy()
+    sc_off = dict(sc); sc_off["env"] = None
+    o3 = ptref.Oracle(); o3.set_scene(sc_off); o3.set_camera(camd); o3.set_settings(S); o3.resize(w, h); o3.render(first, n)
+    assert np.array_equal(dark, o3.radiance())
 
 
 def test_procedural_sky_cube_at_1024_and_a_frame_lit_by_it():
