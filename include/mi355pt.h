@@ -538,10 +538,10 @@ int32_t pt_tonemap_from_parameters(const PtToneMappingParameters* ui, float avgL
    ToneMappingConstants::avgLuminance (the reference reads it back with a lag of a few frames; here it is the current image). */
 int32_t pt_average_luminance(pt_context* ctx, float* avgLuminance);
 /* Float images for the environment source. The reference takes .exr / .hdr / .dds environment maps (Rtxpt/Sample.cpp:116) through Donut's TextureCache
-   (EnvMapBaker.cpp:392-415; Donut is not vendored: the formats are read from their published specifications). OpenEXR: single-part scan-line files with
+   (EnvMapBaker.cpp:392-415; Donut is not vendored: the formats are read from their published specifications). OpenEXR: single-part scan-line and tiled files (of a mip- / rip-mapped tiled file: level 0) with
    half or float R G B (or Y) channels, compression NONE / RLE / ZIPS / ZIP; Radiance .hdr: 32-bit_rle_rgbe, "-Y h +X w". *rgb: width x height x 3 floats, top
    row first (what pt_set_environment takes), allocated by the library, released with pt_image_free. PT_ERROR_IO: unreadable or malformed;
-   PT_ERROR_UNSUPPORTED: tiled / multi-part / deep EXR, PXR24 / B44 / DWA compression (NONE / RLE / ZIPS / ZIP / PIZ are read), sub-sampled or integer channels, other orientations.
+   PT_ERROR_UNSUPPORTED: multi-part / deep EXR, PXR24 / B44 / DWA compression (NONE / RLE / ZIPS / ZIP / PIZ are read), sub-sampled or integer channels, other orientations.
    A .dds with RGBA16F / RGBA32F pixels is read too (alpha dropped); 8-bit and block-compressed .dds files are textures, not environment sources: pt_image_read_dds. */
 int32_t pt_image_read_float(const char* path, uint32_t* width, uint32_t* height, float** rgb);
 void    pt_image_free(float* rgb);

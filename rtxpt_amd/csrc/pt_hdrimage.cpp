@@ -2,7 +2,7 @@
 // Donut's TextureCache (EnvMapBaker.cpp:392-415), which is not vendored in the reference tree: the two HDR formats are read here from their published
 // specifications. Host code, no device.
 //   OpenEXR: single-part scan-line files, channels R G B (or Y) of type half or float, compression NONE / RLE / ZIPS / ZIP / PIZ (the default of most HDRI
-//            tools). Tiled, multi-part and deep files and the PXR24 / B44 / DWA codecs are reported as PT_ERROR_UNSUPPORTED.
+//            tools). Single-part TILED files: level (0, 0) of any level mode, the same codecs per tile. Multi-part and deep files and the PXR24 / B44 / DWA codecs are reported as PT_ERROR_UNSUPPORTED.
 //   Radiance .hdr: "#?RADIANCE" / "#?RGBE", FORMAT=32-bit_rle_rgbe, -Y h +X w; flat and new-style run-length scan lines.
 // Output: width x height x 3 floats, top row first (the first scan line of either format is the top of the picture).
 #include "../../include/mi355pt.h"
@@ -199,10 +199,12 @@ int32_t read_exr(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H, 
     if (d.size() < 8 || (unsigned)r.i32() != 20000630u) return PT_ERROR_IO;
     const unsigned ver = (unsigned)r.i32();
     if ((ver & 0xFFu) != 2u) return PT_ERROR_UNSUPPORTED;
-    if (ver & (0x200u | 0x800u | 0x1000u)) return PT_ERROR_UNSUPPORTED;           // tiled, deep, multi-part
+    if (ver & (0x800u | 0x1000u)) return PT_ERROR_UNSUPPORTED;                     // deep, multi-part
+    const bool tiled = (ver & 0x200u) != 0u;                                        // single-part tiled: level (0, 0) is read (the full-resolution image of a mip-mapped / rip-mapped file)
     const size_t maxName = (ver & 0x400u) ? 255 : 31;
     struct Chan { std::string name; int type, xs, ys; };
     std::vector<Chan> ch; int comp = -1, dw[4] = {0, 0, -1, -1}, lineOrder = 0; bool haveDw = false;
+    unsigned tileW = 0, tileH = 0; bool haveTiles = false;
     for (;;) {
         std::string name, type; if (!r.cstr(name, maxName)) return PT_ERROR_IO;
         if (name.empty()) break;
@@ -215,49 +217,70 @@ int32_t read_exr(const std::vector<unsigned char>& d, uint32_t& W, uint32_t& H, 
         } else if (name == "compression") comp = a.u8();
         else if (name == "dataWindow" && type == "box2i") { for (int k = 0; k < 4; k++) dw[k] = a.i32(); haveDw = a.ok; }
         else if (name == "lineOrder") lineOrder = a.u8();
+        else if (name == "tiles" && type == "tiledesc") { tileW = (unsigned)a.i32(); tileH = (unsigned)a.i32(); (void)a.u8(); haveTiles = a.ok; }      // (the mode byte — level and rounding mode — is not needed for level 0)
     }
     if (ch.empty() || comp < 0 || !haveDw) return PT_ERROR_IO;
     if (comp > 4) return PT_ERROR_UNSUPPORTED;                                      // 0 none, 1 RLE, 2 ZIPS, 3 ZIP, 4 PIZ; PXR24 / B44 / DWA are not read
     const long long w = (long long)dw[2] - dw[0] + 1, h = (long long)dw[3] - dw[1] + 1;
     if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || w * h > (1ll << 28)) return PT_ERROR_IO;      // (a damaged data window must not turn into a 12 GB allocation)
-    size_t lineBytes = 0; int idx[3] = {-1, -1, -1}, yIdx = -1; std::vector<size_t> chOff(ch.size());
+    size_t pixelBytes = 0; int idx[3] = {-1, -1, -1}, yIdx = -1; std::vector<size_t> chBytesBefore(ch.size());      // a line of a block: channel after channel, `width` values each
     for (size_t k = 0; k < ch.size(); k++) {
         if (ch[k].xs != 1 || ch[k].ys != 1) return PT_ERROR_UNSUPPORTED;            // sub-sampled (luminance / chroma) channels
         if (ch[k].type < 0 || ch[k].type > 2) return PT_ERROR_IO;
-        chOff[k] = lineBytes; lineBytes += (size_t)w * (ch[k].type == 1 ? 2u : 4u);
+        chBytesBefore[k] = pixelBytes; pixelBytes += (ch[k].type == 1 ? 2u : 4u);
         if (ch[k].name == "R") idx[0] = (int)k; else if (ch[k].name == "G") idx[1] = (int)k; else if (ch[k].name == "B") idx[2] = (int)k; else if (ch[k].name == "Y") yIdx = (int)k;
     }
     if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0) { if (yIdx < 0) return PT_ERROR_UNSUPPORTED; idx[0] = idx[1] = idx[2] = yIdx; }
     for (int k = 0; k < 3; k++) if (ch[(size_t)idx[k]].type == 0) return PT_ERROR_UNSUPPORTED;      // uint channels carry ids, not radiance
-    const unsigned linesPerBlock = comp == 3 ? 16u : (comp == 4 ? 32u : 1u);
     std::vector<int> pizWords; for (auto& c : ch) pizWords.push_back(c.type == 1 ? 1 : 2);
+    W = (uint32_t)w; H = (uint32_t)h; rgb.assign((size_t)w * h * 3, 0.f);
+    std::vector<unsigned char> raw, tmp;
+    // one chunk of pixel data — a block of scan lines or a tile — of bw x lines pixels at (x0, y0): undo the codec, then pick R, G, B out of the channel-planar lines
+    auto chunk = [&](const unsigned char* src, size_t size, size_t x0, size_t y0, size_t bw, size_t lines) -> bool {
+        const size_t lineBytes = bw * pixelBytes, want = lines * lineBytes;
+        if (size == want) raw.assign(src, src + want);                              // stored as is (also what the codecs fall back to when they do not shrink the chunk)
+        else if (comp == 0) return false;
+        else if (comp == 1) { if (!exr_rle_decode(src, size, tmp, want)) return false; exr_unpredict_interleave(tmp, raw); }
+        else if (comp == 4) { if (!exr_piz_decode(src, size, bw, lines, pizWords, raw) || raw.size() != want) return false; }
+        else { tmp.resize(want); uLongf got = (uLongf)want; if (uncompress(tmp.data(), &got, src, (uLong)size) != Z_OK || got != want) return false; exr_unpredict_interleave(tmp, raw); }
+        for (size_t l = 0; l < lines; l++) {
+            const unsigned char* line = raw.data() + l * lineBytes; float* o = &rgb[((y0 + l) * (size_t)w + x0) * 3];
+            for (int k = 0; k < 3; k++) {
+                const Chan& cc = ch[(size_t)idx[k]]; const unsigned char* p = line + chBytesBefore[(size_t)idx[k]] * bw;
+                if (cc.type == 1) for (size_t x = 0; x < bw; x++) { unsigned short v; memcpy(&v, p + 2 * x, 2); o[3 * x + (size_t)k] = half_to_float(v); }
+                else for (size_t x = 0; x < bw; x++) { float v; memcpy(&v, p + 4 * x, 4); o[3 * x + (size_t)k] = v; }
+            }
+        }
+        return true;
+    };
+    (void)lineOrder;                                                                // every chunk carries its own position: the order of the chunks in the file does not matter
+    if (tiled) {
+        if (!haveTiles || tileW == 0u || tileH == 0u || tileW > 32768u || tileH > 32768u) return PT_ERROR_IO;
+        const size_t nx = ((size_t)w + tileW - 1) / tileW, ny = ((size_t)h + tileH - 1) / tileH;
+        if (nx * ny * 8 > d.size()) return PT_ERROR_IO;
+        std::vector<unsigned long long> offs(nx * ny); for (auto& o : offs) o = r.u64();      // the table's first nx x ny entries are level (0, 0) in every level mode; further levels follow and are not read
+        if (!r.ok) return PT_ERROR_IO;
+        for (size_t t = 0; t < offs.size(); t++) {
+            if (offs[t] > d.size() || d.size() - (size_t)offs[t] < 20) return PT_ERROR_IO;
+            Rd c{d.data(), d.size(), (size_t)offs[t], true};
+            const long long tx = c.i32(), ty = c.i32(), lx = c.i32(), ly = c.i32(); const int size = c.i32();
+            if (!c.ok || size < 0 || c.i + (size_t)size > c.n || lx != 0 || ly != 0 || tx < 0 || ty < 0 || (size_t)tx >= nx || (size_t)ty >= ny) return PT_ERROR_IO;
+            const size_t x0 = (size_t)tx * tileW, y0 = (size_t)ty * tileH;
+            if (!chunk(d.data() + c.i, (size_t)size, x0, y0, std::min<size_t>(tileW, (size_t)w - x0), std::min<size_t>(tileH, (size_t)h - y0))) return PT_ERROR_IO;
+        }
+        return PT_OK;
+    }
+    const unsigned linesPerBlock = comp == 3 ? 16u : (comp == 4 ? 32u : 1u);
     const size_t blocks = ((size_t)h + linesPerBlock - 1) / linesPerBlock;
     if (blocks * 8 > d.size()) return PT_ERROR_IO;                                   // the offset table alone would not fit the file
     std::vector<unsigned long long> offs(blocks); for (auto& o : offs) o = r.u64();
     if (!r.ok) return PT_ERROR_IO;
-    W = (uint32_t)w; H = (uint32_t)h; rgb.assign((size_t)w * h * 3, 0.f);
-    std::vector<unsigned char> raw, tmp;
-    (void)lineOrder;                                                                // every block carries its own y: the order of the blocks in the file does not matter
     for (size_t b = 0; b < blocks; b++) {
         if (offs[b] > d.size() || d.size() - (size_t)offs[b] < 8) return PT_ERROR_IO;
         Rd c{d.data(), d.size(), (size_t)offs[b], true};
         const long long y0 = (long long)c.i32() - dw[1]; const int size = c.i32();
         if (!c.ok || size < 0 || c.i + (size_t)size > c.n || y0 < 0 || y0 >= h) return PT_ERROR_IO;
-        const size_t lines = (size_t)std::min<long long>(linesPerBlock, h - y0), want = lines * lineBytes;
-        const unsigned char* src = d.data() + c.i;
-        if ((size_t)size == want) raw.assign(src, src + want);                      // stored as is (also what the codecs fall back to when they do not shrink the block)
-        else if (comp == 0) return PT_ERROR_IO;
-        else if (comp == 1) { if (!exr_rle_decode(src, (size_t)size, tmp, want)) return PT_ERROR_IO; exr_unpredict_interleave(tmp, raw); }
-        else if (comp == 4) { if (!exr_piz_decode(src, (size_t)size, (size_t)w, lines, pizWords, raw) || raw.size() != want) return PT_ERROR_IO; }
-        else { tmp.resize(want); uLongf got = (uLongf)want; if (uncompress(tmp.data(), &got, src, (uLong)size) != Z_OK || got != want) return PT_ERROR_IO; exr_unpredict_interleave(tmp, raw); }
-        for (size_t l = 0; l < lines; l++) {
-            const unsigned char* line = raw.data() + l * lineBytes; float* o = &rgb[((size_t)(y0 + (long long)l) * (size_t)w) * 3];
-            for (int k = 0; k < 3; k++) {
-                const Chan& cc = ch[(size_t)idx[k]]; const unsigned char* p = line + chOff[(size_t)idx[k]];
-                if (cc.type == 1) for (size_t x = 0; x < (size_t)w; x++) { unsigned short v; memcpy(&v, p + 2 * x, 2); o[3 * x + (size_t)k] = half_to_float(v); }
-                else for (size_t x = 0; x < (size_t)w; x++) { float v; memcpy(&v, p + 4 * x, 4); o[3 * x + (size_t)k] = v; }
-            }
-        }
+        if (!chunk(d.data() + c.i, (size_t)size, 0, (size_t)y0, (size_t)w, (size_t)std::min<long long>(linesPerBlock, h - y0))) return PT_ERROR_IO;
     }
     return PT_OK;
 }

@@ -178,6 +178,72 @@ def write_exr(path, chans, comp, origin=(0, 0), version=2, extra_attrs=b""):
     open(path, "wb").write(hdr + table + b"".join(blocks))
 
 
+def write_exr_tiled(path, chans, comp, tile, level_mode=0, origin=(0, 0)):
+    """a single-part TILED file (version bit 0x200, attribute `tiles`): level (0, 0) holds the image; level_mode 1 (MIPMAP_LEVELS, rounding down) appends the further levels'
+    tiles — filled with a constant — after it, in the offset table as in the file, so a reader that took anything but level 0 would show it."""
+    names = sorted(chans); h, w = chans[names[0]].shape; tw, th = tile
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 1 if chans[n].dtype == np.float16 else 2, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    x0, y0 = origin
+    hdr = struct.pack("<ii", 20000630, 2 | 0x200) + _attr("channels", "chlist", chlist) + _attr("compression", "compression", bytes([comp])) + \
+        _attr("dataWindow", "box2i", struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)) + _attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + \
+        _attr("lineOrder", "lineOrder", b"\0") + _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + \
+        _attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + _attr("tiles", "tiledesc", struct.pack("<IIB", tw, th, level_mode)) + b"\0"
+    levels = [dict(chans)]
+    if level_mode == 1:
+        lw, lh = w, h
+        while lw > 1 or lh > 1:
+            lw, lh = max(1, lw // 2), max(1, lh // 2)
+            levels.append({n: np.full((lh, lw), 777.0, chans[n].dtype) for n in names})
+    chunks = []
+    for l, lc in enumerate(levels):
+        lh, lw = lc[names[0]].shape
+        for ty in range((lh + th - 1) // th):
+            for tx in range((lw + tw - 1) // tw):
+                sub = {n: np.ascontiguousarray(lc[n][ty * th:min(lh, (ty + 1) * th), tx * tw:min(lw, (tx + 1) * tw)]) for n in names}
+                rows = sub[names[0]].shape[0]
+                raw = b"".join(sub[n][y].tobytes() for y in range(rows) for n in names)
+                if comp == 0: data = raw
+                elif comp == 4: data = _piz_block(range(rows), names, sub)
+                else:
+                    t = _exr_transform(raw); data = _exr_rle(t) if comp == 1 else zlib.compress(t)
+                    if len(data) >= len(raw): data = raw
+                chunks.append(struct.pack("<iiiii", tx, ty, l, l, len(data)) + data)
+    off = len(hdr) + 8 * len(chunks); table = b""
+    for c in chunks: table += struct.pack("<Q", off); off += len(c)
+    open(path, "wb").write(hdr + table + b"".join(chunks))
+
+
+@pytest.mark.parametrize("comp", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile,level_mode", [((16, 16), 0), ((7, 5), 0), ((64, 64), 0), ((8, 12), 1)])
+def test_tiled_exr(tmp_path, comp, tile, level_mode):
+    """Single-part tiled OpenEXR files: every codec per tile, tiles that do not divide the image (narrower / shorter edge tiles), a tile larger than the image, half and float
+    channels with an extra channel between them, a data window that does not start at the origin, and a mip-mapped file of which only level 0 is the image."""
+    rng = np.random.default_rng(100 * comp + tile[0])
+    h, w = 23, 37
+    R = (rng.random((h, w), np.float32) * 9).astype(np.float16); G = (rng.random((h, w), np.float32) * 1e4).astype(np.float32); B = (rng.random((h, w), np.float32)).astype(np.float16)
+    A = np.full((h, w), 0.5, np.float16)
+    write_exr_tiled(tmp_path / "t.exr", {"R": R, "G": G, "B": B, "A": A}, comp, tile, level_mode, origin=(3, -2))
+    img = pt.read_float_image(tmp_path / "t.exr")
+    assert img.shape == (h, w, 3)
+    assert np.array_equal(img[..., 0], R.astype(np.float32)) and np.array_equal(img[..., 1], G) and np.array_equal(img[..., 2], B.astype(np.float32))
+
+
+def test_tiled_exr_damage(tmp_path):
+    rng = np.random.default_rng(4); img = (rng.random((20, 24), np.float32) * 5).astype(np.float16)
+    write_exr_tiled(tmp_path / "t.exr", {"R": img, "G": img, "B": img}, 3, (8, 8)); src = open(tmp_path / "t.exr", "rb").read()
+    ok = 0
+    for k in range(300):
+        d = bytearray(src); n = int(rng.integers(1, 4))
+        for _ in range(n): d[int(rng.integers(8, len(d)))] = int(rng.integers(0, 256))
+        if k % 5 == 0: d = d[:int(rng.integers(8, len(d)))]
+        open(tmp_path / "d.exr", "wb").write(bytes(d))
+        try:
+            out = pt.read_float_image(tmp_path / "d.exr"); ok += 1; assert out.shape[2] == 3
+        except pt.PtError as e:
+            assert e.code in (4, 5)
+    assert ok < 300
+
+
 def write_hdr(path, rgbe, rle):
     h, w = rgbe.shape[:2]
     out = bytearray(b"#?RADIANCE\n# written by tests/test_hdr_images.py\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y %d +X %d\n" % (h, w))
@@ -283,7 +349,8 @@ def test_refused_files(tmp_path):
     write_exr(tmp_path / "pxr24.exr", {"R": img, "G": img, "B": img}, 0); d = bytearray(open(tmp_path / "pxr24.exr", "rb").read())
     i = d.index(b"compression\0compression\0") + 24 + 4; d[i] = 5; open(tmp_path / "pxr24.exr", "wb").write(d)      # PXR24 (B44, DWA likewise): lossy codecs nobody keeps radiance in
     assert code(tmp_path / "pxr24.exr") == 5                # PT_ERROR_UNSUPPORTED
-    write_exr(tmp_path / "tiled.exr", {"R": img, "G": img, "B": img}, 0, version=2 | 0x200); assert code(tmp_path / "tiled.exr") == 5
+    write_exr(tmp_path / "tiled.exr", {"R": img, "G": img, "B": img}, 0, version=2 | 0x200); assert code(tmp_path / "tiled.exr") == 4      # says "tiled" but has no tile description: malformed
+    write_exr(tmp_path / "deep.exr", {"R": img, "G": img, "B": img}, 0, version=2 | 0x800); assert code(tmp_path / "deep.exr") == 5
     write_exr(tmp_path / "multi.exr", {"R": img, "G": img, "B": img}, 0, version=2 | 0x1000); assert code(tmp_path / "multi.exr") == 5
     write_exr(tmp_path / "nocolour.exr", {"Z": img.astype(np.float32)}, 0); assert code(tmp_path / "nocolour.exr") == 5
     open(tmp_path / "junk.bin", "wb").write(b"not an image at all"); assert code(tmp_path / "junk.bin") == 5
