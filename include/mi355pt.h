@@ -167,7 +167,10 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out);
 int32_t pt_destroy(pt_context* ctx);
 const char* pt_get_last_error(pt_context* ctx);
 
-/* Sample::LoadScene + SceneLoaded + MaterialsBaker::ImportFromDonut (Rtxpt/Sample.cpp:447-560, Rtxpt/Materials/MaterialsBaker.cpp:660-705) */
+/* Sample::LoadScene + SceneLoaded + MaterialsBaker::ImportFromDonut (Rtxpt/Sample.cpp:447-560, Rtxpt/Materials/MaterialsBaker.cpp:660-705): a `.gltf` / `.glb` file, or —
+   a path ending in `.json` — an RTXPT `.scene.json` asset folder (the media folder is the file's own): pt_scene_json_import + pt_scene_import_apply, the graph's directional
+   lights (pt_set_scene_directional_lights) and the EnvironmentLight's image, lat-long (.exr / .hdr / float .dds) or cube map (.dds), with the environment UI block at identity
+   as after a scene load (Sample.cpp:554); an unreadable image leaves the scene without one, as there. Camera and SampleSettings: pt_scene_json_import's getters. */
 int32_t pt_load_scene_gltf(pt_context* ctx, const char* path);
 /* glTF 2.0 animations of the file pt_load_scene_gltf read (Sample::Animate -> Scene::Animate, Rtxpt/Sample.cpp:785-811; Donut's SceneGraphAnimation is not
    vendored: samplers and channels are evaluated as the glTF specification defines them — LINEAR (spherical for rotations) / STEP / CUBICSPLINE over node
@@ -448,7 +451,7 @@ int32_t pt_convert_light(const PtAnalyticLightDesc* light, PolymorphicLightInfo*
    textures other than PNG, JPEG and .dds files (counted in texturesNotLoaded, the
    material then renders untextured as when the reference fails to load one). A point / spot light's "proxyMeshNodes" (ExtendedScene.cpp:46, 246-263) are resolved
    as Donut's SceneGraph::FindNode resolves them — '/'-separated node names from the root, a model's own root node named after its file — and the mesh instances at those
-   nodes come out with analyticProxyLight set (LightsBaker.cpp:718-753). The environment map is reported (envPath), not loaded: pt_image_read_float reads .exr / .hdr files for pt_set_environment (.dds is not read). NOTE: of
+   nodes come out with analyticProxyLight set (LightsBaker.cpp:718-753). The environment map is reported (envPath), not loaded by the import itself (pt_load_scene_gltf on the `.scene.json` does load it): pt_image_read_float reads .exr / .hdr / float .dds files for pt_set_environment, pt_image_read_dds_cube cube maps for pt_set_environment_cube. NOTE: of
    an EnvironmentLight the reference application consumes only `path` (Sample.cpp:552-553); radianceScale / rotation / textureIndex are read by
    EnvironmentLight::Load but never used — tint, intensity and rotation of the environment come from the UI block (EnvironmentMapRuntimeParameters,
    reset to identity on every scene load, Sample.cpp:554, 1936-1948). They are reported for completeness; to match the reference do not apply them. */

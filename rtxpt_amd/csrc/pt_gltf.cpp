@@ -622,8 +622,10 @@ static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path);
 extern "C" int32_t pt_load_scene_gltf(pt_context* ctx, const char* path) {
     try { return load_scene_gltf_impl(ctx, path); } catch (...) { return PT_ERROR_IO; }      // bad_alloc / length_error on a damaged file: an error code, not an abort
 }
+static int32_t load_scene_json_into(pt_context* ctx, const char* path);
 static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path) {
     if (!ctx || !path) return PT_ERROR_INVALID_ARGUMENT;
+    { const size_t n = strlen(path); if (n >= 5 && strcmp(path + n - 5, ".json") == 0) return load_scene_json_into(ctx, path); }      // an RTXPT asset folder's `.scene.json`
     Loader L; L.ctx = ctx;
     int32_t lr = load_gltf_file(path, L);
     if (lr != PT_OK) return lr;
@@ -1230,6 +1232,28 @@ extern "C" int32_t pt_scene_import_tone_mapping(const pt_scene_import* S, int32_
     ui->exposureValue = (c.exposureMask & 4u) ? c.exposureValue : 0.0f;
     ui->exposureValueMin = (c.exposureMask & 8u) ? c.exposureValueMin : -16.0f;
     ui->exposureValueMax = (c.exposureMask & 16u) ? c.exposureValueMax : 16.0f;
+    return PT_OK;
+}
+// pt_load_scene_gltf on a `.scene.json`: what Sample::SceneLoaded leaves behind as far as this library holds it (Sample.cpp:520-640) — materials, geometry, instances, analytic
+// lights (pt_scene_import_apply), the graph's directional lights for the environment bake (Sample::UpdateLighting's inputs), and the EnvironmentLight's image: the reference
+// hands its `path` (relative to the media folder) to EnvMapBaker, which loads a lat-long image or a cube map (EnvMapBaker.cpp:392-415) with the UI block at identity
+// (Sample.cpp:554, 1936-1948): tint 1, intensity 1, no rotation. A file that cannot be read leaves the scene without an image, as there. Camera and SampleSettings stay with
+// the caller (pt_scene_json_import + pt_scene_import_cameras / _settings / _tone_mapping read them).
+static int32_t load_scene_json_into(pt_context* ctx, const char* path) {
+    pt_scene_import* S = nullptr; PtSceneJsonInfo info;
+    int32_t r = pt_scene_json_import(path, nullptr, &S, &info);
+    if (r != PT_OK) return r;
+    std::unique_ptr<pt_scene_import> hold(S);
+    r = pt_scene_import_apply(ctx, S); if (r != PT_OK) return r;
+    r = pt_set_scene_directional_lights(ctx, S->directionalLights.empty() ? nullptr : S->directionalLights.data(), (uint32_t)std::min<size_t>(S->directionalLights.size(), 16)); if (r != PT_OK) return r;
+    if (info.hasEnvironment && info.envPath[0] && strncmp(info.envPath, "==", 2) != 0) {      // ("==PROCEDURAL_SKY==" and its presets name the procedural sky: pt_set_procedural_sky, the caller's)
+        std::string sp(path); const size_t slash = sp.find_last_of('/'); const std::string file = (slash == std::string::npos ? std::string() : sp.substr(0, slash + 1)) + info.envPath;
+        uint32_t w = 0, h = 0, dim = 0; float* px = nullptr;
+        if (pt_image_read_float(file.c_str(), &w, &h, &px) == PT_OK) { r = pt_set_environment(ctx, px, w, h, nullptr); pt_image_free(px); }
+        else if (pt_image_read_dds_cube(file.c_str(), &dim, &px) == PT_OK) { r = pt_set_environment_cube(ctx, px, dim, nullptr); pt_image_free(px); }
+        else r = pt_set_environment(ctx, nullptr, 0, 0, nullptr);
+        if (r != PT_OK) return r;
+    }
     return PT_OK;
 }
 extern "C" int32_t pt_scene_import_apply(pt_context* ctx, const pt_scene_import* S) {

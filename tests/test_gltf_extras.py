@@ -218,3 +218,42 @@ def test_gltf_punctual_lights_reach_the_context(tmp_path):
     assert not np.array_equal(a.radiance(), c.radiance())
     for t in (a, b, c): t.close()
     imp.close()
+
+
+@pytest.mark.gpu
+def test_scene_json_through_pt_load_scene_gltf(tmp_path):
+    """pt_load_scene_gltf on a `.scene.json`: import + apply + the graph's directional light + the EnvironmentLight's image — here a cube-map .dds (EnvMapBaker's
+    BackgroundSourceType 2) — with the environment UI block at identity, as after Sample::SceneLoaded. The frame equals the same steps taken by hand; a second folder names a
+    lat-long .hdr; an unreadable image leaves the scene without one."""
+    import ctypes, struct
+    from test_hdr_images import write_hdr
+    media = tmp_path / "m"; media.mkdir()
+    sc, cam = scenes.cornell_box("C2")
+    write_gltf(sc, str(media / "box.gltf"))
+    rng = np.random.default_rng(8); d = 24
+    faces = np.concatenate([(rng.random((6, d, d, 3), np.float32) ** 2 * 3.0).astype(np.float16).astype(np.float32), np.ones((6, d, d, 1), np.float32)], axis=-1)
+    hdr = b"DDS " + struct.pack("<7I", 124, 0x1007, d, d, d * 8, 0, 1) + b"\0" * 44 + struct.pack("<2I4s5I", 32, 4, struct.pack("<I", 113), 0, 0, 0, 0, 0) + struct.pack("<5I", 0x1008, 0xFE00, 0, 0, 0)
+    (media / "sky.dds").write_bytes(hdr + faces.astype(np.float16).tobytes())
+    rgbe = rng.integers(100, 140, (16, 32, 4)).astype(np.uint8); write_hdr(media / "sky.hdr", rgbe, True)
+    graph = lambda env: [{"model": 0}, {"name": "sun", "type": "DirectionalLight", "rotation": [math.sin(0.5), 0.0, 0.0, math.cos(0.5)], "color": [1.0, 0.9, 0.8], "irradiance": 1.5, "angularSize": 2.0},
+                         {"type": "EnvironmentLight", "path": env}]
+    for name in ("sky.dds", "sky.hdr", "nothing.exr"):
+        (media / ("s_%s.scene.json" % name)).write_text(json.dumps({"models": ["box.gltf"], "graph": graph(name)}))
+    S = scenes.config_settings("C2"); w, h = 128, 80
+    camd = scenes.bridge_camera(w, h, **cam)
+    frames = {}
+    for name in ("sky.dds", "sky.hdr", "nothing.exr"):
+        scene = media / ("s_%s.scene.json" % name)
+        a = pt.PathTracer(); a.load_scene_gltf(str(scene)); a.set_camera(camd); a.set_settings(S); a.resize(w, h); a.render(0, 2)
+        imp = pt.SceneImport(scene); assert imp.directional_lights.shape[0] == 1
+        b = pt.PathTracer(); b.apply_scene_import(imp)
+        dl = np.ascontiguousarray(imp.directional_lights, np.float32)
+        assert b.L.pt_set_scene_directional_lights(b.h, dl.ctypes.data_as(ctypes.c_void_p), 1) == 0
+        if name == "sky.dds": assert b.L.pt_set_environment_cube(b.h, np.ascontiguousarray(pt.read_dds_cube(media / name)).ctypes.data_as(ctypes.c_void_p), d, None) == 0
+        elif name == "sky.hdr":
+            img = np.ascontiguousarray(pt.read_float_image(media / name)); assert b.L.pt_set_environment(b.h, img.ctypes.data_as(ctypes.c_void_p), img.shape[1], img.shape[0], None) == 0
+        b.set_camera(camd); b.set_settings(S); b.resize(w, h); b.render(0, 2)
+        assert np.array_equal(a.radiance(), b.radiance()), name
+        if name != "nothing.exr": assert np.array_equal(a.env_cube()[0], b.env_cube()[0]) and a.env_cube()[0].any()
+        frames[name] = a.radiance().copy(); a.close(); b.close(); imp.close()
+    assert not np.array_equal(frames["sky.dds"], frames["sky.hdr"]) and not np.array_equal(frames["sky.dds"], frames["nothing.exr"])
