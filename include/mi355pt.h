@@ -630,8 +630,6 @@ int32_t pt_get_lights(pt_context* ctx, uint32_t* numLights, uint32_t* numProxies
 int32_t pt_get_env_cube(pt_context* ctx, uint32_t* texelCount, uint32_t* dim, uint32_t* mipLevels, void* texels8B, uint32_t capacityTexels);
 int32_t pt_get_subinstances(pt_context* ctx, uint32_t* count, void* out32B);
 int32_t pt_get_scene_info(pt_context* ctx, uint32_t* numTriangles, uint32_t* numBvhNodes, uint32_t* numInstances, uint32_t* numMaterials);
-/* device-side evaluation of leaf functions for known-answer tests (kind: see pt_probe.h values in rtxpt_amd/csrc/pt_api.hip) */
-int32_t pt_probe(pt_context* ctx, int32_t kind, const void* in, size_t inBytes, void* out, size_t outBytes, uint32_t n);
 /* BVH build/refit timing of the last geometry update, milliseconds */
 int32_t pt_get_build_stats(pt_context* ctx, double* buildMs, double* refitMs, double* lightBakeMs);
 /* which builder made the tree the kernels traverse, and where it ran. builder: 0 = PLOC (device, "prefer fast build"), 1 = Karras radix tree (device, developer A/B),
@@ -650,13 +648,6 @@ int32_t pt_set_serial_kernels(pt_context* ctx, int32_t enable);
    pt_create). The image does not depend on the value (paths do not interact; tests render whole frames through the tail kernel). Ignored for NEEFullSamples > 1,
    serial-kernel and counter frames. */
 int32_t pt_set_tail_paths(pt_context* ctx, uint32_t maxPaths);
-/* Streaming frames (path regeneration): pt_render generates a batch's paths in slices and keeps at most `pathsInFlight` of them in flight — after every bounce fresh paths top the
-   batch's extend queue up again, so the traversal launches keep one size while the frame lasts and dwindle once, at its end. The reference has no analogue (its raygen thread
-   loops over the bounces of one pixel, Rtxpt/Shaders/PathTracerSample.hlsl:200-250; DXR schedules); this is launch composition only: one pool slot per (pixel, sample), stateless
-   random streams, samples folded in sample order afterwards — the image does not depend on either value (tests/test_gpu_streaming.py). pathsInFlight 0 = off (all paths of a
-   call generated up front), values below 1024 are raised to that; batches 0 = pt_render's size rule, else 1..4 streams. Environment MI355PT_STREAM_PATHS / MI355PT_STREAM_BATCHES
-   override the defaults at pt_create. Ignored in serial-kernel and counter frames. */
-int32_t pt_set_stream_paths(pt_context* ctx, uint32_t pathsInFlight, uint32_t batches);
 
 #ifdef __cplusplus
 }

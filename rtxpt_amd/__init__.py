@@ -17,6 +17,8 @@ from . import scenes  # noqa: F401  (scene generators + data-contract dtypes)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355PT_LIB", os.path.join(_HERE, "libmi355pt.so"))   # MI355PT_LIB: developer A/B builds only
+HOOKS_LIB_PATH = os.path.join(_HERE, "libmi355pt_testhooks.so")                  # the tests' build: + include/mi355pt_testhooks.h
+_libs = {}
 
 PT_OK = 0
 PT_ERROR_INVALID_ARGUMENT, PT_ERROR_NO_DEVICE, PT_ERROR_HIP, PT_ERROR_IO, PT_ERROR_UNSUPPORTED, PT_ERROR_NOT_READY = 1, 2, 3, 4, 5, 6
@@ -29,14 +31,15 @@ EXPORTS = [
     "pt_set_environment", "pt_set_environment_cube", "pt_image_read_dds_cube", "pt_set_environment_bake", "pt_set_environment_compression", "pt_set_procedural_sky", "pt_procedural_sky_default_params", "pt_procedural_sky_update", "pt_env_bake_lights", "pt_set_lights", "pt_set_light_importance_boost", "pt_set_local_light_sampling", "pt_get_light_feedback", "pt_set_neeat", "pt_set_view_projection", "pt_neeat_reset", "pt_get_neeat_tables", "pt_neeat_pack_feedback", "pt_neeat_unpack_feedback", "pt_bridge_camera", "pt_set_camera", "pt_default_settings", "pt_set_settings", "pt_animate",
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
-    "pt_get_scene_info", "pt_probe", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_set_stream_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_exchange_planes_host", "pt_neeat_update_begin", "pt_neeat_update_end", "pt_pack_stable_plane_guides", "pt_unpack_stable_plane_guides", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
+    "pt_get_scene_info", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_exchange_planes_host", "pt_neeat_update_begin", "pt_neeat_update_end", "pt_pack_stable_plane_guides", "pt_unpack_stable_plane_guides", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_vertices", "pt_set_scene_directional_lights", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
     "pt_stable_planes_plane_stride", "pt_build_stable_planes", "pt_fill_stable_planes", "pt_denoise_spec_hit_t", "pt_stable_planes_merge", "pt_get_stable_planes",
     "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_shard_layout", "pt_gather_host", "pt_neeat_exchange_host",
 ]
+TEST_HOOK_EXPORTS = ["pt_probe"]      # include/mi355pt_testhooks.h: libmi355pt_testhooks.so only
 
 
 class PtError(RuntimeError):
@@ -137,7 +140,6 @@ def build_library(verbose=False):
     return LIB_PATH
 
 
-_lib = None
 
 
 def _share_hip_runtime_with_torch():
@@ -274,28 +276,39 @@ def exchange_planes_host(width, height, rank, world, planes, send, recv, to_root
 
 
 def kernel_source_digest():
-    """SHA-256 over the kernel sources of the library (rtxpt_amd/csrc/*.h and *.hip, names and contents, in name order): what ties a rocprofv3 counter summary under
-    profiles/ to the kernels a bench.py run executes (tools/profile_round.sh writes it, bench.py compares it before quoting `bound` / `traffic`)."""
+    """SHA-256 over the sources of the library (rtxpt_amd/csrc/*.h, *.hip and *.cpp, names and contents, in name order): what ties a rocprofv3 counter summary under
+    profiles/ to the code a bench.py run executes (tools/profile_round.sh writes it, bench.py compares it before quoting `bound` / `traffic`). The binary itself is tied by
+    library_digest()."""
     import glob, hashlib
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cpp"))):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()
 
 
-def load_library():
-    """dlopen libmi355pt.so. Raises if it has not been built: the product path never falls back to anything else."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("libmi355pt.so is missing (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C rtxpt_amd/csrc`." % LIB_PATH)
+def library_digest(test_hooks=False):
+    """SHA-256 of the shared library file load_library() opens — the binary the numbers of a run come from (bench.py prints it, tools/profile_round.sh records it)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(HOOKS_LIB_PATH if test_hooks else LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""): h.update(blk)
+    return h.hexdigest()
+
+
+def load_library(test_hooks=False):
+    """dlopen libmi355pt.so (test_hooks: libmi355pt_testhooks.so, the tests' build with include/mi355pt_testhooks.h's evaluation hooks). Raises if it has not been built:
+    the product path never falls back to anything else."""
+    if _libs.get(test_hooks) is None:
+        path = HOOKS_LIB_PATH if test_hooks else LIB_PATH
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C rtxpt_amd/csrc`." % (os.path.basename(path), path))
         _share_hip_runtime_with_torch()
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         L.pt_get_last_error.restype = ctypes.c_char_p
         L.pt_get_last_error.argtypes = [ctypes.c_void_p]
-        _lib = L
-    return _lib
+        _libs[test_hooks] = L
+    return _libs[test_hooks]
 
 
 def _p(a):
@@ -637,11 +650,13 @@ def bridge_camera(width, height, pos, direction, up, fov_y, near_z=0.01, far_z=1
 class PathTracer:
     """One pt_context (one GPU). Method names follow the C-ABI; the call order follows Sample::Render."""
 
-    def __init__(self, device=0, shard_rank=0, shard_count=1, serial_kernels=False, prefer_fast_build=False, host_sah_builder=False):
+    def __init__(self, device=0, shard_rank=0, shard_count=1, serial_kernels=False, prefer_fast_build=False, host_sah_builder=False, test_hooks=False):
         """serial_kernels: PT_DEVICE_SERIAL_KERNELS — pt_render runs one batch on one stream (clean per-kernel timings) instead of two pipelined half-frame batches.
         prefer_fast_build: PT_DEVICE_PREFER_FAST_BUILD — scene builds use the plain device-side PLOC builder instead of the default fast-trace tree (PLOC + parallel
-        re-insertion + cost-driven wide nodes, on the device); host_sah_builder: PT_DEVICE_HOST_SAH_BUILDER — round 2's binned SAH + re-insertion on the host's cores."""
-        self.L = load_library()
+        re-insertion + cost-driven wide nodes, on the device); host_sah_builder: PT_DEVICE_HOST_SAH_BUILDER — round 2's binned SAH + re-insertion on the host's cores.
+        test_hooks: run on libmi355pt_testhooks.so, the tests' build of the same sources that also exports pt_probe (include/mi355pt_testhooks.h)."""
+        self.L = load_library(test_hooks)
+        self.test_hooks = test_hooks
         self.h = ctypes.c_void_p()
         desc = PtDeviceDesc(device, shard_rank, shard_count, (1 if serial_kernels else 0) | (2 if prefer_fast_build else 0) | (4 if host_sah_builder else 0))
         r = self.L.pt_create(ctypes.byref(desc), ctypes.byref(self.h))
@@ -948,10 +963,6 @@ class PathTracer:
         """pt_set_tail_paths: batches with at most this many live paths are finished by the tail kernel (0: never)."""
         self._chk(self.L.pt_set_tail_paths(self.h, int(max_paths)), "pt_set_tail_paths")
 
-    def set_stream_paths(self, paths_in_flight, batches=0):
-        """pt_set_stream_paths: streaming frames — at most this many paths per batch in flight, generation topping the extend queue up after every bounce (0: off)."""
-        self._chk(self.L.pt_set_stream_paths(self.h, int(paths_in_flight), int(batches)), "pt_set_stream_paths")
-
     def tonemap(self, params=None):
         """pt_tonemap: the accumulation buffer through ToneMappingPass into sRGB RGBA8 -> (H, W, 4) uint8."""
         t = default_tonemap() if params is None else params
@@ -1056,6 +1067,8 @@ class PathTracer:
         return d
 
     def probe(self, kind, inp, out_shape, out_dtype=np.float32):
+        """pt_probe (include/mi355pt_testhooks.h): only on a PathTracer(test_hooks=True)"""
+        if not self.test_hooks: raise RuntimeError("pt_probe is not part of the shipped library: PathTracer(test_hooks=True)")
         inp = np.ascontiguousarray(inp)
         out = np.zeros(out_shape, out_dtype)
         self._chk(self.L.pt_probe(self.h, kind, _p(inp), inp.nbytes, _p(out), out.nbytes, out_shape[0]), "pt_probe")

@@ -3,6 +3,9 @@
 // (Rtxpt/Sample.cpp:1891-2313 Render, :2438-2559 PathTrace, :1464-1556 UpdatePathTracerConstants, :2770-2778 accumulation).
 // There is NO CPU fallback: every entry point that needs the device fails with PT_ERROR_NO_DEVICE / PT_ERROR_HIP.
 #include "../../include/mi355pt.h"
+#ifdef MI355PT_TEST_HOOKS
+#include "../../include/mi355pt_testhooks.h"
+#endif
 #include "pt_wavefront.h"
 #include "pt_stableplanes_launch.h"
 #include "pt_build.h"
@@ -72,12 +75,6 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #ifndef PT_TAIL_PATHS
 #define PT_TAIL_PATHS 32768u     // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never
 #endif
-#ifndef PT_STREAM_PATHS
-#define PT_STREAM_PATHS 0u       // streaming frames (pt_render, pt_set_stream_paths): paths a batch keeps in flight, generation topping its extend queue up to this after every bounce; 0: all paths generated up front
-#endif
-#ifndef PT_STREAM_BATCHES
-#define PT_STREAM_BATCHES 0u     // batches of a streaming frame (0: the size rule of pt_render)
-#endif
 #ifndef PT_PIPELINE_BATCHES
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
 #endif
@@ -86,7 +83,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
-    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0, streamPaths = PT_STREAM_PATHS, streamBatches = PT_STREAM_BATCHES;   // second half-frame batch (pt_render pipelines two batches)
+    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -699,8 +696,6 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     { const char* e = getenv("MI355PT_BVH_BUILDER");        // developer A/B switch
       if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; else if (e && (!strcmp(e, "ploc_opt") || !strcmp(e, "device"))) c->bvhBuilder = BVH_BUILDER_PLOC_OPT; }
     { const char* e = getenv("MI355PT_TAIL_PATHS"); if (e) c->tailBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch (pt_set_tail_paths)
-    { const char* e = getenv("MI355PT_STREAM_PATHS"); if (e) c->streamPaths = (uint)strtoul(e, nullptr, 10); }      // developer A/B switches (pt_set_stream_paths)
-    { const char* e = getenv("MI355PT_STREAM_BATCHES"); if (e) c->streamBatches = (uint)strtoul(e, nullptr, 10); }
     { const char* e = getenv("MI355PT_TAIL_DEFER"); if (e) c->tailDefer = (uint)strtoul(e, nullptr, 10); }      // test switch: iterations after which the tail kernel hands a ray back (0: T8_TAIL_DEFER); a small value sends most rays through the hand-back path
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
@@ -1249,19 +1244,12 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
-        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false; uint bound = 0, genPos = 0;      // genPos: paths of the batch generated so far (a streaming frame generates in slices)      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
+        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false; uint bound = 0;      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; uint items; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         bool timed = false;      // per-launch HIP events: only when somebody reads them (serial-kernel steps, the pass log) — ten API calls per pass and batch otherwise
         size_t mark() { if (!timed) return 0; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
-    // Streaming (pt_set_stream_paths; verdict r04 item 1): a batch generates its paths in slices and keeps at most `streamPaths` of them in flight — after every bounce k_generate tops the
-    // next extend queue up with fresh paths, so the traversal launches stay one size while the frame lasts and dwindle only once, at its end, instead of once per batch from the second
-    // bounce on. The pool still holds one slot per (pixel, sample), the random streams are stateless and k_accumulate folds the samples in sample order afterwards: which paths share
-    // a launch is free, the image cannot change. Not in serial-kernel / counter frames (their per-bounce attribution is the point).
-    const bool streaming = c->streamPaths && !c->serialKernels && !c->countersEnabled;
     uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
-    if (c->streamBatches && !c->serialKernels) numBatches = c->streamBatches < (uint)PT_PIPELINE_BATCHES ? c->streamBatches : (uint)PT_PIPELINE_BATCHES;
-    const uint streamK = streaming ? (c->streamPaths < 1024u ? 1024u : c->streamPaths) : 0xFFFFFFFFu;
     Batch B[PT_PIPELINE_BATCHES];
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
@@ -1282,9 +1270,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         { static const uint blocksOverride = []() { const char* e = getenv("MI355PT_MAX_BLOCKS"); return e ? (uint)strtoul(e, nullptr, 10) : 0u; }(); if (blocksOverride) t.aux.maxBlocks = blocksOverride; }      // developer A/B switch
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
         t.timed = c->serialKernels || c->countersEnabled || getenv("MI355PT_PASS_LOG") != nullptr;
-        t.genPos = t.total < streamK ? t.total : streamK;
-        memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.genPos;
-        t.active = t.genPos;
+        memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
+        t.active = t.total;
     }
     if (numBatches > 1) PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // uploads issued on the main stream (prepare) must be visible to the second stream
     hipEvent_t frame0, frame1; PT_CHECK_HIP(c, hipEventCreate(&frame0)); PT_CHECK_HIP(c, hipEventCreate(&frame1));
@@ -1293,7 +1280,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         Batch& t = B[b];
         t.t0 = t.mark();
         PT_CHECK_HIP(c, hipMemcpyAsync(t.wc, t.hwc, sizeof(WaveCounters), hipMemcpyHostToDevice, t.st));
-        launch_generate(t.k, t.pool, c->dOwned.p + t.pixFirst, t.numPix, first, count, 0u, t.genPos, t.queue[0], nullptr, t.st);
+        launch_generate(t.k, t.pool, c->dOwned.p + t.pixFirst, t.numPix, first, count, 0u, t.total, t.queue[0], nullptr, t.st);
     }
     // upper bound on extend passes: bounceCount+1 vertices plus rejected (nested dielectric) re-traces
     uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u));
@@ -1314,7 +1301,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (!t.active || t.bound >= maxIter) continue;
             uint nxt = t.cur ^ 1u;
             launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch
-            if (tailBelow && t.active <= tailBelow && !t.afterTail && t.genPos == t.total) {      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
+            if (tailBelow && t.active <= tailBelow && !t.afterTail) {      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
                 size_t e0 = t.mark(); launch_tail(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, maxIter - t.bound, c->tailDefer, t.aux.maxBlocks, t.st); size_t e1 = t.mark();
                 if (t.timed) t.spans.push_back({e0, e1, 3, t.active});
                 t.tailLaunches++; t.afterTail = true; t.inTail = true;      // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
@@ -1322,7 +1309,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
                 t.waiting = true;
                 continue;
             }
-            t.afterTail = false; if (t.genPos == t.total) t.bound++; wavefrontPasses++;      // (the bounce bound counts from the pass that carries the batch's last fresh paths)
+            t.afterTail = false; t.bound++; wavefrontPasses++;
             size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
             launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
             t.extendRays += t.active;
@@ -1346,11 +1333,6 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
             if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
             t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
-            if (t.genPos < t.total && t.active < streamK) {      // streaming: fresh paths fill the next extend queue up (k_generate adds them to its device-side count)
-                const uint n = (streamK - t.active < t.total - t.genPos) ? streamK - t.active : t.total - t.genPos;
-                launch_generate(t.k, t.pool, c->dOwned.p + t.pixFirst, t.numPix, first, count, t.genPos, n, t.queue[nxt] + t.active, &t.wc->extendCount[nxt], t.st);
-                t.genPos += n; t.active += n;
-            }
             if (t.active && t.bound < maxIter) any = true;
         }
     }
@@ -1400,7 +1382,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     (void)hipEventDestroy(frame0); (void)hipEventDestroy(frame1);
     if (overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
     // The pass bound (maxIter) is a safety net, never what ends a path: a path ends by its own bounce / rejected-hit counters (PathTracer.hlsli:40-45, PathTracerNestedDielectrics.hlsli).
-    // Were a path still alive here, the set of dropped paths — the image — would depend on how the passes were composed (tail threshold, streaming): reported, not swallowed.
+    // Were a path still alive here, the set of dropped paths — the image — would depend on how the passes were composed (tail threshold): reported, not swallowed.
     for (uint b = 0; b < numBatches; b++) if (B[b].active) return fail(c, PT_ERROR_HIP, "pt_render: paths still alive at the pass bound (bounceCount + 2 + the nested-dielectric allowance): the bound must be raised");
     return PT_OK;
 }
@@ -1927,6 +1909,7 @@ int32_t pt_get_scene_info(pt_context* c, uint32_t* nTris, uint32_t* nNodes, uint
     if (nTris) *nTris = c->numTris; if (nNodes) *nNodes = c->numTris ? c->bvh.numNodes8 : 0;      /* BVH8 nodes */ if (nInst) *nInst = (uint32_t)c->instances.size(); if (nMat) *nMat = (uint32_t)c->materials.size();
     return PT_OK;
 }
+#ifdef MI355PT_TEST_HOOKS      // include/mi355pt_testhooks.h: exported by libmi355pt_testhooks.so only
 int32_t pt_probe(pt_context* c, int32_t kind, const void* in, size_t inBytes, void* out, size_t outBytes, uint32_t n) {
     if (!c || !in || !out || !n) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad argument");
     (void)hipSetDevice(c->device);
@@ -1941,6 +1924,7 @@ int32_t pt_probe(pt_context* c, int32_t kind, const void* in, size_t inBytes, vo
     di.free(); dout.free();
     return PT_OK;
 }
+#endif
 // ---- the frame gather (include/mi355pt.h "the frame gather itself")
 int32_t pt_shard_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t* pixels, uint32_t capacity, uint32_t* count) {
     if (!width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
@@ -2115,6 +2099,5 @@ int32_t pt_get_bvh_info(pt_context* c, PtBvhInfo* out) {
 int32_t pt_set_counters(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->countersEnabled = enable != 0; return PT_OK; }
 int32_t pt_set_serial_kernels(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->serialKernels = enable != 0; return PT_OK; }
 int32_t pt_set_tail_paths(pt_context* c, uint32_t maxPaths) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->tailBelow = maxPaths; return PT_OK; }
-int32_t pt_set_stream_paths(pt_context* c, uint32_t pathsInFlight, uint32_t batches) { if (!c || batches > (uint32_t)PT_PIPELINE_BATCHES) return PT_ERROR_INVALID_ARGUMENT; c->streamPaths = pathsInFlight; c->streamBatches = batches; return PT_OK; }
 
 } // extern "C"

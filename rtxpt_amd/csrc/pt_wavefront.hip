@@ -24,8 +24,7 @@ namespace ptk {
 #define T8_TASK_BLOCKS_N 512        // blocks of a task-round launch: task rounds hold thousands of sub-trees, not millions
 #endif
 
-// Paths [first, first + n) of the batch's pool region (slot i = sample i % spp of owned pixel i / spp) are generated and their indices written to queue[0 .. n). A streaming frame
-// (pt_render, pt_set_stream_paths) generates its paths in slices: `queue` is then the end of a queue that already holds the survivors of the last bounce, and thread 0 adds n to its counter.
+// Paths [first, first + n) of the batch's pool region (slot i = sample i % spp of owned pixel i / spp) are generated and their indices written to queue[0 .. n).
 __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint first, uint n, uint* __restrict__ queue, uint* countPtr) {
     const uint t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n) return;
@@ -513,6 +512,7 @@ __global__ void __launch_bounds__(256) k_bake_emissive(DeviceScene sc, const uin
     lights[lightBase + t] = lf.Base; lightsEx[lightBase + t] = lf.Extended;
 }
 
+#ifdef MI355PT_TEST_HOOKS      // libmi355pt_testhooks.so only (the tests' build of the library): the shipped library carries no evaluation hooks
 // known-answer probes for the tests: the device evaluates leaf functions so they can be compared bit-for-bit with the oracle
 __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, const float* __restrict__ in, float* __restrict__ out, uint n) {
     uint i = blockIdx.x * 64u + threadIdx.x; if (i >= n) return;
@@ -618,6 +618,7 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
     default: break;
     }
 }
+#endif
 
 #ifndef T8_ADAPTIVE_CHUNKS
 #define T8_ADAPTIVE_CHUNKS 1        // 1: launches below (resident waves x 64) rays use shorter chunks (see traverse8_pairs), 0: always 64 rays per chunk
@@ -918,8 +919,10 @@ void launch_bake_emissive(const DeviceScene& sc, const uint* subInstList, const 
     if (!totalTris) return;
     hipLaunchKernelGGL(k_bake_emissive, dim3((totalTris + 255) / 256), dim3(256), 0, st, sc, subInstList, subInstTriOffset, numEmissiveSubInst, totalTris, lightBase, lights, lightsEx);
 }
+#ifdef MI355PT_TEST_HOOKS
 void launch_probe(const PathKernelContext& k, int kind, const void* dIn, void* dOut, uint n, hipStream_t st) {
     hipLaunchKernelGGL(k_probe, dim3((n + 63) / 64), dim3(64), 0, st, k, kind, (const float*)dIn, (float*)dOut, n);
 }
+#endif
 
 } // namespace ptk

@@ -37,7 +37,7 @@ def test_device_cube_fetch_matches_oracle():
     directions along face edges and corners, and on axis-aligned ones."""
     pt, scenes, ptref, pin_scenes = _imports()
     sc = pin_scenes.env_cube_cases()["sky_64_hdr_sun"]
-    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(scenes.default_settings())
+    g = pt.PathTracer(test_hooks=True); g.set_scene(sc); g.set_settings(scenes.default_settings())
     o = ptref.Oracle(); o.set_scene(sc)
     rng = np.random.default_rng(11)
     d = rng.normal(size=(20000, 3)).astype(np.float32)

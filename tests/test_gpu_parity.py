@@ -128,7 +128,7 @@ def test_leaf_functions_bit_exact():
     """Device vs oracle: deterministic math, fp16 packing, sample streams, BSDF eval/sample, camera rays."""
     pt, scenes, parallel, ptref = _imports()
     L = ptref.lib()
-    g = pt.PathTracer()
+    g = pt.PathTracer(test_hooks=True)      # pt_probe: the tests' build of the library (include/mi355pt_testhooks.h)
     rng = np.random.default_rng(3)
     n = 20000
     for fn, lo, hi in ((0, -30, 30), (1, -30, 30), (2, -140, 130), (3, 1e-30, 1e30), (4, -5, 5), (5, 1e-3, 50), (6, -1, 1), (7, 0, 4)):
@@ -483,7 +483,7 @@ def test_device_load_surface_matches_oracle(name, lp16):
     pt, scenes, parallel, ptref = _imports()
     make, S, w, h, first, n = (_pin_cases_lp16() if lp16 else _pin_cases())[name]
     sc, cam = make()
-    g = pt.PathTracer(); g.set_scene(sc); g.set_settings(S); g.set_camera(scenes.bridge_camera(w, h, **cam)); g.resize(w, h)
+    g = pt.PathTracer(test_hooks=True); g.set_scene(sc); g.set_settings(S); g.set_camera(scenes.bridge_camera(w, h, **cam)); g.resize(w, h)
     o = ptref.Oracle(lp16=lp16); o.set_scene(sc); o.set_settings(S); o.resize(8, 8)
     nt = o.num_tris()
     rng = np.random.default_rng(0x5F + len(name)); k = 20000

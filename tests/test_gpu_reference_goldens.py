@@ -23,7 +23,7 @@ def _same(a, b):
 @pytest.fixture(scope="module")
 def tracer():
     import rtxpt_amd as pt
-    return pt.PathTracer()
+    return pt.PathTracer(test_hooks=True)      # pt_probe: the tests' build of the library (include/mi355pt_testhooks.h)
 
 
 @pytest.mark.parametrize("fn", range(len(PIN_NAMES)), ids=PIN_NAMES)
@@ -124,7 +124,7 @@ def test_device_load_surface_matches_reference_text(name, lp16):
     prims, rows, want = g[tag + "_prims"], g[tag + "_rows"], g[tag + "_out"]
     make, S, w, h, first, n = _pin_case(name, lp16)
     sc, cam = make()
-    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h)
+    t = pt.PathTracer(test_hooks=True); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h)
     rows8 = np.zeros((len(prims), 8), np.float32); rows8[:, 0] = prims.view(np.float32); rows8[:, 1:] = rows
     got = t.probe(8, rows8, (len(prims), 45), out_dtype=np.uint32)
     bad = (got != want).any(1)
@@ -143,7 +143,7 @@ def test_device_alpha_test_matches_reference_text(name):
     prims, uv, want = g["alpha_%s_prims" % name], g["alpha_%s_uv" % name], g["alpha_%s_out" % name]
     make, S, w, h, first, n = _pin_case(name, False)
     sc, cam = make()
-    t = pt.PathTracer(); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h)
+    t = pt.PathTracer(test_hooks=True); t.set_scene(sc); t.set_settings(S); t.set_camera(scenes.bridge_camera(w, h, **cam)); t.resize(w, h)
     rows = np.zeros((len(prims), 3), np.uint32); rows[:, 0] = prims; rows[:, 1:] = uv.view(np.uint32)
     got = t.probe(10, rows, (len(prims), 2), out_dtype=np.uint32)
     bad = (got != want).any(1)

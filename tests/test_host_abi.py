@@ -34,6 +34,18 @@ def test_exports_every_declared_symbol(lib):
     assert sorted(pt.EXPORTS) == names
 
 
+def test_shipped_library_carries_no_test_hooks(lib):
+    """include/mi355pt_testhooks.h: the evaluation hooks live in libmi355pt_testhooks.so (same sources, -DMI355PT_TEST_HOOKS), the shipped library exports none of them."""
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mi355pt_testhooks.h")).read(), flags=re.S)
+    hooks = sorted(set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", src)))
+    assert hooks == sorted(pt.TEST_HOOK_EXPORTS) and hooks
+    for n in hooks:
+        assert not hasattr(lib, n), "the shipped library exports the test hook " + n
+    hl = pt.load_library(test_hooks=True)
+    for n in declared_symbols() + hooks:
+        assert hasattr(hl, n), "libmi355pt_testhooks.so misses " + n
+
+
 def test_no_cpu_fallback(lib):
     import torch
     if torch.cuda.is_available():
