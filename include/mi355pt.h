@@ -644,10 +644,16 @@ int32_t pt_set_counters(pt_context* ctx, int32_t enable);
 int32_t pt_set_serial_kernels(pt_context* ctx, int32_t enable);
 /* The tail kernel: once a batch of pt_render holds at most `maxPaths` live paths, ONE launch runs them to their end — every wave loops trace -> shade -> visibility ->
    next bounce over 32 paths, the shape of the reference's raygen loop (Rtxpt/Shaders/PathTracerSample.hlsl:200-250) where it fits: few paths, bound by the length of
-   the launch chain of a wavefront pass, not by throughput. 0 = never (every pass is a wavefront pass); default 32768 (environment MI355PT_TAIL_PATHS overrides it at
+   the launch chain of a wavefront pass, not by throughput. 0 = never (every pass is a wavefront pass) — the default since round 6 (fused traversal launches made the late passes cheap; 32768 still helps small closed scenes by 2-3 %; environment MI355PT_TAIL_PATHS overrides it at
    pt_create). The image does not depend on the value (paths do not interact; tests render whole frames through the tail kernel). Ignored for NEEFullSamples > 1,
    serial-kernel and counter frames. */
 int32_t pt_set_tail_paths(pt_context* ctx, uint32_t maxPaths);
+/* Fused traversal launches: the visibility rays of path vertex k (Bridge::traceVisibilityRay, PathTracerNEE.hlsli:185-275) are traced in the same launch as the closest-hit rays of
+   vertex k + 1 (Bridge::traceScatterRay) — blocks of either kind side by side, straggler rounds and resolve passes shared — instead of in a launch of their own; their contributions
+   land before vertex k + 1 is shaded, as before, so the image does not depend on the mode (tests/test_gpu_fused_traversal.py). Launch composition only: it halves the traversal
+   launches of a bounce, which is what a small frame (one rank of a tile-sharded frame) is bound by. mode 0 = off, 1 = on, 2 = by the size of the pt_render call (default; environment
+   MI355PT_FUSED_TRAVERSAL overrides it at pt_create). Ignored for NEEFullSamples > 1, serial-kernel and counter frames. */
+int32_t pt_set_fused_traversal(pt_context* ctx, uint32_t mode);
 
 #ifdef __cplusplus
 }

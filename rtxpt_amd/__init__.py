@@ -32,7 +32,7 @@ EXPORTS = [
     "pt_resize", "pt_render", "pt_reset_accumulation", "pt_map_radiance", "pt_unmap_radiance", "pt_shard_info", "pt_pack_shard",
     "pt_unpack_shard", "pt_device_radiance", "pt_trace_closest", "pt_trace_visibility", "pt_get_lights", "pt_get_env_cube", "pt_get_subinstances",
     "pt_get_scene_info", "pt_get_build_stats", "pt_get_bvh_info", "pt_set_counters",
-    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_exchange_planes_host", "pt_neeat_update_begin", "pt_neeat_update_end", "pt_pack_stable_plane_guides", "pt_unpack_stable_plane_guides", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
+    "pt_default_tonemap", "pt_tonemap", "pt_image_read_float", "pt_image_free", "pt_image_read_dds", "pt_image_read_dds_memory", "pt_image_read_jpeg", "pt_scene_import_texture", "pt_write_png", "pt_write_bmp", "pt_set_fused_traversal", "pt_set_serial_kernels", "pt_set_tail_paths", "pt_animate_ranges", "pt_set_motion_history", "pt_set_previous_pose", "pt_realtime_frame", "pt_exchange_planes_host", "pt_neeat_update_begin", "pt_neeat_update_end", "pt_pack_stable_plane_guides", "pt_unpack_stable_plane_guides", "pt_stable_planes_shard_bytes", "pt_pack_stable_planes", "pt_unpack_stable_planes", "pt_gather_stable_planes", "pt_material_from_json", "pt_convert_light",
     "pt_tonemap_color_transform", "pt_scene_json_import", "pt_scene_import_free", "pt_scene_import_cameras", "pt_scene_import_lights",
     "pt_scene_import_directional_lights", "pt_scene_import_instances", "pt_scene_import_geometries", "pt_scene_import_materials", "pt_scene_import_vertices", "pt_set_scene_directional_lights", "pt_scene_import_apply", "pt_scene_import_settings", "pt_average_luminance",
     "pt_default_tone_mapping_parameters", "pt_tonemap_from_parameters", "pt_scene_import_tone_mapping",
@@ -962,6 +962,10 @@ class PathTracer:
     def set_tail_paths(self, max_paths):
         """pt_set_tail_paths: batches with at most this many live paths are finished by the tail kernel (0: never)."""
         self._chk(self.L.pt_set_tail_paths(self.h, int(max_paths)), "pt_set_tail_paths")
+
+    def set_fused_traversal(self, mode):
+        """pt_set_fused_traversal: 0 = visibility rays in launches of their own, 1 = in the next bounce's closest-hit launch (k_trace_pair), 2 = by the size of the call (default)."""
+        self._chk(self.L.pt_set_fused_traversal(self.h, int(mode)), "pt_set_fused_traversal")
 
     def tonemap(self, params=None):
         """pt_tonemap: the accumulation buffer through ToneMappingPass into sRGB RGBA8 -> (H, W, 4) uint8."""

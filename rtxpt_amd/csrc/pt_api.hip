@@ -73,7 +73,15 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #define PT_SP_FILL_RANGED 1      // the fill pass's first traversal launch uses FirstHitFromVBuffer's narrowed ray interval (pt_stableplanes.h firstHitInterval); 0: the whole ray (A/B) — same hits
 #endif
 #ifndef PT_TAIL_PATHS
-#define PT_TAIL_PATHS 32768u     // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never
+#define PT_TAIL_PATHS 0u         // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never. Off by default since round 6: with fused traversal
+                                  // launches the late passes are cheap enough that the tail kernel's idle GPU costs more than it saves (profiles/r06e_tail_threshold_fused_ab.txt: rank of eight 12.56 -> 12.11 ms,
+                                  // full frame 74.2 -> 73.6; only C2 — a small closed scene without long rays — keeps a gain from it, 6.21 -> 6.05 ms with 32768)
+#endif
+#ifndef PT_FUSED_TRAVERSAL
+#define PT_FUSED_TRAVERSAL 1u      // pt_set_fused_traversal (default: on — it pays at every size, profiles/r06b_fused_traversal_ab.txt): 0 = every bounce traces its visibility rays in a launch of their own, 1 = together with the closest-hit rays of the next bounce
+#endif                              // (k_trace_pair, pt_wavefront.hip), 2 = by the size of the call (PT_FUSED_BELOW)
+#ifndef PT_FUSED_BELOW
+#define PT_FUSED_BELOW (12u << 20)  // mode 2: calls of fewer paths than this fuse (one rank of a 4- or 8-way sharded 4K frame, 1080p frames); a full 4K x 4 spp frame (33 M) keeps its own launches
 #endif
 #ifndef PT_PIPELINE_BATCHES
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
@@ -83,7 +91,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
-    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0;   // second half-frame batch (pt_render pipelines two batches)
+    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0, fusedTraversal = PT_FUSED_TRAVERSAL;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -121,7 +129,7 @@ struct pt_context {
         void reset() { W = H = 0; updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; frameOpen = false; exportDepth = true; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
         void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); xSend.free(); xRecv.free(); xPixels.free(); depth.free(); histDepth.free(); }
     } neeat;
-    DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList; DevBuf<unsigned long long> dBestKey;
+    DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList, dResolveListSh; DevBuf<unsigned long long> dBestKey, dBestKeySh; DevBuf<ptk::TravTask> dTaskQSh;      // ...Sh: the visibility rays' own straggler state in a frame of fused traversal launches
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
     BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0; uint bvhBuilder = BVH_BUILDER_SAH;
     DeviceScene dsc;
@@ -696,6 +704,7 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     { const char* e = getenv("MI355PT_BVH_BUILDER");        // developer A/B switch
       if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; else if (e && (!strcmp(e, "ploc_opt") || !strcmp(e, "device"))) c->bvhBuilder = BVH_BUILDER_PLOC_OPT; }
     { const char* e = getenv("MI355PT_TAIL_PATHS"); if (e) c->tailBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch (pt_set_tail_paths)
+    { const char* e = getenv("MI355PT_FUSED_TRAVERSAL"); if (e) c->fusedTraversal = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch (pt_set_fused_traversal)
     { const char* e = getenv("MI355PT_TAIL_DEFER"); if (e) c->tailDefer = (uint)strtoul(e, nullptr, 10); }      // test switch: iterations after which the tail kernel hands a ray back (0: T8_TAIL_DEFER); a small value sends most rays through the hand-back path
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
@@ -715,7 +724,7 @@ int32_t pt_destroy(pt_context* c) {
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dPrevPositions.free(); c->dPrevInstances.free(); c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
     c->dPrimInfo.free(); c->dShadeTris.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvImageCube.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
-    c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free();
+    c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free(); c->dResolveListSh.free(); c->dBestKeySh.free(); c->dTaskQSh.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
     delete c;
@@ -1244,12 +1253,13 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
-        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false; uint bound = 0;      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
+        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false; uint bound = 0, pendingShadow = 0; TravAux auxSh;      // pendingShadow / auxSh: fused traversal launches (below)      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; uint items; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         bool timed = false;      // per-launch HIP events: only when somebody reads them (serial-kernel steps, the pass log) — ten API calls per pass and batch otherwise
         size_t mark() { if (!timed) return 0; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
     uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
+    { static const uint batchesOverride = []() { const char* e = getenv("MI355PT_BATCHES"); return e ? (uint)strtoul(e, nullptr, 10) : 0u; }(); if (batchesOverride && !c->serialKernels) numBatches = batchesOverride < (uint)PT_PIPELINE_BATCHES ? batchesOverride : (uint)PT_PIPELINE_BATCHES; }      // developer A/B switch
     Batch B[PT_PIPELINE_BATCHES];
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
@@ -1267,7 +1277,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         // then works through more chunks before it runs dry and fewer of its rays are cut into sub-trees; the other batches keep the GPU full. profiles/r05q_grid_cap_ab.txt:
         // a rank of eight (4.1 M paths) 896 blocks -1 ... -3 %, a rank of four / two 1120 blocks -1 %, the full frame (33 M paths) +1 % with either: hence by size.
         t.aux.maxBlocks = (numBatches >= 3u) ? (total < (6u << 20) ? 256u * 7u / 2u : (total < (24u << 20) ? 256u * 35u / 8u : 256u * 7u)) : 0u;
-        { static const uint blocksOverride = []() { const char* e = getenv("MI355PT_MAX_BLOCKS"); return e ? (uint)strtoul(e, nullptr, 10) : 0u; }(); if (blocksOverride) t.aux.maxBlocks = blocksOverride; }      // developer A/B switch
+        { static const uint blocksOverride = []() { const char* e = getenv("MI355PT_MAX_BLOCKS"); return e ? (uint)strtoul(e, nullptr, 10) : 0u; }(); if (blocksOverride) t.aux.maxBlocks = blocksOverride < T8_MAX_BLOCKS ? blocksOverride : T8_MAX_BLOCKS; }      // (clamped: a batch's stack-tail slice is sized for T8_MAX_BLOCKS blocks)      // developer A/B switch
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
         t.timed = c->serialKernels || c->countersEnabled || getenv("MI355PT_PASS_LOG") != nullptr;
         memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
@@ -1287,6 +1297,17 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     // the tail kernel takes over a batch once it holds at most this many paths (0: never). Not in serial-kernel / counter frames (their per-kernel attribution is the point), not with
     // grouped NEE samples (NEEFullSamples > 1 folds a vertex's samples in k_resolve_nee) and not without a tree (the traversal's empty-scene path is per launch, not per wave)
     const uint tailBelow = (!c->serialKernels && !c->countersEnabled && !shadowGroup && c->dsc.rootIsValid) ? c->tailBelow : 0u;
+    // Fused traversal launches (round 6; pt_set_fused_traversal, k_trace_pair): the visibility rays a bounce's shading leaves in the shadow queue are not traced in a launch of their own
+    // but wait (Batch::pendingShadow) for the next bounce's closest-hit launch and share it — and its task rounds and resolve pass — block by block. Nothing of vertex k + 1 needs the
+    // visibility of vertex k before vertex k + 1 is shaded (the order of the fp16 additions into a path's L), and that is exactly where the fused launch sits, so the image cannot change;
+    // the visibility rays need their own task queues, merge keys and resolve list (auxSh). A batch whose paths have ended, or which goes to the tail kernel, traces what is pending in a
+    // plain visibility launch first. Not in serial-kernel / counter frames (their per-kernel attribution is the point) and not with grouped NEE samples (k_resolve_nee).
+    const bool fused = !c->serialKernels && !c->countersEnabled && !shadowGroup && c->dsc.rootIsValid && (c->fusedTraversal == 1u || (c->fusedTraversal == 2u && total < PT_FUSED_BELOW));
+    if (fused) {
+        PT_CHECK_HIP(c, c->dBestKeySh.resize(c->shadowCapacity)); PT_CHECK_HIP(c, c->dResolveListSh.resize(c->shadowCapacity)); PT_CHECK_HIP(c, c->dTaskQSh.resize((size_t)PT_PIPELINE_BATCHES * 2 * TASK_QUEUE_CAPACITY));
+        for (uint b = 0; b < numBatches; b++) { Batch& t = B[b]; t.auxSh = t.aux; t.auxSh.counts = t.aux.counts + PASS_SHADOW_OFFSET; t.auxSh.taskQ[0] = c->dTaskQSh.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.auxSh.taskQ[1] = t.auxSh.taskQ[0] + TASK_QUEUE_CAPACITY;
+            t.auxSh.bestKey = c->dBestKeySh.p + (size_t)t.base * shadowPerPath; t.auxSh.resolveList = c->dResolveListSh.p + (size_t)t.base * shadowPerPath; }
+    }
     // Batches run in lockstep: a batch's next half-pass is queued when ALL batches have delivered their counts, which keeps one batch's shading next to the others' traversal
     // (free-running streams drift into running the same kernel at the same time: 7 % slower on the full frame and no gain on a rank of a sharded frame, DESIGN.md §4,
     // profiles/r04i_event_loop_ab.txt).
@@ -1300,8 +1321,9 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             if (t.waiting) continue;                        // a tail launch still in flight (below): the batch rejoins the lockstep when it is done
             if (!t.active || t.bound >= maxIter) continue;
             uint nxt = t.cur ^ 1u;
-            launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch
-            if (tailBelow && t.active <= tailBelow && !t.afterTail) {      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
+            launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], fused ? nullptr : &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch (fused: the shadow queue's counter still counts the pending rays; k_resolve_pair zeroes it)
+            if (tailBelow && t.active <= tailBelow && !t.afterTail) {
+                if (t.pendingShadow) { launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, false, t.auxSh, t.st); PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st)); t.pendingShadow = 0; }      // (the tail kernel adds to the paths' radiance itself: what is pending lands first)      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
                 size_t e0 = t.mark(); launch_tail(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, maxIter - t.bound, c->tailDefer, t.aux.maxBlocks, t.st); size_t e1 = t.mark();
                 if (t.timed) t.spans.push_back({e0, e1, 3, t.active});
                 t.tailLaunches++; t.afterTail = true; t.inTail = true;      // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
@@ -1310,7 +1332,10 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
                 continue;
             }
             t.afterTail = false; t.bound++; wavefrontPasses++;
-            size_t e0 = t.mark(); launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st); size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
+            size_t e0 = t.mark();
+            if (t.pendingShadow) { launch_trace_pair(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, t.aux, t.auxSh, t.st); t.pendingShadow = 0; }
+            else launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st);
+            size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
             launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
             t.extendRays += t.active;
             PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
@@ -1331,8 +1356,11 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
                 fprintf(stderr, "[pass log]   b%u pass %u: %u paths -> extend splits %u / %u / %u / %u sub-trees, %u rays resolved; %u visibility rays next\n", b, t.iterations, t.active, pc[0], pc[1], pc[2], pc[3], pc[TRAV_RESOLVE], nShadow);
             }
             TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
-            if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow; }
-            t.active = t.hwc->extendCount[nxt]; t.cur = nxt; t.iterations++;
+            t.active = t.hwc->extendCount[nxt];
+            if (fused && nShadow && t.active && t.bound < maxIter) { t.pendingShadow = nShadow; t.shadowRays += nShadow; }      // they ride with the next closest-hit launch
+            else if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, fused ? t.auxSh : auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow;
+                                if (fused) PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st)); }
+            t.cur = nxt; t.iterations++;
             if (t.active && t.bound < maxIter) any = true;
         }
     }
@@ -2099,5 +2127,6 @@ int32_t pt_get_bvh_info(pt_context* c, PtBvhInfo* out) {
 int32_t pt_set_counters(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->countersEnabled = enable != 0; return PT_OK; }
 int32_t pt_set_serial_kernels(pt_context* c, int32_t enable) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->serialKernels = enable != 0; return PT_OK; }
 int32_t pt_set_tail_paths(pt_context* c, uint32_t maxPaths) { if (!c) return PT_ERROR_INVALID_ARGUMENT; c->tailBelow = maxPaths; return PT_OK; }
+int32_t pt_set_fused_traversal(pt_context* c, uint32_t mode) { if (!c || mode > 2u) return PT_ERROR_INVALID_ARGUMENT; c->fusedTraversal = mode; return PT_OK; }
 
 } // extern "C"

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(T8_BLOCK, 2) k_tail(PKC k, PathPool pool, cons
             if (alive) { wRay[r][0] = make_float4(path.origin.x, path.origin.y, path.origin.z, kMaxRayTravel); wRay[r][1] = make_float4(path.dir.x, path.dir.y, path.dir.z, 0.f); }
             {
                 auto commit = [&](uint rr, const HitInfo& h) { wHit[rr] = make_uint4(asuint(h.t), h.prim, asuint(h.u), asuint(h.v)); };
-                traverse8_pairs<false, false, true, false, true, true>(sc, vbase + n, T8_CHUNK, stack, rayBuf, mineUV, fetchRay, commit, defer, TravTaskOut{nullptr, nullptr, deferIters}, ctr, &wc->overflow);
+                traverse8_pairs<false, false, true, false, true, true>(sc, vbase + n, T8_CHUNK, stack, rayBuf, mineUV, fetchRay, commit, defer, TravTaskOut{nullptr, nullptr, deferIters}, ctr, &wc->overflow, blockIdx.x, gridDim.x);
             }
             ShadowRequest req; req.valid = false;
             bool deferred = false;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(T8_BLOCK, 2) k_tail(PKC k, PathPool pool, cons
                 if (wantShadow) { wRay[rs][0] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax); wRay[rs][1] = make_float4(req.dir.x, req.dir.y, req.dir.z, 0.f); }
                 {
                     auto commit = [&](uint rr, const HitInfo& h) { wHit[rr] = make_uint4(h.prim == 0xFFFFFFFFu ? 1u : 0u, 0u, 0u, 0u); };
-                    traverse8_pairs<true, false, false, false, true, true>(sc, vbase + ns, T8_CHUNK, stack, rayBuf, nullptr, fetchRay, commit, defer, TravTaskOut{nullptr, nullptr, deferIters}, ctr, &wc->overflow);
+                    traverse8_pairs<true, false, false, false, true, true>(sc, vbase + ns, T8_CHUNK, stack, rayBuf, nullptr, fetchRay, commit, defer, TravTaskOut{nullptr, nullptr, deferIters}, ctr, &wc->overflow, blockIdx.x, gridDim.x);
                 }
                 bool shadowDeferred = false;
                 if (wantShadow) {

@@ -34,14 +34,16 @@ __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { retur
 // only reported through publish() — the caller has them traced again elsewhere (the tail kernel, pt_tail.hip, hands their paths back to the host loop). No task queue is touched.
 template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, bool DEFER = false, class Src, class Dst, class Pub>
 __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
-                                                Traverse8Counters& ctr, uint* overflowFlag) {
+                                                Traverse8Counters& ctr, uint* overflowFlag, const uint vBlock, const uint vGrid) {
+    // vBlock / vGrid: the block's index among, and the number of, the blocks that work on THIS launch's items — blockIdx.x / gridDim.x for a kernel of one kind; a fused launch
+    // (k_trace_pair: closest-hit blocks next to visibility blocks, pt_wavefront.hip) hands each kind its own range. The stack tails are addressed by the physical block index.
     static_assert(T8_LANES == 2u, "traverse8_pairs is the two-lanes-per-ray build");
     const uint RAY_STRIDE = TASKS ? T8_TASK_STRIDE : T8_RAY_STRIDE;
     const uint lane = threadIdx.x & 63u, h = lane & 1u, pl = lane & ~1u;
     const uint grp = threadIdx.x >> 1;
     uint2* stack = stackBase + grp * BVH8_STACK_STRIDE;
     const uint wavesPerBlock = T8_BLOCK / 64u;
-    const uint waveId = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6), numWaves = gridDim.x * wavesPerBlock;
+    const uint waveId = vBlock * wavesPerBlock + (threadIdx.x >> 6), numWaves = vGrid * wavesPerBlock;
     const char* nodesBase = reinterpret_cast<const char*>(sc.nodes8);
     const char* trisBase = reinterpret_cast<const char*>(sc.tris);
     const uint laneChildOff = 16u + 48u * h, laneTriOff = 48u * h;
@@ -161,6 +163,17 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
 #ifdef T8_PROBE_VNOPS
 #pragma unroll
         for (int k_ = 0; k_ < T8_PROBE_VNOPS; k_++) asm volatile("v_nop");
+#endif
+#ifdef T8_PROBE_FILL      // issue-slot probes (developer builds; tools/valu_ceiling): T8_PROBE_FILL_N independent filler instructions per wave iteration — 1: of the class that issues every
+        {                 // 2 cycles per SIMD (v_add_u32), 2: of the class that issues every 4 (v_max_f32), 3: v_cndmask_b32_e64. Outputs are dead; no register lives across the loop.
+            uint f0_, f1_;
+#pragma unroll
+            for (int k_ = 0; k_ < T8_PROBE_FILL_N / 2; k_++) {
+                if (T8_PROBE_FILL == 1) asm volatile("v_add_u32 %0, %2, %2\n v_add_u32 %1, %2, %2" : "=v"(f0_), "=v"(f1_) : "v"(lane));
+                else if (T8_PROBE_FILL == 2) asm volatile("v_max_f32 %0, %2, %2\n v_max_f32 %1, %2, %2" : "=v"(f0_), "=v"(f1_) : "v"(lane));
+                else asm volatile("v_cndmask_b32_e64 %0, %2, %2, s[0:1]\n v_cndmask_b32_e64 %1, %2, %2, s[0:1]" : "=v"(f0_), "=v"(f1_) : "v"(lane));
+            }
+        }
 #endif
         if (COUNT && lane == 0u) ctr.iters++;
         if (COUNT && active) rayIters++;

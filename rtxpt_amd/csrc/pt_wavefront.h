@@ -47,6 +47,9 @@ void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn
                   ShadowQueue sq, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st);
 void launch_classify(PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* classScratch, uint* classCount, hipStream_t st);      // k_classify: {continuing hit, terminating hit, miss} made contiguous
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
+// the closest-hit rays of the extend queue and the visibility rays of the previous vertex (shadow queue) in ONE traversal launch, their task rounds and resolve passes in shared launches
+// too (k_trace_pair; sq.group == 0 only). auxE / auxS must not share task queues, counters, keys or resolve lists; *shCountPtr is zero afterwards
+void launch_trace_pair(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* extCountPtr, uint extCount, ShadowQueue sq, uint* shCountPtr, uint shCount, WaveCounters* wc, TravAux auxE, TravAux auxS, hipStream_t st);
 // the late bounces of a batch in one launch: every wave runs 32 paths of queueIn to their end (at most maxBounces bounces each); stragglers and paths beyond the bound come back through
 // queueOut / countOutPtr (and, for visibility rays, the shadow queue / wc->shadowCount). NEEFullSamples 1 only (sq.group == 0); the pass's counters zeroed by the caller as for launch_shade
 void launch_tail(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, uint maxBounces, uint deferIters /* 0: T8_TAIL_DEFER */, uint maxBlocks, hipStream_t st);

@@ -40,14 +40,13 @@ __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool 
     if (countPtr && t == 0u) atomicAdd(countPtr, n);
 }
 
-template <bool COUNT, bool RANGED = false>
-__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux, uint rpc) {
+// The closest-hit launch of a bounce (Bridge::traceScatterRay for every path of the extend queue) as a device function, so that two kernels can run it: k_extend, and k_trace_pair
+// next to the visibility rays of the previous vertex. vBlock / vGrid: this block's place among the blocks that work on the extend queue (traverse8_pairs).
+template <bool COUNT, bool RANGED>
+__device__ __forceinline__ void t8_extend_body(const DeviceScene& sc, const PathPool& pool, const uint* __restrict__ queue, const uint count, WaveCounters* wc, const TravAux& aux, const uint rpc,
+                                               uint2* stack, uint* rayBuf, float2* mineUV, const uint vBlock, const uint vGrid) {
     // RANGED: every ray brings its own interval in the first two words of its (not yet written) hit record — the stable-plane fill pass's first launch, FirstHitFromVBuffer
     // (pt_stableplanes.h firstHitInterval). A ray of such a launch that is cut into sub-trees continues over [0, best hit so far]: the lower bound is a hint, not part of the query.
-    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
-    __shared__ uint rayBuf[T8_RAYBUF_WORDS];
-    __shared__ float2 mineUV[T8_BLOCK];
-    const uint count = *countPtr;
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
         uint p = queue[i];
@@ -61,10 +60,17 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
     // a split ray: its best hit so far seeds the merge key, the resolve pass will write pool.hit (k_resolve_extend)
     auto publish = [&](uint p, float bestT, uint bestPrim) { aux.bestKey[p] = t8_hit_key(bestT, bestPrim); aux.resolveList[atomicAdd(&aux.counts[TRAV_RESOLVE], 1u)] = p; };
     if (COUNT) { ctr.rayIterHist = wc->rayIterHistExt; ctr.longRayCount = &wc->longRayCount; ctr.longRays = &wc->longRays[0][0]; }
-    T8_TRAVERSE<false, COUNT, !RANGED, false, true>(sc, count, rpc, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<false, COUNT, !RANGED, false, true>(sc, count, rpc, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow, vBlock, vGrid);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsExt); wave_add64(ctr.triTests, &wc->triTestsExt); wave_add64(ctr.leafVisits, &wc->leafVisitsExt); wave_add64(ctr.iters, &wc->itersExt); wave_add64(ctr.leafBlocks, &wc->leafBlocksExt); if ((threadIdx.x & 63u) == 0u) atomicMax(&wc->itersMaxExt, (unsigned long long)ctr.iters);
                  if ((threadIdx.x & 63u) == 0u) for (int q = 0; q < 4; q++) atomicAdd(&wc->phaseCycExt[q], ctr.cyc[q]);
                  for (int q = 0; q < 8; q++) wave_add64(ctr.ev[q], &wc->eventsExt[q]); }
+}
+template <bool COUNT, bool RANGED = false>
+__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux, uint rpc) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
+    __shared__ uint rayBuf[T8_RAYBUF_WORDS];
+    __shared__ float2 mineUV[T8_BLOCK];
+    t8_extend_body<COUNT, RANGED>(sc, pool, queue, *countPtr, wc, aux, rpc, stack, rayBuf, mineUV, blockIdx.x, gridDim.x);
 }
 
 // Task rounds hold hundreds to thousands of sub-trees, far fewer than the launch has quads. A 64-item chunk would put them on count/64 waves (one rank of
@@ -78,11 +84,9 @@ __device__ __forceinline__ uint t8_tasks_per_chunk(uint count) { return (!T8_TAS
 // the sub-trees are split again into the other queue (count: counts[STAGE + 1]). One counter per round: the whole block is zeroed once per pass (pt_wavefront.h TravAux).
 // Task i of the launch is queue entry (i % 64) * ceil(count / 64) + i / 64: the sub-trees of one ray sit next to each other in the queue and
 // would otherwise land in one 64-item chunk, i.e. on one wave.
-template <int STAGE, bool FINAL = (STAGE == 3)>
-__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks(DeviceScene sc, PathPool pool, WaveCounters* wc, TravAux aux) {
+template <int STAGE, bool FINAL>
+__device__ __forceinline__ void t8_extend_tasks_body(const DeviceScene& sc, const PathPool& pool, WaveCounters* wc, const TravAux& aux, uint2* stack, uint* rayBuf, const uint vBlock, const uint vGrid) {
     constexpr int IN = STAGE & 1;
-    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
-    __shared__ uint rayBuf[T8_TASKBUF_WORDS];
     uint count = aux.counts[STAGE]; if (count > aux.taskCap) count = aux.taskCap;
     if (count == 0u) return;
     const TravTask* tasks = aux.taskQ[IN];
@@ -102,13 +106,19 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks
     };
     auto commit = [&](uint p, const HitInfo& h) { atomicMin(&aux.bestKey[p], t8_hit_key(h.t, h.prim)); };
     auto publish = [&](uint p, float bestT, uint bestPrim) { if (bestPrim != 0xFFFFFFFFu) atomicMin(&aux.bestKey[p], t8_hit_key(bestT, bestPrim)); };
-    T8_TRAVERSE<false, false, true, true, !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<false, false, true, true, !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow, vBlock, vGrid);
+}
+template <int STAGE, bool FINAL = (STAGE == 3)>
+__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend_tasks(DeviceScene sc, PathPool pool, WaveCounters* wc, TravAux aux) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
+    __shared__ uint rayBuf[T8_TASKBUF_WORDS];
+    t8_extend_tasks_body<STAGE, FINAL>(sc, pool, wc, aux, stack, rayBuf, blockIdx.x, gridDim.x);
 }
 
 // split extend rays: the merged key -> hit record; the barycentrics come from re-intersecting the winning triangle (same arithmetic, same operands)
-__global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool pool, TravAux aux) {
+__device__ __forceinline__ void t8_resolve_extend_body(const DeviceScene& sc, const PathPool& pool, const TravAux& aux, const uint vBlock, const uint vGrid) {
     const uint n = aux.counts[TRAV_RESOLVE];
-    for (uint i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    for (uint i = vBlock * 256u + threadIdx.x; i < n; i += vGrid * 256u) {
         uint p = aux.resolveList[i];
         unsigned long long key = aux.bestKey[p];
         uint prim = (uint)key;
@@ -123,6 +133,7 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
         pool.hit[p] = out;
     }
 }
+__global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool pool, TravAux aux) { t8_resolve_extend_body(sc, pool, aux, blockIdx.x, gridDim.x); }
 
 #ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 256       // threads per k_shade block (the queue appends meet per block: one atomic per block and counter)
@@ -278,11 +289,11 @@ __device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, ui
     }
 }
 
+// The visibility launch of a path vertex (Bridge::traceVisibilityRay for every entry of the shadow queue) as a device function: k_shadow, and k_trace_pair next to the closest-hit
+// rays of the next vertex.
 template <bool COUNT, bool GROUPED>
-__global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux, uint rpc) {
-    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
-    __shared__ uint rayBuf[T8_RAYBUF_WORDS];
-    const uint count = *countPtr;
+__device__ __forceinline__ void t8_shadow_body(const DeviceScene& sc, const PathPool& pool, const ShadowQueue& sq, const uint count, WaveCounters* wc, const TravAux& aux, const uint rpc,
+                                               uint2* stack, uint* rayBuf, const uint vBlock, const uint vGrid) {
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
         float4 a = sq.q0[i], b = sq.q1[i];
@@ -292,15 +303,19 @@ __global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_s
     auto commit = [&](uint i, const HitInfo& h) { if (h.prim == 0xFFFFFFFFu) shadow_visible<GROUPED>(pool, sq, i); };      // occluded: nothing is committed
     // a split shadow ray: "visible so far"; its sub-trees may set the flag, k_resolve_shadow applies the contribution if none did
     auto publish = [&](uint i, float, uint) { aux.bestKey[i] = 0ull; aux.resolveList[atomicAdd(&aux.counts[TRAV_RESOLVE], 1u)] = i; };
-    T8_TRAVERSE<true, COUNT, false, false, true>(sc, count, rpc, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<true, COUNT, false, false, true>(sc, count, rpc, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[0], &aux.counts[0], aux.taskCap}, ctr, &wc->overflow, vBlock, vGrid);
     if (COUNT) { wave_add64(ctr.nodeVisits, &wc->nodeVisitsSh); wave_add64(ctr.triTests, &wc->triTestsSh); wave_add64(ctr.leafVisits, &wc->leafVisitsSh); wave_add64(ctr.iters, &wc->itersSh); }
 }
-
-template <int STAGE, bool FINAL = (STAGE == 3)>
-__global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, ShadowQueue sq, WaveCounters* wc, TravAux aux) {
-    constexpr int IN = STAGE & 1;
+template <bool COUNT, bool GROUPED>
+__global__ void __launch_bounds__(T8_BLOCK, COUNT ? 1 : T8_SHADOW_MIN_WAVES) k_shadow(DeviceScene sc, PathPool pool, ShadowQueue sq, const uint* __restrict__ countPtr, WaveCounters* wc, TravAux aux, uint rpc) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
-    __shared__ uint rayBuf[T8_TASKBUF_WORDS];
+    __shared__ uint rayBuf[T8_RAYBUF_WORDS];
+    t8_shadow_body<COUNT, GROUPED>(sc, pool, sq, *countPtr, wc, aux, rpc, stack, rayBuf, blockIdx.x, gridDim.x);
+}
+
+template <int STAGE, bool FINAL>
+__device__ __forceinline__ void t8_shadow_tasks_body(const DeviceScene& sc, const ShadowQueue& sq, WaveCounters* wc, const TravAux& aux, uint2* stack, uint* rayBuf, const uint vBlock, const uint vGrid) {
+    constexpr int IN = STAGE & 1;
     uint count = aux.counts[STAGE]; if (count > aux.taskCap) count = aux.taskCap;
     if (count == 0u) return;
     const TravTask* tasks = aux.taskQ[IN];
@@ -317,16 +332,53 @@ __global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, Shado
     };
     auto commit = [&](uint i, const HitInfo& h) { if (h.prim != 0xFFFFFFFFu) aux.bestKey[i] = 1ull; };
     auto publish = [&](uint, float, uint) {};
-    T8_TRAVERSE<true, false, false, true, !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow);
+    T8_TRAVERSE<true, false, false, true, !FINAL>(sc, per * T8_CHUNK, T8_CHUNK, stack, rayBuf, nullptr, fetch, commit, publish, TravTaskOut{aux.taskQ[IN ^ 1], &aux.counts[FINAL ? STAGE : STAGE + 1], FINAL ? 0u : aux.taskCap}, ctr, &wc->overflow, vBlock, vGrid);
+}
+template <int STAGE, bool FINAL = (STAGE == 3)>
+__global__ void __launch_bounds__(T8_BLOCK) k_shadow_tasks(DeviceScene sc, ShadowQueue sq, WaveCounters* wc, TravAux aux) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
+    __shared__ uint rayBuf[T8_TASKBUF_WORDS];
+    t8_shadow_tasks_body<STAGE, FINAL>(sc, sq, wc, aux, stack, rayBuf, blockIdx.x, gridDim.x);
 }
 
 template <bool GROUPED>
-__global__ void __launch_bounds__(256) k_resolve_shadow(PathPool pool, ShadowQueue sq, TravAux aux) {
+__device__ __forceinline__ void t8_resolve_shadow_body(const PathPool& pool, const ShadowQueue& sq, const TravAux& aux, const uint vBlock, const uint vGrid) {
     const uint n = aux.counts[TRAV_RESOLVE];
-    for (uint k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+    for (uint k = vBlock * 256u + threadIdx.x; k < n; k += vGrid * 256u) {
         uint i = aux.resolveList[k];
         if (aux.bestKey[i] == 0ull) shadow_visible<GROUPED>(pool, sq, i);
     }
+}
+template <bool GROUPED>
+__global__ void __launch_bounds__(256) k_resolve_shadow(PathPool pool, ShadowQueue sq, TravAux aux) { t8_resolve_shadow_body<GROUPED>(pool, sq, aux, blockIdx.x, gridDim.x); }
+
+// ---- Fused traversal launches (round 6). The visibility rays of path vertex k and the closest-hit rays of vertex k + 1 are independent of each other — the visibility results only
+// have to be in the paths' radiance before vertex k + 1 is SHADED (the order of the fp16 additions into PathState::L: the light sample of vertex k, then the emission found at
+// vertex k + 1; PathTracer.hlsli:505-762, PathTracerNEE.hlsli:185-275) — so one launch traces both: blocks [0, blocksE) work through the extend queue, the others through the shadow
+// queue; every block is of one kind, the traversal loops themselves are the ones k_extend / k_shadow run (no per-ray kind, not one instruction more in the loop). What it buys a
+// small frame (one rank of a tile-sharded frame): half the traversal launches of a pass and half the straggler rounds behind them — the two kinds' task rounds and resolve passes
+// share their launches too (k_tasks_pair, k_resolve_pair) — and each kind's dry tail runs beside the other kind's work instead of in a launch of its own.
+__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_trace_pair(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ extCountPtr, ShadowQueue sq, const uint* __restrict__ shCountPtr,
+                                                                              WaveCounters* wc, TravAux auxE, TravAux auxS, uint rpcE, uint rpcS, uint blocksE) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
+    __shared__ uint rayBuf[T8_RAYBUF_WORDS];
+    __shared__ float2 mineUV[T8_BLOCK];
+    if (blockIdx.x < blocksE) t8_extend_body<false, false>(sc, pool, queue, *extCountPtr, wc, auxE, rpcE, stack, rayBuf, mineUV, blockIdx.x, blocksE);
+    else t8_shadow_body<false, false>(sc, pool, sq, *shCountPtr, wc, auxS, rpcS, stack, rayBuf, blockIdx.x - blocksE, gridDim.x - blocksE);
+}
+template <int STAGE, bool FINAL = (STAGE == 3)>
+__global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_tasks_pair(DeviceScene sc, PathPool pool, ShadowQueue sq, WaveCounters* wc, TravAux auxE, TravAux auxS) {
+    __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
+    __shared__ uint rayBuf[T8_TASKBUF_WORDS];
+    const uint half = gridDim.x >> 1;
+    if (blockIdx.x < half) t8_extend_tasks_body<STAGE, FINAL>(sc, pool, wc, auxE, stack, rayBuf, blockIdx.x, half);
+    else t8_shadow_tasks_body<STAGE, FINAL>(sc, sq, wc, auxS, stack, rayBuf, blockIdx.x - half, gridDim.x - half);
+}
+// ... and the two resolve passes; the shadow queue's counter is zeroed here for the k_shade that follows (every reader of it — k_trace_pair — is an earlier launch of the stream)
+__global__ void __launch_bounds__(256) k_resolve_pair(DeviceScene sc, PathPool pool, ShadowQueue sq, TravAux auxE, TravAux auxS, uint* shadowCount) {
+    const uint half = gridDim.x >> 1;
+    if (blockIdx.x < half) t8_resolve_extend_body(sc, pool, auxE, blockIdx.x, half);
+    else { t8_resolve_shadow_body<false>(pool, sq, auxS, blockIdx.x - half, gridDim.x - half); if (blockIdx.x == half && threadIdx.x == 0u) *shadowCount = 0u; }
 }
 
 // NEEFullSamples != 1: NEEResult accumulates the visible samples of a path vertex in sample order (fp16, PathTracerTypes.hlsli:170-207), then the
@@ -378,10 +430,10 @@ __global__ void __launch_bounds__(T8_BLOCK) k_trace_probe(DeviceScene sc, const 
     auto publish = [&](uint, float, uint) {};
     if (outClosest) {
         auto commit = [&](uint i, const HitInfo& h) { outClosest[i] = make_float4(h.t, asfloat(h.prim), h.u, h.v); };
-        T8_TRAVERSE<false, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
+        T8_TRAVERSE<false, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow, blockIdx.x, gridDim.x);
     } else {
         auto commit = [&](uint i, const HitInfo& h) { outVisible[i] = (h.prim == 0xFFFFFFFFu) ? 1u : 0u; };
-        T8_TRAVERSE<true, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow);
+        T8_TRAVERSE<true, false, false, false, false>(sc, n, T8_CHUNK, stack, rayBuf, mineUV, fetch, commit, publish, TravTaskOut{nullptr, nullptr, 0u}, ctr, overflow, blockIdx.x, gridDim.x);
     }
 }
 
@@ -685,6 +737,32 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
     hipLaunchKernelGGL((k_extend_tasks<3>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 1, to the end
     hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
 }
+// One launch for the closest-hit rays of the extend queue AND the visibility rays the previous vertex left in the shadow queue (k_trace_pair), then the task rounds and resolve passes of
+// both. auxE / auxS: separate task queues, counters, merge keys and resolve lists. The grid is what the two launches would use if it fits the bound, else the bound split by ray count
+// (a visibility ray costs about what a closest-hit ray costs: 0.50 against 0.44 ns on C3). Zeroes *shCountPtr at its end.
+void launch_trace_pair(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* extCountPtr, uint extCount, ShadowQueue sq, uint* shCountPtr, uint shCount, WaveCounters* wc, TravAux auxE, TravAux auxS, hipStream_t st) {
+    const uint rpc = rays_per_chunk(extCount + shCount);
+    const uint bound = (auxE.maxBlocks && auxE.maxBlocks < T8_MAX_BLOCKS) ? auxE.maxBlocks : T8_MAX_BLOCKS;
+    uint gE = grid_for(extCount, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, bound), gS = grid_for(shCount, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, bound);
+    if (gE + gS > bound) {
+        uint s = (uint)(((unsigned long long)bound * shCount + (extCount + shCount) / 2u) / (extCount + shCount)); if (s < 1u) s = 1u; if (s > bound - 1u) s = bound - 1u;
+        if (s > gS) s = gS;
+        uint e = bound - s; if (e > gE) { e = gE; s = (bound - e < gS) ? bound - e : gS; }
+        gE = e; gS = s;
+    }
+    hipLaunchKernelGGL(k_trace_pair, dim3(gE + gS), dim3(T8_BLOCK), 0, st, sc, pool, queue, extCountPtr, sq, shCountPtr, wc, auxE, auxS, rpc, rpc, gE);
+    const dim3 tg(2u * T8_TASK_BLOCKS), tb(T8_BLOCK);
+    if (extCount <= T8_SHORT_TAIL_BELOW && shCount <= T8_SHORT_TAIL_BELOW) {      // (as launch_extend: two task rounds behind a small launch)
+        hipLaunchKernelGGL((k_tasks_pair<0>), tg, tb, 0, st, sc, pool, sq, wc, auxE, auxS);
+        hipLaunchKernelGGL((k_tasks_pair<1, true>), tg, tb, 0, st, sc, pool, sq, wc, auxE, auxS);
+    } else {
+        hipLaunchKernelGGL((k_tasks_pair<0>), tg, tb, 0, st, sc, pool, sq, wc, auxE, auxS);
+        hipLaunchKernelGGL((k_tasks_pair<1>), tg, tb, 0, st, sc, pool, sq, wc, auxE, auxS);
+        hipLaunchKernelGGL((k_tasks_pair<2>), tg, tb, 0, st, sc, pool, sq, wc, auxE, auxS);
+        hipLaunchKernelGGL((k_tasks_pair<3>), tg, tb, 0, st, sc, pool, sq, wc, auxE, auxS);
+    }
+    hipLaunchKernelGGL(k_resolve_pair, dim3(2u * T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, sq, auxE, auxS, shCountPtr);
+}
 // k_classify for a caller in another translation unit (the stable-plane fill pass): classScratch 2 x countIn words, classCount 3 words (zero on entry)
 void launch_classify(PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* classScratch, uint* classCount, hipStream_t st) {
     hipLaunchKernelGGL(k_classify, dim3((countIn + 1024u * PT_CLASSIFY_ITEMS - 1u) / (1024u * PT_CLASSIFY_ITEMS)), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
@@ -730,7 +808,7 @@ void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const u
 __global__ void __launch_bounds__(64) k_pass_begin(uint* __restrict__ passCounters, uint* __restrict__ nextCount, uint* __restrict__ shadowCount) {
     if (threadIdx.x < PASS_COUNTERS) passCounters[threadIdx.x] = 0u;
     if (threadIdx.x == 32u) *nextCount = 0u;
-    if (threadIdx.x == 33u) *shadowCount = 0u;
+    if (threadIdx.x == 33u && shadowCount) *shadowCount = 0u;      // (null: a frame of fused traversal launches, whose k_resolve_pair zeroes it)
 }
 void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st) { static_assert(PASS_COUNTERS <= 32u, "k_pass_begin"); hipLaunchKernelGGL(k_pass_begin, dim3(1), dim3(64), 0, st, passCounters, nextCount, shadowCount); }
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
