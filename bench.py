@@ -26,7 +26,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 # algorithmic bytes: extend ray 52 B fixed + BVH: 128 B per BVH8 node visit + 48 B per triangle test
 B_EXTEND_FIXED, B_NODE, B_TRI, B_SHADE, B_SHADOW_FIXED = 52.0, 128.0, 48.0, 656.0, 80.0
-COUNTERS_FILE = "r05z_counters.json"     # rocprofv3 --pmc summary of this workload (tools/profile_round.sh), quoted in roofline{} — only if it was collected on the kernels that run here (kernel_source_sha256)
+def _newest_counters():
+    """the newest committed end-of-round counter summary, profiles/rNNz_counters.json (tools/profile_round.sh): quoted in roofline{} — only if it was collected on the sources this library was built from"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]z_counters.json")))
+    return os.path.basename(c[-1]) if c else "none"
+
+
+COUNTERS_FILE = _newest_counters()
+ISSUE_CEILING, ISSUE_CEILING_4CYCLE = 0.486, 0.248      # VALU instructions per SIMD and cycle on gfx950: in total / for the 4-cycle class (tools/valu_ceiling, profiles/r06a_valu_ceiling.txt)
 
 
 def main():
@@ -201,11 +209,12 @@ def main():
         traffic = cj["hbm_bytes_per_launch"]; hbm_counter_gbs = cj["hbm_counter_gbs"]; l2 = cj["l2_hit_rate"]
         valu = {"busy": cj["valu_busy"], "lane_utilisation": cj["lane_utilisation"], "valu_instructions_per_vmem_read": cj["valu_per_vmem_read"],
                 "wait_any_share_of_wave_cycles": cj["wait_any_share_of_wave_cycles"]}
-        # Round 3: what is full is the VALU issue port. Extra v_nop issue slots in the traversal loop lengthen k_extend one for one (+10 % slots = +9 % time,
-        # +20 % = +21 %, profiles/r03i_valu_bound_probe.txt), and SQ_INSTS_VALU per SIMD and cycle sits at the 1/4 a 16-lane SIMD can issue for wave64.
+        # What limits the loop (round 6, calibrated: tools/valu_ceiling -> profiles/r06a_valu_ceiling.txt). gfx950 issues at most 0.486 VALU instructions per SIMD and cycle in total
+        # and 0.248 of the 4-cycle class (everything but two-operand add / mul / logic / mov); a lone wave issues one instruction per ~4.5 cycles. Filler instructions of either
+        # class in the loop (+10 %) lengthen k_extend by 4-6 %: the loop is about half bound by the instructions a wave has to issue, half by its dependent loads.
         vps = cj.get("valu_instr_per_simd_cycle") or 0.0
-        busy = cj.get("valu_busy") or 0.0       # SQ_ACTIVE_INST_VALU per SIMD and cycle: the share of cycles in which the VALU is occupied
-        bound = "hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else ("valu" if (vps >= 0.22 or busy >= 0.85) else "latency")      # wave64 on a 16-lane SIMD issues at most 0.25 VALU instructions per cycle
+        bound = "hbm" if (hbm_counter_gbs or 0) >= 0.5 * HBM_PEAK_GBS else ("issue" if vps >= 0.4 * ISSUE_CEILING else "latency")
+        valu["share_of_total_issue_ceiling"] = vps / ISSUE_CEILING; valu["issue_ceilings"] = {"total": ISSUE_CEILING, "four_cycle_class": ISSUE_CEILING_4CYCLE}
         valu["instructions_per_simd_cycle"] = vps
 
     if rank == 0:
@@ -219,20 +228,20 @@ def main():
                                       "RGBA16F" if args.no_env_compression else "2048 BC6H (reference default on D3D12)", bvh["builderName"], bvh["builtOn"], bvh["buildMs"], bvh["hostMs"], bvh["numWideNodes"]),
                        "bvh": bvh,
                        "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "transport": args.transport if world > 1 else "none",
-                       "rehearsal": bool(host_transport), "kernel_source_sha256": digest, "rays_per_step": rays_total / args.steps,
+                       "rehearsal": bool(host_transport), "kernel_source_sha256": digest, "library_sha256": pt.library_digest(), "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP,
                        "tail_kernel_launches_per_step": sum(s["tailLaunches"] for s in stats) / args.steps},
             # `frac` is the prescribed figure: algorithmic bytes / launch time / 8 TB/s. `bound` is what the counters say limits the kernel:
-            # the BVH is served from L1/L2, HBM itself carries `hbm_counter_gbs`, and the VALU issue slots are what is full (`bound`: "valu").
+            # the BVH is served from L1/L2, HBM itself carries `hbm_counter_gbs`; the loop is bound by instruction issue and dependent-load latency together (`bound`: "issue").
             "roofline": {"bound": bound, "prescribed_bound": "hbm", "kernel": "k_extend", "achieved": ext_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "quoted from the committed rocprofv3 --pmc summary (counters_source), not measured in this run", "hbm_counter_gbs": hbm_counter_gbs, "l2_hit_rate": l2, "valu": valu, "counters_source": counters_src,
-                         "bound_evidence": "profiles/r03i_valu_bound_probe.txt: +10 % / +20 % VALU issue slots (v_nop) in the traversal loop = +9 % / +21 % k_extend time; HBM at ~16 % of peak",
+                         "bound_evidence": "profiles/r06a_valu_ceiling.txt: measured issue ceilings (0.486 VALU instructions per SIMD and cycle in total, 0.248 for the 4-cycle class) and the filler probe (+10 % instructions of either class in the traversal loop = +4 ... 6 % k_extend time): 'issue' = about half bound by the instructions a wave issues, half by dependent-load latency; HBM itself at ~18 % of peak",
                          "whole_frame": {"algorithmic_bytes_per_step": frame_bytes, "achieved": frame_gbs, "frac": frame_gbs / HBM_PEAK_GBS,
                                          "terms": "extend rays x (52 + 128 nodes + 48 tris) + hits x 656 + shadow rays x (80 + 128 nodes + 48 tris), over the pipelined step time"},
                          "bytes_per_ray": bytes_per_ext, "node_visits_per_ray": nodes_per_ext, "tri_tests_per_ray": tris_per_ext,
                          "avg_launch_ms": ext_ms / max(1, ext_launches), "launches": ext_launches,
                          "kernel_ms_per_step": {"k_extend": ext_ms / ROOF_STEPS, "k_shade": shade_ms / ROOF_STEPS, "k_shadow": sh_ms / ROOF_STEPS},
-                         "measured_on": "%d serial-kernel steps after the timed region (launches do not overlap); serial frame %.1f ms vs pipelined %.1f ms" % (ROOF_STEPS, serial_ms, elapsed / args.steps * 1e3),
+                         "measured_on": "%d serial-kernel steps after the timed region (launches do not overlap, closest-hit and visibility rays in launches of their own; the timed region fuses them: k_trace_pair runs the same two loops); serial frame %.1f ms vs pipelined %.1f ms" % (ROOF_STEPS, serial_ms, elapsed / args.steps * 1e3),
                          "shadow_node_visits_per_ray": nodes_per_sh, "shadow_tri_tests_per_ray": tris_per_sh,
                          "leaf_visits_per_ray": cst["leafVisitsExtend"] / max(1, cst["extendRays"]),
                          "wave_iterations_per_ray": cst["waveItersExtend"] / max(1, cst["extendRays"]),

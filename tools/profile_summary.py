@@ -2,9 +2,11 @@
 A "launch" of a traversal stage is the stage kernel plus its straggler task rounds and resolve pass (what bench.py brackets with HIP events).
 Formulas (gfx94x definitions, the ones rocprofv3 falls back to on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots"):
   gpu_cycles       = GRBM_GUI_ACTIVE / 8        the counter comes back summed over the 8 XCDs (18.9 G "cycles" per second = 8 x 2.36 GHz)
-  valu_busy        = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * gpu_cycles)      the VALUBusy formula: 4 cycles per issued wave64 VALU instruction. It comes out
-                     slightly above 1 on the traversal kernels (packed-fp32 and other double-rate instructions take 2 cycles): the issue slots are full
-  valu_instr_per_simd_cycle = SQ_INSTS_VALU / (1024 * gpu_cycles)
+  valu_busy        = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * gpu_cycles)      the VALUBusy formula. The counter charges every issued wave64 VALU instruction one quad-cycle
+                     whatever its class, so this is "VALU instructions x 4 cycles": exact for the 4-cycle class, an over-statement for the two-operand ALU instructions that
+                     issue every 2 cycles (profiles/r06a_valu_ceiling.txt, tools/valu_ceiling)
+  valu_instr_per_simd_cycle = SQ_INSTS_VALU / (1024 * gpu_cycles)             measured ceilings on gfx950 (same file): 0.486 in total, 0.248 for the 4-cycle class
+  valu_share_of_issue_ceiling = valu_instr_per_simd_cycle / 0.486
   lane_utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64)           active lanes per issued VALU instruction
   hbm_bytes        = (2 * FETCH_SIZE + WRITE_SIZE) * 1024      FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); WRITE_SIZE uncalibrated;
                      Infinity-Cache hits are counted as traffic
@@ -49,6 +51,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rtxpt_amd
 out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc (separate passes), 1 serial-kernel step of bench.py's default workload",
        "kernel_source_sha256": rtxpt_amd.kernel_source_digest(),      # bench.py quotes these counters only for the kernels they were collected on
+       "library_sha256": rtxpt_amd.library_digest(),                  # ... and the binary they ran in
+       "issue_ceilings": {"total_instr_per_simd_cycle": 0.486, "four_cycle_class_instr_per_simd_cycle": 0.248, "source": "profiles/r06a_valu_ceiling.txt (tools/valu_ceiling on this GPU)"},
        "kernel_trace_stats": stats, "groups": {}}
 for g, _ in GROUPS:
     c = cnt[g]
@@ -61,6 +65,7 @@ for g, _ in GROUPS:
          "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(1.0, c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0)),
          "valu_busy": c.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0) if c.get("GRBM_GUI_ACTIVE") else None,
          "valu_instr_per_simd_cycle": c.get("SQ_INSTS_VALU", 0.0) / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0) if c.get("GRBM_GUI_ACTIVE") else None,
+         "valu_share_of_issue_ceiling": c.get("SQ_INSTS_VALU", 0.0) / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0) / 0.486 if c.get("GRBM_GUI_ACTIVE") else None,
          "gpu_clock_ghz": c["GRBM_GUI_ACTIVE"] / 8.0 / (dur[g] * 1e-3) / 1e9 if c.get("GRBM_GUI_ACTIVE") and dur[g] else None,
          "lane_utilisation": c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_ACTIVE_INST_VALU") else None,
          "wait_any_share_of_wave_cycles": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
