@@ -83,6 +83,9 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #ifndef PT_FUSED_BELOW
 #define PT_FUSED_BELOW (12u << 20)  // mode 2: calls of fewer paths than this fuse (one rank of a 4- or 8-way sharded 4K frame, 1080p frames); a full 4K x 4 spp frame (33 M) keeps its own launches
 #endif
+#ifndef PT_FREE_RUN_BELOW
+#define PT_FREE_RUN_BELOW (1u << 22)   // pt_render: once every live batch holds fewer paths than this, the batches stop advancing in lockstep (0: lockstep to the end)
+#endif
 #ifndef PT_PIPELINE_BATCHES
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
 #endif
@@ -105,7 +108,7 @@ struct pt_context {
     std::vector<ptk::PolymorphicLightInfo> lights; std::vector<ptk::PolymorphicLightInfoEx> lightsEx; std::vector<uint> envLookup; uint envLookupDim = 0; uint numProxies = 0, envLightsBaked = 0;      // (light weights / proxy table live on the device only)
     DevBuf<float> dLightW; DevBuf<uint> dProxyOffsets; void* dScanTemp = nullptr; size_t scanTempBytes = 0;
     // device
-    DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
+    DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dOwnedDealt, dQueue[2], dEmissiveList, dEmissiveOffsets;
     DevBuf<float> dPrevPositions; DevBuf<InstanceDesc> dPrevInstances; bool motionHistory = false, prevAllStale = false; std::vector<uint32_t> prevStaleRanges;      // pt_set_motion_history: the previous frame's pose; the (first, count) vertex ranges in which it differs from the current one
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::AlphaPlane> dAlphaPlanes; DevBuf<unsigned char> dAlphaPool; DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
@@ -721,7 +724,7 @@ int32_t pt_destroy(pt_context* c) {
     c->neeat.free(); c->dLocalTable.free(); c->dFbWeight.free(); c->dFbCand.free(); c->dSq3.free();
     c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free(); c->dLightW.free(); c->dProxyOffsets.free(); if (c->dScanTemp) (void)hipFree(c->dScanTemp);
     if (c->bvhAllocated) bvh_free(c->bvh);
-    c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
+    c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dOwnedDealt.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dPrevPositions.free(); c->dPrevInstances.free(); c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
     c->dPrimInfo.free(); c->dShadeTris.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvImageCube.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free(); c->dResolveListSh.free(); c->dBestKeySh.free(); c->dTaskQSh.free();
@@ -1062,6 +1065,15 @@ int32_t pt_resize(pt_context* c, uint32_t w, uint32_t h) {
     PT_CHECK_HIP(c, c->dAccum.resize((size_t)w * h));
     PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)w * h, c->stream));
     PT_CHECK_HIP(c, c->dOwned.upload(c->owned, c->stream));
+    {   // pt_render's order of the same pixels: the tiles dealt round-robin into PT_PIPELINE_BATCHES groups, group after group. Its batches are contiguous ranges of this list, so every
+        // batch is an even sample of the frame instead of one quadrant of it (the shard lists are in Morton order: sky in one batch, the street in another) — the batches of a pass
+        // then take equally long, which is what their lockstep wants. Paths do not interact and k_accumulate folds a pixel's samples in sample order: the image cannot depend on it.
+        std::vector<uint> dealt; dealt.reserve(c->owned.size());
+        std::vector<std::pair<size_t, size_t>> tiles;      // runs of pixels of one 32 x 32 tile (first, count)
+        for (size_t i = 0; i < c->owned.size();) { const uint tx = (c->owned[i] >> 16) / 32u, ty = (c->owned[i] & 0xFFFFu) / 32u; size_t j = i; while (j < c->owned.size() && (c->owned[j] >> 16) / 32u == tx && (c->owned[j] & 0xFFFFu) / 32u == ty) j++; tiles.push_back({i, j - i}); i = j; }
+        for (uint g = 0; g < (uint)PT_PIPELINE_BATCHES; g++) for (size_t k = g; k < tiles.size(); k += PT_PIPELINE_BATCHES) dealt.insert(dealt.end(), c->owned.begin() + tiles[k].first, c->owned.begin() + tiles[k].first + tiles[k].second);
+        PT_CHECK_HIP(c, c->dOwnedDealt.upload(dealt, c->stream));
+    }
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }
@@ -1260,6 +1272,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     };
     uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
     { static const uint batchesOverride = []() { const char* e = getenv("MI355PT_BATCHES"); return e ? (uint)strtoul(e, nullptr, 10) : 0u; }(); if (batchesOverride && !c->serialKernels) numBatches = batchesOverride < (uint)PT_PIPELINE_BATCHES ? batchesOverride : (uint)PT_PIPELINE_BATCHES; }      // developer A/B switch
+    static const bool dealTiles = []() { const char* e = getenv("MI355PT_DEAL_TILES"); return !e || atoi(e) != 0; }();      // developer A/B switch (0: batches = contiguous ranges of the shard list)
+    const uint* ownedOrder = dealTiles ? c->dOwnedDealt.p : c->dOwned.p;
     Batch B[PT_PIPELINE_BATCHES];
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
@@ -1290,7 +1304,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         Batch& t = B[b];
         t.t0 = t.mark();
         PT_CHECK_HIP(c, hipMemcpyAsync(t.wc, t.hwc, sizeof(WaveCounters), hipMemcpyHostToDevice, t.st));
-        launch_generate(t.k, t.pool, c->dOwned.p + t.pixFirst, t.numPix, first, count, 0u, t.total, t.queue[0], nullptr, t.st);
+        launch_generate(t.k, t.pool, ownedOrder + t.pixFirst, t.numPix, first, count, 0u, t.total, t.queue[0], nullptr, t.st);
     }
     // upper bound on extend passes: bounceCount+1 vertices plus rejected (nested dielectric) re-traces
     uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u));
@@ -1312,61 +1326,94 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     // (free-running streams drift into running the same kernel at the same time: 7 % slower on the full frame and no gain on a rank of a sharded frame, DESIGN.md §4,
     // profiles/r04i_event_loop_ab.txt).
     const bool passLog = getenv("MI355PT_PASS_LOG") != nullptr;
+    // One pass of a batch is queued by queue_pass (counter reset, traversal — fused with the pending visibility rays — classify + shade, read-back of the two queue counts) and
+    // finished by finish_pass once those counts have arrived (the visibility rays become pending, or are traced if the batch ends here).
+    uint wavefrontPasses = 0;
+    auto queue_pass = [&](Batch& t) -> int32_t {
+        uint nxt = t.cur ^ 1u;
+        launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], fused ? nullptr : &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch (fused: the shadow queue's counter still counts the pending rays; k_resolve_pair zeroes it)
+        if (tailBelow && t.active <= tailBelow && !t.afterTail) {
+            if (t.pendingShadow) { launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, false, t.auxSh, t.st); PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st)); t.pendingShadow = 0; }      // (the tail kernel adds to the paths' radiance itself: what is pending lands first)      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
+            size_t e0 = t.mark(); launch_tail(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, maxIter - t.bound, c->tailDefer, t.aux.maxBlocks, t.st); size_t e1 = t.mark();
+            if (t.timed) t.spans.push_back({e0, e1, 3, t.active});
+            t.tailLaunches++; t.afterTail = true; t.inTail = true;      // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
+            PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
+            t.waiting = true;
+            return PT_OK;
+        }
+        t.afterTail = false; t.bound++; wavefrontPasses++;
+        size_t e0 = t.mark();
+        if (t.pendingShadow) { launch_trace_pair(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, t.aux, t.auxSh, t.st); t.pendingShadow = 0; }
+        else launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st);
+        size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
+        launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
+        t.extendRays += t.active;
+        PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
+        t.waiting = true;
+        return PT_OK;
+    };
+    auto finish_pass = [&](Batch& t, uint b) -> int32_t {
+        t.waiting = false; t.inTail = false;
+        uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
+        if (passLog) {      // the pass's straggler counters: sub-trees split off by k_extend and by task rounds 0..2, rays sent to the resolve pass (the previous pass's shadow launch is reported with the next line)
+            uint pc[PASS_COUNTERS]; PT_CHECK_HIP(c, hipMemcpy(pc, t.aux.counts, sizeof(pc), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pass log]   b%u pass %u: %u paths -> extend splits %u / %u / %u / %u sub-trees, %u rays resolved; %u visibility rays next\n", b, t.iterations, t.active, pc[0], pc[1], pc[2], pc[3], pc[TRAV_RESOLVE], nShadow);
+        }
+        TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
+        t.active = t.hwc->extendCount[nxt];
+        if (fused && nShadow && t.active && t.bound < maxIter) { t.pendingShadow = nShadow; t.shadowRays += nShadow; }      // they ride with the next closest-hit launch
+        else if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, fused ? t.auxSh : auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow;
+                            if (fused) PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st)); }
+        t.cur = nxt; t.iterations++;
+        return PT_OK;
+    };
+    auto live = [&](const Batch& t) { return t.active && t.bound < maxIter; };
+    // Small passes run free (round 6). The lockstep above pays while every pass fills the GPU; at the end of a frame — and for the whole of a small frame — a pass is a chain of
+    // a dozen short launches, the batches no longer take equally long, and in lockstep three streams sit idle until the slowest has delivered its counts (0.7 - 1 ms per late pass of
+    // the 4K frame, profiles/r06i_*). Once every live batch holds fewer than `freeRunBelow` paths the loop turns event-driven: whichever batch's counts arrive first is finished and
+    // its next pass queued at once.
+    static const uint freeRunBelow = []() { const char* e = getenv("MI355PT_FREE_RUN_BELOW"); return e ? (uint)strtoul(e, nullptr, 10) : (uint)PT_FREE_RUN_BELOW; }();
     bool any = true;
     while (any) {
+        bool freeRun = freeRunBelow != 0u && numBatches > 1u;
+        for (uint b = 0; b < numBatches; b++) if (live(B[b]) && B[b].active >= freeRunBelow) freeRun = false;
         // phase 1: every live batch queues extend + shade and the read-back of its queue counts
-        uint wavefrontPasses = 0;
+        wavefrontPasses = 0;
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b];
             if (t.waiting) continue;                        // a tail launch still in flight (below): the batch rejoins the lockstep when it is done
-            if (!t.active || t.bound >= maxIter) continue;
-            uint nxt = t.cur ^ 1u;
-            launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], fused ? nullptr : &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch (fused: the shadow queue's counter still counts the pending rays; k_resolve_pair zeroes it)
-            if (tailBelow && t.active <= tailBelow && !t.afterTail) {
-                if (t.pendingShadow) { launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, false, t.auxSh, t.st); PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st)); t.pendingShadow = 0; }      // (the tail kernel adds to the paths' radiance itself: what is pending lands first)      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
-                size_t e0 = t.mark(); launch_tail(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, maxIter - t.bound, c->tailDefer, t.aux.maxBlocks, t.st); size_t e1 = t.mark();
-                if (t.timed) t.spans.push_back({e0, e1, 3, t.active});
-                t.tailLaunches++; t.afterTail = true; t.inTail = true;      // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
-                PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
-                t.waiting = true;
-                continue;
-            }
-            t.afterTail = false; t.bound++; wavefrontPasses++;
-            size_t e0 = t.mark();
-            if (t.pendingShadow) { launch_trace_pair(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, t.aux, t.auxSh, t.st); t.pendingShadow = 0; }
-            else launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st);
-            size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
-            launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
-            t.extendRays += t.active;
-            PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
-            t.waiting = true;
+            if (!live(t)) continue;
+            int32_t r1 = queue_pass(t); if (r1 != PT_OK) return r1;
         }
-        // phase 2: as each batch's counts arrive, queue its shadow rays; the other batch keeps the GPU busy meanwhile
         any = false;
+        if (freeRun) {      // event-driven until every batch has ended
+            uint waiting = 0; for (uint b = 0; b < numBatches; b++) waiting += B[b].waiting ? 1u : 0u;
+            while (waiting) {
+                for (uint b = 0; b < numBatches; b++) {
+                    Batch& t = B[b];
+                    if (!t.waiting || hipStreamQuery(t.st) == hipErrorNotReady) continue;
+                    PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
+                    int32_t r2 = finish_pass(t, b); if (r2 != PT_OK) return r2;
+                    waiting--;
+                    if (live(t)) { int32_t r1 = queue_pass(t); if (r1 != PT_OK) return r1; waiting++; }
+                }
+            }
+            break;
+        }
+        // phase 2: as each batch's counts arrive, its visibility rays become pending (or are traced, if the batch ends); the other batches keep the GPU busy meanwhile
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b];
             if (!t.waiting) continue;
             // a tail launch runs for about a millisecond — several of the other batches' passes: while those have wavefront passes to queue, it is only polled
             if (t.inTail && wavefrontPasses && hipStreamQuery(t.st) == hipErrorNotReady) { any = true; continue; }
             PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
-            t.waiting = false; t.inTail = false;
-            uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
-            if (passLog) {      // the pass's straggler counters: sub-trees split off by k_extend and by task rounds 0..2, rays sent to the resolve pass (the previous pass's shadow launch is reported with the next line)
-                uint pc[PASS_COUNTERS]; PT_CHECK_HIP(c, hipMemcpy(pc, t.aux.counts, sizeof(pc), hipMemcpyDeviceToHost));
-                fprintf(stderr, "[pass log]   b%u pass %u: %u paths -> extend splits %u / %u / %u / %u sub-trees, %u rays resolved; %u visibility rays next\n", b, t.iterations, t.active, pc[0], pc[1], pc[2], pc[3], pc[TRAV_RESOLVE], nShadow);
-            }
-            TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
-            t.active = t.hwc->extendCount[nxt];
-            if (fused && nShadow && t.active && t.bound < maxIter) { t.pendingShadow = nShadow; t.shadowRays += nShadow; }      // they ride with the next closest-hit launch
-            else if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, fused ? t.auxSh : auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow;
-                                if (fused) PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st)); }
-            t.cur = nxt; t.iterations++;
-            if (t.active && t.bound < maxIter) any = true;
+            int32_t r2 = finish_pass(t, b); if (r2 != PT_OK) return r2;
+            if (live(t)) any = true;
         }
     }
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
-        launch_accumulate(t.pool, c->dOwned.p + t.pixFirst, t.numPix, count, c->dAccum.p, c->accumCount, c->width, t.st);
+        launch_accumulate(t.pool, ownedOrder + t.pixFirst, t.numPix, count, c->dAccum.p, c->accumCount, c->width, t.st);
         t.t1 = t.mark();
         PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, sizeof(WaveCounters), hipMemcpyDeviceToHost, t.st));
     }

@@ -694,19 +694,28 @@ template <bool LP16> struct PathKernelContextT {
         path.SetPackedMISInfo_ThpRuRuCorrection(path.GetPackedMISInfo(), 1.0f / (1.0f - prob));
         return false;
     }
+    // Where the path's state lives while HandleHit runs. PathInRegisters: the caller loaded all of it and stores it afterwards (the tail kernel, the probes). A kernel that streams paths
+    // through the pool (k_shade, pt_wavefront.hip) passes an IO that (i) loads the words the surface does not need only after loadSurface, (ii) stores the scattered path's first four
+    // word groups as soon as GenerateScatterRay has made them — before the light sampling, the vertex's register peak, which then carries 5 words of the path instead of 21 — and
+    // (iii) stores the last group ({firefly K | pdf, MIS info | roulette correction, flags | vertex index, sample index}) at the end. Same values either way: order of loads and stores only.
+    struct PathInRegisters { static constexpr bool streams = false; void mark(int) const {} void load_rest(PathState&) const {} void store_front(const PathState&) const {} void store_back(const PathState&) const {} void store_all(const PathState&) const {} };
     // PathTracer.hlsli:505-762 (reference mode), shadow test deferred through `req`
     // (a split of this vertex at NEE — a light-sample kernel and a scatter kernel — was built and measured in round 4: 21.5 -> 27.5 ms, profiles/r04p_shade_split_ab.txt; history: af4c2b2)
-    template <bool MULTI, bool NEEAT>
-    __attribute__((always_inline)) void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req, const ShadowSink* sink) const {
-        req.valid = false;
-        const float3 rayOrigin = path.origin, rayDir = path.dir;
-        UpdatePathTravelled(path, hit.t);
+    template <bool MULTI, bool NEEAT, class IO = PathInRegisters>
+    __attribute__((always_inline)) void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req, const ShadowSink* sink, const IO& io = IO()) const {
+        req.valid = false; io.mark(0);      // (mark: cycle stamps of the phases in PT_SHADE_PHASE_PROBE builds, nothing otherwise)
+        const float3 rayDir = path.dir;
+        path.rayCone = path.rayCone.propagateDistance(hit.t); path.sceneLength = fminf_(path.sceneLength + hit.t, kMaxRayTravel);      // UpdatePathTravelled, the two updates the surface needs ...
         SurfaceData sfd = loadSurface(hit.prim, hit.u, hit.v, rayDir, path.rayCone);
+        io.mark(1);
+        io.load_rest(path);
+        path.incrementVertexIndex();                                                                                                    // ... and the third, once the flags word is there
+        const float3 rayOrigin = path.origin;
         if (S.nestedDielectricsQuality > 0 && !path.interiorList.isEmpty()) {
             float3 tr = volumeTransmittance(path.interiorList.getTopMaterialID(), hit.t);
             path.SetThp(path.GetThp() * tr);
         }
-        if (!HandleNestedDielectrics(sfd, path)) return;
+        if (!HandleNestedDielectrics(sfd, path)) { io.store_all(path); return; }
         const ShadingData& sd = sfd.shadingData; const StandardBSDF& bsdf = sfd.bsdf;
         float3 surfaceEmission = make_float3(0.f);
         NEEBSDFMISInfo misInfo = NEEBSDFMISInfo::Unpack16bit(path.GetPackedMISInfo());
@@ -735,14 +744,18 @@ template <bool LP16> struct PathKernelContextT {
             float3 co, cd; computeCameraRay(path.id >> 16, path.id & 0xFFFFu, path.sampleIndex, co, cd);
             ExportDepth(path, co + cd * path.sceneLength);
         }
-        if (path.isTerminatingAtNextBounce()) { path.terminate(); return; }
+        if (path.isTerminatingAtNextBounce()) { path.terminate(); io.store_all(path); return; }
         float rr = path.GetThpRuRuCorrection();
         path.SetThp(path.GetThp() * make_float3(rr));
+        io.mark(2);
         SampleGeneratorVertexBase vb = SampleGeneratorVertexBase::make(path.id, path.getVertexIndex(), path.sampleIndex);
         UniformSampleSequenceGenerator uniformSG = UniformSampleSequenceGenerator::make(vb, SGES_Base);
         const PathState preScatterPath = path;
         bool scatterValid = GenerateScatterRay(sd, bsdf, path, vb);
+        io.mark(3);
+        io.store_front(path);      // origin | id, direction | length, throughput | radiance, interior list | counters | ray cone: final from here on
         const uint misPacked = S.NEEEnabled ? HandleNEE<MULTI, NEEAT>(preScatterPath, sd, bsdf, uniformSG, req, sink) : NEEBSDFMISInfo::empty().Pack16bit();
+        io.mark(4);
         path.SetPackedMISInfo_ThpRuRuCorrection(misPacked, path.GetThpRuRuCorrection());
         if (!scatterValid) path.terminate();
         bool shouldTerminate = HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces));
@@ -754,6 +767,8 @@ template <bool LP16> struct PathKernelContextT {
             req.rrFix = (terminateVisible != shouldTerminate ? 1u : 0u) | (terminateVisible ? 2u : 0u) | ((visiblePath.pack1 & 0xFFFFu) << 16);
         } else shouldTerminate |= HandleRussianRoulette(path, uniformSG);
         if (shouldTerminate) path.setFlag(PF_terminateAtNextBounce);
+        io.store_back(path);
+        io.mark(5);
     }
     // the deferred half: NEEResult::AccumulateRadiance (fp16, PathTracerTypes.hlsli:170-207) then AccumulatePathRadiance (PathTracer.hlsli:722-746)
     static void NeeAccumulate(uint nee[2], float3 radiance) {                       // NEEResult::AccumulateRadiance (the spec-average lane is not used in reference mode)

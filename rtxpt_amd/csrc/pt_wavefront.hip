@@ -204,23 +204,31 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
             const uint nGo = classCount[0], nEnd = classCount[1];
             p = queueIn[i < nGo ? i : (i < nGo + nEnd ? count - 1u - (i - nGo) : count + (i - nGo - nEnd))];
         } else p = queueIn[i];
-        PathState path = load_path(pool, p);
         uint4 hr = pool.hit[p];
         HitInfo h; h.t = asfloat(hr.x); h.prim = hr.y; h.u = asfloat(hr.z); h.v = asfloat(hr.w);
+#if PT_SHADE_PROBE
+        PathState path = load_path(pool, p);
 #if PT_SHADE_PROBE == 1          // timing probes (developer builds only, the image is wrong by design): 1 = stream the path state through, nothing else
         if (h.prim != 0xFFFFFFFFu) { isHit = true; path.sceneLength += h.t; } path.terminate();
 #elif PT_SHADE_PROBE == 2        // 2 = the surface gather (record, instance, material, textures) and nothing after it
         if (h.prim != 0xFFFFFFFFu) { isHit = true; SurfaceData sfd = k.loadSurface(h.prim, h.u, h.v, path.dir, path.rayCone); path.origin = sfd.shadingData.posW + sfd.shadingData.N * sfd.bsdf.data.roughness + sfd.bsdf.data.diffuse + sfd.shadingData.T; } path.terminate();
-#else
-        if (h.prim == 0xFFFFFFFFu) k.template HandleMiss<NEEAT>(path, path.dir, kMaxRayTravel);
-        else {
-            isHit = true;
-            if (MULTI) { ShadowSink sink{sq.q0, sq.q1, sq.q2, &wc->shadowCount, &wc->shadowValid, p}; k.template HandleHit<true, NEEAT>(path, h, req, &sink); }
-            else k.template HandleHit<false, NEEAT>(path, h, req, nullptr);
-        }
 #endif
         store_path(pool, p, path);
         alive = path.isActive();
+#else
+        if (h.prim == 0xFFFFFFFFu) { PathState path = load_path(pool, p); k.template HandleMiss<NEEAT>(path, path.dir, kMaxRayTravel); store_path(pool, p, path); alive = path.isActive(); }
+        else {
+            isHit = true;
+            const PathPoolIO io{pool, p};      // the path streams through HandleHit: late loads, early stores (pt_wavefront_device.h)
+            PathState path = io.load_first();
+            if (MULTI) { ShadowSink sink{sq.q0, sq.q1, sq.q2, &wc->shadowCount, &wc->shadowValid, p}; k.template HandleHit<true, NEEAT>(path, h, req, &sink, io); }
+            else k.template HandleHit<false, NEEAT>(path, h, req, nullptr, io);
+            alive = path.isActive();
+#ifdef PT_SHADE_PHASE_PROBE
+            for (int q = 1; q < 6; q++) wave_add64(io.tk[q] ? (unsigned long long)(uint)(io.tk[q] - io.tk[q - 1 - (io.tk[q - 1] ? 0 : 1)]) : 0ull, &wc->eventsExt[q - 1]);      // (a vertex that returns early leaves later stamps at 0)
+#endif
+        }
+#endif
     }
 #if PT_SHADE_BLOCK_APPEND
     // Queue appends, one atomic per BLOCK and counter: the four waves' counts meet in LDS, thread 0 reserves both ranges. A launch of 33 M paths has 518 k waves; one

@@ -41,6 +41,40 @@ __device__ __forceinline__ PathState load_path(const PathPool& pool, uint i) {
     return p;
 }
 
+// k_shade's view of a path (PathKernelContext::HandleHit's IO policy, pt_path.h): the words loadSurface needs come first (direction | length, interior list | counters | ray cone), the
+// rest after the surface is loaded; the scattered path's first four groups are stored before the light sampling, the last group at the end
+struct PathPoolIO {
+    static constexpr bool streams = true;
+    PathPool pool; uint i;
+#ifdef PT_SHADE_PHASE_PROBE      // developer build: cycle stamps at HandleHit's phase boundaries (k_shade adds the differences up in WaveCounters::eventsExt)
+    mutable uint tk[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    __device__ __forceinline__ void mark(int k) const { tk[k] = (uint)__builtin_readcyclecounter(); }
+#else
+    __device__ __forceinline__ void mark(int) const {}
+#endif
+    __device__ __forceinline__ PathState load_first() const {
+        PathState p; uint4 b = pool.s1[i], d = pool.s3[i];
+        p.dir = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z)); p.sceneLength = asfloat(b.w);
+        p.interiorList.slots[0] = d.x; p.interiorList.slots[1] = d.y; p.packedCounters = d.z; p.rayCone.widthSpreadAngleFP16 = d.w;
+        return p;
+    }
+    __device__ __forceinline__ void load_rest(PathState& p) const {
+        asm volatile("" ::: "memory");      // (not before the surface is loaded: these twelve registers are what the load order is about)
+        uint4 a = pool.s0[i], c = pool.s2[i], e = pool.s4[i];
+        p.origin = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)); p.id = a.w;
+        p.pack23[0] = c.x; p.pack23[1] = c.y; p.pack45[0] = c.z; p.pack45[1] = c.w;
+        p.pack0 = e.x; p.pack1 = e.y; p.flagsAndVertexIndex = e.z; p.sampleIndex = e.w;
+    }
+    __device__ __forceinline__ void store_front(const PathState& p) const {
+        pool.s0[i] = make_uint4(asuint(p.origin.x), asuint(p.origin.y), asuint(p.origin.z), p.id);
+        pool.s1[i] = make_uint4(asuint(p.dir.x), asuint(p.dir.y), asuint(p.dir.z), asuint(p.sceneLength));
+        pool.s2[i] = make_uint4(p.pack23[0], p.pack23[1], p.pack45[0], p.pack45[1]);
+        pool.s3[i] = make_uint4(p.interiorList.slots[0], p.interiorList.slots[1], p.packedCounters, p.rayCone.widthSpreadAngleFP16);
+    }
+    __device__ __forceinline__ void store_back(const PathState& p) const { pool.s4[i] = make_uint4(p.pack0, p.pack1, p.flagsAndVertexIndex, p.sampleIndex); }
+    __device__ __forceinline__ void store_all(const PathState& p) const { store_path(pool, i, p); }
+};
+
 __device__ __forceinline__ void t8_counters_init(Traverse8Counters& ctr) {
     ctr.nodeVisits = 0; ctr.triTests = 0; ctr.leafVisits = 0; ctr.iters = 0; ctr.leafBlocks = 0; for (int q = 0; q < 8; q++) ctr.ev[q] = 0u; ctr.cyc[0] = ctr.cyc[1] = ctr.cyc[2] = ctr.cyc[3] = 0ull;
     ctr.rayIterHist = nullptr; ctr.longRayCount = nullptr; ctr.longRays = nullptr;
