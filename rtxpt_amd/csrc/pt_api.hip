@@ -108,7 +108,7 @@ struct pt_context {
     std::vector<ptk::PolymorphicLightInfo> lights; std::vector<ptk::PolymorphicLightInfoEx> lightsEx; std::vector<uint> envLookup; uint envLookupDim = 0; uint numProxies = 0, envLightsBaked = 0;      // (light weights / proxy table live on the device only)
     DevBuf<float> dLightW; DevBuf<uint> dProxyOffsets; void* dScanTemp = nullptr; size_t scanTempBytes = 0;
     // device
-    DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dOwnedDealt, dQueue[2], dEmissiveList, dEmissiveOffsets;
+    DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
     DevBuf<float> dPrevPositions; DevBuf<InstanceDesc> dPrevInstances; bool motionHistory = false, prevAllStale = false; std::vector<uint32_t> prevStaleRanges;      // pt_set_motion_history: the previous frame's pose; the (first, count) vertex ranges in which it differs from the current one
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::AlphaPlane> dAlphaPlanes; DevBuf<unsigned char> dAlphaPool; DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
@@ -724,7 +724,7 @@ int32_t pt_destroy(pt_context* c) {
     c->neeat.free(); c->dLocalTable.free(); c->dFbWeight.free(); c->dFbCand.free(); c->dSq3.free();
     c->dGatherSend.free(); c->dGatherRecv.free(); c->dGatherPixels.free(); c->dLightW.free(); c->dProxyOffsets.free(); if (c->dScanTemp) (void)hipFree(c->dScanTemp);
     if (c->bvhAllocated) bvh_free(c->bvh);
-    c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dOwnedDealt.free(); c->dQueue[0].free(); c->dQueue[1].free();
+    c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dPrevPositions.free(); c->dPrevInstances.free(); c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
     c->dPrimInfo.free(); c->dShadeTris.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvImageCube.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
     c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free(); c->dResolveListSh.free(); c->dBestKeySh.free(); c->dTaskQSh.free();
@@ -1065,15 +1065,6 @@ int32_t pt_resize(pt_context* c, uint32_t w, uint32_t h) {
     PT_CHECK_HIP(c, c->dAccum.resize((size_t)w * h));
     PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)w * h, c->stream));
     PT_CHECK_HIP(c, c->dOwned.upload(c->owned, c->stream));
-    {   // pt_render's order of the same pixels: the tiles dealt round-robin into PT_PIPELINE_BATCHES groups, group after group. Its batches are contiguous ranges of this list, so every
-        // batch is an even sample of the frame instead of one quadrant of it (the shard lists are in Morton order: sky in one batch, the street in another) — the batches of a pass
-        // then take equally long, which is what their lockstep wants. Paths do not interact and k_accumulate folds a pixel's samples in sample order: the image cannot depend on it.
-        std::vector<uint> dealt; dealt.reserve(c->owned.size());
-        std::vector<std::pair<size_t, size_t>> tiles;      // runs of pixels of one 32 x 32 tile (first, count)
-        for (size_t i = 0; i < c->owned.size();) { const uint tx = (c->owned[i] >> 16) / 32u, ty = (c->owned[i] & 0xFFFFu) / 32u; size_t j = i; while (j < c->owned.size() && (c->owned[j] >> 16) / 32u == tx && (c->owned[j] & 0xFFFFu) / 32u == ty) j++; tiles.push_back({i, j - i}); i = j; }
-        for (uint g = 0; g < (uint)PT_PIPELINE_BATCHES; g++) for (size_t k = g; k < tiles.size(); k += PT_PIPELINE_BATCHES) dealt.insert(dealt.end(), c->owned.begin() + tiles[k].first, c->owned.begin() + tiles[k].first + tiles[k].second);
-        PT_CHECK_HIP(c, c->dOwnedDealt.upload(dealt, c->stream));
-    }
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }
@@ -1272,8 +1263,6 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     };
     uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
     { static const uint batchesOverride = []() { const char* e = getenv("MI355PT_BATCHES"); return e ? (uint)strtoul(e, nullptr, 10) : 0u; }(); if (batchesOverride && !c->serialKernels) numBatches = batchesOverride < (uint)PT_PIPELINE_BATCHES ? batchesOverride : (uint)PT_PIPELINE_BATCHES; }      // developer A/B switch
-    static const bool dealTiles = []() { const char* e = getenv("MI355PT_DEAL_TILES"); return !e || atoi(e) != 0; }();      // developer A/B switch (0: batches = contiguous ranges of the shard list)
-    const uint* ownedOrder = dealTiles ? c->dOwnedDealt.p : c->dOwned.p;
     Batch B[PT_PIPELINE_BATCHES];
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
@@ -1304,7 +1293,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         Batch& t = B[b];
         t.t0 = t.mark();
         PT_CHECK_HIP(c, hipMemcpyAsync(t.wc, t.hwc, sizeof(WaveCounters), hipMemcpyHostToDevice, t.st));
-        launch_generate(t.k, t.pool, ownedOrder + t.pixFirst, t.numPix, first, count, 0u, t.total, t.queue[0], nullptr, t.st);
+        launch_generate(t.k, t.pool, c->dOwned.p + t.pixFirst, t.numPix, first, count, 0u, t.total, t.queue[0], nullptr, t.st);
     }
     // upper bound on extend passes: bounceCount+1 vertices plus rejected (nested dielectric) re-traces
     uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u));
@@ -1413,7 +1402,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     }
     for (uint b = 0; b < numBatches; b++) {
         Batch& t = B[b];
-        launch_accumulate(t.pool, ownedOrder + t.pixFirst, t.numPix, count, c->dAccum.p, c->accumCount, c->width, t.st);
+        launch_accumulate(t.pool, c->dOwned.p + t.pixFirst, t.numPix, count, c->dAccum.p, c->accumCount, c->width, t.st);
         t.t1 = t.mark();
         PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, sizeof(WaveCounters), hipMemcpyDeviceToHost, t.st));
     }
