@@ -126,16 +126,20 @@ def main():
             counts = [parallel.shard_pixels(W, H, r, world).size for r in range(world)]
             send = torch.empty((n_owned, 4), dtype=torch.float32, device="cuda")
 
+    gather_ms = []
+
     def step():
         g.reset_accumulation()
         st = g.render(0, SPP)
         if host_transport:
             nonlocal host_frame
+            tg = time.perf_counter()
             host_frame = g.radiance()      # this rank's accumulation buffer (its own tiles are valid), then the library's gather towards rank 0 through the host
-            pt.gather_host(W, H, rank, world, host_frame, _send, _recv)
+            pt.gather_host(W, H, rank, world, host_frame, _send, _recv); gather_ms.append((time.perf_counter() - tg) * 1e3)
         elif world > 1:
+            torch.cuda.synchronize(); tg = time.perf_counter()      # (pt_render has drained its streams; the gather is timed on its own: pack + ncclSend / ncclRecv + unpack on the library's stream)
             if send is None:
-                g.gather()
+                g.gather(); torch.cuda.synchronize(); gather_ms.append((time.perf_counter() - tg) * 1e3)
             else:
                 g.pack_shard(send.data_ptr(), packed_bytes)
                 got = parallel.gather_packed(send, rank, world, dist, counts)
@@ -153,6 +157,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    gather_ms.clear()
     t0 = time.perf_counter()
     stats = [step() for _ in range(args.steps)]
     fence()
@@ -227,7 +232,7 @@ def main():
                                    % (info["triangles"], args.tex, len(g.lights()["proxyCounters"]), W, H, SPP, "fp32" if args.fp32_lp_types else "binary16 (reference default)",
                                       "RGBA16F" if args.no_env_compression else "2048 BC6H (reference default on D3D12)", bvh["builderName"], bvh["builtOn"], bvh["buildMs"], bvh["hostMs"], bvh["numWideNodes"]),
                        "bvh": bvh,
-                       "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "transport": args.transport if world > 1 else "none",
+                       "parallelism": "pixel-tile shard x%d + 1 gather" % world, "gather": gather_mode, "gather_ms_per_step_rank0": (sum(gather_ms) / len(gather_ms)) if gather_ms else None, "transport": args.transport if world > 1 else "none",
                        "rehearsal": bool(host_transport), "kernel_source_sha256": digest, "library_sha256": pt.library_digest(), "rays_per_step": rays_total / args.steps,
                        "extend_rays_per_step": sum(s["extendRays"] for s in stats) / args.steps * (world if world > 1 else 1), "paths_per_step": W * H * SPP,
                        "tail_kernel_launches_per_step": sum(s["tailLaunches"] for s in stats) / args.steps},

@@ -70,6 +70,9 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
     uint rayIters = 0;
     float taskT0 = 0.f; uint taskPrim0 = 0xFFFFFFFFu;
     uint pend1 = BVH_EMPTY, pend2 = BVH_EMPTY;
+#ifdef T8_PROBE_INSTANCE_SWITCHES
+    uint lastInst_ = 0xFFFFFFFFu;
+#endif
 
     // sb: the pair's stack base. The caller forms it anew for every node that pushes (stack_base(): two instructions) instead of keeping it across the loop: the loop is one
     // register short since the watertight leaf block, and the allocator's choice was to spill exactly this value — a scratch load and a full vmcnt(0) wait at every push.
@@ -148,6 +151,9 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                         bestT = tmax; bestPrim = 0xFFFFFFFFu; cur = 0u;
                     }
                     minePrim = 0xFFFFFFFFu; rayIters = 0u;
+#ifdef T8_PROBE_INSTANCE_SWITCHES
+                    lastInst_ = 0xFFFFFFFFu;
+#endif
                     pend = BVH_EMPTY; pend1 = BVH_EMPTY; pend2 = BVH_EMPTY; sp = 0u; active = true;
                 }
                 chunkPos = (uint)__builtin_amdgcn_readfirstlane((int)(chunkPos + ((n < avail) ? n : avail)));
@@ -185,6 +191,14 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         const bool runLeaves = t8_ballot(leafBlocked) != 0ull;      // (a second trigger — "n pairs hold a postponed leaf" — never paid: profiles/r05o_leaf_batch_ab.txt, r05t_refill_flat_ab.txt)
         const bool leaf = leafReady && runLeaves;
         if (COUNT && leaf && h == 0u) ctr.leafVisits++;
+#ifdef T8_PROBE_INSTANCE_SWITCHES      // developer probe (counter builds): how often would a two-level traversal have to enter an instance? Counted per ray as the visited leaves whose
+        if (COUNT && leaf && h == 0u) {      // instance differs from the previous visited leaf's (event slot 4 — the alpha-test count — carries it in such a build)
+            const uint prim_ = *reinterpret_cast<const uint*>(trisBase + (((pend & 0x7FFFFFFFu) >> 3) * 48u + 12u));
+            const uint inst_ = *reinterpret_cast<const uint*>(reinterpret_cast<const char*>(sc.shadeTris) + (size_t)prim_ * 128u);
+            if (inst_ != lastInst_) ctr.ev[4]++;
+            lastInst_ = inst_;
+        }
+#endif
         T8_EVENT(2, inner); T8_EVENT(3, leaf);
 
         // ---- inner node: lane h tests children 4h .. 4h + 3
@@ -327,7 +341,10 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
             const bool cand = (lp != 0xFFFFFFFFu);
             pend = pend1; pend1 = pend2; pend2 = BVH_EMPTY;
             uint candBits = pair_bits(t8_ballot(cand), pl);
-            T8_EVENT(4, alphaRan); T8_EVENT(5, candBits != 0u);
+#ifndef T8_PROBE_INSTANCE_SWITCHES
+            T8_EVENT(4, alphaRan);
+#endif
+            T8_EVENT(5, candBits != 0u);
             if (candBits) {
                 if (ANYHIT) {
                     if (h == (uint)__ffs((int)candBits) - 1u) { HitInfo hh; hh.t = lt; hh.prim = lp; hh.u = hh.v = 0.f; commit(tag, hh); }
