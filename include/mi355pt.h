@@ -542,10 +542,11 @@ int32_t pt_tonemap_from_parameters(const PtToneMappingParameters* ui, float avgL
 int32_t pt_average_luminance(pt_context* ctx, float* avgLuminance);
 /* Float images for the environment source. The reference takes .exr / .hdr / .dds environment maps (Rtxpt/Sample.cpp:116) through Donut's TextureCache
    (EnvMapBaker.cpp:392-415; Donut is not vendored: the formats are read from their published specifications). OpenEXR: single-part scan-line and tiled files (of a mip- / rip-mapped tiled file: level 0) with
-   half or float R G B (or Y) channels, compression NONE / RLE / ZIPS / ZIP; Radiance .hdr: 32-bit_rle_rgbe, "-Y h +X w". *rgb: width x height x 3 floats, top
+   half or float R G B (or Y) channels, compression NONE / RLE / ZIPS / ZIP / PIZ; Radiance .hdr: 32-bit_rle_rgbe, "-Y h +X w". *rgb: width x height x 3 floats, top
    row first (what pt_set_environment takes), allocated by the library, released with pt_image_free. PT_ERROR_IO: unreadable or malformed;
    PT_ERROR_UNSUPPORTED: multi-part / deep EXR, PXR24 / B44 / DWA compression (NONE / RLE / ZIPS / ZIP / PIZ are read), sub-sampled or integer channels, other orientations.
-   A .dds with RGBA16F / RGBA32F pixels is read too (alpha dropped); 8-bit and block-compressed .dds files are textures, not environment sources: pt_image_read_dds. */
+   A 2D .dds with RGBA16F / RGBA32F / BC6H (UF16, SF16) pixels is read too (alpha dropped) — the reference takes BC6H lat-long .dds environments (EnvMapBaker.cpp:399-411);
+   8-bit and BC1-5 / BC7 .dds files are textures, not environment sources: pt_image_read_dds. Cube-map .dds files: pt_image_read_dds_cube. */
 int32_t pt_image_read_float(const char* path, uint32_t* width, uint32_t* height, float** rgb);
 void    pt_image_free(float* rgb);
 /* .dds textures: the reference's material pipeline prefers `x.dds` next to `x.png` (MaterialsBaker.cpp:178-191; its compression script writes BC7, SampleCommon.cpp:

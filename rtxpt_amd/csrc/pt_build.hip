@@ -522,7 +522,12 @@ __global__ void __launch_bounds__(256) k_shade_tris(DeviceScene sc, uint firstPr
     r.materialAndFlags = (sc.subInstances[pi.x].GlobalGeometryIndex_PTMaterialDataIndex & 0xFFFFu) | (g.flags << 16);
     r.p0 = make_float3(P[3 * v0], P[3 * v0 + 1], P[3 * v0 + 2]); r.p1 = make_float3(P[3 * v1], P[3 * v1 + 1], P[3 * v1 + 2]); r.p2 = make_float3(P[3 * v2], P[3 * v2 + 1], P[3 * v2 + 2]);
     if (g.flags & GEOM_HAS_UV) { r.t0 = sc.uvs[v0]; r.t1 = sc.uvs[v1]; r.t2 = sc.uvs[v2]; }
-    if (g.flags & GEOM_HAS_NORMAL) { r.n0 = sc.normals[v0]; r.n1 = sc.normals[v1]; r.n2 = sc.normals[v2]; }
+    if (g.flags & GEOM_HAS_NORMAL) {      // exactly loadSurface's expressions (pt_path.h, the PT_SHADE_TRI == 0 branch keeps them): the same floats, formed once
+        const float3 objFlatN = SafeNormalize(cross(r.p1 - r.p0, r.p2 - r.p0));
+        const uint pn[3] = {sc.normals[v0], sc.normals[v1], sc.normals[v2]}; float3 n[3];
+        for (int k = 0; k < 3; k++) { n[k] = normalize(Unpack_RGB8_SNORM(pn[k])); if (dot(n[k], objFlatN) < 0.f) n[k] = -n[k]; }
+        r.n0 = n[0]; r.n1 = n[1]; r.n2 = n[2];
+    }
     if (g.flags & GEOM_HAS_TANGENT) { r.g0 = sc.tangents[v0]; r.g1 = sc.tangents[v1]; r.g2 = sc.tangents[v2]; }
     uint4* o = reinterpret_cast<uint4*>(out + p); const uint4* src = reinterpret_cast<const uint4*>(&r);
     for (int k = 0; k < 8; k++) o[k] = src[k];

@@ -357,7 +357,12 @@ struct Loader {
         const JValue* sparse = a.get("sparse");
         if (count < 0 || count > (1 << 28)) { err = "accessor with a negative or absurd count / offset / stride"; return false; }
         if (a.get("bufferView")) { if (!read_view(a.intOr("bufferView", -1), a.numOr("byteOffset", 0), ct, comps, count, normalized, false, out)) return false; }
-        else if (sparse) out.assign((size_t)count * comps, 0.0);      // glTF 2.0, 3.6.2.3: a sparse accessor without a bufferView starts from zeros
+        else if (sparse) {      // glTF 2.0, 3.6.2.3: a sparse accessor without a bufferView starts from zeros
+            // ... of which there is no buffer to bound the count by (a few bytes of JSON with count = 2^28 and MAT4 would ask for 32 GiB of zeros): no more elements than every vertex
+            // of a 2^26-component stream, the bound the file's own buffers put on any other accessor of a scene this library can hold
+            if ((size_t)count * (size_t)comps > ((size_t)1 << 26)) { err = "sparse accessor without a bufferView and with an absurd count"; return false; }
+            out.assign((size_t)count * comps, 0.0);
+        }
         else { err = "accessor without bufferView"; return false; }
         if (sparse) {      // sparse.count elements are replaced: sparse.indices (tightly packed u8 / u16 / u32) name them, sparse.values (tightly packed, the accessor's type) hold them.
             // cgltf — what Donut's importer reads glTF with — resolves sparse accessors when it unpacks floats (cgltf_accessor_unpack_floats), so the reference accepts such files
@@ -640,15 +645,17 @@ static int32_t load_scene_gltf_impl(pt_context* ctx, const char* path) {
     r = pt_set_instances(ctx, L.instances.data(), (uint32_t)L.instances.size());
     if (r != PT_OK) return r;
     // KHR_lights_punctual: point / spot lights become the context's analytic lights (what LightsBaker collects from the scene graph), directional ones the scene's list for the
-    // environment bake (pt_set_scene_directional_lights: Sample::UpdateLighting's conversion runs at bake time). A file without the extension leaves both as the host set them.
+    // environment bake (pt_set_scene_directional_lights: Sample::UpdateLighting's conversion runs at bake time). A file without the extension clears both.
     std::vector<PtAnalyticLightDesc> analytic; std::vector<PtEnvDirectionalLight> directional;
     for (const Loader::PunctualRaw& l : L.punctual) Loader::emit_punctual(l, m4_identity(), analytic, directional);
-    if (!analytic.empty()) {
+    // A scene load REPLACES the scene's lights, also with nothing (Sample::SceneLoaded rebuilds m_lights on every load, Sample.cpp:553-575): a second file loaded into the same
+    // context must not inherit the first one's analytic lights or sun discs.
+    {
         std::vector<PolymorphicLightInfo> base(analytic.size()); std::vector<PolymorphicLightInfoEx> ex(analytic.size());
         for (size_t i = 0; i < analytic.size(); i++) { r = pt_convert_light(&analytic[i], &base[i], &ex[i]); if (r != PT_OK) return r; }
-        r = pt_set_lights(ctx, base.data(), ex.data(), (uint32_t)base.size()); if (r != PT_OK) return r;
+        r = pt_set_lights(ctx, analytic.empty() ? nullptr : base.data(), analytic.empty() ? nullptr : ex.data(), (uint32_t)base.size()); if (r != PT_OK) return r;
     }
-    if (!directional.empty()) { r = pt_set_scene_directional_lights(ctx, directional.data(), (uint32_t)std::min<size_t>(directional.size(), 16)); if (r != PT_OK) return r; }
+    r = pt_set_scene_directional_lights(ctx, directional.empty() ? nullptr : directional.data(), (uint32_t)std::min<size_t>(directional.size(), 16)); if (r != PT_OK) return r;
     return PT_OK;
 }
 

@@ -328,7 +328,7 @@ template <bool LP16> struct PathKernelContextT {
 #if PT_SHADE_TRI
         // one 128-byte line per primitive (pt_scene.h ShadeTri) instead of primInfo -> subInstToInstGeom -> {instance, subInstance, geometry} -> indices -> vertex streams
         const uint4* rec = reinterpret_cast<const uint4*>(sc.shadeTris + prim);
-        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];      // seven independent 16-byte loads of one line
+        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7];      // eight independent 16-byte loads of one line
         const uint subInst = r0.y, triangleIndex = r0.z, materialIndex = r0.w & 0xFFFFu;
         struct { uint flags; } g; g.flags = r0.w >> 16;
         const float3x4& M = sc.instances[r0.x].transform;
@@ -345,19 +345,15 @@ template <bool LP16> struct PathKernelContextT {
         if (mvBlock) mvBlock->curvatureWS = 0.0f;
         float3 geometryNormal = make_float3(0.f);
         if (g.flags & GEOM_HAS_NORMAL) {
-            const uint pn[3] = {r4.w, r5.x, r5.y};
-            float3 n[3];
-            for (int k = 0; k < 3; k++) {
-                n[k] = normalize(Unpack_RGB8_SNORM(pn[k]));
-                if (dot(n[k], objFlatN) < 0.f) n[k] = -n[k];
-            }
+            // (the record holds them unpacked, normalised and turned towards the flat normal: k_shade_tris, pt_scene.h ShadeTri)
+            const float3 n[3] = {make_float3(asfloat(r4.w), asfloat(r5.x), asfloat(r5.y)), make_float3(asfloat(r5.z), asfloat(r5.w), asfloat(r6.x)), make_float3(asfloat(r6.y), asfloat(r6.z), asfloat(r6.w))};
             if (mvBlock) mvBlock->curvatureWS = TriangleCurvatureApprox_GradN(vp, n, M);
             geometryNormal = (n[0] * bary.x + n[1] * bary.y) + n[2] * bary.z;
             geometryNormal = SafeNormalize(xform_direction4(M, geometryNormal));
         }
         float4 tangent = make_float4(0, 0, 0, 0);
         if (g.flags & GEOM_HAS_TANGENT) {
-            const uint pg[3] = {r5.z, r5.w, r6.x};
+            const uint pg[3] = {r7.x, r7.y, r7.z};
             float4 tg[3];
 #else      // the gather as the reference's bridge walks it (developer A/B)
         uint2 pinfo = sc.primInfo[prim];

@@ -125,9 +125,11 @@ struct ShadeTri {
     uint instance, subInstance, triangleIndex, materialAndFlags;      // words 0-3; materialAndFlags = material index | GeometryDesc::flags << 16
     float3 p0, p1, p2;            // words  4-12: object-space positions
     float2 t0, t1, t2;            // words 13-18: texture coordinates (zero without GEOM_HAS_UV)
-    uint n0, n1, n2;              // words 19-21: RGBA8_SNORM normals
-    uint g0, g1, g2;              // words 22-24: RGBA8_SNORM tangents
-    uint _pad[7];
+    float3 n0, n1, n2;            // words 19-27: the vertex normals as loadSurface uses them — normalize(Unpack_RGB8_SNORM(packed)), negated where they point away from the flat normal
+                                  //   normalize(cross(p1 - p0, p2 - p0)) (BridgeDonut:655-668) — formed once per record by k_shade_tris with loadSurface's own expressions instead of
+                                  //   per hit (three unpacks, square roots and nine divisions: ~200 of k_shade's 4 600 VALU instructions per vertex); zero without GEOM_HAS_NORMAL
+    uint g0, g1, g2;              // words 28-30: RGBA8_SNORM tangents
+    uint _pad;
 };
 static_assert(sizeof(ShadeTri) == 128, "ShadeTri must be one 128-byte line");
 
@@ -177,7 +179,11 @@ static inline float4 sample_bilinear(const DeviceScene& sc, const TexInfo& t, ui
     float fx = uv.x * (float)mw - 0.5f, fy = uv.y * (float)mh - 0.5f;
     float flx = floorf(fx), fly = floorf(fy);
     float ax = fx - flx, ay = fy - fly;
-    flx = flx - floorf(flx / (float)mw) * (float)mw; fly = fly - floorf(fly / (float)mh) * (float)mh;
+    // the wrap: flx - floorf(flx / mw) * mw. For a power-of-two side the quotient is an exact scaling: the product with the exact reciprocal (2^-k from 2^k by exponent arithmetic) is the
+    // same float as the correctly rounded division (as in alpha_test_slot); k_shade is bound by its VALU instructions and a trilinear fetch holds four of these divisions
+    const float fmw = (float)mw, fmh = (float)mh;
+    if (((mw & (mw - 1u)) | (mh & (mh - 1u))) == 0u) { flx = flx - floorf(flx * asfloat(0x7F000000u - asuint(fmw))) * fmw; fly = fly - floorf(fly * asfloat(0x7F000000u - asuint(fmh))) * fmh; }
+    else { flx = flx - floorf(flx / fmw) * fmw; fly = fly - floorf(fly / fmh) * fmh; }
     int x0 = (int)flx, y0 = (int)fly;
     float4 a = lerp4(tex_texel(sc, t, mip, x0, y0), tex_texel(sc, t, mip, x0 + 1, y0), ax);
     float4 b = lerp4(tex_texel(sc, t, mip, x0, y0 + 1), tex_texel(sc, t, mip, x0 + 1, y0 + 1), ax);
