@@ -645,7 +645,7 @@ int32_t pt_set_counters(pt_context* ctx, int32_t enable);
 int32_t pt_set_serial_kernels(pt_context* ctx, int32_t enable);
 /* The tail kernel: once a batch of pt_render holds at most `maxPaths` live paths, ONE launch runs them to their end — every wave loops trace -> shade -> visibility ->
    next bounce over 32 paths, the shape of the reference's raygen loop (Rtxpt/Shaders/PathTracerSample.hlsl:200-250) where it fits: few paths, bound by the length of
-   the launch chain of a wavefront pass, not by throughput. 0 = never (every pass is a wavefront pass) — the default since round 6 (fused traversal launches made the late passes cheap; 32768 still helps small closed scenes by 2-3 %; environment MI355PT_TAIL_PATHS overrides it at
+   the launch chain of a wavefront pass, not by throughput. 0 = never (every pass is a wavefront pass); default 4096 since round 6 (32768 before: fused traversal launches made passes of tens of thousands of paths cheaper than the tail kernel's under-filled GPU; the chains of tiny passes that nested dielectrics leave are what it is for; environment MI355PT_TAIL_PATHS overrides it at
    pt_create). The image does not depend on the value (paths do not interact; tests render whole frames through the tail kernel). Ignored for NEEFullSamples > 1,
    serial-kernel and counter frames. */
 int32_t pt_set_tail_paths(pt_context* ctx, uint32_t maxPaths);

@@ -73,9 +73,10 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #define PT_SP_FILL_RANGED 1      // the fill pass's first traversal launch uses FirstHitFromVBuffer's narrowed ray interval (pt_stableplanes.h firstHitInterval); 0: the whole ray (A/B) — same hits
 #endif
 #ifndef PT_TAIL_PATHS
-#define PT_TAIL_PATHS 0u         // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never. Off by default since round 6: with fused traversal
-                                  // launches the late passes are cheap enough that the tail kernel's idle GPU costs more than it saves (profiles/r06e_tail_threshold_fused_ab.txt: rank of eight 12.56 -> 12.11 ms,
-                                  // full frame 74.2 -> 73.6; only C2 — a small closed scene without long rays — keeps a gain from it, 6.21 -> 6.05 ms with 32768)
+#define PT_TAIL_PATHS 4096u      // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never. 32768 in rounds 4-5; with fused traversal
+                                  // launches and free-running small passes (round 6) a pass of tens of thousands of paths is cheaper as a wavefront pass than in the tail kernel's under-filled GPU
+                                  // (rank of eight 12.56 -> 12.11 ms without it), while the chains of passes that hold a few hundred paths each — nested-dielectric re-traces: C5 runs 19 passes, twelve of
+                                  // them below 10 k paths at ~0.25 ms each — are what the kernel is for: 4096 takes C5's rank of eight 13.9 -> 13.2 ms, C3's 12.0 -> 11.8 (profiles/r06o_tail_small_ab.txt)
 #endif
 #ifndef PT_FUSED_TRAVERSAL
 #define PT_FUSED_TRAVERSAL 1u      // pt_set_fused_traversal (default: on — it pays at every size, profiles/r06b_fused_traversal_ab.txt): 0 = every bounce traces its visibility rays in a launch of their own, 1 = together with the closest-hit rays of the next bounce

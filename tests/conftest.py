@@ -3,11 +3,12 @@ import sys
 
 import pytest
 
-# The tail kernel (pt_set_tail_paths) is off in the product's default configuration since round 6, and contexts made by the tests start that way. In the modules of
-# TAIL_BOTH_WAYS below (the golden-digest tests against the reference's text at HD and full size, the sharded frames, NEE-AT with its exported depth) every test runs twice:
-# in the default configuration and with the tail kernel on at 32768 live paths per batch (the default of rounds 4-5; fixture value "tail_default" keeps that name).
-# tests/test_gpu_tail_kernel.py renders the pinned frames entirely through the tail kernel. Fused traversal launches (pt_set_fused_traversal) are on in both; the separate
-# launches are compared with them in tests/test_gpu_fused_traversal.py.
+# The suite drives the wavefront kernels on frames of a few thousand paths, which the product would hand to the tail kernel (pt_set_tail_paths, default 4096 live paths per
+# batch since round 6) from the first pass on. So contexts made by the tests start with the tail kernel OFF unless a test asks for it — except in the modules of TAIL_BOTH_WAYS
+# below (the golden-digest tests against the reference's text at HD and full size, the sharded frames, NEE-AT with its exported depth): every test of those runs twice, once with
+# the tail kernel off and once in the product's default configuration. tests/test_gpu_tail_kernel.py renders the pinned frames entirely through the tail kernel (thresholds up to
+# 300 000); smoke() and bench.py's parity block run the product default. Fused traversal launches (pt_set_fused_traversal) are on in both; the separate launches are compared
+# with them in tests/test_gpu_fused_traversal.py.
 os.environ.setdefault("MI355PT_TAIL_PATHS", "0")
 TAIL_BOTH_WAYS = ("test_gpu_reference_goldens", "test_gpu_parity_hd", "test_gpu_full_size", "test_gpu_multigpu_c4", "test_gpu_multigpu_c5", "test_gpu_neeat", "test_gpu_neeat_baker")
 
@@ -44,6 +45,6 @@ def pytest_generate_tests(metafunc):
 def tail_configuration(request, monkeypatch):
     """MI355PT_TAIL_PATHS for the contexts a test creates (read at pt_create): 0 everywhere, and the product default as a second run in the modules of TAIL_BOTH_WAYS."""
     mode = getattr(request, "param", "tail_off")
-    if mode == "tail_default": monkeypatch.setenv("MI355PT_TAIL_PATHS", "32768")
+    if mode == "tail_default": monkeypatch.delenv("MI355PT_TAIL_PATHS", raising=False)
     else: monkeypatch.setenv("MI355PT_TAIL_PATHS", "0")
     return mode

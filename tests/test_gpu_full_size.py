@@ -91,7 +91,7 @@ def test_c5_full_size_4k_animated_refit_rows_bit_exact():
     assert np.array_equal(a, g.radiance())
 
 
-@pytest.mark.tail_once("tail_off")      # (the stable-plane passes and the display path have their own loops: the tail kernel is pt_render's)
+@pytest.mark.tail_once("tail_default")      # (the stable-plane passes and the display path have their own loops: the tail kernel is pt_render's)
 def test_realtime_frames_4k_animated_match_oracle():
     """The realtime mode's coupled frame (pt_realtime_frame: baker UpdateBegin, build pass, UpdateEnd on the frame's depth + motion vectors, fill pass feeding the reservoirs) at
     3840x2160 on C5's scene, two frames with the camera and the scene moving in between (pt_set_motion_history, pt_animate_ranges: refit, light re-bake, object motion in the motion
@@ -178,7 +178,7 @@ def test_config_frames_equal_the_reference_text_frames(name):
     g.close()
 
 
-@pytest.mark.tail_once("tail_off")      # (the stable-plane passes and the display path have their own loops: the tail kernel is pt_render's)
+@pytest.mark.tail_once("tail_default")      # (the stable-plane passes and the display path have their own loops: the tail kernel is pt_render's)
 def test_realtime_passes_4k_equal_the_reference_text():
     """The stable-plane build pass and one fill sub-sample at 3840x2160 on C5's scene in an animated pose (previous pose = the rest pose: object motion; the camera moved as well)
     against what the REFERENCE'S text of those passes produced (tests/golden/realtime_4k_golden.npz: SHA-256 digests of header, depth, motion vectors, stable radiance, throughput,
@@ -223,7 +223,7 @@ def test_neeat_4k_equals_the_reference_text():
     g.close()
 
 
-@pytest.mark.tail_once("tail_off")      # (the stable-plane passes and the display path have their own loops: the tail kernel is pt_render's)
+@pytest.mark.tail_once("tail_default")      # (the stable-plane passes and the display path have their own loops: the tail kernel is pt_render's)
 def test_coupled_realtime_frames_4k_equal_the_reference_text():
     """Two coupled realtime frames at 3840x2160 — baker UpdateBegin, build pass, UpdateEnd on the frame's depth and motion vectors, fill pass feeding the reservoirs — against the
     REFERENCE'S text with LightsBaker.hlsl run thread by thread (tests/golden/realtime_coupled_4k_golden.npz): per frame the digests of the tile tables, proxy counters, reservoirs
@@ -279,7 +279,7 @@ def test_neeat_loop_4k_equals_the_reference_text():
     g.close()
 
 
-@pytest.mark.tail_once("tail_off")      # (the stable-plane passes and the display path have their own loops: the tail kernel is pt_render's)
+@pytest.mark.tail_once("tail_default")      # (the stable-plane passes and the display path have their own loops: the tail kernel is pt_render's)
 def test_display_path_4k_equals_the_reference_text():
     """pt_tonemap of the device's bench frame for the six operators x three exposure compensations and auto exposure against tests/golden/display_4k_golden.npz: the SRGBA8 image of
     the frame the reference's integrator text rendered, through the reference's ToneMapping.ps.hlsli text (== its restatement on all 8.3 M pixels, asserted when the fixture was made)"""

@@ -21,7 +21,7 @@ def _imports():
     return pt, scenes, parallel, ptref
 
 
-@pytest.mark.tail_once("tail_off")      # (half a minute of 16-spp frames: in the product's configuration; the tail-off kernels render the same frames in tests/test_gpu_full_size.py)
+@pytest.mark.tail_once("tail_default")      # (half a minute of 16-spp frames: in the product's configuration; the tail-off kernels render the same frames in tests/test_gpu_full_size.py)
 def test_c4_ranks_0_and_7_of_8_match_the_oracle_at_16_spp():
     pt, scenes, parallel, ptref = _imports()
     SPP, WORLD = 16, 8
@@ -51,7 +51,7 @@ def test_c4_ranks_0_and_7_of_8_match_the_oracle_at_16_spp():
     o.close()
 
 
-@pytest.mark.tail_once("tail_off")      # (half a minute of 16-spp frames: in the product's configuration; the tail-off kernels render the same frames in tests/test_gpu_full_size.py)
+@pytest.mark.tail_once("tail_default")      # (half a minute of 16-spp frames: in the product's configuration; the tail-off kernels render the same frames in tests/test_gpu_full_size.py)
 def test_c4_eight_shards_reassemble_to_the_single_rank_frame():
     """All 8 ranks' shards of the 4K frame (4 spp here: every rank is rendered in turn on the one GPU), packed by pt_pack_shard and put back by pt_unpack_shard on a
     rank-0 context, equal the frame one rank renders alone."""

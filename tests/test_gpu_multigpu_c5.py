@@ -53,7 +53,7 @@ def test_c5_ranks_0_and_7_of_8_animated_frames_match_the_oracle():
     for g in tracers.values(): g.close()
 
 
-@pytest.mark.tail_once("tail_off")      # (eight 4K shards: in the product's configuration; the ranks test below runs in both)
+@pytest.mark.tail_once("tail_default")      # (eight 4K shards: in the product's configuration; the ranks test below runs in both)
 def test_c5_eight_refitted_shards_reassemble_to_the_single_rank_frame():
     import torch
     pt, scenes, parallel, ptref = _imports()

@@ -41,7 +41,7 @@ import make_stable_planes_hd_golden as sph
 SP_GOLD = os.path.join(ROOT, "tests", "golden", "stable_planes_hd_golden.npz")
 
 
-@pytest.mark.tail_once("tail_off")      # (no pt_render in this test: the tail kernel plays no part)
+@pytest.mark.tail_once("tail_default")      # (no pt_render in this test: the tail kernel plays no part)
 @pytest.mark.parametrize("key", sph.all_cases())
 def test_device_stable_planes_equal_the_reference_text(key):
     """the stable-plane cases (incl. object motion and the edge cases) at 1920x1080: the build pass and two fill sub-samples against the REFERENCE'S text of those passes
@@ -65,7 +65,7 @@ import make_env_cube_2048_golden as cubes
 CUBE_GOLD = os.path.join(ROOT, "tests", "golden", "env_cube_2048_golden.npz")
 
 
-@pytest.mark.tail_once("tail_off")      # (no pt_render in this test: the tail kernel plays no part)
+@pytest.mark.tail_once("tail_default")      # (no pt_render in this test: the tail kernel plays no part)
 @pytest.mark.parametrize("name", list(cubes.cases()))
 def test_device_env_cube_2048_equals_the_reference_text(name):
     """the 2048^2 environment cube with its mips (33.5 M texels) as the device bakes it against the bake of the REFERENCE'S EnvMapBaker text (SHA-256 of the whole cube): the bench's
@@ -106,7 +106,7 @@ import realtime_cases as _rc
 RT_GOLD = os.path.join(ROOT, "tests", "golden", "realtime_hd_golden.npz")
 
 
-@pytest.mark.tail_once("tail_off")      # (no pt_render in this test: the tail kernel plays no part)
+@pytest.mark.tail_once("tail_default")      # (no pt_render in this test: the tail kernel plays no part)
 @pytest.mark.parametrize("name", list(_rc.cases()))
 def test_device_realtime_runs_equal_the_reference_text(name):
     """the coupled realtime runs of tests/realtime_cases.py at 1920x1080 (pt_realtime_frame per frame; the animated case through pt_set_motion_history + pt_animate) against the
@@ -157,7 +157,7 @@ import make_fuzz_sp_hd_golden as fsp
 FUZZ_SP_GOLD = os.path.join(ROOT, "tests", "golden", "fuzz_sp_hd_golden.npz")
 
 
-@pytest.mark.tail_once("tail_off")      # (no pt_render in this test: the tail kernel plays no part)
+@pytest.mark.tail_once("tail_default")      # (no pt_render in this test: the tail kernel plays no part)
 @pytest.mark.parametrize("seed", _fz.SP_SEEDS)
 def test_device_fuzz_stable_planes_equal_the_reference_text(seed):
     """30 seeded random stable-plane frames at 1280x720 (random viewpoints, plane counts, vertex depths, settings, previous poses, sub-sample counts) against the REFERENCE'S text of
