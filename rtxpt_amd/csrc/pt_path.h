@@ -323,7 +323,12 @@ template <bool LP16> struct PathKernelContextT {
         const float3 objPos = (vp[0] * bary.x + vp[1] * bary.y) + vp[2] * bary.z;
         return xform_point(M, objPos);
     }
-    // Bridge::loadSurface (BridgeDonut:612-853): the divergent gather of the pipeline
+    // Bridge::loadSurface (BridgeDonut:612-853): the divergent gather of the pipeline.
+    // LEAN (round 6): the vertex of a path that terminates right after its emission term (PF_terminateAtNextBounce: a fifth of a bounce's hits, shaded as a class of their own, k_classify)
+    // reads of the surface only what HandleHit touches before it returns — position, flat normal and facing, material header, emission (with its texture), the two light links, the
+    // interior IoR — so the vertex normals and tangents, the base / normal / metal-rough / transmission fetches, the normal map, the tangent frame and the BSDF inputs are not formed
+    // at all. What IS formed is formed by the same expressions: the values HandleHit reads are the same floats.
+    template <bool LEAN = false>
     SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone, MVBlockInputs* mvBlock = nullptr) const {
 #if PT_SHADE_TRI
         // one 128-byte line per primitive (pt_scene.h ShadeTri) instead of primInfo -> subInstToInstGeom -> {instance, subInstance, geometry} -> indices -> vertex streams
@@ -344,7 +349,7 @@ template <bool LP16> struct PathKernelContextT {
         float3 objFlatN = SafeNormalize(cross(vp[1] - vp[0], vp[2] - vp[0]));
         if (mvBlock) mvBlock->curvatureWS = 0.0f;
         float3 geometryNormal = make_float3(0.f);
-        if (g.flags & GEOM_HAS_NORMAL) {
+        if (!LEAN && (g.flags & GEOM_HAS_NORMAL)) {
             // (the record holds them unpacked, normalised and turned towards the flat normal: k_shade_tris, pt_scene.h ShadeTri)
             const float3 n[3] = {make_float3(asfloat(r4.w), asfloat(r5.x), asfloat(r5.y)), make_float3(asfloat(r5.z), asfloat(r5.w), asfloat(r6.x)), make_float3(asfloat(r6.y), asfloat(r6.z), asfloat(r6.w))};
             if (mvBlock) mvBlock->curvatureWS = TriangleCurvatureApprox_GradN(vp, n, M);
@@ -352,7 +357,7 @@ template <bool LP16> struct PathKernelContextT {
             geometryNormal = SafeNormalize(xform_direction4(M, geometryNormal));
         }
         float4 tangent = make_float4(0, 0, 0, 0);
-        if (g.flags & GEOM_HAS_TANGENT) {
+        if (!LEAN && (g.flags & GEOM_HAS_TANGENT)) {
             const uint pg[3] = {r7.x, r7.y, r7.z};
             float4 tg[3];
 #else      // the gather as the reference's bridge walks it (developer A/B)
@@ -377,7 +382,7 @@ template <bool LP16> struct PathKernelContextT {
         float3 objFlatN = SafeNormalize(cross(vp[1] - vp[0], vp[2] - vp[0]));
         if (mvBlock) mvBlock->curvatureWS = 0.0f;
         float3 geometryNormal = make_float3(0.f);
-        if (g.flags & GEOM_HAS_NORMAL) {
+        if (!LEAN && (g.flags & GEOM_HAS_NORMAL)) {
             float3 n[3];
             for (int k = 0; k < 3; k++) {
                 n[k] = normalize(Unpack_RGB8_SNORM(sc.normals[vi[k]]));
@@ -388,7 +393,7 @@ template <bool LP16> struct PathKernelContextT {
             geometryNormal = SafeNormalize(xform_direction4(M, geometryNormal));
         }
         float4 tangent = make_float4(0, 0, 0, 0);
-        if (g.flags & GEOM_HAS_TANGENT) {
+        if (!LEAN && (g.flags & GEOM_HAS_TANGENT)) {
             float4 tg[3];
             const uint pg[3] = {sc.tangents[vi[0]], sc.tangents[vi[1]], sc.tangents[vi[2]]};
 #endif
@@ -399,7 +404,7 @@ template <bool LP16> struct PathKernelContextT {
         }
         float3 flatNormal = SafeNormalize(xform_direction4(M, objFlatN));
         bool frontFacing = dot(-rayDir, flatNormal) >= 0.0f;
-        if (!(g.flags & GEOM_HAS_NORMAL)) geometryNormal = flatNormal;
+        if (LEAN || !(g.flags & GEOM_HAS_NORMAL)) geometryNormal = flatNormal;      // (LEAN: never read)
         float3 posW = xform_point(M, objPos);
         float coneTexLODValue = computeRayConeTriangleLODValue(vp, vt, M);
         float lambda = rayCone.computeLOD(coneTexLODValue, rayDir, flatNormal, true) + S.texLODBias;
@@ -411,12 +416,26 @@ template <bool LP16> struct PathKernelContextT {
         float4 texBase = make_float4(1, 1, 1, 1), texEmissive = make_float4(1, 1, 1, 1), texNormal = make_float4(0.5f, 0.5f, 1.0f, 0.f),
                texMR = make_float4(1, 1, 1, 1), texTrans = make_float4(1, 1, 1, 1);
         bool hasUV = (g.flags & GEOM_HAS_UV) != 0;
-        if (hasUV && (mflags & PTMaterialFlags_UseBaseOrDiffuseTexture)) texBase = sampleTexture(material.BaseOrDiffuseTextureIndex, lambda, texcoord);
-        if (hasUV && (mflags & PTMaterialFlags_UseNormalTexture)) texNormal = sampleTexture(material.NormalTextureIndex, lambda, texcoord);
-        if (hasUV && (mflags & PTMaterialFlags_UseMetalRoughOrSpecularTexture)) texMR = sampleTexture(material.MetalRoughOrSpecularTextureIndex, lambda, texcoord);
+        if (!LEAN && hasUV && (mflags & PTMaterialFlags_UseBaseOrDiffuseTexture)) texBase = sampleTexture(material.BaseOrDiffuseTextureIndex, lambda, texcoord);
+        if (!LEAN && hasUV && (mflags & PTMaterialFlags_UseNormalTexture)) texNormal = sampleTexture(material.NormalTextureIndex, lambda, texcoord);
+        if (!LEAN && hasUV && (mflags & PTMaterialFlags_UseMetalRoughOrSpecularTexture)) texMR = sampleTexture(material.MetalRoughOrSpecularTextureIndex, lambda, texcoord);
         if (hasUV && (mflags & PTMaterialFlags_UseEmissiveTexture)) texEmissive = sampleTexture(material.EmissiveTextureIndex, lambda, texcoord);
-        if (hasUV && (mflags & PTMaterialFlags_UseTransmissionTexture)) texTrans = sampleTexture(material.TransmissionTextureIndex, lambda, texcoord);
+        if (!LEAN && hasUV && (mflags & PTMaterialFlags_UseTransmissionTexture)) texTrans = sampleTexture(material.TransmissionTextureIndex, lambda, texcoord);
 
+        float3 emissiveColor = LP::r3(material.EmissiveColor);
+        if (mflags & PTMaterialFlags_UseEmissiveTexture) emissiveColor = LP::mul3(emissiveColor, LP::r3(xyz(texEmissive)));
+        float matIoR = LP::r(material.IoR);
+        sd.faceNCorrected = frontFacing ? flatNormal : -flatNormal;
+        sd.frontFacing = frontFacing;
+        bool thin = (mflags & PTMaterialFlags_ThinSurface) != 0;
+        sd.materialID = materialIndex;
+        sd.mtl = MaterialHeader::make();
+        { uint pr = 1 + (mflags >> PTMaterialFlags_NestedPriorityShift); sd.mtl.setNestedPriority(pr < InteriorList::kMaxNestedPriority ? pr : InteriorList::kMaxNestedPriority); }
+        sd.mtl.setThinSurface(thin);
+        sd.mtl.setActiveLobes(Lobe_All);
+        sd.IoR = 1.f;
+        StandardBSDFData bd; __builtin_memset(&bd, 0, sizeof(bd));
+        if (!LEAN) {
         float3 mGeometryNormal = normalize(geometryNormal), mShadingNormal = mGeometryNormal;
         // MaterialProperties holds lp values: a conversion lpfloat(x) per assignment, half operations between lp operands
         float3 baseColor = LP::r3(material.BaseOrDiffuseColor * xyz(texBase));
@@ -430,9 +449,6 @@ template <bool LP16> struct PathKernelContextT {
         }
         float transmission = LP::r(material.TransmissionFactor), diffuseTransmission = LP::r(material.DiffuseTransmissionFactor);
         if (mflags & PTMaterialFlags_UseTransmissionTexture) { transmission = LP::mul(transmission, LP::r(texTrans.x)); diffuseTransmission = LP::mul(diffuseTransmission, LP::r(texTrans.x)); }
-        float3 emissiveColor = LP::r3(material.EmissiveColor);
-        if (mflags & PTMaterialFlags_UseEmissiveTexture) emissiveColor = LP::mul3(emissiveColor, LP::r3(xyz(texEmissive)));
-        float matIoR = LP::r(material.IoR);
         if (hasUV && (mflags & PTMaterialFlags_UseNormalTexture)) {                                   // ApplyNormalMapRTXPT
             float sqT = dot(xyz(tangent), xyz(tangent));
             if (sqT != 0 && tangent.w != 0) {
@@ -450,30 +466,21 @@ template <bool LP16> struct PathKernelContextT {
         }
         bool ignoreTangent = (mflags & PTMaterialFlags_IgnoreMeshTangentSpace) != 0;
         computeTangentSpace(sd, tangent, ignoreTangent);
-        sd.faceNCorrected = frontFacing ? flatNormal : -flatNormal;
         sd.vertexN = frontFacing ? geometryNormal : -geometryNormal;
-        sd.frontFacing = frontFacing;
         sd.N = frontFacing ? mShadingNormal : -mShadingNormal;
         if (mvBlock) mvBlock->projectionTerm = fabsf(dot(rayDir, -sd.N));
-        bool thin = (mflags & PTMaterialFlags_ThinSurface) != 0;
-        sd.materialID = materialIndex;
-        sd.mtl = MaterialHeader::make();
-        { uint pr = 1 + (mflags >> PTMaterialFlags_NestedPriorityShift); sd.mtl.setNestedPriority(pr < InteriorList::kMaxNestedPriority ? pr : InteriorList::kMaxNestedPriority); }
-        sd.mtl.setThinSurface(thin);
         adjustShadingNormal(sd, tangent, true, ignoreTangent);
         sd.shadowNoLFadeout = LP::r(material.ShadowNoLFadeout);
         float bsdfSpecTrans = LP::mul(transmission, LP::sub(1, metalness)), bsdfDiffTrans = LP::mul(diffuseTransmission, LP::sub(1, metalness));      // lp * (1 - lp)
-        sd.mtl.setActiveLobes(Lobe_All);
         float f = (matIoR - 1.f) / (matIoR + 1.f);
         float F0 = f * f;
-        StandardBSDFData bd;
         bd.diffuse = LP::lerp3(baseColor, make_float3(0.f), metalness);          // StandardBSDFData holds lp values (BxDF.hlsli:625-634); FalcorBSDF computes from them in float
         bd.specular = LP::lerp3(make_float3(LP::r(F0)), baseColor, metalness);
         bd.roughness = roughness; bd.metallic = metalness;
         bd.transmission = baseColor; bd.diffuseTransmission = bsdfDiffTrans; bd.specularTransmission = bsdfSpecTrans;
-        sd.IoR = 1.f;
         bd.eta = LP::div(sd.IoR, matIoR);
         if (!sd.mtl.isThinSurface() && !sd.frontFacing) bd.eta = LP::div(matIoR, sd.IoR);
+        }
         SurfaceData ret;
         ret.neeTriangleLightIndex = RTXPT_INVALID_LIGHT_INDEX; ret.neeAnalyticLightIndex = RTXPT_INVALID_LIGHT_INDEX;
         if (mflags & PTMaterialFlags_EnableAsAnalyticLightProxy) ret.neeAnalyticLightIndex = sc.subInstances[subInst].AnalyticProxyLightIndex;      // BridgeDonut:828-829
@@ -702,7 +709,8 @@ template <bool LP16> struct PathKernelContextT {
         req.valid = false; io.mark(0);      // (mark: cycle stamps of the phases in PT_SHADE_PHASE_PROBE builds, nothing otherwise)
         const float3 rayDir = path.dir;
         path.rayCone = path.rayCone.propagateDistance(hit.t); path.sceneLength = fminf_(path.sceneLength + hit.t, kMaxRayTravel);      // UpdatePathTravelled, the two updates the surface needs ...
-        SurfaceData sfd = loadSurface(hit.prim, hit.u, hit.v, rayDir, path.rayCone);
+        // a vertex that ends right after its emission term needs a fraction of the surface (loadSurface<LEAN>); the flag is in the word group the IO loads first
+        SurfaceData sfd = path.isTerminatingAtNextBounce() ? loadSurface<true>(hit.prim, hit.u, hit.v, rayDir, path.rayCone) : loadSurface<false>(hit.prim, hit.u, hit.v, rayDir, path.rayCone);
         io.mark(1);
         io.load_rest(path);
         path.incrementVertexIndex();                                                                                                    // ... and the third, once the flags word is there

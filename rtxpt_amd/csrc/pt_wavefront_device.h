@@ -56,6 +56,7 @@ struct PathPoolIO {
         PathState p; uint4 b = pool.s1[i], d = pool.s3[i];
         p.dir = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z)); p.sceneLength = asfloat(b.w);
         p.interiorList.slots[0] = d.x; p.interiorList.slots[1] = d.y; p.packedCounters = d.z; p.rayCone.widthSpreadAngleFP16 = d.w;
+        p.flagsAndVertexIndex = reinterpret_cast<const uint*>(pool.s4)[4u * (size_t)i + 2u];      // (PF_terminateAtNextBounce decides how much of the surface is loaded; load_rest brings the word again with its group)
         return p;
     }
     __device__ __forceinline__ void load_rest(PathState& p) const {
