@@ -58,34 +58,46 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 #define PT_SHARD_TILE_GROUP 1      // consecutive Morton-ordered 32x32 tiles dealt to the same rank (locality vs load balance)
 #endif
 #ifndef PT_PIPELINE_FULL_AT
-#define PT_PIPELINE_FULL_AT (1u << 21)      // paths per pt_render call from which all PT_PIPELINE_BATCHES are used (one rank of an 8-way sharded 4K frame has 4.1 M)
+// paths per pt_render call from which all PT_PIPELINE_BATCHES are used (one rank of an 8-way sharded 4K frame has 4.1 M)
+#define PT_PIPELINE_FULL_AT (1u << 21)
 #endif
 #ifndef PT_PIPELINE_MID_BATCHES
 #define PT_PIPELINE_MID_BATCHES 2      // batches between 1 M paths and PT_PIPELINE_FULL_AT
 #endif
 #ifndef PT_CLASSIFY_FROM
-#define PT_CLASSIFY_FROM 65536u     // passes with fewer paths skip k_classify (class-ordered shading pays through coherence, which a handful of waves do not have)
+// passes with fewer paths skip k_classify (class-ordered shading pays through coherence, which a handful of waves do not have)
+#define PT_CLASSIFY_FROM 65536u
 #endif
 #ifndef PT_SP_FILL_CLASSES
 #define PT_SP_FILL_CLASSES 1     // the stable-plane fill pass shades in class order (k_classify), like reference mode; 0: queue order (A/B)
 #endif
 #ifndef PT_SP_FILL_RANGED
-#define PT_SP_FILL_RANGED 1      // the fill pass's first traversal launch uses FirstHitFromVBuffer's narrowed ray interval (pt_stableplanes.h firstHitInterval); 0: the whole ray (A/B) — same hits
+// the fill pass's first traversal launch uses FirstHitFromVBuffer's narrowed ray interval (pt_stableplanes.h firstHitInterval); 0: the whole ray (A/B) — same
+// hits
+#define PT_SP_FILL_RANGED 1
 #endif
 #ifndef PT_TAIL_PATHS
-#define PT_TAIL_PATHS 4096u      // a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never. 32768 in rounds 4-5; with fused traversal
-                                  // launches and free-running small passes (round 6) a pass of tens of thousands of paths is cheaper as a wavefront pass than in the tail kernel's under-filled GPU
-                                  // (rank of eight 12.56 -> 12.11 ms without it), while the chains of passes that hold a few hundred paths each — nested-dielectric re-traces: C5 runs 19 passes, twelve of
-                                  // them below 10 k paths at ~0.25 ms each — are what the kernel is for: 4096 takes C5's rank of eight 13.9 -> 13.2 ms, C3's 12.0 -> 11.8 (profiles/r06o_tail_small_ab.txt)
+// a batch with at most this many live paths is finished by the tail kernel (pt_tail.hip, pt_set_tail_paths); 0: never. 32768 in rounds 4-5; with fused
+// traversal
+#define PT_TAIL_PATHS 4096u
+                                  // launches and free-running small passes (round 6) a pass of tens of thousands of paths is cheaper as a wavefront pass than
+                                  // in the tail kernel's under-filled GPU (rank of eight 12.56 -> 12.11 ms without it), while the chains of passes that hold a
+                                  // few hundred paths each — nested-dielectric re-traces: C5 runs 19 passes, twelve of them below 10 k paths at ~0.25 ms each —
+                                  // are what the kernel is for: 4096 takes C5's rank of eight 13.9 -> 13.2 ms, C3's 12.0 -> 11.8
+                                  // (profiles/r06o_tail_small_ab.txt)
 #endif
 #ifndef PT_FUSED_TRAVERSAL
-#define PT_FUSED_TRAVERSAL 1u      // pt_set_fused_traversal (default: on — it pays at every size, profiles/r06b_fused_traversal_ab.txt): 0 = every bounce traces its visibility rays in a launch of their own, 1 = together with the closest-hit rays of the next bounce
+// pt_set_fused_traversal (default: on — it pays at every size, profiles/r06b_fused_traversal_ab.txt): 0 = every bounce traces its visibility rays in a launch
+// of their own, 1 = together with the closest-hit rays of the next bounce
+#define PT_FUSED_TRAVERSAL 1u
 #endif                              // (k_trace_pair, pt_wavefront.hip), 2 = by the size of the call (PT_FUSED_BELOW)
 #ifndef PT_FUSED_BELOW
-#define PT_FUSED_BELOW (12u << 20)  // mode 2: calls of fewer paths than this fuse (one rank of a 4- or 8-way sharded 4K frame, 1080p frames); a full 4K x 4 spp frame (33 M) keeps its own launches
+// mode 2: calls of fewer paths than this fuse (one rank of a 4- or 8-way sharded 4K frame, 1080p frames); a full 4K x 4 spp frame (33 M) keeps its own launches
+#define PT_FUSED_BELOW (12u << 20)
 #endif
 #ifndef PT_FREE_RUN_BELOW
-#define PT_FREE_RUN_BELOW (1u << 22)   // pt_render: once every live batch holds fewer paths than this, the batches stop advancing in lockstep (0: lockstep to the end)
+// pt_render: once every live batch holds fewer paths than this, the batches stop advancing in lockstep (0: lockstep to the end)
+#define PT_FREE_RUN_BELOW (1u << 22)
 #endif
 #ifndef PT_PIPELINE_BATCHES
 #define PT_PIPELINE_BATCHES 4      // independent sub-frame batches pt_render keeps in flight on separate streams (A/B on C3 in DESIGN.md)
@@ -102,7 +114,8 @@ struct pt_context {
     std::vector<GeometryDesc> geometries; std::vector<MeshDesc> meshes; std::vector<InstanceDesc> instances;
     std::vector<ptk::PTMaterialData> materials; std::vector<HostTexture> textures; HostTexture envTex; bool envEnabled = false;
     float3x4 envToWorld, envToLocal; ptk::float3 envColorMul;
-    uint envCubeDim = 2048; std::vector<ptk::EnvDirectionalLight> envDirLights, sceneDirLights; bool envCubeDirty = true;      // sceneDirLights: world-space lights of the loaded scene (pt_set_scene_directional_lights), converted at bake time
+    // sceneDirLights: world-space lights of the loaded scene (pt_set_scene_directional_lights), converted at bake time
+    uint envCubeDim = 2048; std::vector<ptk::EnvDirectionalLight> envDirLights, sceneDirLights; bool envCubeDirty = true;
     ptk::EnvCube envCube;      // EnvMapBaker state (pt_set_environment_bake)
     std::vector<PolymorphicLightInfoFull> analyticLights;
     std::vector<SubInstanceData> subInstances; std::vector<ptk::uint2> subInstToInstGeom; std::vector<ptk::uint2> primInfo; std::vector<uint> subInstFirstPrim;
@@ -110,26 +123,34 @@ struct pt_context {
     DevBuf<float> dLightW; DevBuf<uint> dProxyOffsets; void* dScanTemp = nullptr; size_t scanTempBytes = 0;
     // device
     DevBuf<uint> dIndices, dNormals, dTangents, dProxyCounters, dProxyIndices, dEnvLookup, dOwned, dQueue[2], dEmissiveList, dEmissiveOffsets;
-    DevBuf<float> dPrevPositions; DevBuf<InstanceDesc> dPrevInstances; bool motionHistory = false, prevAllStale = false; std::vector<uint32_t> prevStaleRanges;      // pt_set_motion_history: the previous frame's pose; the (first, count) vertex ranges in which it differs from the current one
+    // pt_set_motion_history: the previous frame's pose; the (first, count) vertex ranges in which it differs from the current one
+    DevBuf<float> dPrevPositions; DevBuf<InstanceDesc> dPrevInstances; bool motionHistory = false, prevAllStale = false; std::vector<uint32_t> prevStaleRanges;
     DevBuf<float> dPositions; DevBuf<ptk::float2> dUvs; DevBuf<GeometryDesc> dGeometries; DevBuf<InstanceDesc> dInstances; DevBuf<SubInstanceData> dSubInstances;
     DevBuf<ptk::AlphaPlane> dAlphaPlanes; DevBuf<unsigned char> dAlphaPool; DevBuf<ptk::ShadeTri> dShadeTris; DevBuf<ptk::uint2> dSubInstToInstGeom, dPrimInfo; DevBuf<ptk::PTMaterialData> dMaterials; DevBuf<TexInfo> dTexInfos; DevBuf<ptk::float4> dTexels;
     bool skyEnabled = false; ptk::ProceduralSkyContext sky; DevBuf<ptk::float4> dSkyTex[4]; DevBuf<ptk::ProceduralSkyContext> dSky; DevBuf<ptk::uint2> dSkyLowRes;      // pt_set_procedural_sky
-    DevBuf<ptk::uint2> dEnvImageCube; uint envImageCubeDim = 0;      // pt_set_environment_cube: the environment image as a cube map (RGBA16F), uploaded by the setter
-    DevBuf<ptk::uint2> dEnvCube, dEnvCubeSource; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights; uint envCompression = 0;      // envCompression: EnvMapBaker's BC6U compression (0 off, 1 fast)
+    // pt_set_environment_cube: the environment image as a cube map (RGBA16F), uploaded by the setter
+    DevBuf<ptk::uint2> dEnvImageCube; uint envImageCubeDim = 0;
+    // envCompression: EnvMapBaker's BC6U compression (0 off, 1 fast)
+    DevBuf<ptk::uint2> dEnvCube, dEnvCubeSource; DevBuf<ptk::EnvDirectionalLight> dEnvDirLights; uint envCompression = 0;
     DevBuf<ptk::PolymorphicLightInfo> dLights; DevBuf<ptk::PolymorphicLightInfoEx> dLightsEx;
-    // NEE-AT (pt_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback reservoirs of the last pt_render call (one plane per sample)
+    // NEE-AT (pt_set_local_light_sampling): the screen-tile local samplers as the host hands them in, and the feedback reservoirs of the last pt_render call
+    // (one plane per sample)
     DevBuf<uint> dLocalTable; uint localResX = 0, localResY = 0, localJitterX = 0, localJitterY = 0, localMaxLight = 0; float localRatio = 0.f, sscThreshold = 0.f; bool feedbackRequired = false;
     DevBuf<float> dFbWeight; DevBuf<uint> dFbCand; DevBuf<ptk::float4> dSq3; uint fbSamples = 0;
     ptk::LightFrustumBoost lightBoost = {}; bool weightsDirty = false;      // pt_set_light_importance_boost: ImportanceBooster's frustum term (mul 0: off)
-    // NEE-AT with the baker in the loop (pt_set_neeat): what LightsBaker keeps between frames (LightsBaker.h:225-260) and the textures / buffers its feedback passes bind
+    // NEE-AT with the baker in the loop (pt_set_neeat): what LightsBaker keeps between frames (LightsBaker.h:225-260) and the textures / buffers its feedback
+    // passes bind
     struct NeeAt {
         bool enabled = false; float globalFeedbackWeight = 0.75f, localRatio = 0.65f, sscThreshold = 0.3f, dropoff = 0.005f, intensityDeltaMul = 64.0f; bool preFilter = true;
         uint updateCounter = 0; float jitterF[2] = {0, 0}; uint jitter[2] = {0, 0}, prevJitter[2] = {0, 0};
         bool feedbackFilled = false, lastFeedbackAvailable = false; uint historicTotalLightCount = 0, W = 0, H = 0, nHist = 0;
-        bool frameOpen = false, frameFeedbackAvailable = false, frameLocalAvailable = false, exportDepth = true; uint framePrevLightCount = 0;      // between UpdateBegin and UpdateEnd of a frame (realtime mode: the build pass runs in between)
+        // between UpdateBegin and UpdateEnd of a frame (realtime mode: the build pass runs in between)
+        bool frameOpen = false, frameFeedbackAvailable = false, frameLocalAvailable = false, exportDepth = true; uint framePrevLightCount = 0;
         DevBuf<float> fbW, scW, blW, snapW, curW, histW; DevBuf<uint> fbC, scC, blC, snapC, local, counters;
-        DevBuf<float> depth, histDepth; bool haveClip = false; float clipZ[4] = {0, 0, 0, 0}, clipW[4] = {0, 0, 0, 0};      // the exported depth of the last traced frame / of the one before; columns 2 and 3 of pt_set_view_projection's matrix
-        DevBuf<uint> xSend, xRecv; DevBuf<uint> xPixels; uint xW = 0, xH = 0;      // tile-sharded frames: the exchange of the owned pixels' reservoirs between frames
+        // the exported depth of the last traced frame / of the one before; columns 2 and 3 of pt_set_view_projection's matrix
+        DevBuf<float> depth, histDepth; bool haveClip = false; float clipZ[4] = {0, 0, 0, 0}, clipW[4] = {0, 0, 0, 0};
+        // tile-sharded frames: the exchange of the owned pixels' reservoirs between frames
+        DevBuf<uint> xSend, xRecv; DevBuf<uint> xPixels; uint xW = 0, xH = 0;
         void reset() { W = H = 0; updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; frameOpen = false; exportDepth = true; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
         void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); xSend.free(); xRecv.free(); xPixels.free(); depth.free(); histDepth.free(); }
     } neeat;
@@ -198,7 +219,8 @@ void shard_pixel_lists(uint width, uint height, uint world, std::vector<std::vec
 void build_shards(pt_context* c) {
     shard_pixel_lists(c->width, c->height, c->shardCount, c->shardPixels);
     c->owned = c->shardPixels[c->shardRank];
-    c->gatherW = c->gatherH = 0; c->spGatherW = c->spGatherH = 0;                // pt_gather's (and the stable-plane guide exchange's) per-rank counts and pixel lists follow the shard lists, not only the frame size
+    // pt_gather's (and the stable-plane guide exchange's) per-rank counts and pixel lists follow the shard lists, not only the frame size
+    c->gatherW = c->gatherH = 0; c->spGatherW = c->spGatherH = 0;
 }
 
 // ---- RCCL, bound at run time. One process may already hold a librccl.so (PyTorch ships its own): RTLD_NOLOAD finds that copy first, so that a single
@@ -335,7 +357,8 @@ int finalize_geometry(pt_context* c) {
             for (uint t = 0; t < gd.numIndices / 3; t++) c->primInfo.push_back(ptk::make_uint2(subInst, t));
         }
     }
-    if (c->primInfo.size() > 0x7FFFFFFull / 3ull * 2ull)      // traversal addresses triangles with 32-bit byte offsets (48 B records) and 28-bit leaf references
+    // traversal addresses triangles with 32-bit byte offsets (48 B records) and 28-bit leaf references
+    if (c->primInfo.size() > 0x7FFFFFFull / 3ull * 2ull)
         return fail(c, PT_ERROR_UNSUPPORTED, "more than 89 M triangles per scene are not supported by the traversal kernels");
     c->numTris = (uint)c->primInfo.size();
     hipStream_t st = c->stream;
@@ -344,13 +367,17 @@ int finalize_geometry(pt_context* c) {
     PT_CHECK_HIP(c, c->dGeometries.upload(c->geometries, st)); PT_CHECK_HIP(c, c->dInstances.upload(c->instances, st));
     PT_CHECK_HIP(c, c->dSubInstances.upload(c->subInstances, st)); PT_CHECK_HIP(c, c->dSubInstToInstGeom.upload(c->subInstToInstGeom, st));
     PT_CHECK_HIP(c, c->dPrimInfo.upload(c->primInfo, st)); PT_CHECK_HIP(c, c->dMaterials.upload(c->materials, st));
-    if (c->motionHistory) { c->prevAllStale = true; c->prevStaleRanges.clear(); int r = motion_history_sync(c); if (r != PT_OK) return r; }      // a new scene: its history starts here (previous = current)
+    // a new scene: its history starts here (previous = current)
+    if (c->motionHistory) { c->prevAllStale = true; c->prevStaleRanges.clear(); int r = motion_history_sync(c); if (r != PT_OK) return r; }
     if (c->bvhAllocated && c->bvh.capacity < c->numTris) { bvh_free(c->bvh); c->bvhAllocated = false; }
     if (!c->bvhAllocated) { PT_CHECK_HIP(c, bvh_alloc(c->bvh, c->numTris)); c->bvhAllocated = true; }
     c->bvh.builder = c->bvhBuilder;
-    { const char* e = getenv("MI355PT_REINSERT_PASSES"); c->bvh.riPasses = e ? (uint)atoi(e) : 12u; }      // BVH_BUILDER_PLOC_OPT: parallel re-insertion passes (MI355X, C3: 8 passes = 1463 Mrays/s in 63 ms, 12 = 1477 in 81 ms, 16 = 1476 in 98 ms; host SAH + re-insertion 1479 in 1824 ms — profiles/r03k_device_reinsertion_sweep.txt)
+    // BVH_BUILDER_PLOC_OPT: parallel re-insertion passes (MI355X, C3: 8 passes = 1463 Mrays/s in 63 ms, 12 = 1477 in 81 ms, 16 = 1476 in 98 ms; host SAH +
+    // re-insertion 1479 in 1824 ms — profiles/r03k_device_reinsertion_sweep.txt)
+    { const char* e = getenv("MI355PT_REINSERT_PASSES"); c->bvh.riPasses = e ? (uint)atoi(e) : 12u; }
     PT_CHECK_HIP(c, c->dShadeTris.resize(c->numTris));
-    if (!c->dTravSpill.p) PT_CHECK_HIP(c, c->dTravSpill.resize(PT_PIPELINE_BATCHES * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH));   // traversal stack tails, one region per pipelined batch (4 x 302 MB of 288 GB)
+    // traversal stack tails, one region per pipelined batch (4 x 302 MB of 288 GB)
+    if (!c->dTravSpill.p) PT_CHECK_HIP(c, c->dTravSpill.resize(PT_PIPELINE_BATCHES * (size_t)T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH));
     refresh_scene_view(c);
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, st));
@@ -409,7 +436,8 @@ int bake_env_quads(pt_context* c) {
         const std::vector<ptk::float4>& p = im.mips[l - 1];
         for (uint y = 0; y < d; y++) for (uint x = 0; x < d; x++) {
             ptk::float4 s = (p[(size_t)(2 * y) * pd + 2 * x] + p[(size_t)(2 * y) * pd + 2 * x + 1]) + (p[(size_t)(2 * y + 1) * pd + 2 * x] + p[(size_t)(2 * y + 1) * pd + 2 * x + 1]);
-            im.mips[l][(size_t)y * d + x] = ptk::env_round_rgba16f(s * 0.25f);      // MipMapGenPass MODE_COLOR (Donut, not vendored: the 2x2 mean of the stored texels, stored as binary16)
+            // MipMapGenPass MODE_COLOR (Donut, not vendored: the 2x2 mean of the stored texels, stored as binary16)
+            im.mips[l][(size_t)y * d + x] = ptk::env_round_rgba16f(s * 0.25f);
         }
     }
     std::vector<QTNode> base; std::vector<uint> packed;
@@ -442,14 +470,15 @@ int bake_env_quads(pt_context* c) {
     }
     return PT_OK;
 }
-// geometryOnly: the instances / vertices moved but materials, environment, analytic lights and settings did not (pt_animate): the environment quad-tree
-// lights are kept, only the emissive triangles are re-baked, and everything downstream (weights, proxy counts, proxy table) runs on the device.
-// ComputeProxyCounts + the proxy fill (LightsBaker.hlsl:880-948, 1009-1060) from the weights in dWeights[0 .. N) (dWeights[N] receives their sum). usage != null: NEE-AT's
-// feedback term. Leaves numProxies and the scene view current.
+// geometryOnly: the instances / vertices moved but materials, environment, analytic lights and settings did not (pt_animate): the environment quad-tree lights
+// are kept, only the emissive triangles are re-baked, and everything downstream (weights, proxy counts, proxy table) runs on the device. ComputeProxyCounts +
+// the proxy fill (LightsBaker.hlsl:880-948, 1009-1060) from the weights in dWeights[0 .. N) (dWeights[N] receives their sum). usage != null: NEE-AT's feedback
+// term. Leaves numProxies and the scene view current.
 int build_light_proxies(pt_context* c, float* dWeights, const uint* dUsage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight) {
     const uint N = (uint)c->lights.size(); if (!N) return PT_OK;
     const uint budget = RTXPT_LIGHTING_SAMPLING_PROXY_RATIO * std::max(N, RTXPT_LIGHTING_MAX_LIGHTS / 10);
-    const size_t proxyCapacity = (size_t)budget + N;                       // sum of ceil((budget - N) w_i / W) <= budget - N + N (the feedback lerp keeps the weights' sum at W)
+    // sum of ceil((budget - N) w_i / W) <= budget - N + N (the feedback lerp keeps the weights' sum at W)
+    const size_t proxyCapacity = (size_t)budget + N;
     PT_CHECK_HIP(c, c->dProxyCounters.resize(N)); PT_CHECK_HIP(c, c->dProxyOffsets.resize(N)); PT_CHECK_HIP(c, c->dProxyIndices.resize(proxyCapacity));
     launch_light_proxy_counts(dWeights, N, dWeights + N, budget, c->S.NEEType == 0, RTXPT_LIGHTING_MAX_SAMPLING_PROXIES_PER_LIGHT - 1, c->dProxyCounters.p, dUsage, totalMaxFeedbackCount, globalFeedbackUseWeight, c->stream);
     size_t need = 0;
@@ -478,7 +507,8 @@ int bake_lights(pt_context* c, bool geometryOnly = false) {
         if (c->envEnabled && !keepEnv) { c->lights.resize(QT_TOTAL); c->lightsEx.resize(QT_TOTAL); int r = bake_env_quads(c); if (r != PT_OK) return r; c->envLightsBaked = QT_TOTAL; }
         const uint analyticBase = (uint)c->lights.size();
         for (auto& a : c->analyticLights) { c->lights.push_back(a.Base); c->lightsEx.push_back(a.Extended); }
-        // analytic light proxies (LightsBaker.cpp:718-753): a mesh instance that stands in for an analytic light carries that light's index in its sub-instances
+        // analytic light proxies (LightsBaker.cpp:718-753): a mesh instance that stands in for an analytic light carries that light's index in its
+        // sub-instances
         for (size_t s = 0; s < c->subInstances.size(); s++) {
             const uint proxy = c->instances[c->subInstToInstGeom[s].x].analyticProxyLight;
             if (proxy && proxy <= c->analyticLights.size() && (c->materials[c->subInstances[s].GlobalGeometryIndex_PTMaterialDataIndex & 0xFFFFu].Flags & PTMaterialFlags_EnableAsAnalyticLightProxy))
@@ -495,7 +525,8 @@ int bake_lights(pt_context* c, bool geometryOnly = false) {
             c->subInstances[s].EmissiveLightMappingOffset = lightBase + total;
             list.push_back((uint)s); offsets.push_back(total); total += ntri;
         }
-        c->lights.resize((size_t)lightBase + total); c->lightsEx.resize((size_t)lightBase + total);      // (the emissive part of the host mirror only holds the size)
+        // (the emissive part of the host mirror only holds the size)
+        c->lights.resize((size_t)lightBase + total); c->lightsEx.resize((size_t)lightBase + total);
         const uint N = (uint)c->lights.size();
         PT_CHECK_HIP(c, c->dLights.resize(N)); PT_CHECK_HIP(c, c->dLightsEx.resize(N));
         if (lightBase && !keepEnv) {                       // environment quads + analytic lights: computed on the host, static under animation
@@ -506,7 +537,8 @@ int bake_lights(pt_context* c, bool geometryOnly = false) {
             PT_CHECK_HIP(c, hipMemcpyAsync(c->dLightsEx.p + QT_TOTAL, c->lightsEx.data() + QT_TOTAL, sizeof(ptk::PolymorphicLightInfoEx) * (lightBase - QT_TOTAL), hipMemcpyHostToDevice, c->stream));
         }
         if (total) {
-            PT_CHECK_HIP(c, c->dEmissiveList.upload(list, c->stream)); PT_CHECK_HIP(c, c->dEmissiveOffsets.upload(offsets, c->stream));      // (a few KB; always: the list is not keyed on a capacity)
+            // (a few KB; always: the list is not keyed on a capacity)
+            PT_CHECK_HIP(c, c->dEmissiveList.upload(list, c->stream)); PT_CHECK_HIP(c, c->dEmissiveOffsets.upload(offsets, c->stream));
             launch_bake_emissive(c->dsc, c->dEmissiveList.p, c->dEmissiveOffsets.p, (uint)list.size(), total, lightBase, c->dLights.p, c->dLightsEx.p, c->stream);
         }
         // ComputeWeights + ComputeProxyCounts + proxy fill (LightsBaker.hlsl:738-751, 836-948) on the device; NEEType 0 = uniform (1 proxy per light)
@@ -533,8 +565,9 @@ int bake_env_cube(pt_context* c) {
     ptk::EnvCube& e = c->envCube; memset(&e, 0, sizeof(e)); e.dim = c->envCubeDim; e.mipLevels = ptk::env_cube_mip_levels(e.dim);
     size_t total = 0; for (uint l = 0; l < e.mipLevels; l++) { e.mipOffset[l] = (uint)total; total += 6ull * (e.dim >> l) * (e.dim >> l); }
     PT_CHECK_HIP(c, c->dEnvCube.resize(total));
-    // the lights drawn into the cube: what the host handed over in the environment's frame (pt_set_environment_bake), then the loaded scene's own directional lights, taken there by
-    // Sample::UpdateLighting's step (pt_env_bake_lights) with THIS bake's cube size and the environment's current orientation; EMB_MAXDIRLIGHTS in all
+    // the lights drawn into the cube: what the host handed over in the environment's frame (pt_set_environment_bake), then the loaded scene's own directional
+    // lights, taken there by Sample::UpdateLighting's step (pt_env_bake_lights) with THIS bake's cube size and the environment's current orientation;
+    // EMB_MAXDIRLIGHTS in all
     std::vector<ptk::EnvDirectionalLight> dirLights = c->envDirLights;
     if (!c->sceneDirLights.empty()) {
         PtEnvMapSceneParams prm; memset(&prm, 0, sizeof(prm)); memcpy(prm.Transform, c->envToWorld.m, 48); prm.Enabled = 1.f;
@@ -565,7 +598,8 @@ int prepare(pt_context* c) {
     if (c->envEnabled && c->envCubeDirty) { int r = bake_env_cube(c); if (r != PT_OK) return r; }
     if (c->geomDirty) { int r = finalize_geometry(c); if (r != PT_OK) return r; }
     if (c->lightsDirty) { int r = bake_lights(c); if (r != PT_OK) return r; }
-    else if (c->weightsDirty && !c->lights.empty()) {      // the camera moved under a frustum boost: weights and proxies only (the lights themselves do not depend on it)
+    // the camera moved under a frustum boost: weights and proxies only (the lights themselves do not depend on it)
+    else if (c->weightsDirty && !c->lights.empty()) {
         launch_light_weights(c->dLights.p, c->dLightsEx.p, (uint)c->lights.size(), c->dLightW.p, c->lightBoost, c->stream);
         int r = build_light_proxies(c, c->dLightW.p, nullptr, 0u, 0.f); if (r != PT_OK) return r;
         refresh_scene_view(c);
@@ -587,11 +621,12 @@ int ensure_pool(pt_context* c, uint n, uint shadowPerPath) {      // shadowPerPa
     return PT_OK;
 }
 
-// Tile-sharded frames (pt_create with shardCount > 1): a rank traces, and feeds back for, its own pixels only, but the baker's passes read whole neighbourhoods. Between two
-// frames every rank therefore receives the other ranks' reservoirs and exported depth (12 bytes per pixel: 100 MB for a 4K frame; the depth is what the reprojection tests — a
-// pixel another rank traced would otherwise read as depth 0, "valid" by NaN compare, whatever its owner sees) and then runs the same deterministic passes on the same
-// planes as everybody else: identical tables and proxy counts on all ranks, identical to the unsharded run. With a communicator (pt_comm_init) the exchange is RCCL point-to-point
-// inside one group, un-padded like pt_gather; without one the host moves the packed buffers (pt_neeat_pack_feedback / pt_neeat_unpack_feedback).
+// Tile-sharded frames (pt_create with shardCount > 1): a rank traces, and feeds back for, its own pixels only, but the baker's passes read whole
+// neighbourhoods. Between two frames every rank therefore receives the other ranks' reservoirs and exported depth (12 bytes per pixel: 100 MB for a 4K frame;
+// the depth is what the reprojection tests — a pixel another rank traced would otherwise read as depth 0, "valid" by NaN compare, whatever its owner sees) and
+// then runs the same deterministic passes on the same planes as everybody else: identical tables and proxy counts on all ranks, identical to the unsharded run.
+// With a communicator (pt_comm_init) the exchange is RCCL point-to-point inside one group, un-padded like pt_gather; without one the host moves the packed
+// buffers (pt_neeat_pack_feedback / pt_neeat_unpack_feedback).
 int neeat_exchange_feedback(pt_context* c) {
     pt_context::NeeAt& st = c->neeat;
     if (c->shardCount == 1 || !c->comm || !st.feedbackFilled || st.W != c->width || st.H != c->height) return PT_OK;
@@ -617,15 +652,17 @@ int neeat_exchange_feedback(pt_context* c) {
     launch_unpack_feedback(st.fbW.p, st.fbC.p, st.depth.p, st.xPixels.p, (uint)off, c->width, st.xRecv.p, s);
     return PT_OK;
 }
-// One frame of LightsBaker::UpdateBegin + UpdateEnd for the NEE-AT layer (LightsBaker.cpp:943-962, 985-1075, 1186-1213, 1335-1420) ahead of the frame's path tracing; the
-// order and the constants are spelled out in pt_neeat.h. The light set is the baked one; what changes per frame is the global proxy table, the tile tables and the jitter.
-// phases: NEEAT_BEGIN = LightsBaker::UpdateBegin (before the frame's G-buffer), NEEAT_END = UpdateEnd (after it, on the frame's depth and motion vectors: Sample.cpp:2491-2494; pt_realtime_frame),
-// NEEAT_BOTH = reference mode: nothing happens in between, UpdateEnd reads the depth the last traced frame exported (depth == nullptr) and the motion vectors are zero
+// One frame of LightsBaker::UpdateBegin + UpdateEnd for the NEE-AT layer (LightsBaker.cpp:943-962, 985-1075, 1186-1213, 1335-1420) ahead of the frame's path
+// tracing; the order and the constants are spelled out in pt_neeat.h. The light set is the baked one; what changes per frame is the global proxy table, the
+// tile tables and the jitter. phases: NEEAT_BEGIN = LightsBaker::UpdateBegin (before the frame's G-buffer), NEEAT_END = UpdateEnd (after it, on the frame's
+// depth and motion vectors: Sample.cpp:2491-2494; pt_realtime_frame), NEEAT_BOTH = reference mode: nothing happens in between, UpdateEnd reads the depth the
+// last traced frame exported (depth == nullptr) and the motion vectors are zero
 enum { NEEAT_BEGIN = 1, NEEAT_END = 2, NEEAT_BOTH = 3 };
 int neeat_frame(pt_context* c, int phases = NEEAT_BOTH, const float* depth = nullptr, const ptk::uint2* motion = nullptr) {
     pt_context::NeeAt& st = c->neeat;
     const uint N = (uint)c->lights.size();
-    if (!N || !c->numProxies) {                     // nothing to sample (no lights, or all of them dark): NEE does not run (LightSampler::IsEmpty), the frame is traced without a local layer
+    // nothing to sample (no lights, or all of them dark): NEE does not run (LightSampler::IsEmpty), the frame is traced without a local layer
+    if (!N || !c->numProxies) {
         c->localResX = c->localResY = c->localJitterX = c->localJitterY = c->localMaxLight = 0; c->localRatio = 0.f; c->feedbackRequired = false; st.feedbackFilled = st.lastFeedbackAvailable = false; st.frameOpen = false;
         refresh_scene_view(c); return PT_OK;
     }
@@ -633,7 +670,8 @@ int neeat_frame(pt_context* c, int phases = NEEAT_BOTH, const float* depth = nul
     F.W = c->width; F.H = c->height; F.BW = (F.W + 1) / 2; F.BH = (F.H + 1) / 2; F.tilesX = (F.W + 7) / 8 + 1; F.tilesY = (F.H + 7) / 8 + 1;
     const size_t px = (size_t)F.W * F.H, bpx = (size_t)F.BW * F.BH, tiles = (size_t)F.tilesX * F.tilesY;
     if (phases & NEEAT_BEGIN) {
-        if (st.historicTotalLightCount && st.historicTotalLightCount != N) st.feedbackFilled = st.lastFeedbackAvailable = false;      // another light set: its indices mean nothing to the old reservoirs and tiles
+        // another light set: its indices mean nothing to the old reservoirs and tiles
+        if (st.historicTotalLightCount && st.historicTotalLightCount != N) st.feedbackFilled = st.lastFeedbackAvailable = false;
         if (st.W != F.W || st.H != F.H) {               // (re)create the textures: LightsBaker::CreateRenderPasses (LightsBaker.cpp:300-345)
             st.W = F.W; st.H = F.H; st.feedbackFilled = false; st.lastFeedbackAvailable = false;
             PT_CHECK_HIP(c, st.fbW.resize(px)); PT_CHECK_HIP(c, st.fbC.resize(px)); PT_CHECK_HIP(c, st.scW.resize(px)); PT_CHECK_HIP(c, st.scC.resize(px)); PT_CHECK_HIP(c, st.snapW.resize(px)); PT_CHECK_HIP(c, st.snapC.resize(px));
@@ -671,8 +709,10 @@ int neeat_frame(pt_context* c, int phases = NEEAT_BOTH, const float* depth = nul
     F.samplingProxyCount = c->numProxies; F.proxies = c->dProxyIndices.p;
     // ---- UpdateEnd
     launch_neeat_end(F, c->stream);
-    if (!depth) PT_CHECK_HIP(c, hipMemsetAsync(st.depth.p, 0, 4 * px, c->stream));      // reference mode: Bridge::ExportSurfaceInit of every pixel of the frame about to be traced
-    st.exportDepth = depth == nullptr;                                                    // (the fill passes of realtime mode export nothing: the build pass wrote this frame's depth)
+    // reference mode: Bridge::ExportSurfaceInit of every pixel of the frame about to be traced
+    if (!depth) PT_CHECK_HIP(c, hipMemsetAsync(st.depth.p, 0, 4 * px, c->stream));
+    // (the fill passes of realtime mode export nothing: the build pass wrote this frame's depth)
+    st.exportDepth = depth == nullptr;
     st.feedbackFilled = true; st.frameOpen = false;
     // what the path tracer binds this frame (the local layer is sampled only once feedback exists: LightsBaker.cpp:1048)
     c->localResX = F.tilesX; c->localResY = F.tilesY; c->localJitterX = st.jitter[0]; c->localJitterY = st.jitter[1]; c->localMaxLight = 0;
@@ -702,14 +742,17 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) if (hipStreamCreateWithFlags(&c->streams[b], hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     if (hipHostMalloc(&c->hostCounters, PT_PIPELINE_BATCHES * sizeof(WaveCounters), hipHostMallocDefault) != hipSuccess) { delete c; return PT_ERROR_HIP; }
     c->serialKernels = desc && (desc->flags & PT_DEVICE_SERIAL_KERNELS);
-    // scene builds prefer fast trace, as the reference asks of its driver (Sample.cpp:1093): PLOC + parallel re-insertion + cost-driven wide nodes, all on the device (round 3;
-    // PT_DEVICE_HOST_SAH_BUILDER: round 2's host-side binned SAH + re-insertion) unless the host asks for fast builds; pt_animate's rebuilds are always plain PLOC
+    // scene builds prefer fast trace, as the reference asks of its driver (Sample.cpp:1093): PLOC + parallel re-insertion + cost-driven wide nodes, all on the
+    // device (round 3; PT_DEVICE_HOST_SAH_BUILDER: round 2's host-side binned SAH + re-insertion) unless the host asks for fast builds; pt_animate's rebuilds
+    // are always plain PLOC
     c->bvhBuilder = (desc && (desc->flags & PT_DEVICE_PREFER_FAST_BUILD)) ? BVH_BUILDER_PLOC : ((desc && (desc->flags & PT_DEVICE_HOST_SAH_BUILDER)) ? BVH_BUILDER_SAH : BVH_BUILDER_PLOC_OPT);
     { const char* e = getenv("MI355PT_BVH_BUILDER");        // developer A/B switch
       if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; else if (e && (!strcmp(e, "ploc_opt") || !strcmp(e, "device"))) c->bvhBuilder = BVH_BUILDER_PLOC_OPT; }
     { const char* e = getenv("MI355PT_TAIL_PATHS"); if (e) c->tailBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch (pt_set_tail_paths)
-    { const char* e = getenv("MI355PT_FUSED_TRAVERSAL"); if (e) c->fusedTraversal = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch (pt_set_fused_traversal)
-    { const char* e = getenv("MI355PT_TAIL_DEFER"); if (e) c->tailDefer = (uint)strtoul(e, nullptr, 10); }      // test switch: iterations after which the tail kernel hands a ray back (0: T8_TAIL_DEFER); a small value sends most rays through the hand-back path
+    // developer A/B switch (pt_set_fused_traversal)
+    { const char* e = getenv("MI355PT_FUSED_TRAVERSAL"); if (e) c->fusedTraversal = (uint)strtoul(e, nullptr, 10); }
+    // test switch: iterations after which the tail kernel hands a ray back (0: T8_TAIL_DEFER); a small value sends most rays through the hand-back path
+    { const char* e = getenv("MI355PT_TAIL_DEFER"); if (e) c->tailDefer = (uint)strtoul(e, nullptr, 10); }
     memset(&c->dsc, 0, sizeof(c->dsc)); memset(&c->cam, 0, sizeof(c->cam)); memset(&c->bvh, 0, sizeof(c->bvh));
     pt_default_settings(reinterpret_cast<::PtSettings*>(&c->S));
     const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48); c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale);      // no params = tint 1, intensity 1: the cube holds radiance x 1/4
@@ -807,7 +850,8 @@ static void set_env_params(pt_context* c, const PtEnvMapSceneParams* params) {
         memset(&c->envToLocal, 0, sizeof(float3x4));
         for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) c->envToLocal.m[r * 4 + k] = c->envToWorld.m[k * 4 + r];   // rotation inverse = transpose
         c->envColorMul = ptk::make_float3(params->ColorMultiplier[0], params->ColorMultiplier[1], params->ColorMultiplier[2]);
-    } else {                                               // no params: identity orientation, the supplied radiance as it is (ColorMultiplier = 1 / c_envMapRadianceScale undoes the cube's 1/4)
+    // no params: identity orientation, the supplied radiance as it is (ColorMultiplier = 1 / c_envMapRadianceScale undoes the cube's 1/4)
+    } else {
         const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; memcpy(c->envToWorld.m, I, 48); memcpy(c->envToLocal.m, I, 48);
         c->envColorMul = ptk::make_float3(1.0f / ptk::kEnvMapRadianceScale);
     }
@@ -833,7 +877,8 @@ int32_t pt_set_environment_cube(pt_context* c, const float* rgbaFaces, uint32_t 
     c->envTex.w = c->envTex.h = 0; c->envTex.mips.clear();    // one image source at a time
     c->envEnabled = (dim != 0 && rgbaFaces && (!params || params->Enabled != 0.f));
     if (!c->envEnabled) { c->envImageCubeDim = 0; c->dEnvImageCube.free(); if (c->skyEnabled && (!params || params->Enabled != 0.f)) c->envEnabled = true; }
-    else {                                                 // stored as the RGBA16F texels a BC6H / RGBA16F cube file decodes to (a RGBA32F file is rounded to them)
+    // stored as the RGBA16F texels a BC6H / RGBA16F cube file decodes to (a RGBA32F file is rounded to them)
+    else {
         const size_t n = 6ull * dim * dim; std::vector<ptk::uint2> h(n);
         for (size_t i = 0; i < n; i++) h[i] = ptk::env_pack_rgba16f(ptk::make_float4(rgbaFaces[4 * i], rgbaFaces[4 * i + 1], rgbaFaces[4 * i + 2], rgbaFaces[4 * i + 3]));
         PT_CHECK_HIP(c, c->dEnvImageCube.resize(n)); PT_CHECK_HIP(c, hipMemcpy(c->dEnvImageCube.p, h.data(), n * sizeof(ptk::uint2), hipMemcpyHostToDevice));
@@ -903,7 +948,8 @@ int32_t pt_set_local_light_sampling(pt_context* c, const uint32_t* table, uint32
     if (table) {
         if (!resX || !resY || jitterX >= TILE_PX || jitterY >= TILE_PX) return fail(c, PT_ERROR_INVALID_ARGUMENT, "local sampling table: resolution in tiles of 8 x 8 pixels, jitter below the tile size");
         uint maxLight = 0;
-        for (size_t t = 0; t < (size_t)resX * resY; t++) for (uint k = 0; k < N; k++) {      // SampleLocalPDF searches the tile by light index (LightingAlgorithms.hlsli:654): the entries must be sorted
+        // SampleLocalPDF searches the tile by light index (LightingAlgorithms.hlsli:654): the entries must be sorted
+        for (size_t t = 0; t < (size_t)resX * resY; t++) for (uint k = 0; k < N; k++) {
             const uint light = table[t * N + k] >> 9;
             if (k && light < (table[t * N + k - 1] >> 9)) return fail(c, PT_ERROR_INVALID_ARGUMENT, "local sampling table: a tile's entries must be sorted by light index");
             if (light > maxLight) maxLight = light;
@@ -941,7 +987,8 @@ int32_t pt_set_neeat(pt_context* c, int32_t enable, float globalTemporalFeedback
     refresh_scene_view(c);
     return PT_OK;
 }
-// the owned pixels' reservoirs and exported depth as (weight bits, candidate, depth bits) triples, 12 bytes per pixel in the order of the rank's pixel list — pt_pack_shard's order; device pointers
+// the owned pixels' reservoirs and exported depth as (weight bits, candidate, depth bits) triples, 12 bytes per pixel in the order of the rank's pixel list —
+// pt_pack_shard's order; device pointers
 int32_t pt_neeat_pack_feedback(pt_context* c, void* dst, size_t bytes) {
     if (!c || !dst) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->neeat.enabled || !c->neeat.W || c->neeat.W != c->width || c->neeat.H != c->height) return fail(c, PT_ERROR_NOT_READY, "no NEE-AT frame yet: pt_set_neeat, then pt_render");
@@ -1050,7 +1097,8 @@ int32_t pt_default_settings(::PtSettings* s) {
 int32_t pt_set_settings(pt_context* c, const ::PtSettings* s) {
     if (!c || !s) return fail(c, PT_ERROR_INVALID_ARGUMENT, "null argument");
     // NEEType 2 (NEE-AT): the global table is built as for type 1 (LightsBaker.hlsl:920-923 treats every type but 0 alike; the feedback-weighted boost of the
-    // global proxies belongs to the baker's feedback passes, which the host does not have yet); the local layer and the feedback come from pt_set_local_light_sampling
+    // global proxies belongs to the baker's feedback passes, which the host does not have yet); the local layer and the feedback come from
+    // pt_set_local_light_sampling
     if (s->NEEType > 2) return fail(c, PT_ERROR_INVALID_ARGUMENT, "NEEType: 0 (uniform), 1 (power) or 2 (NEE-AT)");
     if (s->NEECandidateSamples == 0 || s->NEECandidateSamples > 63) return fail(c, PT_ERROR_INVALID_ARGUMENT, "NEECandidateSamples must be in [1,63]");
     if (s->nestedDielectricsQuality > 2 || (s->diffuseBrdf != 0 && s->diffuseBrdf != 2) || s->bounceCount > 96 || s->useFp16Types > 1) return fail(c, PT_ERROR_INVALID_ARGUMENT, "setting out of range");
@@ -1077,20 +1125,23 @@ int32_t pt_reset_accumulation(pt_context* c) {
     return PT_OK;
 }
 int32_t pt_animate(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts, int32_t rebuild) { return pt_animate_ranges(c, inst, nInst, positions, nVerts, nullptr, 0u, rebuild); }
-// Motion history (Donut: SceneGraph::Refresh keeps every node's previous global transform, the skinning pass the previous positions of the meshes it rewrites; InstanceData.prevTransform,
-// GeometryData.prevPositionOffset): with it on, every pt_animate / pt_animate_ranges call is one scene refresh — the pose it finds becomes the previous pose, the pose it brings the
-// current one — and the stable-plane build pass's motion vectors carry the objects' motion (Bridge::loadSurface's prevPosW). A call without instances and positions only advances the
-// history (a frame in which nothing moved: previous = current, no refit). Device-to-device copies of the instance table and of the vertex ranges that differ.
+// Motion history (Donut: SceneGraph::Refresh keeps every node's previous global transform, the skinning pass the previous positions of the meshes it rewrites;
+// InstanceData.prevTransform, GeometryData.prevPositionOffset): with it on, every pt_animate / pt_animate_ranges call is one scene refresh — the pose it finds
+// becomes the previous pose, the pose it brings the current one — and the stable-plane build pass's motion vectors carry the objects' motion
+// (Bridge::loadSurface's prevPosW). A call without instances and positions only advances the history (a frame in which nothing moved: previous = current, no
+// refit). Device-to-device copies of the instance table and of the vertex ranges that differ.
 int32_t pt_set_motion_history(pt_context* c, int32_t enable) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
     if (!enable) { c->motionHistory = false; c->dPrevPositions.free(); c->dPrevInstances.free(); c->prevStaleRanges.clear(); c->prevAllStale = false; refresh_scene_view(c); return PT_OK; }
     if (c->geomDirty || c->texDirty) { int r = prepare(c); if (r != PT_OK) return r; }
-    if (!c->motionHistory) { c->motionHistory = true; c->prevAllStale = true; int r = motion_history_sync(c); if (r != PT_OK) return r; }      // previous = current: nothing has moved yet
+    // previous = current: nothing has moved yet
+    if (!c->motionHistory) { c->motionHistory = true; c->prevAllStale = true; int r = motion_history_sync(c); if (r != PT_OK) return r; }
     refresh_scene_view(c);
     return PT_OK;
 }
-// the previous pose handed over directly (a host that keeps its own history, or a test): arrays shaped like the scene's; either may be NULL (= that part did not move). Turns the history on.
+// the previous pose handed over directly (a host that keeps its own history, or a test): arrays shaped like the scene's; either may be NULL (= that part did
+// not move). Turns the history on.
 int32_t pt_set_previous_pose(pt_context* c, const PtInstanceDesc* inst, uint32_t nInst, const float* positions, uint32_t nVerts) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
@@ -1114,7 +1165,8 @@ int32_t pt_animate_ranges(pt_context* c, const PtInstanceDesc* inst, uint32_t nI
     if (positions && (size_t)nVerts * 3 != c->positions.size()) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: vertex count must not change");
     if (positions && vertexRanges) for (uint32_t r = 0; r < nRanges; r++) if ((unsigned long long)vertexRanges[2 * r] + vertexRanges[2 * r + 1] > nVerts) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate_ranges: vertex range beyond the vertex count");
     if (inst) for (uint32_t i = 0; i < nInst; i++) if (inst[i].meshIndex != c->instances[i].meshIndex) return fail(c, PT_ERROR_INVALID_ARGUMENT, "pt_animate: topology must not change");
-    // (every argument is validated by now: a rejected call must not advance the motion history — the next build pass would report zero object motion for what moved last frame)
+    // (every argument is validated by now: a rejected call must not advance the motion history — the next build pass would report zero object motion for what
+    // moved last frame)
     if (c->motionHistory) {      // one scene refresh: what is current becomes previous (before the uploads below overwrite it)
         int r = motion_history_sync(c); if (r != PT_OK) return r;
         if (positions) { if (vertexRanges) c->prevStaleRanges.assign(vertexRanges, vertexRanges + 2 * (size_t)nRanges); else c->prevAllStale = true; }
@@ -1157,7 +1209,8 @@ int32_t pt_animate_ranges(pt_context* c, const PtInstanceDesc* inst, uint32_t nI
         if (c->bvh.builder == BVH_BUILDER_SAH || c->bvh.builder == BVH_BUILDER_PLOC_OPT) c->bvh.builder = BVH_BUILDER_PLOC;
         PT_CHECK_HIP(c, bvh_build(c->bvh, c->dsc, c->numTris, c->stream));
     } else PT_CHECK_HIP(c, bvh_refit(c->bvh, c->dsc, c->numTris, c->stream));
-    c->dsc.nodes = c->bvh.bvh2Stale ? nullptr : c->bvh.nodes;      // (a fast refit leaves the BVH2 behind: nothing may read it until the next full build, pt_build.h bvh2Stale)
+    // (a fast refit leaves the BVH2 behind: nothing may read it until the next full build, pt_build.h bvh2Stale)
+    c->dsc.nodes = c->bvh.bvh2Stale ? nullptr : c->bvh.nodes;
     PT_CHECK_HIP(c, hipEventRecord(e1, c->stream));
     tC = now();
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
@@ -1167,7 +1220,8 @@ int32_t pt_animate_ranges(pt_context* c, const PtInstanceDesc* inst, uint32_t nI
     c->lightsDirty = true;                    // emissive triangle lights move with the geometry (Sample.cpp:1170-1198)
     c->accumCount = 0;                        // any scene change resets accumulation in reference mode
     PT_CHECK_HIP(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(ptk::float4) * (size_t)c->width * c->height, c->stream));
-    const int32_t rb = bake_lights(c, !lightsWereDirty);     // geometry moved, nothing else: environment lights kept, emissive re-bake + weights + proxy table on the device
+    // geometry moved, nothing else: environment lights kept, emissive re-bake + weights + proxy table on the device
+    const int32_t rb = bake_lights(c, !lightsWereDirty);
     tE = now();
     if (animLog) fprintf(stderr, "[animate] copy + upload %.3f ms, launches %.3f ms, wait %.3f ms (refit %.3f ms on the device), light re-bake %.3f ms: %.3f ms\n", tB - tA, tC - tB, tD - tC, ms, tE - tD, tE - tA);
     return rb;
@@ -1207,18 +1261,21 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     if (!count) return PT_OK;
     (void)hipSetDevice(c->device);
     int r = prepare(c); if (r != PT_OK) return r;
-    if (c->neeat.enabled && c->S.NEEEnabled && c->S.NEEFullSamples != 0u) {      // NEE-AT with the baker in the loop: every sample is a frame — baker passes, then the path tracer
+    // NEE-AT with the baker in the loop: every sample is a frame — baker passes, then the path tracer
+    if (c->neeat.enabled && c->S.NEEEnabled && c->S.NEEFullSamples != 0u) {
         if (count > 1) {
             PtFrameStats total; memset(&total, 0, sizeof(total));
             for (uint32_t s = 0; s < count; s++) {
                 PtFrameStats one; r = pt_render(c, first + s, 1, &one);
-                if (r != PT_OK) { if (stats) *stats = total; return r; }      // (the samples before the failing one were accumulated: their counts are reported)
+                // (the samples before the failing one were accumulated: their counts are reported)
+                if (r != PT_OK) { if (stats) *stats = total; return r; }
                 add_frame_stats(total, one);
             }
             if (stats) *stats = total;
             return PT_OK;
         }
-        r = neeat_exchange_feedback(c); if (r != PT_OK) return r;      // (tile shards with a communicator; a host without one exchanges through pt_neeat_pack / unpack_feedback)
+        // (tile shards with a communicator; a host without one exchanges through pt_neeat_pack / unpack_feedback)
+        r = neeat_exchange_feedback(c); if (r != PT_OK) return r;
         r = neeat_frame(c); if (r != PT_OK) return r;
     }
     uint numOwned = (uint)c->owned.size();
@@ -1226,8 +1283,10 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     uint total = numOwned * count;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (total == 0) { c->accumCount += count; return PT_OK; }
-    const uint neeSamples = c->S.NEEFullSamples < 63u ? c->S.NEEFullSamples : 63u;          // min(RTXPT_LIGHTING_MAX_SAMPLE_COUNT, NEEFullSamples), PathTracerNEE.hlsli:312
-    const uint shadowGroup = (c->S.NEEEnabled && neeSamples > 1u) ? neeSamples : 0u;            // 0: one shadow-queue entry per path vertex, written by k_shade itself
+    // min(RTXPT_LIGHTING_MAX_SAMPLE_COUNT, NEEFullSamples), PathTracerNEE.hlsli:312
+    const uint neeSamples = c->S.NEEFullSamples < 63u ? c->S.NEEFullSamples : 63u;
+    // 0: one shadow-queue entry per path vertex, written by k_shade itself
+    const uint shadowGroup = (c->S.NEEEnabled && neeSamples > 1u) ? neeSamples : 0u;
     const uint shadowPerPath = shadowGroup ? shadowGroup : 1u;
     r = ensure_pool(c, total, shadowPerPath); if (r != PT_OK) return r;
     if (c->localResX) {                     // NEE-AT local layer: every pixel's (jittered) tile must exist, and a table can only name lights that were baked
@@ -1248,18 +1307,21 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     }
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
-    if (neeSamples == 0u) k.S.NEEEnabled = 0;            // `applyNEE &= fullSamples > 0` (PathTracerNEE.hlsli:322): the vertices behave as without NEE; the light tables stay as baked
+    // `applyNEE &= fullSamples > 0` (PathTracerNEE.hlsli:322): the vertices behave as without NEE; the light tables stay as baked
+    if (neeSamples == 0u) k.S.NEEEnabled = 0;
 
-    // The owned pixels are traced as up to PT_PIPELINE_BATCHES independent sub-frame batches, each on its own stream. Paths never interact, so this changes nothing in the
-    // result; it lets the k_shade of one batch (3 waves per SIMD, mostly waiting on memory) overlap the traversal of the others and hides the ~0.5 ms drain at the
-    // end of every launch (C3: 241 ms with one batch, 199 ms with four). The batches advance in lockstep (queue all, then service each as its counts arrive): an
-    // event-driven variant that re-queued each batch independently was 7 % slower. Small frames use fewer batches, PT_DEVICE_SERIAL_KERNELS one.
+    // The owned pixels are traced as up to PT_PIPELINE_BATCHES independent sub-frame batches, each on its own stream. Paths never interact, so this changes
+    // nothing in the result; it lets the k_shade of one batch (3 waves per SIMD, mostly waiting on memory) overlap the traversal of the others and hides the
+    // ~0.5 ms drain at the end of every launch (C3: 241 ms with one batch, 199 ms with four). The batches advance in lockstep (queue all, then service each as
+    // its counts arrive): an event-driven variant that re-queued each batch independently was 7 % slower. Small frames use fewer batches,
+    // PT_DEVICE_SERIAL_KERNELS one.
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
         uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false; uint bound = 0, pendingShadow = 0; TravAux auxSh;      // pendingShadow / auxSh: fused traversal launches (below)      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; uint items; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
-        bool timed = false;      // per-launch HIP events: only when somebody reads them (serial-kernel steps, the pass log) — ten API calls per pass and batch otherwise
+        // per-launch HIP events: only when somebody reads them (serial-kernel steps, the pass log) — ten API calls per pass and batch otherwise
+        bool timed = false;
         size_t mark() { if (!timed) return 0; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); return ev.size() - 1; }
     };
     uint numBatches = (c->serialKernels || total < (1u << 20)) ? 1u : ((total < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
@@ -1277,9 +1339,10 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
         t.k = k; t.k.sc = t.sc;
         t.aux.taskQ[0] = c->dTaskQ.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.aux.taskQ[1] = t.aux.taskQ[0] + TASK_QUEUE_CAPACITY; t.aux.counts = c->dTravCounts.p + PASS_COUNTERS * b;
-        // pipelined batches: one GPU-full of blocks per traversal launch (pt_scene.h PT_T8_MAX_BLOCKS) — and fewer for the launches of a small frame (one rank of a sharded frame): every wave
-        // then works through more chunks before it runs dry and fewer of its rays are cut into sub-trees; the other batches keep the GPU full. profiles/r05q_grid_cap_ab.txt:
-        // a rank of eight (4.1 M paths) 896 blocks -1 ... -3 %, a rank of four / two 1120 blocks -1 %, the full frame (33 M paths) +1 % with either: hence by size.
+        // pipelined batches: one GPU-full of blocks per traversal launch (pt_scene.h PT_T8_MAX_BLOCKS) — and fewer for the launches of a small frame (one rank
+        // of a sharded frame): every wave then works through more chunks before it runs dry and fewer of its rays are cut into sub-trees; the other batches
+        // keep the GPU full. profiles/r05q_grid_cap_ab.txt: a rank of eight (4.1 M paths) 896 blocks -1 ... -3 %, a rank of four / two 1120 blocks -1 %, the
+        // full frame (33 M paths) +1 % with either: hence by size.
         t.aux.maxBlocks = (numBatches >= 3u) ? (total < (6u << 20) ? 256u * 7u / 2u : (total < (24u << 20) ? 256u * 35u / 8u : 256u * 7u)) : 0u;
         { static const uint blocksOverride = []() { const char* e = getenv("MI355PT_MAX_BLOCKS"); return e ? (uint)strtoul(e, nullptr, 10) : 0u; }(); if (blocksOverride) t.aux.maxBlocks = blocksOverride < T8_MAX_BLOCKS ? blocksOverride : T8_MAX_BLOCKS; }      // (clamped: a batch's stack-tail slice is sized for T8_MAX_BLOCKS blocks)      // developer A/B switch
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + sbase; t.aux.resolveList = c->dResolveList.p + sbase; t.aux.primToSlot = c->bvh.primToSlot;
@@ -1287,7 +1350,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         memset(t.hwc, 0, sizeof(WaveCounters)); t.hwc->extendCount[0] = t.total;
         t.active = t.total;
     }
-    if (numBatches > 1) PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // uploads issued on the main stream (prepare) must be visible to the second stream
+    // uploads issued on the main stream (prepare) must be visible to the second stream
+    if (numBatches > 1) PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     hipEvent_t frame0, frame1; PT_CHECK_HIP(c, hipEventCreate(&frame0)); PT_CHECK_HIP(c, hipEventCreate(&frame1));
     PT_CHECK_HIP(c, hipEventRecord(frame0, c->stream));
     for (uint b = 0; b < numBatches; b++) {
@@ -1298,35 +1362,40 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     }
     // upper bound on extend passes: bounceCount+1 vertices plus rejected (nested dielectric) re-traces
     uint maxIter = c->S.bounceCount + 2 + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u : 0u));
-    // the tail kernel takes over a batch once it holds at most this many paths (0: never). Not in serial-kernel / counter frames (their per-kernel attribution is the point), not with
-    // grouped NEE samples (NEEFullSamples > 1 folds a vertex's samples in k_resolve_nee) and not without a tree (the traversal's empty-scene path is per launch, not per wave)
+    // the tail kernel takes over a batch once it holds at most this many paths (0: never). Not in serial-kernel / counter frames (their per-kernel attribution
+    // is the point), not with grouped NEE samples (NEEFullSamples > 1 folds a vertex's samples in k_resolve_nee) and not without a tree (the traversal's
+    // empty-scene path is per launch, not per wave)
     const uint tailBelow = (!c->serialKernels && !c->countersEnabled && !shadowGroup && c->dsc.rootIsValid) ? c->tailBelow : 0u;
-    // Fused traversal launches (round 6; pt_set_fused_traversal, k_trace_pair): the visibility rays a bounce's shading leaves in the shadow queue are not traced in a launch of their own
-    // but wait (Batch::pendingShadow) for the next bounce's closest-hit launch and share it — and its task rounds and resolve pass — block by block. Nothing of vertex k + 1 needs the
-    // visibility of vertex k before vertex k + 1 is shaded (the order of the fp16 additions into a path's L), and that is exactly where the fused launch sits, so the image cannot change;
-    // the visibility rays need their own task queues, merge keys and resolve list (auxSh). A batch whose paths have ended, or which goes to the tail kernel, traces what is pending in a
-    // plain visibility launch first. Not in serial-kernel / counter frames (their per-kernel attribution is the point) and not with grouped NEE samples (k_resolve_nee).
+    // Fused traversal launches (round 6; pt_set_fused_traversal, k_trace_pair): the visibility rays a bounce's shading leaves in the shadow queue are not
+    // traced in a launch of their own but wait (Batch::pendingShadow) for the next bounce's closest-hit launch and share it — and its task rounds and resolve
+    // pass — block by block. Nothing of vertex k + 1 needs the visibility of vertex k before vertex k + 1 is shaded (the order of the fp16 additions into a
+    // path's L), and that is exactly where the fused launch sits, so the image cannot change; the visibility rays need their own task queues, merge keys and
+    // resolve list (auxSh). A batch whose paths have ended, or which goes to the tail kernel, traces what is pending in a plain visibility launch first. Not in
+    // serial-kernel / counter frames (their per-kernel attribution is the point) and not with grouped NEE samples (k_resolve_nee).
     const bool fused = !c->serialKernels && !c->countersEnabled && !shadowGroup && c->dsc.rootIsValid && (c->fusedTraversal == 1u || (c->fusedTraversal == 2u && total < PT_FUSED_BELOW));
     if (fused) {
         PT_CHECK_HIP(c, c->dBestKeySh.resize(c->shadowCapacity)); PT_CHECK_HIP(c, c->dResolveListSh.resize(c->shadowCapacity)); PT_CHECK_HIP(c, c->dTaskQSh.resize((size_t)PT_PIPELINE_BATCHES * 2 * TASK_QUEUE_CAPACITY));
         for (uint b = 0; b < numBatches; b++) { Batch& t = B[b]; t.auxSh = t.aux; t.auxSh.counts = t.aux.counts + PASS_SHADOW_OFFSET; t.auxSh.taskQ[0] = c->dTaskQSh.p + (size_t)(2 * b) * TASK_QUEUE_CAPACITY; t.auxSh.taskQ[1] = t.auxSh.taskQ[0] + TASK_QUEUE_CAPACITY;
             t.auxSh.bestKey = c->dBestKeySh.p + (size_t)t.base * shadowPerPath; t.auxSh.resolveList = c->dResolveListSh.p + (size_t)t.base * shadowPerPath; }
     }
-    // Batches run in lockstep: a batch's next half-pass is queued when ALL batches have delivered their counts, which keeps one batch's shading next to the others' traversal
-    // (free-running streams drift into running the same kernel at the same time: 7 % slower on the full frame and no gain on a rank of a sharded frame, DESIGN.md §4,
-    // profiles/r04i_event_loop_ab.txt).
+    // Batches run in lockstep: a batch's next half-pass is queued when ALL batches have delivered their counts, which keeps one batch's shading next to the
+    // others' traversal (free-running streams drift into running the same kernel at the same time: 7 % slower on the full frame and no gain on a rank of a
+    // sharded frame, DESIGN.md §4, profiles/r04i_event_loop_ab.txt).
     const bool passLog = getenv("MI355PT_PASS_LOG") != nullptr;
-    // One pass of a batch is queued by queue_pass (counter reset, traversal — fused with the pending visibility rays — classify + shade, read-back of the two queue counts) and
-    // finished by finish_pass once those counts have arrived (the visibility rays become pending, or are traced if the batch ends here).
+    // One pass of a batch is queued by queue_pass (counter reset, traversal — fused with the pending visibility rays — classify + shade, read-back of the two
+    // queue counts) and finished by finish_pass once those counts have arrived (the visibility rays become pending, or are traced if the batch ends here).
     uint wavefrontPasses = 0;
     auto queue_pass = [&](Batch& t) -> int32_t {
         uint nxt = t.cur ^ 1u;
-        launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], fused ? nullptr : &t.wc->shadowCount, t.st);      // the pass's traversal / class counters and the two queue counters it refills: one launch (fused: the shadow queue's counter still counts the pending rays; k_resolve_pair zeroes it)
+        // the pass's traversal / class counters and the two queue counters it refills: one launch (fused: the shadow queue's counter still counts the pending
+        // rays; k_resolve_pair zeroes it)
+        launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], fused ? nullptr : &t.wc->shadowCount, t.st);
         if (tailBelow && t.active <= tailBelow && !t.afterTail) {
             if (t.pendingShadow) { launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, false, t.auxSh, t.st); PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st)); t.pendingShadow = 0; }      // (the tail kernel adds to the paths' radiance itself: what is pending lands first)      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
             size_t e0 = t.mark(); launch_tail(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, maxIter - t.bound, c->tailDefer, t.aux.maxBlocks, t.st); size_t e1 = t.mark();
             if (t.timed) t.spans.push_back({e0, e1, 3, t.active});
-            t.tailLaunches++; t.afterTail = true; t.inTail = true;      // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
+            // what comes back — stragglers — is traced by a wavefront pass (task rounds included) before the tail kernel gets another turn
+            t.tailLaunches++; t.afterTail = true; t.inTail = true;
             PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
             t.waiting = true;
             return PT_OK;
@@ -1345,23 +1414,26 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     auto finish_pass = [&](Batch& t, uint b) -> int32_t {
         t.waiting = false; t.inTail = false;
         uint nxt = t.cur ^ 1u, nShadow = t.hwc->shadowCount;
-        if (passLog) {      // the pass's straggler counters: sub-trees split off by k_extend and by task rounds 0..2, rays sent to the resolve pass (the previous pass's shadow launch is reported with the next line)
+        // the pass's straggler counters: sub-trees split off by k_extend and by task rounds 0..2, rays sent to the resolve pass (the previous pass's shadow
+        // launch is reported with the next line)
+        if (passLog) {
             uint pc[PASS_COUNTERS]; PT_CHECK_HIP(c, hipMemcpy(pc, t.aux.counts, sizeof(pc), hipMemcpyDeviceToHost));
             fprintf(stderr, "[pass log]   b%u pass %u: %u paths -> extend splits %u / %u / %u / %u sub-trees, %u rays resolved; %u visibility rays next\n", b, t.iterations, t.active, pc[0], pc[1], pc[2], pc[3], pc[TRAV_RESOLVE], nShadow);
         }
         TravAux auxShadow = t.aux; auxShadow.counts = t.aux.counts + PASS_SHADOW_OFFSET;
         t.active = t.hwc->extendCount[nxt];
-        if (fused && nShadow && t.active && t.bound < maxIter) { t.pendingShadow = nShadow; t.shadowRays += nShadow; }      // they ride with the next closest-hit launch
+        // they ride with the next closest-hit launch
+        if (fused && nShadow && t.active && t.bound < maxIter) { t.pendingShadow = nShadow; t.shadowRays += nShadow; }
         else if (nShadow) { size_t s0 = t.mark(); launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, nShadow, t.wc, c->countersEnabled, fused ? t.auxSh : auxShadow, t.st); size_t s1 = t.mark(); if (t.timed) t.spans.push_back({s0, s1, 2, nShadow}); if (!shadowGroup) t.shadowRays += nShadow;
                             if (fused) PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st)); }
         t.cur = nxt; t.iterations++;
         return PT_OK;
     };
     auto live = [&](const Batch& t) { return t.active && t.bound < maxIter; };
-    // Small passes run free (round 6). The lockstep above pays while every pass fills the GPU; at the end of a frame — and for the whole of a small frame — a pass is a chain of
-    // a dozen short launches, the batches no longer take equally long, and in lockstep three streams sit idle until the slowest has delivered its counts (0.7 - 1 ms per late pass of
-    // the 4K frame, profiles/r06i_*). Once every live batch holds fewer than `freeRunBelow` paths the loop turns event-driven: whichever batch's counts arrive first is finished and
-    // its next pass queued at once.
+    // Small passes run free (round 6). The lockstep above pays while every pass fills the GPU; at the end of a frame — and for the whole of a small frame — a
+    // pass is a chain of a dozen short launches, the batches no longer take equally long, and in lockstep three streams sit idle until the slowest has
+    // delivered its counts (0.7 - 1 ms per late pass of the 4K frame, profiles/r06i_*). Once every live batch holds fewer than `freeRunBelow` paths the loop
+    // turns event-driven: whichever batch's counts arrive first is finished and its next pass queued at once.
     static const uint freeRunBelow = []() { const char* e = getenv("MI355PT_FREE_RUN_BELOW"); return e ? (uint)strtoul(e, nullptr, 10) : (uint)PT_FREE_RUN_BELOW; }();
     bool any = true;
     while (any) {
@@ -1390,7 +1462,8 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
             }
             break;
         }
-        // phase 2: as each batch's counts arrive, its visibility rays become pending (or are traced, if the batch ends); the other batches keep the GPU busy meanwhile
+        // phase 2: as each batch's counts arrive, its visibility rays become pending (or are traced, if the batch ends); the other batches keep the GPU busy
+        // meanwhile
         for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b];
             if (!t.waiting) continue;
@@ -1446,8 +1519,9 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     for (uint b = 0; b < numBatches; b++) for (auto e : B[b].ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(frame0); (void)hipEventDestroy(frame1);
     if (overflow) return fail(c, PT_ERROR_HIP, "BVH8 traversal: stack tail or straggler task queue overflow (raise T8_SPILL_DEPTH / TASK_QUEUE_CAPACITY)");
-    // The pass bound (maxIter) is a safety net, never what ends a path: a path ends by its own bounce / rejected-hit counters (PathTracer.hlsli:40-45, PathTracerNestedDielectrics.hlsli).
-    // Were a path still alive here, the set of dropped paths — the image — would depend on how the passes were composed (tail threshold): reported, not swallowed.
+    // The pass bound (maxIter) is a safety net, never what ends a path: a path ends by its own bounce / rejected-hit counters (PathTracer.hlsli:40-45,
+    // PathTracerNestedDielectrics.hlsli). Were a path still alive here, the set of dropped paths — the image — would depend on how the passes were composed
+    // (tail threshold): reported, not swallowed.
     for (uint b = 0; b < numBatches; b++) if (B[b].active) return fail(c, PT_ERROR_HIP, "pt_render: paths still alive at the pass bound (bounceCount + 2 + the nested-dielectric allowance): the bound must be raised");
     return PT_OK;
 }
@@ -1466,7 +1540,8 @@ int32_t pt_build_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStab
     StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
     PT_CHECK_HIP(c, c->dSpHeader.resize(4 * N)); PT_CHECK_HIP(c, c->dSpPlanes.resize((size_t)cStablePlaneCount * sp.C.genericTSPlaneStride)); PT_CHECK_HIP(c, c->dSpRadiance.resize(N)); PT_CHECK_HIP(c, c->dSpMotion.resize(N));
     PT_CHECK_HIP(c, c->dSpDepth.resize(N)); PT_CHECK_HIP(c, c->dSpHitT.resize(N)); PT_CHECK_HIP(c, c->dSpThroughput.resize(N));
-    if (c->spW != c->width || c->spH != c->height) {      // a new size: nothing of the old frame is meaningful (pixels of other ranks' tiles and the records of planes that do not exist stay zero)
+    // a new size: nothing of the old frame is meaningful (pixels of other ranks' tiles and the records of planes that do not exist stay zero)
+    if (c->spW != c->width || c->spH != c->height) {
         PT_CHECK_HIP(c, hipMemsetAsync(c->dSpHeader.p, 0xFF, 16 * N, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpPlanes.p, 0, sizeof(ptk::StablePlane) * cStablePlaneCount * sp.C.genericTSPlaneStride, c->stream));
         PT_CHECK_HIP(c, hipMemsetAsync(c->dSpRadiance.p, 0, 8 * N, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpMotion.p, 0, 8 * N, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpDepth.p, 0, 4 * N, c->stream));
         PT_CHECK_HIP(c, hipMemsetAsync(c->dSpHitT.p, 0, 4 * N, c->stream)); PT_CHECK_HIP(c, hipMemsetAsync(c->dSpThroughput.p, 0, 4 * N, c->stream));
@@ -1486,7 +1561,8 @@ int32_t pt_build_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStab
     PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
     PT_CHECK_HIP(c, hipMemcpyAsync(wc, hwc, sizeof(WaveCounters), hipMemcpyHostToDevice, c->stream));
     launch_sp_generate(k, sp, pool, c->dOwned.p, numOwned, sampleIndex, queue[0], c->stream);
-    // every pass is one vertex of every pixel that still explores: at most three planes of at most maxStablePlaneVertexDepth + 1 vertices, plus the false hits nested dielectrics reject
+    // every pass is one vertex of every pixel that still explores: at most three planes of at most maxStablePlaneVertexDepth + 1 vertices, plus the false hits
+    // nested dielectrics reject
     const uint maxIter = cStablePlaneCount * (sp.C.maxStablePlaneVertexDepth + 2u + ((c->S.nestedDielectricsQuality == 2) ? 16u : (c->S.nestedDielectricsQuality == 1 ? 4u * (sp.C.maxStablePlaneVertexDepth + 1u) : 0u)));
     uint cur = 0, active = numOwned, iterations = 0; unsigned long long rays = 0;
     while (active && iterations < maxIter) {
@@ -1515,8 +1591,8 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
     if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
     if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes first");
     if (c->S.NEEEnabled && c->S.NEEFullSamples > 1u) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill pass traces one full NEE sample per vertex (NEEFullSamples 0 or 1, the reference's default)");
-    // temporal feedback: with the baker in the loop (pt_set_neeat + pt_realtime_frame) the pass's visible light samples fill the run's reservoirs; a host that runs its own baker
-    // (pt_set_local_light_sampling with temporalFeedback) gets its per-sample planes from pt_render only
+    // temporal feedback: with the baker in the loop (pt_set_neeat + pt_realtime_frame) the pass's visible light samples fill the run's reservoirs; a host that
+    // runs its own baker (pt_set_local_light_sampling with temporalFeedback) gets its per-sample planes from pt_render only
     const bool feedback = c->neeat.enabled && c->feedbackRequired && c->S.NEEEnabled && c->S.NEEFullSamples != 0u;
     if (c->feedbackRequired && !c->neeat.enabled) return fail(c, PT_ERROR_INVALID_ARGUMENT, "the fill pass feeds NEE-AT's reservoirs only with the baker in the loop (pt_set_neeat, pt_realtime_frame): switch the temporal feedback of pt_set_local_light_sampling off");
     if (feedback && (!c->neeat.fbW.p || c->neeat.W != c->width || c->neeat.H != c->height)) return fail(c, PT_ERROR_NOT_READY, "NEE-AT: no baker frame of this size yet (pt_realtime_frame runs it)");
@@ -1529,13 +1605,15 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
     const bool freshMark = c->dSpMark.n < numOwned;
     PT_CHECK_HIP(c, c->dSpMark.resize(numOwned)); PT_CHECK_HIP(c, c->dSpNewL.resize(numOwned));
     if (feedback) PT_CHECK_HIP(c, c->dSq3.resize(c->shadowCapacity));
-    if (freshMark) PT_CHECK_HIP(c, hipMemsetAsync(c->dSpMark.p, 0, sizeof(ptk::uint4) * c->dSpMark.n, c->stream));      // (k_sp_fill_resolve clears what a pass marked)
+    // (k_sp_fill_resolve clears what a pass marked)
+    if (freshMark) PT_CHECK_HIP(c, hipMemsetAsync(c->dSpMark.p, 0, sizeof(ptk::uint4) * c->dSpMark.n, c->stream));
     ptk::StablePlanesParams prm; memcpy(&prm, params, sizeof(prm));
     StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
     sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p; sp.B.Depth = c->dSpDepth.p; sp.B.SpecularHitT = c->dSpHitT.p; sp.B.MotionVectors = c->dSpMotion.p; sp.B.Throughput = c->dSpThroughput.p;
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
-    // As pt_render: the pixels are traced as up to PT_PIPELINE_BATCHES independent batches, each on its own stream with its own queues, counters, task queues and slice of the pool, advancing in
-    // lockstep (queue all, then service each as its counts arrive) — the shading of one batch overlaps the traversal of the others and the drain at the end of every launch is hidden.
+    // As pt_render: the pixels are traced as up to PT_PIPELINE_BATCHES independent batches, each on its own stream with its own queues, counters, task queues
+    // and slice of the pool, advancing in lockstep (queue all, then service each as its counts arrive) — the shading of one batch overlaps the traversal of the
+    // others and the drain at the end of every launch is hidden.
     struct Batch { uint pixFirst = 0, numPix = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr; PathPool pool, markPool; ShadowQueue sq; ptk::float4* newL = nullptr; uint* queue[2] = {nullptr, nullptr};
                    DeviceScene sc; PathKernelContext k; TravAux aux; uint cur = 0, active = 0, iterations = 0; unsigned long long rays = 0, shadowRays = 0; bool waiting = false; };
     const uint numBatches = (c->serialKernels || numOwned < (1u << 20)) ? 1u : ((numOwned < PT_PIPELINE_FULL_AT) ? (uint)PT_PIPELINE_MID_BATCHES : PT_PIPELINE_BATCHES);
@@ -1548,8 +1626,8 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
         t.pool = PathPool{c->dS0.p + base, c->dS1.p + base, c->dS2.p + base, c->dS3.p + base, c->dS4.p + base, c->dHit.p + base};
         t.markPool = t.pool; t.markPool.s2 = c->dSpMark.p + base; t.newL = c->dSpNewL.p + base;
         t.sq = ShadowQueue{c->dSq0.p + base, c->dSq1.p + base, c->dSq2.p + base, 0u, nullptr, nullptr, nullptr, 0u, 0u, 0u};
-        // feedback: the fourth word group of an entry and the reservoir planes; the reference mode's shadow kernels then apply the reservoir update and the roulette fix-up of a visible entry
-        // themselves (pt_wavefront.hip shadow_visible; one slot per pixel: plane stride 0)
+        // feedback: the fourth word group of an entry and the reservoir planes; the reference mode's shadow kernels then apply the reservoir update and the
+        // roulette fix-up of a visible entry themselves (pt_wavefront.hip shadow_visible; one slot per pixel: plane stride 0)
         if (feedback) { t.sq.q3 = c->dSq3.p + base; t.sq.fbTotalWeight = c->neeat.fbW.p; t.sq.fbCandidates = c->neeat.fbC.p; t.sq.fbWidth = c->width; t.sq.fbPlane = 0u; t.sq.fbSampleFirst = 0u; }
         t.queue[0] = c->dQueue[0].p + base; t.queue[1] = c->dQueue[1].p + base;
         t.sc = c->dsc; t.sc.travSpill = c->dsc.travSpill + (size_t)b * T8_MAX_BLOCKS * T8_GROUPS_PER_BLOCK * T8_SPILL_DEPTH;
@@ -1559,7 +1637,8 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
         t.aux.taskCap = TASK_QUEUE_CAPACITY; t.aux.bestKey = c->dBestKey.p + base; t.aux.resolveList = c->dResolveList.p + base; t.aux.primToSlot = c->bvh.primToSlot;
         memset(t.hwc, 0, sizeof(WaveCounters));
     }
-    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));      // uploads / memsets issued on the main stream (prepare, the marks) must be visible to the batch streams
+    // uploads / memsets issued on the main stream (prepare, the marks) must be visible to the batch streams
+    PT_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     hipEvent_t e0, e1; PT_CHECK_HIP(c, hipEventCreate(&e0)); PT_CHECK_HIP(c, hipEventCreate(&e1));
     PT_CHECK_HIP(c, hipEventRecord(e0, c->stream));
     for (uint b = 0; b < numBatches; b++) {
@@ -1585,7 +1664,8 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
             t.waiting = true;
         }
         any = false;
-        for (uint b = 0; b < numBatches; b++) {      // phase 2: as each batch's counts arrive, its visibility rays and their resolve; the other batches keep the GPU busy meanwhile
+        // phase 2: as each batch's counts arrive, its visibility rays and their resolve; the other batches keep the GPU busy meanwhile
+        for (uint b = 0; b < numBatches; b++) {
             Batch& t = B[b];
             if (!t.waiting) continue;
             PT_CHECK_HIP(c, hipStreamSynchronize(t.st));
@@ -1621,25 +1701,28 @@ int32_t pt_fill_stable_planes(pt_context* c, uint32_t sampleIndex, const PtStabl
     if (active) return fail(c, PT_ERROR_HIP, "stable-plane fill pass: paths still alive after the iteration bound");
     return PT_OK;
 }
-// The realtime mode's frame with everything coupled (Sample.cpp:2438-2516; pt_set_neeat on): LightsBaker::UpdateBegin -> build pass -> LightsBaker::UpdateEnd on THAT frame's depth and
-// screen-space motion vectors -> the fill passes, which sample the tables just made and fill the reservoirs the next frame's UpdateBegin reads.
+// The realtime mode's frame with everything coupled (Sample.cpp:2438-2516; pt_set_neeat on): LightsBaker::UpdateBegin -> build pass -> LightsBaker::UpdateEnd
+// on THAT frame's depth and screen-space motion vectors -> the fill passes, which sample the tables just made and fill the reservoirs the next frame's
+// UpdateBegin reads.
 static StablePlanesContext sp_buffers(pt_context* c) {
     ptk::StablePlanesParams prm; memset(&prm, 0, sizeof(prm)); prm.activeStablePlaneCount = cStablePlaneCount;
     StablePlanesContext sp; sp.C = ptk::SP_make_consts(prm, c->width, c->height, c->S.bounceCount);
     sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p; sp.B.Depth = c->dSpDepth.p; sp.B.SpecularHitT = c->dSpHitT.p; sp.B.MotionVectors = c->dSpMotion.p; sp.B.Throughput = c->dSpThroughput.p;
     return sp;
 }
-// ---- the realtime frame on tile shards (no reference analogue). The baker's passes read whole neighbourhoods of three things a rank only has for its own tiles: last frame's
-// reservoirs (UpdateBegin resolves them into the history), and this frame's depth and motion vectors (UpdateEnd reprojects through them). So a sharded frame has two exchanges:
-// the reservoirs before UpdateBegin (neeat_exchange_feedback, as between two reference-mode frames) and the build pass's guides — depth and motion vectors, 16 bytes per pixel
-// with the hit-distance word that lies between them — before UpdateEnd; every rank then runs the same deterministic baker passes on the same planes. With a communicator
-// pt_realtime_frame does both itself (RCCL point-to-point in one group, un-padded, like pt_gather); without one the host drives the parts and moves the packed buffers:
-//   pt_neeat_pack / unpack_feedback -> pt_neeat_update_begin -> pt_build_stable_planes -> pt_pack / unpack_stable_plane_guides -> pt_neeat_update_end -> pt_fill_stable_planes
+// ---- the realtime frame on tile shards (no reference analogue). The baker's passes read whole neighbourhoods of three things a rank only has for its own
+// tiles: last frame's reservoirs (UpdateBegin resolves them into the history), and this frame's depth and motion vectors (UpdateEnd reprojects through them).
+// So a sharded frame has two exchanges: the reservoirs before UpdateBegin (neeat_exchange_feedback, as between two reference-mode frames) and the build pass's
+// guides — depth and motion vectors, 16 bytes per pixel with the hit-distance word that lies between them — before UpdateEnd; every rank then runs the same
+// deterministic baker passes on the same planes. With a communicator pt_realtime_frame does both itself (RCCL point-to-point in one group, un-padded, like
+// pt_gather); without one the host drives the parts and moves the packed buffers: pt_neeat_pack / unpack_feedback -> pt_neeat_update_begin ->
+// pt_build_stable_planes -> pt_pack / unpack_stable_plane_guides -> pt_neeat_update_end -> pt_fill_stable_planes
 static int sp_exchange_guides(pt_context* c) {
     if (c->shardCount == 1 || !c->comm) return PT_OK;
     hipStream_t s = c->stream;
     const size_t n = c->owned.size(), W = SP_GUIDE_WORDS;
-    if (c->spGatherW != c->width || c->spGatherH != c->height) {      // the other ranks' pixel list and the staging buffers: once per frame size, not per realtime frame (the shard layout is a function of the size)
+    // the other ranks' pixel list and the staging buffers: once per frame size, not per realtime frame (the shard layout is a function of the size)
+    if (c->spGatherW != c->width || c->spGatherH != c->height) {
         std::vector<uint> others; for (uint r = 0; r < c->shardCount; r++) if (r != c->shardRank) others.insert(others.end(), c->shardPixels[r].begin(), c->shardPixels[r].end());
         PT_CHECK_HIP(c, c->dSpGatherPixels.upload(others, s)); PT_CHECK_HIP(c, c->dSpGatherRecv.resize(others.size() * W)); PT_CHECK_HIP(c, c->dSpGatherSend.resize(n * W)); PT_CHECK_HIP(c, hipStreamSynchronize(s));
         c->spGatherW = c->width; c->spGatherH = c->height;
@@ -1681,8 +1764,8 @@ int32_t pt_unpack_stable_plane_guides(pt_context* c, const void* src, size_t byt
     tmp.free();
     return PT_OK;
 }
-// LightsBaker::UpdateBegin / UpdateEnd as calls of their own (Rtxpt/Sample.cpp:1380-1412, 2491-2494): what pt_realtime_frame runs around the build pass, for a host that puts something
-// of its own in between (a tile-sharded frame without a communicator: the exchanges above)
+// LightsBaker::UpdateBegin / UpdateEnd as calls of their own (Rtxpt/Sample.cpp:1380-1412, 2491-2494): what pt_realtime_frame runs around the build pass, for a
+// host that puts something of its own in between (a tile-sharded frame without a communicator: the exchanges above)
 int32_t pt_neeat_update_begin(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->width) return fail(c, PT_ERROR_NOT_READY, "pt_resize first");
@@ -1726,12 +1809,14 @@ int32_t pt_stable_planes_merge(pt_context* c) {
     sp.B.Header = c->dSpHeader.p; sp.B.Planes = c->dSpPlanes.p; sp.B.StableRadiance = c->dSpRadiance.p;
     const uint numOwned = (uint)c->owned.size();
     if (numOwned) launch_sp_merge(sp, c->dOwned.p, numOwned, c->dAccum.p, c->stream);
-    c->accumCount = 1;                                    // the buffer now holds one finished frame: pt_map_radiance / pt_tonemap / pt_gather read it, the next pt_render blends into it like into any first sample
+    // the buffer now holds one finished frame: pt_map_radiance / pt_tonemap / pt_gather read it, the next pt_render blends into it like into any first sample
+    c->accumCount = 1;
     PT_CHECK_HIP(c, hipStreamSynchronize(c->stream)); PT_CHECK_HIP(c, hipGetLastError());
     return PT_OK;
 }
-// ---- the plane buffers of tile-sharded frames (no reference analogue): every rank builds and fills the planes of its own tiles; the rank that denoises or shows the frame needs them all.
-// 284 bytes per pixel (SP_SHARD_WORDS): header, three plane records, stable radiance, depth, specular hit distance, motion vectors, throughput.
+// ---- the plane buffers of tile-sharded frames (no reference analogue): every rank builds and fills the planes of its own tiles; the rank that denoises or
+// shows the frame needs them all. 284 bytes per pixel (SP_SHARD_WORDS): header, three plane records, stable radiance, depth, specular hit distance, motion
+// vectors, throughput.
 int32_t pt_stable_planes_shard_bytes(pt_context* c, uint32_t rank, size_t* bytes) {
     if (!c || !bytes || rank >= c->shardCount || !c->width) return PT_ERROR_INVALID_ARGUMENT;
     *bytes = c->shardPixels[rank].size() * (size_t)SP_SHARD_WORDS * 4u; return PT_OK;
@@ -1758,8 +1843,8 @@ int32_t pt_unpack_stable_planes(pt_context* c, const void* src, size_t bytes, ui
     c->spGathered = true;      // (the host says when all ranks are in: pt_denoise_spec_hit_t trusts it from here on)
     return PT_OK;
 }
-// pt_gather for the plane buffers: every rank sends its tiles' records to rank 0 (RCCL point-to-point inside one group, un-padded, on the library's stream); a world of one with a
-// communicator runs the protocol as a loop-back with the buffers poisoned in between, like pt_gather
+// pt_gather for the plane buffers: every rank sends its tiles' records to rank 0 (RCCL point-to-point inside one group, un-padded, on the library's stream); a
+// world of one with a communicator runs the protocol as a loop-back with the buffers poisoned in between, like pt_gather
 int32_t pt_gather_stable_planes(pt_context* c) {
     if (!c) return PT_ERROR_INVALID_ARGUMENT;
     if (!c->spW || c->spW != c->width || c->spH != c->height) return fail(c, PT_ERROR_NOT_READY, "no stable planes of this frame size yet: pt_build_stable_planes");
@@ -1844,7 +1929,8 @@ int32_t pt_default_tonemap(PtToneMapParams* out, float exposureCompensation, flo
     if (!out || !(shutter > 0.f) || !(fNumber > 0.f)) return PT_ERROR_INVALID_ARGUMENT;
     memset(out, 0, sizeof(*out));
     out->whiteScale = 5.1f; out->whiteMaxLuminance = 1.0f; out->toneMapOperator = 5u; out->clamped = 1u; out->enabled = 1u;      // ToneMappingPasses.h:36-53
-    out->autoExposure = 0u; out->avgLuminance = 1.0f; out->autoExposureLumValueMin = exp2f(-16.0f); out->autoExposureLumValueMax = exp2f(16.0f);   // ToneMappingPasses.cpp:337-338
+    // ToneMappingPasses.cpp:337-338
+    out->autoExposure = 0u; out->avgLuminance = 1.0f; out->autoExposureLumValueMin = exp2f(-16.0f); out->autoExposureLumValueMax = exp2f(16.0f);
     // UpdateColorTransform (ToneMappingPasses.cpp:428-441), white balance off => identity * exposureScale * manualExposureScale
     float exposureScale = powf(2.f, exposureCompensation);
     float manualExposureScale = ((1.f / 100.f) * filmSpeed) / (shutter * fNumber * fNumber);
@@ -1978,7 +2064,8 @@ int32_t pt_get_scene_info(pt_context* c, uint32_t* nTris, uint32_t* nNodes, uint
 int32_t pt_probe(pt_context* c, int32_t kind, const void* in, size_t inBytes, void* out, size_t outBytes, uint32_t n) {
     if (!c || !in || !out || !n) return fail(c, PT_ERROR_INVALID_ARGUMENT, "bad argument");
     (void)hipSetDevice(c->device);
-    if (kind == 8 || kind == 9 || kind == 10) { int r = prepare(c); if (r != PT_OK) return r; }      // the surface, environment and alpha-test probes read the scene
+    // the surface, environment and alpha-test probes read the scene
+    if (kind == 8 || kind == 9 || kind == 10) { int r = prepare(c); if (r != PT_OK) return r; }
     DevBuf<unsigned char> di, dout;
     PT_CHECK_HIP(c, di.upload((const unsigned char*)in, inBytes, c->stream)); PT_CHECK_HIP(c, dout.resize(outBytes));
     PathKernelContext k; k.sc = c->dsc; k.S = c->S; k.cam = c->cam;
@@ -2032,9 +2119,9 @@ int32_t pt_gather(pt_context* c) {
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
     if (c->shardCount == 1) {
-        // a world of one WITH a communicator: the whole protocol as a loop-back — pack, ncclSend to self + ncclRecv from self inside one group, unpack — so that
-        // the run-time-bound RCCL path can be exercised (and checked) on a one-GPU box. The frame is poisoned between pack and unpack: what pt_map_radiance
-        // returns afterwards has been through RCCL.
+        // a world of one WITH a communicator: the whole protocol as a loop-back — pack, ncclSend to self + ncclRecv from self inside one group, unpack — so
+        // that the run-time-bound RCCL path can be exercised (and checked) on a one-GPU box. The frame is poisoned between pack and unpack: what
+        // pt_map_radiance returns afterwards has been through RCCL.
         const size_t n = c->owned.size();
         if (!n) return PT_OK;
         PT_CHECK_HIP(c, c->dGatherSend.resize(n)); PT_CHECK_HIP(c, c->dGatherRecv.resize(n));
@@ -2048,7 +2135,8 @@ int32_t pt_gather(pt_context* c) {
         launch_unpack(c->dAccum.p, c->dOwned.p, (uint)n, c->width, c->dGatherRecv.p, st);
         return PT_OK;
     }
-    if (c->gatherW != c->width || c->gatherH != c->height) {                    // per-size state: counts of every rank; on rank 0 the other ranks' pixel lists on the device
+    // per-size state: counts of every rank; on rank 0 the other ranks' pixel lists on the device
+    if (c->gatherW != c->width || c->gatherH != c->height) {
         c->gatherCounts.assign(c->shardCount, 0);
         std::vector<uint> others;
         for (uint r = 0; r < c->shardCount; r++) { c->gatherCounts[r] = c->shardPixels[r].size(); if (r != 0 && c->shardRank == 0) others.insert(others.end(), c->shardPixels[r].begin(), c->shardPixels[r].end()); }
@@ -2076,8 +2164,9 @@ int32_t pt_gather(pt_context* c) {
     if (total) launch_unpack(c->dAccum.p, c->dGatherPixels.p, (uint)total, c->width, c->dGatherRecv.p, st);
     return PT_OK;
 }
-// The NEE-AT feedback exchange of tile-sharded frames (neeat_exchange_feedback) over HOST memory and the caller's transport: every rank sends the reservoirs and the exported depth of its own
-// pixels (12 bytes each) to every other rank and receives theirs. Pairs meet in rank order (the lower rank sends first), so blocking transports cannot deadlock.
+// The NEE-AT feedback exchange of tile-sharded frames (neeat_exchange_feedback) over HOST memory and the caller's transport: every rank sends the reservoirs
+// and the exported depth of its own pixels (12 bytes each) to every other rank and receives theirs. Pairs meet in rank order (the lower rank sends first), so
+// blocking transports cannot deadlock.
 int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, float* totalWeight, uint32_t* candidates, float* depth, const PtTransport* t) {
     if (!totalWeight || !candidates || !depth || !t || !t->send || !t->recv || !width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
     if (world == 1) return PT_OK;
@@ -2100,10 +2189,11 @@ int32_t pt_neeat_exchange_host(uint32_t width, uint32_t height, uint32_t rank, u
         return PT_OK;
     } catch (...) { return PT_ERROR_IO; }
 }
-// The general form over HOST memory: numPlanes row-major width x height planes of bytesPerPixel[k] bytes per pixel each (depth: 4, motion vectors: 8, a header plane: 4 ...).
-// toRoot = 0: every rank sends the records of its own pixels to every other rank and receives theirs (the guide exchange of a tile-sharded realtime frame; pt_neeat_exchange_host is
-// this with three 4-byte planes). toRoot = 1: every rank sends to rank 0 only (the plane-buffer gather). A record = the planes' bytes of one pixel back to back, in the rank's pixel
-// order (pt_shard_layout); transfers are un-padded; pairs meet in rank order, so blocking transports cannot deadlock.
+// The general form over HOST memory: numPlanes row-major width x height planes of bytesPerPixel[k] bytes per pixel each (depth: 4, motion vectors: 8, a header
+// plane: 4 ...). toRoot = 0: every rank sends the records of its own pixels to every other rank and receives theirs (the guide exchange of a tile-sharded
+// realtime frame; pt_neeat_exchange_host is this with three 4-byte planes). toRoot = 1: every rank sends to rank 0 only (the plane-buffer gather). A record =
+// the planes' bytes of one pixel back to back, in the rank's pixel order (pt_shard_layout); transfers are un-padded; pairs meet in rank order, so blocking
+// transports cannot deadlock.
 int32_t pt_exchange_planes_host(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, void* const* planes, const uint32_t* bytesPerPixel, uint32_t numPlanes, int32_t toRoot, const PtTransport* t) {
     if (!planes || !bytesPerPixel || !numPlanes || !t || !t->send || !t->recv || !width || !height || width > 65535 || height > 65535 || !world || rank >= world) return PT_ERROR_INVALID_ARGUMENT;
     size_t rec = 0; for (uint32_t k = 0; k < numPlanes; k++) { if (!planes[k] || !bytesPerPixel[k]) return PT_ERROR_INVALID_ARGUMENT; rec += bytesPerPixel[k]; }

@@ -16,7 +16,9 @@
 #include "pt_scene.h"
 
 #ifndef PT_SHADE_TRI
-#define PT_SHADE_TRI 1          // 1: loadSurface reads the flat 128-byte ShadeTri record of the hit primitive; 0: the five-hop gather through primInfo / sub-instance / geometry / index / vertex streams
+// 1: loadSurface reads the flat 128-byte ShadeTri record of the hit primitive; 0: the five-hop gather through primInfo / sub-instance / geometry / index /
+// vertex streams
+#define PT_SHADE_TRI 1
 #endif
 #ifndef PT_SHADE_NOINLINE
 #define PT_SHADE_NOINLINE
@@ -124,11 +126,11 @@ struct LightSample {
     bool Valid() const { return any_gt0(Li); }
 };
 struct SurfaceData { ShadingData shadingData; StandardBSDF bsdf; float interiorIoR; uint neeTriangleLightIndex; uint neeAnalyticLightIndex; };
-// what k_shade hands to the shadow queue (the deferred half of ProcessLightSample)
-// NEE-AT feedback (TemporalFeedbackRequired, NEEFullSamples 1): ProcessLightSample draws one more random number and writes the pixel's feedback reservoir only when the
-// light is VISIBLE (PathTracerNEE.hlsli:266-273), and the same generator then serves Russian roulette (PathTracer.hlsli:757-759). k_shade therefore works out both
-// continuations: the path is stored as "not visible"; fbLight / fbWeight / fbRandom are the reservoir update and rrFix what the visible case changes on the path
-// (bit 0: the roulette outcomes differ, bit 1: terminate-at-next-bounce in the visible case, bits 16-31: the fp16 roulette correction of the visible case).
+// what k_shade hands to the shadow queue (the deferred half of ProcessLightSample) NEE-AT feedback (TemporalFeedbackRequired, NEEFullSamples 1):
+// ProcessLightSample draws one more random number and writes the pixel's feedback reservoir only when the light is VISIBLE (PathTracerNEE.hlsli:266-273), and
+// the same generator then serves Russian roulette (PathTracer.hlsli:757-759). k_shade therefore works out both continuations: the path is stored as "not
+// visible"; fbLight / fbWeight / fbRandom are the reservoir update and rrFix what the visible case changes on the path (bit 0: the roulette outcomes differ,
+// bit 1: terminate-at-next-bounce in the visible case, bits 16-31: the fp16 roulette correction of the visible case).
 struct ShadowRequest { bool valid; float3 origin, dir; float tmax; float3 radiance; uint fbLight; float fbWeight, fbRandom; uint rrFix; };
 // NEEFullSamples != 1 (HandleNEE_MultipleSamples, PathTracerNEE.hlsli:277-301): every path vertex that applies NEE reserves a group of fullSamples
 // consecutive shadow-queue entries (sample s at base + s, samples without a light marked tmax < 0) and k_resolve_nee folds the visible ones in sample order.
@@ -147,7 +149,8 @@ template <class LP> static inline float ComputeNewScatterFireflyFilterK(float cu
     p *= FastSqrt(lobeP);
     return LP::r(fmaxf_(minK, currentK * p));               // returns lpfloat: the NEE path uses the value before it is ever packed
 }
-template <class LP> static inline float3 FireflyFilter(float3 signalIn, float threshold, float fireflyFilterK) {      // lpfloat3 (lpfloat3, lpfloat, lpfloat): all three are lp values
+// lpfloat3 (lpfloat3, lpfloat, lpfloat): all three are lp values
+template <class LP> static inline float3 FireflyFilter(float3 signalIn, float threshold, float fireflyFilterK) {
     float t = LP::mul(threshold, fireflyFilterK);
     float maxR = LP::average3(signalIn);
     if (maxR > t) signalIn = LP::mul3(LP::div3(signalIn, maxR), t);
@@ -161,11 +164,11 @@ static inline float FireflyFilterShort(float signalAverage, float threshold, flo
 static inline float ComputeLowGrazingAngleFalloff(float3 lightDirection, float3 n, float falloffFrom, float falloffRange) {
     return saturate((dot(lightDirection, n) - falloffFrom) / falloffRange);
 }
-// TexLODHelpers.hlsli:129-143
-// Donut's ConvertSpecularGlossToMetalRough (donut/shaders/scene_material.hlsli, un-vendored), called by EvaluateSceneMaterialRTXPT for
-// PTMaterialFlags_UseSpecularGlossModel materials (PathTracerBridgeDonut.hlsli:318-333; ENABLE_METAL_ROUGH_RECONSTRUCTION 1, :15, :772-774): restated from the
-// algorithm it follows, the Khronos KHR_materials_pbrSpecularGlossiness "convert-between-workflows" sample (solveMetallic + the two base-colour estimates blended
-// by metallic^2, perceived brightness = sqrt(0.299 r^2 + 0.587 g^2 + 0.114 b^2), dielectric specular 0.04). UNPINNED: the function's own text is outside the tree.
+// TexLODHelpers.hlsli:129-143 Donut's ConvertSpecularGlossToMetalRough (donut/shaders/scene_material.hlsli, un-vendored), called by EvaluateSceneMaterialRTXPT
+// for PTMaterialFlags_UseSpecularGlossModel materials (PathTracerBridgeDonut.hlsli:318-333; ENABLE_METAL_ROUGH_RECONSTRUCTION 1, :15, :772-774): restated from
+// the algorithm it follows, the Khronos KHR_materials_pbrSpecularGlossiness "convert-between-workflows" sample (solveMetallic + the two base-colour estimates
+// blended by metallic^2, perceived brightness = sqrt(0.299 r^2 + 0.587 g^2 + 0.114 b^2), dielectric specular 0.04). UNPINNED: the function's own text is
+// outside the tree.
 static inline float GetPerceivedBrightness(float3 c) { return sqrtf_((0.299f * c.x * c.x + 0.587f * c.y * c.y) + 0.114f * c.z * c.z); }
 static inline void ConvertSpecularGlossToMetalRough(float3 diffuseColor, float3 specularColor, float3& baseColor, float& metalness) {
     const float epsilon = 1e-6f, dielectricSpecular = 0.04f;
@@ -191,8 +194,9 @@ static inline float computeRayConeTriangleLODValue(const float3 v[3], const floa
     return 0.5f * RayCone::SafeLog2(Ta / Pa);
 }
 
-// TriangleCurvatureApprox_GradN (PathTracerBridgeDonut.hlsli:92-149): a curvature proxy of one triangle in ~1/length units — the RMS gradient of a linear normal field fitted
-// over the triangle in a 2D basis of its (world-space) plane. Feeds the automatic motion-vector block types of Bridge::loadSurface (:704-716).
+// TriangleCurvatureApprox_GradN (PathTracerBridgeDonut.hlsli:92-149): a curvature proxy of one triangle in ~1/length units — the RMS gradient of a linear
+// normal field fitted over the triangle in a 2D basis of its (world-space) plane. Feeds the automatic motion-vector block types of Bridge::loadSurface
+// (:704-716).
 static inline float TriangleCurvatureApprox_GradN(const float3 vertexPositions[3], const float3 vertexNormals[3], const float3x4& transform) {
     const float eps = 1e-8f;
     float3 e10 = xform_vector(transform, vertexPositions[1] - vertexPositions[0]);      // mul((float3x3)transform, p1 - p0)
@@ -213,8 +217,9 @@ static inline float TriangleCurvatureApprox_GradN(const float3 vertexPositions[3
     float3 b = (dn2 - a * u2) / denomV;
     return sqrtf_(dot(a, a) + dot(b, b));
 }
-// what Bridge::loadSurface hands to its motion-vector block decision (BridgeDonut:704-716): donutGS.curvatureWS (0 for a mesh without vertex normals: the sample is zero-initialised, :164)
-// and abs(dot(rayDir, -N)) with the shading normal BEFORE adjustShadingNormal. Asked for by the stable-plane passes only (null otherwise: nothing is computed).
+// what Bridge::loadSurface hands to its motion-vector block decision (BridgeDonut:704-716): donutGS.curvatureWS (0 for a mesh without vertex normals: the
+// sample is zero-initialised, :164) and abs(dot(rayDir, -N)) with the shading normal BEFORE adjustShadingNormal. Asked for by the stable-plane passes only
+// (null otherwise: nothing is computed).
 struct MVBlockInputs { float curvatureWS, projectionTerm; };
 
 // LP16: which build of the reference's lp types this instance restates (PtSettings::useFp16Types selects it at launch; the data members are the same)
@@ -246,7 +251,8 @@ template <bool LP16> struct PathKernelContextT {
         float tMin = cam.NearZ * invCos;
         o = org + dir * tMin; d = dir;
     }
-    // the reference-mode guide-buffer dump (PathTracer.hlsli:487, 684 -> Bridge::ExportNonSurface / ExportSurface): only the depth is kept, for NEE-AT's disocclusion test
+    // the reference-mode guide-buffer dump (PathTracer.hlsli:487, 684 -> Bridge::ExportNonSurface / ExportSurface): only the depth is kept, for NEE-AT's
+    // disocclusion test
     void ExportDepth(const PathState& path, float3 virtualWorldPos) const {
         sc.lights.DepthExport[(path.id & 0xFFFFu) * sc.lights.DepthWidth + (path.id >> 16)] = LightTable_ClipDepth(sc.lights, virtualWorldPos);
     }
@@ -279,7 +285,8 @@ template <bool LP16> struct PathKernelContextT {
         return p;
     }
 
-    PT_SHADE_NOINLINE float4 sampleTexture(uint textureIndexAndInfo, float lambdaNoDims, float2 uv) const {       // BridgeDonut:270-278, TextureSampler.hlsli:126-134
+    // BridgeDonut:270-278, TextureSampler.hlsli:126-134
+    PT_SHADE_NOINLINE float4 sampleTexture(uint textureIndexAndInfo, float lambdaNoDims, float2 uv) const {
         uint textureIndex = textureIndexAndInfo & 0xFFFFu, baseLOD = textureIndexAndInfo >> 24, mipLevels = (textureIndexAndInfo >> 16) & 0xFFu;
         float lambda = 0.5f * (float)baseLOD + lambdaNoDims;
         lambda = fminf_(lambda, fmaxf_((float)mipLevels - 5.0f, 0.0f));
@@ -306,9 +313,9 @@ template <bool LP16> struct PathKernelContextT {
         }
         if (cosTheta <= kCosThetaThreshold || recompute) computeTangentSpace(sd, tangentW, ignoreTangent);
     }
-    // prevPosW of Bridge::loadSurface in the stable-plane build pass (BridgeDonut:187-199, 619, 631): the hit point in the previous frame's pose — the previous positions of the
-    // triangle's vertices (Donut keeps them for skinned meshes; for the others they equal the current ones, which is what interpolating a copy gives) under the previous transform.
-    // Only the base vertices of the planes ask for it: the reference's own five-hop gather is good enough here.
+    // prevPosW of Bridge::loadSurface in the stable-plane build pass (BridgeDonut:187-199, 619, 631): the hit point in the previous frame's pose — the previous
+    // positions of the triangle's vertices (Donut keeps them for skinned meshes; for the others they equal the current ones, which is what interpolating a copy
+    // gives) under the previous transform. Only the base vertices of the planes ask for it: the reference's own five-hop gather is good enough here.
     float3 prevPosW(uint prim, float bu, float bv) const {
         const uint2 pinfo = sc.primInfo[prim];
         const uint2 ig = sc.subInstToInstGeom[pinfo.x];
@@ -323,17 +330,19 @@ template <bool LP16> struct PathKernelContextT {
         const float3 objPos = (vp[0] * bary.x + vp[1] * bary.y) + vp[2] * bary.z;
         return xform_point(M, objPos);
     }
-    // Bridge::loadSurface (BridgeDonut:612-853): the divergent gather of the pipeline.
-    // LEAN (round 6): the vertex of a path that terminates right after its emission term (PF_terminateAtNextBounce: a fifth of a bounce's hits, shaded as a class of their own, k_classify)
-    // reads of the surface only what HandleHit touches before it returns — position, flat normal and facing, material header, emission (with its texture), the two light links, the
-    // interior IoR — so the vertex normals and tangents, the base / normal / metal-rough / transmission fetches, the normal map, the tangent frame and the BSDF inputs are not formed
-    // at all. What IS formed is formed by the same expressions: the values HandleHit reads are the same floats.
+    // Bridge::loadSurface (BridgeDonut:612-853): the divergent gather of the pipeline. LEAN (round 6): the vertex of a path that terminates right after its
+    // emission term (PF_terminateAtNextBounce: a fifth of a bounce's hits, shaded as a class of their own, k_classify) reads of the surface only what HandleHit
+    // touches before it returns — position, flat normal and facing, material header, emission (with its texture), the two light links, the interior IoR — so
+    // the vertex normals and tangents, the base / normal / metal-rough / transmission fetches, the normal map, the tangent frame and the BSDF inputs are not
+    // formed at all. What IS formed is formed by the same expressions: the values HandleHit reads are the same floats.
     template <bool LEAN = false>
     SurfaceData loadSurface(uint prim, float bu, float bv, float3 rayDir, RayCone rayCone, MVBlockInputs* mvBlock = nullptr) const {
 #if PT_SHADE_TRI
-        // one 128-byte line per primitive (pt_scene.h ShadeTri) instead of primInfo -> subInstToInstGeom -> {instance, subInstance, geometry} -> indices -> vertex streams
+        // one 128-byte line per primitive (pt_scene.h ShadeTri) instead of primInfo -> subInstToInstGeom -> {instance, subInstance, geometry} -> indices ->
+        // vertex streams
         const uint4* rec = reinterpret_cast<const uint4*>(sc.shadeTris + prim);
-        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7];      // eight independent 16-byte loads of one line
+        // eight independent 16-byte loads of one line
+        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7];
         const uint subInst = r0.y, triangleIndex = r0.z, materialIndex = r0.w & 0xFFFFu;
         struct { uint flags; } g; g.flags = r0.w >> 16;
         const float3x4& M = sc.instances[r0.x].transform;
@@ -441,7 +450,8 @@ template <bool LP16> struct PathKernelContextT {
         float3 baseColor = LP::r3(material.BaseOrDiffuseColor * xyz(texBase));
         float roughness = LP::r(material.Roughness * texMR.y);
         float metalness = LP::r((mflags & PTMaterialFlags_MetalnessInRedChannel) ? material.Metalness * texMR.x : material.Metalness * texMR.z);
-        if (mflags & PTMaterialFlags_UseSpecularGlossModel) {                                  // EvaluateSceneMaterialRTXPT, BridgeDonut:318-333: float colours in, lp base colour / metalness out
+        // EvaluateSceneMaterialRTXPT, BridgeDonut:318-333: float colours in, lp base colour / metalness out
+        if (mflags & PTMaterialFlags_UseSpecularGlossModel) {
             float3 bc; float mt;
             ConvertSpecularGlossToMetalRough(material.BaseOrDiffuseColor * xyz(texBase), material.SpecularColor * xyz(texMR), bc, mt);
             baseColor = LP::r3(bc); metalness = LP::r(mt);
@@ -471,10 +481,12 @@ template <bool LP16> struct PathKernelContextT {
         if (mvBlock) mvBlock->projectionTerm = fabsf(dot(rayDir, -sd.N));
         adjustShadingNormal(sd, tangent, true, ignoreTangent);
         sd.shadowNoLFadeout = LP::r(material.ShadowNoLFadeout);
-        float bsdfSpecTrans = LP::mul(transmission, LP::sub(1, metalness)), bsdfDiffTrans = LP::mul(diffuseTransmission, LP::sub(1, metalness));      // lp * (1 - lp)
+        // lp * (1 - lp)
+        float bsdfSpecTrans = LP::mul(transmission, LP::sub(1, metalness)), bsdfDiffTrans = LP::mul(diffuseTransmission, LP::sub(1, metalness));
         float f = (matIoR - 1.f) / (matIoR + 1.f);
         float F0 = f * f;
-        bd.diffuse = LP::lerp3(baseColor, make_float3(0.f), metalness);          // StandardBSDFData holds lp values (BxDF.hlsli:625-634); FalcorBSDF computes from them in float
+        // StandardBSDFData holds lp values (BxDF.hlsli:625-634); FalcorBSDF computes from them in float
+        bd.diffuse = LP::lerp3(baseColor, make_float3(0.f), metalness);
         bd.specular = LP::lerp3(make_float3(LP::r(F0)), baseColor, metalness);
         bd.roughness = roughness; bd.metallic = metalness;
         bd.transmission = baseColor; bd.diffuseTransmission = bsdfDiffTrans; bd.specularTransmission = bsdfSpecTrans;
@@ -483,10 +495,12 @@ template <bool LP16> struct PathKernelContextT {
         }
         SurfaceData ret;
         ret.neeTriangleLightIndex = RTXPT_INVALID_LIGHT_INDEX; ret.neeAnalyticLightIndex = RTXPT_INVALID_LIGHT_INDEX;
-        if (mflags & PTMaterialFlags_EnableAsAnalyticLightProxy) ret.neeAnalyticLightIndex = sc.subInstances[subInst].AnalyticProxyLightIndex;      // BridgeDonut:828-829
+        // BridgeDonut:828-829
+        if (mflags & PTMaterialFlags_EnableAsAnalyticLightProxy) ret.neeAnalyticLightIndex = sc.subInstances[subInst].AnalyticProxyLightIndex;
         if (sd.frontFacing && any_gt0(emissiveColor)) {
             sd.emission = emissiveColor;
-            uint baseIndex = sc.subInstances[subInst].EmissiveLightMappingOffset;      // (the light links are re-baked with the lights: read from the sub-instance, by emissive hits only)
+            // (the light links are re-baked with the lights: read from the sub-instance, by emissive hits only)
+            uint baseIndex = sc.subInstances[subInst].EmissiveLightMappingOffset;
             if (baseIndex != 0xFFFFFFFFu) ret.neeTriangleLightIndex = baseIndex + triangleIndex;
         }
         ret.shadingData = sd; ret.bsdf.data = bd; ret.bsdf.diffuseModel = (int)S.diffuseBrdf; ret.interiorIoR = matIoR;
@@ -508,8 +522,8 @@ template <bool LP16> struct PathKernelContextT {
     }
     static void AccumulatePathRadiance(PathState& path, float3 radiance) { float4 L = path.GetL(); path.SetL(make_float4(L.x + radiance.x, L.y + radiance.y, L.z + radiance.z, L.w + 0.f)); }
 
-    // PathTracer.hlsli:407-503
-    // NEEAT == false (NEEType 0 / 1, the kernels every frame without a local table runs): "screen-space coherent" is a compile-time false, the local sampler folds away
+    // PathTracer.hlsli:407-503 NEEAT == false (NEEType 0 / 1, the kernels every frame without a local table runs): "screen-space coherent" is a compile-time
+    // false, the local sampler folds away
     template <bool NEEAT>
     __attribute__((always_inline)) void HandleMiss(PathState& path, float3 rayDir, float rayT) const {
         UpdatePathTravelled(path, rayT);
@@ -668,7 +682,8 @@ template <bool LP16> struct PathKernelContextT {
                     radiance = radiance * FireflyFilterShort(radianceAvg, S.fireflyFilterThreshold, k);
                 }
                 radiance = radiance * pre.GetThp();
-                if (NEEAT && !MULTI && lightSampler.IsTemporalFeedbackRequired()) {      // the reservoir update of the visible case (:246-273; radianceAvg is the value before the firefly filter)
+                // the reservoir update of the visible case (:246-273; radianceAvg is the value before the firefly filter)
+                if (NEEAT && !MULTI && lightSampler.IsTemporalFeedbackRequired()) {
                     req.fbLight = ls.LightIndex | (lightSampler.IsScreenSpaceCoherent ? LFR_SCREEN_SPACE_COHERENT_FLAG : 0u);
                     req.fbWeight = lightSampler.FeedbackWeightFromNEE(ls.LightIndex, radianceAvg * Average(pre.GetThp()));
                     UniformSampleSequenceGenerator after = sg; req.fbRandom = sampleNext1D(after);
@@ -697,23 +712,28 @@ template <bool LP16> struct PathKernelContextT {
         path.SetPackedMISInfo_ThpRuRuCorrection(path.GetPackedMISInfo(), 1.0f / (1.0f - prob));
         return false;
     }
-    // Where the path's state lives while HandleHit runs. PathInRegisters: the caller loaded all of it and stores it afterwards (the tail kernel, the probes). A kernel that streams paths
-    // through the pool (k_shade, pt_wavefront.hip) passes an IO that (i) loads the words the surface does not need only after loadSurface, (ii) stores the scattered path's first four
-    // word groups as soon as GenerateScatterRay has made them — before the light sampling, the vertex's register peak, which then carries 5 words of the path instead of 21 — and
-    // (iii) stores the last group ({firefly K | pdf, MIS info | roulette correction, flags | vertex index, sample index}) at the end. Same values either way: order of loads and stores only.
+    // Where the path's state lives while HandleHit runs. PathInRegisters: the caller loaded all of it and stores it afterwards (the tail kernel, the probes). A
+    // kernel that streams paths through the pool (k_shade, pt_wavefront.hip) passes an IO that (i) loads the words the surface does not need only after
+    // loadSurface, (ii) stores the scattered path's first four word groups as soon as GenerateScatterRay has made them — before the light sampling, the
+    // vertex's register peak, which then carries 5 words of the path instead of 21 — and
+    // (iii) stores the last group ({firefly K | pdf, MIS info | roulette correction, flags | vertex index, sample index}) at the end. Same values either way:
+    //       order of loads and stores only.
     struct PathInRegisters { static constexpr bool streams = false; void mark(int) const {} void load_rest(PathState&) const {} void store_front(const PathState&) const {} void store_back(const PathState&) const {} void store_all(const PathState&) const {} };
-    // PathTracer.hlsli:505-762 (reference mode), shadow test deferred through `req`
-    // (a split of this vertex at NEE — a light-sample kernel and a scatter kernel — was built and measured in round 4: 21.5 -> 27.5 ms, profiles/r04p_shade_split_ab.txt; history: af4c2b2)
+    // PathTracer.hlsli:505-762 (reference mode), shadow test deferred through `req` (a split of this vertex at NEE — a light-sample kernel and a scatter kernel
+    // — was built and measured in round 4: 21.5 -> 27.5 ms, profiles/r04p_shade_split_ab.txt; history: af4c2b2)
     template <bool MULTI, bool NEEAT, class IO = PathInRegisters>
     __attribute__((always_inline)) void HandleHit(PathState& path, const HitInfo& hit, ShadowRequest& req, const ShadowSink* sink, const IO& io = IO()) const {
         req.valid = false; io.mark(0);      // (mark: cycle stamps of the phases in PT_SHADE_PHASE_PROBE builds, nothing otherwise)
         const float3 rayDir = path.dir;
-        path.rayCone = path.rayCone.propagateDistance(hit.t); path.sceneLength = fminf_(path.sceneLength + hit.t, kMaxRayTravel);      // UpdatePathTravelled, the two updates the surface needs ...
-        // a vertex that ends right after its emission term needs a fraction of the surface (loadSurface<LEAN>); the flag is in the word group the IO loads first
+        // UpdatePathTravelled, the two updates the surface needs ...
+        path.rayCone = path.rayCone.propagateDistance(hit.t); path.sceneLength = fminf_(path.sceneLength + hit.t, kMaxRayTravel);
+        // a vertex that ends right after its emission term needs a fraction of the surface (loadSurface<LEAN>); the flag is in the word group the IO loads
+        // first
         SurfaceData sfd = path.isTerminatingAtNextBounce() ? loadSurface<true>(hit.prim, hit.u, hit.v, rayDir, path.rayCone) : loadSurface<false>(hit.prim, hit.u, hit.v, rayDir, path.rayCone);
         io.mark(1);
         io.load_rest(path);
-        path.incrementVertexIndex();                                                                                                    // ... and the third, once the flags word is there
+        // ... and the third, once the flags word is there
+        path.incrementVertexIndex();
         const float3 rayOrigin = path.origin;
         if (S.nestedDielectricsQuality > 0 && !path.interiorList.isEmpty()) {
             float3 tr = volumeTransmittance(path.interiorList.getTopMaterialID(), hit.t);
@@ -732,7 +752,8 @@ template <bool LP16> struct PathKernelContextT {
             }
             surfaceEmission = LP::r3(sd.emission * misWeight);
         }
-        if (sfd.neeAnalyticLightIndex != RTXPT_INVALID_LIGHT_INDEX) {                  // PathTracer.hlsli:636-648: the mesh stands in for an analytic (sphere) light
+        // PathTracer.hlsli:636-648: the mesh stands in for an analytic (sphere) light
+        if (sfd.neeAnalyticLightIndex != RTXPT_INVALID_LIGHT_INDEX) {
             LightSampler lightSampler = LightSampler::make(sc.lights, path.id >> 16, path.id & 0xFFFFu, NEEAT && misInfo.LightSamplingIsSSC);
             const float bsdfPdf = misInfo.LightSamplingEnabled ? LP::r(path.GetBsdfScatterPdf()) : 0.0f; float3 add;
             if (lightSampler.ComputeAnalyticLightProxyContribution(sfd.neeAnalyticLightIndex, bsdfPdf, rayOrigin, rayDir, misInfo.CandidateSamples, misInfo.FullSamples, add)) {
@@ -744,7 +765,8 @@ template <bool LP16> struct PathKernelContextT {
             if (baseFFThreshold != 0) surfaceEmission = FireflyFilter<LP>(surfaceEmission, baseFFThreshold, path.GetFireflyFilterK());
             if (any_gt0(surfaceEmission)) AccumulatePathRadiance(path, path.GetThp() * surfaceEmission);
         }
-        if (NEEAT && sc.lights.DepthExport) {                     // ExportSurface(path, surfaceData, path.GetSceneLength(), 0): the camera ray of this pixel and sample, at the path's length
+        // ExportSurface(path, surfaceData, path.GetSceneLength(), 0): the camera ray of this pixel and sample, at the path's length
+        if (NEEAT && sc.lights.DepthExport) {
             float3 co, cd; computeCameraRay(path.id >> 16, path.id & 0xFFFFu, path.sampleIndex, co, cd);
             ExportDepth(path, co + cd * path.sceneLength);
         }
@@ -763,7 +785,8 @@ template <bool LP16> struct PathKernelContextT {
         path.SetPackedMISInfo_ThpRuRuCorrection(misPacked, path.GetThpRuRuCorrection());
         if (!scatterValid) path.terminate();
         bool shouldTerminate = HasFinishedSurfaceBounces(path.getVertexIndex() + 1, path.getCounter(PC_DiffuseBounces));
-        if (NEEAT && req.fbLight != RTXPT_INVALID_LIGHT_INDEX) {       // feedback pending on the visibility test: the visible case has drawn one more number before the roulette
+        // feedback pending on the visibility test: the visible case has drawn one more number before the roulette
+        if (NEEAT && req.fbLight != RTXPT_INVALID_LIGHT_INDEX) {
             UniformSampleSequenceGenerator sgVisible = uniformSG; (void)sampleNext1D(sgVisible);
             PathState visiblePath = path;
             const bool terminateVisible = shouldTerminate | HandleRussianRoulette(visiblePath, sgVisible);
@@ -775,7 +798,8 @@ template <bool LP16> struct PathKernelContextT {
         io.mark(5);
     }
     // the deferred half: NEEResult::AccumulateRadiance (fp16, PathTracerTypes.hlsli:170-207) then AccumulatePathRadiance (PathTracer.hlsli:722-746)
-    static void NeeAccumulate(uint nee[2], float3 radiance) {                       // NEEResult::AccumulateRadiance (the spec-average lane is not used in reference mode)
+    // NEEResult::AccumulateRadiance (the spec-average lane is not used in reference mode)
+    static void NeeAccumulate(uint nee[2], float3 radiance) {
         float2 a = Fp16ToFp32(nee[0]), b = Fp16ToFp32(nee[1]);
         nee[0] = Fp32ToFp16(make_float2(a.x + radiance.x, a.y + radiance.y)); nee[1] = Fp32ToFp16(make_float2(b.x + radiance.z, b.y + 0.f));
     }

@@ -1,14 +1,14 @@
 // mi355pt — cooperative BVH8 traversal for wave64, two lanes per ray: a wave carries 32 rays, each owned by a PAIR of lanes; lane h of a pair tests
 // children 4h .. 4h + 3 of the current 128-byte node (48 contiguous bytes: three 16-byte loads) and triangle h of a leaf.
 //
-// Why pairs (round 3): with four lanes per ray (the kernel of rounds 1-3, in the history) the loop is VALU-issue bound at 8 waves per SIMD — extra v_nop slots lengthen k_extend one
-// for one (profiles/r03i_valu_bound_probe.txt) — and a wave64 VALU instruction costs its four cycles whatever the lanes do. Of the ~325 VALU instructions of an
-// average wave iteration only the slab tests (~50) and the triangle tests (~110 when the leaf block runs) are work that belongs to a child or a triangle;
-// the rest — refill, child ranking, stack, slot bookkeeping, the alpha test's addressing, the hit reduction — is per-RAY work that every lane of the ray's
-// group repeats. Two lanes per ray halve the replicated share per ray: per lane the slab and triangle work doubles (four children, two triangle rounds), per
-// wave iteration the instruction count rises by about a third, and the iteration advances 32 rays instead of 16.
-// The closest hit is traversal-order free (min t, ties to the lower primitive id); an occlusion query reports whether any accepted hit exists. Straggler splitting, Src / Dst / Pub
-// and the template flags: pt_traverse8.h.
+// Why pairs (round 3): with four lanes per ray (the kernel of rounds 1-3, in the history) the loop is VALU-issue bound at 8 waves per SIMD — extra v_nop slots
+// lengthen k_extend one for one (profiles/r03i_valu_bound_probe.txt) — and a wave64 VALU instruction costs its four cycles whatever the lanes do. Of the ~325
+// VALU instructions of an average wave iteration only the slab tests (~50) and the triangle tests (~110 when the leaf block runs) are work that belongs to a
+// child or a triangle; the rest — refill, child ranking, stack, slot bookkeeping, the alpha test's addressing, the hit reduction — is per-RAY work that every
+// lane of the ray's group repeats. Two lanes per ray halve the replicated share per ray: per lane the slab and triangle work doubles (four children, two
+// triangle rounds), per wave iteration the instruction count rises by about a third, and the iteration advances 32 rays instead of 16. The closest hit is
+// traversal-order free (min t, ties to the lower primitive id); an occlusion query reports whether any accepted hit exists. Straggler splitting, Src / Dst /
+// Pub and the template flags: pt_traverse8.h.
 #pragma once
 #include "pt_traverse8.h"
 
@@ -19,24 +19,28 @@ namespace ptk {
 __device__ __forceinline__ uint pair_bits(unsigned long long m, uint pl) { return (uint)(m >> pl) & 0x3u; }
 
 #ifndef T8_EMPTY_SLOT_CHECK
-#define T8_EMPTY_SLOT_CHECK 0    // 0: an empty child slot needs no test of its own — the builder writes it as an inverted box (lo = 255, hi = 0 on every axis: pt_build.hip k_collapse8),
-#endif                           //    which no ray's slab interval enters; were it ever "hit" (a node of zero extent), its reference is BVH_EMPTY, which the slot bookkeeping skips
+// 0: an empty child slot needs no test of its own — the builder writes it as an inverted box (lo = 255, hi = 0 on every axis: pt_build.hip k_collapse8),
+#define T8_EMPTY_SLOT_CHECK 0
+// which no ray's slab interval enters; were it ever "hit" (a node of zero extent), its reference is BVH_EMPTY, which the slot bookkeeping skips
+#endif
 #if T8_EMPTY_SLOT_CHECK
 #define T8_HIT(ref, tn, tf) (((ref) != BVH_EMPTY) && ((tn) <= (tf) * 1.0000012f))
 #else
 #define T8_HIT(ref, tn, tf) ((tn) <= (tf) * 1.0000012f)
 #endif
-// Measured and removed (history: commit af4c2b2 has the code; numbers in DESIGN.md §4): a dense leaf block (profiles/r04y_dense_leaf_ab.txt, +13 %), batched refills
-// (r04y_refill_batch_ab.txt), one pop trip per iteration (r04v_pop_once_ab.txt), two entries per pop trip, octant-ordered child slots (r04u_octant_order_ab.txt, +25 %);
-// round 5: a ray with nothing left but postponed leaves waiting one or three iterations (or for a second / fourth such ray) before it forces the leaf block — the block then runs in
-// 0.50 instead of 0.65 of the iterations and the rays take 0.63 instead of 0.58 iterations: k_extend unchanged (profiles/r05s_leaf_patience_ab.txt).
-// DEFER (with CAN_SPLIT): a dry wave keeps going for taskOut.capacity iterations (instead of T8_TAIL_ITERS), and the rays then still in flight are not cut into sub-trees,
-// only reported through publish() — the caller has them traced again elsewhere (the tail kernel, pt_tail.hip, hands their paths back to the host loop). No task queue is touched.
+// Measured and removed (history: commit af4c2b2 has the code; numbers in DESIGN.md §4): a dense leaf block (profiles/r04y_dense_leaf_ab.txt, +13 %), batched
+// refills (r04y_refill_batch_ab.txt), one pop trip per iteration (r04v_pop_once_ab.txt), two entries per pop trip, octant-ordered child slots
+// (r04u_octant_order_ab.txt, +25 %); round 5: a ray with nothing left but postponed leaves waiting one or three iterations (or for a second / fourth such ray)
+// before it forces the leaf block — the block then runs in 0.50 instead of 0.65 of the iterations and the rays take 0.63 instead of 0.58 iterations: k_extend
+// unchanged (profiles/r05s_leaf_patience_ab.txt). DEFER (with CAN_SPLIT): a dry wave keeps going for taskOut.capacity iterations (instead of T8_TAIL_ITERS),
+// and the rays then still in flight are not cut into sub-trees, only reported through publish() — the caller has them traced again elsewhere (the tail kernel,
+// pt_tail.hip, hands their paths back to the host loop). No task queue is touched.
 template <bool ANYHIT, bool COUNT, bool FIXED_RANGE, bool TASKS, bool CAN_SPLIT, bool DEFER = false, class Src, class Dst, class Pub>
 __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint count, uint raysPerChunk, uint2* stackBase, uint* rayBufBase, float2* mineUV, Src fetch, Dst commit, Pub publish, TravTaskOut taskOut,
                                                 Traverse8Counters& ctr, uint* overflowFlag, const uint vBlock, const uint vGrid) {
-    // vBlock / vGrid: the block's index among, and the number of, the blocks that work on THIS launch's items — blockIdx.x / gridDim.x for a kernel of one kind; a fused launch
-    // (k_trace_pair: closest-hit blocks next to visibility blocks, pt_wavefront.hip) hands each kind its own range. The stack tails are addressed by the physical block index.
+    // vBlock / vGrid: the block's index among, and the number of, the blocks that work on THIS launch's items — blockIdx.x / gridDim.x for a kernel of one
+    // kind; a fused launch (k_trace_pair: closest-hit blocks next to visibility blocks, pt_wavefront.hip) hands each kind its own range. The stack tails are
+    // addressed by the physical block index.
     static_assert(T8_LANES == 2u, "traverse8_pairs is the two-lanes-per-ray build");
     const uint RAY_STRIDE = TASKS ? T8_TASK_STRIDE : T8_RAY_STRIDE;
     const uint lane = threadIdx.x & 63u, h = lane & 1u, pl = lane & ~1u;
@@ -60,7 +64,8 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
     }
     bool active = false;
     float3 o = make_float3(0.f);
-    float Sx = 0.f, Sy = 0.f; uint axes = 0u;      // the ray's shear (d[kx] / d[kz], d[ky] / d[kz]) and the byte offsets of the record groups of its axes kx | ky << 8 | kz << 16 (leaf block)
+    // the ray's shear (d[kx] / d[kz], d[ky] / d[kz]) and the byte offsets of the record groups of its axes kx | ky << 8 | kz << 16 (leaf block)
+    float Sx = 0.f, Sy = 0.f; uint axes = 0u;
     float ix = 0.f, iy = 0.f, iz = 0.f;
     uint selN = 0u, selF = 0u;
     float tmin = 0.f, tmax = FIXED_RANGE ? kMaxRayTravel : 0.f;
@@ -74,11 +79,12 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
     uint lastInst_ = 0xFFFFFFFFu;
 #endif
 
-    // sb: the pair's stack base. The caller forms it anew for every node that pushes (stack_base(): two instructions) instead of keeping it across the loop: the loop is one
-    // register short since the watertight leaf block, and the allocator's choice was to spill exactly this value — a scratch load and a full vmcnt(0) wait at every push.
+    // sb: the pair's stack base. The caller forms it anew for every node that pushes (stack_base(): two instructions) instead of keeping it across the loop:
+    // the loop is one register short since the watertight leaf block, and the allocator's choice was to spill exactly this value — a scratch load and a full
+    // vmcnt(0) wait at every push.
     auto stack_base = [&]() -> uint2* { uint g_ = threadIdx.x >> 1; asm volatile("" : "+v"(g_)); return stackBase + g_ * BVH8_STACK_STRIDE; };
-    // the pair's stack tail in global memory (entries BVH8_STACK and up: rare). Formed where it is used, for the same reason: hoisted out of the loop, the address is the value the
-    // allocator spills.
+    // the pair's stack tail in global memory (entries BVH8_STACK and up: rare). Formed where it is used, for the same reason: hoisted out of the loop, the
+    // address is the value the allocator spills.
     auto spill_slot = [&](uint idx) -> uint2* { uint g_ = threadIdx.x >> 1; asm volatile("" : "+v"(g_)); return sc.travSpill + ((size_t)(blockIdx.x * T8_GROUPS_PER_BLOCK + g_) * T8_SPILL_DEPTH + (idx - BVH8_STACK)); };
     auto stackStore = [&](uint2* sb, uint idx, uint ref, uint tbits) {
         if (idx < BVH8_STACK) sb[idx] = make_uint2(ref, tbits);
@@ -107,8 +113,9 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     uint rtag = fetch(chunkPos + lane, ro, rd, rtmin, rtmax, rstart, rbestT, rbestPrim);
                     uint* slot = rayBuf + lane * RAY_STRIDE;
                     slot[0] = __float_as_uint(ro.x); slot[1] = __float_as_uint(ro.y); slot[2] = __float_as_uint(ro.z);
-                    // what the leaf block needs of the direction (intersect_tri_wt, pt_scene.h), formed once by the fetching lane: kz = the axis of the largest |d| (ties to the lower
-                    // axis), kx / ky the next two in cyclic order; Sz = the reciprocal of d[kz], Sx = d[kx] * Sz, Sy = d[ky] * Sz. The direction itself is not kept.
+                    // what the leaf block needs of the direction (intersect_tri_wt, pt_scene.h), formed once by the fetching lane: kz = the axis of the largest
+                    // |d| (ties to the lower axis), kx / ky the next two in cyclic order; Sz = the reciprocal of d[kz], Sx = d[kx] * Sz, Sy = d[ky] * Sz. The
+                    // direction itself is not kept.
                     const float rix = t8_rcp_dir(rd.x), riy = t8_rcp_dir(rd.y), riz = t8_rcp_dir(rd.z);
                     const float adx = fabsf(rd.x), ady = fabsf(rd.y), adz = fabsf(rd.z);
                     const bool rk2 = adz > adx && adz > ady, rk1 = !rk2 && ady > adx;
@@ -116,7 +123,8 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                     slot[3] = __float_as_uint((rk2 ? rd.x : (rk1 ? rd.z : rd.y)) * rSz); slot[4] = __float_as_uint((rk2 ? rd.y : (rk1 ? rd.x : rd.z)) * rSz);
                     slot[5] = rk2 ? (0u | (16u << 8) | (32u << 16)) : (rk1 ? (32u | (0u << 8) | (16u << 16)) : (16u | (32u << 8) | (0u << 16)));
                     slot[6] = rtag;
-                    if (FIXED_RANGE && !TASKS) {      // the interval's two words are free (every ray of the launch has [0, kMaxRayTravel]): they carry the byte selectors of the slab test
+                    // the interval's two words are free (every ray of the launch has [0, kMaxRayTravel]): they carry the byte selectors of the slab test
+                    if (FIXED_RANGE && !TASKS) {
                         const uint nxb = rix < 0.f ? 3u : 0u, fxb = rix < 0.f ? 0u : 3u, nyb = riy < 0.f ? 4u : 1u, fyb = riy < 0.f ? 1u : 4u, nzb = riz < 0.f ? 5u : 2u, fzb = riz < 0.f ? 2u : 5u;
                         slot[7] = nxb | (nyb << 8) | (nzb << 16) | (fxb << 24); slot[8] = fyb | (fzb << 8);
                     } else { slot[7] = __float_as_uint(TASKS ? rtmax : rtmin); slot[8] = TASKS ? __float_as_uint(rbestT) : __float_as_uint(rtmax); }
@@ -125,9 +133,10 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 }
             }
             uint avail = chunkEnd - chunkPos;
-            // Two statements, not if / else: with "queue empty -> flags, else -> take a ray" every loop-carried value of the ray is a three-way phi at the join, which the compiler
-            // lowers as a copy of the loop's registers out to temporaries and back on every pass through this block (38 v_mov). An empty queue simply makes the take condition
-            // below false (rank < 0) and the cursor advance zero (profiles/r05t_refill_flat_ab.txt: k_extend 46.2 -> 45.1 ms).
+            // Two statements, not if / else: with "queue empty -> flags, else -> take a ray" every loop-carried value of the ray is a three-way phi at the
+            // join, which the compiler lowers as a copy of the loop's registers out to temporaries and back on every pass through this block (38 v_mov). An
+            // empty queue simply makes the take condition below false (rank < 0) and the cursor advance zero (profiles/r05t_refill_flat_ab.txt: k_extend 46.2
+            // -> 45.1 ms).
             if (avail == 0u) { if (need) exhausted = true; waveDry = 1u; }
             {
                 uint rank = (uint)__popcll(needMask & ((1ull << pl) - 1ull));
@@ -170,8 +179,12 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
 #pragma unroll
         for (int k_ = 0; k_ < T8_PROBE_VNOPS; k_++) asm volatile("v_nop");
 #endif
-#ifdef T8_PROBE_FILL      // issue-slot probes (developer builds; tools/valu_ceiling): T8_PROBE_FILL_N independent filler instructions per wave iteration — 1: of the class that issues every
-        {                 // 2 cycles per SIMD (v_add_u32), 2: of the class that issues every 4 (v_max_f32), 3: v_cndmask_b32_e64. Outputs are dead; no register lives across the loop.
+// issue-slot probes (developer builds; tools/valu_ceiling): T8_PROBE_FILL_N independent filler instructions per wave iteration — 1: of the class that issues
+// every
+#ifdef T8_PROBE_FILL
+        // 2 cycles per SIMD (v_add_u32), 2: of the class that issues every 4 (v_max_f32), 3: v_cndmask_b32_e64. Outputs are dead; no register lives across the
+        // loop.
+        {
             uint f0_, f1_;
 #pragma unroll
             for (int k_ = 0; k_ < T8_PROBE_FILL_N / 2; k_++) {
@@ -188,11 +201,14 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         const bool leafReady = active && (pend != BVH_EMPTY);
         const bool queueFull = (T8_LEAF_QUEUE == 1) ? true : ((T8_LEAF_QUEUE == 2) ? (pend1 != BVH_EMPTY) : (pend2 != BVH_EMPTY));
         const bool leafBlocked = leafReady && (cur & BVH_LEAF_BIT) && (cur == BVH_EMPTY || queueFull);
-        const bool runLeaves = t8_ballot(leafBlocked) != 0ull;      // (a second trigger — "n pairs hold a postponed leaf" — never paid: profiles/r05o_leaf_batch_ab.txt, r05t_refill_flat_ab.txt)
+        // (a second trigger — "n pairs hold a postponed leaf" — never paid: profiles/r05o_leaf_batch_ab.txt, r05t_refill_flat_ab.txt)
+        const bool runLeaves = t8_ballot(leafBlocked) != 0ull;
         const bool leaf = leafReady && runLeaves;
         if (COUNT && leaf && h == 0u) ctr.leafVisits++;
-#ifdef T8_PROBE_INSTANCE_SWITCHES      // developer probe (counter builds): how often would a two-level traversal have to enter an instance? Counted per ray as the visited leaves whose
-        if (COUNT && leaf && h == 0u) {      // instance differs from the previous visited leaf's (event slot 4 — the alpha-test count — carries it in such a build)
+// developer probe (counter builds): how often would a two-level traversal have to enter an instance? Counted per ray as the visited leaves whose
+#ifdef T8_PROBE_INSTANCE_SWITCHES
+        // instance differs from the previous visited leaf's (event slot 4 — the alpha-test count — carries it in such a build)
+        if (COUNT && leaf && h == 0u) {
             const uint prim_ = *reinterpret_cast<const uint*>(trisBase + (((pend & 0x7FFFFFFFu) >> 3) * 48u + 12u));
             const uint inst_ = *reinterpret_cast<const uint*>(reinterpret_cast<const char*>(sc.shadeTris) + (size_t)prim_ * 128u);
             if (inst_ != lastInst_) ctr.ev[4]++;
@@ -222,8 +238,8 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, bestT));
             };
             uint ref[4] = {c0.x, c0.w, c1.z, c2.y};
-            // integer sort keys: tn >= 0 so its bits order like the value; the low 3 mantissa bits carry the child index (unique keys, ties to the lower child);
-            // a child that is not hit gets +inf. The stack entry's distance is the key without its index bits.
+            // integer sort keys: tn >= 0 so its bits order like the value; the low 3 mantissa bits carry the child index (unique keys, ties to the lower
+            // child); a child that is not hit gets +inf. The stack entry's distance is the key without its index bits.
             uint key[4]; bool hit[4];
             {   float tn, tf;
                 slab(c0.y, c0.z, tn, tf); hit[0] = T8_HIT(ref[0], tn, tf); key[0] = (hit[0] ? (__float_as_uint(tn) & ~7u) : INF_BITS) | (4u * h);
@@ -274,8 +290,9 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
         }
 
         if (COUNT) { tc2 = __builtin_readcyclecounter(); if (t8_ballot(leaf) != 0ull && lane == 0u) ctr.leafBlocks++; }
-        // ---- postponed leaf: lane h tests triangle h (h + 2, ... when leaves hold more than two). The watertight test of pt_scene.h (intersect_tri_wt) on the same operands: the
-        // axis permutation (kx, ky, kz) is the ORDER in which the record's three 16-byte groups are loaded; the ray's own quantities are selected once per leaf block.
+        // ---- postponed leaf: lane h tests triangle h (h + 2, ... when leaves hold more than two). The watertight test of pt_scene.h (intersect_tri_wt) on the
+        // same operands: the axis permutation (kx, ky, kz) is the ORDER in which the record's three 16-byte groups are loaded; the ray's own quantities are
+        // selected once per leaf block.
         if (leaf) {
             const uint cnt = (pend & 7u) + 1u;
             const uint slot0 = (pend & 0x7FFFFFFFu) >> 3;
@@ -292,35 +309,38 @@ __device__ __forceinline__ void traverse8_pairs(const DeviceScene& sc, uint coun
                 if (r > 0u && t8_ballot(doit) == 0ull) break;
                 if (doit) {
                     const uint toff = triOff0 + (T8_LANES * 48u) * r;      // (32-bit byte offsets from the SGPR base: global_load ... saddr)
-                    // twelve bytes per group (global_load_dwordx3): the fourth word is not needed here, and a 16-byte destination whose last register the allocator then reuses for the next
-                    // load's address makes that load wait for this one — two memory latencies in a row instead of one (seen in the ISA, measured: +10 % on k_extend)
+                    // twelve bytes per group (global_load_dwordx3): the fourth word is not needed here, and a 16-byte destination whose last register the
+                    // allocator then reuses for the next load's address makes that load wait for this one — two memory latencies in a row instead of one (seen
+                    // in the ISA, measured: +10 % on k_extend)
                     struct __attribute__((packed, aligned(4))) f32x3p { float x, y, z; };
                     const f32x3p g0 = *reinterpret_cast<const f32x3p*>(trisBase + (toff + gx)), g1 = *reinterpret_cast<const f32x3p*>(trisBase + (toff + gy)), g2 = *reinterpret_cast<const f32x3p*>(trisBase + (toff + gz));
                     if (COUNT) ctr.triTests++;
-                    // intersect_tri_wt's arithmetic, two values per instruction where the operands already sit in neighbouring registers (vertices 0 and 1 of a loaded group):
-                    // packed fp32 operations round each half like the scalar ones
+                    // intersect_tri_wt's arithmetic, two values per instruction where the operands already sit in neighbouring registers (vertices 0 and 1 of a
+                    // loaded group): packed fp32 operations round each half like the scalar ones
                     const f32x2 ABkz = (f32x2){g2.x, g2.y} - (f32x2){okz, okz}; const float Ckz = g2.z - okz;
                     const f32x2 ABx = __builtin_elementwise_fma((f32x2){-Sx, -Sx}, ABkz, (f32x2){g0.x, g0.y} - (f32x2){okx, okx}), ABy = __builtin_elementwise_fma((f32x2){-Sy, -Sy}, ABkz, (f32x2){g1.x, g1.y} - (f32x2){oky, oky});
                     const float Cx = fmaf(-Sx, Ckz, g0.z - okx), Cy = fmaf(-Sy, Ckz, g1.z - oky);
                     const float Ax = ABx.x, Bx = ABx.y, Ay = ABy.x, By = ABy.y, Akz = ABkz.x, Bkz = ABkz.y;
                     const f32x2 m1 = ABx * (f32x2){Cy, Cy}, m2 = ABy * (f32x2){Cx, Cx};      // (Ax Cy, Bx Cy), (Ay Cx, By Cx)
                     float V = m1.x - m2.x, U = m2.y - m1.y, W = Bx * Ay - By * Ax;            // U = Cx By - Cy Bx, V = Ax Cy - Ay Cx, W = Bx Ay - By Ax
-                    if (U == 0.0f || V == 0.0f || W == 0.0f) {      // on an edge or a vertex (or a degenerate triangle): the exact sign from the products' rounding errors (wt_edge)
+                    // on an edge or a vertex (or a degenerate triangle): the exact sign from the products' rounding errors (wt_edge)
+                    if (U == 0.0f || V == 0.0f || W == 0.0f) {
                         if (U == 0.0f) U = fmaf(Cx, By, -(Cx * By)) - fmaf(Cy, Bx, -(Cy * Bx));
                         if (V == 0.0f) V = fmaf(Ax, Cy, -(Ax * Cy)) - fmaf(Ay, Cx, -(Ay * Cx));
                         if (W == 0.0f) W = fmaf(Bx, Ay, -(Bx * Ay)) - fmaf(By, Ax, -(By * Ax));
                     }
                     const float det = (U + V) + W;
-                    // no edge function negative, or none positive (pt_scene.h writes it as !((U < 0 || V < 0 || W < 0) && (U > 0 || V > 0 || W > 0)): the same boolean for numbers; a NaN
-                    // ends as "no hit" either way, through t); without short-circuits: v_min3, v_max3 and three compares, no branch
+                    // no edge function negative, or none positive (pt_scene.h writes it as !((U < 0 || V < 0 || W < 0) && (U > 0 || V > 0 || W > 0)): the same
+                    // boolean for numbers; a NaN ends as "no hit" either way, through t); without short-circuits: v_min3, v_max3 and three compares, no branch
                     const bool inside = (bool)(((int)(fminf(U, fminf(V, W)) >= 0.0f) | (int)(fmaxf(U, fmaxf(V, W)) <= 0.0f)) & (int)(det != 0.0f));
                     if (inside) {
                         const float T = fmaf(W, Sz * Ckz, fmaf(V, Sz * Bkz, U * (Sz * Akz)));
                         const float inv = 1.0f / det;
                         const float t = T * inv, u = V * inv, v = W * inv;
                         if (t > tmin && t < tmax) {
-                            // a candidate (about one test in six): the record again, in its own order this time — prim rides with the x group, flags with y, pad with z. Reloaded (the line
-                            // is in the L1) instead of kept: twelve registers that the loop does not have — with them live across the test the kernels spill inside the loop.
+                            // a candidate (about one test in six): the record again, in its own order this time — prim rides with the x group, flags with y,
+                            // pad with z. Reloaded (the line is in the L1) instead of kept: twelve registers that the loop does not have — with them live
+                            // across the test the kernels spill inside the loop.
                             uint off2 = toff; asm volatile("" : "+v"(off2));      // (an address the compiler cannot match with the loads above)
                             const f32x4 rx = *reinterpret_cast<const f32x4*>(trisBase + off2), ry = *reinterpret_cast<const f32x4*>(trisBase + (off2 + 16u)), rz = *reinterpret_cast<const f32x4*>(trisBase + (off2 + 32u));
                             const uint prim = __float_as_uint(rx.w), flags = __float_as_uint(ry.w);

@@ -24,13 +24,15 @@ namespace ptk {
 #define T8_TASK_BLOCKS_N 512        // blocks of a task-round launch: task rounds hold thousands of sub-trees, not millions
 #endif
 
-// Paths [first, first + n) of the batch's pool region (slot i = sample i % spp of owned pixel i / spp) are generated and their indices written to queue[0 .. n).
+// Paths [first, first + n) of the batch's pool region (slot i = sample i % spp of owned pixel i / spp) are generated and their indices written to queue[0 ..
+// n).
 __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool pool, const uint* __restrict__ ownedPixels, uint numOwned, uint sampleFirst, uint spp, uint first, uint n, uint* __restrict__ queue, uint* countPtr) {
     const uint t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n) return;
     const uint i = first + t;
 #if PT_SAMPLE_MINOR
-    uint kpx = i / spp, s = i - kpx * spp, px = ownedPixels[kpx];      // the samples of a pixel are neighbours in the pool: a 64-path chunk is 16 pixels x 4 samples
+    // the samples of a pixel are neighbours in the pool: a 64-path chunk is 16 pixels x 4 samples
+    uint kpx = i / spp, s = i - kpx * spp, px = ownedPixels[kpx];
 #else
     uint s = i / numOwned, px = ownedPixels[i - s * numOwned];
 #endif
@@ -40,13 +42,15 @@ __global__ void __launch_bounds__(256) k_generate(PathKernelContext k, PathPool 
     if (countPtr && t == 0u) atomicAdd(countPtr, n);
 }
 
-// The closest-hit launch of a bounce (Bridge::traceScatterRay for every path of the extend queue) as a device function, so that two kernels can run it: k_extend, and k_trace_pair
-// next to the visibility rays of the previous vertex. vBlock / vGrid: this block's place among the blocks that work on the extend queue (traverse8_pairs).
+// The closest-hit launch of a bounce (Bridge::traceScatterRay for every path of the extend queue) as a device function, so that two kernels can run it:
+// k_extend, and k_trace_pair next to the visibility rays of the previous vertex. vBlock / vGrid: this block's place among the blocks that work on the extend
+// queue (traverse8_pairs).
 template <bool COUNT, bool RANGED>
 __device__ __forceinline__ void t8_extend_body(const DeviceScene& sc, const PathPool& pool, const uint* __restrict__ queue, const uint count, WaveCounters* wc, const TravAux& aux, const uint rpc,
                                                uint2* stack, uint* rayBuf, float2* mineUV, const uint vBlock, const uint vGrid) {
-    // RANGED: every ray brings its own interval in the first two words of its (not yet written) hit record — the stable-plane fill pass's first launch, FirstHitFromVBuffer
-    // (pt_stableplanes.h firstHitInterval). A ray of such a launch that is cut into sub-trees continues over [0, best hit so far]: the lower bound is a hint, not part of the query.
+    // RANGED: every ray brings its own interval in the first two words of its (not yet written) hit record — the stable-plane fill pass's first launch,
+    // FirstHitFromVBuffer (pt_stableplanes.h firstHitInterval). A ray of such a launch that is cut into sub-trees continues over [0, best hit so far]: the
+    // lower bound is a hint, not part of the query.
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
         uint p = queue[i];
@@ -80,10 +84,10 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_extend(Devic
 #define T8_TASK_SPREAD 1
 #endif
 __device__ __forceinline__ uint t8_tasks_per_chunk(uint count) { return (!T8_TASK_SPREAD || count > T8_GROUPS_PER_WAVE * 4u * T8_TASK_BLOCKS_N || T8_GROUPS_PER_WAVE > T8_CHUNK) ? T8_CHUNK : T8_GROUPS_PER_WAVE; }
-// sub-trees of split extend rays, round STAGE (0..3) of a traversal launch: reads queue STAGE & 1 (count: counts[STAGE]); unless it is the final round, stragglers among
-// the sub-trees are split again into the other queue (count: counts[STAGE + 1]). One counter per round: the whole block is zeroed once per pass (pt_wavefront.h TravAux).
-// Task i of the launch is queue entry (i % 64) * ceil(count / 64) + i / 64: the sub-trees of one ray sit next to each other in the queue and
-// would otherwise land in one 64-item chunk, i.e. on one wave.
+// sub-trees of split extend rays, round STAGE (0..3) of a traversal launch: reads queue STAGE & 1 (count: counts[STAGE]); unless it is the final round,
+// stragglers among the sub-trees are split again into the other queue (count: counts[STAGE + 1]). One counter per round: the whole block is zeroed once per
+// pass (pt_wavefront.h TravAux). Task i of the launch is queue entry (i % 64) * ceil(count / 64) + i / 64: the sub-trees of one ray sit next to each other in
+// the queue and would otherwise land in one 64-item chunk, i.e. on one wave.
 template <int STAGE, bool FINAL>
 __device__ __forceinline__ void t8_extend_tasks_body(const DeviceScene& sc, const PathPool& pool, WaveCounters* wc, const TravAux& aux, uint2* stack, uint* rayBuf, const uint vBlock, const uint vGrid) {
     constexpr int IN = STAGE & 1;
@@ -127,7 +131,8 @@ __device__ __forceinline__ void t8_resolve_extend_body(const DeviceScene& sc, co
             uint4 a = pool.s0[p], b = pool.s1[p];
             float3 o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)), d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
             float t, u = 0.f, v = 0.f;
-            const TriRecord tr = sc.tris[aux.primToSlot[prim]]; (void)intersect_tri_wt(tri_v0(tr), tri_v1(tr), tri_v2(tr), o, d, 0.0f, kMaxRayTravel, t, u, v);      // the winner was accepted by the traversal; only (u, v) are needed
+            // the winner was accepted by the traversal; only (u, v) are needed
+            const TriRecord tr = sc.tris[aux.primToSlot[prim]]; (void)intersect_tri_wt(tri_v0(tr), tri_v1(tr), tri_v2(tr), o, d, 0.0f, kMaxRayTravel, t, u, v);
             out.z = asuint(u); out.w = asuint(v);
         }
         pool.hit[p] = out;
@@ -151,16 +156,19 @@ __global__ void __launch_bounds__(256) k_resolve_extend(DeviceScene sc, PathPool
 #define PT_SHADE_CLASSES 1      // 1: k_classify sorts the bounce's paths into {hit that goes on, hit that terminates after its emission, miss} before k_shade
 #endif
 
-// Path classes for k_shade. A shading wave lives ~90 us, nearly all of it waiting on dependent loads, and as long as ONE lane runs the whole of HandleHit (surface,
-// scatter, light sampling) the wave stays for all of it — while 13 % of a bounce's paths are misses and ~20 % are hits that terminate right after their emission
-// term (PF_terminateAtNextBounce). k_classify makes the classes contiguous (continuing hits from the front of one array, terminating hits from its back, misses
-// in a second one; one atomic per class per 1024 paths), so all but two waves of a launch are of one class and the short classes leave early. Radiance, queues
-// and counters do not depend on the order in which paths are shaded.
-#define PT_CLASSIFY_ITEMS 4u      // paths per thread: 4096 per block, one atomic per class and block (with 1024 per block the 32 000 blocks of a 4K bounce spent 0.3 ms queueing on three L2 lines)
+// Path classes for k_shade. A shading wave lives ~90 us, nearly all of it waiting on dependent loads, and as long as ONE lane runs the whole of HandleHit
+// (surface, scatter, light sampling) the wave stays for all of it — while 13 % of a bounce's paths are misses and ~20 % are hits that terminate right after
+// their emission term (PF_terminateAtNextBounce). k_classify makes the classes contiguous (continuing hits from the front of one array, terminating hits from
+// its back, misses in a second one; one atomic per class per 1024 paths), so all but two waves of a launch are of one class and the short classes leave early.
+// Radiance, queues and counters do not depend on the order in which paths are shaded.
+// paths per thread: 4096 per block, one atomic per class and block (with 1024 per block the 32 000 blocks of a 4K bounce spent 0.3 ms queueing on three L2
+// lines)
+#define PT_CLASSIFY_ITEMS 4u
 __global__ void __launch_bounds__(1024) k_classify(PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr, uint* __restrict__ classQ, uint* __restrict__ classCount) {
     __shared__ uint waveCnt[PT_CLASSIFY_ITEMS][16][3]; __shared__ uint blockBase[3];
     const uint count = *countInPtr, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint p[PT_CLASSIFY_ITEMS], cls[PT_CLASSIFY_ITEMS]; unsigned long long mine[PT_CLASSIFY_ITEMS];      // cls: 0 continuing hit, 1 terminating hit, 2 miss, 3 out of range
+    // cls: 0 continuing hit, 1 terminating hit, 2 miss, 3 out of range
+    uint p[PT_CLASSIFY_ITEMS], cls[PT_CLASSIFY_ITEMS]; unsigned long long mine[PT_CLASSIFY_ITEMS];
 #pragma unroll
     for (uint j = 0; j < PT_CLASSIFY_ITEMS; j++) {
         const uint i = (blockIdx.x * PT_CLASSIFY_ITEMS + j) * 1024u + threadIdx.x;
@@ -185,7 +193,8 @@ __global__ void __launch_bounds__(1024) k_classify(PathPool pool, const uint* __
     for (uint j = 0; j < PT_CLASSIFY_ITEMS; j++) {
         if (cls[j] > 2u) continue;
         const uint rank = blockBase[cls[j]] + waveCnt[j][wave][cls[j]] + (uint)__popcll(mine[j] & ((1ull << lane) - 1ull));
-        // continuing hits from the front of [0, count), terminating hits from its back (they cannot meet: together they are at most count), misses in [count, 2 count)
+        // continuing hits from the front of [0, count), terminating hits from its back (they cannot meet: together they are at most count), misses in [count, 2
+        // count)
         classQ[cls[j] == 0u ? rank : (cls[j] == 1u ? count - 1u - rank : count + rank)] = p[j];
     }
 }
@@ -200,7 +209,8 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
     bool alive = false; bool isHit = false; uint p = 0;
     ShadowRequest req; req.valid = false;
     if (inRange) {
-        if (classCount) {                                     // queueIn = k_classify's arrays: thread i takes the i-th path of the order {continuing, terminating, miss}
+        // queueIn = k_classify's arrays: thread i takes the i-th path of the order {continuing, terminating, miss}
+        if (classCount) {
             const uint nGo = classCount[0], nEnd = classCount[1];
             p = queueIn[i < nGo ? i : (i < nGo + nEnd ? count - 1u - (i - nGo) : count + (i - nGo - nEnd))];
         } else p = queueIn[i];
@@ -231,9 +241,10 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
 #endif
     }
 #if PT_SHADE_BLOCK_APPEND
-    // Queue appends, one atomic per BLOCK and counter: the four waves' counts meet in LDS, thread 0 reserves both ranges. A launch of 33 M paths has 518 k waves; one
-    // returning atomic per wave on each of three words — all waves of the GPU on the same three addresses — is what the kernel waited for (same-address atomics
-    // serialise in the L2: ~10^8 per second and address). The hit count needs no atomic at all when the paths were classified: it is the size of two classes.
+    // Queue appends, one atomic per BLOCK and counter: the four waves' counts meet in LDS, thread 0 reserves both ranges. A launch of 33 M paths has 518 k
+    // waves; one returning atomic per wave on each of three words — all waves of the GPU on the same three addresses — is what the kernel waited for
+    // (same-address atomics serialise in the L2: ~10^8 per second and address). The hit count needs no atomic at all when the paths were classified: it is the
+    // size of two classes.
     __shared__ uint sCnt[PT_SHADE_BLOCK / 64][2]; __shared__ uint sBase[2];
     const uint wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const unsigned long long mAlive = __builtin_amdgcn_ballot_w64(alive), mReq = __builtin_amdgcn_ballot_w64(!MULTI && req.valid);
@@ -270,8 +281,10 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
 }
 
 template <bool GROUPED>
-__device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, uint i) {           // visible == the deferred NEE contribution lands (BridgeDonut:1026)
-    if (GROUPED) { reinterpret_cast<float*>(sq.q2 + i)[3] = 1.0f; return; }                      // grouped queue: only mark, k_resolve_nee folds the group in sample order
+// visible == the deferred NEE contribution lands (BridgeDonut:1026)
+__device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, uint i) {
+    // grouped queue: only mark, k_resolve_nee folds the group in sample order
+    if (GROUPED) { reinterpret_cast<float*>(sq.q2 + i)[3] = 1.0f; return; }
     float4 r = sq.q2[i];
     uint p = asuint(sq.q1[i].w);
     uint4 c = pool.s2[p];
@@ -279,7 +292,8 @@ __device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, ui
     PathKernelContext::ResolveShadow(pack45, make_float3(r.x, r.y, r.z));
     c.z = pack45[0]; c.w = pack45[1];
     pool.s2[p] = c;
-    if (sq.q3) {                                              // NEE-AT: the visible light feeds the pixel's reservoir (LightSampler.hlsli:184-200), and the path continues as k_shade worked out for this case
+    // NEE-AT: the visible light feeds the pixel's reservoir (LightSampler.hlsli:184-200), and the path continues as k_shade worked out for this case
+    if (sq.q3) {
         const float4 f = sq.q3[i];
         const uint light = asuint(f.z), fix = asuint(f.w);
         if (light != RTXPT_INVALID_LIGHT_INDEX) {
@@ -297,8 +311,8 @@ __device__ __forceinline__ void shadow_visible(PathPool pool, ShadowQueue sq, ui
     }
 }
 
-// The visibility launch of a path vertex (Bridge::traceVisibilityRay for every entry of the shadow queue) as a device function: k_shadow, and k_trace_pair next to the closest-hit
-// rays of the next vertex.
+// The visibility launch of a path vertex (Bridge::traceVisibilityRay for every entry of the shadow queue) as a device function: k_shadow, and k_trace_pair next
+// to the closest-hit rays of the next vertex.
 template <bool COUNT, bool GROUPED>
 __device__ __forceinline__ void t8_shadow_body(const DeviceScene& sc, const PathPool& pool, const ShadowQueue& sq, const uint count, WaveCounters* wc, const TravAux& aux, const uint rpc,
                                                uint2* stack, uint* rayBuf, const uint vBlock, const uint vGrid) {
@@ -360,12 +374,13 @@ __device__ __forceinline__ void t8_resolve_shadow_body(const PathPool& pool, con
 template <bool GROUPED>
 __global__ void __launch_bounds__(256) k_resolve_shadow(PathPool pool, ShadowQueue sq, TravAux aux) { t8_resolve_shadow_body<GROUPED>(pool, sq, aux, blockIdx.x, gridDim.x); }
 
-// ---- Fused traversal launches (round 6). The visibility rays of path vertex k and the closest-hit rays of vertex k + 1 are independent of each other — the visibility results only
-// have to be in the paths' radiance before vertex k + 1 is SHADED (the order of the fp16 additions into PathState::L: the light sample of vertex k, then the emission found at
-// vertex k + 1; PathTracer.hlsli:505-762, PathTracerNEE.hlsli:185-275) — so one launch traces both: blocks [0, blocksE) work through the extend queue, the others through the shadow
-// queue; every block is of one kind, the traversal loops themselves are the ones k_extend / k_shadow run (no per-ray kind, not one instruction more in the loop). What it buys a
-// small frame (one rank of a tile-sharded frame): half the traversal launches of a pass and half the straggler rounds behind them — the two kinds' task rounds and resolve passes
-// share their launches too (k_tasks_pair, k_resolve_pair) — and each kind's dry tail runs beside the other kind's work instead of in a launch of its own.
+// ---- Fused traversal launches (round 6). The visibility rays of path vertex k and the closest-hit rays of vertex k + 1 are independent of each other — the
+// visibility results only have to be in the paths' radiance before vertex k + 1 is SHADED (the order of the fp16 additions into PathState::L: the light sample
+// of vertex k, then the emission found at vertex k + 1; PathTracer.hlsli:505-762, PathTracerNEE.hlsli:185-275) — so one launch traces both: blocks [0, blocksE)
+// work through the extend queue, the others through the shadow queue; every block is of one kind, the traversal loops themselves are the ones k_extend /
+// k_shadow run (no per-ray kind, not one instruction more in the loop). What it buys a small frame (one rank of a tile-sharded frame): half the traversal
+// launches of a pass and half the straggler rounds behind them — the two kinds' task rounds and resolve passes share their launches too (k_tasks_pair,
+// k_resolve_pair) — and each kind's dry tail runs beside the other kind's work instead of in a launch of its own.
 __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_trace_pair(DeviceScene sc, PathPool pool, const uint* __restrict__ queue, const uint* __restrict__ extCountPtr, ShadowQueue sq, const uint* __restrict__ shCountPtr,
                                                                               WaveCounters* wc, TravAux auxE, TravAux auxS, uint rpcE, uint rpcS, uint blocksE) {
     __shared__ uint2 stack[T8_GROUPS_PER_BLOCK * BVH8_STACK_STRIDE];
@@ -382,7 +397,8 @@ __global__ void __launch_bounds__(T8_BLOCK, T8_EXTEND_MIN_BLOCKS) k_tasks_pair(D
     if (blockIdx.x < half) t8_extend_tasks_body<STAGE, FINAL>(sc, pool, wc, auxE, stack, rayBuf, blockIdx.x, half);
     else t8_shadow_tasks_body<STAGE, FINAL>(sc, sq, wc, auxS, stack, rayBuf, blockIdx.x - half, gridDim.x - half);
 }
-// ... and the two resolve passes; the shadow queue's counter is zeroed here for the k_shade that follows (every reader of it — k_trace_pair — is an earlier launch of the stream)
+// ... and the two resolve passes; the shadow queue's counter is zeroed here for the k_shade that follows (every reader of it — k_trace_pair — is an earlier
+// launch of the stream)
 __global__ void __launch_bounds__(256) k_resolve_pair(DeviceScene sc, PathPool pool, ShadowQueue sq, TravAux auxE, TravAux auxS, uint* shadowCount) {
     const uint half = gridDim.x >> 1;
     if (blockIdx.x < half) t8_resolve_extend_body(sc, pool, auxE, blockIdx.x, half);
@@ -526,11 +542,13 @@ __global__ void __launch_bounds__(256) k_env_importance(DeviceScene sc, uint dim
     for (uint j = 0; j < sy; j++) for (uint ii = 0; ii < sx; ii++) {
         float2 p = make_float2(((float)(x * sx + ii) + 0.5f) / (float)(dim * sx), ((float)(y * sy + j) + 0.5f) / (float)(dim * sy));
         float3 dir = oct_to_ndir_equal_area_unorm(p);
-        float3 radiance = xyz(env_cube_sample_level(sc.envCubeSource, dir, 0.f));    // t_EnvMapCube.SampleLevel(s_LinearWrap, dir, 0) (:77) — the uncompressed cube (EnvMapBaker.cpp:635)
+        // t_EnvMapCube.SampleLevel(s_LinearWrap, dir, 0) (:77) — the uncompressed cube (EnvMapBaker.cpp:635)
+        float3 radiance = xyz(env_cube_sample_level(sc.envCubeSource, dir, 0.f));
         L += (Luminance(radiance) + Average(radiance)) * 0.5f;
         R += radiance;
     }
-    out[i] = env_round_rgba16f(make_float4(R.x * invSamples, R.y * invSamples, R.z * invSamples, L * invSamples));      // u_RadianceMap is RGBA16_FLOAT (EnvMapImportanceSamplingBaker.cpp:170)
+    // u_RadianceMap is RGBA16_FLOAT (EnvMapImportanceSamplingBaker.cpp:170)
+    out[i] = env_round_rgba16f(make_float4(R.x * invSamples, R.y * invSamples, R.z * invSamples, L * invSamples));
 }
 
 // BakeEmissiveTriangles (Rtxpt/Lighting/LightsBaker.hlsl:544-716): one thread per emissive triangle, output in sub-instance order
@@ -560,7 +578,8 @@ __global__ void __launch_bounds__(256) k_bake_emissive(DeviceScene sc, const uin
         float2 sg = shortE * (2.0f / 3.0f); float2 lg = (longE1 + longE2) * (1.0f / 3.0f);
         const TexInfo& tex = sc.textures[mat.EmissiveTextureIndex & 0xFFFFu];
         float2 c = (uv0 + uv1 + uv2) * (1.0f / 3.0f);
-        radiance = radiance * xyz(sample_grad_anisotropic(sc, tex, c, sg, lg));      // emissiveTexture.SampleGrad(s_materialSampler, centerUV, shortGradient, longGradient) (:647)
+        // emissiveTexture.SampleGrad(s_materialSampler, centerUV, shortGradient, longGradient) (:647)
+        radiance = radiance * xyz(sample_grad_anisotropic(sc, tex, c, sg, lg));
     }
     radiance = max3v(radiance, make_float3(0.f));
     bool isFlipped = det3(inst.transform) < 0.f;
@@ -582,14 +601,16 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
                       case 4: r = dm_atan2(y, x); break; case 5: r = dm_pow(x, y); break; case 6: r = FastACos(x); break; default: r = FastSqrt(x); break; }
         out[i] = r; } break;
     case 1: { float x = in[i]; uint hbits = f32tof16(x); out[2 * i] = asfloat(hbits); out[2 * i + 1] = f16tof32(hbits); } break;          // fp16 round trip
-    case 2: { const uint* p = reinterpret_cast<const uint*>(in) + 6 * i;                                   // sample stream: pixel, vertex, sample, seed, kind, count(<=8)
+    // sample stream: pixel, vertex, sample, seed, kind, count(<=8)
+    case 2: { const uint* p = reinterpret_cast<const uint*>(in) + 6 * i;
         SampleGeneratorVertexBase vb = SampleGeneratorVertexBase::make(p[0], p[1], p[2]);
         uint cnt = p[5] > 8 ? 8 : p[5];
         if (p[4] == 0) { float4 v = SampleSequenceGenerator::Generate(cnt, vb, p[3]); out[8 * i] = v.x; out[8 * i + 1] = v.y; out[8 * i + 2] = v.z; out[8 * i + 3] = v.w; }
         else if (p[4] == 1) { float4 v = UniformSampleSequenceGenerator::Generate(cnt, vb, p[3]); out[8 * i] = v.x; out[8 * i + 1] = v.y; out[8 * i + 2] = v.z; out[8 * i + 3] = v.w; }
         else if (p[4] == 2) { UniformSampleSequenceGenerator g = UniformSampleSequenceGenerator::make(vb, p[3]); for (uint j = 0; j < cnt; j++) out[8 * i + j] = sampleNext1D(g); }
         else { SampleSequenceGenerator g = SampleSequenceGenerator::make(vb, p[3], p[4] == 4); for (uint j = 0; j < cnt; j++) out[8 * i + j] = sampleNext1D(g); } } break;
-    case 3: { const float* p = in + 24 * i;                                                              // bsdf probe: params[14], thin, model, wi[3], w[3], mode
+    // bsdf probe: params[14], thin, model, wi[3], w[3], mode
+    case 3: { const float* p = in + 24 * i;
         ShadingData sd; __builtin_memset(&sd, 0, sizeof(sd));
         sd.N = make_float3(0, 0, 1); sd.T = make_float3(1, 0, 0); sd.B = make_float3(0, 1, 0); sd.V = make_float3(p[16], p[17], p[18]);
         sd.faceNCorrected = sd.N; sd.vertexN = sd.N; sd.frontFacing = true; sd.mtl = MaterialHeader::make(); sd.mtl.setActiveLobes(Lobe_All); sd.mtl.setThinSurface(p[14] != 0.f);
@@ -603,7 +624,8 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
     case 4: { const uint* p = reinterpret_cast<const uint*>(in) + 3 * i;                                   // camera ray: px, py, sampleIndex
         PathState ps = k.generate(p[0], p[1], p[2]);
         out[6 * i] = ps.origin.x; out[6 * i + 1] = ps.origin.y; out[6 * i + 2] = ps.origin.z; out[6 * i + 3] = ps.dir.x; out[6 * i + 4] = ps.dir.y; out[6 * i + 5] = ps.dir.z; } break;
-    case 5: { const float* a = in + 9 * i + 1; int fn = (int)in[9 * i]; float* o = out + 4 * i; o[0] = o[1] = o[2] = o[3] = 0.f;      // leaf functions pinned to the reference text (tests/golden/refpin_hlsl_golden.npz): (fn, 8 args) -> 4 results
+    // leaf functions pinned to the reference text (tests/golden/refpin_hlsl_golden.npz): (fn, 8 args) -> 4 results
+    case 5: { const float* a = in + 9 * i + 1; int fn = (int)in[9 * i]; float* o = out + 4 * i; o[0] = o[1] = o[2] = o[3] = 0.f;
         switch (fn) {
         case 0: o[0] = evalFresnelSchlick(a[0], a[1], a[2]); break;
         case 1: { float3 r = evalFresnelSchlick(make_float3(a[0], a[1], a[2]), a[3], a[4]); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
@@ -650,7 +672,8 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
             o[0] = asuint(t.CalcSolidAnglePdfForMIS(make_float3(asfloat(a[12]), asfloat(a[13]), asfloat(a[14])), make_float3(asfloat(a[15]), asfloat(a[16]), asfloat(a[17])))); }
         else { uint pk = NDirToOctUnorm32(make_float3(asfloat(a[0]), asfloat(a[1]), asfloat(a[2]))); float3 d = OctToNDirUnorm32(pk); o[0] = pk; o[1] = asuint(d.x); o[2] = asuint(d.y); o[3] = asuint(d.z); }
         } break;
-    case 8: { const float* a = in + 8 * i; uint* o = reinterpret_cast<uint*>(out) + 45 * i;      // loadSurface: (prim bits, u, v, dir.xyz, coneWidth, coneSpread) -> 45 words (layout of the oracle's surface probe)
+    // loadSurface: (prim bits, u, v, dir.xyz, coneWidth, coneSpread) -> 45 words (layout of the oracle's surface probe)
+    case 8: { const float* a = in + 8 * i; uint* o = reinterpret_cast<uint*>(out) + 45 * i;
         RayCone rc = RayCone::make(a[6], a[7]);
         auto emit = [&](const SurfaceData& q) {
             const ShadingData& s = q.shadingData; const StandardBSDFData& b = q.bsdf.data;
@@ -662,17 +685,21 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
         if (k.S.useFp16Types) { PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16)); emit(k16.loadSurface(asuint(a[0]), a[1], a[2], make_float3(a[3], a[4], a[5]), rc)); }
         else emit(k.loadSurface(asuint(a[0]), a[1], a[2], make_float3(a[3], a[4], a[5]), rc));
         } break;
-    case 7: { const float* a = in + 4 * i; const int op = (int)a[0]; typedef LPOps<true> H; float r = 0.f;      // the half-typed operators of the lp16 build: (op, a, b, c) -> result
+    // the half-typed operators of the lp16 build: (op, a, b, c) -> result
+    case 7: { const float* a = in + 4 * i; const int op = (int)a[0]; typedef LPOps<true> H; float r = 0.f;
         switch (op) { case 0: r = H::r(a[1]); break; case 1: r = H::add(H::r(a[1]), H::r(a[2])); break; case 2: r = H::sub(H::r(a[1]), H::r(a[2])); break; case 3: r = H::mul(H::r(a[1]), H::r(a[2])); break;
                       case 4: r = H::div(H::r(a[1]), H::r(a[2])); break; case 5: r = H::lerp(H::r(a[1]), H::r(a[2]), H::r(a[3])); break;
                       case 7: r = H::r(a[1] * a[2]); break; case 8: r = H::r(H::r(a[1]) * a[2]); break; case 9: r = H::r(a[1] + a[2]); break; case 10: r = H::r(a[1] / a[2]); break;      // lpfloat(float expression)
                       default: r = H::average3(make_float3(H::r(a[1]), H::r(a[2]), H::r(a[3]))); break; }
         out[i] = r; } break;
-    case 10: { const uint* a = reinterpret_cast<const uint*>(in) + 3 * i; uint* o = reinterpret_cast<uint*>(out) + 2 * i;      // the traversal's alpha test: (primitive, u, v) -> (scatter ray accepts, visibility ray accepts)
-        const uint slot = k.sc.primToSlot[a[0]]; const TriRecord tr = k.sc.tris[slot];      // AlphaTestImpl / Bridge::AlphaTest / AlphaTestVisibilityRay (BridgeDonut:929-989) as the leaf block applies them
+    // the traversal's alpha test: (primitive, u, v) -> (scatter ray accepts, visibility ray accepts)
+    case 10: { const uint* a = reinterpret_cast<const uint*>(in) + 3 * i; uint* o = reinterpret_cast<uint*>(out) + 2 * i;
+        // AlphaTestImpl / Bridge::AlphaTest / AlphaTestVisibilityRay (BridgeDonut:929-989) as the leaf block applies them
+        const uint slot = k.sc.primToSlot[a[0]]; const TriRecord tr = k.sc.tris[slot];
         const bool solid = !(tr.flags & 1u) || alpha_test_slot(k.sc, slot, asfloat(a[1]), asfloat(a[2]));
         o[0] = solid ? 1u : 0u; o[1] = (!(tr.flags & 1u) || (!(tr.flags & 2u) && solid)) ? 1u : 0u; } break;
-    case 9: { const float* a = in + 4 * i; float* o = out + 3 * i;                                       // EnvMap::EvalLocal on the baked cube: (localDir.xyz, lod)
+    // EnvMap::EvalLocal on the baked cube: (localDir.xyz, lod)
+    case 9: { const float* a = in + 4 * i; float* o = out + 3 * i;
         float3 r = k.sc.envEnabled ? env_eval_local(k.sc, make_float3(a[0], a[1], a[2]), a[3]) : make_float3(0.f);
         o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
     default: break;
@@ -683,7 +710,8 @@ __global__ void __launch_bounds__(64) k_probe(PathKernelContext k, int kind, con
 #ifndef T8_ADAPTIVE_CHUNKS
 #define T8_ADAPTIVE_CHUNKS 1        // 1: launches below (resident waves x 64) rays use shorter chunks (see traverse8_pairs), 0: always 64 rays per chunk
 #endif
-// rays per chunk of a traversal launch: the waves the GPU can hold (256 CUs x 4 SIMDs x 8 waves) should cover the launch in one go, 16 .. 64 rays each, in steps of 16
+// rays per chunk of a traversal launch: the waves the GPU can hold (256 CUs x 4 SIMDs x 8 waves) should cover the launch in one go, 16 .. 64 rays each, in
+// steps of 16
 static inline uint rays_per_chunk(uint count) {
     if (!T8_ADAPTIVE_CHUNKS) return T8_CHUNK;
     const uint resident = 256u * 4u * 8u;
@@ -733,8 +761,10 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
                   else hipLaunchKernelGGL((k_extend<false, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc); }
     else if (counters) hipLaunchKernelGGL((k_extend<true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
     else hipLaunchKernelGGL((k_extend<false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, queue, countPtr, wc, aux, rpc);
-    if (count <= T8_SHORT_TAIL_BELOW) {      // a small launch holds few stragglers and short ones: two task rounds (split once more, then finish) instead of four — late bounces are
-        hipLaunchKernelGGL((k_extend_tasks<0>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);             // bound by the host's launch rate, not by the GPU
+    // a small launch holds few stragglers and short ones: two task rounds (split once more, then finish) instead of four — late bounces are
+    if (count <= T8_SHORT_TAIL_BELOW) {
+        // bound by the host's launch rate, not by the GPU
+        hipLaunchKernelGGL((k_extend_tasks<0>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);
         hipLaunchKernelGGL((k_extend_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);
         hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
         return;
@@ -745,9 +775,10 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
     hipLaunchKernelGGL((k_extend_tasks<3>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, pool, wc, aux);      // queue 1, to the end
     hipLaunchKernelGGL(k_resolve_extend, dim3(T8_RESOLVE_BLOCKS), dim3(256), 0, st, sc, pool, aux);
 }
-// One launch for the closest-hit rays of the extend queue AND the visibility rays the previous vertex left in the shadow queue (k_trace_pair), then the task rounds and resolve passes of
-// both. auxE / auxS: separate task queues, counters, merge keys and resolve lists. The grid is what the two launches would use if it fits the bound, else the bound split by ray count
-// (a visibility ray costs about what a closest-hit ray costs: 0.50 against 0.44 ns on C3). Zeroes *shCountPtr at its end.
+// One launch for the closest-hit rays of the extend queue AND the visibility rays the previous vertex left in the shadow queue (k_trace_pair), then the task
+// rounds and resolve passes of both. auxE / auxS: separate task queues, counters, merge keys and resolve lists. The grid is what the two launches would use if
+// it fits the bound, else the bound split by ray count (a visibility ray costs about what a closest-hit ray costs: 0.50 against 0.44 ns on C3). Zeroes
+// *shCountPtr at its end.
 void launch_trace_pair(const DeviceScene& sc, PathPool pool, const uint* queue, const uint* extCountPtr, uint extCount, ShadowQueue sq, uint* shCountPtr, uint shCount, WaveCounters* wc, TravAux auxE, TravAux auxS, hipStream_t st) {
     const uint rpc = rays_per_chunk(extCount + shCount);
     const uint bound = (auxE.maxBlocks && auxE.maxBlocks < T8_MAX_BLOCKS) ? auxE.maxBlocks : T8_MAX_BLOCKS;
@@ -778,11 +809,13 @@ void launch_classify(PathPool pool, const uint* queueIn, const uint* countInPtr,
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc,
                   uint* classScratch, uint* classCount, hipStream_t st) {
     const dim3 g((countIn + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), b(PT_SHADE_BLOCK);
-    if (PT_SHADE_CLASSES && classScratch) {                   // (scratch: 2 x countIn words, free between the extend and the shadow launches; classCount: 3 words, zeroed with the pass's traversal counters)
+    // (scratch: 2 x countIn words, free between the extend and the shadow launches; classCount: 3 words, zeroed with the pass's traversal counters)
+    if (PT_SHADE_CLASSES && classScratch) {
         hipLaunchKernelGGL(k_classify, dim3((countIn + 1024u * PT_CLASSIFY_ITEMS - 1u) / (1024u * PT_CLASSIFY_ITEMS)), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
         queueIn = classScratch;
     } else classCount = nullptr;
-    // NEE-AT (a local sampling table and / or temporal feedback, pt_set_local_light_sampling) runs its own instantiations: the frames without it keep their kernels unchanged
+    // NEE-AT (a local sampling table and / or temporal feedback, pt_set_local_light_sampling) runs its own instantiations: the frames without it keep their
+    // kernels unchanged
     const bool neeat = k.sc.lights.LocalSamplingBuffer != nullptr || k.sc.lights.TemporalFeedbackRequired != 0u;
 #define PT_LAUNCH_SHADE(MULTI, PKC, CTX) do { if (neeat) hipLaunchKernelGGL((k_shade<MULTI, PKC, true>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount); \
                                               else hipLaunchKernelGGL((k_shade<MULTI, PKC, false>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount); } while (0)
@@ -798,11 +831,13 @@ void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st) {
     const uint rpc = rays_per_chunk(count);
     uint g = grid_for(count, (T8_BLOCK / 64u) * rpc * T8_CHUNKS_PER_WAVE_MIN, (aux.maxBlocks && aux.maxBlocks < T8_MAX_BLOCKS) ? aux.maxBlocks : T8_MAX_BLOCKS);
-    if (sq.group) hipLaunchKernelGGL((k_shadow<false, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);       // (no traversal counters in the grouped mode)
+    // (no traversal counters in the grouped mode)
+    if (sq.group) hipLaunchKernelGGL((k_shadow<false, true>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);
     else if (counters) hipLaunchKernelGGL((k_shadow<true, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);
     else hipLaunchKernelGGL((k_shadow<false, false>), dim3(g), dim3(T8_BLOCK), 0, st, sc, pool, sq, countPtr, wc, aux, rpc);
     hipLaunchKernelGGL((k_shadow_tasks<0>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
-    if (count <= T8_SHORT_TAIL_BELOW) hipLaunchKernelGGL((k_shadow_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);      // (as launch_extend: two rounds for a small launch)
+    // (as launch_extend: two rounds for a small launch)
+    if (count <= T8_SHORT_TAIL_BELOW) hipLaunchKernelGGL((k_shadow_tasks<1, true>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     else {
     hipLaunchKernelGGL((k_shadow_tasks<1>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
     hipLaunchKernelGGL((k_shadow_tasks<2>), dim3(T8_TASK_BLOCKS), dim3(T8_BLOCK), 0, st, sc, sq, wc, aux);
@@ -825,8 +860,9 @@ void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, ui
 void launch_trace_probe(const DeviceScene& sc, const float4* rays, uint n, float4* outClosest, uint* outVisible, uint* overflow, hipStream_t st) {
     hipLaunchKernelGGL(k_trace_probe, dim3(grid_for(n, T8_BLOCK, T8_MAX_BLOCKS)), dim3(T8_BLOCK), 0, st, sc, rays, n, outClosest, outVisible, overflow);
 }
-// the NEE-AT feedback of a list of pixels as (weight bits, candidate, exported depth bits) triples, 12 bytes per pixel: what the ranks of a tile-sharded frame exchange between
-// frames — the reservoirs AND the depth the baker's reprojection tests (neeat_reproject): a neighbourhood crosses shard borders, so every rank needs every pixel's depth
+// the NEE-AT feedback of a list of pixels as (weight bits, candidate, exported depth bits) triples, 12 bytes per pixel: what the ranks of a tile-sharded frame
+// exchange between frames — the reservoirs AND the depth the baker's reprojection tests (neeat_reproject): a neighbourhood crosses shard borders, so every rank
+// needs every pixel's depth
 __global__ void __launch_bounds__(256) k_pack_feedback(const float* __restrict__ fbW, const uint* __restrict__ fbC, const float* __restrict__ depth, const uint* __restrict__ pixels, uint num, uint width, uint* __restrict__ dst) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= num) return;
     const uint px = pixels[i], slot = (px & 0xFFFFu) * width + (px >> 16);
@@ -852,10 +888,11 @@ void launch_unpack(float4* accum, const uint* pixels, uint num, uint width, cons
 void launch_env_importance(const DeviceScene& sc, uint dim, uint sx, uint sy, float4* out, hipStream_t st) {
     hipLaunchKernelGGL(k_env_importance, dim3((dim * dim + 255) / 256), dim3(256), 0, st, sc, dim, sx, sy, out);
 }
-// ---- light weights and the sampling-proxy table on the device (ComputeWeights / ComputeProxyCounts / the proxy fill of LightsBaker.hlsl:738-751, 836-948), so that
-// a per-frame re-bake of animated emissives (C5) needs no D2H / host loop / H2D. Arithmetic = the host loop it replaces (and the oracle's): weight = power^0.8 with
-// the deterministic pow, thresholded; the weight SUM is taken in light order by ONE lane, because a float sum is only reproducible in a fixed order (7 k lights:
-// ~10 us; the table limit of 512 k lights: ~1 ms); counts = ceil((budget - N) * w / sum), capped; offsets by an exclusive scan (integers); the fill is per proxy.
+// ---- light weights and the sampling-proxy table on the device (ComputeWeights / ComputeProxyCounts / the proxy fill of LightsBaker.hlsl:738-751, 836-948), so
+// that a per-frame re-bake of animated emissives (C5) needs no D2H / host loop / H2D. Arithmetic = the host loop it replaces (and the oracle's): weight =
+// power^0.8 with the deterministic pow, thresholded; the weight SUM is taken in light order by ONE lane, because a float sum is only reproducible in a fixed
+// order (7 k lights: ~10 us; the table limit of 512 k lights: ~1 ms); counts = ceil((budget - N) * w / sum), capped; offsets by an exclusive scan (integers);
+// the fill is per proxy.
 __global__ void __launch_bounds__(256) k_light_weights(const PolymorphicLightInfo* __restrict__ lights, const PolymorphicLightInfoEx* __restrict__ lightsEx, uint n, float* __restrict__ w, LightFrustumBoost boost) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= n) return;
     PolymorphicLightInfoFull lf; lf.Base = lights[i]; lf.Extended = lightsEx[i];
@@ -876,7 +913,8 @@ __global__ void __launch_bounds__(256) k_light_weight_sum(const float* __restric
     }
     if (threadIdx.x == 0) *sum = s;
 }
-// usage != null (NEE-AT, last frame left feedback): the weight is pulled towards the number of pixels that asked for the light (pt_neeat.h neeat_feedback_light_weight)
+// usage != null (NEE-AT, last frame left feedback): the weight is pulled towards the number of pixels that asked for the light (pt_neeat.h
+// neeat_feedback_light_weight)
 __global__ void __launch_bounds__(256) k_light_proxy_counts(const float* __restrict__ w, uint n, const float* __restrict__ sum, uint budget, uint uniform, uint maxPerLight, uint* __restrict__ counts,
                                                             const uint* __restrict__ usage, uint totalMaxFeedbackCount, float globalFeedbackUseWeight) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= n) return;
@@ -886,25 +924,29 @@ __global__ void __launch_bounds__(256) k_light_proxy_counts(const float* __restr
     if (lightWeight > 0) cnt = uniform ? 1u : (uint)ceilf(((float)(budget - n) * lightWeight) / *sum);
     counts[i] = cnt < maxPerLight ? cnt : maxPerLight;
 }
-// ComputeWeights of a NEE-AT frame: the baked weight, boosted where the light got brighter than 1.1 x what it weighed last frame (ImportanceBooster, LightsBaker.hlsl:137-147)
+// ComputeWeights of a NEE-AT frame: the baked weight, boosted where the light got brighter than 1.1 x what it weighed last frame (ImportanceBooster,
+// LightsBaker.hlsl:137-147)
 __global__ void __launch_bounds__(256) k_neeat_boost_weights(const float* __restrict__ base, const float* __restrict__ hist, uint nHist, uint n, float mul, float* __restrict__ cur) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= n) return;
     cur[i] = hist ? neeat_intensity_delta_boost(base[i], i < nHist ? hist[i] : 0.f, mul) : base[i];
 }
-// ---- NEE-AT feedback passes (pt_neeat.h): one thread per pixel / low-resolution pixel / tile; every pass reads what the previous one wrote and writes only its own slot
+// ---- NEE-AT feedback passes (pt_neeat.h): one thread per pixel / low-resolution pixel / tile; every pass reads what the previous one wrote and writes only
+// its own slot
 __global__ void __launch_bounds__(256) k_neeat_prefilter(NeeAtFrame F, const float* __restrict__ snapW, const uint* __restrict__ snapC) {
     uint i = blockIdx.x * 256u + threadIdx.x; if (i >= F.W * F.H) return;
     neeat_prefilter_pixel(F, snapW, snapC, (int)(i % F.W), (int)(i / F.W));
 }
-// P0's counts: neighbouring pixels mostly ask for the same few lights, and same-address atomics serialise in the L2. Two merges before anything reaches memory (the
-// reference merges equal lanes with WaveMatch, LightsBaker.hlsl:1287-1305): the lanes of a wave (an 8 x 8 pixel block) that count the same light become one entry, and the
-// sixteen waves of a block (32 x 32 pixels) add their entries into a small LDS hash table that is flushed once — one global atomic per distinct light and 32 x 32 pixels.
+// P0's counts: neighbouring pixels mostly ask for the same few lights, and same-address atomics serialise in the L2. Two merges before anything reaches memory
+// (the reference merges equal lanes with WaveMatch, LightsBaker.hlsl:1287-1305): the lanes of a wave (an 8 x 8 pixel block) that count the same light become
+// one entry, and the sixteen waves of a block (32 x 32 pixels) add their entries into a small LDS hash table that is flushed once — one global atomic per
+// distinct light and 32 x 32 pixels.
 static const uint NEEAT_P0_TABLE = 512u;      // LDS hash slots per block (a full table falls back to a global atomic per entry)
 __global__ void __launch_bounds__(1024) k_neeat_p0(NeeAtFrame F, uint totalThreads) {
     __shared__ uint hKey[NEEAT_P0_TABLE]; __shared__ uint hCnt[NEEAT_P0_TABLE];
     const uint NONE = 0xFFFFFFFFu, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint k = threadIdx.x; k < NEEAT_P0_TABLE; k += 1024u) { hKey[k] = NONE; hCnt[k] = 0u; }
-    if (blockIdx.x == 0u && threadIdx.x == 0u && totalThreads > F.W * F.H) atomicAdd(&F.perLightCounters[F.totalLightCount], totalThreads - F.W * F.H);      // the dispatch's threads beyond the frame count as "no valid feedback"
+    // the dispatch's threads beyond the frame count as "no valid feedback"
+    if (blockIdx.x == 0u && threadIdx.x == 0u && totalThreads > F.W * F.H) atomicAdd(&F.perLightCounters[F.totalLightCount], totalThreads - F.W * F.H);
     __syncthreads();
     const uint regionsX = (F.W + 31u) / 32u;
     const uint px = (blockIdx.x % regionsX) * 32u + (wave & 3u) * 8u + (lane & 7u), py = (blockIdx.x / regionsX) * 32u + (wave >> 2) * 8u + (lane >> 3);
@@ -931,8 +973,9 @@ __global__ void __launch_bounds__(1024) k_neeat_p0(NeeAtFrame F, uint totalThrea
 __global__ void __launch_bounds__(256) k_neeat_p1a(NeeAtFrame F) { uint i = blockIdx.x * 256u + threadIdx.x; if (i < F.BW * F.BH) neeat_p1a_pixel(F, i % F.BW, i / F.BW); }
 __global__ void __launch_bounds__(256) k_neeat_p1b(NeeAtFrame F) { uint i = blockIdx.x * 256u + threadIdx.x; if (i < F.W * F.H) neeat_p1b_pixel(F, i % F.W, i / F.W); }
 __global__ void __launch_bounds__(64) k_neeat_p2(NeeAtFrame F) { uint i = blockIdx.x * 64u + threadIdx.x; if (i < F.tilesX * F.tilesY) neeat_fill_tile(F, i % F.tilesX, i / F.tilesX); }
-// P3: one 64-lane block per tile. The 128 light indices are sorted in LDS with a bitonic network (compare-exchange pairs as in MiniEngine's Bitonic32PreSortCS, which
-// the reference cites: element `hi` = lane with a one inserted at bit j, partner = hi ^ (first step of a merge ? k - 1 : j)); then every entry finds the ends of its run.
+// P3: one 64-lane block per tile. The 128 light indices are sorted in LDS with a bitonic network (compare-exchange pairs as in MiniEngine's Bitonic32PreSortCS,
+// which the reference cites: element `hi` = lane with a one inserted at bit j, partner = hi ^ (first step of a merge ? k - 1 : j)); then every entry finds the
+// ends of its run.
 __global__ void __launch_bounds__(64) k_neeat_p3(NeeAtFrame F) {
     __shared__ uint key[RTXPT_LIGHTING_LOCAL_PROXY_COUNT];
     const uint N = RTXPT_LIGHTING_LOCAL_PROXY_COUNT, t = threadIdx.x;
@@ -958,7 +1001,8 @@ __global__ void __launch_bounds__(256) k_light_proxy_fill(const uint* __restrict
     const uint p = blockIdx.x * 256u + threadIdx.x;
     const uint total = offsets[n - 1u] + counts[n - 1u];
     if (p >= total || p >= capacity) return;
-    uint lo = 0u, hi = n;                                  // last light with offset <= p (lights without proxies share their successor's offset: skipped by taking the last)
+    // last light with offset <= p (lights without proxies share their successor's offset: skipped by taking the last)
+    uint lo = 0u, hi = n;
     while (hi - lo > 1u) { uint mid = (lo + hi) >> 1; if (offsets[mid] <= p) lo = mid; else hi = mid; }
     proxies[p] = lo;
 }
@@ -973,7 +1017,8 @@ void launch_light_proxy_counts(const float* w, uint n, float* sum, uint budget, 
 void launch_neeat_boost_weights(const float* base, const float* hist, uint nHist, uint n, float mul, float* cur, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_neeat_boost_weights, dim3((n + 255) / 256), dim3(256), 0, st, base, hist, nHist, n, mul, cur);
 }
-// UpdateBegin's feedback half: PreFilter from a snapshot of the reservoirs (snapW / snapC: W x H scratch), then P0's counts. The counters are expected zeroed (totalLightCount + 1 words).
+// UpdateBegin's feedback half: PreFilter from a snapshot of the reservoirs (snapW / snapC: W x H scratch), then P0's counts. The counters are expected zeroed
+// (totalLightCount + 1 words).
 void launch_neeat_begin(const NeeAtFrame& F, float* snapW, uint* snapC, bool preFilter, uint totalThreads, hipStream_t st) {
     const uint px = F.W * F.H;
     if (preFilter) {

@@ -41,8 +41,9 @@ __device__ __forceinline__ PathState load_path(const PathPool& pool, uint i) {
     return p;
 }
 
-// k_shade's view of a path (PathKernelContext::HandleHit's IO policy, pt_path.h): the words loadSurface needs come first (direction | length, interior list | counters | ray cone), the
-// rest after the surface is loaded; the scattered path's first four groups are stored before the light sampling, the last group at the end
+// k_shade's view of a path (PathKernelContext::HandleHit's IO policy, pt_path.h): the words loadSurface needs come first (direction | length, interior list |
+// counters | ray cone), the rest after the surface is loaded; the scattered path's first four groups are stored before the light sampling, the last group at
+// the end
 struct PathPoolIO {
     static constexpr bool streams = true;
     PathPool pool; uint i;
@@ -56,7 +57,8 @@ struct PathPoolIO {
         PathState p; uint4 b = pool.s1[i], d = pool.s3[i];
         p.dir = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z)); p.sceneLength = asfloat(b.w);
         p.interiorList.slots[0] = d.x; p.interiorList.slots[1] = d.y; p.packedCounters = d.z; p.rayCone.widthSpreadAngleFP16 = d.w;
-        p.flagsAndVertexIndex = reinterpret_cast<const uint*>(pool.s4)[4u * (size_t)i + 2u];      // (PF_terminateAtNextBounce decides how much of the surface is loaded; load_rest brings the word again with its group)
+        // (PF_terminateAtNextBounce decides how much of the surface is loaded; load_rest brings the word again with its group)
+        p.flagsAndVertexIndex = reinterpret_cast<const uint*>(pool.s4)[4u * (size_t)i + 2u];
         return p;
     }
     __device__ __forceinline__ void load_rest(PathState& p) const {
@@ -80,7 +82,8 @@ __device__ __forceinline__ void t8_counters_init(Traverse8Counters& ctr) {
     ctr.nodeVisits = 0; ctr.triTests = 0; ctr.leafVisits = 0; ctr.iters = 0; ctr.leafBlocks = 0; for (int q = 0; q < 8; q++) ctr.ev[q] = 0u; ctr.cyc[0] = ctr.cyc[1] = ctr.cyc[2] = ctr.cyc[3] = 0ull;
     ctr.rayIterHist = nullptr; ctr.longRayCount = nullptr; ctr.longRays = nullptr;
 }
-__device__ __forceinline__ unsigned long long t8_hit_key(float t, uint prim) { return ((unsigned long long)__float_as_uint(t) << 32) | prim; }      // t > 0: bits order like the value
+// t > 0: bits order like the value
+__device__ __forceinline__ unsigned long long t8_hit_key(float t, uint prim) { return ((unsigned long long)__float_as_uint(t) << 32) | prim; }
 
 
 } // namespace ptk
