@@ -95,6 +95,9 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 // mode 2: calls of fewer paths than this fuse (one rank of a 4- or 8-way sharded 4K frame, 1080p frames); a full 4K x 4 spp frame (33 M) keeps its own launches
 #define PT_FUSED_BELOW (12u << 20)
 #endif
+#ifndef PT_COMPACT_POOL
+#define PT_COMPACT_POOL 1      // pt_render keeps the live paths' state compacted by queue position (ptk::PathPool::home; environment MI355PT_COMPACT_POOL overrides)
+#endif
 #ifndef PT_FREE_RUN_BELOW
 // pt_render: once every live batch holds fewer paths than this, the batches stop advancing in lockstep (0: lockstep to the end)
 #define PT_FREE_RUN_BELOW (1u << 22)
@@ -107,7 +110,7 @@ static const uint TASK_QUEUE_CAPACITY = 1u << 22;      // sub-tree tasks per que
 
 struct pt_context {
     int device = 0; hipStream_t stream = nullptr; uint shardRank = 0, shardCount = 1;
-    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0, fusedTraversal = PT_FUSED_TRAVERSAL;   // second half-frame batch (pt_render pipelines two batches)
+    hipStream_t streams[PT_PIPELINE_BATCHES] = {}; WaveCounters* hostCounters = nullptr; bool serialKernels = false; uint tailBelow = PT_TAIL_PATHS, tailDefer = 0, fusedTraversal = PT_FUSED_TRAVERSAL; bool compactPool = PT_COMPACT_POOL != 0;   // second half-frame batch (pt_render pipelines two batches)
     std::string lastError;
     // host copies of the scene (kept for re-bake / animation)
     std::vector<uint> indices; std::vector<float> positions; std::vector<ptk::float2> uvs; std::vector<uint> normals, tangents;
@@ -154,7 +157,7 @@ struct pt_context {
         void reset() { W = H = 0; updateCounter = 0; jitterF[0] = jitterF[1] = 0; jitter[0] = jitter[1] = prevJitter[0] = prevJitter[1] = 0; feedbackFilled = lastFeedbackAvailable = false; frameOpen = false; exportDepth = true; historicTotalLightCount = 0; W = H = 0; nHist = 0; }
         void free() { fbW.free(); scW.free(); blW.free(); snapW.free(); curW.free(); histW.free(); fbC.free(); scC.free(); blC.free(); snapC.free(); local.free(); counters.free(); xSend.free(); xRecv.free(); xPixels.free(); depth.free(); histDepth.free(); }
     } neeat;
-    DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList, dResolveListSh; DevBuf<unsigned long long> dBestKey, dBestKeySh; DevBuf<ptk::TravTask> dTaskQSh;      // ...Sh: the visibility rays' own straggler state in a frame of fused traversal launches
+    DevBuf<ptk::uint4> dS0, dS1, dS2, dS3, dS4, dHit, dS0b, dS1b, dS3b, dS4b, dHitb /* ...b: the second array set of a compacted pool (pt_render) */; DevBuf<ptk::float4> dSq0, dSq1, dSq2, dAccum, dScratch4; DevBuf<WaveCounters> dCounters; DevBuf<ptk::uint2> dTravSpill; DevBuf<ptk::TravTask> dTaskQ; DevBuf<uint> dTravCounts, dResolveList, dResolveListSh; DevBuf<unsigned long long> dBestKey, dBestKeySh; DevBuf<ptk::TravTask> dTaskQSh;      // ...Sh: the visibility rays' own straggler state in a frame of fused traversal launches
     std::vector<TexInfo> texInfos; TexInfo envTexInfo;
     BvhBuildBuffers bvh; bool bvhAllocated = false; uint numTris = 0; uint bvhBuilder = BVH_BUILDER_SAH;
     DeviceScene dsc;
@@ -750,6 +753,7 @@ int32_t pt_create(const PtDeviceDesc* desc, pt_context** out) {
       if (e && !strcmp(e, "karras")) c->bvhBuilder = BVH_BUILDER_KARRAS; else if (e && !strcmp(e, "ploc")) c->bvhBuilder = BVH_BUILDER_PLOC; else if (e && !strcmp(e, "sah")) c->bvhBuilder = BVH_BUILDER_SAH; else if (e && (!strcmp(e, "ploc_opt") || !strcmp(e, "device"))) c->bvhBuilder = BVH_BUILDER_PLOC_OPT; }
     { const char* e = getenv("MI355PT_TAIL_PATHS"); if (e) c->tailBelow = (uint)strtoul(e, nullptr, 10); }      // developer A/B switch (pt_set_tail_paths)
     // developer A/B switch (pt_set_fused_traversal)
+    { const char* e = getenv("MI355PT_COMPACT_POOL"); if (e) c->compactPool = atoi(e) != 0; }      // developer A/B / test switch, read at pt_create like the others
     { const char* e = getenv("MI355PT_FUSED_TRAVERSAL"); if (e) c->fusedTraversal = (uint)strtoul(e, nullptr, 10); }
     // test switch: iterations after which the tail kernel hands a ray back (0: T8_TAIL_DEFER); a small value sends most rays through the hand-back path
     { const char* e = getenv("MI355PT_TAIL_DEFER"); if (e) c->tailDefer = (uint)strtoul(e, nullptr, 10); }
@@ -771,7 +775,7 @@ int32_t pt_destroy(pt_context* c) {
     c->dIndices.free(); c->dNormals.free(); c->dTangents.free(); c->dProxyCounters.free(); c->dProxyIndices.free(); c->dEnvLookup.free(); c->dOwned.free(); c->dQueue[0].free(); c->dQueue[1].free();
     c->dPrevPositions.free(); c->dPrevInstances.free(); c->dEmissiveList.free(); c->dEmissiveOffsets.free(); c->dPositions.free(); c->dUvs.free(); c->dGeometries.free(); c->dInstances.free(); c->dSubInstances.free(); c->dSubInstToInstGeom.free();
     c->dPrimInfo.free(); c->dShadeTris.free(); c->dAlphaPlanes.free(); c->dAlphaPool.free(); c->dMaterials.free(); c->dTexInfos.free(); c->dTexels.free(); c->dEnvCube.free(); c->dEnvCubeSource.free(); c->dEnvImageCube.free(); c->dEnvDirLights.free(); c->dLights.free(); c->dLightsEx.free(); c->dS0.free(); c->dS1.free(); c->dS2.free(); c->dS3.free(); c->dS4.free();
-    c->dHit.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free(); c->dResolveListSh.free(); c->dBestKeySh.free(); c->dTaskQSh.free();
+    c->dHit.free(); c->dS0b.free(); c->dS1b.free(); c->dS3b.free(); c->dS4b.free(); c->dHitb.free(); c->dSq0.free(); c->dSq1.free(); c->dSq2.free(); c->dAccum.free(); c->dScratch4.free(); c->dCounters.free(); c->dTravSpill.free(); c->dTaskQ.free(); c->dTravCounts.free(); c->dResolveList.free(); c->dBestKey.free(); c->dResolveListSh.free(); c->dBestKeySh.free(); c->dTaskQSh.free();
     for (uint b = 1; b < PT_PIPELINE_BATCHES; b++) (void)hipStreamDestroy(c->streams[b]);
     (void)hipStreamDestroy(c->stream); (void)hipHostFree(c->hostCounters);
     delete c;
@@ -1318,7 +1322,7 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     struct Batch {
         uint pixFirst = 0, numPix = 0, total = 0, base = 0; hipStream_t st = nullptr; WaveCounters* wc = nullptr; WaveCounters* hwc = nullptr;
         PathPool pool; ShadowQueue sq; uint* queue[2] = {nullptr, nullptr}; DeviceScene sc; PathKernelContext k; TravAux aux;
-        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false; uint bound = 0, pendingShadow = 0; TravAux auxSh;      // pendingShadow / auxSh: fused traversal launches (below)      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
+        uint cur = 0, active = 0, iterations = 0, tailLaunches = 0; unsigned long long extendRays = 0, shadowRays = 0; bool waiting = false, afterTail = false, inTail = false; uint bound = 0, pendingShadow = 0; TravAux auxSh; PathPool poolSet[2]; uint set = 0; bool compact = false;      // poolSet / set / compact: the compacted pool (below)      // pendingShadow / auxSh: fused traversal launches (below)      // bound: wavefront passes so far (what maxIter limits; a tail launch is followed by one, so the loop ends)
         std::vector<hipEvent_t> ev; struct Span { size_t a, b; int kind; uint items; }; std::vector<Span> spans; size_t t0 = 0, t1 = 0;
         // per-launch HIP events: only when somebody reads them (serial-kernel steps, the pass log) — ten API calls per pass and batch otherwise
         bool timed = false;
@@ -1382,6 +1386,20 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
     // others' traversal (free-running streams drift into running the same kernel at the same time: 7 % slower on the full frame and no gain on a rank of a
     // sharded frame, DESIGN.md §4, profiles/r04i_event_loop_ab.txt).
     const bool passLog = getenv("MI355PT_PASS_LOG") != nullptr;
+    // Compacted pool (round 6; ptk::PathPool::home). A path's state lives at its home slot (owned pixel x sample) for the whole frame in the layout above, and from the second bounce on
+    // the survivors are scattered over the pool: a wave's 64 paths touch up to 64 lines per word group where the first bounce touches 8. Here k_shade writes a survivor's origin, direction,
+    // interior list | counters | ray cone and {firefly K, MIS info, flags, sample index} at the POSITION it appends the path to, into the other of two array sets; the next bounce's
+    // traversal reads rays, and writes hits, by position (the extend queue is the identity), k_classify and k_shade read dense arrays. Only throughput | radiance — what the
+    // visibility resolve and k_accumulate address by path — stays at the home slot, which the extend queue keeps carrying (and the shadow queue names). Same values, another place:
+    // the image cannot change. A batch that goes to the tail kernel is scattered back to its home slots first (k_uncompact) and continues in the home-slot layout. Not for NEE-AT
+    // (its visibility resolve patches the path's flags), grouped NEE samples, serial-kernel and counter frames.
+    const bool neeatShade = c->dsc.lights.LocalSamplingBuffer != nullptr || c->dsc.lights.TemporalFeedbackRequired != 0u;
+    const bool compactPool = c->compactPool && !c->serialKernels && !c->countersEnabled && !shadowGroup && !neeatShade && !feedback && c->dsc.rootIsValid;
+    if (compactPool) {
+        PT_CHECK_HIP(c, c->dS0b.resize(c->poolCapacity)); PT_CHECK_HIP(c, c->dS1b.resize(c->poolCapacity)); PT_CHECK_HIP(c, c->dS3b.resize(c->poolCapacity)); PT_CHECK_HIP(c, c->dS4b.resize(c->poolCapacity)); PT_CHECK_HIP(c, c->dHitb.resize(c->poolCapacity));
+        for (uint b = 0; b < numBatches; b++) { Batch& t = B[b]; t.compact = true; t.set = 0; t.poolSet[0] = t.pool;
+            t.poolSet[1] = PathPool{c->dS0b.p + t.base, c->dS1b.p + t.base, t.pool.s2, c->dS3b.p + t.base, c->dS4b.p + t.base, c->dHitb.p + t.base, nullptr}; }
+    }
     // One pass of a batch is queued by queue_pass (counter reset, traversal — fused with the pending visibility rays — classify + shade, read-back of the two
     // queue counts) and finished by finish_pass once those counts have arrived (the visibility rays become pending, or are traced if the batch ends here).
     uint wavefrontPasses = 0;
@@ -1390,6 +1408,11 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         // the pass's traversal / class counters and the two queue counters it refills: one launch (fused: the shadow queue's counter still counts the pending
         // rays; k_resolve_pair zeroes it)
         launch_pass_reset(t.aux.counts, &t.wc->extendCount[nxt], fused ? nullptr : &t.wc->shadowCount, t.st);
+        if (tailBelow && t.active <= tailBelow && !t.afterTail && t.compact) {      // the tail kernel works on home slots: scatter the live paths back, into the array set that is not being read
+            PathPool in = t.poolSet[t.set]; in.home = t.queue[t.cur];
+            launch_uncompact(in, t.poolSet[t.set ^ 1u], &t.wc->extendCount[t.cur], t.active, t.st);
+            t.pool = t.poolSet[t.set ^ 1u]; t.compact = false;
+        }
         if (tailBelow && t.active <= tailBelow && !t.afterTail) {
             if (t.pendingShadow) { launch_shadow(t.sc, t.pool, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, false, t.auxSh, t.st); PT_CHECK_HIP(c, hipMemsetAsync(&t.wc->shadowCount, 0, 4, t.st)); t.pendingShadow = 0; }      // (the tail kernel adds to the paths' radiance itself: what is pending lands first)      // few paths left: one launch runs them to their end, wave by wave (pt_tail.hip); stragglers come back through queue[nxt] / the shadow queue
             size_t e0 = t.mark(); launch_tail(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, maxIter - t.bound, c->tailDefer, t.aux.maxBlocks, t.st); size_t e1 = t.mark();
@@ -1402,10 +1425,12 @@ int32_t pt_render(pt_context* c, uint32_t first, uint32_t count, PtFrameStats* s
         }
         t.afterTail = false; t.bound++; wavefrontPasses++;
         size_t e0 = t.mark();
-        if (t.pendingShadow) { launch_trace_pair(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, t.aux, t.auxSh, t.st); t.pendingShadow = 0; }
-        else launch_extend(t.sc, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st);
+        PathPool pin = t.pool, pout = PathPool{};
+        if (t.compact) { pin = t.poolSet[t.set]; pin.home = t.queue[t.cur]; pout = t.poolSet[t.set ^ 1u]; t.set ^= 1u; }
+        if (t.pendingShadow) { launch_trace_pair(t.sc, pin, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.sq, &t.wc->shadowCount, t.pendingShadow, t.wc, t.aux, t.auxSh, t.st); t.pendingShadow = 0; }
+        else launch_extend(t.sc, pin, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.wc, c->countersEnabled, t.aux, t.st);
         size_t e1 = t.mark(); if (t.timed) t.spans.push_back({e0, e1, 0, t.active});
-        launch_shade(t.k, t.pool, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
+        launch_shade(t.k, pin, t.queue[t.cur], &t.wc->extendCount[t.cur], t.active, t.queue[nxt], &t.wc->extendCount[nxt], t.sq, t.wc, t.active >= PT_CLASSIFY_FROM ? reinterpret_cast<uint*>(t.aux.bestKey) : nullptr /* the straggler keys are idle between k_resolve_extend and the shadow launch; a few thousand paths are shaded in queue order: one launch fewer */, t.aux.counts + PASS_CLASS_OFFSET, t.st, pout); size_t e2 = t.mark(); if (t.timed) t.spans.push_back({e1, e2, 1, t.active});
         t.extendRays += t.active;
         PT_CHECK_HIP(c, hipMemcpyAsync(t.hwc, t.wc, 16, hipMemcpyDeviceToHost, t.st));
         t.waiting = true;

@@ -17,7 +17,11 @@
 
 namespace ptk {
 
-struct PathPool { uint4* s0; uint4* s1; uint4* s2; uint4* s3; uint4* s4; uint4* hit; };
+struct PathPool { uint4* s0; uint4* s1; uint4* s2; uint4* s3; uint4* s4; uint4* hit;
+    // Compacted pool (round 6, pt_render): home == nullptr — every array is indexed by the path's home slot (owned pixel x sample), the extend queue holds home slots. home != nullptr —
+    // s0, s1, s3, s4 and hit are indexed by the path's POSITION in the extend queue (k_shade writes a surviving path's state at the position it appends it to, into the other of two
+    // array sets), home[position] is its home slot, and s2 — throughput and radiance, what the visibility resolve and k_accumulate address — stays at the home slot.
+    const uint* home; };
 struct ShadowQueue { float4* q0; float4* q1; float4* q2; uint group;           // group: 0 = one entry per path vertex (NEEFullSamples 1), else entries come in groups of `group` (pt_path.h ShadowSink)
     // NEE-AT feedback (null: off): q3 = {weight, random, light | SSC flag, roulette fix-up} per entry (pt_path.h ShadowRequest); the sub-frame's feedback reservoirs, one slot per pixel
     float4* q3; float* fbTotalWeight; uint* fbCandidates; uint fbWidth, fbPlane, fbSampleFirst; };      // slot = (sample - fbSampleFirst) * fbPlane + y * fbWidth + x
@@ -44,7 +48,9 @@ void launch_extend(const DeviceScene& sc, PathPool pool, const uint* queue, cons
 // classScratch (2 x countIn words: memory that is free between the extend and the shadow launches of a bounce) + classCount (3 words, zero on entry): k_classify's output; null = shade in queue order
 // launch_extend / launch_shade / launch_shadow expect the pass's counter block zeroed by the caller (launch_pass_reset)
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr,
-                  ShadowQueue sq, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st);
+                  ShadowQueue sq, WaveCounters* wc, uint* classScratch, uint* classCount, hipStream_t st, PathPool outPool = PathPool{});      // outPool: a compacted pool's other array set (pool.home != nullptr)
+// a compacted pool's live paths back to their home slots: out.s0 / s1 / s3 / s4 [home[i]] = in...[i] for the *countPtr positions (out: another array set than in's); the queue `in.home` is then an ordinary extend queue
+void launch_uncompact(PathPool in, PathPool out, const uint* countPtr, uint count, hipStream_t st);
 void launch_classify(PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* classScratch, uint* classCount, hipStream_t st);      // k_classify: {continuing hit, terminating hit, miss} made contiguous
 void launch_shadow(const DeviceScene& sc, PathPool pool, ShadowQueue sq, const uint* countPtr, uint count, WaveCounters* wc, bool counters, TravAux aux, hipStream_t st);
 // the closest-hit rays of the extend queue and the visibility rays of the previous vertex (shadow queue) in ONE traversal launch, their task rounds and resolve passes in shared launches

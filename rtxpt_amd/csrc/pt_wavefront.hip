@@ -53,7 +53,7 @@ __device__ __forceinline__ void t8_extend_body(const DeviceScene& sc, const Path
     // lower bound is a hint, not part of the query.
     Traverse8Counters ctr; t8_counters_init(ctr);
     auto fetch = [&](uint i, float3& o, float3& d, float& tmin, float& tmax, uint& startRef, float& bestT0, uint& bestPrim0) -> uint {
-        uint p = queue[i];
+        uint p = pool.home ? i : queue[i];      // (a compacted pool's ray i is the path at position i)
         uint4 a = pool.s0[p], b = pool.s1[p];
         o = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)); d = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z));
         tmin = 0.0f; tmax = kMaxRayTravel; startRef = 0u; bestT0 = kMaxRayTravel; bestPrim0 = 0xFFFFFFFFu;
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(1024) k_classify(PathPool pool, const uint* __
         const uint i = (blockIdx.x * PT_CLASSIFY_ITEMS + j) * 1024u + threadIdx.x;
         p[j] = 0u; cls[j] = 3u;
         if (i < count) {
-            p[j] = queueIn[i];
+            p[j] = pool.home ? i : queueIn[i];
             const uint prim = reinterpret_cast<const uint*>(pool.hit)[4u * (size_t)p[j] + 1u], flags = reinterpret_cast<const uint*>(pool.s4)[4u * (size_t)p[j] + 2u];
             cls[j] = (prim == 0xFFFFFFFFu) ? 2u : (((flags >> kVertexIndexBitCount) & PF_terminateAtNextBounce) ? 1u : 0u);
         }
@@ -200,20 +200,25 @@ __global__ void __launch_bounds__(1024) k_classify(PathPool pool, const uint* __
 }
 
 // PKC: PathKernelContextT<false> (lp types in fp32) or PathKernelContextT<true> (the reference's default build, lp types in binary16)
-template <bool MULTI, class PKC, bool NEEAT>
+// COMPACT: the pool is compacted (PathPool::home): the path at position p of this bounce's array set is written, if it survives, to the position it is appended at in `outPool`'s set;
+// its throughput | radiance word group stays at its home slot, which is also what the extend queue keeps and the shadow queue names
+template <bool MULTI, class PKC, bool NEEAT, bool COMPACT = false>
 __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(PKC k, PathPool pool, const uint* __restrict__ queueIn, const uint* __restrict__ countInPtr,
-                                               uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, const uint* __restrict__ classCount) {
+                                               uint* __restrict__ queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc, const uint* __restrict__ classCount, PathPool outPool) {
     const uint count = *countInPtr;
     uint i = blockIdx.x * (uint)PT_SHADE_BLOCK + threadIdx.x;
     bool inRange = i < count;
-    bool alive = false; bool isHit = false; uint p = 0;
+    bool alive = false; bool isHit = false; uint p = 0, hp = 0;
     ShadowRequest req; req.valid = false;
+    PathState cpath;      // COMPACT: the shaded path, kept until its position is known
+    if (COMPACT) __builtin_memset(&cpath, 0, sizeof(cpath));
     if (inRange) {
         // queueIn = k_classify's arrays: thread i takes the i-th path of the order {continuing, terminating, miss}
         if (classCount) {
             const uint nGo = classCount[0], nEnd = classCount[1];
             p = queueIn[i < nGo ? i : (i < nGo + nEnd ? count - 1u - (i - nGo) : count + (i - nGo - nEnd))];
-        } else p = queueIn[i];
+        } else p = COMPACT ? i : queueIn[i];
+        hp = COMPACT ? pool.home[p] : p;
         uint4 hr = pool.hit[p];
         HitInfo h; h.t = asfloat(hr.x); h.prim = hr.y; h.u = asfloat(hr.z); h.v = asfloat(hr.w);
 #if PT_SHADE_PROBE
@@ -226,7 +231,14 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
         store_path(pool, p, path);
         alive = path.isActive();
 #else
-        if (h.prim == 0xFFFFFFFFu) { PathState path = load_path(pool, p); k.template HandleMiss<NEEAT>(path, path.dir, kMaxRayTravel); store_path(pool, p, path); alive = path.isActive(); }
+        if (COMPACT) {
+            const PathCompactIO io{pool, p, hp};
+            if (h.prim == 0xFFFFFFFFu) { cpath = io.load_all(); k.template HandleMiss<NEEAT>(cpath, cpath.dir, kMaxRayTravel); }
+            else { isHit = true; cpath = io.load_first(); k.template HandleHit<false, NEEAT>(cpath, h, req, nullptr, io); }
+            alive = cpath.isActive();
+            pool.s2[hp] = make_uint4(cpath.pack23[0], cpath.pack23[1], cpath.pack45[0], cpath.pack45[1]);      // throughput | radiance: at home, alive or not
+        }
+        else if (h.prim == 0xFFFFFFFFu) { PathState path = load_path(pool, p); k.template HandleMiss<NEEAT>(path, path.dir, kMaxRayTravel); store_path(pool, p, path); alive = path.isActive(); }
         else {
             isHit = true;
             const PathPoolIO io{pool, p};      // the path streams through HandleHit: late loads, early stores (pt_wavefront_device.h)
@@ -256,11 +268,20 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) k_shade(P
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (alive) queueOut[sBase[0] + sCnt[wave][0] + (uint)__popcll(mAlive & below)] = p;
+    if (alive) {
+        const uint slot = sBase[0] + sCnt[wave][0] + (uint)__popcll(mAlive & below);
+        queueOut[slot] = hp;
+        if (COMPACT) {      // the survivor's state at its new position, in the other array set
+            outPool.s0[slot] = make_uint4(asuint(cpath.origin.x), asuint(cpath.origin.y), asuint(cpath.origin.z), cpath.id);
+            outPool.s1[slot] = make_uint4(asuint(cpath.dir.x), asuint(cpath.dir.y), asuint(cpath.dir.z), asuint(cpath.sceneLength));
+            outPool.s3[slot] = make_uint4(cpath.interiorList.slots[0], cpath.interiorList.slots[1], cpath.packedCounters, cpath.rayCone.widthSpreadAngleFP16);
+            outPool.s4[slot] = make_uint4(cpath.pack0, cpath.pack1, cpath.flagsAndVertexIndex, cpath.sampleIndex);
+        }
+    }
     if (!MULTI && req.valid) {
         const uint sslot = sBase[1] + sCnt[wave][1] + (uint)__popcll(mReq & below);
         sq.q0[sslot] = make_float4(req.origin.x, req.origin.y, req.origin.z, req.tmax);
-        sq.q1[sslot] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(p));
+        sq.q1[sslot] = make_float4(req.dir.x, req.dir.y, req.dir.z, asfloat(hp));
         sq.q2[sslot] = make_float4(req.radiance.x, req.radiance.y, req.radiance.z, 0.f);
         if (NEEAT && sq.q3) sq.q3[sslot] = make_float4(req.fbWeight, req.fbRandom, asfloat(req.fbLight), asfloat(req.rrFix));
     }
@@ -807,7 +828,7 @@ void launch_classify(PathPool pool, const uint* queueIn, const uint* countInPtr,
     hipLaunchKernelGGL(k_classify, dim3((countIn + 1024u * PT_CLASSIFY_ITEMS - 1u) / (1024u * PT_CLASSIFY_ITEMS)), dim3(1024), 0, st, pool, queueIn, countInPtr, classScratch, classCount);
 }
 void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn, const uint* countInPtr, uint countIn, uint* queueOut, uint* countOutPtr, ShadowQueue sq, WaveCounters* wc,
-                  uint* classScratch, uint* classCount, hipStream_t st) {
+                  uint* classScratch, uint* classCount, hipStream_t st, PathPool outPool) {
     const dim3 g((countIn + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), b(PT_SHADE_BLOCK);
     // (scratch: 2 x countIn words, free between the extend and the shadow launches; classCount: 3 words, zeroed with the pass's traversal counters)
     if (PT_SHADE_CLASSES && classScratch) {
@@ -817,8 +838,9 @@ void launch_shade(const PathKernelContext& k, PathPool pool, const uint* queueIn
     // NEE-AT (a local sampling table and / or temporal feedback, pt_set_local_light_sampling) runs its own instantiations: the frames without it keep their
     // kernels unchanged
     const bool neeat = k.sc.lights.LocalSamplingBuffer != nullptr || k.sc.lights.TemporalFeedbackRequired != 0u;
-#define PT_LAUNCH_SHADE(MULTI, PKC, CTX) do { if (neeat) hipLaunchKernelGGL((k_shade<MULTI, PKC, true>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount); \
-                                              else hipLaunchKernelGGL((k_shade<MULTI, PKC, false>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount); } while (0)
+#define PT_LAUNCH_SHADE(MULTI, PKC, CTX) do { if (neeat) hipLaunchKernelGGL((k_shade<MULTI, PKC, true>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount, outPool); \
+                                              else if (pool.home && !MULTI) hipLaunchKernelGGL((k_shade<false, PKC, false, true>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount, outPool); \
+                                              else hipLaunchKernelGGL((k_shade<MULTI, PKC, false>), g, b, 0, st, CTX, pool, queueIn, countInPtr, queueOut, countOutPtr, sq, wc, classCount, outPool); } while (0)
     if (k.S.useFp16Types) {          // the reference's default build of its lp types (binary16): same context data, the other instantiation of the shading code
         static_assert(sizeof(PathKernelContextT<true>) == sizeof(PathKernelContext), "the two lp builds share one context layout");
         PathKernelContextT<true> k16; __builtin_memcpy(&k16, &k, sizeof(k16));
@@ -854,6 +876,15 @@ __global__ void __launch_bounds__(64) k_pass_begin(uint* __restrict__ passCounte
     if (threadIdx.x == 33u && shadowCount) *shadowCount = 0u;      // (null: a frame of fused traversal launches, whose k_resolve_pair zeroes it)
 }
 void launch_pass_reset(uint* passCounters, uint* nextCount, uint* shadowCount, hipStream_t st) { static_assert(PASS_COUNTERS <= 32u, "k_pass_begin"); hipLaunchKernelGGL(k_pass_begin, dim3(1), dim3(64), 0, st, passCounters, nextCount, shadowCount); }
+__global__ void __launch_bounds__(256) k_uncompact(PathPool in, PathPool out, const uint* __restrict__ countPtr) {
+    const uint i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= *countPtr) return;
+    const uint hp = in.home[i];
+    out.s0[hp] = in.s0[i]; out.s1[hp] = in.s1[i]; out.s3[hp] = in.s3[i]; out.s4[hp] = in.s4[i];
+}
+void launch_uncompact(PathPool in, PathPool out, const uint* countPtr, uint count, hipStream_t st) {
+    if (count) hipLaunchKernelGGL(k_uncompact, dim3((count + 255u) / 256u), dim3(256), 0, st, in, out, countPtr);
+}
 void launch_accumulate(PathPool pool, const uint* ownedPixels, uint numOwned, uint spp, float4* accum, uint accumCountBase, uint width, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3((numOwned + 255) / 256), dim3(256), 0, st, pool, ownedPixels, numOwned, spp, accum, accumCountBase, width);
 }

@@ -78,6 +78,32 @@ struct PathPoolIO {
     __device__ __forceinline__ void store_all(const PathState& p) const { store_path(pool, i, p); }
 };
 
+// ... and of a compacted pool (PathPool::home): the same load order from the position's word groups and the home slot's throughput | radiance; nothing is stored from inside HandleHit —
+// the surviving path's position is only known once its block has counted its survivors (k_shade stores it there)
+struct PathCompactIO {
+    static constexpr bool streams = true;
+    PathPool pool; uint i, hp;
+    __device__ __forceinline__ void mark(int) const {}
+    __device__ __forceinline__ PathState load_first() const {
+        PathState p; uint4 b = pool.s1[i], d = pool.s3[i];
+        p.dir = make_float3(asfloat(b.x), asfloat(b.y), asfloat(b.z)); p.sceneLength = asfloat(b.w);
+        p.interiorList.slots[0] = d.x; p.interiorList.slots[1] = d.y; p.packedCounters = d.z; p.rayCone.widthSpreadAngleFP16 = d.w;
+        p.flagsAndVertexIndex = reinterpret_cast<const uint*>(pool.s4)[4u * (size_t)i + 2u];
+        return p;
+    }
+    __device__ __forceinline__ void load_rest(PathState& p) const {
+        asm volatile("" ::: "memory");
+        uint4 a = pool.s0[i], c = pool.s2[hp], e = pool.s4[i];
+        p.origin = make_float3(asfloat(a.x), asfloat(a.y), asfloat(a.z)); p.id = a.w;
+        p.pack23[0] = c.x; p.pack23[1] = c.y; p.pack45[0] = c.z; p.pack45[1] = c.w;
+        p.pack0 = e.x; p.pack1 = e.y; p.flagsAndVertexIndex = e.z; p.sampleIndex = e.w;
+    }
+    __device__ __forceinline__ PathState load_all() const { PathState p = load_first(); load_rest(p); return p; }
+    __device__ __forceinline__ void store_front(const PathState&) const {}
+    __device__ __forceinline__ void store_back(const PathState&) const {}
+    __device__ __forceinline__ void store_all(const PathState&) const {}
+};
+
 __device__ __forceinline__ void t8_counters_init(Traverse8Counters& ctr) {
     ctr.nodeVisits = 0; ctr.triTests = 0; ctr.leafVisits = 0; ctr.iters = 0; ctr.leafBlocks = 0; for (int q = 0; q < 8; q++) ctr.ev[q] = 0u; ctr.cyc[0] = ctr.cyc[1] = ctr.cyc[2] = ctr.cyc[3] = 0ull;
     ctr.rayIterHist = nullptr; ctr.longRayCount = nullptr; ctr.longRays = nullptr;
