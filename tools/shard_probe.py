@@ -12,6 +12,7 @@ RANGES = (None if os.environ.get("SHARD_PROBE_ANIMATE") == "full" else scenes.an
 POSES = [(scenes.animate_instances(sc, 0.1 * f), scenes.animate_positions(sc, 0.1 * f)) for f in range(1, 4)] if ANIMATE else []
 sc["env_cube_dim"] = 2048; sc["env_compression"] = 1      # as bench.py: EnvMapBaker's cube for an image source, BC6H on (the reference's D3D12 default)
 camd = scenes.bridge_camera(W, H, **cam)
+FRAMES = int(os.environ.get("SHARD_PROBE_FRAMES", "6"))      # timed frames per rank
 MAXR = int(os.environ.get("SHARD_PROBE_RANKS", "0"))          # > 0: time only this many evenly spaced ranks per world size (every rank costs a scene build)
 worlds = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]
 TAILS = [int(x) for x in os.environ.get("SHARD_PROBE_TAILS", "").split(",") if x]      # tail-kernel thresholds to A/B on one context per rank (pt_set_tail_paths); empty: the product default only
@@ -23,14 +24,14 @@ for world in worlds if not TAILS else []:
     for rank in ranks:
         g = pt.PathTracer(device=0, shard_rank=rank, shard_count=world)
         g.set_scene(sc); g.set_camera(camd); g.set_settings(SETTINGS); g.resize(W, H)
-        g.reset_accumulation(); g.render(0, SPP)
+        for _ in range(2): g.reset_accumulation(); g.render(0, SPP)      # (first calls allocate; round 6: two warm-up frames and FRAMES timed ones instead of 1 + 2 — a 12 ms frame needs more than two samples)
         if ANIMATE:
-            for inst, pos in POSES: g.animate(instances=inst, positions=pos, rebuild=False, vertex_ranges=RANGES)      # (first calls allocate)
-        t0 = time.perf_counter()
-        for f in range(2):
-            if ANIMATE: g.animate(instances=POSES[f][0], positions=POSES[f][1], rebuild=False, vertex_ranges=RANGES)
+            for inst, pos in POSES: g.animate(instances=inst, positions=pos, rebuild=False, vertex_ranges=RANGES)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for f in range(FRAMES):
+            if ANIMATE: g.animate(instances=POSES[f % len(POSES)][0], positions=POSES[f % len(POSES)][1], rebuild=False, vertex_ranges=RANGES)
             g.reset_accumulation(); st = g.render(0, SPP)
-        torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / 2); rays.append(st["extendRays"] + st["shadowRays"])
+        torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / FRAMES); rays.append(st["extendRays"] + st["shadowRays"])
         del g
     print("   ranks timed:", ranks); print("   per rank ms:", " ".join("%.1f" % (t * 1e3) for t in times)); print("   per rank Mrays:", " ".join("%.1f" % (r / 1e6) for r in rays))
     base = base or max(times)
