@@ -7,7 +7,9 @@
 # usage: tools/profile_round.sh <outdir>
 OUT=${1:-gpurun_out/profile}; mkdir -p $OUT; OUT=$(realpath $OUT); REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --warmup 0 --no-cpu-baseline --serial-kernels --skip-roofline-steps"
+# PIPELINED=1: the product's composition (four batches, fused traversal launches, compacted pool) instead of serial-kernel steps: what k_trace_pair and k_shade<..., COMPACT> move
+SERIAL=--serial-kernels; [ -n "$PIPELINED" ] && SERIAL=""
+BENCH="python $REPO/bench.py --warmup 0 --no-cpu-baseline $SERIAL --skip-roofline-steps"
 [ -n "$SKIP_STATS" ] || timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $BENCH --steps 3 > $OUT/stats.log 2>&1      # SKIP_STATS=1: the stats pass is already in <out>
 i=0
 while read -r line; do

@@ -15,8 +15,9 @@ import os, csv, glob, json, sys, collections
 
 d = sys.argv[1]
 GROUPS = (("extend", ("k_extend<false, false>", "k_extend_tasks", "k_resolve_extend")), ("shadow", ("k_shadow<false, false>", "k_shadow_tasks", "k_resolve_shadow")), ("shade", ("k_shade<false", "k_classify")),
+          ("pair", ("k_trace_pair", "k_tasks_pair", "k_resolve_pair")),      # the fused traversal launches of a pipelined frame (PIPELINED=1 tools/profile_round.sh)
           ("generate", ("k_generate",)), ("accumulate", ("k_accumulate",)))
-MAIN = {"extend": "k_extend<false, false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false", "generate": "k_generate", "accumulate": "k_accumulate"}
+MAIN = {"pair": "k_trace_pair", "extend": "k_extend<false, false>", "shadow": "k_shadow<false, false>", "shade": "k_shade<false", "generate": "k_generate", "accumulate": "k_accumulate"}
 
 
 def group_of(name):
@@ -49,7 +50,7 @@ for f in glob.glob(d + "/**/stats_kernel_stats.csv", recursive=True):
         stats[n] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) * 1e-6, "total_ms": float(r["TotalDurationNs"]) * 1e-6, "percent": float(r["Percentage"])}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rtxpt_amd
-out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc (separate passes), 1 serial-kernel step of bench.py's default workload",
+out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc (separate passes), 1 %s step of bench.py's default workload" % ("pipelined (product composition: fused traversal launches, compacted pool; rocprofv3 serialises the dispatches it counts)" if os.environ.get("PIPELINED") else "serial-kernel"),
        "kernel_source_sha256": rtxpt_amd.kernel_source_digest(),      # bench.py quotes these counters only for the kernels they were collected on
        "library_sha256": rtxpt_amd.library_digest(),                  # ... and the binary they ran in
        "issue_ceilings": {"total_instr_per_simd_cycle": 0.486, "four_cycle_class_instr_per_simd_cycle": 0.248, "source": "profiles/r06a_valu_ceiling.txt (tools/valu_ceiling on this GPU)"},
